@@ -1,0 +1,32 @@
+"""advancedvi.jl_amd: MI355X-native RepGradELBO / ADVI hot path of AdvancedVI.jl behind the
+reference's own interface.  Import as `import advancedvi_jl_amd as avi` (shim at the repo root).
+
+Everything numerical is a hand-written HIP kernel in libmivi.so (csrc/, C ABI in include/mivi.h);
+this package is the host-side mirror of the reference's operator interface for that path."""
+from ._lib import LIB_PATH, MiviError, load as load_library
+from .families import MvLocationScale, MeanFieldGaussian, FullRankGaussian, destructure, MEANFIELD, FULLRANK
+from .problems import (LogDensityOrder, DiagNormalProblem, DenseNormalProblem, LogRegProblem, FunnelProblem,
+                       dimension, capabilities)
+from .objectives import (RepGradELBO, RepGradELBOState, ClosedFormEntropy, ClosedFormEntropyZeroGradient,
+                         MonteCarloEntropy, StickingTheLandingEntropy, StickingTheLandingEntropyZeroGradient,
+                         AutoMIVI, PhiloxRNG, DiffResult, estimate_gradient_, set_objective_state_problem, rand)
+from . import objectives as _objectives
+from . import optimize as _optimize
+from .optimize import (KLMinRepGradDescent, ADVI, ClipScale, IdentityOperator, Descent, Adam, DoG, DoWG, NoAveraging,
+                       PolynomialAveraging, optimize, step, output)
+from .context import MiviContext
+
+
+def estimate_objective(*args, **kwargs):
+    """Dispatches like the reference: (rng, alg|obj, q, prob) or (alg|obj, q, prob)."""
+    head = args[1] if isinstance(args[0], PhiloxRNG) else args[0]
+    if isinstance(head, KLMinRepGradDescent):
+        return _optimize.estimate_objective(*args, **kwargs)
+    return _objectives.estimate_objective(*args, **kwargs)
+
+
+def init(*args, **kwargs):
+    """init(rng, alg, q_init, prob)  or  init(rng, obj, adtype, q, prob, params, restructure)."""
+    if isinstance(args[1], KLMinRepGradDescent):
+        return _optimize.init(*args, **kwargs)
+    return _objectives.init(*args, **kwargs)

@@ -1,0 +1,96 @@
+"""ctypes binding of libmivi.so (include/mivi.h).  There is NO fallback: if the HIP library is
+missing or cannot be loaded, importing the hot path raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmivi.so")
+
+MIVI_OK, ERR_BAD_ARG, ERR_NONFINITE, ERR_NONPOSITIVE_SCALE, ERR_HIP, ERR_NO_TARGET, ERR_UNSUPPORTED = range(7)
+F32, F64 = 0, 1
+MEANFIELD, FULLRANK = 0, 1
+
+
+class MiviConfig(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int32), ("family", C.c_int32), ("d", C.c_int32), ("n_mc", C.c_int32),
+        ("entropy", C.c_int32), ("device", C.c_int32), ("seed", C.c_uint64),
+        ("m_offset", C.c_int32), ("m_total", C.c_int32), ("stream", C.c_void_p),
+        ("own_stream", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+LOGDENSITY_AND_GRADIENT_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p)
+LOGDENSITY_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p)
+
+# name -> (restype, argtypes): every symbol include/mivi.h declares
+SIGNATURES = {
+    "mivi_create": (C.c_int32, [C.POINTER(MiviConfig), C.POINTER(C.c_void_p)]),
+    "mivi_destroy": (C.c_int32, [C.c_void_p]),
+    "mivi_last_error": (C.c_char_p, [C.c_void_p]),
+    "mivi_version": (C.c_int32, []),
+    "mivi_set_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "mivi_synchronize": (C.c_int32, [C.c_void_p]),
+    "mivi_params_len": (C.c_int64, [C.c_void_p]),
+    "mivi_partials_len": (C.c_int64, [C.c_void_p]),
+    "mivi_set_target_diag_gauss": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mivi_set_target_dense_gauss": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mivi_set_target_logreg": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int32]),
+    "mivi_set_target_funnel": (C.c_int32, [C.c_void_p, C.c_double]),
+    "mivi_set_target_callback": (C.c_int32, [C.c_void_p, LOGDENSITY_AND_GRADIENT_FN, LOGDENSITY_FN, C.c_void_p]),
+    "mivi_sample": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "mivi_estimate_gradient": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "mivi_estimate_gradient_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "mivi_estimate_gradient_n": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mivi_estimate_objective": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p]),
+    "mivi_estimate_objective_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p]),
+    "mivi_estimate_partials": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "mivi_finalize": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mivi_clip_scale": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_double]),
+    "mivi_descent_update": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]),
+    "mivi_adam_update": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "mivi_axpby": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_int64]),
+    "mivi_dog_state_bytes": (C.c_int64, [C.c_void_p]),
+    "mivi_dog_init": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]),
+    "mivi_dog_update": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "mivi_optimize_steps": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p]),
+    "mivi_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "mivi_eps_bits_host": (None, [C.c_uint64, C.c_uint64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]),
+    "mivi_eps_host": (None, [C.c_uint64, C.c_uint64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmivi.so (once).  Raises RuntimeError when it has not been built: the product path
+    never falls back to a CPU implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libmivi.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class MiviError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"libmivi status {status}: {msg}")
+        self.status = status
+
+
+def check(lib, ctx, status):
+    if status != MIVI_OK:
+        msg = lib.mivi_last_error(ctx).decode() if ctx else "context creation failed"
+        raise MiviError(status, msg)

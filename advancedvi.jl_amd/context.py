@@ -1,0 +1,247 @@
+"""Thin object wrapper over the libmivi C ABI (include/mivi.h).  Device memory and the HIP stream
+come from torch (plumbing only); every computation is a libmivi kernel."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .families import FULLRANK, MEANFIELD
+from . import problems as P
+
+_NP2MIVI = {np.dtype(np.float32): _lib.F32, np.dtype(np.float64): _lib.F64}
+
+
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError("libmivi needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+    return torch
+
+
+def torch_dtype(np_dtype):
+    torch = _torch()
+    return torch.float32 if np.dtype(np_dtype) == np.float32 else torch.float64
+
+
+class MiviContext:
+    """One RepGradELBO estimator instance on one GPU (mivi_create ... mivi_destroy)."""
+
+    def __init__(self, dtype, family, d, n_mc, entropy, seed, device=0, m_offset=0, m_total=0, stream=None):
+        torch = _torch()
+        self.lib = _lib.load()
+        self.np_dtype = np.dtype(dtype)
+        self.family, self.d, self.n_mc, self.entropy = int(family), int(d), int(n_mc), int(entropy)
+        self.device = int(device)
+        self.tdtype = torch_dtype(self.np_dtype)
+        self.tdevice = torch.device("cuda", self.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(self.tdevice).cuda_stream
+        cfg = _lib.MiviConfig(_NP2MIVI[self.np_dtype], self.family, self.d, self.n_mc, self.entropy, self.device,
+                              C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), int(m_offset), int(m_total), C.c_void_p(stream), 0, 0)
+        h = C.c_void_p()
+        st = self.lib.mivi_create(C.byref(cfg), C.byref(h))
+        _lib.check(self.lib, None, st)
+        self.h = h
+        self.m_total = int(m_total) if m_total else self.n_mc
+        self._keep = []      # keep-alive for callbacks / borrowed device arrays
+        self.problem = None
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mivi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st):
+        _lib.check(self.lib, self.h, st)
+
+    @property
+    def params_len(self):
+        return int(self.lib.mivi_params_len(self.h))
+
+    @property
+    def partials_len(self):
+        return int(self.lib.mivi_partials_len(self.h))
+
+    def synchronize(self):
+        self._chk(self.lib.mivi_synchronize(self.h))
+
+    # -- tensors ----------------------------------------------------------------------------------
+    def to_device(self, x):
+        torch = _torch()
+        if isinstance(x, torch.Tensor):
+            if x.device != self.tdevice or x.dtype != self.tdtype or not x.is_contiguous():
+                x = x.to(device=self.tdevice, dtype=self.tdtype).contiguous()
+            return x
+        return torch.as_tensor(np.ascontiguousarray(x, dtype=self.np_dtype)).to(self.tdevice)
+
+    def empty(self, n):
+        return _torch().empty(int(n), dtype=self.tdtype, device=self.tdevice)
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
+    # -- targets ----------------------------------------------------------------------------------
+    def set_problem(self, prob):
+        if P.dimension(prob) != self.d:
+            raise ValueError("dimension(prob) does not match the variational family")
+        dt = self.np_dtype
+        if isinstance(prob, P.DiagNormalProblem):
+            m = np.ascontiguousarray(prob.mean, dtype=dt)
+            s = np.ascontiguousarray(np.broadcast_to(prob.std, m.shape), dtype=dt)
+            self._chk(self.lib.mivi_set_target_diag_gauss(self.h, m.ctypes.data, s.ctypes.data))
+        elif isinstance(prob, P.DenseNormalProblem):
+            m = np.ascontiguousarray(prob.mean, dtype=dt)
+            L = np.asfortranarray(prob.L, dtype=dt)
+            self._chk(self.lib.mivi_set_target_dense_gauss(self.h, m.ctypes.data, L.ctypes.data))
+        elif isinstance(prob, P.LogRegProblem):
+            torch = _torch()
+            X = prob.X
+            if isinstance(X, torch.Tensor):   # device-resident, column-major n x p expected
+                Xd, yd = X, prob.y
+                n = X.shape[1] if getattr(prob, "x_is_colmajor_tensor", False) else X.shape[0]
+                self._keep += [Xd, yd]
+                self._chk(self.lib.mivi_set_target_logreg(self.h, self._p(Xd), self._p(yd), n,
+                                                          P.LogRegProblem.VARIANTS[prob.variant], prob.likeadj, 1))
+            else:
+                Xf = np.asfortranarray(X, dtype=dt)
+                y = np.ascontiguousarray(prob.y, dtype=np.uint8)
+                self._chk(self.lib.mivi_set_target_logreg(self.h, Xf.ctypes.data, y.ctypes.data, Xf.shape[0],
+                                                          P.LogRegProblem.VARIANTS[prob.variant], prob.likeadj, 0))
+        elif isinstance(prob, P.FunnelProblem):
+            self._chk(self.lib.mivi_set_target_funnel(self.h, prob.sigma_v))
+        else:
+            self._set_callback(prob)
+        self.problem = prob
+
+    def _set_callback(self, prob):
+        if not hasattr(prob, "logdensity_and_gradient") and not hasattr(prob, "logdensity_and_gradient_batch"):
+            raise TypeError(
+                "generic targets must implement logdensity_and_gradient (LogDensityOrder >= 1): libmivi has no AD; "
+                "see INTEGRATION.md")
+        dt = self.np_dtype
+
+        def as_mat(ptr, d, M):
+            buf = (C.c_char * (d * M * dt.itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dt).reshape((d, M), order="F")
+
+        def fg(user, Zp, d, M, ellp, Gp):
+            try:
+                Z = as_mat(Zp, d, M)
+                ell = as_mat(ellp, 1, M)
+                G = as_mat(Gp, d, M)
+                if hasattr(prob, "logdensity_and_gradient_batch"):
+                    l, g = prob.logdensity_and_gradient_batch(Z)
+                    ell[0, :] = l
+                    G[:, :] = g
+                else:
+                    for m in range(M):
+                        l, g = prob.logdensity_and_gradient(Z[:, m])   # column view, like eachcol(samples)
+                        ell[0, m] = l
+                        G[:, m] = g
+                return 0
+            except Exception as e:  # no exceptions across the ABI
+                self._cb_error = e
+                return 1
+
+        def fv(user, Zp, d, M, ellp):
+            try:
+                Z = as_mat(Zp, d, M)
+                ell = as_mat(ellp, 1, M)
+                for m in range(M):
+                    ell[0, m] = prob.logdensity(Z[:, m])
+                return 0
+            except Exception as e:
+                self._cb_error = e
+                return 1
+
+        cfg = _lib.LOGDENSITY_AND_GRADIENT_FN(fg)
+        cfv = _lib.LOGDENSITY_FN(fv) if hasattr(prob, "logdensity") else C.cast(None, _lib.LOGDENSITY_FN)
+        self._keep += [cfg, cfv]
+        self._cb_error = None
+        self._chk(self.lib.mivi_set_target_callback(self.h, cfg, cfv, None))
+
+    def _raise_cb(self, st):
+        err = getattr(self, "_cb_error", None)
+        if st != 0 and err is not None:
+            self._cb_error = None
+            raise err
+        self._chk(st)
+
+    # -- hot path ---------------------------------------------------------------------------------
+    def sample(self, params, idx, want_eps=True):
+        p = self.to_device(params)
+        Z = self.empty(self.d * self.n_mc)
+        eps = self.empty(self.d * self.n_mc) if want_eps else None
+        self._chk(self.lib.mivi_sample(self.h, self._p(p), idx, self._p(Z), self._p(eps) if want_eps else None))
+        # d x M column-major -> torch (M, d) row-major view transposed
+        Zv = Z.view(self.n_mc, self.d).t()
+        return (Zv, eps.view(self.n_mc, self.d).t()) if want_eps else Zv
+
+    def estimate_gradient(self, params, idx, value=None, grad=None):
+        p = self.to_device(params)
+        value = self.empty(1) if value is None else value
+        grad = self.empty(self.params_len) if grad is None else grad
+        self._raise_cb(self.lib.mivi_estimate_gradient(self.h, self._p(p), idx, self._p(value), self._p(grad)))
+        return value, grad
+
+    def estimate_gradient_n(self, params, idx0, count, value, grad):
+        self._chk(self.lib.mivi_estimate_gradient_n(self.h, self._p(params), idx0, int(count), self._p(value), self._p(grad)))
+
+    def estimate_objective(self, params, idx, n_samples=0, entropy=-1, value=None):
+        p = self.to_device(params)
+        value = self.empty(1) if value is None else value
+        self._raise_cb(self.lib.mivi_estimate_objective(self.h, self._p(p), idx, int(n_samples), int(entropy), self._p(value)))
+        return value
+
+    def estimate_partials(self, params, idx, partials=None):
+        p = self.to_device(params)
+        partials = self.empty(self.partials_len) if partials is None else partials
+        self._raise_cb(self.lib.mivi_estimate_partials(self.h, self._p(p), idx, self._p(partials)))
+        return partials
+
+    def finalize(self, params, partials, value=None, grad=None):
+        p = self.to_device(params)
+        value = self.empty(1) if value is None else value
+        grad = self.empty(self.params_len) if grad is None else grad
+        self._chk(self.lib.mivi_finalize(self.h, self._p(p), self._p(partials), self._p(value), self._p(grad)))
+        return value, grad
+
+    # -- next to the hot path ---------------------------------------------------------------------
+    def clip_scale(self, params, epsilon):
+        self._chk(self.lib.mivi_clip_scale(self.h, self._p(params), float(epsilon)))
+
+    def descent_update(self, params, grad, eta):
+        self._chk(self.lib.mivi_descent_update(self.h, self._p(params), self._p(grad), float(eta)))
+
+    def adam_update(self, params, grad, state, t, eta, beta1=0.9, beta2=0.999, eps=1e-8):
+        self._chk(self.lib.mivi_adam_update(self.h, self._p(params), self._p(grad), self._p(state), int(t), eta, beta1, beta2, eps))
+
+    def axpby(self, y, a, x, b):
+        self._chk(self.lib.mivi_axpby(self.h, self._p(y), float(a), self._p(x), float(b), y.numel()))
+
+    def dog_state(self):
+        torch = _torch()
+        return torch.zeros(int(self.lib.mivi_dog_state_bytes(self.h)), dtype=torch.uint8, device=self.tdevice)
+
+    def dog_init(self, params, state, alpha):
+        self._chk(self.lib.mivi_dog_init(self.h, self._p(params), self._p(state), float(alpha)))
+
+    def dog_update(self, params, grad, state, kind):
+        self._chk(self.lib.mivi_dog_update(self.h, self._p(params), self._p(grad), self._p(state), int(kind)))
+
+    def optimize_steps(self, params, opt_state, idx0, t0, n_steps, rule, eta, clip_epsilon, elbo=None):
+        st = self.lib.mivi_optimize_steps(self.h, self._p(params), self._p(opt_state) if opt_state is not None else None,
+                                          idx0, int(t0), int(n_steps), int(rule), float(eta), float(clip_epsilon),
+                                          self._p(elbo) if elbo is not None else None)
+        self._chk(st)

@@ -1,0 +1,100 @@
+// Device-side helpers shared by the kernels: wave64 / workgroup reductions and the objective-value
+// finalisation (negative ELBO assembly of src/algorithms/repgradelbo.jl:112-118,142-149).
+#pragma once
+#include "mivi_internal.h"
+
+namespace mivi {
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Sum `v` over the workgroup; result valid in every thread. `red` must hold NT/64 elements.
+// Fixed reduction tree => bitwise reproducible for a given launch geometry.
+template <typename T, int NT>
+__device__ __forceinline__ T block_sum(T v, T *red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  T s = red[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) s += red[i];
+  return s;
+}
+
+__device__ __forceinline__ uint64_t rng_index(const RngArgs &r) {
+  return r.idx_base + (r.idx_ptr ? *r.idx_ptr : 0ull);
+}
+
+__device__ __forceinline__ double direct_entropy_coeff(int ent_kind) {
+  // coefficient of diag(1/C_ii) in d(entropy estimate)/dC  
+  switch (ent_kind) {
+    case MIVI_ENT_CLOSED_FORM: return 1.0;
+    case MIVI_ENT_CLOSED_FORM_ZERO_GRAD: return 0.0;
+    case MIVI_ENT_MONTE_CARLO: return 1.0;
+    case MIVI_ENT_STL: return 0.0;
+    default: return -1.0;  // STL zero-gradient
+  }
+}
+
+__device__ __forceinline__ bool ent_is_stl(int k) { return k == MIVI_ENT_STL || k == MIVI_ENT_STL_ZERO_GRAD; }
+__device__ __forceinline__ bool ent_is_closed(int k) {
+  return k == MIVI_ENT_CLOSED_FORM || k == MIVI_ENT_CLOSED_FORM_ZERO_GRAD;
+}
+
+template <bool ATOMIC>
+__device__ __forceinline__ double ld_f64(const double *p) {
+  if (ATOMIC) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+
+// One whole workgroup (NT threads) assembles the objective value (or the two scalar partials).
+//   value = -( sum_ell / M_total + entropy_estimate )
+//   closed-form estimators: d/2 (1 + log 2pi) + sum_i log C_ii            location_scale.jl:52-57
+//   MC / STL estimators   : mean_m 0.5|eps_m|^2 + d/2 log 2pi + sum_i log C_ii   (C^-1 (z_m - mu) == eps_m)
+// `scale_diag(i)` returns C_ii. `red` holds NT/64 doubles.
+template <typename T, int NT, bool ATOMIC, typename DiagFn>
+__device__ void finalize_value_block(int d, const ValueIn &vin, const OutArgs &out, int64_t plen, DiagFn scale_diag,
+                                     double *red) {
+  const int tid = threadIdx.x;
+  double s_ell = 0.0, s_he = 0.0, s_ld = 0.0, bad = 0.0;
+  for (int i = tid; i < vin.n_ell_part; i += NT) s_ell += ld_f64<ATOMIC>(vin.ell_part + i);
+  for (int i = tid; i < vin.n_ell; i += NT) s_ell += (double)((const T *)vin.ell)[i];
+  for (int i = tid; i < vin.n_he_part; i += NT) s_he += ld_f64<ATOMIC>(vin.he_part + i);
+  if (!out.partials_mode) {
+    for (int i = tid; i < d; i += NT) {
+      const double c = (double)scale_diag(i);
+      if (!(c > 0.0)) bad = 1.0;
+      s_ld += log(c);
+    }
+  }
+  s_ell = block_sum<double, NT>(s_ell, red);
+  s_he = block_sum<double, NT>(s_he, red);
+  s_ld = block_sum<double, NT>(s_ld, red);
+  bad = block_sum<double, NT>(bad, red);
+  if (tid == 0) {
+    const double sum_ell = s_ell + (double)out.M_local * vin.ell_const;
+    if (out.partials_mode) {
+      T *p = (T *)out.partials;
+      p[plen] = (T)sum_ell;
+      p[plen + 1] = (T)s_he;
+    } else {
+      const double Mt = (double)out.M_total;
+      const double ent = (ent_is_closed(out.ent_kind) ? 0.5 * d * (1.0 + kLog2Pi) : s_he / Mt + 0.5 * d * kLog2Pi) + s_ld;
+      const double value = -(sum_ell / Mt + ent);
+      *(T *)out.value = (T)value;
+      int st = 0;
+      if (!isfinite(value)) st |= 1;
+      if (bad > 0.0) st |= 2;
+      if (st && out.status) atomicOr(out.status, st);
+      if (out.elbo_rec) out.elbo_rec[out.rec_slot] = -value;
+    }
+  }
+}
+
+}  // namespace mivi

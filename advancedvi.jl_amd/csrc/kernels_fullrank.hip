@@ -1,0 +1,516 @@
+// Full-rank (lower-triangular Cholesky scale) RepGradELBO kernels for gfx950.
+//
+// Reference semantics (AdvancedVI.jl v0.7.0):
+//   sampling   Z = scale * eps .+ mu   (d x d  by  d x M)            src/families/location_scale.jl:71-77
+//   gradient   d/dC = -(1/M) tril(W eps') - direct * diag(1/C_ii),  d/dmu = -(1/M) W 1   
+//   STL term   W += C^-T eps                                         src/algorithms/entropy.jl:59-65,80-90
+//
+// The two contractions (C eps and W eps') are the only MFMA work in the library. Both are
+// "sum_k A[:,k] (x) B[:,k]" with 32-float contiguous operand columns, so one kernel template serves
+// both (and the dense-Gaussian target's P (Z-m) product):
+//   * one workgroup per 32x32 output tile, NW waves split the K range, v_mfma_f32_32x32x2_f32
+//     (exact f32, k-ordered fma chain), operands straight from L2 (one dword per lane per MFMA),
+//     partial accumulators reduced through LDS (stride-65 rows => <=2-way bank conflicts), then a
+//     fused epilogue (mu add, target, tril mask, -1/M scaling, row sums, objective value).
+//   * only lower-triangular tiles are computed for C eps (K <= i) and tril(W eps').
+// eps is generated once per estimate by k_eps in both layouts the contractions need:
+//   eps [i + m*dP] (column-major, the reference's layout)  and  epsT[m + k*MP].
+#include "device_common.h"
+
+namespace mivi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { MODE_SAMPLE = 0, MODE_VJP = 1, MODE_DENSE = 2 };
+
+// ---------------------------------------------------------------------------------------------
+// K0: eps generation (Philox4x32-10 + Box-Muller), both layouts, + sum 0.5 eps^2 partials
+// block = 256 threads = 64 columns x 4 row-quads, loops 4x over row-quads => 64x64 tile
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_eps(SampleArgs<T> a) {
+  __shared__ T tile[64][65];
+  __shared__ double red[4];
+  const int d = a.d, d4 = (d + 3) >> 2;
+  const int tid = threadIdx.x;
+  const int i0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+  const int ml = tid & 63, rql = tid >> 6;
+  const int m = m0 + ml;
+  const uint64_t idx = rng_index(a.rng);
+  T he = 0;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int rq_local = it * 4 + rql;          // 0..15
+    const int rq = (i0 >> 2) + rq_local;
+    T e[4] = {0, 0, 0, 0};
+    if (m < a.M && rq < d4)
+      eps_block<T>(a.rng.seed, idx, (uint64_t)(a.rng.m_offset + m) * (uint64_t)d4 + (uint64_t)rq, e);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * rq + r;
+      const bool ok = (m < a.M) && (i < d);
+      const T v = ok ? e[r] : T(0);
+      he += T(0.5) * v * v;
+      tile[ml][rq_local * 4 + r] = v;
+      if (a.epsT && ok) a.epsT[(size_t)i * a.ld_epsT + m] = v;   // lanes along m: coalesced
+    }
+  }
+  __syncthreads();
+  if (a.eps) {
+    const int row = tid & 63;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int col = (tid >> 6) + 4 * j;
+      const int i = i0 + row, mm = m0 + col;
+      if (i < d && mm < a.M) a.eps[(size_t)mm * a.ld_eps + i] = tile[col][row];  // lanes along i: coalesced
+    }
+  }
+  if (a.he_part) {
+    const double s = block_sum<double, 256>((double)he, red);
+    if (tid == 0) a.he_part[blockIdx.y * gridDim.x + blockIdx.x] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tile decomposition helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tri_tile(int t, int &ib, int &jb) {
+  // t = ib*(ib+1)/2 + jb, 0 <= jb <= ib
+  int r = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while (r * (r + 1) / 2 > t) --r;
+  while ((r + 1) * (r + 2) / 2 <= t) ++r;
+  ib = r;
+  jb = t - r * (r + 1) / 2;
+}
+
+template <int MODE>
+__device__ __forceinline__ void tile_coords(const int d, const int M, int &ib, int &nb_col, int &Ktile) {
+  if (MODE == MODE_VJP) {
+    tri_tile(blockIdx.x, ib, nb_col);
+    Ktile = M;
+  } else {
+    const int ncb = (M + 31) >> 5, nrb = (d + 31) >> 5;
+    ib = nrb - 1 - (int)(blockIdx.x / ncb);   // heavy (large K) tiles dispatch first
+    nb_col = blockIdx.x % ncb;
+    Ktile = (MODE == MODE_SAMPLE) ? min(d, 32 * (ib + 1)) : d;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Epilogue shared by the MFMA and the generic tile kernels.  `get(row, col)` returns the reduced
+// accumulator of tile element (row, col); rs_lds[NT] holds per-thread partial row sums of A
+// (only meaningful for diagonal VJP tiles).  NT threads, all participate.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MODE, int NT, typename Get>
+__device__ void tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *rs_lds, double *red) {
+  const int tid = threadIdx.x;
+  const int d = a.d, M = a.M;
+  const int i0 = ib * 32, n0 = cb * 32;
+  const int row = tid & 31, cg = tid >> 5;
+  constexpr int CG = NT / 32;
+  T ell = 0;
+
+  if (MODE == MODE_SAMPLE) {
+    const int gi = i0 + row;
+    const T mu = gi < d ? a.params[gi] : T(0);
+    const T tm = (gi < d && a.fused_target != TGT_NONE) ? a.t_mean[gi] : T(0);
+    const T tis = (gi < d && a.fused_target == TGT_DIAG_GAUSS) ? a.t_istd[gi] : T(0);
+#pragma unroll
+    for (int col = cg; col < 32; col += CG) {
+      const int gm = n0 + col;
+      if (gi < d && gm < M) {
+        const T z = mu + get(row, col);
+        if (a.Z) a.Z[(size_t)gm * d + gi] = z;
+        if (a.fused_target == TGT_DIAG_GAUSS) {
+          const T u = (z - tm) * tis;
+          ell += T(-0.5) * u * u;
+          a.W[(size_t)gm * d + gi] = -u * tis;
+        }
+      }
+    }
+    if (a.fused_target == TGT_DENSE_GAUSS) {
+      // second pass, lanes along the sample axis: RT[m + i*MP] = z - t_mean (coalesced)
+      const int col = tid & 31;
+      for (int r2 = cg; r2 < 32; r2 += CG) {
+        const int gi2 = i0 + r2, gm = n0 + col;
+        if (gi2 < d && gm < M) a.RT[(size_t)gi2 * a.MP + gm] = a.params[gi2] + get(r2, col) - a.t_mean[gi2];
+      }
+    }
+    if (a.fused_target == TGT_DIAG_GAUSS) {
+      const double s = block_sum<double, NT>((double)ell, red);
+      if (tid == 0) a.ell_part[blockIdx.x] = s;
+    }
+  } else if (MODE == MODE_DENSE) {
+    // G = -P (Z - m);  ell_m = 0.5 * sum_i (z-m)_i G_im + const
+    const int gi = i0 + row;
+    const T tm = gi < d ? a.t_mean[gi] : T(0);
+#pragma unroll
+    for (int col = cg; col < 32; col += CG) {
+      const int gm = n0 + col;
+      if (gi < d && gm < M) {
+        const T g = -get(row, col);
+        const T r = a.Z[(size_t)gm * d + gi] - tm;
+        ell += T(0.5) * r * g;
+        a.W[(size_t)gm * d + gi] = g;
+      }
+    }
+    const double s = block_sum<double, NT>((double)ell, red);
+    if (tid == 0) a.ell_part[blockIdx.x] = s;
+  } else {  // MODE_VJP: tile (ib, jb = cb) of tril(W eps^T)
+    const int jb = cb;
+    const int gi = i0 + row;
+    const double invM = 1.0 / (double)a.out.M_total;
+    const double direct = direct_entropy_coeff(a.out.ent_kind);
+    T *dst = a.out.partials_mode ? (T *)a.out.partials : (T *)a.out.grad;
+#pragma unroll
+    for (int col = cg; col < 32; col += CG) {
+      const int gj = n0 + col;
+      if (gi < d && gj < d) {
+        T v = get(row, col);
+        T o;
+        if (gj > gi) {
+          o = T(0);
+        } else if (a.out.partials_mode) {
+          o = v;
+        } else {
+          double x = -(double)v * invM;
+          if (gi == gj) x -= direct / (double)a.params[d + (size_t)gi * d + gi];
+          o = (T)x;
+        }
+        dst[d + (size_t)gj * d + gi] = o;
+      }
+      // mirrored strictly-upper tile is structurally zero
+      if (jb != ib) {
+        const int ui = n0 + row, uj = i0 + col;   // element (ui, uj) with ui < uj
+        if (ui < d && uj < d) dst[d + (size_t)uj * d + ui] = T(0);
+      }
+    }
+    if (jb == ib) {  // row sums of W over all samples -> d/dmu
+      __syncthreads();
+      if (tid < 32) {
+        double s = 0.0;
+#pragma unroll
+        for (int g = 0; g < CG; ++g) s += (double)rs_lds[tid + 32 * g];
+        const int gr = i0 + tid;
+        if (gr < d) dst[gr] = a.out.partials_mode ? (T)s : (T)(-s * invM);
+      }
+    }
+    if (blockIdx.x == 0) {
+      const T *p = a.params;
+      const int dd = d;
+      finalize_value_block<T, NT, false>(d, a.vin, a.out, (int64_t)d + (int64_t)d * d,
+                                         [p, dd](int i) { return p[dd + (size_t)i * dd + i]; }, red);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA tile kernel (float only): NW waves split K, v_mfma_f32_32x32x2_f32
+//   A operand lane l: A[i = l&31][k slot = l>>5],  B operand: B[k slot = l>>5][n = l&31]
+//   D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+// ---------------------------------------------------------------------------------------------
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
+  constexpr int NT = NW * 64;
+  __shared__ float red_acc[NW][16 * 65];
+  __shared__ float rs_lds[NT];
+  __shared__ double red[NW];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int d = a.d, M = a.M;
+  int ib, cb, Ktile;
+  tile_coords<MODE>(d, M, ib, cb, Ktile);
+  const int i0 = ib * 32, n0 = cb * 32;
+
+  int chunk = (Ktile + NW - 1) / NW;
+  chunk = (chunk + 15) & ~15;
+  const int kbeg = w * chunk;
+  const int kend = min(kbeg + chunk, (Ktile + 15) & ~15);
+
+  const int gi = i0 + l31;
+  const float *Abase;
+  int lda;
+  const float *Bbase;
+  int ldb;
+  if (MODE == MODE_SAMPLE) {
+    Abase = a.params + d;  lda = d;   Bbase = a.epsT + n0 + l31;  ldb = a.MP;
+  } else if (MODE == MODE_VJP) {
+    Abase = a.W;           lda = d;   Bbase = a.eps + n0 + l31;   ldb = a.dP;
+  } else {
+    Abase = a.t_prec;      lda = a.dP; Bbase = a.RT + n0 + l31;   ldb = a.MP;
+  }
+  const bool row_ok = gi < d;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float rs = 0.f;
+
+  for (int k = kbeg; k < kend; k += 16) {
+    float av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = k + 2 * u + h;
+      bool ok;
+      if (MODE == MODE_SAMPLE)
+        ok = row_ok && (kk <= gi);
+      else if (MODE == MODE_VJP)
+        ok = row_ok && (kk < M);
+      else
+        ok = true;
+      av[u] = ok ? Abase[(size_t)kk * lda + gi] : 0.f;
+      bv[u] = Bbase[(size_t)kk * ldb];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (MODE == MODE_VJP) rs += av[u];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red_acc[w][r * 65 + lane] = acc[r];
+  rs_lds[tid] = rs;
+  __syncthreads();
+
+  auto get = [&](int row, int col) -> float {
+    const int r = (row & 3) + 4 * (row >> 3);
+    const int hh = (row >> 2) & 1;
+    const int off = r * 65 + col + 32 * hh;
+    float s = red_acc[0][off];
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) s += red_acc[ww][off];
+    return s;
+  };
+  tile_epilogue<float, MODE, NT>(a, ib, cb, get, rs_lds, red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic tile kernel (any T, VALU): same tiles and epilogue, 256 threads, LDS-staged 32x32x32.
+// Used for MIVI_F64 and as the in-library cross-check of the MFMA kernel.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void k_fr_tile_generic(FrArgs<T> a) {
+  constexpr int NT = 256;
+  __shared__ T As[32][33];   // As[k][i]
+  __shared__ T Bs[32][33];   // Bs[k][n]
+  __shared__ T outt[32][33]; // outt[col][row]
+  __shared__ T rs_lds[NT];
+  __shared__ double red[4];
+  const int tid = threadIdx.x;
+  const int d = a.d, M = a.M;
+  int ib, cb, Ktile;
+  tile_coords<MODE>(d, M, ib, cb, Ktile);
+  const int i0 = ib * 32, n0 = cb * 32;
+  const int row = tid & 31, cg = tid >> 5;
+  T acc[4] = {0, 0, 0, 0};
+  T rs = 0;
+  for (int k0 = 0; k0 < Ktile; k0 += 32) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kl = cg + 8 * u, kk = k0 + kl;
+      const int gi = i0 + row, gn = n0 + row;
+      T av = 0, bv = 0;
+      if (MODE == MODE_SAMPLE) {
+        if (gi < d && kk <= gi && kk < d) av = a.params[d + (size_t)kk * d + gi];
+        if (kk < d) bv = a.epsT[(size_t)kk * a.MP + gn];
+      } else if (MODE == MODE_VJP) {
+        if (gi < d && kk < M) av = a.W[(size_t)kk * d + gi];
+        if (kk < M) bv = a.eps[(size_t)kk * a.dP + gn];
+      } else {
+        if (kk < d) av = a.t_prec[(size_t)kk * a.dP + gi];
+        if (kk < d) bv = a.RT[(size_t)kk * a.MP + gn];
+      }
+      As[kl][row] = av;
+      Bs[kl][row] = bv;
+      if (MODE == MODE_VJP) rs += av;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kl = 0; kl < 32; ++kl) {
+      const T av = As[kl][row];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += av * Bs[kl][cg + 8 * j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) outt[cg + 8 * j][row] = acc[j];
+  rs_lds[tid] = rs;
+  __syncthreads();
+  auto get = [&](int r, int c) -> T { return outt[c][r]; };
+  tile_epilogue<T, MODE, NT>(a, ib, cb, get, rs_lds, red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// STL term for the full-rank family: W += C^-T eps  (back substitution with C^T, 8 columns per
+// workgroup, blocked by 32 rows).  O(d^2 M); the reference's own docs call this the expensive
+// estimator (docs/src/klminrepgraddescent.md:93-95).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_fr_stl(FrArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T *x = (T *)smem_raw;                 // x[col][dP]   (in place: rhs -> solution)
+  const int d = a.d, M = a.M, dP = a.dP;
+  T *Cd = x + 8 * (size_t)dP;           // Cd[s][r] = C[i0+s, i0+r] (33 stride)
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.x * 8;
+  const T *C = a.params + d;
+  const int nb = (d + 31) >> 5;
+  for (int t = tid; t < 8 * dP; t += 256) {
+    const int col = t / dP, i = t - col * dP;
+    const int m = m0 + col;
+    x[t] = (i < d && m < M) ? a.eps[(size_t)m * dP + i] : T(0);
+  }
+  __syncthreads();
+  for (int b = nb - 1; b >= 0; --b) {
+    const int i0 = b * 32;
+    for (int t = tid; t < 32 * 32; t += 256) {
+      const int s = t >> 5, r = t & 31;   // want C[i0+s, i0+r], s >= r
+      const int gs = i0 + s, gr = i0 + r;
+      T v = 0;
+      if (gs < d && gr < d && gs >= gr) v = C[(size_t)gr * d + gs];
+      if (gs >= d && s == r) v = 1;       // padding rows: identity
+      Cd[s * 33 + r] = v;
+    }
+    __syncthreads();
+    {  // solve the 32x32 block: 8 columns x 32 lanes; lane r holds row i0+r
+      const int col = tid >> 5, r = tid & 31;
+      T v = x[(size_t)col * dP + i0 + r];
+      for (int s = 31; s >= 0; --s) {
+        const T xs = __shfl(v, s, 32) / Cd[s * 33 + s];
+        if (r == s) v = xs;
+        if (r < s) v -= Cd[s * 33 + r] * xs;   // C[i0+s, i0+r] * x_s
+      }
+      x[(size_t)col * dP + i0 + r] = v;
+    }
+    __syncthreads();
+    // right-looking update of rows i < i0: rhs_i -= sum_k C[i0+k, i] * x_{i0+k}
+    for (int i = tid; i < i0; i += 256) {
+      T accv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const T *cc = C + (size_t)i * d + i0;
+      const int kmax = min(32, d - i0);
+      for (int k = 0; k < kmax; ++k) {
+        const T c = cc[k];
+#pragma unroll
+        for (int col = 0; col < 8; ++col) accv[col] += c * x[(size_t)col * dP + i0 + k];
+      }
+#pragma unroll
+      for (int col = 0; col < 8; ++col) x[(size_t)col * dP + i] -= accv[col];
+    }
+    __syncthreads();
+  }
+  for (int t = tid; t < 8 * dP; t += 256) {
+    const int col = t / dP, i = t - col * dP;
+    const int m = m0 + col;
+    if (i < d && m < M) a.W[(size_t)m * d + i] += x[t];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side launchers
+// ---------------------------------------------------------------------------------------------
+int eps_blocks(const mivi_ctx *c, int M) { return ((c->cfg.d + 63) / 64) * ((M + 63) / 64); }
+int fr_sample_blocks(const mivi_ctx *c, int M) { return ((c->cfg.d + 31) / 32) * ((M + 31) / 32); }
+int fr_dense_blocks(const mivi_ctx *c, int M) { return fr_sample_blocks(c, M); }
+
+template <typename T>
+static void eps_impl(mivi_ctx *c, const RngArgs &rng, int M) {
+  SampleArgs<T> a;
+  a.d = c->cfg.d;
+  a.M = M;
+  a.params = nullptr;
+  a.rng = rng;
+  a.Z = nullptr;
+  a.eps = (T *)c->eps.p;
+  a.ld_eps = c->dP;
+  a.epsT = (T *)c->epsT.p;
+  a.ld_epsT = c->MP;
+  a.he_part = (double *)c->he_part.p;
+  dim3 grid((a.d + 63) / 64, (M + 63) / 64);
+  hipLaunchKernelGGL(k_eps<T>, grid, dim3(256), 0, c->stream, a);
+}
+void launch_eps(mivi_ctx *c, const RngArgs &rng, int M) {
+  if (c->cfg.dtype == MIVI_F32) eps_impl<float>(c, rng, M); else eps_impl<double>(c, rng, M);
+}
+
+template <typename T>
+static FrArgs<T> fr_args(mivi_ctx *c, const void *params, int M) {
+  FrArgs<T> a;
+  a.d = c->cfg.d;
+  a.M = M;
+  a.dP = c->dP;
+  a.MP = c->MP;
+  a.params = (const T *)params;
+  a.eps = (const T *)c->eps.p;
+  a.epsT = (const T *)c->epsT.p;
+  a.Z = (T *)c->Z.p;
+  a.W = (T *)c->W.p;
+  a.RT = (T *)c->RT.p;
+  a.fused_target = TGT_NONE;
+  a.t_mean = (const T *)c->t_mean.p;
+  a.t_istd = (const T *)c->t_istd.p;
+  a.t_prec = (const T *)c->t_prec.p;
+  a.ell_part = (double *)c->ell_part.p;
+  a.vin = ValueIn{};
+  a.out = OutArgs{};
+  return a;
+}
+
+void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, void *Z) {
+  const int nblk = fr_sample_blocks(c, M);
+  if (c->cfg.dtype == MIVI_F32) {
+    FrArgs<float> a = fr_args<float>(c, params, M);
+    a.fused_target = fused_target;
+    a.Z = (float *)Z;
+    hipLaunchKernelGGL((k_fr_tile_mfma<MODE_SAMPLE, 8>), dim3(nblk), dim3(512), 0, c->stream, a);
+  } else {
+    FrArgs<double> a = fr_args<double>(c, params, M);
+    a.fused_target = fused_target;
+    a.Z = (double *)Z;
+    hipLaunchKernelGGL((k_fr_tile_generic<double, MODE_SAMPLE>), dim3(nblk), dim3(256), 0, c->stream, a);
+  }
+}
+
+void launch_fr_dense_target(mivi_ctx *c, int M, int want_grad) {
+  (void)want_grad;
+  const int nblk = fr_dense_blocks(c, M);
+  if (c->cfg.dtype == MIVI_F32) {
+    FrArgs<float> a = fr_args<float>(c, nullptr, M);
+    hipLaunchKernelGGL((k_fr_tile_mfma<MODE_DENSE, 8>), dim3(nblk), dim3(512), 0, c->stream, a);
+  } else {
+    FrArgs<double> a = fr_args<double>(c, nullptr, M);
+    hipLaunchKernelGGL((k_fr_tile_generic<double, MODE_DENSE>), dim3(nblk), dim3(256), 0, c->stream, a);
+  }
+}
+
+void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const ValueIn &vin, const OutArgs &out) {
+  const int nb = (c->cfg.d + 31) / 32;
+  const int nblk = nb * (nb + 1) / 2;
+  if (c->cfg.dtype == MIVI_F32) {
+    FrArgs<float> a = fr_args<float>(c, params, M);
+    a.vin = vin;
+    a.out = out;
+    hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 4>), dim3(nblk), dim3(256), 0, c->stream, a);
+  } else {
+    FrArgs<double> a = fr_args<double>(c, params, M);
+    a.vin = vin;
+    a.out = out;
+    hipLaunchKernelGGL((k_fr_tile_generic<double, MODE_VJP>), dim3(nblk), dim3(256), 0, c->stream, a);
+  }
+}
+
+void launch_fr_stl(mivi_ctx *c, const void *params, int M) {
+  const int nblk = (M + 7) / 8;
+  if (c->cfg.dtype == MIVI_F32) {
+    FrArgs<float> a = fr_args<float>(c, params, M);
+    const size_t sh = (8 * (size_t)c->dP + 32 * 33) * sizeof(float);
+    hipLaunchKernelGGL(k_fr_stl<float>, dim3(nblk), dim3(256), sh, c->stream, a);
+  } else {
+    FrArgs<double> a = fr_args<double>(c, params, M);
+    const size_t sh = (8 * (size_t)c->dP + 32 * 33) * sizeof(double);
+    hipLaunchKernelGGL(k_fr_stl<double>, dim3(nblk), dim3(256), sh, c->stream, a);
+  }
+}
+
+}  // namespace mivi

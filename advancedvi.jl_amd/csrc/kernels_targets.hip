@@ -1,0 +1,315 @@
+// Built-in target log-densities evaluated as standalone kernels: Z (d x M) -> ell (M), G (d x M).
+// These sit where the reference calls the LogDensityProblems plugin once per column
+// (`mean(logdensity(prob, z_m))`, src/algorithms/repgradelbo.jl:84-86; gradient through the rrule
+// seam src/mixedad_logdensity.jl:23-34).
+//
+//   diag Gaussian  MvNormal(mean, Diagonal(std^2))          test/models/normal.jl:56-75
+//   funnel         Neal's funnel + Stacked([log, identity])  SURVEY.md 8d (README.md:76-82,102-106 wrapper)
+//   logreg         hierarchical logistic regression           docs/src/tutorials/subsampling.md:26-38 (variant 0)
+//                                                              README.md:42-66,91-106                (variant 1)
+#include "device_common.h"
+
+namespace mivi {
+
+// one workgroup per sample column; rows strided over threads (coalesced)
+template <typename T>
+__global__ __launch_bounds__(256) void k_col_target(ColTargetArgs<T> a) {
+  __shared__ double red[4];
+  const int m = blockIdx.x, tid = threadIdx.x, d = a.d;
+  const T *z = a.Z + (size_t)m * d;
+  T *g = a.G + (size_t)m * d;
+  if (a.kind == TGT_DIAG_GAUSS) {
+    T acc = 0;
+    for (int i = tid; i < d; i += 256) {
+      const T u = (z[i] - a.t_mean[i]) * a.t_istd[i];
+      acc += T(-0.5) * u * u;
+      if (a.want_grad) g[i] = -u * a.t_istd[i];
+    }
+    const double s = block_sum<double, 256>((double)acc, red);
+    if (tid == 0) a.ell[m] = (T)s;
+  } else {  // TGT_FUNNEL
+    const double e1 = (double)z[0];
+    const double inv_s2 = exp(-2.0 * e1);
+    T acc = 0;
+    for (int i = 1 + tid; i < d; i += 256) {
+      const T x = z[i];
+      acc += x * x;
+      if (a.want_grad) g[i] = (T)(-(double)x * inv_s2);
+    }
+    const double sx2 = block_sum<double, 256>((double)acc, red);
+    if (tid == 0) {
+      const double n = (double)(d - 1), sv2 = a.sigma_v * a.sigma_v;
+      // log LogNormal(e^{e1}; 0, sv) + sum_i log N(x_i; 0, e^{e1}) + log|det J| (= e1); constants in ell_const
+      a.ell[m] = (T)((-e1 - e1 * e1 / (2.0 * sv2)) + (-n * e1 - 0.5 * sx2 * inv_s2) + e1);
+      if (a.want_grad) g[0] = (T)((-1.0 - e1 / sv2) + (-n + sx2 * inv_s2) + 1.0);
+    }
+  }
+}
+
+template <typename T>
+static void col_target_impl(mivi_ctx *c, int M, int want_grad) {
+  ColTargetArgs<T> a;
+  a.d = c->cfg.d;
+  a.M = M;
+  a.kind = c->target;
+  a.Z = (const T *)c->Z.p;
+  a.G = (T *)c->W.p;
+  a.ell = (T *)c->ell.p;
+  a.t_mean = (const T *)c->t_mean.p;
+  a.t_istd = (const T *)c->t_istd.p;
+  a.sigma_v = c->funnel_sigma_v;
+  a.want_grad = want_grad;
+  hipLaunchKernelGGL(k_col_target<T>, dim3(M), dim3(256), 0, c->stream, a);
+}
+
+void launch_col_target(mivi_ctx *c, int M, int want_grad) {
+  if (c->cfg.dtype == MIVI_F32) col_target_impl<float>(c, M, want_grad); else col_target_impl<double>(c, M, want_grad);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hierarchical logistic regression, generic route (any T): three kernels
+//   L1: logits = X B (n x p by p x M), resid = y - sigmoid(logit), per-(rowblock, m) loglik partials
+//   L2: split-K  X^T resid  partials
+//   L3: per column: reduce, add priors, write ell_m and G[:, m]
+// X is n x p COLUMN-major (X[r + k*n], Julia's native Matrix layout), theta = [beta (p); s].
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct LrArgs {
+  int d, p, M;
+  int64_t n;
+  const T *X;
+  const uint8_t *y;
+  const T *Z;      // d x M
+  T *R;            // n x M resid (col-major)
+  double *ll_part; // [nrb][M]
+  T *g_part;       // [S][p*M]
+  int S, nrb;
+  int64_t rows_per_split;
+  T *G;
+  T *ell;
+  int variant;
+  double likeadj;
+  int want_grad;
+};
+
+template <typename T>
+__device__ __forceinline__ T softplus_t(T x) {
+  // log(1 + e^x), stable
+  return x > T(0) ? x + log1p(exp(-x)) : log1p(exp(x));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_lr_logits(LrArgs<T> a) {
+  __shared__ T As[16][65];  // As[k][r]
+  __shared__ T Bs[16][65];  // Bs[k][m]
+  __shared__ double colsum[4][64];
+  const int tid = threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int m0 = blockIdx.y * 64;
+  const int tr = tid & 15, tc = tid >> 4;  // thread computes rows tr + 16*i, cols tc + 16*j
+  T acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+  for (int k0 = 0; k0 < a.p; k0 += 16) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u;     // 0..1023
+      const int rl = e & 63, kl = e >> 6;
+      const int64_t r = r0 + rl;
+      const int k = k0 + kl;
+      As[kl][rl] = (r < a.n && k < a.p) ? a.X[(size_t)k * a.n + r] : T(0);
+      const int kl2 = e & 15, ml = e >> 4;
+      const int k2 = k0 + kl2, m = m0 + ml;
+      Bs[kl2][ml] = (k2 < a.p && m < a.M) ? a.Z[(size_t)m * a.d + k2] : T(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kl = 0; kl < 16; ++kl) {
+      T av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = As[kl][tr + 16 * i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = Bs[kl][tc + 16 * j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+    }
+    __syncthreads();
+  }
+  // epilogue: residuals + log-likelihood column partials
+  double ll[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t r = r0 + tr + 16 * i;
+    if (r < a.n) {
+      const T yv = (T)a.y[r];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = m0 + tc + 16 * j;
+        if (m < a.M) {
+          const T lg = acc[i][j];
+          ll[j] += (double)(yv * lg - softplus_t(lg));
+          if (a.want_grad) a.R[(size_t)m * a.n + r] = yv - T(1) / (T(1) + exp(-lg));
+        }
+      }
+    }
+  }
+  // reduce over the 16 threads (tr) sharing a column set: lanes tid&15 are adjacent
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    double v = ll[j];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    if (tr == 0) colsum[j][tc] = v;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int j = tid >> 4, tcc = tid & 15;
+    const int m = m0 + tcc + 16 * j;
+    if (m < a.M) a.ll_part[(size_t)blockIdx.x * a.M + m] = colsum[j][tcc];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_lr_xtr(LrArgs<T> a) {
+  __shared__ T As[16][65];  // As[r][k]
+  __shared__ T Bs[16][65];  // Bs[r][m]
+  const int tid = threadIdx.x;
+  const int k0 = blockIdx.x * 64, m0 = blockIdx.y * 64, s = blockIdx.z;
+  const int64_t rbeg = (int64_t)s * a.rows_per_split;
+  const int64_t rend = min(a.n, rbeg + a.rows_per_split);
+  const int tr = tid & 15, tc = tid >> 4;
+  T acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+  for (int64_t r0 = rbeg; r0 < rend; r0 += 16) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + 256 * u;
+      const int rl = e & 15, cl = e >> 4;   // 16 consecutive rows per column: 64-byte segments
+      const int64_t r = r0 + rl;
+      const int k = k0 + cl, m = m0 + cl;
+      As[rl][cl] = (r < rend && k < a.p) ? a.X[(size_t)k * a.n + r] : T(0);
+      Bs[rl][cl] = (r < rend && m < a.M) ? a.R[(size_t)m * a.n + r] : T(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rl = 0; rl < 16; ++rl) {
+      T av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = As[rl][tr + 16 * i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = Bs[rl][tc + 16 * j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + tr + 16 * i, m = m0 + tc + 16 * j;
+      if (k < a.p && m < a.M) a.g_part[((size_t)s * a.M + m) * a.p + k] = acc[i][j];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_lr_finish(LrArgs<T> a) {
+  __shared__ double red[4];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int p = a.p, d = a.d;
+  const T *z = a.Z + (size_t)m * d;
+  const double sv = (double)z[p];
+  const double sigma = exp(sv), inv_s2 = exp(-2.0 * sv);
+  double ll = 0.0;
+  for (int b = tid; b < a.nrb; b += 256) ll += a.ll_part[(size_t)b * a.M + m];
+  ll = block_sum<double, 256>(ll, red);
+  double bb = 0.0;
+  for (int k = tid; k < p; k += 256) {
+    const double bk = (double)z[k];
+    bb += bk * bk;
+    if (a.want_grad) {
+      double g = 0.0;
+      for (int s = 0; s < a.S; ++s) g += (double)a.g_part[((size_t)s * a.M + m) * p + k];
+      a.G[(size_t)m * d + k] = (T)(a.likeadj * g - bk * inv_s2);
+    }
+  }
+  bb = block_sum<double, 256>(bb, red);
+  if (tid == 0) {
+    const double logprior_beta = -0.5 * p * kLog2Pi - p * sv - 0.5 * bb * inv_s2;
+    double gs = -(double)p + bb * inv_s2;
+    double logprior_sigma, jac;
+    if (a.variant == 0) {
+      logprior_sigma = -0.5 * log(2.0 * 3.14159265358979323846 * 9.0) - sigma * sigma / 18.0;
+      gs += -(sigma * sigma) / 9.0;
+      jac = 0.0;
+    } else {
+      logprior_sigma = -sv - log(3.0) - 0.5 * kLog2Pi - sv * sv / 18.0;
+      gs += -1.0 - sv / 9.0 + 1.0;
+      jac = sv;
+    }
+    a.ell[m] = (T)(a.likeadj * ll + logprior_beta + logprior_sigma + jac);
+    if (a.want_grad) a.G[(size_t)m * d + p] = (T)gs;
+  }
+}
+
+template <typename T>
+static void logreg_impl(mivi_ctx *c, int M, int want_grad) {
+  LrArgs<T> a;
+  a.d = c->cfg.d;
+  a.p = a.d - 1;
+  a.M = M;
+  a.n = c->lr_n;
+  a.X = (const T *)c->lr_X;
+  a.y = c->lr_y;
+  a.Z = (const T *)c->Z.p;
+  a.nrb = (int)((a.n + 63) / 64);
+  int S = (int)((a.n + 4095) / 4096);
+  if (S > 128) S = 128;
+  if (S < 1) S = 1;
+  int64_t rps = (a.n + S - 1) / S;
+  rps = (rps + 15) / 16 * 16;
+  S = (int)((a.n + rps - 1) / rps);
+  a.S = S;
+  a.rows_per_split = rps;
+  const size_t need_R = (size_t)a.n * M * sizeof(T);
+  const size_t need_ll = (size_t)a.nrb * M * sizeof(double);
+  const size_t need_g = (size_t)S * a.p * M * sizeof(T);
+  // scratch layout inside lr_scratch: [R | g_part], lr_part: ll_part
+  if (c->lr_scratch.bytes < need_R + need_g) {
+    if (c->lr_scratch.p) (void)hipFree(c->lr_scratch.p);
+    (void)hipMalloc(&c->lr_scratch.p, need_R + need_g);
+    c->lr_scratch.bytes = need_R + need_g;
+  }
+  if (c->lr_part.bytes < need_ll) {
+    if (c->lr_part.p) (void)hipFree(c->lr_part.p);
+    (void)hipMalloc(&c->lr_part.p, need_ll);
+    c->lr_part.bytes = need_ll;
+  }
+  a.R = (T *)c->lr_scratch.p;
+  a.g_part = (T *)((char *)c->lr_scratch.p + need_R);
+  a.ll_part = (double *)c->lr_part.p;
+  a.G = (T *)c->W.p;
+  a.ell = (T *)c->ell.p;
+  a.variant = c->lr_variant;
+  a.likeadj = c->lr_likeadj;
+  a.want_grad = want_grad;
+  hipLaunchKernelGGL(k_lr_logits<T>, dim3(a.nrb, (M + 63) / 64), dim3(256), 0, c->stream, a);
+  if (want_grad)
+    hipLaunchKernelGGL(k_lr_xtr<T>, dim3((a.p + 63) / 64, (M + 63) / 64, S), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_lr_finish<T>, dim3(M), dim3(256), 0, c->stream, a);
+}
+
+void launch_logreg_target(mivi_ctx *c, int M, int want_grad) {
+  if (c->cfg.dtype == MIVI_F32) logreg_impl<float>(c, M, want_grad); else logreg_impl<double>(c, M, want_grad);
+}
+
+}  // namespace mivi

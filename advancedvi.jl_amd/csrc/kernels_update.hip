@@ -1,0 +1,286 @@
+// Small elementwise kernels next to the hot path:
+//   finalize   partials (after the RCCL all-reduce) -> value, gradient        
+//   value-only objective assembly for estimate_objective                      src/algorithms/repgradelbo.jl:112-118
+//   ClipScale  scale[diagind] = max(scale[diagind], eps)                      src/optimization/clip_scale.jl:18-29
+//   Descent / Adam parameter updates (Optimisers.update!)                     src/algorithms/common.jl:92
+#include "device_common.h"
+
+namespace mivi {
+
+template <typename T>
+struct FinArgs {
+  int d, family;
+  const T *params;
+  const T *partials;
+  T *grad;
+  T *value;
+  int ent_kind, M_total;
+  int *status;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_finalize(FinArgs<T> a) {
+  __shared__ double red[4];
+  const int d = a.d;
+  const int64_t plen = a.family == MIVI_MEANFIELD ? 2 * (int64_t)d : (int64_t)d + (int64_t)d * d;
+  const double invM = 1.0 / (double)a.M_total;
+  const double direct = direct_entropy_coeff(a.ent_kind);
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < plen; t += (int64_t)gridDim.x * 256) {
+    double g = -(double)a.partials[t] * invM;
+    if (a.family == MIVI_MEANFIELD) {
+      if (t >= d) g -= direct / (double)a.params[t];
+    } else if (t >= d) {
+      const int64_t e = t - d;
+      const int j = (int)(e / d), i = (int)(e - (int64_t)j * d);
+      if (i == j) g -= direct / (double)a.params[t];
+      if (j > i) g = 0.0;
+    }
+    a.grad[t] = (T)g;
+  }
+  if (blockIdx.x == 0) {
+    double s_ld = 0.0, bad = 0.0;
+    for (int i = threadIdx.x; i < d; i += 256) {
+      const double c = (double)(a.family == MIVI_MEANFIELD ? a.params[d + i] : a.params[d + (size_t)i * d + i]);
+      if (!(c > 0.0)) bad = 1.0;
+      s_ld += log(c);
+    }
+    s_ld = block_sum<double, 256>(s_ld, red);
+    bad = block_sum<double, 256>(bad, red);
+    if (threadIdx.x == 0) {
+      const double sum_ell = (double)a.partials[plen], s_he = (double)a.partials[plen + 1];
+      const double Mt = (double)a.M_total;
+      const double ent = (ent_is_closed(a.ent_kind) ? 0.5 * d * (1.0 + kLog2Pi) : s_he / Mt + 0.5 * d * kLog2Pi) + s_ld;
+      const double value = -(sum_ell / Mt + ent);
+      *a.value = (T)value;
+      int st = 0;
+      if (!isfinite(value)) st |= 1;
+      if (bad > 0.0) st |= 2;
+      if (st && a.status) atomicOr(a.status, st);
+    }
+  }
+}
+
+template <typename T>
+static void finalize_impl(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad) {
+  FinArgs<T> a;
+  a.d = c->cfg.d;
+  a.family = c->cfg.family;
+  a.params = (const T *)params;
+  a.partials = (const T *)partials;
+  a.grad = (T *)grad;
+  a.value = (T *)value;
+  a.ent_kind = c->cfg.entropy;
+  a.M_total = c->M_total;
+  a.status = (int *)c->status.p;
+  const int64_t plen = mivi_params_len(c);
+  int nb = (int)((plen + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_finalize<T>, dim3(nb), dim3(256), 0, c->stream, a);
+}
+void launch_finalize(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad) {
+  if (c->cfg.dtype == MIVI_F32) finalize_impl<float>(c, params, partials, value, grad);
+  else finalize_impl<double>(c, params, partials, value, grad);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_value_only(int d, int family, const T *params, ValueIn vin, OutArgs out) {
+  __shared__ double red[4];
+  const int64_t plen = family == MIVI_MEANFIELD ? 2 * (int64_t)d : (int64_t)d + (int64_t)d * d;
+  const int fam = family;
+  finalize_value_block<T, 256, false>(d, vin, out, plen,
+      [params, d, fam](int i) { return fam == MIVI_MEANFIELD ? params[d + i] : params[d + (size_t)i * d + i]; }, red);
+}
+void launch_value_only(mivi_ctx *c, const void *params, const ValueIn &vin, const OutArgs &out) {
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_value_only<float>, dim3(1), dim3(256), 0, c->stream, c->cfg.d, c->cfg.family,
+                       (const float *)params, vin, out);
+  else
+    hipLaunchKernelGGL(k_value_only<double>, dim3(1), dim3(256), 0, c->stream, c->cfg.d, c->cfg.family,
+                       (const double *)params, vin, out);
+}
+
+template <typename T>
+__global__ void k_clip(int d, int family, T *params, T epsilon) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < d) {
+    const size_t o = family == MIVI_MEANFIELD ? (size_t)d + i : (size_t)d + (size_t)i * d + i;
+    const T v = params[o];
+    params[o] = v > epsilon ? v : epsilon;   // max(v, eps); NaN propagates like Julia's max
+    if (v != v) params[o] = v;
+  }
+}
+void launch_clip(mivi_ctx *c, void *params, double epsilon) {
+  const int d = c->cfg.d;
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_clip<float>, dim3((d + 255) / 256), dim3(256), 0, c->stream, d, c->cfg.family, (float *)params,
+                       (float)epsilon);
+  else
+    hipLaunchKernelGGL(k_clip<double>, dim3((d + 255) / 256), dim3(256), 0, c->stream, d, c->cfg.family,
+                       (double *)params, epsilon);
+}
+
+template <typename T>
+__global__ void k_descent(int64_t n, T *params, const T *grad, T eta) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    params[i] -= eta * grad[i];
+}
+void launch_descent(mivi_ctx *c, void *params, const void *grad, double eta) {
+  const int64_t n = mivi_params_len(c);
+  int nb = (int)((n + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_descent<float>, dim3(nb), dim3(256), 0, c->stream, n, (float *)params, (const float *)grad,
+                       (float)eta);
+  else
+    hipLaunchKernelGGL(k_descent<double>, dim3(nb), dim3(256), 0, c->stream, n, (double *)params, (const double *)grad,
+                       eta);
+}
+
+// Optimisers.Adam: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; x -= eta * m/(1-b1^t) / (sqrt(v/(1-b2^t)) + eps)
+template <typename T>
+__global__ void k_adam(int64_t n, T *params, const T *grad, T *state, const int64_t *t_ptr, int64_t t_base, double eta,
+                       double b1, double b2, double eps) {
+  const int64_t t = t_base + (t_ptr ? *t_ptr : 0);
+  const double c1 = 1.0 - pow(b1, (double)t), c2 = 1.0 - pow(b2, (double)t);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double g = (double)grad[i];
+    const double m = b1 * (double)state[i] + (1.0 - b1) * g;
+    const double v = b2 * (double)state[n + i] + (1.0 - b2) * g * g;
+    state[i] = (T)m;
+    state[n + i] = (T)v;
+    params[i] = (T)((double)params[i] - eta * (m / c1) / (sqrt(v / c2) + eps));
+  }
+}
+void launch_adam(mivi_ctx *c, void *params, const void *grad, void *state, const int64_t *t_ptr, int64_t t_base,
+                 double eta, double b1, double b2, double eps) {
+  const int64_t n = mivi_params_len(c);
+  int nb = (int)((n + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_adam<float>, dim3(nb), dim3(256), 0, c->stream, n, (float *)params, (const float *)grad,
+                       (float *)state, t_ptr, t_base, eta, b1, b2, eps);
+  else
+    hipLaunchKernelGGL(k_adam<double>, dim3(nb), dim3(256), 0, c->stream, n, (double *)params, (const double *)grad,
+                       (double *)state, t_ptr, t_base, eta, b1, b2, eps);
+}
+
+__global__ void k_bump(uint64_t *ctr, uint64_t by) { *ctr += by; }
+void launch_bump(mivi_ctx *c, uint64_t *ctr, uint64_t by) {
+  hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, c->stream, ctr, by);
+}
+
+}  // namespace mivi
+
+// ---------------------------------------------------------------------------------------------
+// axpby (PolynomialAveraging, src/optimization/averaging.jl:40-47) and DoG / DoWG
+// (src/optimization/rules.jl:17-64).  DoG/DoWG need two global norms; one 1024-thread workgroup
+// reduces and applies (O(params) work, off the estimator's critical path).
+// ---------------------------------------------------------------------------------------------
+namespace mivi {
+
+template <typename T>
+__global__ void k_axpby(int64_t n, T *y, double a, const T *x, double b) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = (T)(a * (double)x[i] + b * (double)y[i]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_dog_init(int64_t n, const T *params, T *x0, double *sc, double alpha) {
+  __shared__ double red[16];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const T v = params[i];
+    x0[i] = v;
+    s += (double)v * (double)v;
+  }
+  s = block_sum<double, 1024>(s, red);
+  if (threadIdx.x == 0) {
+    sc[0] = 0.0;                          // v
+    sc[1] = alpha * (1.0 + sqrt(s));      // r
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void k_dog_update(int64_t n, T *params, const T *grad, const T *x0, double *sc, int kind) {
+  __shared__ double red[16];
+  double dist2 = 0.0, g2 = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const double dx = (double)params[i] - (double)x0[i];
+    const double g = (double)grad[i];
+    dist2 += dx * dx;
+    g2 += g * g;
+  }
+  dist2 = block_sum<double, 1024>(dist2, red);
+  g2 = block_sum<double, 1024>(g2, red);
+  double r = sc[1], v = sc[0];
+  r = fmax(sqrt(dist2), r);
+  double eta;
+  if (kind == 1) {  // DoWG
+    const double r2 = r * r;
+    v = v + r2 * g2;
+    eta = r2 / sqrt(v);
+  } else {          // DoG
+    v = v + g2;
+    eta = r / sqrt(v);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sc[0] = v;
+    sc[1] = r;
+  }
+  for (int64_t i = threadIdx.x; i < n; i += 1024) params[i] = (T)((double)params[i] - eta * (double)grad[i]);
+}
+
+void launch_axpby(mivi_ctx *c, void *y, double a, const void *x, double b, int64_t n) {
+  int nb = (int)((n + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_axpby<float>, dim3(nb), dim3(256), 0, c->stream, n, (float *)y, a, (const float *)x, b);
+  else
+    hipLaunchKernelGGL(k_axpby<double>, dim3(nb), dim3(256), 0, c->stream, n, (double *)y, a, (const double *)x, b);
+}
+void launch_dog_init(mivi_ctx *c, const void *params, void *state, double alpha) {
+  const int64_t n = mivi_params_len(c);
+  double *sc = (double *)((char *)state + mivi_dog_state_bytes(c) - 16);
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_dog_init<float>, dim3(1), dim3(1024), 0, c->stream, n, (const float *)params, (float *)state, sc, alpha);
+  else
+    hipLaunchKernelGGL(k_dog_init<double>, dim3(1), dim3(1024), 0, c->stream, n, (const double *)params, (double *)state, sc, alpha);
+}
+void launch_dog_update(mivi_ctx *c, void *params, const void *grad, void *state, int kind) {
+  const int64_t n = mivi_params_len(c);
+  double *sc = (double *)((char *)state + mivi_dog_state_bytes(c) - 16);
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_dog_update<float>, dim3(1), dim3(1024), 0, c->stream, n, (float *)params, (const float *)grad,
+                       (const float *)state, sc, kind);
+  else
+    hipLaunchKernelGGL(k_dog_update<double>, dim3(1), dim3(1024), 0, c->stream, n, (double *)params, (const double *)grad,
+                       (const double *)state, sc, kind);
+}
+
+}  // namespace mivi
+
+extern "C" {
+int64_t mivi_dog_state_bytes(const mivi_ctx_t *c) {
+  const int64_t b = mivi_params_len(c) * (int64_t)c->esize;
+  return (b + 7) / 8 * 8 + 16;
+}
+mivi_status_t mivi_axpby(mivi_ctx_t *c, void *y, double a, const void *x, double b, int64_t n) {
+  if (!c || !y || !x || n < 0) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  mivi::launch_axpby(c, y, a, x, b, n);
+  return hipGetLastError() == hipSuccess ? MIVI_OK : MIVI_ERR_HIP;
+}
+mivi_status_t mivi_dog_init(mivi_ctx_t *c, const void *params, void *state, double alpha) {
+  if (!c || !params || !state) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  mivi::launch_dog_init(c, params, state, alpha);
+  return hipGetLastError() == hipSuccess ? MIVI_OK : MIVI_ERR_HIP;
+}
+mivi_status_t mivi_dog_update(mivi_ctx_t *c, void *params, const void *grad, void *state, int32_t kind) {
+  if (!c || !params || !grad || !state || (kind != 0 && kind != 1)) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  mivi::launch_dog_update(c, params, grad, state, kind);
+  return hipGetLastError() == hipSuccess ? MIVI_OK : MIVI_ERR_HIP;
+}
+}

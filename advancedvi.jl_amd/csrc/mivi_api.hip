@@ -1,0 +1,703 @@
+// libmivi C ABI (include/mivi.h): context management, target set-up and the estimate drivers that
+// sequence the HIP kernels.  Reference call stack being replaced: SURVEY.md section 3.2
+// (estimate_gradient! -> _value_and_gradient! -> AD of estimate_repgradelbo_ad_forward).
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "mivi_internal.h"
+
+using namespace mivi;
+
+#define HIPCHK(c, call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+      return MIVI_ERR_HIP;                                                                \
+    }                                                                                     \
+  } while (0)
+
+static mivi_status_t fail(mivi_ctx *c, mivi_status_t s, const char *msg) {
+  if (c) c->err = msg;
+  return s;
+}
+
+static mivi_status_t ensure(mivi_ctx *c, DevBuf &b, size_t bytes, bool zero) {
+  if (b.bytes >= bytes && b.p) return MIVI_OK;
+  if (b.p) HIPCHK(c, hipFree(b.p));
+  b.p = nullptr;
+  b.bytes = 0;
+  if (bytes == 0) bytes = 16;
+  HIPCHK(c, hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  if (zero) HIPCHK(c, hipMemsetAsync(b.p, 0, bytes, c->stream));
+  return MIVI_OK;
+}
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// work buffers for up to M samples per launch
+static mivi_status_t ensure_work(mivi_ctx *c, int M) {
+  const int d = c->cfg.d;
+  const size_t es = c->esize;
+  mivi_status_t s;
+  if (M > c->cap_M) {
+    // a capacity change re-zeros the padded RNG buffers (their padding must stay 0 / finite)
+    const int capM = round_up(M, 64);
+    c->dP = round_up(d, 64);
+    c->MP = capM;
+    if (c->cfg.family == MIVI_FULLRANK) {
+      c->eps.bytes = 0; c->epsT.bytes = 0; c->RT.bytes = 0;
+      if ((s = ensure(c, c->eps, (size_t)c->dP * c->MP * es, true))) return s;
+      if ((s = ensure(c, c->epsT, (size_t)c->dP * c->MP * es, true))) return s;
+      if (c->target == TGT_DENSE_GAUSS || c->target == TGT_LOGREG) {
+        if ((s = ensure(c, c->RT, (size_t)c->dP * c->MP * es, true))) return s;
+      }
+    }
+    if ((s = ensure(c, c->Z, (size_t)d * capM * es, false))) return s;
+    if ((s = ensure(c, c->W, (size_t)d * capM * es, false))) return s;
+    if ((s = ensure(c, c->ell, (size_t)capM * es, false))) return s;
+    const int d4 = (d + 3) / 4;
+    size_t n_part = (size_t)((d + 31) / 32) * (size_t)((capM + 31) / 32) + 64;
+    size_t n_he = (size_t)((d + 63) / 64) * (size_t)(capM / 64 + 1);
+    const size_t n_he_mf = (size_t)((d4 + 255) / 256) * (size_t)capM;
+    if (n_he_mf > n_he) n_he = n_he_mf;
+    if ((s = ensure(c, c->ell_part, n_part * sizeof(double), false))) return s;
+    if ((s = ensure(c, c->he_part, (n_he + 64) * sizeof(double), false))) return s;
+    const size_t ncc = (size_t)(capM / 256 + 2);
+    if ((s = ensure(c, c->row_part, ncc * d4 * 8 * sizeof(double), false))) return s;
+    if ((s = ensure(c, c->sc_part, 2 * ncc * d4 * sizeof(double) + 64, false))) return s;
+    c->cap_M = capM;
+  }
+  return MIVI_OK;
+}
+
+extern "C" {
+
+int32_t mivi_version(void) { return MIVI_VERSION_MAJOR * 1000 + MIVI_VERSION_MINOR; }
+
+const char *mivi_last_error(const mivi_ctx_t *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int64_t mivi_params_len(const mivi_ctx_t *c) {
+  const int64_t d = c->cfg.d;
+  return c->cfg.family == MIVI_MEANFIELD ? 2 * d : d + d * d;
+}
+int64_t mivi_partials_len(const mivi_ctx_t *c) { return mivi_params_len(c) + 2; }
+
+mivi_status_t mivi_create(const mivi_config_t *cfg, mivi_ctx_t **out) {
+  if (!cfg || !out) return MIVI_ERR_BAD_ARG;
+  if (cfg->d <= 0 || cfg->n_mc <= 0) return MIVI_ERR_BAD_ARG;
+  if (cfg->dtype != MIVI_F32 && cfg->dtype != MIVI_F64) return MIVI_ERR_BAD_ARG;
+  if (cfg->family != MIVI_MEANFIELD && cfg->family != MIVI_FULLRANK) return MIVI_ERR_BAD_ARG;
+  if (cfg->entropy < 0 || cfg->entropy > MIVI_ENT_STL_ZERO_GRAD) return MIVI_ERR_BAD_ARG;
+  if (cfg->m_offset < 0) return MIVI_ERR_BAD_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) {
+    fprintf(stderr, "libmivi: no usable HIP device %d (found %d): this library has no CPU fallback\n", cfg->device, ndev);
+    return MIVI_ERR_HIP;
+  }
+  mivi_ctx *c = new mivi_ctx();
+  c->cfg = *cfg;
+  c->esize = cfg->dtype == MIVI_F32 ? 4 : 8;
+  c->M_total = cfg->m_total > 0 ? cfg->m_total : cfg->n_mc;
+  if (hipSetDevice(cfg->device) != hipSuccess) { delete c; return MIVI_ERR_HIP; }
+  if (!cfg->own_stream) {
+    c->stream = (hipStream_t)cfg->stream;   // NULL = the null stream
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MIVI_ERR_HIP; }
+    c->own_stream = true;
+  }
+  mivi_status_t s;
+  if ((s = ensure(c, c->ticket, 64, true)) || (s = ensure(c, c->status, 64, true)) ||
+      (s = ensure(c, c->d_idx, 64, true)) || (s = ensure(c, c->acc, 64, true)) ||
+      (s = ensure(c, c->tmp_params, (size_t)mivi_params_len(c) * c->esize, false)) ||
+      (s = ensure(c, c->tmp_out, ((size_t)mivi_partials_len(c) + 8) * c->esize, false))) {
+    delete c;
+    return s;
+  }
+  *out = c;
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_destroy(mivi_ctx_t *c) {
+  if (!c) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->graph.exec) (void)hipGraphExecDestroy(c->graph.exec);
+  DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part,
+                    &c->eps, &c->epsT, &c->Z, &c->W, &c->RT, &c->ell, &c->X, &c->ell_part, &c->he_part, &c->row_part,
+                    &c->sc_part, &c->ticket, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+  for (DevBuf *b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+  delete c;
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_set_stream(mivi_ctx_t *c, void *s) {
+  if (!c) return MIVI_ERR_BAD_ARG;
+  if (c->own_stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); c->own_stream = false; }
+  c->stream = (hipStream_t)s;   // NULL = the null stream
+  if (c->graph.exec) { (void)hipGraphExecDestroy(c->graph.exec); c->graph = GraphCache{}; }
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_synchronize(mivi_ctx_t *c) {
+  if (!c) return MIVI_ERR_BAD_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MIVI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// targets
+// ---------------------------------------------------------------------------------------------
+static double host_get(const void *p, int dtype, size_t i) {
+  return dtype == MIVI_F32 ? (double)((const float *)p)[i] : ((const double *)p)[i];
+}
+static mivi_status_t upload_vec(mivi_ctx *c, DevBuf &b, const std::vector<double> &v) {
+  mivi_status_t s = ensure(c, b, v.size() * c->esize, false);
+  if (s) return s;
+  if (c->cfg.dtype == MIVI_F32) {
+    std::vector<float> f(v.begin(), v.end());
+    HIPCHK(c, hipMemcpy(b.p, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+  } else {
+    HIPCHK(c, hipMemcpy(b.p, v.data(), v.size() * 8, hipMemcpyHostToDevice));
+  }
+  return MIVI_OK;
+}
+static void invalidate_graph(mivi_ctx *c) {
+  if (c->graph.exec) { (void)hipGraphExecDestroy(c->graph.exec); c->graph = GraphCache{}; }
+}
+
+mivi_status_t mivi_set_target_diag_gauss(mivi_ctx_t *c, const void *mean, const void *stdv) {
+  if (!c || !mean || !stdv) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  const int d = c->cfg.d;
+  std::vector<double> m(d), is(d);
+  double cst = -0.5 * d * kLog2Pi;
+  for (int i = 0; i < d; ++i) {
+    const double s = host_get(stdv, c->cfg.dtype, i);
+    if (!(s > 0.0)) return fail(c, MIVI_ERR_BAD_ARG, "diag_gauss: std must be positive");
+    m[i] = host_get(mean, c->cfg.dtype, i);
+    is[i] = 1.0 / s;
+    cst -= log(s);
+  }
+  mivi_status_t s;
+  if ((s = upload_vec(c, c->t_mean, m)) || (s = upload_vec(c, c->t_istd, is))) return s;
+  c->t_const = cst;
+  c->target = TGT_DIAG_GAUSS;
+  invalidate_graph(c);
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_set_target_dense_gauss(mivi_ctx_t *c, const void *mean, const void *Lh) {
+  if (!c || !mean || !Lh) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  const int d = c->cfg.d;
+  const int dP = round_up(d, 64);
+  std::vector<double> L((size_t)d * d, 0.0), Li((size_t)d * d, 0.0), m(d);
+  double logdet = 0.0;
+  for (int j = 0; j < d; ++j)
+    for (int i = j; i < d; ++i) L[(size_t)j * d + i] = host_get(Lh, c->cfg.dtype, (size_t)j * d + i);
+  for (int i = 0; i < d; ++i) {
+    m[i] = host_get(mean, c->cfg.dtype, i);
+    const double lii = L[(size_t)i * d + i];
+    if (!(lii > 0.0)) return fail(c, MIVI_ERR_BAD_ARG, "dense_gauss: Cholesky diagonal must be positive");
+    logdet += 2.0 * log(lii);
+  }
+  // Li = L^-1 (lower), column by column (forward substitution), fp64 on the host
+  for (int j = 0; j < d; ++j) {
+    Li[(size_t)j * d + j] = 1.0 / L[(size_t)j * d + j];
+    for (int i = j + 1; i < d; ++i) {
+      double s = 0.0;
+      for (int k = j; k < i; ++k) s += L[(size_t)k * d + i] * Li[(size_t)j * d + k];
+      Li[(size_t)j * d + i] = -s / L[(size_t)i * d + i];
+    }
+  }
+  // P = Li^T Li, padded to dP x dP (zeros)
+  std::vector<double> P((size_t)dP * dP, 0.0);
+  for (int i = 0; i < d; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = 0.0;
+      for (int k = i; k < d; ++k) s += Li[(size_t)i * d + k] * Li[(size_t)j * d + k];
+      P[(size_t)j * dP + i] = s;
+      P[(size_t)i * dP + j] = s;
+    }
+  mivi_status_t s;
+  if ((s = upload_vec(c, c->t_mean, m)) || (s = upload_vec(c, c->t_prec, P))) return s;
+  c->t_const = -0.5 * logdet - 0.5 * d * kLog2Pi;
+  c->target = TGT_DENSE_GAUSS;
+  c->cap_M = 0;  // force (re)allocation of RT
+  invalidate_graph(c);
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_set_target_logreg(mivi_ctx_t *c, const void *X, const uint8_t *y, int64_t n, int32_t variant,
+                                     double likeadj, int32_t on_device) {
+  if (!c || !X || !y || n <= 0 || (variant != 0 && variant != 1) || c->cfg.d < 2) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  const int p = c->cfg.d - 1;
+  if (on_device) {
+    c->lr_X = X;
+    c->lr_y = y;
+  } else {
+    mivi_status_t s;
+    if ((s = ensure(c, c->lr_X_own, (size_t)n * p * c->esize, false)) || (s = ensure(c, c->lr_y_own, (size_t)n, false)))
+      return s;
+    HIPCHK(c, hipMemcpy(c->lr_X_own.p, X, (size_t)n * p * c->esize, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->lr_y_own.p, y, (size_t)n, hipMemcpyHostToDevice));
+    c->lr_X = c->lr_X_own.p;
+    c->lr_y = (const uint8_t *)c->lr_y_own.p;
+  }
+  c->lr_n = n;
+  c->lr_variant = variant;
+  c->lr_likeadj = likeadj;
+  c->t_const = 0.0;
+  c->target = TGT_LOGREG;
+  invalidate_graph(c);
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_set_target_funnel(mivi_ctx_t *c, double sigma_v) {
+  if (!c || !(sigma_v > 0.0) || c->cfg.d < 2) return MIVI_ERR_BAD_ARG;
+  c->funnel_sigma_v = sigma_v;
+  c->t_const = -log(sigma_v) - 0.5 * kLog2Pi - 0.5 * (c->cfg.d - 1) * kLog2Pi;
+  c->target = TGT_FUNNEL;
+  invalidate_graph(c);
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_set_target_callback(mivi_ctx_t *c, mivi_logdensity_and_gradient_fn fg, mivi_logdensity_fn fv,
+                                       void *user) {
+  if (!c || !fg) return MIVI_ERR_BAD_ARG;
+  c->cb_grad = fg;
+  c->cb_value = fv;
+  c->cb_user = user;
+  c->t_const = 0.0;
+  c->target = TGT_CALLBACK;
+  invalidate_graph(c);
+  return MIVI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// estimate driver
+// ---------------------------------------------------------------------------------------------
+static mivi_status_t eval_generic_target(mivi_ctx *c, int M, int want_grad) {
+  switch (c->target) {
+    case TGT_DIAG_GAUSS:
+    case TGT_FUNNEL:
+      launch_col_target(c, M, want_grad);
+      return MIVI_OK;
+    case TGT_LOGREG:
+      launch_logreg_target(c, M, want_grad);
+      return MIVI_OK;
+    case TGT_CALLBACK: {
+      const size_t es = c->esize, d = c->cfg.d;
+      c->h_Z.resize(d * M * es);
+      c->h_G.resize(d * M * es);
+      c->h_ell.resize((size_t)M * es);
+      HIPCHK(c, hipMemcpyAsync(c->h_Z.data(), c->Z.p, d * M * es, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      int rc;
+      if (!want_grad && c->cb_value)
+        rc = c->cb_value(c->cb_user, c->h_Z.data(), (int)d, M, c->h_ell.data());
+      else
+        rc = c->cb_grad(c->cb_user, c->h_Z.data(), (int)d, M, c->h_ell.data(), c->h_G.data());
+      if (rc != 0) return fail(c, MIVI_ERR_BAD_ARG, "target callback returned non-zero");
+      HIPCHK(c, hipMemcpyAsync(c->ell.p, c->h_ell.data(), (size_t)M * es, hipMemcpyHostToDevice, c->stream));
+      if (want_grad) HIPCHK(c, hipMemcpyAsync(c->W.p, c->h_G.data(), d * M * es, hipMemcpyHostToDevice, c->stream));
+      return MIVI_OK;
+    }
+    default:
+      return fail(c, MIVI_ERR_NO_TARGET, "no target set");
+  }
+}
+
+// One estimate over M local samples. out.partials_mode selects final vs shard partials.
+static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs &rng, int M, int want_grad,
+                                  OutArgs out) {
+  if (c->target == TGT_NONE) return fail(c, MIVI_ERR_NO_TARGET, "no target set");
+  mivi_status_t s = ensure_work(c, M);
+  if (s) return s;
+  out.M_local = M;
+  if (!out.status) out.status = (int *)c->status.p;
+  ValueIn vin{};
+  vin.ell_const = c->t_const;
+  const int d = c->cfg.d, d4 = (d + 3) / 4;
+  if (c->cfg.family == MIVI_MEANFIELD) {
+    if (c->target == TGT_DIAG_GAUSS) {
+      launch_mf_main(c, params, rng, M, want_grad, nullptr, vin, out);
+    } else {
+      launch_sample_mf(c, params, rng, M, c->Z.p, nullptr, 0, want_grad ? nullptr : (double *)c->he_part.p);
+      if ((s = eval_generic_target(c, M, want_grad))) return s;
+      vin.ell = c->ell.p;
+      vin.n_ell = M;
+      if (want_grad) {
+        launch_mf_main(c, params, rng, M, 1, c->W.p, vin, out);
+      } else {
+        vin.he_part = (const double *)c->he_part.p;
+        vin.n_he_part = ((d4 + 255) / 256) * M;
+        launch_value_only(c, params, vin, out);
+      }
+    }
+  } else {
+    launch_eps(c, rng, M);
+    vin.he_part = (const double *)c->he_part.p;
+    vin.n_he_part = eps_blocks(c, M);
+    if (c->target == TGT_DIAG_GAUSS) {
+      launch_fr_sample(c, params, M, TGT_DIAG_GAUSS, nullptr);
+      vin.ell_part = (const double *)c->ell_part.p;
+      vin.n_ell_part = fr_sample_blocks(c, M);
+    } else if (c->target == TGT_DENSE_GAUSS) {
+      launch_fr_sample(c, params, M, TGT_DENSE_GAUSS, c->Z.p);
+      launch_fr_dense_target(c, M, want_grad);
+      vin.ell_part = (const double *)c->ell_part.p;
+      vin.n_ell_part = fr_dense_blocks(c, M);
+    } else {
+      launch_fr_sample(c, params, M, TGT_NONE, c->Z.p);
+      if ((s = eval_generic_target(c, M, want_grad))) return s;
+      vin.ell = c->ell.p;
+      vin.n_ell = M;
+    }
+    if (want_grad) {
+      if (out.ent_kind == MIVI_ENT_STL || out.ent_kind == MIVI_ENT_STL_ZERO_GRAD) {
+        const size_t sh = (8 * (size_t)c->dP + 32 * 33) * c->esize;
+        if (sh > 160 * 1024) return fail(c, MIVI_ERR_UNSUPPORTED, "full-rank STL: d too large for the LDS-resident solve");
+        launch_fr_stl(c, params, M);
+      }
+      launch_fr_vjp(c, params, M, vin, out);
+    } else {
+      launch_value_only(c, params, vin, out);
+    }
+  }
+  HIPCHK(c, hipGetLastError());
+  return MIVI_OK;
+}
+
+static OutArgs final_out(mivi_ctx *c, void *value, void *grad) {
+  OutArgs o{};
+  o.grad = grad;
+  o.value = value;
+  o.partials = nullptr;
+  o.partials_mode = 0;
+  o.ent_kind = c->cfg.entropy;
+  o.M_total = c->M_total;
+  o.status = (int *)c->status.p;
+  return o;
+}
+
+static RngArgs rng_of(mivi_ctx *c, uint64_t idx) {
+  RngArgs r;
+  r.seed = c->cfg.seed;
+  r.idx_base = idx;
+  r.idx_ptr = nullptr;
+  r.m_offset = c->cfg.m_offset;
+  return r;
+}
+
+mivi_status_t mivi_sample(mivi_ctx_t *c, const void *params, uint64_t idx, void *Z, void *eps) {
+  if (!c || !params || !Z) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  const int M = c->cfg.n_mc, d = c->cfg.d;
+  mivi_status_t s = ensure_work(c, M);
+  if (s) return s;
+  if (c->cfg.family == MIVI_MEANFIELD) {
+    launch_sample_mf(c, params, rng_of(c, idx), M, Z, eps, d, nullptr);
+  } else {
+    launch_eps(c, rng_of(c, idx), M);
+    launch_fr_sample(c, params, M, TGT_NONE, Z);
+    if (eps)
+      HIPCHK(c, hipMemcpy2DAsync(eps, (size_t)d * c->esize, c->eps.p, (size_t)c->dP * c->esize, (size_t)d * c->esize, M,
+                                 hipMemcpyDeviceToDevice, c->stream));
+  }
+  HIPCHK(c, hipGetLastError());
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_estimate_gradient(mivi_ctx_t *c, const void *params, uint64_t idx, void *value, void *grad) {
+  if (!c || !params || !value || !grad) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  return run_estimate(c, params, rng_of(c, idx), c->cfg.n_mc, 1, final_out(c, value, grad));
+}
+
+static mivi_status_t read_status(mivi_ctx *c) {
+  int st = 0;
+  HIPCHK(c, hipMemcpyAsync(&st, c->status.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (st) HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream));
+  if (st & 2) return fail(c, MIVI_ERR_NONPOSITIVE_SCALE, "scale diagonal is not positive (use ClipScale)");
+  if (st & 1) return fail(c, MIVI_ERR_NONFINITE, "the objective value is not finite: the optimization run diverged");
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_estimate_gradient_host(mivi_ctx_t *c, const void *params_h, uint64_t idx, void *value_h, void *grad_h) {
+  if (!c || !params_h || !value_h || !grad_h) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  const size_t plen = (size_t)mivi_params_len(c), es = c->esize;
+  HIPCHK(c, hipMemcpyAsync(c->tmp_params.p, params_h, plen * es, hipMemcpyHostToDevice, c->stream));
+  char *o = (char *)c->tmp_out.p;
+  mivi_status_t s = run_estimate(c, c->tmp_params.p, rng_of(c, idx), c->cfg.n_mc, 1, final_out(c, o, o + 8));
+  if (s) return s;
+  HIPCHK(c, hipMemcpyAsync(value_h, o, es, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(grad_h, o + 8, plen * es, hipMemcpyDeviceToHost, c->stream));
+  return read_status(c);
+}
+
+mivi_status_t mivi_estimate_partials(mivi_ctx_t *c, const void *params, uint64_t idx, void *partials) {
+  if (!c || !params || !partials) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  OutArgs o = final_out(c, nullptr, nullptr);
+  o.partials = partials;
+  o.partials_mode = 1;
+  return run_estimate(c, params, rng_of(c, idx), c->cfg.n_mc, 1, o);
+}
+
+mivi_status_t mivi_finalize(mivi_ctx_t *c, const void *params, const void *partials, void *value, void *grad) {
+  if (!c || !params || !partials || !value || !grad) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  launch_finalize(c, params, partials, value, grad);
+  HIPCHK(c, hipGetLastError());
+  return MIVI_OK;
+}
+
+// weighted accumulation of chunk objective values
+__global__ void k_acc_value_f32(double *acc, const float *v, double w, int first) { acc[0] = (first ? 0.0 : acc[0]) + w * (double)v[0]; }
+__global__ void k_acc_value_f64(double *acc, const double *v, double w, int first) { acc[0] = (first ? 0.0 : acc[0]) + w * v[0]; }
+__global__ void k_store_value_f32(float *out, const double *acc) { out[0] = (float)acc[0]; }
+__global__ void k_store_value_f64(double *out, const double *acc) { out[0] = acc[0]; }
+
+mivi_status_t mivi_estimate_objective(mivi_ctx_t *c, const void *params, uint64_t idx, int32_t n_samples, int32_t entropy,
+                                      void *value) {
+  if (!c || !params || !value) return MIVI_ERR_BAD_ARG;
+  if (n_samples <= 0) n_samples = c->cfg.n_mc;
+  if (entropy < 0) entropy = c->cfg.entropy;
+  if (entropy > MIVI_ENT_STL_ZERO_GRAD) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  const int CH = 16384;
+  // all estimators share their *value* within {closed-form} / {MC, STL, STL-zero-grad}
+  if (n_samples <= CH) {
+    OutArgs o = final_out(c, value, nullptr);
+    o.ent_kind = entropy;
+    o.M_total = n_samples;
+    return run_estimate(c, params, rng_of(c, idx), n_samples, 0, o);
+  }
+  // chunked: the objective is a mean over samples plus parameter-only terms, so the weighted mean of the
+  // chunk objectives is the full objective
+  char *tmpv = (char *)c->tmp_out.p;
+  for (int off = 0, first = 1; off < n_samples; off += CH, first = 0) {
+    const int Mc = n_samples - off < CH ? n_samples - off : CH;
+    OutArgs o = final_out(c, tmpv, nullptr);
+    o.ent_kind = entropy;
+    o.M_total = Mc;
+    RngArgs r = rng_of(c, idx);
+    r.m_offset += off;
+    mivi_status_t s = run_estimate(c, params, r, Mc, 0, o);
+    if (s) return s;
+    const double w = (double)Mc / (double)n_samples;
+    if (c->cfg.dtype == MIVI_F32)
+      hipLaunchKernelGGL(k_acc_value_f32, dim3(1), dim3(1), 0, c->stream, (double *)c->acc.p, (const float *)tmpv, w, first);
+    else
+      hipLaunchKernelGGL(k_acc_value_f64, dim3(1), dim3(1), 0, c->stream, (double *)c->acc.p, (const double *)tmpv, w, first);
+  }
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_store_value_f32, dim3(1), dim3(1), 0, c->stream, (float *)value, (const double *)c->acc.p);
+  else
+    hipLaunchKernelGGL(k_store_value_f64, dim3(1), dim3(1), 0, c->stream, (double *)value, (const double *)c->acc.p);
+  HIPCHK(c, hipGetLastError());
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_estimate_objective_host(mivi_ctx_t *c, const void *params_h, uint64_t idx, int32_t n_samples,
+                                           int32_t entropy, void *value_h) {
+  if (!c || !params_h || !value_h) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  const size_t plen = (size_t)mivi_params_len(c), es = c->esize;
+  HIPCHK(c, hipMemcpyAsync(c->tmp_params.p, params_h, plen * es, hipMemcpyHostToDevice, c->stream));
+  char *o = (char *)c->tmp_out.p + 16;
+  mivi_status_t s = mivi_estimate_objective(c, c->tmp_params.p, idx, n_samples, entropy, o);
+  if (s) return s;
+  HIPCHK(c, hipMemcpyAsync(value_h, o, es, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int st = 0;
+  HIPCHK(c, hipMemcpy(&st, c->status.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (st) HIPCHK(c, hipMemset(c->status.p, 0, sizeof(int)));
+  if (st & 2) return fail(c, MIVI_ERR_NONPOSITIVE_SCALE, "scale diagonal is not positive (use ClipScale)");
+  return MIVI_OK;  // a non-finite value is returned as-is, like the reference's estimate_objective
+}
+
+// ---------------------------------------------------------------------------------------------
+// hipGraph-batched estimates and the device-resident optimisation loop
+// ---------------------------------------------------------------------------------------------
+// The null stream cannot be captured: record on an internal stream, replay on the context's stream.
+static mivi_status_t begin_capture(mivi_ctx *c, hipStream_t *saved) {
+  if (!c->cap_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // pending memsets / uploads on the launch stream
+  *saved = c->stream;
+  c->stream = c->cap_stream;
+  hipError_t e = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) { c->stream = *saved; c->err = std::string("hipStreamBeginCapture: ") + hipGetErrorString(e); return MIVI_ERR_HIP; }
+  return MIVI_OK;
+}
+static hipError_t end_capture(mivi_ctx *c, hipStream_t saved, hipGraph_t *graph) {
+  hipError_t e = hipStreamEndCapture(c->cap_stream, graph);
+  c->stream = saved;
+  return e;
+}
+
+static bool graph_capturable(const mivi_ctx *c) {
+  return c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS || c->target == TGT_FUNNEL;
+}
+
+mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64_t idx0, int32_t count, void *value,
+                                       void *grad) {
+  if (!c || !params || !value || !grad || count <= 0) return MIVI_ERR_BAD_ARG;
+  if (!graph_capturable(c)) return fail(c, MIVI_ERR_UNSUPPORTED, "graph batching needs a device-resident built-in target");
+  (void)hipSetDevice(c->cfg.device);
+  mivi_status_t s = ensure_work(c, c->cfg.n_mc);
+  if (s) return s;
+  GraphCache &g = c->graph;
+  if (!(g.exec && g.kind == 1 && g.count == count && g.params == params && g.value == value && g.grad == grad)) {
+    invalidate_graph(c);
+    hipGraph_t graph = nullptr;
+    hipStream_t saved;
+    if ((s = begin_capture(c, &saved))) return s;
+    for (int i = 0; i < count && s == MIVI_OK; ++i) {
+      RngArgs r = rng_of(c, (uint64_t)i);
+      r.idx_ptr = (const uint64_t *)c->d_idx.p;
+      s = run_estimate(c, params, r, c->cfg.n_mc, 1, final_out(c, value, grad));
+    }
+    hipError_t e = end_capture(c, saved, &graph);
+    if (s) { if (graph) (void)hipGraphDestroy(graph); return s; }
+    HIPCHK(c, e);
+    HIPCHK(c, hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    g.kind = 1; g.count = count; g.params = params; g.value = value; g.grad = grad;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_idx.p, &idx0, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_clip_scale(mivi_ctx_t *c, void *params, double epsilon) {
+  if (!c || !params) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  launch_clip(c, params, epsilon);
+  HIPCHK(c, hipGetLastError());
+  return MIVI_OK;
+}
+mivi_status_t mivi_descent_update(mivi_ctx_t *c, void *params, const void *grad, double eta) {
+  if (!c || !params || !grad) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  launch_descent(c, params, grad, eta);
+  HIPCHK(c, hipGetLastError());
+  return MIVI_OK;
+}
+mivi_status_t mivi_adam_update(mivi_ctx_t *c, void *params, const void *grad, void *state, int64_t t, double eta,
+                               double b1, double b2, double eps) {
+  if (!c || !params || !grad || !state || t < 1) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  launch_adam(c, params, grad, state, nullptr, t, eta, b1, b2, eps);
+  HIPCHK(c, hipGetLastError());
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, uint64_t idx0, int64_t t0, int32_t n_steps,
+                                  int32_t rule, double eta, double clip_eps, void *elbo) {
+  if (!c || !params || n_steps <= 0 || (rule != 0 && rule != 1) || (rule == 1 && !opt_state)) return MIVI_ERR_BAD_ARG;
+  if (!graph_capturable(c)) return fail(c, MIVI_ERR_UNSUPPORTED, "device-resident loop needs a built-in target");
+  (void)hipSetDevice(c->cfg.device);
+  mivi_status_t s = ensure_work(c, c->cfg.n_mc);
+  if (s) return s;
+  const size_t plen = (size_t)mivi_params_len(c), es = c->esize;
+  // internal value/grad/elbo-record buffers
+  if ((s = ensure(c, c->X, (plen + 8) * es + (size_t)n_steps * sizeof(double), false))) return s;
+  char *vbuf = (char *)c->X.p;
+  char *gbuf = vbuf + 8 * es;
+  double *rec = (double *)(gbuf + plen * es);
+  GraphCache &g = c->graph;
+  if (!(g.exec && g.kind == 2 + rule && g.count == n_steps && g.params == params && g.aux0 == opt_state && g.p0 == eta &&
+        g.p1 == clip_eps && g.value == (void *)vbuf)) {
+    invalidate_graph(c);
+    hipGraph_t graph = nullptr;
+    hipStream_t saved;
+    if ((s = begin_capture(c, &saved))) return s;
+    for (int i = 0; i < n_steps && s == MIVI_OK; ++i) {
+      RngArgs r = rng_of(c, (uint64_t)i);
+      r.idx_ptr = (const uint64_t *)c->d_idx.p;
+      OutArgs o = final_out(c, vbuf, gbuf);
+      o.elbo_rec = rec;
+      o.rec_slot = i;
+      s = run_estimate(c, params, r, c->cfg.n_mc, 1, o);
+      if (s) break;
+      if (rule == 0)
+        launch_descent(c, params, gbuf, eta);
+      else
+        launch_adam(c, params, gbuf, opt_state, (const int64_t *)c->d_idx.p + 1, (int64_t)i + 1, eta, 0.9, 0.999, 1e-8);
+      if (clip_eps > 0.0) launch_clip(c, params, clip_eps);
+    }
+    hipError_t e = end_capture(c, saved, &graph);
+    if (s) { if (graph) (void)hipGraphDestroy(graph); return s; }
+    HIPCHK(c, e);
+    HIPCHK(c, hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    g.kind = 2 + rule; g.count = n_steps; g.params = params; g.aux0 = opt_state; g.p0 = eta; g.p1 = clip_eps;
+    g.value = vbuf;
+  }
+  uint64_t hdr[2] = {idx0, (uint64_t)t0};
+  HIPCHK(c, hipMemcpyAsync(c->d_idx.p, hdr, sizeof(hdr), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
+  if (elbo) {
+    // elbo_dev: T[n_steps]
+    if (c->cfg.dtype == MIVI_F64) {
+      HIPCHK(c, hipMemcpyAsync(elbo, rec, (size_t)n_steps * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+      std::vector<double> h(n_steps);
+      HIPCHK(c, hipMemcpyAsync(h.data(), rec, (size_t)n_steps * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      std::vector<float> f(h.begin(), h.end());
+      HIPCHK(c, hipMemcpy(elbo, f.data(), (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice));
+    }
+  }
+  return read_status(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side RNG restatement
+// ---------------------------------------------------------------------------------------------
+void mivi_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  u32x4 c{ctr[0], ctr[1], ctr[2], ctr[3]};
+  const u32x4 r = philox4x32_10(c, key[0], key[1]);
+  out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+void mivi_eps_bits_host(uint64_t seed, uint64_t idx, int32_t d, int64_t m, int32_t i0, int32_t count, uint32_t *out) {
+  const uint64_t d4 = (uint64_t)((d + 3) / 4);
+  for (int32_t t = 0; t < count; ++t) {
+    const int32_t i = i0 + t;
+    const u32x4 b = eps_block_bits(seed, idx, (uint64_t)m * d4 + (uint64_t)(i / 4));
+    const uint32_t w[4] = {b.x, b.y, b.z, b.w};
+    out[t] = w[i & 3];
+  }
+}
+
+void mivi_eps_host(uint64_t seed, uint64_t idx, int32_t d, int64_t m, int32_t i0, int32_t count, int32_t dtype,
+                   double *out) {
+  const uint64_t d4 = (uint64_t)((d + 3) / 4);
+  for (int32_t t = 0; t < count; ++t) {
+    const int32_t i = i0 + t;
+    const uint64_t q = (uint64_t)m * d4 + (uint64_t)(i / 4);
+    if (dtype == MIVI_F32) {
+      float e[4];
+      eps_block<float>(seed, idx, q, e);
+      out[t] = (double)e[i & 3];
+    } else {
+      double e[4];
+      eps_block<double>(seed, idx, q, e);
+      out[t] = e[i & 3];
+    }
+  }
+}
+
+}  // extern "C"

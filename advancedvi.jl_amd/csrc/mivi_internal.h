@@ -1,0 +1,212 @@
+// Internal declarations shared by the libmivi translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mivi.h"
+#include "philox.h"
+
+namespace mivi {
+
+constexpr double kLog2Pi = 1.8378770664093454835606594728112;
+
+// --------------------------------------------------------------------------------------------
+// Kernel argument blocks (plain structs passed by value)
+// --------------------------------------------------------------------------------------------
+struct RngArgs {
+  uint64_t seed;
+  uint64_t idx_base;        // estimate index = idx_base + (idx_ptr ? *idx_ptr : 0)
+  const uint64_t *idx_ptr;  // device counter (graph replay) or nullptr
+  int m_offset;             // first GLOBAL sample column of this context
+};
+
+enum TargetKind : int {
+  TGT_NONE = 0,
+  TGT_DIAG_GAUSS = 1,
+  TGT_DENSE_GAUSS = 2,
+  TGT_LOGREG = 3,
+  TGT_FUNNEL = 4,
+  TGT_CALLBACK = 5
+};
+
+// reduction inputs of the objective value, summed in a fixed order by one workgroup
+struct ValueIn {
+  const double *ell_part;  // per-workgroup partial sums of sum_m ell_m (variable part)
+  int n_ell_part;
+  const void *ell;         // per-sample ell (T), generic target route
+  int n_ell;
+  const double *he_part;   // partial sums of sum_m 0.5|eps_m|^2
+  int n_he_part;
+  double ell_const;        // constant added per sample (target normaliser)
+};
+
+// how results are emitted
+struct OutArgs {
+  void *grad;        // T[params_len]  (final mode)
+  void *value;       // T[1]           (final mode)
+  void *partials;    // T[params_len+2] (partials mode, un-normalised)
+  int partials_mode; // 0 final, 1 partials
+  int ent_kind;
+  int M_total;       // global n_samples (normaliser)
+  int M_local;
+  int *status;       // device status word: bit0 nonfinite value, bit1 non-positive scale diag
+  double *elbo_rec;  // optional: elbo_rec[rec_slot] = -value (optimize loop)
+  int rec_slot;
+};
+
+template <typename T>
+struct MfArgs {
+  int d;
+  int M;               // local samples processed by this launch
+  int n_cc;            // column chunks (gridDim.y)
+  int cols_per_cc;
+  const T *params;     // [mu; sigma]
+  RngArgs rng;
+  int target;          // TGT_DIAG_GAUSS (fused) or TGT_NONE (W from G buffer)
+  const T *t_mean;     // diag gauss mean[d]
+  const T *t_istd;     // 1/std[d]
+  const T *G;          // generic route: d x M gradient of log pi (ld = d)
+  int want_grad;
+  // scratch
+  double *row_part;    // [n_cc][2*d4*4] partial row sums when n_cc > 1
+  double *sc_part;     // [n_blocks][2]  scalar partials
+  unsigned int *ticket;
+  ValueIn vin;
+  OutArgs out;
+};
+
+template <typename T>
+struct SampleArgs {  // rand(rng, q, M) -> Z (and eps)
+  int d, M;
+  const T *params;
+  RngArgs rng;
+  T *Z;       // d x M, ld = d
+  T *eps;     // d x M, ld = ld_eps (or nullptr)
+  int ld_eps;
+  T *epsT;    // M x d transposed, epsT[m + k*ld_epsT] (or nullptr)
+  int ld_epsT;
+  double *he_part;  // per-block partial of sum 0.5 eps^2 (or nullptr)
+};
+
+template <typename T>
+struct FrArgs {
+  int d, M, dP, MP;
+  const T *params;     // [mu; vec C]
+  const T *eps;        // eps[i + m*dP]
+  const T *epsT;       // epsT[m + k*MP]
+  T *Z;                // Z[i + m*d] or nullptr
+  T *W;                // W[i + m*d]: grad log pi (+ STL term)
+  T *RT;               // (Z - t_mean)^T: RT[m + k*MP]  (dense target)
+  int fused_target;    // TGT_NONE: write Z; TGT_DIAG_GAUSS: write W + ell partial; TGT_DENSE_GAUSS: write Z,RT
+  const T *t_mean;
+  const T *t_istd;
+  const T *t_prec;     // precision matrix, ld = dP, zero padded
+  double *ell_part;    // written by sample/target kernels
+  ValueIn vin;
+  OutArgs out;
+};
+
+template <typename T>
+struct ColTargetArgs {  // standalone per-column targets: Z -> (ell, G)
+  int d, M, kind;
+  const T *Z;
+  T *G;
+  T *ell;
+  const T *t_mean;
+  const T *t_istd;
+  double sigma_v;
+  int want_grad;
+};
+
+// --------------------------------------------------------------------------------------------
+// Context
+// --------------------------------------------------------------------------------------------
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+};
+
+struct GraphCache {
+  hipGraphExec_t exec = nullptr;
+  int count = 0;
+  const void *params = nullptr;
+  void *value = nullptr;
+  void *grad = nullptr;
+  int kind = 0;
+  double p0 = 0, p1 = 0;
+  void *aux0 = nullptr, *aux1 = nullptr;
+};
+
+}  // namespace mivi
+
+struct mivi_ctx {
+  mivi_config_t cfg;
+  hipStream_t stream = nullptr;
+  hipStream_t cap_stream = nullptr;   // internal stream used only for graph capture
+  bool own_stream = false;
+  std::string err;
+  int target = mivi::TGT_NONE;
+  int M_total = 0;
+  size_t esize = 4;
+
+  // target data
+  mivi::DevBuf t_mean, t_istd, t_prec;
+  double t_const = 0.0;  // per-sample constant of log pi
+  double funnel_sigma_v = 1.5;
+  // logreg
+  const void *lr_X = nullptr;
+  const uint8_t *lr_y = nullptr;
+  mivi::DevBuf lr_X_own, lr_y_own, lr_scratch, lr_part;
+  int64_t lr_n = 0;
+  int lr_variant = 0;
+  double lr_likeadj = 1.0;
+  // callback
+  mivi_logdensity_and_gradient_fn cb_grad = nullptr;
+  mivi_logdensity_fn cb_value = nullptr;
+  void *cb_user = nullptr;
+  std::vector<char> h_Z, h_G, h_ell;
+
+  // work buffers (sized for `cap_M` samples)
+  int cap_M = 0;
+  mivi::DevBuf eps, epsT, Z, W, RT, ell, X;
+  mivi::DevBuf ell_part, he_part, row_part, sc_part, ticket, status, d_idx, acc, tmp_params, tmp_out;
+  int dP = 0, MP = 0;
+
+  mivi::GraphCache graph;
+};
+
+namespace mivi {
+
+// kernels_meanfield.hip
+void launch_mf_main(mivi_ctx *c, const void *params, const RngArgs &rng, int M, int want_grad, const void *G,
+                    const ValueIn &vin, const OutArgs &out);
+void launch_sample_mf(mivi_ctx *c, const void *params, const RngArgs &rng, int M, void *Z, void *eps, int ld_eps,
+                      double *he_part);
+
+// kernels_fullrank.hip
+void launch_eps(mivi_ctx *c, const RngArgs &rng, int M);
+void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, void *Z);
+void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const ValueIn &vin, const OutArgs &out);
+void launch_fr_dense_target(mivi_ctx *c, int M, int want_grad);
+void launch_fr_stl(mivi_ctx *c, const void *params, int M);
+int fr_sample_blocks(const mivi_ctx *c, int M);
+int fr_dense_blocks(const mivi_ctx *c, int M);
+int eps_blocks(const mivi_ctx *c, int M);
+
+// kernels_targets.hip
+void launch_col_target(mivi_ctx *c, int M, int want_grad);
+void launch_logreg_target(mivi_ctx *c, int M, int want_grad);
+
+// kernels_update.hip
+void launch_finalize(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad);
+void launch_value_only(mivi_ctx *c, const void *params, const ValueIn &vin, const OutArgs &out);
+void launch_clip(mivi_ctx *c, void *params, double epsilon);
+void launch_descent(mivi_ctx *c, void *params, const void *grad, double eta);
+void launch_adam(mivi_ctx *c, void *params, const void *grad, void *state, const int64_t *t_ptr, int64_t t_base,
+                 double eta, double b1, double b2, double eps);
+void launch_bump(mivi_ctx *c, uint64_t *ctr, uint64_t by);
+
+}  // namespace mivi

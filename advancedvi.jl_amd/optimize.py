@@ -1,0 +1,209 @@
+"""Callers of the hot path: KLMinRepGradDescent (= ADVI), init / step / output and `optimize`.
+Host-side mirror of src/algorithms/constructors.jl:44-79, src/algorithms/common.jl:29-120 and
+src/optimize.jl:42-94 (AdvancedVI.jl v0.7.0); parameters stay resident in HBM between steps and every
+update is a libmivi kernel."""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+from . import objectives as O
+from .families import MvLocationScale, destructure
+
+
+# --- operators (src/optimization/clip_scale.jl, src/AdvancedVI.jl:173-204) ------------------------
+class IdentityOperator:
+    def apply(self, ctx, params):
+        return params
+
+
+class ClipScale:
+    """ClipScale(eps = 1e-5): src/optimization/clip_scale.jl:8-29."""
+
+    def __init__(self, epsilon=1e-5):
+        self.epsilon = epsilon
+
+    def apply(self, ctx, params):
+        ctx.clip_scale(params, self.epsilon)
+        return params
+
+
+# --- optimisation rules (Optimisers.jl rules used by the reference's tests/bench) -----------------
+class Descent:
+    def __init__(self, eta=0.1):
+        self.eta = eta
+
+    def setup(self, ctx, params):
+        return None
+
+    def update(self, ctx, state, params, grad, t):
+        ctx.descent_update(params, grad, self.eta)
+        return state
+
+
+class Adam:
+    def __init__(self, eta=1e-3, beta=(0.9, 0.999), epsilon=1e-8):
+        self.eta, self.beta, self.epsilon = eta, beta, epsilon
+
+    def setup(self, ctx, params):
+        import torch
+        return torch.zeros(2 * params.numel(), dtype=params.dtype, device=params.device)
+
+    def update(self, ctx, state, params, grad, t):
+        ctx.adam_update(params, grad, state, t, self.eta, self.beta[0], self.beta[1], self.epsilon)
+        return state
+
+
+class DoG:
+    """src/optimization/rules.jl:48-64."""
+    kind = 0
+
+    def __init__(self, alpha=1e-6):
+        self.alpha = alpha
+
+    def setup(self, ctx, params):
+        st = ctx.dog_state()
+        ctx.dog_init(params, st, self.alpha)
+        return st
+
+    def update(self, ctx, state, params, grad, t):
+        ctx.dog_update(params, grad, state, self.kind)
+        return state
+
+
+class DoWG(DoG):
+    """src/optimization/rules.jl:17-34."""
+    kind = 1
+
+
+# --- averagers (src/optimization/averaging.jl) -----------------------------------------------------
+class NoAveraging:
+    def init(self, ctx, params):
+        return params
+
+    def apply(self, ctx, state, params):
+        return params
+
+    def value(self, state):
+        return state
+
+
+class PolynomialAveraging:
+    """x_bar_t = (1 - w_t) x_bar_{t-1} + w_t x_t, w_t = (eta+1)/(t+eta): averaging.jl:36-53."""
+
+    def __init__(self, eta=8):
+        self.eta = eta
+
+    def init(self, ctx, params):
+        return (params.clone(), 1)
+
+    def apply(self, ctx, state, params):
+        x_bar, t = state
+        w = (self.eta + 1) / (t + self.eta)
+        ctx.axpby(x_bar, w, params, 1.0 - w)
+        return (x_bar, t + 1)
+
+    def value(self, state):
+        return state[0]
+
+
+class KLMinRepGradDescent:
+    """KLMinRepGradDescent(adtype; entropy, optimizer, n_samples, averager, operator): constructors.jl:44-79."""
+
+    def __init__(self, adtype, entropy=None, optimizer=None, n_samples: int = 1, averager=None, operator=None,
+                 subsampling=None):
+        if subsampling is not None:
+            raise NotImplementedError("SubsampledObjective is outside the hot path built here (SURVEY.md 8f-4)")
+        entropy = entropy if entropy is not None else O.ClosedFormEntropy()
+        if not isinstance(entropy, (O.ClosedFormEntropy, O.StickingTheLandingEntropy, O.MonteCarloEntropy)):
+            raise TypeError("entropy must be ClosedFormEntropy, StickingTheLandingEntropy or MonteCarloEntropy")
+        self.objective = O.RepGradELBO(n_samples, entropy=entropy)
+        self.adtype = adtype
+        self.optimizer = optimizer if optimizer is not None else DoWG()
+        self.averager = averager if averager is not None else PolynomialAveraging()
+        self.operator = operator if operator is not None else IdentityOperator()
+
+
+ADVI = KLMinRepGradDescent
+
+
+def estimate_objective(rng, alg, q, prob, n_samples=None, entropy=None):
+    """estimate_objective([rng,] alg, q, prob; n_samples, entropy=MonteCarloEntropy()): common.jl:29-38."""
+    if isinstance(rng, KLMinRepGradDescent):
+        rng, alg, q, prob = O.default_rng(), rng, alg, q
+    n = n_samples if n_samples is not None else alg.objective.n_samples
+    ent = entropy if entropy is not None else O.MonteCarloEntropy()
+    return O.estimate_objective(rng, O.RepGradELBO(n, entropy=ent), q, prob, adtype=alg.adtype)
+
+
+def init(rng, alg: KLMinRepGradDescent, q_init, prob):
+    """init(rng, alg::ParamSpaceSGD, q_init, prob): common.jl:40-61."""
+    if isinstance(q_init, MvLocationScale) and isinstance(alg.operator, IdentityOperator):
+        warnings.warn(
+            "IdentityOperator is used with a variational family <:MvLocationScale. Optimization can easily fail under "
+            "this combination due to singular scale matrices. Consider using the operator `ClipScale` in the algorithm "
+            "instead.")
+    params_h, re = destructure(q_init)
+    obj_st = O.init(rng, alg.objective, alg.adtype, q_init, prob, params_h, re)
+    ctx = obj_st.obj_ad_prep
+    params = ctx.to_device(params_h).clone()
+    opt_st = alg.optimizer.setup(ctx, params)
+    avg_st = alg.averager.init(ctx, params)
+    grad_buf = O.DiffResult(ctx.empty(1), ctx.empty(ctx.params_len))
+    return dict(prob=prob, q=q_init, params=params, restructure=re, iteration=0, grad_buf=grad_buf, opt_st=opt_st,
+                obj_st=obj_st, avg_st=avg_st)
+
+
+def output(alg, state):
+    """output(alg, state) = re(value(averager, avg_st)): common.jl:63-67."""
+    return state["restructure"](alg.averager.value(state["avg_st"]).cpu().numpy())
+
+
+def step(rng, alg, state, callback, *objargs):
+    """step(rng, alg::ParamSpaceSGD, state, callback): common.jl:69-120."""
+    state = dict(state)
+    state["iteration"] += 1
+    t = state["iteration"]
+    ctx = state["obj_st"].obj_ad_prep
+    params, re = state["params"], state["restructure"]
+    grad_buf, obj_st, info = O.estimate_gradient_(rng, alg.objective, alg.adtype, state["grad_buf"], state["obj_st"],
+                                                  params, re, *objargs)
+    value = grad_buf.value()          # host sync, like the reference's eager isfinite check
+    if not np.isfinite(value):        # common.jl:83-89
+        raise RuntimeError(f"The objective value is {value}. This indicates that the optimization run diverged.")
+    grad = grad_buf.gradient()
+    state["opt_st"] = alg.optimizer.update(ctx, state["opt_st"], params, grad, t)   # Optimisers.update!
+    params = alg.operator.apply(ctx, params)
+    state["avg_st"] = alg.averager.apply(ctx, state["avg_st"], params)
+    state["params"] = params
+    state["q"] = None  # materialised lazily by `output` / callbacks (params are device resident)
+    info = {"elbo": -value}
+    if callback is not None:
+        extra = callback(rng=rng, iteration=t, restructure=re, params=params,
+                         averaged_params=alg.averager.value(state["avg_st"]), gradient=grad, state=state)
+        if extra is not None:
+            info = {**extra, **info}
+    return state, False, info
+
+
+def optimize(rng, algorithm, max_iter: int, prob=None, q_init=None, *objargs, show_progress=False, state=None,
+             callback=None):
+    """optimize([rng,] algorithm, max_iter, prob, q_init; show_progress, state, callback): src/optimize.jl:42-94.
+    Returns (output, info, state)."""
+    if isinstance(rng, KLMinRepGradDescent):   # default-rng overload, optimize.jl:83-94
+        extra = (q_init,) if q_init is not None else ()
+        rng, algorithm, max_iter, prob, q_init = O.default_rng(), rng, algorithm, max_iter, prob
+        objargs = extra + objargs
+    info_total = []
+    if state is None:
+        state = init(rng, algorithm, q_init, prob)
+    for t in range(1, max_iter + 1):
+        state, terminate, info = step(rng, algorithm, state, callback, *objargs)
+        info = {**info, "iteration": t}
+        if terminate:
+            break
+        if show_progress:
+            print(f"\rOptimizing {t}/{max_iter} elbo={info['elbo']:.6g}", end="" if t < max_iter else "\n")
+        info_total.append(info)
+    return output(algorithm, state), info_total, state

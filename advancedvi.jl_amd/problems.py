@@ -1,0 +1,103 @@
+"""Target log-density problems: the LogDensityProblems plugin seam of the hot path
+(`logdensity`, `logdensity_and_gradient`, `dimension`, `capabilities`; call sites
+src/algorithms/repgradelbo.jl:32,50,85 and src/mixedad_logdensity.jl:13-28).
+
+Built-in problems are *descriptors*: their arithmetic lives in libmivi's fused HIP kernels.
+Any other object exposing `dimension()` and `logdensity_and_gradient(z) -> (ell, grad)` is a
+generic plugin and is evaluated through the host-callback route (batched over the columns of Z,
+exactly the `logdensity_and_gradient` contract of src/mixedad_logdensity.jl:28)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+class LogDensityOrder:
+    """LogDensityProblems.LogDensityOrder{K}."""
+
+    def __init__(self, k: int):
+        self.k = k
+
+    def __lt__(self, other):
+        return self.k < other.k
+
+    def __repr__(self):
+        return f"LogDensityOrder{{{self.k}}}()"
+
+
+def dimension(prob) -> int:
+    return int(prob.dimension())
+
+
+def capabilities(prob) -> LogDensityOrder:
+    if hasattr(prob, "capabilities"):
+        return prob.capabilities()
+    return LogDensityOrder(1 if hasattr(prob, "logdensity_and_gradient") else 0)
+
+
+class DiagNormalProblem:
+    """MvNormal(mean, Diagonal(std.^2)) -- test/models/normal.jl:56-75, bench/benchmarks.jl:43-47."""
+
+    def __init__(self, mean, std):
+        self.mean = np.asarray(mean)
+        self.std = np.asarray(std)
+
+    def dimension(self):
+        return self.mean.shape[0]
+
+    def capabilities(self):
+        return LogDensityOrder(1)
+
+
+class DenseNormalProblem:
+    """MvNormal(mean, L L') -- test/models/normal.jl:36-54 (`normal_fullrank`)."""
+
+    def __init__(self, mean, L):
+        self.mean = np.asarray(mean)
+        self.L = np.tril(np.asarray(L))
+
+    def dimension(self):
+        return self.mean.shape[0]
+
+    def capabilities(self):
+        return LogDensityOrder(1)
+
+
+class LogRegProblem:
+    """Hierarchical logistic regression over theta = [beta; s].
+    variant "logsigma_normal": docs/src/tutorials/subsampling.md:26-38
+    variant "lognormal_exp_bijector": README.md:42-66 inside the TransformedLogDensityProblem of README.md:91-106.
+    X is n x p (features), y in {0,1}; likeadj = n_data / n."""
+
+    VARIANTS = {"logsigma_normal": 0, "lognormal_exp_bijector": 1}
+
+    def __init__(self, X, y, variant="logsigma_normal", likeadj=1.0):
+        self.X = np.asarray(X)
+        self.y = np.asarray(y)
+        if variant not in self.VARIANTS:
+            raise ValueError(f"unknown variant {variant}")
+        self.variant = variant
+        self.likeadj = float(likeadj)
+
+    def dimension(self):
+        return self.X.shape[1] + 1
+
+    def capabilities(self):
+        return LogDensityOrder(1)
+
+
+class FunnelProblem:
+    """Neal's funnel on the constrained scale under Stacked([log-bijector, identity]) (SURVEY.md 8d;
+    wrapper pattern of README.md:76-82,102-106)."""
+
+    def __init__(self, d, sigma_v=1.5):
+        self.d = int(d)
+        self.sigma_v = float(sigma_v)
+
+    def dimension(self):
+        return self.d
+
+    def capabilities(self):
+        return LogDensityOrder(1)
+
+
+BUILTIN = (DiagNormalProblem, DenseNormalProblem, LogRegProblem, FunnelProblem)

@@ -1,0 +1,198 @@
+/*
+ * mivi.h -- C ABI of libmivi: the MI355X-native (gfx950) RepGradELBO / ADVI hot path of
+ * AdvancedVI.jl v0.7.0.  extern "C", plain pointers and sizes, no exceptions across the ABI.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to the
+ * AdvancedVI.jl repository).  The Julia-side `ccall` binding is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - All functions return mivi_status_t (0 = ok).  mivi_last_error(ctx) gives text.
+ *   - T is float (MIVI_F32) or double (MIVI_F64), fixed per context.
+ *   - `*_dev` pointers are device (HBM) pointers valid on the context's device; calls taking
+ *     only device pointers are ASYNCHRONOUS on the context's stream (no host sync).
+ *     `*_host` convenience variants copy in/out and synchronise.
+ *   - Sample layout: d x M column-major, one sample per column (src/utils.jl:6 `eachsample=eachcol`).
+ *   - Parameter layout (what `Optimisers.destructure(q)` yields):
+ *       mean-field: [location (d); diag(scale) (d)]                 src/families/location_scale.jl:39-43
+ *       full-rank : [location (d); vec(scale) column-major (d*d)]   src/families/location_scale.jl:21
+ *                   entries above the diagonal are ignored on input (LowerTriangular) and the
+ *                   gradient written there is exactly 0.
+ *   - The objective value is the NEGATIVE ELBO (src/algorithms/repgradelbo.jl:117,148).
+ *   - Randomness is explicit: eps is a pure function of (seed, estimate_idx, global sample m, i)
+ *     through Philox4x32-10 + Box-Muller (csrc/philox.h), replacing the mutable `rng` threaded
+ *     through src/algorithms/repgradelbo.jl:104-110.  One estimate consumes one estimate_idx.
+ *   - A context is single-owner (like the reference's rng); distinct contexts are independent.
+ */
+#ifndef MIVI_H
+#define MIVI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIVI_VERSION_MAJOR 0
+#define MIVI_VERSION_MINOR 1
+
+typedef int32_t mivi_status_t;
+enum {
+  MIVI_OK = 0,
+  MIVI_ERR_BAD_ARG = 1,
+  MIVI_ERR_NONFINITE = 2,      /* objective not finite: host maps to the ErrorException of src/algorithms/common.jl:83-89 */
+  MIVI_ERR_NONPOSITIVE_SCALE = 3, /* log of a non-positive scale diagonal: the DomainError ClipScale exists to prevent */
+  MIVI_ERR_HIP = 4,
+  MIVI_ERR_NO_TARGET = 5,
+  MIVI_ERR_UNSUPPORTED = 6
+};
+
+typedef enum { MIVI_F32 = 0, MIVI_F64 = 1 } mivi_dtype_t;
+
+/* MeanFieldGaussian / FullRankGaussian: src/families/location_scale.jl:139-141 / :124-128 */
+typedef enum { MIVI_MEANFIELD = 0, MIVI_FULLRANK = 1 } mivi_family_t;
+
+/* src/algorithms/entropy.jl: ClosedFormEntropy :25-29, ClosedFormEntropyZeroGradient :11-15,
+ * MonteCarloEntropy :40-46, StickingTheLandingEntropy :57-65, StickingTheLandingEntropyZeroGradient :78-90 */
+typedef enum {
+  MIVI_ENT_CLOSED_FORM = 0,
+  MIVI_ENT_CLOSED_FORM_ZERO_GRAD = 1,
+  MIVI_ENT_MONTE_CARLO = 2,
+  MIVI_ENT_STL = 3,
+  MIVI_ENT_STL_ZERO_GRAD = 4
+} mivi_entropy_t;
+
+/* RepGradELBO(n_samples; entropy) + family + RNG key: src/algorithms/repgradelbo.jl:21-24,72-74 */
+typedef struct {
+  int32_t dtype;      /* mivi_dtype_t */
+  int32_t family;     /* mivi_family_t */
+  int32_t d;          /* LogDensityProblems.dimension(prob) */
+  int32_t n_mc;       /* samples THIS context draws per estimate (RepGradELBO.n_samples / world size) */
+  int32_t entropy;    /* mivi_entropy_t */
+  int32_t device;     /* HIP device ordinal */
+  uint64_t seed;      /* Philox key */
+  int32_t m_offset;   /* first GLOBAL sample index owned by this context (multi-GPU shard); 0 on one GPU */
+  int32_t m_total;    /* GLOBAL n_samples the estimate is normalised by; 0 => n_mc */
+  void *stream;       /* hipStream_t to launch on; NULL = the HIP null (legacy default) stream */
+  int32_t own_stream; /* != 0: ignore `stream` and create a non-blocking stream owned by the context */
+  int32_t reserved;
+} mivi_config_t;
+
+typedef struct mivi_ctx mivi_ctx_t;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+/* replaces AdvancedVI.init(rng, obj::RepGradELBO, adtype, q, prob, params, restructure)
+ * (src/algorithms/repgradelbo.jl:41-70): one-time preparation, no AD to prepare. */
+mivi_status_t mivi_create(const mivi_config_t *cfg, mivi_ctx_t **out);
+mivi_status_t mivi_destroy(mivi_ctx_t *ctx);
+const char *mivi_last_error(const mivi_ctx_t *ctx);
+int32_t mivi_version(void);
+mivi_status_t mivi_set_stream(mivi_ctx_t *ctx, void *hip_stream);
+mivi_status_t mivi_synchronize(mivi_ctx_t *ctx);
+/* length of `params` / gradient: 2d or d + d*d  (test/families/location_scale.jl:146-155) */
+int64_t mivi_params_len(const mivi_ctx_t *ctx);
+/* length of the shard-additive partials buffer: params_len + 2  ([... ; sum ell ; sum 0.5|eps|^2]) */
+int64_t mivi_partials_len(const mivi_ctx_t *ctx);
+
+/* ---- targets: the LogDensityProblems plugin seam --------------------------------------------- *
+ * replaces LogDensityProblems.logdensity / logdensity_and_gradient / dimension as called from
+ * src/algorithms/repgradelbo.jl:84-86 and src/mixedad_logdensity.jl:23-34.  Built-in targets run
+ * fused on the device; the callback target is the generic plugin route (batched over columns). */
+
+/* MvNormal(mean, Diagonal(std.^2)): test/models/normal.jl:56-75, bench/benchmarks.jl:43-47. host ptrs, T[d]. */
+mivi_status_t mivi_set_target_diag_gauss(mivi_ctx_t *ctx, const void *mean_host, const void *std_host);
+/* MvNormal(mean, L*L'): test/models/normal.jl:36-54.  host ptrs: mean T[d], L T[d*d] column-major lower. */
+mivi_status_t mivi_set_target_dense_gauss(mivi_ctx_t *ctx, const void *mean_host, const void *chol_L_host);
+/* Hierarchical logistic regression over theta = [beta (d-1); s]:
+ *   variant 0: docs/src/tutorials/subsampling.md:26-38 (s = log sigma, Normal(0,3) prior on sigma, likeadj = n_data/n)
+ *   variant 1: README.md:42-66 under the exp-bijector wrapper README.md:91-106 (LogNormal(0,3) prior, + log|det J| = s)
+ * X: n x (d-1) COLUMN-major T (X[r + k*n], Julia's native Matrix layout), y: n bytes {0,1}.  x_on_device != 0 => X,y are device ptrs
+ * (borrowed, must outlive the ctx); otherwise host ptrs, copied. */
+mivi_status_t mivi_set_target_logreg(mivi_ctx_t *ctx, const void *X, const uint8_t *y, int64_t n,
+                                     int32_t variant, double likeadj, int32_t x_on_device);
+/* Neal's funnel on the constrained scale + Stacked([log, identity]) bijector (README.md:76-82,102-106):
+ * theta_1 = exp(eta_1) ~ LogNormal(0, sigma_v), theta_i ~ Normal(0, theta_1), log|det J| = eta_1. */
+mivi_status_t mivi_set_target_funnel(mivi_ctx_t *ctx, double sigma_v);
+
+/* Generic plugin: batched `logdensity_and_gradient` (src/mixedad_logdensity.jl:28) over the columns of Z.
+ * Called on the host thread inside mivi_estimate_* with HOST buffers: Z (d x M col-major) in,
+ * ell (M) and G (d x M) out.  Return non-zero to abort (-> MIVI_ERR_BAD_ARG). */
+typedef int32_t (*mivi_logdensity_and_gradient_fn)(void *user, const void *Z_host, int32_t d, int32_t M,
+                                                   void *ell_host, void *G_host);
+/* value-only plugin (LogDensityProblems.logdensity), used by mivi_estimate_objective when set; may be NULL */
+typedef int32_t (*mivi_logdensity_fn)(void *user, const void *Z_host, int32_t d, int32_t M, void *ell_host);
+mivi_status_t mivi_set_target_callback(mivi_ctx_t *ctx, mivi_logdensity_and_gradient_fn fn_grad,
+                                       mivi_logdensity_fn fn_value, void *user);
+
+/* ---- the hot path ----------------------------------------------------------------------------- */
+/* rand(rng, q, n_mc): src/families/location_scale.jl:71-87 (exposes the sample kernel for parity).
+ * Z_dev: T[d*n_mc]; eps_dev: T[d*n_mc] or NULL. */
+mivi_status_t mivi_sample(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx,
+                          void *Z_dev, void *eps_dev);
+
+/* estimate_gradient!(rng, obj::RepGradELBO, adtype, out, state, params, restructure):
+ * src/algorithms/repgradelbo.jl:151-177 (+ the AD shim src/AdvancedVI.jl:57-67 it replaces).
+ * value_dev: T[1] <- -elbo; grad_dev: T[params_len] fully overwritten. Asynchronous for built-in
+ * targets; synchronous (host round trip) for the callback target. */
+mivi_status_t mivi_estimate_gradient(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx,
+                                     void *value_dev, void *grad_dev);
+/* Same, host buffers, synchronous; additionally returns MIVI_ERR_NONFINITE when !isfinite(value)
+ * (the check `step` performs at src/algorithms/common.jl:83-89). */
+mivi_status_t mivi_estimate_gradient_host(mivi_ctx_t *ctx, const void *params_host, uint64_t estimate_idx,
+                                          void *value_host, void *grad_host);
+/* `count` consecutive estimates estimate_idx0 .. estimate_idx0+count-1 of the same params replayed as ONE
+ * hipGraph launch; value/grad hold the LAST estimate on return.  Built-in targets only. */
+mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx0,
+                                       int32_t count, void *value_dev, void *grad_dev);
+
+/* estimate_objective(rng, obj::RepGradELBO, q, prob; n_samples): src/algorithms/repgradelbo.jl:112-118;
+ * `entropy` override mirrors the algorithm-level wrapper src/algorithms/common.jl:29-38 (default there:
+ * MonteCarloEntropy).  n_samples may differ from cfg.n_mc.  value_dev: T[1]. */
+mivi_status_t mivi_estimate_objective(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx,
+                                      int32_t n_samples, int32_t entropy, void *value_dev);
+mivi_status_t mivi_estimate_objective_host(mivi_ctx_t *ctx, const void *params_host, uint64_t estimate_idx,
+                                           int32_t n_samples, int32_t entropy, void *value_host);
+
+/* ---- multi-GPU: shard the MC batch, all-reduce the partials, finalize -------------------------- *
+ * No counterpart in the reference (single task).  partials_dev: T[partials_len] un-normalised sums over
+ * this context's samples; the caller all-reduces (RCCL sum) and calls mivi_finalize on every rank. */
+mivi_status_t mivi_estimate_partials(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx,
+                                     void *partials_dev);
+mivi_status_t mivi_finalize(mivi_ctx_t *ctx, const void *params_dev, const void *partials_dev,
+                            void *value_dev, void *grad_dev);
+
+/* ---- next to the hot path: projection + optimiser step, device-resident ---------- */
+/* ClipScale: scale[diagind] = max(scale[diagind], eps)   src/optimization/clip_scale.jl:18-29 */
+mivi_status_t mivi_clip_scale(mivi_ctx_t *ctx, void *params_dev, double epsilon);
+/* Optimisers.Descent(eta): params .-= eta .* grad  (the rule of test/algorithms/klminrepgraddescent.jl:110) */
+mivi_status_t mivi_descent_update(mivi_ctx_t *ctx, void *params_dev, const void *grad_dev, double eta);
+/* Optimisers.Adam(eta, (b1,b2), eps) (bench/benchmarks.jl:64): state_dev T[2*params_len] (m; v), t = step number >= 1 */
+mivi_status_t mivi_adam_update(mivi_ctx_t *ctx, void *params_dev, const void *grad_dev, void *state_dev,
+                               int64_t t, double eta, double beta1, double beta2, double eps);
+/* y <- a*x + b*y over n elements of T.  PolynomialAveraging: x_bar = (1-w) x_bar + w x, src/optimization/averaging.jl:40-47 */
+mivi_status_t mivi_axpby(mivi_ctx_t *ctx, void *y_dev, double a, const void *x_dev, double b, int64_t n);
+/* DoG (kind 0) / DoWG (kind 1): src/optimization/rules.jl:48-64 / :17-34.  state_dev holds x0 (T[params_len]) followed
+ * by two doubles (v, r) at byte offset mivi_dog_state_bytes(ctx)-16.  init: x0 = params, v = 0, r = alpha*(1+norm(params)). */
+int64_t mivi_dog_state_bytes(const mivi_ctx_t *ctx);
+mivi_status_t mivi_dog_init(mivi_ctx_t *ctx, const void *params_dev, void *state_dev, double alpha);
+mivi_status_t mivi_dog_update(mivi_ctx_t *ctx, void *params_dev, const void *grad_dev, void *state_dev, int32_t kind);
+/* `n_steps` iterations of src/algorithms/common.jl:69-104 {estimate_gradient!, update!, ClipScale} with params
+ * resident in HBM, one hipGraph per call; rule: 0 = Descent(eta), 1 = Adam(eta).  elbo_dev: T[n_steps] or NULL
+ * receives info.elbo (= -value) per iteration.  Returns MIVI_ERR_NONFINITE if any objective was not finite. */
+mivi_status_t mivi_optimize_steps(mivi_ctx_t *ctx, void *params_dev, void *opt_state_dev, uint64_t estimate_idx0,
+                                  int64_t t0, int32_t n_steps, int32_t rule, double eta, double clip_epsilon,
+                                  void *elbo_dev);
+
+/* ---- host-side RNG restatement (no GPU needed; used by the parity tests) ------------------------- */
+void mivi_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+/* raw words of the eps stream for element (i, global m): out[count] for i = i0 .. i0+count-1 */
+void mivi_eps_bits_host(uint64_t seed, uint64_t estimate_idx, int32_t d, int64_t m, int32_t i0, int32_t count,
+                        uint32_t *out);
+/* eps values themselves evaluated on the host with the same formulas: out_f64[count] */
+void mivi_eps_host(uint64_t seed, uint64_t estimate_idx, int32_t d, int64_t m, int32_t i0, int32_t count,
+                   int32_t dtype, double *out_f64);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIVI_H */

@@ -1,0 +1,470 @@
+"""
+CPU ORACLE (TEST INFRASTRUCTURE ONLY -- never imported by the product path).
+
+A float64 NumPy restatement of the AdvancedVI.jl v0.7.0 RepGradELBO hot path.
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this module; `advancedvi.jl_amd/` must not (and fails loudly without its
+HIP library instead of falling back to anything here).
+
+Pinning status: the reference is pure Julia, Julia is not installed in the build
+container, and the reference ships NO golden numeric vectors.
+The oracle is therefore pinned against the reference's own *known-answer* tests
+(tests/test_oracle_pinning.py restates each one, with the reference file:line):
+  * STL gradient == 0 at q = pi            test/algorithms/klminrepgraddescent.jl:66-87
+  * estimate_objective(q = pi) ~ 0         test/algorithms/klminrepgraddescent.jl:36-37
+  * entropy(q) == entropy(MvNormal)        test/families/location_scale.jl:44-47
+  * logpdf(q, z) == logpdf(MvNormal, z)    test/families/location_scale.jl:38-42
+  * sample mean / var / cov                test/families/location_scale.jl:68-97
+  * mean-field destructure length 2d       test/families/location_scale.jl:146-155
+  * rrule seam returns plugin gradient     test/general/mixedad_logdensity.jl:37-61
+and its analytic gradient is cross-checked against reverse-mode AD (torch CPU
+autograd standing in for the reference's AD backends) of the *forward* function
+restated line by line in `oracle_torch.py`.  Parity against real Julia output is
+"unpinned" (no Julia toolchain); see DESIGN.md.
+
+All `file:line` citations are relative to /root/reference.
+
+Randomness: the reference draws `eps = rand(rng, Normal{T}(0,1), d, M)` column-major
+(src/families/location_scale.jl:76,86).  Julia's RNG stream cannot be reproduced
+here, so every function below takes `eps` (d x M, one sample per column,
+src/utils.jl:6) as an explicit input: "identical RNG streams" is defined at the
+eps level.  `philox4x32_10` / `philox_normal_block` restate the counter-based
+generator the HIP kernels use so eps itself can be checked.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+LOG2PI = math.log(2.0 * math.pi)
+
+# entropy estimator ids == include/mivi.h mivi_entropy_t
+ENT_CLOSED_FORM = 0          # ClosedFormEntropy                      src/algorithms/entropy.jl:25-29
+ENT_CLOSED_FORM_ZERO_GRAD = 1  # ClosedFormEntropyZeroGradient        src/algorithms/entropy.jl:11-15
+ENT_MONTE_CARLO = 2          # MonteCarloEntropy                      src/algorithms/entropy.jl:40-46
+ENT_STL = 3                  # StickingTheLandingEntropy              src/algorithms/entropy.jl:57-65
+ENT_STL_ZERO_GRAD = 4        # StickingTheLandingEntropyZeroGradient  src/algorithms/entropy.jl:78-90
+
+MEANFIELD = 0
+FULLRANK = 1
+
+
+# --------------------------------------------------------------------------------------
+# Variational family: MvLocationScale with a standard normal base distribution
+# --------------------------------------------------------------------------------------
+@dataclass
+class MvLocationScale:
+    """src/families/location_scale.jl:15-19.  `scale` is a length-d vector (Diagonal,
+    mean-field) or a d x d lower-triangular matrix (full-rank)."""
+
+    location: np.ndarray
+    scale: np.ndarray
+
+    @property
+    def is_meanfield(self) -> bool:
+        return self.scale.ndim == 1
+
+    @property
+    def d(self) -> int:
+        return self.location.shape[0]
+
+
+def destructure(q: MvLocationScale) -> np.ndarray:
+    """Flat trainable parameters.
+    mean-field: [location; diag(scale)]          src/families/location_scale.jl:39-43
+    full-rank : [location; vec(scale)] column-major with the strict upper triangle zero
+                (default Optimisers.destructure over `@functor (location, scale)`,
+                src/families/location_scale.jl:21; layout fixed explicitly in mivi.h)."""
+    if q.is_meanfield:
+        return np.concatenate([q.location, q.scale])
+    return np.concatenate([q.location, np.tril(q.scale).reshape(-1, order="F")])
+
+
+def restructure(params: np.ndarray, d: int, family: int) -> MvLocationScale:
+    """RestructureMeanField, src/families/location_scale.jl:32-37; full-rank re-projects
+    onto LowerTriangular (entries above the diagonal are ignored)."""
+    params = np.asarray(params, dtype=np.float64)
+    if family == MEANFIELD:
+        assert params.shape[0] == 2 * d
+        return MvLocationScale(params[:d].copy(), params[d:].copy())
+    assert params.shape[0] == d + d * d
+    C = params[d:].reshape(d, d, order="F")
+    return MvLocationScale(params[:d].copy(), np.tril(C))
+
+
+def rand_batch(q: MvLocationScale, eps: np.ndarray) -> np.ndarray:
+    """`rand(rng, q, M)`: samples = scale * eps .+ location, d x M, one sample per column.
+    dense: src/families/location_scale.jl:71-77; Diagonal: :80-87."""
+    if q.is_meanfield:
+        return q.scale[:, None] * eps + q.location[:, None]
+    return q.scale @ eps + q.location[:, None]
+
+
+def entropy_closed_form(q: MvLocationScale) -> float:
+    """StatsBase.entropy(q) = d * entropy(Normal(0,1)) + logdet(scale)
+    src/families/location_scale.jl:52-57."""
+    diag = q.scale if q.is_meanfield else np.diag(q.scale)
+    return q.d * 0.5 * (1.0 + LOG2PI) + float(np.sum(np.log(diag)))
+
+
+def _solve_scale(q: MvLocationScale, r: np.ndarray) -> np.ndarray:
+    if q.is_meanfield:
+        return r / (q.scale if r.ndim == 1 else q.scale[:, None])
+    # forward substitution with the lower-triangular scale ("scale \\ (z - location)")
+    return np.linalg.solve(np.tril(q.scale), r)
+
+
+def logpdf(q: MvLocationScale, z: np.ndarray) -> float:
+    """Distributions.logpdf(q, z) = sum(logpdf.(Normal(0,1), scale \\ (z - location))) - logdet(scale)
+    src/families/location_scale.jl:59-63."""
+    z_std = _solve_scale(q, z - q.location)
+    diag = q.scale if q.is_meanfield else np.diag(q.scale)
+    return float(np.sum(-0.5 * z_std * z_std - 0.5 * LOG2PI) - np.sum(np.log(diag)))
+
+
+def estimate_entropy(kind: int, samples: np.ndarray, q: MvLocationScale, q_stop: MvLocationScale) -> float:
+    """The five `estimate_entropy` methods, src/algorithms/entropy.jl:13-15, 27-29, 42-46,
+    59-65, 80-90 (for MonteCarloEntropy the more specific method at :42 wins dispatch)."""
+    M = samples.shape[1]
+    if kind == ENT_CLOSED_FORM:
+        return entropy_closed_form(q)
+    if kind == ENT_CLOSED_FORM_ZERO_GRAD:
+        return entropy_closed_form(q_stop)
+    if kind == ENT_MONTE_CARLO:
+        return float(np.mean([-logpdf(q, samples[:, m]) for m in range(M)]))
+    if kind == ENT_STL:
+        return float(np.mean([-logpdf(q_stop, samples[:, m]) for m in range(M)]))
+    if kind == ENT_STL_ZERO_GRAD:
+        ent_stl = float(np.mean([-logpdf(q_stop, samples[:, m]) for m in range(M)]))
+        return ent_stl - entropy_closed_form(q) + entropy_closed_form(q_stop)
+    raise ValueError(kind)
+
+
+# --------------------------------------------------------------------------------------
+# Target log-densities (the LogDensityProblems plugin side)
+# --------------------------------------------------------------------------------------
+class DiagNormalTarget:
+    """MvNormal(mean, Diagonal(std.^2)); the reference's mean-field test target
+    (test/models/normal.jl:56-75) and bench target (bench/benchmarks.jl:43-47)."""
+
+    def __init__(self, mean, std):
+        self.mean = np.asarray(mean, dtype=np.float64)
+        self.std = np.asarray(std, dtype=np.float64)
+
+    def dimension(self):
+        return self.mean.shape[0]
+
+    def logdensity(self, z):
+        r = (z - self.mean) / self.std
+        return float(-0.5 * np.sum(r * r) - np.sum(np.log(self.std)) - 0.5 * self.dimension() * LOG2PI)
+
+    def logdensity_and_gradient(self, z):
+        return self.logdensity(z), -(z - self.mean) / (self.std ** 2)
+
+
+class DenseNormalTarget:
+    """MvNormal(mean, L L'), `TestNormal` with a dense covariance: test/models/normal.jl:2-11, 36-54."""
+
+    def __init__(self, mean, L):
+        self.mean = np.asarray(mean, dtype=np.float64)
+        self.L = np.tril(np.asarray(L, dtype=np.float64))
+        self.cov = self.L @ self.L.T
+        self.prec = np.linalg.inv(self.cov)
+        self.logdet_cov = 2.0 * float(np.sum(np.log(np.diag(self.L))))
+
+    def dimension(self):
+        return self.mean.shape[0]
+
+    def logdensity(self, z):
+        r = z - self.mean
+        return float(-0.5 * r @ self.prec @ r - 0.5 * self.logdet_cov - 0.5 * self.dimension() * LOG2PI)
+
+    def logdensity_and_gradient(self, z):
+        return self.logdensity(z), -self.prec @ (z - self.mean)
+
+
+def _log1pexp(x):
+    return np.logaddexp(0.0, x)
+
+
+class LogRegTarget:
+    """Hierarchical logistic regression, theta = [beta (p); s] with
+        beta ~ MvNormal(0, sigma^2 I),  y ~ BernoulliLogit(X beta)
+    variant "logsigma_normal" (docs/src/tutorials/subsampling.md:26-38):
+        s = log sigma, sigma = exp(s), logprior_sigma = logpdf(Normal(0,3), sigma), no Jacobian,
+        likelihood scaled by likeadj = n_data / n.
+    variant "lognormal_exp_bijector" (README.md:42-66 wrapped by the TransformedLogDensityProblem
+        of README.md:91-106 with Bijectors.Stacked([identity, log-bijector])):
+        sigma = exp(s), logprior_sigma = logpdf(LogNormal(0,3), sigma), + logabsdetjac = s.
+    """
+
+    def __init__(self, X, y, variant="logsigma_normal", likeadj=1.0):
+        self.X = np.asarray(X, dtype=np.float64)
+        self.y = np.asarray(y, dtype=np.float64)
+        self.variant = variant
+        self.likeadj = float(likeadj)
+
+    def dimension(self):
+        return self.X.shape[1] + 1
+
+    def logdensity_and_gradient(self, z):
+        p = self.X.shape[1]
+        beta, s = z[:p], z[p]
+        sigma = math.exp(s)
+        logit = self.X @ beta
+        loglike = float(np.sum(self.y * logit - _log1pexp(logit)))
+        resid = self.y - 1.0 / (1.0 + np.exp(-logit))
+        bb = float(beta @ beta)
+        logprior_beta = -0.5 * p * LOG2PI - p * s - 0.5 * bb / sigma ** 2
+        g = np.empty(p + 1)
+        g[:p] = self.likeadj * (self.X.T @ resid) - beta / sigma ** 2
+        g_s = -p + bb / sigma ** 2
+        if self.variant == "logsigma_normal":
+            logprior_sigma = -0.5 * math.log(2.0 * math.pi * 9.0) - sigma ** 2 / 18.0
+            g_s += -(sigma ** 2) / 9.0
+            jac = 0.0
+        elif self.variant == "lognormal_exp_bijector":
+            logprior_sigma = -s - math.log(3.0) - 0.5 * LOG2PI - s * s / 18.0
+            g_s += -1.0 - s / 9.0
+            jac = s
+            g_s += 1.0
+        else:
+            raise ValueError(self.variant)
+        g[p] = g_s
+        return self.likeadj * loglike + logprior_beta + logprior_sigma + jac, g
+
+    def logdensity(self, z):
+        return self.logdensity_and_gradient(z)[0]
+
+
+class FunnelStackedTarget:
+    """Neal's funnel on its constrained scale (defined in SURVEY.md section 8d -- the reference has
+    no funnel): s ~ LogNormal(0, sigma_v), x_i ~ Normal(0, s) (std-dev s), theta = [s; x],
+    unconstrained via binv = inverse(Stacked([log-bijector, identity], [1:1, 2:d])) exactly as
+    README.md:76-82,102-106 does: s = exp(eta_1), logabsdetjac = eta_1."""
+
+    def __init__(self, d, sigma_v=1.5):
+        self.d = d
+        self.sigma_v = float(sigma_v)
+
+    def dimension(self):
+        return self.d
+
+    def logdensity_and_gradient(self, eta):
+        e1 = eta[0]
+        x = eta[1:]
+        n = self.d - 1
+        sv2 = self.sigma_v ** 2
+        log_lognormal = -e1 - math.log(self.sigma_v) - 0.5 * LOG2PI - e1 * e1 / (2.0 * sv2)
+        inv_s2 = math.exp(-2.0 * e1)
+        sx2 = float(x @ x)
+        log_x = -n * e1 - 0.5 * n * LOG2PI - 0.5 * sx2 * inv_s2
+        val = log_lognormal + log_x + e1
+        g = np.empty(self.d)
+        g[0] = (-1.0 - e1 / sv2) + (-n + sx2 * inv_s2) + 1.0
+        g[1:] = -x * inv_s2
+        return val, g
+
+    def logdensity(self, eta):
+        return self.logdensity_and_gradient(eta)[0]
+
+
+# --------------------------------------------------------------------------------------
+# RepGradELBO
+# --------------------------------------------------------------------------------------
+def estimate_energy_with_samples(prob, samples: np.ndarray) -> float:
+    """mean(logdensity(prob, z_m) for z_m in eachcol(samples)), src/algorithms/repgradelbo.jl:84-86."""
+    return float(np.mean([prob.logdensity(samples[:, m]) for m in range(samples.shape[1])]))
+
+
+def reparam_with_entropy(q, q_stop, eps, ent_kind):
+    """src/algorithms/repgradelbo.jl:104-110."""
+    samples = rand_batch(q, eps)
+    return samples, estimate_entropy(ent_kind, samples, q, q_stop)
+
+
+def estimate_objective(q: MvLocationScale, prob, eps: np.ndarray, ent_kind: int = ENT_MONTE_CARLO) -> float:
+    """estimate_objective(rng, obj::RepGradELBO, q, prob; n_samples): q_stop := q, returns the
+    NEGATIVE elbo.  src/algorithms/repgradelbo.jl:112-118; the algorithm-level wrapper defaults to
+    MonteCarloEntropy (src/algorithms/common.jl:29-38)."""
+    samples, ent = reparam_with_entropy(q, q, eps, ent_kind)
+    return -(estimate_energy_with_samples(prob, samples) + ent)
+
+
+def estimate_repgradelbo_forward(params, d, family, prob, eps, ent_kind, q_stop=None) -> float:
+    """estimate_repgradelbo_ad_forward(params, aux) = -(energy + entropy),
+    src/algorithms/repgradelbo.jl:142-149 (q_stop = restructure(params), :162)."""
+    q = restructure(params, d, family)
+    if q_stop is None:
+        q_stop = restructure(params, d, family)
+    samples, ent = reparam_with_entropy(q, q_stop, eps, ent_kind)
+    return -(estimate_energy_with_samples(prob, samples) + ent)
+
+
+def c_inv_t_eps(q: MvLocationScale, eps: np.ndarray) -> np.ndarray:
+    """C^{-T} eps == -grad_z log q_stop(z) at z = mu + C eps  (SURVEY.md section 3.4)."""
+    if q.is_meanfield:
+        return eps / q.scale[:, None]
+    return np.linalg.solve(np.tril(q.scale).T, eps)
+
+
+def estimate_gradient(params, d, family, prob, eps, ent_kind):
+    """What `estimate_gradient!` (src/algorithms/repgradelbo.jl:151-177) leaves in `out`:
+    value = -elbo and gradient = d(value)/d(params), written out in closed form
+    (checked against AD of the forward in tests/test_oracle_pinning.py).
+
+    Returns dict(value, grad, elbo, Z, ell, G, W, entropy, partials) where `partials` is the
+    un-normalised shard-additive buffer of include/mivi.h:
+        mean-field: [sum_m W_im (d); sum_m W_im eps_im (d); sum_m ell_m; sum_m 0.5|eps_m|^2]
+        full-rank : [sum_m W_im (d); vec(tril(sum_m W_im eps_jm)) (d*d); sum ell; sum 0.5|eps|^2]
+    """
+    q = restructure(params, d, family)
+    M = eps.shape[1]
+    Z = rand_batch(q, eps)
+    ell = np.empty(M)
+    G = np.empty((d, M))
+    for m in range(M):
+        ell[m], G[:, m] = prob.logdensity_and_gradient(Z[:, m])
+    diag = q.scale if q.is_meanfield else np.diag(q.scale)
+    ent_cf = entropy_closed_form(q)
+    half_eps2 = 0.5 * np.sum(eps * eps, axis=0)
+    ent_mc = float(np.mean(half_eps2)) + 0.5 * d * LOG2PI + float(np.sum(np.log(diag)))
+    if ent_kind in (ENT_CLOSED_FORM, ENT_CLOSED_FORM_ZERO_GRAD):
+        ent = ent_cf
+    else:
+        ent = ent_mc
+    stl = ent_kind in (ENT_STL, ENT_STL_ZERO_GRAD)
+    W = G + (c_inv_t_eps(q, eps) if stl else 0.0)
+    direct = {ENT_CLOSED_FORM: 1.0, ENT_CLOSED_FORM_ZERO_GRAD: 0.0, ENT_MONTE_CARLO: 1.0,
+              ENT_STL: 0.0, ENT_STL_ZERO_GRAD: -1.0}[ent_kind]
+    g_mu = -W.sum(axis=1) / M
+    if q.is_meanfield:
+        P_scale = (W * eps).sum(axis=1)
+        g_scale = -P_scale / M - direct / diag
+        grad = np.concatenate([g_mu, g_scale])
+        partials = np.concatenate([W.sum(axis=1), P_scale, [ell.sum()], [half_eps2.sum()]])
+    else:
+        P_scale = np.tril(W @ eps.T)
+        gC = -P_scale / M - direct * np.diag(1.0 / diag)
+        grad = np.concatenate([g_mu, gC.reshape(-1, order="F")])
+        partials = np.concatenate([W.sum(axis=1), P_scale.reshape(-1, order="F"), [ell.sum()], [half_eps2.sum()]])
+    value = -(float(np.mean(ell)) + ent)
+    return dict(value=value, grad=grad, elbo=-value, Z=Z, ell=ell, G=G, W=W, entropy=ent, partials=partials)
+
+
+def finalize_partials(partials, params, d, family, ent_kind, M_total):
+    """Host restatement of the finalize step applied after the all-reduce of shard partials
+    (SURVEY.md section 8e): scale by -1/M_total, add the parameter-only entropy terms once."""
+    q = restructure(params, d, family)
+    diag = q.scale if q.is_meanfield else np.diag(q.scale)
+    direct = {ENT_CLOSED_FORM: 1.0, ENT_CLOSED_FORM_ZERO_GRAD: 0.0, ENT_MONTE_CARLO: 1.0,
+              ENT_STL: 0.0, ENT_STL_ZERO_GRAD: -1.0}[ent_kind]
+    sum_ell, sum_half_eps2 = partials[-2], partials[-1]
+    logdet = float(np.sum(np.log(diag)))
+    if ent_kind in (ENT_CLOSED_FORM, ENT_CLOSED_FORM_ZERO_GRAD):
+        ent = d * 0.5 * (1.0 + LOG2PI) + logdet
+    else:
+        ent = sum_half_eps2 / M_total + 0.5 * d * LOG2PI + logdet
+    g_mu = -partials[:d] / M_total
+    if family == MEANFIELD:
+        g_scale = -partials[d:2 * d] / M_total - direct / diag
+        grad = np.concatenate([g_mu, g_scale])
+    else:
+        gC = -partials[d:d + d * d].reshape(d, d, order="F") / M_total - direct * np.diag(1.0 / diag)
+        grad = np.concatenate([g_mu, gC.reshape(-1, order="F")])
+    return -(sum_ell / M_total + ent), grad
+
+
+# --------------------------------------------------------------------------------------
+# Host-side operators next to the hot path (section 8f)
+# --------------------------------------------------------------------------------------
+def clip_scale(params, d, family, epsilon=1e-5):
+    """ClipScale: scale[diagind] = max(scale[diagind], eps); src/optimization/clip_scale.jl:18-29."""
+    out = np.array(params, dtype=np.float64, copy=True)
+    if family == MEANFIELD:
+        out[d:] = np.maximum(out[d:], epsilon)
+    else:
+        idx = d + np.arange(d) * (d + 1)
+        out[idx] = np.maximum(out[idx], epsilon)
+        # restructure -> destructure re-projects onto LowerTriangular
+        C = np.tril(out[d:].reshape(d, d, order="F"))
+        out[d:] = C.reshape(-1, order="F")
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Counter-based RNG: Philox4x32-10 + Box-Muller (the eps stream of the HIP kernels)
+# --------------------------------------------------------------------------------------
+_PHILOX_M0 = np.uint64(0xD2511F53)
+_PHILOX_M1 = np.uint64(0xCD9E8D57)
+_PHILOX_W0 = 0x9E3779B9
+_PHILOX_W1 = 0xBB67AE85
+_MASK32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon et al., SC'11; Random123 v1.09).  `ctr`: (..., 4) uint32 array,
+    `key`: (k0, k1).  Vectorised over leading dims.  Known-answer vectors in tests."""
+    c = [np.asarray(ctr[..., i], dtype=np.uint64) for i in range(4)]
+    k0, k1 = int(key[0]) & 0xFFFFFFFF, int(key[1]) & 0xFFFFFFFF
+    for r in range(10):
+        p0 = _PHILOX_M0 * c[0]
+        p1 = _PHILOX_M1 * c[2]
+        hi0, lo0 = p0 >> np.uint64(32), p0 & _MASK32
+        hi1, lo1 = p1 >> np.uint64(32), p1 & _MASK32
+        c = [hi1 ^ c[1] ^ np.uint64(k0), lo1, hi0 ^ c[3] ^ np.uint64(k1), lo0]
+        k0 = (k0 + _PHILOX_W0) & 0xFFFFFFFF
+        k1 = (k1 + _PHILOX_W1) & 0xFFFFFFFF
+    return np.stack([x.astype(np.uint32) for x in c], axis=-1)
+
+
+def philox_bits(seed: int, estimate_idx: int, d: int, m_lo: int, m_hi: int) -> np.ndarray:
+    """Raw 32-bit words of the eps stream for global sample columns [m_lo, m_hi):
+    element (i, m) uses word i%4 of the Philox block with
+        counter = (lo32(q), hi32(q), lo32(estimate_idx), hi32(estimate_idx)),  q = m*ceil(d/4) + i//4
+        key     = (lo32(seed), hi32(seed)).
+    Returns uint32 array (d, m_hi-m_lo).  Mirrors advancedvi.jl_amd/csrc/philox.h."""
+    d4 = (d + 3) // 4
+    m = np.arange(m_lo, m_hi, dtype=np.uint64)
+    blk = np.arange(d4, dtype=np.uint64)
+    q = m[None, :] * np.uint64(d4) + blk[:, None]          # (d4, M)
+    ctr = np.empty(q.shape + (4,), dtype=np.uint32)
+    ctr[..., 0] = (q & _MASK32).astype(np.uint32)
+    ctr[..., 1] = (q >> np.uint64(32)).astype(np.uint32)
+    ctr[..., 2] = np.uint32(estimate_idx & 0xFFFFFFFF)
+    ctr[..., 3] = np.uint32((estimate_idx >> 32) & 0xFFFFFFFF)
+    out = philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))   # (d4, M, 4)
+    words = np.transpose(out, (0, 2, 1)).reshape(d4 * 4, m_hi - m_lo)
+    return words[:d]
+
+
+def box_muller_from_bits(words: np.ndarray, f64: bool = False) -> np.ndarray:
+    """Box-Muller on the (d, M) word array produced by `philox_bits`; rows 4b, 4b+1 form one
+    pair and 4b+2, 4b+3 the other:
+        n_{4b}   = r(w0) cos(2 pi u(w1)),  n_{4b+1} = r(w0) sin(2 pi u(w1)),   r(w) = sqrt(-2 ln u(w))
+    f32 stream: u(w) = ((w >> 9) + 0.5) * 2^-23   (exact in float32);
+    f64 stream: u(w) = (w + 0.5) * 2^-32.
+    Evaluated here in float64 (the device evaluates in its compute dtype)."""
+    d, M = words.shape
+    dpad = (d + 3) // 4 * 4
+    w = np.zeros((dpad, M), dtype=np.uint32)
+    w[:d] = words
+    w = w.reshape(dpad // 4, 4, M).astype(np.float64)
+    if f64:
+        u = (w + 0.5) * 2.0 ** -32
+    else:
+        u = (np.floor(w / 512.0) + 0.5) * 2.0 ** -23
+    out = np.empty_like(u)
+    for a, b in ((0, 1), (2, 3)):
+        r = np.sqrt(-2.0 * np.log(u[:, a]))
+        ang = 2.0 * np.pi * u[:, b]
+        out[:, a] = r * np.cos(ang)
+        out[:, b] = r * np.sin(ang)
+    return out.reshape(dpad, M)[:d]
+
+
+def philox_normal(seed: int, estimate_idx: int, d: int, m_lo: int, m_hi: int, f64: bool = False) -> np.ndarray:
+    """eps[:, m_lo:m_hi] of the estimate `estimate_idx` (d x (m_hi-m_lo), float64 evaluation)."""
+    return box_muller_from_bits(philox_bits(seed, estimate_idx, d, m_lo, m_hi), f64=f64)

@@ -1,0 +1,192 @@
+"""GPU parity tests proper: libmivi (through the C ABI) vs the CPU oracle on identical eps.
+
+eps is read back from the device (mivi_sample) and handed to the oracle, so both sides consume the
+same random stream (SURVEY.md 8c "identical RNG streams at the eps level"); the stream itself is
+checked bit-exactly (Philox words) and to a few ulp (Box-Muller) in test_gpu_rng.py.
+
+Tolerances (stated per the north star, fp32 compute vs fp64 oracle):
+    objective value : rel 1e-5 (f32), 1e-12 (f64)
+    gradient        : rel-L2 2e-5 (f32), 1e-11 (f64)
+"""
+import numpy as np
+import pytest
+
+import advancedvi_jl_amd as avi
+from oracle import oracle as O
+from tests.helpers import SEED, OraclePlugin, make_family, make_problem, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float32: (1e-5, 2e-5), np.float64: (1e-12, 1e-11)}
+ENTROPIES = [avi.ClosedFormEntropy(), avi.ClosedFormEntropyZeroGradient(), avi.MonteCarloEntropy(),
+             avi.StickingTheLandingEntropy(), avi.StickingTheLandingEntropyZeroGradient()]
+
+
+def run_case(d, M, family, kind, ent, dtype, idx=3, plugin=False):
+    rng = np.random.default_rng(1234 + d + 7 * M)
+    q, q_o = make_family(rng, d, family, dtype)
+    prob, tgt = make_problem(rng, kind, d, dtype)
+    if plugin:
+        prob = OraclePlugin(tgt)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(dtype, family, d, M, ent.code, SEED)
+    ctx.set_problem(prob)
+    Z, eps = ctx.sample(params, idx)
+    eps = eps.cpu().numpy().astype(np.float64)
+    Z = Z.cpu().numpy().astype(np.float64)
+    value, grad = ctx.estimate_gradient(params, idx)
+    value = float(value.item())
+    grad = grad.cpu().numpy().astype(np.float64)
+    ref = O.estimate_gradient(O.destructure(q_o), d, family, tgt, eps, ent.code)
+    vt, gt = TOL[dtype]
+    assert rel_err(Z, ref["Z"]) < (1e-6 if dtype == np.float32 else 1e-14)
+    assert abs(value - ref["value"]) <= vt * abs(ref["value"]), (value, ref["value"])
+    gscale = np.linalg.norm(ref["grad"])
+    assert np.linalg.norm(grad - ref["grad"]) <= gt * max(gscale, 1.0), (rel_err(grad, ref["grad"]))
+    if family == avi.FULLRANK:  # structural zeros above the diagonal
+        gC = grad[d:].reshape(d, d, order="F")
+        assert np.all(np.triu(gC, 1) == 0.0)
+    # partials route (multi-GPU building block) must agree with the fused route
+    part = ctx.estimate_partials(params, idx)
+    v2, g2 = ctx.finalize(params, part)
+    assert abs(float(v2.item()) - ref["value"]) <= 2 * vt * abs(ref["value"])
+    assert np.linalg.norm(g2.cpu().numpy() - ref["grad"]) <= 2 * gt * max(gscale, 1.0)
+    assert rel_err(part.cpu().numpy(), ref["partials"]) < (5e-6 if dtype == np.float32 else 1e-12)
+    ctx.close()
+    return value, grad
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("ent", ENTROPIES, ids=lambda e: type(e).__name__)
+@pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
+def test_diag_gauss_all_estimators(family, ent, dtype):
+    run_case(40, 24, family, "diag", ent, dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["dense", "logreg0", "logreg1", "funnel"])
+@pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
+def test_targets(family, kind, dtype):
+    for ent in (avi.ClosedFormEntropy(), avi.StickingTheLandingEntropy()):
+        run_case(33, 17, family, kind, ent, dtype)
+
+
+@pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
+def test_plugin_callback_route(family):
+    """Generic LogDensityProblems plugin: batched logdensity_and_gradient over the columns of Z
+    (src/mixedad_logdensity.jl:23-34 seam)."""
+    run_case(12, 9, family, "logreg1", avi.ClosedFormEntropy(), np.float64, plugin=True)
+    run_case(12, 9, family, "dense", avi.StickingTheLandingEntropy(), np.float32, plugin=True)
+
+
+@pytest.mark.parametrize("family,d,M", [(avi.MEANFIELD, 1024, 256), (avi.FULLRANK, 256, 128), (avi.FULLRANK, 1024, 256),
+                                        (avi.MEANFIELD, 5, 1), (avi.FULLRANK, 5, 1), (avi.FULLRANK, 70, 300),
+                                        (avi.MEANFIELD, 3, 1000)])
+def test_sizes_including_ragged(family, d, M):
+    """BASELINE sizes (C2, north star) and ragged / minimal shapes (d, M not multiples of the tile)."""
+    run_case(d, M, family, "diag", avi.ClosedFormEntropy(), np.float32)
+    if d <= 256:
+        run_case(d, M, family, "dense", avi.MonteCarloEntropy(), np.float32)
+
+
+def test_stl_zero_gradient_known_answer():
+    """Reference known answer: STL gradient == 0 when q == pi, for any M
+    (test/algorithms/klminrepgraddescent.jl:66-87, atol 1e-5)."""
+    d = 5
+    for family in (avi.MEANFIELD, avi.FULLRANK):
+        for M in (1, 10):
+            mu = np.full(d, 5.0)
+            if family == avi.MEANFIELD:
+                q = avi.MeanFieldGaussian(mu, np.full(d, 0.3))
+                prob = avi.DiagNormalProblem(mu, np.full(d, 0.3))
+            else:
+                L = 0.3 * np.eye(d) + 0.05 * np.tril(np.ones((d, d)), -1)
+                q = avi.FullRankGaussian(mu, L)
+                prob = avi.DenseNormalProblem(mu, L)
+            params, _ = avi.destructure(q)
+            ctx = avi.MiviContext(np.float64, family, d, M, avi.StickingTheLandingEntropy.code, SEED)
+            ctx.set_problem(prob)
+            _, grad = ctx.estimate_gradient(params, 0)
+            assert np.linalg.norm(grad.cpu().numpy()) < 1e-5
+            ctx.close()
+
+
+def test_estimate_objective_at_optimum_is_zero():
+    """estimate_objective(q = pi, n_samples = 10^5) ~ 0, atol 1e-2
+    (test/algorithms/klminrepgraddescent.jl:36-37; default monitor entropy = MonteCarloEntropy)."""
+    d = 5
+    mu = np.full(d, 5.0)
+    q = avi.MeanFieldGaussian(mu, np.full(d, 0.3))
+    prob = avi.DiagNormalProblem(mu, np.full(d, 0.3))
+    alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), operator=avi.ClipScale())
+    rng = avi.PhiloxRNG(SEED)
+    for n in (None, 1, 3):
+        assert np.isfinite(avi.estimate_objective(rng, alg, q, prob, n_samples=n))
+    assert abs(avi.estimate_objective(rng, alg, q, prob, n_samples=10 ** 5)) < 1e-2
+    L = 0.3 * np.eye(d) + 0.05 * np.tril(np.ones((d, d)), -1)
+    qf = avi.FullRankGaussian(mu, L)
+    assert abs(avi.estimate_objective(rng, alg, qf, avi.DenseNormalProblem(mu, L), n_samples=10 ** 5)) < 1e-2
+
+
+def test_estimate_objective_matches_oracle():
+    rng = np.random.default_rng(5)
+    for family in (avi.MEANFIELD, avi.FULLRANK):
+        for kind in ("diag", "dense", "funnel"):
+            d, M = 24, 50
+            q, q_o = make_family(rng, d, family, np.float64)
+            prob, tgt = make_problem(rng, kind, d, np.float64)
+            params, _ = avi.destructure(q)
+            ctx = avi.MiviContext(np.float64, family, d, M, 0, SEED)
+            ctx.set_problem(prob)
+            _, eps = ctx.sample(params, 11)
+            for ent in (0, 2):
+                v = float(ctx.estimate_objective(params, 11, n_samples=M, entropy=ent).item())
+                ref = O.estimate_objective(q_o, tgt, eps.cpu().numpy(), ent)
+                assert abs(v - ref) <= 1e-11 * abs(ref)
+            ctx.close()
+
+
+def test_determinism_bitwise():
+    """Same seed => bitwise identical results (test/algorithms/klminrepgraddescent.jl:40-57)."""
+    for family, d, M in ((avi.MEANFIELD, 1024, 256), (avi.FULLRANK, 256, 64)):
+        rng = np.random.default_rng(9)
+        q, _ = make_family(rng, d, family, np.float32)
+        prob, _ = make_problem(rng, "diag", d, np.float32)
+        params, _ = avi.destructure(q)
+        outs = []
+        for _ in range(2):
+            ctx = avi.MiviContext(np.float32, family, d, M, 0, SEED)
+            ctx.set_problem(prob)
+            v, g = ctx.estimate_gradient(params, 5)
+            outs.append((v.cpu().numpy().copy(), g.cpu().numpy().copy()))
+            ctx.close()
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_graph_batched_estimates_match_single():
+    for family, d, M in ((avi.MEANFIELD, 256, 64), (avi.FULLRANK, 128, 64)):
+        rng = np.random.default_rng(10)
+        q, _ = make_family(rng, d, family, np.float32)
+        prob, _ = make_problem(rng, "diag", d, np.float32)
+        params, _ = avi.destructure(q)
+        ctx = avi.MiviContext(np.float32, family, d, M, 0, SEED)
+        ctx.set_problem(prob)
+        p = ctx.to_device(params)
+        v1, g1 = ctx.estimate_gradient(p, 7 + 4)
+        v1, g1 = v1.cpu().numpy().copy(), g1.cpu().numpy().copy()
+        v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+        ctx.estimate_gradient_n(p, 7, 5, v, g)   # estimates 7..11; last one left in the buffers
+        ctx.synchronize()
+        assert np.array_equal(v.cpu().numpy(), v1) and np.array_equal(g.cpu().numpy(), g1)
+        ctx.close()
+
+
+def test_nonpositive_scale_and_nonfinite_status():
+    """Error conventions: non-finite objective -> the reference's ErrorException (common.jl:83-89)."""
+    d = 8
+    q = avi.MeanFieldGaussian(np.zeros(d), np.ones(d))
+    prob = avi.DiagNormalProblem(np.zeros(d), np.ones(d))
+    alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), optimizer=avi.Descent(1e300), n_samples=4, operator=avi.IdentityOperator())
+    with pytest.warns(UserWarning, match="IdentityOperator"):
+        with pytest.raises(RuntimeError, match="diverged"):
+            avi.optimize(avi.PhiloxRNG(1), alg, 5, prob, q)
