@@ -64,6 +64,7 @@ __device__ void finalize_value_block(int d, const ValueIn &vin, const OutArgs &o
   const int tid = threadIdx.x;
   double s_ell = 0.0, s_he = 0.0, s_ld = 0.0, bad = 0.0;
   for (int i = tid; i < vin.n_ell_part; i += NT) s_ell += ld_f64<ATOMIC>(vin.ell_part + i);
+  for (int i = tid; i < vin.n_ell_part2; i += NT) s_ell += ld_f64<ATOMIC>(vin.ell_part2 + i);
   for (int i = tid; i < vin.n_ell; i += NT) s_ell += (double)((const T *)vin.ell)[i];
   for (int i = tid; i < vin.n_he_part; i += NT) s_he += ld_f64<ATOMIC>(vin.he_part + i);
   if (!out.partials_mode) {

@@ -407,6 +407,26 @@ __global__ __launch_bounds__(256) void k_fr_stl(FrArgs<T> a) {
   }
 }
 
+// RT[m + i*MP] = Z[i + m*d] - t_mean[i]: feeds the dense-Gaussian target product when Z was not
+// produced by the full-rank sample kernel (mean-field family).  64x64 LDS-tiled transpose.
+template <typename T>
+__global__ __launch_bounds__(256) void k_rt_from_z(int d, int M, int MP, const T *Z, const T *t_mean, T *RT) {
+  __shared__ T tile[64][65];
+  const int i0 = blockIdx.x * 64, m0 = blockIdx.y * 64, tid = threadIdx.x;
+  const int a = tid & 63, b = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int col = b + 4 * j, i = i0 + a, m = m0 + col;
+    tile[col][a] = (i < d && m < M) ? Z[(size_t)m * d + i] - t_mean[i] : T(0);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int row = b + 4 * j, i = i0 + row, m = m0 + a;
+    if (i < d && m < M) RT[(size_t)i * MP + m] = tile[a][row];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host-side launchers
 // ---------------------------------------------------------------------------------------------
@@ -470,6 +490,16 @@ void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, 
     a.Z = (double *)Z;
     hipLaunchKernelGGL((k_fr_tile_generic<double, MODE_SAMPLE>), dim3(nblk), dim3(256), 0, c->stream, a);
   }
+}
+
+void launch_rt_from_z(mivi_ctx *c, int M) {
+  dim3 grid((c->cfg.d + 63) / 64, (M + 63) / 64);
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_rt_from_z<float>, grid, dim3(256), 0, c->stream, c->cfg.d, M, c->MP, (const float *)c->Z.p,
+                       (const float *)c->t_mean.p, (float *)c->RT.p);
+  else
+    hipLaunchKernelGGL(k_rt_from_z<double>, grid, dim3(256), 0, c->stream, c->cfg.d, M, c->MP, (const double *)c->Z.p,
+                       (const double *)c->t_mean.p, (double *)c->RT.p);
 }
 
 void launch_fr_dense_target(mivi_ctx *c, int M, int want_grad) {

@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
     __syncthreads();
     if (s_last) {
       ValueIn vin = a.vin;
-      vin.ell_part = a.sc_part;
-      vin.n_ell_part = nblk;
+      vin.ell_part2 = a.sc_part;
+      vin.n_ell_part2 = nblk;
       vin.he_part = a.sc_part + nblk;
       vin.n_he_part = nblk;
       const T *sig = a.params + d;
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256) void k_mf_colreduce(MfArgs<T> a, int nblk_main
   }
   if (blockIdx.x == 0) {
     ValueIn vin = a.vin;
-    vin.ell_part = a.sc_part;
-    vin.n_ell_part = nblk_main;
+    vin.ell_part2 = a.sc_part;
+    vin.n_ell_part2 = nblk_main;
     vin.he_part = a.sc_part + nblk_main;
     vin.n_he_part = nblk_main;
     const T *sig = a.params + d;

@@ -48,12 +48,13 @@ static mivi_status_t ensure_work(mivi_ctx *c, int M) {
     c->dP = round_up(d, 64);
     c->MP = capM;
     if (c->cfg.family == MIVI_FULLRANK) {
-      c->eps.bytes = 0; c->epsT.bytes = 0; c->RT.bytes = 0;
+      c->eps.bytes = 0; c->epsT.bytes = 0;
       if ((s = ensure(c, c->eps, (size_t)c->dP * c->MP * es, true))) return s;
       if ((s = ensure(c, c->epsT, (size_t)c->dP * c->MP * es, true))) return s;
-      if (c->target == TGT_DENSE_GAUSS || c->target == TGT_LOGREG) {
-        if ((s = ensure(c, c->RT, (size_t)c->dP * c->MP * es, true))) return s;
-      }
+    }
+    if (c->target == TGT_DENSE_GAUSS) {
+      c->RT.bytes = 0;
+      if ((s = ensure(c, c->RT, (size_t)c->dP * c->MP * es, true))) return s;
     }
     if ((s = ensure(c, c->Z, (size_t)d * capM * es, false))) return s;
     if ((s = ensure(c, c->W, (size_t)d * capM * es, false))) return s;
@@ -331,9 +332,16 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
       launch_mf_main(c, params, rng, M, want_grad, nullptr, vin, out);
     } else {
       launch_sample_mf(c, params, rng, M, c->Z.p, nullptr, 0, want_grad ? nullptr : (double *)c->he_part.p);
-      if ((s = eval_generic_target(c, M, want_grad))) return s;
-      vin.ell = c->ell.p;
-      vin.n_ell = M;
+      if (c->target == TGT_DENSE_GAUSS) {
+        launch_rt_from_z(c, M);
+        launch_fr_dense_target(c, M, want_grad);
+        vin.ell_part = (const double *)c->ell_part.p;
+        vin.n_ell_part = fr_dense_blocks(c, M);
+      } else {
+        if ((s = eval_generic_target(c, M, want_grad))) return s;
+        vin.ell = c->ell.p;
+        vin.n_ell = M;
+      }
       if (want_grad) {
         launch_mf_main(c, params, rng, M, 1, c->W.p, vin, out);
       } else {

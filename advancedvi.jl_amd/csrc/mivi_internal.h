@@ -36,6 +36,8 @@ enum TargetKind : int {
 struct ValueIn {
   const double *ell_part;  // per-workgroup partial sums of sum_m ell_m (variable part)
   int n_ell_part;
+  const double *ell_part2; // second set (the launching kernel's own partials)
+  int n_ell_part2;
   const void *ell;         // per-sample ell (T), generic target route
   int n_ell;
   const double *he_part;   // partial sums of sum_m 0.5|eps_m|^2
@@ -191,6 +193,7 @@ void launch_eps(mivi_ctx *c, const RngArgs &rng, int M);
 void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, void *Z);
 void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const ValueIn &vin, const OutArgs &out);
 void launch_fr_dense_target(mivi_ctx *c, int M, int want_grad);
+void launch_rt_from_z(mivi_ctx *c, int M);
 void launch_fr_stl(mivi_ctx *c, const void *params, int M);
 int fr_sample_blocks(const mivi_ctx *c, int M);
 int fr_dense_blocks(const mivi_ctx *c, int M);

@@ -420,12 +420,13 @@ def philox4x32_10(ctr, key):
     return np.stack([x.astype(np.uint32) for x in c], axis=-1)
 
 
-def philox_bits(seed: int, estimate_idx: int, d: int, m_lo: int, m_hi: int) -> np.ndarray:
+def philox_bits(seed: int, estimate_idx: int, d: int, m_lo: int, m_hi: int, pad: bool = False) -> np.ndarray:
     """Raw 32-bit words of the eps stream for global sample columns [m_lo, m_hi):
     element (i, m) uses word i%4 of the Philox block with
         counter = (lo32(q), hi32(q), lo32(estimate_idx), hi32(estimate_idx)),  q = m*ceil(d/4) + i//4
         key     = (lo32(seed), hi32(seed)).
-    Returns uint32 array (d, m_hi-m_lo).  Mirrors advancedvi.jl_amd/csrc/philox.h."""
+    Returns uint32 array (d, m_hi-m_lo), or all 4*ceil(d/4) rows when `pad` (the last Philox block of a
+    column is only partly consumed when d % 4 != 0).  Mirrors advancedvi.jl_amd/csrc/philox.h."""
     d4 = (d + 3) // 4
     m = np.arange(m_lo, m_hi, dtype=np.uint64)
     blk = np.arange(d4, dtype=np.uint64)
@@ -437,21 +438,19 @@ def philox_bits(seed: int, estimate_idx: int, d: int, m_lo: int, m_hi: int) -> n
     ctr[..., 3] = np.uint32((estimate_idx >> 32) & 0xFFFFFFFF)
     out = philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))   # (d4, M, 4)
     words = np.transpose(out, (0, 2, 1)).reshape(d4 * 4, m_hi - m_lo)
-    return words[:d]
+    return words if pad else words[:d]
 
 
 def box_muller_from_bits(words: np.ndarray, f64: bool = False) -> np.ndarray:
-    """Box-Muller on the (d, M) word array produced by `philox_bits`; rows 4b, 4b+1 form one
+    """Box-Muller on the (4*ceil(d/4), M) word array produced by `philox_bits(..., pad=True)`; rows 4b, 4b+1 form one
     pair and 4b+2, 4b+3 the other:
         n_{4b}   = r(w0) cos(2 pi u(w1)),  n_{4b+1} = r(w0) sin(2 pi u(w1)),   r(w) = sqrt(-2 ln u(w))
     f32 stream: u(w) = ((w >> 9) + 0.5) * 2^-23   (exact in float32);
     f64 stream: u(w) = (w + 0.5) * 2^-32.
     Evaluated here in float64 (the device evaluates in its compute dtype)."""
-    d, M = words.shape
-    dpad = (d + 3) // 4 * 4
-    w = np.zeros((dpad, M), dtype=np.uint32)
-    w[:d] = words
-    w = w.reshape(dpad // 4, 4, M).astype(np.float64)
+    dpad, M = words.shape
+    assert dpad % 4 == 0, "pass whole Philox blocks (philox_bits(..., pad=True))"
+    w = words.reshape(dpad // 4, 4, M).astype(np.float64)
     if f64:
         u = (w + 0.5) * 2.0 ** -32
     else:
@@ -462,9 +461,9 @@ def box_muller_from_bits(words: np.ndarray, f64: bool = False) -> np.ndarray:
         ang = 2.0 * np.pi * u[:, b]
         out[:, a] = r * np.cos(ang)
         out[:, b] = r * np.sin(ang)
-    return out.reshape(dpad, M)[:d]
+    return out.reshape(dpad, M)
 
 
 def philox_normal(seed: int, estimate_idx: int, d: int, m_lo: int, m_hi: int, f64: bool = False) -> np.ndarray:
     """eps[:, m_lo:m_hi] of the estimate `estimate_idx` (d x (m_hi-m_lo), float64 evaluation)."""
-    return box_muller_from_bits(philox_bits(seed, estimate_idx, d, m_lo, m_hi), f64=f64)
+    return box_muller_from_bits(philox_bits(seed, estimate_idx, d, m_lo, m_hi, pad=True), f64=f64)[:d]
