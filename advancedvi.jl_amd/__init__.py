@@ -15,6 +15,7 @@ from . import optimize as _optimize
 from .optimize import (KLMinRepGradDescent, ADVI, ClipScale, IdentityOperator, Descent, Adam, DoG, DoWG, NoAveraging,
                        PolynomialAveraging, optimize, step, output)
 from .context import MiviContext
+from . import distributed
 
 
 def estimate_objective(*args, **kwargs):

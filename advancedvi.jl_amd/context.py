@@ -217,6 +217,12 @@ class MiviContext:
         self._chk(self.lib.mivi_finalize(self.h, self._p(p), self._p(partials), self._p(value), self._p(grad)))
         return value, grad
 
+    def profile_kernel(self, which, params, reps):
+        """ms per launch of one pipeline stage, hipEvent-timed on the context's stream (mivi_profile_kernel)."""
+        ms = C.c_double(0.0)
+        self._chk(self.lib.mivi_profile_kernel(self.h, int(which), self._p(params), int(reps), C.byref(ms)))
+        return ms.value
+
     # -- next to the hot path ---------------------------------------------------------------------
     def clip_scale(self, params, epsilon):
         self._chk(self.lib.mivi_clip_scale(self.h, self._p(params), float(epsilon)))

@@ -12,6 +12,20 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// f32 wave64 sum on the DPP crossbar (no LDS traffic): quad_perm, quad_perm, row_half_mirror, row_mirror
+// leave every lane with its 16-lane row sum; four v_readlane finish.  Result is wave-uniform.
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  const int iv = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16)) +
+         __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+}
+__device__ __forceinline__ double wave_sum_fast(float v) { return (double)wave_sum_f32(v); }
+__device__ __forceinline__ double wave_sum_fast(double v) { return wave_sum(v); }
+
 // Sum `v` over the workgroup; result valid in every thread. `red` must hold NT/64 elements.
 // Fixed reduction tree => bitwise reproducible for a given launch geometry.
 template <typename T, int NT>
@@ -26,6 +40,8 @@ __device__ __forceinline__ T block_sum(T v, T *red) {
   for (int i = 1; i < NT / 64; ++i) s += red[i];
   return s;
 }
+
+#define MIVI_STAMP(dbgp, slot) do { if ((dbgp) && threadIdx.x == 0) (dbgp)[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ uint64_t rng_index(const RngArgs &r) {
   return r.idx_base + (r.idx_ptr ? *r.idx_ptr : 0ull);
@@ -68,10 +84,17 @@ __device__ void finalize_value_block(int d, const ValueIn &vin, const OutArgs &o
   for (int i = tid; i < vin.n_ell; i += NT) s_ell += (double)((const T *)vin.ell)[i];
   for (int i = tid; i < vin.n_he_part; i += NT) s_he += ld_f64<ATOMIC>(vin.he_part + i);
   if (!out.partials_mode) {
-    for (int i = tid; i < d; i += NT) {
-      const double c = (double)scale_diag(i);
-      if (!(c > 0.0)) bad = 1.0;
-      s_ld += log(c);
+    if (vin.ld_part) {   // per-workgroup partials of sum_i log C_ii and of the non-positive-diagonal count
+      for (int i = tid; i < vin.n_ld_part; i += NT) {
+        s_ld += ld_f64<ATOMIC>(vin.ld_part + i);
+        bad += ld_f64<ATOMIC>(vin.ld_part + vin.n_ld_part + i);
+      }
+    } else {
+      for (int i = tid; i < d; i += NT) {
+        const double c = (double)scale_diag(i);
+        if (!(c > 0.0)) bad = 1.0;
+        s_ld += log(c);
+      }
     }
   }
   s_ell = block_sum<double, NT>(s_ell, red);

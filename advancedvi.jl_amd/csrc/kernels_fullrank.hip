@@ -222,56 +222,80 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
   tile_coords<MODE>(d, M, ib, cb, Ktile);
   const int i0 = ib * 32, n0 = cb * 32;
 
+  MIVI_STAMP(a.dbg, 0);
+  // K split: NW contiguous chunks, multiples of the 32-k pipeline stage
   int chunk = (Ktile + NW - 1) / NW;
-  chunk = (chunk + 15) & ~15;
+  chunk = (chunk + 31) & ~31;
   const int kbeg = w * chunk;
-  const int kend = min(kbeg + chunk, (Ktile + 15) & ~15);
+  const int kend = min(kbeg + chunk, (Ktile + 31) & ~31);
 
   const int gi = i0 + l31;
   const float *Abase;
-  int lda;
+  int lda, kmaxA;
   const float *Bbase;
   int ldb;
   if (MODE == MODE_SAMPLE) {
-    Abase = a.params + d;  lda = d;   Bbase = a.epsT + n0 + l31;  ldb = a.MP;
+    Abase = a.params + d;  lda = d;    kmaxA = d - 1;  Bbase = a.epsT + n0 + l31;  ldb = a.MP;
   } else if (MODE == MODE_VJP) {
-    Abase = a.W;           lda = d;   Bbase = a.eps + n0 + l31;   ldb = a.dP;
+    Abase = a.W;           lda = d;    kmaxA = M - 1;  Bbase = a.eps + n0 + l31;   ldb = a.dP;
   } else {
-    Abase = a.t_prec;      lda = a.dP; Bbase = a.RT + n0 + l31;   ldb = a.MP;
+    Abase = a.t_prec;      lda = a.dP; kmaxA = a.dP - 1; Bbase = a.RT + n0 + l31;  ldb = a.MP;
   }
   const bool row_ok = gi < d;
+  // every load is unconditional on a clamped (always valid) address; out-of-range operands are zeroed
+  // at use.  (A guarded `ok ? load : 0` makes hipcc wrap each load in its own exec-mask branch.)
+  const float *Arow = Abase + (MODE == MODE_DENSE ? gi : min(gi, d - 1));
 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float rs = 0.f;
 
-  for (int k = kbeg; k < kend; k += 16) {
-    float av[8], bv[8];
+  float a0[16], b0[16], a1[16], b1[16];
+  auto load_stage = [&](int k, float (&av)[16], float (&bv)[16]) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 16; ++u) {
       const int kk = k + 2 * u + h;
-      bool ok;
-      if (MODE == MODE_SAMPLE)
-        ok = row_ok && (kk <= gi);
-      else if (MODE == MODE_VJP)
-        ok = row_ok && (kk < M);
-      else
-        ok = true;
-      av[u] = ok ? Abase[(size_t)kk * lda + gi] : 0.f;
+      av[u] = Arow[(size_t)min(kk, kmaxA) * lda];
       bv[u] = Bbase[(size_t)kk * ldb];
     }
+  };
+  auto mma_stage = [&](int k, const float (&av)[16], const float (&bv)[16]) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (MODE == MODE_VJP) rs += av[u];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    for (int u = 0; u < 16; ++u) {
+      const int kk = k + 2 * u + h;
+      bool ok;
+      if (MODE == MODE_SAMPLE) ok = row_ok && (kk <= gi);
+      else if (MODE == MODE_VJP) ok = row_ok && (kk < M);
+      else ok = true;
+      const float av_m = ok ? av[u] : 0.f;
+      if (MODE == MODE_VJP) rs += av_m;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_m, bv[u], acc, 0, 0, 0);
+    }
+  };
+  if (kbeg < kend) {
+    load_stage(kbeg, a0, b0);
+    int k = kbeg;
+    while (true) {
+      const bool more1 = (k + 32) < kend;
+      if (more1) load_stage(k + 32, a1, b1);
+      mma_stage(k, a0, b0);
+      if (!more1) break;
+      k += 32;
+      const bool more0 = (k + 32) < kend;
+      if (more0) load_stage(k + 32, a0, b0);
+      mma_stage(k, a1, b1);
+      if (!more0) break;
+      k += 32;
     }
   }
 
+  MIVI_STAMP(a.dbg, 1);
 #pragma unroll
   for (int r = 0; r < 16; ++r) red_acc[w][r * 65 + lane] = acc[r];
   rs_lds[tid] = rs;
   __syncthreads();
+  MIVI_STAMP(a.dbg, 2);
 
   auto get = [&](int row, int col) -> float {
     const int r = (row & 3) + 4 * (row >> 3);
@@ -283,6 +307,7 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
     return s;
   };
   tile_epilogue<float, MODE, NT>(a, ib, cb, get, rs_lds, red);
+  MIVI_STAMP(a.dbg, 3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -474,6 +499,7 @@ static FrArgs<T> fr_args(mivi_ctx *c, const void *params, int M) {
   a.ell_part = (double *)c->ell_part.p;
   a.vin = ValueIn{};
   a.out = OutArgs{};
+  a.dbg = c->dbg;
   return a;
 }
 

@@ -21,13 +21,15 @@ namespace mivi {
 template <typename T>
 __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
   __shared__ double red[4];
-  __shared__ double red_rows[8];
+  __shared__ double xw[4][12];   // per-wave partials: 0-3 sum W, 4-7 sum W*eps, 8 ell, 9 0.5 eps^2
+  __shared__ double tot[12];
   __shared__ int s_last;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int rq = blockIdx.x, cc = blockIdx.y;
   const int d = a.d, d4 = (d + 3) >> 2;
   const uint64_t idx = rng_index(a.rng);
   const bool stl = ent_is_stl(a.out.ent_kind);
+  MIVI_STAMP(a.dbg, 0);
 
   T mu[4], sg[4], isg[4], tm[4], tis[4];
 #pragma unroll
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
   for (int m = cc * a.cols_per_cc + tid; m < c_end; m += 256) {
     T e[4];
     eps_block<T>(a.rng.seed, idx, (uint64_t)(a.rng.m_offset + m) * (uint64_t)d4 + (uint64_t)rq, e);
-    T g[4];
+    T g[4] = {0, 0, 0, 0};
     if (a.target == TGT_DIAG_GAUSS) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = 4 * rq + r;
-        g[r] = (i < d) ? a.G[(size_t)m * d + i] : T(0);
+        g[r] = a.G[(size_t)m * d + min(i, d - 1)];
       }
     }
 #pragma unroll
@@ -76,70 +78,95 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
     }
   }
 
-  // ---- row sums over this workgroup's columns -------------------------------------------------
-  if (a.want_grad) {
-    const int lane = tid & 63, w = tid >> 6;
-    __shared__ double rows_w[4][8];
+  MIVI_STAMP(a.dbg, 1);
+  // ---- one wave-level pass (f32 DPP for T = float), one LDS exchange ---------------------------
+  {
+    double v[10];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const double x0 = wave_sum((double)sW[r]);
-      const double x1 = wave_sum((double)sWe[r]);
-      if (lane == 0) {
-        rows_w[w][r] = x0;
-        rows_w[w][4 + r] = x1;
-      }
+      v[r] = a.want_grad ? wave_sum_fast(sW[r]) : 0.0;
+      v[4 + r] = a.want_grad ? wave_sum_fast(sWe[r]) : 0.0;
     }
-    __syncthreads();
-    if (tid < 8) red_rows[tid] = rows_w[0][tid] + rows_w[1][tid] + rows_w[2][tid] + rows_w[3][tid];
-    __syncthreads();
+    v[8] = wave_sum_fast(s_ell);
+    v[9] = wave_sum_fast(s_he);
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 10; ++k) xw[wv][k] = v[k];
+    }
+  }
+  __syncthreads();
+  if (tid < 10) tot[tid] = xw[0][tid] + xw[1][tid] + xw[2][tid] + xw[3][tid];
+  // log-determinant / positivity partials of this workgroup's four rows (cc == 0 only counts once)
+  if (tid >= 16 && tid < 20) {
+    const int r = tid - 16, i = 4 * rq + r;
+    double lg = 0.0, bad = 0.0;
+    if (i < d && cc == 0) {
+      const T sv = a.params[d + i];
+      lg = (double)log(sv);
+      bad = (sv > T(0)) ? 0.0 : 1.0;
+    }
+    lg += __shfl_xor(lg, 1, 64);
+    lg += __shfl_xor(lg, 2, 64);
+    bad += __shfl_xor(bad, 1, 64);
+    bad += __shfl_xor(bad, 2, 64);
+    if (r == 0) {
+      tot[10] = lg;
+      tot[11] = bad;
+    }
+  }
+  __syncthreads();
+
+  if (a.want_grad) {
     if (a.n_cc == 1) {
       if (tid < 4) {
         const int i = 4 * rq + tid;
         if (i < d) {
           if (a.out.partials_mode) {
             T *p = (T *)a.out.partials;
-            p[i] = (T)red_rows[tid];
-            p[d + i] = (T)red_rows[4 + tid];
+            p[i] = (T)tot[tid];
+            p[d + i] = (T)tot[4 + tid];
           } else {
             T *gr = (T *)a.out.grad;
             const double invM = 1.0 / (double)a.out.M_total;
-            gr[i] = (T)(-red_rows[tid] * invM);
-            gr[d + i] = (T)(-red_rows[4 + tid] * invM - direct_entropy_coeff(a.out.ent_kind) / (double)sg[tid]);
+            const double sgi = (double)a.params[d + i];
+            gr[i] = (T)(-tot[tid] * invM);
+            gr[d + i] = (T)(-tot[4 + tid] * invM - direct_entropy_coeff(a.out.ent_kind) / sgi);
           }
         }
       }
     } else if (tid < 8) {
-      a.row_part[((size_t)cc * d4 + rq) * 8 + tid] = red_rows[tid];
+      a.row_part[((size_t)cc * d4 + rq) * 8 + tid] = tot[tid];
     }
   }
 
-  // ---- scalar partials ------------------------------------------------------------------------
-  const double b_ell = block_sum<double, 256>((double)s_ell, red);
-  const double b_he = block_sum<double, 256>((double)s_he, red);
+  MIVI_STAMP(a.dbg, 2);
+  // ---- scalar partials: [ell | he | logdet | bad] x nblk ----------------------------------------
   const int nblk = gridDim.x * gridDim.y;
   const int blk = cc * gridDim.x + rq;
   if (a.n_cc == 1) {
+    if (tid < 4) __hip_atomic_store(a.sc_part + (size_t)tid * nblk + blk, tot[8 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {
-      __hip_atomic_store(a.sc_part + blk, b_ell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.sc_part + nblk + blk, b_he, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = (t == (unsigned)(nblk - 1));
       if (s_last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    MIVI_STAMP(a.dbg, 3);
     if (s_last) {
       ValueIn vin = a.vin;
       vin.ell_part2 = a.sc_part;
       vin.n_ell_part2 = nblk;
       vin.he_part = a.sc_part + nblk;
       vin.n_he_part = nblk;
+      vin.ld_part = a.sc_part + 2 * (size_t)nblk;
+      vin.n_ld_part = nblk;
       const T *sig = a.params + d;
       finalize_value_block<T, 256, true>(d, vin, a.out, 2 * (int64_t)d, [sig](int i) { return sig[i]; }, red);
+      MIVI_STAMP(a.dbg, 4);
     }
-  } else if (tid == 0) {
-    a.sc_part[blk] = b_ell;
-    a.sc_part[nblk + blk] = b_he;
+  } else if (tid < 4) {
+    a.sc_part[(size_t)tid * nblk + blk] = tot[8 + tid];
   }
 }
 
@@ -173,6 +200,8 @@ __global__ __launch_bounds__(256) void k_mf_colreduce(MfArgs<T> a, int nblk_main
     vin.n_ell_part2 = nblk_main;
     vin.he_part = a.sc_part + nblk_main;
     vin.n_he_part = nblk_main;
+    vin.ld_part = a.sc_part + 2 * (size_t)nblk_main;
+    vin.n_ld_part = nblk_main;
     const T *sig = a.params + d;
     finalize_value_block<T, 256, false>(d, vin, a.out, 2 * (int64_t)d, [sig](int i) { return sig[i]; }, red);
   }
@@ -238,6 +267,7 @@ static void mf_main_impl(mivi_ctx *c, const void *params, const RngArgs &rng, in
   a.ticket = (unsigned int *)c->ticket.p;
   a.vin = vin;
   a.out = out;
+  a.dbg = c->dbg;
   dim3 grid(d4, n_cc);
   hipLaunchKernelGGL(k_mf_main<T>, grid, dim3(256), 0, c->stream, a);
   if (n_cc > 1) {

@@ -68,7 +68,7 @@ static mivi_status_t ensure_work(mivi_ctx *c, int M) {
     if ((s = ensure(c, c->he_part, (n_he + 64) * sizeof(double), false))) return s;
     const size_t ncc = (size_t)(capM / 256 + 2);
     if ((s = ensure(c, c->row_part, ncc * d4 * 8 * sizeof(double), false))) return s;
-    if ((s = ensure(c, c->sc_part, 2 * ncc * d4 * sizeof(double) + 64, false))) return s;
+    if ((s = ensure(c, c->sc_part, 4 * ncc * d4 * sizeof(double) + 64, false))) return s;
     c->cap_M = capM;
   }
   return MIVI_OK;
@@ -669,6 +669,66 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, 
     }
   }
   return read_status(c);
+}
+
+mivi_status_t mivi_debug_timeline(mivi_ctx_t *c, void *buf) {
+  if (!c) return MIVI_ERR_BAD_ARG;
+  c->dbg = (long long *)buf;
+  invalidate_graph(c);
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *params, int32_t reps, double *ms_out) {
+  if (!c || !params || reps <= 0 || !ms_out || which < 0 || which > 4) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  const int M = c->cfg.n_mc;
+  char *o = (char *)c->tmp_out.p;
+  OutArgs out = final_out(c, o, o + 8);
+  RngArgs rng = rng_of(c, 0);
+  mivi_status_t s = run_estimate(c, params, rng, M, 1, out);   // warm + populate eps / W / partial buffers
+  if (s) return s;
+  out.M_local = M;
+  ValueIn vin{};
+  vin.ell_const = c->t_const;
+  const bool fr = c->cfg.family == MIVI_FULLRANK;
+  if (fr) {
+    vin.he_part = (const double *)c->he_part.p;
+    vin.n_he_part = eps_blocks(c, M);
+    vin.ell_part = (const double *)c->ell_part.p;
+    vin.n_ell_part = fr_sample_blocks(c, M);
+  }
+  if (which != 0) {
+    if (!fr && which != 2) return fail(c, MIVI_ERR_UNSUPPORTED, "mean-field has a single fused kernel (which = 2)");
+    if (which == 4 && c->target != TGT_DENSE_GAUSS) return fail(c, MIVI_ERR_UNSUPPORTED, "no dense target set");
+    if (which == 2 && c->target != TGT_DIAG_GAUSS && c->target != TGT_DENSE_GAUSS && fr)
+      return fail(c, MIVI_ERR_UNSUPPORTED, "stage timing needs a fused built-in target");
+  }
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  for (int r = 0; r < reps; ++r) {
+    switch (which) {
+      case 0: s = run_estimate(c, params, rng_of(c, (uint64_t)r + 1), M, 1, out); break;
+      case 1: launch_eps(c, rng, M); break;
+      case 2:
+        if (fr) launch_fr_sample(c, params, M, c->target, c->target == TGT_DENSE_GAUSS ? c->Z.p : nullptr);
+        else launch_mf_main(c, params, rng, M, 1, nullptr, vin, out);
+        break;
+      case 3: launch_fr_vjp(c, params, M, vin, out); break;
+      default: launch_fr_dense_target(c, M, 1); break;
+    }
+    if (s) break;
+  }
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (s) return s;
+  *ms_out = (double)ms / reps;
+  return MIVI_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -42,6 +42,8 @@ struct ValueIn {
   int n_ell;
   const double *he_part;   // partial sums of sum_m 0.5|eps_m|^2
   int n_he_part;
+  const double *ld_part;   // [2][n_ld_part]: partial sums of log C_ii, then counts of non-positive C_ii (or nullptr)
+  int n_ld_part;
   double ell_const;        // constant added per sample (target normaliser)
 };
 
@@ -78,6 +80,7 @@ struct MfArgs {
   unsigned int *ticket;
   ValueIn vin;
   OutArgs out;
+  long long *dbg;      // optional timeline: dbg[block*8 + k] = wall_clock64() stamps (nullptr = off)
 };
 
 template <typename T>
@@ -109,6 +112,7 @@ struct FrArgs {
   double *ell_part;    // written by sample/target kernels
   ValueIn vin;
   OutArgs out;
+  long long *dbg;      // optional timeline (nullptr = off)
 };
 
 template <typename T>
@@ -175,6 +179,7 @@ struct mivi_ctx {
   int cap_M = 0;
   mivi::DevBuf eps, epsT, Z, W, RT, ell, X;
   mivi::DevBuf ell_part, he_part, row_part, sc_part, ticket, status, d_idx, acc, tmp_params, tmp_out;
+  long long *dbg = nullptr;   // timeline buffer supplied through mivi_debug_timeline (tools only)
   int dP = 0, MP = 0;
 
   mivi::GraphCache graph;

@@ -1,0 +1,116 @@
+# MIVI.jl -- Julia-side glue that makes libmivi a drop-in for AdvancedVI.jl's RepGradELBO hot path.
+#
+# UNTESTED IN THIS REPOSITORY'S CI: the build image has no Julia toolchain (SURVEY.md fact 2).  The same
+# C ABI is exercised end-to-end from Python (advancedvi.jl_amd/*.py + tests/); this file is the binding a
+# maintainer would add on the reference side, see INTEGRATION.md.
+#
+# Seam (SURVEY.md 8b): `KLMinRepGradDescent`'s objective type is bounded to RepGradELBO, so the plug point is
+# the `adtype` argument: `AutoMIVI()` selects more specific methods of `AdvancedVI.init` and
+# `AdvancedVI.estimate_gradient!` (src/algorithms/repgradelbo.jl:41-70, 151-177) that call libmivi instead of
+# preparing / running an AD backend.  `optimize`, `step`, ClipScale, Optimisers rules stay untouched.
+module MIVI
+
+using AdvancedVI, ADTypes, DiffResults, LogDensityProblems, Optimisers, Random, LinearAlgebra
+using AdvancedVI: MvLocationScale, RepGradELBO, ClosedFormEntropy, ClosedFormEntropyZeroGradient,
+                  MonteCarloEntropy, StickingTheLandingEntropy, StickingTheLandingEntropyZeroGradient
+
+const libmivi = get(ENV, "LIBMIVI", "libmivi.so")
+
+struct AutoMIVI <: ADTypes.AbstractADType
+    device::Int32
+end
+AutoMIVI() = AutoMIVI(0)
+
+# mivi_config_t (include/mivi.h)
+struct MiviConfig
+    dtype::Int32; family::Int32; d::Int32; n_mc::Int32; entropy::Int32; device::Int32
+    seed::UInt64; m_offset::Int32; m_total::Int32; stream::Ptr{Cvoid}; own_stream::Int32; reserved::Int32
+end
+
+entropy_code(::ClosedFormEntropy) = Int32(0)
+entropy_code(::ClosedFormEntropyZeroGradient) = Int32(1)
+entropy_code(::MonteCarloEntropy) = Int32(2)
+entropy_code(::StickingTheLandingEntropy) = Int32(3)
+entropy_code(::StickingTheLandingEntropyZeroGradient) = Int32(4)
+dtype_code(::Type{Float32}) = Int32(0)
+dtype_code(::Type{Float64}) = Int32(1)
+family_code(::MvLocationScale{<:Diagonal}) = Int32(0)
+family_code(::MvLocationScale) = Int32(1)
+
+mutable struct MIVIState{P}
+    problem::P
+    ctx::Ptr{Cvoid}
+    estimate_idx::UInt64         # replaces the hidden position of `rng`
+    cb::Any                      # keeps the @cfunction closure alive
+end
+
+function check(ctx, status)
+    status == 0 && return nothing
+    msg = unsafe_string(ccall((:mivi_last_error, libmivi), Cstring, (Ptr{Cvoid},), ctx))
+    status == 3 && throw(DomainError(msg))                       # non-positive scale diagonal (what `logdet` throws)
+    throw(ErrorException("libmivi status $status: $msg"))
+end
+
+# Batched LogDensityProblems.logdensity_and_gradient over the columns of Z: the generic plugin route
+# (src/mixedad_logdensity.jl:23-34 seam).  Built-in targets would instead call mivi_set_target_*.
+function target_callback(user::Ptr{Cvoid}, Zp::Ptr{Cvoid}, d::Int32, M::Int32, ellp::Ptr{Cvoid}, Gp::Ptr{Cvoid})::Int32
+    st = unsafe_pointer_to_objref(user)::MIVIState
+    T = st.T
+    Z = unsafe_wrap(Array, Ptr{T}(Zp), (Int(d), Int(M)))
+    ell = unsafe_wrap(Array, Ptr{T}(ellp), (Int(M),))
+    G = unsafe_wrap(Array, Ptr{T}(Gp), (Int(d), Int(M)))
+    try
+        for m in 1:M
+            l, g = LogDensityProblems.logdensity_and_gradient(st.problem, view(Z, :, m))
+            ell[m] = l
+            G[:, m] .= g
+        end
+        return Int32(0)
+    catch
+        return Int32(1)
+    end
+end
+
+function AdvancedVI.init(rng::Random.AbstractRNG, obj::RepGradELBO, ad::AutoMIVI, q::MvLocationScale, prob, params, restructure)
+    T = eltype(params)
+    cfg = Ref(MiviConfig(dtype_code(T), family_code(q), length(q), obj.n_samples, entropy_code(obj.entropy),
+                         ad.device, rand(rng, UInt64), 0, 0, C_NULL, 1, 0))
+    ctx = Ref{Ptr{Cvoid}}(C_NULL)
+    status = ccall((:mivi_create, libmivi), Int32, (Ref{MiviConfig}, Ref{Ptr{Cvoid}}), cfg, ctx)
+    status == 0 || error("mivi_create failed with status $status (no HIP device?)")
+    st = MIVIState(prob, ctx[], UInt64(0), nothing)
+    cb = @cfunction(target_callback, Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}))
+    st.cb = cb
+    check(st.ctx, ccall((:mivi_set_target_callback, libmivi), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Any), st.ctx, cb, C_NULL, st))
+    finalizer(s -> ccall((:mivi_destroy, libmivi), Int32, (Ptr{Cvoid},), s.ctx), st)
+    return st
+end
+
+function AdvancedVI.estimate_gradient!(rng::Random.AbstractRNG, obj::RepGradELBO, ::AutoMIVI,
+                                       out::DiffResults.MutableDiffResult, state::MIVIState, params, restructure, args...)
+    T = eltype(params)
+    value = Ref{T}(zero(T))
+    grad = DiffResults.gradient(out)
+    status = ccall((:mivi_estimate_gradient_host, libmivi), Int32,
+                   (Ptr{Cvoid}, Ptr{T}, UInt64, Ref{T}, Ptr{T}), state.ctx, params, state.estimate_idx, value, grad)
+    state.estimate_idx += 1
+    # status 2 (non-finite) is NOT thrown here: `step` raises the reference's own ErrorException
+    # from `!isfinite(DiffResults.value(grad_buf))` (src/algorithms/common.jl:83-89)
+    status == 2 || check(state.ctx, status)
+    DiffResults.value!(out, value[])
+    return out, state, (elbo = -value[],)
+end
+
+function AdvancedVI.estimate_objective(rng::Random.AbstractRNG, obj::RepGradELBO, q::MvLocationScale, prob, ad::AutoMIVI;
+                                       n_samples::Int = obj.n_samples)
+    params, re = Optimisers.destructure(q)
+    st = AdvancedVI.init(rng, RepGradELBO(min(n_samples, 16384); entropy = obj.entropy), ad, q, prob, params, re)
+    T = eltype(params)
+    value = Ref{T}(zero(T))
+    check(st.ctx, ccall((:mivi_estimate_objective_host, libmivi), Int32, (Ptr{Cvoid}, Ptr{T}, UInt64, Int32, Int32, Ref{T}),
+                        st.ctx, params, UInt64(0), n_samples, entropy_code(obj.entropy), value))
+    return value[]
+end
+
+export AutoMIVI
+end # module

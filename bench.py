@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""bench.py -- ELBO-gradient estimates / second of the RepGradELBO hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
+torch.distributed.run with one rank per GPU.  A *step* is one full `estimate_gradient!` (objective value
++ complete gradient vector) over one synthetic batch with every input resident in HBM.  W untimed warm-up
+steps, then exactly K timed steps bracketed by barrier + synchronize, max over ranks, ONE JSON line on rank 0.
+
+Workloads (BASELINE.json `configs` / north star):
+  ns  (default) north-star: d=1024 full-rank Gaussian family, n_mc=256 per GPU, target MvNormal(5*1, I)
+                (the reference's own bench target, bench/benchmarks.jl:43-47), ClosedFormEntropy, f32
+  c2            BASELINE configs[1]: d=1024 mean-field, n_mc=256, same target, f32
+  ns_dense      north-star family with the dense-Gaussian target N(m, L L') of SURVEY.md 8d
+N > 1: weak scaling -- every rank draws its own n_mc-sample shard of ONE estimate of n_mc*N samples
+(shard-invariant Philox stream), one RCCL all-reduce on the gradient partials, finalize on every rank;
+`value` counts n_mc-sample estimate units processed by all ranks per second.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SEED = 0x38BEF07CF9CC549D
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
+PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA peak (155 TF measured)
+
+WORKLOADS = {
+    "ns": dict(family=1, d=1024, n_mc=256, target="iso", entropy=0,
+               name="north-star: d=1024 full-rank Gaussian family, n_mc=256, target MvNormal(5*1, I), ClosedFormEntropy"),
+    "c2": dict(family=0, d=1024, n_mc=256, target="iso", entropy=0,
+               name="configs[1]: d=1024 mean-field MvLocationScale, n_mc=256, target MvNormal(5*1, I), ClosedFormEntropy"),
+    "ns_dense": dict(family=1, d=1024, n_mc=256, target="dense", entropy=0,
+                     name="north-star family, dense-Gaussian target N(5*1, L L'), L = tril(I + 11'/(2d))"),
+    "ns_stl": dict(family=1, d=1024, n_mc=256, target="iso", entropy=3,
+                   name="north-star family, StickingTheLandingEntropy (adds the C^-T eps solve)"),
+}
+
+
+def algorithmic_cost(w):
+    """SURVEY.md 8(d) per-estimate figures (s = 4 bytes): bytes and flops of one estimate."""
+    d, M, s = w["d"], w["n_mc"], 4
+    if w["family"] == 0:
+        return dict(bytes=4 * d * M * s + 4 * d * s, flops=6 * d * M)
+    return dict(bytes=(d * (d + 1) // 2) * s + d * d * s + 4 * d * M * s + 2 * d * s, flops=2 * d * d * M)
+
+
+def make_problem(avi, w):
+    d = w["d"]
+    q = (avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32)) if w["family"] == 0
+         else avi.FullRankGaussian(np.zeros(d, np.float32), np.eye(d, dtype=np.float32)))
+    if w["target"] == "iso":
+        prob = avi.DiagNormalProblem(np.full(d, 5.0, np.float32), np.ones(d, np.float32))
+    else:
+        L = np.tril(np.eye(d) + np.ones((d, d)) / (2.0 * d)).astype(np.float32)
+        prob = avi.DenseNormalProblem(np.full(d, 5.0, np.float32), L)
+    return q, prob
+
+
+def cpu_baseline(w, params, budget_s=15.0):
+    """The oracle's C leg (oracle/mivi_oracle.c: a port of the reference semantics with the closed-form VJP,
+    cheaper than the reference's AD path) timed on this box's host cores on a bounded sample."""
+    from oracle import c_oracle as CO
+    if not os.path.exists(CO.PATH):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    lib = CO.load()
+    d, M, fam = w["d"], w["n_mc"], w["family"]
+    cores = os.cpu_count() or 1
+    lib.mo32_set_threads(cores)
+    tm, ts = np.full(d, 5.0, np.float32), np.ones(d, np.float32)
+    work = np.empty(2 * d * M, dtype=np.float32)
+    eps = CO.fill_eps(lib, np.float32, SEED, 0, d, M)
+    t0 = time.perf_counter()
+    CO.estimate_gradient(lib, np.float32, fam, d, M, params, eps, tm, ts, w["entropy"], work)
+    t1 = time.perf_counter() - t0
+    n = int(min(400, max(3, budget_s / max(t1, 1e-4))))
+    t0 = time.perf_counter()
+    for i in range(n):
+        eps = CO.fill_eps(lib, np.float32, SEED, i + 1, d, M)
+        CO.estimate_gradient(lib, np.float32, fam, d, M, params, eps, tm, ts, w["entropy"], work)
+    dt = time.perf_counter() - t0
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=n / dt, unit="ELBO-grad-estimates/s", cores=cores, kind="port",
+                sample=f"{n} estimates of the same (d={d}, n_mc={M}) workload incl. eps generation, f32, OpenMP {cores} threads"
+                       f" on '{model}', {dt:.1f} s", threads=lib.mo32_max_threads())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
+    ap.add_argument("--graph-chunk", type=int, default=100, help="estimates per hipGraph replay (N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import advancedvi_jl_amd as avi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: libmivi has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    w = WORKLOADS[args.workload]
+    q, prob = make_problem(avi, w)
+    params_h, _ = avi.destructure(q)
+    K, W = args.steps, args.warmup
+    stream = torch.cuda.Stream(device=local_rank)
+    ent = [avi.ClosedFormEntropy(), avi.ClosedFormEntropyZeroGradient(), avi.MonteCarloEntropy(),
+           avi.StickingTheLandingEntropy(), avi.StickingTheLandingEntropyZeroGradient()][w["entropy"]]
+
+    with torch.cuda.stream(stream):
+        if world == 1:
+            ctx = avi.MiviContext(np.float32, w["family"], w["d"], w["n_mc"], ent.code, SEED, device=local_rank)
+            ctx.set_problem(prob)
+            params = ctx.to_device(params_h)
+            value, grad = ctx.empty(1), ctx.empty(ctx.params_len)
+            chunk = max(1, min(args.graph_chunk, K))
+
+            def run(idx0, n):
+                done = 0
+                while done + chunk <= n:
+                    ctx.estimate_gradient_n(params, idx0 + done, chunk, value, grad)
+                    done += chunk
+                for i in range(done, n):
+                    ctx.estimate_gradient(params, idx0 + i, value, grad)
+        else:
+            drv = avi.distributed.DistributedRepGradELBO(q, prob, w["n_mc"] * world, ent, SEED, device=local_rank)
+            ctx = drv.ctx
+            params = ctx.to_device(params_h)
+
+            def run(idx0, n):
+                for i in range(n):
+                    drv.estimate_gradient(params, idx0 + i)
+            value, grad = drv.value, drv.grad
+
+        run(0, W)
+        stream.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(W, K)
+        stream.synchronize()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+
+        out = None
+        if rank == 0:
+            cost = algorithmic_cost(w)
+            est_per_s = K * world / dt
+            # ---- roofline leg: hipEvent-timed launches of the dominant kernel on the launch stream ----------
+            roof = None
+            stages = {}
+            if world == 1:
+                reps = 300
+                if w["family"] == 0:
+                    ms = ctx.profile_kernel(2, params, reps)
+                    stages = {"mf_fused_main": ms}
+                    ach = cost["bytes"] / (ms * 1e-3) / 1e9
+                    roof = dict(bound="hbm", kernel="k_mf_main<float>", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
+                                frac=ach / PEAK_HBM_GBS, traffic=None, algorithmic_bytes_per_launch=cost["bytes"],
+                                avg_launch_us=ms * 1e3)
+                else:
+                    stages = {"eps": ctx.profile_kernel(1, params, reps), "sample": ctx.profile_kernel(2, params, reps),
+                              "vjp": ctx.profile_kernel(3, params, reps)}
+                    if w["target"] == "dense":
+                        stages["dense_target"] = ctx.profile_kernel(4, params, reps)
+                    # both contractions carry d^2*M algorithmic flops (lower triangle only); report the slower one
+                    dom = "vjp" if stages["vjp"] >= stages["sample"] else "sample"
+                    kname = {"vjp": "k_fr_tile_mfma<MODE_VJP,4>", "sample": "k_fr_tile_mfma<MODE_SAMPLE,8>"}[dom]
+                    fl = cost["flops"] / 2
+                    ach = fl / (stages[dom] * 1e-3) / 1e12
+                    roof = dict(bound="mfma", kernel=kname, achieved=ach, peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
+                                frac=ach / PEAK_F32_MFMA_TF, traffic=None, algorithmic_flops_per_launch=fl,
+                                avg_launch_us=stages[dom] * 1e3)
+                stages = {k: round(v * 1e3, 3) for k, v in stages.items()}   # us
+            whole = dict(hbm_equiv_GBs=cost["bytes"] * est_per_s / world / 1e9,
+                         hbm_equiv_frac_of_8TBs=cost["bytes"] * est_per_s / world / 1e9 / PEAK_HBM_GBS,
+                         f32_mfma_TFs=cost["flops"] * est_per_s / world / 1e12 if w["family"] == 1 else None)
+            # ---- parity + cpu_baseline leg (rank 0, N = 1 only) ---------------------------------------------
+            rel = None
+            cpub = None
+            if world == 1 and not args.no_cpu_baseline:
+                from oracle import c_oracle as CO
+                if w["target"] == "iso":
+                    cpub = cpu_baseline(w, params_h)
+                    lib = CO.load()
+                    _, eps = ctx.sample(params, 7)
+                    v, _ = ctx.estimate_gradient(params, 7)
+                    vref, _ = CO.estimate_gradient(lib, np.float64, w["family"], w["d"], w["n_mc"], params_h,
+                                                   eps.cpu().numpy().astype(np.float64), np.full(w["d"], 5.0), np.ones(w["d"]),
+                                                   w["entropy"])
+                    rel = abs(float(v.item()) - vref) / abs(vref)
+            out = {
+                "metric": "ELBO-grad-estimates/sec", "value": est_per_s, "unit": "estimates/s",
+                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic",
+                "config": {"workload": w["name"], "d": w["d"], "n_mc_per_gpu": w["n_mc"], "n_mc_total": w["n_mc"] * world,
+                           "family": "fullrank" if w["family"] else "meanfield", "seed": hex(SEED),
+                           "launch": f"hipGraph x{chunk}" if world == 1 else "eager + RCCL all-reduce"},
+                "roofline": roof, "cpu_baseline": cpub,
+                "elbo_rel_err_vs_cpu_fp64": rel, "stage_us": stages, "whole_estimate": whole,
+            }
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -183,6 +183,18 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *ctx, void *params_dev, void *opt_s
                                   int64_t t0, int32_t n_steps, int32_t rule, double eta, double clip_epsilon,
                                   void *elbo_dev);
 
+/* ---- measurement hook (bench.py roofline leg) --------------------------------------------------------- *
+ * Times `reps` back-to-back launches of ONE stage of the estimate with hipEvents recorded on the context's
+ * stream (after one full warm estimate so every input buffer is populated).
+ *   which: 0 = whole estimate, 1 = eps generation, 2 = sample(+fused target) kernel (mean-field: the fused main kernel),
+ *          3 = VJP kernel, 4 = dense-target kernel.  ms_per_launch_host: double[1]. */
+mivi_status_t mivi_profile_kernel(mivi_ctx_t *ctx, int32_t which, const void *params_dev, int32_t reps,
+                                  double *ms_per_launch_host);
+
+/* Developer tool: when buf_dev != NULL every workgroup of the main kernels records wall_clock64() stamps
+ * (100 MHz) at buf_dev[block*8 + phase].  NULL switches it off.  Not part of the drop-in surface. */
+mivi_status_t mivi_debug_timeline(mivi_ctx_t *ctx, void *buf_dev);
+
 /* ---- host-side RNG restatement (no GPU needed; used by the parity tests) ------------------------- */
 void mivi_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 /* raw words of the eps stream for element (i, global m): out[count] for i = i0 .. i0+count-1 */

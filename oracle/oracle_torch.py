@@ -121,4 +121,4 @@ def value_and_gradient(params, d, family, prob, eps, ent_kind):
     e = torch.as_tensor(eps, dtype=torch.float64)
     val = forward(p, d, family, prob, e, ent_kind)
     (g,) = torch.autograd.grad(val, p)
-    return float(val), g.numpy()
+    return float(val.detach()), g.numpy()

@@ -1,0 +1,168 @@
+"""CPU-side checks of the boundary: the C-ABI library loads without a GPU and exports every symbol
+include/mivi.h declares; the host-side RNG restatement inside the library matches the numpy oracle
+bit-exactly; host-side mirror logic (families, constructors, error behaviour).  No GPU compute."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import advancedvi_jl_amd as avi
+from advancedvi_jl_amd import _lib
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "mivi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mivi_[a-z0-9_]+)\s*\(", src)) - {"mivi_logdensity_and_gradient_fn", "mivi_logdensity_fn"})
+
+
+def test_library_loads_and_exports_every_declared_symbol(lib):
+    names = header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"libmivi.so does not export {n}"
+        assert n in _lib.SIGNATURES, f"{n} is declared in mivi.h but not bound in _lib.SIGNATURES"
+    for n in _lib.SIGNATURES:
+        assert n in names, f"{n} is bound but not declared in include/mivi.h"
+    assert lib.mivi_version() == 1
+
+
+def test_config_struct_layout_matches_header():
+    # int32 x6, uint64, int32 x2, void*, int32 x2  (natural alignment)
+    assert C.sizeof(_lib.MiviConfig) == 56
+    assert _lib.MiviConfig.seed.offset == 24 and _lib.MiviConfig.stream.offset == 40
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmivi.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_no_gpu_means_error_not_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        avi.MiviContext(np.float32, avi.MEANFIELD, 4, 4, 0, 1)
+    cfg = _lib.MiviConfig(0, 0, 4, 4, 0, 0, 1, 0, 0, None, 0, 0)
+    h = C.c_void_p()
+    assert lib.mivi_create(C.byref(cfg), C.byref(h)) == _lib.ERR_HIP
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "advancedvi.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".jl")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f
+                assert "libmivi_oracle" not in txt and "mivi_oracle.c" not in txt, f
+
+
+def test_host_philox_matches_oracle_bit_exact(lib):
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        ctr = rng.integers(0, 2 ** 32, size=4, dtype=np.uint64).astype(np.uint32)
+        key = rng.integers(0, 2 ** 32, size=2, dtype=np.uint64).astype(np.uint32)
+        out = (C.c_uint32 * 4)()
+        lib.mivi_philox4x32_10((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+        assert list(out) == [int(x) for x in O.philox4x32_10(ctr, (int(key[0]), int(key[1])))]
+
+
+@pytest.mark.parametrize("d", [1, 4, 7, 37, 64])
+def test_host_eps_stream_matches_oracle(lib, d):
+    seed, idx, M = 0x38BEF07CF9CC549D, 12345678901, 9
+    ref_bits = O.philox_bits(seed, idx, d, 3, 3 + M)
+    for dtype, f64, tol in ((_lib.F32, False, 4e-6), (_lib.F64, True, 1e-14)):
+        ref = O.philox_normal(seed, idx, d, 3, 3 + M, f64=f64)
+        for m in range(M):
+            bits = (C.c_uint32 * d)()
+            lib.mivi_eps_bits_host(seed, idx, d, 3 + m, 0, d, bits)
+            assert np.array_equal(np.array(bits, dtype=np.uint32), ref_bits[:, m])
+            out = (C.c_double * d)()
+            lib.mivi_eps_host(seed, idx, d, 3 + m, 0, d, dtype, out)
+            assert np.max(np.abs(np.array(out) - ref[:, m])) < tol
+
+
+def test_family_constructors_and_destructure():
+    """test/families/location_scale.jl:146-155 on the host mirror."""
+    d = 5
+    for dt in (np.float32, np.float64):
+        q = avi.MeanFieldGaussian(np.zeros(d, dt), np.ones(d, dt))
+        p, re_ = avi.destructure(q)
+        assert p.shape == (2 * d,) and p.dtype == dt and q.eltype == dt and len(q) == d
+        q2 = re_(p)
+        assert np.array_equal(q2.location, q.location) and np.array_equal(q2.scale, q.scale)
+        L = np.tril(np.arange(1, d * d + 1, dtype=dt).reshape(d, d))
+        qf = avi.FullRankGaussian(np.arange(d, dtype=dt), L + np.triu(np.ones((d, d), dt), 1))
+        assert np.array_equal(qf.scale, L)   # LowerTriangular projection
+        pf, ref_ = avi.destructure(qf)
+        assert pf.shape == (d + d * d,) and np.array_equal(pf, O.destructure(O.MvLocationScale(qf.location, L)))
+        assert np.array_equal(ref_(pf).scale, L)
+    with pytest.raises(TypeError):
+        avi.MeanFieldGaussian(np.zeros(3), np.eye(3))
+    with pytest.raises(TypeError):
+        avi.MvLocationScale(np.zeros(3, dtype=np.int32), np.ones(3))
+    with pytest.raises(ValueError):
+        avi.MvLocationScale(np.zeros(3), np.ones(4))
+
+
+def test_objective_and_algorithm_constructors():
+    obj = avi.RepGradELBO(10)
+    assert isinstance(obj.entropy, avi.ClosedFormEntropy) and obj.n_samples == 10        # repgradelbo.jl:72-74
+    assert repr(avi.RepGradELBO(3, entropy=avi.StickingTheLandingEntropy())) == \
+        "RepGradELBO(entropy=StickingTheLandingEntropy(), n_samples=3)"
+    with pytest.raises(ValueError):
+        avi.RepGradELBO(0)
+    with pytest.raises(TypeError):
+        avi.RepGradELBO(3, entropy="closed")
+    alg = avi.KLMinRepGradDescent(avi.AutoMIVI())                                       # constructors.jl:58-66 defaults
+    assert alg.objective.n_samples == 1 and isinstance(alg.optimizer, avi.DoWG)
+    assert isinstance(alg.averager, avi.PolynomialAveraging) and isinstance(alg.operator, avi.IdentityOperator)
+    assert avi.ADVI is avi.KLMinRepGradDescent
+    with pytest.raises(TypeError):   # ZeroGradient estimators belong to KLMinRepGradProxDescent (constructors.jl:60)
+        avi.KLMinRepGradDescent(avi.AutoMIVI(), entropy=avi.ClosedFormEntropyZeroGradient())
+    codes = [e.code for e in (avi.ClosedFormEntropy(), avi.ClosedFormEntropyZeroGradient(), avi.MonteCarloEntropy(),
+                              avi.StickingTheLandingEntropy(), avi.StickingTheLandingEntropyZeroGradient())]
+    assert codes == [O.ENT_CLOSED_FORM, O.ENT_CLOSED_FORM_ZERO_GRAD, O.ENT_MONTE_CARLO, O.ENT_STL, O.ENT_STL_ZERO_GRAD]
+
+
+def test_rng_counter_semantics():
+    r = avi.PhiloxRNG(5)
+    assert [r.next_index() for _ in range(3)] == [0, 1, 2]
+    c = r.copy()
+    assert c.next_index() == 3 and r.next_index() == 3
+
+
+def test_order0_plugin_is_rejected():
+    class Order0:
+        def dimension(self):
+            return 2
+
+        def logdensity(self, z):
+            return 0.0
+
+    q = avi.MeanFieldGaussian(np.zeros(2), np.ones(2))
+    p, re_ = avi.destructure(q)
+    with pytest.raises(TypeError, match="LogDensityOrder"):
+        avi.init(avi.PhiloxRNG(1), avi.RepGradELBO(2), avi.AutoMIVI(), q, Order0(), p, re_)
+
+
+def test_shard_plan():
+    from advancedvi_jl_amd.distributed import ShardPlan, partials_len
+    for n, w in ((1024, 8), (10, 3), (7, 7), (512, 1)):
+        plan = ShardPlan(n, w)
+        ranges = [plan.range(r) for r in range(w)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(ranges[i][1] == ranges[i + 1][0] for i in range(w - 1))
+        assert max(plan.count(r) for r in range(w)) - min(plan.count(r) for r in range(w)) <= 1
+    with pytest.raises(ValueError):
+        ShardPlan(3, 4)
+    assert partials_len(4, 0) == 10 and partials_len(4, 1) == 22
