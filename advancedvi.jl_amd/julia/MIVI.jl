@@ -39,6 +39,7 @@ family_code(::MvLocationScale) = Int32(1)
 
 mutable struct MIVIState{P}
     problem::P
+    T::DataType                  # element type of params (Float32 / Float64)
     ctx::Ptr{Cvoid}
     estimate_idx::UInt64         # replaces the hidden position of `rng`
     cb::Any                      # keeps the @cfunction closure alive
@@ -78,7 +79,7 @@ function AdvancedVI.init(rng::Random.AbstractRNG, obj::RepGradELBO, ad::AutoMIVI
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     status = ccall((:mivi_create, libmivi), Int32, (Ref{MiviConfig}, Ref{Ptr{Cvoid}}), cfg, ctx)
     status == 0 || error("mivi_create failed with status $status (no HIP device?)")
-    st = MIVIState(prob, ctx[], UInt64(0), nothing)
+    st = MIVIState(prob, T, ctx[], UInt64(0), nothing)
     cb = @cfunction(target_callback, Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}))
     st.cb = cb
     check(st.ctx, ccall((:mivi_set_target_callback, libmivi), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Any), st.ctx, cb, C_NULL, st))
