@@ -41,7 +41,9 @@ __device__ __forceinline__ T block_sum(T v, T *red) {
   return s;
 }
 
-#define MIVI_STAMP(dbgp, slot) do { if ((dbgp) && threadIdx.x == 0) (dbgp)[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
+// timeline stamps: region `kind` (0 mean-field / sample, 1 vjp, 2 dense) x 4096 blocks x 8 slots
+#define MIVI_STAMP_K(dbgp, kind, slot) do { if ((dbgp) && threadIdx.x == 0 && blockIdx.x < 4096) (dbgp)[((size_t)(kind) * 4096 + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
+#define MIVI_STAMP(dbgp, slot) MIVI_STAMP_K(dbgp, 0, slot)
 
 __device__ __forceinline__ uint64_t rng_index(const RngArgs &r) {
   return r.idx_base + (r.idx_ptr ? *r.idx_ptr : 0ull);

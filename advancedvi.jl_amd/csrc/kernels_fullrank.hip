@@ -15,6 +15,8 @@
 //   * only lower-triangular tiles are computed for C eps (K <= i) and tril(W eps').
 // eps is generated once per estimate by k_eps in both layouts the contractions need:
 //   eps [i + m*dP] (column-major, the reference's layout)  and  epsT[m + k*MP].
+#include <algorithm>
+
 #include "device_common.h"
 
 namespace mivi {
@@ -24,51 +26,54 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum { MODE_SAMPLE = 0, MODE_VJP = 1, MODE_DENSE = 2 };
 
 // ---------------------------------------------------------------------------------------------
-// K0: eps generation (Philox4x32-10 + Box-Muller), both layouts, + sum 0.5 eps^2 partials
-// block = 256 threads = 64 columns x 4 row-quads, loops 4x over row-quads => 64x64 tile
+// eps generation (Philox4x32-10 + Box-Muller), both layouts, + sum 0.5 eps^2 partials.
+// One 256-thread workgroup = 64 columns x 16 rows (one Philox block per thread).  Runs either as the
+// standalone kernel k_eps or as extra workgroups inside the VJP kernel of the PREVIOUS estimate
+// (VALU work under the MFMA waves; eps depends only on the estimate index).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void k_eps(SampleArgs<T> a) {
-  __shared__ T tile[64][65];
-  __shared__ double red[4];
+__device__ void eps_tile_block(const SampleArgs<T> &a, int tile, T (*lds)[17], double *red) {
   const int d = a.d, d4 = (d + 3) >> 2;
   const int tid = threadIdx.x;
-  const int i0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+  const int nrt = (d + 15) >> 4;
+  const int i0 = (tile % nrt) * 16, m0 = (tile / nrt) * 64;
   const int ml = tid & 63, rql = tid >> 6;
-  const int m = m0 + ml;
+  const int m = m0 + ml, rq = (i0 >> 2) + rql;
   const uint64_t idx = rng_index(a.rng);
+  T e[4] = {0, 0, 0, 0};
+  if (m < a.M && rq < d4)
+    eps_block<T>(a.rng.seed, idx, (uint64_t)(a.rng.m_offset + m) * (uint64_t)d4 + (uint64_t)rq, e);
   T he = 0;
 #pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int rq_local = it * 4 + rql;          // 0..15
-    const int rq = (i0 >> 2) + rq_local;
-    T e[4] = {0, 0, 0, 0};
-    if (m < a.M && rq < d4)
-      eps_block<T>(a.rng.seed, idx, (uint64_t)(a.rng.m_offset + m) * (uint64_t)d4 + (uint64_t)rq, e);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = 4 * rq + r;
-      const bool ok = (m < a.M) && (i < d);
-      const T v = ok ? e[r] : T(0);
-      he += T(0.5) * v * v;
-      tile[ml][rq_local * 4 + r] = v;
-      if (a.epsT && ok) a.epsT[(size_t)i * a.ld_epsT + m] = v;   // lanes along m: coalesced
-    }
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * rq + r;
+    const bool ok = (m < a.M) && (i < d);
+    const T v = ok ? e[r] : T(0);
+    he += T(0.5) * v * v;
+    lds[ml][rql * 4 + r] = v;
+    if (a.epsT && ok) a.epsT[(size_t)i * a.ld_epsT + m] = v;   // lanes along m: coalesced
   }
   __syncthreads();
   if (a.eps) {
-    const int row = tid & 63;
+    const int row = tid & 15;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int col = (tid >> 6) + 4 * j;
+    for (int j = 0; j < 4; ++j) {
+      const int col = (tid >> 4) + 16 * j;
       const int i = i0 + row, mm = m0 + col;
-      if (i < d && mm < a.M) a.eps[(size_t)mm * a.ld_eps + i] = tile[col][row];  // lanes along i: coalesced
+      if (i < d && mm < a.M) a.eps[(size_t)mm * a.ld_eps + i] = lds[col][row];  // 64-byte row segments
     }
   }
   if (a.he_part) {
     const double s = block_sum<double, 256>((double)he, red);
-    if (tid == 0) a.he_part[blockIdx.y * gridDim.x + blockIdx.x] = s;
+    if (tid == 0) a.he_part[tile] = s;
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_eps(SampleArgs<T> a) {
+  __shared__ T lds[64][17];
+  __shared__ double red[4];
+  eps_tile_block<T>(a, blockIdx.x, lds, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -102,7 +107,7 @@ __device__ __forceinline__ void tile_coords(const int d, const int M, int &ib, i
 // (only meaningful for diagonal VJP tiles).  NT threads, all participate.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int MODE, int NT, typename Get>
-__device__ void tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *rs_lds, double *red) {
+__device__ double tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *rs_lds, double *red) {
   const int tid = threadIdx.x;
   const int d = a.d, M = a.M;
   const int i0 = ib * 32, n0 = cb * 32;
@@ -136,10 +141,6 @@ __device__ void tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *rs
         if (gi2 < d && gm < M) a.RT[(size_t)gi2 * a.MP + gm] = a.params[gi2] + get(r2, col) - a.t_mean[gi2];
       }
     }
-    if (a.fused_target == TGT_DIAG_GAUSS) {
-      const double s = block_sum<double, NT>((double)ell, red);
-      if (tid == 0) a.ell_part[blockIdx.x] = s;
-    }
   } else if (MODE == MODE_DENSE) {
     // G = -P (Z - m);  ell_m = 0.5 * sum_i (z-m)_i G_im + const
     const int gi = i0 + row;
@@ -154,8 +155,6 @@ __device__ void tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *rs
         a.W[(size_t)gm * d + gi] = g;
       }
     }
-    const double s = block_sum<double, NT>((double)ell, red);
-    if (tid == 0) a.ell_part[blockIdx.x] = s;
   } else {  // MODE_VJP: tile (ib, jb = cb) of tril(W eps^T)
     const int jb = cb;
     const int gi = i0 + row;
@@ -185,72 +184,69 @@ __device__ void tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *rs
         if (ui < d && uj < d) dst[d + (size_t)uj * d + ui] = T(0);
       }
     }
-    if (jb == ib) {  // row sums of W over all samples -> d/dmu
-      __syncthreads();
+    if (jb == ib) {  // row sums of W over all samples -> d/dmu; log-determinant partial of this diagonal block
       if (tid < 32) {
         double s = 0.0;
 #pragma unroll
         for (int g = 0; g < CG; ++g) s += (double)rs_lds[tid + 32 * g];
         const int gr = i0 + tid;
         if (gr < d) dst[gr] = a.out.partials_mode ? (T)s : (T)(-s * invM);
+        double lg = 0.0, bad = 0.0;
+        if (gr < d) {
+          const T cii = a.params[d + (size_t)gr * d + gr];
+          lg = (double)log(cii);
+          bad = (cii > T(0)) ? 0.0 : 1.0;
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          lg += __shfl_xor(lg, o, 64);
+          bad += __shfl_xor(bad, o, 64);
+        }
+        if (tid == 0 && a.ld_part) {
+          const int nbk = (d + 31) >> 5;
+          a.ld_part[ib] = lg;
+          a.ld_part[nbk + ib] = bad;
+        }
       }
     }
-    if (blockIdx.x == 0) {
-      const T *p = a.params;
-      const int dd = d;
-      finalize_value_block<T, NT, false>(d, a.vin, a.out, (int64_t)d + (int64_t)d * d,
-                                         [p, dd](int i) { return p[dd + (size_t)i * dd + i]; }, red);
-    }
   }
+  return (double)ell;
 }
 
 // ---------------------------------------------------------------------------------------------
-// MFMA tile kernel (float only): NW waves split K, v_mfma_f32_32x32x2_f32
+// MFMA tile kernel (float only): v_mfma_f32_32x32x2_f32, NW waves split the K range of the workgroup's
+// tile(s) in 32-k blocks; operands come straight from L2 through a double-buffered 32-k stage.
 //   A operand lane l: A[i = l&31][k slot = l>>5],  B operand: B[k slot = l>>5][n = l&31]
 //   D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+// Work descriptors come from a host-built table (one int2 per workgroup) so that the block -> tile map
+// can be XCD-aware (observed dispatch: block b -> XCD b % 8; a wrong guess costs speed only):
+//   MODE_SAMPLE : .x = pair index p, .y = column block; the workgroup owns row-blocks p and nb-1-p
+//                 (total K = 32(nb+1) for every pair => balanced), XCD x owns pairs p = x (mod 8)
+//   MODE_VJP    : .x = ib, .y = jb; XCDs own 8x8 super-blocks of the lower triangle
+//   MODE_DENSE  : .x = ib, .y = cb
+// Heterogeneous workgroups: blockIdx < a.n_pre run `eps(t+1)` tiles (VJP kernel); the workgroup after the
+// last tile assembles the objective value of the PREVIOUS estimate (sample kernel).
 // ---------------------------------------------------------------------------------------------
-template <int MODE, int NW>
-__global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
-  constexpr int NT = NW * 64;
-  __shared__ float red_acc[NW][16 * 65];
-  __shared__ float rs_lds[NT];
-  __shared__ double red[NW];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int l31 = lane & 31, h = lane >> 5;
+template <int MODE>
+__device__ __forceinline__ void run_kblocks(const FrArgs<float> &a, int ib, int cb, int kb_beg, int kb_end, f32x16 &acc,
+                                            float &rs) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   const int d = a.d, M = a.M;
-  int ib, cb, Ktile;
-  tile_coords<MODE>(d, M, ib, cb, Ktile);
-  const int i0 = ib * 32, n0 = cb * 32;
-
-  MIVI_STAMP(a.dbg, 0);
-  // K split: NW contiguous chunks, multiples of the 32-k pipeline stage
-  int chunk = (Ktile + NW - 1) / NW;
-  chunk = (chunk + 31) & ~31;
-  const int kbeg = w * chunk;
-  const int kend = min(kbeg + chunk, (Ktile + 31) & ~31);
-
-  const int gi = i0 + l31;
+  const int gi = ib * 32 + l31, n0 = cb * 32;
   const float *Abase;
   int lda, kmaxA;
   const float *Bbase;
   int ldb;
   if (MODE == MODE_SAMPLE) {
-    Abase = a.params + d;  lda = d;    kmaxA = d - 1;  Bbase = a.epsT + n0 + l31;  ldb = a.MP;
+    Abase = a.params + d;  lda = d;    kmaxA = d - 1;    Bbase = a.epsT + n0 + l31;  ldb = a.MP;
   } else if (MODE == MODE_VJP) {
-    Abase = a.W;           lda = d;    kmaxA = M - 1;  Bbase = a.eps + n0 + l31;   ldb = a.dP;
+    Abase = a.W;           lda = d;    kmaxA = M - 1;    Bbase = a.eps + n0 + l31;   ldb = a.dP;
   } else {
-    Abase = a.t_prec;      lda = a.dP; kmaxA = a.dP - 1; Bbase = a.RT + n0 + l31;  ldb = a.MP;
+    Abase = a.t_prec;      lda = a.dP; kmaxA = a.dP - 1; Bbase = a.RT + n0 + l31;   ldb = a.MP;
   }
   const bool row_ok = gi < d;
-  // every load is unconditional on a clamped (always valid) address; out-of-range operands are zeroed
-  // at use.  (A guarded `ok ? load : 0` makes hipcc wrap each load in its own exec-mask branch.)
+  // unconditional loads on clamped addresses; out-of-range operands are zeroed at use
   const float *Arow = Abase + (MODE == MODE_DENSE ? gi : min(gi, d - 1));
-
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float rs = 0.f;
-
   float a0[16], b0[16], a1[16], b1[16];
   auto load_stage = [&](int k, float (&av)[16], float (&bv)[16]) {
 #pragma unroll
@@ -273,9 +269,10 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_m, bv[u], acc, 0, 0, 0);
     }
   };
-  if (kbeg < kend) {
-    load_stage(kbeg, a0, b0);
-    int k = kbeg;
+  if (kb_beg < kb_end) {
+    int k = kb_beg * 32;
+    const int kend = kb_end * 32;
+    load_stage(k, a0, b0);
     while (true) {
       const bool more1 = (k + 32) < kend;
       if (more1) load_stage(k + 32, a1, b1);
@@ -289,25 +286,95 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
       k += 32;
     }
   }
+}
 
-  MIVI_STAMP(a.dbg, 1);
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
+  constexpr int NT = NW * 64;
+  constexpr int NSEG = (MODE == MODE_SAMPLE) ? 2 : 1;
+  __shared__ float red_acc[NSEG][NW][16 * 65];
+  __shared__ float rs_lds[NT];
+  __shared__ double red[NW];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int d = a.d, M = a.M;
+
+  // ---- heterogeneous workgroups -----------------------------------------------------------------
+  if (MODE == MODE_VJP && (int)blockIdx.x < a.n_pre) {   // eps(t+1) tile
+    float(*lds)[17] = reinterpret_cast<float(*)[17]>(&red_acc[0][0][0]);
+    eps_tile_block<float>(a.next_eps, blockIdx.x, lds, red);
+    return;
+  }
+  const int widx = (int)blockIdx.x - (MODE == MODE_VJP ? a.n_pre : 0);
+  if (MODE == MODE_SAMPLE && widx == a.n_work) {          // objective value of the previous estimate
+    const float *pp = a.params;
+    finalize_value_block<float, NT, false>(d, a.prev_vin, a.prev_out, (int64_t)d + (int64_t)d * d,
+                                           [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, red);
+    return;
+  }
+  MIVI_STAMP_K(a.dbg, MODE, 0);
+  const int2 wk = a.work_tab[widx];
+  if (wk.x < 0) {
+    if (tid == 0 && MODE != MODE_VJP) a.ell_part[widx] = 0.0;
+    return;
+  }
+
+  // ---- segments and the K split -----------------------------------------------------------------
+  const int nb = (d + 31) >> 5;
+  int seg_ib[2], seg_kb[2];
+  int cb = wk.y;
+  if (MODE == MODE_SAMPLE) {
+    seg_ib[0] = wk.x;
+    seg_ib[1] = nb - 1 - wk.x;
+    seg_kb[0] = min(nb, seg_ib[0] + 1);                    // K = min(d, 32(ib+1)) in 32-blocks
+    seg_kb[1] = (seg_ib[1] > seg_ib[0]) ? min(nb, seg_ib[1] + 1) : 0;
+  } else {
+    seg_ib[0] = wk.x;
+    seg_ib[1] = -1;
+    seg_kb[0] = (MODE == MODE_VJP) ? ((M + 31) >> 5) : nb;
+    seg_kb[1] = 0;
+  }
+  const int U = seg_kb[0] + seg_kb[1];
+  const int u0 = (w * U) / NW, u1 = ((w + 1) * U) / NW;
+
+  f32x16 acc0, acc1;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red_acc[w][r * 65 + lane] = acc[r];
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  float rs = 0.f, rs_dummy = 0.f;
+  run_kblocks<MODE>(a, seg_ib[0], cb, min(u0, seg_kb[0]), min(u1, seg_kb[0]), acc0, rs);
+  if (NSEG == 2 && seg_kb[1] > 0)
+    run_kblocks<MODE>(a, seg_ib[1], cb, max(u0, seg_kb[0]) - seg_kb[0], max(u1, seg_kb[0]) - seg_kb[0], acc1, rs_dummy);
+  MIVI_STAMP_K(a.dbg, MODE, 1);
+
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red_acc[0][w][r * 65 + lane] = acc0[r];
+  if (NSEG == 2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red_acc[NSEG - 1][w][r * 65 + lane] = acc1[r];
+  }
   rs_lds[tid] = rs;
   __syncthreads();
-  MIVI_STAMP(a.dbg, 2);
+  MIVI_STAMP_K(a.dbg, MODE, 2);
 
-  auto get = [&](int row, int col) -> float {
-    const int r = (row & 3) + 4 * (row >> 3);
-    const int hh = (row >> 2) & 1;
-    const int off = r * 65 + col + 32 * hh;
-    float s = red_acc[0][off];
+  double ell_acc = 0.0;
 #pragma unroll
-    for (int ww = 1; ww < NW; ++ww) s += red_acc[ww][off];
-    return s;
-  };
-  tile_epilogue<float, MODE, NT>(a, ib, cb, get, rs_lds, red);
-  MIVI_STAMP(a.dbg, 3);
+  for (int sg = 0; sg < NSEG; ++sg) {
+    if (sg == 1 && seg_kb[1] == 0) break;
+    auto get = [&](int row, int col) -> float {
+      const int r = (row & 3) + 4 * (row >> 3);
+      const int hh = (row >> 2) & 1;
+      const int off = r * 65 + col + 32 * hh;
+      float s = red_acc[sg][0][off];
+#pragma unroll
+      for (int ww = 1; ww < NW; ++ww) s += red_acc[sg][ww][off];
+      return s;
+    };
+    ell_acc += tile_epilogue<float, MODE, NT>(a, seg_ib[sg], cb, get, rs_lds, red);
+  }
+  if (MODE != MODE_VJP && (MODE == MODE_DENSE || a.fused_target == TGT_DIAG_GAUSS)) {
+    const double s = block_sum<double, NT>(ell_acc, red);
+    if (tid == 0) a.ell_part[widx] = s;
+  }
+  MIVI_STAMP_K(a.dbg, MODE, 3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -364,7 +431,11 @@ __global__ __launch_bounds__(256) void k_fr_tile_generic(FrArgs<T> a) {
   rs_lds[tid] = rs;
   __syncthreads();
   auto get = [&](int r, int c) -> T { return outt[c][r]; };
-  tile_epilogue<T, MODE, NT>(a, ib, cb, get, rs_lds, red);
+  const double ell = tile_epilogue<T, MODE, NT>(a, ib, cb, get, rs_lds, red);
+  if (MODE != MODE_VJP && (MODE == MODE_DENSE || a.fused_target == TGT_DIAG_GAUSS)) {
+    const double s2 = block_sum<double, NT>(ell, red);
+    if (tid == 0) a.ell_part[blockIdx.x] = s2;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -453,30 +524,117 @@ __global__ __launch_bounds__(256) void k_rt_from_z(int d, int M, int MP, const T
 }
 
 // ---------------------------------------------------------------------------------------------
-// Host-side launchers
+// Host side: work tables (XCD-aware block -> tile maps) and launchers
 // ---------------------------------------------------------------------------------------------
-int eps_blocks(const mivi_ctx *c, int M) { return ((c->cfg.d + 63) / 64) * ((M + 63) / 64); }
-int fr_sample_blocks(const mivi_ctx *c, int M) { return ((c->cfg.d + 31) / 32) * ((M + 31) / 32); }
-int fr_dense_blocks(const mivi_ctx *c, int M) { return fr_sample_blocks(c, M); }
+static void upload_tab(mivi_ctx *c, DevBuf &b, const std::vector<int2> &t) {
+  const size_t bytes = t.size() * sizeof(int2);
+  if (b.bytes < bytes) {
+    if (b.p) (void)hipFree(b.p);
+    (void)hipMalloc(&b.p, bytes);
+    b.bytes = bytes;
+  }
+  (void)hipMemcpy(b.p, t.data(), bytes, hipMemcpyHostToDevice);
+}
+
+static std::vector<int2> interleave_xcd(const std::vector<std::vector<int2>> &lists) {
+  size_t L = 0;
+  for (auto &l : lists) L = l.size() > L ? l.size() : L;
+  std::vector<int2> tab(8 * L, make_int2(-1, -1));
+  for (int x = 0; x < 8; ++x)
+    for (size_t s2 = 0; s2 < lists[x].size(); ++s2) tab[s2 * 8 + x] = lists[x][s2];
+  return tab;
+}
+
+// (re)build the tables for M samples per launch
+static void ensure_tabs(mivi_ctx *c, int M) {
+  if (c->tab_M == M && c->tabA.p) return;
+  const int d = c->cfg.d, nb = (d + 31) / 32, ncb = (M + 31) / 32;
+  {  // sample: pairs (p, nb-1-p), XCD x owns pairs p = x (mod 8), all column blocks
+    const int npairs = (nb + 1) / 2;
+    std::vector<std::vector<int2>> lists(8);
+    for (int pq = 0; pq < npairs; ++pq)
+      for (int cb = 0; cb < ncb; ++cb) lists[pq % 8].push_back(make_int2(pq, cb));
+    auto tab = interleave_xcd(lists);
+    c->nA = (int)tab.size();
+    upload_tab(c, c->tabA, tab);
+  }
+  {  // dense target: XCD x owns row-blocks ib = x (mod 8)
+    std::vector<std::vector<int2>> lists(8);
+    for (int ib = 0; ib < nb; ++ib)
+      for (int cb = 0; cb < ncb; ++cb) lists[ib % 8].push_back(make_int2(ib, cb));
+    auto tab = interleave_xcd(lists);
+    c->nD = (int)tab.size();
+    upload_tab(c, c->tabD, tab);
+  }
+  {  // vjp: 8x8 super-blocks of the lower triangle, longest-processing-time assignment to the 8 XCDs
+    std::vector<std::vector<int2>> lists(8);
+    if (nb >= 16) {
+      const int S = 8, ns = (nb + S - 1) / S;
+      std::vector<std::vector<int2>> sbs;
+      for (int sr = 0; sr < ns; ++sr)
+        for (int sc = 0; sc <= sr; ++sc) {
+          std::vector<int2> t;
+          for (int ib = sr * S; ib < (sr + 1) * S && ib < nb; ++ib)
+            for (int jb = sc * S; jb < (sc + 1) * S && jb <= ib; ++jb) t.push_back(make_int2(ib, jb));
+          if (!t.empty()) sbs.push_back(t);
+        }
+      std::sort(sbs.begin(), sbs.end(), [](const std::vector<int2> &u, const std::vector<int2> &v) { return u.size() > v.size(); });
+      for (auto &sb : sbs) {
+        int best = 0;
+        for (int x = 1; x < 8; ++x)
+          if (lists[x].size() < lists[best].size()) best = x;
+        lists[best].insert(lists[best].end(), sb.begin(), sb.end());
+      }
+    } else {
+      int t = 0;
+      for (int ib = 0; ib < nb; ++ib)
+        for (int jb = 0; jb <= ib; ++jb) lists[(t++) % 8].push_back(make_int2(ib, jb));
+    }
+    auto tab = interleave_xcd(lists);
+    c->nB = (int)tab.size();
+    upload_tab(c, c->tabB, tab);
+  }
+  c->tab_M = M;
+}
+
+void prepare_tables(mivi_ctx *c, int M) {
+  if (c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32) ensure_tabs(c, M);
+  if (c->cfg.family == MIVI_MEANFIELD && c->cfg.dtype == MIVI_F32 && c->target == TGT_DENSE_GAUSS) ensure_tabs(c, M);
+}
+
+int eps_blocks(const mivi_ctx *c, int M) { return ((c->cfg.d + 15) / 16) * ((M + 63) / 64); }
+int fr_sample_blocks(const mivi_ctx *c, int M) {
+  if (c->cfg.dtype == MIVI_F32) { ensure_tabs(const_cast<mivi_ctx *>(c), M); return c->nA; }
+  return ((c->cfg.d + 31) / 32) * ((M + 31) / 32);
+}
+int fr_dense_blocks(const mivi_ctx *c, int M) {
+  if (c->cfg.dtype == MIVI_F32) { ensure_tabs(const_cast<mivi_ctx *>(c), M); return c->nD; }
+  return ((c->cfg.d + 31) / 32) * ((M + 31) / 32);
+}
+int fr_ld_blocks(const mivi_ctx *c) { return (c->cfg.d + 31) / 32; }
 
 template <typename T>
-static void eps_impl(mivi_ctx *c, const RngArgs &rng, int M) {
+static SampleArgs<T> eps_args(mivi_ctx *c, const RngArgs &rng, int M, int parity) {
   SampleArgs<T> a;
   a.d = c->cfg.d;
   a.M = M;
   a.params = nullptr;
   a.rng = rng;
   a.Z = nullptr;
-  a.eps = (T *)c->eps.p;
+  a.eps = (T *)c->eps[parity].p;
   a.ld_eps = c->dP;
-  a.epsT = (T *)c->epsT.p;
+  a.epsT = (T *)c->epsT[parity].p;
   a.ld_epsT = c->MP;
-  a.he_part = (double *)c->he_part.p;
-  dim3 grid((a.d + 63) / 64, (M + 63) / 64);
-  hipLaunchKernelGGL(k_eps<T>, grid, dim3(256), 0, c->stream, a);
+  a.he_part = (double *)c->he_part[parity].p;
+  return a;
 }
+
 void launch_eps(mivi_ctx *c, const RngArgs &rng, int M) {
-  if (c->cfg.dtype == MIVI_F32) eps_impl<float>(c, rng, M); else eps_impl<double>(c, rng, M);
+  const int nblk = eps_blocks(c, M);
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_eps<float>, dim3(nblk), dim3(256), 0, c->stream, eps_args<float>(c, rng, M, c->cur));
+  else
+    hipLaunchKernelGGL(k_eps<double>, dim3(nblk), dim3(256), 0, c->stream, eps_args<double>(c, rng, M, c->cur));
 }
 
 template <typename T>
@@ -487,8 +645,8 @@ static FrArgs<T> fr_args(mivi_ctx *c, const void *params, int M) {
   a.dP = c->dP;
   a.MP = c->MP;
   a.params = (const T *)params;
-  a.eps = (const T *)c->eps.p;
-  a.epsT = (const T *)c->epsT.p;
+  a.eps = (const T *)c->eps[c->cur].p;
+  a.epsT = (const T *)c->epsT[c->cur].p;
   a.Z = (T *)c->Z.p;
   a.W = (T *)c->W.p;
   a.RT = (T *)c->RT.p;
@@ -496,25 +654,82 @@ static FrArgs<T> fr_args(mivi_ctx *c, const void *params, int M) {
   a.t_mean = (const T *)c->t_mean.p;
   a.t_istd = (const T *)c->t_istd.p;
   a.t_prec = (const T *)c->t_prec.p;
-  a.ell_part = (double *)c->ell_part.p;
+  a.ell_part = (double *)c->ell_part[c->cur].p;
+  a.ld_part = (double *)c->ld_part[c->cur].p;
   a.vin = ValueIn{};
   a.out = OutArgs{};
   a.dbg = c->dbg;
+  a.work_tab = nullptr;
+  a.n_work = 0;
+  a.n_pre = 0;
+  a.prev_vin = ValueIn{};
+  a.prev_out = OutArgs{};
+  a.next_eps = SampleArgs<T>{};
   return a;
 }
 
-void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, void *Z) {
-  const int nblk = fr_sample_blocks(c, M);
+// Z = mu + C eps (+ fused target).  prev != nullptr: one extra workgroup assembles the PREVIOUS estimate's value.
+void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, void *Z, const ValueJob *prev) {
   if (c->cfg.dtype == MIVI_F32) {
+    ensure_tabs(c, M);
     FrArgs<float> a = fr_args<float>(c, params, M);
     a.fused_target = fused_target;
     a.Z = (float *)Z;
-    hipLaunchKernelGGL((k_fr_tile_mfma<MODE_SAMPLE, 8>), dim3(nblk), dim3(512), 0, c->stream, a);
+    a.work_tab = (const int2 *)c->tabA.p;
+    a.n_work = c->nA;
+    int grid = c->nA;
+    if (prev) {
+      a.prev_vin = prev->vin;
+      a.prev_out = prev->out;
+      grid += 1;
+    } else {
+      a.n_work = 0x7fffffff;   // no value workgroup
+    }
+    hipLaunchKernelGGL((k_fr_tile_mfma<MODE_SAMPLE, 8>), dim3(grid), dim3(512), 0, c->stream, a);
   } else {
+    const int nblk = ((c->cfg.d + 31) / 32) * ((M + 31) / 32);
     FrArgs<double> a = fr_args<double>(c, params, M);
     a.fused_target = fused_target;
     a.Z = (double *)Z;
     hipLaunchKernelGGL((k_fr_tile_generic<double, MODE_SAMPLE>), dim3(nblk), dim3(256), 0, c->stream, a);
+  }
+}
+
+void launch_fr_dense_target(mivi_ctx *c, int M, int want_grad) {
+  (void)want_grad;
+  if (c->cfg.dtype == MIVI_F32) {
+    ensure_tabs(c, M);
+    FrArgs<float> a = fr_args<float>(c, nullptr, M);
+    a.work_tab = (const int2 *)c->tabD.p;
+    a.n_work = 0x7fffffff;
+    hipLaunchKernelGGL((k_fr_tile_mfma<MODE_DENSE, 8>), dim3(c->nD), dim3(512), 0, c->stream, a);
+  } else {
+    const int nblk = ((c->cfg.d + 31) / 32) * ((M + 31) / 32);
+    FrArgs<double> a = fr_args<double>(c, nullptr, M);
+    hipLaunchKernelGGL((k_fr_tile_generic<double, MODE_DENSE>), dim3(nblk), dim3(256), 0, c->stream, a);
+  }
+}
+
+// tril(W eps^T) (+ d/dmu, log-det partials).  next != nullptr: extra leading workgroups generate eps of the NEXT estimate.
+void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const EpsJob *next) {
+  if (c->cfg.dtype == MIVI_F32) {
+    ensure_tabs(c, M);
+    FrArgs<float> a = fr_args<float>(c, params, M);
+    a.out = out;
+    a.work_tab = (const int2 *)c->tabB.p;
+    a.n_work = 0x7fffffff;
+    int grid = c->nB;
+    if (next) {
+      a.n_pre = (eps_blocks(c, M) + 7) / 8 * 8;     // keep (blockIdx - n_pre) % 8 == blockIdx % 8
+      a.next_eps = eps_args<float>(c, next->rng, M, next->parity);
+      grid += a.n_pre;
+    }
+    hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 4>), dim3(grid), dim3(256), 0, c->stream, a);
+  } else {
+    const int nb = (c->cfg.d + 31) / 32;
+    FrArgs<double> a = fr_args<double>(c, params, M);
+    a.out = out;
+    hipLaunchKernelGGL((k_fr_tile_generic<double, MODE_VJP>), dim3(nb * (nb + 1) / 2), dim3(256), 0, c->stream, a);
   }
 }
 
@@ -528,43 +743,17 @@ void launch_rt_from_z(mivi_ctx *c, int M) {
                        (const double *)c->t_mean.p, (double *)c->RT.p);
 }
 
-void launch_fr_dense_target(mivi_ctx *c, int M, int want_grad) {
-  (void)want_grad;
-  const int nblk = fr_dense_blocks(c, M);
-  if (c->cfg.dtype == MIVI_F32) {
-    FrArgs<float> a = fr_args<float>(c, nullptr, M);
-    hipLaunchKernelGGL((k_fr_tile_mfma<MODE_DENSE, 8>), dim3(nblk), dim3(512), 0, c->stream, a);
-  } else {
-    FrArgs<double> a = fr_args<double>(c, nullptr, M);
-    hipLaunchKernelGGL((k_fr_tile_generic<double, MODE_DENSE>), dim3(nblk), dim3(256), 0, c->stream, a);
-  }
-}
-
-void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const ValueIn &vin, const OutArgs &out) {
-  const int nb = (c->cfg.d + 31) / 32;
-  const int nblk = nb * (nb + 1) / 2;
-  if (c->cfg.dtype == MIVI_F32) {
-    FrArgs<float> a = fr_args<float>(c, params, M);
-    a.vin = vin;
-    a.out = out;
-    hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 4>), dim3(nblk), dim3(256), 0, c->stream, a);
-  } else {
-    FrArgs<double> a = fr_args<double>(c, params, M);
-    a.vin = vin;
-    a.out = out;
-    hipLaunchKernelGGL((k_fr_tile_generic<double, MODE_VJP>), dim3(nblk), dim3(256), 0, c->stream, a);
-  }
-}
-
 void launch_fr_stl(mivi_ctx *c, const void *params, int M) {
   const int nblk = (M + 7) / 8;
   if (c->cfg.dtype == MIVI_F32) {
     FrArgs<float> a = fr_args<float>(c, params, M);
     const size_t sh = (8 * (size_t)c->dP + 32 * 33) * sizeof(float);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_stl<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL(k_fr_stl<float>, dim3(nblk), dim3(256), sh, c->stream, a);
   } else {
     FrArgs<double> a = fr_args<double>(c, params, M);
     const size_t sh = (8 * (size_t)c->dP + 32 * 33) * sizeof(double);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_stl<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     hipLaunchKernelGGL(k_fr_stl<double>, dim3(nblk), dim3(256), sh, c->stream, a);
   }
 }

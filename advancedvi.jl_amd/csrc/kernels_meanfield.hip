@@ -18,29 +18,49 @@
 
 namespace mivi {
 
+// DPP reduction to the 16-lane row level: afterwards every lane holds the sum of its row of 16 lanes.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+__device__ __forceinline__ double row16_sum(double v) {   // f64 contexts: plain shuffles within the row
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Scalar partial layout written by k_mf_main and consumed by k_mf_value: sc[k*nblk + blk],
+// k = 0 sum ell (variable part), 1 sum 0.5 eps^2, 2 sum log sigma_i (this block's rows), 3 #non-positive sigma.
 template <typename T>
 __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
-  __shared__ double red[4];
-  __shared__ double xw[4][12];   // per-wave partials: 0-3 sum W, 4-7 sum W*eps, 8 ell, 9 0.5 eps^2
+  __shared__ T xw[10][16];        // [value][wave*4 + row16] partial sums
   __shared__ double tot[12];
-  __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int rq = blockIdx.x, cc = blockIdx.y;
   const int d = a.d, d4 = (d + 3) >> 2;
+  if (rq >= d4) {   // heterogeneous workgroup: objective value of the PREVIOUS estimate
+    if (a.has_prev && cc == 0) {
+      __shared__ double red[4];
+      const T *sig = a.params + d;
+      finalize_value_block<T, 256, false>(d, a.prev_vin, a.prev_out, 2 * (int64_t)d, [sig](int i) { return sig[i]; }, red);
+    }
+    return;
+  }
+  MIVI_STAMP(a.dbg, 0);
   const uint64_t idx = rng_index(a.rng);
   const bool stl = ent_is_stl(a.out.ent_kind);
-  MIVI_STAMP(a.dbg, 0);
 
   T mu[4], sg[4], isg[4], tm[4], tis[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int i = 4 * rq + r;
-    const bool ok = i < d;
-    mu[r] = ok ? a.params[i] : T(0);
-    sg[r] = ok ? a.params[d + i] : T(1);
-    isg[r] = T(1) / sg[r];
-    tm[r] = (ok && a.target == TGT_DIAG_GAUSS) ? a.t_mean[i] : T(0);
-    tis[r] = (ok && a.target == TGT_DIAG_GAUSS) ? a.t_istd[i] : T(0);
+    const int i = min(4 * rq + r, d - 1);
+    mu[r] = a.params[i];
+    sg[r] = a.params[d + i];
+    tm[r] = (a.target == TGT_DIAG_GAUSS) ? a.t_mean[i] : T(0);
+    tis[r] = (a.target == TGT_DIAG_GAUSS) ? a.t_istd[i] : T(0);
   }
 
   T sW[4] = {0, 0, 0, 0}, sWe[4] = {0, 0, 0, 0};
@@ -55,15 +75,12 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
       for (int r = 0; r < 4; ++r) {
         const T z = mu[r] + sg[r] * e[r];
         const T u = (z - tm[r]) * tis[r];
-        s_ell += T(-0.5) * u * u;
+        if (4 * rq + r < d) s_ell += T(-0.5) * u * u;
         g[r] = -u * tis[r];
       }
     } else if (a.want_grad) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 4 * rq + r;
-        g[r] = a.G[(size_t)m * d + min(i, d - 1)];
-      }
+      for (int r = 0; r < 4; ++r) g[r] = a.G[(size_t)m * d + min(4 * rq + r, d - 1)];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -71,33 +88,38 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
       const T er = ok ? e[r] : T(0);
       s_he += T(0.5) * er * er;
       if (a.want_grad) {
+        isg[r] = T(1) / sg[r];
         const T w = ok ? (g[r] + (stl ? er * isg[r] : T(0))) : T(0);
         sW[r] += w;
         sWe[r] += w * er;
       }
     }
   }
-
   MIVI_STAMP(a.dbg, 1);
-  // ---- one wave-level pass (f32 DPP for T = float), one LDS exchange ---------------------------
+
+  // ---- reductions: DPP to 16-lane rows, one LDS exchange, 12 threads finish in fp64 ------------
   {
-    double v[10];
+    T v[10];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      v[r] = a.want_grad ? wave_sum_fast(sW[r]) : 0.0;
-      v[4 + r] = a.want_grad ? wave_sum_fast(sWe[r]) : 0.0;
+      v[r] = row16_sum(sW[r]);
+      v[4 + r] = row16_sum(sWe[r]);
     }
-    v[8] = wave_sum_fast(s_ell);
-    v[9] = wave_sum_fast(s_he);
-    if (lane == 0) {
+    v[8] = row16_sum(s_ell);
+    v[9] = row16_sum(s_he);
+    if ((lane & 15) == 0) {
+      const int slot = wv * 4 + (lane >> 4);
 #pragma unroll
-      for (int k = 0; k < 10; ++k) xw[wv][k] = v[k];
+      for (int k = 0; k < 10; ++k) xw[k][slot] = v[k];
     }
   }
   __syncthreads();
-  if (tid < 10) tot[tid] = xw[0][tid] + xw[1][tid] + xw[2][tid] + xw[3][tid];
-  // log-determinant / positivity partials of this workgroup's four rows (cc == 0 only counts once)
-  if (tid >= 16 && tid < 20) {
+  if (tid < 10) {
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += (double)xw[tid][j];
+    tot[tid] = s;
+  } else if (tid >= 16 && tid < 20) {   // log-determinant / positivity partial of this block's rows
     const int r = tid - 16, i = 4 * rq + r;
     double lg = 0.0, bad = 0.0;
     if (i < d && cc == 0) {
@@ -115,65 +137,34 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
     }
   }
   __syncthreads();
+  MIVI_STAMP(a.dbg, 2);
 
-  if (a.want_grad) {
+  const int nblk = d4 * gridDim.y;
+  const int blk = cc * d4 + rq;
+  if (a.want_grad && tid < 8) {
     if (a.n_cc == 1) {
-      if (tid < 4) {
-        const int i = 4 * rq + tid;
-        if (i < d) {
-          if (a.out.partials_mode) {
-            T *p = (T *)a.out.partials;
-            p[i] = (T)tot[tid];
-            p[d + i] = (T)tot[4 + tid];
-          } else {
-            T *gr = (T *)a.out.grad;
-            const double invM = 1.0 / (double)a.out.M_total;
-            const double sgi = (double)a.params[d + i];
-            gr[i] = (T)(-tot[tid] * invM);
-            gr[d + i] = (T)(-tot[4 + tid] * invM - direct_entropy_coeff(a.out.ent_kind) / sgi);
-          }
+      const int r = tid & 3, i = 4 * rq + r;
+      if (i < d) {
+        if (a.out.partials_mode) {
+          ((T *)a.out.partials)[(tid < 4 ? 0 : d) + i] = (T)tot[tid];
+        } else {
+          T *gr = (T *)a.out.grad;
+          const double invM = 1.0 / (double)a.out.M_total;
+          if (tid < 4) gr[i] = (T)(-tot[tid] * invM);
+          else gr[d + i] = (T)(-tot[tid] * invM - direct_entropy_coeff(a.out.ent_kind) / (double)a.params[d + i]);
         }
       }
-    } else if (tid < 8) {
+    } else {
       a.row_part[((size_t)cc * d4 + rq) * 8 + tid] = tot[tid];
     }
   }
-
-  MIVI_STAMP(a.dbg, 2);
-  // ---- scalar partials: [ell | he | logdet | bad] x nblk ----------------------------------------
-  const int nblk = gridDim.x * gridDim.y;
-  const int blk = cc * gridDim.x + rq;
-  if (a.n_cc == 1) {
-    if (tid < 4) __hip_atomic_store(a.sc_part + (size_t)tid * nblk + blk, tot[8 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) {
-      const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_last = (t == (unsigned)(nblk - 1));
-      if (s_last) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    MIVI_STAMP(a.dbg, 3);
-    if (s_last) {
-      ValueIn vin = a.vin;
-      vin.ell_part2 = a.sc_part;
-      vin.n_ell_part2 = nblk;
-      vin.he_part = a.sc_part + nblk;
-      vin.n_he_part = nblk;
-      vin.ld_part = a.sc_part + 2 * (size_t)nblk;
-      vin.n_ld_part = nblk;
-      const T *sig = a.params + d;
-      finalize_value_block<T, 256, true>(d, vin, a.out, 2 * (int64_t)d, [sig](int i) { return sig[i]; }, red);
-      MIVI_STAMP(a.dbg, 4);
-    }
-  } else if (tid < 4) {
-    a.sc_part[(size_t)tid * nblk + blk] = tot[8 + tid];
-  }
+  if (tid >= 8 && tid < 12) a.sc_part[(size_t)(tid - 8) * nblk + blk] = tot[tid];
+  MIVI_STAMP(a.dbg, 3);
 }
 
-// second pass when the columns were split over gridDim.y > 1 workgroups
+// Row-sum second pass when the columns were split over gridDim.y > 1 workgroups.
 template <typename T>
-__global__ __launch_bounds__(256) void k_mf_colreduce(MfArgs<T> a, int nblk_main) {
-  __shared__ double red[4];
+__global__ __launch_bounds__(256) void k_mf_colreduce(MfArgs<T> a) {
   const int d = a.d, d4 = (d + 3) >> 2;
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (a.want_grad && t < d4 * 8) {
@@ -193,17 +184,6 @@ __global__ __launch_bounds__(256) void k_mf_colreduce(MfArgs<T> a, int nblk_main
           gr[d + i] = (T)(-s * invM - direct_entropy_coeff(a.out.ent_kind) / (double)a.params[d + i]);
       }
     }
-  }
-  if (blockIdx.x == 0) {
-    ValueIn vin = a.vin;
-    vin.ell_part2 = a.sc_part;
-    vin.n_ell_part2 = nblk_main;
-    vin.he_part = a.sc_part + nblk_main;
-    vin.n_he_part = nblk_main;
-    vin.ld_part = a.sc_part + 2 * (size_t)nblk_main;
-    vin.n_ld_part = nblk_main;
-    const T *sig = a.params + d;
-    finalize_value_block<T, 256, false>(d, vin, a.out, 2 * (int64_t)d, [sig](int i) { return sig[i]; }, red);
   }
 }
 
@@ -238,7 +218,7 @@ __global__ __launch_bounds__(256) void k_mf_sample(SampleArgs<T> a) {
 
 template <typename T>
 static void mf_main_impl(mivi_ctx *c, const void *params, const RngArgs &rng, int M, int want_grad, const void *G,
-                         const ValueIn &vin, const OutArgs &out) {
+                         const ValueIn &vin, const OutArgs &out, const ValueJob *prev) {
   MfArgs<T> a;
   a.d = c->cfg.d;
   a.M = M;
@@ -263,25 +243,34 @@ static void mf_main_impl(mivi_ctx *c, const void *params, const RngArgs &rng, in
   a.G = (const T *)G;
   a.want_grad = want_grad;
   a.row_part = (double *)c->row_part.p;
-  a.sc_part = (double *)c->sc_part.p;
-  a.ticket = (unsigned int *)c->ticket.p;
+  a.sc_part = (double *)c->sc_part[c->cur].p;
+  a.ticket = nullptr;
   a.vin = vin;
   a.out = out;
   a.dbg = c->dbg;
-  dim3 grid(d4, n_cc);
-  hipLaunchKernelGGL(k_mf_main<T>, grid, dim3(256), 0, c->stream, a);
-  if (n_cc > 1) {
-    const int nb = (d4 * 8 + 255) / 256;
-    hipLaunchKernelGGL(k_mf_colreduce<T>, dim3(nb), dim3(256), 0, c->stream, a, d4 * n_cc);
+  a.has_prev = prev ? 1 : 0;
+  if (prev) {
+    a.prev_vin = prev->vin;
+    a.prev_out = prev->out;
+  } else {
+    a.prev_vin = ValueIn{};
+    a.prev_out = OutArgs{};
   }
+  dim3 grid(d4 + (prev ? 1 : 0), n_cc);
+  hipLaunchKernelGGL(k_mf_main<T>, grid, dim3(256), 0, c->stream, a);
+  if (n_cc > 1 && want_grad) {
+    const int nb = (d4 * 8 + 255) / 256;
+    hipLaunchKernelGGL(k_mf_colreduce<T>, dim3(nb), dim3(256), 0, c->stream, a);
+  }
+  c->mf_nblk = d4 * n_cc;
 }
 
 void launch_mf_main(mivi_ctx *c, const void *params, const RngArgs &rng, int M, int want_grad, const void *G,
-                    const ValueIn &vin, const OutArgs &out) {
+                    const ValueIn &vin, const OutArgs &out, const ValueJob *prev) {
   if (c->cfg.dtype == MIVI_F32)
-    mf_main_impl<float>(c, params, rng, M, want_grad, G, vin, out);
+    mf_main_impl<float>(c, params, rng, M, want_grad, G, vin, out, prev);
   else
-    mf_main_impl<double>(c, params, rng, M, want_grad, G, vin, out);
+    mf_main_impl<double>(c, params, rng, M, want_grad, G, vin, out, prev);
 }
 
 template <typename T>

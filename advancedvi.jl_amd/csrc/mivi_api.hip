@@ -47,10 +47,23 @@ static mivi_status_t ensure_work(mivi_ctx *c, int M) {
     const int capM = round_up(M, 64);
     c->dP = round_up(d, 64);
     c->MP = capM;
-    if (c->cfg.family == MIVI_FULLRANK) {
-      c->eps.bytes = 0; c->epsT.bytes = 0;
-      if ((s = ensure(c, c->eps, (size_t)c->dP * c->MP * es, true))) return s;
-      if ((s = ensure(c, c->epsT, (size_t)c->dP * c->MP * es, true))) return s;
+    const int d4 = (d + 3) / 4;
+    // per-workgroup ell partials: the XCD-interleaved work tables have up to 8*ceil(nb/8)*ncb slots
+    size_t n_part = 8 * (size_t)(((d + 31) / 32 + 7) / 8) * (size_t)((capM + 31) / 32) + 64;
+    size_t n_he = (size_t)((d + 15) / 16) * (size_t)(capM / 64 + 1);
+    const size_t n_he_mf = (size_t)((d4 + 255) / 256) * (size_t)capM;
+    if (n_he_mf > n_he) n_he = n_he_mf;
+    const size_t ncc = (size_t)(capM / 256 + 2);
+    for (int b = 0; b < 2; ++b) {
+      if (c->cfg.family == MIVI_FULLRANK) {
+        c->eps[b].bytes = 0; c->epsT[b].bytes = 0;
+        if ((s = ensure(c, c->eps[b], (size_t)c->dP * c->MP * es, true))) return s;
+        if ((s = ensure(c, c->epsT[b], (size_t)c->dP * c->MP * es, true))) return s;
+      }
+      if ((s = ensure(c, c->ell_part[b], n_part * sizeof(double), false))) return s;
+      if ((s = ensure(c, c->he_part[b], (n_he + 64) * sizeof(double), false))) return s;
+      if ((s = ensure(c, c->sc_part[b], 4 * ncc * d4 * sizeof(double) + 64, false))) return s;
+      if ((s = ensure(c, c->ld_part[b], 2 * (size_t)((d + 31) / 32) * sizeof(double) + 64, false))) return s;
     }
     if (c->target == TGT_DENSE_GAUSS) {
       c->RT.bytes = 0;
@@ -59,16 +72,7 @@ static mivi_status_t ensure_work(mivi_ctx *c, int M) {
     if ((s = ensure(c, c->Z, (size_t)d * capM * es, false))) return s;
     if ((s = ensure(c, c->W, (size_t)d * capM * es, false))) return s;
     if ((s = ensure(c, c->ell, (size_t)capM * es, false))) return s;
-    const int d4 = (d + 3) / 4;
-    size_t n_part = (size_t)((d + 31) / 32) * (size_t)((capM + 31) / 32) + 64;
-    size_t n_he = (size_t)((d + 63) / 64) * (size_t)(capM / 64 + 1);
-    const size_t n_he_mf = (size_t)((d4 + 255) / 256) * (size_t)capM;
-    if (n_he_mf > n_he) n_he = n_he_mf;
-    if ((s = ensure(c, c->ell_part, n_part * sizeof(double), false))) return s;
-    if ((s = ensure(c, c->he_part, (n_he + 64) * sizeof(double), false))) return s;
-    const size_t ncc = (size_t)(capM / 256 + 2);
     if ((s = ensure(c, c->row_part, ncc * d4 * 8 * sizeof(double), false))) return s;
-    if ((s = ensure(c, c->sc_part, 4 * ncc * d4 * sizeof(double) + 64, false))) return s;
     c->cap_M = capM;
   }
   return MIVI_OK;
@@ -127,12 +131,16 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->graph.exec) (void)hipGraphExecDestroy(c->graph.exec);
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part,
-                    &c->eps, &c->epsT, &c->Z, &c->W, &c->RT, &c->ell, &c->X, &c->ell_part, &c->he_part, &c->row_part,
-                    &c->sc_part, &c->ticket, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
+                    &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->ticket, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
+  for (hipEvent_t e : c->cap_events) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+  if (c->side_eps) (void)hipStreamDestroy(c->side_eps);
+  if (c->side_val) (void)hipStreamDestroy(c->side_val);
   delete c;
   return MIVI_OK;
 }
@@ -316,9 +324,29 @@ static mivi_status_t eval_generic_target(mivi_ctx *c, int M, int want_grad) {
   }
 }
 
+// Chained mode (graph-batched estimates, device-resident optimisation loop): everything stays on ONE stream and
+// the two pieces of an estimate that do not sit on its critical path ride along as heterogeneous workgroups:
+//   * eps of estimate t+1 is generated by extra workgroups of estimate t's VJP kernel (VALU under the MFMA waves),
+//   * the objective value of estimate t is assembled by one extra workgroup of estimate t+1's first kernel.
+// Buffers those jobs touch are double-buffered by the parity c->cur.  The chain is closed by flush_chain().
+struct Chain {
+  bool on = false;
+  bool first = true;        // eps of this estimate has not been generated yet
+  bool has_next = false;    // another estimate follows: prefetch its eps
+  RngArgs next_rng{};
+  bool have_prev = false;   // a value job is pending
+  ValueJob prev{};
+};
+
+static bool hetero_ok(const mivi_ctx *c, int want_grad) {
+  if (!want_grad) return false;
+  if (c->cfg.family == MIVI_MEANFIELD) return c->target == TGT_DIAG_GAUSS;
+  return c->cfg.dtype == MIVI_F32 && (c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS);
+}
+
 // One estimate over M local samples. out.partials_mode selects final vs shard partials.
 static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs &rng, int M, int want_grad,
-                                  OutArgs out) {
+                                  OutArgs out, Chain *ch = nullptr) {
   if (c->target == TGT_NONE) return fail(c, MIVI_ERR_NO_TARGET, "no target set");
   mivi_status_t s = ensure_work(c, M);
   if (s) return s;
@@ -327,15 +355,26 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
   ValueIn vin{};
   vin.ell_const = c->t_const;
   const int d = c->cfg.d, d4 = (d + 3) / 4;
+  const bool chained = ch && ch->on && hetero_ok(c, want_grad) && !out.partials_mode;
+  if (!chained) c->cur = 0;
+  const int p = c->cur;
+  const ValueJob *prev = (chained && ch->have_prev) ? &ch->prev : nullptr;
+
   if (c->cfg.family == MIVI_MEANFIELD) {
     if (c->target == TGT_DIAG_GAUSS) {
-      launch_mf_main(c, params, rng, M, want_grad, nullptr, vin, out);
+      launch_mf_main(c, params, rng, M, want_grad, nullptr, vin, out, prev);
+      vin.ell_part2 = (const double *)c->sc_part[p].p;
+      vin.n_ell_part2 = c->mf_nblk;
+      vin.he_part = (const double *)c->sc_part[p].p + c->mf_nblk;
+      vin.n_he_part = c->mf_nblk;
+      vin.ld_part = (const double *)c->sc_part[p].p + 2 * (size_t)c->mf_nblk;
+      vin.n_ld_part = c->mf_nblk;
     } else {
-      launch_sample_mf(c, params, rng, M, c->Z.p, nullptr, 0, want_grad ? nullptr : (double *)c->he_part.p);
+      launch_sample_mf(c, params, rng, M, c->Z.p, nullptr, 0, want_grad ? nullptr : (double *)c->he_part[p].p);
       if (c->target == TGT_DENSE_GAUSS) {
         launch_rt_from_z(c, M);
         launch_fr_dense_target(c, M, want_grad);
-        vin.ell_part = (const double *)c->ell_part.p;
+        vin.ell_part = (const double *)c->ell_part[p].p;
         vin.n_ell_part = fr_dense_blocks(c, M);
       } else {
         if ((s = eval_generic_target(c, M, want_grad))) return s;
@@ -344,24 +383,29 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
       }
       if (want_grad) {
         launch_mf_main(c, params, rng, M, 1, c->W.p, vin, out);
+        vin.ell_part2 = (const double *)c->sc_part[p].p;   // zeros for the non-fused target; he / logdet live here
+        vin.n_ell_part2 = c->mf_nblk;
+        vin.he_part = (const double *)c->sc_part[p].p + c->mf_nblk;
+        vin.n_he_part = c->mf_nblk;
+        vin.ld_part = (const double *)c->sc_part[p].p + 2 * (size_t)c->mf_nblk;
+        vin.n_ld_part = c->mf_nblk;
       } else {
-        vin.he_part = (const double *)c->he_part.p;
+        vin.he_part = (const double *)c->he_part[p].p;
         vin.n_he_part = ((d4 + 255) / 256) * M;
-        launch_value_only(c, params, vin, out);
       }
     }
   } else {
-    launch_eps(c, rng, M);
-    vin.he_part = (const double *)c->he_part.p;
+    if (!chained || ch->first) launch_eps(c, rng, M);   // otherwise generated inside the previous VJP kernel
+    vin.he_part = (const double *)c->he_part[p].p;
     vin.n_he_part = eps_blocks(c, M);
     if (c->target == TGT_DIAG_GAUSS) {
-      launch_fr_sample(c, params, M, TGT_DIAG_GAUSS, nullptr);
-      vin.ell_part = (const double *)c->ell_part.p;
+      launch_fr_sample(c, params, M, TGT_DIAG_GAUSS, nullptr, prev);
+      vin.ell_part = (const double *)c->ell_part[p].p;
       vin.n_ell_part = fr_sample_blocks(c, M);
     } else if (c->target == TGT_DENSE_GAUSS) {
-      launch_fr_sample(c, params, M, TGT_DENSE_GAUSS, c->Z.p);
+      launch_fr_sample(c, params, M, TGT_DENSE_GAUSS, c->Z.p, prev);
       launch_fr_dense_target(c, M, want_grad);
-      vin.ell_part = (const double *)c->ell_part.p;
+      vin.ell_part = (const double *)c->ell_part[p].p;
       vin.n_ell_part = fr_dense_blocks(c, M);
     } else {
       launch_fr_sample(c, params, M, TGT_NONE, c->Z.p);
@@ -375,13 +419,35 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
         if (sh > 160 * 1024) return fail(c, MIVI_ERR_UNSUPPORTED, "full-rank STL: d too large for the LDS-resident solve");
         launch_fr_stl(c, params, M);
       }
-      launch_fr_vjp(c, params, M, vin, out);
-    } else {
-      launch_value_only(c, params, vin, out);
+      EpsJob nx{};
+      const EpsJob *next = nullptr;
+      if (chained && ch->has_next) {
+        nx.rng = ch->next_rng;
+        nx.parity = p ^ 1;
+        next = &nx;
+      }
+      launch_fr_vjp(c, params, M, out, next);
+      vin.ld_part = (const double *)c->ld_part[p].p;   // emitted by the VJP kernel's diagonal tiles
+      vin.n_ld_part = fr_ld_blocks(c);
     }
+  }
+  // ---- objective value (or the two scalar partials) -------------------------------------------------
+  if (chained) {
+    ch->prev.vin = vin;
+    ch->prev.out = out;
+    ch->have_prev = true;
+    ch->first = false;
+  } else {
+    if (ch) { ch->have_prev = false; ch->first = true; }
+    launch_value_only(c, params, vin, out);
   }
   HIPCHK(c, hipGetLastError());
   return MIVI_OK;
+}
+
+static void flush_chain(mivi_ctx *c, const void *params, Chain *ch) {
+  if (ch->have_prev) launch_value_only(c, params, ch->prev.vin, ch->prev.out);
+  ch->have_prev = false;
 }
 
 static OutArgs final_out(mivi_ctx *c, void *value, void *grad) {
@@ -414,10 +480,11 @@ mivi_status_t mivi_sample(mivi_ctx_t *c, const void *params, uint64_t idx, void 
   if (c->cfg.family == MIVI_MEANFIELD) {
     launch_sample_mf(c, params, rng_of(c, idx), M, Z, eps, d, nullptr);
   } else {
+    c->cur = 0;
     launch_eps(c, rng_of(c, idx), M);
     launch_fr_sample(c, params, M, TGT_NONE, Z);
     if (eps)
-      HIPCHK(c, hipMemcpy2DAsync(eps, (size_t)d * c->esize, c->eps.p, (size_t)c->dP * c->esize, (size_t)d * c->esize, M,
+      HIPCHK(c, hipMemcpy2DAsync(eps, (size_t)d * c->esize, c->eps[0].p, (size_t)c->dP * c->esize, (size_t)d * c->esize, M,
                                  hipMemcpyDeviceToDevice, c->stream));
   }
   HIPCHK(c, hipGetLastError());
@@ -541,6 +608,7 @@ mivi_status_t mivi_estimate_objective_host(mivi_ctx_t *c, const void *params_h, 
 // The null stream cannot be captured: record on an internal stream, replay on the context's stream.
 static mivi_status_t begin_capture(mivi_ctx *c, hipStream_t *saved) {
   if (!c->cap_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+
   HIPCHK(c, hipStreamSynchronize(c->stream));   // pending memsets / uploads on the launch stream
   *saved = c->stream;
   c->stream = c->cap_stream;
@@ -565,17 +633,26 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
   (void)hipSetDevice(c->cfg.device);
   mivi_status_t s = ensure_work(c, c->cfg.n_mc);
   if (s) return s;
+  prepare_tables(c, c->cfg.n_mc);   // host->device uploads are not allowed inside the capture
   GraphCache &g = c->graph;
   if (!(g.exec && g.kind == 1 && g.count == count && g.params == params && g.value == value && g.grad == grad)) {
     invalidate_graph(c);
     hipGraph_t graph = nullptr;
     hipStream_t saved;
     if ((s = begin_capture(c, &saved))) return s;
+    Chain chn;
+    chn.on = true;
     for (int i = 0; i < count && s == MIVI_OK; ++i) {
       RngArgs r = rng_of(c, (uint64_t)i);
       r.idx_ptr = (const uint64_t *)c->d_idx.p;
-      s = run_estimate(c, params, r, c->cfg.n_mc, 1, final_out(c, value, grad));
+      c->cur = i & 1;
+      chn.has_next = (i + 1 < count);
+      chn.next_rng = rng_of(c, (uint64_t)i + 1);
+      chn.next_rng.idx_ptr = r.idx_ptr;
+      s = run_estimate(c, params, r, c->cfg.n_mc, 1, final_out(c, value, grad), &chn);
     }
+    if (s == MIVI_OK) flush_chain(c, params, &chn);
+    c->cur = 0;
     hipError_t e = end_capture(c, saved, &graph);
     if (s) { if (graph) (void)hipGraphDestroy(graph); return s; }
     HIPCHK(c, e);
@@ -618,6 +695,7 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, 
   (void)hipSetDevice(c->cfg.device);
   mivi_status_t s = ensure_work(c, c->cfg.n_mc);
   if (s) return s;
+  prepare_tables(c, c->cfg.n_mc);
   const size_t plen = (size_t)mivi_params_len(c), es = c->esize;
   // internal value/grad/elbo-record buffers
   if ((s = ensure(c, c->X, (plen + 8) * es + (size_t)n_steps * sizeof(double), false))) return s;
@@ -631,13 +709,19 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, 
     hipGraph_t graph = nullptr;
     hipStream_t saved;
     if ((s = begin_capture(c, &saved))) return s;
+    Chain chn;
+    chn.on = true;
     for (int i = 0; i < n_steps && s == MIVI_OK; ++i) {
       RngArgs r = rng_of(c, (uint64_t)i);
       r.idx_ptr = (const uint64_t *)c->d_idx.p;
       OutArgs o = final_out(c, vbuf, gbuf);
       o.elbo_rec = rec;
       o.rec_slot = i;
-      s = run_estimate(c, params, r, c->cfg.n_mc, 1, o);
+      c->cur = i & 1;
+      chn.has_next = (i + 1 < n_steps);
+      chn.next_rng = rng_of(c, (uint64_t)i + 1);
+      chn.next_rng.idx_ptr = r.idx_ptr;
+      s = run_estimate(c, params, r, c->cfg.n_mc, 1, o, &chn);
       if (s) break;
       if (rule == 0)
         launch_descent(c, params, gbuf, eta);
@@ -645,6 +729,8 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, 
         launch_adam(c, params, gbuf, opt_state, (const int64_t *)c->d_idx.p + 1, (int64_t)i + 1, eta, 0.9, 0.999, 1e-8);
       if (clip_eps > 0.0) launch_clip(c, params, clip_eps);
     }
+    if (s == MIVI_OK) flush_chain(c, params, &chn);
+    c->cur = 0;
     hipError_t e = end_capture(c, saved, &graph);
     if (s) { if (graph) (void)hipGraphDestroy(graph); return s; }
     HIPCHK(c, e);
@@ -691,16 +777,11 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
   ValueIn vin{};
   vin.ell_const = c->t_const;
   const bool fr = c->cfg.family == MIVI_FULLRANK;
-  if (fr) {
-    vin.he_part = (const double *)c->he_part.p;
-    vin.n_he_part = eps_blocks(c, M);
-    vin.ell_part = (const double *)c->ell_part.p;
-    vin.n_ell_part = fr_sample_blocks(c, M);
-  }
+  c->cur = 0;
   if (which != 0) {
     if (!fr && which != 2) return fail(c, MIVI_ERR_UNSUPPORTED, "mean-field has a single fused kernel (which = 2)");
     if (which == 4 && c->target != TGT_DENSE_GAUSS) return fail(c, MIVI_ERR_UNSUPPORTED, "no dense target set");
-    if (which == 2 && c->target != TGT_DIAG_GAUSS && c->target != TGT_DENSE_GAUSS && fr)
+    if (which == 2 && c->target != TGT_DIAG_GAUSS && c->target != TGT_DENSE_GAUSS)
       return fail(c, MIVI_ERR_UNSUPPORTED, "stage timing needs a fused built-in target");
   }
   hipEvent_t e0, e1;
@@ -715,7 +796,7 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
         if (fr) launch_fr_sample(c, params, M, c->target, c->target == TGT_DENSE_GAUSS ? c->Z.p : nullptr);
         else launch_mf_main(c, params, rng, M, 1, nullptr, vin, out);
         break;
-      case 3: launch_fr_vjp(c, params, M, vin, out); break;
+      case 3: launch_fr_vjp(c, params, M, out); break;
       default: launch_fr_dense_target(c, M, 1); break;
     }
     if (s) break;

@@ -81,6 +81,9 @@ struct MfArgs {
   ValueIn vin;
   OutArgs out;
   long long *dbg;      // optional timeline: dbg[block*8 + k] = wall_clock64() stamps (nullptr = off)
+  int has_prev;        // extra workgroup (blockIdx.x == ceil(d/4)) assembles the previous estimate's value
+  ValueIn prev_vin;
+  OutArgs prev_out;
 };
 
 template <typename T>
@@ -110,9 +113,26 @@ struct FrArgs {
   const T *t_istd;
   const T *t_prec;     // precision matrix, ld = dP, zero padded
   double *ell_part;    // written by sample/target kernels
+  double *ld_part;     // [2][nb]: per diagonal block sum log C_ii, then #non-positive C_ii (VJP kernel)
   ValueIn vin;
   OutArgs out;
   long long *dbg;      // optional timeline (nullptr = off)
+  // work distribution + heterogeneous workgroups (MFMA kernel only)
+  const int2 *work_tab;
+  int n_work;          // index of the value workgroup (sample kernel) or INT_MAX
+  int n_pre;           // leading workgroups that generate the next estimate's eps (VJP kernel)
+  SampleArgs<T> next_eps;
+  ValueIn prev_vin;
+  OutArgs prev_out;
+};
+
+struct ValueJob {      // deferred objective-value assembly of the previous estimate
+  ValueIn vin;
+  OutArgs out;
+};
+struct EpsJob {        // eps generation for the next estimate
+  RngArgs rng;
+  int parity;
 };
 
 template <typename T>
@@ -177,8 +197,17 @@ struct mivi_ctx {
 
   // work buffers (sized for `cap_M` samples)
   int cap_M = 0;
-  mivi::DevBuf eps, epsT, Z, W, RT, ell, X;
-  mivi::DevBuf ell_part, he_part, row_part, sc_part, ticket, status, d_idx, acc, tmp_params, tmp_out;
+  // buffers indexed [cur] are double-buffered so that, inside a captured graph, eps generation of estimate t+1
+  // and the value assembly of estimate t overlap the contractions of the neighbouring estimates
+  mivi::DevBuf eps[2], epsT[2], ell_part[2], he_part[2], sc_part[2], ld_part[2];
+  mivi::DevBuf tabA, tabB, tabD;   // XCD-aware work tables of the MFMA kernels
+  int nA = 0, nB = 0, nD = 0, tab_M = -1;
+  int cur = 0;
+  int mf_nblk = 0;
+  mivi::DevBuf Z, W, RT, ell, X;
+  mivi::DevBuf row_part, ticket, status, d_idx, acc, tmp_params, tmp_out;
+  hipStream_t side_eps = nullptr, side_val = nullptr;   // capture-only fork streams
+  std::vector<hipEvent_t> cap_events;
   long long *dbg = nullptr;   // timeline buffer supplied through mivi_debug_timeline (tools only)
   int dP = 0, MP = 0;
 
@@ -188,15 +217,18 @@ struct mivi_ctx {
 namespace mivi {
 
 // kernels_meanfield.hip
+struct ValueJob;
 void launch_mf_main(mivi_ctx *c, const void *params, const RngArgs &rng, int M, int want_grad, const void *G,
-                    const ValueIn &vin, const OutArgs &out);
+                    const ValueIn &vin, const OutArgs &out, const ValueJob *prev = nullptr);
 void launch_sample_mf(mivi_ctx *c, const void *params, const RngArgs &rng, int M, void *Z, void *eps, int ld_eps,
                       double *he_part);
 
 // kernels_fullrank.hip
 void launch_eps(mivi_ctx *c, const RngArgs &rng, int M);
-void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, void *Z);
-void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const ValueIn &vin, const OutArgs &out);
+void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, void *Z, const ValueJob *prev = nullptr);
+void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const EpsJob *next = nullptr);
+int fr_ld_blocks(const mivi_ctx *c);
+void prepare_tables(mivi_ctx *c, int M);   // build + upload the MFMA work tables (no-op for f64 / mean-field)
 void launch_fr_dense_target(mivi_ctx *c, int M, int want_grad);
 void launch_rt_from_z(mivi_ctx *c, int M);
 void launch_fr_stl(mivi_ctx *c, const void *params, int M);
@@ -210,7 +242,7 @@ void launch_logreg_target(mivi_ctx *c, int M, int want_grad);
 
 // kernels_update.hip
 void launch_finalize(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad);
-void launch_value_only(mivi_ctx *c, const void *params, const ValueIn &vin, const OutArgs &out);
+void launch_value_only(mivi_ctx *c, const void *params, const ValueIn &vin, const OutArgs &out);   // on c->stream
 void launch_clip(mivi_ctx *c, void *params, double epsilon);
 void launch_descent(mivi_ctx *c, void *params, const void *grad, double eta);
 void launch_adam(mivi_ctx *c, void *params, const void *grad, void *state, const int64_t *t_ptr, int64_t t_base,

@@ -159,6 +159,8 @@ def main():
             value, grad = drv.value, drv.grad
 
         run(0, W)
+        if world == 1 and W < chunk:   # make sure the hipGraph is captured + instantiated outside the timed region
+            run(W, chunk)
         stream.synchronize()
         if dist:
             dist.barrier()

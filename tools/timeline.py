@@ -15,25 +15,29 @@ ctx = avi.MiviContext(np.float32, w["family"], w["d"], w["n_mc"], w["entropy"], 
 ctx.set_problem(prob)
 params = ctx.to_device(params_h)
 ctx.profile_kernel(which, params, 20)
-nb = 4096
+nb = 3 * 4096
 buf = torch.zeros(nb * 8, dtype=torch.int64, device="cuda")
 ctx.lib.mivi_debug_timeline(ctx.h, buf.data_ptr())
-ms = ctx.profile_kernel(which, params, 1)
+ctx.profile_kernel(which, params, 1)
 torch.cuda.synchronize()
-t = buf.cpu().numpy().reshape(nb, 8).astype(np.float64)
-used = t[:, 0] > 0
-t = t[used]
+buf.zero_()
+torch.cuda.synchronize()
+ms = ctx.profile_kernel(which, params, 1)   # warm estimate (all kernels stamp) + the stage alone (latest stamps win)
+torch.cuda.synchronize()
+kind = {1: 0, 2: 0, 3: 1, 4: 2}[which]
+t = buf.cpu().numpy().reshape(3, 4096, 8)[kind].astype(np.float64)
+t = t[t[:, 0] > 0]
+print(f"workload {wl} stage {which}: {len(t)} blocks stamped")
 t0 = t[:, 0].min()
-print(f"workload {wl} stage {which}: {used.sum()} blocks, launch ms {ms*1e3:.2f} us (incl. warm estimate)")
 ns = 10.0  # ns per tick
-for k in range(5):
+for k in range(4):
     col = t[:, k]
     ok = col > 0
     if ok.sum() == 0:
         continue
     rel = (col[ok] - t0) * ns / 1e3
     print(f"  stamp {k}: n={ok.sum():5d} min {rel.min():7.2f} us  median {np.median(rel):7.2f}  p90 {np.percentile(rel,90):7.2f}  max {rel.max():7.2f}")
-for k in range(1, 5):
+for k in range(1, 4):
     ok = (t[:, k] > 0) & (t[:, k - 1] > 0)
     if ok.sum():
         dd = (t[ok, k] - t[ok, k - 1]) * ns / 1e3
