@@ -227,9 +227,13 @@ __device__ double tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *
 // Heterogeneous workgroups: blockIdx < a.n_pre run `eps(t+1)` tiles (VJP kernel); the workgroup after the
 // last tile assembles the objective value of the PREVIOUS estimate (sample kernel).
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
+// One wave accumulates 32-k blocks [kb_beg, kb_end) of tile (ib, cb) into `acc`.
+// ALIGNED (d and M multiples of 32): every operand read is in bounds, so a stage is 32 loads whose
+// addresses are (scalar stage base) + (per-lane 32-bit offsets computed once) -- no per-load VALU -- and the
+// triangular mask is applied only in the diagonal k-block of the sampling product.
+template <int MODE, bool ALIGNED>
 __device__ __forceinline__ void run_kblocks(const FrArgs<float> &a, int ib, int cb, int kb_beg, int kb_end, f32x16 &acc,
-                                            float &rs) {
+                                            float &rs, bool want_rs) {
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   const int d = a.d, M = a.M;
   const int gi = ib * 32 + l31, n0 = cb * 32;
@@ -238,22 +242,72 @@ __device__ __forceinline__ void run_kblocks(const FrArgs<float> &a, int ib, int 
   const float *Bbase;
   int ldb;
   if (MODE == MODE_SAMPLE) {
-    Abase = a.params + d;  lda = d;    kmaxA = d - 1;    Bbase = a.epsT + n0 + l31;  ldb = a.MP;
+    Abase = a.params + d;  lda = d;    kmaxA = d - 1;    Bbase = a.epsT;  ldb = a.MP;
   } else if (MODE == MODE_VJP) {
-    Abase = a.W;           lda = d;    kmaxA = M - 1;    Bbase = a.eps + n0 + l31;   ldb = a.dP;
+    Abase = a.W;           lda = d;    kmaxA = M - 1;    Bbase = a.eps;   ldb = a.dP;
   } else {
-    Abase = a.t_prec;      lda = a.dP; kmaxA = a.dP - 1; Bbase = a.RT + n0 + l31;   ldb = a.MP;
+    Abase = a.t_prec;      lda = a.dP; kmaxA = a.dP - 1; Bbase = a.RT;    ldb = a.MP;
   }
   const bool row_ok = gi < d;
-  // unconditional loads on clamped addresses; out-of-range operands are zeroed at use
-  const float *Arow = Abase + (MODE == MODE_DENSE ? gi : min(gi, d - 1));
   float a0[16], b0[16], a1[16], b1[16];
+
+  if (ALIGNED) {
+    // address = (uniform pointer, SALU arithmetic) + (one per-lane unsigned 32-bit offset)
+    const unsigned voffA = (unsigned)(gi + h * lda), voffB = (unsigned)(n0 + l31 + h * ldb);
+    auto load_stage = [&](int k, float (&av)[16], float (&bv)[16]) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float *pa = Abase + (size_t)(k + 2 * u) * (size_t)lda;   // uniform
+        const float *pb = Bbase + (size_t)(k + 2 * u) * (size_t)ldb;
+        av[u] = pa[voffA];
+        bv[u] = pb[voffB];
+      }
+    };
+    auto mma_stage = [&](int k, const float (&av)[16], const float (&bv)[16]) {
+      const bool masked = (MODE == MODE_SAMPLE) && (k == ib * 32);   // uniform: diagonal block of tril(C)
+      if (masked) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const float av_m = (k + 2 * u + h <= gi) ? av[u] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av_m, bv[u], acc, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          if (MODE == MODE_VJP && want_rs) rs += av[u];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+      }
+    };
+    if (kb_beg < kb_end) {
+      int k = kb_beg * 32;
+      const int kend = kb_end * 32;
+      load_stage(k, a0, b0);
+      while (true) {
+        const bool more1 = (k + 32) < kend;
+        if (more1) load_stage(k + 32, a1, b1);
+        mma_stage(k, a0, b0);
+        if (!more1) break;
+        k += 32;
+        const bool more0 = (k + 32) < kend;
+        if (more0) load_stage(k + 32, a0, b0);
+        mma_stage(k, a1, b1);
+        if (!more0) break;
+        k += 32;
+      }
+    }
+    return;
+  }
+
+  // ---- general shapes: unconditional loads on clamped addresses, operands zeroed at use ----------
+  const float *Arow = Abase + (MODE == MODE_DENSE ? gi : min(gi, d - 1));
+  const float *Bcol = Bbase + n0 + l31;
   auto load_stage = [&](int k, float (&av)[16], float (&bv)[16]) {
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int kk = k + 2 * u + h;
       av[u] = Arow[(size_t)min(kk, kmaxA) * lda];
-      bv[u] = Bbase[(size_t)kk * ldb];
+      bv[u] = Bcol[(size_t)kk * ldb];
     }
   };
   auto mma_stage = [&](int k, const float (&av)[16], const float (&bv)[16]) {
@@ -288,14 +342,15 @@ __device__ __forceinline__ void run_kblocks(const FrArgs<float> &a, int ib, int 
   }
 }
 
-template <int MODE, int NW>
+template <int MODE, int NW, bool ALIGNED>
 __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
   constexpr int NT = NW * 64;
   constexpr int NSEG = (MODE == MODE_SAMPLE) ? 2 : 1;
   __shared__ float red_acc[NSEG][NW][16 * 65];
   __shared__ float rs_lds[NT];
   __shared__ double red[NW];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform
   const int d = a.d, M = a.M;
 
   // ---- heterogeneous workgroups -----------------------------------------------------------------
@@ -340,9 +395,11 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
   float rs = 0.f, rs_dummy = 0.f;
-  run_kblocks<MODE>(a, seg_ib[0], cb, min(u0, seg_kb[0]), min(u1, seg_kb[0]), acc0, rs);
+  const bool want_rs = (MODE == MODE_VJP) && (seg_ib[0] == cb);   // row sums only on diagonal tiles
+  run_kblocks<MODE, ALIGNED>(a, seg_ib[0], cb, min(u0, seg_kb[0]), min(u1, seg_kb[0]), acc0, rs, want_rs);
   if (NSEG == 2 && seg_kb[1] > 0)
-    run_kblocks<MODE>(a, seg_ib[1], cb, max(u0, seg_kb[0]) - seg_kb[0], max(u1, seg_kb[0]) - seg_kb[0], acc1, rs_dummy);
+    run_kblocks<MODE, ALIGNED>(a, seg_ib[1], cb, max(u0, seg_kb[0]) - seg_kb[0], max(u1, seg_kb[0]) - seg_kb[0], acc1, rs_dummy,
+                               false);
   MIVI_STAMP_K(a.dbg, MODE, 1);
 
 #pragma unroll
@@ -685,7 +742,10 @@ void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, 
     } else {
       a.n_work = 0x7fffffff;   // no value workgroup
     }
-    hipLaunchKernelGGL((k_fr_tile_mfma<MODE_SAMPLE, 8>), dim3(grid), dim3(512), 0, c->stream, a);
+    if (c->cfg.d % 32 == 0 && M % 32 == 0)
+      hipLaunchKernelGGL((k_fr_tile_mfma<MODE_SAMPLE, 8, true>), dim3(grid), dim3(512), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL((k_fr_tile_mfma<MODE_SAMPLE, 8, false>), dim3(grid), dim3(512), 0, c->stream, a);
   } else {
     const int nblk = ((c->cfg.d + 31) / 32) * ((M + 31) / 32);
     FrArgs<double> a = fr_args<double>(c, params, M);
@@ -702,7 +762,10 @@ void launch_fr_dense_target(mivi_ctx *c, int M, int want_grad) {
     FrArgs<float> a = fr_args<float>(c, nullptr, M);
     a.work_tab = (const int2 *)c->tabD.p;
     a.n_work = 0x7fffffff;
-    hipLaunchKernelGGL((k_fr_tile_mfma<MODE_DENSE, 8>), dim3(c->nD), dim3(512), 0, c->stream, a);
+    if (c->cfg.d % 32 == 0 && M % 32 == 0)
+      hipLaunchKernelGGL((k_fr_tile_mfma<MODE_DENSE, 8, true>), dim3(c->nD), dim3(512), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL((k_fr_tile_mfma<MODE_DENSE, 8, false>), dim3(c->nD), dim3(512), 0, c->stream, a);
   } else {
     const int nblk = ((c->cfg.d + 31) / 32) * ((M + 31) / 32);
     FrArgs<double> a = fr_args<double>(c, nullptr, M);
@@ -724,7 +787,10 @@ void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, c
       a.next_eps = eps_args<float>(c, next->rng, M, next->parity);
       grid += a.n_pre;
     }
-    hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 4>), dim3(grid), dim3(256), 0, c->stream, a);
+    if (c->cfg.d % 32 == 0 && M % 32 == 0)
+      hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 4, true>), dim3(grid), dim3(256), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 4, false>), dim3(grid), dim3(256), 0, c->stream, a);
   } else {
     const int nb = (c->cfg.d + 31) / 32;
     FrArgs<double> a = fr_args<double>(c, params, M);
