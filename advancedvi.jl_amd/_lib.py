@@ -56,6 +56,7 @@ SIGNATURES = {
     "mivi_dog_init": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]),
     "mivi_dog_update": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "mivi_optimize_steps": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p]),
+    "mivi_set_index_source": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "mivi_debug_timeline": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "mivi_profile_kernel": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "mivi_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -217,6 +217,11 @@ class MiviContext:
         self._chk(self.lib.mivi_finalize(self.h, self._p(p), self._p(partials), self._p(value), self._p(grad)))
         return value, grad
 
+    def set_index_source(self, idx_tensor):
+        """idx_tensor: 1-element int64/uint64 device tensor added to every estimate index (None to unset)."""
+        self._idx_src = idx_tensor
+        self._chk(self.lib.mivi_set_index_source(self.h, self._p(idx_tensor) if idx_tensor is not None else None))
+
     def profile_kernel(self, which, params, reps):
         """ms per launch of one pipeline stage, hipEvent-timed on the context's stream (mivi_profile_kernel)."""
         ms = C.c_double(0.0)

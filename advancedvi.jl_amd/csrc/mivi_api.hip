@@ -466,7 +466,7 @@ static RngArgs rng_of(mivi_ctx *c, uint64_t idx) {
   RngArgs r;
   r.seed = c->cfg.seed;
   r.idx_base = idx;
-  r.idx_ptr = nullptr;
+  r.idx_ptr = c->idx_src;
   r.m_offset = c->cfg.m_offset;
   return r;
 }
@@ -755,6 +755,13 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, 
     }
   }
   return read_status(c);
+}
+
+mivi_status_t mivi_set_index_source(mivi_ctx_t *c, const uint64_t *idx_dev) {
+  if (!c) return MIVI_ERR_BAD_ARG;
+  c->idx_src = idx_dev;
+  invalidate_graph(c);
+  return MIVI_OK;
 }
 
 mivi_status_t mivi_debug_timeline(mivi_ctx_t *c, void *buf) {

@@ -208,6 +208,7 @@ struct mivi_ctx {
   mivi::DevBuf row_part, ticket, status, d_idx, acc, tmp_params, tmp_out;
   hipStream_t side_eps = nullptr, side_val = nullptr;   // capture-only fork streams
   std::vector<hipEvent_t> cap_events;
+  const uint64_t *idx_src = nullptr;   // mivi_set_index_source
   long long *dbg = nullptr;   // timeline buffer supplied through mivi_debug_timeline (tools only)
   int dP = 0, MP = 0;
 

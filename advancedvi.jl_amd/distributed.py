@@ -42,11 +42,12 @@ def partials_len(d: int, family: int) -> int:
     return (2 * d if family == 0 else d + d * d) + 2
 
 
-def allreduce_partials(partials, group=None):
-    """In-place SUM all-reduce of the partial buffer over the process group (RCCL on GPUs)."""
+def allreduce_partials(partials, group=None, force=False):
+    """In-place SUM all-reduce of the partial buffer over the process group (RCCL on GPUs).
+    `force` issues the collective even for a single-rank group (used to exercise the path on one GPU)."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (force or dist.get_world_size(group) > 1):
         dist.all_reduce(partials, op=dist.ReduceOp.SUM, group=group)
     return partials
 
@@ -57,13 +58,14 @@ class DistributedRepGradELBO:
     estimate_gradient(params, idx) -> (value, grad) device tensors, identical on every rank and equal
     (up to fp32 summation order) to the single-GPU estimate with n_samples = plan.n_samples."""
 
-    def __init__(self, q, prob, n_samples, entropy, seed, device=0, group=None):
+    def __init__(self, q, prob, n_samples, entropy, seed, device=0, group=None, force_collective=False):
         import torch.distributed as dist
 
         from .context import MiviContext
         from .families import destructure
 
         self.group = group
+        self.force_collective = force_collective
         if dist.is_available() and dist.is_initialized():
             self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         else:
@@ -79,10 +81,10 @@ class DistributedRepGradELBO:
 
     def estimate_gradient(self, params, idx):
         p = self.ctx.to_device(params)
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             return self.ctx.estimate_gradient(p, idx, self.value, self.grad)
         self.ctx.estimate_partials(p, idx, self.partials)
-        allreduce_partials(self.partials, self.group)
+        allreduce_partials(self.partials, self.group, force=self.force_collective)
         return self.ctx.finalize(p, self.partials, self.value, self.grad)
 
     def close(self):

@@ -119,11 +119,29 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libmivi has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    import contextlib
+
+    @contextlib.contextmanager
+    def quiet_stdout():
+        """RCCL prints a version banner on stdout at init; keep stdout for the one JSON line."""
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            yield
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
+
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("MIVI_FORCE_DIST", "0") == "1"   # exercise the N>1 code path on one GPU
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        with quiet_stdout():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.all_reduce(torch.zeros(1, device=f"cuda:{local_rank}"))   # communicator set-up (and its banner) up front
 
     w = WORKLOADS[args.workload]
     q, prob = make_problem(avi, w)
@@ -134,7 +152,8 @@ def main():
            avi.StickingTheLandingEntropy(), avi.StickingTheLandingEntropyZeroGradient()][w["entropy"]]
 
     with torch.cuda.stream(stream):
-        if world == 1:
+        single = (world == 1 and not force_dist)
+        if single:
             ctx = avi.MiviContext(np.float32, w["family"], w["d"], w["n_mc"], ent.code, SEED, device=local_rank)
             ctx.set_problem(prob)
             params = ctx.to_device(params_h)
@@ -149,17 +168,47 @@ def main():
                 for i in range(done, n):
                     ctx.estimate_gradient(params, idx0 + i, value, grad)
         else:
-            drv = avi.distributed.DistributedRepGradELBO(q, prob, w["n_mc"] * world, ent, SEED, device=local_rank)
+            drv = avi.distributed.DistributedRepGradELBO(q, prob, w["n_mc"] * world, ent, SEED, device=local_rank,
+                                                         force_collective=force_dist)
             ctx = drv.ctx
             params = ctx.to_device(params_h)
 
-            def run(idx0, n):
-                for i in range(n):
-                    drv.estimate_gradient(params, idx0 + i)
             value, grad = drv.value, drv.grad
+            drv.estimate_gradient(params, 0)          # allocate every work buffer before any capture
+            stream.synchronize()
+            # Steps are {partials kernels -> RCCL all-reduce -> finalize}.  Capture `chunk` of them in one graph (kernels AND
+            # the collective), estimate index = offset + device counter; fall back to eager launches if capture is refused.
+            chunk = max(1, min(20, K))
+            idx_dev = torch.zeros(1, dtype=torch.int64, device=f"cuda:{local_rank}")
+            graph = None
+            try:
+                ctx.set_index_source(idx_dev)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=stream):
+                    for i in range(chunk):
+                        drv.estimate_gradient(params, i)
+                graph = g
+            except Exception as e:   # noqa: BLE001
+                print(f"[bench] graph capture of the distributed step failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+                ctx.set_index_source(None)
+                torch.cuda.synchronize()
+
+            def run(idx0, n):
+                done = 0
+                if graph is not None:
+                    while done + chunk <= n:
+                        idx_dev.fill_(idx0 + done)
+                        graph.replay()
+                        done += chunk
+                    idx_dev.fill_(idx0 + done)
+                    for i in range(n - done):
+                        drv.estimate_gradient(params, i)
+                else:
+                    for i in range(n):
+                        drv.estimate_gradient(params, idx0 + i)
 
         run(0, W)
-        if world == 1 and W < chunk:   # make sure the hipGraph is captured + instantiated outside the timed region
+        if single and W < chunk:   # make sure the hipGraph is captured + instantiated outside the timed region
             run(W, chunk)
         stream.synchronize()
         if dist:
@@ -184,7 +233,7 @@ def main():
             # ---- roofline leg: hipEvent-timed launches of the dominant kernel on the launch stream ----------
             roof = None
             stages = {}
-            if world == 1:
+            if single:
                 reps = 300
                 if w["family"] == 0:
                     ms = ctx.profile_kernel(2, params, reps)
@@ -213,7 +262,7 @@ def main():
             # ---- parity + cpu_baseline leg (rank 0, N = 1 only) ---------------------------------------------
             rel = None
             cpub = None
-            if world == 1 and not args.no_cpu_baseline:
+            if single and not args.no_cpu_baseline:
                 from oracle import c_oracle as CO
                 if w["target"] == "iso":
                     cpub = cpu_baseline(w, params_h)
@@ -231,7 +280,7 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": w["name"], "d": w["d"], "n_mc_per_gpu": w["n_mc"], "n_mc_total": w["n_mc"] * world,
                            "family": "fullrank" if w["family"] else "meanfield", "seed": hex(SEED),
-                           "launch": f"hipGraph x{chunk}" if world == 1 else "eager + RCCL all-reduce"},
+                           "launch": f"hipGraph x{chunk}" if single else (f"CUDAGraph x{chunk} incl. RCCL all-reduce" if graph is not None else "eager + RCCL all-reduce")},
                 "roofline": roof, "cpu_baseline": cpub,
                 "elbo_rel_err_vs_cpu_fp64": rel, "stage_us": stages, "whole_estimate": whole,
             }

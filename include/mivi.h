@@ -183,6 +183,11 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *ctx, void *params_dev, void *opt_s
                                   int64_t t0, int32_t n_steps, int32_t rule, double eta, double clip_epsilon,
                                   void *elbo_dev);
 
+/* Estimate-index source: when idx_dev != NULL every estimate uses estimate_idx + *idx_dev (read on the device at
+ * kernel time), so a captured graph (e.g. a torch CUDAGraph holding kernels + the RCCL all-reduce) advances the
+ * eps stream on replay by bumping one device word.  NULL restores by-value indices. */
+mivi_status_t mivi_set_index_source(mivi_ctx_t *ctx, const uint64_t *idx_dev);
+
 /* ---- measurement hook (bench.py roofline leg) --------------------------------------------------------- *
  * Times `reps` back-to-back launches of ONE stage of the estimate with hipEvents recorded on the context's
  * stream (after one full warm estimate so every input buffer is populated).

