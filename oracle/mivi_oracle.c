@@ -119,20 +119,35 @@ double FN(estimate_gradient)(int family, int d, int M, const REAL *params, const
   const int stl = (ent_kind == 3 || ent_kind == 4);
   double sum_ell = 0.0, sum_he = 0.0;
 
-  /* z = scale*eps + mu; ell; W = grad log pi(z)   (location_scale.jl:71-87; repgradelbo.jl:84-86) */
+  /* z = scale*eps + mu   (location_scale.jl:71-87).  Full-rank: cache-blocked lower-triangular product, one
+   * 64-row block of C per task reused across every sample column (what a BLAS trmm would do). */
+  if (family == 1) {
+    const int RB = 64;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int ib = (d + RB - 1) / RB - 1; ib >= 0; --ib) {
+      const int i0 = ib * RB, i1 = (i0 + RB < d) ? i0 + RB : d;
+      for (int m = 0; m < M; ++m) {
+        REAL *z = W + (size_t)m * d;
+        for (int i = i0; i < i1; ++i) z[i] = mu[i];
+      }
+      for (int k = 0; k < i1; ++k) {
+        const REAL *ck = C + (size_t)k * d;
+        const int is = k > i0 ? k : i0;
+        for (int m = 0; m < M; ++m) {
+          const REAL ek = eps[(size_t)m * d + k];
+          REAL *z = W + (size_t)m * d;
+          for (int i = is; i < i1; ++i) z[i] += ck[i] * ek;
+        }
+      }
+    }
+  }
+  /* ell; W = grad log pi(z)   (repgradelbo.jl:84-86) */
 #pragma omp parallel for schedule(static) reduction(+ : sum_ell, sum_he)
   for (int m = 0; m < M; ++m) {
     const REAL *e = eps + (size_t)m * d;
     REAL *z = W + (size_t)m * d;
     if (family == 0) {
       for (int i = 0; i < d; ++i) z[i] = mu[i] + C[i] * e[i];
-    } else {
-      for (int i = 0; i < d; ++i) z[i] = mu[i];
-      for (int k = 0; k < d; ++k) {            /* column-major lower-triangular axpy */
-        const REAL ek = e[k];
-        const REAL *ck = C + (size_t)k * d;
-        for (int i = k; i < d; ++i) z[i] += ck[i] * ek;
-      }
     }
     double ell = 0.0, he = 0.0;
     for (int i = 0; i < d; ++i) {

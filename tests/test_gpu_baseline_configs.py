@@ -1,0 +1,129 @@
+"""BASELINE.json configs at (or near) their full sizes.
+C1  README LogReg n=1000, 32 features + sigma (theta in R^33), mean-field, n_mc=16, fp64 -- through the generic
+    LogDensityProblems plugin route (host callback), checked against the oracle.
+C2 / NS: covered by tests/test_gpu_parity.py::test_sizes_including_ragged (d=1024, M=256).
+C3  hierarchical LogReg, D=512, full-rank, n_mc=128: oracle parity at n=20 000 and, at n=10^6, size-independent
+    properties (row duplication with likeadj=1/2 leaves the estimate unchanged; f32 agrees with f64).
+C5  funnel d=2048 + Stacked bijector, mean-field, STL, 64 samples per GPU: oracle parity at full size and
+    shard-sum == single estimate over the 8 x 64 = 512 global samples."""
+import numpy as np
+import pytest
+
+import advancedvi_jl_amd as avi
+from advancedvi_jl_amd.distributed import ShardPlan
+from oracle import oracle as O
+from tests.helpers import SEED, OraclePlugin, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c1_readme_logreg_plugin_route():
+    rng = np.random.default_rng(11)
+    n, p = 1000, 32
+    X = np.hstack([rng.normal(size=(n, p - 1)), np.ones((n, 1))])           # intercept column, README.md:139-140
+    beta = rng.normal(size=p)
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-X @ beta))).astype(float)
+    tgt = O.LogRegTarget(X, y, "lognormal_exp_bijector")                     # README model + exp bijector on sigma
+    d, M = p + 1, 16
+    q = avi.MeanFieldGaussian(np.zeros(d), np.ones(d))                        # q0 of README.md:184
+    params, _ = avi.destructure(q)
+    plug = OraclePlugin(tgt)
+    ctx = avi.MiviContext(np.float64, avi.MEANFIELD, d, M, 0, SEED)
+    ctx.set_problem(plug)
+    _, eps = ctx.sample(params, 0)
+    v, g = ctx.estimate_gradient(params, 0)
+    assert plug.calls == M                                                    # one logdensity_and_gradient per column
+    ref = O.estimate_gradient(params, d, O.MEANFIELD, tgt, eps.cpu().numpy(), 0)
+    assert abs(float(v.item()) - ref["value"]) <= 1e-12 * abs(ref["value"])
+    assert rel_err(g.cpu().numpy(), ref["grad"]) < 1e-11
+    # built-in device target gives the same answer as the plugin
+    ctx2 = avi.MiviContext(np.float64, avi.MEANFIELD, d, M, 0, SEED)
+    ctx2.set_problem(avi.LogRegProblem(X, y.astype(np.uint8), "lognormal_exp_bijector"))
+    v2, g2 = ctx2.estimate_gradient(params, 0)
+    assert abs(float(v2.item()) - ref["value"]) <= 1e-11 * abs(ref["value"])
+    assert rel_err(g2.cpu().numpy(), ref["grad"]) < 1e-10
+    ctx.close(); ctx2.close()
+
+
+def _c3_data(n, rng):
+    p = 511
+    X = np.empty((n, p), dtype=np.float32)
+    X[:, :510] = rng.normal(size=(n, 510)).astype(np.float32) / np.sqrt(510.0)   # SURVEY.md 8d synthetic inputs
+    X[:, 510] = 1.0
+    beta = rng.normal(size=p).astype(np.float32)
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-(X @ beta)))).astype(np.uint8)
+    return X, y
+
+
+def test_c3_logreg_fullrank_oracle_parity_reduced_n():
+    rng = np.random.default_rng(12)
+    n, d, M = 20000, 512, 128
+    X, y = _c3_data(n, rng)
+    q = avi.FullRankGaussian(np.zeros(d, np.float32), 0.6 * np.eye(d, dtype=np.float32))   # docs/src/tutorials/basic.md:170
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+    ctx.set_problem(avi.LogRegProblem(X, y, "logsigma_normal", 1.0))
+    _, eps = ctx.sample(params, 1)
+    v, g = ctx.estimate_gradient(params, 1)
+    ref = O.estimate_gradient(params.astype(np.float64), d, O.FULLRANK, O.LogRegTarget(X, y, "logsigma_normal", 1.0),
+                              eps.cpu().numpy().astype(np.float64), 0)
+    assert abs(float(v.item()) - ref["value"]) <= 1e-5 * abs(ref["value"])
+    assert rel_err(g.cpu().numpy(), ref["grad"]) < 5e-5
+    ctx.close()
+
+
+def test_c3_logreg_full_size_properties():
+    """n = 10^6 rows, D = 512, full-rank, n_mc = 128 (BASELINE config 3): no CPU oracle at this size."""
+    rng = np.random.default_rng(13)
+    n_half, d, M = 500_000, 512, 128
+    X, y = _c3_data(n_half, rng)
+    q = avi.FullRankGaussian(np.zeros(d, np.float32), 0.6 * np.eye(d, dtype=np.float32))
+    params, _ = avi.destructure(q)
+    # (i) single copy, likeadj 1
+    c1 = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+    c1.set_problem(avi.LogRegProblem(X, y, "logsigma_normal", 1.0))
+    v1, g1 = c1.estimate_gradient(params, 2)
+    v1, g1 = float(v1.item()), g1.cpu().numpy().astype(np.float64)
+    c1.close()
+    # (ii) rows duplicated (n = 10^6), likelihood scaled by n_data/n = 1/2: identical posterior => identical estimate
+    X2, y2 = np.vstack([X, X]), np.concatenate([y, y])
+    c2 = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+    c2.set_problem(avi.LogRegProblem(X2, y2, "logsigma_normal", 0.5))
+    v2, g2 = c2.estimate_gradient(params, 2)
+    assert np.isfinite(float(v2.item()))
+    assert abs(float(v2.item()) - v1) <= 2e-5 * abs(v1)
+    assert rel_err(g2.cpu().numpy(), g1) < 1e-4
+    # structural zeros above the diagonal at full size
+    gC = g2.cpu().numpy()[d:].reshape(d, d, order="F")
+    assert np.all(np.triu(gC, 1) == 0.0)
+    c2.close()
+
+
+def test_c5_funnel_stl_full_size_and_sharding():
+    d, M_total, R = 2048, 512, 8                  # BASELINE config 5: 64 samples per GPU on 8 GPUs
+    q = avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32))
+    params, _ = avi.destructure(q)
+    prob = avi.FunnelProblem(d, 1.5)
+    ent = avi.StickingTheLandingEntropy.code
+    plan = ShardPlan(M_total, R)
+    total = None
+    ctxs = []
+    for r in range(R):
+        c = avi.MiviContext(np.float32, avi.MEANFIELD, d, plan.count(r), ent, SEED, m_offset=plan.offset(r), m_total=M_total)
+        c.set_problem(prob)
+        part = c.estimate_partials(params, 4).double()
+        total = part if total is None else total + part
+        ctxs.append(c)
+    v, g = ctxs[0].finalize(params, total.float())
+    full = avi.MiviContext(np.float32, avi.MEANFIELD, d, M_total, ent, SEED)
+    full.set_problem(prob)
+    _, eps = full.sample(params, 4)
+    vf, gf = full.estimate_gradient(params, 4)
+    ref = O.estimate_gradient(params.astype(np.float64), d, O.MEANFIELD, O.FunnelStackedTarget(d, 1.5),
+                              eps.cpu().numpy().astype(np.float64), ent)
+    for vv, gg in ((v, g), (vf, gf)):
+        assert abs(float(vv.item()) - ref["value"]) <= 1e-5 * abs(ref["value"])
+        assert rel_err(gg.cpu().numpy(), ref["grad"]) < 5e-5
+    for c in ctxs:
+        c.close()
+    full.close()
