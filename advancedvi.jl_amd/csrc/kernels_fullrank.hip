@@ -16,6 +16,7 @@
 // eps is generated once per estimate by k_eps in both layouts the contractions need:
 //   eps [i + m*dP] (column-major, the reference's layout)  and  epsT[m + k*MP].
 #include <algorithm>
+#include <cstdlib>
 
 #include "device_common.h"
 
@@ -742,7 +743,10 @@ void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, 
     } else {
       a.n_work = 0x7fffffff;   // no value workgroup
     }
-    if (c->cfg.d % 32 == 0 && M % 32 == 0)
+    static const int nw_s = getenv("MIVI_NW_SAMPLE") ? atoi(getenv("MIVI_NW_SAMPLE")) : 8;
+    if (c->cfg.d % 32 == 0 && M % 32 == 0 && nw_s == 16)
+      hipLaunchKernelGGL((k_fr_tile_mfma<MODE_SAMPLE, 16, true>), dim3(grid), dim3(1024), 0, c->stream, a);
+    else if (c->cfg.d % 32 == 0 && M % 32 == 0)
       hipLaunchKernelGGL((k_fr_tile_mfma<MODE_SAMPLE, 8, true>), dim3(grid), dim3(512), 0, c->stream, a);
     else
       hipLaunchKernelGGL((k_fr_tile_mfma<MODE_SAMPLE, 8, false>), dim3(grid), dim3(512), 0, c->stream, a);
@@ -787,7 +791,12 @@ void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, c
       a.next_eps = eps_args<float>(c, next->rng, M, next->parity);
       grid += a.n_pre;
     }
-    if (c->cfg.d % 32 == 0 && M % 32 == 0)
+    static const int nw_v = getenv("MIVI_NW_VJP") ? atoi(getenv("MIVI_NW_VJP")) : 4;
+    if (c->cfg.d % 32 == 0 && M % 32 == 0 && nw_v == 8 && !next)
+      hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 8, true>), dim3(grid), dim3(512), 0, c->stream, a);
+    else if (c->cfg.d % 32 == 0 && M % 32 == 0 && nw_v == 2 && !next)
+      hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 2, true>), dim3(grid), dim3(128), 0, c->stream, a);
+    else if (c->cfg.d % 32 == 0 && M % 32 == 0)
       hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 4, true>), dim3(grid), dim3(256), 0, c->stream, a);
     else
       hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 4, false>), dim3(grid), dim3(256), 0, c->stream, a);

@@ -37,6 +37,10 @@ WORKLOADS = {
                name="configs[1]: d=1024 mean-field MvLocationScale, n_mc=256, target MvNormal(5*1, I), ClosedFormEntropy"),
     "ns_dense": dict(family=1, d=1024, n_mc=256, target="dense", entropy=0,
                      name="north-star family, dense-Gaussian target N(5*1, L L'), L = tril(I + 11'/(2d))"),
+    "c3": dict(family=1, d=512, n_mc=128, target="logreg", entropy=0, n=1_000_000,
+               name="configs[2]: hierarchical LogReg n=1e6, D=512 (511 coefficients + log sigma), full-rank q0=(0, 0.6 I), n_mc=128"),
+    "c5": dict(family=0, d=2048, n_mc=64, target="funnel", entropy=3,
+               name="configs[4] per-GPU shard: funnel d=2048 + Stacked bijector, mean-field, STL, 64 samples per GPU"),
     "ns_stl": dict(family=1, d=1024, n_mc=256, target="iso", entropy=3,
                    name="north-star family, StickingTheLandingEntropy (adds the C^-T eps solve)"),
 }
@@ -50,10 +54,38 @@ def algorithmic_cost(w):
     return dict(bytes=(d * (d + 1) // 2) * s + d * d * s + 4 * d * M * s + 2 * d * s, flops=2 * d * d * M)
 
 
+def pmc_traffic(kernel_substr):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+    (profiles/pmc_traffic.json, produced by tools/pmc_traffic.py; separate passes, counters in KiB).  gfx950 caveat
+    (MI355X_MICROARCH.md, HBM): FETCH_SIZE under-reports wide (16 B/lane) streaming reads by 2x; these kernels
+    issue 4 B/lane loads, for which the counter is uncalibrated -- WRITE_SIZE matches known byte counts exactly."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    for k, v in tab.get("kernels", {}).items():
+        if kernel_substr in k:
+            return dict(bytes_per_launch=(v["fetch_kib"] + v["write_kib"]) * 1024.0, fetch_bytes=v["fetch_kib"] * 1024.0,
+                        write_bytes=v["write_kib"] * 1024.0, source=tab.get("source"))
+    return None
+
+
 def make_problem(avi, w):
     d = w["d"]
     q = (avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32)) if w["family"] == 0
          else avi.FullRankGaussian(np.zeros(d, np.float32), np.eye(d, dtype=np.float32)))
+    if w["target"] == "logreg":
+        rng = np.random.default_rng(3)
+        n, p = w["n"], d - 1
+        X = np.empty((n, p), dtype=np.float32)
+        X[:, :p - 1] = rng.standard_normal((n, p - 1), dtype=np.float32) / np.sqrt(p - 1.0)
+        X[:, p - 1] = 1.0
+        beta = rng.standard_normal(p, dtype=np.float32)
+        y = (rng.random(n) < 1 / (1 + np.exp(-(X @ beta)))).astype(np.uint8)
+        q = avi.FullRankGaussian(np.zeros(d, np.float32), 0.6 * np.eye(d, dtype=np.float32))
+        return q, avi.LogRegProblem(X, y, "logsigma_normal", 1.0)
+    if w["target"] == "funnel":
+        return q, avi.FunnelProblem(d, 1.5)
     if w["target"] == "iso":
         prob = avi.DiagNormalProblem(np.full(d, 5.0, np.float32), np.ones(d, np.float32))
     else:
@@ -72,21 +104,41 @@ def cpu_baseline(w, params, budget_s=15.0):
     lib = CO.load()
     d, M, fam = w["d"], w["n_mc"], w["family"]
     try:
-        cores = len(os.sched_getaffinity(0))     # CPUs this process may actually run on
+        avail = len(os.sched_getaffinity(0))     # CPUs this process may run on
     except AttributeError:
-        cores = os.cpu_count() or 1
-    lib.mo32_set_threads(cores)
+        avail = os.cpu_count() or 1
+    try:                                          # cgroup v2 CPU quota, if any
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            avail = max(1, min(avail, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
     tm, ts = np.full(d, 5.0, np.float32), np.ones(d, np.float32)
     work = np.empty(2 * d * M, dtype=np.float32)
-    eps = CO.fill_eps(lib, np.float32, SEED, 0, d, M)
-    t0 = time.perf_counter()
-    CO.estimate_gradient(lib, np.float32, fam, d, M, params, eps, tm, ts, w["entropy"], work)
-    t1 = time.perf_counter() - t0
-    n = int(min(400, max(3, budget_s / max(t1, 1e-4))))
+
+    def one(i):
+        eps = CO.fill_eps(lib, np.float32, SEED, i, d, M)
+        CO.estimate_gradient(lib, np.float32, fam, d, M, params, eps, tm, ts, w["entropy"], work)
+
+    # pick the fastest OpenMP team size (more threads than useful work slows this small problem down)
+    best, cores = None, 1
+    for nt in sorted({1, 8, 16, 32, 64, 128, avail}):
+        if nt > avail:
+            continue
+        lib.mo32_set_threads(nt)
+        one(0)
+        t0 = time.perf_counter()
+        one(1)
+        one(2)
+        t = (time.perf_counter() - t0) / 2
+        if best is None or t < best:
+            best, cores = t, nt
+    lib.mo32_set_threads(cores)
+    t1 = best
+    n = int(min(200000, max(3, budget_s / max(t1, 1e-5))))
     t0 = time.perf_counter()
     for i in range(n):
-        eps = CO.fill_eps(lib, np.float32, SEED, i + 1, d, M)
-        CO.estimate_gradient(lib, np.float32, fam, d, M, params, eps, tm, ts, w["entropy"], work)
+        one(i + 3)
     dt = time.perf_counter() - t0
     model = ""
     try:
@@ -97,7 +149,7 @@ def cpu_baseline(w, params, budget_s=15.0):
     except OSError:
         pass
     return dict(value=n / dt, unit="ELBO-grad-estimates/s", cores=cores, kind="port",
-                sample=f"{n} estimates of the same (d={d}, n_mc={M}) workload incl. eps generation, f32, OpenMP {cores} threads"
+                sample=f"{n} estimates of the same (d={d}, n_mc={M}) workload incl. eps generation, f32, OpenMP {cores} threads (best of the team sizes tried; {avail} CPUs available)"
                        f" on '{model}', {dt:.1f} s", threads=lib.mo32_max_threads())
 
 
@@ -164,10 +216,11 @@ def main():
             params = ctx.to_device(params_h)
             value, grad = ctx.empty(1), ctx.empty(ctx.params_len)
             chunk = max(1, min(args.graph_chunk, K))
+            use_graph = w["target"] != "logreg"
 
             def run(idx0, n):
                 done = 0
-                while done + chunk <= n:
+                while use_graph and done + chunk <= n:
                     ctx.estimate_gradient_n(params, idx0 + done, chunk, value, grad)
                     done += chunk
                 for i in range(done, n):
@@ -238,14 +291,14 @@ def main():
             # ---- roofline leg: hipEvent-timed launches of the dominant kernel on the launch stream ----------
             roof = None
             stages = {}
-            if single:
+            if single and w["target"] in ("iso", "dense"):
                 reps = 300
                 if w["family"] == 0:
                     ms = ctx.profile_kernel(2, params, reps)
                     stages = {"mf_fused_main": ms}
                     ach = cost["bytes"] / (ms * 1e-3) / 1e9
                     roof = dict(bound="hbm", kernel="k_mf_main<float>", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
-                                frac=ach / PEAK_HBM_GBS, traffic=None, algorithmic_bytes_per_launch=cost["bytes"],
+                                frac=ach / PEAK_HBM_GBS, traffic=pmc_traffic("k_mf_main"), algorithmic_bytes_per_launch=cost["bytes"],
                                 avg_launch_us=ms * 1e3)
                 else:
                     stages = {"eps": ctx.profile_kernel(1, params, reps), "sample": ctx.profile_kernel(2, params, reps),
@@ -258,7 +311,8 @@ def main():
                     fl = cost["flops"] / 2
                     ach = fl / (stages[dom] * 1e-3) / 1e12
                     roof = dict(bound="mfma", kernel=kname, achieved=ach, peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
-                                frac=ach / PEAK_F32_MFMA_TF, traffic=None, algorithmic_flops_per_launch=fl,
+                                frac=ach / PEAK_F32_MFMA_TF,
+                                traffic=pmc_traffic("mfmaILi1" if dom == "vjp" else "mfmaILi0"), algorithmic_flops_per_launch=fl,
                                 avg_launch_us=stages[dom] * 1e3)
                 stages = {k: round(v * 1e3, 3) for k, v in stages.items()}   # us
             whole = dict(hbm_equiv_GBs=cost["bytes"] * est_per_s / world / 1e9,
@@ -268,7 +322,7 @@ def main():
             # `value` above is a single dependent chain of estimates on one stream (what an SGD loop sees; latency
             # bound at these sizes).  Independent chains (multi-start VI, monitoring estimates) can overlap on the device.
             conc = None
-            if single and args.concurrent > 1:
+            if single and args.concurrent > 1 and w["target"] in ("iso", "dense"):
                 S = args.concurrent
                 streams = [torch.cuda.Stream(device=local_rank) for _ in range(S)]
                 ctxs, bufs = [], []
@@ -294,6 +348,32 @@ def main():
                             note="independent estimate chains on separate HIP streams; not the headline value")
                 for cx in ctxs:
                     cx.close()
+            # ---- BASELINE configs[1] (mean-field d=1024, n_mc=256) measured alongside the north-star workload ----
+            also = None
+            if single and args.workload == "ns":
+                w2 = WORKLOADS["c2"]
+                q2, prob2 = make_problem(avi, w2)
+                p2h, _ = avi.destructure(q2)
+                cx = avi.MiviContext(np.float32, w2["family"], w2["d"], w2["n_mc"], w2["entropy"], SEED, device=local_rank)
+                cx.set_problem(prob2)
+                p2 = cx.to_device(p2h)
+                v2, g2 = cx.empty(1), cx.empty(cx.params_len)
+                cx.estimate_gradient_n(p2, 0, 100, v2, g2)
+                stream.synchronize()
+                n2 = 50
+                t20 = time.perf_counter()
+                for r in range(n2):
+                    cx.estimate_gradient_n(p2, 100 * (r + 1), 100, v2, g2)
+                stream.synchronize()
+                t2 = time.perf_counter() - t20
+                ms2 = cx.profile_kernel(2, p2, 300)
+                c2cost = algorithmic_cost(w2)
+                also = {"c2": dict(workload=w2["name"], value=n2 * 100 / t2, unit="estimates/s", us_per_step=t2 / (n2 * 100) * 1e6,
+                                   roofline=dict(bound="hbm", kernel="k_mf_main<float>", achieved=c2cost["bytes"] / (ms2 * 1e-3) / 1e9,
+                                                 peak=PEAK_HBM_GBS, unit="GB/s", frac=c2cost["bytes"] / (ms2 * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                                 algorithmic_bytes_per_launch=c2cost["bytes"], avg_launch_us=ms2 * 1e3,
+                                                 traffic=pmc_traffic("k_mf_main")))}
+                cx.close()
             # ---- parity + cpu_baseline leg (rank 0, N = 1 only) ---------------------------------------------
             rel = None
             cpub = None
@@ -317,7 +397,7 @@ def main():
                            "family": "fullrank" if w["family"] else "meanfield", "seed": hex(SEED),
                            "launch": f"hipGraph x{chunk}" if single else (f"CUDAGraph x{chunk} incl. RCCL all-reduce" if graph is not None else "eager + RCCL all-reduce")},
                 "roofline": roof, "cpu_baseline": cpub,
-                "elbo_rel_err_vs_cpu_fp64": rel, "stage_us": stages, "whole_estimate": whole, "concurrent": conc,
+                "elbo_rel_err_vs_cpu_fp64": rel, "stage_us": stages, "whole_estimate": whole, "concurrent": conc, "also": also,
             }
         if dist:
             dist.barrier()
