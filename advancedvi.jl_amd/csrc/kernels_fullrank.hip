@@ -343,6 +343,79 @@ __device__ __forceinline__ void run_kblocks(const FrArgs<float> &a, int ib, int 
   }
 }
 
+// Sampling product, ALIGNED shapes: one continuous double-buffered pipeline over the wave's 32-k blocks of BOTH
+// paired tiles (row-blocks ib0 then ib1), so the wave that straddles the junction does not drain and refill.
+// Blocks [b0, e0) of tile ib0 are followed by blocks [b1, e1) of tile ib1; the accumulator is picked by a
+// wave-uniform branch (no dynamic register indexing).
+__device__ __forceinline__ void run_pair_sample(const FrArgs<float> &a, int ib0, int ib1, int cb, int b0, int e0, int b1,
+                                                int e1, f32x16 &acc0, f32x16 &acc1) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+  const int d = a.d;
+  const float *Abase = a.params + d;
+  const float *Bbase = a.epsT;
+  const int lda = d, ldb = a.MP;
+  const unsigned voffB = (unsigned)(cb * 32 + l31 + h * ldb);
+  const int n0 = e0 - b0, n1 = e1 - b1, n = n0 + n1;
+  if (n <= 0) return;
+  float a0[16], bb0[16], a1[16], bb1[16], a2[16], bb2[16], a3[16], bb3[16];   // 4-deep stage ring
+  auto load_stage = [&](int sidx, float (&av)[16], float (&bv)[16]) {
+    const bool second = sidx >= n0;                       // uniform
+    const int k = (second ? b1 + (sidx - n0) : b0 + sidx) * 32;
+    const unsigned voffA = (unsigned)((second ? ib1 : ib0) * 32 + l31 + h * lda);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float *pa = Abase + (size_t)(k + 2 * u) * (size_t)lda;   // uniform
+      const float *pb = Bbase + (size_t)(k + 2 * u) * (size_t)ldb;
+      av[u] = pa[voffA];
+      bv[u] = pb[voffB];
+    }
+  };
+  auto mma_stage = [&](int sidx, const float (&av)[16], const float (&bv)[16]) {
+    const bool second = sidx >= n0;
+    const int ib = second ? ib1 : ib0;
+    const int k = (second ? b1 + (sidx - n0) : b0 + sidx) * 32;
+    const bool masked = (k == ib * 32);                   // diagonal block of tril(C)
+    const int gi = ib * 32 + l31;
+    if (!second) {
+      if (masked) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32((k + 2 * u + h <= gi) ? av[u] : 0.f, bv[u], acc0, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc0, 0, 0, 0);
+      }
+    } else {
+      if (masked) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32((k + 2 * u + h <= gi) ? av[u] : 0.f, bv[u], acc1, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc1, 0, 0, 0);
+      }
+    }
+  };
+  int sidx = 0;
+  load_stage(0, a0, bb0);
+  if (1 < n) load_stage(1, a1, bb1);
+  if (2 < n) load_stage(2, a2, bb2);
+  while (true) {   // three stages of loads stay in flight behind the MFMAs of the current one
+    if (sidx + 3 < n) load_stage(sidx + 3, a3, bb3);
+    mma_stage(sidx, a0, bb0);
+    if (++sidx >= n) break;
+    if (sidx + 3 < n) load_stage(sidx + 3, a0, bb0);
+    mma_stage(sidx, a1, bb1);
+    if (++sidx >= n) break;
+    if (sidx + 3 < n) load_stage(sidx + 3, a1, bb1);
+    mma_stage(sidx, a2, bb2);
+    if (++sidx >= n) break;
+    if (sidx + 3 < n) load_stage(sidx + 3, a2, bb2);
+    mma_stage(sidx, a3, bb3);
+    if (++sidx >= n) break;
+  }
+}
+
 template <int MODE, int NW, bool ALIGNED>
 __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
   constexpr int NT = NW * 64;
@@ -368,6 +441,7 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
     return;
   }
   MIVI_STAMP_K(a.dbg, MODE, 0);
+  if (a.dbg && threadIdx.x == 0 && blockIdx.x < 4096) a.dbg[((size_t)MODE * 4096 + blockIdx.x) * 8 + 6] = clock64();
   const int2 wk = a.work_tab[widx];
   if (wk.x < 0) {
     if (tid == 0 && MODE != MODE_VJP) a.ell_part[widx] = 0.0;
@@ -397,10 +471,15 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
   float rs = 0.f, rs_dummy = 0.f;
   const bool want_rs = (MODE == MODE_VJP) && (seg_ib[0] == cb);   // row sums only on diagonal tiles
-  run_kblocks<MODE, ALIGNED>(a, seg_ib[0], cb, min(u0, seg_kb[0]), min(u1, seg_kb[0]), acc0, rs, want_rs);
-  if (NSEG == 2 && seg_kb[1] > 0)
-    run_kblocks<MODE, ALIGNED>(a, seg_ib[1], cb, max(u0, seg_kb[0]) - seg_kb[0], max(u1, seg_kb[0]) - seg_kb[0], acc1, rs_dummy,
-                               false);
+  if (MODE == MODE_SAMPLE && ALIGNED) {
+    run_pair_sample(a, seg_ib[0], seg_ib[1], cb, min(u0, seg_kb[0]), min(u1, seg_kb[0]), max(u0, seg_kb[0]) - seg_kb[0],
+                    max(u1, seg_kb[0]) - seg_kb[0], acc0, acc1);
+  } else {
+    run_kblocks<MODE, ALIGNED>(a, seg_ib[0], cb, min(u0, seg_kb[0]), min(u1, seg_kb[0]), acc0, rs, want_rs);
+    if (NSEG == 2 && seg_kb[1] > 0)
+      run_kblocks<MODE, ALIGNED>(a, seg_ib[1], cb, max(u0, seg_kb[0]) - seg_kb[0], max(u1, seg_kb[0]) - seg_kb[0], acc1,
+                                 rs_dummy, false);
+  }
   MIVI_STAMP_K(a.dbg, MODE, 1);
 
 #pragma unroll
@@ -412,6 +491,7 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
   rs_lds[tid] = rs;
   __syncthreads();
   MIVI_STAMP_K(a.dbg, MODE, 2);
+  if (a.dbg && threadIdx.x == 0 && blockIdx.x < 4096) a.dbg[((size_t)MODE * 4096 + blockIdx.x) * 8 + 7] = clock64();
 
   double ell_acc = 0.0;
 #pragma unroll

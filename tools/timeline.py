@@ -42,3 +42,9 @@ for k in range(1, 4):
     if ok.sum():
         dd = (t[ok, k] - t[ok, k - 1]) * ns / 1e3
         print(f"  phase {k-1}->{k}: median {np.median(dd):6.2f} us  p90 {np.percentile(dd,90):6.2f}  max {dd.max():6.2f}")
+
+ok = (t[:, 6] > 0) & (t[:, 7] > 0) & (t[:, 2] > 0)
+if ok.sum():
+    cyc = t[ok, 7] - t[ok, 6]
+    wall_us = (t[ok, 2] - t[ok, 0]) * ns / 1e3
+    print(f"  shader clock during main loop: median {np.median(cyc / wall_us) / 1e3:.2f} GHz  (cycles {np.median(cyc):.0f} over {np.median(wall_us):.2f} us)")
