@@ -119,7 +119,7 @@ __device__ double tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *
   if (MODE == MODE_SAMPLE) {
     const int gi = i0 + row;
     const T mu = gi < d ? a.params[gi] : T(0);
-    const T tm = (gi < d && a.fused_target != TGT_NONE) ? a.t_mean[gi] : T(0);
+    const T tm = (gi < d && (a.fused_target == TGT_DIAG_GAUSS || a.fused_target == TGT_DENSE_GAUSS)) ? a.t_mean[gi] : T(0);
     const T tis = (gi < d && a.fused_target == TGT_DIAG_GAUSS) ? a.t_istd[gi] : T(0);
 #pragma unroll
     for (int col = cg; col < 32; col += CG) {
@@ -134,12 +134,14 @@ __device__ double tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *
         }
       }
     }
-    if (a.fused_target == TGT_DENSE_GAUSS) {
-      // second pass, lanes along the sample axis: RT[m + i*MP] = z - t_mean (coalesced)
+    if (a.fused_target == TGT_DENSE_GAUSS || a.fused_target == TGT_LOGREG) {
+      // second pass, lanes along the sample axis: RT[m + i*MP] = z - t_mean (coalesced); LogReg wants plain z^T
       const int col = tid & 31;
       for (int r2 = cg; r2 < 32; r2 += CG) {
         const int gi2 = i0 + r2, gm = n0 + col;
-        if (gi2 < d && gm < M) a.RT[(size_t)gi2 * a.MP + gm] = a.params[gi2] + get(r2, col) - a.t_mean[gi2];
+        if (gi2 < d && gm < M)
+          a.RT[(size_t)gi2 * a.MP + gm] =
+              a.params[gi2] + get(r2, col) - (a.fused_target == TGT_DENSE_GAUSS ? a.t_mean[gi2] : T(0));
       }
     }
   } else if (MODE == MODE_DENSE) {
@@ -651,7 +653,7 @@ __global__ __launch_bounds__(256) void k_rt_from_z(int d, int M, int MP, const T
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int col = b + 4 * j, i = i0 + a, m = m0 + col;
-    tile[col][a] = (i < d && m < M) ? Z[(size_t)m * d + i] - t_mean[i] : T(0);
+    tile[col][a] = (i < d && m < M) ? Z[(size_t)m * d + i] - (t_mean ? t_mean[i] : T(0)) : T(0);
   }
   __syncthreads();
 #pragma unroll
@@ -890,12 +892,13 @@ void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, c
 
 void launch_rt_from_z(mivi_ctx *c, int M) {
   dim3 grid((c->cfg.d + 63) / 64, (M + 63) / 64);
+  const void *tm = c->target == TGT_DENSE_GAUSS ? c->t_mean.p : nullptr;   // LogReg: plain transpose
   if (c->cfg.dtype == MIVI_F32)
     hipLaunchKernelGGL(k_rt_from_z<float>, grid, dim3(256), 0, c->stream, c->cfg.d, M, c->MP, (const float *)c->Z.p,
-                       (const float *)c->t_mean.p, (float *)c->RT.p);
+                       (const float *)tm, (float *)c->RT.p);
   else
     hipLaunchKernelGGL(k_rt_from_z<double>, grid, dim3(256), 0, c->stream, c->cfg.d, M, c->MP, (const double *)c->Z.p,
-                       (const double *)c->t_mean.p, (double *)c->RT.p);
+                       (const double *)tm, (double *)c->RT.p);
 }
 
 void launch_fr_stl(mivi_ctx *c, const void *params, int M) {

@@ -7,6 +7,8 @@
 //   funnel         Neal's funnel + Stacked([log, identity])  SURVEY.md 8d (README.md:76-82,102-106 wrapper)
 //   logreg         hierarchical logistic regression           docs/src/tutorials/subsampling.md:26-38 (variant 0)
 //                                                              README.md:42-66,91-106                (variant 1)
+#include <cstdlib>
+
 #include "device_common.h"
 
 namespace mivi {
@@ -261,6 +263,276 @@ __global__ __launch_bounds__(256) void k_lr_finish(LrArgs<T> a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// f32 MFMA route for the two LogReg contractions (v_mfma_f32_32x32x2_f32, 64x64 register blocking per wave,
+// operands straight from L2/HBM in operand layout, double-buffered 16-k stages):
+//   logits  L[r, m] = sum_k X[r + k n] * ZT[m + k ldz]          -> resid stored sample-contiguous R[m + r ldr]
+//   X^T r   G[k, m] = sum_r Xrm[k + r ldx] * R[m + r ldr]        (row range split over gridDim.x, partials)
+// Xrm is a row-major, 32-padded copy of X built once by mivi_set_target_logreg; ZT is the transposed sample
+// matrix the sampling kernel (or k_rt_from_z) leaves in c->RT.  Every load and store is a contiguous 128-byte
+// segment per half-wave.
+// ---------------------------------------------------------------------------------------------
+typedef float lr_f32x16 __attribute__((ext_vector_type(16)));
+
+struct LrMfmaArgs {
+  int d, p, M;
+  long long n;
+  const float *X;      // n x p column-major
+  const float *Xrm;    // n x ldx row-major (zero padded columns)
+  int ldx;
+  const uint8_t *y;
+  const float *ZT;     // ZT[m + k*ldz]
+  int ldz;
+  float *R;            // R[m + r*ldr]
+  int ldr;
+  double *ll_part;     // [gridDim.x][M]
+  float *g_part;       // [S][p*M]
+  long long rows_per_split;
+  int want_grad;
+};
+
+__device__ __forceinline__ float lr_softplus(float x) { return x > 0.f ? x + log1pf(expf(-x)) : log1pf(expf(x)); }
+
+// 128 rows x 128 samples per workgroup, 4 waves as 2 (rows) x 2 (samples), each 64 x 64
+__global__ __launch_bounds__(256) void k_lr_logits_mfma(LrMfmaArgs a) {
+  __shared__ float ll_lds[128];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wm = w & 1;
+  const long long r0 = (long long)blockIdx.x * 128 + wr * 64;
+  const int m0 = blockIdx.y * 128 + wm * 64;
+  if (tid < 128) ll_lds[tid] = 0.f;
+  __syncthreads();
+  // per-lane offsets: A rows (clamped), B columns (ZT is padded to a multiple of 64 columns)
+  const long long ra0 = min(r0 + l31, a.n - 1), ra1 = min(r0 + 32 + l31, a.n - 1);
+  const float *A0 = a.X + ra0, *A1 = a.X + ra1;
+  const float *B0 = a.ZT + m0 + l31, *B1 = a.ZT + m0 + 32 + l31;
+  lr_f32x16 c00, c01, c10, c11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
+  const int p = a.p;
+  const int nst = (p + 15) / 16;
+  float xa0[8], xa1[8], xb0[8], xb1[8], ya0[8], ya1[8], yb0[8], yb1[8];
+  auto load_stage = [&](int st, float (&A0v)[8], float (&A1v)[8], float (&B0v)[8], float (&B1v)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = st * 16 + 2 * u + h;
+      const int kc = min(kk, p - 1);
+      A0v[u] = A0[(size_t)kc * (size_t)a.n];
+      A1v[u] = A1[(size_t)kc * (size_t)a.n];
+      B0v[u] = B0[(size_t)kc * (size_t)a.ldz];
+      B1v[u] = B1[(size_t)kc * (size_t)a.ldz];
+    }
+  };
+  auto mma_stage = [&](int st, const float (&A0v)[8], const float (&A1v)[8], const float (&B0v)[8], const float (&B1v)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = (st * 16 + 2 * u + h) < p;
+      const float x0 = ok ? A0v[u] : 0.f, x1 = ok ? A1v[u] : 0.f;
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, B0v[u], c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, B1v[u], c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, B0v[u], c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, B1v[u], c11, 0, 0, 0);
+    }
+  };
+  int st = 0;
+  load_stage(0, xa0, xa1, xb0, xb1);
+  while (true) {
+    if (st + 1 < nst) load_stage(st + 1, ya0, ya1, yb0, yb1);
+    mma_stage(st, xa0, xa1, xb0, xb1);
+    if (++st >= nst) break;
+    if (st + 1 < nst) load_stage(st + 1, xa0, xa1, xb0, xb1);
+    mma_stage(st, ya0, ya1, yb0, yb1);
+    if (++st >= nst) break;
+  }
+  // epilogue: D element (row = (q&3) + 8*(q>>2) + 4*h, col = l31); rows are data rows, cols are samples
+  float ll0 = 0.f, ll1 = 0.f;   // samples m0 + l31 and m0 + 32 + l31
+  auto epi = [&](const lr_f32x16 &c, int rb, int mb, float &ll) {
+    const int m = m0 + mb * 32 + l31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const long long r = r0 + rb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (r < a.n && m < a.M) {
+        const float yv = (float)a.y[r];
+        const float lg = c[q];
+        ll += yv * lg - lr_softplus(lg);
+        if (a.want_grad) a.R[(size_t)r * a.ldr + m] = yv - 1.f / (1.f + expf(-lg));
+      }
+    }
+  };
+  epi(c00, 0, 0, ll0);
+  epi(c10, 1, 0, ll0);
+  epi(c01, 0, 1, ll1);
+  epi(c11, 1, 1, ll1);
+  ll0 += __shfl_xor(ll0, 32, 64);
+  ll1 += __shfl_xor(ll1, 32, 64);
+  if (h == 0) {
+    atomicAdd(&ll_lds[wm * 64 + l31], ll0);
+    atomicAdd(&ll_lds[wm * 64 + 32 + l31], ll1);
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int m = blockIdx.y * 128 + tid;
+    if (m < a.M) a.ll_part[(size_t)blockIdx.x * a.M + m] = (double)ll_lds[tid];
+  }
+}
+
+// Output G^T tile set: 128 samples x 256 features per workgroup (blockIdx.y = feature half... general: feature
+// group of 256), 8 waves as 2 (samples) x 4 (features), each 64 x 64; rows [rbeg, rend) of split blockIdx.x.
+__global__ __launch_bounds__(512) void k_lr_xtr_mfma(LrMfmaArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wk = w & 3;
+  const int m0 = blockIdx.z * 128 + wm * 64;
+  const int k0 = blockIdx.y * 256 + wk * 64;
+  const long long rbeg = (long long)blockIdx.x * a.rows_per_split;
+  const long long rend = min(a.n, rbeg + a.rows_per_split);
+  const float *A0 = a.R + m0 + l31, *A1 = a.R + m0 + 32 + l31;           // lanes along samples
+  const float *B0 = a.Xrm + k0 + l31, *B1 = a.Xrm + k0 + 32 + l31;       // lanes along features
+  const bool kvalid = k0 < a.ldx;                                         // feature group may exceed the padding
+  lr_f32x16 c00, c01, c10, c11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
+  float xa0[8], xa1[8], xb0[8], xb1[8], ya0[8], ya1[8], yb0[8], yb1[8];
+  const long long nst = kvalid ? (rend - rbeg + 15) / 16 : 0;
+  auto load_stage = [&](long long st, float (&A0v)[8], float (&A1v)[8], float (&B0v)[8], float (&B1v)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long rr = min(rbeg + st * 16 + 2 * u + h, a.n - 1);
+      A0v[u] = A0[(size_t)rr * a.ldr];
+      A1v[u] = A1[(size_t)rr * a.ldr];
+      B0v[u] = B0[(size_t)rr * a.ldx];
+      B1v[u] = (k0 + 32 < a.ldx) ? B1[(size_t)rr * a.ldx] : 0.f;
+    }
+  };
+  auto mma_stage = [&](long long st, const float (&A0v)[8], const float (&A1v)[8], const float (&B0v)[8], const float (&B1v)[8]) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool ok = (rbeg + st * 16 + 2 * u + h) < rend;
+      const float x0 = ok ? A0v[u] : 0.f, x1 = ok ? A1v[u] : 0.f;
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, B0v[u], c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, B1v[u], c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, B0v[u], c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, B1v[u], c11, 0, 0, 0);
+    }
+  };
+  if (nst > 0) {
+    long long st = 0;
+    load_stage(0, xa0, xa1, xb0, xb1);
+    while (true) {
+      if (st + 1 < nst) load_stage(st + 1, ya0, ya1, yb0, yb1);
+      mma_stage(st, xa0, xa1, xb0, xb1);
+      if (++st >= nst) break;
+      if (st + 1 < nst) load_stage(st + 1, xa0, xa1, xb0, xb1);
+      mma_stage(st, ya0, ya1, yb0, yb1);
+      if (++st >= nst) break;
+    }
+  }
+  // D: row = sample (m0 + mb*32 + rowidx), col = feature (k0 + kb*32 + l31): lanes along features -> contiguous stores
+  auto epi = [&](const lr_f32x16 &c, int mb, int kb) {
+    const int k = k0 + kb * 32 + l31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = m0 + mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (k < a.p && m < a.M) a.g_part[((size_t)blockIdx.x * a.M + m) * a.p + k] = c[q];
+    }
+  };
+  epi(c00, 0, 0);
+  epi(c01, 0, 1);
+  epi(c10, 1, 0);
+  epi(c11, 1, 1);
+}
+
+// one-time: row-major zero-padded copy of X (n x p column-major -> n x ldx row-major), 64x64 LDS transpose
+__global__ __launch_bounds__(256) void k_lr_make_xrm(long long n, int p, int ldx, const float *X, float *Xrm) {
+  __shared__ float tile[64][65];
+  const long long r0 = (long long)blockIdx.x * 64;
+  const int k0 = blockIdx.y * 64, tid = threadIdx.x;
+  const int a = tid & 63, b = tid >> 6;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int kc = b + 4 * j;
+    const long long r = r0 + a;
+    const int k = k0 + kc;
+    tile[kc][a] = (r < n && k < p) ? X[(size_t)k * n + r] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int rr = b + 4 * j;
+    const long long r = r0 + rr;
+    const int k = k0 + a;
+    if (r < n && k < ldx) Xrm[(size_t)r * ldx + k] = tile[a][rr];
+  }
+}
+
+void logreg_prepare_f32(mivi_ctx *c) {
+  // builds Xrm in c->lr_Xrm (called by mivi_set_target_logreg for MIVI_F32)
+  const int p = c->cfg.d - 1;
+  const int ldx = (p + 31) / 32 * 32;
+  const size_t bytes = (size_t)c->lr_n * ldx * sizeof(float);
+  if (c->lr_Xrm.bytes < bytes) {
+    if (c->lr_Xrm.p) (void)hipFree(c->lr_Xrm.p);
+    (void)hipMalloc(&c->lr_Xrm.p, bytes);
+    c->lr_Xrm.bytes = bytes;
+  }
+  dim3 grid((unsigned)((c->lr_n + 63) / 64), (ldx + 63) / 64);
+  hipLaunchKernelGGL(k_lr_make_xrm, grid, dim3(256), 0, c->stream, (long long)c->lr_n, p, ldx, (const float *)c->lr_X,
+                     (float *)c->lr_Xrm.p);
+}
+
+static void logreg_mfma(mivi_ctx *c, int M, int want_grad) {
+  LrMfmaArgs a;
+  a.d = c->cfg.d;
+  a.p = a.d - 1;
+  a.M = M;
+  a.n = c->lr_n;
+  a.X = (const float *)c->lr_X;
+  a.Xrm = (const float *)c->lr_Xrm.p;
+  a.ldx = (a.p + 31) / 32 * 32;
+  a.y = c->lr_y;
+  a.ZT = (const float *)c->RT.p;
+  a.ldz = c->MP;
+  a.ldr = (M + 63) / 64 * 64;
+  const int nrb = (int)((a.n + 127) / 128);
+  int S = (int)((a.n + 2047) / 2048);
+  if (S > 256) S = 256;
+  if (S < 1) S = 1;
+  long long rps = (a.n + S - 1) / S;
+  rps = (rps + 15) / 16 * 16;
+  S = (int)((a.n + rps - 1) / rps);
+  a.rows_per_split = rps;
+  a.want_grad = want_grad;
+  const size_t need_R = ((size_t)a.n * a.ldr * sizeof(float) + 255) / 256 * 256;
+  const size_t need_g = (size_t)S * a.p * M * sizeof(float);
+  const size_t need_ll = (size_t)nrb * M * sizeof(double);
+  if (c->lr_scratch.bytes < need_R + need_g) {
+    if (c->lr_scratch.p) (void)hipFree(c->lr_scratch.p);
+    (void)hipMalloc(&c->lr_scratch.p, need_R + need_g);
+    c->lr_scratch.bytes = need_R + need_g;
+  }
+  if (c->lr_part.bytes < need_ll) {
+    if (c->lr_part.p) (void)hipFree(c->lr_part.p);
+    (void)hipMalloc(&c->lr_part.p, need_ll);
+    c->lr_part.bytes = need_ll;
+  }
+  a.R = (float *)c->lr_scratch.p;
+  a.g_part = (float *)((char *)c->lr_scratch.p + need_R);
+  a.ll_part = (double *)c->lr_part.p;
+  hipLaunchKernelGGL(k_lr_logits_mfma, dim3(nrb, (M + 127) / 128), dim3(256), 0, c->stream, a);
+  if (want_grad)
+    hipLaunchKernelGGL(k_lr_xtr_mfma, dim3(S, (a.p + 255) / 256, (M + 127) / 128), dim3(512), 0, c->stream, a);
+  // finish (shared with the generic route)
+  LrArgs<float> f;
+  f.d = a.d; f.p = a.p; f.M = M; f.n = a.n;
+  f.X = a.X; f.y = a.y; f.Z = (const float *)c->Z.p;
+  f.R = nullptr; f.ll_part = a.ll_part; f.g_part = a.g_part;
+  f.S = S; f.nrb = nrb; f.rows_per_split = rps;
+  f.G = (float *)c->W.p; f.ell = (float *)c->ell.p;
+  f.variant = c->lr_variant; f.likeadj = c->lr_likeadj; f.want_grad = want_grad;
+  hipLaunchKernelGGL(k_lr_finish<float>, dim3(M), dim3(256), 0, c->stream, f);
+}
+
 template <typename T>
 static void logreg_impl(mivi_ctx *c, int M, int want_grad) {
   LrArgs<T> a;
@@ -309,7 +581,10 @@ static void logreg_impl(mivi_ctx *c, int M, int want_grad) {
 }
 
 void launch_logreg_target(mivi_ctx *c, int M, int want_grad) {
-  if (c->cfg.dtype == MIVI_F32) logreg_impl<float>(c, M, want_grad); else logreg_impl<double>(c, M, want_grad);
+  static const bool force_generic = getenv("MIVI_LOGREG_GENERIC") != nullptr;
+  if (c->cfg.dtype == MIVI_F32 && c->lr_Xrm.p && !force_generic) logreg_mfma(c, M, want_grad);
+  else if (c->cfg.dtype == MIVI_F32) logreg_impl<float>(c, M, want_grad);
+  else logreg_impl<double>(c, M, want_grad);
 }
 
 }  // namespace mivi

@@ -65,7 +65,7 @@ static mivi_status_t ensure_work(mivi_ctx *c, int M) {
       if ((s = ensure(c, c->sc_part[b], 4 * ncc * d4 * sizeof(double) + 64, false))) return s;
       if ((s = ensure(c, c->ld_part[b], 2 * (size_t)((d + 31) / 32) * sizeof(double) + 64, false))) return s;
     }
-    if (c->target == TGT_DENSE_GAUSS) {
+    if (c->target == TGT_DENSE_GAUSS || (c->target == TGT_LOGREG && c->cfg.dtype == MIVI_F32)) {
       c->RT.bytes = 0;
       if ((s = ensure(c, c->RT, (size_t)c->dP * c->MP * es, true))) return s;
     }
@@ -130,7 +130,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   (void)hipSetDevice(c->cfg.device);
   (void)hipStreamSynchronize(c->stream);
   if (c->graph.exec) (void)hipGraphExecDestroy(c->graph.exec);
-  DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part,
+  DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
                     &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->ticket, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
@@ -265,6 +265,8 @@ mivi_status_t mivi_set_target_logreg(mivi_ctx_t *c, const void *X, const uint8_t
   c->lr_likeadj = likeadj;
   c->t_const = 0.0;
   c->target = TGT_LOGREG;
+  c->cap_M = 0;   // (re)allocate the transposed-sample buffer
+  if (c->cfg.dtype == MIVI_F32) logreg_prepare_f32(c);
   invalidate_graph(c);
   return MIVI_OK;
 }
@@ -377,6 +379,7 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
         vin.ell_part = (const double *)c->ell_part[p].p;
         vin.n_ell_part = fr_dense_blocks(c, M);
       } else {
+        if (c->target == TGT_LOGREG && c->cfg.dtype == MIVI_F32) launch_rt_from_z(c, M);   // Z^T for the MFMA route
         if ((s = eval_generic_target(c, M, want_grad))) return s;
         vin.ell = c->ell.p;
         vin.n_ell = M;
@@ -408,7 +411,8 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
       vin.ell_part = (const double *)c->ell_part[p].p;
       vin.n_ell_part = fr_dense_blocks(c, M);
     } else {
-      launch_fr_sample(c, params, M, TGT_NONE, c->Z.p);
+      const bool lr32 = c->target == TGT_LOGREG && c->cfg.dtype == MIVI_F32;
+      launch_fr_sample(c, params, M, lr32 ? TGT_LOGREG : TGT_NONE, c->Z.p);   // LogReg: also leaves Z^T in RT
       if ((s = eval_generic_target(c, M, want_grad))) return s;
       vin.ell = c->ell.p;
       vin.n_ell = M;

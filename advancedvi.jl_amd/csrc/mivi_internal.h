@@ -185,7 +185,7 @@ struct mivi_ctx {
   // logreg
   const void *lr_X = nullptr;
   const uint8_t *lr_y = nullptr;
-  mivi::DevBuf lr_X_own, lr_y_own, lr_scratch, lr_part;
+  mivi::DevBuf lr_X_own, lr_y_own, lr_scratch, lr_part, lr_Xrm;
   int64_t lr_n = 0;
   int lr_variant = 0;
   double lr_likeadj = 1.0;
@@ -240,6 +240,7 @@ int eps_blocks(const mivi_ctx *c, int M);
 // kernels_targets.hip
 void launch_col_target(mivi_ctx *c, int M, int want_grad);
 void launch_logreg_target(mivi_ctx *c, int M, int want_grad);
+void logreg_prepare_f32(mivi_ctx *c);   // row-major padded copy of X for the MFMA route
 
 // kernels_update.hip
 void launch_finalize(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad);
