@@ -293,13 +293,13 @@ struct LrMfmaArgs {
 
 __device__ __forceinline__ float lr_softplus(float x) { return x > 0.f ? x + log1pf(expf(-x)) : log1pf(expf(x)); }
 
-// 128 rows x 128 samples per workgroup, 4 waves as 2 (rows) x 2 (samples), each 64 x 64
-__global__ __launch_bounds__(256) void k_lr_logits_mfma(LrMfmaArgs a) {
+// 256 rows x 128 samples per workgroup, 8 waves as 4 (rows) x 2 (samples), each 64 x 64
+__global__ __launch_bounds__(512) void k_lr_logits_mfma(LrMfmaArgs a) {
   __shared__ float ll_lds[128];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 1, wm = w & 1;
-  const long long r0 = (long long)blockIdx.x * 128 + wr * 64;
+  const long long r0 = (long long)blockIdx.x * 256 + wr * 64;
   const int m0 = blockIdx.y * 128 + wm * 64;
   if (tid < 128) ll_lds[tid] = 0.f;
   __syncthreads();
@@ -355,8 +355,11 @@ __global__ __launch_bounds__(256) void k_lr_logits_mfma(LrMfmaArgs a) {
       if (r < a.n && m < a.M) {
         const float yv = (float)a.y[r];
         const float lg = c[q];
-        ll += yv * lg - lr_softplus(lg);
-        if (a.want_grad) a.R[(size_t)r * a.ldr + m] = yv - 1.f / (1.f + expf(-lg));
+        // one exp serves both: e = exp(-|x|); softplus = max(x,0) + log1p(e); sigmoid = x>=0 ? 1/(1+e) : e/(1+e)
+        const float e = __expf(-fabsf(lg));
+        const float inv = 1.f / (1.f + e);
+        ll += yv * lg - (fmaxf(lg, 0.f) + log1pf(e));
+        if (a.want_grad) a.R[(size_t)r * a.ldr + m] = yv - (lg >= 0.f ? inv : e * inv);
       }
     }
   };
@@ -466,6 +469,15 @@ __global__ __launch_bounds__(256) void k_lr_make_xrm(long long n, int p, int ldx
   }
 }
 
+// g_part[0][e] = sum_s g_part[s][e] in a fixed order (coalesced over e); k_lr_finish then reads one slab
+__global__ __launch_bounds__(256) void k_lr_greduce(int S, size_t len, float *g_part) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= len) return;
+  float s = g_part[e];
+  for (int i = 1; i < S; ++i) s += g_part[(size_t)i * len + e];
+  g_part[e] = s;
+}
+
 void logreg_prepare_f32(mivi_ctx *c) {
   // builds Xrm in c->lr_Xrm (called by mivi_set_target_logreg for MIVI_F32)
   const int p = c->cfg.d - 1;
@@ -494,7 +506,7 @@ static void logreg_mfma(mivi_ctx *c, int M, int want_grad) {
   a.ZT = (const float *)c->RT.p;
   a.ldz = c->MP;
   a.ldr = (M + 63) / 64 * 64;
-  const int nrb = (int)((a.n + 127) / 128);
+  const int nrb = (int)((a.n + 255) / 256);
   int S = (int)((a.n + 2047) / 2048);
   if (S > 256) S = 256;
   if (S < 1) S = 1;
@@ -519,15 +531,19 @@ static void logreg_mfma(mivi_ctx *c, int M, int want_grad) {
   a.R = (float *)c->lr_scratch.p;
   a.g_part = (float *)((char *)c->lr_scratch.p + need_R);
   a.ll_part = (double *)c->lr_part.p;
-  hipLaunchKernelGGL(k_lr_logits_mfma, dim3(nrb, (M + 127) / 128), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_lr_logits_mfma, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
   if (want_grad)
     hipLaunchKernelGGL(k_lr_xtr_mfma, dim3(S, (a.p + 255) / 256, (M + 127) / 128), dim3(512), 0, c->stream, a);
+  if (want_grad && S > 1) {
+    const size_t len = (size_t)a.p * M;
+    hipLaunchKernelGGL(k_lr_greduce, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, S, len, a.g_part);
+  }
   // finish (shared with the generic route)
   LrArgs<float> f;
   f.d = a.d; f.p = a.p; f.M = M; f.n = a.n;
   f.X = a.X; f.y = a.y; f.Z = (const float *)c->Z.p;
   f.R = nullptr; f.ll_part = a.ll_part; f.g_part = a.g_part;
-  f.S = S; f.nrb = nrb; f.rows_per_split = rps;
+  f.S = 1; f.nrb = nrb; f.rows_per_split = rps;
   f.G = (float *)c->W.p; f.ell = (float *)c->ell.p;
   f.variant = c->lr_variant; f.likeadj = c->lr_likeadj; f.want_grad = want_grad;
   hipLaunchKernelGGL(k_lr_finish<float>, dim3(M), dim3(256), 0, c->stream, f);
