@@ -45,6 +45,10 @@ __device__ __forceinline__ T block_sum(T v, T *red) {
 #define MIVI_STAMP_K(dbgp, kind, slot) do { if ((dbgp) && threadIdx.x == 0 && blockIdx.x < 4096) (dbgp)[((size_t)(kind) * 4096 + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
 #define MIVI_STAMP(dbgp, slot) MIVI_STAMP_K(dbgp, 0, slot)
 
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain outstanding global
+// stores (vmcnt), so fire-and-forget stores do not put an HBM round trip on a loop's critical path.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ uint64_t rng_index(const RngArgs &r) {
   return r.idx_base + (r.idx_ptr ? *r.idx_ptr : 0ull);
 }

@@ -15,6 +15,7 @@
 // assembles the scalar objective from per-workgroup partials (agent-scope atomics both sides;
 // fixed summation order => bitwise reproducible).
 #include "device_common.h"
+#include "optim_rules.h"
 
 namespace mivi {
 
@@ -185,6 +186,214 @@ __global__ __launch_bounds__(256) void k_mf_colreduce(MfArgs<T> a) {
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launch-free SGD loop for the mean-field family with the fused diagonal-Gaussian target:
+// workgroup b owns rows 4b..4b+3 of (mu, sigma) -- the gradient of those rows needs nothing from any other
+// workgroup -- so `n_steps` iterations of {estimate_gradient!, Optimisers.update!, ClipScale}
+// (src/algorithms/common.jl:69-104) run inside ONE kernel with the parameters in registers.  The per-step
+// scalar partials (sum ell, sum 0.5 eps^2, sum log sigma, #non-positive sigma) go to hist[t][k][block] and are
+// assembled into elbo[t] afterwards by k_mf_loop_value.  Arithmetic (and therefore every bit of the result) is
+// identical to the launch-per-step path.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct MfLoopArgs {
+  int d, M, n_steps, rule;      // rule 0 Descent, 1 Adam
+  T *params;                    // [mu; sigma], updated in place
+  T *opt_state;                 // Adam: [m (2d); v (2d)]
+  const T *t_mean, *t_istd;
+  uint64_t seed, idx0;
+  int m_offset, M_total, ent_kind;
+  long long t0;                 // Adam step count before this call
+  double eta, clip_eps, b1, b2, adam_eps;
+  double *hist;                 // [n_steps][4][nblk]
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_mf_sgd_loop(MfLoopArgs<T> a) {
+  __shared__ T xw[10][16];
+  __shared__ double tot[12];
+  __shared__ T cc[2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int rq = blockIdx.x, d = a.d, d4 = (d + 3) >> 2, nblk = gridDim.x;
+  const int M = a.M, n_steps = a.n_steps, rule = a.rule;
+  const bool stl = ent_is_stl(a.ent_kind);
+  const double direct = direct_entropy_coeff(a.ent_kind);
+  const double invM = 1.0 / (double)a.M_total;
+  const T eta = (T)a.eta, b1 = (T)a.b1, b2 = (T)a.b2, aeps = (T)a.adam_eps, ceps = (T)a.clip_eps;
+  const bool clip = a.clip_eps > 0.0;
+  // every lane holds the four (mu, sigma) rows of this workgroup; lane j < 8 additionally owns the optimiser state
+  // of row j (j < 4: mu_j, j >= 4: sigma_{j-4}) and performs that row's update, which is then broadcast
+  T mu[4], sg[4], tm[4], tis[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = min(4 * rq + r, d - 1);
+    mu[r] = a.params[i];
+    sg[r] = a.params[d + i];
+    tm[r] = a.t_mean[i];
+    tis[r] = a.t_istd[i];
+  }
+  const int myrow = lane & 7;
+  const int myi = min(4 * rq + (myrow & 3), d - 1);
+  T st_m = 0, st_v = 0;
+  if (rule == 1) {
+    st_m = a.opt_state[(myrow < 4 ? 0 : d) + myi];
+    st_v = a.opt_state[2 * d + (myrow < 4 ? 0 : d) + myi];
+  }
+  for (int t = 0; t < n_steps; ++t) {
+    T sW[4] = {0, 0, 0, 0}, sWe[4] = {0, 0, 0, 0};
+    T s_ell = 0, s_he = 0;
+    T isg[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) isg[r] = stl ? T(1) / sg[r] : T(0);
+    for (int m = tid; m < M; m += 256) {
+      T e[4];
+      eps_block<T>(a.seed, a.idx0 + (uint64_t)t, (uint64_t)(a.m_offset + m) * (uint64_t)d4 + (uint64_t)rq, e);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = (4 * rq + r) < d;
+        const T er = ok ? e[r] : T(0);
+        const T z = mu[r] + sg[r] * e[r];
+        const T u = (z - tm[r]) * tis[r];
+        if (ok) s_ell += T(-0.5) * u * u;
+        const T w = ok ? (-u * tis[r] + (stl ? er * isg[r] : T(0))) : T(0);
+        s_he += T(0.5) * er * er;
+        sW[r] += w;
+        sWe[r] += w * er;
+      }
+    }
+    {
+      T v[10];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = row16_sum(sW[r]);
+        v[4 + r] = row16_sum(sWe[r]);
+      }
+      v[8] = row16_sum(s_ell);
+      v[9] = row16_sum(s_he);
+      if ((lane & 15) == 0) {
+        const int slot = wv * 4 + (lane >> 4);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) xw[k][slot] = v[k];
+      }
+    }
+    lds_barrier();
+    if (tid < 10) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s += (double)xw[tid][j];
+      tot[tid] = s;
+    } else if (tid >= 16 && tid < 20) {
+      const int r = tid - 16, i = 4 * rq + r;
+      double lg = 0.0, bad = 0.0;
+      if (i < d) {
+        lg = (double)log(sg[r]);
+        bad = (sg[r] > T(0)) ? 0.0 : 1.0;
+      }
+      lg += __shfl_xor(lg, 1, 64);
+      lg += __shfl_xor(lg, 2, 64);
+      bad += __shfl_xor(bad, 1, 64);
+      bad += __shfl_xor(bad, 2, 64);
+      if (r == 0) {
+        tot[10] = lg;
+        tot[11] = bad;
+      }
+    } else if (tid == 64 && rule == 1) {   // Adam bias corrections for this step (one lane of an otherwise idle wave)
+      adam_bias<T>(a.t0 + t + 1, a.b1, a.b2, cc[0], cc[1]);
+    }
+    lds_barrier();
+    if (tid >= 8 && tid < 12) a.hist[((size_t)t * 4 + (tid - 8)) * nblk + rq] = tot[tid];
+    // lane j < 8 of every wave: gradient of row j exactly as k_mf_main writes it (rounded to T), update, clip
+    T mine = (myrow < 4) ? mu[0] : sg[0];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+      if ((myrow & 3) == r) mine = (myrow < 4) ? mu[r] : sg[r];
+    }
+    {
+      const T sgv = (myrow & 3) == 0 ? sg[0] : (myrow & 3) == 1 ? sg[1] : (myrow & 3) == 2 ? sg[2] : sg[3];
+      const double tr = tot[myrow];
+      const T g = (myrow < 4) ? (T)(-tr * invM) : (T)(-tr * invM - direct / (double)sgv);
+      if (rule == 0) mine = descent_step(mine, g, eta);
+      else mine = adam_step<T>(mine, g, st_m, st_v, cc[0], cc[1], eta, b1, b2, aeps);
+      if (clip && myrow >= 4) mine = clip_step(mine, ceps);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      mu[r] = __shfl(mine, r, 8);
+      sg[r] = __shfl(mine, 4 + r, 8);
+    }
+    lds_barrier();   // tot / xw are reused by the next iteration
+  }
+  if (tid < 8) {
+    const int i = 4 * rq + (tid & 3);
+    if (i < d) {
+      const T val = (tid < 4) ? mu[tid & 3] : sg[tid & 3];
+      a.params[(tid < 4 ? 0 : d) + i] = val;
+      if (rule == 1) {
+        a.opt_state[(tid < 4 ? 0 : d) + i] = st_m;
+        a.opt_state[2 * d + (tid < 4 ? 0 : d) + i] = st_v;
+      }
+    }
+  }
+}
+
+// elbo[t] (and the status word) from the per-step partials of k_mf_sgd_loop; one workgroup per step
+template <typename T>
+__global__ __launch_bounds__(256) void k_mf_loop_value(int d, int nblk, int M_local, int M_total, int ent_kind,
+                                                       double ell_const, const double *hist, double *elbo, int *status) {
+  __shared__ double red[4];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  double s[4] = {0, 0, 0, 0};
+  for (int k = 0; k < 4; ++k)
+    for (int i = tid; i < nblk; i += 256) s[k] += hist[((size_t)t * 4 + k) * nblk + i];
+  for (int k = 0; k < 4; ++k) s[k] = block_sum<double, 256>(s[k], red);
+  if (tid == 0) {
+    const double Mt = (double)M_total;
+    const double ent = (ent_is_closed(ent_kind) ? 0.5 * d * (1.0 + kLog2Pi) : s[1] / Mt + 0.5 * d * kLog2Pi) + s[2];
+    const double value = -((s[0] + (double)M_local * ell_const) / Mt + ent);
+    elbo[t] = -value;
+    int st = 0;
+    if (!isfinite(value)) st |= 1;
+    if (s[3] > 0.0) st |= 2;
+    if (st) atomicOr(status, st);
+  }
+}
+
+template <typename T>
+static void mf_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule,
+                             double eta, double clip_eps, double *hist, double *elbo) {
+  MfLoopArgs<T> a;
+  a.d = c->cfg.d;
+  a.M = c->cfg.n_mc;
+  a.n_steps = n_steps;
+  a.rule = rule;
+  a.params = (T *)params;
+  a.opt_state = (T *)opt_state;
+  a.t_mean = (const T *)c->t_mean.p;
+  a.t_istd = (const T *)c->t_istd.p;
+  a.seed = c->cfg.seed;
+  a.idx0 = idx0;
+  a.m_offset = c->cfg.m_offset;
+  a.M_total = c->M_total;
+  a.ent_kind = c->cfg.entropy;
+  a.t0 = t0;
+  a.eta = eta;
+  a.clip_eps = clip_eps;
+  a.b1 = 0.9;
+  a.b2 = 0.999;
+  a.adam_eps = 1e-8;
+  a.hist = hist;
+  const int d4 = (a.d + 3) / 4;
+  hipLaunchKernelGGL(k_mf_sgd_loop<T>, dim3(d4), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_mf_loop_value<T>, dim3(n_steps), dim3(256), 0, c->stream, a.d, d4, a.M, a.M_total, a.ent_kind,
+                     c->t_const, (const double *)hist, elbo, (int *)c->status.p);
+}
+
+void launch_mf_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule,
+                        double eta, double clip_eps, double *hist, double *elbo) {
+  if (c->cfg.dtype == MIVI_F32) mf_sgd_loop_impl<float>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo);
+  else mf_sgd_loop_impl<double>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo);
 }
 
 // rand(rng, q::MvLocationScale{<:Diagonal}, M): Z = mu + sigma .* eps  (location_scale.jl:80-87)

@@ -4,6 +4,7 @@
 //   ClipScale  scale[diagind] = max(scale[diagind], eps)                      src/optimization/clip_scale.jl:18-29
 //   Descent / Adam parameter updates (Optimisers.update!)                     src/algorithms/common.jl:92
 #include "device_common.h"
+#include "optim_rules.h"
 
 namespace mivi {
 
@@ -104,9 +105,7 @@ __global__ void k_clip(int d, int family, T *params, T epsilon) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < d) {
     const size_t o = family == MIVI_MEANFIELD ? (size_t)d + i : (size_t)d + (size_t)i * d + i;
-    const T v = params[o];
-    params[o] = v > epsilon ? v : epsilon;   // max(v, eps); NaN propagates like Julia's max
-    if (v != v) params[o] = v;
+    params[o] = clip_step(params[o], epsilon);
   }
 }
 void launch_clip(mivi_ctx *c, void *params, double epsilon) {
@@ -122,7 +121,7 @@ void launch_clip(mivi_ctx *c, void *params, double epsilon) {
 template <typename T>
 __global__ void k_descent(int64_t n, T *params, const T *grad, T eta) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    params[i] -= eta * grad[i];
+    params[i] = descent_step(params[i], grad[i], eta);
 }
 void launch_descent(mivi_ctx *c, void *params, const void *grad, double eta) {
   const int64_t n = mivi_params_len(c);
@@ -136,19 +135,19 @@ void launch_descent(mivi_ctx *c, void *params, const void *grad, double eta) {
                        eta);
 }
 
-// Optimisers.Adam: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; x -= eta * m/(1-b1^t) / (sqrt(v/(1-b2^t)) + eps)
+// Optimisers.Adam (optim_rules.h); bias corrections once per workgroup
 template <typename T>
 __global__ void k_adam(int64_t n, T *params, const T *grad, T *state, const int64_t *t_ptr, int64_t t_base, double eta,
                        double b1, double b2, double eps) {
-  const int64_t t = t_base + (t_ptr ? *t_ptr : 0);
-  const double c1 = 1.0 - pow(b1, (double)t), c2 = 1.0 - pow(b2, (double)t);
+  __shared__ T cc[2];
+  if (threadIdx.x == 0) adam_bias<T>(t_base + (t_ptr ? *t_ptr : 0), b1, b2, cc[0], cc[1]);
+  __syncthreads();
+  const T c1 = cc[0], c2 = cc[1];
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const double g = (double)grad[i];
-    const double m = b1 * (double)state[i] + (1.0 - b1) * g;
-    const double v = b2 * (double)state[n + i] + (1.0 - b2) * g * g;
-    state[i] = (T)m;
-    state[n + i] = (T)v;
-    params[i] = (T)((double)params[i] - eta * (m / c1) / (sqrt(v / c2) + eps));
+    T m = state[i], v = state[n + i];
+    params[i] = adam_step<T>(params[i], grad[i], m, v, c1, c2, (T)eta, (T)b1, (T)b2, (T)eps);
+    state[i] = m;
+    state[n + i] = v;
   }
 }
 void launch_adam(mivi_ctx *c, void *params, const void *grad, void *state, const int64_t *t_ptr, int64_t t_base,

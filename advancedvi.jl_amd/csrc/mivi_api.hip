@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "mivi_internal.h"
 
@@ -702,10 +703,30 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, 
   prepare_tables(c, c->cfg.n_mc);
   const size_t plen = (size_t)mivi_params_len(c), es = c->esize;
   // internal value/grad/elbo-record buffers
-  if ((s = ensure(c, c->X, (plen + 8) * es + (size_t)n_steps * sizeof(double), false))) return s;
+  const size_t hist_doubles = (size_t)n_steps * 4 * (size_t)((c->cfg.d + 3) / 4);
+  if ((s = ensure(c, c->X, (plen + 8) * es + ((size_t)n_steps + hist_doubles + 8) * sizeof(double), false))) return s;
   char *vbuf = (char *)c->X.p;
   char *gbuf = vbuf + 8 * es;
-  double *rec = (double *)(gbuf + plen * es);
+  double *rec = (double *)(((uintptr_t)(gbuf + plen * es) + 7) & ~(uintptr_t)7);
+  static const bool no_fused_loop = getenv("MIVI_NO_FUSED_LOOP") != nullptr;
+  if (c->cfg.family == MIVI_MEANFIELD && c->target == TGT_DIAG_GAUSS && c->cfg.n_mc <= 4096 && !no_fused_loop) {
+    // launch-free loop: every workgroup owns four rows of (mu, sigma); no graph, two launches for all n_steps
+    HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream));
+    launch_mf_sgd_loop(c, params, opt_state, idx0, (long long)t0, n_steps, rule, eta, clip_eps, rec + n_steps, rec);
+    HIPCHK(c, hipGetLastError());
+    if (elbo) {
+      if (c->cfg.dtype == MIVI_F64) {
+        HIPCHK(c, hipMemcpyAsync(elbo, rec, (size_t)n_steps * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+      } else {
+        std::vector<double> h(n_steps);
+        HIPCHK(c, hipMemcpyAsync(h.data(), rec, (size_t)n_steps * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        std::vector<float> f(h.begin(), h.end());
+        HIPCHK(c, hipMemcpy(elbo, f.data(), (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice));
+      }
+    }
+    return read_status(c);
+  }
   GraphCache &g = c->graph;
   if (!(g.exec && g.kind == 2 + rule && g.count == n_steps && g.params == params && g.aux0 == opt_state && g.p0 == eta &&
         g.p1 == clip_eps && g.value == (void *)vbuf)) {
