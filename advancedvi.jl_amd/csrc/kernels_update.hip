@@ -118,49 +118,62 @@ void launch_clip(mivi_ctx *c, void *params, double epsilon) {
                        (double *)params, epsilon);
 }
 
-template <typename T>
-__global__ void k_descent(int64_t n, T *params, const T *grad, T eta) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    params[i] = descent_step(params[i], grad[i], eta);
+// is flat index i a scale-diagonal entry? (ClipScale fused into the update, clip_eps > 0)
+__device__ __forceinline__ bool is_scale_diag(int64_t i, int d, int family) {
+  if (i < d) return false;
+  if (family == MIVI_MEANFIELD) return true;
+  const int64_t e = i - d;
+  return (e / d) == (e % d);
 }
-void launch_descent(mivi_ctx *c, void *params, const void *grad, double eta) {
+
+template <typename T>
+__global__ void k_descent(int64_t n, T *params, const T *grad, T eta, int d, int family, T clip_eps) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    T x = descent_step(params[i], grad[i], eta);
+    if (clip_eps > T(0) && is_scale_diag(i, d, family)) x = clip_step(x, clip_eps);
+    params[i] = x;
+  }
+}
+void launch_descent(mivi_ctx *c, void *params, const void *grad, double eta, double clip_eps) {
   const int64_t n = mivi_params_len(c);
   int nb = (int)((n + 255) / 256);
   if (nb > 2048) nb = 2048;
   if (c->cfg.dtype == MIVI_F32)
     hipLaunchKernelGGL(k_descent<float>, dim3(nb), dim3(256), 0, c->stream, n, (float *)params, (const float *)grad,
-                       (float)eta);
+                       (float)eta, c->cfg.d, c->cfg.family, (float)clip_eps);
   else
     hipLaunchKernelGGL(k_descent<double>, dim3(nb), dim3(256), 0, c->stream, n, (double *)params, (const double *)grad,
-                       eta);
+                       eta, c->cfg.d, c->cfg.family, clip_eps);
 }
 
 // Optimisers.Adam (optim_rules.h); bias corrections once per workgroup
 template <typename T>
 __global__ void k_adam(int64_t n, T *params, const T *grad, T *state, const int64_t *t_ptr, int64_t t_base, double eta,
-                       double b1, double b2, double eps) {
+                       double b1, double b2, double eps, int d, int family, T clip_eps) {
   __shared__ T cc[2];
   if (threadIdx.x == 0) adam_bias<T>(t_base + (t_ptr ? *t_ptr : 0), b1, b2, cc[0], cc[1]);
   __syncthreads();
   const T c1 = cc[0], c2 = cc[1];
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     T m = state[i], v = state[n + i];
-    params[i] = adam_step<T>(params[i], grad[i], m, v, c1, c2, (T)eta, (T)b1, (T)b2, (T)eps);
+    T x = adam_step<T>(params[i], grad[i], m, v, c1, c2, (T)eta, (T)b1, (T)b2, (T)eps);
+    if (clip_eps > T(0) && is_scale_diag(i, d, family)) x = clip_step(x, clip_eps);
+    params[i] = x;
     state[i] = m;
     state[n + i] = v;
   }
 }
 void launch_adam(mivi_ctx *c, void *params, const void *grad, void *state, const int64_t *t_ptr, int64_t t_base,
-                 double eta, double b1, double b2, double eps) {
+                 double eta, double b1, double b2, double eps, double clip_eps) {
   const int64_t n = mivi_params_len(c);
   int nb = (int)((n + 255) / 256);
   if (nb > 2048) nb = 2048;
   if (c->cfg.dtype == MIVI_F32)
     hipLaunchKernelGGL(k_adam<float>, dim3(nb), dim3(256), 0, c->stream, n, (float *)params, (const float *)grad,
-                       (float *)state, t_ptr, t_base, eta, b1, b2, eps);
+                       (float *)state, t_ptr, t_base, eta, b1, b2, eps, c->cfg.d, c->cfg.family, (float)clip_eps);
   else
     hipLaunchKernelGGL(k_adam<double>, dim3(nb), dim3(256), 0, c->stream, n, (double *)params, (const double *)grad,
-                       (double *)state, t_ptr, t_base, eta, b1, b2, eps);
+                       (double *)state, t_ptr, t_base, eta, b1, b2, eps, c->cfg.d, c->cfg.family, clip_eps);
 }
 
 __global__ void k_bump(uint64_t *ctr, uint64_t by) { *ctr += by; }

@@ -748,11 +748,10 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, 
       chn.next_rng.idx_ptr = r.idx_ptr;
       s = run_estimate(c, params, r, c->cfg.n_mc, 1, o, &chn);
       if (s) break;
-      if (rule == 0)
-        launch_descent(c, params, gbuf, eta);
+      if (rule == 0)   // update and ClipScale in one launch
+        launch_descent(c, params, gbuf, eta, clip_eps);
       else
-        launch_adam(c, params, gbuf, opt_state, (const int64_t *)c->d_idx.p + 1, (int64_t)i + 1, eta, 0.9, 0.999, 1e-8);
-      if (clip_eps > 0.0) launch_clip(c, params, clip_eps);
+        launch_adam(c, params, gbuf, opt_state, (const int64_t *)c->d_idx.p + 1, (int64_t)i + 1, eta, 0.9, 0.999, 1e-8, clip_eps);
     }
     if (s == MIVI_OK) flush_chain(c, params, &chn);
     c->cur = 0;

@@ -248,9 +248,9 @@ void logreg_prepare_f32(mivi_ctx *c);   // row-major padded copy of X for the MF
 void launch_finalize(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad);
 void launch_value_only(mivi_ctx *c, const void *params, const ValueIn &vin, const OutArgs &out);   // on c->stream
 void launch_clip(mivi_ctx *c, void *params, double epsilon);
-void launch_descent(mivi_ctx *c, void *params, const void *grad, double eta);
+void launch_descent(mivi_ctx *c, void *params, const void *grad, double eta, double clip_eps = 0.0);
 void launch_adam(mivi_ctx *c, void *params, const void *grad, void *state, const int64_t *t_ptr, int64_t t_base,
-                 double eta, double b1, double b2, double eps);
+                 double eta, double b1, double b2, double eps, double clip_eps = 0.0);
 void launch_bump(mivi_ctx *c, uint64_t *ctr, uint64_t by);
 
 }  // namespace mivi
