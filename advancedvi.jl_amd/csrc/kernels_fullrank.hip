@@ -108,7 +108,8 @@ __device__ __forceinline__ void tile_coords(const int d, const int M, int &ib, i
 // (only meaningful for diagonal VJP tiles).  NT threads, all participate.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int MODE, int NT, typename Get>
-__device__ double tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *rs_lds, double *red) {
+__device__ double tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *rs_lds, double *red,
+                                const T *cii_lds = nullptr) {
   const int tid = threadIdx.x;
   const int d = a.d, M = a.M;
   const int i0 = ib * 32, n0 = cb * 32;
@@ -176,7 +177,7 @@ __device__ double tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *
           o = v;
         } else {
           double x = -(double)v * invM;
-          if (gi == gj) x -= direct / (double)a.params[d + (size_t)gi * d + gi];
+          if (gi == gj) x -= direct / (double)(cii_lds ? cii_lds[row] : a.params[d + (size_t)gi * d + gi]);
           o = (T)x;
         }
         dst[d + (size_t)gj * d + gi] = o;
@@ -194,21 +195,21 @@ __device__ double tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *
         for (int g = 0; g < CG; ++g) s += (double)rs_lds[tid + 32 * g];
         const int gr = i0 + tid;
         if (gr < d) dst[gr] = a.out.partials_mode ? (T)s : (T)(-s * invM);
-        double lg = 0.0, bad = 0.0;
+        T lg = 0, bad = 0;
         if (gr < d) {
-          const T cii = a.params[d + (size_t)gr * d + gr];
-          lg = (double)log(cii);
-          bad = (cii > T(0)) ? 0.0 : 1.0;
+          const T cii = cii_lds ? cii_lds[tid] : a.params[d + (size_t)gr * d + gr];
+          lg = log(cii);
+          bad = (cii > T(0)) ? T(0) : T(1);
         }
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
+        for (int o = 16; o > 0; o >>= 1) {   // lanes 0..31 of wave 0
           lg += __shfl_xor(lg, o, 64);
           bad += __shfl_xor(bad, o, 64);
         }
         if (tid == 0 && a.ld_part) {
           const int nbk = (d + 31) >> 5;
-          a.ld_part[ib] = lg;
-          a.ld_part[nbk + ib] = bad;
+          a.ld_part[ib] = (double)lg;
+          a.ld_part[nbk + ib] = (double)bad;
         }
       }
     }
@@ -424,6 +425,7 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
   constexpr int NSEG = (MODE == MODE_SAMPLE) ? 2 : 1;
   __shared__ float red_acc[NSEG][NW][16 * 65];
   __shared__ float rs_lds[NT];
+  __shared__ float cii_lds[32];
   __shared__ double red[NW];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
     if (tid == 0 && MODE != MODE_VJP) a.ell_part[widx] = 0.0;
     return;
   }
+  if (a.dbg && threadIdx.x == 0 && blockIdx.x < 4096) a.dbg[((size_t)MODE * 4096 + blockIdx.x) * 8 + 5] = ((long long)wk.x << 16) | wk.y;
 
   // ---- segments and the K split -----------------------------------------------------------------
   const int nb = (d + 31) >> 5;
@@ -473,6 +476,10 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
   float rs = 0.f, rs_dummy = 0.f;
   const bool want_rs = (MODE == MODE_VJP) && (seg_ib[0] == cb);   // row sums only on diagonal tiles
+  if (MODE == MODE_VJP && want_rs && tid < 32) {                    // C_ii of this diagonal block: issue the loads now
+    const int gr = seg_ib[0] * 32 + tid;
+    cii_lds[tid] = gr < d ? a.params[d + (size_t)gr * d + gr] : 1.f;
+  }
   if (MODE == MODE_SAMPLE && ALIGNED) {
     run_pair_sample(a, seg_ib[0], seg_ib[1], cb, min(u0, seg_kb[0]), min(u1, seg_kb[0]), max(u0, seg_kb[0]) - seg_kb[0],
                     max(u1, seg_kb[0]) - seg_kb[0], acc0, acc1);
@@ -508,7 +515,7 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
       for (int ww = 1; ww < NW; ++ww) s += red_acc[sg][ww][off];
       return s;
     };
-    ell_acc += tile_epilogue<float, MODE, NT>(a, seg_ib[sg], cb, get, rs_lds, red);
+    ell_acc += tile_epilogue<float, MODE, NT>(a, seg_ib[sg], cb, get, rs_lds, red, cii_lds);
   }
   if (MODE != MODE_VJP && (MODE == MODE_DENSE || a.fused_target == TGT_DIAG_GAUSS)) {
     const double s = block_sum<double, NT>(ell_acc, red);
@@ -676,6 +683,20 @@ static void upload_tab(mivi_ctx *c, DevBuf &b, const std::vector<int2> &t) {
   (void)hipMemcpy(b.p, t.data(), bytes, hipMemcpyHostToDevice);
 }
 
+// move work from the fullest to the emptiest XCD list until they differ by at most one item
+static void rebalance(std::vector<std::vector<int2>> &lists) {
+  while (true) {
+    int mx = 0, mn = 0;
+    for (int x = 1; x < 8; ++x) {
+      if (lists[x].size() > lists[mx].size()) mx = x;
+      if (lists[x].size() < lists[mn].size()) mn = x;
+    }
+    if (lists[mx].size() <= lists[mn].size() + 1) break;
+    lists[mn].push_back(lists[mx].back());
+    lists[mx].pop_back();
+  }
+}
+
 static std::vector<int2> interleave_xcd(const std::vector<std::vector<int2>> &lists) {
   size_t L = 0;
   for (auto &l : lists) L = l.size() > L ? l.size() : L;
@@ -725,6 +746,7 @@ static void ensure_tabs(mivi_ctx *c, int M) {
           if (lists[x].size() < lists[best].size()) best = x;
         lists[best].insert(lists[best].end(), sb.begin(), sb.end());
       }
+      rebalance(lists);
     } else {
       int t = 0;
       for (int ib = 0; ib < nb; ++ib)

@@ -48,3 +48,15 @@ if ok.sum():
     cyc = t[ok, 7] - t[ok, 6]
     wall_us = (t[ok, 2] - t[ok, 0]) * ns / 1e3
     print(f"  shader clock during main loop: median {np.median(cyc / wall_us) / 1e3:.2f} GHz  (cycles {np.median(cyc):.0f} over {np.median(wall_us):.2f} us)")
+
+ok = (t[:, 5] > 0) | True
+end = (t[:, 3] - t0) * ns / 1e3
+tile = t[:, 5].astype(np.int64)
+ib, jb = tile >> 16, tile & 0xFFFF
+order = np.argsort(-end)[:12]
+print("  slowest blocks (end us, ib, jb, start us, main, reduce, epi):")
+for o in order:
+    print(f"    {end[o]:6.2f}  ib={ib[o]:2d} jb={jb[o]:2d}  start {(t[o,0]-t0)*ns/1e3:5.2f}  main {(t[o,1]-t[o,0])*ns/1e3:5.2f}  red {(t[o,2]-t[o,1])*ns/1e3:5.2f}  epi {(t[o,3]-t[o,2])*ns/1e3:5.2f}")
+if which == 3:
+    diag = ib == jb
+    print(f"  diag tiles: end median {np.median(end[diag]):.2f} max {end[diag].max():.2f}; off-diag: median {np.median(end[~diag]):.2f} max {end[~diag].max():.2f}")
