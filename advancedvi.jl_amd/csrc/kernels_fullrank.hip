@@ -650,6 +650,159 @@ __global__ __launch_bounds__(256) void k_fr_stl(FrArgs<T> a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// STL term, f32 MFMA route:  W += X,  C^T X = eps  (blocked back substitution).
+//   pre-kernel  k_stl_prep : CT[i + k*dP] = C[k, i]  (the lower triangle transposed, so that the update's A operand
+//               has its lanes along the output row) and DinvT[b][i + 32 k] = (C_bb^{-1})[k, i] for every 32x32
+//               diagonal block b (forward substitution, one workgroup per block).
+//   main kernel k_stl_solve: one workgroup per 32 sample columns; X (dP x 32) lives in LDS as x[k][m].
+//               for b = nb-1 .. 0:  S = sum_{j>b} CT(b, j) X_j   (32-k units split over the waves, MFMA, LDS reduce)
+//                                   X_b = DinvT_b (eps_b - S)     (16 MFMAs)
+//               The column groups are independent, the row blocks are inherently sequential: the reference's
+//               docs call this estimator O(d^3) per step for the same reason (docs/src/klminrepgraddescent.md:93-95).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stl_prep(int d, int dP, const float *C, float *CT, float *DinvT) {
+  __shared__ float tile[32][33];
+  const int nb = (d + 31) >> 5;
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x < nb) {          // ---- inverse of diagonal block b ----
+    const int b = blockIdx.x, i0 = b * 32;
+    for (int t = tid; t < 1024; t += 256) {
+      const int r = t & 31, c = t >> 5;         // D[r][c], lower triangular (identity on padding)
+      const int gr = i0 + r, gc = i0 + c;
+      float v = 0.f;
+      if (gr < d && gc < d && gr >= gc) v = C[(size_t)gc * d + gr];
+      if (gr >= d && r == c) v = 1.f;
+      tile[r][c] = v;
+    }
+    __syncthreads();
+    if (tid < 32) {                     // lane c: column c of D^{-1} by forward substitution
+      const int c = tid;
+      float y[32];
+#pragma unroll
+      for (int r = 0; r < 32; ++r) y[r] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        float sacc = (r == c) ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < r; ++k) sacc -= tile[r][k] * y[k];
+        y[r] = sacc / tile[r][r];
+      }
+#pragma unroll
+      for (int r = 0; r < 32; ++r) DinvT[(size_t)b * 1024 + c + 32 * r] = y[r];   // DinvT[i=c][k=r] = Dinv[r][c]
+    }
+    return;
+  }
+  // ---- transpose tile (ib, jb), ib >= jb: CT[(jb*32 + c) + (ib*32 + r)*dP] = C[ib*32 + r, jb*32 + c] ----
+  int ib, jb;
+  tri_tile((int)blockIdx.x - nb, ib, jb);
+  for (int t = tid; t < 1024; t += 256) {
+    const int r = t & 31, c = t >> 5;
+    const int gr = ib * 32 + r, gc = jb * 32 + c;
+    tile[c][r] = (gr < d && gc < d && gr >= gc) ? C[(size_t)gc * d + gr] : 0.f;
+  }
+  __syncthreads();
+  for (int t = tid; t < 1024; t += 256) {
+    const int c = t & 31, r = t >> 5;
+    CT[(size_t)(ib * 32 + r) * dP + jb * 32 + c] = tile[c][r];
+  }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_stl_solve(FrArgs<float> a, const float *CT, const float *DinvT) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *x = (float *)smem_raw;                           // x[k*32 + m], k < dP
+  const int d = a.d, M = a.M, dP = a.dP;
+  float *part = x + (size_t)dP * 32;                      // part[w][16*64] (read along columns: no padding needed)
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * 32;
+  const int nb = (d + 31) >> 5;
+  // rhs: x[k][m] = eps[k, m0 + m]  (eps[i + m*dP], zero padded)
+  for (int t = tid; t < dP * 32; t += NW * 64) {
+    const int k = t % dP, m = t / dP;                     // lanes along k: coalesced global reads
+    x[k * 32 + m] = a.eps[(size_t)(m0 + m) * dP + k];
+  }
+  __syncthreads();
+  for (int b = nb - 1; b >= 0; --b) {
+    // wave 0 will need DinvT_b at the end of this step: issue those loads first (independent of X)
+    float dv[16];
+    if (w == 0) {
+      const float *Di = DinvT + (size_t)b * 1024 + l31;   // A[i][k] = DinvT[i + 32 k]
+#pragma unroll
+      for (int u = 0; u < 16; ++u) dv[u] = Di[32 * (2 * u + h)];
+    }
+    // ---- S = sum_{j > b} CT(b, j) X_j : units j = b+1 .. nb-1 dealt round-robin to the waves; the A operands of
+    //      the next unit are in flight while the current one multiplies ----
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float *Arow = CT + b * 32 + l31;                // A[i][k] = CT[(b*32+i) + k*dP]
+    float av0[16], av1[16];
+    auto loadA = [&](int j, float (&av)[16]) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) av[u] = Arow[(size_t)(j * 32 + 2 * u + h) * dP];
+    };
+    auto mma = [&](int j, const float (&av)[16]) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float bv = x[(j * 32 + 2 * u + h) * 32 + l31];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv, acc, 0, 0, 0);
+      }
+    };
+    int j = b + 1 + w;
+    if (j < nb) {
+      loadA(j, av0);
+      while (true) {
+        if (j + NW < nb) loadA(j + NW, av1);
+        mma(j, av0);
+        j += NW;
+        if (j >= nb) break;
+        if (j + NW < nb) loadA(j + NW, av0);
+        mma(j, av1);
+        j += NW;
+        if (j >= nb) break;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[w * (16 * 64) + r * 64 + lane] = acc[r];
+    __syncthreads();
+    // ---- R = eps_b - S  (written back over x_b), then X_b = DinvT_b R by wave 0 ----
+    for (int t = tid; t < 1024; t += NW * 64) {
+      const int row = t >> 5, col = t & 31;               // lanes along m
+      const int r = (row & 3) + 4 * (row >> 3), hh = (row >> 2) & 1;
+      const int off = r * 64 + col + 32 * hh;
+      float sacc = part[off];
+#pragma unroll
+      for (int ww = 1; ww < NW; ++ww) sacc += part[ww * (16 * 64) + off];
+      x[(b * 32 + row) * 32 + col] -= sacc;
+    }
+    __syncthreads();
+    if (w == 0) {
+      f32x16 xa;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xa[r] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float bv = x[(b * 32 + 2 * u + h) * 32 + l31];
+        xa = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[u], bv, xa, 0, 0, 0);
+      }
+      // all reads of x_b are done (same wave, in order): overwrite with the solution
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        x[(b * 32 + row) * 32 + l31] = xa[r];
+      }
+    }
+    __syncthreads();
+  }
+  // W[i + m*d] += X[i, m]
+  for (int t = tid; t < dP * 32; t += NW * 64) {
+    const int i = t % dP, m = t / dP;
+    if (i < d && m0 + m < M) a.W[(size_t)(m0 + m) * d + i] += x[i * 32 + m];
+  }
+}
+
 // RT[m + i*MP] = Z[i + m*d] - t_mean[i]: feeds the dense-Gaussian target product when Z was not
 // produced by the full-rank sample kernel (mean-field family).  64x64 LDS-tiled transpose.
 template <typename T>
@@ -925,15 +1078,40 @@ void launch_rt_from_z(mivi_ctx *c, int M) {
 
 void launch_fr_stl(mivi_ctx *c, const void *params, int M) {
   const int nblk = (M + 7) / 8;
+  static const bool old_stl = getenv("MIVI_STL_VALU") != nullptr;
+  const size_t sh_mfma = ((size_t)c->dP * 32 + 8 * 16 * 64) * sizeof(float);
+  if (c->cfg.dtype == MIVI_F32 && c->stl_CT.p && sh_mfma <= 160 * 1024 && !old_stl) {
+    FrArgs<float> a = fr_args<float>(c, params, M);
+    const int nb = (c->cfg.d + 31) / 32;
+    hipLaunchKernelGGL(k_stl_prep, dim3(nb + nb * (nb + 1) / 2), dim3(256), 0, c->stream, c->cfg.d, c->dP,
+                       (const float *)params + c->cfg.d, (float *)c->stl_CT.p, (float *)c->stl_Dinv.p);
+    static size_t attr_set = 0;   // raise the dynamic-LDS cap once per size (the call is slow)
+    if (attr_set < sh_mfma) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stl_solve<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sh_mfma);
+      attr_set = sh_mfma;
+    }
+    hipLaunchKernelGGL(k_stl_solve<8>, dim3((M + 31) / 32), dim3(512), sh_mfma, c->stream, a, (const float *)c->stl_CT.p,
+                       (const float *)c->stl_Dinv.p);
+    return;
+  }
   if (c->cfg.dtype == MIVI_F32) {
     FrArgs<float> a = fr_args<float>(c, params, M);
     const size_t sh = (8 * (size_t)c->dP + 32 * 33) * sizeof(float);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_stl<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    static size_t attr_f = 0;
+    if (attr_f < sh) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_stl<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      attr_f = sh;
+    }
     hipLaunchKernelGGL(k_fr_stl<float>, dim3(nblk), dim3(256), sh, c->stream, a);
   } else {
     FrArgs<double> a = fr_args<double>(c, params, M);
     const size_t sh = (8 * (size_t)c->dP + 32 * 33) * sizeof(double);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_stl<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    static size_t attr_d = 0;
+    if (attr_d < sh) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fr_stl<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      attr_d = sh;
+    }
     hipLaunchKernelGGL(k_fr_stl<double>, dim3(nblk), dim3(256), sh, c->stream, a);
   }
 }

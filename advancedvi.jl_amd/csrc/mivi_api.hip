@@ -70,6 +70,11 @@ static mivi_status_t ensure_work(mivi_ctx *c, int M) {
       c->RT.bytes = 0;
       if ((s = ensure(c, c->RT, (size_t)c->dP * c->MP * es, true))) return s;
     }
+    if (c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 &&
+        (c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD)) {
+      if ((s = ensure(c, c->stl_CT, (size_t)c->dP * c->dP * sizeof(float), true))) return s;
+      if ((s = ensure(c, c->stl_Dinv, (size_t)((d + 31) / 32) * 1024 * sizeof(float), false))) return s;
+    }
     if ((s = ensure(c, c->Z, (size_t)d * capM * es, false))) return s;
     if ((s = ensure(c, c->W, (size_t)d * capM * es, false))) return s;
     if ((s = ensure(c, c->ell, (size_t)capM * es, false))) return s;
@@ -134,7 +139,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->ticket, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->ticket, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t e : c->cap_events) (void)hipEventDestroy(e);
@@ -421,7 +426,7 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
     if (want_grad) {
       if (out.ent_kind == MIVI_ENT_STL || out.ent_kind == MIVI_ENT_STL_ZERO_GRAD) {
         const size_t sh = (8 * (size_t)c->dP + 32 * 33) * c->esize;
-        if (sh > 160 * 1024) return fail(c, MIVI_ERR_UNSUPPORTED, "full-rank STL: d too large for the LDS-resident solve");
+        if (sh > 160 * 1024 && !c->stl_CT.p) return fail(c, MIVI_ERR_UNSUPPORTED, "full-rank STL: d too large for the LDS-resident solve");
         launch_fr_stl(c, params, M);
       }
       EpsJob nx{};

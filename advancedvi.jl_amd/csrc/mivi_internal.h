@@ -201,6 +201,7 @@ struct mivi_ctx {
   // and the value assembly of estimate t overlap the contractions of the neighbouring estimates
   mivi::DevBuf eps[2], epsT[2], ell_part[2], he_part[2], sc_part[2], ld_part[2];
   mivi::DevBuf tabA, tabB, tabD;   // XCD-aware work tables of the MFMA kernels
+  mivi::DevBuf stl_CT, stl_Dinv;   // transposed scale + inverted diagonal blocks (full-rank STL, f32)
   int nA = 0, nB = 0, nD = 0, tab_M = -1;
   int cur = 0;
   int mf_nblk = 0;
