@@ -111,8 +111,9 @@ __device__ void finalize_value_block(int d, const ValueIn &vin, const OutArgs &o
     const double sum_ell = s_ell + (double)out.M_local * vin.ell_const;
     if (out.partials_mode) {
       T *p = (T *)out.partials;
-      p[plen] = (T)sum_ell;
-      p[plen + 1] = (T)s_he;
+      (void)plen;
+      p[out.scalars_off] = (T)sum_ell;
+      p[out.scalars_off + 1] = (T)s_he;
     } else {
       const double Mt = (double)out.M_total;
       const double ent = (ent_is_closed(out.ent_kind) ? 0.5 * d * (1.0 + kLog2Pi) : s_he / Mt + 0.5 * d * kLog2Pi) + s_ld;

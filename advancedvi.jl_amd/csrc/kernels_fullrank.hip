@@ -168,13 +168,15 @@ __device__ double tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *
 #pragma unroll
     for (int col = cg; col < 32; col += CG) {
       const int gj = n0 + col;
+      if (a.out.partials_mode) {   // shard partials: packed lower triangle, nothing above the diagonal
+        if (gi < d && gj <= gi) dst[d + (size_t)gj * d - ((size_t)gj * (gj - 1)) / 2 + (gi - gj)] = get(row, col);
+        continue;
+      }
       if (gi < d && gj < d) {
         T v = get(row, col);
         T o;
         if (gj > gi) {
           o = T(0);
-        } else if (a.out.partials_mode) {
-          o = v;
         } else {
           double x = -(double)v * invM;
           if (gi == gj) x -= direct / (double)(cii_lds ? cii_lds[row] : a.params[d + (size_t)gi * d + gi]);
@@ -438,7 +440,9 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
     return;
   }
   const int widx = (int)blockIdx.x - (MODE == MODE_VJP ? a.n_pre : 0);
-  if (MODE == MODE_SAMPLE && widx == a.n_work) {          // objective value of the previous estimate
+  // objective value: of the previous estimate (sample kernel, chained mode) or of THIS estimate (VJP kernel,
+  // single calls: everything it sums was written by earlier kernels; log|det C| is taken from the parameters)
+  if ((MODE == MODE_SAMPLE || MODE == MODE_VJP) && widx == a.n_work) {
     const float *pp = a.params;
     finalize_value_block<float, NT, false>(d, a.prev_vin, a.prev_out, (int64_t)d + (int64_t)d * d,
                                            [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, red);
@@ -1035,7 +1039,7 @@ void launch_fr_dense_target(mivi_ctx *c, int M, int want_grad) {
 }
 
 // tril(W eps^T) (+ d/dmu, log-det partials).  next != nullptr: extra leading workgroups generate eps of the NEXT estimate.
-void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const EpsJob *next) {
+void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const EpsJob *next, const ValueJob *self) {
   if (c->cfg.dtype == MIVI_F32) {
     ensure_tabs(c, M);
     FrArgs<float> a = fr_args<float>(c, params, M);
@@ -1043,15 +1047,21 @@ void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, c
     a.work_tab = (const int2 *)c->tabB.p;
     a.n_work = 0x7fffffff;
     int grid = c->nB;
+    if (self) {   // one trailing workgroup assembles this estimate's value (or its two scalar partials)
+      a.n_work = c->nB;
+      a.prev_vin = self->vin;
+      a.prev_out = self->out;
+      grid += 1;
+    }
     if (next) {
       a.n_pre = (eps_blocks(c, M) + 7) / 8 * 8;     // keep (blockIdx - n_pre) % 8 == blockIdx % 8
       a.next_eps = eps_args<float>(c, next->rng, M, next->parity);
       grid += a.n_pre;
     }
     static const int nw_v = getenv("MIVI_NW_VJP") ? atoi(getenv("MIVI_NW_VJP")) : 4;
-    if (c->cfg.d % 32 == 0 && M % 32 == 0 && nw_v == 8 && !next)
+    if (c->cfg.d % 32 == 0 && M % 32 == 0 && nw_v == 8 && !next && !self)
       hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 8, true>), dim3(grid), dim3(512), 0, c->stream, a);
-    else if (c->cfg.d % 32 == 0 && M % 32 == 0 && nw_v == 2 && !next)
+    else if (c->cfg.d % 32 == 0 && M % 32 == 0 && nw_v == 2 && !next && !self)
       hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 2, true>), dim3(grid), dim3(128), 0, c->stream, a);
     else if (c->cfg.d % 32 == 0 && M % 32 == 0)
       hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 4, true>), dim3(grid), dim3(256), 0, c->stream, a);

@@ -27,14 +27,19 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs<T> a) {
   const double invM = 1.0 / (double)a.M_total;
   const double direct = direct_entropy_coeff(a.ent_kind);
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < plen; t += (int64_t)gridDim.x * 256) {
-    double g = -(double)a.partials[t] * invM;
-    if (a.family == MIVI_MEANFIELD) {
+    double g;
+    if (a.family == MIVI_MEANFIELD || t < d) {
+      g = -(double)a.partials[t] * invM;
       if (t >= d) g -= direct / (double)a.params[t];
-    } else if (t >= d) {
+    } else {   // unpack the column-packed lower triangle; the strict upper triangle of the gradient is exact zeros
       const int64_t e = t - d;
-      const int j = (int)(e / d), i = (int)(e - (int64_t)j * d);
-      if (i == j) g -= direct / (double)a.params[t];
-      if (j > i) g = 0.0;
+      const int64_t j = e / d, i = e - j * d;
+      if (j > i) {
+        g = 0.0;
+      } else {
+        g = -(double)a.partials[d + j * d - (j * (j - 1)) / 2 + (i - j)] * invM;
+        if (i == j) g -= direct / (double)a.params[t];
+      }
     }
     a.grad[t] = (T)g;
   }
@@ -48,7 +53,8 @@ __global__ __launch_bounds__(256) void k_finalize(FinArgs<T> a) {
     s_ld = block_sum<double, 256>(s_ld, red);
     bad = block_sum<double, 256>(bad, red);
     if (threadIdx.x == 0) {
-      const double sum_ell = (double)a.partials[plen], s_he = (double)a.partials[plen + 1];
+      const int64_t so = a.family == MIVI_MEANFIELD ? plen : (int64_t)d + ((int64_t)d * (d + 1)) / 2;
+      const double sum_ell = (double)a.partials[so], s_he = (double)a.partials[so + 1];
       const double Mt = (double)a.M_total;
       const double ent = (ent_is_closed(a.ent_kind) ? 0.5 * d * (1.0 + kLog2Pi) : s_he / Mt + 0.5 * d * kLog2Pi) + s_ld;
       const double value = -(sum_ell / Mt + ent);

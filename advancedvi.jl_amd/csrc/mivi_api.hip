@@ -94,7 +94,10 @@ int64_t mivi_params_len(const mivi_ctx_t *c) {
   const int64_t d = c->cfg.d;
   return c->cfg.family == MIVI_MEANFIELD ? 2 * d : d + d * d;
 }
-int64_t mivi_partials_len(const mivi_ctx_t *c) { return mivi_params_len(c) + 2; }
+int64_t mivi_partials_len(const mivi_ctx_t *c) {
+  const int64_t d = c->cfg.d;
+  return (c->cfg.family == MIVI_MEANFIELD ? 2 * d : d + d * (d + 1) / 2) + 2;
+}
 
 mivi_status_t mivi_create(const mivi_config_t *cfg, mivi_ctx_t **out) {
   if (!cfg || !out) return MIVI_ERR_BAD_ARG;
@@ -123,7 +126,7 @@ mivi_status_t mivi_create(const mivi_config_t *cfg, mivi_ctx_t **out) {
   if ((s = ensure(c, c->ticket, 64, true)) || (s = ensure(c, c->status, 64, true)) ||
       (s = ensure(c, c->d_idx, 64, true)) || (s = ensure(c, c->acc, 64, true)) ||
       (s = ensure(c, c->tmp_params, (size_t)mivi_params_len(c) * c->esize, false)) ||
-      (s = ensure(c, c->tmp_out, ((size_t)mivi_partials_len(c) + 8) * c->esize, false))) {
+      (s = ensure(c, c->tmp_out, ((size_t)mivi_params_len(c) + 16) * c->esize, false))) {
     delete c;
     return s;
   }
@@ -155,6 +158,7 @@ mivi_status_t mivi_set_stream(mivi_ctx_t *c, void *s) {
   if (!c) return MIVI_ERR_BAD_ARG;
   if (c->own_stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); c->own_stream = false; }
   c->stream = (hipStream_t)s;   // NULL = the null stream
+  c->pre_valid = false;
   if (c->graph.exec) { (void)hipGraphExecDestroy(c->graph.exec); c->graph = GraphCache{}; }
   return MIVI_OK;
 }
@@ -183,6 +187,7 @@ static mivi_status_t upload_vec(mivi_ctx *c, DevBuf &b, const std::vector<double
   return MIVI_OK;
 }
 static void invalidate_graph(mivi_ctx *c) {
+  c->pre_valid = false;
   if (c->graph.exec) { (void)hipGraphExecDestroy(c->graph.exec); c->graph = GraphCache{}; }
 }
 
@@ -364,7 +369,22 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
   vin.ell_const = c->t_const;
   const int d = c->cfg.d, d4 = (d + 3) / 4;
   const bool chained = ch && ch->on && hetero_ok(c, want_grad) && !out.partials_mode;
-  if (!chained) c->cur = 0;
+  // single calls on the MFMA full-rank path: did the previous call's VJP kernel already generate this estimate's eps?
+  const bool spec = !chained && c->cfg.family == MIVI_FULLRANK && hetero_ok(c, want_grad);
+  bool hit = false;
+  int capturing = 0;
+  unsigned long long cap_id = 0;
+  if (spec) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamGetCaptureInfo(c->stream, &cs, &cap_id) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    capturing = cs == hipStreamCaptureStatusActive;
+    if (!capturing) cap_id = 0;
+    hit = c->pre_valid && c->pre_M == M && c->pre_rng.seed == rng.seed && c->pre_rng.idx_base == rng.idx_base &&
+          c->pre_rng.idx_ptr == rng.idx_ptr && c->pre_rng.m_offset == rng.m_offset && c->pre_capturing == capturing &&
+          c->pre_capture_id == cap_id;
+  }
+  c->pre_valid = false;
+  if (!chained) c->cur = hit ? c->pre_parity : 0;
   const int p = c->cur;
   const ValueJob *prev = (chained && ch->have_prev) ? &ch->prev : nullptr;
 
@@ -404,7 +424,7 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
       }
     }
   } else {
-    if (!chained || ch->first) launch_eps(c, rng, M);   // otherwise generated inside the previous VJP kernel
+    if (chained ? ch->first : !hit) launch_eps(c, rng, M);   // otherwise generated inside the previous VJP kernel
     vin.he_part = (const double *)c->he_part[p].p;
     vin.n_he_part = eps_blocks(c, M);
     if (c->target == TGT_DIAG_GAUSS) {
@@ -435,6 +455,24 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
         nx.rng = ch->next_rng;
         nx.parity = p ^ 1;
         next = &nx;
+      } else if (spec) {   // speculate that the caller asks for estimate idx + 1 next (an SGD loop does)
+        nx.rng = rng;
+        nx.rng.idx_base = rng.idx_base + 1;
+        nx.parity = p ^ 1;
+        next = &nx;
+      }
+      if (spec) {          // this estimate's value rides in the same kernel: no separate value launch
+        ValueJob self{vin, out};
+        launch_fr_vjp(c, params, M, out, next, &self);
+        c->pre_valid = true;
+        c->pre_rng = nx.rng;
+        c->pre_M = M;
+        c->pre_parity = p ^ 1;
+        c->pre_capturing = capturing;
+        c->pre_capture_id = cap_id;
+        if (ch) { ch->have_prev = false; ch->first = true; }
+        HIPCHK(c, hipGetLastError());
+        return MIVI_OK;
       }
       launch_fr_vjp(c, params, M, out, next);
       vin.ld_part = (const double *)c->ld_part[p].p;   // emitted by the VJP kernel's diagonal tiles
@@ -491,6 +529,7 @@ mivi_status_t mivi_sample(mivi_ctx_t *c, const void *params, uint64_t idx, void 
     launch_sample_mf(c, params, rng_of(c, idx), M, Z, eps, d, nullptr);
   } else {
     c->cur = 0;
+    c->pre_valid = false;
     launch_eps(c, rng_of(c, idx), M);
     launch_fr_sample(c, params, M, TGT_NONE, Z);
     if (eps)
@@ -536,6 +575,7 @@ mivi_status_t mivi_estimate_partials(mivi_ctx_t *c, const void *params, uint64_t
   OutArgs o = final_out(c, nullptr, nullptr);
   o.partials = partials;
   o.partials_mode = 1;
+  o.scalars_off = mivi_partials_len(c) - 2;
   return run_estimate(c, params, rng_of(c, idx), c->cfg.n_mc, 1, o);
 }
 
@@ -807,8 +847,10 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
   char *o = (char *)c->tmp_out.p;
   OutArgs out = final_out(c, o, o + 8);
   RngArgs rng = rng_of(c, 0);
+  c->pre_valid = false;
   mivi_status_t s = run_estimate(c, params, rng, M, 1, out);   // warm + populate eps / W / partial buffers
   if (s) return s;
+  if (which != 0) c->pre_valid = false;                        // the stage launches below work on parity 0
   out.M_local = M;
   ValueIn vin{};
   vin.ell_const = c->t_const;
@@ -843,6 +885,7 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
   HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  if (which != 0) c->pre_valid = false;
   if (s) return s;
   *ms_out = (double)ms / reps;
   return MIVI_OK;

@@ -53,6 +53,7 @@ struct OutArgs {
   void *value;       // T[1]           (final mode)
   void *partials;    // T[params_len+2] (partials mode, un-normalised)
   int partials_mode; // 0 final, 1 partials
+  long long scalars_off;  // index of [sum ell, sum 0.5 eps^2] inside the partials buffer
   int ent_kind;
   int M_total;       // global n_samples (normaliser)
   int M_local;
@@ -210,6 +211,13 @@ struct mivi_ctx {
   hipStream_t side_eps = nullptr, side_val = nullptr;   // capture-only fork streams
   std::vector<hipEvent_t> cap_events;
   const uint64_t *idx_src = nullptr;   // mivi_set_index_source
+  // speculative eps prefetch across single calls: the VJP kernel of estimate (seed, idx) also generates eps of
+  // (seed, idx + 1) into the other parity; a following call for exactly that estimate skips its eps kernel
+  bool pre_valid = false;
+  mivi::RngArgs pre_rng{};
+  int pre_M = 0, pre_parity = 0;
+  int pre_capturing = 0;
+  unsigned long long pre_capture_id = 0;
   long long *dbg = nullptr;   // timeline buffer supplied through mivi_debug_timeline (tools only)
   int dP = 0, MP = 0;
 
@@ -230,7 +238,8 @@ void launch_sample_mf(mivi_ctx *c, const void *params, const RngArgs &rng, int M
 // kernels_fullrank.hip
 void launch_eps(mivi_ctx *c, const RngArgs &rng, int M);
 void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, void *Z, const ValueJob *prev = nullptr);
-void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const EpsJob *next = nullptr);
+void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const EpsJob *next = nullptr,
+                   const ValueJob *self = nullptr);
 int fr_ld_blocks(const mivi_ctx *c);
 void prepare_tables(mivi_ctx *c, int M);   // build + upload the MFMA work tables (no-op for f64 / mean-field)
 void launch_fr_dense_target(mivi_ctx *c, int M, int want_grad);

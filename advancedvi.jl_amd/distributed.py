@@ -38,8 +38,9 @@ class ShardPlan:
 
 
 def partials_len(d: int, family: int) -> int:
-    """Length of the shard-additive buffer: params_len + 2 (mivi_partials_len)."""
-    return (2 * d if family == 0 else d + d * d) + 2
+    """Length of the shard-additive buffer (mivi_partials_len): [sum W; sum W (x) eps; sum ell; sum 0.5|eps|^2],
+    the full-rank outer product packed to its lower triangle (d(d+1)/2 entries) so the all-reduce moves half the bytes."""
+    return (2 * d if family == 0 else d + d * (d + 1) // 2) + 2
 
 
 def allreduce_partials(partials, group=None, force=False):

@@ -91,7 +91,9 @@ mivi_status_t mivi_set_stream(mivi_ctx_t *ctx, void *hip_stream);
 mivi_status_t mivi_synchronize(mivi_ctx_t *ctx);
 /* length of `params` / gradient: 2d or d + d*d  (test/families/location_scale.jl:146-155) */
 int64_t mivi_params_len(const mivi_ctx_t *ctx);
-/* length of the shard-additive partials buffer: params_len + 2  ([... ; sum ell ; sum 0.5|eps|^2]) */
+/* length of the shard-additive partials buffer ([sum_m W (d); sum_m W (x) eps; sum ell; sum 0.5|eps|^2]):
+ * mean-field 2d + 2; full-rank d + d(d+1)/2 + 2 -- only the lower triangle travels, packed column by column
+ * (entry (i, j), j <= i, at d + j*d - j(j-1)/2 + (i - j)) so the all-reduce moves half the bytes of the gradient. */
 int64_t mivi_partials_len(const mivi_ctx_t *ctx);
 
 /* ---- targets: the LogDensityProblems plugin seam --------------------------------------------- *

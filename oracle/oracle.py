@@ -349,7 +349,8 @@ def estimate_gradient(params, d, family, prob, eps, ent_kind):
         P_scale = np.tril(W @ eps.T)
         gC = -P_scale / M - direct * np.diag(1.0 / diag)
         grad = np.concatenate([g_mu, gC.reshape(-1, order="F")])
-        partials = np.concatenate([W.sum(axis=1), P_scale.reshape(-1, order="F"), [ell.sum()], [half_eps2.sum()]])
+        packed = np.concatenate([P_scale[j:, j] for j in range(d)])       # lower triangle, column by column
+        partials = np.concatenate([W.sum(axis=1), packed, [ell.sum()], [half_eps2.sum()]])
     value = -(float(np.mean(ell)) + ent)
     return dict(value=value, grad=grad, elbo=-value, Z=Z, ell=ell, G=G, W=W, entropy=ent, partials=partials)
 
@@ -372,7 +373,12 @@ def finalize_partials(partials, params, d, family, ent_kind, M_total):
         g_scale = -partials[d:2 * d] / M_total - direct / diag
         grad = np.concatenate([g_mu, g_scale])
     else:
-        gC = -partials[d:d + d * d].reshape(d, d, order="F") / M_total - direct * np.diag(1.0 / diag)
+        P = np.zeros((d, d))
+        off = d
+        for j in range(d):                                                # unpack column j (rows j..d-1)
+            P[j:, j] = partials[off:off + d - j]
+            off += d - j
+        gC = -P / M_total - direct * np.diag(1.0 / diag)
         grad = np.concatenate([g_mu, gC.reshape(-1, order="F")])
     return -(sum_ell / M_total + ent), grad
 

@@ -165,4 +165,4 @@ def test_shard_plan():
         assert max(plan.count(r) for r in range(w)) - min(plan.count(r) for r in range(w)) <= 1
     with pytest.raises(ValueError):
         ShardPlan(3, 4)
-    assert partials_len(4, 0) == 10 and partials_len(4, 1) == 22
+    assert partials_len(4, 0) == 10 and partials_len(4, 1) == 16

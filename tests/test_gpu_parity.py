@@ -190,3 +190,43 @@ def test_nonpositive_scale_and_nonfinite_status():
     with pytest.warns(UserWarning, match="IdentityOperator"):
         with pytest.raises(RuntimeError, match="diverged"):
             avi.optimize(avi.PhiloxRNG(1), alg, 5, prob, q)
+
+
+@pytest.mark.parametrize("kind", ["diag", "dense"])
+@pytest.mark.parametrize("d,M", [(64, 32), (70, 19), (256, 64)])
+def test_fullrank_speculative_eps_prefetch(d, M, kind):
+    """Single calls on the MFMA full-rank path let the VJP kernel of estimate idx also draw eps of idx + 1 and the
+    following call skip its eps kernel.  Consecutive indices (prefetch hits), a jump (miss), the partials route and
+    an interleaved sample() must all give exactly what a fresh context gives for the same (seed, idx)."""
+    rng = np.random.default_rng(99 + d)
+    q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
+    prob, _ = make_problem(rng, kind, d, np.float32)
+    params, _ = avi.destructure(q)
+    ent = avi.MonteCarloEntropy().code
+
+    def fresh(idx):
+        c = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
+        c.set_problem(prob)
+        v, g = c.estimate_gradient(params, idx)
+        out = (float(v.item()), g.cpu().numpy().copy())
+        c.close()
+        return out
+
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
+    ctx.set_problem(prob)
+    seq = [5, 6, 7, 3, 4, 4, 9]
+    want = {i: fresh(i) for i in set(seq)}
+    for n, idx in enumerate(seq):
+        if n == 4:
+            ctx.sample(params, 1234)          # touches the eps buffers: the pending prefetch must be dropped
+        if n % 2 == 0:
+            v, g = ctx.estimate_gradient(params, idx)
+        else:
+            v, g = ctx.finalize(params, ctx.estimate_partials(params, idx))
+        v, g = float(v.item()), g.cpu().numpy()
+        if n % 2 == 0:
+            assert v == want[idx][0] and np.array_equal(g, want[idx][1]), (n, idx)
+        else:                                  # partials route: same sums, normalised in a different kernel
+            assert abs(v - want[idx][0]) <= 2e-6 * abs(want[idx][0])
+            assert np.linalg.norm(g - want[idx][1]) <= 2e-6 * max(np.linalg.norm(want[idx][1]), 1.0)
+    ctx.close()
