@@ -163,10 +163,12 @@ mivi_status_t mivi_set_stream(mivi_ctx_t *c, void *s) {
   return MIVI_OK;
 }
 
+static mivi_status_t read_status(mivi_ctx *c);
+
+// waits for the context's stream and reports (then clears) the sticky device flags of the estimates since the last read
 mivi_status_t mivi_synchronize(mivi_ctx_t *c) {
   if (!c) return MIVI_ERR_BAD_ARG;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return MIVI_OK;
+  return read_status(c);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -88,6 +88,10 @@ mivi_status_t mivi_destroy(mivi_ctx_t *ctx);
 const char *mivi_last_error(const mivi_ctx_t *ctx);
 int32_t mivi_version(void);
 mivi_status_t mivi_set_stream(mivi_ctx_t *ctx, void *hip_stream);
+/* Wait for the context's stream.  Device entries never synchronise; a non-finite objective or a non-positive scale
+ * diagonal is recorded in a sticky device flag which this call (and the _host entries / mivi_optimize_steps) reads and
+ * clears, returning MIVI_ERR_NONFINITE / MIVI_ERR_NONPOSITIVE_SCALE -- the once-per-step isfinite check of
+ * src/algorithms/common.jl:83-89. */
 mivi_status_t mivi_synchronize(mivi_ctx_t *ctx);
 /* length of `params` / gradient: 2d or d + d*d  (test/families/location_scale.jl:146-155) */
 int64_t mivi_params_len(const mivi_ctx_t *ctx);

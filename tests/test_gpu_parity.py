@@ -192,6 +192,26 @@ def test_nonpositive_scale_and_nonfinite_status():
             avi.optimize(avi.PhiloxRNG(1), alg, 5, prob, q)
 
 
+@pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK])
+def test_device_entries_report_sticky_status_on_synchronize(family):
+    """Device entries never synchronise: a non-positive scale diagonal (the DomainError ClipScale exists to prevent,
+    clip_scale.jl:18-29) is flagged on the device and reported -- once -- by the next mivi_synchronize."""
+    d, M = 32, 16
+    rng = np.random.default_rng(5)
+    q, _ = make_family(rng, d, family, np.float32)
+    prob, _ = make_problem(rng, "diag", d, np.float32)
+    params, _ = avi.destructure(q)
+    params = params.copy()
+    params[d + (3 if family == avi.MEANFIELD else 3 * d + 3)] = -0.25
+    ctx = avi.MiviContext(np.float32, family, d, M, 0, SEED)
+    ctx.set_problem(prob)
+    ctx.estimate_gradient(params, 0)
+    with pytest.raises(Exception, match="scale diagonal"):
+        ctx.synchronize()
+    ctx.synchronize()                      # flag was cleared by the read
+    ctx.close()
+
+
 @pytest.mark.parametrize("kind", ["diag", "dense"])
 @pytest.mark.parametrize("d,M", [(64, 32), (70, 19), (256, 64)])
 def test_fullrank_speculative_eps_prefetch(d, M, kind):
