@@ -90,16 +90,20 @@ __device__ __forceinline__ void tri_tile(int t, int &ib, int &jb) {
 }
 
 template <int MODE>
-__device__ __forceinline__ void tile_coords(const int d, const int M, int &ib, int &nb_col, int &Ktile) {
+__device__ __forceinline__ void tile_coords(const int d, const int M, int &ib, int &nb_col, int &Ktile, int bidx) {
   if (MODE == MODE_VJP) {
-    tri_tile(blockIdx.x, ib, nb_col);
+    tri_tile(bidx, ib, nb_col);
     Ktile = M;
   } else {
     const int ncb = (M + 31) >> 5, nrb = (d + 31) >> 5;
-    ib = nrb - 1 - (int)(blockIdx.x / ncb);   // heavy (large K) tiles dispatch first
-    nb_col = blockIdx.x % ncb;
+    ib = nrb - 1 - bidx / ncb;   // heavy (large K) tiles dispatch first
+    nb_col = bidx % ncb;
     Ktile = (MODE == MODE_SAMPLE) ? min(d, 32 * (ib + 1)) : d;
   }
+}
+template <int MODE>
+__device__ __forceinline__ void tile_coords(const int d, const int M, int &ib, int &nb_col, int &Ktile) {
+  tile_coords<MODE>(d, M, ib, nb_col, Ktile, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -590,6 +594,132 @@ __global__ __launch_bounds__(256) void k_fr_tile_generic(FrArgs<T> a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// MIVI_F64 on the matrix cores: v_mfma_f64_16x16x4_f64 (78.6 TF dense peak).  One 32x32 tile per workgroup
+// (the generic tile map), 8 waves split K in 32-k blocks, each wave holds the tile as 2x2 MFMA blocks.
+//   A operand lane l: A[row = l&15][k = l>>4],  B: B[k = l>>4][col = l&15],  D: col = l&15, row = (l>>4) + 4*reg
+// Operands come straight from L2 (every layout keeps 32 consecutive rows/cols of one k contiguous); loads are
+// unconditional on clamped addresses, masks applied at use.  Same epilogue as the other tile kernels.
+// ---------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma64(FrArgs<double> a) {
+  constexpr int NT = NW * 64, NS = NW / 2;
+  __shared__ double part[NS][32 * 33];   // part[slot][col * 33 + row]
+  __shared__ double rs_lds[NT];
+  __shared__ double red[NW];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int d = a.d, M = a.M;
+  // heterogeneous workgroups, as in the f32 kernel: leading eps(t+1) tiles (VJP), one value workgroup
+  int bidx = (int)blockIdx.x;
+  if (MODE == MODE_VJP) {
+    if (bidx < a.n_pre) {
+      if (tid < 256) eps_tile_block<double>(a.next_eps, bidx, reinterpret_cast<double(*)[17]>(&part[0][0]), red);
+      return;
+    }
+    bidx -= a.n_pre;
+  }
+  if (MODE != MODE_DENSE && bidx == a.n_work) {
+    const double *pp = a.params;
+    finalize_value_block<double, NT, false>(d, a.prev_vin, a.prev_out, (int64_t)d + (int64_t)d * d,
+                                            [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, red);
+    return;
+  }
+  int ib, cb, Ktile;
+  tile_coords<MODE>(d, M, ib, cb, Ktile, bidx);
+  const int i0 = ib * 32, n0 = cb * 32;
+  const int r16 = lane & 15, ks = lane >> 4;
+
+  const double *A, *B;
+  size_t lda, ldb;
+  int rowsA;   // rows of A that exist in memory
+  if (MODE == MODE_SAMPLE) {
+    A = a.params + d; lda = (size_t)d; rowsA = d;
+    B = a.epsT; ldb = (size_t)a.MP;
+  } else if (MODE == MODE_VJP) {
+    A = a.W; lda = (size_t)d; rowsA = d;
+    B = a.eps; ldb = (size_t)a.dP;
+  } else {
+    A = a.t_prec; lda = (size_t)a.dP; rowsA = a.dP;
+    B = a.RT; ldb = (size_t)a.MP;
+  }
+  const int klim = (MODE == MODE_VJP) ? M : Ktile;
+  const int gi0 = i0 + r16, gi1 = gi0 + 16;
+  const int gn0 = n0 + r16, gn1 = gn0 + 16;
+
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  const int nkb = (klim + 31) >> 5;
+  for (int kb = w; kb < nkb; kb += NW) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int k = kb * 32 + 4 * s + ks;
+      const bool kok = k < klim;
+      const bool ok0 = kok && gi0 < rowsA && (MODE != MODE_SAMPLE || k <= gi0);
+      const bool ok1 = kok && gi1 < rowsA && (MODE != MODE_SAMPLE || k <= gi1);
+      const size_t ka = kok ? (size_t)k : 0;
+      double a0 = A[ka * lda + (gi0 < rowsA ? gi0 : 0)];
+      double a1 = A[ka * lda + (gi1 < rowsA ? gi1 : 0)];
+      double b0 = B[ka * ldb + gn0];
+      double b1 = B[ka * ldb + gn1];
+      a0 = ok0 ? a0 : 0.0;
+      a1 = ok1 ? a1 : 0.0;
+      b0 = kok ? b0 : 0.0;
+      b1 = kok ? b1 : 0.0;
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+
+  // ---- cross-wave reduction: waves 4..7 park their tiles, waves 0..3 add their own on top ----------------
+  if (w >= NS) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[w - NS][(16 * j + r16) * 33 + 16 * i + ks + 4 * r] = acc[i][j][r];
+  }
+  // row sums of W (d/dmu) for diagonal VJP tiles: thread (row = tid & 31, group = tid >> 5) strides the samples
+  double rs = 0.0;
+  if (MODE == MODE_VJP && ib == cb) {
+    const int gi = i0 + (tid & 31);
+    if (gi < d)
+      for (int k = tid >> 5; k < M; k += NT / 32) rs += a.W[(size_t)k * d + gi];
+  }
+  rs_lds[tid] = rs;
+  __syncthreads();
+  if (w < NS) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[w][(16 * j + r16) * 33 + 16 * i + ks + 4 * r] += acc[i][j][r];
+  }
+  __syncthreads();
+  auto get = [&](int r, int c) -> double {
+    const int o = c * 33 + r;
+    double v = part[0][o];
+#pragma unroll
+    for (int q = 1; q < NS; ++q) v += part[q][o];
+    return v;
+  };
+  const double ell = tile_epilogue<double, MODE, NT>(a, ib, cb, get, rs_lds, red);
+  if (MODE != MODE_VJP && (MODE == MODE_DENSE || a.fused_target == TGT_DIAG_GAUSS)) {
+    const double s2 = block_sum<double, NT>(ell, red);
+    if (tid == 0) a.ell_part[bidx] = s2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // STL term for the full-rank family: W += C^-T eps  (back substitution with C^T, 8 columns per
 // workgroup, blocked by 32 rows).  O(d^2 M); the reference's own docs call this the expensive
 // estimator (docs/src/klminrepgraddescent.md:93-95).
@@ -987,6 +1117,12 @@ static FrArgs<T> fr_args(mivi_ctx *c, const void *params, int M) {
   return a;
 }
 
+// MIVI_F64_VALU=1 keeps the f64 tiles on the vector ALU (the in-library cross-check of the f64 MFMA kernel)
+bool f64_valu() {
+  static const bool v = getenv("MIVI_F64_VALU") != nullptr;
+  return v;
+}
+
 // Z = mu + C eps (+ fused target).  prev != nullptr: one extra workgroup assembles the PREVIOUS estimate's value.
 void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, void *Z, const ValueJob *prev) {
   if (c->cfg.dtype == MIVI_F32) {
@@ -1016,7 +1152,19 @@ void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, 
     FrArgs<double> a = fr_args<double>(c, params, M);
     a.fused_target = fused_target;
     a.Z = (double *)Z;
-    hipLaunchKernelGGL((k_fr_tile_generic<double, MODE_SAMPLE>), dim3(nblk), dim3(256), 0, c->stream, a);
+    a.n_work = 0x7fffffff;
+    if (f64_valu()) {
+      hipLaunchKernelGGL((k_fr_tile_generic<double, MODE_SAMPLE>), dim3(nblk), dim3(256), 0, c->stream, a);
+    } else {
+      int grid = nblk;
+      if (prev) {   // one trailing workgroup assembles the previous estimate's value
+        a.n_work = nblk;
+        a.prev_vin = prev->vin;
+        a.prev_out = prev->out;
+        grid += 1;
+      }
+      hipLaunchKernelGGL((k_fr_tile_mfma64<MODE_SAMPLE, 8>), dim3(grid), dim3(512), 0, c->stream, a);
+    }
   }
 }
 
@@ -1034,7 +1182,11 @@ void launch_fr_dense_target(mivi_ctx *c, int M, int want_grad) {
   } else {
     const int nblk = ((c->cfg.d + 31) / 32) * ((M + 31) / 32);
     FrArgs<double> a = fr_args<double>(c, nullptr, M);
-    hipLaunchKernelGGL((k_fr_tile_generic<double, MODE_DENSE>), dim3(nblk), dim3(256), 0, c->stream, a);
+    a.n_work = 0x7fffffff;
+    if (f64_valu())
+      hipLaunchKernelGGL((k_fr_tile_generic<double, MODE_DENSE>), dim3(nblk), dim3(256), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL((k_fr_tile_mfma64<MODE_DENSE, 8>), dim3(nblk), dim3(512), 0, c->stream, a);
   }
 }
 
@@ -1071,7 +1223,25 @@ void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, c
     const int nb = (c->cfg.d + 31) / 32;
     FrArgs<double> a = fr_args<double>(c, params, M);
     a.out = out;
-    hipLaunchKernelGGL((k_fr_tile_generic<double, MODE_VJP>), dim3(nb * (nb + 1) / 2), dim3(256), 0, c->stream, a);
+    const int ntile = nb * (nb + 1) / 2;
+    a.n_work = 0x7fffffff;
+    if (f64_valu()) {
+      hipLaunchKernelGGL((k_fr_tile_generic<double, MODE_VJP>), dim3(ntile), dim3(256), 0, c->stream, a);
+    } else {
+      int grid = ntile;
+      if (self) {
+        a.n_work = ntile;
+        a.prev_vin = self->vin;
+        a.prev_out = self->out;
+        grid += 1;
+      }
+      if (next) {
+        a.n_pre = eps_blocks(c, M);
+        a.next_eps = eps_args<double>(c, next->rng, M, next->parity);
+        grid += a.n_pre;
+      }
+      hipLaunchKernelGGL((k_fr_tile_mfma64<MODE_VJP, 8>), dim3(grid), dim3(512), 0, c->stream, a);
+    }
   }
 }
 

@@ -356,7 +356,8 @@ struct Chain {
 static bool hetero_ok(const mivi_ctx *c, int want_grad) {
   if (!want_grad) return false;
   if (c->cfg.family == MIVI_MEANFIELD) return c->target == TGT_DIAG_GAUSS;
-  return c->cfg.dtype == MIVI_F32 && (c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS);
+  if (c->cfg.dtype != MIVI_F32 && f64_valu()) return false;
+  return c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS;
 }
 
 // One estimate over M local samples. out.partials_mode selects final vs shard partials.

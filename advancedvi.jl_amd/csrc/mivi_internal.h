@@ -241,6 +241,7 @@ void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, 
 void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const EpsJob *next = nullptr,
                    const ValueJob *self = nullptr);
 int fr_ld_blocks(const mivi_ctx *c);
+bool f64_valu();   // MIVI_F64_VALU=1: keep the f64 full-rank tiles on the vector ALU
 void prepare_tables(mivi_ctx *c, int M);   // build + upload the MFMA work tables (no-op for f64 / mean-field)
 void launch_fr_dense_target(mivi_ctx *c, int M, int want_grad);
 void launch_rt_from_z(mivi_ctx *c, int M);

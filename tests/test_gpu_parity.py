@@ -163,13 +163,14 @@ def test_determinism_bitwise():
         assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
-def test_graph_batched_estimates_match_single():
-    for family, d, M in ((avi.MEANFIELD, 256, 64), (avi.FULLRANK, 128, 64)):
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_graph_batched_estimates_match_single(dtype):
+    for family, d, M in ((avi.MEANFIELD, 256, 64), (avi.FULLRANK, 128, 64), (avi.FULLRANK, 70, 19)):
         rng = np.random.default_rng(10)
-        q, _ = make_family(rng, d, family, np.float32)
-        prob, _ = make_problem(rng, "diag", d, np.float32)
+        q, _ = make_family(rng, d, family, dtype)
+        prob, _ = make_problem(rng, "diag", d, dtype)
         params, _ = avi.destructure(q)
-        ctx = avi.MiviContext(np.float32, family, d, M, 0, SEED)
+        ctx = avi.MiviContext(dtype, family, d, M, 0, SEED)
         ctx.set_problem(prob)
         p = ctx.to_device(params)
         v1, g1 = ctx.estimate_gradient(p, 7 + 4)
@@ -212,27 +213,28 @@ def test_device_entries_report_sticky_status_on_synchronize(family):
     ctx.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("kind", ["diag", "dense"])
 @pytest.mark.parametrize("d,M", [(64, 32), (70, 19), (256, 64)])
-def test_fullrank_speculative_eps_prefetch(d, M, kind):
+def test_fullrank_speculative_eps_prefetch(d, M, kind, dtype):
     """Single calls on the MFMA full-rank path let the VJP kernel of estimate idx also draw eps of idx + 1 and the
     following call skip its eps kernel.  Consecutive indices (prefetch hits), a jump (miss), the partials route and
     an interleaved sample() must all give exactly what a fresh context gives for the same (seed, idx)."""
     rng = np.random.default_rng(99 + d)
-    q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
-    prob, _ = make_problem(rng, kind, d, np.float32)
+    q, _ = make_family(rng, d, avi.FULLRANK, dtype)
+    prob, _ = make_problem(rng, kind, d, dtype)
     params, _ = avi.destructure(q)
     ent = avi.MonteCarloEntropy().code
 
     def fresh(idx):
-        c = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
+        c = avi.MiviContext(dtype, avi.FULLRANK, d, M, ent, SEED)
         c.set_problem(prob)
         v, g = c.estimate_gradient(params, idx)
         out = (float(v.item()), g.cpu().numpy().copy())
         c.close()
         return out
 
-    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
+    ctx = avi.MiviContext(dtype, avi.FULLRANK, d, M, ent, SEED)
     ctx.set_problem(prob)
     seq = [5, 6, 7, 3, 4, 4, 9]
     want = {i: fresh(i) for i in set(seq)}
@@ -247,6 +249,6 @@ def test_fullrank_speculative_eps_prefetch(d, M, kind):
         if n % 2 == 0:
             assert v == want[idx][0] and np.array_equal(g, want[idx][1]), (n, idx)
         else:                                  # partials route: same sums, normalised in a different kernel
-            assert abs(v - want[idx][0]) <= 2e-6 * abs(want[idx][0])
-            assert np.linalg.norm(g - want[idx][1]) <= 2e-6 * max(np.linalg.norm(want[idx][1]), 1.0)
+            assert abs(v - want[idx][0]) <= (2e-6 if dtype == np.float32 else 1e-13) * abs(want[idx][0])
+            assert np.linalg.norm(g - want[idx][1]) <= (2e-6 if dtype == np.float32 else 1e-13) * max(np.linalg.norm(want[idx][1]), 1.0)
     ctx.close()
