@@ -337,11 +337,11 @@ __global__ __launch_bounds__(512) void k_lr_logits_mfma(LrMfmaArgs a) {
   };
   int st = 0;
   load_stage(0, xa0, xa1, xb0, xb1);
-  while (true) {
-    if (st + 1 < nst) load_stage(st + 1, ya0, ya1, yb0, yb1);
+  while (true) {   // unconditional, clamped prefetch (see k_lr_logits_mfma_rm)
+    load_stage(min(st + 1, nst - 1), ya0, ya1, yb0, yb1);
     mma_stage(st, xa0, xa1, xb0, xb1);
     if (++st >= nst) break;
-    if (st + 1 < nst) load_stage(st + 1, xa0, xa1, xb0, xb1);
+    load_stage(min(st + 1, nst - 1), xa0, xa1, xb0, xb1);
     mma_stage(st, ya0, ya1, yb0, yb1);
     if (++st >= nst) break;
   }
@@ -379,6 +379,8 @@ __global__ __launch_bounds__(512) void k_lr_logits_mfma(LrMfmaArgs a) {
     if (m < a.M) a.ll_part[(size_t)blockIdx.x * a.M + m] = (double)ll_lds[tid];
   }
 }
+
+typedef float lr_f32x4 __attribute__((ext_vector_type(4)));
 
 // Output G^T tile set: 128 samples x 256 features per workgroup (blockIdx.y = feature half... general: feature
 // group of 256), 8 waves as 2 (samples) x 4 (features), each 64 x 64; rows [rbeg, rend) of split blockIdx.x.
@@ -422,11 +424,11 @@ __global__ __launch_bounds__(512) void k_lr_xtr_mfma(LrMfmaArgs a) {
   if (nst > 0) {
     long long st = 0;
     load_stage(0, xa0, xa1, xb0, xb1);
-    while (true) {
-      if (st + 1 < nst) load_stage(st + 1, ya0, ya1, yb0, yb1);
+    while (true) {   // unconditional, clamped prefetch (see k_lr_logits_mfma_rm)
+      load_stage(min(st + 1, nst - 1), ya0, ya1, yb0, yb1);
       mma_stage(st, xa0, xa1, xb0, xb1);
       if (++st >= nst) break;
-      if (st + 1 < nst) load_stage(st + 1, xa0, xa1, xb0, xb1);
+      load_stage(min(st + 1, nst - 1), xa0, xa1, xb0, xb1);
       mma_stage(st, ya0, ya1, yb0, yb1);
       if (++st >= nst) break;
     }
@@ -444,6 +446,219 @@ __global__ __launch_bounds__(512) void k_lr_xtr_mfma(LrMfmaArgs a) {
   epi(c01, 0, 1);
   epi(c10, 1, 0);
   epi(c11, 1, 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Second generation: operands staged through LDS.  What was measured on the first generation (MFMA pipe busy 48 % /
+// 63 %, PMC) and on register-pipelined variants of it:
+//   * a branch around the prefetch loads makes the compiler merge the s_waitcnt of both paths to the conservative one
+//     (it then waits for the loads it has just issued) -> prefetch must be unconditional on a clamped stage index;
+//   * without a scheduling barrier the machine scheduler sinks every prefetch load down to its first use
+//     (load -> s_waitcnt vmcnt(0) -> mfma), silently removing the software pipeline;
+//   * a wave can have at most 63 loads outstanding (vmcnt is 6 bits): dword operand loads cap the prefetch depth;
+//   * with the pipeline pinned, the deeper the per-wave prefetch the SLOWER X^T R ran (1.5 -> 2.3-2.7 ms): the waves of
+//     a workgroup share operand rows only through the 32 KB L1, and with several stages in flight per wave the shared
+//     lines are evicted before the sibling waves ask for them.
+// Staging makes the sharing explicit: every operand byte is fetched once per workgroup with 16-byte coalesced loads
+// (3 per thread per stage instead of 32 dword loads per wave), a two-slot LDS ring feeds the MFMAs through ds_read,
+// global loads run two stages ahead in registers, one barrier per stage.  X^T R 1.52 -> 1.13 ms (74 % of the f32 MFMA
+// peak), logits 1.90 -> 1.33 ms (63 %) at n = 1e6, p = 511, M = 128.
+//   stage = 16 data rows: Rs[16][128] samples, Xs[16][256] features  (24 KB per slot)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_lr_xtr_mfma_lds(LrMfmaArgs a) {
+  __shared__ __attribute__((aligned(16))) float Rs[2][16 * 128];
+  __shared__ __attribute__((aligned(16))) float Xs[2][16 * 256];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wk = w & 3;
+  const int mbase = blockIdx.z * 128, kbase = blockIdx.y * 256;
+  const int m0 = mbase + wm * 64, k0 = kbase + wk * 64;
+  const long long rbeg = (long long)blockIdx.x * a.rows_per_split;
+  const long long rend = min(a.n, rbeg + a.rows_per_split);
+  const int ldr = a.ldr, ldx = a.ldx;
+  const int nst = (int)((rend - rbeg + 15) / 16);
+  // cooperative loads: R one float4 per thread (row t>>5, 4 samples), X two (rows t>>6 and 8 + t>>6, 4 features)
+  const int rrow = tid >> 5, rcol = min(mbase + 4 * (tid & 31), ldr - 4);
+  const int xrow = tid >> 6, xcol = min(kbase + 4 * (tid & 63), ldx - 4);
+  struct G { lr_f32x4 r, x0, x1; };
+  auto gload = [&](int st, G &g) {
+    st = min(st, nst - 1);
+    const long long rb = rbeg + 16LL * st;
+    const long long r_r = rb + rrow, r_x0 = rb + xrow, r_x1 = rb + 8 + xrow;
+    const bool okr = r_r < rend;
+    g.r = *(const lr_f32x4 *)(a.R + (size_t)(okr ? r_r : rend - 1) * ldr + rcol);
+    g.x0 = *(const lr_f32x4 *)(a.Xrm + (size_t)min(r_x0, rend - 1) * ldx + xcol);
+    g.x1 = *(const lr_f32x4 *)(a.Xrm + (size_t)min(r_x1, rend - 1) * ldx + xcol);
+    if (!okr) g.r = lr_f32x4{0.f, 0.f, 0.f, 0.f};   // rows past the split contribute nothing (X stays finite)
+  };
+  auto lstore = [&](int slot, const G &g) {
+    *(lr_f32x4 *)&Rs[slot][rrow * 128 + 4 * (tid & 31)] = g.r;
+    *(lr_f32x4 *)&Xs[slot][xrow * 256 + 4 * (tid & 63)] = g.x0;
+    *(lr_f32x4 *)&Xs[slot][(8 + xrow) * 256 + 4 * (tid & 63)] = g.x1;
+  };
+  lr_f32x16 c00, c01, c10, c11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
+  const int ao = h * 128 + wm * 64 + l31, bo = h * 256 + wk * 64 + l31;
+  auto compute = [&](int slot) {
+    const float *rs = &Rs[slot][ao], *xs = &Xs[slot][bo];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float a0 = rs[2 * u * 128], a1 = rs[2 * u * 128 + 32];
+      const float b0 = xs[2 * u * 256], b1 = xs[2 * u * 256 + 32];
+      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, c11, 0, 0, 0);
+    }
+  };
+  if (nst > 0) {
+    G ga, gb;
+    gload(0, ga);
+    lstore(0, ga);
+    gload(1, ga);
+    gload(2, gb);
+    lds_barrier();   // LDS-only: __syncthreads() would also drain the prefetch loads (vmcnt)
+    int st = 0;
+    while (true) {
+      lstore((st + 1) & 1, ga);      // stage st+1 (loaded two iterations ago)
+      gload(st + 3, ga);
+      compute(st & 1);
+      lds_barrier();   // LDS-only: __syncthreads() would also drain the prefetch loads (vmcnt)
+      if (++st >= nst) break;
+      lstore((st + 1) & 1, gb);
+      gload(st + 3, gb);
+      compute(st & 1);
+      lds_barrier();   // LDS-only: __syncthreads() would also drain the prefetch loads (vmcnt)
+      if (++st >= nst) break;
+    }
+  }
+  auto epi = [&](const lr_f32x16 &c, int mb, int kb) {
+    const int k = k0 + kb * 32 + l31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = m0 + mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (k < a.p && m < a.M) a.g_part[((size_t)blockIdx.x * a.M + m) * a.p + k] = c[q];
+    }
+  };
+  epi(c00, 0, 0);
+  epi(c01, 0, 1);
+  epi(c10, 1, 0);
+  epi(c11, 1, 1);
+}
+
+// logits through LDS: 256 rows x 128 samples per workgroup (8 waves as 4 x 2, each 64 x 64), stage = 16 k:
+//   Xs[256][20]  (row-major slab of Xrm, row stride 20 words: 16-byte aligned and conflict-free for the b128 operand reads)
+//   Zs[16][128]  (ZT rows)
+// Lane half h feeds k = 8g + 4h + i to MFMA i of group g on both operands (the order of k inside a dot product is free),
+// so the A operand is one ds_read_b128 per 4 MFMAs.
+__global__ __launch_bounds__(512) void k_lr_logits_mfma_lds(LrMfmaArgs a) {
+  __shared__ __attribute__((aligned(16))) float Xs[2][256 * 20];
+  __shared__ __attribute__((aligned(16))) float Zs[2][16 * 128];
+  __shared__ float ll_lds[128];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wm = w & 1;
+  const long long rb0 = (long long)blockIdx.x * 256;
+  const long long r0 = rb0 + wr * 64;
+  const int mbase = blockIdx.y * 128, m0 = mbase + wm * 64;
+  const int ldx = a.ldx, ldz = a.ldz;
+  const int nst = ldx / 16;
+  if (tid < 128) ll_lds[tid] = 0.f;
+  const int xrow = tid >> 2, xc = 4 * (tid & 3);
+  const float *Xg0 = a.Xrm + (size_t)min(rb0 + xrow, a.n - 1) * ldx + xc;
+  const float *Xg1 = a.Xrm + (size_t)min(rb0 + 128 + xrow, a.n - 1) * ldx + xc;
+  const int zk = tid >> 5, zc = min(mbase + 4 * (tid & 31), ldz - 4);
+  struct G { lr_f32x4 x0, x1, z; };
+  auto gload = [&](int st, G &g) {
+    st = min(st, nst - 1);
+    g.x0 = *(const lr_f32x4 *)(Xg0 + 16 * st);
+    g.x1 = *(const lr_f32x4 *)(Xg1 + 16 * st);
+    g.z = *(const lr_f32x4 *)(a.ZT + (size_t)(16 * st + zk) * ldz + zc);
+  };
+  auto lstore = [&](int slot, const G &g) {
+    *(lr_f32x4 *)&Xs[slot][xrow * 20 + xc] = g.x0;
+    *(lr_f32x4 *)&Xs[slot][(128 + xrow) * 20 + xc] = g.x1;
+    *(lr_f32x4 *)&Zs[slot][zk * 128 + 4 * (tid & 31)] = g.z;
+  };
+  lr_f32x16 c00, c01, c10, c11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
+  const int ao = (wr * 64 + l31) * 20 + 4 * h, bo = 4 * h * 128 + wm * 64 + l31;
+  auto compute = [&](int slot) {
+    const float *xs = &Xs[slot][ao], *zs = &Zs[slot][bo];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const lr_f32x4 a0 = *(const lr_f32x4 *)(xs + 8 * g), a1 = *(const lr_f32x4 *)(xs + 32 * 20 + 8 * g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float b0 = zs[(8 * g + i) * 128], b1 = zs[(8 * g + i) * 128 + 32];
+        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0, c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b1, c01, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b0, c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1, c11, 0, 0, 0);
+      }
+    }
+  };
+  {
+    G ga, gb;
+    gload(0, ga);
+    lstore(0, ga);
+    gload(1, ga);
+    gload(2, gb);
+    lds_barrier();   // LDS-only: __syncthreads() would also drain the prefetch loads (vmcnt)
+    int st = 0;
+    while (true) {
+      lstore((st + 1) & 1, ga);
+      gload(st + 3, ga);
+      compute(st & 1);
+      lds_barrier();   // LDS-only: __syncthreads() would also drain the prefetch loads (vmcnt)
+      if (++st >= nst) break;
+      lstore((st + 1) & 1, gb);
+      gload(st + 3, gb);
+      compute(st & 1);
+      lds_barrier();   // LDS-only: __syncthreads() would also drain the prefetch loads (vmcnt)
+      if (++st >= nst) break;
+    }
+  }
+  float ll0 = 0.f, ll1 = 0.f;
+  auto epi = [&](const lr_f32x16 &ca, const lr_f32x16 &cb, int rb) {
+    const int ma = m0 + l31, mb = m0 + 32 + l31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const long long r = r0 + rb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (r < a.n) {
+        const float yv = (float)a.y[r];
+        {
+          const float lg = ca[q], e = __expf(-fabsf(lg)), inv = __frcp_rn(1.f + e);
+          if (ma < a.M) {
+            ll0 += yv * lg - (fmaxf(lg, 0.f) + __logf(1.f + e));
+            if (a.want_grad) a.R[(size_t)r * a.ldr + ma] = yv - (lg >= 0.f ? inv : e * inv);
+          }
+        }
+        {
+          const float lg = cb[q], e = __expf(-fabsf(lg)), inv = __frcp_rn(1.f + e);
+          if (mb < a.M) {
+            ll1 += yv * lg - (fmaxf(lg, 0.f) + __logf(1.f + e));
+            if (a.want_grad) a.R[(size_t)r * a.ldr + mb] = yv - (lg >= 0.f ? inv : e * inv);
+          }
+        }
+      }
+    }
+  };
+  epi(c00, c01, 0);
+  epi(c10, c11, 1);
+  ll0 += __shfl_xor(ll0, 32, 64);
+  ll1 += __shfl_xor(ll1, 32, 64);
+  if (h == 0) {
+    atomicAdd(&ll_lds[wm * 64 + l31], ll0);
+    atomicAdd(&ll_lds[wm * 64 + 32 + l31], ll1);
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int m = mbase + tid;
+    if (m < a.M) a.ll_part[(size_t)blockIdx.x * a.M + m] = (double)ll_lds[tid];
+  }
 }
 
 // one-time: row-major zero-padded copy of X (n x p column-major -> n x ldx row-major), 64x64 LDS transpose
@@ -506,9 +721,11 @@ static void logreg_mfma(mivi_ctx *c, int M, int want_grad) {
   a.ZT = (const float *)c->RT.p;
   a.ldz = c->MP;
   a.ldr = (M + 63) / 64 * 64;
+  static const bool gen1 = getenv("MIVI_LR_GEN1") != nullptr;
   const int nrb = (int)((a.n + 255) / 256);
+  // one X^T R workgroup per CU: 128 row splits x 2 feature groups at p = 511 (fewer, longer splits also halve k_lr_greduce)
   int S = (int)((a.n + 2047) / 2048);
-  if (S > 256) S = 256;
+  if (S > 128) S = 128;
   if (S < 1) S = 1;
   long long rps = (a.n + S - 1) / S;
   rps = (rps + 15) / 16 * 16;
@@ -531,9 +748,16 @@ static void logreg_mfma(mivi_ctx *c, int M, int want_grad) {
   a.R = (float *)c->lr_scratch.p;
   a.g_part = (float *)((char *)c->lr_scratch.p + need_R);
   a.ll_part = (double *)c->lr_part.p;
-  hipLaunchKernelGGL(k_lr_logits_mfma, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
-  if (want_grad)
-    hipLaunchKernelGGL(k_lr_xtr_mfma, dim3(S, (a.p + 255) / 256, (M + 127) / 128), dim3(512), 0, c->stream, a);
+  // MIVI_LR_GEN1=1 selects the first-generation (register-operand) kernels: the in-library A/B reference
+  if (gen1)
+    hipLaunchKernelGGL(k_lr_logits_mfma, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
+  else
+    hipLaunchKernelGGL(k_lr_logits_mfma_lds, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
+  if (want_grad) {
+    const dim3 gx(S, (a.p + 255) / 256, (M + 127) / 128);
+    if (gen1) hipLaunchKernelGGL(k_lr_xtr_mfma, gx, dim3(512), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_lr_xtr_mfma_lds, gx, dim3(512), 0, c->stream, a);
+  }
   if (want_grad && S > 1) {
     const size_t len = (size_t)a.p * M;
     hipLaunchKernelGGL(k_lr_greduce, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c->stream, S, len, a.g_part);

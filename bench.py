@@ -239,17 +239,26 @@ def main():
             chunk = max(1, min(20, K))
             idx_dev = torch.zeros(1, dtype=torch.int64, device=f"cuda:{local_rank}")
             graph = None
-            try:
-                ctx.set_index_source(idx_dev)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=stream):
-                    for i in range(chunk):
-                        drv.estimate_gradient(params, i)
-                graph = g
-            except Exception as e:   # noqa: BLE001
-                print(f"[bench] graph capture of the distributed step failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+            if os.environ.get("MIVI_DIST_EAGER") is None:
+                try:
+                    ctx.set_index_source(idx_dev)
+                    g = torch.cuda.CUDAGraph()
+                    # thread-local capture mode: RCCL's watchdog thread may query events while this thread captures
+                    with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                        for i in range(chunk):
+                            drv.estimate_gradient(params, i)
+                    graph = g
+                except Exception as e:   # noqa: BLE001
+                    print(f"[bench] rank {rank}: graph capture of the distributed step failed ({type(e).__name__}: {e}); eager launches",
+                          file=sys.stderr)
+                    torch.cuda.synchronize()
+            # every rank must take the same route: replay the graph only if the capture succeeded everywhere
+            okflag = torch.tensor([1 if graph is not None else 0], dtype=torch.int32, device=f"cuda:{local_rank}")
+            if dist:
+                dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
+            if int(okflag.item()) == 0:
+                graph = None
                 ctx.set_index_source(None)
-                torch.cuda.synchronize()
 
             def run(idx0, n):
                 done = 0
