@@ -1,0 +1,38 @@
+"""Ragged, degenerate and large shapes through the C ABI vs the oracle on identical eps (edge cases the reference's
+own tests touch only implicitly: d = 1, a single sample, dimensions that are no multiple of any tile, d >> BASELINE)."""
+import numpy as np
+import pytest
+
+import advancedvi_jl_amd as avi
+from oracle import oracle as O
+from tests.helpers import SEED, make_family, make_problem
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    (avi.FULLRANK, 2048, 64, "diag", 0, np.float32), (avi.FULLRANK, 2048, 64, "diag", 3, np.float32),
+    (avi.FULLRANK, 1000, 100, "dense", 0, np.float32), (avi.FULLRANK, 1537, 33, "diag", 4, np.float32),
+    (avi.FULLRANK, 1537, 33, "diag", 4, np.float64), (avi.FULLRANK, 1024, 64, "diag", 3, np.float64),
+    (avi.MEANFIELD, 1 << 20, 8, "diag", 0, np.float32), (avi.MEANFIELD, 100003, 7, "diag", 3, np.float32),
+    (avi.FULLRANK, 1, 1, "diag", 0, np.float32), (avi.FULLRANK, 3, 1000, "diag", 2, np.float32),
+    (avi.MEANFIELD, 1, 1, "diag", 2, np.float64), (avi.FULLRANK, 33, 4096, "dense", 3, np.float32),
+    (avi.FULLRANK, 2, 1, "dense", 1, np.float64), (avi.MEANFIELD, 5, 3, "funnel", 3, np.float32),
+]
+
+
+@pytest.mark.parametrize("family,d,M,kind,ent,dtype", CASES)
+def test_shape(family, d, M, kind, ent, dtype):
+    rng = np.random.default_rng(d + M)
+    q, q_o = make_family(rng, d, family, dtype)
+    prob, tgt = make_problem(rng, kind, d, dtype)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(dtype, family, d, M, ent, SEED)
+    ctx.set_problem(prob)
+    _, eps = ctx.sample(params, 3)
+    v, g = ctx.estimate_gradient(params, 3)
+    ctx.synchronize()
+    ref = O.estimate_gradient(O.destructure(q_o), d, family, tgt, eps.cpu().numpy().astype(np.float64), ent)
+    vt, gt = (1e-5, 2e-5) if dtype == np.float32 else (1e-12, 1e-11)
+    assert abs(float(v.item()) - ref["value"]) <= vt * max(abs(ref["value"]), 1.0)
+    assert np.linalg.norm(g.cpu().numpy() - ref["grad"]) <= gt * max(np.linalg.norm(ref["grad"]), 1.0)
+    ctx.close()
