@@ -12,7 +12,8 @@ from .objectives import (RepGradELBO, RepGradELBOState, ClosedFormEntropy, Close
                          AutoMIVI, PhiloxRNG, DiffResult, estimate_gradient_, set_objective_state_problem, rand)
 from . import objectives as _objectives
 from . import optimize as _optimize
-from .optimize import (KLMinRepGradDescent, ADVI, ClipScale, IdentityOperator, Descent, Adam, DoG, DoWG, NoAveraging,
+from .optimize import (KLMinRepGradDescent, KLMinRepGradProxDescent, ADVI, ClipScale, IdentityOperator,
+                       ProximalLocationScaleEntropy, Descent, Adam, DoG, DoWG, NoAveraging,
                        PolynomialAveraging, optimize, step, output)
 from .context import MiviContext
 from . import distributed

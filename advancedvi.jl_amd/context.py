@@ -232,6 +232,10 @@ class MiviContext:
     def clip_scale(self, params, epsilon):
         self._chk(self.lib.mivi_clip_scale(self.h, self._p(params), float(epsilon)))
 
+    def prox_scale_entropy(self, params, stepsize=0.0, dog_state=None, dog_kind=0):
+        self._chk(self.lib.mivi_prox_scale_entropy(self.h, self._p(params), float(stepsize),
+                                                   self._p(dog_state) if dog_state is not None else None, int(dog_kind)))
+
     def descent_update(self, params, grad, eta):
         self._chk(self.lib.mivi_descent_update(self.h, self._p(params), self._p(grad), float(eta)))
 

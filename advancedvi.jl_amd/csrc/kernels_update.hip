@@ -124,6 +124,32 @@ void launch_clip(mivi_ctx *c, void *params, double epsilon) {
                        (double *)params, epsilon);
 }
 
+// ProximalLocationScaleEntropy (src/optimization/proximal_location_scale_entropy.jl:44-61).  The step size comes from the
+// optimiser: Descent -> eta (by value); DoG -> r / sqrt(v); DoWG -> r^2 / sqrt(v) read from the device-resident (v, r) (:26-42).
+template <typename T>
+__global__ void k_prox(int d, int family, T *params, double stepsize, const double *dog_sc, int dog_kind) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < d) {
+    double g = stepsize;
+    if (dog_sc) {
+      const double v = dog_sc[0], r = dog_sc[1];
+      g = (dog_kind == 1 ? r * r : r) / sqrt(v);
+    }
+    const size_t o = family == MIVI_MEANFIELD ? (size_t)d + i : (size_t)d + (size_t)i * d + i;
+    params[o] = prox_entropy_step(params[o], (T)g);
+  }
+}
+void launch_prox(mivi_ctx *c, void *params, double stepsize, const void *dog_state, int dog_kind) {
+  const int d = c->cfg.d;
+  const double *sc = dog_state ? (const double *)((const char *)dog_state + mivi_dog_state_bytes(c) - 16) : nullptr;
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_prox<float>, dim3((d + 255) / 256), dim3(256), 0, c->stream, d, c->cfg.family, (float *)params,
+                       stepsize, sc, dog_kind);
+  else
+    hipLaunchKernelGGL(k_prox<double>, dim3((d + 255) / 256), dim3(256), 0, c->stream, d, c->cfg.family, (double *)params,
+                       stepsize, sc, dog_kind);
+}
+
 // is flat index i a scale-diagonal entry? (ClipScale fused into the update, clip_eps > 0)
 __device__ __forceinline__ bool is_scale_diag(int64_t i, int d, int family) {
   if (i < d) return false;

@@ -725,6 +725,14 @@ mivi_status_t mivi_clip_scale(mivi_ctx_t *c, void *params, double epsilon) {
   HIPCHK(c, hipGetLastError());
   return MIVI_OK;
 }
+mivi_status_t mivi_prox_scale_entropy(mivi_ctx_t *c, void *params, double stepsize, const void *dog_state, int32_t dog_kind) {
+  if (!c || !params || (dog_state && dog_kind != 0 && dog_kind != 1)) return MIVI_ERR_BAD_ARG;
+  if (!dog_state && !(stepsize >= 0.0)) return fail(c, MIVI_ERR_BAD_ARG, "proximal step size must be non-negative");
+  (void)hipSetDevice(c->cfg.device);
+  launch_prox(c, params, stepsize, dog_state, dog_kind);
+  HIPCHK(c, hipGetLastError());
+  return MIVI_OK;
+}
 mivi_status_t mivi_descent_update(mivi_ctx_t *c, void *params, const void *grad, double eta) {
   if (!c || !params || !grad) return MIVI_ERR_BAD_ARG;
   (void)hipSetDevice(c->cfg.device);

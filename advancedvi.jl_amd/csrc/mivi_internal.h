@@ -257,6 +257,7 @@ void logreg_prepare_f32(mivi_ctx *c);   // row-major padded copy of X for the MF
 
 // kernels_update.hip
 void launch_finalize(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad);
+void launch_prox(mivi_ctx *c, void *params, double stepsize, const void *dog_state, int dog_kind);
 void launch_value_only(mivi_ctx *c, const void *params, const ValueIn &vin, const OutArgs &out);   // on c->stream
 void launch_clip(mivi_ctx *c, void *params, double epsilon);
 void launch_descent(mivi_ctx *c, void *params, const void *grad, double eta, double clip_eps = 0.0);

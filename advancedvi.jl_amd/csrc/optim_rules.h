@@ -47,4 +47,11 @@ __device__ __forceinline__ T clip_step(T v, T eps) {
   return v > eps ? v : eps;
 }
 
+// ProximalLocationScaleEntropy on one scale-diagonal entry: argmin_c' -log c' + (c' - c)^2 / (2 gamma)
+// = c + (sqrt(c^2 + 4 gamma) - c) / 2     (src/optimization/proximal_location_scale_entropy.jl:56)
+template <typename T>
+__device__ __forceinline__ T prox_entropy_step(T c, T gamma) {
+  return c + (sqrt(c * c + T(4) * gamma) - c) / T(2);
+}
+
 }  // namespace mivi

@@ -14,7 +14,7 @@ from .families import MvLocationScale, destructure
 
 # --- operators (src/optimization/clip_scale.jl, src/AdvancedVI.jl:173-204) ------------------------
 class IdentityOperator:
-    def apply(self, ctx, params):
+    def apply(self, ctx, params, optimizer=None, opt_st=None):
         return params
 
 
@@ -24,8 +24,23 @@ class ClipScale:
     def __init__(self, epsilon=1e-5):
         self.epsilon = epsilon
 
-    def apply(self, ctx, params):
+    def apply(self, ctx, params, optimizer=None, opt_st=None):
         ctx.clip_scale(params, self.epsilon)
+        return params
+
+
+class ProximalLocationScaleEntropy:
+    """Proximal operator of the entropy of a location-scale family, applied after the optimiser step with that step's
+    size: src/optimization/proximal_location_scale_entropy.jl:17-61.  Supports Descent, DoG, DoWG (:26-42); the DoG/DoWG
+    step size is read from the optimiser state on the device."""
+
+    def apply(self, ctx, params, optimizer=None, opt_st=None):
+        if isinstance(optimizer, DoG):            # DoWG is a subclass
+            ctx.prox_scale_entropy(params, 0.0, opt_st, optimizer.kind)
+        elif isinstance(optimizer, Descent):
+            ctx.prox_scale_entropy(params, optimizer.eta)
+        else:
+            raise TypeError(f"`ProximalLocationScaleEntropy` does not support optimization rule {type(optimizer).__name__}.")
         return params
 
 
@@ -128,6 +143,27 @@ class KLMinRepGradDescent:
 ADVI = KLMinRepGradDescent
 
 
+class KLMinRepGradProxDescent(KLMinRepGradDescent):
+    """KLMinRepGradProxDescent(adtype; entropy_zerograd, optimizer, n_samples, averager): constructors.jl:122-157.
+    The entropy is handled by the proximal operator, so the gradient estimator must ignore it: the entropy estimator is
+    one of the two *ZeroGradient kinds; optimizer one of Descent / DoG / DoWG."""
+
+    def __init__(self, adtype, entropy_zerograd=None, optimizer=None, n_samples: int = 1, averager=None, subsampling=None):
+        if subsampling is not None:
+            raise NotImplementedError("SubsampledObjective is outside the hot path built here (SURVEY.md 8f-4)")
+        entropy = entropy_zerograd if entropy_zerograd is not None else O.ClosedFormEntropyZeroGradient()
+        if not isinstance(entropy, (O.ClosedFormEntropyZeroGradient, O.StickingTheLandingEntropyZeroGradient)):
+            raise TypeError("entropy_zerograd must be ClosedFormEntropyZeroGradient or StickingTheLandingEntropyZeroGradient")
+        optimizer = optimizer if optimizer is not None else DoWG()
+        if not isinstance(optimizer, (Descent, DoG)):
+            raise TypeError("optimizer must be Descent, DoG or DoWG")
+        self.objective = O.RepGradELBO(n_samples, entropy=entropy)
+        self.adtype = adtype
+        self.optimizer = optimizer
+        self.averager = averager if averager is not None else PolynomialAveraging()
+        self.operator = ProximalLocationScaleEntropy()
+
+
 def estimate_objective(rng, alg, q, prob, n_samples=None, entropy=None):
     """estimate_objective([rng,] alg, q, prob; n_samples, entropy=MonteCarloEntropy()): common.jl:29-38."""
     if isinstance(rng, KLMinRepGradDescent):
@@ -174,7 +210,7 @@ def step(rng, alg, state, callback, *objargs):
         raise RuntimeError(f"The objective value is {value}. This indicates that the optimization run diverged.")
     grad = grad_buf.gradient()
     state["opt_st"] = alg.optimizer.update(ctx, state["opt_st"], params, grad, t)   # Optimisers.update!
-    params = alg.operator.apply(ctx, params)
+    params = alg.operator.apply(ctx, params, alg.optimizer, state["opt_st"])   # apply(operator, typeof(q), opt_st, params, re)
     state["avg_st"] = alg.averager.apply(ctx, state["avg_st"], params)
     state["params"] = params
     state["q"] = None  # materialised lazily by `output` / callbacks (params are device resident)

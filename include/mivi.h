@@ -182,6 +182,12 @@ mivi_status_t mivi_axpby(mivi_ctx_t *ctx, void *y_dev, double a, const void *x_d
 int64_t mivi_dog_state_bytes(const mivi_ctx_t *ctx);
 mivi_status_t mivi_dog_init(mivi_ctx_t *ctx, const void *params_dev, void *state_dev, double alpha);
 mivi_status_t mivi_dog_update(mivi_ctx_t *ctx, void *params_dev, const void *grad_dev, void *state_dev, int32_t kind);
+/* ProximalLocationScaleEntropy (src/optimization/proximal_location_scale_entropy.jl:44-61), the operator of
+ * KLMinRepGradProxDescent (src/algorithms/constructors.jl:122-157): every scale-diagonal entry
+ * c <- c + (sqrt(c^2 + 4 gamma) - c) / 2.  gamma = `stepsize` (Descent: eta) when dog_state_dev is NULL, otherwise it is read
+ * on the device from the DoG / DoWG state (r / sqrt(v) resp. r^2 / sqrt(v), :26-42) -- no host round trip. */
+mivi_status_t mivi_prox_scale_entropy(mivi_ctx_t *ctx, void *params_dev, double stepsize, const void *dog_state_dev,
+                                      int32_t dog_kind);
 /* `n_steps` iterations of src/algorithms/common.jl:69-104 {estimate_gradient!, update!, ClipScale} with params
  * resident in HBM, one hipGraph per call; rule: 0 = Descent(eta), 1 = Adam(eta).  elbo_dev: T[n_steps] or NULL
  * receives info.elbo (= -value) per iteration.  Returns MIVI_ERR_NONFINITE if any objective was not finite. */

@@ -400,6 +400,44 @@ def clip_scale(params, d, family, epsilon=1e-5):
     return out
 
 
+def proximal_location_scale_entropy(params, d, family, stepsize):
+    """ProximalLocationScaleEntropy: diag(scale) <- c + (sqrt(c^2 + 4 gamma) - c) / 2, the minimiser of
+    -log|det L'| + ||L' - L||^2 / (2 gamma); src/optimization/proximal_location_scale_entropy.jl:44-61."""
+    out = np.array(params, dtype=np.float64, copy=True)
+    idx = d + np.arange(d) if family == MEANFIELD else d + np.arange(d) * (d + 1)
+    c = out[idx]
+    out[idx] = c + (np.sqrt(c * c + 4.0 * stepsize) - c) / 2.0
+    if family != MEANFIELD:   # restructure -> destructure re-projects onto LowerTriangular
+        out[d:] = np.tril(out[d:].reshape(d, d, order="F")).reshape(-1, order="F")
+    return out
+
+
+def stepsize_from_optimizer_state(rule, eta=None, v=None, r=None):
+    """Descent -> eta; DoG -> r / sqrt(v); DoWG -> r^2 / sqrt(v); proximal_location_scale_entropy.jl:26-42."""
+    if rule == "descent":
+        return float(eta)
+    if rule == "dog":
+        return float(r) / np.sqrt(float(v))
+    if rule == "dowg":
+        return float(r) * float(r) / np.sqrt(float(v))
+    raise ValueError(f"`ProximalLocationScaleEntropy` does not support optimization rule {rule}.")
+
+
+def dog_step(params, grad, state, kind):
+    """One DoG (kind 0) / DoWG (kind 1) update; state = (x0, v, r); src/optimization/rules.jl:17-64."""
+    x0, v, r = state
+    params = np.asarray(params, dtype=np.float64)
+    r = max(float(np.sqrt(np.sum((params - x0) ** 2))), r)
+    g2 = float(np.sum(np.asarray(grad, dtype=np.float64) ** 2))
+    if kind == 1:
+        v = v + r * r * g2
+        eta = r * r / np.sqrt(v)
+    else:
+        v = v + g2
+        eta = r / np.sqrt(v)
+    return params - eta * np.asarray(grad, dtype=np.float64), (x0, v, r)
+
+
 # --------------------------------------------------------------------------------------
 # Counter-based RNG: Philox4x32-10 + Box-Muller (the eps stream of the HIP kernels)
 # --------------------------------------------------------------------------------------

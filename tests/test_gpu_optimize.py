@@ -6,7 +6,7 @@ import pytest
 
 import advancedvi_jl_amd as avi
 from oracle import oracle as O
-from tests.helpers import SEED
+from tests.helpers import SEED, make_family
 
 pytestmark = pytest.mark.gpu
 
@@ -198,3 +198,68 @@ def test_dog_dowg_and_averaging_match_oracle_formulas():
         t += 1
     assert np.allclose(avg.value(state).cpu().numpy(), ref, rtol=1e-12)
     ctx.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK])
+def test_proximal_operator_matches_oracle(family, dtype):
+    """mivi_prox_scale_entropy vs the oracle for the three supported rules (Descent by value, DoG / DoWG from the
+    device-resident optimiser state), incl. the reference's own known answer (d = 5, L = I, eta = 1e-2)."""
+    d = 5
+    q = (avi.MeanFieldGaussian(np.zeros(d, dtype), np.ones(d, dtype)) if family == avi.MEANFIELD
+         else avi.FullRankGaussian(np.zeros(d, dtype), np.eye(d, dtype=dtype)))
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(dtype, family, d, 4, 1, SEED)
+    p = ctx.to_device(params).clone()
+    ctx.prox_scale_entropy(p, 1e-2)
+    ref = O.proximal_location_scale_entropy(params, d, family, 1e-2)
+    tol = 1e-6 if dtype == np.float32 else 1e-14
+    assert np.allclose(p.cpu().numpy(), ref, rtol=tol, atol=0)
+    # DoG / DoWG: one optimiser step on the device, then prox with the step size implied by its (v, r)
+    rng = np.random.default_rng(3)
+    qq, _ = make_family(rng, 16, family, dtype)
+    params, _ = avi.destructure(qq)
+    grad = rng.normal(size=params.shape).astype(dtype)
+    if family == avi.FULLRANK:   # gradients of a triangular scale have an exactly-zero upper triangle
+        grad[16:] = np.tril(grad[16:].reshape(16, 16, order="F")).reshape(-1, order="F")
+    c2 = avi.MiviContext(dtype, family, 16, 4, 1, SEED)
+    for kind, name in ((0, "dog"), (1, "dowg")):
+        p = c2.to_device(params).clone()
+        st = c2.dog_state()
+        c2.dog_init(p, st, 1e-2)
+        c2.dog_update(p, c2.to_device(grad), st, kind)
+        c2.prox_scale_entropy(p, 0.0, st, kind)
+        x0 = params.astype(np.float64)
+        p_ref, (_, v, r) = O.dog_step(x0, grad, (x0, 0.0, 1e-2 * (1.0 + np.linalg.norm(x0))), kind)
+        ref = O.proximal_location_scale_entropy(p_ref, 16, family, O.stepsize_from_optimizer_state(name, v=v, r=r))
+        assert np.allclose(p.cpu().numpy(), ref, rtol=(2e-6 if dtype == np.float32 else 1e-13), atol=1e-7 if dtype == np.float32 else 0)
+    ctx.close(); c2.close()
+
+
+def test_klminrepgradproxdescent_runs_deterministically_and_converges():
+    """test/algorithms/klminrepgradproxdescent.jl: same-seed determinism (:40-57), estimate_objective at q = pi ~ 0
+    (:36-37, atol 1e-3), and a convergence check in the spirit of :105-121 (distance to the optimum at least halves)."""
+    d = 5
+    rng = np.random.default_rng(1)
+    mu_true = rng.normal(size=d)
+    sig_true = rng.uniform(0.5, 1.5, size=d)
+    prob = avi.DiagNormalProblem(mu_true, sig_true)
+    q0 = avi.MeanFieldGaussian(np.zeros(d), np.ones(d))
+    alg = avi.KLMinRepGradProxDescent(avi.AutoMIVI(), n_samples=10, optimizer=avi.DoG(1e-2))
+    assert isinstance(alg.operator, avi.ProximalLocationScaleEntropy)
+    assert isinstance(alg.objective.entropy, avi.ClosedFormEntropyZeroGradient)
+    outs = []
+    for _ in range(2):
+        q, info, _ = avi.optimize(avi.PhiloxRNG(0x38bef07cf9cc549d), alg, 300, prob, q0)
+        outs.append((q.location.copy(), np.asarray(q.scale).copy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    d0 = np.linalg.norm(mu_true) ** 2 + np.linalg.norm(1.0 - sig_true) ** 2
+    d1 = np.linalg.norm(outs[0][0] - mu_true) ** 2 + np.linalg.norm(np.asarray(outs[0][1]).reshape(-1)[:d] - sig_true) ** 2 \
+        if np.asarray(outs[0][1]).ndim == 1 else np.linalg.norm(outs[0][0] - mu_true) ** 2 + np.linalg.norm(np.diag(outs[0][1]) - sig_true) ** 2
+    assert d1 <= d0 / 2, (d0, d1)
+    q_true = avi.MeanFieldGaussian(mu_true, sig_true)
+    assert abs(avi.estimate_objective(avi.PhiloxRNG(1), alg, q_true, prob, n_samples=10 ** 5)) < 1e-3
+    with pytest.raises(TypeError):
+        avi.KLMinRepGradProxDescent(avi.AutoMIVI(), optimizer=avi.Adam())
+    with pytest.raises(TypeError):
+        avi.KLMinRepGradProxDescent(avi.AutoMIVI(), entropy_zerograd=avi.ClosedFormEntropy())

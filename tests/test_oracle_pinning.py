@@ -195,3 +195,31 @@ def test_clip_scale():
     pf = np.concatenate([np.zeros(d), C.reshape(-1, order="F")])
     out = O.clip_scale(pf, d, O.FULLRANK, 1e-5)[d:].reshape(d, d, order="F")
     assert out[1, 1] == 1e-5 and out[2, 1] == 1.0 and np.all(np.triu(out, 1) == 0)
+
+
+@pytest.mark.parametrize("family", [O.MEANFIELD, O.FULLRANK])
+def test_proximal_location_scale_entropy_stationarity(family):
+    """test/general/proximal_location_scale_entropy.jl:3-56: the operator's output L' must satisfy
+    grad logabsdet(L') = grad ||L' - L||^2 / (2 eta)  (d = 5, L = I, eta = 1e-2), checked with AD of both sides."""
+    import torch
+    d, eta = 5, 1e-2
+    L = np.eye(d)
+    params = np.concatenate([np.zeros(d), np.ones(d) if family == O.MEANFIELD else L.reshape(-1, order="F")])
+    out = O.proximal_location_scale_entropy(params, d, family, eta)
+    Lp = np.diag(out[d:]) if family == O.MEANFIELD else out[d:].reshape(d, d, order="F")
+    x = torch.tensor(Lp, dtype=torch.float64, requires_grad=True)
+    left = torch.autograd.grad(torch.linalg.slogdet(torch.tril(x))[1], x)[0].numpy()
+    right = ((Lp - L) / eta)
+    assert np.allclose(np.diag(left), np.diag(right), rtol=1e-10)       # the diagonal is where logabsdet lives
+    assert np.allclose(np.tril(right, -1), 0.0) and np.allclose(out[:d], params[:d])
+    # closed form of the scalar problem: c' = (c + sqrt(c^2 + 4 eta)) / 2
+    assert np.allclose(np.diag(Lp), (1.0 + np.sqrt(1.0 + 4 * eta)) / 2)
+
+
+def test_stepsize_from_optimizer_state():
+    """src/optimization/proximal_location_scale_entropy.jl:26-42."""
+    assert O.stepsize_from_optimizer_state("descent", eta=0.3) == 0.3
+    assert np.isclose(O.stepsize_from_optimizer_state("dog", v=4.0, r=3.0), 1.5)
+    assert np.isclose(O.stepsize_from_optimizer_state("dowg", v=4.0, r=3.0), 4.5)
+    with pytest.raises(ValueError):
+        O.stepsize_from_optimizer_state("adam")
