@@ -9,13 +9,17 @@ from .problems import (LogDensityOrder, DiagNormalProblem, DenseNormalProblem, L
                        dimension, capabilities)
 from .objectives import (RepGradELBO, RepGradELBOState, ClosedFormEntropy, ClosedFormEntropyZeroGradient,
                          MonteCarloEntropy, StickingTheLandingEntropy, StickingTheLandingEntropyZeroGradient,
-                         AutoMIVI, PhiloxRNG, DiffResult, estimate_gradient_, set_objective_state_problem, rand)
+                         AutoMIVI, PhiloxRNG, DiffResult, set_objective_state_problem, rand)
 from . import objectives as _objectives
 from . import optimize as _optimize
 from .optimize import (KLMinRepGradDescent, KLMinRepGradProxDescent, ADVI, ClipScale, IdentityOperator,
                        ProximalLocationScaleEntropy, Descent, Adam, DoG, DoWG, NoAveraging,
                        PolynomialAveraging, optimize, step, output)
 from .context import MiviContext
+from .problems import subsample, LogRegSubset
+from .subsampling import (ReshufflingBatchSubsampling, ReshufflingBatchSubsamplingState, SubsampledObjective,
+                          SubsampledObjectiveState)
+from . import subsampling as _subsampling
 from . import distributed
 
 
@@ -24,11 +28,22 @@ def estimate_objective(*args, **kwargs):
     head = args[1] if isinstance(args[0], PhiloxRNG) else args[0]
     if isinstance(head, KLMinRepGradDescent):
         return _optimize.estimate_objective(*args, **kwargs)
+    if isinstance(head, SubsampledObjective):
+        return _subsampling.estimate_objective(*args, **kwargs)
     return _objectives.estimate_objective(*args, **kwargs)
+
+
+def estimate_gradient_(rng, obj, *args, **kwargs):
+    """`estimate_gradient!(rng, obj, adtype, out, state, params, restructure)` for RepGradELBO or SubsampledObjective."""
+    if isinstance(obj, SubsampledObjective):
+        return _subsampling.estimate_gradient_(rng, obj, *args, **kwargs)
+    return _objectives.estimate_gradient_(rng, obj, *args, **kwargs)
 
 
 def init(*args, **kwargs):
     """init(rng, alg, q_init, prob)  or  init(rng, obj, adtype, q, prob, params, restructure)."""
     if isinstance(args[1], KLMinRepGradDescent):
         return _optimize.init(*args, **kwargs)
+    if isinstance(args[1], SubsampledObjective):
+        return _subsampling.init(*args, **kwargs)
     return _objectives.init(*args, **kwargs)

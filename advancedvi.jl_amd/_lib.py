@@ -35,6 +35,7 @@ SIGNATURES = {
     "mivi_synchronize": (C.c_int32, [C.c_void_p]),
     "mivi_params_len": (C.c_int64, [C.c_void_p]),
     "mivi_partials_len": (C.c_int64, [C.c_void_p]),
+    "mivi_logreg_select_rows": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double]),
     "mivi_prox_scale_entropy": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int32]),
     "mivi_set_target_diag_gauss": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mivi_set_target_dense_gauss": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -96,6 +96,8 @@ class MiviContext:
         if P.dimension(prob) != self.d:
             raise ValueError("dimension(prob) does not match the variational family")
         dt = self.np_dtype
+        if not isinstance(prob, (P.LogRegProblem, P.LogRegSubset)):
+            self._lr_full = None   # another target kind replaces the resident data set
         if isinstance(prob, P.DiagNormalProblem):
             m = np.ascontiguousarray(prob.mean, dtype=dt)
             s = np.ascontiguousarray(np.broadcast_to(prob.std, m.shape), dtype=dt)
@@ -104,7 +106,10 @@ class MiviContext:
             m = np.ascontiguousarray(prob.mean, dtype=dt)
             L = np.asfortranarray(prob.L, dtype=dt)
             self._chk(self.lib.mivi_set_target_dense_gauss(self.h, m.ctypes.data, L.ctypes.data))
+        elif isinstance(prob, P.LogRegProblem) and getattr(self, "_lr_full", None) is prob:
+            self._chk(self.lib.mivi_logreg_select_rows(self.h, None, 0, 1.0))   # already resident: back to all rows
         elif isinstance(prob, P.LogRegProblem):
+            self._lr_full = prob
             torch = _torch()
             X = prob.X
             if isinstance(X, torch.Tensor):   # device-resident, column-major n x p expected
@@ -118,6 +123,10 @@ class MiviContext:
                 y = np.ascontiguousarray(prob.y, dtype=np.uint8)
                 self._chk(self.lib.mivi_set_target_logreg(self.h, Xf.ctypes.data, y.ctypes.data, Xf.shape[0],
                                                           P.LogRegProblem.VARIANTS[prob.variant], prob.likeadj, 0))
+        elif isinstance(prob, P.LogRegSubset):
+            if getattr(self, "_lr_full", None) is not prob.parent:   # upload the full data set once, then only select rows
+                self.set_problem(prob.parent)
+            self._chk(self.lib.mivi_logreg_select_rows(self.h, prob.batch.ctypes.data, prob.batch.size, prob.likeadj))
         elif isinstance(prob, P.FunnelProblem):
             self._chk(self.lib.mivi_set_target_funnel(self.h, prob.sigma_v))
         else:

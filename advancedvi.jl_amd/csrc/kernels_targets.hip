@@ -708,6 +708,39 @@ void logreg_prepare_f32(mivi_ctx *c) {
                      (float *)c->lr_Xrm.p);
 }
 
+// minibatch gather: column-major subset (generic / f64 route), labels, and -- f32 -- whole rows of the row-major copy
+template <typename T>
+__global__ void k_lr_gather_cm(long long n, long long b, int p, const long long *idx, const T *X, const uint8_t *y, T *Xs,
+                               uint8_t *ys) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= b) return;
+  const long long r = idx[j];
+  const int k = blockIdx.y;
+  Xs[(size_t)k * b + j] = X[(size_t)k * n + r];
+  if (k == 0) ys[j] = y[r];
+}
+__global__ void k_lr_gather_rm(long long b, int ldx, const long long *idx, const float *Xrm, float *Xs) {
+  const long long j = blockIdx.x;
+  const float4 *src = (const float4 *)(Xrm + (size_t)idx[j] * ldx);
+  float4 *dst = (float4 *)(Xs + (size_t)j * ldx);
+  for (int t = threadIdx.x; t < ldx / 4; t += 128) dst[t] = src[t];
+}
+void launch_logreg_gather(mivi_ctx *c, int64_t b) {
+  const int p = c->cfg.d - 1;
+  const dim3 g((unsigned)((b + 255) / 256), p);
+  const long long *idx = (const long long *)c->lr_idx.p;
+  if (c->cfg.dtype == MIVI_F32) {
+    hipLaunchKernelGGL(k_lr_gather_cm<float>, g, dim3(256), 0, c->stream, (long long)c->lr_n_full, (long long)b, p, idx,
+                       (const float *)c->lr_X_full, c->lr_y_full, (float *)c->lr_Xsub.p, (uint8_t *)c->lr_ysub.p);
+    const int ldx = (p + 31) / 32 * 32;
+    hipLaunchKernelGGL(k_lr_gather_rm, dim3((unsigned)b), dim3(128), 0, c->stream, (long long)b, ldx, idx,
+                       (const float *)c->lr_Xrm.p, (float *)c->lr_Xrm_sub.p);
+  } else {
+    hipLaunchKernelGGL(k_lr_gather_cm<double>, g, dim3(256), 0, c->stream, (long long)c->lr_n_full, (long long)b, p, idx,
+                       (const double *)c->lr_X_full, c->lr_y_full, (double *)c->lr_Xsub.p, (uint8_t *)c->lr_ysub.p);
+  }
+}
+
 static void logreg_mfma(mivi_ctx *c, int M, int want_grad) {
   LrMfmaArgs a;
   a.d = c->cfg.d;
@@ -715,7 +748,7 @@ static void logreg_mfma(mivi_ctx *c, int M, int want_grad) {
   a.M = M;
   a.n = c->lr_n;
   a.X = (const float *)c->lr_X;
-  a.Xrm = (const float *)c->lr_Xrm.p;
+  a.Xrm = (const float *)c->lr_Xrm_act;
   a.ldx = (a.p + 31) / 32 * 32;
   a.y = c->lr_y;
   a.ZT = (const float *)c->RT.p;
@@ -822,7 +855,7 @@ static void logreg_impl(mivi_ctx *c, int M, int want_grad) {
 
 void launch_logreg_target(mivi_ctx *c, int M, int want_grad) {
   static const bool force_generic = getenv("MIVI_LOGREG_GENERIC") != nullptr;
-  if (c->cfg.dtype == MIVI_F32 && c->lr_Xrm.p && !force_generic) logreg_mfma(c, M, want_grad);
+  if (c->cfg.dtype == MIVI_F32 && c->lr_Xrm_act && !force_generic) logreg_mfma(c, M, want_grad);
   else if (c->cfg.dtype == MIVI_F32) logreg_impl<float>(c, M, want_grad);
   else logreg_impl<double>(c, M, want_grad);
 }

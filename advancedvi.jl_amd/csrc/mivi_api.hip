@@ -142,7 +142,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->ticket, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->ticket, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t e : c->cap_events) (void)hipEventDestroy(e);
@@ -276,11 +276,51 @@ mivi_status_t mivi_set_target_logreg(mivi_ctx_t *c, const void *X, const uint8_t
   c->lr_n = n;
   c->lr_variant = variant;
   c->lr_likeadj = likeadj;
+  c->lr_X_full = c->lr_X;
+  c->lr_y_full = c->lr_y;
+  c->lr_n_full = n;
+  c->lr_likeadj_full = likeadj;
   c->t_const = 0.0;
   c->target = TGT_LOGREG;
   c->cap_M = 0;   // (re)allocate the transposed-sample buffer
   if (c->cfg.dtype == MIVI_F32) logreg_prepare_f32(c);
+  c->lr_Xrm_act = c->cfg.dtype == MIVI_F32 ? c->lr_Xrm.p : nullptr;
   invalidate_graph(c);
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_logreg_select_rows(mivi_ctx_t *c, const int64_t *idx, int64_t b, double likeadj) {
+  if (!c || b < 0 || (b > 0 && !idx)) return MIVI_ERR_BAD_ARG;
+  if (c->target != TGT_LOGREG || !c->lr_X_full) return fail(c, MIVI_ERR_NO_TARGET, "no logistic-regression target set");
+  (void)hipSetDevice(c->cfg.device);
+  invalidate_graph(c);
+  if (b == 0) {   // back to the full data set
+    c->lr_X = c->lr_X_full;
+    c->lr_y = c->lr_y_full;
+    c->lr_n = c->lr_n_full;
+    c->lr_likeadj = c->lr_likeadj_full;
+    c->lr_Xrm_act = c->cfg.dtype == MIVI_F32 ? c->lr_Xrm.p : nullptr;
+    return MIVI_OK;
+  }
+  if (!(likeadj > 0.0)) return fail(c, MIVI_ERR_BAD_ARG, "likelihood adjustment must be positive");
+  for (int64_t j = 0; j < b; ++j)
+    if (idx[j] < 0 || idx[j] >= c->lr_n_full) return fail(c, MIVI_ERR_BAD_ARG, "batch row index out of range");
+  const int p = c->cfg.d - 1;
+  mivi_status_t s;
+  if ((s = ensure(c, c->lr_idx, (size_t)b * sizeof(int64_t), false)) ||
+      (s = ensure(c, c->lr_Xsub, (size_t)b * p * c->esize, false)) || (s = ensure(c, c->lr_ysub, (size_t)b, false)))
+    return s;
+  if (c->cfg.dtype == MIVI_F32 && (s = ensure(c, c->lr_Xrm_sub, (size_t)b * ((p + 31) / 32 * 32) * sizeof(float), false))) return s;
+  // the previous estimate may still be reading the batch buffers: order the upload behind it
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->lr_idx.p, idx, (size_t)b * sizeof(int64_t), hipMemcpyHostToDevice));
+  launch_logreg_gather(c, b);
+  HIPCHK(c, hipGetLastError());
+  c->lr_X = c->lr_Xsub.p;
+  c->lr_y = (const uint8_t *)c->lr_ysub.p;
+  c->lr_n = b;
+  c->lr_likeadj = likeadj;
+  c->lr_Xrm_act = c->cfg.dtype == MIVI_F32 ? c->lr_Xrm_sub.p : nullptr;
   return MIVI_OK;
 }
 

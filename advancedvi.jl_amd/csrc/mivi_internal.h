@@ -187,6 +187,14 @@ struct mivi_ctx {
   const void *lr_X = nullptr;
   const uint8_t *lr_y = nullptr;
   mivi::DevBuf lr_X_own, lr_y_own, lr_scratch, lr_part, lr_Xrm;
+  // minibatch view (AdvancedVI.subsample, docs/src/tutorials/subsampling.md:99-102): the full data set stays resident,
+  // mivi_logreg_select_rows gathers the batch rows into lr_Xsub / lr_ysub / lr_Xrm_sub and points the active fields at them
+  const void *lr_X_full = nullptr;
+  const uint8_t *lr_y_full = nullptr;
+  int64_t lr_n_full = 0;
+  double lr_likeadj_full = 1.0;
+  const void *lr_Xrm_act = nullptr;      // row-major copy the MFMA kernels read (full or batch)
+  mivi::DevBuf lr_Xsub, lr_ysub, lr_Xrm_sub, lr_idx;
   int64_t lr_n = 0;
   int lr_variant = 0;
   double lr_likeadj = 1.0;
@@ -258,6 +266,7 @@ void logreg_prepare_f32(mivi_ctx *c);   // row-major padded copy of X for the MF
 // kernels_update.hip
 void launch_finalize(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad);
 void launch_prox(mivi_ctx *c, void *params, double stepsize, const void *dog_state, int dog_kind);
+void launch_logreg_gather(mivi_ctx *c, int64_t b);   // batch rows lr_idx[0..b) of the full data set -> lr_Xsub / lr_ysub / lr_Xrm_sub
 void launch_value_only(mivi_ctx *c, const void *params, const ValueIn &vin, const OutArgs &out);   // on c->stream
 void launch_clip(mivi_ctx *c, void *params, double epsilon);
 void launch_descent(mivi_ctx *c, void *params, const void *grad, double eta, double clip_eps = 0.0);

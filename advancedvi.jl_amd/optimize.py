@@ -9,6 +9,7 @@ import warnings
 import numpy as np
 
 from . import objectives as O
+from . import subsampling as S
 from .families import MvLocationScale, destructure
 
 
@@ -128,12 +129,12 @@ class KLMinRepGradDescent:
 
     def __init__(self, adtype, entropy=None, optimizer=None, n_samples: int = 1, averager=None, operator=None,
                  subsampling=None):
-        if subsampling is not None:
-            raise NotImplementedError("SubsampledObjective is outside the hot path built here (SURVEY.md 8f-4)")
         entropy = entropy if entropy is not None else O.ClosedFormEntropy()
         if not isinstance(entropy, (O.ClosedFormEntropy, O.StickingTheLandingEntropy, O.MonteCarloEntropy)):
             raise TypeError("entropy must be ClosedFormEntropy, StickingTheLandingEntropy or MonteCarloEntropy")
         self.objective = O.RepGradELBO(n_samples, entropy=entropy)
+        if subsampling is not None:   # constructors.jl:69-73
+            self.objective = S.SubsampledObjective(self.objective, subsampling)
         self.adtype = adtype
         self.optimizer = optimizer if optimizer is not None else DoWG()
         self.averager = averager if averager is not None else PolynomialAveraging()
@@ -149,8 +150,6 @@ class KLMinRepGradProxDescent(KLMinRepGradDescent):
     one of the two *ZeroGradient kinds; optimizer one of Descent / DoG / DoWG."""
 
     def __init__(self, adtype, entropy_zerograd=None, optimizer=None, n_samples: int = 1, averager=None, subsampling=None):
-        if subsampling is not None:
-            raise NotImplementedError("SubsampledObjective is outside the hot path built here (SURVEY.md 8f-4)")
         entropy = entropy_zerograd if entropy_zerograd is not None else O.ClosedFormEntropyZeroGradient()
         if not isinstance(entropy, (O.ClosedFormEntropyZeroGradient, O.StickingTheLandingEntropyZeroGradient)):
             raise TypeError("entropy_zerograd must be ClosedFormEntropyZeroGradient or StickingTheLandingEntropyZeroGradient")
@@ -158,10 +157,24 @@ class KLMinRepGradProxDescent(KLMinRepGradDescent):
         if not isinstance(optimizer, (Descent, DoG)):
             raise TypeError("optimizer must be Descent, DoG or DoWG")
         self.objective = O.RepGradELBO(n_samples, entropy=entropy)
+        if subsampling is not None:   # constructors.jl:145-149
+            self.objective = S.SubsampledObjective(self.objective, subsampling)
         self.adtype = adtype
         self.optimizer = optimizer
         self.averager = averager if averager is not None else PolynomialAveraging()
         self.operator = ProximalLocationScaleEntropy()
+
+
+def _obj_init(rng, obj, *a):
+    return (S.init if isinstance(obj, S.SubsampledObjective) else O.init)(rng, obj, *a)
+
+
+def _obj_estimate_gradient(rng, obj, *a):
+    return (S.estimate_gradient_ if isinstance(obj, S.SubsampledObjective) else O.estimate_gradient_)(rng, obj, *a)
+
+
+def _ctx_of(obj_st):
+    return obj_st.obj_st.obj_ad_prep if isinstance(obj_st, S.SubsampledObjectiveState) else obj_st.obj_ad_prep
 
 
 def estimate_objective(rng, alg, q, prob, n_samples=None, entropy=None):
@@ -170,6 +183,9 @@ def estimate_objective(rng, alg, q, prob, n_samples=None, entropy=None):
         rng, alg, q, prob = O.default_rng(), rng, alg, q
     n = n_samples if n_samples is not None else alg.objective.n_samples
     ent = entropy if entropy is not None else O.MonteCarloEntropy()
+    if isinstance(alg.objective, S.SubsampledObjective):
+        sub = S.SubsampledObjective(O.RepGradELBO(n, entropy=ent), alg.objective.subsampling)
+        return S.estimate_objective(rng, sub, q, prob, adtype=alg.adtype)
     return O.estimate_objective(rng, O.RepGradELBO(n, entropy=ent), q, prob, adtype=alg.adtype)
 
 
@@ -181,8 +197,8 @@ def init(rng, alg: KLMinRepGradDescent, q_init, prob):
             "this combination due to singular scale matrices. Consider using the operator `ClipScale` in the algorithm "
             "instead.")
     params_h, re = destructure(q_init)
-    obj_st = O.init(rng, alg.objective, alg.adtype, q_init, prob, params_h, re)
-    ctx = obj_st.obj_ad_prep
+    obj_st = _obj_init(rng, alg.objective, alg.adtype, q_init, prob, params_h, re)
+    ctx = _ctx_of(obj_st)
     params = ctx.to_device(params_h).clone()
     opt_st = alg.optimizer.setup(ctx, params)
     avg_st = alg.averager.init(ctx, params)
@@ -201,10 +217,11 @@ def step(rng, alg, state, callback, *objargs):
     state = dict(state)
     state["iteration"] += 1
     t = state["iteration"]
-    ctx = state["obj_st"].obj_ad_prep
+    ctx = _ctx_of(state["obj_st"])
     params, re = state["params"], state["restructure"]
-    grad_buf, obj_st, info = O.estimate_gradient_(rng, alg.objective, alg.adtype, state["grad_buf"], state["obj_st"],
+    grad_buf, obj_st, info = _obj_estimate_gradient(rng, alg.objective, alg.adtype, state["grad_buf"], state["obj_st"],
                                                   params, re, *objargs)
+    state["obj_st"] = obj_st
     value = grad_buf.value()          # host sync, like the reference's eager isfinite check
     if not np.isfinite(value):        # common.jl:83-89
         raise RuntimeError(f"The objective value is {value}. This indicates that the optimization run diverged.")
@@ -214,7 +231,7 @@ def step(rng, alg, state, callback, *objargs):
     state["avg_st"] = alg.averager.apply(ctx, state["avg_st"], params)
     state["params"] = params
     state["q"] = None  # materialised lazily by `output` / callbacks (params are device resident)
-    info = {"elbo": -value}
+    info = {**{k: v for k, v in info.items() if k != "elbo"}, "elbo": -value}   # subsampling adds (epoch, step)
     if callback is not None:
         extra = callback(rng=rng, iteration=t, restructure=re, params=params,
                          averaged_params=alg.averager.value(state["avg_st"]), gradient=grad, state=state)

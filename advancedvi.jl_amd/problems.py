@@ -84,6 +84,42 @@ class LogRegProblem:
     def capabilities(self):
         return LogDensityOrder(1)
 
+    def n_rows(self):
+        X = self.X
+        return X.shape[1] if getattr(self, "x_is_colmajor_tensor", False) else X.shape[0]
+
+    def subsample(self, batch):
+        """AdvancedVI.subsample(prob, batch): the rows `batch` (0-based) with the likelihood scaled by n_data / n
+        (docs/src/tutorials/subsampling.md:37,99-102).  The data stay on the device; see mivi_logreg_select_rows."""
+        return LogRegSubset(self, batch)
+
+
+class LogRegSubset:
+    """A minibatch view of a LogRegProblem (what `subsample` returns); never copies X on the host."""
+
+    def __init__(self, parent: LogRegProblem, batch):
+        self.parent = parent
+        self.batch = np.ascontiguousarray(np.asarray(batch, dtype=np.int64).reshape(-1))
+        if self.batch.size == 0:
+            raise ValueError("empty batch")
+        self.likeadj = parent.likeadj * parent.n_rows() / self.batch.size
+
+    def dimension(self):
+        return self.parent.dimension()
+
+    def capabilities(self):
+        return LogDensityOrder(1)
+
+    def subsample(self, batch):
+        return LogRegSubset(self.parent, self.batch[np.asarray(batch, dtype=np.int64)])
+
+
+def subsample(model, batch):
+    """AdvancedVI.subsample(model, batch): models that do not specialise it are returned unchanged
+    (src/AdvancedVI.jl:313; the tutorial's warning at docs/src/tutorials/subsampling.md:106-110)."""
+    fn = getattr(model, "subsample", None)
+    return fn(batch) if fn is not None else model
+
 
 class FunnelProblem:
     """Neal's funnel on the constrained scale under Stacked([log-bijector, identity]) (SURVEY.md 8d;
@@ -100,4 +136,4 @@ class FunnelProblem:
         return LogDensityOrder(1)
 
 
-BUILTIN = (DiagNormalProblem, DenseNormalProblem, LogRegProblem, FunnelProblem)
+BUILTIN = (DiagNormalProblem, DenseNormalProblem, LogRegProblem, LogRegSubset, FunnelProblem)

@@ -116,6 +116,12 @@ mivi_status_t mivi_set_target_dense_gauss(mivi_ctx_t *ctx, const void *mean_host
  * (borrowed, must outlive the ctx); otherwise host ptrs, copied. */
 mivi_status_t mivi_set_target_logreg(mivi_ctx_t *ctx, const void *X, const uint8_t *y, int64_t n,
                                      int32_t variant, double likeadj, int32_t x_on_device);
+/* AdvancedVI.subsample(prob, batch) for the built-in logistic regression (docs/src/tutorials/subsampling.md:99-102,
+ * src/algorithms/subsampledobjective.jl:85-87): the data set given to mivi_set_target_logreg stays resident, the target
+ * becomes its rows idx_host[0..b) (0-based) with the likelihood scaled by `likeadj` (= n_data / b, subsampling.md:37).
+ * b = 0 restores the full data set.  Synchronises the stream (the batch buffers are reused from step to step). */
+mivi_status_t mivi_logreg_select_rows(mivi_ctx_t *ctx, const int64_t *idx_host, int64_t b, double likeadj);
+
 /* Neal's funnel on the constrained scale + Stacked([log, identity]) bijector (README.md:76-82,102-106):
  * theta_1 = exp(eta_1) ~ LogNormal(0, sigma_v), theta_i ~ Normal(0, theta_1), log|det J| = eta_1. */
 mivi_status_t mivi_set_target_funnel(mivi_ctx_t *ctx, double sigma_v);

@@ -238,6 +238,12 @@ class LogRegTarget:
     def logdensity(self, z):
         return self.logdensity_and_gradient(z)[0]
 
+    def subsample(self, idx):
+        """AdvancedVI.subsample for the tutorial's LogReg (docs/src/tutorials/subsampling.md:99-102): the rows `idx`,
+        likelihood rescaled by n_data / n (:37)."""
+        idx = np.asarray(idx, dtype=np.int64)
+        return LogRegTarget(self.X[idx], self.y[idx], self.variant, self.likeadj * self.X.shape[0] / idx.size)
+
 
 class FunnelStackedTarget:
     """Neal's funnel on its constrained scale (defined in SURVEY.md section 8d -- the reference has

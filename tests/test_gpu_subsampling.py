@@ -1,0 +1,143 @@
+"""SubsampledObjective on the GPU (src/algorithms/subsampledobjective.jl, test/general/subsampledobj.jl):
+minibatches of the built-in logistic regression are device-side row selections of the resident data set."""
+import numpy as np
+import pytest
+
+import advancedvi_jl_amd as avi
+from oracle import oracle as O
+from tests.helpers import SEED, make_family
+
+pytestmark = pytest.mark.gpu
+
+
+class SubsampledNormals:
+    """test/models/subsamplednormals.jl:1-48 restated as a plugin target: 1-d, sum of unit-variance normals, likelihood
+    rescaled by n_data / n on subsampling."""
+
+    def __init__(self, mus, likeadj=1.0):
+        self.mus = np.asarray(mus, dtype=np.float64)
+        self.likeadj = float(likeadj)
+
+    def dimension(self):
+        return 1
+
+    def capabilities(self):
+        return avi.LogDensityOrder(1)
+
+    def logdensity_and_gradient(self, x):
+        r = float(x[0]) - self.mus
+        return self.likeadj * float(np.sum(-0.5 * r * r - 0.5 * np.log(2 * np.pi))), np.array([-self.likeadj * np.sum(r)])
+
+    def subsample(self, idx):
+        idx = np.asarray(idx, dtype=np.int64)
+        return SubsampledNormals(self.mus[idx], self.mus.size / idx.size)
+
+
+@pytest.mark.parametrize("batchsize", [1, 2, 4])
+def test_mean_of_minibatch_gradients_is_the_full_gradient(batchsize):
+    """test/general/subsampledobj.jl:62-89: same Monte-Carlo samples for every minibatch (rng re-seeded), n_data = 8."""
+    n_data = 8
+    rng0 = np.random.default_rng(3)
+    model = SubsampledNormals(rng0.normal(size=n_data))
+    q0 = avi.MeanFieldGaussian(np.array([model.mus.mean()]), np.array([np.sqrt(1.0 / n_data)]))
+    params, re = avi.destructure(q0)
+    full_obj = avi.RepGradELBO(10)
+    ad = avi.AutoMIVI()
+
+    rng = avi.PhiloxRNG(SEED)
+    st = avi.init(rng, full_obj, ad, q0, model, params, re)
+    ctx = st.obj_ad_prep
+    out = avi.DiffResult(ctx.empty(1), ctx.empty(ctx.params_len))
+    avi.estimate_gradient_(avi.PhiloxRNG(SEED, 100), full_obj, ad, out, st, ctx.to_device(params), re)
+    grad_ref = out.gradient().cpu().numpy().copy()
+
+    sub = avi.ReshufflingBatchSubsampling(np.arange(n_data), batchsize)
+    sub_obj = avi.SubsampledObjective(full_obj, sub)
+    rng = avi.PhiloxRNG(SEED)
+    sst = avi.init(rng, sub_obj, ad, q0, model, params, re)
+    ctx2 = sst.obj_st.obj_ad_prep
+    out2 = avi.DiffResult(ctx2.empty(1), ctx2.empty(ctx2.params_len))
+    grads, seen = [], []
+    shuffle_rng = rng
+    for _ in range(len(sub)):
+        # the reference re-seeds the rng before every call so that all minibatches see the same eps; here the eps stream
+        # position is explicit, so: batches come from `shuffle_rng`, the estimate index is pinned to 100
+        batch, sub_st, _ = avi._subsampling.step_subsampling(shuffle_rng, sub, sst.sub_st, True)
+        seen.extend(batch.tolist())
+        obj_st = avi.set_objective_state_problem(sst.obj_st, avi.subsample(model, batch))
+        avi.estimate_gradient_(avi.PhiloxRNG(SEED, 100), full_obj, ad, out2, obj_st, ctx2.to_device(params), re)
+        sst = avi.SubsampledObjectiveState(model, sub_st, obj_st)
+        grads.append(out2.gradient().cpu().numpy().copy())
+    assert sorted(seen) == list(range(n_data))
+    assert np.allclose(np.mean(grads, axis=0), grad_ref, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_logreg_row_selection_matches_the_oracle(dtype):
+    """mivi_logreg_select_rows: estimate on a minibatch == oracle on tgt.subsample(batch), same eps; back to all rows."""
+    rng = np.random.default_rng(8)
+    n, p, M = 700, 9, 24
+    d = p + 1
+    X = rng.normal(size=(n, p)) / np.sqrt(p)
+    y = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    prob = avi.LogRegProblem(X.astype(dtype), y)
+    tgt = O.LogRegTarget(X.astype(dtype).astype(np.float64), y)
+    q, q_o = make_family(rng, d, avi.FULLRANK, dtype, mu_scale=0.1)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(dtype, avi.FULLRANK, d, M, 0, SEED)
+    vt, gt = (2e-5, 5e-5) if dtype == np.float32 else (1e-11, 1e-10)
+    for batch in (rng.permutation(n)[:257], np.array([3]), np.arange(n)[::-1], None, rng.integers(0, n, size=64)):
+        if batch is None:
+            ctx.set_problem(prob)
+            t = tgt
+        else:
+            ctx.set_problem(avi.subsample(prob, batch))
+            t = tgt.subsample(batch)
+        _, eps = ctx.sample(params, 5)
+        v, g = ctx.estimate_gradient(params, 5)
+        ref = O.estimate_gradient(O.destructure(q_o), d, O.FULLRANK, t, eps.cpu().numpy().astype(np.float64), 0)
+        assert abs(float(v.item()) - ref["value"]) <= vt * abs(ref["value"])
+        assert np.linalg.norm(g.cpu().numpy() - ref["grad"]) <= gt * max(np.linalg.norm(ref["grad"]), 1.0)
+    with pytest.raises(Exception, match="out of range"):
+        ctx.set_problem(avi.subsample(prob, [n]))
+    ctx.close()
+
+
+@pytest.mark.parametrize("batchsize", [1, 3, 4])
+def test_algorithms_run_with_subsampling_and_are_deterministic(batchsize):
+    """test/general/subsampledobj.jl:12-52: constructors with `subsampling`, finite elbo, same-seed determinism,
+    info carries (epoch, step)."""
+    n_data = 8
+    model = SubsampledNormals(np.random.default_rng(3).normal(size=n_data))
+    q0 = avi.MeanFieldGaussian(np.array([model.mus.mean()]), np.array([np.sqrt(1.0 / n_data)]))
+    sub = avi.ReshufflingBatchSubsampling(np.arange(n_data), batchsize)
+    for alg in (avi.KLMinRepGradDescent(avi.AutoMIVI(), n_samples=10, subsampling=sub, operator=avi.ClipScale()),
+                avi.KLMinRepGradProxDescent(avi.AutoMIVI(), n_samples=10, subsampling=sub)):
+        outs = []
+        for _ in range(2):
+            q, info, _ = avi.optimize(avi.PhiloxRNG(SEED), alg, 10, model, q0)
+            assert np.isfinite(info[-1]["elbo"]) and info[-1]["epoch"] >= 1 and 1 <= info[-1]["step"] <= len(sub)
+            outs.append((q.location.copy(), np.asarray(q.scale).copy()))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("batchsize", [1, 3, 4])
+def test_subsampled_objective_value_matches_full(batchsize):
+    """test/general/subsampledobj.jl:54-60 (rtol 0.1)."""
+    n_data = 8
+    model = SubsampledNormals(np.random.default_rng(3).normal(size=n_data))
+    q0 = avi.MeanFieldGaussian(np.array([model.mus.mean()]), np.array([np.sqrt(1.0 / n_data)]))
+    full_obj = avi.RepGradELBO(10)
+    sub_obj = avi.SubsampledObjective(full_obj, avi.ReshufflingBatchSubsampling(np.arange(n_data), batchsize))
+    full = avi.estimate_objective(avi.PhiloxRNG(1), full_obj, q0, model, n_samples=10 ** 5)
+    subv = avi.estimate_objective(avi.PhiloxRNG(2), sub_obj, q0, model, n_samples=10 ** 5)
+    assert abs(full - subv) <= 0.1 * abs(full)
+    # built-in LogReg: minibatches are row selections on one context
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(64, 5)); y = (rng.uniform(size=64) < 0.5).astype(np.uint8)
+    prob = avi.LogRegProblem(X, y)
+    q = avi.MeanFieldGaussian(np.zeros(6), np.full(6, 0.3))
+    so = avi.SubsampledObjective(avi.RepGradELBO(8), avi.ReshufflingBatchSubsampling(np.arange(64), 16))
+    a = avi.estimate_objective(avi.PhiloxRNG(1), avi.RepGradELBO(8), q, prob, n_samples=20000)
+    b = avi.estimate_objective(avi.PhiloxRNG(2), so, q, prob, n_samples=20000)
+    assert abs(a - b) <= 0.05 * abs(a)
