@@ -858,6 +858,14 @@ __global__ __launch_bounds__(NW * 64) void k_stl_solve(FrArgs<float> a, const fl
     x[k * 32 + m] = a.eps[(size_t)(m0 + m) * dP + k];
   }
   __syncthreads();
+  // The A operands (blocks of C^T) never depend on X: the first unit of block row b-1 is fetched while block row b is
+  // still being reduced and solved, so its L2 latency is off the sequential chain.
+  float av0[16], av1[16];
+  auto loadA = [&](int brow, int j, float (&av)[16]) {    // A[i][k] = CT[(brow*32+i) + k*dP]
+    const float *Arow = CT + brow * 32 + l31;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) av[u] = Arow[(size_t)(j * 32 + 2 * u + h) * dP];
+  };
   for (int b = nb - 1; b >= 0; --b) {
     // wave 0 will need DinvT_b at the end of this step: issue those loads first (independent of X)
     float dv[16];
@@ -871,12 +879,6 @@ __global__ __launch_bounds__(NW * 64) void k_stl_solve(FrArgs<float> a, const fl
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const float *Arow = CT + b * 32 + l31;                // A[i][k] = CT[(b*32+i) + k*dP]
-    float av0[16], av1[16];
-    auto loadA = [&](int j, float (&av)[16]) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) av[u] = Arow[(size_t)(j * 32 + 2 * u + h) * dP];
-    };
     auto mma = [&](int j, const float (&av)[16]) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
@@ -886,18 +888,20 @@ __global__ __launch_bounds__(NW * 64) void k_stl_solve(FrArgs<float> a, const fl
     };
     int j = b + 1 + w;
     if (j < nb) {
-      loadA(j, av0);
+      // av0 already holds unit j of this block row (prefetched during the previous step)
       while (true) {
-        if (j + NW < nb) loadA(j + NW, av1);
+        if (j + NW < nb) loadA(b, j + NW, av1);
         mma(j, av0);
         j += NW;
         if (j >= nb) break;
-        if (j + NW < nb) loadA(j + NW, av0);
+        if (j + NW < nb) loadA(b, j + NW, av0);
         mma(j, av1);
         j += NW;
         if (j >= nb) break;
       }
     }
+    // prefetch the first unit of the next block row (b-1): unit j = b + w
+    if (b > 0 && b + w < nb) loadA(b - 1, b + w, av0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) part[w * (16 * 64) + r * 64 + lane] = acc[r];
     __syncthreads();
