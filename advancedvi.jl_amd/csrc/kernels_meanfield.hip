@@ -79,6 +79,25 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
         if (4 * rq + r < d) s_ell += T(-0.5) * u * u;
         g[r] = -u * tis[r];
       }
+    } else if (a.target == TGT_FUNNEL) {
+      // Neal's funnel + Stacked([log, identity]) fused (see FunnelFin): rows >= 1 need only e1[m] = z[0, m], re-derived
+      // from the eps stream; row 0 and ell are finished by the value workgroup from the per-quad sums of squares
+      T e0q[4];
+      if (rq == 0) { e0q[0] = e[0]; }
+      else eps_block<T>(a.rng.seed, idx, (uint64_t)(a.rng.m_offset + m) * (uint64_t)d4, e0q);
+      const T e1 = a.params[0] + a.params[d] * e0q[0];
+      const T inv_s2 = exp(T(-2) * e1);
+      T x2 = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * rq + r;
+        const T z = mu[r] + sg[r] * e[r];
+        if (i >= 1 && i < d) {
+          g[r] = -z * inv_s2;
+          x2 += z * z;
+        }
+      }
+      a.fn_cs[(size_t)rq * a.fn_Mld + m] = x2;
     } else if (a.want_grad) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) g[r] = a.G[(size_t)m * d + min(4 * rq + r, d - 1)];
@@ -90,7 +109,8 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
       s_he += T(0.5) * er * er;
       if (a.want_grad) {
         isg[r] = T(1) / sg[r];
-        const T w = ok ? (g[r] + (stl ? er * isg[r] : T(0))) : T(0);
+        const bool mine = ok && !(a.target == TGT_FUNNEL && 4 * rq + r == 0);   // funnel row 0: value workgroup
+        const T w = mine ? (g[r] + (stl ? er * isg[r] : T(0))) : T(0);
         sW[r] += w;
         sWe[r] += w * er;
       }
@@ -145,7 +165,7 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
   if (a.want_grad && tid < 8) {
     if (a.n_cc == 1) {
       const int r = tid & 3, i = 4 * rq + r;
-      if (i < d) {
+      if (i < d && !(a.target == TGT_FUNNEL && i == 0)) {
         if (a.out.partials_mode) {
           ((T *)a.out.partials)[(tid < 4 ? 0 : d) + i] = (T)tot[tid];
         } else {
@@ -173,7 +193,7 @@ __global__ __launch_bounds__(256) void k_mf_colreduce(MfArgs<T> a) {
     double s = 0.0;
     for (int cc = 0; cc < a.n_cc; ++cc) s += a.row_part[((size_t)cc * d4 + rq) * 8 + k];
     const int i = 4 * rq + (k & 3);
-    if (i < d) {
+    if (i < d && !(a.target == TGT_FUNNEL && i == 0)) {   // funnel row 0 belongs to the value workgroup
       if (a.out.partials_mode) {
         ((T *)a.out.partials)[(k < 4 ? 0 : d) + i] = (T)s;
       } else {
@@ -446,7 +466,9 @@ static void mf_main_impl(mivi_ctx *c, const void *params, const RngArgs &rng, in
   a.cols_per_cc = cols;
   a.params = (const T *)params;
   a.rng = rng;
-  a.target = (G == nullptr && c->target == TGT_DIAG_GAUSS) ? TGT_DIAG_GAUSS : TGT_NONE;
+  a.target = (G == nullptr && (c->target == TGT_DIAG_GAUSS || c->target == TGT_FUNNEL)) ? c->target : TGT_NONE;
+  a.fn_cs = (T *)c->fn_cs[c->cur].p;
+  a.fn_Mld = c->MP;
   a.t_mean = (const T *)c->t_mean.p;
   a.t_istd = (const T *)c->t_istd.p;
   a.G = (const T *)G;

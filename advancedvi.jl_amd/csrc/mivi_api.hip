@@ -75,6 +75,9 @@ static mivi_status_t ensure_work(mivi_ctx *c, int M) {
       if ((s = ensure(c, c->stl_CT, (size_t)c->dP * c->dP * sizeof(float), true))) return s;
       if ((s = ensure(c, c->stl_Dinv, (size_t)((d + 31) / 32) * 1024 * sizeof(float), false))) return s;
     }
+    if (c->cfg.family == MIVI_MEANFIELD && c->target == TGT_FUNNEL)
+      for (int b = 0; b < 2; ++b)
+        if ((s = ensure(c, c->fn_cs[b], (size_t)d4 * capM * es, false))) return s;
     if ((s = ensure(c, c->Z, (size_t)d * capM * es, false))) return s;
     if ((s = ensure(c, c->W, (size_t)d * capM * es, false))) return s;
     if ((s = ensure(c, c->ell, (size_t)capM * es, false))) return s;
@@ -142,7 +145,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->ticket, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->ticket, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   for (hipEvent_t e : c->cap_events) (void)hipEventDestroy(e);
@@ -395,6 +398,8 @@ struct Chain {
 
 static bool hetero_ok(const mivi_ctx *c, int want_grad) {
   if (!want_grad) return false;
+  // (the fused funnel target is NOT chained: its value workgroup also finishes two gradient entries, which an optimiser
+  //  step right after the estimate must already see)
   if (c->cfg.family == MIVI_MEANFIELD) return c->target == TGT_DIAG_GAUSS;
   if (c->cfg.dtype != MIVI_F32 && f64_valu()) return false;
   return c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS;
@@ -432,8 +437,17 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
   const ValueJob *prev = (chained && ch->have_prev) ? &ch->prev : nullptr;
 
   if (c->cfg.family == MIVI_MEANFIELD) {
-    if (c->target == TGT_DIAG_GAUSS) {
+    if (c->target == TGT_DIAG_GAUSS || (c->target == TGT_FUNNEL && want_grad)) {
       launch_mf_main(c, params, rng, M, want_grad, nullptr, vin, out, prev);
+      if (c->target == TGT_FUNNEL) {   // row 0 and ell are finished by whoever assembles the value (FunnelFin)
+        vin.fn.cs = c->fn_cs[p].p;
+        vin.fn.params = params;
+        vin.fn.rng = rng;
+        vin.fn.d4 = d4;
+        vin.fn.M = M;
+        vin.fn.Mld = c->MP;
+        vin.fn.sigma_v = c->funnel_sigma_v;
+      }
       vin.ell_part2 = (const double *)c->sc_part[p].p;
       vin.n_ell_part2 = c->mf_nblk;
       vin.he_part = (const double *)c->sc_part[p].p + c->mf_nblk;

@@ -32,8 +32,20 @@ enum TargetKind : int {
   TGT_CALLBACK = 5
 };
 
+// Fused funnel target (mean-field): the only cross-row coupling of Neal's funnel is sum_i x_i^2 per sample, needed by
+// row 0's gradient and by ell.  The main kernel handles rows >= 1 on its own (every block re-derives e1[m] = z[0, m] from
+// the eps stream) and leaves per-(row-quad, column) sums of squares here; the value workgroup finishes row 0 and ell.
+struct FunnelFin {
+  const void *cs;      // T[d4][Mld] sum over the quad's rows i >= 1 of z_i^2  (nullptr = no funnel work)
+  const void *params;  // [mu; sigma]
+  RngArgs rng;
+  int d4, M, Mld;
+  double sigma_v;
+};
+
 // reduction inputs of the objective value, summed in a fixed order by one workgroup
 struct ValueIn {
+  FunnelFin fn;
   const double *ell_part;  // per-workgroup partial sums of sum_m ell_m (variable part)
   int n_ell_part;
   const double *ell_part2; // second set (the launching kernel's own partials)
@@ -74,6 +86,8 @@ struct MfArgs {
   const T *t_mean;     // diag gauss mean[d]
   const T *t_istd;     // 1/std[d]
   const T *G;          // generic route: d x M gradient of log pi (ld = d)
+  T *fn_cs;            // fused funnel target (TGT_FUNNEL): out, [d4][fn_Mld] per-quad sums of z_i^2 (rows >= 1)
+  int fn_Mld;
   int want_grad;
   // scratch
   double *row_part;    // [n_cc][2*d4*4] partial row sums when n_cc > 1
@@ -195,6 +209,7 @@ struct mivi_ctx {
   double lr_likeadj_full = 1.0;
   const void *lr_Xrm_act = nullptr;      // row-major copy the MFMA kernels read (full or batch)
   mivi::DevBuf lr_Xsub, lr_ysub, lr_Xrm_sub, lr_idx;
+  mivi::DevBuf fn_cs[2];                   // funnel per-(row-quad, column) sums of squares, by parity
   int64_t lr_n = 0;
   int lr_variant = 0;
   double lr_likeadj = 1.0;
