@@ -8,12 +8,11 @@
 //              d/dmu = -(1/M) sum_m W_m,  d/dsigma = -(1/M) sum_m W_m .* eps_m - direct/sigma,
 //              W = grad logpi(z) (+ eps/sigma for the sticking-the-landing estimators)
 //
-// HBM-bound elementwise work + row reductions: eps is generated in registers (one Philox block =
-// rows 4b..4b+3 of one column), lanes run along the sample axis so every row sum is a wave64
-// reduction, and the whole estimate is ONE launch: workgroup (b, 0) owns rows 4b..4b+3 for all
-// columns, writes their gradient entries directly, and the last workgroup to draw a ticket
-// assembles the scalar objective from per-workgroup partials (agent-scope atomics both sides;
-// fixed summation order => bitwise reproducible).
+// Elementwise work + row reductions: eps is generated in registers (one Philox block = rows 4b..4b+3 of one column),
+// lanes run along the sample axis so every row sum is a wave64 reduction, and the whole estimate is ONE launch:
+// workgroup (b, 0) owns rows 4b..4b+3 for all columns and writes their gradient entries directly; per-workgroup scalar
+// partials are assembled into the objective value by one extra workgroup of the NEXT estimate's launch (graph-chained
+// mode) or by k_value_only (single calls) in a fixed summation order => bitwise reproducible.
 #include "device_common.h"
 #include "optim_rules.h"
 
@@ -475,7 +474,6 @@ static void mf_main_impl(mivi_ctx *c, const void *params, const RngArgs &rng, in
   a.want_grad = want_grad;
   a.row_part = (double *)c->row_part.p;
   a.sc_part = (double *)c->sc_part[c->cur].p;
-  a.ticket = nullptr;
   a.vin = vin;
   a.out = out;
   a.dbg = c->dbg;

@@ -92,7 +92,6 @@ struct MfArgs {
   // scratch
   double *row_part;    // [n_cc][2*d4*4] partial row sums when n_cc > 1
   double *sc_part;     // [n_blocks][2]  scalar partials
-  unsigned int *ticket;
   ValueIn vin;
   OutArgs out;
   long long *dbg;      // optional timeline: dbg[block*8 + k] = wall_clock64() stamps (nullptr = off)
@@ -230,7 +229,7 @@ struct mivi_ctx {
   int cur = 0;
   int mf_nblk = 0;
   mivi::DevBuf Z, W, RT, ell, X;
-  mivi::DevBuf row_part, ticket, status, d_idx, acc, tmp_params, tmp_out;
+  mivi::DevBuf row_part, status, d_idx, acc, tmp_params, tmp_out;
   hipStream_t side_eps = nullptr, side_val = nullptr;   // capture-only fork streams
   std::vector<hipEvent_t> cap_events;
   const uint64_t *idx_src = nullptr;   // mivi_set_index_source

@@ -37,8 +37,8 @@ dtype_code(::Type{Float64}) = Int32(1)
 family_code(::MvLocationScale{<:Diagonal}) = Int32(0)
 family_code(::MvLocationScale) = Int32(1)
 
-mutable struct MIVIState{P}
-    problem::P
+mutable struct MIVIState
+    problem::Any                 # the (possibly minibatch-conditioned) LogDensityProblem
     T::DataType                  # element type of params (Float32 / Float64)
     ctx::Ptr{Cvoid}
     estimate_idx::UInt64         # replaces the hidden position of `rng`
@@ -113,5 +113,42 @@ function AdvancedVI.estimate_objective(rng::Random.AbstractRNG, obj::RepGradELBO
     return value[]
 end
 
-export AutoMIVI
+# set_objective_state_problem (src/algorithms/repgradelbo.jl:31-39): SubsampledObjective swaps the minibatch-conditioned
+# problem in before every estimate (src/algorithms/subsampledobjective.jl:85-87).  With the host-callback target only the
+# Julia-side problem changes; a native logistic-regression target (see `native_logreg!`) re-points its rows instead.
+function AdvancedVI.set_objective_state_problem(state::MIVIState, prob)
+    state.problem = prob
+    if prob isa NativeLogRegBatch
+        check(state.ctx, ccall((:mivi_logreg_select_rows, libmivi), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int64, Float64),
+                               state.ctx, prob.rows0, length(prob.rows0), prob.likeadj))
+    end
+    return state
+end
+
+# A target whose arithmetic stays on the GPU: hierarchical logistic regression (docs/src/tutorials/subsampling.md:20-46).
+# `AdvancedVI.subsample` returns a NativeLogRegBatch (0-based rows + n_data / n), consumed above.
+struct NativeLogReg{XT,YT}
+    X::XT            # n x p, column-major (Julia's native layout), eltype = the family's eltype
+    y::YT            # Vector{UInt8} in {0, 1}
+end
+struct NativeLogRegBatch
+    parent::NativeLogReg
+    rows0::Vector{Int64}
+    likeadj::Float64
+end
+LogDensityProblems.dimension(m::NativeLogReg) = size(m.X, 2) + 1
+LogDensityProblems.dimension(m::NativeLogRegBatch) = LogDensityProblems.dimension(m.parent)
+AdvancedVI.subsample(m::NativeLogReg, idx) = NativeLogRegBatch(m, Int64.(collect(idx)) .- 1, size(m.X, 1) / length(idx))
+
+function native_logreg!(state::MIVIState, m::NativeLogReg; variant::Int = 0, likeadj::Real = 1.0)
+    check(state.ctx, ccall((:mivi_set_target_logreg, libmivi), Int32,
+                           (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt8}, Int64, Int32, Float64, Int32),
+                           state.ctx, m.X, m.y, size(m.X, 1), variant, likeadj, 0))
+    return state
+end
+
+# ProximalLocationScaleEntropy on the host arrays works unchanged (src/optimization/proximal_location_scale_entropy.jl);
+# the device-resident variant for a parameter vector that lives in HBM is mivi_prox_scale_entropy.
+
+export AutoMIVI, NativeLogReg, native_logreg!
 end # module
