@@ -148,11 +148,8 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
                     &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
-  for (hipEvent_t e : c->cap_events) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
-  if (c->side_eps) (void)hipStreamDestroy(c->side_eps);
-  if (c->side_val) (void)hipStreamDestroy(c->side_val);
   delete c;
   return MIVI_OK;
 }

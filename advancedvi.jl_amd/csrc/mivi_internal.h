@@ -230,8 +230,6 @@ struct mivi_ctx {
   int mf_nblk = 0;
   mivi::DevBuf Z, W, RT, ell, X;
   mivi::DevBuf row_part, status, d_idx, acc, tmp_params, tmp_out;
-  hipStream_t side_eps = nullptr, side_val = nullptr;   // capture-only fork streams
-  std::vector<hipEvent_t> cap_events;
   const uint64_t *idx_src = nullptr;   // mivi_set_index_source
   // speculative eps prefetch across single calls: the VJP kernel of estimate (seed, idx) also generates eps of
   // (seed, idx + 1) into the other parity; a following call for exactly that estimate skips its eps kernel
