@@ -19,6 +19,7 @@
 #include <cstdlib>
 
 #include "device_common.h"
+#include "optim_rules.h"
 
 namespace mivi {
 
@@ -111,7 +112,7 @@ __device__ __forceinline__ void tile_coords(const int d, const int M, int &ib, i
 // accumulator of tile element (row, col); rs_lds[NT] holds per-thread partial row sums of A
 // (only meaningful for diagonal VJP tiles).  NT threads, all participate.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int MODE, int NT, typename Get>
+template <typename T, int MODE, int NT, bool FUSED = false, typename Get>
 __device__ double tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *rs_lds, double *red,
                                 const T *cii_lds = nullptr) {
   const int tid = threadIdx.x;
@@ -169,6 +170,58 @@ __device__ double tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *
     const double invM = 1.0 / (double)a.out.M_total;
     const double direct = direct_entropy_coeff(a.out.ent_kind);
     T *dst = a.out.partials_mode ? (T *)a.out.partials : (T *)a.out.grad;
+    // optimiser step applied in place (FusedUpdate); a separate instantiation so that the plain VJP kernel carries none of it
+    const bool fused = FUSED && !a.out.partials_mode && a.upd.rule >= 0;
+    const size_t plen = (size_t)d + (size_t)d * d;
+    auto apply_update = [&](size_t pi, T g, bool is_diag) {
+      T *pp = (T *)a.upd.params;
+      T x;
+      if (a.upd.rule == 0) {
+        x = descent_step(pp[pi], g, (T)a.upd.eta);
+      } else {
+        T *st = (T *)a.upd.state;
+        T m = st[pi], vv = st[plen + pi];
+        x = adam_step<T>(pp[pi], g, m, vv, a.adam_cc[0], a.adam_cc[1], (T)a.upd.eta, (T)a.upd.b1, (T)a.upd.b2, (T)a.upd.eps);
+        st[pi] = m;
+        st[plen + pi] = vv;
+      }
+      if (is_diag && a.upd.clip_eps > 0.0) x = clip_step(x, (T)a.upd.clip_eps);
+      pp[pi] = x;
+    };
+    // fused optimiser step: fetch this thread's parameters (and Adam moments) up front -- one memory round trip for
+    // all of its elements instead of one per element (the stores below would otherwise order the loads behind them)
+    // fused optimiser step: fetch this thread's parameters (and Adam moments) in one batch at the top of the epilogue --
+    // one memory round trip for all of its elements instead of one per element (the stores below would otherwise order
+    // the loads behind them).  (Fetching them before the main loop was tried: the registers held across the loop cost
+    // more than the hidden round trip gained.)
+    constexpr int NE = (32 + CG - 1) / CG;
+    T px[NE], pm[NE], pv[NE];
+    if (fused) {
+      const T *pp = (const T *)a.upd.params;
+      const T *st = (const T *)a.upd.state;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int col = cg + e * CG, gj = n0 + col;
+        const bool mine = col < 32 && gi < d && gj <= gi;
+        const size_t pi = mine ? d + (size_t)gj * d + gi : 0;
+        px[e] = pp[pi];
+        pm[e] = (a.upd.rule == 1) ? st[pi] : T(0);
+        pv[e] = (a.upd.rule == 1) ? st[plen + pi] : T(0);
+      }
+    }
+    auto apply_loaded = [&](int e, size_t pi, T g, bool is_diag) {
+      T x;
+      if (a.upd.rule == 0) {
+        x = descent_step(px[e], g, (T)a.upd.eta);
+      } else {
+        T m = pm[e], vv = pv[e];
+        x = adam_step<T>(px[e], g, m, vv, a.adam_cc[0], a.adam_cc[1], (T)a.upd.eta, (T)a.upd.b1, (T)a.upd.b2, (T)a.upd.eps);
+        ((T *)a.upd.state)[pi] = m;
+        ((T *)a.upd.state)[plen + pi] = vv;
+      }
+      if (is_diag && a.upd.clip_eps > 0.0) x = clip_step(x, (T)a.upd.clip_eps);
+      ((T *)a.upd.params)[pi] = x;
+    };
 #pragma unroll
     for (int col = cg; col < 32; col += CG) {
       const int gj = n0 + col;
@@ -186,8 +239,10 @@ __device__ double tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *
           if (gi == gj) x -= direct / (double)(cii_lds ? cii_lds[row] : a.params[d + (size_t)gi * d + gi]);
           o = (T)x;
         }
-        dst[d + (size_t)gj * d + gi] = o;
+        if (!fused) dst[d + (size_t)gj * d + gi] = o;
+        else if (gj <= gi) apply_loaded((col - cg) / CG, d + (size_t)gj * d + gi, o, gi == gj);   // zero gradients above the diagonal move nothing
       }
+      if (fused) continue;
       // mirrored strictly-upper tile is structurally zero
       if (jb != ib) {
         const int ui = n0 + row, uj = i0 + col;   // element (ui, uj) with ui < uj
@@ -200,7 +255,10 @@ __device__ double tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *
 #pragma unroll
         for (int g = 0; g < CG; ++g) s += (double)rs_lds[tid + 32 * g];
         const int gr = i0 + tid;
-        if (gr < d) dst[gr] = a.out.partials_mode ? (T)s : (T)(-s * invM);
+        if (gr < d) {
+          if (fused) apply_update((size_t)gr, (T)(-s * invM), false);
+          else dst[gr] = a.out.partials_mode ? (T)s : (T)(-s * invM);
+        }
         T lg = 0, bad = 0;
         if (gr < d) {
           const T cii = cii_lds ? cii_lds[tid] : a.params[d + (size_t)gr * d + gr];
@@ -425,17 +483,21 @@ __device__ __forceinline__ void run_pair_sample(const FrArgs<float> &a, int ib0,
   }
 }
 
-template <int MODE, int NW, bool ALIGNED>
+template <int MODE, int NW, bool ALIGNED, bool FUSED = false>
 __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
   constexpr int NT = NW * 64;
   constexpr int NSEG = (MODE == MODE_SAMPLE) ? 2 : 1;
   __shared__ float red_acc[NSEG][NW][16 * 65];
   __shared__ float rs_lds[NT];
   __shared__ float cii_lds[32];
+  __shared__ float adam_cc[2];
   __shared__ double red[NW];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform
   const int d = a.d, M = a.M;
+  if (FUSED && a.upd.rule == 1 && tid == 0)                 // visible to everyone after the reduction barrier below
+    adam_bias<float>(a.upd.t_base + (a.upd.t_ptr ? *a.upd.t_ptr : 0), a.upd.b1, a.upd.b2, adam_cc[0], adam_cc[1]);
+  a.adam_cc = adam_cc;
 
   // ---- heterogeneous workgroups -----------------------------------------------------------------
   if (MODE == MODE_VJP && (int)blockIdx.x < a.n_pre) {   // eps(t+1) tile
@@ -523,7 +585,7 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
       for (int ww = 1; ww < NW; ++ww) s += red_acc[sg][ww][off];
       return s;
     };
-    ell_acc += tile_epilogue<float, MODE, NT>(a, seg_ib[sg], cb, get, rs_lds, red, cii_lds);
+    ell_acc += tile_epilogue<float, MODE, NT, FUSED>(a, seg_ib[sg], cb, get, rs_lds, red, cii_lds);
   }
   if (MODE != MODE_VJP && (MODE == MODE_DENSE || a.fused_target == TGT_DIAG_GAUSS)) {
     const double s = block_sum<double, NT>(ell_acc, red);
@@ -1118,6 +1180,8 @@ static FrArgs<T> fr_args(mivi_ctx *c, const void *params, int M) {
   a.prev_vin = ValueIn{};
   a.prev_out = OutArgs{};
   a.next_eps = SampleArgs<T>{};
+  a.upd = FusedUpdate{};
+  a.adam_cc = nullptr;
   return a;
 }
 
@@ -1195,11 +1259,13 @@ void launch_fr_dense_target(mivi_ctx *c, int M, int want_grad) {
 }
 
 // tril(W eps^T) (+ d/dmu, log-det partials).  next != nullptr: extra leading workgroups generate eps of the NEXT estimate.
-void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const EpsJob *next, const ValueJob *self) {
+void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const EpsJob *next, const ValueJob *self,
+                   const FusedUpdate *upd) {
   if (c->cfg.dtype == MIVI_F32) {
     ensure_tabs(c, M);
     FrArgs<float> a = fr_args<float>(c, params, M);
     a.out = out;
+    if (upd) a.upd = *upd;
     a.work_tab = (const int2 *)c->tabB.p;
     a.n_work = 0x7fffffff;
     int grid = c->nB;
@@ -1215,10 +1281,14 @@ void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, c
       grid += a.n_pre;
     }
     static const int nw_v = getenv("MIVI_NW_VJP") ? atoi(getenv("MIVI_NW_VJP")) : 4;
-    if (c->cfg.d % 32 == 0 && M % 32 == 0 && nw_v == 8 && !next && !self)
+    if (c->cfg.d % 32 == 0 && M % 32 == 0 && nw_v == 8 && !next && !self && !upd)
       hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 8, true>), dim3(grid), dim3(512), 0, c->stream, a);
-    else if (c->cfg.d % 32 == 0 && M % 32 == 0 && nw_v == 2 && !next && !self)
+    else if (c->cfg.d % 32 == 0 && M % 32 == 0 && nw_v == 2 && !next && !self && !upd)
       hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 2, true>), dim3(grid), dim3(128), 0, c->stream, a);
+    else if (c->cfg.d % 32 == 0 && M % 32 == 0 && upd)
+      hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 4, true, true>), dim3(grid), dim3(256), 0, c->stream, a);
+    else if (upd)
+      hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 4, false, true>), dim3(grid), dim3(256), 0, c->stream, a);
     else if (c->cfg.d % 32 == 0 && M % 32 == 0)
       hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 4, true>), dim3(grid), dim3(256), 0, c->stream, a);
     else

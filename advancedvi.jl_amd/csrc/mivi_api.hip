@@ -393,6 +393,11 @@ struct Chain {
   ValueJob prev{};
 };
 
+static bool no_fused_update() {   // MIVI_NO_FUSED_UPDATE=1: separate update kernel in the graph loop (A/B reference)
+  static const bool v = getenv("MIVI_NO_FUSED_UPDATE") != nullptr;
+  return v;
+}
+
 static bool hetero_ok(const mivi_ctx *c, int want_grad) {
   if (!want_grad) return false;
   // (the fused funnel target is NOT chained: its value workgroup also finishes two gradient entries, which an optimiser
@@ -404,7 +409,7 @@ static bool hetero_ok(const mivi_ctx *c, int want_grad) {
 
 // One estimate over M local samples. out.partials_mode selects final vs shard partials.
 static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs &rng, int M, int want_grad,
-                                  OutArgs out, Chain *ch = nullptr) {
+                                  OutArgs out, Chain *ch = nullptr, const FusedUpdate *upd = nullptr) {
   if (c->target == TGT_NONE) return fail(c, MIVI_ERR_NO_TARGET, "no target set");
   mivi_status_t s = ensure_work(c, M);
   if (s) return s;
@@ -528,7 +533,7 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
         HIPCHK(c, hipGetLastError());
         return MIVI_OK;
       }
-      launch_fr_vjp(c, params, M, out, next);
+      launch_fr_vjp(c, params, M, out, next, nullptr, chained ? upd : nullptr);
       vin.ld_part = (const double *)c->ld_part[p].p;   // emitted by the VJP kernel's diagonal tiles
       vin.n_ld_part = fr_ld_blocks(c);
     }
@@ -853,8 +858,24 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, 
       chn.has_next = (i + 1 < n_steps);
       chn.next_rng = rng_of(c, (uint64_t)i + 1);
       chn.next_rng.idx_ptr = r.idx_ptr;
-      s = run_estimate(c, params, r, c->cfg.n_mc, 1, o, &chn);
+      // full-rank f32 MFMA path: the optimiser step (and ClipScale) rides in the VJP epilogue -- no update kernel
+      const bool fuse_upd = c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && hetero_ok(c, 1) && !no_fused_update();
+      FusedUpdate fu;
+      if (fuse_upd) {
+        fu.rule = rule;
+        fu.params = params;
+        fu.state = opt_state;
+        fu.t_ptr = (const long long *)c->d_idx.p + 1;
+        fu.t_base = (long long)i + 1;
+        fu.eta = eta;
+        fu.b1 = 0.9;
+        fu.b2 = 0.999;
+        fu.eps = 1e-8;
+        fu.clip_eps = clip_eps;
+      }
+      s = run_estimate(c, params, r, c->cfg.n_mc, 1, o, &chn, fuse_upd ? &fu : nullptr);
       if (s) break;
+      if (fuse_upd) continue;
       if (rule == 0)   // update and ClipScale in one launch
         launch_descent(c, params, gbuf, eta, clip_eps);
       else

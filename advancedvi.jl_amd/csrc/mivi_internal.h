@@ -74,6 +74,18 @@ struct OutArgs {
   int rec_slot;
 };
 
+// Optimiser step fused into the VJP epilogue (device-resident optimisation loop, full-rank f32): every lower-triangle
+// tile applies Descent / Adam (+ ClipScale on the diagonal) to its own parameters right where the gradient entry is
+// produced, so the separate update kernel and the gradient round trip through HBM disappear.  rule < 0: off.
+struct FusedUpdate {
+  int rule = -1;              // 0 Descent, 1 Adam (optim_rules.h: bitwise the same arithmetic as kernels_update.hip)
+  void *params;               // the parameter vector being optimised (same buffer the estimate reads)
+  void *state;                // Adam: [m (params_len); v (params_len)]
+  const long long *t_ptr;     // Adam step count = t_base + *t_ptr
+  long long t_base;
+  double eta, b1, b2, eps, clip_eps;
+};
+
 template <typename T>
 struct MfArgs {
   int d;
@@ -138,6 +150,8 @@ struct FrArgs {
   SampleArgs<T> next_eps;
   ValueIn prev_vin;
   OutArgs prev_out;
+  FusedUpdate upd;     // VJP kernel, final mode only
+  const T *adam_cc;    // LDS: the two Adam bias corrections of this step (set by the kernel)
 };
 
 struct ValueJob {      // deferred objective-value assembly of the previous estimate
@@ -259,7 +273,7 @@ void launch_sample_mf(mivi_ctx *c, const void *params, const RngArgs &rng, int M
 void launch_eps(mivi_ctx *c, const RngArgs &rng, int M);
 void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, void *Z, const ValueJob *prev = nullptr);
 void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const EpsJob *next = nullptr,
-                   const ValueJob *self = nullptr);
+                   const ValueJob *self = nullptr, const FusedUpdate *upd = nullptr);
 int fr_ld_blocks(const mivi_ctx *c);
 bool f64_valu();   // MIVI_F64_VALU=1: keep the f64 full-rank tiles on the vector ALU
 void prepare_tables(mivi_ctx *c, int M);   // build + upload the MFMA work tables (no-op for f64 / mean-field)

@@ -101,12 +101,15 @@ def test_convergence_host_loop(entropy, family):
     assert d1 <= d0 / 2
 
 
+@pytest.mark.parametrize("shape", [(64, 32), (70, 19)], ids=["aligned", "ragged"])
 @pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
 @pytest.mark.parametrize("rule", [0, 1], ids=["descent", "adam"])
-def test_device_resident_loop_matches_host_loop(family, rule):
-    """mivi_optimize_steps (one hipGraph of n {estimate -> update -> clip} iterations with deferred value /
-    prefetched eps) must reproduce, bitwise, the step-by-step sequence of separate launches."""
-    d, M, T = 64, 32, 12
+def test_device_resident_loop_matches_host_loop(family, rule, shape):
+    """mivi_optimize_steps (mean-field: one launch-free kernel; full-rank: one hipGraph of n estimates with deferred
+    value / prefetched eps and the optimiser step + ClipScale fused into the VJP epilogue) must reproduce, bitwise, the
+    step-by-step sequence of separate launches."""
+    d, M = shape
+    T = 12
     rng = np.random.default_rng(4)
     tm, ts = rng.normal(size=d).astype(np.float32), rng.uniform(0.5, 2, size=d).astype(np.float32)
     if family == avi.MEANFIELD:
