@@ -162,12 +162,15 @@ __device__ double funnel_finish(int d, const FunnelFin &f, const OutArgs &out, d
 //   closed-form estimators: d/2 (1 + log 2pi) + sum_i log C_ii            location_scale.jl:52-57
 //   MC / STL estimators   : mean_m 0.5|eps_m|^2 + d/2 log 2pi + sum_i log C_ii   (C^-1 (z_m - mu) == eps_m)
 // `scale_diag(i)` returns C_ii. `red` holds NT/64 doubles.
-template <typename T, int NT, bool ATOMIC, typename DiagFn>
+// FUNNEL: also finish the fused funnel target (funnel_finish).  Only k_value_only instantiates it: inlined into the
+// big kernels it raised their register count (VJP tile kernel 104 -> 162 VGPRs, occupancy 3 -> 2, +1.2 us) for a path
+// they never take.
+template <typename T, int NT, bool ATOMIC, bool FUNNEL = false, typename DiagFn>
 __device__ void finalize_value_block(int d, const ValueIn &vin, const OutArgs &out, int64_t plen, DiagFn scale_diag,
                                      double *red) {
   const int tid = threadIdx.x;
   double s_ell = 0.0, s_he = 0.0, s_ld = 0.0, bad = 0.0;
-  if (vin.fn.cs) s_ell += funnel_finish<T, NT>(d, vin.fn, out, red);
+  if (FUNNEL && vin.fn.cs) s_ell += funnel_finish<T, NT>(d, vin.fn, out, red);
   for (int i = tid; i < vin.n_ell_part; i += NT) s_ell += ld_f64<ATOMIC>(vin.ell_part + i);
   for (int i = tid; i < vin.n_ell_part2; i += NT) s_ell += ld_f64<ATOMIC>(vin.ell_part2 + i);
   for (int i = tid; i < vin.n_ell; i += NT) s_ell += (double)((const T *)vin.ell)[i];

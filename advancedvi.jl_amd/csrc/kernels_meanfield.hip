@@ -34,7 +34,9 @@ __device__ __forceinline__ double row16_sum(double v) {   // f64 contexts: plain
 
 // Scalar partial layout written by k_mf_main and consumed by k_mf_value: sc[k*nblk + blk],
 // k = 0 sum ell (variable part), 1 sum 0.5 eps^2, 2 sum log sigma_i (this block's rows), 3 #non-positive sigma.
-template <typename T>
+// FN: the fused funnel target is a separate instantiation (its extra Philox block / exp / partial store would otherwise
+// sit in the register budget of the plain kernel).
+template <typename T, bool FN = false>
 __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
   __shared__ T xw[10][16];        // [value][wave*4 + row16] partial sums
   __shared__ double tot[12];
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
         if (4 * rq + r < d) s_ell += T(-0.5) * u * u;
         g[r] = -u * tis[r];
       }
-    } else if (a.target == TGT_FUNNEL) {
+    } else if (FN && a.target == TGT_FUNNEL) {
       // Neal's funnel + Stacked([log, identity]) fused (see FunnelFin): rows >= 1 need only e1[m] = z[0, m], re-derived
       // from the eps stream; row 0 and ell are finished by the value workgroup from the per-quad sums of squares
       T e0q[4];
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
       s_he += T(0.5) * er * er;
       if (a.want_grad) {
         isg[r] = T(1) / sg[r];
-        const bool mine = ok && !(a.target == TGT_FUNNEL && 4 * rq + r == 0);   // funnel row 0: value workgroup
+        const bool mine = ok && !(FN && a.target == TGT_FUNNEL && 4 * rq + r == 0);   // funnel row 0: value workgroup
         const T w = mine ? (g[r] + (stl ? er * isg[r] : T(0))) : T(0);
         sW[r] += w;
         sWe[r] += w * er;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
   if (a.want_grad && tid < 8) {
     if (a.n_cc == 1) {
       const int r = tid & 3, i = 4 * rq + r;
-      if (i < d && !(a.target == TGT_FUNNEL && i == 0)) {
+      if (i < d && !(FN && a.target == TGT_FUNNEL && i == 0)) {
         if (a.out.partials_mode) {
           ((T *)a.out.partials)[(tid < 4 ? 0 : d) + i] = (T)tot[tid];
         } else {
@@ -486,7 +488,8 @@ static void mf_main_impl(mivi_ctx *c, const void *params, const RngArgs &rng, in
     a.prev_out = OutArgs{};
   }
   dim3 grid(d4 + (prev ? 1 : 0), n_cc);
-  hipLaunchKernelGGL(k_mf_main<T>, grid, dim3(256), 0, c->stream, a);
+  if (a.target == TGT_FUNNEL) hipLaunchKernelGGL((k_mf_main<T, true>), grid, dim3(256), 0, c->stream, a);
+  else hipLaunchKernelGGL((k_mf_main<T, false>), grid, dim3(256), 0, c->stream, a);
   if (n_cc > 1 && want_grad) {
     const int nb = (d4 * 8 + 255) / 256;
     hipLaunchKernelGGL(k_mf_colreduce<T>, dim3(nb), dim3(256), 0, c->stream, a);

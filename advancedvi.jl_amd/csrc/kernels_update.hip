@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_value_only(int d, int family, const T *
   __shared__ double red[4];
   const int64_t plen = family == MIVI_MEANFIELD ? 2 * (int64_t)d : (int64_t)d + (int64_t)d * d;
   const int fam = family;
-  finalize_value_block<T, 256, false>(d, vin, out, plen,
+  finalize_value_block<T, 256, false, true>(d, vin, out, plen,
       [params, d, fam](int i) { return fam == MIVI_MEANFIELD ? params[d + i] : params[d + (size_t)i * d + i]; }, red);
 }
 void launch_value_only(mivi_ctx *c, const void *params, const ValueIn &vin, const OutArgs &out) {
