@@ -188,6 +188,11 @@ def main():
             yield
         finally:
             sys.stdout.flush()
+            try:   # RCCL writes through C stdio: flush its buffer while fd 1 still points at stderr
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:   # noqa: BLE001
+                pass
             os.dup2(saved, 1)
             os.close(saved)
 
@@ -196,6 +201,10 @@ def main():
     if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:   # MIVI_FORCE_DIST=1 without a launcher: a one-rank group
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_PORT", "29533")
         with quiet_stdout():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
             dist.all_reduce(torch.zeros(1, device=f"cuda:{local_rank}"))   # communicator set-up (and its banner) up front
