@@ -930,6 +930,116 @@ __global__ __launch_bounds__(256) void k_stl_prep(int d, int dP, const float *C,
   }
 }
 
+// Look-ahead variant of the blocked back substitution.  In k_stl_solve every block row does
+//   S_b = sum_{j>b} CT(b,j) X_j  ->  reduce  ->  X_b = Dinv_b (eps_b - S_b)
+// strictly one after the other, although only the LAST term of S_b (j = b+1) depends on the block solved just before.
+// Here wave 0 is the sequential chain -- last term of row b, R_b = eps_b - bulk_b - last, X_b = Dinv_b R_b (32 MFMAs per
+// block row) -- while waves 1..NW-1 already accumulate the bulk of row b-1 (all j >= b+1, known) next to it.  A block row
+// then costs max(chain, bulk / 7 waves) instead of their sum.  Measured per block row (in-kernel stamps, d = 1024): chain
+// 1.7-2.8 us, bulk ~1 us per 32x32x32 unit per wave (two waves share a SIMD's MFMA pipe), i.e. the kernel is bound by
+// the MFMA throughput of the 8 CUs that M = 256 gives it (496 units -> ~62 us floor, 124 us with the round-robin
+// imbalance); 16-column workgroups on 16x16x4 MFMAs would double the CUs and are the next step.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_stl_solve_la(FrArgs<float> a, const float *CT, const float *DinvT) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *x = (float *)smem_raw;                           // x[k*32 + m], k < dP
+  const int d = a.d, M = a.M, dP = a.dP;
+  float *part = x + (size_t)dP * 32;                      // part[w][16*64]; part[0] = reduced bulk of the current row
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * 32;
+  const int nb = (d + 31) >> 5;
+  for (int t = tid; t < dP * 32; t += NW * 64) {
+    const int k = t % dP, m = t / dP;                     // lanes along k: coalesced global reads
+    x[k * 32 + m] = a.eps[(size_t)(m0 + m) * dP + k];
+  }
+  for (int t = tid; t < 16 * 64; t += NW * 64) part[t] = 0.f;   // bulk of the last block row is empty
+  float av0[16], av1[16];
+  auto loadA = [&](int brow, int j, float (&av)[16]) {    // A[i][k] = CT[(brow*32+i) + k*dP]
+    const float *Arow = CT + brow * 32 + l31;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) av[u] = Arow[(size_t)(j * 32 + 2 * u + h) * dP];
+  };
+  // first operands: wave 0 has no last term for row nb-1; bulk of row nb-2 is empty as well
+  __syncthreads();
+  for (int b = nb - 1; b >= 0; --b) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto mma = [&](int j, const float (&av)[16]) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const float bv = x[(j * 32 + 2 * u + h) * 32 + l31];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv, acc, 0, 0, 0);
+      }
+    };
+    if (w == 0) {
+      // ---- the sequential chain ------------------------------------------------------------------
+      float dv[16];
+      const float *Di = DinvT + (size_t)b * 1024 + l31;   // A[i][k] = DinvT[i + 32 k]
+#pragma unroll
+      for (int u = 0; u < 16; ++u) dv[u] = Di[32 * (2 * u + h)];
+      if (b + 1 < nb) mma(b + 1, av0);                    // av0: CT(b, b+1), fetched during the previous block row
+      if (b > 0) loadA(b - 1, b, av0);                    // operands of the next block row's last term
+      // R_b = eps_b - bulk_b - last term, in the accumulator layout (row = (r&3) + 8(r>>2) + 4h, col = l31)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float *xe = &x[(b * 32 + row) * 32 + l31];
+        *xe = *xe - part[r * 64 + lane] - acc[r];
+      }
+      f32x16 xa;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xa[r] = 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {                      // same wave wrote R: LDS ordering is program order
+        const float bv = x[(b * 32 + 2 * u + h) * 32 + l31];
+        xa = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[u], bv, xa, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        x[(b * 32 + row) * 32 + l31] = xa[r];
+      }
+    } else if (b > 0) {
+      // ---- bulk of block row b-1: units j = b+1 .. nb-1 dealt to waves 1 .. NW-1 ------------------------
+      int j = b + w;                                       // b + 1 + (w - 1)
+      if (j < nb) {                                        // av0 holds unit j (fetched during the previous block row)
+        while (true) {
+          if (j + (NW - 1) < nb) loadA(b - 1, j + (NW - 1), av1);
+          mma(j, av0);
+          j += NW - 1;
+          if (j >= nb) break;
+          if (j + (NW - 1) < nb) loadA(b - 1, j + (NW - 1), av0);
+          mma(j, av1);
+          j += NW - 1;
+          if (j >= nb) break;
+        }
+      }
+      if (b > 1 && b - 1 + w < nb) loadA(b - 2, b - 1 + w, av0);   // first unit of the next block row's bulk
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[w * (16 * 64) + r * 64 + lane] = acc[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[w * (16 * 64) + r * 64 + lane] = 0.f;
+    }
+    __syncthreads();
+    // bulk_{b-1} = sum of the partials (fixed order); it becomes part[0] for the next block row
+    for (int t = tid; t < 16 * 64; t += NW * 64) {
+      float sacc = part[1 * (16 * 64) + t];
+#pragma unroll
+      for (int ww = 2; ww < NW; ++ww) sacc += part[ww * (16 * 64) + t];
+      part[t] = sacc;
+    }
+    __syncthreads();
+  }
+  // W[i + m*d] += X[i, m]
+  for (int t = tid; t < dP * 32; t += NW * 64) {
+    const int i = t % dP, m = t / dP;
+    if (i < d && m0 + m < M) a.W[(size_t)(m0 + m) * d + i] += x[i * 32 + m];
+  }
+}
+
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_stl_solve(FrArgs<float> a, const float *CT, const float *DinvT) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1371,8 +1481,20 @@ void launch_fr_stl(mivi_ctx *c, const void *params, int M) {
                                 (int)sh_mfma);
       attr_set = sh_mfma;
     }
-    hipLaunchKernelGGL(k_stl_solve<8>, dim3((M + 31) / 32), dim3(512), sh_mfma, c->stream, a, (const float *)c->stl_CT.p,
-                       (const float *)c->stl_Dinv.p);
+    static const bool left_looking = getenv("MIVI_STL_LEFT") != nullptr;   // A/B: the strictly sequential block rows
+    if (left_looking) {
+      hipLaunchKernelGGL(k_stl_solve<8>, dim3((M + 31) / 32), dim3(512), sh_mfma, c->stream, a, (const float *)c->stl_CT.p,
+                         (const float *)c->stl_Dinv.p);
+    } else {
+      static size_t attr_la = 0;
+      if (attr_la < sh_mfma) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stl_solve_la<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sh_mfma);
+        attr_la = sh_mfma;
+      }
+      hipLaunchKernelGGL(k_stl_solve_la<8>, dim3((M + 31) / 32), dim3(512), sh_mfma, c->stream, a,
+                         (const float *)c->stl_CT.p, (const float *)c->stl_Dinv.p);
+    }
     return;
   }
   if (c->cfg.dtype == MIVI_F32) {
