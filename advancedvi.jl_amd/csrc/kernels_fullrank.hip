@@ -1040,6 +1040,123 @@ __global__ __launch_bounds__(NW * 64) void k_stl_solve_la(FrArgs<float> a, const
   }
 }
 
+// 16 sample columns per workgroup on v_mfma_f32_16x16x4_f32: the look-ahead solve is bound by the MFMA throughput of
+// the CUs it runs on, and M / 32 workgroups are only 8 CUs at M = 256.  Half the columns per workgroup = twice the CUs at
+// half the MFMA time per 32x32 unit (16 MFMAs of 8 passes instead of 16 of 16 passes).
+//   A operand lane l: A[row = l&15][k = l>>4],  B: B[k = l>>4][col = l&15],  D reg r: row = 4*(l>>4) + r, col = l&15
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_stl_solve_la16(FrArgs<float> a, const float *CT, const float *DinvT) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float *x = (float *)smem_raw;                           // x[k*16 + m], k < dP
+  const int d = a.d, M = a.M, dP = a.dP;
+  float *part = x + (size_t)dP * 16;                      // part[w][8*64]; part[0] = reduced bulk of the current row
+  const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, kq = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * 16;
+  const int nb = (d + 31) >> 5;
+  for (int t = tid; t < dP * 16; t += NW * 64) {
+    const int k = t % dP, m = t / dP;                     // lanes along k: coalesced global reads
+    x[k * 16 + m] = (m0 + m < M) ? a.eps[(size_t)(m0 + m) * dP + k] : 0.f;
+  }
+  for (int t = tid; t < 8 * 64; t += NW * 64) part[t] = 0.f;
+  // one 32x32 unit of A = CT(brow, j): av[2g + hb] = A[row = 16*hb + c16][k = 4g + kq]
+  float av0[16], av1[16];
+  auto loadA = [&](int brow, int j, float (&av)[16]) {
+    const float *Arow = CT + brow * 32 + c16 + (size_t)(j * 32 + kq) * dP;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      av[2 * g] = Arow[(size_t)(4 * g) * dP];
+      av[2 * g + 1] = Arow[(size_t)(4 * g) * dP + 16];
+    }
+  };
+  __syncthreads();
+  float dv[16];
+  auto loadD = [&](int b) {   // inverted diagonal block, same operand shape: A[i][k] = DinvT[i + 32 k]
+    const float *Di = DinvT + (size_t)b * 1024 + c16 + 32 * kq;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      dv[2 * g] = Di[32 * 4 * g];
+      dv[2 * g + 1] = Di[32 * 4 * g + 16];
+    }
+  };
+  if (w == 0) loadD(nb - 1);
+  for (int b = nb - 1; b >= 0; --b) {
+    f32x4a acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // rows 0..15 / 16..31 of the block
+    auto mma = [&](int j, const float (&av)[16]) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const float bv = x[(j * 32 + 4 * g + kq) * 16 + c16];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2 * g], bv, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2 * g + 1], bv, acc1, 0, 0, 0);
+      }
+    };
+    if (w == 0) {
+      // ---- the sequential chain ------------------------------------------------------------------
+      if (b + 1 < nb) mma(b + 1, av0);                    // av0: CT(b, b+1), fetched during the previous block row
+      if (b > 0) loadA(b - 1, b, av0);
+      // R_b = eps_b - bulk_b - last term (accumulator layout)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float *x0 = &x[(b * 32 + 4 * kq + r) * 16 + c16], *x1 = x0 + 16 * 16;
+        *x0 = *x0 - part[r * 64 + lane] - acc0[r];
+        *x1 = *x1 - part[(4 + r) * 64 + lane] - acc1[r];
+      }
+      f32x4a xa0 = {0.f, 0.f, 0.f, 0.f}, xa1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        const float bv = x[(b * 32 + 4 * g + kq) * 16 + c16];
+        xa0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[2 * g], bv, xa0, 0, 0, 0);
+        xa1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[2 * g + 1], bv, xa1, 0, 0, 0);
+      }
+      if (b > 0) loadD(b - 1);                            // next block row's inverse: in flight across the barriers
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        x[(b * 32 + 4 * kq + r) * 16 + c16] = xa0[r];
+        x[(b * 32 + 16 + 4 * kq + r) * 16 + c16] = xa1[r];
+      }
+    } else if (b > 0) {
+      // ---- bulk of block row b-1: units j = b+1 .. nb-1 dealt to waves 1 .. NW-1 ------------------------
+      int j = b + w;
+      if (j < nb) {
+        while (true) {
+          if (j + (NW - 1) < nb) loadA(b - 1, j + (NW - 1), av1);
+          mma(j, av0);
+          j += NW - 1;
+          if (j >= nb) break;
+          if (j + (NW - 1) < nb) loadA(b - 1, j + (NW - 1), av0);
+          mma(j, av1);
+          j += NW - 1;
+          if (j >= nb) break;
+        }
+      }
+      if (b > 1 && b - 1 + w < nb) loadA(b - 2, b - 1 + w, av0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        part[w * 512 + r * 64 + lane] = acc0[r];
+        part[w * 512 + (4 + r) * 64 + lane] = acc1[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) part[w * 512 + r * 64 + lane] = 0.f;
+    }
+    __syncthreads();
+    if (tid < 512) {
+      float sacc = part[512 + tid];
+#pragma unroll
+      for (int ww = 2; ww < NW; ++ww) sacc += part[ww * 512 + tid];
+      part[tid] = sacc;
+    }
+    __syncthreads();
+  }
+  // W[i + m*d] += X[i, m]
+  for (int t = tid; t < dP * 16; t += NW * 64) {
+    const int i = t % dP, m = t / dP;
+    if (i < d && m0 + m < M) a.W[(size_t)(m0 + m) * d + i] += x[i * 16 + m];
+  }
+}
+
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void k_stl_solve(FrArgs<float> a, const float *CT, const float *DinvT) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1482,6 +1599,19 @@ void launch_fr_stl(mivi_ctx *c, const void *params, int M) {
       attr_set = sh_mfma;
     }
     static const bool left_looking = getenv("MIVI_STL_LEFT") != nullptr;   // A/B: the strictly sequential block rows
+    static const bool cols32 = getenv("MIVI_STL_COLS32") != nullptr;       // A/B: 32 columns per workgroup
+    if (!left_looking && !cols32) {
+      const size_t sh16 = ((size_t)c->dP * 16 + 8 * 8 * 64) * sizeof(float);
+      static size_t attr16 = 0;
+      if (attr16 < sh16) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stl_solve_la16<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)sh16);
+        attr16 = sh16;
+      }
+      hipLaunchKernelGGL(k_stl_solve_la16<8>, dim3((M + 15) / 16), dim3(512), sh16, c->stream, a, (const float *)c->stl_CT.p,
+                         (const float *)c->stl_Dinv.p);
+      return;
+    }
     if (left_looking) {
       hipLaunchKernelGGL(k_stl_solve<8>, dim3((M + 31) / 32), dim3(512), sh_mfma, c->stream, a, (const float *)c->stl_CT.p,
                          (const float *)c->stl_Dinv.p);
