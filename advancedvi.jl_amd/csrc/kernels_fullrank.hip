@@ -1587,13 +1587,15 @@ void launch_fr_stl(mivi_ctx *c, const void *params, int M) {
   const int nblk = (M + 7) / 8;
   static const bool old_stl = getenv("MIVI_STL_VALU") != nullptr;
   const size_t sh_mfma = ((size_t)c->dP * 32 + 8 * 16 * 64) * sizeof(float);
-  if (c->cfg.dtype == MIVI_F32 && c->stl_CT.p && sh_mfma <= 160 * 1024 && !old_stl) {
+  const size_t sh_mfma16 = ((size_t)c->dP * 16 + 8 * 8 * 64) * sizeof(float);   // 16-column solve: d up to 2304
+  static const bool want32 = getenv("MIVI_STL_LEFT") != nullptr || getenv("MIVI_STL_COLS32") != nullptr;
+  if (c->cfg.dtype == MIVI_F32 && c->stl_CT.p && (want32 ? sh_mfma : sh_mfma16) <= 160 * 1024 && !old_stl) {
     FrArgs<float> a = fr_args<float>(c, params, M);
     const int nb = (c->cfg.d + 31) / 32;
     hipLaunchKernelGGL(k_stl_prep, dim3(nb + nb * (nb + 1) / 2), dim3(256), 0, c->stream, c->cfg.d, c->dP,
                        (const float *)params + c->cfg.d, (float *)c->stl_CT.p, (float *)c->stl_Dinv.p);
     static size_t attr_set = 0;   // raise the dynamic-LDS cap once per size (the call is slow)
-    if (attr_set < sh_mfma) {
+    if (want32 && attr_set < sh_mfma) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stl_solve<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)sh_mfma);
       attr_set = sh_mfma;
