@@ -1062,7 +1062,9 @@ __global__ __launch_bounds__(NW * 64) void k_stl_solve_la16(FrArgs<float> a, con
   }
   for (int t = tid; t < 8 * 64; t += NW * 64) part[t] = 0.f;
   // one 32x32 unit of A = CT(brow, j): av[2g + hb] = A[row = 16*hb + c16][k = 4g + kq]
-  float av0[16], av1[16];
+  // up to four units of the NEXT block row are requested at the end of the current one (their L2 latency, ~0.7 us,
+  // then hides under the barriers and the chain); a fifth unit (only the last few block rows have one) is fetched in place
+  float av0[16], av1[16], av2[16], av3[16];
   auto loadA = [&](int brow, int j, float (&av)[16]) {
     const float *Arow = CT + brow * 32 + c16 + (size_t)(j * 32 + kq) * dP;
 #pragma unroll
@@ -1081,7 +1083,10 @@ __global__ __launch_bounds__(NW * 64) void k_stl_solve_la16(FrArgs<float> a, con
       dv[2 * g + 1] = Di[32 * 4 * g + 16];
     }
   };
-  if (w == 0) loadD(nb - 1);
+  if (w == 0) {
+    loadD(nb - 1);
+    __builtin_amdgcn_s_setprio(3);   // the sequential chain shares its SIMD with a bulk wave: let it issue first
+  }
   for (int b = nb - 1; b >= 0; --b) {
     f32x4a acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // rows 0..15 / 16..31 of the block
     auto mma = [&](int j, const float (&av)[16]) {
@@ -1118,20 +1123,28 @@ __global__ __launch_bounds__(NW * 64) void k_stl_solve_la16(FrArgs<float> a, con
       }
     } else if (b > 0) {
       // ---- bulk of block row b-1: units j = b+1 .. nb-1 dealt to waves 1 .. NW-1 ------------------------
-      int j = b + w;
-      if (j < nb) {
-        while (true) {
-          if (j + (NW - 1) < nb) loadA(b - 1, j + (NW - 1), av1);
-          mma(j, av0);
-          j += NW - 1;
-          if (j >= nb) break;
-          if (j + (NW - 1) < nb) loadA(b - 1, j + (NW - 1), av0);
-          mma(j, av1);
-          j += NW - 1;
-          if (j >= nb) break;
+      const int j = b + w, S = NW - 1;                     // units j, j+S, j+2S, ... < nb (at most five at nb = 32)
+      if (j + 4 * S < nb) {                                // rare fifth unit: request it before the burst, use it last
+        float av4[16];
+        loadA(b - 1, j + 4 * S, av4);
+        mma(j, av0); mma(j + S, av1); mma(j + 2 * S, av2); mma(j + 3 * S, av3);
+        for (int jj = j + 4 * S; jj < nb; jj += S) {       // (and any beyond, for nb > 32, one by one)
+          if (jj != j + 4 * S) loadA(b - 1, jj, av4);
+          mma(jj, av4);
         }
+      } else {
+        if (j < nb) mma(j, av0);
+        if (j + S < nb) mma(j + S, av1);
+        if (j + 2 * S < nb) mma(j + 2 * S, av2);
+        if (j + 3 * S < nb) mma(j + 3 * S, av3);
       }
-      if (b > 1 && b - 1 + w < nb) loadA(b - 2, b - 1 + w, av0);
+      if (b > 1) {                                         // next block row (b-2): units b-1+w, +S, +2S, +3S
+        const int jn = b - 1 + w;
+        if (jn < nb) loadA(b - 2, jn, av0);
+        if (jn + S < nb) loadA(b - 2, jn + S, av1);
+        if (jn + 2 * S < nb) loadA(b - 2, jn + 2 * S, av2);
+        if (jn + 3 * S < nb) loadA(b - 2, jn + 3 * S, av3);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         part[w * 512 + r * 64 + lane] = acc0[r];
