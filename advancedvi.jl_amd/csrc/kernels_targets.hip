@@ -693,19 +693,27 @@ __global__ __launch_bounds__(256) void k_lr_greduce(int S, size_t len, float *g_
   g_part[e] = s;
 }
 
-void logreg_prepare_f32(mivi_ctx *c) {
+// grow-only device buffer; false on allocation failure (the buffer is then empty)
+static bool grow(DevBuf &b, size_t bytes) {
+  if (b.bytes >= bytes) return true;
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+  if (hipMalloc(&b.p, bytes) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; return false; }
+  b.bytes = bytes;
+  return true;
+}
+
+bool logreg_prepare_f32(mivi_ctx *c) {
   // builds Xrm in c->lr_Xrm (called by mivi_set_target_logreg for MIVI_F32)
   const int p = c->cfg.d - 1;
   const int ldx = (p + 31) / 32 * 32;
   const size_t bytes = (size_t)c->lr_n * ldx * sizeof(float);
-  if (c->lr_Xrm.bytes < bytes) {
-    if (c->lr_Xrm.p) (void)hipFree(c->lr_Xrm.p);
-    (void)hipMalloc(&c->lr_Xrm.p, bytes);
-    c->lr_Xrm.bytes = bytes;
-  }
+  if (!grow(c->lr_Xrm, bytes)) return false;
   dim3 grid((unsigned)((c->lr_n + 63) / 64), (ldx + 63) / 64);
   hipLaunchKernelGGL(k_lr_make_xrm, grid, dim3(256), 0, c->stream, (long long)c->lr_n, p, ldx, (const float *)c->lr_X,
                      (float *)c->lr_Xrm.p);
+  return true;
 }
 
 // minibatch gather: column-major subset (generic / f64 route), labels, and -- f32 -- whole rows of the row-major copy
@@ -741,7 +749,57 @@ void launch_logreg_gather(mivi_ctx *c, int64_t b) {
   }
 }
 
-static void logreg_mfma(mivi_ctx *c, int M, int want_grad) {
+// Scratch geometry of the two routes.  logreg_reserve() sizes the buffers ahead of time (and is what makes the target
+// graph-capturable: no allocation at launch); the launchers call it again as a no-op / safety net.
+struct LrGeom {
+  bool mfma;
+  int nrb, S, ldr;
+  long long rps;
+  size_t need_R, need_g, need_ll;
+};
+static LrGeom lr_geom(const mivi_ctx *c, int M) {
+  static const bool force_generic = getenv("MIVI_LOGREG_GENERIC") != nullptr;
+  LrGeom g;
+  const long long n = c->lr_n;
+  const int p = c->cfg.d - 1;
+  g.mfma = c->cfg.dtype == MIVI_F32 && c->lr_Xrm_act && !force_generic;
+  if (g.mfma) {
+    g.ldr = (M + 63) / 64 * 64;
+    g.nrb = (int)((n + 255) / 256);
+    int S = (int)((n + 2047) / 2048);   // one X^T R workgroup per CU: 128 row splits x 2 feature groups at p = 511
+    if (S > 128) S = 128;
+    if (S < 1) S = 1;
+    long long rps = (n + S - 1) / S;
+    rps = (rps + 15) / 16 * 16;
+    g.S = (int)((n + rps - 1) / rps);
+    g.rps = rps;
+    g.need_R = ((size_t)n * g.ldr * sizeof(float) + 255) / 256 * 256;
+    g.need_g = (size_t)g.S * p * M * sizeof(float);
+    g.need_ll = (size_t)g.nrb * M * sizeof(double);
+  } else {
+    g.ldr = M;
+    g.nrb = (int)((n + 63) / 64);
+    int S = (int)((n + 4095) / 4096);
+    if (S > 128) S = 128;
+    if (S < 1) S = 1;
+    long long rps = (n + S - 1) / S;
+    rps = (rps + 15) / 16 * 16;
+    g.S = (int)((n + rps - 1) / rps);
+    g.rps = rps;
+    g.need_R = (size_t)n * M * c->esize;
+    g.need_g = (size_t)g.S * p * M * c->esize;
+    g.need_ll = (size_t)g.nrb * M * sizeof(double);
+  }
+  return g;
+}
+bool logreg_reserve(mivi_ctx *c, int M) {
+  const LrGeom g = lr_geom(c, M);
+  return grow(c->lr_scratch, g.need_R + g.need_g) && grow(c->lr_part, g.need_ll);
+}
+
+static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
+  if (!logreg_reserve(c, M)) return false;
+  const LrGeom geo = lr_geom(c, M);
   LrMfmaArgs a;
   a.d = c->cfg.d;
   a.p = a.d - 1;
@@ -755,29 +813,11 @@ static void logreg_mfma(mivi_ctx *c, int M, int want_grad) {
   a.ldz = c->MP;
   a.ldr = (M + 63) / 64 * 64;
   static const bool gen1 = getenv("MIVI_LR_GEN1") != nullptr;
-  const int nrb = (int)((a.n + 255) / 256);
-  // one X^T R workgroup per CU: 128 row splits x 2 feature groups at p = 511 (fewer, longer splits also halve k_lr_greduce)
-  int S = (int)((a.n + 2047) / 2048);
-  if (S > 128) S = 128;
-  if (S < 1) S = 1;
-  long long rps = (a.n + S - 1) / S;
-  rps = (rps + 15) / 16 * 16;
-  S = (int)((a.n + rps - 1) / rps);
+  const int nrb = geo.nrb, S = geo.S;
+  const long long rps = geo.rps;
   a.rows_per_split = rps;
   a.want_grad = want_grad;
-  const size_t need_R = ((size_t)a.n * a.ldr * sizeof(float) + 255) / 256 * 256;
-  const size_t need_g = (size_t)S * a.p * M * sizeof(float);
-  const size_t need_ll = (size_t)nrb * M * sizeof(double);
-  if (c->lr_scratch.bytes < need_R + need_g) {
-    if (c->lr_scratch.p) (void)hipFree(c->lr_scratch.p);
-    (void)hipMalloc(&c->lr_scratch.p, need_R + need_g);
-    c->lr_scratch.bytes = need_R + need_g;
-  }
-  if (c->lr_part.bytes < need_ll) {
-    if (c->lr_part.p) (void)hipFree(c->lr_part.p);
-    (void)hipMalloc(&c->lr_part.p, need_ll);
-    c->lr_part.bytes = need_ll;
-  }
+  const size_t need_R = geo.need_R;
   a.R = (float *)c->lr_scratch.p;
   a.g_part = (float *)((char *)c->lr_scratch.p + need_R);
   a.ll_part = (double *)c->lr_part.p;
@@ -804,10 +844,13 @@ static void logreg_mfma(mivi_ctx *c, int M, int want_grad) {
   f.G = (float *)c->W.p; f.ell = (float *)c->ell.p;
   f.variant = c->lr_variant; f.likeadj = c->lr_likeadj; f.want_grad = want_grad;
   hipLaunchKernelGGL(k_lr_finish<float>, dim3(M), dim3(256), 0, c->stream, f);
+  return true;
 }
 
 template <typename T>
-static void logreg_impl(mivi_ctx *c, int M, int want_grad) {
+static bool logreg_impl(mivi_ctx *c, int M, int want_grad) {
+  if (!logreg_reserve(c, M)) return false;
+  const LrGeom geo = lr_geom(c, M);
   LrArgs<T> a;
   a.d = c->cfg.d;
   a.p = a.d - 1;
@@ -816,29 +859,12 @@ static void logreg_impl(mivi_ctx *c, int M, int want_grad) {
   a.X = (const T *)c->lr_X;
   a.y = c->lr_y;
   a.Z = (const T *)c->Z.p;
-  a.nrb = (int)((a.n + 63) / 64);
-  int S = (int)((a.n + 4095) / 4096);
-  if (S > 128) S = 128;
-  if (S < 1) S = 1;
-  int64_t rps = (a.n + S - 1) / S;
-  rps = (rps + 15) / 16 * 16;
-  S = (int)((a.n + rps - 1) / rps);
+  a.nrb = geo.nrb;
+  const int S = geo.S;
   a.S = S;
-  a.rows_per_split = rps;
-  const size_t need_R = (size_t)a.n * M * sizeof(T);
-  const size_t need_ll = (size_t)a.nrb * M * sizeof(double);
-  const size_t need_g = (size_t)S * a.p * M * sizeof(T);
+  a.rows_per_split = geo.rps;
+  const size_t need_R = geo.need_R;
   // scratch layout inside lr_scratch: [R | g_part], lr_part: ll_part
-  if (c->lr_scratch.bytes < need_R + need_g) {
-    if (c->lr_scratch.p) (void)hipFree(c->lr_scratch.p);
-    (void)hipMalloc(&c->lr_scratch.p, need_R + need_g);
-    c->lr_scratch.bytes = need_R + need_g;
-  }
-  if (c->lr_part.bytes < need_ll) {
-    if (c->lr_part.p) (void)hipFree(c->lr_part.p);
-    (void)hipMalloc(&c->lr_part.p, need_ll);
-    c->lr_part.bytes = need_ll;
-  }
   a.R = (T *)c->lr_scratch.p;
   a.g_part = (T *)((char *)c->lr_scratch.p + need_R);
   a.ll_part = (double *)c->lr_part.p;
@@ -851,13 +877,14 @@ static void logreg_impl(mivi_ctx *c, int M, int want_grad) {
   if (want_grad)
     hipLaunchKernelGGL(k_lr_xtr<T>, dim3((a.p + 63) / 64, (M + 63) / 64, S), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_lr_finish<T>, dim3(M), dim3(256), 0, c->stream, a);
+  return true;
 }
 
-void launch_logreg_target(mivi_ctx *c, int M, int want_grad) {
-  static const bool force_generic = getenv("MIVI_LOGREG_GENERIC") != nullptr;
-  if (c->cfg.dtype == MIVI_F32 && c->lr_Xrm_act && !force_generic) logreg_mfma(c, M, want_grad);
-  else if (c->cfg.dtype == MIVI_F32) logreg_impl<float>(c, M, want_grad);
-  else logreg_impl<double>(c, M, want_grad);
+// false: device allocation of the residual / partial buffers failed
+bool launch_logreg_target(mivi_ctx *c, int M, int want_grad) {
+  if (lr_geom(c, M).mfma) return logreg_mfma(c, M, want_grad);
+  if (c->cfg.dtype == MIVI_F32) return logreg_impl<float>(c, M, want_grad);
+  return logreg_impl<double>(c, M, want_grad);
 }
 
 }  // namespace mivi

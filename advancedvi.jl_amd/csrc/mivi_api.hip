@@ -283,7 +283,7 @@ mivi_status_t mivi_set_target_logreg(mivi_ctx_t *c, const void *X, const uint8_t
   c->t_const = 0.0;
   c->target = TGT_LOGREG;
   c->cap_M = 0;   // (re)allocate the transposed-sample buffer
-  if (c->cfg.dtype == MIVI_F32) logreg_prepare_f32(c);
+  if (c->cfg.dtype == MIVI_F32 && !logreg_prepare_f32(c)) return fail(c, MIVI_ERR_HIP, "logistic regression: row-major copy allocation failed");
   c->lr_Xrm_act = c->cfg.dtype == MIVI_F32 ? c->lr_Xrm.p : nullptr;
   invalidate_graph(c);
   return MIVI_OK;
@@ -355,7 +355,7 @@ static mivi_status_t eval_generic_target(mivi_ctx *c, int M, int want_grad) {
       launch_col_target(c, M, want_grad);
       return MIVI_OK;
     case TGT_LOGREG:
-      launch_logreg_target(c, M, want_grad);
+      if (!launch_logreg_target(c, M, want_grad)) return fail(c, MIVI_ERR_HIP, "logistic regression: scratch allocation failed");
       return MIVI_OK;
     case TGT_CALLBACK: {
       const size_t es = c->esize, d = c->cfg.d;
@@ -731,8 +731,13 @@ static hipError_t end_capture(mivi_ctx *c, hipStream_t saved, hipGraph_t *graph)
   return e;
 }
 
-static bool graph_capturable(const mivi_ctx *c) {
-  return c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS || c->target == TGT_FUNNEL;
+static bool graph_capturable(const mivi_ctx *c) {   // every device-resident target (the host callback is not)
+  return c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS || c->target == TGT_FUNNEL || c->target == TGT_LOGREG;
+}
+// allocations are not allowed inside a capture: size whatever the target's launchers would otherwise grow lazily
+static mivi_status_t reserve_target(mivi_ctx *c, int M) {
+  if (c->target == TGT_LOGREG && !logreg_reserve(c, M)) return fail(c, MIVI_ERR_HIP, "logistic regression: scratch allocation failed");
+  return MIVI_OK;
 }
 
 mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64_t idx0, int32_t count, void *value,
@@ -743,6 +748,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
   mivi_status_t s = ensure_work(c, c->cfg.n_mc);
   if (s) return s;
   prepare_tables(c, c->cfg.n_mc);   // host->device uploads are not allowed inside the capture
+  if ((s = reserve_target(c, c->cfg.n_mc))) return s;
   GraphCache &g = c->graph;
   if (!(g.exec && g.kind == 1 && g.count == count && g.params == params && g.value == value && g.grad == grad)) {
     invalidate_graph(c);
@@ -813,6 +819,7 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, 
   mivi_status_t s = ensure_work(c, c->cfg.n_mc);
   if (s) return s;
   prepare_tables(c, c->cfg.n_mc);
+  if ((s = reserve_target(c, c->cfg.n_mc))) return s;
   const size_t plen = (size_t)mivi_params_len(c), es = c->esize;
   // internal value/grad/elbo-record buffers
   const size_t hist_doubles = (size_t)n_steps * 4 * (size_t)((c->cfg.d + 3) / 4);

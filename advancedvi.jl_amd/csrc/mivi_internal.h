@@ -286,8 +286,9 @@ int eps_blocks(const mivi_ctx *c, int M);
 
 // kernels_targets.hip
 void launch_col_target(mivi_ctx *c, int M, int want_grad);
-void launch_logreg_target(mivi_ctx *c, int M, int want_grad);
-void logreg_prepare_f32(mivi_ctx *c);   // row-major padded copy of X for the MFMA route
+bool launch_logreg_target(mivi_ctx *c, int M, int want_grad);   // false: scratch allocation failed
+bool logreg_reserve(mivi_ctx *c, int M);                        // size the scratch ahead of a graph capture
+bool logreg_prepare_f32(mivi_ctx *c);   // row-major padded copy of X for the MFMA route (false: allocation failed)
 
 // kernels_update.hip
 void launch_finalize(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad);

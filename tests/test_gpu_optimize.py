@@ -266,3 +266,31 @@ def test_klminrepgradproxdescent_runs_deterministically_and_converges():
         avi.KLMinRepGradProxDescent(avi.AutoMIVI(), optimizer=avi.Adam())
     with pytest.raises(TypeError):
         avi.KLMinRepGradProxDescent(avi.AutoMIVI(), entropy_zerograd=avi.ClosedFormEntropy())
+
+
+def test_device_loop_with_the_logreg_target():
+    """The built-in logistic regression is graph-capturable (its scratch is reserved before the capture), so the
+    device-resident loop serves it too; it must reproduce the step-by-step sequence bitwise."""
+    rng = np.random.default_rng(2)
+    n, p, M, T = 500, 7, 16, 6
+    d = p + 1
+    X = (rng.normal(size=(n, p)) / np.sqrt(p)).astype(np.float32)
+    y = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    for family in (avi.MEANFIELD, avi.FULLRANK):
+        q0 = (avi.MeanFieldGaussian(np.zeros(d, np.float32), np.full(d, 0.5, np.float32)) if family == avi.MEANFIELD
+              else avi.FullRankGaussian(np.zeros(d, np.float32), 0.5 * np.eye(d, dtype=np.float32)))
+        p0, _ = avi.destructure(q0)
+        ctx = avi.MiviContext(np.float32, family, d, M, 0, SEED)
+        ctx.set_problem(avi.LogRegProblem(X, y))
+        pa = ctx.to_device(p0).clone()
+        st = ctx.empty(2 * pa.numel()).zero_()
+        for t in range(T):
+            v, g = ctx.estimate_gradient(pa, 50 + t)
+            ctx.adam_update(pa, g, st, t + 1, 1e-2)
+            ctx.clip_scale(pa, 1e-5)
+        pb = ctx.to_device(p0).clone()
+        st2 = ctx.empty(2 * pb.numel()).zero_()
+        ctx.optimize_steps(pb, st2, 50, 0, T, 1, 1e-2, 1e-5, None)
+        ctx.synchronize()
+        assert np.array_equal(pa.cpu().numpy(), pb.cpu().numpy())
+        ctx.close()
