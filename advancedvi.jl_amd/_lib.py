@@ -35,6 +35,7 @@ SIGNATURES = {
     "mivi_synchronize": (C.c_int32, [C.c_void_p]),
     "mivi_params_len": (C.c_int64, [C.c_void_p]),
     "mivi_partials_len": (C.c_int64, [C.c_void_p]),
+    "mivi_optimize_loop": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mivi_logreg_select_rows": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_double]),
     "mivi_prox_scale_entropy": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int32]),
     "mivi_set_target_diag_gauss": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -93,6 +94,15 @@ class MiviError(RuntimeError):
     def __init__(self, status, msg):
         super().__init__(f"libmivi status {status}: {msg}")
         self.status = status
+
+
+class MiviLoop(C.Structure):
+    """mivi_loop_t (include/mivi.h)"""
+    _fields_ = [("rule", C.c_int32), ("op", C.c_int32), ("averager", C.c_int32), ("n_steps", C.c_int32),
+                ("eta", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("adam_eps", C.c_double),
+                ("clip_epsilon", C.c_double), ("avg_eta", C.c_double),
+                ("opt_state_dev", C.c_void_p), ("avg_params_dev", C.c_void_p),
+                ("estimate_idx0", C.c_uint64), ("t0", C.c_int64), ("elbo_dev", C.c_void_p)]
 
 
 def check(lib, ctx, status):

@@ -264,6 +264,17 @@ class MiviContext:
     def dog_update(self, params, grad, state, kind):
         self._chk(self.lib.mivi_dog_update(self.h, self._p(params), self._p(grad), self._p(state), int(kind)))
 
+    def optimize_loop(self, params, n_steps, idx0, t0, rule=0, op=0, averager=0, eta=0.0, beta=(0.9, 0.999), adam_eps=1e-8,
+                      clip_epsilon=0.0, avg_eta=8.0, opt_state=None, avg_params=None, elbo=None):
+        """mivi_optimize_loop: n_steps iterations of {estimate, update, operator, averager} on the device."""
+        import ctypes as C
+        l = _lib.MiviLoop(int(rule), int(op), int(averager), int(n_steps), float(eta), float(beta[0]), float(beta[1]),
+                          float(adam_eps), float(clip_epsilon), float(avg_eta),
+                          self._p(opt_state) if opt_state is not None else None,
+                          self._p(avg_params) if avg_params is not None else None, int(idx0), int(t0),
+                          self._p(elbo) if elbo is not None else None)
+        self._chk(self.lib.mivi_optimize_loop(self.h, self._p(params), C.byref(l)))
+
     def optimize_steps(self, params, opt_state, idx0, t0, n_steps, rule, eta, clip_epsilon, elbo=None):
         st = self.lib.mivi_optimize_steps(self.h, self._p(params), self._p(opt_state) if opt_state is not None else None,
                                           idx0, int(t0), int(n_steps), int(rule), float(eta), float(clip_epsilon),

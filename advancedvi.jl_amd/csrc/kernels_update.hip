@@ -222,6 +222,26 @@ void launch_bump(mivi_ctx *c, uint64_t *ctr, uint64_t by) {
 // ---------------------------------------------------------------------------------------------
 namespace mivi {
 
+// PolynomialAveraging inside a captured loop: the weight depends on the step, which lives in a device counter
+// (same double arithmetic as the host computes for mivi_axpby: bitwise identical averages)
+template <typename T>
+__global__ void k_poly_average(int64_t n, T *y, const T *x, double avg_eta, const long long *t_ptr, long long t_base) {
+  const double t = (double)(t_base + (t_ptr ? *t_ptr : 0));
+  const double w = (avg_eta + 1.0) / (t + avg_eta);
+  const double a = w, b = 1.0 - w;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = (T)(a * (double)x[i] + b * (double)y[i]);
+}
+void launch_poly_average(mivi_ctx *c, void *avg, const void *params, double avg_eta, const long long *t_ptr, long long t_base) {
+  const int64_t n = mivi_params_len(c);
+  int nb = (int)((n + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_poly_average<float>, dim3(nb), dim3(256), 0, c->stream, n, (float *)avg, (const float *)params, avg_eta, t_ptr, t_base);
+  else
+    hipLaunchKernelGGL(k_poly_average<double>, dim3(nb), dim3(256), 0, c->stream, n, (double *)avg, (const double *)params, avg_eta, t_ptr, t_base);
+}
+
 template <typename T>
 __global__ void k_axpby(int64_t n, T *y, double a, const T *x, double b) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)

@@ -813,7 +813,53 @@ mivi_status_t mivi_adam_update(mivi_ctx_t *c, void *params, const void *grad, vo
 
 mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, uint64_t idx0, int64_t t0, int32_t n_steps,
                                   int32_t rule, double eta, double clip_eps, void *elbo) {
-  if (!c || !params || n_steps <= 0 || (rule != 0 && rule != 1) || (rule == 1 && !opt_state)) return MIVI_ERR_BAD_ARG;
+  if (rule != 0 && rule != 1) return MIVI_ERR_BAD_ARG;
+  mivi_loop_t l{};
+  l.rule = rule;
+  l.op = clip_eps > 0.0 ? 1 : 0;
+  l.averager = 0;
+  l.n_steps = n_steps;
+  l.eta = eta;
+  l.beta1 = 0.9;
+  l.beta2 = 0.999;
+  l.adam_eps = 1e-8;
+  l.clip_epsilon = clip_eps;
+  l.opt_state_dev = opt_state;
+  l.estimate_idx0 = idx0;
+  l.t0 = t0;
+  l.elbo_dev = elbo;
+  return mivi_optimize_loop(c, params, &l);
+}
+
+// elbo record (double, device) -> caller's T[n_steps]
+static mivi_status_t deliver_elbo(mivi_ctx *c, const double *rec, int n_steps, void *elbo) {
+  if (!elbo) return MIVI_OK;
+  if (c->cfg.dtype == MIVI_F64) {
+    HIPCHK(c, hipMemcpyAsync(elbo, rec, (size_t)n_steps * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  } else {
+    std::vector<double> h(n_steps);
+    HIPCHK(c, hipMemcpyAsync(h.data(), rec, (size_t)n_steps * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    std::vector<float> f(h.begin(), h.end());
+    HIPCHK(c, hipMemcpy(elbo, f.data(), (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return MIVI_OK;
+}
+
+static bool same_loop(const mivi_loop_t &a, const mivi_loop_t &b) {   // everything baked into a captured loop
+  return a.rule == b.rule && a.op == b.op && a.averager == b.averager && a.n_steps == b.n_steps && a.eta == b.eta &&
+         a.beta1 == b.beta1 && a.beta2 == b.beta2 && a.adam_eps == b.adam_eps && a.clip_epsilon == b.clip_epsilon &&
+         a.avg_eta == b.avg_eta && a.opt_state_dev == b.opt_state_dev && a.avg_params_dev == b.avg_params_dev;
+}
+
+mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t *lp) {
+  if (!c || !params || !lp) return MIVI_ERR_BAD_ARG;
+  const mivi_loop_t &l = *lp;
+  const int n_steps = l.n_steps, rule = l.rule;
+  if (n_steps <= 0 || rule < 0 || rule > 3 || l.op < 0 || l.op > 2 || l.averager < 0 || l.averager > 1) return MIVI_ERR_BAD_ARG;
+  if (rule != 0 && !l.opt_state_dev) return fail(c, MIVI_ERR_BAD_ARG, "this optimisation rule needs opt_state_dev");
+  if (l.averager == 1 && !l.avg_params_dev) return fail(c, MIVI_ERR_BAD_ARG, "PolynomialAveraging needs avg_params_dev");
+  if (l.op == 2 && rule == 1) return fail(c, MIVI_ERR_BAD_ARG, "ProximalLocationScaleEntropy does not support Adam (Descent, DoG, DoWG)");
   if (!graph_capturable(c)) return fail(c, MIVI_ERR_UNSUPPORTED, "device-resident loop needs a built-in target");
   (void)hipSetDevice(c->cfg.device);
   mivi_status_t s = ensure_work(c, c->cfg.n_mc);
@@ -821,6 +867,8 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, 
   prepare_tables(c, c->cfg.n_mc);
   if ((s = reserve_target(c, c->cfg.n_mc))) return s;
   const size_t plen = (size_t)mivi_params_len(c), es = c->esize;
+  const double eta = l.eta, clip_eps = (l.op == 1) ? l.clip_epsilon : 0.0;
+  void *opt_state = l.opt_state_dev;
   // internal value/grad/elbo-record buffers
   const size_t hist_doubles = (size_t)n_steps * 4 * (size_t)((c->cfg.d + 3) / 4);
   if ((s = ensure(c, c->X, (plen + 8) * es + ((size_t)n_steps + hist_doubles + 8) * sizeof(double), false))) return s;
@@ -828,33 +876,26 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, 
   char *gbuf = vbuf + 8 * es;
   double *rec = (double *)(((uintptr_t)(gbuf + plen * es) + 7) & ~(uintptr_t)7);
   static const bool no_fused_loop = getenv("MIVI_NO_FUSED_LOOP") != nullptr;
-  if (c->cfg.family == MIVI_MEANFIELD && c->target == TGT_DIAG_GAUSS && c->cfg.n_mc <= 4096 && !no_fused_loop) {
+  const bool simple = rule <= 1 && l.op <= 1 && l.averager == 0;   // what the fused paths implement
+  const bool default_adam = l.beta1 == 0.9 && l.beta2 == 0.999 && l.adam_eps == 1e-8;
+  if (simple && (rule == 0 || default_adam) && c->cfg.family == MIVI_MEANFIELD && c->target == TGT_DIAG_GAUSS &&
+      c->cfg.n_mc <= 4096 && !no_fused_loop) {
     // launch-free loop: every workgroup owns four rows of (mu, sigma); no graph, two launches for all n_steps
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream));
-    launch_mf_sgd_loop(c, params, opt_state, idx0, (long long)t0, n_steps, rule, eta, clip_eps, rec + n_steps, rec);
+    launch_mf_sgd_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, rec + n_steps, rec);
     HIPCHK(c, hipGetLastError());
-    if (elbo) {
-      if (c->cfg.dtype == MIVI_F64) {
-        HIPCHK(c, hipMemcpyAsync(elbo, rec, (size_t)n_steps * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-      } else {
-        std::vector<double> h(n_steps);
-        HIPCHK(c, hipMemcpyAsync(h.data(), rec, (size_t)n_steps * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        std::vector<float> f(h.begin(), h.end());
-        HIPCHK(c, hipMemcpy(elbo, f.data(), (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice));
-      }
-    }
+    if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);
   }
   GraphCache &g = c->graph;
-  if (!(g.exec && g.kind == 2 + rule && g.count == n_steps && g.params == params && g.aux0 == opt_state && g.p0 == eta &&
-        g.p1 == clip_eps && g.value == (void *)vbuf)) {
+  if (!(g.exec && g.kind == 9 && g.params == params && g.value == (void *)vbuf && same_loop(g.loop, l))) {
     invalidate_graph(c);
     hipGraph_t graph = nullptr;
     hipStream_t saved;
     if ((s = begin_capture(c, &saved))) return s;
     Chain chn;
     chn.on = true;
+    const long long *t_ptr = (const long long *)c->d_idx.p + 1;   // iterations done before this call
     for (int i = 0; i < n_steps && s == MIVI_OK; ++i) {
       RngArgs r = rng_of(c, (uint64_t)i);
       r.idx_ptr = (const uint64_t *)c->d_idx.p;
@@ -866,27 +907,33 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, 
       chn.next_rng = rng_of(c, (uint64_t)i + 1);
       chn.next_rng.idx_ptr = r.idx_ptr;
       // full-rank f32 MFMA path: the optimiser step (and ClipScale) rides in the VJP epilogue -- no update kernel
-      const bool fuse_upd = c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && hetero_ok(c, 1) && !no_fused_update();
+      const bool fuse_upd = simple && c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && hetero_ok(c, 1) &&
+                            !no_fused_update();
       FusedUpdate fu;
       if (fuse_upd) {
         fu.rule = rule;
         fu.params = params;
         fu.state = opt_state;
-        fu.t_ptr = (const long long *)c->d_idx.p + 1;
+        fu.t_ptr = t_ptr;
         fu.t_base = (long long)i + 1;
         fu.eta = eta;
-        fu.b1 = 0.9;
-        fu.b2 = 0.999;
-        fu.eps = 1e-8;
+        fu.b1 = l.beta1;
+        fu.b2 = l.beta2;
+        fu.eps = l.adam_eps;
         fu.clip_eps = clip_eps;
       }
       s = run_estimate(c, params, r, c->cfg.n_mc, 1, o, &chn, fuse_upd ? &fu : nullptr);
       if (s) break;
       if (fuse_upd) continue;
-      if (rule == 0)   // update and ClipScale in one launch
-        launch_descent(c, params, gbuf, eta, clip_eps);
-      else
-        launch_adam(c, params, gbuf, opt_state, (const int64_t *)c->d_idx.p + 1, (int64_t)i + 1, eta, 0.9, 0.999, 1e-8, clip_eps);
+      // Optimisers.update! (common.jl:92); ClipScale rides in the Descent / Adam kernels
+      if (rule == 0) launch_descent(c, params, gbuf, eta, clip_eps);
+      else if (rule == 1) launch_adam(c, params, gbuf, opt_state, (const int64_t *)t_ptr, (int64_t)i + 1, eta, l.beta1, l.beta2, l.adam_eps, clip_eps);
+      else launch_dog_update(c, params, gbuf, opt_state, rule - 2);
+      // operator (common.jl:93-95)
+      if (l.op == 1 && rule >= 2) launch_clip(c, params, clip_eps);
+      if (l.op == 2) launch_prox(c, params, eta, rule >= 2 ? opt_state : nullptr, rule - 2);
+      // averager (common.jl:96)
+      if (l.averager == 1) launch_poly_average(c, l.avg_params_dev, params, l.avg_eta, t_ptr, (long long)i + 1);
     }
     if (s == MIVI_OK) flush_chain(c, params, &chn);
     c->cur = 0;
@@ -895,24 +942,13 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, 
     HIPCHK(c, e);
     HIPCHK(c, hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
     (void)hipGraphDestroy(graph);
-    g.kind = 2 + rule; g.count = n_steps; g.params = params; g.aux0 = opt_state; g.p0 = eta; g.p1 = clip_eps;
-    g.value = vbuf;
+    g.kind = 9; g.count = n_steps; g.params = params; g.value = vbuf;
+    g.loop = l;
   }
-  uint64_t hdr[2] = {idx0, (uint64_t)t0};
+  uint64_t hdr[2] = {l.estimate_idx0, (uint64_t)l.t0};
   HIPCHK(c, hipMemcpyAsync(c->d_idx.p, hdr, sizeof(hdr), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
-  if (elbo) {
-    // elbo_dev: T[n_steps]
-    if (c->cfg.dtype == MIVI_F64) {
-      HIPCHK(c, hipMemcpyAsync(elbo, rec, (size_t)n_steps * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    } else {
-      std::vector<double> h(n_steps);
-      HIPCHK(c, hipMemcpyAsync(h.data(), rec, (size_t)n_steps * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      std::vector<float> f(h.begin(), h.end());
-      HIPCHK(c, hipMemcpy(elbo, f.data(), (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice));
-    }
-  }
+  if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
   return read_status(c);
 }
 

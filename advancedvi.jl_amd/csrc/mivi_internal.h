@@ -192,6 +192,7 @@ struct GraphCache {
   int kind = 0;
   double p0 = 0, p1 = 0;
   void *aux0 = nullptr, *aux1 = nullptr;
+  mivi_loop_t loop{};   // kind 9: the configuration the captured loop was built for
 };
 
 }  // namespace mivi
@@ -293,6 +294,8 @@ bool logreg_prepare_f32(mivi_ctx *c);   // row-major padded copy of X for the MF
 // kernels_update.hip
 void launch_finalize(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad);
 void launch_prox(mivi_ctx *c, void *params, double stepsize, const void *dog_state, int dog_kind);
+void launch_poly_average(mivi_ctx *c, void *avg, const void *params, double avg_eta, const long long *t_ptr, long long t_base);
+void launch_dog_update(mivi_ctx *c, void *params, const void *grad, void *state, int kind);
 void launch_logreg_gather(mivi_ctx *c, int64_t b);   // batch rows lr_idx[0..b) of the full data set -> lr_Xsub / lr_ysub / lr_Xrm_sub
 void launch_value_only(mivi_ctx *c, const void *params, const ValueIn &vin, const OutArgs &out);   // on c->stream
 void launch_clip(mivi_ctx *c, void *params, double epsilon);

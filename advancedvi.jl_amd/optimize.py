@@ -240,10 +240,68 @@ def step(rng, alg, state, callback, *objargs):
     return state, False, info
 
 
+_RULES = {Descent: 0, Adam: 1, DoG: 2, DoWG: 3}
+_OPS = {IdentityOperator: 0, ClipScale: 1, ProximalLocationScaleEntropy: 2}
+_AVGS = {NoAveraging: 0, PolynomialAveraging: 1}
+DEVICE_LOOP_CHUNK = 256   # iterations per mivi_optimize_loop call (bounds the work done past a divergence)
+
+
+def _device_loop_codes(alg, callback, objargs):
+    """(rule, op, averager) when a whole `step` can run inside mivi_optimize_loop, else None: no callback (it needs the
+    parameters on the host every iteration), a plain RepGradELBO, and rule / operator / averager of the exact reference
+    types (subclasses may override behaviour)."""
+    if callback is not None or objargs or not isinstance(alg.objective, O.RepGradELBO):
+        return None
+    r, o, a = _RULES.get(type(alg.optimizer)), _OPS.get(type(alg.operator)), _AVGS.get(type(alg.averager))
+    if r is None or o is None or a is None or (o == 2 and r == 1):
+        return None
+    return r, o, a
+
+
+def _optimize_on_device(rng, alg, max_iter, state, codes, show_progress):
+    """The loop of `optimize` with every iteration on the device (bitwise the same parameters as the host-driven loop).
+    Returns None when the target cannot be captured (host-callback targets): the caller then takes the host loop."""
+    from ._lib import MiviError
+    rule, op, avg = codes
+    ctx = _ctx_of(state["obj_st"])
+    params = state["params"]
+    opt, info_total = alg.optimizer, []
+    done = 0
+    while done < max_iter:
+        n = min(DEVICE_LOOP_CHUNK, max_iter - done)
+        elbo = ctx.empty(n)
+        avg_params = state["avg_st"][0] if avg == 1 else None
+        try:
+            ctx.optimize_loop(params, n, rng.counter, state["iteration"], rule=rule, op=op, averager=avg,
+                              eta=getattr(opt, "eta", 0.0), beta=getattr(opt, "beta", (0.9, 0.999)),
+                              adam_eps=getattr(opt, "epsilon", 1e-8), clip_epsilon=getattr(alg.operator, "epsilon", 0.0),
+                              avg_eta=getattr(alg.averager, "eta", 8), opt_state=state["opt_st"], avg_params=avg_params,
+                              elbo=elbo)
+        except MiviError as e:
+            if e.status == 6 and done == 0:      # MIVI_ERR_UNSUPPORTED: not a device-resident target
+                return None
+            if e.status in (2, 3):               # common.jl:83-89 (a non-positive scale makes the objective NaN)
+                raise RuntimeError("The objective value is not finite. This indicates that the optimization run diverged.") from e
+            raise
+        for _ in range(n):
+            rng.next_index()
+        vals = elbo.cpu().numpy()
+        t0 = state["iteration"]
+        info_total += [{"elbo": float(vals[i]), "iteration": t0 + i + 1} for i in range(n)]
+        state["iteration"] = t0 + n
+        state["avg_st"] = (state["avg_st"][0], state["avg_st"][1] + n) if avg == 1 else params
+        done += n
+        if show_progress:
+            print(f"\rOptimizing {done}/{max_iter} elbo={info_total[-1]['elbo']:.6g}", end="" if done < max_iter else "\n")
+    state["q"] = None
+    return info_total
+
+
 def optimize(rng, algorithm, max_iter: int, prob=None, q_init=None, *objargs, show_progress=False, state=None,
-             callback=None):
+             callback=None, device_loop=True):
     """optimize([rng,] algorithm, max_iter, prob, q_init; show_progress, state, callback): src/optimize.jl:42-94.
-    Returns (output, info, state)."""
+    Returns (output, info, state).  Without a callback and with a device-resident target every iteration runs inside
+    mivi_optimize_loop (`device_loop=False` forces the host-driven `step` loop; both give bitwise the same result)."""
     if isinstance(rng, KLMinRepGradDescent):   # default-rng overload, optimize.jl:83-94
         extra = (q_init,) if q_init is not None else ()
         rng, algorithm, max_iter, prob, q_init = O.default_rng(), rng, algorithm, max_iter, prob
@@ -251,6 +309,12 @@ def optimize(rng, algorithm, max_iter: int, prob=None, q_init=None, *objargs, sh
     info_total = []
     if state is None:
         state = init(rng, algorithm, q_init, prob)
+    codes = _device_loop_codes(algorithm, callback, objargs) if device_loop else None
+    if codes is not None and max_iter > 0:
+        state = dict(state)
+        info_dev = _optimize_on_device(rng, algorithm, max_iter, state, codes, show_progress)
+        if info_dev is not None:
+            return output(algorithm, state), info_dev, state
     for t in range(1, max_iter + 1):
         state, terminate, info = step(rng, algorithm, state, callback, *objargs)
         info = {**info, "iteration": t}

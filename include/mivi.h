@@ -201,6 +201,28 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *ctx, void *params_dev, void *opt_s
                                   int64_t t0, int32_t n_steps, int32_t rule, double eta, double clip_epsilon,
                                   void *elbo_dev);
 
+/* The general device-resident loop: `n_steps` iterations of `step` (src/algorithms/common.jl:69-104)
+ *     estimate_gradient!  ->  Optimisers.update!  ->  operator  ->  averager
+ * for every rule / operator / averager the reference's ParamSpaceSGD algorithms combine (constructors.jl:44-157):
+ *   rule      0 Descent(eta) | 1 Adam(eta, beta1, beta2, adam_eps) | 2 DoG | 3 DoWG      (src/optimization/rules.jl:17-64)
+ *   op        0 IdentityOperator | 1 ClipScale(clip_epsilon) | 2 ProximalLocationScaleEntropy (step size from the rule)
+ *   averager  0 NoAveraging | 1 PolynomialAveraging(avg_eta): x_bar <- (1-w_t) x_bar + w_t x, w_t = (eta+1)/(t+eta)
+ * opt_state: Adam T[2 params_len] (zeros before the first step) | DoG/DoWG mivi_dog_state_bytes (after mivi_dog_init).
+ * avg_params: T[params_len] running average, in/out (any content when t0 = 0: w_1 = 1).  t0 = iterations already done
+ * (warm start, src/optimize.jl:58-62).  Results are bitwise those of the step-by-step entries.  Descent/Adam with
+ * Identity/ClipScale and no averaging take the fused paths of mivi_optimize_steps. */
+typedef struct mivi_loop {
+  int32_t rule, op, averager, n_steps;
+  double eta, beta1, beta2, adam_eps;
+  double clip_epsilon, avg_eta;
+  void *opt_state_dev;
+  void *avg_params_dev;
+  uint64_t estimate_idx0;
+  int64_t t0;
+  void *elbo_dev;     /* T[n_steps] or NULL: info.elbo of every iteration */
+} mivi_loop_t;
+mivi_status_t mivi_optimize_loop(mivi_ctx_t *ctx, void *params_dev, const mivi_loop_t *loop);
+
 /* Estimate-index source: when idx_dev != NULL every estimate uses estimate_idx + *idx_dev (read on the device at
  * kernel time), so a captured graph (e.g. a torch CUDAGraph holding kernels + the RCCL all-reduce) advances the
  * eps stream on replay by bumping one device word.  NULL restores by-value indices. */

@@ -294,3 +294,65 @@ def test_device_loop_with_the_logreg_target():
         ctx.synchronize()
         assert np.array_equal(pa.cpu().numpy(), pb.cpu().numpy())
         ctx.close()
+
+
+@pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
+@pytest.mark.parametrize("combo", [
+    ("descent", "clip", "poly"), ("adam", "identity", "none"), ("adam", "clip", "poly"), ("dog", "clip", "poly"),
+    ("dowg", "identity", "poly"), ("dowg", "prox", "poly"), ("descent", "prox", "none"), ("dog", "prox", "none")])
+def test_optimize_device_loop_equals_host_loop(family, combo):
+    """`optimize` runs every iteration inside mivi_optimize_loop when there is no callback; the result (parameters,
+    averaged output, per-iteration elbo) must be bitwise what the host-driven `step` loop produces, for every
+    rule x operator x averager the reference's algorithms combine -- including a warm start (optimize.jl:58-62)."""
+    rule, op, avg = combo
+    d, T = 12, 37
+    rng = np.random.default_rng(7)
+    mu, sig = rng.normal(size=d), rng.uniform(0.5, 1.5, size=d)
+    prob = avi.DiagNormalProblem(mu, sig) if family == avi.MEANFIELD else avi.DenseNormalProblem(mu, np.tril(rng.normal(size=(d, d)) * 0.1) + np.diag(sig))
+    q0 = avi.MeanFieldGaussian(np.zeros(d), np.ones(d)) if family == avi.MEANFIELD else avi.FullRankGaussian(np.zeros(d), np.eye(d))
+    opt = {"descent": avi.Descent(1e-2), "adam": avi.Adam(5e-2), "dog": avi.DoG(1e-2), "dowg": avi.DoWG(1e-2)}[rule]
+    averager = avi.PolynomialAveraging() if avg == "poly" else avi.NoAveraging()
+    if op == "prox":
+        alg = avi.KLMinRepGradProxDescent(avi.AutoMIVI(), n_samples=8, optimizer=opt, averager=averager)
+    else:
+        alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), n_samples=8, optimizer=opt, averager=averager,
+                                      operator=avi.ClipScale() if op == "clip" else avi.IdentityOperator())
+    outs = []
+    import warnings
+    for dev in (True, False):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q1, info1, st = avi.optimize(avi.PhiloxRNG(5), alg, T, prob, q0, device_loop=dev)
+            rng2 = avi.PhiloxRNG(5, T)      # the estimate stream continues where the first call stopped
+            q2, info2, st2 = avi.optimize(rng2, alg, 11, prob, None, state=st, device_loop=dev)
+        outs.append((q2.location.copy(), np.asarray(q2.scale).copy(), st2["params"].cpu().numpy().copy(),
+                     np.array([i["elbo"] for i in info1 + info2]), [i["iteration"] for i in info1]))
+    a, b = outs
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.allclose(a[3], b[3], rtol=1e-12, atol=0) and a[4] == b[4] == list(range(1, T + 1))
+
+
+def test_optimize_falls_back_to_the_host_loop_for_plugin_targets_and_callbacks():
+    class Plug:
+        def __init__(self, mu):
+            self.mu = mu
+
+        def dimension(self):
+            return self.mu.size
+
+        def capabilities(self):
+            return avi.LogDensityOrder(1)
+
+        def logdensity_and_gradient(self, x):
+            r = x - self.mu
+            return -0.5 * float(r @ r), -r
+
+    d = 4
+    q0 = avi.MeanFieldGaussian(np.zeros(d), np.ones(d))
+    alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), n_samples=8, optimizer=avi.Adam(5e-2), operator=avi.ClipScale())
+    q, info, _ = avi.optimize(avi.PhiloxRNG(1), alg, 60, Plug(np.arange(d, dtype=float)), q0)     # host callback target
+    assert len(info) == 60 and np.linalg.norm(q.location - np.arange(d)) < 0.8
+    seen = []
+    avi.optimize(avi.PhiloxRNG(1), alg, 5, avi.DiagNormalProblem(np.zeros(d), np.ones(d)), q0,
+                 callback=lambda **kw: seen.append(kw["iteration"]))
+    assert seen == [1, 2, 3, 4, 5]
