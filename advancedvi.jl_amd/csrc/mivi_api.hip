@@ -128,6 +128,7 @@ mivi_status_t mivi_create(const mivi_config_t *cfg, mivi_ctx_t **out) {
   mivi_status_t s;
   if ((s = ensure(c, c->status, 64, true)) ||
       (s = ensure(c, c->d_idx, 64, true)) || (s = ensure(c, c->acc, 64, true)) ||
+      (s = ensure(c, c->dog_part, (2 * 512 + 8) * sizeof(double), true)) ||
       (s = ensure(c, c->tmp_params, (size_t)mivi_params_len(c) * c->esize, false)) ||
       (s = ensure(c, c->tmp_out, ((size_t)mivi_params_len(c) + 16) * c->esize, false))) {
     delete c;
@@ -145,7 +146,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->dog_part, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);

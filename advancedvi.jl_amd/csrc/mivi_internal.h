@@ -245,6 +245,7 @@ struct mivi_ctx {
   int mf_nblk = 0;
   mivi::DevBuf Z, W, RT, ell, X;
   mivi::DevBuf row_part, status, d_idx, acc, tmp_params, tmp_out;
+  mivi::DevBuf dog_part;   // DoG / DoWG on large parameter vectors: 512 x 2 partial norms + the step size
   const uint64_t *idx_src = nullptr;   // mivi_set_index_source
   // speculative eps prefetch across single calls: the VJP kernel of estimate (seed, idx) also generates eps of
   // (seed, idx + 1) into the other parity; a following call for exactly that estimate skips its eps kernel
