@@ -779,7 +779,9 @@ static LrGeom lr_geom(const mivi_ctx *c, int M) {
   } else {
     g.ldr = M;
     g.nrb = (int)((n + 63) / 64);
-    int S = (int)((n + 4095) / 4096);
+    // row splits of the X^T r pass: at least 64 rows each, up to 128 of them (one 64 x 64 output tile per workgroup
+    // otherwise leaves a README-sized problem, n = 1000, on a single workgroup: 125 us)
+    int S = (int)((n + 63) / 64);
     if (S > 128) S = 128;
     if (S < 1) S = 1;
     long long rps = (n + S - 1) / S;
