@@ -766,7 +766,9 @@ static LrGeom lr_geom(const mivi_ctx *c, int M) {
   if (g.mfma) {
     g.ldr = (M + 63) / 64 * 64;
     g.nrb = (int)((n + 255) / 256);
-    int S = (int)((n + 2047) / 2048);   // one X^T R workgroup per CU: 128 row splits x 2 feature groups at p = 511
+    // row splits of X^T R: 128 x 2 feature groups = one workgroup per CU at C3 (n = 1e6, p = 511); small data sets still
+    // get a split per 128 rows (one workgroup walking n = 20 000 rows alone is a 270 us chain of 16-row stages)
+    int S = (int)((n + 127) / 128);
     if (S > 128) S = 128;
     if (S < 1) S = 1;
     long long rps = (n + S - 1) / S;
