@@ -883,8 +883,9 @@ __global__ __launch_bounds__(256) void k_fr_stl(FrArgs<T> a) {
 //               The column groups are independent, the row blocks are inherently sequential: the reference's
 //               docs call this estimator O(d^3) per step for the same reason (docs/src/klminrepgraddescent.md:93-95).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stl_prep(int d, int dP, const float *C, float *CT, float *DinvT) {
-  __shared__ float tile[32][33];
+template <typename T>
+__global__ __launch_bounds__(256) void k_stl_prep(int d, int dP, const T *C, T *CT, T *DinvT) {
+  __shared__ T tile[32][33];
   const int nb = (d + 31) >> 5;
   const int tid = threadIdx.x;
   if ((int)blockIdx.x < nb) {          // ---- inverse of diagonal block b ----
@@ -892,20 +893,20 @@ __global__ __launch_bounds__(256) void k_stl_prep(int d, int dP, const float *C,
     for (int t = tid; t < 1024; t += 256) {
       const int r = t & 31, c = t >> 5;         // D[r][c], lower triangular (identity on padding)
       const int gr = i0 + r, gc = i0 + c;
-      float v = 0.f;
+      T v = 0;
       if (gr < d && gc < d && gr >= gc) v = C[(size_t)gc * d + gr];
-      if (gr >= d && r == c) v = 1.f;
+      if (gr >= d && r == c) v = 1;
       tile[r][c] = v;
     }
     __syncthreads();
     if (tid < 32) {                     // lane c: column c of D^{-1} by forward substitution
       const int c = tid;
-      float y[32];
+      T y[32];
 #pragma unroll
-      for (int r = 0; r < 32; ++r) y[r] = 0.f;
+      for (int r = 0; r < 32; ++r) y[r] = 0;
 #pragma unroll
       for (int r = 0; r < 32; ++r) {
-        float sacc = (r == c) ? 1.f : 0.f;
+        T sacc = (r == c) ? T(1) : T(0);
 #pragma unroll
         for (int k = 0; k < r; ++k) sacc -= tile[r][k] * y[k];
         y[r] = sacc / tile[r][r];
@@ -921,7 +922,7 @@ __global__ __launch_bounds__(256) void k_stl_prep(int d, int dP, const float *C,
   for (int t = tid; t < 1024; t += 256) {
     const int r = t & 31, c = t >> 5;
     const int gr = ib * 32 + r, gc = jb * 32 + c;
-    tile[c][r] = (gr < d && gc < d && gr >= gc) ? C[(size_t)gc * d + gr] : 0.f;
+    tile[c][r] = (gr < d && gc < d && gr >= gc) ? C[(size_t)gc * d + gr] : T(0);
   }
   __syncthreads();
   for (int t = tid; t < 1024; t += 256) {
@@ -1044,29 +1045,45 @@ __global__ __launch_bounds__(NW * 64) void k_stl_solve_la(FrArgs<float> a, const
 // the CUs it runs on, and M / 32 workgroups are only 8 CUs at M = 256.  Half the columns per workgroup = twice the CUs at
 // half the MFMA time per 32x32 unit (16 MFMAs of 8 passes instead of 16 of 16 passes).
 //   A operand lane l: A[row = l&15][k = l>>4],  B: B[k = l>>4][col = l&15],  D reg r: row = 4*(l>>4) + r, col = l&15
-typedef float f32x4a __attribute__((ext_vector_type(4)));
+// The same kernel serves MIVI_F64 through v_mfma_f64_16x16x4_f64: identical A / B operand shapes, only the accumulator
+// rows differ (f32: row = 4*(l>>4) + r;  f64: row = (l>>4) + 4*r).
+template <typename T>
+struct Mfma16;
+template <>
+struct Mfma16<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int kq, int r) { return 4 * kq + r; }
+};
+template <>
+struct Mfma16<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int kq, int r) { return kq + 4 * r; }
+};
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_stl_solve_la16(FrArgs<float> a, const float *CT, const float *DinvT) {
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void k_stl_solve_la16(FrArgs<T> a, const T *CT, const T *DinvT) {
+  typedef typename Mfma16<T>::acc_t f32x4a;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float *x = (float *)smem_raw;                           // x[k*16 + m], k < dP
+  T *x = (T *)smem_raw;                                   // x[k*16 + m], k < dP
   const int d = a.d, M = a.M, dP = a.dP;
-  float *part = x + (size_t)dP * 16;                      // part[w][8*64]; part[0] = reduced bulk of the current row
+  T *part = x + (size_t)dP * 16;                      // part[w][8*64]; part[0] = reduced bulk of the current row
   const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, kq = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * 16;
   const int nb = (d + 31) >> 5;
   for (int t = tid; t < dP * 16; t += NW * 64) {
     const int k = t % dP, m = t / dP;                     // lanes along k: coalesced global reads
-    x[k * 16 + m] = (m0 + m < M) ? a.eps[(size_t)(m0 + m) * dP + k] : 0.f;
+    x[k * 16 + m] = (m0 + m < M) ? a.eps[(size_t)(m0 + m) * dP + k] : T(0);
   }
-  for (int t = tid; t < 8 * 64; t += NW * 64) part[t] = 0.f;
+  for (int t = tid; t < 8 * 64; t += NW * 64) part[t] = T(0);
   // one 32x32 unit of A = CT(brow, j): av[2g + hb] = A[row = 16*hb + c16][k = 4g + kq]
   // up to four units of the NEXT block row are requested at the end of the current one (their L2 latency, ~0.7 us,
   // then hides under the barriers and the chain); a fifth unit (only the last few block rows have one) is fetched in place
-  float av0[16], av1[16], av2[16], av3[16];
-  auto loadA = [&](int brow, int j, float (&av)[16]) {
-    const float *Arow = CT + brow * 32 + c16 + (size_t)(j * 32 + kq) * dP;
+  T av0[16], av1[16], av2[16], av3[16];
+  auto loadA = [&](int brow, int j, T (&av)[16]) {
+    const T *Arow = CT + brow * 32 + c16 + (size_t)(j * 32 + kq) * dP;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       av[2 * g] = Arow[(size_t)(4 * g) * dP];
@@ -1074,9 +1091,9 @@ __global__ __launch_bounds__(NW * 64) void k_stl_solve_la16(FrArgs<float> a, con
     }
   };
   __syncthreads();
-  float dv[16];
+  T dv[16];
   auto loadD = [&](int b) {   // inverted diagonal block, same operand shape: A[i][k] = DinvT[i + 32 k]
-    const float *Di = DinvT + (size_t)b * 1024 + c16 + 32 * kq;
+    const T *Di = DinvT + (size_t)b * 1024 + c16 + 32 * kq;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
       dv[2 * g] = Di[32 * 4 * g];
@@ -1088,13 +1105,13 @@ __global__ __launch_bounds__(NW * 64) void k_stl_solve_la16(FrArgs<float> a, con
     __builtin_amdgcn_s_setprio(3);   // the sequential chain shares its SIMD with a bulk wave: let it issue first
   }
   for (int b = nb - 1; b >= 0; --b) {
-    f32x4a acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};   // rows 0..15 / 16..31 of the block
-    auto mma = [&](int j, const float (&av)[16]) {
+    f32x4a acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};   // rows 0..15 / 16..31 of the block
+    auto mma = [&](int j, const T (&av)[16]) {
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
-        const float bv = x[(j * 32 + 4 * g + kq) * 16 + c16];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2 * g], bv, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2 * g + 1], bv, acc1, 0, 0, 0);
+        const T bv = x[(j * 32 + 4 * g + kq) * 16 + c16];
+        acc0 = Mfma16<T>::mma(av[2 * g], bv, acc0);
+        acc1 = Mfma16<T>::mma(av[2 * g + 1], bv, acc1);
       }
     };
     if (w == 0) {
@@ -1104,28 +1121,28 @@ __global__ __launch_bounds__(NW * 64) void k_stl_solve_la16(FrArgs<float> a, con
       // R_b = eps_b - bulk_b - last term (accumulator layout)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float *x0 = &x[(b * 32 + 4 * kq + r) * 16 + c16], *x1 = x0 + 16 * 16;
+        T *x0 = &x[(b * 32 + Mfma16<T>::row(kq, r)) * 16 + c16], *x1 = x0 + 16 * 16;
         *x0 = *x0 - part[r * 64 + lane] - acc0[r];
         *x1 = *x1 - part[(4 + r) * 64 + lane] - acc1[r];
       }
-      f32x4a xa0 = {0.f, 0.f, 0.f, 0.f}, xa1 = {0.f, 0.f, 0.f, 0.f};
+      f32x4a xa0 = {0, 0, 0, 0}, xa1 = {0, 0, 0, 0};
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
-        const float bv = x[(b * 32 + 4 * g + kq) * 16 + c16];
-        xa0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[2 * g], bv, xa0, 0, 0, 0);
-        xa1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[2 * g + 1], bv, xa1, 0, 0, 0);
+        const T bv = x[(b * 32 + 4 * g + kq) * 16 + c16];
+        xa0 = Mfma16<T>::mma(dv[2 * g], bv, xa0);
+        xa1 = Mfma16<T>::mma(dv[2 * g + 1], bv, xa1);
       }
       if (b > 0) loadD(b - 1);                            // next block row's inverse: in flight across the barriers
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        x[(b * 32 + 4 * kq + r) * 16 + c16] = xa0[r];
-        x[(b * 32 + 16 + 4 * kq + r) * 16 + c16] = xa1[r];
+        x[(b * 32 + Mfma16<T>::row(kq, r)) * 16 + c16] = xa0[r];
+        x[(b * 32 + 16 + Mfma16<T>::row(kq, r)) * 16 + c16] = xa1[r];
       }
     } else if (b > 0) {
       // ---- bulk of block row b-1: units j = b+1 .. nb-1 dealt to waves 1 .. NW-1 ------------------------
       const int j = b + w, S = NW - 1;                     // units j, j+S, j+2S, ... < nb (at most five at nb = 32)
       if (j + 4 * S < nb) {                                // rare fifth unit: request it before the burst, use it last
-        float av4[16];
+        T av4[16];
         loadA(b - 1, j + 4 * S, av4);
         mma(j, av0); mma(j + S, av1); mma(j + 2 * S, av2); mma(j + 3 * S, av3);
         for (int jj = j + 4 * S; jj < nb; jj += S) {       // (and any beyond, for nb > 32, one by one)
@@ -1152,11 +1169,11 @@ __global__ __launch_bounds__(NW * 64) void k_stl_solve_la16(FrArgs<float> a, con
       }
     } else {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) part[w * 512 + r * 64 + lane] = 0.f;
+      for (int r = 0; r < 8; ++r) part[w * 512 + r * 64 + lane] = T(0);
     }
     __syncthreads();
     if (tid < 512) {
-      float sacc = part[512 + tid];
+      T sacc = part[512 + tid];
 #pragma unroll
       for (int ww = 2; ww < NW; ++ww) sacc += part[ww * 512 + tid];
       part[tid] = sacc;
@@ -1602,10 +1619,26 @@ void launch_fr_stl(mivi_ctx *c, const void *params, int M) {
   const size_t sh_mfma = ((size_t)c->dP * 32 + 8 * 16 * 64) * sizeof(float);
   const size_t sh_mfma16 = ((size_t)c->dP * 16 + 8 * 8 * 64) * sizeof(float);   // 16-column solve: d up to 2304
   static const bool want32 = getenv("MIVI_STL_LEFT") != nullptr || getenv("MIVI_STL_COLS32") != nullptr;
+  const size_t sh16_f64 = ((size_t)c->dP * 16 + 8 * 8 * 64) * sizeof(double);   // f64: d up to 1024
+  if (c->cfg.dtype == MIVI_F64 && c->stl_CT.p && sh16_f64 <= 160 * 1024 && !old_stl && !f64_valu()) {
+    FrArgs<double> a = fr_args<double>(c, params, M);
+    const int nb = (c->cfg.d + 31) / 32;
+    hipLaunchKernelGGL(k_stl_prep<double>, dim3(nb + nb * (nb + 1) / 2), dim3(256), 0, c->stream, c->cfg.d, c->dP,
+                       (const double *)params + c->cfg.d, (double *)c->stl_CT.p, (double *)c->stl_Dinv.p);
+    static size_t attr64 = 0;
+    if (attr64 < sh16_f64) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stl_solve_la16<double, 8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh16_f64);
+      attr64 = sh16_f64;
+    }
+    hipLaunchKernelGGL((k_stl_solve_la16<double, 8>), dim3((M + 15) / 16), dim3(512), sh16_f64, c->stream, a,
+                       (const double *)c->stl_CT.p, (const double *)c->stl_Dinv.p);
+    return;
+  }
   if (c->cfg.dtype == MIVI_F32 && c->stl_CT.p && (want32 ? sh_mfma : sh_mfma16) <= 160 * 1024 && !old_stl) {
     FrArgs<float> a = fr_args<float>(c, params, M);
     const int nb = (c->cfg.d + 31) / 32;
-    hipLaunchKernelGGL(k_stl_prep, dim3(nb + nb * (nb + 1) / 2), dim3(256), 0, c->stream, c->cfg.d, c->dP,
+    hipLaunchKernelGGL(k_stl_prep<float>, dim3(nb + nb * (nb + 1) / 2), dim3(256), 0, c->stream, c->cfg.d, c->dP,
                        (const float *)params + c->cfg.d, (float *)c->stl_CT.p, (float *)c->stl_Dinv.p);
     static size_t attr_set = 0;   // raise the dynamic-LDS cap once per size (the call is slow)
     if (want32 && attr_set < sh_mfma) {
@@ -1619,11 +1652,11 @@ void launch_fr_stl(mivi_ctx *c, const void *params, int M) {
       const size_t sh16 = ((size_t)c->dP * 16 + 8 * 8 * 64) * sizeof(float);
       static size_t attr16 = 0;
       if (attr16 < sh16) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stl_solve_la16<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stl_solve_la16<float, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)sh16);
         attr16 = sh16;
       }
-      hipLaunchKernelGGL(k_stl_solve_la16<8>, dim3((M + 15) / 16), dim3(512), sh16, c->stream, a, (const float *)c->stl_CT.p,
+      hipLaunchKernelGGL((k_stl_solve_la16<float, 8>), dim3((M + 15) / 16), dim3(512), sh16, c->stream, a, (const float *)c->stl_CT.p,
                          (const float *)c->stl_Dinv.p);
       return;
     }

@@ -70,10 +70,9 @@ static mivi_status_t ensure_work(mivi_ctx *c, int M) {
       c->RT.bytes = 0;
       if ((s = ensure(c, c->RT, (size_t)c->dP * c->MP * es, true))) return s;
     }
-    if (c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 &&
-        (c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD)) {
-      if ((s = ensure(c, c->stl_CT, (size_t)c->dP * c->dP * sizeof(float), true))) return s;
-      if ((s = ensure(c, c->stl_Dinv, (size_t)((d + 31) / 32) * 1024 * sizeof(float), false))) return s;
+    if (c->cfg.family == MIVI_FULLRANK && (c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD)) {
+      if ((s = ensure(c, c->stl_CT, (size_t)c->dP * c->dP * es, true))) return s;
+      if ((s = ensure(c, c->stl_Dinv, (size_t)((d + 31) / 32) * 1024 * es, false))) return s;
     }
     if (c->cfg.family == MIVI_MEANFIELD && c->target == TGT_FUNNEL)
       for (int b = 0; b < 2; ++b)
