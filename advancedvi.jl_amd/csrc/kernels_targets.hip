@@ -283,6 +283,7 @@ struct LrMfmaArgs {
   const uint8_t *y;
   const float *ZT;     // ZT[m + k*ldz]
   int ldz;
+  const float *Zcm;    // the sample matrix itself, d x M column-major (k contiguous per sample): bf16x3 logits
   float *R;            // R[m + r*ldr]
   int ldr;
   double *ll_part;     // [gridDim.x][M]
@@ -661,6 +662,280 @@ __global__ __launch_bounds__(512) void k_lr_logits_mfma_lds(LrMfmaArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// logits on the bf16 matrix cores with f32 accuracy ("bf16x3"): every f32 operand is split exactly into three bf16
+// pieces x = hi + mid + lo (8 + 8 + 8 mantissa bits) when it is staged into LDS, and a product block is the six
+// MFMAs hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi (the dropped terms are below 2^-24 of the product) accumulated in
+// f32 by v_mfma_f32_32x32x16_bf16.  24 bf16 MFMAs of 8 passes replace 32 f32 MFMAs of 16 passes per 16-k stage, i.e.
+// 2.7x the MFMA throughput; X is still read from HBM once, as f32.  Same tile shape, ring and epilogue as
+// k_lr_logits_mfma_lds; the B operand comes from the column-major sample matrix (k contiguous per sample), which is
+// what a 16-byte operand of 8 consecutive k needs (requires d % 4 == 0).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 lr_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 lr_bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void lr_split3(const lr_f32x4 &v, lr_bf16x4 &hi, lr_bf16x4 &mid, lr_bf16x4 &lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 h = (__bf16)v[i];
+    const float r1 = v[i] - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    hi[i] = h;
+    mid[i] = m;
+    lo[i] = (__bf16)r2;
+  }
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lr_logits_bf16x3(LrMfmaArgs a) {
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[2][3][256 * 16];   // [slot][piece][row][16 k]
+  __shared__ __attribute__((aligned(16))) __bf16 Zs[2][3][128 * 16];   // [slot][piece][sample][16 k]
+  __shared__ float ll_lds[128];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 1, wm = w & 1;
+  const long long rb0 = (long long)blockIdx.x * 256;
+  const long long r0 = rb0 + wr * 64;
+  const int mbase = blockIdx.y * 128, m0 = mbase + wm * 64;
+  const int ldx = a.ldx, d = a.d;
+  const int nst = ldx / 16;
+  if (tid < 128) ll_lds[tid] = 0.f;
+  const int xrow = tid >> 2, xc = 4 * (tid & 3);
+  const float *Xg0 = a.Xrm + (size_t)min(rb0 + xrow, a.n - 1) * ldx + xc;
+  const float *Xg1 = a.Xrm + (size_t)min(rb0 + 128 + xrow, a.n - 1) * ldx + xc;
+  const float *Zg = a.Zcm + (size_t)min(mbase + xrow, a.M - 1) * d;   // sample xrow of this block (128 samples x 4 chunks)
+  struct G { lr_f32x4 x0, x1, z; };
+  auto gload = [&](int st, G &g) {
+    st = min(st, nst - 1);
+    g.x0 = *(const lr_f32x4 *)(Xg0 + 16 * st);
+    g.x1 = *(const lr_f32x4 *)(Xg1 + 16 * st);
+    // k >= p multiplies the zero padding of Xrm: any finite in-bounds value will do there
+    g.z = *(const lr_f32x4 *)(Zg + min(16 * st + xc, d - 4));
+  };
+  auto lstore = [&](int slot, const G &g) {
+    lr_bf16x4 p0, p1, p2;
+    lr_split3(g.x0, p0, p1, p2);
+    *(lr_bf16x4 *)&Xs[slot][0][xrow * 16 + xc] = p0;
+    *(lr_bf16x4 *)&Xs[slot][1][xrow * 16 + xc] = p1;
+    *(lr_bf16x4 *)&Xs[slot][2][xrow * 16 + xc] = p2;
+    lr_split3(g.x1, p0, p1, p2);
+    *(lr_bf16x4 *)&Xs[slot][0][(128 + xrow) * 16 + xc] = p0;
+    *(lr_bf16x4 *)&Xs[slot][1][(128 + xrow) * 16 + xc] = p1;
+    *(lr_bf16x4 *)&Xs[slot][2][(128 + xrow) * 16 + xc] = p2;
+    lr_split3(g.z, p0, p1, p2);
+    *(lr_bf16x4 *)&Zs[slot][0][xrow * 16 + xc] = p0;
+    *(lr_bf16x4 *)&Zs[slot][1][xrow * 16 + xc] = p1;
+    *(lr_bf16x4 *)&Zs[slot][2][xrow * 16 + xc] = p2;
+  };
+  lr_f32x16 c00, c01, c10, c11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
+  const int ao = (wr * 64 + l31) * 16 + 8 * h, bo = (wm * 64 + l31) * 16 + 8 * h;
+  auto compute = [&](int slot) {
+    lr_bf16x8 A0[3], A1[3], B0[3], B1[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      A0[s] = *(const lr_bf16x8 *)&Xs[slot][s][ao];
+      A1[s] = *(const lr_bf16x8 *)&Xs[slot][s][ao + 32 * 16];
+      B0[s] = *(const lr_bf16x8 *)&Zs[slot][s][bo];
+      B1[s] = *(const lr_bf16x8 *)&Zs[slot][s][bo + 32 * 16];
+    }
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B0[PB[t]], c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B1[PB[t]], c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B0[PB[t]], c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B1[PB[t]], c11, 0, 0, 0);
+    }
+  };
+  {
+    G ga, gb;
+    gload(0, ga);
+    lstore(0, ga);
+    gload(1, ga);
+    gload(2, gb);
+    lds_barrier();
+    int st = 0;
+    while (true) {
+      lstore((st + 1) & 1, ga);
+      gload(st + 3, ga);
+      compute(st & 1);
+      lds_barrier();
+      if (++st >= nst) break;
+      lstore((st + 1) & 1, gb);
+      gload(st + 3, gb);
+      compute(st & 1);
+      lds_barrier();
+      if (++st >= nst) break;
+    }
+  }
+  float ll0 = 0.f, ll1 = 0.f;
+  auto epi = [&](const lr_f32x16 &ca, const lr_f32x16 &cb, int rb) {
+    const int ma = m0 + l31, mb = m0 + 32 + l31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const long long r = r0 + rb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (r < a.n) {
+        const float yv = (float)a.y[r];
+        {
+          const float lg = ca[q], e = __expf(-fabsf(lg)), inv = __frcp_rn(1.f + e);
+          if (ma < a.M) {
+            ll0 += yv * lg - (fmaxf(lg, 0.f) + __logf(1.f + e));
+            if (a.want_grad) a.R[(size_t)r * a.ldr + ma] = yv - (lg >= 0.f ? inv : e * inv);
+          }
+        }
+        {
+          const float lg = cb[q], e = __expf(-fabsf(lg)), inv = __frcp_rn(1.f + e);
+          if (mb < a.M) {
+            ll1 += yv * lg - (fmaxf(lg, 0.f) + __logf(1.f + e));
+            if (a.want_grad) a.R[(size_t)r * a.ldr + mb] = yv - (lg >= 0.f ? inv : e * inv);
+          }
+        }
+      }
+    }
+  };
+  epi(c00, c01, 0);
+  epi(c10, c11, 1);
+  ll0 += __shfl_xor(ll0, 32, 64);
+  ll1 += __shfl_xor(ll1, 32, 64);
+  if (h == 0) {
+    atomicAdd(&ll_lds[wm * 64 + l31], ll0);
+    atomicAdd(&ll_lds[wm * 64 + 32 + l31], ll1);
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int m = mbase + tid;
+    if (m < a.M) a.ll_part[(size_t)blockIdx.x * a.M + m] = (double)ll_lds[tid];
+  }
+}
+
+// X^T R on the bf16 matrix cores, same bf16x3 scheme.  The contraction runs over data rows, so both operands need 8
+// consecutive ROWS per lane while memory has rows outermost: a thread loads a 4-row x 1-column strip (lanes along the
+// contiguous axis: coalesced dword loads), splits it, and writes the 4 row-consecutive bf16 of each piece as one 8-byte
+// LDS word into [column][16 rows] tiles -- the transposition costs nothing.  Column stride 40 bytes: conflict-free for
+// the 8-byte writes and the 8-byte operand reads (a 16-byte operand = two reads).
+__device__ __forceinline__ void lr_split3s(const float (&v)[4], lr_bf16x4 &hi, lr_bf16x4 &mid, lr_bf16x4 &lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 h = (__bf16)v[i];
+    const float r1 = v[i] - (float)h;
+    const __bf16 m = (__bf16)r1;
+    hi[i] = h;
+    mid[i] = m;
+    lo[i] = (__bf16)(r1 - (float)m);
+  }
+}
+
+__global__ __launch_bounds__(512) void k_lr_xtr_bf16x3(LrMfmaArgs a) {
+  constexpr int CS = 20;   // column stride in bf16 (40 bytes)
+  __shared__ __attribute__((aligned(16))) __bf16 Rs[2][3][128 * CS];   // [slot][piece][sample][16 rows]
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[2][3][256 * CS];   // [slot][piece][feature][16 rows]
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wk = w & 3;
+  const int mbase = blockIdx.z * 128, kbase = blockIdx.y * 256;
+  const int m0 = mbase + wm * 64, k0 = kbase + wk * 64;
+  const long long rbeg = (long long)blockIdx.x * a.rows_per_split;
+  const long long rend = min(a.n, rbeg + a.rows_per_split);
+  const int ldr = a.ldr, ldx = a.ldx;
+  const int nst = (int)((rend - rbeg + 15) / 16);
+  // strips: R  sample tid & 127, rows 4*(tid >> 7) .. +3;  X  feature tid & 255, rows 4*q .. +3 for q = tid >> 8 and q + 2
+  const int rm = tid & 127, rrg = tid >> 7;
+  const int xf = tid & 255, xrg = tid >> 8;
+  const int rcol = min(mbase + rm, ldr - 1), xcol = min(kbase + xf, ldx - 1);
+  struct G { float r[4], x0[4], x1[4]; };
+  auto gload = [&](int st, G &g) {
+    st = min(st, nst - 1);
+    const long long rb = rbeg + 16LL * st;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long rr = rb + 4 * rrg + i, rx0 = rb + 4 * xrg + i, rx1 = rx0 + 8;
+      const float rv = a.R[(size_t)min(rr, rend - 1) * ldr + rcol];
+      g.r[i] = rr < rend ? rv : 0.f;                                   // rows past the split contribute nothing
+      g.x0[i] = a.Xrm[(size_t)min(rx0, rend - 1) * ldx + xcol];
+      g.x1[i] = a.Xrm[(size_t)min(rx1, rend - 1) * ldx + xcol];
+    }
+  };
+  auto lstore = [&](int slot, const G &g) {
+    lr_bf16x4 p0, p1, p2;
+    lr_split3s(g.r, p0, p1, p2);
+    *(lr_bf16x4 *)&Rs[slot][0][rm * CS + 4 * rrg] = p0;
+    *(lr_bf16x4 *)&Rs[slot][1][rm * CS + 4 * rrg] = p1;
+    *(lr_bf16x4 *)&Rs[slot][2][rm * CS + 4 * rrg] = p2;
+    lr_split3s(g.x0, p0, p1, p2);
+    *(lr_bf16x4 *)&Xs[slot][0][xf * CS + 4 * xrg] = p0;
+    *(lr_bf16x4 *)&Xs[slot][1][xf * CS + 4 * xrg] = p1;
+    *(lr_bf16x4 *)&Xs[slot][2][xf * CS + 4 * xrg] = p2;
+    lr_split3s(g.x1, p0, p1, p2);
+    *(lr_bf16x4 *)&Xs[slot][0][xf * CS + 4 * xrg + 8] = p0;
+    *(lr_bf16x4 *)&Xs[slot][1][xf * CS + 4 * xrg + 8] = p1;
+    *(lr_bf16x4 *)&Xs[slot][2][xf * CS + 4 * xrg + 8] = p2;
+  };
+  lr_f32x16 c00, c01, c10, c11;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
+  const int ao = (wm * 64 + l31) * CS + 8 * h, bo = (wk * 64 + l31) * CS + 8 * h;
+  auto ld8 = [&](const __bf16 *p) {   // 8 consecutive rows of one column = two 8-byte words
+    const lr_bf16x4 lo4 = *(const lr_bf16x4 *)p, hi4 = *(const lr_bf16x4 *)(p + 4);
+    lr_bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = lo4[i]; v[4 + i] = hi4[i]; }
+    return v;
+  };
+  auto compute = [&](int slot) {
+    lr_bf16x8 A0[3], A1[3], B0[3], B1[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      A0[s] = ld8(&Rs[slot][s][ao]);
+      A1[s] = ld8(&Rs[slot][s][ao + 32 * CS]);
+      B0[s] = ld8(&Xs[slot][s][bo]);
+      B1[s] = ld8(&Xs[slot][s][bo + 32 * CS]);
+    }
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+      c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B0[PB[t]], c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B1[PB[t]], c01, 0, 0, 0);
+      c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B0[PB[t]], c10, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B1[PB[t]], c11, 0, 0, 0);
+    }
+  };
+  if (nst > 0) {
+    G ga, gb;
+    gload(0, ga);
+    lstore(0, ga);
+    gload(1, ga);
+    gload(2, gb);
+    lds_barrier();
+    int st = 0;
+    while (true) {
+      lstore((st + 1) & 1, ga);
+      gload(st + 3, ga);
+      compute(st & 1);
+      lds_barrier();
+      if (++st >= nst) break;
+      lstore((st + 1) & 1, gb);
+      gload(st + 3, gb);
+      compute(st & 1);
+      lds_barrier();
+      if (++st >= nst) break;
+    }
+  }
+  auto epi = [&](const lr_f32x16 &c, int mb, int kb) {
+    const int k = k0 + kb * 32 + l31;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = m0 + mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+      if (k < a.p && m < a.M) a.g_part[((size_t)blockIdx.x * a.M + m) * a.p + k] = c[q];
+    }
+  };
+  epi(c00, 0, 0);
+  epi(c01, 0, 1);
+  epi(c10, 1, 0);
+  epi(c11, 1, 1);
+}
+
 // one-time: row-major zero-padded copy of X (n x p column-major -> n x ldx row-major), 64x64 LDS transpose
 __global__ __launch_bounds__(256) void k_lr_make_xrm(long long n, int p, int ldx, const float *X, float *Xrm) {
   __shared__ float tile[64][65];
@@ -826,13 +1101,19 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
   a.g_part = (float *)((char *)c->lr_scratch.p + need_R);
   a.ll_part = (double *)c->lr_part.p;
   // MIVI_LR_GEN1=1 selects the first-generation (register-operand) kernels: the in-library A/B reference
+  static const bool no_bf16x3 = getenv("MIVI_LR_F32_LOGITS") != nullptr;   // A/B: f32 MFMA logits
+  a.Zcm = (const float *)c->Z.p;
   if (gen1)
     hipLaunchKernelGGL(k_lr_logits_mfma, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
+  else if (a.d % 4 == 0 && a.d >= 4 && !no_bf16x3)
+    hipLaunchKernelGGL(k_lr_logits_bf16x3, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
   else
     hipLaunchKernelGGL(k_lr_logits_mfma_lds, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
   if (want_grad) {
     const dim3 gx(S, (a.p + 255) / 256, (M + 127) / 128);
+    static const bool xtr_f32 = getenv("MIVI_LR_F32_XTR") != nullptr;   // A/B: f32 MFMA X^T R
     if (gen1) hipLaunchKernelGGL(k_lr_xtr_mfma, gx, dim3(512), 0, c->stream, a);
+    else if (!xtr_f32) hipLaunchKernelGGL(k_lr_xtr_bf16x3, gx, dim3(512), 0, c->stream, a);
     else hipLaunchKernelGGL(k_lr_xtr_mfma_lds, gx, dim3(512), 0, c->stream, a);
   }
   if (want_grad && S > 1) {
