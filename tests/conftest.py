@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no built artefacts (they are git-ignored): build them once, like the driver's build step."""
+    need = [os.path.join(ROOT, "advancedvi.jl_amd", "libmivi.so"), os.path.join(ROOT, "oracle", "libmivi_oracle.so")]
+    if all(os.path.exists(p) for p in need):
+        return
+    try:
+        import __graft_entry__ as g
+        g.build()
+    except Exception as e:   # noqa: BLE001  -- the tests that need the libraries will say so themselves
+        print(f"[conftest] build() failed: {e}", file=sys.stderr)
+
+
 @pytest.fixture(scope="session")
 def lib():
     import advancedvi_jl_amd as avi
