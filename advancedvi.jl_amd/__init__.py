@@ -9,7 +9,8 @@ from .problems import (LogDensityOrder, DiagNormalProblem, DenseNormalProblem, L
                        dimension, capabilities)
 from .objectives import (RepGradELBO, RepGradELBOState, ClosedFormEntropy, ClosedFormEntropyZeroGradient,
                          MonteCarloEntropy, StickingTheLandingEntropy, StickingTheLandingEntropyZeroGradient,
-                         AutoMIVI, PhiloxRNG, DiffResult, set_objective_state_problem, rand)
+                         AutoMIVI, PhiloxRNG, DiffResult, set_objective_state_problem, rand,
+                         gaussian_expectation_gradient_and_hessian_)
 from . import objectives as _objectives
 from . import optimize as _optimize
 from .optimize import (KLMinRepGradDescent, KLMinRepGradProxDescent, ADVI, ClipScale, IdentityOperator,

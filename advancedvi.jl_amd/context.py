@@ -213,6 +213,16 @@ class MiviContext:
         self._raise_cb(self.lib.mivi_estimate_objective(self.h, self._p(p), idx, int(n_samples), int(entropy), self._p(value)))
         return value
 
+    def gauss_expected_grad_hess(self, params, idx, n_samples=0, grad=None, hess=None):
+        """(logpi_avg T[1], grad T[d], hess (d, d)) of mivi_gauss_expected_grad_hess; `hess[i, j]` is the matrix entry."""
+        p = self.to_device(params)
+        logpi = self.empty(1)
+        grad = self.empty(self.d) if grad is None else grad
+        hess = self.empty(self.d * self.d) if hess is None else hess
+        self._raise_cb(self.lib.mivi_gauss_expected_grad_hess(self.h, self._p(p), idx, int(n_samples), self._p(logpi),
+                                                              self._p(grad), self._p(hess)))
+        return logpi, grad, hess.view(self.d, self.d).t()   # column-major d x d
+
     def estimate_partials(self, params, idx, partials=None):
         p = self.to_device(params)
         partials = self.empty(self.partials_len) if partials is None else partials

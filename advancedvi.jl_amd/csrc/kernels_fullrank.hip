@@ -1613,7 +1613,115 @@ void launch_rt_from_z(mivi_ctx *c, int M) {
                        (const double *)tm, (double *)c->RT.p);
 }
 
-void launch_fr_stl(mivi_ctx *c, const void *params, int M) {
+// ---------------------------------------------------------------------------------------------
+// Stein / Price estimator of E_q[hess log pi] (src/algorithms/gauss_expected_grad_hess.jl:32-60), accumulation stage:
+//   A (+)= eps G^T   -- the whole d x d product, not only the lower triangle the ELBO gradient needs
+//   gsum (+)= G 1
+// One workgroup per 32x32 tile of A, the sample axis dealt to its four waves (16x16x4 MFMA in T, so f32 and f64 share
+// the kernel); `scale` = 1/n on the last chunk.  The solve  hess = C^-T A  reuses the STL back-substitution kernels.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_stein_outer(int d, int dP, int M, const T *eps, const T *G, T *A, double *gsum,
+                                                     int first, T scale) {
+  typedef typename Mfma16<T>::acc_t acc_t;
+  __shared__ T red[4][32 * 33];
+  __shared__ double gred[8][32];
+  const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, kq = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+  acc_t acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+  const bool okA = j0 + c16 < d, okB = j0 + 16 + c16 < d;
+  const T *e0 = eps + i0 + c16;                           // rows < dP: eps is zero padded
+  const T *g0 = G + (okA ? j0 + c16 : 0), *g1 = G + (okB ? j0 + 16 + c16 : 0);
+  int k0 = 4 * w;
+  for (; k0 + 48 + 4 <= M; k0 += 64) {                    // four 4-sample steps of this wave, all in range: loads first
+    T a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t kk = (size_t)(k0 + 16 * u + kq);
+      a0[u] = e0[kk * dP];
+      a1[u] = e0[kk * dP + 16];
+      b0[u] = okA ? g0[kk * d] : T(0);
+      b1[u] = okB ? g1[kk * d] : T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc00 = Mfma16<T>::mma(a0[u], b0[u], acc00);
+      acc01 = Mfma16<T>::mma(a0[u], b1[u], acc01);
+      acc10 = Mfma16<T>::mma(a1[u], b0[u], acc10);
+      acc11 = Mfma16<T>::mma(a1[u], b1[u], acc11);
+    }
+  }
+  for (; k0 < M; k0 += 16) {
+    const int k = k0 + kq;
+    const bool ok = k < M;
+    const size_t kk = ok ? (size_t)k : 0;
+    const T a0 = ok ? e0[kk * dP] : T(0), a1 = ok ? e0[kk * dP + 16] : T(0);
+    const T b0 = (ok && okA) ? g0[kk * d] : T(0), b1 = (ok && okB) ? g1[kk * d] : T(0);
+    acc00 = Mfma16<T>::mma(a0, b0, acc00);
+    acc01 = Mfma16<T>::mma(a0, b1, acc01);
+    acc10 = Mfma16<T>::mma(a1, b0, acc10);
+    acc11 = Mfma16<T>::mma(a1, b1, acc11);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = Mfma16<T>::row(kq, r);
+    red[w][row * 33 + c16] = acc00[r];
+    red[w][row * 33 + 16 + c16] = acc01[r];
+    red[w][(16 + row) * 33 + c16] = acc10[r];
+    red[w][(16 + row) * 33 + 16 + c16] = acc11[r];
+  }
+  if (blockIdx.x == 0) {                                   // column sums of G for this block of coordinates
+    const int jj = tid & 31, part = tid >> 5;
+    double sacc = 0.0;
+    if (j0 + jj < d)
+      for (int b = part; b < M; b += 8) sacc += (double)G[(size_t)b * d + j0 + jj];
+    gred[part][jj] = sacc;
+  }
+  __syncthreads();
+  for (int t = tid; t < 1024; t += 256) {
+    const int row = t & 31, col = t >> 5;
+    if (j0 + col >= d) continue;
+    const T sum = (red[0][row * 33 + col] + red[1][row * 33 + col]) + (red[2][row * 33 + col] + red[3][row * 33 + col]);
+    T *dst = A + (size_t)(j0 + col) * dP + i0 + row;
+    *dst = ((first ? T(0) : *dst) + sum) * scale;
+  }
+  if (blockIdx.x == 0 && tid < 32 && j0 + tid < d) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sacc += gred[q][tid];
+    gsum[j0 + tid] = (first ? 0.0 : gsum[j0 + tid]) + sacc;
+  }
+}
+
+template <typename T>
+__global__ void k_stein_finish(int d, double n, const double *gsum, const double *ell_sum, T *grad, T *logpi_avg) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < d) grad[i] = (T)(gsum[i] / n);
+  if (i == 0) *logpi_avg = (T)(ell_sum[0] / n);
+}
+
+void launch_stein_outer(mivi_ctx *c, int M, void *A, double *gsum, int first, double scale) {
+  dim3 grid(c->dP / 32, (c->cfg.d + 31) / 32);
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_stein_outer<float>, grid, dim3(256), 0, c->stream, c->cfg.d, c->dP, M, (const float *)c->eps[c->cur].p,
+                       (const float *)c->W.p, (float *)A, gsum, first, (float)scale);
+  else
+    hipLaunchKernelGGL(k_stein_outer<double>, grid, dim3(256), 0, c->stream, c->cfg.d, c->dP, M, (const double *)c->eps[c->cur].p,
+                       (const double *)c->W.p, (double *)A, gsum, first, scale);
+}
+
+void launch_stein_finish(mivi_ctx *c, double n, const double *gsum, const double *ell_sum, void *grad, void *logpi_avg) {
+  const int nb = (c->cfg.d + 255) / 256;
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_stein_finish<float>, dim3(nb), dim3(256), 0, c->stream, c->cfg.d, n, gsum, ell_sum, (float *)grad, (float *)logpi_avg);
+  else
+    hipLaunchKernelGGL(k_stein_finish<double>, dim3(nb), dim3(256), 0, c->stream, c->cfg.d, n, gsum, ell_sum, (double *)grad, (double *)logpi_avg);
+}
+
+// W += C^-T eps for the M sample columns -- or, with `rhs` / `out` given, out += C^-T rhs for any M-column right-hand
+// side laid out like eps (leading dimension dP, zero padded) and any output laid out like W (leading dimension d)
+void launch_fr_stl(mivi_ctx *c, const void *params, int M, const void *rhs, void *out) {
   const int nblk = (M + 7) / 8;
   static const bool old_stl = getenv("MIVI_STL_VALU") != nullptr;
   const size_t sh_mfma = ((size_t)c->dP * 32 + 8 * 16 * 64) * sizeof(float);
@@ -1622,6 +1730,8 @@ void launch_fr_stl(mivi_ctx *c, const void *params, int M) {
   const size_t sh16_f64 = ((size_t)c->dP * 16 + 8 * 8 * 64) * sizeof(double);   // f64: d up to 1024
   if (c->cfg.dtype == MIVI_F64 && c->stl_CT.p && sh16_f64 <= 160 * 1024 && !old_stl && !f64_valu()) {
     FrArgs<double> a = fr_args<double>(c, params, M);
+    if (rhs) a.eps = (const double *)rhs;
+    if (out) a.W = (double *)out;
     const int nb = (c->cfg.d + 31) / 32;
     hipLaunchKernelGGL(k_stl_prep<double>, dim3(nb + nb * (nb + 1) / 2), dim3(256), 0, c->stream, c->cfg.d, c->dP,
                        (const double *)params + c->cfg.d, (double *)c->stl_CT.p, (double *)c->stl_Dinv.p);
@@ -1637,6 +1747,8 @@ void launch_fr_stl(mivi_ctx *c, const void *params, int M) {
   }
   if (c->cfg.dtype == MIVI_F32 && c->stl_CT.p && (want32 ? sh_mfma : sh_mfma16) <= 160 * 1024 && !old_stl) {
     FrArgs<float> a = fr_args<float>(c, params, M);
+    if (rhs) a.eps = (const float *)rhs;
+    if (out) a.W = (float *)out;
     const int nb = (c->cfg.d + 31) / 32;
     hipLaunchKernelGGL(k_stl_prep<float>, dim3(nb + nb * (nb + 1) / 2), dim3(256), 0, c->stream, c->cfg.d, c->dP,
                        (const float *)params + c->cfg.d, (float *)c->stl_CT.p, (float *)c->stl_Dinv.p);
@@ -1677,6 +1789,8 @@ void launch_fr_stl(mivi_ctx *c, const void *params, int M) {
   }
   if (c->cfg.dtype == MIVI_F32) {
     FrArgs<float> a = fr_args<float>(c, params, M);
+    if (rhs) a.eps = (const float *)rhs;
+    if (out) a.W = (float *)out;
     const size_t sh = (8 * (size_t)c->dP + 32 * 33) * sizeof(float);
     static size_t attr_f = 0;
     if (attr_f < sh) {
@@ -1686,6 +1800,8 @@ void launch_fr_stl(mivi_ctx *c, const void *params, int M) {
     hipLaunchKernelGGL(k_fr_stl<float>, dim3(nblk), dim3(256), sh, c->stream, a);
   } else {
     FrArgs<double> a = fr_args<double>(c, params, M);
+    if (rhs) a.eps = (const double *)rhs;
+    if (out) a.W = (double *)out;
     const size_t sh = (8 * (size_t)c->dP + 32 * 33) * sizeof(double);
     static size_t attr_d = 0;
     if (attr_d < sh) {

@@ -362,6 +362,50 @@ __global__ void k_dog_apply(int64_t n, T *params, const T *grad, const double *e
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     params[i] = (T)((double)params[i] - eta * (double)grad[i]);
 }
+// the same update with the operator (ClipScale) and the averager (PolynomialAveraging) of the iteration folded in --
+// one pass over the parameters instead of three launches; element for element the arithmetic of the separate kernels
+template <typename T>
+__global__ void k_dog_apply_fused(int64_t n, T *params, const T *grad, const double *eta_ptr, int d, int family, T clip_eps,
+                                  T *avg, double avg_eta, const long long *t_ptr, long long t_base) {
+  const double eta = *eta_ptr;
+  double wa = 0.0, wb = 0.0;
+  if (avg) {
+    const double t = (double)(t_base + (t_ptr ? *t_ptr : 0));
+    wa = (avg_eta + 1.0) / (t + avg_eta);
+    wb = 1.0 - wa;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    T x = (T)((double)params[i] - eta * (double)grad[i]);
+    if (clip_eps > T(0) && is_scale_diag(i, d, family)) x = clip_step(x, clip_eps);
+    params[i] = x;
+    if (avg) avg[i] = (T)(wa * (double)x + wb * (double)avg[i]);
+  }
+}
+
+// DoG / DoWG step with ClipScale and PolynomialAveraging folded into the apply pass (device-resident loop, large vectors).
+// Returns false when the caller has to launch the operator / averager itself (small vectors: single-workgroup kernel).
+bool launch_dog_update_fused(mivi_ctx *c, void *params, const void *grad, void *state, int kind, double clip_eps, void *avg,
+                             double avg_eta, const long long *t_ptr, long long t_base) {
+  const int64_t n = mivi_params_len(c);
+  if (!(n > 16384 && c->dog_part.p)) return false;
+  double *sc = (double *)((char *)state + mivi_dog_state_bytes(c) - 16);
+  const int nb = 512;
+  double *part = (double *)c->dog_part.p, *eta = part + 2 * nb;
+  if (c->cfg.dtype == MIVI_F32) {
+    hipLaunchKernelGGL(k_dog_norms<float>, dim3(nb), dim3(256), 0, c->stream, n, (const float *)params, (const float *)grad,
+                       (const float *)state, part);
+    hipLaunchKernelGGL(k_dog_eta, dim3(1), dim3(256), 0, c->stream, nb, part, sc, eta, kind);
+    hipLaunchKernelGGL(k_dog_apply_fused<float>, dim3(2048), dim3(256), 0, c->stream, n, (float *)params, (const float *)grad,
+                       eta, c->cfg.d, c->cfg.family, (float)clip_eps, (float *)avg, avg_eta, t_ptr, t_base);
+  } else {
+    hipLaunchKernelGGL(k_dog_norms<double>, dim3(nb), dim3(256), 0, c->stream, n, (const double *)params, (const double *)grad,
+                       (const double *)state, part);
+    hipLaunchKernelGGL(k_dog_eta, dim3(1), dim3(256), 0, c->stream, nb, part, sc, eta, kind);
+    hipLaunchKernelGGL(k_dog_apply_fused<double>, dim3(2048), dim3(256), 0, c->stream, n, (double *)params,
+                       (const double *)grad, eta, c->cfg.d, c->cfg.family, clip_eps, (double *)avg, avg_eta, t_ptr, t_base);
+  }
+  return true;
+}
 
 void launch_dog_update(mivi_ctx *c, void *params, const void *grad, void *state, int kind) {
   const int64_t n = mivi_params_len(c);

@@ -145,7 +145,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->dog_part, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->dog_part, &c->stein_A, &c->stein_g, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -409,7 +409,8 @@ static bool hetero_ok(const mivi_ctx *c, int want_grad) {
 
 // One estimate over M local samples. out.partials_mode selects final vs shard partials.
 static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs &rng, int M, int want_grad,
-                                  OutArgs out, Chain *ch = nullptr, const FusedUpdate *upd = nullptr) {
+                                  OutArgs out, Chain *ch = nullptr, const FusedUpdate *upd = nullptr,
+                                  bool stop_after_target = false) {
   if (c->target == TGT_NONE) return fail(c, MIVI_ERR_NO_TARGET, "no target set");
   mivi_status_t s = ensure_work(c, M);
   if (s) return s;
@@ -420,7 +421,7 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
   const int d = c->cfg.d, d4 = (d + 3) / 4;
   const bool chained = ch && ch->on && hetero_ok(c, want_grad) && !out.partials_mode;
   // single calls on the MFMA full-rank path: did the previous call's VJP kernel already generate this estimate's eps?
-  const bool spec = !chained && c->cfg.family == MIVI_FULLRANK && hetero_ok(c, want_grad);
+  const bool spec = !chained && c->cfg.family == MIVI_FULLRANK && hetero_ok(c, want_grad) && !stop_after_target;
   bool hit = false;
   int capturing = 0;
   unsigned long long cap_id = 0;
@@ -502,7 +503,7 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
       vin.ell = c->ell.p;
       vin.n_ell = M;
     }
-    if (want_grad) {
+    if (want_grad && !stop_after_target) {   // (the Stein estimator stops here: eps, W = grad log pi and the ell sums are ready)
       if (out.ent_kind == MIVI_ENT_STL || out.ent_kind == MIVI_ENT_STL_ZERO_GRAD) {
         const size_t sh = (8 * (size_t)c->dP + 32 * 33) * c->esize;
         if (sh > 160 * 1024 && !c->stl_CT.p) return fail(c, MIVI_ERR_UNSUPPORTED, "full-rank STL: d too large for the LDS-resident solve");
@@ -709,6 +710,71 @@ mivi_status_t mivi_estimate_objective_host(mivi_ctx_t *c, const void *params_h, 
   if (st) HIPCHK(c, hipMemset(c->status.p, 0, sizeof(int)));
   if (st & 2) return fail(c, MIVI_ERR_NONPOSITIVE_SCALE, "scale diagonal is not positive (use ClipScale)");
   return MIVI_OK;  // a non-finite value is returned as-is, like the reference's estimate_objective
+}
+
+// gaussian_expectation_gradient_and_hessian!, first-order branch (src/algorithms/gauss_expected_grad_hess.jl:32-60):
+//   u ~ N(0, I) (d x n), z = C u + m, per sample (logpi, g) from the target;  logpi_avg = mean logpi, grad = mean g,
+//   hess = C' \ mean(u g').  Same eps stream and sample/target kernels as the ELBO path; the extra work is the full
+//   eps G^T product (k_stein_outer) and one back substitution with d right-hand sides (the STL solve kernels).
+mivi_status_t mivi_gauss_expected_grad_hess(mivi_ctx_t *c, const void *params, uint64_t idx, int32_t n_samples,
+                                            void *logpi_avg, void *grad, void *hess) {
+  if (!c || !params || !logpi_avg || !grad || !hess) return MIVI_ERR_BAD_ARG;
+  if (c->cfg.family != MIVI_FULLRANK)
+    return fail(c, MIVI_ERR_UNSUPPORTED, "gauss_expected_grad_hess takes a triangular scale (full-rank family)");
+  if (n_samples <= 0) n_samples = c->cfg.n_mc;
+  (void)hipSetDevice(c->cfg.device);
+  const int d = c->cfg.d, dP = round_up(d, 64);
+  const size_t es = c->esize;
+  if ((8 * (size_t)dP + 32 * 33) * es > 160 * 1024 && ((size_t)dP * 16 + 8 * 8 * 64) * es > 160 * 1024)
+    return fail(c, MIVI_ERR_UNSUPPORTED, "gauss_expected_grad_hess: d too large for the LDS-resident solve");
+  mivi_status_t s;
+  if ((s = ensure(c, c->stein_A, (size_t)dP * dP * es, true)) || (s = ensure(c, c->stein_g, (size_t)(d + 8) * sizeof(double), true)) ||
+      (s = ensure(c, c->stl_CT, (size_t)dP * dP * es, true)) || (s = ensure(c, c->stl_Dinv, (size_t)((d + 31) / 32) * 1024 * es, false)))
+    return s;
+  const int CH = 16384;
+  char *part = (char *)c->tmp_out.p;   // [sum ell, sum 0.5 eps^2] of a chunk
+  for (int off = 0, first = 1; off < n_samples; off += CH, first = 0) {
+    const int Mc = n_samples - off < CH ? n_samples - off : CH;
+    OutArgs o = final_out(c, nullptr, nullptr);
+    o.partials = part;
+    o.partials_mode = 1;
+    o.scalars_off = 0;
+    o.ent_kind = MIVI_ENT_CLOSED_FORM;
+    o.M_total = Mc;
+    RngArgs r = rng_of(c, idx);
+    r.m_offset += off;
+    if ((s = run_estimate(c, params, r, Mc, 1, o, nullptr, nullptr, true))) return s;
+    if (c->cfg.dtype == MIVI_F32)
+      hipLaunchKernelGGL(k_acc_value_f32, dim3(1), dim3(1), 0, c->stream, (double *)c->acc.p, (const float *)part, 1.0, first);
+    else
+      hipLaunchKernelGGL(k_acc_value_f64, dim3(1), dim3(1), 0, c->stream, (double *)c->acc.p, (const double *)part, 1.0, first);
+    const bool last = off + CH >= n_samples;
+    launch_stein_outer(c, Mc, c->stein_A.p, (double *)c->stein_g.p, first, last ? 1.0 / (double)n_samples : 1.0);
+  }
+  launch_stein_finish(c, (double)n_samples, (const double *)c->stein_g.p, (const double *)c->acc.p, grad, logpi_avg);
+  HIPCHK(c, hipMemsetAsync(hess, 0, (size_t)d * d * es, c->stream));
+  launch_fr_stl(c, params, d, c->stein_A.p, hess);   // hess = C^-T (eps G^T / n)
+  HIPCHK(c, hipGetLastError());
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_gauss_expected_grad_hess_host(mivi_ctx_t *c, const void *params_h, uint64_t idx, int32_t n_samples,
+                                                 void *logpi_avg_h, void *grad_h, void *hess_h) {
+  if (!c || !params_h || !logpi_avg_h || !grad_h || !hess_h) return MIVI_ERR_BAD_ARG;
+  if (c->cfg.family != MIVI_FULLRANK)
+    return fail(c, MIVI_ERR_UNSUPPORTED, "gauss_expected_grad_hess takes a triangular scale (full-rank family)");
+  (void)hipSetDevice(c->cfg.device);
+  const size_t plen = (size_t)mivi_params_len(c), es = c->esize, d = (size_t)c->cfg.d;
+  HIPCHK(c, hipMemcpyAsync(c->tmp_params.p, params_h, plen * es, hipMemcpyHostToDevice, c->stream));
+  // the chunk partials use tmp_out[0..1]; results go behind them: [.., logpi (slot 2), grad (d), hess (d*d)] <= params_len + 16
+  char *o = (char *)c->tmp_out.p + 2 * 8;
+  mivi_status_t s = mivi_gauss_expected_grad_hess(c, c->tmp_params.p, idx, n_samples, o, o + 8, o + 8 + d * es);
+  if (s) return s;
+  HIPCHK(c, hipMemcpyAsync(logpi_avg_h, o, es, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(grad_h, o + 8, d * es, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(hess_h, o + 8 + d * es, d * d * es, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MIVI_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -928,6 +994,9 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
       // Optimisers.update! (common.jl:92); ClipScale rides in the Descent / Adam kernels
       if (rule == 0) launch_descent(c, params, gbuf, eta, clip_eps);
       else if (rule == 1) launch_adam(c, params, gbuf, opt_state, (const int64_t *)t_ptr, (int64_t)i + 1, eta, l.beta1, l.beta2, l.adam_eps, clip_eps);
+      else if (l.op <= 1 && launch_dog_update_fused(c, params, gbuf, opt_state, rule - 2, clip_eps,
+                                                     l.averager == 1 ? l.avg_params_dev : nullptr, l.avg_eta, t_ptr, (long long)i + 1))
+        continue;   // DoG / DoWG + ClipScale + averaging in one apply pass (large parameter vectors)
       else launch_dog_update(c, params, gbuf, opt_state, rule - 2);
       // operator (common.jl:93-95)
       if (l.op == 1 && rule >= 2) launch_clip(c, params, clip_eps);

@@ -245,6 +245,7 @@ struct mivi_ctx {
   int mf_nblk = 0;
   mivi::DevBuf Z, W, RT, ell, X;
   mivi::DevBuf row_part, status, d_idx, acc, tmp_params, tmp_out;
+  mivi::DevBuf stein_A, stein_g;   // Stein estimator: eps G^T accumulator (dP x dP, T) and the f64 column sums of G
   mivi::DevBuf dog_part;   // DoG / DoWG on large parameter vectors: 512 x 2 partial norms + the step size
   const uint64_t *idx_src = nullptr;   // mivi_set_index_source
   // speculative eps prefetch across single calls: the VJP kernel of estimate (seed, idx) also generates eps of
@@ -281,7 +282,9 @@ bool f64_valu();   // MIVI_F64_VALU=1: keep the f64 full-rank tiles on the vecto
 void prepare_tables(mivi_ctx *c, int M);   // build + upload the MFMA work tables (no-op for f64 / mean-field)
 void launch_fr_dense_target(mivi_ctx *c, int M, int want_grad);
 void launch_rt_from_z(mivi_ctx *c, int M);
-void launch_fr_stl(mivi_ctx *c, const void *params, int M);
+void launch_fr_stl(mivi_ctx *c, const void *params, int M, const void *rhs = nullptr, void *out = nullptr);
+void launch_stein_outer(mivi_ctx *c, int M, void *A, double *gsum, int first, double scale);
+void launch_stein_finish(mivi_ctx *c, double n, const double *gsum, const double *ell_sum, void *grad, void *logpi_avg);
 int fr_sample_blocks(const mivi_ctx *c, int M);
 int fr_dense_blocks(const mivi_ctx *c, int M);
 int eps_blocks(const mivi_ctx *c, int M);
@@ -297,6 +300,8 @@ void launch_finalize(mivi_ctx *c, const void *params, const void *partials, void
 void launch_prox(mivi_ctx *c, void *params, double stepsize, const void *dog_state, int dog_kind);
 void launch_poly_average(mivi_ctx *c, void *avg, const void *params, double avg_eta, const long long *t_ptr, long long t_base);
 void launch_dog_update(mivi_ctx *c, void *params, const void *grad, void *state, int kind);
+bool launch_dog_update_fused(mivi_ctx *c, void *params, const void *grad, void *state, int kind, double clip_eps, void *avg,
+                             double avg_eta, const long long *t_ptr, long long t_base);
 void launch_logreg_gather(mivi_ctx *c, int64_t b);   // batch rows lr_idx[0..b) of the full data set -> lr_Xsub / lr_ysub / lr_Xrm_sub
 void launch_value_only(mivi_ctx *c, const void *params, const ValueIn &vin, const OutArgs &out);   // on c->stream
 void launch_clip(mivi_ctx *c, void *params, double epsilon);

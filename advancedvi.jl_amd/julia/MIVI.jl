@@ -11,6 +11,7 @@
 module MIVI
 
 using AdvancedVI, ADTypes, DiffResults, LogDensityProblems, Optimisers, Random, LinearAlgebra
+using Distributions: Normal
 using AdvancedVI: MvLocationScale, RepGradELBO, ClosedFormEntropy, ClosedFormEntropyZeroGradient,
                   MonteCarloEntropy, StickingTheLandingEntropy, StickingTheLandingEntropyZeroGradient
 
@@ -147,8 +148,34 @@ function native_logreg!(state::MIVIState, m::NativeLogReg; variant::Int = 0, lik
     return state
 end
 
+# gaussian_expectation_gradient_and_hessian! (src/algorithms/gauss_expected_grad_hess.jl:20-60), the inner estimator of
+# KLMinWassFwdBwd / KLMinNaturalGradDescent / KLMinSqrtNaturalGradDescent.  That function has no `adtype` to dispatch on,
+# so the seam is the problem argument: wrap the target in `MIVITarget(prob, state)` (state from `AdvancedVI.init` above,
+# created for a full-rank `q`) and the more specific method below takes the Stein / Price branch on the GPU.
+struct MIVITarget{P}
+    prob::P
+    state::MIVIState
+end
+LogDensityProblems.dimension(t::MIVITarget) = LogDensityProblems.dimension(t.prob)
+LogDensityProblems.capabilities(::Type{<:MIVITarget}) = LogDensityProblems.LogDensityOrder{1}()
+LogDensityProblems.logdensity(t::MIVITarget, x) = LogDensityProblems.logdensity(t.prob, x)
+LogDensityProblems.logdensity_and_gradient(t::MIVITarget, x) = LogDensityProblems.logdensity_and_gradient(t.prob, x)
+
+function AdvancedVI.gaussian_expectation_gradient_and_hessian!(
+    rng::Random.AbstractRNG, q::MvLocationScale{<:LinearAlgebra.AbstractTriangular,<:Normal}, n_samples::Int,
+    grad_buf::AbstractVector{T}, hess_buf::AbstractMatrix{T}, t::MIVITarget) where {T<:Real}
+    st = t.state
+    params, _ = Optimisers.destructure(q)
+    logpi = Ref{T}(zero(T))
+    check(st.ctx, ccall((:mivi_gauss_expected_grad_hess_host, libmivi), Int32,
+                        (Ptr{Cvoid}, Ptr{T}, UInt64, Int32, Ref{T}, Ptr{T}, Ptr{T}),
+                        st.ctx, params, st.estimate_idx, n_samples, logpi, grad_buf, hess_buf))   # hess_buf: dense column-major
+    st.estimate_idx += 1
+    return logpi[], grad_buf, hess_buf
+end
+
 # ProximalLocationScaleEntropy on the host arrays works unchanged (src/optimization/proximal_location_scale_entropy.jl);
 # the device-resident variant for a parameter vector that lives in HBM is mivi_prox_scale_entropy.
 
-export AutoMIVI, NativeLogReg, native_logreg!
+export AutoMIVI, NativeLogReg, native_logreg!, MIVITarget
 end # module

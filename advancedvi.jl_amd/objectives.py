@@ -182,3 +182,27 @@ def rand(rng, q: MvLocationScale, num_samples: int, device: int = 0):
         return ctx.sample(params, rng.next_index(), want_eps=False).clone()
     finally:
         ctx.close()
+
+
+def gaussian_expectation_gradient_and_hessian_(rng, q: MvLocationScale, n_samples: int, grad_buf, hess_buf, prob,
+                                               adtype=None, _ctx=None):
+    """`gaussian_expectation_gradient_and_hessian!(rng, q, n_samples, grad_buf, hess_buf, prob)`:
+    src/algorithms/gauss_expected_grad_hess.jl:20-60, the Stein / Price-identity branch (what a target with
+    `logdensity_and_gradient` takes, :32-60).  `grad_buf` (d) / `hess_buf` (d*d, column-major) are device tensors
+    that are overwritten, or None to allocate.  Returns (logpi_avg: float, grad (d), hess (d, d)) -- `hess` is not
+    symmetrised, like the reference's.  Second-order targets take this same branch (there is no plugin Hessian ABI)."""
+    if not isinstance(q, MvLocationScale) or q.family != 1:
+        raise TypeError("gaussian_expectation_gradient_and_hessian_ expects a Gaussian with a triangular scale "
+                        "(gauss_expected_grad_hess.jl:22)")
+    ctx = _ctx
+    if ctx is None:
+        ctx = MiviContext(q.eltype, q.family, len(q), min(int(n_samples), 16384), 0, rng.seed,
+                          device=getattr(adtype, "device", 0))
+        ctx.set_problem(prob)
+    try:
+        params, _ = destructure(q)
+        logpi, g, H = ctx.gauss_expected_grad_hess(params, rng.next_index(), int(n_samples), grad_buf, hess_buf)
+        return float(logpi.item()), g, H
+    finally:
+        if _ctx is None:
+            ctx.close()

@@ -165,6 +165,21 @@ mivi_status_t mivi_estimate_objective(mivi_ctx_t *ctx, const void *params_dev, u
 mivi_status_t mivi_estimate_objective_host(mivi_ctx_t *ctx, const void *params_host, uint64_t estimate_idx,
                                            int32_t n_samples, int32_t entropy, void *value_host);
 
+/* gaussian_expectation_gradient_and_hessian!(rng, q, n_samples, grad_buf, hess_buf, prob), the first-order
+ * (Stein / Price identity) branch: src/algorithms/gauss_expected_grad_hess.jl:20-60 -- the inner estimator of
+ * KLMinWassFwdBwd / KLMinNaturalGradDescent / KLMinSqrtNaturalGradDescent (klminwassfwdbwd.jl:101,
+ * klminnaturalgraddescent.jl:120, klminsqrtnaturalgraddescent.jl:104).  Full-rank family only (the reference method
+ * takes a triangular scale).  With u = the eps stream of `estimate_idx` (d x n_samples) and z = C u + m:
+ *   logpi_avg_dev T[1]    <- mean_b logpi(z_b)
+ *   grad_dev      T[d]    <- mean_b grad logpi(z_b)
+ *   hess_dev      T[d*d]  <- C' \ mean_b(u_b grad logpi(z_b)')      column-major, NOT symmetrised (as the reference)
+ * n_samples <= 0 means cfg.n_mc; any n_samples is processed in chunks of 16384 columns.  Asynchronous for built-in
+ * targets.  The second-order branch (sample average of plugin Hessians, :61-83) has no counterpart here. */
+mivi_status_t mivi_gauss_expected_grad_hess(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx,
+                                            int32_t n_samples, void *logpi_avg_dev, void *grad_dev, void *hess_dev);
+mivi_status_t mivi_gauss_expected_grad_hess_host(mivi_ctx_t *ctx, const void *params_host, uint64_t estimate_idx,
+                                                 int32_t n_samples, void *logpi_avg_host, void *grad_host, void *hess_host);
+
 /* ---- multi-GPU: shard the MC batch, all-reduce the partials, finalize -------------------------- *
  * No counterpart in the reference (single task).  partials_dev: T[partials_len] un-normalised sums over
  * this context's samples; the caller all-reduces (RCCL sum) and calls mivi_finalize on every rank. */

@@ -309,6 +309,29 @@ def estimate_repgradelbo_forward(params, d, family, prob, eps, ent_kind, q_stop=
     return -(estimate_energy_with_samples(prob, samples) + ent)
 
 
+def gaussian_expectation_gradient_and_hessian(q: MvLocationScale, prob, u: np.ndarray):
+    """gaussian_expectation_gradient_and_hessian!, first-order (Stein / Price) branch:
+    src/algorithms/gauss_expected_grad_hess.jl:32-60.  `u` (d x n) are the standard-normal draws,
+    z = C u + m; per sample the loop accumulates logpi/n, grad/n and u * (grad/n)'; finally
+    hess = C' \ hess.  Returns (logpi_avg, grad (d), hess (d x d))."""
+    if q.is_meanfield:
+        raise TypeError("the reference method takes a triangular scale (gauss_expected_grad_hess.jl:22)")
+    d, n = u.shape
+    C = np.tril(q.scale)
+    z = C @ u + q.location[:, None]
+    logpi_avg = 0.0
+    grad = np.zeros(d)
+    hess = np.zeros((d, d))
+    for b in range(n):
+        lp, g = prob.logdensity_and_gradient(z[:, b])
+        logpi_avg += lp / n
+        g = np.asarray(g, dtype=np.float64) / n
+        grad += g
+        hess += np.outer(u[:, b], g)
+    hess = np.linalg.solve(C.T, hess)
+    return float(logpi_avg), grad, hess
+
+
 def c_inv_t_eps(q: MvLocationScale, eps: np.ndarray) -> np.ndarray:
     """C^{-T} eps == -grad_z log q_stop(z) at z = mu + C eps  (SURVEY.md section 3.4)."""
     if q.is_meanfield:

@@ -1,0 +1,120 @@
+"""`gaussian_expectation_gradient_and_hessian!` (Stein / Price branch, src/algorithms/gauss_expected_grad_hess.jl:32-60)
+through the C ABI vs the oracle on identical eps, plus the reference's own known-answer test
+(test/general/gauss_expected_grad_hess.jl:31-56).
+
+Tolerances (fp32 compute vs fp64 oracle): logpi_avg rel 1e-5, grad rel-L2 2e-5, hess rel-Frobenius 5e-5 (one extra
+triangular solve); f64: 1e-12 / 1e-11 / 1e-10."""
+import numpy as np
+import pytest
+
+import advancedvi_jl_amd as avi
+from oracle import oracle as O
+from tests.helpers import SEED, OraclePlugin, make_family, make_problem
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float32: (1e-5, 2e-5, 5e-5), np.float64: (1e-12, 1e-11, 1e-10)}
+
+
+def run_case(d, M, kind, dtype, n_samples=0, idx=5, plugin=False):
+    rng = np.random.default_rng(99 + d + 3 * M)
+    q, q_o = make_family(rng, d, avi.FULLRANK, dtype)
+    prob, tgt = make_problem(rng, kind, d, dtype)
+    if plugin:
+        prob = OraclePlugin(tgt)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(dtype, avi.FULLRANK, d, M, 0, SEED)
+    ctx.set_problem(prob)
+    n = n_samples or M
+    if n == M:
+        _, eps = ctx.sample(params, idx)
+        eps = eps.cpu().numpy().astype(np.float64)
+    else:       # chunked call: the host restatement of the stream (checked against the device in test_gpu_rng.py)
+        eps = O.philox_normal(SEED, idx, d, 0, n, f64=(dtype == np.float64))
+    logpi, g, H = ctx.gauss_expected_grad_hess(params, idx, n_samples)
+    logpi = float(logpi.item())
+    g = g.cpu().numpy().astype(np.float64)
+    H = H.cpu().numpy().astype(np.float64)
+    lp_ref, g_ref, H_ref = O.gaussian_expectation_gradient_and_hessian(q_o, tgt, eps)
+    tv, tg, th = TOL[dtype]
+    if n != M and dtype == np.float32:
+        tv, tg, th = 3 * tv, 3 * tg, 3 * th     # host-restated eps differs from the device's by a few ulp
+    assert abs(logpi - lp_ref) <= tv * max(abs(lp_ref), 1.0), (logpi, lp_ref)
+    assert np.linalg.norm(g - g_ref) <= tg * max(np.linalg.norm(g_ref), 1.0)
+    assert np.linalg.norm(H - H_ref) <= th * max(np.linalg.norm(H_ref), 1.0), np.linalg.norm(H - H_ref) / np.linalg.norm(H_ref)
+    ctx.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["diag", "dense", "logreg0", "logreg1", "funnel"])
+def test_targets(kind, dtype):
+    run_case(33, 17, kind, dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("d,M", [(1, 1), (2, 3), (31, 64), (32, 5), (64, 100), (65, 16), (130, 257)])
+def test_shapes(d, M, dtype):
+    run_case(d, M, "diag", dtype)
+    run_case(d, M, "dense", dtype)
+
+
+def test_plugin_callback_route():
+    run_case(12, 9, "logreg1", np.float64, plugin=True)
+    run_case(12, 9, "dense", np.float32, plugin=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_chunked_n_samples(dtype):
+    """n_samples larger than one chunk (16384 columns): chunks accumulate into the same estimate."""
+    run_case(6, 64, "dense", dtype, n_samples=16384 * 2 + 77)
+
+
+def test_repeatable_and_idx_dependent():
+    rng = np.random.default_rng(5)
+    q, _ = make_family(rng, 40, avi.FULLRANK, np.float32)
+    prob, _ = make_problem(rng, "dense", 40, np.float32)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, 40, 32, 0, SEED)
+    ctx.set_problem(prob)
+    a = [t.clone() for t in ctx.gauss_expected_grad_hess(params, 7)]
+    ctx.estimate_gradient(params, 3)                      # interleaved ELBO estimates do not disturb it
+    b = [t.clone() for t in ctx.gauss_expected_grad_hess(params, 7)]
+    c = ctx.gauss_expected_grad_hess(params, 8)
+    for x, y in zip(a, b):
+        assert (x == y).all()
+    assert not (a[2] == c[2]).all()
+    ctx.close()
+
+
+def test_meanfield_rejected():
+    ctx = avi.MiviContext(np.float32, avi.MEANFIELD, 8, 4, 0, SEED)
+    ctx.set_problem(avi.DiagNormalProblem(np.zeros(8, np.float32), np.ones(8, np.float32)))
+    with pytest.raises(avi.MiviError):
+        ctx.gauss_expected_grad_hess(np.concatenate([np.zeros(8), np.ones(8)]).astype(np.float32), 0)
+    ctx.close()
+    with pytest.raises(TypeError):
+        avi.gaussian_expectation_gradient_and_hessian_(avi.PhiloxRNG(1), avi.MeanFieldGaussian(np.zeros(2), np.ones(2)), 10,
+                                                       None, None, avi.DiagNormalProblem(np.zeros(2), np.ones(2)))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_reference_known_answer(dtype):
+    """test/general/gauss_expected_grad_hess.jl:31-56: logpi(x) = -x' S x / 2 (here: a zero-mean Gaussian with precision
+    S, same gradient), q = N(1, 0.1^2 I), n = 10^6: E grad = -S mu, E hess = -S, atol 1e-1."""
+    S = np.array([[2.0, -0.1], [-0.1, 2.0]])
+    prob = avi.DenseNormalProblem(np.zeros(2, dtype), np.linalg.cholesky(np.linalg.inv(S)).astype(dtype))
+    q = avi.FullRankGaussian(np.ones(2, dtype), np.diag(np.full(2, 0.1)).astype(dtype))
+    lp, g, H = avi.gaussian_expectation_gradient_and_hessian_(avi.PhiloxRNG(), q, 10**6, None, None, prob)
+    assert np.allclose(g.cpu().numpy(), -S @ np.ones(2), atol=1e-1)
+    assert np.allclose(H.cpu().numpy(), -S, atol=1e-1)
+    assert np.isfinite(lp)
+
+
+def test_north_star_size():
+    run_case(1024, 256, "diag", np.float32)
+    run_case(512, 128, "dense", np.float64)
+
+
+def test_beyond_the_mfma_solve():
+    """d > 2304 (f32): the blocked MFMA solve no longer fits LDS; the column-block fallback takes over."""
+    run_case(2400, 8, "diag", np.float32)

@@ -223,3 +223,26 @@ def test_stepsize_from_optimizer_state():
     assert np.isclose(O.stepsize_from_optimizer_state("dowg", v=4.0, r=3.0), 4.5)
     with pytest.raises(ValueError):
         O.stepsize_from_optimizer_state("adam")
+
+
+def test_gaussian_expectation_gradient_and_hessian_known_answer():
+    """test/general/gauss_expected_grad_hess.jl:31-56 (first-order capability): logpi(x) = -x' S x / 2,
+    q = N(1, 0.1^2 I): E grad = -S mu, E hess = -S, atol 1e-1 (n = 10^6 there; 2*10^5 of the fixed Philox stream here)."""
+    class TestQuad:
+        def __init__(self, S):
+            self.S = S
+
+        def logdensity_and_gradient(self, x):
+            return float(-x @ self.S @ x / 2), -self.S @ x
+
+    S = np.array([[2.0, -0.1], [-0.1, 2.0]])
+    q = O.MvLocationScale(np.ones(2), np.diag([0.1, 0.1]))
+    u = O.philox_normal(SEED, 0, 2, 0, 200000, f64=True)
+    lp, g, H = O.gaussian_expectation_gradient_and_hessian(q, TestQuad(S), u)
+    assert np.allclose(g, -S @ np.ones(2), atol=1e-1)
+    assert np.allclose(H, -S, atol=1e-1)
+    # exact identity behind the estimator: for a quadratic target, C' \ mean(u g') = -(C' \ mean(u z')) S
+    z = np.tril(q.scale) @ u + q.location[:, None]
+    assert np.allclose(H, -np.linalg.solve(np.tril(q.scale).T, (u @ z.T) / u.shape[1]) @ S, rtol=1e-10)
+    with pytest.raises(TypeError):
+        O.gaussian_expectation_gradient_and_hessian(O.MvLocationScale(np.ones(2), np.ones(2)), TestQuad(S), u)
