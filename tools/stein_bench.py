@@ -2,11 +2,14 @@
 from a rocprofv3 run if wanted (tools/profile_round.sh style), here simply hipEvent-free wall clock over many calls."""
 import sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch
 import advancedvi_jl_amd as avi
 
-for d, M, kind in [(1024, 256, "diag"), (1024, 256, "dense"), (512, 128, "diag"), (2048, 256, "diag")]:
+CASES = [(1024, 256, "diag"), (1024, 256, "dense"), (512, 128, "diag"), (2048, 256, "diag")]
+if len(sys.argv) > 1 and sys.argv[1] == "ns":
+    CASES = CASES[:1]
+for d, M, kind in CASES:
     rng = np.random.default_rng(0)
     q = avi.FullRankGaussian(np.zeros(d, np.float32), np.eye(d, dtype=np.float32))
     if kind == "diag":
