@@ -229,6 +229,7 @@ struct MfLoopArgs {
   long long t0;                 // Adam step count before this call
   double eta, clip_eps, b1, b2, adam_eps;
   double *hist;                 // [n_steps][4][nblk]
+  T *grad_out;                  // rule < 0 (estimates at fixed parameters): gradient of the LAST estimate
 };
 
 template <typename T>
@@ -335,9 +336,13 @@ __global__ __launch_bounds__(256) void k_mf_sgd_loop(MfLoopArgs<T> a) {
       const T sgv = (myrow & 3) == 0 ? sg[0] : (myrow & 3) == 1 ? sg[1] : (myrow & 3) == 2 ? sg[2] : sg[3];
       const double tr = tot[myrow];
       const T g = (myrow < 4) ? (T)(-tr * invM) : (T)(-tr * invM - direct / (double)sgv);
-      if (rule == 0) mine = descent_step(mine, g, eta);
-      else mine = adam_step<T>(mine, g, st_m, st_v, cc[0], cc[1], eta, b1, b2, aeps);
-      if (clip && myrow >= 4) mine = clip_step(mine, ceps);
+      if (rule < 0) {   // estimates only: parameters stay, the last estimate's gradient is the result
+        if (t == n_steps - 1 && tid < 8 && 4 * rq + (myrow & 3) < d) a.grad_out[(myrow < 4 ? 0 : d) + myi] = g;
+      } else {
+        if (rule == 0) mine = descent_step(mine, g, eta);
+        else mine = adam_step<T>(mine, g, st_m, st_v, cc[0], cc[1], eta, b1, b2, aeps);
+        if (clip && myrow >= 4) mine = clip_step(mine, ceps);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(256) void k_mf_sgd_loop(MfLoopArgs<T> a) {
     }
     lds_barrier();   // tot / xw are reused by the next iteration
   }
-  if (tid < 8) {
+  if (tid < 8 && rule >= 0) {
     const int i = 4 * rq + (tid & 3);
     if (i < d) {
       const T val = (tid < 4) ? mu[tid & 3] : sg[tid & 3];
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(256) void k_mf_loop_value(int d, int nblk, int M_lo
 
 template <typename T>
 static void mf_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule,
-                             double eta, double clip_eps, double *hist, double *elbo) {
+                             double eta, double clip_eps, double *hist, double *elbo, void *grad_out) {
   MfLoopArgs<T> a;
   a.d = c->cfg.d;
   a.M = c->cfg.n_mc;
@@ -405,16 +410,19 @@ static void mf_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint64_
   a.b2 = 0.999;
   a.adam_eps = 1e-8;
   a.hist = hist;
+  a.grad_out = (T *)grad_out;
   const int d4 = (a.d + 3) / 4;
   hipLaunchKernelGGL(k_mf_sgd_loop<T>, dim3(d4), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_mf_loop_value<T>, dim3(n_steps), dim3(256), 0, c->stream, a.d, d4, a.M, a.M_total, a.ent_kind,
                      c->t_const, (const double *)hist, elbo, (int *)c->status.p);
 }
 
+// rule 0 Descent / 1 Adam: n_steps SGD iterations;  rule -1: n_steps estimates at fixed parameters, the last one's gradient
+// into grad_out (what mivi_estimate_gradient_n returns).  elbo[t] of every step / estimate either way.
 void launch_mf_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule,
-                        double eta, double clip_eps, double *hist, double *elbo) {
-  if (c->cfg.dtype == MIVI_F32) mf_sgd_loop_impl<float>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo);
-  else mf_sgd_loop_impl<double>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo);
+                        double eta, double clip_eps, double *hist, double *elbo, void *grad_out) {
+  if (c->cfg.dtype == MIVI_F32) mf_sgd_loop_impl<float>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo, grad_out);
+  else mf_sgd_loop_impl<double>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo, grad_out);
 }
 
 // rand(rng, q::MvLocationScale{<:Diagonal}, M): Z = mu + sigma .* eps  (location_scale.jl:80-87)

@@ -650,6 +650,8 @@ mivi_status_t mivi_finalize(mivi_ctx_t *c, const void *params, const void *parti
 // weighted accumulation of chunk objective values
 __global__ void k_acc_value_f32(double *acc, const float *v, double w, int first) { acc[0] = (first ? 0.0 : acc[0]) + w * (double)v[0]; }
 __global__ void k_acc_value_f64(double *acc, const double *v, double w, int first) { acc[0] = (first ? 0.0 : acc[0]) + w * v[0]; }
+__global__ void k_neg_value_f32(float *out, const double *elbo) { out[0] = (float)(-elbo[0]); }
+__global__ void k_neg_value_f64(double *out, const double *elbo) { out[0] = -elbo[0]; }
 __global__ void k_store_value_f32(float *out, const double *acc) { out[0] = (float)acc[0]; }
 __global__ void k_store_value_f64(double *out, const double *acc) { out[0] = acc[0]; }
 
@@ -815,6 +817,19 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
   if (s) return s;
   prepare_tables(c, c->cfg.n_mc);   // host->device uploads are not allowed inside the capture
   if ((s = reserve_target(c, c->cfg.n_mc))) return s;
+  static const bool no_fused_loop_n = getenv("MIVI_NO_FUSED_LOOP") != nullptr;
+  if (c->cfg.family == MIVI_MEANFIELD && c->target == TGT_DIAG_GAUSS && c->cfg.n_mc <= 4096 && !c->idx_src && !no_fused_loop_n) {
+    // rows are independent for this family / target pair: all `count` estimates run inside ONE launch (every workgroup
+    // keeps its four rows and walks the estimate indices), the value partials are reduced by a second launch
+    const size_t hist_doubles = (size_t)count * 4 * (size_t)((c->cfg.d + 3) / 4);
+    if ((s = ensure(c, c->X, ((size_t)count + hist_doubles + 8) * sizeof(double), false))) return s;
+    double *rec = (double *)c->X.p;
+    launch_mf_sgd_loop(c, const_cast<void *>(params), nullptr, idx0, 0, count, -1, 0.0, 0.0, rec + count, rec, grad);
+    if (c->cfg.dtype == MIVI_F32) hipLaunchKernelGGL(k_neg_value_f32, dim3(1), dim3(1), 0, c->stream, (float *)value, rec + count - 1);
+    else hipLaunchKernelGGL(k_neg_value_f64, dim3(1), dim3(1), 0, c->stream, (double *)value, rec + count - 1);
+    HIPCHK(c, hipGetLastError());
+    return MIVI_OK;
+  }
   GraphCache &g = c->graph;
   if (!(g.exec && g.kind == 1 && g.count == count && g.params == params && g.value == value && g.grad == grad)) {
     invalidate_graph(c);
@@ -1036,7 +1051,7 @@ mivi_status_t mivi_debug_timeline(mivi_ctx_t *c, void *buf) {
 }
 
 mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *params, int32_t reps, double *ms_out) {
-  if (!c || !params || reps <= 0 || !ms_out || which < 0 || which > 4) return MIVI_ERR_BAD_ARG;
+  if (!c || !params || reps <= 0 || !ms_out || which < 0 || which > 5) return MIVI_ERR_BAD_ARG;
   (void)hipSetDevice(c->cfg.device);
   const int M = c->cfg.n_mc;
   char *o = (char *)c->tmp_out.p;
@@ -1051,7 +1066,10 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
   vin.ell_const = c->t_const;
   const bool fr = c->cfg.family == MIVI_FULLRANK;
   c->cur = 0;
-  if (which != 0) {
+  if (which == 5) {   // the launch-free loop of 100 estimates (mean-field + diagonal target): one launch per rep
+    if (fr || c->target != TGT_DIAG_GAUSS || M > 4096) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 5: mean-field + diagonal-Gaussian target");
+    if ((s = ensure(c, c->X, ((size_t)100 + 400 * (size_t)((c->cfg.d + 3) / 4) + 8) * sizeof(double), false))) return s;
+  } else if (which != 0) {
     if (!fr && which != 2) return fail(c, MIVI_ERR_UNSUPPORTED, "mean-field has a single fused kernel (which = 2)");
     if (which == 4 && c->target != TGT_DENSE_GAUSS) return fail(c, MIVI_ERR_UNSUPPORTED, "no dense target set");
     if (which == 2 && c->target != TGT_DIAG_GAUSS && c->target != TGT_DENSE_GAUSS)
@@ -1070,6 +1088,10 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
         else launch_mf_main(c, params, rng, M, 1, nullptr, vin, out);
         break;
       case 3: launch_fr_vjp(c, params, M, out); break;
+      case 5:
+        launch_mf_sgd_loop(c, const_cast<void *>(params), nullptr, (uint64_t)r * 100, 0, 100, -1, 0.0, 0.0, (double *)c->X.p + 100,
+                           (double *)c->X.p, o + 8);
+        break;
       default: launch_fr_dense_target(c, M, 1); break;
     }
     if (s) break;

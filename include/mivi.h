@@ -153,7 +153,8 @@ mivi_status_t mivi_estimate_gradient(mivi_ctx_t *ctx, const void *params_dev, ui
 mivi_status_t mivi_estimate_gradient_host(mivi_ctx_t *ctx, const void *params_host, uint64_t estimate_idx,
                                           void *value_host, void *grad_host);
 /* `count` consecutive estimates estimate_idx0 .. estimate_idx0+count-1 of the same params replayed as ONE
- * hipGraph launch; value/grad hold the LAST estimate on return.  Built-in targets only. */
+ * hipGraph launch; value/grad hold the LAST estimate on return.  Built-in targets only.  Mean-field family with the
+ * diagonal-Gaussian target (rows independent): all `count` estimates run inside one launch-free kernel instead. */
 mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx0,
                                        int32_t count, void *value_dev, void *grad_dev);
 
@@ -247,7 +248,8 @@ mivi_status_t mivi_set_index_source(mivi_ctx_t *ctx, const uint64_t *idx_dev);
  * Times `reps` back-to-back launches of ONE stage of the estimate with hipEvents recorded on the context's
  * stream (after one full warm estimate so every input buffer is populated).
  *   which: 0 = whole estimate, 1 = eps generation, 2 = sample(+fused target) kernel (mean-field: the fused main kernel),
- *          3 = VJP kernel, 4 = dense-target kernel.  ms_per_launch_host: double[1]. */
+ *          3 = VJP kernel, 4 = dense-target kernel, 5 = the launch-free loop of 100 estimates (mean-field + diagonal
+ *          target; what mivi_estimate_gradient_n runs there).  ms_per_launch_host: double[1]. */
 mivi_status_t mivi_profile_kernel(mivi_ctx_t *ctx, int32_t which, const void *params_dev, int32_t reps,
                                   double *ms_per_launch_host);
 
