@@ -836,25 +836,28 @@ __global__ __launch_bounds__(512) void k_lr_xtr_bf16x3(LrMfmaArgs a) {
   const int wm = w >> 2, wk = w & 3;
   const int mbase = blockIdx.z * 128, kbase = blockIdx.y * 256;
   const int m0 = mbase + wm * 64, k0 = kbase + wk * 64;
+  // R and Xrm carry zero rows up to the next multiple of 16 (logreg_mfma / logreg_prepare_f32), so every 16-row stage
+  // is whole: no per-row clamps or masks, and an address is one uniform stage base (SALU) + a per-lane offset that never
+  // changes (the 64-bit per-load address arithmetic this replaces was 100 of the 266 VALU instructions of a stage)
   const long long rbeg = (long long)blockIdx.x * a.rows_per_split;
-  const long long rend = min(a.n, rbeg + a.rows_per_split);
+  const long long rend = min((a.n + 15) / 16 * 16, rbeg + a.rows_per_split);
   const int ldr = a.ldr, ldx = a.ldx;
-  const int nst = (int)((rend - rbeg + 15) / 16);
+  const int nst = (int)((rend - rbeg) / 16);
   // strips: R  sample tid & 127, rows 4*(tid >> 7) .. +3;  X  feature tid & 255, rows 4*q .. +3 for q = tid >> 8 and q + 2
   const int rm = tid & 127, rrg = tid >> 7;
   const int xf = tid & 255, xrg = tid >> 8;
   const int rcol = min(mbase + rm, ldr - 1), xcol = min(kbase + xf, ldx - 1);
+  const float *Rb = a.R + (size_t)rbeg * ldr, *Xb = a.Xrm + (size_t)rbeg * ldx;
+  const int roff = 4 * rrg * ldr + rcol, xoff = 4 * xrg * ldx + xcol;
   struct G { float r[4], x0[4], x1[4]; };
   auto gload = [&](int st, G &g) {
     st = min(st, nst - 1);
-    const long long rb = rbeg + 16LL * st;
+    const float *rs = Rb + (size_t)st * 16 * ldr, *xs = Xb + (size_t)st * 16 * ldx;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long rr = rb + 4 * rrg + i, rx0 = rb + 4 * xrg + i, rx1 = rx0 + 8;
-      const float rv = a.R[(size_t)min(rr, rend - 1) * ldr + rcol];
-      g.r[i] = rr < rend ? rv : 0.f;                                   // rows past the split contribute nothing
-      g.x0[i] = a.Xrm[(size_t)min(rx0, rend - 1) * ldx + xcol];
-      g.x1[i] = a.Xrm[(size_t)min(rx1, rend - 1) * ldx + xcol];
+      g.r[i] = (rs + i * ldr)[roff];
+      g.x0[i] = (xs + i * ldx)[xoff];
+      g.x1[i] = (xs + (8 + i) * ldx)[xoff];
     }
   };
   auto lstore = [&](int slot, const G &g) {
@@ -983,8 +986,12 @@ bool logreg_prepare_f32(mivi_ctx *c) {
   // builds Xrm in c->lr_Xrm (called by mivi_set_target_logreg for MIVI_F32)
   const int p = c->cfg.d - 1;
   const int ldx = (p + 31) / 32 * 32;
-  const size_t bytes = (size_t)c->lr_n * ldx * sizeof(float);
+  const size_t n16 = ((size_t)c->lr_n + 15) / 16 * 16;   // zero rows up to a whole 16-row stage (k_lr_xtr_bf16x3)
+  const size_t bytes = n16 * ldx * sizeof(float);
   if (!grow(c->lr_Xrm, bytes)) return false;
+  if (n16 > (size_t)c->lr_n &&
+      hipMemsetAsync((float *)c->lr_Xrm.p + (size_t)c->lr_n * ldx, 0, (n16 - (size_t)c->lr_n) * ldx * sizeof(float), c->stream) != hipSuccess)
+    return false;
   dim3 grid((unsigned)((c->lr_n + 63) / 64), (ldx + 63) / 64);
   hipLaunchKernelGGL(k_lr_make_xrm, grid, dim3(256), 0, c->stream, (long long)c->lr_n, p, ldx, (const float *)c->lr_X,
                      (float *)c->lr_Xrm.p);
@@ -1003,10 +1010,10 @@ __global__ void k_lr_gather_cm(long long n, long long b, int p, const long long 
   if (k == 0) ys[j] = y[r];
 }
 __global__ void k_lr_gather_rm(long long b, int ldx, const long long *idx, const float *Xrm, float *Xs) {
-  const long long j = blockIdx.x;
-  const float4 *src = (const float4 *)(Xrm + (size_t)idx[j] * ldx);
+  const long long j = blockIdx.x;   // rows b .. gridDim.x-1: the zero padding up to a whole 16-row stage
+  const float4 *src = (const float4 *)(Xrm + (size_t)(j < b ? idx[j] : 0) * ldx);
   float4 *dst = (float4 *)(Xs + (size_t)j * ldx);
-  for (int t = threadIdx.x; t < ldx / 4; t += 128) dst[t] = src[t];
+  for (int t = threadIdx.x; t < ldx / 4; t += 128) dst[t] = j < b ? src[t] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 void launch_logreg_gather(mivi_ctx *c, int64_t b) {
   const int p = c->cfg.d - 1;
@@ -1016,7 +1023,7 @@ void launch_logreg_gather(mivi_ctx *c, int64_t b) {
     hipLaunchKernelGGL(k_lr_gather_cm<float>, g, dim3(256), 0, c->stream, (long long)c->lr_n_full, (long long)b, p, idx,
                        (const float *)c->lr_X_full, c->lr_y_full, (float *)c->lr_Xsub.p, (uint8_t *)c->lr_ysub.p);
     const int ldx = (p + 31) / 32 * 32;
-    hipLaunchKernelGGL(k_lr_gather_rm, dim3((unsigned)b), dim3(128), 0, c->stream, (long long)b, ldx, idx,
+    hipLaunchKernelGGL(k_lr_gather_rm, dim3((unsigned)((b + 15) / 16 * 16)), dim3(128), 0, c->stream, (long long)b, ldx, idx,
                        (const float *)c->lr_Xrm.p, (float *)c->lr_Xrm_sub.p);
   } else {
     hipLaunchKernelGGL(k_lr_gather_cm<double>, g, dim3(256), 0, c->stream, (long long)c->lr_n_full, (long long)b, p, idx,
@@ -1050,7 +1057,7 @@ static LrGeom lr_geom(const mivi_ctx *c, int M) {
     rps = (rps + 15) / 16 * 16;
     g.S = (int)((n + rps - 1) / rps);
     g.rps = rps;
-    g.need_R = ((size_t)n * g.ldr * sizeof(float) + 255) / 256 * 256;
+    g.need_R = ((size_t)((n + 15) / 16 * 16) * g.ldr * sizeof(float) + 255) / 256 * 256;   // + zero rows to a whole stage
     g.need_g = (size_t)g.S * p * M * sizeof(float);
     g.need_ll = (size_t)g.nrb * M * sizeof(double);
   } else {
@@ -1109,6 +1116,8 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
     hipLaunchKernelGGL(k_lr_logits_bf16x3, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
   else
     hipLaunchKernelGGL(k_lr_logits_mfma_lds, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
+  if (want_grad && a.n % 16 != 0)   // the zero residual rows k_lr_xtr_bf16x3's last stage reads (the logits kernels stop at n)
+    (void)hipMemsetAsync(a.R + (size_t)a.n * a.ldr, 0, (size_t)(16 - a.n % 16) * a.ldr * sizeof(float), c->stream);
   if (want_grad) {
     const dim3 gx(S, (a.p + 255) / 256, (M + 127) / 128);
     static const bool xtr_f32 = getenv("MIVI_LR_F32_XTR") != nullptr;   // A/B: f32 MFMA X^T R

@@ -310,7 +310,7 @@ mivi_status_t mivi_logreg_select_rows(mivi_ctx_t *c, const int64_t *idx, int64_t
   if ((s = ensure(c, c->lr_idx, (size_t)b * sizeof(int64_t), false)) ||
       (s = ensure(c, c->lr_Xsub, (size_t)b * p * c->esize, false)) || (s = ensure(c, c->lr_ysub, (size_t)b, false)))
     return s;
-  if (c->cfg.dtype == MIVI_F32 && (s = ensure(c, c->lr_Xrm_sub, (size_t)b * ((p + 31) / 32 * 32) * sizeof(float), false))) return s;
+  if (c->cfg.dtype == MIVI_F32 && (s = ensure(c, c->lr_Xrm_sub, (size_t)((b + 15) / 16 * 16) * ((p + 31) / 32 * 32) * sizeof(float), false))) return s;
   // the previous estimate may still be reading the batch buffers: order the upload behind it
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->lr_idx.p, idx, (size_t)b * sizeof(int64_t), hipMemcpyHostToDevice));
