@@ -827,14 +827,20 @@ __device__ __forceinline__ void lr_split3s(const float (&v)[4], lr_bf16x4 &hi, l
   }
 }
 
-__global__ __launch_bounds__(512) void k_lr_xtr_bf16x3(LrMfmaArgs a) {
+// NWK = waves along the feature axis: 4 -> 256-feature tile, 512 threads, one workgroup per CU (91 KB of LDS);
+// 2 -> 128-feature tile, 256 threads, 61 KB: two workgroups per CU that are not in barrier lock-step with each other (R is
+// then read by four feature groups instead of two).  Measured at C3: 880 us against 790 us for NWK = 4, which stays the
+// default; MIVI_LR_XTR_NARROW=1 selects NWK = 2.
+template <int NWK>
+__global__ __launch_bounds__(128 * NWK) void k_lr_xtr_bf16x3(LrMfmaArgs a) {
+  constexpr int NT = 128 * NWK, KT = 64 * NWK, RN = 4 / NWK;   // threads, features per tile, R strips per thread
   constexpr int CS = 20;   // column stride in bf16 (40 bytes)
   __shared__ __attribute__((aligned(16))) __bf16 Rs[2][3][128 * CS];   // [slot][piece][sample][16 rows]
-  __shared__ __attribute__((aligned(16))) __bf16 Xs[2][3][256 * CS];   // [slot][piece][feature][16 rows]
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[2][3][KT * CS];   // [slot][piece][feature][16 rows]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w >> 2, wk = w & 3;
-  const int mbase = blockIdx.z * 128, kbase = blockIdx.y * 256;
+  const int wm = w / NWK, wk = w % NWK;
+  const int mbase = blockIdx.z * 128, kbase = blockIdx.y * KT;
   const int m0 = mbase + wm * 64, k0 = kbase + wk * 64;
   // R and Xrm carry zero rows up to the next multiple of 16 (logreg_mfma / logreg_prepare_f32), so every 16-row stage
   // is whole: no per-row clamps or masks, and an address is one uniform stage base (SALU) + a per-lane offset that never
@@ -843,29 +849,34 @@ __global__ __launch_bounds__(512) void k_lr_xtr_bf16x3(LrMfmaArgs a) {
   const long long rend = min((a.n + 15) / 16 * 16, rbeg + a.rows_per_split);
   const int ldr = a.ldr, ldx = a.ldx;
   const int nst = (int)((rend - rbeg) / 16);
-  // strips: R  sample tid & 127, rows 4*(tid >> 7) .. +3;  X  feature tid & 255, rows 4*q .. +3 for q = tid >> 8 and q + 2
+  // strips (4 rows x 1 column per load group): R  sample tid & 127, row groups tid >> 7 (+ NT/128 per extra strip);
+  // X  feature tid % KT, row groups q = tid / KT and q + 2
   const int rm = tid & 127, rrg = tid >> 7;
-  const int xf = tid & 255, xrg = tid >> 8;
+  const int xf = tid % KT, xrg = tid / KT;
   const int rcol = min(mbase + rm, ldr - 1), xcol = min(kbase + xf, ldx - 1);
   const float *Rb = a.R + (size_t)rbeg * ldr, *Xb = a.Xrm + (size_t)rbeg * ldx;
   const int roff = 4 * rrg * ldr + rcol, xoff = 4 * xrg * ldx + xcol;
-  struct G { float r[4], x0[4], x1[4]; };
+  struct G { float r[RN][4], x0[4], x1[4]; };
   auto gload = [&](int st, G &g) {
     st = min(st, nst - 1);
     const float *rs = Rb + (size_t)st * 16 * ldr, *xs = Xb + (size_t)st * 16 * ldx;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      g.r[i] = (rs + i * ldr)[roff];
+#pragma unroll
+      for (int u = 0; u < RN; ++u) g.r[u][i] = (rs + (4 * u * (NT / 128) + i) * ldr)[roff];
       g.x0[i] = (xs + i * ldx)[xoff];
       g.x1[i] = (xs + (8 + i) * ldx)[xoff];
     }
   };
   auto lstore = [&](int slot, const G &g) {
     lr_bf16x4 p0, p1, p2;
-    lr_split3s(g.r, p0, p1, p2);
-    *(lr_bf16x4 *)&Rs[slot][0][rm * CS + 4 * rrg] = p0;
-    *(lr_bf16x4 *)&Rs[slot][1][rm * CS + 4 * rrg] = p1;
-    *(lr_bf16x4 *)&Rs[slot][2][rm * CS + 4 * rrg] = p2;
+#pragma unroll
+    for (int u = 0; u < RN; ++u) {
+      lr_split3s(g.r[u], p0, p1, p2);
+      *(lr_bf16x4 *)&Rs[slot][0][rm * CS + 4 * (rrg + u * (NT / 128))] = p0;
+      *(lr_bf16x4 *)&Rs[slot][1][rm * CS + 4 * (rrg + u * (NT / 128))] = p1;
+      *(lr_bf16x4 *)&Rs[slot][2][rm * CS + 4 * (rrg + u * (NT / 128))] = p2;
+    }
     lr_split3s(g.x0, p0, p1, p2);
     *(lr_bf16x4 *)&Xs[slot][0][xf * CS + 4 * xrg] = p0;
     *(lr_bf16x4 *)&Xs[slot][1][xf * CS + 4 * xrg] = p1;
@@ -1122,7 +1133,11 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
     const dim3 gx(S, (a.p + 255) / 256, (M + 127) / 128);
     static const bool xtr_f32 = getenv("MIVI_LR_F32_XTR") != nullptr;   // A/B: f32 MFMA X^T R
     if (gen1) hipLaunchKernelGGL(k_lr_xtr_mfma, gx, dim3(512), 0, c->stream, a);
-    else if (!xtr_f32) hipLaunchKernelGGL(k_lr_xtr_bf16x3, gx, dim3(512), 0, c->stream, a);
+    else if (!xtr_f32) {
+      static const bool narrow = getenv("MIVI_LR_XTR_NARROW") != nullptr;   // A/B: two 4-wave workgroups per CU (measured slower)
+      if (!narrow) hipLaunchKernelGGL(k_lr_xtr_bf16x3<4>, gx, dim3(512), 0, c->stream, a);
+      else hipLaunchKernelGGL(k_lr_xtr_bf16x3<2>, dim3(S, (a.p + 127) / 128, (M + 127) / 128), dim3(256), 0, c->stream, a);
+    }
     else hipLaunchKernelGGL(k_lr_xtr_mfma_lds, gx, dim3(512), 0, c->stream, a);
   }
   if (want_grad && S > 1) {
