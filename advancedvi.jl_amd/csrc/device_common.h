@@ -162,7 +162,7 @@ __device__ double funnel_finish(int d, const FunnelFin &f, const OutArgs &out, d
 //   closed-form estimators: d/2 (1 + log 2pi) + sum_i log C_ii            location_scale.jl:52-57
 //   MC / STL estimators   : mean_m 0.5|eps_m|^2 + d/2 log 2pi + sum_i log C_ii   (C^-1 (z_m - mu) == eps_m)
 // `scale_diag(i)` returns C_ii. `red` holds NT/64 doubles.
-// FUNNEL: also finish the fused funnel target (funnel_finish).  Only k_value_only instantiates it: inlined into the
+// FUNNEL: also finish the fused funnel target (funnel_finish).  Only k_value_funnel instantiates it: inlined into the
 // big kernels it raised their register count (VJP tile kernel 104 -> 162 VGPRs, occupancy 3 -> 2, +1.2 us) for a path
 // they never take.
 template <typename T, int NT, bool ATOMIC, bool FUNNEL = false, typename DiagFn>

@@ -94,10 +94,25 @@ __global__ __launch_bounds__(256) void k_value_only(int d, int family, const T *
   __shared__ double red[4];
   const int64_t plen = family == MIVI_MEANFIELD ? 2 * (int64_t)d : (int64_t)d + (int64_t)d * d;
   const int fam = family;
-  finalize_value_block<T, 256, false, true>(d, vin, out, plen,
+  finalize_value_block<T, 256, false, false>(d, vin, out, plen,
       [params, d, fam](int i) { return fam == MIVI_MEANFIELD ? params[d + i] : params[d + (size_t)i * d + i]; }, red);
 }
+// the fused funnel's finisher (funnel_finish) is its own kernel: inlined into k_value_only it would sit in every caller's
+// register budget.  (Neither 1024 threads (10.0 us) nor 32 loads in flight per lane (8.1 us) beat this 8.1 us: a dependent
+// single-workgroup launch costs 4.5 us before it does anything.)
+template <typename T>
+__global__ __launch_bounds__(256) void k_value_funnel(int d, const T *params, ValueIn vin, OutArgs out) {
+  __shared__ double red[4];
+  finalize_value_block<T, 256, false, true>(d, vin, out, 2 * (int64_t)d, [params, d](int i) { return params[d + i]; }, red);
+}
 void launch_value_only(mivi_ctx *c, const void *params, const ValueIn &vin, const OutArgs &out) {
+  if (vin.fn.cs && c->cfg.family == MIVI_MEANFIELD) {
+    if (c->cfg.dtype == MIVI_F32)
+      hipLaunchKernelGGL(k_value_funnel<float>, dim3(1), dim3(256), 0, c->stream, c->cfg.d, (const float *)params, vin, out);
+    else
+      hipLaunchKernelGGL(k_value_funnel<double>, dim3(1), dim3(256), 0, c->stream, c->cfg.d, (const double *)params, vin, out);
+    return;
+  }
   if (c->cfg.dtype == MIVI_F32)
     hipLaunchKernelGGL(k_value_only<float>, dim3(1), dim3(256), 0, c->stream, c->cfg.d, c->cfg.family,
                        (const float *)params, vin, out);
