@@ -16,3 +16,9 @@ prob = avi.DiagNormalProblem(np.full(d, 5, np.float32), np.ones(d, np.float32))
 alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), n_samples=256, optimizer=avi.Adam(1e-1), operator=avi.ClipScale())
 q, info, state = avi.optimize(avi.PhiloxRNG(1), alg, 300, prob, q0)
 print("mean", q.location[:3], "elbo", info[-1]["elbo"])
+# the Stein / Price estimator of E_q[grad log pi], E_q[hess log pi] (inner estimator of the measure-space algorithms)
+S = np.array([[2.0, -0.1], [-0.1, 2.0]])
+quad = avi.DenseNormalProblem(np.zeros(2), np.linalg.cholesky(np.linalg.inv(S)))
+lp, g, H = avi.gaussian_expectation_gradient_and_hessian_(avi.PhiloxRNG(3), avi.FullRankGaussian(np.ones(2), 0.1 * np.eye(2)),
+                                                          10**6, None, None, quad)
+print("E grad", g.cpu().numpy(), "(-S mu =", -S @ np.ones(2), ")  E hess", H.cpu().numpy().round(2).tolist())
