@@ -51,6 +51,7 @@ SIGNATURES = {
     "mivi_estimate_objective_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p]),
     "mivi_gauss_expected_grad_hess": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mivi_gauss_expected_grad_hess_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mivi_set_logreg_route": (C.c_int32, [C.c_void_p, C.c_int32]),
     "mivi_estimate_partials": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "mivi_finalize": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mivi_clip_scale": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_double]),

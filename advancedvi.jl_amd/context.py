@@ -236,6 +236,10 @@ class MiviContext:
         self._chk(self.lib.mivi_finalize(self.h, self._p(p), self._p(partials), self._p(value), self._p(grad)))
         return value, grad
 
+    def set_logreg_route(self, route):
+        """0 = by problem size, 1 = matrix-core kernels, 2 = VALU kernels (built-in logistic regression, f32)."""
+        self._chk(self.lib.mivi_set_logreg_route(self.h, int(route)))
+
     def set_index_source(self, idx_tensor):
         """idx_tensor: 1-element int64/uint64 device tensor added to every estimate index (None to unset)."""
         self._idx_src = idx_tensor

@@ -240,7 +240,15 @@ __global__ __launch_bounds__(256) void k_lr_finish(LrArgs<T> a) {
     bb += bk * bk;
     if (a.want_grad) {
       double g = 0.0;
-      for (int s = 0; s < a.S; ++s) g += (double)a.g_part[((size_t)s * a.M + m) * p + k];
+      int s = 0;
+      for (; s + 8 <= a.S; s += 8) {   // eight loads in flight, same summation order
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = a.g_part[((size_t)(s + u) * a.M + m) * p + k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g += (double)v[u];
+      }
+      for (; s < a.S; ++s) g += (double)a.g_part[((size_t)s * a.M + m) * p + k];
       a.G[(size_t)m * d + k] = (T)(a.likeadj * g - bk * inv_s2);
     }
   }
@@ -553,6 +561,9 @@ __global__ __launch_bounds__(512) void k_lr_xtr_mfma_lds(LrMfmaArgs a) {
 //   Zs[16][128]  (ZT rows)
 // Lane half h feeds k = 8g + 4h + i to MFMA i of group g on both operands (the order of k inside a dot product is free),
 // so the A operand is one ds_read_b128 per 4 MFMAs.
+// PART: some 32-sample tiles of the 128-sample workgroup tile lie entirely beyond M (small n_samples): their MFMAs are skipped
+// (a separate instantiation, so the full-tile kernel keeps its branch-free stage body).
+template <bool PART>
 __global__ __launch_bounds__(512) void k_lr_logits_mfma_lds(LrMfmaArgs a) {
   __shared__ __attribute__((aligned(16))) float Xs[2][256 * 20];
   __shared__ __attribute__((aligned(16))) float Zs[2][16 * 128];
@@ -586,6 +597,7 @@ __global__ __launch_bounds__(512) void k_lr_logits_mfma_lds(LrMfmaArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
   const int ao = (wr * 64 + l31) * 20 + 4 * h, bo = 4 * h * 128 + wm * 64 + l31;
+  const bool has0 = m0 < a.M, has1 = m0 + 32 < a.M;   // wave-uniform
   auto compute = [&](int slot) {
     const float *xs = &Xs[slot][ao], *zs = &Zs[slot][bo];
 #pragma unroll
@@ -594,10 +606,14 @@ __global__ __launch_bounds__(512) void k_lr_logits_mfma_lds(LrMfmaArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float b0 = zs[(8 * g + i) * 128], b1 = zs[(8 * g + i) * 128 + 32];
-        c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0, c00, 0, 0, 0);
-        c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b1, c01, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b0, c10, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1, c11, 0, 0, 0);
+        if (!PART || has0) {
+          c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0, c00, 0, 0, 0);
+          c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b0, c10, 0, 0, 0);
+        }
+        if (!PART || has1) {
+          c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b1, c01, 0, 0, 0);
+          c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1, c11, 0, 0, 0);
+        }
       }
     }
   };
@@ -687,7 +703,8 @@ __device__ __forceinline__ void lr_split3(const lr_f32x4 &v, lr_bf16x4 &hi, lr_b
   }
 }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lr_logits_bf16x3(LrMfmaArgs a) {
+template <bool PART>
+__device__ __forceinline__ void lr_logits_bf16x3_body(const LrMfmaArgs &a) {
   __shared__ __attribute__((aligned(16))) __bf16 Xs[2][3][256 * 16];   // [slot][piece][row][16 k]
   __shared__ __attribute__((aligned(16))) __bf16 Zs[2][3][128 * 16];   // [slot][piece][sample][16 k]
   __shared__ float ll_lds[128];
@@ -731,6 +748,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
   for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
   const int ao = (wr * 64 + l31) * 16 + 8 * h, bo = (wm * 64 + l31) * 16 + 8 * h;
+  const bool has0 = m0 < a.M, has1 = m0 + 32 < a.M;   // wave-uniform
   auto compute = [&](int slot) {
     lr_bf16x8 A0[3], A1[3], B0[3], B1[3];
 #pragma unroll
@@ -743,10 +761,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
-      c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B0[PB[t]], c00, 0, 0, 0);
-      c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B1[PB[t]], c01, 0, 0, 0);
-      c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B0[PB[t]], c10, 0, 0, 0);
-      c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B1[PB[t]], c11, 0, 0, 0);
+      if (!PART || has0) {
+        c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B0[PB[t]], c00, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B0[PB[t]], c10, 0, 0, 0);
+      }
+      if (!PART || has1) {
+        c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B1[PB[t]], c01, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B1[PB[t]], c11, 0, 0, 0);
+      }
     }
   };
   {
@@ -810,6 +832,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
+// the full-tile kernel is pinned to 128 VGPRs (4 waves per SIMD, two workgroups per CU); the partial-tile variant's extra
+// control flow does not fit that budget without scratch (228 B/lane, 3x slower), so it runs unconstrained
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lr_logits_bf16x3(LrMfmaArgs a) {
+  lr_logits_bf16x3_body<false>(a);
+}
+__global__ __launch_bounds__(512) void k_lr_logits_bf16x3_part(LrMfmaArgs a) { lr_logits_bf16x3_body<true>(a); }
+
 // X^T R on the bf16 matrix cores, same bf16x3 scheme.  The contraction runs over data rows, so both operands need 8
 // consecutive ROWS per lane while memory has rows outermost: a thread loads a 4-row x 1-column strip (lanes along the
 // contiguous axis: coalesced dword loads), splits it, and writes the 4 row-consecutive bf16 of each piece as one 8-byte
@@ -831,7 +860,7 @@ __device__ __forceinline__ void lr_split3s(const float (&v)[4], lr_bf16x4 &hi, l
 // 2 -> 128-feature tile, 256 threads, 61 KB: two workgroups per CU that are not in barrier lock-step with each other (R is
 // then read by four feature groups instead of two).  Measured at C3: 880 us against 790 us for NWK = 4, which stays the
 // default; MIVI_LR_XTR_NARROW=1 selects NWK = 2.
-template <int NWK>
+template <int NWK, bool PART>
 __global__ __launch_bounds__(128 * NWK) void k_lr_xtr_bf16x3(LrMfmaArgs a) {
   constexpr int NT = 128 * NWK, KT = 64 * NWK, RN = 4 / NWK;   // threads, features per tile, R strips per thread
   constexpr int CS = 20;   // column stride in bf16 (40 bytes)
@@ -890,6 +919,7 @@ __global__ __launch_bounds__(128 * NWK) void k_lr_xtr_bf16x3(LrMfmaArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
   const int ao = (wm * 64 + l31) * CS + 8 * h, bo = (wk * 64 + l31) * CS + 8 * h;
+  const bool has0 = m0 < a.M, has1 = m0 + 32 < a.M;   // wave-uniform (PART: sample tiles beyond M are skipped)
   auto ld8 = [&](const __bf16 *p) {   // 8 consecutive rows of one column = two 8-byte words
     const lr_bf16x4 lo4 = *(const lr_bf16x4 *)p, hi4 = *(const lr_bf16x4 *)(p + 4);
     lr_bf16x8 v;
@@ -909,10 +939,14 @@ __global__ __launch_bounds__(128 * NWK) void k_lr_xtr_bf16x3(LrMfmaArgs a) {
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
-      c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B0[PB[t]], c00, 0, 0, 0);
-      c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B1[PB[t]], c01, 0, 0, 0);
-      c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B0[PB[t]], c10, 0, 0, 0);
-      c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B1[PB[t]], c11, 0, 0, 0);
+      if (!PART || has0) {   // A = residuals of samples m0 .. m0+31
+        c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B0[PB[t]], c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B1[PB[t]], c01, 0, 0, 0);
+      }
+      if (!PART || has1) {   // samples m0+32 .. m0+63
+        c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B0[PB[t]], c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B1[PB[t]], c11, 0, 0, 0);
+      }
     }
   };
   if (nst > 0) {
@@ -978,7 +1012,15 @@ __global__ __launch_bounds__(256) void k_lr_greduce(int S, size_t len, float *g_
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= len) return;
   float s = g_part[e];
-  for (int i = 1; i < S; ++i) s += g_part[(size_t)i * len + e];
+  int i = 1;
+  for (; i + 16 <= S; i += 16) {   // sixteen loads in flight, summed in the same fixed order (one load per add was a
+    float v[16];                   // latency chain: 29 us for S = 128 at n = 20 000)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = g_part[(size_t)(i + u) * len + e];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
+  }
+  for (; i < S; ++i) s += g_part[(size_t)i * len + e];
   g_part[e] = s;
 }
 
@@ -1055,7 +1097,11 @@ static LrGeom lr_geom(const mivi_ctx *c, int M) {
   LrGeom g;
   const long long n = c->lr_n;
   const int p = c->cfg.d - 1;
-  g.mfma = c->cfg.dtype == MIVI_F32 && c->lr_Xrm_act && !force_generic;
+  // small problems take the VALU route: the matrix-core kernels carry fixed 256-row x 128-sample tiles and three more
+  // launches (measured crossover around n p M = 2e7: n = 1000, p = 32: 35 vs 47 us at 16 samples, 50 vs 57 us at 128)
+  static const bool force_mfma = getenv("MIVI_LOGREG_MFMA") != nullptr;
+  g.mfma = c->cfg.dtype == MIVI_F32 && c->lr_Xrm_act && !force_generic && c->lr_route != 2 &&
+           (force_mfma || c->lr_route == 1 || (double)n * (double)p * (double)M >= 1.6e7);
   if (g.mfma) {
     g.ldr = (M + 63) / 64 * 64;
     g.nrb = (int)((n + 255) / 256);
@@ -1089,6 +1135,7 @@ static LrGeom lr_geom(const mivi_ctx *c, int M) {
   }
   return g;
 }
+bool logreg_uses_mfma(const mivi_ctx *c, int M) { return c->target == TGT_LOGREG && lr_geom(c, M).mfma; }
 bool logreg_reserve(mivi_ctx *c, int M) {
   const LrGeom g = lr_geom(c, M);
   return grow(c->lr_scratch, g.need_R + g.need_g) && grow(c->lr_part, g.need_ll);
@@ -1121,22 +1168,36 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
   // MIVI_LR_GEN1=1 selects the first-generation (register-operand) kernels: the in-library A/B reference
   static const bool no_bf16x3 = getenv("MIVI_LR_F32_LOGITS") != nullptr;   // A/B: f32 MFMA logits
   a.Zcm = (const float *)c->Z.p;
+  const bool part = M % 128 != 0 && M % 128 <= 96;   // whole 32-sample tiles of the last 128-sample group are empty
   if (gen1)
     hipLaunchKernelGGL(k_lr_logits_mfma, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
-  else if (a.d % 4 == 0 && a.d >= 4 && !no_bf16x3)
-    hipLaunchKernelGGL(k_lr_logits_bf16x3, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
-  else
-    hipLaunchKernelGGL(k_lr_logits_mfma_lds, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
-  if (want_grad && a.n % 16 != 0)   // the zero residual rows k_lr_xtr_bf16x3's last stage reads (the logits kernels stop at n)
-    (void)hipMemsetAsync(a.R + (size_t)a.n * a.ldr, 0, (size_t)(16 - a.n % 16) * a.ldr * sizeof(float), c->stream);
+  else if (a.d % 4 == 0 && a.d >= 4 && !no_bf16x3) {
+    if (part) hipLaunchKernelGGL(k_lr_logits_bf16x3_part, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_lr_logits_bf16x3, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
+  } else {
+    if (part) hipLaunchKernelGGL(k_lr_logits_mfma_lds<true>, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_lr_logits_mfma_lds<false>, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
+  }
+  if (want_grad && a.n % 16 != 0) {
+    // the zero residual rows k_lr_xtr_bf16x3's last stage reads (the logits kernels stop at n).  Nobody writes them, so
+    // they are zeroed once per geometry -- and every time while the stream is being captured (a graph must carry its own)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    const bool cap = cs == hipStreamCaptureStatusActive;
+    if (cap || c->lr_pad_R != (const void *)a.R || c->lr_pad_n != (long long)a.n || c->lr_pad_ldr != a.ldr) {
+      (void)hipMemsetAsync(a.R + (size_t)a.n * a.ldr, 0, (size_t)(16 - a.n % 16) * a.ldr * sizeof(float), c->stream);
+      if (!cap) { c->lr_pad_R = a.R; c->lr_pad_n = (long long)a.n; c->lr_pad_ldr = a.ldr; }
+    }
+  }
   if (want_grad) {
     const dim3 gx(S, (a.p + 255) / 256, (M + 127) / 128);
     static const bool xtr_f32 = getenv("MIVI_LR_F32_XTR") != nullptr;   // A/B: f32 MFMA X^T R
     if (gen1) hipLaunchKernelGGL(k_lr_xtr_mfma, gx, dim3(512), 0, c->stream, a);
     else if (!xtr_f32) {
       static const bool narrow = getenv("MIVI_LR_XTR_NARROW") != nullptr;   // A/B: two 4-wave workgroups per CU (measured slower)
-      if (!narrow) hipLaunchKernelGGL(k_lr_xtr_bf16x3<4>, gx, dim3(512), 0, c->stream, a);
-      else hipLaunchKernelGGL(k_lr_xtr_bf16x3<2>, dim3(S, (a.p + 127) / 128, (M + 127) / 128), dim3(256), 0, c->stream, a);
+      if (narrow) hipLaunchKernelGGL((k_lr_xtr_bf16x3<2, false>), dim3(S, (a.p + 127) / 128, (M + 127) / 128), dim3(256), 0, c->stream, a);
+      else if (part) hipLaunchKernelGGL((k_lr_xtr_bf16x3<4, true>), gx, dim3(512), 0, c->stream, a);
+      else hipLaunchKernelGGL((k_lr_xtr_bf16x3<4, false>), gx, dim3(512), 0, c->stream, a);
     }
     else hipLaunchKernelGGL(k_lr_xtr_mfma_lds, gx, dim3(512), 0, c->stream, a);
   }
@@ -1174,6 +1235,7 @@ static bool logreg_impl(mivi_ctx *c, int M, int want_grad) {
   a.rows_per_split = geo.rps;
   const size_t need_R = geo.need_R;
   // scratch layout inside lr_scratch: [R | g_part], lr_part: ll_part
+  c->lr_pad_n = -1;   // this route lays the scratch out differently: the MFMA route's zero pad rows are gone
   a.R = (T *)c->lr_scratch.p;
   a.g_part = (T *)((char *)c->lr_scratch.p + need_R);
   a.ll_part = (double *)c->lr_part.p;

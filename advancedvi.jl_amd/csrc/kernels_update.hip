@@ -279,8 +279,11 @@ __global__ __launch_bounds__(1024) void k_dog_init(int64_t n, const T *params, T
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(1024) void k_dog_update(int64_t n, T *params, const T *grad, const T *x0, double *sc, int kind) {
+// FUSE: ClipScale and PolynomialAveraging folded into the apply loop (device-resident loop), same per-element arithmetic
+template <typename T, bool FUSE = false>
+__global__ __launch_bounds__(1024) void k_dog_update(int64_t n, T *params, const T *grad, const T *x0, double *sc, int kind,
+                                                     int d = 0, int family = 0, T clip_eps = T(0), T *avg = nullptr,
+                                                     double avg_eta = 0.0, const long long *t_ptr = nullptr, long long t_base = 0) {
   __shared__ double red[16];
   double dist2 = 0.0, g2 = 0.0;
   for (int64_t i = threadIdx.x; i < n; i += 1024) {
@@ -307,7 +310,22 @@ __global__ __launch_bounds__(1024) void k_dog_update(int64_t n, T *params, const
     sc[0] = v;
     sc[1] = r;
   }
-  for (int64_t i = threadIdx.x; i < n; i += 1024) params[i] = (T)((double)params[i] - eta * (double)grad[i]);
+  if (!FUSE) {
+    for (int64_t i = threadIdx.x; i < n; i += 1024) params[i] = (T)((double)params[i] - eta * (double)grad[i]);
+  } else {
+    double wa = 0.0, wb = 0.0;
+    if (avg) {
+      const double t = (double)(t_base + (t_ptr ? *t_ptr : 0));
+      wa = (avg_eta + 1.0) / (t + avg_eta);
+      wb = 1.0 - wa;
+    }
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+      T x = (T)((double)params[i] - eta * (double)grad[i]);
+      if (clip_eps > T(0) && is_scale_diag(i, d, family)) x = clip_step(x, clip_eps);
+      params[i] = x;
+      if (avg) avg[i] = (T)(wa * (double)x + wb * (double)avg[i]);
+    }
+  }
 }
 
 void launch_axpby(mivi_ctx *c, void *y, double a, const void *x, double b, int64_t n) {
@@ -398,12 +416,20 @@ __global__ void k_dog_apply_fused(int64_t n, T *params, const T *grad, const dou
 }
 
 // DoG / DoWG step with ClipScale and PolynomialAveraging folded into the apply pass (device-resident loop, large vectors).
-// Returns false when the caller has to launch the operator / averager itself (small vectors: single-workgroup kernel).
+// Always handles the step (returns true); kept as a bool for callers that fall back to separate launches.
 bool launch_dog_update_fused(mivi_ctx *c, void *params, const void *grad, void *state, int kind, double clip_eps, void *avg,
                              double avg_eta, const long long *t_ptr, long long t_base) {
   const int64_t n = mivi_params_len(c);
-  if (!(n > 16384 && c->dog_part.p)) return false;
   double *sc = (double *)((char *)state + mivi_dog_state_bytes(c) - 16);
+  if (!(n > 16384 && c->dog_part.p)) {   // small vectors: the single-workgroup kernel, with the same fused tail
+    if (c->cfg.dtype == MIVI_F32)
+      hipLaunchKernelGGL((k_dog_update<float, true>), dim3(1), dim3(1024), 0, c->stream, n, (float *)params, (const float *)grad,
+                         (const float *)state, sc, kind, c->cfg.d, c->cfg.family, (float)clip_eps, (float *)avg, avg_eta, t_ptr, t_base);
+    else
+      hipLaunchKernelGGL((k_dog_update<double, true>), dim3(1), dim3(1024), 0, c->stream, n, (double *)params, (const double *)grad,
+                         (const double *)state, sc, kind, c->cfg.d, c->cfg.family, clip_eps, (double *)avg, avg_eta, t_ptr, t_base);
+    return true;
+  }
   const int nb = 512;
   double *part = (double *)c->dog_part.p, *eta = part + 2 * nb;
   if (c->cfg.dtype == MIVI_F32) {

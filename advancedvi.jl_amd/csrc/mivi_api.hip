@@ -465,7 +465,7 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
         vin.ell_part = (const double *)c->ell_part[p].p;
         vin.n_ell_part = fr_dense_blocks(c, M);
       } else {
-        if (c->target == TGT_LOGREG && c->cfg.dtype == MIVI_F32) launch_rt_from_z(c, M);   // Z^T for the MFMA route
+        if (logreg_uses_mfma(c, M)) launch_rt_from_z(c, M);   // Z^T for the MFMA route
         if ((s = eval_generic_target(c, M, want_grad))) return s;
         vin.ell = c->ell.p;
         vin.n_ell = M;
@@ -1034,6 +1034,13 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
   HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
   if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
   return read_status(c);
+}
+
+mivi_status_t mivi_set_logreg_route(mivi_ctx_t *c, int32_t route) {
+  if (!c || route < 0 || route > 2) return MIVI_ERR_BAD_ARG;
+  c->lr_route = route;
+  invalidate_graph(c);
+  return MIVI_OK;
 }
 
 mivi_status_t mivi_set_index_source(mivi_ctx_t *c, const uint64_t *idx_dev) {

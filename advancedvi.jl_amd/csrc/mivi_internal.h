@@ -223,6 +223,10 @@ struct mivi_ctx {
   double lr_likeadj_full = 1.0;
   const void *lr_Xrm_act = nullptr;      // row-major copy the MFMA kernels read (full or batch)
   mivi::DevBuf lr_Xsub, lr_ysub, lr_Xrm_sub, lr_idx;
+  int lr_route = 0;                        // 0 auto (by problem size), 1 matrix-core kernels, 2 VALU kernels (mivi_set_logreg_route)
+  const void *lr_pad_R = nullptr;          // geometry for which R's zero pad rows are in place
+  long long lr_pad_n = -1;
+  int lr_pad_ldr = 0;
   mivi::DevBuf fn_cs[2];                   // funnel per-(row-quad, column) sums of squares, by parity
   int64_t lr_n = 0;
   int lr_variant = 0;
@@ -292,6 +296,7 @@ int eps_blocks(const mivi_ctx *c, int M);
 // kernels_targets.hip
 void launch_col_target(mivi_ctx *c, int M, int want_grad);
 bool launch_logreg_target(mivi_ctx *c, int M, int want_grad);   // false: scratch allocation failed
+bool logreg_uses_mfma(const mivi_ctx *c, int M);          // the matrix-core route (needs Z^T staged in RT)
 bool logreg_reserve(mivi_ctx *c, int M);                        // size the scratch ahead of a graph capture
 bool logreg_prepare_f32(mivi_ctx *c);   // row-major padded copy of X for the MFMA route (false: allocation failed)
 

@@ -244,6 +244,11 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *ctx, void *params_dev, const mivi_l
  * eps stream on replay by bumping one device word.  NULL restores by-value indices. */
 mivi_status_t mivi_set_index_source(mivi_ctx_t *ctx, const uint64_t *idx_dev);
 
+/* Tools / tests: which kernels evaluate the built-in logistic regression (f32): 0 = by problem size (default: the VALU
+ * kernels below n*p*n_mc = 1.6e7, the matrix-core kernels above), 1 = matrix-core kernels, 2 = VALU kernels.  Results
+ * agree to rounding; f64 always takes the VALU kernels. */
+mivi_status_t mivi_set_logreg_route(mivi_ctx_t *ctx, int32_t route);
+
 /* ---- measurement hook (bench.py roofline leg) --------------------------------------------------------- *
  * Times `reps` back-to-back launches of ONE stage of the estimate with hipEvents recorded on the context's
  * stream (after one full warm estimate so every input buffer is populated).

@@ -276,12 +276,13 @@ def test_device_loop_with_the_logreg_target():
     d = p + 1
     X = (rng.normal(size=(n, p)) / np.sqrt(p)).astype(np.float32)
     y = (rng.uniform(size=n) < 0.5).astype(np.uint8)
-    for family in (avi.MEANFIELD, avi.FULLRANK):
+    for family, route in ((avi.MEANFIELD, 1), (avi.MEANFIELD, 2), (avi.FULLRANK, 1), (avi.FULLRANK, 2)):
         q0 = (avi.MeanFieldGaussian(np.zeros(d, np.float32), np.full(d, 0.5, np.float32)) if family == avi.MEANFIELD
               else avi.FullRankGaussian(np.zeros(d, np.float32), 0.5 * np.eye(d, dtype=np.float32)))
         p0, _ = avi.destructure(q0)
         ctx = avi.MiviContext(np.float32, family, d, M, 0, SEED)
         ctx.set_problem(avi.LogRegProblem(X, y))
+        ctx.set_logreg_route(route)      # matrix-core kernels / VALU kernels (the default picks by problem size)
         pa = ctx.to_device(p0).clone()
         st = ctx.empty(2 * pa.numel()).zero_()
         for t in range(T):

@@ -22,7 +22,7 @@ ENTROPIES = [avi.ClosedFormEntropy(), avi.ClosedFormEntropyZeroGradient(), avi.M
              avi.StickingTheLandingEntropy(), avi.StickingTheLandingEntropyZeroGradient()]
 
 
-def run_case(d, M, family, kind, ent, dtype, idx=3, plugin=False):
+def run_case(d, M, family, kind, ent, dtype, idx=3, plugin=False, route=None):
     rng = np.random.default_rng(1234 + d + 7 * M)
     q, q_o = make_family(rng, d, family, dtype)
     prob, tgt = make_problem(rng, kind, d, dtype)
@@ -34,6 +34,13 @@ def run_case(d, M, family, kind, ent, dtype, idx=3, plugin=False):
     Z, eps = ctx.sample(params, idx)
     eps = eps.cpu().numpy().astype(np.float64)
     Z = Z.cpu().numpy().astype(np.float64)
+    if kind.startswith("logreg") and dtype == np.float32 and not plugin and route is None:
+        # the built-in logistic regression has two f32 kernel families, chosen by problem size: cover both
+        ctx.close()
+        run_case(d, M, family, kind, ent, dtype, idx, plugin, route=1)
+        return run_case(d, M, family, kind, ent, dtype, idx, plugin, route=2)
+    if route is not None:
+        ctx.set_logreg_route(route)
     value, grad = ctx.estimate_gradient(params, idx)
     value = float(value.item())
     grad = grad.cpu().numpy().astype(np.float64)

@@ -94,10 +94,12 @@ def test_logreg_row_selection_matches_the_oracle(dtype):
             ctx.set_problem(avi.subsample(prob, batch))
             t = tgt.subsample(batch)
         _, eps = ctx.sample(params, 5)
-        v, g = ctx.estimate_gradient(params, 5)
         ref = O.estimate_gradient(O.destructure(q_o), d, O.FULLRANK, t, eps.cpu().numpy().astype(np.float64), 0)
-        assert abs(float(v.item()) - ref["value"]) <= vt * abs(ref["value"])
-        assert np.linalg.norm(g.cpu().numpy() - ref["grad"]) <= gt * max(np.linalg.norm(ref["grad"]), 1.0)
+        for route in ((1, 2) if dtype == np.float32 else (0,)):      # matrix-core (row-major gather) and VALU kernels
+            ctx.set_logreg_route(route)
+            v, g = ctx.estimate_gradient(params, 5)
+            assert abs(float(v.item()) - ref["value"]) <= vt * abs(ref["value"])
+            assert np.linalg.norm(g.cpu().numpy() - ref["grad"]) <= gt * max(np.linalg.norm(ref["grad"]), 1.0)
     with pytest.raises(Exception, match="out of range"):
         ctx.set_problem(avi.subsample(prob, [n]))
     ctx.close()
