@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, ".")
+import sys; sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import numpy as np, advancedvi_jl_amd as avi
 rng = np.random.default_rng(0)
 n, p = 2000, 8

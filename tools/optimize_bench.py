@@ -2,7 +2,7 @@
 (DoWG + PolynomialAveraging + ClipScale) on the README-sized LogReg (n=1000, d=33, mean-field, 16 samples) and C2."""
 import sys, time, warnings
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import advancedvi_jl_amd as avi
 rng = np.random.default_rng(0)
 X = rng.normal(size=(1000, 32)); y = (rng.uniform(size=1000) < 0.5).astype(np.uint8)

@@ -2,7 +2,7 @@
 anything far above (number of kernels) x 5 us deserves a profile."""
 import sys, time, warnings
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import advancedvi_jl_amd as avi
 rng = np.random.default_rng(0)
 def logreg(n, p, dt):
