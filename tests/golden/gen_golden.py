@@ -5,7 +5,7 @@ The reference is pure Julia (no toolchain here) and commits no numeric vectors (
 fixtures are produced by the restatement that tests/test_oracle_pinning.py pins against the reference's
 known-answer tests.  One cell per {mean-field, full-rank} x {5 entropy estimators} x {diag, dense, logreg0,
 logreg1, funnel} target: inputs (seed, estimate_idx, d, M, params, target parameters) and expected outputs
-(eps of the Philox stream, Z, ell, G, entropy, value, grad).  Re-run: `python tests/golden/gen_golden.py`."""
+(eps of the Philox stream, Z, ell, G, entropy, value, grad; full-rank cells also the Stein gradient / Hessian estimate).  Re-run: `python tests/golden/gen_golden.py`."""
 import os
 import sys
 
@@ -53,6 +53,11 @@ def main():
                     out[key + "_Z"] = r["Z"]
                     out[key + "_ell"] = r["ell"]
                     out[key + "_G"] = r["G"]
+            if family == O.FULLRANK:   # gaussian_expectation_gradient_and_hessian! (Stein branch) on the same inputs
+                lp, g, H = O.gaussian_expectation_gradient_and_hessian(q, tgt, eps)
+                out[key + "_stein_logpi"] = np.array(lp)
+                out[key + "_stein_grad"] = g
+                out[key + "_stein_hess"] = H
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "repgradelbo_cells.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes,", len(out), "arrays")
