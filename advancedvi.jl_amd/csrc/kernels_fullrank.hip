@@ -185,7 +185,7 @@ __device__ double tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *
         st[pi] = m;
         st[plen + pi] = vv;
       }
-      if (is_diag && a.upd.clip_eps > 0.0) x = clip_step(x, (T)a.upd.clip_eps);
+      if (is_diag && a.upd.do_clip) x = clip_step(x, (T)a.upd.clip_eps);
       pp[pi] = x;
     };
     // fused optimiser step: fetch this thread's parameters (and Adam moments) up front -- one memory round trip for
@@ -219,7 +219,7 @@ __device__ double tile_epilogue(const FrArgs<T> &a, int ib, int cb, Get get, T *
         ((T *)a.upd.state)[pi] = m;
         ((T *)a.upd.state)[plen + pi] = vv;
       }
-      if (is_diag && a.upd.clip_eps > 0.0) x = clip_step(x, (T)a.upd.clip_eps);
+      if (is_diag && a.upd.do_clip) x = clip_step(x, (T)a.upd.clip_eps);
       ((T *)a.upd.params)[pi] = x;
     };
 #pragma unroll
@@ -1396,6 +1396,7 @@ static void ensure_tabs(mivi_ctx *c, int M) {
 }
 
 void prepare_tables(mivi_ctx *c, int M) {
+  if (lds_path_shape_ok(c, M) && (c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS)) (void)lds_prepare(c, M);
   if (c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32) ensure_tabs(c, M);
   if (c->cfg.family == MIVI_MEANFIELD && c->cfg.dtype == MIVI_F32 && c->target == TGT_DENSE_GAUSS) ensure_tabs(c, M);
 }

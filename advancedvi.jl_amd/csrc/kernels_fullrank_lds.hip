@@ -1,0 +1,1238 @@
+// Full-rank RepGradELBO contractions, second generation: LDS-staged macro-tiles on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// Reference semantics (AdvancedVI.jl v0.7.0), unchanged from kernels_fullrank.hip:
+//   sampling   Z = scale * eps .+ mu                                  src/families/location_scale.jl:71-77
+//   gradient   d/dC = -(1/M) tril(W eps') - direct * diag(1/C_ii),  d/dmu = -(1/M) W 1   
+//   dense-Gaussian target  G = -P (Z - m)                             (bench target of the north star)
+//
+// Why a second generation: the first one gives every 32x32 output tile its own workgroup and feeds the MFMAs one dword
+// per lane straight from L2 -- each operand element is fetched for exactly one MFMA (34.6 MB of L2->L1 traffic per
+// contraction at d=1024, M=256 against 3.1 MB of input) and the triangular product only ever occupies 128 CUs.  Here:
+//   * operands travel global -> registers (16-byte coalesced loads, two stages ahead) -> LDS, and every LDS element feeds
+//     BM/32 (resp. BN/32) MFMAs of the workgroup's BM x BN macro-tile;
+//   * the triangular product  tril(C) eps  and the dense target product are SPLIT-K over workgroups from a host-built
+//     work list (equal k-ranges => all 256 CUs busy); a workgroup leaves its partial macro-tile in a slab, and the
+//     reduction is deterministic and rides on the kernel boundary: k_fr_reduce sums a tile's slabs in list order, adds mu,
+//     applies the fused target, and -- VALU work under its memory latency -- draws eps of the NEXT estimate and the
+//     log-determinant partials;
+//   * eps lives in ONE layout, eps[i + m*dP]: the sampling product reads it k-major (16-byte loads along k, LDS image
+//     [n][k], b128 fragment reads), the VJP reads the same buffer row-major.  The MFMA k-slots of both operands are
+//     permuted identically (k = 8s + 4(lane>>5) + j), which leaves the sum unchanged;
+//   * the VJP  tril(W eps')  has a short K (= n_mc), so it is not split over workgroups: 64x32 tiles, the two k-halves
+//     of every stage on two waves, reduced through LDS in the epilogue (16-byte coalesced gradient stores).
+// One estimate = k_fr_gemm<SAMPLE> -> k_fr_reduce (-> k_fr_gemm<DENSE> -> k_fr_reduce) -> k_fr_gemm<VJP>.
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+#include "device_common.h"
+#include "optim_rules.h"
+
+namespace mivi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { G_SAMPLE = 0, G_VJP = 1, G_DENSE = 2 };
+
+struct GemmArgs {
+  int d, M, dP;
+  const float *A;   // MN-major operand A[row + k*lda]: tril(C) (sample), W (vjp), P (dense)
+  int lda;
+  const float *B;   // sample / dense: k-major B[k + n*ldb] (eps, Z - m); vjp: B[n + k*ldb] (eps)
+  int ldb;
+  const int4 *work;  // .x = rb | cb << 16, .y = first stage | end stage << 16, .z = slab, .w = flags
+  int n_work;        // the workgroup after the last item assembles the objective value (vjp, optional)
+  float *slab;       // split-K partial macro-tiles, slab s at slab + s*BM*BN, image [n][BM]
+  // vjp epilogue
+  const float *params;
+  OutArgs out;
+  FusedUpdate upd;
+  ValueIn self_vin;
+  OutArgs self_out;
+  int n_items;       // sample kernel: blocks >= n_items draw eps of the NEXT estimate (0 = no such blocks)
+  SampleArgs<float> next_eps;
+  long long *dbg;    // optional timeline (tools/timeline2.py)
+  int knock;         // developer knock-outs (MIVI_KNOCK): 1 no loads after the prologue, 2 no MFMAs, 4 no loads at all
+};
+
+struct ReduceArgs {
+  int d, M, dP, mode;
+  const float *slab;
+  const int2 *tiles;     // per macro-tile (rb*ncb + cb): .x first slab, .y slab count
+  int ncb;
+  int zero_slab;         // an all-zero slab (unconditional loads beyond a tile's slab count)
+  const float *params;
+  const float *t_mean, *t_istd;
+  float *Z;              // optional sample output, ld = d
+  float *W;              // ld = d
+  float *R;              // Z - t_mean, ld = dP (dense target)
+  double *ell_part;      // per-workgroup partial of sum_m ell_m
+  double *ld_part;       // [2][d/64] log-determinant partials, non-positive counts (or nullptr)
+  long long *dbg;
+};
+
+// -----------------------------------------------------------------------------------------------------------------
+// Epilogue of the VJP kernels: tile (row0, col0) of tril(W eps^T), KW partial images Cs[kw][n][LDC] in LDS (rows contiguous),
+// rs_lds[NT/BM][BM] partial row sums of W.  Final mode: -1/M scaling, entropy diagonal term, exact zeros above the diagonal
+// (and in the mirrored tile), d/dmu on the tiles that hold a diagonal block's first columns; shard mode: packed triangle;
+// FUSED: Descent / Adam (+ ClipScale) applied in place instead of writing the gradient.
+// -----------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int KW, int NT, bool FUSED>
+__device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs, const float *rs_lds, const float *adam_cc, int4 wk,
+                                             int row0, int col0) {
+  constexpr int LDC = BM + 4;
+  constexpr int NE = BM * BN / 4 / NT;
+  const int tid = threadIdx.x;
+  const int d = a.d;
+  const bool mu_tile = (wk.w & 2);
+  // ---- vjp epilogue: tile (rb, cb) of tril(W eps^T) -------------------------------------------------------------------
+  const double invM = 1.0 / (double)a.out.M_total;
+  const double direct = direct_entropy_coeff(a.out.ent_kind);
+  const bool diag_tile = (wk.w & 1);
+  if (a.out.partials_mode) {   // shard partials: raw sums, packed lower triangle
+    float *dst = (float *)a.out.partials;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = tid + u * NT, i4 = 4 * (e % (BM / 4)), n = e / (BM / 4);
+      f32x4 v = *(const f32x4 *)(Cs + n * LDC + i4);
+#pragma unroll
+      for (int k2 = 1; k2 < KW; ++k2) v += *(const f32x4 *)(Cs + (k2 * BN + n) * LDC + i4);
+      const int gj = col0 + n;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int gi = row0 + i4 + c;
+        if (gj <= gi) dst[d + (size_t)gj * d - ((size_t)gj * (gj - 1)) / 2 + (gi - gj)] = v[c];
+      }
+    }
+  } else {
+    const bool fused = FUSED && a.upd.rule >= 0;
+    float *dst = (float *)a.out.grad;
+    const size_t plen = (size_t)d + (size_t)d * d;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = tid + u * NT, i4 = 4 * (e % (BM / 4)), n = e / (BM / 4);
+      const int gi = row0 + i4, gj = col0 + n;
+      const size_t pi = d + (size_t)gj * d + gi;
+      f32x4 px, pm, pv;
+      if (fused) {   // parameters (and Adam moments) of this thread's elements: one round trip, issued before the LDS reads
+        px = *(const f32x4 *)((const float *)a.upd.params + pi);
+        if (a.upd.rule == 1) {
+          pm = *(const f32x4 *)((const float *)a.upd.state + pi);
+          pv = *(const f32x4 *)((const float *)a.upd.state + plen + pi);
+        }
+      }
+      float cjj = 1.f;
+      if (diag_tile && gj >= gi && gj < gi + 4) cjj = a.params[d + (size_t)gj * d + gj];
+      f32x4 v = *(const f32x4 *)(Cs + n * LDC + i4);
+#pragma unroll
+      for (int k2 = 1; k2 < KW; ++k2) v += *(const f32x4 *)(Cs + (k2 * BN + n) * LDC + i4);
+      f32x4 o;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (gj > gi + c) {
+          o[c] = 0.f;
+        } else {
+          double x = -(double)v[c] * invM;
+          if (gj == gi + c) x -= direct / (double)cjj;
+          o[c] = (float)x;
+        }
+      }
+      if (!fused) {
+        *(f32x4 *)(dst + pi) = o;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          if (gj > gi + c) continue;   // zero gradients above the diagonal move nothing
+          float x;
+          if (a.upd.rule == 0) {
+            x = descent_step(px[c], o[c], (float)a.upd.eta);
+          } else {
+            float m = pm[c], vv = pv[c];
+            x = adam_step<float>(px[c], o[c], m, vv, adam_cc[0], adam_cc[1], (float)a.upd.eta, (float)a.upd.b1,
+                                 (float)a.upd.b2, (float)a.upd.eps);
+            pm[c] = m;
+            pv[c] = vv;
+          }
+          if (gj == gi + c && a.upd.do_clip) x = clip_step(x, (float)a.upd.clip_eps);
+          px[c] = x;
+        }
+        *(f32x4 *)((float *)a.upd.params + pi) = px;
+        if (a.upd.rule == 1) {
+          *(f32x4 *)((float *)a.upd.state + pi) = pm;
+          *(f32x4 *)((float *)a.upd.state + plen + pi) = pv;
+        }
+      }
+    }
+    if (!fused && !diag_tile) {   // the mirrored, strictly upper tile is structurally zero
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < NE; ++u) {
+        const int e = tid + u * NT, j4 = 4 * (e % (BN / 4)), ii = e / (BN / 4);
+        *(f32x4 *)(dst + d + (size_t)(row0 + ii) * d + col0 + j4) = z4;
+      }
+    }
+  }
+  if (mu_tile && tid < BM) {   // d/dmu rows of this row block: sum of W over all samples
+    double sm = 0.0;
+#pragma unroll
+    for (int g = 0; g < NT / BM; ++g) sm += (double)rs_lds[g * BM + tid];
+    const int gr = row0 + tid;
+    if (a.out.partials_mode) {
+      ((float *)a.out.partials)[gr] = (float)sm;
+    } else {
+      const float g = (float)(-sm * invM);
+      if (FUSED && a.upd.rule >= 0) {
+        float *pp = (float *)a.upd.params;
+        float x;
+        if (a.upd.rule == 0) {
+          x = descent_step(pp[gr], g, (float)a.upd.eta);
+        } else {
+          float *st = (float *)a.upd.state;
+          const size_t plen = (size_t)d + (size_t)d * d;
+          float m = st[gr], vv = st[plen + gr];
+          x = adam_step<float>(pp[gr], g, m, vv, adam_cc[0], adam_cc[1], (float)a.upd.eta, (float)a.upd.b1, (float)a.upd.b2,
+                               (float)a.upd.eps);
+          st[gr] = m;
+          st[plen + gr] = vv;
+        }
+        pp[gr] = x;
+      } else {
+        ((float *)a.out.grad)[gr] = g;
+      }
+    }
+  }
+  MIVI_STAMP_K(a.dbg, G_VJP, 4);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// k_fr_gemm: one BM x BN macro-tile (or one k-range of it) per workgroup.
+//   waves: (BM/WM) x (BN/WN) x KW; every wave holds (WM/32) x (WN/32) accumulators of 32x32; the KW wave groups split
+//   each BK-stage's k range.
+//   Staging is direct-to-LDS (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of NBUF stage
+//   buffers, NBUF-1 stages in flight: the wait for stage s is a counted vmcnt (never 0 inside the loop), followed by ONE
+//   raw s_barrier per stage; the buffer freed by stage s-1 is re-issued right behind that barrier.
+//   LDS-DMA writes lane-linear 1 KiB pieces, so the images are linear in the order the lanes fetch:
+//     As[k][BM]                      (row-major operand: a piece = 256/BM consecutive k)
+//     Bs[k][BN]                      (vjp: eps rows)
+//     Bs[n][BK], 16-byte chunk c of row n stored at chunk position c ^ ((n >> 1) & 7)   (k-major operand, BK = 32):
+//                                    the swizzle sits on the SOURCE address and on the b128 fragment read.
+// -----------------------------------------------------------------------------------------------------------------
+#define MIVI_GLDS16(gptr, lptr)                                                                            \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                 \
+                                   (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `stages` whole stages (L loads each) of this wave's LDS-DMA are still in flight
+template <int L>
+__device__ __forceinline__ void wait_stages(int stages) {
+  static_assert(7 * L <= 63, "vmcnt is a 6-bit counter");
+  switch (stages) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<L>(); break;
+    case 2: wait_vmcnt<2 * L>(); break;
+    case 3: wait_vmcnt<3 * L>(); break;
+    case 4: wait_vmcnt<4 * L>(); break;
+    case 5: wait_vmcnt<5 * L>(); break;
+    case 6: wait_vmcnt<6 * L>(); break;
+    default: wait_vmcnt<7 * L>(); break;
+  }
+}
+
+template <int MODE, int BM, int BN, int WM, int WN, int KW, int BK, int NBUF, bool FUSED>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * KW * 64) void k_fr_gemm(GemmArgs a) {
+  // Every scalar argument the main path needs, fetched in ONE batch: hipcc otherwise sinks each s_load to its first use, and
+  // every such use is a scalar-cache miss (the cache is invalidated at kernel start) on the critical path of every workgroup.
+  {
+    const unsigned long long pA = (unsigned long long)a.A, pB = (unsigned long long)a.B, pW = (unsigned long long)a.work,
+                             pS = (unsigned long long)a.slab, pP = (unsigned long long)a.params, pD = (unsigned long long)a.dbg,
+                             pG = (unsigned long long)a.out.grad, pQ = (unsigned long long)a.out.partials;
+    asm volatile("" ::"s"(pA), "s"(pB), "s"(pW), "s"(pS), "s"(pP), "s"(pD), "s"(pG), "s"(pQ), "s"(a.d), "s"(a.lda), "s"(a.ldb),
+                 "s"(a.n_work), "s"(a.knock), "s"(a.out.partials_mode), "s"(a.out.ent_kind), "s"(a.out.M_total));
+  }
+  constexpr int NWM = BM / WM, NWN = BN / WN, NW = NWM * NWN * KW, NT = NW * 64;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr bool BKM = (MODE != G_VJP);            // B operand is k-major in memory
+  constexpr int A_STAGE = BK * BM, B_STAGE = BK * BN;
+  constexpr int STAGE = A_STAGE + B_STAGE;
+  constexpr int NA = A_STAGE / 256 / NW, NB = B_STAGE / 256 / NW;   // 1 KiB pieces per wave and stage
+  constexpr int KROWS_A = 256 / BM;                  // k rows of As per piece
+  constexpr int KPW = BK / KW;                      // k range of one wave inside a stage
+  constexpr int LDC = BM + 4;
+  constexpr int EPI = KW * BN * LDC + (MODE == G_VJP ? (NT / BM) * BM : 0);
+  constexpr int MAIN = (NBUF * STAGE > EPI) ? NBUF * STAGE : EPI;
+  static_assert(NA >= 1 && NB >= 1 && KPW % 8 == 0 && NBUF >= 2 && NBUF <= 9, "tile geometry");
+  static_assert(!BKM || BK == 32, "k-major operand image: 128-byte rows");
+  static_assert(NT % BM == 0, "row-sum pass geometry");
+  // ONE LDS object (a second one makes hipcc drain the LDS-DMA queue before every fragment read)
+  __shared__ __attribute__((aligned(16))) float lds[MAIN + 2 * NW + 4];
+  double *red = reinterpret_cast<double *>(lds + MAIN);
+  float *adam_cc = lds + MAIN + 2 * NW;
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w % NWM, wn = (w / NWM) % NWN, kw = w / (NWM * NWN);
+  const int d = a.d;
+
+  if (MODE == G_VJP && (int)blockIdx.x == a.n_work) {   // objective value of THIS estimate (everything it sums is older)
+    const float *pp = a.params;
+    finalize_value_block<float, NT, false>(d, a.self_vin, a.self_out, (int64_t)d + (int64_t)d * d,
+                                           [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, red);
+    return;
+  }
+  if (MODE == G_SAMPLE && a.n_items > 0 && (int)blockIdx.x >= a.n_items) {
+    // eps(t+1): one Philox block per thread = rows gi..gi+3 of column gm, the same stream as k_eps.  Pure VALU work that runs
+    // on the CUs while the tile workgroups wait for their operands and while their waves sit in MFMA chains.
+    const SampleArgs<float> &n = a.next_eps;
+    constexpr int CPB = NT / 16;   // columns per block
+    const int eb = blockIdx.x - a.n_items, nrb = d >> 6;
+    const int gi = (eb % nrb) * 64 + 4 * (tid & 15), gm = (eb / nrb) * CPB + (tid >> 4);
+    float e[4];
+    eps_block<float>(n.rng.seed, rng_index(n.rng), (uint64_t)(n.rng.m_offset + gm) * (uint64_t)(d >> 2) + (uint64_t)(gi >> 2), e);
+    const f32x4 ev = {e[0], e[1], e[2], e[3]};
+    *(f32x4 *)(n.eps + (size_t)gm * n.ld_eps + gi) = ev;
+    const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
+    const double sh = block_sum<double, NT>((double)he, red);
+    if (tid == 0) n.he_part[eb] = sh;
+    return;
+  }
+  MIVI_STAMP_K(a.dbg, MODE, 0);
+  // the work item through the scalar cache (constant address space => s_load_dwordx4), not a vector-memory round trip
+  const __attribute__((address_space(4))) int *wp = (const __attribute__((address_space(4))) int *)a.work + 4 * blockIdx.x;
+  const int4 wk = make_int4(wp[0], wp[1], wp[2], wp[3]);
+  asm volatile("" ::"s"(wk.x), "s"(wk.y), "s"(wk.z), "s"(wk.w));   // one s_load_dwordx4, not one load per field at its first use
+  const int rb = wk.x & 0xffff, cb = wk.x >> 16;
+  const int s_beg = wk.y & 0xffff, s_end = wk.y >> 16;
+  const int row0 = rb * BM, col0 = cb * BN;
+  const int ns = s_end - s_beg;
+  const bool mu_tile = (MODE == G_VJP) && (wk.w & 2);
+
+  // this wave's sub-tile lies strictly above the diagonal: nothing to accumulate (it still stages and synchronises)
+  const bool skip = (MODE == G_VJP) && (row0 + wm * WM + WM - 1 < col0 + wn * WN);
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+  float rsum = 0.f;
+
+  // ---- staging: per-lane source pointers of this wave's first A / B piece of stage 0 ------------------------------------
+  const float *Ag = a.A + row0 + (4 * lane) % BM + (size_t)(s_beg * BK + w * KROWS_A + (4 * lane) / BM) * a.lda;
+  const float *Bg;
+  size_t b_piece, b_stage;   // element strides between this wave's successive pieces / between stages
+  if (BKM) {
+    constexpr int NROWS = 256 / BK;   // n rows per piece (8)
+    const int n = w * NROWS + lane / (BK / 4);
+    const int c = (lane % (BK / 4)) ^ ((n >> 1) & 7);
+    Bg = a.B + (size_t)s_beg * BK + 4 * c + (size_t)(col0 + n) * a.ldb;
+    b_piece = (size_t)(NW * NROWS) * a.ldb;
+    b_stage = BK;
+  } else {
+    constexpr int KROWS_B = 256 / BN;
+    Bg = a.B + col0 + (4 * lane) % BN + (size_t)(s_beg * BK + w * KROWS_B + (4 * lane) / BN) * a.ldb;
+    b_piece = (size_t)(NW * KROWS_B) * a.ldb;
+    b_stage = (size_t)BK * a.ldb;
+  }
+  const size_t a_piece = (size_t)(NW * KROWS_A) * a.lda, a_stage = (size_t)BK * a.lda;
+
+  auto issue_piece = [&](int s, int p) {   // piece p (0 .. NA+NB-1, compile-time after unrolling) of stage s -> ring buffer s % NBUF
+    float *dst = lds + (s % NBUF) * STAGE + w * 256;
+    if (p < NA) MIVI_GLDS16(Ag + (size_t)s * a_stage + p * a_piece, dst + p * (NW * 256));
+    else MIVI_GLDS16(Bg + (size_t)s * b_stage + (p - NA) * b_piece, dst + A_STAGE + (p - NA) * (NW * 256));
+  };
+  auto issue = [&](int s) {
+#pragma unroll
+    for (int p = 0; p < NA + NB; ++p) issue_piece(s, p);
+  };
+
+  // fragment addressing (floats): A row of this lane, B column of this lane
+  const int a_off = wm * WM + l31;
+  int b_row[NI], b_swz[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = wn * WN + ni * 32 + l31;
+    b_row[ni] = BKM ? n * BK : n;
+    b_swz[ni] = h ^ ((n >> 1) & 7);
+  }
+
+  // fragment reads of stage s, then its MFMA chain; do_issue: the LDS-DMA pieces of stage s_issue ride between the MFMAs
+  // (an in-order wave issues them while the matrix pipe works; issued ahead of the chain they would delay both waves of the SIMD)
+  auto compute = [&](int s, auto do_issue, int s_issue) {
+    const float *As = lds + (s % NBUF) * STAGE, *Bs = As + A_STAGE;
+    if (MODE == G_VJP && mu_tile) {   // d/dmu: row sums of W, this thread's share of the stage
+      const float *p = As + (tid / BM) * (BK / (NT / BM)) * BM + tid % BM;
+#pragma unroll
+      for (int k = 0; k < BK / (NT / BM); ++k) rsum += p[k * BM];
+    }
+    if (skip) {
+      if (decltype(do_issue)::value) issue(s_issue);
+      return;
+    }
+    const int k0 = (s_beg + s) * BK;
+    const bool diag = (MODE == G_SAMPLE) && (k0 >= row0);   // stage inside the diagonal block of tril(C): keep k <= i only
+    const float *Ar = As + a_off;
+    // all fragment reads of this wave's k range first (KPW A values, KPW B values per sub-tile), then the MFMA chain:
+    // the other wave of the SIMD computes while these are in flight
+    float av[KPW / 8][4][MI], bv[KPW / 8][4][NI];
+#pragma unroll
+    for (int s8 = 0; s8 < KPW / 8; ++s8) {
+      const int kb = kw * KPW + 8 * s8 + 4 * h;
+      if (BKM) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const f32x4 bq = *(const f32x4 *)(Bs + b_row[ni] + 4 * (((kw * KPW + 8 * s8) >> 2) ^ b_swz[ni]));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bv[s8][j][ni] = bq[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) av[s8][j][mi] = Ar[(kb + j) * BM + mi * 32];
+        if (!BKM) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) bv[s8][j][ni] = Bs[(kb + j) * BN + b_row[ni]];
+        }
+      }
+    }
+    if (diag) {
+#pragma unroll
+      for (int s8 = 0; s8 < KPW / 8; ++s8)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            if (k0 - row0 + kw * KPW + 8 * s8 + 4 * h + j > a_off + mi * 32) av[s8][j][mi] = 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s8 = 0; s8 < KPW / 8; ++s8)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s8][j][mi], bv[s8][j][ni], acc[mi][ni], 0, 0, 0);
+        if (decltype(do_issue)::value && 4 * s8 + j < NA + NB) {
+          issue_piece(s_issue, 4 * s8 + j);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    if (decltype(do_issue)::value) {
+#pragma unroll
+      for (int p = KPW / 2; p < NA + NB; ++p) issue_piece(s_issue, p);
+    }
+  };
+
+  if (a.knock & 8) return;    // developer knock-out: entry cost only
+  // ---- main loop ---------------------------------------------------------------------------------------------------------
+  constexpr int L = NA + NB;
+  if (FUSED && a.upd.rule == 1 && tid == 0)
+    adam_bias<float>(a.upd.t_base + (a.upd.t_ptr ? *a.upd.t_ptr : 0), a.upd.b1, a.upd.b2, adam_cc[0], adam_cc[1]);
+  if (ns <= NBUF) {
+    // the whole k range fits the ring (every north-star shape): all pieces in flight at once, ONE wait, ONE barrier, then an
+    // uninterrupted MFMA chain -- per-stage barriers re-synchronise the two waves of a SIMD and cost more than the overlap buys
+    if (!(a.knock & 4))
+      for (int s = 0; s < ns; ++s) issue(s);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    MIVI_STAMP_K(a.dbg, MODE, 1);
+    if (a.dbg && tid == 0 && blockIdx.x < 4096) a.dbg[((size_t)MODE * 4096 + blockIdx.x) * 8 + 5] = clock64();
+    if (!(a.knock & 2))
+      for (int s = 0; s < ns; ++s) compute(s, std::false_type{}, 0);
+  } else {
+    const int npre = NBUF - 1;
+    if (!(a.knock & 4))
+      for (int s = 0; s < npre; ++s) issue(s);
+    for (int s = 0; s < ns; ++s) {
+      const int issued = (s + NBUF - 1 < ns) ? s + NBUF - 1 : ns;   // stages issued so far
+      wait_stages<L>(issued - (s + 1));
+      __builtin_amdgcn_s_barrier();       // stage s has landed for every wave; every wave is done with stage s-1
+      if (s == 0) {
+        MIVI_STAMP_K(a.dbg, MODE, 1);
+        if (a.dbg && tid == 0 && blockIdx.x < 4096) a.dbg[((size_t)MODE * 4096 + blockIdx.x) * 8 + 5] = clock64();
+      }
+      if (s + NBUF - 1 < ns && !(a.knock & 5)) issue(s + NBUF - 1);
+      if (!(a.knock & 2)) compute(s, std::false_type{}, 0);
+    }
+  }
+  __builtin_amdgcn_s_barrier();   // every wave is done reading the stage buffers: they become the epilogue image
+  MIVI_STAMP_K(a.dbg, MODE, 2);
+  if (a.dbg && tid == 0 && blockIdx.x < 4096) a.dbg[((size_t)MODE * 4096 + blockIdx.x) * 8 + 6] = clock64();
+
+  if (a.knock & 16) return;   // developer knock-out: no epilogue
+  // ---- accumulators -> LDS image Cs[kw][n][LDC] (rows contiguous) ---------------------------------------------------
+  float *Cs = lds;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+        *(f32x4 *)(Cs + (kw * BN + wn * WN + ni * 32 + l31) * LDC + wm * WM + mi * 32 + 8 * q + 4 * h) = v;
+      }
+  float *rs_lds = lds + KW * BN * LDC;   // [NT/BM][BM] partial row sums of A (vjp, d/dmu tiles)
+  if (MODE == G_VJP && mu_tile) rs_lds[tid] = rsum;
+  lds_barrier();
+  MIVI_STAMP_K(a.dbg, MODE, 3);
+
+  if (a.knock & 32) return;   // developer knock-out: no global stores
+  constexpr int NE = BM * BN / 4 / NT;   // float4 groups per thread
+  if (MODE != G_VJP) {
+    float *dst = a.slab + (size_t)wk.z * (BM * BN);
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int e = tid + u * NT, i4 = 4 * (e % (BM / 4)), n = e / (BM / 4);
+      f32x4 v = *(const f32x4 *)(Cs + n * LDC + i4);
+#pragma unroll
+      for (int k2 = 1; k2 < KW; ++k2) v += *(const f32x4 *)(Cs + (k2 * BN + n) * LDC + i4);
+      *(f32x4 *)(dst + n * BM + i4) = v;
+    }
+    MIVI_STAMP_K(a.dbg, MODE, 4);
+    return;
+  }
+
+  vjp_epilogue<BM, BN, KW, NT, FUSED>(a, Cs, rs_lds, adam_cc, wk, row0, col0);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// k_fr_vjp32: tril(W eps^T), one 32 x 32 tile per workgroup, the four waves split K = n_mc into contiguous quarters.
+//   With a 32 x 32 tile no operand element is shared between waves (they differ only in k), so every wave stages its OWN
+//   k range: LDS-DMA into a private 8 KiB buffer (32 k of W rows and of eps rows), wait on its own vmcnt, fragments to
+//   registers, re-issue the next 32 k into the same buffer, MFMA chain -- no workgroup barrier until the epilogue, the waves of
+//   a SIMD (2-3 workgroups are resident per CU: 32 KiB of LDS each) drift apart and fill each other's load latency.
+//   All 528 tiles of the north star are resident at once: no second dispatch round for the tiles beyond 2 x 256.
+// -----------------------------------------------------------------------------------------------------------------
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) {
+  constexpr int BM = 32, BN = 32, KW = 4, NT = 256, SUB = 32;
+  constexpr int LDC = BM + 4;
+  constexpr int WAVE_F = 2 * SUB * 32;                      // floats per wave buffer: As[32 k][32] + Bs[32 k][32]
+  constexpr int EPI = KW * BN * LDC + (NT / BM) * BM;
+  // LDS is padded to ~52 KiB so that at most THREE workgroups share a CU: with the 32 KiB the kernel needs the dispatcher packs
+  // up to five onto some CUs and leaves others with one, and the packed CUs finish last
+  constexpr int MAIN = 13 * 1024;
+  static_assert(MAIN >= KW * WAVE_F && MAIN >= EPI, "LDS budget");
+  __shared__ __attribute__((aligned(16))) float lds[MAIN + 2 * KW + 4];
+  double *red = reinterpret_cast<double *>(lds + MAIN);
+  float *adam_cc = lds + MAIN + 2 * KW;
+  {
+    const unsigned long long pA = (unsigned long long)a.A, pB = (unsigned long long)a.B, pW = (unsigned long long)a.work,
+                             pP = (unsigned long long)a.params, pD = (unsigned long long)a.dbg, pG = (unsigned long long)a.out.grad,
+                             pQ = (unsigned long long)a.out.partials;
+    asm volatile("" ::"s"(pA), "s"(pB), "s"(pW), "s"(pP), "s"(pD), "s"(pG), "s"(pQ), "s"(a.d), "s"(a.M), "s"(a.lda), "s"(a.ldb),
+                 "s"(a.n_work), "s"(a.knock), "s"(a.out.partials_mode), "s"(a.out.ent_kind), "s"(a.out.M_total));
+  }
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int d = a.d;
+  if ((int)blockIdx.x == a.n_work) {   // objective value of THIS estimate (everything it sums is older)
+    const float *pp = a.params;
+    finalize_value_block<float, NT, false>(d, a.self_vin, a.self_out, (int64_t)d + (int64_t)d * d,
+                                           [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, red);
+    return;
+  }
+  MIVI_STAMP_K(a.dbg, G_VJP, 0);
+  const __attribute__((address_space(4))) int *wp = (const __attribute__((address_space(4))) int *)a.work + 4 * blockIdx.x;
+  const int4 wk = make_int4(wp[0], wp[1], wp[2], wp[3]);
+  asm volatile("" ::"s"(wk.x), "s"(wk.y), "s"(wk.z), "s"(wk.w));
+  const int rb = wk.x & 0xffff, cb = wk.x >> 16;
+  const int row0 = rb * BM, col0 = cb * BN;
+  const bool mu_tile = (wk.w & 2);
+  const int Kq = a.M / KW, nsub = Kq / SUB;   // this wave's k range: [w * Kq, (w + 1) * Kq)
+  if (a.dbg && tid == 0 && blockIdx.x < 4096) a.dbg[((size_t)G_VJP * 4096 + blockIdx.x) * 8 + 7] = wk.x;
+
+  if (FUSED && a.upd.rule == 1 && tid == 0)
+    adam_bias<float>(a.upd.t_base + (a.upd.t_ptr ? *a.upd.t_ptr : 0), a.upd.b1, a.upd.b2, adam_cc[0], adam_cc[1]);
+
+  // a 1 KiB piece = 8 k of 32 rows; lane -> (k = lane / 8, rows 4 (lane % 8) ..)
+  float *buf = lds + w * WAVE_F;
+  const float *Ag = a.A + row0 + 4 * (lane & 7) + (size_t)(w * Kq + (lane >> 3)) * a.lda;
+  const float *Bg = a.B + col0 + 4 * (lane & 7) + (size_t)(w * Kq + (lane >> 3)) * a.ldb;
+  auto issue = [&](int t) {
+    const float *pa = Ag + (size_t)(t * SUB) * a.lda, *pb = Bg + (size_t)(t * SUB) * a.ldb;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      MIVI_GLDS16(pa + (size_t)(8 * p) * a.lda, buf + p * 256);
+      MIVI_GLDS16(pb + (size_t)(8 * p) * a.ldb, buf + SUB * 32 + p * 256);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float rsum = 0.f;
+  // a wave that is requesting operands outranks the waves already inside their MFMA chains (which only need an issue slot
+  // every 64 cycles): without this the youngest workgroup of a CU gets its first data after the older ones are done
+  __builtin_amdgcn_s_setprio(3);
+  if (!(a.knock & 4)) issue(0);
+  // workgroups beyond two per CU (dispatch order = block order) arrive last and are the youngest waves of their SIMD: age
+  // arbitration would give them the matrix pipe only after the older two are done -- let them go first instead
+  if (blockIdx.x >= 512) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(0);
+  for (int t = 0; t < nsub; ++t) {
+    wait_vmcnt<0>();
+    float av[16], bv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {   // MFMA step i uses k = 8 (i / 4) + 4 h + (i % 4) on both operands
+      const int k = 8 * (i >> 2) + 4 * h + (i & 3);
+      av[i] = buf[k * 32 + l31];
+      bv[i] = buf[SUB * 32 + k * 32 + l31];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer is free again before the next 32 k are requested
+    if (t == 0) MIVI_STAMP_K(a.dbg, G_VJP, 1);
+    if (t + 1 < nsub && !(a.knock & 4)) issue(t + 1);
+    if (mu_tile) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) rsum += av[i];
+    }
+    if (!(a.knock & 2)) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_s_barrier();   // every wave is done with its buffer: LDS becomes the epilogue image
+  MIVI_STAMP_K(a.dbg, G_VJP, 2);
+  if (a.knock & 16) return;
+  float *Cs = lds;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+    *(f32x4 *)(Cs + (w * BN + l31) * LDC + 8 * q + 4 * h) = v;
+  }
+  float *rs_lds = lds + KW * BN * LDC;   // [NT/BM = 8][BM]: wave w, half h -> slot 2 w + h
+  if (mu_tile) rs_lds[(2 * w + h) * BM + l31] = rsum;
+  lds_barrier();
+  MIVI_STAMP_K(a.dbg, G_VJP, 3);
+  if (a.knock & 32) return;
+  vjp_epilogue<BM, BN, KW, NT, FUSED>(a, Cs, rs_lds, adam_cc, wk, row0, col0);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// k_fr_prod32: Z = mu + tril(C) eps (G_SAMPLE) or G = -P (Z - m) (G_DENSE) WITHOUT split-K: one 32 x 32 output tile per
+// workgroup, eight waves split the tile's k range into contiguous runs of 32-k sub-stages and stage their OWN operands
+// (private 8 KiB LDS buffer per wave, LDS-DMA, no workgroup barrier before the epilogue -- the structure of k_fr_vjp32).
+// The epilogue sums the eight partial tiles in wave order through LDS and applies mu / the fused target right there:
+//   R_DIAG: W = grad log pi(z), ell partial      R_DENSE_R: R = z - m (k-major operand of the dense product)
+//   R_DENSE_G: W = g, ell += r g / 2              R_PLAIN: Z = z
+// so no slab, no reduce kernel and no second kernel boundary sits between the draw and the VJP.  The heaviest tile (K = d)
+// bounds the kernel (d/32 sub-stages on one CU); shapes where that is too long take the split-K route (k_fr_gemm + k_fr_reduce).
+// Trailing workgroups draw eps of the next estimate; the first column block's workgroups leave the log-det partials.
+// -----------------------------------------------------------------------------------------------------------------
+struct Prod32Args {
+  int d, M, dP, mode;
+  const float *A;    // tril(C) (lda = d) or P (lda = dP), row-major operand A[row + k*lda]
+  int lda;
+  const float *B;    // eps or Z - m, k-major B[k + n*dP]
+  const float *params;
+  const float *t_mean, *t_istd;
+  float *Z, *W, *R;
+  double *ell_part;  // one per tile workgroup
+  double *ld_part;   // [2][d/32] or nullptr
+  int n_tiles;       // blocks >= n_tiles draw eps of the next estimate
+  int ncb;
+  SampleArgs<float> next_eps;
+  long long *dbg;
+  int knock;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
+  constexpr int NW = 8, NT = 512, SUB = 32, LDC = 36;
+  constexpr int WAVE_F = 2 * 2 * SUB * 32;   // two sub-stage buffers per wave: {As[32 k][32], Bs[32 cols][32 k]} x 2
+  constexpr int EPI = NW * 32 * LDC;
+  constexpr int MAIN = (NW * WAVE_F > EPI) ? NW * WAVE_F : EPI;
+  __shared__ __attribute__((aligned(16))) float lds[MAIN + 2 * NW];
+  double *red = reinterpret_cast<double *>(lds + MAIN);
+  {
+    const unsigned long long p0 = (unsigned long long)a.A, p1 = (unsigned long long)a.B, p2 = (unsigned long long)a.params,
+                             p3 = (unsigned long long)a.t_mean, p4 = (unsigned long long)a.t_istd, p5 = (unsigned long long)a.Z,
+                             p6 = (unsigned long long)a.W, p7 = (unsigned long long)a.R, p8 = (unsigned long long)a.ell_part,
+                             p9 = (unsigned long long)a.ld_part, p10 = (unsigned long long)a.dbg;
+    asm volatile("" ::"s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5), "s"(p6), "s"(p7), "s"(p8), "s"(p9), "s"(p10), "s"(a.d),
+                 "s"(a.dP), "s"(a.mode), "s"(a.lda), "s"(a.n_tiles), "s"(a.ncb), "s"(a.knock));
+  }
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int d = a.d;
+  if ((int)blockIdx.x >= a.n_tiles) {   // eps(t+1): one Philox block per thread (rows gi..gi+3 of column gm), the k_eps stream
+    const SampleArgs<float> &n = a.next_eps;
+    const int eb = blockIdx.x - a.n_tiles, nrb = d >> 6;
+    const int gi = (eb % nrb) * 64 + 4 * (tid & 15), gm = (eb / nrb) * 32 + (tid >> 4);
+    float e[4];
+    eps_block<float>(n.rng.seed, rng_index(n.rng), (uint64_t)(n.rng.m_offset + gm) * (uint64_t)(d >> 2) + (uint64_t)(gi >> 2), e);
+    const f32x4 ev = {e[0], e[1], e[2], e[3]};
+    *(f32x4 *)(n.eps + (size_t)gm * n.ld_eps + gi) = ev;
+    const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
+    const double sh = block_sum<double, NT>((double)he, red);
+    if (tid == 0) n.he_part[eb] = sh;
+    return;
+  }
+  MIVI_STAMP_K(a.dbg, MODE, 0);
+  // heaviest row blocks first (they bound the kernel)
+  const int nrb = d >> 5;
+  const int rb = nrb - 1 - (int)blockIdx.x / a.ncb, cb = (int)blockIdx.x % a.ncb;
+  const int row0 = rb * 32, col0 = cb * 32;
+  const int nst = (MODE == G_SAMPLE) ? rb + 1 : nrb;            // 32-k sub-stages of this tile
+  const int t_beg = (w * nst) / NW, t_end = ((w + 1) * nst) / NW;   // this wave's run
+
+  // epilogue operands that do not depend on the product: requested now, consumed after the MFMA chain
+  const int ei4 = 4 * (tid & 7), en = (tid >> 3) & 31;   // threads 0..255: rows ei4..+3 of column en
+  const int gi = row0 + ei4, gm = col0 + en;
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, tm = mu, tis = mu, rr = mu;
+  float cii = 1.f;
+  const bool ld_blk = a.ld_part && cb == 0 && tid < 32;
+  if (tid < 256) {
+    if (a.mode == R_DENSE_G) {
+      rr = *(const f32x4 *)(a.B + (size_t)gm * a.dP + gi);
+    } else {
+      mu = *(const f32x4 *)(a.params + gi);
+      if (a.mode == R_DIAG || a.mode == R_DENSE_R) tm = *(const f32x4 *)(a.t_mean + gi);
+      if (a.mode == R_DIAG) tis = *(const f32x4 *)(a.t_istd + gi);
+    }
+    if (ld_blk) cii = a.params[d + (size_t)(row0 + tid) * d + row0 + tid];
+  }
+
+  // staging: a 1 KiB piece of A = 8 k x 32 rows (lane -> k = lane / 8, rows 4 (lane % 8)); a piece of B = 8 columns x 32 k,
+  // lane -> column lane / 8, 16-byte chunk (lane % 8) ^ swizzle(column) of that column's 128 contiguous bytes
+  float *buf = lds + w * WAVE_F;
+  const float *Ag = a.A + row0 + 4 * (lane & 7) + (size_t)(lane >> 3) * a.lda;
+  const float *Bg[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int n = 8 * p + (lane >> 3);
+    Bg[p] = a.B + (size_t)(col0 + n) * a.dP + 4 * ((lane & 7) ^ ((n >> 1) & 7));
+  }
+  auto issue = [&](int t, int slot) {
+    const float *pa = Ag + (size_t)(t * SUB) * a.lda;
+    float *dst = buf + slot * (2 * SUB * 32);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      MIVI_GLDS16(pa + (size_t)(8 * p) * a.lda, dst + p * 256);
+      MIVI_GLDS16(Bg[p] + t * SUB, dst + SUB * 32 + p * 256);
+    }
+  };
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int b_off = SUB * 32 + l31 * 32;            // this lane's column of the B image
+  const int b_swz = h ^ ((l31 >> 1) & 7);
+  __builtin_amdgcn_s_setprio(3);
+  if (t_beg < t_end) issue(t_beg, 0);
+  if (t_beg + 1 < t_end) issue(t_beg + 1, 1);
+  __builtin_amdgcn_s_setprio(0);
+  for (int t = t_beg; t < t_end; ++t) {
+    const int slot = (t - t_beg) & 1;
+    if (t + 1 < t_end) wait_vmcnt<8>();   // the sub-stage behind this one (8 pieces) may stay in flight
+    else wait_vmcnt<0>();
+    const float *cur = buf + slot * (2 * SUB * 32);
+    float av[16];
+    f32x4 bq[4];
+#pragma unroll
+    for (int s8 = 0; s8 < 4; ++s8) {   // MFMA step (s8, j) uses k = 8 s8 + 4 h + j on both operands
+      bq[s8] = *(const f32x4 *)(cur + b_off + 4 * ((2 * s8) ^ b_swz));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) av[4 * s8 + j] = cur[(8 * s8 + 4 * h + j) * 32 + l31];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this buffer is free again before it is requested anew
+    if (t == t_beg) MIVI_STAMP_K(a.dbg, MODE, 1);
+    if (t + 2 < t_end) issue(t + 2, slot);
+    if (MODE == G_SAMPLE && t == rb) {   // the diagonal block of tril(C): keep k <= i
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (8 * (i >> 2) + 4 * h + (i & 3) > l31) av[i] = 0.f;
+    }
+    if (!(a.knock & 2)) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bq[i >> 2][i & 3], acc, 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_s_barrier();   // every wave is done with its buffer: LDS becomes the epilogue image
+  MIVI_STAMP_K(a.dbg, MODE, 2);
+  float *Cs = lds;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+    *(f32x4 *)(Cs + (w * 32 + l31) * LDC + 8 * q + 4 * h) = v;
+  }
+  lds_barrier();
+  MIVI_STAMP_K(a.dbg, MODE, 3);
+  float ell = 0.f;
+  if (tid < 256) {
+    f32x4 v = *(const f32x4 *)(Cs + en * LDC + ei4);
+#pragma unroll
+    for (int k2 = 1; k2 < NW; ++k2) v += *(const f32x4 *)(Cs + (k2 * 32 + en) * LDC + ei4);   // fixed order
+    if (a.mode == R_DENSE_G) {
+      const f32x4 g = -v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ell += 0.5f * rr[c] * g[c];
+      *(f32x4 *)(a.W + (size_t)gm * d + gi) = g;
+    } else {
+      const f32x4 z = mu + v;
+      if (a.Z) *(f32x4 *)(a.Z + (size_t)gm * d + gi) = z;
+      if (a.mode == R_DIAG) {
+        f32x4 wv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float u = (z[c] - tm[c]) * tis[c];
+          ell += -0.5f * u * u;
+          wv[c] = -u * tis[c];
+        }
+        *(f32x4 *)(a.W + (size_t)gm * d + gi) = wv;
+      } else if (a.mode == R_DENSE_R) {
+        *(f32x4 *)(a.R + (size_t)gm * a.dP + gi) = z - tm;
+      }
+    }
+  }
+  if (a.mode == R_DIAG || a.mode == R_DENSE_G) {
+    const double sl = block_sum<double, NT>((double)ell, red);
+    if (tid == 0) a.ell_part[blockIdx.x] = sl;
+  }
+  if (ld_blk) {   // log|det C| partial of this 32-row block (lanes 0..31 of wave 0)
+    float lg = logf(cii), bad = (cii > 0.f) ? 0.f : 1.f;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      lg += __shfl_xor(lg, o, 64);
+      bad += __shfl_xor(bad, o, 64);
+    }
+    if (tid == 0) {
+      a.ld_part[rb] = (double)lg;
+      a.ld_part[nrb + rb] = (double)bad;
+    }
+  }
+  MIVI_STAMP_K(a.dbg, MODE, 4);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// k_fr_reduce: deterministic split-K reduction on the kernel boundary + everything elementwise that follows it.
+//   workgroup = 64 rows x 16 sample columns of one 64x64 macro-tile, thread = 4 rows of one column.
+//   R_DIAG   : z = mu + sum slabs; u = (z - m) / s; ell -= u^2 / 2; W = -u / s
+//   R_DENSE_R: R = z - m  (k-major operand of the dense product, ld = dP)
+//   R_DENSE_G: g = -sum slabs; ell += r g / 2; W = g
+//   R_PLAIN  : Z = z
+//   + the log-determinant partials (the VJP kernel may already be updating C when the value is assembled).
+// -----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fr_reduce(ReduceArgs a) {
+  __shared__ double red[4];
+  {   // every scalar argument in one batch (see k_fr_gemm)
+    const unsigned long long p0 = (unsigned long long)a.slab, p1 = (unsigned long long)a.tiles, p2 = (unsigned long long)a.params,
+                             p3 = (unsigned long long)a.t_mean, p4 = (unsigned long long)a.t_istd, p5 = (unsigned long long)a.Z,
+                             p6 = (unsigned long long)a.W, p7 = (unsigned long long)a.R, p8 = (unsigned long long)a.ell_part,
+                             p9 = (unsigned long long)a.ld_part, p10 = (unsigned long long)a.dbg;
+    asm volatile("" ::"s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5), "s"(p6), "s"(p7), "s"(p8), "s"(p9), "s"(p10), "s"(a.d),
+                 "s"(a.dP), "s"(a.mode), "s"(a.ncb), "s"(a.zero_slab));
+  }
+  const int tid = threadIdx.x;
+  const int d = a.d;
+  const int nsub = 4;   // 16-column sub-blocks per macro-tile column block
+  const int rb = blockIdx.x / (a.ncb * nsub), rem = blockIdx.x % (a.ncb * nsub);
+  const int cb = rem / nsub, sub = rem % nsub;
+  const int i4 = 4 * (tid & 15), nl = sub * 16 + (tid >> 4);
+  const int gi = rb * 64 + i4, gm = cb * 64 + nl;
+  const __attribute__((address_space(4))) int *tp = (const __attribute__((address_space(4))) int *)a.tiles + 2 * (rb * a.ncb + cb);
+  const int first = tp[0], count = tp[1];   // scalar loads
+  const float *sp = a.slab + nl * 64 + i4;
+  MIVI_STAMP_K(a.dbg, 3, 0);
+
+  // everything that does not depend on the slab sum is requested first: one memory round trip for the whole workgroup
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, tm = mu, tis = mu, r = mu;
+  if (a.mode == R_DENSE_G) {
+    r = *(const f32x4 *)(a.R + (size_t)gm * a.dP + gi);
+  } else {
+    mu = *(const f32x4 *)(a.params + gi);
+    if (a.mode == R_DIAG || a.mode == R_DENSE_R) tm = *(const f32x4 *)(a.t_mean + gi);
+    if (a.mode == R_DIAG) tis = *(const f32x4 *)(a.t_istd + gi);
+  }
+  float cii = 1.f;
+  const bool ld_blk = a.ld_part && cb == 0 && sub == 0 && tid < 64;
+  if (ld_blk) cii = a.params[d + (size_t)(rb * 64 + tid) * d + rb * 64 + tid];
+
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < count; s0 += 4) {   // fixed order; loads beyond the count read the all-zero slab
+    f32x4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int sl = (s0 + u < count) ? first + s0 + u : a.zero_slab;
+      t[u] = *(const f32x4 *)(sp + (size_t)sl * 4096);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v += t[u];
+  }
+
+  MIVI_STAMP_K(a.dbg, 3, 1);
+  float ell = 0.f;
+  if (a.mode == R_DENSE_G) {
+    f32x4 g = -v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ell += 0.5f * r[c] * g[c];
+    *(f32x4 *)(a.W + (size_t)gm * d + gi) = g;
+  } else {
+    f32x4 z = mu + v;
+    if (a.Z) *(f32x4 *)(a.Z + (size_t)gm * d + gi) = z;
+    if (a.mode == R_DIAG) {
+      f32x4 wv;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float u = (z[c] - tm[c]) * tis[c];
+        ell += -0.5f * u * u;
+        wv[c] = -u * tis[c];
+      }
+      *(f32x4 *)(a.W + (size_t)gm * d + gi) = wv;
+    } else if (a.mode == R_DENSE_R) {
+      *(f32x4 *)(a.R + (size_t)gm * a.dP + gi) = z - tm;
+    }
+  }
+  MIVI_STAMP_K(a.dbg, 3, 2);
+  if (a.mode == R_DIAG || a.mode == R_DENSE_G) {
+    const double sl = block_sum<double, 256>((double)ell, red);
+    if (tid == 0) a.ell_part[blockIdx.x] = sl;
+  }
+  if (ld_blk) {   // log|det C| partial of this 64-row block (wave 0)
+    float lg = logf(cii), bad = (cii > 0.f) ? 0.f : 1.f;
+    lg = wave_sum(lg);
+    bad = wave_sum(bad);
+    if (tid == 0) {
+      const int nb = d >> 6;
+      a.ld_part[rb] = (double)lg;
+      a.ld_part[nb + rb] = (double)bad;
+    }
+  }
+  MIVI_STAMP_K(a.dbg, 3, 3);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// Host side: work lists
+// -----------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kBM = 64, kBN = 64, kBK = 32;      // sample / dense macro-tile and stage
+constexpr int kVBM = 32, kVBN = 32, kVBK = 64;   // vjp tile (the four waves split every stage's k range)
+
+struct Item {
+  int rb, cb, s0, s1, slab, flags, cost;
+};
+
+// greedy list schedule of `costs` (in dispatch order) on `ncu` units: makespan
+long long makespan(const std::vector<int> &costs, int ncu) {
+  std::vector<long long> load(ncu, 0);   // min-heap on the load
+  auto cmp = [](long long x, long long y) { return x > y; };
+  for (int cst : costs) {
+    std::pop_heap(load.begin(), load.end(), cmp);
+    load.back() += cst;
+    std::push_heap(load.begin(), load.end(), cmp);
+  }
+  long long mx = 0;
+  for (long long l : load) mx = l > mx ? l : mx;
+  return mx;
+}
+
+// interleave 8 per-XCD lists so that workgroup b (observed to run on XCD b % 8) takes list b % 8's next item
+std::vector<Item> interleave8(std::vector<std::vector<Item>> &lists) {
+  while (true) {   // even the lists out (a wrong XCD guess costs speed only)
+    int mx = 0, mn = 0;
+    for (int x = 1; x < 8; ++x) {
+      if (lists[x].size() > lists[mx].size()) mx = x;
+      if (lists[x].size() < lists[mn].size()) mn = x;
+    }
+    if (lists[mx].size() <= lists[mn].size() + 1) break;
+    lists[mn].push_back(lists[mx].back());
+    lists[mx].pop_back();
+  }
+  std::vector<Item> out;
+  size_t L = 0;
+  for (auto &l : lists) L = std::max(L, l.size());
+  for (size_t s2 = 0; s2 < L; ++s2)
+    for (int x = 0; x < 8; ++x)
+      if (s2 < lists[x].size()) out.push_back(lists[x][s2]);
+  return out;
+}
+
+void upload(mivi_ctx *c, DevBuf &b, const void *src, size_t bytes) {
+  if (b.bytes < bytes || !b.p) {
+    if (b.p) (void)hipFree(b.p);
+    (void)hipMalloc(&b.p, bytes);
+    b.bytes = bytes;
+  }
+  (void)hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice);
+}
+
+std::vector<int4> pack(const std::vector<Item> &v) {
+  std::vector<int4> t(v.size());
+  for (size_t i = 0; i < v.size(); ++i) t[i] = make_int4(v[i].rb | (v[i].cb << 16), v[i].s0 | (v[i].s1 << 16), v[i].slab, v[i].flags);
+  return t;
+}
+
+// split-K work list of a (possibly triangular) product: row block rb needs stages [0, stages(rb)).
+// Chunk length T (stages per workgroup) minimises the list-schedule makespan on the chip, each workgroup paying a fixed
+// prologue/epilogue overhead worth ~3 stages.
+void build_splitk(mivi_ctx *c, int nrb, int ncb, bool triangular, int full_stages, DevBuf &tab, DevBuf &tiles, int &n_items,
+                  int &n_slabs) {
+  const int NCU = 256, OVH = 3;
+  auto stages = [&](int rb) { return triangular ? std::min(full_stages, (rb + 1) * (kBM / kBK)) : full_stages; };
+  int bestT = 1;
+  long long bestMs = -1;
+  for (int T = 1; T <= full_stages; T += std::max(1, T / 8)) {   // ~25 candidates per decade
+    std::vector<int> costs;
+    for (int rb = nrb - 1; rb >= 0; --rb) {
+      const int S = stages(rb), nch = (S + T - 1) / T;
+      for (int ch = 0; ch < nch; ++ch) {
+        const int len = S / nch + (ch < S % nch ? 1 : 0);
+        for (int cb = 0; cb < ncb; ++cb) costs.push_back(len + OVH);
+      }
+    }
+    std::sort(costs.begin(), costs.end(), [](int x, int y) { return x > y; });
+    const long long ms = makespan(costs, NCU);
+    if (bestMs < 0 || ms < bestMs) { bestMs = ms; bestT = T; }
+  }
+  std::vector<int2> tl((size_t)nrb * ncb);
+  std::vector<std::vector<Item>> groups;   // the ncb column blocks of one (row block, chunk): they share the A operand
+  int slab = 0;
+  for (int rb = 0; rb < nrb; ++rb) {
+    const int S = stages(rb), nch = (S + bestT - 1) / bestT;
+    for (int cb = 0; cb < ncb; ++cb) tl[(size_t)rb * ncb + cb] = make_int2(slab + cb * nch, nch);
+    int s0 = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+      const int len = S / nch + (ch < S % nch ? 1 : 0);
+      std::vector<Item> g;
+      for (int cb = 0; cb < ncb; ++cb) g.push_back(Item{rb, cb, s0, s0 + len, slab + cb * nch + ch, 0, len});
+      groups.push_back(g);
+      s0 += len;
+    }
+    slab += ncb * nch;
+  }
+  n_slabs = slab;
+  // longest groups first onto the least-loaded XCD list
+  std::sort(groups.begin(), groups.end(), [](const std::vector<Item> &x, const std::vector<Item> &y) { return x[0].cost > y[0].cost; });
+  std::vector<std::vector<Item>> lists(8);
+  std::vector<long long> load(8, 0);
+  for (auto &g : groups) {
+    int best = 0;
+    for (int x = 1; x < 8; ++x)
+      if (load[x] < load[best]) best = x;
+    for (auto &it : g) { lists[best].push_back(it); load[best] += it.cost; }
+  }
+  auto items = interleave8(lists);
+  n_items = (int)items.size();
+  auto packed = pack(items);
+  upload(c, tab, packed.data(), packed.size() * sizeof(int4));
+  upload(c, tiles, tl.data(), tl.size() * sizeof(int2));
+}
+
+void build_vjp(mivi_ctx *c, int d, int M, DevBuf &tab, int &n_items) {
+  const int nrb = d / kVBM;
+  const int SR = 256 / kVBM, SC = 256 / kVBN;   // super-blocks of 256 x 256 elements: one XCD's L2 holds their operands
+  std::vector<std::vector<Item>> sbs;
+  for (int sr = 0; sr * SR < nrb; ++sr)
+    for (int sc = 0; sc <= sr; ++sc) {
+      std::vector<Item> t;
+      for (int rb = sr * SR; rb < (sr + 1) * SR && rb < nrb; ++rb)
+        for (int cb = sc * SC; cb < (sc + 1) * SC && cb * kVBN <= rb * kVBM + kVBM - 1; ++cb) {
+          const bool diag = cb * kVBN + kVBN - 1 >= rb * kVBM;          // touches the diagonal
+          const bool mu = cb * kVBN == rb * kVBM;
+          const bool half = cb * kVBN > rb * kVBM;                      // only the lower 32x32 sub-tile has work
+          t.push_back(Item{rb, cb, 0, M / kVBK, 0, (diag ? 1 : 0) | (mu ? 2 : 0), half ? 1 : 2});
+        }
+      if (!t.empty()) sbs.push_back(t);
+    }
+  std::sort(sbs.begin(), sbs.end(), [](const std::vector<Item> &x, const std::vector<Item> &y) { return x.size() > y.size(); });
+  std::vector<std::vector<Item>> lists(8);
+  for (auto &sb : sbs) {
+    int best = 0;
+    for (int x = 1; x < 8; ++x)
+      if (lists[x].size() < lists[best].size()) best = x;
+    lists[best].insert(lists[best].end(), sb.begin(), sb.end());
+  }
+  for (auto &l : lists) std::stable_sort(l.begin(), l.end(), [](const Item &x, const Item &y) { return x.cost > y.cost; });
+  auto items = interleave8(lists);
+  n_items = (int)items.size();
+  auto packed = pack(items);
+  upload(c, tab, packed.data(), packed.size() * sizeof(int4));
+}
+
+}  // namespace
+
+bool lds_path_shape_ok(const mivi_ctx *c, int M) {
+  static const bool off = getenv("MIVI_FR_GEN1") != nullptr;   // A/B: first-generation tile kernels
+  return !off && c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && c->cfg.d % 64 == 0 && M % 128 == 0 &&
+         c->cfg.d <= 65535 * 32 && M > 0;
+}
+
+// (re)build the work lists for M samples per launch; allocates the slab buffer
+bool lds_prepare(mivi_ctx *c, int M) {
+  const bool dense = c->target == TGT_DENSE_GAUSS;
+  if (c->lds_M == M && c->lds_dense == dense && c->lds_tabS.p) return true;
+  invalidate_graph(c);   // a captured graph bakes the list contents, sizes and the slab pointer
+  const int d = c->cfg.d, nrb = d / kBM, ncb = M / kBN;
+  int slabs_s = 0, slabs_d = 0;
+  build_splitk(c, nrb, ncb, true, d / kBK, c->lds_tabS, c->lds_tilesS, c->lds_nS, slabs_s);
+  if (dense) build_splitk(c, nrb, ncb, false, d / kBK, c->lds_tabD, c->lds_tilesD, c->lds_nD, slabs_d);
+  build_vjp(c, d, M, c->lds_tabV, c->lds_nV);
+  const int ns = std::max(slabs_s, slabs_d) + 1;
+  const size_t bytes = (size_t)ns * kBM * kBN * sizeof(float);
+  if (c->lds_slab.bytes < bytes) {
+    if (c->lds_slab.p) (void)hipFree(c->lds_slab.p);
+    c->lds_slab.p = nullptr;
+    c->lds_slab.bytes = 0;
+    if (hipMalloc(&c->lds_slab.p, bytes) != hipSuccess) return false;
+    c->lds_slab.bytes = bytes;
+  }
+  c->lds_zero_slab = ns - 1;
+  (void)hipMemset((char *)c->lds_slab.p + (size_t)(ns - 1) * kBM * kBN * sizeof(float), 0, kBM * kBN * sizeof(float));
+  c->lds_M = M;
+  c->lds_dense = dense;
+  return true;
+}
+
+int lds_reduce_blocks(const mivi_ctx *c, int M) { return (c->cfg.d / 64) * (M / 64) * 4; }
+int lds_ld_blocks(const mivi_ctx *c) { return c->cfg.d / 64; }
+
+static int cfg_waves() {   // MIVI_LDS_WAVES=4: one wave per SIMD (A/B against the default two)
+  static const int v = getenv("MIVI_LDS_WAVES") ? atoi(getenv("MIVI_LDS_WAVES")) : 8;
+  return v;
+}
+static int knock_flags() {
+  static const int v = getenv("MIVI_KNOCK") ? atoi(getenv("MIVI_KNOCK")) : 0;
+  return v;
+}
+
+// Z-partials = tril(C) eps over the split-K list
+int lds_eps_blocks(const mivi_ctx *c, int M) { return (c->cfg.d / 64) * (M / (cfg_waves() == 4 ? 16 : 32)); }
+
+void launch_lds_sample(mivi_ctx *c, const void *params, int M, const EpsJob *next) {
+  GemmArgs a{};
+  a.d = c->cfg.d; a.M = M; a.dP = c->dP;
+  a.A = (const float *)params + c->cfg.d; a.lda = c->cfg.d;
+  a.B = (const float *)c->eps[c->cur].p; a.ldb = c->dP;
+  a.work = (const int4 *)c->lds_tabS.p; a.n_work = 0x7fffffff;
+  a.slab = (float *)c->lds_slab.p;
+  a.dbg = c->dbg;
+  a.knock = knock_flags();
+  int grid = c->lds_nS;
+  if (next) {   // trailing workgroups draw eps of the next estimate
+    a.n_items = c->lds_nS;
+    a.next_eps.d = c->cfg.d;
+    a.next_eps.M = M;
+    a.next_eps.rng = next->rng;
+    a.next_eps.eps = (float *)c->eps[next->parity].p;
+    a.next_eps.ld_eps = c->dP;
+    a.next_eps.he_part = (double *)c->he_part[next->parity].p;
+    grid += lds_eps_blocks(c, M);
+  }
+  if (cfg_waves() == 4)
+    hipLaunchKernelGGL((k_fr_gemm<G_SAMPLE, kBM, kBN, 32, 32, 1, kBK, 4, false>), dim3(grid), dim3(256), 0, c->stream, a);
+  else
+    hipLaunchKernelGGL((k_fr_gemm<G_SAMPLE, kBM, kBN, 32, 32, 2, kBK, 5, false>), dim3(grid), dim3(512), 0, c->stream, a);
+}
+
+// G-partials = P (Z - m) over the split-K list (R = Z - m was left by the reduce kernel, ld = dP)
+void launch_lds_dense(mivi_ctx *c, int M) {
+  GemmArgs a{};
+  a.d = c->cfg.d; a.M = M; a.dP = c->dP;
+  a.A = (const float *)c->t_prec.p; a.lda = c->dP;
+  a.B = (const float *)c->RT.p; a.ldb = c->dP;
+  a.work = (const int4 *)c->lds_tabD.p; a.n_work = 0x7fffffff;
+  a.slab = (float *)c->lds_slab.p;
+  a.dbg = c->dbg;
+  if (cfg_waves() == 4)
+    hipLaunchKernelGGL((k_fr_gemm<G_DENSE, kBM, kBN, 32, 32, 1, kBK, 4, false>), dim3(c->lds_nD), dim3(256), 0, c->stream, a);
+  else
+    hipLaunchKernelGGL((k_fr_gemm<G_DENSE, kBM, kBN, 32, 32, 2, kBK, 5, false>), dim3(c->lds_nD), dim3(512), 0, c->stream, a);
+}
+
+// unsplit 32 x 32-tile product + fused epilogue (k_fr_prod32).  dense = false: Z = mu + tril(C) eps with `mode` in
+// {R_DIAG, R_DENSE_R, R_PLAIN}; dense = true: G = -P (Z - m) (mode R_DENSE_G, R = Z - m in c->RT).
+void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int mode, void *Z, const EpsJob *next, bool want_ld) {
+  Prod32Args a{};
+  a.d = c->cfg.d; a.M = M; a.dP = c->dP; a.mode = mode;
+  if (dense) { a.A = (const float *)c->t_prec.p; a.lda = c->dP; a.B = (const float *)c->RT.p; }
+  else { a.A = (const float *)params + c->cfg.d; a.lda = c->cfg.d; a.B = (const float *)c->eps[c->cur].p; }
+  a.params = (const float *)params;
+  a.t_mean = (const float *)c->t_mean.p;
+  a.t_istd = (const float *)c->t_istd.p;
+  a.Z = (float *)Z;
+  a.W = (float *)c->W.p;
+  a.R = (float *)c->RT.p;
+  a.ell_part = (double *)c->ell_part[c->cur].p;
+  a.ld_part = want_ld ? (double *)c->ld_part[c->cur].p : nullptr;
+  a.ncb = M / 32;
+  a.n_tiles = (c->cfg.d / 32) * a.ncb;
+  a.dbg = c->dbg;
+  a.knock = knock_flags();
+  int grid = a.n_tiles;
+  if (next) {
+    a.next_eps.d = c->cfg.d;
+    a.next_eps.M = M;
+    a.next_eps.rng = next->rng;
+    a.next_eps.eps = (float *)c->eps[next->parity].p;
+    a.next_eps.ld_eps = c->dP;
+    a.next_eps.he_part = (double *)c->he_part[next->parity].p;
+    grid += (c->cfg.d / 64) * (M / 32);
+  }
+  if (dense) hipLaunchKernelGGL(k_fr_prod32<G_DENSE>, dim3(grid), dim3(512), 0, c->stream, a);
+  else hipLaunchKernelGGL(k_fr_prod32<G_SAMPLE>, dim3(grid), dim3(512), 0, c->stream, a);
+}
+int lds_prod32_tiles(const mivi_ctx *c, int M) { return (c->cfg.d / 32) * (M / 32); }
+int lds_prod32_eps_blocks(const mivi_ctx *c, int M) { return (c->cfg.d / 64) * (M / 32); }
+// the unsplit product is bounded by its heaviest tile (d/32 sub-stages on one CU); beyond this the split-K route wins
+bool lds_use_prod32(const mivi_ctx *c, int M) {
+  static const int force = getenv("MIVI_LDS_SPLITK") ? atoi(getenv("MIVI_LDS_SPLITK")) : -1;   // 1: split-K always, 0: never
+  if (force >= 0) return force == 0;
+  return (long long)c->cfg.d * M <= 1024LL * 512;
+}
+
+// slab reduction + mu + target (+ eps of the next estimate, + log-det partials).  mode: R_*
+void launch_lds_reduce(mivi_ctx *c, const void *params, int M, int mode, void *Z, bool want_ld) {
+  ReduceArgs a{};
+  a.d = c->cfg.d; a.M = M; a.dP = c->dP; a.mode = mode;
+  a.slab = (const float *)c->lds_slab.p;
+  a.tiles = (const int2 *)(mode == R_DENSE_G ? c->lds_tilesD.p : c->lds_tilesS.p);
+  a.ncb = M / kBN;
+  a.zero_slab = c->lds_zero_slab;
+  a.params = (const float *)params;
+  a.t_mean = (const float *)c->t_mean.p;
+  a.t_istd = (const float *)c->t_istd.p;
+  a.Z = (float *)Z;
+  a.W = (float *)c->W.p;
+  a.R = (float *)c->RT.p;
+  a.ell_part = (double *)c->ell_part[c->cur].p;
+  a.ld_part = want_ld ? (double *)c->ld_part[c->cur].p : nullptr;
+  a.dbg = c->dbg;
+  hipLaunchKernelGGL(k_fr_reduce, dim3(lds_reduce_blocks(c, M)), dim3(256), 0, c->stream, a);
+}
+
+// tril(W eps^T) (+ d/dmu); self != nullptr: one trailing workgroup assembles this estimate's objective value
+void launch_lds_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const ValueJob *self, const FusedUpdate *upd) {
+  GemmArgs a{};
+  a.d = c->cfg.d; a.M = M; a.dP = c->dP;
+  a.A = (const float *)c->W.p; a.lda = c->cfg.d;
+  a.B = (const float *)c->eps[c->cur].p; a.ldb = c->dP;
+  a.work = (const int4 *)c->lds_tabV.p;
+  a.n_work = 0x7fffffff;
+  a.params = (const float *)params;
+  a.out = out;
+  a.dbg = c->dbg;
+  a.knock = knock_flags();
+  int grid = c->lds_nV;
+  if (self) {
+    a.n_work = c->lds_nV;
+    a.self_vin = self->vin;
+    a.self_out = self->out;
+    grid += 1;
+  }
+  if (upd) {
+    a.upd = *upd;
+    hipLaunchKernelGGL(k_fr_vjp32<true>, dim3(grid), dim3(256), 0, c->stream, a);
+  } else {
+    hipLaunchKernelGGL(k_fr_vjp32<false>, dim3(grid), dim3(256), 0, c->stream, a);
+  }
+}
+
+}  // namespace mivi

@@ -38,12 +38,22 @@ static mivi_status_t ensure(mivi_ctx *c, DevBuf &b, size_t bytes, bool zero) {
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// A captured graph bakes buffer pointers, leading dimensions and work-list contents; the eps speculation remembers a buffer
+// parity.  Anything that reallocates or rewrites those calls this.
+namespace mivi {
+void invalidate_graph(mivi_ctx *c) {
+  c->pre_valid = false;
+  if (c->graph.exec) { (void)hipGraphExecDestroy(c->graph.exec); c->graph = GraphCache{}; }
+}
+}  // namespace mivi
+
 // work buffers for up to M samples per launch
 static mivi_status_t ensure_work(mivi_ctx *c, int M) {
   const int d = c->cfg.d;
   const size_t es = c->esize;
   mivi_status_t s;
   if (M > c->cap_M) {
+    invalidate_graph(c);   // the work buffers below are reallocated and MP / dP change under any cached graph
     // a capacity change re-zeros the padded RNG buffers (their padding must stay 0 / finite)
     const int capM = round_up(M, 64);
     c->dP = round_up(d, 64);
@@ -145,7 +155,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->dog_part, &c->stein_A, &c->stein_g, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->dog_part, &c->stein_A, &c->stein_g, &c->lds_tabS, &c->lds_tilesS, &c->lds_tabD, &c->lds_tilesD, &c->lds_tabV, &c->lds_slab, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -187,10 +197,6 @@ static mivi_status_t upload_vec(mivi_ctx *c, DevBuf &b, const std::vector<double
     HIPCHK(c, hipMemcpy(b.p, v.data(), v.size() * 8, hipMemcpyHostToDevice));
   }
   return MIVI_OK;
-}
-static void invalidate_graph(mivi_ctx *c) {
-  c->pre_valid = false;
-  if (c->graph.exec) { (void)hipGraphExecDestroy(c->graph.exec); c->graph = GraphCache{}; }
 }
 
 mivi_status_t mivi_set_target_diag_gauss(mivi_ctx_t *c, const void *mean, const void *stdv) {
@@ -407,6 +413,107 @@ static bool hetero_ok(const mivi_ctx *c, int want_grad) {
   return c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS;
 }
 
+// Second-generation full-rank route (kernels_fullrank_lds.hip): f32, d and M multiples of 64, fused Gaussian targets,
+// 16-byte aligned parameter / gradient vectors.  Everything else (and MIVI_FR_GEN1=1) takes the first-generation kernels.
+static bool lds_route(const mivi_ctx *c, const void *params, int M, int want_grad, const OutArgs &out) {
+  if (!lds_path_shape_ok(c, M)) return false;
+  if (c->target != TGT_DIAG_GAUSS && c->target != TGT_DENSE_GAUSS) return false;
+  if ((uintptr_t)params & 15) return false;
+  if (want_grad && !out.partials_mode && ((uintptr_t)out.grad & 15)) return false;
+  return true;
+}
+
+// One estimate on the second-generation route:
+//   [k_eps unless the previous estimate's reduce kernel already drew this eps]
+//   k_fr_gemm<SAMPLE> (split-K slabs) -> k_fr_reduce (z, target, ell partials, eps of the next estimate, log-det partials)
+//   [dense target: k_fr_gemm<DENSE> -> k_fr_reduce]  [STL: back substitution]  -> k_fr_gemm<VJP> (+ this estimate's value)
+static mivi_status_t run_estimate_lds(mivi_ctx *c, const void *params, const RngArgs &rng, int M, int want_grad, OutArgs out,
+                                      Chain *ch, const FusedUpdate *upd, bool stop_after_target) {
+  if (!lds_prepare(c, M)) return fail(c, MIVI_ERR_HIP, "full-rank work lists: allocation failed");
+  ValueIn vin{};
+  vin.ell_const = c->t_const;
+  const bool grad_stage = want_grad && !stop_after_target;
+  const bool chained = ch && ch->on && grad_stage && !out.partials_mode;
+  const bool spec = !chained && grad_stage;
+  bool hit = false;
+  int capturing = 0;
+  unsigned long long cap_id = 0;
+  if (spec) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamGetCaptureInfo(c->stream, &cs, &cap_id) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    capturing = cs == hipStreamCaptureStatusActive;
+    if (!capturing) cap_id = 0;
+    hit = c->pre_valid && c->pre_M == M && c->pre_rng.seed == rng.seed && c->pre_rng.idx_base == rng.idx_base &&
+          c->pre_rng.idx_ptr == rng.idx_ptr && c->pre_rng.m_offset == rng.m_offset && c->pre_capturing == capturing &&
+          c->pre_capture_id == cap_id;
+  }
+  c->pre_valid = false;
+  if (!chained) c->cur = hit ? c->pre_parity : 0;
+  const int p = c->cur;
+  if (chained ? ch->first : !hit) {
+    launch_eps(c, rng, M);
+    c->he_n[p] = eps_blocks(c, M);
+  }
+  vin.he_part = (const double *)c->he_part[p].p;
+  vin.n_he_part = c->he_n[p];
+  EpsJob nx{};
+  const EpsJob *next = nullptr;
+  if (chained && ch->has_next) {
+    nx.rng = ch->next_rng;
+    nx.parity = p ^ 1;
+    next = &nx;
+  } else if (spec) {   // speculate that the caller asks for estimate idx + 1 next (an SGD loop does)
+    nx.rng = rng;
+    nx.rng.idx_base = rng.idx_base + 1;
+    nx.parity = p ^ 1;
+    next = &nx;
+  }
+  const bool dense = c->target == TGT_DENSE_GAUSS;
+  const bool p32 = lds_use_prod32(c, M);
+  if (p32) {   // unsplit 32 x 32 tiles with the target fused into the epilogue: one kernel from eps to W
+    launch_lds_prod32(c, params, M, false, dense ? R_DENSE_R : R_DIAG, nullptr, next, grad_stage);
+    if (next) c->he_n[p ^ 1] = lds_prod32_eps_blocks(c, M);
+    if (dense) launch_lds_prod32(c, params, M, true, R_DENSE_G, nullptr, nullptr, false);
+    vin.ell_part = (const double *)c->ell_part[p].p;
+    vin.n_ell_part = lds_prod32_tiles(c, M);
+  } else {     // split-K slabs + reduce kernel (large shapes)
+    launch_lds_sample(c, params, M, next);
+    launch_lds_reduce(c, params, M, dense ? R_DENSE_R : R_DIAG, nullptr, grad_stage);
+    if (next) c->he_n[p ^ 1] = lds_eps_blocks(c, M);
+    if (dense) {
+      launch_lds_dense(c, M);
+      launch_lds_reduce(c, params, M, R_DENSE_G, nullptr, false);
+    }
+    vin.ell_part = (const double *)c->ell_part[p].p;
+    vin.n_ell_part = lds_reduce_blocks(c, M);
+  }
+  if (ch) { ch->have_prev = false; ch->first = !chained; }
+  if (grad_stage) {
+    if (out.ent_kind == MIVI_ENT_STL || out.ent_kind == MIVI_ENT_STL_ZERO_GRAD) {
+      const size_t sh = (8 * (size_t)c->dP + 32 * 33) * c->esize;
+      if (sh > 160 * 1024 && !c->stl_CT.p) return fail(c, MIVI_ERR_UNSUPPORTED, "full-rank STL: d too large for the LDS-resident solve");
+      launch_fr_stl(c, params, M);
+    }
+    vin.ld_part = (const double *)c->ld_part[p].p;   // left by the reduce kernel (the VJP kernel may already be updating C)
+    vin.n_ld_part = p32 ? fr_ld_blocks(c) : lds_ld_blocks(c);
+    ValueJob self{vin, out};
+    launch_lds_vjp(c, params, M, out, &self, chained ? upd : nullptr);
+    if (spec) {
+      c->pre_valid = true;
+      c->pre_rng = nx.rng;
+      c->pre_M = M;
+      c->pre_parity = p ^ 1;
+      c->pre_capturing = capturing;
+      c->pre_capture_id = cap_id;
+    }
+    HIPCHK(c, hipGetLastError());
+    return MIVI_OK;
+  }
+  launch_value_only(c, params, vin, out);
+  HIPCHK(c, hipGetLastError());
+  return MIVI_OK;
+}
+
 // One estimate over M local samples. out.partials_mode selects final vs shard partials.
 static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs &rng, int M, int want_grad,
                                   OutArgs out, Chain *ch = nullptr, const FusedUpdate *upd = nullptr,
@@ -416,6 +523,8 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
   if (s) return s;
   out.M_local = M;
   if (!out.status) out.status = (int *)c->status.p;
+  if (c->cfg.family == MIVI_FULLRANK && lds_route(c, params, M, want_grad, out))
+    return run_estimate_lds(c, params, rng, M, want_grad, out, ch, upd, stop_after_target);
   ValueIn vin{};
   vin.ell_const = c->t_const;
   const int d = c->cfg.d, d4 = (d + 3) / 4;
@@ -622,10 +731,10 @@ mivi_status_t mivi_estimate_gradient_host(mivi_ctx_t *c, const void *params_h, u
   const size_t plen = (size_t)mivi_params_len(c), es = c->esize;
   HIPCHK(c, hipMemcpyAsync(c->tmp_params.p, params_h, plen * es, hipMemcpyHostToDevice, c->stream));
   char *o = (char *)c->tmp_out.p;
-  mivi_status_t s = run_estimate(c, c->tmp_params.p, rng_of(c, idx), c->cfg.n_mc, 1, final_out(c, o, o + 8));
+  mivi_status_t s = run_estimate(c, c->tmp_params.p, rng_of(c, idx), c->cfg.n_mc, 1, final_out(c, o, o + 16));
   if (s) return s;
   HIPCHK(c, hipMemcpyAsync(value_h, o, es, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(grad_h, o + 8, plen * es, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(grad_h, o + 16, plen * es, hipMemcpyDeviceToHost, c->stream));
   return read_status(c);
 }
 
@@ -1001,7 +1110,8 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
         fu.b1 = l.beta1;
         fu.b2 = l.beta2;
         fu.eps = l.adam_eps;
-        fu.clip_eps = clip_eps;
+        fu.clip_eps = l.clip_epsilon;
+        fu.do_clip = (l.op == 1);
       }
       s = run_estimate(c, params, r, c->cfg.n_mc, 1, o, &chn, fuse_upd ? &fu : nullptr);
       if (s) break;
@@ -1058,11 +1168,11 @@ mivi_status_t mivi_debug_timeline(mivi_ctx_t *c, void *buf) {
 }
 
 mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *params, int32_t reps, double *ms_out) {
-  if (!c || !params || reps <= 0 || !ms_out || which < 0 || which > 5) return MIVI_ERR_BAD_ARG;
+  if (!c || !params || reps <= 0 || !ms_out || which < 0 || which > 7) return MIVI_ERR_BAD_ARG;
   (void)hipSetDevice(c->cfg.device);
   const int M = c->cfg.n_mc;
   char *o = (char *)c->tmp_out.p;
-  OutArgs out = final_out(c, o, o + 8);
+  OutArgs out = final_out(c, o, o + 16);
   RngArgs rng = rng_of(c, 0);
   c->pre_valid = false;
   mivi_status_t s = run_estimate(c, params, rng, M, 1, out);   // warm + populate eps / W / partial buffers
@@ -1073,6 +1183,8 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
   vin.ell_const = c->t_const;
   const bool fr = c->cfg.family == MIVI_FULLRANK;
   c->cur = 0;
+  const bool lds = fr && lds_route(c, params, M, 1, out);   // second-generation kernels: stages 2 / 4 include their reduce
+  if ((which == 6 || which == 7) && !lds) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 6 / 7: second-generation full-rank route only");
   if (which == 5) {   // the launch-free loop of 100 estimates (mean-field + diagonal target): one launch per rep
     if (fr || c->target != TGT_DIAG_GAUSS || M > 4096) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 5: mean-field + diagonal-Gaussian target");
     if ((s = ensure(c, c->X, ((size_t)100 + 400 * (size_t)((c->cfg.d + 3) / 4) + 8) * sizeof(double), false))) return s;
@@ -1082,31 +1194,75 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
     if (which == 2 && c->target != TGT_DIAG_GAUSS && c->target != TGT_DENSE_GAUSS)
       return fail(c, MIVI_ERR_UNSUPPORTED, "stage timing needs a fused built-in target");
   }
+  // Stage launches are captured into ONE graph and replayed: eager back-to-back launches of a 2-5 us kernel are bound by the
+  // host's launch rate (3-7 us per launch with these argument blocks), not by the kernel.  which = 0 stays eager (it is what
+  // a host-driven loop sees); the graph-batched whole estimate is mivi_estimate_gradient_n.
+  auto one = [&](int r) -> mivi_status_t {
+    mivi_status_t st = MIVI_OK;
+    switch (which) {
+      case 0: st = run_estimate(c, params, rng_of(c, (uint64_t)r + 1), M, 1, out); break;
+      case 1: launch_eps(c, rng, M); break;
+      case 2:
+        if (lds && lds_use_prod32(c, M)) {
+          launch_lds_prod32(c, params, M, false, c->target == TGT_DENSE_GAUSS ? R_DENSE_R : R_DIAG, nullptr, nullptr, true);
+        } else if (lds) {
+          launch_lds_sample(c, params, M);
+          launch_lds_reduce(c, params, M, c->target == TGT_DENSE_GAUSS ? R_DENSE_R : R_DIAG, nullptr, true);
+        } else if (fr) launch_fr_sample(c, params, M, c->target, c->target == TGT_DENSE_GAUSS ? c->Z.p : nullptr);
+        else launch_mf_main(c, params, rng, M, 1, nullptr, vin, out);
+        break;
+      case 3:
+        if (lds) launch_lds_vjp(c, params, M, out, nullptr, nullptr);
+        else launch_fr_vjp(c, params, M, out);
+        break;
+      case 6: launch_lds_sample(c, params, M); break;
+      case 7: launch_lds_reduce(c, params, M, c->target == TGT_DENSE_GAUSS ? R_DENSE_R : R_DIAG, nullptr, true); break;
+      case 5:
+        launch_mf_sgd_loop(c, const_cast<void *>(params), nullptr, (uint64_t)r * 100, 0, 100, -1, 0.0, 0.0, (double *)c->X.p + 100,
+                           (double *)c->X.p, o + 16);
+        break;
+      default:
+        if (lds && lds_use_prod32(c, M)) {
+          launch_lds_prod32(c, params, M, true, R_DENSE_G, nullptr, nullptr, false);
+        } else if (lds) {
+          launch_lds_dense(c, M);
+          launch_lds_reduce(c, params, M, R_DENSE_G, nullptr, false);
+        } else launch_fr_dense_target(c, M, 1);
+        break;
+    }
+    return st;
+  };
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0));
   HIPCHK(c, hipEventCreate(&e1));
-  HIPCHK(c, hipEventRecord(e0, c->stream));
-  for (int r = 0; r < reps; ++r) {
-    switch (which) {
-      case 0: s = run_estimate(c, params, rng_of(c, (uint64_t)r + 1), M, 1, out); break;
-      case 1: launch_eps(c, rng, M); break;
-      case 2:
-        if (fr) launch_fr_sample(c, params, M, c->target, c->target == TGT_DENSE_GAUSS ? c->Z.p : nullptr);
-        else launch_mf_main(c, params, rng, M, 1, nullptr, vin, out);
-        break;
-      case 3: launch_fr_vjp(c, params, M, out); break;
-      case 5:
-        launch_mf_sgd_loop(c, const_cast<void *>(params), nullptr, (uint64_t)r * 100, 0, 100, -1, 0.0, 0.0, (double *)c->X.p + 100,
-                           (double *)c->X.p, o + 8);
-        break;
-      default: launch_fr_dense_target(c, M, 1); break;
-    }
-    if (s) break;
-  }
-  HIPCHK(c, hipEventRecord(e1, c->stream));
-  HIPCHK(c, hipEventSynchronize(e1));
   float ms = 0.f;
-  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  const bool graphed = which != 0 && which != 5 && !c->dbg;
+  if (graphed) {
+    invalidate_graph(c);
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t saved;
+    if ((s = begin_capture(c, &saved))) return s;
+    for (int r = 0; r < reps && s == MIVI_OK; ++r) s = one(r);
+    hipError_t e = end_capture(c, saved, &graph);
+    if (s) { if (graph) (void)hipGraphDestroy(graph); return s; }
+    HIPCHK(c, e);
+    HIPCHK(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    HIPCHK(c, hipGraphLaunch(exec, c->stream));   // warm replay
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    HIPCHK(c, hipGraphLaunch(exec, c->stream));
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipGraphExecDestroy(exec);
+  } else {
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps && s == MIVI_OK; ++r) s = one(r);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   if (which != 0) c->pre_valid = false;

@@ -84,6 +84,7 @@ struct FusedUpdate {
   const long long *t_ptr;     // Adam step count = t_base + *t_ptr
   long long t_base;
   double eta, b1, b2, eps, clip_eps;
+  int do_clip = 0;            // ClipScale on the scale diagonal after the step (explicit: epsilon <= 0 is a legal ClipScale)
 };
 
 template <typename T>
@@ -244,6 +245,11 @@ struct mivi_ctx {
   mivi::DevBuf eps[2], epsT[2], ell_part[2], he_part[2], sc_part[2], ld_part[2];
   mivi::DevBuf tabA, tabB, tabD;   // XCD-aware work tables of the MFMA kernels
   mivi::DevBuf stl_CT, stl_Dinv;   // transposed scale + inverted diagonal blocks (full-rank STL, f32)
+  // second-generation full-rank kernels (kernels_fullrank_lds.hip): split-K work lists, per-tile slab ranges, slabs
+  mivi::DevBuf lds_tabS, lds_tilesS, lds_tabD, lds_tilesD, lds_tabV, lds_slab;
+  int lds_nS = 0, lds_nD = 0, lds_nV = 0, lds_M = -1, lds_zero_slab = 0;
+  bool lds_dense = false;
+  int he_n[2] = {0, 0};            // number of sum-0.5-eps^2 partials behind he_part[parity] (depends on who drew eps)
   int nA = 0, nB = 0, nD = 0, tab_M = -1;
   int cur = 0;
   int mf_nblk = 0;
@@ -292,6 +298,23 @@ void launch_stein_finish(mivi_ctx *c, double n, const double *gsum, const double
 int fr_sample_blocks(const mivi_ctx *c, int M);
 int fr_dense_blocks(const mivi_ctx *c, int M);
 int eps_blocks(const mivi_ctx *c, int M);
+
+// kernels_fullrank_lds.hip (f32, d and M multiples of 64)
+enum LdsReduceMode : int { R_DIAG = 0, R_DENSE_R = 1, R_DENSE_G = 2, R_PLAIN = 3 };
+bool lds_path_shape_ok(const mivi_ctx *c, int M);
+bool lds_prepare(mivi_ctx *c, int M);          // work lists + slab buffer for M samples per launch (false: allocation failed)
+int lds_reduce_blocks(const mivi_ctx *c, int M);
+int lds_ld_blocks(const mivi_ctx *c);
+void launch_lds_sample(mivi_ctx *c, const void *params, int M, const EpsJob *next = nullptr);   // next: also draws eps(t+1)
+int lds_eps_blocks(const mivi_ctx *c, int M);
+void launch_lds_dense(mivi_ctx *c, int M);
+void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int mode, void *Z, const EpsJob *next, bool want_ld);
+int lds_prod32_tiles(const mivi_ctx *c, int M);
+int lds_prod32_eps_blocks(const mivi_ctx *c, int M);
+bool lds_use_prod32(const mivi_ctx *c, int M);
+void launch_lds_reduce(mivi_ctx *c, const void *params, int M, int mode, void *Z, bool want_ld);
+void launch_lds_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const ValueJob *self, const FusedUpdate *upd);
+void invalidate_graph(mivi_ctx *c);            // mivi_api.hip: drop the cached hipGraphExec and the eps speculation
 
 // kernels_targets.hip
 void launch_col_target(mivi_ctx *c, int M, int want_grad);
