@@ -251,6 +251,11 @@ class MiviContext:
         self._chk(self.lib.mivi_profile_kernel(self.h, int(which), self._p(params), int(reps), C.byref(ms)))
         return ms.value
 
+    def fullrank_route(self, n_samples=0):
+        """(generation, bf16x3): which full-rank kernels run for n_samples per launch (mivi_fullrank_route)."""
+        r = int(self.lib.mivi_fullrank_route(self.h, int(n_samples)))
+        return r & 3, bool(r & 16)
+
     # -- next to the hot path ---------------------------------------------------------------------
     def clip_scale(self, params, epsilon):
         self._chk(self.lib.mivi_clip_scale(self.h, self._p(params), float(epsilon)))

@@ -505,18 +505,60 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * KW * 64) void k_fr_gemm(Gem
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// f32 products on the bf16 matrix cores ("bf16x3"): every f32 operand is split EXACTLY into three bf16 pieces
+// (x = hi + mid + lo: 8 + 8 + 8 significand bits, by truncation, all of one sign) and a 32 x 32 x 16 product block is the six
+// v_mfma_f32_32x32x16_bf16  lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi  accumulated in f32 (smallest terms first).  The three
+// dropped terms are <= 3 * 2^-24 of |x y|: f32-roundoff class (measured against the fp64 oracle: the same 1e-7 as the
+// f32-MFMA chain).  Six 8-pass MFMAs per 16 k replace eight 16-pass f32 MFMAs: 2.7x less matrix-pipe time; the split costs
+// ~5.5 VALU per operand element, which runs beside the other wave's MFMAs.  MIVI_FR_F32MFMA=1 selects the f32-MFMA chain.
+// -----------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3_bf16(const float *x, bf16x8 &hi, bf16x8 &mid, bf16x8 &lo) {   // x[0..7]
+  u32x4v uh, um, ul;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a = x[2 * p], b = x[2 * p + 1];
+    const unsigned ab = __builtin_bit_cast(unsigned, a), bb = __builtin_bit_cast(unsigned, b);
+    const float ra = a - __builtin_bit_cast(float, ab & 0xFFFF0000u), rb = b - __builtin_bit_cast(float, bb & 0xFFFF0000u);
+    const unsigned rab = __builtin_bit_cast(unsigned, ra), rbb = __builtin_bit_cast(unsigned, rb);
+    const float sa = ra - __builtin_bit_cast(float, rab & 0xFFFF0000u), sb = rb - __builtin_bit_cast(float, rbb & 0xFFFF0000u);
+    uh[p] = __builtin_amdgcn_perm(bb, ab, 0x07060302u);    // {b.hi16, a.hi16}
+    um[p] = __builtin_amdgcn_perm(rbb, rab, 0x07060302u);
+    ul[p] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), 0x07060302u);
+  }
+  hi = __builtin_bit_cast(bf16x8, uh);
+  mid = __builtin_bit_cast(bf16x8, um);
+  lo = __builtin_bit_cast(bf16x8, ul);
+}
+
+// acc += A(32 x 16) B(16 x 32) from the eight f32 fragment values av[0..7], bv[0..7] of this lane (same k slots in both)
+__device__ __forceinline__ void mfma_bf16x3(const float *av, const float *bv, f32x16 &acc) {
+  bf16x8 ah, am, al, bh, bm, bl;
+  split3_bf16(av, ah, am, al);
+  split3_bf16(bv, bh, bm, bl);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // k_fr_vjp32: tril(W eps^T), one 32 x 32 tile per workgroup, the four waves split K = n_mc into contiguous quarters.
 //   With a 32 x 32 tile no operand element is shared between waves (they differ only in k), so every wave stages its OWN
 //   k range: LDS-DMA into a private 8 KiB buffer (32 k of W rows and of eps rows), wait on its own vmcnt, fragments to
-//   registers, re-issue the next 32 k into the same buffer, MFMA chain -- no workgroup barrier until the epilogue, the waves of
-//   a SIMD (2-3 workgroups are resident per CU: 32 KiB of LDS each) drift apart and fill each other's load latency.
+//   registers, the buffer re-requested at once, MFMA chain -- no workgroup barrier until the epilogue, the waves of
+//   a SIMD (2-3 workgroups are resident per CU: 48 KiB of LDS each) drift apart and fill each other's load latency.
 //   All 528 tiles of the north star are resident at once: no second dispatch round for the tiles beyond 2 x 256.
 // -----------------------------------------------------------------------------------------------------------------
-template <bool FUSED>
+template <bool FUSED, bool BF3>
 __global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) {
-  constexpr int BM = 32, BN = 32, KW = 4, NT = 256, SUB = 32;
+  constexpr int BM = 32, BN = 32, KW = 4, NT = 256, SUB = 32, RING = 1, NV = SUB / 2;   // (SUB 16, RING 3 measured slower: 7.4 vs 6.6 us)
   constexpr int LDC = BM + 4;
-  constexpr int WAVE_F = 2 * SUB * 32;                      // floats per wave buffer: As[32 k][32] + Bs[32 k][32]
+  constexpr int WAVE_F = RING * 2 * SUB * 32;               // floats per wave: RING x {As[16 k][32] + Bs[16 k][32]}
   constexpr int EPI = KW * BN * LDC + (NT / BM) * BM;
   // LDS is padded to ~52 KiB so that at most THREE workgroups share a CU: with the 32 KiB the kernel needs the dispatcher packs
   // up to five onto some CUs and leaves others with one, and the packed CUs finish last
@@ -548,22 +590,24 @@ __global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) {
   const int rb = wk.x & 0xffff, cb = wk.x >> 16;
   const int row0 = rb * BM, col0 = cb * BN;
   const bool mu_tile = (wk.w & 2);
-  const int Kq = a.M / KW, nsub = Kq / SUB;   // this wave's k range: [w * Kq, (w + 1) * Kq)
+  const int Kq = a.M / KW, nsub = Kq / SUB;   // this wave's k range: [w * Kq, (w + 1) * Kq), in sub-stages of 16
   if (a.dbg && tid == 0 && blockIdx.x < 4096) a.dbg[((size_t)G_VJP * 4096 + blockIdx.x) * 8 + 7] = wk.x;
 
   if (FUSED && a.upd.rule == 1 && tid == 0)
     adam_bias<float>(a.upd.t_base + (a.upd.t_ptr ? *a.upd.t_ptr : 0), a.upd.b1, a.upd.b2, adam_cc[0], adam_cc[1]);
 
   // a 1 KiB piece = 8 k of 32 rows; lane -> (k = lane / 8, rows 4 (lane % 8) ..)
+  // ring of RING sub-stages of 16 k per wave: {As[16 k][32 rows], Bs[16 k][32 cols]} = 4 KiB each, 4 LDS-DMA pieces
   float *buf = lds + w * WAVE_F;
   const float *Ag = a.A + row0 + 4 * (lane & 7) + (size_t)(w * Kq + (lane >> 3)) * a.lda;
   const float *Bg = a.B + col0 + 4 * (lane & 7) + (size_t)(w * Kq + (lane >> 3)) * a.ldb;
   auto issue = [&](int t) {
     const float *pa = Ag + (size_t)(t * SUB) * a.lda, *pb = Bg + (size_t)(t * SUB) * a.ldb;
+    float *dst = buf + (t % RING) * (2 * SUB * 32);
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      MIVI_GLDS16(pa + (size_t)(8 * p) * a.lda, buf + p * 256);
-      MIVI_GLDS16(pb + (size_t)(8 * p) * a.ldb, buf + SUB * 32 + p * 256);
+    for (int p = 0; p < SUB / 8; ++p) {
+      MIVI_GLDS16(pa + (size_t)(8 * p) * a.lda, dst + p * 256);
+      MIVI_GLDS16(pb + (size_t)(8 * p) * a.ldb, dst + SUB * 32 + p * 256);
     }
   };
   f32x16 acc;
@@ -571,32 +615,42 @@ __global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) {
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float rsum = 0.f;
   // a wave that is requesting operands outranks the waves already inside their MFMA chains (which only need an issue slot
-  // every 64 cycles): without this the youngest workgroup of a CU gets its first data after the older ones are done
+  // now and then): without this the youngest workgroup of a CU gets its first data after the older ones are done
   __builtin_amdgcn_s_setprio(3);
-  if (!(a.knock & 4)) issue(0);
+  if (!(a.knock & 4))
+    for (int t = 0; t < RING && t < nsub; ++t) issue(t);
   // workgroups beyond two per CU (dispatch order = block order) arrive last and are the youngest waves of their SIMD: age
   // arbitration would give them the matrix pipe only after the older two are done -- let them go first instead
   if (blockIdx.x >= 512) __builtin_amdgcn_s_setprio(2);
   else __builtin_amdgcn_s_setprio(0);
   for (int t = 0; t < nsub; ++t) {
-    wait_vmcnt<0>();
-    float av[16], bv[16];
+    const int behind = nsub - 1 - t < RING - 1 ? nsub - 1 - t : RING - 1;   // sub-stages that may stay in flight
+    if (behind >= 2) wait_vmcnt<2 * (SUB / 4)>();
+    else if (behind == 1) wait_vmcnt<SUB / 4>();
+    else wait_vmcnt<0>();
+    const float *cur = buf + (t % RING) * (2 * SUB * 32);
+    float av[NV], bv[NV];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {   // MFMA step i uses k = 8 (i / 4) + 4 h + (i % 4) on both operands
+    for (int i = 0; i < NV; ++i) {   // the lane's k slots of this sub-stage: k = 8 (i / 4) + 4 h + (i % 4), both operands
       const int k = 8 * (i >> 2) + 4 * h + (i & 3);
-      av[i] = buf[k * 32 + l31];
-      bv[i] = buf[SUB * 32 + k * 32 + l31];
+      av[i] = cur[k * 32 + l31];
+      bv[i] = cur[SUB * 32 + k * 32 + l31];
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer is free again before the next 32 k are requested
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this ring slot is free again before it is requested anew
     if (t == 0) MIVI_STAMP_K(a.dbg, G_VJP, 1);
-    if (t + 1 < nsub && !(a.knock & 4)) issue(t + 1);
+    if (t + RING < nsub && !(a.knock & 4)) issue(t + RING);
     if (mu_tile) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) rsum += av[i];
+      for (int i = 0; i < NV; ++i) rsum += av[i];
     }
     if (!(a.knock & 2)) {
+      if (BF3) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+        for (int g = 0; g < NV / 8; ++g) mfma_bf16x3(av + 8 * g, bv + 8 * g, acc);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
+      }
     }
   }
   __builtin_amdgcn_s_barrier();   // every wave is done with its buffer: LDS becomes the epilogue image
@@ -644,7 +698,7 @@ struct Prod32Args {
   int knock;
 };
 
-template <int MODE>
+template <int MODE, bool BF3>
 __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
   constexpr int NW = 8, NT = 512, SUB = 32, LDC = 36;
   constexpr int WAVE_F = 2 * 2 * SUB * 32;   // two sub-stage buffers per wave: {As[32 k][32], Bs[32 cols][32 k]} x 2
@@ -751,8 +805,16 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
         if (8 * (i >> 2) + 4 * h + (i & 3) > l31) av[i] = 0.f;
     }
     if (!(a.knock & 2)) {
+      if (BF3) {
+        float bv[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bq[i >> 2][i & 3], acc, 0, 0, 0);
+        for (int i = 0; i < 16; ++i) bv[i] = bq[i >> 2][i & 3];
+        mfma_bf16x3(av, bv, acc);
+        mfma_bf16x3(av + 8, bv + 8, acc);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bq[i >> 2][i & 3], acc, 0, 0, 0);
+      }
     }
   }
   __builtin_amdgcn_s_barrier();   // every wave is done with its buffer: LDS becomes the epilogue image
@@ -1098,6 +1160,10 @@ static int cfg_waves() {   // MIVI_LDS_WAVES=4: one wave per SIMD (A/B against t
   static const int v = getenv("MIVI_LDS_WAVES") ? atoi(getenv("MIVI_LDS_WAVES")) : 8;
   return v;
 }
+static bool f32_mfma() {   // MIVI_FR_F32MFMA=1: v_mfma_f32_32x32x2_f32 chains instead of bf16x3 (A/B reference)
+  static const bool v = getenv("MIVI_FR_F32MFMA") != nullptr;
+  return v;
+}
 static int knock_flags() {
   static const int v = getenv("MIVI_KNOCK") ? atoi(getenv("MIVI_KNOCK")) : 0;
   return v;
@@ -1176,12 +1242,15 @@ void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int m
     a.next_eps.he_part = (double *)c->he_part[next->parity].p;
     grid += (c->cfg.d / 64) * (M / 32);
   }
-  if (dense) hipLaunchKernelGGL(k_fr_prod32<G_DENSE>, dim3(grid), dim3(512), 0, c->stream, a);
-  else hipLaunchKernelGGL(k_fr_prod32<G_SAMPLE>, dim3(grid), dim3(512), 0, c->stream, a);
+  if (dense && f32_mfma()) hipLaunchKernelGGL((k_fr_prod32<G_DENSE, false>), dim3(grid), dim3(512), 0, c->stream, a);
+  else if (dense) hipLaunchKernelGGL((k_fr_prod32<G_DENSE, true>), dim3(grid), dim3(512), 0, c->stream, a);
+  else if (f32_mfma()) hipLaunchKernelGGL((k_fr_prod32<G_SAMPLE, false>), dim3(grid), dim3(512), 0, c->stream, a);
+  else hipLaunchKernelGGL((k_fr_prod32<G_SAMPLE, true>), dim3(grid), dim3(512), 0, c->stream, a);
 }
 int lds_prod32_tiles(const mivi_ctx *c, int M) { return (c->cfg.d / 32) * (M / 32); }
 int lds_prod32_eps_blocks(const mivi_ctx *c, int M) { return (c->cfg.d / 64) * (M / 32); }
 // the unsplit product is bounded by its heaviest tile (d/32 sub-stages on one CU); beyond this the split-K route wins
+bool lds_bf16x3() { return !f32_mfma(); }
 bool lds_use_prod32(const mivi_ctx *c, int M) {
   static const int force = getenv("MIVI_LDS_SPLITK") ? atoi(getenv("MIVI_LDS_SPLITK")) : -1;   // 1: split-K always, 0: never
   if (force >= 0) return force == 0;
@@ -1227,12 +1296,11 @@ void launch_lds_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, 
     a.self_out = self->out;
     grid += 1;
   }
-  if (upd) {
-    a.upd = *upd;
-    hipLaunchKernelGGL(k_fr_vjp32<true>, dim3(grid), dim3(256), 0, c->stream, a);
-  } else {
-    hipLaunchKernelGGL(k_fr_vjp32<false>, dim3(grid), dim3(256), 0, c->stream, a);
-  }
+  if (upd) a.upd = *upd;
+  if (upd && f32_mfma()) hipLaunchKernelGGL((k_fr_vjp32<true, false>), dim3(grid), dim3(256), 0, c->stream, a);
+  else if (upd) hipLaunchKernelGGL((k_fr_vjp32<true, true>), dim3(grid), dim3(256), 0, c->stream, a);
+  else if (f32_mfma()) hipLaunchKernelGGL((k_fr_vjp32<false, false>), dim3(grid), dim3(256), 0, c->stream, a);
+  else hipLaunchKernelGGL((k_fr_vjp32<false, true>), dim3(grid), dim3(256), 0, c->stream, a);
 }
 
 }  // namespace mivi

@@ -1146,6 +1146,13 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
   return read_status(c);
 }
 
+int32_t mivi_fullrank_route(const mivi_ctx_t *c, int32_t n_samples) {
+  if (!c || c->cfg.family != MIVI_FULLRANK) return 0;
+  if (n_samples <= 0) n_samples = c->cfg.n_mc;
+  if (!lds_path_shape_ok(c, n_samples) || (c->target != TGT_DIAG_GAUSS && c->target != TGT_DENSE_GAUSS)) return 0;
+  return (lds_use_prod32(c, n_samples) ? 1 : 2) | (lds_bf16x3() ? 16 : 0);
+}
+
 mivi_status_t mivi_set_logreg_route(mivi_ctx_t *c, int32_t route) {
   if (!c || route < 0 || route > 2) return MIVI_ERR_BAD_ARG;
   c->lr_route = route;

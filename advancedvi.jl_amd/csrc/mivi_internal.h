@@ -312,6 +312,7 @@ void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int m
 int lds_prod32_tiles(const mivi_ctx *c, int M);
 int lds_prod32_eps_blocks(const mivi_ctx *c, int M);
 bool lds_use_prod32(const mivi_ctx *c, int M);
+bool lds_bf16x3();   // products on the bf16 matrix cores (three-way exact operand split); MIVI_FR_F32MFMA=1 turns it off
 void launch_lds_reduce(mivi_ctx *c, const void *params, int M, int mode, void *Z, bool want_ld);
 void launch_lds_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const ValueJob *self, const FusedUpdate *upd);
 void invalidate_graph(mivi_ctx *c);            // mivi_api.hip: drop the cached hipGraphExec and the eps speculation

@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 SEED = 0x38BEF07CF9CC549D
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
 PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA peak (155 TF measured)
+PEAK_BF16_MFMA_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 WORKLOADS = {
     "ns": dict(family=1, d=1024, n_mc=256, target="iso", entropy=0,
@@ -90,6 +91,36 @@ def mf_roofline(ctx, params, cost):
                 estimates_per_launch=100, avg_launch_us=msl * 1e3, single_call=single), {"mf_fused_main": ms1, "mf_loop_per_estimate": msl / 100}
 
 
+def fr_roofline(ctx, params, cost, w, reps=300):
+    """Full-rank roofline leg: graph-replayed launches of each stage (mivi_profile_kernel), the slower of the two
+    contractions is the dominant kernel.  Both carry d^2*M algorithmic flops (lower triangle only).  On the second-generation
+    route the products run on the bf16 matrix cores with the exact three-way operand split (six bf16 MFMAs per product
+    block): `frac` stays f32-equivalent flops / the f32-MFMA peak the north star is priced against, and `bf16_pipe` says what
+    the matrix pipe actually executes."""
+    gen, bf3 = ctx.fullrank_route()
+    stages = {"eps": ctx.profile_kernel(1, params, reps), "sample": ctx.profile_kernel(2, params, reps),
+              "vjp": ctx.profile_kernel(3, params, reps)}
+    if w["target"] == "dense":
+        stages["dense_target"] = ctx.profile_kernel(4, params, reps)
+    dom = "vjp" if stages["vjp"] >= stages["sample"] else "sample"
+    names = {0: {"vjp": "k_fr_tile_mfma<MODE_VJP,4>", "sample": "k_fr_tile_mfma<MODE_SAMPLE,8>"},
+             1: {"vjp": "k_fr_vjp32", "sample": "k_fr_prod32<SAMPLE> (product + fused target)"},
+             2: {"vjp": "k_fr_vjp32", "sample": "k_fr_gemm<SAMPLE> + k_fr_reduce (split-K)"}}[gen]
+    fl = cost["flops"] / 2
+    ach = fl / (stages[dom] * 1e-3) / 1e12
+    roof = dict(bound="mfma", kernel=names[dom], achieved=ach, peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=ach / PEAK_F32_MFMA_TF,
+                traffic=pmc_traffic({"vjp": "k_fr_vjp32", "sample": "k_fr_prod32"}[dom] if gen else ("mfmaILi1" if dom == "vjp" else "mfmaILi0")),
+                algorithmic_flops_per_launch=fl, avg_launch_us=stages[dom] * 1e3,
+                timing="hipGraph replay of %d launches, hipEvents on the launch stream" % reps,
+                other_contraction=dict(kernel=names["sample" if dom == "vjp" else "vjp"],
+                                       avg_launch_us=stages["sample" if dom == "vjp" else "vjp"] * 1e3,
+                                       achieved=fl / (stages["sample" if dom == "vjp" else "vjp"] * 1e-3) / 1e12))
+    if gen and bf3:
+        roof["bf16_pipe"] = dict(mfma="v_mfma_f32_32x32x16_bf16 x6 per product block (exact 3-way f32 split)",
+                                 executed_TFLOPs=6 * ach, peak=PEAK_BF16_MFMA_TF, frac=6 * ach / PEAK_BF16_MFMA_TF)
+    return roof, stages
+
+
 def make_problem(avi, w):
     d = w["d"]
     q = (avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32)) if w["family"] == 0
@@ -114,9 +145,12 @@ def make_problem(avi, w):
     return q, prob
 
 
-def cpu_baseline(w, params, budget_s=15.0):
+def cpu_baseline(w, params, budget_s=24.0):
     """The oracle's C leg (oracle/mivi_oracle.c: a port of the reference semantics with the closed-form VJP,
-    cheaper than the reference's AD path) timed on this box's host cores on a bounded sample."""
+    cheaper than the reference's AD path) timed on this box's host cores.  Protocol (the reference's
+    bench/benchmarks.jl:15 runs with the BLAS threads of the box): TWO team sizes -- 1 thread and every CPU this
+    process may use -- each >= 20 repetitions of one whole estimate incl. eps generation, MEDIAN reported, the whole leg
+    bounded by `budget_s` seconds of wall time (the repetition count shrinks, never below 5, if the box is slow)."""
     from oracle import c_oracle as CO
     if not os.path.exists(CO.PATH):
         import subprocess
@@ -140,26 +174,25 @@ def cpu_baseline(w, params, budget_s=15.0):
         eps = CO.fill_eps(lib, np.float32, SEED, i, d, M)
         CO.estimate_gradient(lib, np.float32, fam, d, M, params, eps, tm, ts, w["entropy"], work)
 
-    # pick the fastest OpenMP team size (more threads than useful work slows this small problem down)
-    best, cores = None, 1
-    for nt in sorted({1, 8, 16, 32, 64, 128, avail}):
-        if nt > avail:
-            continue
+    legs = {}
+    t_leg0 = time.perf_counter()
+    for nt in sorted({1, avail}):
         lib.mo32_set_threads(nt)
-        one(0)
+        one(0)                                   # warm (thread team start-up, page faults)
         t0 = time.perf_counter()
         one(1)
-        one(2)
-        t = (time.perf_counter() - t0) / 2
-        if best is None or t < best:
-            best, cores = t, nt
-    lib.mo32_set_threads(cores)
-    t1 = best
-    n = int(min(200000, max(3, budget_s / max(t1, 1e-5))))
-    t0 = time.perf_counter()
-    for i in range(n):
-        one(i + 3)
-    dt = time.perf_counter() - t0
+        t1 = time.perf_counter() - t0
+        reps = int(max(5, min(200, (budget_s / 2) / max(t1, 1e-6))))
+        reps = max(reps, 20) if 20 * t1 <= budget_s / 2 else reps
+        ts_ = []
+        for i in range(reps):
+            t0 = time.perf_counter()
+            one(i + 2)
+            ts_.append(time.perf_counter() - t0)
+        ts_.sort()
+        med = ts_[len(ts_) // 2]
+        legs[nt] = dict(threads=nt, reps=reps, median_s=med, min_s=ts_[0], max_s=ts_[-1], estimates_per_s=1.0 / med)
+    wall = time.perf_counter() - t_leg0
     model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -168,9 +201,11 @@ def cpu_baseline(w, params, budget_s=15.0):
                 break
     except OSError:
         pass
-    return dict(value=n / dt, unit="ELBO-grad-estimates/s", cores=cores, kind="port",
-                sample=f"{n} estimates of the same (d={d}, n_mc={M}) workload incl. eps generation, f32, OpenMP {cores} threads (best of the team sizes tried; {avail} CPUs available)"
-                       f" on '{model}', {dt:.1f} s", threads=lib.mo32_max_threads())
+    best = max(legs.values(), key=lambda l: l["estimates_per_s"])
+    return dict(value=best["estimates_per_s"], unit="ELBO-grad-estimates/s", cores=best["threads"], kind="port",
+                sample=f"median of {best['reps']} whole estimates of the same (d={d}, n_mc={M}) workload incl. eps generation, f32, OpenMP "
+                       f"{best['threads']} threads on '{model}' ({avail} CPUs available), leg wall time {wall:.1f} s",
+                one_thread=legs.get(1), all_cores=legs.get(avail), threads=lib.mo32_max_threads())
 
 
 def main():
@@ -181,6 +216,7 @@ def main():
     ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
     ap.add_argument("--graph-chunk", type=int, default=100, help="estimates per hipGraph replay (N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configurations (c2, ns_dense, ns_stl, c5, c3)")
     ap.add_argument("--concurrent", type=int, default=4,
                     help="extra (non-headline) leg: this many independent estimator contexts on separate HIP streams")
     args = ap.parse_args()
@@ -334,19 +370,7 @@ def main():
                 if w["family"] == 0:
                     roof, stages = mf_roofline(ctx, params, cost)
                 else:
-                    stages = {"eps": ctx.profile_kernel(1, params, reps), "sample": ctx.profile_kernel(2, params, reps),
-                              "vjp": ctx.profile_kernel(3, params, reps)}
-                    if w["target"] == "dense":
-                        stages["dense_target"] = ctx.profile_kernel(4, params, reps)
-                    # both contractions carry d^2*M algorithmic flops (lower triangle only); report the slower one
-                    dom = "vjp" if stages["vjp"] >= stages["sample"] else "sample"
-                    kname = {"vjp": "k_fr_tile_mfma<MODE_VJP,4>", "sample": "k_fr_tile_mfma<MODE_SAMPLE,8>"}[dom]
-                    fl = cost["flops"] / 2
-                    ach = fl / (stages[dom] * 1e-3) / 1e12
-                    roof = dict(bound="mfma", kernel=kname, achieved=ach, peak=PEAK_F32_MFMA_TF, unit="TFLOP/s",
-                                frac=ach / PEAK_F32_MFMA_TF,
-                                traffic=pmc_traffic("mfmaILi1" if dom == "vjp" else "mfmaILi0"), algorithmic_flops_per_launch=fl,
-                                avg_launch_us=stages[dom] * 1e3)
+                    roof, stages = fr_roofline(ctx, params, cost, w)
                 stages = {k: round(v * 1e3, 3) for k, v in stages.items()}   # us
             whole = dict(hbm_equiv_GBs=cost["bytes"] * est_per_s / world / 1e9,
                          hbm_equiv_frac_of_8TBs=cost["bytes"] * est_per_s / world / 1e9 / PEAK_HBM_GBS,
@@ -382,28 +406,72 @@ def main():
                 for cx in ctxs:
                     cx.close()
             # ---- BASELINE configs[1] (mean-field d=1024, n_mc=256) measured alongside the north-star workload ----
+            # ---- the other BASELINE configurations, measured alongside the north-star line (N = 1) -----------------
+            # each: a steady-state leg of >= 1000 estimates (hipGraph x100 where the target is graph-capturable) independent of
+            # the driver's --steps, and its own roofline block
             also = None
-            if single and args.workload == "ns":
-                w2 = WORKLOADS["c2"]
-                q2, prob2 = make_problem(avi, w2)
-                p2h, _ = avi.destructure(q2)
-                cx = avi.MiviContext(np.float32, w2["family"], w2["d"], w2["n_mc"], w2["entropy"], SEED, device=local_rank)
-                cx.set_problem(prob2)
-                p2 = cx.to_device(p2h)
-                v2, g2 = cx.empty(1), cx.empty(cx.params_len)
-                cx.estimate_gradient_n(p2, 0, 100, v2, g2)
+            steady = None
+            if single:
+                n_ss = 1000
+                run(W + K, chunk)          # (graph already instantiated)
                 stream.synchronize()
-                n2 = 50
-                t20 = time.perf_counter()
-                for r in range(n2):
-                    cx.estimate_gradient_n(p2, 100 * (r + 1), 100, v2, g2)
+                t0s = time.perf_counter()
+                run(W + K + chunk, n_ss)
                 stream.synchronize()
-                t2 = time.perf_counter() - t20
-                c2cost = algorithmic_cost(w2)
-                roof2, _ = mf_roofline(cx, p2, c2cost)
-                also = {"c2": dict(workload=w2["name"], value=n2 * 100 / t2, unit="estimates/s", us_per_step=t2 / (n2 * 100) * 1e6,
-                                   roofline=roof2)}
-                cx.close()
+                tss = time.perf_counter() - t0s
+                steady = dict(estimates=n_ss, us_per_step=tss / n_ss * 1e6, estimates_per_s=n_ss / tss)
+            if single and args.workload == "ns" and not args.no_also:
+                also = {}
+                for wn in ("c2", "ns_dense", "ns_stl", "c5") + (() if os.environ.get("MIVI_BENCH_SKIP_C3") else ("c3",)):
+                    w2 = WORKLOADS[wn]
+                    q2, prob2 = make_problem(avi, w2)
+                    p2h, _ = avi.destructure(q2)
+                    cx = avi.MiviContext(np.float32, w2["family"], w2["d"], w2["n_mc"], w2["entropy"], SEED, device=local_rank)
+                    cx.set_problem(prob2)
+                    p2 = cx.to_device(p2h)
+                    v2, g2 = cx.empty(1), cx.empty(cx.params_len)
+                    graphable = w2["target"] != "logreg"
+                    n_est = 1000 if graphable else 40
+
+                    def run2(i0, n):
+                        if graphable:
+                            for r in range(n // 100):
+                                cx.estimate_gradient_n(p2, i0 + 100 * r, 100, v2, g2)
+                        else:
+                            for i in range(n):
+                                cx.estimate_gradient(p2, i0 + i, v2, g2)
+                    run2(0, 100 if graphable else 3)
+                    stream.synchronize()
+                    t20 = time.perf_counter()
+                    run2(100, n_est)
+                    stream.synchronize()
+                    t2 = (time.perf_counter() - t20) / n_est
+                    c2cost = algorithmic_cost(w2)
+                    if w2["target"] == "logreg":
+                        n, pdim, M2 = w2["n"], w2["d"] - 1, w2["n_mc"]
+                        fl = 4.0 * n * pdim * M2                      # logits X beta and X^T R, 2 flops per MAC
+                        by = 2.0 * n * pdim * 4 + 2.0 * n * M2 * 4     # X read once per contraction, R written + read
+                        roof2 = dict(bound="mfma", kernel="k_lr_logits_bf16x3 + k_lr_xtr_bf16x3", achieved=fl / t2 / 1e12,
+                                     peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=fl / t2 / 1e12 / PEAK_F32_MFMA_TF,
+                                     note="f32-equivalent flops of the two data contractions / the f32-MFMA peak (the kernels run the exact "
+                                          "3-way bf16 split on the bf16 pipe: x6 executed flops, peak 2500 TF)",
+                                     bf16_pipe=dict(executed_TFLOPs=6 * fl / t2 / 1e12, peak=PEAK_BF16_MFMA_TF, frac=6 * fl / t2 / 1e12 / PEAK_BF16_MFMA_TF),
+                                     hbm=dict(achieved_GBs=by / t2 / 1e9, peak=PEAK_HBM_GBS, frac=by / t2 / 1e9 / PEAK_HBM_GBS,
+                                              bytes_per_estimate=by), traffic=None)
+                    elif w2["family"] == 0:
+                        try:
+                            roof2, _ = mf_roofline(cx, p2, c2cost)
+                        except Exception:   # noqa: BLE001  -- stage hook not applicable to this target: whole-estimate HBM equivalent
+                            roof2 = dict(bound="hbm", kernel="k_mf_main<float> (+ value / row-0 finisher)", achieved=c2cost["bytes"] / t2 / 1e9,
+                                         peak=PEAK_HBM_GBS, unit="GB/s", frac=c2cost["bytes"] / t2 / 1e9 / PEAK_HBM_GBS, traffic=None,
+                                         algorithmic_bytes_per_launch=c2cost["bytes"], avg_launch_us=t2 * 1e6,
+                                         note="whole estimate (hipGraph steady state), not a single kernel")
+                    else:
+                        roof2, _ = fr_roofline(cx, p2, c2cost, w2, reps=100)
+                    also[wn] = dict(workload=w2["name"], value=1.0 / t2, unit="estimates/s", us_per_step=t2 * 1e6, estimates=n_est,
+                                    launch="hipGraph x100" if graphable else "eager", roofline=roof2)
+                    cx.close()
+                    del prob2, q2
             # ---- parity + cpu_baseline leg (rank 0, N = 1 only) ---------------------------------------------
             rel = None
             cpub = None
@@ -427,7 +495,7 @@ def main():
                            "family": "fullrank" if w["family"] else "meanfield", "seed": hex(SEED),
                            "launch": f"hipGraph x{chunk}" if single else (f"CUDAGraph x{chunk} incl. RCCL all-reduce" if graph is not None else "eager + RCCL all-reduce")},
                 "roofline": roof, "cpu_baseline": cpub,
-                "elbo_rel_err_vs_cpu_fp64": rel, "stage_us": stages, "whole_estimate": whole, "concurrent": conc, "also": also,
+                "elbo_rel_err_vs_cpu_fp64": rel, "stage_us": stages, "whole_estimate": whole, "steady_state": steady, "concurrent": conc, "also": also,
             }
         if dist:
             dist.barrier()

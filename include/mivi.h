@@ -254,9 +254,17 @@ mivi_status_t mivi_set_logreg_route(mivi_ctx_t *ctx, int32_t route);
  * stream (after one full warm estimate so every input buffer is populated).
  *   which: 0 = whole estimate, 1 = eps generation, 2 = sample(+fused target) kernel (mean-field: the fused main kernel),
  *          3 = VJP kernel, 4 = dense-target kernel, 5 = the launch-free loop of 100 estimates (mean-field + diagonal
- *          target; what mivi_estimate_gradient_n runs there).  ms_per_launch_host: double[1]. */
+ *          target; what mivi_estimate_gradient_n runs there), 6 / 7 = the split-K product / its reduce kernel alone
+ *          (second-generation full-rank route only).  Stages 1-4, 6, 7 are captured `reps` times into one hipGraph and the
+ *          replay is timed (eager launches of 2-5 us kernels are host-bound); 0 and 5 are eager.  ms_per_launch_host: double[1]. */
 mivi_status_t mivi_profile_kernel(mivi_ctx_t *ctx, int32_t which, const void *params_dev, int32_t reps,
                                   double *ms_per_launch_host);
+
+/* Which kernels the full-rank f32 path runs for `n_samples` per launch on this context (measurement / documentation hook):
+ *   bits 0-1: 0 = first generation (32x32 tiles fed from L2, any shape), 1 = unsplit 32x32 product with fused target
+ *             (k_fr_prod32) + private-wave VJP (k_fr_vjp32), 2 = split-K LDS-staged product + reduce (k_fr_gemm, k_fr_reduce)
+ *             + k_fr_vjp32;   bit 4: products on the bf16 matrix cores with the exact three-way operand split. */
+int32_t mivi_fullrank_route(const mivi_ctx_t *ctx, int32_t n_samples);
 
 /* Developer tool: when buf_dev != NULL every workgroup of the main kernels records wall_clock64() stamps
  * (100 MHz) at buf_dev[block*8 + phase].  NULL switches it off.  Not part of the drop-in surface. */

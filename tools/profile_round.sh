@@ -9,7 +9,7 @@ OUT=$REPO/gpurun_out/summ
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline --concurrent 1"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-also --concurrent 1"
 for w in ns c2 ns_stl ns_dense c3 c5; do
   steps=200; [ $w = c3 ] && steps=20; [ $w = ns_stl ] && steps=100
   rm -rf /tmp/prof_$w
