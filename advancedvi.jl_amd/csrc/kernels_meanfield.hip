@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_mf_sgd_loop(MfLoopArgs<T> a) {
   const double direct = direct_entropy_coeff(a.ent_kind);
   const double invM = 1.0 / (double)a.M_total;
   const T eta = (T)a.eta, b1 = (T)a.b1, b2 = (T)a.b2, aeps = (T)a.adam_eps, ceps = (T)a.clip_eps;
-  const bool clip = a.clip_eps > 0.0;
+  const bool clip = a.clip_eps == a.clip_eps;   // NaN = no ClipScale (a real epsilon <= 0 is still a ClipScale)
   // every lane holds the four (mu, sigma) rows of this workgroup; lane j < 8 additionally owns the optimiser state
   // of row j (j < 4: mu_j, j >= 4: sigma_{j-4}) and performs that row's update, which is then broadcast
   T mu[4], sg[4], tm[4], tis[4];

@@ -165,7 +165,7 @@ void launch_prox(mivi_ctx *c, void *params, double stepsize, const void *dog_sta
                        stepsize, sc, dog_kind);
 }
 
-// is flat index i a scale-diagonal entry? (ClipScale fused into the update, clip_eps > 0)
+// is flat index i a scale-diagonal entry? (ClipScale fused into the update; clip_eps = NaN means "no ClipScale": any real epsilon, also <= 0, is a legal one)
 __device__ __forceinline__ bool is_scale_diag(int64_t i, int d, int family) {
   if (i < d) return false;
   if (family == MIVI_MEANFIELD) return true;
@@ -177,7 +177,7 @@ template <typename T>
 __global__ void k_descent(int64_t n, T *params, const T *grad, T eta, int d, int family, T clip_eps) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     T x = descent_step(params[i], grad[i], eta);
-    if (clip_eps > T(0) && is_scale_diag(i, d, family)) x = clip_step(x, clip_eps);
+    if (clip_eps == clip_eps && is_scale_diag(i, d, family)) x = clip_step(x, clip_eps);
     params[i] = x;
   }
 }
@@ -204,7 +204,7 @@ __global__ void k_adam(int64_t n, T *params, const T *grad, T *state, const int6
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     T m = state[i], v = state[n + i];
     T x = adam_step<T>(params[i], grad[i], m, v, c1, c2, (T)eta, (T)b1, (T)b2, (T)eps);
-    if (clip_eps > T(0) && is_scale_diag(i, d, family)) x = clip_step(x, clip_eps);
+    if (clip_eps == clip_eps && is_scale_diag(i, d, family)) x = clip_step(x, clip_eps);
     params[i] = x;
     state[i] = m;
     state[n + i] = v;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(1024) void k_dog_init(int64_t n, const T *params, T
 // FUSE: ClipScale and PolynomialAveraging folded into the apply loop (device-resident loop), same per-element arithmetic
 template <typename T, bool FUSE = false>
 __global__ __launch_bounds__(1024) void k_dog_update(int64_t n, T *params, const T *grad, const T *x0, double *sc, int kind,
-                                                     int d = 0, int family = 0, T clip_eps = T(0), T *avg = nullptr,
+                                                     int d = 0, int family = 0, T clip_eps = T(NAN), T *avg = nullptr,
                                                      double avg_eta = 0.0, const long long *t_ptr = nullptr, long long t_base = 0) {
   __shared__ double red[16];
   double dist2 = 0.0, g2 = 0.0;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(1024) void k_dog_update(int64_t n, T *params, const
     }
     for (int64_t i = threadIdx.x; i < n; i += 1024) {
       T x = (T)((double)params[i] - eta * (double)grad[i]);
-      if (clip_eps > T(0) && is_scale_diag(i, d, family)) x = clip_step(x, clip_eps);
+      if (clip_eps == clip_eps && is_scale_diag(i, d, family)) x = clip_step(x, clip_eps);
       params[i] = x;
       if (avg) avg[i] = (T)(wa * (double)x + wb * (double)avg[i]);
     }
@@ -409,7 +409,7 @@ __global__ void k_dog_apply_fused(int64_t n, T *params, const T *grad, const dou
   }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     T x = (T)((double)params[i] - eta * (double)grad[i]);
-    if (clip_eps > T(0) && is_scale_diag(i, d, family)) x = clip_step(x, clip_eps);
+    if (clip_eps == clip_eps && is_scale_diag(i, d, family)) x = clip_step(x, clip_eps);
     params[i] = x;
     if (avg) avg[i] = (T)(wa * (double)x + wb * (double)avg[i]);
   }

@@ -763,6 +763,8 @@ __global__ void k_neg_value_f32(float *out, const double *elbo) { out[0] = (floa
 __global__ void k_neg_value_f64(double *out, const double *elbo) { out[0] = -elbo[0]; }
 __global__ void k_store_value_f32(float *out, const double *acc) { out[0] = (float)acc[0]; }
 __global__ void k_store_value_f64(double *out, const double *acc) { out[0] = acc[0]; }
+// device counters of the graph-batched calls, set BY VALUE (an async copy from a stack local may outlive the caller's frame)
+__global__ void k_set_u64x2(uint64_t *dst, uint64_t a, uint64_t b, int n) { dst[0] = a; if (n > 1) dst[1] = b; }
 
 mivi_status_t mivi_estimate_objective(mivi_ctx_t *c, const void *params, uint64_t idx, int32_t n_samples, int32_t entropy,
                                       void *value) {
@@ -921,6 +923,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
                                        void *grad) {
   if (!c || !params || !value || !grad || count <= 0) return MIVI_ERR_BAD_ARG;
   if (!graph_capturable(c)) return fail(c, MIVI_ERR_UNSUPPORTED, "graph batching needs a device-resident built-in target");
+  if (c->idx_src) return fail(c, MIVI_ERR_UNSUPPORTED, "an index source is set (mivi_set_index_source): graph-batched calls keep their own device counter");
   (void)hipSetDevice(c->cfg.device);
   mivi_status_t s = ensure_work(c, c->cfg.n_mc);
   if (s) return s;
@@ -933,7 +936,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
     const size_t hist_doubles = (size_t)count * 4 * (size_t)((c->cfg.d + 3) / 4);
     if ((s = ensure(c, c->X, ((size_t)count + hist_doubles + 8) * sizeof(double), false))) return s;
     double *rec = (double *)c->X.p;
-    launch_mf_sgd_loop(c, const_cast<void *>(params), nullptr, idx0, 0, count, -1, 0.0, 0.0, rec + count, rec, grad);
+    launch_mf_sgd_loop(c, const_cast<void *>(params), nullptr, idx0, 0, count, -1, 0.0, (double)NAN, rec + count, rec, grad);
     if (c->cfg.dtype == MIVI_F32) hipLaunchKernelGGL(k_neg_value_f32, dim3(1), dim3(1), 0, c->stream, (float *)value, rec + count - 1);
     else hipLaunchKernelGGL(k_neg_value_f64, dim3(1), dim3(1), 0, c->stream, (double *)value, rec + count - 1);
     HIPCHK(c, hipGetLastError());
@@ -965,7 +968,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
     (void)hipGraphDestroy(graph);
     g.kind = 1; g.count = count; g.params = params; g.value = value; g.grad = grad;
   }
-  HIPCHK(c, hipMemcpyAsync(c->d_idx.p, &idx0, sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, idx0, 0ull, 1);
   HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
   return MIVI_OK;
 }
@@ -1051,13 +1054,14 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
   if (l.averager == 1 && !l.avg_params_dev) return fail(c, MIVI_ERR_BAD_ARG, "PolynomialAveraging needs avg_params_dev");
   if (l.op == 2 && rule == 1) return fail(c, MIVI_ERR_BAD_ARG, "ProximalLocationScaleEntropy does not support Adam (Descent, DoG, DoWG)");
   if (!graph_capturable(c)) return fail(c, MIVI_ERR_UNSUPPORTED, "device-resident loop needs a built-in target");
+  if (c->idx_src) return fail(c, MIVI_ERR_UNSUPPORTED, "an index source is set (mivi_set_index_source): the device-resident loop keeps its own counter");
   (void)hipSetDevice(c->cfg.device);
   mivi_status_t s = ensure_work(c, c->cfg.n_mc);
   if (s) return s;
   prepare_tables(c, c->cfg.n_mc);
   if ((s = reserve_target(c, c->cfg.n_mc))) return s;
   const size_t plen = (size_t)mivi_params_len(c), es = c->esize;
-  const double eta = l.eta, clip_eps = (l.op == 1) ? l.clip_epsilon : 0.0;
+  const double eta = l.eta, clip_eps = (l.op == 1) ? l.clip_epsilon : (double)NAN;   // NaN = no ClipScale
   void *opt_state = l.opt_state_dev;
   // internal value/grad/elbo-record buffers
   const size_t hist_doubles = (size_t)n_steps * 4 * (size_t)((c->cfg.d + 3) / 4);
@@ -1139,8 +1143,8 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     g.kind = 9; g.count = n_steps; g.params = params; g.value = vbuf;
     g.loop = l;
   }
-  uint64_t hdr[2] = {l.estimate_idx0, (uint64_t)l.t0};
-  HIPCHK(c, hipMemcpyAsync(c->d_idx.p, hdr, sizeof(hdr), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, l.estimate_idx0, (uint64_t)l.t0, 2);
+  HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream));   // a stale flag of earlier host-driven estimates is not this run's
   HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
   if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
   return read_status(c);
@@ -1225,7 +1229,7 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
       case 6: launch_lds_sample(c, params, M); break;
       case 7: launch_lds_reduce(c, params, M, c->target == TGT_DENSE_GAUSS ? R_DENSE_R : R_DIAG, nullptr, true); break;
       case 5:
-        launch_mf_sgd_loop(c, const_cast<void *>(params), nullptr, (uint64_t)r * 100, 0, 100, -1, 0.0, 0.0, (double *)c->X.p + 100,
+        launch_mf_sgd_loop(c, const_cast<void *>(params), nullptr, (uint64_t)r * 100, 0, 100, -1, 0.0, (double)NAN, (double *)c->X.p + 100,
                            (double *)c->X.p, o + 16);
         break;
       default:

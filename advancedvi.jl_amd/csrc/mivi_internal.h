@@ -1,6 +1,7 @@
 // Internal declarations shared by the libmivi translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include <string>
@@ -334,9 +335,9 @@ bool launch_dog_update_fused(mivi_ctx *c, void *params, const void *grad, void *
 void launch_logreg_gather(mivi_ctx *c, int64_t b);   // batch rows lr_idx[0..b) of the full data set -> lr_Xsub / lr_ysub / lr_Xrm_sub
 void launch_value_only(mivi_ctx *c, const void *params, const ValueIn &vin, const OutArgs &out);   // on c->stream
 void launch_clip(mivi_ctx *c, void *params, double epsilon);
-void launch_descent(mivi_ctx *c, void *params, const void *grad, double eta, double clip_eps = 0.0);
+void launch_descent(mivi_ctx *c, void *params, const void *grad, double eta, double clip_eps = NAN);   // NaN: no ClipScale
 void launch_adam(mivi_ctx *c, void *params, const void *grad, void *state, const int64_t *t_ptr, int64_t t_base,
-                 double eta, double b1, double b2, double eps, double clip_eps = 0.0);
+                 double eta, double b1, double b2, double eps, double clip_eps = NAN);
 void launch_bump(mivi_ctx *c, uint64_t *ctr, uint64_t by);
 
 }  // namespace mivi

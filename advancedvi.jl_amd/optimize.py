@@ -267,10 +267,23 @@ def _optimize_on_device(rng, alg, max_iter, state, codes, show_progress):
     params = state["params"]
     opt, info_total = alg.optimizer, []
     done = 0
+    import torch
+
+    def _tensors(x):   # the device tensors inside an optimiser / averager state (tensor, tuple of tensors and scalars, None)
+        if torch.is_tensor(x):
+            return [x]
+        if isinstance(x, (tuple, list)):
+            return [t for e in x for t in _tensors(e)]
+        return []
+
     while done < max_iter:
         n = min(DEVICE_LOOP_CHUNK, max_iter - done)
         elbo = ctx.empty(n)
         avg_params = state["avg_st"][0] if avg == 1 else None
+        # what a divergence inside the chunk must not destroy: the reference throws AT the offending step, before
+        # Optimisers.update! (common.jl:83-94), leaving every earlier step applied
+        live = [params] + _tensors(state["opt_st"]) + _tensors(state["avg_st"])
+        snap = [t.clone() for t in live]
         try:
             ctx.optimize_loop(params, n, rng.counter, state["iteration"], rule=rule, op=op, averager=avg,
                               eta=getattr(opt, "eta", 0.0), beta=getattr(opt, "beta", (0.9, 0.999)),
@@ -281,6 +294,18 @@ def _optimize_on_device(rng, alg, max_iter, state, codes, show_progress):
             if e.status == 6 and done == 0:      # MIVI_ERR_UNSUPPORTED: not a device-resident target
                 return None
             if e.status in (2, 3):               # common.jl:83-89 (a non-positive scale makes the objective NaN)
+                # the chunk ran past the bad step: restore its entry state and replay it on the host-driven loop, which raises
+                # at the offending iteration with the steps before it applied and rng / iteration advanced consistently
+                for t_live, t_snap in zip(live, snap):
+                    t_live.copy_(t_snap)
+                try:
+                    ctx.synchronize()            # drop the sticky device flag of the failed chunk
+                except MiviError:
+                    pass
+                for _ in range(n):
+                    new_state, _, info = step(rng, alg, state, None)
+                    state.update(new_state)
+                    info_total.append({**info, "iteration": state["iteration"]})
                 raise RuntimeError("The objective value is not finite. This indicates that the optimization run diverged.") from e
             raise
         for _ in range(n):

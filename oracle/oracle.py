@@ -468,6 +468,34 @@ def dog_step(params, grad, state, kind):
 
 
 # --------------------------------------------------------------------------------------
+# Optimisers.jl rules used by `step` (src/algorithms/common.jl:92: `Optimisers.update!(opt_st, params, grad)`).
+# Optimisers.jl is a dependency of the reference, NOT vendored in /root/reference (Project.toml:49 pins
+# "0.2.16, 0.3, 0.4"); what follows restates its published rules (Optimisers.jl src/rules.jl, `apply!`):
+#   Descent(eta):            dx' = eta * dx;                                   x <- x - dx'
+#   Adam(eta, (b1, b2), eps): mt <- b1 mt + (1 - b1) dx;  vt <- b2 vt + (1 - b2) dx^2;
+#                            dx' = mt / (1 - b1^t) / (sqrt(vt / (1 - b2^t)) + eps) * eta;   x <- x - dx'
+#                            (state (mt, vt, beta^t) starts at (0, 0, beta): the first step divides by 1 - beta)
+# Arithmetic is carried in `dtype` (Optimisers keeps the parameter eltype), so an f32 run can be followed to the ulp level.
+# --------------------------------------------------------------------------------------
+def descent_step(params, grad, eta, dtype=np.float64):
+    x = np.asarray(params, dtype=dtype)
+    return (x - dtype(eta) * np.asarray(grad, dtype=dtype)).astype(dtype)
+
+
+def adam_step(params, grad, state, t, eta=1e-3, beta=(0.9, 0.999), eps=1e-8, dtype=np.float64):
+    """One Adam update at step t (1-based); state = (mt, vt) arrays (zeros before the first step)."""
+    x, g = np.asarray(params, dtype=dtype), np.asarray(grad, dtype=dtype)
+    mt, vt = (np.asarray(s, dtype=dtype) for s in state)
+    b1, b2 = dtype(beta[0]), dtype(beta[1])
+    mt = b1 * mt + (dtype(1) - b1) * g
+    vt = b2 * vt + (dtype(1) - b2) * g * g
+    c1 = dtype(1.0 - float(beta[0]) ** t)
+    c2 = dtype(1.0 - float(beta[1]) ** t)
+    step = (dtype(eta) * (mt / c1)) / (np.sqrt(vt / c2) + dtype(eps))
+    return (x - step).astype(dtype), (mt.astype(dtype), vt.astype(dtype))
+
+
+# --------------------------------------------------------------------------------------
 # Counter-based RNG: Philox4x32-10 + Box-Muller (the eps stream of the HIP kernels)
 # --------------------------------------------------------------------------------------
 _PHILOX_M0 = np.uint64(0xD2511F53)

@@ -101,7 +101,7 @@ def test_convergence_host_loop(entropy, family):
     assert d1 <= d0 / 2
 
 
-@pytest.mark.parametrize("shape", [(64, 32), (70, 19)], ids=["aligned", "ragged"])
+@pytest.mark.parametrize("shape", [(64, 32), (70, 19), (128, 128)], ids=["aligned", "ragged", "gen2"])
 @pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
 @pytest.mark.parametrize("rule", [0, 1], ids=["descent", "adam"])
 def test_device_resident_loop_matches_host_loop(family, rule, shape):
@@ -140,7 +140,71 @@ def test_device_resident_loop_matches_host_loop(family, rule, shape):
     ctx.synchronize()
     assert np.array_equal(p.cpu().numpy(), p2.cpu().numpy())
     assert np.allclose(elbo.cpu().numpy(), np.array(elbos, dtype=np.float32), rtol=1e-6)
-    # and the first step agrees with the oracle's gradient step
+    # and the whole trajectory agrees with an independent restatement: oracle gradient (on the device's own eps) ->
+    # numpy Descent / Adam (oracle.descent_step / adam_step, Optimisers.jl semantics) -> ClipScale, followed in f64
+    x = p0.astype(np.float64)
+    ost = (np.zeros_like(x), np.zeros_like(x))
+    tgt = O.DiagNormalTarget(tm, ts)
+    for t in range(3):
+        _, eps = ctx.sample(x.astype(np.float32), 100 + t)
+        ref = O.estimate_gradient(x.astype(np.float32).astype(np.float64), d, family, tgt, eps.cpu().numpy().astype(np.float64), 0)
+        if rule == 0:
+            x = O.descent_step(x, ref["grad"], eta)
+        else:
+            x, ost = O.adam_step(x, ref["grad"], ost, t + 1, eta)
+        x = O.clip_scale(x, d, family, 1e-5)
+    p3 = ctx.to_device(p0).clone()
+    st3 = ctx.empty(2 * p3.numel()).zero_()
+    ctx.optimize_steps(p3, st3 if rule == 1 else None, 100, 0, 3, rule, eta, 1e-5, ctx.empty(3))
+    ctx.synchronize()
+    got = p3.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got - x)) <= 5e-6 * max(1.0, np.max(np.abs(x))), np.max(np.abs(got - x))
+    ctx.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
+def test_update_and_projection_kernels_match_the_numpy_restatement(family, dtype):
+    """mivi_descent_update / mivi_adam_update / mivi_clip_scale against oracle.descent_step / adam_step / clip_scale
+    (Optimisers.jl Descent / Adam, src/optimization/clip_scale.jl:18-29) on a fixed gradient sequence: f32 to the ulp level
+    (the restatement carries f32 arithmetic), f64 to 1e-13."""
+    d = 37
+    rng = np.random.default_rng(11)
+    ctx = avi.MiviContext(dtype, family, d, 4, 0, SEED)
+    plen = ctx.params_len
+    x0 = rng.normal(size=plen).astype(dtype)
+    if family == avi.FULLRANK:
+        C = np.tril(x0[d:].reshape(d, d, order="F"))
+        x0[d:] = C.reshape(-1, order="F")
+    idx = d + np.arange(d) if family == avi.MEANFIELD else d + np.arange(d) * (d + 1)
+    x0[idx] = rng.uniform(-0.5, 1.5, d).astype(dtype)        # some diagonals below the clip threshold (incl. negative)
+    grads = [rng.normal(size=plen).astype(dtype) * dtype(10.0 ** rng.integers(-3, 2)) for _ in range(4)]
+    if family == avi.FULLRANK:   # the estimator's gradient is exactly zero above the diagonal
+        for g in grads:
+            g[d:] = np.tril(g[d:].reshape(d, d, order="F")).reshape(-1, order="F")
+    tol = 1e-13 if dtype == np.float64 else 4 * np.finfo(np.float32).eps
+    # Descent
+    x = x0.copy()
+    p = ctx.to_device(x0).clone()
+    for g in grads:
+        ctx.descent_update(p, ctx.to_device(g), 0.0625)
+        x = O.descent_step(x, g, 0.0625, dtype=dtype)
+    assert np.max(np.abs(p.cpu().numpy().astype(np.float64) - x) / np.maximum(1.0, np.abs(x))) <= tol
+    # Adam (bias correction in t), then ClipScale
+    x, st = x0.copy(), (np.zeros(plen, dtype), np.zeros(plen, dtype))
+    p = ctx.to_device(x0).clone()
+    dst = ctx.empty(2 * plen).zero_()
+    for t, g in enumerate(grads):
+        ctx.adam_update(p, ctx.to_device(g), dst, t + 1, 1e-2)
+        x, st = O.adam_step(x, g, st, t + 1, 1e-2, dtype=dtype)
+    got = p.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got - x) / np.maximum(1.0, np.abs(x))) <= 8 * tol
+    assert np.max(np.abs(dst.cpu().numpy()[:plen].astype(np.float64) - st[0])) <= 8 * tol * max(1.0, np.max(np.abs(st[0])))
+    ctx.clip_scale(p, 1e-5)
+    ref = O.clip_scale(got, d, family, 1e-5)
+    out = p.cpu().numpy().astype(np.float64)
+    assert np.array_equal(out[idx], np.maximum(got[idx], dtype(1e-5)).astype(np.float64))
+    assert np.max(np.abs(out - ref)) <= 1e-7        # (the oracle's threshold is the f64 1e-5, the kernel's the dtype's)
     ctx.close()
 
 
@@ -357,3 +421,74 @@ def test_optimize_falls_back_to_the_host_loop_for_plugin_targets_and_callbacks()
     avi.optimize(avi.PhiloxRNG(1), alg, 5, avi.DiagNormalProblem(np.zeros(d), np.ones(d)), q0,
                  callback=lambda **kw: seen.append(kw["iteration"]))
     assert seen == [1, 2, 3, 4, 5]
+
+
+def test_cached_graph_survives_a_capacity_change():
+    """A captured loop bakes work-buffer pointers and leading dimensions; an objective estimate with more samples than n_mc
+    reallocates them.  The next loop call must not replay into freed memory (round-1 advisor finding): same result as a
+    context that never grew."""
+    d, M, T = 128, 128, 6
+    rng = np.random.default_rng(21)
+    tm, ts = rng.normal(size=d).astype(np.float32), rng.uniform(0.5, 2, size=d).astype(np.float32)
+    q0 = avi.FullRankGaussian(np.zeros(d, np.float32), np.eye(d, dtype=np.float32))
+    p0, _ = avi.destructure(q0)
+    outs = []
+    for grow in (False, True):
+        ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+        ctx.set_problem(avi.DiagNormalProblem(tm, ts))
+        p = ctx.to_device(p0).clone()
+        st = ctx.empty(2 * p.numel()).zero_()
+        ctx.optimize_steps(p, st, 0, 0, T, 1, 1e-2, 1e-5)
+        if grow:
+            ctx.estimate_objective(p, 99, n_samples=4 * M)       # M grows: work buffers are reallocated
+        ctx.optimize_steps(p, st, T, T, T, 1, 1e-2, 1e-5)
+        ctx.synchronize()
+        outs.append(p.cpu().numpy().copy())
+        ctx.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
+def test_clipscale_with_nonpositive_epsilon_is_the_same_on_both_loops(family):
+    """ClipScale(epsilon <= 0) still clamps negative diagonals to epsilon (clip_scale.jl:18-29): the device-resident loop must
+    not read `epsilon <= 0` as `no operator` (round-1 advisor finding)."""
+    d, M = 64, 32
+    rng = np.random.default_rng(22)
+    tm, ts = rng.normal(size=d).astype(np.float32), rng.uniform(0.5, 2, size=d).astype(np.float32)
+    scale = -0.5 * np.ones(d, np.float32)            # negative diagonals: only a ClipScale can repair them
+    q0 = avi.MeanFieldGaussian(np.zeros(d, np.float32), scale) if family == avi.MEANFIELD else \
+        avi.FullRankGaussian(np.zeros(d, np.float32), np.diag(scale).astype(np.float32))
+    res = []
+    for dev in (True, False):
+        alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), optimizer=avi.Descent(1e-3), n_samples=M, operator=avi.ClipScale(0.0),
+                                      averager=avi.NoAveraging())
+        try:
+            out, info, st = avi.optimize(avi.PhiloxRNG(SEED), alg, 3, avi.DiagNormalProblem(tm, ts), q0, device_loop=dev)
+            res.append(("ok", st["params"].cpu().numpy().copy()))
+        except RuntimeError as e:
+            res.append(("diverged", str(e)))
+    assert res[0][0] == res[1][0]
+    if res[0][0] == "ok":
+        assert np.array_equal(res[0][1], res[1][1])
+
+
+def test_divergence_inside_a_device_chunk_leaves_the_host_loop_state():
+    """A run that diverges at step k: the device loop must raise with the steps before k applied and rng / iteration
+    advanced exactly like the host-driven loop (the reference throws at the offending step, common.jl:83-89)."""
+    d, M = 16, 16
+    tm, ts = np.full(d, 5.0, np.float32), np.full(d, 0.3, np.float32)
+    q0 = avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32))
+    states = []
+    for dev in (True, False):
+        alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), optimizer=avi.Descent(3.0e1), n_samples=M, operator=avi.IdentityOperator(),
+                                      averager=avi.NoAveraging())
+        rng = avi.PhiloxRNG(SEED)
+        st = avi.init(rng, alg, q0, avi.DiagNormalProblem(tm, ts))
+        with pytest.raises(RuntimeError):
+            for _ in range(4):                       # chunks of the public API; the failure is somewhere inside
+                _, _, st = avi.optimize(rng, alg, 50, state=st, device_loop=dev)
+        states.append((st["iteration"], rng.counter, st["params"].cpu().numpy().copy()))
+    # the failing call raises before returning its state: compare what the caller still holds + the rng position
+    assert states[0][0] == states[1][0]
+    assert states[0][1] == states[1][1]
+    assert np.array_equal(states[0][2], states[1][2], equal_nan=True)
