@@ -17,7 +17,7 @@ from .optimize import (KLMinRepGradDescent, KLMinRepGradProxDescent, ADVI, ClipS
                        ProximalLocationScaleEntropy, Descent, Adam, DoG, DoWG, NoAveraging,
                        PolynomialAveraging, optimize, step, output)
 from .context import MiviContext
-from .problems import subsample, LogRegSubset
+from .problems import subsample, LogRegSubset, FunnelConstrainedProblem, StackedBijector, TransformedProblem
 from .subsampling import (ReshufflingBatchSubsampling, ReshufflingBatchSubsamplingState, SubsampledObjective,
                           SubsampledObjectiveState)
 from . import subsampling as _subsampling

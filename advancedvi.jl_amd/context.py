@@ -96,6 +96,12 @@ class MiviContext:
         if P.dimension(prob) != self.d:
             raise ValueError("dimension(prob) does not match the variational family")
         dt = self.np_dtype
+        if isinstance(prob, P.TransformedProblem):   # inner target first, then the Stacked bijector around it
+            self.set_problem(prob.prob)
+            self.set_bijector(prob.bijector)
+            self.problem = prob
+            return
+        self.set_bijector(None)
         if not isinstance(prob, (P.LogRegProblem, P.LogRegSubset)):
             self._lr_full = None   # another target kind replaces the resident data set
         if isinstance(prob, P.DiagNormalProblem):
@@ -129,9 +135,20 @@ class MiviContext:
             self._chk(self.lib.mivi_logreg_select_rows(self.h, prob.batch.ctypes.data, prob.batch.size, prob.likeadj))
         elif isinstance(prob, P.FunnelProblem):
             self._chk(self.lib.mivi_set_target_funnel(self.h, prob.sigma_v))
+        elif isinstance(prob, P.FunnelConstrainedProblem):
+            self._chk(self.lib.mivi_set_target_funnel_constrained(self.h, prob.sigma_v))
         else:
             self._set_callback(prob)
         self.problem = prob
+
+    def set_bijector(self, bij):
+        """mivi_set_bijector_stacked: a P.StackedBijector around whatever target is set (None removes it)."""
+        if bij is None:
+            self._chk(self.lib.mivi_set_bijector_stacked(self.h, 0, None, None))
+            return
+        rng = np.ascontiguousarray([[lo, hi] for lo, hi, _ in bij.blocks], dtype=np.int32)
+        kinds = np.ascontiguousarray([P.StackedBijector.KINDS[k] for _, _, k in bij.blocks], dtype=np.int32)
+        self._chk(self.lib.mivi_set_bijector_stacked(self.h, len(bij.blocks), rng.ctypes.data, kinds.ctypes.data))
 
     def _set_callback(self, prob):
         if not hasattr(prob, "logdensity_and_gradient") and not hasattr(prob, "logdensity_and_gradient_batch"):

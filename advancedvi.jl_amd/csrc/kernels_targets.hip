@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void k_col_target(ColTargetArgs<T> a) {
     const double s = block_sum<double, 256>((double)acc, red);
     if (tid == 0) a.ell[m] = (T)s;
   } else {  // TGT_FUNNEL
-    const double e1 = (double)z[0];
+    // unconstrained form: z[0] = eta_1 = log s (exp bijector + log-Jacobian built in); constrained form: z[0] = s itself
+    const double e1 = a.constrained ? log((double)z[0]) : (double)z[0];
     const double inv_s2 = exp(-2.0 * e1);
     T acc = 0;
     for (int i = 1 + tid; i < d; i += 256) {
@@ -42,8 +43,14 @@ __global__ __launch_bounds__(256) void k_col_target(ColTargetArgs<T> a) {
     if (tid == 0) {
       const double n = (double)(d - 1), sv2 = a.sigma_v * a.sigma_v;
       // log LogNormal(e^{e1}; 0, sv) + sum_i log N(x_i; 0, e^{e1}) + log|det J| (= e1); constants in ell_const
-      a.ell[m] = (T)((-e1 - e1 * e1 / (2.0 * sv2)) + (-n * e1 - 0.5 * sx2 * inv_s2) + e1);
-      if (a.want_grad) g[0] = (T)((-1.0 - e1 / sv2) + (-n + sx2 * inv_s2) + 1.0);
+      if (a.constrained) {   // d/ds of log LogNormal(s) + sum_i log N(x_i; 0, s), no Jacobian term
+        const double s_ = (double)z[0];
+        a.ell[m] = (T)((-e1 - e1 * e1 / (2.0 * sv2)) + (-n * e1 - 0.5 * sx2 * inv_s2));
+        if (a.want_grad) g[0] = (T)(((-1.0 - e1 / sv2) + (-n + sx2 * inv_s2)) / s_);
+      } else {
+        a.ell[m] = (T)((-e1 - e1 * e1 / (2.0 * sv2)) + (-n * e1 - 0.5 * sx2 * inv_s2) + e1);
+        if (a.want_grad) g[0] = (T)((-1.0 - e1 / sv2) + (-n + sx2 * inv_s2) + 1.0);
+      }
     }
   }
 }
@@ -61,11 +68,58 @@ static void col_target_impl(mivi_ctx *c, int M, int want_grad) {
   a.t_istd = (const T *)c->t_istd.p;
   a.sigma_v = c->funnel_sigma_v;
   a.want_grad = want_grad;
+  a.constrained = c->funnel_constrained;
   hipLaunchKernelGGL(k_col_target<T>, dim3(M), dim3(256), 0, c->stream, a);
 }
 
 void launch_col_target(mivi_ctx *c, int M, int want_grad) {
   if (c->cfg.dtype == MIVI_F32) col_target_impl<float>(c, M, want_grad); else col_target_impl<double>(c, M, want_grad);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stacked bijector around any target (README.md:76-82,91-119): one workgroup per sample column.
+//   forward : x = binv(eta) in place (exp rows), ld[m] = sum over exp rows of eta   (= logabsdetjac(binv, eta))
+//   backward: G <- J' G + d logabsdetjac / d eta = x .* G + 1 on exp rows;  ell[m] += ld[m]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_bij_fwd(int d, const uint8_t *mask, T *Z, T *ld) {
+  __shared__ double red[4];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  T *z = Z + (size_t)m * d;
+  double acc = 0.0;
+  for (int i = tid; i < d; i += 256)
+    if (mask[i]) {
+      const T eta = z[i];
+      acc += (double)eta;
+      z[i] = exp(eta);
+    }
+  const double s = block_sum<double, 256>(acc, red);
+  if (tid == 0) ld[m] = (T)s;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_bij_bwd(int d, const uint8_t *mask, const T *X, T *G, T *ell, const T *ld, int want_grad) {
+  const int m = blockIdx.x, tid = threadIdx.x;
+  if (want_grad) {
+    const T *x = X + (size_t)m * d;
+    T *g = G + (size_t)m * d;
+    for (int i = tid; i < d; i += 256)
+      if (mask[i]) g[i] = fma(x[i], g[i], T(1));
+  }
+  if (ell && tid == 0) ell[m] += ld[m];
+}
+void launch_bij_forward(mivi_ctx *c, int M) {
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_bij_fwd<float>, dim3(M), dim3(256), 0, c->stream, c->cfg.d, (const uint8_t *)c->bij_mask.p, (float *)c->Z.p, (float *)c->bij_ld.p);
+  else
+    hipLaunchKernelGGL(k_bij_fwd<double>, dim3(M), dim3(256), 0, c->stream, c->cfg.d, (const uint8_t *)c->bij_mask.p, (double *)c->Z.p, (double *)c->bij_ld.p);
+}
+void launch_bij_backward(mivi_ctx *c, int M, int want_grad, bool add_to_ell) {
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_bij_bwd<float>, dim3(M), dim3(256), 0, c->stream, c->cfg.d, (const uint8_t *)c->bij_mask.p, (const float *)c->Z.p,
+                       (float *)c->W.p, add_to_ell ? (float *)c->ell.p : nullptr, (const float *)c->bij_ld.p, want_grad);
+  else
+    hipLaunchKernelGGL(k_bij_bwd<double>, dim3(M), dim3(256), 0, c->stream, c->cfg.d, (const uint8_t *)c->bij_mask.p, (const double *)c->Z.p,
+                       (double *)c->W.p, add_to_ell ? (double *)c->ell.p : nullptr, (const double *)c->bij_ld.p, want_grad);
 }
 
 // ---------------------------------------------------------------------------------------------

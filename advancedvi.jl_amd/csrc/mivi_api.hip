@@ -90,6 +90,7 @@ static mivi_status_t ensure_work(mivi_ctx *c, int M) {
     if ((s = ensure(c, c->Z, (size_t)d * capM * es, false))) return s;
     if ((s = ensure(c, c->W, (size_t)d * capM * es, false))) return s;
     if ((s = ensure(c, c->ell, (size_t)capM * es, false))) return s;
+    if (c->bij_on && (s = ensure(c, c->bij_ld, (size_t)capM * es, false))) return s;
     if ((s = ensure(c, c->row_part, ncc * d4 * 8 * sizeof(double), false))) return s;
     c->cap_M = capM;
   }
@@ -155,7 +156,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->dog_part, &c->stein_A, &c->stein_g, &c->lds_tabS, &c->lds_tilesS, &c->lds_tabD, &c->lds_tilesD, &c->lds_tabV, &c->lds_slab, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->lds_tabS, &c->lds_tilesS, &c->lds_tabD, &c->lds_tilesD, &c->lds_tabV, &c->lds_slab, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -330,8 +331,46 @@ mivi_status_t mivi_logreg_select_rows(mivi_ctx_t *c, const int64_t *idx, int64_t
   return MIVI_OK;
 }
 
+mivi_status_t mivi_set_target_funnel_constrained(mivi_ctx_t *c, double sigma_v) {
+  mivi_status_t s = mivi_set_target_funnel(c, sigma_v);
+  if (s == MIVI_OK) c->funnel_constrained = 1;
+  return s;
+}
+
+mivi_status_t mivi_set_bijector_stacked(mivi_ctx_t *c, int32_t n_blocks, const int32_t *ranges, const int32_t *kinds) {
+  if (!c || n_blocks < 0 || (n_blocks > 0 && (!ranges || !kinds))) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  const int d = c->cfg.d;
+  std::vector<uint8_t> mask(d, 0), seen(d, 0);
+  bool any = false;
+  for (int b = 0; b < n_blocks; ++b) {
+    const int lo = ranges[2 * b], hi = ranges[2 * b + 1];
+    if (lo < 0 || hi > d || lo > hi) return fail(c, MIVI_ERR_BAD_ARG, "stacked bijector: block range outside [0, d)");
+    if (kinds[b] != 0 && kinds[b] != 1) return fail(c, MIVI_ERR_BAD_ARG, "stacked bijector: kind must be 0 (identity) or 1 (exp)");
+    for (int i = lo; i < hi; ++i) {
+      if (seen[i]) return fail(c, MIVI_ERR_BAD_ARG, "stacked bijector: blocks overlap");
+      seen[i] = 1;
+      mask[i] = (uint8_t)kinds[b];
+      any = any || kinds[b] == 1;
+    }
+  }
+  invalidate_graph(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // an estimate in flight may still read the old mask
+  if (!any) {   // all-identity (or no) bijector: nothing to apply
+    c->bij_on = false;
+    return MIVI_OK;
+  }
+  mivi_status_t s = ensure(c, c->bij_mask, (size_t)d, false);
+  if (s) return s;
+  HIPCHK(c, hipMemcpy(c->bij_mask.p, mask.data(), (size_t)d, hipMemcpyHostToDevice));
+  c->bij_on = true;
+  c->cap_M = 0;   // (re)allocate the work buffers incl. the per-column log-Jacobian sums
+  return MIVI_OK;
+}
+
 mivi_status_t mivi_set_target_funnel(mivi_ctx_t *c, double sigma_v) {
   if (!c || !(sigma_v > 0.0) || c->cfg.d < 2) return MIVI_ERR_BAD_ARG;
+  c->funnel_constrained = 0;
   c->funnel_sigma_v = sigma_v;
   c->t_const = -log(sigma_v) - 0.5 * kLog2Pi - 0.5 * (c->cfg.d - 1) * kLog2Pi;
   c->target = TGT_FUNNEL;
@@ -405,7 +444,7 @@ static bool no_fused_update() {   // MIVI_NO_FUSED_UPDATE=1: separate update ker
 }
 
 static bool hetero_ok(const mivi_ctx *c, int want_grad) {
-  if (!want_grad) return false;
+  if (!want_grad || c->bij_on) return false;   // (a Stacked bijector runs on the explicit-sample route)
   // (the fused funnel target is NOT chained: its value workgroup also finishes two gradient entries, which an optimiser
   //  step right after the estimate must already see)
   if (c->cfg.family == MIVI_MEANFIELD) return c->target == TGT_DIAG_GAUSS;
@@ -416,7 +455,7 @@ static bool hetero_ok(const mivi_ctx *c, int want_grad) {
 // Second-generation full-rank route (kernels_fullrank_lds.hip): f32, d and M multiples of 64, fused Gaussian targets,
 // 16-byte aligned parameter / gradient vectors.  Everything else (and MIVI_FR_GEN1=1) takes the first-generation kernels.
 static bool lds_route(const mivi_ctx *c, const void *params, int M, int want_grad, const OutArgs &out) {
-  if (!lds_path_shape_ok(c, M)) return false;
+  if (!lds_path_shape_ok(c, M) || c->bij_on) return false;
   if (c->target != TGT_DIAG_GAUSS && c->target != TGT_DENSE_GAUSS) return false;
   if ((uintptr_t)params & 15) return false;
   if (want_grad && !out.partials_mode && ((uintptr_t)out.grad & 15)) return false;
@@ -549,7 +588,8 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
   const ValueJob *prev = (chained && ch->have_prev) ? &ch->prev : nullptr;
 
   if (c->cfg.family == MIVI_MEANFIELD) {
-    if (c->target == TGT_DIAG_GAUSS || (c->target == TGT_FUNNEL && want_grad)) {
+    const bool bij = c->bij_on;
+    if (!bij && (c->target == TGT_DIAG_GAUSS || (c->target == TGT_FUNNEL && want_grad && !c->funnel_constrained))) {
       launch_mf_main(c, params, rng, M, want_grad, nullptr, vin, out, prev);
       if (c->target == TGT_FUNNEL) {   // row 0 and ell are finished by whoever assembles the value (FunnelFin)
         vin.fn.cs = c->fn_cs[p].p;
@@ -568,17 +608,20 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
       vin.n_ld_part = c->mf_nblk;
     } else {
       launch_sample_mf(c, params, rng, M, c->Z.p, nullptr, 0, want_grad ? nullptr : (double *)c->he_part[p].p);
+      if (bij) launch_bij_forward(c, M);   // the target sees binv(z)
       if (c->target == TGT_DENSE_GAUSS) {
         launch_rt_from_z(c, M);
         launch_fr_dense_target(c, M, want_grad);
         vin.ell_part = (const double *)c->ell_part[p].p;
         vin.n_ell_part = fr_dense_blocks(c, M);
+        if (bij) { vin.ell = c->bij_ld.p; vin.n_ell = M; }   // + logabsdetjac per sample
       } else {
         if (logreg_uses_mfma(c, M)) launch_rt_from_z(c, M);   // Z^T for the MFMA route
         if ((s = eval_generic_target(c, M, want_grad))) return s;
         vin.ell = c->ell.p;
         vin.n_ell = M;
       }
+      if (bij) launch_bij_backward(c, M, want_grad, c->target != TGT_DENSE_GAUSS);
       if (want_grad) {
         launch_mf_main(c, params, rng, M, 1, c->W.p, vin, out);
         vin.ell_part2 = (const double *)c->sc_part[p].p;   // zeros for the non-fused target; he / logdet live here
@@ -596,7 +639,24 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
     if (chained ? ch->first : !hit) launch_eps(c, rng, M);   // otherwise generated inside the previous VJP kernel
     vin.he_part = (const double *)c->he_part[p].p;
     vin.n_he_part = eps_blocks(c, M);
-    if (c->target == TGT_DIAG_GAUSS) {
+    if (c->bij_on) {   // Stacked bijector: explicit samples, transformed in place around whatever target is set
+      launch_fr_sample(c, params, M, TGT_NONE, c->Z.p);
+      launch_bij_forward(c, M);
+      if (c->target == TGT_DENSE_GAUSS) {
+        launch_rt_from_z(c, M);
+        launch_fr_dense_target(c, M, want_grad);
+        vin.ell_part = (const double *)c->ell_part[p].p;
+        vin.n_ell_part = fr_dense_blocks(c, M);
+        vin.ell = c->bij_ld.p;
+        vin.n_ell = M;
+      } else {
+        if (logreg_uses_mfma(c, M)) launch_rt_from_z(c, M);
+        if ((s = eval_generic_target(c, M, want_grad))) return s;
+        vin.ell = c->ell.p;
+        vin.n_ell = M;
+      }
+      launch_bij_backward(c, M, want_grad, c->target != TGT_DENSE_GAUSS);
+    } else if (c->target == TGT_DIAG_GAUSS) {
       launch_fr_sample(c, params, M, TGT_DIAG_GAUSS, nullptr, prev);
       vin.ell_part = (const double *)c->ell_part[p].p;
       vin.n_ell_part = fr_sample_blocks(c, M);

@@ -175,6 +175,7 @@ struct ColTargetArgs {  // standalone per-column targets: Z -> (ell, G)
   const T *t_istd;
   double sigma_v;
   int want_grad;
+  int constrained;   // funnel: theta_1 = s itself (no built-in exp bijector / log-Jacobian)
 };
 
 // --------------------------------------------------------------------------------------------
@@ -213,6 +214,10 @@ struct mivi_ctx {
   mivi::DevBuf t_mean, t_istd, t_prec;
   double t_const = 0.0;  // per-sample constant of log pi
   double funnel_sigma_v = 1.5;
+  int funnel_constrained = 0;
+  // Stacked bijector (mivi_set_bijector_stacked): per-coordinate kind (0 identity, 1 exp) and per-column sum of eta over exp rows
+  mivi::DevBuf bij_mask, bij_ld;
+  bool bij_on = false;
   // logreg
   const void *lr_X = nullptr;
   const uint8_t *lr_y = nullptr;
@@ -320,6 +325,8 @@ void invalidate_graph(mivi_ctx *c);            // mivi_api.hip: drop the cached 
 
 // kernels_targets.hip
 void launch_col_target(mivi_ctx *c, int M, int want_grad);
+void launch_bij_forward(mivi_ctx *c, int M);                        // Z <- binv(Z) in place, bij_ld[m] = sum_exp eta
+void launch_bij_backward(mivi_ctx *c, int M, int want_grad, bool add_to_ell);   // G <- J' G + 1_exp; ell[m] += bij_ld[m]
 bool launch_logreg_target(mivi_ctx *c, int M, int want_grad);   // false: scratch allocation failed
 bool logreg_uses_mfma(const mivi_ctx *c, int M);          // the matrix-core route (needs Z^T staged in RT)
 bool logreg_reserve(mivi_ctx *c, int M);                        // size the scratch ahead of a graph capture

@@ -136,4 +136,49 @@ class FunnelProblem:
         return LogDensityOrder(1)
 
 
-BUILTIN = (DiagNormalProblem, DenseNormalProblem, LogRegProblem, LogRegSubset, FunnelProblem)
+
+
+class FunnelConstrainedProblem:
+    """Neal's funnel on the constrained scale theta = [s; x] (s > 0), WITHOUT a bijector (mivi_set_target_funnel_constrained);
+    TransformedProblem(FunnelConstrainedProblem(d, sv), StackedBijector([(0, 1, "exp"), (1, d, "identity")])) is FunnelProblem."""
+
+    def __init__(self, d, sigma_v=1.5):
+        self.d = int(d)
+        self.sigma_v = float(sigma_v)
+
+    def dimension(self):
+        return self.d
+
+    def capabilities(self):
+        return LogDensityOrder(1)
+
+
+class StackedBijector:
+    """inverse(Bijectors.Stacked(bijectors, ranges)) restricted to identity / exp blocks (README.md:76-82):
+    blocks = [(begin, end, kind)], 0-based half-open ranges, kind in {"identity", "exp"}."""
+
+    KINDS = {"identity": 0, "exp": 1}
+
+    def __init__(self, blocks):
+        self.blocks = [(int(lo), int(hi), str(kind)) for lo, hi, kind in blocks]
+        for _, _, kind in self.blocks:
+            if kind not in self.KINDS:
+                raise ValueError(f"unknown bijector kind {kind}")
+
+
+class TransformedProblem:
+    """TransformedLogDensityProblem(prob, binv) of README.md:91-119: logdensity(eta) = logdensity(prob, binv(eta)) +
+    logabsdetjac(binv, eta).  `prob` is any problem the context accepts (built-in descriptor or LogDensityProblems plugin)."""
+
+    def __init__(self, prob, bijector: StackedBijector):
+        self.prob = prob
+        self.bijector = bijector
+
+    def dimension(self):
+        return self.prob.dimension()
+
+    def capabilities(self):
+        return self.prob.capabilities()
+
+
+BUILTIN = (DiagNormalProblem, DenseNormalProblem, LogRegProblem, LogRegSubset, FunnelProblem, FunnelConstrainedProblem)

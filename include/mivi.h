@@ -126,6 +126,21 @@ mivi_status_t mivi_logreg_select_rows(mivi_ctx_t *ctx, const int64_t *idx_host, 
  * theta_1 = exp(eta_1) ~ LogNormal(0, sigma_v), theta_i ~ Normal(0, theta_1), log|det J| = eta_1. */
 mivi_status_t mivi_set_target_funnel(mivi_ctx_t *ctx, double sigma_v);
 
+/* The same funnel WITHOUT the built-in bijector: theta = [s; x] on the constrained scale (s > 0), log p = log LogNormal(s; 0,
+ * sigma_v) + sum_i log Normal(x_i; 0, s).  Compose it with mivi_set_bijector_stacked({exp on [0,1), identity on [1,d)}) to obtain
+ * the target of mivi_set_target_funnel (tests/test_gpu_bijector.py pins the two against each other). */
+mivi_status_t mivi_set_target_funnel_constrained(mivi_ctx_t *ctx, double sigma_v);
+
+/* Bijectors.Stacked over index blocks, wrapping WHATEVER target is set (README.md:76-82,91-119,
+ * docs/src/tutorials/constrained.md:154-196: `TransformedLogDensityProblem(prob, binv)`):
+ *   logdensity(eta) = log pi(binv(eta)) + logabsdetjac(binv, eta),  binv = identity or exp per block.
+ * ranges_host[2 b], ranges_host[2 b + 1] = [begin, end) of block b (0-based, disjoint, inside [0, d)); kinds_host[b]: 0 identity,
+ * 1 exp.  Coordinates in no block are identity.  n_blocks = 0 removes the bijector.  The variational family stays on the
+ * unconstrained scale; the target (built-in or plugin callback) sees constrained samples binv(z), its gradient g comes back as
+ * J' g + d logabsdetjac / d eta  (exp block: x_i g_i + 1), its value gains sum over exp coordinates of eta_i.
+ * With a bijector the estimate runs on the explicit-sample route (Z materialised, transformed in place). */
+mivi_status_t mivi_set_bijector_stacked(mivi_ctx_t *ctx, int32_t n_blocks, const int32_t *ranges_host, const int32_t *kinds_host);
+
 /* Generic plugin: batched `logdensity_and_gradient` (src/mixedad_logdensity.jl:28) over the columns of Z.
  * Called on the host thread inside mivi_estimate_* with HOST buffers: Z (d x M col-major) in,
  * ell (M) and G (d x M) out.  Return non-zero to abort (-> MIVI_ERR_BAD_ARG). */

@@ -277,6 +277,66 @@ class FunnelStackedTarget:
         return self.logdensity_and_gradient(eta)[0]
 
 
+class FunnelConstrainedTarget:
+    """The same funnel on its CONSTRAINED scale, theta = [s; x], s > 0, no bijector:
+    log p = log LogNormal(s; 0, sigma_v) + sum_i log Normal(x_i; 0, s).  StackedBijectorTarget(this, exp on [0, 1)) is
+    FunnelStackedTarget (pinned in tests/test_oracle_pinning.py)."""
+
+    def __init__(self, d, sigma_v=1.5):
+        self.d = d
+        self.sigma_v = float(sigma_v)
+
+    def dimension(self):
+        return self.d
+
+    def logdensity_and_gradient(self, theta):
+        s = theta[0]
+        x = theta[1:]
+        n = self.d - 1
+        sv2 = self.sigma_v ** 2
+        ls = math.log(s)
+        sx2 = float(x @ x)
+        val = (-ls - math.log(self.sigma_v) - 0.5 * LOG2PI - ls * ls / (2.0 * sv2)) + (-n * ls - 0.5 * n * LOG2PI - 0.5 * sx2 / (s * s))
+        g = np.empty(self.d)
+        g[0] = (-1.0 - ls / sv2 - n + sx2 / (s * s)) / s
+        g[1:] = -x / (s * s)
+        return val, g
+
+    def logdensity(self, theta):
+        return self.logdensity_and_gradient(theta)[0]
+
+
+class StackedBijectorTarget:
+    """TransformedLogDensityProblem(prob, binv) with binv = inverse(Bijectors.Stacked(...)) over index blocks
+    (README.md:76-82, 91-119; docs/src/tutorials/constrained.md:154-196):
+        logdensity(eta) = logdensity(prob, binv(eta)) + logabsdetjac(binv, eta)
+    blocks: list of (begin, end, kind), 0-based half-open, kind "identity" or "exp" (binv = exp: x = exp(eta),
+    logabsdetjac = eta).  The gradient follows by the chain rule: J' g + 1 on exp coordinates."""
+
+    def __init__(self, inner, blocks):
+        self.inner = inner
+        self.mask = np.zeros(inner.dimension(), dtype=bool)
+        for lo, hi, kind in blocks:
+            if kind == "exp":
+                self.mask[lo:hi] = True
+            elif kind != "identity":
+                raise ValueError(kind)
+
+    def dimension(self):
+        return self.inner.dimension()
+
+    def logdensity_and_gradient(self, eta):
+        eta = np.asarray(eta, dtype=np.float64)
+        x = np.where(self.mask, np.exp(eta), eta)
+        v, g = self.inner.logdensity_and_gradient(x)
+        return v + float(np.sum(eta[self.mask])), np.where(self.mask, x * g + 1.0, g)
+
+    def logdensity(self, eta):
+        eta = np.asarray(eta, dtype=np.float64)
+        x = np.where(self.mask, np.exp(eta), eta)
+        return self.inner.logdensity(x) + float(np.sum(eta[self.mask]))
+
+
 # --------------------------------------------------------------------------------------
 # RepGradELBO
 # --------------------------------------------------------------------------------------

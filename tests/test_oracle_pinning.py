@@ -246,3 +246,25 @@ def test_gaussian_expectation_gradient_and_hessian_known_answer():
     assert np.allclose(H, -np.linalg.solve(np.tril(q.scale).T, (u @ z.T) / u.shape[1]) @ S, rtol=1e-10)
     with pytest.raises(TypeError):
         O.gaussian_expectation_gradient_and_hessian(O.MvLocationScale(np.ones(2), np.ones(2)), TestQuad(S), u)
+
+
+def test_stacked_bijector_target_chain_rule_and_the_funnel_identity():
+    """oracle.StackedBijectorTarget (README.md:76-82,91-119): gradient == central finite differences of its own value, and
+    wrapping the constrained funnel with exp on coordinate 0 reproduces FunnelStackedTarget (value and gradient)."""
+    rng = np.random.default_rng(5)
+    d = 9
+    inner = O.DiagNormalTarget(rng.normal(size=d), rng.uniform(0.5, 2.0, size=d))
+    tgt = O.StackedBijectorTarget(inner, [(0, 2, "exp"), (2, 5, "identity"), (6, 8, "exp")])
+    eta = 0.4 * rng.normal(size=d)
+    v, g = tgt.logdensity_and_gradient(eta)
+    h = 1e-6
+    fd = np.array([(tgt.logdensity(eta + h * e) - tgt.logdensity(eta - h * e)) / (2 * h) for e in np.eye(d)])
+    assert np.allclose(g, fd, rtol=1e-7, atol=1e-7)
+    assert abs(v - tgt.logdensity(eta)) < 1e-12
+    # funnel: constrained + Stacked(exp on s) == the hand-derived unconstrained funnel
+    f_c = O.StackedBijectorTarget(O.FunnelConstrainedTarget(d, 1.5), [(0, 1, "exp"), (1, d, "identity")])
+    f_u = O.FunnelStackedTarget(d, 1.5)
+    v1, g1 = f_c.logdensity_and_gradient(eta)
+    v2, g2 = f_u.logdensity_and_gradient(eta)
+    assert abs(v1 - v2) <= 1e-12 * max(1.0, abs(v2))
+    assert np.allclose(g1, g2, rtol=1e-12, atol=1e-12)
