@@ -67,6 +67,13 @@ SIGNATURES = {
     "mivi_profile_kernel": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "mivi_fullrank_route": (C.c_int32, [C.c_void_p, C.c_int32]),
     "mivi_set_target_funnel_constrained": (C.c_int32, [C.c_void_p, C.c_double]),
+    "mivi_slice_len": (C.c_int64, [C.c_void_p, C.c_int32]),
+    "mivi_finalize_slice": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "mivi_unpack_final": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mivi_comm_unique_id": (C.c_int32, [C.c_void_p]),
+    "mivi_comm_init": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    "mivi_comm_destroy": (C.c_int32, [C.c_void_p]),
+    "mivi_estimate_gradient_dist": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "mivi_set_bijector_stacked": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mivi_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mivi_eps_bits_host": (None, [C.c_uint64, C.c_uint64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]),

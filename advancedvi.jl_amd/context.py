@@ -268,6 +268,36 @@ class MiviContext:
         self._chk(self.lib.mivi_profile_kernel(self.h, int(which), self._p(params), int(reps), C.byref(ms)))
         return ms.value
 
+    # -- sharded finalisation / collective behind the ABI ----------------------------------------------------------
+    def slice_len(self, world):
+        return int(self.lib.mivi_slice_len(self.h, int(world)))
+
+    def finalize_slice(self, params, slice_sum, rank, world, out=None):
+        out = self.empty(self.slice_len(world)) if out is None else out
+        self._chk(self.lib.mivi_finalize_slice(self.h, self._p(params), self._p(slice_sum), int(rank), int(world), self._p(out)))
+        return out
+
+    def unpack_final(self, packed_final, value=None, grad=None):
+        value = self.empty(1) if value is None else value
+        grad = self.empty(self.params_len) if grad is None else grad
+        self._chk(self.lib.mivi_unpack_final(self.h, self._p(packed_final), self._p(value), self._p(grad)))
+        return value, grad
+
+    def comm_unique_id(self):
+        buf = (C.c_char * 128)()
+        _lib.check(self.lib, self.h, self.lib.mivi_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        self._chk(self.lib.mivi_comm_init(self.h, unique_id, int(rank), int(world)))
+
+    def estimate_gradient_dist(self, params, idx, value=None, grad=None):
+        p = self.to_device(params)
+        value = self.empty(1) if value is None else value
+        grad = self.empty(self.params_len) if grad is None else grad
+        self._raise_cb(self.lib.mivi_estimate_gradient_dist(self.h, self._p(p), idx, self._p(value), self._p(grad)))
+        return value, grad
+
     def fullrank_route(self, n_samples=0):
         """(generation, bf16x3): which full-rank kernels run for n_samples per launch (mivi_fullrank_route)."""
         r = int(self.lib.mivi_fullrank_route(self.h, int(n_samples)))

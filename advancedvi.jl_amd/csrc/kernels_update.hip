@@ -89,6 +89,131 @@ void launch_finalize(mivi_ctx *c, const void *params, const void *partials, void
   else finalize_impl<double>(c, params, partials, value, grad);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sharded finalisation (multi-GPU): reduce-scatter -> every rank finalises ITS 1/R slice of the partial vector in the packed
+// domain -> all-gather -> every rank unpacks.  The packed "final" vector F has the layout of the partial vector:
+//   [d/dmu (d); mean-field: d/dsigma (d) | full-rank: column-packed lower triangle of d/dC (d(d+1)/2); value; status bits]
+// so that the collective moves the packed triangle both ways and no rank normalises more than its slice.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct SliceArgs {
+  int d, family, ent_kind, M_total;
+  long long L, g0, n;      // partial length, first global index of this slice, slice length
+  const T *params;
+  const T *sum;            // summed partials of this slice [n]
+  T *fin;                  // packed final values of this slice [n]
+  double ell_const;
+  int M_units;             // number of sample columns behind sum(ell): ell_const is added once per column
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_finalize_slice(SliceArgs<T> a) {
+  __shared__ double red[4];
+  const int d = a.d;
+  const double invM = 1.0 / (double)a.M_total;
+  const double direct = direct_entropy_coeff(a.ent_kind);
+  const long long tri_end = a.L - 2;
+  if (blockIdx.x + 1 < gridDim.x) {
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < a.n; t += (long long)(gridDim.x - 1) * 256) {
+      const long long g = a.g0 + t;
+      if (g >= tri_end) continue;          // the two scalars (and the padding) belong to the value block
+      double v = -(double)a.sum[t] * invM;
+      if (g >= d) {
+        if (a.family == MIVI_MEANFIELD) {
+          v -= direct / (double)a.params[g];
+        } else {                           // packed entry e = j d - j (j - 1) / 2 + (i - j): find its column j
+          const long long e = g - d;
+          const double b = 2.0 * d + 1.0;
+          long long j = (long long)((b - sqrt(b * b - 8.0 * (double)e)) * 0.5);
+          if (j < 0) j = 0;
+          if (j > d - 1) j = d - 1;
+          while (j > 0 && j * d - (j * (j - 1)) / 2 > e) --j;
+          while (j + 1 < d && (j + 1) * d - ((j + 1) * j) / 2 <= e) ++j;
+          const long long i = j + (e - (j * d - (j * (j - 1)) / 2));
+          if (i == j) v -= direct / (double)a.params[d + (size_t)j * d + j];
+        }
+      }
+      a.fin[t] = (T)v;
+    }
+    return;
+  }
+  // value block: only on the rank whose slice holds the scalars
+  if (a.g0 > tri_end || a.g0 + a.n < a.L) {
+    for (long long t = threadIdx.x; t < a.n; t += 256)
+      if (a.g0 + t >= tri_end) a.fin[t] = T(0);      // padding beyond L
+    return;
+  }
+  double s_ld = 0.0, bad = 0.0;
+  for (int i = threadIdx.x; i < d; i += 256) {
+    const double c = (double)(a.family == MIVI_MEANFIELD ? a.params[d + i] : a.params[d + (size_t)i * d + i]);
+    if (!(c > 0.0)) bad = 1.0;
+    s_ld += log(c);
+  }
+  s_ld = block_sum<double, 256>(s_ld, red);
+  bad = block_sum<double, 256>(bad, red);
+  for (long long t = threadIdx.x; t < a.n; t += 256)
+    if (a.g0 + t >= a.L) a.fin[t] = T(0);
+  if (threadIdx.x == 0) {
+    const long long so = tri_end - a.g0;
+    const double sum_ell = (double)a.sum[so], s_he = (double)a.sum[so + 1];
+    const double Mt = (double)a.M_total;
+    const double ent = (ent_is_closed(a.ent_kind) ? 0.5 * d * (1.0 + kLog2Pi) : s_he / Mt + 0.5 * d * kLog2Pi) + s_ld;
+    const double value = -(sum_ell / Mt + ent);
+    int st = 0;
+    if (!isfinite(value)) st |= 1;
+    if (bad > 0.0) st |= 2;
+    a.fin[so] = (T)value;
+    a.fin[so + 1] = (T)st;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_unpack_final(int d, int family, long long L, const T *fin, T *value, T *grad, int *status) {
+  const int64_t plen = family == MIVI_MEANFIELD ? 2 * (int64_t)d : (int64_t)d + (int64_t)d * d;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < plen; t += (int64_t)gridDim.x * 256) {
+    T g;
+    if (family == MIVI_MEANFIELD || t < d) {
+      g = fin[t];
+    } else {
+      const int64_t e = t - d;
+      const int64_t j = e / d, i = e - j * d;
+      g = (j > i) ? T(0) : fin[d + j * d - (j * (j - 1)) / 2 + (i - j)];
+    }
+    grad[t] = g;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    *value = fin[L - 2];
+    const int st = (int)fin[L - 1];
+    if (st && status) atomicOr(status, st);
+  }
+}
+
+void launch_finalize_slice(mivi_ctx *c, const void *params, const void *sum, long long g0, long long n, void *fin) {
+  const long long L = mivi_partials_len(c);
+  int nb = (int)((n + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  if (c->cfg.dtype == MIVI_F32) {
+    SliceArgs<float> a{c->cfg.d, c->cfg.family, c->cfg.entropy, c->M_total, L, g0, n, (const float *)params, (const float *)sum, (float *)fin, 0.0, 0};
+    hipLaunchKernelGGL(k_finalize_slice<float>, dim3(nb + 1), dim3(256), 0, c->stream, a);
+  } else {
+    SliceArgs<double> a{c->cfg.d, c->cfg.family, c->cfg.entropy, c->M_total, L, g0, n, (const double *)params, (const double *)sum, (double *)fin, 0.0, 0};
+    hipLaunchKernelGGL(k_finalize_slice<double>, dim3(nb + 1), dim3(256), 0, c->stream, a);
+  }
+}
+void launch_unpack_final(mivi_ctx *c, const void *fin, void *value, void *grad) {
+  const long long L = mivi_partials_len(c);
+  const int64_t plen = mivi_params_len(c);
+  int nb = (int)((plen + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_unpack_final<float>, dim3(nb), dim3(256), 0, c->stream, c->cfg.d, c->cfg.family, L, (const float *)fin, (float *)value,
+                       (float *)grad, (int *)c->status.p);
+  else
+    hipLaunchKernelGGL(k_unpack_final<double>, dim3(nb), dim3(256), 0, c->stream, c->cfg.d, c->cfg.family, L, (const double *)fin, (double *)value,
+                       (double *)grad, (int *)c->status.p);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_value_only(int d, int family, const T *params, ValueIn vin, OutArgs out) {
   __shared__ double red[4];

@@ -6,6 +6,9 @@
 #include <string.h>
 #include <stdlib.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the library is opened at run time (mivi_comm_init), libmivi has no link-time RCCL dependency
+
 #include "mivi_internal.h"
 
 using namespace mivi;
@@ -152,11 +155,12 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   if (!c) return MIVI_ERR_BAD_ARG;
   (void)hipSetDevice(c->cfg.device);
   (void)hipStreamSynchronize(c->stream);
+  (void)mivi_comm_destroy(c);
   if (c->graph.exec) (void)hipGraphExecDestroy(c->graph.exec);
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->lds_tabS, &c->lds_tilesS, &c->lds_tabD, &c->lds_tilesD, &c->lds_tabV, &c->lds_slab, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_S, &c->dist_F, &c->lds_tabS, &c->lds_tilesS, &c->lds_tabD, &c->lds_tilesD, &c->lds_tabV, &c->lds_slab, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -812,6 +816,152 @@ mivi_status_t mivi_finalize(mivi_ctx_t *c, const void *params, const void *parti
   if (!c || !params || !partials || !value || !grad) return MIVI_ERR_BAD_ARG;
   (void)hipSetDevice(c->cfg.device);
   launch_finalize(c, params, partials, value, grad);
+  HIPCHK(c, hipGetLastError());
+  return MIVI_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Sharded finalisation and the collective behind the C ABI: reduce-scatter -> slice finalise -> all-gather ->
+// unpack.  RCCL is opened with dlopen: a host without it (or a CPU-only symbol check) still loads libmivi.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi *rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api.lib ? &api : nullptr;
+  tried = true;
+  const char *env = getenv("MIVI_RCCL_LIB");
+  const char *cands[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (int pass = 0; pass < 2 && !api.lib; ++pass)       // pass 0: a copy the process already loaded (e.g. the host framework's)
+    for (const char *n : cands)
+      if (n && !api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+  if (!api.lib) return nullptr;
+  api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+  api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+  api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+  api.ReduceScatter = (decltype(api.ReduceScatter))dlsym(api.lib, "ncclReduceScatter");
+  api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+  api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.ReduceScatter || !api.AllGather) { api.lib = nullptr; return nullptr; }
+  return &api;
+}
+long long slice_len_of(const mivi_ctx *c, int world) {
+  const long long L = mivi_partials_len(c);
+  return (L + world - 1) / world;
+}
+}  // namespace
+
+int64_t mivi_slice_len(const mivi_ctx_t *c, int32_t world) { return (c && world > 0) ? slice_len_of(c, world) : 0; }
+
+mivi_status_t mivi_finalize_slice(mivi_ctx_t *c, const void *params, const void *slice_sum, int32_t rank, int32_t world, void *final_slice) {
+  if (!c || !params || !slice_sum || !final_slice || world <= 0 || rank < 0 || rank >= world) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  const long long n = slice_len_of(c, world);
+  if (world > 1 && n < world + 2) return fail(c, MIVI_ERR_UNSUPPORTED, "parameter vector too short to shard over this many ranks");
+  launch_finalize_slice(c, params, slice_sum, (long long)rank * n, n, final_slice);
+  HIPCHK(c, hipGetLastError());
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_unpack_final(mivi_ctx_t *c, const void *packed_final, void *value, void *grad) {
+  if (!c || !packed_final || !value || !grad) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  launch_unpack_final(c, packed_final, value, grad);
+  HIPCHK(c, hipGetLastError());
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_comm_unique_id(void *id_host) {
+  if (!id_host) return MIVI_ERR_BAD_ARG;
+  RcclApi *r = rccl();
+  if (!r) return MIVI_ERR_UNSUPPORTED;
+  ncclUniqueId id;
+  if (r->GetUniqueId(&id) != ncclSuccess) return MIVI_ERR_HIP;
+  memcpy(id_host, &id, sizeof(id));
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_comm_destroy(mivi_ctx_t *c) {
+  if (!c) return MIVI_ERR_BAD_ARG;
+  if (c->comm) {
+    RcclApi *r = rccl();
+    (void)hipStreamSynchronize(c->stream);
+    if (r) (void)r->CommDestroy((ncclComm_t)c->comm);
+    c->comm = nullptr;
+  }
+  c->comm_rank = 0;
+  c->comm_world = 1;
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_comm_init(mivi_ctx_t *c, const void *id_host, int32_t rank, int32_t world) {
+  if (!c || world <= 0 || rank < 0 || rank >= world || (world > 1 && !id_host)) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  (void)mivi_comm_destroy(c);
+  invalidate_graph(c);
+  if (id_host) {   // also for world == 1: exercises the collective path on one GPU
+    RcclApi *r = rccl();
+    if (!r) return fail(c, MIVI_ERR_UNSUPPORTED, "librccl could not be opened (set MIVI_RCCL_LIB)");
+    ncclUniqueId id;
+    memcpy(&id, id_host, sizeof(id));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t e = r->CommInitRank(&comm, world, id, rank);
+    if (e != ncclSuccess) {
+      c->err = std::string("ncclCommInitRank: ") + (r->GetErrorString ? r->GetErrorString(e) : "error");
+      return MIVI_ERR_HIP;
+    }
+    c->comm = comm;
+  }
+  c->comm_rank = rank;
+  c->comm_world = world;
+  return MIVI_OK;
+}
+
+// estimate_gradient! of ONE estimate whose n_mc * world samples are sharded over the ranks of the communicator (this context draws
+// columns [m_offset, m_offset + n_mc) of m_total): partials -> reduce-scatter -> slice finalise -> all-gather -> unpack.
+mivi_status_t mivi_estimate_gradient_dist(mivi_ctx_t *c, const void *params, uint64_t idx, void *value, void *grad) {
+  if (!c || !params || !value || !grad) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  const int R = c->comm_world, rank = c->comm_rank;
+  if (R > 1 && !c->comm) return fail(c, MIVI_ERR_BAD_ARG, "mivi_comm_init has not been called");
+  const long long n = slice_len_of(c, R), Lp = n * R;
+  if (R > 1 && n < R + 2) return fail(c, MIVI_ERR_UNSUPPORTED, "parameter vector too short to shard over this many ranks");
+  const size_t es = c->esize;
+  mivi_status_t s;
+  if (c->dist_P.bytes < (size_t)Lp * es) {
+    invalidate_graph(c);
+    if ((s = ensure(c, c->dist_P, (size_t)Lp * es, true)) || (s = ensure(c, c->dist_S, (size_t)n * es, true)) ||
+        (s = ensure(c, c->dist_F, (size_t)Lp * es, true)))
+      return s;
+  }
+  if ((s = mivi_estimate_partials(c, params, idx, c->dist_P.p))) return s;
+  const void *sum = (const char *)c->dist_P.p + (size_t)rank * n * es;   // one rank: its "slice" is the whole vector
+  if (c->comm) {
+    RcclApi *r = rccl();
+    const ncclDataType_t dt = c->cfg.dtype == MIVI_F32 ? ncclFloat : ncclDouble;
+    if (r->ReduceScatter(c->dist_P.p, c->dist_S.p, (size_t)n, dt, ncclSum, (ncclComm_t)c->comm, c->stream) != ncclSuccess)
+      return fail(c, MIVI_ERR_HIP, "ncclReduceScatter failed");
+    sum = c->dist_S.p;
+  }
+  char *fin_slice = (char *)c->dist_F.p + (size_t)rank * n * es;
+  launch_finalize_slice(c, params, sum, (long long)rank * n, n, fin_slice);
+  if (c->comm) {
+    RcclApi *r = rccl();
+    const ncclDataType_t dt = c->cfg.dtype == MIVI_F32 ? ncclFloat : ncclDouble;
+    if (r->AllGather(fin_slice, c->dist_F.p, (size_t)n, dt, (ncclComm_t)c->comm, c->stream) != ncclSuccess)
+      return fail(c, MIVI_ERR_HIP, "ncclAllGather failed");
+  }
+  launch_unpack_final(c, c->dist_F.p, value, grad);
   HIPCHK(c, hipGetLastError());
   return MIVI_OK;
 }

@@ -217,6 +217,10 @@ struct mivi_ctx {
   int funnel_constrained = 0;
   // Stacked bijector (mivi_set_bijector_stacked): per-coordinate kind (0 identity, 1 exp) and per-column sum of eta over exp rows
   mivi::DevBuf bij_mask, bij_ld;
+  // collective behind the C ABI (mivi_comm_init): RCCL communicator + padded partial / packed-final buffers
+  void *comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  mivi::DevBuf dist_P, dist_S, dist_F;
   bool bij_on = false;
   // logreg
   const void *lr_X = nullptr;
@@ -334,6 +338,8 @@ bool logreg_prepare_f32(mivi_ctx *c);   // row-major padded copy of X for the MF
 
 // kernels_update.hip
 void launch_finalize(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad);
+void launch_finalize_slice(mivi_ctx *c, const void *params, const void *sum, long long g0, long long n, void *fin);
+void launch_unpack_final(mivi_ctx *c, const void *fin, void *value, void *grad);
 void launch_prox(mivi_ctx *c, void *params, double stepsize, const void *dog_state, int dog_kind);
 void launch_poly_average(mivi_ctx *c, void *avg, const void *params, double avg_eta, const long long *t_ptr, long long t_base);
 void launch_dog_update(mivi_ctx *c, void *params, const void *grad, void *state, int kind);

@@ -53,13 +53,45 @@ def allreduce_partials(partials, group=None, force=False):
     return partials
 
 
+def slice_len(n_partials: int, world: int) -> int:
+    """Elements per rank of the partial vector padded to a multiple of `world` (mivi_slice_len)."""
+    return (n_partials + world - 1) // world
+
+
+def reduce_scatter_partials(padded, out_slice, group=None):
+    """SUM reduce-scatter of the padded partial vector: rank r receives elements [r n, (r+1) n).  RCCL does it in one
+    collective; gloo (CPU tests) has no reduce-scatter, there it is an all-reduce followed by taking the slice."""
+    import torch.distributed as dist
+
+    if dist.get_backend(group) == "gloo":
+        dist.all_reduce(padded, op=dist.ReduceOp.SUM, group=group)
+        n = out_slice.numel()
+        r = dist.get_rank(group)
+        out_slice.copy_(padded[r * n:(r + 1) * n])
+    else:
+        dist.reduce_scatter_tensor(out_slice, padded, op=dist.ReduceOp.SUM, group=group)
+    return out_slice
+
+
+def allgather_final(final_slice, packed_final, group=None):
+    """All-gather of the finalised slices into the packed final vector (rank order)."""
+    import torch.distributed as dist
+
+    dist.all_gather_into_tensor(packed_final, final_slice, group=group)
+    return packed_final
+
+
 class DistributedRepGradELBO:
     """RepGradELBO with the MC batch sharded over the ranks of a torch.distributed process group.
 
     estimate_gradient(params, idx) -> (value, grad) device tensors, identical on every rank and equal
     (up to fp32 summation order) to the single-GPU estimate with n_samples = plan.n_samples."""
 
-    def __init__(self, q, prob, n_samples, entropy, seed, device=0, group=None, force_collective=False):
+    def __init__(self, q, prob, n_samples, entropy, seed, device=0, group=None, force_collective=False, mode="auto"):
+        """mode "rsag": reduce-scatter -> every rank finalises its 1/R slice (mivi_finalize_slice) -> all-gather -> unpack
+        (mivi_unpack_final); "allreduce": all-reduce + the whole finalisation on every rank (first-round structure, A/B);
+        "mivi": the collective runs behind the C ABI (mivi_comm_init / mivi_estimate_gradient_dist, RCCL opened by libmivi;
+        the unique id travels through the torch process group)."""
         import torch.distributed as dist
 
         from .context import MiviContext
@@ -75,18 +107,42 @@ class DistributedRepGradELBO:
         self.ctx = MiviContext(q.eltype, q.family, len(q), self.plan.count(self.rank), entropy.code, seed, device=device,
                                m_offset=self.plan.offset(self.rank), m_total=self.plan.n_samples)
         self.ctx.set_problem(prob)
-        self.partials = self.ctx.empty(self.ctx.partials_len)
+        L = self.ctx.partials_len
+        if mode == "auto":   # two collectives cost one more launch + rendezvous (~10 us) than one all-reduce: they pay off only for
+            mode = "rsag" if L * self.ctx.np_dtype.itemsize >= (16 << 20) else "allreduce"   # bandwidth-bound vectors
+        self.mode = mode
+        self.n_slice = slice_len(L, self.world)
+        self.padded = self.ctx.empty(self.n_slice * self.world).zero_()   # partial vector + padding (stays zero)
+        self.partials = self.padded[:L]
+        self.slice_sum = self.ctx.empty(self.n_slice)
+        self.final = self.ctx.empty(self.n_slice * self.world)
         self.value = self.ctx.empty(1)
+        if mode == "mivi":
+            import torch
+            idt = torch.zeros(128, dtype=torch.uint8, device=self.ctx.tdevice)
+            if self.rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(self.ctx.comm_unique_id()), dtype=torch.uint8))
+            if self.world > 1:
+                dist.broadcast(idt, src=0, group=group)
+            self.ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), self.rank, self.world)
         self.grad = self.ctx.empty(self.ctx.params_len)
         self._destructure = destructure
 
     def estimate_gradient(self, params, idx):
         p = self.ctx.to_device(params)
-        if self.world == 1 and not self.force_collective:
+        if self.world == 1 and not self.force_collective and self.mode != "mivi":
             return self.ctx.estimate_gradient(p, idx, self.value, self.grad)
+        if self.mode == "mivi":
+            return self.ctx.estimate_gradient_dist(p, idx, self.value, self.grad)
         self.ctx.estimate_partials(p, idx, self.partials)
-        allreduce_partials(self.partials, self.group, force=self.force_collective)
-        return self.ctx.finalize(p, self.partials, self.value, self.grad)
+        if self.mode == "allreduce":
+            allreduce_partials(self.partials, self.group, force=self.force_collective)
+            return self.ctx.finalize(p, self.partials, self.value, self.grad)
+        reduce_scatter_partials(self.padded, self.slice_sum, self.group)
+        mine = self.final[self.rank * self.n_slice:(self.rank + 1) * self.n_slice]
+        self.ctx.finalize_slice(p, self.slice_sum, self.rank, self.world, mine)
+        allgather_final(mine, self.final, self.group)
+        return self.ctx.unpack_final(self.final, self.value, self.grad)
 
     def close(self):
         self.ctx.close()

@@ -292,7 +292,7 @@ def main():
                     ctx.estimate_gradient(params, idx0 + i, value, grad)
         else:
             drv = avi.distributed.DistributedRepGradELBO(q, prob, w["n_mc"] * world, ent, SEED, device=local_rank,
-                                                         force_collective=force_dist)
+                                                         force_collective=force_dist, mode=os.environ.get("MIVI_DIST_MODE", "auto"))
             ctx = drv.ctx
             params = ctx.to_device(params_h)
 
@@ -493,7 +493,7 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": w["name"], "d": w["d"], "n_mc_per_gpu": w["n_mc"], "n_mc_total": w["n_mc"] * world,
                            "family": "fullrank" if w["family"] else "meanfield", "seed": hex(SEED),
-                           "launch": f"hipGraph x{chunk}" if single else (f"CUDAGraph x{chunk} incl. RCCL all-reduce" if graph is not None else "eager + RCCL all-reduce")},
+                           "launch": f"hipGraph x{chunk}" if single else ((f"CUDAGraph x{chunk} incl. RCCL " if graph is not None else "eager + RCCL ") + {"allreduce": "all-reduce", "rsag": "reduce-scatter + all-gather", "mivi": "reduce-scatter + all-gather behind the C ABI"}[drv.mode])},
                 "roofline": roof, "cpu_baseline": cpub,
                 "elbo_rel_err_vs_cpu_fp64": rel, "stage_us": stages, "whole_estimate": whole, "steady_state": steady, "concurrent": conc, "also": also,
             }

@@ -264,6 +264,32 @@ mivi_status_t mivi_set_index_source(mivi_ctx_t *ctx, const uint64_t *idx_dev);
  * agree to rounding; f64 always takes the VALU kernels. */
 mivi_status_t mivi_set_logreg_route(mivi_ctx_t *ctx, int32_t route);
 
+/* ---- sharded finalisation + the collective behind the ABI --------------------------------------------------
+ * The Monte-Carlo mean of src/algorithms/repgradelbo.jl:84-86 shards over the sample axis; what crosses GPUs is the partial
+ * vector of mivi_estimate_partials.  Instead of all-reduce + a finalisation replicated on every rank:
+ *     reduce-scatter  ->  every rank finalises ITS slice (mivi_finalize_slice)  ->  all-gather  ->  unpack (mivi_unpack_final)
+ * The slice of rank r is elements [r * n, (r + 1) * n) of the partial vector padded to n * world, n = mivi_slice_len(ctx, world).
+ * The packed "final" vector has the layout of the partial vector: [d/dmu; d/dsigma or the column-packed lower triangle of d/dC;
+ * value; status bits].  Both functions are plain kernels on the context's stream: a host that owns its collectives
+ * (torch.distributed, MPI.jl, RCCL from Julia) calls them around its own reduce-scatter / all-gather. */
+int64_t mivi_slice_len(const mivi_ctx_t *ctx, int32_t world);
+mivi_status_t mivi_finalize_slice(mivi_ctx_t *ctx, const void *params_dev, const void *slice_sum_dev, int32_t rank, int32_t world,
+                                  void *final_slice_dev);
+mivi_status_t mivi_unpack_final(mivi_ctx_t *ctx, const void *packed_final_dev, void *value_dev, void *grad_dev);
+
+/* The collective itself, for hosts without one (julia/MIVI.jl): RCCL opened at run time (dlopen of librccl.so, override with
+ * MIVI_RCCL_LIB; a copy the process already loaded is reused).  mivi_comm_unique_id fills 128 bytes on rank 0 (ship them to the
+ * other ranks any way you like), mivi_comm_init joins `world` ranks -- one process per GPU, the context created with n_mc = the
+ * local share, m_offset = its first global column, m_total = n_mc * world.  mivi_estimate_gradient_dist is then estimate_gradient!
+ * of the m_total-sample estimate on every rank: {partials kernels, ncclReduceScatter, slice finalise, ncclAllGather, unpack}, all
+ * on the context's stream (graph-capturable).  world = 1 without a communicator runs the same kernels without the collectives;
+ * world = 1 WITH an id runs them through RCCL (single-GPU test of the whole path). */
+#define MIVI_COMM_ID_BYTES 128
+mivi_status_t mivi_comm_unique_id(void *id_host);
+mivi_status_t mivi_comm_init(mivi_ctx_t *ctx, const void *id_host, int32_t rank, int32_t world);
+mivi_status_t mivi_comm_destroy(mivi_ctx_t *ctx);
+mivi_status_t mivi_estimate_gradient_dist(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx, void *value_dev, void *grad_dev);
+
 /* ---- measurement hook (bench.py roofline leg) --------------------------------------------------------- *
  * Times `reps` back-to-back launches of ONE stage of the estimate with hipEvents recorded on the context's
  * stream (after one full warm estimate so every input buffer is populated).

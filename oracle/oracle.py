@@ -472,6 +472,53 @@ def finalize_partials(partials, params, d, family, ent_kind, M_total):
     return -(sum_ell / M_total + ent), grad
 
 
+def finalize_slice(slice_sum, g0, params, d, family, ent_kind, M_total, L):
+    """Host restatement of mivi_finalize_slice: the packed final values of partial-vector elements [g0, g0 + n) given their
+    sums over the ranks.  Gradient entries: -(1/M) sum - direct * [diagonal] / C_ii; element L-2 becomes the
+    objective value, L-1 the status bits; padding beyond L is zero."""
+    slice_sum = np.asarray(slice_sum, dtype=np.float64)
+    n = slice_sum.shape[0]
+    direct = {ENT_CLOSED_FORM: 1.0, ENT_CLOSED_FORM_ZERO_GRAD: 0.0, ENT_MONTE_CARLO: 1.0, ENT_STL: 0.0,
+              ENT_STL_ZERO_GRAD: -1.0}[ent_kind]
+    out = np.zeros(n)
+    if family == MEANFIELD:
+        diag_of = {d + i: params[d + i] for i in range(d)}
+    else:
+        diag_of = {}
+        C = params[d:].reshape(d, d, order="F")
+        for j in range(d):
+            diag_of[d + j * d - (j * (j - 1)) // 2] = C[j, j]
+    for t in range(n):
+        g = g0 + t
+        if g >= L - 2:
+            continue
+        v = -slice_sum[t] / M_total
+        if g in diag_of:
+            v -= direct / diag_of[g]
+        out[t] = v
+    if g0 <= L - 2 and g0 + n >= L:
+        so = L - 2 - g0
+        diag = params[d:] if family == MEANFIELD else np.diag(params[d:].reshape(d, d, order="F"))
+        s_ld = float(np.sum(np.log(diag)))
+        ent = (0.5 * d * (1.0 + LOG2PI) if ent_kind in (ENT_CLOSED_FORM, ENT_CLOSED_FORM_ZERO_GRAD)
+               else slice_sum[so + 1] / M_total + 0.5 * d * LOG2PI) + s_ld
+        out[so] = -(slice_sum[so] / M_total + ent)
+        out[so + 1] = 0.0
+    return out
+
+
+def unpack_final(packed, d, family):
+    """Host restatement of mivi_unpack_final: packed final vector -> (value, gradient in the parameter layout)."""
+    L = (2 * d if family == MEANFIELD else d + d * (d + 1) // 2) + 2
+    if family == MEANFIELD:
+        return float(packed[L - 2]), np.array(packed[:2 * d], dtype=np.float64)
+    gC = np.zeros((d, d))
+    for j in range(d):
+        o = d + j * d - (j * (j - 1)) // 2
+        gC[j:, j] = packed[o:o + d - j]
+    return float(packed[L - 2]), np.concatenate([packed[:d], gC.reshape(-1, order="F")])
+
+
 # --------------------------------------------------------------------------------------
 # Host-side operators next to the hot path (section 8f)
 # --------------------------------------------------------------------------------------

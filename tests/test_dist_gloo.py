@@ -46,6 +46,21 @@ def _worker(rank, world, port, family, ent, q_out):
         t = torch.from_numpy(part.copy())
         allreduce_partials(t)                                           # product code: the collective
         value, grad = O.finalize_partials(t.numpy(), params, d, family, ent, M)
+        # the sharded finalisation: reduce-scatter -> every rank finalises its 1/R slice -> all-gather -> unpack.  Product
+        # code: slice_len / reduce_scatter_partials / allgather_final; the slice arithmetic is the host restatement of the
+        # kernels (oracle.finalize_slice / unpack_final, compared with the kernels themselves in tests/test_gpu_dist.py).
+        from advancedvi_jl_amd.distributed import allgather_final, reduce_scatter_partials, slice_len
+        L = part.shape[0]
+        n = slice_len(L, world)
+        padded = torch.zeros(n * world, dtype=torch.float64)
+        padded[:L] = torch.from_numpy(part)
+        mine_sum = torch.zeros(n, dtype=torch.float64)
+        reduce_scatter_partials(padded, mine_sum)
+        fin = torch.zeros(n * world, dtype=torch.float64)
+        mine = torch.from_numpy(O.finalize_slice(mine_sum.numpy(), rank * n, params, d, family, ent, M, L))
+        allgather_final(mine, fin)
+        value2, grad2 = O.unpack_final(fin.numpy(), d, family)
+        assert abs(value2 - value) <= 1e-13 * abs(value) and np.max(np.abs(grad2 - grad)) <= 1e-13 * max(1.0, np.max(np.abs(grad)))
         if rank == 0:
             eps_full = O.philox_normal(SEED, idx, d, 0, M, f64=True)
             ref = O.estimate_gradient(params, d, family, tgt, eps_full, ent)

@@ -36,3 +36,74 @@ def test_sharded_partials_sum_to_single_gpu_estimate(family, d, M, R, ent):
     for sh in shards:
         sh.close()
     full.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("family,d,M,R", [(avi.MEANFIELD, 64, 48, 4), (avi.FULLRANK, 96, 64, 2), (avi.FULLRANK, 40, 30, 3),
+                                           (avi.FULLRANK, 128, 256, 8)])
+@pytest.mark.parametrize("ent", [0, 3])
+def test_slice_finalisation_kernels(family, d, M, R, ent, dtype):
+    """reduce-scatter -> per-rank slice finalise -> all-gather -> unpack, the collectives played by host slicing: the kernels
+    mivi_finalize_slice / mivi_unpack_final against (i) the replicated finalize kernel and (ii) the numpy restatement
+    oracle.finalize_slice / unpack_final that the gloo test runs."""
+    from oracle import oracle as O
+    import torch
+    rng = np.random.default_rng(3)
+    q, _ = make_family(rng, d, family, dtype)
+    prob, _ = make_problem(rng, "diag", d, dtype)
+    params, _ = avi.destructure(q)
+    plan = ShardPlan(M, R)
+    total, shards = None, []
+    for r in range(R):
+        sh = avi.MiviContext(dtype, family, d, plan.count(r), ent, SEED, m_offset=plan.offset(r), m_total=M)
+        sh.set_problem(prob)
+        part = sh.estimate_partials(params, 23).double()
+        total = part if total is None else total + part
+        shards.append(sh)
+    c0 = shards[0]
+    tdt = torch.float32 if dtype == np.float32 else torch.float64
+    L, n = c0.partials_len, c0.slice_len(R)
+    padded = torch.zeros(n * R, dtype=tdt, device="cuda")
+    padded[:L] = total.to(tdt)
+    fin = torch.empty(n * R, dtype=tdt, device="cuda")
+    p_dev = c0.to_device(params)
+    for r in range(R):      # each rank's kernel on its slice; the all-gather is the concatenation
+        shards[r].finalize_slice(p_dev, padded[r * n:(r + 1) * n].clone(), r, R, fin[r * n:(r + 1) * n])
+    v, g = c0.unpack_final(fin)
+    v0, g0 = c0.finalize(params, total.to(tdt))
+    tol = 1e-6 if dtype == np.float32 else 1e-13
+    assert abs(float(v.item()) - float(v0.item())) <= tol * abs(float(v0.item()))
+    assert np.max(np.abs(g.cpu().numpy() - g0.cpu().numpy())) <= tol * max(1.0, float(g0.abs().max()))
+    if family == avi.FULLRANK:
+        assert np.all(np.triu(g.cpu().numpy()[d:].reshape(d, d, order="F"), 1) == 0.0)
+    ref = np.concatenate([O.finalize_slice(padded[r * n:(r + 1) * n].cpu().numpy(), r * n, params.astype(np.float64), d, family, ent, M, L)
+                          for r in range(R)])
+    vr, gr = O.unpack_final(ref, d, family)
+    assert abs(float(v.item()) - vr) <= (2e-6 if dtype == np.float32 else 1e-13) * abs(vr)
+    assert np.max(np.abs(g.cpu().numpy() - gr)) <= (2e-6 if dtype == np.float32 else 1e-13) * max(1.0, np.max(np.abs(gr)))
+    for sh in shards:
+        sh.close()
+
+
+@pytest.mark.parametrize("family,d,M", [(avi.MEANFIELD, 64, 48), (avi.FULLRANK, 128, 128), (avi.FULLRANK, 40, 30)])
+def test_collective_behind_the_c_abi_on_one_gpu(family, d, M):
+    """mivi_comm_init(world = 1, WITH a unique id) + mivi_estimate_gradient_dist: the whole {partials, ncclReduceScatter, slice
+    finalise, ncclAllGather, unpack} chain through the RCCL that libmivi opens itself, against the plain estimate."""
+    rng = np.random.default_rng(4)
+    q, _ = make_family(rng, d, family, np.float32)
+    prob, _ = make_problem(rng, "diag", d, np.float32)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, family, d, M, 0, SEED)
+    ctx.set_problem(prob)
+    v0, g0 = ctx.estimate_gradient(params, 5)
+    v0, g0 = float(v0.item()), g0.cpu().numpy().copy()
+    ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    v1, g1 = ctx.estimate_gradient_dist(params, 5)
+    ctx.synchronize()
+    assert abs(float(v1.item()) - v0) <= 2e-6 * abs(v0)
+    assert np.linalg.norm(g1.cpu().numpy() - g0) <= 5e-6 * max(1.0, np.linalg.norm(g0))
+    # and without a communicator (world 1): same kernels, no collective
+    ctx.comm_init(None, 0, 1)
+    v2, g2 = ctx.estimate_gradient_dist(params, 5)
+    assert np.array_equal(g2.cpu().numpy(), g1.cpu().numpy())
+    ctx.close()
