@@ -28,6 +28,7 @@
 
 #include "device_common.h"
 #include "optim_rules.h"
+#include "stl_dinv.h"
 
 namespace mivi {
 
@@ -691,7 +692,9 @@ struct Prod32Args {
   float *Z, *W, *R;
   double *ell_part;  // one per tile workgroup
   double *ld_part;   // [2][d/32] or nullptr
-  int n_tiles;       // blocks >= n_tiles draw eps of the next estimate
+  int n_tiles;       // blocks in [n_tiles, n_tiles + n_eps) draw eps of the next estimate
+  int n_eps;         // ... and the ones behind them invert the 64x64 diagonal blocks of C for the STL solve (dinv != nullptr)
+  float *dinv;
   int ncb;
   SampleArgs<float> next_eps;
   long long *dbg;
@@ -717,6 +720,10 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int d = a.d;
+  if ((int)blockIdx.x >= a.n_tiles + a.n_eps) {   // STL: C_JJ^{-1} of one diagonal block (parameters only: off the critical path)
+    stl_dinv64_block<NT>(d, a.A, a.dinv, (int)blockIdx.x - a.n_tiles - a.n_eps, lds);
+    return;
+  }
   if ((int)blockIdx.x >= a.n_tiles) {   // eps(t+1): one Philox block per thread (rows gi..gi+3 of column gm), the k_eps stream
     const SampleArgs<float> &n = a.next_eps;
     const int eb = blockIdx.x - a.n_tiles, nrb = d >> 6;
@@ -1215,7 +1222,8 @@ void launch_lds_dense(mivi_ctx *c, int M) {
 
 // unsplit 32 x 32-tile product + fused epilogue (k_fr_prod32).  dense = false: Z = mu + tril(C) eps with `mode` in
 // {R_DIAG, R_DENSE_R, R_PLAIN}; dense = true: G = -P (Z - m) (mode R_DENSE_G, R = Z - m in c->RT).
-void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int mode, void *Z, const EpsJob *next, bool want_ld) {
+void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int mode, void *Z, const EpsJob *next, bool want_ld,
+                       bool with_dinv) {
   Prod32Args a{};
   a.d = c->cfg.d; a.M = M; a.dP = c->dP; a.mode = mode;
   if (dense) { a.A = (const float *)c->t_prec.p; a.lda = c->dP; a.B = (const float *)c->RT.p; }
@@ -1240,8 +1248,16 @@ void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int m
     a.next_eps.eps = (float *)c->eps[next->parity].p;
     a.next_eps.ld_eps = c->dP;
     a.next_eps.he_part = (double *)c->he_part[next->parity].p;
-    grid += (c->cfg.d / 64) * (M / 32);
+    a.n_eps = (c->cfg.d / 64) * (M / 32);
+    grid += a.n_eps;
   }
+  if (with_dinv && !dense) {
+    a.dinv = (float *)c->stl_Dinv.p;
+    grid += c->cfg.d / 64;
+  } else {
+    a.dinv = nullptr;
+  }
+  if (!a.dinv) grid = a.n_tiles + a.n_eps;
   if (dense && f32_mfma()) hipLaunchKernelGGL((k_fr_prod32<G_DENSE, false>), dim3(grid), dim3(512), 0, c->stream, a);
   else if (dense) hipLaunchKernelGGL((k_fr_prod32<G_DENSE, true>), dim3(grid), dim3(512), 0, c->stream, a);
   else if (f32_mfma()) hipLaunchKernelGGL((k_fr_prod32<G_SAMPLE, false>), dim3(grid), dim3(512), 0, c->stream, a);

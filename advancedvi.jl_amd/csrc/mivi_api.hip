@@ -85,7 +85,8 @@ static mivi_status_t ensure_work(mivi_ctx *c, int M) {
     }
     if (c->cfg.family == MIVI_FULLRANK && (c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD)) {
       if ((s = ensure(c, c->stl_CT, (size_t)c->dP * c->dP * es, true))) return s;
-      if ((s = ensure(c, c->stl_Dinv, (size_t)((d + 31) / 32) * 1024 * es, false))) return s;
+      if ((s = ensure(c, c->stl_Dinv, (size_t)((d + 63) / 64) * 4096 * es, false))) return s;   // 32x32 or 64x64 diagonal inverses
+      if ((s = ensure(c, c->stl_X, (size_t)d * capM * es, false))) return s;
     }
     if (c->cfg.family == MIVI_MEANFIELD && c->target == TGT_FUNNEL)
       for (int b = 0; b < 2; ++b)
@@ -160,7 +161,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_S, &c->dist_F, &c->lds_tabS, &c->lds_tilesS, &c->lds_tabD, &c->lds_tilesD, &c->lds_tabV, &c->lds_slab, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_S, &c->dist_F, &c->lds_tabS, &c->lds_tilesS, &c->lds_tabD, &c->lds_tilesD, &c->lds_tabV, &c->lds_slab, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -513,8 +514,11 @@ static mivi_status_t run_estimate_lds(mivi_ctx *c, const void *params, const Rng
   }
   const bool dense = c->target == TGT_DENSE_GAUSS;
   const bool p32 = lds_use_prod32(c, M);
+  bool dinv_done = false;
   if (p32) {   // unsplit 32 x 32 tiles with the target fused into the epilogue: one kernel from eps to W
-    launch_lds_prod32(c, params, M, false, dense ? R_DENSE_R : R_DIAG, nullptr, next, grad_stage);
+    const bool stl_here = grad_stage && (out.ent_kind == MIVI_ENT_STL || out.ent_kind == MIVI_ENT_STL_ZERO_GRAD) && stl2_shape_ok(c, M);
+    launch_lds_prod32(c, params, M, false, dense ? R_DENSE_R : R_DIAG, nullptr, next, grad_stage, stl_here);
+    dinv_done = stl_here;
     if (next) c->he_n[p ^ 1] = lds_prod32_eps_blocks(c, M);
     if (dense) launch_lds_prod32(c, params, M, true, R_DENSE_G, nullptr, nullptr, false);
     vin.ell_part = (const double *)c->ell_part[p].p;
@@ -535,7 +539,8 @@ static mivi_status_t run_estimate_lds(mivi_ctx *c, const void *params, const Rng
     if (out.ent_kind == MIVI_ENT_STL || out.ent_kind == MIVI_ENT_STL_ZERO_GRAD) {
       const size_t sh = (8 * (size_t)c->dP + 32 * 33) * c->esize;
       if (sh > 160 * 1024 && !c->stl_CT.p) return fail(c, MIVI_ERR_UNSUPPORTED, "full-rank STL: d too large for the LDS-resident solve");
-      launch_fr_stl(c, params, M);
+      if (stl2_shape_ok(c, M)) launch_stl2(c, params, M, dinv_done);
+      else launch_fr_stl(c, params, M);
     }
     vin.ld_part = (const double *)c->ld_part[p].p;   // left by the reduce kernel (the VJP kernel may already be updating C)
     vin.n_ld_part = p32 ? fr_ld_blocks(c) : lds_ld_blocks(c);
@@ -680,7 +685,8 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
       if (out.ent_kind == MIVI_ENT_STL || out.ent_kind == MIVI_ENT_STL_ZERO_GRAD) {
         const size_t sh = (8 * (size_t)c->dP + 32 * 33) * c->esize;
         if (sh > 160 * 1024 && !c->stl_CT.p) return fail(c, MIVI_ERR_UNSUPPORTED, "full-rank STL: d too large for the LDS-resident solve");
-        launch_fr_stl(c, params, M);
+        if (stl2_shape_ok(c, M)) launch_stl2(c, params, M);
+        else launch_fr_stl(c, params, M);
       }
       EpsJob nx{};
       const EpsJob *next = nullptr;

@@ -255,6 +255,7 @@ struct mivi_ctx {
   mivi::DevBuf eps[2], epsT[2], ell_part[2], he_part[2], sc_part[2], ld_part[2];
   mivi::DevBuf tabA, tabB, tabD;   // XCD-aware work tables of the MFMA kernels
   mivi::DevBuf stl_CT, stl_Dinv;   // transposed scale + inverted diagonal blocks (full-rank STL, f32)
+  mivi::DevBuf stl_X;              // second-generation STL solve: X of the lower half + updated right-hand side of the upper half
   // second-generation full-rank kernels (kernels_fullrank_lds.hip): split-K work lists, per-tile slab ranges, slabs
   mivi::DevBuf lds_tabS, lds_tilesS, lds_tabD, lds_tilesD, lds_tabV, lds_slab;
   int lds_nS = 0, lds_nD = 0, lds_nV = 0, lds_M = -1, lds_zero_slab = 0;
@@ -318,7 +319,8 @@ int lds_ld_blocks(const mivi_ctx *c);
 void launch_lds_sample(mivi_ctx *c, const void *params, int M, const EpsJob *next = nullptr);   // next: also draws eps(t+1)
 int lds_eps_blocks(const mivi_ctx *c, int M);
 void launch_lds_dense(mivi_ctx *c, int M);
-void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int mode, void *Z, const EpsJob *next, bool want_ld);
+void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int mode, void *Z, const EpsJob *next, bool want_ld,
+                       bool with_dinv = false);   // with_dinv: trailing workgroups invert the 64x64 diagonal blocks of C (STL)
 int lds_prod32_tiles(const mivi_ctx *c, int M);
 int lds_prod32_eps_blocks(const mivi_ctx *c, int M);
 bool lds_use_prod32(const mivi_ctx *c, int M);
@@ -326,6 +328,10 @@ bool lds_bf16x3();   // products on the bf16 matrix cores (three-way exact opera
 void launch_lds_reduce(mivi_ctx *c, const void *params, int M, int mode, void *Z, bool want_ld);
 void launch_lds_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const ValueJob *self, const FusedUpdate *upd);
 void invalidate_graph(mivi_ctx *c);            // mivi_api.hip: drop the cached hipGraphExec and the eps speculation
+
+// kernels_stl.hip (f32, d in {256, 512, 1024, 2048}, M % 32 == 0)
+bool stl2_shape_ok(const mivi_ctx *c, int M);
+void launch_stl2(mivi_ctx *c, const void *params, int M, bool dinv_done = false);   // W += C^-T eps: dinv64 -> solve (lower half) -> update -> solve (upper half)
 
 // kernels_targets.hip
 void launch_col_target(mivi_ctx *c, int M, int want_grad);
