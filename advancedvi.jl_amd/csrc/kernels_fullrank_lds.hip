@@ -693,8 +693,10 @@ struct Prod32Args {
   double *ell_part;  // one per tile workgroup
   double *ld_part;   // [2][d/32] or nullptr
   int n_tiles;       // blocks in [n_tiles, n_tiles + n_eps) draw eps of the next estimate
-  int n_eps;         // ... and the ones behind them invert the 64x64 diagonal blocks of C for the STL solve (dinv != nullptr)
-  float *dinv;
+  int n_eps;
+  int n_dinv;        // STL riders (parameters only, off the critical path; stl_dinv.h): the FIRST n_dinv blocks invert the 64x64
+  int n_pack;        // diagonal blocks of C (a long latency chain: started first), the LAST n_pack re-lay its off-diagonal blocks
+  unsigned *stl_pack;
   int ncb;
   SampleArgs<float> next_eps;
   long long *dbg;
@@ -720,13 +722,18 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int d = a.d;
-  if ((int)blockIdx.x >= a.n_tiles + a.n_eps) {   // STL: C_JJ^{-1} of one diagonal block (parameters only: off the critical path)
-    stl_dinv64_block<NT>(d, a.A, a.dinv, (int)blockIdx.x - a.n_tiles - a.n_eps, lds);
+  if ((int)blockIdx.x < a.n_dinv) {
+    stl_dinv64_block<NT>(d, a.A, a.stl_pack, (int)blockIdx.x, lds);
     return;
   }
-  if ((int)blockIdx.x >= a.n_tiles) {   // eps(t+1): one Philox block per thread (rows gi..gi+3 of column gm), the k_eps stream
+  const int bid = (int)blockIdx.x - a.n_dinv;
+  if (bid >= a.n_tiles + a.n_eps) {
+    stl_pack_block<NT>(d, a.A, a.stl_pack, bid - a.n_tiles - a.n_eps);
+    return;
+  }
+  if (bid >= a.n_tiles) {   // eps(t+1): one Philox block per thread (rows gi..gi+3 of column gm), the k_eps stream
     const SampleArgs<float> &n = a.next_eps;
-    const int eb = blockIdx.x - a.n_tiles, nrb = d >> 6;
+    const int eb = bid - a.n_tiles, nrb = d >> 6;
     const int gi = (eb % nrb) * 64 + 4 * (tid & 15), gm = (eb / nrb) * 32 + (tid >> 4);
     float e[4];
     eps_block<float>(n.rng.seed, rng_index(n.rng), (uint64_t)(n.rng.m_offset + gm) * (uint64_t)(d >> 2) + (uint64_t)(gi >> 2), e);
@@ -740,7 +747,7 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
   MIVI_STAMP_K(a.dbg, MODE, 0);
   // heaviest row blocks first (they bound the kernel)
   const int nrb = d >> 5;
-  const int rb = nrb - 1 - (int)blockIdx.x / a.ncb, cb = (int)blockIdx.x % a.ncb;
+  const int rb = nrb - 1 - bid / a.ncb, cb = bid % a.ncb;
   const int row0 = rb * 32, col0 = cb * 32;
   const int nst = (MODE == G_SAMPLE) ? rb + 1 : nrb;            // 32-k sub-stages of this tile
   const int t_beg = (w * nst) / NW, t_end = ((w + 1) * nst) / NW;   // this wave's run
@@ -863,7 +870,7 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
   }
   if (a.mode == R_DIAG || a.mode == R_DENSE_G) {
     const double sl = block_sum<double, NT>((double)ell, red);
-    if (tid == 0) a.ell_part[blockIdx.x] = sl;
+    if (tid == 0) a.ell_part[bid] = sl;
   }
   if (ld_blk) {   // log|det C| partial of this 32-row block (lanes 0..31 of wave 0)
     float lg = logf(cii), bad = (cii > 0.f) ? 0.f : 1.f;
@@ -1252,12 +1259,11 @@ void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int m
     grid += a.n_eps;
   }
   if (with_dinv && !dense) {
-    a.dinv = (float *)c->stl_Dinv.p;
-    grid += c->cfg.d / 64;
-  } else {
-    a.dinv = nullptr;
+    a.stl_pack = (unsigned *)c->stl_F.p;
+    a.n_dinv = c->cfg.d / 64;
+    a.n_pack = stl_pack_riders(c->cfg.d);
+    grid += a.n_dinv + a.n_pack;
   }
-  if (!a.dinv) grid = a.n_tiles + a.n_eps;
   if (dense && f32_mfma()) hipLaunchKernelGGL((k_fr_prod32<G_DENSE, false>), dim3(grid), dim3(512), 0, c->stream, a);
   else if (dense) hipLaunchKernelGGL((k_fr_prod32<G_DENSE, true>), dim3(grid), dim3(512), 0, c->stream, a);
   else if (f32_mfma()) hipLaunchKernelGGL((k_fr_prod32<G_SAMPLE, false>), dim3(grid), dim3(512), 0, c->stream, a);

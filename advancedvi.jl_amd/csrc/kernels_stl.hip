@@ -11,13 +11,17 @@
 //         R1 = E1 - C21^T X2        (a plain (d/2 x d/2) x (d/2 x M) product on the whole chip: k_stl_update32)
 //         X1 = C11^{-T} R1          (half-size solve)
 //     half of the work becomes a GEMM, each solve streams a quarter of C;
-//   * the chain itself (k_stl_solve64) runs on 64-row blocks with PRE-INVERTED diagonal blocks (k_stl_dinv64), 16 columns per
-//     workgroup, the residual tiles resident in MFMA accumulators (a wave owns the 16-row tiles t = w, w + 8, ...), the pivot
-//     block exchanged through LDS already split into bf16 pieces in fragment order; products on v_mfma_f32_16x16x32_bf16 with the
-//     exact three-way split (kernels_fullrank_lds.hip); the C fragments of the updates come straight from L2 with 16-byte
-//     loads issued one chain step ahead (every C element is used by exactly one wave: nothing to share through LDS).
+//   * the chain itself (k_stl_solve64) runs on 64-row blocks with PRE-INVERTED diagonal blocks, 16 columns per workgroup, four
+//     waves on the dependency chain and four on the updates that are not urgent, the pivot block exchanged through LDS already
+//     split into bf16 pieces in fragment order; products on v_mfma_f32_16x16x32_bf16 with the exact three-way split
+//     (kernels_fullrank_lds.hip);
+//   * everything that depends only on the parameters -- the inverses of the diagonal blocks, the re-laying of the off-diagonal
+//     blocks into fragment order, the bf16 split of what the chain waves consume -- is done by workgroups that RIDE in the
+//     sampling kernel (stl_dinv.h), off the critical path.
 // d in {256, 512, 1024, 2048}, M % 32 == 0; other shapes keep the first-generation kernels.
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include "device_common.h"
 #include "stl_dinv.h"
@@ -72,153 +76,229 @@ __device__ __forceinline__ void mfma16_bf16x3(const f32x4 &a0, const f32x4 &a1, 
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// k_stl_dinv64: DinvT[J][i * 64 + k] = (C_JJ^{-1})[k, i] for every 64 x 64 diagonal block J, one workgroup per block.
+// k_stl_prep: the parameter-only preparation as a kernel of its own (routes where the sampling kernel carries no riders):
+// blocks [0, d/64) invert the diagonal blocks, the rest re-lay the off-diagonal blocks (stl_dinv.h).
 // Recursive doubling inside LDS: with inverses of the b x b diagonal sub-blocks in place,
 //     [A 0; C B]^{-1} = [A^{-1} 0; -B^{-1} (C A^{-1}) B^{-1}]
-// gives the 2b x 2b ones from two b x b x b products (all pairs and all outputs in parallel over the 256 threads):
+// gives the 2b x 2b ones from two b x b x b products (all pairs and all outputs in parallel over the threads):
 // 87 k MACs per block instead of a 64-step substitution chain per column.
 // -----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stl_dinv64(int d, const float *C, float *DinvT) {
+__global__ __launch_bounds__(256) void k_stl_prep(int d, const float *C, unsigned *pack) {
   __shared__ float sm[3 * 64 * 65];
-  stl_dinv64_block<256>(d, C, DinvT, blockIdx.x, sm);
+  if ((int)blockIdx.x < (d >> 6)) stl_dinv64_block<256>(d, C, pack, blockIdx.x, sm);
+  else stl_pack_block<256>(d, C, pack, (int)blockIdx.x - (d >> 6));
 }
 
 // -----------------------------------------------------------------------------------------------------------------
 // k_stl_solve64: T^T X = R for the n x n diagonal sub-block T = C[r0 : r0 + n, r0 : r0 + n], 16 right-hand-side columns per
-// workgroup, 8 waves, wave w owns the 16-row tiles t = w + 8 j (j < TPW = n / 128).  Block J = rows 64 J .. 64 J + 63 = tiles
-// 4 J .. 4 J + 3, owned by waves 0-3 (J even) / 4-7 (J odd).  Back substitution over the blocks, bottom up:
-//   (1) owners of block J: residual tile E - acc, split, to LDS in B-fragment order         | barrier
-//   (2) owners: X tile = DinvT_J (rows of the tile) . R_J  (12 MFMAs), W += X / X stored, X split to LDS   | barrier
-//   (3) every wave: acc_t += C[J, t]^T X_J for its tiles t above block J (12 MFMAs per tile; the C fragments were requested
-//       during the previous step)
+// workgroup, NB = n / 64 block steps bottom up.  The eight waves have FIXED ROLES and the step loop is fully unrolled, so every
+// address, every prefetch distance and every s_waitcnt count is a compile-time constant (a first version with data-dependent
+// roles compiled to vmcnt(0) at every branch merge: 3 us per step, all of it exposed load latency):
+//   * chain waves 0-3 (wave q owns the 16-row tile q of every block) walk the dependency chain, step J:
+//       (a) u  = T[J+1, J]^T-tile . X_{J+1}                 12 MFMAs, X block from LDS, operand planes requested PD steps ahead
+//       (b) r  = E_J - P_J - u                               P_J: partial tile left in LDS by bulk wave q (updates from K >= J + 2)
+//       (c) r split to LDS (B-fragment order)                | barrier A_J
+//       (e) x  = DinvT_J (rows of the tile) . R_J            12 MFMAs; X split to LDS, x stored / added into W   | barrier B_J
+//     Everything they multiply with arrives ALREADY SPLIT into bf16 planes in fragment order (stl_dinv.h): no VALU work on the
+//     operands, six coalesced 1 KiB loads per product.
+//   * bulk waves 4-7 (wave 4 + q owns tile q of the accumulators of blocks 0 .. NB - 3) apply X_K to the blocks I <= K - 2, the
+//     most urgent tile (I = K - 2) first, and hand P_{K-2} to the chain through LDS (lane-to-lane, 16 bytes per lane).  Their C
+//     tiles are f32 in fragment order, DEPTH tiles in flight in registers, split in the wave (88 VALU + 12 MFMAs per tile).
+// What bounds it (tools/stl_stamps.py prints the per-step shader-clock stamps, tools/ubench_cu_stream.hip the per-CU streaming
+// rates): a workgroup pulls its whole triangle (n = 512: 336 KiB of bulk tiles + 384 KiB of planes) through ONE CU, ~30 B/clk;
+// the early windows are bulk-bound (6, 5, 4 tiles of ~650 cycles each), the late ones chain-bound (~1400 cycles per step).
 // k slots: MFMA m (K = 32) takes rows 32 m .. 32 m + 31 of the block; lane group g = lane / 16 supplies rows
-// {32 m + 4 g + r} and {32 m + 16 + 4 g + r}, r < 4 -- exactly the rows an accumulator lane of tiles 2 m and 2 m + 1 holds, and
-// two 16-byte runs of a column of C / a row of DinvT.
+// {32 m + 4 g + r} and {32 m + 16 + 4 g + r}, r < 4 -- exactly the rows an accumulator lane of tiles 2 m and 2 m + 1 holds.
 // -----------------------------------------------------------------------------------------------------------------
 struct StlSolveArgs {
   int d, n, r0;
-  const float *C;        // params + d, column-major, ld = d
-  const float *DinvT;    // [d / 64][64 * 64]
+  const unsigned *pack;  // the packed operands of stl_dinv.h (pivot inverses, chain blocks, bulk blocks of both halves)
   const float *rhs;      // R(i, m) = rhs[(rhs_r0 + i) + m * ld_rhs]
   int rhs_r0, ld_rhs;
   float *X;              // optional: X(i, m) -> X[i + m * ld_x] (rows of this system only)
   int ld_x;
   float *W;              // optional: W[(r0 + i) + m * ld_w] += X(i, m)
   int ld_w;
-  int knock;             // developer knock-outs (MIVI_STL_KNOCK): 1 no C-fragment loads, 2 no update MFMAs, 4 no pivot MFMAs
+  unsigned *stamps;      // developer (MIVI_STL_STAMPS): shader-clock stamps of workgroup 0, [role 2][step 16][4]
 };
 
-template <int TPW>
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F &&f) {   // f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>)
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+// acc(16x16) += A(16 x 32) B(32 x 16), both already split
+__device__ __forceinline__ void mfma16_pre(const bf16x8 &ah, const bf16x8 &am, const bf16x8 &al, const bf16x8 &bh, const bf16x8 &bm,
+                                           const bf16x8 &bl, f32x4 &acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+template <int NB>
 __global__ __launch_bounds__(512) void k_stl_solve64(StlSolveArgs a) {
-  // LDS: pivot block in B-fragment order, [plane 3][m 2][lane 64] x 16 bytes, one image for R and one for X
-  __shared__ __attribute__((aligned(16))) unsigned img[2][3 * 2 * 64 * 4];
+  constexpr int PD = 2;                                   // chain operands are requested PD steps ahead
+  constexpr int IMG = 3 * 2 * 64 * 4;                     // one pivot-block image: [plane 3][m 2][lane 64] x 16 bytes
+  constexpr int P_OFF = 2 * IMG, STAMP_OFF = P_OFF + 2 * 4 * 256;
+  __shared__ __attribute__((aligned(16))) float lds[STAMP_OFF + 128];
+  unsigned *Rimg = reinterpret_cast<unsigned *>(lds), *Ximg = Rimg + IMG;
+  float *Pb = lds + P_OFF;                                // [slot 2][q 4][lane 64][4]
   const int tid = threadIdx.x, lane = tid & 63, n16 = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int d = a.d, nb = a.n >> 6;
+  const int q = w & 3;
+  const int d = a.d;
   const int col = blockIdx.x * 16 + n16;
-  const float *Cs = a.C + (size_t)a.r0 * d + a.r0;    // the sub-block: Cs[i + j * d]
+  const unsigned *Dp = a.pack + (size_t)(a.r0 >> 6) * STL_PLANE_BLOCK;
+  const unsigned *Cp = a.pack + (size_t)(d >> 6) * STL_PLANE_BLOCK + (a.r0 ? stl_solve_units(NB) : 0);   // crit blocks, then the bulk sequence
+  unsigned *stp = reinterpret_cast<unsigned *>(lds + STAMP_OFF);   // developer: [role 2][step 8][4]
+  const bool stamping = a.stamps != nullptr && blockIdx.x == 0 && q == 0 && lane == 0;
+  auto stamp = [&](int r, int J, int k) {
+    if (stamping && J < 8) stp[(r * 8 + J) * 4 + k] = (unsigned)__builtin_readcyclecounter();
+  };
 
-  f32x4 E[TPW], acc[TPW], Wt[TPW];   // right-hand side, accumulated updates, and the W tile X is added to (off the chain)
+  if (w < 4) {
+    // ------------------------------------------------ chain ------------------------------------------------
+    __builtin_amdgcn_s_setprio(3);
+    const unsigned *Dg = Dp + q * 1536 + lane * 4;               // + J * 6144 + (m * 3 + plane) * 256
+    const unsigned *Cg = Cp + q * 1536 + lane * 4;
+    const float *Eg = a.rhs + (size_t)col * a.ld_rhs + a.rhs_r0 + 16 * q + 4 * g;                 // + 64 J
+    const float *Wg = a.W ? a.W + (size_t)col * a.ld_w + a.r0 + 16 * q + 4 * g : nullptr;
+    f32x4 ef[NB], wf[NB];
+    bf16x8 df[NB][6], cf[NB][6];
+    auto request = [&](int J) {
+      ef[J] = *(const f32x4 *)(Eg + 64 * J);
+      if (Wg) wf[J] = *(const f32x4 *)(Wg + 64 * J);
 #pragma unroll
-  for (int j = 0; j < TPW; ++j) {
-    const int t = w + 8 * j;
-    E[j] = *(const f32x4 *)(a.rhs + (size_t)col * a.ld_rhs + a.rhs_r0 + 16 * t + 4 * g);
-    if (a.W) Wt[j] = *(const f32x4 *)(a.W + (size_t)col * a.ld_w + a.r0 + 16 * t + 4 * g);
-    acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  // C fragments of the update by block J for tile j: column (16 t + i) of Cs, rows 64 J + {32 m + 4 g, 32 m + 16 + 4 g} (+ r)
-  f32x4 cf[TPW][4];
-  auto load_cf = [&](int J) {
+      for (int u = 0; u < 6; ++u) df[J][u] = *(const bf16x8 *)(Dg + (size_t)J * STL_PLANE_BLOCK + u * 256);
+      if (J < NB - 1) {
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-      const int t = w + 8 * j;
-      if ((t >> 2) < J && !(a.knock & 1)) {
-        const float *p = Cs + (size_t)(16 * t + n16) * d + 64 * J + 4 * g;
-        cf[j][0] = *(const f32x4 *)(p);
-        cf[j][1] = *(const f32x4 *)(p + 16);
-        cf[j][2] = *(const f32x4 *)(p + 32);
-        cf[j][3] = *(const f32x4 *)(p + 48);
+        for (int u = 0; u < 6; ++u) cf[J][u] = *(const bf16x8 *)(Cg + (size_t)J * STL_PLANE_BLOCK + u * 256);
       }
-    }
-  };
-  f32x4 df[4];   // DinvT fragments of the owner's tile of the current block
-  auto load_df = [&](int J) {
-    const int q = w & 3;
-    const float *p = a.DinvT + (size_t)((a.r0 >> 6) + J) * 4096 + (size_t)(16 * q + n16) * 64 + 4 * g;
-    df[0] = *(const f32x4 *)(p);
-    df[1] = *(const f32x4 *)(p + 16);
-    df[2] = *(const f32x4 *)(p + 32);
-    df[3] = *(const f32x4 *)(p + 48);
-  };
-  if (((nb - 1) & 1) == (w >> 2)) load_df(nb - 1);
-  load_cf(nb - 1);
-
-  for (int J = nb - 1; J >= 0; --J) {
-    const bool owner = (J & 1) == (w >> 2);
-    const int q = w & 3;                    // owner: its tile inside the block (tile 4 J + q, local index j = (4 J + q) / 8)
-    const int jo = (4 * J + q) >> 3;
-    unsigned *Rimg = img[0], *Ximg = img[1];
+    };
+#pragma unroll
+    for (int J = NB - 1; J > NB - 1 - PD && J >= 0; --J) request(J);   // (compile-time trip count: plain indices)
     const int slot = ((q >> 1) * 64 + lane) * 4 + (q & 1) * 2;   // [m = q / 2][lane], half q & 1 (8 bytes)
-    if (owner) {   // (1) residual tile -> LDS, split
-      f32x4 r;
-#pragma unroll
-      for (int j = 0; j < TPW; ++j)
-        if (j == jo) r = E[j] - acc[j];
-      u32x2v h2, m2, l2;
-      split3x4(r, h2, m2, l2);
-      *(u32x2v *)(Rimg + 0 * 512 + slot) = h2;
-      *(u32x2v *)(Rimg + 1 * 512 + slot) = m2;
-      *(u32x2v *)(Rimg + 2 * 512 + slot) = l2;
-    }
-    lds_barrier();
-    if (owner) {   // (2) X tile = DinvT rows . R_J
-      f32x4 x = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const bf16x8 bh = *(const bf16x8 *)(Rimg + 0 * 512 + (m * 64 + lane) * 4);
-        const bf16x8 bm = *(const bf16x8 *)(Rimg + 1 * 512 + (m * 64 + lane) * 4);
-        const bf16x8 bl = *(const bf16x8 *)(Rimg + 2 * 512 + (m * 64 + lane) * 4);
-        if (!(a.knock & 4)) mfma16_bf16x3(df[2 * m], df[2 * m + 1], bh, bm, bl, x);
+    static_for<0, NB>([&](auto jc) {
+      constexpr int J = NB - 1 - decltype(jc)::value;
+      stamp(0, J, 0);
+      if constexpr (J - PD >= 0) request(J - PD);
+      f32x4 r = ef[J];
+      if constexpr (J < NB - 1) {
+        f32x4 u0 = {0.f, 0.f, 0.f, 0.f}, u1 = {0.f, 0.f, 0.f, 0.f};
+        {
+          const bf16x8 xh = *(const bf16x8 *)(Ximg + 0 * 512 + lane * 4);
+          const bf16x8 xm = *(const bf16x8 *)(Ximg + 1 * 512 + lane * 4);
+          const bf16x8 xl = *(const bf16x8 *)(Ximg + 2 * 512 + lane * 4);
+          mfma16_pre(cf[J][0], cf[J][1], cf[J][2], xh, xm, xl, u0);
+        }
+        {
+          const bf16x8 xh = *(const bf16x8 *)(Ximg + 0 * 512 + (64 + lane) * 4);
+          const bf16x8 xm = *(const bf16x8 *)(Ximg + 1 * 512 + (64 + lane) * 4);
+          const bf16x8 xl = *(const bf16x8 *)(Ximg + 2 * 512 + (64 + lane) * 4);
+          mfma16_pre(cf[J][3], cf[J][4], cf[J][5], xh, xm, xl, u1);
+        }
+        r -= u0 + u1;
       }
-      u32x2v h2, m2, l2;
-      split3x4(x, h2, m2, l2);
-      *(u32x2v *)(Ximg + 0 * 512 + slot) = h2;
-      *(u32x2v *)(Ximg + 1 * 512 + slot) = m2;
-      *(u32x2v *)(Ximg + 2 * 512 + slot) = l2;
+      if constexpr (J < NB - 2) r -= *(const f32x4 *)(Pb + ((J & 1) * 4 + q) * 256 + lane * 4);
+      {
+        u32x2v h2, m2, l2;
+        split3x4(r, h2, m2, l2);
+        *(u32x2v *)(Rimg + 0 * 512 + slot) = h2;
+        *(u32x2v *)(Rimg + 1 * 512 + slot) = m2;
+        *(u32x2v *)(Rimg + 2 * 512 + slot) = l2;
+      }
+      stamp(0, J, 1);
+      lds_barrier();   // A_J
+      stamp(0, J, 2);
+      f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = {0.f, 0.f, 0.f, 0.f};
+      {
+        const bf16x8 bh = *(const bf16x8 *)(Rimg + 0 * 512 + lane * 4);
+        const bf16x8 bm = *(const bf16x8 *)(Rimg + 1 * 512 + lane * 4);
+        const bf16x8 bl = *(const bf16x8 *)(Rimg + 2 * 512 + lane * 4);
+        mfma16_pre(df[J][0], df[J][1], df[J][2], bh, bm, bl, x0);
+      }
+      {
+        const bf16x8 bh = *(const bf16x8 *)(Rimg + 0 * 512 + (64 + lane) * 4);
+        const bf16x8 bm = *(const bf16x8 *)(Rimg + 1 * 512 + (64 + lane) * 4);
+        const bf16x8 bl = *(const bf16x8 *)(Rimg + 2 * 512 + (64 + lane) * 4);
+        mfma16_pre(df[J][3], df[J][4], df[J][5], bh, bm, bl, x1);
+      }
+      const f32x4 x = x0 + x1;
+      if constexpr (J > 0) {
+        u32x2v h2, m2, l2;
+        split3x4(x, h2, m2, l2);
+        *(u32x2v *)(Ximg + 0 * 512 + slot) = h2;
+        *(u32x2v *)(Ximg + 1 * 512 + slot) = m2;
+        *(u32x2v *)(Ximg + 2 * 512 + slot) = l2;
+      }
       const int row = 64 * J + 16 * q + 4 * g;
       if (a.X) *(f32x4 *)(a.X + (size_t)col * a.ld_x + row) = x;
-      if (a.W) {
-        f32x4 wv;
-#pragma unroll
-        for (int j = 0; j < TPW; ++j)
-          if (j == jo) wv = Wt[j] + x;
-        *(f32x4 *)(a.W + (size_t)col * a.ld_w + a.r0 + row) = wv;
-      }
-    }
-    if (J == 0) break;
-    if (((J - 1) & 1) == (w >> 2)) load_df(J - 1);   // next pivot's inverse rows: in flight across the barrier
-    lds_barrier();
-    // (3) updates with X_J; the fragments of the NEXT step's updates are requested before this step's MFMAs run
-    bf16x8 xb[2][3];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) xb[m][pl] = *(const bf16x8 *)(Ximg + pl * 512 + (m * 64 + lane) * 4);
-    f32x4 cur[TPW][4];
-#pragma unroll
-    for (int j = 0; j < TPW; ++j)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) cur[j][u] = cf[j][u];
-    load_cf(J - 1);
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-      const int t = w + 8 * j;
-      if ((t >> 2) < J && !(a.knock & 2)) {
-        mfma16_bf16x3(cur[j][0], cur[j][1], xb[0][0], xb[0][1], xb[0][2], acc[j]);
-        mfma16_bf16x3(cur[j][2], cur[j][3], xb[1][0], xb[1][1], xb[1][2], acc[j]);
-      }
-    }
+      if (a.W) *(f32x4 *)(a.W + (size_t)col * a.ld_w + a.r0 + row) = wf[J] + x;
+      stamp(0, J, 3);
+      if constexpr (J > 0) lds_barrier();   // B_J
+    });
+    if (stamping)
+      for (int i = 0; i < 32; ++i) a.stamps[i] = stp[i];
+    return;
   }
+  // -------------------------------------------------- bulk --------------------------------------------------
+  // update sequence s: K = NB - 1 .. 2, I = K - 2 .. 0 -- the order the packed buffer stores the blocks in: wave q streams the
+  // 4 KiB tile [s][q] with plain 16-byte loads, DEPTH tiles (16 registers each) in flight.  (LDS-DMA would save the registers, but
+  // one wave gets only ~1 KiB per 250 cycles through it -- tools/ubench_cu_stream.hip: 36 GB/s per CU with four waves against
+  // 77 GB/s with sixteen plain loads in flight per wave -- and this kernel is bound by what one CU can pull.)
+  constexpr int S = stl_seq_len(NB), DEPTH = 6;
+  const float *Bg = reinterpret_cast<const float *>(Cp + (size_t)(NB - 1) * STL_PLANE_BLOCK) + q * 1024 + lane * 4;
+  f32x4 fb[S > 0 ? S : 1][4];
+  auto issue = [&](auto sc_) {   // request tile s of the sequence
+    constexpr int s = decltype(sc_)::value;
+    if constexpr (s < S) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) fb[s][p] = *(const f32x4 *)(Bg + (size_t)s * STL_F32_BLOCK + p * 256);
+    }
+  };
+  static_for<0, DEPTH>(issue);
+  constexpr int NACC = NB > 2 ? NB - 2 : 1;
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int I = 0; I < NACC; ++I) acc[I] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 xb[2][3];
+  auto update = [&](auto sc_) {   // tile s of the sequence: acc[I] += T[K, I]^T-tile . X_K
+    constexpr int s = decltype(sc_)::value;
+    constexpr int I = stl_seq_I(NB, s);
+    mfma16_bf16x3(fb[s][0], fb[s][1], xb[0][0], xb[0][1], xb[0][2], acc[I]);
+    mfma16_bf16x3(fb[s][2], fb[s][3], xb[1][0], xb[1][1], xb[1][2], acc[I]);
+    issue(std::integral_constant<int, s + DEPTH>{});
+  };
+  static_for<0, NB>([&](auto jc) {
+    constexpr int J = NB - 1 - decltype(jc)::value;
+    stamp(1, J, 0);
+    lds_barrier();   // A_J
+    stamp(1, J, 1);
+    if constexpr (J + 1 <= NB - 1 && J + 1 >= 2) {   // the rest of the X_{J+1} updates
+      constexpr int K = J + 1, nf = K / 2, s0 = stl_seq_first(NB, K);
+      static_for<s0 + nf, s0 + K - 1>(update);
+    }
+    stamp(1, J, 2);
+    if constexpr (J > 0) lds_barrier();   // B_J
+    stamp(1, J, 3);
+    if constexpr (J >= 2) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) xb[m][pl] = *(const bf16x8 *)(Ximg + pl * 512 + (m * 64 + lane) * 4);
+      constexpr int nf = J / 2, s0 = stl_seq_first(NB, J);   // the first nf of the J - 1 tiles, I = J - 2 first
+      update(std::integral_constant<int, s0>{});
+      *(f32x4 *)(Pb + (((J - 2) & 1) * 4 + q) * 256 + lane * 4) = acc[J - 2];
+      static_for<s0 + 1, s0 + nf>(update);
+    }
+  });
+  if (stamping)
+    for (int i = 32; i < 64; ++i) a.stamps[i] = stp[i];
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -315,12 +395,12 @@ bool stl2_shape_ok(const mivi_ctx *c, int M) {
 }
 
 static void launch_solve(mivi_ctx *c, const StlSolveArgs &a, int M) {
-  const int tpw = a.n / 128;
+  const int nb = a.n / 64;
   const dim3 grid(M / 16), block(512);
-  if (tpw == 1) hipLaunchKernelGGL(k_stl_solve64<1>, grid, block, 0, c->stream, a);
-  else if (tpw == 2) hipLaunchKernelGGL(k_stl_solve64<2>, grid, block, 0, c->stream, a);
-  else if (tpw == 4) hipLaunchKernelGGL(k_stl_solve64<4>, grid, block, 0, c->stream, a);
-  else hipLaunchKernelGGL(k_stl_solve64<8>, grid, block, 0, c->stream, a);
+  if (nb == 2) hipLaunchKernelGGL(k_stl_solve64<2>, grid, block, 0, c->stream, a);
+  else if (nb == 4) hipLaunchKernelGGL(k_stl_solve64<4>, grid, block, 0, c->stream, a);
+  else if (nb == 8) hipLaunchKernelGGL(k_stl_solve64<8>, grid, block, 0, c->stream, a);
+  else hipLaunchKernelGGL(k_stl_solve64<16>, grid, block, 0, c->stream, a);
 }
 
 // W += C^{-T} eps for the current estimate (W: d x M, ld d; eps: ld dP).  Needs c->stl_Dinv (d/64 * 4096 floats) and
@@ -328,14 +408,14 @@ static void launch_solve(mivi_ctx *c, const StlSolveArgs &a, int M) {
 void launch_stl2(mivi_ctx *c, const void *params, int M, bool dinv_done) {
   const int d = c->cfg.d, n = d / 2;
   const float *C = (const float *)params + d;
-  float *Dinv = (float *)c->stl_Dinv.p;
+  unsigned *pack = (unsigned *)c->stl_F.p;
   float *Xb = (float *)c->stl_X.p, *Rt = Xb + (size_t)n * M;
   const float *eps = (const float *)c->eps[c->cur].p;
-  if (!dinv_done) hipLaunchKernelGGL(k_stl_dinv64, dim3(d / 64), dim3(256), 0, c->stream, d, C, Dinv);
+  if (!dinv_done) hipLaunchKernelGGL(k_stl_prep, dim3(d / 64 + stl_pack_riders(d)), dim3(256), 0, c->stream, d, C, pack);
   StlSolveArgs s{};
-  static const int knock = getenv("MIVI_STL_KNOCK") ? atoi(getenv("MIVI_STL_KNOCK")) : 0;
-  s.knock = knock;
-  s.d = d; s.n = n; s.C = C; s.DinvT = Dinv;
+  s.d = d; s.n = n; s.pack = pack;
+  static const bool stamps = getenv("MIVI_STL_STAMPS") != nullptr;
+  if (stamps) s.stamps = (unsigned *)((char *)c->stl_X.p + c->stl_X.bytes - 4096);
   // lower half: C22^T X2 = E2
   s.r0 = n; s.rhs = eps; s.rhs_r0 = n; s.ld_rhs = c->dP; s.X = Xb; s.ld_x = n; s.W = (float *)c->W.p; s.ld_w = d;
   launch_solve(c, s, M);
@@ -347,7 +427,25 @@ void launch_stl2(mivi_ctx *c, const void *params, int M, bool dinv_done) {
   hipLaunchKernelGGL(k_stl_update32, dim3((n / 32) * (M / 32)), dim3(512), 0, c->stream, u);
   // upper half: C11^T X1 = R1
   s.r0 = 0; s.rhs = Rt; s.rhs_r0 = 0; s.ld_rhs = n; s.X = nullptr; s.ld_x = 0;
+  if (stamps) s.stamps += 64;
   launch_solve(c, s, M);
+  if (stamps) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(c->stream, &cs);
+    if (cs == hipStreamCaptureStatusNone) {
+      unsigned h[128];
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipMemcpy(h, s.stamps - 64, sizeof h, hipMemcpyDeviceToHost);
+      for (int k = 0; k < 2; ++k)
+        for (int role = 0; role < 2; ++role) {
+          fprintf(stderr, "[stl stamps] solve %d %s:", k, role ? "bulk " : "chain");
+          const unsigned t0 = h[k * 64 + (0 * 8 + 7) * 4];
+          for (int J = 7; J >= 0; --J)
+            for (int i = 0; i < 4; ++i) fprintf(stderr, "%s%u", i ? " " : " | ", h[k * 64 + (role * 8 + J) * 4 + i] - t0);
+          fprintf(stderr, "\n");
+        }
+    }
+  }
 }
 
 }  // namespace mivi

@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>   // types only: the library is opened at run time (mivi_comm_init), libmivi has no link-time RCCL dependency
 
 #include "mivi_internal.h"
+#include "stl_dinv.h"
 
 using namespace mivi;
 
@@ -86,7 +87,8 @@ static mivi_status_t ensure_work(mivi_ctx *c, int M) {
     if (c->cfg.family == MIVI_FULLRANK && (c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD)) {
       if ((s = ensure(c, c->stl_CT, (size_t)c->dP * c->dP * es, true))) return s;
       if ((s = ensure(c, c->stl_Dinv, (size_t)((d + 63) / 64) * 4096 * es, false))) return s;   // 32x32 or 64x64 diagonal inverses
-      if ((s = ensure(c, c->stl_X, (size_t)d * capM * es, false))) return s;
+      if ((s = ensure(c, c->stl_X, (size_t)d * capM * es + 4096, false))) return s;
+      if (d % 128 == 0 && (s = ensure(c, c->stl_F, mivi::stl_pack_units(d) * 4, false))) return s;   // + developer stamp page (MIVI_STL_STAMPS)
     }
     if (c->cfg.family == MIVI_MEANFIELD && c->target == TGT_FUNNEL)
       for (int b = 0; b < 2; ++b)
@@ -161,7 +163,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_S, &c->dist_F, &c->lds_tabS, &c->lds_tilesS, &c->lds_tabD, &c->lds_tilesD, &c->lds_tabV, &c->lds_slab, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_S, &c->dist_F, &c->lds_tabS, &c->lds_tilesS, &c->lds_tabD, &c->lds_tilesD, &c->lds_tabV, &c->lds_slab, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);

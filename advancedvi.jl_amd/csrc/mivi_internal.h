@@ -255,6 +255,7 @@ struct mivi_ctx {
   mivi::DevBuf eps[2], epsT[2], ell_part[2], he_part[2], sc_part[2], ld_part[2];
   mivi::DevBuf tabA, tabB, tabD;   // XCD-aware work tables of the MFMA kernels
   mivi::DevBuf stl_CT, stl_Dinv;   // transposed scale + inverted diagonal blocks (full-rank STL, f32)
+  mivi::DevBuf stl_F;              // second-generation STL solve: packed operands (stl_dinv.h: pivot inverses + off-diagonal blocks, fragment order)
   mivi::DevBuf stl_X;              // second-generation STL solve: X of the lower half + updated right-hand side of the upper half
   // second-generation full-rank kernels (kernels_fullrank_lds.hip): split-K work lists, per-tile slab ranges, slabs
   mivi::DevBuf lds_tabS, lds_tilesS, lds_tabD, lds_tilesD, lds_tabV, lds_slab;
