@@ -76,69 +76,31 @@ __device__ __forceinline__ double ld_f64(const double *p) {
   return *p;
 }
 
-// Row 0 and ell of the fused funnel target (see FunnelFin): per column, total sum of squares from the per-quad partials,
-// e1 from the eps stream, then  ell_m, W_0m (kernels_targets.hip k_col_target / oracle FunnelStackedTarget); writes the
-// two gradient (or shard-partial) entries of row 0 and returns this thread's share of sum_m ell_m.
+// Row 0 and the column-only part of ell of the fused funnel target (see FunnelFin): e1 / eps_0 per column from the eps stream,
+// the A / B partials of the main kernel summed in index order; writes the two gradient (or shard-partial) entries of row 0 and
+// returns this thread's share of sum_m ell_m (kernels_targets.hip k_col_target / oracle FunnelStackedTarget).
 template <typename T, int NT>
 __device__ double funnel_finish(int d, const FunnelFin &f, const OutArgs &out, double *red) {
-  __shared__ double fcs[NT / 64][64];
-  const int tid = threadIdx.x, col = tid & 63, slot = tid >> 6;
+  const int tid = threadIdx.x;
   const T *params = (const T *)f.params;
-  const T *cs = (const T *)f.cs;
   const double mu0 = (double)params[0], sg0 = (double)params[d];
   const uint64_t idx = rng_index(f.rng);
   const bool stl = ent_is_stl(out.ent_kind);
   const double n = (double)(d - 1), sv2 = f.sigma_v * f.sigma_v;
   double s_ell = 0.0, sW = 0.0, sWe = 0.0;
-  typedef T T4 __attribute__((ext_vector_type(4)));
-  const int lane = tid & 63, m4 = lane & 15, rsub = lane >> 4;
-  for (int m0 = 0; m0 < f.M; m0 += 64) {
-    const int m = m0 + col;
-    // 64 columns x d4 row-quads of partials: a lane takes 4 columns (one 16/32-byte load), a wave 4 row-quads per load,
-    // eight independent loads in flight per lane -- this runs on ONE workgroup, so latency, not bandwidth, is the cost
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    const T *base = cs + m0 + 4 * m4;
-    int rq = slot * 4 + rsub;
-    const int stride = 4 * (NT / 64);
-    for (; rq + 7 * stride < f.d4; rq += 8 * stride) {
-      T4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *(const T4 *)(base + (size_t)(rq + u * stride) * f.Mld);
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += (double)v[u][j];
-    }
-    for (; rq < f.d4; rq += stride) {
-      const T4 v = *(const T4 *)(base + (size_t)rq * f.Mld);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] += (double)v[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {   // fold the four row-quad lanes groups of the wave
-      acc[j] += __shfl_xor(acc[j], 16, 64);
-      acc[j] += __shfl_xor(acc[j], 32, 64);
-    }
-    if (rsub == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fcs[slot][4 * m4 + j] = acc[j];
-    }
-    __syncthreads();
-    if (slot == 0 && m < f.M) {
-      double sx2 = 0.0;
-#pragma unroll
-      for (int q = 0; q < NT / 64; ++q) sx2 += fcs[q][col];
-      T e[4];
-      eps_block<T>(f.rng.seed, idx, (uint64_t)(f.rng.m_offset + m) * (uint64_t)f.d4, e);   // row-quad 0 of column m
-      const double e0 = (double)e[0];
-      const double e1 = (double)((T)mu0 + (T)sg0 * e[0]);   // the same rounding as the main kernel's z
-      const double inv_s2 = exp(-2.0 * e1);
-      s_ell += (-e1 - e1 * e1 / (2.0 * sv2)) + (-n * e1 - 0.5 * sx2 * inv_s2) + e1;
-      const double w = (-1.0 - e1 / sv2) + (-n + sx2 * inv_s2) + 1.0 + (stl ? e0 / sg0 : 0.0);
-      sW += w;
-      sWe += w * e0;
-    }
-    __syncthreads();
+  for (int m = tid; m < f.M; m += NT) {
+    T e[4];
+    eps_block<T>(f.rng.seed, idx, (uint64_t)(f.rng.m_offset + m) * (uint64_t)f.d4, e);   // row-quad 0 of column m
+    const double e0 = (double)e[0];
+    const double e1 = (double)((T)mu0 + (T)sg0 * e[0]);   // the same rounding as the main kernel's z
+    s_ell += (-e1 - e1 * e1 / (2.0 * sv2)) + (-n * e1) + e1;
+    const double w = (-1.0 - e1 / sv2) + (-n) + 1.0 + (stl ? e0 / sg0 : 0.0);
+    sW += w;
+    sWe += w * e0;
+  }
+  for (int i = tid; i < f.n_part; i += NT) {
+    sW += f.ab[i];
+    sWe += f.ab[f.n_part + i];
   }
   sW = block_sum<double, NT>(sW, red);
   sWe = block_sum<double, NT>(sWe, red);
@@ -162,15 +124,14 @@ __device__ double funnel_finish(int d, const FunnelFin &f, const OutArgs &out, d
 //   closed-form estimators: d/2 (1 + log 2pi) + sum_i log C_ii            location_scale.jl:52-57
 //   MC / STL estimators   : mean_m 0.5|eps_m|^2 + d/2 log 2pi + sum_i log C_ii   (C^-1 (z_m - mu) == eps_m)
 // `scale_diag(i)` returns C_ii. `red` holds NT/64 doubles.
-// FUNNEL: also finish the fused funnel target (funnel_finish).  Only k_value_funnel instantiates it: inlined into the
-// big kernels it raised their register count (VJP tile kernel 104 -> 162 VGPRs, occupancy 3 -> 2, +1.2 us) for a path
-// they never take.
+// FUNNEL: also finish the fused funnel target (funnel_finish).  Only k_value_funnel and the funnel instantiation of k_mf_main
+// carry it: the other kernels never take that path.
 template <typename T, int NT, bool ATOMIC, bool FUNNEL = false, typename DiagFn>
 __device__ void finalize_value_block(int d, const ValueIn &vin, const OutArgs &out, int64_t plen, DiagFn scale_diag,
                                      double *red) {
   const int tid = threadIdx.x;
   double s_ell = 0.0, s_he = 0.0, s_ld = 0.0, bad = 0.0;
-  if (FUNNEL && vin.fn.cs) s_ell += funnel_finish<T, NT>(d, vin.fn, out, red);
+  if (FUNNEL && vin.fn.ab) s_ell += funnel_finish<T, NT>(d, vin.fn, out, red);
   for (int i = tid; i < vin.n_ell_part; i += NT) s_ell += ld_f64<ATOMIC>(vin.ell_part + i);
   for (int i = tid; i < vin.n_ell_part2; i += NT) s_ell += ld_f64<ATOMIC>(vin.ell_part2 + i);
   for (int i = tid; i < vin.n_ell; i += NT) s_ell += (double)((const T *)vin.ell)[i];

@@ -38,16 +38,17 @@ __device__ __forceinline__ double row16_sum(double v) {   // f64 contexts: plain
 // sit in the register budget of the plain kernel).
 template <typename T, bool FN = false>
 __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
-  __shared__ T xw[10][16];        // [value][wave*4 + row16] partial sums
-  __shared__ double tot[12];
+  constexpr int NV = FN ? 12 : 10;   // reduced values: sW[4], sWe[4], ell, 0.5 eps^2 (+ the funnel's A, B)
+  __shared__ T xw[NV][16];        // [value][wave*4 + row16] partial sums
+  __shared__ double tot[14];      // 0-7 rows, 8 ell, 9 he, 10 log sigma, 11 bad, 12 A, 13 B
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int rq = blockIdx.x, cc = blockIdx.y;
+  const int rq = (int)blockIdx.x - a.has_prev, cc = blockIdx.y;
   const int d = a.d, d4 = (d + 3) >> 2;
-  if (rq >= d4) {   // heterogeneous workgroup: objective value of the PREVIOUS estimate
-    if (a.has_prev && cc == 0) {
+  if (rq < 0) {   // heterogeneous workgroup: objective value of the PREVIOUS estimate.  Block 0: a one-workgroup latency chain
+    if (cc == 0) {   // (partials from memory, block sums) as long as the rest of the kernel, so it has to start first
       __shared__ double red[4];
       const T *sig = a.params + d;
-      finalize_value_block<T, 256, false>(d, a.prev_vin, a.prev_out, 2 * (int64_t)d, [sig](int i) { return sig[i]; }, red);
+      finalize_value_block<T, 256, false, FN>(d, a.prev_vin, a.prev_out, 2 * (int64_t)d, [sig](int i) { return sig[i]; }, red);
     }
     return;
   }
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
   }
 
   T sW[4] = {0, 0, 0, 0}, sWe[4] = {0, 0, 0, 0};
-  T s_ell = 0, s_he = 0;
+  T s_ell = 0, s_he = 0, sA = 0, sB = 0;
   const int c_end = min(a.M, (cc + 1) * a.cols_per_cc);
   for (int m = cc * a.cols_per_cc + tid; m < c_end; m += 256) {
     T e[4];
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
       }
     } else if (FN && a.target == TGT_FUNNEL) {
       // Neal's funnel + Stacked([log, identity]) fused (see FunnelFin): rows >= 1 need only e1[m] = z[0, m], re-derived
-      // from the eps stream; row 0 and ell are finished by the value workgroup from the per-quad sums of squares
+      // from the eps stream; their sum of squares enters row 0 and ell only through x^2 exp(-2 e1) (and that times eps_0)
       T e0q[4];
       if (rq == 0) { e0q[0] = e[0]; }
       else eps_block<T>(a.rng.seed, idx, (uint64_t)(a.rng.m_offset + m) * (uint64_t)d4, e0q);
@@ -98,7 +99,10 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
           x2 += z * z;
         }
       }
-      a.fn_cs[(size_t)rq * a.fn_Mld + m] = x2;
+      const T xi = x2 * inv_s2;
+      s_ell += T(-0.5) * xi;
+      sA += xi;
+      sB += xi * e0q[0];
     } else if (a.want_grad) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) g[r] = a.G[(size_t)m * d + min(4 * rq + r, d - 1)];
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
 
   // ---- reductions: DPP to 16-lane rows, one LDS exchange, 12 threads finish in fp64 ------------
   {
-    T v[10];
+    T v[NV];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       v[r] = row16_sum(sW[r]);
@@ -129,18 +133,22 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
     }
     v[8] = row16_sum(s_ell);
     v[9] = row16_sum(s_he);
+    if (FN) {
+      v[NV - 2] = row16_sum(sA);
+      v[NV - 1] = row16_sum(sB);
+    }
     if ((lane & 15) == 0) {
       const int slot = wv * 4 + (lane >> 4);
 #pragma unroll
-      for (int k = 0; k < 10; ++k) xw[k][slot] = v[k];
+      for (int k = 0; k < NV; ++k) xw[k][slot] = v[k];
     }
   }
   __syncthreads();
-  if (tid < 10) {
+  if (tid < NV) {
     double s = 0.0;
 #pragma unroll
     for (int j = 0; j < 16; ++j) s += (double)xw[tid][j];
-    tot[tid] = s;
+    tot[tid < 10 ? tid : tid + 2] = s;
   } else if (tid >= 16 && tid < 20) {   // log-determinant / positivity partial of this block's rows
     const int r = tid - 16, i = 4 * rq + r;
     double lg = 0.0, bad = 0.0;
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
       a.row_part[((size_t)cc * d4 + rq) * 8 + tid] = tot[tid];
     }
   }
-  if (tid >= 8 && tid < 12) a.sc_part[(size_t)(tid - 8) * nblk + blk] = tot[tid];
+  if (tid >= 8 && tid < (FN ? 14 : 12)) a.sc_part[(size_t)(tid - 8) * nblk + blk] = tot[tid];
   MIVI_STAMP(a.dbg, 3);
 }
 
@@ -476,8 +484,6 @@ static void mf_main_impl(mivi_ctx *c, const void *params, const RngArgs &rng, in
   a.params = (const T *)params;
   a.rng = rng;
   a.target = (G == nullptr && (c->target == TGT_DIAG_GAUSS || c->target == TGT_FUNNEL)) ? c->target : TGT_NONE;
-  a.fn_cs = (T *)c->fn_cs[c->cur].p;
-  a.fn_Mld = c->MP;
   a.t_mean = (const T *)c->t_mean.p;
   a.t_istd = (const T *)c->t_istd.p;
   a.G = (const T *)G;

@@ -419,7 +419,6 @@ void launch_stl2(mivi_ctx *c, const void *params, int M, bool dinv_done) {
   // lower half: C22^T X2 = E2
   s.r0 = n; s.rhs = eps; s.rhs_r0 = n; s.ld_rhs = c->dP; s.X = Xb; s.ld_x = n; s.W = (float *)c->W.p; s.ld_w = d;
   launch_solve(c, s, M);
-  if (getenv("MIVI_STL_TWICE")) { s.W = nullptr; launch_solve(c, s, M); s.W = (float *)c->W.p; }   // developer: does a repeat hit a warm L2?
   // R1 = E1 - C21^T X2
   StlUpdArgs u{};
   u.d = d; u.n_i = n; u.n_k = n; u.i0 = 0; u.k0 = n; u.C = C; u.X = Xb; u.ld_x = n; u.E = eps; u.e_r0 = 0; u.ld_e = c->dP;

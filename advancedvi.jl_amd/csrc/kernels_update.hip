@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_value_funnel(int d, const T *params, Va
   finalize_value_block<T, 256, false, true>(d, vin, out, 2 * (int64_t)d, [params, d](int i) { return params[d + i]; }, red);
 }
 void launch_value_only(mivi_ctx *c, const void *params, const ValueIn &vin, const OutArgs &out) {
-  if (vin.fn.cs && c->cfg.family == MIVI_MEANFIELD) {
+  if (vin.fn.ab && c->cfg.family == MIVI_MEANFIELD) {
     if (c->cfg.dtype == MIVI_F32)
       hipLaunchKernelGGL(k_value_funnel<float>, dim3(1), dim3(256), 0, c->stream, c->cfg.d, (const float *)params, vin, out);
     else

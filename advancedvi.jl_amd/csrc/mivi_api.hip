@@ -77,7 +77,7 @@ static mivi_status_t ensure_work(mivi_ctx *c, int M) {
       }
       if ((s = ensure(c, c->ell_part[b], n_part * sizeof(double), false))) return s;
       if ((s = ensure(c, c->he_part[b], (n_he + 64) * sizeof(double), false))) return s;
-      if ((s = ensure(c, c->sc_part[b], 4 * ncc * d4 * sizeof(double) + 64, false))) return s;
+      if ((s = ensure(c, c->sc_part[b], 6 * ncc * d4 * sizeof(double) + 64, false))) return s;
       if ((s = ensure(c, c->ld_part[b], 2 * (size_t)((d + 31) / 32) * sizeof(double) + 64, false))) return s;
     }
     if (c->target == TGT_DENSE_GAUSS || (c->target == TGT_LOGREG && c->cfg.dtype == MIVI_F32)) {
@@ -90,9 +90,6 @@ static mivi_status_t ensure_work(mivi_ctx *c, int M) {
       if ((s = ensure(c, c->stl_X, (size_t)d * capM * es + 4096, false))) return s;
       if (d % 128 == 0 && (s = ensure(c, c->stl_F, mivi::stl_pack_units(d) * 4, false))) return s;   // + developer stamp page (MIVI_STL_STAMPS)
     }
-    if (c->cfg.family == MIVI_MEANFIELD && c->target == TGT_FUNNEL)
-      for (int b = 0; b < 2; ++b)
-        if ((s = ensure(c, c->fn_cs[b], (size_t)d4 * capM * es, false))) return s;
     if ((s = ensure(c, c->Z, (size_t)d * capM * es, false))) return s;
     if ((s = ensure(c, c->W, (size_t)d * capM * es, false))) return s;
     if ((s = ensure(c, c->ell, (size_t)capM * es, false))) return s;
@@ -163,7 +160,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->fn_cs[0], &c->fn_cs[1], &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_S, &c->dist_F, &c->lds_tabS, &c->lds_tilesS, &c->lds_tabD, &c->lds_tilesD, &c->lds_tabV, &c->lds_slab, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_S, &c->dist_F, &c->lds_tabS, &c->lds_tilesS, &c->lds_tabD, &c->lds_tilesD, &c->lds_tabV, &c->lds_slab, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -442,6 +439,7 @@ struct Chain {
   bool has_next = false;    // another estimate follows: prefetch its eps
   RngArgs next_rng{};
   bool have_prev = false;   // a value job is pending
+  bool estimates_only = false;   // no optimiser step between the estimates: a gradient entry may be finished one launch late
   ValueJob prev{};
 };
 
@@ -450,11 +448,12 @@ static bool no_fused_update() {   // MIVI_NO_FUSED_UPDATE=1: separate update ker
   return v;
 }
 
-static bool hetero_ok(const mivi_ctx *c, int want_grad) {
+static bool hetero_ok(const mivi_ctx *c, int want_grad, const Chain *ch = nullptr) {
   if (!want_grad || c->bij_on) return false;   // (a Stacked bijector runs on the explicit-sample route)
-  // (the fused funnel target is NOT chained: its value workgroup also finishes two gradient entries, which an optimiser
-  //  step right after the estimate must already see)
-  if (c->cfg.family == MIVI_MEANFIELD) return c->target == TGT_DIAG_GAUSS;
+  // (the fused funnel target's value workgroup also finishes two gradient entries, which an optimiser step right after the
+  //  estimate must already see: chained only when nothing reads the gradient between the estimates)
+  if (c->cfg.family == MIVI_MEANFIELD)
+    return c->target == TGT_DIAG_GAUSS || (c->target == TGT_FUNNEL && !c->funnel_constrained && ch && ch->estimates_only);
   if (c->cfg.dtype != MIVI_F32 && f64_valu()) return false;
   return c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS;
 }
@@ -578,7 +577,7 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
   ValueIn vin{};
   vin.ell_const = c->t_const;
   const int d = c->cfg.d, d4 = (d + 3) / 4;
-  const bool chained = ch && ch->on && hetero_ok(c, want_grad) && !out.partials_mode;
+  const bool chained = ch && ch->on && hetero_ok(c, want_grad, ch) && !out.partials_mode;
   // single calls on the MFMA full-rank path: did the previous call's VJP kernel already generate this estimate's eps?
   const bool spec = !chained && c->cfg.family == MIVI_FULLRANK && hetero_ok(c, want_grad) && !stop_after_target;
   bool hit = false;
@@ -603,12 +602,12 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
     if (!bij && (c->target == TGT_DIAG_GAUSS || (c->target == TGT_FUNNEL && want_grad && !c->funnel_constrained))) {
       launch_mf_main(c, params, rng, M, want_grad, nullptr, vin, out, prev);
       if (c->target == TGT_FUNNEL) {   // row 0 and ell are finished by whoever assembles the value (FunnelFin)
-        vin.fn.cs = c->fn_cs[p].p;
+        vin.fn.ab = (const double *)c->sc_part[p].p + 4 * (size_t)c->mf_nblk;
+        vin.fn.n_part = c->mf_nblk;
         vin.fn.params = params;
         vin.fn.rng = rng;
         vin.fn.d4 = d4;
         vin.fn.M = M;
-        vin.fn.Mld = c->MP;
         vin.fn.sigma_v = c->funnel_sigma_v;
       }
       vin.ell_part2 = (const double *)c->sc_part[p].p;
@@ -1168,6 +1167,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
     if ((s = begin_capture(c, &saved))) return s;
     Chain chn;
     chn.on = true;
+    chn.estimates_only = true;
     for (int i = 0; i < count && s == MIVI_OK; ++i) {
       RngArgs r = rng_of(c, (uint64_t)i);
       r.idx_ptr = (const uint64_t *)c->d_idx.p;

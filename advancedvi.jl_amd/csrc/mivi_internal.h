@@ -33,14 +33,17 @@ enum TargetKind : int {
   TGT_CALLBACK = 5
 };
 
-// Fused funnel target (mean-field): the only cross-row coupling of Neal's funnel is sum_i x_i^2 per sample, needed by
-// row 0's gradient and by ell.  The main kernel handles rows >= 1 on its own (every block re-derives e1[m] = z[0, m] from
-// the eps stream) and leaves per-(row-quad, column) sums of squares here; the value workgroup finishes row 0 and ell.
+// Fused funnel target (mean-field): the only cross-row coupling of Neal's funnel is S_m = sum_i x_im^2 per sample, needed by
+// row 0's gradient and by ell -- and every use of it is LINEAR in S_m with a per-column weight any workgroup can re-derive
+// from the eps stream (exp(-2 e1_m), exp(-2 e1_m) eps_0m).  So the main kernel's workgroups (rows >= 1) leave two scalar
+// partials each,  A = sum_{i,m} x_im^2 exp(-2 e1_m)  and  B = sum_{i,m} x_im^2 exp(-2 e1_m) eps_0m  over their own rows, fold
+// -A/2 into their ell partial, and whoever assembles the value adds the O(M) per-column terms and finishes row 0.
 struct FunnelFin {
-  const void *cs;      // T[d4][Mld] sum over the quad's rows i >= 1 of z_i^2  (nullptr = no funnel work)
+  const double *ab;    // [2][n_part] the A and B partials of the main kernel's workgroups  (nullptr = no funnel work)
+  int n_part;
   const void *params;  // [mu; sigma]
   RngArgs rng;
-  int d4, M, Mld;
+  int d4, M;
   double sigma_v;
 };
 
@@ -100,12 +103,10 @@ struct MfArgs {
   const T *t_mean;     // diag gauss mean[d]
   const T *t_istd;     // 1/std[d]
   const T *G;          // generic route: d x M gradient of log pi (ld = d)
-  T *fn_cs;            // fused funnel target (TGT_FUNNEL): out, [d4][fn_Mld] per-quad sums of z_i^2 (rows >= 1)
-  int fn_Mld;
   int want_grad;
   // scratch
   double *row_part;    // [n_cc][2*d4*4] partial row sums when n_cc > 1
-  double *sc_part;     // [n_blocks][2]  scalar partials
+  double *sc_part;     // [4 or 6][n_blocks] scalar partials: ell, 0.5 eps^2, log sigma, #bad sigma (+ funnel A, B)
   ValueIn vin;
   OutArgs out;
   long long *dbg;      // optional timeline: dbg[block*8 + k] = wall_clock64() stamps (nullptr = off)
@@ -238,7 +239,6 @@ struct mivi_ctx {
   const void *lr_pad_R = nullptr;          // geometry for which R's zero pad rows are in place
   long long lr_pad_n = -1;
   int lr_pad_ldr = 0;
-  mivi::DevBuf fn_cs[2];                   // funnel per-(row-quad, column) sums of squares, by parity
   int64_t lr_n = 0;
   int lr_variant = 0;
   double lr_likeadj = 1.0;
