@@ -31,6 +31,16 @@ __device__ __forceinline__ double row16_sum(double v) {   // f64 contexts: plain
   for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Wave total, valid in LANE 63 (f32: the row sums above, then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2-3 --
+// six DPP adds, nothing through LDS; f64: shuffles, valid everywhere).  One fixed tree, shared by the one-launch kernel and
+// the device loop, so both produce the same bits.
+__device__ __forceinline__ float wave_total63(float v) {
+  v = row16_sum(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+  return v;
+}
+__device__ __forceinline__ double wave_total63(double v) { return wave_sum(v); }
 
 // Scalar partial layout written by k_mf_main and consumed by k_mf_value: sc[k*nblk + blk],
 // k = 0 sum ell (variable part), 1 sum 0.5 eps^2, 2 sum log sigma_i (this block's rows), 3 #non-positive sigma.
@@ -39,7 +49,7 @@ __device__ __forceinline__ double row16_sum(double v) {   // f64 contexts: plain
 template <typename T, bool FN = false>
 __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
   constexpr int NV = FN ? 12 : 10;   // reduced values: sW[4], sWe[4], ell, 0.5 eps^2 (+ the funnel's A, B)
-  __shared__ T xw[NV][16];        // [value][wave*4 + row16] partial sums
+  __shared__ T xw[NV][4];         // [value][wave] partial sums
   __shared__ double tot[14];      // 0-7 rows, 8 ell, 9 he, 10 log sigma, 11 bad, 12 A, 13 B
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int rq = (int)blockIdx.x - a.has_prev, cc = blockIdx.y;
@@ -123,31 +133,30 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
   }
   MIVI_STAMP(a.dbg, 1);
 
-  // ---- reductions: DPP to 16-lane rows, one LDS exchange, 12 threads finish in fp64 ------------
+  // ---- reductions: wave totals on the DPP crossbar, one LDS exchange, NV threads finish in fp64 ------------
   {
     T v[NV];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      v[r] = row16_sum(sW[r]);
-      v[4 + r] = row16_sum(sWe[r]);
+      v[r] = wave_total63(sW[r]);
+      v[4 + r] = wave_total63(sWe[r]);
     }
-    v[8] = row16_sum(s_ell);
-    v[9] = row16_sum(s_he);
+    v[8] = wave_total63(s_ell);
+    v[9] = wave_total63(s_he);
     if (FN) {
-      v[NV - 2] = row16_sum(sA);
-      v[NV - 1] = row16_sum(sB);
+      v[NV - 2] = wave_total63(sA);
+      v[NV - 1] = wave_total63(sB);
     }
-    if ((lane & 15) == 0) {
-      const int slot = wv * 4 + (lane >> 4);
+    if (lane == 63) {
 #pragma unroll
-      for (int k = 0; k < NV; ++k) xw[k][slot] = v[k];
+      for (int k = 0; k < NV; ++k) xw[k][wv] = v[k];
     }
   }
   __syncthreads();
   if (tid < NV) {
     double s = 0.0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) s += (double)xw[tid][j];
+    for (int j = 0; j < 4; ++j) s += (double)xw[tid][j];
     tot[tid < 10 ? tid : tid + 2] = s;
   } else if (tid >= 16 && tid < 20) {   // log-determinant / positivity partial of this block's rows
     const int r = tid - 16, i = 4 * rq + r;
@@ -237,17 +246,22 @@ struct MfLoopArgs {
   long long t0;                 // Adam step count before this call
   double eta, clip_eps, b1, b2, adam_eps;
   double *hist;                 // [n_steps][4][nblk]
-  T *grad_out;                  // rule < 0 (estimates at fixed parameters): gradient of the LAST estimate
+  T *grad_out;                  // rule < 0 (estimates at fixed parameters): every estimate writes its gradient here
 };
 
-template <typename T>
+// RULE is a template parameter: the update rules' scalars (eta, betas, clip, Adam state) would otherwise all be live across the
+// Philox block of every variant -- 68 spilled SGPRs in the estimates-only loop.
+template <typename T, int RULE>
 __global__ __launch_bounds__(256) void k_mf_sgd_loop(MfLoopArgs<T> a) {
-  __shared__ T xw[10][16];
-  __shared__ double tot[12];
-  __shared__ T cc[2];
+  // ONE barrier per iteration: the wave totals of the ten sums go to xw[t & 1] (double-buffered, so the next iteration may
+  // write while a slow wave still reads), and after the barrier the eight lanes that own a parameter row read the four
+  // per-wave partials of their row directly.  The Adam bias corrections of 256 steps at a time are tabulated by all threads.
+  __shared__ T xw[2][10][4];
+  __shared__ T cc_tab[256][2];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int rq = blockIdx.x, d = a.d, d4 = (d + 3) >> 2, nblk = gridDim.x;
-  const int M = a.M, n_steps = a.n_steps, rule = a.rule;
+  const int M = a.M, n_steps = a.n_steps;
+  constexpr int rule = RULE;
   const bool stl = ent_is_stl(a.ent_kind);
   const double direct = direct_entropy_coeff(a.ent_kind);
   const double invM = 1.0 / (double)a.M_total;
@@ -266,17 +280,26 @@ __global__ __launch_bounds__(256) void k_mf_sgd_loop(MfLoopArgs<T> a) {
   }
   const int myrow = lane & 7;
   const int myi = min(4 * rq + (myrow & 3), d - 1);
+  const bool row_ok = 4 * rq + (myrow & 3) < d;
+  double lg = 0.0, bad = 0.0;
   T st_m = 0, st_v = 0;
   if (rule == 1) {
     st_m = a.opt_state[(myrow < 4 ? 0 : d) + myi];
     st_v = a.opt_state[2 * d + (myrow < 4 ? 0 : d) + myi];
   }
   for (int t = 0; t < n_steps; ++t) {
+    if (rule == 1 && (t & 255) == 0) {
+      __syncthreads();
+      adam_bias<T>(a.t0 + t + tid + 1, a.b1, a.b2, cc_tab[tid][0], cc_tab[tid][1]);
+      __syncthreads();
+    }
     T sW[4] = {0, 0, 0, 0}, sWe[4] = {0, 0, 0, 0};
     T s_ell = 0, s_he = 0;
-    T isg[4];
+    T isg[4] = {0, 0, 0, 0};
+    if (stl) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) isg[r] = stl ? T(1) / sg[r] : T(0);
+      for (int r = 0; r < 4; ++r) isg[r] = T(1) / sg[r];
+    }
     for (int m = tid; m < M; m += 256) {
       T e[4];
       eps_block<T>(a.seed, a.idx0 + (uint64_t)t, (uint64_t)(a.m_offset + m) * (uint64_t)d4 + (uint64_t)rq, e);
@@ -293,48 +316,60 @@ __global__ __launch_bounds__(256) void k_mf_sgd_loop(MfLoopArgs<T> a) {
         sWe[r] += w * er;
       }
     }
+    T(*xb)[4] = xw[t & 1];
     {
       T v[10];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = row16_sum(sW[r]);
-        v[4 + r] = row16_sum(sWe[r]);
+        v[r] = wave_total63(sW[r]);
+        v[4 + r] = wave_total63(sWe[r]);
       }
-      v[8] = row16_sum(s_ell);
-      v[9] = row16_sum(s_he);
-      if ((lane & 15) == 0) {
-        const int slot = wv * 4 + (lane >> 4);
+      v[8] = wave_total63(s_ell);
+      v[9] = wave_total63(s_he);
+      if (lane == 63) {
 #pragma unroll
-        for (int k = 0; k < 10; ++k) xw[k][slot] = v[k];
+        for (int k = 0; k < 10; ++k) xb[k][wv] = v[k];
       }
     }
-    lds_barrier();
-    if (tid < 10) {
-      double s = 0.0;
+    // log-determinant / positivity partial of this workgroup's rows, the same association as k_mf_main: (l0 + l1) + (l2 + l3)
+    // (estimates at fixed parameters: the parameters do not move, computed once)
+    if (rule >= 0 || t == 0) {
+      double lgs[4], bads[4];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) s += (double)xw[tid][j];
-      tot[tid] = s;
-    } else if (tid >= 16 && tid < 20) {
-      const int r = tid - 16, i = 4 * rq + r;
-      double lg = 0.0, bad = 0.0;
-      if (i < d) {
-        lg = (double)log(sg[r]);
-        bad = (sg[r] > T(0)) ? 0.0 : 1.0;
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = 4 * rq + r < d;
+        lgs[r] = ok ? (double)log(sg[r]) : 0.0;
+        bads[r] = (ok && !(sg[r] > T(0))) ? 1.0 : 0.0;
       }
-      lg += __shfl_xor(lg, 1, 64);
-      lg += __shfl_xor(lg, 2, 64);
-      bad += __shfl_xor(bad, 1, 64);
-      bad += __shfl_xor(bad, 2, 64);
-      if (r == 0) {
-        tot[10] = lg;
-        tot[11] = bad;
-      }
-    } else if (tid == 64 && rule == 1) {   // Adam bias corrections for this step (one lane of an otherwise idle wave)
-      adam_bias<T>(a.t0 + t + 1, a.b1, a.b2, cc[0], cc[1]);
+      lg = (lgs[0] + lgs[1]) + (lgs[2] + lgs[3]);
+      bad = (bads[0] + bads[1]) + (bads[2] + bads[3]);
     }
     lds_barrier();
-    if (tid >= 8 && tid < 12) a.hist[((size_t)t * 4 + (tid - 8)) * nblk + rq] = tot[tid];
-    // lane j < 8 of every wave: gradient of row j exactly as k_mf_main writes it (rounded to T), update, clip
+    if (tid >= 8 && tid < 12) {   // ell and he: wave partials in index order
+      double hv = tid == 10 ? lg : bad;
+      if (tid < 10) {
+        hv = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hv += (double)xb[tid][j];
+      }
+      a.hist[((size_t)t * 4 + (tid - 8)) * nblk + rq] = hv;
+    }
+    if (rule < 0) {   // estimates at fixed parameters: every estimate's gradient is written (the last one stays)
+      if (tid < 8) {
+        double trow = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) trow += (double)xb[myrow][j];
+        const T sgv = (myrow & 3) == 0 ? sg[0] : (myrow & 3) == 1 ? sg[1] : (myrow & 3) == 2 ? sg[2] : sg[3];
+        const T g = (myrow < 4) ? (T)(-trow * invM) : (T)(-trow * invM - direct / (double)sgv);
+        if (row_ok) a.grad_out[(myrow < 4 ? 0 : d) + myi] = g;
+      }
+      continue;
+    }
+    // every lane: total of its row (value lane & 7) in fp64, wave partials in index order; lane j < 8 of every group of eight:
+    // gradient of row j exactly as k_mf_main writes it (rounded to T), update, clip
+    double trow = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) trow += (double)xb[myrow][j];
     T mine = (myrow < 4) ? mu[0] : sg[0];
 #pragma unroll
     for (int r = 1; r < 4; ++r) {
@@ -342,27 +377,24 @@ __global__ __launch_bounds__(256) void k_mf_sgd_loop(MfLoopArgs<T> a) {
     }
     {
       const T sgv = (myrow & 3) == 0 ? sg[0] : (myrow & 3) == 1 ? sg[1] : (myrow & 3) == 2 ? sg[2] : sg[3];
-      const double tr = tot[myrow];
-      const T g = (myrow < 4) ? (T)(-tr * invM) : (T)(-tr * invM - direct / (double)sgv);
-      if (rule < 0) {   // estimates only: parameters stay, the last estimate's gradient is the result
-        if (t == n_steps - 1 && tid < 8 && 4 * rq + (myrow & 3) < d) a.grad_out[(myrow < 4 ? 0 : d) + myi] = g;
-      } else {
-        if (rule == 0) mine = descent_step(mine, g, eta);
-        else mine = adam_step<T>(mine, g, st_m, st_v, cc[0], cc[1], eta, b1, b2, aeps);
-        if (clip && myrow >= 4) mine = clip_step(mine, ceps);
-      }
+      const T g = (myrow < 4) ? (T)(-trow * invM) : (T)(-trow * invM - direct / (double)sgv);
+      if (rule == 0) mine = descent_step(mine, g, eta);
+      else mine = adam_step<T>(mine, g, st_m, st_v, cc_tab[t & 255][0], cc_tab[t & 255][1], eta, b1, b2, aeps);
+      if (clip && myrow >= 4) mine = clip_step(mine, ceps);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       mu[r] = __shfl(mine, r, 8);
       sg[r] = __shfl(mine, 4 + r, 8);
     }
-    lds_barrier();   // tot / xw are reused by the next iteration
   }
   if (tid < 8 && rule >= 0) {
     const int i = 4 * rq + (tid & 3);
     if (i < d) {
-      const T val = (tid < 4) ? mu[tid & 3] : sg[tid & 3];
+      T val = (tid < 4) ? mu[0] : sg[0];   // (select chain, not mu[tid & 3]: a dynamic index would put both arrays in scratch
+#pragma unroll                            //  memory for the whole kernel -- a memory round trip per loop iteration)
+      for (int r = 1; r < 4; ++r)
+        if ((tid & 3) == r) val = (tid < 4) ? mu[r] : sg[r];
       a.params[(tid < 4 ? 0 : d) + i] = val;
       if (rule == 1) {
         a.opt_state[(tid < 4 ? 0 : d) + i] = st_m;
@@ -420,7 +452,9 @@ static void mf_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint64_
   a.hist = hist;
   a.grad_out = (T *)grad_out;
   const int d4 = (a.d + 3) / 4;
-  hipLaunchKernelGGL(k_mf_sgd_loop<T>, dim3(d4), dim3(256), 0, c->stream, a);
+  if (rule < 0) hipLaunchKernelGGL((k_mf_sgd_loop<T, -1>), dim3(d4), dim3(256), 0, c->stream, a);
+  else if (rule == 0) hipLaunchKernelGGL((k_mf_sgd_loop<T, 0>), dim3(d4), dim3(256), 0, c->stream, a);
+  else hipLaunchKernelGGL((k_mf_sgd_loop<T, 1>), dim3(d4), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_mf_loop_value<T>, dim3(n_steps), dim3(256), 0, c->stream, a.d, d4, a.M, a.M_total, a.ent_kind,
                      c->t_const, (const double *)hist, elbo, (int *)c->status.p);
 }
