@@ -3,6 +3,7 @@
 #pragma once
 #include "mivi_internal.h"
 #include "philox.h"
+#include <type_traits>
 
 namespace mivi {
 
@@ -40,6 +41,15 @@ __device__ __forceinline__ T block_sum(T v, T *red) {
 #pragma unroll
   for (int i = 1; i < NT / 64; ++i) s += red[i];
   return s;
+}
+
+// compile-time loop: f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>) -- indices usable as template arguments
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
 }
 
 // timeline stamps: region `kind` (0 mean-field / sample, 1 vjp, 2 dense) x 4096 blocks x 8 slots

@@ -747,7 +747,18 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
   MIVI_STAMP_K(a.dbg, MODE, 0);
   // heaviest row blocks first (they bound the kernel)
   const int nrb = d >> 5;
-  const int rb = nrb - 1 - bid / a.ncb, cb = bid % a.ncb;
+  // tile <- block: workgroup b runs on XCD b % 8 (each XCD has its own L2).  XCD x = (xr, xc) = (x & 3, x >> 2) owns the row
+  // blocks of class rb % 4 == xr and the column blocks of class cb % 2 == xc: an A row panel comes over the fabric twice and a
+  // B column panel four times (8 MB at the north star) instead of A eight times (17 MB with cb = b % 8).
+  int rb, cb;
+  if (!(a.knock & 8) && (nrb & 3) == 0 && (a.ncb & 1) == 0) {
+    const int x = bid & 7, j = bid >> 3, hc = a.ncb >> 1;
+    rb = nrb - 1 - (4 * (j / hc) + (x & 3));
+    cb = 2 * (j % hc) + (x >> 2);
+  } else {
+    rb = nrb - 1 - bid / a.ncb;
+    cb = bid % a.ncb;
+  }
   const int row0 = rb * 32, col0 = cb * 32;
   const int nst = (MODE == G_SAMPLE) ? rb + 1 : nrb;            // 32-k sub-stages of this tile
   const int t_beg = (w * nst) / NW, t_end = ((w + 1) * nst) / NW;   // this wave's run

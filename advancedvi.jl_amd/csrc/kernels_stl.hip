@@ -122,13 +122,6 @@ struct StlSolveArgs {
   unsigned *stamps;      // developer (MIVI_STL_STAMPS): shader-clock stamps of workgroup 0, [role 2][step 16][4]
 };
 
-template <int B, int E, typename F>
-__device__ __forceinline__ void static_for(F &&f) {   // f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>)
-  if constexpr (B < E) {
-    f(std::integral_constant<int, B>{});
-    static_for<B + 1, E>(f);
-  }
-}
 // acc(16x16) += A(16 x 32) B(32 x 16), both already split
 __device__ __forceinline__ void mfma16_pre(const bf16x8 &ah, const bf16x8 &am, const bf16x8 &al, const bf16x8 &bh, const bf16x8 &bm,
                                            const bf16x8 &bl, f32x4 &acc) {
