@@ -76,14 +76,14 @@ __device__ __forceinline__ void mfma16_bf16x3(const f32x4 &a0, const f32x4 &a1, 
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// k_stl_prep: the parameter-only preparation as a kernel of its own (routes where the sampling kernel carries no riders):
+// k_stl_pack: the parameter-only preparation as a kernel of its own (routes where the sampling kernel carries no riders):
 // blocks [0, d/64) invert the diagonal blocks, the rest re-lay the off-diagonal blocks (stl_dinv.h).
 // Recursive doubling inside LDS: with inverses of the b x b diagonal sub-blocks in place,
 //     [A 0; C B]^{-1} = [A^{-1} 0; -B^{-1} (C A^{-1}) B^{-1}]
 // gives the 2b x 2b ones from two b x b x b products (all pairs and all outputs in parallel over the threads):
 // 87 k MACs per block instead of a 64-step substitution chain per column.
 // -----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stl_prep(int d, const float *C, unsigned *pack) {
+__global__ __launch_bounds__(256) void k_stl_pack(int d, const float *C, unsigned *pack) {
   __shared__ float sm[3 * 64 * 65];
   if ((int)blockIdx.x < (d >> 6)) stl_dinv64_block<256>(d, C, pack, blockIdx.x, sm);
   else stl_pack_block<256>(d, C, pack, (int)blockIdx.x - (d >> 6));
@@ -404,7 +404,7 @@ void launch_stl2(mivi_ctx *c, const void *params, int M, bool dinv_done) {
   unsigned *pack = (unsigned *)c->stl_F.p;
   float *Xb = (float *)c->stl_X.p, *Rt = Xb + (size_t)n * M;
   const float *eps = (const float *)c->eps[c->cur].p;
-  if (!dinv_done) hipLaunchKernelGGL(k_stl_prep, dim3(d / 64 + stl_pack_riders(d)), dim3(256), 0, c->stream, d, C, pack);
+  if (!dinv_done) hipLaunchKernelGGL(k_stl_pack, dim3(d / 64 + stl_pack_riders(d)), dim3(256), 0, c->stream, d, C, pack);
   StlSolveArgs s{};
   s.d = d; s.n = n; s.pack = pack;
   static const bool stamps = getenv("MIVI_STL_STAMPS") != nullptr;

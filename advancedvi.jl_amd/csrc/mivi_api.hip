@@ -1397,7 +1397,7 @@ mivi_status_t mivi_debug_timeline(mivi_ctx_t *c, void *buf) {
 }
 
 mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *params, int32_t reps, double *ms_out) {
-  if (!c || !params || reps <= 0 || !ms_out || which < 0 || which > 7) return MIVI_ERR_BAD_ARG;
+  if (!c || !params || reps <= 0 || !ms_out || which < 0 || which > 8) return MIVI_ERR_BAD_ARG;
   (void)hipSetDevice(c->cfg.device);
   const int M = c->cfg.n_mc;
   char *o = (char *)c->tmp_out.p;
@@ -1414,10 +1414,12 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
   c->cur = 0;
   const bool lds = fr && lds_route(c, params, M, 1, out);   // second-generation kernels: stages 2 / 4 include their reduce
   if ((which == 6 || which == 7) && !lds) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 6 / 7: second-generation full-rank route only");
+  if (which == 8 && !(fr && (c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD)))
+    return fail(c, MIVI_ERR_UNSUPPORTED, "which = 8: full-rank family with a sticking-the-landing estimator");
   if (which == 5) {   // the launch-free loop of 100 estimates (mean-field + diagonal target): one launch per rep
     if (fr || c->target != TGT_DIAG_GAUSS || M > 4096) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 5: mean-field + diagonal-Gaussian target");
     if ((s = ensure(c, c->X, ((size_t)100 + 400 * (size_t)((c->cfg.d + 3) / 4) + 8) * sizeof(double), false))) return s;
-  } else if (which != 0) {
+  } else if (which != 0 && which != 8) {
     if (!fr && which != 2) return fail(c, MIVI_ERR_UNSUPPORTED, "mean-field has a single fused kernel (which = 2)");
     if (which == 4 && c->target != TGT_DENSE_GAUSS) return fail(c, MIVI_ERR_UNSUPPORTED, "no dense target set");
     if (which == 2 && c->target != TGT_DIAG_GAUSS && c->target != TGT_DENSE_GAUSS)
@@ -1443,6 +1445,10 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
       case 3:
         if (lds) launch_lds_vjp(c, params, M, out, nullptr, nullptr);
         else launch_fr_vjp(c, params, M, out);
+        break;
+      case 8:   // the STL term W += C^-T eps alone (the parameter-only preparation was left by the warm estimate)
+        if (stl2_shape_ok(c, M)) launch_stl2(c, params, M, lds && lds_use_prod32(c, M));
+        else launch_fr_stl(c, params, M);
         break;
       case 6: launch_lds_sample(c, params, M); break;
       case 7: launch_lds_reduce(c, params, M, c->target == TGT_DENSE_GAUSS ? R_DENSE_R : R_DIAG, nullptr, true); break;

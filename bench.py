@@ -121,6 +121,48 @@ def fr_roofline(ctx, params, cost, w, reps=300):
     return roof, stages
 
 
+def other_roofline(cx, p, w, t_est):
+    """Roofline block of the workloads whose dominant kernel is not one of the two full-rank contractions:
+    C3 (logistic regression: the two data contractions), C5 / other mean-field targets (HBM)."""
+    cost = algorithmic_cost(w)
+    if w["target"] == "logreg":
+        n, pdim, M2 = w["n"], w["d"] - 1, w["n_mc"]
+        fl = 4.0 * n * pdim * M2                      # logits X beta and X^T R, 2 flops per MAC
+        by = 2.0 * n * pdim * 4 + 2.0 * n * M2 * 4     # X read once per contraction, R written + read
+        tl, tx = pmc_traffic("k_lr_logits_bf16x3"), pmc_traffic("k_lr_xtr_bf16x3")
+        return dict(bound="mfma", kernel="k_lr_logits_bf16x3 + k_lr_xtr_bf16x3", achieved=fl / t_est / 1e12,
+                    peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=fl / t_est / 1e12 / PEAK_F32_MFMA_TF,
+                    note="f32-equivalent flops of the two data contractions / the f32-MFMA peak (the kernels run the exact "
+                         "3-way bf16 split on the bf16 pipe: x6 executed flops, peak 2500 TF); timed as the whole estimate",
+                    bf16_pipe=dict(executed_TFLOPs=6 * fl / t_est / 1e12, peak=PEAK_BF16_MFMA_TF, frac=6 * fl / t_est / 1e12 / PEAK_BF16_MFMA_TF),
+                    hbm=dict(achieved_GBs=by / t_est / 1e9, peak=PEAK_HBM_GBS, frac=by / t_est / 1e9 / PEAK_HBM_GBS, bytes_per_estimate=by),
+                    traffic=(dict(bytes_per_launch=tl["bytes_per_launch"] + tx["bytes_per_launch"], logits=tl, xtr=tx) if tl and tx else None),
+                    avg_launch_us=t_est * 1e6)
+    try:
+        roof, _ = mf_roofline(cx, p, cost)
+        return roof
+    except Exception:   # noqa: BLE001  -- stage hook not applicable to this target: whole-estimate HBM equivalent
+        return dict(bound="hbm", kernel="k_mf_main<float, funnel> (one launch per estimate; the previous estimate's value / row-0 finisher rides in it)",
+                    achieved=cost["bytes"] / t_est / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=cost["bytes"] / t_est / 1e9 / PEAK_HBM_GBS,
+                    traffic=pmc_traffic("k_mf_mainIfLb1"), algorithmic_bytes_per_launch=cost["bytes"], avg_launch_us=t_est * 1e6,
+                    note="whole estimate (hipGraph steady state); launch / latency bound: 0.27 MB of real traffic per estimate")
+
+
+def stl_block(cx, p, w, reps=100):
+    """The sticking-the-landing term of a full-rank workload: W += C^-T eps (two half-size chain solves + one update product),
+    hipGraph-replayed alone (mivi_profile_kernel which = 8).  Algorithmic flops d^2 M (a triangular solve with M right-hand sides)."""
+    try:
+        ms = cx.profile_kernel(8, p, reps)
+    except Exception:   # noqa: BLE001
+        return None
+    fl = float(w["d"]) ** 2 * w["n_mc"]
+    sv, up = pmc_traffic("k_stl_solve64"), pmc_traffic("k_stl_update32")
+    return dict(kernel="k_stl_solve64 x2 + k_stl_update32", avg_us=ms * 1e3, achieved_TFLOPs=fl / (ms * 1e-3) / 1e12,
+                frac_of_f32_mfma_peak=fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF,
+                bound="dependency chain: 2 x d/128 block steps on 16-column workgroups (M / 16 CUs busy), each pulling its triangle through one CU",
+                traffic=(dict(solve=sv, update=up) if sv and up else None))
+
+
 def make_problem(avi, w):
     d = w["d"]
     q = (avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32)) if w["family"] == 0
@@ -372,6 +414,10 @@ def main():
                 else:
                     roof, stages = fr_roofline(ctx, params, cost, w)
                 stages = {k: round(v * 1e3, 3) for k, v in stages.items()}   # us
+                if w["family"] == 1 and w["entropy"] in (3, 4):
+                    roof["stl_term"] = stl_block(ctx, params, w)
+            elif single:
+                roof = other_roofline(ctx, params, w, dt / K)
             whole = dict(hbm_equiv_GBs=cost["bytes"] * est_per_s / world / 1e9,
                          hbm_equiv_frac_of_8TBs=cost["bytes"] * est_per_s / world / 1e9 / PEAK_HBM_GBS,
                          f32_mfma_TFs=cost["flops"] * est_per_s / world / 1e12 if w["family"] == 1 else None)
@@ -447,27 +493,14 @@ def main():
                     stream.synchronize()
                     t2 = (time.perf_counter() - t20) / n_est
                     c2cost = algorithmic_cost(w2)
-                    if w2["target"] == "logreg":
-                        n, pdim, M2 = w2["n"], w2["d"] - 1, w2["n_mc"]
-                        fl = 4.0 * n * pdim * M2                      # logits X beta and X^T R, 2 flops per MAC
-                        by = 2.0 * n * pdim * 4 + 2.0 * n * M2 * 4     # X read once per contraction, R written + read
-                        roof2 = dict(bound="mfma", kernel="k_lr_logits_bf16x3 + k_lr_xtr_bf16x3", achieved=fl / t2 / 1e12,
-                                     peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=fl / t2 / 1e12 / PEAK_F32_MFMA_TF,
-                                     note="f32-equivalent flops of the two data contractions / the f32-MFMA peak (the kernels run the exact "
-                                          "3-way bf16 split on the bf16 pipe: x6 executed flops, peak 2500 TF)",
-                                     bf16_pipe=dict(executed_TFLOPs=6 * fl / t2 / 1e12, peak=PEAK_BF16_MFMA_TF, frac=6 * fl / t2 / 1e12 / PEAK_BF16_MFMA_TF),
-                                     hbm=dict(achieved_GBs=by / t2 / 1e9, peak=PEAK_HBM_GBS, frac=by / t2 / 1e9 / PEAK_HBM_GBS,
-                                              bytes_per_estimate=by), traffic=None)
+                    if w2["target"] == "logreg" or (w2["family"] == 0 and w2["target"] != "iso"):
+                        roof2 = other_roofline(cx, p2, w2, t2)
                     elif w2["family"] == 0:
-                        try:
-                            roof2, _ = mf_roofline(cx, p2, c2cost)
-                        except Exception:   # noqa: BLE001  -- stage hook not applicable to this target: whole-estimate HBM equivalent
-                            roof2 = dict(bound="hbm", kernel="k_mf_main<float> (+ value / row-0 finisher)", achieved=c2cost["bytes"] / t2 / 1e9,
-                                         peak=PEAK_HBM_GBS, unit="GB/s", frac=c2cost["bytes"] / t2 / 1e9 / PEAK_HBM_GBS, traffic=None,
-                                         algorithmic_bytes_per_launch=c2cost["bytes"], avg_launch_us=t2 * 1e6,
-                                         note="whole estimate (hipGraph steady state), not a single kernel")
+                        roof2, _ = mf_roofline(cx, p2, c2cost)
                     else:
                         roof2, _ = fr_roofline(cx, p2, c2cost, w2, reps=100)
+                        if w2["entropy"] in (3, 4):
+                            roof2["stl_term"] = stl_block(cx, p2, w2)
                     also[wn] = dict(workload=w2["name"], value=1.0 / t2, unit="estimates/s", us_per_step=t2 * 1e6, estimates=n_est,
                                     launch="hipGraph x100" if graphable else "eager", roofline=roof2)
                     cx.close()
