@@ -17,7 +17,6 @@ for w in ns c2 ns_stl ns_dense c3 c5; do
   db=$(find /tmp/prof_$w -name '*.db' | head -1)
   { echo "# $TAG: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --concurrent 1 --workload $w --steps $steps --warmup 20"; echo;
     python $REPO/tools/rocpd_stats.py $db; } > $OUT/${TAG}_${w}_kernel_stats.md
-  tail -1 /tmp/prof_$w.log > $OUT/${TAG}_bench_${w}_under_rocprof.json
 done
 # PMC passes (own runs, kernel-trace only), NS default bench (which also runs C2 as `also`)
 for c in FETCH_SIZE WRITE_SIZE; do
