@@ -44,6 +44,8 @@ mutable struct MIVIState
     ctx::Ptr{Cvoid}
     estimate_idx::UInt64         # replaces the hidden position of `rng`
     cb::Any                      # keeps the @cfunction closure alive
+    distributed::Bool            # a communicator is attached (comm_init!): estimates run sharded over the ranks
+    dev::Any                     # device scratch for the sharded route: (params, value, grad) pointers or nothing
 end
 
 function check(ctx, status)
@@ -80,7 +82,9 @@ function AdvancedVI.init(rng::Random.AbstractRNG, obj::RepGradELBO, ad::AutoMIVI
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     status = ccall((:mivi_create, libmivi), Int32, (Ref{MiviConfig}, Ref{Ptr{Cvoid}}), cfg, ctx)
     status == 0 || error("mivi_create failed with status $status (no HIP device?)")
-    st = MIVIState(prob, T, ctx[], UInt64(0), nothing)
+    LogDensityProblems.capabilities(prob) isa LogDensityProblems.LogDensityOrder{0} &&
+        throw(ArgumentError("libmivi has no AD: the target must provide logdensity_and_gradient (wrap it in ADgradient)"))
+    st = MIVIState(prob, T, ctx[], UInt64(0), nothing, false, nothing)
     cb = @cfunction(target_callback, Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}))
     st.cb = cb
     check(st.ctx, ccall((:mivi_set_target_callback, libmivi), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Any), st.ctx, cb, C_NULL, st))
@@ -174,8 +178,48 @@ function AdvancedVI.gaussian_expectation_gradient_and_hessian!(
     return logpi[], grad_buf, hess_buf
 end
 
+# Constrained supports (README.md:76-82, 91-119; docs/src/tutorials/constrained.md:154-196): a Bijectors.Stacked of identity / exp
+# blocks is applied by the library around whatever target is set.  `ranges` are the Stacked's UnitRanges (1-based, as Bijectors
+# stores them), `kinds[i]` is :identity or :exp.  An empty list removes the constraint.
+function set_bijector!(state::MIVIState, ranges::Vector{UnitRange{Int}}, kinds::Vector{Symbol})
+    r = Int32[]
+    for rg in ranges
+        push!(r, Int32(first(rg) - 1)); push!(r, Int32(last(rg)))          # [begin, end) 0-based
+    end
+    k = Int32[kd === :exp ? 1 : 0 for kd in kinds]
+    check(state.ctx, ccall((:mivi_set_bijector_stacked, libmivi), Int32, (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int32}),
+                           state.ctx, Int32(length(kinds)), r, k))
+    return state
+end
+
+# Multi-GPU (one process per GPU): the collective lives behind the C ABI (RCCL opened by libmivi).  Rank 0 creates the id,
+# the host broadcasts its 128 bytes by its own means (MPI.Bcast!, a file, ...), every rank attaches it.  The context must have
+# been created with this rank's slice of the sample axis (MiviConfig.m_offset / m_total; see `init_sharded`).
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    status = ccall((:mivi_comm_unique_id, libmivi), Int32, (Ptr{UInt8},), id)
+    status == 0 || error("mivi_comm_unique_id failed with status $status (no RCCL?)")
+    return id
+end
+function comm_init!(state::MIVIState, id::Vector{UInt8}, rank::Integer, world::Integer)
+    check(state.ctx, ccall((:mivi_comm_init, libmivi), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), state.ctx, id, Int32(rank), Int32(world)))
+    state.distributed = true
+    return state
+end
+comm_destroy!(state::MIVIState) = (check(state.ctx, ccall((:mivi_comm_destroy, libmivi), Int32, (Ptr{Cvoid},), state.ctx)); state.distributed = false; state)
+
+# one sharded estimate on device pointers (params_dev / value_dev / grad_dev live in HBM: AMDGPU.jl arrays or hipMalloc'd buffers);
+# every rank passes the SAME estimate_idx and receives the same value and gradient
+function estimate_gradient_dist!(state::MIVIState, params_dev::Ptr{Cvoid}, value_dev::Ptr{Cvoid}, grad_dev::Ptr{Cvoid})
+    check(state.ctx, ccall((:mivi_estimate_gradient_dist, libmivi), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Ptr{Cvoid}, Ptr{Cvoid}),
+                           state.ctx, params_dev, state.estimate_idx, value_dev, grad_dev))
+    state.estimate_idx += 1
+    check(state.ctx, ccall((:mivi_synchronize, libmivi), Int32, (Ptr{Cvoid},), state.ctx))
+    return state
+end
+
 # ProximalLocationScaleEntropy on the host arrays works unchanged (src/optimization/proximal_location_scale_entropy.jl);
 # the device-resident variant for a parameter vector that lives in HBM is mivi_prox_scale_entropy.
 
-export AutoMIVI, NativeLogReg, native_logreg!, MIVITarget
+export AutoMIVI, NativeLogReg, native_logreg!, MIVITarget, set_bijector!, comm_unique_id, comm_init!, comm_destroy!, estimate_gradient_dist!
 end # module

@@ -32,6 +32,61 @@ def test_library_loads_and_exports_every_declared_symbol(lib):
     assert lib.mivi_version() == 1
 
 
+def header_prototypes():
+    """name -> number of parameters, from include/mivi.h (comments stripped)."""
+    src = open(os.path.join(ROOT, "include", "mivi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(mivi_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        if name.endswith("_fn"):
+            continue
+        out[name] = 0 if args in ("", "void") else len(args.split(","))
+    return out
+
+
+def test_julia_wrapper_ccalls_match_the_header():
+    """julia/MIVI.jl cannot be executed here (no Julia in the image); what can be checked is that every ccall names an entry
+    point include/mivi.h declares and passes as many arguments as the prototype has, with an argument-type tuple of that length."""
+    protos = header_prototypes()
+    txt = open(os.path.join(ROOT, "advancedvi.jl_amd", "julia", "MIVI.jl")).read()
+    calls = list(re.finditer(r"ccall\(\(:(mivi_[a-z0-9_]+),\s*libmivi\),\s*(\w+),\s*\(", txt))
+    assert len(calls) >= 12
+    seen = set()
+    for m in calls:
+        name = m.group(1)
+        assert name in protos, f"MIVI.jl calls {name}, which include/mivi.h does not declare"
+        # the argument-type tuple: balanced parentheses starting at the '(' the regex ended on
+        i = m.end() - 1
+        depth, j = 0, i
+        while True:
+            depth += txt[j] == "("
+            depth -= txt[j] == ")"
+            if depth == 0:
+                break
+            j += 1
+        tup = txt[i + 1:j]
+        parts, depth, cur = [], 0, ""
+        for ch in tup:
+            if ch in "({":
+                depth += 1
+            if ch in ")}":
+                depth -= 1
+            if ch == "," and depth == 0:
+                parts.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            parts.append(cur)
+        assert len(parts) == protos[name], f"{name}: {len(parts)} argument types in MIVI.jl, {protos[name]} parameters in mivi.h"
+        seen.add(name)
+    for must in ("mivi_create", "mivi_destroy", "mivi_set_target_callback", "mivi_estimate_gradient_host", "mivi_estimate_objective_host",
+                 "mivi_set_bijector_stacked", "mivi_comm_unique_id", "mivi_comm_init", "mivi_estimate_gradient_dist",
+                 "mivi_gauss_expected_grad_hess_host", "mivi_logreg_select_rows"):
+        assert must in seen, f"MIVI.jl does not bind {must}"
+
+
 def test_config_struct_layout_matches_header():
     # int32 x6, uint64, int32 x2, void*, int32 x2  (natural alignment)
     assert C.sizeof(_lib.MiviConfig) == 56
