@@ -80,6 +80,12 @@ struct ReduceArgs {
 // (and in the mirrored tile), d/dmu on the tiles that hold a diagonal block's first columns; shard mode: packed triangle;
 // FUSED: Descent / Adam (+ ClipScale) applied in place instead of writing the gradient.
 // -----------------------------------------------------------------------------------------------------------------
+// 16-byte store that does not stay in the XCD's L2 (sc1): the dense gradient (4 MB at the north star) is not read by the next
+// kernels of the chain, while C / eps / W are -- a plain store would push them out of the 4 MB L2.
+__device__ __forceinline__ void store16_drop(float *p, const f32x4 &v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
 template <int BM, int BN, int KW, int NT, bool FUSED>
 __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs, const float *rs_lds, const float *adam_cc, int4 wk,
                                              int row0, int col0) {
@@ -141,7 +147,8 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
         }
       }
       if (!fused) {
-        *(f32x4 *)(dst + pi) = o;
+        if (a.knock & 64) *(f32x4 *)(dst + pi) = o;
+        else store16_drop(dst + pi, o);
       } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -171,7 +178,8 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
 #pragma unroll
       for (int u = 0; u < NE; ++u) {
         const int e = tid + u * NT, j4 = 4 * (e % (BN / 4)), ii = e / (BN / 4);
-        *(f32x4 *)(dst + d + (size_t)(row0 + ii) * d + col0 + j4) = z4;
+        if (a.knock & 64) *(f32x4 *)(dst + d + (size_t)(row0 + ii) * d + col0 + j4) = z4;
+        else store16_drop(dst + d + (size_t)(row0 + ii) * d + col0 + j4, z4);
       }
     }
   }
