@@ -1696,10 +1696,10 @@ __global__ __launch_bounds__(256) void k_stein_outer(int d, int dP, int M, const
 }
 
 template <typename T>
-__global__ void k_stein_finish(int d, double n, const double *gsum, const double *ell_sum, T *grad, T *logpi_avg) {
+__global__ void k_stein_finish(int d, double n, const double *gsum, const double *ell_sum, const T *ell_single, T *grad, T *logpi_avg) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < d) grad[i] = (T)(gsum[i] / n);
-  if (i == 0) *logpi_avg = (T)(ell_sum[0] / n);
+  if (i == 0) *logpi_avg = (T)((ell_single ? (double)ell_single[0] : ell_sum[0]) / n);   // one chunk: straight from its partial
 }
 
 void launch_stein_outer(mivi_ctx *c, int M, void *A, double *gsum, int first, double scale) {
@@ -1712,12 +1712,12 @@ void launch_stein_outer(mivi_ctx *c, int M, void *A, double *gsum, int first, do
                        (const double *)c->W.p, (double *)A, gsum, first, scale);
 }
 
-void launch_stein_finish(mivi_ctx *c, double n, const double *gsum, const double *ell_sum, void *grad, void *logpi_avg) {
+void launch_stein_finish(mivi_ctx *c, double n, const double *gsum, const double *ell_sum, const void *ell_single, void *grad, void *logpi_avg) {
   const int nb = (c->cfg.d + 255) / 256;
   if (c->cfg.dtype == MIVI_F32)
-    hipLaunchKernelGGL(k_stein_finish<float>, dim3(nb), dim3(256), 0, c->stream, c->cfg.d, n, gsum, ell_sum, (float *)grad, (float *)logpi_avg);
+    hipLaunchKernelGGL(k_stein_finish<float>, dim3(nb), dim3(256), 0, c->stream, c->cfg.d, n, gsum, ell_sum, (const float *)ell_single, (float *)grad, (float *)logpi_avg);
   else
-    hipLaunchKernelGGL(k_stein_finish<double>, dim3(nb), dim3(256), 0, c->stream, c->cfg.d, n, gsum, ell_sum, (double *)grad, (double *)logpi_avg);
+    hipLaunchKernelGGL(k_stein_finish<double>, dim3(nb), dim3(256), 0, c->stream, c->cfg.d, n, gsum, ell_sum, (const double *)ell_single, (double *)grad, (double *)logpi_avg);
 }
 
 // W += C^-T eps for the M sample columns -- or, with `rhs` / `out` given, out += C^-T rhs for any M-column right-hand

@@ -119,6 +119,7 @@ struct StlSolveArgs {
   int ld_x;
   float *W;              // optional: W[(r0 + i) + m * ld_w] += X(i, m)
   int ld_w;
+  int w_set;             // W = X instead of W += X
   unsigned *stamps;      // developer (MIVI_STL_STAMPS): shader-clock stamps of workgroup 0, [role 2][step 16][4]
 };
 
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(512) void k_stl_solve64(StlSolveArgs a) {
     bf16x8 df[NB][6], cf[NB][6];
     auto request = [&](int J) {
       ef[J] = *(const f32x4 *)(Eg + 64 * J);
-      if (Wg) wf[J] = *(const f32x4 *)(Wg + 64 * J);
+      if (Wg && !a.w_set) wf[J] = *(const f32x4 *)(Wg + 64 * J);
 #pragma unroll
       for (int u = 0; u < 6; ++u) df[J][u] = *(const bf16x8 *)(Dg + (size_t)J * STL_PLANE_BLOCK + u * 256);
       if (J < NB - 1) {
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(512) void k_stl_solve64(StlSolveArgs a) {
       }
       const int row = 64 * J + 16 * q + 4 * g;
       if (a.X) *(f32x4 *)(a.X + (size_t)col * a.ld_x + row) = x;
-      if (a.W) *(f32x4 *)(a.W + (size_t)col * a.ld_w + a.r0 + row) = wf[J] + x;
+      if (a.W) *(f32x4 *)(a.W + (size_t)col * a.ld_w + a.r0 + row) = a.w_set ? x : wf[J] + x;
       stamp(0, J, 3);
       if constexpr (J > 0) lds_barrier();   // B_J
     });
@@ -398,19 +399,20 @@ static void launch_solve(mivi_ctx *c, const StlSolveArgs &a, int M) {
 
 // W += C^{-T} eps for the current estimate (W: d x M, ld d; eps: ld dP).  Needs c->stl_Dinv (d/64 * 4096 floats) and
 // c->stl_X (d x M floats: X of the lower half, then the updated right-hand side of the upper half).
-void launch_stl2(mivi_ctx *c, const void *params, int M, bool dinv_done) {
+void launch_stl2(mivi_ctx *c, const void *params, int M, bool dinv_done, const void *rhs, void *out, bool overwrite) {
   const int d = c->cfg.d, n = d / 2;
   const float *C = (const float *)params + d;
   unsigned *pack = (unsigned *)c->stl_F.p;
   float *Xb = (float *)c->stl_X.p, *Rt = Xb + (size_t)n * M;
-  const float *eps = (const float *)c->eps[c->cur].p;
+  const float *eps = rhs ? (const float *)rhs : (const float *)c->eps[c->cur].p;   // right-hand sides, ld dP
+  float *Wout = out ? (float *)out : (float *)c->W.p;                               // X is ADDED here, ld d
   if (!dinv_done) hipLaunchKernelGGL(k_stl_pack, dim3(d / 64 + stl_pack_riders(d)), dim3(256), 0, c->stream, d, C, pack);
   StlSolveArgs s{};
-  s.d = d; s.n = n; s.pack = pack;
+  s.d = d; s.n = n; s.pack = pack; s.w_set = overwrite ? 1 : 0;
   static const bool stamps = getenv("MIVI_STL_STAMPS") != nullptr;
   if (stamps) s.stamps = (unsigned *)((char *)c->stl_X.p + c->stl_X.bytes - 4096);
   // lower half: C22^T X2 = E2
-  s.r0 = n; s.rhs = eps; s.rhs_r0 = n; s.ld_rhs = c->dP; s.X = Xb; s.ld_x = n; s.W = (float *)c->W.p; s.ld_w = d;
+  s.r0 = n; s.rhs = eps; s.rhs_r0 = n; s.ld_rhs = c->dP; s.X = Xb; s.ld_x = n; s.W = Wout; s.ld_w = d;
   launch_solve(c, s, M);
   // R1 = E1 - C21^T X2
   StlUpdArgs u{};

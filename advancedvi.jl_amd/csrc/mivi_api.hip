@@ -517,9 +517,11 @@ static mivi_status_t run_estimate_lds(mivi_ctx *c, const void *params, const Rng
   const bool p32 = lds_use_prod32(c, M);
   bool dinv_done = false;
   if (p32) {   // unsplit 32 x 32 tiles with the target fused into the epilogue: one kernel from eps to W
-    const bool stl_here = grad_stage && (out.ent_kind == MIVI_ENT_STL || out.ent_kind == MIVI_ENT_STL_ZERO_GRAD) && stl2_shape_ok(c, M);
+    const bool stl_here = (grad_stage && (out.ent_kind == MIVI_ENT_STL || out.ent_kind == MIVI_ENT_STL_ZERO_GRAD) && stl2_shape_ok(c, M)) ||
+                          (c->want_stl_pack && c->stl_F.p);   // (the Stein estimator's solve: the riders prepare its operands too)
     launch_lds_prod32(c, params, M, false, dense ? R_DENSE_R : R_DIAG, nullptr, next, grad_stage, stl_here);
     dinv_done = stl_here;
+    c->stl_pack_done = stl_here;
     if (next) c->he_n[p ^ 1] = lds_prod32_eps_blocks(c, M);
     if (dense) launch_lds_prod32(c, params, M, true, R_DENSE_G, nullptr, nullptr, false);
     vin.ell_part = (const double *)c->ell_part[p].p;
@@ -1061,7 +1063,11 @@ mivi_status_t mivi_gauss_expected_grad_hess(mivi_ctx_t *c, const void *params, u
   if ((s = ensure(c, c->stein_A, (size_t)dP * dP * es, true)) || (s = ensure(c, c->stein_g, (size_t)(d + 8) * sizeof(double), true)) ||
       (s = ensure(c, c->stl_CT, (size_t)dP * dP * es, true)) || (s = ensure(c, c->stl_Dinv, (size_t)((d + 31) / 32) * 1024 * es, false)))
     return s;
+  const bool stl2 = stl2_shape_ok(c, d);   // second-generation solve with the d columns of the product as right-hand sides
+  if (stl2 && ((s = ensure(c, c->stl_X, (size_t)d * d * es + 4096, false)) || (s = ensure(c, c->stl_F, mivi::stl_pack_units(d) * 4, false)))) return s;
   const int CH = 16384;
+  const bool single_chunk = n_samples <= CH;
+  bool pack_done = false;
   char *part = (char *)c->tmp_out.p;   // [sum ell, sum 0.5 eps^2] of a chunk
   for (int off = 0, first = 1; off < n_samples; off += CH, first = 0) {
     const int Mc = n_samples - off < CH ? n_samples - off : CH;
@@ -1073,17 +1079,28 @@ mivi_status_t mivi_gauss_expected_grad_hess(mivi_ctx_t *c, const void *params, u
     o.M_total = Mc;
     RngArgs r = rng_of(c, idx);
     r.m_offset += off;
-    if ((s = run_estimate(c, params, r, Mc, 1, o, nullptr, nullptr, true))) return s;
-    if (c->cfg.dtype == MIVI_F32)
+    c->want_stl_pack = stl2 && first;   // the solve's parameter-only preparation rides in the first chunk's sampling kernel
+    c->stl_pack_done = false;
+    s = run_estimate(c, params, r, Mc, 1, o, nullptr, nullptr, true);
+    c->want_stl_pack = false;
+    if (s) return s;
+    if (first) pack_done = c->stl_pack_done;
+    if (single_chunk) {
+      // (its partial is read by the finishing kernel directly: no accumulation launch)
+    } else if (c->cfg.dtype == MIVI_F32)
       hipLaunchKernelGGL(k_acc_value_f32, dim3(1), dim3(1), 0, c->stream, (double *)c->acc.p, (const float *)part, 1.0, first);
     else
       hipLaunchKernelGGL(k_acc_value_f64, dim3(1), dim3(1), 0, c->stream, (double *)c->acc.p, (const double *)part, 1.0, first);
     const bool last = off + CH >= n_samples;
     launch_stein_outer(c, Mc, c->stein_A.p, (double *)c->stein_g.p, first, last ? 1.0 / (double)n_samples : 1.0);
   }
-  launch_stein_finish(c, (double)n_samples, (const double *)c->stein_g.p, (const double *)c->acc.p, grad, logpi_avg);
-  HIPCHK(c, hipMemsetAsync(hess, 0, (size_t)d * d * es, c->stream));
-  launch_fr_stl(c, params, d, c->stein_A.p, hess);   // hess = C^-T (eps G^T / n)
+  launch_stein_finish(c, (double)n_samples, (const double *)c->stein_g.p, (const double *)c->acc.p, single_chunk ? part : nullptr, grad, logpi_avg);
+  if (stl2) {
+    launch_stl2(c, params, d, pack_done, c->stein_A.p, hess, true);   // hess = C^-T (eps G^T / n), written (not added)
+  } else {
+    HIPCHK(c, hipMemsetAsync(hess, 0, (size_t)d * d * es, c->stream));
+    launch_fr_stl(c, params, d, c->stein_A.p, hess);
+  }
   HIPCHK(c, hipGetLastError());
   return MIVI_OK;
 }

@@ -256,6 +256,7 @@ struct mivi_ctx {
   mivi::DevBuf tabA, tabB, tabD;   // XCD-aware work tables of the MFMA kernels
   mivi::DevBuf stl_CT, stl_Dinv;   // transposed scale + inverted diagonal blocks (full-rank STL, f32)
   mivi::DevBuf stl_F;              // second-generation STL solve: packed operands (stl_dinv.h: pivot inverses + off-diagonal blocks, fragment order)
+  bool want_stl_pack = false, stl_pack_done = false;   // Stein estimator: ask the sampling kernel to carry the solve's riders
   mivi::DevBuf stl_X;              // second-generation STL solve: X of the lower half + updated right-hand side of the upper half
   // second-generation full-rank kernels (kernels_fullrank_lds.hip): split-K work lists, per-tile slab ranges, slabs
   mivi::DevBuf lds_tabS, lds_tilesS, lds_tabD, lds_tilesD, lds_tabV, lds_slab;
@@ -306,7 +307,7 @@ void launch_fr_dense_target(mivi_ctx *c, int M, int want_grad);
 void launch_rt_from_z(mivi_ctx *c, int M);
 void launch_fr_stl(mivi_ctx *c, const void *params, int M, const void *rhs = nullptr, void *out = nullptr);
 void launch_stein_outer(mivi_ctx *c, int M, void *A, double *gsum, int first, double scale);
-void launch_stein_finish(mivi_ctx *c, double n, const double *gsum, const double *ell_sum, void *grad, void *logpi_avg);
+void launch_stein_finish(mivi_ctx *c, double n, const double *gsum, const double *ell_sum, const void *ell_single, void *grad, void *logpi_avg);
 int fr_sample_blocks(const mivi_ctx *c, int M);
 int fr_dense_blocks(const mivi_ctx *c, int M);
 int eps_blocks(const mivi_ctx *c, int M);
@@ -332,7 +333,8 @@ void invalidate_graph(mivi_ctx *c);            // mivi_api.hip: drop the cached 
 
 // kernels_stl.hip (f32, d in {256, 512, 1024, 2048}, M % 32 == 0)
 bool stl2_shape_ok(const mivi_ctx *c, int M);
-void launch_stl2(mivi_ctx *c, const void *params, int M, bool dinv_done = false);   // W += C^-T eps: dinv64 -> solve (lower half) -> update -> solve (upper half)
+void launch_stl2(mivi_ctx *c, const void *params, int M, bool dinv_done = false, const void *rhs = nullptr, void *out = nullptr,
+                 bool overwrite = false);   // rhs (ld dP) / out (ld d) default to eps / W; overwrite: out = X instead of out += X   // W += C^-T eps: dinv64 -> solve (lower half) -> update -> solve (upper half)
 
 // kernels_targets.hip
 void launch_col_target(mivi_ctx *c, int M, int want_grad);
