@@ -14,7 +14,7 @@ from .objectives import (RepGradELBO, RepGradELBOState, ClosedFormEntropy, Close
 from . import objectives as _objectives
 from . import optimize as _optimize
 from .optimize import (KLMinRepGradDescent, KLMinRepGradProxDescent, ADVI, ClipScale, IdentityOperator,
-                       ProximalLocationScaleEntropy, Descent, Adam, DoG, DoWG, NoAveraging,
+                       ProximalLocationScaleEntropy, Descent, Adam, DoG, DoWG, COCOB, NoAveraging,
                        PolynomialAveraging, optimize, step, output)
 from .context import MiviContext
 from .problems import subsample, LogRegSubset, FunnelConstrainedProblem, StackedBijector, TransformedProblem

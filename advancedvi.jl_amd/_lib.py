@@ -56,6 +56,7 @@ SIGNATURES = {
     "mivi_finalize": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mivi_clip_scale": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_double]),
     "mivi_descent_update": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]),
+    "mivi_cocob_update": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]),
     "mivi_adam_update": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double]),
     "mivi_axpby": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_int64]),
     "mivi_dog_state_bytes": (C.c_int64, [C.c_void_p]),

@@ -317,6 +317,9 @@ class MiviContext:
     def adam_update(self, params, grad, state, t, eta, beta1=0.9, beta2=0.999, eps=1e-8):
         self._chk(self.lib.mivi_adam_update(self.h, self._p(params), self._p(grad), self._p(state), int(t), eta, beta1, beta2, eps))
 
+    def cocob_update(self, params, grad, state, alpha=100.0):
+        self._chk(self.lib.mivi_cocob_update(self.h, self._p(params), self._p(grad), self._p(state), float(alpha)))
+
     def axpby(self, y, a, x, b):
         self._chk(self.lib.mivi_axpby(self.h, self._p(y), float(a), self._p(x), float(b), y.numel()))
 

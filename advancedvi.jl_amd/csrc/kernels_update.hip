@@ -348,6 +348,32 @@ void launch_adam(mivi_ctx *c, void *params, const void *grad, void *state, const
                        (double *)state, t_ptr, t_base, eta, b1, b2, eps, c->cfg.d, c->cfg.family, clip_eps);
 }
 
+// COCOB (optim_rules.h): state = [L; G; R; theta; x1], n elements each
+template <typename T>
+__global__ void k_cocob(int64_t n, T *params, const T *grad, T *state, T alpha, int d, int family, T clip_eps) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    T L = state[i], G = state[n + i], R = state[2 * n + i], th = state[3 * n + i];
+    T x = cocob_step<T>(params[i], grad[i], L, G, R, th, state[4 * n + i], alpha);
+    if (clip_eps == clip_eps && is_scale_diag(i, d, family)) x = clip_step(x, clip_eps);
+    params[i] = x;
+    state[i] = L;
+    state[n + i] = G;
+    state[2 * n + i] = R;
+    state[3 * n + i] = th;
+  }
+}
+void launch_cocob(mivi_ctx *c, void *params, const void *grad, void *state, double alpha, double clip_eps) {
+  const int64_t n = mivi_params_len(c);
+  int nb = (int)((n + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_cocob<float>, dim3(nb), dim3(256), 0, c->stream, n, (float *)params, (const float *)grad, (float *)state,
+                       (float)alpha, c->cfg.d, c->cfg.family, (float)clip_eps);
+  else
+    hipLaunchKernelGGL(k_cocob<double>, dim3(nb), dim3(256), 0, c->stream, n, (double *)params, (const double *)grad, (double *)state,
+                       alpha, c->cfg.d, c->cfg.family, clip_eps);
+}
+
 __global__ void k_bump(uint64_t *ctr, uint64_t by) { *ctr += by; }
 void launch_bump(mivi_ctx *c, uint64_t *ctr, uint64_t by) {
   hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, c->stream, ctr, by);

@@ -1239,6 +1239,14 @@ mivi_status_t mivi_adam_update(mivi_ctx_t *c, void *params, const void *grad, vo
   return MIVI_OK;
 }
 
+mivi_status_t mivi_cocob_update(mivi_ctx_t *c, void *params, const void *grad, void *state, double alpha) {
+  if (!c || !params || !grad || !state || !(alpha > 0.0)) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  launch_cocob(c, params, grad, state, alpha);
+  HIPCHK(c, hipGetLastError());
+  return MIVI_OK;
+}
+
 mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, uint64_t idx0, int64_t t0, int32_t n_steps,
                                   int32_t rule, double eta, double clip_eps, void *elbo) {
   if (rule != 0 && rule != 1) return MIVI_ERR_BAD_ARG;

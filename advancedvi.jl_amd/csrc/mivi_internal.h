@@ -360,6 +360,7 @@ void launch_clip(mivi_ctx *c, void *params, double epsilon);
 void launch_descent(mivi_ctx *c, void *params, const void *grad, double eta, double clip_eps = NAN);   // NaN: no ClipScale
 void launch_adam(mivi_ctx *c, void *params, const void *grad, void *state, const int64_t *t_ptr, int64_t t_base,
                  double eta, double b1, double b2, double eps, double clip_eps = NAN);
+void launch_cocob(mivi_ctx *c, void *params, const void *grad, void *state, double alpha, double clip_eps = (double)NAN);
 void launch_bump(mivi_ctx *c, uint64_t *ctr, uint64_t by);
 
 }  // namespace mivi

@@ -41,6 +41,24 @@ __device__ __forceinline__ T adam_step(T x, T g, T &m, T &v, T c1, T c2, T eta, 
   return x - step;
 }
 
+// COCOB-Backprop (src/optimization/rules.jl:78-96): per-coordinate coin betting.  State (L, G, R, theta, x1); returns the new x.
+//   L = max(L, |g|); G += |g|; R = max(R + (x - x1)(-g), 0); theta -= g;  x' = x1 + theta / (L max(G + L, alpha L)) (L + R)
+// A coordinate that has never seen a non-zero gradient (L = 0: the ignored entries above the diagonal of a full-rank scale) stays
+// where it is -- the reference's expression is 0/0 there.
+template <typename T>
+__device__ __forceinline__ T cocob_step(T x, T g, T &L, T &G, T &R, T &th, T x1, T alpha) {
+  const T ag = g < T(0) ? -g : g;
+  L = L > ag ? L : ag;
+  G = G + ag;
+  const T r = R + (x - x1) * -g;
+  R = r > T(0) ? r : T(0);
+  th = th + -g;
+  if (!(L > T(0))) return x;
+  const T den = G + L > alpha * L ? G + L : alpha * L;
+  const T dx = -(x1 - x) - (th / (L * den) * (L + R));
+  return x - dx;
+}
+
 template <typename T>
 __device__ __forceinline__ T clip_step(T v, T eps) {
   if (v != v) return v;           // NaN propagates, like Julia's max

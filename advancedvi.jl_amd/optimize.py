@@ -93,6 +93,25 @@ class DoWG(DoG):
     kind = 1
 
 
+class COCOB:
+    """src/optimization/rules.jl:78-96 (COCOB-Backprop); state (L, G, R, theta, x1) = (0, 0, 0, 0, params) (:84-86).
+    Runs through the host-driven `step` loop (one update launch per iteration)."""
+
+    def __init__(self, alpha=100):
+        self.alpha = alpha
+
+    def setup(self, ctx, params):
+        import torch
+        n = params.numel()
+        st = torch.zeros(5 * n, dtype=params.dtype, device=params.device)
+        st[4 * n:] = params
+        return st
+
+    def update(self, ctx, state, params, grad, t):
+        ctx.cocob_update(params, grad, state, self.alpha)
+        return state
+
+
 # --- averagers (src/optimization/averaging.jl) -----------------------------------------------------
 class NoAveraging:
     def init(self, ctx, params):

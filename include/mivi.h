@@ -212,6 +212,10 @@ mivi_status_t mivi_descent_update(mivi_ctx_t *ctx, void *params_dev, const void 
 /* Optimisers.Adam(eta, (b1,b2), eps) (bench/benchmarks.jl:64): state_dev T[2*params_len] (m; v), t = step number >= 1 */
 mivi_status_t mivi_adam_update(mivi_ctx_t *ctx, void *params_dev, const void *grad_dev, void *state_dev,
                                int64_t t, double eta, double beta1, double beta2, double eps);
+/* COCOB(alpha), the "COCOB-Backprop" coin-betting rule (src/optimization/rules.jl:78-96): state_dev T[5*params_len] =
+ * (L; G; R; theta; x1), initialised by the caller to (0; 0; 0; 0; params) as Optimisers.init does (:84-86).  Coordinates whose
+ * gradient has been exactly zero so far (L = 0; the reference's expression is 0/0 there) are left unchanged. */
+mivi_status_t mivi_cocob_update(mivi_ctx_t *ctx, void *params_dev, const void *grad_dev, void *state_dev, double alpha);
 /* y <- a*x + b*y over n elements of T.  PolynomialAveraging: x_bar = (1-w) x_bar + w x, src/optimization/averaging.jl:40-47 */
 mivi_status_t mivi_axpby(mivi_ctx_t *ctx, void *y_dev, double a, const void *x_dev, double b, int64_t n);
 /* DoG (kind 0) / DoWG (kind 1): src/optimization/rules.jl:48-64 / :17-34.  state_dev holds x0 (T[params_len]) followed

@@ -589,6 +589,26 @@ def descent_step(params, grad, eta, dtype=np.float64):
     return (x - dtype(eta) * np.asarray(grad, dtype=dtype)).astype(dtype)
 
 
+def cocob_init(x):
+    """Optimisers.init(::COCOB, x): (L, G, R, theta, x1) = (0, 0, 0, 0, copy(x))  (src/optimization/rules.jl:84-86)."""
+    z = np.zeros_like(x)
+    return (z.copy(), z.copy(), z.copy(), z.copy(), x.copy())
+
+
+def cocob_step(x, dx, state, alpha=100.0):
+    """Optimisers.apply!(::COCOB, ...) followed by x .-= dx' (src/optimization/rules.jl:88-96).  Coordinates with L == 0 (no non-zero
+    gradient seen yet) are left unchanged: the reference's expression is 0/0 there."""
+    L, G, R, th, x1 = state
+    L = np.maximum(L, np.abs(dx))
+    G = G + np.abs(dx)
+    R = np.maximum(R + (x - x1) * -dx, 0.0)
+    th = th + -dx
+    with np.errstate(invalid="ignore", divide="ignore"):
+        dxp = -(x1 - x) - (th / (L * np.maximum(G + L, alpha * L)) * (L + R))
+    dxp = np.where(L > 0, dxp, 0.0)
+    return x - dxp, (L, G, R, th, x1)
+
+
 def adam_step(params, grad, state, t, eta=1e-3, beta=(0.9, 0.999), eps=1e-8, dtype=np.float64):
     """One Adam update at step t (1-based); state = (mt, vt) arrays (zeros before the first step)."""
     x, g = np.asarray(params, dtype=dtype), np.asarray(grad, dtype=dtype)

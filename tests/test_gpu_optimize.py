@@ -208,6 +208,51 @@ def test_update_and_projection_kernels_match_the_numpy_restatement(family, dtype
     ctx.close()
 
 
+@pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cocob_kernel_matches_the_numpy_restatement(family, dtype):
+    """mivi_cocob_update against oracle.cocob_step (src/optimization/rules.jl:78-96) on a fixed gradient sequence; the entries
+    above the diagonal of a full-rank scale never see a gradient and must stay put (the reference's expression is 0/0 there)."""
+    d = 23
+    rng = np.random.default_rng(12)
+    ctx = avi.MiviContext(dtype, family, d, 4, 0, SEED)
+    plen = ctx.params_len
+    x0 = rng.normal(size=plen).astype(dtype)
+    grads = [rng.normal(size=plen).astype(dtype) * dtype(10.0 ** rng.integers(-2, 2)) for _ in range(6)]
+    if family == avi.FULLRANK:
+        for g in grads:
+            g[d:] = np.tril(g[d:].reshape(d, d, order="F")).reshape(-1, order="F")
+    opt = avi.COCOB(100)
+    p = ctx.to_device(x0).clone()
+    st_dev = opt.setup(ctx, p)
+    x, st = x0.copy(), O.cocob_init(x0)
+    for t, g in enumerate(grads):
+        opt.update(ctx, st_dev, p, ctx.to_device(g), t + 1)
+        x, st = O.cocob_step(x, g, st, dtype(100))
+    got = p.cpu().numpy()
+    tol = 1e-12 if dtype == np.float64 else 64 * np.finfo(np.float32).eps
+    assert np.all(np.isfinite(got))
+    assert np.max(np.abs(got.astype(np.float64) - x) / np.maximum(1.0, np.abs(x))) <= tol
+    sd = st_dev.cpu().numpy().astype(np.float64)
+    for k in range(5):
+        assert np.max(np.abs(sd[k * plen:(k + 1) * plen] - st[k]) / np.maximum(1.0, np.abs(st[k]))) <= tol
+    if family == avi.FULLRANK:
+        up = np.triu(np.ones((d, d), bool), 1).reshape(-1, order="F")
+        assert np.array_equal(got[d:][up], x0[d:][up])
+    ctx.close()
+
+
+def test_cocob_through_optimize_reduces_the_objective():
+    """KLMinRepGradDescent with COCOB (host-driven step loop: the rule is not in the device loop's table)."""
+    d = 8
+    tm, ts = np.full(d, 3.0, np.float32), np.full(d, 0.5, np.float32)
+    q0 = avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32))
+    alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), n_samples=16, optimizer=avi.COCOB(), operator=avi.ClipScale())
+    q, info, _ = avi.optimize(avi.PhiloxRNG(3), alg, 400, avi.DiagNormalProblem(tm, ts), q0)
+    assert np.mean([i["elbo"] for i in info[-20:]]) > np.mean([i["elbo"] for i in info[:20]]) + 1.0
+    assert np.linalg.norm(q.location - tm) < 0.5 * np.linalg.norm(tm)
+
+
 def test_device_loop_converges_and_flags_divergence():
     d, M = 16, 16
     tm, ts = np.full(d, 5.0, np.float32), np.full(d, 0.3, np.float32)

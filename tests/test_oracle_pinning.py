@@ -268,3 +268,24 @@ def test_stacked_bijector_target_chain_rule_and_the_funnel_identity():
     v2, g2 = f_u.logdensity_and_gradient(eta)
     assert abs(v1 - v2) <= 1e-12 * max(1.0, abs(v2))
     assert np.allclose(g1, g2, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("alpha", [100, 100.0])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cocob_restatement_passes_the_reference_rule_test(alpha, dtype):
+    """test/general/rules.jl:1-31 for COCOB (src/optimization/rules.jl:78-96): single-sample least-squares SGD, 10^4 steps,
+    loss(X, w) < loss_0 / 10, eltype preserved."""
+    rng = np.random.default_rng(5)
+    d, n, T = 10, 1000, 10 ** 4
+    w = rng.normal(size=d).astype(dtype)
+    X = rng.random((n, d)).astype(dtype)
+    w_true = rng.normal(size=d).astype(dtype)
+    loss = lambda A, v: float(np.mean((A @ v - A @ w_true) ** 2))
+    l0 = loss(X, w)
+    st = O.cocob_init(w)
+    for t in range(T):
+        xi = X[rng.integers(n)]
+        g = (2 * (xi @ w - xi @ w_true) * xi).astype(dtype)       # gradient of the one-row loss
+        w, st = O.cocob_step(w, g, st, dtype(alpha))
+    assert w.dtype == dtype
+    assert loss(X, w) < l0 / 10
