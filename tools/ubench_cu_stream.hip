@@ -73,7 +73,8 @@ int main() {
   const int KB = 448;
   for (int same = 1; same >= 0; --same) {
     const size_t stride = same ? 0 : (size_t)KB * 256 * 4;   // floats: own region (spread wide) or the same bytes
-    for (int wgs : {16, 64}) {
+    for (int wgs : {16, 64, 256}) {
+      if (!same && (size_t)wgs * KB * 1024 > total) continue;   // (own regions must fit the buffer)
       for (int waves : {2, 4, 8}) {
         const int kbw = KB / waves;
         double t;
