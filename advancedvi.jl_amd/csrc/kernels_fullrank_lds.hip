@@ -82,8 +82,11 @@ struct ReduceArgs {
 // -----------------------------------------------------------------------------------------------------------------
 // 16-byte store that does not stay in the XCD's L2 (sc1): the dense gradient (4 MB at the north star) is not read by the next
 // kernels of the chain, while C / eps / W are -- a plain store would push them out of the 4 MB L2.
+// (The s_nop is the gfx9 store-data hazard: a VMEM store of more than 8 bytes still reads its data registers for two cycles
+// after issue, and the compiler's hazard recognizer does not look inside inline asm -- without it the next VALU write into
+// one of those registers reached memory instead of the gradient.)
 __device__ __forceinline__ void store16_drop(float *p, const f32x4 &v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 template <int BM, int BN, int KW, int NT, bool FUSED>
@@ -680,6 +683,162 @@ __global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) {
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// k_fr_vjp64: tril(W eps^T) on 64 x 64 tiles, eight waves split K = n_mc into contiguous runs of 32-k sub-stages; every wave
+// stages its own 64 rows of W and 64 rows of eps (16 KiB, wave-private, LDS-DMA) and holds all four 32 x 32 accumulators of
+// the tile, so an operand element feeds two MFMA tiles instead of one and is split into bf16 pieces once for both.
+//   Used for the large shapes (n_mc >= 1024: every wave has four or more sub-stages, so its one-deep staging overlaps with
+//   its own MFMA chains): 4096 x 1024 VJP 108 -> 118 TF f32-equivalent.  At the north star the 32 x 32 kernel stays faster
+//   (6.0 vs 7.4 us) although its most loaded CUs carry 192 KiB against 128 KiB here -- see launch_lds_vjp.
+// Epilogue: vjp_epilogue<64, 64, 8, 512> (the eight partial tiles summed in wave order through LDS).
+// -----------------------------------------------------------------------------------------------------------------
+template <bool FUSED, bool BF3>
+__global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
+  constexpr int BM = 64, BN = 64, KW = 8, NT = 512, SUB = 32;
+  constexpr int LDC = BM + 4;
+  constexpr int WAVE_F = 2 * SUB * 64;                      // floats per wave: As[32 k][64 rows] + Bs[32 k][64 rows]
+  constexpr int EPI = KW * BN * LDC + (NT / BM) * BM;
+  constexpr int MAIN = EPI > KW * WAVE_F ? EPI : KW * WAVE_F;
+  __shared__ __attribute__((aligned(16))) float lds[MAIN + 2 * KW + 4];
+  double *red = reinterpret_cast<double *>(lds + MAIN);
+  float *adam_cc = lds + MAIN + 2 * KW;
+  {
+    const unsigned long long pA = (unsigned long long)a.A, pB = (unsigned long long)a.B, pW = (unsigned long long)a.work,
+                             pP = (unsigned long long)a.params, pD = (unsigned long long)a.dbg, pG = (unsigned long long)a.out.grad,
+                             pQ = (unsigned long long)a.out.partials;
+    asm volatile("" ::"s"(pA), "s"(pB), "s"(pW), "s"(pP), "s"(pD), "s"(pG), "s"(pQ), "s"(a.d), "s"(a.M), "s"(a.lda), "s"(a.ldb),
+                 "s"(a.n_work), "s"(a.knock), "s"(a.out.partials_mode), "s"(a.out.ent_kind), "s"(a.out.M_total));
+  }
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int d = a.d;
+  if ((int)blockIdx.x == a.n_work) {   // objective value of THIS estimate (everything it sums is older)
+    const float *pp = a.params;
+    finalize_value_block<float, NT, false>(d, a.self_vin, a.self_out, (int64_t)d + (int64_t)d * d,
+                                           [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, red);
+    return;
+  }
+  MIVI_STAMP_K(a.dbg, G_VJP, 0);
+  const __attribute__((address_space(4))) int *wp = (const __attribute__((address_space(4))) int *)a.work + 4 * blockIdx.x;
+  const int4 wk = make_int4(wp[0], wp[1], wp[2], wp[3]);
+  asm volatile("" ::"s"(wk.x), "s"(wk.y), "s"(wk.z), "s"(wk.w));
+  const int rb = wk.x & 0xffff, cb = wk.x >> 16;
+  const int row0 = rb * BM, col0 = cb * BN;
+  const bool mu_tile = (wk.w & 2);
+  const int nsub = a.M / SUB;
+  const int t_beg = (w * nsub) / KW, t_end = ((w + 1) * nsub) / KW;   // this wave's run of sub-stages
+  if (a.dbg && tid == 0 && blockIdx.x < 4096) a.dbg[((size_t)G_VJP * 4096 + blockIdx.x) * 8 + 7] = wk.x;
+
+  if (FUSED && a.upd.rule == 1 && tid == 0)
+    adam_bias<float>(a.upd.t_base + (a.upd.t_ptr ? *a.upd.t_ptr : 0), a.upd.b1, a.upd.b2, adam_cc[0], adam_cc[1]);
+
+  // a 1 KiB piece = 8 k of 32 rows (lane -> k = lane / 8, rows 4 (lane % 8) ..); image [k][64 rows]: piece (kq, rh) at
+  // k = 8 kq .., rows 32 rh .. -> float offset (8 kq + lane / 8) * 64 + 32 rh + 4 (lane % 8): NOT lane-linear inside a k row of
+  // 64, so the two row halves of a k group are kept as two separate [8 k][32] blocks: offset ((kq * 2 + rh) * 8 + k) * 32 + row
+  float *buf = lds + w * WAVE_F;
+  const float *Ag = a.A + row0 + 4 * (lane & 7) + (size_t)(lane >> 3) * a.lda;
+  const float *Bg = a.B + col0 + 4 * (lane & 7) + (size_t)(lane >> 3) * a.ldb;
+  auto issue = [&](int t) {
+    const float *pa = Ag + (size_t)(t * SUB) * a.lda, *pb = Bg + (size_t)(t * SUB) * a.ldb;
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh) {
+        MIVI_GLDS16(pa + (size_t)(8 * kq) * a.lda + 32 * rh, buf + (kq * 2 + rh) * 256);
+        MIVI_GLDS16(pb + (size_t)(8 * kq) * a.ldb + 32 * rh, buf + SUB * 64 + (kq * 2 + rh) * 256);
+      }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float rsum[2] = {0.f, 0.f};
+  __builtin_amdgcn_s_setprio(3);
+  if (t_beg < t_end && !(a.knock & 4)) issue(t_beg);
+  __builtin_amdgcn_s_setprio(0);
+  for (int t = t_beg; t < t_end; ++t) {
+    wait_vmcnt<0>();
+    float av[2][16], bv[2][16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {   // the lane's k slots of this sub-stage: k = 8 (i / 4) + 4 h + (i % 4), both operands
+      const int kq = i >> 2, kk = 4 * h + (i & 3);
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh) {
+        av[rh][i] = buf[((kq * 2 + rh) * 8 + kk) * 32 + l31];
+        bv[rh][i] = buf[SUB * 64 + ((kq * 2 + rh) * 8 + kk) * 32 + l31];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer is free again before it is requested anew
+    if (t == t_beg) MIVI_STAMP_K(a.dbg, G_VJP, 1);
+    if (t + 1 < t_end && !(a.knock & 4)) issue(t + 1);
+    if (mu_tile) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { rsum[0] += av[0][i]; rsum[1] += av[1][i]; }
+    }
+    if (!(a.knock & 2)) {
+      if (BF3) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {   // two K = 16 groups per sub-stage; every operand half is split ONCE for its two tiles
+          bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+          for (int x = 0; x < 2; ++x) {
+            split3_bf16(av[x] + 8 * g, ah[x], am[x], al[x]);
+            split3_bf16(bv[x] + 8 * g, bh[x], bm[x], bl[x]);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              f32x16 c = acc[i][j];
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], c, 0, 0, 0);
+              c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], c, 0, 0, 0);
+              acc[i][j] = c;
+            }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  __builtin_amdgcn_s_barrier();   // every wave is done with its buffer: LDS becomes the epilogue image
+  MIVI_STAMP_K(a.dbg, G_VJP, 2);
+  if (a.knock & 16) return;
+  float *Cs = lds;   // Cs[kw][n (64 eps rows = tile columns)][LDC]: rows of the tile contiguous
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        *(f32x4 *)(Cs + (w * BN + 32 * j + l31) * LDC + 32 * i + 8 * q + 4 * h) = v;
+      }
+  float *rs_lds = lds + KW * BN * LDC;   // [NT/BM = 8 waves][BM]
+  if (mu_tile) {
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+      const float o = rsum[x] + __shfl_xor(rsum[x], 32, 64);   // the two k halves of the wave
+      if (h == 0) rs_lds[w * BM + 32 * x + l31] = o;
+    }
+  }
+  lds_barrier();
+  MIVI_STAMP_K(a.dbg, G_VJP, 3);
+  if (a.knock & 32) return;
+  vjp_epilogue<BM, BN, KW, NT, FUSED>(a, Cs, rs_lds, adam_cc, wk, row0, col0);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // k_fr_prod32: Z = mu + tril(C) eps (G_SAMPLE) or G = -P (Z - m) (G_DENSE) WITHOUT split-K: one 32 x 32 output tile per
 // workgroup, eight waves split the tile's k range into contiguous runs of 32-k sub-stages and stage their OWN operands
 // (private 8 KiB LDS buffer per wave, LDS-DMA, no workgroup barrier before the epilogue -- the structure of k_fr_vjp32).
@@ -1121,7 +1280,8 @@ void build_splitk(mivi_ctx *c, int nrb, int ncb, bool triangular, int full_stage
   upload(c, tiles, tl.data(), tl.size() * sizeof(int2));
 }
 
-void build_vjp(mivi_ctx *c, int d, int M, DevBuf &tab, int &n_items) {
+void build_vjp(mivi_ctx *c, int d, int M, int tile, DevBuf &tab, int &n_items) {
+  const int kVBM = tile, kVBN = tile;   // (shadows the 32 x 32 constants: the same table for either tile size)
   const int nrb = d / kVBM;
   const int SR = 256 / kVBM, SC = 256 / kVBN;   // super-blocks of 256 x 256 elements: one XCD's L2 holds their operands
   std::vector<std::vector<Item>> sbs;
@@ -1169,7 +1329,8 @@ bool lds_prepare(mivi_ctx *c, int M) {
   int slabs_s = 0, slabs_d = 0;
   build_splitk(c, nrb, ncb, true, d / kBK, c->lds_tabS, c->lds_tilesS, c->lds_nS, slabs_s);
   if (dense) build_splitk(c, nrb, ncb, false, d / kBK, c->lds_tabD, c->lds_tilesD, c->lds_nD, slabs_d);
-  build_vjp(c, d, M, c->lds_tabV, c->lds_nV);
+  build_vjp(c, d, M, 32, c->lds_tabV, c->lds_nV);
+  build_vjp(c, d, M, 64, c->lds_tabV64, c->lds_nV64);
   const int ns = std::max(slabs_s, slabs_d) + 1;
   const size_t bytes = (size_t)ns * kBM * kBN * sizeof(float);
   if (c->lds_slab.bytes < bytes) {
@@ -1338,6 +1499,22 @@ void launch_lds_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, 
     grid += 1;
   }
   if (upd) a.upd = *upd;
+  // tile size: 64 x 64 (half the operand bytes per flop) pays once a wave has several sub-stages to overlap its one-deep
+  // staging with -- measured: 4096 x 1024 VJP 159 -> 145 us (118 TF), but 1024 x 256 6.0 -> 7.4 us and 2048 x 256 16.9 -> 20.4 us
+  // (a wave's single sub-stage there is load, then compute, then a four times larger epilogue, nothing overlapped, against
+  // two or three 32 x 32 workgroups per CU covering for each other).  MIVI_VJP_TILE=32 / 64 pins it.
+  static const int pin = getenv("MIVI_VJP_TILE") ? atoi(getenv("MIVI_VJP_TILE")) : 0;
+  const bool t64 = pin ? pin == 64 : (M >= 1024 && c->cfg.d >= 2048);
+  if (t64) {
+    a.work = (const int4 *)c->lds_tabV64.p;
+    grid = c->lds_nV64;
+    if (self) { a.n_work = c->lds_nV64; grid += 1; }
+    if (upd && f32_mfma()) hipLaunchKernelGGL((k_fr_vjp64<true, false>), dim3(grid), dim3(512), 0, c->stream, a);
+    else if (upd) hipLaunchKernelGGL((k_fr_vjp64<true, true>), dim3(grid), dim3(512), 0, c->stream, a);
+    else if (f32_mfma()) hipLaunchKernelGGL((k_fr_vjp64<false, false>), dim3(grid), dim3(512), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_fr_vjp64<false, true>), dim3(grid), dim3(512), 0, c->stream, a);
+    return;
+  }
   if (upd && f32_mfma()) hipLaunchKernelGGL((k_fr_vjp32<true, false>), dim3(grid), dim3(256), 0, c->stream, a);
   else if (upd) hipLaunchKernelGGL((k_fr_vjp32<true, true>), dim3(grid), dim3(256), 0, c->stream, a);
   else if (f32_mfma()) hipLaunchKernelGGL((k_fr_vjp32<false, false>), dim3(grid), dim3(256), 0, c->stream, a);

@@ -259,8 +259,8 @@ struct mivi_ctx {
   bool want_stl_pack = false, stl_pack_done = false;   // Stein estimator: ask the sampling kernel to carry the solve's riders
   mivi::DevBuf stl_X;              // second-generation STL solve: X of the lower half + updated right-hand side of the upper half
   // second-generation full-rank kernels (kernels_fullrank_lds.hip): split-K work lists, per-tile slab ranges, slabs
-  mivi::DevBuf lds_tabS, lds_tilesS, lds_tabD, lds_tilesD, lds_tabV, lds_slab;
-  int lds_nS = 0, lds_nD = 0, lds_nV = 0, lds_M = -1, lds_zero_slab = 0;
+  mivi::DevBuf lds_tabS, lds_tilesS, lds_tabD, lds_tilesD, lds_tabV, lds_tabV64, lds_slab;
+  int lds_nS = 0, lds_nD = 0, lds_nV = 0, lds_nV64 = 0, lds_M = -1, lds_zero_slab = 0;
   bool lds_dense = false;
   int he_n[2] = {0, 0};            // number of sum-0.5-eps^2 partials behind he_part[parity] (depends on who drew eps)
   int nA = 0, nB = 0, nD = 0, tab_M = -1;
