@@ -10,7 +10,8 @@ from tests.helpers import SEED, make_family, make_problem
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("family,d,M,R", [(avi.MEANFIELD, 64, 48, 4), (avi.FULLRANK, 96, 64, 2), (avi.FULLRANK, 40, 30, 3)])
+@pytest.mark.parametrize("family,d,M,R", [(avi.MEANFIELD, 64, 48, 4), (avi.FULLRANK, 96, 64, 2), (avi.FULLRANK, 40, 30, 3),
+                                          (avi.FULLRANK, 256, 256, 2)])   # (last: second-generation kernels, 128 samples per shard)
 @pytest.mark.parametrize("ent", [0, 2, 3])
 def test_sharded_partials_sum_to_single_gpu_estimate(family, d, M, R, ent):
     rng = np.random.default_rng(2)
