@@ -842,6 +842,7 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*ReduceScatter)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi *rccl() {
@@ -860,6 +861,7 @@ RcclApi *rccl() {
   api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
   api.ReduceScatter = (decltype(api.ReduceScatter))dlsym(api.lib, "ncclReduceScatter");
   api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+  api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
   api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
   if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.ReduceScatter || !api.AllGather) { api.lib = nullptr; return nullptr; }
   return &api;
@@ -954,6 +956,19 @@ mivi_status_t mivi_estimate_gradient_dist(mivi_ctx_t *c, const void *params, uin
       return s;
   }
   if ((s = mivi_estimate_partials(c, params, idx, c->dist_P.p))) return s;
+  // Route: two collectives cost one more launch + rendezvous than one; below 16 MB of partials the step is
+  // latency bound and ONE all-reduce + the whole finalisation on every rank is the faster form.  MIVI_DIST_ROUTE=allreduce / rsag pins it.
+  const char *pin = getenv("MIVI_DIST_ROUTE");   // (read per call: tests drive both routes in one process)
+  const bool rsag = pin ? (pin[0] == 'r') : ((size_t)mivi_partials_len(c) * es >= ((size_t)16 << 20));
+  if (c->comm && !rsag) {
+    RcclApi *r = rccl();
+    const ncclDataType_t dt = c->cfg.dtype == MIVI_F32 ? ncclFloat : ncclDouble;
+    if (!r->AllReduce || r->AllReduce(c->dist_P.p, c->dist_P.p, (size_t)mivi_partials_len(c), dt, ncclSum, (ncclComm_t)c->comm, c->stream) != ncclSuccess)
+      return fail(c, MIVI_ERR_HIP, "ncclAllReduce failed");
+    if ((s = mivi_finalize(c, params, c->dist_P.p, value, grad))) return s;
+    HIPCHK(c, hipGetLastError());
+    return MIVI_OK;
+  }
   const void *sum = (const char *)c->dist_P.p + (size_t)rank * n * es;   // one rank: its "slice" is the whole vector
   if (c->comm) {
     RcclApi *r = rccl();

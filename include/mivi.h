@@ -287,7 +287,8 @@ mivi_status_t mivi_unpack_final(mivi_ctx_t *ctx, const void *packed_final_dev, v
  * local share, m_offset = its first global column, m_total = n_mc * world.  mivi_estimate_gradient_dist is then estimate_gradient!
  * of the m_total-sample estimate on every rank: {partials kernels, ncclReduceScatter, slice finalise, ncclAllGather, unpack}, all
  * on the context's stream (graph-capturable).  world = 1 without a communicator runs the same kernels without the collectives;
- * world = 1 WITH an id runs them through RCCL (single-GPU test of the whole path). */
+ * world = 1 WITH an id runs them through RCCL (single-GPU test of the whole path).  Route: ONE ncclAllReduce + the whole finalisation on every rank below 16 MB of partials (latency bound),
+ * ncclReduceScatter -> slice finalisation -> ncclAllGather -> unpack above; MIVI_DIST_ROUTE=allreduce|rsag pins it. */
 #define MIVI_COMM_ID_BYTES 128
 mivi_status_t mivi_comm_unique_id(void *id_host);
 mivi_status_t mivi_comm_init(mivi_ctx_t *ctx, const void *id_host, int32_t rank, int32_t world);

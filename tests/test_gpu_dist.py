@@ -87,9 +87,10 @@ def test_slice_finalisation_kernels(family, d, M, R, ent, dtype):
 
 
 @pytest.mark.parametrize("family,d,M", [(avi.MEANFIELD, 64, 48), (avi.FULLRANK, 128, 128), (avi.FULLRANK, 40, 30)])
-def test_collective_behind_the_c_abi_on_one_gpu(family, d, M):
-    """mivi_comm_init(world = 1, WITH a unique id) + mivi_estimate_gradient_dist: the whole {partials, ncclReduceScatter, slice
-    finalise, ncclAllGather, unpack} chain through the RCCL that libmivi opens itself, against the plain estimate."""
+def test_collective_behind_the_c_abi_on_one_gpu(family, d, M, monkeypatch):
+    """mivi_comm_init(world = 1, WITH a unique id) + mivi_estimate_gradient_dist through the RCCL that libmivi opens itself, both
+    routes -- {partials, ncclAllReduce, finalise} (the default below 16 MB of partials) and {partials, ncclReduceScatter, slice
+    finalise, ncclAllGather, unpack} -- against the plain estimate."""
     rng = np.random.default_rng(4)
     q, _ = make_family(rng, d, family, np.float32)
     prob, _ = make_problem(rng, "diag", d, np.float32)
@@ -99,12 +100,19 @@ def test_collective_behind_the_c_abi_on_one_gpu(family, d, M):
     v0, g0 = ctx.estimate_gradient(params, 5)
     v0, g0 = float(v0.item()), g0.cpu().numpy().copy()
     ctx.comm_init(ctx.comm_unique_id(), 0, 1)
-    v1, g1 = ctx.estimate_gradient_dist(params, 5)
-    ctx.synchronize()
-    assert abs(float(v1.item()) - v0) <= 2e-6 * abs(v0)
-    assert np.linalg.norm(g1.cpu().numpy() - g0) <= 5e-6 * max(1.0, np.linalg.norm(g0))
-    # and without a communicator (world 1): same kernels, no collective
+    got = {}
+    for route in ("allreduce", "rsag"):
+        monkeypatch.setenv("MIVI_DIST_ROUTE", route)
+        v1, g1 = ctx.estimate_gradient_dist(params, 5)
+        ctx.synchronize()
+        assert abs(float(v1.item()) - v0) <= 2e-6 * abs(v0)
+        assert np.linalg.norm(g1.cpu().numpy() - g0) <= 5e-6 * max(1.0, np.linalg.norm(g0))
+        got[route] = g1.cpu().numpy().copy()
+    monkeypatch.delenv("MIVI_DIST_ROUTE")
+    v1, g1 = ctx.estimate_gradient_dist(params, 5)       # default route for this size: one all-reduce
+    assert np.array_equal(g1.cpu().numpy(), got["allreduce"])
+    # and without a communicator (world 1): the slice kernels, no collective
     ctx.comm_init(None, 0, 1)
     v2, g2 = ctx.estimate_gradient_dist(params, 5)
-    assert np.array_equal(g2.cpu().numpy(), g1.cpu().numpy())
+    assert np.array_equal(g2.cpu().numpy(), got["rsag"])
     ctx.close()
