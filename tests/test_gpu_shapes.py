@@ -17,6 +17,11 @@ CASES = [
     (avi.FULLRANK, 1, 1, "diag", 0, np.float32), (avi.FULLRANK, 3, 1000, "diag", 2, np.float32),
     (avi.MEANFIELD, 1, 1, "diag", 2, np.float64), (avi.FULLRANK, 33, 4096, "dense", 3, np.float32),
     (avi.FULLRANK, 2, 1, "dense", 1, np.float64), (avi.MEANFIELD, 5, 3, "funnel", 3, np.float32),
+    # second-generation full-rank route: unsplit product with the STL riders (d = 2048 / 512 / 256: 16 / 4 / 2 chain blocks per half),
+    # split-K route with the stand-alone STL preparation, dense target on the unsplit product
+    (avi.FULLRANK, 2048, 128, "diag", 3, np.float32), (avi.FULLRANK, 512, 256, "dense", 3, np.float32),
+    (avi.FULLRANK, 256, 128, "diag", 4, np.float32), (avi.FULLRANK, 2048, 512, "diag", 3, np.float32),
+    (avi.FULLRANK, 1024, 1024, "diag", 0, np.float32),
 ]
 
 
