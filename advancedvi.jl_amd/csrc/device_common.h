@@ -52,6 +52,23 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
+// 16-byte WRITE-THROUGH store (sc1): the line does not stay dirty in the XCD's L2.
+//   * Dirty lines left in L2 are written back when the kernel ENDS, on its critical path: 1 MB of eps(t+1) written by rider
+//     workgroups early in the sampling kernel cost +0.9 us at its end, wherever in the kernel it was produced; written through, it
+//     has left long before.  The next kernel cannot use the line anyway (the per-XCD L2s are not coherent: its consumers may sit
+//     on another XCD and read memory / the memory-side cache).
+//   * It also keeps outputs nobody re-reads (the 4 MB dense gradient) from pushing the operands out of the 4 MB L2.
+// The s_nop is the gfx9 store-data hazard: a VMEM store of more than 8 bytes still reads its data registers for two cycles
+// after issue, and the compiler's hazard recognizer does not look inside inline asm -- without it the next VALU write into one of
+// those registers reached memory instead of the value.
+template <typename V16>
+__device__ __forceinline__ void store16_wt(void *p, const V16 &v) {
+  static_assert(sizeof(V16) == 16, "16-byte vector");
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const u32x4_t r = __builtin_bit_cast(u32x4_t, v);   // (HIP's float4 is a struct: the asm wants a register tuple)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
+}
+
 // timeline stamps: region `kind` (0 mean-field / sample, 1 vjp, 2 dense) x 4096 blocks x 8 slots
 #define MIVI_STAMP_K(dbgp, kind, slot) do { if ((dbgp) && threadIdx.x == 0 && blockIdx.x < 4096) (dbgp)[((size_t)(kind) * 4096 + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
 #define MIVI_STAMP(dbgp, slot) MIVI_STAMP_K(dbgp, 0, slot)

@@ -80,15 +80,6 @@ struct ReduceArgs {
 // (and in the mirrored tile), d/dmu on the tiles that hold a diagonal block's first columns; shard mode: packed triangle;
 // FUSED: Descent / Adam (+ ClipScale) applied in place instead of writing the gradient.
 // -----------------------------------------------------------------------------------------------------------------
-// 16-byte store that does not stay in the XCD's L2 (sc1): the dense gradient (4 MB at the north star) is not read by the next
-// kernels of the chain, while C / eps / W are -- a plain store would push them out of the 4 MB L2.
-// (The s_nop is the gfx9 store-data hazard: a VMEM store of more than 8 bytes still reads its data registers for two cycles
-// after issue, and the compiler's hazard recognizer does not look inside inline asm -- without it the next VALU write into
-// one of those registers reached memory instead of the gradient.)
-__device__ __forceinline__ void store16_drop(float *p, const f32x4 &v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
-
 template <int BM, int BN, int KW, int NT, bool FUSED>
 __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs, const float *rs_lds, const float *adam_cc, int4 wk,
                                              int row0, int col0) {
@@ -151,7 +142,7 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
       }
       if (!fused) {
         if (a.knock & 64) *(f32x4 *)(dst + pi) = o;
-        else store16_drop(dst + pi, o);
+        else store16_wt(dst + pi, o);
       } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -182,7 +173,7 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
       for (int u = 0; u < NE; ++u) {
         const int e = tid + u * NT, j4 = 4 * (e % (BN / 4)), ii = e / (BN / 4);
         if (a.knock & 64) *(f32x4 *)(dst + d + (size_t)(row0 + ii) * d + col0 + j4) = z4;
-        else store16_drop(dst + d + (size_t)(row0 + ii) * d + col0 + j4, z4);
+        else store16_wt(dst + d + (size_t)(row0 + ii) * d + col0 + j4, z4);
       }
     }
   }
@@ -889,26 +880,38 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int d = a.d;
-  if ((int)blockIdx.x < a.n_dinv) {
+  // Block -> tile.  Tiles are listed heaviest first (t = 0 ..); the n_dinv lightest ones (the END of that list) are dispatched FIRST
+  // and invert one 64 x 64 diagonal block of C each before their own tile (a 6.6 us latency chain + a 1-2 us tile against the
+  // 8 us of the heaviest tile): with workgroups of their own the inversions took 16 CUs for most of the kernel, 16 tiles had
+  // to wait for a CU, and the riders hitched to those tiles finished last (+2.4 us).
+  const bool trailing = (int)blockIdx.x >= a.n_tiles;
+  const int bid = trailing ? (int)blockIdx.x : ((int)blockIdx.x < a.n_dinv ? a.n_tiles - 1 - (int)blockIdx.x : (int)blockIdx.x - a.n_dinv);
+  if (!trailing && (int)blockIdx.x < a.n_dinv) {
     stl_dinv64_block<NT>(d, a.A, a.stl_pack, (int)blockIdx.x, lds);
-    return;
+    __syncthreads();
   }
-  const int bid = (int)blockIdx.x - a.n_dinv;
-  if (bid >= a.n_tiles + a.n_eps) {
-    stl_pack_block<NT>(d, a.A, a.stl_pack, bid - a.n_tiles - a.n_eps);
-    return;
-  }
-  if (bid >= a.n_tiles) {   // eps(t+1): one Philox block per thread (rows gi..gi+3 of column gm), the k_eps stream
+  // Riders (work that is off this kernel's critical path): the re-lay of the STL operands (n_pack blocks), then eps(t+1)
+  // (n_eps blocks).  Rider r hitches onto the (n_dinv + r)-th lightest tile's workgroup AFTER that tile's epilogue: the light
+  // tiles are done after 1-3 us of a ~8 us kernel.  Riders beyond the number of tiles get trailing workgroups.
+  auto rider = [&](int r) {
+    if (r < a.n_pack) {
+      stl_pack_block<NT>(d, a.A, a.stl_pack, r);
+      return;
+    }
+    // eps(t+1): one Philox block per thread (rows gi..gi+3 of column gm), the k_eps stream
     const SampleArgs<float> &n = a.next_eps;
-    const int eb = bid - a.n_tiles, nrb = d >> 6;
-    const int gi = (eb % nrb) * 64 + 4 * (tid & 15), gm = (eb / nrb) * 32 + (tid >> 4);
+    const int eb = r - a.n_pack, nrb6 = d >> 6;
+    const int gi = (eb % nrb6) * 64 + 4 * (tid & 15), gm = (eb / nrb6) * 32 + (tid >> 4);
     float e[4];
     eps_block<float>(n.rng.seed, rng_index(n.rng), (uint64_t)(n.rng.m_offset + gm) * (uint64_t)(d >> 2) + (uint64_t)(gi >> 2), e);
     const f32x4 ev = {e[0], e[1], e[2], e[3]};
-    *(f32x4 *)(n.eps + (size_t)gm * n.ld_eps + gi) = ev;
+    store16_wt(n.eps + (size_t)gm * n.ld_eps + gi, ev);   // (written through: see store16_wt)
     const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
     const double sh = block_sum<double, NT>((double)he, red);
     if (tid == 0) n.he_part[eb] = sh;
+  };
+  if (trailing) {   // riders beyond the tile count
+    rider(bid - a.n_dinv);
     return;
   }
   MIVI_STAMP_K(a.dbg, MODE, 0);
@@ -1028,10 +1031,10 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
       const f32x4 g = -v;
 #pragma unroll
       for (int c = 0; c < 4; ++c) ell += 0.5f * rr[c] * g[c];
-      *(f32x4 *)(a.W + (size_t)gm * d + gi) = g;
+      store16_wt(a.W + (size_t)gm * d + gi, g);
     } else {
       const f32x4 z = mu + v;
-      if (a.Z) *(f32x4 *)(a.Z + (size_t)gm * d + gi) = z;
+      if (a.Z) store16_wt(a.Z + (size_t)gm * d + gi, z);
       if (a.mode == R_DIAG) {
         f32x4 wv;
 #pragma unroll
@@ -1040,9 +1043,10 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
           ell += -0.5f * u * u;
           wv[c] = -u * tis[c];
         }
-        *(f32x4 *)(a.W + (size_t)gm * d + gi) = wv;
+        store16_wt(a.W + (size_t)gm * d + gi, wv);
       } else if (a.mode == R_DENSE_R) {
-        *(f32x4 *)(a.R + (size_t)gm * a.dP + gi) = z - tm;
+        const f32x4 rz = z - tm;
+        store16_wt(a.R + (size_t)gm * a.dP + gi, rz);
       }
     }
   }
@@ -1063,6 +1067,13 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
     }
   }
   MIVI_STAMP_K(a.dbg, MODE, 4);
+  {
+    const int r = a.n_tiles - 1 - bid - a.n_dinv;   // this tile's rider, if any (the n_dinv lightest tiles carried an inversion)
+    if (r >= 0 && r < a.n_pack + a.n_eps) {
+      __syncthreads();                   // (the riders reuse `red` / LDS)
+      rider(r);
+    }
+  }
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -1436,14 +1447,14 @@ void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int m
     a.next_eps.ld_eps = c->dP;
     a.next_eps.he_part = (double *)c->he_part[next->parity].p;
     a.n_eps = (c->cfg.d / 64) * (M / 32);
-    grid += a.n_eps;
   }
   if (with_dinv && !dense) {
     a.stl_pack = (unsigned *)c->stl_F.p;
     a.n_dinv = c->cfg.d / 64;
     a.n_pack = stl_pack_riders(c->cfg.d);
-    grid += a.n_dinv + a.n_pack;
   }
+  // riders hitch onto the tile workgroups; only the ones beyond the tile count get workgroups of their own
+  grid = a.n_tiles > a.n_dinv + a.n_pack + a.n_eps ? a.n_tiles : a.n_dinv + a.n_pack + a.n_eps;
   if (dense && f32_mfma()) hipLaunchKernelGGL((k_fr_prod32<G_DENSE, false>), dim3(grid), dim3(512), 0, c->stream, a);
   else if (dense) hipLaunchKernelGGL((k_fr_prod32<G_DENSE, true>), dim3(grid), dim3(512), 0, c->stream, a);
   else if (f32_mfma()) hipLaunchKernelGGL((k_fr_prod32<G_SAMPLE, false>), dim3(grid), dim3(512), 0, c->stream, a);

@@ -231,8 +231,11 @@ __global__ __launch_bounds__(512) void k_stl_solve64(StlSolveArgs a) {
         *(u32x2v *)(Ximg + 2 * 512 + slot) = l2;
       }
       const int row = 64 * J + 16 * q + 4 * g;
-      if (a.X) *(f32x4 *)(a.X + (size_t)col * a.ld_x + row) = x;
-      if (a.W) *(f32x4 *)(a.W + (size_t)col * a.ld_w + a.r0 + row) = a.w_set ? x : wf[J] + x;
+      if (a.X) store16_wt(a.X + (size_t)col * a.ld_x + row, x);   // (written through: see store16_wt)
+      if (a.W) {
+        const f32x4 wo = a.w_set ? x : wf[J] + x;
+        store16_wt(a.W + (size_t)col * a.ld_w + a.r0 + row, wo);
+      }
       stamp(0, J, 3);
       if constexpr (J > 0) lds_barrier();   // B_J
     });
@@ -376,7 +379,8 @@ __global__ __launch_bounds__(512) void k_stl_update32(StlUpdArgs a) {
 #pragma unroll
     for (int k2 = 1; k2 < NW; ++k2) v += *(const f32x4 *)(Cs + (k2 * 32 + en) * LDC + ei4);
     const f32x4 e = *(const f32x4 *)(a.E + (size_t)(col0 + en) * a.ld_e + a.e_r0 + row0 + ei4);
-    *(f32x4 *)(a.R + (size_t)(col0 + en) * a.ld_r + row0 + ei4) = e - v;
+    const f32x4 ro = e - v;
+    store16_wt(a.R + (size_t)(col0 + en) * a.ld_r + row0 + ei4, ro);
   }
 }
 

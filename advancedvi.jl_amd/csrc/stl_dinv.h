@@ -7,6 +7,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "device_common.h"
+
 namespace mivi {
 
 // ---- the packed operand buffer (32-bit units) -----------------------------------------------------------------------
@@ -44,9 +46,9 @@ __device__ __forceinline__ void stl_store_planes(unsigned *tile, int m, int lane
   const u4 ph = {h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16)};
   const u4 pm = {mm[0] | (mm[1] << 16), mm[2] | (mm[3] << 16), mm[4] | (mm[5] << 16), mm[6] | (mm[7] << 16)};
   const u4 pl = {l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)};
-  *(u4 *)(tile + ((m * 3 + 0) * 64 + lane) * 4) = ph;
-  *(u4 *)(tile + ((m * 3 + 1) * 64 + lane) * 4) = pm;
-  *(u4 *)(tile + ((m * 3 + 2) * 64 + lane) * 4) = pl;
+  store16_wt(tile + ((m * 3 + 0) * 64 + lane) * 4, ph);   // (written through: see store16_wt -- these are rider outputs)
+  store16_wt(tile + ((m * 3 + 1) * 64 + lane) * 4, pm);
+  store16_wt(tile + ((m * 3 + 2) * 64 + lane) * 4, pl);
 }
 
 // Inverse of the 64 x 64 diagonal block J by recursive doubling inside LDS, written as plane tiles.  `sm` holds 3 * 64 * 65
@@ -58,32 +60,56 @@ __device__ __forceinline__ void stl_dinv64_block(int d, const float *C, unsigned
   float(*T)[65] = reinterpret_cast<float(*)[65]>(sm + 2 * 64 * 65);
   const int tid = threadIdx.x;
   const float *src = C + (size_t)(64 * J) * d + 64 * J;
-  for (int e = tid; e < 4096; e += NT) {
-    const int r = e & 63, c = e >> 6;                    // lanes along rows: 256-byte runs of a column of C
-    const float v = (r >= c) ? src[(size_t)c * d + r] : 0.f;
-    L[r][c] = v;
-    Li[r][c] = (r == c) ? 1.f / v : 0.f;
+  for (int e = tid; e < 1024; e += NT) {                // 16-byte loads along the rows of a column (256-byte runs): one round trip
+    const int r4 = 4 * (e & 15), c = e >> 4;
+    const float4 v4 = *(const float4 *)(src + (size_t)c * d + r4);
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = r4 + t;
+      const float x = (r >= c) ? v[t] : 0.f;
+      L[r][c] = x;
+      Li[r][c] = (r == c) ? 1.f / x : 0.f;
+    }
+  }
+  __syncthreads();
+  // [A 0; C B]^{-1} = [A^{-1} 0; -B^{-1} (C A^{-1}) B^{-1}] for every pair of b x b diagonal sub-blocks.  A thread owns a 2 x 2
+  // block of outputs (half the LDS reads per FMA: the b = 32 level was bound by LDS bandwidth).
+  for (int e = tid; e < 32; e += NT) {                  // b = 1
+    const int r0 = 2 * e;
+    const float t = L[r0 + 1][r0] * Li[r0][r0];
+    Li[r0 + 1][r0] = -(Li[r0 + 1][r0 + 1] * t);
   }
   __syncthreads();
 #pragma unroll
-  for (int b = 1; b < 64; b <<= 1) {
-    // [A 0; C B]^{-1} = [A^{-1} 0; -B^{-1} (C A^{-1}) B^{-1}] for every pair of b x b diagonal sub-blocks
-    for (int e = tid; e < 32 * b; e += NT) {
-      const int pr = e / (b * b), rem = e % (b * b), i = rem / b, j = rem % b;
+  for (int b = 2; b < 64; b <<= 1) {
+    const int hb = b >> 1, nblk = hb * hb;
+    for (int e = tid; e < 8 * b; e += NT) {
+      const int pr = e / nblk, rem = e % nblk, i = 2 * (rem / hb), j = 2 * (rem % hb);
       const int r0 = 2 * b * pr;
-      float s = 0.f;
+      float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
 #pragma unroll 8
-      for (int k = 0; k < b; ++k) s += L[r0 + b + i][r0 + k] * Li[r0 + k][r0 + j];   // (A^{-1} lower triangular: k < j terms are zeros)
-      T[r0 + b + i][r0 + j] = s;
+      for (int k = 0; k < b; ++k) {   // (full range, fixed trip count: the reads pipeline; A^{-1}[k][j] = 0 for k < j adds exact zeros)
+        const float a0 = L[r0 + b + i][r0 + k], a1 = L[r0 + b + i + 1][r0 + k];
+        const float b0 = Li[r0 + k][r0 + j], b1 = Li[r0 + k][r0 + j + 1];
+        s00 += a0 * b0; s01 += a0 * b1; s10 += a1 * b0; s11 += a1 * b1;
+      }
+      T[r0 + b + i][r0 + j] = s00; T[r0 + b + i][r0 + j + 1] = s01;
+      T[r0 + b + i + 1][r0 + j] = s10; T[r0 + b + i + 1][r0 + j + 1] = s11;
     }
     __syncthreads();
-    for (int e = tid; e < 32 * b; e += NT) {
-      const int pr = e / (b * b), rem = e % (b * b), i = rem / b, j = rem % b;
+    for (int e = tid; e < 8 * b; e += NT) {
+      const int pr = e / nblk, rem = e % nblk, i = 2 * (rem / hb), j = 2 * (rem % hb);
       const int r0 = 2 * b * pr;
-      float s = 0.f;
+      float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
 #pragma unroll 8
-      for (int k = 0; k < b; ++k) s += Li[r0 + b + i][r0 + b + k] * T[r0 + b + k][r0 + j];   // (B^{-1} lower triangular: k > i terms are zeros)
-      Li[r0 + b + i][r0 + j] = -s;
+      for (int k = 0; k < b; ++k) {
+        const float a0 = Li[r0 + b + i][r0 + b + k], a1 = Li[r0 + b + i + 1][r0 + b + k];
+        const float b0 = T[r0 + b + k][r0 + j], b1 = T[r0 + b + k][r0 + j + 1];
+        s00 += a0 * b0; s01 += a0 * b1; s10 += a1 * b0; s11 += a1 * b1;
+      }
+      Li[r0 + b + i][r0 + j] = -s00; Li[r0 + b + i][r0 + j + 1] = -s01;
+      Li[r0 + b + i + 1][r0 + j] = -s10; Li[r0 + b + i + 1][r0 + j + 1] = -s11;
     }
     __syncthreads();
   }
@@ -123,7 +149,7 @@ __device__ __forceinline__ void stl_pack_block(int d, const float *C, unsigned *
     for (int e = tid; e < 1024; e += NT) {               // consecutive threads along a column of C (256-byte runs)
       const int ch = e & 15, c = e >> 4, g = ch & 3, u = ch >> 2, q = c >> 4, i = c & 15;
       const float4 v = *(const float4 *)(blk + (size_t)c * d + 4 * ch);
-      *(float4 *)(dst + ((q * 4 + u) * 64 + 16 * g + i) * 4) = v;
+      store16_wt(dst + ((q * 4 + u) * 64 + 16 * g + i) * 4, v);
     }
   }
 }
