@@ -141,8 +141,7 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
         }
       }
       if (!fused) {
-        if (a.knock & 64) *(f32x4 *)(dst + pi) = o;
-        else store16_wt(dst + pi, o);
+        store16_wt(dst + pi, o);
       } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -160,10 +159,10 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
           if (gj == gi + c && a.upd.do_clip) x = clip_step(x, (float)a.upd.clip_eps);
           px[c] = x;
         }
-        *(f32x4 *)((float *)a.upd.params + pi) = px;
+        store16_wt((float *)a.upd.params + pi, px);   // (written through: see store16_wt)
         if (a.upd.rule == 1) {
-          *(f32x4 *)((float *)a.upd.state + pi) = pm;
-          *(f32x4 *)((float *)a.upd.state + plen + pi) = pv;
+          store16_wt((float *)a.upd.state + pi, pm);
+          store16_wt((float *)a.upd.state + plen + pi, pv);
         }
       }
     }
@@ -172,8 +171,7 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
 #pragma unroll
       for (int u = 0; u < NE; ++u) {
         const int e = tid + u * NT, j4 = 4 * (e % (BN / 4)), ii = e / (BN / 4);
-        if (a.knock & 64) *(f32x4 *)(dst + d + (size_t)(row0 + ii) * d + col0 + j4) = z4;
-        else store16_wt(dst + d + (size_t)(row0 + ii) * d + col0 + j4, z4);
+        store16_wt(dst + d + (size_t)(row0 + ii) * d + col0 + j4, z4);
       }
     }
   }
@@ -297,7 +295,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * KW * 64) void k_fr_gemm(Gem
     float e[4];
     eps_block<float>(n.rng.seed, rng_index(n.rng), (uint64_t)(n.rng.m_offset + gm) * (uint64_t)(d >> 2) + (uint64_t)(gi >> 2), e);
     const f32x4 ev = {e[0], e[1], e[2], e[3]};
-    *(f32x4 *)(n.eps + (size_t)gm * n.ld_eps + gi) = ev;
+    store16_wt(n.eps + (size_t)gm * n.ld_eps + gi, ev);
     const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
     const double sh = block_sum<double, NT>((double)he, red);
     if (tid == 0) n.he_part[eb] = sh;
@@ -498,7 +496,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * KW * 64) void k_fr_gemm(Gem
       f32x4 v = *(const f32x4 *)(Cs + n * LDC + i4);
 #pragma unroll
       for (int k2 = 1; k2 < KW; ++k2) v += *(const f32x4 *)(Cs + (k2 * BN + n) * LDC + i4);
-      *(f32x4 *)(dst + n * BM + i4) = v;
+      store16_wt(dst + n * BM + i4, v);
     }
     MIVI_STAMP_K(a.dbg, MODE, 4);
     return;
@@ -1138,10 +1136,10 @@ __global__ __launch_bounds__(256) void k_fr_reduce(ReduceArgs a) {
     f32x4 g = -v;
 #pragma unroll
     for (int c = 0; c < 4; ++c) ell += 0.5f * r[c] * g[c];
-    *(f32x4 *)(a.W + (size_t)gm * d + gi) = g;
+    store16_wt(a.W + (size_t)gm * d + gi, g);
   } else {
     f32x4 z = mu + v;
-    if (a.Z) *(f32x4 *)(a.Z + (size_t)gm * d + gi) = z;
+    if (a.Z) store16_wt(a.Z + (size_t)gm * d + gi, z);
     if (a.mode == R_DIAG) {
       f32x4 wv;
 #pragma unroll
@@ -1150,9 +1148,12 @@ __global__ __launch_bounds__(256) void k_fr_reduce(ReduceArgs a) {
         ell += -0.5f * u * u;
         wv[c] = -u * tis[c];
       }
-      *(f32x4 *)(a.W + (size_t)gm * d + gi) = wv;
+      store16_wt(a.W + (size_t)gm * d + gi, wv);
     } else if (a.mode == R_DENSE_R) {
-      *(f32x4 *)(a.R + (size_t)gm * a.dP + gi) = z - tm;
+      {
+        const f32x4 rz = z - tm;
+        store16_wt(a.R + (size_t)gm * a.dP + gi, rz);
+      }
     }
   }
   MIVI_STAMP_K(a.dbg, 3, 2);
