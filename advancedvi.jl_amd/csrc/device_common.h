@@ -43,6 +43,30 @@ __device__ __forceinline__ T block_sum(T v, T *red) {
   return s;
 }
 
+// Sum N values over the workgroup in ONE pass: the N wave reductions are independent shuffle chains (they pipeline), one LDS
+// exchange, one barrier pair -- instead of N x {6-step shuffle chain, two barriers} one after the other, which is what made the
+// one-workgroup value assembly a 6 us latency chain.  Same tree per value as block_sum (bitwise the same results).
+// `red` holds N * NT / 64 elements.  Results valid in every thread.
+template <typename T, int NT, int N>
+__device__ __forceinline__ void block_sum_n(T (&v)[N], T *red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) red[k * (NT / 64) + w] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    T s = red[k * (NT / 64)];
+#pragma unroll
+    for (int i = 1; i < NT / 64; ++i) s += red[k * (NT / 64) + i];
+    v[k] = s;
+  }
+}
+
 // compile-time loop: f(integral_constant<int, B>) ... f(integral_constant<int, E - 1>) -- indices usable as template arguments
 template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -103,18 +127,18 @@ __device__ __forceinline__ double ld_f64(const double *p) {
   return *p;
 }
 
-// Row 0 and the column-only part of ell of the fused funnel target (see FunnelFin): e1 / eps_0 per column from the eps stream,
-// the A / B partials of the main kernel summed in index order; writes the two gradient (or shard-partial) entries of row 0 and
-// returns this thread's share of sum_m ell_m (kernels_targets.hip k_col_target / oracle FunnelStackedTarget).
+// Row 0 and the column-only part of ell of the fused funnel target (see FunnelFin): e1 / eps_0 per column from the eps stream, the
+// A / B partials of the main kernel in index order.  Per-THREAD shares of sum_m ell_m, sum_m w_0m and sum_m w_0m eps_0m (the
+// caller reduces them together with its other sums and writes the two gradient / shard-partial entries of row 0;
+// kernels_targets.hip k_col_target / oracle FunnelStackedTarget).
 template <typename T, int NT>
-__device__ double funnel_finish(int d, const FunnelFin &f, const OutArgs &out, double *red) {
+__device__ __forceinline__ void funnel_finish(int d, const FunnelFin &f, const OutArgs &out, double &s_ell, double &sW, double &sWe) {
   const int tid = threadIdx.x;
   const T *params = (const T *)f.params;
   const double mu0 = (double)params[0], sg0 = (double)params[d];
   const uint64_t idx = rng_index(f.rng);
   const bool stl = ent_is_stl(out.ent_kind);
   const double n = (double)(d - 1), sv2 = f.sigma_v * f.sigma_v;
-  double s_ell = 0.0, sW = 0.0, sWe = 0.0;
   for (int m = tid; m < f.M; m += NT) {
     T e[4];
     eps_block<T>(f.rng.seed, idx, (uint64_t)(f.rng.m_offset + m) * (uint64_t)f.d4, e);   // row-quad 0 of column m
@@ -129,36 +153,22 @@ __device__ double funnel_finish(int d, const FunnelFin &f, const OutArgs &out, d
     sW += f.ab[i];
     sWe += f.ab[f.n_part + i];
   }
-  sW = block_sum<double, NT>(sW, red);
-  sWe = block_sum<double, NT>(sWe, red);
-  if (tid == 0) {
-    if (out.partials_mode) {
-      T *p = (T *)out.partials;
-      p[0] = (T)sW;
-      p[d] = (T)sWe;
-    } else {
-      T *gr = (T *)out.grad;
-      const double invM = 1.0 / (double)out.M_total;
-      gr[0] = (T)(-sW * invM);
-      gr[d] = (T)(-sWe * invM - direct_entropy_coeff(out.ent_kind) / sg0);
-    }
-  }
-  return s_ell;
 }
 
 // One whole workgroup (NT threads) assembles the objective value (or the two scalar partials).
 //   value = -( sum_ell / M_total + entropy_estimate )
 //   closed-form estimators: d/2 (1 + log 2pi) + sum_i log C_ii            location_scale.jl:52-57
 //   MC / STL estimators   : mean_m 0.5|eps_m|^2 + d/2 log 2pi + sum_i log C_ii   (C^-1 (z_m - mu) == eps_m)
-// `scale_diag(i)` returns C_ii. `red` holds NT/64 doubles.
+// `scale_diag(i)` returns C_ii. `red` holds 6 * NT/64 doubles.
 // FUNNEL: also finish the fused funnel target (funnel_finish).  Only k_value_funnel and the funnel instantiation of k_mf_main
 // carry it: the other kernels never take that path.
 template <typename T, int NT, bool ATOMIC, bool FUNNEL = false, typename DiagFn>
 __device__ void finalize_value_block(int d, const ValueIn &vin, const OutArgs &out, int64_t plen, DiagFn scale_diag,
                                      double *red) {
   const int tid = threadIdx.x;
-  double s_ell = 0.0, s_he = 0.0, s_ld = 0.0, bad = 0.0;
-  if (FUNNEL && vin.fn.ab) s_ell += funnel_finish<T, NT>(d, vin.fn, out, red);
+  double s_ell = 0.0, s_he = 0.0, s_ld = 0.0, bad = 0.0, sW = 0.0, sWe = 0.0;
+  const bool funnel = FUNNEL && vin.fn.ab;
+  if (funnel) funnel_finish<T, NT>(d, vin.fn, out, s_ell, sW, sWe);
   for (int i = tid; i < vin.n_ell_part; i += NT) s_ell += ld_f64<ATOMIC>(vin.ell_part + i);
   for (int i = tid; i < vin.n_ell_part2; i += NT) s_ell += ld_f64<ATOMIC>(vin.ell_part2 + i);
   for (int i = tid; i < vin.n_ell; i += NT) s_ell += (double)((const T *)vin.ell)[i];
@@ -177,10 +187,28 @@ __device__ void finalize_value_block(int d, const ValueIn &vin, const OutArgs &o
       }
     }
   }
-  s_ell = block_sum<double, NT>(s_ell, red);
-  s_he = block_sum<double, NT>(s_he, red);
-  s_ld = block_sum<double, NT>(s_ld, red);
-  bad = block_sum<double, NT>(bad, red);
+  if (FUNNEL) {
+    double v[6] = {s_ell, s_he, s_ld, bad, sW, sWe};
+    block_sum_n<double, NT, 6>(v, red);
+    s_ell = v[0]; s_he = v[1]; s_ld = v[2]; bad = v[3]; sW = v[4]; sWe = v[5];
+    if (funnel && tid == 0) {   // row 0 of the fused funnel target
+      const double sg0 = (double)((const T *)vin.fn.params)[d];
+      if (out.partials_mode) {
+        T *p = (T *)out.partials;
+        p[0] = (T)sW;
+        p[d] = (T)sWe;
+      } else {
+        T *gr = (T *)out.grad;
+        const double invM = 1.0 / (double)out.M_total;
+        gr[0] = (T)(-sW * invM);
+        gr[d] = (T)(-sWe * invM - direct_entropy_coeff(out.ent_kind) / sg0);
+      }
+    }
+  } else {
+    double v[4] = {s_ell, s_he, s_ld, bad};
+    block_sum_n<double, NT, 4>(v, red);
+    s_ell = v[0]; s_he = v[1]; s_ld = v[2]; bad = v[3];
+  }
   if (tid == 0) {
     const double sum_ell = s_ell + (double)out.M_local * vin.ell_const;
     if (out.partials_mode) {

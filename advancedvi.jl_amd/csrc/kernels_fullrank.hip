@@ -517,7 +517,7 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
   __shared__ float rs_lds[NT];
   __shared__ float cii_lds[32];
   __shared__ float adam_cc[2];
-  __shared__ double red[NW];
+  __shared__ double red[4 * NW];   // (finalize_value_block sums four values in one pass)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform
   const int d = a.d, M = a.M;
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma64(FrArgs<double> a) {
   constexpr int NT = NW * 64, NS = NW / 2;
   __shared__ double part[NS][32 * 33];   // part[slot][col * 33 + row]
   __shared__ double rs_lds[NT];
-  __shared__ double red[NW];
+  __shared__ double red[4 * NW];   // (finalize_value_block sums four values in one pass)
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int d = a.d, M = a.M;

@@ -282,7 +282,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * KW * 64) void k_fr_gemm(Gem
   if (MODE == G_VJP && (int)blockIdx.x == a.n_work) {   // objective value of THIS estimate (everything it sums is older)
     const float *pp = a.params;
     finalize_value_block<float, NT, false>(d, a.self_vin, a.self_out, (int64_t)d + (int64_t)d * d,
-                                           [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, red);
+                                           [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, reinterpret_cast<double *>(lds));   // (scratch: the idle staging area)
     return;
   }
   if (MODE == G_SAMPLE && a.n_items > 0 && (int)blockIdx.x >= a.n_items) {
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) {
   if ((int)blockIdx.x == a.n_work) {   // objective value of THIS estimate (everything it sums is older)
     const float *pp = a.params;
     finalize_value_block<float, NT, false>(d, a.self_vin, a.self_out, (int64_t)d + (int64_t)d * d,
-                                           [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, red);
+                                           [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, reinterpret_cast<double *>(lds));   // (scratch: the idle staging area)
     return;
   }
   MIVI_STAMP_K(a.dbg, G_VJP, 0);
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
   if ((int)blockIdx.x == a.n_work) {   // objective value of THIS estimate (everything it sums is older)
     const float *pp = a.params;
     finalize_value_block<float, NT, false>(d, a.self_vin, a.self_out, (int64_t)d + (int64_t)d * d,
-                                           [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, red);
+                                           [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, reinterpret_cast<double *>(lds));   // (scratch: the idle staging area)
     return;
   }
   MIVI_STAMP_K(a.dbg, G_VJP, 0);

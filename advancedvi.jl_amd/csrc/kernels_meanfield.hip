@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
   const int d = a.d, d4 = (d + 3) >> 2;
   if (rq < 0) {   // heterogeneous workgroup: objective value of the PREVIOUS estimate.  Block 0: a one-workgroup latency chain
     if (cc == 0) {   // (partials from memory, block sums) as long as the rest of the kernel, so it has to start first
-      __shared__ double red[4];
+      __shared__ double red[6 * 4];
       const T *sig = a.params + d;
       finalize_value_block<T, 256, false, FN>(d, a.prev_vin, a.prev_out, 2 * (int64_t)d, [sig](int i) { return sig[i]; }, red);
     }

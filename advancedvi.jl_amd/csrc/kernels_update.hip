@@ -216,7 +216,7 @@ void launch_unpack_final(mivi_ctx *c, const void *fin, void *value, void *grad) 
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_value_only(int d, int family, const T *params, ValueIn vin, OutArgs out) {
-  __shared__ double red[4];
+  __shared__ double red[4 * 4];
   const int64_t plen = family == MIVI_MEANFIELD ? 2 * (int64_t)d : (int64_t)d + (int64_t)d * d;
   const int fam = family;
   finalize_value_block<T, 256, false, false>(d, vin, out, plen,
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_value_only(int d, int family, const T *
 // single-workgroup launch costs 4.5 us before it does anything.)
 template <typename T>
 __global__ __launch_bounds__(256) void k_value_funnel(int d, const T *params, ValueIn vin, OutArgs out) {
-  __shared__ double red[4];
+  __shared__ double red[6 * 4];
   finalize_value_block<T, 256, false, true>(d, vin, out, 2 * (int64_t)d, [params, d](int i) { return params[d + i]; }, red);
 }
 void launch_value_only(mivi_ctx *c, const void *params, const ValueIn &vin, const OutArgs &out) {
