@@ -12,22 +12,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // each issuing wave streams `kb_per_wave` KiB in 1 KiB pieces, DEPTH pieces in flight
 template <int DEPTH, bool LDSDMA>
-__global__ __launch_bounds__(512) void k_stream(const float *src, float *out, int waves, int kb_per_wave, size_t wg_stride) {
-  __shared__ __attribute__((aligned(16))) float lds[8 * 16 * 256];
+__global__ __launch_bounds__(1024) void k_stream(const float *src, float *out, int waves, int kb_per_wave, size_t wg_stride) {
+  __shared__ __attribute__((aligned(16))) float lds[16 * 8 * 256];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (w >= waves) return;
   const float *p = src + blockIdx.x * wg_stride + (size_t)w * kb_per_wave * 256 + lane * 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (LDSDMA) {
-    float *ring = lds + w * 16 * 256;
+    float *ring = lds + w * 8 * 256;
 #pragma unroll
-    for (int i = 0; i < DEPTH; ++i) GLDS16(p + i * 256, ring + (i % 16) * 256);
+    for (int i = 0; i < DEPTH; ++i) GLDS16(p + i * 256, ring + (i % 8) * 256);
     for (int i = 0; i < kb_per_wave; ++i) {
       if (i + DEPTH <= kb_per_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH - 1) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      acc += *(const f32x4 *)(ring + (i % 16) * 256 + lane * 4);
+      acc += *(const f32x4 *)(ring + (i % 8) * 256 + lane * 4);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (i + DEPTH < kb_per_wave) GLDS16(p + (size_t)(i + DEPTH) * 256, ring + ((i + DEPTH) % 16) * 256);
+      if (i + DEPTH < kb_per_wave) GLDS16(p + (size_t)(i + DEPTH) * 256, ring + ((i + DEPTH) % 8) * 256);
     }
   } else {
     f32x4 buf[DEPTH];
@@ -72,20 +72,20 @@ int main() {
   hipMemset(buf, 0, total);
   const int KB = 448;
   for (int same = 1; same >= 0; --same) {
-    const size_t stride = same ? 0 : (size_t)KB * 256 * 4;   // floats: own region (spread wide) or the same bytes
-    for (int wgs : {16, 64, 256}) {
+    const size_t stride = same ? 0 : (size_t)KB * 256;   // floats: own region (spread wide) or the same bytes
+    for (int wgs : {256}) {
       if (!same && (size_t)wgs * KB * 1024 > total) continue;   // (own regions must fit the buffer)
-      for (int waves : {2, 4, 8}) {
+      for (int waves : {4, 8, 16}) {
         const int kbw = KB / waves;
         double t;
-        t = time_us([&] { hipLaunchKernelGGL((k_stream<8, false>), dim3(wgs), dim3(512), 0, st, buf, out, waves, kbw, stride); }, st);
+        t = time_us([&] { hipLaunchKernelGGL((k_stream<8, false>), dim3(wgs), dim3(1024), 0, st, buf, out, waves, kbw, stride); }, st);
         printf("%s bytes, %2d WGs, %d waves, plain x8 : %6.2f us  -> %6.1f GB/s per CU\n", same ? "same" : "own ", wgs, waves, t, KB * 1024.0 / t / 1e3);
-        t = time_us([&] { hipLaunchKernelGGL((k_stream<16, false>), dim3(wgs), dim3(512), 0, st, buf, out, waves, kbw, stride); }, st);
+        t = time_us([&] { hipLaunchKernelGGL((k_stream<16, false>), dim3(wgs), dim3(1024), 0, st, buf, out, waves, kbw, stride); }, st);
         printf("%s bytes, %2d WGs, %d waves, plain x16: %6.2f us  -> %6.1f GB/s per CU\n", same ? "same" : "own ", wgs, waves, t, KB * 1024.0 / t / 1e3);
-        t = time_us([&] { hipLaunchKernelGGL((k_stream<8, true>), dim3(wgs), dim3(512), 0, st, buf, out, waves, kbw, stride); }, st);
+        t = time_us([&] { hipLaunchKernelGGL((k_stream<8, true>), dim3(wgs), dim3(1024), 0, st, buf, out, waves, kbw, stride); }, st);
         printf("%s bytes, %2d WGs, %d waves, glds  x8 : %6.2f us  -> %6.1f GB/s per CU\n", same ? "same" : "own ", wgs, waves, t, KB * 1024.0 / t / 1e3);
-        t = time_us([&] { hipLaunchKernelGGL((k_stream<16, true>), dim3(wgs), dim3(512), 0, st, buf, out, waves, kbw, stride); }, st);
-        printf("%s bytes, %2d WGs, %d waves, glds  x16: %6.2f us  -> %6.1f GB/s per CU\n", same ? "same" : "own ", wgs, waves, t, KB * 1024.0 / t / 1e3);
+        t = time_us([&] { hipLaunchKernelGGL((k_stream<8, true>), dim3(wgs), dim3(1024), 0, st, buf, out, waves, kbw, stride); }, st);
+        printf("%s bytes, %2d WGs, %d waves, glds  x8b: %6.2f us  -> %6.1f GB/s per CU\n", same ? "same" : "own ", wgs, waves, t, KB * 1024.0 / t / 1e3);
       }
     }
   }
