@@ -56,6 +56,15 @@ struct GemmArgs {
   SampleArgs<float> next_eps;
   long long *dbg;    // optional timeline (tools/timeline2.py)
   int knock;         // developer knock-outs (MIVI_KNOCK): 1 no loads after the prologue, 2 no MFMAs, 4 no loads at all
+  // Stein mode of k_fr_vjp64 (the whole product eps G^T, A = eps, B = G): see stein_epilogue
+  float *st_A;       // d x d accumulation target, element (i, j) at st_A[j * st_ld + i]
+  int st_ld;
+  double *st_gsum;   // [d] column sums of G (accumulated over chunks)
+  float *st_grad;    // single chunk: grad = gsum / n written directly (else nullptr)
+  float *st_logpi;   // single chunk: mean log-density, by the value workgroup (else nullptr)
+  int st_first;      // first chunk: overwrite instead of accumulate
+  float st_scale;    // 1 / n on the last chunk
+  double st_n;
 };
 
 struct ReduceArgs {
@@ -205,6 +214,39 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
     }
   }
   MIVI_STAMP_K(a.dbg, G_VJP, 4);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// Epilogue of the Stein mode (E_q[hess log pi] estimator, accumulation stage; kernels_fullrank.hip k_stein_outer is the generic
+// version): tile (row0, col0) of eps G^T summed over the KW partial images, A = ((first ? 0 : A) + sum) * scale, rows of eps
+// contiguous in memory.  cs_lds[KW][BN]: partial column sums of G (tiles of the first row block only): gsum (+)= and, with one
+// chunk, grad = gsum / n.
+// -----------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int KW, int NT>
+__device__ __forceinline__ void stein_epilogue(const GemmArgs &a, const float *Cs, const float *cs_lds, bool col_tile, int row0, int col0) {
+  constexpr int LDC = BM + 4;
+  constexpr int NE = BM * BN / 4 / NT;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const int e = tid + u * NT, i4 = 4 * (e % (BM / 4)), n = e / (BM / 4);
+    float *dst = a.st_A + (size_t)(col0 + n) * a.st_ld + row0 + i4;
+    f32x4 old = {0.f, 0.f, 0.f, 0.f};
+    if (!a.st_first) old = *(const f32x4 *)dst;
+    f32x4 v = *(const f32x4 *)(Cs + n * LDC + i4);
+#pragma unroll
+    for (int k2 = 1; k2 < KW; ++k2) v += *(const f32x4 *)(Cs + (k2 * BN + n) * LDC + i4);
+    const f32x4 o = (old + v) * a.st_scale;
+    store16_wt(dst, o);
+  }
+  if (col_tile && tid < BN) {
+    double sm = 0.0;
+#pragma unroll
+    for (int g = 0; g < KW; ++g) sm += (double)cs_lds[g * BN + tid];
+    if (!a.st_first) sm += a.st_gsum[col0 + tid];
+    a.st_gsum[col0 + tid] = sm;
+    if (a.st_grad) a.st_grad[col0 + tid] = (float)(sm / a.st_n);
+  }
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -680,7 +722,7 @@ __global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) {
 //   (6.0 vs 7.4 us) although its most loaded CUs carry 192 KiB against 128 KiB here -- see launch_lds_vjp.
 // Epilogue: vjp_epilogue<64, 64, 8, 512> (the eight partial tiles summed in wave order through LDS).
 // -----------------------------------------------------------------------------------------------------------------
-template <bool FUSED, bool BF3>
+template <bool FUSED, bool BF3, bool STEIN = false>
 __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
   constexpr int BM = 64, BN = 64, KW = 8, NT = 512, SUB = 32;
   constexpr int LDC = BM + 4;
@@ -704,6 +746,8 @@ __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
     const float *pp = a.params;
     finalize_value_block<float, NT, false>(d, a.self_vin, a.self_out, (int64_t)d + (int64_t)d * d,
                                            [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, reinterpret_cast<double *>(lds));   // (scratch: the idle staging area)
+    if (STEIN && a.st_logpi && tid == 0)   // (partials mode: thread 0 just wrote sum_m ell_m)
+      *a.st_logpi = (float)((double)((const float *)a.self_out.partials)[a.self_out.scalars_off] / a.st_n);
     return;
   }
   MIVI_STAMP_K(a.dbg, G_VJP, 0);
@@ -712,7 +756,8 @@ __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
   asm volatile("" ::"s"(wk.x), "s"(wk.y), "s"(wk.z), "s"(wk.w));
   const int rb = wk.x & 0xffff, cb = wk.x >> 16;
   const int row0 = rb * BM, col0 = cb * BN;
-  const bool mu_tile = (wk.w & 2);
+  const bool mu_tile = !STEIN && (wk.w & 2);
+  const bool col_tile = STEIN && rb == 0;   // column sums of the B operand (G)
   const int nsub = a.M / SUB;
   const int t_beg = (w * nsub) / KW, t_end = ((w + 1) * nsub) / KW;   // this wave's run of sub-stages
   if (a.dbg && tid == 0 && blockIdx.x < 4096) a.dbg[((size_t)G_VJP * 4096 + blockIdx.x) * 8 + 7] = wk.x;
@@ -743,7 +788,7 @@ __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float rsum[2] = {0.f, 0.f};
+  float rsum[2] = {0.f, 0.f};   // row sums of A (d/dmu tiles) / column sums of B (Stein mode)
   __builtin_amdgcn_s_setprio(3);
   if (t_beg < t_end && !(a.knock & 4)) issue(t_beg);
   __builtin_amdgcn_s_setprio(0);
@@ -765,6 +810,10 @@ __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
     if (mu_tile) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) { rsum[0] += av[0][i]; rsum[1] += av[1][i]; }
+    }
+    if (col_tile) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { rsum[0] += bv[0][i]; rsum[1] += bv[1][i]; }
     }
     if (!(a.knock & 2)) {
       if (BF3) {
@@ -814,7 +863,7 @@ __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
         *(f32x4 *)(Cs + (w * BN + 32 * j + l31) * LDC + 32 * i + 8 * q + 4 * h) = v;
       }
   float *rs_lds = lds + KW * BN * LDC;   // [NT/BM = 8 waves][BM]
-  if (mu_tile) {
+  if (mu_tile || col_tile) {
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
       const float o = rsum[x] + __shfl_xor(rsum[x], 32, 64);   // the two k halves of the wave
@@ -824,7 +873,8 @@ __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
   lds_barrier();
   MIVI_STAMP_K(a.dbg, G_VJP, 3);
   if (a.knock & 32) return;
-  vjp_epilogue<BM, BN, KW, NT, FUSED>(a, Cs, rs_lds, adam_cc, wk, row0, col0);
+  if (STEIN) stein_epilogue<BM, BN, KW, NT>(a, Cs, rs_lds, col_tile, row0, col0);
+  else vjp_epilogue<BM, BN, KW, NT, FUSED>(a, Cs, rs_lds, adam_cc, wk, row0, col0);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -1332,6 +1382,9 @@ bool lds_path_shape_ok(const mivi_ctx *c, int M) {
          c->cfg.d <= 65535 * 32 && M > 0;
 }
 
+static bool f32_mfma();
+static int knock_flags();
+
 // (re)build the work lists for M samples per launch; allocates the slab buffer
 bool lds_prepare(mivi_ctx *c, int M) {
   const bool dense = c->target == TGT_DENSE_GAUSS;
@@ -1357,6 +1410,53 @@ bool lds_prepare(mivi_ctx *c, int M) {
   c->lds_M = M;
   c->lds_dense = dense;
   return true;
+}
+
+// Stein accumulation stage on the second-generation kernels: A (+)= eps G^T (all of it), gsum (+)= G 1, one 64 x 64 tile per workgroup
+// (k_fr_vjp64<.., STEIN>); self: the chunk's value partials are assembled by one more workgroup of the same launch.
+bool lds_stein_ok(const mivi_ctx *c, int M) {
+  static const bool off = getenv("MIVI_STEIN_GEN1") != nullptr;   // A/B: the first-generation kernel
+  return !off && lds_path_shape_ok(c, M) && !f32_mfma();   // (d is a multiple of 64: the padded leading dimension dP equals d)
+}
+void launch_lds_stein_outer(mivi_ctx *c, int M, void *A, double *gsum, int first, double scale, double n, void *grad, void *logpi,
+                            const ValueJob *self) {
+  const int d = c->cfg.d, nb = d / 64;
+  if (c->lds_st_d != d) {   // full square of 64 x 64 tiles; 4 x 4 super-blocks (256 x 256 elements: one XCD's L2 holds their operands)
+    std::vector<std::vector<Item>> lists(8);
+    int sbi = 0;
+    for (int sr = 0; sr * 4 < nb; ++sr)
+      for (int sc = 0; sc * 4 < nb; ++sc, ++sbi)
+        for (int rb = sr * 4; rb < sr * 4 + 4 && rb < nb; ++rb)
+          for (int cb = sc * 4; cb < sc * 4 + 4 && cb < nb; ++cb) lists[sbi % 8].push_back(Item{rb, cb, 0, 0, 0, 0, 1});
+    auto items = interleave8(lists);
+    auto packed = pack(items);
+    upload(c, c->lds_tabSt, packed.data(), packed.size() * sizeof(int4));
+    c->lds_nSt = (int)items.size();
+    c->lds_st_d = d;
+  }
+  GemmArgs a{};
+  a.d = d; a.M = M; a.dP = c->dP;
+  a.A = (const float *)c->eps[c->cur].p; a.lda = c->dP;   // rows of the product: eps coordinates
+  a.B = (const float *)c->W.p; a.ldb = d;                  // columns: the target's gradient coordinates
+  a.work = (const int4 *)c->lds_tabSt.p;
+  a.n_work = 0x7fffffff;
+  a.dbg = c->dbg;
+  a.knock = knock_flags();
+  a.st_A = (float *)A; a.st_ld = c->dP;
+  a.st_gsum = gsum;
+  a.st_grad = (float *)grad;
+  a.st_logpi = (float *)logpi;
+  a.st_first = first;
+  a.st_scale = (float)scale;
+  a.st_n = n;
+  int grid = c->lds_nSt;
+  if (self) {
+    a.n_work = grid;
+    a.self_vin = self->vin;
+    a.self_out = self->out;
+    grid += 1;
+  }
+  hipLaunchKernelGGL((k_fr_vjp64<false, true, true>), dim3(grid), dim3(512), 0, c->stream, a);
 }
 
 int lds_reduce_blocks(const mivi_ctx *c, int M) { return (c->cfg.d / 64) * (M / 64) * 4; }

@@ -160,7 +160,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_S, &c->dist_F, &c->lds_tabS, &c->lds_tilesS, &c->lds_tabD, &c->lds_tilesD, &c->lds_tabV, &c->lds_tabV64, &c->lds_slab, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_S, &c->dist_F, &c->lds_tabS, &c->lds_tilesS, &c->lds_tabD, &c->lds_tilesD, &c->lds_tabV, &c->lds_tabV64, &c->lds_tabSt, &c->lds_slab, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -479,7 +479,7 @@ static mivi_status_t run_estimate_lds(mivi_ctx *c, const void *params, const Rng
   vin.ell_const = c->t_const;
   const bool grad_stage = want_grad && !stop_after_target;
   const bool chained = ch && ch->on && grad_stage && !out.partials_mode;
-  const bool spec = !chained && grad_stage;
+  const bool spec = !chained && want_grad;   // (also the Stein estimator's calls: stop_after_target)
   bool hit = false;
   int capturing = 0;
   unsigned long long cap_id = 0;
@@ -560,7 +560,20 @@ static mivi_status_t run_estimate_lds(mivi_ctx *c, const void *params, const Rng
     HIPCHK(c, hipGetLastError());
     return MIVI_OK;
   }
-  launch_value_only(c, params, vin, out);
+  if (spec) {
+    c->pre_valid = true;
+    c->pre_rng = nx.rng;
+    c->pre_M = M;
+    c->pre_parity = p ^ 1;
+    c->pre_capturing = capturing;
+    c->pre_capture_id = cap_id;
+  }
+  if (c->defer_value) {   // (Stein estimator: its accumulation kernel assembles the value partials in one of its own workgroups)
+    *c->defer_value = ValueJob{vin, out};
+    c->value_deferred = true;
+  } else {
+    launch_value_only(c, params, vin, out);
+  }
   HIPCHK(c, hipGetLastError());
   return MIVI_OK;
 }
@@ -1082,7 +1095,7 @@ mivi_status_t mivi_gauss_expected_grad_hess(mivi_ctx_t *c, const void *params, u
   if (stl2 && ((s = ensure(c, c->stl_X, (size_t)d * d * es + 4096, false)) || (s = ensure(c, c->stl_F, mivi::stl_pack_units(d) * 4, false)))) return s;
   const int CH = 16384;
   const bool single_chunk = n_samples <= CH;
-  bool pack_done = false;
+  bool pack_done = false, tail_done = false;
   char *part = (char *)c->tmp_out.p;   // [sum ell, sum 0.5 eps^2] of a chunk
   for (int off = 0, first = 1; off < n_samples; off += CH, first = 0) {
     const int Mc = n_samples - off < CH ? n_samples - off : CH;
@@ -1096,9 +1109,18 @@ mivi_status_t mivi_gauss_expected_grad_hess(mivi_ctx_t *c, const void *params, u
     r.m_offset += off;
     c->want_stl_pack = stl2 && first;   // the solve's parameter-only preparation rides in the first chunk's sampling kernel
     c->stl_pack_done = false;
+    // second-generation accumulation kernel (f32, d and chunk multiples of 64 / 128): with ONE chunk it also assembles the chunk's
+    // value partials (no k_value_only launch) and writes grad / logpi_avg itself (no finishing launch)
+    const bool st2 = c->cfg.dtype == MIVI_F32 && lds_stein_ok(c, Mc);
+    ValueJob vj{};
+    c->value_deferred = false;
+    c->defer_value = (st2 && single_chunk) ? &vj : nullptr;
     s = run_estimate(c, params, r, Mc, 1, o, nullptr, nullptr, true);
+    c->defer_value = nullptr;
     c->want_stl_pack = false;
     if (s) return s;
+    const bool fused_tail = c->value_deferred;
+    c->value_deferred = false;
     if (first) pack_done = c->stl_pack_done;
     if (single_chunk) {
       // (its partial is read by the finishing kernel directly: no accumulation launch)
@@ -1107,9 +1129,17 @@ mivi_status_t mivi_gauss_expected_grad_hess(mivi_ctx_t *c, const void *params, u
     else
       hipLaunchKernelGGL(k_acc_value_f64, dim3(1), dim3(1), 0, c->stream, (double *)c->acc.p, (const double *)part, 1.0, first);
     const bool last = off + CH >= n_samples;
-    launch_stein_outer(c, Mc, c->stein_A.p, (double *)c->stein_g.p, first, last ? 1.0 / (double)n_samples : 1.0);
+    const double scale = last ? 1.0 / (double)n_samples : 1.0;
+    if (st2) {
+      launch_lds_stein_outer(c, Mc, c->stein_A.p, (double *)c->stein_g.p, first, scale, (double)n_samples, fused_tail ? grad : nullptr,
+                             fused_tail ? logpi_avg : nullptr, fused_tail ? &vj : nullptr);
+      tail_done = fused_tail;
+    } else {
+      launch_stein_outer(c, Mc, c->stein_A.p, (double *)c->stein_g.p, first, scale);
+    }
   }
-  launch_stein_finish(c, (double)n_samples, (const double *)c->stein_g.p, (const double *)c->acc.p, single_chunk ? part : nullptr, grad, logpi_avg);
+  if (!tail_done)
+    launch_stein_finish(c, (double)n_samples, (const double *)c->stein_g.p, (const double *)c->acc.p, single_chunk ? part : nullptr, grad, logpi_avg);
   if (stl2) {
     launch_stl2(c, params, d, pack_done, c->stein_A.p, hess, true);   // hess = C^-T (eps G^T / n), written (not added)
   } else {

@@ -262,6 +262,10 @@ struct mivi_ctx {
   mivi::DevBuf lds_tabS, lds_tilesS, lds_tabD, lds_tilesD, lds_tabV, lds_tabV64, lds_slab;
   int lds_nS = 0, lds_nD = 0, lds_nV = 0, lds_nV64 = 0, lds_M = -1, lds_zero_slab = 0;
   bool lds_dense = false;
+  mivi::DevBuf lds_tabSt;            // Stein accumulation stage: the full square of 64 x 64 tiles
+  int lds_nSt = 0, lds_st_d = -1;
+  mivi::ValueJob *defer_value = nullptr;   // non-null: run_estimate_lds(stop_after_target) hands its value job over instead of launching it
+  bool value_deferred = false;
   int he_n[2] = {0, 0};            // number of sum-0.5-eps^2 partials behind he_part[parity] (depends on who drew eps)
   int nA = 0, nB = 0, nD = 0, tab_M = -1;
   int cur = 0;
@@ -329,6 +333,9 @@ bool lds_use_prod32(const mivi_ctx *c, int M);
 bool lds_bf16x3();   // products on the bf16 matrix cores (three-way exact operand split); MIVI_FR_F32MFMA=1 turns it off
 void launch_lds_reduce(mivi_ctx *c, const void *params, int M, int mode, void *Z, bool want_ld);
 void launch_lds_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const ValueJob *self, const FusedUpdate *upd);
+bool lds_stein_ok(const mivi_ctx *c, int M);
+void launch_lds_stein_outer(mivi_ctx *c, int M, void *A, double *gsum, int first, double scale, double n, void *grad, void *logpi,
+                            const ValueJob *self);
 void invalidate_graph(mivi_ctx *c);            // mivi_api.hip: drop the cached hipGraphExec and the eps speculation
 
 // kernels_stl.hip (f32, d in {256, 512, 1024, 2048}, M % 32 == 0)

@@ -115,6 +115,40 @@ def test_north_star_size():
     run_case(512, 128, "dense", np.float64)
 
 
+@pytest.mark.parametrize("d,M,kind", [(256, 128, "diag"), (512, 256, "dense"), (1024, 128, "diag"), (2048, 256, "diag")])
+def test_second_generation_accumulation_kernel(d, M, kind):
+    """f32, d a multiple of 64, n a multiple of 128: eps G^T on 64 x 64 bf16x3 tiles (k_fr_vjp64<STEIN>); the same launch assembles
+    the value partials and writes grad / logpi_avg."""
+    run_case(d, M, kind, np.float32)
+
+
+def test_second_generation_kernel_accumulates_chunks():
+    """two chunks of 16384 columns through the second-generation kernel (first: overwrite, then accumulate; 1/n on the last)."""
+    run_case(64, 128, "diag", np.float32, n_samples=2 * 16384)
+
+
+def test_consecutive_calls_use_the_speculated_eps():
+    """call idx, idx + 1, ...: the sampling kernel of call idx draws eps(idx + 1) on the side; results equal a fresh context's."""
+    d, M = 256, 128
+    rng = np.random.default_rng(11)
+    q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
+    prob, _ = make_problem(rng, "diag", d, np.float32)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+    ctx.set_problem(prob)
+    seq = [[t.clone() for t in ctx.gauss_expected_grad_hess(params, i)] for i in (4, 5, 6)]
+    ctx.estimate_gradient(params, 8)                       # an ELBO estimate speculates eps(9) as well
+    seq.append([t.clone() for t in ctx.gauss_expected_grad_hess(params, 9)])
+    ctx.close()
+    for i, got in zip((4, 5, 6, 9), seq):
+        fresh = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+        fresh.set_problem(prob)
+        ref = fresh.gauss_expected_grad_hess(params, i)
+        for x, y in zip(got, ref):
+            assert (x == y).all(), i
+        fresh.close()
+
+
 def test_beyond_the_mfma_solve():
     """d > 2304 (f32): the blocked MFMA solve no longer fits LDS; the column-block fallback takes over."""
     run_case(2400, 8, "diag", np.float32)
