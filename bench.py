@@ -505,6 +505,24 @@ def main():
                                     launch="hipGraph x100" if graphable else "eager", roofline=roof2)
                     cx.close()
                     del prob2, q2
+                # the Stein / Price estimator of E_q[grad], E_q[hess] on the north-star shape (gaussian_expectation_gradient_and_hessian!,
+                # src/algorithms/gauss_expected_grad_hess.jl:32-60): the ELBO path's sampling + target kernels, eps G^T, one C^-T solve
+                # with d right-hand sides; eager calls with consecutive indices, device-resident outputs
+                g_s, H_s = ctx.empty(w["d"]), ctx.empty(w["d"] * w["d"])
+                for i in range(20):
+                    ctx.gauss_expected_grad_hess(params, 50_000 + i, 0, g_s, H_s)
+                stream.synchronize()
+                n_st = 300
+                t0s = time.perf_counter()
+                for i in range(n_st):
+                    ctx.gauss_expected_grad_hess(params, 50_020 + i, 0, g_s, H_s)
+                stream.synchronize()
+                t_st = (time.perf_counter() - t0s) / n_st
+                also["stein"] = dict(workload=f"mivi_gauss_expected_grad_hess, d={w['d']} full-rank, n={w['n_mc']}, the north-star target",
+                                     us_per_call=t_st * 1e6, calls=n_st, launch="eager, consecutive indices",
+                                     f32_mfma_TFs=(2.0 * w["d"] * w["d"] * w["n_mc"] * 1.5 + 2.0 * w["d"] ** 3 / 2) / t_st / 1e12,
+                                     note="flops: triangular product + eps G^T (d^2 n each, the first half-counted) + the d-column solve (d^3 / 2 MACs)")
+                del g_s, H_s
             # ---- parity + cpu_baseline leg (rank 0, N = 1 only) ---------------------------------------------
             rel = None
             cpub = None
