@@ -43,6 +43,23 @@ __device__ __forceinline__ T block_sum(T v, T *red) {
   return s;
 }
 
+// block_sum with barriers that order LDS traffic only (lds_barrier): the caller's outstanding global stores are NOT drained.  For
+// sums taken right behind write-through stores (their acknowledge is ~1.5 us: a __syncthreads() there puts that wait in front
+// of whatever the workgroup does next -- a rider, its exit).  Same tree: bitwise the same result as block_sum.
+__device__ __forceinline__ void lds_barrier();
+template <typename T, int NT>
+__device__ __forceinline__ T block_sum_nodrain(T v, T *red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  v = wave_sum(v);
+  lds_barrier();
+  if (lane == 0) red[w] = v;
+  lds_barrier();
+  T s = red[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) s += red[i];
+  return s;
+}
+
 // Sum N values over the workgroup in ONE pass: the N wave reductions are independent shuffle chains (they pipeline), one LDS
 // exchange, one barrier pair -- instead of N x {6-step shuffle chain, two barriers} one after the other, which is what made the
 // one-workgroup value assembly a 6 us latency chain.  Same tree per value as block_sum (bitwise the same results).

@@ -936,7 +936,8 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
   const int bid = trailing ? (int)blockIdx.x : ((int)blockIdx.x < a.n_dinv ? a.n_tiles - 1 - (int)blockIdx.x : (int)blockIdx.x - a.n_dinv);
   if (!trailing && (int)blockIdx.x < a.n_dinv) {
     stl_dinv64_block<NT>(d, a.A, a.stl_pack, (int)blockIdx.x, lds);
-    __syncthreads();
+    lds_barrier();   // (LDS reuse only: the inverse's write-through stores drain behind the tile)
+    MIVI_STAMP_K(a.dbg, MODE, 6);
   }
   // Riders (work that is off this kernel's critical path): the re-lay of the STL operands (n_pack blocks), then eps(t+1)
   // (n_eps blocks).  Rider r hitches onto the (n_dinv + r)-th lightest tile's workgroup AFTER that tile's epilogue: the light
@@ -955,7 +956,7 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
     const f32x4 ev = {e[0], e[1], e[2], e[3]};
     store16_wt(n.eps + (size_t)gm * n.ld_eps + gi, ev);   // (written through: see store16_wt)
     const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
-    const double sh = block_sum<double, NT>((double)he, red);
+    const double sh = block_sum_nodrain<double, NT>((double)he, red);
     if (tid == 0) n.he_part[eb] = sh;
   };
   if (trailing) {   // riders beyond the tile count
@@ -1099,7 +1100,7 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
     }
   }
   if (a.mode == R_DIAG || a.mode == R_DENSE_G) {
-    const double sl = block_sum<double, NT>((double)ell, red);
+    const double sl = block_sum_nodrain<double, NT>((double)ell, red);
     if (tid == 0) a.ell_part[bid] = sl;
   }
   if (ld_blk) {   // log|det C| partial of this 32-row block (lanes 0..31 of wave 0)
@@ -1118,8 +1119,9 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
   {
     const int r = a.n_tiles - 1 - bid - a.n_dinv;   // this tile's rider, if any (the n_dinv lightest tiles carried an inversion)
     if (r >= 0 && r < a.n_pack + a.n_eps) {
-      __syncthreads();                   // (the riders reuse `red` / LDS)
+      lds_barrier();                     // (the riders reuse `red` / LDS; no drain of this tile's stores: see block_sum_nodrain)
       rider(r);
+      MIVI_STAMP_K(a.dbg, MODE, 5);
     }
   }
 }
