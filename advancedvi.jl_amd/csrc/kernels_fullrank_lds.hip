@@ -956,7 +956,7 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
     const f32x4 ev = {e[0], e[1], e[2], e[3]};
     store16_wt(n.eps + (size_t)gm * n.ld_eps + gi, ev);   // (written through: see store16_wt)
     const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
-    const double sh = block_sum_nodrain<double, NT>((double)he, red);
+    const double sh = block_sum_nodrain_f32<NT>(he, red);
     if (tid == 0) n.he_part[eb] = sh;
   };
   if (trailing) {   // riders beyond the tile count
@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
     }
   }
   if (a.mode == R_DIAG || a.mode == R_DENSE_G) {
-    const double sl = block_sum_nodrain<double, NT>((double)ell, red);
+    const double sl = block_sum_nodrain_f32<NT>(ell, red);
     if (tid == 0) a.ell_part[bid] = sl;
   }
   if (ld_blk) {   // log|det C| partial of this 32-row block (lanes 0..31 of wave 0)
