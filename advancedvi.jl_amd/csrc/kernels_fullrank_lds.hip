@@ -339,7 +339,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * KW * 64) void k_fr_gemm(Gem
     const f32x4 ev = {e[0], e[1], e[2], e[3]};
     store16_wt(n.eps + (size_t)gm * n.ld_eps + gi, ev);
     const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
-    const double sh = block_sum<double, NT>((double)he, red);
+    const double sh = block_sum_nodrain_f32<NT>(he, red);   // (behind write-through stores: see block_sum_nodrain)
     if (tid == 0) n.he_part[eb] = sh;
     return;
   }
@@ -1127,6 +1127,217 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// k_fr_prod64: the unsplit product on 64 x 64 tiles for the LARGE shapes (more tiles than CUs): Z = mu + tril(C) eps (G_SAMPLE) or
+// G = -P (Z - m) (G_DENSE) with the target fused into the epilogue, the structure of k_fr_vjp64 -- eight waves split the tile's k
+// range into contiguous runs of 32-k sub-stages, every wave stages its OWN 64 rows of A ([k][64 rows], the VJP kernel's image) and
+// 64 columns of B (k-major source: [column][32 k] with the 16-byte chunks XOR-swizzled, k_fr_prod32's image), 16 KiB per wave, holds
+// the tile's four 32 x 32 accumulators and splits every operand element into bf16 pieces once for two MFMA tiles; no workgroup
+// barrier before the epilogue, no partial slabs, no reduce kernel (k_fr_gemm + k_fr_reduce: 87 TF f32-equivalent at 8192 x 2048
+// against the 152 TF of the VJP kernel with this structure).  Tiles heaviest first (K = 64 (rb + 1) for the triangular product).
+// Trailing workgroups draw eps of the next estimate.
+// -----------------------------------------------------------------------------------------------------------------
+template <int MODE, bool BF3>
+__global__ __launch_bounds__(512) void k_fr_prod64(Prod32Args a) {
+  constexpr int BM = 64, BN = 64, KW = 8, NT = 512, SUB = 32;
+  constexpr int LDC = BM + 4;
+  constexpr int WAVE_F = 2 * SUB * 64;                      // floats per wave: As[32 k][64 rows] + Bs[64 cols][32 k]
+  constexpr int EPI = KW * BN * LDC;
+  constexpr int MAIN = EPI > KW * WAVE_F ? EPI : KW * WAVE_F;
+  __shared__ __attribute__((aligned(16))) float lds[MAIN + 2 * KW];
+  double *red = reinterpret_cast<double *>(lds + MAIN);
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int d = a.d;
+  if ((int)blockIdx.x >= a.n_tiles) {   // eps(t+1): one Philox block per thread (rows gi..gi+3 of column gm), the k_eps stream
+    const SampleArgs<float> &n = a.next_eps;
+    const int eb = (int)blockIdx.x - a.n_tiles, nrb6 = d >> 6;
+    const int gi = (eb % nrb6) * 64 + 4 * (tid & 15), gm = (eb / nrb6) * 32 + (tid >> 4);
+    float e[4];
+    eps_block<float>(n.rng.seed, rng_index(n.rng), (uint64_t)(n.rng.m_offset + gm) * (uint64_t)(d >> 2) + (uint64_t)(gi >> 2), e);
+    const f32x4 ev = {e[0], e[1], e[2], e[3]};
+    store16_wt(n.eps + (size_t)gm * n.ld_eps + gi, ev);
+    const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
+    const double sh = block_sum_nodrain_f32<NT>(he, red);
+    if (tid == 0) n.he_part[eb] = sh;
+    return;
+  }
+  const int bid = blockIdx.x;
+  const int nrb = d >> 6;
+  int rb, cb;   // block -> tile: heavy row blocks first; XCD x = b % 8 = (x & 3, x >> 2) owns row class rb % 4 and column class cb % 2
+  if ((nrb & 3) == 0 && (a.ncb & 1) == 0) {
+    const int x = bid & 7, j = bid >> 3, hc = a.ncb >> 1;
+    rb = nrb - 1 - (4 * (j / hc) + (x & 3));
+    cb = 2 * (j % hc) + (x >> 2);
+  } else {
+    rb = nrb - 1 - bid / a.ncb;
+    cb = bid % a.ncb;
+  }
+  const int row0 = rb * BM, col0 = cb * BN;
+  const int nst = (MODE == G_SAMPLE) ? 2 * (rb + 1) : (d >> 5);     // 32-k sub-stages of this tile
+  const int t_beg = (w * nst) / KW, t_end = ((w + 1) * nst) / KW;   // this wave's run
+
+  // A piece = 8 k of 32 rows (lane -> k = lane / 8, rows 4 (lane % 8) ..), kept as [8 k][32] blocks (kq, rh) like k_fr_vjp64;
+  // B piece = 8 columns x 32 k (lane -> column lane / 8, 16-byte chunk (lane % 8) ^ swizzle(column) of its 128 contiguous bytes)
+  float *buf = lds + w * WAVE_F;
+  const float *Ag = a.A + row0 + 4 * (lane & 7) + (size_t)(lane >> 3) * a.lda;
+  const float *Bg[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int n = 8 * p + (lane >> 3);
+    Bg[p] = a.B + (size_t)(col0 + n) * a.dP + 4 * ((lane & 7) ^ ((n >> 1) & 7));
+  }
+  auto issue = [&](int t) {
+    const float *pa = Ag + (size_t)(t * SUB) * a.lda;
+#pragma unroll
+    for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+      for (int rh = 0; rh < 2; ++rh) MIVI_GLDS16(pa + (size_t)(8 * kq) * a.lda + 32 * rh, buf + (kq * 2 + rh) * 256);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) MIVI_GLDS16(Bg[p] + t * SUB, buf + SUB * 64 + p * 256);
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // epilogue operands that do not depend on the product: requested now
+  const int ei4 = 4 * (tid & 15), en = tid >> 4;   // rows ei4..+3 of columns en and en + 32
+  const int gi = row0 + ei4;
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, tm = mu, tis = mu, rr[2] = {mu, mu};
+  float cii = 1.f;
+  const bool ld_blk = a.ld_part && cb == 0 && tid < 64;
+  if (a.mode == R_DENSE_G) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) rr[u] = *(const f32x4 *)(a.B + (size_t)(col0 + en + 32 * u) * a.dP + gi);
+  } else {
+    mu = *(const f32x4 *)(a.params + gi);
+    if (a.mode == R_DIAG || a.mode == R_DENSE_R) tm = *(const f32x4 *)(a.t_mean + gi);
+    if (a.mode == R_DIAG) tis = *(const f32x4 *)(a.t_istd + gi);
+  }
+  if (ld_blk) cii = a.params[d + (size_t)(row0 + tid) * d + row0 + tid];
+  __builtin_amdgcn_s_setprio(3);
+  if (t_beg < t_end) issue(t_beg);
+  __builtin_amdgcn_s_setprio(0);
+  for (int t = t_beg; t < t_end; ++t) {
+    wait_vmcnt<0>();
+    float av[2][16], bv[2][16];
+#pragma unroll
+    for (int s8 = 0; s8 < 4; ++s8) {   // MFMA step (s8, jj) uses k = 8 s8 + 4 h + jj on both operands
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int n = 32 * x + l31;
+        const f32x4 bq = *(const f32x4 *)(buf + SUB * 64 + n * 32 + 4 * ((2 * s8 + h) ^ ((n >> 1) & 7)));
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          bv[x][4 * s8 + jj] = bq[jj];
+          av[x][4 * s8 + jj] = buf[((s8 * 2 + x) * 8 + 4 * h + jj) * 32 + l31];
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer is free again before it is requested anew
+    if (t + 1 < t_end) issue(t + 1);
+    if (MODE == G_SAMPLE && t >= 2 * rb) {   // the diagonal block of tril(C): keep k <= i
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (32 * t + 8 * (i >> 2) + 4 * h + (i & 3) > row0 + 32 * x + l31) av[x][i] = 0.f;
+    }
+    if (BF3) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {   // two K = 16 groups per sub-stage; every operand half is split ONCE for its two tiles
+        bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          split3_bf16(av[x] + 8 * g, ah[x], am[x], al[x]);
+          split3_bf16(bv[x] + 8 * g, bh[x], bm[x], bl[x]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            f32x16 c = acc[i][j];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm[j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], c, 0, 0, 0);
+            acc[i][j] = c;
+          }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+    }
+  }
+  __builtin_amdgcn_s_barrier();   // every wave is done with its buffer: LDS becomes the epilogue image
+  float *Cs = lds;   // Cs[kw][n (64 columns)][LDC]: rows of the tile contiguous
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        *(f32x4 *)(Cs + (w * BN + 32 * j + l31) * LDC + 32 * i + 8 * q + 4 * h) = v;
+      }
+  lds_barrier();
+  float ell = 0.f;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int n = en + 32 * u, gm = col0 + n;
+    f32x4 v = *(const f32x4 *)(Cs + n * LDC + ei4);
+#pragma unroll
+    for (int k2 = 1; k2 < KW; ++k2) v += *(const f32x4 *)(Cs + (k2 * BN + n) * LDC + ei4);   // fixed order
+    if (a.mode == R_DENSE_G) {
+      const f32x4 g = -v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) ell += 0.5f * rr[u][c] * g[c];
+      store16_wt(a.W + (size_t)gm * d + gi, g);
+    } else {
+      const f32x4 z = mu + v;
+      if (a.Z) store16_wt(a.Z + (size_t)gm * d + gi, z);
+      if (a.mode == R_DIAG) {
+        f32x4 wv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float uu = (z[c] - tm[c]) * tis[c];
+          ell += -0.5f * uu * uu;
+          wv[c] = -uu * tis[c];
+        }
+        store16_wt(a.W + (size_t)gm * d + gi, wv);
+      } else if (a.mode == R_DENSE_R) {
+        const f32x4 rz = z - tm;
+        store16_wt(a.R + (size_t)gm * a.dP + gi, rz);
+      }
+    }
+  }
+  if (a.mode == R_DIAG || a.mode == R_DENSE_G) {
+    const double sl = block_sum_nodrain_f32<NT>(ell, red);
+    if (tid == 0) a.ell_part[bid] = sl;
+  }
+  if (ld_blk) {   // log|det C| partial of this 64-row block (wave 0)
+    float lg = logf(cii), bad = (cii > 0.f) ? 0.f : 1.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      lg += __shfl_xor(lg, o, 64);
+      bad += __shfl_xor(bad, o, 64);
+    }
+    if (tid == 0) {
+      a.ld_part[rb] = (double)lg;
+      a.ld_part[nrb + rb] = (double)bad;
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // k_fr_reduce: deterministic split-K reduction on the kernel boundary + everything elementwise that follows it.
 //   workgroup = 64 rows x 16 sample columns of one 64x64 macro-tile, thread = 4 rows of one column.
 //   R_DIAG   : z = mu + sum slabs; u = (z - m) / s; ell -= u^2 / 2; W = -u / s
@@ -1210,7 +1421,7 @@ __global__ __launch_bounds__(256) void k_fr_reduce(ReduceArgs a) {
   }
   MIVI_STAMP_K(a.dbg, 3, 2);
   if (a.mode == R_DIAG || a.mode == R_DENSE_G) {
-    const double sl = block_sum<double, 256>((double)ell, red);
+    const double sl = block_sum_nodrain_f32<256>(ell, red);   // (behind write-through stores: see block_sum_nodrain)
     if (tid == 0) a.ell_part[blockIdx.x] = sl;
   }
   if (ld_blk) {   // log|det C| partial of this 64-row block (wave 0)
@@ -1562,6 +1773,48 @@ void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int m
   else if (dense) hipLaunchKernelGGL((k_fr_prod32<G_DENSE, true>), dim3(grid), dim3(512), 0, c->stream, a);
   else if (f32_mfma()) hipLaunchKernelGGL((k_fr_prod32<G_SAMPLE, false>), dim3(grid), dim3(512), 0, c->stream, a);
   else hipLaunchKernelGGL((k_fr_prod32<G_SAMPLE, true>), dim3(grid), dim3(512), 0, c->stream, a);
+}
+// unsplit 64 x 64-tile product + fused epilogue for the large shapes (k_fr_prod64); arguments as launch_lds_prod32
+void launch_lds_prod64(mivi_ctx *c, const void *params, int M, bool dense, int mode, void *Z, const EpsJob *next, bool want_ld) {
+  Prod32Args a{};
+  a.d = c->cfg.d; a.M = M; a.dP = c->dP; a.mode = mode;
+  if (dense) { a.A = (const float *)c->t_prec.p; a.lda = c->dP; a.B = (const float *)c->RT.p; }
+  else { a.A = (const float *)params + c->cfg.d; a.lda = c->cfg.d; a.B = (const float *)c->eps[c->cur].p; }
+  a.params = (const float *)params;
+  a.t_mean = (const float *)c->t_mean.p;
+  a.t_istd = (const float *)c->t_istd.p;
+  a.Z = (float *)Z;
+  a.W = (float *)c->W.p;
+  a.R = (float *)c->RT.p;
+  a.ell_part = (double *)c->ell_part[c->cur].p;
+  a.ld_part = want_ld ? (double *)c->ld_part[c->cur].p : nullptr;
+  a.ncb = M / 64;
+  a.n_tiles = (c->cfg.d / 64) * a.ncb;
+  a.dbg = c->dbg;
+  int grid = a.n_tiles;
+  if (next) {
+    a.next_eps.d = c->cfg.d;
+    a.next_eps.M = M;
+    a.next_eps.rng = next->rng;
+    a.next_eps.eps = (float *)c->eps[next->parity].p;
+    a.next_eps.ld_eps = c->dP;
+    a.next_eps.he_part = (double *)c->he_part[next->parity].p;
+    a.n_eps = (c->cfg.d / 64) * (M / 32);
+    grid += a.n_eps;
+  }
+  if (dense && f32_mfma()) hipLaunchKernelGGL((k_fr_prod64<G_DENSE, false>), dim3(grid), dim3(512), 0, c->stream, a);
+  else if (dense) hipLaunchKernelGGL((k_fr_prod64<G_DENSE, true>), dim3(grid), dim3(512), 0, c->stream, a);
+  else if (f32_mfma()) hipLaunchKernelGGL((k_fr_prod64<G_SAMPLE, false>), dim3(grid), dim3(512), 0, c->stream, a);
+  else hipLaunchKernelGGL((k_fr_prod64<G_SAMPLE, true>), dim3(grid), dim3(512), 0, c->stream, a);
+}
+int lds_prod64_tiles(const mivi_ctx *c, int M) { return (c->cfg.d / 64) * (M / 64); }
+// beyond the 32 x 32 kernel's range (d n_mc > 1024 x 512: at least 128 tiles of 64 x 64) the 64 x 64 kernel; measured against the
+// split-K route it replaces: 1536 x 512 sample stage 25.4 -> 20.0 us, 2048 x 1024 59.3 -> 35.5 us, 4096 x 1024 206 -> 119 us
+// (145 TF f32-equivalent); at and below the boundary the 32 x 32 kernel wins (1024 x 512: 11.8 vs 14.7 us).  MIVI_PROD64=0: the
+// split-K route (k_fr_gemm + k_fr_reduce, A/B reference).
+bool lds_use_prod64(const mivi_ctx *c, int M) {
+  static const bool off = getenv("MIVI_PROD64") && atoi(getenv("MIVI_PROD64")) == 0;
+  return !off && !lds_use_prod32(c, M) && M % 64 == 0;
 }
 int lds_prod32_tiles(const mivi_ctx *c, int M) { return (c->cfg.d / 32) * (M / 32); }
 int lds_prod32_eps_blocks(const mivi_ctx *c, int M) { return (c->cfg.d / 64) * (M / 32); }

@@ -526,7 +526,13 @@ static mivi_status_t run_estimate_lds(mivi_ctx *c, const void *params, const Rng
     if (dense) launch_lds_prod32(c, params, M, true, R_DENSE_G, nullptr, nullptr, false);
     vin.ell_part = (const double *)c->ell_part[p].p;
     vin.n_ell_part = lds_prod32_tiles(c, M);
-  } else {     // split-K slabs + reduce kernel (large shapes)
+  } else if (lds_use_prod64(c, M)) {   // large shapes: unsplit 64 x 64 tiles, the target fused into the epilogue
+    launch_lds_prod64(c, params, M, false, dense ? R_DENSE_R : R_DIAG, nullptr, next, grad_stage);
+    if (next) c->he_n[p ^ 1] = lds_eps_blocks(c, M);
+    if (dense) launch_lds_prod64(c, params, M, true, R_DENSE_G, nullptr, nullptr, false);
+    vin.ell_part = (const double *)c->ell_part[p].p;
+    vin.n_ell_part = lds_prod64_tiles(c, M);
+  } else {     // split-K slabs + reduce kernel (shapes in between)
     launch_lds_sample(c, params, M, next);
     launch_lds_reduce(c, params, M, dense ? R_DENSE_R : R_DIAG, nullptr, grad_stage);
     if (next) c->he_n[p ^ 1] = lds_eps_blocks(c, M);
@@ -1442,7 +1448,7 @@ int32_t mivi_fullrank_route(const mivi_ctx_t *c, int32_t n_samples) {
   if (!c || c->cfg.family != MIVI_FULLRANK) return 0;
   if (n_samples <= 0) n_samples = c->cfg.n_mc;
   if (!lds_path_shape_ok(c, n_samples) || (c->target != TGT_DIAG_GAUSS && c->target != TGT_DENSE_GAUSS)) return 0;
-  return (lds_use_prod32(c, n_samples) ? 1 : 2) | (lds_bf16x3() ? 16 : 0);
+  return (lds_use_prod32(c, n_samples) ? 1 : (lds_use_prod64(c, n_samples) ? 3 : 2)) | (lds_bf16x3() ? 16 : 0);
 }
 
 mivi_status_t mivi_set_logreg_route(mivi_ctx_t *c, int32_t route) {
@@ -1506,6 +1512,8 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
       case 2:
         if (lds && lds_use_prod32(c, M)) {
           launch_lds_prod32(c, params, M, false, c->target == TGT_DENSE_GAUSS ? R_DENSE_R : R_DIAG, nullptr, nullptr, true);
+        } else if (lds && lds_use_prod64(c, M)) {
+          launch_lds_prod64(c, params, M, false, c->target == TGT_DENSE_GAUSS ? R_DENSE_R : R_DIAG, nullptr, nullptr, true);
         } else if (lds) {
           launch_lds_sample(c, params, M);
           launch_lds_reduce(c, params, M, c->target == TGT_DENSE_GAUSS ? R_DENSE_R : R_DIAG, nullptr, true);
@@ -1529,6 +1537,8 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
       default:
         if (lds && lds_use_prod32(c, M)) {
           launch_lds_prod32(c, params, M, true, R_DENSE_G, nullptr, nullptr, false);
+        } else if (lds && lds_use_prod64(c, M)) {
+          launch_lds_prod64(c, params, M, true, R_DENSE_G, nullptr, nullptr, false);
         } else if (lds) {
           launch_lds_dense(c, M);
           launch_lds_reduce(c, params, M, R_DENSE_G, nullptr, false);

@@ -328,6 +328,9 @@ void launch_lds_dense(mivi_ctx *c, int M);
 void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int mode, void *Z, const EpsJob *next, bool want_ld,
                        bool with_dinv = false);   // with_dinv: trailing workgroups invert the 64x64 diagonal blocks of C (STL)
 int lds_prod32_tiles(const mivi_ctx *c, int M);
+void launch_lds_prod64(mivi_ctx *c, const void *params, int M, bool dense, int mode, void *Z, const EpsJob *next, bool want_ld);
+int lds_prod64_tiles(const mivi_ctx *c, int M);
+bool lds_use_prod64(const mivi_ctx *c, int M);   // large shapes: unsplit 64 x 64 tiles instead of split-K slabs + reduce
 int lds_prod32_eps_blocks(const mivi_ctx *c, int M);
 bool lds_use_prod32(const mivi_ctx *c, int M);
 bool lds_bf16x3();   // products on the bf16 matrix cores (three-way exact operand split); MIVI_FR_F32MFMA=1 turns it off

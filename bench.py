@@ -105,7 +105,8 @@ def fr_roofline(ctx, params, cost, w, reps=300):
     dom = "vjp" if stages["vjp"] >= stages["sample"] else "sample"
     names = {0: {"vjp": "k_fr_tile_mfma<MODE_VJP,4>", "sample": "k_fr_tile_mfma<MODE_SAMPLE,8>"},
              1: {"vjp": "k_fr_vjp32", "sample": "k_fr_prod32<SAMPLE> (product + fused target)"},
-             2: {"vjp": "k_fr_vjp32", "sample": "k_fr_gemm<SAMPLE> + k_fr_reduce (split-K)"}}[gen]
+             2: {"vjp": "k_fr_vjp32", "sample": "k_fr_gemm<SAMPLE> + k_fr_reduce (split-K)"},
+             3: {"vjp": "k_fr_vjp32 / k_fr_vjp64", "sample": "k_fr_prod64<SAMPLE> (product + fused target)"}}[gen]
     fl = cost["flops"] / 2
     ach = fl / (stages[dom] * 1e-3) / 1e12
     roof = dict(bound="mfma", kernel=names[dom], achieved=ach, peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=ach / PEAK_F32_MFMA_TF,

@@ -309,7 +309,8 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *ctx, int32_t which, const void *pa
 /* Which kernels the full-rank f32 path runs for `n_samples` per launch on this context (measurement / documentation hook):
  *   bits 0-1: 0 = first generation (32x32 tiles fed from L2, any shape), 1 = unsplit 32x32 product with fused target
  *             (k_fr_prod32) + private-wave VJP (k_fr_vjp32), 2 = split-K LDS-staged product + reduce (k_fr_gemm, k_fr_reduce)
- *             + k_fr_vjp32;   bit 4: products on the bf16 matrix cores with the exact three-way operand split. */
+ *             + k_fr_vjp32, 3 = unsplit 64x64 product with fused target (k_fr_prod64, shapes with at least as many tiles as CUs)
+ *             + k_fr_vjp32 / k_fr_vjp64;   bit 4: products on the bf16 matrix cores with the exact three-way operand split. */
 int32_t mivi_fullrank_route(const mivi_ctx_t *ctx, int32_t n_samples);
 
 /* Developer tool: when buf_dev != NULL every workgroup of the main kernels records wall_clock64() stamps
