@@ -519,7 +519,10 @@ static mivi_status_t run_estimate_lds(mivi_ctx *c, const void *params, const Rng
   if (p32) {   // unsplit 32 x 32 tiles with the target fused into the epilogue: one kernel from eps to W
     const bool stl_here = (grad_stage && (out.ent_kind == MIVI_ENT_STL || out.ent_kind == MIVI_ENT_STL_ZERO_GRAD) && stl2_shape_ok(c, M)) ||
                           (c->want_stl_pack && c->stl_F.p);   // (the Stein estimator's solve: the riders prepare its operands too)
-    launch_lds_prod32(c, params, M, false, dense ? R_DENSE_R : R_DIAG, nullptr, next, grad_stage, stl_here);
+    // (a chain of estimates with no optimiser step in between reads the SAME parameters: the solve's parameter-only preparation of
+    //  the chain's first estimate stays valid, the later ones carry no STL riders)
+    const bool reuse_pack = stl_here && chained && ch->estimates_only && !ch->first;
+    launch_lds_prod32(c, params, M, false, dense ? R_DENSE_R : R_DIAG, nullptr, next, grad_stage, stl_here && !reuse_pack);
     dinv_done = stl_here;
     c->stl_pack_done = stl_here;
     if (next) c->he_n[p ^ 1] = lds_prod32_eps_blocks(c, M);

@@ -189,6 +189,31 @@ def test_graph_batched_estimates_match_single(dtype):
         ctx.close()
 
 
+@pytest.mark.parametrize("ent", [3, 4])
+def test_graph_batched_stl_estimates_reuse_the_solve_preparation(ent):
+    """Second-generation STL route: inside one batched call the parameters are fixed, so only the chain's first estimate carries the
+    solve's parameter-only riders.  The last estimate of the batch equals the single call; a replay of the SAME cached graph after
+    the parameters changed in place prepares again."""
+    d, M = 256, 128
+    rng = np.random.default_rng(21)
+    q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
+    prob, _ = make_problem(rng, "diag", d, np.float32)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
+    ctx.set_problem(prob)
+    p = ctx.to_device(params).clone()
+    v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+    for scale in (1.0, 1.25):
+        if scale != 1.0:
+            p[d:] *= scale                                   # the scale matrix changes in place: same buffer, same cached graph
+        v1, g1 = ctx.estimate_gradient(p, 7 + 4)
+        v1, g1 = v1.cpu().numpy().copy(), g1.cpu().numpy().copy()
+        ctx.estimate_gradient_n(p, 7, 5, v, g)
+        ctx.synchronize()
+        assert np.array_equal(v.cpu().numpy(), v1) and np.array_equal(g.cpu().numpy(), g1), scale
+    ctx.close()
+
+
 def test_nonpositive_scale_and_nonfinite_status():
     """Error conventions: non-finite objective -> the reference's ErrorException (common.jl:83-89)."""
     d = 8
