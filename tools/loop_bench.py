@@ -1,6 +1,6 @@
 """Device-resident SGD loop throughput (mivi_optimize_steps): steps/s for C2-shaped and bench/benchmarks.jl-shaped problems."""
-import sys, time, numpy as np, torch
-sys.path.insert(0, ".")
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import advancedvi_jl_amd as avi
 for name, d, M, fam in (("C2 mean-field d=1024 M=256", 1024, 256, 0), ("reference bench shape d=10 M=1 mean-field", 10, 1, 0),
                         ("NS full-rank d=1024 M=256", 1024, 256, 1)):
