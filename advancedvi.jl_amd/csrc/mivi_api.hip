@@ -1021,6 +1021,7 @@ __global__ void k_store_value_f32(float *out, const double *acc) { out[0] = (flo
 __global__ void k_store_value_f64(double *out, const double *acc) { out[0] = acc[0]; }
 // device counters of the graph-batched calls, set BY VALUE (an async copy from a stack local may outlive the caller's frame)
 __global__ void k_set_u64x2(uint64_t *dst, uint64_t a, uint64_t b, int n) { dst[0] = a; if (n > 1) dst[1] = b; }
+__global__ void k_bump_u64(uint64_t *dst, uint64_t by) { dst[0] += by; }
 
 mivi_status_t mivi_estimate_objective(mivi_ctx_t *c, const void *params, uint64_t idx, int32_t n_samples, int32_t entropy,
                                       void *value) {
@@ -1249,6 +1250,9 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
       s = run_estimate(c, params, r, c->cfg.n_mc, 1, final_out(c, value, grad), &chn);
     }
     if (s == MIVI_OK) flush_chain(c, params, &chn);
+    // the graph leaves the device-side estimate counter at idx0 + count: a caller that walks the indices in order (an SGD-style
+    // driver does) needs no counter-setting launch in front of the next replay
+    if (s == MIVI_OK) hipLaunchKernelGGL(k_bump_u64, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, (uint64_t)count);
     c->cur = 0;
     hipError_t e = end_capture(c, saved, &graph);
     if (s) { if (graph) (void)hipGraphDestroy(graph); return s; }
@@ -1257,8 +1261,11 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
     (void)hipGraphDestroy(graph);
     g.kind = 1; g.count = count; g.params = params; g.value = value; g.grad = grad;
   }
-  hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, idx0, 0ull, 1);
+  if (!(c->d_idx_valid && c->d_idx_expect == idx0))
+    hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, idx0, 0ull, 1);
   HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
+  c->d_idx_valid = true;
+  c->d_idx_expect = idx0 + (uint64_t)count;
   return MIVI_OK;
 }
 
@@ -1440,6 +1447,7 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     g.kind = 9; g.count = n_steps; g.params = params; g.value = vbuf;
     g.loop = l;
   }
+  c->d_idx_valid = false;
   hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, l.estimate_idx0, (uint64_t)l.t0, 2);
   HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream));   // a stale flag of earlier host-driven estimates is not this run's
   HIPCHK(c, hipGraphLaunch(g.exec, c->stream));

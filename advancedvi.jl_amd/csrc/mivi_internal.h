@@ -262,6 +262,8 @@ struct mivi_ctx {
   mivi::DevBuf lds_tabS, lds_tilesS, lds_tabD, lds_tilesD, lds_tabV, lds_tabV64, lds_slab;
   int lds_nS = 0, lds_nD = 0, lds_nV = 0, lds_nV64 = 0, lds_M = -1, lds_zero_slab = 0;
   bool lds_dense = false;
+  bool d_idx_valid = false;          // the device-side estimate counter (d_idx[0]) is known to hold d_idx_expect
+  uint64_t d_idx_expect = 0;
   mivi::DevBuf lds_tabSt;            // Stein accumulation stage: the full square of 64 x 64 tiles
   int lds_nSt = 0, lds_st_d = -1;
   mivi::ValueJob *defer_value = nullptr;   // non-null: run_estimate_lds(stop_after_target) hands its value job over instead of launching it

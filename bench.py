@@ -391,8 +391,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run(W, K)
-        stream.synchronize()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()   # (device-wide: covers the launch stream)
         if dist:
             dist.barrier()
         dt = time.perf_counter() - t0
