@@ -1871,7 +1871,7 @@ void launch_lds_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, 
   // (a wave's single sub-stage there is load, then compute, then a four times larger epilogue, nothing overlapped, against
   // two or three 32 x 32 workgroups per CU covering for each other).  MIVI_VJP_TILE=32 / 64 pins it.
   static const int pin = getenv("MIVI_VJP_TILE") ? atoi(getenv("MIVI_VJP_TILE")) : 0;
-  const bool t64 = pin ? pin == 64 : (M >= 1024 && c->cfg.d >= 2048);
+  const bool t64 = pin ? pin == 64 : ((M >= 1024 && c->cfg.d >= 2048) || (M >= 512 && c->cfg.d >= 4096));   // (4096 x 512: 90.6 -> 83.7 us)
   if (t64) {
     a.work = (const int4 *)c->lds_tabV64.p;
     grid = c->lds_nV64;
