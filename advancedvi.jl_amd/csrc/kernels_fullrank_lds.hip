@@ -1,4 +1,4 @@
-// Full-rank RepGradELBO contractions, second generation: LDS-staged macro-tiles on v_mfma_f32_32x32x2_f32 (gfx950).
+// Full-rank RepGradELBO contractions, second generation (gfx950): LDS-staged tiles, exact f32 products on the bf16 matrix cores.
 //
 // Reference semantics (AdvancedVI.jl v0.7.0), unchanged from kernels_fullrank.hip:
 //   sampling   Z = scale * eps .+ mu                                  src/families/location_scale.jl:71-77
@@ -7,20 +7,20 @@
 //
 // Why a second generation: the first one gives every 32x32 output tile its own workgroup and feeds the MFMAs one dword
 // per lane straight from L2 -- each operand element is fetched for exactly one MFMA (34.6 MB of L2->L1 traffic per
-// contraction at d=1024, M=256 against 3.1 MB of input) and the triangular product only ever occupies 128 CUs.  Here:
-//   * operands travel global -> registers (16-byte coalesced loads, two stages ahead) -> LDS, and every LDS element feeds
-//     BM/32 (resp. BN/32) MFMAs of the workgroup's BM x BN macro-tile;
-//   * the triangular product  tril(C) eps  and the dense target product are SPLIT-K over workgroups from a host-built
-//     work list (equal k-ranges => all 256 CUs busy); a workgroup leaves its partial macro-tile in a slab, and the
-//     reduction is deterministic and rides on the kernel boundary: k_fr_reduce sums a tile's slabs in list order, adds mu,
-//     applies the fused target, and -- VALU work under its memory latency -- draws eps of the NEXT estimate and the
-//     log-determinant partials;
-//   * eps lives in ONE layout, eps[i + m*dP]: the sampling product reads it k-major (16-byte loads along k, LDS image
-//     [n][k], b128 fragment reads), the VJP reads the same buffer row-major.  The MFMA k-slots of both operands are
-//     permuted identically (k = 8s + 4(lane>>5) + j), which leaves the sum unchanged;
-//   * the VJP  tril(W eps')  has a short K (= n_mc), so it is not split over workgroups: 64x32 tiles, the two k-halves
-//     of every stage on two waves, reduced through LDS in the epilogue (16-byte coalesced gradient stores).
-// One estimate = k_fr_gemm<SAMPLE> -> k_fr_reduce (-> k_fr_gemm<DENSE> -> k_fr_reduce) -> k_fr_gemm<VJP>.
+// contraction at d=1024, M=256 against 3.1 MB of input).  What runs now, by shape (launch_* at the end of the file):
+//   * every wave stages its OWN k range of both operands through a private LDS buffer with direct-to-LDS loads
+//     (global_load_lds_dwordx4) and waits on its own vmcnt: no workgroup barrier before the epilogue;
+//   * products are v_mfma_f32_32x32x16_bf16 x 6 on the exact three-way bf16 split of the f32 operands (mfma_bf16x3);
+//     MIVI_FR_F32MFMA=1 keeps the v_mfma_f32_32x32x2_f32 chains as a reference;
+//   * k_fr_prod32 / k_fr_vjp32: 32x32 tiles, one per workgroup, for d * n_mc <= 1024 * 512 (the north star: 256 product tiles = 256
+//     CUs, 528 VJP tiles, three resident per CU); the target, the ell / log-det partials and (riders) eps of the next estimate
+//     and the STL solve's parameter-only preparation live in the product kernel, the optimiser step in the VJP epilogue;
+//   * k_fr_prod64 / k_fr_vjp64: 64x64 tiles beyond that (four accumulators per wave, every operand element split once for two MFMA
+//     tiles): 186 / 151 TF f32-equivalent at 8192 x 2048; k_fr_vjp64<STEIN> is the Stein estimator's accumulation stage;
+//   * k_fr_gemm + k_fr_reduce: the split-K route the 64x64 product replaced (MIVI_PROD64=0, A/B reference);
+//   * eps lives in ONE layout, eps[i + m*dP]: the sampling product reads it k-major (LDS image [n][k] with XOR-swizzled 16-byte
+//     chunks, b128 fragment reads), the VJP reads the same buffer row-major.  The MFMA k-slots of both operands are permuted
+//     identically (k = 8s + 4(lane>>5) + j), which leaves the sum unchanged.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
