@@ -26,6 +26,7 @@ CASES = [
     # is no multiple of 4 (plain block -> tile map), the STL estimator behind it
     (avi.FULLRANK, 1024, 1024, "dense", 0, np.float32), (avi.FULLRANK, 1152, 512, "diag", 0, np.float32),
     (avi.FULLRANK, 1536, 512, "dense", 2, np.float32), (avi.FULLRANK, 2048, 384, "diag", 4, np.float32),
+    (avi.FULLRANK, 4096, 512, "diag", 0, np.float32),   # 64 x 64 tiles for both contractions (k_fr_prod64 + k_fr_vjp64)
 ]
 
 
