@@ -53,8 +53,12 @@ def test_fuzz(family, dtype, ent, kind, d, M):
         check(*ctx.finalize(params, ctx.estimate_partials(params, idx)), 2.0)       # shard route
         p = ctx.to_device(params)
         v, g = ctx.empty(1), ctx.empty(ctx.params_len)
-        ctx.estimate_gradient_n(p, idx - 2 if idx >= 2 else 0, 3 if idx >= 2 else 1, v, g)   # graph route, last = idx
-        ctx.synchronize()
+        ctx.estimate_gradient_n(p, idx - 2 if idx >= 2 else 0, 3 if idx >= 2 else 1, v, g)   # batched route, last = idx
+        ctx.synchronize()                                                                  # (short batch: eager chain for the full-rank family)
         if idx >= 2:
+            check(v, g)
+        if idx >= 6:
+            ctx.estimate_gradient_n(p, idx - 6, 7, v, g)                                   # captured graph, last = idx
+            ctx.synchronize()
             check(v, g)
     ctx.close()

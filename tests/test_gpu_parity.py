@@ -180,12 +180,13 @@ def test_graph_batched_estimates_match_single(dtype):
         ctx = avi.MiviContext(dtype, family, d, M, 0, SEED)
         ctx.set_problem(prob)
         p = ctx.to_device(params)
-        v1, g1 = ctx.estimate_gradient(p, 7 + 4)
-        v1, g1 = v1.cpu().numpy().copy(), g1.cpu().numpy().copy()
         v, g = ctx.empty(1), ctx.empty(ctx.params_len)
-        ctx.estimate_gradient_n(p, 7, 5, v, g)   # estimates 7..11; last one left in the buffers
-        ctx.synchronize()
-        assert np.array_equal(v.cpu().numpy(), v1) and np.array_equal(g.cpu().numpy(), g1)
+        for count in (3, 9):   # a short batch runs as an eager chain, a longer one as a captured graph
+            v1, g1 = ctx.estimate_gradient(p, 7 + count - 1)
+            v1, g1 = v1.cpu().numpy().copy(), g1.cpu().numpy().copy()
+            ctx.estimate_gradient_n(p, 7, count, v, g)   # estimates 7 .. 7 + count - 1; the last one is left in the buffers
+            ctx.synchronize()
+            assert np.array_equal(v.cpu().numpy(), v1) and np.array_equal(g.cpu().numpy(), g1), count
         ctx.close()
 
 
@@ -206,11 +207,12 @@ def test_graph_batched_stl_estimates_reuse_the_solve_preparation(ent):
     for scale in (1.0, 1.25):
         if scale != 1.0:
             p[d:] *= scale                                   # the scale matrix changes in place: same buffer, same cached graph
-        v1, g1 = ctx.estimate_gradient(p, 7 + 4)
-        v1, g1 = v1.cpu().numpy().copy(), g1.cpu().numpy().copy()
-        ctx.estimate_gradient_n(p, 7, 5, v, g)
-        ctx.synchronize()
-        assert np.array_equal(v.cpu().numpy(), v1) and np.array_equal(g.cpu().numpy(), g1), scale
+        for count in (4, 9):   # eager chain / captured graph
+            v1, g1 = ctx.estimate_gradient(p, 7 + count - 1)
+            v1, g1 = v1.cpu().numpy().copy(), g1.cpu().numpy().copy()
+            ctx.estimate_gradient_n(p, 7, count, v, g)
+            ctx.synchronize()
+            assert np.array_equal(v.cpu().numpy(), v1) and np.array_equal(g.cpu().numpy(), g1), (scale, count)
     ctx.close()
 
 
