@@ -523,6 +523,22 @@ def main():
                                      f32_mfma_TFs=(2.0 * w["d"] * w["d"] * w["n_mc"] * 1.5 + 2.0 * w["d"] ** 3 / 2) / t_st / 1e12,
                                      note="flops: triangular product + eps G^T (d^2 n each, the first half-counted) + the d-column solve (d^3 / 2 MACs)")
                 del g_s, H_s
+                # the device-resident optimisation loop on the north-star problem (mivi_optimize_steps: estimate -> Adam + ClipScale fused into
+                # the VJP epilogue, hipGraph of the whole chunk): what `optimize()` sustains, one dependent chain
+                p_l = params.clone()
+                st_l = ctx.empty(2 * p_l.numel()).zero_()
+                T_l = 1000
+                ctx.optimize_steps(p_l, st_l, 0, 0, T_l, 1, 1e-3, 1e-5)
+                stream.synchronize()
+                t0s = time.perf_counter()
+                for r in range(3):
+                    ctx.optimize_steps(p_l, st_l, (r + 1) * T_l, (r + 1) * T_l, T_l, 1, 1e-3, 1e-5)
+                stream.synchronize()
+                t_l = (time.perf_counter() - t0s) / (3 * T_l)
+                also["ns_adam_loop"] = dict(workload="north-star problem, mivi_optimize_steps: Adam(1e-3) + ClipScale(1e-5), 3 x 1000 steps",
+                                            value=1.0 / t_l, unit="steps/s", us_per_step=t_l * 1e6,
+                                            note="the optimiser step rides in the VJP epilogue (k_fr_vjp32<FUSED>): 12.6 MB of parameter / moment traffic per step")
+                del p_l, st_l
             # ---- parity + cpu_baseline leg (rank 0, N = 1 only) ---------------------------------------------
             rel = None
             cpub = None
