@@ -126,7 +126,18 @@ __device__ __forceinline__ void store16_wt(void *p, const V16 &v) {
 }
 
 // timeline stamps: region `kind` (0 mean-field / sample, 1 vjp, 2 dense) x 4096 blocks x 8 slots
+// Developer instrumentation exists only in -DMIVI_DEV builds (csrc/Makefile: `make DEV=1`): the per-workgroup timeline stamps
+// (mivi_debug_timeline) and the work-skipping knock-outs (MIVI_KNOCK) are compiled OUT of the release library -- no environment
+// variable can make it skip operand loads, MFMAs, epilogues or stores.
+#ifdef MIVI_DEV
 #define MIVI_STAMP_K(dbgp, kind, slot) do { if ((dbgp) && threadIdx.x == 0 && blockIdx.x < 4096) (dbgp)[((size_t)(kind) * 4096 + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
+#define MIVI_KNOCKED(args, bits) ((args).knock & (bits))
+#define MIVI_DEV_ONLY(...) __VA_ARGS__
+#else
+#define MIVI_STAMP_K(dbgp, kind, slot) do { } while (0)
+#define MIVI_KNOCKED(args, bits) false
+#define MIVI_DEV_ONLY(...)
+#endif
 #define MIVI_STAMP(dbgp, slot) MIVI_STAMP_K(dbgp, 0, slot)
 
 // Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain outstanding global

@@ -541,13 +541,13 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
     return;
   }
   MIVI_STAMP_K(a.dbg, MODE, 0);
-  if (a.dbg && threadIdx.x == 0 && blockIdx.x < 4096) a.dbg[((size_t)MODE * 4096 + blockIdx.x) * 8 + 6] = clock64();
+  MIVI_DEV_ONLY(if (a.dbg && threadIdx.x == 0 && blockIdx.x < 4096) a.dbg[((size_t)MODE * 4096 + blockIdx.x) * 8 + 6] = clock64();)
   const int2 wk = a.work_tab[widx];
   if (wk.x < 0) {
     if (tid == 0 && MODE != MODE_VJP) a.ell_part[widx] = 0.0;
     return;
   }
-  if (a.dbg && threadIdx.x == 0 && blockIdx.x < 4096) a.dbg[((size_t)MODE * 4096 + blockIdx.x) * 8 + 5] = ((long long)wk.x << 16) | wk.y;
+  MIVI_DEV_ONLY(if (a.dbg && threadIdx.x == 0 && blockIdx.x < 4096) a.dbg[((size_t)MODE * 4096 + blockIdx.x) * 8 + 5] = ((long long)wk.x << 16) | wk.y;)
 
   // ---- segments and the K split -----------------------------------------------------------------
   const int nb = (d + 31) >> 5;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(NW * 64) void k_fr_tile_mfma(FrArgs<float> a) {
   rs_lds[tid] = rs;
   __syncthreads();
   MIVI_STAMP_K(a.dbg, MODE, 2);
-  if (a.dbg && threadIdx.x == 0 && blockIdx.x < 4096) a.dbg[((size_t)MODE * 4096 + blockIdx.x) * 8 + 7] = clock64();
+  MIVI_DEV_ONLY(if (a.dbg && threadIdx.x == 0 && blockIdx.x < 4096) a.dbg[((size_t)MODE * 4096 + blockIdx.x) * 8 + 7] = clock64();)
 
   double ell_acc = 0.0;
 #pragma unroll
@@ -931,116 +931,11 @@ __global__ __launch_bounds__(256) void k_stl_prep(int d, int dP, const T *C, T *
   }
 }
 
-// Look-ahead variant of the blocked back substitution.  In k_stl_solve every block row does
-//   S_b = sum_{j>b} CT(b,j) X_j  ->  reduce  ->  X_b = Dinv_b (eps_b - S_b)
-// strictly one after the other, although only the LAST term of S_b (j = b+1) depends on the block solved just before.
-// Here wave 0 is the sequential chain -- last term of row b, R_b = eps_b - bulk_b - last, X_b = Dinv_b R_b (32 MFMAs per
-// block row) -- while waves 1..NW-1 already accumulate the bulk of row b-1 (all j >= b+1, known) next to it.  A block row
-// then costs max(chain, bulk / 7 waves) instead of their sum.  Measured per block row (in-kernel stamps, d = 1024): chain
-// 1.7-2.8 us, bulk ~1 us per 32x32x32 unit per wave (two waves share a SIMD's MFMA pipe), i.e. the kernel is bound by
-// the MFMA throughput of the 8 CUs that M = 256 gives it (496 units -> ~62 us floor, 124 us with the round-robin
-// imbalance); 16-column workgroups on 16x16x4 MFMAs would double the CUs and are the next step.
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_stl_solve_la(FrArgs<float> a, const float *CT, const float *DinvT) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float *x = (float *)smem_raw;                           // x[k*32 + m], k < dP
-  const int d = a.d, M = a.M, dP = a.dP;
-  float *part = x + (size_t)dP * 32;                      // part[w][16*64]; part[0] = reduced bulk of the current row
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.x * 32;
-  const int nb = (d + 31) >> 5;
-  for (int t = tid; t < dP * 32; t += NW * 64) {
-    const int k = t % dP, m = t / dP;                     // lanes along k: coalesced global reads
-    x[k * 32 + m] = a.eps[(size_t)(m0 + m) * dP + k];
-  }
-  for (int t = tid; t < 16 * 64; t += NW * 64) part[t] = 0.f;   // bulk of the last block row is empty
-  float av0[16], av1[16];
-  auto loadA = [&](int brow, int j, float (&av)[16]) {    // A[i][k] = CT[(brow*32+i) + k*dP]
-    const float *Arow = CT + brow * 32 + l31;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) av[u] = Arow[(size_t)(j * 32 + 2 * u + h) * dP];
-  };
-  // first operands: wave 0 has no last term for row nb-1; bulk of row nb-2 is empty as well
-  __syncthreads();
-  for (int b = nb - 1; b >= 0; --b) {
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    auto mma = [&](int j, const float (&av)[16]) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const float bv = x[(j * 32 + 2 * u + h) * 32 + l31];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv, acc, 0, 0, 0);
-      }
-    };
-    if (w == 0) {
-      // ---- the sequential chain ------------------------------------------------------------------
-      float dv[16];
-      const float *Di = DinvT + (size_t)b * 1024 + l31;   // A[i][k] = DinvT[i + 32 k]
-#pragma unroll
-      for (int u = 0; u < 16; ++u) dv[u] = Di[32 * (2 * u + h)];
-      if (b + 1 < nb) mma(b + 1, av0);                    // av0: CT(b, b+1), fetched during the previous block row
-      if (b > 0) loadA(b - 1, b, av0);                    // operands of the next block row's last term
-      // R_b = eps_b - bulk_b - last term, in the accumulator layout (row = (r&3) + 8(r>>2) + 4h, col = l31)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        float *xe = &x[(b * 32 + row) * 32 + l31];
-        *xe = *xe - part[r * 64 + lane] - acc[r];
-      }
-      f32x16 xa;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xa[r] = 0.f;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {                      // same wave wrote R: LDS ordering is program order
-        const float bv = x[(b * 32 + 2 * u + h) * 32 + l31];
-        xa = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[u], bv, xa, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        x[(b * 32 + row) * 32 + l31] = xa[r];
-      }
-    } else if (b > 0) {
-      // ---- bulk of block row b-1: units j = b+1 .. nb-1 dealt to waves 1 .. NW-1 ------------------------
-      int j = b + w;                                       // b + 1 + (w - 1)
-      if (j < nb) {                                        // av0 holds unit j (fetched during the previous block row)
-        while (true) {
-          if (j + (NW - 1) < nb) loadA(b - 1, j + (NW - 1), av1);
-          mma(j, av0);
-          j += NW - 1;
-          if (j >= nb) break;
-          if (j + (NW - 1) < nb) loadA(b - 1, j + (NW - 1), av0);
-          mma(j, av1);
-          j += NW - 1;
-          if (j >= nb) break;
-        }
-      }
-      if (b > 1 && b - 1 + w < nb) loadA(b - 2, b - 1 + w, av0);   // first unit of the next block row's bulk
-#pragma unroll
-      for (int r = 0; r < 16; ++r) part[w * (16 * 64) + r * 64 + lane] = acc[r];
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) part[w * (16 * 64) + r * 64 + lane] = 0.f;
-    }
-    __syncthreads();
-    // bulk_{b-1} = sum of the partials (fixed order); it becomes part[0] for the next block row
-    for (int t = tid; t < 16 * 64; t += NW * 64) {
-      float sacc = part[1 * (16 * 64) + t];
-#pragma unroll
-      for (int ww = 2; ww < NW; ++ww) sacc += part[ww * (16 * 64) + t];
-      part[t] = sacc;
-    }
-    __syncthreads();
-  }
-  // W[i + m*d] += X[i, m]
-  for (int t = tid; t < dP * 32; t += NW * 64) {
-    const int i = t % dP, m = t / dP;
-    if (i < d && m0 + m < M) a.W[(size_t)(m0 + m) * d + i] += x[i * 32 + m];
-  }
-}
-
+// Blocked back substitution with look-ahead: every block row is  S_b = sum_{j>b} CT(b,j) X_j -> X_b = Dinv_b (eps_b - S_b), and only
+// the LAST term of S_b (j = b+1) depends on the block solved just before.  Wave 0 is the sequential chain (last term of row b,
+// R_b = eps_b - bulk_b - last, X_b = Dinv_b R_b), waves 1..NW-1 already accumulate the bulk of row b-1 next to it: a block row costs
+// max(chain, bulk / 7 waves) instead of their sum.  (The strictly sequential and the 32-column variants this replaced were removed
+// in round 3: no default path reached them.)
 // 16 sample columns per workgroup on v_mfma_f32_16x16x4_f32: the look-ahead solve is bound by the MFMA throughput of
 // the CUs it runs on, and M / 32 workgroups are only 8 CUs at M = 256.  Half the columns per workgroup = twice the CUs at
 // half the MFMA time per 32x32 unit (16 MFMAs of 8 passes instead of 16 of 16 passes).
@@ -1184,105 +1079,6 @@ __global__ __launch_bounds__(NW * 64) void k_stl_solve_la16(FrArgs<T> a, const T
   for (int t = tid; t < dP * 16; t += NW * 64) {
     const int i = t % dP, m = t / dP;
     if (i < d && m0 + m < M) a.W[(size_t)(m0 + m) * d + i] += x[i * 16 + m];
-  }
-}
-
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_stl_solve(FrArgs<float> a, const float *CT, const float *DinvT) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float *x = (float *)smem_raw;                           // x[k*32 + m], k < dP
-  const int d = a.d, M = a.M, dP = a.dP;
-  float *part = x + (size_t)dP * 32;                      // part[w][16*64] (read along columns: no padding needed)
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.x * 32;
-  const int nb = (d + 31) >> 5;
-  // rhs: x[k][m] = eps[k, m0 + m]  (eps[i + m*dP], zero padded)
-  for (int t = tid; t < dP * 32; t += NW * 64) {
-    const int k = t % dP, m = t / dP;                     // lanes along k: coalesced global reads
-    x[k * 32 + m] = a.eps[(size_t)(m0 + m) * dP + k];
-  }
-  __syncthreads();
-  // The A operands (blocks of C^T) never depend on X: the first unit of block row b-1 is fetched while block row b is
-  // still being reduced and solved, so its L2 latency is off the sequential chain.
-  float av0[16], av1[16];
-  auto loadA = [&](int brow, int j, float (&av)[16]) {    // A[i][k] = CT[(brow*32+i) + k*dP]
-    const float *Arow = CT + brow * 32 + l31;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) av[u] = Arow[(size_t)(j * 32 + 2 * u + h) * dP];
-  };
-  for (int b = nb - 1; b >= 0; --b) {
-    // wave 0 will need DinvT_b at the end of this step: issue those loads first (independent of X)
-    float dv[16];
-    if (w == 0) {
-      const float *Di = DinvT + (size_t)b * 1024 + l31;   // A[i][k] = DinvT[i + 32 k]
-#pragma unroll
-      for (int u = 0; u < 16; ++u) dv[u] = Di[32 * (2 * u + h)];
-    }
-    // ---- S = sum_{j > b} CT(b, j) X_j : units j = b+1 .. nb-1 dealt round-robin to the waves; the A operands of
-    //      the next unit are in flight while the current one multiplies ----
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    auto mma = [&](int j, const float (&av)[16]) {
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const float bv = x[(j * 32 + 2 * u + h) * 32 + l31];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv, acc, 0, 0, 0);
-      }
-    };
-    int j = b + 1 + w;
-    if (j < nb) {
-      // av0 already holds unit j of this block row (prefetched during the previous step)
-      while (true) {
-        if (j + NW < nb) loadA(b, j + NW, av1);
-        mma(j, av0);
-        j += NW;
-        if (j >= nb) break;
-        if (j + NW < nb) loadA(b, j + NW, av0);
-        mma(j, av1);
-        j += NW;
-        if (j >= nb) break;
-      }
-    }
-    // prefetch the first unit of the next block row (b-1): unit j = b + w
-    if (b > 0 && b + w < nb) loadA(b - 1, b + w, av0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) part[w * (16 * 64) + r * 64 + lane] = acc[r];
-    __syncthreads();
-    // ---- R = eps_b - S  (written back over x_b), then X_b = DinvT_b R by wave 0 ----
-    for (int t = tid; t < 1024; t += NW * 64) {
-      const int row = t >> 5, col = t & 31;               // lanes along m
-      const int r = (row & 3) + 4 * (row >> 3), hh = (row >> 2) & 1;
-      const int off = r * 64 + col + 32 * hh;
-      float sacc = part[off];
-#pragma unroll
-      for (int ww = 1; ww < NW; ++ww) sacc += part[ww * (16 * 64) + off];
-      x[(b * 32 + row) * 32 + col] -= sacc;
-    }
-    __syncthreads();
-    if (w == 0) {
-      f32x16 xa;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xa[r] = 0.f;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const float bv = x[(b * 32 + 2 * u + h) * 32 + l31];
-        xa = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[u], bv, xa, 0, 0, 0);
-      }
-      // all reads of x_b are done (same wave, in order): overwrite with the solution
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        x[(b * 32 + row) * 32 + l31] = xa[r];
-      }
-    }
-    __syncthreads();
-  }
-  // W[i + m*d] += X[i, m]
-  for (int t = tid; t < dP * 32; t += NW * 64) {
-    const int i = t % dP, m = t / dP;
-    if (i < d && m0 + m < M) a.W[(size_t)(m0 + m) * d + i] += x[i * 32 + m];
   }
 }
 
@@ -1725,9 +1521,7 @@ void launch_stein_finish(mivi_ctx *c, double n, const double *gsum, const double
 void launch_fr_stl(mivi_ctx *c, const void *params, int M, const void *rhs, void *out) {
   const int nblk = (M + 7) / 8;
   static const bool old_stl = getenv("MIVI_STL_VALU") != nullptr;
-  const size_t sh_mfma = ((size_t)c->dP * 32 + 8 * 16 * 64) * sizeof(float);
   const size_t sh_mfma16 = ((size_t)c->dP * 16 + 8 * 8 * 64) * sizeof(float);   // 16-column solve: d up to 2304
-  static const bool want32 = getenv("MIVI_STL_LEFT") != nullptr || getenv("MIVI_STL_COLS32") != nullptr;
   const size_t sh16_f64 = ((size_t)c->dP * 16 + 8 * 8 * 64) * sizeof(double);   // f64: d up to 1024
   if (c->cfg.dtype == MIVI_F64 && c->stl_CT.p && sh16_f64 <= 160 * 1024 && !old_stl && !f64_valu()) {
     FrArgs<double> a = fr_args<double>(c, params, M);
@@ -1746,46 +1540,21 @@ void launch_fr_stl(mivi_ctx *c, const void *params, int M, const void *rhs, void
                        (const double *)c->stl_CT.p, (const double *)c->stl_Dinv.p);
     return;
   }
-  if (c->cfg.dtype == MIVI_F32 && c->stl_CT.p && (want32 ? sh_mfma : sh_mfma16) <= 160 * 1024 && !old_stl) {
+  if (c->cfg.dtype == MIVI_F32 && c->stl_CT.p && sh_mfma16 <= 160 * 1024 && !old_stl) {
     FrArgs<float> a = fr_args<float>(c, params, M);
     if (rhs) a.eps = (const float *)rhs;
     if (out) a.W = (float *)out;
     const int nb = (c->cfg.d + 31) / 32;
     hipLaunchKernelGGL(k_stl_prep<float>, dim3(nb + nb * (nb + 1) / 2), dim3(256), 0, c->stream, c->cfg.d, c->dP,
                        (const float *)params + c->cfg.d, (float *)c->stl_CT.p, (float *)c->stl_Dinv.p);
-    static size_t attr_set = 0;   // raise the dynamic-LDS cap once per size (the call is slow)
-    if (want32 && attr_set < sh_mfma) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stl_solve<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)sh_mfma);
-      attr_set = sh_mfma;
+    static size_t attr16 = 0;   // raise the dynamic-LDS cap once per size (the call is slow)
+    if (attr16 < sh_mfma16) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stl_solve_la16<float, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)sh_mfma16);
+      attr16 = sh_mfma16;
     }
-    static const bool left_looking = getenv("MIVI_STL_LEFT") != nullptr;   // A/B: the strictly sequential block rows
-    static const bool cols32 = getenv("MIVI_STL_COLS32") != nullptr;       // A/B: 32 columns per workgroup
-    if (!left_looking && !cols32) {
-      const size_t sh16 = ((size_t)c->dP * 16 + 8 * 8 * 64) * sizeof(float);
-      static size_t attr16 = 0;
-      if (attr16 < sh16) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stl_solve_la16<float, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)sh16);
-        attr16 = sh16;
-      }
-      hipLaunchKernelGGL((k_stl_solve_la16<float, 8>), dim3((M + 15) / 16), dim3(512), sh16, c->stream, a, (const float *)c->stl_CT.p,
-                         (const float *)c->stl_Dinv.p);
-      return;
-    }
-    if (left_looking) {
-      hipLaunchKernelGGL(k_stl_solve<8>, dim3((M + 31) / 32), dim3(512), sh_mfma, c->stream, a, (const float *)c->stl_CT.p,
-                         (const float *)c->stl_Dinv.p);
-    } else {
-      static size_t attr_la = 0;
-      if (attr_la < sh_mfma) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stl_solve_la<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)sh_mfma);
-        attr_la = sh_mfma;
-      }
-      hipLaunchKernelGGL(k_stl_solve_la<8>, dim3((M + 31) / 32), dim3(512), sh_mfma, c->stream, a,
-                         (const float *)c->stl_CT.p, (const float *)c->stl_Dinv.p);
-    }
+    hipLaunchKernelGGL((k_stl_solve_la16<float, 8>), dim3((M + 15) / 16), dim3(512), sh_mfma16, c->stream, a, (const float *)c->stl_CT.p,
+                       (const float *)c->stl_Dinv.p);
     return;
   }
   if (c->cfg.dtype == MIVI_F32) {

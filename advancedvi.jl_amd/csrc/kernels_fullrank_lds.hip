@@ -17,7 +17,6 @@
 //     and the STL solve's parameter-only preparation live in the product kernel, the optimiser step in the VJP epilogue;
 //   * k_fr_prod64 / k_fr_vjp64: 64x64 tiles beyond that (four accumulators per wave, every operand element split once for two MFMA
 //     tiles): 186 / 151 TF f32-equivalent at 8192 x 2048; k_fr_vjp64<STEIN> is the Stein estimator's accumulation stage;
-//   * k_fr_gemm + k_fr_reduce: the split-K route the 64x64 product replaced (MIVI_PROD64=0, A/B reference);
 //   * eps lives in ONE layout, eps[i + m*dP]: the sampling product reads it k-major (LDS image [n][k] with XOR-swizzled 16-byte
 //     chunks, b128 fragment reads), the VJP reads the same buffer row-major.  The MFMA k-slots of both operands are permuted
 //     identically (k = 8s + 4(lane>>5) + j), which leaves the sum unchanged.
@@ -43,17 +42,14 @@ struct GemmArgs {
   int lda;
   const float *B;   // sample / dense: k-major B[k + n*ldb] (eps, Z - m); vjp: B[n + k*ldb] (eps)
   int ldb;
-  const int4 *work;  // .x = rb | cb << 16, .y = first stage | end stage << 16, .z = slab, .w = flags
+  const int4 *work;  // .x = rb | cb << 16, .y = first stage | end stage << 16, .z unused, .w = flags
   int n_work;        // the workgroup after the last item assembles the objective value (vjp, optional)
-  float *slab;       // split-K partial macro-tiles, slab s at slab + s*BM*BN, image [n][BM]
   // vjp epilogue
   const float *params;
   OutArgs out;
   FusedUpdate upd;
   ValueIn self_vin;
   OutArgs self_out;
-  int n_items;       // sample kernel: blocks >= n_items draw eps of the NEXT estimate (0 = no such blocks)
-  SampleArgs<float> next_eps;
   long long *dbg;    // optional timeline (tools/timeline2.py)
   int knock;         // developer knock-outs (MIVI_KNOCK): 1 no loads after the prologue, 2 no MFMAs, 4 no loads at all
   // Stein mode of k_fr_vjp64 (the whole product eps G^T, A = eps, B = G): see stein_epilogue
@@ -65,22 +61,6 @@ struct GemmArgs {
   int st_first;      // first chunk: overwrite instead of accumulate
   float st_scale;    // 1 / n on the last chunk
   double st_n;
-};
-
-struct ReduceArgs {
-  int d, M, dP, mode;
-  const float *slab;
-  const int2 *tiles;     // per macro-tile (rb*ncb + cb): .x first slab, .y slab count
-  int ncb;
-  int zero_slab;         // an all-zero slab (unconditional loads beyond a tile's slab count)
-  const float *params;
-  const float *t_mean, *t_istd;
-  float *Z;              // optional sample output, ld = d
-  float *W;              // ld = d
-  float *R;              // Z - t_mean, ld = dP (dense target)
-  double *ell_part;      // per-workgroup partial of sum_m ell_m
-  double *ld_part;       // [2][d/64] log-determinant partials, non-positive counts (or nullptr)
-  long long *dbg;
 };
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -249,19 +229,7 @@ __device__ __forceinline__ void stein_epilogue(const GemmArgs &a, const float *C
   }
 }
 
-// -----------------------------------------------------------------------------------------------------------------
-// k_fr_gemm: one BM x BN macro-tile (or one k-range of it) per workgroup.
-//   waves: (BM/WM) x (BN/WN) x KW; every wave holds (WM/32) x (WN/32) accumulators of 32x32; the KW wave groups split
-//   each BK-stage's k range.
-//   Staging is direct-to-LDS (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of NBUF stage
-//   buffers, NBUF-1 stages in flight: the wait for stage s is a counted vmcnt (never 0 inside the loop), followed by ONE
-//   raw s_barrier per stage; the buffer freed by stage s-1 is re-issued right behind that barrier.
-//   LDS-DMA writes lane-linear 1 KiB pieces, so the images are linear in the order the lanes fetch:
-//     As[k][BM]                      (row-major operand: a piece = 256/BM consecutive k)
-//     Bs[k][BN]                      (vjp: eps rows)
-//     Bs[n][BK], 16-byte chunk c of row n stored at chunk position c ^ ((n >> 1) & 7)   (k-major operand, BK = 32):
-//                                    the swizzle sits on the SOURCE address and on the b128 fragment read.
-// -----------------------------------------------------------------------------------------------------------------
+// direct-to-LDS load of 16 bytes per lane (LDS-DMA): lane-linear 1 KiB pieces, no staging registers, no ds_write pass
 #define MIVI_GLDS16(gptr, lptr)                                                                            \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                 \
                                    (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
@@ -270,283 +238,6 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-// wait until at most `stages` whole stages (L loads each) of this wave's LDS-DMA are still in flight
-template <int L>
-__device__ __forceinline__ void wait_stages(int stages) {
-  static_assert(7 * L <= 63, "vmcnt is a 6-bit counter");
-  switch (stages) {
-    case 0: wait_vmcnt<0>(); break;
-    case 1: wait_vmcnt<L>(); break;
-    case 2: wait_vmcnt<2 * L>(); break;
-    case 3: wait_vmcnt<3 * L>(); break;
-    case 4: wait_vmcnt<4 * L>(); break;
-    case 5: wait_vmcnt<5 * L>(); break;
-    case 6: wait_vmcnt<6 * L>(); break;
-    default: wait_vmcnt<7 * L>(); break;
-  }
-}
-
-template <int MODE, int BM, int BN, int WM, int WN, int KW, int BK, int NBUF, bool FUSED>
-__global__ __launch_bounds__((BM / WM) * (BN / WN) * KW * 64) void k_fr_gemm(GemmArgs a) {
-  // Every scalar argument the main path needs, fetched in ONE batch: hipcc otherwise sinks each s_load to its first use, and
-  // every such use is a scalar-cache miss (the cache is invalidated at kernel start) on the critical path of every workgroup.
-  {
-    const unsigned long long pA = (unsigned long long)a.A, pB = (unsigned long long)a.B, pW = (unsigned long long)a.work,
-                             pS = (unsigned long long)a.slab, pP = (unsigned long long)a.params, pD = (unsigned long long)a.dbg,
-                             pG = (unsigned long long)a.out.grad, pQ = (unsigned long long)a.out.partials;
-    asm volatile("" ::"s"(pA), "s"(pB), "s"(pW), "s"(pS), "s"(pP), "s"(pD), "s"(pG), "s"(pQ), "s"(a.d), "s"(a.lda), "s"(a.ldb),
-                 "s"(a.n_work), "s"(a.knock), "s"(a.out.partials_mode), "s"(a.out.ent_kind), "s"(a.out.M_total));
-  }
-  constexpr int NWM = BM / WM, NWN = BN / WN, NW = NWM * NWN * KW, NT = NW * 64;
-  constexpr int MI = WM / 32, NI = WN / 32;
-  constexpr bool BKM = (MODE != G_VJP);            // B operand is k-major in memory
-  constexpr int A_STAGE = BK * BM, B_STAGE = BK * BN;
-  constexpr int STAGE = A_STAGE + B_STAGE;
-  constexpr int NA = A_STAGE / 256 / NW, NB = B_STAGE / 256 / NW;   // 1 KiB pieces per wave and stage
-  constexpr int KROWS_A = 256 / BM;                  // k rows of As per piece
-  constexpr int KPW = BK / KW;                      // k range of one wave inside a stage
-  constexpr int LDC = BM + 4;
-  constexpr int EPI = KW * BN * LDC + (MODE == G_VJP ? (NT / BM) * BM : 0);
-  constexpr int MAIN = (NBUF * STAGE > EPI) ? NBUF * STAGE : EPI;
-  static_assert(NA >= 1 && NB >= 1 && KPW % 8 == 0 && NBUF >= 2 && NBUF <= 9, "tile geometry");
-  static_assert(!BKM || BK == 32, "k-major operand image: 128-byte rows");
-  static_assert(NT % BM == 0, "row-sum pass geometry");
-  // ONE LDS object (a second one makes hipcc drain the LDS-DMA queue before every fragment read)
-  __shared__ __attribute__((aligned(16))) float lds[MAIN + 2 * NW + 4];
-  double *red = reinterpret_cast<double *>(lds + MAIN);
-  float *adam_cc = lds + MAIN + 2 * NW;
-
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w % NWM, wn = (w / NWM) % NWN, kw = w / (NWM * NWN);
-  const int d = a.d;
-
-  if (MODE == G_VJP && (int)blockIdx.x == a.n_work) {   // objective value of THIS estimate (everything it sums is older)
-    const float *pp = a.params;
-    finalize_value_block<float, NT, false>(d, a.self_vin, a.self_out, (int64_t)d + (int64_t)d * d,
-                                           [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, reinterpret_cast<double *>(lds));   // (scratch: the idle staging area)
-    return;
-  }
-  if (MODE == G_SAMPLE && a.n_items > 0 && (int)blockIdx.x >= a.n_items) {
-    // eps(t+1): one Philox block per thread = rows gi..gi+3 of column gm, the same stream as k_eps.  Pure VALU work that runs
-    // on the CUs while the tile workgroups wait for their operands and while their waves sit in MFMA chains.
-    const SampleArgs<float> &n = a.next_eps;
-    constexpr int CPB = NT / 16;   // columns per block
-    const int eb = blockIdx.x - a.n_items, nrb = d >> 6;
-    const int gi = (eb % nrb) * 64 + 4 * (tid & 15), gm = (eb / nrb) * CPB + (tid >> 4);
-    float e[4];
-    eps_block<float>(n.rng.seed, rng_index(n.rng), (uint64_t)(n.rng.m_offset + gm) * (uint64_t)(d >> 2) + (uint64_t)(gi >> 2), e);
-    const f32x4 ev = {e[0], e[1], e[2], e[3]};
-    store16_wt(n.eps + (size_t)gm * n.ld_eps + gi, ev);
-    const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
-    const double sh = block_sum_nodrain_f32<NT>(he, red);   // (behind write-through stores: see block_sum_nodrain)
-    if (tid == 0) n.he_part[eb] = sh;
-    return;
-  }
-  MIVI_STAMP_K(a.dbg, MODE, 0);
-  // the work item through the scalar cache (constant address space => s_load_dwordx4), not a vector-memory round trip
-  const __attribute__((address_space(4))) int *wp = (const __attribute__((address_space(4))) int *)a.work + 4 * blockIdx.x;
-  const int4 wk = make_int4(wp[0], wp[1], wp[2], wp[3]);
-  asm volatile("" ::"s"(wk.x), "s"(wk.y), "s"(wk.z), "s"(wk.w));   // one s_load_dwordx4, not one load per field at its first use
-  const int rb = wk.x & 0xffff, cb = wk.x >> 16;
-  const int s_beg = wk.y & 0xffff, s_end = wk.y >> 16;
-  const int row0 = rb * BM, col0 = cb * BN;
-  const int ns = s_end - s_beg;
-  const bool mu_tile = (MODE == G_VJP) && (wk.w & 2);
-
-  // this wave's sub-tile lies strictly above the diagonal: nothing to accumulate (it still stages and synchronises)
-  const bool skip = (MODE == G_VJP) && (row0 + wm * WM + WM - 1 < col0 + wn * WN);
-
-  f32x16 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-  float rsum = 0.f;
-
-  // ---- staging: per-lane source pointers of this wave's first A / B piece of stage 0 ------------------------------------
-  const float *Ag = a.A + row0 + (4 * lane) % BM + (size_t)(s_beg * BK + w * KROWS_A + (4 * lane) / BM) * a.lda;
-  const float *Bg;
-  size_t b_piece, b_stage;   // element strides between this wave's successive pieces / between stages
-  if (BKM) {
-    constexpr int NROWS = 256 / BK;   // n rows per piece (8)
-    const int n = w * NROWS + lane / (BK / 4);
-    const int c = (lane % (BK / 4)) ^ ((n >> 1) & 7);
-    Bg = a.B + (size_t)s_beg * BK + 4 * c + (size_t)(col0 + n) * a.ldb;
-    b_piece = (size_t)(NW * NROWS) * a.ldb;
-    b_stage = BK;
-  } else {
-    constexpr int KROWS_B = 256 / BN;
-    Bg = a.B + col0 + (4 * lane) % BN + (size_t)(s_beg * BK + w * KROWS_B + (4 * lane) / BN) * a.ldb;
-    b_piece = (size_t)(NW * KROWS_B) * a.ldb;
-    b_stage = (size_t)BK * a.ldb;
-  }
-  const size_t a_piece = (size_t)(NW * KROWS_A) * a.lda, a_stage = (size_t)BK * a.lda;
-
-  auto issue_piece = [&](int s, int p) {   // piece p (0 .. NA+NB-1, compile-time after unrolling) of stage s -> ring buffer s % NBUF
-    float *dst = lds + (s % NBUF) * STAGE + w * 256;
-    if (p < NA) MIVI_GLDS16(Ag + (size_t)s * a_stage + p * a_piece, dst + p * (NW * 256));
-    else MIVI_GLDS16(Bg + (size_t)s * b_stage + (p - NA) * b_piece, dst + A_STAGE + (p - NA) * (NW * 256));
-  };
-  auto issue = [&](int s) {
-#pragma unroll
-    for (int p = 0; p < NA + NB; ++p) issue_piece(s, p);
-  };
-
-  // fragment addressing (floats): A row of this lane, B column of this lane
-  const int a_off = wm * WM + l31;
-  int b_row[NI], b_swz[NI];
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int n = wn * WN + ni * 32 + l31;
-    b_row[ni] = BKM ? n * BK : n;
-    b_swz[ni] = h ^ ((n >> 1) & 7);
-  }
-
-  // fragment reads of stage s, then its MFMA chain; do_issue: the LDS-DMA pieces of stage s_issue ride between the MFMAs
-  // (an in-order wave issues them while the matrix pipe works; issued ahead of the chain they would delay both waves of the SIMD)
-  auto compute = [&](int s, auto do_issue, int s_issue) {
-    const float *As = lds + (s % NBUF) * STAGE, *Bs = As + A_STAGE;
-    if (MODE == G_VJP && mu_tile) {   // d/dmu: row sums of W, this thread's share of the stage
-      const float *p = As + (tid / BM) * (BK / (NT / BM)) * BM + tid % BM;
-#pragma unroll
-      for (int k = 0; k < BK / (NT / BM); ++k) rsum += p[k * BM];
-    }
-    if (skip) {
-      if (decltype(do_issue)::value) issue(s_issue);
-      return;
-    }
-    const int k0 = (s_beg + s) * BK;
-    const bool diag = (MODE == G_SAMPLE) && (k0 >= row0);   // stage inside the diagonal block of tril(C): keep k <= i only
-    const float *Ar = As + a_off;
-    // all fragment reads of this wave's k range first (KPW A values, KPW B values per sub-tile), then the MFMA chain:
-    // the other wave of the SIMD computes while these are in flight
-    float av[KPW / 8][4][MI], bv[KPW / 8][4][NI];
-#pragma unroll
-    for (int s8 = 0; s8 < KPW / 8; ++s8) {
-      const int kb = kw * KPW + 8 * s8 + 4 * h;
-      if (BKM) {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const f32x4 bq = *(const f32x4 *)(Bs + b_row[ni] + 4 * (((kw * KPW + 8 * s8) >> 2) ^ b_swz[ni]));
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bv[s8][j][ni] = bq[j];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) av[s8][j][mi] = Ar[(kb + j) * BM + mi * 32];
-        if (!BKM) {
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) bv[s8][j][ni] = Bs[(kb + j) * BN + b_row[ni]];
-        }
-      }
-    }
-    if (diag) {
-#pragma unroll
-      for (int s8 = 0; s8 < KPW / 8; ++s8)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-            if (k0 - row0 + kw * KPW + 8 * s8 + 4 * h + j > a_off + mi * 32) av[s8][j][mi] = 0.f;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s8 = 0; s8 < KPW / 8; ++s8)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s8][j][mi], bv[s8][j][ni], acc[mi][ni], 0, 0, 0);
-        if (decltype(do_issue)::value && 4 * s8 + j < NA + NB) {
-          issue_piece(s_issue, 4 * s8 + j);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    if (decltype(do_issue)::value) {
-#pragma unroll
-      for (int p = KPW / 2; p < NA + NB; ++p) issue_piece(s_issue, p);
-    }
-  };
-
-  if (a.knock & 8) return;    // developer knock-out: entry cost only
-  // ---- main loop ---------------------------------------------------------------------------------------------------------
-  constexpr int L = NA + NB;
-  if (FUSED && a.upd.rule == 1 && tid == 0)
-    adam_bias<float>(a.upd.t_base + (a.upd.t_ptr ? *a.upd.t_ptr : 0), a.upd.b1, a.upd.b2, adam_cc[0], adam_cc[1]);
-  if (ns <= NBUF) {
-    // the whole k range fits the ring (every north-star shape): all pieces in flight at once, ONE wait, ONE barrier, then an
-    // uninterrupted MFMA chain -- per-stage barriers re-synchronise the two waves of a SIMD and cost more than the overlap buys
-    if (!(a.knock & 4))
-      for (int s = 0; s < ns; ++s) issue(s);
-    wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    MIVI_STAMP_K(a.dbg, MODE, 1);
-    if (a.dbg && tid == 0 && blockIdx.x < 4096) a.dbg[((size_t)MODE * 4096 + blockIdx.x) * 8 + 5] = clock64();
-    if (!(a.knock & 2))
-      for (int s = 0; s < ns; ++s) compute(s, std::false_type{}, 0);
-  } else {
-    const int npre = NBUF - 1;
-    if (!(a.knock & 4))
-      for (int s = 0; s < npre; ++s) issue(s);
-    for (int s = 0; s < ns; ++s) {
-      const int issued = (s + NBUF - 1 < ns) ? s + NBUF - 1 : ns;   // stages issued so far
-      wait_stages<L>(issued - (s + 1));
-      __builtin_amdgcn_s_barrier();       // stage s has landed for every wave; every wave is done with stage s-1
-      if (s == 0) {
-        MIVI_STAMP_K(a.dbg, MODE, 1);
-        if (a.dbg && tid == 0 && blockIdx.x < 4096) a.dbg[((size_t)MODE * 4096 + blockIdx.x) * 8 + 5] = clock64();
-      }
-      if (s + NBUF - 1 < ns && !(a.knock & 5)) issue(s + NBUF - 1);
-      if (!(a.knock & 2)) compute(s, std::false_type{}, 0);
-    }
-  }
-  __builtin_amdgcn_s_barrier();   // every wave is done reading the stage buffers: they become the epilogue image
-  MIVI_STAMP_K(a.dbg, MODE, 2);
-  if (a.dbg && tid == 0 && blockIdx.x < 4096) a.dbg[((size_t)MODE * 4096 + blockIdx.x) * 8 + 6] = clock64();
-
-  if (a.knock & 16) return;   // developer knock-out: no epilogue
-  // ---- accumulators -> LDS image Cs[kw][n][LDC] (rows contiguous) ---------------------------------------------------
-  float *Cs = lds;
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
-        *(f32x4 *)(Cs + (kw * BN + wn * WN + ni * 32 + l31) * LDC + wm * WM + mi * 32 + 8 * q + 4 * h) = v;
-      }
-  float *rs_lds = lds + KW * BN * LDC;   // [NT/BM][BM] partial row sums of A (vjp, d/dmu tiles)
-  if (MODE == G_VJP && mu_tile) rs_lds[tid] = rsum;
-  lds_barrier();
-  MIVI_STAMP_K(a.dbg, MODE, 3);
-
-  if (a.knock & 32) return;   // developer knock-out: no global stores
-  constexpr int NE = BM * BN / 4 / NT;   // float4 groups per thread
-  if (MODE != G_VJP) {
-    float *dst = a.slab + (size_t)wk.z * (BM * BN);
-#pragma unroll
-    for (int u = 0; u < NE; ++u) {
-      const int e = tid + u * NT, i4 = 4 * (e % (BM / 4)), n = e / (BM / 4);
-      f32x4 v = *(const f32x4 *)(Cs + n * LDC + i4);
-#pragma unroll
-      for (int k2 = 1; k2 < KW; ++k2) v += *(const f32x4 *)(Cs + (k2 * BN + n) * LDC + i4);
-      store16_wt(dst + n * BM + i4, v);
-    }
-    MIVI_STAMP_K(a.dbg, MODE, 4);
-    return;
-  }
-
-  vjp_epilogue<BM, BN, KW, NT, FUSED>(a, Cs, rs_lds, adam_cc, wk, row0, col0);
-}
-
 // -----------------------------------------------------------------------------------------------------------------
 // f32 products on the bf16 matrix cores ("bf16x3"): every f32 operand is split EXACTLY into three bf16 pieces
 // (x = hi + mid + lo: 8 + 8 + 8 significand bits, by truncation, all of one sign) and a 32 x 32 x 16 product block is the six
@@ -634,7 +325,7 @@ __global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) {
   const int row0 = rb * BM, col0 = cb * BN;
   const bool mu_tile = (wk.w & 2);
   const int Kq = a.M / KW, nsub = Kq / SUB;   // this wave's k range: [w * Kq, (w + 1) * Kq), in sub-stages of 16
-  if (a.dbg && tid == 0 && blockIdx.x < 4096) a.dbg[((size_t)G_VJP * 4096 + blockIdx.x) * 8 + 7] = wk.x;
+  MIVI_DEV_ONLY(if (a.dbg && tid == 0 && blockIdx.x < 4096) a.dbg[((size_t)G_VJP * 4096 + blockIdx.x) * 8 + 7] = wk.x;)
 
   if (FUSED && a.upd.rule == 1 && tid == 0)
     adam_bias<float>(a.upd.t_base + (a.upd.t_ptr ? *a.upd.t_ptr : 0), a.upd.b1, a.upd.b2, adam_cc[0], adam_cc[1]);
@@ -660,7 +351,7 @@ __global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) {
   // a wave that is requesting operands outranks the waves already inside their MFMA chains (which only need an issue slot
   // now and then): without this the youngest workgroup of a CU gets its first data after the older ones are done
   __builtin_amdgcn_s_setprio(3);
-  if (!(a.knock & 4))
+  if (!MIVI_KNOCKED(a, 4))
     for (int t = 0; t < RING && t < nsub; ++t) issue(t);
   // workgroups beyond two per CU (dispatch order = block order) arrive last and are the youngest waves of their SIMD: age
   // arbitration would give them the matrix pipe only after the older two are done -- let them go first instead
@@ -681,12 +372,12 @@ __global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this ring slot is free again before it is requested anew
     if (t == 0) MIVI_STAMP_K(a.dbg, G_VJP, 1);
-    if (t + RING < nsub && !(a.knock & 4)) issue(t + RING);
+    if (t + RING < nsub && !MIVI_KNOCKED(a, 4)) issue(t + RING);
     if (mu_tile) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) rsum += av[i];
     }
-    if (!(a.knock & 2)) {
+    if (!MIVI_KNOCKED(a, 2)) {
       if (BF3) {
 #pragma unroll
         for (int g = 0; g < NV / 8; ++g) mfma_bf16x3(av + 8 * g, bv + 8 * g, acc);
@@ -698,7 +389,7 @@ __global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) {
   }
   __builtin_amdgcn_s_barrier();   // every wave is done with its buffer: LDS becomes the epilogue image
   MIVI_STAMP_K(a.dbg, G_VJP, 2);
-  if (a.knock & 16) return;
+  if (MIVI_KNOCKED(a, 16)) return;
   float *Cs = lds;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -709,7 +400,7 @@ __global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) {
   if (mu_tile) rs_lds[(2 * w + h) * BM + l31] = rsum;
   lds_barrier();
   MIVI_STAMP_K(a.dbg, G_VJP, 3);
-  if (a.knock & 32) return;
+  if (MIVI_KNOCKED(a, 32)) return;
   vjp_epilogue<BM, BN, KW, NT, FUSED>(a, Cs, rs_lds, adam_cc, wk, row0, col0);
 }
 
@@ -760,7 +451,7 @@ __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
   const bool col_tile = STEIN && rb == 0;   // column sums of the B operand (G)
   const int nsub = a.M / SUB;
   const int t_beg = (w * nsub) / KW, t_end = ((w + 1) * nsub) / KW;   // this wave's run of sub-stages
-  if (a.dbg && tid == 0 && blockIdx.x < 4096) a.dbg[((size_t)G_VJP * 4096 + blockIdx.x) * 8 + 7] = wk.x;
+  MIVI_DEV_ONLY(if (a.dbg && tid == 0 && blockIdx.x < 4096) a.dbg[((size_t)G_VJP * 4096 + blockIdx.x) * 8 + 7] = wk.x;)
 
   if (FUSED && a.upd.rule == 1 && tid == 0)
     adam_bias<float>(a.upd.t_base + (a.upd.t_ptr ? *a.upd.t_ptr : 0), a.upd.b1, a.upd.b2, adam_cc[0], adam_cc[1]);
@@ -790,7 +481,7 @@ __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float rsum[2] = {0.f, 0.f};   // row sums of A (d/dmu tiles) / column sums of B (Stein mode)
   __builtin_amdgcn_s_setprio(3);
-  if (t_beg < t_end && !(a.knock & 4)) issue(t_beg);
+  if (t_beg < t_end && !MIVI_KNOCKED(a, 4)) issue(t_beg);
   __builtin_amdgcn_s_setprio(0);
   for (int t = t_beg; t < t_end; ++t) {
     wait_vmcnt<0>();
@@ -806,7 +497,7 @@ __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer is free again before it is requested anew
     if (t == t_beg) MIVI_STAMP_K(a.dbg, G_VJP, 1);
-    if (t + 1 < t_end && !(a.knock & 4)) issue(t + 1);
+    if (t + 1 < t_end && !MIVI_KNOCKED(a, 4)) issue(t + 1);
     if (mu_tile) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) { rsum[0] += av[0][i]; rsum[1] += av[1][i]; }
@@ -815,7 +506,7 @@ __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) { rsum[0] += bv[0][i]; rsum[1] += bv[1][i]; }
     }
-    if (!(a.knock & 2)) {
+    if (!MIVI_KNOCKED(a, 2)) {
       if (BF3) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {   // two K = 16 groups per sub-stage; every operand half is split ONCE for its two tiles
@@ -851,7 +542,7 @@ __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
   }
   __builtin_amdgcn_s_barrier();   // every wave is done with its buffer: LDS becomes the epilogue image
   MIVI_STAMP_K(a.dbg, G_VJP, 2);
-  if (a.knock & 16) return;
+  if (MIVI_KNOCKED(a, 16)) return;
   float *Cs = lds;   // Cs[kw][n (64 eps rows = tile columns)][LDC]: rows of the tile contiguous
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -872,7 +563,7 @@ __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
   }
   lds_barrier();
   MIVI_STAMP_K(a.dbg, G_VJP, 3);
-  if (a.knock & 32) return;
+  if (MIVI_KNOCKED(a, 32)) return;
   if (STEIN) stein_epilogue<BM, BN, KW, NT>(a, Cs, rs_lds, col_tile, row0, col0);
   else vjp_epilogue<BM, BN, KW, NT, FUSED>(a, Cs, rs_lds, adam_cc, wk, row0, col0);
 }
@@ -885,7 +576,7 @@ __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
 //   R_DIAG: W = grad log pi(z), ell partial      R_DENSE_R: R = z - m (k-major operand of the dense product)
 //   R_DENSE_G: W = g, ell += r g / 2              R_PLAIN: Z = z
 // so no slab, no reduce kernel and no second kernel boundary sits between the draw and the VJP.  The heaviest tile (K = d)
-// bounds the kernel (d/32 sub-stages on one CU); shapes where that is too long take the split-K route (k_fr_gemm + k_fr_reduce).
+// bounds the kernel (d/32 sub-stages on one CU); shapes where that is too long take the 64 x 64 kernel (k_fr_prod64).
 // Trailing workgroups draw eps of the next estimate; the first column block's workgroups leave the log-det partials.
 // -----------------------------------------------------------------------------------------------------------------
 struct Prod32Args {
@@ -970,7 +661,7 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
   // blocks of class rb % 4 == xr and the column blocks of class cb % 2 == xc: an A row panel comes over the fabric twice and a
   // B column panel four times (8 MB at the north star) instead of A eight times (17 MB with cb = b % 8).
   int rb, cb;
-  if (!(a.knock & 8) && (nrb & 3) == 0 && (a.ncb & 1) == 0) {
+  if (!MIVI_KNOCKED(a, 8) && (nrb & 3) == 0 && (a.ncb & 1) == 0) {
     const int x = bid & 7, j = bid >> 3, hc = a.ncb >> 1;
     rb = nrb - 1 - (4 * (j / hc) + (x & 3));
     cb = 2 * (j % hc) + (x >> 2);
@@ -1048,7 +739,7 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
       for (int i = 0; i < 16; ++i)
         if (8 * (i >> 2) + 4 * h + (i & 3) > l31) av[i] = 0.f;
     }
-    if (!(a.knock & 2)) {
+    if (!MIVI_KNOCKED(a, 2)) {
       if (BF3) {
         float bv[16];
 #pragma unroll
@@ -1132,8 +823,8 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
 // range into contiguous runs of 32-k sub-stages, every wave stages its OWN 64 rows of A ([k][64 rows], the VJP kernel's image) and
 // 64 columns of B (k-major source: [column][32 k] with the 16-byte chunks XOR-swizzled, k_fr_prod32's image), 16 KiB per wave, holds
 // the tile's four 32 x 32 accumulators and splits every operand element into bf16 pieces once for two MFMA tiles; no workgroup
-// barrier before the epilogue, no partial slabs, no reduce kernel (k_fr_gemm + k_fr_reduce: 87 TF f32-equivalent at 8192 x 2048
-// against the 152 TF of the VJP kernel with this structure).  Tiles heaviest first (K = 64 (rb + 1) for the triangular product).
+// barrier before the epilogue, no partial slabs, no reduce kernel (the split-K route of round 2 reached 87 TF f32-equivalent at
+// 8192 x 2048 against the 152 TF of the VJP kernel with this structure).  Tiles heaviest first (K = 64 (rb + 1) for the triangular product).
 // Trailing workgroups draw eps of the next estimate.
 // -----------------------------------------------------------------------------------------------------------------
 template <int MODE, bool BF3>
@@ -1338,130 +1029,15 @@ __global__ __launch_bounds__(512) void k_fr_prod64(Prod32Args a) {
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// k_fr_reduce: deterministic split-K reduction on the kernel boundary + everything elementwise that follows it.
-//   workgroup = 64 rows x 16 sample columns of one 64x64 macro-tile, thread = 4 rows of one column.
-//   R_DIAG   : z = mu + sum slabs; u = (z - m) / s; ell -= u^2 / 2; W = -u / s
-//   R_DENSE_R: R = z - m  (k-major operand of the dense product, ld = dP)
-//   R_DENSE_G: g = -sum slabs; ell += r g / 2; W = g
-//   R_PLAIN  : Z = z
-//   + the log-determinant partials (the VJP kernel may already be updating C when the value is assembled).
-// -----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fr_reduce(ReduceArgs a) {
-  __shared__ double red[4];
-  {   // every scalar argument in one batch (see k_fr_gemm)
-    const unsigned long long p0 = (unsigned long long)a.slab, p1 = (unsigned long long)a.tiles, p2 = (unsigned long long)a.params,
-                             p3 = (unsigned long long)a.t_mean, p4 = (unsigned long long)a.t_istd, p5 = (unsigned long long)a.Z,
-                             p6 = (unsigned long long)a.W, p7 = (unsigned long long)a.R, p8 = (unsigned long long)a.ell_part,
-                             p9 = (unsigned long long)a.ld_part, p10 = (unsigned long long)a.dbg;
-    asm volatile("" ::"s"(p0), "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5), "s"(p6), "s"(p7), "s"(p8), "s"(p9), "s"(p10), "s"(a.d),
-                 "s"(a.dP), "s"(a.mode), "s"(a.ncb), "s"(a.zero_slab));
-  }
-  const int tid = threadIdx.x;
-  const int d = a.d;
-  const int nsub = 4;   // 16-column sub-blocks per macro-tile column block
-  const int rb = blockIdx.x / (a.ncb * nsub), rem = blockIdx.x % (a.ncb * nsub);
-  const int cb = rem / nsub, sub = rem % nsub;
-  const int i4 = 4 * (tid & 15), nl = sub * 16 + (tid >> 4);
-  const int gi = rb * 64 + i4, gm = cb * 64 + nl;
-  const __attribute__((address_space(4))) int *tp = (const __attribute__((address_space(4))) int *)a.tiles + 2 * (rb * a.ncb + cb);
-  const int first = tp[0], count = tp[1];   // scalar loads
-  const float *sp = a.slab + nl * 64 + i4;
-  MIVI_STAMP_K(a.dbg, 3, 0);
-
-  // everything that does not depend on the slab sum is requested first: one memory round trip for the whole workgroup
-  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, tm = mu, tis = mu, r = mu;
-  if (a.mode == R_DENSE_G) {
-    r = *(const f32x4 *)(a.R + (size_t)gm * a.dP + gi);
-  } else {
-    mu = *(const f32x4 *)(a.params + gi);
-    if (a.mode == R_DIAG || a.mode == R_DENSE_R) tm = *(const f32x4 *)(a.t_mean + gi);
-    if (a.mode == R_DIAG) tis = *(const f32x4 *)(a.t_istd + gi);
-  }
-  float cii = 1.f;
-  const bool ld_blk = a.ld_part && cb == 0 && sub == 0 && tid < 64;
-  if (ld_blk) cii = a.params[d + (size_t)(rb * 64 + tid) * d + rb * 64 + tid];
-
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  for (int s0 = 0; s0 < count; s0 += 4) {   // fixed order; loads beyond the count read the all-zero slab
-    f32x4 t[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int sl = (s0 + u < count) ? first + s0 + u : a.zero_slab;
-      t[u] = *(const f32x4 *)(sp + (size_t)sl * 4096);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) v += t[u];
-  }
-
-  MIVI_STAMP_K(a.dbg, 3, 1);
-  float ell = 0.f;
-  if (a.mode == R_DENSE_G) {
-    f32x4 g = -v;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) ell += 0.5f * r[c] * g[c];
-    store16_wt(a.W + (size_t)gm * d + gi, g);
-  } else {
-    f32x4 z = mu + v;
-    if (a.Z) store16_wt(a.Z + (size_t)gm * d + gi, z);
-    if (a.mode == R_DIAG) {
-      f32x4 wv;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float u = (z[c] - tm[c]) * tis[c];
-        ell += -0.5f * u * u;
-        wv[c] = -u * tis[c];
-      }
-      store16_wt(a.W + (size_t)gm * d + gi, wv);
-    } else if (a.mode == R_DENSE_R) {
-      {
-        const f32x4 rz = z - tm;
-        store16_wt(a.R + (size_t)gm * a.dP + gi, rz);
-      }
-    }
-  }
-  MIVI_STAMP_K(a.dbg, 3, 2);
-  if (a.mode == R_DIAG || a.mode == R_DENSE_G) {
-    const double sl = block_sum_nodrain_f32<256>(ell, red);   // (behind write-through stores: see block_sum_nodrain)
-    if (tid == 0) a.ell_part[blockIdx.x] = sl;
-  }
-  if (ld_blk) {   // log|det C| partial of this 64-row block (wave 0)
-    float lg = logf(cii), bad = (cii > 0.f) ? 0.f : 1.f;
-    lg = wave_sum(lg);
-    bad = wave_sum(bad);
-    if (tid == 0) {
-      const int nb = d >> 6;
-      a.ld_part[rb] = (double)lg;
-      a.ld_part[nb + rb] = (double)bad;
-    }
-  }
-  MIVI_STAMP_K(a.dbg, 3, 3);
-}
-
-// -----------------------------------------------------------------------------------------------------------------
 // Host side: work lists
 // -----------------------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int kBM = 64, kBN = 64, kBK = 32;      // sample / dense macro-tile and stage
-constexpr int kVBM = 32, kVBN = 32, kVBK = 64;   // vjp tile (the four waves split every stage's k range)
+constexpr int kVBK = 64;   // vjp work item: k range in units of 64 (informational: the kernels derive their runs from M)
 
 struct Item {
   int rb, cb, s0, s1, slab, flags, cost;
 };
-
-// greedy list schedule of `costs` (in dispatch order) on `ncu` units: makespan
-long long makespan(const std::vector<int> &costs, int ncu) {
-  std::vector<long long> load(ncu, 0);   // min-heap on the load
-  auto cmp = [](long long x, long long y) { return x > y; };
-  for (int cst : costs) {
-    std::pop_heap(load.begin(), load.end(), cmp);
-    load.back() += cst;
-    std::push_heap(load.begin(), load.end(), cmp);
-  }
-  long long mx = 0;
-  for (long long l : load) mx = l > mx ? l : mx;
-  return mx;
-}
 
 // interleave 8 per-XCD lists so that workgroup b (observed to run on XCD b % 8) takes list b % 8's next item
 std::vector<Item> interleave8(std::vector<std::vector<Item>> &lists) {
@@ -1497,62 +1073,6 @@ std::vector<int4> pack(const std::vector<Item> &v) {
   std::vector<int4> t(v.size());
   for (size_t i = 0; i < v.size(); ++i) t[i] = make_int4(v[i].rb | (v[i].cb << 16), v[i].s0 | (v[i].s1 << 16), v[i].slab, v[i].flags);
   return t;
-}
-
-// split-K work list of a (possibly triangular) product: row block rb needs stages [0, stages(rb)).
-// Chunk length T (stages per workgroup) minimises the list-schedule makespan on the chip, each workgroup paying a fixed
-// prologue/epilogue overhead worth ~3 stages.
-void build_splitk(mivi_ctx *c, int nrb, int ncb, bool triangular, int full_stages, DevBuf &tab, DevBuf &tiles, int &n_items,
-                  int &n_slabs) {
-  const int NCU = 256, OVH = 3;
-  auto stages = [&](int rb) { return triangular ? std::min(full_stages, (rb + 1) * (kBM / kBK)) : full_stages; };
-  int bestT = 1;
-  long long bestMs = -1;
-  for (int T = 1; T <= full_stages; T += std::max(1, T / 8)) {   // ~25 candidates per decade
-    std::vector<int> costs;
-    for (int rb = nrb - 1; rb >= 0; --rb) {
-      const int S = stages(rb), nch = (S + T - 1) / T;
-      for (int ch = 0; ch < nch; ++ch) {
-        const int len = S / nch + (ch < S % nch ? 1 : 0);
-        for (int cb = 0; cb < ncb; ++cb) costs.push_back(len + OVH);
-      }
-    }
-    std::sort(costs.begin(), costs.end(), [](int x, int y) { return x > y; });
-    const long long ms = makespan(costs, NCU);
-    if (bestMs < 0 || ms < bestMs) { bestMs = ms; bestT = T; }
-  }
-  std::vector<int2> tl((size_t)nrb * ncb);
-  std::vector<std::vector<Item>> groups;   // the ncb column blocks of one (row block, chunk): they share the A operand
-  int slab = 0;
-  for (int rb = 0; rb < nrb; ++rb) {
-    const int S = stages(rb), nch = (S + bestT - 1) / bestT;
-    for (int cb = 0; cb < ncb; ++cb) tl[(size_t)rb * ncb + cb] = make_int2(slab + cb * nch, nch);
-    int s0 = 0;
-    for (int ch = 0; ch < nch; ++ch) {
-      const int len = S / nch + (ch < S % nch ? 1 : 0);
-      std::vector<Item> g;
-      for (int cb = 0; cb < ncb; ++cb) g.push_back(Item{rb, cb, s0, s0 + len, slab + cb * nch + ch, 0, len});
-      groups.push_back(g);
-      s0 += len;
-    }
-    slab += ncb * nch;
-  }
-  n_slabs = slab;
-  // longest groups first onto the least-loaded XCD list
-  std::sort(groups.begin(), groups.end(), [](const std::vector<Item> &x, const std::vector<Item> &y) { return x[0].cost > y[0].cost; });
-  std::vector<std::vector<Item>> lists(8);
-  std::vector<long long> load(8, 0);
-  for (auto &g : groups) {
-    int best = 0;
-    for (int x = 1; x < 8; ++x)
-      if (load[x] < load[best]) best = x;
-    for (auto &it : g) { lists[best].push_back(it); load[best] += it.cost; }
-  }
-  auto items = interleave8(lists);
-  n_items = (int)items.size();
-  auto packed = pack(items);
-  upload(c, tab, packed.data(), packed.size() * sizeof(int4));
-  upload(c, tiles, tl.data(), tl.size() * sizeof(int2));
 }
 
 void build_vjp(mivi_ctx *c, int d, int M, int tile, DevBuf &tab, int &n_items) {
@@ -1598,30 +1118,15 @@ bool lds_path_shape_ok(const mivi_ctx *c, int M) {
 static bool f32_mfma();
 static int knock_flags();
 
-// (re)build the work lists for M samples per launch; allocates the slab buffer
+// (re)build the VJP work lists for M samples per launch (the product kernels derive their tile from blockIdx)
 bool lds_prepare(mivi_ctx *c, int M) {
-  const bool dense = c->target == TGT_DENSE_GAUSS;
-  if (c->lds_M == M && c->lds_dense == dense && c->lds_tabS.p) return true;
-  invalidate_graph(c);   // a captured graph bakes the list contents, sizes and the slab pointer
-  const int d = c->cfg.d, nrb = d / kBM, ncb = M / kBN;
-  int slabs_s = 0, slabs_d = 0;
-  build_splitk(c, nrb, ncb, true, d / kBK, c->lds_tabS, c->lds_tilesS, c->lds_nS, slabs_s);
-  if (dense) build_splitk(c, nrb, ncb, false, d / kBK, c->lds_tabD, c->lds_tilesD, c->lds_nD, slabs_d);
+  if (c->lds_M == M && c->lds_tabV.p) return true;
+  invalidate_graph(c);   // a captured graph bakes the list contents and sizes
+  const int d = c->cfg.d;
   build_vjp(c, d, M, 32, c->lds_tabV, c->lds_nV);
   build_vjp(c, d, M, 64, c->lds_tabV64, c->lds_nV64);
-  const int ns = std::max(slabs_s, slabs_d) + 1;
-  const size_t bytes = (size_t)ns * kBM * kBN * sizeof(float);
-  if (c->lds_slab.bytes < bytes) {
-    if (c->lds_slab.p) (void)hipFree(c->lds_slab.p);
-    c->lds_slab.p = nullptr;
-    c->lds_slab.bytes = 0;
-    if (hipMalloc(&c->lds_slab.p, bytes) != hipSuccess) return false;
-    c->lds_slab.bytes = bytes;
-  }
-  c->lds_zero_slab = ns - 1;
-  (void)hipMemset((char *)c->lds_slab.p + (size_t)(ns - 1) * kBM * kBN * sizeof(float), 0, kBM * kBN * sizeof(float));
+  if (!c->lds_tabV.p || !c->lds_tabV64.p) return false;
   c->lds_M = M;
-  c->lds_dense = dense;
   return true;
 }
 
@@ -1672,65 +1177,23 @@ void launch_lds_stein_outer(mivi_ctx *c, int M, void *A, double *gsum, int first
   hipLaunchKernelGGL((k_fr_vjp64<false, true, true>), dim3(grid), dim3(512), 0, c->stream, a);
 }
 
-int lds_reduce_blocks(const mivi_ctx *c, int M) { return (c->cfg.d / 64) * (M / 64) * 4; }
 int lds_ld_blocks(const mivi_ctx *c) { return c->cfg.d / 64; }
 
-static int cfg_waves() {   // MIVI_LDS_WAVES=4: one wave per SIMD (A/B against the default two)
-  static const int v = getenv("MIVI_LDS_WAVES") ? atoi(getenv("MIVI_LDS_WAVES")) : 8;
-  return v;
-}
 static bool f32_mfma() {   // MIVI_FR_F32MFMA=1: v_mfma_f32_32x32x2_f32 chains instead of bf16x3 (A/B reference)
   static const bool v = getenv("MIVI_FR_F32MFMA") != nullptr;
   return v;
 }
-static int knock_flags() {
+static int knock_flags() {   // developer knock-outs (operand loads / MFMAs / epilogue / stores): -DMIVI_DEV builds only (make DEV=1)
+#ifdef MIVI_DEV
   static const int v = getenv("MIVI_KNOCK") ? atoi(getenv("MIVI_KNOCK")) : 0;
   return v;
+#else
+  return 0;
+#endif
 }
 
-// Z-partials = tril(C) eps over the split-K list
-int lds_eps_blocks(const mivi_ctx *c, int M) { return (c->cfg.d / 64) * (M / (cfg_waves() == 4 ? 16 : 32)); }
-
-void launch_lds_sample(mivi_ctx *c, const void *params, int M, const EpsJob *next) {
-  GemmArgs a{};
-  a.d = c->cfg.d; a.M = M; a.dP = c->dP;
-  a.A = (const float *)params + c->cfg.d; a.lda = c->cfg.d;
-  a.B = (const float *)c->eps[c->cur].p; a.ldb = c->dP;
-  a.work = (const int4 *)c->lds_tabS.p; a.n_work = 0x7fffffff;
-  a.slab = (float *)c->lds_slab.p;
-  a.dbg = c->dbg;
-  a.knock = knock_flags();
-  int grid = c->lds_nS;
-  if (next) {   // trailing workgroups draw eps of the next estimate
-    a.n_items = c->lds_nS;
-    a.next_eps.d = c->cfg.d;
-    a.next_eps.M = M;
-    a.next_eps.rng = next->rng;
-    a.next_eps.eps = (float *)c->eps[next->parity].p;
-    a.next_eps.ld_eps = c->dP;
-    a.next_eps.he_part = (double *)c->he_part[next->parity].p;
-    grid += lds_eps_blocks(c, M);
-  }
-  if (cfg_waves() == 4)
-    hipLaunchKernelGGL((k_fr_gemm<G_SAMPLE, kBM, kBN, 32, 32, 1, kBK, 4, false>), dim3(grid), dim3(256), 0, c->stream, a);
-  else
-    hipLaunchKernelGGL((k_fr_gemm<G_SAMPLE, kBM, kBN, 32, 32, 2, kBK, 5, false>), dim3(grid), dim3(512), 0, c->stream, a);
-}
-
-// G-partials = P (Z - m) over the split-K list (R = Z - m was left by the reduce kernel, ld = dP)
-void launch_lds_dense(mivi_ctx *c, int M) {
-  GemmArgs a{};
-  a.d = c->cfg.d; a.M = M; a.dP = c->dP;
-  a.A = (const float *)c->t_prec.p; a.lda = c->dP;
-  a.B = (const float *)c->RT.p; a.ldb = c->dP;
-  a.work = (const int4 *)c->lds_tabD.p; a.n_work = 0x7fffffff;
-  a.slab = (float *)c->lds_slab.p;
-  a.dbg = c->dbg;
-  if (cfg_waves() == 4)
-    hipLaunchKernelGGL((k_fr_gemm<G_DENSE, kBM, kBN, 32, 32, 1, kBK, 4, false>), dim3(c->lds_nD), dim3(256), 0, c->stream, a);
-  else
-    hipLaunchKernelGGL((k_fr_gemm<G_DENSE, kBM, kBN, 32, 32, 2, kBK, 5, false>), dim3(c->lds_nD), dim3(512), 0, c->stream, a);
-}
+// eps(t+1) rider blocks of the 64 x 64 product kernel: 512 threads = 64 rows x 32 columns each
+int lds_eps_blocks(const mivi_ctx *c, int M) { return (c->cfg.d / 64) * (M / 32); }
 
 // unsplit 32 x 32-tile product + fused epilogue (k_fr_prod32).  dense = false: Z = mu + tril(C) eps with `mode` in
 // {R_DIAG, R_DENSE_R, R_PLAIN}; dense = true: G = -P (Z - m) (mode R_DENSE_G, R = Z - m in c->RT).
@@ -1808,43 +1271,15 @@ void launch_lds_prod64(mivi_ctx *c, const void *params, int M, bool dense, int m
   else hipLaunchKernelGGL((k_fr_prod64<G_SAMPLE, true>), dim3(grid), dim3(512), 0, c->stream, a);
 }
 int lds_prod64_tiles(const mivi_ctx *c, int M) { return (c->cfg.d / 64) * (M / 64); }
-// beyond the 32 x 32 kernel's range (d n_mc > 1024 x 512: at least 128 tiles of 64 x 64) the 64 x 64 kernel; measured against the
-// split-K route it replaces: 1536 x 512 sample stage 25.4 -> 20.0 us, 2048 x 1024 59.3 -> 35.5 us, 4096 x 1024 206 -> 119 us
-// (145 TF f32-equivalent); at and below the boundary the 32 x 32 kernel wins (1024 x 512: 11.8 vs 14.7 us).  MIVI_PROD64=0: the
-// split-K route (k_fr_gemm + k_fr_reduce, A/B reference).
-bool lds_use_prod64(const mivi_ctx *c, int M) {
-  static const bool off = getenv("MIVI_PROD64") && atoi(getenv("MIVI_PROD64")) == 0;
-  return !off && !lds_use_prod32(c, M) && M % 64 == 0;
-}
+// beyond the 32 x 32 kernel's range (d n_mc > 1024 x 512: at least 128 tiles of 64 x 64) the 64 x 64 kernel; at and below the boundary
+// the 32 x 32 kernel wins (1024 x 512: 11.8 vs 14.7 us).  (The split-K slabs + reduce route these two replaced -- 1536 x 512 sample stage
+// 25.4 -> 20.0 us, 4096 x 1024 206 -> 119 us -- was removed in round 3: no default path reached it.)
+bool lds_use_prod64(const mivi_ctx *c, int M) { return !lds_use_prod32(c, M); }
 int lds_prod32_tiles(const mivi_ctx *c, int M) { return (c->cfg.d / 32) * (M / 32); }
 int lds_prod32_eps_blocks(const mivi_ctx *c, int M) { return (c->cfg.d / 64) * (M / 32); }
-// the unsplit product is bounded by its heaviest tile (d/32 sub-stages on one CU); beyond this the split-K route wins
+// the unsplit 32 x 32 product is bounded by its heaviest tile (d/32 sub-stages on one CU); beyond this the 64 x 64 kernel takes over
 bool lds_bf16x3() { return !f32_mfma(); }
-bool lds_use_prod32(const mivi_ctx *c, int M) {
-  static const int force = getenv("MIVI_LDS_SPLITK") ? atoi(getenv("MIVI_LDS_SPLITK")) : -1;   // 1: split-K always, 0: never
-  if (force >= 0) return force == 0;
-  return (long long)c->cfg.d * M <= 1024LL * 512;
-}
-
-// slab reduction + mu + target (+ eps of the next estimate, + log-det partials).  mode: R_*
-void launch_lds_reduce(mivi_ctx *c, const void *params, int M, int mode, void *Z, bool want_ld) {
-  ReduceArgs a{};
-  a.d = c->cfg.d; a.M = M; a.dP = c->dP; a.mode = mode;
-  a.slab = (const float *)c->lds_slab.p;
-  a.tiles = (const int2 *)(mode == R_DENSE_G ? c->lds_tilesD.p : c->lds_tilesS.p);
-  a.ncb = M / kBN;
-  a.zero_slab = c->lds_zero_slab;
-  a.params = (const float *)params;
-  a.t_mean = (const float *)c->t_mean.p;
-  a.t_istd = (const float *)c->t_istd.p;
-  a.Z = (float *)Z;
-  a.W = (float *)c->W.p;
-  a.R = (float *)c->RT.p;
-  a.ell_part = (double *)c->ell_part[c->cur].p;
-  a.ld_part = want_ld ? (double *)c->ld_part[c->cur].p : nullptr;
-  a.dbg = c->dbg;
-  hipLaunchKernelGGL(k_fr_reduce, dim3(lds_reduce_blocks(c, M)), dim3(256), 0, c->stream, a);
-}
+bool lds_use_prod32(const mivi_ctx *c, int M) { return (long long)c->cfg.d * M <= 1024LL * 512; }
 
 // tril(W eps^T) (+ d/dmu); self != nullptr: one trailing workgroup assembles this estimate's objective value
 void launch_lds_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const ValueJob *self, const FusedUpdate *upd) {

@@ -356,164 +356,11 @@ struct LrMfmaArgs {
 
 __device__ __forceinline__ float lr_softplus(float x) { return x > 0.f ? x + log1pf(expf(-x)) : log1pf(expf(x)); }
 
-// 256 rows x 128 samples per workgroup, 8 waves as 4 (rows) x 2 (samples), each 64 x 64
-__global__ __launch_bounds__(512) void k_lr_logits_mfma(LrMfmaArgs a) {
-  __shared__ float ll_lds[128];
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = w >> 1, wm = w & 1;
-  const long long r0 = (long long)blockIdx.x * 256 + wr * 64;
-  const int m0 = blockIdx.y * 128 + wm * 64;
-  if (tid < 128) ll_lds[tid] = 0.f;
-  __syncthreads();
-  // per-lane offsets: A rows (clamped), B columns (ZT is padded to a multiple of 64 columns)
-  const long long ra0 = min(r0 + l31, a.n - 1), ra1 = min(r0 + 32 + l31, a.n - 1);
-  const float *A0 = a.X + ra0, *A1 = a.X + ra1;
-  const float *B0 = a.ZT + m0 + l31, *B1 = a.ZT + m0 + 32 + l31;
-  lr_f32x16 c00, c01, c10, c11;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
-  const int p = a.p;
-  const int nst = (p + 15) / 16;
-  float xa0[8], xa1[8], xb0[8], xb1[8], ya0[8], ya1[8], yb0[8], yb1[8];
-  auto load_stage = [&](int st, float (&A0v)[8], float (&A1v)[8], float (&B0v)[8], float (&B1v)[8]) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int kk = st * 16 + 2 * u + h;
-      const int kc = min(kk, p - 1);
-      A0v[u] = A0[(size_t)kc * (size_t)a.n];
-      A1v[u] = A1[(size_t)kc * (size_t)a.n];
-      B0v[u] = B0[(size_t)kc * (size_t)a.ldz];
-      B1v[u] = B1[(size_t)kc * (size_t)a.ldz];
-    }
-  };
-  auto mma_stage = [&](int st, const float (&A0v)[8], const float (&A1v)[8], const float (&B0v)[8], const float (&B1v)[8]) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const bool ok = (st * 16 + 2 * u + h) < p;
-      const float x0 = ok ? A0v[u] : 0.f, x1 = ok ? A1v[u] : 0.f;
-      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, B0v[u], c00, 0, 0, 0);
-      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, B1v[u], c01, 0, 0, 0);
-      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, B0v[u], c10, 0, 0, 0);
-      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, B1v[u], c11, 0, 0, 0);
-    }
-  };
-  int st = 0;
-  load_stage(0, xa0, xa1, xb0, xb1);
-  while (true) {   // unconditional, clamped prefetch (see k_lr_logits_mfma_rm)
-    load_stage(min(st + 1, nst - 1), ya0, ya1, yb0, yb1);
-    mma_stage(st, xa0, xa1, xb0, xb1);
-    if (++st >= nst) break;
-    load_stage(min(st + 1, nst - 1), xa0, xa1, xb0, xb1);
-    mma_stage(st, ya0, ya1, yb0, yb1);
-    if (++st >= nst) break;
-  }
-  // epilogue: D element (row = (q&3) + 8*(q>>2) + 4*h, col = l31); rows are data rows, cols are samples
-  float ll0 = 0.f, ll1 = 0.f;   // samples m0 + l31 and m0 + 32 + l31
-  auto epi = [&](const lr_f32x16 &c, int rb, int mb, float &ll) {
-    const int m = m0 + mb * 32 + l31;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const long long r = r0 + rb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      if (r < a.n && m < a.M) {
-        const float yv = (float)a.y[r];
-        const float lg = c[q];
-        // one exp serves both: e = exp(-|x|); softplus = max(x,0) + log1p(e); sigmoid = x>=0 ? 1/(1+e) : e/(1+e)
-        const float e = __expf(-fabsf(lg));
-        const float inv = 1.f / (1.f + e);
-        ll += yv * lg - (fmaxf(lg, 0.f) + log1pf(e));
-        if (a.want_grad) a.R[(size_t)r * a.ldr + m] = yv - (lg >= 0.f ? inv : e * inv);
-      }
-    }
-  };
-  epi(c00, 0, 0, ll0);
-  epi(c10, 1, 0, ll0);
-  epi(c01, 0, 1, ll1);
-  epi(c11, 1, 1, ll1);
-  ll0 += __shfl_xor(ll0, 32, 64);
-  ll1 += __shfl_xor(ll1, 32, 64);
-  if (h == 0) {
-    atomicAdd(&ll_lds[wm * 64 + l31], ll0);
-    atomicAdd(&ll_lds[wm * 64 + 32 + l31], ll1);
-  }
-  __syncthreads();
-  if (tid < 128) {
-    const int m = blockIdx.y * 128 + tid;
-    if (m < a.M) a.ll_part[(size_t)blockIdx.x * a.M + m] = (double)ll_lds[tid];
-  }
-}
-
 typedef float lr_f32x4 __attribute__((ext_vector_type(4)));
 
-// Output G^T tile set: 128 samples x 256 features per workgroup (blockIdx.y = feature half... general: feature
-// group of 256), 8 waves as 2 (samples) x 4 (features), each 64 x 64; rows [rbeg, rend) of split blockIdx.x.
-__global__ __launch_bounds__(512) void k_lr_xtr_mfma(LrMfmaArgs a) {
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w >> 2, wk = w & 3;
-  const int m0 = blockIdx.z * 128 + wm * 64;
-  const int k0 = blockIdx.y * 256 + wk * 64;
-  const long long rbeg = (long long)blockIdx.x * a.rows_per_split;
-  const long long rend = min(a.n, rbeg + a.rows_per_split);
-  const float *A0 = a.R + m0 + l31, *A1 = a.R + m0 + 32 + l31;           // lanes along samples
-  const float *B0 = a.Xrm + k0 + l31, *B1 = a.Xrm + k0 + 32 + l31;       // lanes along features
-  const bool kvalid = k0 < a.ldx;                                         // feature group may exceed the padding
-  lr_f32x16 c00, c01, c10, c11;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
-  float xa0[8], xa1[8], xb0[8], xb1[8], ya0[8], ya1[8], yb0[8], yb1[8];
-  const long long nst = kvalid ? (rend - rbeg + 15) / 16 : 0;
-  auto load_stage = [&](long long st, float (&A0v)[8], float (&A1v)[8], float (&B0v)[8], float (&B1v)[8]) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const long long rr = min(rbeg + st * 16 + 2 * u + h, a.n - 1);
-      A0v[u] = A0[(size_t)rr * a.ldr];
-      A1v[u] = A1[(size_t)rr * a.ldr];
-      B0v[u] = B0[(size_t)rr * a.ldx];
-      B1v[u] = (k0 + 32 < a.ldx) ? B1[(size_t)rr * a.ldx] : 0.f;
-    }
-  };
-  auto mma_stage = [&](long long st, const float (&A0v)[8], const float (&A1v)[8], const float (&B0v)[8], const float (&B1v)[8]) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const bool ok = (rbeg + st * 16 + 2 * u + h) < rend;
-      const float x0 = ok ? A0v[u] : 0.f, x1 = ok ? A1v[u] : 0.f;
-      c00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, B0v[u], c00, 0, 0, 0);
-      c01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, B1v[u], c01, 0, 0, 0);
-      c10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, B0v[u], c10, 0, 0, 0);
-      c11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, B1v[u], c11, 0, 0, 0);
-    }
-  };
-  if (nst > 0) {
-    long long st = 0;
-    load_stage(0, xa0, xa1, xb0, xb1);
-    while (true) {   // unconditional, clamped prefetch (see k_lr_logits_mfma_rm)
-      load_stage(min(st + 1, nst - 1), ya0, ya1, yb0, yb1);
-      mma_stage(st, xa0, xa1, xb0, xb1);
-      if (++st >= nst) break;
-      load_stage(min(st + 1, nst - 1), xa0, xa1, xb0, xb1);
-      mma_stage(st, ya0, ya1, yb0, yb1);
-      if (++st >= nst) break;
-    }
-  }
-  // D: row = sample (m0 + mb*32 + rowidx), col = feature (k0 + kb*32 + l31): lanes along features -> contiguous stores
-  auto epi = [&](const lr_f32x16 &c, int mb, int kb) {
-    const int k = k0 + kb * 32 + l31;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int m = m0 + mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      if (k < a.p && m < a.M) a.g_part[((size_t)blockIdx.x * a.M + m) * a.p + k] = c[q];
-    }
-  };
-  epi(c00, 0, 0);
-  epi(c01, 0, 1);
-  epi(c10, 1, 0);
-  epi(c11, 1, 1);
-}
-
 // ---------------------------------------------------------------------------------------------
-// Second generation: operands staged through LDS.  What was measured on the first generation (MFMA pipe busy 48 % /
-// 63 %, PMC) and on register-pipelined variants of it:
+// f32-MFMA kernels with operands staged through LDS.  What was measured on their register-operand first generation (MFMA pipe busy
+// 48 % / 63 %, PMC; removed in round 3) and on register-pipelined variants of it:
 //   * a branch around the prefetch loads makes the compiler merge the s_waitcnt of both paths to the conservative one
 //     (it then waits for the loads it has just issued) -> prefetch must be unconditional on a clamped stage index;
 //   * without a scheduling barrier the machine scheduler sinks every prefetch load down to its first use
@@ -912,8 +759,7 @@ __device__ __forceinline__ void lr_split3s(const float (&v)[4], lr_bf16x4 &hi, l
 
 // NWK = waves along the feature axis: 4 -> 256-feature tile, 512 threads, one workgroup per CU (91 KB of LDS);
 // 2 -> 128-feature tile, 256 threads, 61 KB: two workgroups per CU that are not in barrier lock-step with each other (R is
-// then read by four feature groups instead of two).  Measured at C3: 880 us against 790 us for NWK = 4, which stays the
-// default; MIVI_LR_XTR_NARROW=1 selects NWK = 2.
+// then read by four feature groups instead of two).  Measured at C3: 880 us against 790 us for NWK = 4, the only one instantiated.
 template <int NWK, bool PART>
 __global__ __launch_bounds__(128 * NWK) void k_lr_xtr_bf16x3(LrMfmaArgs a) {
   constexpr int NT = 128 * NWK, KT = 64 * NWK, RN = 4 / NWK;   // threads, features per tile, R strips per thread
@@ -1210,7 +1056,6 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
   a.ZT = (const float *)c->RT.p;
   a.ldz = c->MP;
   a.ldr = (M + 63) / 64 * 64;
-  static const bool gen1 = getenv("MIVI_LR_GEN1") != nullptr;
   const int nrb = geo.nrb, S = geo.S;
   const long long rps = geo.rps;
   a.rows_per_split = rps;
@@ -1219,13 +1064,10 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
   a.R = (float *)c->lr_scratch.p;
   a.g_part = (float *)((char *)c->lr_scratch.p + need_R);
   a.ll_part = (double *)c->lr_part.p;
-  // MIVI_LR_GEN1=1 selects the first-generation (register-operand) kernels: the in-library A/B reference
   static const bool no_bf16x3 = getenv("MIVI_LR_F32_LOGITS") != nullptr;   // A/B: f32 MFMA logits
   a.Zcm = (const float *)c->Z.p;
   const bool part = M % 128 != 0 && M % 128 <= 96;   // whole 32-sample tiles of the last 128-sample group are empty
-  if (gen1)
-    hipLaunchKernelGGL(k_lr_logits_mfma, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
-  else if (a.d % 4 == 0 && a.d >= 4 && !no_bf16x3) {
+  if (a.d % 4 == 0 && a.d >= 4 && !no_bf16x3) {
     if (part) hipLaunchKernelGGL(k_lr_logits_bf16x3_part, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
     else hipLaunchKernelGGL(k_lr_logits_bf16x3, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
   } else {
@@ -1246,11 +1088,8 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
   if (want_grad) {
     const dim3 gx(S, (a.p + 255) / 256, (M + 127) / 128);
     static const bool xtr_f32 = getenv("MIVI_LR_F32_XTR") != nullptr;   // A/B: f32 MFMA X^T R
-    if (gen1) hipLaunchKernelGGL(k_lr_xtr_mfma, gx, dim3(512), 0, c->stream, a);
-    else if (!xtr_f32) {
-      static const bool narrow = getenv("MIVI_LR_XTR_NARROW") != nullptr;   // A/B: two 4-wave workgroups per CU (measured slower)
-      if (narrow) hipLaunchKernelGGL((k_lr_xtr_bf16x3<2, false>), dim3(S, (a.p + 127) / 128, (M + 127) / 128), dim3(256), 0, c->stream, a);
-      else if (part) hipLaunchKernelGGL((k_lr_xtr_bf16x3<4, true>), gx, dim3(512), 0, c->stream, a);
+    if (!xtr_f32) {
+      if (part) hipLaunchKernelGGL((k_lr_xtr_bf16x3<4, true>), gx, dim3(512), 0, c->stream, a);
       else hipLaunchKernelGGL((k_lr_xtr_bf16x3<4, false>), gx, dim3(512), 0, c->stream, a);
     }
     else hipLaunchKernelGGL(k_lr_xtr_mfma_lds, gx, dim3(512), 0, c->stream, a);

@@ -160,7 +160,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_S, &c->dist_F, &c->lds_tabS, &c->lds_tilesS, &c->lds_tabD, &c->lds_tilesD, &c->lds_tabV, &c->lds_tabV64, &c->lds_tabSt, &c->lds_slab, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_S, &c->dist_F, &c->lds_tabV, &c->lds_tabV64, &c->lds_tabSt, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -469,9 +469,9 @@ static bool lds_route(const mivi_ctx *c, const void *params, int M, int want_gra
 }
 
 // One estimate on the second-generation route:
-//   [k_eps unless the previous estimate's reduce kernel already drew this eps]
-//   k_fr_gemm<SAMPLE> (split-K slabs) -> k_fr_reduce (z, target, ell partials, eps of the next estimate, log-det partials)
-//   [dense target: k_fr_gemm<DENSE> -> k_fr_reduce]  [STL: back substitution]  -> k_fr_gemm<VJP> (+ this estimate's value)
+//   [k_eps unless the previous estimate's product kernel already drew this eps]
+//   k_fr_prod32 / k_fr_prod64 <SAMPLE> (z, fused target, ell / log-det partials, riders: eps of the next estimate, STL operands)
+//   [dense target: the same kernel <DENSE>]  [STL: back substitution]  -> k_fr_vjp32 / k_fr_vjp64 (+ this estimate's value)
 static mivi_status_t run_estimate_lds(mivi_ctx *c, const void *params, const RngArgs &rng, int M, int want_grad, OutArgs out,
                                       Chain *ch, const FusedUpdate *upd, bool stop_after_target) {
   if (!lds_prepare(c, M)) return fail(c, MIVI_ERR_HIP, "full-rank work lists: allocation failed");
@@ -529,22 +529,12 @@ static mivi_status_t run_estimate_lds(mivi_ctx *c, const void *params, const Rng
     if (dense) launch_lds_prod32(c, params, M, true, R_DENSE_G, nullptr, nullptr, false);
     vin.ell_part = (const double *)c->ell_part[p].p;
     vin.n_ell_part = lds_prod32_tiles(c, M);
-  } else if (lds_use_prod64(c, M)) {   // large shapes: unsplit 64 x 64 tiles, the target fused into the epilogue
+  } else {   // large shapes: unsplit 64 x 64 tiles, the target fused into the epilogue
     launch_lds_prod64(c, params, M, false, dense ? R_DENSE_R : R_DIAG, nullptr, next, grad_stage);
     if (next) c->he_n[p ^ 1] = lds_eps_blocks(c, M);
     if (dense) launch_lds_prod64(c, params, M, true, R_DENSE_G, nullptr, nullptr, false);
     vin.ell_part = (const double *)c->ell_part[p].p;
     vin.n_ell_part = lds_prod64_tiles(c, M);
-  } else {     // split-K slabs + reduce kernel (shapes in between)
-    launch_lds_sample(c, params, M, next);
-    launch_lds_reduce(c, params, M, dense ? R_DENSE_R : R_DIAG, nullptr, grad_stage);
-    if (next) c->he_n[p ^ 1] = lds_eps_blocks(c, M);
-    if (dense) {
-      launch_lds_dense(c, M);
-      launch_lds_reduce(c, params, M, R_DENSE_G, nullptr, false);
-    }
-    vin.ell_part = (const double *)c->ell_part[p].p;
-    vin.n_ell_part = lds_reduce_blocks(c, M);
   }
   if (ch) { ch->have_prev = false; ch->first = !chained; }
   if (grad_stage) {
@@ -867,17 +857,14 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
-RcclApi *rccl() {
-  static RcclApi api;
-  static bool tried = false;
-  if (tried) return api.lib ? &api : nullptr;
-  tried = true;
+RcclApi load_rccl() {
+  RcclApi api;
   const char *env = getenv("MIVI_RCCL_LIB");
   const char *cands[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (int pass = 0; pass < 2 && !api.lib; ++pass)       // pass 0: a copy the process already loaded (e.g. the host framework's)
     for (const char *n : cands)
       if (n && !api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
-  if (!api.lib) return nullptr;
+  if (!api.lib) return api;
   api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
   api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
   api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
@@ -885,8 +872,13 @@ RcclApi *rccl() {
   api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
   api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
   api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
-  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.ReduceScatter || !api.AllGather) { api.lib = nullptr; return nullptr; }
-  return &api;
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.ReduceScatter || !api.AllGather) api.lib = nullptr;
+  return api;
+}
+// the fully built table behind a C++11 magic static: contexts initialised from different host threads see it complete or not at all
+RcclApi *rccl() {
+  static RcclApi api = load_rccl();
+  return api.lib ? &api : nullptr;
 }
 long long slice_len_of(const mivi_ctx *c, int world) {
   const long long L = mivi_partials_len(c);
@@ -968,7 +960,6 @@ mivi_status_t mivi_estimate_gradient_dist(mivi_ctx_t *c, const void *params, uin
   const int R = c->comm_world, rank = c->comm_rank;
   if (R > 1 && !c->comm) return fail(c, MIVI_ERR_BAD_ARG, "mivi_comm_init has not been called");
   const long long n = slice_len_of(c, R), Lp = n * R;
-  if (R > 1 && n < R + 2) return fail(c, MIVI_ERR_UNSUPPORTED, "parameter vector too short to shard over this many ranks");
   const size_t es = c->esize;
   mivi_status_t s;
   if (c->dist_P.bytes < (size_t)Lp * es) {
@@ -981,11 +972,18 @@ mivi_status_t mivi_estimate_gradient_dist(mivi_ctx_t *c, const void *params, uin
   // Route: two collectives cost one more launch + rendezvous than one; below 16 MB of partials the step is
   // latency bound and ONE all-reduce + the whole finalisation on every rank is the faster form.  MIVI_DIST_ROUTE=allreduce / rsag pins it.
   const char *pin = getenv("MIVI_DIST_ROUTE");   // (read per call: tests drive both routes in one process)
-  const bool rsag = pin ? (pin[0] == 'r') : ((size_t)mivi_partials_len(c) * es >= ((size_t)16 << 20));
+  bool rsag = pin ? (pin[0] == 'r') : ((size_t)mivi_partials_len(c) * es >= ((size_t)16 << 20));
+  if (c->comm && !rsag && !rccl()->AllReduce) rsag = true;   // (a librccl without ncclAllReduce: the two-collective route needs only the required symbols)
+  // the slice route gives every rank n >= world + 2 elements (the two trailing scalars must not straddle more than one slice boundary);
+  // short parameter vectors are exactly the ones the single all-reduce serves, so fall back to it instead of refusing
+  if (rsag && R > 1 && n < R + 2) {
+    if (c->comm && rccl()->AllReduce) rsag = false;
+    else return fail(c, MIVI_ERR_UNSUPPORTED, "parameter vector too short to shard over this many ranks");
+  }
   if (c->comm && !rsag) {
     RcclApi *r = rccl();
     const ncclDataType_t dt = c->cfg.dtype == MIVI_F32 ? ncclFloat : ncclDouble;
-    if (!r->AllReduce || r->AllReduce(c->dist_P.p, c->dist_P.p, (size_t)mivi_partials_len(c), dt, ncclSum, (ncclComm_t)c->comm, c->stream) != ncclSuccess)
+    if (r->AllReduce(c->dist_P.p, c->dist_P.p, (size_t)mivi_partials_len(c), dt, ncclSum, (ncclComm_t)c->comm, c->stream) != ncclSuccess)
       return fail(c, MIVI_ERR_HIP, "ncclAllReduce failed");
     if ((s = mivi_finalize(c, params, c->dist_P.p, value, grad))) return s;
     HIPCHK(c, hipGetLastError());
@@ -1219,7 +1217,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
   prepare_tables(c, c->cfg.n_mc);   // host->device uploads are not allowed inside the capture
   if ((s = reserve_target(c, c->cfg.n_mc))) return s;
   static const bool no_fused_loop_n = getenv("MIVI_NO_FUSED_LOOP") != nullptr;
-  if (c->cfg.family == MIVI_MEANFIELD && c->target == TGT_DIAG_GAUSS && c->cfg.n_mc <= 4096 && !c->idx_src && !no_fused_loop_n) {
+  if (c->cfg.family == MIVI_MEANFIELD && c->target == TGT_DIAG_GAUSS && !c->bij_on && c->cfg.n_mc <= 4096 && !c->idx_src && !no_fused_loop_n) {
     // rows are independent for this family / target pair: all `count` estimates run inside ONE launch (every workgroup
     // keeps its four rows and walks the estimate indices), the value partials are reduced by a second launch
     const size_t hist_doubles = (size_t)count * 4 * (size_t)((c->cfg.d + 3) / 4);
@@ -1398,8 +1396,8 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
   static const bool no_fused_loop = getenv("MIVI_NO_FUSED_LOOP") != nullptr;
   const bool simple = rule <= 1 && l.op <= 1 && l.averager == 0;   // what the fused paths implement
   const bool default_adam = l.beta1 == 0.9 && l.beta2 == 0.999 && l.adam_eps == 1e-8;
-  if (simple && (rule == 0 || default_adam) && c->cfg.family == MIVI_MEANFIELD && c->target == TGT_DIAG_GAUSS &&
-      c->cfg.n_mc <= 4096 && !no_fused_loop) {
+  if (simple && (rule == 0 || default_adam) && c->cfg.family == MIVI_MEANFIELD && c->target == TGT_DIAG_GAUSS && !c->bij_on &&
+      c->cfg.n_mc <= 4096 && !no_fused_loop) {   // (the launch-free kernel has no Stacked-bijector handling: explicit-sample route)
     // launch-free loop: every workgroup owns four rows of (mu, sigma); no graph, two launches for all n_steps
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream));
     launch_mf_sgd_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, rec + n_steps, rec);
@@ -1481,7 +1479,7 @@ int32_t mivi_fullrank_route(const mivi_ctx_t *c, int32_t n_samples) {
   if (!c || c->cfg.family != MIVI_FULLRANK) return 0;
   if (n_samples <= 0) n_samples = c->cfg.n_mc;
   if (!lds_path_shape_ok(c, n_samples) || (c->target != TGT_DIAG_GAUSS && c->target != TGT_DENSE_GAUSS)) return 0;
-  return (lds_use_prod32(c, n_samples) ? 1 : (lds_use_prod64(c, n_samples) ? 3 : 2)) | (lds_bf16x3() ? 16 : 0);
+  return (lds_use_prod32(c, n_samples) ? 1 : 3) | (lds_bf16x3() ? 16 : 0);
 }
 
 mivi_status_t mivi_set_logreg_route(mivi_ctx_t *c, int32_t route) {
@@ -1500,9 +1498,14 @@ mivi_status_t mivi_set_index_source(mivi_ctx_t *c, const uint64_t *idx_dev) {
 
 mivi_status_t mivi_debug_timeline(mivi_ctx_t *c, void *buf) {
   if (!c) return MIVI_ERR_BAD_ARG;
+#ifdef MIVI_DEV
   c->dbg = (long long *)buf;
   invalidate_graph(c);
   return MIVI_OK;
+#else
+  if (!buf) return MIVI_OK;
+  return fail(c, MIVI_ERR_UNSUPPORTED, "timeline stamps are compiled out of the release library (build with `make DEV=1`)");
+#endif
 }
 
 mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *params, int32_t reps, double *ms_out) {
@@ -1522,11 +1525,11 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
   const bool fr = c->cfg.family == MIVI_FULLRANK;
   c->cur = 0;
   const bool lds = fr && lds_route(c, params, M, 1, out);   // second-generation kernels: stages 2 / 4 include their reduce
-  if ((which == 6 || which == 7) && !lds) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 6 / 7: second-generation full-rank route only");
+  if (which == 6 || which == 7) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 6 / 7: the split-K product / reduce stages were removed (round 3)");
   if (which == 8 && !(fr && (c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD)))
     return fail(c, MIVI_ERR_UNSUPPORTED, "which = 8: full-rank family with a sticking-the-landing estimator");
   if (which == 5) {   // the launch-free loop of 100 estimates (mean-field + diagonal target): one launch per rep
-    if (fr || c->target != TGT_DIAG_GAUSS || M > 4096) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 5: mean-field + diagonal-Gaussian target");
+    if (fr || c->target != TGT_DIAG_GAUSS || c->bij_on || M > 4096) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 5: mean-field + diagonal-Gaussian target, no bijector");
     if ((s = ensure(c, c->X, ((size_t)100 + 400 * (size_t)((c->cfg.d + 3) / 4) + 8) * sizeof(double), false))) return s;
   } else if (which != 0 && which != 8) {
     if (!fr && which != 2) return fail(c, MIVI_ERR_UNSUPPORTED, "mean-field has a single fused kernel (which = 2)");
@@ -1545,11 +1548,8 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
       case 2:
         if (lds && lds_use_prod32(c, M)) {
           launch_lds_prod32(c, params, M, false, c->target == TGT_DENSE_GAUSS ? R_DENSE_R : R_DIAG, nullptr, nullptr, true);
-        } else if (lds && lds_use_prod64(c, M)) {
-          launch_lds_prod64(c, params, M, false, c->target == TGT_DENSE_GAUSS ? R_DENSE_R : R_DIAG, nullptr, nullptr, true);
         } else if (lds) {
-          launch_lds_sample(c, params, M);
-          launch_lds_reduce(c, params, M, c->target == TGT_DENSE_GAUSS ? R_DENSE_R : R_DIAG, nullptr, true);
+          launch_lds_prod64(c, params, M, false, c->target == TGT_DENSE_GAUSS ? R_DENSE_R : R_DIAG, nullptr, nullptr, true);
         } else if (fr) launch_fr_sample(c, params, M, c->target, c->target == TGT_DENSE_GAUSS ? c->Z.p : nullptr);
         else launch_mf_main(c, params, rng, M, 1, nullptr, vin, out);
         break;
@@ -1561,8 +1561,6 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
         if (stl2_shape_ok(c, M)) launch_stl2(c, params, M, lds && lds_use_prod32(c, M));
         else launch_fr_stl(c, params, M);
         break;
-      case 6: launch_lds_sample(c, params, M); break;
-      case 7: launch_lds_reduce(c, params, M, c->target == TGT_DENSE_GAUSS ? R_DENSE_R : R_DIAG, nullptr, true); break;
       case 5:
         launch_mf_sgd_loop(c, const_cast<void *>(params), nullptr, (uint64_t)r * 100, 0, 100, -1, 0.0, (double)NAN, (double *)c->X.p + 100,
                            (double *)c->X.p, o + 16);
@@ -1570,11 +1568,8 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
       default:
         if (lds && lds_use_prod32(c, M)) {
           launch_lds_prod32(c, params, M, true, R_DENSE_G, nullptr, nullptr, false);
-        } else if (lds && lds_use_prod64(c, M)) {
-          launch_lds_prod64(c, params, M, true, R_DENSE_G, nullptr, nullptr, false);
         } else if (lds) {
-          launch_lds_dense(c, M);
-          launch_lds_reduce(c, params, M, R_DENSE_G, nullptr, false);
+          launch_lds_prod64(c, params, M, true, R_DENSE_G, nullptr, nullptr, false);
         } else launch_fr_dense_target(c, M, 1);
         break;
     }

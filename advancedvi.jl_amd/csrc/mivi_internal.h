@@ -258,10 +258,9 @@ struct mivi_ctx {
   mivi::DevBuf stl_F;              // second-generation STL solve: packed operands (stl_dinv.h: pivot inverses + off-diagonal blocks, fragment order)
   bool want_stl_pack = false, stl_pack_done = false;   // Stein estimator: ask the sampling kernel to carry the solve's riders
   mivi::DevBuf stl_X;              // second-generation STL solve: X of the lower half + updated right-hand side of the upper half
-  // second-generation full-rank kernels (kernels_fullrank_lds.hip): split-K work lists, per-tile slab ranges, slabs
-  mivi::DevBuf lds_tabS, lds_tilesS, lds_tabD, lds_tilesD, lds_tabV, lds_tabV64, lds_slab;
-  int lds_nS = 0, lds_nD = 0, lds_nV = 0, lds_nV64 = 0, lds_M = -1, lds_zero_slab = 0;
-  bool lds_dense = false;
+  // second-generation full-rank kernels (kernels_fullrank_lds.hip): VJP work lists (32 x 32 and 64 x 64 tiles)
+  mivi::DevBuf lds_tabV, lds_tabV64;
+  int lds_nV = 0, lds_nV64 = 0, lds_M = -1;
   bool d_idx_valid = false;          // the device-side estimate counter (d_idx[0]) is known to hold d_idx_expect
   uint64_t d_idx_expect = 0;
   mivi::DevBuf lds_tabSt;            // Stein accumulation stage: the full square of 64 x 64 tiles
@@ -322,21 +321,17 @@ int eps_blocks(const mivi_ctx *c, int M);
 enum LdsReduceMode : int { R_DIAG = 0, R_DENSE_R = 1, R_DENSE_G = 2, R_PLAIN = 3 };
 bool lds_path_shape_ok(const mivi_ctx *c, int M);
 bool lds_prepare(mivi_ctx *c, int M);          // work lists + slab buffer for M samples per launch (false: allocation failed)
-int lds_reduce_blocks(const mivi_ctx *c, int M);
 int lds_ld_blocks(const mivi_ctx *c);
-void launch_lds_sample(mivi_ctx *c, const void *params, int M, const EpsJob *next = nullptr);   // next: also draws eps(t+1)
 int lds_eps_blocks(const mivi_ctx *c, int M);
-void launch_lds_dense(mivi_ctx *c, int M);
 void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int mode, void *Z, const EpsJob *next, bool want_ld,
                        bool with_dinv = false);   // with_dinv: trailing workgroups invert the 64x64 diagonal blocks of C (STL)
 int lds_prod32_tiles(const mivi_ctx *c, int M);
 void launch_lds_prod64(mivi_ctx *c, const void *params, int M, bool dense, int mode, void *Z, const EpsJob *next, bool want_ld);
 int lds_prod64_tiles(const mivi_ctx *c, int M);
-bool lds_use_prod64(const mivi_ctx *c, int M);   // large shapes: unsplit 64 x 64 tiles instead of split-K slabs + reduce
+bool lds_use_prod64(const mivi_ctx *c, int M);   // large shapes: unsplit 64 x 64 tiles
 int lds_prod32_eps_blocks(const mivi_ctx *c, int M);
 bool lds_use_prod32(const mivi_ctx *c, int M);
 bool lds_bf16x3();   // products on the bf16 matrix cores (three-way exact operand split); MIVI_FR_F32MFMA=1 turns it off
-void launch_lds_reduce(mivi_ctx *c, const void *params, int M, int mode, void *Z, bool want_ld);
 void launch_lds_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const ValueJob *self, const FusedUpdate *upd);
 bool lds_stein_ok(const mivi_ctx *c, int M);
 void launch_lds_stein_outer(mivi_ctx *c, int M, void *A, double *gsum, int first, double scale, double n, void *grad, void *logpi,

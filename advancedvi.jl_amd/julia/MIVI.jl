@@ -77,13 +77,14 @@ end
 
 function AdvancedVI.init(rng::Random.AbstractRNG, obj::RepGradELBO, ad::AutoMIVI, q::MvLocationScale, prob, params, restructure)
     T = eltype(params)
+    # (checked before any native resource exists: nothing to release on this error path)
+    LogDensityProblems.capabilities(prob) isa LogDensityProblems.LogDensityOrder{0} &&
+        throw(ArgumentError("libmivi has no AD: the target must provide logdensity_and_gradient (wrap it in ADgradient)"))
     cfg = Ref(MiviConfig(dtype_code(T), family_code(q), length(q), obj.n_samples, entropy_code(obj.entropy),
                          ad.device, rand(rng, UInt64), 0, 0, C_NULL, 1, 0))
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     status = ccall((:mivi_create, libmivi), Int32, (Ref{MiviConfig}, Ref{Ptr{Cvoid}}), cfg, ctx)
     status == 0 || error("mivi_create failed with status $status (no HIP device?)")
-    LogDensityProblems.capabilities(prob) isa LogDensityProblems.LogDensityOrder{0} &&
-        throw(ArgumentError("libmivi has no AD: the target must provide logdensity_and_gradient (wrap it in ADgradient)"))
     st = MIVIState(prob, T, ctx[], UInt64(0), nothing, false, nothing)
     cb = @cfunction(target_callback, Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}))
     st.cb = cb

@@ -31,6 +31,9 @@ PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB
 PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA peak (155 TF measured)
 PEAK_BF16_MFMA_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
+# environment variables that do NOT change which kernels run: bench-harness controls and the RCCL library location
+BENCH_ENV_OK = {"MIVI_FORCE_DIST", "MIVI_DIST_MODE", "MIVI_DIST_EAGER", "MIVI_BENCH_SKIP_C3", "MIVI_RCCL_LIB", "MIVI_DIST_PIPELINE"}
+
 WORKLOADS = {
     "ns": dict(family=1, d=1024, n_mc=256, target="iso", entropy=0,
                name="north-star: d=1024 full-rank Gaussian family, n_mc=256, target MvNormal(5*1, I), ClosedFormEntropy"),
@@ -57,9 +60,9 @@ def algorithmic_cost(w):
 
 def pmc_traffic(kernel_substr):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    (profiles/pmc_traffic.json, produced by tools/pmc_traffic.py; separate passes, counters in KiB).  gfx950 caveat
-    (MI355X_MICROARCH.md, HBM): FETCH_SIZE under-reports wide (16 B/lane) streaming reads by 2x; these kernels
-    issue 4 B/lane loads, for which the counter is uncalibrated -- WRITE_SIZE matches known byte counts exactly."""
+    (profiles/pmc_traffic.json, produced by tools/pmc_traffic.py: separate passes, counters in KiB, the gfx950 FETCH_SIZE
+    correction of MI355X_MICROARCH.md already applied there per kernel according to the width of its loads -- the file records
+    the factor it used and the calibration run it came from)."""
     try:
         tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except (OSError, ValueError):
@@ -263,6 +266,11 @@ def main():
     ap.add_argument("--concurrent", type=int, default=4,
                     help="extra (non-headline) leg: this many independent estimator contexts on separate HIP streams")
     args = ap.parse_args()
+
+    # A/B switches select in-library REFERENCE routes: a bench line measured under one is not the product's number.  Refuse to run.
+    ab = sorted(k for k in os.environ if k.startswith("MIVI_") and k not in BENCH_ENV_OK)
+    if ab:
+        raise SystemExit(f"bench.py: refusing to run with libmivi A/B switches set: {ab} (unset them; allowed: {sorted(BENCH_ENV_OK)})")
 
     import torch
     import advancedvi_jl_amd as avi

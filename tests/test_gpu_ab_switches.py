@@ -1,0 +1,116 @@
+"""Every environment switch libmivi still reads selects an in-library reference route (switch table).  Each is
+read once per process, so every case runs in a child process: the route under the switch must agree with the oracle (estimates) or
+with the step-by-step entries (loops) exactly like the default route does."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+ESTIMATE = """
+import numpy as np, advancedvi_jl_amd as avi
+from oracle import oracle as O
+from tests.helpers import SEED, make_family, make_problem
+fam, d, M, kind, ent, dt = {fam}, {d}, {M}, {kind!r}, {ent}, np.{dt}
+rng = np.random.default_rng(d + M)
+q, q_o = make_family(rng, d, fam, dt)
+prob, tgt = make_problem(rng, kind, d, dt)
+params, _ = avi.destructure(q)
+ctx = avi.MiviContext(dt, fam, d, M, ent, SEED)
+ctx.set_problem(prob)
+{pre}
+_, eps = ctx.sample(params, 3)
+v, g = ctx.estimate_gradient(params, 3)
+ref = O.estimate_gradient(O.destructure(q_o), d, fam, tgt, eps.cpu().numpy().astype(np.float64), ent)
+vt, gt = (1e-5, 2e-5) if dt == np.float32 else (1e-12, 1e-11)
+assert abs(float(v.item()) - ref['value']) <= vt * max(abs(ref['value']), 1.0), (float(v.item()), ref['value'])
+assert np.linalg.norm(g.cpu().numpy() - ref['grad']) <= gt * max(np.linalg.norm(ref['grad']), 1.0)
+print('ok')
+"""
+
+LOOP = """
+import numpy as np, advancedvi_jl_amd as avi
+from tests.helpers import SEED
+fam, d, M, T = {fam}, {d}, {M}, 7
+tm, ts = np.full(d, 2.0, np.float32), np.full(d, 0.7, np.float32)
+q0 = (avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32)) if fam == avi.MEANFIELD
+      else avi.FullRankGaussian(np.zeros(d, np.float32), np.eye(d, dtype=np.float32)))
+p0, _ = avi.destructure(q0)
+ctx = avi.MiviContext(np.float32, fam, d, M, 0, SEED)
+ctx.set_problem(avi.DiagNormalProblem(tm, ts))
+pa = ctx.to_device(p0).clone(); st = ctx.empty(2 * pa.numel()).zero_()
+for t in range(T):
+    v, g = ctx.estimate_gradient(pa, 50 + t)
+    ctx.adam_update(pa, g, st, t + 1, 1e-2)
+    ctx.clip_scale(pa, 1e-5)
+pb = ctx.to_device(p0).clone(); st2 = ctx.empty(2 * pb.numel()).zero_()
+ctx.optimize_steps(pb, st2, 50, 0, T, 1, 1e-2, 1e-5, None)
+ctx.synchronize()
+assert np.array_equal(pa.cpu().numpy(), pb.cpu().numpy())
+v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+ctx.estimate_gradient_n(pb, 90, 4, v, g)
+v1, g1 = ctx.estimate_gradient(pb, 93)
+assert np.array_equal(g.cpu().numpy(), g1.cpu().numpy()) and float(v.item()) == float(v1.item())
+print('ok')
+"""
+
+STEIN = """
+import numpy as np, advancedvi_jl_amd as avi
+from oracle import oracle as O
+from tests.helpers import SEED, make_family, make_problem
+d, n = 256, 256
+rng = np.random.default_rng(5)
+q, q_o = make_family(rng, d, avi.FULLRANK, np.float32)
+prob, tgt = make_problem(rng, 'dense', d, np.float32)
+params, _ = avi.destructure(q)
+ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, n, 0, SEED)
+ctx.set_problem(prob)
+_, eps = ctx.sample(params, 4)
+lp, g, H = ctx.gauss_expected_grad_hess(params, 4)
+ref = O.gaussian_expectation_gradient_and_hessian(q_o, tgt, eps.cpu().numpy().astype(np.float64))
+assert np.linalg.norm(H.cpu().numpy() - ref[2]) <= 5e-5 * np.linalg.norm(ref[2])
+assert np.linalg.norm(g.cpu().numpy() - ref[1]) <= 2e-5 * max(1.0, np.linalg.norm(ref[1]))
+print('ok')
+"""
+
+F, MF = 1, 0
+CASES = [
+    # switch, script, parameters
+    ("MIVI_FR_GEN1=1", ESTIMATE, dict(fam=F, d=512, M=256, kind="diag", ent=0, dt="float32")),            # first-generation tile kernels
+    ("MIVI_FR_F32MFMA=1", ESTIMATE, dict(fam=F, d=512, M=256, kind="dense", ent=0, dt="float32")),         # f32-MFMA chains instead of bf16x3
+    ("MIVI_FR_F32MFMA=1", ESTIMATE, dict(fam=F, d=2048, M=512, kind="diag", ent=0, dt="float32")),         # ... on the 64 x 64 kernels
+    ("MIVI_VJP_TILE=64", ESTIMATE, dict(fam=F, d=1024, M=256, kind="diag", ent=0, dt="float32")),          # 64 x 64 VJP tiles at the north star
+    ("MIVI_VJP_TILE=32", ESTIMATE, dict(fam=F, d=2048, M=1024, kind="diag", ent=0, dt="float32")),         # 32 x 32 VJP tiles at a large shape
+    ("MIVI_STL_GEN1=1", ESTIMATE, dict(fam=F, d=512, M=128, kind="diag", ent=3, dt="float32")),            # look-ahead solve instead of k_stl_solve64
+    ("MIVI_STL_VALU=1", ESTIMATE, dict(fam=F, d=256, M=64, kind="diag", ent=3, dt="float32")),             # VALU back substitution
+    ("MIVI_STL_VALU=1", ESTIMATE, dict(fam=F, d=128, M=32, kind="diag", ent=4, dt="float64")),
+    ("MIVI_F64_VALU=1", ESTIMATE, dict(fam=F, d=160, M=48, kind="dense", ent=3, dt="float64")),            # f64 tiles on the vector ALU
+    ("MIVI_NW_SAMPLE=4", ESTIMATE, dict(fam=F, d=200, M=72, kind="diag", ent=0, dt="float32")),            # waves per first-generation tile
+    ("MIVI_NW_VJP=8", ESTIMATE, dict(fam=F, d=200, M=72, kind="diag", ent=0, dt="float32")),
+    ("MIVI_LR_F32_LOGITS=1", ESTIMATE, dict(fam=F, d=64, M=128, kind="logreg0", ent=0, dt="float32", pre="ctx.set_logreg_route(1)")),
+    ("MIVI_LR_F32_XTR=1", ESTIMATE, dict(fam=F, d=64, M=128, kind="logreg0", ent=0, dt="float32", pre="ctx.set_logreg_route(1)")),
+    ("MIVI_LOGREG_GENERIC=1", ESTIMATE, dict(fam=MF, d=64, M=128, kind="logreg0", ent=0, dt="float32")),
+    ("MIVI_LOGREG_MFMA=1", ESTIMATE, dict(fam=MF, d=64, M=128, kind="logreg0", ent=0, dt="float32")),
+    ("MIVI_NO_FUSED_LOOP=1", LOOP, dict(fam=MF, d=64, M=32)),                                             # graph loop instead of the launch-free kernel
+    ("MIVI_NO_FUSED_UPDATE=1", LOOP, dict(fam=F, d=128, M=128)),                                          # separate update kernel in the graph loop
+    ("MIVI_GRAPH_MIN=1", LOOP, dict(fam=F, d=128, M=128)),                                                # graph replay even for the shortest batches
+    ("MIVI_GRAPH_MIN=100", LOOP, dict(fam=F, d=128, M=128)),                                              # eager chain for every batch
+    ("MIVI_STEIN_GEN1=1", STEIN, dict()),                                                                 # first-generation accumulation kernel
+]
+
+
+@pytest.mark.parametrize("switch,script,par", CASES, ids=[f"{c[0]}-{i}" for i, c in enumerate(CASES)])
+def test_route_under_switch_agrees(switch, script, par):
+    par = dict(par)
+    par.setdefault("pre", "")
+    code = script.format(**par)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("MIVI_")}
+    k, v = switch.split("=")
+    env[k] = v
+    env["PYTHONPATH"] = ROOT
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -76,3 +76,51 @@ def test_bijector_argument_checks():
         with pytest.raises(avi.MiviError):
             ctx.set_bijector(avi.StackedBijector(bad))
     ctx.close()
+
+
+@pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
+@pytest.mark.parametrize("rule", ["descent", "adam"])
+def test_device_loop_honours_the_bijector(family, rule):
+    """the launch-free mean-field loop has no Stacked-bijector handling, so a TransformedProblem must NOT take it.
+    `optimize(device_loop=True)` == the host-driven `step` loop, and both differ from the untransformed problem."""
+    import warnings
+    d, T = 12, 9
+    rng = np.random.default_rng(11)
+    mu, sig = rng.normal(size=d).astype(np.float32), rng.uniform(0.5, 1.5, size=d).astype(np.float32)
+    base = avi.DiagNormalProblem(mu, sig)
+    prob = avi.TransformedProblem(base, avi.StackedBijector([(0, 4, "exp"), (4, d, "identity")]))
+    q0 = (avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32)) if family == avi.MEANFIELD
+          else avi.FullRankGaussian(np.zeros(d, np.float32), np.eye(d, dtype=np.float32)))
+    opt = avi.Descent(1e-2) if rule == "descent" else avi.Adam(5e-2)
+    alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), n_samples=8, optimizer=opt, averager=avi.NoAveraging(), operator=avi.ClipScale())
+    res = {}
+    for name, pr, dev in (("dev", prob, True), ("host", prob, False), ("plain", base, True)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _, info, st = avi.optimize(avi.PhiloxRNG(5), alg, T, pr, q0, device_loop=dev)
+        res[name] = (st["params"].cpu().numpy().copy(), np.array([i["elbo"] for i in info]))
+    assert np.array_equal(res["dev"][0], res["host"][0])
+    assert np.allclose(res["dev"][1], res["host"][1], rtol=1e-6)
+    assert not np.allclose(res["dev"][0], res["plain"][0], rtol=1e-3)   # the bijector changed the problem
+
+
+@pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
+def test_estimate_gradient_n_honours_the_bijector(family):
+    """mivi_estimate_gradient_n under a bijector == the last of n single calls (and != the untransformed estimate)."""
+    d, M, n = 16, 32, 7
+    rng = np.random.default_rng(12)
+    q, _ = make_family(rng, d, family, np.float32, mu_scale=0.3)
+    prob_a, _ = make_problem(rng, "diag", d, np.float32)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, family, d, M, 0, SEED)
+    ctx.set_problem(avi.TransformedProblem(prob_a, avi.StackedBijector([(0, 5, "exp")])))
+    p = ctx.to_device(params)
+    v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+    ctx.estimate_gradient_n(p, 20, n, v, g)
+    v1, g1 = ctx.estimate_gradient(p, 20 + n - 1)
+    assert abs(float(v.item()) - float(v1.item())) <= 1e-6 * abs(float(v1.item()))
+    assert rel_err(g.cpu().numpy(), g1.cpu().numpy()) < 1e-6
+    ctx.set_problem(prob_a)
+    v0, _ = ctx.estimate_gradient(p, 20 + n - 1)
+    assert abs(float(v0.item()) - float(v1.item())) > 1e-3 * abs(float(v1.item()))
+    ctx.close()

@@ -18,7 +18,7 @@ CASES = [
     (avi.MEANFIELD, 1, 1, "diag", 2, np.float64), (avi.FULLRANK, 33, 4096, "dense", 3, np.float32),
     (avi.FULLRANK, 2, 1, "dense", 1, np.float64), (avi.MEANFIELD, 5, 3, "funnel", 3, np.float32),
     # second-generation full-rank route: unsplit product with the STL riders (d = 2048 / 512 / 256: 16 / 4 / 2 chain blocks per half),
-    # split-K route with the stand-alone STL preparation, dense target on the unsplit product
+    # dense target on the unsplit product
     (avi.FULLRANK, 2048, 128, "diag", 3, np.float32), (avi.FULLRANK, 512, 256, "dense", 3, np.float32),
     (avi.FULLRANK, 256, 128, "diag", 4, np.float32), (avi.FULLRANK, 2048, 512, "diag", 3, np.float32),
     (avi.FULLRANK, 1024, 1024, "diag", 0, np.float32),
@@ -27,6 +27,10 @@ CASES = [
     (avi.FULLRANK, 1024, 1024, "dense", 0, np.float32), (avi.FULLRANK, 1152, 512, "diag", 0, np.float32),
     (avi.FULLRANK, 1536, 512, "dense", 2, np.float32), (avi.FULLRANK, 2048, 384, "diag", 4, np.float32),
     (avi.FULLRANK, 4096, 512, "diag", 0, np.float32),   # 64 x 64 tiles for both contractions (k_fr_prod64 + k_fr_vjp64)
+    # the shapes bench.py times: north star with the STL estimators (k_stl_* fed by the riders of the
+    # north-star-size k_fr_prod32) and with the dense target (k_fr_prod32<DENSE> at 1024 x 256)
+    (avi.FULLRANK, 1024, 256, "diag", 3, np.float32), (avi.FULLRANK, 1024, 256, "diag", 4, np.float32),
+    (avi.FULLRANK, 1024, 256, "dense", 0, np.float32), (avi.FULLRANK, 1024, 256, "dense", 3, np.float32),
 ]
 
 
@@ -46,32 +50,3 @@ def test_shape(family, d, M, kind, ent, dtype):
     assert abs(float(v.item()) - ref["value"]) <= vt * max(abs(ref["value"]), 1.0)
     assert np.linalg.norm(g.cpu().numpy() - ref["grad"]) <= gt * max(np.linalg.norm(ref["grad"]), 1.0)
     ctx.close()
-
-
-def test_split_k_route_still_agrees():
-    """MIVI_PROD64=0 keeps the split-K product (k_fr_gemm + k_fr_reduce) that k_fr_prod64 replaced as an A/B reference: the switch
-    is read once per process, so the case runs in a child process."""
-    import os, subprocess, sys
-    code = (
-        "import numpy as np, advancedvi_jl_amd as avi\n"
-        "from oracle import oracle as O\n"
-        "from tests.helpers import SEED, make_family, make_problem\n"
-        "d, M = 1024, 1024\n"
-        "rng = np.random.default_rng(d + M)\n"
-        "q, q_o = make_family(rng, d, avi.FULLRANK, np.float32)\n"
-        "prob, tgt = make_problem(rng, 'dense', d, np.float32)\n"
-        "params, _ = avi.destructure(q)\n"
-        "ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)\n"
-        "ctx.set_problem(prob)\n"
-        "assert ctx.fullrank_route()[0] == 2, ctx.fullrank_route()\n"
-        "_, eps = ctx.sample(params, 3)\n"
-        "v, g = ctx.estimate_gradient(params, 3)\n"
-        "ref = O.estimate_gradient(O.destructure(q_o), d, avi.FULLRANK, tgt, eps.cpu().numpy().astype(np.float64), 0)\n"
-        "assert abs(float(v.item()) - ref['value']) <= 1e-5 * max(abs(ref['value']), 1.0)\n"
-        "assert np.linalg.norm(g.cpu().numpy() - ref['grad']) <= 2e-5 * max(np.linalg.norm(ref['grad']), 1.0)\n"
-        "print('ok')\n")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MIVI_PROD64="0", PYTHONPATH=root)
-    env.pop("MIVI_FR_GEN1", None)   # (the A/B suite runs this file under every switch; this case is about one specific route)
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
