@@ -75,6 +75,16 @@ SIGNATURES = {
     "mivi_comm_init": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "mivi_comm_destroy": (C.c_int32, [C.c_void_p]),
     "mivi_estimate_gradient_dist": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "mivi_p2p_export": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "mivi_p2p_attach": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "mivi_p2p_detach": (C.c_int32, [C.c_void_p]),
+    "mivi_p2p_geometry": (None, [C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),
+    "mivi_comm_enable_p2p": (C.c_int32, [C.c_void_p]),
+    "mivi_comm_set_route": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "mivi_comm_route": (C.c_int32, [C.c_void_p]),
+    "mivi_estimate_gradient_dist_n": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mivi_p2p_exchange": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "mivi_profile_dist": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "mivi_set_bijector_stacked": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mivi_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mivi_eps_bits_host": (None, [C.c_uint64, C.c_uint64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]),

@@ -291,6 +291,44 @@ class MiviContext:
     def comm_init(self, unique_id, rank, world):
         self._chk(self.lib.mivi_comm_init(self.h, unique_id, int(rank), int(world)))
 
+    # -- the exchange written for xGMI (kernels_p2p.hip) ------------------------------------------------------------------
+    P2P_HANDLE_BYTES = 256
+    ROUTES = {"auto": 0, "allreduce": 1, "rsag": 2, "p2p": 3}
+
+    def p2p_export(self, rank, world):
+        buf = (C.c_char * self.P2P_HANDLE_BYTES)()
+        self._chk(self.lib.mivi_p2p_export(self.h, int(rank), int(world), buf))
+        return bytes(buf)
+
+    def p2p_attach(self, handles):
+        """handles: the `world` blobs of p2p_export in rank order (bytes or a list of bytes)."""
+        blob = b"".join(handles) if isinstance(handles, (list, tuple)) else bytes(handles)
+        self._chk(self.lib.mivi_p2p_attach(self.h, blob))
+
+    def p2p_detach(self):
+        self._chk(self.lib.mivi_p2p_detach(self.h))
+
+    def comm_enable_p2p(self):
+        self._chk(self.lib.mivi_comm_enable_p2p(self.h))
+
+    def comm_set_route(self, route):
+        self._chk(self.lib.mivi_comm_set_route(self.h, self.ROUTES.get(route, route)))
+
+    def comm_route(self):
+        return {0: "none", 1: "allreduce", 2: "rsag", 3: "p2p"}[int(self.lib.mivi_comm_route(self.h))]
+
+    def p2p_exchange(self, params, partials, value, grad, phases=7):
+        self._chk(self.lib.mivi_p2p_exchange(self.h, self._p(params), self._p(partials), self._p(value), self._p(grad), int(phases)))
+
+    def estimate_gradient_dist_n(self, params, idx0, count, value, grad):
+        self._chk(self.lib.mivi_estimate_gradient_dist_n(self.h, self._p(params), idx0, int(count), self._p(value), self._p(grad)))
+
+    def profile_dist(self, params, reps):
+        """us per estimate: dict(partials, exchange, serial, pipelined) (mivi_profile_dist; every rank calls it collectively)."""
+        out = (C.c_double * 4)()
+        self._chk(self.lib.mivi_profile_dist(self.h, self._p(params), int(reps), out))
+        return dict(partials=out[0], exchange=out[1], serial=out[2], pipelined=out[3])
+
     def estimate_gradient_dist(self, params, idx, value=None, grad=None):
         p = self.to_device(params)
         value = self.empty(1) if value is None else value

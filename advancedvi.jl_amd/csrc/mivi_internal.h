@@ -223,6 +223,22 @@ struct mivi_ctx {
   int comm_rank = 0, comm_world = 1;
   mivi::DevBuf dist_P, dist_S, dist_F;
   bool bij_on = false;
+  // Pipelined exchange (mivi_estimate_gradient_dist_n): the collective of estimate t runs on comm_stream under the kernels of t + 1;
+  // partial vectors double-buffered (dist_P, dist_P2), event pairs per parity
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_part[2] = {nullptr, nullptr}, ev_comm[2] = {nullptr, nullptr};
+  mivi::DevBuf dist_P2;
+  int dist_route = 0;   // mivi_comm_set_route: 0 by size, 1 ncclAllReduce, 2 ncclReduceScatter / ncclAllGather, 3 peer-to-peer kernel
+  // peer-to-peer exchange over xGMI (kernels_p2p.hip): one uncached allocation per rank [stage | final | flags], mapped into the peers by IPC
+  void *p2p_buf = nullptr;
+  size_t p2p_bytes = 0;
+  void *p2p_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // mapped bases (own entry = p2p_buf)
+  bool p2p_opened[8] = {false, false, false, false, false, false, false, false};                   // hipIpcOpenMemHandle'd (to be closed)
+  mivi::DevBuf p2p_tab, p2p_ctr;
+  bool p2p_on = false;
+  int p2p_rank = 0, p2p_world = 1, p2p_G = 1, p2p_vs = 0, p2p_spin = 1 << 21;
+  long long p2p_n = 0, p2p_cn = 0;
+  size_t p2p_off_fin = 0, p2p_off_arr = 0, p2p_off_farr = 0;
   // logreg
   const void *lr_X = nullptr;
   const uint8_t *lr_y = nullptr;
@@ -351,6 +367,9 @@ bool launch_logreg_target(mivi_ctx *c, int M, int want_grad);   // false: scratc
 bool logreg_uses_mfma(const mivi_ctx *c, int M);          // the matrix-core route (needs Z^T staged in RT)
 bool logreg_reserve(mivi_ctx *c, int M);                        // size the scratch ahead of a graph capture
 bool logreg_prepare_f32(mivi_ctx *c);   // row-major padded copy of X for the MFMA route (false: allocation failed)
+
+// kernels_p2p.hip: phases bit 0 push, 1 reduce + finalise, 2 unpack (7 = the whole exchange in one launch)
+void launch_p2p_exchange(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad, int phases = 7);
 
 // kernels_update.hip
 void launch_finalize(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad);

@@ -58,6 +58,17 @@ def slice_len(n_partials: int, world: int) -> int:
     return (n_partials + world - 1) // world
 
 
+def p2p_geometry(n_partials: int, world: int):
+    """(slice length, chunk length, chunk workgroups, value-owner rank) of the peer-to-peer exchange (mivi_p2p_geometry: host-only,
+    identical on every rank)."""
+    import ctypes as C
+
+    from . import _lib
+    out = (C.c_int64 * 4)()
+    _lib.load().mivi_p2p_geometry(int(n_partials), int(world), out)
+    return int(out[0]), int(out[1]), int(out[2]), int(out[3])
+
+
 def reduce_scatter_partials(padded, out_slice, group=None):
     """SUM reduce-scatter of the padded partial vector: rank r receives elements [r n, (r+1) n).  RCCL does it in one
     collective; gloo (CPU tests) has no reduce-scatter, there it is an all-reduce followed by taking the slice."""

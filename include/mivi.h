@@ -287,13 +287,50 @@ mivi_status_t mivi_unpack_final(mivi_ctx_t *ctx, const void *packed_final_dev, v
  * local share, m_offset = its first global column, m_total = n_mc * world.  mivi_estimate_gradient_dist is then estimate_gradient!
  * of the m_total-sample estimate on every rank: {partials kernels, ncclReduceScatter, slice finalise, ncclAllGather, unpack}, all
  * on the context's stream (graph-capturable).  world = 1 without a communicator runs the same kernels without the collectives;
- * world = 1 WITH an id runs them through RCCL (single-GPU test of the whole path).  Route: ONE ncclAllReduce + the whole finalisation on every rank below 16 MB of partials (latency bound),
- * ncclReduceScatter -> slice finalisation -> ncclAllGather -> unpack above; MIVI_DIST_ROUTE=allreduce|rsag pins it. */
+ * world = 1 WITH an id runs them through RCCL (single-GPU test of the whole path).  Route: see mivi_comm_set_route. */
 #define MIVI_COMM_ID_BYTES 128
 mivi_status_t mivi_comm_unique_id(void *id_host);
 mivi_status_t mivi_comm_init(mivi_ctx_t *ctx, const void *id_host, int32_t rank, int32_t world);
 mivi_status_t mivi_comm_destroy(mivi_ctx_t *ctx);
 mivi_status_t mivi_estimate_gradient_dist(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx, void *value_dev, void *grad_dev);
+
+/* The exchange written for xGMI (csrc/kernels_p2p.hip), no RCCL involved: every GPU of a node has a direct link to every other one, so
+ * the sum of the partial vectors is ONE kernel per rank with two one-hop phases -- every rank stores slice s of its partial vector
+ * straight into rank s's staging area; rank s sums the `world` contributions of its slice in rank order, finalises it (the owner of
+ * the two scalars also assembles the objective value) and stores the packed final slice into every rank's final buffer; every rank
+ * unpacks.  All ranks hold bit-identical results.  One fine-grained allocation per rank, mapped into its peers through HIP IPC:
+ *   mivi_p2p_export   allocates this rank's exchange area and fills MIVI_P2P_HANDLE_BYTES describing it (world <= 8: one node);
+ *   (the host gathers the `world` blobs in rank order by whatever channel it has: MPI, a file, torch.distributed, ...)
+ *   mivi_p2p_attach   maps the peers' areas (ranks inside one process -- tests -- are mapped by pointer); the context then behaves as
+ *                     rank `rank` of `world` for mivi_estimate_gradient_dist[_n] even without an RCCL communicator;
+ *   mivi_comm_enable_p2p = export + gather through the RCCL communicator of mivi_comm_init + attach, for hosts with no other channel.
+ * Every wait inside the kernel is bounded: a peer that never arrives makes the next mivi_synchronize return MIVI_ERR_HIP. */
+#define MIVI_P2P_HANDLE_BYTES 256
+mivi_status_t mivi_p2p_export(mivi_ctx_t *ctx, int32_t rank, int32_t world, void *handle_host);
+mivi_status_t mivi_p2p_attach(mivi_ctx_t *ctx, const void *handles_host /* world x MIVI_P2P_HANDLE_BYTES, rank order */);
+mivi_status_t mivi_p2p_detach(mivi_ctx_t *ctx);
+/* host-only: out4 = {slice length n, chunk length cn, chunk workgroups G, rank that owns the two scalars} for a partial vector of
+ * length L over `world` ranks (no GPU needed) */
+void mivi_p2p_geometry(int64_t L, int32_t world, int64_t *out4);
+mivi_status_t mivi_comm_enable_p2p(mivi_ctx_t *ctx);
+/* Which exchange mivi_estimate_gradient_dist[_n] uses: 0 = automatic (peer-to-peer when attached, otherwise ONE ncclAllReduce + the whole
+ * finalisation on every rank below 16 MB of partials and ncclReduceScatter -> slice finalisation -> ncclAllGather -> unpack above),
+ * 1 = ncclAllReduce, 2 = ncclReduceScatter / ncclAllGather, 3 = peer-to-peer.  mivi_comm_route reports the route in force. */
+mivi_status_t mivi_comm_set_route(mivi_ctx_t *ctx, int32_t route);
+int32_t mivi_comm_route(const mivi_ctx_t *ctx);
+/* `count` consecutive sharded estimates of the same params (estimates at fixed parameters are independent: the multi-GPU form of
+ * mivi_estimate_gradient_n): the exchange + finalisation of estimate t runs on a second stream UNDER the partial kernels of estimate
+ * t + 1 (partial vectors double-buffered), one hipGraph per batch; value / grad hold the last estimate on return.  Every rank calls it
+ * with the same arguments. */
+mivi_status_t mivi_estimate_gradient_dist_n(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx0, int32_t count,
+                                            void *value_dev, void *grad_dev);
+/* Tests: the phases of the peer-to-peer exchange as separate launches (bit 0 push, bit 1 reduce + finalise, bit 2 unpack), so that
+ * several ranks living in ONE process can be sequenced from one host thread.  partials_dev: the rank's partial vector, zero padded. */
+mivi_status_t mivi_p2p_exchange(mivi_ctx_t *ctx, const void *params_dev, const void *partials_dev, void *value_dev, void *grad_dev,
+                                int32_t phases);
+/* Measurement (bench.py --gpus N): us per estimate of {partial kernels, exchange + finalisation, the serial step, the pipelined step},
+ * hipEvents around one hipGraph replay of `reps` estimates each; every rank calls it collectively.  us_host: double[4]. */
+mivi_status_t mivi_profile_dist(mivi_ctx_t *ctx, const void *params_dev, int32_t reps, double *us_host);
 
 /* ---- measurement hook (bench.py roofline leg) --------------------------------------------------------- *
  * Times `reps` back-to-back launches of ONE stage of the estimate with hipEvents recorded on the context's

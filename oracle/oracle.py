@@ -519,6 +519,80 @@ def unpack_final(packed, d, family):
     return float(packed[L - 2]), np.concatenate([packed[:d], gC.reshape(-1, order="F")])
 
 
+def p2p_geometry(L, world):
+    """Restatement of the peer-to-peer exchange geometry (csrc/mivi_api.hip p2p_geometry, exported as mivi_p2p_geometry):
+    slice length n (a multiple of 4, the two scalars L-2 / L-1 in ONE slice), chunk length cn, chunk count G, value-owner rank."""
+    n = ((L + world - 1) // world + 3) & ~3
+    while (L - 1) % n == 0:
+        n += 4
+    vs = (L - 2) // n
+    G = min(64, max(1, (n + 2047) // 2048))
+    cn = ((n + G - 1) // G + 3) & ~3
+    return n, cn, G, vs
+
+
+def p2p_exchange(partials_by_rank, params, d, family, ent_kind, M_total, epochs=1):
+    """Host restatement of k_p2p_exchange (csrc/kernels_p2p.hip), phase by phase and chunk by chunk, with every rank's staging / final
+    areas as explicit arrays double-buffered by epoch parity: push (rank r stores chunk g of slice s into stage[s][parity][r]),
+    reduce (owner s sums the contributions in rank order, finalises, stores the final chunk into fin[every rank][parity]), unpack.
+    `partials_by_rank`: list over epochs of lists over ranks (or one list over ranks, reused).  Returns per epoch a list of
+    (value, grad) per rank."""
+    R = len(partials_by_rank[0]) if isinstance(partials_by_rank[0], (list, tuple)) else len(partials_by_rank)
+    per_epoch = partials_by_rank if isinstance(partials_by_rank[0], (list, tuple)) else [partials_by_rank] * epochs
+    L = (2 * d if family == MEANFIELD else d + d * (d + 1) // 2) + 2
+    n, cn, G, vs = p2p_geometry(L, R)
+    Lp = n * R
+    stage = [np.full((2, R, n), np.nan) for _ in range(R)]     # NaN: an element nobody pushed must never be consumed
+    fin = [np.full((2, Lp), np.nan) for _ in range(R)]
+    direct = {ENT_CLOSED_FORM: 1.0, ENT_CLOSED_FORM_ZERO_GRAD: 0.0, ENT_MONTE_CARLO: 1.0, ENT_STL: 0.0,
+              ENT_STL_ZERO_GRAD: -1.0}[ent_kind]
+    if family == MEANFIELD:
+        diag_at = {d + i: params[d + i] for i in range(d)}
+        diag = np.asarray(params[d:], dtype=np.float64)
+    else:
+        C = np.asarray(params[d:], dtype=np.float64).reshape(d, d, order="F")
+        diag_at = {d + j * d - (j * (j - 1)) // 2: C[j, j] for j in range(d)}
+        diag = np.diag(C)
+    out = []
+    for ep, parts in enumerate(per_epoch, start=1):
+        p = ep & 1
+        padded = [np.concatenate([np.asarray(x, dtype=np.float64), np.zeros(Lp - L)]) for x in parts]
+        for r in range(R):                                       # phase 1
+            for g in range(G):
+                c0 = g * cn
+                clen = max(0, min(cn, n - c0))
+                for s in range(R):
+                    stage[s][p, r, c0:c0 + clen] = padded[r][s * n + c0:s * n + c0 + clen]
+        for s in range(R):                                       # phase 2
+            for g in range(G):
+                c0 = g * cn
+                clen = max(0, min(cn, n - c0))
+                acc = np.zeros(clen)
+                for src in range(R):                             # rank order
+                    acc += stage[s][p, src, c0:c0 + clen]
+                o = -acc / M_total
+                for k in range(clen):
+                    gi = s * n + c0 + k
+                    if gi >= L - 2:
+                        o[k] = np.nan                            # scalars: the value workgroup; padding: never read
+                    elif gi in diag_at:
+                        o[k] -= direct / diag_at[gi]
+                for r in range(R):
+                    keep = np.array([s * n + c0 + k < L - 2 for k in range(clen)], dtype=bool)
+                    fin[r][p, s * n + c0:s * n + c0 + clen][keep] = o[keep]
+        o0 = L - 2 - vs * n                                      # the value workgroup of rank vs
+        sum_ell = sum(stage[vs][p, src, o0] for src in range(R))
+        s_he = sum(stage[vs][p, src, o0 + 1] for src in range(R))
+        s_ld = float(np.sum(np.log(diag)))
+        ent = (0.5 * d * (1.0 + LOG2PI) if ent_kind in (ENT_CLOSED_FORM, ENT_CLOSED_FORM_ZERO_GRAD)
+               else s_he / M_total + 0.5 * d * LOG2PI) + s_ld
+        for r in range(R):
+            fin[r][p, L - 2] = -(sum_ell / M_total + ent)
+            fin[r][p, L - 1] = 0.0
+        out.append([unpack_final(fin[r][p], d, family) for r in range(R)])   # phase 3
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # Host-side operators next to the hot path (section 8f)
 # --------------------------------------------------------------------------------------

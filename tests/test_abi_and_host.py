@@ -221,3 +221,42 @@ def test_shard_plan():
     with pytest.raises(ValueError):
         ShardPlan(3, 4)
     assert partials_len(4, 0) == 10 and partials_len(4, 1) == 16
+
+
+def test_p2p_geometry_invariants_and_host_restatement():
+    """The peer-to-peer exchange's geometry (mivi_p2p_geometry, host-only): every rank must derive the same slices / chunks, the two
+    scalars must lie in one slice, 16-byte vectors must never straddle a slice or chunk boundary; the oracle restates it."""
+    from advancedvi_jl_amd.distributed import p2p_geometry
+    from oracle import oracle as O
+    for L in list(range(4, 80)) + [2050, 4098, 131330, 525826, 2098178, 525826 + 1, 525826 + 3]:
+        for R in range(1, 9):
+            n, cn, G, vs = p2p_geometry(L, R)
+            assert (n, cn, G, vs) == O.p2p_geometry(L, R)
+            assert n % 4 == 0 and cn % 4 == 0 and n * R >= L and G * cn >= n and 1 <= G <= 64
+            assert (L - 2) // n == (L - 1) // n == vs and 0 <= vs < R
+
+
+@pytest.mark.parametrize("family,d", [(0, 5), (0, 700), (1, 3), (1, 40)])
+@pytest.mark.parametrize("R", [1, 2, 3, 8])
+def test_p2p_exchange_restatement_equals_allreduce_then_finalize(family, d, R):
+    """oracle.p2p_exchange (the chunked push / reduce / unpack protocol of csrc/kernels_p2p.hip restated on the host, double-buffered
+    over three epochs) == finalize(sum of the rank partials) on every rank, bit-identical across ranks."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(100 * d + R)
+    L = (2 * d if family == 0 else d + d * (d + 1) // 2) + 2
+    if family == 0:
+        params = np.concatenate([rng.normal(size=d), rng.uniform(0.5, 2.0, size=d)])
+    else:
+        Cm = np.tril(rng.normal(size=(d, d)) * 0.1)
+        Cm[np.diag_indices(d)] = rng.uniform(0.5, 2.0, size=d)
+        params = np.concatenate([rng.normal(size=d), Cm.reshape(-1, order="F")])
+    M_total = 16 * R
+    epochs = [[rng.normal(size=L) for _ in range(R)] for _ in range(3)]
+    for ent in (0, 3, 4):
+        res = O.p2p_exchange(epochs, params, d, family, ent, M_total)
+        for parts, per_rank in zip(epochs, res):
+            v_ref, g_ref = O.finalize_partials(np.sum(parts, axis=0), params, d, family, ent, M_total)
+            for v, g in per_rank:
+                assert np.isfinite(v) and np.all(np.isfinite(g))
+                assert abs(v - v_ref) <= 1e-12 * max(1.0, abs(v_ref)) and np.max(np.abs(g - g_ref)) <= 1e-12 * max(1.0, np.max(np.abs(g_ref)))
+                assert v == per_rank[0][0] and np.array_equal(g, per_rank[0][1])

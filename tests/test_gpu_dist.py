@@ -87,7 +87,7 @@ def test_slice_finalisation_kernels(family, d, M, R, ent, dtype):
 
 
 @pytest.mark.parametrize("family,d,M", [(avi.MEANFIELD, 64, 48), (avi.FULLRANK, 128, 128), (avi.FULLRANK, 40, 30)])
-def test_collective_behind_the_c_abi_on_one_gpu(family, d, M, monkeypatch):
+def test_collective_behind_the_c_abi_on_one_gpu(family, d, M):
     """mivi_comm_init(world = 1, WITH a unique id) + mivi_estimate_gradient_dist through the RCCL that libmivi opens itself, both
     routes -- {partials, ncclAllReduce, finalise} (the default below 16 MB of partials) and {partials, ncclReduceScatter, slice
     finalise, ncclAllGather, unpack} -- against the plain estimate."""
@@ -102,13 +102,14 @@ def test_collective_behind_the_c_abi_on_one_gpu(family, d, M, monkeypatch):
     ctx.comm_init(ctx.comm_unique_id(), 0, 1)
     got = {}
     for route in ("allreduce", "rsag"):
-        monkeypatch.setenv("MIVI_DIST_ROUTE", route)
+        ctx.comm_set_route(route)
+        assert ctx.comm_route() == route
         v1, g1 = ctx.estimate_gradient_dist(params, 5)
         ctx.synchronize()
         assert abs(float(v1.item()) - v0) <= 2e-6 * abs(v0)
         assert np.linalg.norm(g1.cpu().numpy() - g0) <= 5e-6 * max(1.0, np.linalg.norm(g0))
         got[route] = g1.cpu().numpy().copy()
-    monkeypatch.delenv("MIVI_DIST_ROUTE")
+    ctx.comm_set_route("auto")
     v1, g1 = ctx.estimate_gradient_dist(params, 5)       # default route for this size: one all-reduce
     assert np.array_equal(g1.cpu().numpy(), got["allreduce"])
     # and without a communicator (world 1): the slice kernels, no collective

@@ -1,0 +1,225 @@
+"""The gradient exchange written for xGMI (csrc/kernels_p2p.hip, mivi_p2p_* / mivi_estimate_gradient_dist_n) on ONE GPU.
+
+No multi-GPU box is available to the build, so the protocol is exercised in every way one device allows:
+  * world = 1: the rank exchanges with itself (every phase, flag and buffer, no peer);
+  * several ranks as several contexts of THIS process (their areas are mapped by pointer instead of IPC), the three phases launched
+    one at a time for all ranks (host-sequenced: no concurrency between the ranks' kernels is needed) -- slices, chunks, the
+    value-owner rank, the double buffers over consecutive epochs, for up to 8 ranks;
+  * two ranks as two PROCESSES sharing the GPU: the areas are mapped through HIP IPC and the fused kernels of the two processes run
+    concurrently, so the flags really synchronise them (two streams of one process can land on one hardware queue and serialise);
+  * the pipelined batch (exchange of estimate t under the kernels of t + 1) against single estimates.
+Reference for every result: the one-context estimate of all R n_mc samples (shard-invariant eps stream) and the host restatement
+oracle.p2p_exchange."""
+import numpy as np
+import pytest
+import torch
+
+import advancedvi_jl_amd as avi
+from advancedvi_jl_amd.distributed import ShardPlan, p2p_geometry
+from oracle import oracle as O
+from tests.helpers import SEED, make_family, make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _ranks(dtype, family, d, M, R, ent, prob, streams=False):
+    plan = ShardPlan(M, R)
+    ctxs = []
+    for r in range(R):
+        st = torch.cuda.Stream() if streams else None
+        c = avi.MiviContext(dtype, family, d, plan.count(r), ent, SEED, m_offset=plan.offset(r), m_total=M,
+                            stream=st.cuda_stream if st else None)
+        c._stream_obj = st
+        c.set_problem(prob)
+        ctxs.append(c)
+    handles = [c.p2p_export(r, R) for r, c in enumerate(ctxs)]
+    for c in ctxs:
+        c.p2p_attach(handles)
+        c.comm_set_route("p2p")
+    return ctxs
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("family,d,M,R", [(avi.MEANFIELD, 64, 48, 4), (avi.MEANFIELD, 3, 8, 8), (avi.FULLRANK, 96, 64, 2),
+                                           (avi.FULLRANK, 40, 30, 3), (avi.FULLRANK, 128, 256, 8), (avi.MEANFIELD, 1024, 256, 8),
+                                           (avi.FULLRANK, 256, 256, 2), (avi.FULLRANK, 5, 7, 5)])
+@pytest.mark.parametrize("ent", [0, 3])
+def test_exchange_phases_for_several_ranks(family, d, M, R, ent, dtype):
+    rng = np.random.default_rng(5)
+    q, _ = make_family(rng, d, family, dtype)
+    prob, _ = make_problem(rng, "diag", d, dtype)
+    params, _ = avi.destructure(q)
+    full = avi.MiviContext(dtype, family, d, M, ent, SEED)
+    full.set_problem(prob)
+    ctxs = _ranks(dtype, family, d, M, R, ent, prob)
+    L = ctxs[0].partials_len
+    n, cn, G, vs = p2p_geometry(L, R)
+    tol_v, tol_g = (2e-6, 5e-6) if dtype == np.float32 else (1e-13, 1e-12)
+    p_dev = [c.to_device(params) for c in ctxs]
+    for epoch, idx in enumerate((17, 18, 19)):            # three exchanges: both buffer parities, the second one reused
+        v_ref, g_ref = full.estimate_gradient(params, idx)
+        v_ref, g_ref = float(v_ref.item()), g_ref.cpu().numpy().astype(np.float64)
+        parts, outs = [], []
+        for r, c in enumerate(ctxs):
+            P = c.empty(n * R).zero_()
+            c.estimate_partials(p_dev[r], idx, P[:L])
+            parts.append(P)
+            outs.append((c.empty(1), c.empty(c.params_len).fill_(float("nan"))))
+        torch.cuda.synchronize()
+        for ph in (1, 2, 4):
+            for r, c in enumerate(ctxs):
+                c.p2p_exchange(p_dev[r], parts[r], outs[r][0], outs[r][1], ph)
+            torch.cuda.synchronize()
+        for c in ctxs:
+            c.synchronize()                                 # raises on a lost peer (status bit 8)
+        g0 = outs[0][1].cpu().numpy()
+        for v, g in outs:
+            assert float(v.item()) == float(outs[0][0].item()) and np.array_equal(g.cpu().numpy(), g0)   # bit-identical on every rank
+        assert abs(float(outs[0][0].item()) - v_ref) <= tol_v * abs(v_ref)
+        assert np.linalg.norm(g0 - g_ref) <= tol_g * max(1.0, np.linalg.norm(g_ref))
+        if family == avi.FULLRANK:
+            assert np.all(np.triu(g0[d:].reshape(d, d, order="F"), 1) == 0.0)
+        # the host restatement of the protocol on the same rank partials
+        sim = O.p2p_exchange([[P[:L].cpu().numpy().astype(np.float64) for P in parts]], params.astype(np.float64), d, family, ent, M)[0][0]
+        assert abs(float(outs[0][0].item()) - sim[0]) <= tol_v * abs(sim[0])
+        assert np.max(np.abs(g0 - sim[1])) <= tol_g * max(1.0, np.max(np.abs(sim[1])))
+    for c in ctxs + [full]:
+        c.close()
+
+
+@pytest.mark.parametrize("family,d,M", [(avi.MEANFIELD, 64, 48), (avi.FULLRANK, 256, 256), (avi.FULLRANK, 40, 30), (avi.FULLRANK, 1024, 256)])
+def test_one_rank_exchanges_with_itself(family, d, M):
+    rng = np.random.default_rng(6)
+    q, _ = make_family(rng, d, family, np.float32)
+    prob, _ = make_problem(rng, "diag", d, np.float32)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, family, d, M, 0, SEED)
+    ctx.set_problem(prob)
+    v0, g0 = ctx.estimate_gradient(params, 5)
+    v0, g0 = float(v0.item()), g0.cpu().numpy().copy()
+    ctx.p2p_attach([ctx.p2p_export(0, 1)])
+    assert ctx.comm_route() == "p2p"                        # automatic route once the exchange areas are attached
+    for idx in (5, 5, 5):
+        v1, g1 = ctx.estimate_gradient_dist(params, idx)
+        ctx.synchronize()
+        assert abs(float(v1.item()) - v0) <= 2e-6 * abs(v0)
+        assert np.linalg.norm(g1.cpu().numpy() - g0) <= 5e-6 * max(1.0, np.linalg.norm(g0))
+    ctx.p2p_detach()
+    assert ctx.comm_route() == "none"
+    ctx.close()
+
+
+def _two_process_worker(rank, world, port, family, d, M, q_out):
+    """One rank = one PROCESS on the (only) GPU: the exchange areas are mapped through HIP IPC (hipIpcGetMemHandle / OpenMemHandle), the
+    128 + 256-byte blobs travel through a gloo group, and the fused exchange kernels of the two processes really run concurrently."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import advancedvi_jl_amd as avi
+    from advancedvi_jl_amd.distributed import ShardPlan
+    from tests.helpers import SEED, make_family, make_problem
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        rng = np.random.default_rng(7)
+        q, _ = make_family(rng, d, family, np.float32)
+        prob, _ = make_problem(rng, "diag", d, np.float32)
+        params, _ = avi.destructure(q)
+        full = avi.MiviContext(np.float32, family, d, M, 0, SEED)
+        full.set_problem(prob)
+        plan = ShardPlan(M, world)
+        ctx = avi.MiviContext(np.float32, family, d, plan.count(rank), 0, SEED, m_offset=plan.offset(rank), m_total=M)
+        ctx.set_problem(prob)
+        mine = torch.frombuffer(bytearray(ctx.p2p_export(rank, world)), dtype=torch.uint8)
+        blobs = [torch.zeros(256, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(blobs, mine)
+        ctx.p2p_attach([bytes(b.numpy().tobytes()) for b in blobs])
+        assert ctx.comm_route() == "p2p"
+        p = ctx.to_device(params)
+        worst_v = worst_g = 0.0
+        for idx in range(30, 36):                      # single sharded estimates: the dependent-chain form
+            v_ref, g_ref = full.estimate_gradient(params, idx)
+            dist.barrier()
+            v, g = ctx.estimate_gradient_dist(p, idx)
+            ctx.synchronize()
+            worst_v = max(worst_v, abs(float(v.item()) - float(v_ref.item())) / abs(float(v_ref.item())))
+            worst_g = max(worst_g, float((g - g_ref).norm() / g_ref.norm()))
+        v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+        for rep in range(2):                           # pipelined batches (graph capture, then replay)
+            dist.barrier()
+            ctx.estimate_gradient_dist_n(p, 60 + 10 * rep, 9, v, g)
+            ctx.synchronize()
+            v_ref, g_ref = full.estimate_gradient(params, 60 + 10 * rep + 8)
+            worst_v = max(worst_v, abs(float(v.item()) - float(v_ref.item())) / abs(float(v_ref.item())))
+            worst_g = max(worst_g, float((g - g_ref).norm() / g_ref.norm()))
+        gsum = torch.tensor([float(g.double().sum())], dtype=torch.float64)
+        both = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(both, gsum)                    # bit-identical results on the two ranks
+        q_out.put((rank, worst_v, worst_g, float(both[0]) == float(both[1])))
+        dist.barrier()
+        ctx.close()
+        full.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("family,d,M", [(avi.FULLRANK, 256, 256), (avi.MEANFIELD, 1024, 128)])
+def test_two_processes_exchange_through_ipc(family, d, M):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q_out = mpc.Queue()
+    procs = [mpc.Process(target=_two_process_worker, args=(r, 2, port, family, d, M, q_out)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(300)
+        assert pr.exitcode == 0
+    for _ in range(2):
+        rank, wv, wg, same = q_out.get(timeout=10)
+        assert wv <= 2e-6 and wg <= 5e-6 and same, (rank, wv, wg, same)
+
+
+@pytest.mark.parametrize("route", ["p2p", "allreduce", "rsag", "none"])
+@pytest.mark.parametrize("family,d,M,count", [(avi.FULLRANK, 256, 128, 7), (avi.MEANFIELD, 512, 64, 5), (avi.FULLRANK, 1024, 256, 12),
+                                               (avi.FULLRANK, 96, 40, 1)])
+def test_pipelined_batch_equals_single_estimates(family, d, M, count, route):
+    """mivi_estimate_gradient_dist_n: the exchange of estimate t overlapped with the kernels of t + 1 (two streams, double-buffered
+    partial vectors) returns what `count` single sharded estimates return, for every exchange route (world = 1)."""
+    rng = np.random.default_rng(8)
+    q, _ = make_family(rng, d, family, np.float32)
+    prob, _ = make_problem(rng, "diag", d, np.float32)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, family, d, M, 3 if family == avi.FULLRANK and d == 256 else 0, SEED)
+    ctx.set_problem(prob)
+    if route == "p2p":
+        ctx.p2p_attach([ctx.p2p_export(0, 1)])
+    elif route != "none":
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+        ctx.comm_set_route(route)
+    p = ctx.to_device(params)
+    v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+    for rep in range(2):                                    # second call: graph replay with a new index base
+        idx0 = 40 + 100 * rep
+        ctx.estimate_gradient_dist_n(p, idx0, count, v, g)
+        ctx.synchronize()
+        v1, g1 = ctx.estimate_gradient_dist(p, idx0 + count - 1)
+        ctx.synchronize()
+        assert float(v.item()) == float(v1.item())
+        assert np.array_equal(g.cpu().numpy(), g1.cpu().numpy())
+        v2, g2 = ctx.estimate_gradient(p, idx0 + count - 1)
+        assert abs(float(v.item()) - float(v2.item())) <= 2e-6 * abs(float(v2.item()))
+        assert np.linalg.norm(g.cpu().numpy() - g2.cpu().numpy()) <= 5e-6 * max(1.0, float(np.linalg.norm(g2.cpu().numpy())))
+    prof = ctx.profile_dist(p, 8)
+    assert all(prof[k] > 0 for k in ("partials", "exchange", "serial", "pipelined"))
+    ctx.close()
