@@ -2,32 +2,45 @@
 // single task: src/algorithms/repgradelbo.jl:84-86 is a mean over samples, so what crosses GPUs is a SUM of partial vectors).
 //
 // RCCL's ring all-reduce of the 2.1 MB north-star partial vector costs 2 (R - 1) dependent hops (50-70 us of latency at R = 8 against
-// 14 us of compute).  xGMI is point to point -- every GPU has a direct link to every other one -- so the exchange is written as ONE
-// kernel per rank with two one-hop phases, all seven links busy in both:
+// 14 us of compute).  xGMI is point to point -- every GPU has a direct link to every other one -- so the exchange is ONE kernel per
+// rank with two one-hop phases, all seven links busy in both:
 //
-//   phase 1  push        every rank stores slice s of its partial vector straight into rank s's staging area (peer stores), flag
+//   phase 1  push        every rank stores slice s of its partial vector straight into rank s's staging area (peer stores)
 //   phase 2  reduce      rank s sums the R contributions of ITS slice in rank order (f64), finalises it (-1/M, entropy diagonal
-//                        terms; the slice that holds the two scalars also assembles the objective value) and stores the packed
-//                        final slice into EVERY rank's final buffer (peer stores), flag
+//                        terms; the owner of the two scalars also assembles the objective value) and stores the packed final
+//                        slice into EVERY rank's final area (peer stores)
 //   phase 3  unpack      every rank expands the packed final vector into value + dense gradient (exact zeros above the diagonal)
 //
 // Every slice is finalised by exactly one rank from contributions summed in rank order: all ranks hold bit-identical results and the
-// sum is independent of arrival order.  Slices are cut into G chunks; workgroup g of every rank handles chunk g of every slice and
-// synchronises only with workgroup g of its peers through (source rank, chunk) flags carrying the exchange's epoch number -- no
-// grid-wide barrier, no dependency cycle (phase 1 never waits).  Staging / final / flag buffers are double-buffered by epoch parity:
-// an exchange can only complete on a rank after every peer finished reducing the previous one, so epoch e + 2 never overwrites data
-// epoch e still needs.  Memory: one fine-grained allocation per rank, mapped into its peers through HIP IPC
-// (mivi_p2p_export / mivi_p2p_attach); stores to peers are system-scope write-through, flags are released / acquired at system scope.
-// Every spin is bounded: a lost peer sets status bit 8 and the kernel leaves (the host reports it; nothing hangs).
+// sum is independent of arrival order.
+//
+// Synchronisation is in the DATA ("LL" layout, as RCCL's low-latency protocol): every 32-bit payload word travels as an 8-byte pair
+// (word, epoch) written by ONE store, so a reader that finds the epoch of this exchange in a pair has the word -- no separate flag,
+// no store acknowledge to wait for, no flag poll: a phase costs one (repeated until complete) load round trip instead of
+// {store acknowledge, flag round trip, data round trip} (the flag version of this kernel: 29 us per exchange on one GPU).  Twice the
+// bytes; the exchange is latency bound (2 MB).
+//
+// Slices are cut into G chunks; workgroup g of every rank handles chunk g of every slice in all three phases, so workgroup g only
+// ever depends on workgroup g of its peers: no grid-wide barrier, no dependency cycle (phase 1 never waits), and the areas can be
+// double-buffered by epoch parity without acknowledgements -- workgroup g of rank a reaches epoch e + 2 only after it unpacked
+// epoch e + 1, which needed workgroup g of every owner to have reduced epoch e + 1, hence to be done with epoch e.
+//
+// The kernel is PERSISTENT over a batch of `count` estimates (mivi_estimate_gradient_dist_n): it runs on its own stream beside the
+// compute chain and is handed each partial vector through two device words -- `ready` (set by the compute chain when the partial
+// vector of estimate t is complete) and `freed` (bumped by every workgroup once it has read its part of that vector; the compute
+// chain checks it before estimate t + 2 overwrites the buffer).  No stream events, no graph fork / join per estimate.
+//
+// Memory: one fine-grained allocation per rank, mapped into its peers through HIP IPC (mivi_p2p_export / mivi_p2p_attach).  Every access
+// to it is system scope (sc0 sc1): stores write through, loads never hit a line an XCD's L2 kept from two epochs ago.  No cache-wide
+// fence is issued (the compute kernels running beside the exchange keep their L2-resident operands).  Every spin is bounded: a lost
+// peer sets status bit 8 and the kernel leaves (the host reports it; nothing hangs).
 #include "device_common.h"
 
 namespace mivi {
 
 struct P2PTable {   // device resident: where every rank's exchange areas are mapped in THIS process
-  char *stage[8];       // [2][R][n] T : stage[s] = rank s's staging area (contribution of rank `src` to slice s at [parity][src])
-  char *fin[8];         // [2][R n] T  : rank s's packed final vector
-  unsigned *arr[8];     // [2][R][G]   : arrival flags of (source rank, chunk)
-  unsigned *farr[8];    // [2][R][G+1] : final-slice arrival flags of (owner rank, chunk); slot G of the value owner = the two scalars
+  unsigned long long *stage[8];   // [2][R][n W] pairs: stage[s] = rank s's staging area (contribution of rank `src` to slice s at [parity][src])
+  unsigned long long *fin[8];     // [2][R n W] pairs : rank s's packed final vector
 };
 
 template <typename T>
@@ -37,201 +50,377 @@ struct P2PArgs {
   int rank, world, G, vs;    // vs = the rank whose slice holds the two scalars (sum ell, sum 0.5|eps|^2)
   const P2PTable *tab;
   unsigned *ctr;             // [0] exchanges completed on this rank, [1] exit ticket
-  const T *partials;         // this rank's partial vector, zero padded to world * n
+  const T *P0, *P1;          // this rank's partial vectors (estimate t of the batch: P[t & 1]), zero padded to world * n
   const T *params;
   T *value, *grad;
   int *status;
-  int phases;                // bit 0 push, bit 1 reduce, bit 2 unpack (all three = the exchange; single phases: host-sequenced tests)
+  int phases;                // bit 0 push, bit 1 reduce, bit 2 unpack (all three = the exchange; single phases: host-sequenced tests, count = 1)
   int spin_budget;
+  int count;                 // estimates in this launch
+  const unsigned *ready;     // batch hand-over (nullptr: the partial vector is complete at launch): estimate t may start when *ready - ready_base >= t + 1
+  unsigned ready_base;
+  unsigned *freed;           // += 1 by every chunk workgroup once its part of estimate t's partial vector has been read
 };
 
-__device__ __forceinline__ void store16_sys(void *p, const void *src16) {   // 16-byte system-scope write-through store
-  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-  const u32x4_t r = *(const u32x4_t *)src16;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void store16_sys(void *p, u32x4_t r) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
 }
-// What a peer (or another XCD of this GPU: every XCD has its own L2, and they are not coherent with each other) stored into the
-// exchange areas is read with SYSTEM-scope loads (sc0 sc1): they never hit a stale line this XCD's L2 kept from the exchange two epochs
-// ago -- plain loads did (found on one GPU: a staging area re-used across epochs / allocations returned the previous contents to the
-// XCDs that had read them before, although memory held the new data).
-template <typename T>
-__device__ __forceinline__ T ld_sys(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void flag_release(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-// wait until *p == want (bounded); returns false on a lost peer
-__device__ __forceinline__ bool flag_wait(const unsigned *p, unsigned want, int budget) {
-  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != want) {
+__device__ __forceinline__ void store8_sys(void *p, u32x2_t r) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(r) : "memory");
+}
+// eight independent 16-byte system-scope loads in flight, ONE wait (such a load is a full memory round trip: issued one per loop
+// iteration the exchange was a chain of ~1.5 us latencies)
+__device__ __forceinline__ void ld16x8_sys(const void *const (&p)[8], u32x4_t (&o)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc0 sc1\n\t"
+      "global_load_dwordx4 %1, %9, off sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %10, off sc0 sc1\n\t"
+      "global_load_dwordx4 %3, %11, off sc0 sc1\n\t"
+      "global_load_dwordx4 %4, %12, off sc0 sc1\n\t"
+      "global_load_dwordx4 %5, %13, off sc0 sc1\n\t"
+      "global_load_dwordx4 %6, %14, off sc0 sc1\n\t"
+      "global_load_dwordx4 %7, %15, off sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
+      : "memory");
+}
+__device__ __forceinline__ unsigned long long ld8_sys(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Eight LL units (16 bytes = two (word, epoch) pairs each) until every pair the caller needs carries `epoch`.  need[u]: bit 0 / 1 =
+// the first / second pair of unit u matters (0: the slot is padding).  Bounded: false = a word never arrived.
+__device__ __forceinline__ bool ll_load8(const void *const (&p)[8], const unsigned (&need)[8], unsigned epoch, int budget, u32x4_t (&o)[8]) {
+  for (;;) {
+    ld16x8_sys(p, o);
+    bool ok = true;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if ((need[u] & 1u) && o[u][1] != epoch) ok = false;
+      if ((need[u] & 2u) && o[u][3] != epoch) ok = false;
+    }
+    if (ok) return true;
     if (--budget <= 0) return false;
-    __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_s_sleep(2);
   }
-  return true;
+}
+// one LL pair (bounded)
+__device__ __forceinline__ bool ll_load1(const unsigned long long *p, unsigned epoch, int budget, unsigned &word) {
+  for (;;) {
+    const unsigned long long v = ld8_sys(p);
+    if ((unsigned)(v >> 32) == epoch) { word = (unsigned)v; return true; }
+    if (--budget <= 0) { word = 0; return false; }
+    __builtin_amdgcn_s_sleep(2);
+  }
 }
 
-// one workgroup waits for `count` flags flags[stride * k] (k < count): thread k polls flag k; result uniform
-template <int NT>
-__device__ __forceinline__ bool wait_flags(const unsigned *flags, int count, int stride, unsigned want, int budget, int *sh_ok) {
-  if (threadIdx.x == 0) *sh_ok = 1;
-  __syncthreads();
-  for (int k = threadIdx.x; k < count; k += NT)
-    if (!flag_wait(flags + (size_t)k * stride, want, budget)) atomicAnd(sh_ok, 0);
-  __syncthreads();
-  const bool ok = *sh_ok != 0;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope: what the flags' writers stored before releasing them is visible
-  __syncthreads();
-  return ok;
+template <typename T> struct Words;
+template <> struct Words<float> {
+  static constexpr int W = 1;
+  static __device__ __forceinline__ float make(unsigned w0, unsigned) { return __builtin_bit_cast(float, w0); }
+  static __device__ __forceinline__ void split(float x, unsigned &w0, unsigned &w1) { w0 = __builtin_bit_cast(unsigned, x); w1 = 0u; }
+};
+template <> struct Words<double> {
+  static constexpr int W = 2;
+  static __device__ __forceinline__ double make(unsigned w0, unsigned w1) {
+    return __builtin_bit_cast(double, (unsigned long long)w0 | ((unsigned long long)w1 << 32));
+  }
+  static __device__ __forceinline__ void split(double x, unsigned &w0, unsigned &w1) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
+    w0 = (unsigned)b;
+    w1 = (unsigned)(b >> 32);
+  }
+};
+
+// packed index (>= d, full-rank) -> (column j, row i) of the lower triangle: e2 = j d - j (j - 1) / 2 + (i - j)
+__device__ __forceinline__ void packed_col_row(long long gi, int d, long long &j, long long &i) {
+  const long long e2 = gi - d;
+  const double b = 2.0 * d + 1.0;
+  j = (long long)((b - sqrt(b * b - 8.0 * (double)e2)) * 0.5);
+  if (j < 0) j = 0;
+  if (j > d - 1) j = d - 1;
+  while (j > 0 && j * d - (j * (j - 1)) / 2 > e2) --j;
+  while (j + 1 < d && (j + 1) * d - ((j + 1) * j) / 2 <= e2) ++j;
+  i = j + (e2 - (j * d - (j * (j - 1)) / 2));
+}
+
+// packed final entry -> its finalised value: -(1/M) sum, the diagonal entries of the scale carry the entropy term
+template <typename T>
+__device__ __forceinline__ double p2p_finalise(const P2PArgs<T> &a, long long gi, double sum, double invM, double direct) {
+  const int d = a.d;
+  double v = -sum * invM;
+  if (gi < d) return v;
+  if (a.family == MIVI_MEANFIELD) return v - direct / (double)a.params[gi];
+  long long j, i;
+  packed_col_row(gi, d, j, i);
+  if (i == j) v -= direct / (double)a.params[d + (size_t)j * d + j];
+  return v;
+}
+
+// phase 2 for R <= K sources (K in {1, 2, 4, 8}): 8 / K units of this thread x K sources per batch of eight loads.
+// A unit = 16 bytes = two payload words = EPU elements (float: 2, double: 1).
+template <typename T, int K, int NT>
+__device__ __forceinline__ bool p2p_reduce_chunk(const P2PArgs<T> &a, const P2PTable &tb, int p, unsigned epoch, long long c0, long long clen) {
+  constexpr int W = Words<T>::W, EPU = 2 / W, NV = 8 / K;
+  const int tid = threadIdx.x, R = a.world;
+  const long long n = a.n, tri_end = a.L - 2;
+  const double invM = 1.0 / (double)a.M_total, direct = direct_entropy_coeff(a.ent_kind);
+  const unsigned long long *st = tb.stage[a.rank] + ((size_t)(p * R) * n + c0) * W;   // + src * n * W + 2 * unit
+  const long long g0 = (long long)a.rank * n + c0;
+  const long long units = clen / EPU;
+  bool all_ok = true;
+  for (long long base = 0; base < units; base += (long long)NV * NT) {
+    const void *ptr[8];
+    unsigned need[8];
+    u32x4_t raw[8];
+    long long un[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      un[v] = base + (long long)v * NT + tid;
+      const bool in = un[v] < units;
+      const long long uc = in ? un[v] : 0;
+      // (elements at or beyond tri_end -- the two scalars, the padding -- are never pushed as final values and are not needed here
+      //  either: the scalars are summed by the value workgroup)
+      unsigned nd = 0;
+      if (in) {
+        const long long gi = g0 + uc * EPU;
+        if (EPU == 2) nd = (gi < tri_end ? 1u : 0u) | (gi + 1 < tri_end ? 2u : 0u);
+        else nd = gi < tri_end ? 3u : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        ptr[v * K + k] = st + (size_t)(k < R ? k : R - 1) * n * W + 2 * uc;
+        need[v * K + k] = k < R ? nd : 0u;
+      }
+    }
+    if (!ll_load8(ptr, need, epoch, a.spin_budget, raw)) all_ok = false;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (un[v] >= units) continue;
+      const long long gi0 = g0 + un[v] * EPU;
+      if (gi0 >= tri_end) continue;
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {   // rank order: the sum does not depend on who arrived first
+        if (k < R) {
+          unsigned wd[4];
+          __builtin_memcpy(wd, &raw[v * K + k], 16);   // {word, epoch, word, epoch}
+          if (EPU == 2) {
+            acc0 += (double)__builtin_bit_cast(float, wd[0]);
+            acc1 += (double)__builtin_bit_cast(float, wd[2]);
+          } else {
+            acc0 += Words<double>::make(wd[0], wd[2]);
+          }
+        }
+      }
+      unsigned ow0, ow1, dummy;
+      bool both = true;
+      if (EPU == 2) {
+        Words<float>::split((float)p2p_finalise(a, gi0, acc0, invM, direct), ow0, dummy);
+        both = gi0 + 1 < tri_end;
+        ow1 = 0u;
+        if (both) Words<float>::split((float)p2p_finalise(a, gi0 + 1, acc1, invM, direct), ow1, dummy);
+      } else {
+        Words<double>::split(p2p_finalise(a, gi0, acc0, invM, direct), ow0, ow1);
+      }
+      const size_t off = ((size_t)p * R * n + (size_t)gi0) * W;   // pair index inside a final area
+      if (both) {
+        const u32x4_t ov = {ow0, epoch, ow1, epoch};
+        for (int k = 0; k < R; ++k) store16_sys(tb.fin[(a.rank + 1 + k) % R] + off, ov);
+      } else {   // (the last element below the scalars at an even index: one pair)
+        const u32x2_t ov = {ow0, epoch};
+        for (int k = 0; k < R; ++k) store8_sys(tb.fin[(a.rank + 1 + k) % R] + off, ov);
+      }
+    }
+  }
+  return all_ok;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_p2p_exchange(P2PArgs<T> a) {
-  constexpr int NT = 256, V = 16 / sizeof(T);   // elements per 16-byte vector
+  constexpr int NT = 256, W = Words<T>::W, EPU = 2 / W;
   __shared__ int sh_ok;
   __shared__ double red[4];
   const int tid = threadIdx.x, g = blockIdx.x, R = a.world, G = a.G;
-  const unsigned epoch = a.ctr[0] + 1u;
-  const int p = (int)(epoch & 1u);
-  const long long n = a.n, Lp = n * R;
+  const unsigned epoch0 = a.ctr[0] + 1u;
+  const long long n = a.n;
   const P2PTable &tb = *a.tab;
   const bool value_wg = (g == G);
   const long long c0 = value_wg ? 0 : (long long)g * a.cn;
   const long long clen = value_wg ? 0 : ((c0 + a.cn <= n ? a.cn : (n > c0 ? n - c0 : 0)));
-  bool lost = false;
-
-  // ---- phase 1: push chunk g of every slice to its owner ---------------------------------------------------------------------
-  if ((a.phases & 1) && !value_wg) {
-    for (int k = 0; k < R; ++k) {
-      const int s = (a.rank + 1 + k) % R;   // start with the neighbour: the links fill evenly, the local copy comes last
-      const T *src = a.partials + (size_t)s * n + c0;
-      T *dst = (T *)tb.stage[s] + ((size_t)(p * R + a.rank)) * n + c0;
-      for (long long e = (long long)tid * V; e < clen; e += (long long)NT * V) store16_sys(dst + e, src + e);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid < R) flag_release(tb.arr[tid] + ((size_t)(p * R + a.rank)) * G + g, epoch);
-  }
-
-  // ---- phase 2: reduce + finalise chunk g of MY slice, push the final chunk to every rank -------------------------------------------
-  const double invM = 1.0 / (double)a.M_total;
-  const double direct = direct_entropy_coeff(a.ent_kind);
   const long long tri_end = a.L - 2;
   const int d = a.d;
-  if ((a.phases & 2) && !value_wg) {
-    if (!wait_flags<NT>(tb.arr[a.rank] + (size_t)(p * R) * G + g, R, G, epoch, a.spin_budget, &sh_ok)) lost = true;
-    const T *st = (const T *)tb.stage[a.rank] + (size_t)(p * R) * n + c0;
-    const long long g0 = (long long)a.rank * n + c0;
-    for (long long e = (long long)tid * V; e < clen; e += (long long)NT * V) {
-      double acc[V];
-#pragma unroll
-      for (int c = 0; c < V; ++c) acc[c] = 0.0;
-      for (int src = 0; src < R; ++src) {   // rank order: the sum does not depend on who arrived first
-#pragma unroll
-        for (int c = 0; c < V; ++c) acc[c] += (double)ld_sys(st + (size_t)src * n + e + c);
+  bool lost = false;
+
+  for (int t = 0; t < a.count; ++t) {
+    const unsigned epoch = epoch0 + (unsigned)t;
+    const int p = (int)(epoch & 1u);
+    const T *P = (t & 1) ? a.P1 : a.P0;
+    if (a.ready) {   // hand-over from the compute chain: the partial vector of estimate t is complete
+      if (tid == 0) {
+        int budget = a.spin_budget;
+        sh_ok = 1;
+        while ((int)(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ready_base) < t + 1) {
+          if (--budget <= 0) { sh_ok = 0; break; }
+          __builtin_amdgcn_s_sleep(4);
+        }
       }
-      T o[V] __attribute__((aligned(16)));
+      __syncthreads();
+      if (!sh_ok) lost = true;
+      __syncthreads();
+    }
+
+    // ---- phase 1: push chunk g of every slice to its owner (LL pairs) -----------------------------------------------------------------
+    if ((a.phases & 1) && !value_wg) {
+      const long long vecs = clen * W / 4;   // 16-byte vectors of payload words in a chunk (clen is a multiple of 4)
+      for (long long base = 0; base < vecs; base += 8LL * NT) {
+        for (int k = 0; k < R; ++k) {
+          const int s = (a.rank + 1 + k) % R;   // start with the neighbour: the links fill evenly, the local copy comes last
+          const unsigned *src = (const unsigned *)(P + (size_t)s * n + c0);
+          unsigned long long *dst = tb.stage[s] + ((size_t)(p * R + a.rank) * n + c0) * W;
+          const void *ptr[8];
+          u32x4_t r[8];
+          long long vi[8];
 #pragma unroll
-      for (int c = 0; c < V; ++c) {
-        const long long gi = g0 + e + c;
-        double v = -acc[c] * invM;
-        if (gi >= tri_end) {
-          v = 0.0;   // the two scalars belong to the value workgroup (which stores them itself), the rest is padding
-        } else if (gi >= d) {
-          if (a.family == MIVI_MEANFIELD) {
-            v -= direct / (double)a.params[gi];
-          } else {   // packed entry e2 = j d - j (j - 1) / 2 + (i - j): the diagonal entries carry the entropy term
-            const long long e2 = gi - d;
-            const double b = 2.0 * d + 1.0;
-            long long j = (long long)((b - sqrt(b * b - 8.0 * (double)e2)) * 0.5);
-            if (j < 0) j = 0;
-            if (j > d - 1) j = d - 1;
-            while (j > 0 && j * d - (j * (j - 1)) / 2 > e2) --j;
-            while (j + 1 < d && (j + 1) * d - ((j + 1) * j) / 2 <= e2) ++j;
-            if (e2 == j * d - (j * (j - 1)) / 2) v -= direct / (double)a.params[d + (size_t)j * d + j];
+          for (int u = 0; u < 8; ++u) {
+            vi[u] = base + (long long)u * NT + tid;
+            ptr[u] = src + 4 * (vi[u] < vecs ? vi[u] : 0);
+          }
+          ld16x8_sys(ptr, r);   // (system scope: the vector was written by the compute kernels' XCDs and this kernel never restarts)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (vi[u] >= vecs) continue;
+            const u32x4_t lo = {r[u][0], epoch, r[u][1], epoch}, hi = {r[u][2], epoch, r[u][3], epoch};
+            store16_sys(dst + 4 * vi[u], lo);
+            store16_sys(dst + 4 * vi[u] + 2, hi);
           }
         }
-        o[c] = (T)v;
       }
-      // (the vector that holds the scalars is stored without them: elements >= tri_end only ever sit in the value owner's slice, and
-      //  the value workgroup writes them with their own flag)
-      const long long gi0 = g0 + e;
-      if (gi0 + V <= tri_end || gi0 >= a.L) {
-        for (int k = 0; k < R; ++k) {
-          const int s = (a.rank + 1 + k) % R;
-          store16_sys((T *)tb.fin[s] + (size_t)p * Lp + gi0, o);
+      if (a.freed) {   // this workgroup is done reading estimate t's partial vector
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(a.freed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+
+    // ---- phase 3a (needs nothing from anybody): exact zeros above the diagonal of the dense gradient -------------------------------------
+    if ((a.phases & 4) && !value_wg && a.family == MIVI_FULLRANK && t == a.count - 1) {   // (every estimate of a batch writes the same buffer)
+      T *gc = a.grad + d;
+      for (int j = g + 1; j < d; j += G)
+        for (int i = tid; i < j; i += NT) gc[(size_t)j * d + i] = T(0);
+    }
+
+    // ---- phase 2: reduce + finalise chunk g of MY slice, push the final chunk to every rank -------------------------------------------
+    if ((a.phases & 2) && !value_wg) {
+      bool ok;
+      if (R == 1) ok = p2p_reduce_chunk<T, 1, NT>(a, tb, p, epoch, c0, clen);
+      else if (R == 2) ok = p2p_reduce_chunk<T, 2, NT>(a, tb, p, epoch, c0, clen);
+      else if (R <= 4) ok = p2p_reduce_chunk<T, 4, NT>(a, tb, p, epoch, c0, clen);
+      else ok = p2p_reduce_chunk<T, 8, NT>(a, tb, p, epoch, c0, clen);
+      if (!ok) lost = true;
+    }
+    if ((a.phases & 2) && value_wg && a.rank == a.vs) {   // the objective value: sum ell, sum 0.5|eps|^2 of all ranks + the parameter-only terms
+      double s_ld = 0.0, bad = 0.0;
+      for (int i = tid; i < d; i += NT) {
+        const double c = (double)(a.family == MIVI_MEANFIELD ? a.params[d + i] : a.params[d + (size_t)i * d + i]);
+        if (!(c > 0.0)) bad = 1.0;
+        s_ld += log(c);
+      }
+      s_ld = block_sum<double, NT>(s_ld, red);
+      bad = block_sum<double, NT>(bad, red);
+      if (tid == 0) {
+        const long long o0 = tri_end - (long long)a.vs * n;   // offset of the first scalar inside my slice
+        double sc[2] = {0.0, 0.0};
+        for (int src = 0; src < R; ++src)
+          for (int q = 0; q < 2; ++q) {
+            unsigned w[2] = {0u, 0u};
+            for (int h = 0; h < W; ++h)
+              if (!ll_load1(tb.stage[a.rank] + ((size_t)(p * R + src) * n + o0 + q) * W + h, epoch, a.spin_budget, w[h])) lost = true;
+            sc[q] += (double)Words<T>::make(w[0], w[1]);
+          }
+        const double Mt = (double)a.M_total;
+        const double ent = (ent_is_closed(a.ent_kind) ? 0.5 * d * (1.0 + kLog2Pi) : sc[1] / Mt + 0.5 * d * kLog2Pi) + s_ld;
+        const double value = -(sc[0] / Mt + ent);
+        int stt = 0;
+        if (!isfinite(value)) stt |= 1;
+        if (bad > 0.0) stt |= 2;
+        unsigned wv[2], ws[2];
+        Words<T>::split((T)value, wv[0], wv[1]);
+        Words<T>::split((T)stt, ws[0], ws[1]);
+        for (int s = 0; s < R; ++s) {
+          unsigned long long *dst = tb.fin[s] + ((size_t)p * R * n + tri_end) * W;
+          for (int h = 0; h < W; ++h) {
+            const u32x2_t v1 = {wv[h], epoch}, v2 = {ws[h], epoch};
+            store8_sys(dst + h, v1);
+            store8_sys(dst + W + h, v2);
+          }
+        }
+      }
+    }
+
+    // ---- phase 3: unpack chunk g of every final slice ------------------------------------------------------------------------------------
+    if (a.phases & 4) {
+      const unsigned long long *fin = tb.fin[a.rank] + (size_t)p * R * n * W;
+      if (value_wg) {
+        if (tid == 0) {
+          unsigned wv[2] = {0u, 0u}, ws[2] = {0u, 0u};
+          for (int h = 0; h < W; ++h) {
+            if (!ll_load1(fin + (size_t)tri_end * W + h, epoch, a.spin_budget, wv[h])) lost = true;
+            if (!ll_load1(fin + (size_t)(tri_end + 1) * W + h, epoch, a.spin_budget, ws[h])) lost = true;
+          }
+          *a.value = Words<T>::make(wv[0], wv[1]);
+          const int stt = (int)Words<T>::make(ws[0], ws[1]);
+          if (stt && a.status) atomicOr(a.status, stt);
         }
       } else {
-        for (int k = 0; k < R; ++k) {
-          const int s = (a.rank + 1 + k) % R;
-          T *dst = (T *)tb.fin[s] + (size_t)p * Lp + gi0;
-          for (int c = 0; c < V; ++c)
-            if (gi0 + c < tri_end) __hip_atomic_store(dst + c, o[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long units = clen / EPU, total = units * R;   // unit index x = s * units + u
+        for (long long base = 0; base < total; base += 8LL * NT) {
+          const void *ptr[8];
+          unsigned need[8];
+          u32x4_t raw[8];
+          long long gi0[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const long long x = base + (long long)u * NT + tid;
+            const bool in = x < total;
+            const long long s = in ? x / units : 0, uu = in ? x % units : 0;
+            gi0[u] = s * n + c0 + uu * EPU;
+            ptr[u] = fin + (size_t)gi0[u] * W;
+            need[u] = 0;
+            if (in) {
+              if (EPU == 2) need[u] = (gi0[u] < tri_end ? 1u : 0u) | (gi0[u] + 1 < tri_end ? 2u : 0u);
+              else need[u] = gi0[u] < tri_end ? 3u : 0u;
+            }
+          }
+          if (!ll_load8(ptr, need, epoch, a.spin_budget, raw)) lost = true;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (!need[u]) continue;
+            unsigned wd[4];
+            __builtin_memcpy(wd, &raw[u], 16);   // {word, epoch, word, epoch}
+            T x0, x1 = T(0);
+            if (EPU == 2) {
+              x0 = Words<T>::make(wd[0], 0u);
+              x1 = Words<T>::make(wd[2], 0u);
+            } else {
+              x0 = Words<T>::make(wd[0], wd[2]);
+            }
+#pragma unroll
+            for (int c = 0; c < EPU; ++c) {
+              const long long gi = gi0[u] + c;
+              if (gi >= tri_end) continue;
+              long long di = gi;
+              if (a.family != MIVI_MEANFIELD && gi >= d) {
+                long long j, i;
+                packed_col_row(gi, d, j, i);
+                di = d + j * d + i;
+              }
+              a.grad[di] = c == 0 ? x0 : x1;
+            }
+          }
         }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid < R) flag_release(tb.farr[tid] + ((size_t)(p * R + a.rank)) * (G + 1) + g, epoch);
-  }
-  if ((a.phases & 2) && value_wg && a.rank == a.vs) {   // the objective value: sum ell, sum 0.5|eps|^2 of all ranks + the parameter-only terms
-    const long long o0 = tri_end - (long long)a.vs * n, o1 = o0 + 1;   // offsets of the two scalars inside my slice
-    const int ga = (int)(o0 / a.cn), gb = (int)(o1 / a.cn);
-    if (!wait_flags<NT>(tb.arr[a.rank] + (size_t)(p * R) * G + ga, R, G, epoch, a.spin_budget, &sh_ok)) lost = true;
-    if (gb != ga && !wait_flags<NT>(tb.arr[a.rank] + (size_t)(p * R) * G + gb, R, G, epoch, a.spin_budget, &sh_ok)) lost = true;
-    double s_ld = 0.0, bad = 0.0;
-    for (int i = tid; i < d; i += NT) {
-      const double c = (double)(a.family == MIVI_MEANFIELD ? a.params[d + i] : a.params[d + (size_t)i * d + i]);
-      if (!(c > 0.0)) bad = 1.0;
-      s_ld += log(c);
-    }
-    s_ld = block_sum<double, NT>(s_ld, red);
-    bad = block_sum<double, NT>(bad, red);
-    if (tid == 0) {
-      const T *st = (const T *)tb.stage[a.rank] + (size_t)(p * R) * n;
-      double sum_ell = 0.0, s_he = 0.0;
-      for (int src = 0; src < R; ++src) {
-        sum_ell += (double)ld_sys(st + (size_t)src * n + o0);
-        s_he += (double)ld_sys(st + (size_t)src * n + o1);
-      }
-      const double Mt = (double)a.M_total;
-      const double ent = (ent_is_closed(a.ent_kind) ? 0.5 * d * (1.0 + kLog2Pi) : s_he / Mt + 0.5 * d * kLog2Pi) + s_ld;
-      const double value = -(sum_ell / Mt + ent);
-      int stt = 0;
-      if (!isfinite(value)) stt |= 1;
-      if (bad > 0.0) stt |= 2;
-      for (int s = 0; s < R; ++s) {
-        T *dst = (T *)tb.fin[s] + (size_t)p * Lp;
-        __hip_atomic_store(dst + tri_end, (T)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(dst + tri_end + 1, (T)stt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      for (int s = 0; s < R; ++s) flag_release(tb.farr[s] + ((size_t)(p * R + a.vs)) * (G + 1) + G, epoch);
-    }
-  }
-
-  // ---- phase 3: unpack the packed final vector ---------------------------------------------------------------------------------------
-  if (a.phases & 4) {
-    const T *fin = (const T *)tb.fin[a.rank] + (size_t)p * Lp;
-    if (value_wg) {
-      if (!wait_flags<NT>(tb.farr[a.rank] + ((size_t)(p * R + a.vs)) * (G + 1) + G, 1, 1, epoch, a.spin_budget, &sh_ok)) lost = true;
-      if (tid == 0) {
-        *a.value = ld_sys(fin + tri_end);
-        const int stt = (int)ld_sys(fin + tri_end + 1);
-        if (stt && a.status) atomicOr(a.status, stt);
-      }
-    } else {
-      // my share of the dense gradient touches chunks of every slice: wait for all R x G final chunks
-      bool ok = true;
-      for (int s = 0; s < R; ++s)
-        if (!wait_flags<NT>(tb.farr[a.rank] + ((size_t)(p * R + s)) * (G + 1), G, 1, epoch, a.spin_budget, &sh_ok)) ok = false;
-      if (!ok) lost = true;
-      const long long plen = a.family == MIVI_MEANFIELD ? 2 * (long long)d : (long long)d + (long long)d * d;
-      const long long pc = ((plen + G - 1) / G + 3) & ~3LL;
-      const long long t0 = (long long)g * pc, t1 = t0 + pc < plen ? t0 + pc : plen;
-      for (long long t = t0 + tid; t < t1; t += NT) {
-        T v;
-        if (a.family == MIVI_MEANFIELD || t < d) {
-          v = ld_sys(fin + t);
-        } else {
-          const long long e2 = t - d, j = e2 / d, i = e2 - j * d;
-          v = (j > i) ? T(0) : ld_sys(fin + d + j * d - (j * (j - 1)) / 2 + (i - j));
-        }
-        a.grad[t] = v;
       }
     }
   }
@@ -241,17 +430,34 @@ __global__ __launch_bounds__(256) void k_p2p_exchange(P2PArgs<T> a) {
   if (a.phases & 4) {
     __syncthreads();
     if (tid == 0) {
-      const unsigned t = __hip_atomic_fetch_add(a.ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      if (t == (unsigned)G) {
+      const unsigned tk = __hip_atomic_fetch_add(a.ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (tk == (unsigned)G) {
         __hip_atomic_store(a.ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.ctr, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.ctr, epoch0 + (unsigned)a.count - 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
 }
 
+// hand-over words of the pipelined batch on the COMPUTE chain (one thread): announce a complete partial vector (ready = ready_val), then
+// hold the chain until the exchange has read the buffer the NEXT estimate's kernels are going to overwrite (freed - freed_min >= 0)
+__global__ void k_p2p_handover(unsigned *ready, unsigned ready_val, const unsigned *freed, unsigned freed_min, int budget, int *status) {
+  if (ready) __hip_atomic_store(ready, ready_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (freed) {
+    while ((int)(__hip_atomic_load(freed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - freed_min) < 0) {
+      if (--budget <= 0) { if (status) atomicOr(status, 8); break; }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+}
+
 // host side -------------------------------------------------------------------------------------------------------------------------
-void launch_p2p_exchange(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad, int phases) {
+void launch_p2p_handover(mivi_ctx *c, unsigned *ready, unsigned ready_val, const unsigned *freed, unsigned freed_min) {
+  hipLaunchKernelGGL(k_p2p_handover, dim3(1), dim3(1), 0, c->stream, ready, ready_val, freed, freed_min, c->p2p_spin, (int *)c->status.p);
+}
+
+void launch_p2p_exchange(mivi_ctx *c, const void *params, const void *P0, const void *P1, void *value, void *grad, int phases, int count,
+                         const unsigned *ready, unsigned ready_base, unsigned *freed) {
   auto fill = [&](auto &a) {
     a.d = c->cfg.d; a.family = c->cfg.family; a.ent_kind = c->cfg.entropy; a.M_total = c->M_total;
     a.L = mivi_partials_len(c); a.n = c->p2p_n; a.cn = c->p2p_cn;
@@ -261,16 +467,20 @@ void launch_p2p_exchange(mivi_ctx *c, const void *params, const void *partials, 
     a.status = (int *)c->status.p;
     a.phases = phases;
     a.spin_budget = c->p2p_spin;
+    a.count = count;
+    a.ready = ready;
+    a.ready_base = ready_base;
+    a.freed = freed;
   };
   if (c->cfg.dtype == MIVI_F32) {
     P2PArgs<float> a{};
     fill(a);
-    a.partials = (const float *)partials; a.params = (const float *)params; a.value = (float *)value; a.grad = (float *)grad;
+    a.P0 = (const float *)P0; a.P1 = (const float *)P1; a.params = (const float *)params; a.value = (float *)value; a.grad = (float *)grad;
     hipLaunchKernelGGL(k_p2p_exchange<float>, dim3(c->p2p_G + 1), dim3(256), 0, c->stream, a);
   } else {
     P2PArgs<double> a{};
     fill(a);
-    a.partials = (const double *)partials; a.params = (const double *)params; a.value = (double *)value; a.grad = (double *)grad;
+    a.P0 = (const double *)P0; a.P1 = (const double *)P1; a.params = (const double *)params; a.value = (double *)value; a.grad = (double *)grad;
     hipLaunchKernelGGL(k_p2p_exchange<double>, dim3(c->p2p_G + 1), dim3(256), 0, c->stream, a);
   }
 }

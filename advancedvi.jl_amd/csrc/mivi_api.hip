@@ -935,7 +935,7 @@ struct P2PHandle {   // what travels between the ranks (MIVI_P2P_HANDLE_BYTES = 
 };
 static_assert(sizeof(P2PHandle) <= MIVI_P2P_HANDLE_BYTES, "handle blob");
 constexpr uint32_t kP2PMagic = 0x4D495650u;   // "MIVP"
-struct P2PTableHost { char *stage[8]; char *fin[8]; unsigned *arr[8]; unsigned *farr[8]; };
+struct P2PTableHost { unsigned long long *stage[8]; unsigned long long *fin[8]; };
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -944,8 +944,10 @@ void p2p_geometry(long long L, int R, long long &n, long long &cn, int &G, int &
   n = ((L + R - 1) / R + 3) & ~3LL;
   while ((L - 1) % n == 0) n += 4;        // the two scalars (L - 2, L - 1) must lie in ONE slice
   vs = (int)((L - 2) / n);
-  long long g = (n + 2047) / 2048;
-  G = (int)(g < 1 ? 1 : (g > 64 ? 64 : g));
+  // many small chunks: system-scope (L2-bypassing) accesses are limited per CU (a few GB/s each: ~0.4 TB/s with 128 workgroups), so
+  // the exchange wants every CU, not few workgroups with long loops
+  long long g = (n + 511) / 512;
+  G = (int)(g < 1 ? 1 : (g > 512 ? 512 : g));
   cn = ((n + G - 1) / G + 3) & ~3LL;
 }
 }  // namespace
@@ -986,9 +988,10 @@ mivi_status_t mivi_p2p_export(mivi_ctx_t *c, int32_t rank, int32_t world, void *
   int G, vs;
   p2p_geometry(L, world, n, cn, G, vs);
   const size_t es = c->esize;
-  const size_t b_stage = align256((size_t)2 * world * n * es), b_fin = align256((size_t)2 * world * n * es);
-  const size_t b_arr = align256((size_t)2 * world * G * 4), b_farr = align256((size_t)2 * world * (G + 1) * 4);
-  const size_t bytes = b_stage + b_fin + b_arr + b_farr;
+  // LL layout: every 32-bit payload word travels as an 8-byte (word, epoch) pair
+  const size_t W = es / 4;
+  const size_t b_stage = align256((size_t)2 * world * n * W * 8), b_fin = align256((size_t)2 * world * n * W * 8);
+  const size_t bytes = b_stage + b_fin;
   // FINE-GRAINED device memory: peers write it over xGMI, system-scope releases / acquires and the consumers' system-scope loads
   // (kernels_p2p.hip ld_sys) keep it coherent.  NOT hipDeviceMallocUncached: on this stack (ROCm 7.0 / gfx950) running the exchange on an
   // uncached allocation corrupted UNRELATED buffers of later contexts once the area had been freed and its pages re-used (found on one
@@ -1002,7 +1005,7 @@ mivi_status_t mivi_p2p_export(mivi_ctx_t *c, int32_t rank, int32_t world, void *
   c->p2p_buf = buf;
   c->p2p_bytes = bytes;
   c->p2p_rank = rank; c->p2p_world = world; c->p2p_n = n; c->p2p_cn = cn; c->p2p_G = G; c->p2p_vs = vs;
-  c->p2p_off_fin = b_stage; c->p2p_off_arr = b_stage + b_fin; c->p2p_off_farr = b_stage + b_fin + b_arr;
+  c->p2p_off_fin = b_stage;
   P2PHandle h{};
   h.magic = kP2PMagic; h.version = 1; h.rank = rank; h.world = world; h.L = L; h.n = n; h.cn = cn; h.esize = (int32_t)es; h.G = G;
   h.bytes = bytes; h.pid = (uint64_t)getpid(); h.local_ptr = (uint64_t)(uintptr_t)buf; h.device = c->cfg.device;
@@ -1048,20 +1051,25 @@ mivi_status_t mivi_p2p_attach(mivi_ctx_t *c, const void *handles) {
       c->p2p_opened[r] = true;
     }
     c->p2p_peer[r] = base;
-    tab.stage[r] = (char *)base;
-    tab.fin[r] = (char *)base + c->p2p_off_fin;
-    tab.arr[r] = (unsigned *)((char *)base + c->p2p_off_arr);
-    tab.farr[r] = (unsigned *)((char *)base + c->p2p_off_farr);
+    tab.stage[r] = (unsigned long long *)base;
+    tab.fin[r] = (unsigned long long *)((char *)base + c->p2p_off_fin);
   }
   mivi_status_t s;
-  if ((s = ensure(c, c->p2p_tab, sizeof(tab), false)) || (s = ensure(c, c->p2p_ctr, 64, false))) return s;
+  if ((s = ensure(c, c->p2p_tab, sizeof(tab), false)) || (s = ensure(c, c->p2p_ctr, 256, false))) return s;
   HIPCHK(c, hipMemcpy(c->p2p_tab.p, &tab, sizeof(tab), hipMemcpyHostToDevice));
   // (stream-ordered on the context's stream and waited for: a null-stream memset is NOT ordered against a non-blocking stream and
   //  would zero the epoch counter after the first exchange has advanced it)
-  HIPCHK(c, hipMemsetAsync(c->p2p_ctr.p, 0, 64, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->p2p_ctr.p, 0, 256, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   invalidate_graph(c);
   c->p2p_on = true;
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_p2p_set_spin_budget(mivi_ctx_t *c, int32_t polls) {
+  if (!c || polls < 16) return MIVI_ERR_BAD_ARG;
+  c->p2p_spin = polls;
+  invalidate_graph(c);
   return MIVI_OK;
 }
 
@@ -1174,7 +1182,7 @@ static mivi_status_t dist_collective(mivi_ctx *c, const void *params, void *P, v
   const size_t es = c->esize;
   const int route = mivi_comm_route(c);
   if (route == 3) {
-    launch_p2p_exchange(c, params, P, value, grad, 7);
+    launch_p2p_exchange(c, params, P, P, value, grad, 7, 1, nullptr, 0u, nullptr);
     HIPCHK(c, hipGetLastError());
     return MIVI_OK;
   }
@@ -1542,6 +1550,11 @@ static mivi_status_t dist_sequence(mivi_ctx *c, const void *params, bool counter
       if ((s = run_estimate(c, params, r, c->cfg.n_mc, 1, o))) break;
     }
     if (mode == 2) continue;
+    if (mode == 4) {   // peer-to-peer pipeline, compute chain: announce partial vector i, then wait until the exchange has read the buffer estimate i + 1 overwrites
+      unsigned *w = (unsigned *)c->p2p_ctr.p;
+      launch_p2p_handover(c, w + 16, (unsigned)i + 1u, i >= 1 ? w + 32 : nullptr, (unsigned)i * (unsigned)c->p2p_G);
+      continue;
+    }
     if (mode == 0) {
       HIPCHK(c, hipEventRecord(c->ev_part[par], main));
       HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_part[par], 0));
@@ -1578,8 +1591,12 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
     }
   }
   GraphCache &g = c->graph;
-  const int kind = 20 + mode;
   const int route = mivi_comm_route(c);
+  // Peer-to-peer route, pipelined: the exchange is ONE persistent kernel on comm_stream for the whole batch (kernels_p2p.hip), the compute
+  // chain is a single-stream graph of {partial kernels, hand-over} per estimate; the two talk through two device words.
+  const bool p2p_pipe = mode == 0 && route == 3;
+  if (p2p_pipe) mode = 4;
+  const int kind = 20 + mode;
   static bool capture_refused = false;   // (a collective library that cannot be captured: do not retry on every call)
   if (!(g.exec && g.kind == kind && g.count == count && g.params == params && g.value == value && g.grad == grad && g.p0 == (double)route) && !capture_refused) {
     invalidate_graph(c);
@@ -1602,17 +1619,33 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
       g.kind = kind; g.count = count; g.params = params; g.value = value; g.grad = grad; g.p0 = (double)route;
     }
   }
+  auto p2p_front = [&]() -> mivi_status_t {   // hand-over words reset, then the persistent exchange kernel on its own stream
+    unsigned *w = (unsigned *)c->p2p_ctr.p;
+    HIPCHK(c, hipMemsetAsync(w + 16, 0, 128, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev_part[0], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_part[0], 0));
+    hipStream_t main = c->stream;
+    c->stream = c->comm_stream;
+    launch_p2p_exchange(c, params, c->dist_P.p, c->dist_P2.p, value, grad, 7, count, w + 16, 0u, w + 32);
+    c->stream = main;
+    HIPCHK(c, hipEventRecord(c->ev_comm[0], c->comm_stream));
+    return MIVI_OK;
+  };
   if (g.exec && g.kind == kind && g.count == count && g.params == params && g.value == value && g.grad == grad && g.p0 == (double)route) {
     if (!(c->d_idx_valid && c->d_idx_expect == idx0))
       hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, idx0, 0ull, 1);
+    if (p2p_pipe && (s = p2p_front())) return s;
     HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
+    if (p2p_pipe) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_comm[0], 0));
     c->d_idx_valid = mode != 3;
     c->d_idx_expect = idx0 + (uint64_t)count;
     return MIVI_OK;
   }
   // eager: the same sequence with by-value indices
   c->pre_valid = false;
+  if (p2p_pipe && (s = p2p_front())) return s;
   s = dist_sequence(c, params, false, idx0, count, value, grad, mode);
+  if (p2p_pipe && s == MIVI_OK) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_comm[0], 0));
   c->cur = 0;
   c->pre_valid = false;
   return s;
@@ -1629,7 +1662,7 @@ mivi_status_t mivi_p2p_exchange(mivi_ctx_t *c, const void *params, const void *p
   if (!c || !params || !partials || !value || !grad || phases < 1 || phases > 7) return MIVI_ERR_BAD_ARG;
   if (!c->p2p_on) return fail(c, MIVI_ERR_BAD_ARG, "no peer-to-peer exchange buffers attached");
   (void)hipSetDevice(c->cfg.device);
-  launch_p2p_exchange(c, params, partials, value, grad, phases);
+  launch_p2p_exchange(c, params, partials, partials, value, grad, phases, 1, nullptr, 0u, nullptr);
   HIPCHK(c, hipGetLastError());
   return MIVI_OK;
 }

@@ -238,7 +238,7 @@ struct mivi_ctx {
   bool p2p_on = false;
   int p2p_rank = 0, p2p_world = 1, p2p_G = 1, p2p_vs = 0, p2p_spin = 1 << 21;
   long long p2p_n = 0, p2p_cn = 0;
-  size_t p2p_off_fin = 0, p2p_off_arr = 0, p2p_off_farr = 0;
+  size_t p2p_off_fin = 0;
   // logreg
   const void *lr_X = nullptr;
   const uint8_t *lr_y = nullptr;
@@ -369,7 +369,9 @@ bool logreg_reserve(mivi_ctx *c, int M);                        // size the scra
 bool logreg_prepare_f32(mivi_ctx *c);   // row-major padded copy of X for the MFMA route (false: allocation failed)
 
 // kernels_p2p.hip: phases bit 0 push, 1 reduce + finalise, 2 unpack (7 = the whole exchange in one launch)
-void launch_p2p_exchange(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad, int phases = 7);
+void launch_p2p_exchange(mivi_ctx *c, const void *params, const void *P0, const void *P1, void *value, void *grad, int phases, int count,
+                         const unsigned *ready, unsigned ready_base, unsigned *freed);   // count > 1: persistent over a batch (P[t & 1])
+void launch_p2p_handover(mivi_ctx *c, unsigned *ready, unsigned ready_val, const unsigned *freed, unsigned freed_min);
 
 // kernels_update.hip
 void launch_finalize(mivi_ctx *c, const void *params, const void *partials, void *value, void *grad);

@@ -12,8 +12,10 @@ Workloads (BASELINE.json `configs` / north star):
   c2            BASELINE configs[1]: d=1024 mean-field, n_mc=256, same target, f32
   ns_dense      north-star family with the dense-Gaussian target N(m, L L') of SURVEY.md 8d
 N > 1: weak scaling -- every rank draws its own n_mc-sample shard of ONE estimate of n_mc*N samples
-(shard-invariant Philox stream), one RCCL all-reduce on the gradient partials, finalize on every rank;
-`value` counts n_mc-sample estimate units processed by all ranks per second.
+(shard-invariant Philox stream); the partial vectors are summed by the peer-to-peer exchange kernel written for xGMI
+(csrc/kernels_p2p.hip; RCCL when the areas cannot be mapped), the exchange of estimate t overlapped with the kernels of
+estimate t+1; `value` counts n_mc-sample estimate units processed by all ranks per second; `dist` holds the route taken and the
+per-stage times {partials, exchange, serial, pipelined}.
 """
 import argparse
 import json
@@ -342,53 +344,79 @@ def main():
                 for i in range(done, n):
                     ctx.estimate_gradient(params, idx0 + i, value, grad)
         else:
-            drv = avi.distributed.DistributedRepGradELBO(q, prob, w["n_mc"] * world, ent, SEED, device=local_rank,
-                                                         force_collective=force_dist, mode=os.environ.get("MIVI_DIST_MODE", "auto"))
-            ctx = drv.ctx
+            # N > 1 (or MIVI_FORCE_DIST=1 on one GPU): every rank draws its n_mc-sample shard of ONE estimate of n_mc * N samples; the
+            # exchange runs behind the C ABI.  Route: the peer-to-peer kernel written for xGMI when the exchange areas can be mapped
+            # (checked against the RCCL all-reduce route on the first estimate, every rank must agree), RCCL otherwise;
+            # MIVI_DIST_MODE = auto | p2p | allreduce | rsag pins it.  Timed: the PIPELINED batch (mivi_estimate_gradient_dist_n: exchange of
+            # estimate t under the kernels of t + 1 -- estimates at fixed parameters are independent, as in the N = 1 line); the
+            # dependent-chain step and the per-stage times are reported beside it (`dist`).
+            plan = avi.distributed.ShardPlan(w["n_mc"] * world, world)
+            ctx = avi.MiviContext(np.float32, w["family"], w["d"], plan.count(rank), ent.code, SEED, device=local_rank,
+                                  m_offset=plan.offset(rank), m_total=plan.n_samples)
+            ctx.set_problem(prob)
             params = ctx.to_device(params_h)
+            value, grad = ctx.empty(1), ctx.empty(ctx.params_len)
+            dev = f"cuda:{local_rank}"
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
+            if world > 1:
+                dist.broadcast(idt, src=0)
+            with quiet_stdout():
+                ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
 
-            value, grad = drv.value, drv.grad
-            drv.estimate_gradient(params, 0)          # allocate every work buffer before any capture
-            stream.synchronize()
-            # Steps are {partials kernels -> RCCL all-reduce -> finalize}.  Capture `chunk` of them in one graph (kernels AND
-            # the collective), estimate index = offset + device counter; fall back to eager launches if capture is refused.
-            chunk = max(1, min(20, K))
-            idx_dev = torch.zeros(1, dtype=torch.int64, device=f"cuda:{local_rank}")
-            graph = None
-            if os.environ.get("MIVI_DIST_EAGER") is None:
+            def all_ok(flag):
+                t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+                if dist:
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return int(t.item()) == 1
+
+            want = os.environ.get("MIVI_DIST_MODE", "auto")
+            dist_info = {"requested": want}
+            p2p_ok = False
+            if want in ("auto", "p2p"):
                 try:
-                    ctx.set_index_source(idx_dev)
-                    g = torch.cuda.CUDAGraph()
-                    # thread-local capture mode: RCCL's watchdog thread may query events while this thread captures
-                    with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
-                        for i in range(chunk):
-                            drv.estimate_gradient(params, i)
-                    graph = g
-                except Exception as e:   # noqa: BLE001
-                    print(f"[bench] rank {rank}: graph capture of the distributed step failed ({type(e).__name__}: {e}); eager launches",
-                          file=sys.stderr)
-                    torch.cuda.synchronize()
-            # every rank must take the same route: replay the graph only if the capture succeeded everywhere
-            okflag = torch.tensor([1 if graph is not None else 0], dtype=torch.int32, device=f"cuda:{local_rank}")
-            if dist:
-                dist.all_reduce(okflag, op=dist.ReduceOp.MIN)
-            if int(okflag.item()) == 0:
-                graph = None
-                ctx.set_index_source(None)
+                    with quiet_stdout():
+                        ctx.comm_enable_p2p()
+                    p2p_ok = True
+                except avi.MiviError as e:
+                    dist_info["p2p_error"] = str(e)
+                p2p_ok = all_ok(p2p_ok)
+                if p2p_ok:   # self-check: the peer-to-peer estimate against the RCCL all-reduce estimate, on every rank
+                    try:
+                        ctx.comm_set_route("allreduce")
+                        v_r, g_r = ctx.estimate_gradient_dist(params, 3)
+                        ctx.synchronize()
+                        v_r, g_r = float(v_r.item()), g_r.clone()
+                        ctx.comm_set_route("p2p")
+                        v_p, g_p = ctx.estimate_gradient_dist(params, 3)
+                        ctx.synchronize()
+                        rel_g = float((g_p - g_r).norm() / g_r.norm())
+                        good = abs(float(v_p.item()) - v_r) <= 1e-5 * abs(v_r) and rel_g <= 1e-5
+                        dist_info["p2p_vs_allreduce"] = dict(value_rel=abs(float(v_p.item()) - v_r) / abs(v_r), grad_rel_l2=rel_g)
+                    except avi.MiviError as e:
+                        good = False
+                        dist_info["p2p_error"] = str(e)
+                    p2p_ok = all_ok(good)
+                if not p2p_ok:
+                    try:
+                        ctx.p2p_detach()
+                    except avi.MiviError:
+                        pass
+            ctx.comm_set_route("p2p" if p2p_ok else (want if want in ("allreduce", "rsag") else "auto"))
+            dist_info["route"] = ctx.comm_route()
+            ctx.estimate_gradient_dist(params, 0, value, grad)          # allocate every work buffer before any capture
+            ctx.synchronize()
+            chunk = max(1, min(20, K))
+            pipelined = os.environ.get("MIVI_DIST_PIPELINE", "1") != "0"
 
             def run(idx0, n):
                 done = 0
-                if graph is not None:
-                    while done + chunk <= n:
-                        idx_dev.fill_(idx0 + done)
-                        graph.replay()
-                        done += chunk
-                    idx_dev.fill_(idx0 + done)
-                    for i in range(n - done):
-                        drv.estimate_gradient(params, i)
-                else:
-                    for i in range(n):
-                        drv.estimate_gradient(params, idx0 + i)
+                while pipelined and done + chunk <= n:
+                    ctx.estimate_gradient_dist_n(params, idx0 + done, chunk, value, grad)
+                    done += chunk
+                for i in range(done, n):
+                    ctx.estimate_gradient_dist(params, idx0 + i, value, grad)
 
         run(0, W)
         if single and W < chunk:   # make sure the hipGraph is captured + instantiated outside the timed region
@@ -408,6 +436,17 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
 
+        if not single:
+            # per-stage times of the sharded step (hipEvents around hipGraph replays of 20 estimates, every rank collectively):
+            # partial kernels | exchange + finalisation | the dependent-chain step | the pipelined step
+            try:
+                dist_info["us_per_estimate"] = {k: round(v, 3) for k, v in ctx.profile_dist(params, 20).items()}
+            except avi.MiviError as e:
+                dist_info["profile_error"] = str(e)
+            try:
+                ctx.synchronize()
+            except avi.MiviError as e:
+                dist_info["status_error"] = str(e)
         out = None
         if rank == 0:
             cost = algorithmic_cost(w)
@@ -568,9 +607,11 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": w["name"], "d": w["d"], "n_mc_per_gpu": w["n_mc"], "n_mc_total": w["n_mc"] * world,
                            "family": "fullrank" if w["family"] else "meanfield", "seed": hex(SEED),
-                           "launch": f"hipGraph x{chunk}" if single else ((f"CUDAGraph x{chunk} incl. RCCL " if graph is not None else "eager + RCCL ") + {"allreduce": "all-reduce", "rsag": "reduce-scatter + all-gather", "mivi": "reduce-scatter + all-gather behind the C ABI"}[drv.mode])},
+                           "launch": f"hipGraph x{chunk}" if single else (f"mivi_estimate_gradient_dist_n x{chunk} (pipelined: exchange of estimate t under the kernels of t+1), route {dist_info['route']}" if pipelined else f"mivi_estimate_gradient_dist (dependent chain), route {dist_info['route']}"),
+                           "fullrank_route": (list(ctx.fullrank_route()) if w["family"] == 1 else None)},
                 "roofline": roof, "cpu_baseline": cpub,
                 "elbo_rel_err_vs_cpu_fp64": rel, "stage_us": stages, "whole_estimate": whole, "steady_state": steady, "concurrent": conc, "also": also,
+                "dist": (None if single else dist_info),
             }
         if dist:
             dist.barrier()

@@ -313,6 +313,8 @@ mivi_status_t mivi_p2p_detach(mivi_ctx_t *ctx);
  * length L over `world` ranks (no GPU needed) */
 void mivi_p2p_geometry(int64_t L, int32_t world, int64_t *out4);
 mivi_status_t mivi_comm_enable_p2p(mivi_ctx_t *ctx);
+/* how many polls (about 1 us each) a wait inside the exchange may take before the peer counts as lost (default 2^21, about 2 s) */
+mivi_status_t mivi_p2p_set_spin_budget(mivi_ctx_t *ctx, int32_t polls);
 /* Which exchange mivi_estimate_gradient_dist[_n] uses: 0 = automatic (peer-to-peer when attached, otherwise ONE ncclAllReduce + the whole
  * finalisation on every rank below 16 MB of partials and ncclReduceScatter -> slice finalisation -> ncclAllGather -> unpack above),
  * 1 = ncclAllReduce, 2 = ncclReduceScatter / ncclAllGather, 3 = peer-to-peer.  mivi_comm_route reports the route in force. */
