@@ -17,7 +17,7 @@
 // Synchronisation is in the DATA ("LL" layout, as RCCL's low-latency protocol): every 32-bit payload word travels as an 8-byte pair
 // (word, epoch) written by ONE store, so a reader that finds the epoch of this exchange in a pair has the word -- no separate flag,
 // no store acknowledge to wait for, no flag poll: a phase costs one (repeated until complete) load round trip instead of
-// {store acknowledge, flag round trip, data round trip} (the flag version of this kernel: 29 us per exchange on one GPU).  Twice the
+// {store acknowledge, flag round trip, data round trip} (measured on one GPU, DESIGN.md 7: the flag version of this kernel 29-40 us per exchange, this one 33 us).  Twice the
 // bytes; the exchange is latency bound (2 MB).
 //
 // Slices are cut into G chunks; workgroup g of every rank handles chunk g of every slice in all three phases, so workgroup g only
@@ -27,8 +27,10 @@
 //
 // The kernel is PERSISTENT over a batch of `count` estimates (mivi_estimate_gradient_dist_n): it runs on its own stream beside the
 // compute chain and is handed each partial vector through two device words -- `ready` (set by the compute chain when the partial
-// vector of estimate t is complete) and `freed` (bumped by every workgroup once it has read its part of that vector; the compute
-// chain checks it before estimate t + 2 overwrites the buffer).  No stream events, no graph fork / join per estimate.
+// vector of estimate t is complete) and `freed[slot]` (bumped by every workgroup once it has read its part of the vector in ring slot `slot`; the compute
+// chain checks it before that ring slot is overwritten).  No stream events, no graph fork / join per estimate.  A batch is served by
+// `lanes` such kernels (estimate t by lane t mod lanes, each lane with its own areas and epochs): an exchange is a chain of memory round
+// trips, two in flight hide each other's waits.
 //
 // Memory: one fine-grained allocation per rank, mapped into its peers through HIP IPC (mivi_p2p_export / mivi_p2p_attach).  Every access
 // to it is system scope (sc0 sc1): stores write through, loads never hit a line an XCD's L2 kept from two epochs ago.  No cache-wide
@@ -38,9 +40,11 @@
 
 namespace mivi {
 
-struct P2PTable {   // device resident: where every rank's exchange areas are mapped in THIS process
-  unsigned long long *stage[8];   // [2][R][n W] pairs: stage[s] = rank s's staging area (contribution of rank `src` to slice s at [parity][src])
-  unsigned long long *fin[8];     // [2][R n W] pairs : rank s's packed final vector
+constexpr int kP2PLanes = 2, kP2PRing = 4;
+
+struct P2PTable {   // device resident: where every rank's exchange areas are mapped in THIS process, per lane
+  unsigned long long *stage[kP2PLanes][8];   // [2][R][n W] pairs: stage[s] = rank s's staging area (contribution of rank `src` to slice s at [parity][src])
+  unsigned long long *fin[kP2PLanes][8];     // [2][R n W] pairs : rank s's packed final vector
 };
 
 template <typename T>
@@ -49,17 +53,18 @@ struct P2PArgs {
   long long L, n, cn;        // partial length; slice length (multiple of 4); chunk length (multiple of 4)
   int rank, world, G, vs;    // vs = the rank whose slice holds the two scalars (sum ell, sum 0.5|eps|^2)
   const P2PTable *tab;
-  unsigned *ctr;             // [0] exchanges completed on this rank, [1] exit ticket
-  const T *P0, *P1;          // this rank's partial vectors (estimate t of the batch: P[t & 1]), zero padded to world * n
+  unsigned *ctr;             // this lane's counters: [0] exchanges completed, [1] exit ticket
+  const T *P[kP2PRing];      // this rank's partial vectors: estimate t of the batch sits in P[t % ring], zero padded to world * n
+  int ring;
   const T *params;
-  T *value, *grad;
+  T *value, *grad;           // results of the batch's LAST estimate
+  T *scratch;                // value (4 slots) + gradient of the estimates before it (this lane's own: every estimate is fully written)
   int *status;
   int phases;                // bit 0 push, bit 1 reduce, bit 2 unpack (all three = the exchange; single phases: host-sequenced tests, count = 1)
   int spin_budget;
-  int count;                 // estimates in this launch
-  const unsigned *ready;     // batch hand-over (nullptr: the partial vector is complete at launch): estimate t may start when *ready - ready_base >= t + 1
-  unsigned ready_base;
-  unsigned *freed;           // += 1 by every chunk workgroup once its part of estimate t's partial vector has been read
+  int lane, lanes, count;    // this launch serves estimates t = lane, lane + lanes, ... < count
+  const unsigned *ready;     // batch hand-over (nullptr: the partial vector is complete at launch): estimate t may start when *ready >= t + 1
+  unsigned *freed;           // [ring]: += 1 by every chunk workgroup once its part of the vector in that ring slot has been read
 };
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -168,7 +173,7 @@ __device__ __forceinline__ bool p2p_reduce_chunk(const P2PArgs<T> &a, const P2PT
   const int tid = threadIdx.x, R = a.world;
   const long long n = a.n, tri_end = a.L - 2;
   const double invM = 1.0 / (double)a.M_total, direct = direct_entropy_coeff(a.ent_kind);
-  const unsigned long long *st = tb.stage[a.rank] + ((size_t)(p * R) * n + c0) * W;   // + src * n * W + 2 * unit
+  const unsigned long long *st = tb.stage[a.lane][a.rank] + ((size_t)(p * R) * n + c0) * W;   // + src * n * W + 2 * unit
   const long long g0 = (long long)a.rank * n + c0;
   const long long units = clen / EPU;
   bool all_ok = true;
@@ -229,10 +234,10 @@ __device__ __forceinline__ bool p2p_reduce_chunk(const P2PArgs<T> &a, const P2PT
       const size_t off = ((size_t)p * R * n + (size_t)gi0) * W;   // pair index inside a final area
       if (both) {
         const u32x4_t ov = {ow0, epoch, ow1, epoch};
-        for (int k = 0; k < R; ++k) store16_sys(tb.fin[(a.rank + 1 + k) % R] + off, ov);
+        for (int k = 0; k < R; ++k) store16_sys(tb.fin[a.lane][(a.rank + 1 + k) % R] + off, ov);
       } else {   // (the last element below the scalars at an even index: one pair)
         const u32x2_t ov = {ow0, epoch};
-        for (int k = 0; k < R; ++k) store8_sys(tb.fin[(a.rank + 1 + k) % R] + off, ov);
+        for (int k = 0; k < R; ++k) store8_sys(tb.fin[a.lane][(a.rank + 1 + k) % R] + off, ov);
       }
     }
   }
@@ -240,12 +245,12 @@ __device__ __forceinline__ bool p2p_reduce_chunk(const P2PArgs<T> &a, const P2PT
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_p2p_exchange(P2PArgs<T> a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_p2p_exchange(P2PArgs<T> a) {   // (<= 128 VGPRs: the spinning workgroups must leave the compute kernels their registers)
   constexpr int NT = 256, W = Words<T>::W, EPU = 2 / W;
   __shared__ int sh_ok;
   __shared__ double red[4];
-  const int tid = threadIdx.x, g = blockIdx.x, R = a.world, G = a.G;
-  const unsigned epoch0 = a.ctr[0] + 1u;
+  const int tid = threadIdx.x, g = blockIdx.x, R = a.world, G = a.G, ln = a.lane;
+  unsigned epoch = a.ctr[0];
   const long long n = a.n;
   const P2PTable &tb = *a.tab;
   const bool value_wg = (g == G);
@@ -255,15 +260,18 @@ __global__ __launch_bounds__(256) void k_p2p_exchange(P2PArgs<T> a) {
   const int d = a.d;
   bool lost = false;
 
-  for (int t = 0; t < a.count; ++t) {
-    const unsigned epoch = epoch0 + (unsigned)t;
+  for (int t = a.lane; t < a.count; t += a.lanes) {
+    ++epoch;
     const int p = (int)(epoch & 1u);
-    const T *P = (t & 1) ? a.P1 : a.P0;
+    const int slot = t % a.ring;
+    const T *P = a.P[slot];
+    const bool last = (t == a.count - 1);
+    T *out_v = last ? a.value : a.scratch, *out_g = last ? a.grad : a.scratch + 4;
     if (a.ready) {   // hand-over from the compute chain: the partial vector of estimate t is complete
       if (tid == 0) {
         int budget = a.spin_budget;
         sh_ok = 1;
-        while ((int)(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ready_base) < t + 1) {
+        while ((int)__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t + 1) {
           if (--budget <= 0) { sh_ok = 0; break; }
           __builtin_amdgcn_s_sleep(4);
         }
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(256) void k_p2p_exchange(P2PArgs<T> a) {
         for (int k = 0; k < R; ++k) {
           const int s = (a.rank + 1 + k) % R;   // start with the neighbour: the links fill evenly, the local copy comes last
           const unsigned *src = (const unsigned *)(P + (size_t)s * n + c0);
-          unsigned long long *dst = tb.stage[s] + ((size_t)(p * R + a.rank) * n + c0) * W;
+          unsigned long long *dst = tb.stage[ln][s] + ((size_t)(p * R + a.rank) * n + c0) * W;
           const void *ptr[8];
           u32x4_t r[8];
           long long vi[8];
@@ -299,15 +307,15 @@ __global__ __launch_bounds__(256) void k_p2p_exchange(P2PArgs<T> a) {
           }
         }
       }
-      if (a.freed) {   // this workgroup is done reading estimate t's partial vector
+      if (a.freed) {   // this workgroup is done reading the partial vector in this ring slot
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(a.freed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(a.freed + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
 
     // ---- phase 3a (needs nothing from anybody): exact zeros above the diagonal of the dense gradient -------------------------------------
-    if ((a.phases & 4) && !value_wg && a.family == MIVI_FULLRANK && t == a.count - 1) {   // (every estimate of a batch writes the same buffer)
-      T *gc = a.grad + d;
+    if ((a.phases & 4) && !value_wg && a.family == MIVI_FULLRANK) {
+      T *gc = out_g + d;
       for (int j = g + 1; j < d; j += G)
         for (int i = tid; i < j; i += NT) gc[(size_t)j * d + i] = T(0);
     }
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(256) void k_p2p_exchange(P2PArgs<T> a) {
           for (int q = 0; q < 2; ++q) {
             unsigned w[2] = {0u, 0u};
             for (int h = 0; h < W; ++h)
-              if (!ll_load1(tb.stage[a.rank] + ((size_t)(p * R + src) * n + o0 + q) * W + h, epoch, a.spin_budget, w[h])) lost = true;
+              if (!ll_load1(tb.stage[ln][a.rank] + ((size_t)(p * R + src) * n + o0 + q) * W + h, epoch, a.spin_budget, w[h])) lost = true;
             sc[q] += (double)Words<T>::make(w[0], w[1]);
           }
         const double Mt = (double)a.M_total;
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(256) void k_p2p_exchange(P2PArgs<T> a) {
         Words<T>::split((T)value, wv[0], wv[1]);
         Words<T>::split((T)stt, ws[0], ws[1]);
         for (int s = 0; s < R; ++s) {
-          unsigned long long *dst = tb.fin[s] + ((size_t)p * R * n + tri_end) * W;
+          unsigned long long *dst = tb.fin[ln][s] + ((size_t)p * R * n + tri_end) * W;
           for (int h = 0; h < W; ++h) {
             const u32x2_t v1 = {wv[h], epoch}, v2 = {ws[h], epoch};
             store8_sys(dst + h, v1);
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(256) void k_p2p_exchange(P2PArgs<T> a) {
 
     // ---- phase 3: unpack chunk g of every final slice ------------------------------------------------------------------------------------
     if (a.phases & 4) {
-      const unsigned long long *fin = tb.fin[a.rank] + (size_t)p * R * n * W;
+      const unsigned long long *fin = tb.fin[ln][a.rank] + (size_t)p * R * n * W;
       if (value_wg) {
         if (tid == 0) {
           unsigned wv[2] = {0u, 0u}, ws[2] = {0u, 0u};
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(256) void k_p2p_exchange(P2PArgs<T> a) {
             if (!ll_load1(fin + (size_t)tri_end * W + h, epoch, a.spin_budget, wv[h])) lost = true;
             if (!ll_load1(fin + (size_t)(tri_end + 1) * W + h, epoch, a.spin_budget, ws[h])) lost = true;
           }
-          *a.value = Words<T>::make(wv[0], wv[1]);
+          *out_v = Words<T>::make(wv[0], wv[1]);
           const int stt = (int)Words<T>::make(ws[0], ws[1]);
           if (stt && a.status) atomicOr(a.status, stt);
         }
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(256) void k_p2p_exchange(P2PArgs<T> a) {
                 packed_col_row(gi, d, j, i);
                 di = d + j * d + i;
               }
-              a.grad[di] = c == 0 ? x0 : x1;
+              out_g[di] = c == 0 ? x0 : x1;
             }
           }
         }
@@ -426,21 +434,21 @@ __global__ __launch_bounds__(256) void k_p2p_exchange(P2PArgs<T> a) {
   }
   if (lost && tid == 0 && a.status) atomicOr(a.status, 8);
 
-  // ---- exit ticket: the last workgroup out advances the epoch (every workgroup has read it by then) ------------------------------------
+  // ---- exit ticket: the last workgroup out publishes the lane's epoch (every workgroup has read it by then) ------------------------------------
   if (a.phases & 4) {
     __syncthreads();
     if (tid == 0) {
       const unsigned tk = __hip_atomic_fetch_add(a.ctr + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       if (tk == (unsigned)G) {
         __hip_atomic_store(a.ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(a.ctr, epoch0 + (unsigned)a.count - 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.ctr, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
 }
 
 // hand-over words of the pipelined batch on the COMPUTE chain (one thread): announce a complete partial vector (ready = ready_val), then
-// hold the chain until the exchange has read the buffer the NEXT estimate's kernels are going to overwrite (freed - freed_min >= 0)
+// hold the chain until the exchange has read the ring slot the NEXT estimate's kernels are going to overwrite (*freed >= freed_min)
 __global__ void k_p2p_handover(unsigned *ready, unsigned ready_val, const unsigned *freed, unsigned freed_min, int budget, int *status) {
   if (ready) __hip_atomic_store(ready, ready_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   if (freed) {
@@ -456,31 +464,37 @@ void launch_p2p_handover(mivi_ctx *c, unsigned *ready, unsigned ready_val, const
   hipLaunchKernelGGL(k_p2p_handover, dim3(1), dim3(1), 0, c->stream, ready, ready_val, freed, freed_min, c->p2p_spin, (int *)c->status.p);
 }
 
-void launch_p2p_exchange(mivi_ctx *c, const void *params, const void *P0, const void *P1, void *value, void *grad, int phases, int count,
-                         const unsigned *ready, unsigned ready_base, unsigned *freed) {
+// one lane of the exchange on c->stream: estimates t = lane, lane + lanes, ... < count with partial vectors P[t % ring]
+void launch_p2p_exchange(mivi_ctx *c, const void *params, const void *const *P, int ring, void *value, void *grad, int phases, int lane, int lanes,
+                         int count, const unsigned *ready, unsigned *freed) {
   auto fill = [&](auto &a) {
     a.d = c->cfg.d; a.family = c->cfg.family; a.ent_kind = c->cfg.entropy; a.M_total = c->M_total;
     a.L = mivi_partials_len(c); a.n = c->p2p_n; a.cn = c->p2p_cn;
     a.rank = c->p2p_rank; a.world = c->p2p_world; a.G = c->p2p_G; a.vs = c->p2p_vs;
     a.tab = (const P2PTable *)c->p2p_tab.p;
-    a.ctr = (unsigned *)c->p2p_ctr.p;
+    a.ctr = (unsigned *)c->p2p_ctr.p + 16 * lane;
     a.status = (int *)c->status.p;
     a.phases = phases;
     a.spin_budget = c->p2p_spin;
-    a.count = count;
+    a.lane = lane; a.lanes = lanes; a.count = count;
+    a.ring = ring;
     a.ready = ready;
-    a.ready_base = ready_base;
     a.freed = freed;
   };
+  const size_t plen4 = (size_t)mivi_params_len(c) + 4;
   if (c->cfg.dtype == MIVI_F32) {
     P2PArgs<float> a{};
     fill(a);
-    a.P0 = (const float *)P0; a.P1 = (const float *)P1; a.params = (const float *)params; a.value = (float *)value; a.grad = (float *)grad;
+    for (int k = 0; k < ring; ++k) a.P[k] = (const float *)P[k];
+    a.params = (const float *)params; a.value = (float *)value; a.grad = (float *)grad;
+    a.scratch = (float *)c->p2p_scratch.p + plen4 * lane;
     hipLaunchKernelGGL(k_p2p_exchange<float>, dim3(c->p2p_G + 1), dim3(256), 0, c->stream, a);
   } else {
     P2PArgs<double> a{};
     fill(a);
-    a.P0 = (const double *)P0; a.P1 = (const double *)P1; a.params = (const double *)params; a.value = (double *)value; a.grad = (double *)grad;
+    for (int k = 0; k < ring; ++k) a.P[k] = (const double *)P[k];
+    a.params = (const double *)params; a.value = (double *)value; a.grad = (double *)grad;
+    a.scratch = (double *)c->p2p_scratch.p + plen4 * lane;
     hipLaunchKernelGGL(k_p2p_exchange<double>, dim3(c->p2p_G + 1), dim3(256), 0, c->stream, a);
   }
 }

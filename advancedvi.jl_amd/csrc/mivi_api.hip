@@ -161,12 +161,13 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_P2, &c->dist_S, &c->dist_F, &c->p2p_tab, &c->p2p_ctr, &c->lds_tabV, &c->lds_tabV64, &c->lds_tabSt, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_P2, &c->dist_P3, &c->dist_P4, &c->p2p_scratch, &c->dist_S, &c->dist_F, &c->p2p_tab, &c->p2p_ctr, &c->lds_tabV, &c->lds_tabV64, &c->lds_tabSt, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  if (c->comm_stream2) (void)hipStreamDestroy(c->comm_stream2);
   for (int k = 0; k < 2; ++k) {
     if (c->ev_part[k]) (void)hipEventDestroy(c->ev_part[k]);
     if (c->ev_comm[k]) (void)hipEventDestroy(c->ev_comm[k]);
@@ -935,7 +936,8 @@ struct P2PHandle {   // what travels between the ranks (MIVI_P2P_HANDLE_BYTES = 
 };
 static_assert(sizeof(P2PHandle) <= MIVI_P2P_HANDLE_BYTES, "handle blob");
 constexpr uint32_t kP2PMagic = 0x4D495650u;   // "MIVP"
-struct P2PTableHost { unsigned long long *stage[8]; unsigned long long *fin[8]; };
+constexpr int kLanes = 2, kRing = 4;   // (kernels_p2p.hip: kP2PLanes, kP2PRing)
+struct P2PTableHost { unsigned long long *stage[kLanes][8]; unsigned long long *fin[kLanes][8]; };
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -944,10 +946,12 @@ void p2p_geometry(long long L, int R, long long &n, long long &cn, int &G, int &
   n = ((L + R - 1) / R + 3) & ~3LL;
   while ((L - 1) % n == 0) n += 4;        // the two scalars (L - 2, L - 1) must lie in ONE slice
   vs = (int)((L - 2) / n);
-  // many small chunks: system-scope (L2-bypassing) accesses are limited per CU (a few GB/s each: ~0.4 TB/s with 128 workgroups), so
-  // the exchange wants every CU, not few workgroups with long loops
+  // Small chunks, but at most 127 (+ the value workgroup = 128 per lane): the exchange kernels are persistent and spin beside the
+  // compute chain, so with two lanes they hold about one workgroup per CU.  More would be faster for an exchange on its own (system-
+  // scope accesses are limited per CU: 46 us with 128 workgroups, 33 us with 512) but 513 spinning workgroups per lane held every
+  // CU's registers and the compute kernels could not be scheduled beside them at all (found on the GPU: the hand-over timed out).
   long long g = (n + 511) / 512;
-  G = (int)(g < 1 ? 1 : (g > 512 ? 512 : g));
+  G = (int)(g < 1 ? 1 : (g > 127 ? 127 : g));
   cn = ((n + G - 1) / G + 3) & ~3LL;
 }
 }  // namespace
@@ -966,6 +970,7 @@ mivi_status_t mivi_p2p_detach(mivi_ctx_t *c) {
   (void)hipSetDevice(c->cfg.device);
   (void)hipStreamSynchronize(c->stream);
   if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+  if (c->comm_stream2) (void)hipStreamSynchronize(c->comm_stream2);
   invalidate_graph(c);
   for (int r = 0; r < 8; ++r) {
     if (c->p2p_opened[r] && c->p2p_peer[r]) (void)hipIpcCloseMemHandle(c->p2p_peer[r]);
@@ -988,10 +993,11 @@ mivi_status_t mivi_p2p_export(mivi_ctx_t *c, int32_t rank, int32_t world, void *
   int G, vs;
   p2p_geometry(L, world, n, cn, G, vs);
   const size_t es = c->esize;
-  // LL layout: every 32-bit payload word travels as an 8-byte (word, epoch) pair
+  // per lane, LL layout (every 32-bit payload word travels as an 8-byte (word, epoch) pair): staging [2][R][n W] pairs, final [2][R n W] pairs
   const size_t W = es / 4;
   const size_t b_stage = align256((size_t)2 * world * n * W * 8), b_fin = align256((size_t)2 * world * n * W * 8);
-  const size_t bytes = b_stage + b_fin;
+  const size_t lane_bytes = b_stage + b_fin;
+  const size_t bytes = lane_bytes * kLanes;
   // FINE-GRAINED device memory: peers write it over xGMI, system-scope releases / acquires and the consumers' system-scope loads
   // (kernels_p2p.hip ld_sys) keep it coherent.  NOT hipDeviceMallocUncached: on this stack (ROCm 7.0 / gfx950) running the exchange on an
   // uncached allocation corrupted UNRELATED buffers of later contexts once the area had been freed and its pages re-used (found on one
@@ -1005,7 +1011,7 @@ mivi_status_t mivi_p2p_export(mivi_ctx_t *c, int32_t rank, int32_t world, void *
   c->p2p_buf = buf;
   c->p2p_bytes = bytes;
   c->p2p_rank = rank; c->p2p_world = world; c->p2p_n = n; c->p2p_cn = cn; c->p2p_G = G; c->p2p_vs = vs;
-  c->p2p_off_fin = b_stage;
+  c->p2p_lane_bytes = lane_bytes; c->p2p_off_fin = b_stage;
   P2PHandle h{};
   h.magic = kP2PMagic; h.version = 1; h.rank = rank; h.world = world; h.L = L; h.n = n; h.cn = cn; h.esize = (int32_t)es; h.G = G;
   h.bytes = bytes; h.pid = (uint64_t)getpid(); h.local_ptr = (uint64_t)(uintptr_t)buf; h.device = c->cfg.device;
@@ -1051,18 +1057,36 @@ mivi_status_t mivi_p2p_attach(mivi_ctx_t *c, const void *handles) {
       c->p2p_opened[r] = true;
     }
     c->p2p_peer[r] = base;
-    tab.stage[r] = (unsigned long long *)base;
-    tab.fin[r] = (unsigned long long *)((char *)base + c->p2p_off_fin);
+    for (int ln = 0; ln < kLanes; ++ln) {
+      char *lb = (char *)base + (size_t)ln * c->p2p_lane_bytes;
+      tab.stage[ln][r] = (unsigned long long *)lb;
+      tab.fin[ln][r] = (unsigned long long *)(lb + c->p2p_off_fin);
+    }
   }
   mivi_status_t s;
-  if ((s = ensure(c, c->p2p_tab, sizeof(tab), false)) || (s = ensure(c, c->p2p_ctr, 256, false))) return s;
+  if ((s = ensure(c, c->p2p_tab, sizeof(tab), false)) || (s = ensure(c, c->p2p_ctr, 512, false)) ||
+      (s = ensure(c, c->p2p_scratch, ((size_t)mivi_params_len(c) + 4) * kLanes * c->esize, false)))
+    return s;
   HIPCHK(c, hipMemcpy(c->p2p_tab.p, &tab, sizeof(tab), hipMemcpyHostToDevice));
   // (stream-ordered on the context's stream and waited for: a null-stream memset is NOT ordered against a non-blocking stream and
   //  would zero the epoch counter after the first exchange has advanced it)
-  HIPCHK(c, hipMemsetAsync(c->p2p_ctr.p, 0, 256, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->p2p_ctr.p, 0, 512, c->stream));   // [lane] {epoch, ticket} at 64-byte spacing, ready at byte 256, freed[ring] at byte 320
   HIPCHK(c, hipStreamSynchronize(c->stream));
   invalidate_graph(c);
   c->p2p_on = true;
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_p2p_debug_words(mivi_ctx_t *c, uint32_t *out128) {   // developer: the exchange's device words (lane epochs, ready, freed)
+  if (!c || !out128 || !c->p2p_ctr.p) return MIVI_ERR_BAD_ARG;
+  HIPCHK(c, hipMemcpy(out128, c->p2p_ctr.p, 512, hipMemcpyDeviceToHost));
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_p2p_set_pipeline(mivi_ctx_t *c, int32_t on) {
+  if (!c) return MIVI_ERR_BAD_ARG;
+  c->p2p_pipe_state = on ? 1 : -1;
+  invalidate_graph(c);
   return MIVI_OK;
 }
 
@@ -1164,10 +1188,13 @@ static mivi_status_t ensure_dist(mivi_ctx *c) {
   if (c->p2p_on && c->p2p_n * c->p2p_world > need) need = c->p2p_n * c->p2p_world;
   (void)R;
   const size_t es = c->esize;
-  if (c->dist_P.bytes < (size_t)need * es || c->dist_P2.bytes < (size_t)need * es || c->dist_S.bytes < (size_t)n * es || c->dist_F.bytes < (size_t)Lp * es) {
+  const size_t need34 = c->p2p_on ? (size_t)need * es : 0;
+  if (c->dist_P.bytes < (size_t)need * es || c->dist_P2.bytes < (size_t)need * es || c->dist_P3.bytes < need34 || c->dist_P4.bytes < need34 ||
+      c->dist_S.bytes < (size_t)n * es || c->dist_F.bytes < (size_t)Lp * es) {
     invalidate_graph(c);
     mivi_status_t s;
-    c->dist_P.bytes = 0; c->dist_P2.bytes = 0;   // (re-zero: the padding behind the partial vector must be 0)
+    c->dist_P.bytes = 0; c->dist_P2.bytes = 0; c->dist_P3.bytes = 0; c->dist_P4.bytes = 0;   // (re-zero: the padding behind the partial vector must be 0)
+    if (need34 && ((s = ensure(c, c->dist_P3, need34, true)) || (s = ensure(c, c->dist_P4, need34, true)))) return s;
     if ((s = ensure(c, c->dist_P, (size_t)need * es, true)) || (s = ensure(c, c->dist_P2, (size_t)need * es, true)) ||
         (s = ensure(c, c->dist_S, (size_t)n * es, true)) || (s = ensure(c, c->dist_F, (size_t)Lp * es, true)))
       return s;
@@ -1182,7 +1209,8 @@ static mivi_status_t dist_collective(mivi_ctx *c, const void *params, void *P, v
   const size_t es = c->esize;
   const int route = mivi_comm_route(c);
   if (route == 3) {
-    launch_p2p_exchange(c, params, P, P, value, grad, 7, 1, nullptr, 0u, nullptr);
+    const void *Ps[1] = {P};
+    launch_p2p_exchange(c, params, Ps, 1, value, grad, 7, 0, 1, 1, nullptr, nullptr);
     HIPCHK(c, hipGetLastError());
     return MIVI_OK;
   }
@@ -1538,7 +1566,8 @@ static mivi_status_t dist_sequence(mivi_ctx *c, const void *params, bool counter
   hipStream_t main = c->stream;
   for (int i = 0; i < count && s == MIVI_OK; ++i) {
     const int par = i & 1;
-    void *P = par ? c->dist_P2.p : c->dist_P.p;
+    void *ringP[4] = {c->dist_P.p, c->dist_P2.p, c->dist_P3.p, c->dist_P4.p};
+    void *P = mode == 4 ? ringP[i % kRing] : (par ? c->dist_P2.p : c->dist_P.p);
     if (mode == 0 && i >= 2) HIPCHK(c, hipStreamWaitEvent(main, c->ev_comm[par], 0));   // the exchange of i - 2 has released this partial buffer
     if (mode != 3) {
       RngArgs r = rng_of(c, counter_idx ? (uint64_t)i : idx0 + (uint64_t)i);
@@ -1550,9 +1579,10 @@ static mivi_status_t dist_sequence(mivi_ctx *c, const void *params, bool counter
       if ((s = run_estimate(c, params, r, c->cfg.n_mc, 1, o))) break;
     }
     if (mode == 2) continue;
-    if (mode == 4) {   // peer-to-peer pipeline, compute chain: announce partial vector i, then wait until the exchange has read the buffer estimate i + 1 overwrites
+    if (mode == 4) {   // peer-to-peer pipeline, compute chain: announce partial vector i, then wait until the exchange has read the ring slot estimate i + 1 overwrites
       unsigned *w = (unsigned *)c->p2p_ctr.p;
-      launch_p2p_handover(c, w + 16, (unsigned)i + 1u, i >= 1 ? w + 32 : nullptr, (unsigned)i * (unsigned)c->p2p_G);
+      const int slot = (i + 1) % kRing, prev_users = (i + 1) / kRing;
+      launch_p2p_handover(c, w + 64, (unsigned)i + 1u, prev_users >= 1 ? w + 80 + slot : nullptr, (unsigned)prev_users * (unsigned)c->p2p_G);
       continue;
     }
     if (mode == 0) {
@@ -1584,7 +1614,23 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
   if ((s = reserve_target(c, c->cfg.n_mc)) || (s = ensure_dist(c))) return s;
   if (c->cfg.family == MIVI_FULLRANK && lds_path_shape_ok(c, c->cfg.n_mc) && !lds_prepare(c, c->cfg.n_mc)) return fail(c, MIVI_ERR_HIP, "full-rank work lists: allocation failed");
   if (!c->comm_stream) {
-    HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    // (plain non-blocking streams: a HIGH-priority stream starved the compute chain it was supposed to run beside -- its spinning
+    //  kernel was scheduled first and the normal-priority graph never progressed; found on the GPU)
+    // The persistent exchange kernels run BESIDE the compute chain on these streams.  Non-blocking: a blocking stream (what
+    // hipExtStreamCreateWithCUMask creates) synchronises with the null stream, so a context living on the null stream deadlocked
+    // against its own exchange kernel; a HIGH-priority stream starved the compute chain (both found on the GPU).
+    // They need hardware queues of their own (HIP maps streams onto a small pool, GPU_MAX_HW_QUEUES, and two streams on one queue
+    // serialise: the bounded hand-over waits then expire): a stream created with a CU mask carries the mask in its queue and gets one
+    // -- all CUs enabled = no restriction.  Only for contexts on a real stream (see above).
+    uint32_t mask[16];
+    for (int k = 0; k < 16; ++k) mask[k] = 0xFFFFFFFFu;
+    hipStream_t *cs[2] = {&c->comm_stream, &c->comm_stream2};
+    for (int k = 0; k < 2; ++k) {
+      if (c->stream == nullptr || hipExtStreamCreateWithCUMask(cs[k], 16, mask) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(c, hipStreamCreateWithFlags(cs[k], hipStreamNonBlocking));
+      }
+    }
     for (int k = 0; k < 2; ++k) {
       HIPCHK(c, hipEventCreateWithFlags(&c->ev_part[k], hipEventDisableTiming));
       HIPCHK(c, hipEventCreateWithFlags(&c->ev_comm[k], hipEventDisableTiming));
@@ -1594,7 +1640,8 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
   const int route = mivi_comm_route(c);
   // Peer-to-peer route, pipelined: the exchange is ONE persistent kernel on comm_stream for the whole batch (kernels_p2p.hip), the compute
   // chain is a single-stream graph of {partial kernels, hand-over} per estimate; the two talk through two device words.
-  const bool p2p_pipe = mode == 0 && route == 3;
+  bool p2p_pipe = mode == 0 && route == 3;
+  if (p2p_pipe && c->p2p_pipe_state < 0) { p2p_pipe = false; mode = 1; }   // (its kernels did not run beside the compute chain on this context: serial steps)
   if (p2p_pipe) mode = 4;
   const int kind = 20 + mode;
   static bool capture_refused = false;   // (a collective library that cannot be captured: do not retry on every call)
@@ -1619,16 +1666,26 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
       g.kind = kind; g.count = count; g.params = params; g.value = value; g.grad = grad; g.p0 = (double)route;
     }
   }
-  auto p2p_front = [&]() -> mivi_status_t {   // hand-over words reset, then the persistent exchange kernel on its own stream
+  auto p2p_front = [&]() -> mivi_status_t {   // hand-over words reset, then the persistent exchange kernels (one per lane) on their own streams
     unsigned *w = (unsigned *)c->p2p_ctr.p;
-    HIPCHK(c, hipMemsetAsync(w + 16, 0, 128, c->stream));
+    HIPCHK(c, hipMemsetAsync(w + 64, 0, 128, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_part[0], c->stream));
-    HIPCHK(c, hipStreamWaitEvent(c->comm_stream, c->ev_part[0], 0));
     hipStream_t main = c->stream;
-    c->stream = c->comm_stream;
-    launch_p2p_exchange(c, params, c->dist_P.p, c->dist_P2.p, value, grad, 7, count, w + 16, 0u, w + 32);
-    c->stream = main;
-    HIPCHK(c, hipEventRecord(c->ev_comm[0], c->comm_stream));
+    const void *ringP[4] = {c->dist_P.p, c->dist_P2.p, c->dist_P3.p, c->dist_P4.p};
+    const int lanes = count >= 2 ? kLanes : 1;
+    for (int ln = 0; ln < lanes; ++ln) {
+      hipStream_t cs = ln ? c->comm_stream2 : c->comm_stream;
+      HIPCHK(c, hipStreamWaitEvent(cs, c->ev_part[0], 0));
+      c->stream = cs;
+      launch_p2p_exchange(c, params, ringP, kRing, value, grad, 7, ln, lanes, count, w + 64, w + 80);
+      c->stream = main;
+      HIPCHK(c, hipEventRecord(c->ev_comm[ln], cs));
+    }
+    return MIVI_OK;
+  };
+  auto p2p_back = [&]() -> mivi_status_t {
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_comm[0], 0));
+    if (count >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_comm[1], 0));
     return MIVI_OK;
   };
   if (g.exec && g.kind == kind && g.count == count && g.params == params && g.value == value && g.grad == grad && g.p0 == (double)route) {
@@ -1636,7 +1693,7 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
       hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, idx0, 0ull, 1);
     if (p2p_pipe && (s = p2p_front())) return s;
     HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
-    if (p2p_pipe) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_comm[0], 0));
+    if (p2p_pipe && (s = p2p_back())) return s;
     c->d_idx_valid = mode != 3;
     c->d_idx_expect = idx0 + (uint64_t)count;
     return MIVI_OK;
@@ -1645,7 +1702,7 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
   c->pre_valid = false;
   if (p2p_pipe && (s = p2p_front())) return s;
   s = dist_sequence(c, params, false, idx0, count, value, grad, mode);
-  if (p2p_pipe && s == MIVI_OK) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_comm[0], 0));
+  if (p2p_pipe && s == MIVI_OK) s = p2p_back();
   c->cur = 0;
   c->pre_valid = false;
   return s;
@@ -1662,7 +1719,8 @@ mivi_status_t mivi_p2p_exchange(mivi_ctx_t *c, const void *params, const void *p
   if (!c || !params || !partials || !value || !grad || phases < 1 || phases > 7) return MIVI_ERR_BAD_ARG;
   if (!c->p2p_on) return fail(c, MIVI_ERR_BAD_ARG, "no peer-to-peer exchange buffers attached");
   (void)hipSetDevice(c->cfg.device);
-  launch_p2p_exchange(c, params, partials, partials, value, grad, phases, 1, nullptr, 0u, nullptr);
+  const void *Ps[1] = {partials};
+  launch_p2p_exchange(c, params, Ps, 1, value, grad, phases, 0, 1, 1, nullptr, nullptr);
   HIPCHK(c, hipGetLastError());
   return MIVI_OK;
 }

@@ -227,18 +227,20 @@ struct mivi_ctx {
   // partial vectors double-buffered (dist_P, dist_P2), event pairs per parity
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_part[2] = {nullptr, nullptr}, ev_comm[2] = {nullptr, nullptr};
-  mivi::DevBuf dist_P2;
+  mivi::DevBuf dist_P2, dist_P3, dist_P4;   // ring of partial vectors (two for the RCCL pipeline, four for the peer-to-peer lanes)
+  hipStream_t comm_stream2 = nullptr;
+  int p2p_pipe_state = 1;   // persistent peer-to-peer pipeline in batched calls: 1 on, -1 off (mivi_p2p_set_pipeline: serial steps)
   int dist_route = 0;   // mivi_comm_set_route: 0 by size, 1 ncclAllReduce, 2 ncclReduceScatter / ncclAllGather, 3 peer-to-peer kernel
   // peer-to-peer exchange over xGMI (kernels_p2p.hip): one uncached allocation per rank [stage | final | flags], mapped into the peers by IPC
   void *p2p_buf = nullptr;
   size_t p2p_bytes = 0;
   void *p2p_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // mapped bases (own entry = p2p_buf)
   bool p2p_opened[8] = {false, false, false, false, false, false, false, false};                   // hipIpcOpenMemHandle'd (to be closed)
-  mivi::DevBuf p2p_tab, p2p_ctr;
+  mivi::DevBuf p2p_tab, p2p_ctr, p2p_scratch;
   bool p2p_on = false;
   int p2p_rank = 0, p2p_world = 1, p2p_G = 1, p2p_vs = 0, p2p_spin = 1 << 21;
   long long p2p_n = 0, p2p_cn = 0;
-  size_t p2p_off_fin = 0;
+  size_t p2p_lane_bytes = 0, p2p_off_fin = 0;
   // logreg
   const void *lr_X = nullptr;
   const uint8_t *lr_y = nullptr;
@@ -369,8 +371,8 @@ bool logreg_reserve(mivi_ctx *c, int M);                        // size the scra
 bool logreg_prepare_f32(mivi_ctx *c);   // row-major padded copy of X for the MFMA route (false: allocation failed)
 
 // kernels_p2p.hip: phases bit 0 push, 1 reduce + finalise, 2 unpack (7 = the whole exchange in one launch)
-void launch_p2p_exchange(mivi_ctx *c, const void *params, const void *P0, const void *P1, void *value, void *grad, int phases, int count,
-                         const unsigned *ready, unsigned ready_base, unsigned *freed);   // count > 1: persistent over a batch (P[t & 1])
+void launch_p2p_exchange(mivi_ctx *c, const void *params, const void *const *P, int ring, void *value, void *grad, int phases, int lane, int lanes,
+                         int count, const unsigned *ready, unsigned *freed);   // one lane: estimates lane, lane + lanes, ... < count; P[t % ring]
 void launch_p2p_handover(mivi_ctx *c, unsigned *ready, unsigned ready_val, const unsigned *freed, unsigned freed_min);
 
 // kernels_update.hip

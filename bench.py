@@ -409,6 +409,21 @@ def main():
             ctx.synchronize()
             chunk = max(1, min(20, K))
             pipelined = os.environ.get("MIVI_DIST_PIPELINE", "1") != "0"
+            if pipelined and dist_info["route"] == "p2p":
+                # the persistent exchange kernels must really run beside the compute chain on every rank: one warm batch, checked
+                # (bounded waits: a device that serialises them reports an error instead of hanging); all ranks switch together
+                try:
+                    ctx.estimate_gradient_dist_n(params, 1, chunk, value, grad)
+                    ctx.synchronize()
+                    pipe_ok = True
+                except avi.MiviError as e:
+                    pipe_ok = False
+                    dist_info["pipeline_error"] = str(e)
+                if not all_ok(pipe_ok):
+                    ctx.p2p_set_pipeline(False)
+                    dist_info["pipeline"] = "off (exchange kernels did not run beside the compute chain): serial steps in one graph"
+                else:
+                    dist_info["pipeline"] = "persistent exchange kernels, 2 lanes"
 
             def run(idx0, n):
                 done = 0

@@ -313,6 +313,11 @@ mivi_status_t mivi_p2p_detach(mivi_ctx_t *ctx);
  * length L over `world` ranks (no GPU needed) */
 void mivi_p2p_geometry(int64_t L, int32_t world, int64_t *out4);
 mivi_status_t mivi_comm_enable_p2p(mivi_ctx_t *ctx);
+/* Batched sharded estimates on the peer-to-peer route run the exchange as persistent kernels on their own high-priority streams BESIDE
+ * the compute chain (csrc/kernels_p2p.hip).  That needs the device to schedule the two concurrently; where it does not (streams
+ * sharing one hardware queue), the bounded waits end in MIVI_ERR_HIP at the next mivi_synchronize -- the host then switches the
+ * pipeline off ON EVERY RANK (all ranks must agree: the lanes the estimates use differ) and batched calls run serial steps. */
+mivi_status_t mivi_p2p_set_pipeline(mivi_ctx_t *ctx, int32_t on);
 /* how many polls (about 1 us each) a wait inside the exchange may take before the peer counts as lost (default 2^21, about 2 s) */
 mivi_status_t mivi_p2p_set_spin_budget(mivi_ctx_t *ctx, int32_t polls);
 /* Which exchange mivi_estimate_gradient_dist[_n] uses: 0 = automatic (peer-to-peer when attached, otherwise ONE ncclAllReduce + the whole

@@ -83,3 +83,69 @@ def test_sharded_estimate_equals_single(family, ent):
         assert p.exitcode == 0
     rel_v, max_g = q.get(timeout=10)
     assert rel_v < 1e-12 and max_g < 1e-11
+
+
+def _p2p_worker(rank, world, port, family, q_out):
+    """The peer-to-peer exchange protocol (csrc/kernels_p2p.hip) played over gloo by two real processes: what a rank would store into
+    its peers' staging / final areas travels by all_gather, the areas are double-buffered by epoch parity over three exchanges and
+    every rank only ever touches ITS slice in the reduce phase (product geometry: advancedvi_jl_amd.distributed.p2p_geometry)."""
+    sys.path.insert(0, ROOT)
+    from advancedvi_jl_amd.distributed import ShardPlan, p2p_geometry, partials_len
+    from oracle import oracle as O
+    from tests.helpers import SEED, make_family, make_problem
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d, M, ent = 12, 11, 3
+        rng = np.random.default_rng(78)
+        _, q = make_family(rng, d, family)
+        _, tgt = make_problem(rng, "dense", d)
+        params = O.destructure(q)
+        plan = ShardPlan(M, world)
+        lo, hi = plan.range(rank)
+        L = partials_len(d, family)
+        n, cn, G, vs = p2p_geometry(L, world)
+        assert (n, cn, G, vs) == O.p2p_geometry(L, world)
+        stage = np.full((2, world, n), np.nan)          # my staging area: [parity][source rank][my slice]
+        fin = np.full((2, world * n), np.nan)           # my final area
+        worst = 0.0
+        for epoch, idx in enumerate((9, 10, 11), start=1):
+            p = epoch & 1
+            part = O.estimate_gradient(params, d, family, tgt, O.philox_normal(SEED, idx, d, lo, hi, f64=True), ent)["partials"]
+            padded = np.concatenate([part, np.zeros(world * n - L)])
+            # phase 1: every rank "stores" slice s of its vector into rank s's staging area
+            everyone = [torch.zeros(world * n, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(everyone, torch.from_numpy(padded.copy()))
+            for src in range(world):
+                stage[p, src] = everyone[src].numpy()[rank * n:(rank + 1) * n]
+            # phase 2: reduce MY slice in rank order, finalise it (oracle.finalize_slice: the arithmetic of the kernel), "store" it everywhere
+            mine = O.finalize_slice(stage[p].sum(axis=0) if world > 1 else stage[p, 0], rank * n, params, d, family, ent, M, L)
+            slices = [torch.zeros(n, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(slices, torch.from_numpy(mine.copy()))
+            fin[p] = np.concatenate([t.numpy() for t in slices])
+            # phase 3: unpack
+            value, grad = O.unpack_final(fin[p], d, family)
+            ref = O.estimate_gradient(params, d, family, tgt, O.philox_normal(SEED, idx, d, 0, M, f64=True), ent)
+            worst = max(worst, abs(value - ref["value"]) / abs(ref["value"]), float(np.max(np.abs(grad - ref["grad"]))))
+            assert np.isnan(fin[p ^ 1]).all() or epoch > 1   # the other parity is untouched by this exchange
+        q_out.put((rank, worst, vs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("family", [0, 1])
+def test_p2p_exchange_protocol_over_gloo(family):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_p2p_worker, args=(r, 2, port, family, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for _ in range(2):
+        rank, worst, vs = q.get(timeout=10)
+        assert worst < 1e-11 and 0 <= vs < 2

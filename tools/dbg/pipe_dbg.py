@@ -16,13 +16,19 @@ with torch.cuda.stream(st):
     v, g = ctx.empty(1), ctx.empty(ctx.params_len)
     v1, g1 = ctx.estimate_gradient_dist(p, 7); ctx.synchronize()
     print("single ok", float(v1))
-    for count in (1, 2, 3, 8):
+    import ctypes as C
+    def words():
+        buf = (C.c_uint32 * 128)(); ctx.lib.mivi_p2p_debug_words.argtypes = [C.c_void_p, C.c_void_p]; ctx.lib.mivi_p2p_debug_words(ctx.h, buf)
+        return dict(lane0=list(buf[0:2]), lane1=list(buf[16:18]), ready=buf[64], freed=list(buf[80:84]))
+    print(words())
+    for count in (1, 2):
         t0 = time.perf_counter()
         try:
             ctx.estimate_gradient_dist_n(p, 100, count, v, g); ctx.synchronize(); err = None
         except Exception as e: err = str(e)[:70]
         dt = time.perf_counter() - t0
         vr, gr = ctx.estimate_gradient(p, 100 + count - 1)
+        print(words())
         print("count", count, "%.3f ms" % (dt * 1e3), "err", err, "v", float(v), float(vr), "gerr", float((g - gr).norm() / gr.norm()))
         t0 = time.perf_counter()
         try:
