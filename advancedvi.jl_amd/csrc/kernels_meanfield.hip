@@ -42,6 +42,60 @@ __device__ __forceinline__ float wave_total63(float v) {
 }
 __device__ __forceinline__ double wave_total63(double v) { return wave_sum(v); }
 
+// A gradient entry from its row sum: -(1/M) sum, the scale rows also carry the entropy term -direct / sigma.  ONE body, compiled without
+// fused multiply-add contraction, for every kernel that writes mean-field gradient entries (k_mf_main, k_mf_colreduce, the launch-free
+// loops): they must agree to the bit, and left to the optimiser one instantiation fused the product into the subtraction and another
+// did not (1 ulp apart in f64; found on the GPU).
+template <typename T>
+__device__ __forceinline__ T mf_grad_entry(double row_sum, double invM, bool scale_row, double direct, double sigma) {
+#pragma clang fp contract(off)
+  const double m = -row_sum * invM;
+  const double e = direct / sigma;
+  return (T)(scale_row ? m - e : m);
+}
+
+// One sample column of the fused funnel target for rows 4 rq .. 4 rq + 3 (Neal's funnel + Stacked([log, identity]), see FunnelFin):
+// rows >= 1 need only e1 = z[0, m], re-derived from the eps stream; their sum of squares enters row 0 and ell only through
+// x^2 exp(-2 e1) (and that times eps_0).  ONE body for k_mf_main<T, true> and k_mf_funnel_loop: the two must produce the same bits.
+template <typename T>
+__device__ __forceinline__ void funnel_column(int rq, int d, const T (&mu)[4], const T (&sg)[4], const T (&e)[4], T e0, T mu0, T sg0, T (&g)[4],
+                                              T &s_ell, T &sA, T &sB) {
+  const T e1 = mu0 + sg0 * e0;
+  const T inv_s2 = exp(T(-2) * e1);
+  T x2 = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * rq + r;
+    const T z = mu[r] + sg[r] * e[r];
+    if (i >= 1 && i < d) {
+      g[r] = -z * inv_s2;
+      x2 += z * z;
+    }
+  }
+  const T xi = x2 * inv_s2;
+  s_ell += T(-0.5) * xi;
+  sA += xi;
+  sB += xi * e0;
+}
+// The row sums of one column: W = g (+ eps / sigma for the sticking-the-landing estimators), sum W, sum W eps, sum 0.5 eps^2.
+template <typename T>
+__device__ __forceinline__ void mf_accumulate(int rq, int d, bool want_grad, bool stl, bool skip_row0, const T (&sg)[4], const T (&e)[4], const T (&g)[4],
+                                              T (&sW)[4], T (&sWe)[4], T &s_he) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const bool ok = (4 * rq + r) < d;
+    const T er = ok ? e[r] : T(0);
+    s_he += T(0.5) * er * er;
+    if (want_grad) {
+      const T isg = T(1) / sg[r];
+      const bool mine = ok && !(skip_row0 && 4 * rq + r == 0);   // funnel row 0: value workgroup
+      const T w = mine ? (g[r] + (stl ? er * isg : T(0))) : T(0);
+      sW[r] += w;
+      sWe[r] += w * er;
+    }
+  }
+}
+
 // Scalar partial layout written by k_mf_main and consumed by k_mf_value: sc[k*nblk + blk],
 // k = 0 sum ell (variable part), 1 sum 0.5 eps^2, 2 sum log sigma_i (this block's rows), 3 #non-positive sigma.
 // FN: the fused funnel target is a separate instantiation (its extra Philox block / exp / partial store would otherwise
@@ -66,7 +120,7 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
   const uint64_t idx = rng_index(a.rng);
   const bool stl = ent_is_stl(a.out.ent_kind);
 
-  T mu[4], sg[4], isg[4], tm[4], tis[4];
+  T mu[4], sg[4], tm[4], tis[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = min(4 * rq + r, d - 1);
@@ -97,39 +151,12 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
       T e0q[4];
       if (rq == 0) { e0q[0] = e[0]; }
       else eps_block<T>(a.rng.seed, idx, (uint64_t)(a.rng.m_offset + m) * (uint64_t)d4, e0q);
-      const T e1 = a.params[0] + a.params[d] * e0q[0];
-      const T inv_s2 = exp(T(-2) * e1);
-      T x2 = 0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = 4 * rq + r;
-        const T z = mu[r] + sg[r] * e[r];
-        if (i >= 1 && i < d) {
-          g[r] = -z * inv_s2;
-          x2 += z * z;
-        }
-      }
-      const T xi = x2 * inv_s2;
-      s_ell += T(-0.5) * xi;
-      sA += xi;
-      sB += xi * e0q[0];
+      funnel_column<T>(rq, d, mu, sg, e, e0q[0], a.params[0], a.params[d], g, s_ell, sA, sB);
     } else if (a.want_grad) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) g[r] = a.G[(size_t)m * d + min(4 * rq + r, d - 1)];
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool ok = (4 * rq + r) < d;
-      const T er = ok ? e[r] : T(0);
-      s_he += T(0.5) * er * er;
-      if (a.want_grad) {
-        isg[r] = T(1) / sg[r];
-        const bool mine = ok && !(FN && a.target == TGT_FUNNEL && 4 * rq + r == 0);   // funnel row 0: value workgroup
-        const T w = mine ? (g[r] + (stl ? er * isg[r] : T(0))) : T(0);
-        sW[r] += w;
-        sWe[r] += w * er;
-      }
-    }
+    mf_accumulate<T>(rq, d, a.want_grad != 0, stl, FN && a.target == TGT_FUNNEL, sg, e, g, sW, sWe, s_he);
   }
   MIVI_STAMP(a.dbg, 1);
 
@@ -189,8 +216,7 @@ __global__ __launch_bounds__(256) void k_mf_main(MfArgs<T> a) {
         } else {
           T *gr = (T *)a.out.grad;
           const double invM = 1.0 / (double)a.out.M_total;
-          if (tid < 4) gr[i] = (T)(-tot[tid] * invM);
-          else gr[d + i] = (T)(-tot[tid] * invM - direct_entropy_coeff(a.out.ent_kind) / (double)a.params[d + i]);
+          gr[(tid < 4 ? 0 : d) + i] = mf_grad_entry<T>(tot[tid], invM, tid >= 4, direct_entropy_coeff(a.out.ent_kind), (double)a.params[d + i]);
         }
       }
     } else {
@@ -217,10 +243,7 @@ __global__ __launch_bounds__(256) void k_mf_colreduce(MfArgs<T> a) {
       } else {
         const double invM = 1.0 / (double)a.out.M_total;
         T *gr = (T *)a.out.grad;
-        if (k < 4)
-          gr[i] = (T)(-s * invM);
-        else
-          gr[d + i] = (T)(-s * invM - direct_entropy_coeff(a.out.ent_kind) / (double)a.params[d + i]);
+        gr[(k < 4 ? 0 : d) + i] = mf_grad_entry<T>(s, invM, k >= 4, direct_entropy_coeff(a.out.ent_kind), (double)a.params[d + i]);
       }
     }
   }
@@ -360,7 +383,7 @@ __global__ __launch_bounds__(256) void k_mf_sgd_loop(MfLoopArgs<T> a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) trow += (double)xb[myrow][j];
         const T sgv = (myrow & 3) == 0 ? sg[0] : (myrow & 3) == 1 ? sg[1] : (myrow & 3) == 2 ? sg[2] : sg[3];
-        const T g = (myrow < 4) ? (T)(-trow * invM) : (T)(-trow * invM - direct / (double)sgv);
+        const T g = mf_grad_entry<T>(trow, invM, myrow >= 4, direct, (double)sgv);
         if (row_ok) a.grad_out[(myrow < 4 ? 0 : d) + myi] = g;
       }
       continue;
@@ -377,7 +400,7 @@ __global__ __launch_bounds__(256) void k_mf_sgd_loop(MfLoopArgs<T> a) {
     }
     {
       const T sgv = (myrow & 3) == 0 ? sg[0] : (myrow & 3) == 1 ? sg[1] : (myrow & 3) == 2 ? sg[2] : sg[3];
-      const T g = (myrow < 4) ? (T)(-trow * invM) : (T)(-trow * invM - direct / (double)sgv);
+      const T g = mf_grad_entry<T>(trow, invM, myrow >= 4, direct, (double)sgv);
       if (rule == 0) mine = descent_step(mine, g, eta);
       else mine = adam_step<T>(mine, g, st_m, st_v, cc_tab[t & 255][0], cc_tab[t & 255][1], eta, b1, b2, aeps);
       if (clip && myrow >= 4) mine = clip_step(mine, ceps);
@@ -465,6 +488,197 @@ void launch_mf_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx
                         double eta, double clip_eps, double *hist, double *elbo, void *grad_out) {
   if (c->cfg.dtype == MIVI_F32) mf_sgd_loop_impl<float>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo, grad_out);
   else mf_sgd_loop_impl<double>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo, grad_out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launch-free batch of estimates for the mean-field family with the fused FUNNEL target (BASELINE config 5: Neal's funnel +
+// Stacked([log, identity]), d = 2048, 64 samples per GPU): n estimates at fixed parameters inside ONE kernel, EVERY estimate writes
+// its gradient.  The funnel's only cross-row coupling enters row 0 and ell linearly (FunnelFin), so workgroup b (rows 4b..4b+3)
+// needs nothing from the others: per estimate it leaves its eight gradient entries and six scalar partials
+// hist[t][{ell, 0.5 eps^2, log sigma, #bad, A, B}][b]; k_mf_funnel_loop_value (one workgroup per estimate, the code of the
+// single-call value workgroup: finalize_value_block) adds the O(M) per-column terms, finishes row 0 and the objective.
+// Arithmetic and association are those of k_mf_main<T, true>: the results are bitwise those of n single calls.
+// NW waves per workgroup: 1 for n_mc <= 64 (config 5's shard: no LDS exchange, no barrier in the loop), 4 beyond.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct MfFunnelLoopArgs {
+  int d, M, n_steps;
+  const T *params;
+  uint64_t seed, idx0;
+  int m_offset, M_total, ent_kind;
+  double *hist;        // [n_steps][6][nblk]
+  T *grad_out;         // rows >= 1 of every estimate (row 0: the value kernel)
+};
+
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void k_mf_funnel_loop(MfFunnelLoopArgs<T> a) {
+  constexpr int NT = 64 * NW;
+  __shared__ T xw[2][12][4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int rq = blockIdx.x, d = a.d, d4 = (d + 3) >> 2, nblk = gridDim.x;
+  const bool stl = ent_is_stl(a.ent_kind);
+  const double direct = direct_entropy_coeff(a.ent_kind);
+  const double invM = 1.0 / (double)a.M_total;
+  T mu[4], sg[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = min(4 * rq + r, d - 1);
+    mu[r] = a.params[i];
+    sg[r] = a.params[d + i];
+  }
+  const T mu0 = a.params[0], sg0 = a.params[d];
+  double lg, bad;
+  {
+    double lgs[4], bads[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool ok = 4 * rq + r < d;
+      lgs[r] = ok ? (double)log(sg[r]) : 0.0;
+      bads[r] = (ok && !(sg[r] > T(0))) ? 1.0 : 0.0;
+    }
+    lg = (lgs[0] + lgs[1]) + (lgs[2] + lgs[3]);
+    bad = (bads[0] + bads[1]) + (bads[2] + bads[3]);
+  }
+  const int myrow = lane & 7;
+  const int myi = 4 * rq + (myrow & 3);
+  const bool row_ok = myi < d && myi != 0;   // (row 0: the value kernel)
+  const T sgv = (myrow & 3) == 0 ? sg[0] : (myrow & 3) == 1 ? sg[1] : (myrow & 3) == 2 ? sg[2] : sg[3];
+  for (int t = 0; t < a.n_steps; ++t) {
+    T sW[4] = {0, 0, 0, 0}, sWe[4] = {0, 0, 0, 0};
+    T s_ell = 0, s_he = 0, sA = 0, sB = 0;
+    for (int m = tid; m < a.M; m += NT) {
+      T e[4], e0q[4];
+      eps_block<T>(a.seed, a.idx0 + (uint64_t)t, (uint64_t)(a.m_offset + m) * (uint64_t)d4 + (uint64_t)rq, e);
+      if (rq == 0) e0q[0] = e[0];
+      else eps_block<T>(a.seed, a.idx0 + (uint64_t)t, (uint64_t)(a.m_offset + m) * (uint64_t)d4, e0q);
+      T g[4] = {0, 0, 0, 0};
+      funnel_column<T>(rq, d, mu, sg, e, e0q[0], mu0, sg0, g, s_ell, sA, sB);
+      mf_accumulate<T>(rq, d, true, stl, true, sg, e, g, sW, sWe, s_he);
+    }
+    T v[12];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = wave_total63(sW[r]);
+      v[4 + r] = wave_total63(sWe[r]);
+    }
+    v[8] = wave_total63(s_ell);
+    v[9] = wave_total63(s_he);
+    v[10] = wave_total63(sA);
+    v[11] = wave_total63(sB);
+    T(*xb)[4] = xw[t & 1];
+    if (NW > 1) {
+      if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) xb[k][wv] = v[k];
+      }
+      lds_barrier();
+    } else {   // one wave: its totals ARE the workgroup's (lane 63 holds them); hand them to the lanes that finish
+      if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) xb[k][0] = v[k];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (tid < 8) {   // gradient entries of this workgroup's rows, exactly as k_mf_main writes them
+      double trow = 0.0;
+#pragma unroll
+      for (int j = 0; j < NW; ++j) trow += (double)xb[myrow][j];
+      const T g = mf_grad_entry<T>(trow, invM, myrow >= 4, direct, (double)sgv);
+      if (row_ok) a.grad_out[(myrow < 4 ? 0 : d) + myi] = g;
+    } else if (tid >= 8 && tid < 14) {
+      const int k = tid - 8;   // 0 ell, 1 he, 2 log sigma, 3 bad, 4 A, 5 B
+      double hv;
+      if (k == 2) hv = lg;
+      else if (k == 3) hv = bad;
+      else {
+        const int src = k < 2 ? 8 + k : 6 + k;
+        hv = 0.0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) hv += (double)xb[src][j];
+      }
+      a.hist[((size_t)t * 6 + k) * nblk + rq] = hv;
+    }
+  }
+}
+
+template <typename T>
+struct MfFunnelValueArgs {
+  int d, nblk, n_steps, M, M_total, ent_kind, m_offset;
+  const T *params;
+  uint64_t seed, idx0;
+  double sigma_v, ell_const;
+  const double *hist;
+  T *value, *grad;       // the LAST estimate's results
+  T *scratch;            // [n_steps][d + 2]: value (slot d + 1) and the two row-0 gradient entries (slots 0, d) of the earlier ones
+  double *elbo;          // [n_steps]
+  int *status;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_mf_funnel_loop_value(MfFunnelValueArgs<T> a) {
+  __shared__ double red[6 * 4];
+  const int t = blockIdx.x, d = a.d, nblk = a.nblk;
+  const double *h = a.hist + (size_t)t * 6 * nblk;
+  ValueIn vin{};
+  vin.fn.ab = h + 4 * (size_t)nblk;
+  vin.fn.n_part = nblk;
+  vin.fn.params = a.params;
+  vin.fn.rng.seed = a.seed;
+  vin.fn.rng.idx_base = a.idx0 + (uint64_t)t;
+  vin.fn.rng.idx_ptr = nullptr;
+  vin.fn.rng.m_offset = a.m_offset;
+  vin.fn.d4 = (d + 3) >> 2;
+  vin.fn.M = a.M;
+  vin.fn.sigma_v = a.sigma_v;
+  vin.ell_part2 = h;
+  vin.n_ell_part2 = nblk;
+  vin.he_part = h + nblk;
+  vin.n_he_part = nblk;
+  vin.ld_part = h + 2 * (size_t)nblk;
+  vin.n_ld_part = nblk;
+  vin.ell_const = a.ell_const;
+  OutArgs out{};
+  const bool last = t == a.n_steps - 1;
+  T *sc = a.scratch + (size_t)t * (d + 2);
+  out.grad = last ? a.grad : sc;
+  out.value = last ? a.value : sc + d + 1;
+  out.ent_kind = a.ent_kind;
+  out.M_total = a.M_total;
+  out.M_local = a.M;
+  out.status = a.status;
+  out.elbo_rec = a.elbo;
+  out.rec_slot = t;
+  const T *sig = a.params + d;
+  finalize_value_block<T, 256, false, true>(d, vin, out, 2 * (int64_t)d, [sig](int i) { return sig[i]; }, red);
+}
+
+template <typename T>
+static void mf_funnel_loop_impl(mivi_ctx *c, const void *params, uint64_t idx0, int n_steps, double *hist, double *elbo, void *scratch,
+                                void *value, void *grad) {
+  MfFunnelLoopArgs<T> a;
+  a.d = c->cfg.d; a.M = c->cfg.n_mc; a.n_steps = n_steps;
+  a.params = (const T *)params;
+  a.seed = c->cfg.seed; a.idx0 = idx0;
+  a.m_offset = c->cfg.m_offset; a.M_total = c->M_total; a.ent_kind = c->cfg.entropy;
+  a.hist = hist;
+  a.grad_out = (T *)grad;
+  const int d4 = (a.d + 3) / 4;
+  if (a.M <= 64) hipLaunchKernelGGL((k_mf_funnel_loop<T, 1>), dim3(d4), dim3(64), 0, c->stream, a);
+  else hipLaunchKernelGGL((k_mf_funnel_loop<T, 4>), dim3(d4), dim3(256), 0, c->stream, a);
+  MfFunnelValueArgs<T> v;
+  v.d = a.d; v.nblk = d4; v.n_steps = n_steps; v.M = a.M; v.M_total = a.M_total; v.ent_kind = a.ent_kind; v.m_offset = a.m_offset;
+  v.params = a.params; v.seed = a.seed; v.idx0 = idx0;
+  v.sigma_v = c->funnel_sigma_v; v.ell_const = c->t_const;
+  v.hist = hist; v.value = (T *)value; v.grad = (T *)grad; v.scratch = (T *)scratch; v.elbo = elbo; v.status = (int *)c->status.p;
+  hipLaunchKernelGGL(k_mf_funnel_loop_value<T>, dim3(n_steps), dim3(256), 0, c->stream, v);
+}
+
+// n_steps estimates of the fused funnel target at fixed parameters in one launch + one finishing launch (see k_mf_funnel_loop).
+// hist: n_steps * 6 * ceil(d/4) doubles, elbo: n_steps doubles, scratch: n_steps * (d + 2) elements of T.
+void launch_mf_funnel_loop(mivi_ctx *c, const void *params, uint64_t idx0, int n_steps, double *hist, double *elbo, void *scratch,
+                           void *value, void *grad) {
+  if (c->cfg.dtype == MIVI_F32) mf_funnel_loop_impl<float>(c, params, idx0, n_steps, hist, elbo, scratch, value, grad);
+  else mf_funnel_loop_impl<double>(c, params, idx0, n_steps, hist, elbo, scratch, value, grad);
 }
 
 // rand(rng, q::MvLocationScale{<:Diagonal}, M): Z = mu + sigma .* eps  (location_scale.jl:80-87)

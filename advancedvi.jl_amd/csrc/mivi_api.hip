@@ -1493,6 +1493,19 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
     HIPCHK(c, hipGetLastError());
     return MIVI_OK;
   }
+  if (c->cfg.family == MIVI_MEANFIELD && c->target == TGT_FUNNEL && !c->funnel_constrained && !c->bij_on && c->cfg.n_mc <= 256 && !c->idx_src &&
+      !no_fused_loop_n) {
+    // fused funnel target (BASELINE config 5): the cross-row sums enter row 0 and ell linearly, so the batch is launch-free too --
+    // per-estimate partials to a history buffer, one finishing workgroup per estimate (k_mf_funnel_loop / _value)
+    const size_t d4 = (size_t)((c->cfg.d + 3) / 4);
+    const size_t nd = (size_t)count * 6 * d4 + (size_t)count + 8;
+    if ((s = ensure(c, c->X, nd * sizeof(double) + (size_t)count * ((size_t)c->cfg.d + 2) * c->esize + 64, false))) return s;
+    double *hist = (double *)c->X.p, *elbo = hist + (size_t)count * 6 * d4;
+    void *scratch = (void *)(elbo + count + 8);
+    launch_mf_funnel_loop(c, params, idx0, count, hist, elbo, scratch, value, grad);
+    HIPCHK(c, hipGetLastError());
+    return MIVI_OK;
+  }
   // The shortest batches run as an eager chain of the same launches: a graph replay carries ~25 us of fixed host cost (and its first
   // use a capture + instantiation), an eager chain ~17 us but ~0.7 us more per estimate (north star, n = 1 / 5 / 10 / 20 estimates
   // done after 31 / 93 / 168 / 314 us eagerly against 39 / 97 / 166 / 301 us replayed).  MIVI_GRAPH_MIN pins the
@@ -1994,8 +2007,9 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
   if (which == 8 && !(fr && (c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD)))
     return fail(c, MIVI_ERR_UNSUPPORTED, "which = 8: full-rank family with a sticking-the-landing estimator");
   if (which == 5) {   // the launch-free loop of 100 estimates (mean-field + diagonal target): one launch per rep
-    if (fr || c->target != TGT_DIAG_GAUSS || c->bij_on || M > 4096) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 5: mean-field + diagonal-Gaussian target, no bijector");
-    if ((s = ensure(c, c->X, ((size_t)100 + 400 * (size_t)((c->cfg.d + 3) / 4) + 8) * sizeof(double), false))) return s;
+    const bool fn5 = !fr && c->target == TGT_FUNNEL && !c->funnel_constrained;
+    if (fr || (c->target != TGT_DIAG_GAUSS && !fn5) || c->bij_on || M > 4096) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 5: mean-field + diagonal-Gaussian / fused funnel target, no bijector");
+    if ((s = ensure(c, c->X, ((size_t)100 + 600 * (size_t)((c->cfg.d + 3) / 4) + 16) * sizeof(double) + 100 * ((size_t)c->cfg.d + 2) * c->esize + 64, false))) return s;
   } else if (which != 0 && which != 8) {
     if (!fr && which != 2) return fail(c, MIVI_ERR_UNSUPPORTED, "mean-field has a single fused kernel (which = 2)");
     if (which == 4 && c->target != TGT_DENSE_GAUSS) return fail(c, MIVI_ERR_UNSUPPORTED, "no dense target set");
@@ -2027,6 +2041,12 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
         else launch_fr_stl(c, params, M);
         break;
       case 5:
+        if (c->target == TGT_FUNNEL) {
+          const size_t d4 = (size_t)((c->cfg.d + 3) / 4);
+          double *hist = (double *)c->X.p, *elbo = hist + 600 * d4;
+          launch_mf_funnel_loop(c, params, (uint64_t)r * 100, 100, hist, elbo, (void *)(elbo + 108), o, o + 16);
+          break;
+        }
         launch_mf_sgd_loop(c, const_cast<void *>(params), nullptr, (uint64_t)r * 100, 0, 100, -1, 0.0, (double)NAN, (double *)c->X.p + 100,
                            (double *)c->X.p, o + 16);
         break;

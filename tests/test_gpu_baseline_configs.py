@@ -193,3 +193,30 @@ def test_c5_funnel_stl_full_size_and_sharding():
     for c in ctxs:
         c.close()
     full.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("d,M,ent", [(2048, 64, 3), (2048, 64, 0), (7, 5, 3), (300, 200, 4), (64, 1024, 2)])
+def test_c5_launch_free_batch_equals_single_calls(d, M, ent, dtype):
+    """mivi_estimate_gradient_n on the fused funnel target (config 5's shard) runs all estimates inside one launch + one finishing
+    launch (k_mf_funnel_loop / _value); value and gradient of the LAST estimate must be bitwise those of a single call, for one wave
+    per workgroup (n_mc <= 64) and four, and the result must still be the oracle's."""
+    from oracle import oracle as O
+    q = avi.MeanFieldGaussian((0.1 * np.arange(d) / d).astype(dtype), np.full(d, 0.8, dtype))
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(dtype, avi.MEANFIELD, d, M, ent, SEED)
+    ctx.set_problem(avi.FunnelProblem(d, 1.5))
+    p = ctx.to_device(params)
+    v, g = ctx.empty(1), ctx.empty(ctx.params_len).fill_(float("nan"))
+    n = 9
+    ctx.estimate_gradient_n(p, 30, n, v, g)
+    ctx.synchronize()
+    v1, g1 = ctx.estimate_gradient(p, 30 + n - 1)
+    assert float(v.item()) == float(v1.item())
+    assert np.array_equal(g.cpu().numpy(), g1.cpu().numpy())
+    _, eps = ctx.sample(p, 30 + n - 1)
+    ref = O.estimate_gradient(params.astype(np.float64), d, avi.MEANFIELD, O.FunnelStackedTarget(d, 1.5), eps.cpu().numpy().astype(np.float64), ent)
+    vt, gt = (1e-5, 2e-5) if dtype == np.float32 else (1e-12, 1e-11)
+    assert abs(float(v.item()) - ref["value"]) <= vt * max(1.0, abs(ref["value"]))
+    assert np.linalg.norm(g.cpu().numpy() - ref["grad"]) <= gt * max(1.0, np.linalg.norm(ref["grad"]))
+    ctx.close()
