@@ -305,6 +305,17 @@ struct mivi_ctx {
   int dP = 0, MP = 0;
 
   mivi::GraphCache graph;
+
+  // Interleaved chains (mivi_estimate_gradient_n, full-rank + Gaussian targets): estimates at fixed parameters are independent, so a
+  // batch is dealt round-robin onto `1 + n_kids` chains -- this context and child contexts with their own work buffers and streams --
+  // whose kernels overlap on the device (the product of one chain's estimate runs beside the VJP of another's).
+  int idx_stride = 1;            // estimate-index step between consecutive estimates of THIS context's chain
+  bool is_child = false;         // target buffers are borrowed from the parent
+  mivi_ctx *kids[3] = {nullptr, nullptr, nullptr};
+  int n_kids = 0;
+  unsigned long long target_gen = 0, kid_gen = ~0ull;   // parent: bumped whenever a captured graph is invalidated; child: the generation it mirrors
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  mivi::DevBuf kid_out[3];       // value (16 bytes) + gradient of the child chains that do not hold the batch's last estimate
 };
 
 namespace mivi {

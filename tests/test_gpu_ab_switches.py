@@ -77,6 +77,26 @@ assert np.linalg.norm(g.cpu().numpy() - ref[1]) <= 2e-5 * max(1.0, np.linalg.nor
 print('ok')
 """
 
+CHAINS = """
+import numpy as np, advancedvi_jl_amd as avi
+from tests.helpers import SEED, make_family, make_problem
+d, M, n = 256, 128, 25
+rng = np.random.default_rng(9)
+q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
+prob, _ = make_problem(rng, {kind!r}, d, np.float32)
+params, _ = avi.destructure(q)
+ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+ctx.set_problem(prob)
+p = ctx.to_device(params)
+v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+for rep in range(2):
+    ctx.estimate_gradient_n(p, 10 + 40 * rep, n, v, g)
+    ctx.synchronize()
+    v1, g1 = ctx.estimate_gradient(p, 10 + 40 * rep + n - 1)
+    assert float(v.item()) == float(v1.item()) and np.array_equal(g.cpu().numpy(), g1.cpu().numpy())
+print('ok')
+"""
+
 F, MF = 1, 0
 CASES = [
     # switch, script, parameters
@@ -99,7 +119,10 @@ CASES = [
     ("MIVI_NO_FUSED_UPDATE=1", LOOP, dict(fam=F, d=128, M=128)),                                          # separate update kernel in the graph loop
     ("MIVI_GRAPH_MIN=1", LOOP, dict(fam=F, d=128, M=128)),                                                # graph replay even for the shortest batches
     ("MIVI_GRAPH_MIN=100", LOOP, dict(fam=F, d=128, M=128)),                                              # eager chain for every batch
-    ("MIVI_STEIN_GEN1=1", STEIN, dict()),                                                                 # first-generation accumulation kernel
+    ("MIVI_STEIN_GEN1=1", STEIN, dict()),
+    ("MIVI_CHAINS=1", CHAINS, dict(kind="diag")),                                                         # one chain instead of interleaved ones
+    ("MIVI_CHAINS=4", CHAINS, dict(kind="dense")),                                                        # four interleaved chains
+    ("MIVI_DUMMY_DEFAULT=1", CHAINS, dict(kind="dense")),                                                 # (no switch: the default interleaving)                                                                 # first-generation accumulation kernel
 ]
 
 
