@@ -200,6 +200,27 @@ def make_problem(avi, w):
     return q, prob
 
 
+def parity_vs_oracle(cx, p_dev, p_host, w, idx=11):
+    """Value and gradient of ONE estimate of workload `w` at its own shape against the fp64 numpy oracle on identical eps (read back from
+    the device).  Test infrastructure, outside every timed region.  None for workloads the oracle cannot finish in seconds (C3)."""
+    from oracle import oracle as O
+    d = w["d"]
+    if w["target"] == "iso":
+        tgt = O.DiagNormalTarget(np.full(d, 5.0), np.ones(d))
+    elif w["target"] == "dense":
+        tgt = O.DenseNormalTarget(np.full(d, 5.0), np.tril(np.eye(d) + np.ones((d, d)) / (2.0 * d)).astype(np.float32).astype(np.float64))
+    elif w["target"] == "funnel":
+        tgt = O.FunnelStackedTarget(d, 1.5)
+    else:
+        return None
+    _, eps = cx.sample(p_dev, idx)
+    v, g = cx.estimate_gradient(p_dev, idx)
+    ref = O.estimate_gradient(np.asarray(p_host, dtype=np.float64), d, w["family"], tgt, eps.cpu().numpy().astype(np.float64), w["entropy"])
+    g = g.cpu().numpy().astype(np.float64)
+    return dict(value_rel=abs(float(v.item()) - ref["value"]) / abs(ref["value"]),
+                grad_rel_l2=float(np.linalg.norm(g - ref["grad"]) / np.linalg.norm(ref["grad"])), estimate_idx=idx)
+
+
 def cpu_baseline(w, params, budget_s=24.0):
     """The oracle's C leg (oracle/mivi_oracle.c: a port of the reference semantics with the closed-form VJP,
     cheaper than the reference's AD path) timed on this box's host cores.  Protocol (the reference's
@@ -444,15 +465,34 @@ def main():
         if single and W < chunk:   # make sure the hipGraph is captured + instantiated outside the timed region
             run(W, chunk)
         stream.synchronize()
+        # pre-heat (untimed, NOT counted in `steps` / `warmup`): the same batched calls for >= 50 ms, so that the timed region -- 0.3 ms
+        # for the driver's --steps 20 -- does not sit on the clock ramp of a GPU that was idle a moment ago (measured: 15.0-15.7 us per
+        # estimate in the first milliseconds of a process, 14.4 after)
+        t_heat, heat_calls = time.perf_counter(), 0
+        idx_t = W + chunk          # the estimate index walks on, so the timed call continues the device-side counter (no counter-setting launch)
+        while time.perf_counter() - t_heat < 0.05 or heat_calls < 3:
+            run(idx_t, max(chunk, 1))
+            idx_t += max(chunk, 1)
+            stream.synchronize()
+            heat_calls += 1
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run(W, K)
-        torch.cuda.synchronize()   # (device-wide: covers the launch stream)
+        run(idx_t, K)
+        torch.cuda.synchronize()   # (device-wide: covers the launch stream and the interleaved chains' streams)
         if dist:
             dist.barrier()
         dt = time.perf_counter() - t0
+        repeats = []
+        if single:   # the same timed region again, back to back (diagnostic: what a longer-running process sees for the same K steps)
+            for r in range(5):
+                torch.cuda.synchronize()
+                tr = time.perf_counter()
+                run(idx_t + (r + 1) * K, K)
+                torch.cuda.synchronize()
+                repeats.append((time.perf_counter() - tr) / K * 1e3)
+            idx_t += 5 * K
         if dist:
             t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -482,6 +522,12 @@ def main():
                     roof, stages = mf_roofline(ctx, params, cost)
                 else:
                     roof, stages = fr_roofline(ctx, params, cost, w)
+                    try:   # two EMPTY dependent launches with the grids / LDS footprints of the two contraction kernels (graph replay)
+                        roof["latency_floor_us"] = ctx.profile_kernel(9, params, reps) * 1e3
+                        roof["latency_floor_note"] = ("what the two-launch structure costs with no work in it; whole estimate minus this = "
+                                                      "what kernel work can still win")
+                    except Exception:   # noqa: BLE001
+                        pass
                 stages = {k: round(v * 1e3, 3) for k, v in stages.items()}   # us
                 if w["family"] == 1 and w["entropy"] in (3, 4):
                     roof["stl_term"] = stl_block(ctx, params, w)
@@ -528,10 +574,10 @@ def main():
             steady = None
             if single:
                 n_ss = 1000
-                run(W + K, chunk)          # (graph already instantiated)
+                run(idx_t + K, chunk)          # (graph already instantiated)
                 stream.synchronize()
                 t0s = time.perf_counter()
-                run(W + K + chunk, n_ss)
+                run(idx_t + K + chunk, n_ss)
                 stream.synchronize()
                 tss = time.perf_counter() - t0s
                 steady = dict(estimates=n_ss, us_per_step=tss / n_ss * 1e6, estimates_per_s=n_ss / tss)
@@ -571,7 +617,8 @@ def main():
                         if w2["entropy"] in (3, 4):
                             roof2["stl_term"] = stl_block(cx, p2, w2)
                     also[wn] = dict(workload=w2["name"], value=1.0 / t2, unit="estimates/s", us_per_step=t2 * 1e6, estimates=n_est,
-                                    launch="hipGraph x100" if graphable else "eager", roofline=roof2)
+                                    launch="hipGraph x100" if graphable else "eager", roofline=roof2,
+                                    parity_vs_fp64_oracle=(None if args.no_cpu_baseline else parity_vs_oracle(cx, p2, p2h, w2)))
                     cx.close()
                     del prob2, q2
                 # the Stein / Price estimator of E_q[grad], E_q[hess] on the north-star shape (gaussian_expectation_gradient_and_hessian!,
@@ -592,6 +639,26 @@ def main():
                                      f32_mfma_TFs=(2.0 * w["d"] * w["d"] * w["n_mc"] * 1.5 + 2.0 * w["d"] ** 3 / 2) / t_st / 1e12,
                                      note="flops: triangular product + eps G^T (d^2 n each, the first half-counted) + the d-column solve (d^3 / 2 MACs)")
                 del g_s, H_s
+                # what a host that keeps its parameters in host memory sees (julia/MIVI.jl's estimate_gradient! without the device-resident
+                # fast path): mivi_estimate_gradient_host = 4.2 MB of parameters up + 4.2 MB of gradient down over PCIe around the estimate
+                import ctypes as C
+                v_h, g_h = np.zeros(1, np.float32), np.zeros(ctx.params_len, np.float32)
+                ph = np.ascontiguousarray(params_h, dtype=np.float32)
+                def host_call(i):
+                    st_ = ctx.lib.mivi_estimate_gradient_host(ctx.h, ph.ctypes.data_as(C.c_void_p), i, v_h.ctypes.data_as(C.c_void_p),
+                                                              g_h.ctypes.data_as(C.c_void_p))
+                    if st_ != 0:
+                        raise RuntimeError(f"mivi_estimate_gradient_host status {st_}")
+                for i in range(5):
+                    host_call(70_000 + i)
+                t0s = time.perf_counter()
+                for i in range(50):
+                    host_call(70_005 + i)
+                t_hb = (time.perf_counter() - t0s) / 50
+                also["ns_host_boundary"] = dict(workload="north-star estimate through mivi_estimate_gradient_host (host params in, host gradient out, synchronous)",
+                                                us_per_step=t_hb * 1e6, value=1.0 / t_hb, unit="estimates/s",
+                                                pcie_bytes_per_step=2 * ctx.params_len * 4,
+                                                note="PCIe-inclusive rate of the boundary a Julia host without device arrays uses; never the headline value")
                 # the device-resident optimisation loop on the north-star problem (mivi_optimize_steps: estimate -> Adam + ClipScale fused into
                 # the VJP epilogue, hipGraph of the whole chunk): what `optimize()` sustains, one dependent chain
                 p_l = params.clone()
@@ -610,6 +677,7 @@ def main():
                 del p_l, st_l
             # ---- parity + cpu_baseline leg (rank 0, N = 1 only) ---------------------------------------------
             rel = None
+            parity_head = None
             cpub = None
             if single and not args.no_cpu_baseline:
                 from oracle import c_oracle as CO
@@ -622,6 +690,7 @@ def main():
                                                    eps.cpu().numpy().astype(np.float64), np.full(w["d"], 5.0), np.ones(w["d"]),
                                                    w["entropy"])
                     rel = abs(float(v.item()) - vref) / abs(vref)
+                    parity_head = parity_vs_oracle(ctx, params, params_h, w)
             out = {
                 "metric": "ELBO-grad-estimates/sec", "value": est_per_s, "unit": "estimates/s",
                 "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3,
@@ -632,7 +701,8 @@ def main():
                            "launch": f"hipGraph x{chunk}" if single else (f"mivi_estimate_gradient_dist_n x{chunk} (pipelined: exchange of estimate t under the kernels of t+1), route {dist_info['route']}" if pipelined else f"mivi_estimate_gradient_dist (dependent chain), route {dist_info['route']}"),
                            "fullrank_route": (list(ctx.fullrank_route()) if w["family"] == 1 else None)},
                 "roofline": roof, "cpu_baseline": cpub,
-                "elbo_rel_err_vs_cpu_fp64": rel, "stage_us": stages, "whole_estimate": whole, "steady_state": steady, "concurrent": conc, "also": also,
+                "repeat_ms_per_step": repeats, "elbo_rel_err_vs_cpu_fp64": rel, "parity_vs_fp64_oracle": parity_head, "stage_us": stages,
+                "preheat": dict(calls=heat_calls, note="untimed batched calls for >= 50 ms before the timed region (GPU clock ramp); not counted in steps / warmup"), "whole_estimate": whole, "steady_state": steady, "concurrent": conc, "also": also,
                 "dist": (None if single else dist_info),
             }
         if dist:

@@ -345,7 +345,8 @@ mivi_status_t mivi_profile_dist(mivi_ctx_t *ctx, const void *params_dev, int32_t
  *   which: 0 = whole estimate, 1 = eps generation, 2 = sample(+fused target) kernel (mean-field: the fused main kernel),
  *          3 = VJP kernel, 4 = dense-target kernel, 5 = the launch-free loop of 100 estimates (mean-field + diagonal
  *          target; what mivi_estimate_gradient_n runs there), 6 / 7 = the split-K product / its reduce kernel alone
- *          (second-generation full-rank route only), 8 = the sticking-the-landing term W += C^-T eps alone (full-rank, STL estimators).  Stages 1-4, 6, 7 are captured `reps` times into one hipGraph and the
+ *          (removed), 8 = the sticking-the-landing term W += C^-T eps alone (full-rank, STL estimators),
+ *          9 = the LATENCY FLOOR of the full-rank estimate: two empty dependent launches with the grid / block / LDS footprint of the product and VJP kernels.  Stages 1-4, 6, 7 are captured `reps` times into one hipGraph and the
  *          replay is timed (eager launches of 2-5 us kernels are host-bound); 0 and 5 are eager.  ms_per_launch_host: double[1]. */
 mivi_status_t mivi_profile_kernel(mivi_ctx_t *ctx, int32_t which, const void *params_dev, int32_t reps,
                                   double *ms_per_launch_host);
