@@ -80,6 +80,7 @@ SIGNATURES = {
     "mivi_p2p_detach": (C.c_int32, [C.c_void_p]),
     "mivi_p2p_geometry": (None, [C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),
     "mivi_comm_enable_p2p": (C.c_int32, [C.c_void_p]),
+    "mivi_p2p_debug_words": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "mivi_p2p_set_pipeline": (C.c_int32, [C.c_void_p, C.c_int32]),
     "mivi_p2p_set_spin_budget": (C.c_int32, [C.c_void_p, C.c_int32]),
     "mivi_comm_set_route": (C.c_int32, [C.c_void_p, C.c_int32]),

@@ -12,7 +12,7 @@ module MIVI
 
 using AdvancedVI, ADTypes, DiffResults, LogDensityProblems, Optimisers, Random, LinearAlgebra
 using Distributions: Normal
-using AdvancedVI: MvLocationScale, RepGradELBO, ClosedFormEntropy, ClosedFormEntropyZeroGradient,
+using AdvancedVI: MvLocationScale, RepGradELBO, KLMinRepGradDescent, ClosedFormEntropy, ClosedFormEntropyZeroGradient,
                   MonteCarloEntropy, StickingTheLandingEntropy, StickingTheLandingEntropyZeroGradient
 
 const libmivi = get(ENV, "LIBMIVI", "libmivi.so")
@@ -46,6 +46,7 @@ mutable struct MIVIState
     cb::Any                      # keeps the @cfunction closure alive
     distributed::Bool            # a communicator is attached (comm_init!): estimates run sharded over the ranks
     dev::Any                     # device scratch for the sharded route: (params, value, grad) pointers or nothing
+    native::Bool                 # the target runs on the device (mivi_set_target_*): the device-resident `optimize` applies
 end
 
 function check(ctx, status)
@@ -85,11 +86,15 @@ function AdvancedVI.init(rng::Random.AbstractRNG, obj::RepGradELBO, ad::AutoMIVI
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     status = ccall((:mivi_create, libmivi), Int32, (Ref{MiviConfig}, Ref{Ptr{Cvoid}}), cfg, ctx)
     status == 0 || error("mivi_create failed with status $status (no HIP device?)")
-    st = MIVIState(prob, T, ctx[], UInt64(0), nothing, false, nothing)
+    st = MIVIState(prob, T, ctx[], UInt64(0), nothing, false, nothing, false)
+    finalizer(s -> ccall((:mivi_destroy, libmivi), Int32, (Ptr{Cvoid},), s.ctx), st)
+    if prob isa NativeTarget          # a target whose arithmetic stays on the GPU: no host callback at all
+        set_native_target!(st, prob)
+        return st
+    end
     cb = @cfunction(target_callback, Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}))
     st.cb = cb
     check(st.ctx, ccall((:mivi_set_target_callback, libmivi), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Any), st.ctx, cb, C_NULL, st))
-    finalizer(s -> ccall((:mivi_destroy, libmivi), Int32, (Ptr{Cvoid},), s.ctx), st)
     return st
 end
 
@@ -131,6 +136,176 @@ function AdvancedVI.set_objective_state_problem(state::MIVIState, prob)
     return state
 end
 
+# ---- targets that live on the device ---------------------------------------------------------------------------------------------
+# Plain LogDensityProblems (so every other AdvancedVI algorithm can use them on the host) that `init(..., ::AutoMIVI, ...)` recognises
+# and hands to the library's fused kernels instead of the host callback: MvNormal with diagonal / Cholesky covariance
+# (test/models/normal.jl:36-75, bench/benchmarks.jl:43-47) and Neal's funnel under Stacked([log, identity]) (SURVEY.md 8d).
+abstract type NativeTarget end
+struct NativeDiagNormal{V<:AbstractVector} <: NativeTarget
+    mean::V
+    std::V
+end
+struct NativeDenseNormal{V<:AbstractVector,M<:AbstractMatrix} <: NativeTarget
+    mean::V
+    chol_L::M        # lower Cholesky factor of the covariance
+end
+struct NativeFunnel <: NativeTarget
+    d::Int
+    sigma_v::Float64
+end
+LogDensityProblems.dimension(p::NativeDiagNormal) = length(p.mean)
+LogDensityProblems.dimension(p::NativeDenseNormal) = length(p.mean)
+LogDensityProblems.dimension(p::NativeFunnel) = p.d
+LogDensityProblems.capabilities(::Type{<:NativeTarget}) = LogDensityProblems.LogDensityOrder{1}()
+function LogDensityProblems.logdensity_and_gradient(p::NativeDiagNormal, z)
+    u = (z .- p.mean) ./ p.std
+    return -sum(abs2, u) / 2 - sum(log, p.std) - length(z) * log(2pi) / 2, -u ./ p.std
+end
+function LogDensityProblems.logdensity_and_gradient(p::NativeDenseNormal, z)
+    L = LowerTriangular(p.chol_L)
+    w = L \ (z .- p.mean)
+    return -sum(abs2, w) / 2 - logdet(L) - length(z) * log(2pi) / 2, -(L' \ w)
+end
+function LogDensityProblems.logdensity_and_gradient(p::NativeFunnel, eta)
+    e1, x, sv2 = eta[1], @view(eta[2:end]), p.sigma_v^2
+    n = p.d - 1
+    s2 = sum(abs2, x) * exp(-2e1)
+    l = -log(p.sigma_v) - log(2pi) / 2 - e1 - e1^2 / (2sv2) - n * log(2pi) / 2 - n * e1 - s2 / 2 + e1
+    g = similar(eta)
+    g[1] = -1 - e1 / sv2 - n + s2 + 1
+    g[2:end] .= .-x .* exp(-2e1)
+    return l, g
+end
+LogDensityProblems.logdensity(p::NativeTarget, z) = first(LogDensityProblems.logdensity_and_gradient(p, z))
+
+function set_native_target!(st, p::NativeDiagNormal)
+    T = st.T
+    check(st.ctx, ccall((:mivi_set_target_diag_gauss, libmivi), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{T}), st.ctx, Vector{T}(p.mean), Vector{T}(p.std)))
+    st.native = true
+    return st
+end
+function set_native_target!(st, p::NativeDenseNormal)
+    T = st.T
+    check(st.ctx, ccall((:mivi_set_target_dense_gauss, libmivi), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{T}), st.ctx, Vector{T}(p.mean), Matrix{T}(p.chol_L)))
+    st.native = true
+    return st
+end
+function set_native_target!(st, p::NativeFunnel)
+    check(st.ctx, ccall((:mivi_set_target_funnel, libmivi), Int32, (Ptr{Cvoid}, Float64), st.ctx, p.sigma_v))
+    st.native = true
+    return st
+end
+
+# ---- the device-resident `optimize` ---------------------------------------------------------------------------------------------
+# `KLMinRepGradDescent{Obj,AD,...}` carries the AD type as a parameter (src/algorithms/constructors.jl:44-55), so `optimize`
+# (src/optimize.jl:42-81) can be specialised on AutoMIVI: with a device-resident target and no callback the whole loop of
+# `step` (src/algorithms/common.jl:69-120) -- estimate_gradient!, Optimisers.update!, operator, averager, the isfinite guard -- runs
+# inside mivi_optimize_loop with the parameters, optimiser state and running average in HBM: no 4.2 MB parameter upload and 4.2 MB
+# gradient download per step (bench.py `also.ns_host_boundary`: ~1 ms per step through mivi_estimate_gradient_host against ~16 us).
+# Anything else (a callback, a host-callback target, a rule / operator / averager the loop does not implement, subsampling,
+# extra objargs) takes the reference's own `optimize`.
+const libhip = get(ENV, "LIBHIP", "libamdhip64.so")
+hipcheck(e) = e == 0 || error("HIP runtime error $e")
+function dev_alloc(nbytes::Integer)
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    hipcheck(ccall((:hipMalloc, libhip), Int32, (Ref{Ptr{Cvoid}}, Csize_t), p, nbytes))
+    return p[]
+end
+dev_free(p::Ptr{Cvoid}) = ccall((:hipFree, libhip), Int32, (Ptr{Cvoid},), p)
+h2d(dst::Ptr{Cvoid}, src::Array) = hipcheck(ccall((:hipMemcpy, libhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Int32), dst, src, sizeof(src), 1))
+d2h(dst::Array, src::Ptr{Cvoid}) = hipcheck(ccall((:hipMemcpy, libhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Int32), dst, src, sizeof(dst), 2))
+dev_zero(p::Ptr{Cvoid}, nbytes::Integer) = hipcheck(ccall((:hipMemset, libhip), Int32, (Ptr{Cvoid}, Int32, Csize_t), p, 0, nbytes))
+
+# mivi_loop_t (include/mivi.h)
+struct MiviLoop
+    rule::Int32; op::Int32; averager::Int32; n_steps::Int32
+    eta::Float64; beta1::Float64; beta2::Float64; adam_eps::Float64
+    clip_epsilon::Float64; avg_eta::Float64
+    opt_state_dev::Ptr{Cvoid}; avg_params_dev::Ptr{Cvoid}
+    estimate_idx0::UInt64; t0::Int64
+    elbo_dev::Ptr{Cvoid}
+end
+
+loop_rule(o::Optimisers.Descent) = (Int32(0), Float64(o.eta), 0.9, 0.999, 1e-8)
+loop_rule(o::Optimisers.Adam) = (Int32(1), Float64(o.eta), Float64(o.beta[1]), Float64(o.beta[2]), Float64(o.epsilon))
+loop_rule(::Any) = nothing
+loop_op(::AdvancedVI.IdentityOperator) = (Int32(0), 0.0)
+loop_op(o::AdvancedVI.ClipScale) = (Int32(1), Float64(o.epsilon))
+loop_op(::Any) = nothing
+loop_avg(::AdvancedVI.NoAveraging) = (Int32(0), 0.0)
+loop_avg(a::AdvancedVI.PolynomialAveraging) = (Int32(1), Float64(a.eta))
+loop_avg(::Any) = nothing
+
+const DEVICE_LOOP_CHUNK = 256     # iterations per mivi_optimize_loop call (bounds the work done past a divergence)
+
+function AdvancedVI.optimize(rng::Random.AbstractRNG, alg::KLMinRepGradDescent{<:RepGradELBO,<:AutoMIVI}, max_iter::Int, prob, q_init,
+                             objargs...; show_progress::Bool = true, state = nothing, callback = nothing, kwargs...)
+    codes = (loop_rule(alg.optimizer), loop_op(alg.operator), loop_avg(alg.averager))
+    fast = callback === nothing && isempty(objargs) && prob isa NativeTarget && q_init isa MvLocationScale && all(!isnothing, codes)
+    if !fast   # the reference's own loop (host-driven `step`, this module's estimate_gradient!)
+        return invoke(AdvancedVI.optimize, Tuple{Random.AbstractRNG,AdvancedVI.AbstractVariationalAlgorithm,Int,Any,Any,Vararg{Any}},
+                      rng, alg, max_iter, prob, q_init, objargs...; show_progress, state, callback, kwargs...)
+    end
+    state = isnothing(state) ? AdvancedVI.init(rng, alg, q_init, prob) : state
+    st = state.obj_st::MIVIState
+    T = st.T
+    params, re = Optimisers.destructure(state.q)
+    n = length(params)
+    (rule, eta, b1, b2, aeps), (op, ceps), (avg, aeta) = codes
+    # device buffers: parameters, optimiser state (Adam: m; v), running average, per-iteration elbo
+    p_dev = dev_alloc(n * sizeof(T)); h2d(p_dev, params)
+    o_dev = rule == 1 ? dev_alloc(2n * sizeof(T)) : Ptr{Cvoid}(C_NULL)
+    if rule == 1
+        leaf = state.opt_st                      # Optimisers.Leaf(Adam, (mt, vt, betat)): warm starts keep their moments
+        h2d(o_dev, Vector{T}(vcat(leaf.state[1], leaf.state[2])))
+    end
+    a_dev = avg == 1 ? dev_alloc(n * sizeof(T)) : Ptr{Cvoid}(C_NULL)
+    avg == 1 && h2d(a_dev, Vector{T}(AdvancedVI.value(alg.averager, state.avg_st)))
+    e_dev = dev_alloc(DEVICE_LOOP_CHUNK * sizeof(T))
+    info_total = NamedTuple[]
+    t_done = state.iteration
+    try
+        done = 0
+        while done < max_iter
+            k = min(DEVICE_LOOP_CHUNK, max_iter - done)
+            loop = Ref(MiviLoop(rule, op, avg, Int32(k), eta, b1, b2, aeps, ceps, aeta, o_dev, a_dev, st.estimate_idx, Int64(t_done), e_dev))
+            status = ccall((:mivi_optimize_loop, libmivi), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{MiviLoop}), st.ctx, p_dev, loop)
+            status == 2 && throw(ErrorException("The objective value is not finite. This indicates that the optimization run diverged."))
+            check(st.ctx, status)
+            elbo = Vector{T}(undef, k)
+            d2h(elbo, e_dev)
+            for i in 1:k
+                push!(info_total, (elbo = elbo[i], iteration = t_done + i))
+            end
+            st.estimate_idx += k
+            t_done += k
+            done += k
+        end
+        d2h(params, p_dev)
+        opt_st = state.opt_st
+        if rule == 1
+            mv = Vector{T}(undef, 2n)
+            d2h(mv, o_dev)
+            beta = (T(b1), T(b2))
+            opt_st = Optimisers.Leaf(alg.optimizer, (mv[1:n], mv[(n + 1):end], beta .^ (t_done + 1)))
+        end
+        avg_st = state.avg_st
+        if avg == 1
+            pa = Vector{T}(undef, n)
+            d2h(pa, a_dev)
+            avg_st = (pa, t_done + 1)   # (src/optimization/averaging.jl:38-47: (running average, next step number))
+        elseif avg == 0
+            avg_st = copy(params)
+        end
+        state = (prob = prob, q = re(params), iteration = t_done, grad_buf = state.grad_buf, opt_st = opt_st, obj_st = st, avg_st = avg_st)
+    finally
+        dev_free(p_dev); dev_free(e_dev)
+        o_dev != C_NULL && dev_free(o_dev)
+        a_dev != C_NULL && dev_free(a_dev)
+    end
+    return AdvancedVI.output(alg, state), map(identity, info_total), state
+end
+
 # A target whose arithmetic stays on the GPU: hierarchical logistic regression (docs/src/tutorials/subsampling.md:20-46).
 # `AdvancedVI.subsample` returns a NativeLogRegBatch (0-based rows + n_data / n), consumed above.
 struct NativeLogReg{XT,YT}
@@ -150,6 +325,7 @@ function native_logreg!(state::MIVIState, m::NativeLogReg; variant::Int = 0, lik
     check(state.ctx, ccall((:mivi_set_target_logreg, libmivi), Int32,
                            (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{UInt8}, Int64, Int32, Float64, Int32),
                            state.ctx, m.X, m.y, size(m.X, 1), variant, likeadj, 0))
+    state.native = true
     return state
 end
 
@@ -195,7 +371,9 @@ end
 
 # Multi-GPU (one process per GPU): the collective lives behind the C ABI (RCCL opened by libmivi).  Rank 0 creates the id,
 # the host broadcasts its 128 bytes by its own means (MPI.Bcast!, a file, ...), every rank attaches it.  The context must have
-# been created with this rank's slice of the sample axis (MiviConfig.m_offset / m_total; see `init_sharded`).
+# been created with this rank's slice of the sample axis (MiviConfig.m_offset / m_total: build the MiviConfig with n_mc = the local share,
+# m_offset = its first global column, m_total = the global n_samples before mivi_create).  `comm_enable_p2p!` then maps the peers' exchange
+# areas (the exchange written for xGMI, csrc/kernels_p2p.hip) through the communicator; batched estimates: estimate_gradient_dist_n!.
 function comm_unique_id()
     id = Vector{UInt8}(undef, 128)
     status = ccall((:mivi_comm_unique_id, libmivi), Int32, (Ptr{UInt8},), id)
@@ -205,6 +383,14 @@ end
 function comm_init!(state::MIVIState, id::Vector{UInt8}, rank::Integer, world::Integer)
     check(state.ctx, ccall((:mivi_comm_init, libmivi), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), state.ctx, id, Int32(rank), Int32(world)))
     state.distributed = true
+    return state
+end
+comm_enable_p2p!(state::MIVIState) = (check(state.ctx, ccall((:mivi_comm_enable_p2p, libmivi), Int32, (Ptr{Cvoid},), state.ctx)); state)
+function estimate_gradient_dist_n!(state::MIVIState, params_dev::Ptr{Cvoid}, count::Integer, value_dev::Ptr{Cvoid}, grad_dev::Ptr{Cvoid})
+    check(state.ctx, ccall((:mivi_estimate_gradient_dist_n, libmivi), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
+                           state.ctx, params_dev, state.estimate_idx, Int32(count), value_dev, grad_dev))
+    state.estimate_idx += count
+    check(state.ctx, ccall((:mivi_synchronize, libmivi), Int32, (Ptr{Cvoid},), state.ctx))
     return state
 end
 comm_destroy!(state::MIVIState) = (check(state.ctx, ccall((:mivi_comm_destroy, libmivi), Int32, (Ptr{Cvoid},), state.ctx)); state.distributed = false; state)
@@ -222,5 +408,5 @@ end
 # ProximalLocationScaleEntropy on the host arrays works unchanged (src/optimization/proximal_location_scale_entropy.jl);
 # the device-resident variant for a parameter vector that lives in HBM is mivi_prox_scale_entropy.
 
-export AutoMIVI, NativeLogReg, native_logreg!, MIVITarget, set_bijector!, comm_unique_id, comm_init!, comm_destroy!, estimate_gradient_dist!
+export AutoMIVI, NativeDiagNormal, NativeDenseNormal, NativeFunnel, NativeLogReg, native_logreg!, MIVITarget, set_bijector!, comm_unique_id, comm_init!, comm_enable_p2p!, comm_destroy!, estimate_gradient_dist!, estimate_gradient_dist_n!
 end # module

@@ -318,6 +318,8 @@ mivi_status_t mivi_comm_enable_p2p(mivi_ctx_t *ctx);
  * sharing one hardware queue), the bounded waits end in MIVI_ERR_HIP at the next mivi_synchronize -- the host then switches the
  * pipeline off ON EVERY RANK (all ranks must agree: the lanes the estimates use differ) and batched calls run serial steps. */
 mivi_status_t mivi_p2p_set_pipeline(mivi_ctx_t *ctx, int32_t on);
+/* developer: the exchange's device words (per lane {epoch, ticket} at 16-word spacing, ready at word 64, freed[ring] at word 80): out128 = uint32[128] */
+mivi_status_t mivi_p2p_debug_words(mivi_ctx_t *ctx, uint32_t *out128_host);
 /* how many polls (about 1 us each) a wait inside the exchange may take before the peer counts as lost (default 2^21, about 2 s) */
 mivi_status_t mivi_p2p_set_spin_budget(mivi_ctx_t *ctx, int32_t polls);
 /* Which exchange mivi_estimate_gradient_dist[_n] uses: 0 = automatic (peer-to-peer when attached, otherwise ONE ncclAllReduce + the whole

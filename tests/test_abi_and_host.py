@@ -32,6 +32,38 @@ def test_library_loads_and_exports_every_declared_symbol(lib):
     assert lib.mivi_version() == 1
 
 
+def _c_class(decl):
+    """coarse class of a C parameter / return declaration of include/mivi.h"""
+    t = decl.strip()
+    if "*" in t or "[" in t or t.startswith("mivi_logdensity"):
+        return "ptr"
+    for key, cls in (("uint64_t", "u64"), ("int64_t", "i64"), ("int32_t", "i32"), ("mivi_status_t", "i32"), ("double", "f64"), ("void", "void")):
+        if re.search(r"\b" + key + r"\b", t):
+            return cls
+    raise AssertionError(f"unclassified C declaration: {decl!r}")
+
+
+def _jl_class(t):
+    """the same classes for a Julia ccall type"""
+    t = t.strip()
+    if t.startswith(("Ptr{", "Ref{")) or t in ("Any", "Cstring", "Ptr"):
+        return "ptr"
+    return {"Int32": "i32", "Cint": "i32", "UInt64": "u64", "Int64": "i64", "Float64": "f64", "Cdouble": "f64", "Cvoid": "void"}[t]
+
+
+def header_signatures():
+    """name -> (return class, [parameter classes]) from include/mivi.h"""
+    src = open(os.path.join(ROOT, "include", "mivi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ ]*?[ \*]+)(mivi_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        if name.endswith("_fn") or "typedef" in ret:
+            continue
+        out[name] = (_c_class(ret), [] if args in ("", "void") else [_c_class(a) for a in args.split(",")])
+    return out
+
+
 def header_prototypes():
     """name -> number of parameters, from include/mivi.h (comments stripped)."""
     src = open(os.path.join(ROOT, "include", "mivi.h")).read()
@@ -49,6 +81,7 @@ def test_julia_wrapper_ccalls_match_the_header():
     """julia/MIVI.jl cannot be executed here (no Julia in the image); what can be checked is that every ccall names an entry
     point include/mivi.h declares and passes as many arguments as the prototype has, with an argument-type tuple of that length."""
     protos = header_prototypes()
+    sigs = header_signatures()
     txt = open(os.path.join(ROOT, "advancedvi.jl_amd", "julia", "MIVI.jl")).read()
     calls = list(re.finditer(r"ccall\(\(:(mivi_[a-z0-9_]+),\s*libmivi\),\s*(\w+),\s*\(", txt))
     assert len(calls) >= 12
@@ -80,10 +113,16 @@ def test_julia_wrapper_ccalls_match_the_header():
         if cur.strip():
             parts.append(cur)
         assert len(parts) == protos[name], f"{name}: {len(parts)} argument types in MIVI.jl, {protos[name]} parameters in mivi.h"
+        # ... and every argument (and the return value) is of the prototype's class: pointer / int32 / int64 / uint64 / double
+        ret_c, par_c = sigs[name]
+        assert _jl_class(m.group(2)) == ret_c, f"{name}: returns {m.group(2)} in MIVI.jl, {ret_c} in mivi.h"
+        for k, (jt, cc) in enumerate(zip(parts, par_c)):
+            assert _jl_class(jt) == cc, f"{name}: argument {k} is {jt.strip()} in MIVI.jl, {cc} in mivi.h"
         seen.add(name)
     for must in ("mivi_create", "mivi_destroy", "mivi_set_target_callback", "mivi_estimate_gradient_host", "mivi_estimate_objective_host",
                  "mivi_set_bijector_stacked", "mivi_comm_unique_id", "mivi_comm_init", "mivi_estimate_gradient_dist",
-                 "mivi_gauss_expected_grad_hess_host", "mivi_logreg_select_rows"):
+                 "mivi_gauss_expected_grad_hess_host", "mivi_logreg_select_rows", "mivi_optimize_loop", "mivi_set_target_diag_gauss",
+                 "mivi_set_target_dense_gauss", "mivi_set_target_funnel", "mivi_comm_enable_p2p", "mivi_estimate_gradient_dist_n"):
         assert must in seen, f"MIVI.jl does not bind {must}"
 
 
