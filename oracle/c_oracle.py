@@ -8,8 +8,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PATH = os.path.join(_HERE, "libmivi_oracle.so")
 
 
-def load():
-    lib = C.CDLL(PATH)
+NATIVE_PATH = os.path.join(_HERE, "_native", "libmivi_oracle.so")
+
+
+def load(path=None):
+    lib = C.CDLL(path or PATH)
     for pfx, ct in (("mo64_", C.c_double), ("mo32_", C.c_float)):
         f = getattr(lib, pfx + "estimate_gradient")
         f.restype = C.c_double

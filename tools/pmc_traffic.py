@@ -1,6 +1,9 @@
 #!/usr/bin/env python
-"""profiles/pmc_traffic.json from two rocprofv3 passes (--pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs)."""
-import json, sqlite3, sys
+"""profiles/pmc_traffic.json from two rocprofv3 passes (--pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs), with the gfx950 correction
+of MI355X_MICROARCH.md applied per kernel: FETCH_SIZE under-reports wide loads, by the factor profiles/pmc_calibration.json measured on
+this library's own access patterns (tools/ubench_fetchcal.hip: lds16 = 16 B/lane direct-to-LDS loads, ld16 = 16 B/lane register loads,
+ld4 = 4 B/lane loads).  Also: traffic_over_algorithmic for the kernels whose algorithmic bytes SURVEY.md 8d fixes."""
+import json, os, sqlite3, sys
 def per_kernel(db, counter):
     con = sqlite3.connect(db)
     tabs = [r[0] for r in con.execute("select name from sqlite_master where type='table'")]
@@ -12,9 +15,34 @@ def per_kernel(db, counter):
     for k, _, v in con.execute(q):
         acc.setdefault(k, []).append(v)
     return {k: sum(v) / len(v) for k, v in acc.items()}
+# which load flavour dominates a kernel's fetches
+PATTERN = (("k_fr_prod32", "lds16"), ("k_fr_prod64", "lds16"), ("k_fr_vjp32", "lds16"), ("k_fr_vjp64", "lds16"), ("k_stl_solve", "lds16"),
+           ("k_stl_update", "lds16"), ("k_lr_", "ld16"), ("k_p2p_exchange", "ld16"))
+# algorithmic KiB per launch at the north star (d = 1024, n_mc = 256, f32): in + out
+d, M = 1024, 256
+ALGO = {"k_fr_prod32ILi0": (d * (d + 1) // 2 * 4 + d * M * 4 + d * M * 4 + d * M * 4) / 1024.0,   # tril(C) + eps in, W + eps(t+1) out
+        "k_fr_vjp32": (2 * d * M * 4 + d * d * 4) / 1024.0}                                        # W + eps in, dense dC out
+cal = {}
+try:
+    cal = json.load(open("profiles/pmc_calibration.json")).get("patterns", {})
+except (OSError, ValueError):
+    pass
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+kern = {}
+for k in sorted(set(fetch) | set(write)):
+    if k.startswith("__amd"):
+        continue
+    pat = next((p for key, p in PATTERN if key in k), "ld4")
+    f = (cal.get(pat) or {}).get("true_over_counter") or 1.0
+    fw = (cal.get("st16_wt") or {}).get("true_over_counter") or 1.0
+    e = {"fetch_kib": fetch.get(k, 0.0) * f, "write_kib": write.get(k, 0.0) * fw, "fetch_kib_raw": fetch.get(k, 0.0), "write_kib_raw": write.get(k, 0.0),
+         "load_pattern": pat, "fetch_correction": f, "write_correction": fw}
+    for key, alg in ALGO.items():
+        if key in k:
+            e["algorithmic_kib"] = alg
+            e["traffic_over_algorithmic"] = (e["fetch_kib"] + e["write_kib"]) / alg
+    kern[k] = e
 out = {"source": sys.argv[3] if len(sys.argv) > 3 else "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes)",
-       "unit": "KiB per launch", "kernels": {k: {"fetch_kib": fetch.get(k, 0.0), "write_kib": write.get(k, 0.0)}
-                                              for k in sorted(set(fetch) | set(write)) if not k.startswith("__amd")}}
+       "unit": "KiB per launch (corrected; *_raw = the counter as reported)", "calibration": cal, "kernels": kern}
 json.dump(out, open("profiles/pmc_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -11,12 +11,28 @@ export TMPDIR=/tmp
 cd /tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline --no-also --concurrent 1"
 for w in ns c2 ns_stl ns_dense c3 c5; do
-  steps=200; [ $w = c3 ] && steps=20; [ $w = ns_stl ] && steps=100
+  steps=400; [ $w = c3 ] && steps=20; [ $w = ns_stl ] && steps=100
   rm -rf /tmp/prof_$w
   rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -o run -- $BENCH --workload $w --steps $steps --warmup 20 > /tmp/prof_$w.log 2>&1
   db=$(find /tmp/prof_$w -name '*.db' | head -1)
   { echo "# $TAG: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --concurrent 1 --workload $w --steps $steps --warmup 20"; echo;
     python $REPO/tools/rocpd_stats.py $db; } > $OUT/${TAG}_${w}_kernel_stats.md
+done
+# counter calibration on this library's access patterns (tools/ubench_fetchcal.hip), separate passes
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/cal_$c
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/cal_$c -o run -- $REPO/tools/bin/ubench_fetchcal.exe > /tmp/cal_$c.log 2>&1
+done
+( cd $REPO && python tools/pmc_calibrate.py $(find /tmp/cal_FETCH_SIZE -name '*.db' | head -1) $(find /tmp/cal_WRITE_SIZE -name '*.db' | head -1) 2147483648 \
+  "$TAG: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- tools/bin/ubench_fetchcal.exe (2 GiB per launch, separate passes)" > /dev/null; cp profiles/pmc_calibration.json $OUT/ )
+# L2-side requests of the north-star kernels (the operand re-fetch that never reaches the memory-side counters), own pass per counter
+rocprofv3 --list-avail 2>/dev/null | grep -oE "TCC_REQ_sum|TCC_READ_sum|TCC_HIT_sum|TCC_MISS_sum|TCP_TCC_READ_REQ_sum" | sort -u > /tmp/avail_l2.txt
+for c in $(cat /tmp/avail_l2.txt); do
+  rm -rf /tmp/l2_$c
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/l2_$c -o run -- python $REPO/bench.py --steps 200 --warmup 100 --no-cpu-baseline --no-also --concurrent 1 > /tmp/l2_$c.log 2>&1
+  db=$(find /tmp/l2_$c -name '*.db' | head -1)
+  [ -n "$db" ] && { echo "# $TAG: rocprofv3 --kernel-trace --pmc $c -- python bench.py --steps 200 --warmup 100 --no-cpu-baseline --no-also --concurrent 1"; echo;
+    python $REPO/tools/rocpd_pmc.py $db; } > $OUT/${TAG}_ns_pmc_${c}.md
 done
 # PMC passes (own runs, kernel-trace only), NS default bench (which also runs C2 as `also`)
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -30,6 +46,13 @@ cd $REPO
 python tools/pmc_traffic.py $(find /tmp/pmc_FETCH_SIZE -name '*.db' | head -1) $(find /tmp/pmc_WRITE_SIZE -name '*.db' | head -1) \
   "$TAG: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 200 --warmup 100 --no-cpu-baseline --concurrent 1 (two separate passes)" > /dev/null
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
+# the sharded step on one GPU (world 1, exchange forced): kernel stats of the peer-to-peer route
+rm -rf /tmp/prof_dist
+MIVI_FORCE_DIST=1 rocprofv3 --kernel-trace --stats -d /tmp/prof_dist -o run -- python $REPO/bench.py --no-cpu-baseline --steps 400 --warmup 40 > /tmp/prof_dist.log 2>&1
+db=$(find /tmp/prof_dist -name '*.db' | head -1)
+{ echo "# $TAG: MIVI_FORCE_DIST=1 rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 400 --warmup 40 (world 1, peer-to-peer exchange forced)"; echo;
+  python $REPO/tools/rocpd_stats.py $db; } > $OUT/${TAG}_dist_forced_kernel_stats.md
+MIVI_FORCE_DIST=1 python bench.py --no-cpu-baseline --steps 400 --warmup 40 2>/dev/null | tail -1 > $OUT/${TAG}_bench_dist_forced.json
 # un-profiled bench lines
 for w in ns c2 ns_dense ns_stl c3 c5; do
   python bench.py --workload $w $( [ $w = c3 ] && echo "--steps 100 --warmup 10" ) 2>/dev/null | tail -1 > $OUT/${TAG}_bench_$w.json
