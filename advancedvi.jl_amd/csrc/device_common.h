@@ -125,6 +125,10 @@ __device__ __forceinline__ void store16_wt(void *p, const V16 &v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
 }
 
+__device__ __forceinline__ void store4_wt(float *p, float v) {   // (4-byte stores are outside the store-data hazard)
+  asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
 // timeline stamps: region `kind` (0 mean-field / sample, 1 vjp, 2 dense) x 4096 blocks x 8 slots
 // Developer instrumentation exists only in -DMIVI_DEV builds (csrc/Makefile: `make DEV=1`): the per-workgroup timeline stamps
 // (mivi_debug_timeline) and the work-skipping knock-outs (MIVI_KNOCK) are compiled OUT of the release library -- no environment

@@ -7,10 +7,13 @@
 // d/32 block rows: 16 CUs busy, 95 us at d = 1024.  A triangular solve is sequential in its block rows, and a step of the
 // chain is only cheap while it stays inside one CU (LDS + s_barrier: a few hundred cycles; across CUs: a kernel boundary).  So:
 //   * the flops move out of the chain: one level of recursion,  [C11 0; C21 C22]^T [X1; X2] = [E1; E2]  =>
-//         X2 = C22^{-T} E2          (half-size solve)
-//         R1 = E1 - C21^T X2        (a plain (d/2 x d/2) x (d/2 x M) product on the whole chip: k_stl_update32)
-//         X1 = C11^{-T} R1          (half-size solve)
-//     half of the work becomes a GEMM, each solve streams a quarter of C;
+//         X2 = C22^{-T} E2                                   (half-size solve)
+//         X1 = C11^{-T} (E1 - C21^T X2) = Y1 - F^T X2,       Y1 = C11^{-T} E1,   F^T = C11^{-T} C21^T
+//     Y1 does not depend on X2 and F depends on the parameters only, so ALL THREE half-size solves -- X2 and Y1 with the M sample
+//     columns, F^T with the d/2 columns of C21^T as right-hand sides -- run side by side in ONE launch (M/16 + M/16 + d/32
+//     workgroups), followed by one plain (d/2 x d/2) x (d/2 x M) product on the whole chip (k_stl_update32).  (Round 2 ran
+//     X2, then R1 = E1 - C21^T X2, then X1 = C11^{-T} R1: two half-size solves back to back on 16 CUs, 13.5 + 4.9 + 13.5 us at
+//     d = 1024; this order is 13.5 + 4.9 us.)  Half of the work is a GEMM, each solve streams a quarter of C;
 //   * the chain itself (k_stl_solve64) runs on 64-row blocks with PRE-INVERTED diagonal blocks, 16 columns per workgroup, four
 //     waves on the dependency chain and four on the updates that are not urgent, the pivot block exchanged through LDS already
 //     split into bf16 pieces in fragment order; products on v_mfma_f32_16x16x32_bf16 with the exact three-way split
@@ -110,17 +113,21 @@ __global__ __launch_bounds__(256) void k_stl_pack(int d, const float *C, unsigne
 // k slots: MFMA m (K = 32) takes rows 32 m .. 32 m + 31 of the block; lane group g = lane / 16 supplies rows
 // {32 m + 4 g + r} and {32 m + 16 + 4 g + r}, r < 4 -- exactly the rows an accumulator lane of tiles 2 m and 2 m + 1 holds.
 // -----------------------------------------------------------------------------------------------------------------
-struct StlSolveArgs {
-  int d, n, r0;
-  const unsigned *pack;  // the packed operands of stl_dinv.h (pivot inverses, chain blocks, bulk blocks of both halves)
-  const float *rhs;      // R(i, m) = rhs[(rhs_r0 + i) + m * ld_rhs]
-  int rhs_r0, ld_rhs;
-  float *X;              // optional: X(i, m) -> X[i + m * ld_x] (rows of this system only)
-  int ld_x;
-  float *W;              // optional: W[(r0 + i) + m * ld_w] += X(i, m)
+struct StlJob {
+  int r0, nwg;           // the n x n system T = C[r0 : r0 + n, r0 : r0 + n]; workgroups of this job (16 right-hand-side columns each)
+  const float *rhs;      // R(i, m) = rhs[i * rs_i + m * ld_rhs]   (i < n: the pointer is at row 0 of this system)
+  long rs_i, ld_rhs;
+  float *X;              // optional: X(i, m) -> X[i * xs_i + m * ld_x]
+  long xs_i, ld_x;
+  float *W;              // optional: W[i + m * ld_w] += X(i, m)   (pointer at row 0 of this system)
   int ld_w;
   int w_set;             // W = X instead of W += X
-  unsigned *stamps;      // developer (MIVI_STL_STAMPS): shader-clock stamps of workgroup 0, [role 2][step 16][4]
+};
+struct StlSolveArgs {
+  int d, n, njobs;
+  const unsigned *pack;  // the packed operands of stl_dinv.h (pivot inverses, chain blocks, bulk blocks of both halves)
+  StlJob job[3];         // independent solves side by side in one launch: blockIdx.x walks job 0's workgroups, then job 1's, ...
+  unsigned *stamps;      // developer (-DMIVI_DEV, MIVI_STL_STAMPS): shader-clock stamps of workgroup 0, [role 2][step 16][4]
 };
 
 // acc(16x16) += A(16 x 32) B(32 x 16), both already split
@@ -146,27 +153,55 @@ __global__ __launch_bounds__(512) void k_stl_solve64(StlSolveArgs a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int q = w & 3;
   const int d = a.d;
-  const int col = blockIdx.x * 16 + n16;
-  const unsigned *Dp = a.pack + (size_t)(a.r0 >> 6) * STL_PLANE_BLOCK;
-  const unsigned *Cp = a.pack + (size_t)(d >> 6) * STL_PLANE_BLOCK + (a.r0 ? stl_solve_units(NB) : 0);   // crit blocks, then the bulk sequence
+  int wg = blockIdx.x, ji = 0;                            // which job this workgroup belongs to (uniform)
+  if (wg >= a.job[0].nwg) {
+    wg -= a.job[0].nwg; ji = 1;
+    if (a.njobs > 2 && wg >= a.job[1].nwg) { wg -= a.job[1].nwg; ji = 2; }
+  }
+  const StlJob &jb = a.job[ji];
+  const int r0 = jb.r0;
+  const int col = wg * 16 + n16;
+  const unsigned *Dp = a.pack + (size_t)(r0 >> 6) * STL_PLANE_BLOCK;
+  const unsigned *Cp = a.pack + (size_t)(d >> 6) * STL_PLANE_BLOCK + (r0 ? stl_solve_units(NB) : 0);   // crit blocks, then the bulk sequence
+#ifdef MIVI_DEV
   unsigned *stp = reinterpret_cast<unsigned *>(lds + STAMP_OFF);   // developer: [role 2][step 8][4]
   const bool stamping = a.stamps != nullptr && blockIdx.x == 0 && q == 0 && lane == 0;
   auto stamp = [&](int r, int J, int k) {
     if (stamping && J < 8) stp[(r * 8 + J) * 4 + k] = (unsigned)__builtin_readcyclecounter();
   };
+#else
+  constexpr bool stamping = false;
+  unsigned *stp = nullptr;
+  auto stamp = [](int, int, int) {};
+#endif
 
   if (w < 4) {
     // ------------------------------------------------ chain ------------------------------------------------
+    // Two copies of the whole chain, chosen once per workgroup: unit row stride (sample columns: one 16-byte load / store per
+    // step) and strided (the rows of C21 in, F transposed out: four scalar accesses).  A chain wave's memory instructions queue
+    // behind the bulk waves' streaming loads, so every extra one is paid in full (four scalar loads for everybody: 13.5 -> 17 us);
+    // a branch per access instead of two copies would cost the compile-time s_waitcnt counts.
+    auto chain = [&](auto trc) {
+    constexpr bool TR = decltype(trc)::value;
     __builtin_amdgcn_s_setprio(3);
     const unsigned *Dg = Dp + q * 1536 + lane * 4;               // + J * 6144 + (m * 3 + plane) * 256
     const unsigned *Cg = Cp + q * 1536 + lane * 4;
-    const float *Eg = a.rhs + (size_t)col * a.ld_rhs + a.rhs_r0 + 16 * q + 4 * g;                 // + 64 J
-    const float *Wg = a.W ? a.W + (size_t)col * a.ld_w + a.r0 + 16 * q + 4 * g : nullptr;
+    // right-hand side at the job's row stride (1 for sample columns; d for the rows of C21 that are the columns of C21^T)
+    const long rs = jb.rs_i;
+    const float *Eg = jb.rhs + (size_t)col * jb.ld_rhs + (size_t)(16 * q + 4 * g) * rs;          // + (64 J + t) rs
+    float *const Wb = jb.W;
+    const int w_set = jb.w_set, ld_w = jb.ld_w;
+    const float *Wg = Wb ? Wb + (size_t)col * ld_w + 16 * q + 4 * g : nullptr;
+    float *const Xo = jb.X;
+    const long xs = jb.xs_i, ld_x = jb.ld_x;
     f32x4 ef[NB], wf[NB];
     bf16x8 df[NB][6], cf[NB][6];
     auto request = [&](int J) {
-      ef[J] = *(const f32x4 *)(Eg + 64 * J);
-      if (Wg && !a.w_set) wf[J] = *(const f32x4 *)(Wg + 64 * J);
+      if constexpr (TR) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ef[J][t] = Eg[(size_t)(64 * J + t) * rs];
+      } else ef[J] = *(const f32x4 *)(Eg + 64 * J);
+      if (Wg && !w_set) wf[J] = *(const f32x4 *)(Wg + 64 * J);
 #pragma unroll
       for (int u = 0; u < 6; ++u) df[J][u] = *(const bf16x8 *)(Dg + (size_t)J * STL_PLANE_BLOCK + u * 256);
       if (J < NB - 1) {
@@ -231,16 +266,26 @@ __global__ __launch_bounds__(512) void k_stl_solve64(StlSolveArgs a) {
         *(u32x2v *)(Ximg + 2 * 512 + slot) = l2;
       }
       const int row = 64 * J + 16 * q + 4 * g;
-      if (a.X) store16_wt(a.X + (size_t)col * a.ld_x + row, x);   // (written through: see store16_wt)
-      if (a.W) {
-        const f32x4 wo = a.w_set ? x : wf[J] + x;
-        store16_wt(a.W + (size_t)col * a.ld_w + a.r0 + row, wo);
+      if (Xo) {                                                    // (written through: see store16_wt)
+        if constexpr (TR) {
+          float *xp = Xo + (size_t)col * ld_x + (size_t)row * xs;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) store4_wt(xp + (size_t)t * xs, x[t]);
+        } else store16_wt(Xo + (size_t)col * ld_x + row, x);
+      }
+      if (Wb) {
+        const f32x4 wo = w_set ? x : wf[J] + x;
+        store16_wt(Wb + (size_t)col * ld_w + row, wo);
       }
       stamp(0, J, 3);
       if constexpr (J > 0) lds_barrier();   // B_J
     });
+    };
+    if (jb.rs_i == 1 && jb.xs_i == 1) chain(std::false_type{});
+    else chain(std::true_type{});
     if (stamping)
       for (int i = 0; i < 32; ++i) a.stamps[i] = stp[i];
+    (void)stp;
     return;
   }
   // -------------------------------------------------- bulk --------------------------------------------------
@@ -299,17 +344,19 @@ __global__ __launch_bounds__(512) void k_stl_solve64(StlSolveArgs a) {
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// k_stl_update32: R(i, m) = E(i, m) - sum_k C[k0 + k, i0 + i] X(k, m)  for i < n_i, k < n_k (the off-diagonal block C21^T
-// applied to the half already solved).  One 32 x 32 tile per workgroup, eight waves split K into 32-k sub-stages and stage
-// their own operands through a private LDS buffer -- both operands are K-MAJOR here (a column of C, a column of X), so both
-// images are [row][32 k] with the 16-byte chunks XOR-swizzled and both fragments are b128 reads (k_fr_prod32's B side).
+// k_stl_update32: R(i, m) = E(i, m) - sum_k A(i, k) X(k, m) [+ R(i, m)]  for i < n_i, k < n_k, with A(i, k) = A[k + i * lda] -- the
+// combination X1 = Y1 - F^T X2 of the two halves (A = F as k_stl_solve64's third job stores it, E = Y1, R = the rows of W).
+// One 32 x 32 tile per workgroup, eight waves split K into 32-k sub-stages and stage their own operands through a private LDS
+// buffer -- both operands are K-MAJOR here (a column of F, a column of X), so both images are [row][32 k] with the 16-byte chunks
+// XOR-swizzled and both fragments are b128 reads (k_fr_prod32's B side).
 // -----------------------------------------------------------------------------------------------------------------
 struct StlUpdArgs {
-  int d, n_i, n_k, i0, k0;
-  const float *C;
+  int n_i, n_k;
+  const float *A; long lda;
   const float *X; int ld_x;
-  const float *E; int e_r0, ld_e;
+  const float *E; int ld_e;
   float *R; int ld_r;      // R[i + m * ld_r]
+  int accumulate;          // R += (E - A X) instead of R = E - A X
   int ncb;
 };
 
@@ -331,7 +378,7 @@ __global__ __launch_bounds__(512) void k_stl_update32(StlUpdArgs a) {
   for (int p = 0; p < 4; ++p) {
     const int n = 8 * p + (lane >> 3);
     const int ch = 4 * ((lane & 7) ^ ((n >> 1) & 7));
-    Ag[p] = a.C + (size_t)(a.i0 + row0 + n) * a.d + a.k0 + ch;
+    Ag[p] = a.A + (size_t)(row0 + n) * a.lda + ch;
     Bg[p] = a.X + (size_t)(col0 + n) * a.ld_x + ch;
   }
   f32x16 acc;
@@ -378,9 +425,11 @@ __global__ __launch_bounds__(512) void k_stl_update32(StlUpdArgs a) {
     f32x4 v = *(const f32x4 *)(Cs + en * LDC + ei4);
 #pragma unroll
     for (int k2 = 1; k2 < NW; ++k2) v += *(const f32x4 *)(Cs + (k2 * 32 + en) * LDC + ei4);
-    const f32x4 e = *(const f32x4 *)(a.E + (size_t)(col0 + en) * a.ld_e + a.e_r0 + row0 + ei4);
-    const f32x4 ro = e - v;
-    store16_wt(a.R + (size_t)(col0 + en) * a.ld_r + row0 + ei4, ro);
+    const f32x4 e = *(const f32x4 *)(a.E + (size_t)(col0 + en) * a.ld_e + row0 + ei4);
+    float *rp = a.R + (size_t)(col0 + en) * a.ld_r + row0 + ei4;
+    f32x4 ro = e - v;
+    if (a.accumulate) ro += *(const f32x4 *)rp;
+    store16_wt(rp, ro);
   }
 }
 
@@ -392,58 +441,68 @@ bool stl2_shape_ok(const mivi_ctx *c, int M) {
          M % 32 == 0 && M > 0;
 }
 
-static void launch_solve(mivi_ctx *c, const StlSolveArgs &a, int M) {
+static void launch_solve(mivi_ctx *c, const StlSolveArgs &a) {
   const int nb = a.n / 64;
-  const dim3 grid(M / 16), block(512);
+  int nwg = 0;
+  for (int j = 0; j < a.njobs; ++j) nwg += a.job[j].nwg;
+  const dim3 grid(nwg), block(512);
   if (nb == 2) hipLaunchKernelGGL(k_stl_solve64<2>, grid, block, 0, c->stream, a);
   else if (nb == 4) hipLaunchKernelGGL(k_stl_solve64<4>, grid, block, 0, c->stream, a);
   else if (nb == 8) hipLaunchKernelGGL(k_stl_solve64<8>, grid, block, 0, c->stream, a);
   else hipLaunchKernelGGL(k_stl_solve64<16>, grid, block, 0, c->stream, a);
 }
 
-// W += C^{-T} eps for the current estimate (W: d x M, ld d; eps: ld dP).  Needs c->stl_Dinv (d/64 * 4096 floats) and
-// c->stl_X (d x M floats: X of the lower half, then the updated right-hand side of the upper half).
+// W += C^{-T} eps for the current estimate (W: d x M, ld d; eps: ld dP).  Needs c->stl_F (the packed operands) and c->stl_X
+// ((d M + d^2/4) floats: X2, then Y1, then F).
 void launch_stl2(mivi_ctx *c, const void *params, int M, bool dinv_done, const void *rhs, void *out, bool overwrite) {
   const int d = c->cfg.d, n = d / 2;
   const float *C = (const float *)params + d;
   unsigned *pack = (unsigned *)c->stl_F.p;
-  float *Xb = (float *)c->stl_X.p, *Rt = Xb + (size_t)n * M;
+  float *Xb = (float *)c->stl_X.p, *Y1 = Xb + (size_t)n * M, *F = Y1 + (size_t)n * M;
   const float *eps = rhs ? (const float *)rhs : (const float *)c->eps[c->cur].p;   // right-hand sides, ld dP
   float *Wout = out ? (float *)out : (float *)c->W.p;                               // X is ADDED here, ld d
   if (!dinv_done) hipLaunchKernelGGL(k_stl_pack, dim3(d / 64 + stl_pack_riders(d)), dim3(256), 0, c->stream, d, C, pack);
   StlSolveArgs s{};
-  s.d = d; s.n = n; s.pack = pack; s.w_set = overwrite ? 1 : 0;
+  s.d = d; s.n = n; s.pack = pack; s.njobs = 3;
+  // job 0 -- lower half: C22^T X2 = E2, X2 also straight into the rows n .. d of W
+  StlJob &j0 = s.job[0];
+  j0.r0 = n; j0.nwg = M / 16; j0.rhs = eps + n; j0.rs_i = 1; j0.ld_rhs = c->dP; j0.X = Xb; j0.xs_i = 1; j0.ld_x = n;
+  j0.W = Wout + n; j0.ld_w = d; j0.w_set = overwrite ? 1 : 0;
+  // job 1 -- upper half without the coupling: C11^T Y1 = E1
+  StlJob &j1 = s.job[1];
+  j1.r0 = 0; j1.nwg = M / 16; j1.rhs = eps; j1.rs_i = 1; j1.ld_rhs = c->dP; j1.X = Y1; j1.xs_i = 1; j1.ld_x = n;
+  // job 2 -- the coupling, parameters only: C11^T F^T = C21^T.  Column m of C21^T is row n + m of C (stride d along it); the
+  // solution is stored transposed, F[k + i n] = F^T(i, k): k-major rows, the layout k_stl_update32 stages
+  StlJob &j2 = s.job[2];
+  j2.r0 = 0; j2.nwg = n / 16; j2.rhs = C + n; j2.rs_i = d; j2.ld_rhs = 1; j2.X = F; j2.xs_i = n; j2.ld_x = 1;
+#ifdef MIVI_DEV
   static const bool stamps = getenv("MIVI_STL_STAMPS") != nullptr;
   if (stamps) s.stamps = (unsigned *)((char *)c->stl_X.p + c->stl_X.bytes - 4096);
-  // lower half: C22^T X2 = E2
-  s.r0 = n; s.rhs = eps; s.rhs_r0 = n; s.ld_rhs = c->dP; s.X = Xb; s.ld_x = n; s.W = Wout; s.ld_w = d;
-  launch_solve(c, s, M);
-  // R1 = E1 - C21^T X2
+#endif
+  launch_solve(c, s);
+  // rows 0 .. n of W:  X1 = Y1 - F^T X2
   StlUpdArgs u{};
-  u.d = d; u.n_i = n; u.n_k = n; u.i0 = 0; u.k0 = n; u.C = C; u.X = Xb; u.ld_x = n; u.E = eps; u.e_r0 = 0; u.ld_e = c->dP;
-  u.R = Rt; u.ld_r = n; u.ncb = M / 32;
+  u.n_i = n; u.n_k = n; u.A = F; u.lda = n; u.X = Xb; u.ld_x = n; u.E = Y1; u.ld_e = n;
+  u.R = Wout; u.ld_r = d; u.accumulate = overwrite ? 0 : 1; u.ncb = M / 32;
   hipLaunchKernelGGL(k_stl_update32, dim3((n / 32) * (M / 32)), dim3(512), 0, c->stream, u);
-  // upper half: C11^T X1 = R1
-  s.r0 = 0; s.rhs = Rt; s.rhs_r0 = 0; s.ld_rhs = n; s.X = nullptr; s.ld_x = 0;
-  if (stamps) s.stamps += 64;
-  launch_solve(c, s, M);
+#ifdef MIVI_DEV
   if (stamps) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(c->stream, &cs);
     if (cs == hipStreamCaptureStatusNone) {
-      unsigned h[128];
+      unsigned h[64];
       (void)hipStreamSynchronize(c->stream);
-      (void)hipMemcpy(h, s.stamps - 64, sizeof h, hipMemcpyDeviceToHost);
-      for (int k = 0; k < 2; ++k)
-        for (int role = 0; role < 2; ++role) {
-          fprintf(stderr, "[stl stamps] solve %d %s:", k, role ? "bulk " : "chain");
-          const unsigned t0 = h[k * 64 + (0 * 8 + 7) * 4];
-          for (int J = 7; J >= 0; --J)
-            for (int i = 0; i < 4; ++i) fprintf(stderr, "%s%u", i ? " " : " | ", h[k * 64 + (role * 8 + J) * 4 + i] - t0);
-          fprintf(stderr, "\n");
-        }
+      (void)hipMemcpy(h, s.stamps, sizeof h, hipMemcpyDeviceToHost);
+      for (int role = 0; role < 2; ++role) {
+        fprintf(stderr, "[stl stamps] job 0 %s:", role ? "bulk " : "chain");
+        const unsigned t0 = h[(0 * 8 + 7) * 4];
+        for (int J = 7; J >= 0; --J)
+          for (int i = 0; i < 4; ++i) fprintf(stderr, "%s%u", i ? " " : " | ", h[(role * 8 + J) * 4 + i] - t0);
+        fprintf(stderr, "\n");
+      }
     }
   }
+#endif
 }
 
 }  // namespace mivi

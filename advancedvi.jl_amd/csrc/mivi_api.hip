@@ -89,7 +89,7 @@ static mivi_status_t ensure_work(mivi_ctx *c, int M) {
     if (c->cfg.family == MIVI_FULLRANK && (c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD)) {
       if ((s = ensure(c, c->stl_CT, (size_t)c->dP * c->dP * es, true))) return s;
       if ((s = ensure(c, c->stl_Dinv, (size_t)((d + 63) / 64) * 4096 * es, false))) return s;   // 32x32 or 64x64 diagonal inverses
-      if ((s = ensure(c, c->stl_X, (size_t)d * capM * es + 4096, false))) return s;
+      if ((s = ensure(c, c->stl_X, ((size_t)d * capM + (size_t)(d / 2) * (d / 2)) * es + 4096, false))) return s;   // X2, Y1, F (kernels_stl.hip)
       if (d % 128 == 0 && (s = ensure(c, c->stl_F, mivi::stl_pack_units(d) * 4, false))) return s;   // + developer stamp page (MIVI_STL_STAMPS)
     }
     if ((s = ensure(c, c->Z, (size_t)d * capM * es, false))) return s;
@@ -1385,7 +1385,7 @@ mivi_status_t mivi_gauss_expected_grad_hess(mivi_ctx_t *c, const void *params, u
       (s = ensure(c, c->stl_CT, (size_t)dP * dP * es, true)) || (s = ensure(c, c->stl_Dinv, (size_t)((d + 31) / 32) * 1024 * es, false)))
     return s;
   const bool stl2 = stl2_shape_ok(c, d);   // second-generation solve with the d columns of the product as right-hand sides
-  if (stl2 && ((s = ensure(c, c->stl_X, (size_t)d * d * es + 4096, false)) || (s = ensure(c, c->stl_F, mivi::stl_pack_units(d) * 4, false)))) return s;
+  if (stl2 && ((s = ensure(c, c->stl_X, ((size_t)d * d + (size_t)(d / 2) * (d / 2)) * es + 4096, false)) || (s = ensure(c, c->stl_F, mivi::stl_pack_units(d) * 4, false)))) return s;
   const int CH = 16384;
   const bool single_chunk = n_samples <= CH;
   bool pack_done = false, tail_done = false;

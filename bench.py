@@ -170,9 +170,10 @@ def stl_block(cx, p, w, reps=100):
         return None
     fl = float(w["d"]) ** 2 * w["n_mc"]
     sv, up = pmc_traffic("k_stl_solve64"), pmc_traffic("k_stl_update32")
-    return dict(kernel="k_stl_solve64 x2 + k_stl_update32", avg_us=ms * 1e3, achieved_TFLOPs=fl / (ms * 1e-3) / 1e12,
-                frac_of_f32_mfma_peak=fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF,
-                bound="dependency chain: 2 x d/128 block steps on 16-column workgroups (M / 16 CUs busy), each pulling its triangle through one CU",
+    return dict(kernel="k_stl_solve64 (three half-size solves side by side: X2, Y1, F) + k_stl_update32 (X1 = Y1 - F^T X2)", avg_us=ms * 1e3,
+                achieved_TFLOPs=fl / (ms * 1e-3) / 1e12, frac_of_f32_mfma_peak=fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF,
+                algorithmic_flops=fl, executed_flops=2.0 * fl,   # the parameter-only coupling solve has d/2 right-hand sides of its own
+                bound="dependency chain: d/128 block steps per 16-column workgroup (2 M/16 + d/32 CUs busy), each pulling its half-triangle through one CU",
                 traffic=(dict(solve=sv, update=up) if sv and up else None))
 
 
