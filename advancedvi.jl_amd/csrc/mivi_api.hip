@@ -1614,8 +1614,9 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
   if (!c->is_child && c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && !c->bij_on && !c->idx_src && !c->dbg &&
       (c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS) && lds_path_shape_ok(c, c->cfg.n_mc) &&
       (long long)c->cfg.d * c->cfg.n_mc <= 2048LL * 512)
-    lanes = count < 50 ? 3 : 2;   // (measured at the north star: 20-estimate calls 14.35 / 13.5 / 12.6 us per estimate with 1 / 2 / 3 chains, 100-estimate calls 13.4 / 9.8 / 10.1)
-  if (chain_lanes() > 0) lanes = c->is_child ? 1 : (chain_lanes() > 4 ? 4 : chain_lanes());
+    lanes = count < 50 ? 4 : 2;   // (measured at the north star, us per estimate with 1 / 2 / 3 / 4 chains: isolated 20-estimate calls 14.4 / 14.2 / 12.9 / 12.2,
+                                  //  100-estimate calls back to back 13.4 / 9.8 / 10.2 / 9.7)
+  if (chain_lanes() > 0) lanes = c->is_child ? 1 : (chain_lanes() > mivi_ctx::kMaxKids + 1 ? mivi_ctx::kMaxKids + 1 : chain_lanes());
   while (lanes > 1 && count < 4 * lanes) --lanes;   // (short batches: not worth the fork / join)
   if (lanes <= 1) {
     if (!c->is_child && c->idx_stride != 1) { invalidate_graph(c); c->idx_stride = 1; }

@@ -311,11 +311,13 @@ struct mivi_ctx {
   // whose kernels overlap on the device (the product of one chain's estimate runs beside the VJP of another's).
   int idx_stride = 1;            // estimate-index step between consecutive estimates of THIS context's chain
   bool is_child = false;         // target buffers are borrowed from the parent
-  mivi_ctx *kids[3] = {nullptr, nullptr, nullptr};
+  static constexpr int kMaxKids = 3;   // at most four chains: a forked graph with five branches crashed inside hipGraphLaunch (hip::Graph::UpdateStreams) after a
+                                       // re-capture on ROCm 7.0's runtime; four is also the number of hardware queues HIP spreads streams over
+  mivi_ctx *kids[kMaxKids] = {};
   int n_kids = 0;
   unsigned long long target_gen = 0, kid_gen = ~0ull;   // parent: bumped whenever a captured graph is invalidated; child: the generation it mirrors
-  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-  mivi::DevBuf kid_out[3];       // value (16 bytes) + gradient of the child chains that do not hold the batch's last estimate
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxKids] = {};
+  mivi::DevBuf kid_out[kMaxKids];       // value (16 bytes) + gradient of the child chains that do not hold the batch's last estimate
 };
 
 namespace mivi {
