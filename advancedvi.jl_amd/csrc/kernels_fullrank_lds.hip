@@ -603,7 +603,11 @@ struct Prod32Args {
 template <int MODE, bool BF3>
 __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
   constexpr int NW = 8, NT = 512, SUB = 32, LDC = 36;
-  constexpr int WAVE_F = 2 * 2 * SUB * 32;   // two sub-stage buffers per wave: {As[32 k][32], Bs[32 cols][32 k]} x 2
+  // ONE sub-stage buffer per wave (64 KiB per workgroup): with two (128 KiB, the wave's next sub-stage in flight under its MFMAs) a product
+  // workgroup owned its CU; with one, two of them -- or one and a VJP workgroup of another chain -- share it, and the other seven waves cover a
+  // wave's load latency anyway: alone 7.2 -> 6.85 us, isolated 20-estimate batches 13.2 -> 12.4 (-> 10.8 with four chains), steady 9.9 -> 8.1 us
+  constexpr int RING = 1;
+  constexpr int WAVE_F = RING * 2 * SUB * 32;   // RING sub-stage buffers per wave: {As[32 k][32], Bs[32 cols][32 k]} x RING
   constexpr int EPI = NW * 32 * LDC;
   constexpr int MAIN = (NW * WAVE_F > EPI) ? NW * WAVE_F : EPI;
   __shared__ __attribute__((aligned(16))) float lds[MAIN + 2 * NW];
@@ -716,11 +720,11 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
   const int b_swz = h ^ ((l31 >> 1) & 7);
   __builtin_amdgcn_s_setprio(3);
   if (t_beg < t_end) issue(t_beg, 0);
-  if (t_beg + 1 < t_end) issue(t_beg + 1, 1);
+  if (RING == 2 && t_beg + 1 < t_end) issue(t_beg + 1, 1);
   __builtin_amdgcn_s_setprio(0);
   for (int t = t_beg; t < t_end; ++t) {
-    const int slot = (t - t_beg) & 1;
-    if (t + 1 < t_end) wait_vmcnt<8>();   // the sub-stage behind this one (8 pieces) may stay in flight
+    const int slot = RING == 2 ? (t - t_beg) & 1 : 0;
+    if (RING == 2 && t + 1 < t_end) wait_vmcnt<8>();   // the sub-stage behind this one (8 pieces) may stay in flight
     else wait_vmcnt<0>();
     const float *cur = buf + slot * (2 * SUB * 32);
     float av[16];
@@ -733,7 +737,7 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this buffer is free again before it is requested anew
     if (t == t_beg) MIVI_STAMP_K(a.dbg, MODE, 1);
-    if (t + 2 < t_end) issue(t + 2, slot);
+    if (t + RING < t_end) issue(t + RING, slot);
     if (MODE == G_SAMPLE && t == rb) {   // the diagonal block of tril(C): keep k <= i
 #pragma unroll
       for (int i = 0; i < 16; ++i)

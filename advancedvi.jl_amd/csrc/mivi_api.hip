@@ -163,7 +163,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
     if (c->kid_out[j].p) (void)hipFree(c->kid_out[j].p);
   }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->is_child) c->t_mean = c->t_istd = c->t_prec = mivi::DevBuf{};   // borrowed from the parent
+  if (c->is_child) c->t_mean = c->t_istd = c->t_prec = c->status = mivi::DevBuf{};   // borrowed from the parent
   (void)mivi_comm_destroy(c);
   if (c->graph.exec) (void)hipGraphExecDestroy(c->graph.exec);
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
@@ -816,18 +816,15 @@ mivi_status_t mivi_estimate_gradient(mivi_ctx_t *c, const void *params, uint64_t
 }
 
 static mivi_status_t read_status(mivi_ctx *c) {
-  int st = 0;
-  HIPCHK(c, hipMemcpyAsync(&st, c->status.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  // this context's sticky flags (word 0) and, with interleaved chains, the children's (words 1 .. n_kids of the same buffer: their kernels are
+  // joined into this stream by the batch's graph) -- one copy, one wait
+  int sk[1 + mivi_ctx::kMaxKids] = {};
+  const int nw = 1 + c->n_kids;
+  HIPCHK(c, hipMemcpyAsync(sk, c->status.p, sizeof(int) * nw, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (st) HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream));
-  for (int j = 0; j < c->n_kids; ++j) {   // interleaved chains: the children's sticky flags
-    int sk = 0;
-    mivi_ctx *k = c->kids[j];
-    HIPCHK(c, hipMemcpyAsync(&sk, k->status.p, sizeof(int), hipMemcpyDeviceToHost, k->stream));
-    HIPCHK(c, hipStreamSynchronize(k->stream));
-    if (sk) HIPCHK(c, hipMemsetAsync(k->status.p, 0, sizeof(int), k->stream));
-    st |= sk;
-  }
+  int st = 0;
+  for (int j = 0; j < nw; ++j) st |= sk[j];
+  if (st) HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * nw, c->stream));
   if (st & 8) return fail(c, MIVI_ERR_HIP, "peer-to-peer exchange: a peer did not arrive within the spin budget (lost rank or unmapped buffer)");
   if (st & 2) return fail(c, MIVI_ERR_NONPOSITIVE_SCALE, "scale diagonal is not positive (use ClipScale)");
   if (st & 1) return fail(c, MIVI_ERR_NONFINITE, "the objective value is not finite: the optimization run diverged");
@@ -1614,8 +1611,9 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
   if (!c->is_child && c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && !c->bij_on && !c->idx_src && !c->dbg &&
       (c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS) && lds_path_shape_ok(c, c->cfg.n_mc) &&
       (long long)c->cfg.d * c->cfg.n_mc <= 2048LL * 512)
-    lanes = count < 50 ? 4 : 2;   // (measured at the north star, us per estimate with 1 / 2 / 3 / 4 chains: isolated 20-estimate calls 14.4 / 14.2 / 12.9 / 12.2,
-                                  //  100-estimate calls back to back 13.4 / 9.8 / 10.2 / 9.7)
+    lanes = 4;   // (measured at the north star, us per estimate with 1 / 2 / 3 / 4 chains: isolated 20-estimate calls 14.4 / 13.9 / 13.3 / 10.8,
+                 //  100-estimate calls back to back 13.4 / 9.7 / 8.9 / 8.1 -- the product kernel's 64 KiB of LDS lets two of them, or one and
+                 //  a VJP workgroup, share a CU)
   if (chain_lanes() > 0) lanes = c->is_child ? 1 : (chain_lanes() > mivi_ctx::kMaxKids + 1 ? mivi_ctx::kMaxKids + 1 : chain_lanes());
   while (lanes > 1 && count < 4 * lanes) --lanes;   // (short batches: not worth the fork / join)
   if (lanes <= 1) {
@@ -1631,6 +1629,8 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
     if ((s = mivi_create(&cfg, &k))) return fail(c, s, "interleaved chains: child context creation failed");
     k->is_child = true;
     const int j = c->n_kids;
+    (void)hipFree(k->status.p);                                    // the child's sticky flags: word j + 1 of the parent's status buffer
+    k->status.p = (char *)c->status.p + sizeof(int) * (j + 1);    // (borrowed: is_child contexts never free it)
     if ((s = ensure(c, c->kid_out[j], 16 + (size_t)mivi_params_len(c) * c->esize, false))) { (void)mivi_destroy(k); return s; }
     HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[j], hipEventDisableTiming));
     if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));

@@ -534,16 +534,18 @@ def main():
         if single and W < chunk:   # make sure the hipGraph is captured + instantiated outside the timed region
             run(W, chunk)
         stream.synchronize()
-        # pre-heat (untimed, NOT counted in `steps` / `warmup`): the same batched calls for >= 50 ms, so that the timed region -- 0.3 ms
-        # for the driver's --steps 20 -- does not sit on the clock ramp of a GPU that was idle a moment ago (measured: 15.0-15.7 us per
-        # estimate in the first milliseconds of a process, 14.4 after)
+        # pre-heat (untimed, NOT counted in `steps` / `warmup`): the same batched calls back to back for >= 300 ms, so that the timed region
+        # -- 0.2 ms for the driver's --steps 20 -- does not sit on the clock ramp of a GPU that was idle a moment ago (measured in one
+        # process, same call: 16-24 us per estimate in its first tens of milliseconds of GPU work, 11-13 us after a few hundred)
         t_heat, heat_calls = time.perf_counter(), 0
         idx_t = W + chunk          # the estimate index walks on, so the timed call continues the device-side counter (no counter-setting launch)
-        while time.perf_counter() - t_heat < 0.05 or heat_calls < 3:
+        while time.perf_counter() - t_heat < 0.3 or heat_calls < 3:
             run(idx_t, max(chunk, 1))
             idx_t += max(chunk, 1)
-            stream.synchronize()
             heat_calls += 1
+            if heat_calls % 8 == 0:
+                stream.synchronize()
+        stream.synchronize()
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -771,7 +773,7 @@ def main():
                            "fullrank_route": (list(ctx.fullrank_route()) if w["family"] == 1 else None)},
                 "roofline": roof, "cpu_baseline": cpub,
                 "repeat_ms_per_step": repeats, "elbo_rel_err_vs_cpu_fp64": rel, "parity_vs_fp64_oracle": parity_head, "stage_us": stages,
-                "preheat": dict(calls=heat_calls, note="untimed batched calls for >= 50 ms before the timed region (GPU clock ramp); not counted in steps / warmup"), "whole_estimate": whole, "steady_state": steady, "concurrent": conc, "also": also,
+                "preheat": dict(calls=heat_calls, note="untimed batched calls for >= 300 ms before the timed region (GPU clock ramp); not counted in steps / warmup"), "whole_estimate": whole, "steady_state": steady, "concurrent": conc, "also": also,
                 "dist": (None if single else dist_info),
             }
         if dist:
