@@ -57,4 +57,6 @@ MIVI_FORCE_DIST=1 python bench.py --no-cpu-baseline --steps 400 --warmup 40 2>/d
 for w in ns c2 ns_dense ns_stl c3 c5; do
   python bench.py --workload $w $( [ $w = c3 ] && echo "--steps 100 --warmup 10" ) 2>/dev/null | tail -1 > $OUT/${TAG}_bench_$w.json
 done
+# the driver's own command (its BENCH_rNN.json protocol), un-profiled
+python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${TAG}_bench_driver_protocol.json
 ls -la $OUT
