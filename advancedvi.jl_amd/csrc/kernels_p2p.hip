@@ -14,11 +14,13 @@
 // Every slice is finalised by exactly one rank from contributions summed in rank order: all ranks hold bit-identical results and the
 // sum is independent of arrival order.
 //
-// Synchronisation is in the DATA ("LL" layout, as RCCL's low-latency protocol): every 32-bit payload word travels as an 8-byte pair
-// (word, epoch) written by ONE store, so a reader that finds the epoch of this exchange in a pair has the word -- no separate flag,
-// no store acknowledge to wait for, no flag poll: a phase costs one (repeated until complete) load round trip instead of
-// {store acknowledge, flag round trip, data round trip} (measured on one GPU, DESIGN.md 7: the flag version of this kernel 29-40 us per exchange, this one 33 us).  Twice the
-// bytes; the exchange is latency bound (2 MB).
+// Hand-over: payload words travel as they are (4 / 8 bytes each, 16-byte write-through system-scope stores); a workgroup that has
+// pushed its chunk waits for its own stores to be acknowledged (s_waitcnt vmcnt(0)) and then stores ONE flag per destination carrying
+// the exchange's epoch number, (source rank, chunk) -> arr, (owner rank, chunk) -> farr; the consumer polls the R flags it needs and reads
+// the payload with system-scope loads.  Twice per exchange {store acknowledge, flag round trip, data round trip}.  (An "LL" variant --
+// every 32-bit word as an 8-byte (word, epoch) pair, no flags -- saves the acknowledge + flag round trips but doubles the bytes: on one
+// GPU 33-46 us per exchange against 29-40 us, and in the pipelined batches, where the lanes hide latency and the system-scope path's
+// bytes per second are what is left, 32 us per estimate against the figure in DESIGN.md 7; over xGMI the bytes are the bound outright.)
 //
 // Slices are cut into G chunks; workgroup g of every rank handles chunk g of every slice in all three phases, so workgroup g only
 // ever depends on workgroup g of its peers: no grid-wide barrier, no dependency cycle (phase 1 never waits), and the areas can be
@@ -43,8 +45,10 @@ namespace mivi {
 constexpr int kP2PLanes = 2, kP2PRing = 4;
 
 struct P2PTable {   // device resident: where every rank's exchange areas are mapped in THIS process, per lane
-  unsigned long long *stage[kP2PLanes][8];   // [2][R][n W] pairs: stage[s] = rank s's staging area (contribution of rank `src` to slice s at [parity][src])
-  unsigned long long *fin[kP2PLanes][8];     // [2][R n W] pairs : rank s's packed final vector
+  char *stage[kP2PLanes][8];      // [2][R][n] T : stage[s] = rank s's staging area (contribution of rank `src` to slice s at [parity][src])
+  char *fin[kP2PLanes][8];        // [2][R n] T  : rank s's packed final vector
+  unsigned *arr[kP2PLanes][8];    // [2][R][G]   : arrival flags (source rank, chunk) in rank s's memory
+  unsigned *farr[kP2PLanes][8];   // [2][R][G+1] : final-chunk flags (owner rank, chunk) in rank s's memory; [vs][G] = the two scalars
 };
 
 template <typename T>
@@ -68,13 +72,9 @@ struct P2PArgs {
 };
 
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void store16_sys(void *p, u32x4_t r) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(r) : "memory");
-}
-__device__ __forceinline__ void store8_sys(void *p, u32x2_t r) {
-  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(r) : "memory");
 }
 // eight independent 16-byte system-scope loads in flight, ONE wait (such a load is a full memory round trip: issued one per loop
 // iteration the exchange was a chain of ~1.5 us latencies)
@@ -93,160 +93,134 @@ __device__ __forceinline__ void ld16x8_sys(const void *const (&p)[8], u32x4_t (&
       : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7])
       : "memory");
 }
-__device__ __forceinline__ unsigned long long ld8_sys(const unsigned long long *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// Eight LL units (16 bytes = two (word, epoch) pairs each) until every pair the caller needs carries `epoch`.  need[u]: bit 0 / 1 =
-// the first / second pair of unit u matters (0: the slot is padding).  Bounded: false = a word never arrived.
-__device__ __forceinline__ bool ll_load8(const void *const (&p)[8], const unsigned (&need)[8], unsigned epoch, int budget, u32x4_t (&o)[8]) {
-  for (;;) {
-    ld16x8_sys(p, o);
-    bool ok = true;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if ((need[u] & 1u) && o[u][1] != epoch) ok = false;
-      if ((need[u] & 2u) && o[u][3] != epoch) ok = false;
-    }
-    if (ok) return true;
-    if (--budget <= 0) return false;
-    __builtin_amdgcn_s_sleep(2);
-  }
-}
-// one LL pair (bounded)
-__device__ __forceinline__ bool ll_load1(const unsigned long long *p, unsigned epoch, int budget, unsigned &word) {
-  for (;;) {
-    const unsigned long long v = ld8_sys(p);
-    if ((unsigned)(v >> 32) == epoch) { word = (unsigned)v; return true; }
-    if (--budget <= 0) { word = 0; return false; }
-    __builtin_amdgcn_s_sleep(2);
-  }
-}
-
-template <typename T> struct Words;
-template <> struct Words<float> {
-  static constexpr int W = 1;
-  static __device__ __forceinline__ float make(unsigned w0, unsigned) { return __builtin_bit_cast(float, w0); }
-  static __device__ __forceinline__ void split(float x, unsigned &w0, unsigned &w1) { w0 = __builtin_bit_cast(unsigned, x); w1 = 0u; }
-};
-template <> struct Words<double> {
-  static constexpr int W = 2;
-  static __device__ __forceinline__ double make(unsigned w0, unsigned w1) {
-    return __builtin_bit_cast(double, (unsigned long long)w0 | ((unsigned long long)w1 << 32));
-  }
-  static __device__ __forceinline__ void split(double x, unsigned &w0, unsigned &w1) {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, x);
-    w0 = (unsigned)b;
-    w1 = (unsigned)(b >> 32);
-  }
-};
-
-// packed index (>= d, full-rank) -> (column j, row i) of the lower triangle: e2 = j d - j (j - 1) / 2 + (i - j)
-__device__ __forceinline__ void packed_col_row(long long gi, int d, long long &j, long long &i) {
-  const long long e2 = gi - d;
-  const double b = 2.0 * d + 1.0;
-  j = (long long)((b - sqrt(b * b - 8.0 * (double)e2)) * 0.5);
-  if (j < 0) j = 0;
-  if (j > d - 1) j = d - 1;
-  while (j > 0 && j * d - (j * (j - 1)) / 2 > e2) --j;
-  while (j + 1 < d && (j + 1) * d - ((j + 1) * j) / 2 <= e2) ++j;
-  i = j + (e2 - (j * d - (j * (j - 1)) / 2));
-}
-
-// packed final entry -> its finalised value: -(1/M) sum, the diagonal entries of the scale carry the entropy term
 template <typename T>
-__device__ __forceinline__ double p2p_finalise(const P2PArgs<T> &a, long long gi, double sum, double invM, double direct) {
+__device__ __forceinline__ T ld_sys(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+template <typename T>
+__device__ __forceinline__ void st_sys(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// A flag is stored after this workgroup's payload stores have been ACKNOWLEDGED (the caller's s_waitcnt vmcnt(0) + barrier): they are
+// write-through system-scope stores, so nothing of them sits in a cache that a release fence would have to write back -- and no
+// cache-wide fence is issued (the compute kernels running beside the exchange keep their L2-resident operands).
+__device__ __forceinline__ void flag_store(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// thread k < count polls flags[stride * k] until it carries `want` (bounded); result uniform over the workgroup.  The payload behind a
+// flag is read with system-scope loads issued after the flag has been seen (in-order issue + the barrier below).
+template <int NT>
+__device__ __forceinline__ bool wait_flags(const unsigned *flags, int count, int stride, unsigned want, int budget, int *sh_ok) {
+  if (threadIdx.x == 0) *sh_ok = 1;
+  __syncthreads();
+  for (int k = threadIdx.x; k < count; k += NT) {
+    int b = budget;
+    while (ld_sys(flags + (size_t)k * stride) != want) {
+      if (--b <= 0) { atomicAnd(sh_ok, 0); break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  const bool ok = *sh_ok != 0;
+  __syncthreads();
+  return ok;
+}
+
+// packed index (>= d, full-rank) -> (column j, row i) of the lower triangle: e2 = j d - j (j - 1) / 2 + (i - j).  An f32 estimate of the
+// column, made exact by the two integer loops (a few f64 instructions per ELEMENT -- sqrt, the loops' multiplies -- were 20 us of a 50 us
+// exchange: reduce 25.8 -> and unpack 27.5 -> us; callers now resolve one index per 16-byte vector and walk from there).
+__device__ __forceinline__ void packed_col_row(long long gi, int d, long long &j, long long &i) {
+  const int e2 = (int)(gi - d);   // (< d (d + 1) / 2 < 2^31: 32-bit arithmetic -- 64-bit integer multiplies / divides are multi-instruction sequences here)
+  const float b = 2.f * (float)d + 1.f;
+  const float rad = b * b - 8.f * (float)e2;
+  int jj = (int)((b - sqrtf(rad > 0.f ? rad : 0.f)) * 0.5f);
+  if (jj < 0) jj = 0;
+  if (jj > d - 1) jj = d - 1;
+  while (jj > 0 && jj * d - (jj * (jj - 1)) / 2 > e2) --jj;
+  while (jj + 1 < d && (jj + 1) * d - ((jj + 1) * jj) / 2 <= e2) ++jj;
+  j = jj;
+  i = jj + (e2 - (jj * d - (jj * (jj - 1)) / 2));
+}
+// the packed entry after (j, i) (column major, lower triangle)
+__device__ __forceinline__ void packed_next(int d, long long &j, long long &i) {
+  if (++i == d) { ++j; i = j; }
+}
+
+// packed final entry -> its finalised value: -(1/M) sum, the diagonal entries of the scale carry the entropy term.
+// (j, i): the entry's place in the triangle (full-rank, gi >= d; unused otherwise)
+template <typename T>
+__device__ __forceinline__ double p2p_finalise(const P2PArgs<T> &a, long long gi, long long j, long long i, double sum, double invM, double direct) {
   const int d = a.d;
   double v = -sum * invM;
   if (gi < d) return v;
   if (a.family == MIVI_MEANFIELD) return v - direct / (double)a.params[gi];
-  long long j, i;
-  packed_col_row(gi, d, j, i);
   if (i == j) v -= direct / (double)a.params[d + (size_t)j * d + j];
   return v;
 }
 
-// phase 2 for R <= K sources (K in {1, 2, 4, 8}): 8 / K units of this thread x K sources per batch of eight loads.
-// A unit = 16 bytes = two payload words = EPU elements (float: 2, double: 1).
+// phase 2 for R <= K sources (K in {1, 2, 4, 8}): 8 / K vectors of this thread x K sources per batch of eight loads.
+// A vector = 16 bytes = V elements (float: 4, double: 2).  The caller has waited for the R arrival flags of this chunk.
 template <typename T, int K, int NT>
-__device__ __forceinline__ bool p2p_reduce_chunk(const P2PArgs<T> &a, const P2PTable &tb, int p, unsigned epoch, long long c0, long long clen) {
-  constexpr int W = Words<T>::W, EPU = 2 / W, NV = 8 / K;
+__device__ __forceinline__ void p2p_reduce_chunk(const P2PArgs<T> &a, const P2PTable &tb, int p, long long c0, long long clen) {
+  constexpr int V = 16 / (int)sizeof(T), NV = 8 / K;
   const int tid = threadIdx.x, R = a.world;
   const long long n = a.n, tri_end = a.L - 2;
   const double invM = 1.0 / (double)a.M_total, direct = direct_entropy_coeff(a.ent_kind);
-  const unsigned long long *st = tb.stage[a.lane][a.rank] + ((size_t)(p * R) * n + c0) * W;   // + src * n * W + 2 * unit
+  const T *st = (const T *)tb.stage[a.lane][a.rank] + (size_t)(p * R) * n + c0;   // + src * n + V * vector
   const long long g0 = (long long)a.rank * n + c0;
-  const long long units = clen / EPU;
-  bool all_ok = true;
-  for (long long base = 0; base < units; base += (long long)NV * NT) {
+  const int vecs = (int)(clen / V);
+  for (int base = 0; base < vecs; base += NV * NT) {
     const void *ptr[8];
-    unsigned need[8];
     u32x4_t raw[8];
-    long long un[NV];
+    int vn[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      un[v] = base + (long long)v * NT + tid;
-      const bool in = un[v] < units;
-      const long long uc = in ? un[v] : 0;
-      // (elements at or beyond tri_end -- the two scalars, the padding -- are never pushed as final values and are not needed here
-      //  either: the scalars are summed by the value workgroup)
-      unsigned nd = 0;
-      if (in) {
-        const long long gi = g0 + uc * EPU;
-        if (EPU == 2) nd = (gi < tri_end ? 1u : 0u) | (gi + 1 < tri_end ? 2u : 0u);
-        else nd = gi < tri_end ? 3u : 0u;
-      }
+      vn[v] = base + v * NT + tid;
+      const int vc = vn[v] < vecs ? vn[v] : 0;
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        ptr[v * K + k] = st + (size_t)(k < R ? k : R - 1) * n * W + 2 * uc;
-        need[v * K + k] = k < R ? nd : 0u;
-      }
+      for (int k = 0; k < K; ++k) ptr[v * K + k] = st + (size_t)(k < R ? k : R - 1) * n + V * vc;
     }
-    if (!ll_load8(ptr, need, epoch, a.spin_budget, raw)) all_ok = false;
+    ld16x8_sys(ptr, raw);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      if (un[v] >= units) continue;
-      const long long gi0 = g0 + un[v] * EPU;
-      if (gi0 >= tri_end) continue;
-      double acc0 = 0.0, acc1 = 0.0;
+      if (vn[v] >= vecs) continue;
+      const long long gi0 = g0 + (long long)vn[v] * V;
+      if (gi0 >= tri_end) continue;   // (the two scalars belong to the value workgroup, the rest of the slice is padding)
+      double acc[V];
+#pragma unroll
+      for (int c = 0; c < V; ++c) acc[c] = 0.0;
 #pragma unroll
       for (int k = 0; k < K; ++k) {   // rank order: the sum does not depend on who arrived first
         if (k < R) {
-          unsigned wd[4];
-          __builtin_memcpy(wd, &raw[v * K + k], 16);   // {word, epoch, word, epoch}
-          if (EPU == 2) {
-            acc0 += (double)__builtin_bit_cast(float, wd[0]);
-            acc1 += (double)__builtin_bit_cast(float, wd[2]);
-          } else {
-            acc0 += Words<double>::make(wd[0], wd[2]);
-          }
+          T e[V];
+          __builtin_memcpy(e, &raw[v * K + k], 16);
+#pragma unroll
+          for (int c = 0; c < V; ++c) acc[c] += (double)e[c];
         }
       }
-      unsigned ow0, ow1, dummy;
-      bool both = true;
-      if (EPU == 2) {
-        Words<float>::split((float)p2p_finalise(a, gi0, acc0, invM, direct), ow0, dummy);
-        both = gi0 + 1 < tri_end;
-        ow1 = 0u;
-        if (both) Words<float>::split((float)p2p_finalise(a, gi0 + 1, acc1, invM, direct), ow1, dummy);
-      } else {
-        Words<double>::split(p2p_finalise(a, gi0, acc0, invM, direct), ow0, ow1);
+      T o[V];
+      long long pj = 0, pi = 0;   // place of the vector's first packed entry; the others by walking
+      const bool tri = a.family != MIVI_MEANFIELD && gi0 + V > a.d;
+      if (tri) packed_col_row(gi0 > a.d ? gi0 : (long long)a.d, a.d, pj, pi);
+#pragma unroll
+      for (int c = 0; c < V; ++c) {
+        const long long gi = gi0 + c;
+        o[c] = gi < tri_end ? (T)p2p_finalise(a, gi, pj, pi, acc[c], invM, direct) : T(0);
+        if (tri && gi >= a.d) packed_next(a.d, pj, pi);
       }
-      const size_t off = ((size_t)p * R * n + (size_t)gi0) * W;   // pair index inside a final area
-      if (both) {
-        const u32x4_t ov = {ow0, epoch, ow1, epoch};
-        for (int k = 0; k < R; ++k) store16_sys(tb.fin[a.lane][(a.rank + 1 + k) % R] + off, ov);
-      } else {   // (the last element below the scalars at an even index: one pair)
-        const u32x2_t ov = {ow0, epoch};
-        for (int k = 0; k < R; ++k) store8_sys(tb.fin[a.lane][(a.rank + 1 + k) % R] + off, ov);
+      const size_t off = (size_t)p * R * n + (size_t)gi0;   // element index inside a final area
+      if (gi0 + V <= tri_end) {
+        u32x4_t ov;
+        __builtin_memcpy(&ov, o, 16);
+        for (int k = 0; k < R; ++k) store16_sys((T *)tb.fin[a.lane][(a.rank + 1 + k) % R] + off, ov);
+      } else {   // the vector that holds the scalars is stored without them: the value workgroup writes those, with their own flag
+        for (int k = 0; k < R; ++k) {
+          T *dst = (T *)tb.fin[a.lane][(a.rank + 1 + k) % R] + off;
+          for (int c = 0; c < V; ++c)
+            if (gi0 + c < tri_end) st_sys(dst + c, o[c]);
+        }
       }
     }
   }
-  return all_ok;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_p2p_exchange(P2PArgs<T> a) {   // (<= 128 VGPRs: the spinning workgroups must leave the compute kernels their registers)
-  constexpr int NT = 256, W = Words<T>::W, EPU = 2 / W;
+  constexpr int NT = 256, V = 16 / (int)sizeof(T);   // elements per 16-byte vector
   __shared__ int sh_ok;
   __shared__ double red[4];
   const int tid = threadIdx.x, g = blockIdx.x, R = a.world, G = a.G, ln = a.lane;
@@ -281,36 +255,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       __syncthreads();
     }
 
-    // ---- phase 1: push chunk g of every slice to its owner (LL pairs) -----------------------------------------------------------------
+    // ---- phase 1: push chunk g of every slice to its owner, then one arrival flag per owner -------------------------------------------
     if ((a.phases & 1) && !value_wg) {
-      const long long vecs = clen * W / 4;   // 16-byte vectors of payload words in a chunk (clen is a multiple of 4)
-      for (long long base = 0; base < vecs; base += 8LL * NT) {
+      const int vecs = (int)(clen / V);   // (clen is a multiple of 4)
+      for (int base = 0; base < vecs; base += 8 * NT) {
         for (int k = 0; k < R; ++k) {
           const int s = (a.rank + 1 + k) % R;   // start with the neighbour: the links fill evenly, the local copy comes last
-          const unsigned *src = (const unsigned *)(P + (size_t)s * n + c0);
-          unsigned long long *dst = tb.stage[ln][s] + ((size_t)(p * R + a.rank) * n + c0) * W;
+          const T *src = P + (size_t)s * n + c0;
+          T *dst = (T *)tb.stage[ln][s] + (size_t)(p * R + a.rank) * n + c0;
           const void *ptr[8];
           u32x4_t r[8];
-          long long vi[8];
+          int vi[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            vi[u] = base + (long long)u * NT + tid;
-            ptr[u] = src + 4 * (vi[u] < vecs ? vi[u] : 0);
+            vi[u] = base + u * NT + tid;
+            ptr[u] = src + V * (vi[u] < vecs ? vi[u] : 0);
           }
           ld16x8_sys(ptr, r);   // (system scope: the vector was written by the compute kernels' XCDs and this kernel never restarts)
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            if (vi[u] >= vecs) continue;
-            const u32x4_t lo = {r[u][0], epoch, r[u][1], epoch}, hi = {r[u][2], epoch, r[u][3], epoch};
-            store16_sys(dst + 4 * vi[u], lo);
-            store16_sys(dst + 4 * vi[u] + 2, hi);
-          }
+          for (int u = 0; u < 8; ++u)
+            if (vi[u] < vecs) store16_sys(dst + V * vi[u], r[u]);
         }
       }
-      if (a.freed) {   // this workgroup is done reading the partial vector in this ring slot
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(a.freed + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every payload store of this wave has been acknowledged ...
+      __syncthreads();                                    // ... and of this workgroup
+      if (tid < R) flag_store(tb.arr[ln][tid] + (size_t)(p * R + a.rank) * G + g, epoch);
+      if (a.freed && tid == 0)   // this workgroup is done reading the partial vector in this ring slot
+        __hip_atomic_fetch_add(a.freed + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     // ---- phase 3a (needs nothing from anybody): exact zeros above the diagonal of the dense gradient -------------------------------------
@@ -320,16 +291,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         for (int i = tid; i < j; i += NT) gc[(size_t)j * d + i] = T(0);
     }
 
-    // ---- phase 2: reduce + finalise chunk g of MY slice, push the final chunk to every rank -------------------------------------------
+    // ---- phase 2: reduce + finalise chunk g of MY slice, push the final chunk to every rank, one final flag per rank --------------------
     if ((a.phases & 2) && !value_wg) {
-      bool ok;
-      if (R == 1) ok = p2p_reduce_chunk<T, 1, NT>(a, tb, p, epoch, c0, clen);
-      else if (R == 2) ok = p2p_reduce_chunk<T, 2, NT>(a, tb, p, epoch, c0, clen);
-      else if (R <= 4) ok = p2p_reduce_chunk<T, 4, NT>(a, tb, p, epoch, c0, clen);
-      else ok = p2p_reduce_chunk<T, 8, NT>(a, tb, p, epoch, c0, clen);
-      if (!ok) lost = true;
+      if (!wait_flags<NT>(tb.arr[ln][a.rank] + (size_t)(p * R) * G + g, R, G, epoch, a.spin_budget, &sh_ok)) lost = true;
+      if (R == 1) p2p_reduce_chunk<T, 1, NT>(a, tb, p, c0, clen);
+      else if (R == 2) p2p_reduce_chunk<T, 2, NT>(a, tb, p, c0, clen);
+      else if (R <= 4) p2p_reduce_chunk<T, 4, NT>(a, tb, p, c0, clen);
+      else p2p_reduce_chunk<T, 8, NT>(a, tb, p, c0, clen);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid < R) flag_store(tb.farr[ln][tid] + (size_t)(p * R + a.rank) * (G + 1) + g, epoch);
     }
     if ((a.phases & 2) && value_wg && a.rank == a.vs) {   // the objective value: sum ell, sum 0.5|eps|^2 of all ranks + the parameter-only terms
+      const long long o0 = tri_end - (long long)a.vs * n, o1 = o0 + 1;   // offsets of the two scalars inside my slice
+      const int ga = (int)(o0 / a.cn), gb = (int)(o1 / a.cn);
+      if (!wait_flags<NT>(tb.arr[ln][a.rank] + (size_t)(p * R) * G + ga, R, G, epoch, a.spin_budget, &sh_ok)) lost = true;
+      if (gb != ga && !wait_flags<NT>(tb.arr[ln][a.rank] + (size_t)(p * R) * G + gb, R, G, epoch, a.spin_budget, &sh_ok)) lost = true;
       double s_ld = 0.0, bad = 0.0;
       for (int i = tid; i < d; i += NT) {
         const double c = (double)(a.family == MIVI_MEANFIELD ? a.params[d + i] : a.params[d + (size_t)i * d + i]);
@@ -339,93 +316,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       s_ld = block_sum<double, NT>(s_ld, red);
       bad = block_sum<double, NT>(bad, red);
       if (tid == 0) {
-        const long long o0 = tri_end - (long long)a.vs * n;   // offset of the first scalar inside my slice
-        double sc[2] = {0.0, 0.0};
-        for (int src = 0; src < R; ++src)
-          for (int q = 0; q < 2; ++q) {
-            unsigned w[2] = {0u, 0u};
-            for (int h = 0; h < W; ++h)
-              if (!ll_load1(tb.stage[ln][a.rank] + ((size_t)(p * R + src) * n + o0 + q) * W + h, epoch, a.spin_budget, w[h])) lost = true;
-            sc[q] += (double)Words<T>::make(w[0], w[1]);
-          }
+        const T *st = (const T *)tb.stage[ln][a.rank] + (size_t)(p * R) * n;
+        double sum_ell = 0.0, s_he = 0.0;
+        for (int src = 0; src < R; ++src) {
+          sum_ell += (double)ld_sys(st + (size_t)src * n + o0);
+          s_he += (double)ld_sys(st + (size_t)src * n + o1);
+        }
         const double Mt = (double)a.M_total;
-        const double ent = (ent_is_closed(a.ent_kind) ? 0.5 * d * (1.0 + kLog2Pi) : sc[1] / Mt + 0.5 * d * kLog2Pi) + s_ld;
-        const double value = -(sc[0] / Mt + ent);
+        const double ent = (ent_is_closed(a.ent_kind) ? 0.5 * d * (1.0 + kLog2Pi) : s_he / Mt + 0.5 * d * kLog2Pi) + s_ld;
+        const double value = -(sum_ell / Mt + ent);
         int stt = 0;
         if (!isfinite(value)) stt |= 1;
         if (bad > 0.0) stt |= 2;
-        unsigned wv[2], ws[2];
-        Words<T>::split((T)value, wv[0], wv[1]);
-        Words<T>::split((T)stt, ws[0], ws[1]);
         for (int s = 0; s < R; ++s) {
-          unsigned long long *dst = tb.fin[ln][s] + ((size_t)p * R * n + tri_end) * W;
-          for (int h = 0; h < W; ++h) {
-            const u32x2_t v1 = {wv[h], epoch}, v2 = {ws[h], epoch};
-            store8_sys(dst + h, v1);
-            store8_sys(dst + W + h, v2);
-          }
+          T *dst = (T *)tb.fin[ln][s] + (size_t)p * R * n;
+          st_sys(dst + tri_end, (T)value);
+          st_sys(dst + tri_end + 1, (T)stt);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int s = 0; s < R; ++s) flag_store(tb.farr[ln][s] + (size_t)(p * R + a.vs) * (G + 1) + G, epoch);
       }
     }
 
     // ---- phase 3: unpack chunk g of every final slice ------------------------------------------------------------------------------------
     if (a.phases & 4) {
-      const unsigned long long *fin = tb.fin[ln][a.rank] + (size_t)p * R * n * W;
+      const T *fin = (const T *)tb.fin[ln][a.rank] + (size_t)p * R * n;
       if (value_wg) {
+        if (!wait_flags<NT>(tb.farr[ln][a.rank] + (size_t)(p * R + a.vs) * (G + 1) + G, 1, 1, epoch, a.spin_budget, &sh_ok)) lost = true;
         if (tid == 0) {
-          unsigned wv[2] = {0u, 0u}, ws[2] = {0u, 0u};
-          for (int h = 0; h < W; ++h) {
-            if (!ll_load1(fin + (size_t)tri_end * W + h, epoch, a.spin_budget, wv[h])) lost = true;
-            if (!ll_load1(fin + (size_t)(tri_end + 1) * W + h, epoch, a.spin_budget, ws[h])) lost = true;
-          }
-          *out_v = Words<T>::make(wv[0], wv[1]);
-          const int stt = (int)Words<T>::make(ws[0], ws[1]);
+          *out_v = ld_sys(fin + tri_end);
+          const int stt = (int)ld_sys(fin + tri_end + 1);
           if (stt && a.status) atomicOr(a.status, stt);
         }
       } else {
-        const long long units = clen / EPU, total = units * R;   // unit index x = s * units + u
-        for (long long base = 0; base < total; base += 8LL * NT) {
+        // chunk g of every owner's slice: R final flags
+        if (!wait_flags<NT>(tb.farr[ln][a.rank] + (size_t)(p * R) * (G + 1) + g, R, G + 1, epoch, a.spin_budget, &sh_ok)) lost = true;
+        const int vecs = (int)(clen / V), total = vecs * R;   // vector index x = s * vecs + u  (32-bit: 64-bit divides are long sequences)
+        for (int base = 0; base < total; base += 8 * NT) {
           const void *ptr[8];
-          unsigned need[8];
           u32x4_t raw[8];
           long long gi0[8];
+          bool in[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const long long x = base + (long long)u * NT + tid;
-            const bool in = x < total;
-            const long long s = in ? x / units : 0, uu = in ? x % units : 0;
-            gi0[u] = s * n + c0 + uu * EPU;
-            ptr[u] = fin + (size_t)gi0[u] * W;
-            need[u] = 0;
-            if (in) {
-              if (EPU == 2) need[u] = (gi0[u] < tri_end ? 1u : 0u) | (gi0[u] + 1 < tri_end ? 2u : 0u);
-              else need[u] = gi0[u] < tri_end ? 3u : 0u;
-            }
+            const int x = base + u * NT + tid;
+            in[u] = x < total;
+            const int sx = in[u] ? x / vecs : 0, uu = in[u] ? x - sx * vecs : 0;
+            gi0[u] = (long long)sx * n + c0 + (long long)uu * V;
+            if (gi0[u] >= tri_end) in[u] = false;   // (scalars / padding: nothing of this vector is part of the gradient)
+            ptr[u] = fin + (size_t)(in[u] ? gi0[u] : 0);
           }
-          if (!ll_load8(ptr, need, epoch, a.spin_budget, raw)) lost = true;
+          ld16x8_sys(ptr, raw);
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            if (!need[u]) continue;
-            unsigned wd[4];
-            __builtin_memcpy(wd, &raw[u], 16);   // {word, epoch, word, epoch}
-            T x0, x1 = T(0);
-            if (EPU == 2) {
-              x0 = Words<T>::make(wd[0], 0u);
-              x1 = Words<T>::make(wd[2], 0u);
-            } else {
-              x0 = Words<T>::make(wd[0], wd[2]);
-            }
+            if (!in[u]) continue;
+            T e[V];
+            __builtin_memcpy(e, &raw[u], 16);
+            long long pj = 0, pi = 0;
+            const bool tri = a.family != MIVI_MEANFIELD && gi0[u] + V > d;
+            if (tri) packed_col_row(gi0[u] > d ? gi0[u] : (long long)d, d, pj, pi);
 #pragma unroll
-            for (int c = 0; c < EPU; ++c) {
+            for (int c = 0; c < V; ++c) {
               const long long gi = gi0[u] + c;
               if (gi >= tri_end) continue;
               long long di = gi;
-              if (a.family != MIVI_MEANFIELD && gi >= d) {
-                long long j, i;
-                packed_col_row(gi, d, j, i);
-                di = d + j * d + i;
+              if (tri && gi >= d) {
+                di = d + pj * d + pi;
+                packed_next(d, pj, pi);
               }
-              out_g[di] = c == 0 ? x0 : x1;
+              out_g[di] = e[c];
             }
           }
         }
@@ -450,7 +409,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // hand-over words of the pipelined batch on the COMPUTE chain (one thread): announce a complete partial vector (ready = ready_val), then
 // hold the chain until the exchange has read the ring slot the NEXT estimate's kernels are going to overwrite (*freed >= freed_min)
 __global__ void k_p2p_handover(unsigned *ready, unsigned ready_val, const unsigned *freed, unsigned freed_min, int budget, int *status) {
-  if (ready) __hip_atomic_store(ready, ready_val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  // (relaxed: the partial vector was written -- through, sc1 -- by kernels that completed before this one started; a release here is an
+  //  L2 write-back of whatever the exchange kernels running beside the chain have dirtied)
+  if (ready) __hip_atomic_store(ready, ready_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (freed) {
     while ((int)(__hip_atomic_load(freed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - freed_min) < 0) {
       if (--budget <= 0) { if (status) atomicOr(status, 8); break; }

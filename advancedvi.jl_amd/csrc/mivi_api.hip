@@ -950,7 +950,7 @@ struct P2PHandle {   // what travels between the ranks (MIVI_P2P_HANDLE_BYTES = 
 static_assert(sizeof(P2PHandle) <= MIVI_P2P_HANDLE_BYTES, "handle blob");
 constexpr uint32_t kP2PMagic = 0x4D495650u;   // "MIVP"
 constexpr int kLanes = 2, kRing = 4;   // (kernels_p2p.hip: kP2PLanes, kP2PRing)
-struct P2PTableHost { unsigned long long *stage[kLanes][8]; unsigned long long *fin[kLanes][8]; };
+struct P2PTableHost { char *stage[kLanes][8]; char *fin[kLanes][8]; unsigned *arr[kLanes][8]; unsigned *farr[kLanes][8]; };   // == P2PTable (kernels_p2p.hip)
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -1006,10 +1006,10 @@ mivi_status_t mivi_p2p_export(mivi_ctx_t *c, int32_t rank, int32_t world, void *
   int G, vs;
   p2p_geometry(L, world, n, cn, G, vs);
   const size_t es = c->esize;
-  // per lane, LL layout (every 32-bit payload word travels as an 8-byte (word, epoch) pair): staging [2][R][n W] pairs, final [2][R n W] pairs
-  const size_t W = es / 4;
-  const size_t b_stage = align256((size_t)2 * world * n * W * 8), b_fin = align256((size_t)2 * world * n * W * 8);
-  const size_t lane_bytes = b_stage + b_fin;
+  // per lane (double-buffered by epoch parity): staging [2][R][n] T, final [2][R n] T, arrival flags [2][R][G], final flags [2][R][G + 1]
+  const size_t b_stage = align256((size_t)2 * world * n * es), b_fin = align256((size_t)2 * world * n * es);
+  const size_t b_arr = align256((size_t)2 * world * G * 4), b_farr = align256((size_t)2 * world * (G + 1) * 4);
+  const size_t lane_bytes = b_stage + b_fin + b_arr + b_farr;
   const size_t bytes = lane_bytes * kLanes;
   // FINE-GRAINED device memory: peers write it over xGMI, system-scope releases / acquires and the consumers' system-scope loads
   // (kernels_p2p.hip ld_sys) keep it coherent.  NOT hipDeviceMallocUncached: on this stack (ROCm 7.0 / gfx950) running the exchange on an
@@ -1024,9 +1024,9 @@ mivi_status_t mivi_p2p_export(mivi_ctx_t *c, int32_t rank, int32_t world, void *
   c->p2p_buf = buf;
   c->p2p_bytes = bytes;
   c->p2p_rank = rank; c->p2p_world = world; c->p2p_n = n; c->p2p_cn = cn; c->p2p_G = G; c->p2p_vs = vs;
-  c->p2p_lane_bytes = lane_bytes; c->p2p_off_fin = b_stage;
+  c->p2p_lane_bytes = lane_bytes; c->p2p_off_fin = b_stage; c->p2p_off_arr = b_stage + b_fin; c->p2p_off_farr = b_stage + b_fin + b_arr;
   P2PHandle h{};
-  h.magic = kP2PMagic; h.version = 1; h.rank = rank; h.world = world; h.L = L; h.n = n; h.cn = cn; h.esize = (int32_t)es; h.G = G;
+  h.magic = kP2PMagic; h.version = 2; h.rank = rank; h.world = world; h.L = L; h.n = n; h.cn = cn; h.esize = (int32_t)es; h.G = G;
   h.bytes = bytes; h.pid = (uint64_t)getpid(); h.local_ptr = (uint64_t)(uintptr_t)buf; h.device = c->cfg.device;
   if (hipIpcGetMemHandle(&h.ipc, buf) != hipSuccess) {   // single-process use (tests, world = 1) still works through local_ptr
     (void)hipGetLastError();
@@ -1048,7 +1048,7 @@ mivi_status_t mivi_p2p_attach(mivi_ctx_t *c, const void *handles) {
   for (int r = 0; r < R; ++r) {
     P2PHandle h;
     memcpy(&h, (const char *)handles + (size_t)r * MIVI_P2P_HANDLE_BYTES, sizeof(h));
-    if (h.magic != kP2PMagic || h.version != 1 || h.rank != r || h.world != R || h.L != mivi_partials_len(c) || h.n != c->p2p_n ||
+    if (h.magic != kP2PMagic || h.version != 2 || h.rank != r || h.world != R || h.L != mivi_partials_len(c) || h.n != c->p2p_n ||
         h.cn != c->p2p_cn || h.G != c->p2p_G || h.esize != (int32_t)c->esize || h.bytes != c->p2p_bytes)
       return fail(c, MIVI_ERR_BAD_ARG, "peer-to-peer handle does not match this context (rank order, family, d, dtype or world differ)");
     void *base = nullptr;
@@ -1072,8 +1072,10 @@ mivi_status_t mivi_p2p_attach(mivi_ctx_t *c, const void *handles) {
     c->p2p_peer[r] = base;
     for (int ln = 0; ln < kLanes; ++ln) {
       char *lb = (char *)base + (size_t)ln * c->p2p_lane_bytes;
-      tab.stage[ln][r] = (unsigned long long *)lb;
-      tab.fin[ln][r] = (unsigned long long *)(lb + c->p2p_off_fin);
+      tab.stage[ln][r] = lb;
+      tab.fin[ln][r] = lb + c->p2p_off_fin;
+      tab.arr[ln][r] = (unsigned *)(lb + c->p2p_off_arr);
+      tab.farr[ln][r] = (unsigned *)(lb + c->p2p_off_farr);
     }
   }
   mivi_status_t s;
@@ -1098,7 +1100,8 @@ mivi_status_t mivi_p2p_debug_words(mivi_ctx_t *c, uint32_t *out128) {   // devel
 
 mivi_status_t mivi_p2p_set_pipeline(mivi_ctx_t *c, int32_t on) {
   if (!c) return MIVI_ERR_BAD_ARG;
-  c->p2p_pipe_state = on ? 1 : -1;
+  if (on < 0 || on > kLanes) return fail(c, MIVI_ERR_BAD_ARG, "mivi_p2p_set_pipeline: 0 = off, 1 = one persistent exchange lane, 2 = two");
+  c->p2p_pipe_state = on ? on : -1;
   invalidate_graph(c);
   return MIVI_OK;
 }
@@ -1743,6 +1746,8 @@ static mivi_status_t dist_sequence(mivi_ctx *c, const void *params, bool counter
     if (mode == 4) {   // peer-to-peer pipeline, compute chain: announce partial vector i, then wait until the exchange has read the ring slot estimate i + 1 overwrites
       unsigned *w = (unsigned *)c->p2p_ctr.p;
       const int slot = (i + 1) % kRing, prev_users = (i + 1) / kRing;
+      // (folding this one-thread launch into the next estimate's product kernel as an extra workgroup was tried: the 8 us it takes from
+      //  dispatch to completion beside the persistent exchange kernels moved into that kernel -- 9 + 8 -> 21.5 us --, the step stayed at 31 us)
       launch_p2p_handover(c, w + 64, (unsigned)i + 1u, prev_users >= 1 ? w + 80 + slot : nullptr, (unsigned)prev_users * (unsigned)c->p2p_G);
       continue;
     }
@@ -1833,7 +1838,9 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
     HIPCHK(c, hipEventRecord(c->ev_part[0], c->stream));
     hipStream_t main = c->stream;
     const void *ringP[4] = {c->dist_P.p, c->dist_P2.p, c->dist_P3.p, c->dist_P4.p};
-    const int lanes = count >= 2 ? kLanes : 1;
+    // ONE persistent lane by default (measured on one GPU: 21 us per estimate against 31 with two -- a second resident exchange kernel costs
+    // the compute chain more than its overlap wins); two where the exchange's latency is several compute steps (mivi_p2p_set_pipeline(ctx, 2))
+    const int lanes = (count >= 2 && c->p2p_pipe_state >= 2) ? kLanes : 1;
     for (int ln = 0; ln < lanes; ++ln) {
       hipStream_t cs = ln ? c->comm_stream2 : c->comm_stream;
       HIPCHK(c, hipStreamWaitEvent(cs, c->ev_part[0], 0));
@@ -1846,7 +1853,7 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
   };
   auto p2p_back = [&]() -> mivi_status_t {
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_comm[0], 0));
-    if (count >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_comm[1], 0));
+    if (count >= 2 && c->p2p_pipe_state >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_comm[1], 0));
     return MIVI_OK;
   };
   if (g.exec && g.kind == kind && g.count == count && g.params == params && g.value == value && g.grad == grad && g.p0 == (double)route) {

@@ -240,7 +240,7 @@ struct mivi_ctx {
   bool p2p_on = false;
   int p2p_rank = 0, p2p_world = 1, p2p_G = 1, p2p_vs = 0, p2p_spin = 1 << 21;
   long long p2p_n = 0, p2p_cn = 0;
-  size_t p2p_lane_bytes = 0, p2p_off_fin = 0;
+  size_t p2p_lane_bytes = 0, p2p_off_fin = 0, p2p_off_arr = 0, p2p_off_farr = 0;
   // logreg
   const void *lr_X = nullptr;
   const uint8_t *lr_y = nullptr;

@@ -313,11 +313,12 @@ mivi_status_t mivi_p2p_detach(mivi_ctx_t *ctx);
  * length L over `world` ranks (no GPU needed) */
 void mivi_p2p_geometry(int64_t L, int32_t world, int64_t *out4);
 mivi_status_t mivi_comm_enable_p2p(mivi_ctx_t *ctx);
-/* Batched sharded estimates on the peer-to-peer route run the exchange as persistent kernels on their own high-priority streams BESIDE
- * the compute chain (csrc/kernels_p2p.hip).  That needs the device to schedule the two concurrently; where it does not (streams
- * sharing one hardware queue), the bounded waits end in MIVI_ERR_HIP at the next mivi_synchronize -- the host then switches the
- * pipeline off ON EVERY RANK (all ranks must agree: the lanes the estimates use differ) and batched calls run serial steps. */
-mivi_status_t mivi_p2p_set_pipeline(mivi_ctx_t *ctx, int32_t on);
+/* Batched sharded estimates on the peer-to-peer route run the exchange as persistent kernels ("lanes": lane l serves estimates l, l + lanes,
+ * ...) on their own streams BESIDE the compute chain (csrc/kernels_p2p.hip).  lanes = 1 (default) or 2; 0 = no pipeline: batched calls run
+ * serial steps.  The pipeline needs the device to schedule the lanes and the compute chain concurrently; where it does not (streams sharing
+ * one hardware queue), the bounded waits end in MIVI_ERR_HIP at the next mivi_synchronize -- the host then switches the pipeline off ON
+ * EVERY RANK (all ranks must use the same setting: the lanes the estimates use differ). */
+mivi_status_t mivi_p2p_set_pipeline(mivi_ctx_t *ctx, int32_t lanes);
 /* developer: the exchange's device words (per lane {epoch, ticket} at 16-word spacing, ready at word 64, freed[ring] at word 80): out128 = uint32[128] */
 mivi_status_t mivi_p2p_debug_words(mivi_ctx_t *ctx, uint32_t *out128_host);
 /* how many polls (about 1 us each) a wait inside the exchange may take before the peer counts as lost (default 2^21, about 2 s) */
