@@ -285,7 +285,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     }
 
     // ---- phase 3a (needs nothing from anybody): exact zeros above the diagonal of the dense gradient -------------------------------------
-    if ((a.phases & 4) && !value_wg && a.family == MIVI_FULLRANK) {
+    // (the scratch gradient of the batch's earlier estimates keeps its zeros from this launch's first estimate: only the unpack below
+    //  writes it, and only below the diagonal; the caller's buffer gets them with the last estimate)
+    if ((a.phases & 4) && !value_wg && a.family == MIVI_FULLRANK && (last || t == a.lane)) {
       T *gc = out_g + d;
       for (int j = g + 1; j < d; j += G)
         for (int i = tid; i < j; i += NT) gc[(size_t)j * d + i] = T(0);
