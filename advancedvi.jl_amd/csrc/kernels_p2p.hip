@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     T *out_v = last ? a.value : a.scratch, *out_g = last ? a.grad : a.scratch + 4;
     if (a.ready) {   // hand-over from the compute chain: the partial vector of estimate t is complete
       if (tid == 0) {
-        int budget = a.spin_budget;
+        int budget = lost ? 64 : a.spin_budget;   // (after a lost peer every further wait of this launch gives up at once: a dead batch ends in milliseconds)
         sh_ok = 1;
         while ((int)__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t + 1) {
           if (--budget <= 0) { sh_ok = 0; break; }
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 
     // ---- phase 2: reduce + finalise chunk g of MY slice, push the final chunk to every rank, one final flag per rank --------------------
     if ((a.phases & 2) && !value_wg) {
-      if (!wait_flags<NT>(tb.arr[ln][a.rank] + (size_t)(p * R) * G + g, R, G, epoch, a.spin_budget, &sh_ok)) lost = true;
+      if (!wait_flags<NT>(tb.arr[ln][a.rank] + (size_t)(p * R) * G + g, R, G, epoch, lost ? 64 : a.spin_budget, &sh_ok)) lost = true;
       if (R == 1) p2p_reduce_chunk<T, 1, NT>(a, tb, p, c0, clen);
       else if (R == 2) p2p_reduce_chunk<T, 2, NT>(a, tb, p, c0, clen);
       else if (R <= 4) p2p_reduce_chunk<T, 4, NT>(a, tb, p, c0, clen);
@@ -307,8 +307,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     if ((a.phases & 2) && value_wg && a.rank == a.vs) {   // the objective value: sum ell, sum 0.5|eps|^2 of all ranks + the parameter-only terms
       const long long o0 = tri_end - (long long)a.vs * n, o1 = o0 + 1;   // offsets of the two scalars inside my slice
       const int ga = (int)(o0 / a.cn), gb = (int)(o1 / a.cn);
-      if (!wait_flags<NT>(tb.arr[ln][a.rank] + (size_t)(p * R) * G + ga, R, G, epoch, a.spin_budget, &sh_ok)) lost = true;
-      if (gb != ga && !wait_flags<NT>(tb.arr[ln][a.rank] + (size_t)(p * R) * G + gb, R, G, epoch, a.spin_budget, &sh_ok)) lost = true;
+      if (!wait_flags<NT>(tb.arr[ln][a.rank] + (size_t)(p * R) * G + ga, R, G, epoch, lost ? 64 : a.spin_budget, &sh_ok)) lost = true;
+      if (gb != ga && !wait_flags<NT>(tb.arr[ln][a.rank] + (size_t)(p * R) * G + gb, R, G, epoch, lost ? 64 : a.spin_budget, &sh_ok)) lost = true;
       double s_ld = 0.0, bad = 0.0;
       for (int i = tid; i < d; i += NT) {
         const double c = (double)(a.family == MIVI_MEANFIELD ? a.params[d + i] : a.params[d + (size_t)i * d + i]);
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     if (a.phases & 4) {
       const T *fin = (const T *)tb.fin[ln][a.rank] + (size_t)p * R * n;
       if (value_wg) {
-        if (!wait_flags<NT>(tb.farr[ln][a.rank] + (size_t)(p * R + a.vs) * (G + 1) + G, 1, 1, epoch, a.spin_budget, &sh_ok)) lost = true;
+        if (!wait_flags<NT>(tb.farr[ln][a.rank] + (size_t)(p * R + a.vs) * (G + 1) + G, 1, 1, epoch, lost ? 64 : a.spin_budget, &sh_ok)) lost = true;
         if (tid == 0) {
           *out_v = ld_sys(fin + tri_end);
           const int stt = (int)ld_sys(fin + tri_end + 1);
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
       } else {
         // chunk g of every owner's slice: R final flags
-        if (!wait_flags<NT>(tb.farr[ln][a.rank] + (size_t)(p * R) * (G + 1) + g, R, G + 1, epoch, a.spin_budget, &sh_ok)) lost = true;
+        if (!wait_flags<NT>(tb.farr[ln][a.rank] + (size_t)(p * R) * (G + 1) + g, R, G + 1, epoch, lost ? 64 : a.spin_budget, &sh_ok)) lost = true;
         const int vecs = (int)(clen / V), total = vecs * R;   // vector index x = s * vecs + u  (32-bit: 64-bit divides are long sequences)
         for (int base = 0; base < total; base += 8 * NT) {
           const void *ptr[8];

@@ -1654,14 +1654,16 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
     if ((s = ensure_work(k, k->cfg.n_mc))) { c->err = k->err; return s; }
     prepare_tables(k, k->cfg.n_mc);
     if (!lds_prepare(k, k->cfg.n_mc)) return fail(c, MIVI_ERR_HIP, "full-rank work lists: allocation failed");
-    HIPCHK(c, hipStreamSynchronize(k->stream));
   }
   if (!lds_prepare(c, c->cfg.n_mc)) return fail(c, MIVI_ERR_HIP, "full-rank work lists: allocation failed");
   GraphCache &g = c->graph;
   if (!(g.exec && g.kind == 2 && g.count == count && g.params == params && g.value == value && g.grad == grad && g.p0 == (double)lanes)) {
     invalidate_graph(c);
     c->idx_stride = lanes;   // (invalidate_graph leaves it; the children were synced above: re-stamp their generation)
-    for (int j = 0; j < lanes - 1; ++j) c->kids[j]->kid_gen = c->target_gen;
+    for (int j = 0; j < lanes - 1; ++j) {
+      c->kids[j]->kid_gen = c->target_gen;
+      HIPCHK(c, hipStreamSynchronize(c->kids[j]->stream));   // (their table uploads, before the capture -- not on every replay)
+    }
     hipGraph_t graph = nullptr;
     hipStream_t saved;
     if ((s = begin_capture(c, &saved))) return s;

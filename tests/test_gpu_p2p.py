@@ -231,3 +231,30 @@ def test_pipelined_batch_equals_single_estimates(family, d, M, count, route):
     prof = ctx.profile_dist(p, 8)
     assert all(prof[k] > 0 for k in ("partials", "exchange", "serial", "pipelined"))
     ctx.close()
+
+
+def test_lost_peer_is_reported_not_waited_for_forever():
+    """Every wait inside the exchange is bounded (mivi_p2p_set_spin_budget): a rank whose peer never pushes gives up, sets the sticky
+    status bit, and the next synchronize reports it -- and once a peer counts as lost the launch's remaining waits give up at once,
+    so a dead batch costs milliseconds, not its number of waits times the budget."""
+    import time
+    rng = np.random.default_rng(3)
+    d, M, R = 64, 32, 2
+    q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
+    prob, _ = make_problem(rng, "diag", d, np.float32)
+    params, _ = avi.destructure(q)
+    ctxs = _ranks(np.float32, avi.FULLRANK, d, M, R, 0, prob)
+    c0 = ctxs[0]
+    c0.p2p_set_spin_budget(20000)
+    n = p2p_geometry(c0.partials_len, R)[0]
+    p0 = c0.to_device(params)
+    P = c0.empty(n * R).zero_()
+    c0.estimate_partials(p0, 5, P[:c0.partials_len])
+    v, g = c0.empty(1), c0.empty(c0.params_len)
+    t0 = time.perf_counter()
+    c0.p2p_exchange(p0, P, v, g, 7)                       # rank 1 never runs: its arrival flags never come
+    with pytest.raises(avi.MiviError, match="did not arrive"):
+        c0.synchronize()
+    assert time.perf_counter() - t0 < 5.0
+    for c in ctxs:
+        c.close()
