@@ -24,6 +24,7 @@ class MiviConfig(C.Structure):
 
 LOGDENSITY_AND_GRADIENT_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p)
 LOGDENSITY_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p)
+LOGDENSITY_GRADIENT_AND_HESSIAN_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p)
 
 # name -> (restype, argtypes): every symbol include/mivi.h declares
 SIGNATURES = {
@@ -51,6 +52,9 @@ SIGNATURES = {
     "mivi_estimate_objective_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p]),
     "mivi_gauss_expected_grad_hess": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mivi_gauss_expected_grad_hess_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mivi_gauss_expected_grad_hess2": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mivi_gauss_expected_grad_hess2_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mivi_set_target_hess_callback": (C.c_int32, [C.c_void_p, LOGDENSITY_GRADIENT_AND_HESSIAN_FN, C.c_void_p]),
     "mivi_set_logreg_route": (C.c_int32, [C.c_void_p, C.c_int32]),
     "mivi_estimate_partials": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "mivi_finalize": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

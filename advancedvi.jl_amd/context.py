@@ -191,11 +191,32 @@ class MiviContext:
                 self._cb_error = e
                 return 1
 
+        def fh(user, Zp, d, M, ellp, Gp, Hp):   # second-order plugin: ell, G and the SUM of the Hessians over the M columns
+            try:
+                Z = as_mat(Zp, d, M)
+                ell = as_mat(ellp, 1, M)
+                G = as_mat(Gp, d, M)
+                H = as_mat(Hp, d, d)
+                Hacc = np.zeros((d, d), dtype=np.float64)   # (the chunk's sum in f64, rounded once to the context's dtype)
+                for m in range(M):
+                    l, g, h = prob.logdensity_gradient_and_hessian(Z[:, m])
+                    ell[0, m] = l
+                    G[:, m] = g
+                    Hacc += np.asarray(h, dtype=np.float64)
+                H[:, :] = Hacc
+                return 0
+            except Exception as e:
+                self._cb_error = e
+                return 1
+
         cfg = _lib.LOGDENSITY_AND_GRADIENT_FN(fg)
         cfv = _lib.LOGDENSITY_FN(fv) if hasattr(prob, "logdensity") else C.cast(None, _lib.LOGDENSITY_FN)
-        self._keep += [cfg, cfv]
+        cfh = (_lib.LOGDENSITY_GRADIENT_AND_HESSIAN_FN(fh) if hasattr(prob, "logdensity_gradient_and_hessian")
+               else C.cast(None, _lib.LOGDENSITY_GRADIENT_AND_HESSIAN_FN))
+        self._keep += [cfg, cfv, cfh]
         self._cb_error = None
         self._chk(self.lib.mivi_set_target_callback(self.h, cfg, cfv, None))
+        self._chk(self.lib.mivi_set_target_hess_callback(self.h, cfh, None))
 
     def _raise_cb(self, st):
         err = getattr(self, "_cb_error", None)
@@ -230,14 +251,15 @@ class MiviContext:
         self._raise_cb(self.lib.mivi_estimate_objective(self.h, self._p(p), idx, int(n_samples), int(entropy), self._p(value)))
         return value
 
-    def gauss_expected_grad_hess(self, params, idx, n_samples=0, grad=None, hess=None):
-        """(logpi_avg T[1], grad T[d], hess (d, d)) of mivi_gauss_expected_grad_hess; `hess[i, j]` is the matrix entry."""
+    def gauss_expected_grad_hess(self, params, idx, n_samples=0, grad=None, hess=None, second_order=False):
+        """(logpi_avg T[1], grad T[d], hess (d, d)) of mivi_gauss_expected_grad_hess (Stein / Price branch) or, with
+        `second_order`, of mivi_gauss_expected_grad_hess2 (sample average of the Hessians); `hess[i, j]` is the matrix entry."""
         p = self.to_device(params)
         logpi = self.empty(1)
         grad = self.empty(self.d) if grad is None else grad
         hess = self.empty(self.d * self.d) if hess is None else hess
-        self._raise_cb(self.lib.mivi_gauss_expected_grad_hess(self.h, self._p(p), idx, int(n_samples), self._p(logpi),
-                                                              self._p(grad), self._p(hess)))
+        fn = self.lib.mivi_gauss_expected_grad_hess2 if second_order else self.lib.mivi_gauss_expected_grad_hess
+        self._raise_cb(fn(self.h, self._p(p), idx, int(n_samples), self._p(logpi), self._p(grad), self._p(hess)))
         return logpi, grad, hess.view(self.d, self.d).t()   # column-major d x d
 
     def estimate_partials(self, params, idx, partials=None):

@@ -1498,6 +1498,47 @@ __global__ void k_stein_finish(int d, double n, const double *gsum, const double
   if (i == 0) *logpi_avg = (T)((ell_single ? (double)ell_single[0] : ell_sum[0]) / n);   // one chunk: straight from its partial
 }
 
+// second-order branch (src/algorithms/gauss_expected_grad_hess.jl:61-83): only the column sums of G are needed -- gsum (+)= G 1,
+// one workgroup per 32 coordinates, the sample axis dealt to eight 32-lane groups (f64 sums, fixed order)
+template <typename T>
+__global__ __launch_bounds__(256) void k_stein_gsum(int d, int M, const T *G, double *gsum, int first) {
+  __shared__ double gred[8][32];
+  const int tid = threadIdx.x, jj = tid & 31, part = tid >> 5, j0 = blockIdx.x * 32;
+  double sacc = 0.0;
+  if (j0 + jj < d)
+    for (int b = part; b < M; b += 8) sacc += (double)G[(size_t)b * d + j0 + jj];
+  gred[part][jj] = sacc;
+  __syncthreads();
+  if (tid < 32 && j0 + tid < d) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += gred[q][tid];
+    gsum[j0 + tid] = (first ? 0.0 : gsum[j0 + tid]) + t;
+  }
+}
+void launch_stein_gsum(mivi_ctx *c, int M, double *gsum, int first) {
+  const dim3 grid((c->cfg.d + 31) / 32);
+  if (c->cfg.dtype == MIVI_F32) hipLaunchKernelGGL(k_stein_gsum<float>, grid, dim3(256), 0, c->stream, c->cfg.d, M, (const float *)c->W.p, gsum, first);
+  else hipLaunchKernelGGL(k_stein_gsum<double>, grid, dim3(256), 0, c->stream, c->cfg.d, M, (const double *)c->W.p, gsum, first);
+}
+// the built-in Gaussian targets' Hessian, a constant: diagonal N(m, diag(sigma^2)): -diag(1 / sigma^2); dense N(m, L L'): -P, P = (L L')^-1
+template <typename T>
+__global__ void k_const_hess(int d, int ldp, const T *istd, const T *prec, T *hess) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)d * d) return;
+  const int i = (int)(e % d), j = (int)(e / d);
+  hess[e] = prec ? -prec[(size_t)j * ldp + i] : (i == j ? -(istd[i] * istd[i]) : T(0));
+}
+void launch_const_hess(mivi_ctx *c, void *hess) {
+  const size_t n = (size_t)c->cfg.d * c->cfg.d;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  const bool dense = c->target == TGT_DENSE_GAUSS;
+  if (c->cfg.dtype == MIVI_F32)
+    hipLaunchKernelGGL(k_const_hess<float>, grid, dim3(256), 0, c->stream, c->cfg.d, c->dP, (const float *)c->t_istd.p, dense ? (const float *)c->t_prec.p : nullptr, (float *)hess);
+  else
+    hipLaunchKernelGGL(k_const_hess<double>, grid, dim3(256), 0, c->stream, c->cfg.d, c->dP, (const double *)c->t_istd.p, dense ? (const double *)c->t_prec.p : nullptr, (double *)hess);
+}
+
 void launch_stein_outer(mivi_ctx *c, int M, void *A, double *gsum, int first, double scale) {
   dim3 grid(c->dP / 32, (c->cfg.d + 31) / 32);
   if (c->cfg.dtype == MIVI_F32)

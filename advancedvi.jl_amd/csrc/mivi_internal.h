@@ -264,6 +264,8 @@ struct mivi_ctx {
   mivi_logdensity_and_gradient_fn cb_grad = nullptr;
   mivi_logdensity_fn cb_value = nullptr;
   void *cb_user = nullptr;
+  mivi_logdensity_gradient_and_hessian_fn cb_hess = nullptr;   // second-order plugin (mivi_gauss_expected_grad_hess2)
+  void *cb_hess_user = nullptr;
   std::vector<char> h_Z, h_G, h_ell;
 
   // work buffers (sized for `cap_M` samples)
@@ -346,6 +348,8 @@ void launch_rt_from_z(mivi_ctx *c, int M);
 void launch_fr_stl(mivi_ctx *c, const void *params, int M, const void *rhs = nullptr, void *out = nullptr);
 void launch_stein_outer(mivi_ctx *c, int M, void *A, double *gsum, int first, double scale);
 void launch_stein_finish(mivi_ctx *c, double n, const double *gsum, const double *ell_sum, const void *ell_single, void *grad, void *logpi_avg);
+void launch_stein_gsum(mivi_ctx *c, int M, double *gsum, int first);   // gsum (+)= G 1 (the second-order branch: no eps G^T product)
+void launch_const_hess(mivi_ctx *c, void *hess);                      // hess = the built-in Gaussian targets' constant Hessian
 int fr_sample_blocks(const mivi_ctx *c, int M);
 int fr_dense_blocks(const mivi_ctx *c, int M);
 int eps_blocks(const mivi_ctx *c, int M);

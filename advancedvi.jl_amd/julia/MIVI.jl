@@ -338,9 +338,32 @@ struct MIVITarget{P}
     state::MIVIState
 end
 LogDensityProblems.dimension(t::MIVITarget) = LogDensityProblems.dimension(t.prob)
-LogDensityProblems.capabilities(::Type{<:MIVITarget}) = LogDensityProblems.LogDensityOrder{1}()
+LogDensityProblems.capabilities(::Type{MIVITarget{P}}) where {P} = LogDensityProblems.capabilities(P)   # the wrapped problem's order decides the branch
 LogDensityProblems.logdensity(t::MIVITarget, x) = LogDensityProblems.logdensity(t.prob, x)
 LogDensityProblems.logdensity_and_gradient(t::MIVITarget, x) = LogDensityProblems.logdensity_and_gradient(t.prob, x)
+LogDensityProblems.logdensity_gradient_and_hessian(t::MIVITarget, x) = LogDensityProblems.logdensity_gradient_and_hessian(t.prob, x)
+
+# Second-order plugin (src/algorithms/gauss_expected_grad_hess.jl:61-83): ell, G and the SUM of the Hessians over the columns of Z
+function hessian_callback(user::Ptr{Cvoid}, Zp::Ptr{Cvoid}, d::Int32, M::Int32, ellp::Ptr{Cvoid}, Gp::Ptr{Cvoid}, Hp::Ptr{Cvoid})::Int32
+    st = unsafe_pointer_to_objref(user)::MIVIState
+    T = st.T
+    Z = unsafe_wrap(Array, Ptr{T}(Zp), (Int(d), Int(M)))
+    ell = unsafe_wrap(Array, Ptr{T}(ellp), (Int(M),))
+    G = unsafe_wrap(Array, Ptr{T}(Gp), (Int(d), Int(M)))
+    H = unsafe_wrap(Array, Ptr{T}(Hp), (Int(d), Int(d)))
+    try
+        fill!(H, zero(T))
+        for m in 1:M
+            l, g, h = LogDensityProblems.logdensity_gradient_and_hessian(st.problem, view(Z, :, m))
+            ell[m] = l
+            G[:, m] .= g
+            H .+= h
+        end
+        return Int32(0)
+    catch
+        return Int32(1)
+    end
+end
 
 function AdvancedVI.gaussian_expectation_gradient_and_hessian!(
     rng::Random.AbstractRNG, q::MvLocationScale{<:LinearAlgebra.AbstractTriangular,<:Normal}, n_samples::Int,
@@ -348,9 +371,19 @@ function AdvancedVI.gaussian_expectation_gradient_and_hessian!(
     st = t.state
     params, _ = Optimisers.destructure(q)
     logpi = Ref{T}(zero(T))
-    check(st.ctx, ccall((:mivi_gauss_expected_grad_hess_host, libmivi), Int32,
-                        (Ptr{Cvoid}, Ptr{T}, UInt64, Int32, Ref{T}, Ptr{T}, Ptr{T}),
-                        st.ctx, params, st.estimate_idx, n_samples, logpi, grad_buf, hess_buf))   # hess_buf: dense column-major
+    if LogDensityProblems.capabilities(typeof(t.prob)) <= LogDensityProblems.LogDensityOrder{1}()   # the reference's branch test (:31-32)
+        check(st.ctx, ccall((:mivi_gauss_expected_grad_hess_host, libmivi), Int32,
+                            (Ptr{Cvoid}, Ptr{T}, UInt64, Int32, Ref{T}, Ptr{T}, Ptr{T}),
+                            st.ctx, params, st.estimate_idx, n_samples, logpi, grad_buf, hess_buf))   # hess_buf: dense column-major
+    else   # second-order capability: the sample average of the Hessians (native Gaussian targets: their constant Hessian)
+        if !st.native
+            hcb = @cfunction(hessian_callback, Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}))
+            check(st.ctx, ccall((:mivi_set_target_hess_callback, libmivi), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Any), st.ctx, hcb, st))
+        end
+        check(st.ctx, ccall((:mivi_gauss_expected_grad_hess2_host, libmivi), Int32,
+                            (Ptr{Cvoid}, Ptr{T}, UInt64, Int32, Ref{T}, Ptr{T}, Ptr{T}),
+                            st.ctx, params, st.estimate_idx, n_samples, logpi, grad_buf, hess_buf))
+    end
     st.estimate_idx += 1
     return logpi[], grad_buf, hess_buf
 end

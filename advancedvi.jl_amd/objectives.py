@@ -190,7 +190,9 @@ def gaussian_expectation_gradient_and_hessian_(rng, q: MvLocationScale, n_sample
     src/algorithms/gauss_expected_grad_hess.jl:20-60, the Stein / Price-identity branch (what a target with
     `logdensity_and_gradient` takes, :32-60).  `grad_buf` (d) / `hess_buf` (d*d, column-major) are device tensors
     that are overwritten, or None to allocate.  Returns (logpi_avg: float, grad (d), hess (d, d)) -- `hess` is not
-    symmetrised, like the reference's.  Second-order targets take this same branch (there is no plugin Hessian ABI)."""
+    symmetrised, like the reference's.  A target whose `capabilities` exceed LogDensityOrder(1) -- a plugin with
+    `logdensity_gradient_and_hessian`, or a built-in Gaussian problem constructed with order=2 -- takes the reference's second-order
+    branch (:61-83): the sample average of the Hessians, no Stein identity (mivi_gauss_expected_grad_hess2)."""
     if not isinstance(q, MvLocationScale) or q.family != 1:
         raise TypeError("gaussian_expectation_gradient_and_hessian_ expects a Gaussian with a triangular scale "
                         "(gauss_expected_grad_hess.jl:22)")
@@ -201,7 +203,9 @@ def gaussian_expectation_gradient_and_hessian_(rng, q: MvLocationScale, n_sample
         ctx.set_problem(prob)
     try:
         params, _ = destructure(q)
-        logpi, g, H = ctx.gauss_expected_grad_hess(params, rng.next_index(), int(n_samples), grad_buf, hess_buf)
+        from .problems import LogDensityOrder, capabilities
+        second = LogDensityOrder(1) < capabilities(prob)          # (the reference's branch test, gauss_expected_grad_hess.jl:31-32)
+        logpi, g, H = ctx.gauss_expected_grad_hess(params, rng.next_index(), int(n_samples), grad_buf, hess_buf, second_order=second)
         return float(logpi.item()), g, H
     finally:
         if _ctx is None:

@@ -37,29 +37,31 @@ def capabilities(prob) -> LogDensityOrder:
 class DiagNormalProblem:
     """MvNormal(mean, Diagonal(std.^2)) -- test/models/normal.jl:56-75, bench/benchmarks.jl:43-47."""
 
-    def __init__(self, mean, std):
+    def __init__(self, mean, std, order=1):
         self.mean = np.asarray(mean)
         self.std = np.asarray(std)
+        self.order = int(order)   # 2: declares logdensity_gradient_and_hessian (constant Hessian -1 / std^2)
 
     def dimension(self):
         return self.mean.shape[0]
 
     def capabilities(self):
-        return LogDensityOrder(1)
+        return LogDensityOrder(self.order)
 
 
 class DenseNormalProblem:
     """MvNormal(mean, L L') -- test/models/normal.jl:36-54 (`normal_fullrank`)."""
 
-    def __init__(self, mean, L):
+    def __init__(self, mean, L, order=1):
         self.mean = np.asarray(mean)
         self.L = np.tril(np.asarray(L))
+        self.order = int(order)   # 2: declares logdensity_gradient_and_hessian (constant Hessian -(L L')^-1)
 
     def dimension(self):
         return self.mean.shape[0]
 
     def capabilities(self):
-        return LogDensityOrder(1)
+        return LogDensityOrder(self.order)
 
 
 class LogRegProblem:

@@ -190,11 +190,28 @@ mivi_status_t mivi_estimate_objective_host(mivi_ctx_t *ctx, const void *params_h
  *   grad_dev      T[d]    <- mean_b grad logpi(z_b)
  *   hess_dev      T[d*d]  <- C' \ mean_b(u_b grad logpi(z_b)')      column-major, NOT symmetrised (as the reference)
  * n_samples <= 0 means cfg.n_mc; any n_samples is processed in chunks of 16384 columns.  Asynchronous for built-in
- * targets.  The second-order branch (sample average of plugin Hessians, :61-83) has no counterpart here. */
+ * targets.  The second-order branch is mivi_gauss_expected_grad_hess2 below. */
 mivi_status_t mivi_gauss_expected_grad_hess(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx,
                                             int32_t n_samples, void *logpi_avg_dev, void *grad_dev, void *hess_dev);
 mivi_status_t mivi_gauss_expected_grad_hess_host(mivi_ctx_t *ctx, const void *params_host, uint64_t estimate_idx,
                                                  int32_t n_samples, void *logpi_avg_host, void *grad_host, void *hess_host);
+
+/* The second-order branch of the same function (src/algorithms/gauss_expected_grad_hess.jl:61-83; the reference's test runs both
+ * capabilities, test/general/gauss_expected_grad_hess.jl:45-56): for a target with second-order capability
+ * (LogDensityProblems.logdensity_gradient_and_hessian) the Hessian estimate is the SAMPLE AVERAGE of the Hessians at z_b = C u_b + m
+ * (the same eps stream as the first-order branch), no Stein identity and no solve:
+ *   logpi_avg <- mean_b logpi(z_b)     grad <- mean_b grad logpi(z_b)     hess <- mean_b hess logpi(z_b)   (d x d column-major)
+ * Targets with a Hessian: the built-in diagonal / dense Gaussians (constant Hessians -1/sigma^2 / -P: written exactly), or a plugin
+ * that registered a batched Hessian callback next to its order-1 callback -- Z (d x M) in; ell (M), G (d x M) and
+ * Hsum (d x d, column-major) = the SUM over the M columns of hess logpi(z_m) out, host buffers, non-zero return aborts.
+ * Any other target: MIVI_ERR_UNSUPPORTED (use the first-order entry, as the reference does for order-1 problems). */
+typedef int32_t (*mivi_logdensity_gradient_and_hessian_fn)(void *user, const void *Z_host, int32_t d, int32_t M,
+                                                           void *ell_host, void *G_host, void *Hsum_host);
+mivi_status_t mivi_set_target_hess_callback(mivi_ctx_t *ctx, mivi_logdensity_gradient_and_hessian_fn fn, void *user);
+mivi_status_t mivi_gauss_expected_grad_hess2(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx,
+                                             int32_t n_samples, void *logpi_avg_dev, void *grad_dev, void *hess_dev);
+mivi_status_t mivi_gauss_expected_grad_hess2_host(mivi_ctx_t *ctx, const void *params_host, uint64_t estimate_idx,
+                                                  int32_t n_samples, void *logpi_avg_host, void *grad_host, void *hess_host);
 
 /* ---- multi-GPU: shard the MC batch, all-reduce the partials, finalize -------------------------- *
  * No counterpart in the reference (single task).  partials_dev: T[partials_len] un-normalised sums over

@@ -163,6 +163,9 @@ class DiagNormalTarget:
     def logdensity_and_gradient(self, z):
         return self.logdensity(z), -(z - self.mean) / (self.std ** 2)
 
+    def logdensity_gradient_and_hessian(self, z):
+        return self.logdensity(z), -(z - self.mean) / (self.std ** 2), -np.diag(1.0 / self.std ** 2)
+
 
 class DenseNormalTarget:
     """MvNormal(mean, L L'), `TestNormal` with a dense covariance: test/models/normal.jl:2-11, 36-54."""
@@ -183,6 +186,9 @@ class DenseNormalTarget:
 
     def logdensity_and_gradient(self, z):
         return self.logdensity(z), -self.prec @ (z - self.mean)
+
+    def logdensity_gradient_and_hessian(self, z):
+        return self.logdensity(z), -self.prec @ (z - self.mean), -self.prec
 
 
 def _log1pexp(x):
@@ -389,6 +395,25 @@ def gaussian_expectation_gradient_and_hessian(q: MvLocationScale, prob, u: np.nd
         grad += g
         hess += np.outer(u[:, b], g)
     hess = np.linalg.solve(C.T, hess)
+    return float(logpi_avg), grad, hess
+
+
+def gaussian_expectation_gradient_and_hessian_order2(q: MvLocationScale, prob, u: np.ndarray):
+    """gaussian_expectation_gradient_and_hessian!, second-order branch (targets with `logdensity_gradient_and_hessian`):
+    src/algorithms/gauss_expected_grad_hess.jl:61-83.  z = rand(rng, q, n) = C u + m for the standard-normal draws `u` (d x n);
+    per sample the loop accumulates logpi / n, grad / n and hess / n -- the naive sample averages, no Stein identity."""
+    if q.is_meanfield:
+        raise TypeError("the reference method takes a triangular scale (gauss_expected_grad_hess.jl:22)")
+    d, n = u.shape
+    z = np.tril(q.scale) @ u + q.location[:, None]
+    logpi_avg = 0.0
+    grad = np.zeros(d)
+    hess = np.zeros((d, d))
+    for b in range(n):
+        lp, g, h = prob.logdensity_gradient_and_hessian(z[:, b])
+        logpi_avg += lp / n
+        grad += np.asarray(g, dtype=np.float64) / n
+        hess += np.asarray(h, dtype=np.float64) / n
     return float(logpi_avg), grad, hess
 
 

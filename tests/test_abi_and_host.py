@@ -121,7 +121,7 @@ def test_julia_wrapper_ccalls_match_the_header():
         seen.add(name)
     for must in ("mivi_create", "mivi_destroy", "mivi_set_target_callback", "mivi_estimate_gradient_host", "mivi_estimate_objective_host",
                  "mivi_set_bijector_stacked", "mivi_comm_unique_id", "mivi_comm_init", "mivi_estimate_gradient_dist",
-                 "mivi_gauss_expected_grad_hess_host", "mivi_logreg_select_rows", "mivi_optimize_loop", "mivi_set_target_diag_gauss",
+                 "mivi_gauss_expected_grad_hess_host", "mivi_gauss_expected_grad_hess2_host", "mivi_set_target_hess_callback", "mivi_logreg_select_rows", "mivi_optimize_loop", "mivi_set_target_diag_gauss",
                  "mivi_set_target_dense_gauss", "mivi_set_target_funnel", "mivi_comm_enable_p2p", "mivi_estimate_gradient_dist_n"):
         assert must in seen, f"MIVI.jl does not bind {must}"
 

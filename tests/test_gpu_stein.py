@@ -152,3 +152,95 @@ def test_consecutive_calls_use_the_speculated_eps():
 def test_beyond_the_mfma_solve():
     """d > 2304 (f32): the blocked MFMA solve no longer fits LDS; the column-block fallback takes over."""
     run_case(2400, 8, "diag", np.float32)
+
+
+# ---- the second-order branch (gauss_expected_grad_hess.jl:61-83): sample average of the Hessians -------------------------------------
+class QuarticPlugin:
+    """A second-order plugin whose Hessian depends on z: logpi(z) = -1/2 z' S z - 1/4 sum_i a_i z_i^4 (host-callback route)."""
+
+    def __init__(self, S, a):
+        self.S, self.a = np.asarray(S, np.float64), np.asarray(a, np.float64)
+
+    def dimension(self):
+        return self.S.shape[0]
+
+    def capabilities(self):
+        return avi.LogDensityOrder(2)
+
+    def logdensity(self, z):
+        z = np.asarray(z, np.float64)
+        return float(-0.5 * z @ self.S @ z - 0.25 * np.sum(self.a * z ** 4))
+
+    def logdensity_and_gradient(self, z):
+        z = np.asarray(z, np.float64)
+        return self.logdensity(z), -self.S @ z - self.a * z ** 3
+
+    def logdensity_gradient_and_hessian(self, z):
+        z = np.asarray(z, np.float64)
+        return self.logdensity(z), -self.S @ z - self.a * z ** 3, -self.S - np.diag(3.0 * self.a * z ** 2)
+
+
+def run_order2(d, M, kind, dtype, n_samples=0, idx=6):
+    rng = np.random.default_rng(7 + d + 5 * M)
+    q, q_o = make_family(rng, d, avi.FULLRANK, dtype)
+    if kind == "quartic":
+        A = rng.normal(size=(d, d)) / np.sqrt(d)
+        tgt = QuarticPlugin(A @ A.T + np.eye(d), rng.uniform(0.1, 0.5, size=d))
+        prob = tgt
+    else:
+        prob, tgt = make_problem(rng, kind, d, dtype)
+        prob.order = 2                                     # the built-in Gaussian declares its (constant) Hessian
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(dtype, avi.FULLRANK, d, M, 0, SEED)
+    ctx.set_problem(prob)
+    n = n_samples or M
+    if n == M:
+        _, eps = ctx.sample(params, idx)
+        eps = eps.cpu().numpy().astype(np.float64)
+    else:
+        eps = O.philox_normal(SEED, idx, d, 0, n, f64=(dtype == np.float64))
+    logpi, g, H = ctx.gauss_expected_grad_hess(params, idx, n_samples, second_order=True)
+    lp_ref, g_ref, H_ref = O.gaussian_expectation_gradient_and_hessian_order2(q_o, tgt, eps)
+    tv, tg, th = TOL[dtype]
+    if n != M and dtype == np.float32:
+        tv, tg, th = 3 * tv, 3 * tg, 3 * th
+    assert abs(float(logpi.item()) - lp_ref) <= tv * max(abs(lp_ref), 1.0)
+    assert np.linalg.norm(g.cpu().numpy() - g_ref) <= tg * max(np.linalg.norm(g_ref), 1.0)
+    assert np.linalg.norm(H.cpu().numpy() - H_ref) <= th * max(np.linalg.norm(H_ref), 1.0)
+    ctx.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["diag", "dense", "quartic"])
+@pytest.mark.parametrize("d,M", [(2, 3), (33, 17), (64, 128), (130, 257)])
+def test_second_order_branch_matches_the_oracle(kind, d, M, dtype):
+    run_order2(d, M, kind, dtype)
+
+
+def test_second_order_branch_in_chunks_and_at_the_north_star_size():
+    run_order2(16, 64, "quartic", np.float64, n_samples=16384 + 500)     # two chunks through the plugin
+    run_order2(64, 128, "dense", np.float32, n_samples=2 * 16384)         # two chunks, built-in target
+    run_order2(1024, 256, "diag", np.float32)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_reference_known_answer_with_second_order_capability(dtype):
+    """test/general/gauss_expected_grad_hess.jl:45-56 with LogDensityOrder{2}: the same quadratic target, the Hessian estimate is the
+    sample average of -S (here exactly -S), E grad = -S mu; atol 1e-1 as in the reference."""
+    S = np.array([[2.0, -0.1], [-0.1, 2.0]])
+    q = avi.FullRankGaussian(np.ones(2, dtype), np.diag(np.full(2, 0.1)).astype(dtype))
+    for prob in (avi.DenseNormalProblem(np.zeros(2, dtype), np.linalg.cholesky(np.linalg.inv(S)).astype(dtype), order=2),
+                 QuarticPlugin(S, np.zeros(2))):
+        lp, g, H = avi.gaussian_expectation_gradient_and_hessian_(avi.PhiloxRNG(), q, 10**5, None, None, prob)
+        assert np.allclose(g.cpu().numpy(), -S @ np.ones(2), atol=1e-1)
+        assert np.allclose(H.cpu().numpy(), -S, atol=1e-6 if dtype == np.float64 else 1e-5)
+        assert np.isfinite(lp)
+
+
+def test_second_order_branch_needs_a_hessian():
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, 8, 16, 0, SEED)
+    ctx.set_problem(avi.FunnelProblem(8, 1.5))
+    q = avi.FullRankGaussian(np.zeros(8, np.float32), np.eye(8, dtype=np.float32))
+    with pytest.raises(avi.MiviError, match="no Hessian"):
+        ctx.gauss_expected_grad_hess(avi.destructure(q)[0], 0, second_order=True)
+    ctx.close()

@@ -1,5 +1,8 @@
 # developer: cost of the synchronisation bracket around an isolated 20-estimate call (stream sync / device sync / both)
-import numpy as np, torch, sys, time, os
+import numpy as np, torch, sys, time, os, ctypes
+if os.environ.get('SPIN'):
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so'))
+    print('hipSetDeviceFlags ->', hip.hipSetDeviceFlags(ctypes.c_uint(int(os.environ['SPIN']))))
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
 import advancedvi_jl_amd as avi
 from tests.helpers import SEED
