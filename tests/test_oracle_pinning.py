@@ -248,6 +248,40 @@ def test_gaussian_expectation_gradient_and_hessian_known_answer():
         O.gaussian_expectation_gradient_and_hessian(O.MvLocationScale(np.ones(2), np.ones(2)), TestQuad(S), u)
 
 
+def test_gaussian_expectation_gradient_and_hessian_known_answer_second_order():
+    """test/general/gauss_expected_grad_hess.jl:45-56 with LogDensityOrder{2}: the same TestQuad also provides
+    logdensity_gradient_and_hessian (:16-20 there: (lp, -S x, -S)); the second-order branch (src :61-83) averages the Hessians:
+    E hess = -S exactly, E grad = -S mu within atol 1e-1; the gradient and logpi averages equal the first-order branch's on the
+    same draws."""
+    class TestQuad2:
+        def __init__(self, S):
+            self.S = S
+
+        def logdensity_and_gradient(self, x):
+            return float(-x @ self.S @ x / 2), -self.S @ x
+
+        def logdensity_gradient_and_hessian(self, x):
+            return float(-x @ self.S @ x / 2), -self.S @ x, -self.S
+
+    S = np.array([[2.0, -0.1], [-0.1, 2.0]])
+    q = O.MvLocationScale(np.ones(2), np.diag([0.1, 0.1]))
+    u = O.philox_normal(SEED, 0, 2, 0, 200000, f64=True)
+    lp, g, H = O.gaussian_expectation_gradient_and_hessian_order2(q, TestQuad2(S), u)
+    assert np.allclose(g, -S @ np.ones(2), atol=1e-1)
+    assert np.allclose(H, -S, rtol=1e-12)
+    lp1, g1, _ = O.gaussian_expectation_gradient_and_hessian(q, TestQuad2(S), u)
+    assert abs(lp - lp1) <= 1e-12 * abs(lp1) and np.allclose(g, g1, rtol=1e-12)
+    # the oracle's own Gaussian targets carry the Hessians the built-in device targets write
+    rng = np.random.default_rng(2)
+    dn = O.DenseNormalTarget(rng.normal(size=3), np.tril(rng.normal(size=(3, 3))) + 2 * np.eye(3))
+    x, h = rng.normal(size=3), 1e-5
+    fd = np.array([(dn.logdensity_and_gradient(x + h * e)[1] - dn.logdensity_and_gradient(x - h * e)[1]) / (2 * h) for e in np.eye(3)])
+    assert np.allclose(dn.logdensity_gradient_and_hessian(x)[2], fd, rtol=1e-6, atol=1e-8)
+    dg = O.DiagNormalTarget(rng.normal(size=3), rng.uniform(0.5, 2, size=3))
+    fd = np.array([(dg.logdensity_and_gradient(x + h * e)[1] - dg.logdensity_and_gradient(x - h * e)[1]) / (2 * h) for e in np.eye(3)])
+    assert np.allclose(dg.logdensity_gradient_and_hessian(x)[2], fd, rtol=1e-6, atol=1e-8)
+
+
 def test_stacked_bijector_target_chain_rule_and_the_funnel_identity():
     """oracle.StackedBijectorTarget (README.md:76-82,91-119): gradient == central finite differences of its own value, and
     wrapping the constrained funnel with exp on coordinate 0 reproduces FunnelStackedTarget (value and gradient)."""
