@@ -231,6 +231,7 @@ loop_rule(o::Optimisers.Adam) = (Int32(1), Float64(o.eta), Float64(o.beta[1]), F
 loop_rule(::Any) = nothing
 loop_op(::AdvancedVI.IdentityOperator) = (Int32(0), 0.0)
 loop_op(o::AdvancedVI.ClipScale) = (Int32(1), Float64(o.epsilon))
+loop_op(::AdvancedVI.ProximalLocationScaleEntropy) = (Int32(2), 0.0)   # KLMinRepGradProxDescent (constructors.jl:122-157); step size from the rule
 loop_op(::Any) = nothing
 loop_avg(::AdvancedVI.NoAveraging) = (Int32(0), 0.0)
 loop_avg(a::AdvancedVI.PolynomialAveraging) = (Int32(1), Float64(a.eta))
@@ -241,7 +242,8 @@ const DEVICE_LOOP_CHUNK = 256     # iterations per mivi_optimize_loop call (boun
 function AdvancedVI.optimize(rng::Random.AbstractRNG, alg::KLMinRepGradDescent{<:RepGradELBO,<:AutoMIVI}, max_iter::Int, prob, q_init,
                              objargs...; show_progress::Bool = true, state = nothing, callback = nothing, kwargs...)
     codes = (loop_rule(alg.optimizer), loop_op(alg.operator), loop_avg(alg.averager))
-    fast = callback === nothing && isempty(objargs) && prob isa NativeTarget && q_init isa MvLocationScale && all(!isnothing, codes)
+    fast = callback === nothing && isempty(objargs) && prob isa NativeTarget && q_init isa MvLocationScale && all(!isnothing, codes) &&
+           !(codes[2][1] == 2 && codes[1][1] != 0)   # (the proximal operator takes its step size from Descent: rules.jl has no Adam method for it)
     if !fast   # the reference's own loop (host-driven `step`, this module's estimate_gradient!)
         return invoke(AdvancedVI.optimize, Tuple{Random.AbstractRNG,AdvancedVI.AbstractVariationalAlgorithm,Int,Any,Any,Vararg{Any}},
                       rng, alg, max_iter, prob, q_init, objargs...; show_progress, state, callback, kwargs...)
