@@ -270,6 +270,7 @@ struct MfLoopArgs {
   double eta, clip_eps, b1, b2, adam_eps;
   double *hist;                 // [n_steps][4][nblk]
   T *grad_out;                  // rule < 0 (estimates at fixed parameters): every estimate writes its gradient here
+  T *lane_scratch;              // rule < 0 with estimate lanes (gridDim.y > 1): [lanes][2 d], the gradients of every estimate but the last
 };
 
 // RULE is a template parameter: the update rules' scalars (eta, betas, clip, Adam state) would otherwise all be live across the
@@ -310,7 +311,13 @@ __global__ __launch_bounds__(256) void k_mf_sgd_loop(MfLoopArgs<T> a) {
     st_m = a.opt_state[(myrow < 4 ? 0 : d) + myi];
     st_v = a.opt_state[2 * d + (myrow < 4 ? 0 : d) + myi];
   }
-  for (int t = 0; t < n_steps; ++t) {
+  // Estimates at fixed parameters (RULE < 0) are independent: lane blockIdx.y of gridDim.y walks estimates le, le + E, ... -- a row-quad's
+  // workgroup is ONE wave per SIMD, and an iteration is a latency chain (Philox, Box-Muller, reductions, one barrier); E of them per CU
+  // cover each other (C2: 1.16 -> 0.73 us per estimate with 16 lanes, C5: 1.62 -> 0.58 with 32).  Every estimate runs the
+  // same code on the same indices: bitwise unchanged.
+  const int le = RULE < 0 ? (int)blockIdx.y : 0, E = RULE < 0 ? (int)gridDim.y : 1;
+  int it = 0;
+  for (int t = le; t < n_steps; t += E, ++it) {
     if (rule == 1 && (t & 255) == 0) {
       __syncthreads();
       adam_bias<T>(a.t0 + t + tid + 1, a.b1, a.b2, cc_tab[tid][0], cc_tab[tid][1]);
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(256) void k_mf_sgd_loop(MfLoopArgs<T> a) {
         sWe[r] += w * er;
       }
     }
-    T(*xb)[4] = xw[t & 1];
+    T(*xb)[4] = xw[it & 1];
     {
       T v[10];
 #pragma unroll
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(256) void k_mf_sgd_loop(MfLoopArgs<T> a) {
     }
     // log-determinant / positivity partial of this workgroup's rows, the same association as k_mf_main: (l0 + l1) + (l2 + l3)
     // (estimates at fixed parameters: the parameters do not move, computed once)
-    if (rule >= 0 || t == 0) {
+    if (rule >= 0 || it == 0) {
       double lgs[4], bads[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -384,7 +391,8 @@ __global__ __launch_bounds__(256) void k_mf_sgd_loop(MfLoopArgs<T> a) {
         for (int j = 0; j < 4; ++j) trow += (double)xb[myrow][j];
         const T sgv = (myrow & 3) == 0 ? sg[0] : (myrow & 3) == 1 ? sg[1] : (myrow & 3) == 2 ? sg[2] : sg[3];
         const T g = mf_grad_entry<T>(trow, invM, myrow >= 4, direct, (double)sgv);
-        if (row_ok) a.grad_out[(myrow < 4 ? 0 : d) + myi] = g;
+        T *go = (E > 1 && t != n_steps - 1) ? a.lane_scratch + (size_t)le * 2 * d : a.grad_out;   // (the batch's last estimate: the caller's buffer)
+        if (row_ok) go[(myrow < 4 ? 0 : d) + myi] = g;
       }
       continue;
     }
@@ -449,9 +457,22 @@ __global__ __launch_bounds__(256) void k_mf_loop_value(int d, int nblk, int M_lo
   }
 }
 
+// Estimate lanes of the launch-free batches at fixed parameters: enough workgroups per row-quad for about sixteen waves per SIMD's worth of
+// work in flight (a row-quad's workgroup is 4 waves -- or ONE for the funnel shard with n_mc <= 64 -- on a chip of 1024 SIMDs), at most 32,
+// at most n_steps.  Measured (C2 / C5, estimates per second): 1 lane 0.86 M / 0.62 M, 4 / 8 lanes 1.22 M / 1.62 M, 8 / 16: 1.34 M / 1.69 M,
+// 16 / 32: 1.38 M / 1.71 M.
+int mf_loop_lanes(const mivi_ctx *c, int n_steps) {
+  const int d4 = (c->cfg.d + 3) / 4;
+  const int waves = (c->target == TGT_FUNNEL && c->cfg.n_mc <= 64) ? 1 : 4;
+  int e = 16384 / (d4 * waves > 0 ? d4 * waves : 1);
+  if (e > 32) e = 32;
+  if (e > n_steps) e = n_steps;
+  return e < 1 ? 1 : e;
+}
+
 template <typename T>
 static void mf_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule,
-                             double eta, double clip_eps, double *hist, double *elbo, void *grad_out) {
+                             double eta, double clip_eps, double *hist, double *elbo, void *grad_out, void *lane_scratch) {
   MfLoopArgs<T> a;
   a.d = c->cfg.d;
   a.M = c->cfg.n_mc;
@@ -474,8 +495,9 @@ static void mf_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint64_
   a.adam_eps = 1e-8;
   a.hist = hist;
   a.grad_out = (T *)grad_out;
+  a.lane_scratch = (T *)lane_scratch;
   const int d4 = (a.d + 3) / 4;
-  if (rule < 0) hipLaunchKernelGGL((k_mf_sgd_loop<T, -1>), dim3(d4), dim3(256), 0, c->stream, a);
+  if (rule < 0) hipLaunchKernelGGL((k_mf_sgd_loop<T, -1>), dim3(d4, lane_scratch ? mf_loop_lanes(c, n_steps) : 1), dim3(256), 0, c->stream, a);
   else if (rule == 0) hipLaunchKernelGGL((k_mf_sgd_loop<T, 0>), dim3(d4), dim3(256), 0, c->stream, a);
   else hipLaunchKernelGGL((k_mf_sgd_loop<T, 1>), dim3(d4), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_mf_loop_value<T>, dim3(n_steps), dim3(256), 0, c->stream, a.d, d4, a.M, a.M_total, a.ent_kind,
@@ -484,10 +506,11 @@ static void mf_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint64_
 
 // rule 0 Descent / 1 Adam: n_steps SGD iterations;  rule -1: n_steps estimates at fixed parameters, the last one's gradient
 // into grad_out (what mivi_estimate_gradient_n returns).  elbo[t] of every step / estimate either way.
+// lane_scratch (rule < 0): mf_loop_lanes(c, n_steps) * 2 d elements of T, or nullptr = one lane.
 void launch_mf_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule,
-                        double eta, double clip_eps, double *hist, double *elbo, void *grad_out) {
-  if (c->cfg.dtype == MIVI_F32) mf_sgd_loop_impl<float>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo, grad_out);
-  else mf_sgd_loop_impl<double>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo, grad_out);
+                        double eta, double clip_eps, double *hist, double *elbo, void *grad_out, void *lane_scratch) {
+  if (c->cfg.dtype == MIVI_F32) mf_sgd_loop_impl<float>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo, grad_out, lane_scratch);
+  else mf_sgd_loop_impl<double>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo, grad_out, lane_scratch);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -508,6 +531,7 @@ struct MfFunnelLoopArgs {
   int m_offset, M_total, ent_kind;
   double *hist;        // [n_steps][6][nblk]
   T *grad_out;         // rows >= 1 of every estimate (row 0: the value kernel)
+  T *lane_scratch;     // estimate lanes (gridDim.y > 1): [lanes][2 d], the gradient rows of every estimate but the last
 };
 
 template <typename T, int NW>
@@ -543,7 +567,9 @@ __global__ __launch_bounds__(64 * NW) void k_mf_funnel_loop(MfFunnelLoopArgs<T> 
   const int myi = 4 * rq + (myrow & 3);
   const bool row_ok = myi < d && myi != 0;   // (row 0: the value kernel)
   const T sgv = (myrow & 3) == 0 ? sg[0] : (myrow & 3) == 1 ? sg[1] : (myrow & 3) == 2 ? sg[2] : sg[3];
-  for (int t = 0; t < a.n_steps; ++t) {
+  const int le = blockIdx.y, E = gridDim.y;   // estimate lanes: see k_mf_sgd_loop
+  int it = 0;
+  for (int t = le; t < a.n_steps; t += E, ++it) {
     T sW[4] = {0, 0, 0, 0}, sWe[4] = {0, 0, 0, 0};
     T s_ell = 0, s_he = 0, sA = 0, sB = 0;
     for (int m = tid; m < a.M; m += NT) {
@@ -565,7 +591,7 @@ __global__ __launch_bounds__(64 * NW) void k_mf_funnel_loop(MfFunnelLoopArgs<T> 
     v[9] = wave_total63(s_he);
     v[10] = wave_total63(sA);
     v[11] = wave_total63(sB);
-    T(*xb)[4] = xw[t & 1];
+    T(*xb)[4] = xw[it & 1];
     if (NW > 1) {
       if (lane == 63) {
 #pragma unroll
@@ -584,7 +610,8 @@ __global__ __launch_bounds__(64 * NW) void k_mf_funnel_loop(MfFunnelLoopArgs<T> 
 #pragma unroll
       for (int j = 0; j < NW; ++j) trow += (double)xb[myrow][j];
       const T g = mf_grad_entry<T>(trow, invM, myrow >= 4, direct, (double)sgv);
-      if (row_ok) a.grad_out[(myrow < 4 ? 0 : d) + myi] = g;
+      T *go = (E > 1 && t != a.n_steps - 1) ? a.lane_scratch + (size_t)le * 2 * d : a.grad_out;
+      if (row_ok) go[(myrow < 4 ? 0 : d) + myi] = g;
     } else if (tid >= 8 && tid < 14) {
       const int k = tid - 8;   // 0 ell, 1 he, 2 log sigma, 3 bad, 4 A, 5 B
       double hv;
@@ -654,7 +681,7 @@ __global__ __launch_bounds__(256) void k_mf_funnel_loop_value(MfFunnelValueArgs<
 
 template <typename T>
 static void mf_funnel_loop_impl(mivi_ctx *c, const void *params, uint64_t idx0, int n_steps, double *hist, double *elbo, void *scratch,
-                                void *value, void *grad) {
+                                void *value, void *grad, void *lane_scratch) {
   MfFunnelLoopArgs<T> a;
   a.d = c->cfg.d; a.M = c->cfg.n_mc; a.n_steps = n_steps;
   a.params = (const T *)params;
@@ -662,9 +689,10 @@ static void mf_funnel_loop_impl(mivi_ctx *c, const void *params, uint64_t idx0, 
   a.m_offset = c->cfg.m_offset; a.M_total = c->M_total; a.ent_kind = c->cfg.entropy;
   a.hist = hist;
   a.grad_out = (T *)grad;
-  const int d4 = (a.d + 3) / 4;
-  if (a.M <= 64) hipLaunchKernelGGL((k_mf_funnel_loop<T, 1>), dim3(d4), dim3(64), 0, c->stream, a);
-  else hipLaunchKernelGGL((k_mf_funnel_loop<T, 4>), dim3(d4), dim3(256), 0, c->stream, a);
+  a.lane_scratch = (T *)lane_scratch;
+  const int d4 = (a.d + 3) / 4, lanes = lane_scratch ? mf_loop_lanes(c, n_steps) : 1;
+  if (a.M <= 64) hipLaunchKernelGGL((k_mf_funnel_loop<T, 1>), dim3(d4, lanes), dim3(64), 0, c->stream, a);
+  else hipLaunchKernelGGL((k_mf_funnel_loop<T, 4>), dim3(d4, lanes), dim3(256), 0, c->stream, a);
   MfFunnelValueArgs<T> v;
   v.d = a.d; v.nblk = d4; v.n_steps = n_steps; v.M = a.M; v.M_total = a.M_total; v.ent_kind = a.ent_kind; v.m_offset = a.m_offset;
   v.params = a.params; v.seed = a.seed; v.idx0 = idx0;
@@ -676,9 +704,9 @@ static void mf_funnel_loop_impl(mivi_ctx *c, const void *params, uint64_t idx0, 
 // n_steps estimates of the fused funnel target at fixed parameters in one launch + one finishing launch (see k_mf_funnel_loop).
 // hist: n_steps * 6 * ceil(d/4) doubles, elbo: n_steps doubles, scratch: n_steps * (d + 2) elements of T.
 void launch_mf_funnel_loop(mivi_ctx *c, const void *params, uint64_t idx0, int n_steps, double *hist, double *elbo, void *scratch,
-                           void *value, void *grad) {
-  if (c->cfg.dtype == MIVI_F32) mf_funnel_loop_impl<float>(c, params, idx0, n_steps, hist, elbo, scratch, value, grad);
-  else mf_funnel_loop_impl<double>(c, params, idx0, n_steps, hist, elbo, scratch, value, grad);
+                           void *value, void *grad, void *lane_scratch) {
+  if (c->cfg.dtype == MIVI_F32) mf_funnel_loop_impl<float>(c, params, idx0, n_steps, hist, elbo, scratch, value, grad, lane_scratch);
+  else mf_funnel_loop_impl<double>(c, params, idx0, n_steps, hist, elbo, scratch, value, grad, lane_scratch);
 }
 
 // rand(rng, q::MvLocationScale{<:Diagonal}, M): Z = mu + sigma .* eps  (location_scale.jl:80-87)

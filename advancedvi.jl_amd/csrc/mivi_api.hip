@@ -1620,9 +1620,11 @@ static mivi_status_t estimate_gradient_chain(mivi_ctx *c, const void *params, ui
     // rows are independent for this family / target pair: all `count` estimates run inside ONE launch (every workgroup
     // keeps its four rows and walks the estimate indices), the value partials are reduced by a second launch
     const size_t hist_doubles = (size_t)count * 4 * (size_t)((c->cfg.d + 3) / 4);
-    if ((s = ensure(c, c->X, ((size_t)count + hist_doubles + 8) * sizeof(double), false))) return s;
+    const size_t lane_bytes = (size_t)mf_loop_lanes(c, count) * 2 * (size_t)c->cfg.d * c->esize;   // the estimate lanes' gradient scratch
+    if ((s = ensure(c, c->X, ((size_t)count + hist_doubles + 8) * sizeof(double) + lane_bytes, false))) return s;
     double *rec = (double *)c->X.p;
-    launch_mf_sgd_loop(c, const_cast<void *>(params), nullptr, idx0, 0, count, -1, 0.0, (double)NAN, rec + count, rec, grad);
+    launch_mf_sgd_loop(c, const_cast<void *>(params), nullptr, idx0, 0, count, -1, 0.0, (double)NAN, rec + count, rec, grad,
+                       (void *)(rec + count + hist_doubles + 8));
     if (c->cfg.dtype == MIVI_F32) hipLaunchKernelGGL(k_neg_value_f32, dim3(1), dim3(1), 0, c->stream, (float *)value, rec + count - 1);
     else hipLaunchKernelGGL(k_neg_value_f64, dim3(1), dim3(1), 0, c->stream, (double *)value, rec + count - 1);
     HIPCHK(c, hipGetLastError());
@@ -1634,10 +1636,12 @@ static mivi_status_t estimate_gradient_chain(mivi_ctx *c, const void *params, ui
     // per-estimate partials to a history buffer, one finishing workgroup per estimate (k_mf_funnel_loop / _value)
     const size_t d4 = (size_t)((c->cfg.d + 3) / 4);
     const size_t nd = (size_t)count * 6 * d4 + (size_t)count + 8;
-    if ((s = ensure(c, c->X, nd * sizeof(double) + (size_t)count * ((size_t)c->cfg.d + 2) * c->esize + 64, false))) return s;
+    const size_t sc_bytes = ((size_t)count * ((size_t)c->cfg.d + 2) * c->esize + 63) & ~(size_t)63;
+    const size_t lane_bytes = (size_t)mf_loop_lanes(c, count) * 2 * (size_t)c->cfg.d * c->esize;   // the estimate lanes' gradient scratch
+    if ((s = ensure(c, c->X, nd * sizeof(double) + sc_bytes + lane_bytes + 64, false))) return s;
     double *hist = (double *)c->X.p, *elbo = hist + (size_t)count * 6 * d4;
     void *scratch = (void *)(elbo + count + 8);
-    launch_mf_funnel_loop(c, params, idx0, count, hist, elbo, scratch, value, grad);
+    launch_mf_funnel_loop(c, params, idx0, count, hist, elbo, scratch, value, grad, (void *)((char *)scratch + sc_bytes));
     HIPCHK(c, hipGetLastError());
     return MIVI_OK;
   }
@@ -2280,7 +2284,8 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
   if (which == 5) {   // the launch-free loop of 100 estimates (mean-field + diagonal target): one launch per rep
     const bool fn5 = !fr && c->target == TGT_FUNNEL && !c->funnel_constrained;
     if (fr || (c->target != TGT_DIAG_GAUSS && !fn5) || c->bij_on || M > 4096) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 5: mean-field + diagonal-Gaussian / fused funnel target, no bijector");
-    if ((s = ensure(c, c->X, ((size_t)100 + 600 * (size_t)((c->cfg.d + 3) / 4) + 16) * sizeof(double) + 100 * ((size_t)c->cfg.d + 2) * c->esize + 64, false))) return s;
+    if ((s = ensure(c, c->X, ((size_t)100 + 600 * (size_t)((c->cfg.d + 3) / 4) + 16) * sizeof(double) + 100 * ((size_t)c->cfg.d + 2) * c->esize + 64 +
+                              32 * 2 * (size_t)c->cfg.d * c->esize + 64, false))) return s;   // (+ the estimate lanes' gradient scratch)
   } else if (which != 0 && which != 8 && which != 9) {
     if (!fr && which != 2) return fail(c, MIVI_ERR_UNSUPPORTED, "mean-field has a single fused kernel (which = 2)");
     if (which == 4 && c->target != TGT_DENSE_GAUSS) return fail(c, MIVI_ERR_UNSUPPORTED, "no dense target set");
@@ -2323,11 +2328,13 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
         if (c->target == TGT_FUNNEL) {
           const size_t d4 = (size_t)((c->cfg.d + 3) / 4);
           double *hist = (double *)c->X.p, *elbo = hist + 600 * d4;
-          launch_mf_funnel_loop(c, params, (uint64_t)r * 100, 100, hist, elbo, (void *)(elbo + 108), o, o + 16);
+          char *sc = (char *)(elbo + 108);
+          launch_mf_funnel_loop(c, params, (uint64_t)r * 100, 100, hist, elbo, (void *)sc, o, o + 16,
+                                (void *)(sc + ((100 * ((size_t)c->cfg.d + 2) * c->esize + 63) & ~(size_t)63)));
           break;
         }
         launch_mf_sgd_loop(c, const_cast<void *>(params), nullptr, (uint64_t)r * 100, 0, 100, -1, 0.0, (double)NAN, (double *)c->X.p + 100,
-                           (double *)c->X.p, o + 16);
+                           (double *)c->X.p, o + 16, (void *)((double *)c->X.p + 100 + 400 * (size_t)((c->cfg.d + 3) / 4) + 8));
         break;
       default:
         if (lds && lds_use_prod32(c, M)) {
