@@ -289,7 +289,7 @@ __device__ __forceinline__ void mfma_bf16x3(const float *av, const float *bv, f3
 //   All 528 tiles of the north star are resident at once: no second dispatch round for the tiles beyond 2 x 256.
 // -----------------------------------------------------------------------------------------------------------------
 template <bool FUSED, bool BF3>
-__global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) {
+__device__ __forceinline__ void fr_vjp32_body(const GemmArgs &a) {
   constexpr int BM = 32, BN = 32, KW = 4, NT = 256, SUB = 32, RING = 1, NV = SUB / 2;   // (SUB 16, RING 3 measured slower: 7.4 vs 6.6 us)
   constexpr int LDC = BM + 4;
   constexpr int WAVE_F = RING * 2 * SUB * 32;               // floats per wave: RING x {As[16 k][32] + Bs[16 k][32]}
@@ -403,6 +403,12 @@ __global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) {
   if (MIVI_KNOCKED(a, 32)) return;
   vjp_epilogue<BM, BN, KW, NT, FUSED>(a, Cs, rs_lds, adam_cc, wk, row0, col0);
 }
+
+struct GemmMulti { GemmArgs lane[4]; };   // (kMaxLanes, see k_fr_prod32m)
+template <bool FUSED, bool BF3>
+__global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) { fr_vjp32_body<FUSED, BF3>(a); }
+template <bool FUSED, bool BF3>
+__global__ __launch_bounds__(256) void k_fr_vjp32m(GemmMulti m) { fr_vjp32_body<FUSED, BF3>(m.lane[blockIdx.y]); }
 
 // -----------------------------------------------------------------------------------------------------------------
 // k_fr_vjp64: tril(W eps^T) on 64 x 64 tiles, eight waves split K = n_mc into contiguous runs of 32-k sub-stages; every wave
@@ -601,7 +607,7 @@ struct Prod32Args {
 };
 
 template <int MODE, bool BF3>
-__global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
+__device__ __forceinline__ void fr_prod32_body(const Prod32Args &a) {
   constexpr int NW = 8, NT = 512, SUB = 32, LDC = 36;
   // ONE sub-stage buffer per wave (64 KiB per workgroup): with two (128 KiB, the wave's next sub-stage in flight under its MFMAs) a product
   // workgroup owned its CU; with one, two of them -- or one and a VJP workgroup of another chain -- share it, and the other seven waves cover a
@@ -820,6 +826,15 @@ __global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) {
     }
   }
 }
+
+// one estimate per launch, and LANES: the same tiles for up to four independent estimates at once (blockIdx.y = lane; every lane its own
+// operands and outputs: the contexts of mivi_estimate_gradient_n's interleaved estimates, mivi_api.hip)
+constexpr int kMaxLanes = 4;
+struct Prod32Multi { Prod32Args lane[kMaxLanes]; };
+template <int MODE, bool BF3>
+__global__ __launch_bounds__(512) void k_fr_prod32(Prod32Args a) { fr_prod32_body<MODE, BF3>(a); }
+template <int MODE, bool BF3>
+__global__ __launch_bounds__(512) void k_fr_prod32m(Prod32Multi m) { fr_prod32_body<MODE, BF3>(m.lane[blockIdx.y]); }
 
 // -----------------------------------------------------------------------------------------------------------------
 // k_fr_prod64: the unsplit product on 64 x 64 tiles for the LARGE shapes (more tiles than CUs): Z = mu + tril(C) eps (G_SAMPLE) or
@@ -1197,6 +1212,12 @@ static int knock_flags() {   // developer knock-outs (operand loads / MFMAs / ep
 }
 
 // eps(t+1) rider blocks of the 64 x 64 product kernel: 512 threads = 64 rows x 32 columns each
+struct LaneSink {   // one lane's recorded launches of an estimate (see launch_lanes_prod / launch_lanes_vjp)
+  Prod32Args prod[2];
+  int prod_grid[2], prod_dense[2], n_prod;
+  GemmArgs vjp;
+  int vjp_grid, n_vjp;
+};
 int lds_eps_blocks(const mivi_ctx *c, int M) { return (c->cfg.d / 64) * (M / 32); }
 
 // unsplit 32 x 32-tile product + fused epilogue (k_fr_prod32).  dense = false: Z = mu + tril(C) eps with `mode` in
@@ -1236,10 +1257,45 @@ void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int m
   }
   // riders hitch onto the tile workgroups; only the ones beyond the tile count get workgroups of their own
   grid = a.n_tiles > a.n_dinv + a.n_pack + a.n_eps ? a.n_tiles : a.n_dinv + a.n_pack + a.n_eps;
+  if (c->lane_sink) {   // lane-batched estimates (mivi_api.hip): record the launch, the driver issues it for all lanes at once
+    LaneSink &sk = ((LaneSink *)c->lane_sink)[c->lane_id];
+    if (sk.n_prod < 2) { sk.prod[sk.n_prod] = a; sk.prod_grid[sk.n_prod] = grid; sk.prod_dense[sk.n_prod] = dense ? 1 : 0; }
+    ++sk.n_prod;
+    return;
+  }
   if (dense && f32_mfma()) hipLaunchKernelGGL((k_fr_prod32<G_DENSE, false>), dim3(grid), dim3(512), 0, c->stream, a);
   else if (dense) hipLaunchKernelGGL((k_fr_prod32<G_DENSE, true>), dim3(grid), dim3(512), 0, c->stream, a);
   else if (f32_mfma()) hipLaunchKernelGGL((k_fr_prod32<G_SAMPLE, false>), dim3(grid), dim3(512), 0, c->stream, a);
   else hipLaunchKernelGGL((k_fr_prod32<G_SAMPLE, true>), dim3(grid), dim3(512), 0, c->stream, a);
+}
+
+// ---- lane-batched launches: up to kMaxLanes contexts' product / VJP kernels as ONE launch each (blockIdx.y = lane) ---------------------
+LaneSink *lane_sinks_alloc(int n) { return new LaneSink[n](); }
+void lane_sinks_free(LaneSink *s) { delete[] s; }
+void lane_sink_reset(LaneSink *s, int lane) { s[lane].n_prod = 0; s[lane].n_vjp = 0; }
+int lane_sink_counts(const LaneSink *s, int lane) { return s[lane].n_prod * 16 + s[lane].n_vjp; }
+// which: 0 = the sampling product (with the fused diagonal target, or R = Z - m of the dense one), 1 = the dense target's product
+bool launch_lanes_prod(mivi_ctx *c, LaneSink *s, int lanes, int which) {
+  if (lanes < 1 || lanes > kMaxLanes || f32_mfma()) return false;
+  Prod32Multi m;
+  for (int l = 0; l < lanes; ++l) {
+    if (s[l].n_prod <= which || s[l].n_prod > 2 || s[l].prod_grid[which] != s[0].prod_grid[which] || s[l].prod_dense[which] != which) return false;
+    m.lane[l] = s[l].prod[which];
+  }
+  const dim3 grid(s[0].prod_grid[which], lanes);
+  if (which) hipLaunchKernelGGL((k_fr_prod32m<G_DENSE, true>), grid, dim3(512), 0, c->stream, m);
+  else hipLaunchKernelGGL((k_fr_prod32m<G_SAMPLE, true>), grid, dim3(512), 0, c->stream, m);
+  return true;
+}
+bool launch_lanes_vjp(mivi_ctx *c, LaneSink *s, int lanes) {
+  if (lanes < 1 || lanes > kMaxLanes || f32_mfma()) return false;
+  GemmMulti m;
+  for (int l = 0; l < lanes; ++l) {
+    if (s[l].n_vjp != 1 || s[l].vjp_grid != s[0].vjp_grid) return false;
+    m.lane[l] = s[l].vjp;
+  }
+  hipLaunchKernelGGL((k_fr_vjp32m<false, true>), dim3(s[0].vjp_grid, lanes), dim3(256), 0, c->stream, m);
+  return true;
 }
 // unsplit 64 x 64-tile product + fused epilogue for the large shapes (k_fr_prod64); arguments as launch_lds_prod32
 void launch_lds_prod64(mivi_ctx *c, const void *params, int M, bool dense, int mode, void *Z, const EpsJob *next, bool want_ld) {
@@ -1311,6 +1367,7 @@ void launch_lds_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, 
   // two or three 32 x 32 workgroups per CU covering for each other).  MIVI_VJP_TILE=32 / 64 pins it.
   static const int pin = getenv("MIVI_VJP_TILE") ? atoi(getenv("MIVI_VJP_TILE")) : 0;
   const bool t64 = pin ? pin == 64 : ((M >= 1024 && c->cfg.d >= 2048) || (M >= 512 && c->cfg.d >= 4096));   // (4096 x 512: 90.6 -> 83.7 us)
+  if (t64 && c->lane_sink) { ((LaneSink *)c->lane_sink)[c->lane_id].n_vjp += 16; return; }   // (not a lane-batched route: the driver reports it)
   if (t64) {
     a.work = (const int4 *)c->lds_tabV64.p;
     grid = c->lds_nV64;
@@ -1319,6 +1376,12 @@ void launch_lds_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, 
     else if (upd) hipLaunchKernelGGL((k_fr_vjp64<true, true>), dim3(grid), dim3(512), 0, c->stream, a);
     else if (f32_mfma()) hipLaunchKernelGGL((k_fr_vjp64<false, false>), dim3(grid), dim3(512), 0, c->stream, a);
     else hipLaunchKernelGGL((k_fr_vjp64<false, true>), dim3(grid), dim3(512), 0, c->stream, a);
+    return;
+  }
+  if (c->lane_sink) {   // lane-batched estimates: record (the driver only enters this mode where this route is taken)
+    LaneSink &sk = ((LaneSink *)c->lane_sink)[c->lane_id];
+    if (sk.n_vjp < 1 && !upd) { sk.vjp = a; sk.vjp_grid = grid; }
+    sk.n_vjp += upd ? 16 : 1;
     return;
   }
   if (upd && f32_mfma()) hipLaunchKernelGGL((k_fr_vjp32<true, false>), dim3(grid), dim3(256), 0, c->stream, a);

@@ -1735,8 +1735,23 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
     lanes = 4;   // (measured at the north star, us per estimate with 1 / 2 / 3 / 4 chains: isolated 20-estimate calls 14.4 / 13.9 / 13.3 / 10.8,
                  //  100-estimate calls back to back 13.4 / 9.7 / 8.9 / 8.1 -- the product kernel's 64 KiB of LDS lets two of them, or one and
                  //  a VJP workgroup, share a CU)
+  // Without a sticking-the-landing solve between the two kernels the contexts are LANE-BATCHED: E = 4 contexts per graph branch whose
+  // product kernels are ONE launch (blockIdx.y = lane) and so are their VJP kernels -- half the launches per estimate, no fork / join for a
+  // short batch (4 contexts, one branch: isolated 20-estimate calls 10.6 -> 9.7 us per estimate), two branches of four for long ones
+  // (100-estimate calls back to back 8.2 -> 8.0 us: the chip is saturated near 8 us whatever the arrangement -- 8, 12 and 16 contexts agree).
+  // MIVI_LANE_BATCH=0 keeps every context on a branch of its own (A/B reference; the STL estimators always do); MIVI_CHAINS = contexts.
+  static const int lane_env = getenv("MIVI_LANE_BATCH") ? atoi(getenv("MIVI_LANE_BATCH")) : -1;
+  const bool stl_ent = c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD;
+  int lane_e = 0;   // contexts per branch (0: one each)
+  if (lanes > 1 && !stl_ent && lds_use_prod32(c, c->cfg.n_mc) && lds_bf16x3() && ((uintptr_t)params & 15) == 0 && ((uintptr_t)grad & 15) == 0 && lane_env != 0) {
+    lane_e = lane_env > 0 ? (lane_env > 4 ? 4 : lane_env) : 4;
+    lanes = count < 50 ? 4 : 8;
+  }
   if (chain_lanes() > 0) lanes = c->is_child ? 1 : (chain_lanes() > mivi_ctx::kMaxKids + 1 ? mivi_ctx::kMaxKids + 1 : chain_lanes());
-  while (lanes > 1 && count < 4 * lanes) --lanes;   // (short batches: not worth the fork / join)
+  if (lane_e > 0 && (lanes % lane_e != 0 || count < lanes)) lane_e = 0;
+  if (lane_e <= 0 && lanes > 4) lanes = 4;          // (as graph BRANCHES: at most four -- see kMaxKids)
+  if (lane_e > 0 && lanes / lane_e > 4) lanes = 4 * lane_e;
+  while (lanes > 1 && count < 4 * lanes && lane_e <= 0) --lanes;   // (short batches: not worth the fork / join)
   if (lanes <= 1) {
     if (!c->is_child && c->idx_stride != 1) { invalidate_graph(c); c->idx_stride = 1; }
     return estimate_gradient_chain(c, params, idx0, count, value, grad);
@@ -1775,6 +1790,101 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
   }
   if (!lds_prepare(c, c->cfg.n_mc)) return fail(c, MIVI_ERR_HIP, "full-rank work lists: allocation failed");
   GraphCache &g = c->graph;
+  // LANE-BATCHED contexts: the launchers of the two kernels record their arguments into a sink instead of launching
+  // (kernels_fullrank_lds.hip: launch_lanes_*), the driver issues one launch per kernel and branch.
+  if (lane_e > 0) {
+    const int lane_mode = lane_e;
+    const int E = lane_mode, B = lanes / E;
+    if (!(g.exec && g.kind == 3 && g.count == count && g.params == params && g.value == value && g.grad == grad && g.p0 == (double)(lanes * 16 + E))) {
+      invalidate_graph(c);
+      c->idx_stride = lanes;
+      for (int j = 0; j < lanes - 1; ++j) {
+        c->kids[j]->kid_gen = c->target_gen;
+        HIPCHK(c, hipStreamSynchronize(c->kids[j]->stream));
+      }
+      hipGraph_t graph = nullptr;
+      hipStream_t saved;
+      if ((s = begin_capture(c, &saved))) return s;
+      hipError_t he = hipEventRecord(c->ev_fork, c->stream);
+      mivi_ctx *ctxs[1 + mivi_ctx::kMaxKids];
+      ctxs[0] = c;
+      for (int l = 1; l < lanes; ++l) ctxs[l] = c->kids[l - 1];
+      const bool dense = c->target == TGT_DENSE_GAUSS;
+      // branch b: contexts b E .. b E + E - 1 (global lane g serves estimates g, g + lanes, ...), their launches on the stream of the branch's
+      // first context; its product kernels are ONE launch (blockIdx.y = lane) and so are its VJP kernels
+      auto branch = [&](int b) -> mivi_status_t {
+        mivi_status_t st = MIVI_OK;
+        LaneSink *sink = lane_sinks_alloc(E);
+        Chain chn[4];
+        hipStream_t bs = ctxs[b * E]->stream, kept[4];
+        mivi_ctx *lead = ctxs[b * E];
+        for (int l = 0; l < E; ++l) {
+          mivi_ctx *k = ctxs[b * E + l];
+          kept[l] = k->stream;
+          k->stream = bs;   // (the other lanes' few stand-alone launches -- the first eps, the last value -- go to the branch's stream too)
+          chn[l].on = true; chn[l].estimates_only = true;
+          k->lane_sink = sink; k->lane_id = l;
+        }
+        const int steps = (count + lanes - 1) / lanes;
+        for (int i = 0; i < steps && st == MIVI_OK; ++i) {
+          int L = 0;
+          for (int l = 0; l < E && st == MIVI_OK; ++l) {
+            const int gl = b * E + l;
+            const int cnt = (count - gl + lanes - 1) / lanes;   // estimates of global lane gl: gl, gl + lanes, ...
+            if (i >= cnt) break;
+            mivi_ctx *k = ctxs[gl];
+            lane_sink_reset(sink, l);
+            RngArgs r = rng_of(k, (uint64_t)gl + (uint64_t)i * lanes);
+            r.idx_ptr = (const uint64_t *)c->d_idx.p;   // ONE device counter (the parent's) for all lanes
+            k->cur = i & 1;
+            chn[l].has_next = (i + 1 < cnt);
+            chn[l].next_rng = rng_of(k, (uint64_t)gl + ((uint64_t)i + 1) * lanes);
+            chn[l].next_rng.idx_ptr = r.idx_ptr;
+            char *ko = gl ? (char *)c->kid_out[gl - 1].p : (char *)c->tmp_out.p;
+            st = run_estimate(k, params, r, k->cfg.n_mc, 1, final_out(k, gl == q_last ? value : (void *)ko, gl == q_last ? grad : (void *)(ko + 16)), &chn[l]);
+            if (st) { c->err = k->err; break; }
+            if (lane_sink_counts(sink, l) != (dense ? 2 : 1) * 16 + 1) st = fail(c, MIVI_ERR_HIP, "lane-batched estimates: an estimate did not take the two-kernel route");
+            ++L;
+          }
+          if (st == MIVI_OK && L > 0 && !(launch_lanes_prod(lead, sink, L, 0) && (!dense || launch_lanes_prod(lead, sink, L, 1)) && launch_lanes_vjp(lead, sink, L)))
+            st = fail(c, MIVI_ERR_HIP, "lane-batched estimates: the lanes' launches do not match");
+        }
+        for (int l = 0; l < E; ++l) {
+          mivi_ctx *k = ctxs[b * E + l];
+          k->lane_sink = nullptr;
+          if (st == MIVI_OK) flush_chain(k, params, &chn[l]);
+          k->cur = 0;
+          k->pre_valid = false;
+          k->stream = kept[l];
+        }
+        lane_sinks_free(sink);
+        return st;
+      };
+      for (int b = 1; b < B && s == MIVI_OK && he == hipSuccess; ++b) {
+        mivi_ctx *k = ctxs[b * E];
+        he = hipStreamWaitEvent(k->stream, c->ev_fork, 0);   // the branch's stream joins the capture
+        if (he != hipSuccess) break;
+        s = branch(b);
+        if (s == MIVI_OK) he = hipEventRecord(c->ev_join[b * E - 1], k->stream);
+      }
+      if (s == MIVI_OK && he == hipSuccess) s = branch(0);
+      for (int b = 1; b < B && s == MIVI_OK && he == hipSuccess; ++b) he = hipStreamWaitEvent(c->stream, c->ev_join[b * E - 1], 0);
+      if (s == MIVI_OK && he == hipSuccess) hipLaunchKernelGGL(k_bump_u64, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, (uint64_t)count);
+      hipError_t e = end_capture(c, saved, &graph);
+      if (s) { if (graph) (void)hipGraphDestroy(graph); return s; }
+      HIPCHK(c, he);
+      HIPCHK(c, e);
+      HIPCHK(c, hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(graph);
+      g.kind = 3; g.count = count; g.params = params; g.value = value; g.grad = grad; g.p0 = (double)(lanes * 16 + E);
+    }
+    if (!(c->d_idx_valid && c->d_idx_expect == idx0))
+      hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, idx0, 0ull, 1);
+    HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
+    c->d_idx_valid = true;
+    c->d_idx_expect = idx0 + (uint64_t)count;
+    return MIVI_OK;
+  }
   if (!(g.exec && g.kind == 2 && g.count == count && g.params == params && g.value == value && g.grad == grad && g.p0 == (double)lanes)) {
     invalidate_graph(c);
     c->idx_stride = lanes;   // (invalidate_graph leaves it; the children were synced above: re-stamp their generation)

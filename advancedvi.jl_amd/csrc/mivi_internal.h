@@ -313,12 +313,14 @@ struct mivi_ctx {
   // whose kernels overlap on the device (the product of one chain's estimate runs beside the VJP of another's).
   int idx_stride = 1;            // estimate-index step between consecutive estimates of THIS context's chain
   bool is_child = false;         // target buffers are borrowed from the parent
-  static constexpr int kMaxKids = 3;   // at most four chains: a forked graph with five branches crashed inside hipGraphLaunch (hip::Graph::UpdateStreams) after a
-                                       // re-capture on ROCm 7.0's runtime; four is also the number of hardware queues HIP spreads streams over
+  static constexpr int kMaxKids = 15;   // up to eight contexts; at most FOUR graph branches (a forked graph with five branches crashed inside hipGraphLaunch,
+                                       // hip::Graph::UpdateStreams, after a re-capture on ROCm 7.0's runtime; four is also the number of hardware queues)
   mivi_ctx *kids[kMaxKids] = {};
   int n_kids = 0;
   unsigned long long target_gen = 0, kid_gen = ~0ull;   // parent: bumped whenever a captured graph is invalidated; child: the generation it mirrors
   hipEvent_t ev_fork = nullptr, ev_join[kMaxKids] = {};
+  void *lane_sink = nullptr;     // lane-batched estimates: the launchers of the two second-generation kernels record into sink[lane_id] instead of launching
+  int lane_id = 0;
   mivi::DevBuf kid_out[kMaxKids];       // value (16 bytes) + gradient of the child chains that do not hold the batch's last estimate
 };
 
@@ -369,6 +371,13 @@ int lds_prod64_tiles(const mivi_ctx *c, int M);
 bool lds_use_prod64(const mivi_ctx *c, int M);   // large shapes: unsplit 64 x 64 tiles
 int lds_prod32_eps_blocks(const mivi_ctx *c, int M);
 bool lds_use_prod32(const mivi_ctx *c, int M);
+struct LaneSink;
+LaneSink *lane_sinks_alloc(int n);
+void lane_sinks_free(LaneSink *s);
+void lane_sink_reset(LaneSink *s, int lane);
+int lane_sink_counts(const LaneSink *s, int lane);                       // products recorded * 16 + VJPs recorded
+bool launch_lanes_prod(mivi_ctx *c, LaneSink *s, int lanes, int which);   // one launch for all lanes (blockIdx.y = lane)
+bool launch_lanes_vjp(mivi_ctx *c, LaneSink *s, int lanes);
 bool lds_bf16x3();   // products on the bf16 matrix cores (three-way exact operand split); MIVI_FR_F32MFMA=1 turns it off
 void launch_lds_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const ValueJob *self, const FusedUpdate *upd);
 bool lds_stein_ok(const mivi_ctx *c, int M);

@@ -121,7 +121,10 @@ CASES = [
     ("MIVI_GRAPH_MIN=100", LOOP, dict(fam=F, d=128, M=128)),                                              # eager chain for every batch
     ("MIVI_STEIN_GEN1=1", STEIN, dict()),
     ("MIVI_CHAINS=1", CHAINS, dict(kind="diag")),                                                         # one chain instead of interleaved ones
-    ("MIVI_CHAINS=4", CHAINS, dict(kind="dense")),                                                        # four interleaved chains
+    ("MIVI_CHAINS=4", CHAINS, dict(kind="dense")),                                                        # four contexts
+    ("MIVI_LANE_BATCH=0", CHAINS, dict(kind="diag")),                                                     # every context on a graph branch of its own (no lane-batched launches)
+    ("MIVI_LANE_BATCH=2", CHAINS, dict(kind="dense")),                                                    # two contexts per lane-batched launch
+    ("MIVI_CHAINS=8", CHAINS, dict(kind="diag")),                                                         # eight contexts: two branches of four lanes
     ("MIVI_DUMMY_DEFAULT=1", CHAINS, dict(kind="dense")),                                                 # (no switch: the default interleaving)                                                                 # first-generation accumulation kernel
 ]
 
