@@ -113,8 +113,10 @@ __global__ __launch_bounds__(256) void k_stl_pack(int d, const float *C, unsigne
 // k slots: MFMA m (K = 32) takes rows 32 m .. 32 m + 31 of the block; lane group g = lane / 16 supplies rows
 // {32 m + 4 g + r} and {32 m + 16 + 4 g + r}, r < 4 -- exactly the rows an accumulator lane of tiles 2 m and 2 m + 1 holds.
 // -----------------------------------------------------------------------------------------------------------------
+constexpr int kStlMaxJobs = 12;   // three per context, four lane-batched contexts (mivi_api.hip)
 struct StlJob {
   int r0, nwg;           // the n x n system T = C[r0 : r0 + n, r0 : r0 + n]; workgroups of this job (16 right-hand-side columns each)
+  const unsigned *pack;  // the packed operands of stl_dinv.h (pivot inverses, chain blocks, bulk blocks of both halves) of THIS job's scale matrix
   const float *rhs;      // R(i, m) = rhs[i * rs_i + m * ld_rhs]   (i < n: the pointer is at row 0 of this system)
   long rs_i, ld_rhs;
   float *X;              // optional: X(i, m) -> X[i * xs_i + m * ld_x]
@@ -125,8 +127,7 @@ struct StlJob {
 };
 struct StlSolveArgs {
   int d, n, njobs;
-  const unsigned *pack;  // the packed operands of stl_dinv.h (pivot inverses, chain blocks, bulk blocks of both halves)
-  StlJob job[3];         // independent solves side by side in one launch: blockIdx.x walks job 0's workgroups, then job 1's, ...
+  StlJob job[kStlMaxJobs];   // independent solves side by side in one launch: blockIdx.x walks job 0's workgroups, then job 1's, ...
   unsigned *stamps;      // developer (-DMIVI_DEV, MIVI_STL_STAMPS): shader-clock stamps of workgroup 0, [role 2][step 16][4]
 };
 
@@ -154,15 +155,12 @@ __global__ __launch_bounds__(512) void k_stl_solve64(StlSolveArgs a) {
   const int q = w & 3;
   const int d = a.d;
   int wg = blockIdx.x, ji = 0;                            // which job this workgroup belongs to (uniform)
-  if (wg >= a.job[0].nwg) {
-    wg -= a.job[0].nwg; ji = 1;
-    if (a.njobs > 2 && wg >= a.job[1].nwg) { wg -= a.job[1].nwg; ji = 2; }
-  }
+  while (ji + 1 < a.njobs && wg >= a.job[ji].nwg) { wg -= a.job[ji].nwg; ++ji; }
   const StlJob &jb = a.job[ji];
   const int r0 = jb.r0;
   const int col = wg * 16 + n16;
-  const unsigned *Dp = a.pack + (size_t)(r0 >> 6) * STL_PLANE_BLOCK;
-  const unsigned *Cp = a.pack + (size_t)(d >> 6) * STL_PLANE_BLOCK + (r0 ? stl_solve_units(NB) : 0);   // crit blocks, then the bulk sequence
+  const unsigned *Dp = jb.pack + (size_t)(r0 >> 6) * STL_PLANE_BLOCK;
+  const unsigned *Cp = jb.pack + (size_t)(d >> 6) * STL_PLANE_BLOCK + (r0 ? stl_solve_units(NB) : 0);   // crit blocks, then the bulk sequence
 #ifdef MIVI_DEV
   unsigned *stp = reinterpret_cast<unsigned *>(lds + STAMP_OFF);   // developer: [role 2][step 8][4]
   const bool stamping = a.stamps != nullptr && blockIdx.x == 0 && q == 0 && lane == 0;
@@ -360,7 +358,7 @@ struct StlUpdArgs {
   int ncb;
 };
 
-__global__ __launch_bounds__(512) void k_stl_update32(StlUpdArgs a) {
+__device__ __forceinline__ void stl_update32_body(const StlUpdArgs &a) {
   constexpr int NW = 8, SUB = 32, LDC = 36;
   constexpr int WAVE_F = 2 * SUB * 32;
   constexpr int EPI = NW * 32 * LDC;
@@ -433,6 +431,21 @@ __global__ __launch_bounds__(512) void k_stl_update32(StlUpdArgs a) {
   }
 }
 
+struct StlUpdMulti { StlUpdArgs lane[4]; };   // lane-batched contexts: blockIdx.y = lane
+__global__ __launch_bounds__(512) void k_stl_update32(StlUpdArgs a) { stl_update32_body(a); }
+__global__ __launch_bounds__(512) void k_stl_update32m(StlUpdMulti m) { stl_update32_body(m.lane[blockIdx.y]); }
+
+// one context's recorded STL term (lane-batched estimates: launch_stl2 records, launch_lanes_stl issues the lanes together)
+struct StlSink {
+  StlSolveArgs solve;
+  StlUpdArgs upd;
+  int upd_grid, n;
+};
+StlSink *stl_sinks_alloc(int n) { return new StlSink[n](); }
+void stl_sinks_free(StlSink *s) { delete[] s; }
+void stl_sink_reset(StlSink *s, int lane) { s[lane].n = 0; }
+int stl_sink_count(const StlSink *s, int lane) { return s[lane].n; }
+
 // -----------------------------------------------------------------------------------------------------------------
 bool stl2_shape_ok(const mivi_ctx *c, int M) {
   static const bool off = getenv("MIVI_STL_GEN1") != nullptr;
@@ -463,7 +476,8 @@ void launch_stl2(mivi_ctx *c, const void *params, int M, bool dinv_done, const v
   float *Wout = out ? (float *)out : (float *)c->W.p;                               // X is ADDED here, ld d
   if (!dinv_done) hipLaunchKernelGGL(k_stl_pack, dim3(d / 64 + stl_pack_riders(d)), dim3(256), 0, c->stream, d, C, pack);
   StlSolveArgs s{};
-  s.d = d; s.n = n; s.pack = pack; s.njobs = 3;
+  s.d = d; s.n = n; s.njobs = 3;
+  for (int j = 0; j < 3; ++j) s.job[j].pack = pack;
   // job 0 -- lower half: C22^T X2 = E2, X2 also straight into the rows n .. d of W
   StlJob &j0 = s.job[0];
   j0.r0 = n; j0.nwg = M / 16; j0.rhs = eps + n; j0.rs_i = 1; j0.ld_rhs = c->dP; j0.X = Xb; j0.xs_i = 1; j0.ld_x = n;
@@ -475,15 +489,20 @@ void launch_stl2(mivi_ctx *c, const void *params, int M, bool dinv_done, const v
   // solution is stored transposed, F[k + i n] = F^T(i, k): k-major rows, the layout k_stl_update32 stages
   StlJob &j2 = s.job[2];
   j2.r0 = 0; j2.nwg = n / 16; j2.rhs = C + n; j2.rs_i = d; j2.ld_rhs = 1; j2.X = F; j2.xs_i = n; j2.ld_x = 1;
+  StlUpdArgs u{};   // rows 0 .. n of W:  X1 = Y1 - F^T X2
+  u.n_i = n; u.n_k = n; u.A = F; u.lda = n; u.X = Xb; u.ld_x = n; u.E = Y1; u.ld_e = n;
+  u.R = Wout; u.ld_r = d; u.accumulate = overwrite ? 0 : 1; u.ncb = M / 32;
+  if (c->stl_sink) {   // lane-batched estimates (mivi_api.hip): record; the driver issues the lanes' solves and products as one launch each
+    StlSink &sk = ((StlSink *)c->stl_sink)[c->lane_id];
+    if (sk.n == 0) { sk.solve = s; sk.upd = u; sk.upd_grid = (n / 32) * (M / 32); }
+    ++sk.n;
+    return;
+  }
 #ifdef MIVI_DEV
   static const bool stamps = getenv("MIVI_STL_STAMPS") != nullptr;
   if (stamps) s.stamps = (unsigned *)((char *)c->stl_X.p + c->stl_X.bytes - 4096);
 #endif
   launch_solve(c, s);
-  // rows 0 .. n of W:  X1 = Y1 - F^T X2
-  StlUpdArgs u{};
-  u.n_i = n; u.n_k = n; u.A = F; u.lda = n; u.X = Xb; u.ld_x = n; u.E = Y1; u.ld_e = n;
-  u.R = Wout; u.ld_r = d; u.accumulate = overwrite ? 0 : 1; u.ncb = M / 32;
   hipLaunchKernelGGL(k_stl_update32, dim3((n / 32) * (M / 32)), dim3(512), 0, c->stream, u);
 #ifdef MIVI_DEV
   if (stamps) {
@@ -503,6 +522,26 @@ void launch_stl2(mivi_ctx *c, const void *params, int M, bool dinv_done, const v
     }
   }
 #endif
+}
+
+// the recorded STL terms of `lanes` contexts: ONE solve launch with all their jobs, ONE combining product (blockIdx.y = lane).
+// The lanes are estimates at the SAME parameters, so the parameter-only coupling solve (job 2: F) runs for lane 0 only and every lane's
+// product reads lane 0's F; with_F = false (a later step of the same batch): nobody solves for it again.
+bool launch_lanes_stl(mivi_ctx *c, StlSink *sk, int lanes, bool with_F) {
+  if (lanes < 1 || lanes > 4) return false;
+  StlSolveArgs s = sk[0].solve;
+  StlUpdMulti m;
+  s.njobs = 0;
+  for (int l = 0; l < lanes; ++l) {
+    if (sk[l].n != 1 || sk[l].solve.njobs != 3 || sk[l].solve.d != s.d || sk[l].solve.n != s.n || sk[l].upd_grid != sk[0].upd_grid) return false;
+    for (int j = 0; j < 3; ++j)
+      if (j < 2 || (l == 0 && with_F)) s.job[s.njobs++] = sk[l].solve.job[j];
+    m.lane[l] = sk[l].upd;
+    m.lane[l].A = sk[0].upd.A;
+  }
+  launch_solve(c, s);
+  hipLaunchKernelGGL(k_stl_update32m, dim3(sk[0].upd_grid, lanes), dim3(512), 0, c->stream, m);
+  return true;
 }
 
 }  // namespace mivi

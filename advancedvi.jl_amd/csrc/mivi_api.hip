@@ -1743,7 +1743,8 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
   static const int lane_env = getenv("MIVI_LANE_BATCH") ? atoi(getenv("MIVI_LANE_BATCH")) : -1;
   const bool stl_ent = c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD;
   int lane_e = 0;   // contexts per branch (0: one each)
-  if (lanes > 1 && !stl_ent && lds_use_prod32(c, c->cfg.n_mc) && lds_bf16x3() && ((uintptr_t)params & 15) == 0 && ((uintptr_t)grad & 15) == 0 && lane_env != 0) {
+  if (lanes > 1 && (!stl_ent || stl2_shape_ok(c, c->cfg.n_mc)) && lds_use_prod32(c, c->cfg.n_mc) && lds_bf16x3() && ((uintptr_t)params & 15) == 0 &&
+      ((uintptr_t)grad & 15) == 0 && lane_env != 0) {
     lane_e = lane_env > 0 ? (lane_env > 4 ? 4 : lane_env) : 4;
     lanes = count < 50 ? 4 : 8;
   }
@@ -1815,6 +1816,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
       auto branch = [&](int b) -> mivi_status_t {
         mivi_status_t st = MIVI_OK;
         LaneSink *sink = lane_sinks_alloc(E);
+        StlSink *ssink = stl_ent ? stl_sinks_alloc(E) : nullptr;
         Chain chn[4];
         hipStream_t bs = ctxs[b * E]->stream, kept[4];
         mivi_ctx *lead = ctxs[b * E];
@@ -1824,6 +1826,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
           k->stream = bs;   // (the other lanes' few stand-alone launches -- the first eps, the last value -- go to the branch's stream too)
           chn[l].on = true; chn[l].estimates_only = true;
           k->lane_sink = sink; k->lane_id = l;
+          k->stl_sink = ssink;
         }
         const int steps = (count + lanes - 1) / lanes;
         for (int i = 0; i < steps && st == MIVI_OK; ++i) {
@@ -1834,6 +1837,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
             if (i >= cnt) break;
             mivi_ctx *k = ctxs[gl];
             lane_sink_reset(sink, l);
+            if (ssink) stl_sink_reset(ssink, l);
             RngArgs r = rng_of(k, (uint64_t)gl + (uint64_t)i * lanes);
             r.idx_ptr = (const uint64_t *)c->d_idx.p;   // ONE device counter (the parent's) for all lanes
             k->cur = i & 1;
@@ -1843,21 +1847,25 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
             char *ko = gl ? (char *)c->kid_out[gl - 1].p : (char *)c->tmp_out.p;
             st = run_estimate(k, params, r, k->cfg.n_mc, 1, final_out(k, gl == q_last ? value : (void *)ko, gl == q_last ? grad : (void *)(ko + 16)), &chn[l]);
             if (st) { c->err = k->err; break; }
-            if (lane_sink_counts(sink, l) != (dense ? 2 : 1) * 16 + 1) st = fail(c, MIVI_ERR_HIP, "lane-batched estimates: an estimate did not take the two-kernel route");
+            if (lane_sink_counts(sink, l) != (dense ? 2 : 1) * 16 + 1 || (ssink && stl_sink_count(ssink, l) != 1))
+              st = fail(c, MIVI_ERR_HIP, "lane-batched estimates: an estimate did not take the expected kernel route");
             ++L;
           }
-          if (st == MIVI_OK && L > 0 && !(launch_lanes_prod(lead, sink, L, 0) && (!dense || launch_lanes_prod(lead, sink, L, 1)) && launch_lanes_vjp(lead, sink, L)))
+          if (st == MIVI_OK && L > 0 && !(launch_lanes_prod(lead, sink, L, 0) && (!dense || launch_lanes_prod(lead, sink, L, 1)) &&
+                                          (!ssink || launch_lanes_stl(lead, ssink, L, i == 0)) && launch_lanes_vjp(lead, sink, L)))
             st = fail(c, MIVI_ERR_HIP, "lane-batched estimates: the lanes' launches do not match");
         }
         for (int l = 0; l < E; ++l) {
           mivi_ctx *k = ctxs[b * E + l];
           k->lane_sink = nullptr;
+          k->stl_sink = nullptr;
           if (st == MIVI_OK) flush_chain(k, params, &chn[l]);
           k->cur = 0;
           k->pre_valid = false;
           k->stream = kept[l];
         }
         lane_sinks_free(sink);
+        if (ssink) stl_sinks_free(ssink);
         return st;
       };
       for (int b = 1; b < B && s == MIVI_OK && he == hipSuccess; ++b) {

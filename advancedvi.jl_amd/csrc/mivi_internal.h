@@ -319,6 +319,7 @@ struct mivi_ctx {
   int n_kids = 0;
   unsigned long long target_gen = 0, kid_gen = ~0ull;   // parent: bumped whenever a captured graph is invalidated; child: the generation it mirrors
   hipEvent_t ev_fork = nullptr, ev_join[kMaxKids] = {};
+  void *stl_sink = nullptr;      // ... and launch_stl2 into stl_sink[lane_id]
   void *lane_sink = nullptr;     // lane-batched estimates: the launchers of the two second-generation kernels record into sink[lane_id] instead of launching
   int lane_id = 0;
   mivi::DevBuf kid_out[kMaxKids];       // value (16 bytes) + gradient of the child chains that do not hold the batch's last estimate
@@ -378,6 +379,12 @@ void lane_sink_reset(LaneSink *s, int lane);
 int lane_sink_counts(const LaneSink *s, int lane);                       // products recorded * 16 + VJPs recorded
 bool launch_lanes_prod(mivi_ctx *c, LaneSink *s, int lanes, int which);   // one launch for all lanes (blockIdx.y = lane)
 bool launch_lanes_vjp(mivi_ctx *c, LaneSink *s, int lanes);
+struct StlSink;
+StlSink *stl_sinks_alloc(int n);
+void stl_sinks_free(StlSink *s);
+void stl_sink_reset(StlSink *s, int lane);
+int stl_sink_count(const StlSink *s, int lane);
+bool launch_lanes_stl(mivi_ctx *c, StlSink *s, int lanes, bool with_F);  // one solve launch with all lanes' jobs + one combining product
 bool lds_bf16x3();   // products on the bf16 matrix cores (three-way exact operand split); MIVI_FR_F32MFMA=1 turns it off
 void launch_lds_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const ValueJob *self, const FusedUpdate *upd);
 bool lds_stein_ok(const mivi_ctx *c, int M);
