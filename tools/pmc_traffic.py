@@ -20,8 +20,11 @@ PATTERN = (("k_fr_prod32", "lds16"), ("k_fr_prod64", "lds16"), ("k_fr_vjp32", "l
            ("k_stl_update", "lds16"), ("k_lr_", "ld16"), ("k_p2p_exchange", "ld16"))
 # algorithmic KiB per launch at the north star (d = 1024, n_mc = 256, f32): in + out
 d, M = 1024, 256
-ALGO = {"k_fr_prod32ILi0": (d * (d + 1) // 2 * 4 + d * M * 4 + d * M * 4 + d * M * 4) / 1024.0,   # tril(C) + eps in, W + eps(t+1) out
-        "k_fr_vjp32": (2 * d * M * 4 + d * d * 4) / 1024.0}                                        # W + eps in, dense dC out
+_prod = (d * (d + 1) // 2 * 4 + d * M * 4 + d * M * 4 + d * M * 4) / 1024.0   # tril(C) + eps in, W + eps(t+1) out
+_vjp = (2 * d * M * 4 + d * d * 4) / 1024.0                                  # W + eps in, dense dC out
+ALGO = {"k_fr_prod32ILi0": _prod, "k_fr_vjp32ILb0": _vjp,
+        # the lane-batched launches of the timed region: four estimates per launch (tril(C) is shared by the lanes)
+        "k_fr_prod32mILi0": (d * (d + 1) // 2 * 4 + 4 * 3 * d * M * 4) / 1024.0, "k_fr_vjp32mILb0": 4 * _vjp}
 cal = {}
 try:
     cal = json.load(open("profiles/pmc_calibration.json")).get("patterns", {})
