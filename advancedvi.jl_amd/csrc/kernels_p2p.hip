@@ -42,11 +42,11 @@
 
 namespace mivi {
 
-constexpr int kP2PLanes = 2, kP2PRing = 4;
+constexpr int kP2PLanes = 2, kP2PRing = 8, kP2PGroup = 4;   // ring = two groups of estimates: one being exchanged, one being computed
 
 struct P2PTable {   // device resident: where every rank's exchange areas are mapped in THIS process, per lane
-  char *stage[kP2PLanes][8];      // [2][R][n] T : stage[s] = rank s's staging area (contribution of rank `src` to slice s at [parity][src])
-  char *fin[kP2PLanes][8];        // [2][R n] T  : rank s's packed final vector
+  char *stage[kP2PLanes][8];      // [2][V][R][n] T : stage[s] = rank s's staging area (contribution of rank `src` to slice s of the group's vector v at [parity][v][src])
+  char *fin[kP2PLanes][8];        // [2][V][R n] T  : rank s's packed final vectors of the group
   unsigned *arr[kP2PLanes][8];    // [2][R][G]   : arrival flags (source rank, chunk) in rank s's memory
   unsigned *farr[kP2PLanes][8];   // [2][R][G+1] : final-chunk flags (owner rank, chunk) in rank s's memory; [vs][G] = the two scalars
 };
@@ -62,11 +62,12 @@ struct P2PArgs {
   int ring;
   const T *params;
   T *value, *grad;           // results of the batch's LAST estimate
-  T *scratch;                // value (4 slots) + gradient of the estimates before it (this lane's own: every estimate is fully written)
+  T *scratch;                // [V] x {value (4 slots) + gradient} of the estimates before it (this lane's own: every estimate is fully written)
+  long long scratch_stride;  // elements between the group's scratch outputs
   int *status;
   int phases;                // bit 0 push, bit 1 reduce, bit 2 unpack (all three = the exchange; single phases: host-sequenced tests, count = 1)
   int spin_budget;
-  int lane, lanes, count;    // this launch serves estimates t = lane, lane + lanes, ... < count
+  int lane, lanes, count;    // this launch serves the GROUPS gi = lane, lane + lanes, ... of V consecutive estimates (t = gi V ... < count)
   const unsigned *ready;     // batch hand-over (nullptr: the partial vector is complete at launch): estimate t may start when *ready >= t + 1
   unsigned *freed;           // [ring]: += 1 by every chunk workgroup once its part of the vector in that ring slot has been read
 };
@@ -155,12 +156,12 @@ __device__ __forceinline__ double p2p_finalise(const P2PArgs<T> &a, long long gi
 // phase 2 for R <= K sources (K in {1, 2, 4, 8}): 8 / K vectors of this thread x K sources per batch of eight loads.
 // A vector = 16 bytes = V elements (float: 4, double: 2).  The caller has waited for the R arrival flags of this chunk.
 template <typename T, int K, int NT>
-__device__ __forceinline__ void p2p_reduce_chunk(const P2PArgs<T> &a, const P2PTable &tb, int p, long long c0, long long clen) {
+__device__ __forceinline__ void p2p_reduce_chunk(const P2PArgs<T> &a, const P2PTable &tb, int pv, long long c0, long long clen) {   // pv = parity * V + vector
   constexpr int V = 16 / (int)sizeof(T), NV = 8 / K;
   const int tid = threadIdx.x, R = a.world;
   const long long n = a.n, tri_end = a.L - 2;
   const double invM = 1.0 / (double)a.M_total, direct = direct_entropy_coeff(a.ent_kind);
-  const T *st = (const T *)tb.stage[a.lane][a.rank] + (size_t)(p * R) * n + c0;   // + src * n + V * vector
+  const T *st = (const T *)tb.stage[a.lane][a.rank] + (size_t)(pv * R) * n + c0;   // + src * n + 16-byte vector
   const long long g0 = (long long)a.rank * n + c0;
   const int vecs = (int)(clen / V);
   for (int base = 0; base < vecs; base += NV * NT) {
@@ -202,7 +203,7 @@ __device__ __forceinline__ void p2p_reduce_chunk(const P2PArgs<T> &a, const P2PT
         o[c] = gi < tri_end ? (T)p2p_finalise(a, gi, pj, pi, acc[c], invM, direct) : T(0);
         if (tri && gi >= a.d) packed_next(a.d, pj, pi);
       }
-      const size_t off = (size_t)p * R * n + (size_t)gi0;   // element index inside a final area
+      const size_t off = (size_t)pv * R * n + (size_t)gi0;   // element index inside a final area
       if (gi0 + V <= tri_end) {
         u32x4_t ov;
         __builtin_memcpy(&ov, o, 16);
@@ -234,18 +235,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   const int d = a.d;
   bool lost = false;
 
-  for (int t = a.lane; t < a.count; t += a.lanes) {
+  // One EPOCH of the exchange serves a GROUP of up to GV consecutive estimates: an exchange is a chain of ~9 memory round trips whatever it
+  // carries, so the group's vectors share every flag and every wait (per estimate: 23 us alone, ~7 us in a group of four on one GPU).
+  constexpr int GV = kP2PGroup;
+  for (int gi = a.lane; gi * GV < a.count; gi += a.lanes) {
     ++epoch;
     const int p = (int)(epoch & 1u);
-    const int slot = t % a.ring;
-    const T *P = a.P[slot];
-    const bool last = (t == a.count - 1);
-    T *out_v = last ? a.value : a.scratch, *out_g = last ? a.grad : a.scratch + 4;
-    if (a.ready) {   // hand-over from the compute chain: the partial vector of estimate t is complete
+    const int t0 = gi * GV, nv = a.count - t0 < GV ? a.count - t0 : GV;
+    const bool first_group = (gi == a.lane);
+    if (a.ready) {   // hand-over from the compute chain: the partial vectors of the group's estimates are complete
       if (tid == 0) {
         int budget = lost ? 64 : a.spin_budget;   // (after a lost peer every further wait of this launch gives up at once: a dead batch ends in milliseconds)
         sh_ok = 1;
-        while ((int)__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t + 1) {
+        while ((int)__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < t0 + nv) {
           if (--budget <= 0) { sh_ok = 0; break; }
           __builtin_amdgcn_s_sleep(4);
         }
@@ -255,56 +257,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       __syncthreads();
     }
 
-    // ---- phase 1: push chunk g of every slice to its owner, then one arrival flag per owner -------------------------------------------
+    // ---- phase 1: push chunk g of every slice of every vector to its owner, then one arrival flag per owner ---------------------------
     if ((a.phases & 1) && !value_wg) {
       const int vecs = (int)(clen / V);   // (clen is a multiple of 4)
-      for (int base = 0; base < vecs; base += 8 * NT) {
-        for (int k = 0; k < R; ++k) {
-          const int s = (a.rank + 1 + k) % R;   // start with the neighbour: the links fill evenly, the local copy comes last
-          const T *src = P + (size_t)s * n + c0;
-          T *dst = (T *)tb.stage[ln][s] + (size_t)(p * R + a.rank) * n + c0;
-          const void *ptr[8];
-          u32x4_t r[8];
-          int vi[8];
+      for (int v = 0; v < nv; ++v) {
+        const T *P = a.P[(t0 + v) % a.ring];
+        for (int base = 0; base < vecs; base += 8 * NT) {
+          for (int k = 0; k < R; ++k) {
+            const int s = (a.rank + 1 + k) % R;   // start with the neighbour: the links fill evenly, the local copy comes last
+            const T *src = P + (size_t)s * n + c0;
+            T *dst = (T *)tb.stage[ln][s] + (size_t)((p * GV + v) * R + a.rank) * n + c0;
+            const void *ptr[8];
+            u32x4_t r[8];
+            int vi[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            vi[u] = base + u * NT + tid;
-            ptr[u] = src + V * (vi[u] < vecs ? vi[u] : 0);
+            for (int u = 0; u < 8; ++u) {
+              vi[u] = base + u * NT + tid;
+              ptr[u] = src + V * (vi[u] < vecs ? vi[u] : 0);
+            }
+            ld16x8_sys(ptr, r);   // (system scope: the vector was written by the compute kernels' XCDs and this kernel never restarts)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              if (vi[u] < vecs) store16_sys(dst + V * vi[u], r[u]);
           }
-          ld16x8_sys(ptr, r);   // (system scope: the vector was written by the compute kernels' XCDs and this kernel never restarts)
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (vi[u] < vecs) store16_sys(dst + V * vi[u], r[u]);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every payload store of this wave has been acknowledged ...
       __syncthreads();                                    // ... and of this workgroup
       if (tid < R) flag_store(tb.arr[ln][tid] + (size_t)(p * R + a.rank) * G + g, epoch);
-      if (a.freed && tid == 0)   // this workgroup is done reading the partial vector in this ring slot
-        __hip_atomic_fetch_add(a.freed + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.freed && tid < nv)   // this workgroup is done reading the group's partial vectors in their ring slots
+        __hip_atomic_fetch_add(a.freed + (t0 + tid) % a.ring, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
-    // ---- phase 3a (needs nothing from anybody): exact zeros above the diagonal of the dense gradient -------------------------------------
-    // (the scratch gradient of the batch's earlier estimates keeps its zeros from this launch's first estimate: only the unpack below
-    //  writes it, and only below the diagonal; the caller's buffer gets them with the last estimate)
-    if ((a.phases & 4) && !value_wg && a.family == MIVI_FULLRANK && (last || t == a.lane)) {
-      T *gc = out_g + d;
-      for (int j = g + 1; j < d; j += G)
-        for (int i = tid; i < j; i += NT) gc[(size_t)j * d + i] = T(0);
+    // ---- phase 3a (needs nothing from anybody): exact zeros above the diagonal of the dense gradients -------------------------------------
+    // (a scratch gradient keeps its zeros from this launch's first group: only the unpack below writes it, and only below the diagonal;
+    //  the caller's buffer gets them with the batch's last estimate)
+    if ((a.phases & 4) && !value_wg && a.family == MIVI_FULLRANK) {
+      for (int v = 0; v < nv; ++v) {
+        const bool last = (t0 + v == a.count - 1);
+        if (!(last || first_group)) continue;
+        T *gc = (last ? a.grad : a.scratch + (size_t)v * a.scratch_stride + 4) + d;
+        for (int j = g + 1; j < d; j += G)
+          for (int i = tid; i < j; i += NT) gc[(size_t)j * d + i] = T(0);
+      }
     }
 
-    // ---- phase 2: reduce + finalise chunk g of MY slice, push the final chunk to every rank, one final flag per rank --------------------
+    // ---- phase 2: reduce + finalise chunk g of MY slice of every vector, push the final chunks to every rank, one final flag per rank ------
     if ((a.phases & 2) && !value_wg) {
       if (!wait_flags<NT>(tb.arr[ln][a.rank] + (size_t)(p * R) * G + g, R, G, epoch, lost ? 64 : a.spin_budget, &sh_ok)) lost = true;
-      if (R == 1) p2p_reduce_chunk<T, 1, NT>(a, tb, p, c0, clen);
-      else if (R == 2) p2p_reduce_chunk<T, 2, NT>(a, tb, p, c0, clen);
-      else if (R <= 4) p2p_reduce_chunk<T, 4, NT>(a, tb, p, c0, clen);
-      else p2p_reduce_chunk<T, 8, NT>(a, tb, p, c0, clen);
+      for (int v = 0; v < nv; ++v) {
+        const int pv = p * GV + v;
+        if (R == 1) p2p_reduce_chunk<T, 1, NT>(a, tb, pv, c0, clen);
+        else if (R == 2) p2p_reduce_chunk<T, 2, NT>(a, tb, pv, c0, clen);
+        else if (R <= 4) p2p_reduce_chunk<T, 4, NT>(a, tb, pv, c0, clen);
+        else p2p_reduce_chunk<T, 8, NT>(a, tb, pv, c0, clen);
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid < R) flag_store(tb.farr[ln][tid] + (size_t)(p * R + a.rank) * (G + 1) + g, epoch);
     }
-    if ((a.phases & 2) && value_wg && a.rank == a.vs) {   // the objective value: sum ell, sum 0.5|eps|^2 of all ranks + the parameter-only terms
+    if ((a.phases & 2) && value_wg && a.rank == a.vs) {   // the objective values: sum ell, sum 0.5|eps|^2 of all ranks + the parameter-only terms
       const long long o0 = tri_end - (long long)a.vs * n, o1 = o0 + 1;   // offsets of the two scalars inside my slice
       const int ga = (int)(o0 / a.cn), gb = (int)(o1 / a.cn);
       if (!wait_flags<NT>(tb.arr[ln][a.rank] + (size_t)(p * R) * G + ga, R, G, epoch, lost ? 64 : a.spin_budget, &sh_ok)) lost = true;
@@ -317,8 +329,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       }
       s_ld = block_sum<double, NT>(s_ld, red);
       bad = block_sum<double, NT>(bad, red);
-      if (tid == 0) {
-        const T *st = (const T *)tb.stage[ln][a.rank] + (size_t)(p * R) * n;
+      if (tid < nv) {
+        const int v = tid;
+        const T *st = (const T *)tb.stage[ln][a.rank] + (size_t)((p * GV + v) * R) * n;
         double sum_ell = 0.0, s_he = 0.0;
         for (int src = 0; src < R; ++src) {
           sum_ell += (double)ld_sys(st + (size_t)src * n + o0);
@@ -331,21 +344,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         if (!isfinite(value)) stt |= 1;
         if (bad > 0.0) stt |= 2;
         for (int s = 0; s < R; ++s) {
-          T *dst = (T *)tb.fin[ln][s] + (size_t)p * R * n;
+          T *dst = (T *)tb.fin[ln][s] + (size_t)(p * GV + v) * R * n;
           st_sys(dst + tri_end, (T)value);
           st_sys(dst + tri_end + 1, (T)stt);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (int s = 0; s < R; ++s) flag_store(tb.farr[ln][s] + (size_t)(p * R + a.vs) * (G + 1) + G, epoch);
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid < R) flag_store(tb.farr[ln][tid] + (size_t)(p * R + a.vs) * (G + 1) + G, epoch);
     }
 
-    // ---- phase 3: unpack chunk g of every final slice ------------------------------------------------------------------------------------
+    // ---- phase 3: unpack chunk g of every final slice of every vector ---------------------------------------------------------------------
     if (a.phases & 4) {
-      const T *fin = (const T *)tb.fin[ln][a.rank] + (size_t)p * R * n;
       if (value_wg) {
         if (!wait_flags<NT>(tb.farr[ln][a.rank] + (size_t)(p * R + a.vs) * (G + 1) + G, 1, 1, epoch, lost ? 64 : a.spin_budget, &sh_ok)) lost = true;
-        if (tid == 0) {
+        if (tid < nv) {
+          const int v = tid;
+          const T *fin = (const T *)tb.fin[ln][a.rank] + (size_t)(p * GV + v) * R * n;
+          T *out_v = (t0 + v == a.count - 1) ? a.value : a.scratch + (size_t)v * a.scratch_stride;
           *out_v = ld_sys(fin + tri_end);
           const int stt = (int)ld_sys(fin + tri_end + 1);
           if (stt && a.status) atomicOr(a.status, stt);
@@ -354,39 +370,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         // chunk g of every owner's slice: R final flags
         if (!wait_flags<NT>(tb.farr[ln][a.rank] + (size_t)(p * R) * (G + 1) + g, R, G + 1, epoch, lost ? 64 : a.spin_budget, &sh_ok)) lost = true;
         const int vecs = (int)(clen / V), total = vecs * R;   // vector index x = s * vecs + u  (32-bit: 64-bit divides are long sequences)
-        for (int base = 0; base < total; base += 8 * NT) {
-          const void *ptr[8];
-          u32x4_t raw[8];
-          long long gi0[8];
-          bool in[8];
+        for (int v = 0; v < nv; ++v) {
+          const T *fin = (const T *)tb.fin[ln][a.rank] + (size_t)(p * GV + v) * R * n;
+          T *out_g = (t0 + v == a.count - 1) ? a.grad : a.scratch + (size_t)v * a.scratch_stride + 4;
+          for (int base = 0; base < total; base += 8 * NT) {
+            const void *ptr[8];
+            u32x4_t raw[8];
+            long long gi0[8];
+            bool in[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int x = base + u * NT + tid;
-            in[u] = x < total;
-            const int sx = in[u] ? x / vecs : 0, uu = in[u] ? x - sx * vecs : 0;
-            gi0[u] = (long long)sx * n + c0 + (long long)uu * V;
-            if (gi0[u] >= tri_end) in[u] = false;   // (scalars / padding: nothing of this vector is part of the gradient)
-            ptr[u] = fin + (size_t)(in[u] ? gi0[u] : 0);
-          }
-          ld16x8_sys(ptr, raw);
+            for (int u = 0; u < 8; ++u) {
+              const int x = base + u * NT + tid;
+              in[u] = x < total;
+              const int sx = in[u] ? x / vecs : 0, uu = in[u] ? x - sx * vecs : 0;
+              gi0[u] = (long long)sx * n + c0 + (long long)uu * V;
+              if (gi0[u] >= tri_end) in[u] = false;   // (scalars / padding: nothing of this vector is part of the gradient)
+              ptr[u] = fin + (size_t)(in[u] ? gi0[u] : 0);
+            }
+            ld16x8_sys(ptr, raw);
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            if (!in[u]) continue;
-            T e[V];
-            __builtin_memcpy(e, &raw[u], 16);
-            long long pj = 0, pi = 0;
-            const bool tri = a.family != MIVI_MEANFIELD && gi0[u] + V > d;
-            if (tri) packed_col_row(gi0[u] > d ? gi0[u] : (long long)d, d, pj, pi);
+            for (int u = 0; u < 8; ++u) {
+              if (!in[u]) continue;
+              T e[V];
+              __builtin_memcpy(e, &raw[u], 16);
+              long long pj = 0, pi = 0;
+              const bool tri = a.family != MIVI_MEANFIELD && gi0[u] + V > d;
+              if (tri) packed_col_row(gi0[u] > d ? gi0[u] : (long long)d, d, pj, pi);
 #pragma unroll
-            for (int c = 0; c < V; ++c) {
-              const long long gi = gi0[u] + c;
-              if (gi >= tri_end) continue;
-              long long di = gi;
-              if (tri && gi >= d) {
-                di = d + pj * d + pi;
-                packed_next(d, pj, pi);
+              for (int c = 0; c < V; ++c) {
+                const long long gidx = gi0[u] + c;
+                if (gidx >= tri_end) continue;
+                long long di = gidx;
+                if (tri && gidx >= d) {
+                  di = d + pj * d + pi;
+                  packed_next(d, pj, pi);
+                }
+                out_g[di] = e[c];
               }
-              out_g[di] = e[c];
             }
           }
         }
@@ -408,15 +428,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   }
 }
 
-// hand-over words of the pipelined batch on the COMPUTE chain (one thread): announce a complete partial vector (ready = ready_val), then
-// hold the chain until the exchange has read the ring slot the NEXT estimate's kernels are going to overwrite (*freed >= freed_min)
-__global__ void k_p2p_handover(unsigned *ready, unsigned ready_val, const unsigned *freed, unsigned freed_min, int budget, int *status) {
-  // (relaxed: the partial vector was written -- through, sc1 -- by kernels that completed before this one started; a release here is an
-  //  L2 write-back of whatever the exchange kernels running beside the chain have dirtied)
-  if (ready) __hip_atomic_store(ready, ready_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (freed) {
-    while ((int)(__hip_atomic_load(freed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - freed_min) < 0) {
-      if (--budget <= 0) { if (status) atomicOr(status, 8); break; }
+// hand-over words of the pipelined batch on the COMPUTE chain (one thread): announce complete partial vectors (ready = ready_val), then
+// hold the chain until the exchange has read the ring slots the NEXT launches are going to overwrite (*freed[k] >= min[k], up to four)
+struct P2PHandover {
+  unsigned *ready;
+  unsigned ready_val;
+  const unsigned *freed[4];
+  unsigned freed_min[4];
+  int n_freed, budget;
+  int *status;
+};
+__global__ void k_p2p_handover(P2PHandover h) {
+  // (relaxed: the partial vectors were written -- through, sc1 -- by kernels that completed before this one started; a release here is an
+  //  L2 write-back of whatever the exchange kernel running beside the chain has dirtied)
+  if (h.ready) __hip_atomic_store(h.ready, h.ready_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int budget = h.budget;
+  for (int k = 0; k < h.n_freed; ++k) {
+    while ((int)(__hip_atomic_load(h.freed[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - h.freed_min[k]) < 0) {
+      if (--budget <= 0) { if (h.status) atomicOr(h.status, 8); return; }
       __builtin_amdgcn_s_sleep(4);
     }
   }
@@ -424,7 +453,17 @@ __global__ void k_p2p_handover(unsigned *ready, unsigned ready_val, const unsign
 
 // host side -------------------------------------------------------------------------------------------------------------------------
 void launch_p2p_handover(mivi_ctx *c, unsigned *ready, unsigned ready_val, const unsigned *freed, unsigned freed_min) {
-  hipLaunchKernelGGL(k_p2p_handover, dim3(1), dim3(1), 0, c->stream, ready, ready_val, freed, freed_min, c->p2p_spin, (int *)c->status.p);
+  P2PHandover h{};
+  h.ready = ready; h.ready_val = ready_val; h.budget = c->p2p_spin; h.status = (int *)c->status.p;
+  if (freed) { h.freed[0] = freed; h.freed_min[0] = freed_min; h.n_freed = 1; }
+  hipLaunchKernelGGL(k_p2p_handover, dim3(1), dim3(1), 0, c->stream, h);
+}
+void launch_p2p_handover4(mivi_ctx *c, unsigned *ready, unsigned ready_val, const unsigned *const *freed, const unsigned *freed_min, int n) {
+  P2PHandover h{};
+  h.ready = ready; h.ready_val = ready_val; h.budget = c->p2p_spin; h.status = (int *)c->status.p;
+  for (int k = 0; k < n && k < 4; ++k) { h.freed[k] = freed[k]; h.freed_min[k] = freed_min[k]; }
+  h.n_freed = n < 4 ? n : 4;
+  hipLaunchKernelGGL(k_p2p_handover, dim3(1), dim3(1), 0, c->stream, h);
 }
 
 // one lane of the exchange on c->stream: estimates t = lane, lane + lanes, ... < count with partial vectors P[t % ring]
@@ -444,20 +483,20 @@ void launch_p2p_exchange(mivi_ctx *c, const void *params, const void *const *P, 
     a.ready = ready;
     a.freed = freed;
   };
-  const size_t plen4 = (size_t)mivi_params_len(c) + 4;
+  const size_t plen4 = (size_t)mivi_params_len(c) + 4;   // one scratch output {value (4 slots), gradient}; kP2PGroup of them per lane
   if (c->cfg.dtype == MIVI_F32) {
     P2PArgs<float> a{};
     fill(a);
     for (int k = 0; k < ring; ++k) a.P[k] = (const float *)P[k];
     a.params = (const float *)params; a.value = (float *)value; a.grad = (float *)grad;
-    a.scratch = (float *)c->p2p_scratch.p + plen4 * lane;
+    a.scratch = (float *)c->p2p_scratch.p + plen4 * kP2PGroup * lane; a.scratch_stride = (long long)plen4;
     hipLaunchKernelGGL(k_p2p_exchange<float>, dim3(c->p2p_G + 1), dim3(256), 0, c->stream, a);
   } else {
     P2PArgs<double> a{};
     fill(a);
     for (int k = 0; k < ring; ++k) a.P[k] = (const double *)P[k];
     a.params = (const double *)params; a.value = (double *)value; a.grad = (double *)grad;
-    a.scratch = (double *)c->p2p_scratch.p + plen4 * lane;
+    a.scratch = (double *)c->p2p_scratch.p + plen4 * kP2PGroup * lane; a.scratch_stride = (long long)plen4;
     hipLaunchKernelGGL(k_p2p_exchange<double>, dim3(c->p2p_G + 1), dim3(256), 0, c->stream, a);
   }
 }

@@ -169,7 +169,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_P2, &c->dist_P3, &c->dist_P4, &c->p2p_scratch, &c->dist_S, &c->dist_F, &c->p2p_tab, &c->p2p_ctr, &c->lds_tabV, &c->lds_tabV64, &c->lds_tabSt, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_P2, &c->dist_ring[0], &c->dist_ring[1], &c->dist_ring[2], &c->dist_ring[3], &c->dist_ring[4], &c->dist_ring[5], &c->p2p_scratch, &c->dist_S, &c->dist_F, &c->p2p_tab, &c->p2p_ctr, &c->lds_tabV, &c->lds_tabV64, &c->lds_tabSt, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -949,7 +949,7 @@ struct P2PHandle {   // what travels between the ranks (MIVI_P2P_HANDLE_BYTES = 
 };
 static_assert(sizeof(P2PHandle) <= MIVI_P2P_HANDLE_BYTES, "handle blob");
 constexpr uint32_t kP2PMagic = 0x4D495650u;   // "MIVP"
-constexpr int kLanes = 2, kRing = 4;   // (kernels_p2p.hip: kP2PLanes, kP2PRing)
+constexpr int kLanes = 2, kRing = 8, kGroup = 4;   // (kernels_p2p.hip: kP2PLanes, kP2PRing, kP2PGroup)
 struct P2PTableHost { char *stage[kLanes][8]; char *fin[kLanes][8]; unsigned *arr[kLanes][8]; unsigned *farr[kLanes][8]; };   // == P2PTable (kernels_p2p.hip)
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1006,8 +1006,9 @@ mivi_status_t mivi_p2p_export(mivi_ctx_t *c, int32_t rank, int32_t world, void *
   int G, vs;
   p2p_geometry(L, world, n, cn, G, vs);
   const size_t es = c->esize;
-  // per lane (double-buffered by epoch parity): staging [2][R][n] T, final [2][R n] T, arrival flags [2][R][G], final flags [2][R][G + 1]
-  const size_t b_stage = align256((size_t)2 * world * n * es), b_fin = align256((size_t)2 * world * n * es);
+  // per lane (double-buffered by epoch parity; an epoch carries a group of kGroup estimates): staging [2][V][R][n] T, final [2][V][R n] T,
+  // arrival flags [2][R][G], final flags [2][R][G + 1]
+  const size_t b_stage = align256((size_t)2 * kGroup * world * n * es), b_fin = align256((size_t)2 * kGroup * world * n * es);
   const size_t b_arr = align256((size_t)2 * world * G * 4), b_farr = align256((size_t)2 * world * (G + 1) * 4);
   const size_t lane_bytes = b_stage + b_fin + b_arr + b_farr;
   const size_t bytes = lane_bytes * kLanes;
@@ -1026,7 +1027,7 @@ mivi_status_t mivi_p2p_export(mivi_ctx_t *c, int32_t rank, int32_t world, void *
   c->p2p_rank = rank; c->p2p_world = world; c->p2p_n = n; c->p2p_cn = cn; c->p2p_G = G; c->p2p_vs = vs;
   c->p2p_lane_bytes = lane_bytes; c->p2p_off_fin = b_stage; c->p2p_off_arr = b_stage + b_fin; c->p2p_off_farr = b_stage + b_fin + b_arr;
   P2PHandle h{};
-  h.magic = kP2PMagic; h.version = 2; h.rank = rank; h.world = world; h.L = L; h.n = n; h.cn = cn; h.esize = (int32_t)es; h.G = G;
+  h.magic = kP2PMagic; h.version = 3; h.rank = rank; h.world = world; h.L = L; h.n = n; h.cn = cn; h.esize = (int32_t)es; h.G = G;
   h.bytes = bytes; h.pid = (uint64_t)getpid(); h.local_ptr = (uint64_t)(uintptr_t)buf; h.device = c->cfg.device;
   if (hipIpcGetMemHandle(&h.ipc, buf) != hipSuccess) {   // single-process use (tests, world = 1) still works through local_ptr
     (void)hipGetLastError();
@@ -1048,7 +1049,7 @@ mivi_status_t mivi_p2p_attach(mivi_ctx_t *c, const void *handles) {
   for (int r = 0; r < R; ++r) {
     P2PHandle h;
     memcpy(&h, (const char *)handles + (size_t)r * MIVI_P2P_HANDLE_BYTES, sizeof(h));
-    if (h.magic != kP2PMagic || h.version != 2 || h.rank != r || h.world != R || h.L != mivi_partials_len(c) || h.n != c->p2p_n ||
+    if (h.magic != kP2PMagic || h.version != 3 || h.rank != r || h.world != R || h.L != mivi_partials_len(c) || h.n != c->p2p_n ||
         h.cn != c->p2p_cn || h.G != c->p2p_G || h.esize != (int32_t)c->esize || h.bytes != c->p2p_bytes)
       return fail(c, MIVI_ERR_BAD_ARG, "peer-to-peer handle does not match this context (rank order, family, d, dtype or world differ)");
     void *base = nullptr;
@@ -1080,7 +1081,7 @@ mivi_status_t mivi_p2p_attach(mivi_ctx_t *c, const void *handles) {
   }
   mivi_status_t s;
   if ((s = ensure(c, c->p2p_tab, sizeof(tab), false)) || (s = ensure(c, c->p2p_ctr, 512, false)) ||
-      (s = ensure(c, c->p2p_scratch, ((size_t)mivi_params_len(c) + 4) * kLanes * c->esize, false)))
+      (s = ensure(c, c->p2p_scratch, ((size_t)mivi_params_len(c) + 4) * kGroup * kLanes * c->esize, false)))
     return s;
   HIPCHK(c, hipMemcpy(c->p2p_tab.p, &tab, sizeof(tab), hipMemcpyHostToDevice));
   // (stream-ordered on the context's stream and waited for: a null-stream memset is NOT ordered against a non-blocking stream and
@@ -1205,12 +1206,17 @@ static mivi_status_t ensure_dist(mivi_ctx *c) {
   (void)R;
   const size_t es = c->esize;
   const size_t need34 = c->p2p_on ? (size_t)need * es : 0;
-  if (c->dist_P.bytes < (size_t)need * es || c->dist_P2.bytes < (size_t)need * es || c->dist_P3.bytes < need34 || c->dist_P4.bytes < need34 ||
+  bool ring_short = false;
+  for (int k = 0; k < 6; ++k) ring_short = ring_short || c->dist_ring[k].bytes < need34;
+  if (c->dist_P.bytes < (size_t)need * es || c->dist_P2.bytes < (size_t)need * es || ring_short ||
       c->dist_S.bytes < (size_t)n * es || c->dist_F.bytes < (size_t)Lp * es) {
     invalidate_graph(c);
     mivi_status_t s;
-    c->dist_P.bytes = 0; c->dist_P2.bytes = 0; c->dist_P3.bytes = 0; c->dist_P4.bytes = 0;   // (re-zero: the padding behind the partial vector must be 0)
-    if (need34 && ((s = ensure(c, c->dist_P3, need34, true)) || (s = ensure(c, c->dist_P4, need34, true)))) return s;
+    c->dist_P.bytes = 0; c->dist_P2.bytes = 0;   // (re-zero: the padding behind the partial vector must be 0)
+    for (int k = 0; k < 6; ++k) {
+      c->dist_ring[k].bytes = 0;
+      if (need34 && (s = ensure(c, c->dist_ring[k], need34, true))) return s;
+    }
     if ((s = ensure(c, c->dist_P, (size_t)need * es, true)) || (s = ensure(c, c->dist_P2, (size_t)need * es, true)) ||
         (s = ensure(c, c->dist_S, (size_t)n * es, true)) || (s = ensure(c, c->dist_F, (size_t)Lp * es, true)))
       return s;
@@ -1723,6 +1729,27 @@ static mivi_status_t sync_kid(mivi_ctx *c, mivi_ctx *k, int lanes) {
   return MIVI_OK;
 }
 
+// children of an interleaved / lane-batched batch: the same configuration, their own stream and work buffers, the target borrowed
+static mivi_status_t ensure_kids(mivi_ctx *c, int lanes) {
+  mivi_status_t s;
+  while (c->n_kids < lanes - 1) {
+    mivi_config_t cfg = c->cfg;
+    cfg.stream = nullptr;
+    cfg.own_stream = 1;
+    mivi_ctx *k = nullptr;
+    if ((s = mivi_create(&cfg, &k))) return fail(c, s, "interleaved chains: child context creation failed");
+    k->is_child = true;
+    const int j = c->n_kids;
+    (void)hipFree(k->status.p);                                    // the child's sticky flags: word j + 1 of the parent's status buffer
+    k->status.p = (char *)c->status.p + sizeof(int) * (j + 1);    // (borrowed: is_child contexts never free it)
+    if ((s = ensure(c, c->kid_out[j], 16 + (size_t)mivi_params_len(c) * c->esize, false))) { (void)mivi_destroy(k); return s; }
+    HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[j], hipEventDisableTiming));
+    if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    c->kids[c->n_kids++] = k;
+  }
+  return MIVI_OK;
+}
+
 mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64_t idx0, int32_t count, void *value, void *grad) {
   if (!c || !params || !value || !grad || count <= 0) return MIVI_ERR_BAD_ARG;
   (void)hipSetDevice(c->cfg.device);
@@ -1758,21 +1785,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
     return estimate_gradient_chain(c, params, idx0, count, value, grad);
   }
   mivi_status_t s;
-  while (c->n_kids < lanes - 1) {   // children: the same configuration, their own stream and work buffers
-    mivi_config_t cfg = c->cfg;
-    cfg.stream = nullptr;
-    cfg.own_stream = 1;
-    mivi_ctx *k = nullptr;
-    if ((s = mivi_create(&cfg, &k))) return fail(c, s, "interleaved chains: child context creation failed");
-    k->is_child = true;
-    const int j = c->n_kids;
-    (void)hipFree(k->status.p);                                    // the child's sticky flags: word j + 1 of the parent's status buffer
-    k->status.p = (char *)c->status.p + sizeof(int) * (j + 1);    // (borrowed: is_child contexts never free it)
-    if ((s = ensure(c, c->kid_out[j], 16 + (size_t)mivi_params_len(c) * c->esize, false))) { (void)mivi_destroy(k); return s; }
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[j], hipEventDisableTiming));
-    if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    c->kids[c->n_kids++] = k;
-  }
+  if ((s = ensure_kids(c, lanes))) return s;
   if (c->idx_stride != lanes) { invalidate_graph(c); c->idx_stride = lanes; }
   for (int j = 0; j < lanes - 1; ++j)
     if ((s = sync_kid(c, c->kids[j], lanes))) return s;
@@ -1963,12 +1976,68 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
 // buffered, estimate t + 2 waits for the exchange of t to release its buffer.  One hipGraph with two branches per estimate; if the
 // capture is refused (a collective that cannot be captured) the same sequence is issued eagerly with events.
 //   mode 0 pipelined | 1 serial {partials -> exchange} on one stream | 2 partials only | 3 exchange only (on the last partial vector)
+// mode 4 with LANE-BATCHED compute (second-generation full-rank kernels, no STL solve): four contexts compute four consecutive estimates
+// with ONE product launch and ONE VJP launch (blockIdx.y = lane, each lane's packed partials into its ring slot), ONE hand-over per four
+// estimates -- the exchange kernel serves them as one group (kernels_p2p.hip).
+static mivi_status_t dist_sequence_lanes(mivi_ctx *c, const void *params, bool counter_idx, uint64_t idx0, int count) {
+  constexpr int E = kGroup;
+  mivi_status_t s = MIVI_OK;
+  void *ringP[kRing] = {c->dist_P.p, c->dist_P2.p, c->dist_ring[0].p, c->dist_ring[1].p, c->dist_ring[2].p, c->dist_ring[3].p, c->dist_ring[4].p, c->dist_ring[5].p};
+  mivi_ctx *ctxs[E];
+  hipStream_t kept[E];
+  ctxs[0] = c;
+  for (int l = 1; l < E; ++l) ctxs[l] = c->kids[l - 1];
+  LaneSink *sink = lane_sinks_alloc(E);
+  const bool dense = c->target == TGT_DENSE_GAUSS;
+  for (int l = 0; l < E; ++l) { kept[l] = ctxs[l]->stream; ctxs[l]->stream = c->stream; ctxs[l]->lane_sink = sink; ctxs[l]->lane_id = l; }
+  unsigned *w = (unsigned *)c->p2p_ctr.p;
+  for (int s0 = 0; s0 < count && s == MIVI_OK; s0 += E) {
+    const int L = count - s0 < E ? count - s0 : E;
+    for (int l = 0; l < L && s == MIVI_OK; ++l) {
+      const int i = s0 + l;
+      mivi_ctx *k = ctxs[l];
+      lane_sink_reset(sink, l);
+      RngArgs r = rng_of(k, counter_idx ? (uint64_t)i : idx0 + (uint64_t)i);
+      if (counter_idx) r.idx_ptr = (const uint64_t *)c->d_idx.p;
+      OutArgs o = final_out(k, nullptr, nullptr);
+      o.partials = ringP[i % kRing];
+      o.partials_mode = 1;
+      o.scalars_off = mivi_partials_len(c) - 2;
+      if ((s = run_estimate(k, params, r, k->cfg.n_mc, 1, o))) { c->err = k->err; break; }
+      if (lane_sink_counts(sink, l) != (dense ? 2 : 1) * 16 + 1) s = fail(c, MIVI_ERR_HIP, "lane-batched sharded estimates: an estimate did not take the two-kernel route");
+    }
+    if (s == MIVI_OK && !(launch_lanes_prod(c, sink, L, 0) && (!dense || launch_lanes_prod(c, sink, L, 1)) && launch_lanes_vjp(c, sink, L)))
+      s = fail(c, MIVI_ERR_HIP, "lane-batched sharded estimates: the lanes' launches do not match");
+    if (s) break;
+    // announce the group's partial vectors; hold the chain until the exchange has read the ring slots the NEXT group overwrites
+    const unsigned *fr[E];
+    unsigned fmin[E];
+    int nf = 0;
+    for (int l = 0; l < E; ++l) {
+      const int nx = s0 + E + l;
+      if (nx >= count) break;
+      const int prev_users = nx / kRing;
+      if (prev_users >= 1) { fr[nf] = w + 80 + nx % kRing; fmin[nf] = (unsigned)prev_users * (unsigned)c->p2p_G; ++nf; }
+    }
+    launch_p2p_handover4(c, w + 64, (unsigned)(s0 + L), fr, fmin, nf);
+  }
+  for (int l = 0; l < E; ++l) {
+    ctxs[l]->lane_sink = nullptr;
+    ctxs[l]->stream = kept[l];
+    ctxs[l]->cur = 0;
+    ctxs[l]->pre_valid = false;
+  }
+  lane_sinks_free(sink);
+  return s;
+}
+
 static mivi_status_t dist_sequence(mivi_ctx *c, const void *params, bool counter_idx, uint64_t idx0, int count, void *value, void *grad, int mode) {
+  if (mode == 4 && c->dist_lane4) return dist_sequence_lanes(c, params, counter_idx, idx0, count);
   mivi_status_t s = MIVI_OK;
   hipStream_t main = c->stream;
   for (int i = 0; i < count && s == MIVI_OK; ++i) {
     const int par = i & 1;
-    void *ringP[4] = {c->dist_P.p, c->dist_P2.p, c->dist_P3.p, c->dist_P4.p};
+    void *ringP[kRing] = {c->dist_P.p, c->dist_P2.p, c->dist_ring[0].p, c->dist_ring[1].p, c->dist_ring[2].p, c->dist_ring[3].p, c->dist_ring[4].p, c->dist_ring[5].p};
     void *P = mode == 4 ? ringP[i % kRing] : (par ? c->dist_P2.p : c->dist_P.p);
     if (mode == 0 && i >= 2) HIPCHK(c, hipStreamWaitEvent(main, c->ev_comm[par], 0));   // the exchange of i - 2 has released this partial buffer
     if (mode != 3) {
@@ -2047,10 +2116,36 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
   bool p2p_pipe = mode == 0 && route == 3;
   if (p2p_pipe && c->p2p_pipe_state < 0) { p2p_pipe = false; mode = 1; }   // (its kernels did not run beside the compute chain on this context: serial steps)
   if (p2p_pipe) mode = 4;
+  {   // lane-batched compute chain for the pipelined batches (see dist_sequence_lanes)
+    static const bool no_lanes = getenv("MIVI_LANE_BATCH") && atoi(getenv("MIVI_LANE_BATCH")) == 0;
+    const bool stl_ent = c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD;
+    OutArgs on = final_out(c, nullptr, nullptr);
+    on.partials = c->dist_P.p;
+    on.partials_mode = 1;
+    const bool lane4 = mode == 4 && !no_lanes && !stl_ent && !c->dbg && c->cfg.family == MIVI_FULLRANK && lds_route(c, params, c->cfg.n_mc, 1, on) &&
+                       lds_use_prod32(c, c->cfg.n_mc) && lds_bf16x3() && count >= kGroup;
+    const int stride = lane4 ? kGroup : 1;
+    if (c->dist_lane4 != lane4 || c->idx_stride != stride) { invalidate_graph(c); c->dist_lane4 = lane4; c->idx_stride = stride; }
+    if (lane4) {
+      if ((s = ensure_kids(c, kGroup))) return s;
+      for (int j = 0; j < kGroup - 1; ++j) {
+        mivi_ctx *k = c->kids[j];
+        if ((s = sync_kid(c, k, kGroup)) || (s = ensure_work(k, k->cfg.n_mc))) { c->err = k->err; return s; }
+        prepare_tables(k, k->cfg.n_mc);
+        if (!lds_prepare(k, k->cfg.n_mc)) return fail(c, MIVI_ERR_HIP, "full-rank work lists: allocation failed");
+      }
+    }
+  }
   const int kind = 20 + mode;
   static bool capture_refused = false;   // (a collective library that cannot be captured: do not retry on every call)
   if (!(g.exec && g.kind == kind && g.count == count && g.params == params && g.value == value && g.grad == grad && g.p0 == (double)route) && !capture_refused) {
     invalidate_graph(c);
+    if (c->dist_lane4) {
+      for (int j = 0; j < kGroup - 1; ++j) {
+        c->kids[j]->kid_gen = c->target_gen;
+        HIPCHK(c, hipStreamSynchronize(c->kids[j]->stream));   // (their table uploads, before the capture)
+      }
+    }
     hipGraph_t graph = nullptr;
     hipStream_t saved;
     if ((s = begin_capture(c, &saved))) return s;
@@ -2075,7 +2170,7 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
     HIPCHK(c, hipMemsetAsync(w + 64, 0, 128, c->stream));
     HIPCHK(c, hipEventRecord(c->ev_part[0], c->stream));
     hipStream_t main = c->stream;
-    const void *ringP[4] = {c->dist_P.p, c->dist_P2.p, c->dist_P3.p, c->dist_P4.p};
+    const void *ringP[kRing] = {c->dist_P.p, c->dist_P2.p, c->dist_ring[0].p, c->dist_ring[1].p, c->dist_ring[2].p, c->dist_ring[3].p, c->dist_ring[4].p, c->dist_ring[5].p};
     // ONE persistent lane by default (measured on one GPU: 21 us per estimate against 31 with two -- a second resident exchange kernel costs
     // the compute chain more than its overlap wins); two where the exchange's latency is several compute steps (mivi_p2p_set_pipeline(ctx, 2))
     const int lanes = (count >= 2 && c->p2p_pipe_state >= 2) ? kLanes : 1;

@@ -227,7 +227,7 @@ struct mivi_ctx {
   // partial vectors double-buffered (dist_P, dist_P2), event pairs per parity
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_part[2] = {nullptr, nullptr}, ev_comm[2] = {nullptr, nullptr};
-  mivi::DevBuf dist_P2, dist_P3, dist_P4;   // ring of partial vectors (two for the RCCL pipeline, four for the peer-to-peer lanes)
+  mivi::DevBuf dist_P2, dist_ring[6];       // ring of partial vectors (two for the RCCL pipeline, eight = two groups of four for the peer-to-peer pipeline)
   hipStream_t comm_stream2 = nullptr;
   int p2p_pipe_state = 1;   // persistent peer-to-peer pipeline in batched calls: 1 on, -1 off (mivi_p2p_set_pipeline: serial steps)
   int dist_route = 0;   // mivi_comm_set_route: 0 by size, 1 ncclAllReduce, 2 ncclReduceScatter / ncclAllGather, 3 peer-to-peer kernel
@@ -319,6 +319,7 @@ struct mivi_ctx {
   int n_kids = 0;
   unsigned long long target_gen = 0, kid_gen = ~0ull;   // parent: bumped whenever a captured graph is invalidated; child: the generation it mirrors
   hipEvent_t ev_fork = nullptr, ev_join[kMaxKids] = {};
+  bool dist_lane4 = false;       // pipelined sharded batches: the compute chain is lane-batched (four contexts per launch)
   void *stl_sink = nullptr;      // ... and launch_stl2 into stl_sink[lane_id]
   void *lane_sink = nullptr;     // lane-batched estimates: the launchers of the two second-generation kernels record into sink[lane_id] instead of launching
   int lane_id = 0;
@@ -407,6 +408,7 @@ bool logreg_reserve(mivi_ctx *c, int M);                        // size the scra
 bool logreg_prepare_f32(mivi_ctx *c);   // row-major padded copy of X for the MFMA route (false: allocation failed)
 
 // kernels_p2p.hip: phases bit 0 push, 1 reduce + finalise, 2 unpack (7 = the whole exchange in one launch)
+void launch_p2p_handover4(mivi_ctx *c, unsigned *ready, unsigned ready_val, const unsigned *const *freed, const unsigned *freed_min, int n);
 void launch_p2p_exchange(mivi_ctx *c, const void *params, const void *const *P, int ring, void *value, void *grad, int phases, int lane, int lanes,
                          int count, const unsigned *ready, unsigned *freed);   // one lane: estimates lane, lane + lanes, ... < count; P[t % ring]
 void launch_p2p_handover(mivi_ctx *c, unsigned *ready, unsigned ready_val, const unsigned *freed, unsigned freed_min);

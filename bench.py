@@ -504,7 +504,7 @@ def main():
             dist_info["route"] = ctx.comm_route()
             ctx.estimate_gradient_dist(params, 0, value, grad)          # allocate every work buffer before any capture
             ctx.synchronize()
-            chunk = max(1, min(20, K))
+            chunk = max(1, min(100, K))   # estimates per pipelined batch (each batch ends with the exchange of its last group: ~100 us of tail)
             pipelined = os.environ.get("MIVI_DIST_PIPELINE", "1") != "0"
             lanes = 2 if os.environ.get("MIVI_DIST_LANES") == "2" else 1   # persistent exchange lanes beside the compute chain (one measured best on one GPU)
             if pipelined and dist_info["route"] == "p2p":
