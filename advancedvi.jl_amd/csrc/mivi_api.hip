@@ -959,12 +959,13 @@ void p2p_geometry(long long L, int R, long long &n, long long &cn, int &G, int &
   n = ((L + R - 1) / R + 3) & ~3LL;
   while ((L - 1) % n == 0) n += 4;        // the two scalars (L - 2, L - 1) must lie in ONE slice
   vs = (int)((L - 2) / n);
-  // Small chunks, but at most 127 (+ the value workgroup = 128 per lane): the exchange kernels are persistent and spin beside the
-  // compute chain, so with two lanes they hold about one workgroup per CU.  More would be faster for an exchange on its own (system-
-  // scope accesses are limited per CU: 46 us with 128 workgroups, 33 us with 512) but 513 spinning workgroups per lane held every
-  // CU's registers and the compute kernels could not be scheduled beside them at all (found on the GPU: the hand-over timed out).
+  // Small chunks, but at most 255 (+ the value workgroup = one workgroup per CU): the exchange kernel is persistent and spins beside the
+  // compute chain.  More would be faster for an exchange on its own (system-scope accesses are limited per CU) but 513 spinning
+  // workgroups held every CU's registers and the compute kernels could not be scheduled beside them at all (found on the GPU: the
+  // hand-over timed out); measured in the pipelined batch (groups of four estimates, one lane): 127 -> 18.9, 191 -> 16.4, 255 -> 16.3,
+  // 383 -> 17.6 us per estimate.
   long long g = (n + 511) / 512;
-  G = (int)(g < 1 ? 1 : (g > 127 ? 127 : g));
+  G = (int)(g < 1 ? 1 : (g > 255 ? 255 : g));
   cn = ((n + G - 1) / G + 3) & ~3LL;
 }
 }  // namespace

@@ -551,7 +551,7 @@ def p2p_geometry(L, world):
     while (L - 1) % n == 0:
         n += 4
     vs = (L - 2) // n
-    G = min(127, max(1, (n + 511) // 512))
+    G = min(255, max(1, (n + 511) // 512))
     cn = ((n + G - 1) // G + 3) & ~3
     return n, cn, G, vs
 

@@ -271,7 +271,7 @@ def test_p2p_geometry_invariants_and_host_restatement():
         for R in range(1, 9):
             n, cn, G, vs = p2p_geometry(L, R)
             assert (n, cn, G, vs) == O.p2p_geometry(L, R)
-            assert n % 4 == 0 and cn % 4 == 0 and n * R >= L and G * cn >= n and 1 <= G <= 127
+            assert n % 4 == 0 and cn % 4 == 0 and n * R >= L and G * cn >= n and 1 <= G <= 255
             assert (L - 2) // n == (L - 1) // n == vs and 0 <= vs < R
 
 
