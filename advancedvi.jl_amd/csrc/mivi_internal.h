@@ -313,7 +313,7 @@ struct mivi_ctx {
   // whose kernels overlap on the device (the product of one chain's estimate runs beside the VJP of another's).
   int idx_stride = 1;            // estimate-index step between consecutive estimates of THIS context's chain
   bool is_child = false;         // target buffers are borrowed from the parent
-  static constexpr int kMaxKids = 15;   // up to eight contexts; at most FOUR graph branches (a forked graph with five branches crashed inside hipGraphLaunch,
+  static constexpr int kMaxKids = 15;   // up to sixteen contexts (eight are used); at most FOUR graph branches (a forked graph with five branches crashed inside hipGraphLaunch,
                                        // hip::Graph::UpdateStreams, after a re-capture on ROCm 7.0's runtime; four is also the number of hardware queues)
   mivi_ctx *kids[kMaxKids] = {};
   int n_kids = 0;
