@@ -330,9 +330,9 @@ class MiviContext:
     def p2p_detach(self):
         self._chk(self.lib.mivi_p2p_detach(self.h))
 
-    def p2p_set_pipeline(self, lanes):
-        """0 / False: serial steps; 1 / True: one persistent exchange lane beside the compute chain (default); 2: two lanes."""
-        self._chk(self.lib.mivi_p2p_set_pipeline(self.h, int(lanes)))
+    def p2p_set_pipeline(self, on):
+        """False: serial steps; True (default): the persistent exchange kernel beside the compute chain."""
+        self._chk(self.lib.mivi_p2p_set_pipeline(self.h, 1 if on else 0))
 
     def p2p_set_spin_budget(self, polls):
         self._chk(self.lib.mivi_p2p_set_spin_budget(self.h, int(polls)))

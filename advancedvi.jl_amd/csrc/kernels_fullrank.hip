@@ -77,6 +77,13 @@ __global__ __launch_bounds__(256) void k_eps(SampleArgs<T> a) {
   __shared__ double red[4];
   eps_tile_block<T>(a, blockIdx.x, lds, red);
 }
+// lane-batched contexts (mivi_api.hip): the first draws of up to four contexts as ONE launch (blockIdx.y = lane)
+struct EpsMulti { SampleArgs<float> lane[4]; };
+__global__ __launch_bounds__(256) void k_eps_m(EpsMulti m) {
+  __shared__ float lds[64][17];
+  __shared__ double red[4];
+  eps_tile_block<float>(m.lane[blockIdx.y], blockIdx.x, lds, red);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Tile decomposition helpers
@@ -1224,8 +1231,28 @@ static SampleArgs<T> eps_args(mivi_ctx *c, const RngArgs &rng, int M, int parity
   return a;
 }
 
+struct EpsSink { SampleArgs<float> a[4]; int grid[4], n[4]; };
+EpsSink *eps_sink_alloc() { return new EpsSink(); }
+void eps_sink_free(EpsSink *s) { delete s; }
+void eps_sink_reset(EpsSink *s) { for (int l = 0; l < 4; ++l) s->n[l] = 0; }
+// the recorded first draws of the lanes that made one: ONE launch
+void launch_lanes_eps(mivi_ctx *c, EpsSink *s, int lanes) {
+  EpsMulti m;
+  int L = 0, grid = 0;
+  for (int l = 0; l < lanes && l < 4; ++l)
+    if (s->n[l] > 0) { m.lane[L++] = s->a[l]; grid = s->grid[l]; }
+  if (L > 0) hipLaunchKernelGGL(k_eps_m, dim3(grid, L), dim3(256), 0, c->stream, m);
+}
+
 void launch_eps(mivi_ctx *c, const RngArgs &rng, int M) {
   const int nblk = eps_blocks(c, M);
+  if (c->eps_sink && c->cfg.dtype == MIVI_F32) {   // lane-batched contexts: record (every lane has the same shape, so the same grid)
+    EpsSink *sk = (EpsSink *)c->eps_sink;
+    sk->a[c->lane_id] = eps_args<float>(c, rng, M, c->cur);
+    sk->grid[c->lane_id] = nblk;
+    ++sk->n[c->lane_id];
+    return;
+  }
   if (c->cfg.dtype == MIVI_F32)
     hipLaunchKernelGGL(k_eps<float>, dim3(nblk), dim3(256), 0, c->stream, eps_args<float>(c, rng, M, c->cur));
   else

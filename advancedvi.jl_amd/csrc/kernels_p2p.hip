@@ -42,7 +42,7 @@
 
 namespace mivi {
 
-constexpr int kP2PLanes = 2, kP2PRing = 8, kP2PGroup = 4;   // ring = two groups of estimates: one being exchanged, one being computed
+constexpr int kP2PLanes = 1, kP2PRing = 8, kP2PGroup = 4;   // ring = two groups of estimates: one being exchanged, one being computed
 
 struct P2PTable {   // device resident: where every rank's exchange areas are mapped in THIS process, per lane
   char *stage[kP2PLanes][8];      // [2][V][R][n] T : stage[s] = rank s's staging area (contribution of rank `src` to slice s of the group's vector v at [parity][v][src])

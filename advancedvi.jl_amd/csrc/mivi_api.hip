@@ -949,7 +949,7 @@ struct P2PHandle {   // what travels between the ranks (MIVI_P2P_HANDLE_BYTES = 
 };
 static_assert(sizeof(P2PHandle) <= MIVI_P2P_HANDLE_BYTES, "handle blob");
 constexpr uint32_t kP2PMagic = 0x4D495650u;   // "MIVP"
-constexpr int kLanes = 2, kRing = 8, kGroup = 4;   // (kernels_p2p.hip: kP2PLanes, kP2PRing, kP2PGroup)
+constexpr int kLanes = 1, kRing = 8, kGroup = 4;   // (kernels_p2p.hip: kP2PLanes, kP2PRing, kP2PGroup)
 struct P2PTableHost { char *stage[kLanes][8]; char *fin[kLanes][8]; unsigned *arr[kLanes][8]; unsigned *farr[kLanes][8]; };   // == P2PTable (kernels_p2p.hip)
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1102,8 +1102,10 @@ mivi_status_t mivi_p2p_debug_words(mivi_ctx_t *c, uint32_t *out128) {   // devel
 
 mivi_status_t mivi_p2p_set_pipeline(mivi_ctx_t *c, int32_t on) {
   if (!c) return MIVI_ERR_BAD_ARG;
-  if (on < 0 || on > kLanes) return fail(c, MIVI_ERR_BAD_ARG, "mivi_p2p_set_pipeline: 0 = off, 1 = one persistent exchange lane, 2 = two");
-  c->p2p_pipe_state = on ? on : -1;
+  // (a second persistent exchange kernel serving every other group was an option until the groups: two of them are 512 resident
+  //  workgroups, which starve the compute chain of registers, and one measured better wherever both ran)
+  if (on < 0 || on > 1) return fail(c, MIVI_ERR_BAD_ARG, "mivi_p2p_set_pipeline: 0 = off (serial steps), 1 = the persistent exchange kernel beside the compute chain");
+  c->p2p_pipe_state = on ? 1 : -1;
   invalidate_graph(c);
   return MIVI_OK;
 }
@@ -1831,6 +1833,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
         mivi_status_t st = MIVI_OK;
         LaneSink *sink = lane_sinks_alloc(E);
         StlSink *ssink = stl_ent ? stl_sinks_alloc(E) : nullptr;
+        EpsSink *esink = eps_sink_alloc();
         Chain chn[4];
         hipStream_t bs = ctxs[b * E]->stream, kept[4];
         mivi_ctx *lead = ctxs[b * E];
@@ -1841,10 +1844,12 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
           chn[l].on = true; chn[l].estimates_only = true;
           k->lane_sink = sink; k->lane_id = l;
           k->stl_sink = ssink;
+          k->eps_sink = esink;
         }
         const int steps = (count + lanes - 1) / lanes;
         for (int i = 0; i < steps && st == MIVI_OK; ++i) {
           int L = 0;
+          eps_sink_reset(esink);
           for (int l = 0; l < E && st == MIVI_OK; ++l) {
             const int gl = b * E + l;
             const int cnt = (count - gl + lanes - 1) / lanes;   // estimates of global lane gl: gl, gl + lanes, ...
@@ -1865,6 +1870,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
               st = fail(c, MIVI_ERR_HIP, "lane-batched estimates: an estimate did not take the expected kernel route");
             ++L;
           }
+          if (st == MIVI_OK && L > 0) launch_lanes_eps(lead, esink, L);   // (the lanes' first draws, if this is their first estimate: one launch)
           if (st == MIVI_OK && L > 0 && !(launch_lanes_prod(lead, sink, L, 0) && (!dense || launch_lanes_prod(lead, sink, L, 1)) &&
                                           (!ssink || launch_lanes_stl(lead, ssink, L, i == 0)) && launch_lanes_vjp(lead, sink, L)))
             st = fail(c, MIVI_ERR_HIP, "lane-batched estimates: the lanes' launches do not match");
@@ -1873,6 +1879,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
           mivi_ctx *k = ctxs[b * E + l];
           k->lane_sink = nullptr;
           k->stl_sink = nullptr;
+          k->eps_sink = nullptr;
           if (st == MIVI_OK) flush_chain(k, params, &chn[l]);
           k->cur = 0;
           k->pre_valid = false;
@@ -1880,6 +1887,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
         }
         lane_sinks_free(sink);
         if (ssink) stl_sinks_free(ssink);
+        eps_sink_free(esink);
         return st;
       };
       for (int b = 1; b < B && s == MIVI_OK && he == hipSuccess; ++b) {
@@ -1989,11 +1997,13 @@ static mivi_status_t dist_sequence_lanes(mivi_ctx *c, const void *params, bool c
   ctxs[0] = c;
   for (int l = 1; l < E; ++l) ctxs[l] = c->kids[l - 1];
   LaneSink *sink = lane_sinks_alloc(E);
+  EpsSink *esink = eps_sink_alloc();
   const bool dense = c->target == TGT_DENSE_GAUSS;
-  for (int l = 0; l < E; ++l) { kept[l] = ctxs[l]->stream; ctxs[l]->stream = c->stream; ctxs[l]->lane_sink = sink; ctxs[l]->lane_id = l; }
+  for (int l = 0; l < E; ++l) { kept[l] = ctxs[l]->stream; ctxs[l]->stream = c->stream; ctxs[l]->lane_sink = sink; ctxs[l]->lane_id = l; ctxs[l]->eps_sink = esink; }
   unsigned *w = (unsigned *)c->p2p_ctr.p;
   for (int s0 = 0; s0 < count && s == MIVI_OK; s0 += E) {
     const int L = count - s0 < E ? count - s0 : E;
+    eps_sink_reset(esink);
     for (int l = 0; l < L && s == MIVI_OK; ++l) {
       const int i = s0 + l;
       mivi_ctx *k = ctxs[l];
@@ -2007,6 +2017,7 @@ static mivi_status_t dist_sequence_lanes(mivi_ctx *c, const void *params, bool c
       if ((s = run_estimate(k, params, r, k->cfg.n_mc, 1, o))) { c->err = k->err; break; }
       if (lane_sink_counts(sink, l) != (dense ? 2 : 1) * 16 + 1) s = fail(c, MIVI_ERR_HIP, "lane-batched sharded estimates: an estimate did not take the two-kernel route");
     }
+    if (s == MIVI_OK) launch_lanes_eps(c, esink, L);
     if (s == MIVI_OK && !(launch_lanes_prod(c, sink, L, 0) && (!dense || launch_lanes_prod(c, sink, L, 1)) && launch_lanes_vjp(c, sink, L)))
       s = fail(c, MIVI_ERR_HIP, "lane-batched sharded estimates: the lanes' launches do not match");
     if (s) break;
@@ -2024,11 +2035,13 @@ static mivi_status_t dist_sequence_lanes(mivi_ctx *c, const void *params, bool c
   }
   for (int l = 0; l < E; ++l) {
     ctxs[l]->lane_sink = nullptr;
+    ctxs[l]->eps_sink = nullptr;
     ctxs[l]->stream = kept[l];
     ctxs[l]->cur = 0;
     ctxs[l]->pre_valid = false;
   }
   lane_sinks_free(sink);
+  eps_sink_free(esink);
   return s;
 }
 
@@ -2172,9 +2185,9 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
     HIPCHK(c, hipEventRecord(c->ev_part[0], c->stream));
     hipStream_t main = c->stream;
     const void *ringP[kRing] = {c->dist_P.p, c->dist_P2.p, c->dist_ring[0].p, c->dist_ring[1].p, c->dist_ring[2].p, c->dist_ring[3].p, c->dist_ring[4].p, c->dist_ring[5].p};
-    // ONE persistent lane by default (measured on one GPU: 21 us per estimate against 31 with two -- a second resident exchange kernel costs
-    // the compute chain more than its overlap wins); two where the exchange's latency is several compute steps (mivi_p2p_set_pipeline(ctx, 2))
-    const int lanes = (count >= 2 && c->p2p_pipe_state >= 2) ? kLanes : 1;
+    // ONE persistent exchange kernel (measured on one GPU: 21 us per estimate against 31 with two of them serving alternate estimates -- a
+    // second resident kernel costs the compute chain more than its overlap wins)
+    const int lanes = 1;
     for (int ln = 0; ln < lanes; ++ln) {
       hipStream_t cs = ln ? c->comm_stream2 : c->comm_stream;
       HIPCHK(c, hipStreamWaitEvent(cs, c->ev_part[0], 0));
@@ -2187,7 +2200,6 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
   };
   auto p2p_back = [&]() -> mivi_status_t {
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_comm[0], 0));
-    if (count >= 2 && c->p2p_pipe_state >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_comm[1], 0));
     return MIVI_OK;
   };
   if (g.exec && g.kind == kind && g.count == count && g.params == params && g.value == value && g.grad == grad && g.p0 == (double)route) {

@@ -34,7 +34,7 @@ PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA peak (155 TF 
 PEAK_BF16_MFMA_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 # environment variables that do NOT change which kernels run: bench-harness controls and the RCCL library location
-BENCH_ENV_OK = {"MIVI_FORCE_DIST", "MIVI_DIST_MODE", "MIVI_DIST_EAGER", "MIVI_BENCH_SKIP_C3", "MIVI_RCCL_LIB", "MIVI_DIST_PIPELINE", "MIVI_DIST_LANES"}
+BENCH_ENV_OK = {"MIVI_FORCE_DIST", "MIVI_DIST_MODE", "MIVI_DIST_EAGER", "MIVI_BENCH_SKIP_C3", "MIVI_RCCL_LIB", "MIVI_DIST_PIPELINE"}
 
 WORKLOADS = {
     "ns": dict(family=1, d=1024, n_mc=256, target="iso", entropy=0,
@@ -506,9 +506,7 @@ def main():
             ctx.synchronize()
             chunk = max(1, min(100, K))   # estimates per pipelined batch (each batch ends with the exchange of its last group: ~100 us of tail)
             pipelined = os.environ.get("MIVI_DIST_PIPELINE", "1") != "0"
-            lanes = 2 if os.environ.get("MIVI_DIST_LANES") == "2" else 1   # persistent exchange lanes beside the compute chain (one measured best on one GPU)
             if pipelined and dist_info["route"] == "p2p":
-                ctx.p2p_set_pipeline(lanes)
                 # the persistent exchange kernels must really run beside the compute chain on every rank: one warm batch, checked
                 # (bounded waits: a device that serialises them reports an error instead of hanging); all ranks switch together
                 try:
@@ -522,7 +520,7 @@ def main():
                     ctx.p2p_set_pipeline(False)
                     dist_info["pipeline"] = "off (exchange kernels did not run beside the compute chain): serial steps in one graph"
                 else:
-                    dist_info["pipeline"] = f"persistent exchange kernel beside the compute chain, {lanes} lane(s)"
+                    dist_info["pipeline"] = "persistent exchange kernel beside the lane-batched compute chain, groups of four estimates per epoch"
 
             def run(idx0, n):
                 done = 0

@@ -330,12 +330,12 @@ mivi_status_t mivi_p2p_detach(mivi_ctx_t *ctx);
  * length L over `world` ranks (no GPU needed) */
 void mivi_p2p_geometry(int64_t L, int32_t world, int64_t *out4);
 mivi_status_t mivi_comm_enable_p2p(mivi_ctx_t *ctx);
-/* Batched sharded estimates on the peer-to-peer route run the exchange as persistent kernels ("lanes": lane l serves estimates l, l + lanes,
- * ...) on their own streams BESIDE the compute chain (csrc/kernels_p2p.hip).  lanes = 1 (default) or 2; 0 = no pipeline: batched calls run
- * serial steps.  The pipeline needs the device to schedule the lanes and the compute chain concurrently; where it does not (streams sharing
- * one hardware queue), the bounded waits end in MIVI_ERR_HIP at the next mivi_synchronize -- the host then switches the pipeline off ON
- * EVERY RANK (all ranks must use the same setting: the lanes the estimates use differ). */
-mivi_status_t mivi_p2p_set_pipeline(mivi_ctx_t *ctx, int32_t lanes);
+/* Batched sharded estimates on the peer-to-peer route run the exchange as ONE persistent kernel on its own stream BESIDE the compute chain
+ * (csrc/kernels_p2p.hip), serving groups of four estimates per epoch.  on = 1 (default); 0 = no pipeline: batched calls run serial steps.
+ * The pipeline needs the device to schedule the exchange kernel and the compute chain concurrently; where it does not (streams sharing one
+ * hardware queue), the bounded waits end in MIVI_ERR_HIP at the next mivi_synchronize -- the host then switches the pipeline off ON EVERY
+ * RANK (all ranks must use the same setting). */
+mivi_status_t mivi_p2p_set_pipeline(mivi_ctx_t *ctx, int32_t on);
 /* developer: the exchange's device words (per lane {epoch, ticket} at 16-word spacing, ready at word 64, freed[ring] at word 80): out128 = uint32[128] */
 mivi_status_t mivi_p2p_debug_words(mivi_ctx_t *ctx, uint32_t *out128_host);
 /* how many polls (about 1 us each) a wait inside the exchange may take before the peer counts as lost (default 2^21, about 2 s) */

@@ -195,12 +195,12 @@ def test_two_processes_exchange_through_ipc(family, d, M):
         assert wv <= 2e-6 and wg <= 5e-6 and same, (rank, wv, wg, same)
 
 
-@pytest.mark.parametrize("route", ["p2p", "p2p-2lanes", "allreduce", "rsag", "none"])
+@pytest.mark.parametrize("route", ["p2p", "allreduce", "rsag", "none"])
 @pytest.mark.parametrize("family,d,M,count", [(avi.FULLRANK, 256, 128, 7), (avi.MEANFIELD, 512, 64, 5), (avi.FULLRANK, 1024, 256, 12),
                                                (avi.FULLRANK, 96, 40, 1)])
 def test_pipelined_batch_equals_single_estimates(family, d, M, count, route):
     """mivi_estimate_gradient_dist_n: the exchange of estimate t overlapped with the kernels of t + 1 (a ring of partial vectors; on the
-    peer-to-peer route one -- the default -- or two persistent exchange lanes beside the compute chain) returns what `count` single
+    peer-to-peer route the persistent exchange kernel beside a lane-batched compute chain, four estimates per epoch) returns what `count` single
     sharded estimates return, for every exchange route (world = 1)."""
     rng = np.random.default_rng(8)
     q, _ = make_family(rng, d, family, np.float32)
@@ -208,10 +208,8 @@ def test_pipelined_batch_equals_single_estimates(family, d, M, count, route):
     params, _ = avi.destructure(q)
     ctx = avi.MiviContext(np.float32, family, d, M, 3 if family == avi.FULLRANK and d == 256 else 0, SEED)
     ctx.set_problem(prob)
-    if route in ("p2p", "p2p-2lanes"):
+    if route == "p2p":
         ctx.p2p_attach([ctx.p2p_export(0, 1)])
-        if route == "p2p-2lanes":
-            ctx.p2p_set_pipeline(2)
     elif route != "none":
         ctx.comm_init(ctx.comm_unique_id(), 0, 1)
         ctx.comm_set_route(route)
