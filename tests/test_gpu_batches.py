@@ -41,3 +41,55 @@ def test_every_batch_length_equals_single_calls(kind, ent):
     assert float(v.item()) == float(v1.item()) and np.array_equal(g.cpu().numpy(), g1.cpu().numpy())
     ctx.close()
     ref.close()
+
+
+def test_mixed_call_sequences_keep_every_result_exact():
+    """One context through a sequence that changes everything the interleaved contexts cache: batch lengths on both sides of the
+    four / eight-context switch, another target (the children borrow the target buffers), single calls in between, the sharded
+    batches (peer-to-peer route at world 1: their lane-batched compute chain uses the same children with another index stride), and back."""
+    d, M = 128, 128
+    rng = np.random.default_rng(4)
+    q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
+    prob_a, _ = make_problem(rng, "diag", d, np.float32)
+    prob_b, _ = make_problem(rng, "dense", d, np.float32)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+    ref = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+    p, pr = ctx.to_device(params), ref.to_device(params)
+    v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+
+    def check_n(prob_ref, idx, n, dist=False):
+        ref.set_problem(prob_ref)
+        if dist:
+            ctx.estimate_gradient_dist_n(p, idx, n, v, g)
+        else:
+            ctx.estimate_gradient_n(p, idx, n, v, g)
+        ctx.synchronize()
+        v1, g1 = ref.estimate_gradient(pr, idx + n - 1)
+        if dist:   # the sharded finalisation sums in another order than the one-GPU value kernel: rounding, not bits
+            assert abs(float(v.item()) - float(v1.item())) <= 2e-6 * abs(float(v1.item()))
+            assert np.linalg.norm(g.cpu().numpy() - g1.cpu().numpy()) <= 5e-6 * max(1.0, float(np.linalg.norm(g1.cpu().numpy())))
+        else:
+            assert float(v.item()) == float(v1.item()) and np.array_equal(g.cpu().numpy(), g1.cpu().numpy())
+
+    ctx.set_problem(prob_a)
+    check_n(prob_a, 10, 20)
+    check_n(prob_a, 30, 100)
+    check_n(prob_a, 500, 7)
+    ctx.set_problem(prob_b)                       # the children must pick the new target up
+    check_n(prob_b, 40, 20)
+    v1, g1 = ctx.estimate_gradient(p, 77)          # single calls between batches
+    ref.set_problem(prob_b)
+    v2, g2 = ref.estimate_gradient(pr, 77)
+    assert float(v1.item()) == float(v2.item()) and np.array_equal(g1.cpu().numpy(), g2.cpu().numpy())
+    check_n(prob_b, 78, 60)
+    ctx.set_problem(prob_a)
+    ctx.p2p_attach([ctx.p2p_export(0, 1)])
+    ctx.comm_set_route("p2p")
+    check_n(prob_a, 200, 20, dist=True)
+    check_n(prob_a, 220, 9, dist=True)
+    check_n(prob_a, 300, 20)                       # back to the one-GPU batches (another index stride for the same children)
+    check_n(prob_a, 320, 3, dist=True)             # shorter than a group: the one-at-a-time chain
+    check_n(prob_a, 330, 64)
+    ctx.close()
+    ref.close()
