@@ -230,7 +230,31 @@ __global__ __launch_bounds__(256) void k_value_funnel(int d, const T *params, Va
   __shared__ double red[6 * 4];
   finalize_value_block<T, 256, false, true>(d, vin, out, 2 * (int64_t)d, [params, d](int i) { return params[d + i]; }, red);
 }
+// lane-batched contexts (mivi_api.hip): the closing value kernels of up to four contexts as ONE launch (blockIdx.x = lane)
+struct ValueMulti { ValueIn vin[4]; OutArgs out[4]; };
+__global__ __launch_bounds__(256) void k_value_only_m(int d, int family, const float *params, ValueMulti m) {
+  __shared__ double red[4 * 4];
+  const int64_t plen = family == MIVI_MEANFIELD ? 2 * (int64_t)d : (int64_t)d + (int64_t)d * d;
+  const int fam = family;
+  finalize_value_block<float, 256, false, false>(d, m.vin[blockIdx.x], m.out[blockIdx.x], plen,
+      [params, d, fam](int i) { return fam == MIVI_MEANFIELD ? params[d + i] : params[d + (size_t)i * d + i]; }, red);
+}
+struct ValueSink { ValueMulti m; int n; };
+ValueSink *value_sink_alloc() { return new ValueSink(); }
+void value_sink_free(ValueSink *s) { delete s; }
+void launch_lanes_value(mivi_ctx *c, const void *params, ValueSink *s) {
+  if (s->n > 0) hipLaunchKernelGGL(k_value_only_m, dim3(s->n), dim3(256), 0, c->stream, c->cfg.d, c->cfg.family, (const float *)params, s->m);
+  s->n = 0;
+}
+
 void launch_value_only(mivi_ctx *c, const void *params, const ValueIn &vin, const OutArgs &out) {
+  if (c->value_sink && c->cfg.dtype == MIVI_F32 && !(vin.fn.ab && c->cfg.family == MIVI_MEANFIELD) && ((ValueSink *)c->value_sink)->n < 4) {
+    ValueSink *sk = (ValueSink *)c->value_sink;   // record: the driver issues the lanes' value kernels as one launch
+    sk->m.vin[sk->n] = vin;
+    sk->m.out[sk->n] = out;
+    ++sk->n;
+    return;
+  }
   if (vin.fn.ab && c->cfg.family == MIVI_MEANFIELD) {
     if (c->cfg.dtype == MIVI_F32)
       hipLaunchKernelGGL(k_value_funnel<float>, dim3(1), dim3(256), 0, c->stream, c->cfg.d, (const float *)params, vin, out);

@@ -1875,16 +1875,21 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
                                           (!ssink || launch_lanes_stl(lead, ssink, L, i == 0)) && launch_lanes_vjp(lead, sink, L)))
             st = fail(c, MIVI_ERR_HIP, "lane-batched estimates: the lanes' launches do not match");
         }
+        ValueSink *vsink = value_sink_alloc();   // the lanes' closing value kernels (the last estimate of every chain): one launch
         for (int l = 0; l < E; ++l) {
           mivi_ctx *k = ctxs[b * E + l];
           k->lane_sink = nullptr;
           k->stl_sink = nullptr;
           k->eps_sink = nullptr;
+          k->value_sink = vsink;
           if (st == MIVI_OK) flush_chain(k, params, &chn[l]);
+          k->value_sink = nullptr;
           k->cur = 0;
           k->pre_valid = false;
-          k->stream = kept[l];
         }
+        if (st == MIVI_OK) launch_lanes_value(lead, params, vsink);
+        value_sink_free(vsink);
+        for (int l = 0; l < E; ++l) ctxs[b * E + l]->stream = kept[l];
         lane_sinks_free(sink);
         if (ssink) stl_sinks_free(ssink);
         eps_sink_free(esink);

@@ -320,6 +320,7 @@ struct mivi_ctx {
   unsigned long long target_gen = 0, kid_gen = ~0ull;   // parent: bumped whenever a captured graph is invalidated; child: the generation it mirrors
   hipEvent_t ev_fork = nullptr, ev_join[kMaxKids] = {};
   bool dist_lane4 = false;       // pipelined sharded batches: the compute chain is lane-batched (four contexts per launch)
+  void *value_sink = nullptr;    // ... and launch_value_only (a chain's closing value kernel) into the value sink
   void *eps_sink = nullptr;      // ... and launch_eps (a chain's first draw) into the eps sink
   void *stl_sink = nullptr;      // ... and launch_stl2 into stl_sink[lane_id]
   void *lane_sink = nullptr;     // lane-batched estimates: the launchers of the two second-generation kernels record into sink[lane_id] instead of launching
@@ -381,6 +382,10 @@ void lane_sink_reset(LaneSink *s, int lane);
 int lane_sink_counts(const LaneSink *s, int lane);                       // products recorded * 16 + VJPs recorded
 bool launch_lanes_prod(mivi_ctx *c, LaneSink *s, int lanes, int which);   // one launch for all lanes (blockIdx.y = lane)
 bool launch_lanes_vjp(mivi_ctx *c, LaneSink *s, int lanes);
+struct ValueSink;
+ValueSink *value_sink_alloc();
+void value_sink_free(ValueSink *s);
+void launch_lanes_value(mivi_ctx *c, const void *params, ValueSink *s);   // the recorded closing value kernels as one launch
 struct EpsSink;
 EpsSink *eps_sink_alloc();
 void eps_sink_free(EpsSink *s);
