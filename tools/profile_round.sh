@@ -19,6 +19,7 @@ for w in ns c2 ns_stl ns_dense c3 c5; do
     python $REPO/tools/rocpd_stats.py $db; } > $OUT/${TAG}_${w}_kernel_stats.md
 done
 # counter calibration on this library's access patterns (tools/ubench_fetchcal.hip), separate passes
+[ -x $REPO/tools/bin/ubench_fetchcal.exe ] || { mkdir -p $REPO/tools/bin; /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $REPO/tools/ubench_fetchcal.hip -o $REPO/tools/bin/ubench_fetchcal.exe; }
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/cal_$c
   rocprofv3 --kernel-trace --pmc $c -d /tmp/cal_$c -o run -- $REPO/tools/bin/ubench_fetchcal.exe > /tmp/cal_$c.log 2>&1
