@@ -130,7 +130,7 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
         }
       }
       if (!fused) {
-        store16_wt(dst + pi, o);
+        if (!MIVI_KNOCKED(a, 256)) store16_wt(dst + pi, o);
       } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -155,7 +155,7 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
         }
       }
     }
-    if (!fused && !diag_tile) {   // the mirrored, strictly upper tile is structurally zero
+    if (!fused && !diag_tile && !MIVI_KNOCKED(a, 128)) {   // the mirrored, strictly upper tile is structurally zero
       const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int u = 0; u < NE; ++u) {
@@ -409,6 +409,107 @@ template <bool FUSED, bool BF3>
 __global__ __launch_bounds__(256) void k_fr_vjp32(GemmArgs a) { fr_vjp32_body<FUSED, BF3>(a); }
 template <bool FUSED, bool BF3>
 __global__ __launch_bounds__(256) void k_fr_vjp32m(GemmMulti m) { fr_vjp32_body<FUSED, BF3>(m.lane[blockIdx.y]); }
+
+// -----------------------------------------------------------------------------------------------------------------
+// k_fr_vjp32s: the VJP of lane-batched estimates on STRIPS -- a workgroup takes up to NS consecutive 32 x 32 tiles of ONE block row
+// (same W rows, eps rows cb0, cb0 + 1, ..) instead of one tile: the W fragments of a wave's K quarter are loaded once, split into
+// their bf16 pieces once and stay in registers (48 VGPRs) for the whole strip; per tile a wave stages only its eps fragments (the next
+// tile's are requested before this tile's MFMA chain), so the launch boundary, the first-operand latency and half of the split VALU
+// are paid once per strip.  n_mc = 256 only (two sub-stages per wave).  BIT-IDENTICAL to k_fr_vjp32: same K quarters, same MFMA
+// chains, same epilogue (vjp_epilogue on the same four partial images).  The wait before a tile's fragments are read leaves exactly
+// the previous epilogue's two stores in flight (VMEM operations of a wave complete in issue order on gfx9).
+// blockIdx.y = lane, blockIdx.x -> strips[]: {rb | cb0 << 16, tiles, 0, 0}.
+// -----------------------------------------------------------------------------------------------------------------
+struct StripMulti {
+  GemmArgs lane[4];   // (kMaxLanes)
+  const int4 *strips;
+};
+__global__ __launch_bounds__(256) void k_fr_vjp32s(StripMulti m) {
+  constexpr int BM = 32, BN = 32, KW = 4, NT = 256, SUB = 32, LDC = BM + 4;
+  constexpr int WAVE_F = 2 * SUB * 32;                       // the wave's K quarter of one operand: two sub-stages [32 k][32]
+  constexpr int STAGE = KW * WAVE_F;
+  constexpr int EPI = KW * BN * LDC + (NT / BM) * BM;
+  constexpr int MAIN = 13 * 1024;                            // (k_fr_vjp32's footprint: at most three workgroups per CU)
+  static_assert(MAIN >= STAGE + EPI, "LDS budget");
+  __shared__ __attribute__((aligned(16))) float lds[MAIN + 4];
+  const GemmArgs &a = m.lane[blockIdx.y];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if ((int)blockIdx.x == a.n_work) {   // objective value of THIS estimate (everything it sums is older), as in k_fr_vjp32
+    const float *pp = a.params;
+    const int dd = a.d;
+    finalize_value_block<float, NT, false>(dd, a.self_vin, a.self_out, (int64_t)dd + (int64_t)dd * dd,
+                                           [pp, dd](int i) { return pp[dd + (size_t)i * dd + i]; }, reinterpret_cast<double *>(lds));
+    return;
+  }
+  const __attribute__((address_space(4))) int *wp = (const __attribute__((address_space(4))) int *)m.strips + 4 * blockIdx.x;
+  const int sx = wp[0], nc = MIVI_KNOCKED(a, 1024) ? (wp[1] ? 1 : 0) : wp[1];
+  if (nc == 0 || MIVI_KNOCKED(a, 2048)) return;
+  const int rb = sx & 0xffff, cb0 = sx >> 16;
+  const int row0 = rb * BM;
+  const int Kq = a.M / KW;   // = 2 SUB
+  float *buf = lds + w * WAVE_F;
+  float *Cs = lds + STAGE;
+  float *rs_lds = Cs + KW * BN * LDC;
+  auto issue = [&](const float *base, int ld, int c0) {   // rows/columns c0..c0+31, k in the wave's quarter: 8 pieces of 8 k x 32
+    const float *p0 = base + c0 + 4 * (lane & 7) + (size_t)(w * Kq + (lane >> 3)) * ld;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) MIVI_GLDS16(p0 + (size_t)(8 * p) * ld, buf + p * 256);
+  };
+  __builtin_amdgcn_s_setprio(3);
+  issue(a.A, a.lda, row0);
+  __builtin_amdgcn_s_setprio(0);
+  wait_vmcnt<0>();
+  float av[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) av[i] = buf[((i >> 4) * SUB + 8 * ((i & 15) >> 2) + 4 * h + (i & 3)) * 32 + l31];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  issue(a.B, a.ldb, cb0 * BN);
+  float rsum = 0.f;
+  if (cb0 + nc - 1 == rb) {   // the strip ends on the diagonal tile: d/dmu partial row sums, k_fr_vjp32's order
+#pragma unroll
+    for (int i = 0; i < 32; ++i) rsum += av[i];
+  }
+  bf16x8 Ah[4], Am[4], Al[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) split3_bf16(av + 8 * g, Ah[g], Am[g], Al[g]);
+  for (int jt = 0; jt < nc; ++jt) {
+    const int cb = cb0 + jt;
+    if (jt == 0 || a.out.partials_mode) wait_vmcnt<0>();
+    else wait_vmcnt<2>();   // the tile's fragments are in; the previous epilogue's two stores may still be on their way
+    float bv[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) bv[i] = buf[((i >> 4) * SUB + 8 * ((i & 15) >> 2) + 4 * h + (i & 3)) * 32 + l31];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (jt + 1 < nc) issue(a.B, a.ldb, (cb + 1) * BN);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (!MIVI_KNOCKED(a, 2))
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x8 bh, bm, bl;
+      split3_bf16(bv + 8 * g, bh, bm, bl);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[g], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[g], bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[g], bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am[g], bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[g], bm, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[g], bh, acc, 0, 0, 0);
+    }
+    if (MIVI_KNOCKED(a, 16)) { if (acc[0] == 123.f) Cs[tid] = acc[3]; continue; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+      *(f32x4 *)(Cs + (w * BN + l31) * LDC + 8 * q + 4 * h) = v;
+    }
+    const bool diag = cb == rb;
+    if (diag) rs_lds[(2 * w + h) * BM + l31] = rsum;
+    lds_barrier();
+    if (!MIVI_KNOCKED(a, 32)) vjp_epilogue<BM, BN, KW, NT, false>(a, Cs, rs_lds, nullptr, make_int4(rb | (cb << 16), 0, 0, diag ? 3 : 0), row0, cb * BN);
+    lds_barrier();   // the images are free for the next tile
+  }
+}
 
 // -----------------------------------------------------------------------------------------------------------------
 // k_fr_vjp64: tril(W eps^T) on 64 x 64 tiles, eight waves split K = n_mc into contiguous runs of 32-k sub-stages; every wave
@@ -837,6 +938,245 @@ template <int MODE, bool BF3>
 __global__ __launch_bounds__(512) void k_fr_prod32m(Prod32Multi m) { fr_prod32_body<MODE, BF3>(m.lane[blockIdx.y]); }
 
 // -----------------------------------------------------------------------------------------------------------------
+// k_fr_prod32q: the sampling product of FOUR lanes (estimates at the same parameters: one tril(C), four eps) as 2 x 2 work per
+// workgroup -- the tile PAIR {(nrb-1-p, cb), (p, cb)} (K = 32 (nrb + 1) between them: every workgroup carries the same work, where
+// k_fr_prod32's heaviest tile carries 32 x its lightest) for the lane PAIR {2 lp, 2 lp + 1} (every fragment of C is staged once and
+// split into its bf16 pieces once for two estimates).  (d/64) (M/32) 2 workgroups -- 256 at the north star, one per CU, one round --
+// instead of four lanes x 256 tiles whose fixed costs (boundary, first operands, epilogue) were paid 1024 times.
+// BIT-IDENTICAL to k_fr_prod32: a tile's k range is cut into the same eight runs (wave w: run w of both tiles), every run is the same
+// MFMA chain, the epilogue adds the eight partial tiles in the same order and the ell partial lands in the same slot of ell_part.
+// L2 -> LDS bytes per four estimates 135 -> 101 MB, split VALU -25 %.  The eps(t+1) riders (two per workgroup) follow the epilogues.
+// -----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void k_fr_prod32q(Prod32Multi m) {
+  constexpr int NW = 8, NT = 512, SUB = 32, LDC = 36;
+  constexpr int WAVE_F = 3 * SUB * 32;        // per wave: As[32 k][32 rows], Bs of lane 0 [32 cols][32 k], Bs of lane 1
+  constexpr int EPI = 2 * NW * 32 * LDC;      // sixteen partial tiles (two tiles x eight runs) of ONE lane
+  constexpr int MAIN = (NW * WAVE_F > EPI) ? NW * WAVE_F : EPI;
+  __shared__ __attribute__((aligned(16))) float lds[MAIN + 2 * NW + 192];
+  double *red = reinterpret_cast<double *>(lds + MAIN);
+  float *lds_e = lds + MAIN + 2 * NW;   // the epilogue's row vectors {mu, target mean, target 1/std} x {tile 0, tile 1} x 32 rows
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int d = m.lane[0].d, dP = m.lane[0].dP, lda = m.lane[0].lda, ncb = m.lane[0].ncb, mode = m.lane[0].mode;
+  const float *A = m.lane[0].A, *params = m.lane[0].params;
+  const int nrb = d >> 5, nq4 = ncb >> 1;     // (2 ncb (column block, lane pair) combinations, four classes)
+  // workgroup -> (pair, column block, lane pair): XCD x = b % 8 = (x & 1, x >> 1) owns the tile pairs of class p % 2 and the combinations of
+  // class q % 4: a row panel of C crosses the fabric four times, an eps column panel twice
+  const int b = blockIdx.x, x = b & 7, j = b >> 3;
+  const int pp = 2 * (j / nq4) + (x & 1), q = 4 * (j % nq4) + (x >> 1);
+  const int cb = q % ncb, lp = q / ncb;
+  const Prod32Args &a0 = m.lane[2 * lp], &a1 = m.lane[2 * lp + 1];
+  const int rbT[2] = {nrb - 1 - pp, pp};
+  const int col0 = cb * 32;
+  int t_beg[2], t_end[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    t_beg[t] = (w * (rbT[t] + 1)) / NW;
+    t_end[t] = ((w + 1) * (rbT[t] + 1)) / NW;
+  }
+  // epilogue operands that do not depend on the product (threads 0..255: tile 0, 256..511: tile 1; rows ei4..+3 of column en)
+  const int half = tid >> 8, t2 = tid & 255;
+  const int ei4 = 4 * (t2 & 7), en = (t2 >> 3) & 31;
+  const int rowE = 32 * (half ? rbT[1] : rbT[0]);
+  const int gi = rowE + ei4, gm = col0 + en;
+  // (staged through LDS by three waves' LDS-DMA: held in registers across the main loop they cost every thread twelve VGPRs, and two waves
+  //  of this kernel + one of the VJP kernel -- or of the spinning exchange kernel -- have to fit a SIMD's 512)
+  if (w < 3 && (w == 0 || mode == R_DIAG || (w == 1 && mode == R_DENSE_R))) {
+    const float *src = w == 0 ? params : (w == 1 ? m.lane[0].t_mean : m.lane[0].t_istd);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + 32 * (lane < 32 ? rbT[0] : rbT[1]) + l31),
+                                     (__attribute__((address_space(3))) void *)(lds_e + w * 64), 4, 0, 0);
+  }
+  const bool ld_blk = a0.ld_part && cb == 0 && t2 < 32;
+  float cii = 1.f;
+  if (ld_blk) cii = params[d + (size_t)(rowE + t2) * d + rowE + t2];
+
+  float *buf = lds + w * WAVE_F;
+  const float *Ag = A + 4 * (lane & 7) + (size_t)(lane >> 3) * lda;
+  // eps fragments: piece p holds columns n = 8 p + lane / 8, 16-byte chunk (lane % 8) ^ ((n >> 1) & 7) of the column's 128 bytes: the swizzle
+  // repeats every two pieces, so two per-lane bases (even / odd pieces) + uniform offsets address all of them, for either lane
+  const float *Bg0[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const int n = 8 * p + (lane >> 3);
+    Bg0[p] = a0.B + (size_t)(col0 + n) * dP + 4 * ((lane & 7) ^ ((n >> 1) & 7));
+  }
+  const long long dB = a1.B - a0.B;
+  auto issue = [&](int tile, int t) {   // sub-stage t (32 k) of tile `tile`: the C fragment and both lanes' eps fragments
+    const float *pa = Ag + 32 * rbT[tile] + (size_t)(t * SUB) * lda;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      MIVI_GLDS16(pa + (size_t)(8 * p) * lda, buf + p * 256);
+      const float *pb = Bg0[p & 1] + (size_t)(16 * (p >> 1)) * dP + t * SUB;
+      MIVI_GLDS16(pb, buf + SUB * 32 + p * 256);
+      MIVI_GLDS16(pb + dB, buf + 2 * SUB * 32 + p * 256);
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int l = 0; l < 2; ++l)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][l][r] = 0.f;
+  const int b_off = SUB * 32 + l31 * 32;
+  const int b_swz = h ^ ((l31 >> 1) & 7);
+  __builtin_amdgcn_s_setprio(3);
+  if (MIVI_KNOCKED(m.lane[0], 4)) {
+  } else if (t_beg[0] < t_end[0]) issue(0, t_beg[0]);
+  else if (t_beg[1] < t_end[1]) issue(1, t_beg[1]);
+  __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+  for (int tile = 0; tile < 2; ++tile) {
+    for (int t = t_beg[tile]; t < t_end[tile]; ++t) {
+      wait_vmcnt<0>();
+      float av[16];
+      f32x4 bq[2][4];
+#pragma unroll
+      for (int s8 = 0; s8 < 4; ++s8) {
+        bq[0][s8] = *(const f32x4 *)(buf + b_off + 4 * ((2 * s8) ^ b_swz));
+        bq[1][s8] = *(const f32x4 *)(buf + SUB * 32 + b_off + 4 * ((2 * s8) ^ b_swz));
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) av[4 * s8 + jj] = buf[(8 * s8 + 4 * h + jj) * 32 + l31];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the buffer is free again before it is requested anew
+      if (MIVI_KNOCKED(m.lane[0], 4)) {
+      } else if (t + 1 < t_end[tile]) issue(tile, t + 1);
+      else if (tile == 0 && t_beg[1] < t_end[1]) issue(1, t_beg[1]);
+      if (t == rbT[tile]) {   // the diagonal block of tril(C): keep k <= i
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (8 * (i >> 2) + 4 * h + (i & 3) > l31) av[i] = 0.f;
+      }
+      if (MIVI_KNOCKED(m.lane[0], 2)) continue;
+      bf16x8 ah[2], am[2], al[2];
+      split3_bf16(av, ah[0], am[0], al[0]);
+      split3_bf16(av + 8, ah[1], am[1], al[1]);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        bf16x8 bh[2], bm[2], bl[2];
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+          float bv[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) bv[i] = bq[l][2 * g + (i >> 2)][i & 3];
+          split3_bf16(bv, bh[l], bm[l], bl[l]);
+        }
+        // (the two lanes' chains interleaved: a dependent MFMA issues behind an independent one)
+        f32x16 c0 = acc[tile][0], c1 = acc[tile][1];
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[g], bh[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[g], bh[1], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], bl[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], bl[1], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[g], bm[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[g], bm[1], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[g], bh[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[g], bh[1], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], bm[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], bm[1], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], bh[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[g], bh[1], c1, 0, 0, 0);
+        acc[tile][0] = c0;
+        acc[tile][1] = c1;
+      }
+    }
+  }
+  wait_vmcnt<0>();                // (the row vectors' DMA, had this wave no sub-stage to wait for)
+  __builtin_amdgcn_s_barrier();   // every wave is done with its buffer: LDS becomes the epilogue image
+  if (MIVI_KNOCKED(m.lane[0], 16)) return;
+  // ell_part slot of a tile = its workgroup index in k_fr_prod32's own (XCD-aware) order
+  const int rE = nrb - 1 - (half ? rbT[1] : rbT[0]);
+  const int bidE = ((rE & 3) + 4 * (cb & 1)) + 8 * ((rE >> 2) * (ncb >> 1) + (cb >> 1));
+  float *Cs = lds;
+  f32x4 mu = *(const f32x4 *)(lds_e + 32 * half + ei4), tm = {0.f, 0.f, 0.f, 0.f}, tis = tm;
+  if (mode == R_DIAG || mode == R_DENSE_R) tm = *(const f32x4 *)(lds_e + 64 + 32 * half + ei4);
+  if (mode == R_DIAG) tis = *(const f32x4 *)(lds_e + 128 + 32 * half + ei4);
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const Prod32Args &a = l ? a1 : a0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        f32x4 v = {acc[t][l][4 * qq], acc[t][l][4 * qq + 1], acc[t][l][4 * qq + 2], acc[t][l][4 * qq + 3]};
+        *(f32x4 *)(Cs + ((t * NW + w) * 32 + l31) * LDC + 8 * qq + 4 * h) = v;
+      }
+    lds_barrier();
+    float ell = 0.f;
+    {
+      const float *Ct = Cs + half * NW * 32 * LDC;
+      f32x4 v = *(const f32x4 *)(Ct + en * LDC + ei4);
+#pragma unroll
+      for (int k2 = 1; k2 < NW; ++k2) v += *(const f32x4 *)(Ct + (k2 * 32 + en) * LDC + ei4);   // fixed order
+      const f32x4 z = mu + v;
+      if (a.Z) store16_wt(a.Z + (size_t)gm * d + gi, z);
+      if (mode == R_DIAG) {
+        f32x4 wv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float u = (z[c] - tm[c]) * tis[c];
+          ell += -0.5f * u * u;
+          wv[c] = -u * tis[c];
+        }
+        store16_wt(a.W + (size_t)gm * d + gi, wv);
+      } else if (mode == R_DENSE_R) {
+        const f32x4 rz = z - tm;
+        store16_wt(a.R + (size_t)gm * dP + gi, rz);
+      }
+    }
+    if (mode == R_DIAG) {   // the two tiles' ell partials: waves 0..3 / 4..7, each the tree of k_fr_prod32's block sum
+      const double sv = (double)wave_sum_f32(ell);
+      lds_barrier();
+      if (lane == 0) red[w] = sv;
+      lds_barrier();
+      if (t2 == 0) {
+        double s = red[4 * half];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) s += red[4 * half + i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += 0.0;   // (k_fr_prod32 adds its four idle waves' zeros: -0.0 would become +0.0 there)
+        a.ell_part[bidE] = s;
+      }
+    } else {
+      lds_barrier();
+    }
+  }
+  if (ld_blk) {   // log|det C| partial of this 32-row block (lanes 0..31 of waves 0 and 4), the same for both lanes
+    float lg = logf(cii), bad = (cii > 0.f) ? 0.f : 1.f;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {
+      lg += __shfl_xor(lg, o, 64);
+      bad += __shfl_xor(bad, o, 64);
+    }
+    if (t2 == 0) {
+      const int rb = half ? rbT[1] : rbT[0];
+      a0.ld_part[rb] = (double)lg;
+      a0.ld_part[nrb + rb] = (double)bad;
+      if (a1.ld_part) {
+        a1.ld_part[rb] = (double)lg;
+        a1.ld_part[nrb + rb] = (double)bad;
+      }
+    }
+  }
+  // riders: eps(t+1) of both lanes, block eb = this workgroup's index among its lane pair's (d/64) (M/32) workgroups
+  const int eb = pp * ncb + cb;
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const Prod32Args &a = l ? a1 : a0;
+    if (eb >= a.n_eps || MIVI_KNOCKED(m.lane[0], 64)) continue;
+    const SampleArgs<float> &n = a.next_eps;
+    const int nrb6 = d >> 6;
+    const int ri = (eb % nrb6) * 64 + 4 * (tid & 15), rm = (eb / nrb6) * 32 + (tid >> 4);
+    float e[4];
+    eps_block<float>(n.rng.seed, rng_index(n.rng), (uint64_t)(n.rng.m_offset + rm) * (uint64_t)(d >> 2) + (uint64_t)(ri >> 2), e);
+    const f32x4 ev = {e[0], e[1], e[2], e[3]};
+    store16_wt(n.eps + (size_t)rm * n.ld_eps + ri, ev);
+    const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
+    const double sh = block_sum_nodrain_f32<NT>(he, red);
+    if (tid == 0) n.he_part[eb] = sh;
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // k_fr_prod64: the unsplit product on 64 x 64 tiles for the LARGE shapes (more tiles than CUs): Z = mu + tril(C) eps (G_SAMPLE) or
 // G = -P (Z - m) (G_DENSE) with the target fused into the epilogue, the structure of k_fr_vjp64 -- eight waves split the tile's k
 // range into contiguous runs of 32-k sub-stages, every wave stages its OWN 64 rows of A ([k][64 rows], the VJP kernel's image) and
@@ -1126,6 +1466,30 @@ void build_vjp(mivi_ctx *c, int d, int M, int tile, DevBuf &tab, int &n_items) {
   upload(c, tab, packed.data(), packed.size() * sizeof(int4));
 }
 
+// strips of k_fr_vjp32s: up to NS consecutive tiles of one block row per workgroup.  XCD x (= workgroup index % 8) takes the block rows
+// {x, 15 - x, 16 + x, 31 - x} (+ 32 i): the same number of tiles on every XCD, four W panels and the eps panels below them in its L2.
+void build_strips(mivi_ctx *c, int d, int NS, DevBuf &tab, int &n_items) {
+  const int nrb = d / 32;
+  std::vector<std::vector<int4>> lists(8);
+  for (int rb = 0; rb < nrb; ++rb) {
+    const int r = rb & 15, x = (r < 8) ? r : 15 - r;
+    for (int cb0 = 0; cb0 <= rb; cb0 += NS) {
+      const int nc = (rb + 1 - cb0 < NS) ? rb + 1 - cb0 : NS;
+      lists[x].push_back(make_int4(rb | (cb0 << 16), nc, 0, 0));
+    }
+  }
+  size_t L = 0;
+  for (auto &l : lists) {
+    std::stable_sort(l.begin(), l.end(), [](const int4 &p, const int4 &q) { return p.y > q.y; });
+    L = l.size() > L ? l.size() : L;
+  }
+  std::vector<int4> out;
+  for (size_t i = 0; i < L; ++i)
+    for (int x = 0; x < 8; ++x) out.push_back(i < lists[x].size() ? lists[x][i] : make_int4(0, 0, 0, 0));
+  n_items = (int)out.size();
+  upload(c, tab, out.data(), out.size() * sizeof(int4));
+}
+
 }  // namespace
 
 bool lds_path_shape_ok(const mivi_ctx *c, int M) {
@@ -1136,6 +1500,10 @@ bool lds_path_shape_ok(const mivi_ctx *c, int M) {
 
 static bool f32_mfma();
 static int knock_flags();
+static int vjp_strip_len() {   // MIVI_VJP_STRIP: tiles per workgroup of the lane-batched VJP (k_fr_vjp32s); 0 = one tile per workgroup (k_fr_vjp32m)
+  static const int v = getenv("MIVI_VJP_STRIP") ? atoi(getenv("MIVI_VJP_STRIP")) : 3;   // (748 workgroups at the north star: one round of three per CU)
+  return v < 0 ? 0 : (v > 32 ? 32 : v);
+}
 
 // (re)build the VJP work lists for M samples per launch (the product kernels derive their tile from blockIdx)
 bool lds_prepare(mivi_ctx *c, int M) {
@@ -1144,7 +1512,8 @@ bool lds_prepare(mivi_ctx *c, int M) {
   const int d = c->cfg.d;
   build_vjp(c, d, M, 32, c->lds_tabV, c->lds_nV);
   build_vjp(c, d, M, 64, c->lds_tabV64, c->lds_nV64);
-  if (!c->lds_tabV.p || !c->lds_tabV64.p) return false;
+  build_strips(c, d, vjp_strip_len() ? vjp_strip_len() : 1, c->lds_tabS, c->lds_nS);
+  if (!c->lds_tabV.p || !c->lds_tabV64.p || !c->lds_tabS.p) return false;
   c->lds_M = M;
   return true;
 }
@@ -1274,6 +1643,10 @@ LaneSink *lane_sinks_alloc(int n) { return new LaneSink[n](); }
 void lane_sinks_free(LaneSink *s) { delete[] s; }
 void lane_sink_reset(LaneSink *s, int lane) { s[lane].n_prod = 0; s[lane].n_vjp = 0; }
 int lane_sink_counts(const LaneSink *s, int lane) { return s[lane].n_prod * 16 + s[lane].n_vjp; }
+static bool prod_quad_on() {   // MIVI_PROD_QUAD=0: four lanes' sampling products as 4 x k_fr_prod32's tiles again (A/B)
+  static const bool v = !(getenv("MIVI_PROD_QUAD") && atoi(getenv("MIVI_PROD_QUAD")) == 0);
+  return v;
+}
 // which: 0 = the sampling product (with the fused diagonal target, or R = Z - m of the dense one), 1 = the dense target's product
 bool launch_lanes_prod(mivi_ctx *c, LaneSink *s, int lanes, int which) {
   if (lanes < 1 || lanes > kMaxLanes || f32_mfma()) return false;
@@ -1281,6 +1654,22 @@ bool launch_lanes_prod(mivi_ctx *c, LaneSink *s, int lanes, int which) {
   for (int l = 0; l < lanes; ++l) {
     if (s[l].n_prod <= which || s[l].n_prod > 2 || s[l].prod_grid[which] != s[0].prod_grid[which] || s[l].prod_dense[which] != which) return false;
     m.lane[l] = s[l].prod[which];
+  }
+  if (which == 0 && lanes == 4 && prod_quad_on()) {   // two tiles x two lanes per workgroup (k_fr_prod32q) where it applies
+    const Prod32Args &a = m.lane[0];
+    const int nrb = a.d >> 5;
+    bool ok = a.n_dinv == 0 && a.n_pack == 0 && (nrb & 3) == 0 && (a.ncb & 1) == 0 && a.n_tiles >= 256 &&
+              (a.mode == R_DIAG || a.mode == R_DENSE_R || a.mode == R_PLAIN);
+    for (int l = 1; l < lanes && ok; ++l) {
+      const Prod32Args &o = m.lane[l];
+      ok = o.A == a.A && o.params == a.params && o.lda == a.lda && o.d == a.d && o.M == a.M && o.dP == a.dP && o.mode == a.mode &&
+           o.t_mean == a.t_mean && o.t_istd == a.t_istd && o.ncb == a.ncb && o.n_dinv == 0 && o.n_pack == 0 && o.n_eps == a.n_eps &&
+           (o.ld_part != nullptr) == (a.ld_part != nullptr);
+    }
+    if (ok) {
+      hipLaunchKernelGGL(k_fr_prod32q, dim3((nrb >> 1) * a.ncb * 2), dim3(512), 0, c->stream, m);
+      return true;
+    }
   }
   const dim3 grid(s[0].prod_grid[which], lanes);
   if (which) hipLaunchKernelGGL((k_fr_prod32m<G_DENSE, true>), grid, dim3(512), 0, c->stream, m);
@@ -1293,6 +1682,21 @@ bool launch_lanes_vjp(mivi_ctx *c, LaneSink *s, int lanes) {
   for (int l = 0; l < lanes; ++l) {
     if (s[l].n_vjp != 1 || s[l].vjp_grid != s[0].vjp_grid) return false;
     m.lane[l] = s[l].vjp;
+  }
+  if (vjp_strip_len() > 0 && lanes >= 2 && m.lane[0].M == 256 && c->lds_tabS.p) {   // strips of tiles per workgroup where they apply
+    bool ok = true;
+    const bool self = m.lane[0].n_work != 0x7fffffff;   // (one more workgroup per lane assembles the estimate's value)
+    for (int l = 0; l < lanes; ++l) ok = ok && (m.lane[l].n_work != 0x7fffffff) == self && m.lane[l].M == 256 && m.lane[l].d == m.lane[0].d;
+    if (ok) {
+      StripMulti sm;
+      for (int l = 0; l < lanes; ++l) {
+        sm.lane[l] = m.lane[l];
+        if (self) sm.lane[l].n_work = c->lds_nS;
+      }
+      sm.strips = (const int4 *)c->lds_tabS.p;
+      hipLaunchKernelGGL(k_fr_vjp32s, dim3(c->lds_nS + (self ? 1 : 0), lanes), dim3(256), 0, c->stream, sm);
+      return true;
+    }
   }
   hipLaunchKernelGGL((k_fr_vjp32m<false, true>), dim3(s[0].vjp_grid, lanes), dim3(256), 0, c->stream, m);
   return true;

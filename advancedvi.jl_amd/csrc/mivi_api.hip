@@ -169,7 +169,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_P2, &c->dist_ring[0], &c->dist_ring[1], &c->dist_ring[2], &c->dist_ring[3], &c->dist_ring[4], &c->dist_ring[5], &c->p2p_scratch, &c->dist_S, &c->dist_F, &c->p2p_tab, &c->p2p_ctr, &c->lds_tabV, &c->lds_tabV64, &c->lds_tabSt, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_P2, &c->dist_ring[0], &c->dist_ring[1], &c->dist_ring[2], &c->dist_ring[3], &c->dist_ring[4], &c->dist_ring[5], &c->p2p_scratch, &c->dist_S, &c->dist_F, &c->p2p_tab, &c->p2p_ctr, &c->lds_tabV, &c->lds_tabV64, &c->lds_tabS, &c->lds_tabSt, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -2493,7 +2493,7 @@ mivi_status_t mivi_debug_timeline(mivi_ctx_t *c, void *buf) {
 }
 
 mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *params, int32_t reps, double *ms_out) {
-  if (!c || !params || reps <= 0 || !ms_out || which < 0 || which > 9) return MIVI_ERR_BAD_ARG;
+  if (!c || !params || reps <= 0 || !ms_out || which < 0 || which > 11) return MIVI_ERR_BAD_ARG;
   (void)hipSetDevice(c->cfg.device);
   const int M = c->cfg.n_mc;
   char *o = (char *)c->tmp_out.p;
@@ -2510,6 +2510,31 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
   c->cur = 0;
   const bool lds = fr && lds_route(c, params, M, 1, out);   // second-generation kernels: stages 2 / 4 include their reduce
   if (which == 6 || which == 7) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 6 / 7: the split-K product / reduce stages were removed (round 3)");
+  // which = 10 / 11: the product / VJP launch of FOUR lane-batched estimates, as mivi_estimate_gradient_n issues them.  A batch of eight
+  // estimates first (it creates and fills the four contexts), then the four contexts' launches are recorded once and the ONE launch
+  // that serves them is replayed.
+  LaneSink *psink = nullptr;
+  if (which == 10 || which == 11) {
+    if (!(lds && lds_use_prod32(c, M)) || c->is_child || c->target != TGT_DIAG_GAUSS) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 10 / 11: full-rank second-generation kernels, diagonal-Gaussian target");
+    if ((s = mivi_estimate_gradient_n(c, params, 1, 8, o, o + 16))) return s;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!(c->graph.exec && c->graph.kind == 3)) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 10 / 11: this configuration does not take the lane-batched route");
+    psink = lane_sinks_alloc(4);
+    for (int l = 0; l < 4 && s == MIVI_OK; ++l) {
+      mivi_ctx *k = l ? c->kids[l - 1] : c;
+      char *ko = l ? (char *)c->kid_out[l - 1].p : o;
+      hipStream_t kept = k->stream;
+      k->stream = c->stream;
+      k->lane_sink = psink; k->lane_id = l;
+      lane_sink_reset(psink, l);
+      k->cur = 0;
+      EpsJob nx{rng_of(k, (uint64_t)(100 + l)), 1};
+      launch_lds_prod32(k, params, M, false, R_DIAG, nullptr, &nx, true, false);
+      launch_lds_vjp(k, params, M, final_out(k, ko, ko + 16), nullptr, nullptr);
+      k->lane_sink = nullptr;
+      k->stream = kept;
+    }
+  }
   if (which == 8 && !(fr && (c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD)))
     return fail(c, MIVI_ERR_UNSUPPORTED, "which = 8: full-rank family with a sticking-the-landing estimator");
   if (which == 5) {   // the launch-free loop of 100 estimates (mean-field + diagonal target): one launch per rep
@@ -2543,6 +2568,8 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
         if (lds) launch_lds_vjp(c, params, M, out, nullptr, nullptr);
         else launch_fr_vjp(c, params, M, out);
         break;
+      case 10: if (!launch_lanes_prod(c, psink, 4, 0)) st = fail(c, MIVI_ERR_HIP, "lane-batched product: the lanes' launches do not match"); break;
+      case 11: if (!launch_lanes_vjp(c, psink, 4)) st = fail(c, MIVI_ERR_HIP, "lane-batched VJP: the lanes' launches do not match"); break;
       case 9: {   // two EMPTY dependent launches with the grids / blocks / LDS of the product and VJP kernels: what the launch structure costs
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_empty), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
@@ -2610,6 +2637,7 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  if (psink) lane_sinks_free(psink);
   if (which != 0) c->pre_valid = false;
   if (s) return s;
   *ms_out = (double)ms / reps;

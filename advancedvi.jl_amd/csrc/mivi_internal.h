@@ -279,8 +279,8 @@ struct mivi_ctx {
   bool want_stl_pack = false, stl_pack_done = false;   // Stein estimator: ask the sampling kernel to carry the solve's riders
   mivi::DevBuf stl_X;              // second-generation STL solve: X of the lower half + updated right-hand side of the upper half
   // second-generation full-rank kernels (kernels_fullrank_lds.hip): VJP work lists (32 x 32 and 64 x 64 tiles)
-  mivi::DevBuf lds_tabV, lds_tabV64;
-  int lds_nV = 0, lds_nV64 = 0, lds_M = -1;
+  mivi::DevBuf lds_tabV, lds_tabV64, lds_tabS;   // (lds_tabS: the strips of k_fr_vjp32s)
+  int lds_nV = 0, lds_nV64 = 0, lds_nS = 0, lds_M = -1;
   bool d_idx_valid = false;          // the device-side estimate counter (d_idx[0]) is known to hold d_idx_expect
   uint64_t d_idx_expect = 0;
   mivi::DevBuf lds_tabSt;            // Stein accumulation stage: the full square of 64 x 64 tiles

@@ -366,7 +366,9 @@ mivi_status_t mivi_profile_dist(mivi_ctx_t *ctx, const void *params_dev, int32_t
  *          3 = VJP kernel, 4 = dense-target kernel, 5 = the launch-free loop of 100 estimates (mean-field + diagonal
  *          target; what mivi_estimate_gradient_n runs there), 6 / 7 = the split-K product / its reduce kernel alone
  *          (removed), 8 = the sticking-the-landing term W += C^-T eps alone (full-rank, STL estimators),
- *          9 = the LATENCY FLOOR of the full-rank estimate: two empty dependent launches with the grid / block / LDS footprint of the product and VJP kernels.  Stages 1-4, 6, 7 are captured `reps` times into one hipGraph and the
+ *          9 = the LATENCY FLOOR of the full-rank estimate: two empty dependent launches with the grid / block / LDS footprint of the product and VJP kernels,
+ *          10 / 11 = the product / VJP launch of FOUR lane-batched estimates (what mivi_estimate_gradient_n issues at the
+ *          BASELINE sizes: ms_per_launch is then the time of four estimates' stage).  Stages 1-4, 6, 7, 9-11 are captured `reps` times into one hipGraph and the
  *          replay is timed (eager launches of 2-5 us kernels are host-bound); 0 and 5 are eager.  ms_per_launch_host: double[1]. */
 mivi_status_t mivi_profile_kernel(mivi_ctx_t *ctx, int32_t which, const void *params_dev, int32_t reps,
                                   double *ms_per_launch_host);

@@ -97,6 +97,8 @@ for rep in range(2):
 print('ok')
 """
 
+CHAINS_NS = CHAINS.replace("d, M, n = 256, 128, 25", "d, M, n = 1024, 256, 23")   # the shape whose lane-batched launches are k_fr_prod32q / k_fr_vjp32s
+
 F, MF = 1, 0
 CASES = [
     # switch, script, parameters
@@ -125,6 +127,10 @@ CASES = [
     ("MIVI_LANE_BATCH=0", CHAINS, dict(kind="diag")),                                                     # every context on a graph branch of its own (no lane-batched launches)
     ("MIVI_LANE_BATCH=2", CHAINS, dict(kind="dense")),                                                    # two contexts per lane-batched launch
     ("MIVI_CHAINS=8", CHAINS, dict(kind="diag")),                                                         # eight contexts: two branches of four lanes
+    ("MIVI_PROD_QUAD=0", CHAINS_NS, dict(kind="diag")),                                                   # four lanes' products on k_fr_prod32's tiles (k_fr_prod32m)
+    ("MIVI_VJP_STRIP=0", CHAINS_NS, dict(kind="diag")),                                                   # one VJP tile per workgroup (k_fr_vjp32m)
+    ("MIVI_VJP_STRIP=5", CHAINS_NS, dict(kind="dense")),                                                  # another strip length
+    ("MIVI_DUMMY_DEFAULT=1", CHAINS_NS, dict(kind="diag")),                                               # (no switch: k_fr_prod32q + k_fr_vjp32s)
     ("MIVI_DUMMY_DEFAULT=1", CHAINS, dict(kind="dense")),                                                 # (no switch: the default interleaving)                                                                 # first-generation accumulation kernel
 ]
 

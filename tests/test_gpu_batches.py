@@ -1,7 +1,9 @@
 """mivi_estimate_gradient_n on the second-generation full-rank route: a batch is dealt onto interleaved contexts (lane-batched launches:
 four contexts' product kernels as one launch, likewise their VJP kernels; one or two graph branches) -- every estimate must still be
 bitwise the single call's, for every batch length (partial last steps, batches shorter than the number of contexts, the switch from
-four to eight contexts at 50) and for both Gaussian targets; the STL estimators keep one context per branch."""
+four to eight contexts at 50) and for both Gaussian targets; the STL estimators keep one context per branch.  At the BASELINE sizes the
+lane-batched launches are kernels of their own (k_fr_prod32q: two tiles x two lanes per workgroup; k_fr_vjp32s: strips of tiles): the
+same bitwise requirement at the shapes that select them."""
 import numpy as np
 import pytest
 
@@ -91,5 +93,36 @@ def test_mixed_call_sequences_keep_every_result_exact():
     check_n(prob_a, 300, 20)                       # back to the one-GPU batches (another index stride for the same children)
     check_n(prob_a, 320, 3, dist=True)             # shorter than a group: the one-at-a-time chain
     check_n(prob_a, 330, 64)
+    ctx.close()
+    ref.close()
+
+
+@pytest.mark.parametrize("d,M", [(1024, 256), (2048, 256), (512, 256), (512, 512)])
+@pytest.mark.parametrize("kind,ent", [("diag", 0), ("dense", 0), ("diag", 3)])
+def test_lane_batched_kernels_equal_single_calls_at_the_baseline_sizes(d, M, kind, ent):
+    """(1024, 256) and (2048, 256): k_fr_prod32q + k_fr_vjp32s; (512, 256): k_fr_prod32m + k_fr_vjp32s; (512, 512): k_fr_prod32q + k_fr_vjp32m.
+    The dense target keeps its second product on k_fr_prod32m; the STL estimator's first step carries the inversion riders (k_fr_prod32m),
+    its later steps do not.  Batch lengths: one full step of four lanes, a partial last step, two branches of four lanes."""
+    if kind == "dense" and d == 2048:
+        pytest.skip("(the dense target's fixture at d = 2048 is a 16 MiB precision matrix: covered at 1024)")
+    rng = np.random.default_rng(100 + d + M)
+    q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
+    prob, _ = make_problem(rng, kind, d, np.float32)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
+    ctx.set_problem(prob)
+    ref = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
+    ref.set_problem(prob)
+    p, pr = ctx.to_device(params), ref.to_device(params)
+    v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+    idx = 2
+    for n in (4, 7, 20, 52):
+        g.fill_(float("nan"))
+        ctx.estimate_gradient_n(p, idx, n, v, g)
+        ctx.synchronize()
+        v1, g1 = ref.estimate_gradient(pr, idx + n - 1)
+        assert float(v.item()) == float(v1.item()), (n, float(v.item()), float(v1.item()))
+        assert np.array_equal(g.cpu().numpy(), g1.cpu().numpy()), n
+        idx += n
     ctx.close()
     ref.close()

@@ -24,7 +24,8 @@ _prod = (d * (d + 1) // 2 * 4 + d * M * 4 + d * M * 4 + d * M * 4) / 1024.0   # 
 _vjp = (2 * d * M * 4 + d * d * 4) / 1024.0                                  # W + eps in, dense dC out
 ALGO = {"k_fr_prod32ILi0": _prod, "k_fr_vjp32ILb0": _vjp,
         # the lane-batched launches of the timed region: four estimates per launch (tril(C) is shared by the lanes)
-        "k_fr_prod32mILi0": (d * (d + 1) // 2 * 4 + 4 * 3 * d * M * 4) / 1024.0, "k_fr_vjp32mILb0": 4 * _vjp}
+        "k_fr_prod32mILi0": (d * (d + 1) // 2 * 4 + 4 * 3 * d * M * 4) / 1024.0, "k_fr_vjp32mILb0": 4 * _vjp,
+        "k_fr_prod32q": (d * (d + 1) // 2 * 4 + 4 * 3 * d * M * 4) / 1024.0, "k_fr_vjp32s": 4 * _vjp}
 cal = {}
 try:
     cal = json.load(open("profiles/pmc_calibration.json")).get("patterns", {})
