@@ -761,8 +761,8 @@ __device__ __forceinline__ void fr_prod32_body(const Prod32Args &a) {
     const double sh = block_sum_nodrain_f32<NT>(he, red);
     if (tid == 0) n.he_part[eb] = sh;
   };
-  if (trailing) {   // riders beyond the tile count
-    rider(bid - a.n_dinv);
+  if (trailing) {   // riders beyond the tile count (a lane-batched launch is as wide as its widest lane: nothing to do beyond this lane's own)
+    if (bid - a.n_dinv < a.n_pack + a.n_eps) rider(bid - a.n_dinv);
     return;
   }
   MIVI_STAMP_K(a.dbg, MODE, 0);
@@ -1652,9 +1652,11 @@ bool launch_lanes_prod(mivi_ctx *c, LaneSink *s, int lanes, int which) {
   if (lanes < 1 || lanes > kMaxLanes || f32_mfma()) return false;
   Prod32Multi m;
   for (int l = 0; l < lanes; ++l) {
-    if (s[l].n_prod <= which || s[l].n_prod > 2 || s[l].prod_grid[which] != s[0].prod_grid[which] || s[l].prod_dense[which] != which) return false;
+    if (s[l].n_prod <= which || s[l].n_prod > 2 || s[l].prod_dense[which] != which || s[l].prod[which].n_tiles != s[0].prod[which].n_tiles) return false;
     m.lane[l] = s[l].prod[which];
   }
+  int gx = 0;   // (the lane that carries the STL riders may need trailing workgroups the others do not: d = 2048)
+  for (int l = 0; l < lanes; ++l) gx = s[l].prod_grid[which] > gx ? s[l].prod_grid[which] : gx;
   if (which == 0 && lanes == 4 && prod_quad_on()) {   // two tiles x two lanes per workgroup (k_fr_prod32q) where it applies
     const Prod32Args &a = m.lane[0];
     const int nrb = a.d >> 5;
@@ -1671,7 +1673,7 @@ bool launch_lanes_prod(mivi_ctx *c, LaneSink *s, int lanes, int which) {
       return true;
     }
   }
-  const dim3 grid(s[0].prod_grid[which], lanes);
+  const dim3 grid(gx, lanes);
   if (which) hipLaunchKernelGGL((k_fr_prod32m<G_DENSE, true>), grid, dim3(512), 0, c->stream, m);
   else hipLaunchKernelGGL((k_fr_prod32m<G_SAMPLE, true>), grid, dim3(512), 0, c->stream, m);
   return true;
