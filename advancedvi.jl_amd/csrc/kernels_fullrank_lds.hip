@@ -453,6 +453,7 @@ __global__ __launch_bounds__(256) void k_fr_vjp32s(StripMulti m) {
   float *rs_lds = Cs + KW * BN * LDC;
   auto issue = [&](const float *base, int ld, int c0) {   // rows/columns c0..c0+31, k in the wave's quarter: 8 pieces of 8 k x 32
     const float *p0 = base + c0 + 4 * (lane & 7) + (size_t)(w * Kq + (lane >> 3)) * ld;
+    if (MIVI_KNOCKED(a, 4)) return;
 #pragma unroll
     for (int p = 0; p < 8; ++p) MIVI_GLDS16(p0 + (size_t)(8 * p) * ld, buf + p * 256);
   };

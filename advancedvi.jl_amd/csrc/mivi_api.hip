@@ -1767,8 +1767,9 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
                  //  a VJP workgroup, share a CU)
   // Without a sticking-the-landing solve between the two kernels the contexts are LANE-BATCHED: E = 4 contexts per graph branch whose
   // product kernels are ONE launch (blockIdx.y = lane) and so are their VJP kernels -- half the launches per estimate, no fork / join for a
-  // short batch (4 contexts, one branch: isolated 20-estimate calls 10.6 -> 9.7 us per estimate), two branches of four for long ones
-  // (100-estimate calls back to back 8.2 -> 8.0 us: the chip is saturated near 8 us whatever the arrangement -- 8, 12 and 16 contexts agree).
+  // short batch (4 contexts, one branch: isolated 20-estimate calls 10.6 -> 9.7 us per estimate), two branches of four from twelve estimates on
+  // (since the lane-batched launches are kernels of their own -- k_fr_prod32q, k_fr_vjp32s: one product + one VJP workgroup fit a CU -- the second
+  // branch pays for 20-estimate calls too: 9.0 -> 8.1 us; 100-estimate calls back to back 7.0 us; 8, 12 and 16 contexts agree there).
   // MIVI_LANE_BATCH=0 keeps every context on a branch of its own (A/B reference; the STL estimators always do); MIVI_CHAINS = contexts.
   static const int lane_env = getenv("MIVI_LANE_BATCH") ? atoi(getenv("MIVI_LANE_BATCH")) : -1;
   const bool stl_ent = c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD;
@@ -1776,7 +1777,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64
   if (lanes > 1 && (!stl_ent || stl2_shape_ok(c, c->cfg.n_mc)) && lds_use_prod32(c, c->cfg.n_mc) && lds_bf16x3() && ((uintptr_t)params & 15) == 0 &&
       ((uintptr_t)grad & 15) == 0 && lane_env != 0) {
     lane_e = lane_env > 0 ? (lane_env > 4 ? 4 : lane_env) : 4;
-    lanes = count < 50 ? 4 : 8;
+    lanes = count < 12 ? 4 : 8;   // (isolated batches at the north star, 4 vs 8 contexts, us per estimate: 8: 10.8 / 10.4, 10: 11.0 / 11.5, 12: 9.9 / 9.4, 20: 9.1 / 8.1, 48: 8.3 / 7.2)
   }
   if (chain_lanes() > 0) lanes = c->is_child ? 1 : (chain_lanes() > mivi_ctx::kMaxKids + 1 ? mivi_ctx::kMaxKids + 1 : chain_lanes());
   if (lane_e > 0 && (lanes % lane_e != 0 || count < lanes)) lane_e = 0;

@@ -1,7 +1,7 @@
 """mivi_estimate_gradient_n on the second-generation full-rank route: a batch is dealt onto interleaved contexts (lane-batched launches:
 four contexts' product kernels as one launch, likewise their VJP kernels; one or two graph branches) -- every estimate must still be
 bitwise the single call's, for every batch length (partial last steps, batches shorter than the number of contexts, the switch from
-four to eight contexts at 50) and for both Gaussian targets; the STL estimators keep one context per branch.  At the BASELINE sizes the
+four to eight contexts at 12) and for both Gaussian targets; the STL estimators keep one context per branch.  At the BASELINE sizes the
 lane-batched launches are kernels of their own (k_fr_prod32q: two tiles x two lanes per workgroup; k_fr_vjp32s: strips of tiles): the
 same bitwise requirement at the shapes that select them."""
 import numpy as np
@@ -27,7 +27,7 @@ def test_every_batch_length_equals_single_calls(kind, ent):
     p, pr = ctx.to_device(params), ref.to_device(params)
     v, g = ctx.empty(1), ctx.empty(ctx.params_len)
     idx = 3
-    for n in (1, 2, 3, 4, 5, 7, 8, 9, 13, 20, 49, 50, 51, 64, 101):
+    for n in (1, 2, 3, 4, 5, 7, 8, 9, 11, 12, 13, 20, 49, 50, 51, 64, 101):
         g.fill_(float("nan"))
         ctx.estimate_gradient_n(p, idx, n, v, g)
         ctx.synchronize()
