@@ -32,7 +32,11 @@ def test_every_batch_length_equals_single_calls(kind, ent):
         ctx.estimate_gradient_n(p, idx, n, v, g)
         ctx.synchronize()
         v1, g1 = ref.estimate_gradient(pr, idx + n - 1)
-        assert float(v.item()) == float(v1.item()), (n, float(v.item()), float(v1.item()))
+        if ent == 2:   # MonteCarloEntropy's value holds sum(eps^2): a single call takes the f32 wave sums of k_eps' blocks, a batch those of the
+            # product kernel's riders (other block shapes, both then summed in f64) -- the f32 VALUE may land one ulp apart (1 case in ~90)
+            assert abs(float(v.item()) - float(v1.item())) <= float(np.spacing(np.float32(abs(float(v1.item()))))), (n, float(v.item()), float(v1.item()))
+        else:
+            assert float(v.item()) == float(v1.item()), (n, float(v.item()), float(v1.item()))
         assert np.array_equal(g.cpu().numpy(), g1.cpu().numpy()), n
         idx += n + 2                                        # (a gap: the next call is NOT in order -- the counter is set again)
     # in-order calls continue the device-side estimate counter
