@@ -1467,16 +1467,49 @@ void build_vjp(mivi_ctx *c, int d, int M, int tile, DevBuf &tab, int &n_items) {
   upload(c, tab, packed.data(), packed.size() * sizeof(int4));
 }
 
-// strips of k_fr_vjp32s: up to NS consecutive tiles of one block row per workgroup.  XCD x (= workgroup index % 8) takes the block rows
-// {x, 15 - x, 16 + x, 31 - x} (+ 32 i): the same number of tiles on every XCD, four W panels and the eps panels below them in its L2.
+// strips of k_fr_vjp32s: up to NS consecutive tiles of one block row per workgroup.  XCD x (= workgroup index % 8) takes whole 8 x 8-tile
+// super-blocks of the lower triangle (its L2 then holds 8 W panels + 8 eps panels per super-block: 5 MB over the fabric per estimate at the
+// north star, against 9 MB when an XCD owns whole block rows and so pulls every eps panel), super-blocks dealt heaviest first onto the
+// lightest XCD; with fewer than eight super-blocks (d < 1024) the block rows {x, 15 - x, 16 + x, 31 - x} instead.
 void build_strips(mivi_ctx *c, int d, int NS, DevBuf &tab, int &n_items) {
-  const int nrb = d / 32;
+  const int nrb = d / 32, nsr = (nrb + 7) / 8;
+  static const bool rows_env = getenv("MIVI_STRIP_ROWS") != nullptr;   // (A/B: the block-row assignment at every size)
   std::vector<std::vector<int4>> lists(8);
-  for (int rb = 0; rb < nrb; ++rb) {
-    const int r = rb & 15, x = (r < 8) ? r : 15 - r;
-    for (int cb0 = 0; cb0 <= rb; cb0 += NS) {
-      const int nc = (rb + 1 - cb0 < NS) ? rb + 1 - cb0 : NS;
-      lists[x].push_back(make_int4(rb | (cb0 << 16), nc, 0, 0));
+  if (nsr * (nsr + 1) / 2 >= 8 && !rows_env) {
+    std::vector<std::vector<int4>> sbs;
+    std::vector<int> tiles;
+    for (int sr = 0; sr < nsr; ++sr)
+      for (int sc = 0; sc <= sr; ++sc) {
+        std::vector<int4> t;
+        int nt = 0;
+        for (int rb = sr * 8; rb < sr * 8 + 8 && rb < nrb; ++rb) {
+          const int c_hi = (sc * 8 + 8 < rb + 1) ? sc * 8 + 8 : rb + 1;
+          for (int cb0 = sc * 8; cb0 < c_hi; cb0 += NS) {
+            const int nc = (c_hi - cb0 < NS) ? c_hi - cb0 : NS;
+            t.push_back(make_int4(rb | (cb0 << 16), nc, 0, 0));
+            nt += nc;
+          }
+        }
+        if (!t.empty()) { sbs.push_back(t); tiles.push_back(nt); }
+      }
+    std::vector<int> order(sbs.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return tiles[p] > tiles[q]; });
+    int load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i : order) {
+      int best = 0;
+      for (int x = 1; x < 8; ++x)
+        if (load[x] < load[best]) best = x;
+      lists[best].insert(lists[best].end(), sbs[i].begin(), sbs[i].end());
+      load[best] += tiles[i];
+    }
+  } else {
+    for (int rb = 0; rb < nrb; ++rb) {
+      const int r = rb & 15, x = (r < 8) ? r : 15 - r;
+      for (int cb0 = 0; cb0 <= rb; cb0 += NS) {
+        const int nc = (rb + 1 - cb0 < NS) ? rb + 1 - cb0 : NS;
+        lists[x].push_back(make_int4(rb | (cb0 << 16), nc, 0, 0));
+      }
     }
   }
   size_t L = 0;

@@ -76,6 +76,24 @@ def pmc_traffic(kernel_substr):
     return None
 
 
+def rocprof_avg(kernel_substr, workload="ns"):
+    """Average duration (us) of a kernel in the newest committed `rocprofv3 --kernel-trace --stats` summary of this workload's bench command
+    (profiles/<tag>_<workload>_kernel_stats.md, written by tools/profile_round.sh): the in-chain figure -- launches of the timed region, other
+    branches' kernels running beside them -- next to the stand-alone one this process measures."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_kernel_stats.md" % workload)))
+    for f in reversed(files):
+        try:
+            for line in open(f):
+                if kernel_substr in line and line.startswith("|"):
+                    c = [x.strip() for x in line.strip().strip("|").split("|")]
+                    return dict(avg_us=float(c[3]) / 1e3, calls=int(c[1]), source=os.path.relpath(f, ROOT))
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
 def mf_roofline(ctx, params, cost, kernel_names=("k_mf_main<float>", "k_mf_sgd_loop<float> (100 estimates per launch)")):
     """Mean-field roofline leg.  Batched estimates (estimate_gradient_n, what the bench line times) run 100 estimates per
     launch of the launch-free loop kernel; a single call is one launch of the fused main kernel -- both are reported."""
@@ -143,7 +161,11 @@ def fr_roofline(ctx, params, cost, w, reps=300):
             single = {k: roof[k] for k in ("kernel", "achieved", "frac", "traffic", "algorithmic_flops_per_launch", "avg_launch_us", "other_contraction")}
             roof.update(kernel=n4[d4], achieved=a4, frac=a4 / PEAK_F32_MFMA_TF, algorithmic_flops_per_launch=4 * fl, estimates_per_launch=4,
                         avg_launch_us=t4[d4] * 1e3, traffic=pmc_traffic({"vjp": "k_fr_vjp32s", "sample": "k_fr_prod32q"}[d4]),
-                        other_contraction=dict(kernel=n4[o4], avg_launch_us=t4[o4] * 1e3, achieved=4 * fl / (t4[o4] * 1e-3) / 1e12),
+                        other_contraction=dict(kernel=n4[o4], avg_launch_us=t4[o4] * 1e3, achieved=4 * fl / (t4[o4] * 1e-3) / 1e12,
+                                               rocprof_in_chain=rocprof_avg({"vjp": "k_fr_vjp32s", "sample": "k_fr_prod32q"}[o4])),
+                        rocprof_in_chain=rocprof_avg({"vjp": "k_fr_vjp32s", "sample": "k_fr_prod32q"}[d4]),
+                        timing="hipGraph replay of %d launches of the four-lane kernel alone, hipEvents on the launch stream (rocprof_in_chain: "
+                               "the same kernel inside the timed batches, the other branch's kernels beside it)" % reps,
                         single_launch=single)
             ach = a4
     if gen and bf3:

@@ -129,7 +129,8 @@ CASES = [
     ("MIVI_CHAINS=8", CHAINS, dict(kind="diag")),                                                         # eight contexts: two branches of four lanes
     ("MIVI_PROD_QUAD=0", CHAINS_NS, dict(kind="diag")),                                                   # four lanes' products on k_fr_prod32's tiles (k_fr_prod32m)
     ("MIVI_VJP_STRIP=0", CHAINS_NS, dict(kind="diag")),                                                   # one VJP tile per workgroup (k_fr_vjp32m)
-    ("MIVI_VJP_STRIP=5", CHAINS_NS, dict(kind="dense")),                                                  # another strip length
+    ("MIVI_VJP_STRIP=5", CHAINS_NS, dict(kind="dense")),
+    ("MIVI_STRIP_ROWS=1", CHAINS_NS, dict(kind="diag")),                                                  # strips dealt to the XCDs by block row                                                  # another strip length
     ("MIVI_DUMMY_DEFAULT=1", CHAINS_NS, dict(kind="diag")),                                               # (no switch: k_fr_prod32q + k_fr_vjp32s)
     ("MIVI_DUMMY_DEFAULT=1", CHAINS, dict(kind="dense")),                                                 # (no switch: the default interleaving)                                                                 # first-generation accumulation kernel
 ]

@@ -32,7 +32,7 @@ def test_every_batch_length_equals_single_calls(kind, ent):
         ctx.estimate_gradient_n(p, idx, n, v, g)
         ctx.synchronize()
         v1, g1 = ref.estimate_gradient(pr, idx + n - 1)
-        if ent == 2:   # MonteCarloEntropy's value holds sum(eps^2): a single call takes the f32 wave sums of k_eps' blocks, a batch those of the
+        if ent in (2, 3):   # the Monte Carlo entropy value (also the STL estimator's) holds sum(eps^2): a single call takes the f32 wave sums of k_eps' blocks, a batch those of the
             # product kernel's riders (other block shapes, both then summed in f64) -- the f32 VALUE may land one ulp apart (1 case in ~90)
             assert abs(float(v.item()) - float(v1.item())) <= float(np.spacing(np.float32(abs(float(v1.item()))))), (n, float(v.item()), float(v1.item()))
         else:
@@ -44,7 +44,9 @@ def test_every_batch_length_equals_single_calls(kind, ent):
     ctx.estimate_gradient_n(p, 1020, 20, v, g)
     ctx.synchronize()
     v1, g1 = ref.estimate_gradient(pr, 1039)
-    assert float(v.item()) == float(v1.item()) and np.array_equal(g.cpu().numpy(), g1.cpu().numpy())
+    ulps = 1 if ent in (2, 3) else 0
+    assert abs(float(v.item()) - float(v1.item())) <= ulps * float(np.spacing(np.float32(abs(float(v1.item())))))
+    assert np.array_equal(g.cpu().numpy(), g1.cpu().numpy())
     ctx.close()
     ref.close()
 
@@ -125,7 +127,8 @@ def test_lane_batched_kernels_equal_single_calls_at_the_baseline_sizes(d, M, kin
         ctx.estimate_gradient_n(p, idx, n, v, g)
         ctx.synchronize()
         v1, g1 = ref.estimate_gradient(pr, idx + n - 1)
-        assert float(v.item()) == float(v1.item()), (n, float(v.item()), float(v1.item()))
+        ulps = 1 if ent == 3 else 0   # (the STL estimator's value holds sum(eps^2): see test_every_batch_length_equals_single_calls)
+        assert abs(float(v.item()) - float(v1.item())) <= ulps * float(np.spacing(np.float32(abs(float(v1.item()))))), (n, float(v.item()), float(v1.item()))
         assert np.array_equal(g.cpu().numpy(), g1.cpu().numpy()), n
         idx += n
     ctx.close()

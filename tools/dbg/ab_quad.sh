@@ -3,6 +3,7 @@
 run() { echo "== $*"; env "$@" python tools/dbg/chains.py 2>&1 | grep "chunk\|isolated"; }
 for r in 1 2; do
 run MIVI_DUMMY=1
-run MIVI_CHAINS=12
-run MIVI_CHAINS=16
+run MIVI_STRIP_ROWS=1
+run MIVI_VJP_STRIP=4
+run MIVI_VJP_STRIP=2
 done
