@@ -79,6 +79,8 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
   const bool mu_tile = (wk.w & 2);
   // ---- vjp epilogue: tile (rb, cb) of tril(W eps^T) -------------------------------------------------------------------
   const double invM = 1.0 / (double)a.out.M_total;
+  const bool pow2M = (a.out.M_total & (a.out.M_total - 1)) == 0;
+  const float invMf = (float)invM;
   const double direct = direct_entropy_coeff(a.out.ent_kind);
   const bool diag_tile = (wk.w & 1);
   if (a.out.partials_mode) {   // shard partials: raw sums, packed lower triangle
@@ -123,6 +125,8 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
       for (int c = 0; c < 4; ++c) {
         if (gj > gi + c) {
           o[c] = 0.f;
+        } else if (pow2M && gj != gi + c) {
+          o[c] = -v[c] * invMf;   // (a power-of-two sample count: the f32 product is exact, i.e. the f64 route's result without its conversions)
         } else {
           double x = -(double)v[c] * invM;
           if (gj == gi + c) x -= direct / (double)cjj;
