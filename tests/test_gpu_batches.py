@@ -133,3 +133,31 @@ def test_lane_batched_kernels_equal_single_calls_at_the_baseline_sizes(d, M, kin
         idx += n
     ctx.close()
     ref.close()
+
+
+def test_lane_batched_kernels_many_batches_stay_bitwise():
+    """The strip VJP kernel reads a tile's operand fragments while the previous tile's stores are still in flight (exact `vmcnt` accounting),
+    the four-lane product shares one staged fragment between two estimates: sixty batches of random lengths at the north-star shape, every
+    one bitwise the single call's."""
+    d, M = 1024, 256
+    rng = np.random.default_rng(77)
+    q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
+    prob, _ = make_problem(rng, "diag", d, np.float32)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+    ctx.set_problem(prob)
+    ref = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+    ref.set_problem(prob)
+    p, pr = ctx.to_device(params), ref.to_device(params)
+    v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+    idx = 0
+    for n in rng.integers(4, 70, size=60):
+        n = int(n)
+        ctx.estimate_gradient_n(p, idx, n, v, g)
+        ctx.synchronize()
+        v1, g1 = ref.estimate_gradient(pr, idx + n - 1)
+        assert float(v.item()) == float(v1.item()), (n, idx)
+        assert bool((g == g1).all().item()), (n, idx)
+        idx += n
+    ctx.close()
+    ref.close()
