@@ -835,7 +835,7 @@ def main():
                            "fullrank_route": (list(ctx.fullrank_route()) if w["family"] == 1 else None)},
                 "roofline": roof, "cpu_baseline": cpub,
                 "repeat_ms_per_step": repeats, "elbo_rel_err_vs_cpu_fp64": rel, "parity_vs_fp64_oracle": parity_head, "stage_us": stages,
-                "preheat": dict(calls=heat_calls, note="untimed batched calls for >= 300 ms before the timed region (GPU clock ramp); not counted in steps / warmup"), "whole_estimate": whole, "steady_state": steady, "concurrent": conc, "also": also,
+                "preheat": dict(calls=heat_calls, note="untimed batched calls for >= 300 ms before the timed region (GPU clock ramp), the last three each followed by a device-wide synchronize like the timed call; not counted in steps / warmup"), "whole_estimate": whole, "steady_state": steady, "concurrent": conc, "also": also,
                 "dist": (None if single else dist_info),
             }
         if dist:
