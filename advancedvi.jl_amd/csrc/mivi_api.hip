@@ -2515,6 +2515,10 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
   // estimates first (it creates and fills the four contexts), then the four contexts' launches are recorded once and the ONE launch
   // that serves them is replayed.
   LaneSink *psink = nullptr;
+  struct SinkGuard {   // (the stage code below returns early on errors)
+    LaneSink *&p;
+    ~SinkGuard() { if (p) lane_sinks_free(p); }
+  } sink_guard{psink};
   if (which == 10 || which == 11) {
     if (!(lds && lds_use_prod32(c, M)) || c->is_child || c->target != TGT_DIAG_GAUSS) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 10 / 11: full-rank second-generation kernels, diagonal-Gaussian target");
     if ((s = mivi_estimate_gradient_n(c, params, 1, 8, o, o + 16))) return s;
@@ -2638,7 +2642,6 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  if (psink) lane_sinks_free(psink);
   if (which != 0) c->pre_valid = false;
   if (s) return s;
   *ms_out = (double)ms / reps;
