@@ -532,7 +532,20 @@ struct MfFunnelLoopArgs {
   double *hist;        // [n_steps][6][nblk]
   T *grad_out;         // rows >= 1 of every estimate (row 0: the value kernel)
   T *lane_scratch;     // estimate lanes (gridDim.y > 1): [lanes][2 d], the gradient rows of every estimate but the last
+  const T *e0;         // [n_steps][M]: eps[0, m] of every estimate (k_funnel_e0) -- every row quad needs z[0, m]; nullptr: re-derived per thread
 };
+
+// eps[0, m] of estimates idx0 .. idx0 + n_steps - 1: one table for all the row-quad workgroups of k_mf_funnel_loop, each of which would
+// otherwise run a second Philox block + Box-Muller pair per column to re-derive it (a quarter of the loop's vector instructions)
+template <typename T>
+__global__ __launch_bounds__(256) void k_funnel_e0(uint64_t seed, uint64_t idx0, int n_steps, int m_offset, int M, int d4, T *out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_steps * M) return;
+  const int t = i / M, m = i - t * M;
+  T e[4];
+  eps_block<T>(seed, idx0 + (uint64_t)t, (uint64_t)(m_offset + m) * (uint64_t)d4, e);
+  out[i] = e[0];
+}
 
 template <typename T, int NW>
 __global__ __launch_bounds__(64 * NW) void k_mf_funnel_loop(MfFunnelLoopArgs<T> a) {
@@ -576,6 +589,7 @@ __global__ __launch_bounds__(64 * NW) void k_mf_funnel_loop(MfFunnelLoopArgs<T> 
       T e[4], e0q[4];
       eps_block<T>(a.seed, a.idx0 + (uint64_t)t, (uint64_t)(a.m_offset + m) * (uint64_t)d4 + (uint64_t)rq, e);
       if (rq == 0) e0q[0] = e[0];
+      else if (a.e0) e0q[0] = a.e0[(size_t)t * a.M + m];
       else eps_block<T>(a.seed, a.idx0 + (uint64_t)t, (uint64_t)(a.m_offset + m) * (uint64_t)d4, e0q);
       T g[4] = {0, 0, 0, 0};
       funnel_column<T>(rq, d, mu, sg, e, e0q[0], mu0, sg0, g, s_ell, sA, sB);
@@ -681,7 +695,7 @@ __global__ __launch_bounds__(256) void k_mf_funnel_loop_value(MfFunnelValueArgs<
 
 template <typename T>
 static void mf_funnel_loop_impl(mivi_ctx *c, const void *params, uint64_t idx0, int n_steps, double *hist, double *elbo, void *scratch,
-                                void *value, void *grad, void *lane_scratch) {
+                                void *value, void *grad, void *lane_scratch, void *e0_tab) {
   MfFunnelLoopArgs<T> a;
   a.d = c->cfg.d; a.M = c->cfg.n_mc; a.n_steps = n_steps;
   a.params = (const T *)params;
@@ -691,6 +705,9 @@ static void mf_funnel_loop_impl(mivi_ctx *c, const void *params, uint64_t idx0, 
   a.grad_out = (T *)grad;
   a.lane_scratch = (T *)lane_scratch;
   const int d4 = (a.d + 3) / 4, lanes = lane_scratch ? mf_loop_lanes(c, n_steps) : 1;
+  a.e0 = (const T *)e0_tab;
+  if (e0_tab)
+    hipLaunchKernelGGL(k_funnel_e0<T>, dim3((n_steps * a.M + 255) / 256), dim3(256), 0, c->stream, a.seed, idx0, n_steps, a.m_offset, a.M, d4, (T *)e0_tab);
   if (a.M <= 64) hipLaunchKernelGGL((k_mf_funnel_loop<T, 1>), dim3(d4, lanes), dim3(64), 0, c->stream, a);
   else hipLaunchKernelGGL((k_mf_funnel_loop<T, 4>), dim3(d4, lanes), dim3(256), 0, c->stream, a);
   MfFunnelValueArgs<T> v;
@@ -703,10 +720,11 @@ static void mf_funnel_loop_impl(mivi_ctx *c, const void *params, uint64_t idx0, 
 
 // n_steps estimates of the fused funnel target at fixed parameters in one launch + one finishing launch (see k_mf_funnel_loop).
 // hist: n_steps * 6 * ceil(d/4) doubles, elbo: n_steps doubles, scratch: n_steps * (d + 2) elements of T.
+// e0_tab: n_steps * n_mc elements of T (eps[0, m] of every estimate, filled here by k_funnel_e0), or nullptr.
 void launch_mf_funnel_loop(mivi_ctx *c, const void *params, uint64_t idx0, int n_steps, double *hist, double *elbo, void *scratch,
-                           void *value, void *grad, void *lane_scratch) {
-  if (c->cfg.dtype == MIVI_F32) mf_funnel_loop_impl<float>(c, params, idx0, n_steps, hist, elbo, scratch, value, grad, lane_scratch);
-  else mf_funnel_loop_impl<double>(c, params, idx0, n_steps, hist, elbo, scratch, value, grad, lane_scratch);
+                           void *value, void *grad, void *lane_scratch, void *e0_tab) {
+  if (c->cfg.dtype == MIVI_F32) mf_funnel_loop_impl<float>(c, params, idx0, n_steps, hist, elbo, scratch, value, grad, lane_scratch, e0_tab);
+  else mf_funnel_loop_impl<double>(c, params, idx0, n_steps, hist, elbo, scratch, value, grad, lane_scratch, e0_tab);
 }
 
 // rand(rng, q::MvLocationScale{<:Diagonal}, M): Z = mu + sigma .* eps  (location_scale.jl:80-87)

@@ -1647,10 +1647,14 @@ static mivi_status_t estimate_gradient_chain(mivi_ctx *c, const void *params, ui
     const size_t nd = (size_t)count * 6 * d4 + (size_t)count + 8;
     const size_t sc_bytes = ((size_t)count * ((size_t)c->cfg.d + 2) * c->esize + 63) & ~(size_t)63;
     const size_t lane_bytes = (size_t)mf_loop_lanes(c, count) * 2 * (size_t)c->cfg.d * c->esize;   // the estimate lanes' gradient scratch
-    if ((s = ensure(c, c->X, nd * sizeof(double) + sc_bytes + lane_bytes + 64, false))) return s;
+    const size_t lane_al = (lane_bytes + 63) & ~(size_t)63;
+    const size_t e0_bytes = (size_t)count * (size_t)c->cfg.n_mc * c->esize;   // eps[0, m] of every estimate, shared by the row quads
+    if ((s = ensure(c, c->X, nd * sizeof(double) + sc_bytes + lane_al + e0_bytes + 64, false))) return s;
     double *hist = (double *)c->X.p, *elbo = hist + (size_t)count * 6 * d4;
     void *scratch = (void *)(elbo + count + 8);
-    launch_mf_funnel_loop(c, params, idx0, count, hist, elbo, scratch, value, grad, (void *)((char *)scratch + sc_bytes));
+    static const bool no_e0 = getenv("MIVI_FUNNEL_NO_E0TAB") != nullptr;   // (A/B: every thread re-derives eps[0, m])
+    launch_mf_funnel_loop(c, params, idx0, count, hist, elbo, scratch, value, grad, (void *)((char *)scratch + sc_bytes),
+                          no_e0 ? nullptr : (void *)((char *)scratch + sc_bytes + lane_al));
     HIPCHK(c, hipGetLastError());
     return MIVI_OK;
   }
@@ -2546,7 +2550,7 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
     const bool fn5 = !fr && c->target == TGT_FUNNEL && !c->funnel_constrained;
     if (fr || (c->target != TGT_DIAG_GAUSS && !fn5) || c->bij_on || M > 4096) return fail(c, MIVI_ERR_UNSUPPORTED, "which = 5: mean-field + diagonal-Gaussian / fused funnel target, no bijector");
     if ((s = ensure(c, c->X, ((size_t)100 + 600 * (size_t)((c->cfg.d + 3) / 4) + 16) * sizeof(double) + 100 * ((size_t)c->cfg.d + 2) * c->esize + 64 +
-                              32 * 2 * (size_t)c->cfg.d * c->esize + 64, false))) return s;   // (+ the estimate lanes' gradient scratch)
+                              32 * 2 * (size_t)c->cfg.d * c->esize + 64 + 100 * (size_t)M * c->esize + 64, false))) return s;   // (+ the estimate lanes' gradient scratch, + the funnel loop's eps[0, m] table)
   } else if (which != 0 && which != 8 && which != 9) {
     if (!fr && which != 2) return fail(c, MIVI_ERR_UNSUPPORTED, "mean-field has a single fused kernel (which = 2)");
     if (which == 4 && c->target != TGT_DENSE_GAUSS) return fail(c, MIVI_ERR_UNSUPPORTED, "no dense target set");
@@ -2592,8 +2596,9 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *c, int32_t which, const void *para
           const size_t d4 = (size_t)((c->cfg.d + 3) / 4);
           double *hist = (double *)c->X.p, *elbo = hist + 600 * d4;
           char *sc = (char *)(elbo + 108);
-          launch_mf_funnel_loop(c, params, (uint64_t)r * 100, 100, hist, elbo, (void *)sc, o, o + 16,
-                                (void *)(sc + ((100 * ((size_t)c->cfg.d + 2) * c->esize + 63) & ~(size_t)63)));
+          char *ls = sc + ((100 * ((size_t)c->cfg.d + 2) * c->esize + 63) & ~(size_t)63);
+          launch_mf_funnel_loop(c, params, (uint64_t)r * 100, 100, hist, elbo, (void *)sc, o, o + 16, (void *)ls,
+                                (void *)(ls + ((32 * 2 * (size_t)c->cfg.d * c->esize + 63) & ~(size_t)63)));
           break;
         }
         launch_mf_sgd_loop(c, const_cast<void *>(params), nullptr, (uint64_t)r * 100, 0, 100, -1, 0.0, (double)NAN, (double *)c->X.p + 100,

@@ -337,7 +337,7 @@ void launch_mf_main(mivi_ctx *c, const void *params, const RngArgs &rng, int M, 
 void launch_mf_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule,
                         double eta, double clip_eps, double *hist, double *elbo, void *grad_out = nullptr, void *lane_scratch = nullptr);
 void launch_mf_funnel_loop(mivi_ctx *c, const void *params, uint64_t idx0, int n_steps, double *hist, double *elbo, void *scratch,
-                           void *value, void *grad, void *lane_scratch = nullptr);
+                           void *value, void *grad, void *lane_scratch, void *e0_tab = nullptr);
 int mf_loop_lanes(const mivi_ctx *c, int n_steps);   // estimate lanes of the launch-free batches (lane_scratch: lanes * 2 d elements)
 void launch_sample_mf(mivi_ctx *c, const void *params, const RngArgs &rng, int M, void *Z, void *eps, int ld_eps,
                       double *he_part);

@@ -97,6 +97,26 @@ for rep in range(2):
 print('ok')
 """
 
+FUNNEL = """
+import numpy as np, advancedvi_jl_amd as avi
+from oracle import oracle as O
+from tests.helpers import SEED
+d, M, n = 96, 64, 9
+q = avi.MeanFieldGaussian((0.1 * np.arange(d) / d).astype(np.float32), np.full(d, 0.8, np.float32))
+params, _ = avi.destructure(q)
+ctx = avi.MiviContext(np.float32, avi.MEANFIELD, d, M, 3, SEED)
+ctx.set_problem(avi.FunnelProblem(d, 1.5))
+p = ctx.to_device(params)
+v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+ctx.estimate_gradient_n(p, 30, n, v, g)
+ctx.synchronize()
+_, eps = ctx.sample(params, 30 + n - 1)
+ref = O.estimate_gradient(params.astype(np.float64), d, avi.MEANFIELD, O.FunnelStackedTarget(d, 1.5), eps.cpu().numpy().astype(np.float64), 3)
+assert abs(float(v.item()) - ref["value"]) <= 2e-5 * abs(ref["value"])
+assert np.linalg.norm(g.cpu().numpy() - ref["grad"]) <= 2e-5 * max(1.0, np.linalg.norm(ref["grad"]))
+print('ok')
+"""
+
 CHAINS_NS = CHAINS.replace("d, M, n = 256, 128, 25", "d, M, n = 1024, 256, 23")   # the shape whose lane-batched launches are k_fr_prod32q / k_fr_vjp32s
 
 F, MF = 1, 0
@@ -118,6 +138,8 @@ CASES = [
     ("MIVI_LOGREG_GENERIC=1", ESTIMATE, dict(fam=MF, d=64, M=128, kind="logreg0", ent=0, dt="float32")),
     ("MIVI_LOGREG_MFMA=1", ESTIMATE, dict(fam=MF, d=64, M=128, kind="logreg0", ent=0, dt="float32")),
     ("MIVI_NO_FUSED_LOOP=1", LOOP, dict(fam=MF, d=64, M=32)),                                             # graph loop instead of the launch-free kernel
+    ("MIVI_FUNNEL_NO_E0TAB=1", FUNNEL, dict()),                                                          # funnel loop: every thread re-derives eps[0, m] instead of reading the table
+    ("MIVI_DUMMY_DEFAULT=1", FUNNEL, dict()),                                                             # (no switch: the table)
     ("MIVI_NO_FUSED_UPDATE=1", LOOP, dict(fam=F, d=128, M=128)),                                          # separate update kernel in the graph loop
     ("MIVI_GRAPH_MIN=1", LOOP, dict(fam=F, d=128, M=128)),                                                # graph replay even for the shortest batches
     ("MIVI_GRAPH_MIN=100", LOOP, dict(fam=F, d=128, M=128)),                                              # eager chain for every batch
