@@ -103,10 +103,10 @@ def test_mixed_call_sequences_keep_every_result_exact():
     ref.close()
 
 
-@pytest.mark.parametrize("d,M", [(1024, 256), (2048, 256), (512, 256), (512, 512)])
+@pytest.mark.parametrize("d,M", [(1024, 256), (2048, 256), (1536, 256), (512, 256), (512, 512)])
 @pytest.mark.parametrize("kind,ent", [("diag", 0), ("dense", 0), ("diag", 3)])
 def test_lane_batched_kernels_equal_single_calls_at_the_baseline_sizes(d, M, kind, ent):
-    """(1024, 256) and (2048, 256): k_fr_prod32q + k_fr_vjp32s; (512, 256): k_fr_prod32m + k_fr_vjp32s; (512, 512): k_fr_prod32q + k_fr_vjp32m.
+    """(1024, 256), (2048, 256) and (1536, 256: 48 block rows, 24 tile pairs, 21 super-blocks of strips): k_fr_prod32q + k_fr_vjp32s; (512, 256): k_fr_prod32m + k_fr_vjp32s; (512, 512): k_fr_prod32q + k_fr_vjp32m.
     The dense target keeps its second product on k_fr_prod32m; the STL estimator's first step carries the inversion riders (k_fr_prod32m),
     its later steps do not.  Batch lengths: one full step of four lanes, a partial last step, two branches of four lanes."""
     if kind == "dense" and d == 2048:
