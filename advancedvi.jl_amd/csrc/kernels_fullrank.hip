@@ -79,10 +79,21 @@ __global__ __launch_bounds__(256) void k_eps(SampleArgs<T> a) {
 }
 // lane-batched contexts (mivi_api.hip): the first draws of up to four contexts as ONE launch (blockIdx.y = lane)
 struct EpsMulti { SampleArgs<float> lane[4]; };
-__global__ __launch_bounds__(256) void k_eps_m(EpsMulti m) {
-  __shared__ float lds[64][17];
-  __shared__ double red[4];
-  eps_tile_block<float>(m.lane[blockIdx.y], blockIdx.x, lds, red);
+// -- in the BLOCKS of the product kernels' eps(t+1) riders (64 rows x 32 columns, one Philox block per thread, 256 contiguous bytes per
+// column, the same eight wave sums behind he_part): a lane's first draw is laid down exactly like all its later ones
+__global__ __launch_bounds__(512) void k_eps_m(EpsMulti m) {
+  __shared__ double red[8];
+  const SampleArgs<float> &n = m.lane[blockIdx.y];
+  const int tid = threadIdx.x, eb = blockIdx.x, d = n.d, nrb6 = d >> 6;
+  const int ri = (eb % nrb6) * 64 + 4 * (tid & 15), rm = (eb / nrb6) * 32 + (tid >> 4);
+  float e[4];
+  eps_block<float>(n.rng.seed, rng_index(n.rng), (uint64_t)(n.rng.m_offset + rm) * (uint64_t)(d >> 2) + (uint64_t)(ri >> 2), e);
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  const f32x4_t ev = {e[0], e[1], e[2], e[3]};
+  store16_wt(n.eps + (size_t)rm * n.ld_eps + ri, ev);
+  const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
+  const double sh = block_sum_nodrain_f32<512>(he, red);
+  if (tid == 0) n.he_part[eb] = sh;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1241,22 +1252,25 @@ void launch_lanes_eps(mivi_ctx *c, EpsSink *s, int lanes) {
   int L = 0, grid = 0;
   for (int l = 0; l < lanes && l < 4; ++l)
     if (s->n[l] > 0) { m.lane[L++] = s->a[l]; grid = s->grid[l]; }
-  if (L > 0) hipLaunchKernelGGL(k_eps_m, dim3(grid, L), dim3(256), 0, c->stream, m);
+  if (L > 0) hipLaunchKernelGGL(k_eps_m, dim3(grid, L), dim3(512), 0, c->stream, m);
 }
 
-void launch_eps(mivi_ctx *c, const RngArgs &rng, int M) {
+// returns the number of he_part entries the draw leaves
+int launch_eps(mivi_ctx *c, const RngArgs &rng, int M) {
   const int nblk = eps_blocks(c, M);
   if (c->eps_sink && c->cfg.dtype == MIVI_F32) {   // lane-batched contexts: record (every lane has the same shape, so the same grid)
-    EpsSink *sk = (EpsSink *)c->eps_sink;
+    EpsSink *sk = (EpsSink *)c->eps_sink;        // (k_eps_m works in the riders' blocks: d % 64 == 0, M % 32 == 0 on this route)
+    const int nrid = (c->cfg.d / 64) * (M / 32);
     sk->a[c->lane_id] = eps_args<float>(c, rng, M, c->cur);
-    sk->grid[c->lane_id] = nblk;
+    sk->grid[c->lane_id] = nrid;
     ++sk->n[c->lane_id];
-    return;
+    return nrid;
   }
   if (c->cfg.dtype == MIVI_F32)
     hipLaunchKernelGGL(k_eps<float>, dim3(nblk), dim3(256), 0, c->stream, eps_args<float>(c, rng, M, c->cur));
   else
     hipLaunchKernelGGL(k_eps<double>, dim3(nblk), dim3(256), 0, c->stream, eps_args<double>(c, rng, M, c->cur));
+  return nblk;
 }
 
 template <typename T>

@@ -511,8 +511,7 @@ static mivi_status_t run_estimate_lds(mivi_ctx *c, const void *params, const Rng
   if (!chained) c->cur = hit ? c->pre_parity : 0;
   const int p = c->cur;
   if (chained ? ch->first : !hit) {
-    launch_eps(c, rng, M);
-    c->he_n[p] = eps_blocks(c, M);
+    c->he_n[p] = launch_eps(c, rng, M);
   }
   vin.he_part = (const double *)c->he_part[p].p;
   vin.n_he_part = c->he_n[p];

@@ -343,7 +343,7 @@ void launch_sample_mf(mivi_ctx *c, const void *params, const RngArgs &rng, int M
                       double *he_part);
 
 // kernels_fullrank.hip
-void launch_eps(mivi_ctx *c, const RngArgs &rng, int M);
+int launch_eps(mivi_ctx *c, const RngArgs &rng, int M);   // returns the number of he_part entries the draw leaves
 void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, void *Z, const ValueJob *prev = nullptr);
 void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, const EpsJob *next = nullptr,
                    const ValueJob *self = nullptr, const FusedUpdate *upd = nullptr);
