@@ -36,8 +36,11 @@ __device__ __forceinline__ double row16_sum(double v) {   // f64 contexts: plain
 // the device loop, so both produce the same bits.
 __device__ __forceinline__ float wave_total63(float v) {
   v = row16_sum(v);
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+  // (the two cross-row steps as ONE DPP add each: from update_dpp + add the compiler makes v_mov_dpp, v_mov, v_add for a partial row mask --
+  //  forty vector instructions per estimate of the launch-free loops for nothing; same values, same order; s_nop 1: a VALU result read by
+  //  a DPP operand needs two wait states)
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
   return v;
 }
 __device__ __forceinline__ double wave_total63(double v) { return wave_sum(v); }
