@@ -115,7 +115,11 @@ def mf_roofline(ctx, params, cost, kernel_names=("k_mf_main<float>", "k_mf_sgd_l
     return dict(bound="hbm", kernel=kernel_names[1], achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
                 frac=ach / PEAK_HBM_GBS, traffic=pmc_traffic("k_mf_funnel_loop" if "funnel" in kernel_names[1] else "k_mf_sgd_loop"),
                 algorithmic_bytes_per_launch=100 * cost["bytes"],
-                estimates_per_launch=100, avg_launch_us=msl * 1e3, single_call=single), {"mf_fused_main": ms1, "mf_loop_per_estimate": msl / 100}
+                estimates_per_launch=100, avg_launch_us=msl * 1e3, single_call=single,
+                hbm_equivalent=True,
+                note=("HBM-EQUIVALENT of SURVEY 8d's algorithmic bytes: Z and G never exist in memory (the launch moves `traffic.bytes_per_launch`, "
+                      "about 1 % of them), so this fraction is not bounded by 1 -- the kernel is vector-ALU bound (Philox + Box-Muller + ten wave "
+                      "reductions per lane and estimate)")), {"mf_fused_main": ms1, "mf_loop_per_estimate": msl / 100}
 
 
 def fr_roofline(ctx, params, cost, w, reps=300):
