@@ -245,6 +245,16 @@ class MiviContext:
     def estimate_gradient_n(self, params, idx0, count, value, grad):
         self._chk(self.lib.mivi_estimate_gradient_n(self.h, self._p(params), idx0, int(count), self._p(value), self._p(grad)))
 
+    def estimate_gradient_each(self, params, idx0, count, values=None, grads=None, want_grads=True):
+        """Every estimate of the batch idx0 .. idx0 + count - 1 at the same parameters (mivi_estimate_gradient_each):
+        values T[count], grads (count, params_len) -- row i is bitwise mivi_estimate_gradient(idx0 + i)."""
+        p = self.to_device(params)
+        values = self.empty(int(count)) if values is None else values
+        if grads is None and want_grads:
+            grads = self.empty(int(count) * self.params_len)
+        self._chk(self.lib.mivi_estimate_gradient_each(self.h, self._p(p), idx0, int(count), self._p(values), self._p(grads) if grads is not None else None))
+        return values, (grads.view(int(count), self.params_len) if grads is not None else None)
+
     def estimate_objective(self, params, idx, n_samples=0, entropy=-1, value=None):
         p = self.to_device(params)
         value = self.empty(1) if value is None else value

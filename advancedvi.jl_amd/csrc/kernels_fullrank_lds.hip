@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "device_common.h"
+#include "fr_elem.h"
 #include "optim_rules.h"
 #include "stl_dinv.h"
 
@@ -122,17 +123,7 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
       for (int k2 = 1; k2 < KW; ++k2) v += *(const f32x4 *)(Cs + (k2 * BN + n) * LDC + i4);
       f32x4 o;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (gj > gi + c) {
-          o[c] = 0.f;
-        } else if (pow2M && gj != gi + c) {
-          o[c] = -v[c] * invMf;   // (a power-of-two sample count: the f32 product is exact, i.e. the f64 route's result without its conversions)
-        } else {
-          double x = -(double)v[c] * invM;
-          if (gj == gi + c) x -= direct / (double)cjj;
-          o[c] = (float)x;
-        }
-      }
+      for (int c = 0; c < 4; ++c) o[c] = vjp_elem(v[c], gi + c, gj, pow2M, invMf, invM, direct, cjj);   // (fr_elem.h: shared with the batch kernels)
       if (!fused) {
         if (!MIVI_KNOCKED(a, 256)) store16_wt(dst + pi, o);
       } else {
@@ -176,7 +167,7 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
     if (a.out.partials_mode) {
       ((float *)a.out.partials)[gr] = (float)sm;
     } else {
-      const float g = (float)(-sm * invM);
+      const float g = dmu_elem(sm, invM);
       if (FUSED && a.upd.rule >= 0) {
         float *pp = (float *)a.upd.params;
         float x;
@@ -884,9 +875,9 @@ __device__ __forceinline__ void fr_prod32_body(const Prod32Args &a) {
 #pragma unroll
     for (int k2 = 1; k2 < NW; ++k2) v += *(const f32x4 *)(Cs + (k2 * 32 + en) * LDC + ei4);   // fixed order
     if (a.mode == R_DENSE_G) {
-      const f32x4 g = -v;
+      f32x4 g;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) ell += 0.5f * rr[c] * g[c];
+      for (int c = 0; c < 4; ++c) g[c] = dense_target_elem(v[c], rr[c], ell);
       store16_wt(a.W + (size_t)gm * d + gi, g);
     } else {
       const f32x4 z = mu + v;
@@ -894,11 +885,7 @@ __device__ __forceinline__ void fr_prod32_body(const Prod32Args &a) {
       if (a.mode == R_DIAG) {
         f32x4 wv;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float u = (z[c] - tm[c]) * tis[c];
-          ell += -0.5f * u * u;
-          wv[c] = -u * tis[c];
-        }
+        for (int c = 0; c < 4; ++c) wv[c] = diag_target_elem(z[c], tm[c], tis[c], ell);   // (fr_elem.h: shared with the batch kernels)
         store16_wt(a.W + (size_t)gm * d + gi, wv);
       } else if (a.mode == R_DENSE_R) {
         const f32x4 rz = z - tm;
@@ -1117,11 +1104,7 @@ __global__ __launch_bounds__(512) void k_fr_prod32q(Prod32Multi m) {
       if (mode == R_DIAG) {
         f32x4 wv;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float u = (z[c] - tm[c]) * tis[c];
-          ell += -0.5f * u * u;
-          wv[c] = -u * tis[c];
-        }
+        for (int c = 0; c < 4; ++c) wv[c] = diag_target_elem(z[c], tm[c], tis[c], ell);
         store16_wt(a.W + (size_t)gm * d + gi, wv);
       } else if (mode == R_DENSE_R) {
         const f32x4 rz = z - tm;
@@ -1352,9 +1335,9 @@ __global__ __launch_bounds__(512) void k_fr_prod64(Prod32Args a) {
 #pragma unroll
     for (int k2 = 1; k2 < KW; ++k2) v += *(const f32x4 *)(Cs + (k2 * BN + n) * LDC + ei4);   // fixed order
     if (a.mode == R_DENSE_G) {
-      const f32x4 g = -v;
+      f32x4 g;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) ell += 0.5f * rr[u][c] * g[c];
+      for (int c = 0; c < 4; ++c) g[c] = dense_target_elem(v[c], rr[u][c], ell);
       store16_wt(a.W + (size_t)gm * d + gi, g);
     } else {
       const f32x4 z = mu + v;
@@ -1362,11 +1345,7 @@ __global__ __launch_bounds__(512) void k_fr_prod64(Prod32Args a) {
       if (a.mode == R_DIAG) {
         f32x4 wv;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float uu = (z[c] - tm[c]) * tis[c];
-          ell += -0.5f * uu * uu;
-          wv[c] = -uu * tis[c];
-        }
+        for (int c = 0; c < 4; ++c) wv[c] = diag_target_elem(z[c], tm[c], tis[c], ell);
         store16_wt(a.W + (size_t)gm * d + gi, wv);
       } else if (a.mode == R_DENSE_R) {
         const f32x4 rz = z - tm;

@@ -172,6 +172,15 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
                     &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_P2, &c->dist_ring[0], &c->dist_ring[1], &c->dist_ring[2], &c->dist_ring[3], &c->dist_ring[4], &c->dist_ring[5], &c->p2p_scratch, &c->dist_S, &c->dist_F, &c->p2p_tab, &c->p2p_ctr, &c->lds_tabV, &c->lds_tabV64, &c->lds_tabS, &c->lds_tabSt, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
+  {
+    DevBuf *fbb[] = {&c->fb.eps, &c->fb.W, &c->fb.ell, &c->fb.he, &c->fb.ld, &c->fb.grads, &c->fb.values};
+    for (DevBuf *b : fbb)
+      if (b->p) (void)hipFree(b->p);
+    for (auto &tb : c->fb.tab) {
+      if (tb.prod.p) (void)hipFree(tb.prod.p);
+      if (tb.vjp.p) (void)hipFree(tb.vjp.p);
+    }
+  }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
@@ -1756,9 +1765,109 @@ static mivi_status_t ensure_kids(mivi_ctx *c, int lanes) {
   return MIVI_OK;
 }
 
+// ---- third-generation batch engine (kernels_fullrank_batch.hip) -------------------------------------------------------------------------
+// `count` estimates at the same parameters as steps of up to fb_lanes_max() LANES: a step is four launches (eps, product + target, VJP,
+// values) that cover all of its lanes.  No child contexts, no forked graph: a lane's buffers are base + lane * stride.
+static int fb_lanes_max() {   // MIVI_FB_LANES: estimates per step (A/B; default 32)
+  static const int v = getenv("MIVI_FB_LANES") ? atoi(getenv("MIVI_FB_LANES")) : 32;
+  return v < 1 ? 1 : (v > 256 ? 256 : v);
+}
+static bool fb_route(const mivi_ctx *c, const void *params, const void *grad_last, const void *grads_all) {
+  return !c->is_child && c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && !c->bij_on && !c->idx_src && !c->dbg &&
+         c->target == TGT_DIAG_GAUSS && c->cfg.entropy != MIVI_ENT_STL && c->cfg.entropy != MIVI_ENT_STL_ZERO_GRAD &&
+         fb_shape_ok(c, c->cfg.n_mc) && ((uintptr_t)params & 15) == 0 && ((uintptr_t)grad_last & 15) == 0 && ((uintptr_t)grads_all & 15) == 0;
+}
+// value_last / grad_last: the batch's LAST estimate (mivi_estimate_gradient_n's contract), or nullptr; values_all T[count] / grads_all
+// T[count * params_len]: every estimate's (mivi_estimate_gradient_each), or nullptr (lane scratch)
+static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, int count, void *value_last, void *grad_last, void *values_all,
+                              void *grads_all) {
+  mivi_status_t s;
+  const int M = c->cfg.n_mc, d = c->cfg.d;
+  if ((s = ensure_work(c, M))) return s;
+  const int Lmax = fb_lanes_max();
+  const int steps = (count + Lmax - 1) / Lmax, L = (count + steps - 1) / steps, Llast = count - (steps - 1) * L;
+  const size_t plen = (size_t)mivi_params_len(c);
+  FbTables &t = c->fb;
+  if (t.cap_L < L || t.cap_M != M) {
+    invalidate_graph(c);
+    if ((s = ensure(c, t.eps, (size_t)L * c->dP * M * 4, false)) || (s = ensure(c, t.W, (size_t)L * d * M * 4, false)) ||
+        (s = ensure(c, t.ell, (size_t)L * (d / 32) * (M / 32) * sizeof(double), false)) ||
+        (s = ensure(c, t.he, (size_t)L * (d / 64) * (M / 32) * sizeof(double), false)) ||
+        (s = ensure(c, t.ld, 2 * (size_t)(d / 32) * sizeof(double) + 64, false)) || (s = ensure(c, t.values, (size_t)L * 4 + 64, false)))
+      return s;
+    t.grads.bytes = 0;   // (re-zeroed: the lanes' scratch gradients rely on exact zeros above the diagonal that no kernel writes)
+    if ((s = ensure(c, t.grads, (size_t)L * plen * 4, true))) return s;
+    t.cap_L = L;
+    t.cap_M = M;
+  }
+  const FbTab *tabF = fb_prepare(c, M, L), *tabL = Llast != L ? fb_prepare(c, M, Llast) : tabF;
+  if (Llast != L) tabF = fb_prepare(c, M, L);   // (both resident: the second call may have evicted nothing, but re-resolve the pointer)
+  if (!tabF || !tabL) return fail(c, MIVI_ERR_HIP, "batch engine: work table allocation failed");
+  auto issue = [&](bool counter) {
+    for (int st = 0; st < steps; ++st) {
+      FbStep fs{};
+      fs.params = params;
+      fs.M = M;
+      fs.L = st == steps - 1 ? Llast : L;
+      fs.tab = st == steps - 1 ? tabL : tabF;
+      fs.rng = rng_of(c, counter ? (uint64_t)st * L : idx0 + (uint64_t)st * L);
+      fs.rng.idx_ptr = counter ? (const uint64_t *)c->d_idx.p : nullptr;
+      if (grads_all) { fs.grads = (char *)grads_all + (size_t)st * L * plen * 4; fs.grad_stride = (long long)plen; fs.write_upper = 1; }
+      else { fs.grads = t.grads.p; fs.grad_stride = (long long)plen; fs.write_upper = 0; }
+      if (values_all) { fs.values = (char *)values_all + (size_t)st * L * 4; fs.value_stride = 1; }
+      else { fs.values = t.values.p; fs.value_stride = 1; }
+      fs.lane_last = -1;
+      if (st == steps - 1 && (value_last || grad_last)) { fs.lane_last = Llast - 1; fs.grad_last = grad_last; fs.value_last = value_last; }
+      fb_launch_step(c, fs);
+    }
+  };
+  static const int graph_steps = getenv("MIVI_FB_GRAPH_STEPS") ? atoi(getenv("MIVI_FB_GRAPH_STEPS")) : 2;   // batches of fewer steps are issued eagerly
+  if (steps < graph_steps) {
+    issue(false);
+    HIPCHK(c, hipGetLastError());
+    return MIVI_OK;
+  }
+  GraphCache &g = c->graph;
+  if (!(g.exec && g.kind == 4 && g.count == count && g.params == params && g.value == value_last && g.grad == grad_last && g.aux0 == values_all &&
+        g.aux1 == grads_all)) {
+    invalidate_graph(c);
+    hipGraph_t graph = nullptr;
+    hipStream_t saved;
+    if ((s = begin_capture(c, &saved))) return s;
+    issue(true);
+    hipLaunchKernelGGL(k_bump_u64, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, (uint64_t)count);
+    hipError_t e = end_capture(c, saved, &graph);
+    HIPCHK(c, e);
+    HIPCHK(c, hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    g.kind = 4; g.count = count; g.params = params; g.value = value_last; g.grad = grad_last; g.aux0 = values_all; g.aux1 = grads_all;
+  }
+  if (!(c->d_idx_valid && c->d_idx_expect == idx0))
+    hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, idx0, 0ull, 1);
+  HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
+  c->d_idx_valid = true;
+  c->d_idx_expect = idx0 + (uint64_t)count;
+  return MIVI_OK;
+}
+
+mivi_status_t mivi_estimate_gradient_each(mivi_ctx_t *c, const void *params, uint64_t idx0, int32_t count, void *values, void *grads) {
+  if (!c || !params || !values || count <= 0) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  if (c->target == TGT_NONE) return fail(c, MIVI_ERR_NO_TARGET, "no target set");
+  if (fb_route(c, params, nullptr, grads)) return fb_batch(c, params, idx0, count, nullptr, nullptr, values, grads);
+  // every other configuration: the single calls, one after the other (results are those of mivi_estimate_gradient by definition)
+  const size_t plen = (size_t)mivi_params_len(c);
+  mivi_status_t s = MIVI_OK;
+  for (int i = 0; i < count && s == MIVI_OK; ++i)
+    s = run_estimate(c, params, rng_of(c, idx0 + (uint64_t)i), c->cfg.n_mc, 1,
+                     final_out(c, (char *)values + (size_t)i * c->esize, grads ? (void *)((char *)grads + (size_t)i * plen * c->esize) : c->tmp_out.p));
+  return s;
+}
+
 mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64_t idx0, int32_t count, void *value, void *grad) {
   if (!c || !params || !value || !grad || count <= 0) return MIVI_ERR_BAD_ARG;
   (void)hipSetDevice(c->cfg.device);
+  if (count >= 2 && fb_route(c, params, grad, nullptr) && graph_capturable(c)) return fb_batch(c, params, idx0, count, value, grad, nullptr, nullptr);
   // Several interleaved chains pay when an estimate is a short chain of latency-bound launches (the second-generation full-rank
   // kernels at the BASELINE sizes: two launches of 6-8 us that leave most CUs idle half of the time).  One chain otherwise.
   int lanes = 1;

@@ -187,6 +187,29 @@ struct DevBuf {
   size_t bytes = 0;
 };
 
+// third-generation batch engine (kernels_fullrank_batch.hip): work tables per lane count, per-lane work buffers (base + lane * stride)
+struct FbTab {
+  DevBuf prod, vjp;
+  int n_prod = 0, n_vjp = 0, L = 0, M = 0;
+};
+struct FbTables {
+  FbTab tab[4];                           // per lane count (the full step's, the last shorter step's, other batch lengths'), round robin
+  int next_tab = 0;
+  DevBuf eps, W, ell, he, ld, grads, values;
+  int cap_L = 0, cap_M = 0;
+};
+struct FbStep {
+  const void *params;
+  int M, L;
+  RngArgs rng;                            // lane l draws estimate rng_index(rng) + l
+  void *grads; long long grad_stride;     // lane l's gradient (elements)
+  void *values; long long value_stride;
+  void *grad_last, *value_last;           // lane_last writes these instead (nullptr: none)
+  int lane_last;
+  int write_upper;                        // lanes write the exact zeros above the diagonal (0: their buffers hold them already)
+  const FbTab *tab;
+};
+
 struct GraphCache {
   hipGraphExec_t exec = nullptr;
   int count = 0;
@@ -307,6 +330,7 @@ struct mivi_ctx {
   int dP = 0, MP = 0;
 
   mivi::GraphCache graph;
+  mivi::FbTables fb;   // batch engine buffers (mivi_estimate_gradient_n / _each on the third-generation route)
 
   // Interleaved chains (mivi_estimate_gradient_n, full-rank + Gaussian targets): estimates at fixed parameters are independent, so a
   // batch is dealt round-robin onto `1 + n_kids` chains -- this context and child contexts with their own work buffers and streams --
@@ -403,6 +427,11 @@ bool lds_stein_ok(const mivi_ctx *c, int M);
 void launch_lds_stein_outer(mivi_ctx *c, int M, void *A, double *gsum, int first, double scale, double n, void *grad, void *logpi,
                             const ValueJob *self);
 void invalidate_graph(mivi_ctx *c);            // mivi_api.hip: drop the cached hipGraphExec and the eps speculation
+
+// kernels_fullrank_batch.hip (f32, diagonal-Gaussian target, d % 128 == 0, M % 128 == 0): L estimates at the same parameters per launch
+bool fb_shape_ok(const mivi_ctx *c, int M);
+const FbTab *fb_prepare(mivi_ctx *c, int M, int L);   // work tables for L lanes (nullptr: allocation failed)
+void fb_launch_step(mivi_ctx *c, const FbStep &s);
 
 // kernels_stl.hip (f32, d in {256, 512, 1024, 2048}, M % 32 == 0)
 bool stl2_shape_ok(const mivi_ctx *c, int M);

@@ -172,6 +172,13 @@ mivi_status_t mivi_estimate_gradient_host(mivi_ctx_t *ctx, const void *params_ho
  * diagonal-Gaussian target (rows independent): all `count` estimates run inside one launch-free kernel instead. */
 mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx0,
                                        int32_t count, void *value_dev, void *grad_dev);
+/* The same batch with EVERY estimate's result kept: values_dev T[count] <- -elbo of estimate estimate_idx0 + i;
+ * grads_dev T[count * params_len] <- its gradient (row i), or NULL when only the values are wanted.  What a caller of
+ * estimate_objective / estimate_gradient! at fixed parameters wants from many estimates -- monitoring with many samples
+ * (test/algorithms/klminrepgraddescent.jl:36), a gradient averaged over several estimates
+ * (src/algorithms/repgradelbo.jl:151-177 called `count` times on one q).  Estimate i is bitwise mivi_estimate_gradient(estimate_idx0 + i). */
+mivi_status_t mivi_estimate_gradient_each(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx0,
+                                          int32_t count, void *values_dev, void *grads_dev);
 
 /* estimate_objective(rng, obj::RepGradELBO, q, prob; n_samples): src/algorithms/repgradelbo.jl:112-118;
  * `entropy` override mirrors the algorithm-level wrapper src/algorithms/common.jl:29-38 (default there:

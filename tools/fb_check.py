@@ -1,0 +1,112 @@
+#!/usr/bin/env python
+"""Developer check of the third-generation batch engine (csrc/kernels_fullrank_batch.hip): every estimate of a batch against the single
+calls (bitwise) and the timing of batched calls at the north-star shape.  `python tools/fb_check.py [parity] [time]`."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import advancedvi_jl_amd as avi  # noqa: E402
+from tests.helpers import SEED, make_family, make_problem  # noqa: E402
+
+
+def parity(shapes=((128, 128), (256, 128), (384, 256), (1024, 256)), counts=(1, 2, 3, 7, 20, 33, 52), ents=(0, 2)):
+    bad = 0
+    for d, M in shapes:
+        for ent in ents:
+            rng = np.random.default_rng(100 + d + M)
+            q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
+            prob, _ = make_problem(rng, "diag", d, np.float32)
+            params, _ = avi.destructure(q)
+            ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
+            ctx.set_problem(prob)
+            ref = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
+            ref.set_problem(prob)
+            p, pr = ctx.to_device(params), ref.to_device(params)
+            idx = 5
+            for n in counts:
+                vals, grads = ctx.estimate_gradient_each(p, idx, n)
+                ctx.synchronize()
+                vals, grads = vals.cpu().numpy(), grads.cpu().numpy()
+                for i in range(n):
+                    v1, g1 = ref.estimate_gradient(pr, idx + i)
+                    v1, g1 = float(v1.item()), g1.cpu().numpy()
+                    okv = float(vals[i]) == v1
+                    okg = np.array_equal(grads[i], g1)
+                    if not (okv and okg):
+                        bad += 1
+                        dm = np.abs(grads[i][:d] - g1[:d]).max()
+                        G, G1 = grads[i][d:].reshape(d, d), g1[d:].reshape(d, d)   # [col][row]
+                        dc = np.abs(G - G1)
+                        nz = np.argwhere(dc > 0)
+                        print(f"MISMATCH d={d} M={M} ent={ent} n={n} i={i}: value {vals[i]!r} vs {v1!r}; dmu max {dm:.3e}; dC max {dc.max():.3e} "
+                              f"rel {dc.max() / max(np.abs(G1).max(), 1e-30):.3e}, {len(nz)} entries, first (col,row) {nz[:4].tolist()}; "
+                              f"upper nonzero {int((np.triu(G.T, 1) != 0).sum())}")
+                        if bad > 12:
+                            return bad
+                # the _n entry: last estimate only
+                v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+                g.fill_(float("nan"))
+                ctx.estimate_gradient_n(p, idx, n, v, g)
+                ctx.synchronize()
+                v1, g1 = ref.estimate_gradient(pr, idx + n - 1)
+                if not (float(v.item()) == float(v1.item()) and np.array_equal(g.cpu().numpy(), g1.cpu().numpy())):
+                    bad += 1
+                    print(f"MISMATCH (_n) d={d} M={M} ent={ent} n={n}: {float(v.item())!r} vs {float(v1.item())!r}, "
+                          f"grad max diff {np.nanmax(np.abs(g.cpu().numpy() - g1.cpu().numpy())):.3e}, nan {int(np.isnan(g.cpu().numpy()).sum())}")
+                idx += n + 1
+            ctx.close()
+            ref.close()
+            print(f"parity d={d} M={M} ent={ent}: done, mismatches so far {bad}", flush=True)
+    return bad
+
+
+def timing(d=1024, M=256, counts=(20, 100), reps=200):
+    import torch
+    rng = np.random.default_rng(1)
+    q = avi.FullRankGaussian(np.zeros(d, np.float32), np.eye(d, dtype=np.float32))
+    prob = avi.DiagNormalProblem(np.full(d, 5.0, np.float32), np.ones(d, np.float32))
+    params, _ = avi.destructure(q)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+        ctx.set_problem(prob)
+        p = ctx.to_device(params)
+        v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+        for n in counts:
+            idx = 0
+            for _ in range(20):
+                ctx.estimate_gradient_n(p, idx, n, v, g)
+                idx += n
+            stream.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                ctx.estimate_gradient_n(p, idx, n, v, g)
+                idx += n
+            stream.synchronize()
+            dt = time.perf_counter() - t0
+            # isolated calls (the driver's protocol: one call, device-wide synchronize)
+            iso = []
+            for _ in range(30):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                ctx.estimate_gradient_n(p, idx, n, v, g)
+                torch.cuda.synchronize()
+                iso.append(time.perf_counter() - t1)
+                idx += n
+            iso.sort()
+            print(f"timing n={n}: back-to-back {dt / reps / n * 1e6:.3f} us/estimate ({n * reps / dt:.0f} est/s); isolated median "
+                  f"{iso[len(iso) // 2] / n * 1e6:.3f} us/estimate, min {iso[0] / n * 1e6:.3f}", flush=True)
+        ctx.close()
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["parity", "time"]
+    if "parity" in what:
+        b = parity()
+        print("PARITY", "OK" if b == 0 else f"FAILED ({b})")
+    if "time" in what:
+        timing()
