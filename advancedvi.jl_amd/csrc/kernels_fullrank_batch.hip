@@ -8,24 +8,29 @@
 // averaged gradients, the bench's step) are independent, and L of them are ONE matrix product each way:
 //   product   [Z_1 .. Z_L] = mu + tril(C) [eps_1 .. eps_L]            1024 x (256 L) x 1024 (triangular) at the north star
 //   VJP       dC_l = tril(W_l eps_l'),  l = 1 .. L                    L products 1024 x 1024 (lower) x 256
-// The second generation gives every 32 x 32 tile of ONE estimate a workgroup whose waves split K (latency-bound launches, every operand
-// element split into its bf16 pieces by every tile that uses it: 20 vector instructions per MFMA).  Here the launch is shaped like the
-// large product it is:
-//   * a workgroup owns a (64 WGM) x (64 WGN) output tile (128 x 128), a wave a 64 x 64 part of it (2 x 2 MFMA tiles: every operand
-//     fragment is split into bf16 pieces once for two tiles, 7 vector instructions per MFMA) over the WHOLE K range;
-//   * operands are staged through LDS once per workgroup (LDS-DMA, 1 KiB pieces, two stages: the DMA of sub-stage t + 1 runs under the
-//     MFMAs of t), one barrier per 32-k sub-stage;
-//   * no cross-wave reduction: the epilogue works on a wave's own accumulators (transposed through a wave-private LDS image so that
-//     stores are whole 128-byte lines);
+// The second generation gives every 32 x 32 tile of ONE estimate a workgroup whose waves split K: latency-bound launches, and every
+// operand element is split into its three bf16 pieces by every tile that uses it (20 vector instructions per MFMA: the vector ALU is the
+// busiest unit).  Here the launches are shaped like the large products they are, and the split is done ONCE, by whoever produces an operand:
+//   * OPERAND PLANES.  Every operand lives in memory as its exact three-way bf16 split (hi / mid / lo planes, 6 bytes per element) in
+//     MFMA-FRAGMENT ORDER: a fragment = 32 rows x 16 k of one operand = 3 planes x 64 lanes x 16 bytes, lane (row = lane % 32,
+//     h = lane / 32) holding the eight k slots k = 16 g + 8 (e / 4) + 4 h + e % 4 -- the slot assignment of the second-generation kernels.
+//     tril(C) is laid out once per call (k_fb_cplanes, diagonal blocks already masked), eps by its generator in both orientations
+//     (k_fb_eps: rows as k for the product, samples as k for the VJP), W by the product's epilogue.  A main loop is then
+//     LDS-DMA (1 KiB pieces) -> ds_read_b128 -> six MFMAs per fragment pair: no vector arithmetic at all.
+//   * a workgroup owns a 128 x 128 output tile, a wave a 64 x 64 part of it (2 x 2 MFMA tiles) over the WHOLE K range; operands are
+//     staged once per workgroup in a three-slot LDS ring of 16-k stages (the DMA of stage g + 2 is in flight under the MFMAs of g),
+//     one barrier per stage; no cross-wave reduction: the epilogue works on a wave's own accumulators (transposed through a
+//     wave-private LDS image so that stores are whole 128-byte lines);
 //   * the launch covers every lane (estimate) of the step: per-lane buffers are base + lane * stride, the work table names (lane, tile).
 // BIT-IDENTICAL to the one-estimate kernels (k_fr_prod32 / k_fr_vjp32): those cut a tile's K range into runs (one per wave: eight for the
 // product, four for the VJP), every run an MFMA chain from zero, the runs summed in wave order.  A wave here walks the same runs one after
 // the other -- chain accumulator `acc`, folded into `tot` at every run boundary (tot = tot + acc: the same f32 additions in the same
-// order) -- with the same k-slot assignment inside every MFMA and the same per-element epilogue arithmetic (fr_elem.h), the same wave
-// sums behind every ell partial and the same slots for them.  So "a batch's estimates are bitwise the single calls'" holds by construction
-// (tests/test_gpu_batches.py).
+// order) -- on the same bf16 pieces (the same split arithmetic, applied by the producer instead of the consumer) in the same k slots,
+// with the same per-element epilogue arithmetic (fr_elem.h), the same wave sums behind every ell partial and the same slots for them.
+// So "a batch's estimates are bitwise the single calls'" holds by construction (tests/test_gpu_batches.py, tests/test_gpu_each.py).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "device_common.h"
@@ -38,15 +43,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
-#define FB_GLDS16(gptr, lptr)                                                                              \
+// LDS-DMA of 16 bytes per lane; the instruction's immediate offset moves BOTH addresses (global: vaddr + off, LDS: M0 + off + 16 lane):
+// the three planes of a fragment are 1 KiB apart in memory and in the ring, so a stage's three pieces share one pointer and one M0
+#define FB_GLDS16(gptr, lptr, off)                                                                         \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                 \
-                                   (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+                                   (__attribute__((address_space(3))) void *)(lptr), 16, off, 0)
 
-__device__ __forceinline__ void fb_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Waits as BUILTINS (the compiler's wait-count bookkeeping sees them: behind an inline-asm wait it does not know that the fragments read
+// one iteration ago have arrived and puts its own lgkmcnt(0) -- which also waits for the reads just issued for the NEXT group -- in front
+// of the MFMAs), the barrier itself as asm with a memory clobber (nothing moves across it).
+template <int N>
+__device__ __forceinline__ void fb_wait_vm() {
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void fb_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+  asm volatile("s_barrier" ::: "memory");
+}
 
 // exact three-way bf16 split of eight f32 values (kernels_fullrank_lds.hip split3_bf16: the same pieces)
-__device__ __forceinline__ void fb_split3(const float *x, bf16x8 &hi, bf16x8 &mid, bf16x8 &lo) {
-  u32x4v uh, um, ul;
+__device__ __forceinline__ void fb_split3(const float *x, u32x4v &uh, u32x4v &um, u32x4v &ul) {
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const float a = x[2 * p], b = x[2 * p + 1];
@@ -58,14 +75,19 @@ __device__ __forceinline__ void fb_split3(const float *x, bf16x8 &hi, bf16x8 &mi
     um[p] = __builtin_amdgcn_perm(rbb, rab, 0x07060302u);
     ul[p] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), 0x07060302u);
   }
-  hi = __builtin_bit_cast(bf16x8, uh);
-  mid = __builtin_bit_cast(bf16x8, um);
-  lo = __builtin_bit_cast(bf16x8, ul);
+}
+// the f32 value behind slot e of a lane's three plane vectors: hi + mid + lo, exact (the pieces do not overlap)
+__device__ __forceinline__ float fb_unsplit(const u32x4v &uh, const u32x4v &um, const u32x4v &ul, int e) {
+  const int p = e >> 1;
+  const unsigned hh = (e & 1) ? (uh[p] & 0xFFFF0000u) : (uh[p] << 16), mm = (e & 1) ? (um[p] & 0xFFFF0000u) : (um[p] << 16),
+                 ll = (e & 1) ? (ul[p] & 0xFFFF0000u) : (ul[p] << 16);
+  return (__builtin_bit_cast(float, hh) + __builtin_bit_cast(float, mm)) + __builtin_bit_cast(float, ll);
 }
 
-// the six products of one 32 x 32 x 16 block, smallest terms first (mfma_bf16x3's order)
-__device__ __forceinline__ void fb_mfma6(const bf16x8 &ah, const bf16x8 &am, const bf16x8 &al, const bf16x8 &bh, const bf16x8 &bm,
-                                         const bf16x8 &bl, f32x16 &c) {
+// the six products of one 32 x 32 x 16 block, smallest terms first (mfma_bf16x3's order); planes as three 16-byte vectors
+__device__ __forceinline__ void fb_mfma6(const u32x4v *a, const u32x4v *b, f32x16 &c) {   // a[0..2] = hi, mid, lo
+  const bf16x8 ah = __builtin_bit_cast(bf16x8, a[0]), am = __builtin_bit_cast(bf16x8, a[1]), al = __builtin_bit_cast(bf16x8, a[2]);
+  const bf16x8 bh = __builtin_bit_cast(bf16x8, b[0]), bm = __builtin_bit_cast(bf16x8, b[1]), bl = __builtin_bit_cast(bf16x8, b[2]);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, c, 0, 0, 0);
@@ -74,14 +96,38 @@ __device__ __forceinline__ void fb_mfma6(const bf16x8 &ah, const bf16x8 &am, con
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
 }
 
+// A wave's operands of one 16-k group: two A fragments (its two 32-row blocks) and WJ B fragments (its 32-column blocks), three planes each
+template <int WJ>
+struct FbFrags {
+  u32x4v A[2][3], B[WJ][3];
+};
+__device__ __forceinline__ f32x16 fb_mma(const u32x4v &a, const u32x4v &b, const f32x16 &c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// the 12 WJ MFMAs of a group, the 2 WJ accumulators' chains interleaved (a dependent MFMA issues 2 WJ slots behind its predecessor); per
+// accumulator the order is mfma_bf16x3's: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi  (planes: 0 hi, 1 mid, 2 lo)
+template <int WJ>
+__device__ __forceinline__ void fb_group(const FbFrags<WJ> &F, f32x16 (&acc)[2][WJ]) {
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+  for (int p = 0; p < 6; ++p)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < WJ; ++j) acc[i][j] = fb_mma(F.A[i][PA[p]], F.B[j][PB[p]], acc[i][j]);
+}
+
+constexpr int kFrag = 768;   // a fragment blob in 4-byte words: 3 planes x 64 lanes x 16 bytes
+
 struct FbArgs {
-  int d, M, dP, L;
+  int d, M, L;
   const float *params;            // [mu; vec C]
   const float *t_mean, *t_istd;   // diagonal-Gaussian target
-  float *eps;                     // lane l: eps + l * eps_stride, eps[i + m * dP]
-  long long eps_stride;
-  float *W;                       // lane l: W + l * W_stride, W[i + m * d]
-  long long W_stride;
+  unsigned *CA;                   // planes of tril(C): fragment (rb32, kg), kg <= 2 rb32 + 1, at (rb32 (d / 16) + kg) kFrag
+  unsigned *epsP;                 // lane l: epsP + l * plane_stride; fragment (mb32, kg = row group) at (mb32 (d / 16) + kg) kFrag
+  unsigned *epsV;                 // lane l: epsV + l * plane_stride; fragment (jb32, mg = sample group) at (jb32 (M / 16) + mg) kFrag
+  unsigned *WV;                   // lane l: WV + l * plane_stride; fragment (rb32, mg) at (rb32 (M / 16) + mg) kFrag
+  long long plane_stride;         // words per lane = d M / 512 * kFrag
   double *ell_part;               // lane l: ell_part + l * ell_stride; slots = k_fr_prod32's workgroup indices
   long long ell_stride;
   double *he_part;                // lane l: he_part + l * he_stride
@@ -94,179 +140,306 @@ struct FbArgs {
   long long grad_stride;
   float *values;                  // lane l: values + l * value_stride
   long long value_stride;
-  float *grad_last, *value_last;  // lane L_last writes these instead (nullptr: every lane writes grads / values)
+  float *grad_last, *value_last;  // lane_last writes these instead (nullptr: every lane writes grads / values)
   int lane_last;
   int write_upper;                // 1: every lane writes the exact zeros above the diagonal; 0: only lane_last does (the others' buffers hold them already)
   int ent_kind, M_total;
   int *status;
   double ell_const;
-  // eps draws
   RngArgs rng;                    // lane l draws estimate rng_index(rng) + l
+  int knock;                      // developer knock-outs (-DMIVI_DEV builds only: tools/ubench_fb.hip)
+  long long *dbg;                 // developer timeline (-DMIVI_DEV): per workgroup {hw id | xcc << 32, start, main loop done, end}
 };
+#ifdef MIVI_DEV
+#define FB_STAMP(a, slot) do { if ((a).dbg && threadIdx.x == 0 && blockIdx.x == 0 && ((slot) == 1 || (slot) == 2)) (a).dbg[8 * 4096 + (slot)] = (long long)clock64(); \
+  if ((a).dbg && threadIdx.x == 0) (a).dbg[(size_t)blockIdx.x * 8 + (slot)] = (slot) ? (long long)wall_clock64() : \
+  (long long)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32)); } while (0)
+#else
+#define FB_STAMP(a, slot) do { } while (0)
+#endif
 
 // -----------------------------------------------------------------------------------------------------------------
-// k_fb_eps: eps of L estimates, the blocks of the product kernels' riders (64 rows x 32 columns, one Philox block per thread) -- the
-// same stream, the same layout and the same he_part partials as k_eps_m / the riders of k_fr_prod32.  blockIdx.y = lane.
+// k_fb_cplanes: tril(C) as operand planes, one wave per fragment (rb32, kg): lane (row, h) reads its eight k slots (coalesced over the
+// 32 rows), zeroes the entries above the diagonal, splits, stores 3 x 16 bytes.  Once per call: the parameters are fixed inside it.
 // -----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
-  __shared__ double red[8];
-  const int tid = threadIdx.x, eb = blockIdx.x, l = blockIdx.y, d = a.d, nrb6 = d >> 6;
-  const int ri = (eb % nrb6) * 64 + 4 * (tid & 15), rm = (eb / nrb6) * 32 + (tid >> 4);
-  float e[4];
-  eps_block<float>(a.rng.seed, rng_index(a.rng) + (uint64_t)l, (uint64_t)(a.rng.m_offset + rm) * (uint64_t)(d >> 2) + (uint64_t)(ri >> 2), e);
-  const f32x4 ev = {e[0], e[1], e[2], e[3]};
-  store16_wt(a.eps + (size_t)l * a.eps_stride + (size_t)rm * a.dP + ri, ev);
-  const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
-  const double sh = block_sum_nodrain_f32<512>(he, red);
-  if (tid == 0) a.he_part[(size_t)l * a.he_stride + eb] = sh;
+__global__ __launch_bounds__(256) void k_fb_cplanes(FbArgs a) {
+  const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int d = a.d, ng = d >> 4;
+  const int rb = f / ng, kg = f % ng;
+  if (rb >= (d >> 5) || kg > 2 * rb + 3) return;   // (the two groups behind the diagonal block: zero fragments -- a wave of k_fb_prod walks the
+  const int row = 32 * rb + l31;                   //  K range of its SECOND row block with both, the first one's chain then adds exact zeros)
+  const float *C = a.params + d;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 16 * kg + 8 * (e >> 2) + 4 * h + (e & 3);
+    const float v = C[(size_t)k * d + row];
+    x[e] = k > row ? 0.f : v;
+  }
+  u32x4v uh, um, ul;
+  fb_split3(x, uh, um, ul);
+  unsigned *dst = a.CA + (size_t)f * kFrag + 4 * lane;
+  store16_wt(dst, uh);
+  store16_wt(dst + 256, um);
+  store16_wt(dst + 512, ul);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// k_fb_prod: W_l = grad log pi(mu + tril(C) eps_l) + ell partials, for every lane l of the step.
-// Work item = (lane, rb, cb): rows [BM rb, BM rb + BM) of columns [BN cb, BN cb + BN) of lane l; K = 32 (last 32-row block index + 1).
-// LDS stage (32 k): A panel as BM / 32 blocks [32 k][32 rows] (k_fr_prod32's image), B panel [BN columns][32 k] with XOR-swizzled
-// 16-byte chunks (k_fr_prod32's image).  Sub-stage t of a 32-row block r32: active for t <= r32, diagonal mask at t == r32.
-// Run boundaries of row block r32 (nst = r32 + 1 sub-stages): t_beg(w) = (w nst) >> 3, w = 1 .. 7 -- k_fr_prod32's eight runs.
+// k_fb_eps: eps of L estimates as operand planes in both orientations.  Draws: the blocks of the product kernels' riders (64 rows x 32
+// columns, one Philox block per thread: the same stream and the same he_part partials as k_eps_m / the riders of k_fr_prod32); the block's
+// 64 x 32 values go through an LDS tile, threads 0..255 then assemble the four product fragments (column = row of the B operand, k = rows
+// 16 ig ..), threads 256..511 the four VJP fragments (row j, k = samples 16 mg ..).  blockIdx.y = lane.
 // -----------------------------------------------------------------------------------------------------------------
-template <int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void k_fb_prod(FbArgs a) {
-  constexpr int NW = WGM * WGN, BM = 64 * WGM, BN = 64 * WGN, LDC = 36;
-  constexpr int A_F = BM * 32, B_F = BN * 32, STAGE_F = A_F + B_F;
-  constexpr int PPA = (BM / 8) / NW, PPB = (BN / 8) / NW;   // 1 KiB pieces per wave and stage
-  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces per wave");
-  constexpr int EPI_F = NW * 32 * LDC;
-  constexpr int MAIN_F = 2 * STAGE_F > EPI_F ? 2 * STAGE_F : EPI_F;
-  __shared__ __attribute__((aligned(16))) float lds[MAIN_F + 3 * BM];
-  float *vec = lds + MAIN_F;   // mu, target mean, target 1 / std of the tile's rows
+__global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
+  __shared__ double red[8];
+  __shared__ float E[32 * 65];   // E[m][i], leading dimension 65
+  const int tid = threadIdx.x, eb = blockIdx.x, l = blockIdx.y, d = a.d, nrb6 = d >> 6;
+  const int R64 = eb % nrb6, c32 = eb / nrb6;
+  const int q = tid & 15, c = tid >> 4;
+  const int ri = R64 * 64 + 4 * q, rm = c32 * 32 + c;
+  float e[4];
+  eps_block<float>(a.rng.seed, rng_index(a.rng) + (uint64_t)l, (uint64_t)(a.rng.m_offset + rm) * (uint64_t)(d >> 2) + (uint64_t)(ri >> 2), e);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) E[c * 65 + 4 * q + r] = e[r];
+  const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
+  const double sh = block_sum_nodrain_f32<512>(he, red);   // (its barriers also publish the tile)
+  if (tid == 0) a.he_part[(size_t)l * a.he_stride + eb] = sh;
+  const int lane = tid & 63, l31 = lane & 31, h = lane >> 5, f = (tid >> 6) & 3;
+  float x[8];
+  unsigned *dst;
+  if (tid < 256) {   // product fragment (mb32 = c32, kg = 4 R64 + f): lane = column l31, slots = rows 16 f + ..
+#pragma unroll
+    for (int s = 0; s < 8; ++s) x[s] = E[l31 * 65 + 16 * f + 8 * (s >> 2) + 4 * h + (s & 3)];
+    dst = a.epsP + (size_t)l * a.plane_stride + ((size_t)c32 * (d >> 4) + 4 * R64 + f) * kFrag;
+  } else {           // VJP fragment (jb32 = 2 R64 + f / 2, mg = 2 c32 + f % 2): lane = row l31, slots = samples 16 (f % 2) + ..
+    const int jb = f >> 1, mg = f & 1;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) x[s] = E[(16 * mg + 8 * (s >> 2) + 4 * h + (s & 3)) * 65 + 32 * jb + l31];
+    dst = a.epsV + (size_t)l * a.plane_stride + ((size_t)(2 * R64 + jb) * (a.M >> 4) + 2 * c32 + mg) * kFrag;
+  }
+  u32x4v uh, um, ul;
+  fb_split3(x, uh, um, ul);
+  dst += 4 * lane;
+  store16_wt(dst, uh);
+  store16_wt(dst + 256, um);
+  store16_wt(dst + 512, ul);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// The two products share a staging scheme: a 128 x 128 tile, four waves (2 x 2), 16-k stages of 24 KiB (A: four fragments, B: four
+// fragments, three planes each) in a three-slot LDS ring.  Piece pc of a stage (1 KiB): pc < 12: A fragment pc / 3, plane pc % 3; else B.
+// Wave w issues pieces 6 w .. 6 w + 5: always six requests per wave and stage, so the vmcnt accounting is a compile-time constant.
+// -----------------------------------------------------------------------------------------------------------------
+constexpr int kStageW = 24 * 256;   // words per stage
+constexpr int kRing = 4;            // LDS ring slots (96 KiB: ONE workgroup per CU): three stages in flight behind the one being read;
+                                    // the main loops are unrolled by kRing, so every slot address is a compile-time constant
+// Wave layout of a 128 x 128 tile, WJ = 32-column blocks per wave: 8 / WJ waves = 2 (row halves of 64) x 4 / WJ (column parts of 32 WJ).
+//   WJ = 2: four waves (one per SIMD, up to 512 registers each), a wave owns 64 x 64: 48 KiB of LDS reads per group and workgroup
+//   WJ = 1: eight waves (two per SIMD), a wave owns 64 x 32: 72 KiB of LDS reads per group -- the LDS read port then paces the loop
+template <int WJ>
+__device__ __forceinline__ void fb_read_frags(const unsigned *lds, int slot, int wm, int wn, int lane, FbFrags<WJ> &F) {
+  const unsigned *cur = lds + slot * kStageW + 4 * lane;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) F.A[i][p] = *(const u32x4v *)(cur + ((2 * wm + i) * 3 + p) * 256);
+#pragma unroll
+  for (int j = 0; j < WJ; ++j)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) F.B[j][p] = *(const u32x4v *)(cur + (12 + (WJ * wn + j) * 3 + p) * 256);
+}
+// The issue order inside one iteration's straight-line block {3 WJ LDS-DMA requests, 9 WJ.. fragment reads of the next group, 12 WJ MFMAs}:
+// every wave of the workgroup leaves the barrier at the same moment, and with the reads first (where the scheduler puts loads) all of
+// them queue on the LDS port before the first MFMA of anybody issues -- the matrix pipe idles for the length of that burst.  One memory
+// operation behind every MFMA instead: the pipe starts at once, the reads trickle in under it.
+template <int WJ>
+__device__ __forceinline__ void fb_sched_interleave() {
+  constexpr int NM = 12 * WJ, ND = 6 + 3 * WJ, NV = 3 * WJ;
+#pragma unroll
+  for (int k = 0; k < NM; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  // one MFMA
+    if (k < ND) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      // one LDS read
+    else if (k < ND + NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            // one LDS-DMA request
+  }
+}
+using FbI0 = std::integral_constant<int, 0>;
+using FbI1 = std::integral_constant<int, 1>;
+using FbI2 = std::integral_constant<int, 2>;
+using FbI3 = std::integral_constant<int, 3>;
+using FbT = std::true_type;
+using FbN = std::false_type;
+
+// -----------------------------------------------------------------------------------------------------------------
+// k_fb_prod: W_l = grad log pi(mu + tril(C) eps_l) as VJP operand planes + ell partials, for every lane l of the step.
+// Work item = (lane, rb, cb): rows [128 rb, +128) of columns [128 cb, +128) of lane l.  A 32-row block r32 has 2 (r32 + 1) groups;
+// k_fr_prod32's runs of a row block with nst sub-stages are chunks of ceil(nst / 8) sub-stages.
+// Software pipeline: iteration g computes on the fragments of stage g (already in registers) while the fragments of stage g + 1 are read
+// from LDS and the DMA of stage g + kRing is issued.  Per iteration: wait for the own pieces of stage g + 1, barrier (stage g + 1 has landed
+// for every wave; every wave has read stage g, whose slot stage g + kRing takes), issue, read, 12 WJ MFMAs.
+// -----------------------------------------------------------------------------------------------------------------
+// PF = 1: fragments of the next group prefetched into registers (ONE workgroup per CU, four ring slots); PF = 0: no register prefetch, three
+// ring slots, at most 128 registers: TWO workgroups per CU cover each other's barriers, read latencies, prologues and epilogues.
+template <int WJ, int PF>
+__global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbArgs a) {
+  constexpr int LDC = 36, NF = WJ, kPW = 3 * WJ;   // fragments / pieces this wave stages per group
+  constexpr int NR = PF ? kRing : 3;
+  __shared__ __attribute__((aligned(16))) unsigned lds[NR * kStageW + 3 * 128];
+  float *vec = reinterpret_cast<float *>(lds + NR * kStageW);   // mu, target mean, target 1 / std of the tile's rows
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w / WGN, wn = w % WGN;
+  const int wm = w / (4 / WJ), wn = w % (4 / WJ);
   const __attribute__((address_space(4))) int *wp = (const __attribute__((address_space(4))) int *)a.work + 4 * blockIdx.x;
   const int ln = wp[0], rc = wp[1], flags = wp[2];
   const int rb = rc & 0xffff, cb = rc >> 16;
-  const int d = a.d, dP = a.dP;
-  const int row0 = rb * BM, col0 = cb * BN;
-  const int R0 = row0 >> 5;                       // first 32-row block of the tile
-  const int T = R0 + BM / 32;                     // sub-stages of the workgroup (the last row block's K)
-  const float *A = a.params + d;                  // tril(C), A[row + k d]
-  const float *B = a.eps + (size_t)ln * a.eps_stride;
-  // row vectors of the epilogue
-  for (int i = tid; i < BM; i += 64 * NW) {
-    vec[i] = a.params[row0 + i];
-    vec[BM + i] = a.t_mean[row0 + i];
-    vec[2 * BM + i] = a.t_istd[row0 + i];
+  const int d = a.d, ng = d >> 4;
+  const int row0 = rb * 128, col0 = cb * 128;
+  const int R0 = row0 >> 5;               // first 32-row block of the tile
+  const int G = 2 * (R0 + 4);             // groups of the workgroup (the last row block's K)
+  if (tid < 128) {
+    vec[tid] = a.params[row0 + tid];
+    vec[128 + tid] = a.t_mean[row0 + tid];
+    vec[256 + tid] = a.t_istd[row0 + tid];
   }
-  // staging: this wave's pieces
-  const float *Ag[PPA];
-  int a_blk[PPA];
+  // this wave's NF fragments of a stage (fragment f of the stage: f < 4: A fragment f; else B fragment f - 4; three 1 KiB pieces each)
+  const unsigned *sp[NF];   // the stage the next issue takes
+  int gmax[NF];             // last group of the fragment that is ever read (tril(C): the diagonal block + two zero groups: clamped beyond)
 #pragma unroll
-  for (int i = 0; i < PPA; ++i) {
-    const int pa = w * PPA + i, ab = pa >> 2, kq = pa & 3;
-    a_blk[i] = ab;
-    Ag[i] = A + row0 + 32 * ab + 4 * (lane & 7) + (size_t)(8 * kq + (lane >> 3)) * d;
-  }
-  const float *Bg[PPB];
-#pragma unroll
-  for (int i = 0; i < PPB; ++i) {
-    const int n = 8 * (w * PPB + i) + (lane >> 3);
-    Bg[i] = B + (size_t)(col0 + n) * dP + 4 * ((lane & 7) ^ ((n >> 1) & 7));
-  }
-  auto issue = [&](int t, int s) {
-    float *dst = lds + s * STAGE_F;
-#pragma unroll
-    for (int i = 0; i < PPA; ++i) {
-      const int pa = w * PPA + i;
-      if (t <= R0 + a_blk[i]) FB_GLDS16(Ag[i] + (size_t)(32 * t) * d, dst + pa * 256);   // (blocks above the diagonal are never read)
+  for (int f = 0; f < NF; ++f) {
+    const int fs = NF * w + f, fr = fs & 3;
+    if (fs < 4) {
+      sp[f] = a.CA + ((size_t)(R0 + fr) * ng) * kFrag + 4 * lane;
+      gmax[f] = 2 * (R0 + fr) + 3 < G - 1 ? 2 * (R0 + fr) + 3 : G - 1;
+    } else {
+      sp[f] = a.epsP + (size_t)ln * a.plane_stride + ((size_t)((col0 >> 5) + fr) * ng) * kFrag + 4 * lane;
+      gmax[f] = G - 1;
     }
+  }
+  int gd = 0;               // the group the pointers stand at
+  auto issue = [&](int slot) {
 #pragma unroll
-    for (int i = 0; i < PPB; ++i) FB_GLDS16(Bg[i] + 32 * t, dst + A_F + (w * PPB + i) * 256);
+    for (int f = 0; f < NF; ++f) {
+      unsigned *dst = lds + slot * kStageW + (NF * w + f) * 768;
+      FB_GLDS16(sp[f], dst, 0);
+      FB_GLDS16(sp[f], dst, 1024);
+      FB_GLDS16(sp[f], dst, 2048);
+      sp[f] += gd < gmax[f] ? kFrag : 0;
+    }
+    ++gd;
   };
-  f32x16 acc[2][2], tot[2][2];
+  f32x16 acc[2][WJ], tot[2][WJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
   const int r32[2] = {R0 + 2 * wm, R0 + 2 * wm + 1};
-  int wnext[2] = {1, 1};   // next run boundary of each row half
+  // k_fr_prod32's runs are chunks of ceil(nst / 8) sub-stages -- the same chunk for this wave's two row blocks (nst = r32[1] and r32[1] + 1,
+  // the first odd): ONE fold schedule, every 2 rc groups
+  const int rc2 = 2 * ((r32[1] + 1 + 7) >> 3);
+  FB_STAMP(a, 0);
+  FB_STAMP(a, 1);
+  // A wave computes groups 0 .. Gw - 1 (its second row block's K range: a multiple of four groups) with BOTH row blocks, unconditionally:
+  // one straight MFMA block per group (a choice between a full and a half group per iteration made the compiler copy the accumulators
+  // behind every group, i.e. wait for the matrix pipe to drain).  The first row block ends two groups earlier: k_fb_cplanes laid two zero
+  // fragments behind its diagonal block, so its chain adds exact zeros there.
+  const int Gw = 2 * r32[1] + 2;
+  int gfold = rc2;   // the next run boundary (even: checked on even groups only)
+  auto compute = [&](auto S, int g, const FbFrags<WJ> &F) {   // S = g mod kRing
+    if (!MIVI_KNOCKED(a, 2)) fb_group<WJ>(F, acc);
+    if constexpr (PF) fb_sched_interleave<WJ>();
+    if constexpr ((decltype(S)::value & 1) == 1) {   // (behind the MFMAs: the block in front of them stays one basic block; S = -1: every group)
+      if (__builtin_expect(g + 1 == gfold, 0)) {     // a run ended with this group
+        gfold += rc2;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-    while (wnext[i] < 8 && ((wnext[i] * (r32[i] + 1)) >> 3) == 0) ++wnext[i];
-  const int b_swz = (l31 >> 1) & 7;
-  issue(0, 0);
-  for (int t = 0; t < T; ++t) {
-    fb_wait_vm0();
-    lds_barrier();   // sub-stage t has landed for every wave; every wave is done with the other stage
-    if (t + 1 < T) issue(t + 1, (t + 1) & 1);
-    const float *cur = lds + (t & 1) * STAGE_F;
-    bool act[2];
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      act[i] = t <= r32[i];
-      bool fold = false;
-      while (wnext[i] < 8 && ((wnext[i] * (r32[i] + 1)) >> 3) == t) { fold = true; ++wnext[i]; }
-      if (fold && act[i]) {   // a run of this row block ended before sub-stage t
+          for (int j = 0; j < WJ; ++j) {
+            tot[i][j] += acc[i][j];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          tot[i][j] += acc[i][j];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          }
+        asm volatile("" ::: "memory");
       }
     }
-    if (!act[1]) continue;   // (act[0] implies act[1]: r32[0] < r32[1])
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {   // B fragments: column 64 wn + 32 j + l31, k slots 8 (2 g + q) + 4 h + {0..3}
-        const float *bc = cur + A_F + (64 * wn + 32 * j + l31) * 32;
-        const f32x4 q0 = *(const f32x4 *)(bc + 4 * ((4 * g + h) ^ b_swz));
-        const f32x4 q1 = *(const f32x4 *)(bc + 4 * ((4 * g + 2 + h) ^ b_swz));
-        const float bv[8] = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-        fb_split3(bv, bh[j], bm[j], bl[j]);
+  };
+  // iteration g (S = g mod kRing): wait for the own pieces of stage g + 1, barrier, issue stage g + kRing into the slot of stage g, read the
+  // fragments of stage g + 1, compute stage g.  VM = stages that may stay in flight across the wait; CMP: this wave still has work.
+  auto step = [&](auto S, auto VM, auto ISS, auto CMP, int g, const FbFrags<WJ> &Fc, FbFrags<WJ> &Fn) {
+    constexpr int sl = decltype(S)::value;
+    fb_wait_vm<kPW * decltype(VM)::value>();
+    if (!MIVI_KNOCKED(a, 64)) fb_barrier();
+    if constexpr (decltype(ISS)::value) {
+      if (!MIVI_KNOCKED(a, 1)) issue(sl);
+    }
+    if constexpr (decltype(CMP)::value) {
+      if (!MIVI_KNOCKED(a, 32)) fb_read_frags<WJ>(lds, MIVI_KNOCKED(a, 4) ? 0 : (sl + 1) % kRing, wm, wn, lane, Fn);
+      compute(S, g, Fc);
+    }
+  };
+  if constexpr (PF) {
+  static_assert(kRing == 4, "the unrolled loops below are written for four slots");
+  issue(0); issue(1); issue(2); issue(3);   // (G >= 8)
+  fb_wait_vm<kPW * 3>();
+  fb_barrier();
+  FbFrags<WJ> F0, F1;
+  fb_read_frags<WJ>(lds, 0, wm, wn, lane, F0);
+  int g = 0;
+  for (; g + 4 < G; g += 4) {   // (G is a multiple of eight; Gw = G for the waves of the tile's lower half, G - 4 for the upper half's)
+    step(FbI0{}, FbI2{}, FbT{}, FbT{}, g, F0, F1);
+    step(FbI1{}, FbI2{}, FbT{}, FbT{}, g + 1, F1, F0);
+    step(FbI2{}, FbI2{}, FbT{}, FbT{}, g + 2, F0, F1);
+    step(FbI3{}, FbI2{}, FbT{}, FbT{}, g + 3, F1, F0);
+  }
+  if (g < Gw) {   // the last four groups: nothing left to request
+    step(FbI0{}, FbI2{}, FbN{}, FbT{}, g, F0, F1);
+    step(FbI1{}, FbI1{}, FbN{}, FbT{}, g + 1, F1, F0);
+    step(FbI2{}, FbI0{}, FbN{}, FbT{}, g + 2, F0, F1);
+    compute(FbI3{}, g + 3, F1);
+  } else {        // (the upper half's K range has ended: its waves only keep the barriers)
+    step(FbI0{}, FbI2{}, FbN{}, FbN{}, g, F0, F1);
+    step(FbI1{}, FbI1{}, FbN{}, FbN{}, g + 1, F1, F0);
+    step(FbI2{}, FbI0{}, FbN{}, FbN{}, g + 2, F0, F1);
+  }
+  } else {
+    // plain loop: wait for stage g, barrier, request stage g + 2 into the slot of stage g - 1, read, compute -- the other workgroup of the CU
+    // runs its MFMAs under this one's waits
+    issue(0); issue(1);
+    int slot = 0;
+    for (int g = 0; g < G; ++g) {
+      if (g + 1 < G) fb_wait_vm<kPW>();
+      else fb_wait_vm<0>();
+      if (!MIVI_KNOCKED(a, 64)) fb_barrier();
+      if (g + 2 < G && !MIVI_KNOCKED(a, 1)) issue(slot == 0 ? 2 : slot - 1);
+      if (g < Gw) {
+        FbFrags<WJ> F;
+        fb_read_frags<WJ>(lds, slot, wm, wn, lane, F);
+        compute(std::integral_constant<int, -1>{}, g, F);
       }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (!act[i]) continue;
-        const float *ac = cur + (2 * wm + i) * 1024 + l31;
-        float av[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) av[e] = ac[(8 * (2 * g + (e >> 2)) + 4 * h + (e & 3)) * 32];
-        if (t == r32[i]) {   // the diagonal block of tril(C): keep k <= row
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (8 * (2 * g + (e >> 2)) + 4 * h + (e & 3) > l31) av[e] = 0.f;
-        }
-        fb_split3(av, ah[i], am[i], al[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (!act[i]) continue;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) fb_mfma6(ah[i], am[i], al[i], bh[j], bm[j], bl[j], acc[i][j]);
-      }
+      slot = slot == 2 ? 0 : slot + 1;
     }
   }
-  // the last run of each row block
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) tot[i][j] += acc[i][j];
-  lds_barrier();   // every wave is done with the stages: LDS becomes the waves' private epilogue images
-  float *Cs = lds + w * (32 * LDC);
-  float *Wl = a.W + (size_t)ln * a.W_stride;
+    for (int j = 0; j < WJ; ++j) tot[i][j] += acc[i][j];   // the last run
+  fb_barrier();   // every wave is done with the ring: LDS becomes the waves' private epilogue images
+  FB_STAMP(a, 2);
+  if (MIVI_KNOCKED(a, 16)) { if (tot[0][0][0] == 123.f) a.ld_part[0] = tot[1][WJ - 1][3] + tot[0][0][2]; return; }
+  float *Cs = reinterpret_cast<float *>(lds) + w * (32 * LDC);
+  unsigned *WVl = a.WV + (size_t)ln * a.plane_stride;
   double *ellp = a.ell_part + (size_t)ln * a.ell_stride;
-  const int nrb = d >> 5, ncb = a.M >> 5;
+  const int nrb = d >> 5, ncb = a.M >> 5, nmg = a.M >> 4;
   const bool xcd_slots = (nrb & 3) == 0 && (ncb & 1) == 0;   // (k_fr_prod32's block -> tile map)
   const int ei4 = 4 * (lane & 7);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int lr = 64 * wm + 32 * i;   // row offset inside the tile
-    const f32x4 mu = *(const f32x4 *)(vec + lr + ei4), tm = *(const f32x4 *)(vec + BM + lr + ei4), tis = *(const f32x4 *)(vec + 2 * BM + lr + ei4);
+    const f32x4 mu = *(const f32x4 *)(vec + lr + ei4), tm = *(const f32x4 *)(vec + 128 + lr + ei4), tis = *(const f32x4 *)(vec + 256 + lr + ei4);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < WJ; ++j) {
+      const int cb32 = (col0 >> 5) + WJ * wn + j;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 v = {tot[i][j][4 * q], tot[i][j][4 * q + 1], tot[i][j][4 * q + 2], tot[i][j][4 * q + 3]};
@@ -282,21 +455,34 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_fb_prod(FbArgs a) {
         f32x4 wv;
 #pragma unroll
         for (int c = 0; c < 4; ++c) wv[c] = diag_target_elem(z[c], tm[c], tis[c], ell);
-        const int gi = row0 + lr + ei4, gm = col0 + 64 * wn + 32 * j + en;
-        store16_wt(Wl + (size_t)gm * d + gi, wv);
+        *(f32x4 *)(Cs + en * LDC + ei4) = wv;   // the image becomes W[m][i]
         const double sv = (double)wave_sum_f32(ell);
         s = p ? s + sv : sv;
       }
       s += 0.0;   // (k_fr_prod32 adds its four idle waves' zeros: -0.0 becomes +0.0 there)
       if (lane == 0) {
-        const int rbE = r32[i], cbE = (col0 + 64 * wn + 32 * j) >> 5, rE = nrb - 1 - rbE;
-        const int slot = xcd_slots ? ((rE & 3) + 4 * (cbE & 1)) + 8 * ((rE >> 2) * (ncb >> 1) + (cbE >> 1)) : rE * ncb + cbE;
+        const int rE = nrb - 1 - r32[i];
+        const int slot = xcd_slots ? ((rE & 3) + 4 * (cb32 & 1)) + 8 * ((rE >> 2) * (ncb >> 1) + (cb32 >> 1)) : rE * ncb + cb32;
         ellp[slot] = s;
+      }
+      // W as the VJP's A fragments (rb32 = r32[i], mg = 2 cb32 + g2): lane (row l31, h), slots = samples 16 g2 + 8 (e / 4) + 4 h + e % 4
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = Cs[(16 * g2 + 8 * (e >> 2) + 4 * h + (e & 3)) * LDC + l31];
+        u32x4v uh, um, ul;
+        fb_split3(x, uh, um, ul);
+        unsigned *dst = WVl + ((size_t)r32[i] * nmg + 2 * cb32 + g2) * kFrag + 4 * lane;
+        store16_wt(dst, uh);
+        store16_wt(dst + 256, um);
+        store16_wt(dst + 512, ul);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is read before the next tile overwrites it
     }
   }
-  if ((flags & 1) && wn == 0 && lane < 32) {   // log|det C| partials of this wave's two row blocks (one workgroup per row block class carries the flag)
+  FB_STAMP(a, 3);
+  if ((flags & 1) && wn == 0 && lane < 32) {   // log|det C| partials of this wave's two row blocks (lane 0's first column block carries the flag)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = 32 * r32[i] + lane;
@@ -312,150 +498,187 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_fb_prod(FbArgs a) {
 
 // -----------------------------------------------------------------------------------------------------------------
 // k_fb_vjp: dC_l = -(1/M) tril(W_l eps_l') - direct diag(1 / C_ii), dmu_l = -(1/M) W_l 1, for every lane l of the step.
-// Work item = (lane, rb, cb), cb <= rb: the BM x BN tile of the lower triangle; both operands MN-major ([32 k][32 rows] blocks).
-// k_fr_vjp32's four runs = the K quarters (M / 4 each); 32 x 32 sub-tiles strictly above the diagonal are skipped, the exact zeros
-// of the upper triangle are written as the mirror images of the strictly lower ones (lanes with the write_upper duty).
+// Work item = (lane, rb, cb), cb <= rb: the 128 x 128 tile of the lower triangle; K = M samples = M / 16 groups.
+// k_fr_vjp32's four runs = the K quarters; a wave whose sub-tiles all lie strictly above the diagonal only carries its share of the
+// staging, the exact zeros of the upper triangle are written as the mirror images of the strictly lower 32 x 32 blocks (lanes with the
+// write_upper duty).
 // -----------------------------------------------------------------------------------------------------------------
-template <int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void k_fb_vjp(FbArgs a) {
-  constexpr int NW = WGM * WGN, BM = 64 * WGM, BN = 64 * WGN, LDC = 36;
-  constexpr int A_F = BM * 32, B_F = BN * 32, STAGE_F = A_F + B_F;
-  constexpr int PPA = (BM / 8) / NW, PPB = (BN / 8) / NW;
-  static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "pieces per wave");
-  constexpr int EPI_F = NW * 32 * LDC;
-  constexpr int MAIN_F = 2 * STAGE_F > EPI_F ? 2 * STAGE_F : EPI_F;
-  __shared__ __attribute__((aligned(16))) float lds[MAIN_F];
+template <int WJ, int PF>
+__global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArgs a) {
+  constexpr int LDC = 36, NF = WJ, kPW = 3 * WJ;
+  constexpr int NR = PF ? kRing : 3;
+  __shared__ __attribute__((aligned(16))) unsigned lds[NR * kStageW];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w / WGN, wn = w % WGN;
+  const int wm = w / (4 / WJ), wn = w % (4 / WJ);
   const __attribute__((address_space(4))) int *wp = (const __attribute__((address_space(4))) int *)a.work + 4 * blockIdx.x;
   const int ln = wp[0], rc = wp[1];
   const int rb = rc & 0xffff, cb = rc >> 16;
-  const int d = a.d, dP = a.dP, M = a.M;
-  const int row0 = rb * BM, col0 = cb * BN;
-  const float *A = a.W + (size_t)ln * a.W_stride;      // W[row + m d]
-  const float *B = a.eps + (size_t)ln * a.eps_stride;  // eps[row + m dP]
+  const int d = a.d, M = a.M, nmg = M >> 4;
+  const int row0 = rb * 128, col0 = cb * 128;
   const bool last = ln == a.lane_last && a.grad_last;
   float *grad = last ? a.grad_last : a.grads + (size_t)ln * a.grad_stride;
   const bool upper = a.write_upper || last;
-  const int T = M >> 5, nsub = T >> 2;   // sub-stages; per K quarter
-  const float *Ag[PPA], *Bg[PPB];
+  const int G = nmg, gq = G >> 2;   // groups; per K quarter
+  const unsigned *sp[NF];           // the stage the next issue takes
 #pragma unroll
-  for (int i = 0; i < PPA; ++i) {
-    const int pa = w * PPA + i, ab = pa >> 2, kq = pa & 3;
-    Ag[i] = A + row0 + 32 * ab + 4 * (lane & 7) + (size_t)(8 * kq + (lane >> 3)) * d;
+  for (int f = 0; f < NF; ++f) {
+    const int fs = NF * w + f, fr = fs & 3;
+    sp[f] = (fs < 4 ? a.WV + (size_t)ln * a.plane_stride + ((size_t)((row0 >> 5) + fr) * nmg) * kFrag
+                    : a.epsV + (size_t)ln * a.plane_stride + ((size_t)((col0 >> 5) + fr) * nmg) * kFrag) + 4 * lane;
   }
+  auto issue = [&](int slot) {
 #pragma unroll
-  for (int i = 0; i < PPB; ++i) {
-    const int pb = w * PPB + i, bb = pb >> 2, kq = pb & 3;
-    Bg[i] = B + col0 + 32 * bb + 4 * (lane & 7) + (size_t)(8 * kq + (lane >> 3)) * dP;
-  }
-  auto issue = [&](int t, int s) {
-    float *dst = lds + s * STAGE_F;
-#pragma unroll
-    for (int i = 0; i < PPA; ++i) FB_GLDS16(Ag[i] + (size_t)(32 * t) * d, dst + (w * PPA + i) * 256);
-#pragma unroll
-    for (int i = 0; i < PPB; ++i) FB_GLDS16(Bg[i] + (size_t)(32 * t) * dP, dst + A_F + (w * PPB + i) * 256);
+    for (int f = 0; f < NF; ++f) {
+      unsigned *dst = lds + slot * kStageW + (NF * w + f) * 768;
+      FB_GLDS16(sp[f], dst, 0);
+      FB_GLDS16(sp[f], dst, 1024);
+      FB_GLDS16(sp[f], dst, 2048);
+      sp[f] += kFrag;
+    }
   };
-  // this wave's 32 x 32 sub-tiles: (ri, cj) = global 32-blocks; active iff cj <= ri
-  const int ri[2] = {(row0 >> 5) + 2 * wm, (row0 >> 5) + 2 * wm + 1}, cj[2] = {(col0 >> 5) + 2 * wn, (col0 >> 5) + 2 * wn + 1};
-  bool on[2][2];
+  // this wave's 32 x 32 sub-tiles: (ri[i], cj[j]) = global 32-blocks; stored iff cj <= ri
+  const int ri[2] = {(row0 >> 5) + 2 * wm, (row0 >> 5) + 2 * wm + 1};
+  int cj[WJ];
+#pragma unroll
+  for (int j = 0; j < WJ; ++j) cj[j] = (col0 >> 5) + WJ * wn + j;
+  const bool work = cj[0] <= ri[1];   // any sub-tile in the lower triangle
+  bool dg[2];                         // row block i meets the diagonal in this wave: d/dmu
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    dg[i] = false;
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) dg[i] = dg[i] || ri[i] == cj[j];
+  }
+  f32x16 acc[2][WJ], tot[2][WJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) on[i][j] = cj[j] <= ri[i];
-  const bool rowon[2] = {on[0][0] || on[0][1], on[1][0] || on[1][1]}, colon[2] = {on[0][0] || on[1][0], on[0][1] || on[1][1]};
-  const bool dg[2] = {(on[0][0] && ri[0] == cj[0]) || (on[0][1] && ri[0] == cj[1]), (on[1][0] && ri[1] == cj[0]) || (on[1][1] && ri[1] == cj[1])};   // row half i meets the diagonal here: d/dmu
-  f32x16 acc[2][2], tot[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
-  float rs[2][4];      // d/dmu: this lane's partial row sums of W, per row half and K quarter (k_fr_vjp32's rsum of wave q, half h)
+  float rs[2][4];      // d/dmu: this lane's partial row sums of W, per row block and K quarter (k_fr_vjp32's rsum of wave q, half h)
   float rcur[2] = {0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int q = 0; q < 4; ++q) rs[i][q] = 0.f;
-  issue(0, 0);
-  for (int t = 0; t < T; ++t) {
-    fb_wait_vm0();
-    lds_barrier();
-    if (t + 1 < T) issue(t + 1, (t + 1) & 1);
-    const float *cur = lds + (t & 1) * STAGE_F;
-    if (t > 0 && t % nsub == 0) {   // a K quarter ended
+  FB_STAMP(a, 0);
+  FB_STAMP(a, 1);
+  int gfold = gq;   // the next K-quarter boundary (gq is even: checked on even groups only)
+  // A wave with work computes ALL its sub-tiles in every group (one straight MFMA block: see k_fb_prod); a sub-tile strictly above the
+  // diagonal (diagonal tiles only) is simply not stored.
+  auto compute = [&](auto S, int g, const FbFrags<WJ> &F) {
+    if (!MIVI_KNOCKED(a, 2)) fb_group<WJ>(F, acc);
+    if constexpr (PF) fb_sched_interleave<WJ>();
+    if (__builtin_expect(dg[0] || dg[1], 0)) {   // (two waves of a diagonal tile; behind the MFMAs: the block in front of them stays one basic block)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (!on[i][j]) continue;
-          tot[i][j] += acc[i][j];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        }
-      const int q = t / nsub - 1;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq)
-          if (qq == q) rs[i][qq] = rcur[i];
-        rcur[i] = 0.f;
-      }
-    }
-    if (!rowon[0] && !rowon[1]) continue;
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        if (!rowon[i]) continue;
-        const float *ac = cur + (2 * wm + i) * 1024 + l31;
-        float av[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) av[e] = ac[(8 * (2 * g + (e >> 2)) + 4 * h + (e & 3)) * 32];
         if (dg[i]) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) rcur[i] += av[e];
+          for (int e = 0; e < 8; ++e) rcur[i] += fb_unsplit(F.A[i][0], F.A[i][1], F.A[i][2], e);
         }
-        fb_split3(av, ah[i], am[i], al[i]);
+    }
+    if constexpr ((decltype(S)::value & 1) == 1) {
+      if (__builtin_expect(g + 1 == gfold && g + 1 < G, 0)) {   // a K quarter (but the last) ended with this group
+        gfold += gq;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int j = 0; j < WJ; ++j) {
+            tot[i][j] += acc[i][j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+          }
+          rs[i][3] = rs[i][2]; rs[i][2] = rs[i][1]; rs[i][1] = rs[i][0]; rs[i][0] = rcur[i];   // (newest first: re-ordered at the end)
+          rcur[i] = 0.f;
+        }
+        asm volatile("" ::: "memory");
       }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (!colon[j]) continue;
-        const float *bc = cur + A_F + (2 * wn + j) * 1024 + l31;
-        float bv[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = bc[(8 * (2 * g + (e >> 2)) + 4 * h + (e & 3)) * 32];
-        fb_split3(bv, bh[j], bm[j], bl[j]);
+    }
+  };
+  auto step = [&](auto S, auto VM, auto ISS, auto CMP, int g, const FbFrags<WJ> &Fc, FbFrags<WJ> &Fn) {   // (as in k_fb_prod)
+    constexpr int sl = decltype(S)::value;
+    fb_wait_vm<kPW * decltype(VM)::value>();
+    if (!MIVI_KNOCKED(a, 64)) fb_barrier();
+    if constexpr (decltype(ISS)::value) {
+      if (!MIVI_KNOCKED(a, 1)) issue(sl);
+    }
+    if constexpr (decltype(CMP)::value) {
+      if (!MIVI_KNOCKED(a, 32)) fb_read_frags<WJ>(lds, MIVI_KNOCKED(a, 4) ? 0 : (sl + 1) % kRing, wm, wn, lane, Fn);
+      compute(S, g, Fc);
+    }
+  };
+  if constexpr (PF) {
+  static_assert(kRing == 4, "the unrolled loops below are written for four slots");
+  issue(0); issue(1); issue(2); issue(3);   // (G >= 8: M >= 128)
+  fb_wait_vm<kPW * 3>();
+  fb_barrier();
+  FbFrags<WJ> F0, F1;
+  fb_read_frags<WJ>(lds, 0, wm, wn, lane, F0);
+  if (work) {
+    int g = 0;
+    for (; g + 4 < G; g += 4) {   // (G is a multiple of 8)
+      step(FbI0{}, FbI2{}, FbT{}, FbT{}, g, F0, F1);
+      step(FbI1{}, FbI2{}, FbT{}, FbT{}, g + 1, F1, F0);
+      step(FbI2{}, FbI2{}, FbT{}, FbT{}, g + 2, F0, F1);
+      step(FbI3{}, FbI2{}, FbT{}, FbT{}, g + 3, F1, F0);
+    }
+    step(FbI0{}, FbI2{}, FbN{}, FbT{}, g, F0, F1);
+    step(FbI1{}, FbI1{}, FbN{}, FbT{}, g + 1, F1, F0);
+    step(FbI2{}, FbI0{}, FbN{}, FbT{}, g + 2, F0, F1);
+    compute(FbI3{}, g + 3, F1);
+  } else {      // a wave above the diagonal: it only carries its share of the staging
+    int g = 0;
+    for (; g + 4 < G; g += 4) {
+      step(FbI0{}, FbI2{}, FbT{}, FbN{}, g, F0, F1);
+      step(FbI1{}, FbI2{}, FbT{}, FbN{}, g + 1, F1, F0);
+      step(FbI2{}, FbI2{}, FbT{}, FbN{}, g + 2, F0, F1);
+      step(FbI3{}, FbI2{}, FbT{}, FbN{}, g + 3, F1, F0);
+    }
+    step(FbI0{}, FbI2{}, FbN{}, FbN{}, g, F0, F1);
+    step(FbI1{}, FbI1{}, FbN{}, FbN{}, g + 1, F1, F0);
+    step(FbI2{}, FbI0{}, FbN{}, FbN{}, g + 2, F0, F1);
+  }
+  } else {
+    issue(0); issue(1);   // (the plain loop of k_fb_prod<.., 0>)
+    int slot = 0;
+    for (int g = 0; g < G; ++g) {
+      if (g + 1 < G) fb_wait_vm<kPW>();
+      else fb_wait_vm<0>();
+      if (!MIVI_KNOCKED(a, 64)) fb_barrier();
+      if (g + 2 < G && !MIVI_KNOCKED(a, 1)) issue(slot == 0 ? 2 : slot - 1);
+      if (work) {
+        FbFrags<WJ> F;
+        fb_read_frags<WJ>(lds, slot, wm, wn, lane, F);
+        compute(std::integral_constant<int, -1>{}, g, F);
       }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          if (on[i][j]) fb_mfma6(ah[i], am[i], al[i], bh[j], bm[j], bl[j], acc[i][j]);
+      slot = slot == 2 ? 0 : slot + 1;
     }
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-      if (on[i][j]) tot[i][j] += acc[i][j];
-    rs[i][3] = rcur[i];
+    for (int j = 0; j < WJ; ++j) tot[i][j] += acc[i][j];
+    const float r3 = rcur[i], r2 = rs[i][0], r1 = rs[i][1], r0 = rs[i][2];   // quarters 3, 2, 1, 0
+    rs[i][0] = r0; rs[i][1] = r1; rs[i][2] = r2; rs[i][3] = r3;
   }
-  lds_barrier();
-  float *Cs = lds + w * (32 * LDC);
+  fb_barrier();
+  FB_STAMP(a, 2);
+  if (MIVI_KNOCKED(a, 16)) { if (tot[0][0][0] == 123.f) grad[0] = tot[1][WJ - 1][3] + tot[0][0][2]; return; }
+  float *Cs = reinterpret_cast<float *>(lds) + w * (32 * LDC);
   const double invM = 1.0 / (double)a.M_total;
   const bool pow2M = (a.M_total & (a.M_total - 1)) == 0;
   const float invMf = (float)invM;
   const double direct = direct_entropy_coeff(a.ent_kind);
   const int i4 = 4 * (lane & 7);
+  FB_STAMP(a, 4);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
+    if (i == 1) FB_STAMP(a, 5);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (!on[i][j]) continue;
+    for (int j = 0; j < WJ; ++j) {
+      if (cj[j] > ri[i]) continue;
       const bool diag = ri[i] == cj[j];
       const int rbase = 32 * ri[i], cbase = 32 * cj[j];
 #pragma unroll
@@ -471,9 +694,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_fb_vjp(FbArgs a) {
         if (diag && gj >= gi && gj < gi + 4) cjj = a.params[d + (size_t)gj * d + gj];
         const f32x4 v = *(const f32x4 *)(Cs + n * LDC + i4);
         f32x4 o;
+        if (!diag && pow2M) {   // strictly below the diagonal, power-of-two sample count: vjp_elem's f32 branch for all four (no per-element branches)
+          o = -v * invMf;
+        } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) o[c] = vjp_elem(v[c], gi + c, gj, pow2M, invMf, invM, direct, cjj);
-        store16_wt(grad + d + (size_t)gj * d + gi, o);
+          for (int c = 0; c < 4; ++c) o[c] = vjp_elem(v[c], gi + c, gj, pow2M, invMf, invM, direct, cjj);
+        }
+        if (!MIVI_KNOCKED(a, 8)) store16_wt(grad + d + (size_t)gj * d + gi, o);
       }
       if (!diag && upper) {   // the mirrored, strictly upper 32 x 32 block is structurally zero
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -497,6 +724,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void k_fb_vjp(FbArgs a) {
       if (lane < 32) grad[32 * ri[i] + lane] = dmu_elem(sm, invM);
     }
   }
+  FB_STAMP(a, 3);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -529,6 +757,8 @@ __global__ __launch_bounds__(256) void k_fb_value(FbArgs a) {
 // -----------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int kBM = 128, kBN = 128;
+constexpr int kWJ = 1;
+constexpr int kPFprod = 1, kPFvjp = 0;   // register prefetch + one workgroup per CU (product: its heaviest tile must own a CU) / two plain workgroups per CU (VJP: equal tiles)   // 32-column blocks per wave (k_fb_prod / k_fb_vjp): 2 = four waves of 64 x 64 per tile, 1 = eight waves of 64 x 32
 
 void fb_upload(DevBuf &b, const void *src, size_t bytes) {
   if (b.bytes < bytes || !b.p) {
@@ -542,9 +772,11 @@ void fb_upload(DevBuf &b, const void *src, size_t bytes) {
 
 bool fb_shape_ok(const mivi_ctx *c, int M) {
   static const bool off = getenv("MIVI_BATCH_GEN3") && atoi(getenv("MIVI_BATCH_GEN3")) == 0;   // A/B: the lane-batched second-generation kernels
-  return !off && c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && c->cfg.d % kBM == 0 && M % kBN == 0 && M % 128 == 0 &&
-         c->cfg.d >= kBM && c->cfg.d <= 32768;
+  return !off && c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && c->cfg.d % kBM == 0 && M % kBN == 0 && c->cfg.d >= kBM &&
+         c->cfg.d <= 2048 && M >= 128;   // (the run-boundary masks of k_fb_prod hold 64 sub-stages)
 }
+size_t fb_plane_words(const mivi_ctx *c, int M) { return (size_t)c->cfg.d * M / 512 * kFrag; }       // one lane's eps / W planes
+size_t fb_cplane_words(const mivi_ctx *c) { return (size_t)(c->cfg.d / 32) * (c->cfg.d / 16) * kFrag; }
 
 // work tables for L lanes: product tiles heaviest first, (lane, column block) panels dealt round-robin onto the XCDs (workgroup b runs on
 // XCD b % 8: a panel's eps columns stay in one L2); VJP tiles in lane order, cut into eight equal runs
@@ -607,34 +839,51 @@ const FbTab *fb_prepare(mivi_ctx *c, int M, int L) {
   return &t;
 }
 
-// one step of L estimates: eps -> product + target -> VJP -> values, on c->stream
-void fb_launch_step(mivi_ctx *c, const FbStep &s) {
+static FbArgs fb_args(mivi_ctx *c, const void *params, int M) {
   FbTables &t = c->fb;
-  const FbTab &tb = *s.tab;
-  const int d = c->cfg.d, M = s.M, L = s.L;
+  const int d = c->cfg.d;
   FbArgs a{};
-  a.d = d; a.M = M; a.dP = c->dP; a.L = L;
-  a.params = (const float *)s.params;
+  a.d = d; a.M = M;
+  a.params = (const float *)params;
   a.t_mean = (const float *)c->t_mean.p;
   a.t_istd = (const float *)c->t_istd.p;
-  a.eps = (float *)t.eps.p; a.eps_stride = (long long)c->dP * M;
-  a.W = (float *)t.W.p; a.W_stride = (long long)d * M;
+  a.CA = (unsigned *)t.CA.p;
+  a.epsP = (unsigned *)t.epsP.p;
+  a.epsV = (unsigned *)t.epsV.p;
+  a.WV = (unsigned *)t.WV.p;
+  a.plane_stride = (long long)fb_plane_words(c, M);
   a.ell_part = (double *)t.ell.p; a.ell_stride = (long long)(d / 32) * (M / 32);
   a.he_part = (double *)t.he.p; a.he_stride = (long long)(d / 64) * (M / 32);
   a.ld_part = (double *)t.ld.p;
+  a.ent_kind = c->cfg.entropy; a.M_total = c->M_total;
+  a.status = (int *)c->status.p;
+  a.ell_const = c->t_const;
+  return a;
+}
+
+// tril(C) as operand planes: once per call, before its steps
+void fb_launch_cplanes(mivi_ctx *c, const void *params, int M) {
+  FbArgs a = fb_args(c, params, M);
+  const int nf = (c->cfg.d / 32) * (c->cfg.d / 16);
+  hipLaunchKernelGGL(k_fb_cplanes, dim3((nf + 3) / 4), dim3(256), 0, c->stream, a);
+}
+
+// one step of L estimates: eps -> product + target -> VJP -> values, on c->stream
+void fb_launch_step(mivi_ctx *c, const FbStep &s) {
+  const FbTab &tb = *s.tab;
+  const int d = c->cfg.d, M = s.M, L = s.L;
+  FbArgs a = fb_args(c, s.params, M);
+  a.L = L;
   a.grads = (float *)s.grads; a.grad_stride = s.grad_stride;
   a.values = (float *)s.values; a.value_stride = s.value_stride;
   a.grad_last = (float *)s.grad_last; a.value_last = (float *)s.value_last; a.lane_last = s.lane_last;
   a.write_upper = s.write_upper;
-  a.ent_kind = c->cfg.entropy; a.M_total = c->M_total;
-  a.status = (int *)c->status.p;
-  a.ell_const = c->t_const;
   a.rng = s.rng;
   hipLaunchKernelGGL(k_fb_eps, dim3((d / 64) * (M / 32), L), dim3(512), 0, c->stream, a);
   a.work = (const int4 *)tb.prod.p; a.n_work = tb.n_prod;
-  hipLaunchKernelGGL((k_fb_prod<2, 2>), dim3(tb.n_prod), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL((k_fb_prod<kWJ, kPFprod>), dim3(tb.n_prod), dim3(512 / kWJ), 0, c->stream, a);
   a.work = (const int4 *)tb.vjp.p; a.n_work = tb.n_vjp;
-  hipLaunchKernelGGL((k_fb_vjp<2, 2>), dim3(tb.n_vjp), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp>), dim3(tb.n_vjp), dim3(512 / kWJ), 0, c->stream, a);
   hipLaunchKernelGGL(k_fb_value, dim3(L), dim3(256), 0, c->stream, a);
 }
 

@@ -778,7 +778,11 @@ __device__ __forceinline__ void fr_prod32_body(const Prod32Args &a) {
   }
   const int row0 = rb * 32, col0 = cb * 32;
   const int nst = (MODE == G_SAMPLE) ? rb + 1 : nrb;            // 32-k sub-stages of this tile
-  const int t_beg = (w * nst) / NW, t_end = ((w + 1) * nst) / NW;   // this wave's run
+  // this wave's run: chunks of c = ceil(nst / 8) sub-stages (the longest run is what the even split had; the last waves may stay idle).
+  // The boundaries are multiples of c, and c is the same for the row blocks 2 k and 2 k + 1: the batch kernels
+  // (kernels_fullrank_batch.hip), whose waves walk the runs of two row blocks one after the other, fold both at the same places.
+  const int rc = (nst + NW - 1) / NW;
+  const int t_beg = w * rc < nst ? w * rc : nst, t_end = (w + 1) * rc < nst ? (w + 1) * rc : nst;
 
   // epilogue operands that do not depend on the product: requested now, consumed after the MFMA chain
   const int ei4 = 4 * (tid & 7), en = (tid >> 3) & 31;   // threads 0..255: rows ei4..+3 of column en
@@ -962,9 +966,10 @@ __global__ __launch_bounds__(512) void k_fr_prod32q(Prod32Multi m) {
   const int col0 = cb * 32;
   int t_beg[2], t_end[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    t_beg[t] = (w * (rbT[t] + 1)) / NW;
-    t_end[t] = ((w + 1) * (rbT[t] + 1)) / NW;
+  for (int t = 0; t < 2; ++t) {   // (k_fr_prod32's runs: chunks of ceil(nst / 8) sub-stages)
+    const int nst = rbT[t] + 1, rc = (nst + NW - 1) / NW;
+    t_beg[t] = w * rc < nst ? w * rc : nst;
+    t_end[t] = (w + 1) * rc < nst ? (w + 1) * rc : nst;
   }
   // epilogue operands that do not depend on the product (threads 0..255: tile 0, 256..511: tile 1; rows ei4..+3 of column en)
   const int half = tid >> 8, t2 = tid & 255;

@@ -173,7 +173,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   {
-    DevBuf *fbb[] = {&c->fb.eps, &c->fb.W, &c->fb.ell, &c->fb.he, &c->fb.ld, &c->fb.grads, &c->fb.values};
+    DevBuf *fbb[] = {&c->fb.CA, &c->fb.epsP, &c->fb.epsV, &c->fb.WV, &c->fb.ell, &c->fb.he, &c->fb.ld, &c->fb.grads, &c->fb.values};
     for (DevBuf *b : fbb)
       if (b->p) (void)hipFree(b->p);
     for (auto &tb : c->fb.tab) {
@@ -1790,7 +1790,9 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
   FbTables &t = c->fb;
   if (t.cap_L < L || t.cap_M != M) {
     invalidate_graph(c);
-    if ((s = ensure(c, t.eps, (size_t)L * c->dP * M * 4, false)) || (s = ensure(c, t.W, (size_t)L * d * M * 4, false)) ||
+    const size_t pw = fb_plane_words(c, M) * 4;
+    if ((s = ensure(c, t.CA, fb_cplane_words(c) * 4, false)) || (s = ensure(c, t.epsP, (size_t)L * pw, false)) ||
+        (s = ensure(c, t.epsV, (size_t)L * pw, false)) || (s = ensure(c, t.WV, (size_t)L * pw, false)) ||
         (s = ensure(c, t.ell, (size_t)L * (d / 32) * (M / 32) * sizeof(double), false)) ||
         (s = ensure(c, t.he, (size_t)L * (d / 64) * (M / 32) * sizeof(double), false)) ||
         (s = ensure(c, t.ld, 2 * (size_t)(d / 32) * sizeof(double) + 64, false)) || (s = ensure(c, t.values, (size_t)L * 4 + 64, false)))
@@ -1804,6 +1806,7 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
   if (Llast != L) tabF = fb_prepare(c, M, L);   // (both resident: the second call may have evicted nothing, but re-resolve the pointer)
   if (!tabF || !tabL) return fail(c, MIVI_ERR_HIP, "batch engine: work table allocation failed");
   auto issue = [&](bool counter) {
+    fb_launch_cplanes(c, params, M);
     for (int st = 0; st < steps; ++st) {
       FbStep fs{};
       fs.params = params;

@@ -195,7 +195,7 @@ struct FbTab {
 struct FbTables {
   FbTab tab[4];                           // per lane count (the full step's, the last shorter step's, other batch lengths'), round robin
   int next_tab = 0;
-  DevBuf eps, W, ell, he, ld, grads, values;
+  DevBuf CA, epsP, epsV, WV, ell, he, ld, grads, values;   // operand planes (tril(C) once per call; eps in both orientations and W per lane)
   int cap_L = 0, cap_M = 0;
 };
 struct FbStep {
@@ -431,6 +431,9 @@ void invalidate_graph(mivi_ctx *c);            // mivi_api.hip: drop the cached 
 // kernels_fullrank_batch.hip (f32, diagonal-Gaussian target, d % 128 == 0, M % 128 == 0): L estimates at the same parameters per launch
 bool fb_shape_ok(const mivi_ctx *c, int M);
 const FbTab *fb_prepare(mivi_ctx *c, int M, int L);   // work tables for L lanes (nullptr: allocation failed)
+size_t fb_plane_words(const mivi_ctx *c, int M);      // 4-byte words of one lane's operand planes (eps in one orientation, W)
+size_t fb_cplane_words(const mivi_ctx *c);            // ... of tril(C)'s
+void fb_launch_cplanes(mivi_ctx *c, const void *params, int M);   // tril(C) -> operand planes (once per call)
 void fb_launch_step(mivi_ctx *c, const FbStep &s);
 
 // kernels_stl.hip (f32, d in {256, 512, 1024, 2048}, M % 32 == 0)
