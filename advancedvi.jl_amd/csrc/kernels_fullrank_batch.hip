@@ -162,9 +162,8 @@ struct FbArgs {
 // k_fb_cplanes: tril(C) as operand planes, one wave per fragment (rb32, kg): lane (row, h) reads its eight k slots (coalesced over the
 // 32 rows), zeroes the entries above the diagonal, splits, stores 3 x 16 bytes.  Once per call: the parameters are fixed inside it.
 // -----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fb_cplanes(FbArgs a) {
-  const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
-  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void fb_cplanes_frag(const FbArgs &a, int f, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
   const int d = a.d, ng = d >> 4;
   const int rb = f / ng, kg = f % ng;
   if (rb >= (d >> 5) || kg > 2 * rb + 3) return;   // (the two groups behind the diagonal block: zero fragments -- a wave of k_fb_prod walks the
@@ -184,6 +183,9 @@ __global__ __launch_bounds__(256) void k_fb_cplanes(FbArgs a) {
   store16_wt(dst + 256, um);
   store16_wt(dst + 512, ul);
 }
+__global__ __launch_bounds__(256) void k_fb_cplanes(FbArgs a) {   // (stand-alone form: tools/ubench_fb.hip)
+  fb_cplanes_frag(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
 
 // -----------------------------------------------------------------------------------------------------------------
 // k_fb_eps: eps of L estimates as operand planes in both orientations.  Draws: the blocks of the product kernels' riders (64 rows x 32
@@ -195,6 +197,10 @@ __global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
   __shared__ double red[8];
   __shared__ float E[32 * 65];   // E[m][i], leading dimension 65
   const int tid = threadIdx.x, eb = blockIdx.x, l = blockIdx.y, d = a.d, nrb6 = d >> 6;
+  if (l >= a.L) {   // riders of a call's first draw: tril(C) as operand planes (parameters only), eight fragments per workgroup
+    fb_cplanes_frag(a, (((int)blockIdx.y - a.L) * (int)gridDim.x + eb) * 8 + (tid >> 6), tid & 63);
+    return;
+  }
   const int R64 = eb % nrb6, c32 = eb / nrb6;
   const int q = tid & 15, c = tid >> 4;
   const int ri = R64 * 64 + 4 * q, rm = c32 * 32 + c;
@@ -497,6 +503,34 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
 }
 
 // -----------------------------------------------------------------------------------------------------------------
+// The objective value of lane l, by 256 threads (finalize_value_block: the single calls' assembly)
+// -----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fb_value_block(const FbArgs &a, int l, double *red) {
+  const int d = a.d;
+  ValueIn vin{};
+  vin.ell_const = a.ell_const;
+  vin.ell_part = a.ell_part + (size_t)l * a.ell_stride;
+  vin.n_ell_part = (d >> 5) * (a.M >> 5);
+  vin.he_part = a.he_part + (size_t)l * a.he_stride;
+  vin.n_he_part = (d >> 6) * (a.M >> 5);
+  vin.ld_part = a.ld_part;
+  vin.n_ld_part = d >> 5;
+  OutArgs out{};
+  const bool last = l == a.lane_last && a.value_last;
+  out.value = last ? a.value_last : a.values + (size_t)l * a.value_stride;
+  out.ent_kind = a.ent_kind;
+  out.M_total = a.M_total;
+  out.M_local = a.M;
+  out.status = a.status;
+  const float *pp = a.params;
+  finalize_value_block<float, 256, false>(d, vin, out, (int64_t)d + (int64_t)d * d, [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, red);
+}
+__global__ __launch_bounds__(256) void k_fb_value(FbArgs a) {   // (stand-alone form: tools/ubench_fb.hip)
+  __shared__ double red[4 * 4];
+  fb_value_block(a, blockIdx.x, red);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
 // k_fb_vjp: dC_l = -(1/M) tril(W_l eps_l') - direct diag(1 / C_ii), dmu_l = -(1/M) W_l 1, for every lane l of the step.
 // Work item = (lane, rb, cb), cb <= rb: the 128 x 128 tile of the lower triangle; K = M samples = M / 16 groups.
 // k_fr_vjp32's four runs = the K quarters; a wave whose sub-tiles all lie strictly above the diagonal only carries its share of the
@@ -511,6 +545,10 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w / (4 / WJ), wn = w % (4 / WJ);
+  if ((int)blockIdx.x >= a.n_work) {   // the objective values of the step's lanes: everything they sum is older than this launch
+    if (tid < 256) fb_value_block(a, (int)blockIdx.x - a.n_work, reinterpret_cast<double *>(lds));
+    return;
+  }
   const __attribute__((address_space(4))) int *wp = (const __attribute__((address_space(4))) int *)a.work + 4 * blockIdx.x;
   const int ln = wp[0], rc = wp[1];
   const int rb = rc & 0xffff, cb = rc >> 16;
@@ -728,31 +766,6 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// k_fb_value: the objective values of the step's lanes (one workgroup each: finalize_value_block, the single calls' assembly)
-// -----------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fb_value(FbArgs a) {
-  __shared__ double red[4 * 4];
-  const int l = blockIdx.x, d = a.d;
-  ValueIn vin{};
-  vin.ell_const = a.ell_const;
-  vin.ell_part = a.ell_part + (size_t)l * a.ell_stride;
-  vin.n_ell_part = (d >> 5) * (a.M >> 5);
-  vin.he_part = a.he_part + (size_t)l * a.he_stride;
-  vin.n_he_part = (d >> 6) * (a.M >> 5);
-  vin.ld_part = a.ld_part;
-  vin.n_ld_part = d >> 5;
-  OutArgs out{};
-  const bool last = l == a.lane_last && a.value_last;
-  out.value = last ? a.value_last : a.values + (size_t)l * a.value_stride;
-  out.ent_kind = a.ent_kind;
-  out.M_total = a.M_total;
-  out.M_local = a.M;
-  out.status = a.status;
-  const float *pp = a.params;
-  finalize_value_block<float, 256, false>(d, vin, out, (int64_t)d + (int64_t)d * d, [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, red);
-}
-
-// -----------------------------------------------------------------------------------------------------------------
 // Host side
 // -----------------------------------------------------------------------------------------------------------------
 namespace {
@@ -861,30 +874,29 @@ static FbArgs fb_args(mivi_ctx *c, const void *params, int M) {
   return a;
 }
 
-// tril(C) as operand planes: once per call, before its steps
-void fb_launch_cplanes(mivi_ctx *c, const void *params, int M) {
-  FbArgs a = fb_args(c, params, M);
-  const int nf = (c->cfg.d / 32) * (c->cfg.d / 16);
-  hipLaunchKernelGGL(k_fb_cplanes, dim3((nf + 3) / 4), dim3(256), 0, c->stream, a);
-}
-
-// one step of L estimates: eps -> product + target -> VJP -> values, on c->stream
-void fb_launch_step(mivi_ctx *c, const FbStep &s) {
-  const FbTab &tb = *s.tab;
+// the draws of a step (+ tril(C)'s planes as riders of a call's first draw) on `stream`
+void fb_launch_eps(mivi_ctx *c, const FbStep &s, bool with_cplanes, hipStream_t stream) {
   const int d = c->cfg.d, M = s.M, L = s.L;
   FbArgs a = fb_args(c, s.params, M);
   a.L = L;
+  a.rng = s.rng;
+  const int gx = (d / 64) * (M / 32), nf = (d / 32) * (d / 16);
+  const int ycp = with_cplanes ? (nf + 8 * gx - 1) / (8 * gx) : 0;
+  hipLaunchKernelGGL(k_fb_eps, dim3(gx, L + ycp), dim3(512), 0, stream, a);
+}
+// product + target -> VJP (+ the lanes' values as extra workgroups of the VJP launch) on `stream`
+void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream) {
+  const FbTab &tb = *s.tab;
+  FbArgs a = fb_args(c, s.params, s.M);
+  a.L = s.L;
   a.grads = (float *)s.grads; a.grad_stride = s.grad_stride;
   a.values = (float *)s.values; a.value_stride = s.value_stride;
   a.grad_last = (float *)s.grad_last; a.value_last = (float *)s.value_last; a.lane_last = s.lane_last;
   a.write_upper = s.write_upper;
-  a.rng = s.rng;
-  hipLaunchKernelGGL(k_fb_eps, dim3((d / 64) * (M / 32), L), dim3(512), 0, c->stream, a);
   a.work = (const int4 *)tb.prod.p; a.n_work = tb.n_prod;
-  hipLaunchKernelGGL((k_fb_prod<kWJ, kPFprod>), dim3(tb.n_prod), dim3(512 / kWJ), 0, c->stream, a);
+  hipLaunchKernelGGL((k_fb_prod<kWJ, kPFprod>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
   a.work = (const int4 *)tb.vjp.p; a.n_work = tb.n_vjp;
-  hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp>), dim3(tb.n_vjp), dim3(512 / kWJ), 0, c->stream, a);
-  hipLaunchKernelGGL(k_fb_value, dim3(L), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
 }
 
 }  // namespace mivi

@@ -180,6 +180,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
       if (tb.prod.p) (void)hipFree(tb.prod.p);
       if (tb.vjp.p) (void)hipFree(tb.vjp.p);
     }
+
   }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
@@ -1768,8 +1769,8 @@ static mivi_status_t ensure_kids(mivi_ctx *c, int lanes) {
 // ---- third-generation batch engine (kernels_fullrank_batch.hip) -------------------------------------------------------------------------
 // `count` estimates at the same parameters as steps of up to fb_lanes_max() LANES: a step is four launches (eps, product + target, VJP,
 // values) that cover all of its lanes.  No child contexts, no forked graph: a lane's buffers are base + lane * stride.
-static int fb_lanes_max() {   // MIVI_FB_LANES: estimates per step (A/B; default 32)
-  static const int v = getenv("MIVI_FB_LANES") ? atoi(getenv("MIVI_FB_LANES")) : 32;
+static int fb_lanes_max() {   // MIVI_FB_LANES: estimates per step (A/B; default 128: the triangular product is paced by its heaviest tile, 36 us for ANY lane count up to ~40, so long batches take few, wide steps; 100-estimate batches: 4.26 us per estimate with 25-lane steps, 3.92 with one step)
+  static const int v = getenv("MIVI_FB_LANES") ? atoi(getenv("MIVI_FB_LANES")) : 128;
   return v < 1 ? 1 : (v > 256 ? 256 : v);
 }
 static bool fb_route(const mivi_ctx *c, const void *params, const void *grad_last, const void *grads_all) {
@@ -1803,53 +1804,33 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
     t.cap_M = M;
   }
   const FbTab *tabF = fb_prepare(c, M, L), *tabL = Llast != L ? fb_prepare(c, M, Llast) : tabF;
-  if (Llast != L) tabF = fb_prepare(c, M, L);   // (both resident: the second call may have evicted nothing, but re-resolve the pointer)
+  if (Llast != L) tabF = fb_prepare(c, M, L);   // (re-resolve: four table slots, round robin)
   if (!tabF || !tabL) return fail(c, MIVI_ERR_HIP, "batch engine: work table allocation failed");
-  auto issue = [&](bool counter) {
-    fb_launch_cplanes(c, params, M);
-    for (int st = 0; st < steps; ++st) {
-      FbStep fs{};
-      fs.params = params;
-      fs.M = M;
-      fs.L = st == steps - 1 ? Llast : L;
-      fs.tab = st == steps - 1 ? tabL : tabF;
-      fs.rng = rng_of(c, counter ? (uint64_t)st * L : idx0 + (uint64_t)st * L);
-      fs.rng.idx_ptr = counter ? (const uint64_t *)c->d_idx.p : nullptr;
-      if (grads_all) { fs.grads = (char *)grads_all + (size_t)st * L * plen * 4; fs.grad_stride = (long long)plen; fs.write_upper = 1; }
-      else { fs.grads = t.grads.p; fs.grad_stride = (long long)plen; fs.write_upper = 0; }
-      if (values_all) { fs.values = (char *)values_all + (size_t)st * L * 4; fs.value_stride = 1; }
-      else { fs.values = t.values.p; fs.value_stride = 1; }
-      fs.lane_last = -1;
-      if (st == steps - 1 && (value_last || grad_last)) { fs.lane_last = Llast - 1; fs.grad_last = grad_last; fs.value_last = value_last; }
-      fb_launch_step(c, fs);
-    }
+  auto make_step = [&](int st) {
+    FbStep fs{};
+    fs.params = params;
+    fs.M = M;
+    fs.L = st == steps - 1 ? Llast : L;
+    fs.tab = st == steps - 1 ? tabL : tabF;
+    fs.rng = rng_of(c, idx0 + (uint64_t)st * L);
+    if (grads_all) { fs.grads = (char *)grads_all + (size_t)st * L * plen * 4; fs.grad_stride = (long long)plen; fs.write_upper = 1; }
+    else { fs.grads = t.grads.p; fs.grad_stride = (long long)plen; fs.write_upper = 0; }
+    if (values_all) { fs.values = (char *)values_all + (size_t)st * L * 4; fs.value_stride = 1; }
+    else { fs.values = t.values.p; fs.value_stride = 1; }
+    fs.lane_last = -1;
+    if (st == steps - 1 && (value_last || grad_last)) { fs.lane_last = Llast - 1; fs.grad_last = grad_last; fs.value_last = value_last; }
+    return fs;
   };
-  static const int graph_steps = getenv("MIVI_FB_GRAPH_STEPS") ? atoi(getenv("MIVI_FB_GRAPH_STEPS")) : 2;   // batches of fewer steps are issued eagerly
-  if (steps < graph_steps) {
-    issue(false);
-    HIPCHK(c, hipGetLastError());
-    return MIVI_OK;
+  // One stream, no graph: per step {draws (+ tril(C)'s planes as riders of the first) -> product -> VJP + values} = three launches for up to
+  // fb_lanes_max() estimates; the host is far ahead of the device.  (Measured and dropped: the batch as ONE hipGraph -- 4.45 against 4.26 us
+  // per estimate in 100-estimate batches -- and the draws of step s + 1 on a second graph branch beside the products of step s: the draws
+  // are bound by their 3 MB of plane writes per estimate and by the vector ALU, beside them the products ran 25 % longer: 4.58 us.)
+  for (int st = 0; st < steps; ++st) {
+    const FbStep fs = make_step(st);
+    fb_launch_eps(c, fs, st == 0, c->stream);
+    fb_launch_compute(c, fs, c->stream);
   }
-  GraphCache &g = c->graph;
-  if (!(g.exec && g.kind == 4 && g.count == count && g.params == params && g.value == value_last && g.grad == grad_last && g.aux0 == values_all &&
-        g.aux1 == grads_all)) {
-    invalidate_graph(c);
-    hipGraph_t graph = nullptr;
-    hipStream_t saved;
-    if ((s = begin_capture(c, &saved))) return s;
-    issue(true);
-    hipLaunchKernelGGL(k_bump_u64, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, (uint64_t)count);
-    hipError_t e = end_capture(c, saved, &graph);
-    HIPCHK(c, e);
-    HIPCHK(c, hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(graph);
-    g.kind = 4; g.count = count; g.params = params; g.value = value_last; g.grad = grad_last; g.aux0 = values_all; g.aux1 = grads_all;
-  }
-  if (!(c->d_idx_valid && c->d_idx_expect == idx0))
-    hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, idx0, 0ull, 1);
-  HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
-  c->d_idx_valid = true;
-  c->d_idx_expect = idx0 + (uint64_t)count;
+  HIPCHK(c, hipGetLastError());
   return MIVI_OK;
 }
 
@@ -1870,7 +1851,7 @@ mivi_status_t mivi_estimate_gradient_each(mivi_ctx_t *c, const void *params, uin
 mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *c, const void *params, uint64_t idx0, int32_t count, void *value, void *grad) {
   if (!c || !params || !value || !grad || count <= 0) return MIVI_ERR_BAD_ARG;
   (void)hipSetDevice(c->cfg.device);
-  if (count >= 2 && fb_route(c, params, grad, nullptr) && graph_capturable(c)) return fb_batch(c, params, idx0, count, value, grad, nullptr, nullptr);
+  if (count >= 2 && fb_route(c, params, grad, nullptr)) return fb_batch(c, params, idx0, count, value, grad, nullptr, nullptr);
   // Several interleaved chains pay when an estimate is a short chain of latency-bound launches (the second-generation full-rank
   // kernels at the BASELINE sizes: two launches of 6-8 us that leave most CUs idle half of the time).  One chain otherwise.
   int lanes = 1;

@@ -37,7 +37,7 @@ int main(int argc, char **argv) {
     FbArgs a = fb_args(&c, params, M);
     a.L = L; a.grads = (float *)t.grads.p; a.grad_stride = (long long)plen; a.values = (float *)t.values.p; a.value_stride = 1; a.lane_last = -1;
     a.rng.seed = 1; a.rng.idx_base = 5;
-    fb_launch_cplanes(&c, params, M);
+    hipLaunchKernelGGL(k_fb_cplanes, dim3(((d / 32) * (d / 16) + 3) / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_fb_eps, dim3((d / 64) * (M / 32), L), dim3(512), 0, st, a);
     for (int r = 0; r < 4000; ++r) {
       a.work = (const int4 *)tab->prod.p; a.n_work = tab->n_prod; hipLaunchKernelGGL((k_fb_prod<UB_WJ, UB_PF>), dim3(tab->n_prod), dim3(512 / UB_WJ), 0, st, a);
@@ -54,7 +54,7 @@ int main(int argc, char **argv) {
     FbArgs a = fb_args(&c, params, M);
     a.L = L; a.grads = (float *)t.grads.p; a.grad_stride = (long long)plen; a.values = (float *)t.values.p; a.value_stride = 1; a.lane_last = -1;
     a.rng.seed = 1; a.rng.idx_base = 5; a.knock = kn;
-    fb_launch_cplanes(&c, params, M);
+    hipLaunchKernelGGL(k_fb_cplanes, dim3(((d / 32) * (d / 16) + 3) / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_fb_eps, dim3((d / 64) * (M / 32), L), dim3(512), 0, st, a);
     float ms[4] = {0, 0, 0, 0};
     const int reps = 200;
