@@ -300,6 +300,13 @@ class MiviContext:
         self._chk(self.lib.mivi_profile_kernel(self.h, int(which), self._p(params), int(reps), C.byref(ms)))
         return ms.value
 
+    def profile_batch(self, params, lanes, reps):
+        """Average launch duration (us) of the batch engine's three kernels for `lanes` estimates (mivi_profile_batch):
+        dict(eps=.., product=.., vjp=..)."""
+        us = (C.c_double * 3)()
+        self._chk(self.lib.mivi_profile_batch(self.h, self._p(params), int(lanes), int(reps), us))
+        return dict(eps=us[0], product=us[1], vjp=us[2])
+
     # -- sharded finalisation / collective behind the ABI ----------------------------------------------------------
     def slice_len(self, world):
         return int(self.lib.mivi_slice_len(self.h, int(world)))

@@ -1834,6 +1834,43 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
   return MIVI_OK;
 }
 
+// Roofline leg of the batch engine: `reps` launches of each of a step's three kernels for `lanes` estimates, hipEvents on the context's
+// stream.  us_out[0..2] = average launch duration (us) of the draws, the product + target, the VJP (+ values).
+mivi_status_t mivi_profile_batch(mivi_ctx_t *c, const void *params, int32_t lanes, int32_t reps, double *us_out) {
+  if (!c || !params || lanes <= 0 || reps <= 0 || !us_out) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  if (!fb_route(c, params, nullptr, nullptr)) return fail(c, MIVI_ERR_UNSUPPORTED, "mivi_profile_batch: this configuration does not take the batch engine");
+  if (lanes > fb_lanes_max()) lanes = fb_lanes_max();
+  char *o = (char *)c->tmp_out.p;
+  mivi_status_t s = fb_batch(c, params, 1, lanes, o, o + 16, nullptr, nullptr);   // buffers, tables, operand planes of every lane
+  if (s) return s;
+  const FbTab *tab = fb_prepare(c, c->cfg.n_mc, lanes);
+  if (!tab) return fail(c, MIVI_ERR_HIP, "batch engine: work table allocation failed");
+  FbStep fs{};
+  fs.params = params; fs.M = c->cfg.n_mc; fs.L = lanes; fs.tab = tab;
+  fs.rng = rng_of(c, 1);
+  fs.grads = c->fb.grads.p; fs.grad_stride = (long long)mivi_params_len(c); fs.values = c->fb.values.p; fs.value_stride = 1; fs.lane_last = -1;
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  for (int which = 0; which < 3; ++which) {
+    for (int r = -2; r < reps; ++r) {
+      if (r == 0) HIPCHK(c, hipEventRecord(e0, c->stream));
+      if (which == 0) fb_launch_eps(c, fs, true, c->stream);
+      else fb_launch_compute(c, fs, c->stream, which == 1 ? 1 : 2);
+    }
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    us_out[which] = (double)ms * 1e3 / reps;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  HIPCHK(c, hipGetLastError());
+  return MIVI_OK;
+}
+
 mivi_status_t mivi_estimate_gradient_each(mivi_ctx_t *c, const void *params, uint64_t idx0, int32_t count, void *values, void *grads) {
   if (!c || !params || !values || count <= 0) return MIVI_ERR_BAD_ARG;
   (void)hipSetDevice(c->cfg.device);

@@ -434,7 +434,7 @@ const FbTab *fb_prepare(mivi_ctx *c, int M, int L);   // work tables for L lanes
 size_t fb_plane_words(const mivi_ctx *c, int M);      // 4-byte words of one lane's operand planes (eps in one orientation, W)
 size_t fb_cplane_words(const mivi_ctx *c);            // ... of tril(C)'s
 void fb_launch_eps(mivi_ctx *c, const FbStep &s, bool with_cplanes, hipStream_t stream);   // a step's draws (+ tril(C)'s planes, once per call)
-void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream);                 // product + target -> VJP + values
+void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int which = 3);  // product + target -> VJP + values (which: 1 / 2 = one of them)
 
 // kernels_stl.hip (f32, d in {256, 512, 1024, 2048}, M % 32 == 0)
 bool stl2_shape_ok(const mivi_ctx *c, int M);

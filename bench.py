@@ -122,7 +122,7 @@ def mf_roofline(ctx, params, cost, kernel_names=("k_mf_main<float>", "k_mf_sgd_l
                       "reductions per lane and estimate)")), {"mf_fused_main": ms1, "mf_loop_per_estimate": msl / 100}
 
 
-def fr_roofline(ctx, params, cost, w, reps=300):
+def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):
     """Full-rank roofline leg: graph-replayed launches of each stage (mivi_profile_kernel), the slower of the two
     contractions is the dominant kernel.  Both carry d^2*M algorithmic flops (lower triangle only).  On the second-generation
     route the products run on the bf16 matrix cores with the exact three-way operand split (six bf16 MFMAs per product
@@ -172,6 +172,40 @@ def fr_roofline(ctx, params, cost, w, reps=300):
                                "the same kernel inside the timed batches, the other branch's kernels beside it)" % reps,
                         single_launch=single)
             ach = a4
+    # Batches on the BATCH ENGINE (full-rank family, diagonal-Gaussian target; csrc/kernels_fullrank_batch.hip): a step of the timed region is
+    # three launches -- draws, product + target, VJP + values -- that cover ALL the lanes of the step (`lanes` = estimates per call of the
+    # timed loop).  The dominant launch is the headline of the block: lanes x the algorithmic flops per launch / its duration, measured live
+    # (hipEvents around back-to-back launches on the launch stream: nothing runs beside these kernels in the timed region either, so the
+    # stand-alone figure IS the in-chain one; `rocprof_in_chain` quotes the committed rocprofv3 summary of the bench command next to it).
+    if lanes and w["target"] == "iso":
+        try:
+            tb = ctx.profile_batch(params, lanes, max(5, reps // 10))
+        except Exception:   # noqa: BLE001  -- configuration outside the batch engine
+            tb = None
+        if tb:
+            for k, v in tb.items():
+                stages["batch_%s_%d_lanes" % (k, lanes)] = v * 1e-3
+            dk = "vjp" if tb["vjp"] >= tb["product"] else "product"
+            ok = "product" if dk == "vjp" else "vjp"
+            nm = {"product": "k_fb_prod (tril(C) [eps_1 .. eps_L] + fused target for all lanes of a step, operands as bf16 planes in MFMA-fragment order)",
+                  "vjp": "k_fb_vjp (tril(W_l eps_l') for all lanes of a step + their values)"}
+            sub = {"product": "k_fb_prod", "vjp": "k_fb_vjp"}
+            aL = lanes * fl / (tb[dk] * 1e-6) / 1e12
+            keep = {k: roof[k] for k in ("kernel", "achieved", "frac", "traffic", "algorithmic_flops_per_launch", "avg_launch_us", "other_contraction")}
+            if "single_launch" in roof:
+                keep = roof["single_launch"]
+            roof.update(kernel=nm[dk], achieved=aL, frac=aL / PEAK_F32_MFMA_TF, algorithmic_flops_per_launch=lanes * fl, estimates_per_launch=lanes,
+                        avg_launch_us=tb[dk], traffic=pmc_traffic(sub[dk]), rocprof_in_chain=rocprof_avg(sub[dk]),
+                        other_contraction=dict(kernel=nm[ok], avg_launch_us=tb[ok], achieved=lanes * fl / (tb[ok] * 1e-6) / 1e12,
+                                               rocprof_in_chain=rocprof_avg(sub[ok])),
+                        draws=dict(kernel="k_fb_eps (Philox + Box-Muller draws of all lanes as operand planes in both orientations)", avg_launch_us=tb["eps"],
+                                   algorithmic_bytes_per_launch=lanes * 12 * w["d"] * w["n_mc"],
+                                   achieved_GBs=lanes * 12 * w["d"] * w["n_mc"] / (tb["eps"] * 1e-6) / 1e9,
+                                   note="6 bytes per element and orientation written once: bound by the memory side and the vector ALU"),
+                        timing="%d back-to-back launches of each kernel for %d lanes, hipEvents on the launch stream" % (max(5, reps // 10), lanes),
+                        single_launch=keep)
+            roof.pop("estimates_per_launch_note", None)
+            ach = aL
     if gen and bf3:
         roof["bf16_pipe"] = dict(mfma="v_mfma_f32_32x32x16_bf16 x6 per product block (exact 3-way f32 split)",
                                  executed_TFLOPs=6 * ach, peak=PEAK_BF16_MFMA_TF, frac=6 * ach / PEAK_BF16_MFMA_TF)
@@ -248,7 +282,7 @@ def make_problem(avi, w):
     return q, prob
 
 
-def parity_vs_oracle(cx, p_dev, p_host, w, idx=11):
+def parity_vs_oracle(cx, p_dev, p_host, w, idx=11, batch=20):
     """Value and gradient of ONE estimate of workload `w` at its own shape against the fp64 numpy oracle on identical eps (read back from
     the device).  Test infrastructure, outside every timed region.  None for workloads the oracle cannot finish in seconds (C3)."""
     from oracle import oracle as O
@@ -261,12 +295,22 @@ def parity_vs_oracle(cx, p_dev, p_host, w, idx=11):
         tgt = O.FunnelStackedTarget(d, 1.5)
     else:
         return None
-    _, eps = cx.sample(p_dev, idx)
-    v, g = cx.estimate_gradient(p_dev, idx)
-    ref = O.estimate_gradient(np.asarray(p_host, dtype=np.float64), d, w["family"], tgt, eps.cpu().numpy().astype(np.float64), w["entropy"])
-    g = g.cpu().numpy().astype(np.float64)
-    return dict(value_rel=abs(float(v.item()) - ref["value"]) / abs(ref["value"]),
-                grad_rel_l2=float(np.linalg.norm(g - ref["grad"]) / np.linalg.norm(ref["grad"])), estimate_idx=idx)
+    # a batch as the timed region issues it (mivi_estimate_gradient_each: the same kernels as mivi_estimate_gradient_n, every estimate kept):
+    # EVERY value against the oracle, first / middle / last gradient
+    n = int(batch)
+    vals, grads = cx.estimate_gradient_each(p_dev, idx, n)
+    cx.synchronize()
+    vals, grads = vals.cpu().numpy().astype(np.float64), grads.cpu().numpy()
+    p64 = np.asarray(p_host, dtype=np.float64)
+    vrel, grel = 0.0, 0.0
+    for i in range(n):
+        _, eps = cx.sample(p_dev, idx + i)
+        ref = O.estimate_gradient(p64, d, w["family"], tgt, eps.cpu().numpy().astype(np.float64), w["entropy"])
+        vrel = max(vrel, abs(vals[i] - ref["value"]) / abs(ref["value"]))
+        if i in (0, n // 2, n - 1):
+            grel = max(grel, float(np.linalg.norm(grads[i].astype(np.float64) - ref["grad"]) / np.linalg.norm(ref["grad"])))
+    return dict(value_rel=vrel, grad_rel_l2=grel, estimate_idx=idx, batch=n,
+                note="max over EVERY estimate of a %d-estimate batch issued like the timed ones (values); gradients of its first, middle and last estimate" % n)
 
 
 def cpu_baseline_blas(lib, CO, w, params, tm, ts, budget_s=8.0):
@@ -479,6 +523,13 @@ def main():
             value, grad = ctx.empty(1), ctx.empty(ctx.params_len)
             chunk = max(1, min(args.graph_chunk, K))
             use_graph = w["target"] != "logreg"
+            if w["family"] == 1 and w["target"] == "iso" and w["entropy"] in (0, 1, 2):
+                launch_desc = (f"mivi_estimate_gradient_n x{chunk}: batch engine, {-(-chunk // 128)} step(s) of up to 128 estimates, per step three launches on one stream "
+                               f"(draws of all lanes as bf16 operand planes | product + fused target, 128 x 128 tiles, 8 waves | VJP + values); no graph, no side streams")
+            elif use_graph:
+                launch_desc = f"mivi_estimate_gradient_n x{chunk} (one hipGraph / launch-free kernel per call)"
+            else:
+                launch_desc = "eager single calls"
 
             def run(idx0, n):
                 done = 0
@@ -644,7 +695,7 @@ def main():
                 if w["family"] == 0:
                     roof, stages = mf_roofline(ctx, params, cost)
                 else:
-                    roof, stages = fr_roofline(ctx, params, cost, w)
+                    roof, stages = fr_roofline(ctx, params, cost, w, lanes=chunk)
                     try:   # two EMPTY dependent launches with the grids / LDS footprints of the two contraction kernels (graph replay)
                         roof["latency_floor_us"] = ctx.profile_kernel(9, params, reps) * 1e3
                         roof["latency_floor_note"] = ("what the two-launch structure costs with no work in it; whole estimate minus this = "
@@ -668,8 +719,9 @@ def main():
                          hbm_equiv_frac_of_8TBs=cost["bytes"] * est_per_s / world / 1e9 / PEAK_HBM_GBS,
                          f32_mfma_TFs=cost["flops"] * est_per_s / world / 1e12 if w["family"] == 1 else None)
             # ---- capacity leg (NOT the headline): S independent contexts on S streams -------------------------
-            # `value` above is a single dependent chain of estimates on one stream (what an SGD loop sees; latency
-            # bound at these sizes).  Independent chains (multi-start VI, monitoring estimates) can overlap on the device.
+            # `value` above: K estimates at FIXED parameters, issued as batched calls of `chunk` estimates (mivi_estimate_gradient_n; the north
+            # star's family / target: the batch engine, three launches per step of up to 128 estimates -- config.launch).  What an optimiser
+            # loop sees -- every estimate behind the previous update, one dependent chain -- is `also.ns_adam_loop`.
             conc = None
             if single and args.concurrent > 1 and w["target"] in ("iso", "dense"):
                 S = args.concurrent
@@ -747,12 +799,12 @@ def main():
                     elif w2["family"] == 0:
                         roof2, _ = mf_roofline(cx, p2, c2cost)
                     else:
-                        roof2, _ = fr_roofline(cx, p2, c2cost, w2, reps=100)
+                        roof2, _ = fr_roofline(cx, p2, c2cost, w2, reps=100, lanes=100)
                         if w2["entropy"] in (3, 4):
                             roof2["stl_term"] = stl_block(cx, p2, w2)
                     also[wn] = dict(workload=w2["name"], value=1.0 / t2, unit="estimates/s", us_per_step=t2 * 1e6, estimates=n_est,
                                     launch="hipGraph x100" if graphable else "eager", roofline=roof2,
-                                    parity_vs_fp64_oracle=(None if args.no_cpu_baseline else parity_vs_oracle(cx, p2, p2h, w2)))
+                                    parity_vs_fp64_oracle=(None if args.no_cpu_baseline else parity_vs_oracle(cx, p2, p2h, w2, batch=4)))
                     cx.close()
                     del prob2, q2
                 # the Stein / Price estimator of E_q[grad], E_q[hess] on the north-star shape (gaussian_expectation_gradient_and_hessian!,
@@ -835,7 +887,7 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": w["name"], "d": w["d"], "n_mc_per_gpu": w["n_mc"], "n_mc_total": w["n_mc"] * world,
                            "family": "fullrank" if w["family"] else "meanfield", "seed": hex(SEED),
-                           "launch": f"hipGraph x{chunk}" if single else (f"mivi_estimate_gradient_dist_n x{chunk} (pipelined: exchange of estimate t under the kernels of t+1), route {dist_info['route']}" if pipelined else f"mivi_estimate_gradient_dist (dependent chain), route {dist_info['route']}"),
+                           "launch": launch_desc if single else (f"mivi_estimate_gradient_dist_n x{chunk} (pipelined: exchange of estimate t under the kernels of t+1), route {dist_info['route']}" if pipelined else f"mivi_estimate_gradient_dist (dependent chain), route {dist_info['route']}"),
                            "fullrank_route": (list(ctx.fullrank_route()) if w["family"] == 1 else None)},
                 "roofline": roof, "cpu_baseline": cpub,
                 "repeat_ms_per_step": repeats, "elbo_rel_err_vs_cpu_fp64": rel, "parity_vs_fp64_oracle": parity_head, "stage_us": stages,

@@ -144,16 +144,18 @@ CASES = [
     ("MIVI_GRAPH_MIN=1", LOOP, dict(fam=F, d=128, M=128)),                                                # graph replay even for the shortest batches
     ("MIVI_GRAPH_MIN=100", LOOP, dict(fam=F, d=128, M=128)),                                              # eager chain for every batch
     ("MIVI_STEIN_GEN1=1", STEIN, dict()),
-    ("MIVI_CHAINS=1", CHAINS, dict(kind="diag")),                                                         # one chain instead of interleaved ones
+    ("MIVI_BATCH_GEN3=0,MIVI_CHAINS=1", CHAINS, dict(kind="diag")),                                                         # one chain instead of interleaved ones
     ("MIVI_CHAINS=4", CHAINS, dict(kind="dense")),                                                        # four contexts
-    ("MIVI_LANE_BATCH=0", CHAINS, dict(kind="diag")),                                                     # every context on a graph branch of its own (no lane-batched launches)
+    ("MIVI_BATCH_GEN3=0,MIVI_LANE_BATCH=0", CHAINS, dict(kind="diag")),                                                     # every context on a graph branch of its own (no lane-batched launches)
     ("MIVI_LANE_BATCH=2", CHAINS, dict(kind="dense")),                                                    # two contexts per lane-batched launch
-    ("MIVI_CHAINS=8", CHAINS, dict(kind="diag")),                                                         # eight contexts: two branches of four lanes
-    ("MIVI_PROD_QUAD=0", CHAINS_NS, dict(kind="diag")),                                                   # four lanes' products on k_fr_prod32's tiles (k_fr_prod32m)
-    ("MIVI_VJP_STRIP=0", CHAINS_NS, dict(kind="diag")),                                                   # one VJP tile per workgroup (k_fr_vjp32m)
+    ("MIVI_BATCH_GEN3=0,MIVI_CHAINS=8", CHAINS, dict(kind="diag")),                                                         # eight contexts: two branches of four lanes
+    ("MIVI_BATCH_GEN3=0,MIVI_PROD_QUAD=0", CHAINS_NS, dict(kind="diag")),                                                   # four lanes' products on k_fr_prod32's tiles (k_fr_prod32m)
+    ("MIVI_BATCH_GEN3=0,MIVI_VJP_STRIP=0", CHAINS_NS, dict(kind="diag")),                                                   # one VJP tile per workgroup (k_fr_vjp32m)
     ("MIVI_VJP_STRIP=5", CHAINS_NS, dict(kind="dense")),
-    ("MIVI_STRIP_ROWS=1", CHAINS_NS, dict(kind="diag")),                                                  # strips dealt to the XCDs by block row                                                  # another strip length
-    ("MIVI_DUMMY_DEFAULT=1", CHAINS_NS, dict(kind="diag")),                                               # (no switch: k_fr_prod32q + k_fr_vjp32s)
+    ("MIVI_BATCH_GEN3=0,MIVI_STRIP_ROWS=1", CHAINS_NS, dict(kind="diag")),                                                  # strips dealt to the XCDs by block row                                                  # another strip length
+    ("MIVI_BATCH_GEN3=0", CHAINS_NS, dict(kind="diag")),                                                  # the lane-batched second-generation kernels (k_fr_prod32q + k_fr_vjp32s) where the batch engine would run
+    ("MIVI_FB_LANES=7", CHAINS, dict(kind="diag")),                                                       # batch engine: seven estimates per step (25 estimates: four steps, the last one shorter)
+    ("MIVI_DUMMY_DEFAULT=1", CHAINS_NS, dict(kind="diag")),                                               # (no switch: the batch engine, one step)
     ("MIVI_DUMMY_DEFAULT=1", CHAINS, dict(kind="dense")),                                                 # (no switch: the default interleaving)                                                                 # first-generation accumulation kernel
 ]
 
@@ -164,8 +166,9 @@ def test_route_under_switch_agrees(switch, script, par):
     par.setdefault("pre", "")
     code = script.format(**par)
     env = {k: v for k, v in os.environ.items() if not k.startswith("MIVI_")}
-    k, v = switch.split("=")
-    env[k] = v
+    for kv in switch.split(","):   # (the second-generation batch switches only apply once the batch engine is switched off: MIVI_BATCH_GEN3=0)
+        k, v = kv.split("=")
+        env[k] = v
     env["PYTHONPATH"] = ROOT
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

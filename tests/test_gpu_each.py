@@ -1,0 +1,138 @@
+"""mivi_estimate_gradient_each / the batch engine (csrc/kernels_fullrank_batch.hip): EVERY estimate of a batch at fixed parameters, not only
+its last one -- values against the fp64 oracle on the identical eps (read back from the device), gradients bitwise against the single
+calls (`estimate_gradient!` once per estimate, src/algorithms/repgradelbo.jl:151-177), and against the oracle.  The north-star shape
+(1024, 256) with the batch lengths the bench times (20: one step; 52; 150: two steps of the engine) and smaller / other configurations,
+incl. the ones that take the generic route (one single call per estimate)."""
+import numpy as np
+import pytest
+
+import advancedvi_jl_amd as avi
+from oracle import oracle as O
+from tests.helpers import SEED, make_family, make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(d, M, ent, kind="diag", family=avi.FULLRANK, seed=5):
+    rng = np.random.default_rng(seed + d + M)
+    q, q_or = make_family(rng, d, family, np.float32)
+    prob, tgt = make_problem(rng, kind, d, np.float32)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, family, d, M, ent, SEED)
+    ctx.set_problem(prob)
+    ref = avi.MiviContext(np.float32, family, d, M, ent, SEED)
+    ref.set_problem(prob)
+    return ctx, ref, params, tgt
+
+
+@pytest.mark.parametrize("n", [20, 52])
+def test_every_estimate_of_a_north_star_batch(n):
+    d, M, ent = 1024, 256, 0
+    ctx, ref, params, tgt = _setup(d, M, ent)
+    p, pr = ctx.to_device(params), ref.to_device(params)
+    idx0 = 40
+    vals, grads = ctx.estimate_gradient_each(p, idx0, n)
+    ctx.synchronize()
+    vals, grads = vals.cpu().numpy(), grads.cpu().numpy()
+    p64 = params.astype(np.float64)
+    for i in range(n):
+        v1, g1 = ref.estimate_gradient(pr, idx0 + i)
+        g1 = g1.cpu().numpy()
+        assert float(vals[i]) == float(v1.item()), (i, float(vals[i]), float(v1.item()))     # bitwise the single call's
+        assert np.array_equal(grads[i], g1), i
+        _, eps = ref.sample(pr, idx0 + i)
+        o = O.estimate_gradient(p64, d, avi.FULLRANK, tgt, eps.cpu().numpy().astype(np.float64), ent)
+        assert abs(float(vals[i]) - o["value"]) <= 1e-5 * abs(o["value"]), (i, float(vals[i]), o["value"])   # the north star's tolerance
+        if i in (0, n // 2, n - 1):
+            assert np.linalg.norm(grads[i].astype(np.float64) - o["grad"]) <= 2e-5 * np.linalg.norm(o["grad"]), i
+        G = grads[i][d:].reshape(d, d)                           # [column][row]
+        assert not np.any(np.triu(G.T, 1)), i                    # exact zeros above the diagonal in every row of the output
+    ctx.close()
+    ref.close()
+
+
+def test_two_engine_steps_and_the_last_estimate_entry():
+    """150 estimates = two steps of the engine (128 lanes per step at most): every value against single calls, the gradients of the
+    step boundaries, and mivi_estimate_gradient_n's contract (value / gradient of the LAST estimate) on the same batch."""
+    d, M, ent = 256, 128, 0
+    ctx, ref, params, _ = _setup(d, M, ent)
+    p, pr = ctx.to_device(params), ref.to_device(params)
+    n, idx0 = 150, 7
+    vals, grads = ctx.estimate_gradient_each(p, idx0, n)
+    ctx.synchronize()
+    vals, grads = vals.cpu().numpy(), grads.cpu().numpy()
+    for i in range(n):
+        v1, g1 = ref.estimate_gradient(pr, idx0 + i)
+        assert float(vals[i]) == float(v1.item()), i
+        if i in (0, 1, 74, 75, 76, 148, 149):
+            assert np.array_equal(grads[i], g1.cpu().numpy()), i
+    v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+    g.fill_(float("nan"))
+    ctx.estimate_gradient_n(p, idx0, n, v, g)
+    ctx.synchronize()
+    assert float(v.item()) == float(vals[n - 1]) and np.array_equal(g.cpu().numpy(), grads[n - 1])
+    ctx.close()
+    ref.close()
+
+
+@pytest.mark.parametrize("ent", [1, 2])
+def test_other_entropy_estimators_and_values_only(ent):
+    """ClosedFormEntropyZeroGradient / MonteCarloEntropy on the engine; a values-only call (grads = NULL).  The Monte Carlo value holds
+    sum(eps^2): a single call takes the f32 wave sums of k_eps' blocks, the engine those of its own draw blocks -- one ulp at most."""
+    d, M = 384, 256
+    ctx, ref, params, tgt = _setup(d, M, ent)
+    p, pr = ctx.to_device(params), ref.to_device(params)
+    n, idx0 = 33, 3
+    vals, grads = ctx.estimate_gradient_each(p, idx0, n)
+    vals_only, none = ctx.estimate_gradient_each(p, idx0, n, want_grads=False)
+    ctx.synchronize()
+    assert none is None
+    vals, grads, vals_only = vals.cpu().numpy(), grads.cpu().numpy(), vals_only.cpu().numpy()
+    assert np.array_equal(vals, vals_only)
+    p64 = params.astype(np.float64)
+    for i in range(n):
+        v1, g1 = ref.estimate_gradient(pr, idx0 + i)
+        ulps = 1 if ent == 2 else 0
+        assert abs(float(vals[i]) - float(v1.item())) <= ulps * float(np.spacing(np.float32(abs(float(v1.item()))))), i
+        assert np.array_equal(grads[i], g1.cpu().numpy()), i
+        if i % 8 == 0:
+            _, eps = ref.sample(pr, idx0 + i)
+            o = O.estimate_gradient(p64, d, avi.FULLRANK, tgt, eps.cpu().numpy().astype(np.float64), ent)
+            assert abs(float(vals[i]) - o["value"]) <= 1e-5 * abs(o["value"])
+            assert np.linalg.norm(grads[i].astype(np.float64) - o["grad"]) <= 2e-5 * max(1.0, np.linalg.norm(o["grad"]))
+    ctx.close()
+    ref.close()
+
+
+@pytest.mark.parametrize("family,kind,ent,d,M", [(avi.MEANFIELD, "diag", 0, 200, 64), (avi.FULLRANK, "dense", 0, 128, 128),
+                                                 (avi.FULLRANK, "diag", 3, 128, 128), (avi.FULLRANK, "diag", 0, 96, 48),
+                                                 (avi.MEANFIELD, "funnel", 3, 64, 32)])
+def test_generic_route_equals_single_calls(family, kind, ent, d, M):
+    """Configurations outside the engine (mean-field, other targets, the sticking-the-landing estimators, ragged shapes): the entry runs
+    the single calls one after the other -- same results by construction, same contract."""
+    ctx, ref, params, _ = _setup(d, M, ent, kind, family)
+    p, pr = ctx.to_device(params), ref.to_device(params)
+    n, idx0 = 6, 11
+    vals, grads = ctx.estimate_gradient_each(p, idx0, n)
+    ctx.synchronize()
+    vals, grads = vals.cpu().numpy(), grads.cpu().numpy()
+    for i in range(n):
+        v1, g1 = ref.estimate_gradient(pr, idx0 + i)
+        assert float(vals[i]) == float(v1.item()) and np.array_equal(grads[i], g1.cpu().numpy()), i
+    ctx.close()
+    ref.close()
+
+
+def test_engine_leaves_status_and_reports_a_bad_scale():
+    """A non-positive scale diagonal is reported by the engine's value workgroups like by the single calls (sticky status)."""
+    d, M = 128, 128
+    ctx, _, params, _ = _setup(d, M, 0)
+    bad = params.copy()
+    bad[d + 5 * d + 5] = -1.0
+    with pytest.raises(avi.MiviError):
+        ctx.estimate_gradient_each(ctx.to_device(bad), 0, 9)
+        ctx.synchronize()
+    vals, _ = ctx.estimate_gradient_each(ctx.to_device(params), 0, 9)   # the context keeps working
+    ctx.synchronize()
+    assert np.all(np.isfinite(vals.cpu().numpy()))
+    ctx.close()

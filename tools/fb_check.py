@@ -110,3 +110,5 @@ if __name__ == "__main__":
         print("PARITY", "OK" if b == 0 else f"FAILED ({b})")
     if "time" in what:
         timing()
+    if "time100" in what:
+        timing(counts=(100,), reps=20)

@@ -71,6 +71,18 @@ int main(int argc, char **argv) {
     }
     printf("knock %2d: eps %7.2f us  prod %7.2f us  vjp %7.2f us  value %6.2f us   (per estimate: %.3f us)\n", kn, ms[0] * 1e3, ms[1] * 1e3, ms[2] * 1e3, ms[3] * 1e3,
            (ms[0] + ms[1] + ms[2] + ms[3]) * 1e3 / L);
+    if (kn == 0) {   // every lane reading lane 0's operand planes (timing only: what the memory side costs)
+      a.plane_stride = 0;
+      for (int which = 1; which <= 2; ++which) {
+        for (int r = -3; r < reps; ++r) {
+          if (r == 0) CK(hipEventRecord(e0, st));
+          if (which == 1) { a.work = (const int4 *)tab->prod.p; a.n_work = tab->n_prod; hipLaunchKernelGGL((k_fb_prod<UB_WJ, UB_PF>), dim3(tab->n_prod), dim3(512 / UB_WJ), 0, st, a); }
+          if (which == 2) { a.work = (const int4 *)tab->vjp.p; a.n_work = tab->n_vjp; hipLaunchKernelGGL((k_fb_vjp<UB_WJ, UB_PF>), dim3(tab->n_vjp), dim3(512 / UB_WJ), 0, st, a); }
+        }
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms[which], e0, e1));
+      }
+      printf("  all lanes on lane 0's planes: prod %7.2f us  vjp %7.2f us\n", ms[1] / reps * 1e3, ms[2] / reps * 1e3);
+    }
   }
 #ifndef MIVI_DEV
   return 0;
