@@ -57,7 +57,7 @@ struct P2PArgs {
   long long L, n, cn;        // partial length; slice length (multiple of 4); chunk length (multiple of 4)
   int rank, world, G, vs;    // vs = the rank whose slice holds the two scalars (sum ell, sum 0.5|eps|^2)
   const P2PTable *tab;
-  unsigned *ctr;             // this lane's counters: [0] exchanges completed, [1] exit ticket
+  unsigned *ctr;             // this lane's counters: [0] exchanges completed, [1] exit ticket, [2] the last epoch whose value this rank has consumed
   const T *P[kP2PRing];      // this rank's partial vectors: estimate t of the batch sits in P[t % ring], zero padded to world * n
   int ring;
   const T *params;
@@ -259,6 +259,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 
     // ---- phase 1: push chunk g of every slice of every vector to its owner, then one arrival flag per owner ---------------------------
     if ((a.phases & 1) && !value_wg) {
+      // The areas are double-buffered by epoch parity with no acknowledgements: safe for the chunk workgroups because workgroup g of
+      // epoch e + 2 depends, through the flags it waits for, on workgroup g of every peer having finished epoch e.  The VALUE workgroup
+      // sits outside that chain: the two scalars it reads (stage area, rank vs) and writes (final areas) live in the chunks ga / gb of
+      // slice vs.  So the chunk workgroups ga / gb of EVERY rank do not start pushing epoch e + 2 before their own rank's value
+      // workgroup has consumed epoch e (ctr[2], a device-local word): that value was read behind rank vs's final flag, which rank vs
+      // stores after reading its stage scalars -- both parities of both hazards are closed by this one wait.
+      if ((a.phases & 4) && a.rank >= 0) {
+        const long long o0 = tri_end - (long long)a.vs * n;
+        const int ga = (int)(o0 / a.cn), gb = (int)((o0 + 1) / a.cn);
+        if (g == ga || g == gb) {
+          if (tid == 0) {
+            int budget = lost ? 64 : a.spin_budget;
+            sh_ok = 1;
+            while ((int)(epoch - __hip_atomic_load(a.ctr + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) > 2) {
+              if (--budget <= 0) { sh_ok = 0; break; }
+              __builtin_amdgcn_s_sleep(4);
+            }
+          }
+          __syncthreads();
+          if (!sh_ok) lost = true;
+          __syncthreads();
+        }
+      }
       const int vecs = (int)(clen / V);   // (clen is a multiple of 4)
       for (int v = 0; v < nv; ++v) {
         const T *P = a.P[(t0 + v) % a.ring];
@@ -366,6 +389,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
           const int stt = (int)ld_sys(fin + tri_end + 1);
           if (stt && a.status) atomicOr(a.status, stt);
         }
+        __syncthreads();   // (the group's scalars have been read: the chunk workgroups ga / gb may go two epochs ahead, see phase 1)
+        if (tid == 0) __hip_atomic_store(a.ctr + 2, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         // chunk g of every owner's slice: R final flags
         if (!wait_flags<NT>(tb.farr[ln][a.rank] + (size_t)(p * R) * (G + 1) + g, R, G + 1, epoch, lost ? 64 : a.spin_budget, &sh_ok)) lost = true;

@@ -533,7 +533,7 @@ static mivi_status_t run_estimate_lds(mivi_ctx *c, const void *params, const Rng
     next = &nx;
   } else if (spec) {   // speculate that the caller asks for estimate idx + 1 next (an SGD loop does)
     nx.rng = rng;
-    nx.rng.idx_base = rng.idx_base + (uint64_t)c->idx_stride;
+    nx.rng.idx_base = rng.idx_base + 1ull;   // (a single call: the NEXT index, whatever stride an earlier batched call left on this context)
     nx.parity = p ^ 1;
     next = &nx;
   }
@@ -735,7 +735,7 @@ static mivi_status_t run_estimate(mivi_ctx *c, const void *params, const RngArgs
         next = &nx;
       } else if (spec) {   // speculate that the caller asks for estimate idx + 1 next (an SGD loop does)
         nx.rng = rng;
-        nx.rng.idx_base = rng.idx_base + (uint64_t)c->idx_stride;
+        nx.rng.idx_base = rng.idx_base + 1ull;   // (a single call: the NEXT index, whatever stride an earlier batched call left on this context)
         nx.parity = p ^ 1;
         next = &nx;
       }
@@ -2290,7 +2290,7 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
     }
   }
   const int kind = 20 + mode;
-  static bool capture_refused = false;   // (a collective library that cannot be captured: do not retry on every call)
+  bool &capture_refused = c->dist_capture_refused;   // (a collective library that cannot be captured: do not retry on every call of THIS context)
   if (!(g.exec && g.kind == kind && g.count == count && g.params == params && g.value == value && g.grad == grad && g.p0 == (double)route) && !capture_refused) {
     invalidate_graph(c);
     if (c->dist_lane4) {
@@ -2517,8 +2517,8 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
   if (simple && (rule == 0 || default_adam) && c->cfg.family == MIVI_MEANFIELD && c->target == TGT_DIAG_GAUSS && !c->bij_on &&
       c->cfg.n_mc <= 4096 && !no_fused_loop) {   // (the launch-free kernel has no Stacked-bijector handling: explicit-sample route)
     // launch-free loop: every workgroup owns four rows of (mu, sigma); no graph, two launches for all n_steps
-    HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream));
-    launch_mf_sgd_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, rec + n_steps, rec);
+    HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));   // (every word read_status folds in: a stale flag of an
+    launch_mf_sgd_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, rec + n_steps, rec);   //  earlier batch's child contexts is not this run's)
     HIPCHK(c, hipGetLastError());
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);
@@ -2587,7 +2587,7 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
   }
   c->d_idx_valid = false;
   hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, l.estimate_idx0, (uint64_t)l.t0, 2);
-  HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int), c->stream));   // a stale flag of earlier host-driven estimates is not this run's
+  HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));   // a stale flag of earlier estimates (this context's word or a child context's: read_status folds them all in) is not this run's
   HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
   if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
   return read_status(c);

@@ -343,6 +343,7 @@ struct mivi_ctx {
   int n_kids = 0;
   unsigned long long target_gen = 0, kid_gen = ~0ull;   // parent: bumped whenever a captured graph is invalidated; child: the generation it mirrors
   hipEvent_t ev_fork = nullptr, ev_join[kMaxKids] = {};
+  bool dist_capture_refused = false;   // the sharded batch could not be captured into a hipGraph (RCCL route): issued eagerly from then on
   bool dist_lane4 = false;       // pipelined sharded batches: the compute chain is lane-batched (four contexts per launch)
   void *value_sink = nullptr;    // ... and launch_value_only (a chain's closing value kernel) into the value sink
   void *eps_sink = nullptr;      // ... and launch_eps (a chain's first draw) into the eps sink

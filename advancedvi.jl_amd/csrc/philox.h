@@ -38,8 +38,8 @@ MIVI_HD u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
     const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     u32x4 n;
-#if defined(__HIP_DEVICE_COMPILE__)
-    n.x = __builtin_amdgcn_bitop3_b32(hi1, c.y, k0, 0x96);   // a ^ b ^ c as ONE v_bitop3_b32 (gfx950; the compiler emits two v_xor_b32)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__gfx950__)
+    n.x = __builtin_amdgcn_bitop3_b32(hi1, c.y, k0, 0x96);   // a ^ b ^ c as ONE v_bitop3_b32 (gfx950 only; the compiler emits two v_xor_b32)
     n.z = __builtin_amdgcn_bitop3_b32(hi0, c.w, k1, 0x96);
 #else
     n.x = hi1 ^ c.y ^ k0;

@@ -331,8 +331,12 @@ def _optimize_on_device(rng, alg, max_iter, state, codes, show_progress):
                         raise RuntimeError("The objective value is not finite. This indicates that the optimization run "
                                            "diverged.") from e2
                     raise
-                # the host-driven replay of the chunk completed with finite objectives: the device flag was not reproducible
-                # (stale or spurious).  The replayed steps ARE the chunk (bitwise the same arithmetic): carry on from them.
+                # the host-driven replay of the chunk completed with finite objectives: the device flag was not reproducible.
+                # (mivi_optimize_loop clears every status word it later reads, so a stale flag of an earlier call cannot cause
+                # this any more; if it happens, it is worth knowing.)  The replayed steps ARE the chunk (bitwise the same
+                # arithmetic): carry on from them.
+                warnings.warn(f"device optimisation chunk reported status {e.status} ({e}) but its host-driven replay completed with "
+                              "finite objectives; continuing from the replayed steps", RuntimeWarning)
                 done += n
                 continue
             raise
