@@ -316,8 +316,10 @@ def parity_vs_oracle(cx, p_dev, p_host, w, idx=11, batch=20):
 def cpu_baseline_blas(lib, CO, w, params, tm, ts, budget_s=8.0):
     """A second CPU leg for the full-rank family: the same estimate with its two contractions on the BLAS numpy links (OpenBLAS in this
     image), every core -- what the reference's `scale * eps` (src/families/location_scale.jl:76: a BLAS call, bench/benchmarks.jl:15 sets
-    the BLAS threads) and the AD pull-back's products cost at best.  eps from numpy's ziggurat generator; everything else (target, entropy
-    term, tril, scaling) in numpy.  `cpu_baseline.value` is the faster of this leg and the C port's (`cpu_baseline.leg` says which)."""
+    the BLAS threads) and the AD pull-back's products cost at best.  Timed twice: eps drawn inside the timed call with numpy's ziggurat
+    generator (a whole estimate, like every other figure of this bench), and eps PRE-DRAWN outside it (the contractions + elementwise
+    work alone).  Everything else (target, entropy term, tril, scaling) in numpy.  GFLOP/s: `gflops_executed` counts the two full
+    d x d x n_mc GEMMs the BLAS runs (2 * 2 d^2 n_mc), `gflops_algorithmic` the triangular halves the estimate needs (2 d^2 n_mc)."""
     d, M = w["d"], w["n_mc"]
     mu = np.ascontiguousarray(params[:d], dtype=np.float32)
     Cm = np.asfortranarray(np.tril(np.asarray(params[d:], dtype=np.float32).reshape(d, d, order="F")))
@@ -325,11 +327,12 @@ def cpu_baseline_blas(lib, CO, w, params, tm, ts, budget_s=8.0):
 
     rng_np = np.random.default_rng(SEED & 0xFFFFFFFF)
     tril_mask = np.tril(np.ones((d, d), dtype=np.float32))
+    pool = [np.asfortranarray(rng_np.standard_normal((d, M), dtype=np.float32)) for _ in range(8)]
 
-    def one(i):
-        # numpy's ziggurat normals (what `rand(rng, Normal, d, M)` costs the reference, ~5 ns each); the Philox + Box-Muller port spends
-        # ~40 ms per estimate on eps alone, which would hide the BLAS
-        eps = np.asfortranarray(rng_np.standard_normal((d, M), dtype=np.float32))
+    def one(eps=None):
+        if eps is None:
+            # numpy's ziggurat normals (what `rand(rng, Normal, d, M)` costs the reference, ~5 ns each)
+            eps = np.asfortranarray(rng_np.standard_normal((d, M), dtype=np.float32))
         Z = Cm @ eps
         Z += mu[:, None]
         U = (Z - tm[:, None]) * istd[:, None]
@@ -342,32 +345,42 @@ def cpu_baseline_blas(lib, CO, w, params, tm, ts, budget_s=8.0):
         gmu = -W.sum(axis=1) / M
         return ell, gmu, G
 
-    one(0)
-    t0 = time.perf_counter()
-    one(1)
-    t1 = time.perf_counter() - t0
-    reps = int(max(5, min(200, budget_s / max(t1, 1e-6))))
-    ts_ = []
-    for i in range(reps):
+    def leg(predrawn, budget):
+        one(pool[0] if predrawn else None)
         t0 = time.perf_counter()
-        one(i + 2)
-        ts_.append(time.perf_counter() - t0)
-    ts_.sort()
-    med = ts_[len(ts_) // 2]
+        one(pool[1] if predrawn else None)
+        t1 = time.perf_counter() - t0
+        reps = int(max(5, min(200, budget / max(t1, 1e-6))))
+        ts_ = []
+        for i in range(reps):
+            t0 = time.perf_counter()
+            one(pool[i % len(pool)] if predrawn else None)
+            ts_.append(time.perf_counter() - t0)
+        ts_.sort()
+        return ts_[len(ts_) // 2], reps
+
+    med, reps = leg(False, budget_s / 2)
+    med_pre, reps_pre = leg(True, budget_s / 2)
     try:
         import numpy.__config__ as npc
         blas_name = str(npc.CONFIG["Build Dependencies"]["blas"]["name"])
     except Exception:   # noqa: BLE001
         blas_name = "numpy's BLAS"
+    fl = 2.0 * d * d * M
     return dict(estimates_per_s=1.0 / med, median_s=med, reps=reps, blas=blas_name,
+                gflops_algorithmic=fl / med / 1e9, gflops_executed=2 * fl / med / 1e9,
+                eps_predrawn=dict(estimates_per_s=1.0 / med_pre, median_s=med_pre, reps=reps_pre,
+                                  gflops_algorithmic=fl / med_pre / 1e9, gflops_executed=2 * fl / med_pre / 1e9,
+                                  note="eps taken from a pool drawn before the timed region: the two GEMMs + the numpy elementwise work alone"),
                 note="two GEMMs (d x d x n_mc each, f32) on the BLAS + numpy elementwise work, all cores; eps drawn with numpy's ziggurat generator (included)")
 
 
 def cpu_baseline(w, params, budget_s=24.0):
     """The oracle's C leg (oracle/mivi_oracle.c: a port of the reference semantics with the closed-form VJP,
     cheaper than the reference's AD path) timed on this box's host cores.  Protocol (the reference's
-    bench/benchmarks.jl:15 runs with the BLAS threads of the box): TWO team sizes -- 1 thread and every CPU this
-    process may use -- each >= 20 repetitions of one whole estimate incl. eps generation, MEDIAN reported, the whole leg
+    bench/benchmarks.jl:15 runs with the BLAS threads of the box): team sizes 1, 2, 4, ... up to every CPU this
+    process may use -- each >= 20 repetitions of one whole estimate incl. eps generation, MEDIAN reported with the eps
+    generation's share and the contractions' GFLOP/s (2 d^2 n_mc algorithmic flops per full-rank estimate), the whole leg
     bounded by `budget_s` seconds of wall time (the repetition count shrinks, never below 5, if the box is slow)."""
     from oracle import c_oracle as CO
     if not os.path.exists(CO.PATH):
@@ -396,29 +409,38 @@ def cpu_baseline(w, params, budget_s=24.0):
         pass
     tm, ts = np.full(d, 5.0, np.float32), np.ones(d, np.float32)
     work = np.empty(2 * d * M, dtype=np.float32)
+    grad = np.empty_like(np.ascontiguousarray(params, dtype=np.float32))
+    eps_buf = np.empty((d, M), dtype=np.float32, order="F")
+    fl = 2.0 * d * d * M if fam == 1 else 6.0 * d * M
 
     def one(i):
-        eps = CO.fill_eps(lib, np.float32, SEED, i, d, M)
-        CO.estimate_gradient(lib, np.float32, fam, d, M, params, eps, tm, ts, w["entropy"], work)
+        t0 = time.perf_counter()
+        eps = CO.fill_eps(lib, np.float32, SEED, i, d, M, out=eps_buf)
+        t1 = time.perf_counter()
+        CO.estimate_gradient(lib, np.float32, fam, d, M, params, eps, tm, ts, w["entropy"], work, grad)
+        return t1 - t0, time.perf_counter() - t1
 
     legs = {}
     t_leg0 = time.perf_counter()
-    for nt in sorted({1, avail}):
+    teams = sorted({1, avail} | {t for t in (2, 4, 8, 16, 32) if t < avail})
+    for nt in teams:
         lib.mo32_set_threads(nt)
         one(0)                                   # warm (thread team start-up, page faults)
-        t0 = time.perf_counter()
-        one(1)
-        t1 = time.perf_counter() - t0
-        reps = int(max(5, min(200, (budget_s / 2) / max(t1, 1e-6))))
-        reps = max(reps, 20) if 20 * t1 <= budget_s / 2 else reps
-        ts_ = []
+        t1 = sum(one(1))
+        share = budget_s / len(teams)
+        reps = int(max(5, min(100, share / max(t1, 1e-6))))
+        reps = max(reps, 20) if 20 * t1 <= share else reps
+        ts_, te_ = [], []
         for i in range(reps):
-            t0 = time.perf_counter()
-            one(i + 2)
-            ts_.append(time.perf_counter() - t0)
+            a, b = one(i + 2)
+            ts_.append(a + b)
+            te_.append((a, b))
         ts_.sort()
         med = ts_[len(ts_) // 2]
-        legs[nt] = dict(threads=nt, reps=reps, median_s=med, min_s=ts_[0], max_s=ts_[-1], estimates_per_s=1.0 / med)
+        med_eps = sorted(a for a, _ in te_)[len(te_) // 2]
+        med_est = sorted(b for _, b in te_)[len(te_) // 2]
+        legs[nt] = dict(threads=nt, reps=reps, median_s=med, min_s=ts_[0], max_s=ts_[-1], estimates_per_s=1.0 / med,
+                        eps_generation_s=med_eps, estimate_s=med_est, gflops_estimate=fl / med_est / 1e9)
     wall = time.perf_counter() - t_leg0
     model = ""
     try:
@@ -433,15 +455,17 @@ def cpu_baseline(w, params, budget_s=24.0):
     if fam == 1:
         blas = cpu_baseline_blas(lib, CO, w, params, tm, ts, budget_s=8.0)
     sample = (f"median of {best['reps']} whole estimates of the same (d={d}, n_mc={M}) workload incl. eps generation, f32, OpenMP "
-              f"{best['threads']} threads on '{model}' ({avail} CPUs available), leg wall time {wall:.1f} s")
+              f"{best['threads']} threads on '{model}' ({avail} CPUs available), {best['gflops_estimate']:.0f} GFLOP/s in the estimate "
+              f"(2 d^2 n_mc flops, eps generation {best['eps_generation_s'] * 1e3:.2f} ms of {best['median_s'] * 1e3:.2f} ms), leg wall time {wall:.1f} s")
     value, cores, leg = best["estimates_per_s"], best["threads"], "c_port"
     if blas and blas["estimates_per_s"] > value:   # the CPU's best foot forward: whichever leg is faster is the reported baseline
         value, cores, leg = blas["estimates_per_s"], avail, "blas"
         sample = (f"median of {blas['reps']} whole estimates of the same (d={d}, n_mc={M}) workload, f32: both contractions on {blas['blas']} "
-                  f"(all {avail} CPUs of '{model}'), numpy ziggurat normals + numpy elementwise work included; the C port's legs are in "
-                  f"one_thread / all_cores")
+                  f"(all {avail} CPUs of '{model}', {blas['gflops_executed']:.0f} GFLOP/s executed), numpy ziggurat normals + numpy elementwise "
+                  f"work included ({blas['eps_predrawn']['estimates_per_s']:.0f} estimates/s with eps pre-drawn); the C port's legs are in thread_scaling")
     return dict(value=value, unit="ELBO-grad-estimates/s", cores=cores, kind="port", leg=leg, build=build, blas=blas, sample=sample,
-                one_thread=legs.get(1), all_cores=legs.get(avail), threads=lib.mo32_max_threads())
+                gflops=(best["gflops_estimate"] if leg == "c_port" else blas["gflops_algorithmic"]),
+                one_thread=legs.get(1), all_cores=legs.get(avail), thread_scaling=[legs[t] for t in teams], threads=lib.mo32_max_threads())
 
 
 def main():

@@ -25,14 +25,15 @@ def load(path=None):
     return lib
 
 
-def estimate_gradient(lib, dtype, family, d, M, params, eps, t_mean, t_std, ent_kind, work=None):
+def estimate_gradient(lib, dtype, family, d, M, params, eps, t_mean, t_std, ent_kind, work=None, grad=None):
     dt = np.dtype(dtype)
     pfx = "mo64_" if dt == np.float64 else "mo32_"
     params = np.ascontiguousarray(params, dtype=dt)
     eps = np.asfortranarray(eps, dtype=dt)
     t_mean = np.ascontiguousarray(t_mean, dtype=dt)
     t_std = np.ascontiguousarray(t_std, dtype=dt)
-    grad = np.empty_like(params)
+    if grad is None:
+        grad = np.empty_like(params)
     if work is None:
         work = np.empty(2 * d * M, dtype=dt)
     v = getattr(lib, pfx + "estimate_gradient")(family, d, M, params.ctypes.data, eps.ctypes.data, t_mean.ctypes.data,
@@ -40,9 +41,9 @@ def estimate_gradient(lib, dtype, family, d, M, params, eps, t_mean, t_std, ent_
     return v, grad
 
 
-def fill_eps(lib, dtype, seed, idx, d, M, m_offset=0):
+def fill_eps(lib, dtype, seed, idx, d, M, m_offset=0, out=None):
     dt = np.dtype(dtype)
     pfx = "mo64_" if dt == np.float64 else "mo32_"
-    eps = np.empty((d, M), dtype=dt, order="F")
+    eps = np.empty((d, M), dtype=dt, order="F") if out is None else out
     getattr(lib, pfx + "fill_eps")(seed, idx, d, M, m_offset, eps.ctypes.data)
     return eps

@@ -15,7 +15,10 @@
  * Julia toolchain in the image); pinned against the numpy oracle in tests/test_oracle_c.py.
  *
  * Built twice by oracle/Makefile: -DREAL=double (mo64_*) and -DREAL=float (mo32_*).
- * OpenMP over samples / output columns; `mo*_set_threads` selects the thread count.
+ * OpenMP; `mo*_set_threads` selects the thread count.  The two full-rank contractions (tril(C) eps and tril(W eps')) run as
+ * packed, register-blocked panels (2 SIMD vectors of rows x 6 columns per micro-tile, operands packed so that every inner-loop
+ * load is contiguous), one row panel per OpenMP task, heaviest panels first: what a BLAS trmm / syrk-shaped kernel does, so the
+ * threads scale and the single-thread rate is a sane fraction of the core's FMA peak (bench.py prints GFLOP/s beside est/s).
  */
 #include <math.h>
 #include <stdint.h>
@@ -79,6 +82,29 @@ void FN(fill_eps)(uint64_t seed, uint64_t idx, int d, int M, int m_offset, REAL 
   }
 }
 
+/* ---- the register-blocked micro-tile of the two full-rank contractions ----
+ * out[n][v] = sum_k A[k][v] * B[k][n],  v < VL rows (two SIMD vectors), n < NB columns; A and B packed, 64-byte aligned. */
+typedef REAL vreal __attribute__((vector_size(32)));
+#define VW ((int)(32 / sizeof(REAL)))
+#define VL (2 * VW)
+#define NB 6
+static void micro_tile(int K, const REAL *A, const REAL *B, REAL *out) {
+  vreal c00 = {0}, c01 = {0}, c10 = {0}, c11 = {0}, c20 = {0}, c21 = {0}, c30 = {0}, c31 = {0}, c40 = {0}, c41 = {0}, c50 = {0}, c51 = {0};
+  for (int k = 0; k < K; ++k) {
+    const vreal a0 = *(const vreal *)(A + (size_t)k * VL), a1 = *(const vreal *)(A + (size_t)k * VL + VW);
+    const REAL *b = B + (size_t)k * NB;
+    c00 += a0 * b[0]; c01 += a1 * b[0];
+    c10 += a0 * b[1]; c11 += a1 * b[1];
+    c20 += a0 * b[2]; c21 += a1 * b[2];
+    c30 += a0 * b[3]; c31 += a1 * b[3];
+    c40 += a0 * b[4]; c41 += a1 * b[4];
+    c50 += a0 * b[5]; c51 += a1 * b[5];
+  }
+  vreal *o = (vreal *)out;
+  o[0] = c00; o[1] = c01; o[2] = c10; o[3] = c11; o[4] = c20; o[5] = c21;
+  o[6] = c30; o[7] = c31; o[8] = c40; o[9] = c41; o[10] = c50; o[11] = c51;
+}
+
 void FN(set_threads)(int n) {
 #ifdef _OPENMP
   if (n > 0) omp_set_num_threads(n);
@@ -119,26 +145,48 @@ double FN(estimate_gradient)(int family, int d, int M, const REAL *params, const
   const int stl = (ent_kind == 3 || ent_kind == 4);
   double sum_ell = 0.0, sum_he = 0.0;
 
-  /* z = scale*eps + mu   (location_scale.jl:71-87).  Full-rank: cache-blocked lower-triangular product, one
-   * 64-row block of C per task reused across every sample column (what a BLAS trmm would do). */
+  /* z = scale*eps + mu   (location_scale.jl:71-87).  Full-rank: Z = tril(C) eps by row panels of VL rows; the panel of C is
+   * packed [k][VL] with the entries above the diagonal zeroed, eps was packed [column block][k][NB] above. */
+  REAL *epsQ = NULL, *epsP = NULL;
+  const int nmb = (M + NB - 1) / NB, njb = (d + NB - 1) / NB, npan = (d + VL - 1) / VL;
   if (family == 1) {
-    const int RB = 64;
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int ib = (d + RB - 1) / RB - 1; ib >= 0; --ib) {
-      const int i0 = ib * RB, i1 = (i0 + RB < d) ? i0 + RB : d;
-      for (int m = 0; m < M; ++m) {
-        REAL *z = W + (size_t)m * d;
-        for (int i = i0; i < i1; ++i) z[i] = mu[i];
-      }
-      for (int k = 0; k < i1; ++k) {
-        const REAL *ck = C + (size_t)k * d;
-        const int is = k > i0 ? k : i0;
-        for (int m = 0; m < M; ++m) {
-          const REAL ek = eps[(size_t)m * d + k];
-          REAL *z = W + (size_t)m * d;
-          for (int i = is; i < i1; ++i) z[i] += ck[i] * ek;
+    epsQ = (REAL *)aligned_alloc(64, (((size_t)nmb * d * NB + (size_t)njb * M * NB) * sizeof(REAL) + 63) / 64 * 64);
+    epsP = epsQ + (size_t)nmb * d * NB;
+#pragma omp parallel
+    {
+#pragma omp for schedule(static) nowait
+      for (int mb = 0; mb < nmb; ++mb)          /* for the product: B[k][n] = eps[k, mb*NB + n] */
+        for (int k = 0; k < d; ++k)
+          for (int n = 0; n < NB; ++n) {
+            const int m = mb * NB + n;
+            epsQ[((size_t)mb * d + k) * NB + n] = m < M ? eps[(size_t)m * d + k] : (REAL)0;
+          }
+#pragma omp for schedule(static)
+      for (int jb = 0; jb < njb; ++jb)          /* for the VJP: B[m][n] = eps[jb*NB + n, m] */
+        for (int m = 0; m < M; ++m)
+          for (int n = 0; n < NB; ++n) {
+            const int j = jb * NB + n;
+            epsP[((size_t)jb * M + m) * NB + n] = j < d ? eps[(size_t)m * d + j] : (REAL)0;
+          }
+      REAL *Ap = (REAL *)aligned_alloc(64, ((size_t)d * VL * sizeof(REAL) + 63) / 64 * 64);
+      REAL out[NB * VL] __attribute__((aligned(64)));
+#pragma omp for schedule(dynamic, 1)
+      for (int p = npan - 1; p >= 0; --p) {
+        const int i0 = p * VL, K = (i0 + VL < d) ? i0 + VL : d;
+        for (int k = 0; k < K; ++k)
+          for (int v = 0; v < VL; ++v) {
+            const int i = i0 + v;
+            Ap[(size_t)k * VL + v] = (i < d && k <= i) ? C[(size_t)k * d + i] : (REAL)0;
+          }
+        for (int mb = 0; mb < nmb; ++mb) {
+          micro_tile(K, Ap, epsQ + (size_t)mb * d * NB, out);
+          for (int n = 0; n < NB && mb * NB + n < M; ++n) {
+            REAL *z = W + (size_t)(mb * NB + n) * d;
+            for (int v = 0; v < VL && i0 + v < d; ++v) z[i0 + v] = mu[i0 + v] + out[n * VL + v];
+          }
         }
       }
+      free(Ap);
     }
   }
   /* ell; W = grad log pi(z)   (repgradelbo.jl:84-86) */
@@ -183,34 +231,66 @@ double FN(estimate_gradient)(int family, int d, int M, const REAL *params, const
   const double value = -(sum_ell / M + tconst + ent);
   const double direct = direct_coeff(ent_kind), invM = 1.0 / M;
 
-  /* d/dmu = -(1/M) W 1 */
+  /* d/dmu = -(1/M) W 1: chunks of rows, the sample loop outermost inside a chunk (contiguous reads) */
 #pragma omp parallel for schedule(static)
-  for (int i = 0; i < d; ++i) {
-    double s = 0.0;
-    for (int m = 0; m < M; ++m) s += (double)W[(size_t)m * d + i];
-    grad[i] = (REAL)(-s * invM);
+  for (int c0 = 0; c0 < d; c0 += 64) {
+    double s[64];
+    const int nc = (c0 + 64 < d) ? 64 : d - c0;
+    for (int i = 0; i < nc; ++i) s[i] = 0.0;
+    for (int m = 0; m < M; ++m) {
+      const REAL *w = W + (size_t)m * d + c0;
+      for (int i = 0; i < nc; ++i) s[i] += (double)w[i];
+    }
+    for (int i = 0; i < nc; ++i) grad[c0 + i] = (REAL)(-s[i] * invM);
   }
   if (family == 0) {
 #pragma omp parallel for schedule(static)
-    for (int i = 0; i < d; ++i) {
-      double s = 0.0;
-      for (int m = 0; m < M; ++m) s += (double)W[(size_t)m * d + i] * (double)eps[(size_t)m * d + i];
-      grad[d + i] = (REAL)(-s * invM - direct / (double)C[i]);
+    for (int c0 = 0; c0 < d; c0 += 64) {
+      double s[64];
+      const int nc = (c0 + 64 < d) ? 64 : d - c0;
+      for (int i = 0; i < nc; ++i) s[i] = 0.0;
+      for (int m = 0; m < M; ++m) {
+        const REAL *w = W + (size_t)m * d + c0, *e = eps + (size_t)m * d + c0;
+        for (int i = 0; i < nc; ++i) s[i] += (double)w[i] * (double)e[i];
+      }
+      for (int i = 0; i < nc; ++i) grad[d + c0 + i] = (REAL)(-s[i] * invM - direct / (double)C[c0 + i]);
     }
   } else {
-    /* d/dC = -(1/M) tril(W eps') - direct diag(1/C_ii): column j accumulates rank-1 pieces */
-#pragma omp parallel for schedule(dynamic, 4)
-    for (int j = 0; j < d; ++j) {
-      REAL *gj = grad + d + (size_t)j * d;
-      for (int i = 0; i < d; ++i) gj[i] = 0;
-      for (int m = 0; m < M; ++m) {
-        const REAL ej = eps[(size_t)m * d + j];
-        const REAL *w = W + (size_t)m * d;
-        for (int i = j; i < d; ++i) gj[i] += w[i] * ej;
+    /* d/dC = -(1/M) tril(W eps') - direct diag(1/C_ii): row panels of VL rows of W packed [m][VL], column blocks of eps from the
+     * [column block][m][NB] pack; only the micro-tiles that touch the lower triangle are computed, the rest of the panel's rows
+     * is written as zeros */
+#pragma omp parallel
+    {
+      REAL *Wp = (REAL *)aligned_alloc(64, ((size_t)M * VL * sizeof(REAL) + 63) / 64 * 64);
+      REAL out[NB * VL] __attribute__((aligned(64)));
+#pragma omp for schedule(dynamic, 1)
+      for (int p = npan - 1; p >= 0; --p) {
+        const int i0 = p * VL, i1 = (i0 + VL < d) ? i0 + VL : d;
+        for (int m = 0; m < M; ++m)
+          for (int v = 0; v < VL; ++v) Wp[(size_t)m * VL + v] = (i0 + v < d) ? W[(size_t)m * d + i0 + v] : (REAL)0;
+        for (int jb = 0; jb < njb; ++jb) {
+          const int j0 = jb * NB;
+          if (j0 >= i1) {                                  /* wholly above the diagonal */
+            for (int n = 0; n < NB && j0 + n < d; ++n)
+              for (int i = i0; i < i1; ++i) grad[d + (size_t)(j0 + n) * d + i] = (REAL)0;
+            continue;
+          }
+          micro_tile(M, Wp, epsP + (size_t)jb * M * NB, out);
+          for (int n = 0; n < NB && j0 + n < d; ++n) {
+            const int j = j0 + n;
+            REAL *gj = grad + d + (size_t)j * d;
+            for (int i = i0; i < i1; ++i) {
+              if (i < j) { gj[i] = (REAL)0; continue; }
+              double x = -(double)out[n * VL + (i - i0)] * invM;
+              if (i == j) x -= direct / (double)C[(size_t)j * d + j];
+              gj[i] = (REAL)x;
+            }
+          }
+        }
       }
-      for (int i = j; i < d; ++i) gj[i] = (REAL)(-(double)gj[i] * invM);
-      gj[j] = (REAL)((double)gj[j] - direct / (double)C[(size_t)j * d + j]);
+      free(Wp);
     }
   }
+  free(epsQ);
   return value;
 }
