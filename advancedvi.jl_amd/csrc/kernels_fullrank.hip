@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_eps(SampleArgs<T> a) {
   __shared__ double red[4];
   eps_tile_block<T>(a, blockIdx.x, lds, red);
 }
-// lane-batched contexts (mivi_api.hip): the first draws of up to four contexts as ONE launch (blockIdx.y = lane)
+// lane-batched contexts (api_batch.hip): the first draws of up to four contexts as ONE launch (blockIdx.y = lane)
 struct EpsMulti { SampleArgs<float> lane[4]; };
 // -- in the BLOCKS of the product kernels' eps(t+1) riders (64 rows x 32 columns, one Philox block per thread, 256 contiguous bytes per
 // column, the same eight wave sums behind he_part): a lane's first draw is laid down exactly like all its later ones

@@ -925,7 +925,7 @@ __device__ __forceinline__ void fr_prod32_body(const Prod32Args &a) {
 }
 
 // one estimate per launch, and LANES: the same tiles for up to four independent estimates at once (blockIdx.y = lane; every lane its own
-// operands and outputs: the contexts of mivi_estimate_gradient_n's interleaved estimates, mivi_api.hip)
+// operands and outputs: the contexts of mivi_estimate_gradient_n's interleaved estimates, api_batch.hip)
 constexpr int kMaxLanes = 4;
 struct Prod32Multi { Prod32Args lane[kMaxLanes]; };
 template <int MODE, bool BF3>
@@ -1648,7 +1648,7 @@ void launch_lds_prod32(mivi_ctx *c, const void *params, int M, bool dense, int m
   }
   // riders hitch onto the tile workgroups; only the ones beyond the tile count get workgroups of their own
   grid = a.n_tiles > a.n_dinv + a.n_pack + a.n_eps ? a.n_tiles : a.n_dinv + a.n_pack + a.n_eps;
-  if (c->lane_sink) {   // lane-batched estimates (mivi_api.hip): record the launch, the driver issues it for all lanes at once
+  if (c->lane_sink) {   // lane-batched estimates (api_batch.hip): record the launch, the driver issues it for all lanes at once
     LaneSink &sk = ((LaneSink *)c->lane_sink)[c->lane_id];
     if (sk.n_prod < 2) { sk.prod[sk.n_prod] = a; sk.prod_grid[sk.n_prod] = grid; sk.prod_dense[sk.n_prod] = dense ? 1 : 0; }
     ++sk.n_prod;

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_stl_pack(int d, const float *C, unsigne
 // k slots: MFMA m (K = 32) takes rows 32 m .. 32 m + 31 of the block; lane group g = lane / 16 supplies rows
 // {32 m + 4 g + r} and {32 m + 16 + 4 g + r}, r < 4 -- exactly the rows an accumulator lane of tiles 2 m and 2 m + 1 holds.
 // -----------------------------------------------------------------------------------------------------------------
-constexpr int kStlMaxJobs = 12;   // three per context, four lane-batched contexts (mivi_api.hip)
+constexpr int kStlMaxJobs = 12;   // three per context, four lane-batched contexts (api_batch.hip)
 struct StlJob {
   int r0, nwg;           // the n x n system T = C[r0 : r0 + n, r0 : r0 + n]; workgroups of this job (16 right-hand-side columns each)
   const unsigned *pack;  // the packed operands of stl_dinv.h (pivot inverses, chain blocks, bulk blocks of both halves) of THIS job's scale matrix
@@ -492,7 +492,7 @@ void launch_stl2(mivi_ctx *c, const void *params, int M, bool dinv_done, const v
   StlUpdArgs u{};   // rows 0 .. n of W:  X1 = Y1 - F^T X2
   u.n_i = n; u.n_k = n; u.A = F; u.lda = n; u.X = Xb; u.ld_x = n; u.E = Y1; u.ld_e = n;
   u.R = Wout; u.ld_r = d; u.accumulate = overwrite ? 0 : 1; u.ncb = M / 32;
-  if (c->stl_sink) {   // lane-batched estimates (mivi_api.hip): record; the driver issues the lanes' solves and products as one launch each
+  if (c->stl_sink) {   // lane-batched estimates (api_batch.hip): record; the driver issues the lanes' solves and products as one launch each
     StlSink &sk = ((StlSink *)c->stl_sink)[c->lane_id];
     if (sk.n == 0) { sk.solve = s; sk.upd = u; sk.upd_grid = (n / 32) * (M / 32); }
     ++sk.n;

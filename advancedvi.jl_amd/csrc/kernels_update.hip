@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_value_funnel(int d, const T *params, Va
   __shared__ double red[6 * 4];
   finalize_value_block<T, 256, false, true>(d, vin, out, 2 * (int64_t)d, [params, d](int i) { return params[d + i]; }, red);
 }
-// lane-batched contexts (mivi_api.hip): the closing value kernels of up to four contexts as ONE launch (blockIdx.x = lane)
+// lane-batched contexts (api_batch.hip): the closing value kernels of up to four contexts as ONE launch (blockIdx.x = lane)
 struct ValueMulti { ValueIn vin[4]; OutArgs out[4]; };
 __global__ __launch_bounds__(256) void k_value_only_m(int d, int family, const float *params, ValueMulti m) {
   __shared__ double red[4 * 4];

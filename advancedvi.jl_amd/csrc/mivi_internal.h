@@ -427,7 +427,7 @@ void launch_lds_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, 
 bool lds_stein_ok(const mivi_ctx *c, int M);
 void launch_lds_stein_outer(mivi_ctx *c, int M, void *A, double *gsum, int first, double scale, double n, void *grad, void *logpi,
                             const ValueJob *self);
-void invalidate_graph(mivi_ctx *c);            // mivi_api.hip: drop the cached hipGraphExec and the eps speculation
+void invalidate_graph(mivi_ctx *c);            // api_core.hip: drop the cached hipGraphExec and the eps speculation
 
 // kernels_fullrank_batch.hip (f32, diagonal-Gaussian target, d % 128 == 0, M % 128 == 0): L estimates at the same parameters per launch
 bool fb_shape_ok(const mivi_ctx *c, int M);

@@ -32,6 +32,7 @@ SEED = 0x38BEF07CF9CC549D
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
 PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA peak (155 TF measured)
 PEAK_BF16_MFMA_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PEAK_VALU_GINST = 1024 * 2.4 / 4   # wave64 vector instructions per ns: 256 CUs x 4 SIMDs, one per 4 cycles, 2.4 GHz (MI355X_MICROARCH.md)
 
 # environment variables that do NOT change which kernels run: bench-harness controls and the RCCL library location
 BENCH_ENV_OK = {"MIVI_FORCE_DIST", "MIVI_DIST_MODE", "MIVI_DIST_EAGER", "MIVI_BENCH_SKIP_C3", "MIVI_RCCL_LIB", "MIVI_DIST_PIPELINE"}
@@ -76,6 +77,21 @@ def pmc_traffic(kernel_substr):
     return None
 
 
+def pmc_valu(kernel_substr):
+    """Wave-level VALU instruction count per launch of a kernel (SQ_INSTS_VALU, its own rocprofv3 --pmc pass: tools/pmc_valu.sh ->
+    profiles/pmc_valu.json)."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu.json")))
+    except (OSError, ValueError):
+        return None
+    for k, v in tab.get("kernels", {}).items():
+        if kernel_substr in k and "SQ_INSTS_VALU" in v:
+            return dict(insts_valu=v["SQ_INSTS_VALU"], insts_salu=v.get("SQ_INSTS_SALU"), waves=v.get("SQ_WAVES"),
+                        active_inst_valu_cycles=v.get("SQ_ACTIVE_INST_VALU"), busy_cycles=v.get("SQ_BUSY_CYCLES"),
+                        avg_ns_under_the_profiler=v.get("avg_ns"), source=tab.get("source"))
+    return None
+
+
 def rocprof_avg(kernel_substr, workload="ns"):
     """Average duration (us) of a kernel in the newest committed `rocprofv3 --kernel-trace --stats` summary of this workload's bench command
     (profiles/<tag>_<workload>_kernel_stats.md, written by tools/profile_round.sh): the in-chain figure -- launches of the timed region, other
@@ -112,14 +128,28 @@ def mf_roofline(ctx, params, cost, kernel_names=("k_mf_main<float>", "k_mf_sgd_l
                     frac=single["frac"], traffic=single["traffic"], algorithmic_bytes_per_launch=cost["bytes"],
                     avg_launch_us=single["avg_launch_us"]), {"mf_fused_main": ms1}
     ach = 100 * cost["bytes"] / (msl * 1e-3) / 1e9
-    return dict(bound="hbm", kernel=kernel_names[1], achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s",
-                frac=ach / PEAK_HBM_GBS, traffic=pmc_traffic("k_mf_funnel_loop" if "funnel" in kernel_names[1] else "k_mf_sgd_loop"),
-                algorithmic_bytes_per_launch=100 * cost["bytes"],
-                estimates_per_launch=100, avg_launch_us=msl * 1e3, single_call=single,
-                hbm_equivalent=True,
-                note=("HBM-EQUIVALENT of SURVEY 8d's algorithmic bytes: Z and G never exist in memory (the launch moves `traffic.bytes_per_launch`, "
-                      "about 1 % of them), so this fraction is not bounded by 1 -- the kernel is vector-ALU bound (Philox + Box-Muller + ten wave "
-                      "reductions per lane and estimate)")), {"mf_fused_main": ms1, "mf_loop_per_estimate": msl / 100}
+    loop_kernel = "k_mf_funnel_loop" if "funnel" in kernel_names[1] else "k_mf_sgd_loop"
+    hbm_eq = dict(achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, algorithmic_bytes_per_launch=100 * cost["bytes"],
+                  note=("HBM-EQUIVALENT of SURVEY 8d's algorithmic bytes: Z and G never exist in memory (the launch moves `traffic.bytes_per_launch`, "
+                        "about 1 % of them), so this fraction is not bounded by 1"))
+    valu = pmc_valu(loop_kernel)
+    times = {"mf_fused_main": ms1, "mf_loop_per_estimate": msl / 100}
+    if valu is None:
+        return dict(bound="valu", kernel=kernel_names[1], achieved=None, peak=PEAK_VALU_GINST, unit="G wave-instructions/s", frac=None,
+                    traffic=pmc_traffic(loop_kernel), estimates_per_launch=100, avg_launch_us=msl * 1e3, single_call=single, hbm_equivalent=hbm_eq,
+                    note="vector-ALU bound (Philox + Box-Muller + wave reductions); no profiles/pmc_valu.json with this kernel's SQ_INSTS_VALU: "
+                         "tools/pmc_valu.sh collects it"), times
+    # the kernel is vector-ALU bound: wave-level VALU instructions per launch (SQ_INSTS_VALU, own rocprofv3 pass) over the live launch time,
+    # against 1024 SIMDs x one wave64 instruction per 4 cycles x 2.4 GHz
+    g = valu["insts_valu"] / (msl * 1e-3) / 1e9
+    return dict(bound="valu", kernel=kernel_names[1], achieved=g, peak=PEAK_VALU_GINST, unit="G wave-instructions/s", frac=g / PEAK_VALU_GINST,
+                traffic=pmc_traffic(loop_kernel), estimates_per_launch=100, avg_launch_us=msl * 1e3, single_call=single,
+                valu_insts_per_launch=valu["insts_valu"], valu_insts_per_estimate=valu["insts_valu"] / 100.0,
+                valu_bound_us_per_estimate=valu["insts_valu"] / 100.0 / PEAK_VALU_GINST / 1e3, measured_us_per_estimate=msl * 1e3 / 100,
+                pmc=valu, hbm_equivalent=hbm_eq,
+                note=("vector-ALU roofline: SQ_INSTS_VALU per launch (profiles/pmc_valu.json; wave-level, every instruction priced at 4 cycles -- "
+                      "transcendentals and f64 cost more, so the true bound is tighter) / live launch time vs 1024 SIMDs / 4 cycles x 2.4 GHz; "
+                      "the HBM-equivalent of SURVEY 8d's algorithmic bytes is under hbm_equivalent")), times
 
 
 def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):

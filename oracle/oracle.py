@@ -545,7 +545,7 @@ def unpack_final(packed, d, family):
 
 
 def p2p_geometry(L, world):
-    """Restatement of the peer-to-peer exchange geometry (csrc/mivi_api.hip p2p_geometry, exported as mivi_p2p_geometry):
+    """Restatement of the peer-to-peer exchange geometry (csrc/api_dist.hip p2p_geometry, exported as mivi_p2p_geometry):
     slice length n (a multiple of 4, the two scalars L-2 / L-1 in ONE slice), chunk length cn, chunk count G, value-owner rank."""
     n = ((L + world - 1) // world + 3) & ~3
     while (L - 1) % n == 0:
