@@ -183,7 +183,7 @@ static int fb_lanes_max() {   // MIVI_FB_LANES: estimates per step (A/B; default
 }
 static bool fb_route(const mivi_ctx *c, const void *params, const void *grad_last, const void *grads_all) {
   return !c->is_child && c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && !c->bij_on && !c->idx_src && !c->dbg &&
-         c->target == TGT_DIAG_GAUSS && c->cfg.entropy != MIVI_ENT_STL && c->cfg.entropy != MIVI_ENT_STL_ZERO_GRAD &&
+         (c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS) && c->cfg.entropy != MIVI_ENT_STL && c->cfg.entropy != MIVI_ENT_STL_ZERO_GRAD &&
          fb_shape_ok(c, c->cfg.n_mc) && ((uintptr_t)params & 15) == 0 && ((uintptr_t)grad_last & 15) == 0 && ((uintptr_t)grads_all & 15) == 0;
 }
 // value_last / grad_last: the batch's LAST estimate (mivi_estimate_gradient_n's contract), or nullptr; values_all T[count] / grads_all
@@ -210,6 +210,20 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
     if ((s = ensure(c, t.grads, (size_t)L * plen * 4, true))) return s;
     t.cap_L = L;
     t.cap_M = M;
+    t.cap_LR = 0;
+  }
+  const bool dense = c->target == TGT_DENSE_GAUSS;
+  if (dense) {   // R = Z - m planes per lane; the planes of P once per target
+    if (t.cap_LR < L) {
+      invalidate_graph(c);
+      if ((s = ensure(c, t.RP, (size_t)L * fb_plane_words(c, M) * 4, false)) || (s = ensure(c, t.PA, fb_cplane_words(c) * 4, false))) return s;
+      t.cap_LR = L;
+      t.PA_valid = false;
+    }
+    if (!t.PA_valid) {
+      fb_launch_pplanes(c, c->stream);
+      t.PA_valid = true;
+    }
   }
   const FbTab *tabF = fb_prepare(c, M, L), *tabL = Llast != L ? fb_prepare(c, M, Llast) : tabF;
   if (Llast != L) tabF = fb_prepare(c, M, L);   // (re-resolve: four table slots, round robin)
@@ -226,6 +240,7 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
     if (values_all) { fs.values = (char *)values_all + (size_t)st * L * 4; fs.value_stride = 1; }
     else { fs.values = t.values.p; fs.value_stride = 1; }
     fs.lane_last = -1;
+    fs.dense = dense ? 1 : 0;
     if (st == steps - 1 && (value_last || grad_last)) { fs.lane_last = Llast - 1; fs.grad_last = grad_last; fs.value_last = value_last; }
     return fs;
   };
@@ -242,8 +257,9 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
   return MIVI_OK;
 }
 
-// Roofline leg of the batch engine: `reps` launches of each of a step's three kernels for `lanes` estimates, hipEvents on the context's
-// stream.  us_out[0..2] = average launch duration (us) of the draws, the product + target, the VJP (+ values).
+// Roofline leg of the batch engine: `reps` launches of each of a step's kernels for `lanes` estimates, hipEvents on the context's
+// stream.  us_out[0..3] = average launch duration (us) of the draws, the product (+ fused diagonal target), the VJP (+ values), the dense
+// target's product (0 with the diagonal target).
 mivi_status_t mivi_profile_batch(mivi_ctx_t *c, const void *params, int32_t lanes, int32_t reps, double *us_out) {
   if (!c || !params || lanes <= 0 || reps <= 0 || !us_out) return MIVI_ERR_BAD_ARG;
   (void)hipSetDevice(c->cfg.device);
@@ -258,14 +274,16 @@ mivi_status_t mivi_profile_batch(mivi_ctx_t *c, const void *params, int32_t lane
   fs.params = params; fs.M = c->cfg.n_mc; fs.L = lanes; fs.tab = tab;
   fs.rng = rng_of(c, 1);
   fs.grads = c->fb.grads.p; fs.grad_stride = (long long)mivi_params_len(c); fs.values = c->fb.values.p; fs.value_stride = 1; fs.lane_last = -1;
+  fs.dense = c->target == TGT_DENSE_GAUSS ? 1 : 0;
+  us_out[3] = 0.0;
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0));
   HIPCHK(c, hipEventCreate(&e1));
-  for (int which = 0; which < 3; ++which) {
+  for (int which = 0; which < (fs.dense ? 4 : 3); ++which) {
     for (int r = -2; r < reps; ++r) {
       if (r == 0) HIPCHK(c, hipEventRecord(e0, c->stream));
       if (which == 0) fb_launch_eps(c, fs, true, c->stream);
-      else fb_launch_compute(c, fs, c->stream, which == 1 ? 1 : 2);
+      else fb_launch_compute(c, fs, c->stream, which == 1 ? 1 : (which == 2 ? 2 : 4));
     }
     HIPCHK(c, hipEventRecord(e1, c->stream));
     HIPCHK(c, hipEventSynchronize(e1));

@@ -170,14 +170,14 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   {
-    DevBuf *fbb[] = {&c->fb.CA, &c->fb.epsP, &c->fb.epsV, &c->fb.WV, &c->fb.ell, &c->fb.he, &c->fb.ld, &c->fb.grads, &c->fb.values};
+    DevBuf *fbb[] = {&c->fb.CA, &c->fb.epsP, &c->fb.epsV, &c->fb.WV, &c->fb.ell, &c->fb.he, &c->fb.ld, &c->fb.grads, &c->fb.values, &c->fb.PA, &c->fb.RP};
     for (DevBuf *b : fbb)
       if (b->p) (void)hipFree(b->p);
     for (auto &tb : c->fb.tab) {
       if (tb.prod.p) (void)hipFree(tb.prod.p);
       if (tb.vjp.p) (void)hipFree(tb.vjp.p);
+      if (tb.prod2.p) (void)hipFree(tb.prod2.p);
     }
-
   }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
@@ -283,6 +283,7 @@ mivi_status_t mivi_set_target_dense_gauss(mivi_ctx_t *c, const void *mean, const
   if ((s = upload_vec(c, c->t_mean, m)) || (s = upload_vec(c, c->t_prec, P))) return s;
   c->t_const = -0.5 * logdet - 0.5 * d * kLog2Pi;
   c->target = TGT_DENSE_GAUSS;
+  c->fb.PA_valid = false;   // (the batch engine's planes of P)
   c->cap_M = 0;  // force (re)allocation of RT
   invalidate_graph(c);
   return MIVI_OK;

@@ -127,6 +127,11 @@ struct FbArgs {
   unsigned *epsP;                 // lane l: epsP + l * plane_stride; fragment (mb32, kg = row group) at (mb32 (d / 16) + kg) kFrag
   unsigned *epsV;                 // lane l: epsV + l * plane_stride; fragment (jb32, mg = sample group) at (jb32 (M / 16) + mg) kFrag
   unsigned *WV;                   // lane l: WV + l * plane_stride; fragment (rb32, mg) at (rb32 (M / 16) + mg) kFrag
+  // dense-Gaussian target: g = -P (z - m) is a second product per lane (k_fb_prod<MODE 2>) between the draw's product and the VJP
+  const float *t_prec;            // P, leading dimension dP
+  int dP;
+  unsigned *PA;                   // planes of P: fragment (rb32, kg), every kg < d / 16, at (rb32 (d / 16) + kg) kFrag (k_fb_pplanes)
+  unsigned *RP;                   // lane l: RP + l * plane_stride: R = Z - m as the second product's B operand, eps' product layout
   long long plane_stride;         // words per lane = d M / 512 * kFrag
   double *ell_part;               // lane l: ell_part + l * ell_stride; slots = k_fr_prod32's workgroup indices
   long long ell_stride;
@@ -185,6 +190,25 @@ __device__ __forceinline__ void fb_cplanes_frag(const FbArgs &a, int f, int lane
 }
 __global__ __launch_bounds__(256) void k_fb_cplanes(FbArgs a) {   // (stand-alone form: tools/ubench_fb.hip)
   fb_cplanes_frag(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// k_fb_pplanes: the dense-Gaussian target's precision matrix P as operand planes (every k group: P is full), one wave per fragment.
+// Once per target (the planes are kept until the target changes).
+__global__ __launch_bounds__(256) void k_fb_pplanes(FbArgs a) {
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+  const int d = a.d, ng = d >> 4;
+  const int rb = f / ng, kg = f % ng;
+  if (rb >= (d >> 5)) return;
+  const int row = 32 * rb + l31;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = a.t_prec[(size_t)(16 * kg + 8 * (e >> 2) + 4 * h + (e & 3)) * a.dP + row];   // (k_fr_prod32<G_DENSE>: A[row + k lda])
+  u32x4v uh, um, ul;
+  fb_split3(x, uh, um, ul);
+  unsigned *dst = a.PA + (size_t)f * kFrag + 4 * lane;
+  store16_wt(dst, uh);
+  store16_wt(dst + 256, um);
+  store16_wt(dst + 512, ul);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -286,8 +310,14 @@ using FbN = std::false_type;
 // -----------------------------------------------------------------------------------------------------------------
 // PF = 1: fragments of the next group prefetched into registers (ONE workgroup per CU, four ring slots); PF = 0: no register prefetch, three
 // ring slots, at most 128 registers: TWO workgroups per CU cover each other's barriers, read latencies, prologues and epilogues.
-template <int WJ, int PF>
+// MODE (k_fr_prod32's epilogue modes): FB_DIAG: the fused diagonal-Gaussian target, W planes + ell partials (R_DIAG);
+//   FB_DENSE_R: R = (mu + tril(C) eps) - m as the B-operand planes of the dense target's product (R_DENSE_R);
+//   FB_DENSE_G: the dense target's product itself, G = -P R: A = the planes of P over the WHOLE K range (every row block d / 32 sub-stages:
+//   runs of ceil(d / 256) for all of them), B = R's planes, epilogue g = -(P r), ell += r g / 2 (R_DENSE_G), W planes + ell partials.
+enum { FB_DIAG = 0, FB_DENSE_R = 1, FB_DENSE_G = 2 };
+template <int WJ, int PF, int MODE>
 __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbArgs a) {
+  constexpr bool kDG = MODE == FB_DENSE_G;
   constexpr int LDC = 36, NF = WJ, kPW = 3 * WJ;   // fragments / pieces this wave stages per group
   constexpr int NR = PF ? kRing : 3;
   __shared__ __attribute__((aligned(16))) unsigned lds[NR * kStageW + 3 * 128];
@@ -301,11 +331,11 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
   const int d = a.d, ng = d >> 4;
   const int row0 = rb * 128, col0 = cb * 128;
   const int R0 = row0 >> 5;               // first 32-row block of the tile
-  const int G = 2 * (R0 + 4);             // groups of the workgroup (the last row block's K)
-  if (tid < 128) {
+  const int G = kDG ? ng : 2 * (R0 + 4);  // groups of the workgroup (the last row block's K; the dense product: all of K)
+  if (tid < 128 && !kDG) {
     vec[tid] = a.params[row0 + tid];
     vec[128 + tid] = a.t_mean[row0 + tid];
-    vec[256 + tid] = a.t_istd[row0 + tid];
+    if (MODE == FB_DIAG) vec[256 + tid] = a.t_istd[row0 + tid];
   }
   // this wave's NF fragments of a stage (fragment f of the stage: f < 4: A fragment f; else B fragment f - 4; three 1 KiB pieces each)
   const unsigned *sp[NF];   // the stage the next issue takes
@@ -314,10 +344,10 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
   for (int f = 0; f < NF; ++f) {
     const int fs = NF * w + f, fr = fs & 3;
     if (fs < 4) {
-      sp[f] = a.CA + ((size_t)(R0 + fr) * ng) * kFrag + 4 * lane;
-      gmax[f] = 2 * (R0 + fr) + 3 < G - 1 ? 2 * (R0 + fr) + 3 : G - 1;
+      sp[f] = (kDG ? a.PA : a.CA) + ((size_t)(R0 + fr) * ng) * kFrag + 4 * lane;
+      gmax[f] = (!kDG && 2 * (R0 + fr) + 3 < G - 1) ? 2 * (R0 + fr) + 3 : G - 1;
     } else {
-      sp[f] = a.epsP + (size_t)ln * a.plane_stride + ((size_t)((col0 >> 5) + fr) * ng) * kFrag + 4 * lane;
+      sp[f] = (kDG ? a.RP : a.epsP) + (size_t)ln * a.plane_stride + ((size_t)((col0 >> 5) + fr) * ng) * kFrag + 4 * lane;
       gmax[f] = G - 1;
     }
   }
@@ -343,14 +373,14 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
   const int r32[2] = {R0 + 2 * wm, R0 + 2 * wm + 1};
   // k_fr_prod32's runs are chunks of ceil(nst / 8) sub-stages -- the same chunk for this wave's two row blocks (nst = r32[1] and r32[1] + 1,
   // the first odd): ONE fold schedule, every 2 rc groups
-  const int rc2 = 2 * ((r32[1] + 1 + 7) >> 3);
+  const int rc2 = kDG ? 2 * (((d >> 5) + 7) >> 3) : 2 * ((r32[1] + 1 + 7) >> 3);
   FB_STAMP(a, 0);
   FB_STAMP(a, 1);
   // A wave computes groups 0 .. Gw - 1 (its second row block's K range: a multiple of four groups) with BOTH row blocks, unconditionally:
   // one straight MFMA block per group (a choice between a full and a half group per iteration made the compiler copy the accumulators
   // behind every group, i.e. wait for the matrix pipe to drain).  The first row block ends two groups earlier: k_fb_cplanes laid two zero
   // fragments behind its diagonal block, so its chain adds exact zeros there.
-  const int Gw = 2 * r32[1] + 2;
+  const int Gw = kDG ? G : 2 * r32[1] + 2;
   int gfold = rc2;   // the next run boundary (even: checked on even groups only)
   auto compute = [&](auto S, int g, const FbFrags<WJ> &F) {   // S = g mod kRing
     if (!MIVI_KNOCKED(a, 2)) fb_group<WJ>(F, acc);
@@ -435,6 +465,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
   if (MIVI_KNOCKED(a, 16)) { if (tot[0][0][0] == 123.f) a.ld_part[0] = tot[1][WJ - 1][3] + tot[0][0][2]; return; }
   float *Cs = reinterpret_cast<float *>(lds) + w * (32 * LDC);
   unsigned *WVl = a.WV + (size_t)ln * a.plane_stride;
+  unsigned *RPl = a.RP + (size_t)ln * a.plane_stride;
   double *ellp = a.ell_part + (size_t)ln * a.ell_stride;
   const int nrb = d >> 5, ncb = a.M >> 5, nmg = a.M >> 4;
   const bool xcd_slots = (nrb & 3) == 0 && (ncb & 1) == 0;   // (k_fr_prod32's block -> tile map)
@@ -442,7 +473,12 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int lr = 64 * wm + 32 * i;   // row offset inside the tile
-    const f32x4 mu = *(const f32x4 *)(vec + lr + ei4), tm = *(const f32x4 *)(vec + 128 + lr + ei4), tis = *(const f32x4 *)(vec + 256 + lr + ei4);
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, tm = mu, tis = mu;
+    if constexpr (!kDG) {
+      mu = *(const f32x4 *)(vec + lr + ei4);
+      tm = *(const f32x4 *)(vec + 128 + lr + ei4);
+      if constexpr (MODE == FB_DIAG) tis = *(const f32x4 *)(vec + 256 + lr + ei4);
+    }
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
       const int cb32 = (col0 >> 5) + WJ * wn + j;
@@ -456,39 +492,76 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
       for (int p = 0; p < 4; ++p) {   // pass p = wave p of k_fr_prod32's epilogue: columns 8 p .. 8 p + 7, rows ei4 .. ei4 + 3 per lane
         const int en = 8 * p + (lane >> 3);
         const f32x4 v = *(const f32x4 *)(Cs + en * LDC + ei4);
-        const f32x4 z = mu + v;
         float ell = 0.f;
         f32x4 wv;
+        if constexpr (MODE == FB_DIAG) {
+          const f32x4 z = mu + v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) wv[c] = diag_target_elem(z[c], tm[c], tis[c], ell);
-        *(f32x4 *)(Cs + en * LDC + ei4) = wv;   // the image becomes W[m][i]
-        const double sv = (double)wave_sum_f32(ell);
-        s = p ? s + sv : sv;
+          for (int c = 0; c < 4; ++c) wv[c] = diag_target_elem(z[c], tm[c], tis[c], ell);
+        } else if constexpr (MODE == FB_DENSE_R) {
+          const f32x4 z = mu + v;
+          wv = z - tm;
+        } else {
+          // r = (z - m)[rows ei4 .. + 3, column en] back from R's planes, exactly (hi + mid + lo; the pieces do not overlap): fragment
+          // (cb32, kg = 2 r32 + ei4 / 16), lane (en, h' = ei4 / 4 % 2), slots 4 (ei4 / 8 % 2) + c = the two words 2 (ei4 / 8 % 2) + {0, 1}
+          const unsigned *fr = RPl + ((size_t)cb32 * ng + 2 * r32[i] + (ei4 >> 4)) * kFrag + 4 * (en + 32 * ((ei4 >> 2) & 1)) + 2 * ((ei4 >> 3) & 1);
+          const uint2 qh = *(const uint2 *)fr, qm = *(const uint2 *)(fr + 256), ql = *(const uint2 *)(fr + 512);
+          const unsigned uh[2] = {qh.x, qh.y}, um[2] = {qm.x, qm.y}, ul[2] = {ql.x, ql.y};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const unsigned hh = (c & 1) ? (uh[c >> 1] & 0xFFFF0000u) : (uh[c >> 1] << 16), mm = (c & 1) ? (um[c >> 1] & 0xFFFF0000u) : (um[c >> 1] << 16),
+                           ll = (c & 1) ? (ul[c >> 1] & 0xFFFF0000u) : (ul[c >> 1] << 16);
+            const float r = (__builtin_bit_cast(float, hh) + __builtin_bit_cast(float, mm)) + __builtin_bit_cast(float, ll);
+            wv[c] = dense_target_elem(v[c], r, ell);
+          }
+        }
+        *(f32x4 *)(Cs + en * LDC + ei4) = wv;   // the image becomes W[m][i] (FB_DENSE_R: R[m][i])
+        if constexpr (MODE != FB_DENSE_R) {
+          const double sv = (double)wave_sum_f32(ell);
+          s = p ? s + sv : sv;
+        }
       }
-      s += 0.0;   // (k_fr_prod32 adds its four idle waves' zeros: -0.0 becomes +0.0 there)
-      if (lane == 0) {
-        const int rE = nrb - 1 - r32[i];
-        const int slot = xcd_slots ? ((rE & 3) + 4 * (cb32 & 1)) + 8 * ((rE >> 2) * (ncb >> 1) + (cb32 >> 1)) : rE * ncb + cb32;
-        ellp[slot] = s;
+      if constexpr (MODE != FB_DENSE_R) {
+        s += 0.0;   // (k_fr_prod32 adds its four idle waves' zeros: -0.0 becomes +0.0 there)
+        if (lane == 0) {
+          const int rE = nrb - 1 - r32[i];
+          const int slot = xcd_slots ? ((rE & 3) + 4 * (cb32 & 1)) + 8 * ((rE >> 2) * (ncb >> 1) + (cb32 >> 1)) : rE * ncb + cb32;
+          ellp[slot] = s;
+        }
       }
-      // W as the VJP's A fragments (rb32 = r32[i], mg = 2 cb32 + g2): lane (row l31, h), slots = samples 16 g2 + 8 (e / 4) + 4 h + e % 4
+      if constexpr (MODE == FB_DENSE_R) {
+        // R as the dense product's B fragments (mb32 = cb32, kg = 2 r32 + g2): lane (column l31, h), slots = rows 16 g2 + 8 (e / 4) + 4 h + e % 4
 #pragma unroll
-      for (int g2 = 0; g2 < 2; ++g2) {
-        float x[8];
+        for (int g2 = 0; g2 < 2; ++g2) {
+          const f32x4 x0 = *(const f32x4 *)(Cs + l31 * LDC + 16 * g2 + 4 * h), x1 = *(const f32x4 *)(Cs + l31 * LDC + 16 * g2 + 8 + 4 * h);
+          const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+          u32x4v uh, um, ul;
+          fb_split3(x, uh, um, ul);
+          unsigned *dst = RPl + ((size_t)cb32 * ng + 2 * r32[i] + g2) * kFrag + 4 * lane;
+          store16_wt(dst, uh);
+          store16_wt(dst + 256, um);
+          store16_wt(dst + 512, ul);
+        }
+      } else {
+        // W as the VJP's A fragments (rb32 = r32[i], mg = 2 cb32 + g2): lane (row l31, h), slots = samples 16 g2 + 8 (e / 4) + 4 h + e % 4
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = Cs[(16 * g2 + 8 * (e >> 2) + 4 * h + (e & 3)) * LDC + l31];
-        u32x4v uh, um, ul;
-        fb_split3(x, uh, um, ul);
-        unsigned *dst = WVl + ((size_t)r32[i] * nmg + 2 * cb32 + g2) * kFrag + 4 * lane;
-        store16_wt(dst, uh);
-        store16_wt(dst + 256, um);
-        store16_wt(dst + 512, ul);
+        for (int g2 = 0; g2 < 2; ++g2) {
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = Cs[(16 * g2 + 8 * (e >> 2) + 4 * h + (e & 3)) * LDC + l31];
+          u32x4v uh, um, ul;
+          fb_split3(x, uh, um, ul);
+          unsigned *dst = WVl + ((size_t)r32[i] * nmg + 2 * cb32 + g2) * kFrag + 4 * lane;
+          store16_wt(dst, uh);
+          store16_wt(dst + 256, um);
+          store16_wt(dst + 512, ul);
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is read before the next tile overwrites it
     }
   }
   FB_STAMP(a, 3);
-  if ((flags & 1) && wn == 0 && lane < 32) {   // log|det C| partials of this wave's two row blocks (lane 0's first column block carries the flag)
+  if (!kDG && (flags & 1) && wn == 0 && lane < 32) {   // log|det C| partials of this wave's two row blocks (lane 0's first column block carries the flag)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = 32 * r32[i] + lane;
@@ -844,9 +917,17 @@ const FbTab *fb_prepare(mivi_ctx *c, int M, int L) {
       for (int x = 0; x < 8; ++x)
         if (i < lx[x].size()) vjp.push_back(lx[x][i]);
   }
+  // the dense target's second product: every tile walks the whole K range (equal tiles); workgroup b runs on XCD b % 8 -- consecutive
+  // workgroups take different row panels of P, so that with eight (or a multiple of eight) row panels an XCD's L2 keeps ONE of them
+  std::vector<int4> prod2;
+  for (int l = 0; l < L; ++l)
+    for (int cb = 0; cb < ncb; ++cb)
+      for (int rb = 0; rb < nrb; ++rb) prod2.push_back(make_int4(l, rb | (cb << 16), 0, 0));
   fb_upload(t.prod, prod.data(), prod.size() * sizeof(int4));
   fb_upload(t.vjp, vjp.data(), vjp.size() * sizeof(int4));
-  if (!t.prod.p || !t.vjp.p) return nullptr;
+  fb_upload(t.prod2, prod2.data(), prod2.size() * sizeof(int4));
+  if (!t.prod.p || !t.vjp.p || !t.prod2.p) return nullptr;
+  t.n_prod2 = (int)prod2.size();
   t.n_prod = (int)prod.size();
   t.n_vjp = (int)vjp.size();
   t.L = L;
@@ -866,6 +947,9 @@ static FbArgs fb_args(mivi_ctx *c, const void *params, int M) {
   a.epsP = (unsigned *)t.epsP.p;
   a.epsV = (unsigned *)t.epsV.p;
   a.WV = (unsigned *)t.WV.p;
+  a.t_prec = (const float *)c->t_prec.p; a.dP = c->dP;
+  a.PA = (unsigned *)t.PA.p;
+  a.RP = (unsigned *)t.RP.p;
   a.plane_stride = (long long)fb_plane_words(c, M);
   a.ell_part = (double *)t.ell.p; a.ell_stride = (long long)(d / 32) * (M / 32);
   a.he_part = (double *)t.he.p; a.he_stride = (long long)(d / 64) * (M / 32);
@@ -886,8 +970,14 @@ void fb_launch_eps(mivi_ctx *c, const FbStep &s, bool with_cplanes, hipStream_t 
   const int ycp = with_cplanes ? (nf + 8 * gx - 1) / (8 * gx) : 0;
   hipLaunchKernelGGL(k_fb_eps, dim3(gx, L + ycp), dim3(512), 0, stream, a);
 }
-// product + target -> VJP (+ the lanes' values as extra workgroups of the VJP launch) on `stream`
-void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int which) {   // which: 3 both (default), 1 product only, 2 VJP only (profiling)
+// the dense-Gaussian target's precision matrix as operand planes (once per target: FbTables::PA_valid)
+void fb_launch_pplanes(mivi_ctx *c, hipStream_t stream) {
+  FbArgs a = fb_args(c, nullptr, c->cfg.n_mc);
+  const int nf = (c->cfg.d / 32) * (c->cfg.d / 16);
+  hipLaunchKernelGGL(k_fb_pplanes, dim3((nf + 3) / 4), dim3(256), 0, stream, a);
+}
+// product + target (dense target: product -> R, the target's product) -> VJP (+ the lanes' values as extra workgroups of the VJP launch) on `stream`
+void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int which) {   // which (profiling): bit 0 the draw's product, bit 1 the VJP, bit 2 the dense target's product; 7 = all (default)
   const FbTab &tb = *s.tab;
   FbArgs a = fb_args(c, s.params, s.M);
   a.L = s.L;
@@ -896,7 +986,13 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
   a.grad_last = (float *)s.grad_last; a.value_last = (float *)s.value_last; a.lane_last = s.lane_last;
   a.write_upper = s.write_upper;
   a.work = (const int4 *)tb.prod.p; a.n_work = tb.n_prod;
-  if (which & 1) hipLaunchKernelGGL((k_fb_prod<kWJ, kPFprod>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
+  if (s.dense) {
+    if (which & 1) hipLaunchKernelGGL((k_fb_prod<kWJ, kPFprod, FB_DENSE_R>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
+    a.work = (const int4 *)tb.prod2.p; a.n_work = tb.n_prod2;
+    if (which & 4) hipLaunchKernelGGL((k_fb_prod<kWJ, kPFprod, FB_DENSE_G>), dim3(tb.n_prod2), dim3(512 / kWJ), 0, stream, a);
+  } else if (which & 1) {
+    hipLaunchKernelGGL((k_fb_prod<kWJ, kPFprod, FB_DIAG>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
+  }
   a.work = (const int4 *)tb.vjp.p; a.n_work = tb.n_vjp;
   if (which & 2) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
 }

@@ -189,14 +189,16 @@ struct DevBuf {
 
 // third-generation batch engine (kernels_fullrank_batch.hip): work tables per lane count, per-lane work buffers (base + lane * stride)
 struct FbTab {
-  DevBuf prod, vjp;
-  int n_prod = 0, n_vjp = 0, L = 0, M = 0;
+  DevBuf prod, vjp, prod2;                // work tables: the draw's product, the VJP, the dense target's product
+  int n_prod = 0, n_vjp = 0, n_prod2 = 0, L = 0, M = 0;
 };
 struct FbTables {
   FbTab tab[4];                           // per lane count (the full step's, the last shorter step's, other batch lengths'), round robin
   int next_tab = 0;
   DevBuf CA, epsP, epsV, WV, ell, he, ld, grads, values;   // operand planes (tril(C) once per call; eps in both orientations and W per lane)
-  int cap_L = 0, cap_M = 0;
+  DevBuf PA, RP;                          // dense-Gaussian target: planes of P (once per target), R = Z - m per lane
+  bool PA_valid = false;
+  int cap_L = 0, cap_M = 0, cap_LR = 0;
 };
 struct FbStep {
   const void *params;
@@ -207,6 +209,7 @@ struct FbStep {
   void *grad_last, *value_last;           // lane_last writes these instead (nullptr: none)
   int lane_last;
   int write_upper;                        // lanes write the exact zeros above the diagonal (0: their buffers hold them already)
+  int dense;                              // dense-Gaussian target: two products per lane
   const FbTab *tab;
 };
 
@@ -435,7 +438,8 @@ const FbTab *fb_prepare(mivi_ctx *c, int M, int L);   // work tables for L lanes
 size_t fb_plane_words(const mivi_ctx *c, int M);      // 4-byte words of one lane's operand planes (eps in one orientation, W)
 size_t fb_cplane_words(const mivi_ctx *c);            // ... of tril(C)'s
 void fb_launch_eps(mivi_ctx *c, const FbStep &s, bool with_cplanes, hipStream_t stream);   // a step's draws (+ tril(C)'s planes, once per call)
-void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int which = 3);  // product + target -> VJP + values (which: 1 / 2 = one of them)
+void fb_launch_pplanes(mivi_ctx *c, hipStream_t stream);
+void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int which = 7);  // product(s) + target -> VJP + values (which: bit 0 product, 1 VJP, 2 the dense target's product)
 
 // kernels_stl.hip (f32, d in {256, 512, 1024, 2048}, M % 32 == 0)
 bool stl2_shape_ok(const mivi_ctx *c, int M);

@@ -367,8 +367,9 @@ mivi_status_t mivi_p2p_exchange(mivi_ctx_t *ctx, const void *params_dev, const v
 mivi_status_t mivi_profile_dist(mivi_ctx_t *ctx, const void *params_dev, int32_t reps, double *us_host);
 
 /* Measurement hook of the batch engine (kernels_fullrank_batch.hip: what mivi_estimate_gradient_n / _each run for the full-rank family with the
- * diagonal-Gaussian target): `reps` launches of each of a step's three kernels for `lanes` estimates, hipEvents on the context's stream.
- * us_out[0..2] <- average launch duration in microseconds of {draws, product + target, VJP + values}.  bench.py's roofline leg. */
+ * diagonal- or dense-Gaussian target): `reps` launches of each of a step's kernels for `lanes` estimates, hipEvents on the context's stream.
+ * us_out[0..3] (double[4]) <- average launch duration in microseconds of {draws, product (+ the fused diagonal target), VJP + values, the dense
+ * target's product (0 with the diagonal target)}.  bench.py's roofline leg. */
 mivi_status_t mivi_profile_batch(mivi_ctx_t *ctx, const void *params_dev, int32_t lanes, int32_t reps, double *us_out);
 
 /* ---- measurement hook (bench.py roofline leg) --------------------------------------------------------- *

@@ -104,7 +104,42 @@ def test_other_entropy_estimators_and_values_only(ent):
     ref.close()
 
 
-@pytest.mark.parametrize("family,kind,ent,d,M", [(avi.MEANFIELD, "diag", 0, 200, 64), (avi.FULLRANK, "dense", 0, 128, 128),
+@pytest.mark.parametrize("d,M,n,ent", [(1024, 256, 20, 0), (256, 128, 37, 2), (128, 128, 5, 1)])
+def test_dense_gaussian_target_on_the_engine(d, M, n, ent):
+    """The dense-Gaussian target (g = -P (z - m): a second product per estimate, k_fb_prod<FB_DENSE_G> on the planes of P and of R = Z - m):
+    every estimate bitwise the single call's (k_fr_prod32<G_DENSE>'s runs and epilogue), values / gradients against the fp64 oracle."""
+    ctx, ref, params, tgt = _setup(d, M, ent, "dense")
+    assert ctx.profile_batch(ctx.to_device(params), 2, 1)["dense_product"] > 0.0        # (the configuration takes the engine)
+    p, pr = ctx.to_device(params), ref.to_device(params)
+    idx0 = 9
+    vals, grads = ctx.estimate_gradient_each(p, idx0, n)
+    ctx.synchronize()
+    vals, grads = vals.cpu().numpy(), grads.cpu().numpy()
+    p64 = params.astype(np.float64)
+    for i in range(n):
+        v1, g1 = ref.estimate_gradient(pr, idx0 + i)
+        ulps = 1 if ent == 2 else 0
+        assert abs(float(vals[i]) - float(v1.item())) <= ulps * float(np.spacing(np.float32(abs(float(v1.item()))))), i
+        assert np.array_equal(grads[i], g1.cpu().numpy()), i
+        if i in (0, n // 2, n - 1):
+            _, eps = ref.sample(pr, idx0 + i)
+            o = O.estimate_gradient(p64, d, avi.FULLRANK, tgt, eps.cpu().numpy().astype(np.float64), ent)
+            assert abs(float(vals[i]) - o["value"]) <= 1e-5 * abs(o["value"]), (i, float(vals[i]), o["value"])
+            assert np.linalg.norm(grads[i].astype(np.float64) - o["grad"]) <= 2e-5 * max(1.0, np.linalg.norm(o["grad"])), i
+    # a new target replaces the planes of P
+    rng = np.random.default_rng(77)
+    prob2, _ = make_problem(rng, "dense", d, np.float32)
+    ctx.set_problem(prob2)
+    ref.set_problem(prob2)
+    v_b, g_b = ctx.estimate_gradient_each(p, 3, 2)
+    v1, g1 = ref.estimate_gradient(pr, 4)
+    ctx.synchronize()
+    assert float(v_b.cpu().numpy()[1]) == float(v1.item()) and np.array_equal(g_b.cpu().numpy()[1], g1.cpu().numpy())
+    ctx.close()
+    ref.close()
+
+
+@pytest.mark.parametrize("family,kind,ent,d,M", [(avi.MEANFIELD, "diag", 0, 200, 64), (avi.FULLRANK, "dense", 0, 96, 64),
                                                  (avi.FULLRANK, "diag", 3, 128, 128), (avi.FULLRANK, "diag", 0, 96, 48),
                                                  (avi.MEANFIELD, "funnel", 3, 64, 32)])
 def test_generic_route_equals_single_calls(family, kind, ent, d, M):

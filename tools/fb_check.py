@@ -13,13 +13,13 @@ import advancedvi_jl_amd as avi  # noqa: E402
 from tests.helpers import SEED, make_family, make_problem  # noqa: E402
 
 
-def parity(shapes=((128, 128), (256, 128), (384, 256), (1024, 256)), counts=(1, 2, 3, 7, 20, 33, 52), ents=(0, 2)):
+def parity(shapes=((128, 128), (256, 128), (384, 256), (1024, 256)), counts=(1, 2, 3, 7, 20, 33, 52), ents=(0, 2), kind="diag"):
     bad = 0
     for d, M in shapes:
         for ent in ents:
             rng = np.random.default_rng(100 + d + M)
             q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
-            prob, _ = make_problem(rng, "diag", d, np.float32)
+            prob, _ = make_problem(rng, kind, d, np.float32)
             params, _ = avi.destructure(q)
             ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
             ctx.set_problem(prob)
@@ -60,15 +60,17 @@ def parity(shapes=((128, 128), (256, 128), (384, 256), (1024, 256)), counts=(1, 
                 idx += n + 1
             ctx.close()
             ref.close()
-            print(f"parity d={d} M={M} ent={ent}: done, mismatches so far {bad}", flush=True)
+            print(f"parity {kind} d={d} M={M} ent={ent}: done, mismatches so far {bad}", flush=True)
     return bad
 
 
-def timing(d=1024, M=256, counts=(20, 100), reps=200):
+def timing(d=1024, M=256, counts=(20, 100), reps=200, kind="diag"):
     import torch
     rng = np.random.default_rng(1)
     q = avi.FullRankGaussian(np.zeros(d, np.float32), np.eye(d, dtype=np.float32))
     prob = avi.DiagNormalProblem(np.full(d, 5.0, np.float32), np.ones(d, np.float32))
+    if kind == "dense":
+        prob, _ = make_problem(rng, "dense", d, np.float32)
     params, _ = avi.destructure(q)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
@@ -98,7 +100,7 @@ def timing(d=1024, M=256, counts=(20, 100), reps=200):
                 iso.append(time.perf_counter() - t1)
                 idx += n
             iso.sort()
-            print(f"timing n={n}: back-to-back {dt / reps / n * 1e6:.3f} us/estimate ({n * reps / dt:.0f} est/s); isolated median "
+            print(f"timing {kind} n={n}: back-to-back {dt / reps / n * 1e6:.3f} us/estimate ({n * reps / dt:.0f} est/s); isolated median "
                   f"{iso[len(iso) // 2] / n * 1e6:.3f} us/estimate, min {iso[0] / n * 1e6:.3f}", flush=True)
         ctx.close()
 
@@ -110,5 +112,10 @@ if __name__ == "__main__":
         print("PARITY", "OK" if b == 0 else f"FAILED ({b})")
     if "time" in what:
         timing()
+    if "parity_dense" in what:
+        b = parity(kind="dense", counts=(1, 2, 7, 20, 33), ents=(0, 2))
+        print("PARITY dense", "OK" if b == 0 else f"FAILED ({b})")
+    if "time_dense" in what:
+        timing(kind="dense")
     if "time100" in what:
         timing(counts=(100,), reps=20)

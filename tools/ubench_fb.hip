@@ -40,7 +40,7 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(k_fb_cplanes, dim3(((d / 32) * (d / 16) + 3) / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_fb_eps, dim3((d / 64) * (M / 32), L), dim3(512), 0, st, a);
     for (int r = 0; r < 4000; ++r) {
-      a.work = (const int4 *)tab->prod.p; a.n_work = tab->n_prod; hipLaunchKernelGGL((k_fb_prod<UB_WJ, UB_PF>), dim3(tab->n_prod), dim3(512 / UB_WJ), 0, st, a);
+      a.work = (const int4 *)tab->prod.p; a.n_work = tab->n_prod; hipLaunchKernelGGL((k_fb_prod<UB_WJ, UB_PF, FB_DIAG>), dim3(tab->n_prod), dim3(512 / UB_WJ), 0, st, a);
       a.work = (const int4 *)tab->vjp.p; a.n_work = tab->n_vjp; hipLaunchKernelGGL((k_fb_vjp<UB_WJ, UB_PF>), dim3(tab->n_vjp), dim3(512 / UB_WJ), 0, st, a);
     }
     CK(hipStreamSynchronize(st));
@@ -62,7 +62,7 @@ int main(int argc, char **argv) {
       for (int r = -3; r < reps; ++r) {
         if (r == 0) CK(hipEventRecord(e0, st));
         if (which == 0) hipLaunchKernelGGL(k_fb_eps, dim3((d / 64) * (M / 32), L), dim3(512), 0, st, a);
-        if (which == 1) { a.work = (const int4 *)tab->prod.p; a.n_work = tab->n_prod; hipLaunchKernelGGL((k_fb_prod<UB_WJ, UB_PF>), dim3(tab->n_prod), dim3(512 / UB_WJ), 0, st, a); }
+        if (which == 1) { a.work = (const int4 *)tab->prod.p; a.n_work = tab->n_prod; hipLaunchKernelGGL((k_fb_prod<UB_WJ, UB_PF, FB_DIAG>), dim3(tab->n_prod), dim3(512 / UB_WJ), 0, st, a); }
         if (which == 2) { a.work = (const int4 *)tab->vjp.p; a.n_work = tab->n_vjp; hipLaunchKernelGGL((k_fb_vjp<UB_WJ, UB_PF>), dim3(tab->n_vjp), dim3(512 / UB_WJ), 0, st, a); }
         if (which == 3) hipLaunchKernelGGL(k_fb_value, dim3(L), dim3(256), 0, st, a);
       }
@@ -76,7 +76,7 @@ int main(int argc, char **argv) {
       for (int which = 1; which <= 2; ++which) {
         for (int r = -3; r < reps; ++r) {
           if (r == 0) CK(hipEventRecord(e0, st));
-          if (which == 1) { a.work = (const int4 *)tab->prod.p; a.n_work = tab->n_prod; hipLaunchKernelGGL((k_fb_prod<UB_WJ, UB_PF>), dim3(tab->n_prod), dim3(512 / UB_WJ), 0, st, a); }
+          if (which == 1) { a.work = (const int4 *)tab->prod.p; a.n_work = tab->n_prod; hipLaunchKernelGGL((k_fb_prod<UB_WJ, UB_PF, FB_DIAG>), dim3(tab->n_prod), dim3(512 / UB_WJ), 0, st, a); }
           if (which == 2) { a.work = (const int4 *)tab->vjp.p; a.n_work = tab->n_vjp; hipLaunchKernelGGL((k_fb_vjp<UB_WJ, UB_PF>), dim3(tab->n_vjp), dim3(512 / UB_WJ), 0, st, a); }
         }
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms[which], e0, e1));
@@ -97,7 +97,7 @@ int main(int argc, char **argv) {
     const int n = which == 1 ? tab->n_prod : tab->n_vjp;
     a.work = (const int4 *)(which == 1 ? tab->prod.p : tab->vjp.p); a.n_work = n;
     CK(hipMemset(dbg, 0, (4096 * 8 + 8) * 8));
-    if (which == 1) hipLaunchKernelGGL((k_fb_prod<UB_WJ, UB_PF>), dim3(n), dim3(512 / UB_WJ), 0, st, a); else hipLaunchKernelGGL((k_fb_vjp<UB_WJ, UB_PF>), dim3(n), dim3(512 / UB_WJ), 0, st, a);
+    if (which == 1) hipLaunchKernelGGL((k_fb_prod<UB_WJ, UB_PF, FB_DIAG>), dim3(n), dim3(512 / UB_WJ), 0, st, a); else hipLaunchKernelGGL((k_fb_vjp<UB_WJ, UB_PF>), dim3(n), dim3(512 / UB_WJ), 0, st, a);
     CK(hipStreamSynchronize(st));
     CK(hipMemcpy(hd.data(), dbg, (4096 * 8 + 8) * 8, hipMemcpyDeviceToHost));
     printf("shader clock of block 0 over its main loop: %.0f MHz\n", (double)(hd[8 * 4096 + 2] - hd[8 * 4096 + 1]) / (double)(hd[2] - hd[1]) * 100.0);
