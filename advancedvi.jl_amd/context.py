@@ -302,10 +302,11 @@ class MiviContext:
 
     def profile_batch(self, params, lanes, reps):
         """Average launch duration (us) of the batch engine's kernels for `lanes` estimates (mivi_profile_batch):
-        dict(eps=.., product=.., vjp=.., dense_product=..) -- the last one 0 unless the target is the dense Gaussian."""
-        us = (C.c_double * 4)()
+        dict(eps=.., product=.., vjp=.., dense_product=.., stl_product=..) -- dense_product 0 unless the target is the dense Gaussian,
+        stl_product 0 unless the estimator is one of the sticking-the-landing ones."""
+        us = (C.c_double * 5)()
         self._chk(self.lib.mivi_profile_batch(self.h, self._p(params), int(lanes), int(reps), us))
-        return dict(eps=us[0], product=us[1], vjp=us[2], dense_product=us[3])
+        return dict(eps=us[0], product=us[1], vjp=us[2], dense_product=us[3], stl_product=us[4])
 
     # -- sharded finalisation / collective behind the ABI ----------------------------------------------------------
     def slice_len(self, world):

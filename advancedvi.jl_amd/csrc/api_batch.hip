@@ -181,9 +181,14 @@ static int fb_lanes_max() {   // MIVI_FB_LANES: estimates per step (A/B; default
   static const int v = getenv("MIVI_FB_LANES") ? atoi(getenv("MIVI_FB_LANES")) : 128;
   return v < 1 ? 1 : (v > 256 ? 256 : v);
 }
+static bool fb_stl_on() {   // MIVI_FB_STL=0: the sticking-the-landing estimators keep the lane-batched second-generation kernels + solves (A/B)
+  static const bool off = getenv("MIVI_FB_STL") && atoi(getenv("MIVI_FB_STL")) == 0;
+  return !off;
+}
 static bool fb_route(const mivi_ctx *c, const void *params, const void *grad_last, const void *grads_all) {
+  const bool stl = c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD;
   return !c->is_child && c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && !c->bij_on && !c->idx_src && !c->dbg &&
-         (c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS) && c->cfg.entropy != MIVI_ENT_STL && c->cfg.entropy != MIVI_ENT_STL_ZERO_GRAD &&
+         (c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS) && (!stl || (fb_stl_on() && stl2_shape_ok(c, c->cfg.d))) &&
          fb_shape_ok(c, c->cfg.n_mc) && ((uintptr_t)params & 15) == 0 && ((uintptr_t)grad_last & 15) == 0 && ((uintptr_t)grads_all & 15) == 0;
 }
 // value_last / grad_last: the batch's LAST estimate (mivi_estimate_gradient_n's contract), or nullptr; values_all T[count] / grads_all
@@ -225,6 +230,28 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
       t.PA_valid = true;
     }
   }
+  const bool stl = c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD;
+  if (stl) {
+    // W += C^-T eps: inside a call the parameters are fixed, so C^-T is formed ONCE -- the solve kernels (kernels_stl.hip) on the identity's d
+    // columns -- and the term is one more triangular product per lane (k_fb_prod<FB_STL_U>)
+    const size_t es = 4;
+    if (!t.Eye.p) {
+      std::vector<float> eye((size_t)d * d, 0.f);
+      for (int i = 0; i < d; ++i) eye[(size_t)i * d + i] = 1.f;
+      if ((s = ensure(c, t.Eye, (size_t)d * d * es, false))) return s;
+      HIPCHK(c, hipMemcpy(t.Eye.p, eye.data(), (size_t)d * d * es, hipMemcpyHostToDevice));
+    }
+    const bool grow = !t.Tinv.p || c->stl_X.bytes < ((size_t)d * d + (size_t)(d / 2) * (d / 2)) * es + 4096 || !c->stl_F.p;
+    if (grow) {
+      invalidate_graph(c);
+      if ((s = ensure(c, t.Tinv, (size_t)d * d * es, false)) || (s = ensure(c, t.TA, fb_cplane_words(c) * 4, false)) ||
+          (s = ensure(c, c->stl_X, ((size_t)d * d + (size_t)(d / 2) * (d / 2)) * es + 4096, false)) ||
+          (s = ensure(c, c->stl_F, mivi::stl_pack_units(d) * 4, false)))
+        return s;
+    }
+    launch_stl2(c, params, d, false, t.Eye.p, t.Tinv.p, true);
+    fb_launch_tplanes(c, c->stream);
+  }
   const FbTab *tabF = fb_prepare(c, M, L), *tabL = Llast != L ? fb_prepare(c, M, Llast) : tabF;
   if (Llast != L) tabF = fb_prepare(c, M, L);   // (re-resolve: four table slots, round robin)
   if (!tabF || !tabL) return fail(c, MIVI_ERR_HIP, "batch engine: work table allocation failed");
@@ -241,6 +268,7 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
     else { fs.values = t.values.p; fs.value_stride = 1; }
     fs.lane_last = -1;
     fs.dense = dense ? 1 : 0;
+    fs.stl = stl ? 1 : 0;
     if (st == steps - 1 && (value_last || grad_last)) { fs.lane_last = Llast - 1; fs.grad_last = grad_last; fs.value_last = value_last; }
     return fs;
   };
@@ -258,8 +286,8 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
 }
 
 // Roofline leg of the batch engine: `reps` launches of each of a step's kernels for `lanes` estimates, hipEvents on the context's
-// stream.  us_out[0..3] = average launch duration (us) of the draws, the product (+ fused diagonal target), the VJP (+ values), the dense
-// target's product (0 with the diagonal target).
+// stream.  us_out[0..4] = average launch duration (us) of the draws, the product (+ fused diagonal target), the VJP (+ values), the dense
+// target's product (0 with the diagonal target), the sticking-the-landing product (0 with the other estimators).
 mivi_status_t mivi_profile_batch(mivi_ctx_t *c, const void *params, int32_t lanes, int32_t reps, double *us_out) {
   if (!c || !params || lanes <= 0 || reps <= 0 || !us_out) return MIVI_ERR_BAD_ARG;
   (void)hipSetDevice(c->cfg.device);
@@ -275,15 +303,17 @@ mivi_status_t mivi_profile_batch(mivi_ctx_t *c, const void *params, int32_t lane
   fs.rng = rng_of(c, 1);
   fs.grads = c->fb.grads.p; fs.grad_stride = (long long)mivi_params_len(c); fs.values = c->fb.values.p; fs.value_stride = 1; fs.lane_last = -1;
   fs.dense = c->target == TGT_DENSE_GAUSS ? 1 : 0;
-  us_out[3] = 0.0;
+  fs.stl = (c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD) ? 1 : 0;
+  us_out[3] = us_out[4] = 0.0;
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0));
   HIPCHK(c, hipEventCreate(&e1));
-  for (int which = 0; which < (fs.dense ? 4 : 3); ++which) {
+  for (int which = 0; which < 5; ++which) {
+    if ((which == 3 && !fs.dense) || (which == 4 && !fs.stl)) continue;
     for (int r = -2; r < reps; ++r) {
       if (r == 0) HIPCHK(c, hipEventRecord(e0, c->stream));
       if (which == 0) fb_launch_eps(c, fs, true, c->stream);
-      else fb_launch_compute(c, fs, c->stream, which == 1 ? 1 : (which == 2 ? 2 : 4));
+      else fb_launch_compute(c, fs, c->stream, which == 1 ? 1 : (which == 2 ? 2 : (which == 3 ? 4 : 8)));
     }
     HIPCHK(c, hipEventRecord(e1, c->stream));
     HIPCHK(c, hipEventSynchronize(e1));

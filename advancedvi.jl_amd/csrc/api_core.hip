@@ -170,13 +170,14 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   {
-    DevBuf *fbb[] = {&c->fb.CA, &c->fb.epsP, &c->fb.epsV, &c->fb.WV, &c->fb.ell, &c->fb.he, &c->fb.ld, &c->fb.grads, &c->fb.values, &c->fb.PA, &c->fb.RP};
+    DevBuf *fbb[] = {&c->fb.CA, &c->fb.epsP, &c->fb.epsV, &c->fb.WV, &c->fb.ell, &c->fb.he, &c->fb.ld, &c->fb.grads, &c->fb.values, &c->fb.PA, &c->fb.RP, &c->fb.Tinv, &c->fb.TA, &c->fb.Eye};
     for (DevBuf *b : fbb)
       if (b->p) (void)hipFree(b->p);
     for (auto &tb : c->fb.tab) {
       if (tb.prod.p) (void)hipFree(tb.prod.p);
       if (tb.vjp.p) (void)hipFree(tb.vjp.p);
       if (tb.prod2.p) (void)hipFree(tb.prod2.p);
+      if (tb.prod3.p) (void)hipFree(tb.prod3.p);
     }
   }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);

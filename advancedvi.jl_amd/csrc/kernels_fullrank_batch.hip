@@ -132,6 +132,9 @@ struct FbArgs {
   int dP;
   unsigned *PA;                   // planes of P: fragment (rb32, kg), every kg < d / 16, at (rb32 (d / 16) + kg) kFrag (k_fb_pplanes)
   unsigned *RP;                   // lane l: RP + l * plane_stride: R = Z - m as the second product's B operand, eps' product layout
+  // sticking-the-landing estimators: W += C^-T eps with the INVERSE of the scale formed once per call (the parameters are fixed inside it)
+  const float *Tinv;              // C^-T, d x d, (row i, column k) at [i + k d], upper triangular (the solve kernels on the identity)
+  unsigned *TA;                   // its planes: fragment (rb32, kg), every kg, entries k < row zeroed (k_fb_tplanes)
   long long plane_stride;         // words per lane = d M / 512 * kFrag
   double *ell_part;               // lane l: ell_part + l * ell_stride; slots = k_fr_prod32's workgroup indices
   long long ell_stride;
@@ -206,6 +209,28 @@ __global__ __launch_bounds__(256) void k_fb_pplanes(FbArgs a) {
   u32x4v uh, um, ul;
   fb_split3(x, uh, um, ul);
   unsigned *dst = a.PA + (size_t)f * kFrag + 4 * lane;
+  store16_wt(dst, uh);
+  store16_wt(dst + 256, um);
+  store16_wt(dst + 512, ul);
+}
+
+// k_fb_tplanes: C^-T (upper triangular) as operand planes, one wave per fragment; the entries below the diagonal are exact zeros whatever
+// the solve left there.  Once per call.
+__global__ __launch_bounds__(256) void k_fb_tplanes(FbArgs a) {
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+  const int d = a.d, ng = d >> 4;
+  const int rb = f / ng, kg = f % ng;
+  if (rb >= (d >> 5)) return;
+  const int row = 32 * rb + l31;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 16 * kg + 8 * (e >> 2) + 4 * h + (e & 3);
+    x[e] = (kg >= 2 * rb && k >= row) ? a.Tinv[(size_t)k * d + row] : 0.f;
+  }
+  u32x4v uh, um, ul;
+  fb_split3(x, uh, um, ul);
+  unsigned *dst = a.TA + (size_t)f * kFrag + 4 * lane;
   store16_wt(dst, uh);
   store16_wt(dst + 256, um);
   store16_wt(dst + 512, ul);
@@ -314,10 +339,14 @@ using FbN = std::false_type;
 //   FB_DENSE_R: R = (mu + tril(C) eps) - m as the B-operand planes of the dense target's product (R_DENSE_R);
 //   FB_DENSE_G: the dense target's product itself, G = -P R: A = the planes of P over the WHOLE K range (every row block d / 32 sub-stages:
 //   runs of ceil(d / 256) for all of them), B = R's planes, epilogue g = -(P r), ell += r g / 2 (R_DENSE_G), W planes + ell partials.
-enum { FB_DIAG = 0, FB_DENSE_R = 1, FB_DENSE_G = 2 };
+//   FB_STL_U: the sticking-the-landing term, W += C^-T eps: A = the planes of C^-T (upper triangular: a tile's K range starts at its first
+//   row and runs to the end), B = eps' planes, epilogue: the lane's W planes read back, + U, split and stored again.  No counterpart among
+//   the one-estimate kernels (they SOLVE C^T X = eps, kernels_stl.hip): one chain over the tile's K range, results equal to the solve's to
+//   rounding (tests/test_gpu_each.py states the tolerance).
+enum { FB_DIAG = 0, FB_DENSE_R = 1, FB_DENSE_G = 2, FB_STL_U = 3 };
 template <int WJ, int PF, int MODE>
 __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbArgs a) {
-  constexpr bool kDG = MODE == FB_DENSE_G;
+  constexpr bool kDG = MODE == FB_DENSE_G, kSU = MODE == FB_STL_U;
   constexpr int LDC = 36, NF = WJ, kPW = 3 * WJ;   // fragments / pieces this wave stages per group
   constexpr int NR = PF ? kRing : 3;
   __shared__ __attribute__((aligned(16))) unsigned lds[NR * kStageW + 3 * 128];
@@ -331,8 +360,9 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
   const int d = a.d, ng = d >> 4;
   const int row0 = rb * 128, col0 = cb * 128;
   const int R0 = row0 >> 5;               // first 32-row block of the tile
-  const int G = kDG ? ng : 2 * (R0 + 4);  // groups of the workgroup (the last row block's K; the dense product: all of K)
-  if (tid < 128 && !kDG) {
+  const int g0 = kSU ? 2 * R0 : 0;        // first group of the K range
+  const int G = kDG ? ng : (kSU ? ng - g0 : 2 * (R0 + 4));  // groups of the workgroup (the last row block's K; the dense product: all of K)
+  if (tid < 128 && !kDG && !kSU) {
     vec[tid] = a.params[row0 + tid];
     vec[128 + tid] = a.t_mean[row0 + tid];
     if (MODE == FB_DIAG) vec[256 + tid] = a.t_istd[row0 + tid];
@@ -344,10 +374,10 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
   for (int f = 0; f < NF; ++f) {
     const int fs = NF * w + f, fr = fs & 3;
     if (fs < 4) {
-      sp[f] = (kDG ? a.PA : a.CA) + ((size_t)(R0 + fr) * ng) * kFrag + 4 * lane;
-      gmax[f] = (!kDG && 2 * (R0 + fr) + 3 < G - 1) ? 2 * (R0 + fr) + 3 : G - 1;
+      sp[f] = (kDG ? a.PA : (kSU ? a.TA : a.CA)) + ((size_t)(R0 + fr) * ng + g0) * kFrag + 4 * lane;
+      gmax[f] = (!kDG && !kSU && 2 * (R0 + fr) + 3 < G - 1) ? 2 * (R0 + fr) + 3 : G - 1;
     } else {
-      sp[f] = (kDG ? a.RP : a.epsP) + (size_t)ln * a.plane_stride + ((size_t)((col0 >> 5) + fr) * ng) * kFrag + 4 * lane;
+      sp[f] = (kDG ? a.RP : a.epsP) + (size_t)ln * a.plane_stride + ((size_t)((col0 >> 5) + fr) * ng + g0) * kFrag + 4 * lane;
       gmax[f] = G - 1;
     }
   }
@@ -373,14 +403,14 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
   const int r32[2] = {R0 + 2 * wm, R0 + 2 * wm + 1};
   // k_fr_prod32's runs are chunks of ceil(nst / 8) sub-stages -- the same chunk for this wave's two row blocks (nst = r32[1] and r32[1] + 1,
   // the first odd): ONE fold schedule, every 2 rc groups
-  const int rc2 = kDG ? 2 * (((d >> 5) + 7) >> 3) : 2 * ((r32[1] + 1 + 7) >> 3);
+  const int rc2 = kSU ? (1 << 30) : (kDG ? 2 * (((d >> 5) + 7) >> 3) : 2 * ((r32[1] + 1 + 7) >> 3));
   FB_STAMP(a, 0);
   FB_STAMP(a, 1);
   // A wave computes groups 0 .. Gw - 1 (its second row block's K range: a multiple of four groups) with BOTH row blocks, unconditionally:
   // one straight MFMA block per group (a choice between a full and a half group per iteration made the compiler copy the accumulators
   // behind every group, i.e. wait for the matrix pipe to drain).  The first row block ends two groups earlier: k_fb_cplanes laid two zero
   // fragments behind its diagonal block, so its chain adds exact zeros there.
-  const int Gw = kDG ? G : 2 * r32[1] + 2;
+  const int Gw = (kDG || kSU) ? G : 2 * r32[1] + 2;
   int gfold = rc2;   // the next run boundary (even: checked on even groups only)
   auto compute = [&](auto S, int g, const FbFrags<WJ> &F) {   // S = g mod kRing
     if (!MIVI_KNOCKED(a, 2)) fb_group<WJ>(F, acc);
@@ -474,6 +504,33 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
   for (int i = 0; i < 2; ++i) {
     const int lr = 64 * wm + 32 * i;   // row offset inside the tile
     f32x4 mu = {0.f, 0.f, 0.f, 0.f}, tm = mu, tis = mu;
+    if constexpr (kSU) {
+      // U's 32 x 32 tile (image [sample][row]) added to this wave's two W fragments in place
+#pragma unroll
+      for (int j = 0; j < WJ; ++j) {
+        const int cb32 = (col0 >> 5) + WJ * wn + j;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {tot[i][j][4 * q], tot[i][j][4 * q + 1], tot[i][j][4 * q + 2], tot[i][j][4 * q + 3]};
+          *(f32x4 *)(Cs + l31 * LDC + 8 * q + 4 * h) = v;
+        }
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+          unsigned *dst = WVl + ((size_t)r32[i] * nmg + 2 * cb32 + g2) * kFrag + 4 * lane;
+          const u32x4v wh = *(const u32x4v *)dst, wmid = *(const u32x4v *)(dst + 256), wl = *(const u32x4v *)(dst + 512);
+          float x[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = fb_unsplit(wh, wmid, wl, e) + Cs[(16 * g2 + 8 * (e >> 2) + 4 * h + (e & 3)) * LDC + l31];
+          u32x4v uh, um, ul;
+          fb_split3(x, uh, um, ul);
+          store16_wt(dst, uh);
+          store16_wt(dst + 256, um);
+          store16_wt(dst + 512, ul);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      continue;
+    }
     if constexpr (!kDG) {
       mu = *(const f32x4 *)(vec + lr + ei4);
       tm = *(const f32x4 *)(vec + 128 + lr + ei4);
@@ -561,7 +618,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
     }
   }
   FB_STAMP(a, 3);
-  if (!kDG && (flags & 1) && wn == 0 && lane < 32) {   // log|det C| partials of this wave's two row blocks (lane 0's first column block carries the flag)
+  if (!kDG && !kSU && (flags & 1) && wn == 0 && lane < 32) {   // log|det C| partials of this wave's two row blocks (lane 0's first column block carries the flag)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = 32 * r32[i] + lane;
@@ -923,10 +980,17 @@ const FbTab *fb_prepare(mivi_ctx *c, int M, int L) {
   for (int l = 0; l < L; ++l)
     for (int cb = 0; cb < ncb; ++cb)
       for (int rb = 0; rb < nrb; ++rb) prod2.push_back(make_int4(l, rb | (cb << 16), 0, 0));
+  // the sticking-the-landing product: the draw's product's tiles, the first row blocks (the longest K ranges there) first
+  std::vector<int4> prod3;
+  for (auto &li : lists) std::stable_sort(li.begin(), li.end(), [](const int4 &p, const int4 &q) { return (p.y & 0xffff) < (q.y & 0xffff); });
+  for (size_t i = 0; i < mx; ++i)
+    for (int x = 0; x < 8; ++x)
+      if (i < lists[x].size()) prod3.push_back(lists[x][i]);
   fb_upload(t.prod, prod.data(), prod.size() * sizeof(int4));
   fb_upload(t.vjp, vjp.data(), vjp.size() * sizeof(int4));
   fb_upload(t.prod2, prod2.data(), prod2.size() * sizeof(int4));
-  if (!t.prod.p || !t.vjp.p || !t.prod2.p) return nullptr;
+  fb_upload(t.prod3, prod3.data(), prod3.size() * sizeof(int4));
+  if (!t.prod.p || !t.vjp.p || !t.prod2.p || !t.prod3.p) return nullptr;
   t.n_prod2 = (int)prod2.size();
   t.n_prod = (int)prod.size();
   t.n_vjp = (int)vjp.size();
@@ -950,6 +1014,8 @@ static FbArgs fb_args(mivi_ctx *c, const void *params, int M) {
   a.t_prec = (const float *)c->t_prec.p; a.dP = c->dP;
   a.PA = (unsigned *)t.PA.p;
   a.RP = (unsigned *)t.RP.p;
+  a.Tinv = (const float *)t.Tinv.p;
+  a.TA = (unsigned *)t.TA.p;
   a.plane_stride = (long long)fb_plane_words(c, M);
   a.ell_part = (double *)t.ell.p; a.ell_stride = (long long)(d / 32) * (M / 32);
   a.he_part = (double *)t.he.p; a.he_stride = (long long)(d / 64) * (M / 32);
@@ -976,8 +1042,14 @@ void fb_launch_pplanes(mivi_ctx *c, hipStream_t stream) {
   const int nf = (c->cfg.d / 32) * (c->cfg.d / 16);
   hipLaunchKernelGGL(k_fb_pplanes, dim3((nf + 3) / 4), dim3(256), 0, stream, a);
 }
+// C^-T (t.Tinv, left there by the solve kernels on the identity) as operand planes: once per call
+void fb_launch_tplanes(mivi_ctx *c, hipStream_t stream) {
+  FbArgs a = fb_args(c, nullptr, c->cfg.n_mc);
+  const int nf = (c->cfg.d / 32) * (c->cfg.d / 16);
+  hipLaunchKernelGGL(k_fb_tplanes, dim3((nf + 3) / 4), dim3(256), 0, stream, a);
+}
 // product + target (dense target: product -> R, the target's product) -> VJP (+ the lanes' values as extra workgroups of the VJP launch) on `stream`
-void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int which) {   // which (profiling): bit 0 the draw's product, bit 1 the VJP, bit 2 the dense target's product; 7 = all (default)
+void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int which) {   // which (profiling): bit 0 the draw's product, bit 1 the VJP, bit 2 the dense target's product, bit 3 the sticking-the-landing product; 15 = all (default)
   const FbTab &tb = *s.tab;
   FbArgs a = fb_args(c, s.params, s.M);
   a.L = s.L;
@@ -992,6 +1064,10 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
     if (which & 4) hipLaunchKernelGGL((k_fb_prod<kWJ, kPFprod, FB_DENSE_G>), dim3(tb.n_prod2), dim3(512 / kWJ), 0, stream, a);
   } else if (which & 1) {
     hipLaunchKernelGGL((k_fb_prod<kWJ, kPFprod, FB_DIAG>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
+  }
+  if (s.stl && (which & 8)) {
+    a.work = (const int4 *)tb.prod3.p; a.n_work = tb.n_prod;
+    hipLaunchKernelGGL((k_fb_prod<kWJ, kPFprod, FB_STL_U>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
   }
   a.work = (const int4 *)tb.vjp.p; a.n_work = tb.n_vjp;
   if (which & 2) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);

@@ -189,7 +189,7 @@ struct DevBuf {
 
 // third-generation batch engine (kernels_fullrank_batch.hip): work tables per lane count, per-lane work buffers (base + lane * stride)
 struct FbTab {
-  DevBuf prod, vjp, prod2;                // work tables: the draw's product, the VJP, the dense target's product
+  DevBuf prod, vjp, prod2, prod3;         // work tables: the draw's product, the VJP, the dense target's product, the sticking-the-landing product
   int n_prod = 0, n_vjp = 0, n_prod2 = 0, L = 0, M = 0;
 };
 struct FbTables {
@@ -198,6 +198,7 @@ struct FbTables {
   DevBuf CA, epsP, epsV, WV, ell, he, ld, grads, values;   // operand planes (tril(C) once per call; eps in both orientations and W per lane)
   DevBuf PA, RP;                          // dense-Gaussian target: planes of P (once per target), R = Z - m per lane
   bool PA_valid = false;
+  DevBuf Tinv, TA, Eye;                   // sticking-the-landing estimators: C^-T (f32), its planes (once per call), the identity the solve takes
   int cap_L = 0, cap_M = 0, cap_LR = 0;
 };
 struct FbStep {
@@ -210,6 +211,7 @@ struct FbStep {
   int lane_last;
   int write_upper;                        // lanes write the exact zeros above the diagonal (0: their buffers hold them already)
   int dense;                              // dense-Gaussian target: two products per lane
+  int stl;                                // sticking-the-landing estimators: W += C^-T eps as one more product per lane
   const FbTab *tab;
 };
 
@@ -439,7 +441,8 @@ size_t fb_plane_words(const mivi_ctx *c, int M);      // 4-byte words of one lan
 size_t fb_cplane_words(const mivi_ctx *c);            // ... of tril(C)'s
 void fb_launch_eps(mivi_ctx *c, const FbStep &s, bool with_cplanes, hipStream_t stream);   // a step's draws (+ tril(C)'s planes, once per call)
 void fb_launch_pplanes(mivi_ctx *c, hipStream_t stream);
-void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int which = 7);  // product(s) + target -> VJP + values (which: bit 0 product, 1 VJP, 2 the dense target's product)
+void fb_launch_tplanes(mivi_ctx *c, hipStream_t stream);
+void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int which = 15);  // product(s) + target -> VJP + values (which: bit 0 product, 1 VJP, 2 the dense target's product, 3 the sticking-the-landing product)
 
 // kernels_stl.hip (f32, d in {256, 512, 1024, 2048}, M % 32 == 0)
 bool stl2_shape_ok(const mivi_ctx *c, int M);

@@ -368,8 +368,8 @@ mivi_status_t mivi_profile_dist(mivi_ctx_t *ctx, const void *params_dev, int32_t
 
 /* Measurement hook of the batch engine (kernels_fullrank_batch.hip: what mivi_estimate_gradient_n / _each run for the full-rank family with the
  * diagonal- or dense-Gaussian target): `reps` launches of each of a step's kernels for `lanes` estimates, hipEvents on the context's stream.
- * us_out[0..3] (double[4]) <- average launch duration in microseconds of {draws, product (+ the fused diagonal target), VJP + values, the dense
- * target's product (0 with the diagonal target)}.  bench.py's roofline leg. */
+ * us_out[0..4] (double[5]) <- average launch duration in microseconds of {draws, product (+ the fused diagonal target), VJP + values, the dense
+ * target's product (0 with the diagonal target), the sticking-the-landing product (0 with the other estimators)}.  bench.py's roofline leg. */
 mivi_status_t mivi_profile_batch(mivi_ctx_t *ctx, const void *params_dev, int32_t lanes, int32_t reps, double *us_out);
 
 /* ---- measurement hook (bench.py roofline leg) --------------------------------------------------------- *

@@ -376,7 +376,7 @@ def estimate_repgradelbo_forward(params, d, family, prob, eps, ent_kind, q_stop=
 
 
 def gaussian_expectation_gradient_and_hessian(q: MvLocationScale, prob, u: np.ndarray):
-    """gaussian_expectation_gradient_and_hessian!, first-order (Stein / Price) branch:
+    r"""gaussian_expectation_gradient_and_hessian!, first-order (Stein / Price) branch:
     src/algorithms/gauss_expected_grad_hess.jl:32-60.  `u` (d x n) are the standard-normal draws,
     z = C u + m; per sample the loop accumulates logpi/n, grad/n and u * (grad/n)'; finally
     hess = C' \ hess.  Returns (logpi_avg, grad (d), hess (d x d))."""

@@ -119,6 +119,11 @@ print('ok')
 
 CHAINS_NS = CHAINS.replace("d, M, n = 256, 128, 25", "d, M, n = 1024, 256, 23")   # the shape whose lane-batched launches are k_fr_prod32q / k_fr_vjp32s
 
+# the sticking-the-landing estimator at a shape whose batches take the engine by default (values: the Monte Carlo entropy's one-ulp note of tests/test_gpu_batches.py)
+CHAINS_STL = CHAINS_NS.replace("d, M, 0, SEED", "d, M, 3, SEED").replace(
+    "assert float(v.item()) == float(v1.item()) and", "assert abs(float(v.item()) - float(v1.item())) <= float(np.spacing(np.float32(abs(float(v1.item()))))) and")
+assert CHAINS_STL != CHAINS_NS and "M, 3, SEED" in CHAINS_STL
+
 F, MF = 1, 0
 CASES = [
     # switch, script, parameters
@@ -145,17 +150,19 @@ CASES = [
     ("MIVI_GRAPH_MIN=100", LOOP, dict(fam=F, d=128, M=128)),                                              # eager chain for every batch
     ("MIVI_STEIN_GEN1=1", STEIN, dict()),
     ("MIVI_BATCH_GEN3=0,MIVI_CHAINS=1", CHAINS, dict(kind="diag")),                                                         # one chain instead of interleaved ones
-    ("MIVI_CHAINS=4", CHAINS, dict(kind="dense")),                                                        # four contexts
+    ("MIVI_BATCH_GEN3=0,MIVI_CHAINS=4", CHAINS, dict(kind="dense")),                                                        # four contexts
     ("MIVI_BATCH_GEN3=0,MIVI_LANE_BATCH=0", CHAINS, dict(kind="diag")),                                                     # every context on a graph branch of its own (no lane-batched launches)
-    ("MIVI_LANE_BATCH=2", CHAINS, dict(kind="dense")),                                                    # two contexts per lane-batched launch
+    ("MIVI_BATCH_GEN3=0,MIVI_LANE_BATCH=2", CHAINS, dict(kind="dense")),                                                    # two contexts per lane-batched launch
     ("MIVI_BATCH_GEN3=0,MIVI_CHAINS=8", CHAINS, dict(kind="diag")),                                                         # eight contexts: two branches of four lanes
     ("MIVI_BATCH_GEN3=0,MIVI_PROD_QUAD=0", CHAINS_NS, dict(kind="diag")),                                                   # four lanes' products on k_fr_prod32's tiles (k_fr_prod32m)
     ("MIVI_BATCH_GEN3=0,MIVI_VJP_STRIP=0", CHAINS_NS, dict(kind="diag")),                                                   # one VJP tile per workgroup (k_fr_vjp32m)
-    ("MIVI_VJP_STRIP=5", CHAINS_NS, dict(kind="dense")),
+    ("MIVI_BATCH_GEN3=0,MIVI_VJP_STRIP=5", CHAINS_NS, dict(kind="dense")),
     ("MIVI_BATCH_GEN3=0,MIVI_STRIP_ROWS=1", CHAINS_NS, dict(kind="diag")),                                                  # strips dealt to the XCDs by block row                                                  # another strip length
     ("MIVI_BATCH_GEN3=0", CHAINS_NS, dict(kind="diag")),                                                  # the lane-batched second-generation kernels (k_fr_prod32q + k_fr_vjp32s) where the batch engine would run
     ("MIVI_FB_LANES=7", CHAINS, dict(kind="diag")),                                                       # batch engine: seven estimates per step (25 estimates: four steps, the last one shorter)
     ("MIVI_DUMMY_DEFAULT=1", CHAINS_NS, dict(kind="diag")),                                               # (no switch: the batch engine, one step)
+    ("MIVI_BATCH_GEN3=0", CHAINS_NS, dict(kind="dense")),                                                 # ... with the dense target (second product on k_fr_prod32m)
+    ("MIVI_FB_STL=0", CHAINS_STL, dict(kind="diag")),                                                     # sticking-the-landing batches: the lanes' solves instead of the engine's C^-T product -- bitwise the single calls'
     ("MIVI_DUMMY_DEFAULT=1", CHAINS, dict(kind="dense")),                                                 # (no switch: the default interleaving)                                                                 # first-generation accumulation kernel
 ]
 

@@ -129,7 +129,14 @@ def test_lane_batched_kernels_equal_single_calls_at_the_baseline_sizes(d, M, kin
         v1, g1 = ref.estimate_gradient(pr, idx + n - 1)
         ulps = 1 if ent == 3 else 0   # (the STL estimator's value holds sum(eps^2): see test_every_batch_length_equals_single_calls)
         assert abs(float(v.item()) - float(v1.item())) <= ulps * float(np.spacing(np.float32(abs(float(v1.item()))))), (n, float(v.item()), float(v1.item()))
-        assert np.array_equal(g.cpu().numpy(), g1.cpu().numpy()), n
+        if ent == 3 and d in (512, 1024, 2048):
+            # the batch engine forms C^-T once per call and multiplies (k_fb_prod<FB_STL_U>); a single call solves C^T X = eps: equal to
+            # rounding (both are 1-3e-7 from the fp64 oracle, tests/test_gpu_each.py), not bit for bit.  MIVI_FB_STL=0 keeps the solves in
+            # batches (bitwise: tests/test_gpu_ab_switches.py)
+            gb, gs = g.cpu().numpy().astype(np.float64), g1.cpu().numpy().astype(np.float64)
+            assert np.linalg.norm(gb - gs) <= 2e-6 * max(1.0, np.linalg.norm(gs)), (n, np.linalg.norm(gb - gs) / np.linalg.norm(gs))
+        else:
+            assert np.array_equal(g.cpu().numpy(), g1.cpu().numpy()), n
         idx += n
     ctx.close()
     ref.close()

@@ -139,6 +139,45 @@ def test_dense_gaussian_target_on_the_engine(d, M, n, ent):
     ref.close()
 
 
+@pytest.mark.parametrize("d,M,kind,ent", [(1024, 256, "diag", 3), (512, 128, "dense", 4), (256, 256, "diag", 4), (2048, 128, "diag", 3)])
+def test_sticking_the_landing_estimators_on_the_engine(d, M, kind, ent):
+    """StickingTheLandingEntropy / ...ZeroGradient (src/algorithms/entropy.jl:57-90): the extra term W += C^-T eps.  A single call solves
+    C^T X = eps (kernels_stl.hip); inside a batch the parameters are fixed, so the engine forms C^-T once per call (the same solve kernels on
+    the identity) and the term is one more triangular product per estimate.  Every estimate against the fp64 oracle (north-star tolerances:
+    value 1e-5, gradient 2e-5 relative) and against the single calls to rounding (values: the Monte Carlo entropy's one-ulp note above)."""
+    ctx, ref, params, tgt = _setup(d, M, ent, kind)
+    p, pr = ctx.to_device(params), ref.to_device(params)
+    assert ctx.profile_batch(p, 2, 1)["stl_product"] > 0.0        # (the configuration takes the engine)
+    n, idx0 = 9, 21
+    vals, grads = ctx.estimate_gradient_each(p, idx0, n)
+    ctx.synchronize()
+    vals, grads = vals.cpu().numpy(), grads.cpu().numpy()
+    p64 = params.astype(np.float64)
+    for i in range(n):
+        v1, g1 = ref.estimate_gradient(pr, idx0 + i)
+        assert abs(float(vals[i]) - float(v1.item())) <= float(np.spacing(np.float32(abs(float(v1.item()))))), i
+        gs = g1.cpu().numpy().astype(np.float64)
+        assert np.linalg.norm(grads[i] - gs) <= 2e-6 * max(1.0, np.linalg.norm(gs)), i
+        G = grads[i][d:].reshape(d, d)
+        assert not np.any(np.triu(G.T, 1)), i
+        if i in (0, n - 1):
+            _, eps = ref.sample(pr, idx0 + i)
+            o = O.estimate_gradient(p64, d, avi.FULLRANK, tgt, eps.cpu().numpy().astype(np.float64), ent)
+            assert abs(float(vals[i]) - o["value"]) <= 1e-5 * abs(o["value"]), i
+            assert np.linalg.norm(grads[i].astype(np.float64) - o["grad"]) <= 2e-5 * max(1.0, np.linalg.norm(o["grad"])), i
+    # other parameters in the next call: the inverse is formed again
+    params2 = params.copy()
+    params2[d:] *= 1.25
+    p2, pr2 = ctx.to_device(params2), ref.to_device(params2)
+    _, g_b = ctx.estimate_gradient_each(p2, 5, 3)
+    _, g1 = ref.estimate_gradient(pr2, 7)
+    ctx.synchronize()
+    gs = g1.cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(g_b.cpu().numpy()[2] - gs) <= 2e-6 * max(1.0, np.linalg.norm(gs))
+    ctx.close()
+    ref.close()
+
+
 @pytest.mark.parametrize("family,kind,ent,d,M", [(avi.MEANFIELD, "diag", 0, 200, 64), (avi.FULLRANK, "dense", 0, 96, 64),
                                                  (avi.FULLRANK, "diag", 3, 128, 128), (avi.FULLRANK, "diag", 0, 96, 48),
                                                  (avi.MEANFIELD, "funnel", 3, 64, 32)])

@@ -119,3 +119,70 @@ if __name__ == "__main__":
         timing(kind="dense")
     if "time100" in what:
         timing(counts=(100,), reps=20)
+
+
+def stl_check(shapes=((256, 128), (512, 256), (1024, 256), (2048, 128)), n=6):
+    """The sticking-the-landing estimators on the engine (W += C^-T eps through the explicit inverse, formed once per call) against the
+    single calls (which solve C^T X = eps) and against the fp64 oracle: relative l2 distances of the gradients."""
+    from oracle import oracle as O
+    for d, M in shapes:
+        for ent in (3, 4):
+            for kind in ("diag", "dense"):
+                if kind == "dense" and d > 1024:
+                    continue
+                rng = np.random.default_rng(7 + d + M)
+                q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
+                prob, tgt = make_problem(rng, kind, d, np.float32)
+                params, _ = avi.destructure(q)
+                ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
+                ctx.set_problem(prob)
+                ref = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
+                ref.set_problem(prob)
+                p, pr = ctx.to_device(params), ref.to_device(params)
+                vals, grads = ctx.estimate_gradient_each(p, 11, n)
+                ctx.synchronize()
+                vals, grads = vals.cpu().numpy(), grads.cpu().numpy()
+                worst = [0.0, 0.0, 0.0, 0.0]
+                for i in (0, n - 1):
+                    v1, g1 = ref.estimate_gradient(pr, 11 + i)
+                    g1 = g1.cpu().numpy().astype(np.float64)
+                    _, eps = ref.sample(pr, 11 + i)
+                    o = O.estimate_gradient(params.astype(np.float64), d, avi.FULLRANK, tgt, eps.cpu().numpy().astype(np.float64), ent)
+                    gb = grads[i].astype(np.float64)
+                    nrm = max(1.0, np.linalg.norm(o["grad"]))
+                    worst[0] = max(worst[0], np.linalg.norm(gb - g1) / nrm)
+                    worst[1] = max(worst[1], np.linalg.norm(gb - o["grad"]) / nrm)
+                    worst[2] = max(worst[2], np.linalg.norm(g1 - o["grad"]) / nrm)
+                    worst[3] = max(worst[3], abs(float(vals[i]) - o["value"]) / abs(o["value"]))
+                print(f"stl d={d} M={M} ent={ent} {kind}: batch-vs-single {worst[0]:.2e}  batch-vs-oracle {worst[1]:.2e}  single-vs-oracle {worst[2]:.2e}  "
+                      f"value-vs-oracle {worst[3]:.2e}  |grad| {nrm:.3e}", flush=True)
+                ctx.close()
+                ref.close()
+
+
+if __name__ == "__main__" and "stl" in sys.argv[1:]:
+    stl_check()
+    import torch  # noqa: F401
+    rng = np.random.default_rng(1)
+    d, M = 1024, 256
+    q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
+    prob, _ = make_problem(rng, "diag", d, np.float32)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 3, SEED)
+    ctx.set_problem(prob)
+    p = ctx.to_device(params)
+    v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+    for n in (20, 100):
+        idx = 0
+        for _ in range(5):
+            ctx.estimate_gradient_n(p, idx, n, v, g)
+            idx += n
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            ctx.estimate_gradient_n(p, idx, n, v, g)
+            idx += n
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"timing stl n={n}: {dt / 50 / n * 1e6:.3f} us/estimate ({50 * n / dt:.0f} est/s)")
+    print(ctx.profile_batch(p, 20, 20), ctx.profile_batch(p, 100, 10))
