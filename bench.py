@@ -61,6 +61,10 @@ def algorithmic_cost(w):
     return dict(bytes=(d * (d + 1) // 2) * s + d * d * s + 4 * d * M * s + 2 * d * s, flops=2 * d * d * M)
 
 
+for _k, _v in WORKLOADS.items():
+    _v["key"] = _k
+
+
 def pmc_traffic(kernel_substr):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     (profiles/pmc_traffic.json, produced by tools/pmc_traffic.py: separate passes, counters in KiB, the gfx950 FETCH_SIZE
@@ -72,8 +76,11 @@ def pmc_traffic(kernel_substr):
         return None
     for k, v in tab.get("kernels", {}).items():
         if kernel_substr in k:
-            return dict(bytes_per_launch=(v["fetch_kib"] + v["write_kib"]) * 1024.0, fetch_bytes=v["fetch_kib"] * 1024.0,
-                        write_bytes=v["write_kib"] * 1024.0, source=tab.get("source"))
+            out = dict(bytes_per_launch=(v["fetch_kib"] + v["write_kib"]) * 1024.0, fetch_bytes=v["fetch_kib"] * 1024.0,
+                       write_bytes=v["write_kib"] * 1024.0, source=tab.get("source"))
+            if "lanes_per_launch" in v:   # the batch engine: the profiled launches carried this many estimates
+                out["lanes_per_launch"] = v["lanes_per_launch"]
+            return out
     return None
 
 
@@ -207,27 +214,43 @@ def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):
     # timed loop).  The dominant launch is the headline of the block: lanes x the algorithmic flops per launch / its duration, measured live
     # (hipEvents around back-to-back launches on the launch stream: nothing runs beside these kernels in the timed region either, so the
     # stand-alone figure IS the in-chain one; `rocprof_in_chain` quotes the committed rocprofv3 summary of the bench command next to it).
-    if lanes and w["target"] == "iso":
+    if lanes and w["target"] in ("iso", "dense"):
         try:
             tb = ctx.profile_batch(params, lanes, max(5, reps // 10))
         except Exception:   # noqa: BLE001  -- configuration outside the batch engine
             tb = None
         if tb:
             for k, v in tb.items():
-                stages["batch_%s_%d_lanes" % (k, lanes)] = v * 1e-3
-            dk = "vjp" if tb["vjp"] >= tb["product"] else "product"
-            ok = "product" if dk == "vjp" else "vjp"
-            nm = {"product": "k_fb_prod (tril(C) [eps_1 .. eps_L] + fused target for all lanes of a step, operands as bf16 planes in MFMA-fragment order)",
-                  "vjp": "k_fb_vjp (tril(W_l eps_l') for all lanes of a step + their values)"}
-            sub = {"product": "k_fb_prod", "vjp": "k_fb_vjp"}
-            aL = lanes * fl / (tb[dk] * 1e-6) / 1e12
+                if v > 0.0:
+                    stages["batch_%s_%d_lanes" % (k, lanes)] = v * 1e-3
+            nm = {"product": "k_fb_prod<FB_DIAG> (tril(C) [eps_1 .. eps_L] + fused target for all lanes of a step, operands as bf16 planes in MFMA-fragment order)",
+                  "vjp": "k_fb_vjp (tril(W_l eps_l') for all lanes of a step + their values)",
+                  "dense_product": "k_fb_prod<FB_DENSE_G> (the dense target's -P (Z_l - m) for all lanes of a step)",
+                  "stl_product": "k_fb_prod<FB_STL_U> (W_l += C^-T eps_l for all lanes of a step, C^-T formed once per call)"}
+            if w["target"] == "dense":
+                nm["product"] = "k_fb_prod<FB_DENSE_R> (tril(C) [eps_1 .. eps_L] -> R = Z - m as operand planes)"
+            sub = {"product": "k_fb_prodILi1ELi1ELi%dE" % (1 if w["target"] == "dense" else 0), "vjp": "k_fb_vjp",
+                   "dense_product": "k_fb_prodILi1ELi1ELi2E", "stl_product": "k_fb_prodILi1ELi1ELi3E"}   # (mangled template arguments: WJ, PF, MODE)
+            kfl = {"product": fl, "vjp": fl, "dense_product": 2 * fl, "stl_product": fl}   # algorithmic flops per estimate of each launch
+            live = [k for k in ("product", "vjp", "dense_product", "stl_product") if tb.get(k, 0.0) > 0.0]
+            dk = max(live, key=lambda k: tb[k])
+            aL = lanes * kfl[dk] / (tb[dk] * 1e-6) / 1e12
+
+            def traffic_of(k):
+                t = pmc_traffic(sub[k])
+                if t and t.get("lanes_per_launch") and t["lanes_per_launch"] != lanes:   # profiled with another batch length: per-lane bytes scaled
+                    f = lanes / float(t["lanes_per_launch"])
+                    t = dict(t, bytes_per_launch=t["bytes_per_launch"] * f, fetch_bytes=t["fetch_bytes"] * f, write_bytes=t["write_bytes"] * f,
+                             scaled_from_lanes=t["lanes_per_launch"], lanes_per_launch=lanes)
+                return t
             keep = {k: roof[k] for k in ("kernel", "achieved", "frac", "traffic", "algorithmic_flops_per_launch", "avg_launch_us", "other_contraction")}
             if "single_launch" in roof:
                 keep = roof["single_launch"]
-            roof.update(kernel=nm[dk], achieved=aL, frac=aL / PEAK_F32_MFMA_TF, algorithmic_flops_per_launch=lanes * fl, estimates_per_launch=lanes,
-                        avg_launch_us=tb[dk], traffic=pmc_traffic(sub[dk]), rocprof_in_chain=rocprof_avg(sub[dk]),
-                        other_contraction=dict(kernel=nm[ok], avg_launch_us=tb[ok], achieved=lanes * fl / (tb[ok] * 1e-6) / 1e12,
-                                               rocprof_in_chain=rocprof_avg(sub[ok])),
+            others = [dict(kernel=nm[k], avg_launch_us=tb[k], achieved=lanes * kfl[k] / (tb[k] * 1e-6) / 1e12, rocprof_in_chain=rocprof_avg(sub[k], w.get("key", "ns")))
+                      for k in live if k != dk]
+            roof.update(kernel=nm[dk], achieved=aL, frac=aL / PEAK_F32_MFMA_TF, algorithmic_flops_per_launch=lanes * kfl[dk], estimates_per_launch=lanes,
+                        avg_launch_us=tb[dk], traffic=traffic_of(dk), rocprof_in_chain=rocprof_avg(sub[dk], w.get("key", "ns")),
+                        other_contraction=others[0] if len(others) == 1 else others,
                         draws=dict(kernel="k_fb_eps (Philox + Box-Muller draws of all lanes as operand planes in both orientations)", avg_launch_us=tb["eps"],
                                    algorithmic_bytes_per_launch=lanes * 12 * w["d"] * w["n_mc"],
                                    achieved_GBs=lanes * 12 * w["d"] * w["n_mc"] / (tb["eps"] * 1e-6) / 1e9,

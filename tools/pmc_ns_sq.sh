@@ -9,7 +9,7 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA
   i=$((i+1)); rm -rf /tmp/pmc_sq$i
   rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc_sq$i -o run -- python $REPO/bench.py --steps 200 --warmup 100 --no-cpu-baseline --no-also --concurrent 1 > /tmp/pmc_sq$i.log 2>&1
   db=$(find /tmp/pmc_sq$i -name '*.db' | head -1)
-  if [ -n "$db" ]; then python $REPO/tools/rocpd_pmc.py $db | grep -E "k_fr_prod32|k_fr_vjp32|^\| kernel|^\|---" >> $OUT/${TAG}_ns_pmc_sq.md; else echo "(pass $i: no database: $(tail -2 /tmp/pmc_sq$i.log))" >> $OUT/${TAG}_ns_pmc_sq.md; fi
+  if [ -n "$db" ]; then python $REPO/tools/rocpd_pmc.py $db | grep -E "k_fb_|k_fr_prod32|k_fr_vjp32|^\| kernel|^\|---" >> $OUT/${TAG}_ns_pmc_sq.md; else echo "(pass $i: no database: $(tail -2 /tmp/pmc_sq$i.log))" >> $OUT/${TAG}_ns_pmc_sq.md; fi
   echo >> $OUT/${TAG}_ns_pmc_sq.md
 done
 cat $OUT/${TAG}_ns_pmc_sq.md

@@ -16,7 +16,7 @@ def per_kernel(db, counter):
         acc.setdefault(k, []).append(v)
     return {k: sum(v) / len(v) for k, v in acc.items()}
 # which load flavour dominates a kernel's fetches
-PATTERN = (("k_fr_prod32", "lds16"), ("k_fr_prod64", "lds16"), ("k_fr_vjp32", "lds16"), ("k_fr_vjp64", "lds16"), ("k_stl_solve", "lds16"),
+PATTERN = (("k_fb_prod", "lds16"), ("k_fb_vjp", "lds16"), ("k_fr_prod32", "lds16"), ("k_fr_prod64", "lds16"), ("k_fr_vjp32", "lds16"), ("k_fr_vjp64", "lds16"), ("k_stl_solve", "lds16"),
            ("k_stl_update", "lds16"), ("k_lr_", "ld16"), ("k_p2p_exchange", "ld16"))
 # algorithmic KiB per launch at the north star (d = 1024, n_mc = 256, f32): in + out
 d, M = 1024, 256
@@ -26,6 +26,13 @@ ALGO = {"k_fr_prod32ILi0": _prod, "k_fr_vjp32ILb0": _vjp,
         # the lane-batched launches of the timed region: four estimates per launch (tril(C) is shared by the lanes)
         "k_fr_prod32mILi0": (d * (d + 1) // 2 * 4 + 4 * 3 * d * M * 4) / 1024.0, "k_fr_vjp32mILb0": 4 * _vjp,
         "k_fr_prod32q": (d * (d + 1) // 2 * 4 + 4 * 3 * d * M * 4) / 1024.0, "k_fr_vjp32s": 4 * _vjp}
+# the batch engine's launches (kernels_fullrank_batch.hip): FB_LANES estimates per launch in the profiled command (bench.py's default batch:
+# 100 estimates = one step); algorithmic bytes = SURVEY 8d's f32 figures per estimate (tril(C) shared by the lanes) -- the operand PLANES
+# these kernels actually move are 6 bytes per element and eps exists in two orientations: that is what traffic_over_algorithmic shows
+FB_LANES = int(os.environ.get("FB_LANES", "100"))
+ALGO_FB = {"k_fb_prod": (d * (d + 1) // 2 * 4 + FB_LANES * 2 * d * M * 4) / 1024.0,    # tril(C) + L x (eps in, W out)
+           "k_fb_vjp": FB_LANES * _vjp,                                              # L x (W + eps in, dense dC out)
+           "k_fb_eps": FB_LANES * (d * M * 4) / 1024.0}                              # L x eps out (not part of SURVEY 8d's bytes: the draw)
 cal = {}
 try:
     cal = json.load(open("profiles/pmc_calibration.json")).get("patterns", {})
@@ -43,6 +50,11 @@ for k in sorted(set(fetch) | set(write)):
          "load_pattern": pat, "fetch_correction": f, "write_correction": fw}
     for key, alg in ALGO.items():
         if key in k:
+            e["algorithmic_kib"] = alg
+            e["traffic_over_algorithmic"] = (e["fetch_kib"] + e["write_kib"]) / alg
+    for key, alg in ALGO_FB.items():
+        if key in k:
+            e["lanes_per_launch"] = FB_LANES
             e["algorithmic_kib"] = alg
             e["traffic_over_algorithmic"] = (e["fetch_kib"] + e["write_kib"]) / alg
     kern[k] = e
