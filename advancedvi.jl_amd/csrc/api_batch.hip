@@ -177,8 +177,12 @@ mivi_status_t ensure_kids(mivi_ctx *c, int lanes) {
 // ---- third-generation batch engine (kernels_fullrank_batch.hip) -------------------------------------------------------------------------
 // `count` estimates at the same parameters as steps of up to fb_lanes_max() LANES: a step is four launches (eps, product + target, VJP,
 // values) that cover all of its lanes.  No child contexts, no forked graph: a lane's buffers are base + lane * stride.
-static int fb_lanes_max() {   // MIVI_FB_LANES: estimates per step (A/B; default 128: the triangular product is paced by its heaviest tile, 36 us for ANY lane count up to ~40, so long batches take few, wide steps; 100-estimate batches: 4.26 us per estimate with 25-lane steps, 3.92 with one step)
-  static const int v = getenv("MIVI_FB_LANES") ? atoi(getenv("MIVI_FB_LANES")) : 128;
+static int fb_lanes_max() {
+  // MIVI_FB_LANES: estimates per step (A/B).  Per estimate (eps + product + VJP, tools/fb_lane_curve.py, north-star shape): 8 lanes 8.4 us,
+  // 20: 4.6, 32: 4.05, 48: 3.95, 80: 3.90, 100: 4.05, 128: 4.11 -- the triangular product is paced by its heaviest tile up to ~30 lanes, and
+  // beyond ~90 the step's planes (4.5 MB per lane) outgrow the 256 MB memory-side cache (the draws' writes slow down first).  So long batches
+  // are cut into equal steps of at most 80 lanes (100 estimates: two steps of 50).
+  static const int v = getenv("MIVI_FB_LANES") ? atoi(getenv("MIVI_FB_LANES")) : 80;
   return v < 1 ? 1 : (v > 256 ? 256 : v);
 }
 static bool fb_stl_on() {   // MIVI_FB_STL=0: the sticking-the-landing estimators keep the lane-batched second-generation kernels + solves (A/B)

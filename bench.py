@@ -257,6 +257,11 @@ def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):
                                    note="6 bytes per element and orientation written once: bound by the memory side and the vector ALU"),
                         timing="%d back-to-back launches of each kernel for %d lanes, hipEvents on the launch stream" % (max(5, reps // 10), lanes),
                         single_launch=keep)
+            # the pipe these products execute on: six bf16 MFMAs per f32-equivalent product block.  `frac` (f32-equivalent flops over the
+            # f32-MFMA peak, the yardstick of the north star) can exceed 1 on a kernel without triangular waste -- that is the point of the
+            # three-way split -- so the executed bf16 rate over the bf16 peak is quoted with it and bounds it
+            roof["bf16_pipe"] = dict(executed_TFLOPs=6 * aL, peak=PEAK_BF16_MFMA_TF, frac=6 * aL / PEAK_BF16_MFMA_TF,
+                                     note="bf16x3: six v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16 block; this fraction is <= 1 by construction")
             roof.pop("estimates_per_launch_note", None)
             ach = aL
     if gen and bf3:
@@ -601,7 +606,7 @@ def main():
             chunk = max(1, min(args.graph_chunk, K))
             use_graph = w["target"] != "logreg"
             if w["family"] == 1 and w["target"] == "iso" and w["entropy"] in (0, 1, 2):
-                launch_desc = (f"mivi_estimate_gradient_n x{chunk}: batch engine, {-(-chunk // 128)} step(s) of up to 128 estimates, per step three launches on one stream "
+                launch_desc = (f"mivi_estimate_gradient_n x{chunk}: batch engine, {-(-chunk // 80)} step(s) of up to 80 estimates, per step three launches on one stream "
                                f"(draws of all lanes as bf16 operand planes | product + fused target, 128 x 128 tiles, 8 waves | VJP + values); no graph, no side streams")
             elif use_graph:
                 launch_desc = f"mivi_estimate_gradient_n x{chunk} (one hipGraph / launch-free kernel per call)"
@@ -797,7 +802,7 @@ def main():
                          f32_mfma_TFs=cost["flops"] * est_per_s / world / 1e12 if w["family"] == 1 else None)
             # ---- capacity leg (NOT the headline): S independent contexts on S streams -------------------------
             # `value` above: K estimates at FIXED parameters, issued as batched calls of `chunk` estimates (mivi_estimate_gradient_n; the north
-            # star's family / target: the batch engine, three launches per step of up to 128 estimates -- config.launch).  What an optimiser
+            # star's family / target: the batch engine, three launches per step of up to 80 estimates -- config.launch).  What an optimiser
             # loop sees -- every estimate behind the previous update, one dependent chain -- is `also.ns_adam_loop`.
             conc = None
             if single and args.concurrent > 1 and w["target"] in ("iso", "dense"):

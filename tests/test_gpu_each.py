@@ -52,7 +52,7 @@ def test_every_estimate_of_a_north_star_batch(n):
 
 
 def test_two_engine_steps_and_the_last_estimate_entry():
-    """150 estimates = two steps of the engine (128 lanes per step at most): every value against single calls, the gradients of the
+    """150 estimates = two steps of the engine (80 lanes per step at most): every value against single calls, the gradients of the
     step boundaries, and mivi_estimate_gradient_n's contract (value / gradient of the LAST estimate) on the same batch."""
     d, M, ent = 256, 128, 0
     ctx, ref, params, _ = _setup(d, M, ent)

@@ -20,7 +20,7 @@ for w in ("c2", "c5"):
     try:
         for line in open(f"{out}/{tag}_{w}_pmc_valu.md"):
             c = [x.strip() for x in line.strip().strip("|").split("|")]
-            if len(c) >= 6 and c[0].startswith("`k_mf_"):
+            if len(c) >= 6 and "k_mf_" in c[0]:
                 k = c[0].strip("`")
                 tab.setdefault(k, {})[c[1]] = float(c[2])
                 tab[k]["avg_ns"] = float(c[5])
