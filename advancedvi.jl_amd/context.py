@@ -300,6 +300,10 @@ class MiviContext:
         self._chk(self.lib.mivi_profile_kernel(self.h, int(which), self._p(params), int(reps), C.byref(ms)))
         return ms.value
 
+    def batch_lanes(self, count):
+        """Estimates per launch the batch engine uses for a `count`-estimate call (mivi_batch_lanes)."""
+        return int(self.lib.mivi_batch_lanes(self.h, int(count)))
+
     def profile_batch(self, params, lanes, reps):
         """Average launch duration (us) of the batch engine's kernels for `lanes` estimates (mivi_profile_batch):
         dict(eps=.., product=.., vjp=.., dense_product=.., stl_product=..) -- dense_product 0 unless the target is the dense Gaussian,

@@ -289,6 +289,13 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
   return MIVI_OK;
 }
 
+// Lanes per step of a `count`-estimate batch on the batch engine (equal steps of at most MIVI_FB_LANES = 80): what a roofline leg must profile.
+int32_t mivi_batch_lanes(const mivi_ctx_t *c, int32_t count) {
+  if (!c || count <= 0) return 0;
+  const int Lmax = fb_lanes_max(), steps = (count + Lmax - 1) / Lmax;
+  return (count + steps - 1) / steps;
+}
+
 // Roofline leg of the batch engine: `reps` launches of each of a step's kernels for `lanes` estimates, hipEvents on the context's
 // stream.  us_out[0..4] = average launch duration (us) of the draws, the product (+ fused diagonal target), the VJP (+ values), the dense
 // target's product (0 with the diagonal target), the sticking-the-landing product (0 with the other estimators).

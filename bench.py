@@ -216,6 +216,7 @@ def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):
     # stand-alone figure IS the in-chain one; `rocprof_in_chain` quotes the committed rocprofv3 summary of the bench command next to it).
     if lanes and w["target"] in ("iso", "dense"):
         try:
+            lanes = ctx.batch_lanes(lanes) or lanes      # a call of `lanes` estimates runs as equal steps of this many lanes
             tb = ctx.profile_batch(params, lanes, max(5, reps // 10))
         except Exception:   # noqa: BLE001  -- configuration outside the batch engine
             tb = None
@@ -605,9 +606,11 @@ def main():
             value, grad = ctx.empty(1), ctx.empty(ctx.params_len)
             chunk = max(1, min(args.graph_chunk, K))
             use_graph = w["target"] != "logreg"
-            if w["family"] == 1 and w["target"] == "iso" and w["entropy"] in (0, 1, 2):
-                launch_desc = (f"mivi_estimate_gradient_n x{chunk}: batch engine, {-(-chunk // 80)} step(s) of up to 80 estimates, per step three launches on one stream "
-                               f"(draws of all lanes as bf16 operand planes | product + fused target, 128 x 128 tiles, 8 waves | VJP + values); no graph, no side streams")
+            if w["family"] == 1 and w["target"] in ("iso", "dense"):
+                Lstep = ctx.batch_lanes(chunk) or chunk
+                extra = (" | the dense target's product" if w["target"] == "dense" else "") + (" | the sticking-the-landing product (C^-T formed once per call)" if w["entropy"] in (3, 4) else "")
+                launch_desc = (f"mivi_estimate_gradient_n x{chunk}: batch engine, {-(-chunk // Lstep)} step(s) of {Lstep} estimates, per step one launch each on one stream: "
+                               f"draws of all lanes as bf16 operand planes | product (+ fused diagonal target), 128 x 128 tiles, 8 waves{extra} | VJP + values; no graph, no side streams")
             elif use_graph:
                 launch_desc = f"mivi_estimate_gradient_n x{chunk} (one hipGraph / launch-free kernel per call)"
             else:

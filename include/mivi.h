@@ -371,6 +371,8 @@ mivi_status_t mivi_profile_dist(mivi_ctx_t *ctx, const void *params_dev, int32_t
  * us_out[0..4] (double[5]) <- average launch duration in microseconds of {draws, product (+ the fused diagonal target), VJP + values, the dense
  * target's product (0 with the diagonal target), the sticking-the-landing product (0 with the other estimators)}.  bench.py's roofline leg. */
 mivi_status_t mivi_profile_batch(mivi_ctx_t *ctx, const void *params_dev, int32_t lanes, int32_t reps, double *us_out);
+/* Estimates per launch ("lanes" of a step) the batch engine uses for a `count`-estimate call: equal steps of at most 80 lanes. */
+int32_t mivi_batch_lanes(const mivi_ctx_t *ctx, int32_t count);
 
 /* ---- measurement hook (bench.py roofline leg) --------------------------------------------------------- *
  * Times `reps` back-to-back launches of ONE stage of the estimate with hipEvents recorded on the context's
