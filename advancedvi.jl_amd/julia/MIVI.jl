@@ -440,8 +440,19 @@ function estimate_gradient_dist!(state::MIVIState, params_dev::Ptr{Cvoid}, value
     return state
 end
 
+# `count` estimates at fixed parameters on device pointers: `estimate_gradient!` called `count` times without an update in between
+# (src/algorithms/repgradelbo.jl:151-177).  values_dev: T[count]; grads_dev: T[count * length(params)] or C_NULL (values only).
+# Full-rank Float32 with a native Gaussian target runs on libmivi's batch engine (DESIGN.md 3); every estimate equals the single call's.
+function estimate_gradient_each!(state::MIVIState, params_dev::Ptr{Cvoid}, count::Integer, values_dev::Ptr{Cvoid}, grads_dev::Ptr{Cvoid}=C_NULL)
+    check(state.ctx, ccall((:mivi_estimate_gradient_each, libmivi), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, UInt64, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
+                           state.ctx, params_dev, state.estimate_idx, Int32(count), values_dev, grads_dev))
+    state.estimate_idx += count
+    check(state.ctx, ccall((:mivi_synchronize, libmivi), Int32, (Ptr{Cvoid},), state.ctx))
+    return state
+end
+
 # ProximalLocationScaleEntropy on the host arrays works unchanged (src/optimization/proximal_location_scale_entropy.jl);
 # the device-resident variant for a parameter vector that lives in HBM is mivi_prox_scale_entropy.
 
-export AutoMIVI, NativeDiagNormal, NativeDenseNormal, NativeFunnel, NativeLogReg, native_logreg!, MIVITarget, set_bijector!, comm_unique_id, comm_init!, comm_enable_p2p!, comm_destroy!, estimate_gradient_dist!, estimate_gradient_dist_n!
+export AutoMIVI, NativeDiagNormal, NativeDenseNormal, NativeFunnel, NativeLogReg, native_logreg!, MIVITarget, set_bijector!, comm_unique_id, comm_init!, comm_enable_p2p!, comm_destroy!, estimate_gradient_dist!, estimate_gradient_dist_n!, estimate_gradient_each!
 end # module
