@@ -369,7 +369,12 @@ class MiviContext:
         return {0: "none", 1: "allreduce", 2: "rsag", 3: "p2p"}[int(self.lib.mivi_comm_route(self.h))]
 
     def p2p_exchange(self, params, partials, value, grad, phases=7):
-        self._chk(self.lib.mivi_p2p_exchange(self.h, self._p(params), self._p(partials), self._p(value), self._p(grad), int(phases)))
+        """partials = None: direct mode (p2p_partials_direct stored the vector into the owners' staging areas)."""
+        self._chk(self.lib.mivi_p2p_exchange(self.h, self._p(params), self._p(partials) if partials is not None else None, self._p(value),
+                                             self._p(grad), int(phases)))
+
+    def p2p_partials_direct(self, params, idx):
+        self._chk(self.lib.mivi_p2p_partials_direct(self.h, self._p(params), int(idx)))
 
     def estimate_gradient_dist_n(self, params, idx0, count, value, grad):
         self._chk(self.lib.mivi_estimate_gradient_dist_n(self.h, self._p(params), idx0, int(count), self._p(value), self._p(grad)))

@@ -224,6 +224,14 @@ mivi_status_t mivi_p2p_attach(mivi_ctx_t *c, const void *handles) {
       (s = ensure(c, c->p2p_scratch, ((size_t)mivi_params_len(c) + 4) * kGroup * kLanes * c->esize, false)))
     return s;
   HIPCHK(c, hipMemcpy(c->p2p_tab.p, &tab, sizeof(tab), hipMemcpyHostToDevice));
+  {   // what the partial kernels need to store straight into the owners' staging areas (OutArgs::p2p_direct)
+    P2PDirectTab dt{};
+    for (int r = 0; r < R; ++r) dt.stage[r] = tab.stage[0][r];
+    dt.n = c->p2p_n; dt.R = R; dt.rank = c->p2p_rank; dt.GV = kGroup;
+    if ((s = ensure(c, c->p2p_direct, sizeof(dt), false))) return s;
+    dt.ctr = (const unsigned *)c->p2p_ctr.p;
+    HIPCHK(c, hipMemcpy(c->p2p_direct.p, &dt, sizeof(dt), hipMemcpyHostToDevice));
+  }
   // (stream-ordered on the context's stream and waited for: a null-stream memset is NOT ordered against a non-blocking stream and
   //  would zero the epoch counter after the first exchange has advanced it)
   HIPCHK(c, hipMemsetAsync(c->p2p_ctr.p, 0, 512, c->stream));   // [lane] {epoch, ticket} at 64-byte spacing, ready at byte 256, freed[ring] at byte 320
@@ -374,7 +382,7 @@ static mivi_status_t dist_collective(mivi_ctx *c, const void *params, void *P, v
   const int route = mivi_comm_route(c);
   if (route == 3) {
     const void *Ps[1] = {P};
-    launch_p2p_exchange(c, params, Ps, 1, value, grad, 7, 0, 1, 1, nullptr, nullptr);
+    launch_p2p_exchange(c, params, Ps, 1, value, grad, 7, 0, 1, 1, nullptr, nullptr, c->dist_direct);
     HIPCHK(c, hipGetLastError());
     return MIVI_OK;
   }
@@ -419,6 +427,20 @@ static mivi_status_t dist_collective(mivi_ctx *c, const void *params, void *P, v
   return MIVI_OK;
 }
 
+// Direct staging (kernels_p2p.hip; DESIGN.md 7, cut (a)): on the peer-to-peer route the second-generation full-rank f32 kernels store every
+// entry of the partial vector straight into its owner's staging area -- no ring slot, no push pass.  OFF by default (MIVI_P2P_DIRECT=1
+// enables it): measured on one GPU (tools/dist_profile.py, north-star shape) the push pass it removes is worth 1.4 us of the exchange, but the
+// packed triangle's column segments are not 16-byte aligned, so the VJP epilogue's stores become 4-byte system-scope stores (partial kernels
+// 13.4 -> 17.2 us), and a staging slot is released only after the unpack (the compute chain runs one group ahead instead of two): serial step
+// 36.9 -> 38.5 us, pipelined batch 13.2 -> 20.0 us per estimate.  It pays once the packed layout pads every column to 16 bytes.
+static bool p2p_direct_ok(const mivi_ctx *c, const void *params) {
+  static const bool off = !(getenv("MIVI_P2P_DIRECT") && atoi(getenv("MIVI_P2P_DIRECT")) == 1);
+  if (off || !c->p2p_on || !c->p2p_direct.p || c->cfg.family != MIVI_FULLRANK || c->cfg.dtype != MIVI_F32 || c->dbg) return false;
+  OutArgs on{};
+  on.partials_mode = 1;
+  return lds_route(c, params, c->cfg.n_mc, 1, on);
+}
+
 static mivi_status_t dist_check(mivi_ctx *c) {
   if (c->comm_world > 1 && !c->comm && !c->p2p_on) return fail(c, MIVI_ERR_BAD_ARG, "mivi_comm_init has not been called");
   if (c->p2p_on && (c->p2p_world != c->comm_world || c->p2p_rank != c->comm_rank) && (c->comm || c->comm_world > 1))
@@ -434,7 +456,19 @@ mivi_status_t mivi_estimate_gradient_dist(mivi_ctx_t *c, const void *params, uin
   if (c->p2p_on && !c->comm) { c->comm_world = c->p2p_world; c->comm_rank = c->p2p_rank; }   // (peer-to-peer without RCCL)
   mivi_status_t s;
   if ((s = dist_check(c)) || (s = ensure_dist(c))) return s;
-  if ((s = mivi_estimate_partials(c, params, idx, c->dist_P.p))) return s;
+  c->dist_direct = mivi_comm_route(c) == 3 && p2p_direct_ok(c, params);
+  if (c->dist_direct) {   // the partial kernels store into the owners' staging areas (group 0, vector 0 of the exchange launched below)
+    if ((s = ensure_work(c, c->cfg.n_mc))) return s;
+    OutArgs o = final_out(c, nullptr, nullptr);
+    o.partials = c->dist_P.p;
+    o.partials_mode = 1;
+    o.scalars_off = mivi_partials_len(c) - 2;
+    o.p2p_direct = c->p2p_direct.p;
+    o.p2p_gi = 0; o.p2p_v = 0;
+    if ((s = run_estimate(c, params, rng_of(c, idx), c->cfg.n_mc, 1, o))) return s;
+  } else if ((s = mivi_estimate_partials(c, params, idx, c->dist_P.p))) {
+    return s;
+  }
   return dist_collective(c, params, c->dist_P.p, value, grad);
 }
 
@@ -475,6 +509,7 @@ static mivi_status_t dist_sequence_lanes(mivi_ctx *c, const void *params, bool c
       o.partials = ringP[i % kRing];
       o.partials_mode = 1;
       o.scalars_off = mivi_partials_len(c) - 2;
+      if (c->dist_direct) { o.p2p_direct = c->p2p_direct.p; o.p2p_gi = i / kGroup; o.p2p_v = i % kGroup; }
       if ((s = run_estimate(k, params, r, k->cfg.n_mc, 1, o))) { c->err = k->err; break; }
       if (lane_sink_counts(sink, l) != (dense ? 2 : 1) * 16 + 1) s = fail(c, MIVI_ERR_HIP, "lane-batched sharded estimates: an estimate did not take the two-kernel route");
     }
@@ -490,7 +525,7 @@ static mivi_status_t dist_sequence_lanes(mivi_ctx *c, const void *params, bool c
       const int nx = s0 + E + l;
       if (nx >= count) break;
       const int prev_users = nx / kRing;
-      if (prev_users >= 1) { fr[nf] = w + 80 + nx % kRing; fmin[nf] = (unsigned)prev_users * (unsigned)c->p2p_G; ++nf; }
+      if (prev_users >= 1) { fr[nf] = w + 80 + nx % kRing; fmin[nf] = (unsigned)prev_users * (unsigned)(c->p2p_G + (c->dist_direct ? 1 : 0)); ++nf; }   // (direct: the value workgroup releases a slot too)
     }
     launch_p2p_handover4(c, w + 64, (unsigned)(s0 + L), fr, fmin, nf);
   }
@@ -510,6 +545,17 @@ static mivi_status_t dist_sequence(mivi_ctx *c, const void *params, bool counter
   if (mode == 4 && c->dist_lane4) return dist_sequence_lanes(c, params, counter_idx, idx0, count);
   mivi_status_t s = MIVI_OK;
   hipStream_t main = c->stream;
+  if (mode == 3 && c->dist_direct) {   // exchange-only (a measurement leg): both parities of the staging areas hold a complete partial vector
+    for (int g2 = 0; g2 < 2 && s == MIVI_OK; ++g2) {
+      OutArgs o = final_out(c, nullptr, nullptr);
+      o.partials = c->dist_P.p;
+      o.partials_mode = 1;
+      o.scalars_off = mivi_partials_len(c) - 2;
+      o.p2p_direct = c->p2p_direct.p;
+      o.p2p_gi = g2; o.p2p_v = 0;
+      s = run_estimate(c, params, rng_of(c, idx0), c->cfg.n_mc, 1, o);
+    }
+  }
   for (int i = 0; i < count && s == MIVI_OK; ++i) {
     const int par = i & 1;
     void *ringP[kRing] = {c->dist_P.p, c->dist_P2.p, c->dist_ring[0].p, c->dist_ring[1].p, c->dist_ring[2].p, c->dist_ring[3].p, c->dist_ring[4].p, c->dist_ring[5].p};
@@ -522,6 +568,11 @@ static mivi_status_t dist_sequence(mivi_ctx *c, const void *params, bool counter
       o.partials = P;
       o.partials_mode = 1;
       o.scalars_off = mivi_partials_len(c) - 2;
+      if (c->dist_direct) {   // mode 4: the persistent exchange serves groups of kGroup estimates; modes 1 / 2: one exchange launch per estimate
+        o.p2p_direct = c->p2p_direct.p;
+        o.p2p_gi = mode == 4 ? i / kGroup : 0;
+        o.p2p_v = mode == 4 ? i % kGroup : 0;
+      }
       if ((s = run_estimate(c, params, r, c->cfg.n_mc, 1, o))) break;
     }
     if (mode == 2) continue;
@@ -530,7 +581,8 @@ static mivi_status_t dist_sequence(mivi_ctx *c, const void *params, bool counter
       const int slot = (i + 1) % kRing, prev_users = (i + 1) / kRing;
       // (folding this one-thread launch into the next estimate's product kernel as an extra workgroup was tried: the 8 us it takes from
       //  dispatch to completion beside the persistent exchange kernels moved into that kernel -- 9 + 8 -> 21.5 us --, the step stayed at 31 us)
-      launch_p2p_handover(c, w + 64, (unsigned)i + 1u, prev_users >= 1 ? w + 80 + slot : nullptr, (unsigned)prev_users * (unsigned)c->p2p_G);
+      launch_p2p_handover(c, w + 64, (unsigned)i + 1u, prev_users >= 1 ? w + 80 + slot : nullptr,
+                          (unsigned)prev_users * (unsigned)(c->p2p_G + (c->dist_direct ? 1 : 0)));
       continue;
     }
     if (mode == 0) {
@@ -588,6 +640,10 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
   const int route = mivi_comm_route(c);
   // Peer-to-peer route, pipelined: the exchange is ONE persistent kernel on comm_stream for the whole batch (kernels_p2p.hip), the compute
   // chain is a single-stream graph of {partial kernels, hand-over} per estimate; the two talk through two device words.
+  {
+    const bool direct = route == 3 && p2p_direct_ok(c, params);
+    if (c->dist_direct != direct) { invalidate_graph(c); c->dist_direct = direct; }
+  }
   bool p2p_pipe = mode == 0 && route == 3;
   if (p2p_pipe && c->p2p_pipe_state < 0) { p2p_pipe = false; mode = 1; }   // (its kernels did not run beside the compute chain on this context: serial steps)
   if (p2p_pipe) mode = 4;
@@ -653,7 +709,7 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
       hipStream_t cs = ln ? c->comm_stream2 : c->comm_stream;
       HIPCHK(c, hipStreamWaitEvent(cs, c->ev_part[0], 0));
       c->stream = cs;
-      launch_p2p_exchange(c, params, ringP, kRing, value, grad, 7, ln, lanes, count, w + 64, w + 80);
+      launch_p2p_exchange(c, params, ringP, kRing, value, grad, 7, ln, lanes, count, w + 64, w + 80, c->dist_direct);
       c->stream = main;
       HIPCHK(c, hipEventRecord(c->ev_comm[ln], cs));
     }
@@ -691,13 +747,33 @@ mivi_status_t mivi_estimate_gradient_dist_n(mivi_ctx_t *c, const void *params, u
 
 // tests: the phases of the peer-to-peer exchange one launch at a time (several ranks of ONE process driven from one host thread)
 mivi_status_t mivi_p2p_exchange(mivi_ctx_t *c, const void *params, const void *partials, void *value, void *grad, int32_t phases) {
-  if (!c || !params || !partials || !value || !grad || phases < 1 || phases > 7) return MIVI_ERR_BAD_ARG;
+  if (!c || !params || !value || !grad || phases < 1 || phases > 7) return MIVI_ERR_BAD_ARG;
   if (!c->p2p_on) return fail(c, MIVI_ERR_BAD_ARG, "no peer-to-peer exchange buffers attached");
   (void)hipSetDevice(c->cfg.device);
-  const void *Ps[1] = {partials};
-  launch_p2p_exchange(c, params, Ps, 1, value, grad, phases, 0, 1, 1, nullptr, nullptr);
+  const void *Ps[1] = {partials};   // NULL: direct mode -- mivi_p2p_partials_direct stored the vector into the owners' staging areas
+  launch_p2p_exchange(c, params, Ps, 1, value, grad, phases, 0, 1, 1, nullptr, nullptr, partials == nullptr);
   HIPCHK(c, hipGetLastError());
   return MIVI_OK;
+}
+
+// Tests: the partial kernels of ONE estimate in direct mode -- every entry of this rank's partial vector goes straight into its owner's
+// staging area, as vector 0 of the exchange launched next (mivi_p2p_exchange with partials = NULL).  Second-generation full-rank f32 route.
+mivi_status_t mivi_p2p_partials_direct(mivi_ctx_t *c, const void *params, uint64_t idx) {
+  if (!c || !params) return MIVI_ERR_BAD_ARG;
+  if (!c->p2p_on) return fail(c, MIVI_ERR_BAD_ARG, "no peer-to-peer exchange buffers attached");
+  (void)hipSetDevice(c->cfg.device);
+  if (c->target == TGT_NONE) return fail(c, MIVI_ERR_NO_TARGET, "no target set");
+  mivi_status_t s;
+  if ((s = ensure_work(c, c->cfg.n_mc)) || (s = ensure_dist(c))) return s;
+  OutArgs o = final_out(c, nullptr, nullptr);
+  o.partials = c->dist_P.p;
+  o.partials_mode = 1;
+  o.scalars_off = mivi_partials_len(c) - 2;
+  if (!c->p2p_direct.p || c->cfg.family != MIVI_FULLRANK || c->cfg.dtype != MIVI_F32 || !lds_route(c, params, c->cfg.n_mc, 1, o))
+    return fail(c, MIVI_ERR_UNSUPPORTED, "direct staging serves the second-generation full-rank f32 kernels");
+  o.p2p_direct = c->p2p_direct.p;
+  o.p2p_gi = 0; o.p2p_v = 0;
+  return run_estimate(c, params, rng_of(c, idx), c->cfg.n_mc, 1, o);
 }
 
 // us per estimate of the sharded step and of its pieces, every rank calling collectively: out[0] partial kernels, out[1] exchange +

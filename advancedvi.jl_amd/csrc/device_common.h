@@ -202,6 +202,38 @@ __device__ __forceinline__ void funnel_finish(int d, const FunnelFin &f, const O
   }
 }
 
+// Entry idx of this rank's partial vector (partials mode): into the ring slot out.partials, or -- peer-to-peer route, direct mode -- straight
+// into its OWNER's staging area: owner s = idx / n, place ((parity G_V + v) R + rank) n + (idx - s n) there (kernels_p2p.hip's layout), as a
+// system-scope write-through store.  f32 only (the second-generation full-rank kernels).
+struct PartialDst {
+  float *flat;
+  const P2PDirectTab *tab;
+  long long n, off;
+  float inv_n;
+};
+__device__ __forceinline__ PartialDst partial_dst(const OutArgs &out) {
+  PartialDst pd;
+  pd.flat = (float *)out.partials;
+  pd.tab = (const P2PDirectTab *)out.p2p_direct;
+  pd.n = 1; pd.off = 0; pd.inv_n = 1.f;
+  if (pd.tab) {
+    const unsigned epoch = __hip_atomic_load(pd.tab->ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u + (unsigned)out.p2p_gi;
+    pd.n = pd.tab->n;
+    pd.off = ((long long)((int)(epoch & 1u) * pd.tab->GV + out.p2p_v) * pd.tab->R + pd.tab->rank) * pd.n;
+    pd.inv_n = 1.f / (float)pd.n;
+  }
+  return pd;
+}
+__device__ __forceinline__ void partial_store(const PartialDst &pd, long long idx, float v) {
+  if (!pd.tab) { pd.flat[idx] = v; return; }
+  int s = (int)((float)idx * pd.inv_n);
+  if (s > pd.tab->R - 1) s = pd.tab->R - 1;
+  while ((long long)s * pd.n > idx) --s;
+  while ((long long)(s + 1) * pd.n <= idx) ++s;
+  float *dst = (float *)pd.tab->stage[s] + pd.off + (idx - (long long)s * pd.n);
+  __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // One whole workgroup (NT threads) assembles the objective value (or the two scalar partials).
 //   value = -( sum_ell / M_total + entropy_estimate )
 //   closed-form estimators: d/2 (1 + log 2pi) + sum_i log C_ii            location_scale.jl:52-57
@@ -259,10 +291,16 @@ __device__ void finalize_value_block(int d, const ValueIn &vin, const OutArgs &o
   if (tid == 0) {
     const double sum_ell = s_ell + (double)out.M_local * vin.ell_const;
     if (out.partials_mode) {
-      T *p = (T *)out.partials;
       (void)plen;
-      p[out.scalars_off] = (T)sum_ell;
-      p[out.scalars_off + 1] = (T)s_he;
+      if (out.p2p_direct) {   // (f32 by construction: see PartialDst)
+        const PartialDst pd = partial_dst(out);
+        partial_store(pd, out.scalars_off, (float)sum_ell);
+        partial_store(pd, out.scalars_off + 1, (float)s_he);
+      } else {
+        T *p = (T *)out.partials;
+        p[out.scalars_off] = (T)sum_ell;
+        p[out.scalars_off + 1] = (T)s_he;
+      }
     } else {
       const double Mt = (double)out.M_total;
       const double ent = (ent_is_closed(out.ent_kind) ? 0.5 * d * (1.0 + kLog2Pi) : s_he / Mt + 0.5 * d * kLog2Pi) + s_ld;

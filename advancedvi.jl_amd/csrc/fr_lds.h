@@ -60,6 +60,7 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
   const double direct = direct_entropy_coeff(a.out.ent_kind);
   const bool diag_tile = (wk.w & 1);
   if (a.out.partials_mode) {   // shard partials: raw sums, packed lower triangle
+    const PartialDst pd = partial_dst(a.out);
     float *dst = (float *)a.out.partials;
 #pragma unroll
     for (int u = 0; u < NE; ++u) {
@@ -71,7 +72,11 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int gi = row0 + i4 + c;
-        if (gj <= gi) dst[d + (size_t)gj * d - ((size_t)gj * (gj - 1)) / 2 + (gi - gj)] = v[c];
+        if (gj <= gi) {
+          const size_t pi = d + (size_t)gj * d - ((size_t)gj * (gj - 1)) / 2 + (gi - gj);
+          if (pd.tab) partial_store(pd, (long long)pi, v[c]);   // (peer-to-peer route, direct: into the owner's staging area)
+          else dst[pi] = v[c];
+        }
       }
     }
   } else {
@@ -141,7 +146,8 @@ __device__ __forceinline__ void vjp_epilogue(const GemmArgs &a, const float *Cs,
     for (int g = 0; g < NT / BM; ++g) sm += (double)rs_lds[g * BM + tid];
     const int gr = row0 + tid;
     if (a.out.partials_mode) {
-      ((float *)a.out.partials)[gr] = (float)sm;
+      if (a.out.p2p_direct) partial_store(partial_dst(a.out), gr, (float)sm);
+      else ((float *)a.out.partials)[gr] = (float)sm;
     } else {
       const float g = dmu_elem(sm, invM);
       if (FUSED && a.upd.rule >= 0) {

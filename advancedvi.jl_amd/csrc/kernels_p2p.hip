@@ -68,6 +68,9 @@ struct P2PArgs {
   int phases;                // bit 0 push, bit 1 reduce, bit 2 unpack (all three = the exchange; single phases: host-sequenced tests, count = 1)
   int spin_budget;
   int lane, lanes, count;    // this launch serves the GROUPS gi = lane, lane + lanes, ... of V consecutive estimates (t = gi V ... < count)
+  int direct;                // the partial kernels stored every vector straight into the owners' staging areas (OutArgs::p2p_direct): phase 1 only
+                             // raises the arrival flags, and a ring slot = a staging slot, released (`freed`) once this rank has the FINAL chunks of
+                             // its epoch -- which the owners stored after they had read their staging areas
   const unsigned *ready;     // batch hand-over (nullptr: the partial vector is complete at launch): estimate t may start when *ready >= t + 1
   unsigned *freed;           // [ring]: += 1 by every chunk workgroup once its part of the vector in that ring slot has been read
 };
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       // slice vs.  So the chunk workgroups ga / gb of EVERY rank do not start pushing epoch e + 2 before their own rank's value
       // workgroup has consumed epoch e (ctr[2], a device-local word): that value was read behind rank vs's final flag, which rank vs
       // stores after reading its stage scalars -- both parities of both hazards are closed by this one wait.
-      if ((a.phases & 4) && a.rank >= 0) {
+      if ((a.phases & 4) && a.rank >= 0 && !a.direct) {
         const long long o0 = tri_end - (long long)a.vs * n;
         const int ga = (int)(o0 / a.cn), gb = (int)((o0 + 1) / a.cn);
         if (g == ga || g == gb) {
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
       }
       const int vecs = (int)(clen / V);   // (clen is a multiple of 4)
-      for (int v = 0; v < nv; ++v) {
+      for (int v = 0; v < (a.direct ? 0 : nv); ++v) {   // (direct: the vectors are in the staging areas already)
         const T *P = a.P[(t0 + v) % a.ring];
         for (int base = 0; base < vecs; base += 8 * NT) {
           for (int k = 0; k < R; ++k) {
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every payload store of this wave has been acknowledged ...
       __syncthreads();                                    // ... and of this workgroup
       if (tid < R) flag_store(tb.arr[ln][tid] + (size_t)(p * R + a.rank) * G + g, epoch);
-      if (a.freed && tid < nv)   // this workgroup is done reading the group's partial vectors in their ring slots
+      if (a.freed && tid < nv && !a.direct)   // this workgroup is done reading the group's partial vectors in their ring slots
         __hip_atomic_fetch_add(a.freed + (t0 + tid) % a.ring, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
@@ -437,6 +440,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         }
       }
     }
+    // direct mode: this workgroup has seen the final flags of its chunk (the value workgroup: of the scalars) from every owner, i.e. every
+    // owner is done with this epoch's staging data of the chunk -- the compute chain may store the epoch after next into these staging slots
+    if (a.direct && (a.phases & 4) && a.freed) {
+      __syncthreads();
+      if (tid < nv) __hip_atomic_fetch_add(a.freed + (t0 + tid) % a.ring, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if (lost && tid == 0 && a.status) atomicOr(a.status, 8);
 
@@ -493,8 +502,9 @@ void launch_p2p_handover4(mivi_ctx *c, unsigned *ready, unsigned ready_val, cons
 
 // one lane of the exchange on c->stream: estimates t = lane, lane + lanes, ... < count with partial vectors P[t % ring]
 void launch_p2p_exchange(mivi_ctx *c, const void *params, const void *const *P, int ring, void *value, void *grad, int phases, int lane, int lanes,
-                         int count, const unsigned *ready, unsigned *freed) {
+                         int count, const unsigned *ready, unsigned *freed, bool direct) {
   auto fill = [&](auto &a) {
+    a.direct = direct ? 1 : 0;
     a.d = c->cfg.d; a.family = c->cfg.family; a.ent_kind = c->cfg.entropy; a.M_total = c->M_total;
     a.L = mivi_partials_len(c); a.n = c->p2p_n; a.cn = c->p2p_cn;
     a.rank = c->p2p_rank; a.world = c->p2p_world; a.G = c->p2p_G; a.vs = c->p2p_vs;

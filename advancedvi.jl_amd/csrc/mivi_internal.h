@@ -76,6 +76,17 @@ struct OutArgs {
   int *status;       // device status word: bit0 nonfinite value, bit1 non-positive scale diag
   double *elbo_rec;  // optional: elbo_rec[rec_slot] = -value (optimize loop)
   int rec_slot;
+  // partials mode on the peer-to-peer route, DIRECT: every entry of the partial vector is stored straight into its OWNER's staging area
+  // (kernels_p2p.hip: no ring slot, no push pass).  p2p_direct: device-resident P2PDirectTab; (p2p_gi, p2p_v): the exchange group this estimate
+  // belongs to, counted from the exchange kernel's start, and its place in the group.  Second-generation full-rank f32 kernels only.
+  const void *p2p_direct;
+  int p2p_gi, p2p_v;
+};
+struct P2PDirectTab {   // where the ranks' staging areas are mapped in this process (lane 0 of the exchange)
+  char *stage[8];
+  long long n;          // slice length (elements)
+  int R, rank, GV, pad;
+  const unsigned *ctr;  // the exchange lane's counters: ctr[0] = exchanges completed (the next group's epoch is ctr[0] + 1 + p2p_gi)
 };
 
 // Optimiser step fused into the VJP epilogue (device-resident optimisation loop, full-rank f32): every lower-triangle
@@ -264,7 +275,7 @@ struct mivi_ctx {
   size_t p2p_bytes = 0;
   void *p2p_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // mapped bases (own entry = p2p_buf)
   bool p2p_opened[8] = {false, false, false, false, false, false, false, false};                   // hipIpcOpenMemHandle'd (to be closed)
-  mivi::DevBuf p2p_tab, p2p_ctr, p2p_scratch;
+  mivi::DevBuf p2p_tab, p2p_ctr, p2p_scratch, p2p_direct;   // (p2p_direct: P2PDirectTab, what the partial kernels need to store straight into the owners' staging areas)
   bool p2p_on = false;
   int p2p_rank = 0, p2p_world = 1, p2p_G = 1, p2p_vs = 0, p2p_spin = 1 << 21;
   long long p2p_n = 0, p2p_cn = 0;
@@ -349,6 +360,7 @@ struct mivi_ctx {
   unsigned long long target_gen = 0, kid_gen = ~0ull;   // parent: bumped whenever a captured graph is invalidated; child: the generation it mirrors
   hipEvent_t ev_fork = nullptr, ev_join[kMaxKids] = {};
   bool dist_capture_refused = false;   // the sharded batch could not be captured into a hipGraph (RCCL route): issued eagerly from then on
+  bool dist_direct = false;      // sharded estimates on the peer-to-peer route: the partial kernels store straight into the owners' staging areas
   bool dist_lane4 = false;       // pipelined sharded batches: the compute chain is lane-batched (four contexts per launch)
   void *value_sink = nullptr;    // ... and launch_value_only (a chain's closing value kernel) into the value sink
   void *eps_sink = nullptr;      // ... and launch_eps (a chain's first draw) into the eps sink
@@ -461,7 +473,7 @@ bool logreg_prepare_f32(mivi_ctx *c);   // row-major padded copy of X for the MF
 // kernels_p2p.hip: phases bit 0 push, 1 reduce + finalise, 2 unpack (7 = the whole exchange in one launch)
 void launch_p2p_handover4(mivi_ctx *c, unsigned *ready, unsigned ready_val, const unsigned *const *freed, const unsigned *freed_min, int n);
 void launch_p2p_exchange(mivi_ctx *c, const void *params, const void *const *P, int ring, void *value, void *grad, int phases, int lane, int lanes,
-                         int count, const unsigned *ready, unsigned *freed);   // one lane: estimates lane, lane + lanes, ... < count; P[t % ring]
+                         int count, const unsigned *ready, unsigned *freed, bool direct = false);   // one lane: estimates lane, lane + lanes, ... < count; P[t % ring]
 void launch_p2p_handover(mivi_ctx *c, unsigned *ready, unsigned ready_val, const unsigned *freed, unsigned freed_min);
 
 // kernels_update.hip

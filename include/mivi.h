@@ -362,6 +362,10 @@ mivi_status_t mivi_estimate_gradient_dist_n(mivi_ctx_t *ctx, const void *params_
  * several ranks living in ONE process can be sequenced from one host thread.  partials_dev: the rank's partial vector, zero padded. */
 mivi_status_t mivi_p2p_exchange(mivi_ctx_t *ctx, const void *params_dev, const void *partials_dev, void *value_dev, void *grad_dev,
                                 int32_t phases);
+/* Tests: the partial kernels of one estimate with DIRECT staging -- every entry of the rank's partial vector is stored straight into its
+ * owner's staging area (no ring slot, no push pass; what mivi_estimate_gradient_dist[_n] do on the peer-to-peer route for the full-rank f32
+ * family); follow with mivi_p2p_exchange(ctx, params, NULL, value, grad, phases).  MIVI_ERR_UNSUPPORTED for other configurations. */
+mivi_status_t mivi_p2p_partials_direct(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx);
 /* Measurement (bench.py --gpus N): us per estimate of {partial kernels, exchange + finalisation, the serial step, the pipelined step},
  * hipEvents around one hipGraph replay of `reps` estimates each; every rank calls it collectively.  us_host: double[4]. */
 mivi_status_t mivi_profile_dist(mivi_ctx_t *ctx, const void *params_dev, int32_t reps, double *us_host);

@@ -124,6 +124,39 @@ CHAINS_STL = CHAINS_NS.replace("d, M, 0, SEED", "d, M, 3, SEED").replace(
     "assert float(v.item()) == float(v1.item()) and", "assert abs(float(v.item()) - float(v1.item())) <= float(np.spacing(np.float32(abs(float(v1.item()))))) and")
 assert CHAINS_STL != CHAINS_NS and "M, 3, SEED" in CHAINS_STL
 
+# the sharded estimate at world 1 on the peer-to-peer route (single estimates and a pipelined batch): with MIVI_P2P_DIRECT=1 the partial vector
+# goes straight into the staging areas instead of through the ring slots and the push pass (the default)
+P2P = """
+import numpy as np, advancedvi_jl_amd as avi
+from tests.helpers import SEED, make_family, make_problem
+d, M = 256, 128
+rng = np.random.default_rng(6)
+q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
+prob, _ = make_problem(rng, 'diag', d, np.float32)
+params, _ = avi.destructure(q)
+ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+ctx.set_problem(prob)
+ref = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+ref.set_problem(prob)
+ctx.p2p_attach([ctx.p2p_export(0, 1)])
+assert ctx.comm_route() == 'p2p'
+p = ctx.to_device(params)
+for idx in (5, 6, 7):
+    v1, g1 = ctx.estimate_gradient_dist(p, idx)
+    ctx.synchronize()
+    v0, g0 = ref.estimate_gradient(params, idx)
+    assert abs(float(v1.item()) - float(v0.item())) <= 2e-6 * abs(float(v0.item()))
+    assert np.linalg.norm(g1.cpu().numpy() - g0.cpu().numpy()) <= 5e-6 * max(1.0, np.linalg.norm(g0.cpu().numpy()))
+v, g = ctx.empty(1), ctx.empty(ctx.params_len)
+for rep in range(2):
+    ctx.estimate_gradient_dist_n(p, 40 + 20 * rep, 11, v, g)
+    ctx.synchronize()
+    v0, g0 = ref.estimate_gradient(params, 40 + 20 * rep + 10)
+    assert abs(float(v.item()) - float(v0.item())) <= 2e-6 * abs(float(v0.item()))
+    assert np.linalg.norm(g.cpu().numpy() - g0.cpu().numpy()) <= 5e-6 * max(1.0, np.linalg.norm(g0.cpu().numpy()))
+print('ok')
+"""
+
 F, MF = 1, 0
 CASES = [
     # switch, script, parameters
@@ -162,6 +195,8 @@ CASES = [
     ("MIVI_FB_LANES=7", CHAINS, dict(kind="diag")),                                                       # batch engine: seven estimates per step (25 estimates: four steps, the last one shorter)
     ("MIVI_DUMMY_DEFAULT=1", CHAINS_NS, dict(kind="diag")),                                               # (no switch: the batch engine, one step)
     ("MIVI_BATCH_GEN3=0", CHAINS_NS, dict(kind="dense")),                                                 # ... with the dense target (second product on k_fr_prod32m)
+    ("MIVI_P2P_DIRECT=1", P2P, dict()),                                                                   # sharded estimates: direct staging instead of ring slots + push
+    ("MIVI_DUMMY_DEFAULT=1", P2P, dict()),                                                                # (no switch: ring slots + push)
     ("MIVI_FB_STL=0", CHAINS_STL, dict(kind="diag")),                                                     # sticking-the-landing batches: the lanes' solves instead of the engine's C^-T product -- bitwise the single calls'
     ("MIVI_DUMMY_DEFAULT=1", CHAINS, dict(kind="dense")),                                                 # (no switch: the default interleaving)                                                                 # first-generation accumulation kernel
 ]

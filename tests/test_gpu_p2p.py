@@ -87,6 +87,56 @@ def test_exchange_phases_for_several_ranks(family, d, M, R, ent, dtype):
         c.close()
 
 
+@pytest.mark.parametrize("d,M,R,ent", [(256, 256, 2, 0), (128, 1024, 8, 2), (1024, 512, 4, 0), (192, 384, 3, 1)])
+def test_direct_staging_for_several_ranks(d, M, R, ent):
+    """DIRECT staging (full-rank f32, second-generation kernels): the partial kernels store every entry of a rank's partial vector straight
+    into its owner's staging area -- the VJP's shard epilogue, the d/dmu rows, the two scalars -- and the exchange starts at the arrival
+    flags (no ring slot, no push pass).  Several ranks as contexts of this process, phases host-sequenced: every exchange must equal, BIT FOR
+    BIT, the one the same ranks obtain through the ring slots + push on the same estimate, over consecutive epochs (both staging parities)."""
+    rng = np.random.default_rng(8)
+    q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
+    prob, _ = make_problem(rng, "diag", d, np.float32)
+    params, _ = avi.destructure(q)
+    full = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
+    full.set_problem(prob)
+    ctxs = _ranks(np.float32, avi.FULLRANK, d, M, R, ent, prob)
+    L = ctxs[0].partials_len
+    n, cn, G, vs = p2p_geometry(L, R)
+    p_dev = [c.to_device(params) for c in ctxs]
+    for idx in (3, 4, 5, 6):
+        v_ref, g_ref = full.estimate_gradient(params, idx)
+        v_ref, g_ref = float(v_ref.item()), g_ref.cpu().numpy().astype(np.float64)
+        results = []
+        for direct in (False, True):
+            parts, outs = [], []
+            for r, c in enumerate(ctxs):
+                outs.append((c.empty(1), c.empty(c.params_len).fill_(float("nan"))))
+                if direct:
+                    c.p2p_partials_direct(p_dev[r], idx)
+                    parts.append(None)
+                else:
+                    P = c.empty(n * R).zero_()
+                    c.estimate_partials(p_dev[r], idx, P[:L])
+                    parts.append(P)
+            torch.cuda.synchronize()
+            for ph in (1, 2, 4):
+                for r, c in enumerate(ctxs):
+                    c.p2p_exchange(p_dev[r], parts[r], outs[r][0], outs[r][1], ph)
+                torch.cuda.synchronize()
+            for c in ctxs:
+                c.synchronize()
+            g0 = outs[0][1].cpu().numpy()
+            for v, g in outs:
+                assert float(v.item()) == float(outs[0][0].item()) and np.array_equal(g.cpu().numpy(), g0)
+            results.append((float(outs[0][0].item()), g0.copy()))
+        assert results[0][0] == results[1][0] and np.array_equal(results[0][1], results[1][1])
+        assert abs(results[1][0] - v_ref) <= 2e-6 * abs(v_ref)
+        assert np.linalg.norm(results[1][1] - g_ref) <= 5e-6 * max(1.0, np.linalg.norm(g_ref))
+        assert np.all(np.triu(results[1][1][d:].reshape(d, d, order="F"), 1) == 0.0)
+    for c in ctxs + [full]:
+        c.close()
+
+
 @pytest.mark.parametrize("family,d,M", [(avi.MEANFIELD, 64, 48), (avi.FULLRANK, 256, 256), (avi.FULLRANK, 40, 30), (avi.FULLRANK, 1024, 256)])
 def test_one_rank_exchanges_with_itself(family, d, M):
     rng = np.random.default_rng(6)
@@ -109,13 +159,15 @@ def test_one_rank_exchanges_with_itself(family, d, M):
     ctx.close()
 
 
-def _two_process_worker(rank, world, port, family, d, M, q_out):
+def _two_process_worker(rank, world, port, family, d, M, q_out, direct=False):
     """One rank = one PROCESS on the (only) GPU: the exchange areas are mapped through HIP IPC (hipIpcGetMemHandle / OpenMemHandle), the
     128 + 256-byte blobs travel through a gloo group, and the fused exchange kernels of the two processes really run concurrently."""
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
+    if direct:
+        os.environ["MIVI_P2P_DIRECT"] = "1"   # the partial kernels store straight into the OTHER process's staging area (direct staging)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -174,8 +226,8 @@ def _two_process_worker(rank, world, port, family, d, M, q_out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("family,d,M", [(avi.FULLRANK, 256, 256), (avi.MEANFIELD, 1024, 128)])
-def test_two_processes_exchange_through_ipc(family, d, M):
+@pytest.mark.parametrize("family,d,M,direct", [(avi.FULLRANK, 256, 256, False), (avi.MEANFIELD, 1024, 128, False), (avi.FULLRANK, 256, 256, True)])
+def test_two_processes_exchange_through_ipc(family, d, M, direct):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -184,7 +236,7 @@ def test_two_processes_exchange_through_ipc(family, d, M):
     s.close()
     mpc = mp.get_context("spawn")
     q_out = mpc.Queue()
-    procs = [mpc.Process(target=_two_process_worker, args=(r, 2, port, family, d, M, q_out)) for r in range(2)]
+    procs = [mpc.Process(target=_two_process_worker, args=(r, 2, port, family, d, M, q_out, direct)) for r in range(2)]
     for pr in procs:
         pr.start()
     for pr in procs:
