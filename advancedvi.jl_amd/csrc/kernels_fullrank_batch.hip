@@ -990,10 +990,7 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
     hipLaunchKernelGGL((k_fb_prod<kWJ, kPFprod, FB_STL_U>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
   }
   a.work = (const int4 *)tb.vjp.p; a.n_work = tb.n_vjp;
-  static const int pfv = getenv("MIVI_FB_PFV") ? atoi(getenv("MIVI_FB_PFV")) : -1;   // developer A/B: the VJP with register prefetch (one workgroup per CU)
-  if (!(which & 2)) return;
-  if (pfv == 1 || (pfv < 0 && kPFvjp)) hipLaunchKernelGGL((k_fb_vjp<kWJ, 1>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
-  else hipLaunchKernelGGL((k_fb_vjp<kWJ, 0>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
+  if (which & 2) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
 }
 
 }  // namespace mivi
