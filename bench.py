@@ -263,6 +263,11 @@ def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):
             # three-way split -- so the executed bf16 rate over the bf16 peak is quoted with it and bounds it
             roof["bf16_pipe"] = dict(executed_TFLOPs=6 * aL, peak=PEAK_BF16_MFMA_TF, frac=6 * aL / PEAK_BF16_MFMA_TF,
                                      note="bf16x3: six v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16 block; this fraction is <= 1 by construction")
+            if roof["frac"] > 1.0:   # a full (not triangular) product: faster than the f32 MFMA pipe could be -- its roof is the bf16 pipe's
+                roof["f32_equivalent"] = dict(achieved=aL, peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=aL / PEAK_F32_MFMA_TF,
+                                              note="f32-accurate flops over the f32-MFMA peak: above 1, i.e. not this kernel's bound")
+                roof.update(bound="mfma", achieved=6 * aL, peak=PEAK_BF16_MFMA_TF, frac=6 * aL / PEAK_BF16_MFMA_TF,
+                            note="executed bf16 flops (six per f32-equivalent flop) over the dense bf16 MFMA peak")
             roof.pop("estimates_per_launch_note", None)
             ach = aL
     if gen and bf3:
