@@ -100,7 +100,11 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
   const double eta = l.eta, clip_eps = (l.op == 1) ? l.clip_epsilon : (double)NAN;   // NaN = no ClipScale
   void *opt_state = l.opt_state_dev;
   // internal value/grad/elbo-record buffers
-  const size_t hist_doubles = (size_t)n_steps * 4 * (size_t)((c->cfg.d + 3) / 4);
+  size_t hist_doubles = (size_t)n_steps * 4 * (size_t)((c->cfg.d + 3) / 4);
+  {   // (the funnel loop: six partials per row quad and step, every step's set at addresses of its own, 128-byte aligned)
+    const size_t fh = (size_t)n_steps * ((6 * (size_t)((c->cfg.d + 3) / 4) + 15) / 16 * 16) + 16 + (size_t)((c->cfg.d + 3) / 4) / 2 + 8;   // (+ the arrival flags, the published row)
+    if (hist_doubles < fh) hist_doubles = fh;
+  }
   if ((s = ensure(c, c->X, (plen + 8) * es + ((size_t)n_steps + hist_doubles + 8) * sizeof(double), false))) return s;
   char *vbuf = (char *)c->X.p;
   char *gbuf = vbuf + 8 * es;
@@ -113,6 +117,20 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     // launch-free loop: every workgroup owns four rows of (mu, sigma); no graph, two launches for all n_steps
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));   // (every word read_status folds in: a stale flag of an
     launch_mf_sgd_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, rec + n_steps, rec);   //  earlier batch's child contexts is not this run's)
+    HIPCHK(c, hipGetLastError());
+    if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
+    return read_status(c);
+  }
+  if (simple && (rule == 0 || default_adam) && c->cfg.family == MIVI_MEANFIELD && c->target == TGT_FUNNEL && !c->funnel_constrained && !c->bij_on &&
+      c->cfg.n_mc <= 256 && c->cfg.d <= 16384 && !no_fused_loop) {
+    // launch-free loop for the fused funnel target: the row quads and the row-0 workgroup of ONE kernel exchange two scalars per workgroup and
+    // row 0's parameters per step (k_mf_funnel_sgd_loop) instead of three launches per step
+    double *hist = (double *)(((uintptr_t)(rec + n_steps) + 127) & ~(uintptr_t)127);
+    const size_t nq = (size_t)((c->cfg.d + 3) / 4);
+    void *pub = (void *)(rec + n_steps + hist_doubles - (nq / 2 + 8));
+    unsigned *sync = (unsigned *)((double *)pub + 4);
+    HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
+    launch_mf_funnel_sgd_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, hist, sync, pub, gbuf, rec, vbuf);
     HIPCHK(c, hipGetLastError());
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);

@@ -168,6 +168,18 @@ __device__ __forceinline__ bool ent_is_closed(int k) {
   return k == MIVI_ENT_CLOSED_FORM || k == MIVI_ENT_CLOSED_FORM_ZERO_GRAD;
 }
 
+// A gradient entry from its row sum: -(1/M) sum, the scale rows also carry the entropy term -direct / sigma.  ONE body, compiled without
+// fused multiply-add contraction, for every kernel that writes mean-field gradient entries (k_mf_main, k_mf_colreduce, the launch-free
+// loops): they must agree to the bit, and left to the optimiser one instantiation fused the product into the subtraction and another
+// did not (1 ulp apart in f64; found on the GPU).
+template <typename T>
+__device__ __forceinline__ T mf_grad_entry(double row_sum, double invM, bool scale_row, double direct, double sigma) {
+#pragma clang fp contract(off)
+  const double m = -row_sum * invM;
+  const double e = direct / sigma;
+  return (T)(scale_row ? m - e : m);
+}
+
 template <bool ATOMIC>
 __device__ __forceinline__ double ld_f64(const double *p) {
   if (ATOMIC) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -178,27 +190,60 @@ __device__ __forceinline__ double ld_f64(const double *p) {
 // A / B partials of the main kernel in index order.  Per-THREAD shares of sum_m ell_m, sum_m w_0m and sum_m w_0m eps_0m (the
 // caller reduces them together with its other sums and writes the two gradient / shard-partial entries of row 0;
 // kernels_targets.hip k_col_target / oracle FunnelStackedTarget).
-template <typename T, int NT>
+template <typename T, int NT, bool ATOMIC = false>
 __device__ __forceinline__ void funnel_finish(int d, const FunnelFin &f, const OutArgs &out, double &s_ell, double &sW, double &sWe) {
   const int tid = threadIdx.x;
   const T *params = (const T *)f.params;
-  const double mu0 = (double)params[0], sg0 = (double)params[d];
+  const double mu0 = f.row0 ? (double)__hip_atomic_load((const T *)f.row0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (double)params[0];
+  const double sg0 = f.row0 ? (double)__hip_atomic_load((const T *)f.row0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (double)params[d];
   const uint64_t idx = rng_index(f.rng);
   const bool stl = ent_is_stl(out.ent_kind);
   const double n = (double)(d - 1), sv2 = f.sigma_v * f.sigma_v;
+  // (floating-point contraction off, the one intended fused multiply-add explicit: this body is instantiated inside several kernels, and
+  //  what the optimiser would fuse differed between them -- the row-0 gradient of k_mf_funnel_sgd_loop came out one ulp from the single
+  //  calls' once in a few steps)
   for (int m = tid; m < f.M; m += NT) {
+#pragma clang fp contract(off)
     T e[4];
     eps_block<T>(f.rng.seed, idx, (uint64_t)(f.rng.m_offset + m) * (uint64_t)f.d4, e);   // row-quad 0 of column m
     const double e0 = (double)e[0];
-    const double e1 = (double)((T)mu0 + (T)sg0 * e[0]);   // the same rounding as the main kernel's z
+    const double e1 = (double)fma((T)sg0, e[0], (T)mu0);   // funnel_column's e1: one fused multiply-add in T
     s_ell += (-e1 - e1 * e1 / (2.0 * sv2)) + (-n * e1) + e1;
     const double w = (-1.0 - e1 / sv2) + (-n) + 1.0 + (stl ? e0 / sg0 : 0.0);
     sW += w;
     sWe += w * e0;
   }
-  for (int i = tid; i < f.n_part; i += NT) {
-    sW += f.ab[i];
-    sWe += f.ab[f.n_part + i];
+  if (f.wait_word) {   // the other workgroups' partials of this step (k_mf_funnel_sgd_loop): fresh addresses, complete behind this wait
+    for (int i = tid; i < f.wait_n; i += NT) {
+      int budget = f.wait_budget;
+      while ((int)(__hip_atomic_load(f.wait_word + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - f.wait_val) < 0) {
+        if (--budget <= 0) { if (out.status) atomicOr(out.status, 8); break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+    asm volatile("" ::: "memory");
+    if (f.mirror) {
+      constexpr int UN = 8;
+      for (int base = 0; base < f.mirror_n; base += UN * NT) {
+        double v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int i = base + u * NT + tid;
+          v[u] = i < f.mirror_n ? f.mirror_src[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int i = base + u * NT + tid;
+          if (i < f.mirror_n) f.mirror[i] = v[u];
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < f.n_part; i += NT) {   // (ATOMIC: partials left by other workgroups of the SAME launch)
+    sW += ld_f64<ATOMIC>(f.ab + i);
+    sWe += ld_f64<ATOMIC>(f.ab + f.n_part + i);
   }
 }
 
@@ -247,7 +292,7 @@ __device__ void finalize_value_block(int d, const ValueIn &vin, const OutArgs &o
   const int tid = threadIdx.x;
   double s_ell = 0.0, s_he = 0.0, s_ld = 0.0, bad = 0.0, sW = 0.0, sWe = 0.0;
   const bool funnel = FUNNEL && vin.fn.ab;
-  if (funnel) funnel_finish<T, NT>(d, vin.fn, out, s_ell, sW, sWe);
+  if (funnel) funnel_finish<T, NT, ATOMIC>(d, vin.fn, out, s_ell, sW, sWe);
   for (int i = tid; i < vin.n_ell_part; i += NT) s_ell += ld_f64<ATOMIC>(vin.ell_part + i);
   for (int i = tid; i < vin.n_ell_part2; i += NT) s_ell += ld_f64<ATOMIC>(vin.ell_part2 + i);
   for (int i = tid; i < vin.n_ell; i += NT) s_ell += (double)((const T *)vin.ell)[i];
@@ -271,7 +316,8 @@ __device__ void finalize_value_block(int d, const ValueIn &vin, const OutArgs &o
     block_sum_n<double, NT, 6>(v, red);
     s_ell = v[0]; s_he = v[1]; s_ld = v[2]; bad = v[3]; sW = v[4]; sWe = v[5];
     if (funnel && tid == 0) {   // row 0 of the fused funnel target
-      const double sg0 = (double)((const T *)vin.fn.params)[d];
+      const double sg0 = vin.fn.row0 ? (double)__hip_atomic_load((const T *)vin.fn.row0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                     : (double)((const T *)vin.fn.params)[d];
       if (out.partials_mode) {
         T *p = (T *)out.partials;
         p[0] = (T)sW;
@@ -279,8 +325,8 @@ __device__ void finalize_value_block(int d, const ValueIn &vin, const OutArgs &o
       } else {
         T *gr = (T *)out.grad;
         const double invM = 1.0 / (double)out.M_total;
-        gr[0] = (T)(-sW * invM);
-        gr[d] = (T)(-sWe * invM - direct_entropy_coeff(out.ent_kind) / sg0);
+        gr[0] = mf_grad_entry<T>(sW, invM, false, 0.0, 1.0);   // (one body without contraction: every instantiation of this block must
+        gr[d] = mf_grad_entry<T>(sWe, invM, true, direct_entropy_coeff(out.ent_kind), sg0);   //  round these two entries identically)
       }
     }
   } else {

@@ -13,6 +13,8 @@
 // workgroup (b, 0) owns rows 4b..4b+3 for all columns and writes their gradient entries directly; per-workgroup scalar
 // partials are assembled into the objective value by one extra workgroup of the NEXT estimate's launch (graph-chained
 // mode) or by k_value_only (single calls) in a fixed summation order => bitwise reproducible.
+#include <cstdio>
+#include <cstdlib>
 #include "device_common.h"
 #include "optim_rules.h"
 
@@ -45,40 +47,32 @@ __device__ __forceinline__ float wave_total63(float v) {
 }
 __device__ __forceinline__ double wave_total63(double v) { return wave_sum(v); }
 
-// A gradient entry from its row sum: -(1/M) sum, the scale rows also carry the entropy term -direct / sigma.  ONE body, compiled without
-// fused multiply-add contraction, for every kernel that writes mean-field gradient entries (k_mf_main, k_mf_colreduce, the launch-free
-// loops): they must agree to the bit, and left to the optimiser one instantiation fused the product into the subtraction and another
-// did not (1 ulp apart in f64; found on the GPU).
-template <typename T>
-__device__ __forceinline__ T mf_grad_entry(double row_sum, double invM, bool scale_row, double direct, double sigma) {
-#pragma clang fp contract(off)
-  const double m = -row_sum * invM;
-  const double e = direct / sigma;
-  return (T)(scale_row ? m - e : m);
-}
-
 // One sample column of the fused funnel target for rows 4 rq .. 4 rq + 3 (Neal's funnel + Stacked([log, identity]), see FunnelFin):
 // rows >= 1 need only e1 = z[0, m], re-derived from the eps stream; their sum of squares enters row 0 and ell only through
 // x^2 exp(-2 e1) (and that times eps_0).  ONE body for k_mf_main<T, true> and k_mf_funnel_loop: the two must produce the same bits.
 template <typename T>
 __device__ __forceinline__ void funnel_column(int rq, int d, const T (&mu)[4], const T (&sg)[4], const T (&e)[4], T e0, T mu0, T sg0, T (&g)[4],
                                               T &s_ell, T &sA, T &sB) {
-  const T e1 = mu0 + sg0 * e0;
+  // Floating-point contraction off, the fused multiply-adds explicit: this body is instantiated in three kernels (k_mf_main<T, true>,
+  // k_mf_funnel_loop, k_mf_funnel_sgd_loop) that must agree to the bit, and what the optimiser fuses depends on the code around it (the A / B
+  // partials of the third came out one ulp apart from the first's once in a few steps).
+#pragma clang fp contract(off)
+  const T e1 = fma(sg0, e0, mu0);   // (funnel_finish re-derives exactly this value)
   const T inv_s2 = exp(T(-2) * e1);
   T x2 = 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int i = 4 * rq + r;
-    const T z = mu[r] + sg[r] * e[r];
+    const T z = fma(sg[r], e[r], mu[r]);
     if (i >= 1 && i < d) {
       g[r] = -z * inv_s2;
-      x2 += z * z;
+      x2 = fma(z, z, x2);
     }
   }
   const T xi = x2 * inv_s2;
-  s_ell += T(-0.5) * xi;
+  s_ell = fma(T(-0.5), xi, s_ell);
   sA += xi;
-  sB += xi * e0;
+  sB = fma(xi, e0, sB);
 }
 // The row sums of one column: W = g (+ eps / sigma for the sticking-the-landing estimators), sum W, sum W eps, sum 0.5 eps^2.
 template <typename T>
@@ -728,6 +722,338 @@ void launch_mf_funnel_loop(mivi_ctx *c, const void *params, uint64_t idx0, int n
                            void *value, void *grad, void *lane_scratch, void *e0_tab) {
   if (c->cfg.dtype == MIVI_F32) mf_funnel_loop_impl<float>(c, params, idx0, n_steps, hist, elbo, scratch, value, grad, lane_scratch, e0_tab);
   else mf_funnel_loop_impl<double>(c, params, idx0, n_steps, hist, elbo, scratch, value, grad, lane_scratch, e0_tab);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launch-free OPTIMISATION loop for the mean-field family with the fused funnel target (BASELINE config 5's `optimize`): n_steps iterations
+// of {estimate_gradient!, Optimisers.update!, ClipScale} (src/algorithms/common.jl:69-104) inside ONE kernel.
+// Unlike the diagonal-Gaussian loop (k_mf_sgd_loop) the rows are not independent: row 0 of (mu, sigma) enters every other row's sample
+// (z_0 scales the funnel), and every row quad contributes two scalars (A, B: FunnelFin) to row 0's gradient.  So a step is a grid-wide
+// exchange: workgroup b (rows 4b .. 4b+3, parameters and optimiser state in registers) computes its rows from the row-0 parameters of this
+// step, updates them, and leaves its six scalar partials; the ROW-0 WORKGROUP (the last block) waits for all of them, assembles the
+// objective value and row 0's gradient (finalize_value_block: the single calls' code), updates (mu_0, sigma_0) and publishes them for
+// the next step.  Two dependent hand-offs across the chip per step (tools/ubench_handoff.hip: 1-2 us each) instead of three launches; the
+// draws of step t (Philox + Box-Muller: most of a row quad's instructions) do not depend on the parameters and are made BEFORE the wait.
+// Every word that crosses workgroups is an agent-scope atomic (the XCDs' L2s are not coherent); every wait is bounded (status bit 8).
+// Arithmetic and association: k_mf_main<T, true> + k_value_funnel + the update kernels, bit for bit (tests/test_gpu_optimize.py).
+// All n_blk + 1 workgroups must be resident at once (d <= 16 384: 4 097 workgroups of at most four waves).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct MfFunnelSgdArgs {
+  int d, M, n_steps, rule;      // rule 0 Descent, 1 Adam
+  T *params, *opt_state;
+  uint64_t seed, idx0;
+  int m_offset, M_total, ent_kind;
+  long long t0;
+  double eta, clip_eps, b1, b2, adam_eps, sigma_v, ell_const;
+  double *hist;                 // [n_steps][hstride]: the row quads' partials [6][n_blk] of every step at addresses of their own, a multiple of
+  long long hstride;            // 128 bytes apart -- read ONCE, after they are complete, so plain (pipelined) loads cannot see a stale line
+  unsigned *sync;               // [1] steps whose row-0 parameters are published, [2 + b] steps whose partials row quad b has delivered
+  T *pub;                       // [2][2]: (mu_0, sigma_0) at the start of a step, by step parity
+  T *gtmp;                      // [d + 1]: row 0's two gradient entries (the row-0 workgroup's scratch)
+  double *elbo;                 // [n_steps]
+  T *value;
+  int *status;
+  int spin;
+};
+
+template <typename T>
+__device__ __forceinline__ void fn_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T fn_load(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one thread waits until *p >= want (bounded); false: gave up
+__device__ __forceinline__ bool fn_wait(const unsigned *p, unsigned want, int budget) {
+  while ((int)(fn_load(p) - want) < 0) {
+    if (--budget <= 0) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return true;
+}
+
+template <typename T, int NW, int RULE>
+__global__ __launch_bounds__(256) void k_mf_funnel_sgd_loop(MfFunnelSgdArgs<T> a) {
+  constexpr int NT = 64 * NW;
+  __shared__ T xw[2][12][4];
+  __shared__ T cc_tab[64][2];
+  __shared__ T pub_s[2];
+  __shared__ int ok_s;
+  __shared__ double red[6 * 4];
+  constexpr int kFnMirror = 6 * 1024;      // the row-0 workgroup's LDS image of a step's partials (d <= 4096; beyond: read from memory)
+  __shared__ double hmir[kFnMirror];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int d = a.d, d4 = (d + 3) >> 2, nblk = d4, n_steps = a.n_steps;
+  const bool stl = ent_is_stl(a.ent_kind);
+  const double direct = direct_entropy_coeff(a.ent_kind);
+  const double invM = 1.0 / (double)a.M_total;
+  const T eta = (T)a.eta, b1 = (T)a.b1, b2 = (T)a.b2, aeps = (T)a.adam_eps, ceps = (T)a.clip_eps;
+  const bool clip = a.clip_eps == a.clip_eps;   // NaN = no ClipScale
+
+  if ((int)blockIdx.x == nblk) {
+    // ---- the row-0 workgroup: objective value, row 0's gradient and update, publication ------------------------------------------------
+    T mu0 = a.params[0], sg0 = a.params[d];
+    T m_mu = 0, v_mu = 0, m_sg = 0, v_sg = 0;
+    if (RULE == 1 && tid == 0) {
+      m_mu = a.opt_state[0]; m_sg = a.opt_state[d];
+      v_mu = a.opt_state[2 * d]; v_sg = a.opt_state[2 * d + d];
+    }
+    for (int t = 0; t < n_steps; ++t) {
+      if (RULE == 1 && (t & 63) == 0) {
+        __syncthreads();
+        if (tid < 64) adam_bias<T>(a.t0 + t + tid + 1, a.b1, a.b2, cc_tab[tid][0], cc_tab[tid][1]);
+      }
+      const double *hg = a.hist + (size_t)t * a.hstride;
+      const bool mir = 6 * nblk <= kFnMirror;
+      const double *h = mir ? hmir : hg;
+      ValueIn vin{};
+      vin.fn.wait_word = a.sync + 2;       // (waited for inside, behind the per-column work)
+      vin.fn.wait_val = (unsigned)(t + 1);
+      vin.fn.wait_n = nblk;
+      vin.fn.wait_budget = a.spin;
+      if (mir) { vin.fn.mirror = hmir; vin.fn.mirror_src = hg; vin.fn.mirror_n = 6 * nblk; }
+      vin.fn.ab = h + 4 * (size_t)nblk;
+      vin.fn.n_part = nblk;
+      vin.fn.params = a.params;
+      vin.fn.row0 = t ? a.pub + 2 * (t & 1) : nullptr;   // row 0's parameters as of the start of this step (step 0: the parameter vector's)
+      vin.fn.rng.seed = a.seed;
+      vin.fn.rng.idx_base = a.idx0 + (uint64_t)t;
+      vin.fn.rng.idx_ptr = nullptr;
+      vin.fn.rng.m_offset = a.m_offset;
+      vin.fn.d4 = d4;
+      vin.fn.M = a.M;
+      vin.fn.sigma_v = a.sigma_v;
+      vin.ell_part2 = h;
+      vin.n_ell_part2 = nblk;
+      vin.he_part = h + nblk;
+      vin.n_he_part = nblk;
+      vin.ld_part = h + 2 * (size_t)nblk;
+      vin.n_ld_part = nblk;
+      vin.ell_const = a.ell_const;
+      OutArgs out{};
+      out.grad = a.gtmp;
+      out.value = a.value;
+      out.ent_kind = a.ent_kind;
+      out.M_total = a.M_total;
+      out.M_local = a.M;
+      out.status = a.status;
+      out.elbo_rec = a.elbo;
+      out.rec_slot = t;
+      const T *sig = a.params + d;
+      finalize_value_block<T, 256, false, true>(d, vin, out, 2 * (int64_t)d, [sig](int i) { return sig[i]; }, red);
+      __syncthreads();
+      if (tid == 0) {
+        const T g0 = a.gtmp[0], gs = a.gtmp[d];
+        if (RULE == 0) {
+          mu0 = descent_step(mu0, g0, eta);
+          sg0 = descent_step(sg0, gs, eta);
+        } else {
+          const T c1 = cc_tab[t & 63][0], c2 = cc_tab[t & 63][1];
+          mu0 = adam_step<T>(mu0, g0, m_mu, v_mu, c1, c2, eta, b1, b2, aeps);
+          sg0 = adam_step<T>(sg0, gs, m_sg, v_sg, c1, c2, eta, b1, b2, aeps);
+        }
+        if (clip) sg0 = clip_step(sg0, ceps);
+        T *pb = a.pub + 2 * ((t + 1) & 1);
+        fn_store(pb, mu0);
+        fn_store(pb + 1, sg0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fn_store(a.sync + 1, (unsigned)(t + 1));
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      a.params[0] = mu0;
+      a.params[d] = sg0;
+      if (RULE == 1) {
+        a.opt_state[0] = m_mu; a.opt_state[d] = m_sg;
+        a.opt_state[2 * d] = v_mu; a.opt_state[2 * d + d] = v_sg;
+      }
+    }
+    return;
+  }
+
+  // ---- a row-quad workgroup -----------------------------------------------------------------------------------------------------------
+  if (tid >= NT) return;
+  const int rq = blockIdx.x;
+  T mu[4], sg[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = min(4 * rq + r, d - 1);
+    mu[r] = a.params[i];
+    sg[r] = a.params[d + i];
+  }
+  const int myrow = lane & 7;
+  const int myi = min(4 * rq + (myrow & 3), d - 1);
+  const bool row_ok = 4 * rq + (myrow & 3) < d && !(rq == 0 && (myrow & 3) == 0);   // (row 0: the row-0 workgroup)
+  T st_m = 0, st_v = 0;
+  if (RULE == 1) {
+    st_m = a.opt_state[(myrow < 4 ? 0 : d) + myi];
+    st_v = a.opt_state[2 * d + (myrow < 4 ? 0 : d) + myi];
+  }
+  T mu0 = a.params[0], sg0 = a.params[d];
+  bool lost = false;
+  for (int t = 0; t < n_steps; ++t) {
+    if (RULE == 1 && (t & 63) == 0) {
+      if (NW > 1) __syncthreads();
+      if (tid < 64) adam_bias<T>(a.t0 + t + tid + 1, a.b1, a.b2, cc_tab[tid][0], cc_tab[tid][1]);
+      if (NW > 1) __syncthreads();
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // the draws of this step: independent of the parameters, made before the wait
+    const int m = tid;
+    const bool has = m < a.M;
+    T e[4] = {0, 0, 0, 0}, e0q[4] = {0, 0, 0, 0};
+    if (has) {
+      eps_block<T>(a.seed, a.idx0 + (uint64_t)t, (uint64_t)(a.m_offset + m) * (uint64_t)d4 + (uint64_t)rq, e);
+      if (rq == 0) e0q[0] = e[0];
+      else eps_block<T>(a.seed, a.idx0 + (uint64_t)t, (uint64_t)(a.m_offset + m) * (uint64_t)d4, e0q);
+    }
+    if (t > 0) {   // row 0's parameters as of the start of this step
+      if (NW > 1) {
+        if (tid == 0) {
+          ok_s = fn_wait(a.sync + 1, (unsigned)t, lost ? 64 : a.spin) ? 1 : 0;
+          pub_s[0] = fn_load(a.pub + 2 * (t & 1));
+          pub_s[1] = fn_load(a.pub + 2 * (t & 1) + 1);
+        }
+        __syncthreads();
+        if (!ok_s) lost = true;
+        mu0 = pub_s[0];
+        sg0 = pub_s[1];
+      } else {
+        int okv = 1;
+        T p0 = 0, p1 = 0;
+        if (lane == 0) {
+          okv = fn_wait(a.sync + 1, (unsigned)t, lost ? 64 : a.spin) ? 1 : 0;
+          p0 = fn_load(a.pub + 2 * (t & 1));
+          p1 = fn_load(a.pub + 2 * (t & 1) + 1);
+        }
+        okv = __shfl(okv, 0, 64);
+        mu0 = __shfl(p0, 0, 64);
+        sg0 = __shfl(p1, 0, 64);
+        if (!okv) lost = true;
+      }
+      if (rq == 0) { mu[0] = mu0; sg[0] = sg0; }
+    }
+    T sW[4] = {0, 0, 0, 0}, sWe[4] = {0, 0, 0, 0};
+    T s_ell = 0, s_he = 0, sA = 0, sB = 0;
+    if (has) {
+      T g[4] = {0, 0, 0, 0};
+      funnel_column<T>(rq, d, mu, sg, e, e0q[0], mu0, sg0, g, s_ell, sA, sB);
+      mf_accumulate<T>(rq, d, true, stl, true, sg, e, g, sW, sWe, s_he);
+    }
+    T v[12];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = wave_total63(sW[r]);
+      v[4 + r] = wave_total63(sWe[r]);
+    }
+    v[8] = wave_total63(s_ell);
+    v[9] = wave_total63(s_he);
+    v[10] = wave_total63(sA);
+    v[11] = wave_total63(sB);
+    T(*xb)[4] = xw[t & 1];
+    if (lane == 63) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) xb[k][NW > 1 ? wv : 0] = v[k];
+    }
+    double lg, bad;
+    {
+      double lgs[4], bads[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = 4 * rq + r < d;
+        lgs[r] = ok ? (double)log(sg[r]) : 0.0;
+        bads[r] = (ok && !(sg[r] > T(0))) ? 1.0 : 0.0;
+      }
+      lg = (lgs[0] + lgs[1]) + (lgs[2] + lgs[3]);
+      bad = (bads[0] + bads[1]) + (bads[2] + bads[3]);
+    }
+    if (NW > 1) lds_barrier();
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (tid >= 8 && tid < 14) {   // this step's partials: 0 ell, 1 he, 2 log sigma, 3 bad, 4 A, 5 B
+      const int k = tid - 8;
+      double hv;
+      if (k == 2) hv = lg;
+      else if (k == 3) hv = bad;
+      else {
+        const int src = k < 2 ? 8 + k : 6 + k;
+        hv = 0.0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) hv += (double)xb[src][j];
+      }
+      fn_store(a.hist + (size_t)t * a.hstride + (size_t)k * nblk + rq, hv);
+    }
+    if (wv == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the six partials have been acknowledged ...
+      if (tid == 0) fn_store(a.sync + 2 + rq, (unsigned)(t + 1));   // ... before they are announced (a flag of this workgroup's own)
+    }
+    // every lane: the total of its row in fp64 (wave partials in index order), the gradient entry exactly as k_mf_main writes it, the update
+    double trow = 0.0;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) trow += (double)xb[myrow][j];
+    T mine = (myrow < 4) ? mu[0] : sg[0];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+      if ((myrow & 3) == r) mine = (myrow < 4) ? mu[r] : sg[r];
+    }
+    if (row_ok) {
+      const T sgv = (myrow & 3) == 0 ? sg[0] : (myrow & 3) == 1 ? sg[1] : (myrow & 3) == 2 ? sg[2] : sg[3];
+      const T g = mf_grad_entry<T>(trow, invM, myrow >= 4, direct, (double)sgv);
+      if (RULE == 0) mine = descent_step(mine, g, eta);
+      else mine = adam_step<T>(mine, g, st_m, st_v, cc_tab[t & 63][0], cc_tab[t & 63][1], eta, b1, b2, aeps);
+      if (clip && myrow >= 4) mine = clip_step(mine, ceps);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      mu[r] = __shfl(mine, r, 8);
+      sg[r] = __shfl(mine, 4 + r, 8);
+    }
+  }
+  if (tid < 8) {
+    const int i = 4 * rq + (tid & 3);
+    if (i < d && !(rq == 0 && (tid & 3) == 0)) {
+      T val = (tid < 4) ? mu[0] : sg[0];
+#pragma unroll
+      for (int r = 1; r < 4; ++r)
+        if ((tid & 3) == r) val = (tid < 4) ? mu[r] : sg[r];
+      a.params[(tid < 4 ? 0 : d) + i] = val;
+      if (RULE == 1) {
+        a.opt_state[(tid < 4 ? 0 : d) + i] = st_m;
+        a.opt_state[2 * d + (tid < 4 ? 0 : d) + i] = st_v;
+      }
+    }
+  }
+  if (lost && tid == 0 && a.status) atomicOr(a.status, 8);
+}
+
+template <typename T>
+static void mf_funnel_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta,
+                                    double clip_eps, double *hist, unsigned *sync, void *pub, void *gtmp, double *elbo, void *value) {
+  MfFunnelSgdArgs<T> a;
+  a.d = c->cfg.d; a.M = c->cfg.n_mc; a.n_steps = n_steps; a.rule = rule;
+  a.params = (T *)params; a.opt_state = (T *)opt_state;
+  a.seed = c->cfg.seed; a.idx0 = idx0;
+  a.m_offset = c->cfg.m_offset; a.M_total = c->M_total; a.ent_kind = c->cfg.entropy;
+  a.t0 = t0; a.eta = eta; a.clip_eps = clip_eps; a.b1 = 0.9; a.b2 = 0.999; a.adam_eps = 1e-8;
+  a.sigma_v = c->funnel_sigma_v; a.ell_const = c->t_const;
+  a.hist = hist; a.hstride = (long long)((6 * ((a.d + 3) / 4) + 15) / 16 * 16); a.sync = sync; a.pub = (T *)pub; a.gtmp = (T *)gtmp; a.elbo = elbo; a.value = (T *)value;
+  a.status = (int *)c->status.p;
+  a.spin = 1 << 22;
+  const int d4 = (a.d + 3) / 4;
+  (void)hipMemsetAsync(sync, 0, (2 + (size_t)d4) * sizeof(unsigned), c->stream);
+  const dim3 grid(d4 + 1), block(256);
+  if (a.M <= 64) {
+    if (rule == 0) hipLaunchKernelGGL((k_mf_funnel_sgd_loop<T, 1, 0>), grid, block, 0, c->stream, a);
+    else hipLaunchKernelGGL((k_mf_funnel_sgd_loop<T, 1, 1>), grid, block, 0, c->stream, a);
+  } else {
+    if (rule == 0) hipLaunchKernelGGL((k_mf_funnel_sgd_loop<T, 4, 0>), grid, block, 0, c->stream, a);
+    else hipLaunchKernelGGL((k_mf_funnel_sgd_loop<T, 4, 1>), grid, block, 0, c->stream, a);
+  }
+}
+// n_steps optimisation steps of the fused funnel target in ONE launch (n_mc <= 256).  hist: 128-byte aligned, n_steps * roundup(6 * ceil(d/4), 16) doubles; sync: 2 + ceil(d/4) words;
+// pub: 4 elements of T; gtmp: d + 1 elements of T; elbo: n_steps doubles; value: one element of T (the last step's objective value).
+void launch_mf_funnel_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta,
+                               double clip_eps, double *hist, unsigned *sync, void *pub, void *gtmp, double *elbo, void *value) {
+  if (c->cfg.dtype == MIVI_F32) mf_funnel_sgd_loop_impl<float>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, sync, pub, gtmp, elbo, value);
+  else mf_funnel_sgd_loop_impl<double>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, sync, pub, gtmp, elbo, value);
 }
 
 // rand(rng, q::MvLocationScale{<:Diagonal}, M): Z = mu + sigma .* eps  (location_scale.jl:80-87)

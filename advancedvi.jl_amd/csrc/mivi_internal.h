@@ -45,6 +45,14 @@ struct FunnelFin {
   RngArgs rng;
   int d4, M;
   double sigma_v;
+  const void *row0;    // nullptr: row 0's (mu, sigma) are params[0], params[d]; else {mu_0, sigma_0} published by the row-0 workgroup of the SAME
+                       // launch (k_mf_funnel_sgd_loop): read with agent-scope atomic loads
+  const unsigned *wait_word;   // k_mf_funnel_sgd_loop: the A / B (and every other) partial of this step is complete once wait_word[b] >= wait_val
+  unsigned wait_val;           // for every row quad b < wait_n (one flag per workgroup: 512 read-modify-writes on ONE counter took 8 us);
+  int wait_n, wait_budget;     // waited for (bounded, status bit 8) AFTER the per-column work, which needs none of them
+  double *mirror;              // ... then copied in ONE batch of loads (one memory round trip instead of one per partial kind) into this LDS image,
+  const double *mirror_src;    // which the partial pointers of the ValueIn (and `ab`) then point into
+  int mirror_n;
 };
 
 // reduction inputs of the objective value, summed in a fixed order by one workgroup
@@ -378,6 +386,8 @@ void launch_mf_main(mivi_ctx *c, const void *params, const RngArgs &rng, int M, 
                     const ValueIn &vin, const OutArgs &out, const ValueJob *prev = nullptr);
 void launch_mf_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule,
                         double eta, double clip_eps, double *hist, double *elbo, void *grad_out = nullptr, void *lane_scratch = nullptr);
+void launch_mf_funnel_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta,
+                               double clip_eps, double *hist, unsigned *sync, void *pub, void *gtmp, double *elbo, void *value);
 void launch_mf_funnel_loop(mivi_ctx *c, const void *params, uint64_t idx0, int n_steps, double *hist, double *elbo, void *scratch,
                            void *value, void *grad, void *lane_scratch, void *e0_tab = nullptr);
 int mf_loop_lanes(const mivi_ctx *c, int n_steps);   // estimate lanes of the launch-free batches (lane_scratch: lanes * 2 d elements)

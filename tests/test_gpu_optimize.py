@@ -162,6 +162,73 @@ def test_device_resident_loop_matches_host_loop(family, rule, shape):
     ctx.close()
 
 
+@pytest.mark.parametrize("shape", [(64, 32), (2048, 64), (96, 200), (10, 5), (513, 256)], ids=["small", "c5", "four-waves", "tiny", "ragged"])
+@pytest.mark.parametrize("rule", [0, 1], ids=["descent", "adam"])
+@pytest.mark.parametrize("ent", [3, 0], ids=["STL", "CFE"])
+def test_funnel_loop_matches_host_loop(rule, shape, ent):
+    """The fused funnel target (BASELINE config 5: Neal's funnel + Stacked([log, identity]), mean-field): mivi_optimize_steps runs ONE
+    kernel whose row-quad workgroups and row-0 workgroup exchange two scalars per workgroup and row 0's parameters every step
+    (k_mf_funnel_sgd_loop).  It must reproduce, bitwise, the step-by-step sequence of single calls + update + ClipScale launches,
+    including the ELBO record; and the first steps agree with the oracle's gradient + numpy update rules."""
+    d, M = shape
+    T = 9
+    q0 = avi.MeanFieldGaussian((0.05 * np.arange(d) / d).astype(np.float32), np.full(d, 0.7, np.float32))
+    p0, _ = avi.destructure(q0)
+    eta = 5e-3 / max(1.0, d / 64.0)   # (row 0's gradient grows with d: a step that keeps Descent from diverging)
+    ctx = avi.MiviContext(np.float32, avi.MEANFIELD, d, M, ent, SEED)
+    ctx.set_problem(avi.FunnelProblem(d, 1.5))
+    p = ctx.to_device(p0).clone()
+    st = ctx.empty(2 * p.numel()).zero_()
+    elbos = []
+    for t in range(T):
+        v, g = ctx.estimate_gradient(p, 40 + t)
+        elbos.append(-float(v.item()))
+        if rule == 0:
+            ctx.descent_update(p, g, eta)
+        else:
+            ctx.adam_update(p, g, st, t + 1, eta)
+        ctx.clip_scale(p, 1e-5)
+    p2 = ctx.to_device(p0).clone()
+    st2 = ctx.empty(2 * p2.numel()).zero_()
+    elbo = ctx.empty(T)
+    ctx.optimize_steps(p2, st2 if rule == 1 else None, 40, 0, T, rule, eta, 1e-5, elbo)
+    ctx.synchronize()
+    assert np.array_equal(p.cpu().numpy(), p2.cpu().numpy())
+    if rule == 1:
+        assert np.array_equal(st.cpu().numpy(), st2.cpu().numpy())
+    assert np.allclose(elbo.cpu().numpy(), np.array(elbos, dtype=np.float32), rtol=1e-6)
+    # a second call continues (t0 = T: Adam's bias correction, the estimate indices)
+    for t in range(T, T + 3):
+        v, g = ctx.estimate_gradient(p, 40 + t)
+        if rule == 0:
+            ctx.descent_update(p, g, eta)
+        else:
+            ctx.adam_update(p, g, st, t + 1, eta)
+        ctx.clip_scale(p, 1e-5)
+    ctx.optimize_steps(p2, st2 if rule == 1 else None, 40 + T, T, 3, rule, eta, 1e-5, ctx.empty(3))
+    ctx.synchronize()
+    assert np.array_equal(p.cpu().numpy(), p2.cpu().numpy())
+    # independent restatement of the first steps
+    x = p0.astype(np.float64)
+    ost = (np.zeros_like(x), np.zeros_like(x))
+    tgt = O.FunnelStackedTarget(d, 1.5)
+    for t in range(2):
+        _, eps = ctx.sample(x.astype(np.float32), 40 + t)
+        ref = O.estimate_gradient(x.astype(np.float32).astype(np.float64), d, avi.MEANFIELD, tgt, eps.cpu().numpy().astype(np.float64), ent)
+        if rule == 0:
+            x = O.descent_step(x, ref["grad"], eta)
+        else:
+            x, ost = O.adam_step(x, ref["grad"], ost, t + 1, eta)
+        x = O.clip_scale(x, d, avi.MEANFIELD, 1e-5)
+    p3 = ctx.to_device(p0).clone()
+    st3 = ctx.empty(2 * p3.numel()).zero_()
+    ctx.optimize_steps(p3, st3 if rule == 1 else None, 40, 0, 2, rule, eta, 1e-5, ctx.empty(2))
+    ctx.synchronize()
+    got = p3.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got - x)) <= 2e-5 * max(1.0, np.max(np.abs(x))), np.max(np.abs(got - x))
+    ctx.close()
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
 def test_update_and_projection_kernels_match_the_numpy_restatement(family, dtype):

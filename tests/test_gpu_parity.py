@@ -192,9 +192,10 @@ def test_graph_batched_estimates_match_single(dtype):
 
 @pytest.mark.parametrize("ent", [3, 4])
 def test_graph_batched_stl_estimates_reuse_the_solve_preparation(ent):
-    """Second-generation STL route: inside one batched call the parameters are fixed, so only the chain's first estimate carries the
-    solve's parameter-only riders.  The last estimate of the batch equals the single call; a replay of the SAME cached graph after
-    the parameters changed in place prepares again."""
+    """Sticking-the-landing estimators in batched calls: inside one call the parameters are fixed, so the parameter-only work is done once
+    per call (the batch engine forms C^-T once -- DESIGN.md 3; with MIVI_FB_STL=0 only the chain's first estimate carries the solve's
+    riders, bitwise: tests/test_gpu_ab_switches.py).  The last estimate of the batch equals the single call to rounding (2e-6: the
+    engine multiplies by the inverse where a single call solves); a call after the parameters changed IN PLACE prepares again."""
     d, M = 256, 128
     rng = np.random.default_rng(21)
     q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
@@ -212,7 +213,9 @@ def test_graph_batched_stl_estimates_reuse_the_solve_preparation(ent):
             v1, g1 = v1.cpu().numpy().copy(), g1.cpu().numpy().copy()
             ctx.estimate_gradient_n(p, 7, count, v, g)
             ctx.synchronize()
-            assert np.array_equal(v.cpu().numpy(), v1) and np.array_equal(g.cpu().numpy(), g1), (scale, count)
+            assert abs(float(v.item()) - float(v1[0])) <= float(np.spacing(np.float32(abs(float(v1[0]))))), (scale, count)
+            gb, gs = g.cpu().numpy().astype(np.float64), g1.astype(np.float64)
+            assert np.linalg.norm(gb - gs) <= 2e-6 * max(1.0, np.linalg.norm(gs)), (scale, count, np.linalg.norm(gb - gs) / np.linalg.norm(gs))
     ctx.close()
 
 

@@ -3,11 +3,12 @@ import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import advancedvi_jl_amd as avi
 for name, d, M, fam in (("C2 mean-field d=1024 M=256", 1024, 256, 0), ("reference bench shape d=10 M=1 mean-field", 10, 1, 0),
-                        ("NS full-rank d=1024 M=256", 1024, 256, 1)):
+                        ("C5 shard: funnel d=2048 M=64 mean-field STL", 2048, 64, 0), ("NS full-rank d=1024 M=256", 1024, 256, 1)):
     q = avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32)) if fam == 0 else avi.FullRankGaussian(np.zeros(d, np.float32), np.eye(d, dtype=np.float32))
     p0, _ = avi.destructure(q)
-    ctx = avi.MiviContext(np.float32, fam, d, M, 0, 1)
-    ctx.set_problem(avi.DiagNormalProblem(np.full(d, 5.0, np.float32), np.ones(d, np.float32)))
+    funnel = "funnel" in name
+    ctx = avi.MiviContext(np.float32, fam, d, M, 3 if funnel else 0, 1)
+    ctx.set_problem(avi.FunnelProblem(d, 3.0) if funnel else avi.DiagNormalProblem(np.full(d, 5.0, np.float32), np.ones(d, np.float32)))
     p = ctx.to_device(p0).clone()
     st = ctx.empty(2 * p.numel()).zero_()
     T = 1000
