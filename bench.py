@@ -954,6 +954,29 @@ def main():
                                             value=1.0 / t_l, unit="steps/s", us_per_step=t_l * 1e6,
                                             note="the optimiser step rides in the VJP epilogue (k_fr_vjp32<FUSED>): 12.6 MB of parameter / moment traffic per step")
                 del p_l, st_l
+                # the same for BASELINE configs[4]'s shard (fused funnel, mean-field, STL): the launch-free loop with its per-step grid-wide
+                # exchange (k_mf_funnel_sgd_loop)
+                try:
+                    w5 = WORKLOADS["c5"]
+                    q5, prob5 = make_problem(avi, w5)
+                    p5h, _ = avi.destructure(q5)
+                    c5x = avi.MiviContext(np.float32, w5["family"], w5["d"], w5["n_mc"], w5["entropy"], SEED, device=local_rank)
+                    c5x.set_problem(prob5)
+                    p5 = c5x.to_device(p5h).clone()
+                    st5 = c5x.empty(2 * p5.numel()).zero_()
+                    c5x.optimize_steps(p5, st5, 0, 0, T_l, 1, 1e-3, 1e-5)
+                    stream.synchronize()
+                    t0s = time.perf_counter()
+                    for r in range(3):
+                        c5x.optimize_steps(p5, st5, (r + 1) * T_l, (r + 1) * T_l, T_l, 1, 1e-3, 1e-5)
+                    stream.synchronize()
+                    t_5 = (time.perf_counter() - t0s) / (3 * T_l)
+                    also["c5_adam_loop"] = dict(workload="configs[4] shard (funnel d=2048 + Stacked, mean-field, STL, n_mc=64), mivi_optimize_steps: Adam(1e-3) + ClipScale(1e-5), 3 x 1000 steps",
+                                                value=1.0 / t_5, unit="steps/s", us_per_step=t_5 * 1e6,
+                                                note="one kernel for all steps; a step = one grid-wide exchange (row 0 couples every row): two cross-XCD hand-offs")
+                    c5x.close()
+                except Exception as e:   # noqa: BLE001
+                    also["c5_adam_loop"] = dict(error=str(e))
             # ---- parity + cpu_baseline leg (rank 0, N = 1 only) ---------------------------------------------
             rel = None
             parity_head = None
