@@ -167,8 +167,12 @@ mivi_status_t ensure_kids(mivi_ctx *c, int lanes) {
     (void)hipFree(k->status.p);                                    // the child's sticky flags: word j + 1 of the parent's status buffer
     k->status.p = (char *)c->status.p + sizeof(int) * (j + 1);    // (borrowed: is_child contexts never free it)
     if ((s = ensure(c, c->kid_out[j], 16 + (size_t)mivi_params_len(c) * c->esize, false))) { (void)mivi_destroy(k); return s; }
-    HIPCHK(c, hipEventCreateWithFlags(&c->ev_join[j], hipEventDisableTiming));
-    if (!c->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    if (hipEventCreateWithFlags(&c->ev_join[j], hipEventDisableTiming) != hipSuccess ||
+        (!c->ev_fork && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess)) {
+      (void)hipGetLastError();
+      (void)mivi_destroy(k);   // (not yet registered with the parent: nobody else would)
+      return fail(c, MIVI_ERR_HIP, "interleaved chains: event creation failed");
+    }
     c->kids[c->n_kids++] = k;
   }
   return MIVI_OK;

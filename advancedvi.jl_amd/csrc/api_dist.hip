@@ -160,8 +160,11 @@ mivi_status_t mivi_p2p_export(mivi_ctx_t *c, int32_t rank, int32_t world, void *
   void *buf = nullptr;
   hipError_t e = hipExtMallocWithFlags(&buf, bytes, hipDeviceMallocFinegrained);
   if (e != hipSuccess) { (void)hipGetLastError(); return fail(c, MIVI_ERR_HIP, "peer-to-peer exchange buffer: fine-grained allocation failed"); }
-  HIPCHK(c, hipMemset(buf, 0, bytes));
-  HIPCHK(c, hipDeviceSynchronize());
+  if ((e = hipMemset(buf, 0, bytes)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
+    (void)hipFree(buf);   // (not yet owned by the context: nothing else would free it)
+    c->err = std::string("peer-to-peer exchange buffer: ") + hipGetErrorString(e);
+    return MIVI_ERR_HIP;
+  }
   c->p2p_buf = buf;
   c->p2p_bytes = bytes;
   c->p2p_rank = rank; c->p2p_world = world; c->p2p_n = n; c->p2p_cn = cn; c->p2p_G = G; c->p2p_vs = vs;
@@ -332,14 +335,21 @@ mivi_status_t mivi_comm_enable_p2p(mivi_ctx_t *c) {
   if (R > 1) {
     RcclApi *r = rccl();
     DevBuf tmp;
-    if ((s = ensure(c, tmp, all.size(), false))) return s;
-    HIPCHK(c, hipMemcpy((char *)tmp.p + (size_t)c->comm_rank * MIVI_P2P_HANDLE_BYTES, all.data() + (size_t)c->comm_rank * MIVI_P2P_HANDLE_BYTES,
-                        MIVI_P2P_HANDLE_BYTES, hipMemcpyHostToDevice));
+    if ((s = ensure(c, tmp, all.size(), false))) { (void)mivi_p2p_detach(c); return s; }
+    auto give_up = [&](const char *why) {   // (the temporary and the exported areas go with every failure)
+      (void)hipGetLastError();
+      (void)hipFree(tmp.p);
+      (void)mivi_p2p_detach(c);
+      return fail(c, MIVI_ERR_HIP, why);
+    };
+    if (hipMemcpy((char *)tmp.p + (size_t)c->comm_rank * MIVI_P2P_HANDLE_BYTES, all.data() + (size_t)c->comm_rank * MIVI_P2P_HANDLE_BYTES,
+                  MIVI_P2P_HANDLE_BYTES, hipMemcpyHostToDevice) != hipSuccess)
+      return give_up("peer-to-peer handles: upload failed");
     const ncclResult_t e = r->AllGather((char *)tmp.p + (size_t)c->comm_rank * MIVI_P2P_HANDLE_BYTES, tmp.p, MIVI_P2P_HANDLE_BYTES, ncclChar,
                                         (ncclComm_t)c->comm, c->stream);
-    if (e != ncclSuccess) { (void)hipFree(tmp.p); (void)mivi_p2p_detach(c); return fail(c, MIVI_ERR_HIP, "ncclAllGather of the peer-to-peer handles failed"); }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(all.data(), tmp.p, all.size(), hipMemcpyDeviceToHost));
+    if (e != ncclSuccess) return give_up("ncclAllGather of the peer-to-peer handles failed");
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(all.data(), tmp.p, all.size(), hipMemcpyDeviceToHost) != hipSuccess)
+      return give_up("peer-to-peer handles: the gathered blobs could not be read back");
     (void)hipFree(tmp.p);
   }
   s = mivi_p2p_attach(c, all.data());
@@ -723,8 +733,9 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
     if (!(c->d_idx_valid && c->d_idx_expect == idx0))
       hipLaunchKernelGGL(k_set_u64x2, dim3(1), dim3(1), 0, c->stream, (uint64_t *)c->d_idx.p, idx0, 0ull, 1);
     if (p2p_pipe && (s = p2p_front())) return s;
-    HIPCHK(c, hipGraphLaunch(g.exec, c->stream));
-    if (p2p_pipe && (s = p2p_back())) return s;
+    const hipError_t ge = hipGraphLaunch(g.exec, c->stream);
+    if (p2p_pipe && (s = p2p_back())) return s;   // (also behind a failed launch: the exchange kernel's waits are bounded, the caller's stream joins it)
+    HIPCHK(c, ge);
     c->d_idx_valid = mode != 3;
     c->d_idx_expect = idx0 + (uint64_t)count;
     return MIVI_OK;
@@ -733,7 +744,10 @@ static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, 
   c->pre_valid = false;
   if (p2p_pipe && (s = p2p_front())) return s;
   s = dist_sequence(c, params, false, idx0, count, value, grad, mode);
-  if (p2p_pipe && s == MIVI_OK) s = p2p_back();
+  if (p2p_pipe) {   // join the exchange stream whatever happened: after a failed sequence its kernel gives up at its bounded waits (status bit 8)
+    const mivi_status_t sb = p2p_back();
+    if (s == MIVI_OK) s = sb;
+  }
   c->cur = 0;
   c->pre_valid = false;
   return s;
