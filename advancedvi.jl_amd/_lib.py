@@ -95,6 +95,7 @@ SIGNATURES = {
     "mivi_estimate_gradient_dist_n": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
     "mivi_p2p_exchange": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "mivi_p2p_partials_direct": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "mivi_p2p_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.c_int32]),
     "mivi_profile_dist": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "mivi_set_bijector_stacked": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mivi_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

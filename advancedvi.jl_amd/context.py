@@ -373,6 +373,13 @@ class MiviContext:
         self._chk(self.lib.mivi_p2p_exchange(self.h, self._p(params), self._p(partials) if partials is not None else None, self._p(value),
                                              self._p(grad), int(phases)))
 
+    def p2p_stats(self, reset=False):
+        """Exchange diagnostics since the last reset (mivi_p2p_stats): waits in us, groups served, bytes per peer and estimate."""
+        out = (C.c_double * 6)()
+        self._chk(self.lib.mivi_p2p_stats(self.h, out, 1 if reset else 0))
+        return dict(wait_handover_us=out[0], wait_pushes_us=out[1], wait_finals_us=out[2], groups=int(out[3]), bytes_per_peer_per_estimate=out[4],
+                    slice_elements=int(out[5]))
+
     def p2p_partials_direct(self, params, idx):
         self._chk(self.lib.mivi_p2p_partials_direct(self.h, self._p(params), int(idx)))
 

@@ -250,6 +250,25 @@ mivi_status_t mivi_p2p_debug_words(mivi_ctx_t *c, uint32_t *out128) {   // devel
   return MIVI_OK;
 }
 
+// Diagnostics of the peer-to-peer exchange since the last reset (workgroup 0 of the exchange kernel; 100 MHz wall clock): out[0..2] = microseconds
+// spent waiting for {the compute chain's hand-over, the peers' pushes (arrival flags), the owners' reduced chunks (final flags)}, out[3] = groups
+// of estimates served, out[4] = payload bytes this rank stores into EACH peer per estimate (one slice pushed + one finished slice gathered),
+// out[5] = slice length in elements.  A first multi-GPU run is diagnosable from these (bench.py --gpus N prints them per rank).
+mivi_status_t mivi_p2p_stats(mivi_ctx_t *c, double *out6, int32_t reset) {
+  if (!c || !out6) return MIVI_ERR_BAD_ARG;
+  if (!c->p2p_on || !c->p2p_ctr.p) return fail(c, MIVI_ERR_BAD_ARG, "no peer-to-peer exchange buffers attached");
+  (void)hipSetDevice(c->cfg.device);
+  unsigned long long h[4] = {0, 0, 0, 0};
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(h, (unsigned *)c->p2p_ctr.p + 96, sizeof h, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 3; ++k) out6[k] = (double)h[k] * 0.01;
+  out6[3] = (double)h[3];
+  out6[4] = 2.0 * (double)c->p2p_n * (double)c->esize;
+  out6[5] = (double)c->p2p_n;
+  if (reset) HIPCHK(c, hipMemset((unsigned *)c->p2p_ctr.p + 96, 0, sizeof h));
+  return MIVI_OK;
+}
+
 mivi_status_t mivi_p2p_set_pipeline(mivi_ctx_t *c, int32_t on) {
   if (!c) return MIVI_ERR_BAD_ARG;
   // (a second persistent exchange kernel serving every other group was an option until the groups: two of them are 512 resident

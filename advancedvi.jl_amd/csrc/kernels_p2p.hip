@@ -71,6 +71,8 @@ struct P2PArgs {
   int direct;                // the partial kernels stored every vector straight into the owners' staging areas (OutArgs::p2p_direct): phase 1 only
                              // raises the arrival flags, and a ring slot = a staging slot, released (`freed`) once this rank has the FINAL chunks of
                              // its epoch -- which the owners stored after they had read their staging areas
+  unsigned long long *stats; // diagnostics, accumulated by workgroup 0: ticks of the 100 MHz wall clock spent waiting for [0] the compute chain's hand-over,
+                             // [1] the arrival flags of its chunk (the peers' pushes), [2] the final flags (the owners' reduced chunks); [3] groups served
   const unsigned *ready;     // batch hand-over (nullptr: the partial vector is complete at launch): estimate t may start when *ready >= t + 1
   unsigned *freed;           // [ring]: += 1 by every chunk workgroup once its part of the vector in that ring slot has been read
 };
@@ -246,6 +248,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int p = (int)(epoch & 1u);
     const int t0 = gi * GV, nv = a.count - t0 < GV ? a.count - t0 : GV;
     const bool first_group = (gi == a.lane);
+    const bool timed = a.stats && g == 0 && tid == 0;
+    long long tk0 = timed ? (long long)wall_clock64() : 0;
     if (a.ready) {   // hand-over from the compute chain: the partial vectors of the group's estimates are complete
       if (tid == 0) {
         int budget = lost ? 64 : a.spin_budget;   // (after a lost peer every further wait of this launch gives up at once: a dead batch ends in milliseconds)
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
       __syncthreads();
     }
 
+    if (timed) { const long long tk1 = (long long)wall_clock64(); a.stats[0] += (unsigned long long)(tk1 - tk0); a.stats[3] += 1ull; }
     // ---- phase 1: push chunk g of every slice of every vector to its owner, then one arrival flag per owner ---------------------------
     if ((a.phases & 1) && !value_wg) {
       // The areas are double-buffered by epoch parity with no acknowledgements: safe for the chunk workgroups because workgroup g of
@@ -330,7 +335,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 
     // ---- phase 2: reduce + finalise chunk g of MY slice of every vector, push the final chunks to every rank, one final flag per rank ------
     if ((a.phases & 2) && !value_wg) {
+      tk0 = timed ? (long long)wall_clock64() : 0;
       if (!wait_flags<NT>(tb.arr[ln][a.rank] + (size_t)(p * R) * G + g, R, G, epoch, lost ? 64 : a.spin_budget, &sh_ok)) lost = true;
+      if (timed) a.stats[1] += (unsigned long long)((long long)wall_clock64() - tk0);
       for (int v = 0; v < nv; ++v) {
         const int pv = p * GV + v;
         if (R == 1) p2p_reduce_chunk<T, 1, NT>(a, tb, pv, c0, clen);
@@ -396,7 +403,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         if (tid == 0) __hip_atomic_store(a.ctr + 2, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       } else {
         // chunk g of every owner's slice: R final flags
+        tk0 = timed ? (long long)wall_clock64() : 0;
         if (!wait_flags<NT>(tb.farr[ln][a.rank] + (size_t)(p * R) * (G + 1) + g, R, G + 1, epoch, lost ? 64 : a.spin_budget, &sh_ok)) lost = true;
+        if (timed) a.stats[2] += (unsigned long long)((long long)wall_clock64() - tk0);
         const int vecs = (int)(clen / V), total = vecs * R;   // vector index x = s * vecs + u  (32-bit: 64-bit divides are long sequences)
         for (int v = 0; v < nv; ++v) {
           const T *fin = (const T *)tb.fin[ln][a.rank] + (size_t)(p * GV + v) * R * n;
@@ -510,6 +519,7 @@ void launch_p2p_exchange(mivi_ctx *c, const void *params, const void *const *P, 
     a.rank = c->p2p_rank; a.world = c->p2p_world; a.G = c->p2p_G; a.vs = c->p2p_vs;
     a.tab = (const P2PTable *)c->p2p_tab.p;
     a.ctr = (unsigned *)c->p2p_ctr.p + 16 * lane;
+    a.stats = (unsigned long long *)((unsigned *)c->p2p_ctr.p + 96);   // (words 96 .. 103 of the counter block: mivi_p2p_stats)
     a.status = (int *)c->status.p;
     a.phases = phases;
     a.spin_budget = c->p2p_spin;

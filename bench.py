@@ -763,6 +763,28 @@ def main():
             dt = float(t.item())
 
         if not single:
+            # per-rank diagnostics of the timed region's exchange (route p2p): what the exchange kernel waited for -- the own compute chain,
+            # the peers' pushes, the owners' reduced chunks -- and the bytes stored into every peer: one line tells a slow link from a slow rank
+            try:
+                ps = ctx.p2p_stats(reset=True)
+                mine = torch.tensor([float(rank), ps["wait_handover_us"], ps["wait_pushes_us"], ps["wait_finals_us"], float(ps["groups"]),
+                                     ps["bytes_per_peer_per_estimate"]], dtype=torch.float64, device=f"cuda:{local_rank}")
+                allr = [torch.zeros_like(mine) for _ in range(world)]
+                if dist and world > 1:
+                    dist.all_gather(allr, mine)
+                else:
+                    allr = [mine]
+                dist_info["per_rank"] = [dict(rank=int(t[0]), groups_of_estimates=int(t[4]),
+                                              wait_us_per_group=dict(own_compute_chain=round(float(t[1]) / max(1.0, float(t[4])), 2),
+                                                                     peers_pushes=round(float(t[2]) / max(1.0, float(t[4])), 2),
+                                                                     owners_reduced_chunks=round(float(t[3]) / max(1.0, float(t[4])), 2)),
+                                              bytes_to_each_peer_per_estimate=int(t[5]),
+                                              link_GBs_if_exchange_bound=round(float(t[5]) * (K / max(dt, 1e-9)) / 1e9, 2))
+                                         for t in (x.cpu() for x in allr)]
+                dist_info["per_rank_note"] = ("exchange kernel workgroup 0, since the last reset (the pre-heat calls + the timed region); a rank whose "
+                                              "peers_pushes wait stands out sits behind a slow sender or link, a large own_compute_chain wait means the exchange is not the bound")
+            except Exception as e:   # noqa: BLE001  -- another route than p2p
+                dist_info["per_rank_error"] = str(e)
             # per-stage times of the sharded step (hipEvents around hipGraph replays of 20 estimates, every rank collectively):
             # partial kernels | exchange + finalisation | the dependent-chain step | the pipelined step
             try:

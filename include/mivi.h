@@ -362,6 +362,10 @@ mivi_status_t mivi_estimate_gradient_dist_n(mivi_ctx_t *ctx, const void *params_
  * several ranks living in ONE process can be sequenced from one host thread.  partials_dev: the rank's partial vector, zero padded. */
 mivi_status_t mivi_p2p_exchange(mivi_ctx_t *ctx, const void *params_dev, const void *partials_dev, void *value_dev, void *grad_dev,
                                 int32_t phases);
+/* Diagnostics of the peer-to-peer exchange since the last reset, one line per rank makes a first multi-GPU run readable: out6[0..2] <- microseconds
+ * the exchange kernel (its workgroup 0) waited for {the compute chain's hand-over, the peers' pushes, the owners' reduced chunks}, out6[3] <- groups
+ * of estimates served, out6[4] <- payload bytes stored into EACH peer per estimate, out6[5] <- slice length (elements).  reset != 0 zeroes them. */
+mivi_status_t mivi_p2p_stats(mivi_ctx_t *ctx, double *out6, int32_t reset);
 /* Tests: the partial kernels of one estimate with DIRECT staging -- every entry of the rank's partial vector is stored straight into its
  * owner's staging area (no ring slot, no push pass; what mivi_estimate_gradient_dist[_n] do on the peer-to-peer route for the full-rank f32
  * family); follow with mivi_p2p_exchange(ctx, params, NULL, value, grad, phases).  MIVI_ERR_UNSUPPORTED for other configurations. */

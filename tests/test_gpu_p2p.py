@@ -154,6 +154,10 @@ def test_one_rank_exchanges_with_itself(family, d, M):
         ctx.synchronize()
         assert abs(float(v1.item()) - v0) <= 2e-6 * abs(v0)
         assert np.linalg.norm(g1.cpu().numpy() - g0) <= 5e-6 * max(1.0, np.linalg.norm(g0))
+    st = ctx.p2p_stats(reset=True)                          # diagnostics of the three exchanges (bench.py --gpus N prints them per rank)
+    assert st["groups"] == 3 and st["slice_elements"] >= ctx.partials_len and st["bytes_per_peer_per_estimate"] == 2 * st["slice_elements"] * 4
+    assert all(st[k] >= 0.0 for k in ("wait_handover_us", "wait_pushes_us", "wait_finals_us"))
+    assert ctx.p2p_stats()["groups"] == 0
     ctx.p2p_detach()
     assert ctx.comm_route() == "none"
     ctx.close()
