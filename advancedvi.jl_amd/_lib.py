@@ -117,6 +117,13 @@ def load():
             f"libmivi.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback."
         )
+    # torch first: this mirror takes its device memory and streams from torch, whose wheel carries its own HIP runtime.  libmivi must bind to
+    # THAT copy -- loaded before torch it pulls in the system's libamdhip64, the process then holds two HIP / HSA runtimes and the second one
+    # to initialise finds no device ("no usable HIP device 0 (found 0)"; seen with build() and smoke() in one process)
+    try:
+        import torch  # noqa: F401
+    except ImportError:   # (a host without torch: the C ABI alone, the system runtime)
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
