@@ -785,6 +785,46 @@ def main():
                                               "peers_pushes wait stands out sits behind a slow sender or link, a large own_compute_chain wait means the exchange is not the bound")
             except Exception as e:   # noqa: BLE001  -- another route than p2p
                 dist_info["per_rank_error"] = str(e)
+            # Beside the sample-sharded line (`value`: what the north star names -- every estimate's samples over the ranks, the gradient exchanged):
+            # the same K steps per rank with the ESTIMATES sharded instead -- every rank runs the one-GPU batch engine on estimate indices of
+            # its own, no collective.  Estimates at fixed parameters are independent units; this is what a batch of them should do on N GPUs
+            # (DESIGN.md 7), reported as an extra, never as `value`.
+            try:
+                ctx1 = avi.MiviContext(np.float32, w["family"], w["d"], w["n_mc"], ent.code, SEED, device=local_rank)
+                ctx1.set_problem(prob)
+                p1 = ctx1.to_device(params_h)
+                v1, g1 = ctx1.empty(1), ctx1.empty(ctx1.params_len)
+                ch1 = max(1, min(args.graph_chunk, K))
+                base1 = (rank + 1) * (1 << 32)
+
+                def run1(i0, n):
+                    done = 0
+                    while done + ch1 <= n:
+                        ctx1.estimate_gradient_n(p1, base1 + i0 + done, ch1, v1, g1)
+                        done += ch1
+                    for i in range(done, n):
+                        ctx1.estimate_gradient(p1, base1 + i0 + i, v1, g1)
+                for r in range(3):
+                    run1(r * K, K)
+                torch.cuda.synchronize()
+                if dist:
+                    dist.barrier()
+                t1s = time.perf_counter()
+                run1(3 * K, K)
+                torch.cuda.synchronize()
+                if dist:
+                    dist.barrier()
+                dt1 = time.perf_counter() - t1s
+                if dist:
+                    tt = torch.tensor([dt1], dtype=torch.float64, device=f"cuda:{local_rank}")
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    dt1 = float(tt.item())
+                dist_info["estimate_sharded"] = dict(value=K * world / dt1, unit="estimates/s", ms_per_step=dt1 / K * 1e3,
+                                                     note="every rank: K estimates of n_mc samples on indices of its own (mivi_estimate_gradient_n, the batch engine), "
+                                                          "no collective; barrier + max over ranks like the timed region")
+                ctx1.close()
+            except Exception as e:   # noqa: BLE001
+                dist_info["estimate_sharded"] = dict(error=str(e))
             # per-stage times of the sharded step (hipEvents around hipGraph replays of 20 estimates, every rank collectively):
             # partial kernels | exchange + finalisation | the dependent-chain step | the pipelined step
             try:
