@@ -121,6 +121,14 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);
   }
+  if (simple && (rule == 0 || default_adam) && fr_small_loop_ok(c) && !no_fused_loop) {
+    // small full-rank problems (the reference's own benchmark grid: d = 10, one sample per step): the whole loop in ONE workgroup
+    HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
+    launch_fr_small_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, rec, vbuf);
+    HIPCHK(c, hipGetLastError());
+    if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
+    return read_status(c);
+  }
   if (simple && (rule == 0 || default_adam) && c->cfg.family == MIVI_MEANFIELD && c->target == TGT_FUNNEL && !c->funnel_constrained && !c->bij_on &&
       c->cfg.n_mc <= 256 && c->cfg.d <= 16384 && !no_fused_loop) {
     // launch-free loop for the fused funnel target: the row quads and the row-0 workgroup of ONE kernel exchange two scalars per workgroup and

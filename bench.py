@@ -1039,6 +1039,32 @@ def main():
                     c5x.close()
                 except Exception as e:   # noqa: BLE001
                     also["c5_adam_loop"] = dict(error=str(e))
+                # the reference's OWN benchmark grid (bench/benchmarks.jl:43-94: optimize(alg, 10^4, normal(n_dims = 10), q), one sample per step,
+                # Adam(1e-3), ClipScale; families x {ClosedFormEntropy, StickingTheLandingEntropy}): whole loops inside one kernel
+                try:
+                    rb = {}
+                    for nm, fam_r, ent_r in (("meanfield", 0, 0), ("meanfield_stl", 0, 3), ("fullrank", 1, 0), ("fullrank_stl", 1, 3)):
+                        d_r = 10
+                        q_r = (avi.MeanFieldGaussian(np.zeros(d_r, np.float32), np.ones(d_r, np.float32)) if fam_r == 0
+                               else avi.FullRankGaussian(np.zeros(d_r, np.float32), np.eye(d_r, dtype=np.float32)))
+                        p_rh, _ = avi.destructure(q_r)
+                        c_r = avi.MiviContext(np.float32, fam_r, d_r, 1, ent_r, SEED, device=local_rank)
+                        c_r.set_problem(avi.DiagNormalProblem(np.full(d_r, 5.0, np.float32), np.ones(d_r, np.float32)))
+                        p_r = c_r.to_device(p_rh).clone()
+                        s_r = c_r.empty(2 * p_r.numel()).zero_()
+                        c_r.optimize_steps(p_r, s_r, 0, 0, 1000, 1, 1e-3, 1e-5)
+                        stream.synchronize()
+                        t0s = time.perf_counter()
+                        c_r.optimize_steps(p_r, s_r, 1000, 1000, 10_000, 1, 1e-3, 1e-5)
+                        stream.synchronize()
+                        t_r = (time.perf_counter() - t0s) / 10_000
+                        rb[nm] = dict(steps_per_s=1.0 / t_r, us_per_step=t_r * 1e6, seconds_for_the_reference_benchmark_run=t_r * 1e4)
+                        c_r.close()
+                    also["reference_benchmark_grid"] = dict(workload="bench/benchmarks.jl: normal target d=10, n_samples=1, Adam(1e-3) + ClipScale, 10^4 iterations, f32",
+                                                            value=rb["fullrank"]["steps_per_s"], unit="steps/s", grid=rb,
+                                                            note="device-resident loops (mean-field: k_mf_sgd_loop; full-rank: k_fr_small_loop, one workgroup)")
+                except Exception as e:   # noqa: BLE001
+                    also["reference_benchmark_grid"] = dict(error=str(e))
             # ---- parity + cpu_baseline leg (rank 0, N = 1 only) ---------------------------------------------
             rel = None
             parity_head = None

@@ -162,6 +162,73 @@ def test_device_resident_loop_matches_host_loop(family, rule, shape):
     ctx.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", [(10, 1), (10, 8), (32, 16), (5, 64), (17, 3), (32, 64)], ids=["reference-bench", "d10-m8", "d32-m16", "d5-m64", "ragged", "largest"])
+@pytest.mark.parametrize("rule", [0, 1], ids=["descent", "adam"])
+@pytest.mark.parametrize("ent", [0, 3, 2], ids=["CFE", "STL", "MC"])
+def test_small_fullrank_loop(ent, rule, shape, dtype):
+    """Small full-rank problems (d <= 32, n_mc <= 64; the reference's own benchmark grid, bench/benchmarks.jl:43-94: d = 10, one sample per
+    step, full-rank, ClosedFormEntropy / StickingTheLandingEntropy, Adam, ClipScale): mivi_optimize_steps runs the whole loop in ONE
+    workgroup (k_fr_small_loop).  Its sums are sequential fused multiply-adds, not the tile kernels' MFMA chains: the trajectory equals the
+    step-by-step sequence of single calls + update + ClipScale launches to rounding (stated here), and the oracle's gradient + numpy rules."""
+    d, M = shape
+    T = 12
+    rng = np.random.default_rng(11)
+    tm, ts = rng.normal(size=d).astype(dtype), rng.uniform(0.5, 2, size=d).astype(dtype)
+    C0 = (np.eye(d) + 0.1 * np.tril(rng.normal(size=(d, d)), -1)).astype(dtype)
+    q0 = avi.FullRankGaussian(np.zeros(d, dtype), C0)
+    p0, _ = avi.destructure(q0)
+    eta = 1e-2
+    ctx = avi.MiviContext(dtype, avi.FULLRANK, d, M, ent, SEED)
+    ctx.set_problem(avi.DiagNormalProblem(tm, ts))
+    p = ctx.to_device(p0).clone()
+    st = ctx.empty(2 * p.numel()).zero_()
+    elbos = []
+    for t in range(T):
+        v, g = ctx.estimate_gradient(p, 70 + t)
+        elbos.append(-float(v.item()))
+        if rule == 0:
+            ctx.descent_update(p, g, eta)
+        else:
+            ctx.adam_update(p, g, st, t + 1, eta)
+        ctx.clip_scale(p, 1e-5)
+    p2 = ctx.to_device(p0).clone()
+    st2 = ctx.empty(2 * p2.numel()).zero_()
+    elbo = ctx.empty(T)
+    ctx.optimize_steps(p2, st2 if rule == 1 else None, 70, 0, 7, rule, eta, 1e-5, elbo[:7])
+    ctx.optimize_steps(p2, st2 if rule == 1 else None, 77, 7, T - 7, rule, eta, 1e-5, elbo[7:])   # a second call continues (indices, Adam's t)
+    ctx.synchronize()
+    tol = 3e-5 if dtype == np.float32 else 1e-11
+    a, b = p.cpu().numpy().astype(np.float64), p2.cpu().numpy().astype(np.float64)
+    low = np.concatenate([np.ones(d, bool), np.tril(np.ones((d, d), bool)).T.reshape(-1)])      # [mu; vec C column-major]: entries on / below the diagonal
+    assert np.max(np.abs(a[low] - b[low])) <= tol * max(1.0, np.max(np.abs(a[low]))), np.max(np.abs(a[low] - b[low]))
+    assert np.array_equal(b[~low], p0.astype(np.float64)[~low])                                 # nothing above the diagonal is touched
+    assert np.allclose(elbo.cpu().numpy().astype(np.float64), np.array(elbos), rtol=5e-5 if dtype == np.float32 else 1e-10, atol=1e-4 if dtype == np.float32 else 1e-10)
+    if rule == 1:
+        sa, sb = st.cpu().numpy().astype(np.float64), st2.cpu().numpy().astype(np.float64)
+        low2 = np.concatenate([low, low])
+        assert np.max(np.abs(sa[low2] - sb[low2])) <= tol * max(1.0, np.max(np.abs(sa[low2])))
+    # independent restatement: oracle gradient on the device's own eps -> numpy rules -> ClipScale, in f64
+    x = p0.astype(np.float64)
+    ost = (np.zeros_like(x), np.zeros_like(x))
+    tgt = O.DiagNormalTarget(tm, ts)
+    for t in range(3):
+        _, eps = ctx.sample(x.astype(dtype), 70 + t)
+        ref = O.estimate_gradient(x.astype(dtype).astype(np.float64), d, avi.FULLRANK, tgt, eps.cpu().numpy().astype(np.float64), ent)
+        if rule == 0:
+            x = O.descent_step(x, ref["grad"], eta)
+        else:
+            x, ost = O.adam_step(x, ref["grad"], ost, t + 1, eta)
+        x = O.clip_scale(x, d, avi.FULLRANK, 1e-5)
+    p3 = ctx.to_device(p0).clone()
+    st3 = ctx.empty(2 * p3.numel()).zero_()
+    ctx.optimize_steps(p3, st3 if rule == 1 else None, 70, 0, 3, rule, eta, 1e-5, ctx.empty(3))
+    ctx.synchronize()
+    got = p3.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got[low] - x[low])) <= (2e-5 if dtype == np.float32 else 1e-11) * max(1.0, np.max(np.abs(x[low]))), np.max(np.abs(got[low] - x[low]))
+    ctx.close()
+
+
 @pytest.mark.parametrize("shape", [(64, 32), (2048, 64), (96, 200), (10, 5), (513, 256)], ids=["small", "c5", "four-waves", "tiny", "ragged"])
 @pytest.mark.parametrize("rule", [0, 1], ids=["descent", "adam"])
 @pytest.mark.parametrize("ent", [3, 0], ids=["STL", "CFE"])
