@@ -1,4 +1,4 @@
-// Launch-free optimisation loop for SMALL full-rank problems (d <= 32, n_mc <= 64): the reference's own benchmark grid
+// Launch-free optimisation loop for SMALL full-rank problems (d <= 32, n_mc <= 64, d x n_mc <= 768; see fr_small_loop_ok): the reference's own benchmark grid
 // (bench/benchmarks.jl:43-94: `optimize(alg, 10^4, normal(n_dims = 10), q)` with one sample per step, mean-field and full-rank families,
 // ClosedFormEntropy and StickingTheLandingEntropy, Adam(1e-3), ClipScale) and its README-sized neighbours.
 //
@@ -103,7 +103,8 @@ __global__ __launch_bounds__(256) void k_fr_small_loop(FrSmallLoopArgs<T> a) {
     for (int o = tid; o < d * M; o += NT) {
       const int m = o / d, i = o - m * d;
       T z = mus[i];
-      for (int k = 0; k <= i; ++k) z = fma(Cs[k * d + i], E[m * d + k], z);
+#pragma unroll 8
+      for (int k = 0; k <= i; ++k) z = fma(Cs[k * d + i], E[m * d + k], z);   // (unrolled: the LDS reads of eight terms in flight, one chain of fmas)
       const T uu = (z - tms[i]) * tiss[i];
       ell = fma(T(-0.5) * uu, uu, ell);
       const T er = E[m * d + i];
@@ -165,8 +166,10 @@ __global__ __launch_bounds__(256) void k_fr_small_loop(FrSmallLoopArgs<T> a) {
       const int i = ei[u], j = ej[u];
       T v = 0;
       if (j < 0) {
+#pragma unroll 8
         for (int m = 0; m < M; ++m) v += Wl[m * d + i] + (stl ? U[m * d + i] : T(0));
       } else {
+#pragma unroll 8
         for (int m = 0; m < M; ++m) v = fma(Wl[m * d + i] + (stl ? U[m * d + i] : T(0)), E[m * d + j], v);
       }
       double gx = -(double)v * invM;
@@ -189,9 +192,14 @@ __global__ __launch_bounds__(256) void k_fr_small_loop(FrSmallLoopArgs<T> a) {
   }
 }
 
+// Where ONE workgroup beats the graph of launches (tools/small_loop_bench.py, us per step, this loop / the graph): d x n_mc = 10 x 1: 2.3 / 8.8
+// (STL 3.9 / 17.2), 16 x 32: 4.9 / 9.0 (STL 15.5 / 18.5), 32 x 16: 6.3 / 9.7 (STL 17.2 / 19.0), 10 x 64: 7.2 / 9.1 (STL 20.4 / 19.1),
+// 32 x 32: 10.0 / 9.6, 32 x 64: 17.8 / 9.9 -- the single workgroup's time grows with d x n_mc, a launch's hardly does.
 bool fr_small_loop_ok(const mivi_ctx *c) {
+  const bool stl = c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD;
+  const long long dm = (long long)c->cfg.d * c->cfg.n_mc;
   return c->cfg.family == MIVI_FULLRANK && c->target == TGT_DIAG_GAUSS && !c->bij_on && c->cfg.d <= kSmallD && c->cfg.n_mc <= kSmallM &&
-         c->cfg.m_offset == 0 && c->M_total == c->cfg.n_mc;
+         dm <= (stl ? 512 : 768) && c->cfg.m_offset == 0 && c->M_total == c->cfg.n_mc;
 }
 
 template <typename T>

@@ -5,7 +5,8 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import advancedvi_jl_amd as avi
-for fam, d, M, ent in ((0, 10, 1, 0), (1, 10, 1, 0), (1, 10, 1, 3), (1, 10, 8, 0), (1, 32, 16, 0), (1, 64, 32, 0)):
+SHAPES = [tuple(int(x) for x in s.split(",")) for s in sys.argv[1:]] or [(0, 10, 1, 0), (1, 10, 1, 0), (1, 10, 1, 3), (1, 10, 8, 0), (1, 32, 16, 0), (1, 64, 32, 0)]
+for fam, d, M, ent in SHAPES:
     q = avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32)) if fam == 0 else avi.FullRankGaussian(np.zeros(d, np.float32), np.eye(d, dtype=np.float32))
     p0, _ = avi.destructure(q)
     ctx = avi.MiviContext(np.float32, fam, d, M, ent, 1)
