@@ -129,6 +129,16 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);
   }
+  if (simple && (rule == 0 || default_adam) && fr_rows_loop_ok(c) && !no_fused_loop && fr_rows_eps_bytes(c, n_steps) <= ((size_t)1 << 31)) {
+    // full-rank family, few samples per step, elementwise target: the rows are independent -- every workgroup keeps its rows' parameters and
+    // optimiser state in registers for all n_steps (k_fr_rows_loop); eps of the whole call is drawn up front
+    if ((s = ensure(c, c->rows_eps, fr_rows_eps_bytes(c, n_steps), false))) return s;
+    HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
+    launch_fr_rows_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, (float *)c->rows_eps.p, rec + n_steps, rec, vbuf);
+    HIPCHK(c, hipGetLastError());
+    if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
+    return read_status(c);
+  }
   if (simple && (rule == 0 || default_adam) && c->cfg.family == MIVI_MEANFIELD && c->target == TGT_FUNNEL && !c->funnel_constrained && !c->bij_on &&
       c->cfg.n_mc <= 256 && c->cfg.d <= 16384 && !no_fused_loop) {
     // launch-free loop for the fused funnel target: the row quads and the row-0 workgroup of ONE kernel exchange two scalars per workgroup and

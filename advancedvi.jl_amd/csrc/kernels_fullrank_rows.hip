@@ -1,0 +1,379 @@
+// Launch-free optimisation loop for the full-rank family with FEW samples per step (n_mc <= 32; the reference's default is n_samples = 1,
+// src/algorithms/klminrepgraddescent.jl; d <= 1024) and the diagonal-Gaussian target, f32.
+//
+// Reference semantics per iteration (src/algorithms/common.jl:69-104): estimate_gradient! (src/algorithms/repgradelbo.jl:151-177) with
+//   z = mu + tril(C) eps (src/families/location_scale.jl:71-77),  W = grad log pi(z),
+//   d/dmu = -(1/M) W 1,  d/dC = -(1/M) tril(W eps') - direct diag(1 / C_ii)            
+// then Optimisers.update! (Descent / Adam) and ClipScale.
+//
+// With few samples a step of the general route is two launches of tile kernels built for n_mc >= 128 (first generation below that): 13-20 us
+// per step at d = 256 .. 1024, almost all of it launch latency and parameter traffic.  But for a target whose gradient is elementwise in z
+// (the diagonal Gaussian) ROW i of the problem -- C[i, 0..i], mu_i, their optimiser state -- needs nothing from any other row: z_i is a dot
+// product of row i with eps, W_i a function of z_i, and d/dC[i, k] = -(1/M) sum_m W_im eps_km.  The only thing the rows share is eps.  So, as
+// in the mean-field loop (k_mf_sgd_loop), a workgroup can OWN rows for all n_steps with their parameters and Adam moments in registers:
+//   * eps of ALL steps of the call is drawn first by one launch (k_eps_steps: [step][k][m], the same Philox stream as every other route);
+//   * workgroup b owns the row pairs (2b, d-1-2b) and (2b+1, d-2-2b): every pair holds d + 1 entries, so all workgroups carry the same work
+//     (256 of them at d = 1024, one per CU); 128 threads per pair, the first ceil((p+1)/9) of them nine consecutive entries of row p each,
+//     the others nine of row q: a thread works for ONE row (one set of per-sample accumulators);
+//   * a step: the step's eps slab (fresh addresses every step: plain loads, L2-shared by the workgroups of an XCD) is copied into LDS; partial
+//     dot products of the thread's entries for every sample, wave sums + one LDS exchange per pair -> z, W, ell; the gradient entries from W
+//     and the slab; update + ClipScale in registers.  Three barriers per step, no grid-wide synchronisation at all.  The slab's row stride is
+//     padded to 4 x odd words (n_mc 8 -> 12, 16 -> 20, 32 -> 36) so that the 16-byte LDS reads of lanes nine rows apart fall on distinct
+//     banks (unpadded: 26 us per step at n_mc = 16, 87 us at 32, against 20 us for the launches);
+//   * per-step partials {sum ell, sum 0.5 eps^2, sum log C_ii, #non-positive C_ii} per workgroup; elbo[t] assembled afterwards
+//     (k_fr_rows_value).
+// Sums are sequential f32 fused multiply-adds in a fixed order (deterministic); a trajectory equals the launch-per-step one to rounding
+// (tests/test_gpu_optimize.py::test_fullrank_rows_loop).  Not for the sticking-the-landing estimators (C^-T eps couples the rows) and not
+// for other targets; MIVI_NO_FUSED_LOOP=1 keeps the graph of launches.
+#include <cstdlib>
+#include <type_traits>
+
+#include "device_common.h"
+#include "optim_rules.h"
+
+namespace mivi {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct FrRowsArgs {
+  int d, M, Mp, nch, n_steps, rule, ent_kind, m_offset, M_total;
+  float *params, *opt_state;       // [mu; vec C column-major]; Adam: [m (d + d^2); v (d + d^2)]
+  const float *t_mean, *t_istd;
+  const float *eps_all;            // [n_steps][d][Mp], columns M .. Mp - 1 zero
+  long long t0;
+  double eta, clip_eps, b1, b2, adam_eps;
+  double *hist;                    // [n_steps][4][n_wg]
+};
+
+constexpr int kRowsEPT = 9;        // entries of a row per thread (128 threads per pair of rows: d + 1 <= 9 * 126)
+constexpr int kRowsNT = 256;       // two pairs of rows per workgroup, two waves each (three waves -- one for row p, two for row q, no wave
+                                   // working for both rows -- measured slower: 8.4 against 7.7 us per step at d = 1024, n_mc = 16)
+constexpr int kRowsMaxM = 32;
+
+// the slab's sample columns: 1, 2, 4 as they are; above that a multiple of 8 (the kernel's sample chunk) + 4 = 4 x odd
+static int rows_mm(int M) { return M <= 2 ? M : (M <= 4 ? 4 : ((M + 7) & ~7)); }
+static int rows_mp(int MM) { return MM <= 4 ? MM : MM + 4; }
+
+// eps of n_steps estimates, [t][k][Mp]: one Philox block (rows 4 q .. 4 q + 3 of column m of estimate idx0 + t) per thread; zero pads
+__global__ __launch_bounds__(256) void k_eps_steps(uint64_t seed, uint64_t idx0, int n_steps, int d, int M, int Mp, int m_offset, float *out) {
+  const int d4 = (d + 3) >> 2;
+  const long long n = (long long)n_steps * d4 * Mp, i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int t = (int)(i / ((long long)d4 * Mp)), r = (int)(i - (long long)t * d4 * Mp);
+  const int q = r / Mp, m = r - q * Mp;   // (consecutive threads: consecutive samples of one row quad -> contiguous stores per row)
+  float e[4] = {0.f, 0.f, 0.f, 0.f};
+  if (m < M) eps_block<float>(seed, idx0 + (uint64_t)t, (uint64_t)(m_offset + m) * (uint64_t)d4 + (uint64_t)q, e);
+  float *o = out + ((size_t)t * d + 4 * q) * Mp + m;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+    if (4 * q + rr < d) o[(size_t)rr * Mp] = e[rr];
+}
+
+#define ROWS_GLDS16(gptr, lptr)                                                            \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), \
+                                   (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
+
+// RULE: 0 Descent, 1 Adam.  MC: samples per chunk (1, 2, 4: the whole batch; 8: a.nch chunks).  DB: two slabs fit the LDS -- the next
+// step's slab arrives (LDS-DMA, no registers) while this step computes.
+template <int RULE, int MC, bool DB>
+__global__ __launch_bounds__(kRowsNT) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_fr_rows_loop(FrRowsArgs a) {
+  constexpr int NT = kRowsNT, EPT = kRowsEPT, ZS = kRowsMaxM;
+  extern __shared__ __attribute__((aligned(16))) float S[];   // eps slab(s) [k][Mp], then the small exchange areas
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int d = a.d, M = a.M, Mp = a.Mp, nch = MC == 8 ? a.nch : 1, nwg = gridDim.x, b = blockIdx.x;
+  const int slabN = d * Mp;                   // (a multiple of 4)
+  float *zred = S + (DB ? 2 : 1) * slabN;     // [4 waves][2 rows][ZS]: wave partials of the dot products
+  float *sc = zred + 4 * 2 * ZS;              // [step parity][pair][row]{mu, C_rr}; [16 ..]: [pair][row] scalar partials {ell, he, lg, bad}
+  float(*cc_tab)[2] = reinterpret_cast<float(*)[2]>(sc + 16 + 16);   // [256][2] Adam bias corrections
+  const int pr = tid >> 7, t7 = tid & 127;    // the pair this thread works for, its index inside the pair
+  const int p = 2 * b + pr, q = d - 1 - p;    // rows p and q (one row when they meet, none beyond)
+  const bool pair_ok = p <= q, two = p < q;
+  const int nA = pair_ok ? (p + EPT) / EPT : 0;   // threads of row p: ceil((p + 1) / EPT)
+  const bool isA = t7 < nA;
+  const int row = isA ? p : q, k0 = (isA ? t7 : t7 - nA) * EPT;
+  const bool row_ok = pair_ok && (isA || two);
+  const int rs = isA ? 0 : 1;                 // the row's slot inside the pair
+  const bool mixed = !__all(isA) && !__all(!isA);   // (wave-uniform: this wave works for both rows)
+  const double direct = direct_entropy_coeff(a.ent_kind);
+  const float invMf = 1.f / (float)a.M_total;
+  const double invM = 1.0 / (double)a.M_total;
+  const float eta = (float)a.eta, b1 = (float)a.b1, b2 = (float)a.b2, aeps = (float)a.adam_eps, ceps = (float)a.clip_eps;
+  const bool clip = a.clip_eps == a.clip_eps;
+  const size_t plen = (size_t)d + (size_t)d * d;
+
+  // this thread's entries C[row, k0 .. k0 + 8]
+  bool eok[EPT];
+  int eo[EPT];                                // slab offsets of their eps rows (an entry beyond the row has px = 0 and reads row d - 1)
+  float px[EPT], pm[EPT], pv[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    eok[e] = row_ok && k0 + e <= row;
+    eo[e] = min(k0 + e, d - 1) * Mp;
+    const size_t at = (size_t)d + (size_t)(eok[e] ? k0 + e : 0) * d + (eok[e] ? row : 0);
+    px[e] = eok[e] ? a.params[at] : 0.f;
+    pm[e] = (RULE == 1 && eok[e]) ? a.opt_state[at] : 0.f;
+    pv[e] = (RULE == 1 && eok[e]) ? a.opt_state[plen + at] : 0.f;
+  }
+  const bool mu_own = row_ok && k0 == 0;      // the row's first thread also owns mu_row
+  float mx = mu_own ? a.params[row] : 0.f, mm1 = (RULE == 1 && mu_own) ? a.opt_state[row] : 0.f,
+        mv1 = (RULE == 1 && mu_own) ? a.opt_state[plen + row] : 0.f;
+  const float tm = row_ok ? a.t_mean[row] : 0.f, ti = row_ok ? a.t_istd[row] : 0.f;
+  const int diag_e = row_ok ? row - k0 : -1;  // the entry that is C[row, row], if this thread holds it (0 .. 8)
+
+  // 1 KiB per wave and instruction, straight into the LDS
+  auto slab_in = [&](int t, float *buf) {
+    const float *G = a.eps_all + (size_t)t * slabN;
+    const int nv = slabN >> 2;
+    for (int i0 = wv * 64; i0 < nv; i0 += NT)
+      if (i0 + lane < nv) ROWS_GLDS16(G + 4 * (i0 + lane), buf + 4 * i0);
+  };
+  auto publish = [&](int par) {               // this step's mu and scale diagonal of the workgroup's rows
+    float *dst = sc + 8 * par + 2 * (2 * pr + rs);
+    if (mu_own) dst[0] = mx;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+      if (e == diag_e) dst[1] = px[e];
+  };
+  if (tid < 16) sc[16 + tid] = 0.f;           // (a pair beyond the middle never writes its partials)
+  slab_in(0, S);
+  publish(0);
+  __builtin_amdgcn_s_waitcnt(0x0f70);         // vmcnt(0)
+  __syncthreads();
+
+  for (int t = 0; t < a.n_steps; ++t) {
+    const float *cur = S + (DB ? (t & 1) * slabN : 0);
+    if (RULE == 1 && (t & 255) == 0 && tid < 256) adam_bias<float>(a.t0 + t + tid + 1, a.b1, a.b2, cc_tab[tid][0], cc_tab[tid][1]);
+    if (DB && t + 1 < a.n_steps) slab_in(t + 1, S + ((t + 1) & 1) * slabN);
+    // partial dot products of this thread's entries, per sample, chunk by chunk; wave sums -> zred
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ++ch) {
+      float acc[MC];
+#pragma unroll
+      for (int m = 0; m < MC; ++m) acc[m] = 0.f;
+      if (MC >= 4) {
+        f32x4 ev[EPT][MC / 4];               // (all of the chunk's LDS reads in flight before the first multiply-add)
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+#pragma unroll
+          for (int j = 0; j < MC / 4; ++j) ev[e][j] = *(const f32x4 *)(cur + eo[e] + ch * 8 + 4 * j);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+#pragma unroll
+          for (int j = 0; j < MC / 4; ++j) {
+            acc[4 * j + 0] = fmaf(px[e], ev[e][j].x, acc[4 * j + 0]);
+            acc[4 * j + 1] = fmaf(px[e], ev[e][j].y, acc[4 * j + 1]);
+            acc[4 * j + 2] = fmaf(px[e], ev[e][j].z, acc[4 * j + 2]);
+            acc[4 * j + 3] = fmaf(px[e], ev[e][j].w, acc[4 * j + 3]);
+          }
+      } else {
+        float ev[EPT][MC];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+#pragma unroll
+          for (int m = 0; m < MC; ++m) ev[e][m] = cur[eo[e] + m];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+#pragma unroll
+          for (int m = 0; m < MC; ++m) acc[m] = fmaf(px[e], ev[e][m], acc[m]);
+      }
+      // wave sums per row (independent chains: they pipeline); a wave working for both rows sums twice
+      float sb[MC];
+      if (mixed) {
+#pragma unroll
+        for (int m = 0; m < MC; ++m) sb[m] = wave_sum_f32(isA ? 0.f : acc[m]);
+#pragma unroll
+        for (int m = 0; m < MC; ++m) acc[m] = wave_sum_f32(isA ? acc[m] : 0.f);
+      } else {
+#pragma unroll
+        for (int m = 0; m < MC; ++m) {
+          const float sm = wave_sum_f32(acc[m]);
+          acc[m] = isA ? sm : 0.f;
+          sb[m] = isA ? 0.f : sm;
+        }
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < MC; ++m) { zred[(wv * 2 + 0) * ZS + ch * 8 + m] = acc[m]; zred[(wv * 2 + 1) * ZS + ch * 8 + m] = sb[m]; }
+      }
+    }
+    lds_barrier();
+    // z, W of the thread's row (every thread of the row: it needs W for its gradient entries), chunk by chunk, and the gradient sums
+    float gv[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) gv[e] = 0.f;
+    float ell = 0.f, he = 0.f, wsum = 0.f;
+    const float mu = sc[8 * (t & 1) + 2 * (2 * pr + rs)];
+    const float *z0 = zred + ((2 * pr) * 2 + rs) * ZS, *z1 = zred + ((2 * pr + 1) * 2 + rs) * ZS;   // the pair's two waves
+    const float *erow = cur + (row_ok ? row : 0) * Mp;
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ++ch) {
+      float w[MC];
+#pragma unroll
+      for (int m = 0; m < MC; ++m) {
+        const float z = mu + (z0[ch * 8 + m] + z1[ch * 8 + m]);
+        const float u = (z - tm) * ti;
+        const bool on = row_ok && ch * 8 + m < M;
+        w[m] = on ? -u * ti : 0.f;
+        ell = on ? fmaf(-0.5f * u, u, ell) : ell;
+        wsum += w[m];
+        const float ev = row_ok ? erow[ch * 8 + m] : 0.f;   // (pad columns are zero)
+        he = fmaf(0.5f * ev, ev, he);
+      }
+      if (MC >= 4) {
+        f32x4 ev[EPT][MC / 4];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e)
+#pragma unroll
+          for (int j = 0; j < MC / 4; ++j) ev[e][j] = *(const f32x4 *)(cur + eo[e] + ch * 8 + 4 * j);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          float v = gv[e];
+#pragma unroll
+          for (int j = 0; j < MC / 4; ++j) {
+            v = fmaf(w[4 * j + 0], ev[e][j].x, v);
+            v = fmaf(w[4 * j + 1], ev[e][j].y, v);
+            v = fmaf(w[4 * j + 2], ev[e][j].z, v);
+            v = fmaf(w[4 * j + 3], ev[e][j].w, v);
+          }
+          gv[e] = v;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          float v = gv[e];
+#pragma unroll
+          for (int m = 0; m < MC; ++m) v = fmaf(w[m], cur[eo[e] + m], v);
+          gv[e] = v;
+        }
+      }
+    }
+    if (t7 == 0 || t7 == nA) {   // the row's scalar partials; workgroup threads 0 .. 3 write the history entry below
+      float lg = 0.f, bad = 0.f;
+      if (row_ok) {
+        const float cr = sc[8 * (t & 1) + 2 * (2 * pr + rs) + 1];
+        lg = logf(cr);
+        bad = (cr > 0.f) ? 0.f : 1.f;
+      } else {
+        ell = 0.f; he = 0.f;
+      }
+      float *ps = sc + 16 + 4 * (2 * pr + rs);
+      ps[0] = ell; ps[1] = he; ps[2] = lg; ps[3] = bad;
+    }
+    // gradient entries + Optimisers.update! + ClipScale, in registers
+    const float c1 = RULE == 1 ? cc_tab[t & 255][0] : 0.f, c2 = RULE == 1 ? cc_tab[t & 255][1] : 0.f;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      if (!eok[e]) continue;
+      const bool diag = e == diag_e;
+      float g;
+      if (diag) g = (float)(-(double)gv[e] * invM - direct / (double)px[e]);
+      else g = -gv[e] * invMf;
+      if (RULE == 0) px[e] = descent_step(px[e], g, eta);
+      else px[e] = adam_step<float>(px[e], g, pm[e], pv[e], c1, c2, eta, b1, b2, aeps);
+      if (clip && diag) px[e] = clip_step(px[e], ceps);
+    }
+    if (mu_own) {
+      const float g = (float)(-(double)wsum * invM);
+      if (RULE == 0) mx = descent_step(mx, g, eta);
+      else mx = adam_step<float>(mx, g, mm1, mv1, c1, c2, eta, b1, b2, aeps);
+    }
+    publish((t + 1) & 1);
+    if (DB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // vmcnt(0): the next slab is in
+    lds_barrier();   // (every thread is done with this step's slab and the exchange areas; the rows' scalar partials are in place)
+    if (tid < 4) a.hist[((size_t)t * 4 + tid) * nwg + b] = ((double)sc[16 + tid] + (double)sc[20 + tid]) + ((double)sc[24 + tid] + (double)sc[28 + tid]);
+    if (!DB && t + 1 < a.n_steps) {
+      slab_in(t + 1, S);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lds_barrier();
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    if (!eok[e]) continue;
+    const size_t at = (size_t)d + (size_t)(k0 + e) * d + row;
+    a.params[at] = px[e];
+    if (RULE == 1) { a.opt_state[at] = pm[e]; a.opt_state[plen + at] = pv[e]; }
+  }
+  if (mu_own) {
+    a.params[row] = mx;
+    if (RULE == 1) { a.opt_state[row] = mm1; a.opt_state[plen + row] = mv1; }
+  }
+}
+
+// elbo[t] (and the status word) from the per-step partials of k_fr_rows_loop; one workgroup per step
+__global__ __launch_bounds__(256) void k_fr_rows_value(int d, int nwg, int M_local, int M_total, int ent_kind, double ell_const, const double *hist,
+                                                       double *elbo, float *value_last, int n_steps, int *status) {
+  __shared__ double red[4];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  double s[4] = {0, 0, 0, 0};
+  for (int k = 0; k < 4; ++k)
+    for (int i = tid; i < nwg; i += 256) s[k] += hist[((size_t)t * 4 + k) * nwg + i];
+  for (int k = 0; k < 4; ++k) s[k] = block_sum<double, 256>(s[k], red);
+  if (tid == 0) {
+    const double Mt = (double)M_total;
+    const double ent = (ent_is_closed(ent_kind) ? 0.5 * d * (1.0 + kLog2Pi) : s[1] / Mt + 0.5 * d * kLog2Pi) + s[2];
+    const double value = -((s[0] + (double)M_local * ell_const) / Mt + ent);
+    elbo[t] = -value;
+    if (t == n_steps - 1 && value_last) *value_last = (float)value;
+    int st = 0;
+    if (!isfinite(value)) st |= 1;
+    if (s[3] > 0.0) st |= 2;
+    if (st && status) atomicOr(status, st);
+  }
+}
+
+bool fr_rows_loop_ok(const mivi_ctx *c) {
+  const int d = c->cfg.d, M = c->cfg.n_mc;
+  const bool stl = c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD;
+  if (!(c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && c->target == TGT_DIAG_GAUSS && !c->bij_on && !stl && M >= 1 && M <= kRowsMaxM &&
+        c->cfg.m_offset == 0 && c->M_total == M))
+    return false;
+  const int Mp = rows_mp(rows_mm(M));
+  // two rows' threads fit 128 (d <= 1126); the slab fits the LDS beside the exchange areas; 16-byte slab copies
+  return d >= 8 && d <= 126 * kRowsEPT - 8 && ((long long)d * Mp) % 4 == 0 && (size_t)d * Mp * 4 + (8 * kRowsMaxM + 32 + 2 * 256) * 4 <= 160 * 1024;
+}
+size_t fr_rows_eps_bytes(const mivi_ctx *c, int n_steps) { return (size_t)n_steps * c->cfg.d * rows_mp(rows_mm(c->cfg.n_mc)) * sizeof(float); }
+size_t fr_rows_hist_doubles(const mivi_ctx *c, int n_steps) { return (size_t)n_steps * 4 * (size_t)((c->cfg.d + 3) / 4); }
+
+// eps_all: fr_rows_eps_bytes; hist: fr_rows_hist_doubles; elbo: n_steps doubles; value: one float (the last step's objective value)
+void launch_fr_rows_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta, double clip_eps,
+                         float *eps_all, double *hist, double *elbo, void *value) {
+  const int d = c->cfg.d, M = c->cfg.n_mc, d4 = (d + 3) / 4, MM = rows_mm(M), Mp = rows_mp(MM);
+  {
+    const long long n = (long long)n_steps * d4 * Mp;
+    hipLaunchKernelGGL(k_eps_steps, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->cfg.seed, idx0, n_steps, d, M, Mp, c->cfg.m_offset, eps_all);
+  }
+  FrRowsArgs a;
+  a.d = d; a.M = M; a.Mp = Mp; a.n_steps = n_steps; a.rule = rule; a.ent_kind = c->cfg.entropy; a.m_offset = c->cfg.m_offset; a.M_total = c->M_total;
+  a.params = (float *)params; a.opt_state = (float *)opt_state;
+  a.t_mean = (const float *)c->t_mean.p; a.t_istd = (const float *)c->t_istd.p;
+  a.eps_all = eps_all; a.t0 = t0; a.eta = eta; a.clip_eps = clip_eps; a.b1 = 0.9; a.b2 = 0.999; a.adam_eps = 1e-8;
+  a.hist = hist;
+  const int nwg = (d + 3) / 4;   // two row pairs per workgroup
+  a.nch = MM >= 8 ? MM / 8 : 1;
+  const size_t extras = (8 * kRowsMaxM + 32 + 2 * 256) * sizeof(float), slab = (size_t)d * Mp * sizeof(float);
+  const bool db = 2 * slab + extras <= 160 * 1024;
+  const size_t lds = (db ? 2 : 1) * slab + extras;
+  auto go = [&](auto kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(kRowsNT), lds, c->stream, a);
+  };
+  auto pick = [&](auto r, auto dbl) {
+    constexpr int R = decltype(r)::value;
+    constexpr bool D = decltype(dbl)::value;
+    switch (MM) {
+      case 1: go(k_fr_rows_loop<R, 1, D>); break;
+      case 2: go(k_fr_rows_loop<R, 2, D>); break;
+      case 4: go(k_fr_rows_loop<R, 4, D>); break;
+      default: go(k_fr_rows_loop<R, 8, D>); break;
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  if (rule == 0) { if (db) pick(I0{}, std::true_type{}); else pick(I0{}, std::false_type{}); }
+  else { if (db) pick(I1{}, std::true_type{}); else pick(I1{}, std::false_type{}); }
+  hipLaunchKernelGGL(k_fr_rows_value, dim3(n_steps), dim3(256), 0, c->stream, d, nwg, M, c->M_total, c->cfg.entropy, c->t_const, (const double *)hist, elbo,
+                     (float *)value, n_steps, (int *)c->status.p);
+}
+
+}  // namespace mivi

@@ -283,6 +283,7 @@ struct mivi_ctx {
   size_t p2p_bytes = 0;
   void *p2p_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // mapped bases (own entry = p2p_buf)
   bool p2p_opened[8] = {false, false, false, false, false, false, false, false};                   // hipIpcOpenMemHandle'd (to be closed)
+  mivi::DevBuf rows_eps;   // kernels_fullrank_rows.hip: eps of all steps of a device-resident loop call
   mivi::DevBuf p2p_tab, p2p_ctr, p2p_scratch, p2p_direct;   // (p2p_direct: P2PDirectTab, what the partial kernels need to store straight into the owners' staging areas)
   bool p2p_on = false;
   int p2p_rank = 0, p2p_world = 1, p2p_G = 1, p2p_vs = 0, p2p_spin = 1 << 21;
@@ -386,6 +387,10 @@ void launch_mf_main(mivi_ctx *c, const void *params, const RngArgs &rng, int M, 
                     const ValueIn &vin, const OutArgs &out, const ValueJob *prev = nullptr);
 void launch_mf_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule,
                         double eta, double clip_eps, double *hist, double *elbo, void *grad_out = nullptr, void *lane_scratch = nullptr);
+bool fr_rows_loop_ok(const mivi_ctx *c);    // kernels_fullrank_rows.hip: f32, n_mc <= 32, d <= 1024, diagonal-Gaussian target, not STL
+size_t fr_rows_eps_bytes(const mivi_ctx *c, int n_steps);
+void launch_fr_rows_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta, double clip_eps,
+                         float *eps_all, double *hist, double *elbo, void *value);
 bool fr_small_loop_ok(const mivi_ctx *c);   // kernels_fullrank_small.hip: d <= 32, n_mc <= 64, diagonal-Gaussian target
 void launch_fr_small_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta,
                           double clip_eps, double *elbo, void *value);

@@ -1065,6 +1065,32 @@ def main():
                                                             note="device-resident loops (mean-field: k_mf_sgd_loop; full-rank: k_fr_small_loop, one workgroup)")
                 except Exception as e:   # noqa: BLE001
                     also["reference_benchmark_grid"] = dict(error=str(e))
+                # the north-star family with the FEW samples per step the reference's algorithms default to (n_samples = 1 .. 16): every row of
+                # (mu, C) is independent under this target, one launch-free kernel runs the whole loop (k_fr_rows_loop)
+                try:
+                    fs = {}
+                    for M_f in (1, 8, 16):
+                        d_f = w["d"] if w["family"] == 1 else 1024
+                        q_f = avi.FullRankGaussian(np.zeros(d_f, np.float32), np.eye(d_f, dtype=np.float32))
+                        p_fh, _ = avi.destructure(q_f)
+                        c_f = avi.MiviContext(np.float32, 1, d_f, M_f, 0, SEED, device=local_rank)
+                        c_f.set_problem(avi.DiagNormalProblem(np.full(d_f, 5.0, np.float32), np.ones(d_f, np.float32)))
+                        p_f = c_f.to_device(p_fh).clone()
+                        s_f = c_f.empty(2 * p_f.numel()).zero_()
+                        c_f.optimize_steps(p_f, s_f, 0, 0, 1000, 1, 1e-3, 1e-5)
+                        stream.synchronize()
+                        t0s = time.perf_counter()
+                        for r in range(3):
+                            c_f.optimize_steps(p_f, s_f, (r + 1) * 1000, (r + 1) * 1000, 1000, 1, 1e-3, 1e-5)
+                        stream.synchronize()
+                        t_f = (time.perf_counter() - t0s) / 3000
+                        fs[f"n_mc={M_f}"] = dict(steps_per_s=1.0 / t_f, us_per_step=t_f * 1e6)
+                        c_f.close()
+                    also["ns_few_samples_adam_loop"] = dict(workload="north-star family and target (d=1024 full-rank, MvNormal(5*1, I)), n_mc = 1 / 8 / 16 per step, mivi_optimize_steps: Adam(1e-3) + ClipScale(1e-5), 3 x 1000 steps",
+                                                            value=fs["n_mc=1"]["steps_per_s"], unit="steps/s", grid=fs,
+                                                            note="row-separable launch-free loop (k_fr_rows_loop); the launch-per-step graph route at these shapes: 20 us per step (DESIGN.md 9)")
+                except Exception as e:   # noqa: BLE001
+                    also["ns_few_samples_adam_loop"] = dict(error=str(e))
             # ---- parity + cpu_baseline leg (rank 0, N = 1 only) ---------------------------------------------
             rel = None
             parity_head = None

@@ -176,6 +176,8 @@ CASES = [
     ("MIVI_LOGREG_GENERIC=1", ESTIMATE, dict(fam=MF, d=64, M=128, kind="logreg0", ent=0, dt="float32")),
     ("MIVI_LOGREG_MFMA=1", ESTIMATE, dict(fam=MF, d=64, M=128, kind="logreg0", ent=0, dt="float32")),
     ("MIVI_NO_FUSED_LOOP=1", LOOP, dict(fam=MF, d=64, M=32)),                                             # graph loop instead of the launch-free kernel
+    ("MIVI_NO_FUSED_LOOP=1", LOOP, dict(fam=F, d=64, M=32)),                                              # ... instead of the row-separable full-rank loop (few samples per step)
+    ("MIVI_NO_FUSED_LOOP=1", LOOP, dict(fam=F, d=256, M=8)),
     ("MIVI_FUNNEL_NO_E0TAB=1", FUNNEL, dict()),                                                          # funnel loop: every thread re-derives eps[0, m] instead of reading the table
     ("MIVI_DUMMY_DEFAULT=1", FUNNEL, dict()),                                                             # (no switch: the table)
     ("MIVI_NO_FUSED_UPDATE=1", LOOP, dict(fam=F, d=128, M=128)),                                          # separate update kernel in the graph loop

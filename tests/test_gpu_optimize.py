@@ -101,13 +101,14 @@ def test_convergence_host_loop(entropy, family):
     assert d1 <= d0 / 2
 
 
-@pytest.mark.parametrize("shape", [(64, 32), (70, 19), (128, 128)], ids=["aligned", "ragged", "gen2"])
+@pytest.mark.parametrize("shape", [(64, 48), (70, 35), (128, 128)], ids=["aligned", "ragged", "gen2"])
 @pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
 @pytest.mark.parametrize("rule", [0, 1], ids=["descent", "adam"])
 def test_device_resident_loop_matches_host_loop(family, rule, shape):
     """mivi_optimize_steps (mean-field: one launch-free kernel; full-rank: one hipGraph of n estimates with deferred
     value / prefetched eps and the optimiser step + ClipScale fused into the VJP epilogue) must reproduce, bitwise, the
-    step-by-step sequence of separate launches."""
+    step-by-step sequence of separate launches.  (More than 32 samples per step: with fewer, the full-rank family on this target takes
+    the row-separable loop -- test_fullrank_rows_loop, to rounding; its graph route at those shapes: test_gpu_ab_switches.py.)"""
     d, M = shape
     T = 12
     rng = np.random.default_rng(4)
@@ -226,6 +227,74 @@ def test_small_fullrank_loop(ent, rule, shape, dtype):
     ctx.synchronize()
     got = p3.cpu().numpy().astype(np.float64)
     assert np.max(np.abs(got[low] - x[low])) <= (2e-5 if dtype == np.float32 else 1e-11) * max(1.0, np.max(np.abs(x[low]))), np.max(np.abs(got[low] - x[low]))
+    ctx.close()
+
+
+@pytest.mark.parametrize("shape", [(1024, 1), (256, 8), (1024, 16), (512, 32), (130, 2), (129, 4), (1126, 4), (1000, 12), (9, 3)],
+                         ids=["one-sample", "d256-m8", "d1024-m16", "d512-m32", "even-ragged", "odd-middle-row", "widest", "m12", "tiny"])
+@pytest.mark.parametrize("rule", [0, 1], ids=["descent", "adam"])
+@pytest.mark.parametrize("ent", [0, 2], ids=["CFE", "MC"])
+def test_fullrank_rows_loop(ent, rule, shape):
+    """Full-rank family, diagonal-Gaussian target, few samples per step (n_mc <= 32; the reference's default is n_samples = 1,
+    src/algorithms/klminrepgraddescent.jl): every row of (mu, C) needs only eps from the rest of the problem, so mivi_optimize_steps runs
+    ONE kernel whose workgroups own row pairs for all steps (k_fr_rows_loop).  Its sums are sequential fused multiply-adds, not the tile
+    kernels' MFMA chains: the trajectory equals the step-by-step sequence of single calls + update + ClipScale launches to rounding
+    (stated here), and the oracle's gradient + numpy rules."""
+    d, M = shape
+    T = 9
+    rng = np.random.default_rng(13)
+    tm, ts = rng.normal(size=d).astype(np.float32), rng.uniform(0.5, 2, size=d).astype(np.float32)
+    C0 = (np.eye(d) + (0.3 / np.sqrt(d)) * np.tril(rng.normal(size=(d, d)), -1)).astype(np.float32)
+    q0 = avi.FullRankGaussian(np.zeros(d, np.float32), C0)
+    p0, _ = avi.destructure(q0)
+    eta = 1e-2
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
+    ctx.set_problem(avi.DiagNormalProblem(tm, ts))
+    p = ctx.to_device(p0).clone()
+    st = ctx.empty(2 * p.numel()).zero_()
+    elbos = []
+    for t in range(T):
+        v, g = ctx.estimate_gradient(p, 40 + t)
+        elbos.append(-float(v.item()))
+        if rule == 0:
+            ctx.descent_update(p, g, eta)
+        else:
+            ctx.adam_update(p, g, st, t + 1, eta)
+        ctx.clip_scale(p, 1e-5)
+    p2 = ctx.to_device(p0).clone()
+    st2 = ctx.empty(2 * p2.numel()).zero_()
+    elbo = ctx.empty(T)
+    ctx.optimize_steps(p2, st2 if rule == 1 else None, 40, 0, 5, rule, eta, 1e-5, elbo[:5])
+    ctx.optimize_steps(p2, st2 if rule == 1 else None, 45, 5, T - 5, rule, eta, 1e-5, elbo[5:])   # a second call continues (indices, Adam's t)
+    ctx.synchronize()
+    a, b = p.cpu().numpy().astype(np.float64), p2.cpu().numpy().astype(np.float64)
+    low = np.concatenate([np.ones(d, bool), np.tril(np.ones((d, d), bool)).T.reshape(-1)])      # [mu; vec C column-major]: entries on / below the diagonal
+    tol = 3e-5 if rule == 0 else 1e-4   # (Adam's first steps divide by sqrt(v) ~ |g|: an entry whose gradient is rounding noise moves by +-eta either way)
+    assert np.max(np.abs(a[low] - b[low])) <= tol * max(1.0, np.max(np.abs(a[low]))), np.max(np.abs(a[low] - b[low]))
+    assert np.array_equal(b[~low], p0.astype(np.float64)[~low])                                 # nothing above the diagonal is touched
+    assert np.allclose(elbo.cpu().numpy().astype(np.float64), np.array(elbos), rtol=5e-5, atol=1e-3)
+    if rule == 1:
+        sa, sb = st.cpu().numpy().astype(np.float64), st2.cpu().numpy().astype(np.float64)
+        low2 = np.concatenate([low, low])
+        assert np.max(np.abs(sa[low2] - sb[low2])) <= tol * max(1.0, np.max(np.abs(sa[low2])))
+    # independent restatement: oracle gradient on the device's own eps -> numpy rules -> ClipScale, in f64
+    x = p0.astype(np.float64)
+    ost = (np.zeros_like(x), np.zeros_like(x))
+    tgt = O.DiagNormalTarget(tm, ts)
+    for t in range(3):
+        _, eps = ctx.sample(x.astype(np.float32), 40 + t)
+        ref = O.estimate_gradient(x.astype(np.float32).astype(np.float64), d, avi.FULLRANK, tgt, eps.cpu().numpy().astype(np.float64), ent)
+        if rule == 0:
+            x = O.descent_step(x, ref["grad"], eta)
+        else:
+            x, ost = O.adam_step(x, ref["grad"], ost, t + 1, eta)
+        x = O.clip_scale(x, d, avi.FULLRANK, 1e-5)
+    p3 = ctx.to_device(p0).clone()
+    st3 = ctx.empty(2 * p3.numel()).zero_()
+    ctx.optimize_steps(p3, st3 if rule == 1 else None, 40, 0, 3, rule, eta, 1e-5, ctx.empty(3))
+    ctx.synchronize()
+    got = p3.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got[low] - x[low])) <= tol * max(1.0, np.max(np.abs(x[low]))), np.max(np.abs(got[low] - x[low]))
     ctx.close()
 
 
