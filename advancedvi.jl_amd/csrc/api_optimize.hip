@@ -121,6 +121,22 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);
   }
+  if (simple && (rule == 0 || default_adam) && fr_tiles_loop_ok(c) && !no_fused_loop) {
+    // the north-star shape class: ONE persistent kernel whose workgroups own tiles of tril(C) (parameters and moments in registers) and exchange
+    // partial products / W inside their row block, bitwise the launch-per-step trajectory (k_fr_tiles_loop).  eps is drawn up front for a chunk
+    // of steps at a time (1 MB per step at d = 1024, n_mc = 256).
+    const int CH = 256;
+    if ((s = ensure(c, c->tiles_buf, fr_tiles_bytes(c, n_steps < CH ? n_steps : CH), false))) return s;
+    HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
+    for (int off = 0; off < n_steps; off += CH) {
+      const int n = n_steps - off < CH ? n_steps - off : CH;
+      launch_fr_tiles_loop(c, params, opt_state, l.estimate_idx0 + (uint64_t)off, (long long)l.t0 + off, n, rule, eta, clip_eps, (char *)c->tiles_buf.p,
+                           rec + off, vbuf);
+      HIPCHK(c, hipGetLastError());
+    }
+    if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
+    return read_status(c);
+  }
   if (simple && (rule == 0 || default_adam) && fr_small_loop_ok(c) && !no_fused_loop) {
     // small full-rank problems (the reference's own benchmark grid: d = 10, one sample per step): the whole loop in ONE workgroup
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));

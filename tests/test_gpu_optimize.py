@@ -230,6 +230,71 @@ def test_small_fullrank_loop(ent, rule, shape, dtype):
     ctx.close()
 
 
+@pytest.mark.parametrize("shape", [(64, 128), (128, 256), (320, 256), (512, 128), (1024, 256)], ids=["one-block-pair", "d128", "ragged-runs", "d512-m128", "north-star"])
+@pytest.mark.parametrize("rule", [0, 1], ids=["descent", "adam"])
+@pytest.mark.parametrize("ent", [0, 2], ids=["CFE", "MC"])
+def test_fullrank_tiles_loop(ent, rule, shape, monkeypatch):
+    """(Opt-in route, MIVI_TILES_LOOP=1: measured slower than the graph of launches, DESIGN.md 9 -- kept parity-green.)  The north-star shape class (full-rank family, d <= 1024, 128 / 256 samples per step, diagonal-Gaussian target): mivi_optimize_steps runs
+    ONE persistent kernel whose workgroups own tiles of tril(C) -- parameters and Adam moments in registers for all steps -- and exchange partial
+    products / W inside their row block (k_fr_tiles_loop).  Every sum is the launch-per-step kernels' chain: parameters, optimiser state must
+    equal, BITWISE, the step-by-step sequence of single calls + update + ClipScale launches (two calls that continue each other); the ELBO
+    record to rounding; nothing above the diagonal is touched; and the first steps agree with the oracle's gradient + numpy rules."""
+    monkeypatch.setenv("MIVI_TILES_LOOP", "1")
+    d, M = shape
+    T = 11
+    rng = np.random.default_rng(17)
+    tm, ts = rng.normal(size=d).astype(np.float32), rng.uniform(0.5, 2, size=d).astype(np.float32)
+    C0 = (np.eye(d) + (0.3 / np.sqrt(d)) * np.tril(rng.normal(size=(d, d)), -1)).astype(np.float32)
+    q0 = avi.FullRankGaussian((0.1 * rng.normal(size=d)).astype(np.float32), C0)
+    p0, _ = avi.destructure(q0)
+    eta = 1e-2
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
+    ctx.set_problem(avi.DiagNormalProblem(tm, ts))
+    p = ctx.to_device(p0).clone()
+    st = ctx.empty(2 * p.numel()).zero_()
+    elbos = []
+    for t in range(T):
+        v, g = ctx.estimate_gradient(p, 30 + t)
+        elbos.append(-float(v.item()))
+        if rule == 0:
+            ctx.descent_update(p, g, eta)
+        else:
+            ctx.adam_update(p, g, st, t + 1, eta)
+        ctx.clip_scale(p, 1e-5)
+    p2 = ctx.to_device(p0).clone()
+    st2 = ctx.empty(2 * p2.numel()).zero_()
+    elbo = ctx.empty(T)
+    ctx.optimize_steps(p2, st2 if rule == 1 else None, 30, 0, 6, rule, eta, 1e-5, elbo[:6])
+    ctx.optimize_steps(p2, st2 if rule == 1 else None, 36, 6, T - 6, rule, eta, 1e-5, elbo[6:])   # a second call continues (indices, Adam's t)
+    ctx.synchronize()
+    assert np.array_equal(p.cpu().numpy(), p2.cpu().numpy())
+    if rule == 1:
+        assert np.array_equal(st.cpu().numpy(), st2.cpu().numpy())
+    assert np.allclose(elbo.cpu().numpy().astype(np.float64), np.array(elbos), rtol=2e-6, atol=1e-4)
+    low = np.concatenate([np.ones(d, bool), np.tril(np.ones((d, d), bool)).T.reshape(-1)])      # [mu; vec C column-major]: entries on / below the diagonal
+    assert np.array_equal(p2.cpu().numpy()[~low], p0[~low])
+    # independent restatement: oracle gradient on the device's own eps -> numpy rules -> ClipScale, in f64
+    x = p0.astype(np.float64)
+    ost = (np.zeros_like(x), np.zeros_like(x))
+    tgt = O.DiagNormalTarget(tm, ts)
+    for t in range(2):
+        _, eps = ctx.sample(x.astype(np.float32), 30 + t)
+        ref = O.estimate_gradient(x.astype(np.float32).astype(np.float64), d, avi.FULLRANK, tgt, eps.cpu().numpy().astype(np.float64), ent)
+        if rule == 0:
+            x = O.descent_step(x, ref["grad"], eta)
+        else:
+            x, ost = O.adam_step(x, ref["grad"], ost, t + 1, eta)
+        x = O.clip_scale(x, d, avi.FULLRANK, 1e-5)
+    p3 = ctx.to_device(p0).clone()
+    st3 = ctx.empty(2 * p3.numel()).zero_()
+    ctx.optimize_steps(p3, st3 if rule == 1 else None, 30, 0, 2, rule, eta, 1e-5, ctx.empty(2))
+    ctx.synchronize()
+    got = p3.cpu().numpy().astype(np.float64)
+    tol = 2e-5 if rule == 0 else 1e-4
+    assert np.max(np.abs(got[low] - x[low])) <= tol * max(1.0, np.max(np.abs(x[low]))), np.max(np.abs(got[low] - x[low]))
+    ctx.close()
+
+
 @pytest.mark.parametrize("shape", [(1024, 1), (256, 8), (1024, 16), (512, 32), (130, 2), (129, 4), (1126, 4), (1000, 12), (9, 3)],
                          ids=["one-sample", "d256-m8", "d1024-m16", "d512-m32", "even-ragged", "odd-middle-row", "widest", "m12", "tiny"])
 @pytest.mark.parametrize("rule", [0, 1], ids=["descent", "adam"])

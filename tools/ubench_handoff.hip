@@ -13,17 +13,18 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-enum { F_PLAIN = 0, F_SC1 = 1, F_SC01 = 2 };
+enum { F_PLAIN = 0, F_SC1 = 1, F_SC01 = 2, F_SC0 = 3 };
 
 template <int ST>
 __device__ __forceinline__ void store16(void *p, u32x4 v) {
   if (ST == F_PLAIN) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
   else if (ST == F_SC1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  else if (ST == F_SC0) asm volatile("global_store_dwordx4 %0, %1, off sc0\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
   else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 template <int LD>
 __device__ __forceinline__ void glds16(const void *g, void *l) {
-  constexpr int aux = LD == F_PLAIN ? 0 : (LD == F_SC1 ? 16 : 17);
+  constexpr int aux = LD == F_PLAIN ? 0 : (LD == F_SC1 ? 16 : (LD == F_SC0 ? 1 : 17));
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0,
                                    aux);
 }
@@ -40,7 +41,7 @@ struct Args {
   unsigned *flag, *ack; // [npairs] (64-byte spaced)
   int npairs, coff, iters;
   size_t iter_stride;   // floats (0: the same block every iteration -> the consumer's L2 holds last iteration's lines)
-  long long *t_flag, *t_seen, *t_read;   // [npairs][iters]
+  long long *t_flag, *t_seen, *t_read, *t_st;   // [npairs][iters]
   unsigned *err;        // [npairs]: mismatching words | 0x80000000 lost
   unsigned *xcc;        // [2 npairs]
 };
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(256) void k_handoff(Args a) {
       __syncthreads();
       if (!s_ok) return;
       float *dst = blk + (size_t)(it - 1) * a.iter_stride;
+      if (tid == 0) a.t_st[(size_t)b * a.iters + it - 1] = (long long)wall();
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
         const unsigned idx = (unsigned)(p * 1024 + tid * 4);
@@ -136,16 +138,18 @@ void run(const char *name, int npairs, int coff, int iters, bool fresh) {
   hipMalloc(&a.t_flag, nt * 8);
   hipMalloc(&a.t_seen, nt * 8);
   hipMalloc(&a.t_read, nt * 8);
+  hipMalloc(&a.t_st, nt * 8);
   hipMalloc(&a.err, npairs * 4);
   hipMemset(a.err, 0, npairs * 4);
   hipMalloc(&a.xcc, 2 * npairs * 4);
   hipLaunchKernelGGL((k_handoff<ST, LD>), dim3(2 * npairs), dim3(256), 0, 0, a);
   hipError_t e = hipDeviceSynchronize();
-  std::vector<long long> tf(nt), ts(nt), tr(nt);
+  std::vector<long long> tf(nt), ts(nt), tr(nt), t0(nt);
   std::vector<unsigned> err(npairs), xcc(2 * npairs);
   hipMemcpy(tf.data(), a.t_flag, nt * 8, hipMemcpyDeviceToHost);
   hipMemcpy(ts.data(), a.t_seen, nt * 8, hipMemcpyDeviceToHost);
   hipMemcpy(tr.data(), a.t_read, nt * 8, hipMemcpyDeviceToHost);
+  hipMemcpy(t0.data(), a.t_st, nt * 8, hipMemcpyDeviceToHost);
   hipMemcpy(err.data(), a.err, npairs * 4, hipMemcpyDeviceToHost);
   hipMemcpy(xcc.data(), a.xcc, 2 * npairs * 4, hipMemcpyDeviceToHost);
   unsigned long long bad = 0, lost = 0;
@@ -153,10 +157,11 @@ void run(const char *name, int npairs, int coff, int iters, bool fresh) {
     bad += v & 0x7fffffffu;
     lost += v >> 31;
   }
-  double hand = 0, rd = 0;
+  double hand = 0, rd = 0, ack = 0;
   for (size_t i = 0; i < nt; ++i) {
     hand += (double)(ts[i] - tf[i]);
     rd += (double)(tr[i] - ts[i]);
+    ack += (double)(tf[i] - t0[i]);
   }
   int same = 0, map_ok = 0;
   for (int p = 0; p < npairs; ++p) {
@@ -164,10 +169,10 @@ void run(const char *name, int npairs, int coff, int iters, bool fresh) {
     same += xcc[p] == xcc[cb];
     map_ok += (int)xcc[p] == p % 8;
   }
-  printf("%-34s pairs %3d off %d %s: err %s bad words %llu lost %llu | hand-off %.0f ns, 32 KiB read %.0f ns | same-XCD pairs %d, xcc==b%%8 %d/%d\n",
-         name, npairs, coff, fresh ? "fresh blocks" : "same block  ", hipGetErrorString(e), bad, lost, 10.0 * hand / nt, 10.0 * rd / nt, same,
+  printf("%-34s pairs %3d off %d %s: err %s bad words %llu lost %llu | store+ack %.0f ns, hand-off %.0f ns, 32 KiB read %.0f ns | same-XCD pairs %d, xcc==b%%8 %d/%d\n",
+         name, npairs, coff, fresh ? "fresh blocks" : "same block  ", hipGetErrorString(e), bad, lost, 10.0 * ack / nt, 10.0 * hand / nt, 10.0 * rd / nt, same,
          map_ok, npairs);
-  hipFree(a.data); hipFree(a.flag); hipFree(a.ack); hipFree(a.t_flag); hipFree(a.t_seen); hipFree(a.t_read); hipFree(a.err); hipFree(a.xcc);
+  hipFree(a.data); hipFree(a.flag); hipFree(a.ack); hipFree(a.t_flag); hipFree(a.t_seen); hipFree(a.t_read); hipFree(a.t_st); hipFree(a.err); hipFree(a.xcc);
 }
 
 int main() {
@@ -178,6 +183,9 @@ int main() {
       run<F_SC1, F_SC1>("store sc1,   load sc1", 128, coff, 50, fresh);
       run<F_SC01, F_SC01>("store sc0sc1, load sc0sc1", 128, coff, 50, fresh);
       run<F_PLAIN, F_SC1>("store plain, load sc1", 128, coff, 50, fresh);
+      run<F_PLAIN, F_SC0>("store plain, load sc0", 128, coff, 50, fresh);
+      run<F_SC0, F_SC0>("store sc0,   load sc0", 128, coff, 50, fresh);
+      run<F_SC1, F_SC0>("store sc1,   load sc0", 128, coff, 50, fresh);
     }
   }
   return 0;
