@@ -34,6 +34,7 @@
 namespace mivi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct FrRowsArgs {
   int d, M, Mp, nch, n_steps, rule, ent_kind, m_offset, M_total;
@@ -151,20 +152,25 @@ __global__ __launch_bounds__(kRowsNT) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
       for (int m = 0; m < MC; ++m) acc[m] = 0.f;
       if (MC >= 4) {
-        f32x4 ev[EPT][MC / 4];               // (all of the chunk's LDS reads in flight before the first multiply-add)
+        f32x4 ev[EPT][MC >= 4 ? MC / 4 : 1];               // (all of the chunk's LDS reads in flight before the first multiply-add)
 #pragma unroll
         for (int e = 0; e < EPT; ++e)
 #pragma unroll
           for (int j = 0; j < MC / 4; ++j) ev[e][j] = *(const f32x4 *)(cur + eo[e] + ch * 8 + 4 * j);
+        f32x2 a2[MC >= 2 ? MC / 2 : 1];                    // two samples per v_pk_fma_f32; every sample's sum is the same sequential chain
 #pragma unroll
-        for (int e = 0; e < EPT; ++e)
+        for (int j = 0; j < MC / 2; ++j) a2[j] = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+          const f32x2 p2 = {px[e], px[e]};
 #pragma unroll
           for (int j = 0; j < MC / 4; ++j) {
-            acc[4 * j + 0] = fmaf(px[e], ev[e][j].x, acc[4 * j + 0]);
-            acc[4 * j + 1] = fmaf(px[e], ev[e][j].y, acc[4 * j + 1]);
-            acc[4 * j + 2] = fmaf(px[e], ev[e][j].z, acc[4 * j + 2]);
-            acc[4 * j + 3] = fmaf(px[e], ev[e][j].w, acc[4 * j + 3]);
+            a2[2 * j + 0] = __builtin_elementwise_fma(p2, f32x2{ev[e][j].x, ev[e][j].y}, a2[2 * j + 0]);
+            a2[2 * j + 1] = __builtin_elementwise_fma(p2, f32x2{ev[e][j].z, ev[e][j].w}, a2[2 * j + 1]);
           }
+        }
+#pragma unroll
+        for (int j = 0; j < MC / 2; ++j) { acc[2 * j] = a2[j].x; acc[2 * j + 1] = a2[j].y; }
       } else {
         float ev[EPT][MC];
 #pragma unroll
@@ -198,13 +204,14 @@ __global__ __launch_bounds__(kRowsNT) __attribute__((amdgpu_waves_per_eu(1, 1)))
     }
     lds_barrier();
     // z, W of the thread's row (every thread of the row: it needs W for its gradient entries), chunk by chunk, and the gradient sums
-    float gv[EPT];
+    f32x2 gv2[EPT];                          // gradient sums: even / odd samples of a pair (one v_pk_fma_f32 per pair), added at the end
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) gv[e] = 0.f;
+    for (int e = 0; e < EPT; ++e) gv2[e] = f32x2{0.f, 0.f};
     float ell = 0.f, he = 0.f, wsum = 0.f;
     const float mu = sc[8 * (t & 1) + 2 * (2 * pr + rs)];
     const float *z0 = zred + ((2 * pr) * 2 + rs) * ZS, *z1 = zred + ((2 * pr + 1) * 2 + rs) * ZS;   // the pair's two waves
     const float *erow = cur + (row_ok ? row : 0) * Mp;
+    const bool first = t7 == 0 || t7 == nA;   // the row's first thread: mu, the value's partials
 #pragma unroll 1
     for (int ch = 0; ch < nch; ++ch) {
       float w[MC];
@@ -214,39 +221,48 @@ __global__ __launch_bounds__(kRowsNT) __attribute__((amdgpu_waves_per_eu(1, 1)))
         const float u = (z - tm) * ti;
         const bool on = row_ok && ch * 8 + m < M;
         w[m] = on ? -u * ti : 0.f;
-        ell = on ? fmaf(-0.5f * u, u, ell) : ell;
-        wsum += w[m];
-        const float ev = row_ok ? erow[ch * 8 + m] : 0.f;   // (pad columns are zero)
-        he = fmaf(0.5f * ev, ev, he);
+      }
+      if (first) {   // (only the waves that hold a row's first thread run this)
+#pragma unroll
+        for (int m = 0; m < MC; ++m) {
+          const float z = mu + (z0[ch * 8 + m] + z1[ch * 8 + m]);
+          const float u = (z - tm) * ti;
+          const bool on = row_ok && ch * 8 + m < M;
+          ell = on ? fmaf(-0.5f * u, u, ell) : ell;
+          wsum += w[m];
+          const float ev = row_ok ? erow[ch * 8 + m] : 0.f;   // (pad columns are zero)
+          he = fmaf(0.5f * ev, ev, he);
+        }
       }
       if (MC >= 4) {
-        f32x4 ev[EPT][MC / 4];
+        f32x4 ev[EPT][MC >= 4 ? MC / 4 : 1];
 #pragma unroll
         for (int e = 0; e < EPT; ++e)
 #pragma unroll
           for (int j = 0; j < MC / 4; ++j) ev[e][j] = *(const f32x4 *)(cur + eo[e] + ch * 8 + 4 * j);
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-          float v = gv[e];
+          f32x2 v = gv2[e];
 #pragma unroll
           for (int j = 0; j < MC / 4; ++j) {
-            v = fmaf(w[4 * j + 0], ev[e][j].x, v);
-            v = fmaf(w[4 * j + 1], ev[e][j].y, v);
-            v = fmaf(w[4 * j + 2], ev[e][j].z, v);
-            v = fmaf(w[4 * j + 3], ev[e][j].w, v);
+            v = __builtin_elementwise_fma(f32x2{w[4 * j + 0], w[4 * j + 1]}, f32x2{ev[e][j].x, ev[e][j].y}, v);
+            v = __builtin_elementwise_fma(f32x2{w[4 * j + 2], w[4 * j + 3]}, f32x2{ev[e][j].z, ev[e][j].w}, v);
           }
-          gv[e] = v;
+          gv2[e] = v;
         }
       } else {
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-          float v = gv[e];
+          float v = gv2[e].x;
 #pragma unroll
           for (int m = 0; m < MC; ++m) v = fmaf(w[m], cur[eo[e] + m], v);
-          gv[e] = v;
+          gv2[e].x = v;
         }
       }
     }
+    float gv[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) gv[e] = gv2[e].x + gv2[e].y;
     if (t7 == 0 || t7 == nA) {   // the row's scalar partials; workgroup threads 0 .. 3 write the history entry below
       float lg = 0.f, bad = 0.f;
       if (row_ok) {
@@ -260,7 +276,14 @@ __global__ __launch_bounds__(kRowsNT) __attribute__((amdgpu_waves_per_eu(1, 1)))
       ps[0] = ell; ps[1] = he; ps[2] = lg; ps[3] = bad;
     }
     // gradient entries + Optimisers.update! + ClipScale, in registers
-    const float c1 = RULE == 1 ? cc_tab[t & 255][0] : 0.f, c2 = RULE == 1 ? cc_tab[t & 255][1] : 0.f;
+    // Adam with the two bias corrections as reciprocals taken once per step (one division and one square root per entry instead of three
+    // divisions: within an ulp of optim_rules.h adam_step, inside this loop's stated rounding-level agreement)
+    const float rc1 = RULE == 1 ? 1.f / cc_tab[t & 255][0] : 0.f, rc2 = RULE == 1 ? 1.f / cc_tab[t & 255][1] : 0.f;
+    auto adam = [&](float x, float g, float &m, float &v) {
+      m = fmaf(b1, m, (1.f - b1) * g);
+      v = fmaf(b2, v, ((1.f - b2) * g) * g);
+      return x - (eta * (m * rc1)) / (sqrtf(v * rc2) + aeps);
+    };
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       if (!eok[e]) continue;
@@ -269,13 +292,13 @@ __global__ __launch_bounds__(kRowsNT) __attribute__((amdgpu_waves_per_eu(1, 1)))
       if (diag) g = (float)(-(double)gv[e] * invM - direct / (double)px[e]);
       else g = -gv[e] * invMf;
       if (RULE == 0) px[e] = descent_step(px[e], g, eta);
-      else px[e] = adam_step<float>(px[e], g, pm[e], pv[e], c1, c2, eta, b1, b2, aeps);
+      else px[e] = adam(px[e], g, pm[e], pv[e]);
       if (clip && diag) px[e] = clip_step(px[e], ceps);
     }
     if (mu_own) {
       const float g = (float)(-(double)wsum * invM);
       if (RULE == 0) mx = descent_step(mx, g, eta);
-      else mx = adam_step<float>(mx, g, mm1, mv1, c1, c2, eta, b1, b2, aeps);
+      else mx = adam(mx, g, mm1, mv1);
     }
     publish((t + 1) & 1);
     if (DB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // vmcnt(0): the next slab is in
