@@ -254,8 +254,16 @@ mivi_status_t mivi_dog_update(mivi_ctx_t *ctx, void *params_dev, const void *gra
 mivi_status_t mivi_prox_scale_entropy(mivi_ctx_t *ctx, void *params_dev, double stepsize, const void *dog_state_dev,
                                       int32_t dog_kind);
 /* `n_steps` iterations of src/algorithms/common.jl:69-104 {estimate_gradient!, update!, ClipScale} with params
- * resident in HBM, one hipGraph per call; rule: 0 = Descent(eta), 1 = Adam(eta).  elbo_dev: T[n_steps] or NULL
- * receives info.elbo (= -value) per iteration.  Returns MIVI_ERR_NONFINITE if any objective was not finite. */
+ * resident in HBM; rule: 0 = Descent(eta), 1 = Adam(eta).  elbo_dev: T[n_steps] or NULL receives info.elbo (= -value) per
+ * iteration.  Returns MIVI_ERR_NONFINITE if any objective was not finite.
+ * What runs (first match; every launch-free form keeps parameters and optimiser state in registers for all n_steps):
+ *   mean-field, diagonal-Gaussian target                      one launch-free kernel (rows are independent), bitwise the single calls
+ *   full-rank, d <= 32, d n_mc <= 768 (STL 512)              one workgroup for the whole loop (the reference's own benchmark grid), to rounding
+ *   full-rank f32, n_mc <= 32, diagonal-Gaussian target,      row-separable launch-free kernel (workgroups own row pairs), to rounding
+ *     closed-form / Monte-Carlo entropy, d <= 1126
+ *   mean-field, fused funnel target                           one kernel with a per-step grid-wide exchange, bitwise the single calls
+ *   otherwise                                                 one hipGraph of chained estimates (full-rank f32: update + ClipScale in the VJP epilogue)
+ * MIVI_NO_FUSED_LOOP=1 forces the hipGraph everywhere (A/B). */
 mivi_status_t mivi_optimize_steps(mivi_ctx_t *ctx, void *params_dev, void *opt_state_dev, uint64_t estimate_idx0,
                                   int64_t t0, int32_t n_steps, int32_t rule, double eta, double clip_epsilon,
                                   void *elbo_dev);
