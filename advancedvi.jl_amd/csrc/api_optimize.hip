@@ -121,6 +121,16 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);
   }
+  if (!simple && mf_gen_loop_ok(c, rule) && !no_fused_loop) {
+    // every other rule x operator x averager of the reference's algorithms (DoG / DoWG, ProximalLocationScaleEntropy, PolynomialAveraging -- its
+    // defaults), mean-field + diagonal-Gaussian target: launch-free as well (k_mf_gen_loop; DoG / DoWG: one grid-wide exchange of two norms per step)
+    if ((s = ensure(c, c->gen_scratch, mf_gen_loop_scratch_bytes(c, n_steps), false))) return s;
+    HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
+    launch_mf_gen_loop(c, params, l, rec + n_steps, rec, (char *)c->gen_scratch.p);
+    HIPCHK(c, hipGetLastError());
+    if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
+    return read_status(c);
+  }
   if (simple && (rule == 0 || default_adam) && fr_tiles_loop_ok(c) && !no_fused_loop) {
     // the north-star shape class: ONE persistent kernel whose workgroups own tiles of tril(C) (parameters and moments in registers) and exchange
     // partial products / W inside their row block, bitwise the launch-per-step trajectory (k_fr_tiles_loop).  eps is drawn up front for a chunk

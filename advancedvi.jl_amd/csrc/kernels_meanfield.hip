@@ -501,6 +501,280 @@ static void mf_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint64_
                      c->t_const, (const double *)hist, elbo, (int *)c->status.p);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The launch-free loop for EVERY rule x operator x averager the reference's ParamSpaceSGD algorithms combine (constructors.jl:44-157;
+// DoWG + PolynomialAveraging + ClipScale / ProximalLocationScaleEntropy are the reference's DEFAULTS), mean-field family, diagonal-Gaussian
+// target.  k_mf_sgd_loop's structure (workgroup b owns rows 4 b .. 4 b + 3 of (mu, sigma), parameters and optimiser state in registers),
+// plus:
+//   * DoG / DoWG (src/optimization/rules.jl:17-64) need ||x - x0||^2 and ||g||^2 over ALL parameters before the step: every workgroup leaves
+//     its two partials at addresses of this step's own (NaN until then: the data are their own flags); every workgroup then waits for all of
+//     them and adds them in index order (the same order everywhere: (v, r) and the step size are the same bits in every workgroup).  One grid-wide
+//     exchange per step -- the workgroups must be resident together (d <= 2048); every spin is bounded (status bit 8);
+//   * ProximalLocationScaleEntropy (proximal_location_scale_entropy.jl:44-61) and ClipScale on the sigma rows, PolynomialAveraging
+//     (averaging.jl:40-47) with the running average in registers: the per-element arithmetic of kernels_update.hip (optim_rules.h).
+// The two norms are summed in another order than k_dog_norms / k_dog_update sum them: a DoG / DoWG trajectory equals the launch-per-step
+// one to the rounding of those f64 sums (tests/test_gpu_optimize.py::test_meanfield_general_loop), the other rules' bit for bit.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct MfGenLoopArgs {
+  int d, M, n_steps, rule, op, averager;   // rule 0 Descent, 1 Adam, 2 DoG, 3 DoWG; op 0 identity, 1 ClipScale, 2 proximal; averager 0 / 1
+  T *params, *opt_state;                   // Adam: [m (2d); v (2d)]
+  const T *x0;                             // DoG / DoWG: the initial parameters (mivi_dog_init)
+  double *dog_sc;                          // DoG / DoWG: (v, r), in / out
+  T *avg;                                  // PolynomialAveraging: running average, in / out
+  const T *t_mean, *t_istd;
+  uint64_t seed, idx0;
+  int m_offset, M_total, ent_kind;
+  long long t0;
+  double eta, clip_eps, b1, b2, adam_eps, avg_eta;
+  double *hist;                            // [n_steps][4][nblk]
+  double *part;                            // DoG / DoWG: [n_steps][nblk][2] partial norms
+  int *status;
+  int spin;
+};
+
+template <typename T, int RULE>
+__global__ __launch_bounds__(256) void k_mf_gen_loop(MfGenLoopArgs<T> a) {
+  __shared__ T xw[2][10][4];
+  __shared__ T cc_tab[256][2];
+  __shared__ double red[2 * 4];
+  __shared__ int ok_s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int rq = blockIdx.x, d = a.d, d4 = (d + 3) >> 2, nblk = gridDim.x;
+  const int M = a.M, n_steps = a.n_steps;
+  const bool stl = ent_is_stl(a.ent_kind);
+  const double direct = direct_entropy_coeff(a.ent_kind);
+  const double invM = 1.0 / (double)a.M_total;
+  const T eta = (T)a.eta, b1 = (T)a.b1, b2 = (T)a.b2, aeps = (T)a.adam_eps, ceps = (T)a.clip_eps;
+  const bool clip = a.op == 1, prox = a.op == 2, averaging = a.averager == 1;
+  T mu[4], sg[4], tm[4], tis[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int i = min(4 * rq + r, d - 1);
+    mu[r] = a.params[i];
+    sg[r] = a.params[d + i];
+    tm[r] = a.t_mean[i];
+    tis[r] = a.t_istd[i];
+  }
+  const int myrow = lane & 7;
+  const int myi = min(4 * rq + (myrow & 3), d - 1);
+  const bool row_ok = 4 * rq + (myrow & 3) < d;
+  const size_t myp = (size_t)(myrow < 4 ? 0 : d) + myi;   // this lane's parameter
+  T st_m = 0, st_v = 0, x0v = 0, avgv = 0;
+  if (RULE == 1) { st_m = a.opt_state[myp]; st_v = a.opt_state[2 * (size_t)d + myp]; }
+  if (RULE >= 2) x0v = a.x0[myp];
+  if (averaging) avgv = a.avg[myp];
+  double dog_v = 0.0, dog_r = 0.0;
+  if (RULE >= 2) { dog_v = a.dog_sc[0]; dog_r = a.dog_sc[1]; }
+  double lg = 0.0, bad = 0.0;
+  bool lost = false;
+  for (int t = 0; t < n_steps && !lost; ++t) {
+    if (RULE == 1 && (t & 255) == 0) {
+      __syncthreads();
+      adam_bias<T>(a.t0 + t + tid + 1, a.b1, a.b2, cc_tab[tid][0], cc_tab[tid][1]);
+      __syncthreads();
+    }
+    T sW[4] = {0, 0, 0, 0}, sWe[4] = {0, 0, 0, 0};
+    T s_ell = 0, s_he = 0;
+    T isg[4] = {0, 0, 0, 0};
+    if (stl) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) isg[r] = T(1) / sg[r];
+    }
+    for (int m = tid; m < M; m += 256) {   // (k_mf_sgd_loop's column work: the same values in the same order)
+      T e[4];
+      eps_block<T>(a.seed, a.idx0 + (uint64_t)t, (uint64_t)(a.m_offset + m) * (uint64_t)d4 + (uint64_t)rq, e);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = (4 * rq + r) < d;
+        const T er = ok ? e[r] : T(0);
+        const T z = mu[r] + sg[r] * e[r];
+        const T u = (z - tm[r]) * tis[r];
+        if (ok) s_ell += T(-0.5) * u * u;
+        const T w = ok ? (-u * tis[r] + (stl ? er * isg[r] : T(0))) : T(0);
+        s_he += T(0.5) * er * er;
+        sW[r] += w;
+        sWe[r] += w * er;
+      }
+    }
+    T(*xb)[4] = xw[t & 1];
+    {
+      T v[10];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = wave_total63(sW[r]);
+        v[4 + r] = wave_total63(sWe[r]);
+      }
+      v[8] = wave_total63(s_ell);
+      v[9] = wave_total63(s_he);
+      if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) xb[k][wv] = v[k];
+      }
+    }
+    {
+      double lgs[4], bads[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = 4 * rq + r < d;
+        lgs[r] = ok ? (double)log(sg[r]) : 0.0;
+        bads[r] = (ok && !(sg[r] > T(0))) ? 1.0 : 0.0;
+      }
+      lg = (lgs[0] + lgs[1]) + (lgs[2] + lgs[3]);
+      bad = (bads[0] + bads[1]) + (bads[2] + bads[3]);
+    }
+    lds_barrier();
+    if (tid >= 8 && tid < 12) {
+      double hv = tid == 10 ? lg : bad;
+      if (tid < 10) {
+        hv = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hv += (double)xb[tid][j];
+      }
+      a.hist[((size_t)t * 4 + (tid - 8)) * nblk + rq] = hv;
+    }
+    double trow = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) trow += (double)xb[myrow][j];
+    T mine = (myrow < 4) ? mu[0] : sg[0];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+      if ((myrow & 3) == r) mine = (myrow < 4) ? mu[r] : sg[r];
+    }
+    const T sgv = (myrow & 3) == 0 ? sg[0] : (myrow & 3) == 1 ? sg[1] : (myrow & 3) == 2 ? sg[2] : sg[3];
+    const T g = mf_grad_entry<T>(trow, invM, myrow >= 4, direct, (double)sgv);
+    double step_gamma = a.eta;   // the proximal operator's step size (Descent: eta; DoG / DoWG: the step just taken)
+    if (RULE == 0) {
+      mine = descent_step(mine, g, eta);
+    } else if (RULE == 1) {
+      mine = adam_step<T>(mine, g, st_m, st_v, cc_tab[t & 255][0], cc_tab[t & 255][1], eta, b1, b2, aeps);
+    } else {
+      // this workgroup's share of the two norms: its eight rows (lanes 0 .. 7 of every group of eight hold them), a fixed xor tree
+      double dx = row_ok ? (double)mine - (double)x0v : 0.0, gg = row_ok ? (double)g : 0.0;
+      double p0 = dx * dx, p1 = gg * gg;
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) {
+        p0 += __shfl_xor(p0, o, 8);
+        p1 += __shfl_xor(p1, o, 8);
+      }
+      // the partials ARE the flags: this step's slots hold NaN until their workgroup has stored them (8-byte stores do not tear), so a
+      // reader spins on the data itself -- no acknowledge-then-flag round trip on the producer's side
+      if (tid == 0) {
+        double *pp = a.part + ((size_t)t * nblk + rq) * 2;
+        __hip_atomic_store(pp, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 1, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok_s = 1;
+      }
+      __syncthreads();
+      double sums[2] = {0.0, 0.0};
+      for (int k = tid; k < nblk; k += 256) {
+        const double *pp = a.part + ((size_t)t * nblk + k) * 2;
+        int budget = a.spin;
+        double q0, q1;
+        while (true) {
+          q0 = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          q1 = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (q0 == q0 && q1 == q1) break;
+          if (--budget <= 0) { atomicAnd(&ok_s, 0); q0 = q1 = 0.0; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        sums[0] += q0;
+        sums[1] += q1;
+      }
+      __syncthreads();
+      if (!ok_s) {
+        if (tid == 0) atomicOr(a.status, 8);
+        lost = true;
+        continue;
+      }
+      block_sum_n<double, 256, 2>(sums, red);
+      // (v, r) and the step size: rules.jl:26-42 / :48-64, the arithmetic of k_dog_eta
+      dog_r = fmax(sqrt(sums[0]), dog_r);
+      double e_t;
+      if (RULE == 3) {
+        const double r2 = dog_r * dog_r;
+        dog_v = dog_v + r2 * sums[1];
+        e_t = r2 / sqrt(dog_v);
+      } else {
+        dog_v = dog_v + sums[1];
+        e_t = dog_r / sqrt(dog_v);
+      }
+      mine = (T)((double)mine - e_t * (double)g);
+      step_gamma = (RULE == 3 ? dog_r * dog_r : dog_r) / sqrt(dog_v);
+    }
+    if (myrow >= 4) {
+      if (clip) mine = clip_step(mine, ceps);
+      if (prox) mine = prox_entropy_step(mine, (T)step_gamma);
+    }
+    if (averaging) {
+      const double tt = (double)(a.t0 + t + 1);
+      const double wa = (a.avg_eta + 1.0) / (tt + a.avg_eta), wb = 1.0 - wa;
+      avgv = poly_avg_step<T>(mine, avgv, wa, wb);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      mu[r] = __shfl(mine, r, 8);
+      sg[r] = __shfl(mine, 4 + r, 8);
+    }
+  }
+  if (tid < 8) {
+    const int i = 4 * rq + (tid & 3);
+    if (i < d) {
+      T val = (tid < 4) ? mu[0] : sg[0];
+#pragma unroll
+      for (int r = 1; r < 4; ++r)
+        if ((tid & 3) == r) val = (tid < 4) ? mu[r] : sg[r];
+      a.params[myp] = val;
+      if (RULE == 1) { a.opt_state[myp] = st_m; a.opt_state[2 * (size_t)d + myp] = st_v; }
+      if (averaging) a.avg[myp] = avgv;
+    }
+  }
+  if (RULE >= 2 && rq == 0 && tid == 0) { a.dog_sc[0] = dog_v; a.dog_sc[1] = dog_r; }
+}
+
+bool mf_gen_loop_ok(const mivi_ctx *c, int rule) {
+  if (!(c->cfg.family == MIVI_MEANFIELD && c->target == TGT_DIAG_GAUSS && !c->bij_on && c->cfg.n_mc <= 4096)) return false;
+  return rule <= 1 || c->cfg.d <= 2048;   // DoG / DoWG: a grid-wide exchange per step -- every workgroup resident
+}
+size_t mf_gen_loop_scratch_bytes(const mivi_ctx *c, int n_steps) {   // partial norms of every step
+  const size_t nblk = (size_t)(c->cfg.d + 3) / 4;
+  return (size_t)n_steps * nblk * 2 * sizeof(double) + 256;
+}
+
+template <typename T>
+static void mf_gen_loop_impl(mivi_ctx *c, void *params, const mivi_loop_t &l, double *hist, double *elbo, char *scratch) {
+  MfGenLoopArgs<T> a;
+  a.d = c->cfg.d; a.M = c->cfg.n_mc; a.n_steps = l.n_steps; a.rule = l.rule; a.op = l.op; a.averager = l.averager;
+  a.params = (T *)params;
+  a.opt_state = l.rule == 1 ? (T *)l.opt_state_dev : nullptr;
+  a.x0 = l.rule >= 2 ? (const T *)l.opt_state_dev : nullptr;
+  a.dog_sc = l.rule >= 2 ? (double *)((char *)l.opt_state_dev + mivi_dog_state_bytes(c) - 16) : nullptr;
+  a.avg = l.averager == 1 ? (T *)l.avg_params_dev : nullptr;
+  a.t_mean = (const T *)c->t_mean.p; a.t_istd = (const T *)c->t_istd.p;
+  a.seed = c->cfg.seed; a.idx0 = l.estimate_idx0; a.m_offset = c->cfg.m_offset; a.M_total = c->M_total; a.ent_kind = c->cfg.entropy;
+  a.t0 = (long long)l.t0;
+  a.eta = l.eta; a.clip_eps = l.clip_epsilon; a.b1 = l.beta1; a.b2 = l.beta2; a.adam_eps = l.adam_eps; a.avg_eta = l.avg_eta;
+  a.hist = hist;
+  const int d4 = (a.d + 3) / 4;
+  a.part = (double *)scratch;
+  a.status = (int *)c->status.p;
+  a.spin = 1 << 20;
+  if (l.rule >= 2) (void)hipMemsetAsync(a.part, 0xFF, (size_t)l.n_steps * d4 * 2 * sizeof(double), c->stream);   // (NaN: not delivered yet)
+  switch (l.rule) {
+    case 0: hipLaunchKernelGGL((k_mf_gen_loop<T, 0>), dim3(d4), dim3(256), 0, c->stream, a); break;
+    case 1: hipLaunchKernelGGL((k_mf_gen_loop<T, 1>), dim3(d4), dim3(256), 0, c->stream, a); break;
+    case 2: hipLaunchKernelGGL((k_mf_gen_loop<T, 2>), dim3(d4), dim3(256), 0, c->stream, a); break;
+    default: hipLaunchKernelGGL((k_mf_gen_loop<T, 3>), dim3(d4), dim3(256), 0, c->stream, a); break;
+  }
+  hipLaunchKernelGGL(k_mf_loop_value<T>, dim3(l.n_steps), dim3(256), 0, c->stream, a.d, d4, a.M, a.M_total, a.ent_kind, c->t_const, (const double *)hist, elbo,
+                     (int *)c->status.p);
+}
+// hist: n_steps * 4 * ceil(d / 4) doubles; elbo: n_steps doubles; scratch: mf_gen_loop_scratch_bytes
+void launch_mf_gen_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *hist, double *elbo, char *scratch) {
+  if (c->cfg.dtype == MIVI_F32) mf_gen_loop_impl<float>(c, params, l, hist, elbo, scratch);
+  else mf_gen_loop_impl<double>(c, params, l, hist, elbo, scratch);
+}
+
 // rule 0 Descent / 1 Adam: n_steps SGD iterations;  rule -1: n_steps estimates at fixed parameters, the last one's gradient
 // into grad_out (what mivi_estimate_gradient_n returns).  elbo[t] of every step / estimate either way.
 // lane_scratch (rule < 0): mf_loop_lanes(c, n_steps) * 2 d elements of T, or nullptr = one lane.

@@ -420,7 +420,7 @@ __global__ void k_poly_average(int64_t n, T *y, const T *x, double avg_eta, cons
   const double w = (avg_eta + 1.0) / (t + avg_eta);
   const double a = w, b = 1.0 - w;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    y[i] = (T)(a * (double)x[i] + b * (double)y[i]);
+    y[i] = poly_avg_step<T>(x[i], y[i], a, b);
 }
 void launch_poly_average(mivi_ctx *c, void *avg, const void *params, double avg_eta, const long long *t_ptr, long long t_base) {
   const int64_t n = mivi_params_len(c);
@@ -435,7 +435,7 @@ void launch_poly_average(mivi_ctx *c, void *avg, const void *params, double avg_
 template <typename T>
 __global__ void k_axpby(int64_t n, T *y, double a, const T *x, double b) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    y[i] = (T)(a * (double)x[i] + b * (double)y[i]);
+    y[i] = poly_avg_step<T>(x[i], y[i], a, b);
 }
 
 template <typename T>
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(1024) void k_dog_update(int64_t n, T *params, const
       T x = (T)((double)params[i] - eta * (double)grad[i]);
       if (clip_eps == clip_eps && is_scale_diag(i, d, family)) x = clip_step(x, clip_eps);
       params[i] = x;
-      if (avg) avg[i] = (T)(wa * (double)x + wb * (double)avg[i]);
+      if (avg) avg[i] = poly_avg_step<T>(x, avg[i], wa, wb);
     }
   }
 }
@@ -586,7 +586,7 @@ __global__ void k_dog_apply_fused(int64_t n, T *params, const T *grad, const dou
     T x = (T)((double)params[i] - eta * (double)grad[i]);
     if (clip_eps == clip_eps && is_scale_diag(i, d, family)) x = clip_step(x, clip_eps);
     params[i] = x;
-    if (avg) avg[i] = (T)(wa * (double)x + wb * (double)avg[i]);
+    if (avg) avg[i] = poly_avg_step<T>(x, avg[i], wa, wb);
   }
 }
 

@@ -284,6 +284,7 @@ struct mivi_ctx {
   void *p2p_peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // mapped bases (own entry = p2p_buf)
   bool p2p_opened[8] = {false, false, false, false, false, false, false, false};                   // hipIpcOpenMemHandle'd (to be closed)
   mivi::DevBuf rows_eps;   // kernels_fullrank_rows.hip: eps of all steps of a device-resident loop call
+  mivi::DevBuf gen_scratch;  // kernels_meanfield.hip k_mf_gen_loop: DoG / DoWG partial norms of every step, arrival flags
   mivi::DevBuf tiles_buf;  // kernels_fullrank_tiles.hip: eps of a chunk of steps, exchange areas, flags, value partials
   mivi::DevBuf p2p_tab, p2p_ctr, p2p_scratch, p2p_direct;   // (p2p_direct: P2PDirectTab, what the partial kernels need to store straight into the owners' staging areas)
   bool p2p_on = false;
@@ -392,6 +393,9 @@ bool fr_rows_loop_ok(const mivi_ctx *c);    // kernels_fullrank_rows.hip: f32, n
 size_t fr_rows_eps_bytes(const mivi_ctx *c, int n_steps);
 void launch_fr_rows_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta, double clip_eps,
                          float *eps_all, double *hist, double *elbo, void *value);
+bool mf_gen_loop_ok(const mivi_ctx *c, int rule);   // kernels_meanfield.hip: every rule x operator x averager, mean-field + diagonal-Gaussian target
+size_t mf_gen_loop_scratch_bytes(const mivi_ctx *c, int n_steps);
+void launch_mf_gen_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *hist, double *elbo, char *scratch);
 bool fr_tiles_loop_ok(const mivi_ctx *c);   // kernels_fullrank_tiles.hip: f32, d <= 1024 (multiple of 64), n_mc 128 / 256, diagonal-Gaussian target, not STL
 size_t fr_tiles_bytes(const mivi_ctx *c, int n_steps);
 void launch_fr_tiles_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta, double clip_eps,

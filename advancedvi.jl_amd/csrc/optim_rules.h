@@ -69,7 +69,18 @@ __device__ __forceinline__ T clip_step(T v, T eps) {
 // = c + (sqrt(c^2 + 4 gamma) - c) / 2     (src/optimization/proximal_location_scale_entropy.jl:56)
 template <typename T>
 __device__ __forceinline__ T prox_entropy_step(T c, T gamma) {
-  return c + (sqrt(c * c + T(4) * gamma) - c) / T(2);
+#pragma clang fp contract(off)   // (k_prox and the launch-free loops must round it identically)
+  const T cc = c * c, g4 = T(4) * gamma;
+  return c + (sqrt(cc + g4) - c) / T(2);
+}
+
+// PolynomialAveraging on one element (src/optimization/averaging.jl:40-47): avg <- w x + (1 - w) avg in f64, rounded to T.  Contraction off:
+// the expression sits in several kernels (k_poly_average, the fused DoG apply passes, the launch-free loops) that must round it identically.
+template <typename T>
+__device__ __forceinline__ T poly_avg_step(T x, T avg, double wa, double wb) {
+#pragma clang fp contract(off)
+  const double p = wa * (double)x, q = wb * (double)avg;
+  return (T)(p + q);
 }
 
 }  // namespace mivi
