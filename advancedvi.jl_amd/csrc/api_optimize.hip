@@ -131,6 +131,18 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);
   }
+  if (!simple && fr_rows_loop_ok(c) && (rule < 2 || c->cfg.d <= 1024) && !no_fused_loop && fr_rows_eps_bytes(c, n_steps) <= ((size_t)1 << 31)) {
+    // ... and on the full-rank family with few samples per step (the reference's default n_samples = 1): the row-owning workgroups of
+    // k_fr_rows_loop, DoG / DoWG with the same per-step exchange of two norm partials (every workgroup resident: d <= 1024)
+    if ((s = ensure(c, c->rows_eps, fr_rows_eps_bytes(c, n_steps), false))) return s;
+    if (rule >= 2 && (s = ensure(c, c->gen_scratch, fr_rows_part_bytes(c, n_steps) + 256, false))) return s;
+    HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
+    launch_fr_rows_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, (float *)c->rows_eps.p, rec + n_steps, rec, vbuf, &l,
+                        (double *)c->gen_scratch.p);
+    HIPCHK(c, hipGetLastError());
+    if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
+    return read_status(c);
+  }
   if (simple && (rule == 0 || default_adam) && fr_tiles_loop_ok(c) && !no_fused_loop) {
     // the north-star shape class: ONE persistent kernel whose workgroups own tiles of tril(C) (parameters and moments in registers) and exchange
     // partial products / W inside their row block, bitwise the launch-per-step trajectory (k_fr_tiles_loop).  eps is drawn up front for a chunk

@@ -44,6 +44,15 @@ struct FrRowsArgs {
   long long t0;
   double eta, clip_eps, b1, b2, adam_eps;
   double *hist;                    // [n_steps][4][n_wg]
+  // the rules / operators / averager beyond Descent / Adam + ClipScale (k_mf_gen_loop's set: the reference's defaults are DoWG + averaging)
+  int op, averager;                // op 0 identity, 1 ClipScale, 2 ProximalLocationScaleEntropy; averager 1: PolynomialAveraging
+  double avg_eta;
+  float *avg;                      // running average [mu; vec C], in / out
+  const float *x0;                 // DoG / DoWG: the initial parameters
+  double *dog_sc;                  // DoG / DoWG: (v, r), in / out
+  double *part;                    // DoG / DoWG: [n_steps][n_wg][2] partial norms, NaN until delivered
+  int *status;
+  int spin;
 };
 
 constexpr int kRowsEPT = 9;        // entries of a row per thread (128 threads per pair of rows: d + 1 <= 9 * 126)
@@ -74,9 +83,9 @@ __global__ __launch_bounds__(256) void k_eps_steps(uint64_t seed, uint64_t idx0,
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), \
                                    (__attribute__((address_space(3))) void *)(lptr), 16, 0, 0)
 
-// RULE: 0 Descent, 1 Adam.  MC: samples per chunk (1, 2, 4: the whole batch; 8: a.nch chunks).  DB: two slabs fit the LDS -- the next
+// RULE: 0 Descent, 1 Adam, 2 DoG, 3 DoWG (the last two: one grid-wide exchange of two norm partials per step, as in k_mf_gen_loop).  MC: samples per chunk (1, 2, 4: the whole batch; 8: a.nch chunks).  DB: two slabs fit the LDS -- the next
 // step's slab arrives (LDS-DMA, no registers) while this step computes.
-template <int RULE, int MC, bool DB>
+template <int RULE, int MC, bool DB, bool GEN>   // GEN: the proximal operator / PolynomialAveraging code and registers exist
 __global__ __launch_bounds__(kRowsNT) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_fr_rows_loop(FrRowsArgs a) {
   constexpr int NT = kRowsNT, EPT = kRowsEPT, ZS = kRowsMaxM;
   extern __shared__ __attribute__((aligned(16))) float S[];   // eps slab(s) [k][Mp], then the small exchange areas
@@ -86,6 +95,8 @@ __global__ __launch_bounds__(kRowsNT) __attribute__((amdgpu_waves_per_eu(1, 1)))
   float *zred = S + (DB ? 2 : 1) * slabN;     // [4 waves][2 rows][ZS]: wave partials of the dot products
   float *sc = zred + 4 * 2 * ZS;              // [step parity][pair][row]{mu, C_rr}; [16 ..]: [pair][row] scalar partials {ell, he, lg, bad}
   float(*cc_tab)[2] = reinterpret_cast<float(*)[2]>(sc + 16 + 16);   // [256][2] Adam bias corrections
+  double *gred = reinterpret_cast<double *>(sc + 16 + 16 + 512);     // [8] block sums of the two norm partials
+  int *ok_s = reinterpret_cast<int *>(gred + 8);
   const int pr = tid >> 7, t7 = tid & 127;    // the pair this thread works for, its index inside the pair
   const int p = 2 * b + pr, q = d - 1 - p;    // rows p and q (one row when they meet, none beyond)
   const bool pair_ok = p <= q, two = p < q;
@@ -99,25 +110,31 @@ __global__ __launch_bounds__(kRowsNT) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const float invMf = 1.f / (float)a.M_total;
   const double invM = 1.0 / (double)a.M_total;
   const float eta = (float)a.eta, b1 = (float)a.b1, b2 = (float)a.b2, aeps = (float)a.adam_eps, ceps = (float)a.clip_eps;
-  const bool clip = a.clip_eps == a.clip_eps;
+  const bool clip = a.op == 1 && a.clip_eps == a.clip_eps, prox = GEN && a.op == 2, averaging = GEN && a.averager == 1;
   const size_t plen = (size_t)d + (size_t)d * d;
 
   // this thread's entries C[row, k0 .. k0 + 8]
   bool eok[EPT];
   int eo[EPT];                                // slab offsets of their eps rows (an entry beyond the row has px = 0 and reads row d - 1)
-  float px[EPT], pm[EPT], pv[EPT];
+  float px[EPT], pm[EPT], pv[EPT];           // (DoG / DoWG: pm holds x0; pv, with PolynomialAveraging, the running average)
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     eok[e] = row_ok && k0 + e <= row;
     eo[e] = min(k0 + e, d - 1) * Mp;
     const size_t at = (size_t)d + (size_t)(eok[e] ? k0 + e : 0) * d + (eok[e] ? row : 0);
     px[e] = eok[e] ? a.params[at] : 0.f;
-    pm[e] = (RULE == 1 && eok[e]) ? a.opt_state[at] : 0.f;
+    pm[e] = (RULE == 1 && eok[e]) ? a.opt_state[at] : ((RULE >= 2 && eok[e]) ? a.x0[at] : 0.f);
     pv[e] = (RULE == 1 && eok[e]) ? a.opt_state[plen + at] : 0.f;
   }
+  float pa[EPT];                              // PolynomialAveraging: the running average of the thread's entries
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) pa[e] = (averaging && eok[e]) ? a.avg[(size_t)d + (size_t)(k0 + e) * d + row] : 0.f;
   const bool mu_own = row_ok && k0 == 0;      // the row's first thread also owns mu_row
-  float mx = mu_own ? a.params[row] : 0.f, mm1 = (RULE == 1 && mu_own) ? a.opt_state[row] : 0.f,
-        mv1 = (RULE == 1 && mu_own) ? a.opt_state[plen + row] : 0.f;
+  float mx = mu_own ? a.params[row] : 0.f, mm1 = (RULE == 1 && mu_own) ? a.opt_state[row] : ((RULE >= 2 && mu_own) ? a.x0[row] : 0.f),
+        mv1 = (RULE == 1 && mu_own) ? a.opt_state[plen + row] : 0.f, ma = (averaging && mu_own) ? a.avg[row] : 0.f;
+  double dog_v = 0.0, dog_r = 0.0;
+  if (RULE >= 2) { dog_v = a.dog_sc[0]; dog_r = a.dog_sc[1]; }
+  bool lost = false;
   const float tm = row_ok ? a.t_mean[row] : 0.f, ti = row_ok ? a.t_istd[row] : 0.f;
   const int diag_e = row_ok ? row - k0 : -1;  // the entry that is C[row, row], if this thread holds it (0 .. 8)
 
@@ -141,7 +158,7 @@ __global__ __launch_bounds__(kRowsNT) __attribute__((amdgpu_waves_per_eu(1, 1)))
   __builtin_amdgcn_s_waitcnt(0x0f70);         // vmcnt(0)
   __syncthreads();
 
-  for (int t = 0; t < a.n_steps; ++t) {
+  for (int t = 0; t < a.n_steps && !lost; ++t) {
     const float *cur = S + (DB ? (t & 1) * slabN : 0);
     if (RULE == 1 && (t & 255) == 0 && tid < 256) adam_bias<float>(a.t0 + t + tid + 1, a.b1, a.b2, cc_tab[tid][0], cc_tab[tid][1]);
     if (DB && t + 1 < a.n_steps) slab_in(t + 1, S + ((t + 1) & 1) * slabN);
@@ -284,21 +301,91 @@ __global__ __launch_bounds__(kRowsNT) __attribute__((amdgpu_waves_per_eu(1, 1)))
       v = fmaf(b2, v, ((1.f - b2) * g) * g);
       return x - (eta * (m * rc1)) / (sqrtf(v * rc2) + aeps);
     };
+    float gE[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const bool diag = e == diag_e;
+      if (diag) gE[e] = (float)(-(double)gv[e] * invM - direct / (double)px[e]);
+      else gE[e] = -gv[e] * invMf;
+      if (!eok[e]) gE[e] = 0.f;
+    }
+    const float gmu = mu_own ? (float)(-(double)wsum * invM) : 0.f;
+    double e_t = 0.0, gamma = a.eta;   // DoG / DoWG: the step size of this step; gamma: the proximal operator's step size
+    if (RULE >= 2) {
+      // ||x - x0||^2 and ||g||^2 over ALL parameters (src/optimization/rules.jl:26-42, :48-64): this workgroup's share, then every
+      // workgroup's -- slots of this step's own that hold NaN until their workgroup has stored them (the data are their own flags)
+      double nn[2] = {0.0, 0.0};
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const double dx = eok[e] ? (double)px[e] - (double)pm[e] : 0.0, gg = (double)gE[e];
+        nn[0] += dx * dx;
+        nn[1] += gg * gg;
+      }
+      if (mu_own) {
+        const double dx = (double)mx - (double)mm1, gg = (double)gmu;
+        nn[0] += dx * dx;
+        nn[1] += gg * gg;
+      }
+      block_sum_n<double, NT, 2>(nn, gred);
+      if (tid == 0) {
+        double *pp = a.part + ((size_t)t * nwg + b) * 2;
+        // (a NaN norm -- diverged parameters -- travels as +Inf: NaN means "not delivered"; the step size and the value come out non-finite either way)
+        __hip_atomic_store(pp, nn[0] == nn[0] ? nn[0] : (double)INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 1, nn[1] == nn[1] ? nn[1] : (double)INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *ok_s = 1;
+      }
+      lds_barrier();
+      double sums[2] = {0.0, 0.0};
+      for (int k = tid; k < nwg; k += NT) {
+        const double *pp = a.part + ((size_t)t * nwg + k) * 2;
+        int budget = a.spin;
+        double q0, q1;
+        while (true) {
+          q0 = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          q1 = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (q0 == q0 && q1 == q1) break;
+          if (--budget <= 0) { atomicAnd(ok_s, 0); q0 = q1 = 0.0; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        sums[0] += q0;
+        sums[1] += q1;
+      }
+      lds_barrier();
+      if (!*ok_s) {
+        if (tid == 0) atomicOr(a.status, 8);
+        lost = true;
+        continue;
+      }
+      block_sum_n<double, NT, 2>(sums, gred);
+      dog_r = fmax(sqrt(sums[0]), dog_r);
+      if (RULE == 3) {
+        const double r2 = dog_r * dog_r;
+        dog_v = dog_v + r2 * sums[1];
+        e_t = r2 / sqrt(dog_v);
+      } else {
+        dog_v = dog_v + sums[1];
+        e_t = dog_r / sqrt(dog_v);
+      }
+      gamma = e_t;
+    }
+    const double tt = (double)(a.t0 + t + 1);
+    const double wa = (a.avg_eta + 1.0) / (tt + a.avg_eta), wb = 1.0 - wa;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       if (!eok[e]) continue;
       const bool diag = e == diag_e;
-      float g;
-      if (diag) g = (float)(-(double)gv[e] * invM - direct / (double)px[e]);
-      else g = -gv[e] * invMf;
-      if (RULE == 0) px[e] = descent_step(px[e], g, eta);
-      else px[e] = adam(px[e], g, pm[e], pv[e]);
+      if (RULE == 0) px[e] = descent_step(px[e], gE[e], eta);
+      else if (RULE == 1) px[e] = adam(px[e], gE[e], pm[e], pv[e]);
+      else px[e] = (float)((double)px[e] - e_t * (double)gE[e]);
       if (clip && diag) px[e] = clip_step(px[e], ceps);
+      if (prox && diag) px[e] = prox_entropy_step(px[e], (float)gamma);
+      if (averaging) pa[e] = poly_avg_step<float>(px[e], pa[e], wa, wb);
     }
     if (mu_own) {
-      const float g = (float)(-(double)wsum * invM);
-      if (RULE == 0) mx = descent_step(mx, g, eta);
-      else mx = adam(mx, g, mm1, mv1);
+      if (RULE == 0) mx = descent_step(mx, gmu, eta);
+      else if (RULE == 1) mx = adam(mx, gmu, mm1, mv1);
+      else mx = (float)((double)mx - e_t * (double)gmu);
+      if (averaging) ma = poly_avg_step<float>(mx, ma, wa, wb);
     }
     publish((t + 1) & 1);
     if (DB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // vmcnt(0): the next slab is in
@@ -316,11 +403,14 @@ __global__ __launch_bounds__(kRowsNT) __attribute__((amdgpu_waves_per_eu(1, 1)))
     const size_t at = (size_t)d + (size_t)(k0 + e) * d + row;
     a.params[at] = px[e];
     if (RULE == 1) { a.opt_state[at] = pm[e]; a.opt_state[plen + at] = pv[e]; }
+    if (averaging) a.avg[at] = pa[e];
   }
   if (mu_own) {
     a.params[row] = mx;
     if (RULE == 1) { a.opt_state[row] = mm1; a.opt_state[plen + row] = mv1; }
+    if (averaging) a.avg[row] = ma;
   }
+  if (RULE >= 2 && b == 0 && tid == 0) { a.dog_sc[0] = dog_v; a.dog_sc[1] = dog_r; }
 }
 
 // elbo[t] (and the status word) from the per-step partials of k_fr_rows_loop; one workgroup per step
@@ -353,14 +443,17 @@ bool fr_rows_loop_ok(const mivi_ctx *c) {
     return false;
   const int Mp = rows_mp(rows_mm(M));
   // two rows' threads fit 128 (d <= 1126); the slab fits the LDS beside the exchange areas; 16-byte slab copies
-  return d >= 8 && d <= 126 * kRowsEPT - 8 && ((long long)d * Mp) % 4 == 0 && (size_t)d * Mp * 4 + (8 * kRowsMaxM + 32 + 2 * 256) * 4 <= 160 * 1024;
+  return d >= 8 && d <= 126 * kRowsEPT - 8 && ((long long)d * Mp) % 4 == 0 && (size_t)d * Mp * 4 + (8 * kRowsMaxM + 32 + 2 * 256 + 32) * 4 <= 160 * 1024;
 }
 size_t fr_rows_eps_bytes(const mivi_ctx *c, int n_steps) { return (size_t)n_steps * c->cfg.d * rows_mp(rows_mm(c->cfg.n_mc)) * sizeof(float); }
 size_t fr_rows_hist_doubles(const mivi_ctx *c, int n_steps) { return (size_t)n_steps * 4 * (size_t)((c->cfg.d + 3) / 4); }
 
 // eps_all: fr_rows_eps_bytes; hist: fr_rows_hist_doubles; elbo: n_steps doubles; value: one float (the last step's objective value)
+size_t fr_rows_part_bytes(const mivi_ctx *c, int n_steps) { return (size_t)n_steps * (size_t)((c->cfg.d + 3) / 4) * 2 * sizeof(double); }
+
+// gen: the general loop's description (rules / operators / averager beyond Descent / Adam + ClipScale; part: fr_rows_part_bytes) or nullptr
 void launch_fr_rows_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta, double clip_eps,
-                         float *eps_all, double *hist, double *elbo, void *value) {
+                         float *eps_all, double *hist, double *elbo, void *value, const mivi_loop_t *gen, double *part) {
   const int d = c->cfg.d, M = c->cfg.n_mc, d4 = (d + 3) / 4, MM = rows_mm(M), Mp = rows_mp(MM);
   {
     const long long n = (long long)n_steps * d4 * Mp;
@@ -372,29 +465,54 @@ void launch_fr_rows_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t id
   a.t_mean = (const float *)c->t_mean.p; a.t_istd = (const float *)c->t_istd.p;
   a.eps_all = eps_all; a.t0 = t0; a.eta = eta; a.clip_eps = clip_eps; a.b1 = 0.9; a.b2 = 0.999; a.adam_eps = 1e-8;
   a.hist = hist;
+  a.op = (clip_eps == clip_eps) ? 1 : 0; a.averager = 0; a.avg_eta = 0.0; a.avg = nullptr; a.x0 = nullptr; a.dog_sc = nullptr; a.part = part;
+  a.status = (int *)c->status.p; a.spin = 1 << 20;
+  if (gen) {
+    a.op = gen->op; a.averager = gen->averager; a.avg_eta = gen->avg_eta; a.avg = (float *)gen->avg_params_dev;
+    a.b1 = gen->beta1; a.b2 = gen->beta2; a.adam_eps = gen->adam_eps;
+    if (rule >= 2) {
+      a.x0 = (const float *)gen->opt_state_dev;
+      a.dog_sc = (double *)((char *)gen->opt_state_dev + mivi_dog_state_bytes(c) - 16);
+      (void)hipMemsetAsync(part, 0xFF, fr_rows_part_bytes(c, n_steps), c->stream);   // (NaN: not delivered yet)
+    }
+  }
   const int nwg = (d + 3) / 4;   // two row pairs per workgroup
   a.nch = MM >= 8 ? MM / 8 : 1;
-  const size_t extras = (8 * kRowsMaxM + 32 + 2 * 256) * sizeof(float), slab = (size_t)d * Mp * sizeof(float);
+  const size_t extras = (8 * kRowsMaxM + 32 + 2 * 256 + 32) * sizeof(float), slab = (size_t)d * Mp * sizeof(float);
   const bool db = 2 * slab + extras <= 160 * 1024;
   const size_t lds = (db ? 2 : 1) * slab + extras;
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(kRowsNT), lds, c->stream, a);
   };
+  const bool general = gen && (gen->op == 2 || gen->averager == 1);
   auto pick = [&](auto r, auto dbl) {
     constexpr int R = decltype(r)::value;
     constexpr bool D = decltype(dbl)::value;
-    switch (MM) {
-      case 1: go(k_fr_rows_loop<R, 1, D>); break;
-      case 2: go(k_fr_rows_loop<R, 2, D>); break;
-      case 4: go(k_fr_rows_loop<R, 4, D>); break;
-      default: go(k_fr_rows_loop<R, 8, D>); break;
+    if (R < 2 && !general) {
+      switch (MM) {
+        case 1: go(k_fr_rows_loop<R, 1, D, false>); break;
+        case 2: go(k_fr_rows_loop<R, 2, D, false>); break;
+        case 4: go(k_fr_rows_loop<R, 4, D, false>); break;
+        default: go(k_fr_rows_loop<R, 8, D, false>); break;
+      }
+    } else {
+      switch (MM) {
+        case 1: go(k_fr_rows_loop<R, 1, D, true>); break;
+        case 2: go(k_fr_rows_loop<R, 2, D, true>); break;
+        case 4: go(k_fr_rows_loop<R, 4, D, true>); break;
+        default: go(k_fr_rows_loop<R, 8, D, true>); break;
+      }
     }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
   if (rule == 0) { if (db) pick(I0{}, std::true_type{}); else pick(I0{}, std::false_type{}); }
-  else { if (db) pick(I1{}, std::true_type{}); else pick(I1{}, std::false_type{}); }
+  else if (rule == 1) { if (db) pick(I1{}, std::true_type{}); else pick(I1{}, std::false_type{}); }
+  else if (rule == 2) { if (db) pick(I2{}, std::true_type{}); else pick(I2{}, std::false_type{}); }
+  else { if (db) pick(I3{}, std::true_type{}); else pick(I3{}, std::false_type{}); }
   hipLaunchKernelGGL(k_fr_rows_value, dim3(n_steps), dim3(256), 0, c->stream, d, nwg, M, c->M_total, c->cfg.entropy, c->t_const, (const double *)hist, elbo,
                      (float *)value, n_steps, (int *)c->status.p);
 }

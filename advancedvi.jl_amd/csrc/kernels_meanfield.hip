@@ -661,8 +661,9 @@ __global__ __launch_bounds__(256) void k_mf_gen_loop(MfGenLoopArgs<T> a) {
       // reader spins on the data itself -- no acknowledge-then-flag round trip on the producer's side
       if (tid == 0) {
         double *pp = a.part + ((size_t)t * nblk + rq) * 2;
-        __hip_atomic_store(pp, p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(pp + 1, p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (a NaN norm -- diverged parameters -- travels as +Inf: NaN means "not delivered"; the step size and the value come out non-finite either way)
+        __hip_atomic_store(pp, p0 == p0 ? p0 : (double)INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 1, p1 == p1 ? p1 : (double)INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ok_s = 1;
       }
       __syncthreads();

@@ -391,8 +391,9 @@ void launch_mf_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx
                         double eta, double clip_eps, double *hist, double *elbo, void *grad_out = nullptr, void *lane_scratch = nullptr);
 bool fr_rows_loop_ok(const mivi_ctx *c);    // kernels_fullrank_rows.hip: f32, n_mc <= 32, d <= 1024, diagonal-Gaussian target, not STL
 size_t fr_rows_eps_bytes(const mivi_ctx *c, int n_steps);
+size_t fr_rows_part_bytes(const mivi_ctx *c, int n_steps);
 void launch_fr_rows_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta, double clip_eps,
-                         float *eps_all, double *hist, double *elbo, void *value);
+                         float *eps_all, double *hist, double *elbo, void *value, const mivi_loop_t *gen = nullptr, double *part = nullptr);
 bool mf_gen_loop_ok(const mivi_ctx *c, int rule);   // kernels_meanfield.hip: every rule x operator x averager, mean-field + diagonal-Gaussian target
 size_t mf_gen_loop_scratch_bytes(const mivi_ctx *c, int n_steps);
 void launch_mf_gen_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *hist, double *elbo, char *scratch);

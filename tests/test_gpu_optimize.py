@@ -757,6 +757,43 @@ def test_meanfield_general_loop(combo, shape, dtype):
     assert np.allclose(a[3], b[3], rtol=1e-5 if dtype == np.float32 else 1e-10)
 
 
+@pytest.mark.parametrize("shape", [(1024, 1), (256, 8), (130, 2)], ids=["d1024-one-sample", "d256-m8", "ragged"])
+@pytest.mark.parametrize("combo", [
+    ("dowg", "clip", "poly"), ("dowg", "prox", "poly"), ("dog", "clip", "none"), ("descent", "prox", "poly"), ("adam", "clip", "poly")])
+def test_fullrank_rows_general_loop(combo, shape):
+    """Full-rank family with few samples per step (the reference's default is n_samples = 1), diagonal-Gaussian target, the reference's DEFAULT
+    rule / averager (DoWG + PolynomialAveraging) and the other combinations beyond Descent / Adam + ClipScale: the row-owning workgroups of
+    k_fr_rows_loop (DoG / DoWG: two norm partials per workgroup and step).  Against the host-driven `step` loop, to rounding (the loop's sums
+    are sequential multiply-adds, not the tile kernels' MFMA chains): parameters, averaged output, elbo record; a warm start continues."""
+    rule, op, avg = combo
+    d, M = shape
+    T = 14
+    rng = np.random.default_rng(5)
+    mu, sig = rng.normal(size=d).astype(np.float32), rng.uniform(0.5, 1.5, size=d).astype(np.float32)
+    prob = avi.DiagNormalProblem(mu, sig)
+    C0 = (np.eye(d) + (0.3 / np.sqrt(d)) * np.tril(rng.normal(size=(d, d)), -1)).astype(np.float32)
+    q0 = avi.FullRankGaussian(np.zeros(d, np.float32), C0)
+    opt = {"descent": avi.Descent(1e-2), "adam": avi.Adam(1e-2), "dog": avi.DoG(1e-2), "dowg": avi.DoWG(1e-2)}[rule]
+    averager = avi.PolynomialAveraging() if avg == "poly" else avi.NoAveraging()
+    if op == "prox":
+        alg = avi.KLMinRepGradProxDescent(avi.AutoMIVI(), n_samples=M, optimizer=opt, averager=averager)
+    else:
+        alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), n_samples=M, optimizer=opt, averager=averager, operator=avi.ClipScale())
+    outs = []
+    import warnings
+    for dev in (True, False):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q1, info1, st = avi.optimize(avi.PhiloxRNG(11), alg, T, prob, q0, device_loop=dev)
+            q2, info2, st2 = avi.optimize(avi.PhiloxRNG(11, T), alg, 6, prob, None, state=st, device_loop=dev)
+        outs.append((q2.location.copy(), np.asarray(q2.scale).copy(), st2["params"].cpu().numpy().copy(), np.array([i["elbo"] for i in info1 + info2])))
+    a, b = outs
+    tol = 1e-4 if rule == "adam" else 3e-5
+    for x, y in zip(a[:3], b[:3]):
+        assert np.max(np.abs(x.astype(np.float64) - y.astype(np.float64))) <= tol * max(1.0, np.max(np.abs(y))), np.max(np.abs(x - y))
+    assert np.allclose(a[3], b[3], rtol=5e-5, atol=1e-3)
+
+
 def test_optimize_falls_back_to_the_host_loop_for_plugin_targets_and_callbacks():
     class Plug:
         def __init__(self, mu):
