@@ -32,6 +32,13 @@ struct FrSmallLoopArgs {
   double *elbo;                   // [n_steps]
   T *value;                       // the last step's objective value
   int *status;
+  // beyond Descent / Adam + ClipScale (the general loop, mivi_optimize_loop): rule 2 DoG / 3 DoWG (the two norms are block sums: one workgroup),
+  // op 2 ProximalLocationScaleEntropy, PolynomialAveraging -- the reference's defaults are DoWG + averaging
+  int op, averager;
+  double avg_eta;
+  T *avg;
+  const T *x0;
+  double *dog_sc;
 };
 
 constexpr int kSmallD = 32, kSmallM = 64, kSmallNE = 3;   // (32 + 528 entries over 256 threads)
@@ -52,7 +59,8 @@ __global__ __launch_bounds__(256) void k_fr_small_loop(FrSmallLoopArgs<T> a) {
   const double direct = direct_entropy_coeff(a.ent_kind);
   const double invM = 1.0 / (double)a.M_total;
   const T eta = (T)a.eta, b1 = (T)a.b1, b2 = (T)a.b2, aeps = (T)a.adam_eps, ceps = (T)a.clip_eps;
-  const bool clip = a.clip_eps == a.clip_eps;   // NaN = no ClipScale
+  const bool clip = a.op == 1 && a.clip_eps == a.clip_eps, prox = a.op == 2, averaging = a.averager == 1;   // (NaN clip_eps = no ClipScale)
+  __shared__ double nred[2 * (NT / 64)];
   const size_t plen = (size_t)d + (size_t)d * d;
 
   // this thread's entries: e < d: mu_e; else the packed lower entry e - d = j d - j (j - 1) / 2 + (i - j) (column j, row i >= j)
@@ -72,9 +80,14 @@ __global__ __launch_bounds__(256) void k_fr_small_loop(FrSmallLoopArgs<T> a) {
     }
     ep[u] = ej[u] < 0 ? (size_t)ei[u] : (size_t)d + (size_t)ej[u] * d + ei[u];
     px[u] = eok[u] ? a.params[ep[u]] : T(0);
-    pm[u] = (RULE == 1 && eok[u]) ? a.opt_state[ep[u]] : T(0);
-    pv[u] = (RULE == 1 && eok[u]) ? a.opt_state[plen + ep[u]] : T(0);
+    pm[u] = (RULE == 1 && eok[u]) ? a.opt_state[ep[u]] : ((RULE >= 2 && eok[u]) ? a.x0[ep[u]] : T(0));   // (DoG / DoWG: x0)
+    pv[u] = (RULE == 1 && eok[u]) ? a.opt_state[plen + ep[u]] : ((averaging && RULE != 1 && eok[u]) ? a.avg[ep[u]] : T(0));   // (... the running average)
   }
+  T pa[kSmallNE];   // Adam + PolynomialAveraging: the running average beside the two moments
+#pragma unroll
+  for (int u = 0; u < kSmallNE; ++u) pa[u] = (RULE == 1 && averaging && eok[u]) ? a.avg[ep[u]] : T(0);
+  double dog_v = 0.0, dog_r = 0.0;
+  if (RULE >= 2) { dog_v = a.dog_sc[0]; dog_r = a.dog_sc[1]; }
   for (int i = tid; i < d * d; i += NT) Cs[i] = T(0);
   if (tid < d) { tms[tid] = a.t_mean[tid]; tiss[tid] = a.t_istd[tid]; }
   __syncthreads();
@@ -159,9 +172,11 @@ __global__ __launch_bounds__(256) void k_fr_small_loop(FrSmallLoopArgs<T> a) {
       if (s_bad > 0.0) st |= 2;
       if (st && a.status) atomicOr(a.status, st);
     }
-    // gradient entries of this thread + Optimisers.update! + ClipScale
+    // gradient entries of this thread + Optimisers.update! + operator + averager
+    T gE[kSmallNE];
 #pragma unroll
     for (int u = 0; u < kSmallNE; ++u) {
+      gE[u] = T(0);
       if (!eok[u]) continue;
       const int i = ei[u], j = ej[u];
       T v = 0;
@@ -174,10 +189,45 @@ __global__ __launch_bounds__(256) void k_fr_small_loop(FrSmallLoopArgs<T> a) {
       }
       double gx = -(double)v * invM;
       if (j >= 0 && i == j) gx -= direct / (double)Cs[j * d + j];
-      const T g = (T)gx;
-      if (RULE == 0) px[u] = descent_step(px[u], g, eta);
-      else px[u] = adam_step<T>(px[u], g, pm[u], pv[u], cc_tab[t & (NT - 1)][0], cc_tab[t & (NT - 1)][1], eta, b1, b2, aeps);
-      if (clip && j >= 0 && i == j) px[u] = clip_step(px[u], ceps);
+      gE[u] = (T)gx;
+    }
+    double e_t = 0.0, gamma = a.eta;
+    if (RULE >= 2) {   // DoG / DoWG (src/optimization/rules.jl:26-42, :48-64): ||x - x0||^2, ||g||^2 over all parameters, (v, r), the step size
+      double nn[2] = {0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < kSmallNE; ++u) {
+        const double dx = eok[u] ? (double)px[u] - (double)pm[u] : 0.0, gg = (double)gE[u];
+        nn[0] += dx * dx;
+        nn[1] += gg * gg;
+      }
+      block_sum_n<double, NT, 2>(nn, nred);
+      dog_r = fmax(sqrt(nn[0]), dog_r);
+      if (RULE == 3) {
+        const double r2 = dog_r * dog_r;
+        dog_v = dog_v + r2 * nn[1];
+        e_t = r2 / sqrt(dog_v);
+      } else {
+        dog_v = dog_v + nn[1];
+        e_t = dog_r / sqrt(dog_v);
+      }
+      gamma = e_t;
+    }
+    const double tt = (double)(a.t0 + t + 1);
+    const double wa = (a.avg_eta + 1.0) / (tt + a.avg_eta), wb = 1.0 - wa;
+#pragma unroll
+    for (int u = 0; u < kSmallNE; ++u) {
+      if (!eok[u]) continue;
+      const int i = ei[u], j = ej[u];
+      const bool diag = j >= 0 && i == j;
+      if (RULE == 0) px[u] = descent_step(px[u], gE[u], eta);
+      else if (RULE == 1) px[u] = adam_step<T>(px[u], gE[u], pm[u], pv[u], cc_tab[t & (NT - 1)][0], cc_tab[t & (NT - 1)][1], eta, b1, b2, aeps);
+      else px[u] = (T)((double)px[u] - e_t * (double)gE[u]);
+      if (clip && diag) px[u] = clip_step(px[u], ceps);
+      if (prox && diag) px[u] = prox_entropy_step(px[u], (T)gamma);
+      if (averaging) {
+        if (RULE == 1) pa[u] = poly_avg_step<T>(px[u], pa[u], wa, wb);
+        else pv[u] = poly_avg_step<T>(px[u], pv[u], wa, wb);
+      }
     }
     __syncthreads();   // (every thread is done with this step's LDS images)
   }
@@ -189,7 +239,9 @@ __global__ __launch_bounds__(256) void k_fr_small_loop(FrSmallLoopArgs<T> a) {
       a.opt_state[ep[u]] = pm[u];
       a.opt_state[plen + ep[u]] = pv[u];
     }
+    if (averaging) a.avg[ep[u]] = RULE == 1 ? pa[u] : pv[u];
   }
+  if (RULE >= 2 && tid == 0) { a.dog_sc[0] = dog_v; a.dog_sc[1] = dog_r; }
 }
 
 // Where ONE workgroup beats the graph of launches (tools/small_loop_bench.py, us per step, this loop / the graph): d x n_mc = 10 x 1: 2.3 / 8.8
@@ -204,7 +256,7 @@ bool fr_small_loop_ok(const mivi_ctx *c) {
 
 template <typename T>
 static void fr_small_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta,
-                               double clip_eps, double *elbo, void *value) {
+                               double clip_eps, double *elbo, void *value, const mivi_loop_t *gen) {
   FrSmallLoopArgs<T> a;
   a.d = c->cfg.d; a.M = c->cfg.n_mc; a.n_steps = n_steps; a.rule = rule; a.ent_kind = c->cfg.entropy;
   a.m_offset = c->cfg.m_offset; a.M_total = c->M_total;
@@ -213,14 +265,25 @@ static void fr_small_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint6
   a.seed = c->cfg.seed; a.idx0 = idx0; a.t0 = t0;
   a.eta = eta; a.clip_eps = clip_eps; a.b1 = 0.9; a.b2 = 0.999; a.adam_eps = 1e-8; a.ell_const = c->t_const;
   a.elbo = elbo; a.value = (T *)value; a.status = (int *)c->status.p;
+  a.op = (clip_eps == clip_eps) ? 1 : 0; a.averager = 0; a.avg_eta = 0.0; a.avg = nullptr; a.x0 = nullptr; a.dog_sc = nullptr;
+  if (gen) {
+    a.op = gen->op; a.averager = gen->averager; a.avg_eta = gen->avg_eta; a.avg = (T *)gen->avg_params_dev;
+    a.b1 = gen->beta1; a.b2 = gen->beta2; a.adam_eps = gen->adam_eps;
+    if (rule >= 2) {
+      a.x0 = (const T *)gen->opt_state_dev;
+      a.dog_sc = (double *)((char *)gen->opt_state_dev + mivi_dog_state_bytes(c) - 16);
+    }
+  }
   if (rule == 0) hipLaunchKernelGGL((k_fr_small_loop<T, 0>), dim3(1), dim3(256), 0, c->stream, a);
-  else hipLaunchKernelGGL((k_fr_small_loop<T, 1>), dim3(1), dim3(256), 0, c->stream, a);
+  else if (rule == 1) hipLaunchKernelGGL((k_fr_small_loop<T, 1>), dim3(1), dim3(256), 0, c->stream, a);
+  else if (rule == 2) hipLaunchKernelGGL((k_fr_small_loop<T, 2>), dim3(1), dim3(256), 0, c->stream, a);
+  else hipLaunchKernelGGL((k_fr_small_loop<T, 3>), dim3(1), dim3(256), 0, c->stream, a);
 }
 // rule 0 Descent / 1 Adam (default betas); elbo: n_steps doubles; value: one element of T
 void launch_fr_small_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta,
-                          double clip_eps, double *elbo, void *value) {
-  if (c->cfg.dtype == MIVI_F32) fr_small_loop_impl<float>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, elbo, value);
-  else fr_small_loop_impl<double>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, elbo, value);
+                          double clip_eps, double *elbo, void *value, const mivi_loop_t *gen) {
+  if (c->cfg.dtype == MIVI_F32) fr_small_loop_impl<float>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, elbo, value, gen);
+  else fr_small_loop_impl<double>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, elbo, value, gen);
 }
 
 }  // namespace mivi

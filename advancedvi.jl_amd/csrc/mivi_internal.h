@@ -403,7 +403,7 @@ void launch_fr_tiles_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t i
                           char *buf, double *elbo, void *value);
 bool fr_small_loop_ok(const mivi_ctx *c);   // kernels_fullrank_small.hip: d <= 32, n_mc <= 64, diagonal-Gaussian target
 void launch_fr_small_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta,
-                          double clip_eps, double *elbo, void *value);
+                          double clip_eps, double *elbo, void *value, const mivi_loop_t *gen = nullptr);
 void launch_mf_funnel_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta,
                                double clip_eps, double *hist, unsigned *sync, void *pub, void *gtmp, double *elbo, void *value);
 void launch_mf_funnel_loop(mivi_ctx *c, const void *params, uint64_t idx0, int n_steps, double *hist, double *elbo, void *scratch,

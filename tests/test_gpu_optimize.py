@@ -794,6 +794,43 @@ def test_fullrank_rows_general_loop(combo, shape):
     assert np.allclose(a[3], b[3], rtol=5e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("shape", [(10, 1), (32, 16), (17, 3)], ids=["reference-bench", "d32-m16", "ragged"])
+@pytest.mark.parametrize("combo", [
+    ("dowg", "clip", "poly"), ("dowg", "prox", "poly"), ("dog", "clip", "none"), ("descent", "prox", "poly"), ("adam", "clip", "poly")])
+def test_small_fullrank_general_loop(combo, shape, dtype):
+    """Small full-rank problems (one workgroup, k_fr_small_loop) with the reference's DEFAULT rule / averager (DoWG + PolynomialAveraging) and the
+    other combinations beyond Descent / Adam + ClipScale: against the host-driven `step` loop, to rounding -- parameters, averaged output,
+    elbo record; a warm start continues."""
+    rule, op, avg = combo
+    d, M = shape
+    T = 14
+    rng = np.random.default_rng(6)
+    mu, sig = rng.normal(size=d).astype(dtype), rng.uniform(0.5, 1.5, size=d).astype(dtype)
+    prob = avi.DiagNormalProblem(mu, sig)
+    C0 = (np.eye(d) + 0.1 * np.tril(rng.normal(size=(d, d)), -1)).astype(dtype)
+    q0 = avi.FullRankGaussian(np.zeros(d, dtype), C0)
+    opt = {"descent": avi.Descent(1e-2), "adam": avi.Adam(1e-2), "dog": avi.DoG(1e-2), "dowg": avi.DoWG(1e-2)}[rule]
+    averager = avi.PolynomialAveraging() if avg == "poly" else avi.NoAveraging()
+    if op == "prox":
+        alg = avi.KLMinRepGradProxDescent(avi.AutoMIVI(), n_samples=M, optimizer=opt, averager=averager)
+    else:
+        alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), n_samples=M, optimizer=opt, averager=averager, operator=avi.ClipScale())
+    outs = []
+    import warnings
+    for dev in (True, False):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q1, info1, st = avi.optimize(avi.PhiloxRNG(12), alg, T, prob, q0, device_loop=dev)
+            q2, info2, st2 = avi.optimize(avi.PhiloxRNG(12, T), alg, 6, prob, None, state=st, device_loop=dev)
+        outs.append((q2.location.copy(), np.asarray(q2.scale).copy(), st2["params"].cpu().numpy().copy(), np.array([i["elbo"] for i in info1 + info2])))
+    a, b = outs
+    tol = (1e-4 if rule == "adam" else 3e-5) if dtype == np.float32 else 1e-10
+    for x, y in zip(a[:3], b[:3]):
+        assert np.max(np.abs(x.astype(np.float64) - y.astype(np.float64))) <= tol * max(1.0, np.max(np.abs(y))), np.max(np.abs(x - y))
+    assert np.allclose(a[3], b[3], rtol=5e-5 if dtype == np.float32 else 1e-9, atol=1e-4 if dtype == np.float32 else 1e-9)
+
+
 def test_optimize_falls_back_to_the_host_loop_for_plugin_targets_and_callbacks():
     class Plug:
         def __init__(self, mu):
