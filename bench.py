@@ -1091,6 +1091,35 @@ def main():
                                                             note="row-separable launch-free loop (k_fr_rows_loop); the launch-per-step graph route at these shapes: 20 us per step (DESIGN.md 9)")
                 except Exception as e:   # noqa: BLE001
                     also["ns_few_samples_adam_loop"] = dict(error=str(e))
+                # the reference's DEFAULT algorithm settings (KLMinRepGradDescent: DoWG + PolynomialAveraging + ClipScale, n_samples small;
+                # src/algorithms/constructors.jl:44-120) through mivi_optimize_loop: launch-free where the problem separates (round 4)
+                try:
+                    da = {}
+                    for nm, fam_a, d_a, M_a in (("meanfield_d1024_m256", 0, 1024, 256), ("fullrank_d1024_m8", 1, 1024, 8), ("fullrank_d10_m1", 1, 10, 1)):
+                        q_a = (avi.MeanFieldGaussian(np.zeros(d_a, np.float32), np.ones(d_a, np.float32)) if fam_a == 0
+                               else avi.FullRankGaussian(np.zeros(d_a, np.float32), np.eye(d_a, dtype=np.float32)))
+                        p_ah, _ = avi.destructure(q_a)
+                        c_a = avi.MiviContext(np.float32, fam_a, d_a, M_a, 0, SEED, device=local_rank)
+                        c_a.set_problem(avi.DiagNormalProblem(np.full(d_a, 5.0, np.float32), np.ones(d_a, np.float32)))
+                        p_a = c_a.to_device(p_ah).clone()
+                        s_a = c_a.dog_state()
+                        c_a.dog_init(p_a, s_a, 1e-6)
+                        avg_a = p_a.clone()
+                        kw_a = dict(rule=3, op=1, averager=1, clip_epsilon=1e-5, opt_state=s_a, avg_params=avg_a)
+                        c_a.optimize_loop(p_a, 500, 0, 0, **kw_a)
+                        stream.synchronize()
+                        t0s = time.perf_counter()
+                        for r in range(3):
+                            c_a.optimize_loop(p_a, 500, (r + 1) * 500, (r + 1) * 500, **kw_a)
+                        stream.synchronize()
+                        t_a = (time.perf_counter() - t0s) / 1500
+                        da[nm] = dict(steps_per_s=1.0 / t_a, us_per_step=t_a * 1e6)
+                        c_a.close()
+                    also["default_algorithm_loop"] = dict(workload="DoWG + PolynomialAveraging + ClipScale (the reference's default rule / averager / operator), diagonal-Gaussian target, mivi_optimize_loop, 3 x 500 steps",
+                                                          value=da["meanfield_d1024_m256"]["steps_per_s"], unit="steps/s", grid=da,
+                                                          note="launch-free: k_mf_gen_loop / k_fr_rows_loop (one exchange of two norm partials per step) / k_fr_small_loop; the hipGraph of launches: 8.9 / 30.4 / 11.5 us per step (DESIGN.md 9)")
+                except Exception as e:   # noqa: BLE001
+                    also["default_algorithm_loop"] = dict(error=str(e))
             # ---- parity + cpu_baseline leg (rank 0, N = 1 only) ---------------------------------------------
             rel = None
             parity_head = None

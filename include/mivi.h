@@ -276,8 +276,12 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *ctx, void *params_dev, void *opt_s
  *   averager  0 NoAveraging | 1 PolynomialAveraging(avg_eta): x_bar <- (1-w_t) x_bar + w_t x, w_t = (eta+1)/(t+eta)
  * opt_state: Adam T[2 params_len] (zeros before the first step) | DoG/DoWG mivi_dog_state_bytes (after mivi_dog_init).
  * avg_params: T[params_len] running average, in/out (any content when t0 = 0: w_1 = 1).  t0 = iterations already done
- * (warm start, src/optimize.jl:58-62).  Results are bitwise those of the step-by-step entries.  Descent/Adam with
- * Identity/ClipScale and no averaging take the fused paths of mivi_optimize_steps. */
+ * (warm start, src/optimize.jl:58-62).  Descent/Adam with Identity/ClipScale and no averaging take the fused paths of
+ * mivi_optimize_steps; the other combinations are launch-free as well where mivi_optimize_steps is (mean-field + diagonal-Gaussian
+ * target, d <= 2048 for DoG / DoWG; full-rank with n_mc <= 32 or d <= 32 and that target), with DoG / DoWG exchanging two norm
+ * partials per workgroup and step.  Results are bitwise those of the step-by-step entries on the hipGraph route and for
+ * Descent / Adam on the mean-field loop; DoG / DoWG in the launch-free loops to the rounding of the two f64 norm sums, the
+ * full-rank launch-free loops to f32 rounding. */
 typedef struct mivi_loop {
   int32_t rule, op, averager, n_steps;
   double eta, beta1, beta2, adam_eps;
