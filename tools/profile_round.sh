@@ -54,6 +54,12 @@ db=$(find /tmp/prof_dist -name '*.db' | head -1)
 { echo "# $TAG: MIVI_FORCE_DIST=1 rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 400 --warmup 40 (world 1, peer-to-peer exchange forced)"; echo;
   python $REPO/tools/rocpd_stats.py $db; } > $OUT/${TAG}_dist_forced_kernel_stats.md
 MIVI_FORCE_DIST=1 python bench.py --no-cpu-baseline --steps 400 --warmup 40 2>/dev/null | tail -1 > $OUT/${TAG}_bench_dist_forced.json
+# the launch-free optimisation loops (round 4): kernel stats of one call each -- default algorithm settings and Adam, the three families of loops
+rm -rf /tmp/prof_loops
+rocprofv3 --kernel-trace --stats -d /tmp/prof_loops -o run -- python $REPO/tools/loop_rules_bench.py 0,1024,256 1,1024,8 1,10,1 > /tmp/prof_loops.log 2>&1
+db=$(find /tmp/prof_loops -name '*.db' | head -1)
+{ echo "# $TAG: rocprofv3 --kernel-trace --stats -- python tools/loop_rules_bench.py 0,1024,256 1,1024,8 1,10,1 (mivi_optimize_loop, 4 x 500 steps per launch-free kernel call)"; echo;
+  python $REPO/tools/rocpd_stats.py $db; echo; echo '```'; cat /tmp/prof_loops.log | grep -v amdgpu.ids; echo '```'; } > $OUT/${TAG}_loops_kernel_stats.md
 # un-profiled bench lines
 for w in ns c2 ns_dense ns_stl c3 c5; do
   python bench.py --workload $w $( [ $w = c3 ] && echo "--steps 100 --warmup 10" ) 2>/dev/null | tail -1 > $OUT/${TAG}_bench_$w.json
