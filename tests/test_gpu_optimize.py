@@ -831,6 +831,27 @@ def test_small_fullrank_general_loop(combo, shape, dtype):
     assert np.allclose(a[3], b[3], rtol=5e-5 if dtype == np.float32 else 1e-9, atol=1e-4 if dtype == np.float32 else 1e-9)
 
 
+@pytest.mark.parametrize("family,d,M", [(avi.MEANFIELD, 1024, 8), (avi.FULLRANK, 256, 4)], ids=["meanfield", "fullrank-rows"])
+def test_dog_loops_report_divergence_not_a_lost_exchange(family, d, M):
+    """In the launch-free DoG / DoWG loops a partial norm's slot holds NaN until its workgroup has stored it.  Diverged parameters make the
+    norms themselves NaN: they must travel (as +Inf) and the call must end with the reference's `diverged` status (non-finite objective /
+    non-positive scale, src/algorithms/common.jl:83-89), not with an expired device-side wait."""
+    q0 = (avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32)) if family == avi.MEANFIELD
+          else avi.FullRankGaussian(np.zeros(d, np.float32), np.eye(d, dtype=np.float32)))
+    p0, _ = avi.destructure(q0)
+    ctx = avi.MiviContext(np.float32, family, d, M, 0, SEED)
+    ctx.set_problem(avi.DiagNormalProblem(np.zeros(d, np.float32), np.ones(d, np.float32)))
+    p = ctx.to_device(p0).clone()
+    st = ctx.dog_state()
+    ctx.dog_init(p, st, 1e-6)
+    p[3] = float("nan")
+    with pytest.raises(avi.MiviError) as ei:
+        ctx.optimize_loop(p, 5, 0, 0, rule=3, op=1, averager=0, clip_epsilon=1e-5, opt_state=st)
+        ctx.synchronize()
+    assert ei.value.status in (2, 3) and "wait expired" not in str(ei.value)
+    ctx.close()
+
+
 def test_optimize_falls_back_to_the_host_loop_for_plugin_targets_and_callbacks():
     class Plug:
         def __init__(self, mu):
