@@ -1088,7 +1088,7 @@ def main():
                         c_f.close()
                     also["ns_few_samples_adam_loop"] = dict(workload="north-star family and target (d=1024 full-rank, MvNormal(5*1, I)), n_mc = 1 / 8 / 16 per step, mivi_optimize_steps: Adam(1e-3) + ClipScale(1e-5), 3 x 1000 steps",
                                                             value=fs["n_mc=1"]["steps_per_s"], unit="steps/s", grid=fs,
-                                                            note="row-separable launch-free loop (k_fr_rows_loop); the launch-per-step graph route at these shapes: 20 us per step (DESIGN.md 9)")
+                                                            note="row-separable launch-free loop (k_fr_rows_loop); the launch-per-step graph route at these shapes: 20 us per step (DESIGN.md 3)")
                 except Exception as e:   # noqa: BLE001
                     also["ns_few_samples_adam_loop"] = dict(error=str(e))
                 # the reference's DEFAULT algorithm settings (KLMinRepGradDescent: DoWG + PolynomialAveraging + ClipScale, n_samples small;
@@ -1117,7 +1117,7 @@ def main():
                         c_a.close()
                     also["default_algorithm_loop"] = dict(workload="DoWG + PolynomialAveraging + ClipScale (the reference's default rule / averager / operator), diagonal-Gaussian target, mivi_optimize_loop, 3 x 500 steps",
                                                           value=da["meanfield_d1024_m256"]["steps_per_s"], unit="steps/s", grid=da,
-                                                          note="launch-free: k_mf_gen_loop / k_fr_rows_loop (one exchange of two norm partials per step) / k_fr_small_loop; the hipGraph of launches: 8.9 / 30.4 / 11.5 us per step (DESIGN.md 9)")
+                                                          note="launch-free: k_mf_gen_loop / k_fr_rows_loop (one exchange of two norm partials per step) / k_fr_small_loop; the hipGraph of launches: 8.9 / 30.4 / 11.5 us per step (DESIGN.md 3)")
                 except Exception as e:   # noqa: BLE001
                     also["default_algorithm_loop"] = dict(error=str(e))
             # ---- parity + cpu_baseline leg (rank 0, N = 1 only) ---------------------------------------------

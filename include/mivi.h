@@ -281,7 +281,7 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *ctx, void *params_dev, void *opt_s
  * target, d <= 2048 for DoG / DoWG; full-rank with n_mc <= 32 or d <= 32 and that target), with DoG / DoWG exchanging two norm
  * partials per workgroup and step.  Results are bitwise those of the step-by-step entries on the hipGraph route and for
  * Descent / Adam on the mean-field loop; DoG / DoWG in the launch-free loops to the rounding of the two f64 norm sums, the
- * full-rank launch-free loops to f32 rounding (DESIGN.md 9). */
+ * full-rank launch-free loops to f32 rounding (DESIGN.md 3). */
 typedef struct mivi_loop {
   int32_t rule, op, averager, n_steps;
   double eta, beta1, beta2, adam_eps;
