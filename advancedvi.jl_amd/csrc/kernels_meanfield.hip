@@ -568,6 +568,8 @@ __global__ __launch_bounds__(256) void k_mf_gen_loop(MfGenLoopArgs<T> a) {
   if (RULE >= 2) { dog_v = a.dog_sc[0]; dog_r = a.dog_sc[1]; }
   double lg = 0.0, bad = 0.0;
   bool lost = false;
+  T e_next[4] = {0, 0, 0, 0};   // DoG / DoWG: this thread's first draw of the NEXT step, made while the norms are on their way (the draws do not
+  bool have_next = false;       // depend on the parameters)
   for (int t = 0; t < n_steps && !lost; ++t) {
     if (RULE == 1 && (t & 255) == 0) {
       __syncthreads();
@@ -583,7 +585,12 @@ __global__ __launch_bounds__(256) void k_mf_gen_loop(MfGenLoopArgs<T> a) {
     }
     for (int m = tid; m < M; m += 256) {   // (k_mf_sgd_loop's column work: the same values in the same order)
       T e[4];
-      eps_block<T>(a.seed, a.idx0 + (uint64_t)t, (uint64_t)(a.m_offset + m) * (uint64_t)d4 + (uint64_t)rq, e);
+      if (RULE >= 2 && m == tid && have_next) {   // (drawn under the previous step's exchange)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) e[r] = e_next[r];
+      } else {
+        eps_block<T>(a.seed, a.idx0 + (uint64_t)t, (uint64_t)(a.m_offset + m) * (uint64_t)d4 + (uint64_t)rq, e);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool ok = (4 * rq + r) < d;
@@ -667,6 +674,8 @@ __global__ __launch_bounds__(256) void k_mf_gen_loop(MfGenLoopArgs<T> a) {
         ok_s = 1;
       }
       __syncthreads();
+      have_next = t + 1 < n_steps && tid < M;
+      if (have_next) eps_block<T>(a.seed, a.idx0 + (uint64_t)(t + 1), (uint64_t)(a.m_offset + tid) * (uint64_t)d4 + (uint64_t)rq, e_next);
       double sums[2] = {0.0, 0.0};
       for (int k = tid; k < nblk; k += 256) {
         const double *pp = a.part + ((size_t)t * nblk + k) * 2;
