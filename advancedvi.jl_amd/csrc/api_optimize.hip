@@ -121,6 +121,15 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);
   }
+  if (lr_small_loop_ok(c) && !no_fused_loop) {
+    // small hierarchical logistic regressions (the reference README's own example, BASELINE configs[0]): the whole loop in ONE workgroup, every
+    // rule x operator x averager (k_lr_small_loop)
+    HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
+    launch_lr_small_loop(c, params, l, rec, vbuf);
+    HIPCHK(c, hipGetLastError());
+    if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
+    return read_status(c);
+  }
   if (!simple && mf_gen_loop_ok(c, rule) && !no_fused_loop) {
     // every other rule x operator x averager of the reference's algorithms (DoG / DoWG, ProximalLocationScaleEntropy, PolynomialAveraging -- its
     // defaults), mean-field + diagonal-Gaussian target: launch-free as well (k_mf_gen_loop; DoG / DoWG: one grid-wide exchange of two norms per step)

@@ -1115,6 +1115,31 @@ def main():
                         t_a = (time.perf_counter() - t0s) / 1500
                         da[nm] = dict(steps_per_s=1.0 / t_a, us_per_step=t_a * 1e6)
                         c_a.close()
+                    try:   # ... and the reference README's own example (README.md:42-119: logistic regression on 208 rows x 60 features, one sample per step)
+                        rng_l = np.random.default_rng(0)
+                        X_l = rng_l.normal(size=(208, 60)).astype(np.float32)
+                        y_l = (rng_l.uniform(size=208) < 0.5).astype(np.float32)
+                        pr_l = avi.LogRegProblem(X_l, y_l, variant="lognormal_exp_bijector")
+                        q_l = avi.MeanFieldGaussian(np.zeros(61, np.float32), np.full(61, 0.6, np.float32))
+                        p_lh, _ = avi.destructure(q_l)
+                        c_l = avi.MiviContext(np.float32, 0, 61, 1, 0, SEED, device=local_rank)
+                        c_l.set_problem(pr_l)
+                        p_l2 = c_l.to_device(p_lh).clone()
+                        s_l2 = c_l.dog_state()
+                        c_l.dog_init(p_l2, s_l2, 1e-6)
+                        avg_l = p_l2.clone()
+                        kw_l = dict(rule=3, op=1, averager=1, clip_epsilon=1e-5, opt_state=s_l2, avg_params=avg_l)
+                        c_l.optimize_loop(p_l2, 300, 0, 0, **kw_l)
+                        stream.synchronize()
+                        t0s = time.perf_counter()
+                        for r in range(3):
+                            c_l.optimize_loop(p_l2, 300, (r + 1) * 300, (r + 1) * 300, **kw_l)
+                        stream.synchronize()
+                        t_l2 = (time.perf_counter() - t0s) / 900
+                        da["meanfield_readme_logreg_n208_p60_m1"] = dict(steps_per_s=1.0 / t_l2, us_per_step=t_l2 * 1e6)
+                        c_l.close()
+                    except Exception as e:   # noqa: BLE001
+                        da["meanfield_readme_logreg_n208_p60_m1"] = dict(error=str(e))
                     also["default_algorithm_loop"] = dict(workload="DoWG + PolynomialAveraging + ClipScale (the reference's default rule / averager / operator), diagonal-Gaussian target, mivi_optimize_loop, 3 x 500 steps",
                                                           value=da["meanfield_d1024_m256"]["steps_per_s"], unit="steps/s", grid=da,
                                                           note="launch-free: k_mf_gen_loop / k_fr_rows_loop (one exchange of two norm partials per step) / k_fr_small_loop; the hipGraph of launches: 8.9 / 30.4 / 11.5 us per step (DESIGN.md 3)")

@@ -852,6 +852,48 @@ def test_dog_loops_report_divergence_not_a_lost_exchange(family, d, M):
     ctx.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
+@pytest.mark.parametrize("case", [("fullrank", 208, 60, 1, "lognormal_exp_bijector"), ("meanfield", 208, 60, 1, "lognormal_exp_bijector"),
+                                  ("fullrank", 100, 20, 8, "logsigma_normal"), ("meanfield", 333, 7, 3, "logsigma_normal")],
+                         ids=["readme-sonar-fullrank-one-sample", "readme-sonar-meanfield-one-sample", "fullrank-m8", "ragged-meanfield"])
+@pytest.mark.parametrize("combo", [("dowg", "prox", "poly"), ("adam", "clip", "none"), ("descent", "clip", "poly"), ("dog", "clip", "none")])
+def test_logreg_small_loop(combo, case, dtype):
+    """Tiny hierarchical logistic regressions -- the reference README's own example (README.md:42-119: 208 rows, 60 features, theta = [beta; sigma]
+    behind the exp bijector, one sample per step) and neighbours with n (d - 1) n_mc <= 2^14 -- run the whole `optimize` loop in ONE
+    workgroup (k_lr_small_loop), for every rule x operator x averager.  Against the host-driven `step` loop (separate launches of the general
+    route), to rounding: parameters, averaged output, elbo record; a warm start continues."""
+    rule, op, avg = combo
+    fam, n, p, M, variant = case
+    d = p + 1
+    T = 12
+    rng = np.random.default_rng(21)
+    X = rng.normal(size=(n, p)).astype(dtype)
+    beta_true = rng.normal(size=p) * 0.5
+    y = (rng.uniform(size=n) < 1.0 / (1.0 + np.exp(-X.astype(np.float64) @ beta_true))).astype(np.float32)
+    prob = avi.LogRegProblem(X, y, variant=variant)
+    q0 = (avi.MeanFieldGaussian(np.zeros(d, dtype), np.full(d, 0.5, dtype)) if fam == "meanfield"
+          else avi.FullRankGaussian(np.zeros(d, dtype), (0.5 * np.eye(d)).astype(dtype)))
+    opt = {"descent": avi.Descent(1e-4), "adam": avi.Adam(1e-2), "dog": avi.DoG(1e-2), "dowg": avi.DoWG(1e-2)}[rule]
+    averager = avi.PolynomialAveraging() if avg == "poly" else avi.NoAveraging()
+    if op == "prox":
+        alg = avi.KLMinRepGradProxDescent(avi.AutoMIVI(), n_samples=M, optimizer=opt, averager=averager)
+    else:
+        alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), n_samples=M, optimizer=opt, averager=averager, operator=avi.ClipScale())
+    outs = []
+    import warnings
+    for dev in (True, False):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            q1, info1, st = avi.optimize(avi.PhiloxRNG(13), alg, T, prob, q0, device_loop=dev)
+            q2, info2, st2 = avi.optimize(avi.PhiloxRNG(13, T), alg, 5, prob, None, state=st, device_loop=dev)
+        outs.append((q2.location.copy(), np.asarray(q2.scale).copy(), st2["params"].cpu().numpy().copy(), np.array([i["elbo"] for i in info1 + info2])))
+    a, b = outs
+    tol = 2e-4 if dtype == np.float32 else 1e-9
+    for x, yv in zip(a[:3], b[:3]):
+        assert np.max(np.abs(x.astype(np.float64) - yv.astype(np.float64))) <= tol * max(1.0, np.max(np.abs(yv))), np.max(np.abs(x - yv))
+    assert np.allclose(a[3], b[3], rtol=2e-4 if dtype == np.float32 else 1e-9)
+
+
 def test_optimize_falls_back_to_the_host_loop_for_plugin_targets_and_callbacks():
     class Plug:
         def __init__(self, mu):
