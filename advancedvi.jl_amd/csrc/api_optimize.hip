@@ -130,7 +130,8 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);
   }
-  if (!simple && mf_gen_loop_ok(c, rule) && !no_fused_loop) {
+  const bool general = !simple || (rule == 1 && !default_adam);   // (Adam with other betas than the fused paths' defaults: the general loops take them from the call)
+  if (general && mf_gen_loop_ok(c, rule) && !no_fused_loop) {
     // every other rule x operator x averager of the reference's algorithms (DoG / DoWG, ProximalLocationScaleEntropy, PolynomialAveraging -- its
     // defaults), mean-field + diagonal-Gaussian target: launch-free as well (k_mf_gen_loop; DoG / DoWG: one grid-wide exchange of two norms per step)
     if ((s = ensure(c, c->gen_scratch, mf_gen_loop_scratch_bytes(c, n_steps), false))) return s;
@@ -140,7 +141,7 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);
   }
-  if (!simple && fr_small_loop_ok(c) && !no_fused_loop) {
+  if (general && fr_small_loop_ok(c) && !no_fused_loop) {
     // ... and small full-rank problems in one workgroup (k_fr_small_loop: the two norms of DoG / DoWG are block sums there)
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
     launch_fr_small_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, rec, vbuf, &l);
@@ -148,7 +149,7 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);
   }
-  if (!simple && fr_rows_loop_ok(c) && (rule < 2 || c->cfg.d <= 1024) && !no_fused_loop && fr_rows_eps_bytes(c, n_steps) <= ((size_t)1 << 31)) {
+  if (general && fr_rows_loop_ok(c) && (rule < 2 || c->cfg.d <= 1024) && !no_fused_loop && fr_rows_eps_bytes(c, n_steps) <= ((size_t)1 << 31)) {
     // ... and on the full-rank family with few samples per step (the reference's default n_samples = 1): the row-owning workgroups of
     // k_fr_rows_loop, DoG / DoWG with the same per-step exchange of two norm partials (every workgroup resident: d <= 1024)
     if ((s = ensure(c, c->rows_eps, fr_rows_eps_bytes(c, n_steps), false))) return s;
