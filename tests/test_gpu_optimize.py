@@ -894,6 +894,36 @@ def test_logreg_small_loop(combo, case, dtype):
     assert np.allclose(a[3], b[3], rtol=2e-4 if dtype == np.float32 else 1e-9)
 
 
+@pytest.mark.parametrize("family,d,M", [(avi.MEANFIELD, 64, 8), (avi.FULLRANK, 128, 4), (avi.FULLRANK, 10, 1)], ids=["meanfield", "fullrank-rows", "fullrank-small"])
+@pytest.mark.parametrize("rule", [0, 3], ids=["descent", "dowg"])
+def test_launch_free_loops_edge_calls(family, d, M, rule):
+    """Edge calls of the launch-free loops through mivi_optimize_loop: a single step, no ELBO record requested, IdentityOperator (no ClipScale),
+    a second call that continues the first -- the same parameters as one call of two steps (bitwise: the same kernel on the same stream of draws)."""
+    q0 = (avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32)) if family == avi.MEANFIELD
+          else avi.FullRankGaussian(np.zeros(d, np.float32), np.eye(d, dtype=np.float32)))
+    p0, _ = avi.destructure(q0)
+    ctx = avi.MiviContext(np.float32, family, d, M, 0, SEED)
+    ctx.set_problem(avi.DiagNormalProblem(np.full(d, 0.5, np.float32), np.ones(d, np.float32)))
+
+    def run(splits):
+        p = ctx.to_device(p0).clone()
+        st = None
+        if rule == 3:
+            st = ctx.dog_state()
+            ctx.dog_init(p, st, 1e-6)
+        done = 0
+        for n in splits:
+            ctx.optimize_loop(p, n, 7 + done, done, rule=rule, op=0, averager=0, eta=1e-3, opt_state=st, elbo=None)
+            done += n
+        ctx.synchronize()
+        return p.cpu().numpy()
+
+    a, b = run([1, 1]), run([2])
+    assert np.all(np.isfinite(a)) and np.array_equal(a, b)
+    assert not np.array_equal(a, p0)
+    ctx.close()
+
+
 def test_optimize_falls_back_to_the_host_loop_for_plugin_targets_and_callbacks():
     class Plug:
         def __init__(self, mu):
