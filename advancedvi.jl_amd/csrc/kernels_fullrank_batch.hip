@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_fb_tplanes(FbArgs a) {
 __global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
   __shared__ double red[8];
   __shared__ float E[32 * 65];   // E[m][i], leading dimension 65
-  const int tid = threadIdx.x, eb = blockIdx.x, l = blockIdx.y, d = a.d, nrb6 = d >> 6;
+  const int tid = threadIdx.x, eb = blockIdx.x, l = blockIdx.y, d = a.d;
   if (l >= a.L) {   // riders of a call's first draw: tril(C) as operand planes (parameters only), eight fragments per workgroup
     fb_cplanes_frag(a, (((int)blockIdx.y - a.L) * (int)gridDim.x + eb) * 8 + (tid >> 6), tid & 63);
     return;

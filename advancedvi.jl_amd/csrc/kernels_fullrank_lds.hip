@@ -136,7 +136,6 @@ __device__ __forceinline__ void fr_vjp32_body(const GemmArgs &a) {
   constexpr int MAIN = 13 * 1024;
   static_assert(MAIN >= KW * WAVE_F && MAIN >= EPI, "LDS budget");
   __shared__ __attribute__((aligned(16))) float lds[MAIN + 2 * KW + 4];
-  double *red = reinterpret_cast<double *>(lds + MAIN);
   float *adam_cc = lds + MAIN + 2 * KW;
   {
     const unsigned long long pA = (unsigned long long)a.A, pB = (unsigned long long)a.B, pW = (unsigned long long)a.work,
@@ -366,7 +365,6 @@ __global__ __launch_bounds__(512) void k_fr_vjp64(GemmArgs a) {
   constexpr int EPI = KW * BN * LDC + (NT / BM) * BM;
   constexpr int MAIN = EPI > KW * WAVE_F ? EPI : KW * WAVE_F;
   __shared__ __attribute__((aligned(16))) float lds[MAIN + 2 * KW + 4];
-  double *red = reinterpret_cast<double *>(lds + MAIN);
   float *adam_cc = lds + MAIN + 2 * KW;
   {
     const unsigned long long pA = (unsigned long long)a.A, pB = (unsigned long long)a.B, pW = (unsigned long long)a.work,
