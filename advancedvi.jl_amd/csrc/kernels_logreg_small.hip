@@ -73,6 +73,7 @@ __global__ __launch_bounds__(kLrSmallNT) void k_lr_small_loop(LrSmallLoopArgs<T>
   T *Rc = Wl + (size_t)M * d;                                  // resid[m RC + r] of the current row chunk
   T(*cc_tab)[2] = reinterpret_cast<T(*)[2]>(Rc + (size_t)M * RC);   // [256][2]
   T *Xs = reinterpret_cast<T *>(cc_tab + NT);                  // X resident: column k at Xs[k ldx ..], ldx odd
+  uint8_t *ys = reinterpret_cast<uint8_t *>(Xs + (XRES ? (size_t)p * a.ldx : 0));   // y resident (n bytes): no global load inside the loop
   const double direct = direct_entropy_coeff(a.ent_kind);
   const double invM = 1.0 / (double)a.M_total;
   const T eta = (T)a.eta, b1 = (T)a.b1, b2 = (T)a.b2, aeps = (T)a.adam_eps, ceps = (T)a.clip_eps;
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(kLrSmallNT) void k_lr_small_loop(LrSmallLoopArgs<T>
   if (RULE >= 2) { dog_v = a.dog_sc[0]; dog_r = a.dog_sc[1]; }
   if (fr)
     for (int i = tid; i < d * d; i += NT) Cs[i] = T(0);
+  for (long long i = tid; i < n; i += NT) ys[i] = a.y[i];
   if (XRES)
     for (long long i = tid; i < n * p; i += NT) {
       const long long k = i / n, r = i - k * n;
@@ -161,17 +163,39 @@ __global__ __launch_bounds__(kLrSmallNT) void k_lr_small_loop(LrSmallLoopArgs<T>
     for (long long r0 = 0; r0 < n; r0 += RC) {
       const long long r = r0 + tid;
       const bool rok = tid < RC && r < n;
-      const T yv = rok ? (T)a.y[r] : T(0);
+      const T yv = rok ? (T)ys[r] : T(0);
       for (int mb = 0; mb < M; mb += 8) {
         T acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = T(0);
         if (rok) {
-          for (int k = 0; k < p; ++k) {
-            const T x = XRES ? Xs[(size_t)k * a.ldx + r] : a.X[(size_t)k * n + r];
+          // (three bodies: a per-element test of mb + j < M inside the k loop is eight scalar branches per column -- 480 per row at p = 60)
+          const int jn = M - mb < 8 ? M - mb : 8;
+          if (jn == 8) {
+#pragma unroll 2
+            for (int k = 0; k < p; ++k) {
+              const T x = XRES ? Xs[(size_t)k * a.ldx + r] : a.X[(size_t)k * n + r];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (mb + j < M) acc[j] = fma(x, Zl[(mb + j) * d + k], acc[j]);
+              for (int j = 0; j < 8; ++j) acc[j] = fma(x, Zl[(mb + j) * d + k], acc[j]);
+            }
+          } else if (jn == 1) {
+            // one sample: four interleaved partial sums (columns k mod 4), so that four columns' LDS reads are in flight instead of one chain
+            T a4[4] = {T(0), T(0), T(0), T(0)};
+            int k = 0;
+            for (; k + 4 <= p; k += 4) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                a4[u] = fma(XRES ? Xs[(size_t)(k + u) * a.ldx + r] : a.X[(size_t)(k + u) * n + r], Zl[mb * d + k + u], a4[u]);
+            }
+            for (; k < p; ++k) a4[0] = fma(XRES ? Xs[(size_t)k * a.ldx + r] : a.X[(size_t)k * n + r], Zl[mb * d + k], a4[0]);
+            acc[0] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+          } else {
+            for (int k = 0; k < p; ++k) {
+              const T x = XRES ? Xs[(size_t)k * a.ldx + r] : a.X[(size_t)k * n + r];
+#pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (j < jn) acc[j] = fma(x, Zl[(mb + j) * d + k], acc[j]);
+            }
           }
         }
 #pragma unroll
@@ -198,15 +222,19 @@ __global__ __launch_bounds__(kLrSmallNT) void k_lr_small_loop(LrSmallLoopArgs<T>
         if (o < p * M) {
           const int m = o / p, k = o - m * p;
           const T *rr = Rc + m * RC;
+          T g1 = T(0);   // (two interleaved partial sums per thread: two rows' reads in flight)
           if (XRES) {
             const T *xc = Xs + (size_t)k * a.ldx + r0;
-#pragma unroll 4
-            for (int q = part; q < rcn; q += SPL) g = fma(xc[q], rr[q], g);
+            int q = part;
+            for (; q + SPL < rcn; q += 2 * SPL) { g = fma(xc[q], rr[q], g); g1 = fma(xc[q + SPL], rr[q + SPL], g1); }
+            if (q < rcn) g = fma(xc[q], rr[q], g);
           } else {
             const T *xc = a.X + (size_t)k * n + r0;
-#pragma unroll 4
-            for (int q = part; q < rcn; q += SPL) g = fma(xc[q], rr[q], g);
+            int q = part;
+            for (; q + SPL < rcn; q += 2 * SPL) { g = fma(xc[q], rr[q], g); g1 = fma(xc[q + SPL], rr[q + SPL], g1); }
+            if (q < rcn) g = fma(xc[q], rr[q], g);
           }
+          g += g1;
         }
         for (int w2 = SPL >> 1; w2 > 0; w2 >>= 1) g += __shfl_xor(g, w2, 64);
         gacc[0] += g;   // (every thread of the group holds the output's sum)
@@ -372,6 +400,7 @@ static size_t lr_small_lds(const mivi_ctx *c, bool resident, int *ldx_out) {
   size_t b = (16 + (size_t)kLrSmallM * 4 + 2 * kLrSmallM) * sizeof(double);
   b += ((fr ? (size_t)d * d : (size_t)d) + d + 3 * (size_t)M * d + (size_t)M * lr_small_rc(M) + 2 * kLrSmallNT) * es;
   if (resident) b += (size_t)p * ldx * es;
+  b += ((size_t)n + 15) & ~(size_t)15;   // y
   return b;
 }
 bool lr_small_loop_ok(const mivi_ctx *c) {
@@ -384,7 +413,7 @@ bool lr_small_loop_ok(const mivi_ctx *c) {
   const long long ne = d + (fr ? (long long)d * (d + 1) / 2 : d);
   if (ne > (long long)kLrSmallNE * kLrSmallNT || (long long)(d - 1) * M > (long long)kLrSmallGPT * kLrSmallNT) return false;
   // ONE workgroup (four waves, one per SIMD: every sum is a latency chain): its time grows with the n (d - 1) n_mc multiply-adds of a step.
-  // Measured (tools/logreg_loop_bench.py, us per step, this loop / the graph of launches): 208 x 60, one sample: 14.1 (full-rank 18.5) / 30-36;
+  // Measured (tools/logreg_loop_bench.py, us per step, this loop / the graph of launches): 208 x 60, one sample: 9.6 (full-rank 15.2) / 30-36;
   // 208 x 60 x 8: 51 / 36; 1000 x 32 x 1: 31 / 30; 1000 x 32 x 16 (BASELINE configs[0]): 151 / 31.  Taken only where it wins.
   return (long long)c->lr_n * (d - 1) * M <= (1ll << 14) && lr_small_lds(c, false, nullptr) <= 160 * 1024;
 }
