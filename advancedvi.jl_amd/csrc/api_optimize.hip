@@ -124,8 +124,9 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
   if (lr_small_loop_ok(c) && !no_fused_loop) {
     // small hierarchical logistic regressions (the reference README's own example, BASELINE configs[0]): the whole loop in ONE workgroup, every
     // rule x operator x averager (k_lr_small_loop)
+    if (lr_small_part_bytes(c, n_steps) && (s = ensure(c, c->gen_scratch, lr_small_part_bytes(c, n_steps) + 256, false))) return s;
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
-    launch_lr_small_loop(c, params, l, rec, vbuf);
+    launch_lr_small_loop(c, params, l, rec, vbuf, (double *)c->gen_scratch.p);
     HIPCHK(c, hipGetLastError());
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);

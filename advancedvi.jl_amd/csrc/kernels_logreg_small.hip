@@ -1,7 +1,8 @@
-// Launch-free optimisation loop for TINY hierarchical logistic regressions: the reference README's own example (README.md:42-119: the sonar
-// data set, n = 208 rows, 60 features, theta = [beta; sigma] behind the exp bijector, full-rank or mean-field q, KLMinRepGradProxDescent, one
-// sample per step -- the reference's default).  n (d - 1) n_mc <= 2^14: beyond that one workgroup loses to the launches (lr_small_loop_ok;
-// BASELINE configs[0], n = 1000, d = 32, 16 samples, stays on the graph of launches).
+// Launch-free optimisation loop for SMALL hierarchical logistic regressions with few samples per step: the reference README's own example
+// (README.md:42-119: the sonar data set, n = 208 rows, 60 features, theta = [beta; sigma] behind the exp bijector, full-rank or mean-field q,
+// KLMinRepGradProxDescent, one sample per step -- the reference's default) in ONE workgroup; larger data sets (n (d - 1) n_mc <= 2^20) on up to
+// 64 workgroups that split the rows of X and exchange their partial sums once per step.  (d - 1) n_mc <= 256: beyond that the graph of launches
+// wins (lr_small_loop_ok; BASELINE configs[0], n = 1000, d = 32, 16 samples, stays there).
 //
 // At these sizes a step of the general route is eight to ten launches (draws, z, logits, X^T r, finish, the reduction, two or three
 // optimiser launches, operator, averager) that are all launch latency: 30-36 us per step whatever the rule.  The whole problem fits ONE
@@ -47,6 +48,8 @@ struct LrSmallLoopArgs {
   T *avg;
   const T *x0;
   double *dog_sc;
+  double *part;                    // G > 1: [n_steps][G][pstride] partial sums, NaN until delivered
+  int pstride, spin;
 };
 
 template <typename T>
@@ -60,7 +63,12 @@ __global__ __launch_bounds__(kLrSmallNT) void k_lr_small_loop(LrSmallLoopArgs<T>
   const int d = a.d, p = d - 1, M = a.M, d4 = (d + 3) >> 2, RC = a.rc;
   const bool fr = a.family == MIVI_FULLRANK;
   const int nl = fr ? d * (d + 1) / 2 : d, ne = d + nl;
-  const long long n = a.n;
+  // workgroup wb of G works on rows [r_lo, r_hi) of X (G > 1: the partial log-likelihoods and X' r sums are exchanged once per step, below)
+  const long long nstr = a.n;
+  const int G = gridDim.x, wb = blockIdx.x;
+  const long long r_lo = nstr * wb / G, r_hi = nstr * (wb + 1) / G, n = r_hi - r_lo;
+  const T *Xg = a.X + r_lo;
+  const uint8_t *yg = a.y + r_lo;
   // LDS carve-up
   double *red = reinterpret_cast<double *>(lds_raw);          // [16] block sums, [16 ..) per-sample scalars
   double *llw = red + 16;                                      // [M][4] wave partials of the log-likelihood of a chunk
@@ -111,11 +119,11 @@ __global__ __launch_bounds__(kLrSmallNT) void k_lr_small_loop(LrSmallLoopArgs<T>
   if (RULE >= 2) { dog_v = a.dog_sc[0]; dog_r = a.dog_sc[1]; }
   if (fr)
     for (int i = tid; i < d * d; i += NT) Cs[i] = T(0);
-  for (long long i = tid; i < n; i += NT) ys[i] = a.y[i];
+  for (long long i = tid; i < n; i += NT) ys[i] = yg[i];
   if (XRES)
     for (long long i = tid; i < n * p; i += NT) {
       const long long k = i / n, r = i - k * n;
-      Xs[(size_t)k * a.ldx + r] = a.X[i];
+      Xs[(size_t)k * a.ldx + r] = Xg[(size_t)k * nstr + r];
     }
   __syncthreads();
 
@@ -174,7 +182,7 @@ __global__ __launch_bounds__(kLrSmallNT) void k_lr_small_loop(LrSmallLoopArgs<T>
           if (jn == 8) {
 #pragma unroll 2
             for (int k = 0; k < p; ++k) {
-              const T x = XRES ? Xs[(size_t)k * a.ldx + r] : a.X[(size_t)k * n + r];
+              const T x = XRES ? Xs[(size_t)k * a.ldx + r] : Xg[(size_t)k * nstr + r];
 #pragma unroll
               for (int j = 0; j < 8; ++j) acc[j] = fma(x, Zl[(mb + j) * d + k], acc[j]);
             }
@@ -185,13 +193,13 @@ __global__ __launch_bounds__(kLrSmallNT) void k_lr_small_loop(LrSmallLoopArgs<T>
             for (; k + 4 <= p; k += 4) {
 #pragma unroll
               for (int u = 0; u < 4; ++u)
-                a4[u] = fma(XRES ? Xs[(size_t)(k + u) * a.ldx + r] : a.X[(size_t)(k + u) * n + r], Zl[mb * d + k + u], a4[u]);
+                a4[u] = fma(XRES ? Xs[(size_t)(k + u) * a.ldx + r] : Xg[(size_t)(k + u) * nstr + r], Zl[mb * d + k + u], a4[u]);
             }
-            for (; k < p; ++k) a4[0] = fma(XRES ? Xs[(size_t)k * a.ldx + r] : a.X[(size_t)k * n + r], Zl[mb * d + k], a4[0]);
+            for (; k < p; ++k) a4[0] = fma(XRES ? Xs[(size_t)k * a.ldx + r] : Xg[(size_t)k * nstr + r], Zl[mb * d + k], a4[0]);
             acc[0] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
           } else {
             for (int k = 0; k < p; ++k) {
-              const T x = XRES ? Xs[(size_t)k * a.ldx + r] : a.X[(size_t)k * n + r];
+              const T x = XRES ? Xs[(size_t)k * a.ldx + r] : Xg[(size_t)k * nstr + r];
 #pragma unroll
               for (int j = 0; j < 8; ++j)
                 if (j < jn) acc[j] = fma(x, Zl[(mb + j) * d + k], acc[j]);
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(kLrSmallNT) void k_lr_small_loop(LrSmallLoopArgs<T>
             for (; q + SPL < rcn; q += 2 * SPL) { g = fma(xc[q], rr[q], g); g1 = fma(xc[q + SPL], rr[q + SPL], g1); }
             if (q < rcn) g = fma(xc[q], rr[q], g);
           } else {
-            const T *xc = a.X + (size_t)k * n + r0;
+            const T *xc = Xg + (size_t)k * nstr + r0;
             int q = part;
             for (; q + SPL < rcn; q += 2 * SPL) { g = fma(xc[q], rr[q], g); g1 = fma(xc[q + SPL], rr[q + SPL], g1); }
             if (q < rcn) g = fma(xc[q], rr[q], g);
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(kLrSmallNT) void k_lr_small_loop(LrSmallLoopArgs<T>
 #pragma unroll 8
             for (int q = 0; q < rcn; ++q) g = fma(xc[q], rr[q], g);
           } else {
-            const T *xc = a.X + (size_t)k * n + r0;
+            const T *xc = Xg + (size_t)k * nstr + r0;
 #pragma unroll 8
             for (int q = 0; q < rcn; ++q) g = fma(xc[q], rr[q], g);
           }
@@ -259,6 +267,56 @@ __global__ __launch_bounds__(kLrSmallNT) void k_lr_small_loop(LrSmallLoopArgs<T>
         }
       }
       __syncthreads();
+    }
+    if (G > 1) {
+      // every workgroup's partial sums -> slots of this step's own, NaN until stored (the data are their own flags; a NaN sum travels as +Inf);
+      // then every workgroup adds all of them in workgroup order: the same bits everywhere, so the replicated parameters stay identical
+      double *mine = a.part + ((size_t)t * G + wb) * a.pstride;
+      const bool writer = SPL > 1 ? (tid % SPL == 0 && tid / SPL < p * M) : true;
+#pragma unroll
+      for (int u = 0; u < GPT; ++u) {
+        const int o = SPL > 1 ? tid / SPL : tid + u * NT;
+        if ((SPL > 1 && u > 0) || o >= p * M || !writer) break;
+        const double v = (double)gacc[u];
+        __hip_atomic_store(mine + o, v == v ? v : (double)INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (tid < M) __hip_atomic_store(mine + p * M + tid, ll_own == ll_own ? ll_own : (double)INFINITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool ok = true;
+      auto gather = [&](int o) {   // eight workgroups' slots in flight at a time (one load after the other is a memory round trip each)
+        double sum = 0.0;
+        for (int w0 = 0; w0 < G; w0 += 8) {
+          double q[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            q[j] = w0 + j < G ? __hip_atomic_load(a.part + ((size_t)t * G + w0 + j) * a.pstride + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (w0 + j < G && !(q[j] == q[j])) {
+              const double *pp = a.part + ((size_t)t * G + w0 + j) * a.pstride + o;
+              int budget = a.spin;
+              while (true) {
+                q[j] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (q[j] == q[j]) break;
+                if (--budget <= 0) { ok = false; q[j] = 0.0; break; }
+                __builtin_amdgcn_s_sleep(1);
+              }
+            }
+            sum += q[j];
+          }
+        }
+        return sum;
+      };
+#pragma unroll
+      for (int u = 0; u < GPT; ++u) {
+        const int o = SPL > 1 ? tid / SPL : tid + u * NT;
+        if ((SPL > 1 && u > 0) || o >= p * M) break;
+        gacc[u] = (T)gather(o);
+      }
+      if (tid < M) ll_own = gather(p * M + tid);
+      if (__syncthreads_or(ok ? 0 : 1)) {
+        if (tid == 0) atomicOr(a.status, 8);
+        break;
+      }
     }
     // ---- priors, the sigma entry, ell per sample (k_lr_finish's arithmetic) -----------------------------------------------------------------
     if (tid < M) {
@@ -312,7 +370,7 @@ __global__ __launch_bounds__(kLrSmallNT) void k_lr_small_loop(LrSmallLoopArgs<T>
       block_sum_n<double, NT, 4>(v4, red);   // (its barriers also publish W)
       s_ell = v4[0]; s_he = v4[1]; s_ld = v4[2]; s_bad = v4[3];
     }
-    if (tid == 0) {
+    if (tid == 0 && wb == 0) {
       const double Mt = (double)a.M_total;
       const double ent = (ent_is_closed(a.ent_kind) ? 0.5 * d * (1.0 + kLog2Pi) : s_he / Mt + 0.5 * d * kLog2Pi) + s_ld;
       const double value = -(s_ell / Mt + ent);
@@ -380,46 +438,64 @@ __global__ __launch_bounds__(kLrSmallNT) void k_lr_small_loop(LrSmallLoopArgs<T>
   }
 #pragma unroll
   for (int u = 0; u < NE; ++u) {
-    if (!eok[u]) continue;
+    if (!eok[u] || wb != 0) continue;
     a.params[ep[u]] = px[u];
     if (RULE == 1) { a.opt_state[ep[u]] = pm[u]; a.opt_state[plen + ep[u]] = pv[u]; }
     if (averaging) a.avg[ep[u]] = pa[u];
   }
-  if (RULE >= 2 && tid == 0) { a.dog_sc[0] = dog_v; a.dog_sc[1] = dog_r; }
+  if (RULE >= 2 && tid == 0 && wb == 0) { a.dog_sc[0] = dog_v; a.dog_sc[1] = dog_r; }
 }
 
 // rows of X per chunk: the residuals of a chunk (n_mc x RC) stay small
 static int lr_small_rc(int M) { return M <= 16 ? 256 : (M <= 32 ? 128 : 64); }
-static size_t lr_small_lds(const mivi_ctx *c, bool resident, int *ldx_out) {
+// workgroups: about 2^14 multiply-adds of the target per workgroup and step, at least 16 rows each, at most 64 (they exchange their partial sums
+// every step: all of them resident)
+static int lr_small_groups(const mivi_ctx *c) {
+  const long long work = (long long)c->lr_n * (c->cfg.d - 1) * c->cfg.n_mc;
+  long long g = (work + (1 << 14) - 1) >> 14;
+  if (g > 64) g = 64;
+  if (g > c->lr_n / 16) g = c->lr_n / 16;
+  return g < 1 ? 1 : (int)g;
+}
+static size_t lr_small_lds(const mivi_ctx *c, int G, bool resident, int *ldx_out) {
   const int d = c->cfg.d, M = c->cfg.n_mc, p = d - 1;
   const size_t es = c->esize;
   const bool fr = c->cfg.family == MIVI_FULLRANK;
-  const long long n = c->lr_n;
-  const int ldx = (int)(n | 1);   // odd: the columns of X start on different banks
+  const long long nloc = (c->lr_n + G - 1) / G + 1;   // rows of the largest workgroup
+  const int ldx = (int)(nloc | 1);                    // odd: the columns of X start on different banks
   if (ldx_out) *ldx_out = ldx;
   size_t b = (16 + (size_t)kLrSmallM * 4 + 2 * kLrSmallM) * sizeof(double);
   b += ((fr ? (size_t)d * d : (size_t)d) + d + 3 * (size_t)M * d + (size_t)M * lr_small_rc(M) + 2 * kLrSmallNT) * es;
   if (resident) b += (size_t)p * ldx * es;
-  b += ((size_t)n + 15) & ~(size_t)15;   // y
+  b += ((size_t)nloc + 15) & ~(size_t)15;   // y
   return b;
+}
+size_t lr_small_part_bytes(const mivi_ctx *c, int n_steps) {
+  const int G = lr_small_groups(c);
+  if (G <= 1) return 0;
+  const size_t ps = (((size_t)(c->cfg.d - 1) * c->cfg.n_mc + c->cfg.n_mc) + 15) & ~(size_t)15;
+  return (size_t)n_steps * G * ps * sizeof(double);
 }
 bool lr_small_loop_ok(const mivi_ctx *c) {
   const int d = c->cfg.d, M = c->cfg.n_mc;
   const bool stl = c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD;
   if (!(c->target == TGT_LOGREG && !c->bij_on && !stl && d >= 2 && d <= kLrSmallD && M >= 1 && M <= kLrSmallM && c->cfg.m_offset == 0 && c->M_total == M &&
-        c->lr_X && c->lr_y && c->lr_n >= 1))
+        c->lr_X && c->lr_y && c->lr_n >= 1 && c->lr_route == 0))   // (mivi_set_logreg_route pins the general route's kernels: the graph of launches)
     return false;
   const bool fr = c->cfg.family == MIVI_FULLRANK;
   const long long ne = d + (fr ? (long long)d * (d + 1) / 2 : d);
   if (ne > (long long)kLrSmallNE * kLrSmallNT || (long long)(d - 1) * M > (long long)kLrSmallGPT * kLrSmallNT) return false;
-  // ONE workgroup (four waves, one per SIMD: every sum is a latency chain): its time grows with the n (d - 1) n_mc multiply-adds of a step.
-  // Measured (tools/logreg_loop_bench.py, us per step, this loop / the graph of launches): 208 x 60, one sample: 9.6 (full-rank 15.2) / 30-36;
-  // 208 x 60 x 8: 51 / 36; 1000 x 32 x 1: 31 / 30; 1000 x 32 x 16 (BASELINE configs[0]): 151 / 31.  Taken only where it wins.
-  return (long long)c->lr_n * (d - 1) * M <= (1ll << 14) && lr_small_lds(c, false, nullptr) <= 160 * 1024;
+  // One workgroup per ~2^14 multiply-adds of the target (its time grows with them: four waves, every sum a latency chain), up to 64 workgroups
+  // that split the rows of X and exchange their partial sums once per step.  Measured (tools/logreg_loop_bench.py, n x (d - 1) x n_mc, us per
+  // step, this loop / the graph of launches): 208 x 60 x 1 (one workgroup): 9.4 (full-rank 14.3) / 30-36; 1000 x 32 x 1 (two): 12.5 / 30;
+  // 4000 x 16 x 4 (sixteen): 17.5 / 33; 208 x 60 x 8 (seven): 28.9 / 36; 1000 x 32 x 16 (32; BASELINE configs[0]): 35.4 / 31 -- a step's fixed
+  // work and the exchanged partials grow with (d - 1) n_mc.  Taken where it wins: (d - 1) n_mc <= 256.
+  return (long long)(d - 1) * M <= 256 && (long long)c->lr_n * (d - 1) * M <= (1ll << 20) &&
+         lr_small_lds(c, lr_small_groups(c), false, nullptr) <= 160 * 1024;
 }
 
 template <typename T>
-static void lr_small_loop_impl(mivi_ctx *c, void *params, const mivi_loop_t &l, double *elbo, void *value) {
+static void lr_small_loop_impl(mivi_ctx *c, void *params, const mivi_loop_t &l, double *elbo, void *value, double *part) {
   LrSmallLoopArgs<T> a;
   a.family = c->cfg.family; a.d = c->cfg.d; a.M = c->cfg.n_mc; a.n_steps = l.n_steps; a.rule = l.rule; a.ent_kind = c->cfg.entropy;
   a.m_offset = c->cfg.m_offset; a.M_total = c->M_total; a.variant = c->lr_variant; a.n = c->lr_n;
@@ -432,14 +508,19 @@ static void lr_small_loop_impl(mivi_ctx *c, void *params, const mivi_loop_t &l, 
   a.x0 = l.rule >= 2 ? (const T *)l.opt_state_dev : nullptr;
   a.dog_sc = l.rule >= 2 ? (double *)((char *)l.opt_state_dev + mivi_dog_state_bytes(c) - 16) : nullptr;
   a.rc = lr_small_rc(a.M);
+  const int G = lr_small_groups(c);
+  a.part = part;
+  a.pstride = (int)((((size_t)(a.d - 1) * a.M + a.M) + 15) & ~(size_t)15);
+  a.spin = 1 << 20;
+  if (G > 1) (void)hipMemsetAsync(part, 0xFF, lr_small_part_bytes(c, l.n_steps), c->stream);   // (NaN: not delivered yet)
   int ldx = 0;
-  const size_t with_x = lr_small_lds(c, true, &ldx);
+  const size_t with_x = lr_small_lds(c, G, true, &ldx);
   a.x_resident = with_x <= 160 * 1024 ? 1 : 0;
   a.ldx = ldx;
-  const size_t lds = a.x_resident ? with_x : lr_small_lds(c, false, nullptr);
+  const size_t lds = a.x_resident ? with_x : lr_small_lds(c, G, false, nullptr);
   auto go = [&](auto kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(1), dim3(kLrSmallNT), lds, c->stream, a);
+    hipLaunchKernelGGL(kern, dim3(G), dim3(kLrSmallNT), lds, c->stream, a);
   };
   if (a.x_resident) {
     switch (l.rule) {
@@ -458,9 +539,9 @@ static void lr_small_loop_impl(mivi_ctx *c, void *params, const mivi_loop_t &l, 
   }
 }
 // elbo: n_steps doubles; value: one element of T (the last step's objective value)
-void launch_lr_small_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *elbo, void *value) {
-  if (c->cfg.dtype == MIVI_F32) lr_small_loop_impl<float>(c, params, l, elbo, value);
-  else lr_small_loop_impl<double>(c, params, l, elbo, value);
+void launch_lr_small_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *elbo, void *value, double *part) {
+  if (c->cfg.dtype == MIVI_F32) lr_small_loop_impl<float>(c, params, l, elbo, value, part);
+  else lr_small_loop_impl<double>(c, params, l, elbo, value, part);
 }
 
 }  // namespace mivi

@@ -394,8 +394,9 @@ size_t fr_rows_eps_bytes(const mivi_ctx *c, int n_steps);
 size_t fr_rows_part_bytes(const mivi_ctx *c, int n_steps);
 void launch_fr_rows_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta, double clip_eps,
                          float *eps_all, double *hist, double *elbo, void *value, const mivi_loop_t *gen = nullptr, double *part = nullptr);
-bool lr_small_loop_ok(const mivi_ctx *c);   // kernels_logreg_small.hip: the logistic-regression target, d <= 64, n (d - 1) n_mc <= 2^14: one workgroup
-void launch_lr_small_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *elbo, void *value);
+bool lr_small_loop_ok(const mivi_ctx *c);   // kernels_logreg_small.hip: the logistic-regression target, d <= 64, (d - 1) n_mc <= 256, n (d - 1) n_mc <= 2^20: one workgroup per 2^14 of them
+size_t lr_small_part_bytes(const mivi_ctx *c, int n_steps);   // 0: one workgroup, no exchange
+void launch_lr_small_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *elbo, void *value, double *part);
 bool mf_gen_loop_ok(const mivi_ctx *c, int rule);   // kernels_meanfield.hip: every rule x operator x averager, mean-field + diagonal-Gaussian target
 size_t mf_gen_loop_scratch_bytes(const mivi_ctx *c, int n_steps);
 void launch_mf_gen_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *hist, double *elbo, char *scratch);

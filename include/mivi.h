@@ -262,7 +262,8 @@ mivi_status_t mivi_prox_scale_entropy(mivi_ctx_t *ctx, void *params_dev, double 
  *   full-rank f32, n_mc <= 32, diagonal-Gaussian target,      row-separable launch-free kernel (workgroups own row pairs), to rounding
  *     closed-form / Monte-Carlo entropy, d <= 1126
  *   mean-field, fused funnel target                           one kernel with a per-step grid-wide exchange, bitwise the single calls
- *   logistic-regression target, n (d - 1) n_mc <= 2^14, d <= 64 one workgroup for the whole loop (the reference README's own example), to rounding
+ *   logistic-regression target, (d - 1) n_mc <= 256, d <= 64,  one kernel for the whole loop (the reference README's own example: one workgroup;
+ *     n (d - 1) n_mc <= 2^20                                  larger data sets: up to 64 that split the rows and exchange partial sums), to rounding
  *   otherwise                                                 one hipGraph of chained estimates (full-rank f32: update + ClipScale in the VJP epilogue)
  * MIVI_NO_FUSED_LOOP=1 forces the hipGraph everywhere (A/B). */
 mivi_status_t mivi_optimize_steps(mivi_ctx_t *ctx, void *params_dev, void *opt_state_dev, uint64_t estimate_idx0,

@@ -854,13 +854,15 @@ def test_dog_loops_report_divergence_not_a_lost_exchange(family, d, M):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
 @pytest.mark.parametrize("case", [("fullrank", 208, 60, 1, "lognormal_exp_bijector"), ("meanfield", 208, 60, 1, "lognormal_exp_bijector"),
-                                  ("fullrank", 100, 20, 8, "logsigma_normal"), ("meanfield", 333, 7, 3, "logsigma_normal")],
-                         ids=["readme-sonar-fullrank-one-sample", "readme-sonar-meanfield-one-sample", "fullrank-m8", "ragged-meanfield"])
+                                  ("fullrank", 100, 20, 8, "logsigma_normal"), ("meanfield", 333, 7, 3, "logsigma_normal"),
+                                  ("meanfield", 3001, 16, 2, "lognormal_exp_bijector"), ("fullrank", 1500, 12, 4, "logsigma_normal")],
+                         ids=["readme-sonar-fullrank-one-sample", "readme-sonar-meanfield-one-sample", "fullrank-m8", "ragged-meanfield",
+                              "six-workgroups-meanfield", "five-workgroups-fullrank"])
 @pytest.mark.parametrize("combo", [("dowg", "prox", "poly"), ("adam", "clip", "none"), ("descent", "clip", "poly"), ("dog", "clip", "none")])
 def test_logreg_small_loop(combo, case, dtype):
     """Tiny hierarchical logistic regressions -- the reference README's own example (README.md:42-119: 208 rows, 60 features, theta = [beta; sigma]
-    behind the exp bijector, one sample per step) and neighbours with n (d - 1) n_mc <= 2^14 -- run the whole `optimize` loop in ONE
-    workgroup (k_lr_small_loop), for every rule x operator x averager.  Against the host-driven `step` loop (separate launches of the general
+    behind the exp bijector, one sample per step) and neighbours -- run the whole `optimize` loop inside ONE kernel (k_lr_small_loop: one
+    workgroup, or several that split the rows of X and exchange their partial sums every step), for every rule x operator x averager.  Against the host-driven `step` loop (separate launches of the general
     route), to rounding: parameters, averaged output, elbo record; a warm start continues."""
     rule, op, avg = combo
     fam, n, p, M, variant = case
