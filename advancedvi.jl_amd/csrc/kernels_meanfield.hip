@@ -509,7 +509,7 @@ static void mf_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint64_
 //   * DoG / DoWG (src/optimization/rules.jl:17-64) need ||x - x0||^2 and ||g||^2 over ALL parameters before the step: every workgroup leaves
 //     its two partials at addresses of this step's own (NaN until then: the data are their own flags); every workgroup then waits for all of
 //     them and adds them in index order (the same order everywhere: (v, r) and the step size are the same bits in every workgroup).  One grid-wide
-//     exchange per step -- the workgroups must be resident together (d <= 2048); every spin is bounded (status bit 8);
+//     exchange per step -- the workgroups must be resident together (d <= 4096 in f32, 2048 in f64); every spin is bounded (status bit 8);
 //   * ProximalLocationScaleEntropy (proximal_location_scale_entropy.jl:44-61) and ClipScale on the sigma rows, PolynomialAveraging
 //     (averaging.jl:40-47) with the running average in registers: the per-element arithmetic of kernels_update.hip (optim_rules.h).
 // The two norms are summed in another order than k_dog_norms / k_dog_update sum them: a DoG / DoWG trajectory equals the launch-per-step
@@ -744,7 +744,8 @@ __global__ __launch_bounds__(256) void k_mf_gen_loop(MfGenLoopArgs<T> a) {
 
 bool mf_gen_loop_ok(const mivi_ctx *c, int rule) {
   if (!(c->cfg.family == MIVI_MEANFIELD && c->target == TGT_DIAG_GAUSS && !c->bij_on && c->cfg.n_mc <= 4096)) return false;
-  return rule <= 1 || c->cfg.d <= 2048;   // DoG / DoWG: a grid-wide exchange per step -- every workgroup resident
+  // DoG / DoWG: a grid-wide exchange per step -- every workgroup resident (f32: six one-wave-per-SIMD workgroups fit a CU, f64: three)
+  return rule <= 1 || c->cfg.d <= (c->cfg.dtype == MIVI_F32 ? 4096 : 2048);
 }
 size_t mf_gen_loop_scratch_bytes(const mivi_ctx *c, int n_steps) {   // partial norms of every step
   const size_t nblk = (size_t)(c->cfg.d + 3) / 4;

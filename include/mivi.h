@@ -280,7 +280,7 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *ctx, void *params_dev, void *opt_s
  * avg_params: T[params_len] running average, in/out (any content when t0 = 0: w_1 = 1).  t0 = iterations already done
  * (warm start, src/optimize.jl:58-62).  Descent/Adam with Identity/ClipScale and no averaging take the fused paths of
  * mivi_optimize_steps; the other combinations are launch-free as well where mivi_optimize_steps is (mean-field + diagonal-Gaussian
- * target, d <= 2048 for DoG / DoWG; full-rank with n_mc <= 32 or d <= 32 and that target), with DoG / DoWG exchanging two norm
+ * target, d <= 4096 (f64: 2048) for DoG / DoWG; full-rank with n_mc <= 32 or d <= 32 and that target), with DoG / DoWG exchanging two norm
  * partials per workgroup and step.  Results are bitwise those of the step-by-step entries on the hipGraph route and for
  * Descent / Adam on the mean-field loop; DoG / DoWG in the launch-free loops to the rounding of the two f64 norm sums, the
  * full-rank launch-free loops to f32 rounding. */

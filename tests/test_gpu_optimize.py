@@ -716,7 +716,7 @@ def test_optimize_device_loop_equals_host_loop(family, combo):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
-@pytest.mark.parametrize("shape", [(1024, 8), (2048, 256), (70, 19)], ids=["d1024-m8", "d2048-m256", "ragged"])
+@pytest.mark.parametrize("shape", [(1024, 8), (2048, 256), (70, 19), (4096, 4)], ids=["d1024-m8", "d2048-m256", "ragged", "d4096-m4"])
 @pytest.mark.parametrize("combo", [
     ("dowg", "clip", "poly"), ("dowg", "prox", "poly"), ("dog", "clip", "none"), ("descent", "prox", "poly"), ("adam", "clip", "poly")])
 def test_meanfield_general_loop(combo, shape, dtype):
