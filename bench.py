@@ -32,6 +32,7 @@ SEED = 0x38BEF07CF9CC549D
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
 PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA peak (155 TF measured)
 PEAK_BF16_MFMA_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
+PLANE_BYTES = 6                 # bytes per operand-plane element of the batch engine (three bf16 planes)
 PEAK_VALU_GINST = 1024 * 2.4 / 4   # wave64 vector instructions per ns: 256 CUs x 4 SIMDs, one per 4 cycles, 2.4 GHz (MI355X_MICROARCH.md)
 
 # environment variables that do NOT change which kernels run: bench-harness controls and the RCCL library location
@@ -65,19 +66,25 @@ for _k, _v in WORKLOADS.items():
     _v["key"] = _k
 
 
-def pmc_traffic(kernel_substr):
+def pmc_traffic(kernel_substr, lanes=None):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
     (profiles/pmc_traffic.json, produced by tools/pmc_traffic.py: separate passes, counters in KiB, the gfx950 FETCH_SIZE
     correction of MI355X_MICROARCH.md already applied there per kernel according to the width of its loads -- the file records
-    the factor it used and the calibration run it came from)."""
+    the factor it used and the calibration run it came from).  Batch-engine kernels are kept per lane count there (`by_lanes`, the lanes
+    derived from every dispatch's grid): `lanes` picks that entry, or the nearest one (the caller scales per lane and says so)."""
     try:
         tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except (OSError, ValueError):
         return None
     for k, v in tab.get("kernels", {}).items():
         if kernel_substr in k:
+            if lanes and v.get("by_lanes"):
+                key = min(v["by_lanes"], key=lambda x: abs(int(x) - lanes))
+                v = v["by_lanes"][key]
+            elif v.get("by_lanes") or "k_fb_" in k:   # (no lane count asked for / a round-4 file whose lane count was assumed, not derived)
+                return None
             out = dict(bytes_per_launch=(v["fetch_kib"] + v["write_kib"]) * 1024.0, fetch_bytes=v["fetch_kib"] * 1024.0,
-                       write_bytes=v["write_kib"] * 1024.0, source=tab.get("source"))
+                       write_bytes=v["write_kib"] * 1024.0, source=tab.get("source"), profile="profiles/pmc_traffic.json")
             if "lanes_per_launch" in v:   # the batch engine: the profiled launches carried this many estimates
                 out["lanes_per_launch"] = v["lanes_per_launch"]
             return out
@@ -99,19 +106,29 @@ def pmc_valu(kernel_substr):
     return None
 
 
-def rocprof_avg(kernel_substr, workload="ns"):
+def rocprof_avg(kernel_substr, workload="ns", lanes=None):
     """Average duration (us) of a kernel in the newest committed `rocprofv3 --kernel-trace --stats` summary of this workload's bench command
-    (profiles/<tag>_<workload>_kernel_stats.md, written by tools/profile_round.sh): the in-chain figure -- launches of the timed region, other
-    branches' kernels running beside them -- next to the stand-alone one this process measures."""
+    (profiles/<tag>_<workload>_kernel_stats.md, written by tools/profile_round.sh): the in-chain figure next to the stand-alone one this
+    process measures.  With `lanes`: the row of the summary's per-grid table whose launches carried exactly that many estimates (the lane
+    count is derived from the grid there), preferring the summary taken at the driver's own --steps 20 (`<tag>_<workload>20_...`)."""
     import glob
-    import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_kernel_stats.md" % workload)))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_kernel_stats.md" % workload)) +
+                   glob.glob(os.path.join(ROOT, "profiles", "r*_%s20_kernel_stats.md" % workload)),
+                   key=lambda f: os.path.basename(f).split("_")[:2])
     for f in reversed(files):
         try:
+            hit = None
             for line in open(f):
-                if kernel_substr in line and line.startswith("|"):
-                    c = [x.strip() for x in line.strip().strip("|").split("|")]
-                    return dict(avg_us=float(c[3]) / 1e3, calls=int(c[1]), source=os.path.relpath(f, ROOT))
+                if kernel_substr not in line or not line.startswith("|"):
+                    continue
+                c = [x.strip() for x in line.strip().strip("|").split("|")]
+                if len(c) == 7 and "x" in c[1] and not c[1].isdigit():        # per-grid table: kernel | workgroups | lanes | calls | avg_ns | min | max
+                    if lanes and c[2].isdigit() and int(c[2]) == lanes:
+                        return dict(avg_us=float(c[4]) / 1e3, calls=int(c[3]), lanes=lanes, source=os.path.relpath(f, ROOT))
+                elif hit is None and len(c) >= 4 and c[1].isdigit():
+                    hit = dict(avg_us=float(c[3]) / 1e3, calls=int(c[1]), lanes=None, source=os.path.relpath(f, ROOT))
+            if hit and not lanes:
+                return hit
         except (OSError, ValueError, IndexError):
             continue
     return None
@@ -238,38 +255,46 @@ def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):
             aL = lanes * kfl[dk] / (tb[dk] * 1e-6) / 1e12
 
             def traffic_of(k):
-                t = pmc_traffic(sub[k])
-                if t and t.get("lanes_per_launch") and t["lanes_per_launch"] != lanes:   # profiled with another batch length: per-lane bytes scaled
+                # HBM-side bytes of one launch at THIS lane count: tools/pmc_traffic.py keeps the batch-engine kernels per grid size (lanes
+                # derived from the dispatch's grid, not assumed); another lane count's entry is scaled per lane and says so
+                t = pmc_traffic(sub[k], lanes)
+                if t and t.get("lanes_per_launch") and t["lanes_per_launch"] != lanes:
                     f = lanes / float(t["lanes_per_launch"])
                     t = dict(t, bytes_per_launch=t["bytes_per_launch"] * f, fetch_bytes=t["fetch_bytes"] * f, write_bytes=t["write_bytes"] * f,
                              scaled_from_lanes=t["lanes_per_launch"], lanes_per_launch=lanes)
+                if t:
+                    d_, M_ = w["d"], w["n_mc"]
+                    alg = {"product": d_ * (d_ + 1) // 2 * 4 + lanes * 2 * d_ * M_ * 4, "vjp": lanes * (2 * d_ * M_ * 4 + d_ * d_ * 4),
+                           "dense_product": d_ * d_ * 4 + lanes * 2 * d_ * M_ * 4, "stl_product": d_ * (d_ + 1) // 2 * 4 + lanes * 3 * d_ * M_ * 4}[k]
+                    t["algorithmic_bytes_per_launch"] = alg
+                    t["over_algorithmic"] = t["bytes_per_launch"] / alg
                 return t
             keep = {k: roof[k] for k in ("kernel", "achieved", "frac", "traffic", "algorithmic_flops_per_launch", "avg_launch_us", "other_contraction")}
             if "single_launch" in roof:
                 keep = roof["single_launch"]
-            others = [dict(kernel=nm[k], avg_launch_us=tb[k], achieved=lanes * kfl[k] / (tb[k] * 1e-6) / 1e12, rocprof_in_chain=rocprof_avg(sub[k], w.get("key", "ns")))
+            # ONE basis for every kernel of the block: `achieved` = SURVEY 8d's algorithmic (f32-accurate) flops of the launch / its duration,
+            # `peak` = the dense f32-MFMA peak the north star is priced on -- a fraction that a split-operand product may push past 1 --
+            # and ALWAYS beside it `pipe16`: the flops the 16-bit matrix pipe actually executes (kSplitProducts per product block) over its
+            # dense peak, a fraction <= 1 by construction.
+            nprod = ctx.split_products() if hasattr(ctx, "split_products") else 6
+            def tf(k):
+                return lanes * kfl[k] / (tb[k] * 1e-6) / 1e12
+            others = [dict(kernel=nm[k], avg_launch_us=tb[k], achieved=tf(k), frac=tf(k) / PEAK_F32_MFMA_TF, frac_16bit_pipe=nprod * tf(k) / PEAK_BF16_MFMA_TF,
+                           rocprof_in_chain=rocprof_avg(sub[k], w.get("key", "ns"), lanes))
                       for k in live if k != dk]
             roof.update(kernel=nm[dk], achieved=aL, frac=aL / PEAK_F32_MFMA_TF, algorithmic_flops_per_launch=lanes * kfl[dk], estimates_per_launch=lanes,
-                        avg_launch_us=tb[dk], traffic=traffic_of(dk), rocprof_in_chain=rocprof_avg(sub[dk], w.get("key", "ns")),
+                        avg_launch_us=tb[dk], traffic=traffic_of(dk), rocprof_in_chain=rocprof_avg(sub[dk], w.get("key", "ns"), lanes),
                         other_contraction=others[0] if len(others) == 1 else others,
                         draws=dict(kernel="k_fb_eps (Philox + Box-Muller draws of all lanes as operand planes in both orientations)", avg_launch_us=tb["eps"],
-                                   algorithmic_bytes_per_launch=lanes * 12 * w["d"] * w["n_mc"],
-                                   achieved_GBs=lanes * 12 * w["d"] * w["n_mc"] / (tb["eps"] * 1e-6) / 1e9,
-                                   note="6 bytes per element and orientation written once: bound by the memory side and the vector ALU"),
+                                   algorithmic_bytes_per_launch=lanes * 2 * PLANE_BYTES * w["d"] * w["n_mc"],
+                                   achieved_GBs=lanes * 2 * PLANE_BYTES * w["d"] * w["n_mc"] / (tb["eps"] * 1e-6) / 1e9,
+                                   note="%d bytes per element and orientation written once: bound by the memory side and the vector ALU" % PLANE_BYTES),
                         timing="%d back-to-back launches of each kernel for %d lanes, hipEvents on the launch stream" % (max(5, reps // 10), lanes),
+                        basis="achieved = algorithmic f32-accurate flops (SURVEY 8d: d^2 n_mc per contraction and estimate) x lanes / launch time; peak = f32-MFMA 157.3 TF; frac_16bit_pipe = x%d executed flops / 2500 TF" % nprod,
+                        pipe16=dict(products_per_block=nprod, executed_TFLOPs=nprod * aL, peak=PEAK_BF16_MFMA_TF, frac=nprod * aL / PEAK_BF16_MFMA_TF),
                         single_launch=keep)
-            # the pipe these products execute on: six bf16 MFMAs per f32-equivalent product block.  `frac` (f32-equivalent flops over the
-            # f32-MFMA peak, the yardstick of the north star) can exceed 1 on a kernel without triangular waste -- that is the point of the
-            # three-way split -- so the executed bf16 rate over the bf16 peak is quoted with it and bounds it
-            roof["bf16_pipe"] = dict(executed_TFLOPs=6 * aL, peak=PEAK_BF16_MFMA_TF, frac=6 * aL / PEAK_BF16_MFMA_TF,
-                                     note="bf16x3: six v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16 block; this fraction is <= 1 by construction")
-            if roof["frac"] > 1.0:   # a full (not triangular) product: faster than the f32 MFMA pipe could be -- its roof is the bf16 pipe's
-                roof["f32_equivalent"] = dict(achieved=aL, peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=aL / PEAK_F32_MFMA_TF,
-                                              note="f32-accurate flops over the f32-MFMA peak: above 1, i.e. not this kernel's bound")
-                roof.update(bound="mfma", achieved=6 * aL, peak=PEAK_BF16_MFMA_TF, frac=6 * aL / PEAK_BF16_MFMA_TF,
-                            note="executed bf16 flops (six per f32-equivalent flop) over the dense bf16 MFMA peak")
             roof.pop("estimates_per_launch_note", None)
-            ach = aL
+            return roof, stages
     if gen and bf3:
         roof["bf16_pipe"] = dict(mfma="v_mfma_f32_32x32x16_bf16 x6 per product block (exact 3-way f32 split)",
                                  executed_TFLOPs=6 * ach, peak=PEAK_BF16_MFMA_TF, frac=6 * ach / PEAK_BF16_MFMA_TF)
@@ -527,9 +552,134 @@ def cpu_baseline(w, params, budget_s=24.0):
         sample = (f"median of {blas['reps']} whole estimates of the same (d={d}, n_mc={M}) workload, f32: both contractions on {blas['blas']} "
                   f"(all {avail} CPUs of '{model}', {blas['gflops_executed']:.0f} GFLOP/s executed), numpy ziggurat normals + numpy elementwise "
                   f"work included ({blas['eps_predrawn']['estimates_per_s']:.0f} estimates/s with eps pre-drawn); the C port's legs are in thread_scaling")
-    return dict(value=value, unit="ELBO-grad-estimates/s", cores=cores, kind="port", leg=leg, build=build, blas=blas, sample=sample,
+    return dict(value=value, unit="ELBO-grad-estimates/s", cores=cores, kind="port", leg=leg, build=build, blas=blas, sample=sample, cpu=model, cpus_available=avail,
                 gflops=(best["gflops_estimate"] if leg == "c_port" else blas["gflops_algorithmic"]),
                 one_thread=legs.get(1), all_cores=legs.get(avail), thread_scaling=[legs[t] for t in teams], threads=lib.mo32_max_threads())
+
+
+LINE_LIMIT = 4096   # bytes: the driver keeps an 8 KiB stdout tail and parses the LAST line (round 4's 25.7 KB line came back `parsed: null`)
+
+
+def _num(x, sig=6):
+    """A float rounded to `sig` significant digits (None / non-numbers pass through)."""
+    if isinstance(x, bool) or not isinstance(x, (int, float)):
+        return x
+    if isinstance(x, int) or x == 0 or x != x or x in (float("inf"), float("-inf")):
+        return x
+    return float("%.*g" % (sig, x))
+
+
+def _get(o, *path, default=None):
+    for k in path:
+        if not isinstance(o, dict) or k not in o or o[k] is None:
+            return default
+        o = o[k]
+    return o
+
+
+def compact_line(full):
+    """The ONE stdout line the driver parses, built from the full result dict: <= LINE_LIMIT bytes, every contract key, `roofline` and
+    `cpu_baseline` as flat objects, one number per `also` leg.  Everything else (per-kernel traffic blocks, thread scaling, stage times,
+    notes) lives in the full file (`full`: gpurun_out/bench_full.json) and on stderr.  Pure function of its argument: tests/test_bench_line.py
+    feeds it canned dicts on the CPU."""
+    roof = full.get("roofline") or None
+    r = None
+    if roof:
+        tr = roof.get("traffic") or None
+        lanes = roof.get("estimates_per_launch", 1)
+        ric = roof.get("rocprof_in_chain") or None
+        r = {
+            "bound": roof.get("bound"), "kernel": str(roof.get("kernel", ""))[:96],
+            "achieved": _num(roof.get("achieved")), "peak": roof.get("peak"), "unit": roof.get("unit"), "frac": _num(roof.get("frac"), 4),
+            # the same kernel on the pipe it executes on: split-operand products run on the 16-bit matrix pipe (2.5 PFLOP/s dense)
+            "frac_16bit_pipe": _num(_get(roof, "pipe16", "frac"), 4),
+            "basis": str(roof.get("basis", ""))[:160] or None,
+            "avg_launch_us": _num(roof.get("avg_launch_us"), 5), "lanes": lanes,
+            "traffic": (None if not tr else {"bytes_per_launch": _num(tr.get("bytes_per_launch")), "lanes": tr.get("lanes_per_launch", lanes),
+                                             "over_algorithmic": _num(tr.get("over_algorithmic"), 3), "src": str(tr.get("profile", ""))[:64] or None}),
+            "rocprof_in_chain": (None if not ric else {"avg_us": _num(ric.get("avg_us"), 5), "lanes": ric.get("lanes"), "src": str(ric.get("source", ""))[:64]}),
+        }
+        oc = roof.get("other_contraction")
+        if isinstance(oc, list):
+            oc = oc[0] if oc else None
+        if oc:
+            r["other"] = {"kernel": str(oc.get("kernel", ""))[:48], "avg_launch_us": _num(oc.get("avg_launch_us"), 5), "frac": _num(oc.get("frac"), 4)}
+        if roof.get("draws"):
+            r["draws"] = {"avg_launch_us": _num(_get(roof, "draws", "avg_launch_us"), 5), "GBs": _num(_get(roof, "draws", "achieved_GBs"), 4)}
+        we = full.get("whole_estimate") or {}
+        r["whole_estimate"] = {"hbm_frac_of_8TBs": _num(we.get("hbm_equiv_frac_of_8TBs"), 4), "f32_mfma_TFs": _num(we.get("f32_mfma_TFs"), 4)}
+    cb = full.get("cpu_baseline") or None
+    c = None
+    if cb:
+        c = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "threads": cb.get("threads"),
+             "kind": cb.get("kind"), "leg": cb.get("leg"), "cpu": str(cb.get("cpu", ""))[:48], "sample": str(cb.get("sample", ""))[:200],
+             "one_thread": _num(_get(cb, "one_thread", "estimates_per_s"))}
+    also = None
+    if full.get("also"):
+        also = {}
+        for k, v in full["also"].items():
+            if not isinstance(v, dict):
+                continue
+            if "error" in v:
+                also[k] = None
+            elif "value" in v:
+                also[k] = _num(v["value"], 5)
+                if k.endswith("_loop") and "us_per_step" in v:
+                    also[k + "_us"] = _num(v["us_per_step"], 4)
+            elif "us_per_call" in v:
+                also[k] = _num(1e6 / v["us_per_call"], 5)
+        also["units"] = "estimates/s (c2 ns_dense ns_stl c5 c3 ns_host_boundary), steps/s (*_loop, reference_benchmark_grid), calls/s (stein)"
+    cfg = dict(full.get("config") or {})
+    cfg["launch"] = str(cfg.get("launch", ""))[:200]
+    cfg["workload"] = str(cfg.get("workload", ""))[:128]
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype", "data")}
+    line["value"] = _num(line["value"], 7)
+    line["ms_per_step"] = _num(line["ms_per_step"], 6)
+    line["config"] = {k: cfg.get(k) for k in ("workload", "d", "n_mc_per_gpu", "n_mc_total", "family", "launch")}
+    line["roofline"] = r
+    line["cpu_baseline"] = c
+    line["elbo_rel_err_vs_cpu_fp64"] = _num(full.get("elbo_rel_err_vs_cpu_fp64"), 3)
+    line["grad_rel_l2_vs_cpu_fp64"] = _num(_get(full, "parity_vs_fp64_oracle", "grad_rel_l2"), 3)
+    line["steady_state_est_per_s"] = _num(_get(full, "steady_state", "estimates_per_s"), 6)
+    line["repeat_ms_per_step"] = [_num(x, 4) for x in (full.get("repeat_ms_per_step") or [])][:5]
+    line["also"] = also
+    if full.get("dist"):
+        d = full["dist"]
+        line["dist"] = {"route": d.get("route"), "pipeline": str(d.get("pipeline", ""))[:64] or None,
+                        "estimate_sharded_est_per_s": _num(_get(d, "estimate_sharded", "value"), 6),
+                        "us_per_estimate": d.get("us_per_estimate")}
+    line["full"] = full.get("full_path")
+    s = json.dumps(line, separators=(",", ":"))
+    # belt and braces: shed optional blocks, largest first, until the line fits
+    for k in ("repeat_ms_per_step", "also", "dist", "steady_state_est_per_s"):
+        if len(s) <= LINE_LIMIT:
+            break
+        line.pop(k, None)
+        s = json.dumps(line, separators=(",", ":"))
+    if len(s) > LINE_LIMIT:
+        for blk, key in (("roofline", "kernel"), ("cpu_baseline", "sample"), ("config", "launch"), ("config", "workload")):
+            if isinstance(line.get(blk), dict) and key in line[blk]:
+                line[blk][key] = str(line[blk][key])[:40]
+        s = json.dumps(line, separators=(",", ":"))
+    assert len(s) <= LINE_LIMIT, len(s)
+    return s
+
+
+def emit(full):
+    """Full result -> gpurun_out/bench_full.json (+ stderr), compact line -> stdout (the last thing written there)."""
+    path = os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        full["full_path"] = os.path.relpath(path, ROOT)
+    except OSError:
+        full["full_path"] = None
+    sys.stderr.write("bench.py full result: " + json.dumps(full) + "\n")
+    sys.stderr.flush()
+    sys.stdout.write(compact_line(full) + "\n")
+    sys.stdout.flush()
 
 
 def main():
@@ -614,8 +764,8 @@ def main():
             if w["family"] == 1 and w["target"] in ("iso", "dense"):
                 Lstep = ctx.batch_lanes(chunk) or chunk
                 extra = (" | the dense target's product" if w["target"] == "dense" else "") + (" | the sticking-the-landing product (C^-T formed once per call)" if w["entropy"] in (3, 4) else "")
-                launch_desc = (f"mivi_estimate_gradient_n x{chunk}: batch engine, {-(-chunk // Lstep)} step(s) of {Lstep} estimates, per step one launch each on one stream: "
-                               f"draws of all lanes as bf16 operand planes | product (+ fused diagonal target), 128 x 128 tiles, 8 waves{extra} | VJP + values; no graph, no side streams")
+                launch_desc = (f"mivi_estimate_gradient_n x{chunk}: batch engine, {-(-chunk // Lstep)} step(s) of {Lstep} lanes, 3 launches per step on one stream "
+                               f"(draws as operand planes -> product+target{' -> dense product' if w['target'] == 'dense' else ''}{' -> STL product' if w['entropy'] in (3, 4) else ''} -> VJP+values), no graph")
             elif use_graph:
                 launch_desc = f"mivi_estimate_gradient_n x{chunk} (one hipGraph / launch-free kernel per call)"
             else:
@@ -1179,7 +1329,7 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
     if out is not None:
-        print(json.dumps(out))
+        emit(out)
 
 
 if __name__ == "__main__":
