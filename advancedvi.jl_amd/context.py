@@ -304,6 +304,18 @@ class MiviContext:
         """Estimates per launch the batch engine uses for a `count`-estimate call (mivi_batch_lanes)."""
         return int(self.lib.mivi_batch_lanes(self.h, int(count)))
 
+    def batch_takes_engine(self, params):
+        """True when batches of estimates at this configuration run on the batch engine (mivi_batch_info what = 0)."""
+        return int(self.lib.mivi_batch_info(self.h, self._p(params), 0)) == 1
+
+    def split_products(self):
+        """Matrix-pipe products per product block of the engine's split-operand contractions (mivi_batch_info what = 1)."""
+        return int(self.lib.mivi_batch_info(self.h, None, 1))
+
+    def plane_bytes(self):
+        """Bytes per operand-plane element of the batch engine (mivi_batch_info what = 2)."""
+        return int(self.lib.mivi_batch_info(self.h, None, 2))
+
     def profile_batch(self, params, lanes, reps):
         """Average launch duration (us) of the batch engine's kernels for `lanes` estimates (mivi_profile_batch):
         dict(eps=.., product=.., vjp=.., dense_product=.., stl_product=..) -- dense_product 0 unless the target is the dense Gaussian,

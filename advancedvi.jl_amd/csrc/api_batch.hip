@@ -217,7 +217,8 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
         (s = ensure(c, t.epsV, (size_t)L * pw, false)) || (s = ensure(c, t.WV, (size_t)L * pw, false)) ||
         (s = ensure(c, t.ell, (size_t)L * (d / 32) * (M / 32) * sizeof(double), false)) ||
         (s = ensure(c, t.he, (size_t)L * (d / 64) * (M / 32) * sizeof(double), false)) ||
-        (s = ensure(c, t.ld, 2 * (size_t)(d / 32) * sizeof(double) + 64, false)) || (s = ensure(c, t.values, (size_t)L * 4 + 64, false)))
+        (s = ensure(c, t.ld, 2 * (size_t)(d / 32) * sizeof(double) + 64, false)) || (s = ensure(c, t.values, (size_t)L * 4 + 64, false)) ||
+        (s = ensure(c, t.cscale, 2 * (size_t)d * 4, false)) || (s = ensure(c, t.winv, (size_t)L * (M / 128) * d * 4, false)))
       return s;
     t.grads.bytes = 0;   // (re-zeroed: the lanes' scratch gradients rely on exact zeros above the diagonal that no kernel writes)
     if ((s = ensure(c, t.grads, (size_t)L * plen * 4, true))) return s;
@@ -229,7 +230,9 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
   if (dense) {   // R = Z - m planes per lane; the planes of P once per target
     if (t.cap_LR < L) {
       invalidate_graph(c);
-      if ((s = ensure(c, t.RP, (size_t)L * fb_plane_words(c, M) * 4, false)) || (s = ensure(c, t.PA, fb_cplane_words(c) * 4, false))) return s;
+      if ((s = ensure(c, t.RP, (size_t)L * fb_plane_words(c, M) * 4, false)) || (s = ensure(c, t.PA, fb_cplane_words(c) * 4, false)) ||
+          (s = ensure(c, t.pscale, 2 * (size_t)d * 4, false)) || (s = ensure(c, t.rinv, (size_t)L * (d / 128) * M * 4, false)))
+        return s;
       t.cap_LR = L;
       t.PA_valid = false;
     }
@@ -252,7 +255,7 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
     const bool grow = !t.Tinv.p || c->stl_X.bytes < ((size_t)d * d + (size_t)(d / 2) * (d / 2)) * es + 4096 || !c->stl_F.p;
     if (grow) {
       invalidate_graph(c);
-      if ((s = ensure(c, t.Tinv, (size_t)d * d * es, false)) || (s = ensure(c, t.TA, fb_cplane_words(c) * 4, false)) ||
+      if ((s = ensure(c, t.Tinv, (size_t)d * d * es, false)) || (s = ensure(c, t.TA, fb_cplane_words(c) * 4, false)) || (s = ensure(c, t.tscale, 2 * (size_t)d * 4, false)) ||
           (s = ensure(c, c->stl_X, ((size_t)d * d + (size_t)(d / 2) * (d / 2)) * es + 4096, false)) ||
           (s = ensure(c, c->stl_F, mivi::stl_pack_units(d) * 4, false)))
         return s;
@@ -298,6 +301,13 @@ int32_t mivi_batch_lanes(const mivi_ctx_t *c, int32_t count) {
   if (!c || count <= 0) return 0;
   const int Lmax = fb_lanes_max(), steps = (count + Lmax - 1) / Lmax;
   return (count + steps - 1) / steps;
+}
+
+int32_t mivi_batch_info(const mivi_ctx_t *c, const void *params, int32_t what) {
+  if (!c) return 0;
+  if (what == 1) return 3;   // fr_planes.h kSplitProducts
+  if (what == 2) return 4;   // two f16 planes
+  return (what == 0 && params && fb_route(c, params, nullptr, nullptr)) ? 1 : 0;
 }
 
 // Roofline leg of the batch engine: `reps` launches of each of a step's kernels for `lanes` estimates, hipEvents on the context's

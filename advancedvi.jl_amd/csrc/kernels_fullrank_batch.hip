@@ -1,6 +1,6 @@
-// Full-rank RepGradELBO contractions for a BATCH of estimates at the same parameters (gfx950): third generation.
+// Full-rank RepGradELBO contractions for a BATCH of estimates at the same parameters (gfx950): the batch engine.
 //
-// Reference semantics (AdvancedVI.jl v0.7.0), per estimate unchanged from kernels_fullrank_lds.hip:
+// Reference semantics (AdvancedVI.jl v0.7.0), per estimate:
 //   sampling   Z = scale * eps .+ mu                                  src/families/location_scale.jl:71-77
 //   energy     mean_m logdensity(prob, z_m)                           src/algorithms/repgradelbo.jl:84-86
 //   gradient   d/dC = -(1/M) tril(W eps') - direct * diag(1/C_ii),  d/dmu = -(1/M) W 1   (repgradelbo.jl:142-149)
@@ -8,26 +8,18 @@
 // averaged gradients, the bench's step) are independent, and L of them are ONE matrix product each way:
 //   product   [Z_1 .. Z_L] = mu + tril(C) [eps_1 .. eps_L]            1024 x (256 L) x 1024 (triangular) at the north star
 //   VJP       dC_l = tril(W_l eps_l'),  l = 1 .. L                    L products 1024 x 1024 (lower) x 256
-// The second generation gives every 32 x 32 tile of ONE estimate a workgroup whose waves split K: latency-bound launches, and every
-// operand element is split into its three bf16 pieces by every tile that uses it (20 vector instructions per MFMA: the vector ALU is the
-// busiest unit).  Here the launches are shaped like the large products they are, and the split is done ONCE, by whoever produces an operand:
-//   * OPERAND PLANES.  Every operand lives in memory as its exact three-way bf16 split (hi / mid / lo planes, 6 bytes per element) in
-//     MFMA-FRAGMENT ORDER: a fragment = 32 rows x 16 k of one operand = 3 planes x 64 lanes x 16 bytes, lane (row = lane % 32,
-//     h = lane / 32) holding the eight k slots k = 16 g + 8 (e / 4) + 4 h + e % 4 -- the slot assignment of the second-generation kernels.
-//     tril(C) is laid out once per call (k_fb_cplanes, diagonal blocks already masked), eps by its generator in both orientations
-//     (k_fb_eps: rows as k for the product, samples as k for the VJP), W by the product's epilogue.  A main loop is then
-//     LDS-DMA (1 KiB pieces) -> ds_read_b128 -> six MFMAs per fragment pair: no vector arithmetic at all.
-//   * a workgroup owns a 128 x 128 output tile, a wave a 64 x 64 part of it (2 x 2 MFMA tiles) over the WHOLE K range; operands are
-//     staged once per workgroup in a three-slot LDS ring of 16-k stages (the DMA of stage g + 2 is in flight under the MFMAs of g),
-//     one barrier per stage; no cross-wave reduction: the epilogue works on a wave's own accumulators (transposed through a
-//     wave-private LDS image so that stores are whole 128-byte lines);
+//   * OPERAND PLANES (fr_planes.h).  Every operand lives in memory as the two-way f16 split of its power-of-two-scaled f32 elements (hi / lo
+//     planes, 4 bytes per element) in MFMA-FRAGMENT ORDER: a fragment = 32 rows x 16 k of one operand = 2 planes x 64 lanes x 16 bytes.
+//     tril(C) is laid out once per call (rider workgroups of the first draw: row maxima -> row scales -> fragments, diagonal blocks masked),
+//     eps by its generator in both orientations (k_fb_eps: rows as k for the product, samples as k for the VJP), W by the product's
+//     epilogue with one scale per (row, 128-sample tile).  A main loop is then LDS-DMA (1 KiB pieces) -> ds_read_b128 -> three
+//     v_mfma_f32_32x32x16_f16 per fragment pair (lo.hi, hi.lo, hi.hi): no vector arithmetic at all.
+//   * a workgroup owns a 128 x 128 output tile, a wave a 64 x 32 WJ part of it over the WHOLE K range; operands are staged once per
+//     workgroup in an LDS ring of 16-k stages (16 KiB each), one barrier per stage; no cross-wave reduction of products; the epilogue
+//     works through wave-private LDS images (stores are whole 128-byte lines), the tile's scale maxima cross the waves once.
 //   * the launch covers every lane (estimate) of the step: per-lane buffers are base + lane * stride, the work table names (lane, tile).
-// BIT-IDENTICAL to the one-estimate kernels (k_fr_prod32 / k_fr_vjp32): those cut a tile's K range into runs (one per wave: eight for the
-// product, four for the VJP), every run an MFMA chain from zero, the runs summed in wave order.  A wave here walks the same runs one after
-// the other -- chain accumulator `acc`, folded into `tot` at every run boundary (tot = tot + acc: the same f32 additions in the same
-// order) -- on the same bf16 pieces (the same split arithmetic, applied by the producer instead of the consumer) in the same k slots,
-// with the same per-element epilogue arithmetic (fr_elem.h), the same wave sums behind every ell partial and the same slots for them.
-// So "a batch's estimates are bitwise the single calls'" holds by construction (tests/test_gpu_batches.py, tests/test_gpu_each.py).
+// Accuracy: an f32-accurate product (2^-22 per term; measured 3.5e-7 relative l2 at K = 1024) -- the single calls (kernels_fullrank_lds.hip:
+// exact three-way bf16 split) agree with a batch's estimates to rounding, not bitwise (tests/test_gpu_each.py states the tolerances).
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -39,46 +31,49 @@
 
 namespace mivi {
 
-// A wave's operands of one 16-k group: two A fragments (its two 32-row blocks) and WJ B fragments (its 32-column blocks), three planes each
+// A wave's operands of one 16-k group: two A fragments (its two 32-row blocks) and WJ B fragments (its 32-column blocks), two planes each
 template <int WJ>
 struct FbFrags {
-  u32x4v A[2][3], B[WJ][3];
+  u32x4v A[2][2], B[WJ][2];
 };
 __device__ __forceinline__ f32x16 fb_mma(const u32x4v &a, const u32x4v &b, const f32x16 &c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
-// the 12 WJ MFMAs of a group, the 2 WJ accumulators' chains interleaved (a dependent MFMA issues 2 WJ slots behind its predecessor); per
-// accumulator the order is mfma_bf16x3's: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi  (planes: 0 hi, 1 mid, 2 lo)
+// the 6 WJ MFMAs of a group, the 2 WJ accumulators' chains interleaved; per accumulator smallest terms first: lo.hi, hi.lo, hi.hi
 template <int WJ>
 __device__ __forceinline__ void fb_group(const FbFrags<WJ> &F, f32x16 (&acc)[2][WJ]) {
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+  constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};   // planes: 0 hi, 1 lo
 #pragma unroll
-  for (int p = 0; p < 6; ++p)
+  for (int p = 0; p < 3; ++p)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < WJ; ++j) acc[i][j] = fb_mma(F.A[i][PA[p]], F.B[j][PB[p]], acc[i][j]);
 }
 
-
 struct FbArgs {
   int d, M, L;
   const float *params;            // [mu; vec C]
   const float *t_mean, *t_istd;   // diagonal-Gaussian target
-  unsigned *CA;                   // planes of tril(C): fragment (rb32, kg), kg <= 2 rb32 + 1, at (rb32 (d / 16) + kg) kFrag
-  unsigned *epsP;                 // lane l: epsP + l * plane_stride; fragment (mb32, kg = row group) at (mb32 (d / 16) + kg) kFrag
-  unsigned *epsV;                 // lane l: epsV + l * plane_stride; fragment (jb32, mg = sample group) at (jb32 (M / 16) + mg) kFrag
+  unsigned *CA;                   // planes of tril(C): fragment (rb32, kg), kg <= 2 rb32 + 3, at (rb32 (d / 16) + kg) kFrag
+  float *cscale;                  // [2][d]: row scales of tril(C), their inverses
+  unsigned *epsP;                 // lane l: epsP + l * plane_stride; fragment (mb32, kg = row group) at (mb32 (d / 16) + kg) kFrag; 2^11 eps
+  unsigned *epsV;                 // lane l: epsV + l * plane_stride; fragment (jb32, mg = sample group) at (jb32 (M / 16) + mg) kFrag; 2^11 eps
   unsigned *WV;                   // lane l: WV + l * plane_stride; fragment (rb32, mg) at (rb32 (M / 16) + mg) kFrag
-  // dense-Gaussian target: g = -P (z - m) is a second product per lane (k_fb_prod<MODE 2>) between the draw's product and the VJP
+  float *winv;                    // lane l: winv + l * (M / 128) d: inverse scale of W's (row, 128-sample block): [M / 128][d]
+  // dense-Gaussian target: g = -P (z - m) is a second product per lane (k_fb_prod<FB_DENSE_G>) between the draw's product and the VJP
   const float *t_prec;            // P, leading dimension dP
   int dP;
-  unsigned *PA;                   // planes of P: fragment (rb32, kg), every kg < d / 16, at (rb32 (d / 16) + kg) kFrag (k_fb_pplanes)
+  unsigned *PA;                   // planes of P: fragment (rb32, kg), every kg < d / 16 (k_fb_pplanes)
+  float *pscale;                  // [2][d]: row scales of P, their inverses
   unsigned *RP;                   // lane l: RP + l * plane_stride: R = Z - m as the second product's B operand, eps' product layout
+  float *rinv;                    // lane l: rinv + l * (d / 128) M: inverse scale of R's (sample, 128-row block): [d / 128][M]
   // sticking-the-landing estimators: W += C^-T eps with the INVERSE of the scale formed once per call (the parameters are fixed inside it)
   const float *Tinv;              // C^-T, d x d, (row i, column k) at [i + k d], upper triangular (the solve kernels on the identity)
-  unsigned *TA;                   // its planes: fragment (rb32, kg), every kg, entries k < row zeroed (k_fb_tplanes)
+  unsigned *TA;                   // its planes: fragment (rb32, kg), kg >= 2 (rb32 & ~3), entries k < row zeroed (k_fb_tplanes)
+  float *tscale;                  // [2][d]
   long long plane_stride;         // words per lane = d M / 512 * kFrag
-  double *ell_part;               // lane l: ell_part + l * ell_stride; slots = k_fr_prod32's workgroup indices
+  double *ell_part;               // lane l: ell_part + l * ell_stride; slot per (32-row block, 32-column block)
   long long ell_stride;
   double *he_part;                // lane l: he_part + l * he_stride
   long long he_stride;
@@ -97,146 +92,160 @@ struct FbArgs {
   int *status;
   double ell_const;
   RngArgs rng;                    // lane l draws estimate rng_index(rng) + l
-  int knock;                      // developer knock-outs (-DMIVI_DEV builds only: tools/ubench_fb.hip)
-  long long *dbg;                 // developer timeline (-DMIVI_DEV): per workgroup {hw id | xcc << 32, start, main loop done, end}
+  int n_riders;                   // k_fb_eps: grid rows in front of the lanes' that lay out tril(C)
 };
-#ifdef MIVI_DEV
-#define FB_STAMP(a, slot) do { if ((a).dbg && threadIdx.x == 0 && blockIdx.x == 0 && ((slot) == 1 || (slot) == 2)) (a).dbg[8 * 4096 + (slot)] = (long long)clock64(); \
-  if ((a).dbg && threadIdx.x == 0) (a).dbg[(size_t)blockIdx.x * 8 + (slot)] = (slot) ? (long long)wall_clock64() : \
-  (long long)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32)); } while (0)
-#else
-#define FB_STAMP(a, slot) do { } while (0)
-#endif
 
 // -----------------------------------------------------------------------------------------------------------------
-// k_fb_cplanes: tril(C) as operand planes, one wave per fragment (rb32, kg): lane (row, h) reads its eight k slots (coalesced over the
-// 32 rows), zeroes the entries above the diagonal, splits, stores 3 x 16 bytes.  Once per call: the parameters are fixed inside it.
+// A parameter-only A operand as operand planes: ONE workgroup (512 threads) per 32-row block rb -- the rows' largest magnitudes over the
+// k range the products read (fragments kg_lo .. kg_hi) -> one power-of-two scale per row (scale[row], scale[d + row] = its inverse) ->
+// the block's fragments, one wave per fragment.  ld(k, row) returns the (masked) f32 element.  red: 16 * 32 + 32 floats of LDS.
 // -----------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fb_cplanes_frag(const FbArgs &a, int f, int lane) {
-  const int l31 = lane & 31, h = lane >> 5;
+template <class Ld>
+__device__ __forceinline__ void fb_rowblock_planes(int d, int rb, int kg_lo, int kg_hi, Ld ld, unsigned *planes, float *scale, float *red) {
+  const int tid = threadIdx.x, row = tid & 31, part = tid >> 5, ng = d >> 4;
+  float m = 0.f;
+  {
+    int k = 16 * kg_lo + part;
+    for (; k + 112 <= 16 * kg_hi + 15; k += 128) {   // eight independent loads in flight per thread
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = fabsf(ld(k + 16 * u, 32 * rb + row));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
+    }
+    for (; k <= 16 * kg_hi + 15; k += 16) m = fmaxf(m, fabsf(ld(k, 32 * rb + row)));
+  }
+  red[part * 32 + row] = m;
+  lds_barrier();
+  if (tid < 32) {
+    float mm = red[tid];
+#pragma unroll
+    for (int p = 1; p < 16; ++p) mm = fmaxf(mm, red[p * 32 + tid]);
+    float s, inv;
+    fb_scale_of(mm, s, inv);
+    red[512 + tid] = s;
+    scale[32 * rb + tid] = s;
+    scale[d + 32 * rb + tid] = inv;
+  }
+  lds_barrier();
+  const int w = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const float s = red[512 + l31];
+  for (int kg = kg_lo + w; kg <= kg_hi; kg += 8) {
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = ld(16 * kg + 8 * (e >> 2) + 4 * h + (e & 3), 32 * rb + l31) * s;
+    fb_store_frag(planes + ((size_t)rb * ng + kg) * kFrag + 4 * lane, x);
+  }
+}
+// tril(C): the fragments up to the diagonal block + the two zero groups behind it (a wave of k_fb_prod walks the K range of its SECOND row
+// block with both of its blocks: the first one's chain adds exact zeros there)
+__device__ __forceinline__ void fb_cplanes_block(const FbArgs &a, int rb, float *red) {
   const int d = a.d, ng = d >> 4;
-  const int rb = f / ng, kg = f % ng;
-  if (rb >= (d >> 5) || kg > 2 * rb + 3) return;   // (the two groups behind the diagonal block: zero fragments -- a wave of k_fb_prod walks the
-  const int row = 32 * rb + l31;                   //  K range of its SECOND row block with both, the first one's chain then adds exact zeros)
   const float *C = a.params + d;
-  float x[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int k = 16 * kg + 8 * (e >> 2) + 4 * h + (e & 3);
-    const float v = C[(size_t)k * d + row];
-    x[e] = k > row ? 0.f : v;
-  }
-  u32x4v uh, um, ul;
-  fb_split3(x, uh, um, ul);
-  unsigned *dst = a.CA + (size_t)f * kFrag + 4 * lane;
-  store16_wt(dst, uh);
-  store16_wt(dst + 256, um);
-  store16_wt(dst + 512, ul);
+  const int hi = 2 * rb + 3 < ng - 1 ? 2 * rb + 3 : ng - 1;
+  fb_rowblock_planes(d, rb, 0, hi, [C, d](int k, int row) { const float v = C[(size_t)k * d + row]; return k > row ? 0.f : v; }, a.CA, a.cscale, red);
 }
-__global__ __launch_bounds__(256) void k_fb_cplanes(FbArgs a) {   // (stand-alone form: tools/ubench_fb.hip)
-  fb_cplanes_frag(a, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+// k_fb_pplanes: the dense-Gaussian target's precision matrix P (every k group: P is full).  Once per target.
+__global__ __launch_bounds__(512) void k_fb_pplanes(FbArgs a) {
+  __shared__ float red[16 * 32 + 32];
+  const float *P = a.t_prec;
+  const int dP = a.dP;
+  fb_rowblock_planes(a.d, (int)blockIdx.x, 0, (a.d >> 4) - 1, [P, dP](int k, int row) { return P[(size_t)k * dP + row]; }, a.PA, a.pscale, red);
 }
-
-// k_fb_pplanes: the dense-Gaussian target's precision matrix P as operand planes (every k group: P is full), one wave per fragment.
-// Once per target (the planes are kept until the target changes).
-__global__ __launch_bounds__(256) void k_fb_pplanes(FbArgs a) {
-  const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
-  const int d = a.d, ng = d >> 4;
-  const int rb = f / ng, kg = f % ng;
-  if (rb >= (d >> 5)) return;
-  const int row = 32 * rb + l31;
-  float x[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) x[e] = a.t_prec[(size_t)(16 * kg + 8 * (e >> 2) + 4 * h + (e & 3)) * a.dP + row];   // (k_fr_prod32<G_DENSE>: A[row + k lda])
-  u32x4v uh, um, ul;
-  fb_split3(x, uh, um, ul);
-  unsigned *dst = a.PA + (size_t)f * kFrag + 4 * lane;
-  store16_wt(dst, uh);
-  store16_wt(dst + 256, um);
-  store16_wt(dst + 512, ul);
-}
-
-// k_fb_tplanes: C^-T (upper triangular) as operand planes, one wave per fragment; the entries below the diagonal are exact zeros whatever
-// the solve left there.  Once per call.
-__global__ __launch_bounds__(256) void k_fb_tplanes(FbArgs a) {
-  const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
-  const int d = a.d, ng = d >> 4;
-  const int rb = f / ng, kg = f % ng;
-  if (rb >= (d >> 5)) return;
-  const int row = 32 * rb + l31;
-  float x[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int k = 16 * kg + 8 * (e >> 2) + 4 * h + (e & 3);
-    x[e] = (kg >= 2 * rb && k >= row) ? a.Tinv[(size_t)k * d + row] : 0.f;
-  }
-  u32x4v uh, um, ul;
-  fb_split3(x, uh, um, ul);
-  unsigned *dst = a.TA + (size_t)f * kFrag + 4 * lane;
-  store16_wt(dst, uh);
-  store16_wt(dst + 256, um);
-  store16_wt(dst + 512, ul);
+// k_fb_tplanes: C^-T (upper triangular) -- entries below the diagonal are exact zeros whatever the solve left there; a 128-row tile of
+// k_fb_prod<FB_STL_U> starts its K range at its FIRST row block's diagonal, so a row block's fragments start there.  Once per call.
+__global__ __launch_bounds__(512) void k_fb_tplanes(FbArgs a) {
+  __shared__ float red[16 * 32 + 32];
+  const float *T = a.Tinv;
+  const int d = a.d, rb = (int)blockIdx.x;
+  fb_rowblock_planes(d, rb, 2 * (rb & ~3), (d >> 4) - 1, [T, d](int k, int row) { const float v = T[(size_t)k * d + row]; return k >= row ? v : 0.f; }, a.TA,
+                     a.tscale, red);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// k_fb_eps: eps of L estimates as operand planes in both orientations.  Draws: the blocks of the product kernels' riders (64 rows x 32
-// columns, one Philox block per thread: the same stream and the same he_part partials as k_eps_m / the riders of k_fr_prod32); the block's
-// 64 x 32 values go through an LDS tile, threads 0..255 then assemble the four product fragments (column = row of the B operand, k = rows
-// 16 ig ..), threads 256..511 the four VJP fragments (row j, k = samples 16 mg ..).  blockIdx.y = lane.
+// k_fb_eps: eps of L estimates as operand planes (of 2^11 eps) in both orientations.  Draws: blocks of 64 rows x 32 columns, one Philox block
+// per thread (rows 4 q .. 4 q + 3 of one column: the stream and the he_part partials of the single calls' k_eps); the block's values go
+// through an LDS tile, threads 0..255 then assemble the four product fragments (column = row of the B operand, k = rows 16 ig ..),
+// threads 256..511 the four VJP fragments (row j, k = samples 16 mg ..).  blockIdx.y - n_riders = lane; the first n_riders grid rows
+// (a call's first draw only) lay out tril(C): one workgroup per 32-row block, the heaviest first.
 // -----------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
   __shared__ double red[8];
-  __shared__ float E[32 * 65];   // E[m][i], leading dimension 65
-  const int tid = threadIdx.x, eb = blockIdx.x, l = blockIdx.y, d = a.d;
-  if (l >= a.L) {   // riders of a call's first draw: tril(C) as operand planes (parameters only), eight fragments per workgroup
-    fb_cplanes_frag(a, (((int)blockIdx.y - a.L) * (int)gridDim.x + eb) * 8 + (tid >> 6), tid & 63);
+  __shared__ float E[32 * 65];   // E[m][i], leading dimension 65 (the riders' reduction area: 544 floats)
+  const int tid = threadIdx.x, eb = blockIdx.x, d = a.d;
+  if ((int)blockIdx.y < a.n_riders) {
+    const int r = (int)blockIdx.y * (int)gridDim.x + eb;
+    if (r < (d >> 5)) fb_cplanes_block(a, (d >> 5) - 1 - r, E);
     return;
   }
-  PlaneEps pe{};
-  pe.d = d; pe.M = a.M;
-  pe.seed = a.rng.seed; pe.idx = rng_index(a.rng) + (uint64_t)l; pe.m_offset = a.rng.m_offset;
-  pe.epsP = a.epsP + (size_t)l * a.plane_stride;
-  pe.epsV = a.epsV + (size_t)l * a.plane_stride;
-  pe.he_part = a.he_part + (size_t)l * a.he_stride;
-  plane_eps_block(pe, eb, E, red);
+  const int l = (int)blockIdx.y - a.n_riders;
+  const uint64_t idx = rng_index(a.rng) + (uint64_t)l;
+  unsigned *epsP = a.epsP + (size_t)l * a.plane_stride, *epsV = a.epsV + (size_t)l * a.plane_stride;
+  const int nrb6 = d >> 6;
+  const int R64 = eb % nrb6, c32 = eb / nrb6;
+  const int q = tid & 15, c = tid >> 4;
+  const int ri = R64 * 64 + 4 * q, rm = c32 * 32 + c;
+  float e[4];
+  eps_block<float>(a.rng.seed, idx, (uint64_t)(a.rng.m_offset + rm) * (uint64_t)(d >> 2) + (uint64_t)(ri >> 2), e);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) E[c * 65 + 4 * q + r] = e[r] * kEpsScale;
+  const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
+  const double sh = block_sum_nodrain_f32<512>(he, red);   // (its barriers also publish the tile)
+  if (tid == 0) a.he_part[(size_t)l * a.he_stride + eb] = sh;
+  const int lane = tid & 63, l31 = lane & 31, h = lane >> 5, f = (tid >> 6) & 3;
+  float x[8];
+  unsigned *dst;
+  if (tid < 256) {   // product fragment (mb32 = c32, kg = 4 R64 + f): lane = column l31, slots = rows 16 f + ..
+#pragma unroll
+    for (int s = 0; s < 8; ++s) x[s] = E[l31 * 65 + 16 * f + 8 * (s >> 2) + 4 * h + (s & 3)];
+    dst = epsP + ((size_t)c32 * (d >> 4) + 4 * R64 + f) * kFrag;
+  } else {           // VJP fragment (jb32 = 2 R64 + f / 2, mg = 2 c32 + f % 2): lane = row l31, slots = samples 16 (f % 2) + ..
+    const int jb = f >> 1, mg = f & 1;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) x[s] = E[(16 * mg + 8 * (s >> 2) + 4 * h + (s & 3)) * 65 + 32 * jb + l31];
+    dst = epsV + ((size_t)(2 * R64 + jb) * (a.M >> 4) + 2 * c32 + mg) * kFrag;
+  }
+  fb_store_frag(dst + 4 * lane, x);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// The two products share a staging scheme: a 128 x 128 tile, four waves (2 x 2), 16-k stages of 24 KiB (A: four fragments, B: four
-// fragments, three planes each) in a three-slot LDS ring.  Piece pc of a stage (1 KiB): pc < 12: A fragment pc / 3, plane pc % 3; else B.
-// Wave w issues pieces 6 w .. 6 w + 5: always six requests per wave and stage, so the vmcnt accounting is a compile-time constant.
+// The two products share a staging scheme: a 128 x 128 tile, 8 / WJ waves, 16-k stages of 16 KiB (A: four fragments, B: four fragments, two
+// planes each) in an LDS ring.  Fragment f of a stage (2 KiB): f < 4: A fragment f; else B fragment f - 4.  Wave w issues fragments
+// WJ w .. WJ w + WJ - 1: always 2 WJ requests per wave and stage, so the vmcnt accounting is a compile-time constant.
 // -----------------------------------------------------------------------------------------------------------------
-constexpr int kStageW = 24 * 256;   // words per stage
-constexpr int kRing = 4;            // LDS ring slots (96 KiB: ONE workgroup per CU): three stages in flight behind the one being read;
+constexpr int kStageW = 16 * 256;   // words per stage
+constexpr int kRing = 4;            // LDS ring slots of the register-prefetching loops: three stages in flight behind the one being read;
                                     // the main loops are unrolled by kRing, so every slot address is a compile-time constant
+constexpr int kImgW = 32 * 36;      // a wave-private 32 x 32 epilogue image (leading dimension 36), words
 // Wave layout of a 128 x 128 tile, WJ = 32-column blocks per wave: 8 / WJ waves = 2 (row halves of 64) x 4 / WJ (column parts of 32 WJ).
-//   WJ = 2: four waves (one per SIMD, up to 512 registers each), a wave owns 64 x 64: 48 KiB of LDS reads per group and workgroup
-//   WJ = 1: eight waves (two per SIMD), a wave owns 64 x 32: 72 KiB of LDS reads per group -- the LDS read port then paces the loop
+//   WJ = 2: four waves (one per SIMD), a wave owns 64 x 64: 32 KiB of LDS reads per group and workgroup
+//   WJ = 1: eight waves (two per SIMD), a wave owns 64 x 32: 48 KiB of LDS reads per group
 template <int WJ>
 __device__ __forceinline__ void fb_read_frags(const unsigned *lds, int slot, int wm, int wn, int lane, FbFrags<WJ> &F) {
   const unsigned *cur = lds + slot * kStageW + 4 * lane;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) F.A[i][p] = *(const u32x4v *)(cur + ((2 * wm + i) * 3 + p) * 256);
+    for (int p = 0; p < 2; ++p) F.A[i][p] = *(const u32x4v *)(cur + ((2 * wm + i) * 2 + p) * 256);
 #pragma unroll
   for (int j = 0; j < WJ; ++j)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) F.B[j][p] = *(const u32x4v *)(cur + (12 + (WJ * wn + j) * 3 + p) * 256);
+    for (int p = 0; p < 2; ++p) F.B[j][p] = *(const u32x4v *)(cur + (8 + (WJ * wn + j) * 2 + p) * 256);
 }
-// The issue order inside one iteration's straight-line block {3 WJ LDS-DMA requests, 9 WJ.. fragment reads of the next group, 12 WJ MFMAs}:
+// The issue order inside one iteration's straight-line block {2 WJ LDS-DMA requests, 4 + 2 WJ fragment reads of the next group, 6 WJ MFMAs}:
 // every wave of the workgroup leaves the barrier at the same moment, and with the reads first (where the scheduler puts loads) all of
-// them queue on the LDS port before the first MFMA of anybody issues -- the matrix pipe idles for the length of that burst.  One memory
-// operation behind every MFMA instead: the pipe starts at once, the reads trickle in under it.
+// them queue on the LDS port before the first MFMA of anybody issues -- the matrix pipe idles for the length of that burst.  Memory
+// operations behind the MFMAs instead: the pipe starts at once, the reads trickle in under it.
 template <int WJ>
 __device__ __forceinline__ void fb_sched_interleave() {
-  constexpr int NM = 12 * WJ, ND = 6 + 3 * WJ, NV = 3 * WJ;
-#pragma unroll
-  for (int k = 0; k < NM; ++k) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                  // one MFMA
-    if (k < ND) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                      // one LDS read
-    else if (k < ND + NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            // one LDS-DMA request
-  }
+  constexpr int NM = 6 * WJ, ND = 4 + 2 * WJ, NV = 2 * WJ;
+  static_for<0, NM>([&](auto K) {
+    constexpr int k = decltype(K)::value;
+    constexpr int nrd = (k + 1) * ND / NM - k * ND / NM;                                       // this MFMA's share of the LDS reads
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        // one MFMA
+    if constexpr (nrd > 0) __builtin_amdgcn_sched_group_barrier(0x100, nrd, 0);
+    if constexpr (k < NV) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                  // one LDS-DMA request
+  });
 }
 using FbI0 = std::integral_constant<int, 0>;
 using FbI1 = std::integral_constant<int, 1>;
@@ -245,35 +254,47 @@ using FbI3 = std::integral_constant<int, 3>;
 using FbT = std::true_type;
 using FbN = std::false_type;
 
+// max of v over the lanes that differ in the given lane-index bits (xor butterfly)
+template <int MASK>
+__device__ __forceinline__ float fb_lane_max(float v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1)
+    if (MASK & o) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
 // -----------------------------------------------------------------------------------------------------------------
-// k_fb_prod: W_l = grad log pi(mu + tril(C) eps_l) as VJP operand planes + ell partials, for every lane l of the step.
-// Work item = (lane, rb, cb): rows [128 rb, +128) of columns [128 cb, +128) of lane l.  A 32-row block r32 has 2 (r32 + 1) groups;
-// k_fr_prod32's runs of a row block with nst sub-stages are chunks of ceil(nst / 8) sub-stages.
+// k_fb_prod: one 128 x 128 tile of a product whose B operand is a lane's planes, for every lane l of the step.
+// Work item = (lane, rb, cb): rows [128 rb, +128) of columns [128 cb, +128) of lane l.  A 32-row block r32 of tril(C) has 2 (r32 + 1) groups.
 // Software pipeline: iteration g computes on the fragments of stage g (already in registers) while the fragments of stage g + 1 are read
 // from LDS and the DMA of stage g + kRing is issued.  Per iteration: wait for the own pieces of stage g + 1, barrier (stage g + 1 has landed
-// for every wave; every wave has read stage g, whose slot stage g + kRing takes), issue, read, 12 WJ MFMAs.
-// -----------------------------------------------------------------------------------------------------------------
-// PF = 1: fragments of the next group prefetched into registers (ONE workgroup per CU, four ring slots); PF = 0: no register prefetch, three
-// ring slots, at most 128 registers: TWO workgroups per CU cover each other's barriers, read latencies, prologues and epilogues.
-// MODE (k_fr_prod32's epilogue modes): FB_DIAG: the fused diagonal-Gaussian target, W planes + ell partials (R_DIAG);
-//   FB_DENSE_R: R = (mu + tril(C) eps) - m as the B-operand planes of the dense target's product (R_DENSE_R);
-//   FB_DENSE_G: the dense target's product itself, G = -P R: A = the planes of P over the WHOLE K range (every row block d / 32 sub-stages:
-//   runs of ceil(d / 256) for all of them), B = R's planes, epilogue g = -(P r), ell += r g / 2 (R_DENSE_G), W planes + ell partials.
+// for every wave; every wave has read stage g, whose slot stage g + kRing takes), issue, read, 6 WJ MFMAs.
+// MODE: FB_DIAG: A = tril(C), B = eps; epilogue = the fused diagonal-Gaussian target: W planes (the VJP's A operand) + ell partials;
+//   FB_DENSE_R: the same product, epilogue R = (mu + tril(C) eps) - m as the B-operand planes of the dense target's product;
+//   FB_DENSE_G: the dense target's product itself, G = -P R: A = the planes of P over the WHOLE K range, B = R's planes -- scaled per
+//   (sample, 128-row block): the chain accumulator is folded into the total every eight groups with the block's inverse scales --,
+//   epilogue g = -(P r), ell += r g / 2, W planes + ell partials;
 //   FB_STL_U: the sticking-the-landing term, W += C^-T eps: A = the planes of C^-T (upper triangular: a tile's K range starts at its first
-//   row and runs to the end), B = eps' planes, epilogue: the lane's W planes read back, + U, split and stored again.  No counterpart among
-//   the one-estimate kernels (they SOLVE C^T X = eps, kernels_stl.hip): one chain over the tile's K range, results equal to the solve's to
-//   rounding (tests/test_gpu_each.py states the tolerance).
+//   row and runs to the end), B = eps' planes, epilogue: the lane's W planes read back, + U, re-scaled, split and stored again.  No
+//   counterpart among the one-estimate kernels (they SOLVE C^T X = eps, kernels_stl.hip).
+// Epilogues that produce an operand: the values go to wave-private LDS images, the tile's maxima (per row over its 128 samples for W, per
+// sample over its 128 rows for R) cross the waves through LDS once, then the images are scaled, split and stored as fragments.
+// -----------------------------------------------------------------------------------------------------------------
 enum { FB_DIAG = 0, FB_DENSE_R = 1, FB_DENSE_G = 2, FB_STL_U = 3 };
-template <int WJ, int PF, int MODE>
-__global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbArgs a) {
-  constexpr bool kDG = MODE == FB_DENSE_G, kSU = MODE == FB_STL_U;
-  constexpr int LDC = 36, NF = WJ, kPW = 3 * WJ;   // fragments / pieces this wave stages per group
-  constexpr int NR = PF ? kRing : 3;
-  __shared__ __attribute__((aligned(16))) unsigned lds[NR * kStageW + 3 * 128];
-  float *vec = reinterpret_cast<float *>(lds + NR * kStageW);   // mu, target mean, target 1 / std of the tile's rows
+template <int WJ, int MODE>
+__global__ __launch_bounds__(512 / WJ, 2 / WJ) void k_fb_prod(FbArgs a) {
+  constexpr bool kDG = MODE == FB_DENSE_G, kSU = MODE == FB_STL_U, kDR = MODE == FB_DENSE_R;
+  constexpr int LDC = 36, NF = WJ, kPW = 2 * WJ;   // fragments / pieces this wave stages per group
+  constexpr int NW = 8 / WJ, NWN = 4 / WJ;         // waves; waves along the columns
+  constexpr int kBody = (kRing * kStageW > 16 * kImgW) ? kRing * kStageW : 16 * kImgW;   // the ring, later the waves' epilogue images
+  constexpr int kTab = kDG ? 2048 : 0;             // DENSE_G: R's inverse scales of the tile's 128 samples, every 128-row block (d <= 2048)
+  __shared__ __attribute__((aligned(16))) unsigned lds[kBody + 4 * 128 + NW * 64 + kTab];
+  float *vec = reinterpret_cast<float *>(lds + kBody);          // [4][128]: mu, target mean, target 1 / std, the rows' output factor
+  float *red = vec + 4 * 128;                                   // [NW][64]: the waves' maxima
+  float *tab = red + NW * 64;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w / (4 / WJ), wn = w % (4 / WJ);
+  const int wm = w / NWN, wn = w % NWN;
   const __attribute__((address_space(4))) int *wp = (const __attribute__((address_space(4))) int *)a.work + 4 * blockIdx.x;
   const int ln = wp[0], rc = wp[1], flags = wp[2];
   const int rb = rc & 0xffff, cb = rc >> 16;
@@ -282,12 +303,20 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
   const int R0 = row0 >> 5;               // first 32-row block of the tile
   const int g0 = kSU ? 2 * R0 : 0;        // first group of the K range
   const int G = kDG ? ng : (kSU ? ng - g0 : 2 * (R0 + 4));  // groups of the workgroup (the last row block's K; the dense product: all of K)
-  if (tid < 128 && !kDG && !kSU) {
-    vec[tid] = a.params[row0 + tid];
-    vec[128 + tid] = a.t_mean[row0 + tid];
-    if (MODE == FB_DIAG) vec[256 + tid] = a.t_istd[row0 + tid];
+  if (tid < 128) {
+    if constexpr (!kDG && !kSU) {
+      vec[tid] = a.params[row0 + tid];
+      vec[128 + tid] = a.t_mean[row0 + tid];
+      if (MODE == FB_DIAG) vec[256 + tid] = a.t_istd[row0 + tid];
+    }
+    const float *sc = kDG ? a.pscale : (kSU ? a.tscale : a.cscale);
+    vec[384 + tid] = sc[d + row0 + tid] * ((kDG) ? 1.f : kEpsInv);   // what a row's raw sums are multiplied by
   }
-  // this wave's NF fragments of a stage (fragment f of the stage: f < 4: A fragment f; else B fragment f - 4; three 1 KiB pieces each)
+  if constexpr (kDG) {
+    const float *ri = a.rinv + (size_t)ln * (size_t)(d >> 7) * a.M;
+    for (int i = tid; i < d; i += 512 / WJ) tab[i] = ri[(size_t)(i >> 7) * a.M + col0 + (i & 127)];
+  }
+  // this wave's NF fragments of a stage
   const unsigned *sp[NF];   // the stage the next issue takes
   int gmax[NF];             // last group of the fragment that is ever read (tril(C): the diagonal block + two zero groups: clamped beyond)
 #pragma unroll
@@ -305,10 +334,9 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
   auto issue = [&](int slot) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      unsigned *dst = lds + slot * kStageW + (NF * w + f) * 768;
+      unsigned *dst = lds + slot * kStageW + (NF * w + f) * 512;
       FB_GLDS16(sp[f], dst, 0);
       FB_GLDS16(sp[f], dst, 1024);
-      FB_GLDS16(sp[f], dst, 2048);
       sp[f] += gd < gmax[f] ? kFrag : 0;
     }
     ++gd;
@@ -321,31 +349,24 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
   const int r32[2] = {R0 + 2 * wm, R0 + 2 * wm + 1};
-  // k_fr_prod32's runs are chunks of ceil(nst / 8) sub-stages -- the same chunk for this wave's two row blocks (nst = r32[1] and r32[1] + 1,
-  // the first odd): ONE fold schedule, every 2 rc groups
-  const int rc2 = kSU ? (1 << 30) : (kDG ? 2 * (((d >> 5) + 7) >> 3) : 2 * ((r32[1] + 1 + 7) >> 3));
-  FB_STAMP(a, 0);
-  FB_STAMP(a, 1);
   // A wave computes groups 0 .. Gw - 1 (its second row block's K range: a multiple of four groups) with BOTH row blocks, unconditionally:
-  // one straight MFMA block per group (a choice between a full and a half group per iteration made the compiler copy the accumulators
-  // behind every group, i.e. wait for the matrix pipe to drain).  The first row block ends two groups earlier: k_fb_cplanes laid two zero
-  // fragments behind its diagonal block, so its chain adds exact zeros there.
+  // one straight MFMA block per group.  The first row block ends two groups earlier: its planes carry two zero fragments behind its
+  // diagonal block, so its chain adds exact zeros there.
   const int Gw = (kDG || kSU) ? G : 2 * r32[1] + 2;
-  int gfold = rc2;   // the next run boundary (even: checked on even groups only)
   auto compute = [&](auto S, int g, const FbFrags<WJ> &F) {   // S = g mod kRing
-    if (!MIVI_KNOCKED(a, 2)) fb_group<WJ>(F, acc);
-    if constexpr (PF) fb_sched_interleave<WJ>();
-    if constexpr ((decltype(S)::value & 1) == 1) {   // (behind the MFMAs: the block in front of them stays one basic block; S = -1: every group)
-      if (__builtin_expect(g + 1 == gfold, 0)) {     // a run ended with this group
-        gfold += rc2;
+    fb_group<WJ>(F, acc);
+    fb_sched_interleave<WJ>();
+    if constexpr (kDG && decltype(S)::value == 3) {   // (behind the MFMAs: the block in front of them stays one basic block)
+      if (((g + 1) & 7) == 0) {                        // a 128-row block of R ended with this group: its inverse scales, per column
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < WJ; ++j) {
+          const float f = tab[((g >> 3) << 7) + 32 * (WJ * wn + j) + l31];
 #pragma unroll
-          for (int j = 0; j < WJ; ++j) {
-            tot[i][j] += acc[i][j];
+          for (int i = 0; i < 2; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { tot[i][j][r] = __builtin_fmaf(acc[i][j][r], f, tot[i][j][r]); acc[i][j][r] = 0.f; }
           }
+        }
         asm volatile("" ::: "memory");
       }
     }
@@ -355,190 +376,207 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_prod(FbAr
   auto step = [&](auto S, auto VM, auto ISS, auto CMP, int g, const FbFrags<WJ> &Fc, FbFrags<WJ> &Fn) {
     constexpr int sl = decltype(S)::value;
     fb_wait_vm<kPW * decltype(VM)::value>();
-    if (!MIVI_KNOCKED(a, 64)) fb_barrier();
-    if constexpr (decltype(ISS)::value) {
-      if (!MIVI_KNOCKED(a, 1)) issue(sl);
-    }
+    fb_barrier();
+    if constexpr (decltype(ISS)::value) issue(sl);
     if constexpr (decltype(CMP)::value) {
-      if (!MIVI_KNOCKED(a, 32)) fb_read_frags<WJ>(lds, MIVI_KNOCKED(a, 4) ? 0 : (sl + 1) % kRing, wm, wn, lane, Fn);
+      fb_read_frags<WJ>(lds, (sl + 1) % kRing, wm, wn, lane, Fn);
       compute(S, g, Fc);
     }
   };
-  if constexpr (PF) {
   static_assert(kRing == 4, "the unrolled loops below are written for four slots");
   issue(0); issue(1); issue(2); issue(3);   // (G >= 8)
   fb_wait_vm<kPW * 3>();
   fb_barrier();
-  FbFrags<WJ> F0, F1;
-  fb_read_frags<WJ>(lds, 0, wm, wn, lane, F0);
-  int g = 0;
-  for (; g + 4 < G; g += 4) {   // (G is a multiple of eight; Gw = G for the waves of the tile's lower half, G - 4 for the upper half's)
-    step(FbI0{}, FbI2{}, FbT{}, FbT{}, g, F0, F1);
-    step(FbI1{}, FbI2{}, FbT{}, FbT{}, g + 1, F1, F0);
-    step(FbI2{}, FbI2{}, FbT{}, FbT{}, g + 2, F0, F1);
-    step(FbI3{}, FbI2{}, FbT{}, FbT{}, g + 3, F1, F0);
-  }
-  if (g < Gw) {   // the last four groups: nothing left to request
-    step(FbI0{}, FbI2{}, FbN{}, FbT{}, g, F0, F1);
-    step(FbI1{}, FbI1{}, FbN{}, FbT{}, g + 1, F1, F0);
-    step(FbI2{}, FbI0{}, FbN{}, FbT{}, g + 2, F0, F1);
-    compute(FbI3{}, g + 3, F1);
-  } else {        // (the upper half's K range has ended: its waves only keep the barriers)
-    step(FbI0{}, FbI2{}, FbN{}, FbN{}, g, F0, F1);
-    step(FbI1{}, FbI1{}, FbN{}, FbN{}, g + 1, F1, F0);
-    step(FbI2{}, FbI0{}, FbN{}, FbN{}, g + 2, F0, F1);
-  }
-  } else {
-    // plain loop: wait for stage g, barrier, request stage g + 2 into the slot of stage g - 1, read, compute -- the other workgroup of the CU
-    // runs its MFMAs under this one's waits
-    issue(0); issue(1);
-    int slot = 0;
-    for (int g = 0; g < G; ++g) {
-      if (g + 1 < G) fb_wait_vm<kPW>();
-      else fb_wait_vm<0>();
-      if (!MIVI_KNOCKED(a, 64)) fb_barrier();
-      if (g + 2 < G && !MIVI_KNOCKED(a, 1)) issue(slot == 0 ? 2 : slot - 1);
-      if (g < Gw) {
-        FbFrags<WJ> F;
-        fb_read_frags<WJ>(lds, slot, wm, wn, lane, F);
-        compute(std::integral_constant<int, -1>{}, g, F);
-      }
-      slot = slot == 2 ? 0 : slot + 1;
+  {
+    FbFrags<WJ> F0, F1;
+    fb_read_frags<WJ>(lds, 0, wm, wn, lane, F0);
+    int g = 0;
+    for (; g + 4 < G; g += 4) {   // (G is a multiple of eight; Gw = G for the waves of the tile's lower half, G - 4 for the upper half's)
+      step(FbI0{}, FbI2{}, FbT{}, FbT{}, g, F0, F1);
+      step(FbI1{}, FbI2{}, FbT{}, FbT{}, g + 1, F1, F0);
+      step(FbI2{}, FbI2{}, FbT{}, FbT{}, g + 2, F0, F1);
+      step(FbI3{}, FbI2{}, FbT{}, FbT{}, g + 3, F1, F0);
+    }
+    if (g < Gw) {   // the last four groups: nothing left to request
+      step(FbI0{}, FbI2{}, FbN{}, FbT{}, g, F0, F1);
+      step(FbI1{}, FbI1{}, FbN{}, FbT{}, g + 1, F1, F0);
+      step(FbI2{}, FbI0{}, FbN{}, FbT{}, g + 2, F0, F1);
+      compute(FbI3{}, g + 3, F1);
+    } else {        // (the upper half's K range has ended: its waves only keep the barriers)
+      step(FbI0{}, FbI2{}, FbN{}, FbN{}, g, F0, F1);
+      step(FbI1{}, FbI1{}, FbN{}, FbN{}, g + 1, F1, F0);
+      step(FbI2{}, FbI0{}, FbN{}, FbN{}, g + 2, F0, F1);
     }
   }
+  if constexpr (!kDG) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < WJ; ++j) tot[i][j] += acc[i][j];   // the last run
+      for (int j = 0; j < WJ; ++j) tot[i][j] = acc[i][j];
+  }
   fb_barrier();   // every wave is done with the ring: LDS becomes the waves' private epilogue images
-  FB_STAMP(a, 2);
-  if (MIVI_KNOCKED(a, 16)) { if (tot[0][0][0] == 123.f) a.ld_part[0] = tot[1][WJ - 1][3] + tot[0][0][2]; return; }
-  float *Cs = reinterpret_cast<float *>(lds) + w * (32 * LDC);
+  float *img = reinterpret_cast<float *>(lds) + w * (2 * WJ * kImgW);   // image (i, j) at img + (i WJ + j) kImgW: [column][row], then W[m][i]
   unsigned *WVl = a.WV + (size_t)ln * a.plane_stride;
   unsigned *RPl = a.RP + (size_t)ln * a.plane_stride;
   double *ellp = a.ell_part + (size_t)ln * a.ell_stride;
-  const int nrb = d >> 5, ncb = a.M >> 5, nmg = a.M >> 4;
-  const bool xcd_slots = (nrb & 3) == 0 && (ncb & 1) == 0;   // (k_fr_prod32's block -> tile map)
+  const int ncb = a.M >> 5, nmg = a.M >> 4;
   const int ei4 = 4 * (lane & 7);
+  float amax[2][4];        // W-producing modes: rows ei4 .. ei4 + 3 of block i over this lane's columns; STL: amax[i][0] = row l31 of block i
+  float cmax[WJ][4];       // DENSE_R: column 8 p + lane / 8 of block j over this lane's rows
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) amax[i][c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < WJ; ++j)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) cmax[j][p] = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int lr = 64 * wm + 32 * i;   // row offset inside the tile
     f32x4 mu = {0.f, 0.f, 0.f, 0.f}, tm = mu, tis = mu;
-    if constexpr (kSU) {
-      // U's 32 x 32 tile (image [sample][row]) added to this wave's two W fragments in place
-#pragma unroll
-      for (int j = 0; j < WJ; ++j) {
-        const int cb32 = (col0 >> 5) + WJ * wn + j;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 v = {tot[i][j][4 * q], tot[i][j][4 * q + 1], tot[i][j][4 * q + 2], tot[i][j][4 * q + 3]};
-          *(f32x4 *)(Cs + l31 * LDC + 8 * q + 4 * h) = v;
-        }
-#pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
-          unsigned *dst = WVl + ((size_t)r32[i] * nmg + 2 * cb32 + g2) * kFrag + 4 * lane;
-          const u32x4v wh = *(const u32x4v *)dst, wmid = *(const u32x4v *)(dst + 256), wl = *(const u32x4v *)(dst + 512);
-          float x[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] = fb_unsplit(wh, wmid, wl, e) + Cs[(16 * g2 + 8 * (e >> 2) + 4 * h + (e & 3)) * LDC + l31];
-          u32x4v uh, um, ul;
-          fb_split3(x, uh, um, ul);
-          store16_wt(dst, uh);
-          store16_wt(dst + 256, um);
-          store16_wt(dst + 512, ul);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      continue;
-    }
-    if constexpr (!kDG) {
+    const f32x4 zf = *(const f32x4 *)(vec + 384 + lr + ei4);
+    if constexpr (!kDG && !kSU) {
       mu = *(const f32x4 *)(vec + lr + ei4);
       tm = *(const f32x4 *)(vec + 128 + lr + ei4);
       if constexpr (MODE == FB_DIAG) tis = *(const f32x4 *)(vec + 256 + lr + ei4);
     }
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
+      float *I = img + (i * WJ + j) * kImgW;
       const int cb32 = (col0 >> 5) + WJ * wn + j;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 v = {tot[i][j][4 * q], tot[i][j][4 * q + 1], tot[i][j][4 * q + 2], tot[i][j][4 * q + 3]};
-        *(f32x4 *)(Cs + l31 * LDC + 8 * q + 4 * h) = v;
+        *(f32x4 *)(I + l31 * LDC + 8 * q + 4 * h) = v;
+      }
+      if constexpr (kSU) {
+        // U's 32 x 32 tile (image [sample][row]) added to this wave's two W fragments: the new W stays in the image
+        const float uf = vec[384 + lr + l31];
+        const float wo = a.winv[(size_t)ln * (size_t)(a.M >> 7) * d + (size_t)cb * d + row0 + lr + l31];
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+          const unsigned *src = WVl + ((size_t)r32[i] * nmg + 2 * cb32 + g2) * kFrag + 4 * lane;
+          const u32x4v wh = *(const u32x4v *)src, wl = *(const u32x4v *)(src + 256);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float *p = I + (16 * g2 + 8 * (e >> 2) + 4 * h + (e & 3)) * LDC + l31;
+            const float x = __builtin_fmaf(*p, uf, fb_unsplit2(wh, wl, e) * wo);
+            *p = x;
+            amax[i][0] = fmaxf(amax[i][0], fabsf(x));
+          }
+        }
+        continue;
       }
       double s = 0.0;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {   // pass p = wave p of k_fr_prod32's epilogue: columns 8 p .. 8 p + 7, rows ei4 .. ei4 + 3 per lane
+      for (int p = 0; p < 4; ++p) {   // pass p: columns 8 p .. 8 p + 7, rows ei4 .. ei4 + 3 per lane
         const int en = 8 * p + (lane >> 3);
-        const f32x4 v = *(const f32x4 *)(Cs + en * LDC + ei4);
+        const f32x4 v = *(const f32x4 *)(I + en * LDC + ei4) * zf;
         float ell = 0.f;
         f32x4 wv;
         if constexpr (MODE == FB_DIAG) {
           const f32x4 z = mu + v;
 #pragma unroll
           for (int c = 0; c < 4; ++c) wv[c] = diag_target_elem(z[c], tm[c], tis[c], ell);
-        } else if constexpr (MODE == FB_DENSE_R) {
+        } else if constexpr (kDR) {
           const f32x4 z = mu + v;
           wv = z - tm;
         } else {
-          // r = (z - m)[rows ei4 .. + 3, column en] back from R's planes, exactly (hi + mid + lo; the pieces do not overlap): fragment
-          // (cb32, kg = 2 r32 + ei4 / 16), lane (en, h' = ei4 / 4 % 2), slots 4 (ei4 / 8 % 2) + c = the two words 2 (ei4 / 8 % 2) + {0, 1}
+          // r = (z - m)[rows ei4 .. + 3, column en] back from R's planes: fragment (cb32, kg = 2 r32 + ei4 / 16), lane (en, h' = ei4 / 4 % 2),
+          // slots 4 (ei4 / 8 % 2) + c = the two words 2 (ei4 / 8 % 2) + {0, 1}; times the inverse scale of (sample en, this 128-row block)
           const unsigned *fr = RPl + ((size_t)cb32 * ng + 2 * r32[i] + (ei4 >> 4)) * kFrag + 4 * (en + 32 * ((ei4 >> 2) & 1)) + 2 * ((ei4 >> 3) & 1);
-          const uint2 qh = *(const uint2 *)fr, qm = *(const uint2 *)(fr + 256), ql = *(const uint2 *)(fr + 512);
-          const unsigned uh[2] = {qh.x, qh.y}, um[2] = {qm.x, qm.y}, ul[2] = {ql.x, ql.y};
+          const uint2 qh = *(const uint2 *)fr, ql = *(const uint2 *)(fr + 256);
+          const float rs = tab[(rb << 7) + 32 * (WJ * wn + j) + en];
+          const unsigned uh[2] = {qh.x, qh.y}, ul[2] = {ql.x, ql.y};
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const unsigned hh = (c & 1) ? (uh[c >> 1] & 0xFFFF0000u) : (uh[c >> 1] << 16), mm = (c & 1) ? (um[c >> 1] & 0xFFFF0000u) : (um[c >> 1] << 16),
-                           ll = (c & 1) ? (ul[c >> 1] & 0xFFFF0000u) : (ul[c >> 1] << 16);
-            const float r = (__builtin_bit_cast(float, hh) + __builtin_bit_cast(float, mm)) + __builtin_bit_cast(float, ll);
-            wv[c] = dense_target_elem(v[c], r, ell);
-          }
+          for (int c = 0; c < 4; ++c) wv[c] = dense_target_elem(v[c], fb_unsplit2_word(uh[c >> 1], ul[c >> 1], c & 1) * rs, ell);
         }
-        *(f32x4 *)(Cs + en * LDC + ei4) = wv;   // the image becomes W[m][i] (FB_DENSE_R: R[m][i])
-        if constexpr (MODE != FB_DENSE_R) {
+        *(f32x4 *)(I + en * LDC + ei4) = wv;   // the image becomes W[m][i] (FB_DENSE_R: R[m][i])
+        if constexpr (kDR) {
+          cmax[j][p] = fmaxf(cmax[j][p], fmaxf(fmaxf(fabsf(wv[0]), fabsf(wv[1])), fmaxf(fabsf(wv[2]), fabsf(wv[3]))));
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) amax[i][c] = fmaxf(amax[i][c], fabsf(wv[c]));
           const double sv = (double)wave_sum_f32(ell);
           s = p ? s + sv : sv;
         }
       }
-      if constexpr (MODE != FB_DENSE_R) {
-        s += 0.0;   // (k_fr_prod32 adds its four idle waves' zeros: -0.0 becomes +0.0 there)
-        if (lane == 0) {
-          const int rE = nrb - 1 - r32[i];
-          const int slot = xcd_slots ? ((rE & 3) + 4 * (cb32 & 1)) + 8 * ((rE >> 2) * (ncb >> 1) + (cb32 >> 1)) : rE * ncb + cb32;
-          ellp[slot] = s;
-        }
+      if constexpr (!kDR) {
+        if (lane == 0) ellp[(size_t)r32[i] * ncb + cb32] = s;
       }
-      if constexpr (MODE == FB_DENSE_R) {
-        // R as the dense product's B fragments (mb32 = cb32, kg = 2 r32 + g2): lane (column l31, h), slots = rows 16 g2 + 8 (e / 4) + 4 h + e % 4
+    }
+  }
+  // the tile's maxima: across the lanes of a wave, then across the waves that share the rows (W) / the columns (R)
+  if constexpr (kDR) {
+#pragma unroll
+    for (int j = 0; j < WJ; ++j)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float m = fb_lane_max<7>(cmax[j][p]);
+        if ((lane & 7) == 0) red[w * 64 + 32 * j + 8 * p + (lane >> 3)] = m;
+      }
+  } else if constexpr (kSU) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float m = fb_lane_max<32>(amax[i][0]);
+      if (lane < 32) red[w * 64 + 32 * i + lane] = m;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float m = fb_lane_max<56>(amax[i][c]);
+        if (lane < 8) red[w * 64 + 32 * i + ei4 + c] = m;
+      }
+  }
+  fb_barrier();
+  if constexpr (kDR) {
+    // R as the dense product's B fragments (mb32 = cb32, kg = 2 r32 + g2): lane (column l31, h), slots = rows 16 g2 + 8 (e / 4) + 4 h + e % 4
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      const int cb32 = (col0 >> 5) + WJ * wn + j;
+      float s, inv;
+      fb_scale_of(fmaxf(red[wn * 64 + 32 * j + l31], red[(NWN + wn) * 64 + 32 * j + l31]), s, inv);
+      if (wm == 0 && lane < 32) a.rinv[(size_t)ln * (size_t)(d >> 7) * a.M + (size_t)rb * a.M + col0 + 32 * (WJ * wn + j) + lane] = inv;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float *I = img + (i * WJ + j) * kImgW;
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
-          const f32x4 x0 = *(const f32x4 *)(Cs + l31 * LDC + 16 * g2 + 4 * h), x1 = *(const f32x4 *)(Cs + l31 * LDC + 16 * g2 + 8 + 4 * h);
+          const f32x4 x0 = *(const f32x4 *)(I + l31 * LDC + 16 * g2 + 4 * h) * s, x1 = *(const f32x4 *)(I + l31 * LDC + 16 * g2 + 8 + 4 * h) * s;
           const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-          u32x4v uh, um, ul;
-          fb_split3(x, uh, um, ul);
-          unsigned *dst = RPl + ((size_t)cb32 * ng + 2 * r32[i] + g2) * kFrag + 4 * lane;
-          store16_wt(dst, uh);
-          store16_wt(dst + 256, um);
-          store16_wt(dst + 512, ul);
+          fb_store_frag(RPl + ((size_t)cb32 * ng + 2 * r32[i] + g2) * kFrag + 4 * lane, x);
         }
-      } else {
-        // W as the VJP's A fragments (rb32 = r32[i], mg = 2 cb32 + g2): lane (row l31, h), slots = samples 16 g2 + 8 (e / 4) + 4 h + e % 4
+      }
+    }
+  } else {
+    // W as the VJP's A fragments (rb32 = r32[i], mg = 2 cb32 + g2): lane (row l31, h), slots = samples 16 g2 + 8 (e / 4) + 4 h + e % 4
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float mx = red[(wm * NWN) * 64 + 32 * i + l31];
+#pragma unroll
+      for (int x = 1; x < NWN; ++x) mx = fmaxf(mx, red[(wm * NWN + x) * 64 + 32 * i + l31]);
+      float s, inv;
+      fb_scale_of(mx, s, inv);
+      if (wn == 0 && lane < 32) a.winv[(size_t)ln * (size_t)(a.M >> 7) * d + (size_t)cb * d + row0 + 64 * wm + 32 * i + lane] = inv;
+#pragma unroll
+      for (int j = 0; j < WJ; ++j) {
+        const float *I = img + (i * WJ + j) * kImgW;
+        const int cb32 = (col0 >> 5) + WJ * wn + j;
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
           float x[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] = Cs[(16 * g2 + 8 * (e >> 2) + 4 * h + (e & 3)) * LDC + l31];
-          u32x4v uh, um, ul;
-          fb_split3(x, uh, um, ul);
-          unsigned *dst = WVl + ((size_t)r32[i] * nmg + 2 * cb32 + g2) * kFrag + 4 * lane;
-          store16_wt(dst, uh);
-          store16_wt(dst + 256, um);
-          store16_wt(dst + 512, ul);
+          for (int e = 0; e < 8; ++e) x[e] = I[(16 * g2 + 8 * (e >> 2) + 4 * h + (e & 3)) * LDC + l31] * s;
+          fb_store_frag(WVl + ((size_t)r32[i] * nmg + 2 * cb32 + g2) * kFrag + 4 * lane, x);
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is read before the next tile overwrites it
     }
   }
-  FB_STAMP(a, 3);
   if (!kDG && !kSU && (flags & 1) && wn == 0 && lane < 32) {   // log|det C| partials of this wave's two row blocks (lane 0's first column block carries the flag)
+    const int nrb = d >> 5;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int r = 32 * r32[i] + lane;
@@ -575,23 +613,23 @@ __device__ __forceinline__ void fb_value_block(const FbArgs &a, int l, double *r
   const float *pp = a.params;
   finalize_value_block<float, 256, false>(d, vin, out, (int64_t)d + (int64_t)d * d, [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, red);
 }
-__global__ __launch_bounds__(256) void k_fb_value(FbArgs a) {   // (stand-alone form: tools/ubench_fb.hip)
-  __shared__ double red[4 * 4];
-  fb_value_block(a, blockIdx.x, red);
-}
 
 // -----------------------------------------------------------------------------------------------------------------
 // k_fb_vjp: dC_l = -(1/M) tril(W_l eps_l') - direct diag(1 / C_ii), dmu_l = -(1/M) W_l 1, for every lane l of the step.
-// Work item = (lane, rb, cb), cb <= rb: the 128 x 128 tile of the lower triangle; K = M samples = M / 16 groups.
-// k_fr_vjp32's four runs = the K quarters; a wave whose sub-tiles all lie strictly above the diagonal only carries its share of the
-// staging, the exact zeros of the upper triangle are written as the mirror images of the strictly lower 32 x 32 blocks (lanes with the
-// write_upper duty).
+// Work item = (lane, rb, cb), cb <= rb: the 128 x 128 tile of the lower triangle; K = M samples = M / 16 groups.  W's planes are scaled per
+// (row, 128-sample block): every eight groups the chain accumulator is folded into the total with the block's inverse row scales (staged
+// in LDS once per workgroup).  A wave whose sub-tiles all lie strictly above the diagonal only carries its share of the staging; the
+// exact zeros of the upper triangle are written as the mirror images of the strictly lower 32 x 32 blocks (lanes with the write_upper
+// duty).  d/dmu: the waves of the diagonal tiles sum W's fragments (hi + lo, times the block's inverse scale).  The step's objective
+// values ride as extra workgroups.
 // -----------------------------------------------------------------------------------------------------------------
 template <int WJ, int PF>
 __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArgs a) {
-  constexpr int LDC = 36, NF = WJ, kPW = 3 * WJ;
+  constexpr int LDC = 36, NF = WJ, kPW = 2 * WJ;
   constexpr int NR = PF ? kRing : 3;
-  __shared__ __attribute__((aligned(16))) unsigned lds[NR * kStageW];
+  constexpr int kBody = (NR * kStageW > 16 * kImgW / 2) ? NR * kStageW : 16 * kImgW / 2;   // the ring, later one image per wave
+  __shared__ __attribute__((aligned(16))) unsigned lds[kBody + 2048];
+  float *wf = reinterpret_cast<float *>(lds + kBody);   // [M / 128][128]: inverse scales of W's rows of this tile, per 128-sample block (M <= 2048)
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w / (4 / WJ), wn = w % (4 / WJ);
@@ -607,7 +645,11 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
   const bool last = ln == a.lane_last && a.grad_last;
   float *grad = last ? a.grad_last : a.grads + (size_t)ln * a.grad_stride;
   const bool upper = a.write_upper || last;
-  const int G = nmg, gq = G >> 2;   // groups; per K quarter
+  const int G = nmg;
+  {
+    const float *wi = a.winv + (size_t)ln * (size_t)(M >> 7) * d + row0;
+    for (int i = tid; i < M; i += 512 / WJ) wf[i] = wi[(size_t)(i >> 7) * d + (i & 127)];
+  }
   const unsigned *sp[NF];           // the stage the next issue takes
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
@@ -618,10 +660,9 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
   auto issue = [&](int slot) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
-      unsigned *dst = lds + slot * kStageW + (NF * w + f) * 768;
+      unsigned *dst = lds + slot * kStageW + (NF * w + f) * 512;
       FB_GLDS16(sp[f], dst, 0);
       FB_GLDS16(sp[f], dst, 1024);
-      FB_GLDS16(sp[f], dst, 2048);
       sp[f] += kFrag;
     }
   };
@@ -645,40 +686,38 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
     for (int j = 0; j < WJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
-  float rs[2][4];      // d/dmu: this lane's partial row sums of W, per row block and K quarter (k_fr_vjp32's rsum of wave q, half h)
+  double rsd[2] = {0.0, 0.0};   // d/dmu: this lane's share (row l31, its half of the k slots) of the row sums of W
   float rcur[2] = {0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) rs[i][q] = 0.f;
-  FB_STAMP(a, 0);
-  FB_STAMP(a, 1);
-  int gfold = gq;   // the next K-quarter boundary (gq is even: checked on even groups only)
   // A wave with work computes ALL its sub-tiles in every group (one straight MFMA block: see k_fb_prod); a sub-tile strictly above the
   // diagonal (diagonal tiles only) is simply not stored.
   auto compute = [&](auto S, int g, const FbFrags<WJ> &F) {
-    if (!MIVI_KNOCKED(a, 2)) fb_group<WJ>(F, acc);
+    fb_group<WJ>(F, acc);
     if constexpr (PF) fb_sched_interleave<WJ>();
     if (__builtin_expect(dg[0] || dg[1], 0)) {   // (two waves of a diagonal tile; behind the MFMAs: the block in front of them stays one basic block)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         if (dg[i]) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) rcur[i] += fb_unsplit(F.A[i][0], F.A[i][1], F.A[i][2], e);
+          for (int e = 0; e < 8; ++e) rcur[i] += fb_unsplit2(F.A[i][0], F.A[i][1], e);
         }
     }
-    if constexpr ((decltype(S)::value & 1) == 1) {
-      if (__builtin_expect(g + 1 == gfold && g + 1 < G, 0)) {   // a K quarter (but the last) ended with this group
-        gfold += gq;
+    if constexpr (decltype(S)::value == 3 || decltype(S)::value == -1) {
+      if (((g + 1) & 7) == 0) {   // a 128-sample block ended with this group: fold with its inverse row scales
+        const float *wr = wf + ((g >> 3) << 7) + 64 * wm;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
-          for (int j = 0; j < WJ; ++j) {
-            tot[i][j] += acc[i][j];
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 f4 = *(const f32x4 *)(wr + 32 * i + 8 * q + 4 * h);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < WJ; ++j)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                tot[i][j][4 * q + c] = __builtin_fmaf(acc[i][j][4 * q + c], f4[c], tot[i][j][4 * q + c]);
+                acc[i][j][4 * q + c] = 0.f;
+              }
           }
-          rs[i][3] = rs[i][2]; rs[i][2] = rs[i][1]; rs[i][1] = rs[i][0]; rs[i][0] = rcur[i];   // (newest first: re-ordered at the end)
+          rsd[i] += (double)(rcur[i] * wr[32 * i + l31]);
           rcur[i] = 0.f;
         }
         asm volatile("" ::: "memory");
@@ -688,54 +727,54 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
   auto step = [&](auto S, auto VM, auto ISS, auto CMP, int g, const FbFrags<WJ> &Fc, FbFrags<WJ> &Fn) {   // (as in k_fb_prod)
     constexpr int sl = decltype(S)::value;
     fb_wait_vm<kPW * decltype(VM)::value>();
-    if (!MIVI_KNOCKED(a, 64)) fb_barrier();
-    if constexpr (decltype(ISS)::value) {
-      if (!MIVI_KNOCKED(a, 1)) issue(sl);
-    }
+    fb_barrier();
+    if constexpr (decltype(ISS)::value) issue(sl);
     if constexpr (decltype(CMP)::value) {
-      if (!MIVI_KNOCKED(a, 32)) fb_read_frags<WJ>(lds, MIVI_KNOCKED(a, 4) ? 0 : (sl + 1) % kRing, wm, wn, lane, Fn);
+      fb_read_frags<WJ>(lds, (sl + 1) % kRing, wm, wn, lane, Fn);
       compute(S, g, Fc);
     }
   };
   if constexpr (PF) {
-  static_assert(kRing == 4, "the unrolled loops below are written for four slots");
-  issue(0); issue(1); issue(2); issue(3);   // (G >= 8: M >= 128)
-  fb_wait_vm<kPW * 3>();
-  fb_barrier();
-  FbFrags<WJ> F0, F1;
-  fb_read_frags<WJ>(lds, 0, wm, wn, lane, F0);
-  if (work) {
-    int g = 0;
-    for (; g + 4 < G; g += 4) {   // (G is a multiple of 8)
-      step(FbI0{}, FbI2{}, FbT{}, FbT{}, g, F0, F1);
-      step(FbI1{}, FbI2{}, FbT{}, FbT{}, g + 1, F1, F0);
-      step(FbI2{}, FbI2{}, FbT{}, FbT{}, g + 2, F0, F1);
-      step(FbI3{}, FbI2{}, FbT{}, FbT{}, g + 3, F1, F0);
+    static_assert(kRing == 4, "the unrolled loops below are written for four slots");
+    issue(0); issue(1); issue(2); issue(3);   // (G >= 8: M >= 128)
+    fb_wait_vm<kPW * 3>();
+    fb_barrier();
+    FbFrags<WJ> F0, F1;
+    fb_read_frags<WJ>(lds, 0, wm, wn, lane, F0);
+    if (work) {
+      int g = 0;
+      for (; g + 4 < G; g += 4) {   // (G is a multiple of 8)
+        step(FbI0{}, FbI2{}, FbT{}, FbT{}, g, F0, F1);
+        step(FbI1{}, FbI2{}, FbT{}, FbT{}, g + 1, F1, F0);
+        step(FbI2{}, FbI2{}, FbT{}, FbT{}, g + 2, F0, F1);
+        step(FbI3{}, FbI2{}, FbT{}, FbT{}, g + 3, F1, F0);
+      }
+      step(FbI0{}, FbI2{}, FbN{}, FbT{}, g, F0, F1);
+      step(FbI1{}, FbI1{}, FbN{}, FbT{}, g + 1, F1, F0);
+      step(FbI2{}, FbI0{}, FbN{}, FbT{}, g + 2, F0, F1);
+      compute(FbI3{}, g + 3, F1);
+    } else {      // a wave above the diagonal: it only carries its share of the staging
+      int g = 0;
+      for (; g + 4 < G; g += 4) {
+        step(FbI0{}, FbI2{}, FbT{}, FbN{}, g, F0, F1);
+        step(FbI1{}, FbI2{}, FbT{}, FbN{}, g + 1, F1, F0);
+        step(FbI2{}, FbI2{}, FbT{}, FbN{}, g + 2, F0, F1);
+        step(FbI3{}, FbI2{}, FbT{}, FbN{}, g + 3, F1, F0);
+      }
+      step(FbI0{}, FbI2{}, FbN{}, FbN{}, g, F0, F1);
+      step(FbI1{}, FbI1{}, FbN{}, FbN{}, g + 1, F1, F0);
+      step(FbI2{}, FbI0{}, FbN{}, FbN{}, g + 2, F0, F1);
     }
-    step(FbI0{}, FbI2{}, FbN{}, FbT{}, g, F0, F1);
-    step(FbI1{}, FbI1{}, FbN{}, FbT{}, g + 1, F1, F0);
-    step(FbI2{}, FbI0{}, FbN{}, FbT{}, g + 2, F0, F1);
-    compute(FbI3{}, g + 3, F1);
-  } else {      // a wave above the diagonal: it only carries its share of the staging
-    int g = 0;
-    for (; g + 4 < G; g += 4) {
-      step(FbI0{}, FbI2{}, FbT{}, FbN{}, g, F0, F1);
-      step(FbI1{}, FbI2{}, FbT{}, FbN{}, g + 1, F1, F0);
-      step(FbI2{}, FbI2{}, FbT{}, FbN{}, g + 2, F0, F1);
-      step(FbI3{}, FbI2{}, FbT{}, FbN{}, g + 3, F1, F0);
-    }
-    step(FbI0{}, FbI2{}, FbN{}, FbN{}, g, F0, F1);
-    step(FbI1{}, FbI1{}, FbN{}, FbN{}, g + 1, F1, F0);
-    step(FbI2{}, FbI0{}, FbN{}, FbN{}, g + 2, F0, F1);
-  }
   } else {
-    issue(0); issue(1);   // (the plain loop of k_fb_prod<.., 0>)
+    // plain loop: wait for stage g, barrier, request stage g + 2 into the slot of stage g - 1, read, compute -- the other workgroup of the CU
+    // runs its MFMAs under this one's waits
+    issue(0); issue(1);
     int slot = 0;
     for (int g = 0; g < G; ++g) {
       if (g + 1 < G) fb_wait_vm<kPW>();
       else fb_wait_vm<0>();
-      if (!MIVI_KNOCKED(a, 64)) fb_barrier();
-      if (g + 2 < G && !MIVI_KNOCKED(a, 1)) issue(slot == 0 ? 2 : slot - 1);
+      fb_barrier();
+      if (g + 2 < G) issue(slot == 0 ? 2 : slot - 1);
       if (work) {
         FbFrags<WJ> F;
         fb_read_frags<WJ>(lds, slot, wm, wn, lane, F);
@@ -744,26 +783,15 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
       slot = slot == 2 ? 0 : slot + 1;
     }
   }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int j = 0; j < WJ; ++j) tot[i][j] += acc[i][j];
-    const float r3 = rcur[i], r2 = rs[i][0], r1 = rs[i][1], r0 = rs[i][2];   // quarters 3, 2, 1, 0
-    rs[i][0] = r0; rs[i][1] = r1; rs[i][2] = r2; rs[i][3] = r3;
-  }
   fb_barrier();
-  FB_STAMP(a, 2);
-  if (MIVI_KNOCKED(a, 16)) { if (tot[0][0][0] == 123.f) grad[0] = tot[1][WJ - 1][3] + tot[0][0][2]; return; }
-  float *Cs = reinterpret_cast<float *>(lds) + w * (32 * LDC);
+  float *Cs = reinterpret_cast<float *>(lds) + w * kImgW;
   const double invM = 1.0 / (double)a.M_total;
   const bool pow2M = (a.M_total & (a.M_total - 1)) == 0;
-  const float invMf = (float)invM;
+  const float invMe = (float)invM * kEpsInv;   // (eps' planes hold 2^11 eps)
   const double direct = direct_entropy_coeff(a.ent_kind);
   const int i4 = 4 * (lane & 7);
-  FB_STAMP(a, 4);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    if (i == 1) FB_STAMP(a, 5);
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
       if (cj[j] > ri[i]) continue;
@@ -775,20 +803,20 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
         *(f32x4 *)(Cs + l31 * LDC + 8 * q + 4 * h) = v;
       }
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {   // k_fr_vjp32's epilogue thread (i4, n) = lane of pass p
+      for (int p = 0; p < 4; ++p) {   // lane = (rows i4 .. i4 + 3, column n) of pass p
         const int n = 8 * p + (lane >> 3);
         const int gi = rbase + i4, gj = cbase + n;
         float cjj = 1.f;
         if (diag && gj >= gi && gj < gi + 4) cjj = a.params[d + (size_t)gj * d + gj];
         const f32x4 v = *(const f32x4 *)(Cs + n * LDC + i4);
         f32x4 o;
-        if (!diag && pow2M) {   // strictly below the diagonal, power-of-two sample count: vjp_elem's f32 branch for all four (no per-element branches)
-          o = -v * invMf;
+        if (!diag && pow2M) {   // strictly below the diagonal, power-of-two sample count: exact scaling, no per-element branches
+          o = -v * invMe;
         } else {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) o[c] = vjp_elem(v[c], gi + c, gj, pow2M, invMf, invM, direct, cjj);
+          for (int c = 0; c < 4; ++c) o[c] = vjp_elem(v[c] * kEpsInv, gi + c, gj, pow2M, (float)invM, invM, direct, cjj);
         }
-        if (!MIVI_KNOCKED(a, 8)) store16_wt(grad + d + (size_t)gj * d + gi, o);
+        store16_wt(grad + d + (size_t)gj * d + gi, o);
       }
       if (!diag && upper) {   // the mirrored, strictly upper 32 x 32 block is structurally zero
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -798,21 +826,13 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
           store16_wt(grad + d + (size_t)(rbase + ii) * d + cbase + i4, z4);
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is read before the next sub-tile overwrites it
     }
-    if (dg[i]) {   // d/dmu rows of this row block: k_fr_vjp32 sums the eight (wave q, half h) partials in the order 2 q + h, in f64
-      double sm = 0.0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float mine = rs[i][q], other = __shfl_xor(mine, 32, 64);
-        const float r0 = h ? other : mine, r1 = h ? mine : other;
-        sm += (double)r0;
-        sm += (double)r1;
-      }
+    if (dg[i]) {   // d/dmu rows of this row block: the two halves' shares
+      const double sm = rsd[i] + __shfl_xor(rsd[i], 32, 64);
       if (lane < 32) grad[32 * ri[i] + lane] = dmu_elem(sm, invM);
     }
   }
-  FB_STAMP(a, 3);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -820,8 +840,8 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
 // -----------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int kBM = 128, kBN = 128;
-constexpr int kWJ = 1;
-constexpr int kPFprod = 1, kPFvjp = 0;   // register prefetch + one workgroup per CU (product: its heaviest tile must own a CU) / two plain workgroups per CU (VJP: equal tiles)   // 32-column blocks per wave (k_fb_prod / k_fb_vjp): 2 = four waves of 64 x 64 per tile, 1 = eight waves of 64 x 32
+constexpr int kWJ = 1;      // 32-column blocks per wave (k_fb_prod / k_fb_vjp): 2 = four waves of 64 x 64 per tile, 1 = eight waves of 64 x 32
+constexpr int kPFvjp = 0;   // the product: register prefetch + one workgroup per CU (its heaviest tile must own a CU); the VJP: two plain workgroups per CU (equal tiles)
 
 void fb_upload(DevBuf &b, const void *src, size_t bytes) {
   if (b.bytes < bytes || !b.p) {
@@ -836,7 +856,7 @@ void fb_upload(DevBuf &b, const void *src, size_t bytes) {
 bool fb_shape_ok(const mivi_ctx *c, int M) {
   static const bool off = getenv("MIVI_BATCH_GEN3") && atoi(getenv("MIVI_BATCH_GEN3")) == 0;   // A/B: the lane-batched second-generation kernels
   return !off && c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && c->cfg.d % kBM == 0 && M % kBN == 0 && c->cfg.d >= kBM &&
-         c->cfg.d <= 2048 && M >= 128;   // (the run-boundary masks of k_fb_prod hold 64 sub-stages)
+         c->cfg.d <= 2048 && M >= 128 && M <= 2048;   // (the inverse-scale tables of k_fb_prod<FB_DENSE_G> / k_fb_vjp hold 2048 entries)
 }
 size_t fb_plane_words(const mivi_ctx *c, int M) { return (size_t)c->cfg.d * M / 512 * kFrag; }       // one lane's eps / W planes
 size_t fb_cplane_words(const mivi_ctx *c) { return (size_t)(c->cfg.d / 32) * (c->cfg.d / 16) * kFrag; }
@@ -928,6 +948,11 @@ static FbArgs fb_args(mivi_ctx *c, const void *params, int M) {
   a.t_mean = (const float *)c->t_mean.p;
   a.t_istd = (const float *)c->t_istd.p;
   a.CA = (unsigned *)t.CA.p;
+  a.cscale = (float *)t.cscale.p;
+  a.pscale = (float *)t.pscale.p;
+  a.tscale = (float *)t.tscale.p;
+  a.winv = (float *)t.winv.p;
+  a.rinv = (float *)t.rinv.p;
   a.epsP = (unsigned *)t.epsP.p;
   a.epsV = (unsigned *)t.epsV.p;
   a.WV = (unsigned *)t.WV.p;
@@ -952,21 +977,19 @@ void fb_launch_eps(mivi_ctx *c, const FbStep &s, bool with_cplanes, hipStream_t 
   FbArgs a = fb_args(c, s.params, M);
   a.L = L;
   a.rng = s.rng;
-  const int gx = (d / 64) * (M / 32), nf = (d / 32) * (d / 16);
-  const int ycp = with_cplanes ? (nf + 8 * gx - 1) / (8 * gx) : 0;
-  hipLaunchKernelGGL(k_fb_eps, dim3(gx, L + ycp), dim3(512), 0, stream, a);
+  const int gx = (d / 64) * (M / 32);
+  a.n_riders = with_cplanes ? (d / 32 + gx - 1) / gx : 0;   // tril(C)'s planes: one workgroup per 32-row block, in FRONT of the lanes' draws
+  hipLaunchKernelGGL(k_fb_eps, dim3(gx, L + a.n_riders), dim3(512), 0, stream, a);
 }
 // the dense-Gaussian target's precision matrix as operand planes (once per target: FbTables::PA_valid)
 void fb_launch_pplanes(mivi_ctx *c, hipStream_t stream) {
   FbArgs a = fb_args(c, nullptr, c->cfg.n_mc);
-  const int nf = (c->cfg.d / 32) * (c->cfg.d / 16);
-  hipLaunchKernelGGL(k_fb_pplanes, dim3((nf + 3) / 4), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(k_fb_pplanes, dim3(c->cfg.d / 32), dim3(512), 0, stream, a);
 }
 // C^-T (t.Tinv, left there by the solve kernels on the identity) as operand planes: once per call
 void fb_launch_tplanes(mivi_ctx *c, hipStream_t stream) {
   FbArgs a = fb_args(c, nullptr, c->cfg.n_mc);
-  const int nf = (c->cfg.d / 32) * (c->cfg.d / 16);
-  hipLaunchKernelGGL(k_fb_tplanes, dim3((nf + 3) / 4), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(k_fb_tplanes, dim3(c->cfg.d / 32), dim3(512), 0, stream, a);
 }
 // product + target (dense target: product -> R, the target's product) -> VJP (+ the lanes' values as extra workgroups of the VJP launch) on `stream`
 void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int which) {   // which (profiling): bit 0 the draw's product, bit 1 the VJP, bit 2 the dense target's product, bit 3 the sticking-the-landing product; 15 = all (default)
@@ -979,15 +1002,15 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
   a.write_upper = s.write_upper;
   a.work = (const int4 *)tb.prod.p; a.n_work = tb.n_prod;
   if (s.dense) {
-    if (which & 1) hipLaunchKernelGGL((k_fb_prod<kWJ, kPFprod, FB_DENSE_R>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
+    if (which & 1) hipLaunchKernelGGL((k_fb_prod<kWJ, FB_DENSE_R>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
     a.work = (const int4 *)tb.prod2.p; a.n_work = tb.n_prod2;
-    if (which & 4) hipLaunchKernelGGL((k_fb_prod<kWJ, kPFprod, FB_DENSE_G>), dim3(tb.n_prod2), dim3(512 / kWJ), 0, stream, a);
+    if (which & 4) hipLaunchKernelGGL((k_fb_prod<kWJ, FB_DENSE_G>), dim3(tb.n_prod2), dim3(512 / kWJ), 0, stream, a);
   } else if (which & 1) {
-    hipLaunchKernelGGL((k_fb_prod<kWJ, kPFprod, FB_DIAG>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
+    hipLaunchKernelGGL((k_fb_prod<kWJ, FB_DIAG>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
   }
   if (s.stl && (which & 8)) {
     a.work = (const int4 *)tb.prod3.p; a.n_work = tb.n_prod;
-    hipLaunchKernelGGL((k_fb_prod<kWJ, kPFprod, FB_STL_U>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
+    hipLaunchKernelGGL((k_fb_prod<kWJ, FB_STL_U>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
   }
   a.work = (const int4 *)tb.vjp.p; a.n_work = tb.n_vjp;
   if (which & 2) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);

@@ -215,6 +215,7 @@ struct FbTables {
   FbTab tab[4];                           // per lane count (the full step's, the last shorter step's, other batch lengths'), round robin
   int next_tab = 0;
   DevBuf CA, epsP, epsV, WV, ell, he, ld, grads, values;   // operand planes (tril(C) once per call; eps in both orientations and W per lane)
+  DevBuf cscale, pscale, tscale, winv, rinv;               // power-of-two scales of the planes (fr_planes.h): rows of tril(C) / P / C^-T [2][d]; W per lane [M / 128][d]; R per lane [d / 128][M]
   DevBuf PA, RP;                          // dense-Gaussian target: planes of P (once per target), R = Z - m per lane
   bool PA_valid = false;
   DevBuf Tinv, TA, Eye;                   // sticking-the-landing estimators: C^-T (f32), its planes (once per call), the identity the solve takes

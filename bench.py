@@ -32,7 +32,7 @@ SEED = 0x38BEF07CF9CC549D
 PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
 PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA peak (155 TF measured)
 PEAK_BF16_MFMA_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
-PLANE_BYTES = 6                 # bytes per operand-plane element of the batch engine (three bf16 planes)
+PLANE_BYTES = 4                 # bytes per operand-plane element of the batch engine (f16 hi + lo planes; ctx.plane_bytes())
 PEAK_VALU_GINST = 1024 * 2.4 / 4   # wave64 vector instructions per ns: 256 CUs x 4 SIMDs, one per 4 cycles, 2.4 GHz (MI355X_MICROARCH.md)
 
 # environment variables that do NOT change which kernels run: bench-harness controls and the RCCL library location

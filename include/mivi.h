@@ -395,6 +395,11 @@ mivi_status_t mivi_profile_dist(mivi_ctx_t *ctx, const void *params_dev, int32_t
 mivi_status_t mivi_profile_batch(mivi_ctx_t *ctx, const void *params_dev, int32_t lanes, int32_t reps, double *us_out);
 /* Estimates per launch ("lanes" of a step) the batch engine uses for a `count`-estimate call: equal steps of at most 80 lanes. */
 int32_t mivi_batch_lanes(const mivi_ctx_t *ctx, int32_t count);
+/* What a batch of estimates at this context's configuration runs on (measurement / test hook; the reference has no counterpart: every
+ * `estimate_gradient!` there is one AD call, src/algorithms/repgradelbo.jl:151-177).  what = 0: 1 when mivi_estimate_gradient_n / _each with
+ * these (16-byte aligned) device parameters take the batch engine, 0 otherwise; 1: matrix-pipe products per 32 x 32 x 16 block of the engine's
+ * split-operand contractions (3: f16 hi / lo planes); 2: bytes per operand-plane element (4). */
+int32_t mivi_batch_info(const mivi_ctx_t *ctx, const void *params_dev, int32_t what);
 
 /* ---- measurement hook (bench.py roofline leg) --------------------------------------------------------- *
  * Times `reps` back-to-back launches of ONE stage of the estimate with hipEvents recorded on the context's

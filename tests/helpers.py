@@ -62,3 +62,32 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def engine_shape(d, M, family=None, dtype=np.float32, kind="diag", n=2):
+    """Does a batch of n estimates at this configuration run on the batch engine (csrc/kernels_fullrank_batch.hip; api_batch.hip fb_route)?
+    There the products run on two-way f16 operand splits (f32-accurate, 2^-22 per term), so a batch's estimates equal the single calls'
+    (exact three-way bf16 split) to rounding; every other route stays bitwise the single calls'."""
+    family = avi.FULLRANK if family is None else family
+    return (family == avi.FULLRANK and np.dtype(dtype) == np.float32 and kind in ("diag", "dense") and n >= 2 and d % 128 == 0 and
+            128 <= d <= 2048 and M % 128 == 0 and 128 <= M <= 2048)
+
+
+# the stated tolerances of "a batch's estimate equals the single call's" on the batch engine: value relative, gradient relative l2
+BATCH_VALUE_RTOL = 1e-6
+BATCH_GRAD_RTOL = 2e-6
+
+
+def assert_batch_matches_single(v, v1, g, g1, engine, what="", ulps=0):
+    """v, v1: floats; g, g1: numpy gradients (or None).  engine False: bitwise (values within `ulps` f32 spacings)."""
+    v, v1 = float(v), float(v1)
+    if engine:
+        assert abs(v - v1) <= BATCH_VALUE_RTOL * abs(v1), (what, v, v1)
+        if g is not None:
+            gb, gs = np.asarray(g, dtype=np.float64), np.asarray(g1, dtype=np.float64)
+            assert np.linalg.norm(gb - gs) <= BATCH_GRAD_RTOL * max(1.0, np.linalg.norm(gs)), (what, np.linalg.norm(gb - gs) / max(1.0, np.linalg.norm(gs)))
+            assert np.array_equal(gb == 0.0, gs == 0.0) or np.count_nonzero((gb == 0.0) != (gs == 0.0)) < 8, what   # the structural zeros agree
+    else:
+        assert abs(v - v1) <= ulps * float(np.spacing(np.float32(abs(v1)))), (what, v, v1)
+        if g is not None:
+            assert np.array_equal(g, g1), what

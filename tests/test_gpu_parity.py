@@ -213,7 +213,7 @@ def test_graph_batched_stl_estimates_reuse_the_solve_preparation(ent):
             v1, g1 = v1.cpu().numpy().copy(), g1.cpu().numpy().copy()
             ctx.estimate_gradient_n(p, 7, count, v, g)
             ctx.synchronize()
-            assert abs(float(v.item()) - float(v1[0])) <= float(np.spacing(np.float32(abs(float(v1[0]))))), (scale, count)
+            assert abs(float(v.item()) - float(v1[0])) <= 1e-6 * abs(float(v1[0])), (scale, count)
             gb, gs = g.cpu().numpy().astype(np.float64), g1.astype(np.float64)
             assert np.linalg.norm(gb - gs) <= 2e-6 * max(1.0, np.linalg.norm(gs)), (scale, count, np.linalg.norm(gb - gs) / np.linalg.norm(gs))
     ctx.close()
