@@ -23,11 +23,22 @@
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
+#include <cstdio>
 #include <vector>
 
 #include "device_common.h"
 #include "fr_elem.h"
 #include "fr_planes.h"
+
+#ifndef FB_RING_VJP
+#define FB_RING_VJP 4
+#endif
+#ifndef FB_WJ
+#define FB_WJ 1
+#endif
+#ifndef FB_PF_VJP
+#define FB_PF_VJP 0
+#endif
 
 namespace mivi {
 
@@ -93,7 +104,18 @@ struct FbArgs {
   double ell_const;
   RngArgs rng;                    // lane l draws estimate rng_index(rng) + l
   int n_riders;                   // k_fb_eps: grid rows in front of the lanes' that lay out tril(C)
+  int knock;                      // developer knock-outs (-DMIVI_DEV, MIVI_FB_KNOCK): 1 no DMA, 2 no MFMA, 4 no LDS reads, 8 no barriers
+  long long *dbg;                 // developer timeline (-DMIVI_DEV builds, MIVI_FB_DBG=1): per workgroup {entry, first stage landed, main loop done, end} (100 MHz ticks), groups
 };
+#ifdef MIVI_DEV
+#define FB_STAMP(a, slot) do { if ((a).dbg && threadIdx.x == 0) (a).dbg[(size_t)blockIdx.x * 8 + (slot)] = (long long)wall_clock64(); } while (0)
+#define FB_NOTE(a, slot, v) do { if ((a).dbg && threadIdx.x == 0) (a).dbg[(size_t)blockIdx.x * 8 + (slot)] = (long long)(v); } while (0)
+#define FB_KNOCKED(a, b) ((a).knock & (b))
+#else
+#define FB_KNOCKED(a, b) false
+#define FB_STAMP(a, slot) do { } while (0)
+#define FB_NOTE(a, slot, v) do { } while (0)
+#endif
 
 // -----------------------------------------------------------------------------------------------------------------
 // A parameter-only A operand as operand planes: ONE workgroup (512 threads) per 32-row block rb -- the rows' largest magnitudes over the
@@ -216,6 +238,7 @@ __global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
 constexpr int kStageW = 16 * 256;   // words per stage
 constexpr int kRing = 4;            // LDS ring slots of the register-prefetching loops: three stages in flight behind the one being read;
                                     // the main loops are unrolled by kRing, so every slot address is a compile-time constant
+constexpr int kRingVjp = FB_RING_VJP;   // ring slots of the VJP's plain loop (two workgroups per CU)
 constexpr int kImgW = 32 * 36;      // a wave-private 32 x 32 epilogue image (leading dimension 36), words
 // Wave layout of a 128 x 128 tile, WJ = 32-column blocks per wave: 8 / WJ waves = 2 (row halves of 64) x 4 / WJ (column parts of 32 WJ).
 //   WJ = 2: four waves (one per SIMD), a wave owns 64 x 64: 32 KiB of LDS reads per group and workgroup
@@ -269,6 +292,8 @@ __device__ __forceinline__ float fb_lane_max(float v) {
 // Software pipeline: iteration g computes on the fragments of stage g (already in registers) while the fragments of stage g + 1 are read
 // from LDS and the DMA of stage g + kRing is issued.  Per iteration: wait for the own pieces of stage g + 1, barrier (stage g + 1 has landed
 // for every wave; every wave has read stage g, whose slot stage g + kRing takes), issue, read, 6 WJ MFMAs.
+// NRP = LDS ring slots (NRP - 1 stages in flight behind the one being read; the loops are unrolled by NRP): 4 (78 KiB of LDS: two workgroups
+// share a CU and cover each other's barriers and epilogues) or 8 (135 KiB: the workgroup owns its CU) -- the host picks per step width.
 // MODE: FB_DIAG: A = tril(C), B = eps; epilogue = the fused diagonal-Gaussian target: W planes (the VJP's A operand) + ell partials;
 //   FB_DENSE_R: the same product, epilogue R = (mu + tril(C) eps) - m as the B-operand planes of the dense target's product;
 //   FB_DENSE_G: the dense target's product itself, G = -P R: A = the planes of P over the WHOLE K range, B = R's planes -- scaled per
@@ -281,12 +306,12 @@ __device__ __forceinline__ float fb_lane_max(float v) {
 // sample over its 128 rows for R) cross the waves through LDS once, then the images are scaled, split and stored as fragments.
 // -----------------------------------------------------------------------------------------------------------------
 enum { FB_DIAG = 0, FB_DENSE_R = 1, FB_DENSE_G = 2, FB_STL_U = 3 };
-template <int WJ, int MODE>
+template <int WJ, int MODE, int NRP>
 __global__ __launch_bounds__(512 / WJ, 2 / WJ) void k_fb_prod(FbArgs a) {
   constexpr bool kDG = MODE == FB_DENSE_G, kSU = MODE == FB_STL_U, kDR = MODE == FB_DENSE_R;
   constexpr int LDC = 36, NF = WJ, kPW = 2 * WJ;   // fragments / pieces this wave stages per group
   constexpr int NW = 8 / WJ, NWN = 4 / WJ;         // waves; waves along the columns
-  constexpr int kBody = (kRing * kStageW > 16 * kImgW) ? kRing * kStageW : 16 * kImgW;   // the ring, later the waves' epilogue images
+  constexpr int kBody = (NRP * kStageW > 16 * kImgW) ? NRP * kStageW : 16 * kImgW;   // the ring, later the waves' epilogue images
   constexpr int kTab = kDG ? 2048 : 0;             // DENSE_G: R's inverse scales of the tile's 128 samples, every 128-row block (d <= 2048)
   __shared__ __attribute__((aligned(16))) unsigned lds[kBody + 4 * 128 + NW * 64 + kTab];
   float *vec = reinterpret_cast<float *>(lds + kBody);          // [4][128]: mu, target mean, target 1 / std, the rows' output factor
@@ -354,9 +379,9 @@ __global__ __launch_bounds__(512 / WJ, 2 / WJ) void k_fb_prod(FbArgs a) {
   // diagonal block, so its chain adds exact zeros there.
   const int Gw = (kDG || kSU) ? G : 2 * r32[1] + 2;
   auto compute = [&](auto S, int g, const FbFrags<WJ> &F) {   // S = g mod kRing
-    fb_group<WJ>(F, acc);
+    if (!FB_KNOCKED(a, 2)) fb_group<WJ>(F, acc);
     fb_sched_interleave<WJ>();
-    if constexpr (kDG && decltype(S)::value == 3) {   // (behind the MFMAs: the block in front of them stays one basic block)
+    if constexpr (kDG && (decltype(S)::value & 3) == 3) {   // (behind the MFMAs: the block in front of them stays one basic block)
       if (((g + 1) & 7) == 0) {                        // a 128-row block of R ended with this group: its inverse scales, per column
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
@@ -373,40 +398,43 @@ __global__ __launch_bounds__(512 / WJ, 2 / WJ) void k_fb_prod(FbArgs a) {
   };
   // iteration g (S = g mod kRing): wait for the own pieces of stage g + 1, barrier, issue stage g + kRing into the slot of stage g, read the
   // fragments of stage g + 1, compute stage g.  VM = stages that may stay in flight across the wait; CMP: this wave still has work.
-  auto step = [&](auto S, auto VM, auto ISS, auto CMP, int g, const FbFrags<WJ> &Fc, FbFrags<WJ> &Fn) {
+  auto step = [&](auto S, auto VM, auto ISS, int g, const FbFrags<WJ> &Fc, FbFrags<WJ> &Fn) {
     constexpr int sl = decltype(S)::value;
     fb_wait_vm<kPW * decltype(VM)::value>();
-    fb_barrier();
-    if constexpr (decltype(ISS)::value) issue(sl);
-    if constexpr (decltype(CMP)::value) {
-      fb_read_frags<WJ>(lds, (sl + 1) % kRing, wm, wn, lane, Fn);
+    if (!FB_KNOCKED(a, 8)) fb_barrier();
+    if constexpr (decltype(ISS)::value) {
+      if (!FB_KNOCKED(a, 1)) issue(sl);
+      if (!FB_KNOCKED(a, 4)) fb_read_frags<WJ>(lds, (sl + 1) % NRP, wm, wn, lane, Fn);
+      compute(S, g, Fc);
+    } else if (g < Gw) {   // (the tail: a wave-uniform branch)
+      fb_read_frags<WJ>(lds, (sl + 1) % NRP, wm, wn, lane, Fn);
       compute(S, g, Fc);
     }
   };
-  static_assert(kRing == 4, "the unrolled loops below are written for four slots");
-  issue(0); issue(1); issue(2); issue(3);   // (G >= 8)
-  fb_wait_vm<kPW * 3>();
+  FB_STAMP(a, 0);
+  FB_NOTE(a, 4, G);
+  static_for<0, NRP>([&](auto S) { issue(decltype(S)::value); });   // (G >= 8 >= NRP)
+  fb_wait_vm<kPW * (NRP - 1)>();
   fb_barrier();
+  FB_STAMP(a, 1);
   {
     FbFrags<WJ> F0, F1;
     fb_read_frags<WJ>(lds, 0, wm, wn, lane, F0);
     int g = 0;
-    for (; g + 4 < G; g += 4) {   // (G is a multiple of eight; Gw = G for the waves of the tile's lower half, G - 4 for the upper half's)
-      step(FbI0{}, FbI2{}, FbT{}, FbT{}, g, F0, F1);
-      step(FbI1{}, FbI2{}, FbT{}, FbT{}, g + 1, F1, F0);
-      step(FbI2{}, FbI2{}, FbT{}, FbT{}, g + 2, F0, F1);
-      step(FbI3{}, FbI2{}, FbT{}, FbT{}, g + 3, F1, F0);
+    for (; g + NRP < G; g += NRP) {   // (G is a multiple of eight; Gw = G for the waves of the tile's lower half, G - 4 for the upper half's)
+      static_for<0, NRP>([&](auto S) {
+        constexpr int sv = decltype(S)::value;
+        if constexpr (sv % 2 == 0) step(S, std::integral_constant<int, NRP - 2>{}, FbT{}, g + sv, F0, F1);
+        else step(S, std::integral_constant<int, NRP - 2>{}, FbT{}, g + sv, F1, F0);
+      });
     }
-    if (g < Gw) {   // the last four groups: nothing left to request
-      step(FbI0{}, FbI2{}, FbN{}, FbT{}, g, F0, F1);
-      step(FbI1{}, FbI1{}, FbN{}, FbT{}, g + 1, F1, F0);
-      step(FbI2{}, FbI0{}, FbN{}, FbT{}, g + 2, F0, F1);
-      compute(FbI3{}, g + 3, F1);
-    } else {        // (the upper half's K range has ended: its waves only keep the barriers)
-      step(FbI0{}, FbI2{}, FbN{}, FbN{}, g, F0, F1);
-      step(FbI1{}, FbI1{}, FbN{}, FbN{}, g + 1, F1, F0);
-      step(FbI2{}, FbI0{}, FbN{}, FbN{}, g + 2, F0, F1);
-    }
+    // the last NRP groups: nothing left to request; the upper half's K range ends four groups early (its waves then only keep the barriers)
+    static_for<0, NRP - 1>([&](auto S) {
+      constexpr int sv = decltype(S)::value;
+      if constexpr (sv % 2 == 0) step(S, std::integral_constant<int, NRP - 2 - sv>{}, FbN{}, g + sv, F0, F1);
+      else step(S, std::integral_constant<int, NRP - 2 - sv>{}, FbN{}, g + sv, F1, F0);
+    });
+    if (g + NRP - 1 < Gw) compute(std::integral_constant<int, NRP - 1>{}, g + NRP - 1, F1);
   }
   if constexpr (!kDG) {
 #pragma unroll
@@ -415,6 +443,7 @@ __global__ __launch_bounds__(512 / WJ, 2 / WJ) void k_fb_prod(FbArgs a) {
       for (int j = 0; j < WJ; ++j) tot[i][j] = acc[i][j];
   }
   fb_barrier();   // every wave is done with the ring: LDS becomes the waves' private epilogue images
+  FB_STAMP(a, 2);
   float *img = reinterpret_cast<float *>(lds) + w * (2 * WJ * kImgW);   // image (i, j) at img + (i WJ + j) kImgW: [column][row], then W[m][i]
   unsigned *WVl = a.WV + (size_t)ln * a.plane_stride;
   unsigned *RPl = a.RP + (size_t)ln * a.plane_stride;
@@ -575,6 +604,7 @@ __global__ __launch_bounds__(512 / WJ, 2 / WJ) void k_fb_prod(FbArgs a) {
       }
     }
   }
+  FB_STAMP(a, 3);
   if (!kDG && !kSU && (flags & 1) && wn == 0 && lane < 32) {   // log|det C| partials of this wave's two row blocks (lane 0's first column block carries the flag)
     const int nrb = d >> 5;
 #pragma unroll
@@ -626,7 +656,7 @@ __device__ __forceinline__ void fb_value_block(const FbArgs &a, int l, double *r
 template <int WJ, int PF>
 __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArgs a) {
   constexpr int LDC = 36, NF = WJ, kPW = 2 * WJ;
-  constexpr int NR = PF ? kRing : 3;
+  constexpr int NR = PF ? kRing : kRingVjp;
   constexpr int kBody = (NR * kStageW > 16 * kImgW / 2) ? NR * kStageW : 16 * kImgW / 2;   // the ring, later one image per wave
   __shared__ __attribute__((aligned(16))) unsigned lds[kBody + 2048];
   float *wf = reinterpret_cast<float *>(lds + kBody);   // [M / 128][128]: inverse scales of W's rows of this tile, per 128-sample block (M <= 2048)
@@ -766,24 +796,30 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
       step(FbI2{}, FbI0{}, FbN{}, FbN{}, g + 2, F0, F1);
     }
   } else {
-    // plain loop: wait for stage g, barrier, request stage g + 2 into the slot of stage g - 1, read, compute -- the other workgroup of the CU
-    // runs its MFMAs under this one's waits
-    issue(0); issue(1);
+    // plain loop, NR-slot ring: wait for stage g, barrier, request stage g + NR - 1 into the slot stage g - 1 was read from, read, compute -- the
+    // other workgroup of the CU runs its MFMAs under this one's waits
+    FB_STAMP(a, 0);
+    FB_NOTE(a, 4, G);
+#pragma unroll
+    for (int s0 = 0; s0 < NR - 1; ++s0) issue(s0);   // (G >= 8)
     int slot = 0;
     for (int g = 0; g < G; ++g) {
-      if (g + 1 < G) fb_wait_vm<kPW>();
+      if (g == 1) FB_STAMP(a, 1);
+      if (g + NR - 2 < G) fb_wait_vm<kPW * (NR - 2)>();
+      else if (NR > 3 && g + 1 < G) fb_wait_vm<kPW>();
       else fb_wait_vm<0>();
       fb_barrier();
-      if (g + 2 < G) issue(slot == 0 ? 2 : slot - 1);
+      if (g + NR - 1 < G) issue(slot == 0 ? NR - 1 : slot - 1);
       if (work) {
         FbFrags<WJ> F;
         fb_read_frags<WJ>(lds, slot, wm, wn, lane, F);
         compute(std::integral_constant<int, -1>{}, g, F);
       }
-      slot = slot == 2 ? 0 : slot + 1;
+      slot = slot == NR - 1 ? 0 : slot + 1;
     }
   }
   fb_barrier();
+  FB_STAMP(a, 2);
   float *Cs = reinterpret_cast<float *>(lds) + w * kImgW;
   const double invM = 1.0 / (double)a.M_total;
   const bool pow2M = (a.M_total & (a.M_total - 1)) == 0;
@@ -833,6 +869,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
       if (lane < 32) grad[32 * ri[i] + lane] = dmu_elem(sm, invM);
     }
   }
+  FB_STAMP(a, 3);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -840,8 +877,8 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
 // -----------------------------------------------------------------------------------------------------------------
 namespace {
 constexpr int kBM = 128, kBN = 128;
-constexpr int kWJ = 1;      // 32-column blocks per wave (k_fb_prod / k_fb_vjp): 2 = four waves of 64 x 64 per tile, 1 = eight waves of 64 x 32
-constexpr int kPFvjp = 0;   // the product: register prefetch + one workgroup per CU (its heaviest tile must own a CU); the VJP: two plain workgroups per CU (equal tiles)
+constexpr int kWJ = FB_WJ;      // 32-column blocks per wave (k_fb_prod / k_fb_vjp): 2 = four waves of 64 x 64 per tile, 1 = eight waves of 64 x 32
+constexpr int kPFvjp = FB_PF_VJP;   // the product: register prefetch + one workgroup per CU (its heaviest tile must own a CU); the VJP: two plain workgroups per CU (equal tiles)
 
 void fb_upload(DevBuf &b, const void *src, size_t bytes) {
   if (b.bytes < bytes || !b.p) {
@@ -1000,20 +1037,59 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
   a.values = (float *)s.values; a.value_stride = s.value_stride;
   a.grad_last = (float *)s.grad_last; a.value_last = (float *)s.value_last; a.lane_last = s.lane_last;
   a.write_upper = s.write_upper;
+#ifdef MIVI_DEV
+  static long long *dbg_buf = nullptr;
+  static const bool dbg_on = getenv("MIVI_FB_DBG") != nullptr;
+  if (dbg_on && !dbg_buf) (void)hipMalloc(&dbg_buf, 2 * 8192 * 8 * sizeof(long long));
+  auto dump = [&](const char *name, int n) {
+    if (!dbg_on) return;
+    (void)hipStreamSynchronize(stream);
+    std::vector<long long> h((size_t)n * 8);
+    (void)hipMemcpy(h.data(), dbg_buf, h.size() * 8, hipMemcpyDeviceToHost);
+    long long t0 = h[0], t3 = 0;
+    for (int i = 0; i < n; ++i) { t0 = std::min(t0, h[(size_t)i * 8]); t3 = std::max(t3, h[(size_t)i * 8 + 3]); }
+    double pro = 0, loop = 0, epi = 0, pg = 0; long long gs = 0;
+    for (int i = 0; i < n; ++i) { const long long *r = &h[(size_t)i * 8]; pro += r[1] - r[0]; loop += r[2] - r[1]; epi += r[3] - r[2]; gs += r[4]; }
+    pg = loop / (double)gs;
+    fprintf(stderr, "[fbdbg] %s: %d workgroups, span %.2f us | mean prologue %.2f us, main loop %.2f us (%.3f us per group), epilogue %.2f us | last start %.2f us\n", name, n, (t3 - t0) * 0.01, pro / n * 0.01, loop / n * 0.01, pg * 0.01, epi / n * 0.01, 0.0);
+    // start-time histogram: when do workgroups begin, relative to the first
+    std::vector<long long> st; for (int i = 0; i < n; ++i) st.push_back(h[(size_t)i * 8] - t0);
+    std::sort(st.begin(), st.end());
+    fprintf(stderr, "[fbdbg]   starts (us): p25 %.2f p50 %.2f p75 %.2f p90 %.2f max %.2f\n", st[n / 4] * 0.01, st[n / 2] * 0.01, st[3 * n / 4] * 0.01, st[9 * n / 10] * 0.01, st[n - 1] * 0.01);
+  };
+  a.dbg = dbg_on ? dbg_buf : nullptr;
+  a.knock = getenv("MIVI_FB_KNOCK") ? atoi(getenv("MIVI_FB_KNOCK")) : 0;
+#endif
   a.work = (const int4 *)tb.prod.p; a.n_work = tb.n_prod;
+  // One workgroup per CU (eight ring slots) where a step's heaviest tiles pace the launch and a second workgroup on their CU only slows them:
+  // measured at the north star (us, 4 / 8 slots): 16 lanes 23.1 / 23.4, 20: 27.6 / 23.8, 24: 28.9 / 27.7, 28: 30.7 / 30.9, 40: 37.9 / 44.5
+  const bool own_cu = s.L >= 17 && s.L <= 26;
+  auto prod = [&](auto MODE, int n) {
+    constexpr int md = decltype(MODE)::value;
+    if (own_cu) hipLaunchKernelGGL((k_fb_prod<kWJ, md, 8>), dim3(n), dim3(512 / kWJ), 0, stream, a);
+    else hipLaunchKernelGGL((k_fb_prod<kWJ, md, 4>), dim3(n), dim3(512 / kWJ), 0, stream, a);
+  };
   if (s.dense) {
-    if (which & 1) hipLaunchKernelGGL((k_fb_prod<kWJ, FB_DENSE_R>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
+    if (which & 1) prod(std::integral_constant<int, FB_DENSE_R>{}, tb.n_prod);
     a.work = (const int4 *)tb.prod2.p; a.n_work = tb.n_prod2;
-    if (which & 4) hipLaunchKernelGGL((k_fb_prod<kWJ, FB_DENSE_G>), dim3(tb.n_prod2), dim3(512 / kWJ), 0, stream, a);
+    if (which & 4) prod(std::integral_constant<int, FB_DENSE_G>{}, tb.n_prod2);
   } else if (which & 1) {
-    hipLaunchKernelGGL((k_fb_prod<kWJ, FB_DIAG>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
+    prod(std::integral_constant<int, FB_DIAG>{}, tb.n_prod);
+#ifdef MIVI_DEV
+    dump("k_fb_prod<DIAG>", tb.n_prod);
+#endif
   }
   if (s.stl && (which & 8)) {
     a.work = (const int4 *)tb.prod3.p; a.n_work = tb.n_prod;
-    hipLaunchKernelGGL((k_fb_prod<kWJ, FB_STL_U>), dim3(tb.n_prod), dim3(512 / kWJ), 0, stream, a);
+    prod(std::integral_constant<int, FB_STL_U>{}, tb.n_prod);
   }
   a.work = (const int4 *)tb.vjp.p; a.n_work = tb.n_vjp;
-  if (which & 2) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
+  if (which & 2) {
+    hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
+#ifdef MIVI_DEV
+    dump("k_fb_vjp", tb.n_vjp);
+#endif
+  }
 }
 
 }  // namespace mivi

@@ -241,14 +241,14 @@ def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):
             for k, v in tb.items():
                 if v > 0.0:
                     stages["batch_%s_%d_lanes" % (k, lanes)] = v * 1e-3
-            nm = {"product": "k_fb_prod<FB_DIAG> (tril(C) [eps_1 .. eps_L] + fused target for all lanes of a step, operands as bf16 planes in MFMA-fragment order)",
+            nm = {"product": "k_fb_prod<FB_DIAG> (tril(C) [eps_1 .. eps_L] + fused target for all lanes of a step, operands as f16 hi/lo planes in MFMA-fragment order)",
                   "vjp": "k_fb_vjp (tril(W_l eps_l') for all lanes of a step + their values)",
                   "dense_product": "k_fb_prod<FB_DENSE_G> (the dense target's -P (Z_l - m) for all lanes of a step)",
                   "stl_product": "k_fb_prod<FB_STL_U> (W_l += C^-T eps_l for all lanes of a step, C^-T formed once per call)"}
             if w["target"] == "dense":
                 nm["product"] = "k_fb_prod<FB_DENSE_R> (tril(C) [eps_1 .. eps_L] -> R = Z - m as operand planes)"
-            sub = {"product": "k_fb_prodILi1ELi1ELi%dE" % (1 if w["target"] == "dense" else 0), "vjp": "k_fb_vjp",
-                   "dense_product": "k_fb_prodILi1ELi1ELi2E", "stl_product": "k_fb_prodILi1ELi1ELi3E"}   # (mangled template arguments: WJ, PF, MODE)
+            sub = {"product": "k_fb_prodILi1ELi%dE" % (1 if w["target"] == "dense" else 0), "vjp": "k_fb_vjp",
+                   "dense_product": "k_fb_prodILi1ELi2E", "stl_product": "k_fb_prodILi1ELi3E"}   # (mangled template arguments: WJ, MODE; then the ring depth)
             kfl = {"product": fl, "vjp": fl, "dense_product": 2 * fl, "stl_product": fl}   # algorithmic flops per estimate of each launch
             live = [k for k in ("product", "vjp", "dense_product", "stl_product") if tb.get(k, 0.0) > 0.0]
             dk = max(live, key=lambda k: tb[k])
@@ -272,17 +272,26 @@ def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):
             keep = {k: roof[k] for k in ("kernel", "achieved", "frac", "traffic", "algorithmic_flops_per_launch", "avg_launch_us", "other_contraction")}
             if "single_launch" in roof:
                 keep = roof["single_launch"]
-            # ONE basis for every kernel of the block: `achieved` = SURVEY 8d's algorithmic (f32-accurate) flops of the launch / its duration,
-            # `peak` = the dense f32-MFMA peak the north star is priced on -- a fraction that a split-operand product may push past 1 --
-            # and ALWAYS beside it `pipe16`: the flops the 16-bit matrix pipe actually executes (kSplitProducts per product block) over its
-            # dense peak, a fraction <= 1 by construction.
-            nprod = ctx.split_products() if hasattr(ctx, "split_products") else 6
+            # ONE basis for every kernel of the block.  On two f16 planes a product block costs three matrix-pipe products, so SURVEY 8d's
+            # algorithmic flops no longer bound these kernels (the 16-bit pipe would finish them in a third of the time the f32-MFMA peak
+            # allows): the binding roof is the MEMORY side, as the north star's own target says ("% of HBM roofline").  `achieved` = SURVEY 8d's
+            # algorithmic BYTES of the launch / its duration, `peak` = 8 TB/s; beside it, always, the same launch's f32-accurate flops over
+            # the f32-MFMA peak (`frac_f32_mfma`: may exceed 1) and the executed 16-bit-pipe flops over 2.5 PF (`frac_16bit_pipe`, <= 1).
+            nprod = ctx.split_products()
+            d_, M_ = w["d"], w["n_mc"]
+            alg_bytes = {"product": d_ * (d_ + 1) // 2 * 4 + lanes * 2 * d_ * M_ * 4, "vjp": lanes * (2 * d_ * M_ * 4 + d_ * d_ * 4),
+                         "dense_product": d_ * d_ * 4 + lanes * 2 * d_ * M_ * 4, "stl_product": d_ * (d_ + 1) // 2 * 4 + lanes * 3 * d_ * M_ * 4}
+
             def tf(k):
                 return lanes * kfl[k] / (tb[k] * 1e-6) / 1e12
-            others = [dict(kernel=nm[k], avg_launch_us=tb[k], achieved=tf(k), frac=tf(k) / PEAK_F32_MFMA_TF, frac_16bit_pipe=nprod * tf(k) / PEAK_BF16_MFMA_TF,
-                           rocprof_in_chain=rocprof_avg(sub[k], w.get("key", "ns"), lanes))
+
+            def gbs(k):
+                return alg_bytes[k] / (tb[k] * 1e-6) / 1e9
+            others = [dict(kernel=nm[k], avg_launch_us=tb[k], achieved=gbs(k), frac=gbs(k) / PEAK_HBM_GBS, frac_f32_mfma=tf(k) / PEAK_F32_MFMA_TF,
+                           frac_16bit_pipe=nprod * tf(k) / PEAK_BF16_MFMA_TF, rocprof_in_chain=rocprof_avg(sub[k], w.get("key", "ns"), lanes))
                       for k in live if k != dk]
-            roof.update(kernel=nm[dk], achieved=aL, frac=aL / PEAK_F32_MFMA_TF, algorithmic_flops_per_launch=lanes * kfl[dk], estimates_per_launch=lanes,
+            roof.update(bound="hbm", kernel=nm[dk], achieved=gbs(dk), peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs(dk) / PEAK_HBM_GBS,
+                        algorithmic_bytes_per_launch=alg_bytes[dk], algorithmic_flops_per_launch=lanes * kfl[dk], estimates_per_launch=lanes,
                         avg_launch_us=tb[dk], traffic=traffic_of(dk), rocprof_in_chain=rocprof_avg(sub[dk], w.get("key", "ns"), lanes),
                         other_contraction=others[0] if len(others) == 1 else others,
                         draws=dict(kernel="k_fb_eps (Philox + Box-Muller draws of all lanes as operand planes in both orientations)", avg_launch_us=tb["eps"],
@@ -290,7 +299,8 @@ def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):
                                    achieved_GBs=lanes * 2 * PLANE_BYTES * w["d"] * w["n_mc"] / (tb["eps"] * 1e-6) / 1e9,
                                    note="%d bytes per element and orientation written once: bound by the memory side and the vector ALU" % PLANE_BYTES),
                         timing="%d back-to-back launches of each kernel for %d lanes, hipEvents on the launch stream" % (max(5, reps // 10), lanes),
-                        basis="achieved = algorithmic f32-accurate flops (SURVEY 8d: d^2 n_mc per contraction and estimate) x lanes / launch time; peak = f32-MFMA 157.3 TF; frac_16bit_pipe = x%d executed flops / 2500 TF" % nprod,
+                        basis="achieved = SURVEY 8d algorithmic bytes of the launch (vjp: lanes x (2 d n_mc + d^2) x 4 B) / launch time; peak = HBM 8 TB/s; frac_f32_mfma = d^2 n_mc flops x lanes / time / 157.3 TF; frac_16bit_pipe = x%d executed / 2500 TF" % nprod,
+                        f32_mfma=dict(achieved_TFLOPs=aL, peak=PEAK_F32_MFMA_TF, frac=aL / PEAK_F32_MFMA_TF),
                         pipe16=dict(products_per_block=nprod, executed_TFLOPs=nprod * aL, peak=PEAK_BF16_MFMA_TF, frac=nprod * aL / PEAK_BF16_MFMA_TF),
                         single_launch=keep)
             roof.pop("estimates_per_launch_note", None)
@@ -592,8 +602,8 @@ def compact_line(full):
             "bound": roof.get("bound"), "kernel": str(roof.get("kernel", ""))[:96],
             "achieved": _num(roof.get("achieved")), "peak": roof.get("peak"), "unit": roof.get("unit"), "frac": _num(roof.get("frac"), 4),
             # the same kernel on the pipe it executes on: split-operand products run on the 16-bit matrix pipe (2.5 PFLOP/s dense)
-            "frac_16bit_pipe": _num(_get(roof, "pipe16", "frac"), 4),
-            "basis": str(roof.get("basis", ""))[:160] or None,
+            "frac_16bit_pipe": _num(_get(roof, "pipe16", "frac"), 4), "frac_f32_mfma": _num(_get(roof, "f32_mfma", "frac"), 4),
+            "basis": str(roof.get("basis", ""))[:260] or None,
             "avg_launch_us": _num(roof.get("avg_launch_us"), 5), "lanes": lanes,
             "traffic": (None if not tr else {"bytes_per_launch": _num(tr.get("bytes_per_launch")), "lanes": tr.get("lanes_per_launch", lanes),
                                              "over_algorithmic": _num(tr.get("over_algorithmic"), 3), "src": str(tr.get("profile", ""))[:64] or None}),
@@ -603,7 +613,8 @@ def compact_line(full):
         if isinstance(oc, list):
             oc = oc[0] if oc else None
         if oc:
-            r["other"] = {"kernel": str(oc.get("kernel", ""))[:48], "avg_launch_us": _num(oc.get("avg_launch_us"), 5), "frac": _num(oc.get("frac"), 4)}
+            r["other"] = {"kernel": str(oc.get("kernel", ""))[:48], "avg_launch_us": _num(oc.get("avg_launch_us"), 5), "frac": _num(oc.get("frac"), 4),
+                          "frac_f32_mfma": _num(oc.get("frac_f32_mfma"), 4)}
         if roof.get("draws"):
             r["draws"] = {"avg_launch_us": _num(_get(roof, "draws", "avg_launch_us"), 5), "GBs": _num(_get(roof, "draws", "achieved_GBs"), 4)}
         we = full.get("whole_estimate") or {}

@@ -65,8 +65,15 @@ try:
     cal = json.load(open("profiles/pmc_calibration.json")).get("patterns", {})
 except (OSError, ValueError):
     pass
+# argv: fetch.db write.db [source] [fetch2.db write2.db ...]: further database pairs (other bench commands, e.g. the driver's --steps 20) only add
+# lane counts to the batch-engine kernels' by_lanes tables
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 fetch_g, write_g = per_kernel_grid(sys.argv[1], "FETCH_SIZE"), per_kernel_grid(sys.argv[2], "WRITE_SIZE")
+for i in range(4, len(sys.argv) - 1, 2):
+    for dst, db, cn in ((fetch_g, sys.argv[i], "FETCH_SIZE"), (write_g, sys.argv[i + 1], "WRITE_SIZE")):
+        for k, by in per_kernel_grid(db, cn).items():
+            for L, v in by.items():
+                dst.setdefault(k, {}).setdefault(L, v)
 kern = {}
 for k in sorted(set(fetch) | set(write)):
     if k.startswith("__amd"):

@@ -18,6 +18,12 @@ for w in ns c2 ns_stl ns_dense c3 c5; do
   { echo "# $TAG: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --concurrent 1 --workload $w --steps $steps --warmup 20"; echo;
     python $REPO/tools/rocpd_stats.py $db; } > $OUT/${TAG}_${w}_kernel_stats.md
 done
+# the driver's own protocol (--steps 20 --warmup 5: one 20-lane step per call): the in-chain averages of the scored shape
+rm -rf /tmp/prof_ns20
+rocprofv3 --kernel-trace --stats -d /tmp/prof_ns20 -o run -- $BENCH --workload ns --steps 20 --warmup 5 > /tmp/prof_ns20.log 2>&1
+db=$(find /tmp/prof_ns20 -name '*.db' | head -1)
+{ echo "# $TAG: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-also --concurrent 1 --workload ns --steps 20 --warmup 5 (the driver's protocol)"; echo;
+  python $REPO/tools/rocpd_stats.py $db; } > $OUT/${TAG}_ns20_kernel_stats.md
 # counter calibration on this library's access patterns (tools/ubench_fetchcal.hip), separate passes
 [ -x $REPO/tools/bin/ubench_fetchcal.exe ] || { mkdir -p $REPO/tools/bin; /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $REPO/tools/ubench_fetchcal.hip -o $REPO/tools/bin/ubench_fetchcal.exe; }
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -43,9 +49,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
   { echo "# $TAG: rocprofv3 --kernel-trace --pmc $c -- python bench.py --steps 200 --warmup 100 --no-cpu-baseline --concurrent 1"; echo;
     python $REPO/tools/rocpd_pmc.py $db; } > $OUT/${TAG}_ns_pmc_${c}.md
 done
+for c in FETCH_SIZE WRITE_SIZE; do   # ... and at the driver's --steps 20 (20 lanes per launch)
+  rm -rf /tmp/pmc20_$c
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc20_$c -o run -- python $REPO/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-also --concurrent 1 > /tmp/pmc20_$c.log 2>&1
+done
 cd $REPO
 python tools/pmc_traffic.py $(find /tmp/pmc_FETCH_SIZE -name '*.db' | head -1) $(find /tmp/pmc_WRITE_SIZE -name '*.db' | head -1) \
-  "$TAG: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 200 --warmup 100 --no-cpu-baseline --concurrent 1 (two separate passes)" > /dev/null
+  "$TAG: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --steps 200 --warmup 100 --no-cpu-baseline --concurrent 1 (two separate passes); batch-engine kernels also at --steps 20 --warmup 5 (20 lanes per launch)" \
+  $(find /tmp/pmc20_FETCH_SIZE -name '*.db' | head -1) $(find /tmp/pmc20_WRITE_SIZE -name '*.db' | head -1) > /dev/null
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 # the sharded step on one GPU (world 1, exchange forced): kernel stats of the peer-to-peer route
 rm -rf /tmp/prof_dist
