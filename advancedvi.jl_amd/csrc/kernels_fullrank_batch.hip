@@ -907,6 +907,10 @@ const FbTab *fb_prepare(mivi_ctx *c, int M, int L) {
   FbTab &t = ft.tab[ft.next_tab];
   ft.next_tab = (ft.next_tab + 1) & 3;
   invalidate_graph(c);   // a captured graph bakes the table contents
+  // the slot's previous tables may still be read by launches in flight on the context's stream (the uploads below are synchronous copies on
+  // the null stream, which a non-blocking stream does not order against); and a failed upload must not leave the slot looking valid
+  (void)hipStreamSynchronize(c->stream);
+  t.L = t.M = 0;
   const int d = c->cfg.d, nrb = d / kBM, ncb = M / kBN;
   std::vector<std::vector<int4>> lists(8);
   int panel = 0;
