@@ -663,11 +663,11 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w / (4 / WJ), wn = w % (4 / WJ);
-  if ((int)blockIdx.x >= a.n_work) {   // the objective values of the step's lanes: everything they sum is older than this launch
-    if (tid < 256) fb_value_block(a, (int)blockIdx.x - a.n_work, reinterpret_cast<double *>(lds));
+  if ((int)blockIdx.x < a.L) {   // the objective values of the step's lanes: everything they sum is older than this launch.  In FRONT of the
+    if (tid < 256) fb_value_block(a, (int)blockIdx.x, reinterpret_cast<double *>(lds));   // tiles: a one-workgroup latency chain each, hidden under them
     return;
   }
-  const __attribute__((address_space(4))) int *wp = (const __attribute__((address_space(4))) int *)a.work + 4 * blockIdx.x;
+  const __attribute__((address_space(4))) int *wp = (const __attribute__((address_space(4))) int *)a.work + 4 * ((int)blockIdx.x - a.L);
   const int ln = wp[0], rc = wp[1];
   const int rb = rc & 0xffff, cb = rc >> 16;
   const int d = a.d, M = a.M, nmg = M >> 4;
