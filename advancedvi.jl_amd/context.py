@@ -308,6 +308,11 @@ class MiviContext:
         """True when batches of estimates at this configuration run on the batch engine (mivi_batch_info what = 0)."""
         return int(self.lib.mivi_batch_info(self.h, self._p(params), 0)) == 1
 
+    def exchange_lost(self):
+        """True once a launch-free loop's grid-wide exchange was lost on this context: the loops with a per-step exchange are then not taken
+        again, their graph-of-launches equivalents run instead (mivi_batch_info what = 3)."""
+        return int(self.lib.mivi_batch_info(self.h, None, 3)) == 1
+
     def split_products(self):
         """Matrix-pipe products per product block of the engine's split-operand contractions (mivi_batch_info what = 1)."""
         return int(self.lib.mivi_batch_info(self.h, None, 1))

@@ -307,6 +307,7 @@ int32_t mivi_batch_info(const mivi_ctx_t *c, const void *params, int32_t what) {
   if (!c) return 0;
   if (what == 1) return 3;   // fr_planes.h kSplitProducts
   if (what == 2) return 4;   // two f16 planes
+  if (what == 3) return c->exchange_lost ? 1 : 0;
   return (what == 0 && params && fb_route(c, params, nullptr, nullptr)) ? 1 : 0;
 }
 

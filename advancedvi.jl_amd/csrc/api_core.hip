@@ -28,6 +28,12 @@ mivi_status_t fail(mivi_ctx *c, mivi_status_t s, const char *msg) {
   return s;
 }
 
+bool grid_resident(const mivi_ctx *c, const void *kernel, int block, size_t dyn_lds, long long grid) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, dyn_lds) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return c->n_cu > 0 && (long long)nb * c->n_cu >= grid;
+}
+
 mivi_status_t ensure(mivi_ctx *c, DevBuf &b, size_t bytes, bool zero) {
   if (b.bytes >= bytes && b.p) return MIVI_OK;
   if (b.p) HIPCHK(c, hipFree(b.p));
@@ -129,6 +135,12 @@ mivi_status_t mivi_create(const mivi_config_t *cfg, mivi_ctx_t **out) {
   mivi_ctx *c = new mivi_ctx();
   c->cfg = *cfg;
   c->esize = cfg->dtype == MIVI_F32 ? 4 : 8;
+  {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && v > 0) c->n_cu = v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device) == hipSuccess && v > 0) c->lds_max = (size_t)v;
+    (void)hipGetLastError();
+  }
   c->M_total = cfg->m_total > 0 ? cfg->m_total : cfg->n_mc;
   if (hipSetDevice(cfg->device) != hipSuccess) { delete c; return MIVI_ERR_HIP; }
   if (!cfg->own_stream) {
@@ -170,7 +182,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   {
-    DevBuf *fbb[] = {&c->fb.CA, &c->fb.epsP, &c->fb.epsV, &c->fb.WV, &c->fb.ell, &c->fb.he, &c->fb.ld, &c->fb.grads, &c->fb.values, &c->fb.PA, &c->fb.RP, &c->fb.Tinv, &c->fb.TA, &c->fb.Eye, &c->fb.cscale, &c->fb.pscale, &c->fb.tscale, &c->fb.winv, &c->fb.rinv, &c->p2p_direct, &c->rows_eps, &c->tiles_buf, &c->gen_scratch};
+    DevBuf *fbb[] = {&c->fb.CA, &c->fb.epsP, &c->fb.epsV, &c->fb.WV, &c->fb.ell, &c->fb.he, &c->fb.ld, &c->fb.grads, &c->fb.values, &c->fb.PA, &c->fb.RP, &c->fb.Tinv, &c->fb.TA, &c->fb.Eye, &c->snap, &c->fb.cscale, &c->fb.pscale, &c->fb.tscale, &c->fb.winv, &c->fb.rinv, &c->p2p_direct, &c->rows_eps, &c->gen_scratch};
     for (DevBuf *b : fbb)
       if (b->p) (void)hipFree(b->p);
     for (auto &tb : c->fb.tab) {

@@ -401,6 +401,7 @@ mivi_status_t read_status(mivi_ctx *c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int st = 0;
   for (int j = 0; j < nw; ++j) st |= sk[j];
+  c->last_status_bits = st;
   if (st) HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * nw, c->stream));
   if (st & 8) return fail(c, MIVI_ERR_HIP, "a device-side wait expired (peer-to-peer exchange: a peer did not arrive within the spin budget -- lost rank or unmapped buffer; a launch-free loop with a per-step exchange -- funnel target, DoG / DoWG, tile ownership: its workgroups did not run side by side)");
   if (st & 2) return fail(c, MIVI_ERR_NONPOSITIVE_SCALE, "scale diagonal is not positive (use ClipScale)");

@@ -60,17 +60,18 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *c, void *params, void *opt_state, 
   return mivi_optimize_loop(c, params, &l);
 }
 
-// elbo record (double, device) -> caller's T[n_steps]
+// elbo record (double, device) -> caller's T[n_steps], on the device (no host round trip inside a "launch-free" call)
+__global__ void k_elbo_to_f32(int n, const double *__restrict__ rec, float *__restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (float)rec[i];
+}
 static mivi_status_t deliver_elbo(mivi_ctx *c, const double *rec, int n_steps, void *elbo) {
   if (!elbo) return MIVI_OK;
   if (c->cfg.dtype == MIVI_F64) {
     HIPCHK(c, hipMemcpyAsync(elbo, rec, (size_t)n_steps * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   } else {
-    std::vector<double> h(n_steps);
-    HIPCHK(c, hipMemcpyAsync(h.data(), rec, (size_t)n_steps * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    std::vector<float> f(h.begin(), h.end());
-    HIPCHK(c, hipMemcpy(elbo, f.data(), (size_t)n_steps * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_elbo_to_f32, dim3((n_steps + 255) / 256), dim3(256), 0, c->stream, n_steps, rec, (float *)elbo);
+    HIPCHK(c, hipGetLastError());
   }
   return MIVI_OK;
 }
@@ -81,8 +82,9 @@ static bool same_loop(const mivi_loop_t &a, const mivi_loop_t &b) {   // everyth
          a.avg_eta == b.avg_eta && a.opt_state_dev == b.opt_state_dev && a.avg_params_dev == b.avg_params_dev;
 }
 
-mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t *lp) {
-  if (!c || !params || !lp) return MIVI_ERR_BAD_ARG;
+// One call's steps on the best route.  allow_exchange = false: the launch-free loops whose workgroups exchange partials grid-wide every step are
+// skipped (their graph-of-launches equivalents run instead); *used_exchange: one of them was launched.
+static mivi_status_t optimize_loop_run(mivi_ctx_t *c, void *params, const mivi_loop_t *lp, bool allow_exchange, bool *used_exchange) {
   const mivi_loop_t &l = *lp;
   const int n_steps = l.n_steps, rule = l.rule;
   if (n_steps <= 0 || rule < 0 || rule > 3 || l.op < 0 || l.op > 2 || l.averager < 0 || l.averager > 1) return MIVI_ERR_BAD_ARG;
@@ -121,26 +123,30 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);
   }
-  if (lr_small_loop_ok(c) && !no_fused_loop) {
+  if (lr_small_loop_ok(c) && !no_fused_loop && allow_exchange) {
     // small hierarchical logistic regressions (the reference README's own example, BASELINE configs[0]): the whole loop in ONE workgroup, every
-    // rule x operator x averager (k_lr_small_loop)
+    // rule x operator x averager (k_lr_small_loop); larger ones: up to 64 workgroups that exchange partial sums every step
     if (lr_small_part_bytes(c, n_steps) && (s = ensure(c, c->gen_scratch, lr_small_part_bytes(c, n_steps) + 256, false))) return s;
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
-    launch_lr_small_loop(c, params, l, rec, vbuf, (double *)c->gen_scratch.p);
-    HIPCHK(c, hipGetLastError());
-    if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
-    return read_status(c);
+    if (launch_lr_small_loop(c, params, l, rec, vbuf, (double *)c->gen_scratch.p)) {
+      *used_exchange = true;
+      HIPCHK(c, hipGetLastError());
+      if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
+      return read_status(c);
+    }
   }
   const bool general = !simple || (rule == 1 && !default_adam);   // (Adam with other betas than the fused paths' defaults: the general loops take them from the call)
-  if (general && mf_gen_loop_ok(c, rule) && !no_fused_loop) {
+  if (general && mf_gen_loop_ok(c, rule) && !no_fused_loop && (rule < 2 || allow_exchange)) {
     // every other rule x operator x averager of the reference's algorithms (DoG / DoWG, ProximalLocationScaleEntropy, PolynomialAveraging -- its
     // defaults), mean-field + diagonal-Gaussian target: launch-free as well (k_mf_gen_loop; DoG / DoWG: one grid-wide exchange of two norms per step)
     if ((s = ensure(c, c->gen_scratch, mf_gen_loop_scratch_bytes(c, n_steps), false))) return s;
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
-    launch_mf_gen_loop(c, params, l, rec + n_steps, rec, (char *)c->gen_scratch.p);
-    HIPCHK(c, hipGetLastError());
-    if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
-    return read_status(c);
+    if (launch_mf_gen_loop(c, params, l, rec + n_steps, rec, (char *)c->gen_scratch.p)) {
+      if (rule >= 2) *used_exchange = true;
+      HIPCHK(c, hipGetLastError());
+      if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
+      return read_status(c);
+    }
   }
   if (general && fr_small_loop_ok(c) && !no_fused_loop) {
     // ... and small full-rank problems in one workgroup (k_fr_small_loop: the two norms of DoG / DoWG are block sums there)
@@ -150,33 +156,19 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);
   }
-  if (general && fr_rows_loop_ok(c) && (rule < 2 || c->cfg.d <= 1024) && !no_fused_loop && fr_rows_eps_bytes(c, n_steps) <= ((size_t)1 << 31)) {
+  if (general && fr_rows_loop_ok(c) && (rule < 2 || allow_exchange) && !no_fused_loop && fr_rows_eps_bytes(c, n_steps) <= ((size_t)1 << 31)) {
     // ... and on the full-rank family with few samples per step (the reference's default n_samples = 1): the row-owning workgroups of
-    // k_fr_rows_loop, DoG / DoWG with the same per-step exchange of two norm partials (every workgroup resident: d <= 1024)
+    // k_fr_rows_loop, DoG / DoWG with the same per-step exchange of two norm partials (every workgroup resident: checked by the launcher)
     if ((s = ensure(c, c->rows_eps, fr_rows_eps_bytes(c, n_steps), false))) return s;
     if (rule >= 2 && (s = ensure(c, c->gen_scratch, fr_rows_part_bytes(c, n_steps) + 256, false))) return s;
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
-    launch_fr_rows_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, (float *)c->rows_eps.p, rec + n_steps, rec, vbuf, &l,
-                        (double *)c->gen_scratch.p);
-    HIPCHK(c, hipGetLastError());
-    if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
-    return read_status(c);
-  }
-  if (simple && (rule == 0 || default_adam) && fr_tiles_loop_ok(c) && !no_fused_loop) {
-    // the north-star shape class: ONE persistent kernel whose workgroups own tiles of tril(C) (parameters and moments in registers) and exchange
-    // partial products / W inside their row block, bitwise the launch-per-step trajectory (k_fr_tiles_loop).  eps is drawn up front for a chunk
-    // of steps at a time (1 MB per step at d = 1024, n_mc = 256).
-    const int CH = 256;
-    if ((s = ensure(c, c->tiles_buf, fr_tiles_bytes(c, n_steps < CH ? n_steps : CH), false))) return s;
-    HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
-    for (int off = 0; off < n_steps; off += CH) {
-      const int n = n_steps - off < CH ? n_steps - off : CH;
-      launch_fr_tiles_loop(c, params, opt_state, l.estimate_idx0 + (uint64_t)off, (long long)l.t0 + off, n, rule, eta, clip_eps, (char *)c->tiles_buf.p,
-                           rec + off, vbuf);
+    if (launch_fr_rows_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, (float *)c->rows_eps.p, rec + n_steps, rec, vbuf, &l,
+                            (double *)c->gen_scratch.p)) {
+      if (rule >= 2) *used_exchange = true;
       HIPCHK(c, hipGetLastError());
+      if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
+      return read_status(c);
     }
-    if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
-    return read_status(c);
   }
   if (simple && (rule == 0 || default_adam) && fr_small_loop_ok(c) && !no_fused_loop) {
     // small full-rank problems (the reference's own benchmark grid: d = 10, one sample per step): the whole loop in ONE workgroup
@@ -191,13 +183,14 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     // optimiser state in registers for all n_steps (k_fr_rows_loop); eps of the whole call is drawn up front
     if ((s = ensure(c, c->rows_eps, fr_rows_eps_bytes(c, n_steps), false))) return s;
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
-    launch_fr_rows_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, (float *)c->rows_eps.p, rec + n_steps, rec, vbuf);
-    HIPCHK(c, hipGetLastError());
-    if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
-    return read_status(c);
+    if (launch_fr_rows_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, (float *)c->rows_eps.p, rec + n_steps, rec, vbuf)) {
+      HIPCHK(c, hipGetLastError());
+      if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
+      return read_status(c);
+    }
   }
   if (simple && (rule == 0 || default_adam) && c->cfg.family == MIVI_MEANFIELD && c->target == TGT_FUNNEL && !c->funnel_constrained && !c->bij_on &&
-      c->cfg.n_mc <= 256 && c->cfg.d <= 16384 && !no_fused_loop) {
+      c->cfg.n_mc <= 256 && c->cfg.d <= 16384 && !no_fused_loop && allow_exchange) {
     // launch-free loop for the fused funnel target: the row quads and the row-0 workgroup of ONE kernel exchange two scalars per workgroup and
     // row 0's parameters per step (k_mf_funnel_sgd_loop) instead of three launches per step
     double *hist = (double *)(((uintptr_t)(rec + n_steps) + 127) & ~(uintptr_t)127);
@@ -205,10 +198,12 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     void *pub = (void *)(rec + n_steps + hist_doubles - (nq / 2 + 8));
     unsigned *sync = (unsigned *)((double *)pub + 4);
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
-    launch_mf_funnel_sgd_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, hist, sync, pub, gbuf, rec, vbuf);
-    HIPCHK(c, hipGetLastError());
-    if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
-    return read_status(c);
+    if (launch_mf_funnel_sgd_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, hist, sync, pub, gbuf, rec, vbuf)) {
+      *used_exchange = true;
+      HIPCHK(c, hipGetLastError());
+      if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
+      return read_status(c);
+    }
   }
   GraphCache &g = c->graph;
   if (!(g.exec && g.kind == 9 && g.params == params && g.value == (void *)vbuf && same_loop(g.loop, l))) {
@@ -280,3 +275,39 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
   return read_status(c);
 }
 
+// `optimize`'s inner loop (src/optimize.jl:64-77) on the device.  The launch-free loops whose workgroups exchange partials every step need their
+// whole grid resident: the launchers check that against the device (hipOccupancyMaxActiveBlocksPerMultiprocessor x CUs), and should an exchange
+// still be lost at run time (status bit 8: another context's work took the CUs), the call restores the state it was given and runs the same
+// steps on the graph of launches; the context then stays on that route.
+mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t *lp) {
+  if (!c || !params || !lp) return MIVI_ERR_BAD_ARG;
+  const mivi_loop_t &l = *lp;
+  (void)hipSetDevice(c->cfg.device);
+  const size_t plen = (size_t)mivi_params_len(c), es = c->esize;
+  const size_t st_bytes = !l.opt_state_dev ? 0 : (l.rule == 1 ? 2 * plen * es : (l.rule >= 2 ? (size_t)mivi_dog_state_bytes(c) : 0));
+  const size_t avg_bytes = (l.averager == 1 && l.avg_params_dev) ? plen * es : 0;
+  const bool may_exchange = !c->exchange_lost && (l.rule >= 2 || c->target == TGT_FUNNEL || c->target == TGT_LOGREG);
+  if (may_exchange && l.n_steps > 0 && l.rule >= 0 && l.rule <= 3) {
+    mivi_status_t s = ensure(c, c->snap, plen * es + st_bytes + avg_bytes + 64, false);
+    if (s) return s;
+    char *sp = (char *)c->snap.p;
+    HIPCHK(c, hipMemcpyAsync(sp, params, plen * es, hipMemcpyDeviceToDevice, c->stream));
+    if (st_bytes) HIPCHK(c, hipMemcpyAsync(sp + plen * es, l.opt_state_dev, st_bytes, hipMemcpyDeviceToDevice, c->stream));
+    if (avg_bytes) HIPCHK(c, hipMemcpyAsync(sp + plen * es + st_bytes, l.avg_params_dev, avg_bytes, hipMemcpyDeviceToDevice, c->stream));
+  }
+  bool used = false;
+  mivi_status_t s = optimize_loop_run(c, params, lp, may_exchange, &used);
+  static const bool force_lost = getenv("MIVI_FORCE_EXCHANGE_LOST") != nullptr;   // test hook (tests/test_gpu_loop_oracle.py): treat the first exchanging call as lost
+  if (force_lost && used && s == MIVI_OK) { s = MIVI_ERR_HIP; c->last_status_bits |= 8; }
+  if (s == MIVI_ERR_HIP && used && (c->last_status_bits & 8)) {
+    const char *sp = (const char *)c->snap.p;
+    HIPCHK(c, hipMemcpyAsync(params, sp, plen * es, hipMemcpyDeviceToDevice, c->stream));
+    if (st_bytes) HIPCHK(c, hipMemcpyAsync(l.opt_state_dev, sp + plen * es, st_bytes, hipMemcpyDeviceToDevice, c->stream));
+    if (avg_bytes) HIPCHK(c, hipMemcpyAsync(l.avg_params_dev, sp + plen * es + st_bytes, avg_bytes, hipMemcpyDeviceToDevice, c->stream));
+    c->exchange_lost = true;
+    c->err.clear();
+    used = false;
+    s = optimize_loop_run(c, params, lp, false, &used);
+  }
+  return s;
+}

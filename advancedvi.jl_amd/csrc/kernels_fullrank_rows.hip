@@ -443,7 +443,7 @@ bool fr_rows_loop_ok(const mivi_ctx *c) {
     return false;
   const int Mp = rows_mp(rows_mm(M));
   // two rows' threads fit 128 (d <= 1126); the slab fits the LDS beside the exchange areas; 16-byte slab copies
-  return d >= 8 && d <= 126 * kRowsEPT - 8 && ((long long)d * Mp) % 4 == 0 && (size_t)d * Mp * 4 + (8 * kRowsMaxM + 32 + 2 * 256 + 32) * 4 <= 160 * 1024;
+  return d >= 8 && d <= 126 * kRowsEPT - 8 && ((long long)d * Mp) % 4 == 0 && (size_t)d * Mp * 4 + (8 * kRowsMaxM + 32 + 2 * 256 + 32) * 4 <= c->lds_max;
 }
 size_t fr_rows_eps_bytes(const mivi_ctx *c, int n_steps) { return (size_t)n_steps * c->cfg.d * rows_mp(rows_mm(c->cfg.n_mc)) * sizeof(float); }
 size_t fr_rows_hist_doubles(const mivi_ctx *c, int n_steps) { return (size_t)n_steps * 4 * (size_t)((c->cfg.d + 3) / 4); }
@@ -452,7 +452,7 @@ size_t fr_rows_hist_doubles(const mivi_ctx *c, int n_steps) { return (size_t)n_s
 size_t fr_rows_part_bytes(const mivi_ctx *c, int n_steps) { return (size_t)n_steps * (size_t)((c->cfg.d + 3) / 4) * 2 * sizeof(double); }
 
 // gen: the general loop's description (rules / operators / averager beyond Descent / Adam + ClipScale; part: fr_rows_part_bytes) or nullptr
-void launch_fr_rows_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta, double clip_eps,
+bool launch_fr_rows_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta, double clip_eps,
                          float *eps_all, double *hist, double *elbo, void *value, const mivi_loop_t *gen, double *part) {
   const int d = c->cfg.d, M = c->cfg.n_mc, d4 = (d + 3) / 4, MM = rows_mm(M), Mp = rows_mp(MM);
   {
@@ -479,10 +479,18 @@ void launch_fr_rows_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t id
   const int nwg = (d + 3) / 4;   // two row pairs per workgroup
   a.nch = MM >= 8 ? MM / 8 : 1;
   const size_t extras = (8 * kRowsMaxM + 32 + 2 * 256 + 32) * sizeof(float), slab = (size_t)d * Mp * sizeof(float);
-  const bool db = 2 * slab + extras <= 160 * 1024;
+  const bool db = 2 * slab + extras <= c->lds_max;
   const size_t lds = (db ? 2 : 1) * slab + extras;
+  bool launched = true;
   auto go = [&](auto kern) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // the LDS the kernel asks for must be granted, and -- DoG / DoWG: two norm partials exchanged grid-wide every step by spin-wait -- every
+    // workgroup must be resident at once: both checked against the device, not assumed (false: the caller takes the graph of launches)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        (rule >= 2 && !grid_resident(c, reinterpret_cast<const void *>(kern), kRowsNT, lds, nwg))) {
+      (void)hipGetLastError();
+      launched = false;
+      return;
+    }
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(kRowsNT), lds, c->stream, a);
   };
   const bool general = gen && (gen->op == 2 || gen->averager == 1);
@@ -513,8 +521,10 @@ void launch_fr_rows_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t id
   else if (rule == 1) { if (db) pick(I1{}, std::true_type{}); else pick(I1{}, std::false_type{}); }
   else if (rule == 2) { if (db) pick(I2{}, std::true_type{}); else pick(I2{}, std::false_type{}); }
   else { if (db) pick(I3{}, std::true_type{}); else pick(I3{}, std::false_type{}); }
+  if (!launched) return false;
   hipLaunchKernelGGL(k_fr_rows_value, dim3(n_steps), dim3(256), 0, c->stream, d, nwg, M, c->M_total, c->cfg.entropy, c->t_const, (const double *)hist, elbo,
                      (float *)value, n_steps, (int *)c->status.p);
+  return true;
 }
 
 }  // namespace mivi

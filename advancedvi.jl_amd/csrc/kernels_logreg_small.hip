@@ -491,11 +491,11 @@ bool lr_small_loop_ok(const mivi_ctx *c) {
   // 4000 x 16 x 4 (sixteen): 17.5 / 33; 208 x 60 x 8 (seven): 28.9 / 36; 1000 x 32 x 16 (32; BASELINE configs[0]): 35.4 / 31 -- a step's fixed
   // work and the exchanged partials grow with (d - 1) n_mc.  Taken where it wins: (d - 1) n_mc <= 256.
   return (long long)(d - 1) * M <= 256 && (long long)c->lr_n * (d - 1) * M <= (1ll << 20) &&
-         lr_small_lds(c, lr_small_groups(c), false, nullptr) <= 160 * 1024;
+         lr_small_lds(c, lr_small_groups(c), false, nullptr) <= c->lds_max;
 }
 
 template <typename T>
-static void lr_small_loop_impl(mivi_ctx *c, void *params, const mivi_loop_t &l, double *elbo, void *value, double *part) {
+static bool lr_small_loop_impl(mivi_ctx *c, void *params, const mivi_loop_t &l, double *elbo, void *value, double *part) {
   LrSmallLoopArgs<T> a;
   a.family = c->cfg.family; a.d = c->cfg.d; a.M = c->cfg.n_mc; a.n_steps = l.n_steps; a.rule = l.rule; a.ent_kind = c->cfg.entropy;
   a.m_offset = c->cfg.m_offset; a.M_total = c->M_total; a.variant = c->lr_variant; a.n = c->lr_n;
@@ -515,11 +515,18 @@ static void lr_small_loop_impl(mivi_ctx *c, void *params, const mivi_loop_t &l, 
   if (G > 1) (void)hipMemsetAsync(part, 0xFF, lr_small_part_bytes(c, l.n_steps), c->stream);   // (NaN: not delivered yet)
   int ldx = 0;
   const size_t with_x = lr_small_lds(c, G, true, &ldx);
-  a.x_resident = with_x <= 160 * 1024 ? 1 : 0;
+  a.x_resident = with_x <= c->lds_max ? 1 : 0;
   a.ldx = ldx;
   const size_t lds = a.x_resident ? with_x : lr_small_lds(c, G, false, nullptr);
+  bool launched = true;
   auto go = [&](auto kern) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // (the LDS must be granted; G > 1 workgroups exchange their partial sums every step by spin-wait: all of them resident -- checked)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        (G > 1 && !grid_resident(c, reinterpret_cast<const void *>(kern), kLrSmallNT, lds, G))) {
+      (void)hipGetLastError();
+      launched = false;
+      return;
+    }
     hipLaunchKernelGGL(kern, dim3(G), dim3(kLrSmallNT), lds, c->stream, a);
   };
   if (a.x_resident) {
@@ -537,11 +544,12 @@ static void lr_small_loop_impl(mivi_ctx *c, void *params, const mivi_loop_t &l, 
       default: go(k_lr_small_loop<T, 3, false>); break;
     }
   }
+  return launched;
 }
 // elbo: n_steps doubles; value: one element of T (the last step's objective value)
-void launch_lr_small_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *elbo, void *value, double *part) {
-  if (c->cfg.dtype == MIVI_F32) lr_small_loop_impl<float>(c, params, l, elbo, value, part);
-  else lr_small_loop_impl<double>(c, params, l, elbo, value, part);
+bool launch_lr_small_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *elbo, void *value, double *part) {
+  if (c->cfg.dtype == MIVI_F32) return lr_small_loop_impl<float>(c, params, l, elbo, value, part);
+  return lr_small_loop_impl<double>(c, params, l, elbo, value, part);
 }
 
 }  // namespace mivi

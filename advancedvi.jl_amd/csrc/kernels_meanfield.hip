@@ -753,7 +753,7 @@ size_t mf_gen_loop_scratch_bytes(const mivi_ctx *c, int n_steps) {   // partial 
 }
 
 template <typename T>
-static void mf_gen_loop_impl(mivi_ctx *c, void *params, const mivi_loop_t &l, double *hist, double *elbo, char *scratch) {
+static bool mf_gen_loop_impl(mivi_ctx *c, void *params, const mivi_loop_t &l, double *hist, double *elbo, char *scratch) {
   MfGenLoopArgs<T> a;
   a.d = c->cfg.d; a.M = c->cfg.n_mc; a.n_steps = l.n_steps; a.rule = l.rule; a.op = l.op; a.averager = l.averager;
   a.params = (T *)params;
@@ -770,6 +770,9 @@ static void mf_gen_loop_impl(mivi_ctx *c, void *params, const mivi_loop_t &l, do
   a.part = (double *)scratch;
   a.status = (int *)c->status.p;
   a.spin = 1 << 20;
+  // DoG / DoWG: a grid-wide exchange of two norm partials per step by spin-wait -- every workgroup must be resident: checked against the device
+  if (l.rule >= 2 && !grid_resident(c, l.rule == 2 ? reinterpret_cast<const void *>(k_mf_gen_loop<T, 2>) : reinterpret_cast<const void *>(k_mf_gen_loop<T, 3>), 256, 0, d4))
+    return false;
   if (l.rule >= 2) (void)hipMemsetAsync(a.part, 0xFF, (size_t)l.n_steps * d4 * 2 * sizeof(double), c->stream);   // (NaN: not delivered yet)
   switch (l.rule) {
     case 0: hipLaunchKernelGGL((k_mf_gen_loop<T, 0>), dim3(d4), dim3(256), 0, c->stream, a); break;
@@ -779,11 +782,13 @@ static void mf_gen_loop_impl(mivi_ctx *c, void *params, const mivi_loop_t &l, do
   }
   hipLaunchKernelGGL(k_mf_loop_value<T>, dim3(l.n_steps), dim3(256), 0, c->stream, a.d, d4, a.M, a.M_total, a.ent_kind, c->t_const, (const double *)hist, elbo,
                      (int *)c->status.p);
+  return true;
 }
-// hist: n_steps * 4 * ceil(d / 4) doubles; elbo: n_steps doubles; scratch: mf_gen_loop_scratch_bytes
-void launch_mf_gen_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *hist, double *elbo, char *scratch) {
-  if (c->cfg.dtype == MIVI_F32) mf_gen_loop_impl<float>(c, params, l, hist, elbo, scratch);
-  else mf_gen_loop_impl<double>(c, params, l, hist, elbo, scratch);
+// hist: n_steps * 4 * ceil(d / 4) doubles; elbo: n_steps doubles; scratch: mf_gen_loop_scratch_bytes.  false: not launched (the device cannot hold the
+// exchanging grid at once): the caller takes the graph of launches
+bool launch_mf_gen_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *hist, double *elbo, char *scratch) {
+  if (c->cfg.dtype == MIVI_F32) return mf_gen_loop_impl<float>(c, params, l, hist, elbo, scratch);
+  return mf_gen_loop_impl<double>(c, params, l, hist, elbo, scratch);
 }
 
 // rule 0 Descent / 1 Adam: n_steps SGD iterations;  rule -1: n_steps estimates at fixed parameters, the last one's gradient
@@ -1310,7 +1315,7 @@ __global__ __launch_bounds__(256) void k_mf_funnel_sgd_loop(MfFunnelSgdArgs<T> a
 }
 
 template <typename T>
-static void mf_funnel_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta,
+static bool mf_funnel_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta,
                                     double clip_eps, double *hist, unsigned *sync, void *pub, void *gtmp, double *elbo, void *value) {
   MfFunnelSgdArgs<T> a;
   a.d = c->cfg.d; a.M = c->cfg.n_mc; a.n_steps = n_steps; a.rule = rule;
@@ -1323,8 +1328,11 @@ static void mf_funnel_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, 
   a.status = (int *)c->status.p;
   a.spin = 1 << 22;
   const int d4 = (a.d + 3) / 4;
-  (void)hipMemsetAsync(sync, 0, (2 + (size_t)d4) * sizeof(unsigned), c->stream);
   const dim3 grid(d4 + 1), block(256);
+  const void *kern = a.M <= 64 ? (rule == 0 ? reinterpret_cast<const void *>(k_mf_funnel_sgd_loop<T, 1, 0>) : reinterpret_cast<const void *>(k_mf_funnel_sgd_loop<T, 1, 1>))
+                               : (rule == 0 ? reinterpret_cast<const void *>(k_mf_funnel_sgd_loop<T, 4, 0>) : reinterpret_cast<const void *>(k_mf_funnel_sgd_loop<T, 4, 1>));
+  if (!grid_resident(c, kern, 256, 0, d4 + 1)) return false;   // (a grid-wide exchange per step: every workgroup resident -- checked, not assumed)
+  (void)hipMemsetAsync(sync, 0, (2 + (size_t)d4) * sizeof(unsigned), c->stream);
   if (a.M <= 64) {
     if (rule == 0) hipLaunchKernelGGL((k_mf_funnel_sgd_loop<T, 1, 0>), grid, block, 0, c->stream, a);
     else hipLaunchKernelGGL((k_mf_funnel_sgd_loop<T, 1, 1>), grid, block, 0, c->stream, a);
@@ -1332,13 +1340,14 @@ static void mf_funnel_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, 
     if (rule == 0) hipLaunchKernelGGL((k_mf_funnel_sgd_loop<T, 4, 0>), grid, block, 0, c->stream, a);
     else hipLaunchKernelGGL((k_mf_funnel_sgd_loop<T, 4, 1>), grid, block, 0, c->stream, a);
   }
+  return true;
 }
 // n_steps optimisation steps of the fused funnel target in ONE launch (n_mc <= 256).  hist: 128-byte aligned, n_steps * roundup(6 * ceil(d/4), 16) doubles; sync: 2 + ceil(d/4) words;
 // pub: 4 elements of T; gtmp: d + 1 elements of T; elbo: n_steps doubles; value: one element of T (the last step's objective value).
-void launch_mf_funnel_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta,
+bool launch_mf_funnel_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta,
                                double clip_eps, double *hist, unsigned *sync, void *pub, void *gtmp, double *elbo, void *value) {
-  if (c->cfg.dtype == MIVI_F32) mf_funnel_sgd_loop_impl<float>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, sync, pub, gtmp, elbo, value);
-  else mf_funnel_sgd_loop_impl<double>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, sync, pub, gtmp, elbo, value);
+  if (c->cfg.dtype == MIVI_F32) return mf_funnel_sgd_loop_impl<float>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, sync, pub, gtmp, elbo, value);
+  return mf_funnel_sgd_loop_impl<double>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, sync, pub, gtmp, elbo, value);
 }
 
 // rand(rng, q::MvLocationScale{<:Diagonal}, M): Z = mu + sigma .* eps  (location_scale.jl:80-87)

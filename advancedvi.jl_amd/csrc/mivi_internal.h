@@ -286,7 +286,6 @@ struct mivi_ctx {
   bool p2p_opened[8] = {false, false, false, false, false, false, false, false};                   // hipIpcOpenMemHandle'd (to be closed)
   mivi::DevBuf rows_eps;   // kernels_fullrank_rows.hip: eps of all steps of a device-resident loop call
   mivi::DevBuf gen_scratch;  // kernels_meanfield.hip k_mf_gen_loop: DoG / DoWG partial norms of every step, arrival flags
-  mivi::DevBuf tiles_buf;  // kernels_fullrank_tiles.hip: eps of a chunk of steps, exchange areas, flags, value partials
   mivi::DevBuf p2p_tab, p2p_ctr, p2p_scratch, p2p_direct;   // (p2p_direct: P2PDirectTab, what the partial kernels need to store straight into the owners' staging areas)
   bool p2p_on = false;
   int p2p_rank = 0, p2p_world = 1, p2p_G = 1, p2p_vs = 0, p2p_spin = 1 << 21;
@@ -365,6 +364,11 @@ struct mivi_ctx {
   // whose kernels overlap on the device (the product of one chain's estimate runs beside the VJP of another's).
   int idx_stride = 1;            // estimate-index step between consecutive estimates of THIS context's chain
   bool is_child = false;         // target buffers are borrowed from the parent
+  int n_cu = 0;                  // compute units of the device, LDS bytes a workgroup may take: what the launch-free loops with a grid-wide
+  size_t lds_max = 64 * 1024;    // exchange per step check their grids against (hipOccupancyMaxActiveBlocksPerMultiprocessor x n_cu >= grid)
+  bool exchange_lost = false;    // a grid-wide exchange expired once on this context (status bit 8): those loops are not taken again
+  int last_status_bits = 0;      // the sticky device flags read_status saw last
+  mivi::DevBuf snap;             // parameters / optimiser state / average before a loop with a grid-wide exchange (restored if it is lost)
   static constexpr int kMaxKids = 15;   // up to sixteen contexts (eight are used); at most FOUR graph branches (a forked graph with five branches crashed inside hipGraphLaunch,
                                        // hip::Graph::UpdateStreams, after a re-capture on ROCm 7.0's runtime; four is also the number of hardware queues)
   mivi_ctx *kids[kMaxKids] = {};
@@ -393,22 +397,18 @@ void launch_mf_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx
 bool fr_rows_loop_ok(const mivi_ctx *c);    // kernels_fullrank_rows.hip: f32, n_mc <= 32, d <= 1024, diagonal-Gaussian target, not STL
 size_t fr_rows_eps_bytes(const mivi_ctx *c, int n_steps);
 size_t fr_rows_part_bytes(const mivi_ctx *c, int n_steps);
-void launch_fr_rows_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta, double clip_eps,
+bool launch_fr_rows_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta, double clip_eps,
                          float *eps_all, double *hist, double *elbo, void *value, const mivi_loop_t *gen = nullptr, double *part = nullptr);
 bool lr_small_loop_ok(const mivi_ctx *c);   // kernels_logreg_small.hip: the logistic-regression target, d <= 64, (d - 1) n_mc <= 256, n (d - 1) n_mc <= 2^20: one workgroup per 2^14 of them
 size_t lr_small_part_bytes(const mivi_ctx *c, int n_steps);   // 0: one workgroup, no exchange
-void launch_lr_small_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *elbo, void *value, double *part);
+bool launch_lr_small_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *elbo, void *value, double *part);
 bool mf_gen_loop_ok(const mivi_ctx *c, int rule);   // kernels_meanfield.hip: every rule x operator x averager, mean-field + diagonal-Gaussian target
 size_t mf_gen_loop_scratch_bytes(const mivi_ctx *c, int n_steps);
-void launch_mf_gen_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *hist, double *elbo, char *scratch);
-bool fr_tiles_loop_ok(const mivi_ctx *c);   // kernels_fullrank_tiles.hip: f32, d <= 1024 (multiple of 64), n_mc 128 / 256, diagonal-Gaussian target, not STL
-size_t fr_tiles_bytes(const mivi_ctx *c, int n_steps);
-void launch_fr_tiles_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta, double clip_eps,
-                          char *buf, double *elbo, void *value);
+bool launch_mf_gen_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double *hist, double *elbo, char *scratch);
 bool fr_small_loop_ok(const mivi_ctx *c);   // kernels_fullrank_small.hip: d <= 32, n_mc <= 64, diagonal-Gaussian target
 void launch_fr_small_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta,
                           double clip_eps, double *elbo, void *value, const mivi_loop_t *gen = nullptr);
-void launch_mf_funnel_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta,
+bool launch_mf_funnel_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule, double eta,
                                double clip_eps, double *hist, unsigned *sync, void *pub, void *gtmp, double *elbo, void *value);
 void launch_mf_funnel_loop(mivi_ctx *c, const void *params, uint64_t idx0, int n_steps, double *hist, double *elbo, void *scratch,
                            void *value, void *grad, void *lane_scratch, void *e0_tab = nullptr);
@@ -479,6 +479,8 @@ void launch_lds_stein_outer(mivi_ctx *c, int M, void *A, double *gsum, int first
 void invalidate_graph(mivi_ctx *c);            // api_core.hip: drop the cached hipGraphExec and the eps speculation
 
 // kernels_fullrank_batch.hip (f32, diagonal-Gaussian target, d % 128 == 0, M % 128 == 0): L estimates at the same parameters per launch
+// every workgroup of `grid` resident at once?  (loops whose workgroups exchange partials every step by spin-wait: checked at launch, never assumed)
+bool grid_resident(const mivi_ctx *c, const void *kernel, int block, size_t dyn_lds, long long grid);
 bool fb_shape_ok(const mivi_ctx *c, int M);
 const FbTab *fb_prepare(mivi_ctx *c, int M, int L);   // work tables for L lanes (nullptr: allocation failed)
 size_t fb_plane_words(const mivi_ctx *c, int M);      // 4-byte words of one lane's operand planes (eps in one orientation, W)

@@ -67,11 +67,17 @@ __device__ __forceinline__ T clip_step(T v, T eps) {
 
 // ProximalLocationScaleEntropy on one scale-diagonal entry: argmin_c' -log c' + (c' - c)^2 / (2 gamma)
 // = c + (sqrt(c^2 + 4 gamma) - c) / 2     (src/optimization/proximal_location_scale_entropy.jl:56)
+// For c < 0 (an un-clipped DoG / DoWG step overshot: the proximal operator is what brings the entry back) the reference's expression cancels:
+// in Float32 it returns exactly 0 once 4 gamma < eps c^2 -- log|det| = -Inf, the run "diverges" although the exact value gamma / |c| is a
+// perfectly good positive number.  There the same quantity is evaluated without the cancellation, 2 gamma / (sqrt(c^2 + 4 gamma) - c): equal
+// in exact arithmetic, positive in every precision (tests/test_gpu_optimize.py::test_prox_keeps_a_negative_diagonal_positive).
 template <typename T>
 __device__ __forceinline__ T prox_entropy_step(T c, T gamma) {
 #pragma clang fp contract(off)   // (k_prox and the launch-free loops must round it identically)
   const T cc = c * c, g4 = T(4) * gamma;
-  return c + (sqrt(cc + g4) - c) / T(2);
+  const T rt = sqrt(cc + g4);
+  if (c < T(0)) return (T(2) * gamma) / (rt - c);
+  return c + (rt - c) / T(2);
 }
 
 // PolynomialAveraging on one element (src/optimization/averaging.jl:40-47): avg <- w x + (1 - w) avg in f64, rounded to T.  Contraction off:

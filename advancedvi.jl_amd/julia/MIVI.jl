@@ -286,7 +286,7 @@ function AdvancedVI.optimize(rng::Random.AbstractRNG, alg::KLMinRepGradDescent{<
             elbo = Vector{T}(undef, k)
             d2h(elbo, e_dev)
             for i in 1:k
-                push!(info_total, (elbo = elbo[i], iteration = t_done + i))
+                push!(info_total, (elbo = elbo[i], iteration = done + i))   # the loop index of THIS call (src/optimize.jl:64-68), not the state's counter
             end
             st.estimate_idx += k
             t_done += k

@@ -278,7 +278,9 @@ def _device_loop_codes(alg, callback, objargs):
 
 
 def _optimize_on_device(rng, alg, max_iter, state, codes, show_progress):
-    """The loop of `optimize` with every iteration on the device (bitwise the same parameters as the host-driven loop).
+    """The loop of `optimize` with every iteration on the device (the same parameters as the host-driven loop: bitwise for Descent / Adam on the
+    mean-field loops and the graph route, to rounding for the launch-free loops with their own summation order -- DoG / DoWG, the row-owning
+    full-rank loops, the small logistic regression).
     Returns None when the target cannot be captured (host-callback targets): the caller then takes the host loop."""
     from ._lib import MiviError
     rule, op, avg = codes
@@ -322,10 +324,10 @@ def _optimize_on_device(rng, alg, max_iter, state, codes, show_progress):
                 except MiviError:
                     pass
                 try:
-                    for _ in range(n):
+                    for k in range(n):
                         new_state, _, info = step(rng, alg, state, None)
                         state.update(new_state)
-                        info_total.append({**info, "iteration": state["iteration"]})
+                        info_total.append({**info, "iteration": done + k + 1})   # (the loop index of THIS call: optimize.jl:64-68)
                 except MiviError as e2:          # the host replay met the same device flag: the documented exception type
                     if e2.status in (2, 3):
                         raise RuntimeError("The objective value is not finite. This indicates that the optimization run "
@@ -333,8 +335,10 @@ def _optimize_on_device(rng, alg, max_iter, state, codes, show_progress):
                     raise
                 # the host-driven replay of the chunk completed with finite objectives: the device flag was not reproducible.
                 # (mivi_optimize_loop clears every status word it later reads, so a stale flag of an earlier call cannot cause
-                # this any more; if it happens, it is worth knowing.)  The replayed steps ARE the chunk (bitwise the same
-                # arithmetic): carry on from them.
+                # this any more; if it happens, it is worth knowing.)  For Descent / Adam the replayed steps ARE the chunk (bitwise the
+                # same arithmetic); for the launch-free loops that agree with the host loop to rounding only (DoG / DoWG's norm sums, the
+                # row-owning full-rank loops, the small logistic regression) this chunk then comes from host arithmetic and the run carries
+                # on from it -- a flag that does not reproduce is therefore warned about, never silently dropped.
                 warnings.warn(f"device optimisation chunk reported status {e.status} ({e}) but its host-driven replay completed with "
                               "finite objectives; continuing from the replayed steps", RuntimeWarning)
                 done += n
@@ -343,9 +347,10 @@ def _optimize_on_device(rng, alg, max_iter, state, codes, show_progress):
         for _ in range(n):
             rng.next_index()
         vals = elbo.cpu().numpy()
-        t0 = state["iteration"]
-        info_total += [{"elbo": float(vals[i]), "iteration": t0 + i + 1} for i in range(n)]
-        state["iteration"] = t0 + n
+        # info = merge(info', (iteration = t,)) with t the loop index of THIS `optimize` call (src/optimize.jl:64-68) -- not the state's
+        # cumulative counter, which a warm start carries on (common.jl:75): both routes report the same `info`
+        info_total += [{"elbo": float(vals[i]), "iteration": done + i + 1} for i in range(n)]
+        state["iteration"] = state["iteration"] + n
         state["avg_st"] = (state["avg_st"][0], state["avg_st"][1] + n) if avg == 1 else params
         done += n
         if show_progress:
@@ -358,7 +363,8 @@ def optimize(rng, algorithm, max_iter: int, prob=None, q_init=None, *objargs, sh
              callback=None, device_loop=True):
     """optimize([rng,] algorithm, max_iter, prob, q_init; show_progress, state, callback): src/optimize.jl:42-94.
     Returns (output, info, state).  Without a callback and with a device-resident target every iteration runs inside
-    mivi_optimize_loop (`device_loop=False` forces the host-driven `step` loop; both give bitwise the same result)."""
+    mivi_optimize_loop (`device_loop=False` forces the host-driven `step` loop; both give the same result -- bitwise or to rounding, see
+    _optimize_on_device)."""
     if isinstance(rng, KLMinRepGradDescent):   # default-rng overload, optimize.jl:83-94
         extra = (q_init,) if q_init is not None else ()
         rng, algorithm, max_iter, prob, q_init = O.default_rng(), rng, algorithm, max_iter, prob

@@ -398,7 +398,8 @@ int32_t mivi_batch_lanes(const mivi_ctx_t *ctx, int32_t count);
 /* What a batch of estimates at this context's configuration runs on (measurement / test hook; the reference has no counterpart: every
  * `estimate_gradient!` there is one AD call, src/algorithms/repgradelbo.jl:151-177).  what = 0: 1 when mivi_estimate_gradient_n / _each with
  * these (16-byte aligned) device parameters take the batch engine, 0 otherwise; 1: matrix-pipe products per 32 x 32 x 16 block of the engine's
- * split-operand contractions (3: f16 hi / lo planes); 2: bytes per operand-plane element (4). */
+ * split-operand contractions (3: f16 hi / lo planes); 2: bytes per operand-plane element (4); 3: 1 once a launch-free optimisation loop's grid-wide
+ * exchange was lost on this context (mivi_optimize_loop then restored the caller's state, re-ran the steps on the graph of launches and stays there). */
 int32_t mivi_batch_info(const mivi_ctx_t *ctx, const void *params_dev, int32_t what);
 
 /* ---- measurement hook (bench.py roofline leg) --------------------------------------------------------- *

@@ -233,13 +233,11 @@ def test_small_fullrank_loop(ent, rule, shape, dtype):
 @pytest.mark.parametrize("shape", [(64, 128), (128, 256), (320, 256), (512, 128), (1024, 256)], ids=["one-block-pair", "d128", "ragged-runs", "d512-m128", "north-star"])
 @pytest.mark.parametrize("rule", [0, 1], ids=["descent", "adam"])
 @pytest.mark.parametrize("ent", [0, 2], ids=["CFE", "MC"])
-def test_fullrank_tiles_loop(ent, rule, shape, monkeypatch):
-    """(Opt-in route, MIVI_TILES_LOOP=1: measured slower than the graph of launches, DESIGN.md 9 -- kept parity-green.)  The north-star shape class (full-rank family, d <= 1024, 128 / 256 samples per step, diagonal-Gaussian target): mivi_optimize_steps runs
-    ONE persistent kernel whose workgroups own tiles of tril(C) -- parameters and Adam moments in registers for all steps -- and exchange partial
-    products / W inside their row block (k_fr_tiles_loop).  Every sum is the launch-per-step kernels' chain: parameters, optimiser state must
-    equal, BITWISE, the step-by-step sequence of single calls + update + ClipScale launches (two calls that continue each other); the ELBO
-    record to rounding; nothing above the diagonal is touched; and the first steps agree with the oracle's gradient + numpy rules."""
-    monkeypatch.setenv("MIVI_TILES_LOOP", "1")
+def test_fullrank_graph_loop_is_the_step_by_step_sequence(ent, rule, shape):
+    """The north-star shape class (full-rank family, 128 / 256 samples per step, diagonal-Gaussian target): mivi_optimize_steps runs the hipGraph of
+    launches with the optimiser step fused into the VJP epilogue.  Parameters and optimiser state must equal, BITWISE, the step-by-step sequence of
+    single calls + update + ClipScale launches (two calls that continue each other); the ELBO record to rounding; nothing above the diagonal is
+    touched.  (Round 4's persistent tile-owning kernel for this class was slower than this route and is kept under tools/experiments/.)"""
     d, M = shape
     T = 11
     rng = np.random.default_rng(17)
