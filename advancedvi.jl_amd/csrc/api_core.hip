@@ -28,11 +28,13 @@ mivi_status_t fail(mivi_ctx *c, mivi_status_t s, const char *msg) {
   return s;
 }
 
+namespace mivi {
 bool grid_resident(const mivi_ctx *c, const void *kernel, int block, size_t dyn_lds, long long grid) {
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, dyn_lds) != hipSuccess) { (void)hipGetLastError(); return false; }
   return c->n_cu > 0 && (long long)nb * c->n_cu >= grid;
 }
+}  // namespace mivi
 
 mivi_status_t ensure(mivi_ctx *c, DevBuf &b, size_t bytes, bool zero) {
   if (b.bytes >= bytes && b.p) return MIVI_OK;
