@@ -51,6 +51,7 @@ SIGNATURES = {
     "mivi_estimate_gradient_each": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p]),
     "mivi_profile_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "mivi_batch_lanes": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "mivi_p2p_selfcheck": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]),
     "mivi_batch_info": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32]),
     "mivi_estimate_objective": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p]),
     "mivi_estimate_objective_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p]),

@@ -379,6 +379,13 @@ class MiviContext:
     def comm_enable_p2p(self):
         self._chk(self.lib.mivi_comm_enable_p2p(self.h))
 
+    def p2p_selfcheck(self, params, idx=3):
+        """mivi_p2p_selfcheck: the peer-to-peer exchange against the RCCL all-reduce on one sharded estimate, collectively; returns
+        dict(value_rel, grad_rel_l2, verified).  Only a verified context takes the peer-to-peer route automatically at world > 1."""
+        out = (C.c_double * 3)()
+        self._chk(self.lib.mivi_p2p_selfcheck(self.h, self._p(params), int(idx), out))
+        return dict(value_rel=out[0], grad_rel_l2=out[1], verified=bool(out[2]))
+
     def comm_set_route(self, route):
         self._chk(self.lib.mivi_comm_set_route(self.h, self.ROUTES.get(route, route)))
 

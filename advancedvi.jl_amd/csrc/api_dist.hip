@@ -188,6 +188,8 @@ mivi_status_t mivi_p2p_attach(mivi_ctx_t *c, const void *handles) {
   (void)hipSetDevice(c->cfg.device);
   const int R = c->p2p_world;
   const uint64_t me = (uint64_t)getpid();
+  c->p2p_distinct = false;
+  c->p2p_verified = false;
   P2PTableHost tab{};
   for (int r = 0; r < R; ++r) {
     P2PHandle h;
@@ -213,6 +215,7 @@ mivi_status_t mivi_p2p_attach(mivi_ctx_t *c, const void *handles) {
       }
       c->p2p_opened[r] = true;
     }
+    if (r != c->p2p_rank && (h.pid != me || h.device != c->cfg.device)) c->p2p_distinct = true;
     c->p2p_peer[r] = base;
     for (int ln = 0; ln < kLanes; ++ln) {
       char *lb = (char *)base + (size_t)ln * c->p2p_lane_bytes;
@@ -297,7 +300,13 @@ mivi_status_t mivi_comm_set_route(mivi_ctx_t *c, int32_t route) {
 int32_t mivi_comm_route(const mivi_ctx_t *c) {   // the route the next sharded estimate takes: 1 all-reduce, 2 reduce-scatter/all-gather, 3 peer-to-peer, 0 none (one rank, no communicator)
   if (!c) return 0;
   int r = c->dist_route;
-  if (r == 0) r = c->p2p_on ? 3 : (((size_t)mivi_partials_len(c) * c->esize >= ((size_t)16 << 20)) ? 2 : 1);
+  // automatic: across ranks the peer-to-peer kernel only once mivi_p2p_selfcheck has passed on every rank (an attach alone proves nothing
+  // about the links); until then RCCL's reduce-scatter -> slice finalisation -> all-gather.  One rank (tests, world-1 runs): p2p as attached.
+  if (r == 0) {
+    const int world = c->p2p_on ? c->p2p_world : c->comm_world;
+    if (c->p2p_on && (world == 1 || c->p2p_verified)) r = 3;
+    else r = world > 1 ? 2 : (((size_t)mivi_partials_len(c) * c->esize >= ((size_t)16 << 20)) ? 2 : 1);
+  }
   if (r == 3 && !c->p2p_on) r = 1;
   if ((r == 1 || r == 2) && !c->comm) return c->comm_world > 1 ? r : 0;
   return r;
@@ -374,6 +383,50 @@ mivi_status_t mivi_comm_enable_p2p(mivi_ctx_t *c) {
   s = mivi_p2p_attach(c, all.data());
   if (s) { const std::string why = c->err; (void)mivi_p2p_detach(c); c->err = why; }
   return s;
+}
+
+// The peer-to-peer exchange against the RCCL all-reduce route on ONE sharded estimate, every rank collectively: both must give the same value and
+// gradient (1e-5 relative; they differ by the summation order only), and every rank must say so (ncclAllReduce(min) of the verdicts) before the
+// automatic route takes the peer-to-peer kernel.  rel_out (nullable): {value relative difference, gradient relative l2 difference, 1 if verified}.
+// A peer-to-peer exchange that does not complete (bounded waits) detaches the areas: the context stays on the RCCL routes.
+mivi_status_t mivi_p2p_selfcheck(mivi_ctx_t *c, const void *params, uint64_t idx, double *rel_out) {
+  if (!c || !params) return MIVI_ERR_BAD_ARG;
+  (void)hipSetDevice(c->cfg.device);
+  if (!c->p2p_on) return fail(c, MIVI_ERR_UNSUPPORTED, "mivi_p2p_selfcheck: no exchange areas attached");
+  if (c->p2p_world > 1 && !c->comm) return fail(c, MIVI_ERR_BAD_ARG, "mivi_p2p_selfcheck: needs the RCCL communicator of mivi_comm_init to compare against");
+  const size_t plen = (size_t)mivi_params_len(c), es = c->esize;
+  DevBuf a, b;
+  mivi_status_t s;
+  if ((s = ensure(c, a, (plen + 16) * es, false)) || (s = ensure(c, b, (plen + 16) * es + 64, false))) { if (a.p) (void)hipFree(a.p); return s; }
+  const int keep = c->dist_route;
+  auto done = [&](mivi_status_t st) { (void)hipFree(a.p); (void)hipFree(b.p); c->dist_route = keep; invalidate_graph(c); return st; };
+  c->dist_route = c->comm ? 1 : 3;
+  invalidate_graph(c);
+  if ((s = mivi_estimate_gradient_dist(c, params, idx, a.p, (char *)a.p + 16 * es)) || (s = mivi_synchronize(c))) return done(s);
+  c->dist_route = 3;
+  invalidate_graph(c);
+  s = mivi_estimate_gradient_dist(c, params, idx, b.p, (char *)b.p + 16 * es);
+  if (!s) s = mivi_synchronize(c);
+  if (s) { const std::string why = c->err; (void)mivi_p2p_detach(c); c->err = why; return done(s); }
+  std::vector<char> ha((plen + 16) * es), hb((plen + 16) * es);
+  if (hipMemcpy(ha.data(), a.p, ha.size(), hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(hb.data(), b.p, hb.size(), hipMemcpyDeviceToHost) != hipSuccess)
+    return done(fail(c, MIVI_ERR_HIP, "mivi_p2p_selfcheck: read-back failed"));
+  auto at = [&](const std::vector<char> &h, size_t i) { return es == 4 ? (double)((const float *)h.data())[i] : ((const double *)h.data())[i]; };
+  const double v1 = at(ha, 0), v2 = at(hb, 0);
+  double num = 0.0, den = 0.0;
+  for (size_t i = 0; i < plen; ++i) { const double x = at(ha, 16 + i), y = at(hb, 16 + i); num += (y - x) * (y - x); den += x * x; }
+  const double rv = fabs(v2 - v1) / (fabs(v1) > 0 ? fabs(v1) : 1.0), rg = sqrt(num) / (den > 0 ? sqrt(den) : 1.0);
+  int ok = (rv <= 1e-5 && rg <= 1e-5) ? 1 : 0;   // (NaN compares false)
+  if (c->comm && c->comm_world > 1) {
+    RcclApi *r = rccl();
+    int *flag = (int *)((char *)b.p + (plen + 16) * es);
+    if (!r || !r->AllReduce || hipMemcpy(flag, &ok, sizeof(int), hipMemcpyHostToDevice) != hipSuccess || r->AllReduce(flag, flag, 1, ncclInt32, ncclMin, (ncclComm_t)c->comm, c->stream) != ncclSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&ok, flag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+      return done(fail(c, MIVI_ERR_HIP, "mivi_p2p_selfcheck: the ranks' verdicts could not be combined"));
+  }
+  c->p2p_verified = ok == 1 && (c->p2p_distinct || c->p2p_world == 1);
+  if (rel_out) { rel_out[0] = rv; rel_out[1] = rg; rel_out[2] = c->p2p_verified ? 1.0 : 0.0; }
+  return done(MIVI_OK);
 }
 
 // buffers of the sharded estimate: padded partial vectors (two: the pipelined batch double-buffers them), slice sum, packed final

@@ -288,6 +288,8 @@ struct mivi_ctx {
   mivi::DevBuf gen_scratch;  // kernels_meanfield.hip k_mf_gen_loop: DoG / DoWG partial norms of every step, arrival flags
   mivi::DevBuf p2p_tab, p2p_ctr, p2p_scratch, p2p_direct;   // (p2p_direct: P2PDirectTab, what the partial kernels need to store straight into the owners' staging areas)
   bool p2p_on = false;
+  bool p2p_distinct = false;     // the attached exchange areas include one of ANOTHER device (not only this process's own contexts on this device)
+  bool p2p_verified = false;     // mivi_p2p_selfcheck passed on every rank: only then does the automatic route take the peer-to-peer kernel at world > 1
   int p2p_rank = 0, p2p_world = 1, p2p_G = 1, p2p_vs = 0, p2p_spin = 1 << 21;
   long long p2p_n = 0, p2p_cn = 0;
   size_t p2p_lane_bytes = 0, p2p_off_fin = 0, p2p_off_arr = 0, p2p_off_farr = 0;

@@ -659,7 +659,9 @@ def compact_line(full):
         d = full["dist"]
         line["dist"] = {"route": d.get("route"), "pipeline": str(d.get("pipeline", ""))[:64] or None,
                         "estimate_sharded_est_per_s": _num(_get(d, "estimate_sharded", "value"), 6),
-                        "us_per_estimate": d.get("us_per_estimate")}
+                        "us_per_estimate": d.get("us_per_estimate"),
+                        "p2p_verified": _get(d, "p2p_vs_allreduce", "verified"),
+                        "also": ({k: (None if "error" in v else _num(v.get("value"), 5)) for k, v in d["also"].items()} if isinstance(d.get("also"), dict) else None)}
     line["full"] = full.get("full_path")
     s = json.dumps(line, separators=(",", ":"))
     # belt and braces: shed optional blocks, largest first, until the line fits
@@ -828,18 +830,11 @@ def main():
                 except avi.MiviError as e:
                     dist_info["p2p_error"] = str(e)
                 p2p_ok = all_ok(p2p_ok)
-                if p2p_ok:   # self-check: the peer-to-peer estimate against the RCCL all-reduce estimate, on every rank
+                if p2p_ok:   # self-check behind the ABI (mivi_p2p_selfcheck): the peer-to-peer estimate against the RCCL all-reduce estimate, every rank's verdict combined
                     try:
-                        ctx.comm_set_route("allreduce")
-                        v_r, g_r = ctx.estimate_gradient_dist(params, 3)
-                        ctx.synchronize()
-                        v_r, g_r = float(v_r.item()), g_r.clone()
-                        ctx.comm_set_route("p2p")
-                        v_p, g_p = ctx.estimate_gradient_dist(params, 3)
-                        ctx.synchronize()
-                        rel_g = float((g_p - g_r).norm() / g_r.norm())
-                        good = abs(float(v_p.item()) - v_r) <= 1e-5 * abs(v_r) and rel_g <= 1e-5
-                        dist_info["p2p_vs_allreduce"] = dict(value_rel=abs(float(v_p.item()) - v_r) / abs(v_r), grad_rel_l2=rel_g)
+                        chk = ctx.p2p_selfcheck(params, 3)
+                        dist_info["p2p_vs_allreduce"] = dict(value_rel=chk["value_rel"], grad_rel_l2=chk["grad_rel_l2"], verified=chk["verified"])
+                        good = chk["verified"] or (world == 1 and chk["value_rel"] <= 1e-5 and chk["grad_rel_l2"] <= 1e-5)
                     except avi.MiviError as e:
                         good = False
                         dist_info["p2p_error"] = str(e)
@@ -996,6 +991,64 @@ def main():
                 ctx.synchronize()
             except avi.MiviError as e:
                 dist_info["status_error"] = str(e)
+            # BASELINE.json's own multi-GPU configurations and the sample count at which sharding the north-star estimate starts to pay, as
+            # compact extras (`also`): configs[3] (C4: hierarchical LogReg, 128 samples per GPU, X replicated), configs[4] (C5: funnel, 64 per GPU), and
+            # the north-star shape with 256 / 1024 / 4096 samples per GPU.  Each: one sharded estimate per step on the dependent chain
+            # (mivi_estimate_gradient_dist: partial kernels -> exchange -> finalisation), RCCL route unless the peer-to-peer kernel was verified,
+            # barrier + max over ranks; value = n_mc_per_gpu-sample estimate units of ALL ranks per second.
+            if args.workload == "ns" and not args.no_also:
+                dist_also = {}
+                legs = [("c4", dict(WORKLOADS["c3"]), 12), ("c5", dict(WORKLOADS["c5"]), 200)]
+                legs += [("ns_n_mc_%d" % m, dict(WORKLOADS["ns"], n_mc=m), 20) for m in (256, 1024, 4096)]
+                for key, w2, k2 in legs:
+                    if os.environ.get("MIVI_BENCH_SKIP_C3") and key == "c4":
+                        continue
+                    cx = None
+                    try:
+                        q2, prob2 = make_problem(avi, w2)
+                        p2h, _ = avi.destructure(q2)
+                        plan2 = avi.distributed.ShardPlan(w2["n_mc"] * world, world)
+                        cx = avi.MiviContext(np.float32, w2["family"], w2["d"], plan2.count(rank), w2["entropy"], SEED, device=local_rank,
+                                             m_offset=plan2.offset(rank), m_total=plan2.n_samples)
+                        cx.set_problem(prob2)
+                        p2 = cx.to_device(p2h)
+                        v2, g2 = cx.empty(1), cx.empty(cx.params_len)
+                        id2 = torch.zeros(128, dtype=torch.uint8, device=dev)
+                        if rank == 0:
+                            id2.copy_(torch.frombuffer(bytearray(cx.comm_unique_id()), dtype=torch.uint8))
+                        if world > 1:
+                            dist.broadcast(id2, src=0)
+                        with quiet_stdout():
+                            cx.comm_init(bytes(id2.cpu().numpy().tobytes()), rank, world)
+                        for i in range(3):
+                            cx.estimate_gradient_dist(p2, i, v2, g2)
+                        cx.synchronize()
+                        if dist:
+                            dist.barrier()
+                        torch.cuda.synchronize()
+                        t2s = time.perf_counter()
+                        for i in range(k2):
+                            cx.estimate_gradient_dist(p2, 10 + i, v2, g2)
+                        torch.cuda.synchronize()
+                        if dist:
+                            dist.barrier()
+                        dt2 = time.perf_counter() - t2s
+                        if dist:
+                            tt = torch.tensor([dt2], dtype=torch.float64, device=dev)
+                            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                            dt2 = float(tt.item())
+                        dist_also[key] = dict(value=k2 * world / dt2, unit="estimates/s", us_per_step=dt2 / k2 * 1e6, n_mc_per_gpu=w2["n_mc"], route=cx.comm_route(),
+                                              workload=w2["name"] if key in ("c4", "c5") else "north-star shape, %d samples per GPU" % w2["n_mc"])
+                    except Exception as e:   # noqa: BLE001
+                        dist_also[key] = dict(error=str(e))
+                    finally:
+                        if cx is not None:
+                            try:
+                                cx.close()
+                            except Exception:   # noqa: BLE001
+                                pass
+                    del w2
+                dist_info["also"] = dist_also
         out = None
         if rank == 0:
             cost = algorithmic_cost(w)

@@ -351,6 +351,13 @@ mivi_status_t mivi_p2p_detach(mivi_ctx_t *ctx);
  * length L over `world` ranks (no GPU needed) */
 void mivi_p2p_geometry(int64_t L, int32_t world, int64_t *out4);
 mivi_status_t mivi_comm_enable_p2p(mivi_ctx_t *ctx);
+/* One sharded estimate through the RCCL all-reduce route and through the peer-to-peer kernel, every rank collectively; both must agree to 1e-5
+ * (value, gradient l2) on EVERY rank (ncclAllReduce(min) of the verdicts).  Only then -- and only with exchange areas of at least one other
+ * device attached -- does the automatic route (mivi_comm_set_route 0) take the peer-to-peer kernel at world > 1; until then it is RCCL's
+ * reduce-scatter -> mivi_finalize_slice -> all-gather.  rel_out3 (nullable) <- {value rel. difference, gradient rel. l2 difference, 1 if verified}.
+ * The reference has no counterpart (single process: src/algorithms/repgradelbo.jl:84-86 is the mean this exchange sums).  A peer-to-peer
+ * exchange that does not complete (bounded waits) detaches the areas and returns MIVI_ERR_HIP: the context stays on the RCCL routes. */
+mivi_status_t mivi_p2p_selfcheck(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx, double *rel_out3);
 /* Batched sharded estimates on the peer-to-peer route run the exchange as ONE persistent kernel on its own stream BESIDE the compute chain
  * (csrc/kernels_p2p.hip), serving groups of four estimates per epoch.  on = 1 (default); 0 = no pipeline: batched calls run serial steps.
  * The pipeline needs the device to schedule the exchange kernel and the compute chain concurrently; where it does not (streams sharing one

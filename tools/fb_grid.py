@@ -1,7 +1,7 @@
 """Lanes (estimates) of a batch-engine dispatch from its grid -- derived, never assumed (round 4's pmc_traffic.py assumed 100 lanes per
 launch while the launches carried 50).  Grids (kernels_fullrank_batch.hip host side): k_fb_prod: L (d/128)(M/128) workgroups;
 k_fb_vjp: L (nrb (nrb + 1) / 2 + 1) workgroups (the lanes' value blocks ride in the launch); k_fb_eps: grid.y = L (+ the tril(C) plane riders
-of a call's first draw: ceil(d/32 * d/16 / (8 gx)) rows, gx = d/64 * M/32)."""
+of a call's first draw: ceil(d/32 / gx) rows, gx = d/64 * M/32)."""
 
 
 def disp_cols(con, disp):
@@ -28,4 +28,4 @@ def lanes_of(kernel, ngx, ngy, d=1024, M=256):
 
 def eps_riders(d=1024, M=256):
     gx = (d // 64) * (M // 32)
-    return -(-((d // 32) * (d // 16)) // (8 * gx))
+    return -(-(d // 32) // gx)   # (round 5: one rider workgroup per 32-row block of tril(C))
