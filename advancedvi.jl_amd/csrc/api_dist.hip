@@ -304,7 +304,7 @@ int32_t mivi_comm_route(const mivi_ctx_t *c) {   // the route the next sharded e
   // about the links); until then RCCL's reduce-scatter -> slice finalisation -> all-gather.  One rank (tests, world-1 runs): p2p as attached.
   if (r == 0) {
     const int world = c->p2p_on ? c->p2p_world : c->comm_world;
-    if (c->p2p_on && (world == 1 || c->p2p_verified)) r = 3;
+    if (c->p2p_on && (world == 1 || c->p2p_verified || !c->comm)) r = 3;   // (no communicator: the attached areas are the only exchange there is)
     else r = world > 1 ? 2 : (((size_t)mivi_partials_len(c) * c->esize >= ((size_t)16 << 20)) ? 2 : 1);
   }
   if (r == 3 && !c->p2p_on) r = 1;

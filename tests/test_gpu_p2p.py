@@ -312,3 +312,29 @@ def test_lost_peer_is_reported_not_waited_for_forever():
     assert time.perf_counter() - t0 < 5.0
     for c in ctxs:
         c.close()
+
+
+def test_selfcheck_gates_the_automatic_route():
+    """mivi_p2p_selfcheck: the peer-to-peer kernel against the RCCL all-reduce route on one sharded estimate.  With a communicator present the
+    automatic route takes the peer-to-peer kernel across ranks only after the check passed on every rank; at world 1 (this test: one rank with
+    its own communicator) the check runs both routes on the device and must agree to rounding."""
+    d, M = 256, 128
+    rng = np.random.default_rng(8)
+    q, _ = make_family(rng, d, avi.FULLRANK, np.float32)
+    prob, _ = make_problem(rng, "diag", d, np.float32)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+    ctx.set_problem(prob)
+    ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    assert ctx.comm_route() == "allreduce"
+    ctx.comm_enable_p2p()
+    p = ctx.to_device(params)
+    chk = ctx.p2p_selfcheck(p, 3)
+    assert chk["value_rel"] <= 1e-6 and chk["grad_rel_l2"] <= 1e-6 and chk["verified"]
+    assert ctx.comm_route() == "p2p"
+    v, g = ctx.estimate_gradient_dist(p, 5)
+    ctx.comm_set_route("allreduce")
+    v2, g2 = ctx.estimate_gradient_dist(p, 5)
+    ctx.synchronize()
+    assert abs(float(v.item()) - float(v2.item())) <= 1e-6 * abs(float(v2.item())) and float((g - g2).norm() / g2.norm()) <= 1e-6
+    ctx.close()
