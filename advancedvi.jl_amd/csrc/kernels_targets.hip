@@ -345,7 +345,8 @@ struct LrMfmaArgs {
   const uint8_t *y;
   const float *ZT;     // ZT[m + k*ldz]
   int ldz;
-  const float *Zcm;    // the sample matrix itself, d x M column-major (k contiguous per sample): bf16x3 logits
+  const float *Zcm;    // the sample matrix itself, d x M column-major (k contiguous per sample): the split-operand logits
+  const unsigned *xmax;   // bits of max |X| (k_lr_make_xrm): the power-of-two scale of X's f16 splits
   float *R;            // R[m + r*ldr]
   int ldr;
   double *ll_part;     // [gridDim.x][M]
@@ -580,34 +581,40 @@ __global__ __launch_bounds__(512) void k_lr_logits_mfma_lds(LrMfmaArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// logits on the bf16 matrix cores with f32 accuracy ("bf16x3"): every f32 operand is split exactly into three bf16
-// pieces x = hi + mid + lo (8 + 8 + 8 mantissa bits) when it is staged into LDS, and a product block is the six
-// MFMAs hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi (the dropped terms are below 2^-24 of the product) accumulated in
-// f32 by v_mfma_f32_32x32x16_bf16.  24 bf16 MFMAs of 8 passes replace 32 f32 MFMAs of 16 passes per 16-k stage, i.e.
-// 2.7x the MFMA throughput; X is still read from HBM once, as f32.  Same tile shape, ring and epilogue as
+// logits on the 16-bit matrix cores with f32 accuracy (round 5: two-way f16 split; round 3-4: three bf16 pieces, six products): every f32
+// operand is split into hi = f16(s x), lo = f16(s x - hi) when it is staged into LDS (s: a power of two that puts X's largest magnitude
+// into [2^13, 2^14) so that its lo parts stay normal; samples and residuals are O(1) and take s = 1 -- f16 subnormals are honoured by the
+// pipe), and a product block is the three MFMAs lo*hi, hi*lo, hi*hi (the dropped lo*lo term is below 2^-22 of the product) accumulated in
+// f32 by v_mfma_f32_32x32x16_f16.  Half the matrix-pipe work and less than half of the split arithmetic of the bf16 scheme; X is still
+// read from HBM once per contraction, as f32.  Same tile shape, ring and epilogue as
 // k_lr_logits_mfma_lds; the B operand comes from the column-major sample matrix (k contiguous per sample), which is
 // what a 16-byte operand of 8 consecutive k needs (requires d % 4 == 0).
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 lr_bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 lr_bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 lr_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 lr_f16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void lr_split3(const lr_f32x4 &v, lr_bf16x4 &hi, lr_bf16x4 &mid, lr_bf16x4 &lo) {
+// two-way f16 split of s * v (s a power of two: exact): hi = f16(s v), lo = f16(s v - hi)
+__device__ __forceinline__ void lr_split2(const lr_f32x4 &v, float s, lr_f16x4 &hi, lr_f16x4 &lo) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const __bf16 h = (__bf16)v[i];
-    const float r1 = v[i] - (float)h;
-    const __bf16 m = (__bf16)r1;
-    const float r2 = r1 - (float)m;
+    const float x = v[i] * s;
+    const _Float16 h = (_Float16)x;
     hi[i] = h;
-    mid[i] = m;
-    lo[i] = (__bf16)r2;
+    lo[i] = (_Float16)(x - (float)h);
   }
+}
+// the power-of-two scale of X (largest magnitude of the data matrix into [2^13, 2^14): its f16 lo parts stay normal) and its inverse
+__device__ __forceinline__ void lr_xscale(const unsigned *xmax_bits, float &s, float &inv) {
+  unsigned eb = (*xmax_bits >> 23) & 0xffu;
+  eb = eb < 25u ? 25u : (eb > 254u ? 254u : eb);
+  s = __builtin_bit_cast(float, (267u - eb) << 23);
+  inv = __builtin_bit_cast(float, (eb - 13u) << 23);
 }
 
 template <bool PART>
-__device__ __forceinline__ void lr_logits_bf16x3_body(const LrMfmaArgs &a) {
-  __shared__ __attribute__((aligned(16))) __bf16 Xs[2][3][256 * 16];   // [slot][piece][row][16 k]
-  __shared__ __attribute__((aligned(16))) __bf16 Zs[2][3][128 * 16];   // [slot][piece][sample][16 k]
+__device__ __forceinline__ void lr_logits_f16x2_body(const LrMfmaArgs &a) {
+  __shared__ __attribute__((aligned(16))) _Float16 Xs[2][2][256 * 16];   // [slot][piece][row][16 k]
+  __shared__ __attribute__((aligned(16))) _Float16 Zs[2][2][128 * 16];   // [slot][piece][sample][16 k]
   __shared__ float ll_lds[128];
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -630,20 +637,19 @@ __device__ __forceinline__ void lr_logits_bf16x3_body(const LrMfmaArgs &a) {
     // k >= p multiplies the zero padding of Xrm: any finite in-bounds value will do there
     g.z = *(const lr_f32x4 *)(Zg + min(16 * st + xc, d - 4));
   };
+  float xs, xinv;
+  lr_xscale(a.xmax, xs, xinv);
   auto lstore = [&](int slot, const G &g) {
-    lr_bf16x4 p0, p1, p2;
-    lr_split3(g.x0, p0, p1, p2);
-    *(lr_bf16x4 *)&Xs[slot][0][xrow * 16 + xc] = p0;
-    *(lr_bf16x4 *)&Xs[slot][1][xrow * 16 + xc] = p1;
-    *(lr_bf16x4 *)&Xs[slot][2][xrow * 16 + xc] = p2;
-    lr_split3(g.x1, p0, p1, p2);
-    *(lr_bf16x4 *)&Xs[slot][0][(128 + xrow) * 16 + xc] = p0;
-    *(lr_bf16x4 *)&Xs[slot][1][(128 + xrow) * 16 + xc] = p1;
-    *(lr_bf16x4 *)&Xs[slot][2][(128 + xrow) * 16 + xc] = p2;
-    lr_split3(g.z, p0, p1, p2);
-    *(lr_bf16x4 *)&Zs[slot][0][xrow * 16 + xc] = p0;
-    *(lr_bf16x4 *)&Zs[slot][1][xrow * 16 + xc] = p1;
-    *(lr_bf16x4 *)&Zs[slot][2][xrow * 16 + xc] = p2;
+    lr_f16x4 p0, p1;
+    lr_split2(g.x0, xs, p0, p1);
+    *(lr_f16x4 *)&Xs[slot][0][xrow * 16 + xc] = p0;
+    *(lr_f16x4 *)&Xs[slot][1][xrow * 16 + xc] = p1;
+    lr_split2(g.x1, xs, p0, p1);
+    *(lr_f16x4 *)&Xs[slot][0][(128 + xrow) * 16 + xc] = p0;
+    *(lr_f16x4 *)&Xs[slot][1][(128 + xrow) * 16 + xc] = p1;
+    lr_split2(g.z, 1.f, p0, p1);   // (samples: O(1) magnitudes, f16 subnormals are honoured by the matrix pipe)
+    *(lr_f16x4 *)&Zs[slot][0][xrow * 16 + xc] = p0;
+    *(lr_f16x4 *)&Zs[slot][1][xrow * 16 + xc] = p1;
   };
   lr_f32x16 c00, c01, c10, c11;
 #pragma unroll
@@ -651,24 +657,24 @@ __device__ __forceinline__ void lr_logits_bf16x3_body(const LrMfmaArgs &a) {
   const int ao = (wr * 64 + l31) * 16 + 8 * h, bo = (wm * 64 + l31) * 16 + 8 * h;
   const bool has0 = m0 < a.M, has1 = m0 + 32 < a.M;   // wave-uniform
   auto compute = [&](int slot) {
-    lr_bf16x8 A0[3], A1[3], B0[3], B1[3];
+    lr_f16x8 A0[2], A1[2], B0[2], B1[2];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      A0[s] = *(const lr_bf16x8 *)&Xs[slot][s][ao];
-      A1[s] = *(const lr_bf16x8 *)&Xs[slot][s][ao + 32 * 16];
-      B0[s] = *(const lr_bf16x8 *)&Zs[slot][s][bo];
-      B1[s] = *(const lr_bf16x8 *)&Zs[slot][s][bo + 32 * 16];
+    for (int s = 0; s < 2; ++s) {
+      A0[s] = *(const lr_f16x8 *)&Xs[slot][s][ao];
+      A1[s] = *(const lr_f16x8 *)&Xs[slot][s][ao + 32 * 16];
+      B0[s] = *(const lr_f16x8 *)&Zs[slot][s][bo];
+      B1[s] = *(const lr_f16x8 *)&Zs[slot][s][bo + 32 * 16];
     }
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // small terms first
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};   // lo.hi, hi.lo, hi.hi: small terms first
 #pragma unroll
-    for (int t = 0; t < 6; ++t) {
+    for (int t = 0; t < 3; ++t) {
       if (!PART || has0) {
-        c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B0[PB[t]], c00, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B0[PB[t]], c10, 0, 0, 0);
+        c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[PA[t]], B0[PB[t]], c00, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1[PA[t]], B0[PB[t]], c10, 0, 0, 0);
       }
       if (!PART || has1) {
-        c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B1[PB[t]], c01, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B1[PB[t]], c11, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[PA[t]], B1[PB[t]], c01, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1[PA[t]], B1[PB[t]], c11, 0, 0, 0);
       }
     }
   };
@@ -702,14 +708,14 @@ __device__ __forceinline__ void lr_logits_bf16x3_body(const LrMfmaArgs &a) {
       if (r < a.n) {
         const float yv = (float)a.y[r];
         {
-          const float lg = ca[q], e = __expf(-fabsf(lg)), inv = __frcp_rn(1.f + e);
+          const float lg = ca[q] * xinv, e = __expf(-fabsf(lg)), inv = __frcp_rn(1.f + e);
           if (ma < a.M) {
             ll0 += yv * lg - (fmaxf(lg, 0.f) + __logf(1.f + e));
             if (a.want_grad) a.R[(size_t)r * a.ldr + ma] = yv - (lg >= 0.f ? inv : e * inv);
           }
         }
         {
-          const float lg = cb[q], e = __expf(-fabsf(lg)), inv = __frcp_rn(1.f + e);
+          const float lg = cb[q] * xinv, e = __expf(-fabsf(lg)), inv = __frcp_rn(1.f + e);
           if (mb < a.M) {
             ll1 += yv * lg - (fmaxf(lg, 0.f) + __logf(1.f + e));
             if (a.want_grad) a.R[(size_t)r * a.ldr + mb] = yv - (lg >= 0.f ? inv : e * inv);
@@ -735,25 +741,23 @@ __device__ __forceinline__ void lr_logits_bf16x3_body(const LrMfmaArgs &a) {
 
 // the full-tile kernel is pinned to 128 VGPRs (4 waves per SIMD, two workgroups per CU); the partial-tile variant's extra
 // control flow does not fit that budget without scratch (228 B/lane, 3x slower), so it runs unconstrained
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lr_logits_bf16x3(LrMfmaArgs a) {
-  lr_logits_bf16x3_body<false>(a);
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lr_logits_f16x2(LrMfmaArgs a) {
+  lr_logits_f16x2_body<false>(a);
 }
-__global__ __launch_bounds__(512) void k_lr_logits_bf16x3_part(LrMfmaArgs a) { lr_logits_bf16x3_body<true>(a); }
+__global__ __launch_bounds__(512) void k_lr_logits_f16x2_part(LrMfmaArgs a) { lr_logits_f16x2_body<true>(a); }
 
-// X^T R on the bf16 matrix cores, same bf16x3 scheme.  The contraction runs over data rows, so both operands need 8
+// X^T R on the 16-bit matrix cores, same two-way f16 scheme.  The contraction runs over data rows, so both operands need 8
 // consecutive ROWS per lane while memory has rows outermost: a thread loads a 4-row x 1-column strip (lanes along the
-// contiguous axis: coalesced dword loads), splits it, and writes the 4 row-consecutive bf16 of each piece as one 8-byte
+// contiguous axis: coalesced dword loads), splits it, and writes the 4 row-consecutive f16 of each piece as one 8-byte
 // LDS word into [column][16 rows] tiles -- the transposition costs nothing.  Column stride 40 bytes: conflict-free for
 // the 8-byte writes and the 8-byte operand reads (a 16-byte operand = two reads).
-__device__ __forceinline__ void lr_split3s(const float (&v)[4], lr_bf16x4 &hi, lr_bf16x4 &mid, lr_bf16x4 &lo) {
+__device__ __forceinline__ void lr_split2s(const float (&v)[4], float s, lr_f16x4 &hi, lr_f16x4 &lo) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const __bf16 h = (__bf16)v[i];
-    const float r1 = v[i] - (float)h;
-    const __bf16 m = (__bf16)r1;
+    const float x = v[i] * s;
+    const _Float16 h = (_Float16)x;
     hi[i] = h;
-    mid[i] = m;
-    lo[i] = (__bf16)(r1 - (float)m);
+    lo[i] = (_Float16)(x - (float)h);
   }
 }
 
@@ -761,11 +765,11 @@ __device__ __forceinline__ void lr_split3s(const float (&v)[4], lr_bf16x4 &hi, l
 // 2 -> 128-feature tile, 256 threads, 61 KB: two workgroups per CU that are not in barrier lock-step with each other (R is
 // then read by four feature groups instead of two).  Measured at C3: 880 us against 790 us for NWK = 4, the only one instantiated.
 template <int NWK, bool PART>
-__global__ __launch_bounds__(128 * NWK) void k_lr_xtr_bf16x3(LrMfmaArgs a) {
+__global__ __launch_bounds__(128 * NWK) void k_lr_xtr_f16x2(LrMfmaArgs a) {
   constexpr int NT = 128 * NWK, KT = 64 * NWK, RN = 4 / NWK;   // threads, features per tile, R strips per thread
-  constexpr int CS = 20;   // column stride in bf16 (40 bytes)
-  __shared__ __attribute__((aligned(16))) __bf16 Rs[2][3][128 * CS];   // [slot][piece][sample][16 rows]
-  __shared__ __attribute__((aligned(16))) __bf16 Xs[2][3][KT * CS];   // [slot][piece][feature][16 rows]
+  constexpr int CS = 20;   // column stride in f16 (40 bytes)
+  __shared__ __attribute__((aligned(16))) _Float16 Rs[2][2][128 * CS];   // [slot][piece][sample][16 rows]
+  __shared__ __attribute__((aligned(16))) _Float16 Xs[2][2][KT * CS];   // [slot][piece][feature][16 rows]
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w / NWK, wk = w % NWK;
@@ -797,55 +801,54 @@ __global__ __launch_bounds__(128 * NWK) void k_lr_xtr_bf16x3(LrMfmaArgs a) {
       g.x1[i] = (xs + (8 + i) * ldx)[xoff];
     }
   };
+  float xs, xinv;
+  lr_xscale(a.xmax, xs, xinv);
   auto lstore = [&](int slot, const G &g) {
-    lr_bf16x4 p0, p1, p2;
+    lr_f16x4 p0, p1;
 #pragma unroll
     for (int u = 0; u < RN; ++u) {
-      lr_split3s(g.r[u], p0, p1, p2);
-      *(lr_bf16x4 *)&Rs[slot][0][rm * CS + 4 * (rrg + u * (NT / 128))] = p0;
-      *(lr_bf16x4 *)&Rs[slot][1][rm * CS + 4 * (rrg + u * (NT / 128))] = p1;
-      *(lr_bf16x4 *)&Rs[slot][2][rm * CS + 4 * (rrg + u * (NT / 128))] = p2;
+      lr_split2s(g.r[u], 1.f, p0, p1);   // (residuals y - sigmoid: in (-1, 1))
+      *(lr_f16x4 *)&Rs[slot][0][rm * CS + 4 * (rrg + u * (NT / 128))] = p0;
+      *(lr_f16x4 *)&Rs[slot][1][rm * CS + 4 * (rrg + u * (NT / 128))] = p1;
     }
-    lr_split3s(g.x0, p0, p1, p2);
-    *(lr_bf16x4 *)&Xs[slot][0][xf * CS + 4 * xrg] = p0;
-    *(lr_bf16x4 *)&Xs[slot][1][xf * CS + 4 * xrg] = p1;
-    *(lr_bf16x4 *)&Xs[slot][2][xf * CS + 4 * xrg] = p2;
-    lr_split3s(g.x1, p0, p1, p2);
-    *(lr_bf16x4 *)&Xs[slot][0][xf * CS + 4 * xrg + 8] = p0;
-    *(lr_bf16x4 *)&Xs[slot][1][xf * CS + 4 * xrg + 8] = p1;
-    *(lr_bf16x4 *)&Xs[slot][2][xf * CS + 4 * xrg + 8] = p2;
+    lr_split2s(g.x0, xs, p0, p1);
+    *(lr_f16x4 *)&Xs[slot][0][xf * CS + 4 * xrg] = p0;
+    *(lr_f16x4 *)&Xs[slot][1][xf * CS + 4 * xrg] = p1;
+    lr_split2s(g.x1, xs, p0, p1);
+    *(lr_f16x4 *)&Xs[slot][0][xf * CS + 4 * xrg + 8] = p0;
+    *(lr_f16x4 *)&Xs[slot][1][xf * CS + 4 * xrg + 8] = p1;
   };
   lr_f32x16 c00, c01, c10, c11;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { c00[r] = 0.f; c01[r] = 0.f; c10[r] = 0.f; c11[r] = 0.f; }
   const int ao = (wm * 64 + l31) * CS + 8 * h, bo = (wk * 64 + l31) * CS + 8 * h;
   const bool has0 = m0 < a.M, has1 = m0 + 32 < a.M;   // wave-uniform (PART: sample tiles beyond M are skipped)
-  auto ld8 = [&](const __bf16 *p) {   // 8 consecutive rows of one column = two 8-byte words
-    const lr_bf16x4 lo4 = *(const lr_bf16x4 *)p, hi4 = *(const lr_bf16x4 *)(p + 4);
-    lr_bf16x8 v;
+  auto ld8 = [&](const _Float16 *p) {   // 8 consecutive rows of one column = two 8-byte words
+    const lr_f16x4 lo4 = *(const lr_f16x4 *)p, hi4 = *(const lr_f16x4 *)(p + 4);
+    lr_f16x8 v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { v[i] = lo4[i]; v[4 + i] = hi4[i]; }
     return v;
   };
   auto compute = [&](int slot) {
-    lr_bf16x8 A0[3], A1[3], B0[3], B1[3];
+    lr_f16x8 A0[2], A1[2], B0[2], B1[2];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < 2; ++s) {
       A0[s] = ld8(&Rs[slot][s][ao]);
       A1[s] = ld8(&Rs[slot][s][ao + 32 * CS]);
       B0[s] = ld8(&Xs[slot][s][bo]);
       B1[s] = ld8(&Xs[slot][s][bo + 32 * CS]);
     }
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
 #pragma unroll
-    for (int t = 0; t < 6; ++t) {
+    for (int t = 0; t < 3; ++t) {
       if (!PART || has0) {   // A = residuals of samples m0 .. m0+31
-        c00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B0[PB[t]], c00, 0, 0, 0);
-        c01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[PA[t]], B1[PB[t]], c01, 0, 0, 0);
+        c00 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[PA[t]], B0[PB[t]], c00, 0, 0, 0);
+        c01 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A0[PA[t]], B1[PB[t]], c01, 0, 0, 0);
       }
       if (!PART || has1) {   // samples m0+32 .. m0+63
-        c10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B0[PB[t]], c10, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A1[PA[t]], B1[PB[t]], c11, 0, 0, 0);
+        c10 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1[PA[t]], B0[PB[t]], c10, 0, 0, 0);
+        c11 = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1[PA[t]], B1[PB[t]], c11, 0, 0, 0);
       }
     }
   };
@@ -875,7 +878,7 @@ __global__ __launch_bounds__(128 * NWK) void k_lr_xtr_bf16x3(LrMfmaArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int m = m0 + mb * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-      if (k < a.p && m < a.M) a.g_part[((size_t)blockIdx.x * a.M + m) * a.p + k] = c[q];
+      if (k < a.p && m < a.M) a.g_part[((size_t)blockIdx.x * a.M + m) * a.p + k] = c[q] * xinv;
     }
   };
   epi(c00, 0, 0);
@@ -885,8 +888,9 @@ __global__ __launch_bounds__(128 * NWK) void k_lr_xtr_bf16x3(LrMfmaArgs a) {
 }
 
 // one-time: row-major zero-padded copy of X (n x p column-major -> n x ldx row-major), 64x64 LDS transpose
-__global__ __launch_bounds__(256) void k_lr_make_xrm(long long n, int p, int ldx, const float *X, float *Xrm) {
+__global__ __launch_bounds__(256) void k_lr_make_xrm(long long n, int p, int ldx, const float *X, float *Xrm, unsigned *xmax) {
   __shared__ float tile[64][65];
+  float amax = 0.f;
   const long long r0 = (long long)blockIdx.x * 64;
   const int k0 = blockIdx.y * 64, tid = threadIdx.x;
   const int a = tid & 63, b = tid >> 6;
@@ -895,8 +899,14 @@ __global__ __launch_bounds__(256) void k_lr_make_xrm(long long n, int p, int ldx
     const int kc = b + 4 * j;
     const long long r = r0 + a;
     const int k = k0 + kc;
-    tile[kc][a] = (r < n && k < p) ? X[(size_t)k * n + r] : 0.f;
+    const float v = (r < n && k < p) ? X[(size_t)k * n + r] : 0.f;
+    tile[kc][a] = v;
+    amax = fmaxf(amax, fabsf(v));
   }
+  amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  if ((tid & 63) == 0 && amax > 0.f) atomicMax(xmax, __builtin_bit_cast(unsigned, amax));   // (non-negative floats order like their bits)
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -939,15 +949,16 @@ bool logreg_prepare_f32(mivi_ctx *c) {
   // builds Xrm in c->lr_Xrm (called by mivi_set_target_logreg for MIVI_F32)
   const int p = c->cfg.d - 1;
   const int ldx = (p + 31) / 32 * 32;
-  const size_t n16 = ((size_t)c->lr_n + 15) / 16 * 16;   // zero rows up to a whole 16-row stage (k_lr_xtr_bf16x3)
+  const size_t n16 = ((size_t)c->lr_n + 15) / 16 * 16;   // zero rows up to a whole 16-row stage (k_lr_xtr_f16x2)
   const size_t bytes = n16 * ldx * sizeof(float);
   if (!grow(c->lr_Xrm, bytes)) return false;
   if (n16 > (size_t)c->lr_n &&
       hipMemsetAsync((float *)c->lr_Xrm.p + (size_t)c->lr_n * ldx, 0, (n16 - (size_t)c->lr_n) * ldx * sizeof(float), c->stream) != hipSuccess)
     return false;
+  if (!grow(c->lr_xmax, 64) || hipMemsetAsync(c->lr_xmax.p, 0, 64, c->stream) != hipSuccess) return false;
   dim3 grid((unsigned)((c->lr_n + 63) / 64), (ldx + 63) / 64);
   hipLaunchKernelGGL(k_lr_make_xrm, grid, dim3(256), 0, c->stream, (long long)c->lr_n, p, ldx, (const float *)c->lr_X,
-                     (float *)c->lr_Xrm.p);
+                     (float *)c->lr_Xrm.p, (unsigned *)c->lr_xmax.p);
   return true;
 }
 
@@ -1008,7 +1019,7 @@ static LrGeom lr_geom(const mivi_ctx *c, int M) {
     // row splits of X^T R: 128 x 2 feature groups = one workgroup per CU at C3 (n = 1e6, p = 511); small data sets still
     // get a split per 128 rows (one workgroup walking n = 20 000 rows alone is a 270 us chain of 16-row stages)
     int S = (int)((n + 127) / 128);
-    if (S > 128) S = 128;
+    if (S > 128) S = 128;   // (256 / 384 splits -- two workgroups per CU now that a tile's LDS is 60 KB -- measured 713 / 701 against 737 estimates/s at C3)
     if (S < 1) S = 1;
     long long rps = (n + S - 1) / S;
     rps = (rps + 15) / 16 * 16;
@@ -1064,18 +1075,19 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
   a.R = (float *)c->lr_scratch.p;
   a.g_part = (float *)((char *)c->lr_scratch.p + need_R);
   a.ll_part = (double *)c->lr_part.p;
-  static const bool no_bf16x3 = getenv("MIVI_LR_F32_LOGITS") != nullptr;   // A/B: f32 MFMA logits
+  static const bool no_split = getenv("MIVI_LR_F32_LOGITS") != nullptr;   // A/B: f32 MFMA logits
   a.Zcm = (const float *)c->Z.p;
+  a.xmax = (const unsigned *)c->lr_xmax.p;
   const bool part = M % 128 != 0 && M % 128 <= 96;   // whole 32-sample tiles of the last 128-sample group are empty
-  if (a.d % 4 == 0 && a.d >= 4 && !no_bf16x3) {
-    if (part) hipLaunchKernelGGL(k_lr_logits_bf16x3_part, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
-    else hipLaunchKernelGGL(k_lr_logits_bf16x3, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
+  if (a.d % 4 == 0 && a.d >= 4 && !no_split) {
+    if (part) hipLaunchKernelGGL(k_lr_logits_f16x2_part, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_lr_logits_f16x2, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
   } else {
     if (part) hipLaunchKernelGGL(k_lr_logits_mfma_lds<true>, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
     else hipLaunchKernelGGL(k_lr_logits_mfma_lds<false>, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
   }
   if (want_grad && a.n % 16 != 0) {
-    // the zero residual rows k_lr_xtr_bf16x3's last stage reads (the logits kernels stop at n).  Nobody writes them, so
+    // the zero residual rows k_lr_xtr_f16x2's last stage reads (the logits kernels stop at n).  Nobody writes them, so
     // they are zeroed once per geometry -- and every time while the stream is being captured (a graph must carry its own)
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
@@ -1089,8 +1101,8 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
     const dim3 gx(S, (a.p + 255) / 256, (M + 127) / 128);
     static const bool xtr_f32 = getenv("MIVI_LR_F32_XTR") != nullptr;   // A/B: f32 MFMA X^T R
     if (!xtr_f32) {
-      if (part) hipLaunchKernelGGL((k_lr_xtr_bf16x3<4, true>), gx, dim3(512), 0, c->stream, a);
-      else hipLaunchKernelGGL((k_lr_xtr_bf16x3<4, false>), gx, dim3(512), 0, c->stream, a);
+      if (part) hipLaunchKernelGGL((k_lr_xtr_f16x2<4, true>), gx, dim3(512), 0, c->stream, a);
+      else hipLaunchKernelGGL((k_lr_xtr_f16x2<4, false>), gx, dim3(512), 0, c->stream, a);
     }
     else hipLaunchKernelGGL(k_lr_xtr_mfma_lds, gx, dim3(512), 0, c->stream, a);
   }

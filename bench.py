@@ -319,13 +319,16 @@ def other_roofline(cx, p, w, t_est):
         n, pdim, M2 = w["n"], w["d"] - 1, w["n_mc"]
         fl = 4.0 * n * pdim * M2                      # logits X beta and X^T R, 2 flops per MAC
         by = 2.0 * n * pdim * 4 + 2.0 * n * M2 * 4     # X read once per contraction, R written + read
-        tl, tx = pmc_traffic("k_lr_logits_bf16x3"), pmc_traffic("k_lr_xtr_bf16x3")
-        return dict(bound="mfma", kernel="k_lr_logits_bf16x3 + k_lr_xtr_bf16x3", achieved=fl / t_est / 1e12,
-                    peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=fl / t_est / 1e12 / PEAK_F32_MFMA_TF,
-                    note="f32-equivalent flops of the two data contractions / the f32-MFMA peak (the kernels run the exact "
-                         "3-way bf16 split on the bf16 pipe: x6 executed flops, peak 2500 TF); timed as the whole estimate",
-                    bf16_pipe=dict(executed_TFLOPs=6 * fl / t_est / 1e12, peak=PEAK_BF16_MFMA_TF, frac=6 * fl / t_est / 1e12 / PEAK_BF16_MFMA_TF),
-                    hbm=dict(achieved_GBs=by / t_est / 1e9, peak=PEAK_HBM_GBS, frac=by / t_est / 1e9 / PEAK_HBM_GBS, bytes_per_estimate=by),
+        tl, tx = pmc_traffic("k_lr_logits_f16x2"), pmc_traffic("k_lr_xtr_f16x2")
+        # the two data contractions stream X once each (SURVEY 8d prices ONE fused pass: 2.05 GB); with three 16-bit products per block the
+        # binding roof is the memory side: `achieved` = SURVEY 8d's algorithmic bytes / whole-estimate time against 8 TB/s, the flop fractions beside
+        alg = float(n) * (pdim + 1) * 4 + float(n)                      # X (padded to D columns) once + y
+        return dict(bound="hbm", kernel="k_lr_logits_f16x2 + k_lr_xtr_f16x2", achieved=alg / t_est / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+                    frac=alg / t_est / 1e9 / PEAK_HBM_GBS, algorithmic_bytes_per_launch=alg,
+                    basis="achieved = SURVEY 8d algorithmic bytes (one pass over X, 2.05 GB) / whole-estimate time; peak = HBM 8 TB/s; the kernels read X twice (one pass per contraction) + R once each way",
+                    f32_mfma=dict(achieved_TFLOPs=fl / t_est / 1e12, peak=PEAK_F32_MFMA_TF, frac=fl / t_est / 1e12 / PEAK_F32_MFMA_TF),
+                    pipe16=dict(products_per_block=3, executed_TFLOPs=3 * fl / t_est / 1e12, peak=PEAK_BF16_MFMA_TF, frac=3 * fl / t_est / 1e12 / PEAK_BF16_MFMA_TF),
+                    hbm_executed=dict(achieved_GBs=by / t_est / 1e9, peak=PEAK_HBM_GBS, frac=by / t_est / 1e9 / PEAK_HBM_GBS, bytes_per_estimate=by),
                     traffic=(dict(bytes_per_launch=tl["bytes_per_launch"] + tx["bytes_per_launch"], logits=tl, xtr=tx) if tl and tx else None),
                     avg_launch_us=t_est * 1e6)
     try:
