@@ -50,9 +50,7 @@ static mivi_status_t estimate_gradient_chain(mivi_ctx *c, const void *params, ui
     if ((s = ensure(c, c->X, ((size_t)count + hist_doubles + 8) * sizeof(double) + lane_bytes, false))) return s;
     double *rec = (double *)c->X.p;
     launch_mf_sgd_loop(c, const_cast<void *>(params), nullptr, idx0, 0, count, -1, 0.0, (double)NAN, rec + count, rec, grad,
-                       (void *)(rec + count + hist_doubles + 8));
-    if (c->cfg.dtype == MIVI_F32) hipLaunchKernelGGL(k_neg_value_f32, dim3(1), dim3(1), 0, c->stream, (float *)value, rec + count - 1);
-    else hipLaunchKernelGGL(k_neg_value_f64, dim3(1), dim3(1), 0, c->stream, (double *)value, rec + count - 1);
+                       (void *)(rec + count + hist_doubles + 8), value);   // (the value kernel also leaves the last estimate's objective value: no launch of its own)
     HIPCHK(c, hipGetLastError());
     return MIVI_OK;
   }

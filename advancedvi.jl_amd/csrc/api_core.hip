@@ -9,8 +9,6 @@
 // weighted accumulation of chunk objective values
 __global__ void k_acc_value_f32(double *acc, const float *v, double w, int first) { acc[0] = (first ? 0.0 : acc[0]) + w * (double)v[0]; }
 __global__ void k_acc_value_f64(double *acc, const double *v, double w, int first) { acc[0] = (first ? 0.0 : acc[0]) + w * v[0]; }
-__global__ void k_neg_value_f32(float *out, const double *elbo) { out[0] = (float)(-elbo[0]); }
-__global__ void k_neg_value_f64(double *out, const double *elbo) { out[0] = -elbo[0]; }
 __global__ void k_store_value_f32(float *out, const double *acc) { out[0] = (float)acc[0]; }
 __global__ void k_store_value_f64(double *out, const double *acc) { out[0] = acc[0]; }
 // device counters of the graph-batched calls, set BY VALUE (an async copy from a stack local may outlive the caller's frame)

@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) void k_mf_sgd_loop(MfLoopArgs<T> a) {
 // elbo[t] (and the status word) from the per-step partials of k_mf_sgd_loop; one workgroup per step
 template <typename T>
 __global__ __launch_bounds__(256) void k_mf_loop_value(int d, int nblk, int M_local, int M_total, int ent_kind,
-                                                       double ell_const, const double *hist, double *elbo, int *status) {
+                                                       double ell_const, const double *hist, double *elbo, int *status, T *value_last = nullptr) {
   __shared__ double red[4];
   const int t = blockIdx.x, tid = threadIdx.x;
   double s[4] = {0, 0, 0, 0};
@@ -447,6 +447,7 @@ __global__ __launch_bounds__(256) void k_mf_loop_value(int d, int nblk, int M_lo
     const double ent = (ent_is_closed(ent_kind) ? 0.5 * d * (1.0 + kLog2Pi) : s[1] / Mt + 0.5 * d * kLog2Pi) + s[2];
     const double value = -((s[0] + (double)M_local * ell_const) / Mt + ent);
     elbo[t] = -value;
+    if (value_last && t == (int)gridDim.x - 1) value_last[0] = (T)value;   // (the batch's contract: the LAST estimate's objective value -- no launch of its own)
     int st = 0;
     if (!isfinite(value)) st |= 1;
     if (s[3] > 0.0) st |= 2;
@@ -469,7 +470,7 @@ int mf_loop_lanes(const mivi_ctx *c, int n_steps) {
 
 template <typename T>
 static void mf_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule,
-                             double eta, double clip_eps, double *hist, double *elbo, void *grad_out, void *lane_scratch) {
+                             double eta, double clip_eps, double *hist, double *elbo, void *grad_out, void *lane_scratch, void *value_last) {
   MfLoopArgs<T> a;
   a.d = c->cfg.d;
   a.M = c->cfg.n_mc;
@@ -498,7 +499,7 @@ static void mf_sgd_loop_impl(mivi_ctx *c, void *params, void *opt_state, uint64_
   else if (rule == 0) hipLaunchKernelGGL((k_mf_sgd_loop<T, 0>), dim3(d4), dim3(256), 0, c->stream, a);
   else hipLaunchKernelGGL((k_mf_sgd_loop<T, 1>), dim3(d4), dim3(256), 0, c->stream, a);
   hipLaunchKernelGGL(k_mf_loop_value<T>, dim3(n_steps), dim3(256), 0, c->stream, a.d, d4, a.M, a.M_total, a.ent_kind,
-                     c->t_const, (const double *)hist, elbo, (int *)c->status.p);
+                     c->t_const, (const double *)hist, elbo, (int *)c->status.p, (T *)value_last);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -795,9 +796,9 @@ bool launch_mf_gen_loop(mivi_ctx *c, void *params, const mivi_loop_t &l, double 
 // into grad_out (what mivi_estimate_gradient_n returns).  elbo[t] of every step / estimate either way.
 // lane_scratch (rule < 0): mf_loop_lanes(c, n_steps) * 2 d elements of T, or nullptr = one lane.
 void launch_mf_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule,
-                        double eta, double clip_eps, double *hist, double *elbo, void *grad_out, void *lane_scratch) {
-  if (c->cfg.dtype == MIVI_F32) mf_sgd_loop_impl<float>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo, grad_out, lane_scratch);
-  else mf_sgd_loop_impl<double>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo, grad_out, lane_scratch);
+                        double eta, double clip_eps, double *hist, double *elbo, void *grad_out, void *lane_scratch, void *value_last) {
+  if (c->cfg.dtype == MIVI_F32) mf_sgd_loop_impl<float>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo, grad_out, lane_scratch, value_last);
+  else mf_sgd_loop_impl<double>(c, params, opt_state, idx0, t0, n_steps, rule, eta, clip_eps, hist, elbo, grad_out, lane_scratch, value_last);
 }
 
 // ---------------------------------------------------------------------------------------------

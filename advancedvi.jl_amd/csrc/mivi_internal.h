@@ -395,7 +395,8 @@ struct ValueJob;
 void launch_mf_main(mivi_ctx *c, const void *params, const RngArgs &rng, int M, int want_grad, const void *G,
                     const ValueIn &vin, const OutArgs &out, const ValueJob *prev = nullptr);
 void launch_mf_sgd_loop(mivi_ctx *c, void *params, void *opt_state, uint64_t idx0, long long t0, int n_steps, int rule,
-                        double eta, double clip_eps, double *hist, double *elbo, void *grad_out = nullptr, void *lane_scratch = nullptr);
+                        double eta, double clip_eps, double *hist, double *elbo, void *grad_out = nullptr, void *lane_scratch = nullptr,
+                        void *value_last = nullptr);   // value_last: the last step's objective value as an element of T (written by the value kernel)
 bool fr_rows_loop_ok(const mivi_ctx *c);    // kernels_fullrank_rows.hip: f32, n_mc <= 32, d <= 1024, diagonal-Gaussian target, not STL
 size_t fr_rows_eps_bytes(const mivi_ctx *c, int n_steps);
 size_t fr_rows_part_bytes(const mivi_ctx *c, int n_steps);
