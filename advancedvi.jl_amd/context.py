@@ -247,7 +247,7 @@ class MiviContext:
 
     def estimate_gradient_each(self, params, idx0, count, values=None, grads=None, want_grads=True):
         """Every estimate of the batch idx0 .. idx0 + count - 1 at the same parameters (mivi_estimate_gradient_each):
-        values T[count], grads (count, params_len) -- row i is bitwise mivi_estimate_gradient(idx0 + i)."""
+        values T[count], grads (count, params_len) -- row i equals mivi_estimate_gradient(idx0 + i): bitwise on the generic route, to rounding (1e-6 / 2e-6) on the batch engine."""
         p = self.to_device(params)
         values = self.empty(int(count)) if values is None else values
         if grads is None and want_grads:

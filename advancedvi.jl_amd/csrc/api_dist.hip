@@ -407,23 +407,37 @@ mivi_status_t mivi_p2p_selfcheck(mivi_ctx_t *c, const void *params, uint64_t idx
   invalidate_graph(c);
   s = mivi_estimate_gradient_dist(c, params, idx, b.p, (char *)b.p + 16 * es);
   if (!s) s = mivi_synchronize(c);
-  if (s) { const std::string why = c->err; (void)mivi_p2p_detach(c); c->err = why; return done(s); }
-  std::vector<char> ha((plen + 16) * es), hb((plen + 16) * es);
-  if (hipMemcpy(ha.data(), a.p, ha.size(), hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(hb.data(), b.p, hb.size(), hipMemcpyDeviceToHost) != hipSuccess)
-    return done(fail(c, MIVI_ERR_HIP, "mivi_p2p_selfcheck: read-back failed"));
-  auto at = [&](const std::vector<char> &h, size_t i) { return es == 4 ? (double)((const float *)h.data())[i] : ((const double *)h.data())[i]; };
-  const double v1 = at(ha, 0), v2 = at(hb, 0);
-  double num = 0.0, den = 0.0;
-  for (size_t i = 0; i < plen; ++i) { const double x = at(ha, 16 + i), y = at(hb, 16 + i); num += (y - x) * (y - x); den += x * x; }
-  const double rv = fabs(v2 - v1) / (fabs(v1) > 0 ? fabs(v1) : 1.0), rg = sqrt(num) / (den > 0 ? sqrt(den) : 1.0);
-  int ok = (rv <= 1e-5 && rg <= 1e-5) ? 1 : 0;   // (NaN compares false)
+  // From here every rank takes part in the verdict's all-reduce WHATEVER happened to its own peer-to-peer estimate (bounded waits end it on every
+  // rank): a rank that returned early would leave the others waiting inside RCCL.
+  const mivi_status_t s_p2p = s;
+  const std::string why_p2p = c->err;
+  double rv = 1.0, rg = 1.0;
+  int ok = 0;
+  if (!s_p2p) {
+    std::vector<char> ha((plen + 16) * es), hb((plen + 16) * es);
+    if (hipMemcpy(ha.data(), a.p, ha.size(), hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(hb.data(), b.p, hb.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+      auto at = [&](const std::vector<char> &h, size_t i) { return es == 4 ? (double)((const float *)h.data())[i] : ((const double *)h.data())[i]; };
+      const double v1 = at(ha, 0), v2 = at(hb, 0);
+      double num = 0.0, den = 0.0;
+      for (size_t i = 0; i < plen; ++i) { const double x = at(ha, 16 + i), y = at(hb, 16 + i); num += (y - x) * (y - x); den += x * x; }
+      rv = fabs(v2 - v1) / (fabs(v1) > 0 ? fabs(v1) : 1.0);
+      rg = sqrt(num) / (den > 0 ? sqrt(den) : 1.0);
+      ok = (rv <= 1e-5 && rg <= 1e-5) ? 1 : 0;   // (NaN compares false)
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   if (c->comm && c->comm_world > 1) {
     RcclApi *r = rccl();
     int *flag = (int *)((char *)b.p + (plen + 16) * es);
     if (!r || !r->AllReduce || hipMemcpy(flag, &ok, sizeof(int), hipMemcpyHostToDevice) != hipSuccess || r->AllReduce(flag, flag, 1, ncclInt32, ncclMin, (ncclComm_t)c->comm, c->stream) != ncclSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&ok, flag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+        hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&ok, flag, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+      (void)mivi_p2p_detach(c);
       return done(fail(c, MIVI_ERR_HIP, "mivi_p2p_selfcheck: the ranks' verdicts could not be combined"));
+    }
   }
+  if (s_p2p) { (void)mivi_p2p_detach(c); c->err = why_p2p; return done(s_p2p); }
+  if (!ok && c->p2p_world > 1) (void)mivi_p2p_detach(c);   // (some rank disagreed or failed: nobody keeps the areas, every rank stays on the RCCL routes)
   c->p2p_verified = ok == 1 && (c->p2p_distinct || c->p2p_world == 1);
   if (rel_out) { rel_out[0] = rv; rel_out[1] = rg; rel_out[2] = c->p2p_verified ? 1.0 : 0.0; }
   return done(MIVI_OK);

@@ -1176,6 +1176,22 @@ def main():
                                     parity_vs_fp64_oracle=(None if args.no_cpu_baseline else parity_vs_oracle(cx, p2, p2h, w2, batch=4)))
                     cx.close()
                     del prob2, q2
+                # every estimate of a batch delivered (mivi_estimate_gradient_each: values[n] and grads[n x len], dense with the zeros above the
+                # diagonal written per estimate: 4.2 MB per lane instead of the 2.1 MB of the scratch lower triangles) -- timed once, full file only
+                try:
+                    n_e = 100
+                    ve, ge = ctx.estimate_gradient_each(params, 90_000, n_e)
+                    stream.synchronize()
+                    t0s = time.perf_counter()
+                    for r in range(5):
+                        ctx.estimate_gradient_each(params, 90_000 + (r + 1) * n_e, n_e, values=ve, grads=ge)
+                    stream.synchronize()
+                    t_e = (time.perf_counter() - t0s) / (5 * n_e)
+                    also["ns_each"] = dict(workload="north-star batches through mivi_estimate_gradient_each (every estimate's value and dense gradient kept), 5 x 100 estimates",
+                                           value=1.0 / t_e, unit="estimates/s", us_per_step=t_e * 1e6)
+                    del ve, ge
+                except Exception as e:   # noqa: BLE001
+                    also["ns_each"] = dict(error=str(e))
                 # the Stein / Price estimator of E_q[grad], E_q[hess] on the north-star shape (gaussian_expectation_gradient_and_hessian!,
                 # src/algorithms/gauss_expected_grad_hess.jl:32-60): the ELBO path's sampling + target kernels, eps G^T, one C^-T solve
                 # with d right-hand sides; eager calls with consecutive indices, device-resident outputs
