@@ -30,9 +30,6 @@
 #include "fr_elem.h"
 #include "fr_planes.h"
 
-#ifndef FB_RING_VJP
-#define FB_RING_VJP 4
-#endif
 #ifndef FB_WJ
 #define FB_WJ 1
 #endif
@@ -238,7 +235,6 @@ __global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
 constexpr int kStageW = 16 * 256;   // words per stage
 constexpr int kRing = 4;            // LDS ring slots of the register-prefetching loops: three stages in flight behind the one being read;
                                     // the main loops are unrolled by kRing, so every slot address is a compile-time constant
-constexpr int kRingVjp = FB_RING_VJP;   // ring slots of the VJP's plain loop (two workgroups per CU)
 constexpr int kImgW = 32 * 36;      // a wave-private 32 x 32 epilogue image (leading dimension 36), words
 // Wave layout of a 128 x 128 tile, WJ = 32-column blocks per wave: 8 / WJ waves = 2 (row halves of 64) x 4 / WJ (column parts of 32 WJ).
 //   WJ = 2: four waves (one per SIMD), a wave owns 64 x 64: 32 KiB of LDS reads per group and workgroup
@@ -328,19 +324,6 @@ __global__ __launch_bounds__(512 / WJ, 2 / WJ) void k_fb_prod(FbArgs a) {
   const int R0 = row0 >> 5;               // first 32-row block of the tile
   const int g0 = kSU ? 2 * R0 : 0;        // first group of the K range
   const int G = kDG ? ng : (kSU ? ng - g0 : 2 * (R0 + 4));  // groups of the workgroup (the last row block's K; the dense product: all of K)
-  if (tid < 128) {
-    if constexpr (!kDG && !kSU) {
-      vec[tid] = a.params[row0 + tid];
-      vec[128 + tid] = a.t_mean[row0 + tid];
-      if (MODE == FB_DIAG) vec[256 + tid] = a.t_istd[row0 + tid];
-    }
-    const float *sc = kDG ? a.pscale : (kSU ? a.tscale : a.cscale);
-    vec[384 + tid] = sc[d + row0 + tid] * ((kDG) ? 1.f : kEpsInv);   // what a row's raw sums are multiplied by
-  }
-  if constexpr (kDG) {
-    const float *ri = a.rinv + (size_t)ln * (size_t)(d >> 7) * a.M;
-    for (int i = tid; i < d; i += 512 / WJ) tab[i] = ri[(size_t)(i >> 7) * a.M + col0 + (i & 127)];
-  }
   // this wave's NF fragments of a stage
   const unsigned *sp[NF];   // the stage the next issue takes
   int gmax[NF];             // last group of the fragment that is ever read (tril(C): the diagonal block + two zero groups: clamped beyond)
@@ -356,6 +339,21 @@ __global__ __launch_bounds__(512 / WJ, 2 / WJ) void k_fb_prod(FbArgs a) {
     }
   }
   int gd = 0;               // the group the pointers stand at
+  auto stage_tables = [&]() {   // the tile's row vectors (+ DENSE_G: R's inverse scales): behind the prologue's DMA requests, which their loads must not delay
+    if (tid < 128) {
+      if constexpr (!kDG && !kSU) {
+        vec[tid] = a.params[row0 + tid];
+        vec[128 + tid] = a.t_mean[row0 + tid];
+        if (MODE == FB_DIAG) vec[256 + tid] = a.t_istd[row0 + tid];
+      }
+      const float *sc = kDG ? a.pscale : (kSU ? a.tscale : a.cscale);
+      vec[384 + tid] = sc[d + row0 + tid] * ((kDG) ? 1.f : kEpsInv);   // what a row's raw sums are multiplied by
+    }
+    if constexpr (kDG) {
+      const float *ri = a.rinv + (size_t)ln * (size_t)(d >> 7) * a.M;
+      for (int i = tid; i < d; i += 512 / WJ) tab[i] = ri[(size_t)(i >> 7) * a.M + col0 + (i & 127)];
+    }
+  };
   auto issue = [&](int slot) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -414,6 +412,7 @@ __global__ __launch_bounds__(512 / WJ, 2 / WJ) void k_fb_prod(FbArgs a) {
   FB_STAMP(a, 0);
   FB_NOTE(a, 4, G);
   static_for<0, NRP>([&](auto S) { issue(decltype(S)::value); });   // (G >= 8 >= NRP)
+  stage_tables();
   fb_wait_vm<kPW * (NRP - 1)>();
   fb_barrier();
   FB_STAMP(a, 1);
@@ -653,13 +652,20 @@ __device__ __forceinline__ void fb_value_block(const FbArgs &a, int l, double *r
 // duty).  d/dmu: the waves of the diagonal tiles sum W's fragments (hi + lo, times the block's inverse scale).  The step's objective
 // values ride as extra workgroups.
 // -----------------------------------------------------------------------------------------------------------------
-template <int WJ, int PF>
-__global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArgs a) {
+// NRV = ring slots of the plain loop, TABW = words of the scale table (M <= TABW), WPE = waves per SIMD the register budget allows:
+// (3, 256, 6) = 50 KiB of LDS and <= 80 registers: THREE workgroups per CU for n_mc <= 256; (3, 2048, 4): two per CU otherwise.
+template <int WJ, int PF, int NRV, int TABW, int WPE>
+__global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbArgs a) {
   constexpr int LDC = 36, NF = WJ, kPW = 2 * WJ;
-  constexpr int NR = PF ? kRing : kRingVjp;
+  constexpr int NR = PF ? kRing : NRV;
   constexpr int kBody = (NR * kStageW > 16 * kImgW / 2) ? NR * kStageW : 16 * kImgW / 2;   // the ring, later one image per wave
-  __shared__ __attribute__((aligned(16))) unsigned lds[kBody + 2048];
-  float *wf = reinterpret_cast<float *>(lds + kBody);   // [M / 128][128]: inverse scales of W's rows of this tile, per 128-sample block (M <= 2048)
+  __shared__ __attribute__((aligned(16))) unsigned lds[kBody + TABW];
+  // W's planes are scaled per (row, 128-sample block).  The chain accumulator stays ONE accumulator: at a block boundary its rows are
+  // multiplied by s_next / s_current (powers of two: exact), at the end by the last block's inverse scale.  wf[r][row], r < n_blocks - 1: the
+  // boundary ratios, clamped to 2^40 (beyond that the next block's contribution is below 2^-40 of what the row already holds: entering it
+  // in a too small unit over-weights it by the clamped excess, still below 2^-40 of the row's largest block -- and the accumulator cannot
+  // overflow); wf[n_blocks - 1][row]: the closing factor.
+  float *wf = reinterpret_cast<float *>(lds + kBody);
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w / (4 / WJ), wn = w % (4 / WJ);
@@ -676,10 +682,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
   float *grad = last ? a.grad_last : a.grads + (size_t)ln * a.grad_stride;
   const bool upper = a.write_upper || last;
   const int G = nmg;
-  {
-    const float *wi = a.winv + (size_t)ln * (size_t)(M >> 7) * d + row0;
-    for (int i = tid; i < M; i += 512 / WJ) wf[i] = wi[(size_t)(i >> 7) * d + (i & 127)];
-  }
+  const int NB = M >> 7;   // 128-sample blocks
   const unsigned *sp[NF];           // the stage the next issue takes
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
@@ -687,6 +690,19 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
     sp[f] = (fs < 4 ? a.WV + (size_t)ln * a.plane_stride + ((size_t)((row0 >> 5) + fr) * nmg) * kFrag
                     : a.epsV + (size_t)ln * a.plane_stride + ((size_t)((col0 >> 5) + fr) * nmg) * kFrag) + 4 * lane;
   }
+  auto build_table = [&]() {   // (behind the prologue's DMA requests: its loads and divisions must not delay them)
+  if (tid < 128) {
+      const float *wi = a.winv + (size_t)ln * (size_t)NB * d + row0 + tid;
+      float u = wi[0];   // the inverse of the unit the accumulator is in
+      for (int r = 1; r < NB; ++r) {
+        float ratio = u / wi[(size_t)r * d];
+        if (!(ratio <= 1099511627776.f)) ratio = 1099511627776.f;   // 2^40 (also for a non-finite quotient)
+        wf[(r - 1) * 128 + tid] = ratio;
+        u = u / ratio;
+      }
+      wf[(NB - 1) * 128 + tid] = u;
+    }
+  };
   auto issue = [&](int slot) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -709,14 +725,14 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
 #pragma unroll
     for (int j = 0; j < WJ; ++j) dg[i] = dg[i] || ri[i] == cj[j];
   }
-  f32x16 acc[2][WJ], tot[2][WJ];
+  f32x16 acc[2][WJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < WJ; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
-  double rsd[2] = {0.0, 0.0};   // d/dmu: this lane's share (row l31, its half of the k slots) of the row sums of W
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  double rsd[2] = {0.0, 0.0};   // d/dmu: this lane's share (row l31, its half of the k slots) of the row sums of W, in the accumulator's unit
   float rcur[2] = {0.f, 0.f};
   // A wave with work computes ALL its sub-tiles in every group (one straight MFMA block: see k_fb_prod); a sub-tile strictly above the
   // diagonal (diagonal tiles only) is simply not stored.
@@ -732,7 +748,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
         }
     }
     if constexpr (decltype(S)::value == 3 || decltype(S)::value == -1) {
-      if (((g + 1) & 7) == 0) {   // a 128-sample block ended with this group: fold with its inverse row scales
+      if (((g + 1) & 7) == 0 && g + 1 < G) {   // a 128-sample block (but the last) ended with this group: into the next block's unit
         const float *wr = wf + ((g >> 3) << 7) + 64 * wm;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -742,12 +758,9 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
 #pragma unroll
             for (int j = 0; j < WJ; ++j)
 #pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                tot[i][j][4 * q + c] = __builtin_fmaf(acc[i][j][4 * q + c], f4[c], tot[i][j][4 * q + c]);
-                acc[i][j][4 * q + c] = 0.f;
-              }
+              for (int c = 0; c < 4; ++c) acc[i][j][4 * q + c] *= f4[c];
           }
-          rsd[i] += (double)(rcur[i] * wr[32 * i + l31]);
+          rsd[i] = (rsd[i] + (double)rcur[i]) * (double)wr[32 * i + l31];
           rcur[i] = 0.f;
         }
         asm volatile("" ::: "memory");
@@ -767,6 +780,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
   if constexpr (PF) {
     static_assert(kRing == 4, "the unrolled loops below are written for four slots");
     issue(0); issue(1); issue(2); issue(3);   // (G >= 8: M >= 128)
+    build_table();
     fb_wait_vm<kPW * 3>();
     fb_barrier();
     FbFrags<WJ> F0, F1;
@@ -802,6 +816,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
     FB_NOTE(a, 4, G);
 #pragma unroll
     for (int s0 = 0; s0 < NR - 1; ++s0) issue(s0);   // (G >= 8)
+    build_table();
     int slot = 0;
     for (int g = 0; g < G; ++g) {
       if (g == 1) FB_STAMP(a, 1);
@@ -821,6 +836,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
   fb_barrier();
   FB_STAMP(a, 2);
   float *Cs = reinterpret_cast<float *>(lds) + w * kImgW;
+  const float *wfin = wf + (NB - 1) * 128 + 64 * wm;   // the closing factors of this wave's rows
   const double invM = 1.0 / (double)a.M_total;
   const bool pow2M = (a.M_total & (a.M_total - 1)) == 0;
   const float invMe = (float)invM * kEpsInv;   // (eps' planes hold 2^11 eps)
@@ -835,16 +851,17 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
       const int rbase = 32 * ri[i], cbase = 32 * cj[j];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 v = {tot[i][j][4 * q], tot[i][j][4 * q + 1], tot[i][j][4 * q + 2], tot[i][j][4 * q + 3]};
+        const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
         *(f32x4 *)(Cs + l31 * LDC + 8 * q + 4 * h) = v;
       }
+      const f32x4 ff = *(const f32x4 *)(wfin + 32 * i + i4);
 #pragma unroll
       for (int p = 0; p < 4; ++p) {   // lane = (rows i4 .. i4 + 3, column n) of pass p
         const int n = 8 * p + (lane >> 3);
         const int gi = rbase + i4, gj = cbase + n;
         float cjj = 1.f;
         if (diag && gj >= gi && gj < gi + 4) cjj = a.params[d + (size_t)gj * d + gj];
-        const f32x4 v = *(const f32x4 *)(Cs + n * LDC + i4);
+        const f32x4 v = *(const f32x4 *)(Cs + n * LDC + i4) * ff;
         f32x4 o;
         if (!diag && pow2M) {   // strictly below the diagonal, power-of-two sample count: exact scaling, no per-element branches
           o = -v * invMe;
@@ -865,7 +882,8 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : 4 / WJ) void k_fb_vjp(FbArg
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is read before the next sub-tile overwrites it
     }
     if (dg[i]) {   // d/dmu rows of this row block: the two halves' shares
-      const double sm = rsd[i] + __shfl_xor(rsd[i], 32, 64);
+      const double mine = (rsd[i] + (double)rcur[i]) * (double)wfin[32 * i + l31];
+      const double sm = mine + __shfl_xor(mine, 32, 64);
       if (lane < 32) grad[32 * ri[i] + lane] = dmu_elem(sm, invM);
     }
   }
@@ -1089,7 +1107,10 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
   }
   a.work = (const int4 *)tb.vjp.p; a.n_work = tb.n_vjp;
   if (which & 2) {
-    hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
+    // measured at the north star (us per 20 / 50 / 80 lanes): ring 3 + three workgroups per CU 26.5 / 63.3 / 105-115; ring 3, two per CU 26.4 /
+    // 69.8 / 109; ring 4, two per CU 36.7 / 81.5 / 126; ring 2, three per CU 26.4 / 72.6 / 113 (round 4's kernel with its second accumulator: 29 / 70 / 115)
+    if (s.M <= 256) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 256, 6>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
+    else hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 2048, 4>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
 #ifdef MIVI_DEV
     dump("k_fb_vjp", tb.n_vjp);
 #endif
