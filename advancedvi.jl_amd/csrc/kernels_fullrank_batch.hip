@@ -119,37 +119,52 @@ struct FbArgs {
 // k range the products read (fragments kg_lo .. kg_hi) -> one power-of-two scale per row (scale[row], scale[d + row] = its inverse) ->
 // the block's fragments, one wave per fragment.  ld(k, row) returns the (masked) f32 element.  red: 16 * 32 + 32 floats of LDS.
 // -----------------------------------------------------------------------------------------------------------------
-template <class Ld>
-__device__ __forceinline__ void fb_rowblock_planes(int d, int rb, int kg_lo, int kg_hi, Ld ld, unsigned *planes, float *scale, float *red) {
-  const int tid = threadIdx.x, row = tid & 31, part = tid >> 5, ng = d >> 4;
-  float m = 0.f;
+template <class Ld4, class Ld>
+__device__ __forceinline__ void fb_rowblock_planes(int d, int rb, int kg_lo, int kg_hi, int sub, int nsub, Ld4 ld4, Ld ld, unsigned *planes, float *scale, float *red) {
+  // row maxima: a thread takes 4 rows x one k per 16-byte load (rows are the contiguous axis), 64 k parts, eight loads in flight
+  const int tid = threadIdx.x, r4 = tid & 7, part = tid >> 3, ng = d >> 4;
+  f32x4 m = {0.f, 0.f, 0.f, 0.f};
   {
     int k = 16 * kg_lo + part;
-    for (; k + 112 <= 16 * kg_hi + 15; k += 128) {   // eight independent loads in flight per thread
-      float v[8];
+    for (; k + 448 <= 16 * kg_hi + 15; k += 512) {
+      f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = fabsf(ld(k + 16 * u, 32 * rb + row));
+      for (int u = 0; u < 8; ++u) v[u] = ld4(k + 64 * u, 32 * rb + 4 * r4);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) m[c] = fmaxf(m[c], fabsf(v[u][c]));
     }
-    for (; k <= 16 * kg_hi + 15; k += 16) m = fmaxf(m, fabsf(ld(k, 32 * rb + row)));
+    for (; k <= 16 * kg_hi + 15; k += 64) {
+      const f32x4 v = ld4(k, 32 * rb + 4 * r4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) m[c] = fmaxf(m[c], fabsf(v[c]));
+    }
   }
-  red[part * 32 + row] = m;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {   // lanes 8 apart hold the same rows: the wave's eight parts, then the eight waves through LDS
+    m[c] = fmaxf(m[c], __shfl_xor(m[c], 8, 64));
+    m[c] = fmaxf(m[c], __shfl_xor(m[c], 16, 64));
+    m[c] = fmaxf(m[c], __shfl_xor(m[c], 32, 64));
+  }
+  if ((tid & 63) < 8) *(f32x4 *)(red + (tid >> 6) * 32 + 4 * r4) = m;
   lds_barrier();
   if (tid < 32) {
     float mm = red[tid];
 #pragma unroll
-    for (int p = 1; p < 16; ++p) mm = fmaxf(mm, red[p * 32 + tid]);
+    for (int p = 1; p < 8; ++p) mm = fmaxf(mm, red[p * 32 + tid]);
     float s, inv;
     fb_scale_of(mm, s, inv);
     red[512 + tid] = s;
-    scale[32 * rb + tid] = s;
-    scale[d + 32 * rb + tid] = inv;
+    if (sub == 0) {
+      scale[32 * rb + tid] = s;
+      scale[d + 32 * rb + tid] = inv;
+    }
   }
   lds_barrier();
   const int w = tid >> 6, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const float s = red[512 + l31];
-  for (int kg = kg_lo + w; kg <= kg_hi; kg += 8) {
+  for (int kg = kg_lo + w + 8 * sub; kg <= kg_hi; kg += 8 * nsub) {
     float x[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) x[e] = ld(16 * kg + 8 * (e >> 2) + 4 * h + (e & 3), 32 * rb + l31) * s;
@@ -158,18 +173,25 @@ __device__ __forceinline__ void fb_rowblock_planes(int d, int rb, int kg_lo, int
 }
 // tril(C): the fragments up to the diagonal block + the two zero groups behind it (a wave of k_fb_prod walks the K range of its SECOND row
 // block with both of its blocks: the first one's chain adds exact zeros there)
-__device__ __forceinline__ void fb_cplanes_block(const FbArgs &a, int rb, float *red) {
+__device__ __forceinline__ void fb_cplanes_block(const FbArgs &a, int rb, int sub, int nsub, float *red) {
   const int d = a.d, ng = d >> 4;
   const float *C = a.params + d;
   const int hi = 2 * rb + 3 < ng - 1 ? 2 * rb + 3 : ng - 1;
-  fb_rowblock_planes(d, rb, 0, hi, [C, d](int k, int row) { const float v = C[(size_t)k * d + row]; return k > row ? 0.f : v; }, a.CA, a.cscale, red);
+  fb_rowblock_planes(d, rb, 0, hi, sub, nsub,
+                     [C, d](int k, int row) { f32x4 v = *(const f32x4 *)(C + (size_t)k * d + row);
+#pragma unroll
+                                              for (int c = 0; c < 4; ++c) v[c] = k > row + c ? 0.f : v[c];
+                                              return v; },
+                     [C, d](int k, int row) { const float v = C[(size_t)k * d + row]; return k > row ? 0.f : v; }, a.CA, a.cscale, red);
 }
 // k_fb_pplanes: the dense-Gaussian target's precision matrix P (every k group: P is full).  Once per target.
 __global__ __launch_bounds__(512) void k_fb_pplanes(FbArgs a) {
   __shared__ float red[16 * 32 + 32];
   const float *P = a.t_prec;
   const int dP = a.dP;
-  fb_rowblock_planes(a.d, (int)blockIdx.x, 0, (a.d >> 4) - 1, [P, dP](int k, int row) { return P[(size_t)k * dP + row]; }, a.PA, a.pscale, red);
+  fb_rowblock_planes(a.d, (int)blockIdx.x, 0, (a.d >> 4) - 1, (int)blockIdx.y, (int)gridDim.y,
+                     [P, dP](int k, int row) { return *(const f32x4 *)(P + (size_t)k * dP + row); },
+                     [P, dP](int k, int row) { return P[(size_t)k * dP + row]; }, a.PA, a.pscale, red);
 }
 // k_fb_tplanes: C^-T (upper triangular) -- entries below the diagonal are exact zeros whatever the solve left there; a 128-row tile of
 // k_fb_prod<FB_STL_U> starts its K range at its FIRST row block's diagonal, so a row block's fragments start there.  Once per call.
@@ -177,8 +199,12 @@ __global__ __launch_bounds__(512) void k_fb_tplanes(FbArgs a) {
   __shared__ float red[16 * 32 + 32];
   const float *T = a.Tinv;
   const int d = a.d, rb = (int)blockIdx.x;
-  fb_rowblock_planes(d, rb, 2 * (rb & ~3), (d >> 4) - 1, [T, d](int k, int row) { const float v = T[(size_t)k * d + row]; return k >= row ? v : 0.f; }, a.TA,
-                     a.tscale, red);
+  fb_rowblock_planes(d, rb, 2 * (rb & ~3), (d >> 4) - 1, (int)blockIdx.y, (int)gridDim.y,
+                     [T, d](int k, int row) { f32x4 v = *(const f32x4 *)(T + (size_t)k * d + row);
+#pragma unroll
+                                              for (int c = 0; c < 4; ++c) v[c] = k >= row + c ? v[c] : 0.f;
+                                              return v; },
+                     [T, d](int k, int row) { const float v = T[(size_t)k * d + row]; return k >= row ? v : 0.f; }, a.TA, a.tscale, red);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -192,9 +218,9 @@ __global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
   __shared__ double red[8];
   __shared__ float E[32 * 65];   // E[m][i], leading dimension 65 (the riders' reduction area: 544 floats)
   const int tid = threadIdx.x, eb = blockIdx.x, d = a.d;
-  if ((int)blockIdx.y < a.n_riders) {
+  if ((int)blockIdx.y < a.n_riders) {   // four workgroups per 32-row block of tril(C) (each finds the rows' scales, takes every fourth share of the fragments)
     const int r = (int)blockIdx.y * (int)gridDim.x + eb;
-    if (r < (d >> 5)) fb_cplanes_block(a, (d >> 5) - 1 - r, E);
+    if (r < 4 * (d >> 5)) fb_cplanes_block(a, (d >> 5) - 1 - (r >> 2), r & 3, 4, E);
     return;
   }
   const int l = (int)blockIdx.y - a.n_riders;
@@ -1037,18 +1063,18 @@ void fb_launch_eps(mivi_ctx *c, const FbStep &s, bool with_cplanes, hipStream_t 
   a.L = L;
   a.rng = s.rng;
   const int gx = (d / 64) * (M / 32);
-  a.n_riders = with_cplanes ? (d / 32 + gx - 1) / gx : 0;   // tril(C)'s planes: one workgroup per 32-row block, in FRONT of the lanes' draws
+  a.n_riders = with_cplanes ? (4 * (d / 32) + gx - 1) / gx : 0;   // tril(C)'s planes: four workgroups per 32-row block, in FRONT of the lanes' draws
   hipLaunchKernelGGL(k_fb_eps, dim3(gx, L + a.n_riders), dim3(512), 0, stream, a);
 }
 // the dense-Gaussian target's precision matrix as operand planes (once per target: FbTables::PA_valid)
 void fb_launch_pplanes(mivi_ctx *c, hipStream_t stream) {
   FbArgs a = fb_args(c, nullptr, c->cfg.n_mc);
-  hipLaunchKernelGGL(k_fb_pplanes, dim3(c->cfg.d / 32), dim3(512), 0, stream, a);
+  hipLaunchKernelGGL(k_fb_pplanes, dim3(c->cfg.d / 32, 4), dim3(512), 0, stream, a);
 }
 // C^-T (t.Tinv, left there by the solve kernels on the identity) as operand planes: once per call
 void fb_launch_tplanes(mivi_ctx *c, hipStream_t stream) {
   FbArgs a = fb_args(c, nullptr, c->cfg.n_mc);
-  hipLaunchKernelGGL(k_fb_tplanes, dim3(c->cfg.d / 32), dim3(512), 0, stream, a);
+  hipLaunchKernelGGL(k_fb_tplanes, dim3(c->cfg.d / 32, 4), dim3(512), 0, stream, a);
 }
 // product + target (dense target: product -> R, the target's product) -> VJP (+ the lanes' values as extra workgroups of the VJP launch) on `stream`
 void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int which) {   // which (profiling): bit 0 the draw's product, bit 1 the VJP, bit 2 the dense target's product, bit 3 the sticking-the-landing product; 15 = all (default)

@@ -28,4 +28,4 @@ def lanes_of(kernel, ngx, ngy, d=1024, M=256):
 
 def eps_riders(d=1024, M=256):
     gx = (d // 64) * (M // 32)
-    return -(-(d // 32) // gx)   # (round 5: one rider workgroup per 32-row block of tril(C))
+    return -(-(4 * (d // 32)) // gx)   # (round 5: four rider workgroups per 32-row block of tril(C))
