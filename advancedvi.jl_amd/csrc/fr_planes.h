@@ -19,7 +19,7 @@
 //
 // A fragment = 32 rows x 16 k of one operand = 2 planes x 64 lanes x 16 bytes (kFrag words): lane (row = lane % 32, h = lane / 32) holds
 // the eight k slots k = 16 g + 8 (e / 4) + 4 h + e % 4.  Whoever PRODUCES an operand scales and splits it, once.
-// Users: kernels_fullrank_batch.hip.
+// Users: kernels_fullrank_batch.hip, kernels_targets.hip (the logistic regression's logits on planes of X).
 #pragma once
 #include "device_common.h"
 
@@ -91,6 +91,42 @@ __device__ __forceinline__ void fb_store_frag(unsigned *dst, const float *x) {  
   fb_split2(x, uh, ul);
   store16_wt(dst, uh);
   store16_wt(dst + 256, ul);
+}
+
+// ---- shared by the kernels that stage 128 x 128 tiles through an LDS ring of 16-k stages (kernels_fullrank_batch.hip, kernels_targets.hip) ----
+constexpr int kStageW = 16 * 256;   // words per stage: four A + four B fragments, two planes each (16 KiB)
+
+// A wave's operands of one 16-k group: two A fragments (its two 32-row blocks) and WJ B fragments (its 32-column blocks), two planes each
+template <int WJ>
+struct FbFrags {
+  u32x4v A[2][2], B[WJ][2];
+};
+__device__ __forceinline__ f32x16 fb_mma(const u32x4v &a, const u32x4v &b, const f32x16 &c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// the 6 WJ MFMAs of a group, the 2 WJ accumulators' chains interleaved; per accumulator smallest terms first: lo.hi, hi.lo, hi.hi
+template <int WJ>
+__device__ __forceinline__ void fb_group(const FbFrags<WJ> &F, f32x16 (&acc)[2][WJ]) {
+  constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};   // planes: 0 hi, 1 lo
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < WJ; ++j) acc[i][j] = fb_mma(F.A[i][PA[p]], F.B[j][PB[p]], acc[i][j]);
+}
+
+template <int WJ>
+__device__ __forceinline__ void fb_read_frags(const unsigned *lds, int slot, int wm, int wn, int lane, FbFrags<WJ> &F) {
+  const unsigned *cur = lds + slot * kStageW + 4 * lane;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) F.A[i][p] = *(const u32x4v *)(cur + ((2 * wm + i) * 2 + p) * 256);
+#pragma unroll
+  for (int j = 0; j < WJ; ++j)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) F.B[j][p] = *(const u32x4v *)(cur + (8 + (WJ * wn + j) * 2 + p) * 256);
 }
 
 }  // namespace mivi

@@ -39,26 +39,6 @@
 
 namespace mivi {
 
-// A wave's operands of one 16-k group: two A fragments (its two 32-row blocks) and WJ B fragments (its 32-column blocks), two planes each
-template <int WJ>
-struct FbFrags {
-  u32x4v A[2][2], B[WJ][2];
-};
-__device__ __forceinline__ f32x16 fb_mma(const u32x4v &a, const u32x4v &b, const f32x16 &c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-// the 6 WJ MFMAs of a group, the 2 WJ accumulators' chains interleaved; per accumulator smallest terms first: lo.hi, hi.lo, hi.hi
-template <int WJ>
-__device__ __forceinline__ void fb_group(const FbFrags<WJ> &F, f32x16 (&acc)[2][WJ]) {
-  constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};   // planes: 0 hi, 1 lo
-#pragma unroll
-  for (int p = 0; p < 3; ++p)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < WJ; ++j) acc[i][j] = fb_mma(F.A[i][PA[p]], F.B[j][PB[p]], acc[i][j]);
-}
-
 struct FbArgs {
   int d, M, L;
   const float *params;            // [mu; vec C]
@@ -258,25 +238,12 @@ __global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
 // planes each) in an LDS ring.  Fragment f of a stage (2 KiB): f < 4: A fragment f; else B fragment f - 4.  Wave w issues fragments
 // WJ w .. WJ w + WJ - 1: always 2 WJ requests per wave and stage, so the vmcnt accounting is a compile-time constant.
 // -----------------------------------------------------------------------------------------------------------------
-constexpr int kStageW = 16 * 256;   // words per stage
 constexpr int kRing = 4;            // LDS ring slots of the register-prefetching loops: three stages in flight behind the one being read;
                                     // the main loops are unrolled by kRing, so every slot address is a compile-time constant
 constexpr int kImgW = 32 * 36;      // a wave-private 32 x 32 epilogue image (leading dimension 36), words
 // Wave layout of a 128 x 128 tile, WJ = 32-column blocks per wave: 8 / WJ waves = 2 (row halves of 64) x 4 / WJ (column parts of 32 WJ).
 //   WJ = 2: four waves (one per SIMD), a wave owns 64 x 64: 32 KiB of LDS reads per group and workgroup
 //   WJ = 1: eight waves (two per SIMD), a wave owns 64 x 32: 48 KiB of LDS reads per group
-template <int WJ>
-__device__ __forceinline__ void fb_read_frags(const unsigned *lds, int slot, int wm, int wn, int lane, FbFrags<WJ> &F) {
-  const unsigned *cur = lds + slot * kStageW + 4 * lane;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int p = 0; p < 2; ++p) F.A[i][p] = *(const u32x4v *)(cur + ((2 * wm + i) * 2 + p) * 256);
-#pragma unroll
-  for (int j = 0; j < WJ; ++j)
-#pragma unroll
-    for (int p = 0; p < 2; ++p) F.B[j][p] = *(const u32x4v *)(cur + (8 + (WJ * wn + j) * 2 + p) * 256);
-}
 // The issue order inside one iteration's straight-line block {2 WJ LDS-DMA requests, 4 + 2 WJ fragment reads of the next group, 6 WJ MFMAs}:
 // every wave of the workgroup leaves the barrier at the same moment, and with the reads first (where the scheduler puts loads) all of
 // them queue on the LDS port before the first MFMA of anybody issues -- the matrix pipe idles for the length of that burst.  Memory

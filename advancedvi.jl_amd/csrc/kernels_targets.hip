@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "device_common.h"
+#include "fr_planes.h"
 
 namespace mivi {
 
@@ -347,6 +348,8 @@ struct LrMfmaArgs {
   int ldz;
   const float *Zcm;    // the sample matrix itself, d x M column-major (k contiguous per sample): the split-operand logits
   const unsigned *xmax;   // bits of max |X| (k_lr_make_xrm): the power-of-two scale of X's f16 splits
+  const unsigned *XA;     // X as A-operand planes (k_lr_xplanes): fragment (rb32, kg) at (rb32 (ldx / 16) + kg) kFrag
+  unsigned *ZP;           // the samples as B-operand planes (k_lr_zplanes): fragment (mb32, kg)
   float *R;            // R[m + r*ldr]
   int ldr;
   double *ll_part;     // [gridDim.x][M]
@@ -739,6 +742,110 @@ __device__ __forceinline__ void lr_logits_f16x2_body(const LrMfmaArgs &a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// logits on OPERAND PLANES (round 5; fr_planes.h): X is constant across estimates, so its two-way f16 split is made ONCE per data set
+// (k_lr_xplanes: 4 bytes per element in MFMA-fragment order, the power-of-two scale of max|X| applied) and the samples' once per estimate
+// (k_lr_zplanes: 128 x 512 elements).  The contraction is then the batch engine's loop: 128-row x 128-sample tiles, 16-k stages of 16 KiB
+// by LDS-DMA into a three-slot ring, ds_read_b128 -> three v_mfma_f32_32x32x16_f16 per fragment pair, no vector arithmetic, three
+// workgroups per CU.  The epilogue works in the accumulators' own layout (lane = sample, registers = rows: residual stores are 128-byte
+// segments per half-wave), writes R in the f32 layout k_lr_xtr_f16x2 reads, and the per-sample log-likelihood partials.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lr_xplanes(long long n, long long nrb32, int ldx, const float *Xrm, const unsigned *xmax, unsigned *XA) {
+  const long long f = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5, ng = ldx >> 4;
+  const long long rb = f / ng;
+  const int kg = (int)(f % ng);
+  if (rb >= nrb32) return;
+  float s, inv;
+  lr_xscale(xmax, s, inv);
+  const long long row = 32 * rb + l31;
+  float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (row < n) {
+    const float *src = Xrm + (size_t)row * ldx + 16 * kg + 4 * h;
+    const lr_f32x4 p = *(const lr_f32x4 *)src, q = *(const lr_f32x4 *)(src + 8);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { x[c] = p[c] * s; x[4 + c] = q[c] * s; }
+  }
+  fb_store_frag(XA + (size_t)f * kFrag + 4 * lane, x);
+}
+__global__ __launch_bounds__(256) void k_lr_zplanes(int M, int d, int ldx, const float *Zcm, unsigned *ZP) {
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5, ng = ldx >> 4;
+  const int mb = f / ng, kg = f % ng;
+  if (mb >= (M >> 5)) return;
+  const float *src = Zcm + (size_t)(32 * mb + l31) * d;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 16 * kg + 8 * (e >> 2) + 4 * h + (e & 3);
+    x[e] = k < d ? src[k] : 0.f;   // (k >= p meets the zero padding of X)
+  }
+  fb_store_frag(ZP + (size_t)f * kFrag + 4 * lane, x);
+}
+__global__ __launch_bounds__(512, 6) void k_lr_logits_planes(LrMfmaArgs a) {
+  constexpr int NR = 3, kPW = 2;
+  __shared__ __attribute__((aligned(16))) unsigned lds[NR * kStageW];
+  __shared__ float ll_lds[128];
+  __shared__ float y_lds[128];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3;
+  const long long tile = blockIdx.x, row0 = tile * 128;
+  const int ng = a.ldx >> 4, G = ng;
+  const int mb0 = blockIdx.y * 4;
+  // wave w stages fragment w of every stage: w < 4: X's 32-row block 4 tile + w; else the samples' block mb0 + w - 4
+  const unsigned *sp = (w < 4 ? a.XA + (size_t)(4 * tile + w) * ng * kFrag : a.ZP + (size_t)(mb0 + w - 4) * ng * kFrag) + 4 * lane;
+  auto issue = [&](int slot) {
+    unsigned *dst = lds + slot * kStageW + w * 512;
+    FB_GLDS16(sp, dst, 0);
+    FB_GLDS16(sp, dst, 1024);
+    sp += kFrag;
+  };
+  f32x16 acc[2][1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+  issue(0); issue(1);
+  if (tid < 128) {
+    ll_lds[tid] = 0.f;
+    const long long r = row0 + tid;
+    y_lds[tid] = r < a.n ? (float)a.y[r] : 0.f;
+  }
+  int slot = 0;
+  for (int g = 0; g < G; ++g) {
+    if (g + 1 < G) fb_wait_vm<kPW>();
+    else fb_wait_vm<0>();
+    fb_barrier();
+    if (g + 2 < G) issue(slot == 0 ? 2 : slot - 1);
+    FbFrags<1> F;
+    fb_read_frags<1>(lds, slot, wm, wn, lane, F);
+    fb_group<1>(F, acc);
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  float xs, xinv;
+  lr_xscale(a.xmax, xs, xinv);
+  const int m = 128 * blockIdx.y + 32 * wn + l31;
+  float ll = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int lr = 64 * wm + 32 * i + 8 * (r >> 2) + 4 * h + (r & 3);
+      const long long row = row0 + lr;
+      if (row < a.n) {
+        const float yv = y_lds[lr];
+        const float lg = acc[i][0][r] * xinv, e = __expf(-fabsf(lg)), inv = __frcp_rn(1.f + e);
+        ll += yv * lg - (fmaxf(lg, 0.f) + __logf(1.f + e));
+        if (a.want_grad) a.R[(size_t)row * a.ldr + m] = yv - (lg >= 0.f ? inv : e * inv);
+      }
+    }
+  ll += __shfl_xor(ll, 32, 64);
+  if (h == 0) atomicAdd(&ll_lds[32 * wn + l31], ll);
+  __syncthreads();
+  if (tid < 128) a.ll_part[(size_t)tile * a.M + 128 * blockIdx.y + tid] = (double)ll_lds[tid];
+}
+
 // the full-tile kernel is pinned to 128 VGPRs (4 waves per SIMD, two workgroups per CU); the partial-tile variant's extra
 // control flow does not fit that budget without scratch (228 B/lane, 3x slower), so it runs unconstrained
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lr_logits_f16x2(LrMfmaArgs a) {
@@ -959,6 +1066,17 @@ bool logreg_prepare_f32(mivi_ctx *c) {
   dim3 grid((unsigned)((c->lr_n + 63) / 64), (ldx + 63) / 64);
   hipLaunchKernelGGL(k_lr_make_xrm, grid, dim3(256), 0, c->stream, (long long)c->lr_n, p, ldx, (const float *)c->lr_X,
                      (float *)c->lr_Xrm.p, (unsigned *)c->lr_xmax.p);
+  // X as A-operand planes for k_lr_logits_planes (as many bytes again as X; problems large enough for the matrix-core route only)
+  if ((double)c->lr_n * p >= 1.0e5) {
+    const long long nrb32 = (c->lr_n + 127) / 128 * 4;
+    const size_t nfr = (size_t)nrb32 * (ldx / 16);
+    if (!grow(c->lr_XA, nfr * kFrag * 4)) return false;
+    hipLaunchKernelGGL(k_lr_xplanes, dim3((unsigned)((nfr + 3) / 4)), dim3(256), 0, c->stream, (long long)c->lr_n, nrb32, ldx, (const float *)c->lr_Xrm.p,
+                       (const unsigned *)c->lr_xmax.p, (unsigned *)c->lr_XA.p);
+  } else if (c->lr_XA.p) {
+    (void)hipFree(c->lr_XA.p);
+    c->lr_XA = DevBuf{};
+  }
   return true;
 }
 
@@ -998,7 +1116,7 @@ void launch_logreg_gather(mivi_ctx *c, int64_t b) {
 // Scratch geometry of the two routes.  logreg_reserve() sizes the buffers ahead of time (and is what makes the target
 // graph-capturable: no allocation at launch); the launchers call it again as a no-op / safety net.
 struct LrGeom {
-  bool mfma;
+  bool mfma, planes;   // planes: k_lr_logits_planes (128-row tiles on the prebuilt planes of X)
   int nrb, S, ldr;
   long long rps;
   size_t need_R, need_g, need_ll;
@@ -1006,6 +1124,7 @@ struct LrGeom {
 static LrGeom lr_geom(const mivi_ctx *c, int M) {
   static const bool force_generic = getenv("MIVI_LOGREG_GENERIC") != nullptr;
   LrGeom g;
+  g.planes = false;
   const long long n = c->lr_n;
   const int p = c->cfg.d - 1;
   // small problems take the VALU route: the matrix-core kernels carry fixed 256-row x 128-sample tiles and three more
@@ -1015,7 +1134,9 @@ static LrGeom lr_geom(const mivi_ctx *c, int M) {
            (force_mfma || c->lr_route == 1 || (double)n * (double)p * (double)M >= 1.6e7);
   if (g.mfma) {
     g.ldr = (M + 63) / 64 * 64;
-    g.nrb = (int)((n + 255) / 256);
+    static const bool no_planes = getenv("MIVI_LR_NO_PLANES") != nullptr;   // A/B: the logits kernel that splits X in the tile (k_lr_logits_f16x2)
+    g.planes = M % 128 == 0 && c->lr_XA.p && c->lr_Xrm_act == c->lr_Xrm.p && !no_planes && !getenv("MIVI_LR_F32_LOGITS");
+    g.nrb = g.planes ? (int)((n + 127) / 128) : (int)((n + 255) / 256);
     // row splits of X^T R: 128 x 2 feature groups = one workgroup per CU at C3 (n = 1e6, p = 511); small data sets still
     // get a split per 128 rows (one workgroup walking n = 20 000 rows alone is a 270 us chain of 16-row stages)
     int S = (int)((n + 127) / 128);
@@ -1049,6 +1170,7 @@ static LrGeom lr_geom(const mivi_ctx *c, int M) {
 bool logreg_uses_mfma(const mivi_ctx *c, int M) { return c->target == TGT_LOGREG && lr_geom(c, M).mfma; }
 bool logreg_reserve(mivi_ctx *c, int M) {
   const LrGeom g = lr_geom(c, M);
+  if (g.planes && !grow(c->lr_ZP, (size_t)(M / 32) * (((c->cfg.d - 1 + 31) / 32 * 32) / 16) * kFrag * 4)) return false;
   return grow(c->lr_scratch, g.need_R + g.need_g) && grow(c->lr_part, g.need_ll);
 }
 
@@ -1079,7 +1201,14 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
   a.Zcm = (const float *)c->Z.p;
   a.xmax = (const unsigned *)c->lr_xmax.p;
   const bool part = M % 128 != 0 && M % 128 <= 96;   // whole 32-sample tiles of the last 128-sample group are empty
-  if (a.d % 4 == 0 && a.d >= 4 && !no_split) {
+  if (geo.planes) {
+    const int ng = a.ldx / 16, nfz = (M / 32) * ng;
+    if (!grow(c->lr_ZP, (size_t)nfz * kFrag * 4)) return false;
+    a.XA = (const unsigned *)c->lr_XA.p;
+    a.ZP = (unsigned *)c->lr_ZP.p;
+    hipLaunchKernelGGL(k_lr_zplanes, dim3((nfz + 3) / 4), dim3(256), 0, c->stream, M, a.d, a.ldx, a.Zcm, a.ZP);
+    hipLaunchKernelGGL(k_lr_logits_planes, dim3(nrb, M / 128), dim3(512), 0, c->stream, a);
+  } else if (a.d % 4 == 0 && a.d >= 4 && !no_split) {
     if (part) hipLaunchKernelGGL(k_lr_logits_f16x2_part, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
     else hipLaunchKernelGGL(k_lr_logits_f16x2, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
   } else {
