@@ -350,6 +350,10 @@ struct LrMfmaArgs {
   const unsigned *xmax;   // bits of max |X| (k_lr_make_xrm): the power-of-two scale of X's f16 splits
   const unsigned *XA;     // X as A-operand planes (k_lr_xplanes): fragment (rb32, kg) at (rb32 (ldx / 16) + kg) kFrag
   unsigned *ZP;           // the samples as B-operand planes (k_lr_zplanes): fragment (mb32, kg)
+  const unsigned *XB;     // X as B-operand planes of X^T R (k_lr_xbplanes): fragment (fb32, rg = 16-row group) at (fb32 nrg + rg) kFrag
+  unsigned *RP;           // the residuals as A-operand planes (2^13 r): fragment (mb32, rg) at (mb32 nrg + rg) kFrag; nullptr: R in f32
+  long long nrg;          // 16-row groups (rows padded to whole 128-row tiles)
+  int gps;                // row groups per split of k_lr_xtr_planes
   float *R;            // R[m + r*ldr]
   int ldr;
   double *ll_part;     // [gridDim.x][M]
@@ -828,22 +832,108 @@ __global__ __launch_bounds__(512, 6) void k_lr_logits_planes(LrMfmaArgs a) {
   const int m = 128 * blockIdx.y + 32 * wn + l31;
   float ll = 0.f;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
+    float res[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int lr = 64 * wm + 32 * i + 8 * (r >> 2) + 4 * h + (r & 3);
       const long long row = row0 + lr;
+      res[r] = 0.f;
       if (row < a.n) {
         const float yv = y_lds[lr];
         const float lg = acc[i][0][r] * xinv, e = __expf(-fabsf(lg)), inv = __frcp_rn(1.f + e);
         ll += yv * lg - (fmaxf(lg, 0.f) + __logf(1.f + e));
-        if (a.want_grad) a.R[(size_t)row * a.ldr + m] = yv - (lg >= 0.f ? inv : e * inv);
+        res[r] = yv - (lg >= 0.f ? inv : e * inv);
+        if (a.want_grad && !a.RP) a.R[(size_t)row * a.ldr + m] = res[r];
       }
     }
+    if (a.want_grad && a.RP) {
+      // the residuals as the A operand of X^T R (rows = samples, k = data rows): fragment (sample block, 16-row group g2 of this 32-row
+      // block) = this lane's own registers 4 (2 g2 + e / 4) + e % 4 -- no transposition; 2^13 r (|r| < 1), rows beyond n are zeros
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2) {
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = res[4 * (2 * g2 + (e >> 2)) + (e & 3)] * 8192.f;
+        const long long rg = (row0 + 64 * wm + 32 * i) / 16 + g2;
+        fb_store_frag(a.RP + ((size_t)(4 * blockIdx.y + wn) * a.nrg + rg) * kFrag + 4 * lane, x);
+      }
+    }
+  }
   ll += __shfl_xor(ll, 32, 64);
   if (h == 0) atomicAdd(&ll_lds[32 * wn + l31], ll);
   __syncthreads();
   if (tid < 128) a.ll_part[(size_t)tile * a.M + 128 * blockIdx.y + tid] = (double)ll_lds[tid];
+}
+
+// X^T R on operand planes: G[m, k] = sum_r R[r, m] X[r, k].  A = the residuals' planes (rows = samples; left by k_lr_logits_planes straight from
+// its accumulators), B = X's planes in the second orientation (rows = features, k = data rows; k_lr_xbplanes, once per data set); the same
+// three-slot LDS-DMA ring; the data rows are split over gridDim.y workgroups per (128 samples x 128 features) tile, partial sums to
+// g_part[split][m][k] (k_lr_greduce adds them in a fixed order).  blockIdx.x = feature group: the groups of one row range run side by side
+// and share its residual planes in the memory-side cache.
+__global__ __launch_bounds__(256) void k_lr_xbplanes(long long n, long long nrg, int ldx, const float *Xrm, const unsigned *xmax, unsigned *XB) {
+  const long long f = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+  const long long fb = f / nrg, rg = f % nrg;
+  if (fb >= (ldx >> 5)) return;
+  float s, inv;
+  lr_xscale(xmax, s, inv);
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const long long row = 16 * rg + 8 * (e >> 2) + 4 * h + (e & 3);
+    x[e] = row < n ? Xrm[(size_t)row * ldx + 32 * fb + l31] * s : 0.f;
+  }
+  fb_store_frag(XB + (size_t)f * kFrag + 4 * lane, x);
+}
+__global__ __launch_bounds__(512, 6) void k_lr_xtr_planes(LrMfmaArgs a) {
+  constexpr int NR = 3, kPW = 2;
+  __shared__ __attribute__((aligned(16))) unsigned lds[NR * kStageW];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = w >> 2, wn = w & 3;
+  const int fg = blockIdx.x, sp_i = blockIdx.y, mg = blockIdx.z;
+  const long long gbeg = (long long)sp_i * a.gps;
+  const long long gend = gbeg + a.gps < a.nrg ? gbeg + a.gps : a.nrg;
+  const int G = (int)(gend - gbeg);
+  const unsigned *sp = (w < 4 ? a.RP + ((size_t)(4 * mg + w) * a.nrg + gbeg) * kFrag : a.XB + ((size_t)(4 * fg + w - 4) * a.nrg + gbeg) * kFrag) + 4 * lane;
+  auto issue = [&](int slot) {
+    unsigned *dst = lds + slot * kStageW + w * 512;
+    FB_GLDS16(sp, dst, 0);
+    FB_GLDS16(sp, dst, 1024);
+    sp += kFrag;
+  };
+  f32x16 acc[2][1];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+  issue(0);
+  if (G > 1) issue(1);
+  int slot = 0;
+  for (int g = 0; g < G; ++g) {
+    if (g + 1 < G) fb_wait_vm<kPW>();
+    else fb_wait_vm<0>();
+    fb_barrier();
+    if (g + 2 < G) issue(slot == 0 ? 2 : slot - 1);
+    FbFrags<1> F;
+    fb_read_frags<1>(lds, slot, wm, wn, lane, F);
+    fb_group<1>(F, acc);
+    slot = slot == 2 ? 0 : slot + 1;
+  }
+  float xs, xinv;
+  lr_xscale(a.xmax, xs, xinv);
+  const float f = xinv * (1.f / 8192.f);
+  const int k = 128 * fg + 32 * wn + l31;
+  if (k < a.p) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 128 * mg + 64 * wm + 32 * i + 8 * (r >> 2) + 4 * h + (r & 3);
+        a.g_part[((size_t)sp_i * a.M + m) * a.p + k] = acc[i][0][r] * f;
+      }
+  }
 }
 
 // the full-tile kernel is pinned to 128 VGPRs (4 waves per SIMD, two workgroups per CU); the partial-tile variant's extra
@@ -1073,9 +1163,16 @@ bool logreg_prepare_f32(mivi_ctx *c) {
     if (!grow(c->lr_XA, nfr * kFrag * 4)) return false;
     hipLaunchKernelGGL(k_lr_xplanes, dim3((unsigned)((nfr + 3) / 4)), dim3(256), 0, c->stream, (long long)c->lr_n, nrb32, ldx, (const float *)c->lr_Xrm.p,
                        (const unsigned *)c->lr_xmax.p, (unsigned *)c->lr_XA.p);
-  } else if (c->lr_XA.p) {
-    (void)hipFree(c->lr_XA.p);
+    const long long nrg = nrb32 / 4 * 8;
+    const size_t nfb = (size_t)(ldx / 32) * nrg;
+    if (!grow(c->lr_XB, nfb * kFrag * 4)) return false;
+    hipLaunchKernelGGL(k_lr_xbplanes, dim3((unsigned)((nfb + 3) / 4)), dim3(256), 0, c->stream, (long long)c->lr_n, nrg, ldx, (const float *)c->lr_Xrm.p,
+                       (const unsigned *)c->lr_xmax.p, (unsigned *)c->lr_XB.p);
+  } else {
+    if (c->lr_XA.p) (void)hipFree(c->lr_XA.p);
+    if (c->lr_XB.p) (void)hipFree(c->lr_XB.p);
     c->lr_XA = DevBuf{};
+    c->lr_XB = DevBuf{};
   }
   return true;
 }
@@ -1116,7 +1213,9 @@ void launch_logreg_gather(mivi_ctx *c, int64_t b) {
 // Scratch geometry of the two routes.  logreg_reserve() sizes the buffers ahead of time (and is what makes the target
 // graph-capturable: no allocation at launch); the launchers call it again as a no-op / safety net.
 struct LrGeom {
-  bool mfma, planes;   // planes: k_lr_logits_planes (128-row tiles on the prebuilt planes of X)
+  bool mfma, planes, xplanes;   // planes: k_lr_logits_planes (128-row tiles on the prebuilt planes of X); xplanes: also k_lr_xtr_planes
+  long long nrg;
+  int gps;
   int nrb, S, ldr;
   long long rps;
   size_t need_R, need_g, need_ll;
@@ -1125,6 +1224,9 @@ static LrGeom lr_geom(const mivi_ctx *c, int M) {
   static const bool force_generic = getenv("MIVI_LOGREG_GENERIC") != nullptr;
   LrGeom g;
   g.planes = false;
+  g.xplanes = false;
+  g.nrg = 0;
+  g.gps = 0;
   const long long n = c->lr_n;
   const int p = c->cfg.d - 1;
   // small problems take the VALU route: the matrix-core kernels carry fixed 256-row x 128-sample tiles and three more
@@ -1147,6 +1249,18 @@ static LrGeom lr_geom(const mivi_ctx *c, int M) {
     g.S = (int)((n + rps - 1) / rps);
     g.rps = rps;
     g.need_R = ((size_t)((n + 15) / 16 * 16) * g.ldr * sizeof(float) + 255) / 256 * 256;   // + zero rows to a whole stage
+    static const bool no_xplanes = getenv("MIVI_LR_NO_XPLANES") != nullptr;   // A/B: X^T R with the splits made in the tile (k_lr_xtr_f16x2)
+    g.nrg = (n + 127) / 128 * 8;
+    g.xplanes = g.planes && c->lr_XB.p && !no_xplanes && !getenv("MIVI_LR_F32_XTR") && g.nrg >= 16;
+    if (g.xplanes) {
+      // row splits: three workgroups per CU over the feature groups (at C3: 4 feature groups x 192 splits = 768 workgroups), at least 8 row groups each
+      int S2 = (int)(768 / ((p + 127) / 128) / (M / 128));
+      if (S2 > g.nrg / 8) S2 = (int)(g.nrg / 8);
+      if (S2 < 1) S2 = 1;
+      g.gps = (int)((g.nrg + S2 - 1) / S2);
+      g.S = (int)((g.nrg + g.gps - 1) / g.gps);
+      g.need_R = (size_t)(M / 32) * g.nrg * kFrag * 4;
+    }
     g.need_g = (size_t)g.S * p * M * sizeof(float);
     g.need_ll = (size_t)g.nrb * M * sizeof(double);
   } else {
@@ -1206,6 +1320,10 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
     if (!grow(c->lr_ZP, (size_t)nfz * kFrag * 4)) return false;
     a.XA = (const unsigned *)c->lr_XA.p;
     a.ZP = (unsigned *)c->lr_ZP.p;
+    a.XB = (const unsigned *)c->lr_XB.p;
+    a.RP = geo.xplanes ? (unsigned *)c->lr_scratch.p : nullptr;   // (the residuals' planes take the place of the f32 R)
+    a.nrg = geo.nrg;
+    a.gps = geo.gps;
     hipLaunchKernelGGL(k_lr_zplanes, dim3((nfz + 3) / 4), dim3(256), 0, c->stream, M, a.d, a.ldx, a.Zcm, a.ZP);
     hipLaunchKernelGGL(k_lr_logits_planes, dim3(nrb, M / 128), dim3(512), 0, c->stream, a);
   } else if (a.d % 4 == 0 && a.d >= 4 && !no_split) {
@@ -1215,7 +1333,7 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
     if (part) hipLaunchKernelGGL(k_lr_logits_mfma_lds<true>, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
     else hipLaunchKernelGGL(k_lr_logits_mfma_lds<false>, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
   }
-  if (want_grad && a.n % 16 != 0) {
+  if (want_grad && a.n % 16 != 0 && !geo.xplanes) {
     // the zero residual rows k_lr_xtr_f16x2's last stage reads (the logits kernels stop at n).  Nobody writes them, so
     // they are zeroed once per geometry -- and every time while the stream is being captured (a graph must carry its own)
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -1226,7 +1344,9 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
       if (!cap) { c->lr_pad_R = a.R; c->lr_pad_n = (long long)a.n; c->lr_pad_ldr = a.ldr; }
     }
   }
-  if (want_grad) {
+  if (want_grad && geo.xplanes) {
+    hipLaunchKernelGGL(k_lr_xtr_planes, dim3((a.p + 127) / 128, S, M / 128), dim3(512), 0, c->stream, a);
+  } else if (want_grad) {
     const dim3 gx(S, (a.p + 255) / 256, (M + 127) / 128);
     static const bool xtr_f32 = getenv("MIVI_LR_F32_XTR") != nullptr;   // A/B: f32 MFMA X^T R
     if (!xtr_f32) {

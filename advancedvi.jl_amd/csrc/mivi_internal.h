@@ -296,7 +296,7 @@ struct mivi_ctx {
   // logreg
   const void *lr_X = nullptr;
   const uint8_t *lr_y = nullptr;
-  mivi::DevBuf lr_X_own, lr_y_own, lr_scratch, lr_part, lr_Xrm, lr_xmax, lr_XA, lr_ZP;   // (lr_xmax: bits of max |X|, the scale of X's f16 splits)
+  mivi::DevBuf lr_X_own, lr_y_own, lr_scratch, lr_part, lr_Xrm, lr_xmax, lr_XA, lr_XB, lr_ZP;   // (lr_xmax: bits of max |X|, the scale of X's f16 splits)
   // minibatch view (AdvancedVI.subsample, docs/src/tutorials/subsampling.md:99-102): the full data set stays resident,
   // mivi_logreg_select_rows gathers the batch rows into lr_Xsub / lr_ysub / lr_Xrm_sub and points the active fields at them
   const void *lr_X_full = nullptr;
