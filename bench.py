@@ -319,13 +319,13 @@ def other_roofline(cx, p, w, t_est):
         n, pdim, M2 = w["n"], w["d"] - 1, w["n_mc"]
         fl = 4.0 * n * pdim * M2                      # logits X beta and X^T R, 2 flops per MAC
         by = 2.0 * n * pdim * 4 + 2.0 * n * M2 * 4     # X read once per contraction, R written + read
-        tl, tx = pmc_traffic("k_lr_logits_f16x2"), pmc_traffic("k_lr_xtr_f16x2")
-        # the two data contractions stream X once each (SURVEY 8d prices ONE fused pass: 2.05 GB); with three 16-bit products per block the
+        tl, tx = pmc_traffic("k_lr_logits_planes"), pmc_traffic("k_lr_xtr_planes")
+        # the two data contractions stream X's operand planes once each (SURVEY 8d prices ONE fused pass: 2.05 GB); with three 16-bit products per block the
         # binding roof is the memory side: `achieved` = SURVEY 8d's algorithmic bytes / whole-estimate time against 8 TB/s, the flop fractions beside
         alg = float(n) * (pdim + 1) * 4 + float(n)                      # X (padded to D columns) once + y
-        return dict(bound="hbm", kernel="k_lr_logits_f16x2 + k_lr_xtr_f16x2", achieved=alg / t_est / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
+        return dict(bound="hbm", kernel="k_lr_logits_planes + k_lr_xtr_planes", achieved=alg / t_est / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
                     frac=alg / t_est / 1e9 / PEAK_HBM_GBS, algorithmic_bytes_per_launch=alg,
-                    basis="achieved = SURVEY 8d algorithmic bytes (one pass over X, 2.05 GB) / whole-estimate time; peak = HBM 8 TB/s; the kernels read X twice (one pass per contraction) + R once each way",
+                    basis="achieved = SURVEY 8d algorithmic bytes (one pass over X, 2.05 GB) / whole-estimate time; peak = HBM 8 TB/s; the kernels read X's f16x2 planes twice (one orientation per contraction, built once per data set) + the residual planes once each way",
                     f32_mfma=dict(achieved_TFLOPs=fl / t_est / 1e12, peak=PEAK_F32_MFMA_TF, frac=fl / t_est / 1e12 / PEAK_F32_MFMA_TF),
                     pipe16=dict(products_per_block=3, executed_TFLOPs=3 * fl / t_est / 1e12, peak=PEAK_BF16_MFMA_TF, frac=3 * fl / t_est / 1e12 / PEAK_BF16_MFMA_TF),
                     hbm_executed=dict(achieved_GBs=by / t_est / 1e9, peak=PEAK_HBM_GBS, frac=by / t_est / 1e9 / PEAK_HBM_GBS, bytes_per_estimate=by),

@@ -158,6 +158,28 @@ for rep in range(2):
 print('ok')
 """
 
+LOGREG_BIG = """
+import numpy as np, advancedvi_jl_amd as avi
+from oracle import oracle as O
+from tests.helpers import SEED, make_family
+d, M, n = 128, 128, 2048   # n (d - 1) >= 1e5: the planes of X exist (kernels_targets.hip, logreg_prepare_f32)
+rng = np.random.default_rng(77)
+q, q_o = make_family(rng, d, avi.FULLRANK, np.float32)
+X = (rng.normal(size=(n, d - 1)) / np.sqrt(d)).astype(np.float32)
+y = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+prob, tgt = avi.LogRegProblem(X, y, "logsigma_normal", 1.7), O.LogRegTarget(X, y, "logsigma_normal", 1.7)
+params, _ = avi.destructure(q)
+ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+ctx.set_problem(prob)
+ctx.set_logreg_route(1)
+_, eps = ctx.sample(params, 3)
+v, g = ctx.estimate_gradient(params, 3)
+ref = O.estimate_gradient(O.destructure(q_o), d, avi.FULLRANK, tgt, eps.cpu().numpy().astype(np.float64), 0)
+assert abs(float(v.item()) - ref['value']) <= 1e-5 * max(abs(ref['value']), 1.0), (float(v.item()), ref['value'])
+assert np.linalg.norm(g.cpu().numpy() - ref['grad']) <= 2e-5 * max(np.linalg.norm(ref['grad']), 1.0)
+print('ok')
+"""
+
 F, MF = 1, 0
 CASES = [
     # switch, script, parameters
@@ -174,6 +196,9 @@ CASES = [
     ("MIVI_NW_VJP=8", ESTIMATE, dict(fam=F, d=200, M=72, kind="diag", ent=0, dt="float32")),
     ("MIVI_LR_F32_LOGITS=1", ESTIMATE, dict(fam=F, d=64, M=128, kind="logreg0", ent=0, dt="float32", pre="ctx.set_logreg_route(1)")),
     ("MIVI_LR_F32_XTR=1", ESTIMATE, dict(fam=F, d=64, M=128, kind="logreg0", ent=0, dt="float32", pre="ctx.set_logreg_route(1)")),
+    ("MIVI_LR_NO_PLANES=1", LOGREG_BIG, dict()),                                                          # logits with X split in the tile (k_lr_logits_f16x2) instead of the prebuilt planes
+    ("MIVI_LR_NO_XPLANES=1", LOGREG_BIG, dict()),                                                         # X^T R with the splits made in the tile (k_lr_xtr_f16x2); logits still on planes
+    ("MIVI_DUMMY_DEFAULT=1", LOGREG_BIG, dict()),                                                         # (no switch: both contractions on planes)
     ("MIVI_LOGREG_GENERIC=1", ESTIMATE, dict(fam=MF, d=64, M=128, kind="logreg0", ent=0, dt="float32")),
     ("MIVI_LOGREG_MFMA=1", ESTIMATE, dict(fam=MF, d=64, M=128, kind="logreg0", ent=0, dt="float32")),
     ("MIVI_NO_FUSED_LOOP=1", LOOP, dict(fam=MF, d=64, M=32)),                                             # graph loop instead of the launch-free kernel

@@ -41,7 +41,7 @@ def per_kernel(db, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 # which load flavour dominates a kernel's fetches
 PATTERN = (("k_fb_prod", "lds16"), ("k_fb_vjp", "lds16"), ("k_fr_prod32", "lds16"), ("k_fr_prod64", "lds16"), ("k_fr_vjp32", "lds16"), ("k_fr_vjp64", "lds16"), ("k_stl_solve", "lds16"),
-           ("k_stl_update", "lds16"), ("k_lr_", "ld16"), ("k_p2p_exchange", "ld16"))
+           ("k_stl_update", "lds16"), ("k_lr_logits_planes", "lds16"), ("k_lr_xtr_planes", "lds16"), ("k_lr_", "ld16"), ("k_p2p_exchange", "ld16"))
 # algorithmic KiB per launch at the north star (d = 1024, n_mc = 256, f32): in + out
 d, M = 1024, 256
 _prod = (d * (d + 1) // 2 * 4 + d * M * 4 + d * M * 4 + d * M * 4) / 1024.0   # tril(C) + eps in, W + eps(t+1) out
