@@ -968,10 +968,30 @@ const FbTab *fb_prepare(mivi_ctx *c, int M, int L) {
   }
   // the dense target's second product: every tile walks the whole K range (equal tiles); workgroup b runs on XCD b % 8 -- consecutive
   // workgroups take different row panels of P, so that with eight (or a multiple of eight) row panels an XCD's L2 keeps ONE of them
+  // Round 5 (FETCH_SIZE: 9.4 MB per lane against 2 MB of R + W): with one row panel per XCD a lane's R panel (0.5 MB of planes) is fetched by
+  // all eight XCDs.  While two row panels of P fit an L2 beside the streams (<= 1 MiB of planes: d <= 1024), an XCD keeps a PAIR of row
+  // panels and takes every second column panel: R is fetched by four XCDs instead of eight, P still once per XCD
+  // (ns_dense, 50 lanes: 202 k -> 210 k estimates/s; one, two or four row groups measured the same).
   std::vector<int4> prod2;
-  for (int l = 0; l < L; ++l)
-    for (int cb = 0; cb < ncb; ++cb)
-      for (int rb = 0; rb < nrb; ++rb) prod2.push_back(make_int4(l, rb | (cb << 16), 0, 0));
+  const size_t panel_bytes = (size_t)kBM * d * 4;
+  constexpr int NG = 4, NC = 8 / NG;
+  if (nrb % NG == 0 && (size_t)(nrb / NG) * panel_bytes <= (1u << 20)) {
+    std::vector<std::vector<int4>> lp(8);
+    int pn = 0;
+    for (int l = 0; l < L; ++l)
+      for (int cb = 0; cb < ncb; ++cb, ++pn)
+        for (int rg = 0; rg < NG; ++rg)
+          for (int r = 0; r < nrb / NG; ++r) lp[rg + NG * (pn % NC)].push_back(make_int4(l, (rg * (nrb / NG) + r) | (cb << 16), 0, 0));
+    size_t m3 = 0;
+    for (auto &li : lp) m3 = std::max(m3, li.size());
+    for (size_t i = 0; i < m3; ++i)
+      for (int x = 0; x < 8; ++x)
+        if (i < lp[x].size()) prod2.push_back(lp[x][i]);
+  } else {
+    for (int l = 0; l < L; ++l)
+      for (int cb = 0; cb < ncb; ++cb)
+        for (int rb = 0; rb < nrb; ++rb) prod2.push_back(make_int4(l, rb | (cb << 16), 0, 0));
+  }
   // the sticking-the-landing product: the draw's product's tiles, the first row blocks (the longest K ranges there) first
   std::vector<int4> prod3;
   for (auto &li : lists) std::stable_sort(li.begin(), li.end(), [](const int4 &p, const int4 &q) { return (p.y & 0xffff) < (q.y & 0xffff); });
