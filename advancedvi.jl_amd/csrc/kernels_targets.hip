@@ -287,7 +287,13 @@ __global__ __launch_bounds__(256) void k_lr_finish(LrArgs<T> a) {
   const double sv = (double)z[p];
   const double sigma = exp(sv), inv_s2 = exp(-2.0 * sv);
   double ll = 0.0;
-  for (int b = tid; b < a.nrb; b += 256) ll += a.ll_part[(size_t)b * a.M + m];
+  for (int b = tid; b < a.nrb; b += 8 * 256) {   // eight loads in flight (a thread's entries are M doubles apart: one line each), same summation order
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = b + 256 * u < a.nrb ? a.ll_part[(size_t)(b + 256 * u) * a.M + m] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ll += v[u];
+  }
   ll = block_sum<double, 256>(ll, red);
   double bb = 0.0;
   for (int k = tid; k < p; k += 256) {
