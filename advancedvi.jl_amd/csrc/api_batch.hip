@@ -67,9 +67,8 @@ static mivi_status_t estimate_gradient_chain(mivi_ctx *c, const void *params, ui
     if ((s = ensure(c, c->X, nd * sizeof(double) + sc_bytes + lane_al + e0_bytes + 64, false))) return s;
     double *hist = (double *)c->X.p, *elbo = hist + (size_t)count * 6 * d4;
     void *scratch = (void *)(elbo + count + 8);
-    static const bool no_e0 = getenv("MIVI_FUNNEL_NO_E0TAB") != nullptr;   // (A/B: every thread re-derives eps[0, m])
     launch_mf_funnel_loop(c, params, idx0, count, hist, elbo, scratch, value, grad, (void *)((char *)scratch + sc_bytes),
-                          no_e0 ? nullptr : (void *)((char *)scratch + sc_bytes + lane_al));
+                          (void *)((char *)scratch + sc_bytes + lane_al));
     HIPCHK(c, hipGetLastError());
     return MIVI_OK;
   }

@@ -1329,10 +1329,7 @@ void launch_fr_sample(mivi_ctx *c, const void *params, int M, int fused_target, 
     } else {
       a.n_work = 0x7fffffff;   // no value workgroup
     }
-    static const int nw_s = getenv("MIVI_NW_SAMPLE") ? atoi(getenv("MIVI_NW_SAMPLE")) : 8;
-    if (c->cfg.d % 32 == 0 && M % 32 == 0 && nw_s == 16)
-      hipLaunchKernelGGL((k_fr_tile_mfma<MODE_SAMPLE, 16, true>), dim3(grid), dim3(1024), 0, c->stream, a);
-    else if (c->cfg.d % 32 == 0 && M % 32 == 0)
+    if (c->cfg.d % 32 == 0 && M % 32 == 0)   // (eight waves per tile; sixteen measured slower in round 2: the switch and its instantiation are gone)
       hipLaunchKernelGGL((k_fr_tile_mfma<MODE_SAMPLE, 8, true>), dim3(grid), dim3(512), 0, c->stream, a);
     else
       hipLaunchKernelGGL((k_fr_tile_mfma<MODE_SAMPLE, 8, false>), dim3(grid), dim3(512), 0, c->stream, a);
@@ -1401,12 +1398,7 @@ void launch_fr_vjp(mivi_ctx *c, const void *params, int M, const OutArgs &out, c
       a.next_eps = eps_args<float>(c, next->rng, M, next->parity);
       grid += a.n_pre;
     }
-    static const int nw_v = getenv("MIVI_NW_VJP") ? atoi(getenv("MIVI_NW_VJP")) : 4;
-    if (c->cfg.d % 32 == 0 && M % 32 == 0 && nw_v == 8 && !next && !self && !upd)
-      hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 8, true>), dim3(grid), dim3(512), 0, c->stream, a);
-    else if (c->cfg.d % 32 == 0 && M % 32 == 0 && nw_v == 2 && !next && !self && !upd)
-      hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 2, true>), dim3(grid), dim3(128), 0, c->stream, a);
-    else if (c->cfg.d % 32 == 0 && M % 32 == 0 && upd)
+    if (c->cfg.d % 32 == 0 && M % 32 == 0 && upd)   // (four waves per VJP tile: the two- and eight-wave variants and their switch are gone)
       hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 4, true, true>), dim3(grid), dim3(256), 0, c->stream, a);
     else if (upd)
       hipLaunchKernelGGL((k_fr_tile_mfma<MODE_VJP, 4, false, true>), dim3(grid), dim3(256), 0, c->stream, a);

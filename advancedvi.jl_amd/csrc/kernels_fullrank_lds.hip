@@ -1281,9 +1281,8 @@ void build_vjp(mivi_ctx *c, int d, int M, int tile, DevBuf &tab, int &n_items) {
 // lightest XCD; with fewer than eight super-blocks (d < 1024) the block rows {x, 15 - x, 16 + x, 31 - x} instead.
 void build_strips(mivi_ctx *c, int d, int NS, DevBuf &tab, int &n_items) {
   const int nrb = d / 32, nsr = (nrb + 7) / 8;
-  static const bool rows_env = getenv("MIVI_STRIP_ROWS") != nullptr;   // (A/B: the block-row assignment at every size)
   std::vector<std::vector<int4>> lists(8);
-  if (nsr * (nsr + 1) / 2 >= 8 && !rows_env) {
+  if (nsr * (nsr + 1) / 2 >= 8) {
     std::vector<std::vector<int4>> sbs;
     std::vector<int> tiles;
     for (int sr = 0; sr < nsr; ++sr)

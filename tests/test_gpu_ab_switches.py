@@ -192,8 +192,6 @@ CASES = [
     ("MIVI_STL_VALU=1", ESTIMATE, dict(fam=F, d=256, M=64, kind="diag", ent=3, dt="float32")),             # VALU back substitution
     ("MIVI_STL_VALU=1", ESTIMATE, dict(fam=F, d=128, M=32, kind="diag", ent=4, dt="float64")),
     ("MIVI_F64_VALU=1", ESTIMATE, dict(fam=F, d=160, M=48, kind="dense", ent=3, dt="float64")),            # f64 tiles on the vector ALU
-    ("MIVI_NW_SAMPLE=4", ESTIMATE, dict(fam=F, d=200, M=72, kind="diag", ent=0, dt="float32")),            # waves per first-generation tile
-    ("MIVI_NW_VJP=8", ESTIMATE, dict(fam=F, d=200, M=72, kind="diag", ent=0, dt="float32")),
     ("MIVI_LR_F32_LOGITS=1", ESTIMATE, dict(fam=F, d=64, M=128, kind="logreg0", ent=0, dt="float32", pre="ctx.set_logreg_route(1)")),
     ("MIVI_LR_F32_XTR=1", ESTIMATE, dict(fam=F, d=64, M=128, kind="logreg0", ent=0, dt="float32", pre="ctx.set_logreg_route(1)")),
     ("MIVI_LR_NO_PLANES=1", LOGREG_BIG, dict()),                                                          # logits with X split in the tile (k_lr_logits_f16x2) instead of the prebuilt planes
@@ -204,7 +202,6 @@ CASES = [
     ("MIVI_NO_FUSED_LOOP=1", LOOP, dict(fam=MF, d=64, M=32)),                                             # graph loop instead of the launch-free kernel
     ("MIVI_NO_FUSED_LOOP=1", LOOP, dict(fam=F, d=64, M=32)),                                              # ... instead of the row-separable full-rank loop (few samples per step)
     ("MIVI_NO_FUSED_LOOP=1", LOOP, dict(fam=F, d=256, M=8)),
-    ("MIVI_FUNNEL_NO_E0TAB=1", FUNNEL, dict()),                                                          # funnel loop: every thread re-derives eps[0, m] instead of reading the table
     ("MIVI_DUMMY_DEFAULT=1", FUNNEL, dict()),                                                             # (no switch: the table)
     ("MIVI_NO_FUSED_UPDATE=1", LOOP, dict(fam=F, d=128, M=128)),                                          # separate update kernel in the graph loop
     ("MIVI_GRAPH_MIN=1", LOOP, dict(fam=F, d=128, M=128)),                                                # graph replay even for the shortest batches
@@ -218,7 +215,6 @@ CASES = [
     ("MIVI_BATCH_GEN3=0,MIVI_PROD_QUAD=0", CHAINS_NS, dict(kind="diag")),                                                   # four lanes' products on k_fr_prod32's tiles (k_fr_prod32m)
     ("MIVI_BATCH_GEN3=0,MIVI_VJP_STRIP=0", CHAINS_NS, dict(kind="diag")),                                                   # one VJP tile per workgroup (k_fr_vjp32m)
     ("MIVI_BATCH_GEN3=0,MIVI_VJP_STRIP=5", CHAINS_NS, dict(kind="dense")),
-    ("MIVI_BATCH_GEN3=0,MIVI_STRIP_ROWS=1", CHAINS_NS, dict(kind="diag")),                                                  # strips dealt to the XCDs by block row                                                  # another strip length
     ("MIVI_BATCH_GEN3=0", CHAINS_NS, dict(kind="diag")),                                                  # the lane-batched second-generation kernels (k_fr_prod32q + k_fr_vjp32s) where the batch engine would run
     ("MIVI_FB_LANES=7", CHAINS, dict(kind="diag")),                                                       # batch engine: seven estimates per step (25 estimates: four steps, the last one shorter)
     ("MIVI_DUMMY_DEFAULT=1", CHAINS_NS, dict(kind="diag")),                                               # (no switch: the batch engine, one step)
