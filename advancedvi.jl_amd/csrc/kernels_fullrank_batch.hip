@@ -296,16 +296,23 @@ __device__ __forceinline__ float fb_lane_max(float v) {
 // -----------------------------------------------------------------------------------------------------------------
 enum { FB_DIAG = 0, FB_DENSE_R = 1, FB_DENSE_G = 2, FB_STL_U = 3 };
 template <int WJ, int MODE, int NRP>
-__global__ __launch_bounds__(512 / WJ, 2 / WJ) void k_fb_prod(FbArgs a) {
+__global__ __launch_bounds__(512 / WJ, (MODE == 2 && NRP == 4 && WJ == 1) ? 4 : 2 / WJ) void k_fb_prod(FbArgs a) {   // (the dense target's product at two workgroups per CU: 128 registers)
   constexpr bool kDG = MODE == FB_DENSE_G, kSU = MODE == FB_STL_U, kDR = MODE == FB_DENSE_R;
   constexpr int LDC = 36, NF = WJ, kPW = 2 * WJ;   // fragments / pieces this wave stages per group
   constexpr int NW = 8 / WJ, NWN = 4 / WJ;         // waves; waves along the columns
   constexpr int kBody = (NRP * kStageW > 16 * kImgW) ? NRP * kStageW : 16 * kImgW;   // the ring, later the waves' epilogue images
-  constexpr int kTab = kDG ? 2048 : 0;             // DENSE_G: R's inverse scales of the tile's 128 samples, every 128-row block (d <= 2048)
+  // DENSE_G: R's planes are scaled per (sample, 128-row block); the chain accumulator stays ONE accumulator, re-based at every block boundary
+  // by the exact power-of-two ratio of the neighbouring scales of its column (as k_fb_vjp does for W: no second accumulator set, 139 -> <= 128
+  // registers).  `tab` [d / 128][128]: the boundary ratios of the tile's 128 samples, the last row the closing factor.  With four ring slots
+  // it sits in the part of the body that only the epilogue images use (16 images = 72 KiB, the ring 64 KiB), so the kernel takes 78 KiB like
+  // the other modes and TWO workgroups share a CU; `rsv` [128]: R's inverse scales of the tile's OWN row block (the epilogue reads r back).
+  constexpr bool kTabInBody = kDG && NRP * kStageW + 2048 <= kBody;
+  constexpr int kTab = kDG ? (kTabInBody ? 128 : 2048 + 128) : 0;
   __shared__ __attribute__((aligned(16))) unsigned lds[kBody + 4 * 128 + NW * 64 + kTab];
   float *vec = reinterpret_cast<float *>(lds + kBody);          // [4][128]: mu, target mean, target 1 / std, the rows' output factor
   float *red = vec + 4 * 128;                                   // [NW][64]: the waves' maxima
-  float *tab = red + NW * 64;
+  float *rsv = red + NW * 64;
+  float *tab = kTabInBody ? reinterpret_cast<float *>(lds + NRP * kStageW) : rsv + 128;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w / NWN, wn = w % NWN;
@@ -343,8 +350,21 @@ __global__ __launch_bounds__(512 / WJ, 2 / WJ) void k_fb_prod(FbArgs a) {
       vec[384 + tid] = sc[d + row0 + tid] * ((kDG) ? 1.f : kEpsInv);   // what a row's raw sums are multiplied by
     }
     if constexpr (kDG) {
-      const float *ri = a.rinv + (size_t)ln * (size_t)(d >> 7) * a.M;
-      for (int i = tid; i < d; i += 512 / WJ) tab[i] = ri[(size_t)(i >> 7) * a.M + col0 + (i & 127)];
+      if (tid < 128) {
+        const float *ri = a.rinv + (size_t)ln * (size_t)(d >> 7) * a.M + col0 + tid;
+        const int NB = d >> 7;
+        float u = ri[0], grow = 1.f;   // u: the inverse of the unit the accumulator is in; grow: how far the re-basing has scaled it up
+        for (int b = 1; b < NB; ++b) {
+          float ratio = u / ri[(size_t)b * a.M];
+          if (!(ratio <= 1099511627776.f)) ratio = 1099511627776.f;          // 2^40 per boundary (also for a non-finite quotient) ...
+          if (ratio > 1.f && grow * ratio > 1.2089258e24f) ratio = fmaxf(1.2089258e24f / grow, 1.f);   // ... and 2^80 in all: the accumulator cannot overflow
+          if (ratio > 1.f) grow *= ratio;
+          tab[(b - 1) * 128 + tid] = ratio;
+          u = u / ratio;
+        }
+        tab[(NB - 1) * 128 + tid] = u;
+        rsv[tid] = ri[(size_t)rb * a.M];
+      }
     }
   };
   auto issue = [&](int slot) {
@@ -357,13 +377,13 @@ __global__ __launch_bounds__(512 / WJ, 2 / WJ) void k_fb_prod(FbArgs a) {
     }
     ++gd;
   };
-  f32x16 acc[2][WJ], tot[2][WJ];
+  f32x16 acc[2][WJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < WJ; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int r32[2] = {R0 + 2 * wm, R0 + 2 * wm + 1};
   // A wave computes groups 0 .. Gw - 1 (its second row block's K range: a multiple of four groups) with BOTH row blocks, unconditionally:
   // one straight MFMA block per group.  The first row block ends two groups earlier: its planes carry two zero fragments behind its
@@ -373,14 +393,14 @@ __global__ __launch_bounds__(512 / WJ, 2 / WJ) void k_fb_prod(FbArgs a) {
     if (!FB_KNOCKED(a, 2)) fb_group<WJ>(F, acc);
     fb_sched_interleave<WJ>();
     if constexpr (kDG && (decltype(S)::value & 3) == 3) {   // (behind the MFMAs: the block in front of them stays one basic block)
-      if (((g + 1) & 7) == 0) {                        // a 128-row block of R ended with this group: its inverse scales, per column
+      if (((g + 1) & 7) == 0) {                        // a 128-row block of R ended with this group: into the next block's unit (after the last: out of the scaled units)
 #pragma unroll
         for (int j = 0; j < WJ; ++j) {
           const float f = tab[((g >> 3) << 7) + 32 * (WJ * wn + j) + l31];
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { tot[i][j][r] = __builtin_fmaf(acc[i][j][r], f, tot[i][j][r]); acc[i][j][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
           }
         }
         asm volatile("" ::: "memory");
@@ -428,12 +448,7 @@ __global__ __launch_bounds__(512 / WJ, 2 / WJ) void k_fb_prod(FbArgs a) {
     });
     if (g + NRP - 1 < Gw) compute(std::integral_constant<int, NRP - 1>{}, g + NRP - 1, F1);
   }
-  if constexpr (!kDG) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < WJ; ++j) tot[i][j] = acc[i][j];
-  }
+  f32x16 (&tot)[2][WJ] = acc;
   fb_barrier();   // every wave is done with the ring: LDS becomes the waves' private epilogue images
   FB_STAMP(a, 2);
   float *img = reinterpret_cast<float *>(lds) + w * (2 * WJ * kImgW);   // image (i, j) at img + (i WJ + j) kImgW: [column][row], then W[m][i]
@@ -508,7 +523,7 @@ __global__ __launch_bounds__(512 / WJ, 2 / WJ) void k_fb_prod(FbArgs a) {
           // slots 4 (ei4 / 8 % 2) + c = the two words 2 (ei4 / 8 % 2) + {0, 1}; times the inverse scale of (sample en, this 128-row block)
           const unsigned *fr = RPl + ((size_t)cb32 * ng + 2 * r32[i] + (ei4 >> 4)) * kFrag + 4 * (en + 32 * ((ei4 >> 2) & 1)) + 2 * ((ei4 >> 3) & 1);
           const uint2 qh = *(const uint2 *)fr, ql = *(const uint2 *)(fr + 256);
-          const float rs = tab[(rb << 7) + 32 * (WJ * wn + j) + en];
+          const float rs = rsv[32 * (WJ * wn + j) + en];
           const unsigned uh[2] = {qh.x, qh.y}, ul[2] = {ql.x, ql.y};
 #pragma unroll
           for (int c = 0; c < 4; ++c) wv[c] = dense_target_elem(v[c], fb_unsplit2_word(uh[c >> 1], ul[c >> 1], c & 1) * rs, ell);
@@ -656,8 +671,8 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
   // W's planes are scaled per (row, 128-sample block).  The chain accumulator stays ONE accumulator: at a block boundary its rows are
   // multiplied by s_next / s_current (powers of two: exact), at the end by the last block's inverse scale.  wf[r][row], r < n_blocks - 1: the
   // boundary ratios, clamped to 2^40 (beyond that the next block's contribution is below 2^-40 of what the row already holds: entering it
-  // in a too small unit over-weights it by the clamped excess, still below 2^-40 of the row's largest block -- and the accumulator cannot
-  // overflow); wf[n_blocks - 1][row]: the closing factor.
+  // in a too small unit over-weights it by the clamped excess, still below 2^-40 of the row's largest block); the ratios above one are also
+  // capped at 2^80 in all, so the accumulator cannot overflow; wf[n_blocks - 1][row]: the closing factor.
   float *wf = reinterpret_cast<float *>(lds + kBody);
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -686,10 +701,12 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
   auto build_table = [&]() {   // (behind the prologue's DMA requests: its loads and divisions must not delay them)
   if (tid < 128) {
       const float *wi = a.winv + (size_t)ln * (size_t)NB * d + row0 + tid;
-      float u = wi[0];   // the inverse of the unit the accumulator is in
+      float u = wi[0], grow = 1.f;   // u: the inverse of the unit the accumulator is in; grow: how far the re-basing has scaled it up
       for (int r = 1; r < NB; ++r) {
         float ratio = u / wi[(size_t)r * d];
-        if (!(ratio <= 1099511627776.f)) ratio = 1099511627776.f;   // 2^40 (also for a non-finite quotient)
+        if (!(ratio <= 1099511627776.f)) ratio = 1099511627776.f;   // 2^40 per boundary (also for a non-finite quotient) ...
+        if (ratio > 1.f && grow * ratio > 1.2089258e24f) ratio = fmaxf(1.2089258e24f / grow, 1.f);   // ... and 2^80 over all boundaries (up to 15 of them at n_mc = 2048)
+        if (ratio > 1.f) grow *= ratio;
         wf[(r - 1) * 128 + tid] = ratio;
         u = u / ratio;
       }

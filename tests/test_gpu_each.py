@@ -132,6 +132,42 @@ def test_dense_gaussian_target_on_the_engine(d, M, n, ent):
     ref.close()
 
 
+@pytest.mark.parametrize("spread", [1.0e3, 1.0e-4, 1.0e9])
+def test_dense_target_with_row_blocks_of_very_different_magnitude(spread):
+    """R = Z - m is stored per (sample, 128-row block) with a power-of-two scale of its own, and k_fb_prod<FB_DENSE_G> keeps ONE chain
+    accumulator that is re-based at every block boundary by the ratio of the neighbouring scales (clamped: 2^40 per boundary, 2^80 in all).
+    Here the blocks of (z - m) differ by `spread` from one 128-row block to the next (the target mean and the family's location are far
+    apart in some blocks only): every estimate still equals the single call's and the fp64 oracle's."""
+    d, M, n = 512, 128, 5
+    rng = np.random.default_rng(11)
+    q, q_o = make_family(rng, d, avi.FULLRANK, np.float32)
+    prob, tgt = make_problem(rng, "dense", d, np.float32)
+    params, _ = avi.destructure(q)
+    params = params.copy()
+    # locations: block b of the family's mean sits spread^b away from the target's (capped: f32 range, and the gradient's norm stays finite)
+    for b in range(d // 128):
+        params[128 * b:128 * (b + 1)] += np.float32(min(spread ** b, 1.0e12) if spread > 1 else spread ** b) * np.float32(3.0)
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+    ref = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+    ctx.set_problem(prob)
+    ref.set_problem(prob)
+    p, pr = ctx.to_device(params), ref.to_device(params)
+    assert ctx.batch_takes_engine(p)
+    vals, grads = ctx.estimate_gradient_each(p, 5, n)
+    ctx.synchronize()
+    vals, grads = vals.cpu().numpy(), grads.cpu().numpy()
+    p64 = params.astype(np.float64)
+    for i in range(n):
+        v1, g1 = ref.estimate_gradient(pr, 5 + i)
+        assert_batch_matches_single(vals[i], v1.item(), grads[i], g1.cpu().numpy(), True, i)
+        _, eps = ref.sample(pr, 5 + i)
+        o = O.estimate_gradient(p64, d, avi.FULLRANK, tgt, eps.cpu().numpy().astype(np.float64), 0)
+        assert abs(float(vals[i]) - o["value"]) <= 1e-5 * abs(o["value"]), (i, float(vals[i]), o["value"])
+        assert np.linalg.norm(grads[i].astype(np.float64) - o["grad"]) <= 2e-5 * max(1.0, np.linalg.norm(o["grad"])), i
+    ctx.close()
+    ref.close()
+
+
 @pytest.mark.parametrize("d,M,kind,ent", [(1024, 256, "diag", 3), (512, 128, "dense", 4), (256, 256, "diag", 4), (2048, 128, "diag", 3)])
 def test_sticking_the_landing_estimators_on_the_engine(d, M, kind, ent):
     """StickingTheLandingEntropy / ...ZeroGradient (src/algorithms/entropy.jl:57-90): the extra term W += C^-T eps.  A single call solves
