@@ -76,6 +76,7 @@ SIGNATURES = {
     "mivi_debug_timeline": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "mivi_profile_kernel": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
     "mivi_fullrank_route": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "mivi_logreg_kernels": (C.c_int32, [C.c_void_p, C.c_int32]),
     "mivi_set_target_funnel_constrained": (C.c_int32, [C.c_void_p, C.c_double]),
     "mivi_slice_len": (C.c_int64, [C.c_void_p, C.c_int32]),
     "mivi_finalize_slice": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),

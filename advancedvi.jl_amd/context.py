@@ -428,6 +428,11 @@ class MiviContext:
         r = int(self.lib.mivi_fullrank_route(self.h, int(n_samples)))
         return r & 3, bool(r & 16)
 
+    def logreg_kernels(self, n_samples=0):
+        """dict(mfma, logits_planes, xtr_planes): which kernels the native logistic-regression target's contractions run (mivi_logreg_kernels)."""
+        r = int(self.lib.mivi_logreg_kernels(self.h, int(n_samples)))
+        return dict(mfma=bool(r & 1), logits_planes=bool(r & 2), xtr_planes=bool(r & 4))
+
     # -- next to the hot path ---------------------------------------------------------------------
     def clip_scale(self, params, epsilon):
         self._chk(self.lib.mivi_clip_scale(self.h, self._p(params), float(epsilon)))

@@ -436,6 +436,11 @@ int32_t mivi_fullrank_route(const mivi_ctx_t *c, int32_t n_samples) {
   return (lds_use_prod32(c, n_samples) ? 1 : 3) | (lds_bf16x3() ? 16 : 0);
 }
 
+int32_t mivi_logreg_kernels(const mivi_ctx_t *c, int32_t n_samples) {
+  if (!c) return 0;
+  return logreg_kernel_bits(c, n_samples > 0 ? n_samples : c->cfg.n_mc);
+}
+
 mivi_status_t mivi_set_logreg_route(mivi_ctx_t *c, int32_t route) {
   if (!c || route < 0 || route > 2) return MIVI_ERR_BAD_ARG;
   c->lr_route = route;

@@ -1297,6 +1297,11 @@ static LrGeom lr_geom(const mivi_ctx *c, int M) {
   return g;
 }
 bool logreg_uses_mfma(const mivi_ctx *c, int M) { return c->target == TGT_LOGREG && lr_geom(c, M).mfma; }
+int logreg_kernel_bits(const mivi_ctx *c, int M) {
+  if (c->target != TGT_LOGREG) return 0;
+  const LrGeom g = lr_geom(c, M);
+  return (g.mfma ? 1 : 0) | (g.planes ? 2 : 0) | (g.xplanes ? 4 : 0);
+}
 bool logreg_reserve(mivi_ctx *c, int M) {
   const LrGeom g = lr_geom(c, M);
   if (g.planes && !grow(c->lr_ZP, (size_t)(M / 32) * (((c->cfg.d - 1 + 31) / 32 * 32) / 16) * kFrag * 4)) return false;

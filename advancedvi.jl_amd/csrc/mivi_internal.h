@@ -503,6 +503,7 @@ void launch_col_target(mivi_ctx *c, int M, int want_grad);
 void launch_bij_forward(mivi_ctx *c, int M);                        // Z <- binv(Z) in place, bij_ld[m] = sum_exp eta
 void launch_bij_backward(mivi_ctx *c, int M, int want_grad, bool add_to_ell);   // G <- J' G + 1_exp; ell[m] += bij_ld[m]
 bool launch_logreg_target(mivi_ctx *c, int M, int want_grad);   // false: scratch allocation failed
+int logreg_kernel_bits(const mivi_ctx *c, int M);         // mivi_logreg_kernels
 bool logreg_uses_mfma(const mivi_ctx *c, int M);          // the matrix-core route (needs Z^T staged in RT)
 bool logreg_reserve(mivi_ctx *c, int M);                        // size the scratch ahead of a graph capture
 bool logreg_prepare_f32(mivi_ctx *c);   // row-major padded copy of X for the MFMA route (false: allocation failed)

@@ -227,3 +227,37 @@ def test_c5_launch_free_batch_equals_single_calls(d, M, ent, dtype):
     assert abs(float(v.item()) - ref["value"]) <= vt * max(1.0, abs(ref["value"]))
     assert np.linalg.norm(g.cpu().numpy() - ref["grad"]) <= gt * max(1.0, np.linalg.norm(ref["grad"]))
     ctx.close()
+
+
+@pytest.mark.parametrize("n,p,M,family,variant", [(1000, 127, 128, avi.FULLRANK, "logsigma_normal"), (3001, 200, 256, avi.FULLRANK, "lognormal_exp_bijector"),
+                                                   (777, 300, 128, avi.MEANFIELD, "logsigma_normal"), (4096, 40, 384, avi.FULLRANK, "logsigma_normal"),
+                                                   (130, 1000, 128, avi.MEANFIELD, "logsigma_normal")])
+def test_logreg_operand_planes_at_odd_shapes(n, p, M, family, variant):
+    """The operand-plane route of the two data contractions (k_lr_logits_planes / k_lr_xtr_planes: data sets of 10^5 elements and more, n_mc a
+    multiple of 128) at shapes the BASELINE configs do not visit: ragged last row tile, one / several feature groups with a partial last one,
+    two and three sample groups, few rows with many features -- value and gradient against the fp64 oracle on the device's own eps."""
+    rng = np.random.default_rng(n + p)
+    d = p + 1
+    X = (rng.normal(size=(n, p)) / np.sqrt(p)).astype(np.float32)
+    X[:, p - 1] = 1.0
+    y = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    mu = (0.1 * rng.normal(size=d)).astype(np.float32)
+    if family == avi.FULLRANK:
+        C = (0.5 * np.eye(d) + np.tril(rng.normal(size=(d, d)) * (0.05 / np.sqrt(d)), -1)).astype(np.float32)
+        q = avi.FullRankGaussian(mu, C)
+    else:
+        q = avi.MeanFieldGaussian(mu, rng.uniform(0.3, 0.7, size=d).astype(np.float32))
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, family, d, M, 0, SEED)
+    ctx.set_problem(avi.LogRegProblem(X, y, variant, 1.3))
+    ctx.set_logreg_route(1)   # the matrix-core family of kernels whatever the size heuristic says
+    assert ctx.logreg_kernels() == dict(mfma=True, logits_planes=True, xtr_planes=True)
+    _, eps = ctx.sample(params, 4)
+    v, g = ctx.estimate_gradient(params, 4)
+    ref = O.estimate_gradient(params.astype(np.float64), d, family, O.LogRegTarget(X, y, variant, 1.3), eps.cpu().numpy().astype(np.float64), 0)
+    assert abs(float(v.item()) - ref["value"]) <= 1e-5 * abs(ref["value"]), (float(v.item()), ref["value"])
+    assert rel_err(g.cpu().numpy(), ref["grad"]) < C3_GRAD_RTOL
+    # value only (no residual planes are written) agrees with the estimate's value
+    vo = ctx.estimate_objective(params, 4, n_samples=0, entropy=0)
+    assert abs(float(vo.item()) - float(v.item())) <= 2e-6 * abs(float(v.item()))
+    ctx.close()
