@@ -71,6 +71,7 @@ def test_c3_logreg_fullrank_oracle_parity_reduced_n():
     params, _ = avi.destructure(q)
     ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
     ctx.set_problem(avi.LogRegProblem(X, y, "logsigma_normal", 1.0))
+    assert ctx.logreg_kernels() == dict(mfma=True, logits_planes=True, xtr_planes=True)   # (what the size heuristic picks at C3's shape)
     _, eps = ctx.sample(params, 1)
     v, g = ctx.estimate_gradient(params, 1)
     ref = O.estimate_gradient(params.astype(np.float64), d, O.FULLRANK, O.LogRegTarget(X, y, "logsigma_normal", 1.0),
