@@ -116,6 +116,36 @@ __device__ __forceinline__ void fb_group(const FbFrags<WJ> &F, f32x16 (&acc)[2][
       for (int j = 0; j < WJ; ++j) acc[i][j] = fb_mma(F.A[i][PA[p]], F.B[j][PB[p]], acc[i][j]);
 }
 
+// One 16-k group of a 64 x 32 wave tile (WJ = 1) as ONE assembly block: the six MFMAs on the fragments Fc (already in registers) with
+// the six ds_read_b128 of the NEXT group's fragments Fn issued between them -- pinned.  Left to the compiler the reads end up BEHIND the
+// last MFMA (it lets Fn reuse Fc's registers), and the lgkmcnt(0) of the barrier that follows waits out the whole LDS latency with both
+// waves of the SIMD in step (the ~200 cycles of "barrier + wait" per group of round 5's knock-out runs).  Early-clobber outputs keep Fn in
+// registers of its own.  ab / bb: this lane's byte addresses of its first A / B fragment in ring slot 0; OFF: the slot's byte offset
+// (< 64 KiB: slots 4..7 go through a second pair of base registers).  The caller's fb_barrier() (lgkmcnt(0)) stands between this block's
+// reads and the MFMAs that consume them; MFMA chains alternate between the two accumulators (SrcC = vDst back to back needs no nops).
+template <int OFF>
+__device__ __forceinline__ void fb_group_read_asm(f32x16 &acc0, f32x16 &acc1, const FbFrags<1> &Fc, FbFrags<1> &Fn, unsigned ab, unsigned bb) {
+  static_assert(OFF >= 0 && OFF + 3072 < 65536, "ds_read_b128 offset field");
+  asm volatile(
+      "v_mfma_f32_32x32x16_f16 %[c0], %[a0l], %[bh], %[c0]\n\t"
+      "ds_read_b128 %[n0h], %[ab] offset:%[o0]\n\t"
+      "ds_read_b128 %[n0l], %[ab] offset:%[o1]\n\t"
+      "v_mfma_f32_32x32x16_f16 %[c1], %[a1l], %[bh], %[c1]\n\t"
+      "ds_read_b128 %[n1h], %[ab] offset:%[o2]\n\t"
+      "ds_read_b128 %[n1l], %[ab] offset:%[o3]\n\t"
+      "v_mfma_f32_32x32x16_f16 %[c0], %[a0h], %[bl], %[c0]\n\t"
+      "ds_read_b128 %[nbh], %[bb] offset:%[o0]\n\t"
+      "v_mfma_f32_32x32x16_f16 %[c1], %[a1h], %[bl], %[c1]\n\t"
+      "ds_read_b128 %[nbl], %[bb] offset:%[o1]\n\t"
+      "v_mfma_f32_32x32x16_f16 %[c0], %[a0h], %[bh], %[c0]\n\t"
+      "v_mfma_f32_32x32x16_f16 %[c1], %[a1h], %[bh], %[c1]"
+      : [c0] "+v"(acc0), [c1] "+v"(acc1), [n0h] "=&v"(Fn.A[0][0]), [n0l] "=&v"(Fn.A[0][1]), [n1h] "=&v"(Fn.A[1][0]), [n1l] "=&v"(Fn.A[1][1]),
+        [nbh] "=&v"(Fn.B[0][0]), [nbl] "=&v"(Fn.B[0][1])
+      : [a0h] "v"(Fc.A[0][0]), [a0l] "v"(Fc.A[0][1]), [a1h] "v"(Fc.A[1][0]), [a1l] "v"(Fc.A[1][1]), [bh] "v"(Fc.B[0][0]), [bl] "v"(Fc.B[0][1]),
+        [ab] "v"(ab), [bb] "v"(bb), [o0] "n"(OFF), [o1] "n"(OFF + 1024), [o2] "n"(OFF + 2048), [o3] "n"(OFF + 3072)
+      : "memory");
+}
+
 template <int WJ>
 __device__ __forceinline__ void fb_read_frags(const unsigned *lds, int slot, int wm, int wn, int lane, FbFrags<WJ> &F) {
   const unsigned *cur = lds + slot * kStageW + 4 * lane;

@@ -389,9 +389,7 @@ __global__ __launch_bounds__(512 / WJ, (MODE == 2 && NRP == 4 && WJ == 1) ? 4 : 
   // one straight MFMA block per group.  The first row block ends two groups earlier: its planes carry two zero fragments behind its
   // diagonal block, so its chain adds exact zeros there.
   const int Gw = (kDG || kSU) ? G : 2 * r32[1] + 2;
-  auto compute = [&](auto S, int g, const FbFrags<WJ> &F) {   // S = g mod kRing
-    if (!FB_KNOCKED(a, 2)) fb_group<WJ>(F, acc);
-    fb_sched_interleave<WJ>();
+  auto after_group = [&](auto S, int g) {   // S = g mod kRing
     if constexpr (kDG && (decltype(S)::value & 3) == 3) {   // (behind the MFMAs: the block in front of them stays one basic block)
       if (((g + 1) & 7) == 0) {                        // a 128-row block of R ended with this group: into the next block's unit (after the last: out of the scaled units)
 #pragma unroll
@@ -407,19 +405,48 @@ __global__ __launch_bounds__(512 / WJ, (MODE == 2 && NRP == 4 && WJ == 1) ? 4 : 
       }
     }
   };
+  auto compute = [&](auto S, int g, const FbFrags<WJ> &F) {
+    if (!FB_KNOCKED(a, 2)) fb_group<WJ>(F, acc);
+    fb_sched_interleave<WJ>();
+    after_group(S, g);
+  };
+  // (the assembly group body's LDS byte addresses: this lane's first A / B fragment in ring slot 0, and in slot 4)
+  const unsigned lds0 = (unsigned)(uintptr_t)lds + 16u * lane;
+  const unsigned ab_lo = lds0 + (2 * wm) * 2 * 1024, bb_lo = lds0 + (8 + WJ * wn * 2) * 1024;
+  const unsigned ab_hi = ab_lo + 4 * kStageW * 4, bb_hi = bb_lo + 4 * kStageW * 4;
+  (void)ab_hi; (void)bb_hi;
   // iteration g (S = g mod kRing): wait for the own pieces of stage g + 1, barrier, issue stage g + kRing into the slot of stage g, read the
   // fragments of stage g + 1, compute stage g.  VM = stages that may stay in flight across the wait; CMP: this wave still has work.
   auto step = [&](auto S, auto VM, auto ISS, int g, const FbFrags<WJ> &Fc, FbFrags<WJ> &Fn) {
     constexpr int sl = decltype(S)::value;
     fb_wait_vm<kPW * decltype(VM)::value>();
     if (!FB_KNOCKED(a, 8)) fb_barrier();
+#ifdef MIVI_SB
+    __builtin_amdgcn_sched_barrier(0);   // nothing of this group moves up in front of its barrier
+#endif
+    // the group's MFMAs with the next group's fragment reads between them: one pinned assembly block (fr_planes.h) for the shipped wave
+    // tile; the compiler's own schedule (reads behind the last MFMA) for WJ = 2 and the developer knock-outs
+    auto group_and_read = [&]() {
+#ifndef MIVI_DEV
+      if constexpr (WJ == 1) {
+        constexpr int nx = (sl + 1) % NRP, off = (nx & 3) * kStageW * 4;
+        fb_group_read_asm<off>(acc[0][0], acc[1][0], Fc, Fn, nx < 4 ? ab_lo : ab_hi, nx < 4 ? bb_lo : bb_hi);
+        if constexpr (kDG && (sl & 3) == 3) {
+          if (((g + 1) & 7) == 0) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA results -> vector ALU: the wait states the compiler would have counted
+        }
+        after_group(S, g);
+      } else
+#endif
+      {
+        if (!FB_KNOCKED(a, 4)) fb_read_frags<WJ>(lds, (sl + 1) % NRP, wm, wn, lane, Fn);
+        compute(S, g, Fc);
+      }
+    };
     if constexpr (decltype(ISS)::value) {
       if (!FB_KNOCKED(a, 1)) issue(sl);
-      if (!FB_KNOCKED(a, 4)) fb_read_frags<WJ>(lds, (sl + 1) % NRP, wm, wn, lane, Fn);
-      compute(S, g, Fc);
+      group_and_read();
     } else if (g < Gw) {   // (the tail: a wave-uniform branch)
-      fb_read_frags<WJ>(lds, (sl + 1) % NRP, wm, wn, lane, Fn);
-      compute(S, g, Fc);
+      group_and_read();
     }
   };
   FB_STAMP(a, 0);
@@ -446,6 +473,7 @@ __global__ __launch_bounds__(512 / WJ, (MODE == 2 && NRP == 4 && WJ == 1) ? 4 : 
       if constexpr (sv % 2 == 0) step(S, std::integral_constant<int, NRP - 2 - sv>{}, FbN{}, g + sv, F0, F1);
       else step(S, std::integral_constant<int, NRP - 2 - sv>{}, FbN{}, g + sv, F1, F0);
     });
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the last fragments were read inside an assembly block the compiler cannot see into
     if (g + NRP - 1 < Gw) compute(std::integral_constant<int, NRP - 1>{}, g + NRP - 1, F1);
   }
   f32x16 (&tot)[2][WJ] = acc;
@@ -746,9 +774,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
   float rcur[2] = {0.f, 0.f};
   // A wave with work computes ALL its sub-tiles in every group (one straight MFMA block: see k_fb_prod); a sub-tile strictly above the
   // diagonal (diagonal tiles only) is simply not stored.
-  auto compute = [&](auto S, int g, const FbFrags<WJ> &F) {
-    fb_group<WJ>(F, acc);
-    if constexpr (PF) fb_sched_interleave<WJ>();
+  auto after_group = [&](auto S, int g, const FbFrags<WJ> &F) {
     if (__builtin_expect(dg[0] || dg[1], 0)) {   // (two waves of a diagonal tile; behind the MFMAs: the block in front of them stays one basic block)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -777,14 +803,30 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
       }
     }
   };
+  auto compute = [&](auto S, int g, const FbFrags<WJ> &F) {
+    fb_group<WJ>(F, acc);
+    if constexpr (PF) fb_sched_interleave<WJ>();
+    after_group(S, g, F);
+  };
+  const unsigned lds0 = (unsigned)(uintptr_t)lds + 16u * lane;
+  const unsigned ab0 = lds0 + (2 * wm) * 2 * 1024, bb0 = lds0 + (8 + WJ * wn * 2) * 1024;
+  (void)ab0; (void)bb0;
   auto step = [&](auto S, auto VM, auto ISS, auto CMP, int g, const FbFrags<WJ> &Fc, FbFrags<WJ> &Fn) {   // (as in k_fb_prod)
     constexpr int sl = decltype(S)::value;
     fb_wait_vm<kPW * decltype(VM)::value>();
     fb_barrier();
     if constexpr (decltype(ISS)::value) issue(sl);
     if constexpr (decltype(CMP)::value) {
-      fb_read_frags<WJ>(lds, (sl + 1) % kRing, wm, wn, lane, Fn);
-      compute(S, g, Fc);
+      if constexpr (WJ == 1) {
+        fb_group_read_asm<((sl + 1) % kRing) * kStageW * 4>(acc[0][0], acc[1][0], Fc, Fn, ab0, bb0);
+        if constexpr (sl == 3) {
+          if (((g + 1) & 7) == 0) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA results -> vector ALU (the re-basing multiplies)
+        }
+        after_group(S, g, Fc);
+      } else {
+        fb_read_frags<WJ>(lds, (sl + 1) % kRing, wm, wn, lane, Fn);
+        compute(S, g, Fc);
+      }
     }
   };
   if constexpr (PF) {
@@ -806,6 +848,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
       step(FbI0{}, FbI2{}, FbN{}, FbT{}, g, F0, F1);
       step(FbI1{}, FbI1{}, FbN{}, FbT{}, g + 1, F1, F0);
       step(FbI2{}, FbI0{}, FbN{}, FbT{}, g + 2, F0, F1);
+      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the last fragments were read inside an assembly block
       compute(FbI3{}, g + 3, F1);
     } else {      // a wave above the diagonal: it only carries its share of the staging
       int g = 0;
