@@ -432,7 +432,8 @@ __global__ __launch_bounds__(512 / WJ, (MODE == 2 && NRP == 4 && WJ == 1) ? 4 : 
         constexpr int nx = (sl + 1) % NRP, off = (nx & 3) * kStageW * 4;
         fb_group_read_asm<off>(acc[0][0], acc[1][0], Fc, Fn, nx < 4 ? ab_lo : ab_hi, nx < 4 ? bb_lo : bb_hi);
         if constexpr (kDG && (sl & 3) == 3) {
-          if (((g + 1) & 7) == 0) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA results -> vector ALU: the wait states the compiler would have counted
+          // MFMA results -> vector ALU: the wait states the compiler would have counted (tied to the accumulators: nothing that reads them moves above)
+          if (((g + 1) & 7) == 0) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0][0]), "+v"(acc[1][0])::"memory");
         }
         after_group(S, g);
       } else
