@@ -809,25 +809,14 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
     if constexpr (PF) fb_sched_interleave<WJ>();
     after_group(S, g, F);
   };
-  const unsigned lds0 = (unsigned)(uintptr_t)lds + 16u * lane;
-  const unsigned ab0 = lds0 + (2 * wm) * 2 * 1024, bb0 = lds0 + (8 + WJ * wn * 2) * 1024;
-  (void)ab0; (void)bb0;
   auto step = [&](auto S, auto VM, auto ISS, auto CMP, int g, const FbFrags<WJ> &Fc, FbFrags<WJ> &Fn) {   // (as in k_fb_prod)
     constexpr int sl = decltype(S)::value;
     fb_wait_vm<kPW * decltype(VM)::value>();
     fb_barrier();
     if constexpr (decltype(ISS)::value) issue(sl);
-    if constexpr (decltype(CMP)::value) {
-      if constexpr (WJ == 1) {
-        fb_group_read_asm<((sl + 1) % kRing) * kStageW * 4>(acc[0][0], acc[1][0], Fc, Fn, ab0, bb0);
-        if constexpr (sl == 3) {
-          if (((g + 1) & 7) == 0) asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // MFMA results -> vector ALU (the re-basing multiplies)
-        }
-        after_group(S, g, Fc);
-      } else {
-        fb_read_frags<WJ>(lds, (sl + 1) % kRing, wm, wn, lane, Fn);
-        compute(S, g, Fc);
-      }
+    if constexpr (decltype(CMP)::value) {   // (k_fb_prod's pinned assembly group body in here: tools/experiments/r05_vjp_prefetch_asm_body.patch -- faster, not parity clean)
+      fb_read_frags<WJ>(lds, (sl + 1) % kRing, wm, wn, lane, Fn);
+      compute(S, g, Fc);
     }
   };
   if constexpr (PF) {
@@ -849,7 +838,6 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
       step(FbI0{}, FbI2{}, FbN{}, FbT{}, g, F0, F1);
       step(FbI1{}, FbI1{}, FbN{}, FbT{}, g + 1, F1, F0);
       step(FbI2{}, FbI0{}, FbN{}, FbT{}, g + 2, F0, F1);
-      __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the last fragments were read inside an assembly block
       compute(FbI3{}, g + 3, F1);
     } else {      // a wave above the diagonal: it only carries its share of the staging
       int g = 0;
