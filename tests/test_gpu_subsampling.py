@@ -105,6 +105,38 @@ def test_logreg_row_selection_matches_the_oracle(dtype):
     ctx.close()
 
 
+def test_row_selection_on_a_data_set_with_operand_planes():
+    """A data set large enough for the prebuilt operand planes of X (n p >= 1e5): a minibatch (gathered rows: no planes exist for it) and
+    the full set (planes) alternate on one context; each estimate matches the oracle on its own rows, and the kernels in use flip."""
+    rng = np.random.default_rng(18)
+    n, p, M = 2500, 63, 128
+    d = p + 1
+    X = (rng.normal(size=(n, p)) / np.sqrt(p)).astype(np.float32)
+    y = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    prob = avi.LogRegProblem(X, y)
+    tgt = O.LogRegTarget(X.astype(np.float64), y)
+    q, q_o = make_family(rng, d, avi.FULLRANK, np.float32, mu_scale=0.1)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+    ctx.set_logreg_route(1)
+    seen = []
+    for batch in (None, rng.permutation(n)[:1700], None, np.arange(0, n, 2), None):
+        if batch is None:
+            ctx.set_problem(prob)
+            t = tgt
+        else:
+            ctx.set_problem(avi.subsample(prob, batch))
+            t = tgt.subsample(batch)
+        seen.append(ctx.logreg_kernels()["logits_planes"])
+        _, eps = ctx.sample(params, 9)
+        ref = O.estimate_gradient(O.destructure(q_o), d, O.FULLRANK, t, eps.cpu().numpy().astype(np.float64), 0)
+        v, g = ctx.estimate_gradient(params, 9)
+        assert abs(float(v.item()) - ref["value"]) <= 2e-5 * abs(ref["value"])
+        assert np.linalg.norm(g.cpu().numpy() - ref["grad"]) <= 5e-5 * max(np.linalg.norm(ref["grad"]), 1.0)
+    assert seen == [True, False, True, False, True]
+    ctx.close()
+
+
 @pytest.mark.parametrize("batchsize", [1, 3, 4])
 def test_algorithms_run_with_subsampling_and_are_deterministic(batchsize):
     """test/general/subsampledobj.jl:12-52: constructors with `subsampling`, finite elbo, same-seed determinism,
