@@ -881,14 +881,15 @@ __global__ __launch_bounds__(256) void k_lr_xbplanes(long long n, long long nrg,
   const long long f = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   const long long fb = f / nrg, rg = f % nrg;
-  if (fb >= (ldx >> 5)) return;
+  const long long nfb32 = (long long)((ldx + 127) / 128) * 4;   // k_lr_xtr_planes stages whole 128-feature groups: the blocks past ldx / 32 are zeros
+  if (fb >= nfb32) return;
   float s, inv;
   lr_xscale(xmax, s, inv);
   float x[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const long long row = 16 * rg + 8 * (e >> 2) + 4 * h + (e & 3);
-    x[e] = row < n ? Xrm[(size_t)row * ldx + 32 * fb + l31] * s : 0.f;
+    x[e] = (row < n && fb < (ldx >> 5)) ? Xrm[(size_t)row * ldx + 32 * fb + l31] * s : 0.f;
   }
   fb_store_frag(XB + (size_t)f * kFrag + 4 * lane, x);
 }
@@ -1179,7 +1180,7 @@ bool logreg_prepare_f32(mivi_ctx *c) {
     hipLaunchKernelGGL(k_lr_xplanes, dim3((unsigned)((nfr + 3) / 4)), dim3(256), 0, c->stream, (long long)c->lr_n, nrb32, ldx, (const float *)c->lr_Xrm.p,
                        (const unsigned *)c->lr_xmax.p, (unsigned *)c->lr_XA.p);
     const long long nrg = nrb32 / 4 * 8;
-    const size_t nfb = (size_t)(ldx / 32) * nrg;
+    const size_t nfb = (size_t)((ldx + 127) / 128 * 4) * nrg;   // (whole 128-feature groups: k_lr_xtr_planes stages four 32-feature blocks per group)
     if (!grow(c->lr_XB, nfb * kFrag * 4)) return false;
     hipLaunchKernelGGL(k_lr_xbplanes, dim3((unsigned)((nfb + 3) / 4)), dim3(256), 0, c->stream, (long long)c->lr_n, nrg, ldx, (const float *)c->lr_Xrm.p,
                        (const unsigned *)c->lr_xmax.p, (unsigned *)c->lr_XB.p);

@@ -672,6 +672,37 @@ def test_device_loop_with_the_logreg_target():
         ctx.close()
 
 
+def test_device_loop_with_the_logreg_target_on_operand_planes():
+    """The same with a data set that has operand planes (n p >= 1e5, n_mc = 128: k_lr_zplanes / k_lr_logits_planes / k_lr_xtr_planes inside
+    the captured graph, their scratch reserved before the capture): bitwise the step-by-step sequence."""
+    rng = np.random.default_rng(21)
+    n, p, M, T = 2200, 63, 128, 7
+    d = p + 1
+    X = (rng.normal(size=(n, p)) / np.sqrt(p)).astype(np.float32)
+    y = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    for family in (avi.MEANFIELD, avi.FULLRANK):
+        q0 = (avi.MeanFieldGaussian(np.zeros(d, np.float32), np.full(d, 0.5, np.float32)) if family == avi.MEANFIELD
+              else avi.FullRankGaussian(np.zeros(d, np.float32), 0.5 * np.eye(d, dtype=np.float32)))
+        p0, _ = avi.destructure(q0)
+        ctx = avi.MiviContext(np.float32, family, d, M, 0, SEED)
+        ctx.set_problem(avi.LogRegProblem(X, y))
+        ctx.set_logreg_route(1)
+        assert ctx.logreg_kernels()["xtr_planes"]
+        pb = ctx.to_device(p0).clone()
+        st2 = ctx.empty(2 * pb.numel()).zero_()
+        ctx.optimize_steps(pb, st2, 50, 0, T, 1, 1e-2, 1e-5, None)      # (the loop FIRST: nothing of the route has run on this context yet)
+        ctx.synchronize()
+        pa = ctx.to_device(p0).clone()
+        st = ctx.empty(2 * pa.numel()).zero_()
+        for t in range(T):
+            v, g = ctx.estimate_gradient(pa, 50 + t)
+            ctx.adam_update(pa, g, st, t + 1, 1e-2)
+            ctx.clip_scale(pa, 1e-5)
+        ctx.synchronize()
+        assert np.array_equal(pa.cpu().numpy(), pb.cpu().numpy())
+        ctx.close()
+
+
 @pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
 @pytest.mark.parametrize("combo", [
     ("descent", "clip", "poly"), ("adam", "identity", "none"), ("adam", "clip", "poly"), ("dog", "clip", "poly"),
