@@ -262,3 +262,36 @@ def test_logreg_operand_planes_at_odd_shapes(n, p, M, family, variant):
     vo = ctx.estimate_objective(params, 4, n_samples=0, entropy=0)
     assert abs(float(vo.item()) - float(v.item())) <= 2e-6 * abs(float(v.item()))
     ctx.close()
+
+
+def _plane_shapes(k, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(k):
+        p = int(rng.choice([17, 31, 33, 63, 64, 65, 95, 97, 129, 160, 255, 300, 511, 700]))
+        n = int(max(100_000 // p + 1, rng.integers(130, 6000)))
+        M = int(rng.choice([128, 256]))
+        out.append((n, p, M))
+    return out
+
+
+@pytest.mark.parametrize("n,p,M", _plane_shapes(16, 20260930))
+def test_logreg_operand_planes_random_shapes(n, p, M):
+    """Random (rows, features, samples) over the operand-plane route -- feature counts on both sides of every 32- and 128-wide boundary (a
+    p = 63 data set once read past the end of X's second-orientation planes) -- against the fp64 oracle."""
+    rng = np.random.default_rng(n * 7 + p)
+    d = p + 1
+    X = (rng.normal(size=(n, p)) / np.sqrt(p)).astype(np.float32)
+    y = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    q = avi.MeanFieldGaussian((0.1 * rng.normal(size=d)).astype(np.float32), rng.uniform(0.3, 0.7, size=d).astype(np.float32))
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, avi.MEANFIELD, d, M, 0, SEED)
+    ctx.set_problem(avi.LogRegProblem(X, y, "logsigma_normal", 0.9))
+    ctx.set_logreg_route(1)
+    assert ctx.logreg_kernels() == dict(mfma=True, logits_planes=True, xtr_planes=True)
+    _, eps = ctx.sample(params, 2)
+    v, g = ctx.estimate_gradient(params, 2)
+    ref = O.estimate_gradient(params.astype(np.float64), d, avi.MEANFIELD, O.LogRegTarget(X, y, "logsigma_normal", 0.9), eps.cpu().numpy().astype(np.float64), 0)
+    assert abs(float(v.item()) - ref["value"]) <= 1e-5 * abs(ref["value"]), (float(v.item()), ref["value"])
+    assert rel_err(g.cpu().numpy(), ref["grad"]) < C3_GRAD_RTOL
+    ctx.close()
