@@ -24,7 +24,10 @@ def _cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("d,M,kind,ent,count", _cases(28, 20260929))
+_WIDE = [(256, 2048, "diag", 0, 5), (128, 1024, "dense", 2, 9), (256, 1024, "diag", 3, 18), (128, 2048, "dense", 0, 3), (2048, 128, "dense", 1, 4)]   # the widest sample counts (16 re-basing boundaries in the VJP) and the largest d
+
+
+@pytest.mark.parametrize("d,M,kind,ent,count", _cases(28, 20260929) + _WIDE)
 def test_engine_fuzz(d, M, kind, ent, count):
     rng = np.random.default_rng(d * 31 + M * 7 + ent + count)
     q, q_o = make_family(rng, d, avi.FULLRANK, np.float32, mu_scale=0.5)
