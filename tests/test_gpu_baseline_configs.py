@@ -295,3 +295,43 @@ def test_logreg_operand_planes_random_shapes(n, p, M):
     assert abs(float(v.item()) - ref["value"]) <= 1e-5 * abs(ref["value"]), (float(v.item()), ref["value"])
     assert rel_err(g.cpu().numpy(), ref["grad"]) < C3_GRAD_RTOL
     ctx.close()
+
+
+def _intile_shapes(k, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(k):
+        p = int(rng.choice([3, 7, 15, 16, 31, 33, 63, 65, 100, 127, 129, 255]))
+        n = int(min(99_000 // p, rng.integers(17, 3000)))
+        M = int(rng.choice([16, 32, 48, 64, 100, 128, 160, 256]))
+        out.append((n, p, M))
+    return out
+
+
+@pytest.mark.parametrize("n,p,M", _intile_shapes(20, 20260931))
+def test_logreg_matrix_core_kernels_without_planes_random_shapes(n, p, M):
+    """The matrix-core kernels that split X in the tile (k_lr_logits_f16x2[_part] / k_lr_xtr_f16x2: data sets below 10^5 elements, or sample
+    counts that are not multiples of 128) over random shapes, pinned with set_logreg_route(1), against the fp64 oracle."""
+    rng = np.random.default_rng(n * 11 + p + M)
+    d = p + 1
+    X = (rng.normal(size=(n, p)) / np.sqrt(p)).astype(np.float32)
+    y = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    q, q_o = make_family_fr(rng, d)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+    ctx.set_problem(avi.LogRegProblem(X, y, "lognormal_exp_bijector", 1.0))
+    ctx.set_logreg_route(1)
+    k = ctx.logreg_kernels()
+    assert k["mfma"] and not k["logits_planes"]
+    _, eps = ctx.sample(params, 6)
+    v, g = ctx.estimate_gradient(params, 6)
+    ref = O.estimate_gradient(params.astype(np.float64), d, avi.FULLRANK, O.LogRegTarget(X, y, "lognormal_exp_bijector", 1.0), eps.cpu().numpy().astype(np.float64), 0)
+    assert abs(float(v.item()) - ref["value"]) <= 2e-5 * max(abs(ref["value"]), 1.0), (float(v.item()), ref["value"])
+    assert np.linalg.norm(g.cpu().numpy() - ref["grad"]) <= 4e-5 * max(np.linalg.norm(ref["grad"]), 1.0)
+    ctx.close()
+
+
+def make_family_fr(rng, d):
+    mu = (0.1 * rng.normal(size=d)).astype(np.float32)
+    C = (0.5 * np.eye(d) + np.tril(rng.normal(size=(d, d)) * (0.05 / np.sqrt(d)), -1)).astype(np.float32)
+    return avi.FullRankGaussian(mu, C), None
