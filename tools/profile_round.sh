@@ -24,6 +24,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_ns20 -o run -- $BENCH --workload n
 db=$(find /tmp/prof_ns20 -name '*.db' | head -1)
 { echo "# $TAG: rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-also --concurrent 1 --workload ns --steps 20 --warmup 5 (the driver's protocol)"; echo;
   python $REPO/tools/rocpd_stats.py $db; } > $OUT/${TAG}_ns20_kernel_stats.md
+{ echo "# $TAG: idle time between consecutive batch-engine dispatches of the same trace (tools/rocpd_gaps.py)"; echo; python $REPO/tools/rocpd_gaps.py $db; } > $OUT/${TAG}_ns20_gaps.md
 # counter calibration on this library's access patterns (tools/ubench_fetchcal.hip), separate passes
 [ -x $REPO/tools/bin/ubench_fetchcal.exe ] || { mkdir -p $REPO/tools/bin; /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $REPO/tools/ubench_fetchcal.hip -o $REPO/tools/bin/ubench_fetchcal.exe; }
 for c in FETCH_SIZE WRITE_SIZE; do
