@@ -198,8 +198,10 @@ static bool fb_route(const mivi_ctx *c, const void *params, const void *grad_las
 }
 // value_last / grad_last: the batch's LAST estimate (mivi_estimate_gradient_n's contract), or nullptr; values_all T[count] / grads_all
 // T[count * params_len]: every estimate's (mivi_estimate_gradient_each), or nullptr (lane scratch)
+// obj_ent >= 0: objective mode (fb_objective): the `count` lanes are consecutive blocks of n_mc samples of estimate idx0, values only, the
+// value's entropy estimator obj_ent
 static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, int count, void *value_last, void *grad_last, void *values_all,
-                              void *grads_all) {
+                              void *grads_all, int obj_ent = -1) {
   mivi_status_t s;
   const int M = c->cfg.n_mc, d = c->cfg.d;
   if ((s = ensure_work(c, M))) return s;
@@ -238,7 +240,7 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
       t.PA_valid = true;
     }
   }
-  const bool stl = c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD;
+  const bool stl = obj_ent < 0 && (c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD);   // (a value needs no gradient term)
   if (stl) {
     // W += C^-T eps: inside a call the parameters are fixed, so C^-T is formed ONCE -- the solve kernels (kernels_stl.hip) on the identity's d
     // columns -- and the term is one more triangular product per lane (k_fb_prod<FB_STL_U>)
@@ -269,7 +271,10 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
     fs.M = M;
     fs.L = st == steps - 1 ? Llast : L;
     fs.tab = st == steps - 1 ? tabL : tabF;
-    fs.rng = rng_of(c, idx0 + (uint64_t)st * L);
+    fs.rng = rng_of(c, obj_ent >= 0 ? idx0 : idx0 + (uint64_t)st * L);
+    fs.obj = obj_ent >= 0 ? 1 : 0;
+    fs.ent_kind = obj_ent;
+    if (obj_ent >= 0) fs.rng.m_offset += st * L * M;
     if (grads_all) { fs.grads = (char *)grads_all + (size_t)st * L * plen * 4; fs.grad_stride = (long long)plen; fs.write_upper = 1; }
     else { fs.grads = t.grads.p; fs.grad_stride = (long long)plen; fs.write_upper = 0; }
     if (values_all) { fs.values = (char *)values_all + (size_t)st * L * 4; fs.value_stride = 1; }
@@ -291,6 +296,11 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
   }
   HIPCHK(c, hipGetLastError());
   return MIVI_OK;
+}
+
+mivi_status_t mivi::fb_objective(mivi_ctx *c, const void *params, uint64_t idx, int lanes, int entropy, void *values) {
+  if (!fb_route(c, params, nullptr, nullptr) || c->M_total != c->cfg.n_mc) return MIVI_ERR_UNSUPPORTED;
+  return fb_batch(c, params, idx, lanes, nullptr, nullptr, values, nullptr, entropy);
 }
 
 // Lanes per step of a `count`-estimate batch on the batch engine (equal steps of at most MIVI_FB_LANES = 80): what a roofline leg must profile.

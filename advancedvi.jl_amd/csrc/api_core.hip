@@ -10,6 +10,20 @@
 __global__ void k_acc_value_f32(double *acc, const float *v, double w, int first) { acc[0] = (first ? 0.0 : acc[0]) + w * (double)v[0]; }
 __global__ void k_acc_value_f64(double *acc, const double *v, double w, int first) { acc[0] = (first ? 0.0 : acc[0]) + w * v[0]; }
 __global__ void k_store_value_f32(float *out, const double *acc) { out[0] = (float)acc[0]; }
+// acc = w * sum of n values (objective mode of the batch engine: the lanes' values), a fixed order: thread t sums entries t, t + 256, .. in
+// f64, the 256 partials are added in index order by thread 0
+__global__ __launch_bounds__(256) void k_mean_values_f32(double *acc, const float *v, int n, double w) {
+  __shared__ double part[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)v[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 256; ++i) t += part[i];
+    acc[0] = w * t;
+  }
+}
 __global__ void k_store_value_f64(double *out, const double *acc) { out[0] = acc[0]; }
 // device counters of the graph-batched calls, set BY VALUE (an async copy from a stack local may outlive the caller's frame)
 __global__ void k_set_u64x2(uint64_t *dst, uint64_t a, uint64_t b, int n) { dst[0] = a; if (n > 1) dst[1] = b; }
@@ -178,7 +192,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   DevBuf *bufs[] = {&c->t_mean, &c->t_istd, &c->t_prec, &c->lr_X_own, &c->lr_y_own, &c->lr_scratch, &c->lr_part, &c->lr_Xrm,
                     &c->eps[0], &c->eps[1], &c->epsT[0], &c->epsT[1], &c->Z, &c->W, &c->RT, &c->ell, &c->X,
                     &c->ell_part[0], &c->ell_part[1], &c->he_part[0], &c->he_part[1], &c->row_part,
-                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_xmax, &c->lr_XA, &c->lr_XB, &c->lr_ZP, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_P2, &c->dist_ring[0], &c->dist_ring[1], &c->dist_ring[2], &c->dist_ring[3], &c->dist_ring[4], &c->dist_ring[5], &c->p2p_scratch, &c->dist_S, &c->dist_F, &c->p2p_tab, &c->p2p_ctr, &c->lds_tabV, &c->lds_tabV64, &c->lds_tabS, &c->lds_tabSt, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out};
+                    &c->sc_part[0], &c->sc_part[1], &c->ld_part[0], &c->ld_part[1], &c->tabA, &c->tabB, &c->tabD, &c->stl_CT, &c->stl_Dinv, &c->stl_X, &c->stl_F, &c->lr_xmax, &c->lr_XA, &c->lr_XB, &c->lr_ZP, &c->lr_Xsub, &c->lr_ysub, &c->lr_Xrm_sub, &c->lr_idx, &c->dog_part, &c->stein_A, &c->stein_g, &c->bij_mask, &c->bij_ld, &c->dist_P, &c->dist_P2, &c->dist_ring[0], &c->dist_ring[1], &c->dist_ring[2], &c->dist_ring[3], &c->dist_ring[4], &c->dist_ring[5], &c->p2p_scratch, &c->dist_S, &c->dist_F, &c->p2p_tab, &c->p2p_ctr, &c->lds_tabV, &c->lds_tabV64, &c->lds_tabS, &c->lds_tabSt, &c->status, &c->d_idx, &c->acc, &c->tmp_params, &c->tmp_out, &c->obj_vals};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   {

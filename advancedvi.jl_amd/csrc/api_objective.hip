@@ -20,7 +20,27 @@ mivi_status_t mivi_estimate_objective(mivi_ctx_t *c, const void *params, uint64_
   // chunked: the objective is a mean over samples plus parameter-only terms, so the weighted mean of the
   // chunk objectives is the full objective
   char *tmpv = (char *)c->tmp_out.p;
-  for (int off = 0, first = 1; off < n_samples; off += CH, first = 0) {
+  int off0 = 0, first0 = 1;
+  // Full-rank f32 contexts of an engine shape: whole blocks of n_mc samples as LANES of the batch engine (draws -> product + target -> value
+  // workgroups; no VJP), the same (estimate index, global sample column) stream as the chunks below: 73 M -> see DESIGN.md section 8 samples/s
+  // at the north-star shape.  Their values are averaged in a fixed order; what is left over goes through the chunk loop.
+  {
+    const int M = c->cfg.n_mc, lanes = n_samples / M;
+    if (c->cfg.dtype == MIVI_F32 && lanes >= 8) {
+      if (ensure(c, c->obj_vals, (size_t)lanes * 4 + 64, false) == MIVI_OK) {
+        const mivi_status_t sb = mivi::fb_objective(c, params, idx, lanes, entropy, c->obj_vals.p);
+        if (sb == MIVI_OK) {
+          hipLaunchKernelGGL(k_mean_values_f32, dim3(1), dim3(256), 0, c->stream, (double *)c->acc.p, (const float *)c->obj_vals.p, lanes,
+                             (double)M / (double)n_samples);
+          off0 = lanes * M;
+          first0 = 0;
+        } else if (sb != MIVI_ERR_UNSUPPORTED) {
+          return sb;
+        }
+      }
+    }
+  }
+  for (int off = off0, first = first0; off < n_samples; off += CH, first = 0) {
     const int Mc = n_samples - off < CH ? n_samples - off : CH;
     OutArgs o = final_out(c, tmpv, nullptr);
     o.ent_kind = entropy;

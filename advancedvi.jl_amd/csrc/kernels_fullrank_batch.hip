@@ -81,6 +81,7 @@ struct FbArgs {
   double ell_const;
   RngArgs rng;                    // lane l draws estimate rng_index(rng) + l
   int n_riders;                   // k_fb_eps: grid rows in front of the lanes' that lay out tril(C)
+  int obj;                        // k_fb_eps: 1 = lane l draws samples [l M, (l + 1) M) of ONE estimate index (objective mode); 0 = estimate index + l
   int knock;                      // developer knock-outs (-DMIVI_DEV, MIVI_FB_KNOCK): 1 no DMA, 2 no MFMA, 4 no LDS reads, 8 no barriers
   long long *dbg;                 // developer timeline (-DMIVI_DEV builds, MIVI_FB_DBG=1): per workgroup {entry, first stage landed, main loop done, end} (100 MHz ticks), groups
 };
@@ -204,14 +205,15 @@ __global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
     return;
   }
   const int l = (int)blockIdx.y - a.n_riders;
-  const uint64_t idx = rng_index(a.rng) + (uint64_t)l;
+  const uint64_t idx = rng_index(a.rng) + (a.obj ? 0ull : (uint64_t)l);
+  const int moff = a.rng.m_offset + (a.obj ? l * a.M : 0);
   unsigned *epsP = a.epsP + (size_t)l * a.plane_stride, *epsV = a.epsV + (size_t)l * a.plane_stride;
   const int nrb6 = d >> 6;
   const int R64 = eb % nrb6, c32 = eb / nrb6;
   const int q = tid & 15, c = tid >> 4;
   const int ri = R64 * 64 + 4 * q, rm = c32 * 32 + c;
   float e[4];
-  eps_block<float>(a.rng.seed, idx, (uint64_t)(a.rng.m_offset + rm) * (uint64_t)(d >> 2) + (uint64_t)(ri >> 2), e);
+  eps_block<float>(a.rng.seed, idx, (uint64_t)(moff + rm) * (uint64_t)(d >> 2) + (uint64_t)(ri >> 2), e);
 #pragma unroll
   for (int r = 0; r < 4; ++r) E[c * 65 + 4 * q + r] = e[r] * kEpsScale;
   const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
@@ -1098,6 +1100,7 @@ void fb_launch_eps(mivi_ctx *c, const FbStep &s, bool with_cplanes, hipStream_t 
   FbArgs a = fb_args(c, s.params, M);
   a.L = L;
   a.rng = s.rng;
+  a.obj = s.obj;
   const int gx = (d / 64) * (M / 32);
   a.n_riders = with_cplanes ? (4 * (d / 32) + gx - 1) / gx : 0;   // tril(C)'s planes: four workgroups per 32-row block, in FRONT of the lanes' draws
   hipLaunchKernelGGL(k_fb_eps, dim3(gx, L + a.n_riders), dim3(512), 0, stream, a);
@@ -1121,6 +1124,7 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
   a.values = (float *)s.values; a.value_stride = s.value_stride;
   a.grad_last = (float *)s.grad_last; a.value_last = (float *)s.value_last; a.lane_last = s.lane_last;
   a.write_upper = s.write_upper;
+  if (s.obj) { a.ent_kind = s.ent_kind; a.M_total = s.M; }
 #ifdef MIVI_DEV
   static long long *dbg_buf = nullptr;
   static const bool dbg_on = getenv("MIVI_FB_DBG") != nullptr;
@@ -1168,6 +1172,10 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
     prod(std::integral_constant<int, FB_STL_U>{}, tb.n_prod);
   }
   a.work = (const int4 *)tb.vjp.p; a.n_work = tb.n_vjp;
+  if (s.obj) {   // objective mode: the lanes' value workgroups alone (no VJP tile)
+    if (which & 2) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 256, 6>), dim3(s.L), dim3(512 / kWJ), 0, stream, a);
+    return;
+  }
   if (which & 2) {
     // measured at the north star (us per 20 / 50 / 80 lanes): ring 3 + three workgroups per CU 26.5 / 63.3 / 105-115; ring 3, two per CU 26.4 /
     // 69.8 / 109; ring 4, two per CU 36.7 / 81.5 / 126; ring 2, three per CU 26.4 / 72.6 / 113 (round 4's kernel with its second accumulator: 29 / 70 / 115)

@@ -233,6 +233,8 @@ struct FbStep {
   int dense;                              // dense-Gaussian target: two products per lane
   int stl;                                // sticking-the-landing estimators: W += C^-T eps as one more product per lane
   const FbTab *tab;
+  int obj;                                // objective mode (mivi_estimate_objective): the lanes are consecutive blocks of n_mc samples of ONE estimate index; values only
+  int ent_kind;                           // objective mode: the entropy estimator of the value
 };
 
 struct GraphCache {
@@ -345,6 +347,7 @@ struct mivi_ctx {
   int mf_nblk = 0;
   mivi::DevBuf Z, W, RT, ell, X;
   mivi::DevBuf row_part, status, d_idx, acc, tmp_params, tmp_out;
+  mivi::DevBuf obj_vals;   // mivi_estimate_objective on the batch engine: the lanes' values
   mivi::DevBuf stein_A, stein_g;   // Stein estimator: eps G^T accumulator (dP x dP, T) and the f64 column sums of G
   mivi::DevBuf dog_part;   // DoG / DoWG on large parameter vectors: 512 x 2 partial norms + the step size
   const uint64_t *idx_src = nullptr;   // mivi_set_index_source
@@ -485,6 +488,7 @@ void invalidate_graph(mivi_ctx *c);            // api_core.hip: drop the cached 
 // every workgroup of `grid` resident at once?  (loops whose workgroups exchange partials every step by spin-wait: checked at launch, never assumed)
 bool grid_resident(const mivi_ctx *c, const void *kernel, int block, size_t dyn_lds, long long grid);
 bool fb_shape_ok(const mivi_ctx *c, int M);
+mivi_status_t fb_objective(mivi_ctx *c, const void *params, uint64_t idx, int lanes, int entropy, void *values);   // api_batch.hip: lanes x n_mc samples of estimate idx on the batch engine (MIVI_ERR_UNSUPPORTED: not an engine configuration)
 const FbTab *fb_prepare(mivi_ctx *c, int M, int L);   // work tables for L lanes (nullptr: allocation failed)
 size_t fb_plane_words(const mivi_ctx *c, int M);      // 4-byte words of one lane's operand planes (eps in one orientation, W)
 size_t fb_cplane_words(const mivi_ctx *c);            // ... of tril(C)'s
