@@ -11,7 +11,8 @@ mivi_status_t mivi_estimate_objective(mivi_ctx_t *c, const void *params, uint64_
   (void)hipSetDevice(c->cfg.device);
   const int CH = 16384;
   // all estimators share their *value* within {closed-form} / {MC, STL, STL-zero-grad}
-  if (n_samples <= CH) {
+  const bool engine_sized = c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && n_samples / c->cfg.n_mc >= 8 && c->cfg.n_mc >= 128;   // (tried below; falls back to the chunks)
+  if (n_samples <= CH && !engine_sized) {
     OutArgs o = final_out(c, value, nullptr);
     o.ent_kind = entropy;
     o.M_total = n_samples;
@@ -22,8 +23,8 @@ mivi_status_t mivi_estimate_objective(mivi_ctx_t *c, const void *params, uint64_
   char *tmpv = (char *)c->tmp_out.p;
   int off0 = 0, first0 = 1;
   // Full-rank f32 contexts of an engine shape: whole blocks of n_mc samples as LANES of the batch engine (draws -> product + target -> value
-  // workgroups; no VJP), the same (estimate index, global sample column) stream as the chunks below: 73 M -> see DESIGN.md section 8 samples/s
-  // at the north-star shape.  Their values are averaged in a fixed order; what is left over goes through the chunk loop.
+  // workgroups; no VJP), the same (estimate index, global sample column) stream as the chunks below: 73 M -> 204 M samples/s at the
+  // north-star shape.  Their values are averaged in a fixed order; what is left over goes through the chunk loop.
   {
     const int M = c->cfg.n_mc, lanes = n_samples / M;
     if (c->cfg.dtype == MIVI_F32 && lanes >= 8) {

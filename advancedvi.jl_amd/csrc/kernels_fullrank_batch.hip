@@ -232,7 +232,7 @@ __global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
     for (int s = 0; s < 8; ++s) x[s] = E[(16 * mg + 8 * (s >> 2) + 4 * h + (s & 3)) * 65 + 32 * jb + l31];
     dst = epsV + ((size_t)(2 * R64 + jb) * (a.M >> 4) + 2 * c32 + mg) * kFrag;
   }
-  fb_store_frag(dst + 4 * lane, x);
+  if (tid < 256 || !a.obj) fb_store_frag(dst + 4 * lane, x);   // (objective mode: no VJP follows, its orientation of the draws is not written)
 }
 
 // -----------------------------------------------------------------------------------------------------------------
