@@ -642,7 +642,7 @@ def compact_line(full):
                     also[k + "_us"] = _num(v["us_per_step"], 4)
             elif "us_per_call" in v:
                 also[k] = _num(1e6 / v["us_per_call"], 5)
-        also["units"] = "estimates/s (c2 ns_dense ns_stl c5 c3 ns_host_boundary), steps/s (*_loop, reference_benchmark_grid), calls/s (stein)"
+        also["units"] = "estimates/s (c2 ns_dense ns_stl c5 c3 ns_host_boundary), steps/s (*_loop, reference_benchmark_grid), calls/s (stein), samples/s (ns_objective_1e5)"
     cfg = dict(full.get("config") or {})
     cfg["launch"] = str(cfg.get("launch", ""))[:200]
     cfg["workload"] = str(cfg.get("workload", ""))[:128]
@@ -1192,6 +1192,20 @@ def main():
                     del ve, ge
                 except Exception as e:   # noqa: BLE001
                     also["ns_each"] = dict(error=str(e))
+                # estimate_objective at a monitoring sample count (repgradelbo.jl:112-122): 10^5 samples of the north-star family per call
+                try:
+                    n_o = 100_000
+                    vo = ctx.estimate_objective(params, 95_000, n_samples=n_o)
+                    stream.synchronize()
+                    t0s = time.perf_counter()
+                    for r in range(10):
+                        vo = ctx.estimate_objective(params, 95_001 + r, n_samples=n_o, value=vo)
+                    stream.synchronize()
+                    t_o = (time.perf_counter() - t0s) / 10
+                    also["ns_objective_1e5"] = dict(workload="mivi_estimate_objective, 10^5 samples per call, north-star family and target (whole blocks of n_mc samples as lanes of the batch engine, values only)",
+                                                    value=n_o / t_o, unit="samples/s", ms_per_call=t_o * 1e3)
+                except Exception as e:   # noqa: BLE001
+                    also["ns_objective_1e5"] = dict(error=str(e))
                 # the Stein / Price estimator of E_q[grad], E_q[hess] on the north-star shape (gaussian_expectation_gradient_and_hessian!,
                 # src/algorithms/gauss_expected_grad_hess.jl:32-60): the ELBO path's sampling + target kernels, eps G^T, one C^-T solve
                 # with d right-hand sides; eager calls with consecutive indices, device-resident outputs
