@@ -176,13 +176,15 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *ctx, const void *params_dev, 
  * grads_dev T[count * params_len] <- its gradient (row i), or NULL when only the values are wanted.  What a caller of
  * estimate_objective / estimate_gradient! at fixed parameters wants from many estimates -- monitoring with many samples
  * (test/algorithms/klminrepgraddescent.jl:36), a gradient averaged over several estimates
- * (src/algorithms/repgradelbo.jl:151-177 called `count` times on one q).  Estimate i is bitwise mivi_estimate_gradient(estimate_idx0 + i). */
+ * (src/algorithms/repgradelbo.jl:151-177 called `count` times on one q).  Estimate i equals mivi_estimate_gradient(estimate_idx0 + i): bitwise on the generic route, to
+ * rounding (value 1e-6, gradient relative l2 2e-6) on the batch engine (full-rank f32, d and n_mc multiples of 128, Gaussian targets). */
 mivi_status_t mivi_estimate_gradient_each(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx0,
                                           int32_t count, void *values_dev, void *grads_dev);
 
 /* estimate_objective(rng, obj::RepGradELBO, q, prob; n_samples): src/algorithms/repgradelbo.jl:112-118;
  * `entropy` override mirrors the algorithm-level wrapper src/algorithms/common.jl:29-38 (default there:
- * MonteCarloEntropy).  n_samples may differ from cfg.n_mc.  value_dev: T[1]. */
+ * MonteCarloEntropy).  n_samples may differ from cfg.n_mc: sample m of the call is column m of estimate_idx's eps stream whatever route
+ * runs it (chunks of 16384 samples; on batch-engine configurations whole blocks of n_mc samples as engine lanes).  value_dev: T[1]. */
 mivi_status_t mivi_estimate_objective(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx,
                                       int32_t n_samples, int32_t entropy, void *value_dev);
 mivi_status_t mivi_estimate_objective_host(mivi_ctx_t *ctx, const void *params_host, uint64_t estimate_idx,
