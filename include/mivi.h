@@ -169,7 +169,9 @@ mivi_status_t mivi_estimate_gradient_host(mivi_ctx_t *ctx, const void *params_ho
                                           void *value_host, void *grad_host);
 /* `count` consecutive estimates estimate_idx0 .. estimate_idx0+count-1 of the same params replayed as ONE
  * hipGraph launch; value/grad hold the LAST estimate on return.  Built-in targets only.  Mean-field family with the
- * diagonal-Gaussian target (rows independent): all `count` estimates run inside one launch-free kernel instead. */
+ * diagonal-Gaussian target (rows independent): all `count` estimates run inside one launch-free kernel instead.  Full-rank f32 family,
+ * d and n_mc multiples of 128, Gaussian target: the batch engine (kernels_fullrank_batch.hip) -- steps of up to 80 estimates as three
+ * launches (draws, one product, one VJP over all of them), no graph. */
 mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx0,
                                        int32_t count, void *value_dev, void *grad_dev);
 /* The same batch with EVERY estimate's result kept: values_dev T[count] <- -elbo of estimate estimate_idx0 + i;
