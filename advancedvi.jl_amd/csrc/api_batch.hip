@@ -240,7 +240,8 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
       t.PA_valid = true;
     }
   }
-  const bool stl = obj_ent < 0 && (c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD);   // (a value needs no gradient term)
+  const bool values_only = obj_ent >= 0 || (!grads_all && !grad_last);
+  const bool stl = !values_only && (c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD);   // (a value needs no gradient term)
   if (stl) {
     // W += C^-T eps: inside a call the parameters are fixed, so C^-T is formed ONCE -- the solve kernels (kernels_stl.hip) on the identity's d
     // columns -- and the term is one more triangular product per lane (k_fb_prod<FB_STL_U>)
@@ -274,6 +275,7 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
     fs.rng = rng_of(c, obj_ent >= 0 ? idx0 : idx0 + (uint64_t)st * L);
     fs.obj = obj_ent >= 0 ? 1 : 0;
     fs.ent_kind = obj_ent;
+    fs.values_only = values_only ? 1 : 0;
     if (obj_ent >= 0) fs.rng.m_offset += st * L * M;
     if (grads_all) { fs.grads = (char *)grads_all + (size_t)st * L * plen * 4; fs.grad_stride = (long long)plen; fs.write_upper = 1; }
     else { fs.grads = t.grads.p; fs.grad_stride = (long long)plen; fs.write_upper = 0; }

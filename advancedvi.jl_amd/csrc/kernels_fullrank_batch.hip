@@ -1172,7 +1172,7 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
     prod(std::integral_constant<int, FB_STL_U>{}, tb.n_prod);
   }
   a.work = (const int4 *)tb.vjp.p; a.n_work = tb.n_vjp;
-  if (s.obj) {   // objective mode: the lanes' value workgroups alone (no VJP tile)
+  if (s.values_only) {   // values only (objective mode; the each entry without gradients): the lanes' value workgroups alone, no VJP tile
     if (which & 2) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 256, 6>), dim3(s.L), dim3(512 / kWJ), 0, stream, a);
     return;
   }

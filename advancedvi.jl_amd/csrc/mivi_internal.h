@@ -235,6 +235,7 @@ struct FbStep {
   const FbTab *tab;
   int obj;                                // objective mode (mivi_estimate_objective): the lanes are consecutive blocks of n_mc samples of ONE estimate index; values only
   int ent_kind;                           // objective mode: the entropy estimator of the value
+  int values_only;                        // no gradient is wanted (mivi_estimate_gradient_each without grads; objective mode): no VJP tile runs
 };
 
 struct GraphCache {
