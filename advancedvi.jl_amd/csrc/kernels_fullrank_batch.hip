@@ -81,6 +81,7 @@ struct FbArgs {
   double ell_const;
   RngArgs rng;                    // lane l draws estimate rng_index(rng) + l
   int n_riders;                   // k_fb_eps: grid rows in front of the lanes' that lay out tril(C)
+  int skip_v;                     // k_fb_eps: no VJP follows (values only): the draws' VJP orientation is not written
   int obj;                        // k_fb_eps: 1 = lane l draws samples [l M, (l + 1) M) of ONE estimate index (objective mode); 0 = estimate index + l
   int knock;                      // developer knock-outs (-DMIVI_DEV, MIVI_FB_KNOCK): 1 no DMA, 2 no MFMA, 4 no LDS reads, 8 no barriers
   long long *dbg;                 // developer timeline (-DMIVI_DEV builds, MIVI_FB_DBG=1): per workgroup {entry, first stage landed, main loop done, end} (100 MHz ticks), groups
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
     for (int s = 0; s < 8; ++s) x[s] = E[(16 * mg + 8 * (s >> 2) + 4 * h + (s & 3)) * 65 + 32 * jb + l31];
     dst = epsV + ((size_t)(2 * R64 + jb) * (a.M >> 4) + 2 * c32 + mg) * kFrag;
   }
-  if (tid < 256 || !a.obj) fb_store_frag(dst + 4 * lane, x);   // (objective mode: no VJP follows, its orientation of the draws is not written)
+  if (tid < 256 || !a.skip_v) fb_store_frag(dst + 4 * lane, x);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -1101,6 +1102,7 @@ void fb_launch_eps(mivi_ctx *c, const FbStep &s, bool with_cplanes, hipStream_t 
   a.L = L;
   a.rng = s.rng;
   a.obj = s.obj;
+  a.skip_v = s.values_only;
   const int gx = (d / 64) * (M / 32);
   a.n_riders = with_cplanes ? (4 * (d / 32) + gx - 1) / gx : 0;   // tril(C)'s planes: four workgroups per 32-row block, in FRONT of the lanes' draws
   hipLaunchKernelGGL(k_fb_eps, dim3(gx, L + a.n_riders), dim3(512), 0, stream, a);
