@@ -121,8 +121,10 @@ __device__ __forceinline__ void fb_group(const FbFrags<WJ> &F, f32x16 (&acc)[2][
 // last MFMA (it lets Fn reuse Fc's registers), and the lgkmcnt(0) of the barrier that follows waits out the whole LDS latency with both
 // waves of the SIMD in step (the ~200 cycles of "barrier + wait" per group of round 5's knock-out runs).  Early-clobber outputs keep Fn in
 // registers of its own.  ab / bb: this lane's byte addresses of its first A / B fragment in ring slot 0; OFF: the slot's byte offset
-// (< 64 KiB: slots 4..7 go through a second pair of base registers).  The caller's fb_barrier() (lgkmcnt(0)) stands between this block's
-// reads and the MFMAs that consume them; MFMA chains alternate between the two accumulators (SrcC = vDst back to back needs no nops).
+// (< 64 KiB: slots 4..7 go through a second pair of base registers).  The block ENDS with lgkmcnt(0) -- the last read is two MFMAs old by
+// then -- so Fn is valid for whatever the compiler does with it behind the block (it copies loop-carried registers at control-flow joins
+// and cannot know of the reads: found as 3e-6 errors in one estimate of 52 when the VJP's prefetch variant used this block without the
+// wait); MFMA chains alternate between the two accumulators (SrcC = vDst back to back needs no nops).
 template <int OFF>
 __device__ __forceinline__ void fb_group_read_asm(f32x16 &acc0, f32x16 &acc1, const FbFrags<1> &Fc, FbFrags<1> &Fn, unsigned ab, unsigned bb) {
   static_assert(OFF >= 0 && OFF + 3072 < 65536, "ds_read_b128 offset field");
@@ -138,7 +140,8 @@ __device__ __forceinline__ void fb_group_read_asm(f32x16 &acc0, f32x16 &acc1, co
       "v_mfma_f32_32x32x16_f16 %[c1], %[a1h], %[bl], %[c1]\n\t"
       "ds_read_b128 %[nbl], %[bb] offset:%[o1]\n\t"
       "v_mfma_f32_32x32x16_f16 %[c0], %[a0h], %[bh], %[c0]\n\t"
-      "v_mfma_f32_32x32x16_f16 %[c1], %[a1h], %[bh], %[c1]"
+      "v_mfma_f32_32x32x16_f16 %[c1], %[a1h], %[bh], %[c1]\n\t"
+      "s_waitcnt lgkmcnt(0)"   // Fn is VALID when the block ends: the compiler may move or copy it (loop-carried registers) without knowing of the reads
       : [c0] "+v"(acc0), [c1] "+v"(acc1), [n0h] "=&v"(Fn.A[0][0]), [n0l] "=&v"(Fn.A[0][1]), [n1h] "=&v"(Fn.A[1][0]), [n1l] "=&v"(Fn.A[1][1]),
         [nbh] "=&v"(Fn.B[0][0]), [nbl] "=&v"(Fn.B[0][1])
       : [a0h] "v"(Fc.A[0][0]), [a0l] "v"(Fc.A[0][1]), [a1h] "v"(Fc.A[1][0]), [a1l] "v"(Fc.A[1][1]), [bh] "v"(Fc.B[0][0]), [bl] "v"(Fc.B[0][1]),
