@@ -262,6 +262,8 @@ mivi_status_t mivi_prox_scale_entropy(mivi_ctx_t *ctx, void *params_dev, double 
  * iteration.  Returns MIVI_ERR_NONFINITE if any objective was not finite.
  * What runs (first match; every launch-free form keeps parameters and optimiser state in registers for all n_steps):
  *   mean-field, diagonal-Gaussian target                      one launch-free kernel (rows are independent), bitwise the single calls
+ *                                                             (sticking-the-landing estimators: a few entries one ulp apart -- the two
+ *                                                             kernels' residual terms are contracted differently by the compiler)
  *   full-rank, d <= 32, d n_mc <= 768 (STL 512)              one workgroup for the whole loop (the reference's own benchmark grid), to rounding
  *   full-rank f32, n_mc <= 32, diagonal-Gaussian target,      row-separable launch-free kernel (workgroups own row pairs), to rounding
  *     closed-form / Monte-Carlo entropy, d <= 1126
