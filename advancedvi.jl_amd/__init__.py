@@ -17,7 +17,8 @@ from .optimize import (KLMinRepGradDescent, KLMinRepGradProxDescent, ADVI, ClipS
                        ProximalLocationScaleEntropy, Descent, Adam, DoG, DoWG, COCOB, NoAveraging,
                        PolynomialAveraging, optimize, step, output)
 from .context import MiviContext
-from .problems import subsample, LogRegSubset, FunnelConstrainedProblem, StackedBijector, TransformedProblem
+from .problems import subsample, LogRegSubset, FunnelConstrainedProblem, StackedBijector, TransformedProblem, ADgradient
+from . import forwarddiff
 from .subsampling import (ReshufflingBatchSubsampling, ReshufflingBatchSubsamplingState, SubsampledObjective,
                           SubsampledObjectiveState)
 from . import subsampling as _subsampling

@@ -151,10 +151,10 @@ class MiviContext:
         self._chk(self.lib.mivi_set_bijector_stacked(self.h, len(bij.blocks), rng.ctypes.data, kinds.ctypes.data))
 
     def _set_callback(self, prob):
-        if not hasattr(prob, "logdensity_and_gradient") and not hasattr(prob, "logdensity_and_gradient_batch"):
-            raise TypeError(
-                "generic targets must implement logdensity_and_gradient (LogDensityOrder >= 1): libmivi has no AD; "
-                "see INTEGRATION.md")
+        has_grad = hasattr(prob, "logdensity_and_gradient") or hasattr(prob, "logdensity_and_gradient_batch")
+        if not has_grad and not hasattr(prob, "logdensity"):
+            raise TypeError("generic targets must implement logdensity (LogDensityOrder 0: values only -- estimate_objective) or "
+                            "logdensity_and_gradient (LogDensityOrder >= 1); see INTEGRATION.md")
         dt = self.np_dtype
 
         def as_mat(ptr, d, M):
@@ -163,6 +163,9 @@ class MiviContext:
 
         def fg(user, Zp, d, M, ellp, Gp):
             try:
+                if not has_grad:   # an order-0 problem set directly on a context: values only (objectives.init wraps it in ADgradient)
+                    raise TypeError("the target only implements logdensity (LogDensityOrder{0}()): a gradient estimate needs "
+                                    "logdensity_and_gradient -- wrap it in ADgradient(\"forwarddiff\", prob), as init(..., AutoMIVI(), ...) does")
                 Z = as_mat(Zp, d, M)
                 ell = as_mat(ellp, 1, M)
                 G = as_mat(Gp, d, M)

@@ -402,15 +402,18 @@ mivi_status_t mivi_p2p_selfcheck(mivi_ctx_t *c, const void *params, uint64_t idx
   auto done = [&](mivi_status_t st) { (void)hipFree(a.p); (void)hipFree(b.p); c->dist_route = keep; invalidate_graph(c); return st; };
   c->dist_route = c->comm ? 1 : 3;
   invalidate_graph(c);
-  if ((s = mivi_estimate_gradient_dist(c, params, idx, a.p, (char *)a.p + 16 * es)) || (s = mivi_synchronize(c))) return done(s);
+  // Every rank takes part in BOTH estimates and in the verdict's all-reduce WHATEVER happened to its own calls (bounded waits end the peer-to-peer
+  // exchange on every rank): a rank that returned early -- also after a failed FIRST estimate -- would leave the others waiting inside RCCL.
+  s = mivi_estimate_gradient_dist(c, params, idx, a.p, (char *)a.p + 16 * es);
+  if (!s) s = mivi_synchronize(c);
+  const mivi_status_t s_first = s;
+  const std::string why_first = c->err;
   c->dist_route = 3;
   invalidate_graph(c);
   s = mivi_estimate_gradient_dist(c, params, idx, b.p, (char *)b.p + 16 * es);
   if (!s) s = mivi_synchronize(c);
-  // From here every rank takes part in the verdict's all-reduce WHATEVER happened to its own peer-to-peer estimate (bounded waits end it on every
-  // rank): a rank that returned early would leave the others waiting inside RCCL.
-  const mivi_status_t s_p2p = s;
-  const std::string why_p2p = c->err;
+  const mivi_status_t s_p2p = s_first ? s_first : s;
+  const std::string why_p2p = s_first ? why_first : c->err;
   double rv = 1.0, rg = 1.0;
   int ok = 0;
   if (!s_p2p) {

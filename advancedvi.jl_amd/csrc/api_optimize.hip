@@ -296,6 +296,7 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
     if (avg_bytes) HIPCHK(c, hipMemcpyAsync(sp + plen * es + st_bytes, l.avg_params_dev, avg_bytes, hipMemcpyDeviceToDevice, c->stream));
   }
   bool used = false;
+  c->last_status_bits = 0;   // only a bit-8 ("exchange lost") flag read by THIS call may trigger the retry below: a stale one would mask a real HIP error
   mivi_status_t s = optimize_loop_run(c, params, lp, may_exchange, &used);
   static const bool force_lost = getenv("MIVI_FORCE_EXCHANGE_LOST") != nullptr;   // test hook (tests/test_gpu_loop_oracle.py): treat the first exchanging call as lost
   if (force_lost && used && s == MIVI_OK) { s = MIVI_ERR_HIP; c->last_status_bits |= 8; }

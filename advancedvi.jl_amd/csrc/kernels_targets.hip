@@ -1355,15 +1355,10 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
     else hipLaunchKernelGGL(k_lr_logits_mfma_lds<false>, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
   }
   if (want_grad && a.n % 16 != 0 && !geo.xplanes) {
-    // the zero residual rows k_lr_xtr_f16x2's last stage reads (the logits kernels stop at n).  Nobody writes them, so
-    // they are zeroed once per geometry -- and every time while the stream is being captured (a graph must carry its own)
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(c->stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-    const bool cap = cs == hipStreamCaptureStatusActive;
-    if (cap || c->lr_pad_R != (const void *)a.R || c->lr_pad_n != (long long)a.n || c->lr_pad_ldr != a.ldr) {
-      (void)hipMemsetAsync(a.R + (size_t)a.n * a.ldr, 0, (size_t)(16 - a.n % 16) * a.ldr * sizeof(float), c->stream);
-      if (!cap) { c->lr_pad_R = a.R; c->lr_pad_n = (long long)a.n; c->lr_pad_ldr = a.ldr; }
-    }
+    // the zero residual rows k_lr_xtr_f16x2's last stage reads (the logits kernels stop at n).  Nobody else writes them, but other
+    // routes reuse lr_scratch (the residuals' planes, the generic route's layout), so they are zeroed on every call: at most 15 rows
+    // of ldr floats, in stream order (a captured graph carries its own)
+    (void)hipMemsetAsync(a.R + (size_t)a.n * a.ldr, 0, (size_t)(16 - a.n % 16) * a.ldr * sizeof(float), c->stream);
   }
   if (want_grad && geo.xplanes) {
     hipLaunchKernelGGL(k_lr_xtr_planes, dim3((a.p + 127) / 128, S, M / 128), dim3(512), 0, c->stream, a);
@@ -1410,7 +1405,6 @@ static bool logreg_impl(mivi_ctx *c, int M, int want_grad) {
   a.rows_per_split = geo.rps;
   const size_t need_R = geo.need_R;
   // scratch layout inside lr_scratch: [R | g_part], lr_part: ll_part
-  c->lr_pad_n = -1;   // this route lays the scratch out differently: the MFMA route's zero pad rows are gone
   a.R = (T *)c->lr_scratch.p;
   a.g_part = (T *)((char *)c->lr_scratch.p + need_R);
   a.ll_part = (double *)c->lr_part.p;

@@ -309,9 +309,6 @@ struct mivi_ctx {
   const void *lr_Xrm_act = nullptr;      // row-major copy the MFMA kernels read (full or batch)
   mivi::DevBuf lr_Xsub, lr_ysub, lr_Xrm_sub, lr_idx;
   int lr_route = 0;                        // 0 auto (by problem size), 1 matrix-core kernels, 2 VALU kernels (mivi_set_logreg_route)
-  const void *lr_pad_R = nullptr;          // geometry for which R's zero pad rows are in place
-  long long lr_pad_n = -1;
-  int lr_pad_ldr = 0;
   int64_t lr_n = 0;
   int lr_variant = 0;
   double lr_likeadj = 1.0;

@@ -10,17 +10,49 @@
 # preparing / running an AD backend.  `optimize`, `step`, ClipScale, Optimisers rules stay untouched.
 module MIVI
 
-using AdvancedVI, ADTypes, DiffResults, LogDensityProblems, Optimisers, Random, LinearAlgebra
+using AdvancedVI, ADTypes, AbstractPPL, DiffResults, LogDensityProblems, Optimisers, Random, LinearAlgebra
 using Distributions: Normal
 using AdvancedVI: MvLocationScale, RepGradELBO, KLMinRepGradDescent, ClosedFormEntropy, ClosedFormEntropyZeroGradient,
                   MonteCarloEntropy, StickingTheLandingEntropy, StickingTheLandingEntropyZeroGradient
 
 const libmivi = get(ENV, "LIBMIVI", "libmivi.so")
 
-struct AutoMIVI <: ADTypes.AbstractADType
+# `target_ad`: the backend that differentiates an ORDER-0 target's `logdensity` on the host.  The reference hands `adtype` itself to AD and
+# differentiates the whole estimator through `logdensity` (src/algorithms/repgradelbo.jl:50-57); AutoMIVI's estimator is the closed-form
+# VJP, so the only derivative left to provide is the target's own, per sample.  Default: ForwardDiff (BASELINE configs[0]; the user loads it).
+struct AutoMIVI{A<:Union{Nothing,ADTypes.AbstractADType}} <: ADTypes.AbstractADType
     device::Int32
+    target_ad::A
 end
-AutoMIVI() = AutoMIVI(0)
+AutoMIVI(device::Integer = 0; target_ad = ADTypes.AutoForwardDiff()) = AutoMIVI(Int32(device), target_ad)
+
+# An order-0 problem (only `logdensity`) as an order-1 one: the reference's own AD shim (src/AdvancedVI.jl:47-82 uses the same two
+# AbstractPPL calls) applied to `logdensity` alone.  What README.md:168-174 does by hand with LogDensityProblemsAD.ADgradient.
+struct ADTarget{P,A}
+    prob::P
+    ad::A
+end
+LogDensityProblems.dimension(t::ADTarget) = LogDensityProblems.dimension(t.prob)
+LogDensityProblems.capabilities(::Type{<:ADTarget}) = LogDensityProblems.LogDensityOrder{1}()
+LogDensityProblems.logdensity(t::ADTarget, x) = LogDensityProblems.logdensity(t.prob, x)
+function LogDensityProblems.logdensity_and_gradient(t::ADTarget, x)
+    xv = collect(x)                                           # (a column view of Z: docs/src/tutorials/constrained.md:182-184)
+    prep = AbstractPPL.prepare(t.ad, Base.Fix1(LogDensityProblems.logdensity, t.prob), xv)
+    val, grad = AbstractPPL.value_and_gradient!!(prep, xv)
+    return val, copy(grad)                                    # fresh array: callers may mutate it (gauss_expected_grad_hess.jl:51)
+end
+AdvancedVI.subsample(t::ADTarget, batch) = ADTarget(AdvancedVI.subsample(t.prob, batch), t.ad)
+
+# The capability dispatch of `init` / `set_objective_state_problem` (repgradelbo.jl:31-39, 50-62).
+function ad_problem(ad::AutoMIVI, prob; announce::Bool = true)
+    capability = LogDensityProblems.capabilities(typeof(prob))
+    capability < LogDensityProblems.LogDensityOrder{1}() || return prob
+    ad.target_ad === nothing && throw(ArgumentError(
+        "The capability of the supplied `LogDensityProblem` $(capability) is less than $(LogDensityProblems.LogDensityOrder{1}()) and " *
+        "AutoMIVI(; target_ad=nothing) has no AD backend to differentiate `logdensity`"))
+    announce && @info "The capability of the supplied `LogDensityProblem` $(capability) is less than $(LogDensityProblems.LogDensityOrder{1}()). `AdvancedVI` will attempt to directly differentiate through `LogDensityProblems.logdensity`. If this is not intended, please supply a log-density problem with capability at least $(LogDensityProblems.LogDensityOrder{1}())"
+    return ADTarget(prob, ad.target_ad)
+end
 
 # mivi_config_t (include/mivi.h)
 struct MiviConfig
@@ -47,6 +79,7 @@ mutable struct MIVIState
     distributed::Bool            # a communicator is attached (comm_init!): estimates run sharded over the ranks
     dev::Any                     # device scratch for the sharded route: (params, value, grad) pointers or nothing
     native::Bool                 # the target runs on the device (mivi_set_target_*): the device-resident `optimize` applies
+    target_ad::Any               # AutoMIVI's target_ad: re-applied when SubsampledObjective swaps an order-0 problem in
 end
 
 function check(ctx, status)
@@ -78,15 +111,15 @@ end
 
 function AdvancedVI.init(rng::Random.AbstractRNG, obj::RepGradELBO, ad::AutoMIVI, q::MvLocationScale, prob, params, restructure)
     T = eltype(params)
-    # (checked before any native resource exists: nothing to release on this error path)
-    LogDensityProblems.capabilities(prob) isa LogDensityProblems.LogDensityOrder{0} &&
-        throw(ArgumentError("libmivi has no AD: the target must provide logdensity_and_gradient (wrap it in ADgradient)"))
+    # order 0 (README.md:64-66, bench/benchmarks.jl:39-41): differentiate through `logdensity` on the host, with the reference's @info
+    # (checked before any native resource exists: nothing to release on the error path)
+    prob = ad_problem(ad, prob)
     cfg = Ref(MiviConfig(dtype_code(T), family_code(q), length(q), obj.n_samples, entropy_code(obj.entropy),
                          ad.device, rand(rng, UInt64), 0, 0, C_NULL, 1, 0))
     ctx = Ref{Ptr{Cvoid}}(C_NULL)
     status = ccall((:mivi_create, libmivi), Int32, (Ref{MiviConfig}, Ref{Ptr{Cvoid}}), cfg, ctx)
     status == 0 || error("mivi_create failed with status $status (no HIP device?)")
-    st = MIVIState(prob, T, ctx[], UInt64(0), nothing, false, nothing, false)
+    st = MIVIState(prob, T, ctx[], UInt64(0), nothing, false, nothing, false, ad.target_ad)
     finalizer(s -> ccall((:mivi_destroy, libmivi), Int32, (Ptr{Cvoid},), s.ctx), st)
     if prob isa NativeTarget          # a target whose arithmetic stays on the GPU: no host callback at all
         set_native_target!(st, prob)
@@ -128,7 +161,7 @@ end
 # problem in before every estimate (src/algorithms/subsampledobjective.jl:85-87).  With the host-callback target only the
 # Julia-side problem changes; a native logistic-regression target (see `native_logreg!`) re-points its rows instead.
 function AdvancedVI.set_objective_state_problem(state::MIVIState, prob)
-    state.problem = prob
+    state.problem = state.target_ad === nothing ? prob : ad_problem(AutoMIVI(0; target_ad = state.target_ad), prob; announce = false)
     if prob isa NativeLogRegBatch
         check(state.ctx, ccall((:mivi_logreg_select_rows, libmivi), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int64, Float64),
                                state.ctx, prob.rows0, length(prob.rows0), prob.likeadj))

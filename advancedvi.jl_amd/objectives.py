@@ -12,11 +12,16 @@ The AD backend argument is the drop-in seam: `AutoMIVI()` selects
 path that replaces AD of `estimate_repgradelbo_ad_forward` (repgradelbo.jl:142-149)."""
 from __future__ import annotations
 
+import logging
+
 import numpy as np
 
 from . import problems as P
 from .context import MiviContext
 from .families import MvLocationScale, destructure
+
+
+_log = logging.getLogger("advancedvi_jl_amd")
 
 
 # --- entropy estimators (src/algorithms/entropy.jl) -----------------------------------------------
@@ -48,10 +53,14 @@ class StickingTheLandingEntropyZeroGradient(AbstractEntropyEstimator):  # entrop
 
 
 class AutoMIVI:
-    """ADTypes.AbstractADType subtype selecting libmivi's closed-form VJP instead of an AD backend."""
+    """ADTypes.AbstractADType subtype selecting libmivi's closed-form VJP instead of an AD backend for the ESTIMATOR.
+    `target_ad`: the backend that differentiates an ORDER-0 target's `logdensity` on the host (the reference differentiates through it
+    with `adtype` itself, repgradelbo.jl:50-57; here the estimator needs no AD, so only the target's own gradient is left to provide):
+    "forwarddiff" (dual numbers, `forwarddiff.py`) or None = reject order-0 targets."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, target_ad="forwarddiff"):
         self.device = device
+        self.target_ad = target_ad
 
 
 class PhiloxRNG:
@@ -118,6 +127,35 @@ class RepGradELBOState:
         self.obj_ad_prep = ctx
 
 
+def _order0(prob) -> bool:
+    """capability < LogDensityOrder{1}() (repgradelbo.jl:50-51), looking through a TransformedProblem like README.md:115-119."""
+    inner = prob.prob if isinstance(prob, P.TransformedProblem) else prob
+    return not isinstance(inner, P.BUILTIN) and P.capabilities(inner) < P.LogDensityOrder(1)
+
+
+def _ad_problem(adtype, prob, announce=True):
+    """The capability dispatch of `init` / `set_objective_state_problem` (repgradelbo.jl:31-39, 50-62).  Order >= 1: the problem's own
+    `logdensity_and_gradient` is used (the MixedADLogDensityProblem route).  Order 0: the reference differentiates through `logdensity`
+    with the AD backend; AutoMIVI's estimator has none, so the TARGET is wrapped in ADgradient(adtype.target_ad, prob) -- what
+    README.md:168-174 does by hand -- and the reference's @info is emitted."""
+    if not _order0(prob):
+        return prob
+    kind = getattr(adtype, "target_ad", None)
+    cap = P.capabilities(prob.prob if isinstance(prob, P.TransformedProblem) else prob)
+    if kind is None:
+        raise TypeError(
+            f"The capability of the supplied LogDensityProblem {cap} is less than LogDensityOrder{{1}}(): "
+            "AutoMIVI(target_ad=None) has no AD backend to differentiate `logdensity`; supply `logdensity_and_gradient` "
+            "or construct AutoMIVI(target_ad=\"forwarddiff\").")
+    if announce:
+        _log.info("The capability of the supplied `LogDensityProblem` %s is less than %s. `AdvancedVI` will attempt to directly "
+                  "differentiate through `LogDensityProblems.logdensity`. If this is not intended, please supply a log-density problem "
+                  "with capability at least %s", cap, P.LogDensityOrder(1), P.LogDensityOrder(1))
+    if isinstance(prob, P.TransformedProblem):   # the bijector stays on the device; AD only sees the constrained-scale target
+        return P.TransformedProblem(P.ADgradient(kind, prob.prob), prob.bijector)
+    return P.ADgradient(kind, prob)
+
+
 def _make_ctx(rng, obj, adtype, q, prob, n_mc=None, entropy=None):
     if not isinstance(q, MvLocationScale):
         raise TypeError("libmivi implements the RepGradELBO path for MvLocationScale families only")
@@ -130,21 +168,25 @@ def _make_ctx(rng, obj, adtype, q, prob, n_mc=None, entropy=None):
 
 def init(rng, obj: RepGradELBO, adtype, q, prob, params, restructure) -> RepGradELBOState:
     """AdvancedVI.init(rng, obj::RepGradELBO, adtype, q, prob, params, restructure): repgradelbo.jl:41-70.
-    The capability dispatch of :50-62 collapses: libmivi always takes the `logdensity_and_gradient`
-    route (order >= 1); order-0 targets are rejected because there is no AD to differentiate them."""
+    The capability dispatch of :50-62: order >= 1 problems are used through `logdensity_and_gradient`; an order-0 problem (only
+    `logdensity`: the README model, README.md:64-66, and the benchmark target, bench/benchmarks.jl:39-41) is differentiated on the host
+    by `adtype.target_ad` with the reference's @info -- see `_ad_problem`."""
     if not isinstance(adtype, AutoMIVI):
         raise TypeError("adtype must be AutoMIVI() for the libmivi path")
-    if not isinstance(prob, P.BUILTIN) and P.capabilities(prob) < P.LogDensityOrder(1):
-        raise TypeError(
-            f"The capability of the supplied LogDensityProblem {P.capabilities(prob)} is less than LogDensityOrder{{1}}(): "
-            "AutoMIVI() has no AD backend to differentiate `logdensity`; supply `logdensity_and_gradient`.")
-    return RepGradELBOState(prob, _make_ctx(rng, obj, adtype, q, prob))
+    ad_prob = _ad_problem(adtype, prob)
+    st = RepGradELBOState(ad_prob, _make_ctx(rng, obj, adtype, q, ad_prob))
+    st.adtype = adtype
+    return st
 
 
 def set_objective_state_problem(state: RepGradELBOState, prob) -> RepGradELBOState:
-    """repgradelbo.jl:31-39."""
-    state.obj_ad_prep.set_problem(prob)
-    return RepGradELBOState(prob, state.obj_ad_prep)
+    """repgradelbo.jl:31-39 (the same capability dispatch as `init`, without the @info)."""
+    adtype = getattr(state, "adtype", None)
+    ad_prob = _ad_problem(adtype, prob, announce=False) if adtype is not None else prob
+    state.obj_ad_prep.set_problem(ad_prob)
+    st = RepGradELBOState(ad_prob, state.obj_ad_prep)
+    st.adtype = adtype
+    return st
 
 
 def estimate_gradient_(rng, obj: RepGradELBO, adtype, out: DiffResult, state: RepGradELBOState, params, restructure,

@@ -34,6 +34,37 @@ def capabilities(prob) -> LogDensityOrder:
     return LogDensityOrder(1 if hasattr(prob, "logdensity_and_gradient") else 0)
 
 
+class ADgradient:
+    """LogDensityProblemsAD.ADgradient(kind, prob) (README.md:168-174): an order-0 problem (only `logdensity`) wrapped so that it
+    provides `logdensity_and_gradient`.  kind "forwarddiff" = forward-mode dual numbers over numpy (`forwarddiff.py`; BASELINE.json
+    configs[0] names ForwardDiff on the CPU).  `logdensity` must be written with numpy ufuncs / the array functions listed there."""
+
+    KINDS = ("forwarddiff",)
+
+    def __init__(self, kind, prob, chunk: int = 64):
+        if kind not in self.KINDS:
+            raise ValueError(f"ADgradient: unknown backend {kind!r} (available: {self.KINDS})")
+        if not hasattr(prob, "logdensity"):
+            raise TypeError("ADgradient: the problem must implement logdensity")
+        self.kind, self.prob, self.chunk = kind, prob, int(chunk)
+
+    def dimension(self):
+        return dimension(self.prob)
+
+    def capabilities(self):
+        return LogDensityOrder(1)
+
+    def logdensity(self, x):
+        return self.prob.logdensity(x)
+
+    def logdensity_and_gradient(self, x):
+        from . import forwarddiff
+        return forwarddiff.value_and_gradient(self.prob.logdensity, np.asarray(x, dtype=np.float64), self.chunk)
+
+    def subsample(self, batch):   # AdvancedVI.subsample forwards to the wrapped problem (src/AdvancedVI.jl:313)
+        return ADgradient(self.kind, subsample(self.prob, batch), self.chunk)
+
+
 class DiagNormalProblem:
     """MvNormal(mean, Diagonal(std.^2)) -- test/models/normal.jl:56-75, bench/benchmarks.jl:43-47."""
 

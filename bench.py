@@ -36,7 +36,7 @@ PLANE_BYTES = 4                 # bytes per operand-plane element of the batch e
 PEAK_VALU_GINST = 1024 * 2.4 / 4   # wave64 vector instructions per ns: 256 CUs x 4 SIMDs, one per 4 cycles, 2.4 GHz (MI355X_MICROARCH.md)
 
 # environment variables that do NOT change which kernels run: bench-harness controls and the RCCL library location
-BENCH_ENV_OK = {"MIVI_LR_NO_PLANES", "MIVI_LR_NO_XPLANES", "MIVI_FORCE_DIST", "MIVI_DIST_MODE", "MIVI_DIST_EAGER", "MIVI_BENCH_SKIP_C3", "MIVI_RCCL_LIB", "MIVI_DIST_PIPELINE"}
+BENCH_ENV_OK = {"MIVI_FORCE_DIST", "MIVI_DIST_MODE", "MIVI_DIST_EAGER", "MIVI_BENCH_SKIP_C3", "MIVI_RCCL_LIB", "MIVI_DIST_PIPELINE"}
 
 WORKLOADS = {
     "ns": dict(family=1, d=1024, n_mc=256, target="iso", entropy=0,

@@ -641,10 +641,10 @@ def proximal_location_scale_entropy(params, d, family, stepsize):
     out = np.array(params, dtype=np.float64, copy=True)
     idx = d + np.arange(d) if family == MEANFIELD else d + np.arange(d) * (d + 1)
     c = out[idx]
-    rt = np.sqrt(c * c + 4.0 * stepsize)
-    # (c < 0: the same value without the cancellation, 2 gamma / (sqrt(c^2 + 4 gamma) - c) -- equal in exact arithmetic; what the device evaluates)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        out[idx] = np.where(c < 0.0, 2.0 * stepsize / (rt - c), c + (rt - c) / 2.0)
+    # the reference's literal expression, in f64 (no cancellation problem at any magnitude a test uses).  The DEVICE evaluates, for c < 0,
+    # 2 gamma / (sqrt(c^2 + 4 gamma) - c): equal in exact arithmetic, but positive in Float32 where the literal form cancels to 0 -- a
+    # deliberate, documented behavioural difference; tests assert the two agree to rounding.
+    out[idx] = c + (np.sqrt(c * c + 4.0 * stepsize) - c) / 2.0
     if family != MEANFIELD:   # restructure -> destructure re-projects onto LowerTriangular
         out[d:] = np.tril(out[d:].reshape(d, d, order="F")).reshape(-1, order="F")
     return out

@@ -58,6 +58,60 @@ class OraclePlugin:
         return self.tgt.logdensity_and_gradient(np.asarray(z, dtype=np.float64))
 
 
+class ReadmeLogReg:
+    """The reference README's model, restated line by line (README.md:42-66): theta = [beta; sigma] on the CONSTRAINED scale,
+    `logdensity` only, capabilities LogDensityOrder{0}() -- the reference differentiates through it (repgradelbo.jl:50-57)."""
+
+    def __init__(self, X, y):
+        self.X, self.y = np.asarray(X, dtype=np.float64), np.asarray(y, dtype=np.float64)
+        self.calls = 0
+
+    def logdensity(self, theta):
+        self.calls += 1
+        X, y = self.X, self.y
+        d = X.shape[1]
+        beta, sigma = theta[:d], theta[d]
+        logprior_beta = -0.5 * np.sum(beta * beta) / (sigma * sigma) - d * np.log(sigma) - 0.5 * d * np.log(2 * np.pi)   # MvNormal(Zeros(d), sigma)
+        logprior_sigma = -np.log(sigma) - np.log(3.0) - 0.5 * np.log(2 * np.pi) - np.log(sigma) ** 2 / 18.0              # LogNormal(0, 3)
+        logit = X @ beta
+        loglike_y = np.sum(y * logit - np.logaddexp(0.0, logit))                                                         # BernoulliLogit
+        return loglike_y + logprior_beta + logprior_sigma
+
+    def dimension(self):
+        return self.X.shape[1] + 1
+
+    def capabilities(self):
+        return avi.LogDensityOrder(0)
+
+
+def readme_bijector(p):
+    """README.md:76-82: Stacked([identity on beta, log-bijector on sigma]), inverted (theta = binv(eta))."""
+    return avi.StackedBijector([(0, p, "identity"), (p, p + 1, "exp")])
+
+
+class BenchDist:
+    """bench/benchmarks.jl:25-47: `Dist(MvNormal(fill(5, d), I))` -- it HAS logdensity_and_gradient but declares
+    LogDensityOrder{0}(), so the reference differentiates through `logdensity` and never calls it."""
+
+    def __init__(self, n_dims=10):
+        self.mu = np.full(n_dims, 5.0)
+        self.grad_calls = 0
+
+    def logdensity(self, x):
+        r = x - self.mu
+        return -0.5 * np.sum(r * r) - 0.5 * self.mu.size * np.log(2 * np.pi)
+
+    def logdensity_and_gradient(self, x):
+        self.grad_calls += 1
+        return self.logdensity(x), -(np.asarray(x) - self.mu)
+
+    def dimension(self):
+        return self.mu.size
+
+    def capabilities(self):
+        return avi.LogDensityOrder(0)
+
+
 def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)

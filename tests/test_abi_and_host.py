@@ -235,7 +235,9 @@ def test_rng_counter_semantics():
     assert c.next_index() == 3 and r.next_index() == 3
 
 
-def test_order0_plugin_is_rejected():
+def test_order0_plugin_is_rejected_only_without_a_target_ad():
+    """AutoMIVI(target_ad=None): strict mode, the TypeError comes before any native resource exists (with the default
+    target_ad="forwarddiff" the problem is wrapped instead: tests/test_forwarddiff_host.py, test_gpu_baseline_configs.py)."""
     class Order0:
         def dimension(self):
             return 2
@@ -246,7 +248,7 @@ def test_order0_plugin_is_rejected():
     q = avi.MeanFieldGaussian(np.zeros(2), np.ones(2))
     p, re_ = avi.destructure(q)
     with pytest.raises(TypeError, match="LogDensityOrder"):
-        avi.init(avi.PhiloxRNG(1), avi.RepGradELBO(2), avi.AutoMIVI(), q, Order0(), p, re_)
+        avi.init(avi.PhiloxRNG(1), avi.RepGradELBO(2), avi.AutoMIVI(target_ad=None), q, Order0(), p, re_)
 
 
 def test_shard_plan():

@@ -25,6 +25,68 @@ pytestmark = pytest.mark.gpu
 C3_GRAD_RTOL = 2e-5
 
 
+def test_c1_readme_model_from_logdensity_alone_through_automivi(caplog):
+    """BASELINE configs[0] as the reference's README runs it: the model declares LogDensityOrder{0}() and only `logdensity`
+    (README.md:42-66), wrapped in the TransformedLogDensityProblem of README.md:91-119; `init` emits the reference's @info and
+    differentiates through `logdensity` (repgradelbo.jl:50-57) -- here with the host's forward-mode provider, configs[0]'s "ForwardDiff
+    on CPU".  Nothing hands the plugin a gradient: the oracle's closed-form LogReg gradient is only the CHECK."""
+    import logging
+    from tests.helpers import ReadmeLogReg, readme_bijector
+    rng = np.random.default_rng(11)
+    n, p = 1000, 32
+    X = np.hstack([rng.normal(size=(n, p - 1)), np.ones((n, 1))])           # intercept column, README.md:139-140
+    beta = rng.normal(size=p)
+    y = (rng.uniform(size=n) < 1 / (1 + np.exp(-X @ beta))).astype(float)
+    d, M = p + 1, 16
+    model = ReadmeLogReg(X, y)
+    prob = avi.TransformedProblem(model, readme_bijector(p))
+    assert avi.capabilities(prob) < avi.LogDensityOrder(1)
+    q = avi.MeanFieldGaussian(np.zeros(d), np.ones(d))                        # q0 of README.md:184
+    params, re = avi.destructure(q)
+    obj, ad = avi.RepGradELBO(M), avi.AutoMIVI()
+    with caplog.at_level(logging.INFO, logger="advancedvi_jl_amd"):
+        st = avi.init(avi.PhiloxRNG(SEED), obj, ad, q, prob, params, re)
+    assert "directly differentiate through `LogDensityProblems.logdensity`" in caplog.text
+    ctx = st.obj_ad_prep
+    out = avi.DiffResult(ctx.empty(1), ctx.empty(ctx.params_len))
+    _, eps = ctx.sample(params, 0)
+    model.calls = 0
+    _, _, info = avi.estimate_gradient_(avi.PhiloxRNG(SEED, 0), obj, ad, out, st, ctx.to_device(params), re)
+    assert model.calls == M                                                   # one dual-number sweep (chunk 64 >= 33 partials) per column
+    tgt = O.LogRegTarget(X, y, "lognormal_exp_bijector")
+    ref = O.estimate_gradient(params, d, O.MEANFIELD, tgt, eps.cpu().numpy(), 0)
+    assert abs(out.value() - ref["value"]) <= 1e-12 * abs(ref["value"])
+    assert float(info["elbo"]) == -out.value()
+    assert rel_err(out.gradient().cpu().numpy(), ref["grad"]) < 1e-11
+    # estimate_objective only needs `logdensity` (repgradelbo.jl:112-118): the order-0 problem goes in unwrapped
+    v = avi.estimate_objective(avi.PhiloxRNG(SEED, 7), obj, q, prob, n_samples=64)
+    assert np.isfinite(v)
+    # the README's run (README.md:150-200 in outline): KLMinRepGradDescent + ClipScale from `logdensity` alone; the ELBO improves
+    alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), n_samples=M, optimizer=avi.Adam(1e-2), operator=avi.ClipScale())
+    _, info, _ = avi.optimize(avi.PhiloxRNG(SEED), alg, 60, prob, q)
+    assert np.mean([float(i["elbo"]) for i in info[-10:]]) > np.mean([float(i["elbo"]) for i in info[:10]]) + 50.0
+    ctx.close()
+
+
+def test_reference_benchmark_target_order0_optimize():
+    """bench/benchmarks.jl:25-94: `Dist(MvNormal(fill(5, 10), I))` declares LogDensityOrder{0}() (it has logdensity_and_gradient, which the
+    reference therefore never calls), Float64, Adam(1e-3), ClipScale, both families and both entropies.  Through AutoMIVI unchanged: the
+    trajectory equals the one of the built-in device target (same eps stream, f64) to rounding, and the problem's own gradient is unused."""
+    from tests.helpers import BenchDist
+    d = 10
+    for fam in (avi.MEANFIELD, avi.FULLRANK):
+        q0 = (avi.MeanFieldGaussian(np.zeros(d), np.ones(d)) if fam == avi.MEANFIELD else avi.FullRankGaussian(np.zeros(d), np.eye(d)))
+        for ent in (avi.ClosedFormEntropy(), avi.StickingTheLandingEntropy()):
+            alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), optimizer=avi.Adam(1e-3), entropy=ent, operator=avi.ClipScale())
+            prob = BenchDist(d)
+            qa, ia, _ = avi.optimize(avi.PhiloxRNG(SEED), alg, 40, prob, q0)
+            qb, ib, _ = avi.optimize(avi.PhiloxRNG(SEED), alg, 40, avi.DiagNormalProblem(np.full(d, 5.0), np.ones(d)), q0)
+            assert prob.grad_calls == 0
+            assert np.allclose(qa.location, qb.location, rtol=1e-10, atol=1e-12)
+            assert np.allclose(np.asarray(qa.scale), np.asarray(qb.scale), rtol=1e-10, atol=1e-12)
+            assert np.allclose([float(i["elbo"]) for i in ia], [float(i["elbo"]) for i in ib], rtol=1e-10)
+
+
 def test_c1_readme_logreg_plugin_route():
     rng = np.random.default_rng(11)
     n, p = 1000, 32

@@ -120,7 +120,9 @@ def test_row_selection_on_a_data_set_with_operand_planes():
     ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
     ctx.set_logreg_route(1)
     seen = []
-    for batch in (None, rng.permutation(n)[:1700], None, np.arange(0, n, 2), None):
+    # two minibatches of the SAME size around a full-data estimate: the full-data route overwrites the scratch the minibatch route's
+    # zero pad rows live in (n_sub % 16 != 0), so those rows must be re-zeroed -- round 5's advisor finding
+    for batch in (None, rng.permutation(n)[:1700], None, rng.permutation(n)[:1700], None, np.arange(0, n, 2), None):
         if batch is None:
             ctx.set_problem(prob)
             t = tgt
@@ -133,7 +135,7 @@ def test_row_selection_on_a_data_set_with_operand_planes():
         v, g = ctx.estimate_gradient(params, 9)
         assert abs(float(v.item()) - ref["value"]) <= 2e-5 * abs(ref["value"])
         assert np.linalg.norm(g.cpu().numpy() - ref["grad"]) <= 5e-5 * max(np.linalg.norm(ref["grad"]), 1.0)
-    assert seen == [True, False, True, False, True]
+    assert seen == [True, False, True, False, True, False, True]
     ctx.close()
 
 
