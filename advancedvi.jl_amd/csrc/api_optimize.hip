@@ -87,10 +87,12 @@ static bool same_loop(const mivi_loop_t &a, const mivi_loop_t &b) {   // everyth
 static mivi_status_t optimize_loop_run(mivi_ctx_t *c, void *params, const mivi_loop_t *lp, bool allow_exchange, bool *used_exchange) {
   const mivi_loop_t &l = *lp;
   const int n_steps = l.n_steps, rule = l.rule;
-  if (n_steps <= 0 || rule < 0 || rule > 3 || l.op < 0 || l.op > 2 || l.averager < 0 || l.averager > 1) return MIVI_ERR_BAD_ARG;
+  if (n_steps <= 0 || rule < 0 || rule > 4 || l.op < 0 || l.op > 2 || l.averager < 0 || l.averager > 1) return MIVI_ERR_BAD_ARG;
   if (rule != 0 && !l.opt_state_dev) return fail(c, MIVI_ERR_BAD_ARG, "this optimisation rule needs opt_state_dev");
   if (l.averager == 1 && !l.avg_params_dev) return fail(c, MIVI_ERR_BAD_ARG, "PolynomialAveraging needs avg_params_dev");
-  if (l.op == 2 && rule == 1) return fail(c, MIVI_ERR_BAD_ARG, "ProximalLocationScaleEntropy does not support Adam (Descent, DoG, DoWG)");
+  if (l.op == 2 && (rule == 1 || rule == 4)) return fail(c, MIVI_ERR_BAD_ARG, "ProximalLocationScaleEntropy does not support Adam / COCOB (Descent, DoG, DoWG: proximal_location_scale_entropy.jl:26-42)");
+  const bool dog = rule == 2 || rule == 3;        // the rules with two global norms per step
+  const bool loops_know = rule <= 3;              // the launch-free loops implement rules 0..3; COCOB (4) runs on the graph of launches
   if (!graph_capturable(c)) return fail(c, MIVI_ERR_UNSUPPORTED, "device-resident loop needs a built-in target");
   if (c->idx_src) return fail(c, MIVI_ERR_UNSUPPORTED, "an index source is set (mivi_set_index_source): the device-resident loop keeps its own counter");
   (void)hipSetDevice(c->cfg.device);
@@ -123,7 +125,7 @@ static mivi_status_t optimize_loop_run(mivi_ctx_t *c, void *params, const mivi_l
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);
   }
-  if (lr_small_loop_ok(c) && !no_fused_loop && allow_exchange) {
+  if (loops_know && lr_small_loop_ok(c) && !no_fused_loop && allow_exchange) {
     // small hierarchical logistic regressions (the reference README's own example, BASELINE configs[0]): the whole loop in ONE workgroup, every
     // rule x operator x averager (k_lr_small_loop); larger ones: up to 64 workgroups that exchange partial sums every step
     if (lr_small_part_bytes(c, n_steps) && (s = ensure(c, c->gen_scratch, lr_small_part_bytes(c, n_steps) + 256, false))) return s;
@@ -136,7 +138,7 @@ static mivi_status_t optimize_loop_run(mivi_ctx_t *c, void *params, const mivi_l
     }
   }
   const bool general = !simple || (rule == 1 && !default_adam);   // (Adam with other betas than the fused paths' defaults: the general loops take them from the call)
-  if (general && mf_gen_loop_ok(c, rule) && !no_fused_loop && (rule < 2 || allow_exchange)) {
+  if (general && loops_know && mf_gen_loop_ok(c, rule) && !no_fused_loop && (rule < 2 || allow_exchange)) {
     // every other rule x operator x averager of the reference's algorithms (DoG / DoWG, ProximalLocationScaleEntropy, PolynomialAveraging -- its
     // defaults), mean-field + diagonal-Gaussian target: launch-free as well (k_mf_gen_loop; DoG / DoWG: one grid-wide exchange of two norms per step)
     if ((s = ensure(c, c->gen_scratch, mf_gen_loop_scratch_bytes(c, n_steps), false))) return s;
@@ -148,7 +150,7 @@ static mivi_status_t optimize_loop_run(mivi_ctx_t *c, void *params, const mivi_l
       return read_status(c);
     }
   }
-  if (general && fr_small_loop_ok(c) && !no_fused_loop) {
+  if (general && loops_know && fr_small_loop_ok(c) && !no_fused_loop) {
     // ... and small full-rank problems in one workgroup (k_fr_small_loop: the two norms of DoG / DoWG are block sums there)
     HIPCHK(c, hipMemsetAsync(c->status.p, 0, sizeof(int) * (1 + mivi_ctx::kMaxKids), c->stream));
     launch_fr_small_loop(c, params, opt_state, l.estimate_idx0, (long long)l.t0, n_steps, rule, eta, clip_eps, rec, vbuf, &l);
@@ -156,7 +158,7 @@ static mivi_status_t optimize_loop_run(mivi_ctx_t *c, void *params, const mivi_l
     if ((s = deliver_elbo(c, rec, n_steps, l.elbo_dev))) return s;
     return read_status(c);
   }
-  if (general && fr_rows_loop_ok(c) && (rule < 2 || allow_exchange) && !no_fused_loop && fr_rows_eps_bytes(c, n_steps) <= ((size_t)1 << 31)) {
+  if (general && loops_know && fr_rows_loop_ok(c) && (rule < 2 || allow_exchange) && !no_fused_loop && fr_rows_eps_bytes(c, n_steps) <= ((size_t)1 << 31)) {
     // ... and on the full-rank family with few samples per step (the reference's default n_samples = 1): the row-owning workgroups of
     // k_fr_rows_loop, DoG / DoWG with the same per-step exchange of two norm partials (every workgroup resident: checked by the launcher)
     if ((s = ensure(c, c->rows_eps, fr_rows_eps_bytes(c, n_steps), false))) return s;
@@ -247,13 +249,14 @@ static mivi_status_t optimize_loop_run(mivi_ctx_t *c, void *params, const mivi_l
       // Optimisers.update! (common.jl:92); ClipScale rides in the Descent / Adam kernels
       if (rule == 0) launch_descent(c, params, gbuf, eta, clip_eps);
       else if (rule == 1) launch_adam(c, params, gbuf, opt_state, (const int64_t *)t_ptr, (int64_t)i + 1, eta, l.beta1, l.beta2, l.adam_eps, clip_eps);
+      else if (rule == 4) launch_cocob(c, params, gbuf, opt_state, eta /* = alpha */, clip_eps);   // rules.jl:78-96; ClipScale rides in the kernel
       else if (l.op <= 1 && launch_dog_update_fused(c, params, gbuf, opt_state, rule - 2, clip_eps,
                                                      l.averager == 1 ? l.avg_params_dev : nullptr, l.avg_eta, t_ptr, (long long)i + 1))
         continue;   // DoG / DoWG + ClipScale + averaging in one apply pass (large parameter vectors)
       else launch_dog_update(c, params, gbuf, opt_state, rule - 2);
       // operator (common.jl:93-95)
-      if (l.op == 1 && rule >= 2) launch_clip(c, params, clip_eps);
-      if (l.op == 2) launch_prox(c, params, eta, rule >= 2 ? opt_state : nullptr, rule - 2);
+      if (l.op == 1 && dog) launch_clip(c, params, clip_eps);
+      if (l.op == 2) launch_prox(c, params, eta, dog ? opt_state : nullptr, rule - 2);
       // averager (common.jl:96)
       if (l.averager == 1) launch_poly_average(c, l.avg_params_dev, params, l.avg_eta, t_ptr, (long long)i + 1);
     }
@@ -284,10 +287,10 @@ mivi_status_t mivi_optimize_loop(mivi_ctx_t *c, void *params, const mivi_loop_t 
   const mivi_loop_t &l = *lp;
   (void)hipSetDevice(c->cfg.device);
   const size_t plen = (size_t)mivi_params_len(c), es = c->esize;
-  const size_t st_bytes = !l.opt_state_dev ? 0 : (l.rule == 1 ? 2 * plen * es : (l.rule >= 2 ? (size_t)mivi_dog_state_bytes(c) : 0));
+  const size_t st_bytes = !l.opt_state_dev ? 0 : (l.rule == 1 ? 2 * plen * es : (l.rule == 4 ? 5 * plen * es : (l.rule >= 2 ? (size_t)mivi_dog_state_bytes(c) : 0)));
   const size_t avg_bytes = (l.averager == 1 && l.avg_params_dev) ? plen * es : 0;
-  const bool may_exchange = !c->exchange_lost && (l.rule >= 2 || c->target == TGT_FUNNEL || c->target == TGT_LOGREG);
-  if (may_exchange && l.n_steps > 0 && l.rule >= 0 && l.rule <= 3) {
+  const bool may_exchange = !c->exchange_lost && (l.rule == 2 || l.rule == 3 || c->target == TGT_FUNNEL || c->target == TGT_LOGREG);
+  if (may_exchange && l.n_steps > 0 && l.rule >= 0 && l.rule <= 4) {
     mivi_status_t s = ensure(c, c->snap, plen * es + st_bytes + avg_bytes + 64, false);
     if (s) return s;
     char *sp = (char *)c->snap.p;

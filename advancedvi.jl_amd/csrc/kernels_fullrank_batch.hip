@@ -941,6 +941,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
 namespace {
 constexpr int kBM = 128, kBN = 128;
 constexpr int kWJ = FB_WJ;      // 32-column blocks per wave (k_fb_prod / k_fb_vjp): 2 = four waves of 64 x 64 per tile, 1 = eight waves of 64 x 32
+constexpr int kOwnCuTilesPerCU10 = 17;   // (x 0.1) tiles per CU up to which the triangular products keep one workgroup per CU (fb_launch_compute)
 constexpr int kPFvjp = FB_PF_VJP;   // the product: register prefetch + one workgroup per CU (its heaviest tile must own a CU); the VJP: two plain workgroups per CU (equal tiles)
 
 void fb_upload(DevBuf &b, const void *src, size_t bytes) {
@@ -1152,11 +1153,17 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
 #endif
   a.work = (const int4 *)tb.prod.p; a.n_work = tb.n_prod;
   // One workgroup per CU (eight ring slots) where a step's heaviest tiles pace the launch and a second workgroup on their CU only slows them:
-  // measured at the north star (us, 4 / 8 slots): 16 lanes 23.1 / 23.4, 20: 27.6 / 23.8, 24: 28.9 / 27.7, 28: 30.7 / 30.9, 40: 37.9 / 44.5
-  const bool own_cu = s.L >= 17 && s.L <= 26;
+  // measured at the north star (us, 4 / 8 slots): 16 lanes 23.1 / 23.4, 20: 27.6 / 23.8, 24: 28.9 / 27.7, 28: 30.7 / 30.9, 40: 37.9 / 44.5.
+  // Round 6: the rule is on the LAUNCH'S SHAPE, not on the lane count (round 5 keyed it on 17 <= L <= 26, a window around the north star's
+  // 20-lane step that is wrong 4x off at d = 512 or n_mc = 512): the eight-slot ring pays where the triangular product's tiles number between
+  // one and kOwnCuTilesPerCU10 / 10 per CU -- fewer: every tile has a CU to itself either way (measured equal); more: throughput, i.e. two
+  // workgroups per CU covering each other's barriers and epilogues, decides.  The dense target's second product has EQUAL tiles (all of K):
+  // it never takes the one-per-CU ring (20 lanes: 320 tiles would run as two rounds on 256 CUs -- 46.0 against 54.7 us measured).
+  const int n_cu = c->n_cu > 0 ? c->n_cu : 256;
+  auto own_cu_for = [&](int n, bool equal_tiles) { return !equal_tiles && n > n_cu && 10 * (long long)n <= (long long)kOwnCuTilesPerCU10 * n_cu; };
   auto prod = [&](auto MODE, int n) {
     constexpr int md = decltype(MODE)::value;
-    if (own_cu) hipLaunchKernelGGL((k_fb_prod<kWJ, md, 8>), dim3(n), dim3(512 / kWJ), 0, stream, a);
+    if (own_cu_for(n, md == FB_DENSE_G)) hipLaunchKernelGGL((k_fb_prod<kWJ, md, 8>), dim3(n), dim3(512 / kWJ), 0, stream, a);
     else hipLaunchKernelGGL((k_fb_prod<kWJ, md, 4>), dim3(n), dim3(512 / kWJ), 0, stream, a);
   };
   if (s.dense) {

@@ -265,6 +265,8 @@ loop_rule(o::Optimisers.Adam) = (Int32(1), Float64(o.eta), Float64(o.beta[1]), F
 # ([x0 (n T), padded to 8 bytes; v, r as Float64]); the step size needs two global norms per step, exchanged inside the launch-free loops
 loop_rule(::AdvancedVI.DoG) = (Int32(2), 0.0, 0.9, 0.999, 1e-8)
 loop_rule(::AdvancedVI.DoWG) = (Int32(3), 0.0, 0.9, 0.999, 1e-8)
+# COCOB (src/optimization/rules.jl:66-96): state (L, G, R, theta, x1) as T[5 n] on the device; alpha travels in the loop's `eta` field
+loop_rule(o::AdvancedVI.COCOB) = (Int32(4), Float64(o.alpha), 0.9, 0.999, 1e-8)
 loop_rule(::Any) = nothing
 loop_op(::AdvancedVI.IdentityOperator) = (Int32(0), 0.0)
 loop_op(o::AdvancedVI.ClipScale) = (Int32(1), Float64(o.epsilon))
@@ -280,7 +282,7 @@ function AdvancedVI.optimize(rng::Random.AbstractRNG, alg::KLMinRepGradDescent{<
                              objargs...; show_progress::Bool = true, state = nothing, callback = nothing, kwargs...)
     codes = (loop_rule(alg.optimizer), loop_op(alg.operator), loop_avg(alg.averager))
     fast = callback === nothing && isempty(objargs) && prob isa NativeTarget && q_init isa MvLocationScale && all(!isnothing, codes) &&
-           !(codes[2][1] == 2 && codes[1][1] == 1)   # (the proximal operator takes its step size from Descent / DoG / DoWG: proximal_location_scale_entropy.jl:26-42 has no Adam method)
+           !(codes[2][1] == 2 && (codes[1][1] == 1 || codes[1][1] == 4))   # (the proximal operator takes its step size from Descent / DoG / DoWG: proximal_location_scale_entropy.jl:26-42 has no Adam method)
     if !fast   # the reference's own loop (host-driven `step`, this module's estimate_gradient!)
         return invoke(AdvancedVI.optimize, Tuple{Random.AbstractRNG,AdvancedVI.AbstractVariationalAlgorithm,Int,Any,Any,Vararg{Any}},
                       rng, alg, max_iter, prob, q_init, objargs...; show_progress, state, callback, kwargs...)
@@ -293,12 +295,16 @@ function AdvancedVI.optimize(rng::Random.AbstractRNG, alg::KLMinRepGradDescent{<
     (rule, eta, b1, b2, aeps), (op, ceps), (avg, aeta) = codes
     # device buffers: parameters, optimiser state (Adam: m; v), running average, per-iteration elbo
     p_dev = dev_alloc(n * sizeof(T)); h2d(p_dev, params)
-    dog_bytes = rule >= 2 ? Int(ccall((:mivi_dog_state_bytes, libmivi), Int64, (Ptr{Cvoid},), st.ctx)) : 0
-    o_dev = rule == 1 ? dev_alloc(2n * sizeof(T)) : (rule >= 2 ? dev_alloc(dog_bytes) : Ptr{Cvoid}(C_NULL))
-    if rule == 1
+    isdog = rule == 2 || rule == 3
+    dog_bytes = isdog ? Int(ccall((:mivi_dog_state_bytes, libmivi), Int64, (Ptr{Cvoid},), st.ctx)) : 0
+    o_dev = rule == 1 ? dev_alloc(2n * sizeof(T)) : (rule == 4 ? dev_alloc(5n * sizeof(T)) : (isdog ? dev_alloc(dog_bytes) : Ptr{Cvoid}(C_NULL)))
+    if rule == 4
+        L, G, R, th, x1 = state.opt_st.state     # Optimisers.Leaf(COCOB, (L, G, R, theta, x1)): rules.jl:84-86
+        h2d(o_dev, Vector{T}(vcat(L, G, R, th, x1)))
+    elseif rule == 1
         leaf = state.opt_st                      # Optimisers.Leaf(Adam, (mt, vt, betat)): warm starts keep their moments
         h2d(o_dev, Vector{T}(vcat(leaf.state[1], leaf.state[2])))
-    elseif rule >= 2
+    elseif isdog
         x0, v, r = state.opt_st.state            # Optimisers.Leaf(DoG / DoWG, (x0, v, r)): rules.jl:20-22, 49-51
         h2d(o_dev, Vector{T}(x0))
         h2d(o_dev + (dog_bytes - 16), Float64[v, r])
@@ -332,7 +338,11 @@ function AdvancedVI.optimize(rng::Random.AbstractRNG, alg::KLMinRepGradDescent{<
             d2h(mv, o_dev)
             beta = (T(b1), T(b2))
             opt_st = Optimisers.Leaf(alg.optimizer, (mv[1:n], mv[(n + 1):end], beta .^ (t_done + 1)))
-        elseif rule >= 2
+        elseif rule == 4
+            cs = Vector{T}(undef, 5n)
+            d2h(cs, o_dev)
+            opt_st = Optimisers.Leaf(alg.optimizer, ntuple(k -> cs[((k - 1) * n + 1):(k * n)], 5))
+        elseif isdog
             vr = Vector{Float64}(undef, 2)
             d2h(vr, o_dev + (dog_bytes - 16))
             opt_st = Optimisers.Leaf(alg.optimizer, (state.opt_st.state[1], T(vr[1]), T(vr[2])))   # x0 never moves

@@ -95,7 +95,8 @@ class DoWG(DoG):
 
 class COCOB:
     """src/optimization/rules.jl:78-96 (COCOB-Backprop); state (L, G, R, theta, x1) = (0, 0, 0, 0, params) (:84-86).
-    Runs through the host-driven `step` loop (one update launch per iteration)."""
+    Device-resident in `optimize` (mivi_optimize_loop rule 4: a hipGraph of chained estimates + the update kernel, no host round trip per
+    step); `update` below is the host-driven `step` loop's launch."""
 
     def __init__(self, alpha=100):
         self.alpha = alpha
@@ -259,7 +260,7 @@ def step(rng, alg, state, callback, *objargs):
     return state, False, info
 
 
-_RULES = {Descent: 0, Adam: 1, DoG: 2, DoWG: 3}
+_RULES = {Descent: 0, Adam: 1, DoG: 2, DoWG: 3, COCOB: 4}
 _OPS = {IdentityOperator: 0, ClipScale: 1, ProximalLocationScaleEntropy: 2}
 _AVGS = {NoAveraging: 0, PolynomialAveraging: 1}
 DEVICE_LOOP_CHUNK = 256   # iterations per mivi_optimize_loop call (bounds the work done past a divergence)
@@ -272,7 +273,7 @@ def _device_loop_codes(alg, callback, objargs):
     if callback is not None or objargs or not isinstance(alg.objective, O.RepGradELBO):
         return None
     r, o, a = _RULES.get(type(alg.optimizer)), _OPS.get(type(alg.operator)), _AVGS.get(type(alg.averager))
-    if r is None or o is None or a is None or (o == 2 and r == 1):
+    if r is None or o is None or a is None or (o == 2 and r in (1, 4)):
         return None
     return r, o, a
 
@@ -307,7 +308,7 @@ def _optimize_on_device(rng, alg, max_iter, state, codes, show_progress):
         snap = [t.clone() for t in live]
         try:
             ctx.optimize_loop(params, n, rng.counter, state["iteration"], rule=rule, op=op, averager=avg,
-                              eta=getattr(opt, "eta", 0.0), beta=getattr(opt, "beta", (0.9, 0.999)),
+                              eta=getattr(opt, "alpha", 0.0) if rule == 4 else getattr(opt, "eta", 0.0), beta=getattr(opt, "beta", (0.9, 0.999)),
                               adam_eps=getattr(opt, "epsilon", 1e-8), clip_epsilon=getattr(alg.operator, "epsilon", 0.0),
                               avg_eta=getattr(alg.averager, "eta", 8), opt_state=state["opt_st"], avg_params=avg_params,
                               elbo=elbo)

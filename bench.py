@@ -268,6 +268,8 @@ def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):
                            "dense_product": d_ * d_ * 4 + lanes * 2 * d_ * M_ * 4, "stl_product": d_ * (d_ + 1) // 2 * 4 + lanes * 3 * d_ * M_ * 4}[k]
                     t["algorithmic_bytes_per_launch"] = alg
                     t["over_algorithmic"] = t["bytes_per_launch"] / alg
+                    t["GBs"] = t["bytes_per_launch"] / (tb[k] * 1e-6) / 1e9          # the counters' bytes over THIS run's launch time
+                    t["frac_of_8TBs"] = t["GBs"] / PEAK_HBM_GBS
                 return t
             keep = {k: roof[k] for k in ("kernel", "achieved", "frac", "traffic", "algorithmic_flops_per_launch", "avg_launch_us", "other_contraction")}
             if "single_launch" in roof:
@@ -281,6 +283,15 @@ def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):
             d_, M_ = w["d"], w["n_mc"]
             alg_bytes = {"product": d_ * (d_ + 1) // 2 * 4 + lanes * 2 * d_ * M_ * 4, "vjp": lanes * (2 * d_ * M_ * 4 + d_ * d_ * 4),
                          "dense_product": d_ * d_ * 4 + lanes * 2 * d_ * M_ * 4, "stl_product": d_ * (d_ + 1) // 2 * 4 + lanes * 3 * d_ * M_ * 4}
+            # ... and the bytes the VJP launch MOVES as mivi_estimate_gradient_n lays it out (round 5's verdict: SURVEY 8d charges every lane a
+            # dense d^2 gradient write, but only the caller's lane writes the zeros above the diagonal -- the scratch lanes write the 128 x 128
+            # tiles of the lower triangle): W and eps planes read once, T (T + 1) / 2 tiles per scratch lane, d^2 for the caller's, d/dmu.
+            # `roofline.achieved` / `frac` are on THESE bytes (they agree with the PMC counters to a few percent: `traffic`); the SURVEY 8d
+            # figure stays beside them as `frac_survey_8d`.
+            T_ = d_ // 128
+            moved_vjp = lanes * (2 * d_ * M_ * 4 + d_ * 4) + (lanes - 1) * (T_ * (T_ + 1) // 2) * 128 * 128 * 4 + d_ * d_ * 4
+            survey_bytes = dict(alg_bytes)
+            alg_bytes["vjp"] = moved_vjp
 
             def tf(k):
                 return lanes * kfl[k] / (tb[k] * 1e-6) / 1e12
@@ -291,7 +302,9 @@ def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):
                            frac_16bit_pipe=nprod * tf(k) / PEAK_BF16_MFMA_TF, rocprof_in_chain=rocprof_avg(sub[k], w.get("key", "ns"), lanes))
                       for k in live if k != dk]
             roof.update(bound="hbm", kernel=nm[dk], achieved=gbs(dk), peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs(dk) / PEAK_HBM_GBS,
-                        algorithmic_bytes_per_launch=alg_bytes[dk], algorithmic_flops_per_launch=lanes * kfl[dk], estimates_per_launch=lanes,
+                        algorithmic_bytes_per_launch=alg_bytes[dk], survey_8d_bytes_per_launch=survey_bytes[dk],
+                        achieved_survey_8d=survey_bytes[dk] / (tb[dk] * 1e-6) / 1e9, frac_survey_8d=survey_bytes[dk] / (tb[dk] * 1e-6) / 1e9 / PEAK_HBM_GBS,
+                        algorithmic_flops_per_launch=lanes * kfl[dk], estimates_per_launch=lanes,
                         avg_launch_us=tb[dk], traffic=traffic_of(dk), rocprof_in_chain=rocprof_avg(sub[dk], w.get("key", "ns"), lanes),
                         other_contraction=others[0] if len(others) == 1 else others,
                         draws=dict(kernel="k_fb_eps (Philox + Box-Muller draws of all lanes as operand planes in both orientations)", avg_launch_us=tb["eps"],
@@ -299,7 +312,7 @@ def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):
                                    achieved_GBs=lanes * 2 * PLANE_BYTES * w["d"] * w["n_mc"] / (tb["eps"] * 1e-6) / 1e9,
                                    note="%d bytes per element and orientation written once: bound by the memory side and the vector ALU" % PLANE_BYTES),
                         timing="%d back-to-back launches of each kernel for %d lanes, hipEvents on the launch stream" % (max(5, reps // 10), lanes),
-                        basis="achieved = SURVEY 8d algorithmic bytes of the launch (vjp: lanes x (2 d n_mc + d^2) x 4 B) / launch time; peak = HBM 8 TB/s; frac_f32_mfma = d^2 n_mc flops x lanes / time / 157.3 TF; frac_16bit_pipe = x%d executed / 2500 TF" % nprod,
+                        basis="achieved = bytes the launch moves (vjp: W + eps planes read, lower-triangle tiles written per scratch lane, dense d^2 for the caller's lane) / launch time; peak = HBM 8 TB/s; frac_survey_8d = SURVEY 8d's lanes x (2 d n_mc + d^2) x 4 B instead; traffic = PMC counters; frac_f32_mfma = d^2 n_mc flops x lanes / time / 157.3 TF; frac_16bit_pipe = x%d executed / 2500 TF" % nprod,
                         f32_mfma=dict(achieved_TFLOPs=aL, peak=PEAK_F32_MFMA_TF, frac=aL / PEAK_F32_MFMA_TF),
                         pipe16=dict(products_per_block=nprod, executed_TFLOPs=nprod * aL, peak=PEAK_BF16_MFMA_TF, frac=nprod * aL / PEAK_BF16_MFMA_TF),
                         single_launch=keep)
@@ -605,11 +618,13 @@ def compact_line(full):
             "bound": roof.get("bound"), "kernel": str(roof.get("kernel", ""))[:96],
             "achieved": _num(roof.get("achieved")), "peak": roof.get("peak"), "unit": roof.get("unit"), "frac": _num(roof.get("frac"), 4),
             # the same kernel on the pipe it executes on: split-operand products run on the 16-bit matrix pipe (2.5 PFLOP/s dense)
+            "frac_survey_8d": _num(roof.get("frac_survey_8d"), 4),
             "frac_16bit_pipe": _num(_get(roof, "pipe16", "frac"), 4), "frac_f32_mfma": _num(_get(roof, "f32_mfma", "frac"), 4),
-            "basis": str(roof.get("basis", ""))[:260] or None,
+            "basis": str(roof.get("basis", ""))[:330] or None,
             "avg_launch_us": _num(roof.get("avg_launch_us"), 5), "lanes": lanes,
             "traffic": (None if not tr else {"bytes_per_launch": _num(tr.get("bytes_per_launch")), "lanes": tr.get("lanes_per_launch", lanes),
-                                             "over_algorithmic": _num(tr.get("over_algorithmic"), 3), "src": str(tr.get("profile", ""))[:64] or None}),
+                                             "over_algorithmic": _num(tr.get("over_algorithmic"), 3), "GBs": _num(tr.get("GBs"), 5), "frac_of_8TBs": _num(tr.get("frac_of_8TBs"), 4),
+                                             "src": str(tr.get("profile", ""))[:64] or None}),
             "rocprof_in_chain": (None if not ric else {"avg_us": _num(ric.get("avg_us"), 5), "lanes": ric.get("lanes"), "src": str(ric.get("source", ""))[:64]}),
         }
         oc = roof.get("other_contraction")
@@ -642,7 +657,9 @@ def compact_line(full):
                     also[k + "_us"] = _num(v["us_per_step"], 4)
             elif "us_per_call" in v:
                 also[k] = _num(1e6 / v["us_per_call"], 5)
-        also["units"] = "estimates/s (c2 ns_dense ns_stl c5 c3 ns_host_boundary), steps/s (*_loop, reference_benchmark_grid), calls/s (stein), samples/s (ns_objective_1e5)"
+        if isinstance(full["also"].get("ns_f64"), dict) and "frac_f64_mfma" in full["also"]["ns_f64"]:
+            also["ns_f64_frac_f64_mfma"] = _num(full["also"]["ns_f64"]["frac_f64_mfma"], 3)
+        also["units"] = "estimates/s (c2 ns_dense ns_stl c5 c3 ns_host_boundary ns_f64), steps/s (*_loop, reference_benchmark_grid[_f64]), calls/s (stein), samples/s (ns_objective_1e5)"
     cfg = dict(full.get("config") or {})
     cfg["launch"] = str(cfg.get("launch", ""))[:200]
     cfg["workload"] = str(cfg.get("workload", ""))[:128]
@@ -1312,6 +1329,56 @@ def main():
                                                             note="device-resident loops (mean-field: k_mf_sgd_loop; full-rank: k_fr_small_loop, one workgroup)")
                 except Exception as e:   # noqa: BLE001
                     also["reference_benchmark_grid"] = dict(error=str(e))
+                # ... and in the reference's OWN precision: bench/benchmarks.jl:59 sets T = Float64
+                try:
+                    rb = {}
+                    for nm, fam_r, ent_r in (("meanfield", 0, 0), ("meanfield_stl", 0, 3), ("fullrank", 1, 0), ("fullrank_stl", 1, 3)):
+                        d_r = 10
+                        q_r = (avi.MeanFieldGaussian(np.zeros(d_r), np.ones(d_r)) if fam_r == 0 else avi.FullRankGaussian(np.zeros(d_r), np.eye(d_r)))
+                        p_rh, _ = avi.destructure(q_r)
+                        c_r = avi.MiviContext(np.float64, fam_r, d_r, 1, ent_r, SEED, device=local_rank)
+                        c_r.set_problem(avi.DiagNormalProblem(np.full(d_r, 5.0), np.ones(d_r)))
+                        p_r = c_r.to_device(p_rh).clone()
+                        s_r = c_r.empty(2 * p_r.numel()).zero_()
+                        c_r.optimize_steps(p_r, s_r, 0, 0, 1000, 1, 1e-3, 1e-5)
+                        stream.synchronize()
+                        t0s = time.perf_counter()
+                        c_r.optimize_steps(p_r, s_r, 1000, 1000, 10_000, 1, 1e-3, 1e-5)
+                        stream.synchronize()
+                        t_r = (time.perf_counter() - t0s) / 10_000
+                        rb[nm] = dict(steps_per_s=1.0 / t_r, us_per_step=t_r * 1e6, seconds_for_the_reference_benchmark_run=t_r * 1e4)
+                        c_r.close()
+                    also["reference_benchmark_grid_f64"] = dict(workload="bench/benchmarks.jl:59 as written: T = Float64, normal target d=10, n_samples=1, Adam(1e-3) + ClipScale, 10^4 iterations",
+                                                                value=rb["fullrank"]["steps_per_s"], unit="steps/s", grid=rb)
+                except Exception as e:   # noqa: BLE001
+                    also["reference_benchmark_grid_f64"] = dict(error=str(e))
+                # the north-star shape in Float64 (the reference's tests and benchmark run both precisions, klminrepgraddescent.jl:90-103): one
+                # estimate per launch pair on the f64 MFMA tiles (kernels_fullrank.hip), 20 estimates per call like the headline
+                try:
+                    d_6, M_6 = (w["d"], w["n_mc"]) if w["family"] == 1 else (1024, 256)
+                    q_6 = avi.FullRankGaussian(np.zeros(d_6), np.eye(d_6))
+                    p_6h, _ = avi.destructure(q_6)
+                    c_6 = avi.MiviContext(np.float64, 1, d_6, M_6, 0, SEED, device=local_rank)
+                    c_6.set_problem(avi.DiagNormalProblem(np.full(d_6, 5.0), np.ones(d_6)))
+                    p_6 = c_6.to_device(p_6h).clone()
+                    v_6, g_6 = c_6.empty(1), c_6.empty(c_6.params_len)
+                    c_6.estimate_gradient_n(p_6, 0, 20, v_6, g_6)
+                    stream.synchronize()
+                    t0s = time.perf_counter()
+                    for r in range(10):
+                        c_6.estimate_gradient_n(p_6, 20 * (r + 1), 20, v_6, g_6)
+                    stream.synchronize()
+                    t_6 = (time.perf_counter() - t0s) / 200
+                    PEAK_F64_MFMA_TF = 78.6   # AMD's MI355X product figure for dense FP64 matrix; MI355X_MICROARCH.md lists no f64 peak
+                    also["ns_f64"] = dict(workload=f"north-star shape in Float64: d={d_6} full-rank, n_mc={M_6}, MvNormal(5*1, I), 10 x mivi_estimate_gradient_n x20",
+                                          value=1.0 / t_6, unit="estimates/s", us_per_estimate=t_6 * 1e6,
+                                          f64_mfma_TFs=2.0 * d_6 * d_6 * M_6 / t_6 / 1e12,
+                                          frac_f64_mfma=2.0 * d_6 * d_6 * M_6 / t_6 / 1e12 / PEAK_F64_MFMA_TF,
+                                          hbm_frac_of_8TBs=(d_6 * (d_6 + 1) // 2 + d_6 * d_6 + 4 * d_6 * M_6 + 2 * d_6) * 8 / t_6 / 8e12,
+                                          basis="SURVEY 8d: 2 d^2 n_mc flops (triangular product + tril VJP) and [d(d+1)/2 + d^2 + 4 d n_mc + 2 d] x 8 B per estimate; peak 78.6 TF dense f64 MFMA")
+                    c_6.close()
+                except Exception as e:   # noqa: BLE001
+                    also["ns_f64"] = dict(error=str(e))
                 # the north-star family with the FEW samples per step the reference's algorithms default to (n_samples = 1 .. 16): every row of
                 # (mu, C) is independent under this target, one launch-free kernel runs the whole loop (k_fr_rows_loop)
                 try:

@@ -280,9 +280,12 @@ mivi_status_t mivi_optimize_steps(mivi_ctx_t *ctx, void *params_dev, void *opt_s
  *     estimate_gradient!  ->  Optimisers.update!  ->  operator  ->  averager
  * for every rule / operator / averager the reference's ParamSpaceSGD algorithms combine (constructors.jl:44-157):
  *   rule      0 Descent(eta) | 1 Adam(eta, beta1, beta2, adam_eps) | 2 DoG | 3 DoWG      (src/optimization/rules.jl:17-64)
+ *             4 COCOB(alpha = eta)                                                         (src/optimization/rules.jl:66-96)
  *   op        0 IdentityOperator | 1 ClipScale(clip_epsilon) | 2 ProximalLocationScaleEntropy (step size from the rule)
  *   averager  0 NoAveraging | 1 PolynomialAveraging(avg_eta): x_bar <- (1-w_t) x_bar + w_t x, w_t = (eta+1)/(t+eta)
- * opt_state: Adam T[2 params_len] (zeros before the first step) | DoG/DoWG mivi_dog_state_bytes (after mivi_dog_init).
+ * opt_state: Adam T[2 params_len] (zeros before the first step) | DoG/DoWG mivi_dog_state_bytes (after mivi_dog_init) |
+ * COCOB T[5 params_len] = [L; G; R; theta; x1] (zeros, x1 = the initial parameters: rules.jl:84-86).  COCOB runs as the hipGraph of chained
+ * estimates with its update kernel (ClipScale fused), not in the launch-free loops; ProximalLocationScaleEntropy has no step size for it.
  * avg_params: T[params_len] running average, in/out (any content when t0 = 0: w_1 = 1).  t0 = iterations already done
  * (warm start, src/optimize.jl:58-62).  Descent/Adam with Identity/ClipScale and no averaging take the fused paths of
  * mivi_optimize_steps; the other combinations are launch-free as well where mivi_optimize_steps is (mean-field + diagonal-Gaussian

@@ -19,7 +19,7 @@ from tests.helpers import SEED, make_problem
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-RULES = {"descent": 0, "adam": 1, "dog": 2, "dowg": 3}
+RULES = {"descent": 0, "adam": 1, "dog": 2, "dowg": 3, "cocob": 4}
 OPS = {"none": 0, "clip": 1, "prox": 2}
 COMBOS = [("dowg", "clip", "poly"), ("dowg", "prox", "poly"), ("dog", "clip", "none"), ("dog", "prox", "poly"), ("descent", "prox", "poly"),
           ("adam", "clip", "poly")]
@@ -30,6 +30,7 @@ def oracle_trajectory(ctx, p0, d, family, tgt, ent, rule, op, avg, T, idx0, eta,
     x = p0.astype(np.float64)
     dstate = (x.copy(), 0.0, alpha * (1.0 + float(np.linalg.norm(x))))      # DoG / DoWG init (rules.jl:22-24, 53-55)
     ast = (np.zeros_like(x), np.zeros_like(x))
+    cst = O.cocob_init(x)
     xbar, elbos = None, []
     for t in range(T):
         _, eps = ctx.sample(x.astype(p0.dtype), idx0 + t)
@@ -40,6 +41,8 @@ def oracle_trajectory(ctx, p0, d, family, tgt, ent, rule, op, avg, T, idx0, eta,
             x = O.descent_step(x, g, eta)
         elif rule == "adam":
             x, ast = O.adam_step(x, g, ast, t + 1, eta)
+        elif rule == "cocob":
+            x, cst = O.cocob_step(x, g, cst, eta)          # (alpha travels in `eta`: include/mivi.h)
         else:
             x, dstate = O.dog_step(x, g, dstate, 1 if rule == "dowg" else 0)
         if op == "clip":
@@ -61,6 +64,9 @@ def device_loop(ctx, p0, rule, op, avg, T, idx0, eta, alpha, clip_eps, avg_eta=8
     elif rule in ("dog", "dowg"):
         st = ctx.dog_state()
         ctx.dog_init(p, st, alpha)
+    elif rule == "cocob":                                   # (L, G, R, theta, x1) = (0, 0, 0, 0, params): rules.jl:84-86
+        st = ctx.empty(5 * p.numel()).zero_()
+        st[4 * p.numel():] = p
     ap = p.clone() if avg == "poly" else None
     elbo = ctx.empty(T)
     ctx.optimize_loop(p, T, idx0, 0, rule=RULES[rule], op=OPS[op], averager=1 if avg == "poly" else 0, eta=eta, clip_epsilon=clip_eps,
@@ -112,6 +118,48 @@ def test_fullrank_general_loops_follow_the_oracle(combo, shape):
     ctx.close()
 
 
+@pytest.mark.parametrize("combo", [("cocob", "clip", "poly"), ("cocob", "none", "none")], ids=["cocob-clip-poly", "cocob-none-none"])
+@pytest.mark.parametrize("cfg", [(avi.MEANFIELD, 1024, 8, np.float32), (avi.MEANFIELD, 70, 19, np.float64), (avi.FULLRANK, 256, 8, np.float32),
+                                 (avi.FULLRANK, 10, 4, np.float64), (avi.FULLRANK, 128, 128, np.float32)],
+                         ids=["mf-d1024-m8-f32", "mf-ragged-f64", "fr-d256-m8-f32", "fr-d10-m4-f64", "fr-d128-m128-f32"])
+def test_cocob_in_the_device_loop_follows_the_oracle(combo, cfg):
+    """Round 6: COCOB (src/optimization/rules.jl:66-96) as rule 4 of mivi_optimize_loop -- a hipGraph of chained estimates with the update
+    kernel, no host round trip per step -- against oracle.cocob_step (pinned on the reference's own rule test, tests/test_oracle_pinning.py)
+    for three steps, with ClipScale + PolynomialAveraging and bare.  alpha = 100 (the reference's default); the proximal operator is refused."""
+    family, d, M, dtype = cfg
+    rng = np.random.default_rng(14)
+    prob, tgt = make_problem(rng, "diag", d, dtype)
+    if family == avi.MEANFIELD:
+        q0 = avi.MeanFieldGaussian((0.2 * rng.normal(size=d)).astype(dtype), rng.uniform(0.6, 1.4, size=d).astype(dtype))
+    else:
+        q0 = avi.FullRankGaussian((0.2 * rng.normal(size=d)).astype(dtype), (np.eye(d) + (0.3 / np.sqrt(d)) * np.tril(rng.normal(size=(d, d)), -1)).astype(dtype))
+    p0, _ = avi.destructure(q0)
+    ctx = avi.MiviContext(dtype, family, d, M, 0, SEED)
+    ctx.set_problem(prob)
+    _check(ctx, p0, d, family, tgt, 0, combo, tol=5e-6 if dtype == np.float32 else 1e-11, eta=100.0)
+    with pytest.raises(Exception, match="COCOB"):
+        device_loop(ctx, p0, "cocob", "prox", "none", 2, 70, 100.0, 1e-2, 1e-5)
+    ctx.close()
+
+
+def test_cocob_optimize_runs_on_the_device_and_matches_the_host_loop():
+    """`optimize` with COCOB: the device-resident loop (mivi_optimize_loop, rule 4) and the host-driven `step` loop give the same parameters
+    and ELBO record (the same kernels in the same order), including a warm start from the returned state."""
+    d = 40
+    rng = np.random.default_rng(3)
+    prob, _ = make_problem(rng, "diag", d, np.float64)
+    q0 = avi.MeanFieldGaussian(np.zeros(d), np.ones(d))
+    alg = avi.KLMinRepGradDescent(avi.AutoMIVI(), n_samples=8, optimizer=avi.COCOB(), operator=avi.ClipScale(), averager=avi.PolynomialAveraging())
+    qa, ia, sa = avi.optimize(avi.PhiloxRNG(SEED), alg, 12, prob, q0)
+    qb, ib, sb = avi.optimize(avi.PhiloxRNG(SEED), alg, 12, prob, q0, device_loop=False)
+    assert np.array_equal(qa.location, qb.location) and np.array_equal(np.asarray(qa.scale), np.asarray(qb.scale))
+    assert np.array_equal([float(i["elbo"]) for i in ia], [float(i["elbo"]) for i in ib])
+    rng2a, rng2b = avi.PhiloxRNG(SEED, 12), avi.PhiloxRNG(SEED, 12)
+    qa2, _, _ = avi.optimize(rng2a, alg, 5, prob, q0, state=sa)
+    qb2, _, _ = avi.optimize(rng2b, alg, 5, prob, q0, state=sb, device_loop=False)
+    assert np.array_equal(qa2.location, qb2.location) and np.array_equal(np.asarray(qa2.scale), np.asarray(qb2.scale))
+
+
 @pytest.mark.parametrize("combo", [("dowg", "clip", "poly"), ("dog", "prox", "poly"), ("descent", "prox", "poly")], ids=["dowg-clip-poly", "dog-prox-poly", "descent-prox-poly"])
 @pytest.mark.parametrize("family", [avi.MEANFIELD, avi.FULLRANK], ids=["meanfield", "fullrank"])
 def test_small_logreg_loop_follows_the_oracle(combo, family):
@@ -131,7 +179,9 @@ def test_small_logreg_loop_follows_the_oracle(combo, family):
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["f32", "f64"])
 def test_prox_keeps_a_negative_diagonal_positive(dtype):
     """mivi_prox_scale_entropy on entries below zero with a step size far below eps c^2: the exact value gamma / |c| (the reference's literal
-    Float32 expression returns 0 there: tests/test_oracle_pinning.py), against the f64 restatement."""
+    Float32 expression returns 0 there: tests/test_oracle_pinning.py).  The oracle keeps the reference's LITERAL expression in f64, which
+    itself cancels for c < 0 (absolute error about eps64 |c|): the device is held to the exact value -- the cancellation-free form in f64 --
+    at rounding, and to the oracle within the oracle's own cancellation error."""
     d = 8
     c = np.array([-3.0, -1e-3, -1.0, 0.5, 2.0, 1e-4, -40.0, 1.0])
     ctx = avi.MiviContext(dtype, avi.MEANFIELD, d, 4, 1, SEED)
@@ -140,9 +190,14 @@ def test_prox_keeps_a_negative_diagonal_positive(dtype):
         p = ctx.to_device(params).clone()
         ctx.prox_scale_entropy(p, gamma)
         got = p.cpu().numpy()[d:].astype(np.float64)
+        c64 = params[d:].astype(np.float64)
+        rt = np.sqrt(c64 * c64 + 4 * gamma)
+        exact = np.where(c64 < 0, 2 * gamma / (rt - c64), c64 + (rt - c64) / 2.0)
         ref = O.proximal_location_scale_entropy(params.astype(np.float64), d, O.MEANFIELD, gamma)[d:]
+        rtol = 2e-6 if dtype == np.float32 else 1e-13
         assert np.all(got > 0.0), (gamma, got)
-        assert np.allclose(got, ref, rtol=2e-6 if dtype == np.float32 else 1e-13, atol=0.0), (gamma, got, ref)
+        assert np.allclose(got, exact, rtol=rtol, atol=0.0), (gamma, got, exact)
+        assert np.all(np.abs(got - ref) <= rtol * np.abs(ref) + 8 * np.finfo(np.float64).eps * np.abs(c64)), (gamma, got, ref)
     ctx.close()
 
 
