@@ -28,691 +28,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SEED = 0x38BEF07CF9CC549D
-PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
-PEAK_F32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: dense f32 MFMA peak (155 TF measured)
-PEAK_BF16_MFMA_TF = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
-PLANE_BYTES = 4                 # bytes per operand-plane element of the batch engine (f16 hi + lo planes; ctx.plane_bytes())
-PEAK_VALU_GINST = 1024 * 2.4 / 4   # wave64 vector instructions per ns: 256 CUs x 4 SIMDs, one per 4 cycles, 2.4 GHz (MI355X_MICROARCH.md)
-
-# environment variables that do NOT change which kernels run: bench-harness controls and the RCCL library location
-BENCH_ENV_OK = {"MIVI_FORCE_DIST", "MIVI_DIST_MODE", "MIVI_DIST_EAGER", "MIVI_BENCH_SKIP_C3", "MIVI_RCCL_LIB", "MIVI_DIST_PIPELINE"}
-
-WORKLOADS = {
-    "ns": dict(family=1, d=1024, n_mc=256, target="iso", entropy=0,
-               name="north-star: d=1024 full-rank Gaussian family, n_mc=256, target MvNormal(5*1, I), ClosedFormEntropy"),
-    "c2": dict(family=0, d=1024, n_mc=256, target="iso", entropy=0,
-               name="configs[1]: d=1024 mean-field MvLocationScale, n_mc=256, target MvNormal(5*1, I), ClosedFormEntropy"),
-    "ns_dense": dict(family=1, d=1024, n_mc=256, target="dense", entropy=0,
-                     name="north-star family, dense-Gaussian target N(5*1, L L'), L = tril(I + 11'/(2d))"),
-    "c3": dict(family=1, d=512, n_mc=128, target="logreg", entropy=0, n=1_000_000,
-               name="configs[2]: hierarchical LogReg n=1e6, D=512 (511 coefficients + log sigma), full-rank q0=(0, 0.6 I), n_mc=128"),
-    "c5": dict(family=0, d=2048, n_mc=64, target="funnel", entropy=3,
-               name="configs[4] per-GPU shard: funnel d=2048 + Stacked bijector, mean-field, STL, 64 samples per GPU"),
-    "ns_stl": dict(family=1, d=1024, n_mc=256, target="iso", entropy=3,
-                   name="north-star family, StickingTheLandingEntropy (adds the C^-T eps solve)"),
-}
-
-
-def algorithmic_cost(w):
-    """SURVEY.md 8(d) per-estimate figures (s = 4 bytes): bytes and flops of one estimate."""
-    d, M, s = w["d"], w["n_mc"], 4
-    if w["family"] == 0:
-        return dict(bytes=4 * d * M * s + 4 * d * s, flops=6 * d * M)
-    return dict(bytes=(d * (d + 1) // 2) * s + d * d * s + 4 * d * M * s + 2 * d * s, flops=2 * d * d * M)
-
-
-for _k, _v in WORKLOADS.items():
-    _v["key"] = _k
-
-
-def pmc_traffic(kernel_substr, lanes=None):
-    """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-    (profiles/pmc_traffic.json, produced by tools/pmc_traffic.py: separate passes, counters in KiB, the gfx950 FETCH_SIZE
-    correction of MI355X_MICROARCH.md already applied there per kernel according to the width of its loads -- the file records
-    the factor it used and the calibration run it came from).  Batch-engine kernels are kept per lane count there (`by_lanes`, the lanes
-    derived from every dispatch's grid): `lanes` picks that entry, or the nearest one (the caller scales per lane and says so)."""
-    try:
-        tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-    except (OSError, ValueError):
-        return None
-    for k, v in tab.get("kernels", {}).items():
-        if kernel_substr in k:
-            if lanes and v.get("by_lanes"):
-                key = min(v["by_lanes"], key=lambda x: abs(int(x) - lanes))
-                v = v["by_lanes"][key]
-            elif v.get("by_lanes") or "k_fb_" in k:   # (no lane count asked for / a round-4 file whose lane count was assumed, not derived)
-                return None
-            out = dict(bytes_per_launch=(v["fetch_kib"] + v["write_kib"]) * 1024.0, fetch_bytes=v["fetch_kib"] * 1024.0,
-                       write_bytes=v["write_kib"] * 1024.0, source=tab.get("source"), profile="profiles/pmc_traffic.json")
-            if "lanes_per_launch" in v:   # the batch engine: the profiled launches carried this many estimates
-                out["lanes_per_launch"] = v["lanes_per_launch"]
-            return out
-    return None
-
-
-def pmc_valu(kernel_substr):
-    """Wave-level VALU instruction count per launch of a kernel (SQ_INSTS_VALU, its own rocprofv3 --pmc pass: tools/pmc_valu.sh ->
-    profiles/pmc_valu.json)."""
-    try:
-        tab = json.load(open(os.path.join(ROOT, "profiles", "pmc_valu.json")))
-    except (OSError, ValueError):
-        return None
-    for k, v in tab.get("kernels", {}).items():
-        if kernel_substr in k and "SQ_INSTS_VALU" in v:
-            return dict(insts_valu=v["SQ_INSTS_VALU"], insts_salu=v.get("SQ_INSTS_SALU"), waves=v.get("SQ_WAVES"),
-                        active_inst_valu_cycles=v.get("SQ_ACTIVE_INST_VALU"), busy_cycles=v.get("SQ_BUSY_CYCLES"),
-                        avg_ns_under_the_profiler=v.get("avg_ns"), source=tab.get("source"))
-    return None
-
-
-def rocprof_avg(kernel_substr, workload="ns", lanes=None):
-    """Average duration (us) of a kernel in the newest committed `rocprofv3 --kernel-trace --stats` summary of this workload's bench command
-    (profiles/<tag>_<workload>_kernel_stats.md, written by tools/profile_round.sh): the in-chain figure next to the stand-alone one this
-    process measures.  With `lanes`: the row of the summary's per-grid table whose launches carried exactly that many estimates (the lane
-    count is derived from the grid there), preferring the summary taken at the driver's own --steps 20 (`<tag>_<workload>20_...`)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_kernel_stats.md" % workload)) +
-                   glob.glob(os.path.join(ROOT, "profiles", "r*_%s20_kernel_stats.md" % workload)),
-                   key=lambda f: os.path.basename(f).split("_")[:2])
-    for f in reversed(files):
-        try:
-            hit = None
-            for line in open(f):
-                if kernel_substr not in line or not line.startswith("|"):
-                    continue
-                c = [x.strip() for x in line.strip().strip("|").split("|")]
-                if len(c) == 7 and "x" in c[1] and not c[1].isdigit():        # per-grid table: kernel | workgroups | lanes | calls | avg_ns | min | max
-                    if lanes and c[2].isdigit() and int(c[2]) == lanes:
-                        return dict(avg_us=float(c[4]) / 1e3, calls=int(c[3]), lanes=lanes, source=os.path.relpath(f, ROOT))
-                elif hit is None and len(c) >= 4 and c[1].isdigit():
-                    hit = dict(avg_us=float(c[3]) / 1e3, calls=int(c[1]), lanes=None, source=os.path.relpath(f, ROOT))
-            if hit and not lanes:
-                return hit
-        except (OSError, ValueError, IndexError):
-            continue
-    return None
-
-
-def mf_roofline(ctx, params, cost, kernel_names=("k_mf_main<float>", "k_mf_sgd_loop<float> (100 estimates per launch)")):
-    """Mean-field roofline leg.  Batched estimates (estimate_gradient_n, what the bench line times) run 100 estimates per
-    launch of the launch-free loop kernel; a single call is one launch of the fused main kernel -- both are reported."""
-    try:
-        ms1 = ctx.profile_kernel(2, params, 300)
-    except Exception:   # noqa: BLE001  -- no stand-alone stage hook for this target (fused funnel): whole single estimate, eager
-        ms1 = ctx.profile_kernel(0, params, 300)
-    single = dict(kernel=kernel_names[0], avg_launch_us=ms1 * 1e3, achieved=cost["bytes"] / (ms1 * 1e-3) / 1e9,
-                  frac=cost["bytes"] / (ms1 * 1e-3) / 1e9 / PEAK_HBM_GBS, traffic=pmc_traffic("k_mf_main"))
-    try:
-        msl = ctx.profile_kernel(5, params, 30)
-    except Exception:   # noqa: BLE001  -- loop not applicable (other target / MIVI_NO_FUSED_LOOP semantics unchanged)
-        msl = None
-    if msl is None:
-        return dict(bound="hbm", kernel=single["kernel"], achieved=single["achieved"], peak=PEAK_HBM_GBS, unit="GB/s",
-                    frac=single["frac"], traffic=single["traffic"], algorithmic_bytes_per_launch=cost["bytes"],
-                    avg_launch_us=single["avg_launch_us"]), {"mf_fused_main": ms1}
-    ach = 100 * cost["bytes"] / (msl * 1e-3) / 1e9
-    loop_kernel = "k_mf_funnel_loop" if "funnel" in kernel_names[1] else "k_mf_sgd_loop"
-    hbm_eq = dict(achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS, algorithmic_bytes_per_launch=100 * cost["bytes"],
-                  note=("HBM-EQUIVALENT of SURVEY 8d's algorithmic bytes: Z and G never exist in memory (the launch moves `traffic.bytes_per_launch`, "
-                        "about 1 % of them), so this fraction is not bounded by 1"))
-    valu = pmc_valu(loop_kernel)
-    times = {"mf_fused_main": ms1, "mf_loop_per_estimate": msl / 100}
-    if valu is None:
-        return dict(bound="valu", kernel=kernel_names[1], achieved=None, peak=PEAK_VALU_GINST, unit="G wave-instructions/s", frac=None,
-                    traffic=pmc_traffic(loop_kernel), estimates_per_launch=100, avg_launch_us=msl * 1e3, single_call=single, hbm_equivalent=hbm_eq,
-                    note="vector-ALU bound (Philox + Box-Muller + wave reductions); no profiles/pmc_valu.json with this kernel's SQ_INSTS_VALU: "
-                         "tools/pmc_valu.sh collects it"), times
-    # the kernel is vector-ALU bound: wave-level VALU instructions per launch (SQ_INSTS_VALU, own rocprofv3 pass) over the live launch time,
-    # against 1024 SIMDs x one wave64 instruction per 4 cycles x 2.4 GHz
-    g = valu["insts_valu"] / (msl * 1e-3) / 1e9
-    return dict(bound="valu", kernel=kernel_names[1], achieved=g, peak=PEAK_VALU_GINST, unit="G wave-instructions/s", frac=g / PEAK_VALU_GINST,
-                traffic=pmc_traffic(loop_kernel), estimates_per_launch=100, avg_launch_us=msl * 1e3, single_call=single,
-                valu_insts_per_launch=valu["insts_valu"], valu_insts_per_estimate=valu["insts_valu"] / 100.0,
-                valu_bound_us_per_estimate=valu["insts_valu"] / 100.0 / PEAK_VALU_GINST / 1e3, measured_us_per_estimate=msl * 1e3 / 100,
-                pmc=valu, hbm_equivalent=hbm_eq,
-                note=("vector-ALU roofline: SQ_INSTS_VALU per launch (profiles/pmc_valu.json; wave-level, every instruction priced at 4 cycles -- "
-                      "transcendentals and f64 cost more, so the true bound is tighter) / live launch time vs 1024 SIMDs / 4 cycles x 2.4 GHz; "
-                      "the HBM-equivalent of SURVEY 8d's algorithmic bytes is under hbm_equivalent")), times
-
-
-def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):
-    """Full-rank roofline leg: graph-replayed launches of each stage (mivi_profile_kernel), the slower of the two
-    contractions is the dominant kernel.  Both carry d^2*M algorithmic flops (lower triangle only).  On the second-generation
-    route the products run on the bf16 matrix cores with the exact three-way operand split (six bf16 MFMAs per product
-    block): `frac` stays f32-equivalent flops / the f32-MFMA peak the north star is priced against, and `bf16_pipe` says what
-    the matrix pipe actually executes."""
-    gen, bf3 = ctx.fullrank_route()
-    stages = {"eps": ctx.profile_kernel(1, params, reps), "sample": ctx.profile_kernel(2, params, reps),
-              "vjp": ctx.profile_kernel(3, params, reps)}
-    if w["target"] == "dense":
-        stages["dense_target"] = ctx.profile_kernel(4, params, reps)
-    dom = "vjp" if stages["vjp"] >= stages["sample"] else "sample"
-    names = {0: {"vjp": "k_fr_tile_mfma<MODE_VJP,4>", "sample": "k_fr_tile_mfma<MODE_SAMPLE,8>"},
-             1: {"vjp": "k_fr_vjp32", "sample": "k_fr_prod32<SAMPLE> (product + fused target)"},
-             2: {"vjp": "k_fr_vjp32", "sample": "k_fr_gemm<SAMPLE> + k_fr_reduce (split-K)"},
-             3: {"vjp": "k_fr_vjp32 / k_fr_vjp64", "sample": "k_fr_prod64<SAMPLE> (product + fused target)"}}[gen]
-    fl = cost["flops"] / 2
-    ach = fl / (stages[dom] * 1e-3) / 1e12
-    roof = dict(bound="mfma", kernel=names[dom], achieved=ach, peak=PEAK_F32_MFMA_TF, unit="TFLOP/s", frac=ach / PEAK_F32_MFMA_TF,
-                traffic=pmc_traffic({"vjp": "k_fr_vjp32", "sample": "k_fr_prod32"}[dom] if gen else ("mfmaILi1" if dom == "vjp" else "mfmaILi0")),
-                algorithmic_flops_per_launch=fl, avg_launch_us=stages[dom] * 1e3,
-                timing="hipGraph replay of %d launches, hipEvents on the launch stream" % reps,
-                other_contraction=dict(kernel=names["sample" if dom == "vjp" else "vjp"],
-                                       avg_launch_us=stages["sample" if dom == "vjp" else "vjp"] * 1e3,
-                                       achieved=fl / (stages["sample" if dom == "vjp" else "vjp"] * 1e-3) / 1e12))
-    # Batches of estimates at the BASELINE sizes (what the bench line times) are LANE-BATCHED: one product launch and one VJP launch serve
-    # FOUR estimates (k_fr_prod32q / k_fr_vjp32s).  Those are the launches of the timed region: the dominant one becomes the headline of the
-    # block (4 x the algorithmic flops per launch), the one-estimate kernels stay in `single_launch` (an optimisation loop runs those).
-    if gen == 1 and bf3 and w["target"] == "iso":
-        try:
-            t4 = {"sample": ctx.profile_kernel(10, params, reps), "vjp": ctx.profile_kernel(11, params, reps)}
-        except Exception:   # noqa: BLE001  -- configuration outside the lane-batched route
-            t4 = None
-        if t4:
-            stages["sample_4_lanes"], stages["vjp_4_lanes"] = t4["sample"], t4["vjp"]
-            d4 = "vjp" if t4["vjp"] >= t4["sample"] else "sample"
-            o4 = "sample" if d4 == "vjp" else "vjp"
-            n4 = {"sample": "k_fr_prod32q (four estimates' products + fused target per launch, with the next eps draws riding)",
-                  "vjp": "k_fr_vjp32s (four estimates' VJP per launch, strips of tiles)"}
-            a4 = 4 * fl / (t4[d4] * 1e-3) / 1e12
-            single = {k: roof[k] for k in ("kernel", "achieved", "frac", "traffic", "algorithmic_flops_per_launch", "avg_launch_us", "other_contraction")}
-            roof.update(kernel=n4[d4], achieved=a4, frac=a4 / PEAK_F32_MFMA_TF, algorithmic_flops_per_launch=4 * fl, estimates_per_launch=4,
-                        avg_launch_us=t4[d4] * 1e3, traffic=pmc_traffic({"vjp": "k_fr_vjp32s", "sample": "k_fr_prod32q"}[d4]),
-                        other_contraction=dict(kernel=n4[o4], avg_launch_us=t4[o4] * 1e3, achieved=4 * fl / (t4[o4] * 1e-3) / 1e12,
-                                               rocprof_in_chain=rocprof_avg({"vjp": "k_fr_vjp32s", "sample": "k_fr_prod32q"}[o4])),
-                        rocprof_in_chain=rocprof_avg({"vjp": "k_fr_vjp32s", "sample": "k_fr_prod32q"}[d4]),
-                        timing="hipGraph replay of %d launches of the four-lane kernel alone, hipEvents on the launch stream (rocprof_in_chain: "
-                               "the same kernel inside the timed batches, the other branch's kernels beside it)" % reps,
-                        single_launch=single)
-            ach = a4
-    # Batches on the BATCH ENGINE (full-rank family, diagonal-Gaussian target; csrc/kernels_fullrank_batch.hip): a step of the timed region is
-    # three launches -- draws, product + target, VJP + values -- that cover ALL the lanes of the step (`lanes` = estimates per call of the
-    # timed loop).  The dominant launch is the headline of the block: lanes x the algorithmic flops per launch / its duration, measured live
-    # (hipEvents around back-to-back launches on the launch stream: nothing runs beside these kernels in the timed region either, so the
-    # stand-alone figure IS the in-chain one; `rocprof_in_chain` quotes the committed rocprofv3 summary of the bench command next to it).
-    if lanes and w["target"] in ("iso", "dense"):
-        try:
-            lanes = ctx.batch_lanes(lanes) or lanes      # a call of `lanes` estimates runs as equal steps of this many lanes
-            tb = ctx.profile_batch(params, lanes, max(5, reps // 10))
-        except Exception:   # noqa: BLE001  -- configuration outside the batch engine
-            tb = None
-        if tb:
-            for k, v in tb.items():
-                if v > 0.0:
-                    stages["batch_%s_%d_lanes" % (k, lanes)] = v * 1e-3
-            nm = {"product": "k_fb_prod<FB_DIAG> (tril(C) [eps_1 .. eps_L] + fused target for all lanes of a step, operands as f16 hi/lo planes in MFMA-fragment order)",
-                  "vjp": "k_fb_vjp (tril(W_l eps_l') for all lanes of a step + their values)",
-                  "dense_product": "k_fb_prod<FB_DENSE_G> (the dense target's -P (Z_l - m) for all lanes of a step)",
-                  "stl_product": "k_fb_prod<FB_STL_U> (W_l += C^-T eps_l for all lanes of a step, C^-T formed once per call)"}
-            if w["target"] == "dense":
-                nm["product"] = "k_fb_prod<FB_DENSE_R> (tril(C) [eps_1 .. eps_L] -> R = Z - m as operand planes)"
-            sub = {"product": "k_fb_prodILi1ELi%dE" % (1 if w["target"] == "dense" else 0), "vjp": "k_fb_vjp",
-                   "dense_product": "k_fb_prodILi1ELi2E", "stl_product": "k_fb_prodILi1ELi3E"}   # (mangled template arguments: WJ, MODE; then the ring depth)
-            kfl = {"product": fl, "vjp": fl, "dense_product": 2 * fl, "stl_product": fl}   # algorithmic flops per estimate of each launch
-            live = [k for k in ("product", "vjp", "dense_product", "stl_product") if tb.get(k, 0.0) > 0.0]
-            dk = max(live, key=lambda k: tb[k])
-            aL = lanes * kfl[dk] / (tb[dk] * 1e-6) / 1e12
-
-            def traffic_of(k):
-                # HBM-side bytes of one launch at THIS lane count: tools/pmc_traffic.py keeps the batch-engine kernels per grid size (lanes
-                # derived from the dispatch's grid, not assumed); another lane count's entry is scaled per lane and says so
-                t = pmc_traffic(sub[k], lanes)
-                if t and t.get("lanes_per_launch") and t["lanes_per_launch"] != lanes:
-                    f = lanes / float(t["lanes_per_launch"])
-                    t = dict(t, bytes_per_launch=t["bytes_per_launch"] * f, fetch_bytes=t["fetch_bytes"] * f, write_bytes=t["write_bytes"] * f,
-                             scaled_from_lanes=t["lanes_per_launch"], lanes_per_launch=lanes)
-                if t:
-                    d_, M_ = w["d"], w["n_mc"]
-                    alg = {"product": d_ * (d_ + 1) // 2 * 4 + lanes * 2 * d_ * M_ * 4, "vjp": lanes * (2 * d_ * M_ * 4 + d_ * d_ * 4),
-                           "dense_product": d_ * d_ * 4 + lanes * 2 * d_ * M_ * 4, "stl_product": d_ * (d_ + 1) // 2 * 4 + lanes * 3 * d_ * M_ * 4}[k]
-                    t["algorithmic_bytes_per_launch"] = alg
-                    t["over_algorithmic"] = t["bytes_per_launch"] / alg
-                    t["GBs"] = t["bytes_per_launch"] / (tb[k] * 1e-6) / 1e9          # the counters' bytes over THIS run's launch time
-                    t["frac_of_8TBs"] = t["GBs"] / PEAK_HBM_GBS
-                return t
-            keep = {k: roof[k] for k in ("kernel", "achieved", "frac", "traffic", "algorithmic_flops_per_launch", "avg_launch_us", "other_contraction")}
-            if "single_launch" in roof:
-                keep = roof["single_launch"]
-            # ONE basis for every kernel of the block.  On two f16 planes a product block costs three matrix-pipe products, so SURVEY 8d's
-            # algorithmic flops no longer bound these kernels (the 16-bit pipe would finish them in a third of the time the f32-MFMA peak
-            # allows): the binding roof is the MEMORY side, as the north star's own target says ("% of HBM roofline").  `achieved` = SURVEY 8d's
-            # algorithmic BYTES of the launch / its duration, `peak` = 8 TB/s; beside it, always, the same launch's f32-accurate flops over
-            # the f32-MFMA peak (`frac_f32_mfma`: may exceed 1) and the executed 16-bit-pipe flops over 2.5 PF (`frac_16bit_pipe`, <= 1).
-            nprod = ctx.split_products()
-            d_, M_ = w["d"], w["n_mc"]
-            alg_bytes = {"product": d_ * (d_ + 1) // 2 * 4 + lanes * 2 * d_ * M_ * 4, "vjp": lanes * (2 * d_ * M_ * 4 + d_ * d_ * 4),
-                         "dense_product": d_ * d_ * 4 + lanes * 2 * d_ * M_ * 4, "stl_product": d_ * (d_ + 1) // 2 * 4 + lanes * 3 * d_ * M_ * 4}
-            # ... and the bytes the VJP launch MOVES as mivi_estimate_gradient_n lays it out (round 5's verdict: SURVEY 8d charges every lane a
-            # dense d^2 gradient write, but only the caller's lane writes the zeros above the diagonal -- the scratch lanes write the 128 x 128
-            # tiles of the lower triangle): W and eps planes read once, T (T + 1) / 2 tiles per scratch lane, d^2 for the caller's, d/dmu.
-            # `roofline.achieved` / `frac` are on THESE bytes (they agree with the PMC counters to a few percent: `traffic`); the SURVEY 8d
-            # figure stays beside them as `frac_survey_8d`.
-            T_ = d_ // 128
-            moved_vjp = lanes * (2 * d_ * M_ * 4 + d_ * 4) + (lanes - 1) * (T_ * (T_ + 1) // 2) * 128 * 128 * 4 + d_ * d_ * 4
-            survey_bytes = dict(alg_bytes)
-            alg_bytes["vjp"] = moved_vjp
-
-            def tf(k):
-                return lanes * kfl[k] / (tb[k] * 1e-6) / 1e12
-
-            def gbs(k):
-                return alg_bytes[k] / (tb[k] * 1e-6) / 1e9
-            others = [dict(kernel=nm[k], avg_launch_us=tb[k], achieved=gbs(k), frac=gbs(k) / PEAK_HBM_GBS, frac_f32_mfma=tf(k) / PEAK_F32_MFMA_TF,
-                           frac_16bit_pipe=nprod * tf(k) / PEAK_BF16_MFMA_TF, rocprof_in_chain=rocprof_avg(sub[k], w.get("key", "ns"), lanes))
-                      for k in live if k != dk]
-            roof.update(bound="hbm", kernel=nm[dk], achieved=gbs(dk), peak=PEAK_HBM_GBS, unit="GB/s", frac=gbs(dk) / PEAK_HBM_GBS,
-                        algorithmic_bytes_per_launch=alg_bytes[dk], survey_8d_bytes_per_launch=survey_bytes[dk],
-                        achieved_survey_8d=survey_bytes[dk] / (tb[dk] * 1e-6) / 1e9, frac_survey_8d=survey_bytes[dk] / (tb[dk] * 1e-6) / 1e9 / PEAK_HBM_GBS,
-                        algorithmic_flops_per_launch=lanes * kfl[dk], estimates_per_launch=lanes,
-                        avg_launch_us=tb[dk], traffic=traffic_of(dk), rocprof_in_chain=rocprof_avg(sub[dk], w.get("key", "ns"), lanes),
-                        other_contraction=others[0] if len(others) == 1 else others,
-                        draws=dict(kernel="k_fb_eps (Philox + Box-Muller draws of all lanes as operand planes in both orientations)", avg_launch_us=tb["eps"],
-                                   algorithmic_bytes_per_launch=lanes * 2 * PLANE_BYTES * w["d"] * w["n_mc"],
-                                   achieved_GBs=lanes * 2 * PLANE_BYTES * w["d"] * w["n_mc"] / (tb["eps"] * 1e-6) / 1e9,
-                                   note="%d bytes per element and orientation written once: bound by the memory side and the vector ALU" % PLANE_BYTES),
-                        timing="%d back-to-back launches of each kernel for %d lanes, hipEvents on the launch stream" % (max(5, reps // 10), lanes),
-                        basis="achieved = bytes the launch moves (vjp: W + eps planes read, lower-triangle tiles written per scratch lane, dense d^2 for the caller's lane) / launch time; peak = HBM 8 TB/s; frac_survey_8d = SURVEY 8d's lanes x (2 d n_mc + d^2) x 4 B instead; traffic = PMC counters; frac_f32_mfma = d^2 n_mc flops x lanes / time / 157.3 TF; frac_16bit_pipe = x%d executed / 2500 TF" % nprod,
-                        f32_mfma=dict(achieved_TFLOPs=aL, peak=PEAK_F32_MFMA_TF, frac=aL / PEAK_F32_MFMA_TF),
-                        pipe16=dict(products_per_block=nprod, executed_TFLOPs=nprod * aL, peak=PEAK_BF16_MFMA_TF, frac=nprod * aL / PEAK_BF16_MFMA_TF),
-                        single_launch=keep)
-            roof.pop("estimates_per_launch_note", None)
-            return roof, stages
-    if gen and bf3:
-        roof["bf16_pipe"] = dict(mfma="v_mfma_f32_32x32x16_bf16 x6 per product block (exact 3-way f32 split)",
-                                 executed_TFLOPs=6 * ach, peak=PEAK_BF16_MFMA_TF, frac=6 * ach / PEAK_BF16_MFMA_TF)
-    return roof, stages
-
-
-def other_roofline(cx, p, w, t_est):
-    """Roofline block of the workloads whose dominant kernel is not one of the two full-rank contractions:
-    C3 (logistic regression: the two data contractions), C5 / other mean-field targets (HBM)."""
-    cost = algorithmic_cost(w)
-    if w["target"] == "logreg":
-        n, pdim, M2 = w["n"], w["d"] - 1, w["n_mc"]
-        fl = 4.0 * n * pdim * M2                      # logits X beta and X^T R, 2 flops per MAC
-        by = 2.0 * n * pdim * 4 + 2.0 * n * M2 * 4     # X read once per contraction, R written + read
-        tl, tx = pmc_traffic("k_lr_logits_planes"), pmc_traffic("k_lr_xtr_planes")
-        # the two data contractions stream X's operand planes once each (SURVEY 8d prices ONE fused pass: 2.05 GB); with three 16-bit products per block the
-        # binding roof is the memory side: `achieved` = SURVEY 8d's algorithmic bytes / whole-estimate time against 8 TB/s, the flop fractions beside
-        alg = float(n) * (pdim + 1) * 4 + float(n)                      # X (padded to D columns) once + y
-        return dict(bound="hbm", kernel="k_lr_logits_planes + k_lr_xtr_planes", achieved=alg / t_est / 1e9, peak=PEAK_HBM_GBS, unit="GB/s",
-                    frac=alg / t_est / 1e9 / PEAK_HBM_GBS, algorithmic_bytes_per_launch=alg,
-                    basis="achieved = SURVEY 8d algorithmic bytes (one pass over X, 2.05 GB) / whole-estimate time; peak = HBM 8 TB/s; the kernels read X's f16x2 planes twice (one orientation per contraction, built once per data set) + the residual planes once each way",
-                    f32_mfma=dict(achieved_TFLOPs=fl / t_est / 1e12, peak=PEAK_F32_MFMA_TF, frac=fl / t_est / 1e12 / PEAK_F32_MFMA_TF),
-                    pipe16=dict(products_per_block=3, executed_TFLOPs=3 * fl / t_est / 1e12, peak=PEAK_BF16_MFMA_TF, frac=3 * fl / t_est / 1e12 / PEAK_BF16_MFMA_TF),
-                    hbm_executed=dict(achieved_GBs=by / t_est / 1e9, peak=PEAK_HBM_GBS, frac=by / t_est / 1e9 / PEAK_HBM_GBS, bytes_per_estimate=by),
-                    traffic=(dict(bytes_per_launch=tl["bytes_per_launch"] + tx["bytes_per_launch"], logits=tl, xtr=tx) if tl and tx else None),
-                    avg_launch_us=t_est * 1e6)
-    try:
-        roof, _ = mf_roofline(cx, p, cost, ("k_mf_main<float, funnel> + k_value_funnel (single call, eager)",
-                                            "k_mf_funnel_loop<float> + k_mf_funnel_loop_value (100 estimates per launch pair)"))
-        roof["note"] = ("HBM-equivalent of SURVEY 8d's algorithmic bytes; the kernel is VALU bound (two Philox blocks + exp per lane and "
-                        "estimate), real traffic is the gradients and the per-estimate partials")
-        return roof
-    except Exception:   # noqa: BLE001  -- stage hook not applicable to this target: whole-estimate HBM equivalent
-        return dict(bound="hbm", kernel="k_mf_main<float, funnel> (one launch per estimate; the previous estimate's value / row-0 finisher rides in it)",
-                    achieved=cost["bytes"] / t_est / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=cost["bytes"] / t_est / 1e9 / PEAK_HBM_GBS,
-                    traffic=pmc_traffic("k_mf_mainIfLb1"), algorithmic_bytes_per_launch=cost["bytes"], avg_launch_us=t_est * 1e6,
-                    note="whole estimate (hipGraph steady state); launch / latency bound: 0.27 MB of real traffic per estimate")
-
-
-def stl_block(cx, p, w, reps=100):
-    """The sticking-the-landing term of a full-rank workload: W += C^-T eps (two half-size chain solves + one update product),
-    hipGraph-replayed alone (mivi_profile_kernel which = 8).  Algorithmic flops d^2 M (a triangular solve with M right-hand sides)."""
-    try:
-        ms = cx.profile_kernel(8, p, reps)
-    except Exception:   # noqa: BLE001
-        return None
-    fl = float(w["d"]) ** 2 * w["n_mc"]
-    sv, up = pmc_traffic("k_stl_solve64"), pmc_traffic("k_stl_update32")
-    return dict(kernel="k_stl_solve64 (three half-size solves side by side: X2, Y1, F) + k_stl_update32 (X1 = Y1 - F^T X2)", avg_us=ms * 1e3,
-                achieved_TFLOPs=fl / (ms * 1e-3) / 1e12, frac_of_f32_mfma_peak=fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TF,
-                algorithmic_flops=fl, executed_flops=2.0 * fl,   # the parameter-only coupling solve has d/2 right-hand sides of its own
-                bound="dependency chain: d/128 block steps per 16-column workgroup (2 M/16 + d/32 CUs busy), each pulling its half-triangle through one CU",
-                traffic=(dict(solve=sv, update=up) if sv and up else None))
-
-
-def make_problem(avi, w):
-    d = w["d"]
-    q = (avi.MeanFieldGaussian(np.zeros(d, np.float32), np.ones(d, np.float32)) if w["family"] == 0
-         else avi.FullRankGaussian(np.zeros(d, np.float32), np.eye(d, dtype=np.float32)))
-    if w["target"] == "logreg":
-        rng = np.random.default_rng(3)
-        n, p = w["n"], d - 1
-        X = np.empty((n, p), dtype=np.float32)
-        X[:, :p - 1] = rng.standard_normal((n, p - 1), dtype=np.float32) / np.sqrt(p - 1.0)
-        X[:, p - 1] = 1.0
-        beta = rng.standard_normal(p, dtype=np.float32)
-        y = (rng.random(n) < 1 / (1 + np.exp(-(X @ beta)))).astype(np.uint8)
-        q = avi.FullRankGaussian(np.zeros(d, np.float32), 0.6 * np.eye(d, dtype=np.float32))
-        return q, avi.LogRegProblem(X, y, "logsigma_normal", 1.0)
-    if w["target"] == "funnel":
-        return q, avi.FunnelProblem(d, 1.5)
-    if w["target"] == "iso":
-        prob = avi.DiagNormalProblem(np.full(d, 5.0, np.float32), np.ones(d, np.float32))
-    else:
-        L = np.tril(np.eye(d) + np.ones((d, d)) / (2.0 * d)).astype(np.float32)
-        prob = avi.DenseNormalProblem(np.full(d, 5.0, np.float32), L)
-    return q, prob
-
-
-def parity_vs_oracle(cx, p_dev, p_host, w, idx=11, batch=20):
-    """Value and gradient of ONE estimate of workload `w` at its own shape against the fp64 numpy oracle on identical eps (read back from
-    the device).  Test infrastructure, outside every timed region.  None for workloads the oracle cannot finish in seconds (C3)."""
-    from oracle import oracle as O
-    d = w["d"]
-    if w["target"] == "iso":
-        tgt = O.DiagNormalTarget(np.full(d, 5.0), np.ones(d))
-    elif w["target"] == "dense":
-        tgt = O.DenseNormalTarget(np.full(d, 5.0), np.tril(np.eye(d) + np.ones((d, d)) / (2.0 * d)).astype(np.float32).astype(np.float64))
-    elif w["target"] == "funnel":
-        tgt = O.FunnelStackedTarget(d, 1.5)
-    else:
-        return None
-    # a batch as the timed region issues it (mivi_estimate_gradient_each: the same kernels as mivi_estimate_gradient_n, every estimate kept):
-    # EVERY value against the oracle, first / middle / last gradient
-    n = int(batch)
-    vals, grads = cx.estimate_gradient_each(p_dev, idx, n)
-    cx.synchronize()
-    vals, grads = vals.cpu().numpy().astype(np.float64), grads.cpu().numpy()
-    p64 = np.asarray(p_host, dtype=np.float64)
-    vrel, grel = 0.0, 0.0
-    for i in range(n):
-        _, eps = cx.sample(p_dev, idx + i)
-        ref = O.estimate_gradient(p64, d, w["family"], tgt, eps.cpu().numpy().astype(np.float64), w["entropy"])
-        vrel = max(vrel, abs(vals[i] - ref["value"]) / abs(ref["value"]))
-        if i in (0, n // 2, n - 1):
-            grel = max(grel, float(np.linalg.norm(grads[i].astype(np.float64) - ref["grad"]) / np.linalg.norm(ref["grad"])))
-    return dict(value_rel=vrel, grad_rel_l2=grel, estimate_idx=idx, batch=n,
-                note="max over EVERY estimate of a %d-estimate batch issued like the timed ones (values); gradients of its first, middle and last estimate" % n)
-
-
-def cpu_baseline_blas(lib, CO, w, params, tm, ts, budget_s=8.0):
-    """A second CPU leg for the full-rank family: the same estimate with its two contractions on the BLAS numpy links (OpenBLAS in this
-    image), every core -- what the reference's `scale * eps` (src/families/location_scale.jl:76: a BLAS call, bench/benchmarks.jl:15 sets
-    the BLAS threads) and the AD pull-back's products cost at best.  Timed twice: eps drawn inside the timed call with numpy's ziggurat
-    generator (a whole estimate, like every other figure of this bench), and eps PRE-DRAWN outside it (the contractions + elementwise
-    work alone).  Everything else (target, entropy term, tril, scaling) in numpy.  GFLOP/s: `gflops_executed` counts the two full
-    d x d x n_mc GEMMs the BLAS runs (2 * 2 d^2 n_mc), `gflops_algorithmic` the triangular halves the estimate needs (2 d^2 n_mc)."""
-    d, M = w["d"], w["n_mc"]
-    mu = np.ascontiguousarray(params[:d], dtype=np.float32)
-    Cm = np.asfortranarray(np.tril(np.asarray(params[d:], dtype=np.float32).reshape(d, d, order="F")))
-    istd = (1.0 / ts).astype(np.float32)
-
-    rng_np = np.random.default_rng(SEED & 0xFFFFFFFF)
-    tril_mask = np.tril(np.ones((d, d), dtype=np.float32))
-    pool = [np.asfortranarray(rng_np.standard_normal((d, M), dtype=np.float32)) for _ in range(8)]
-
-    def one(eps=None):
-        if eps is None:
-            # numpy's ziggurat normals (what `rand(rng, Normal, d, M)` costs the reference, ~5 ns each)
-            eps = np.asfortranarray(rng_np.standard_normal((d, M), dtype=np.float32))
-        Z = Cm @ eps
-        Z += mu[:, None]
-        U = (Z - tm[:, None]) * istd[:, None]
-        ell = -0.5 * float(np.sum(U * U, dtype=np.float64))
-        W = -U * istd[:, None]
-        G = W @ eps.T
-        G *= tril_mask
-        G *= -1.0 / M
-        G[np.diag_indices(d)] -= 1.0 / np.diag(Cm)
-        gmu = -W.sum(axis=1) / M
-        return ell, gmu, G
-
-    def leg(predrawn, budget):
-        one(pool[0] if predrawn else None)
-        t0 = time.perf_counter()
-        one(pool[1] if predrawn else None)
-        t1 = time.perf_counter() - t0
-        reps = int(max(5, min(200, budget / max(t1, 1e-6))))
-        ts_ = []
-        for i in range(reps):
-            t0 = time.perf_counter()
-            one(pool[i % len(pool)] if predrawn else None)
-            ts_.append(time.perf_counter() - t0)
-        ts_.sort()
-        return ts_[len(ts_) // 2], reps
-
-    med, reps = leg(False, budget_s / 2)
-    med_pre, reps_pre = leg(True, budget_s / 2)
-    try:
-        import numpy.__config__ as npc
-        blas_name = str(npc.CONFIG["Build Dependencies"]["blas"]["name"])
-    except Exception:   # noqa: BLE001
-        blas_name = "numpy's BLAS"
-    fl = 2.0 * d * d * M
-    return dict(estimates_per_s=1.0 / med, median_s=med, reps=reps, blas=blas_name,
-                gflops_algorithmic=fl / med / 1e9, gflops_executed=2 * fl / med / 1e9,
-                eps_predrawn=dict(estimates_per_s=1.0 / med_pre, median_s=med_pre, reps=reps_pre,
-                                  gflops_algorithmic=fl / med_pre / 1e9, gflops_executed=2 * fl / med_pre / 1e9,
-                                  note="eps taken from a pool drawn before the timed region: the two GEMMs + the numpy elementwise work alone"),
-                note="two GEMMs (d x d x n_mc each, f32) on the BLAS + numpy elementwise work, all cores; eps drawn with numpy's ziggurat generator (included)")
-
-
-def cpu_baseline(w, params, budget_s=24.0):
-    """The oracle's C leg (oracle/mivi_oracle.c: a port of the reference semantics with the closed-form VJP,
-    cheaper than the reference's AD path) timed on this box's host cores.  Protocol (the reference's
-    bench/benchmarks.jl:15 runs with the BLAS threads of the box): team sizes 1, 2, 4, ... up to every CPU this
-    process may use -- each >= 20 repetitions of one whole estimate incl. eps generation, MEDIAN reported with the eps
-    generation's share and the contractions' GFLOP/s (2 d^2 n_mc algorithmic flops per full-rank estimate), the whole leg
-    bounded by `budget_s` seconds of wall time (the repetition count shrinks, never below 5, if the box is slow)."""
-    from oracle import c_oracle as CO
-    if not os.path.exists(CO.PATH):
-        import subprocess
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
-    # the port compiled for THIS box (-march=native, BASELINE.md 2) when gcc is here; the shipped x86-64-v3 build otherwise
-    build = "-O3 -march=x86-64-v3 -fopenmp (shipped)"
-    lib = None
-    try:
-        import subprocess
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        lib = CO.load(CO.NATIVE_PATH)
-        build = "-O3 -march=native -fopenmp (built on this box)"
-    except Exception:   # noqa: BLE001
-        lib = CO.load()
-    d, M, fam = w["d"], w["n_mc"], w["family"]
-    try:
-        avail = len(os.sched_getaffinity(0))     # CPUs this process may run on
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    try:                                          # cgroup v2 CPU quota, if any
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            avail = max(1, min(avail, int(int(q) / int(per))))
-    except (OSError, ValueError):
-        pass
-    tm, ts = np.full(d, 5.0, np.float32), np.ones(d, np.float32)
-    work = np.empty(2 * d * M, dtype=np.float32)
-    grad = np.empty_like(np.ascontiguousarray(params, dtype=np.float32))
-    eps_buf = np.empty((d, M), dtype=np.float32, order="F")
-    fl = 2.0 * d * d * M if fam == 1 else 6.0 * d * M
-
-    def one(i):
-        t0 = time.perf_counter()
-        eps = CO.fill_eps(lib, np.float32, SEED, i, d, M, out=eps_buf)
-        t1 = time.perf_counter()
-        CO.estimate_gradient(lib, np.float32, fam, d, M, params, eps, tm, ts, w["entropy"], work, grad)
-        return t1 - t0, time.perf_counter() - t1
-
-    legs = {}
-    t_leg0 = time.perf_counter()
-    teams = sorted({1, avail} | {t for t in (2, 4, 8, 16, 32) if t < avail})
-    for nt in teams:
-        lib.mo32_set_threads(nt)
-        one(0)                                   # warm (thread team start-up, page faults)
-        t1 = sum(one(1))
-        share = budget_s / len(teams)
-        reps = int(max(5, min(100, share / max(t1, 1e-6))))
-        reps = max(reps, 20) if 20 * t1 <= share else reps
-        ts_, te_ = [], []
-        for i in range(reps):
-            a, b = one(i + 2)
-            ts_.append(a + b)
-            te_.append((a, b))
-        ts_.sort()
-        med = ts_[len(ts_) // 2]
-        med_eps = sorted(a for a, _ in te_)[len(te_) // 2]
-        med_est = sorted(b for _, b in te_)[len(te_) // 2]
-        legs[nt] = dict(threads=nt, reps=reps, median_s=med, min_s=ts_[0], max_s=ts_[-1], estimates_per_s=1.0 / med,
-                        eps_generation_s=med_eps, estimate_s=med_est, gflops_estimate=fl / med_est / 1e9)
-    wall = time.perf_counter() - t_leg0
-    model = ""
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    best = max(legs.values(), key=lambda l: l["estimates_per_s"])
-    blas = None
-    if fam == 1:
-        blas = cpu_baseline_blas(lib, CO, w, params, tm, ts, budget_s=8.0)
-    sample = (f"median of {best['reps']} whole estimates of the same (d={d}, n_mc={M}) workload incl. eps generation, f32, OpenMP "
-              f"{best['threads']} threads on '{model}' ({avail} CPUs available), {best['gflops_estimate']:.0f} GFLOP/s in the estimate "
-              f"(2 d^2 n_mc flops, eps generation {best['eps_generation_s'] * 1e3:.2f} ms of {best['median_s'] * 1e3:.2f} ms), leg wall time {wall:.1f} s")
-    value, cores, leg = best["estimates_per_s"], best["threads"], "c_port"
-    if blas and blas["estimates_per_s"] > value:   # the CPU's best foot forward: whichever leg is faster is the reported baseline
-        value, cores, leg = blas["estimates_per_s"], avail, "blas"
-        sample = (f"median of {blas['reps']} whole estimates of the same (d={d}, n_mc={M}) workload, f32: both contractions on {blas['blas']} "
-                  f"(all {avail} CPUs of '{model}', {blas['gflops_executed']:.0f} GFLOP/s executed), numpy ziggurat normals + numpy elementwise "
-                  f"work included ({blas['eps_predrawn']['estimates_per_s']:.0f} estimates/s with eps pre-drawn); the C port's legs are in thread_scaling")
-    return dict(value=value, unit="ELBO-grad-estimates/s", cores=cores, kind="port", leg=leg, build=build, blas=blas, sample=sample, cpu=model, cpus_available=avail,
-                gflops=(best["gflops_estimate"] if leg == "c_port" else blas["gflops_algorithmic"]),
-                one_thread=legs.get(1), all_cores=legs.get(avail), thread_scaling=[legs[t] for t in teams], threads=lib.mo32_max_threads())
-
-
-LINE_LIMIT = 4096   # bytes: the driver keeps an 8 KiB stdout tail and parses the LAST line (round 4's 25.7 KB line came back `parsed: null`)
-
-
-def _num(x, sig=6):
-    """A float rounded to `sig` significant digits (None / non-numbers pass through)."""
-    if isinstance(x, bool) or not isinstance(x, (int, float)):
-        return x
-    if isinstance(x, int) or x == 0 or x != x or x in (float("inf"), float("-inf")):
-        return x
-    return float("%.*g" % (sig, x))
-
-
-def _get(o, *path, default=None):
-    for k in path:
-        if not isinstance(o, dict) or k not in o or o[k] is None:
-            return default
-        o = o[k]
-    return o
-
-
-def compact_line(full):
-    """The ONE stdout line the driver parses, built from the full result dict: <= LINE_LIMIT bytes, every contract key, `roofline` and
-    `cpu_baseline` as flat objects, one number per `also` leg.  Everything else (per-kernel traffic blocks, thread scaling, stage times,
-    notes) lives in the full file (`full`: gpurun_out/bench_full.json) and on stderr.  Pure function of its argument: tests/test_bench_line.py
-    feeds it canned dicts on the CPU."""
-    roof = full.get("roofline") or None
-    r = None
-    if roof:
-        tr = roof.get("traffic") or None
-        lanes = roof.get("estimates_per_launch", 1)
-        ric = roof.get("rocprof_in_chain") or None
-        r = {
-            "bound": roof.get("bound"), "kernel": str(roof.get("kernel", ""))[:96],
-            "achieved": _num(roof.get("achieved")), "peak": roof.get("peak"), "unit": roof.get("unit"), "frac": _num(roof.get("frac"), 4),
-            # the same kernel on the pipe it executes on: split-operand products run on the 16-bit matrix pipe (2.5 PFLOP/s dense)
-            "frac_survey_8d": _num(roof.get("frac_survey_8d"), 4),
-            "frac_16bit_pipe": _num(_get(roof, "pipe16", "frac"), 4), "frac_f32_mfma": _num(_get(roof, "f32_mfma", "frac"), 4),
-            "basis": str(roof.get("basis", ""))[:330] or None,
-            "avg_launch_us": _num(roof.get("avg_launch_us"), 5), "lanes": lanes,
-            "traffic": (None if not tr else {"bytes_per_launch": _num(tr.get("bytes_per_launch")), "lanes": tr.get("lanes_per_launch", lanes),
-                                             "over_algorithmic": _num(tr.get("over_algorithmic"), 3), "GBs": _num(tr.get("GBs"), 5), "frac_of_8TBs": _num(tr.get("frac_of_8TBs"), 4),
-                                             "src": str(tr.get("profile", ""))[:64] or None}),
-            "rocprof_in_chain": (None if not ric else {"avg_us": _num(ric.get("avg_us"), 5), "lanes": ric.get("lanes"), "src": str(ric.get("source", ""))[:64]}),
-        }
-        oc = roof.get("other_contraction")
-        if isinstance(oc, list):
-            oc = oc[0] if oc else None
-        if oc:
-            r["other"] = {"kernel": str(oc.get("kernel", ""))[:48], "avg_launch_us": _num(oc.get("avg_launch_us"), 5), "frac": _num(oc.get("frac"), 4),
-                          "frac_f32_mfma": _num(oc.get("frac_f32_mfma"), 4)}
-        if roof.get("draws"):
-            r["draws"] = {"avg_launch_us": _num(_get(roof, "draws", "avg_launch_us"), 5), "GBs": _num(_get(roof, "draws", "achieved_GBs"), 4)}
-        we = full.get("whole_estimate") or {}
-        r["whole_estimate"] = {"hbm_frac_of_8TBs": _num(we.get("hbm_equiv_frac_of_8TBs"), 4), "f32_mfma_TFs": _num(we.get("f32_mfma_TFs"), 4)}
-    cb = full.get("cpu_baseline") or None
-    c = None
-    if cb:
-        c = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "threads": cb.get("threads"),
-             "kind": cb.get("kind"), "leg": cb.get("leg"), "cpu": str(cb.get("cpu", ""))[:48], "sample": str(cb.get("sample", ""))[:200],
-             "one_thread": _num(_get(cb, "one_thread", "estimates_per_s"))}
-    also = None
-    if full.get("also"):
-        also = {}
-        for k, v in full["also"].items():
-            if not isinstance(v, dict):
-                continue
-            if "error" in v:
-                also[k] = None
-            elif "value" in v:
-                also[k] = _num(v["value"], 5)
-                if k.endswith("_loop") and "us_per_step" in v:
-                    also[k + "_us"] = _num(v["us_per_step"], 4)
-            elif "us_per_call" in v:
-                also[k] = _num(1e6 / v["us_per_call"], 5)
-        if isinstance(full["also"].get("ns_f64"), dict) and "frac_f64_mfma" in full["also"]["ns_f64"]:
-            also["ns_f64_frac_f64_mfma"] = _num(full["also"]["ns_f64"]["frac_f64_mfma"], 3)
-        also["units"] = "estimates/s (c2 ns_dense ns_stl c5 c3 ns_host_boundary ns_f64), steps/s (*_loop, reference_benchmark_grid[_f64]), calls/s (stein), samples/s (ns_objective_1e5)"
-    cfg = dict(full.get("config") or {})
-    cfg["launch"] = str(cfg.get("launch", ""))[:200]
-    cfg["workload"] = str(cfg.get("workload", ""))[:128]
-    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                                     "vs_baseline", "dtype", "data")}
-    line["value"] = _num(line["value"], 7)
-    line["ms_per_step"] = _num(line["ms_per_step"], 6)
-    line["config"] = {k: cfg.get(k) for k in ("workload", "d", "n_mc_per_gpu", "n_mc_total", "family", "launch")}
-    line["roofline"] = r
-    line["cpu_baseline"] = c
-    line["elbo_rel_err_vs_cpu_fp64"] = _num(full.get("elbo_rel_err_vs_cpu_fp64"), 3)
-    line["grad_rel_l2_vs_cpu_fp64"] = _num(_get(full, "parity_vs_fp64_oracle", "grad_rel_l2"), 3)
-    line["steady_state_est_per_s"] = _num(_get(full, "steady_state", "estimates_per_s"), 6)
-    line["repeat_ms_per_step"] = [_num(x, 4) for x in (full.get("repeat_ms_per_step") or [])][:5]
-    line["also"] = also
-    if full.get("dist"):
-        d = full["dist"]
-        line["dist"] = {"route": d.get("route"), "pipeline": str(d.get("pipeline", ""))[:64] or None,
-                        "estimate_sharded_est_per_s": _num(_get(d, "estimate_sharded", "value"), 6),
-                        "us_per_estimate": d.get("us_per_estimate"),
-                        "p2p_verified": _get(d, "p2p_vs_allreduce", "verified"),
-                        "also": ({k: (None if "error" in v else _num(v.get("value"), 5)) for k, v in d["also"].items()} if isinstance(d.get("also"), dict) else None)}
-    line["full"] = full.get("full_path")
-    s = json.dumps(line, separators=(",", ":"))
-    # belt and braces: shed optional blocks, largest first, until the line fits
-    for k in ("repeat_ms_per_step", "also", "dist", "steady_state_est_per_s"):
-        if len(s) <= LINE_LIMIT:
-            break
-        line.pop(k, None)
-        s = json.dumps(line, separators=(",", ":"))
-    if len(s) > LINE_LIMIT:
-        for blk, key in (("roofline", "kernel"), ("cpu_baseline", "sample"), ("config", "launch"), ("config", "workload")):
-            if isinstance(line.get(blk), dict) and key in line[blk]:
-                line[blk][key] = str(line[blk][key])[:40]
-        s = json.dumps(line, separators=(",", ":"))
-    assert len(s) <= LINE_LIMIT, len(s)
-    return s
+from benchlib.config import (SEED, PEAK_HBM_GBS, PEAK_F32_MFMA_TF, PEAK_BF16_MFMA_TF, PLANE_BYTES, PEAK_VALU_GINST, BENCH_ENV_OK, WORKLOADS,   # noqa: E402,F401
+                             algorithmic_cost)
+from benchlib.rooflines import pmc_traffic, pmc_valu, rocprof_avg, mf_roofline, fr_roofline, other_roofline, stl_block   # noqa: E402,F401
+from benchlib.baseline import make_problem, parity_vs_oracle, cpu_baseline_blas, cpu_baseline   # noqa: E402,F401
+from benchlib import line as _line   # noqa: E402
+from benchlib.line import LINE_LIMIT, compact_line, _num, _get   # noqa: E402,F401
 
 
 def emit(full):
-    """Full result -> gpurun_out/bench_full.json (+ stderr), compact line -> stdout (the last thing written there)."""
-    path = os.path.join(ROOT, "gpurun_out", "bench_full.json")
-    try:
-        os.makedirs(os.path.dirname(path), exist_ok=True)
-        with open(path, "w") as f:
-            json.dump(full, f, indent=1)
-        full["full_path"] = os.path.relpath(path, ROOT)
-    except OSError:
-        full["full_path"] = None
-    sys.stderr.write("bench.py full result: " + json.dumps(full) + "\n")
-    sys.stderr.flush()
-    sys.stdout.write(compact_line(full) + "\n")
-    sys.stdout.flush()
+    """Full result -> gpurun_out/bench_full.json under this file's directory (+ stderr), compact line -> stdout (benchlib/line.py)."""
+    return _line.emit(full, ROOT)
 
 
 def main():
@@ -1498,3 +824,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+

@@ -206,8 +206,10 @@ class LogRegTarget:
         sigma = exp(s), logprior_sigma = logpdf(LogNormal(0,3), sigma), + logabsdetjac = s.
     """
 
-    def __init__(self, X, y, variant="logsigma_normal", likeadj=1.0):
-        self.X = np.asarray(X, dtype=np.float64)
+    def __init__(self, X, y, variant="logsigma_normal", likeadj=1.0, keep_storage=False):
+        # keep_storage: X stays in the dtype it was given in (float32 data of 10^6 rows: 2 GB instead of 4); only the batched
+        # evaluation, which promotes every row chunk to f64, may then be used
+        self.X = np.asarray(X) if keep_storage else np.asarray(X, dtype=np.float64)
         self.y = np.asarray(y, dtype=np.float64)
         self.variant = variant
         self.likeadj = float(likeadj)
@@ -216,6 +218,8 @@ class LogRegTarget:
         return self.X.shape[1] + 1
 
     def logdensity_and_gradient(self, z):
+        if self.X.dtype != np.float64:
+            raise TypeError("LogRegTarget(keep_storage=True): use logdensity_and_gradient_batch")
         p = self.X.shape[1]
         beta, s = z[:p], z[p]
         sigma = math.exp(s)
@@ -243,6 +247,40 @@ class LogRegTarget:
 
     def logdensity(self, z):
         return self.logdensity_and_gradient(z)[0]
+
+    def logdensity_and_gradient_batch(self, Z, row_chunk=65536):
+        """The same function for all columns of Z (d x M) at once -- `logdensity_and_gradient` column by column, with the two data products
+        as matrix products over row chunks (X may be float32 storage: every chunk is promoted to f64 before it is used).  What makes the
+        n = 10^6 configuration (BASELINE configs[2]) checkable in seconds; equal to the per-column loop to rounding (tests/test_oracle_c.py)."""
+        Z = np.asarray(Z, dtype=np.float64)
+        p, M = self.X.shape[1], Z.shape[1]
+        B, s = Z[:p], Z[p]
+        sigma = np.exp(s)
+        loglike = np.zeros(M)
+        xtr = np.zeros((p, M))
+        for lo in range(0, self.X.shape[0], row_chunk):
+            Xc = np.asarray(self.X[lo:lo + row_chunk], dtype=np.float64)
+            yc = self.y[lo:lo + row_chunk, None]
+            logit = Xc @ B
+            loglike += np.sum(yc * logit - _log1pexp(logit), axis=0)
+            xtr += Xc.T @ (yc - 1.0 / (1.0 + np.exp(-logit)))
+        bb = np.sum(B * B, axis=0)
+        logprior_beta = -0.5 * p * LOG2PI - p * s - 0.5 * bb / sigma ** 2
+        G = np.empty((p + 1, M))
+        G[:p] = self.likeadj * xtr - B / sigma ** 2
+        g_s = -p + bb / sigma ** 2
+        if self.variant == "logsigma_normal":
+            logprior_sigma = -0.5 * math.log(2.0 * math.pi * 9.0) - sigma ** 2 / 18.0
+            g_s = g_s - (sigma ** 2) / 9.0
+            jac = 0.0
+        elif self.variant == "lognormal_exp_bijector":
+            logprior_sigma = -s - math.log(3.0) - 0.5 * LOG2PI - s * s / 18.0
+            g_s = g_s - 1.0 - s / 9.0 + 1.0
+            jac = s
+        else:
+            raise ValueError(self.variant)
+        G[p] = g_s
+        return self.likeadj * loglike + logprior_beta + logprior_sigma + jac, G
 
     def subsample(self, idx):
         """AdvancedVI.subsample for the tutorial's LogReg (docs/src/tutorials/subsampling.md:99-102): the rows `idx`,
@@ -424,7 +462,7 @@ def c_inv_t_eps(q: MvLocationScale, eps: np.ndarray) -> np.ndarray:
     return np.linalg.solve(np.tril(q.scale).T, eps)
 
 
-def estimate_gradient(params, d, family, prob, eps, ent_kind):
+def estimate_gradient(params, d, family, prob, eps, ent_kind, batch_target=False):
     """What `estimate_gradient!` (src/algorithms/repgradelbo.jl:151-177) leaves in `out`:
     value = -elbo and gradient = d(value)/d(params), written out in closed form
     (checked against AD of the forward in tests/test_oracle_pinning.py).
@@ -439,8 +477,11 @@ def estimate_gradient(params, d, family, prob, eps, ent_kind):
     Z = rand_batch(q, eps)
     ell = np.empty(M)
     G = np.empty((d, M))
-    for m in range(M):
-        ell[m], G[:, m] = prob.logdensity_and_gradient(Z[:, m])
+    if batch_target and hasattr(prob, "logdensity_and_gradient_batch"):   # (the same arithmetic with the data products blocked: large data sets)
+        ell, G = prob.logdensity_and_gradient_batch(Z)
+    else:
+        for m in range(M):
+            ell[m], G[:, m] = prob.logdensity_and_gradient(Z[:, m])
     diag = q.scale if q.is_meanfield else np.diag(q.scale)
     ent_cf = entropy_closed_form(q)
     half_eps2 = 0.5 * np.sum(eps * eps, axis=0)

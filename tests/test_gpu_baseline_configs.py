@@ -143,6 +143,27 @@ def test_c3_logreg_fullrank_oracle_parity_reduced_n():
     ctx.close()
 
 
+def test_c3_logreg_full_size_oracle_parity():
+    """BASELINE configs[2] at its FULL size, n = 10^6 rows, D = 512, full-rank, n_mc = 128, against the fp64 oracle on identical eps (round 5's
+    verdict: parity existed at n = 20 000 only).  The oracle's batched LogReg evaluation -- row-chunked f64 matrix products over the f32 data,
+    equal to the per-column restatement to rounding (tests/test_oracle_pinning.py) -- finishes in seconds."""
+    rng = np.random.default_rng(15)
+    n, d, M = 1_000_000, 512, 128
+    X, y = _c3_data(n, rng)
+    q = avi.FullRankGaussian(np.zeros(d, np.float32), 0.6 * np.eye(d, dtype=np.float32))
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
+    ctx.set_problem(avi.LogRegProblem(X, y, "logsigma_normal", 1.0))
+    assert ctx.logreg_kernels() == dict(mfma=True, logits_planes=True, xtr_planes=True)
+    _, eps = ctx.sample(params, 4)
+    v, g = ctx.estimate_gradient(params, 4)
+    ref = O.estimate_gradient(params.astype(np.float64), d, O.FULLRANK, O.LogRegTarget(X, y, "logsigma_normal", 1.0, keep_storage=True),
+                              eps.cpu().numpy().astype(np.float64), 0, batch_target=True)
+    assert abs(float(v.item()) - ref["value"]) <= 1e-5 * abs(ref["value"])
+    assert rel_err(g.cpu().numpy(), ref["grad"]) < C3_GRAD_RTOL
+    ctx.close()
+
+
 def test_c3_logreg_full_size_properties():
     """n = 10^6 rows, D = 512, full-rank, n_mc = 128 (BASELINE config 3): no CPU oracle at this size."""
     rng = np.random.default_rng(13)

@@ -347,3 +347,28 @@ def test_proximal_operator_negative_diagonal_stays_positive_and_stationary():
     # the failure mode the stable form removes: the literal expression in Float32
     c32, g32 = np.float32(-1.0), np.float32(1e-9)
     assert c32 + (np.sqrt(c32 * c32 + np.float32(4) * g32) - c32) / np.float32(2) == 0.0
+
+
+def test_logreg_batched_evaluation_equals_the_per_column_loop():
+    """oracle.LogRegTarget.logdensity_and_gradient_batch (row-chunked matrix products, what makes BASELINE configs[2]'s n = 10^6 checkable) is
+    the per-column restatement to rounding, for both variants, with f32 storage promoted chunk by chunk, and through estimate_gradient."""
+    rng = np.random.default_rng(21)
+    n, p, M = 1000, 9, 7
+    X32 = (rng.normal(size=(n, p)) / 3).astype(np.float32)
+    y = (rng.uniform(size=n) < 0.4).astype(np.uint8)
+    Z = rng.normal(size=(p + 1, M)) * 0.5
+    for variant, adj in (("logsigma_normal", 1.7), ("lognormal_exp_bijector", 1.0)):
+        t = O.LogRegTarget(X32, y, variant, adj)
+        tb = O.LogRegTarget(X32, y, variant, adj, keep_storage=True)
+        ell, G = tb.logdensity_and_gradient_batch(Z, row_chunk=300)
+        for m in range(M):
+            l1, g1 = t.logdensity_and_gradient(Z[:, m])
+            assert abs(ell[m] - l1) <= 1e-12 * abs(l1) and np.allclose(G[:, m], g1, rtol=1e-11, atol=1e-12)
+        with pytest.raises(TypeError):
+            tb.logdensity_and_gradient(Z[:, 0])
+    d = p + 1
+    params = np.concatenate([rng.normal(size=d) * 0.1, (0.6 * np.eye(d)).reshape(-1)])
+    eps = rng.normal(size=(d, M))
+    a = O.estimate_gradient(params, d, O.FULLRANK, t, eps, 0)
+    b = O.estimate_gradient(params, d, O.FULLRANK, tb, eps, 0, batch_target=True)
+    assert abs(a["value"] - b["value"]) <= 1e-12 * abs(a["value"]) and np.allclose(a["grad"], b["grad"], rtol=1e-10, atol=1e-12)
