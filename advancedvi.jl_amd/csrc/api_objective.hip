@@ -176,11 +176,12 @@ mivi_status_t mivi_gauss_expected_grad_hess2(mivi_ctx_t *c, const void *params, 
   if (!c || !params || !logpi_avg || !grad || !hess) return MIVI_ERR_BAD_ARG;
   if (c->cfg.family != MIVI_FULLRANK)
     return fail(c, MIVI_ERR_UNSUPPORTED, "gauss_expected_grad_hess takes a triangular scale (full-rank family)");
-  const bool builtin = (c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS) && !c->bij_on;
+  const bool sampled = target_has_hess2(c);   // logistic regression / funnel: the Hessian depends on z -- linear in per-sample statistics (kernels_hess2.hip)
+  const bool builtin = ((c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS) && !c->bij_on) || sampled;
   const bool plugin = c->target == TGT_CALLBACK && c->cb_hess && !c->bij_on;
   if (!builtin && !plugin)
-    return fail(c, MIVI_ERR_UNSUPPORTED, "second-order branch: the target has no Hessian here (built-in Gaussian targets, or a plugin with "
-                                         "mivi_set_target_hess_callback, no bijector); use mivi_gauss_expected_grad_hess (Stein identity)");
+    return fail(c, MIVI_ERR_UNSUPPORTED, "second-order branch: the target has no Hessian here (built-in targets without a Stacked bijector, or a "
+                                         "plugin with mivi_set_target_hess_callback); use mivi_gauss_expected_grad_hess (Stein identity)");
   if (n_samples <= 0) n_samples = c->cfg.n_mc;
   (void)hipSetDevice(c->cfg.device);
   const int d = c->cfg.d;
@@ -229,6 +230,10 @@ mivi_status_t mivi_gauss_expected_grad_hess2(mivi_ctx_t *c, const void *params, 
     return MIVI_OK;
   }
   if ((s = ensure(c, c->stein_g, (size_t)(d + 8) * sizeof(double), true))) return s;
+  if (sampled) {
+    if ((s = ensure(c, c->h2_acc, target_hess2_bytes(c), false))) return s;
+    if (!target_hess2_begin(c)) return fail(c, MIVI_ERR_HIP, "second-order branch: clearing the accumulators failed");
+  }
   const bool single_chunk = n_samples <= CH;
   char *part = (char *)c->tmp_out.p;   // [sum ell, sum 0.5 eps^2] of a chunk
   for (int off = 0, first = 1; off < n_samples; off += CH, first = 0) {
@@ -249,9 +254,11 @@ mivi_status_t mivi_gauss_expected_grad_hess2(mivi_ctx_t *c, const void *params, 
         hipLaunchKernelGGL(k_acc_value_f64, dim3(1), dim3(1), 0, c->stream, (double *)c->acc.p, (const double *)part, 1.0, first);
     }
     launch_stein_gsum(c, Mc, (double *)c->stein_g.p, first);
+    if (sampled) target_hess2_accumulate(c, Mc);   // (the chunk's samples are still in c->Z)
   }
   launch_stein_finish(c, (double)n_samples, (const double *)c->stein_g.p, (const double *)c->acc.p, single_chunk ? part : nullptr, grad, logpi_avg);
-  launch_const_hess(c, hess);
+  if (sampled) target_hess2_finish(c, n_samples, hess);
+  else launch_const_hess(c, hess);
   HIPCHK(c, hipGetLastError());
   return MIVI_OK;
 }

@@ -347,6 +347,7 @@ struct mivi_ctx {
   mivi::DevBuf row_part, status, d_idx, acc, tmp_params, tmp_out;
   mivi::DevBuf obj_vals;   // mivi_estimate_objective on the batch engine: the lanes' values
   mivi::DevBuf stein_A, stein_g;   // Stein estimator: eps G^T accumulator (dP x dP, T) and the f64 column sums of G
+  mivi::DevBuf h2_acc;             // second-order branch of the logistic-regression / funnel targets: f64 sums (kernels_hess2.hip)
   mivi::DevBuf dog_part;   // DoG / DoWG on large parameter vectors: 512 x 2 partial norms + the step size
   const uint64_t *idx_src = nullptr;   // mivi_set_index_source
   // speculative eps prefetch across single calls: the VJP kernel of estimate (seed, idx) also generates eps of
@@ -435,6 +436,12 @@ void launch_stein_outer(mivi_ctx *c, int M, void *A, double *gsum, int first, do
 void launch_stein_finish(mivi_ctx *c, double n, const double *gsum, const double *ell_sum, const void *ell_single, void *grad, void *logpi_avg);
 void launch_stein_gsum(mivi_ctx *c, int M, double *gsum, int first);   // gsum (+)= G 1 (the second-order branch: no eps G^T product)
 void launch_const_hess(mivi_ctx *c, void *hess);                      // hess = the built-in Gaussian targets' constant Hessian
+// kernels_hess2.hip: the sample average of the Hessians of the built-in logistic-regression / funnel targets (second-order branch)
+bool target_has_hess2(const mivi_ctx *c);
+size_t target_hess2_bytes(const mivi_ctx *c);
+bool target_hess2_begin(mivi_ctx *c);
+void target_hess2_accumulate(mivi_ctx *c, int Mc);
+void target_hess2_finish(mivi_ctx *c, int n_samples, void *hess);
 int fr_sample_blocks(const mivi_ctx *c, int M);
 int fr_dense_blocks(const mivi_ctx *c, int M);
 int eps_blocks(const mivi_ctx *c, int M);

@@ -103,19 +103,20 @@ class LogRegProblem:
 
     VARIANTS = {"logsigma_normal": 0, "lognormal_exp_bijector": 1}
 
-    def __init__(self, X, y, variant="logsigma_normal", likeadj=1.0):
+    def __init__(self, X, y, variant="logsigma_normal", likeadj=1.0, order=1):
         self.X = np.asarray(X)
         self.y = np.asarray(y)
         if variant not in self.VARIANTS:
             raise ValueError(f"unknown variant {variant}")
         self.variant = variant
         self.likeadj = float(likeadj)
+        self.order = int(order)   # 2: declares logdensity_gradient_and_hessian (the library averages the Hessians: csrc/kernels_hess2.hip)
 
     def dimension(self):
         return self.X.shape[1] + 1
 
     def capabilities(self):
-        return LogDensityOrder(1)
+        return LogDensityOrder(self.order)
 
     def n_rows(self):
         X = self.X
@@ -141,7 +142,7 @@ class LogRegSubset:
         return self.parent.dimension()
 
     def capabilities(self):
-        return LogDensityOrder(1)
+        return self.parent.capabilities()
 
     def subsample(self, batch):
         return LogRegSubset(self.parent, self.batch[np.asarray(batch, dtype=np.int64)])
@@ -158,15 +159,16 @@ class FunnelProblem:
     """Neal's funnel on the constrained scale under Stacked([log-bijector, identity]) (SURVEY.md 8d;
     wrapper pattern of README.md:76-82,102-106)."""
 
-    def __init__(self, d, sigma_v=1.5):
+    def __init__(self, d, sigma_v=1.5, order=1):
         self.d = int(d)
         self.sigma_v = float(sigma_v)
+        self.order = int(order)   # 2: declares logdensity_gradient_and_hessian (an arrow matrix: csrc/kernels_hess2.hip)
 
     def dimension(self):
         return self.d
 
     def capabilities(self):
-        return LogDensityOrder(1)
+        return LogDensityOrder(self.order)
 
 
 
@@ -175,15 +177,16 @@ class FunnelConstrainedProblem:
     """Neal's funnel on the constrained scale theta = [s; x] (s > 0), WITHOUT a bijector (mivi_set_target_funnel_constrained);
     TransformedProblem(FunnelConstrainedProblem(d, sv), StackedBijector([(0, 1, "exp"), (1, d, "identity")])) is FunnelProblem."""
 
-    def __init__(self, d, sigma_v=1.5):
+    def __init__(self, d, sigma_v=1.5, order=1):
         self.d = int(d)
         self.sigma_v = float(sigma_v)
+        self.order = int(order)   # 2: declares logdensity_gradient_and_hessian (an arrow matrix: csrc/kernels_hess2.hip)
 
     def dimension(self):
         return self.d
 
     def capabilities(self):
-        return LogDensityOrder(1)
+        return LogDensityOrder(self.order)
 
 
 class StackedBijector:

@@ -212,10 +212,12 @@ mivi_status_t mivi_gauss_expected_grad_hess_host(mivi_ctx_t *ctx, const void *pa
  * (LogDensityProblems.logdensity_gradient_and_hessian) the Hessian estimate is the SAMPLE AVERAGE of the Hessians at z_b = C u_b + m
  * (the same eps stream as the first-order branch), no Stein identity and no solve:
  *   logpi_avg <- mean_b logpi(z_b)     grad <- mean_b grad logpi(z_b)     hess <- mean_b hess logpi(z_b)   (d x d column-major)
- * Targets with a Hessian: the built-in diagonal / dense Gaussians (constant Hessians -1/sigma^2 / -P: written exactly), or a plugin
- * that registered a batched Hessian callback next to its order-1 callback -- Z (d x M) in; ell (M), G (d x M) and
- * Hsum (d x d, column-major) = the SUM over the M columns of hess logpi(z_m) out, host buffers, non-zero return aborts.
- * Any other target: MIVI_ERR_UNSUPPORTED (use the first-order entry, as the reference does for order-1 problems). */
+ * Targets with a Hessian: the built-in diagonal / dense Gaussians (constant Hessians -1/sigma^2 / -P: written exactly); the built-in
+ * logistic regression (both variants, also on a row selection) and the funnel (unconstrained and constrained) -- their Hessians are linear
+ * in per-sample statistics, so the average is one weighted Gram matrix X' diag(mean_b pi (1 - pi)) X resp. an arrow matrix, f64 sums
+ * (csrc/kernels_hess2.hip); or a plugin that registered a batched Hessian callback next to its order-1 callback -- Z (d x M) in; ell (M),
+ * G (d x M) and Hsum (d x d, column-major) = the SUM over the M columns of hess logpi(z_m) out, host buffers, non-zero return aborts.
+ * A Stacked bijector around the target: MIVI_ERR_UNSUPPORTED (use the first-order entry, as the reference does for order-1 problems). */
 typedef int32_t (*mivi_logdensity_gradient_and_hessian_fn)(void *user, const void *Z_host, int32_t d, int32_t M,
                                                            void *ell_host, void *G_host, void *Hsum_host);
 mivi_status_t mivi_set_target_hess_callback(mivi_ctx_t *ctx, mivi_logdensity_gradient_and_hessian_fn fn, void *user);

@@ -248,6 +248,21 @@ class LogRegTarget:
     def logdensity(self, z):
         return self.logdensity_and_gradient(z)[0]
 
+    def logdensity_gradient_and_hessian(self, z):
+        """LogDensityProblems.logdensity_gradient_and_hessian of the same model (what a LogDensityOrder{2} problem provides to
+        gaussian_expectation_gradient_and_hessian!, src/algorithms/gauss_expected_grad_hess.jl:61-83): the gradient's derivative, written out;
+        pinned by finite differences of `logdensity_and_gradient` (tests/test_oracle_pinning.py)."""
+        val, g = self.logdensity_and_gradient(z)
+        p = self.X.shape[1]
+        beta, s = z[:p], z[p]
+        is2 = math.exp(-2.0 * s)
+        pi = 1.0 / (1.0 + np.exp(-(self.X @ beta)))
+        H = np.zeros((p + 1, p + 1))
+        H[:p, :p] = -self.likeadj * (self.X.T * (pi * (1.0 - pi))) @ self.X - is2 * np.eye(p)
+        H[:p, p] = H[p, :p] = 2.0 * beta * is2
+        H[p, p] = -2.0 * float(beta @ beta) * is2 + (-2.0 * math.exp(2.0 * s) / 9.0 if self.variant == "logsigma_normal" else -1.0 / 9.0)
+        return val, g, H
+
     def logdensity_and_gradient_batch(self, Z, row_chunk=65536):
         """The same function for all columns of Z (d x M) at once -- `logdensity_and_gradient` column by column, with the two data products
         as matrix products over row chunks (X may be float32 storage: every chunk is promoted to f64 before it is used).  What makes the
@@ -320,6 +335,14 @@ class FunnelStackedTarget:
     def logdensity(self, eta):
         return self.logdensity_and_gradient(eta)[0]
 
+    def logdensity_gradient_and_hessian(self, eta):
+        """The arrow-shaped Hessian of the unconstrained funnel (finite-difference pinned in tests/test_oracle_pinning.py)."""
+        val, g = self.logdensity_and_gradient(eta)
+        e2, x = math.exp(-2.0 * eta[0]), eta[1:]
+        H = np.diag(np.concatenate([[-1.0 / self.sigma_v ** 2 - 2.0 * e2 * float(x @ x)], np.full(self.d - 1, -e2)]))
+        H[0, 1:] = H[1:, 0] = 2.0 * e2 * x
+        return val, g, H
+
 
 class FunnelConstrainedTarget:
     """The same funnel on its CONSTRAINED scale, theta = [s; x], s > 0, no bijector:
@@ -348,6 +371,14 @@ class FunnelConstrainedTarget:
 
     def logdensity(self, theta):
         return self.logdensity_and_gradient(theta)[0]
+
+    def logdensity_gradient_and_hessian(self, theta):
+        val, g = self.logdensity_and_gradient(theta)
+        s, x = theta[0], theta[1:]
+        sx2 = float(x @ x)
+        H = np.diag(np.concatenate([[self.d / s ** 2 - (1.0 - math.log(s)) / (self.sigma_v ** 2 * s ** 2) - 3.0 * sx2 / s ** 4], np.full(self.d - 1, -1.0 / s ** 2)]))
+        H[0, 1:] = H[1:, 0] = 2.0 * x / s ** 3
+        return val, g, H
 
 
 class StackedBijectorTarget:

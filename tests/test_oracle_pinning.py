@@ -372,3 +372,29 @@ def test_logreg_batched_evaluation_equals_the_per_column_loop():
     a = O.estimate_gradient(params, d, O.FULLRANK, t, eps, 0)
     b = O.estimate_gradient(params, d, O.FULLRANK, tb, eps, 0, batch_target=True)
     assert abs(a["value"] - b["value"]) <= 1e-12 * abs(a["value"]) and np.allclose(a["grad"], b["grad"], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("kind", ["logreg0", "logreg1", "funnel", "funnel_constrained"])
+def test_second_order_targets_hessian_is_the_derivative_of_the_gradient(kind):
+    """Round 6: `logdensity_gradient_and_hessian` of the logistic-regression and funnel restatements (what a LogDensityOrder{2} problem hands
+    to gaussian_expectation_gradient_and_hessian!'s second-order branch, gauss_expected_grad_hess.jl:61-83), pinned by central differences of
+    the (already pinned) gradients; symmetric."""
+    rng = np.random.default_rng(31)
+    if kind.startswith("logreg"):
+        n, p = 60, 6
+        X = rng.normal(size=(n, p)) / 2
+        y = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+        t = O.LogRegTarget(X, y, "logsigma_normal" if kind == "logreg0" else "lognormal_exp_bijector", 1.7 if kind == "logreg0" else 1.0)
+        z = np.concatenate([rng.normal(size=p) * 0.4, [0.3]])
+    elif kind == "funnel":
+        t = O.FunnelStackedTarget(7, 1.5)
+        z = np.concatenate([[0.4], rng.normal(size=6)])
+    else:
+        t = O.FunnelConstrainedTarget(7, 1.5)
+        z = np.concatenate([[1.3], rng.normal(size=6)])
+    v, g, H = t.logdensity_gradient_and_hessian(z)
+    v1, g1 = t.logdensity_and_gradient(z)
+    assert v == v1 and np.array_equal(g, g1) and np.allclose(H, H.T, rtol=0, atol=1e-14)
+    h = 1e-5
+    Hfd = np.stack([(t.logdensity_and_gradient(z + h * e)[1] - t.logdensity_and_gradient(z - h * e)[1]) / (2 * h) for e in np.eye(z.size)], axis=1)
+    assert np.allclose(H, Hfd, rtol=1e-6, atol=1e-7)
