@@ -432,10 +432,9 @@ class MiviContext:
         return r & 3, bool(r & 16)
 
     def logreg_kernels(self, n_samples=0):
-        """dict(mfma, logits_planes, xtr_planes, fused): which kernels the native logistic-regression target's contractions run
-        (mivi_logreg_kernels); fused = ONE pass over X (k_lr_fused: logits, residuals and X^T R per row tile in one persistent workgroup)."""
+        """dict(mfma, logits_planes, xtr_planes): which kernels the native logistic-regression target's contractions run (mivi_logreg_kernels)."""
         r = int(self.lib.mivi_logreg_kernels(self.h, int(n_samples)))
-        return dict(mfma=bool(r & 1), logits_planes=bool(r & 2), xtr_planes=bool(r & 4), fused=bool(r & 8))
+        return dict(mfma=bool(r & 1), logits_planes=bool(r & 2), xtr_planes=bool(r & 4))
 
     # -- next to the hot path ---------------------------------------------------------------------
     def clip_scale(self, params, epsilon):

@@ -952,195 +952,6 @@ __global__ __launch_bounds__(512, 6) void k_lr_xtr_planes(LrMfmaArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// ONE PASS over X (round 6; asked for since round 4): logits -> residuals -> X^T R per 128-row tile inside one persistent workgroup.
-// The two-kernel route reads X's planes twice from HBM (one orientation per contraction: 2 x 2.0 GB at C3) and hands the residuals over
-// through memory (2 x 0.5 GB): 5.3 GB per estimate against SURVEY 8d's 2.05.  Here a workgroup owns a contiguous range of 128-row tiles and
-// ALL 128 samples of its sample group; per tile
-//   phase A  logits L = X_t Z (k_lr_logits_planes' loop: 16-feature stages of X's A-orientation planes + the samples' planes by LDS-DMA)
-//            -> residuals r = y - logistic(L) straight from the accumulators into an LDS tile as the A-operand fragments of X^T R
-//               (rows = samples, k = data rows: a lane's registers ARE the fragment, as in the two-kernel route -- but 64 KiB of LDS, no memory)
-//   phase B  out[sample, feature] += R_t' X_t with X's SAME A-orientation planes staged again (16 KiB = one 32-row block x 128 features per
-//            stage; the tile was read microseconds ago: L2 / memory-side cache, newest groups first) and TRANSPOSED on the way from LDS to
-//            the registers by ds_read_b64_tr_b16: 16 lanes fetch a 4 x 16 halfword block from per-lane addresses (row stride free) and
-//            lane c receives column c (probed: tools/ubench/tr_b16_probe.hip) -- a fragment of rows = features, k = data rows out of
-//            fragments of rows = data rows, k = features.  X's second orientation (2 GB at C3) is not needed on this route.
-// out[128 samples x 512 features] stays in registers across all tiles of the workgroup (128 accumulator registers per lane, one workgroup
-// of eight waves per CU) and is written ONCE as the workgroup's partial (k_lr_greduce adds the workgroups' partials in a fixed order).
-// Requires ldx % 128 == 0 (whole 128-feature stages), ldx <= 512, M % 128 == 0.  NFQ = ldx / 128.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lr_lds_store_frag(unsigned *dst, const float *x) {   // dst: the lane's 16 bytes of plane 0 of an LDS fragment
-  u32x4v uh, ul;
-  fb_split2(x, uh, ul);
-  *(u32x4v *)dst = uh;
-  *(u32x4v *)(dst + 256) = ul;
-}
-template <int NFQ>
-__global__ __launch_bounds__(512, 2) void k_lr_fused(LrMfmaArgs a) {
-  constexpr int NR = 3, kPW = 2;
-  __shared__ __attribute__((aligned(16))) unsigned lds[NR * kStageW + 32 * kFrag];
-  __shared__ float ll_lds[128];
-  __shared__ float y_lds[128];
-  __shared__ double ll_acc[128];
-  unsigned *Rt = lds + NR * kStageW;   // the tile's residuals: fragment (sample block sb, 16-row group rg8) at (sb 8 + rg8) kFrag
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w >> 2, wn = w & 3;
-  const int ng = a.ldx >> 4;           // = 8 NFQ
-  const long long ntiles = (a.n + 127) / 128;
-  const long long t0 = ntiles * (long long)blockIdx.x / (long long)gridDim.x, t1 = ntiles * ((long long)blockIdx.x + 1) / (long long)gridDim.x;
-  const int mg = blockIdx.y, mb0 = 4 * mg;
-  float xs, xinv;
-  lr_xscale(a.xmax, xs, xinv);
-  f32x16 out[2][NFQ];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int q = 0; q < NFQ; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) out[i][q][r] = 0.f;
-  if (tid < 128) ll_acc[tid] = 0.0;
-  // phase B's transposing reads: this lane's byte address of (kk = 0, half = 0, plane 0) inside ring slot 0 (see the header)
-  const int grp = lane >> 4, i16 = lane & 15, c4 = i16 & 3;
-  const unsigned trb = (unsigned)(uintptr_t)lds + (unsigned)((2 * wn + (grp & 1)) * 2048 + (((c4 & 1) * 32 + 4 * (grp >> 1) + (i16 >> 2)) * 16) + (c4 >> 1) * 8);
-  for (long long tile = t0; tile < t1; ++tile) {
-    const long long row0 = tile * 128;
-    // ---- phase A: logits of the tile (k_lr_logits_planes) ----
-    const unsigned *sp = (w < 4 ? a.XA + (size_t)(4 * tile + w) * ng * kFrag : a.ZP + (size_t)(mb0 + w - 4) * ng * kFrag) + 4 * lane;
-    auto issue = [&](int slot) {
-      unsigned *dst = lds + slot * kStageW + w * 512;
-      FB_GLDS16(sp, dst, 0);
-      FB_GLDS16(sp, dst, 1024);
-      sp += kFrag;
-    };
-    f32x16 acc[2][1];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
-    issue(0); issue(1);
-    if (tid < 128) {
-      ll_lds[tid] = 0.f;
-      const long long r = row0 + tid;
-      y_lds[tid] = r < a.n ? (float)a.y[r] : 0.f;
-    }
-    int slot = 0;
-    for (int g = 0; g < ng; ++g) {
-      if (g + 1 < ng) fb_wait_vm<kPW>();
-      else fb_wait_vm<0>();
-      fb_barrier();
-      if (g + 2 < ng) issue(slot == 0 ? 2 : slot - 1);
-      FbFrags<1> F;
-      fb_read_frags<1>(lds, slot, wm, wn, lane, F);
-      fb_group<1>(F, acc);
-      slot = slot == 2 ? 0 : slot + 1;
-    }
-    // residuals: log-likelihood partials + the A-operand fragments of X^T R into the LDS tile (2^13 r; rows beyond n are zeros)
-    float ll = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      float res[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int lr = 64 * wm + 32 * i + 8 * (r >> 2) + 4 * h + (r & 3);
-        res[r] = 0.f;
-        if (row0 + lr < a.n) {
-          const float yv = y_lds[lr];
-          const float lg = acc[i][0][r] * xinv, e = __expf(-fabsf(lg)), inv = __frcp_rn(1.f + e);
-          ll += yv * lg - (fmaxf(lg, 0.f) + __logf(1.f + e));
-          res[r] = yv - (lg >= 0.f ? inv : e * inv);
-        }
-      }
-      if (a.want_grad) {
-#pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
-          float x[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] = res[4 * (2 * g2 + (e >> 2)) + (e & 3)] * 8192.f;
-          lr_lds_store_frag(Rt + (wn * 8 + 4 * wm + 2 * i + g2) * kFrag + 4 * lane, x);
-        }
-      }
-    }
-    ll += __shfl_xor(ll, 32, 64);
-    if (h == 0) atomicAdd(&ll_lds[32 * wn + l31], ll);
-    fb_barrier();   // the residual tile is complete, every wave is done with the ring
-    if (tid < 128) ll_acc[tid] += (double)ll_lds[tid];
-    if (!a.want_grad) continue;
-    // ---- phase B: out += R_t' X_t, X's planes of the tile once more (newest feature groups first), transposed by the LDS reads ----
-    const unsigned *xb = a.XA + (size_t)(4 * tile) * ng * kFrag + (size_t)w * kFrag + 4 * lane;   // + (rb ng + 8 fq) kFrag: fragment (rb, 8 fq + w)
-    auto issueB = [&](int s, int sl) {   // stage s = (NFQ - 1 - fq) 4 + rb
-      const int fq = NFQ - 1 - (s >> 2), rb = s & 3;
-      const unsigned *src = xb + ((size_t)rb * ng + 8 * fq) * kFrag;
-      unsigned *dst = lds + sl * kStageW + w * 512;
-      FB_GLDS16(src, dst, 0);
-      FB_GLDS16(src, dst, 1024);
-    };
-    constexpr int NS = 4 * NFQ;
-    issueB(0, 0); issueB(1, 1);
-    static_for<0, NFQ>([&](auto Q) {
-      constexpr int qi = decltype(Q)::value, fq = NFQ - 1 - qi;
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-        const int s = 4 * qi + rb, sl = s % 3;
-        if (s + 1 < NS) fb_wait_vm<kPW>();
-        else fb_wait_vm<0>();
-        fb_barrier();
-        if (s + 2 < NS) issueB(s + 2, (s + 2) % 3);
-        // per 16-row group kk: A = the residuals' fragments (sample blocks 2 wm + i, row group 2 rb + kk; plain 16-byte reads), B = features
-        // 32 wn .. + 31 of this stage's 128, rows 16 kk .. + 15 of the 32-row block (four transposing 8-byte reads: [plane][half])
-        const unsigned ta = trb + (unsigned)(sl * kStageW * 4);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          u32x4v Ah[2], Al[2];
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const unsigned *src = Rt + ((2 * wm + i) * 8 + 2 * rb + kk) * kFrag + 4 * lane;
-            Ah[i] = *(const u32x4v *)src;
-            Al[i] = *(const u32x4v *)(src + 256);
-          }
-          unsigned long long t00, t01, t10, t11;
-          if (kk == 0)
-            asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:128\n\tds_read_b64_tr_b16 %2, %4 offset:1024\n\t"
-                         "ds_read_b64_tr_b16 %3, %4 offset:1152\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(t00), "=&v"(t01), "=&v"(t10), "=&v"(t11) : "v"(ta) : "memory");
-          else
-            asm volatile("ds_read_b64_tr_b16 %0, %4 offset:256\n\tds_read_b64_tr_b16 %1, %4 offset:384\n\tds_read_b64_tr_b16 %2, %4 offset:1280\n\t"
-                         "ds_read_b64_tr_b16 %3, %4 offset:1408\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(t00), "=&v"(t01), "=&v"(t10), "=&v"(t11) : "v"(ta) : "memory");
-          const u32x4v Bh = {(unsigned)t00, (unsigned)(t00 >> 32), (unsigned)t01, (unsigned)(t01 >> 32)};
-          const u32x4v Bl = {(unsigned)t10, (unsigned)(t10 >> 32), (unsigned)t11, (unsigned)(t11 >> 32)};
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            out[i][fq] = fb_mma(Al[i], Bh, out[i][fq]);
-            out[i][fq] = fb_mma(Ah[i], Bl, out[i][fq]);
-            out[i][fq] = fb_mma(Ah[i], Bh, out[i][fq]);
-          }
-        }
-      }
-    });
-    fb_barrier();   // the next tile's first stages overwrite ring slots another wave may still be reading
-  }
-  // the workgroup's partials
-  if (a.want_grad) {
-    const float f = xinv * (1.f / 8192.f);
-#pragma unroll
-    for (int q = 0; q < NFQ; ++q) {
-      const int k = 128 * q + 32 * wn + l31;
-      if (k < a.p) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = 128 * mg + 64 * wm + 32 * i + 8 * (r >> 2) + 4 * h + (r & 3);
-            a.g_part[((size_t)blockIdx.x * a.M + m) * a.p + k] = out[i][q][r] * f;
-          }
-      }
-    }
-  }
-  __syncthreads();
-  if (tid < 128) a.ll_part[(size_t)blockIdx.x * a.M + 128 * mg + tid] = ll_acc[tid];
-}
-
 // the full-tile kernel is pinned to 128 VGPRs (4 waves per SIMD, two workgroups per CU); the partial-tile variant's extra
 // control flow does not fit that budget without scratch (228 B/lane, 3x slower), so it runs unconstrained
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lr_logits_f16x2(LrMfmaArgs a) {
@@ -1419,7 +1230,6 @@ void launch_logreg_gather(mivi_ctx *c, int64_t b) {
 // graph-capturable: no allocation at launch); the launchers call it again as a no-op / safety net.
 struct LrGeom {
   bool mfma, planes, xplanes;   // planes: k_lr_logits_planes (128-row tiles on the prebuilt planes of X); xplanes: also k_lr_xtr_planes
-  bool fused;                   // one pass over X: k_lr_fused (persistent workgroups, S = their number)
   long long nrg;
   int gps;
   int nrb, S, ldr;
@@ -1431,7 +1241,6 @@ static LrGeom lr_geom(const mivi_ctx *c, int M) {
   LrGeom g;
   g.planes = false;
   g.xplanes = false;
-  g.fused = false;
   g.nrg = 0;
   g.gps = 0;
   const long long n = c->lr_n;
@@ -1468,21 +1277,6 @@ static LrGeom lr_geom(const mivi_ctx *c, int M) {
       g.S = (int)((g.nrg + g.gps - 1) / g.gps);
       g.need_R = (size_t)(M / 32) * g.nrg * kFrag * 4;
     }
-    // ONE pass over X (k_lr_fused): whole 128-feature stages, the 128 x ldx output tile in 32 ldx / 128 accumulator registers per lane.
-    // One persistent workgroup per CU and sample group; each takes an equal run of 128-row tiles (at least two).  MIVI_LR_NO_FUSED: A/B.
-    static const bool no_fused = getenv("MIVI_LR_NO_FUSED") != nullptr;
-    const int ldx = (p + 31) / 32 * 32;
-    if (g.planes && !no_fused && ldx % 128 == 0 && ldx <= 512 && n >= 4 * 128) {
-      const long long ntiles = (n + 127) / 128;
-      long long nw = (c->n_cu > 0 ? c->n_cu : 256) / (M / 128);
-      if (nw > ntiles / 2) nw = ntiles / 2;
-      if (nw < 1) nw = 1;
-      g.fused = true;
-      g.xplanes = false;
-      g.S = (int)nw;
-      g.nrb = (int)nw;
-      g.need_R = 256;
-    }
     g.need_g = (size_t)g.S * p * M * sizeof(float);
     g.need_ll = (size_t)g.nrb * M * sizeof(double);
   } else {
@@ -1507,7 +1301,7 @@ bool logreg_uses_mfma(const mivi_ctx *c, int M) { return c->target == TGT_LOGREG
 int logreg_kernel_bits(const mivi_ctx *c, int M) {
   if (c->target != TGT_LOGREG) return 0;
   const LrGeom g = lr_geom(c, M);
-  return (g.mfma ? 1 : 0) | (g.planes ? 2 : 0) | (g.xplanes ? 4 : 0) | (g.fused ? 8 : 0);
+  return (g.mfma ? 1 : 0) | (g.planes ? 2 : 0) | (g.xplanes ? 4 : 0);
 }
 bool logreg_reserve(mivi_ctx *c, int M) {
   const LrGeom g = lr_geom(c, M);
@@ -1552,17 +1346,7 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
     a.nrg = geo.nrg;
     a.gps = geo.gps;
     hipLaunchKernelGGL(k_lr_zplanes, dim3((nfz + 3) / 4), dim3(256), 0, c->stream, M, a.d, a.ldx, a.Zcm, a.ZP);
-    if (geo.fused) {
-      const dim3 gf(geo.S, M / 128);
-      switch (a.ldx / 128) {
-        case 1: hipLaunchKernelGGL(k_lr_fused<1>, gf, dim3(512), 0, c->stream, a); break;
-        case 2: hipLaunchKernelGGL(k_lr_fused<2>, gf, dim3(512), 0, c->stream, a); break;
-        case 3: hipLaunchKernelGGL(k_lr_fused<3>, gf, dim3(512), 0, c->stream, a); break;
-        default: hipLaunchKernelGGL(k_lr_fused<4>, gf, dim3(512), 0, c->stream, a); break;
-      }
-    } else {
-      hipLaunchKernelGGL(k_lr_logits_planes, dim3(nrb, M / 128), dim3(512), 0, c->stream, a);
-    }
+    hipLaunchKernelGGL(k_lr_logits_planes, dim3(nrb, M / 128), dim3(512), 0, c->stream, a);
   } else if (a.d % 4 == 0 && a.d >= 4 && !no_split) {
     if (part) hipLaunchKernelGGL(k_lr_logits_f16x2_part, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
     else hipLaunchKernelGGL(k_lr_logits_f16x2, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
@@ -1570,15 +1354,13 @@ static bool logreg_mfma(mivi_ctx *c, int M, int want_grad) {
     if (part) hipLaunchKernelGGL(k_lr_logits_mfma_lds<true>, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
     else hipLaunchKernelGGL(k_lr_logits_mfma_lds<false>, dim3(nrb, (M + 127) / 128), dim3(512), 0, c->stream, a);
   }
-  if (want_grad && a.n % 16 != 0 && !geo.xplanes && !geo.fused) {
+  if (want_grad && a.n % 16 != 0 && !geo.xplanes) {
     // the zero residual rows k_lr_xtr_f16x2's last stage reads (the logits kernels stop at n).  Nobody else writes them, but other
     // routes reuse lr_scratch (the residuals' planes, the generic route's layout), so they are zeroed on every call: at most 15 rows
     // of ldr floats, in stream order (a captured graph carries its own)
     (void)hipMemsetAsync(a.R + (size_t)a.n * a.ldr, 0, (size_t)(16 - a.n % 16) * a.ldr * sizeof(float), c->stream);
   }
-  if (geo.fused) {
-    // (the gradient partials were left by k_lr_fused)
-  } else if (want_grad && geo.xplanes) {
+  if (want_grad && geo.xplanes) {
     hipLaunchKernelGGL(k_lr_xtr_planes, dim3((a.p + 127) / 128, S, M / 128), dim3(512), 0, c->stream, a);
   } else if (want_grad) {
     const dim3 gx(S, (a.p + 255) / 256, (M + 127) / 128);

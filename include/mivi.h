@@ -442,8 +442,7 @@ mivi_status_t mivi_profile_kernel(mivi_ctx_t *ctx, int32_t which, const void *pa
 int32_t mivi_fullrank_route(const mivi_ctx_t *ctx, int32_t n_samples);
 /* Which kernels the native logistic-regression target's two data contractions run for `n_samples` per launch (same kind of hook):
  *   0 = vector-ALU kernels (small problems, f64); bit 0: matrix cores (two-way f16 splits); bit 1: the logits on prebuilt operand planes of X
- *   (k_lr_logits_planes); bit 2: X^T R on planes too (k_lr_xtr_planes, residual planes straight from the logits kernel); bit 3: ONE pass
- *   over X instead of those two (k_lr_fused: logits, residuals and X^T R per 128-row tile inside one persistent workgroup). */
+ *   (k_lr_logits_planes); bit 2: X^T R on planes too (k_lr_xtr_planes, residual planes straight from the logits kernel). */
 int32_t mivi_logreg_kernels(const mivi_ctx_t *ctx, int32_t n_samples);
 
 /* Developer tool: when buf_dev != NULL every workgroup of the main kernels records wall_clock64() stamps

@@ -25,13 +25,6 @@ pytestmark = pytest.mark.gpu
 C3_GRAD_RTOL = 2e-5
 
 
-def _planes_route(ctx):
-    """the operand-plane kernels: logits on X's planes and either X^T R on planes too (two passes over X) or the one-pass kernel
-    (k_lr_fused: whole 128-feature stages, at most 512 padded features, at least four row tiles)"""
-    k = ctx.logreg_kernels()
-    return k["mfma"] and k["logits_planes"] and (k["xtr_planes"] != k["fused"])
-
-
 def test_c1_readme_model_from_logdensity_alone_through_automivi(caplog):
     """BASELINE configs[0] as the reference's README runs it: the model declares LogDensityOrder{0}() and only `logdensity`
     (README.md:42-66), wrapped in the TransformedLogDensityProblem of README.md:91-119; `init` emits the reference's @info and
@@ -140,7 +133,7 @@ def test_c3_logreg_fullrank_oracle_parity_reduced_n():
     params, _ = avi.destructure(q)
     ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
     ctx.set_problem(avi.LogRegProblem(X, y, "logsigma_normal", 1.0))
-    assert ctx.logreg_kernels() == dict(mfma=True, logits_planes=True, xtr_planes=False, fused=True)   # (what the size heuristic picks at C3's shape: ONE pass over X)
+    assert ctx.logreg_kernels() == dict(mfma=True, logits_planes=True, xtr_planes=True)   # (what the size heuristic picks at C3's shape)
     _, eps = ctx.sample(params, 1)
     v, g = ctx.estimate_gradient(params, 1)
     ref = O.estimate_gradient(params.astype(np.float64), d, O.FULLRANK, O.LogRegTarget(X, y, "logsigma_normal", 1.0),
@@ -161,7 +154,7 @@ def test_c3_logreg_full_size_oracle_parity():
     params, _ = avi.destructure(q)
     ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, 0, SEED)
     ctx.set_problem(avi.LogRegProblem(X, y, "logsigma_normal", 1.0))
-    assert ctx.logreg_kernels() == dict(mfma=True, logits_planes=True, xtr_planes=False, fused=True)
+    assert ctx.logreg_kernels() == dict(mfma=True, logits_planes=True, xtr_planes=True)
     _, eps = ctx.sample(params, 4)
     v, g = ctx.estimate_gradient(params, 4)
     ref = O.estimate_gradient(params.astype(np.float64), d, O.FULLRANK, O.LogRegTarget(X, y, "logsigma_normal", 1.0, keep_storage=True),
@@ -322,11 +315,7 @@ def test_c5_launch_free_batch_equals_single_calls(d, M, ent, dtype):
 
 @pytest.mark.parametrize("n,p,M,family,variant", [(1000, 127, 128, avi.FULLRANK, "logsigma_normal"), (3001, 200, 256, avi.FULLRANK, "lognormal_exp_bijector"),
                                                    (777, 300, 128, avi.MEANFIELD, "logsigma_normal"), (4096, 40, 384, avi.FULLRANK, "logsigma_normal"),
-                                                   (130, 1000, 128, avi.MEANFIELD, "logsigma_normal"),
-                                                   # the one-pass kernel (k_lr_fused: padded features a multiple of 128, <= 512): 2, 3 and 4 feature quarters, two
-                                                   # sample groups, a ragged last row tile, p = 512 exactly, fewer tiles than two per CU
-                                                   (5000, 255, 256, avi.FULLRANK, "lognormal_exp_bijector"), (2001, 383, 128, avi.MEANFIELD, "logsigma_normal"),
-                                                   (900, 512, 128, avi.MEANFIELD, "logsigma_normal"), (70000, 500, 128, avi.MEANFIELD, "logsigma_normal")])
+                                                   (130, 1000, 128, avi.MEANFIELD, "logsigma_normal")])
 def test_logreg_operand_planes_at_odd_shapes(n, p, M, family, variant):
     """The operand-plane route of the two data contractions (k_lr_logits_planes / k_lr_xtr_planes: data sets of 10^5 elements and more, n_mc a
     multiple of 128) at shapes the BASELINE configs do not visit: ragged last row tile, one / several feature groups with a partial last one,
@@ -346,7 +335,7 @@ def test_logreg_operand_planes_at_odd_shapes(n, p, M, family, variant):
     ctx = avi.MiviContext(np.float32, family, d, M, 0, SEED)
     ctx.set_problem(avi.LogRegProblem(X, y, variant, 1.3))
     ctx.set_logreg_route(1)   # the matrix-core family of kernels whatever the size heuristic says
-    assert _planes_route(ctx)
+    assert ctx.logreg_kernels() == dict(mfma=True, logits_planes=True, xtr_planes=True)
     _, eps = ctx.sample(params, 4)
     v, g = ctx.estimate_gradient(params, 4)
     ref = O.estimate_gradient(params.astype(np.float64), d, family, O.LogRegTarget(X, y, variant, 1.3), eps.cpu().numpy().astype(np.float64), 0)
@@ -382,7 +371,7 @@ def test_logreg_operand_planes_random_shapes(n, p, M):
     ctx = avi.MiviContext(np.float32, avi.MEANFIELD, d, M, 0, SEED)
     ctx.set_problem(avi.LogRegProblem(X, y, "logsigma_normal", 0.9))
     ctx.set_logreg_route(1)
-    assert _planes_route(ctx)
+    assert ctx.logreg_kernels() == dict(mfma=True, logits_planes=True, xtr_planes=True)
     _, eps = ctx.sample(params, 2)
     v, g = ctx.estimate_gradient(params, 2)
     ref = O.estimate_gradient(params.astype(np.float64), d, avi.MEANFIELD, O.LogRegTarget(X, y, "logsigma_normal", 0.9), eps.cpu().numpy().astype(np.float64), 0)
