@@ -211,6 +211,18 @@ function LogDensityProblems.logdensity_and_gradient(p::NativeFunnel, eta)
 end
 LogDensityProblems.logdensity(p::NativeTarget, z) = first(LogDensityProblems.logdensity_and_gradient(p, z))
 
+# A native target that DECLARES second-order capability: gaussian_expectation_gradient_and_hessian! then takes the sample average of the
+# target's Hessians (src/algorithms/gauss_expected_grad_hess.jl:61-83) -- the constant Hessians of the Gaussian targets, the arrow matrix of the
+# funnel, one weighted Gram matrix for the logistic regression (csrc/kernels_hess2.hip) -- instead of Stein's identity.  On the device only:
+# the host-side `logdensity_gradient_and_hessian` is not provided (the other AdvancedVI algorithms use the wrapped problem's order-1 methods).
+struct SecondOrder{P<:NativeTarget} <: NativeTarget
+    prob::P
+end
+LogDensityProblems.dimension(p::SecondOrder) = LogDensityProblems.dimension(p.prob)
+LogDensityProblems.capabilities(::Type{<:SecondOrder}) = LogDensityProblems.LogDensityOrder{2}()
+LogDensityProblems.logdensity_and_gradient(p::SecondOrder, z) = LogDensityProblems.logdensity_and_gradient(p.prob, z)
+set_native_target!(st, p::SecondOrder) = set_native_target!(st, p.prob)
+
 function set_native_target!(st, p::NativeDiagNormal)
     T = st.T
     check(st.ctx, ccall((:mivi_set_target_diag_gauss, libmivi), Int32, (Ptr{Cvoid}, Ptr{T}, Ptr{T}), st.ctx, Vector{T}(p.mean), Vector{T}(p.std)))
@@ -510,5 +522,5 @@ end
 # ProximalLocationScaleEntropy on the host arrays works unchanged (src/optimization/proximal_location_scale_entropy.jl);
 # the device-resident variant for a parameter vector that lives in HBM is mivi_prox_scale_entropy.
 
-export AutoMIVI, NativeDiagNormal, NativeDenseNormal, NativeFunnel, NativeLogReg, native_logreg!, MIVITarget, set_bijector!, comm_unique_id, comm_init!, comm_enable_p2p!, comm_destroy!, estimate_gradient_dist!, estimate_gradient_dist_n!, estimate_gradient_each!
+export AutoMIVI, SecondOrder, NativeDiagNormal, NativeDenseNormal, NativeFunnel, NativeLogReg, native_logreg!, MIVITarget, set_bijector!, comm_unique_id, comm_init!, comm_enable_p2p!, comm_destroy!, estimate_gradient_dist!, estimate_gradient_dist_n!, estimate_gradient_each!
 end # module
