@@ -200,8 +200,11 @@ static bool fb_route(const mivi_ctx *c, const void *params, const void *grad_las
 // T[count * params_len]: every estimate's (mivi_estimate_gradient_each), or nullptr (lane scratch)
 // obj_ent >= 0: objective mode (fb_objective): the `count` lanes are consecutive blocks of n_mc samples of estimate idx0, values only, the
 // value's entropy estimator obj_ent
+// dist: a SHARDED batch (mivi_estimate_gradient_dist_n on an engine shape): this context draws its n_mc columns of every estimate's n_mc x world
+// samples; the VJP launch leaves the lanes' partial vectors, ONE all-reduce per step sums them over the ranks (dist_allreduce_f32: nothing
+// to do on one rank), k_fb_finalize_parts turns the sums into the lanes' values and gradients.
 static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, int count, void *value_last, void *grad_last, void *values_all,
-                              void *grads_all, int obj_ent = -1) {
+                              void *grads_all, int obj_ent = -1, bool dist = false) {
   mivi_status_t s;
   const int M = c->cfg.n_mc, d = c->cfg.d;
   if ((s = ensure_work(c, M))) return s;
@@ -224,6 +227,12 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
     t.cap_L = L;
     t.cap_M = M;
     t.cap_LR = 0;
+  }
+  const size_t part_len = dist ? fb_part_len(c) : 0;
+  if (dist && t.cap_LP < L) {
+    invalidate_graph(c);
+    if ((s = ensure(c, t.parts, (size_t)L * part_len * 4, false))) return s;
+    t.cap_LP = L;
   }
   const bool dense = c->target == TGT_DENSE_GAUSS;
   if (dense) {   // R = Z - m planes per lane; the planes of P once per target
@@ -285,6 +294,7 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
     fs.dense = dense ? 1 : 0;
     fs.stl = stl ? 1 : 0;
     if (st == steps - 1 && (value_last || grad_last)) { fs.lane_last = Llast - 1; fs.grad_last = grad_last; fs.value_last = value_last; }
+    if (dist) { fs.parts = t.parts.p; fs.part_stride = (long long)part_len; }
     return fs;
   };
   // One stream, no graph: per step {draws (+ tril(C)'s planes as riders of the first) -> product -> VJP + values} = three launches for up to
@@ -295,6 +305,10 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
     const FbStep fs = make_step(st);
     fb_launch_eps(c, fs, st == 0, c->stream);
     fb_launch_compute(c, fs, c->stream);
+    if (dist) {
+      if ((s = dist_allreduce_f32(c, t.parts.p, (size_t)fs.L * part_len))) return s;
+      fb_launch_finalize_parts(c, fs, c->stream);
+    }
   }
   HIPCHK(c, hipGetLastError());
   return MIVI_OK;
@@ -360,6 +374,13 @@ mivi_status_t mivi_profile_batch(mivi_ctx_t *c, const void *params, int32_t lane
   (void)hipEventDestroy(e1);
   HIPCHK(c, hipGetLastError());
   return MIVI_OK;
+}
+
+// mivi_estimate_gradient_dist_n on a batch-engine shape (api_dist.hip decides): every rank runs the engine on ITS sample columns, the lanes'
+// partial vectors cross the ranks in one all-reduce per step
+bool fb_dist_route(const mivi_ctx *c, const void *params, const void *grad) { return fb_route(c, params, grad, nullptr); }
+mivi_status_t fb_batch_dist(mivi_ctx *c, const void *params, uint64_t idx0, int count, void *value, void *grad) {
+  return fb_batch(c, params, idx0, count, value, grad, nullptr, nullptr, -1, true);
 }
 
 mivi_status_t mivi_estimate_gradient_each(mivi_ctx_t *c, const void *params, uint64_t idx0, int32_t count, void *values, void *grads) {

@@ -703,11 +703,28 @@ static mivi_status_t dist_sequence(mivi_ctx *c, const void *params, bool counter
   return s;
 }
 
+// the one collective of the engine's sharded batches: the lanes' partial vectors summed over the ranks, in place, on the context's stream
+mivi_status_t dist_allreduce_f32(mivi_ctx *c, void *buf, size_t count) {
+  if (!c->comm || c->comm_world <= 1) return MIVI_OK;
+  RcclApi *r = rccl();
+  if (!r || !r->AllReduce) return fail(c, MIVI_ERR_UNSUPPORTED, "this librccl exports no ncclAllReduce");
+  if (r->AllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)c->comm, c->stream) != ncclSuccess) return fail(c, MIVI_ERR_HIP, "ncclAllReduce failed");
+  return MIVI_OK;
+}
+
 static mivi_status_t dist_batch(mivi_ctx *c, const void *params, uint64_t idx0, int count, void *value, void *grad, int mode) {
   if (!graph_capturable(c)) return fail(c, MIVI_ERR_UNSUPPORTED, "batched sharded estimates need a device-resident built-in target");
   if (c->idx_src) return fail(c, MIVI_ERR_UNSUPPORTED, "an index source is set (mivi_set_index_source): batched calls keep their own device counter");
   if (c->p2p_on && !c->comm) { c->comm_world = c->p2p_world; c->comm_rank = c->p2p_rank; }
   mivi_status_t s;
+  // Round 6: on a batch-engine shape (full-rank f32, d and n_mc multiples of 128, Gaussian target) and an RCCL route -- or one rank without
+  // peer-to-peer areas -- the batch runs on the ENGINE: draws, product, VJP for up to 80 estimates per step as on one GPU, the lanes' partial
+  // vectors summed by ONE all-reduce per step (20 lanes x 2.4 MB: one large collective instead of twenty 2.1 MB ones), one finalisation
+  // launch.  The peer-to-peer route keeps the four-estimate kernels its persistent exchange kernel is built around.
+  if (mode == 0 && count >= 2 && mivi_comm_route(c) != 3 && (c->comm || c->comm_world <= 1) && fb_dist_route(c, params, grad)) {
+    if ((s = dist_check(c))) return s;
+    return fb_batch_dist(c, params, idx0, count, value, grad);
+  }
   if ((s = dist_check(c)) || (s = ensure_work(c, c->cfg.n_mc))) return s;
   prepare_tables(c, c->cfg.n_mc);
   if ((s = reserve_target(c, c->cfg.n_mc)) || (s = ensure_dist(c))) return s;

@@ -83,6 +83,13 @@ struct FbArgs {
   int n_riders;                   // k_fb_eps: grid rows in front of the lanes' that lay out tril(C)
   int skip_v;                     // k_fb_eps: no VJP follows (values only): the draws' VJP orientation is not written
   int obj;                        // k_fb_eps: 1 = lane l draws samples [l M, (l + 1) M) of ONE estimate index (objective mode); 0 = estimate index + l
+  // sharded batches: the VJP launch leaves lane l's shard-additive, UNNORMALISED partial vector at parts + l part_stride:
+  //   [sum_m W_im (d) | the lower triangle of sum_m W (x) eps as its 128 x 128 tiles, tile (rb, cb <= rb) at d + (rb (rb + 1) / 2 + cb) 128^2,
+  //    column-major inside, exact zeros above the diagonal of the diagonal tiles | sum_m ell_m | sum_m |eps_m|^2 / 2]   (fb_part_len floats)
+  // -- every store a whole 16-byte vector (the column-packed triangle of the C ABI's partial vector is not 16-byte aligned per column);
+  // the ranks' vectors are summed by ONE all-reduce per step, k_fb_finalize_parts turns the sums into values and gradients.
+  float *parts;
+  long long part_stride;
   int knock;                      // developer knock-outs (-DMIVI_DEV, MIVI_FB_KNOCK): 1 no DMA, 2 no MFMA, 4 no LDS reads, 8 no barriers
   long long *dbg;                 // developer timeline (-DMIVI_DEV builds, MIVI_FB_DBG=1): per workgroup {entry, first stage landed, main loop done, end} (100 MHz ticks), groups
 };
@@ -675,6 +682,11 @@ __device__ __forceinline__ void fb_value_block(const FbArgs &a, int l, double *r
   OutArgs out{};
   const bool last = l == a.lane_last && a.value_last;
   out.value = last ? a.value_last : a.values + (size_t)l * a.value_stride;
+  if (a.parts) {   // sharded batches: this shard's two scalars of the lane's partial vector
+    out.partials_mode = 1;
+    out.partials = a.parts + (size_t)l * a.part_stride;
+    out.scalars_off = (int64_t)d + (int64_t)(d >> 7) * ((d >> 7) + 1) / 2 * 16384;
+  }
   out.ent_kind = a.ent_kind;
   out.M_total = a.M_total;
   out.M_local = a.M;
@@ -694,7 +706,7 @@ __device__ __forceinline__ void fb_value_block(const FbArgs &a, int l, double *r
 // -----------------------------------------------------------------------------------------------------------------
 // NRV = ring slots of the plain loop, TABW = words of the scale table (M <= TABW), WPE = waves per SIMD the register budget allows:
 // (3, 256, 6) = 50 KiB of LDS and <= 80 registers: THREE workgroups per CU for n_mc <= 256; (3, 2048, 4): two per CU otherwise.
-template <int WJ, int PF, int NRV, int TABW, int WPE>
+template <int WJ, int PF, int NRV, int TABW, int WPE, bool PART = false>
 __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbArgs a) {
   constexpr int LDC = 36, NF = WJ, kPW = 2 * WJ;
   constexpr int NR = PF ? kRing : NRV;
@@ -908,6 +920,15 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
         if (diag && gj >= gi && gj < gi + 4) cjj = a.params[d + (size_t)gj * d + gj];
         const f32x4 v = *(const f32x4 *)(Cs + n * LDC + i4) * ff;
         f32x4 o;
+        if constexpr (PART) {   // the raw sums into the lane's partial vector, tile-packed (no normalisation, no entropy term: k_fb_finalize_parts)
+          o = v * kEpsInv;
+          if (diag) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = gj > gi + c ? 0.f : o[c];
+          }
+          store16_wt(a.parts + (size_t)ln * a.part_stride + d + ((size_t)(rb * (rb + 1) / 2 + cb) << 14) + (size_t)(gj - col0) * 128 + (gi - row0), o);
+          continue;
+        }
         if (!diag && pow2M) {   // strictly below the diagonal, power-of-two sample count: exact scaling, no per-element branches
           o = -v * invMe;
         } else {
@@ -916,7 +937,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
         }
         store16_wt(grad + d + (size_t)gj * d + gi, o);
       }
-      if (!diag && upper) {   // the mirrored, strictly upper 32 x 32 block is structurally zero
+      if (!PART && !diag && upper) {   // the mirrored, strictly upper 32 x 32 block is structurally zero
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -929,10 +950,69 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
     if (dg[i]) {   // d/dmu rows of this row block: the two halves' shares
       const double mine = (rsd[i] + (double)rcur[i]) * (double)wfin[32 * i + l31];
       const double sm = mine + __shfl_xor(mine, 32, 64);
-      if (lane < 32) grad[32 * ri[i] + lane] = dmu_elem(sm, invM);
+      if constexpr (PART) {
+        if (lane < 32) a.parts[(size_t)ln * a.part_stride + 32 * ri[i] + lane] = (float)sm;
+      } else {
+        if (lane < 32) grad[32 * ri[i] + lane] = dmu_elem(sm, invM);
+      }
     }
   }
   FB_STAMP(a, 3);
+}
+
+// -----------------------------------------------------------------------------------------------------------------
+// k_fb_finalize_parts: the lanes' (all-reduced) partial vectors -> values and dense gradients, what k_finalize does for the C ABI's packed
+// vector.  blockIdx.y = lane, blockIdx.x = column j of d/dC (the last grid column: d/dmu + the value).  Per element vjp_elem / dmu_elem, so a
+// one-rank "sharded" batch reproduces mivi_estimate_gradient_n's numbers.
+// -----------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fb_finalize_parts(FbArgs a) {
+  __shared__ double red[4 * 4];
+  const int d = a.d, l = blockIdx.y, j = blockIdx.x, tid = threadIdx.x;
+  const float *P = a.parts + (size_t)l * a.part_stride;
+  const bool last = l == a.lane_last && a.grad_last;
+  float *grad = last ? a.grad_last : a.grads + (size_t)l * a.grad_stride;
+  const bool upper = a.write_upper || last;
+  const double invM = 1.0 / (double)a.M_total;
+  const bool pow2M = (a.M_total & (a.M_total - 1)) == 0;
+  const double direct = direct_entropy_coeff(a.ent_kind);
+  if (j == d) {   // d/dmu and the objective value
+    for (int i = tid; i < d; i += 256) grad[i] = dmu_elem((double)P[i], invM);
+    double s_ld = 0.0, bad = 0.0;
+    for (int i = tid; i < d; i += 256) {
+      const double c = (double)a.params[d + (size_t)i * d + i];
+      if (!(c > 0.0)) bad = 1.0;
+      s_ld += log(c);
+    }
+    double v[2] = {s_ld, bad};
+    block_sum_n<double, 256, 2>(v, red);
+    if (tid == 0) {
+      const int64_t so = (int64_t)d + (int64_t)(d >> 7) * ((d >> 7) + 1) / 2 * 16384;
+      const double sum_ell = (double)P[so], s_he = (double)P[so + 1], Mt = (double)a.M_total;
+      const double ent = (ent_is_closed(a.ent_kind) ? 0.5 * d * (1.0 + kLog2Pi) : s_he / Mt + 0.5 * d * kLog2Pi) + v[0];
+      const double value = -(sum_ell / Mt + ent);
+      float *vo = (l == a.lane_last && a.value_last) ? a.value_last : a.values + (size_t)l * a.value_stride;
+      *vo = (float)value;
+      int st = 0;
+      if (!isfinite(value)) st |= 1;
+      if (v[1] > 0.0) st |= 2;
+      if (st && a.status) atomicOr(a.status, st);
+    }
+    return;
+  }
+  const int cb = j >> 7, lj = j & 127;
+  const float cjj = a.params[d + (size_t)j * d + j];
+  for (int i4 = 4 * tid; i4 < d; i4 += 1024) {   // rows i4 .. i4 + 3 of column j
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (i4 + 3 >= j) {
+      const int rb = i4 >> 7;
+      const f32x4 v = *(const f32x4 *)(P + d + ((size_t)(rb * (rb + 1) / 2 + cb) << 14) + (size_t)lj * 128 + (i4 & 127));
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c] = vjp_elem(v[c], i4 + c, j, pow2M, (float)invM, invM, direct, cjj);
+    } else if (!upper) {
+      continue;   // (a scratch lane's buffer holds the zeros above the diagonal already)
+    }
+    *(f32x4 *)(grad + d + (size_t)j * d + i4) = o;
+  }
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -961,6 +1041,10 @@ bool fb_shape_ok(const mivi_ctx *c, int M) {
 }
 size_t fb_plane_words(const mivi_ctx *c, int M) { return (size_t)c->cfg.d * M / 512 * kFrag; }       // one lane's eps / W planes
 size_t fb_cplane_words(const mivi_ctx *c) { return (size_t)(c->cfg.d / 32) * (c->cfg.d / 16) * kFrag; }
+size_t fb_part_len(const mivi_ctx *c) {   // [sum W (d) | lower-triangle tiles | sum ell, sum eps^2 / 2 | pad to four floats]
+  const size_t d = (size_t)c->cfg.d, T = d / 128;
+  return (d + T * (T + 1) / 2 * 16384 + 2 + 3) / 4 * 4;
+}
 
 // work tables for L lanes: product tiles heaviest first, (lane, column block) panels dealt round-robin onto the XCDs (workgroup b runs on
 // XCD b % 8: a panel's eps columns stay in one L2); VJP tiles in lane order, cut into eight equal runs
@@ -1127,6 +1211,7 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
   a.values = (float *)s.values; a.value_stride = s.value_stride;
   a.grad_last = (float *)s.grad_last; a.value_last = (float *)s.value_last; a.lane_last = s.lane_last;
   a.write_upper = s.write_upper;
+  a.parts = (float *)s.parts; a.part_stride = s.part_stride;
   if (s.obj) { a.ent_kind = s.ent_kind; a.M_total = s.M; }
 #ifdef MIVI_DEV
   static long long *dbg_buf = nullptr;
@@ -1188,12 +1273,27 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
   if (which & 2) {
     // measured at the north star (us per 20 / 50 / 80 lanes): ring 3 + three workgroups per CU 26.5 / 63.3 / 105-115; ring 3, two per CU 26.4 /
     // 69.8 / 109; ring 4, two per CU 36.7 / 81.5 / 126; ring 2, three per CU 26.4 / 72.6 / 113 (round 4's kernel with its second accumulator: 29 / 70 / 115)
-    if (s.M <= 256) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 256, 6>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
+    if (s.parts) {   // sharded batches: the lanes' partial vectors instead of gradients
+      if (s.M <= 256) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 256, 6, true>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
+      else hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 2048, 4, true>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
+    }
+    else if (s.M <= 256) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 256, 6>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
     else hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 2048, 4>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
 #ifdef MIVI_DEV
     dump("k_fb_vjp", tb.n_vjp);
 #endif
   }
+}
+
+void fb_launch_finalize_parts(mivi_ctx *c, const FbStep &s, hipStream_t stream) {
+  FbArgs a = fb_args(c, s.params, s.M);
+  a.L = s.L;
+  a.grads = (float *)s.grads; a.grad_stride = s.grad_stride;
+  a.values = (float *)s.values; a.value_stride = s.value_stride;
+  a.grad_last = (float *)s.grad_last; a.value_last = (float *)s.value_last; a.lane_last = s.lane_last;
+  a.write_upper = s.write_upper;
+  a.parts = (float *)s.parts; a.part_stride = s.part_stride;
+  hipLaunchKernelGGL(k_fb_finalize_parts, dim3(c->cfg.d + 1, s.L), dim3(256), 0, stream, a);
 }
 
 }  // namespace mivi

@@ -219,7 +219,8 @@ struct FbTables {
   DevBuf PA, RP;                          // dense-Gaussian target: planes of P (once per target), R = Z - m per lane
   bool PA_valid = false;
   DevBuf Tinv, TA, Eye;                   // sticking-the-landing estimators: C^-T (f32), its planes (once per call), the identity the solve takes
-  int cap_L = 0, cap_M = 0, cap_LR = 0;
+  DevBuf parts;                           // sharded batches: the lanes' shard-additive partial vectors (fb_part_len floats each), what one all-reduce sums
+  int cap_L = 0, cap_M = 0, cap_LR = 0, cap_LP = 0;
 };
 struct FbStep {
   const void *params;
@@ -236,6 +237,7 @@ struct FbStep {
   int obj;                                // objective mode (mivi_estimate_objective): the lanes are consecutive blocks of n_mc samples of ONE estimate index; values only
   int ent_kind;                           // objective mode: the entropy estimator of the value
   int values_only;                        // no gradient is wanted (mivi_estimate_gradient_each without grads; objective mode): no VJP tile runs
+  void *parts; long long part_stride;     // sharded batches: the VJP leaves lane l's UNNORMALISED partial vector at parts + l part_stride instead of a gradient
 };
 
 struct GraphCache {
@@ -500,6 +502,8 @@ size_t fb_cplane_words(const mivi_ctx *c);            // ... of tril(C)'s
 void fb_launch_eps(mivi_ctx *c, const FbStep &s, bool with_cplanes, hipStream_t stream);   // a step's draws (+ tril(C)'s planes, once per call)
 void fb_launch_pplanes(mivi_ctx *c, hipStream_t stream);
 void fb_launch_tplanes(mivi_ctx *c, hipStream_t stream);
+size_t fb_part_len(const mivi_ctx *c);                                     // floats of a lane's partial vector on the engine (a multiple of four)
+void fb_launch_finalize_parts(mivi_ctx *c, const FbStep &s, hipStream_t stream);   // (summed) partial vectors -> the lanes' values and gradients
 void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int which = 15);  // product(s) + target -> VJP + values (which: bit 0 product, 1 VJP, 2 the dense target's product, 3 the sticking-the-landing product)
 
 // kernels_stl.hip (f32, d in {256, 512, 1024, 2048}, M % 32 == 0)

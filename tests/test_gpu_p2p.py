@@ -17,7 +17,7 @@ import torch
 import advancedvi_jl_amd as avi
 from advancedvi_jl_amd.distributed import ShardPlan, p2p_geometry
 from oracle import oracle as O
-from tests.helpers import SEED, make_family, make_problem
+from tests.helpers import SEED, assert_batch_matches_single, engine_shape, make_family, make_problem
 
 pytestmark = pytest.mark.gpu
 
@@ -177,7 +177,7 @@ def _two_process_worker(rank, world, port, family, d, M, q_out, direct=False):
     import torch.distributed as dist
     import advancedvi_jl_amd as avi
     from advancedvi_jl_amd.distributed import ShardPlan
-    from tests.helpers import SEED, make_family, make_problem
+    from tests.helpers import SEED, assert_batch_matches_single, engine_shape, make_family, make_problem
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -277,8 +277,13 @@ def test_pipelined_batch_equals_single_estimates(family, d, M, count, route):
         ctx.synchronize()
         v1, g1 = ctx.estimate_gradient_dist(p, idx0 + count - 1)
         ctx.synchronize()
-        assert float(v.item()) == float(v1.item())
-        assert np.array_equal(g.cpu().numpy(), g1.cpu().numpy())
+        if route != "p2p" and count >= 2 and engine_shape(d, M, family, np.float32, "diag", count):
+            # round 6: on the RCCL routes / one rank an engine shape runs the batch on the batch engine (two-way f16 operand splits): equal to the
+            # single sharded estimates (exact three-way bf16 split) to the stated rounding, as mivi_estimate_gradient_n is on one GPU
+            assert_batch_matches_single(v.item(), v1.item(), g.cpu().numpy(), g1.cpu().numpy(), True, (route, count))
+        else:
+            assert float(v.item()) == float(v1.item())
+            assert np.array_equal(g.cpu().numpy(), g1.cpu().numpy())
         v2, g2 = ctx.estimate_gradient(p, idx0 + count - 1)
         assert abs(float(v.item()) - float(v2.item())) <= 2e-6 * abs(float(v2.item()))
         assert np.linalg.norm(g.cpu().numpy() - g2.cpu().numpy()) <= 5e-6 * max(1.0, float(np.linalg.norm(g2.cpu().numpy())))
