@@ -208,8 +208,13 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
   mivi_status_t s;
   const int M = c->cfg.n_mc, d = c->cfg.d;
   if ((s = ensure_work(c, M))) return s;
-  const int Lmax = fb_lanes_max();
+  // sharded batches with a communicator: steps of at most 24 lanes, so that a 100-estimate call is five steps whose all-reduces (on
+  // comm_stream, the partial vectors double-buffered) run UNDER the next steps' kernels -- across ranks the exchange, not the kernels, paces
+  // the batch
+  const bool overlap = dist && c->comm != nullptr;
+  const int Lmax = (overlap && c->comm_world > 1) ? (fb_lanes_max() < 24 ? fb_lanes_max() : 24) : fb_lanes_max();   // (one rank: nothing to hide, the widest steps)
   const int steps = (count + Lmax - 1) / Lmax, L = (count + steps - 1) / steps, Llast = count - (steps - 1) * L;
+  if (overlap && (s = dist_comm_stream(c))) return s;
   const size_t plen = (size_t)mivi_params_len(c);
   FbTables &t = c->fb;
   if (t.cap_L < L || t.cap_M != M) {
@@ -231,7 +236,7 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
   const size_t part_len = dist ? fb_part_len(c) : 0;
   if (dist && t.cap_LP < L) {
     invalidate_graph(c);
-    if ((s = ensure(c, t.parts, (size_t)L * part_len * 4, false))) return s;
+    if ((s = ensure(c, t.parts, 2 * (size_t)L * part_len * 4, false))) return s;   // (two sets: the all-reduce of step s under the kernels of step s + 1)
     t.cap_LP = L;
   }
   const bool dense = c->target == TGT_DENSE_GAUSS;
@@ -294,7 +299,7 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
     fs.dense = dense ? 1 : 0;
     fs.stl = stl ? 1 : 0;
     if (st == steps - 1 && (value_last || grad_last)) { fs.lane_last = Llast - 1; fs.grad_last = grad_last; fs.value_last = value_last; }
-    if (dist) { fs.parts = t.parts.p; fs.part_stride = (long long)part_len; }
+    if (dist) { fs.parts = (char *)t.parts.p + (size_t)(overlap ? (st & 1) : 0) * (size_t)t.cap_LP * part_len * 4; fs.part_stride = (long long)part_len; }
     return fs;
   };
   // One stream, no graph: per step {draws (+ tril(C)'s planes as riders of the first) -> product -> VJP + values} = three launches for up to
@@ -303,12 +308,25 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
   // are bound by their 3 MB of plane writes per estimate and by the vector ALU, beside them the products ran 25 % longer: 4.58 us.)
   for (int st = 0; st < steps; ++st) {
     const FbStep fs = make_step(st);
+    const int b = st & 1;
+    if (overlap && st >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->fb_ev_comm[b], 0));   // the finalisation of step st - 2 has read this set of partial vectors
     fb_launch_eps(c, fs, st == 0, c->stream);
     fb_launch_compute(c, fs, c->stream);
     if (dist) {
-      if ((s = dist_allreduce_f32(c, t.parts.p, (size_t)fs.L * part_len))) return s;
-      fb_launch_finalize_parts(c, fs, c->stream);
+      hipStream_t xs = c->stream;
+      if (overlap) {
+        HIPCHK(c, hipEventRecord(c->fb_ev_part[b], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->fb_comm_stream, c->fb_ev_part[b], 0));
+        xs = c->fb_comm_stream;
+      }
+      if ((s = dist_allreduce_f32(c, fs.parts, (size_t)fs.L * part_len, xs))) return s;
+      fb_launch_finalize_parts(c, fs, xs);
+      if (overlap) HIPCHK(c, hipEventRecord(c->fb_ev_comm[b], c->fb_comm_stream));
     }
+  }
+  if (overlap) {   // join: the batch is complete when its last two exchanges + finalisations are
+    if (steps >= 2) HIPCHK(c, hipStreamWaitEvent(c->stream, c->fb_ev_comm[(steps - 2) & 1], 0));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->fb_ev_comm[(steps - 1) & 1], 0));
   }
   HIPCHK(c, hipGetLastError());
   return MIVI_OK;

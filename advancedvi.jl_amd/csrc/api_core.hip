@@ -210,6 +210,11 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   if (c->comm_stream2) (void)hipStreamDestroy(c->comm_stream2);
+  if (c->fb_comm_stream) (void)hipStreamDestroy(c->fb_comm_stream);
+  for (int k = 0; k < 2; ++k) {
+    if (c->fb_ev_part[k]) (void)hipEventDestroy(c->fb_ev_part[k]);
+    if (c->fb_ev_comm[k]) (void)hipEventDestroy(c->fb_ev_comm[k]);
+  }
   for (int k = 0; k < 2; ++k) {
     if (c->ev_part[k]) (void)hipEventDestroy(c->ev_part[k]);
     if (c->ev_comm[k]) (void)hipEventDestroy(c->ev_comm[k]);

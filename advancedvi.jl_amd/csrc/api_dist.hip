@@ -704,11 +704,20 @@ static mivi_status_t dist_sequence(mivi_ctx *c, const void *params, bool counter
 }
 
 // the one collective of the engine's sharded batches: the lanes' partial vectors summed over the ranks, in place, on the context's stream
-mivi_status_t dist_allreduce_f32(mivi_ctx *c, void *buf, size_t count) {
-  if (!c->comm || c->comm_world <= 1) return MIVI_OK;
+mivi_status_t dist_allreduce_f32(mivi_ctx *c, void *buf, size_t count, hipStream_t stream) {
+  if (!c->comm) return MIVI_OK;   // (one rank without a communicator: the sum over the ranks is the vector itself)
   RcclApi *r = rccl();
   if (!r || !r->AllReduce) return fail(c, MIVI_ERR_UNSUPPORTED, "this librccl exports no ncclAllReduce");
-  if (r->AllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)c->comm, c->stream) != ncclSuccess) return fail(c, MIVI_ERR_HIP, "ncclAllReduce failed");
+  if (r->AllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)c->comm, stream) != ncclSuccess) return fail(c, MIVI_ERR_HIP, "ncclAllReduce failed");
+  return MIVI_OK;
+}
+mivi_status_t dist_comm_stream(mivi_ctx *c) {
+  if (c->fb_comm_stream) return MIVI_OK;
+  HIPCHK(c, hipStreamCreateWithFlags(&c->fb_comm_stream, hipStreamNonBlocking));
+  for (int k = 0; k < 2; ++k) {
+    HIPCHK(c, hipEventCreateWithFlags(&c->fb_ev_part[k], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->fb_ev_comm[k], hipEventDisableTiming));
+  }
   return MIVI_OK;
 }
 

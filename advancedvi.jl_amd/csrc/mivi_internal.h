@@ -282,6 +282,10 @@ struct mivi_ctx {
   hipEvent_t ev_part[2] = {nullptr, nullptr}, ev_comm[2] = {nullptr, nullptr};
   mivi::DevBuf dist_P2, dist_ring[6];       // ring of partial vectors (two for the RCCL pipeline, eight = two groups of four for the peer-to-peer pipeline)
   hipStream_t comm_stream2 = nullptr;
+  // the batch engine's sharded batches (api_batch.hip fb_batch, dist): the all-reduce + finalisation of step s on fb_comm_stream under the
+  // kernels of step s + 1 (streams of their own: comm_stream carries the CU mask the peer-to-peer pipeline needs)
+  hipStream_t fb_comm_stream = nullptr;
+  hipEvent_t fb_ev_part[2] = {nullptr, nullptr}, fb_ev_comm[2] = {nullptr, nullptr};
   int p2p_pipe_state = 1;   // persistent peer-to-peer pipeline in batched calls: 1 on, -1 off (mivi_p2p_set_pipeline: serial steps)
   int dist_route = 0;   // mivi_comm_set_route: 0 by size, 1 ncclAllReduce, 2 ncclReduceScatter / ncclAllGather, 3 peer-to-peer kernel
   // peer-to-peer exchange over xGMI (kernels_p2p.hip): one uncached allocation per rank [stage | final | flags], mapped into the peers by IPC
