@@ -66,6 +66,8 @@ db=$(find /tmp/prof_dist -name '*.db' | head -1)
 { echo "# $TAG: MIVI_FORCE_DIST=1 rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --steps 400 --warmup 40 (world 1, peer-to-peer exchange forced)"; echo;
   python $REPO/tools/rocpd_stats.py $db; } > $OUT/${TAG}_dist_forced_kernel_stats.md
 MIVI_FORCE_DIST=1 python bench.py --no-cpu-baseline --steps 400 --warmup 40 2>/dev/null | tail -1 > $OUT/${TAG}_bench_dist_forced.json
+# ... and the peer-to-peer exchange kernel's route (round 6: the automatic route of an engine shape is the batch engine + one all-reduce per step)
+MIVI_FORCE_DIST=1 MIVI_DIST_MODE=p2p python bench.py --no-cpu-baseline --no-also --steps 400 --warmup 40 2>/dev/null | tail -1 > $OUT/${TAG}_bench_dist_forced_p2p.json
 # the launch-free optimisation loops (round 4): kernel stats of one call each -- default algorithm settings and Adam, the three families of loops
 rm -rf /tmp/prof_loops
 rocprofv3 --kernel-trace --stats -d /tmp/prof_loops -o run -- python $REPO/tools/loop_rules_bench.py 0,1024,256 1,1024,8 1,10,1 > /tmp/prof_loops.log 2>&1
