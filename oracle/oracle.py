@@ -569,6 +569,42 @@ def finalize_partials(partials, params, d, family, ent_kind, M_total):
     return -(sum_ell / M_total + ent), grad
 
 
+def engine_partials(partials, d):
+    """The batch engine's internal layout of a full-rank partial vector (csrc/kernels_fullrank_batch.hip k_fb_vjp<PART>; d a multiple of 128):
+    [sum_m W (d) | the lower triangle of sum_m W (x) eps as its 128 x 128 tiles, tile (rb, cb <= rb) at d + (rb (rb + 1) / 2 + cb) 128^2,
+    column-major inside, zeros above the diagonal of the diagonal tiles | sum ell | sum |eps|^2 / 2 | pad to a multiple of four], from the
+    C ABI's column-packed vector `partials` (estimate_gradient(...)["partials"])."""
+    T = d // 128
+    P = np.zeros((d, d))
+    off = d
+    for j in range(d):
+        P[j:, j] = partials[off:off + d - j]
+        off += d - j
+    n = (d + T * (T + 1) // 2 * 16384 + 2 + 3) // 4 * 4
+    out = np.zeros(n)
+    out[:d] = partials[:d]
+    for rb in range(T):
+        for cb in range(rb + 1):
+            t = d + (rb * (rb + 1) // 2 + cb) * 16384
+            out[t:t + 16384] = P[128 * rb:128 * rb + 128, 128 * cb:128 * cb + 128].reshape(-1, order="F")
+    so = d + T * (T + 1) // 2 * 16384
+    out[so], out[so + 1] = partials[-2], partials[-1]
+    return out
+
+
+def finalize_engine_partials(ep, params, d, ent_kind, M_total):
+    """k_fb_finalize_parts restated: the (summed) engine-layout partial vector -> (value, dense gradient with exact zeros above the diagonal)."""
+    T = d // 128
+    P = np.zeros((d, d))
+    for rb in range(T):
+        for cb in range(rb + 1):
+            t = d + (rb * (rb + 1) // 2 + cb) * 16384
+            P[128 * rb:128 * rb + 128, 128 * cb:128 * cb + 128] = ep[t:t + 16384].reshape(128, 128, order="F")
+    packed = np.concatenate([np.tril(P)[j:, j] for j in range(d)])
+    so = d + T * (T + 1) // 2 * 16384
+    return finalize_partials(np.concatenate([ep[:d], packed, ep[so:so + 2]]), params, d, FULLRANK, ent_kind, M_total)
+
+
 def finalize_slice(slice_sum, g0, params, d, family, ent_kind, M_total, L):
     """Host restatement of mivi_finalize_slice: the packed final values of partial-vector elements [g0, g0 + n) given their
     sums over the ranks.  Gradient entries: -(1/M) sum - direct * [diagonal] / C_ii; element L-2 becomes the
