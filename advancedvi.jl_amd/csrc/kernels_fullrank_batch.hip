@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(256) void k_fb_finalize_parts(FbArgs a) {
 namespace {
 constexpr int kBM = 128, kBN = 128;
 constexpr int kWJ = FB_WJ;      // 32-column blocks per wave (k_fb_prod / k_fb_vjp): 2 = four waves of 64 x 64 per tile, 1 = eight waves of 64 x 32
-constexpr int kOwnCuTilesPerCU10 = 17;   // (x 0.1) tiles per CU up to which the triangular products keep one workgroup per CU (fb_launch_compute)
+constexpr int kOwnCuTilesPerCU10 = 17;   // (x 0.1) tiles per CU up to which the triangular products keep one workgroup per CU at d = 1024 (fb_launch_compute: scaled by the heaviest tile's chain)
 constexpr int kPFvjp = FB_PF_VJP;   // the product: register prefetch + one workgroup per CU (its heaviest tile must own a CU); the VJP: two plain workgroups per CU (equal tiles)
 
 void fb_upload(DevBuf &b, const void *src, size_t bytes) {
@@ -1245,7 +1245,19 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
   // workgroups per CU covering each other's barriers and epilogues, decides.  The dense target's second product has EQUAL tiles (all of K):
   // it never takes the one-per-CU ring (20 lanes: 320 tiles would run as two rounds on 256 CUs -- 46.0 against 54.7 us measured).
   const int n_cu = c->n_cu > 0 ? c->n_cu : 256;
-  auto own_cu_for = [&](int n, bool equal_tiles) { return !equal_tiles && n > n_cu && 10 * (long long)n <= (long long)kOwnCuTilesPerCU10 * n_cu; };
+  auto own_cu_for = [&](int n, bool equal_tiles) {
+#ifdef MIVI_DEV
+    static const int force_ring = getenv("MIVI_FB_RING") ? atoi(getenv("MIVI_FB_RING")) : 0;   // developer builds: 4 / 8 pins the ring (tools/fb_lane_curve.py)
+    if (force_ring == 4) return false;
+    if (force_ring == 8) return true;
+#endif
+    // tiles per CU (x 10) up to which the one-per-CU ring wins, by the heaviest tile's chain (gmax = d / 16 groups): measured at
+    // (512, 128) and (512, 512) -- 32 groups: never --, (1024, 256) -- 64 groups: up to 1.7 --, (2048, 128) -- 128 groups: up to 2.2 (32 lanes:
+    // 58.5 against 65.5 us; 48 lanes: 88.4 against 84.5); interpolated between (tools/experiments/README_r06.md)
+    const int gmax = c->cfg.d / 16;
+    const int thr10 = gmax <= 32 ? 10 : (gmax <= 64 ? 10 + (gmax - 32) * 7 / 32 : kOwnCuTilesPerCU10 + (gmax - 64 < 64 ? gmax - 64 : 64) * 5 / 64);
+    return !equal_tiles && n > n_cu && 10 * (long long)n <= (long long)thr10 * n_cu;
+  };
   auto prod = [&](auto MODE, int n) {
     constexpr int md = decltype(MODE)::value;
     if (own_cu_for(n, md == FB_DENSE_G)) hipLaunchKernelGGL((k_fb_prod<kWJ, md, 8>), dim3(n), dim3(512 / kWJ), 0, stream, a);
