@@ -194,7 +194,8 @@ static bool fb_route(const mivi_ctx *c, const void *params, const void *grad_las
   const bool stl = c->cfg.entropy == MIVI_ENT_STL || c->cfg.entropy == MIVI_ENT_STL_ZERO_GRAD;
   return !c->is_child && c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && !c->bij_on && !c->idx_src && !c->dbg &&
          (c->target == TGT_DIAG_GAUSS || c->target == TGT_DENSE_GAUSS) && (!stl || (fb_stl_on() && stl2_shape_ok(c, c->cfg.d))) &&
-         fb_shape_ok(c, c->cfg.n_mc) && ((uintptr_t)params & 15) == 0 && ((uintptr_t)grad_last & 15) == 0 && ((uintptr_t)grads_all & 15) == 0;
+         fb_shape_ok(c, c->cfg.n_mc) && ((!stl && c->target == TGT_DIAG_GAUSS) || fb_whole_tiles(c, c->cfg.n_mc)) &&   // (padded geometry: the diagonal target, no STL term)
+         ((uintptr_t)params & 15) == 0 && ((uintptr_t)grad_last & 15) == 0 && ((uintptr_t)grads_all & 15) == 0;
 }
 // value_last / grad_last: the batch's LAST estimate (mivi_estimate_gradient_n's contract), or nullptr; values_all T[count] / grads_all
 // T[count * params_len]: every estimate's (mivi_estimate_gradient_each), or nullptr (lane scratch)
@@ -216,16 +217,17 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
   const int steps = (count + Lmax - 1) / Lmax, L = (count + steps - 1) / steps, Llast = count - (steps - 1) * L;
   if (overlap && (s = dist_comm_stream(c))) return s;
   const size_t plen = (size_t)mivi_params_len(c);
+  const int dG = (d + 127) / 128 * 128, MG = (M + 127) / 128 * 128;   // the engine's geometry: whole 128 x 128 tiles (kernels_fullrank_batch.hip fb_pad)
   FbTables &t = c->fb;
   if (t.cap_L < L || t.cap_M != M) {
     invalidate_graph(c);
     const size_t pw = fb_plane_words(c, M) * 4;
     if ((s = ensure(c, t.CA, fb_cplane_words(c) * 4, false)) || (s = ensure(c, t.epsP, (size_t)L * pw, false)) ||
         (s = ensure(c, t.epsV, (size_t)L * pw, false)) || (s = ensure(c, t.WV, (size_t)L * pw, false)) ||
-        (s = ensure(c, t.ell, (size_t)L * (d / 32) * (M / 32) * sizeof(double), false)) ||
-        (s = ensure(c, t.he, (size_t)L * (d / 64) * (M / 32) * sizeof(double), false)) ||
-        (s = ensure(c, t.ld, 2 * (size_t)(d / 32) * sizeof(double) + 64, false)) || (s = ensure(c, t.values, (size_t)L * 4 + 64, false)) ||
-        (s = ensure(c, t.cscale, 2 * (size_t)d * 4, false)) || (s = ensure(c, t.winv, (size_t)L * (M / 128) * d * 4, false)))
+        (s = ensure(c, t.ell, (size_t)L * (dG / 32) * (MG / 32) * sizeof(double), false)) ||
+        (s = ensure(c, t.he, (size_t)L * (dG / 64) * (MG / 32) * sizeof(double), false)) ||
+        (s = ensure(c, t.ld, 2 * (size_t)(dG / 32) * sizeof(double) + 64, false)) || (s = ensure(c, t.values, (size_t)L * 4 + 64, false)) ||
+        (s = ensure(c, t.cscale, 2 * (size_t)dG * 4, false)) || (s = ensure(c, t.winv, (size_t)L * (MG / 128) * dG * 4, false)))
       return s;
     t.grads.bytes = 0;   // (re-zeroed: the lanes' scratch gradients rely on exact zeros above the diagonal that no kernel writes)
     if ((s = ensure(c, t.grads, (size_t)L * plen * 4, true))) return s;
@@ -396,7 +398,7 @@ mivi_status_t mivi_profile_batch(mivi_ctx_t *c, const void *params, int32_t lane
 
 // mivi_estimate_gradient_dist_n on a batch-engine shape (api_dist.hip decides): every rank runs the engine on ITS sample columns, the lanes'
 // partial vectors cross the ranks in one all-reduce per step
-bool fb_dist_route(const mivi_ctx *c, const void *params, const void *grad) { return fb_route(c, params, grad, nullptr); }
+bool fb_dist_route(const mivi_ctx *c, const void *params, const void *grad) { return fb_route(c, params, grad, nullptr) && fb_whole_tiles(c, c->cfg.n_mc); }
 mivi_status_t fb_batch_dist(mivi_ctx *c, const void *params, uint64_t idx0, int count, void *value, void *grad) {
   return fb_batch(c, params, idx0, count, value, grad, nullptr, nullptr, -1, true);
 }

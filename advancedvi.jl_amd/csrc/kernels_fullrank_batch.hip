@@ -40,7 +40,10 @@
 namespace mivi {
 
 struct FbArgs {
-  int d, M, L;
+  int d, M, L;                    // d, M: the GEOMETRY -- rows / samples padded to whole 128 x 128 tiles (planes, tables, work items)
+  int dT, MT;                     // the family's dimension and the samples per estimate (multiples of 32): the parameter / gradient layout (leading
+                                  // dimension dT), the eps stream's index arithmetic, the normalisation; whole 32-blocks beyond them are padding: eps and W
+                                  // planes hold zeros there, nothing of them is summed or stored
   const float *params;            // [mu; vec C]
   const float *t_mean, *t_istd;   // diagonal-Gaussian target
   unsigned *CA;                   // planes of tril(C): fragment (rb32, kg), kg <= 2 rb32 + 3, at (rb32 (d / 16) + kg) kFrag
@@ -163,15 +166,25 @@ __device__ __forceinline__ void fb_rowblock_planes(int d, int rb, int kg_lo, int
 // tril(C): the fragments up to the diagonal block + the two zero groups behind it (a wave of k_fb_prod walks the K range of its SECOND row
 // block with both of its blocks: the first one's chain adds exact zeros there)
 __device__ __forceinline__ void fb_cplanes_block(const FbArgs &a, int rb, int sub, int nsub, float *red) {
-  const int d = a.d, ng = d >> 4;
-  const float *C = a.params + d;
+  const int d = a.d, ng = d >> 4, dT = a.dT;
+  const float *C = a.params + dT;   // (leading dimension dT; rows / columns beyond dT are padding: zeros)
   const int hi = 2 * rb + 3 < ng - 1 ? 2 * rb + 3 : ng - 1;
-  fb_rowblock_planes(d, rb, 0, hi, sub, nsub,
-                     [C, d](int k, int row) { f32x4 v = *(const f32x4 *)(C + (size_t)k * d + row);
+  if (dT == d) {   // whole tiles (the common case, and every benchmark shape): no padding masks in the row-maximum loops
+    fb_rowblock_planes(d, rb, 0, hi, sub, nsub,
+                       [C, d](int k, int row) { f32x4 v = *(const f32x4 *)(C + (size_t)k * d + row);
 #pragma unroll
-                                              for (int c = 0; c < 4; ++c) v[c] = k > row + c ? 0.f : v[c];
-                                              return v; },
-                     [C, d](int k, int row) { const float v = C[(size_t)k * d + row]; return k > row ? 0.f : v; }, a.CA, a.cscale, red);
+                                                for (int c = 0; c < 4; ++c) v[c] = k > row + c ? 0.f : v[c];
+                                                return v; },
+                       [C, d](int k, int row) { const float v = C[(size_t)k * d + row]; return k > row ? 0.f : v; }, a.CA, a.cscale, red);
+    return;
+  }
+  fb_rowblock_planes(d, rb, 0, hi, sub, nsub,
+                     [C, dT](int k, int row) { const bool in = row < dT && k < dT;   // (dT % 4 == 0: a vector is inside or outside; outside: any valid address, masked)
+                                               f32x4 v = *(const f32x4 *)(C + (size_t)(in ? k : 0) * dT + (in ? row : 0));
+#pragma unroll
+                                               for (int c = 0; c < 4; ++c) v[c] = (!in || k > row + c) ? 0.f : v[c];
+                                               return v; },
+                     [C, dT](int k, int row) { if (row >= dT || k > row) return 0.f; return C[(size_t)k * dT + row]; }, a.CA, a.cscale, red);
 }
 // k_fb_pplanes: the dense-Gaussian target's precision matrix P (every k group: P is full).  Once per target.
 __global__ __launch_bounds__(512) void k_fb_pplanes(FbArgs a) {
@@ -214,14 +227,15 @@ __global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
   }
   const int l = (int)blockIdx.y - a.n_riders;
   const uint64_t idx = rng_index(a.rng) + (a.obj ? 0ull : (uint64_t)l);
-  const int moff = a.rng.m_offset + (a.obj ? l * a.M : 0);
+  const int moff = a.rng.m_offset + (a.obj ? l * a.MT : 0);
   unsigned *epsP = a.epsP + (size_t)l * a.plane_stride, *epsV = a.epsV + (size_t)l * a.plane_stride;
   const int nrb6 = d >> 6;
   const int R64 = eb % nrb6, c32 = eb / nrb6;
   const int q = tid & 15, c = tid >> 4;
   const int ri = R64 * 64 + 4 * q, rm = c32 * 32 + c;
-  float e[4];
-  eps_block<float>(a.rng.seed, idx, (uint64_t)(moff + rm) * (uint64_t)(d >> 2) + (uint64_t)(ri >> 2), e);
+  float e[4];   // (the stream's index arithmetic is the family's: dT / 4 Philox blocks per sample; a padding row / sample holds zeros -- drawn and
+  eps_block<float>(a.rng.seed, idx, (uint64_t)(moff + rm) * (uint64_t)(a.dT >> 2) + (uint64_t)(ri >> 2), e);   // discarded: a branch around the draw cost 18 registers)
+  if (!(ri < a.dT && rm < a.MT)) { e[0] = 0.f; e[1] = 0.f; e[2] = 0.f; e[3] = 0.f; }
 #pragma unroll
   for (int r = 0; r < 4; ++r) E[c * 65 + 4 * q + r] = e[r] * kEpsScale;
   const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
@@ -352,9 +366,10 @@ __global__ __launch_bounds__(512 / WJ, (MODE == 2 && NRP == 4 && WJ == 1) ? 4 : 
   auto stage_tables = [&]() {   // the tile's row vectors (+ DENSE_G: R's inverse scales): behind the prologue's DMA requests, which their loads must not delay
     if (tid < 128) {
       if constexpr (!kDG && !kSU) {
-        vec[tid] = a.params[row0 + tid];
-        vec[128 + tid] = a.t_mean[row0 + tid];
-        if (MODE == FB_DIAG) vec[256 + tid] = a.t_istd[row0 + tid];
+        const bool in = row0 + tid < a.dT;   // (padding rows: mu = m = 0, 1 / std = 0)
+        vec[tid] = in ? a.params[row0 + tid] : 0.f;
+        vec[128 + tid] = in ? a.t_mean[row0 + tid] : 0.f;
+        if (MODE == FB_DIAG) vec[256 + tid] = in ? a.t_istd[row0 + tid] : 0.f;
       }
       const float *sc = kDG ? a.pscale : (kSU ? a.tscale : a.cscale);
       vec[384 + tid] = sc[d + row0 + tid] * ((kDG) ? 1.f : kEpsInv);   // what a row's raw sums are multiplied by
@@ -520,6 +535,7 @@ __global__ __launch_bounds__(512 / WJ, (MODE == 2 && NRP == 4 && WJ == 1) ? 4 : 
     for (int j = 0; j < WJ; ++j) {
       float *I = img + (i * WJ + j) * kImgW;
       const int cb32 = (col0 >> 5) + WJ * wn + j;
+      const bool pad = 32 * r32[i] >= a.dT || 32 * cb32 >= a.MT;   // (whole 32-blocks: dT and MT are multiples of 32)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 v = {tot[i][j][4 * q], tot[i][j][4 * q + 1], tot[i][j][4 * q + 2], tot[i][j][4 * q + 3]};
@@ -567,6 +583,7 @@ __global__ __launch_bounds__(512 / WJ, (MODE == 2 && NRP == 4 && WJ == 1) ? 4 : 
 #pragma unroll
           for (int c = 0; c < 4; ++c) wv[c] = dense_target_elem(v[c], fb_unsplit2_word(uh[c >> 1], ul[c >> 1], c & 1) * rs, ell);
         }
+        if (pad) { wv = f32x4{0.f, 0.f, 0.f, 0.f}; ell = 0.f; }   // a padding row block / sample block: zero planes, nothing summed
         *(f32x4 *)(I + en * LDC + ei4) = wv;   // the image becomes W[m][i] (FB_DENSE_R: R[m][i])
         if constexpr (kDR) {
           cmax[j][p] = fmaxf(cmax[j][p], fmaxf(fmaxf(fabsf(wv[0]), fabsf(wv[1])), fmaxf(fabsf(wv[2]), fabsf(wv[3]))));
@@ -657,7 +674,7 @@ __global__ __launch_bounds__(512 / WJ, (MODE == 2 && NRP == 4 && WJ == 1) ? 4 : 
     for (int i = 0; i < 2; ++i) {
       const int r = 32 * r32[i] + lane;
       float lg, bad;
-      logdet_block32(a.params[d + (size_t)r * d + r], lg, bad);
+      logdet_block32(r < a.dT ? a.params[a.dT + (size_t)r * a.dT + r] : 1.f, lg, bad);   // (a padding block: log 1 = 0)
       if (lane == 0) {
         a.ld_part[r32[i]] = (double)lg;
         a.ld_part[nrb + r32[i]] = (double)bad;
@@ -685,14 +702,15 @@ __device__ __forceinline__ void fb_value_block(const FbArgs &a, int l, double *r
   if (a.parts) {   // sharded batches: this shard's two scalars of the lane's partial vector
     out.partials_mode = 1;
     out.partials = a.parts + (size_t)l * a.part_stride;
-    out.scalars_off = (int64_t)d + (int64_t)(d >> 7) * ((d >> 7) + 1) / 2 * 16384;
+    out.scalars_off = (int64_t)d + (int64_t)(d >> 7) * ((d >> 7) + 1) / 2 * 16384;   // (sharded batches run on unpadded shapes: d == dT)
   }
   out.ent_kind = a.ent_kind;
   out.M_total = a.M_total;
-  out.M_local = a.M;
+  out.M_local = a.MT;
   out.status = a.status;
   const float *pp = a.params;
-  finalize_value_block<float, 256, false>(d, vin, out, (int64_t)d + (int64_t)d * d, [pp, d](int i) { return pp[d + (size_t)i * d + i]; }, red);
+  const int dT = a.dT;   // (the partial arrays are laid out by the padded geometry, their padding entries are zeros; the entropy constants are the family's)
+  finalize_value_block<float, 256, false>(dT, vin, out, (int64_t)dT + (int64_t)dT * dT, [pp, dT](int i) { return pp[dT + (size_t)i * dT + i]; }, red);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -728,7 +746,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
   const __attribute__((address_space(4))) int *wp = (const __attribute__((address_space(4))) int *)a.work + 4 * ((int)blockIdx.x - a.L);
   const int ln = wp[0], rc = wp[1];
   const int rb = rc & 0xffff, cb = rc >> 16;
-  const int d = a.d, M = a.M, nmg = M >> 4;
+  const int d = a.d, M = a.M, nmg = M >> 4, dT = a.dT;   // (d, M: the padded geometry; the gradient has leading dimension dT)
   const int row0 = rb * 128, col0 = cb * 128;
   const bool last = ln == a.lane_last && a.grad_last;
   float *grad = last ? a.grad_last : a.grads + (size_t)ln * a.grad_stride;
@@ -903,7 +921,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
-      if (cj[j] > ri[i]) continue;
+      if (cj[j] > ri[i] || 32 * ri[i] >= dT) continue;   // above the diagonal / a padding row block (then cj <= ri: the columns are inside too)
       const bool diag = ri[i] == cj[j];
       const int rbase = 32 * ri[i], cbase = 32 * cj[j];
 #pragma unroll
@@ -917,7 +935,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
         const int n = 8 * p + (lane >> 3);
         const int gi = rbase + i4, gj = cbase + n;
         float cjj = 1.f;
-        if (diag && gj >= gi && gj < gi + 4) cjj = a.params[d + (size_t)gj * d + gj];
+        if (diag && gj >= gi && gj < gi + 4) cjj = a.params[dT + (size_t)gj * dT + gj];
         const f32x4 v = *(const f32x4 *)(Cs + n * LDC + i4) * ff;
         f32x4 o;
         if constexpr (PART) {   // the raw sums into the lane's partial vector, tile-packed (no normalisation, no entropy term: k_fb_finalize_parts)
@@ -935,19 +953,19 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
 #pragma unroll
           for (int c = 0; c < 4; ++c) o[c] = vjp_elem(v[c] * kEpsInv, gi + c, gj, pow2M, (float)invM, invM, direct, cjj);
         }
-        store16_wt(grad + d + (size_t)gj * d + gi, o);
+        store16_wt(grad + dT + (size_t)gj * dT + gi, o);
       }
       if (!PART && !diag && upper) {   // the mirrored, strictly upper 32 x 32 block is structurally zero
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
           const int ii = 8 * p + (lane >> 3);
-          store16_wt(grad + d + (size_t)(rbase + ii) * d + cbase + i4, z4);
+          store16_wt(grad + dT + (size_t)(rbase + ii) * dT + cbase + i4, z4);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image is read before the next sub-tile overwrites it
     }
-    if (dg[i]) {   // d/dmu rows of this row block: the two halves' shares
+    if (dg[i] && 32 * ri[i] < dT) {   // d/dmu rows of this row block: the two halves' shares
       const double mine = (rsd[i] + (double)rcur[i]) * (double)wfin[32 * i + l31];
       const double sm = mine + __shfl_xor(mine, 32, 64);
       if constexpr (PART) {
@@ -1034,13 +1052,18 @@ void fb_upload(DevBuf &b, const void *src, size_t bytes) {
 }
 }  // namespace
 
+// Round 6: d and n_mc are multiples of 32 (round 5: of 128); the geometry is padded to whole 128 x 128 tiles (fb_pad), whole 32-blocks of
+// padding carry zero planes and are neither summed nor stored.  The dense target, the sticking-the-landing estimators and the sharded
+// batches keep whole tiles (fb_whole_tiles: their parameter-only operands P / C^-T and the tile-packed partial vector are laid out by d).
+static int fb_pad(int x) { return (x + 127) / 128 * 128; }
 bool fb_shape_ok(const mivi_ctx *c, int M) {
   static const bool off = getenv("MIVI_BATCH_GEN3") && atoi(getenv("MIVI_BATCH_GEN3")) == 0;   // A/B: the lane-batched second-generation kernels
-  return !off && c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && c->cfg.d % kBM == 0 && M % kBN == 0 && c->cfg.d >= kBM &&
+  return !off && c->cfg.family == MIVI_FULLRANK && c->cfg.dtype == MIVI_F32 && c->cfg.d % 32 == 0 && M % 32 == 0 && c->cfg.d >= kBM &&
          c->cfg.d <= 2048 && M >= 128 && M <= 2048;   // (the inverse-scale tables of k_fb_prod<FB_DENSE_G> / k_fb_vjp hold 2048 entries)
 }
-size_t fb_plane_words(const mivi_ctx *c, int M) { return (size_t)c->cfg.d * M / 512 * kFrag; }       // one lane's eps / W planes
-size_t fb_cplane_words(const mivi_ctx *c) { return (size_t)(c->cfg.d / 32) * (c->cfg.d / 16) * kFrag; }
+bool fb_whole_tiles(const mivi_ctx *c, int M) { return c->cfg.d % kBM == 0 && M % kBN == 0; }
+size_t fb_plane_words(const mivi_ctx *c, int M) { return (size_t)fb_pad(c->cfg.d) * fb_pad(M) / 512 * kFrag; }       // one lane's eps / W planes
+size_t fb_cplane_words(const mivi_ctx *c) { return (size_t)(fb_pad(c->cfg.d) / 32) * (fb_pad(c->cfg.d) / 16) * kFrag; }
 size_t fb_part_len(const mivi_ctx *c) {   // [sum W (d) | lower-triangle tiles | sum ell, sum eps^2 / 2 | pad to four floats]
   const size_t d = (size_t)c->cfg.d, T = d / 128;
   return (d + T * (T + 1) / 2 * 16384 + 2 + 3) / 4 * 4;
@@ -1059,7 +1082,7 @@ const FbTab *fb_prepare(mivi_ctx *c, int M, int L) {
   // the null stream, which a non-blocking stream does not order against); and a failed upload must not leave the slot looking valid
   (void)hipStreamSynchronize(c->stream);
   t.L = t.M = 0;
-  const int d = c->cfg.d, nrb = d / kBM, ncb = M / kBN;
+  const int d = fb_pad(c->cfg.d), nrb = d / kBM, ncb = fb_pad(M) / kBN;   // (the padded geometry)
   std::vector<std::vector<int4>> lists(8);
   int panel = 0;
   for (int l = 0; l < L; ++l)
@@ -1148,11 +1171,12 @@ const FbTab *fb_prepare(mivi_ctx *c, int M, int L) {
   return &t;
 }
 
-static FbArgs fb_args(mivi_ctx *c, const void *params, int M) {
+static FbArgs fb_args(mivi_ctx *c, const void *params, int M_true) {
   FbTables &t = c->fb;
-  const int d = c->cfg.d;
+  const int d = fb_pad(c->cfg.d), M = fb_pad(M_true);   // the geometry; dT / MT: the family's dimension, the samples per estimate
   FbArgs a{};
   a.d = d; a.M = M;
+  a.dT = c->cfg.d; a.MT = M_true;
   a.params = (const float *)params;
   a.t_mean = (const float *)c->t_mean.p;
   a.t_istd = (const float *)c->t_istd.p;
@@ -1182,8 +1206,8 @@ static FbArgs fb_args(mivi_ctx *c, const void *params, int M) {
 
 // the draws of a step (+ tril(C)'s planes as riders of a call's first draw) on `stream`
 void fb_launch_eps(mivi_ctx *c, const FbStep &s, bool with_cplanes, hipStream_t stream) {
-  const int d = c->cfg.d, M = s.M, L = s.L;
-  FbArgs a = fb_args(c, s.params, M);
+  const int d = fb_pad(c->cfg.d), M = fb_pad(s.M), L = s.L;
+  FbArgs a = fb_args(c, s.params, s.M);
   a.L = L;
   a.rng = s.rng;
   a.obj = s.obj;
@@ -1254,7 +1278,7 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
     // tiles per CU (x 10) up to which the one-per-CU ring wins, by the heaviest tile's chain (gmax = d / 16 groups): measured at
     // (512, 128) and (512, 512) -- 32 groups: never --, (1024, 256) -- 64 groups: up to 1.7 --, (2048, 128) -- 128 groups: up to 2.2 (32 lanes:
     // 58.5 against 65.5 us; 48 lanes: 88.4 against 84.5); interpolated between (tools/experiments/README_r06.md)
-    const int gmax = c->cfg.d / 16;
+    const int gmax = fb_pad(c->cfg.d) / 16;
     const int thr10 = gmax <= 32 ? 10 : (gmax <= 64 ? 10 + (gmax - 32) * 7 / 32 : kOwnCuTilesPerCU10 + (gmax - 64 < 64 ? gmax - 64 : 64) * 5 / 64);
     return !equal_tiles && n > n_cu && 10 * (long long)n <= (long long)thr10 * n_cu;
   };
@@ -1286,10 +1310,10 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
     // measured at the north star (us per 20 / 50 / 80 lanes): ring 3 + three workgroups per CU 26.5 / 63.3 / 105-115; ring 3, two per CU 26.4 /
     // 69.8 / 109; ring 4, two per CU 36.7 / 81.5 / 126; ring 2, three per CU 26.4 / 72.6 / 113 (round 4's kernel with its second accumulator: 29 / 70 / 115)
     if (s.parts) {   // sharded batches: the lanes' partial vectors instead of gradients
-      if (s.M <= 256) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 256, 6, true>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
+      if (a.M <= 256) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 256, 6, true>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
       else hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 2048, 4, true>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
     }
-    else if (s.M <= 256) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 256, 6>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
+    else if (a.M <= 256) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 256, 6>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
     else hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 2048, 4>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
 #ifdef MIVI_DEV
     dump("k_fb_vjp", tb.n_vjp);

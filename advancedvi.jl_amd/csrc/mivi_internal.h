@@ -499,6 +499,7 @@ void invalidate_graph(mivi_ctx *c);            // api_core.hip: drop the cached 
 // every workgroup of `grid` resident at once?  (loops whose workgroups exchange partials every step by spin-wait: checked at launch, never assumed)
 bool grid_resident(const mivi_ctx *c, const void *kernel, int block, size_t dyn_lds, long long grid);
 bool fb_shape_ok(const mivi_ctx *c, int M);
+bool fb_whole_tiles(const mivi_ctx *c, int M);        // d and M multiples of 128: no padding (what the dense target, the STL term and the sharded batches need)
 mivi_status_t fb_objective(mivi_ctx *c, const void *params, uint64_t idx, int lanes, int entropy, void *values);   // api_batch.hip: lanes x n_mc samples of estimate idx on the batch engine (MIVI_ERR_UNSUPPORTED: not an engine configuration)
 const FbTab *fb_prepare(mivi_ctx *c, int M, int L);   // work tables for L lanes (nullptr: allocation failed)
 size_t fb_plane_words(const mivi_ctx *c, int M);      // 4-byte words of one lane's operand planes (eps in one orientation, W)

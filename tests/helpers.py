@@ -123,8 +123,9 @@ def engine_shape(d, M, family=None, dtype=np.float32, kind="diag", n=2):
     There the products run on two-way f16 operand splits (f32-accurate, 2^-22 per term), so a batch's estimates equal the single calls'
     (exact three-way bf16 split) to rounding; every other route stays bitwise the single calls'."""
     family = avi.FULLRANK if family is None else family
-    return (family == avi.FULLRANK and np.dtype(dtype) == np.float32 and kind in ("diag", "dense") and n >= 2 and d % 128 == 0 and
-            128 <= d <= 2048 and M % 128 == 0 and 128 <= M <= 2048)
+    whole = d % 128 == 0 and M % 128 == 0     # round 6: d and n_mc multiples of 32 (geometry padded to whole tiles) with the diagonal target; the
+    return (family == avi.FULLRANK and np.dtype(dtype) == np.float32 and kind in ("diag", "dense") and n >= 2 and d % 32 == 0 and   # dense target (and the STL term: ask ctx.batch_takes_engine) keep whole tiles
+            128 <= d <= 2048 and M % 32 == 0 and 128 <= M <= 2048 and (kind == "diag" or whole))
 
 
 # the stated tolerances of "a batch's estimate equals the single call's" on the batch engine: value relative, gradient relative l2

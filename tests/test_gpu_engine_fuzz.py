@@ -1,4 +1,4 @@
-"""Randomised sweep over the batch engine's own shapes (d and n_mc multiples of 128, d <= 2048): family full-rank f32, diagonal / dense target,
+"""Randomised sweep over the batch engine's own shapes (d and n_mc multiples of 128 -- round 6: also of 32, padded --, d <= 2048): family full-rank f32, diagonal / dense target,
 the five entropy estimators, batch lengths that cut into one or several steps of different widths -- every checked estimate against the
 single call (to rounding) and against the fp64 oracle on the device's own eps.  Fixed seed: reproducible."""
 import numpy as np
@@ -24,10 +24,25 @@ def _cases(n, seed):
     return out
 
 
+def _ragged(n, seed):
+    """round 6: d and n_mc multiples of 32 that are NOT multiples of 128 -- the geometry is padded to whole tiles, whole 32-blocks of padding carry
+    zero planes and are neither summed nor stored (diagonal target; the dense target and the STL estimators fall to the single calls: bitwise)"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        d = int(rng.choice([160, 288, 416, 544, 992, 1056, 1504, 2016]))
+        M = int(rng.choice([128, 160, 224, 288, 352, 480]))
+        ent = int(rng.integers(0, 5))
+        kind = "diag" if rng.integers(0, 5) else "dense"
+        count = int(rng.choice([2, 5, 20, 27, 83]))
+        out.append((d, M, kind, ent, count))
+    return out + [(1024, 160, "diag", 0, 20), (160, 256, "diag", 2, 9), (2016, 2016, "diag", 0, 2)]
+
+
 _WIDE = [(256, 2048, "diag", 0, 5), (128, 1024, "dense", 2, 9), (256, 1024, "diag", 3, 18), (128, 2048, "dense", 0, 3), (2048, 128, "dense", 1, 4)]   # the widest sample counts (16 re-basing boundaries in the VJP) and the largest d
 
 
-@pytest.mark.parametrize("d,M,kind,ent,count", _cases(28, 20260929) + _WIDE)
+@pytest.mark.parametrize("d,M,kind,ent,count", _cases(28, 20260929) + _WIDE + _ragged(16, 20260930))
 def test_engine_fuzz(d, M, kind, ent, count):
     rng = np.random.default_rng(d * 31 + M * 7 + ent + count)
     q, q_o = make_family(rng, d, avi.FULLRANK, np.float32, mu_scale=0.5)
