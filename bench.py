@@ -545,11 +545,13 @@ def main():
                     n_e = 100
                     ve, ge = ctx.estimate_gradient_each(params, 90_000, n_e)
                     stream.synchronize()
-                    t0s = time.perf_counter()
-                    for r in range(5):
-                        ctx.estimate_gradient_each(params, 90_000 + (r + 1) * n_e, n_e, values=ve, grads=ge)
-                    stream.synchronize()
-                    t_e = (time.perf_counter() - t0s) / (5 * n_e)
+                    t_e = float("inf")
+                    for rr in range(3):
+                        t0s = time.perf_counter()
+                        for r in range(5):
+                            ctx.estimate_gradient_each(params, 90_000 + (5 * rr + r + 1) * n_e, n_e, values=ve, grads=ge)
+                        stream.synchronize()
+                        t_e = min(t_e, (time.perf_counter() - t0s) / (5 * n_e))
                     also["ns_each"] = dict(workload="north-star batches through mivi_estimate_gradient_each (every estimate's value and dense gradient kept), 5 x 100 estimates",
                                            value=1.0 / t_e, unit="estimates/s", us_per_step=t_e * 1e6)
                     del ve, ge
@@ -560,11 +562,13 @@ def main():
                     n_o = 100_000
                     vo = ctx.estimate_objective(params, 95_000, n_samples=n_o)
                     stream.synchronize()
-                    t0s = time.perf_counter()
-                    for r in range(10):
-                        vo = ctx.estimate_objective(params, 95_001 + r, n_samples=n_o, value=vo)
-                    stream.synchronize()
-                    t_o = (time.perf_counter() - t0s) / 10
+                    t_o = float("inf")
+                    for rr in range(3):   # (best of three, like the legs above)
+                        t0s = time.perf_counter()
+                        for r in range(10):
+                            vo = ctx.estimate_objective(params, 95_001 + 10 * rr + r, n_samples=n_o, value=vo)
+                        stream.synchronize()
+                        t_o = min(t_o, (time.perf_counter() - t0s) / 10)
                     also["ns_objective_1e5"] = dict(workload="mivi_estimate_objective, 10^5 samples per call, north-star family and target (whole blocks of n_mc samples as lanes of the batch engine, values only)",
                                                     value=n_o / t_o, unit="samples/s", ms_per_call=t_o * 1e3)
                 except Exception as e:   # noqa: BLE001
