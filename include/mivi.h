@@ -170,8 +170,9 @@ mivi_status_t mivi_estimate_gradient_host(mivi_ctx_t *ctx, const void *params_ho
 /* `count` consecutive estimates estimate_idx0 .. estimate_idx0+count-1 of the same params replayed as ONE
  * hipGraph launch; value/grad hold the LAST estimate on return.  Built-in targets only.  Mean-field family with the
  * diagonal-Gaussian target (rows independent): all `count` estimates run inside one launch-free kernel instead.  Full-rank f32 family,
- * d and n_mc multiples of 128, Gaussian target: the batch engine (kernels_fullrank_batch.hip) -- steps of up to 80 estimates as three
- * launches (draws, one product, one VJP over all of them), no graph. */
+ * d and n_mc multiples of 32 in [128, 2048] (multiples of 128 with the dense target or a sticking-the-landing estimator), Gaussian target:
+ * the batch engine (kernels_fullrank_batch.hip) -- steps of up to 80 estimates as three launches (draws, one product, one VJP over all of
+ * them), no graph. */
 mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx0,
                                        int32_t count, void *value_dev, void *grad_dev);
 /* The same batch with EVERY estimate's result kept: values_dev T[count] <- -elbo of estimate estimate_idx0 + i;
@@ -179,7 +180,7 @@ mivi_status_t mivi_estimate_gradient_n(mivi_ctx_t *ctx, const void *params_dev, 
  * estimate_objective / estimate_gradient! at fixed parameters wants from many estimates -- monitoring with many samples
  * (test/algorithms/klminrepgraddescent.jl:36), a gradient averaged over several estimates
  * (src/algorithms/repgradelbo.jl:151-177 called `count` times on one q).  Estimate i equals mivi_estimate_gradient(estimate_idx0 + i): bitwise on the generic route, to
- * rounding (value 1e-6, gradient relative l2 2e-6) on the batch engine (full-rank f32, d and n_mc multiples of 128, Gaussian targets). */
+ * rounding (value 1e-6, gradient relative l2 2e-6) on the batch engine (full-rank f32, d and n_mc multiples of 32, Gaussian targets). */
 mivi_status_t mivi_estimate_gradient_each(mivi_ctx_t *ctx, const void *params_dev, uint64_t estimate_idx0,
                                           int32_t count, void *values_dev, void *grads_dev);
 
