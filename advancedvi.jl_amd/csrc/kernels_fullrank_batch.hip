@@ -363,32 +363,56 @@ __global__ __launch_bounds__(512 / WJ, (MODE == 2 && NRP == 4 && WJ == 1) ? 4 : 
     }
   }
   int gd = 0;               // the group the pointers stand at
-  auto stage_tables = [&]() {   // the tile's row vectors (+ DENSE_G: R's inverse scales): behind the prologue's DMA requests, which their loads must not delay
+  // The tile's row vectors (+ DENSE_G: R's inverse scales) in two halves.  load_tables: every global load of them, issued IN FRONT of the
+  // prologue's DMA requests and not waited for -- the loads and the first stages travel together; stage_tables: behind the requests, the
+  // arithmetic and the LDS writes.  (Round 6: the inverse scales used to be loaded inside the serial re-basing loop, behind the requests --
+  // d / 128 dependent round trips, each behind a vmcnt(0), before the tile's first group: 6.5 us of a dense tile's lifetime at d = 1024.)
+  constexpr int kMaxNB = 16;   // d <= 2048
+  float tv[4] = {0.f, 0.f, 0.f, 0.f}, tri[kDG ? kMaxNB : 1], trs = 0.f;
+  auto load_tables = [&]() {
     if (tid < 128) {
       if constexpr (!kDG && !kSU) {
         const bool in = row0 + tid < a.dT;   // (padding rows: mu = m = 0, 1 / std = 0)
-        vec[tid] = in ? a.params[row0 + tid] : 0.f;
-        vec[128 + tid] = in ? a.t_mean[row0 + tid] : 0.f;
-        if (MODE == FB_DIAG) vec[256 + tid] = in ? a.t_istd[row0 + tid] : 0.f;
+        tv[0] = in ? a.params[row0 + tid] : 0.f;
+        tv[1] = in ? a.t_mean[row0 + tid] : 0.f;
+        if (MODE == FB_DIAG) tv[2] = in ? a.t_istd[row0 + tid] : 0.f;
       }
       const float *sc = kDG ? a.pscale : (kSU ? a.tscale : a.cscale);
-      vec[384 + tid] = sc[d + row0 + tid] * ((kDG) ? 1.f : kEpsInv);   // what a row's raw sums are multiplied by
-    }
-    if constexpr (kDG) {
-      if (tid < 128) {
+      tv[3] = sc[d + row0 + tid];
+      if constexpr (kDG) {
         const float *ri = a.rinv + (size_t)ln * (size_t)(d >> 7) * a.M + col0 + tid;
         const int NB = d >> 7;
-        float u = ri[0], grow = 1.f;   // u: the inverse of the unit the accumulator is in; grow: how far the re-basing has scaled it up
-        for (int b = 1; b < NB; ++b) {
-          float ratio = u / ri[(size_t)b * a.M];
-          if (!(ratio <= 1099511627776.f)) ratio = 1099511627776.f;          // 2^40 per boundary (also for a non-finite quotient) ...
-          if (ratio > 1.f && grow * ratio > 1.2089258e24f) ratio = fmaxf(1.2089258e24f / grow, 1.f);   // ... and 2^80 in all: the accumulator cannot overflow
-          if (ratio > 1.f) grow *= ratio;
-          tab[(b - 1) * 128 + tid] = ratio;
-          u = u / ratio;
+#pragma unroll
+        for (int b = 0; b < kMaxNB; ++b) tri[b] = ri[(size_t)(b < NB ? b : NB - 1) * a.M];   // (clamped, not predicated: straight-line loads -- a branch per load and the compiler sinks the lot behind the requests)
+        trs = ri[(size_t)rb * a.M];
+      }
+    }
+    asm volatile("" ::: "memory");   // (the loads stay in front of the requests: the compiler otherwise sinks them into stage_tables' branch)
+  };
+  auto stage_tables = [&]() {
+    if (tid < 128) {
+      if constexpr (!kDG && !kSU) {
+        vec[tid] = tv[0];
+        vec[128 + tid] = tv[1];
+        if (MODE == FB_DIAG) vec[256 + tid] = tv[2];
+      }
+      vec[384 + tid] = tv[3] * ((kDG) ? 1.f : kEpsInv);   // what a row's raw sums are multiplied by
+      if constexpr (kDG) {
+        const int NB = d >> 7;
+        float u = tri[0], grow = 1.f;   // u: the inverse of the unit the accumulator is in; grow: how far the re-basing has scaled it up
+#pragma unroll
+        for (int b = 1; b < kMaxNB; ++b) {
+          if (b < NB) {
+            float ratio = u / tri[b];
+            if (!(ratio <= 1099511627776.f)) ratio = 1099511627776.f;          // 2^40 per boundary (also for a non-finite quotient) ...
+            if (ratio > 1.f && grow * ratio > 1.2089258e24f) ratio = fmaxf(1.2089258e24f / grow, 1.f);   // ... and 2^80 in all: the accumulator cannot overflow
+            if (ratio > 1.f) grow *= ratio;
+            tab[(b - 1) * 128 + tid] = ratio;
+            u = u / ratio;
+          }
         }
         tab[(NB - 1) * 128 + tid] = u;
-        rsv[tid] = ri[(size_t)rb * a.M];
+        rsv[tid] = trs;
       }
     }
   };
@@ -477,7 +501,9 @@ __global__ __launch_bounds__(512 / WJ, (MODE == 2 && NRP == 4 && WJ == 1) ? 4 : 
   };
   FB_STAMP(a, 0);
   FB_NOTE(a, 4, G);
+  load_tables();
   static_for<0, NRP>([&](auto S) { issue(decltype(S)::value); });   // (G >= 8 >= NRP)
+  fb_wait_vm<kPW * NRP>();   // the tables' loads are older than every request: they have landed, the stages need not have
   stage_tables();
   fb_wait_vm<kPW * (NRP - 1)>();
   fb_barrier();
@@ -760,17 +786,32 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
     sp[f] = (fs < 4 ? a.WV + (size_t)ln * a.plane_stride + ((size_t)((row0 >> 5) + fr) * nmg) * kFrag
                     : a.epsV + (size_t)ln * a.plane_stride + ((size_t)((col0 >> 5) + fr) * nmg) * kFrag) + 4 * lane;
   }
-  auto build_table = [&]() {   // (behind the prologue's DMA requests: its loads and divisions must not delay them)
-  if (tid < 128) {
+  // W's inverse scales: loaded IN FRONT of the prologue's DMA requests and not waited for (load_table); the divisions and the LDS writes
+  // behind the requests (build_table).  (Round 6: they were loaded inside the serial loop, behind the requests: n_mc / 128 dependent round
+  // trips, each behind a vmcnt(0), in front of a main loop of only n_mc / 16 groups.)
+  constexpr int kMaxNBv = 16;   // n_mc <= 2048
+  float twi[kMaxNBv];
+  auto load_table = [&]() {
+    if (tid < 128) {
       const float *wi = a.winv + (size_t)ln * (size_t)NB * d + row0 + tid;
-      float u = wi[0], grow = 1.f;   // u: the inverse of the unit the accumulator is in; grow: how far the re-basing has scaled it up
-      for (int r = 1; r < NB; ++r) {
-        float ratio = u / wi[(size_t)r * d];
-        if (!(ratio <= 1099511627776.f)) ratio = 1099511627776.f;   // 2^40 per boundary (also for a non-finite quotient) ...
-        if (ratio > 1.f && grow * ratio > 1.2089258e24f) ratio = fmaxf(1.2089258e24f / grow, 1.f);   // ... and 2^80 over all boundaries (up to 15 of them at n_mc = 2048)
-        if (ratio > 1.f) grow *= ratio;
-        wf[(r - 1) * 128 + tid] = ratio;
-        u = u / ratio;
+#pragma unroll
+      for (int r = 0; r < kMaxNBv; ++r) twi[r] = wi[(size_t)(r < NB ? r : NB - 1) * d];   // (clamped, not predicated: straight-line loads)
+    }
+    asm volatile("" ::: "memory");   // (the loads stay in front of the requests)
+  };
+  auto build_table = [&]() {
+    if (tid < 128) {
+      float u = twi[0], grow = 1.f;   // u: the inverse of the unit the accumulator is in; grow: how far the re-basing has scaled it up
+#pragma unroll
+      for (int r = 1; r < kMaxNBv; ++r) {
+        if (r < NB) {
+          float ratio = u / twi[r];
+          if (!(ratio <= 1099511627776.f)) ratio = 1099511627776.f;   // 2^40 per boundary (also for a non-finite quotient) ...
+          if (ratio > 1.f && grow * ratio > 1.2089258e24f) ratio = fmaxf(1.2089258e24f / grow, 1.f);   // ... and 2^80 over all boundaries (up to 15 of them at n_mc = 2048)
+          if (ratio > 1.f) grow *= ratio;
+          wf[(r - 1) * 128 + tid] = ratio;
+          u = u / ratio;
+        }
       }
       wf[(NB - 1) * 128 + tid] = u;
     }
@@ -854,7 +895,9 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
   };
   if constexpr (PF) {
     static_assert(kRing == 4, "the unrolled loops below are written for four slots");
+    load_table();
     issue(0); issue(1); issue(2); issue(3);   // (G >= 8: M >= 128)
+    fb_wait_vm<kPW * 4>();   // (the table's loads are older than the requests)
     build_table();
     fb_wait_vm<kPW * 3>();
     fb_barrier();
@@ -889,8 +932,10 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
     // other workgroup of the CU runs its MFMAs under this one's waits
     FB_STAMP(a, 0);
     FB_NOTE(a, 4, G);
+    load_table();
 #pragma unroll
     for (int s0 = 0; s0 < NR - 1; ++s0) issue(s0);   // (G >= 8)
+    fb_wait_vm<kPW * (NR - 1)>();   // (the table's loads are older than the requests)
     build_table();
     int slot = 0;
     for (int g = 0; g < G; ++g) {
