@@ -223,7 +223,7 @@ static mivi_status_t fb_batch(mivi_ctx *c, const void *params, uint64_t idx0, in
     invalidate_graph(c);
     const size_t pw = fb_plane_words(c, M) * 4;
     if ((s = ensure(c, t.CA, fb_cplane_words(c) * 4, false)) || (s = ensure(c, t.epsP, (size_t)L * pw, false)) ||
-        (s = ensure(c, t.epsV, (size_t)L * pw, false)) || (s = ensure(c, t.WV, (size_t)L * pw, false)) ||
+        (s = ensure(c, t.WV, (size_t)L * pw, false)) ||
         (s = ensure(c, t.ell, (size_t)L * (dG / 32) * (MG / 32) * sizeof(double), false)) ||
         (s = ensure(c, t.he, (size_t)L * (dG / 64) * (MG / 32) * sizeof(double), false)) ||
         (s = ensure(c, t.ld, 2 * (size_t)(dG / 32) * sizeof(double) + 64, false)) || (s = ensure(c, t.values, (size_t)L * 4 + 64, false)) ||

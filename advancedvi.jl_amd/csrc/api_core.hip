@@ -196,7 +196,7 @@ mivi_status_t mivi_destroy(mivi_ctx_t *c) {
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   {
-    DevBuf *fbb[] = {&c->fb.CA, &c->fb.epsP, &c->fb.epsV, &c->fb.WV, &c->fb.ell, &c->fb.he, &c->fb.ld, &c->fb.grads, &c->fb.values, &c->fb.PA, &c->fb.RP, &c->fb.Tinv, &c->fb.TA, &c->fb.Eye, &c->snap, &c->fb.cscale, &c->fb.pscale, &c->fb.tscale, &c->fb.winv, &c->fb.rinv, &c->p2p_direct, &c->rows_eps, &c->gen_scratch};
+    DevBuf *fbb[] = {&c->fb.CA, &c->fb.epsP, &c->fb.WV, &c->fb.ell, &c->fb.he, &c->fb.ld, &c->fb.grads, &c->fb.values, &c->fb.PA, &c->fb.RP, &c->fb.Tinv, &c->fb.TA, &c->fb.Eye, &c->snap, &c->fb.cscale, &c->fb.pscale, &c->fb.tscale, &c->fb.winv, &c->fb.rinv, &c->p2p_direct, &c->rows_eps, &c->gen_scratch};
     for (DevBuf *b : fbb)
       if (b->p) (void)hipFree(b->p);
     for (auto &tb : c->fb.tab) {

@@ -11,7 +11,8 @@
 //   * OPERAND PLANES (fr_planes.h).  Every operand lives in memory as the two-way f16 split of its power-of-two-scaled f32 elements (hi / lo
 //     planes, 4 bytes per element) in MFMA-FRAGMENT ORDER: a fragment = 32 rows x 16 k of one operand = 2 planes x 64 lanes x 16 bytes.
 //     tril(C) is laid out once per call (rider workgroups of the first draw: row maxima -> row scales -> fragments, diagonal blocks masked),
-//     eps by its generator in both orientations (k_fb_eps: rows as k for the product, samples as k for the VJP), W by the product's
+//     eps by its generator ONCE, in the product's orientation (k_fb_eps: rows as k; round 6 -- the VJP, whose k are the samples, gathers its
+//     B pieces from the same planes and transposes them on the way out of LDS with ds_read_b64_tr_b16), W by the product's
 //     epilogue with one scale per (row, 128-sample tile).  A main loop is then LDS-DMA (1 KiB pieces) -> ds_read_b128 -> three
 //     v_mfma_f32_32x32x16_f16 per fragment pair (lo.hi, hi.lo, hi.hi): no vector arithmetic at all.
 //   * a workgroup owns a 128 x 128 output tile, a wave a 64 x 32 WJ part of it over the WHOLE K range; operands are staged once per
@@ -33,9 +34,6 @@
 #ifndef FB_WJ
 #define FB_WJ 1
 #endif
-#ifndef FB_PF_VJP
-#define FB_PF_VJP 0
-#endif
 
 namespace mivi {
 
@@ -49,7 +47,6 @@ struct FbArgs {
   unsigned *CA;                   // planes of tril(C): fragment (rb32, kg), kg <= 2 rb32 + 3, at (rb32 (d / 16) + kg) kFrag
   float *cscale;                  // [2][d]: row scales of tril(C), their inverses
   unsigned *epsP;                 // lane l: epsP + l * plane_stride; fragment (mb32, kg = row group) at (mb32 (d / 16) + kg) kFrag; 2^11 eps
-  unsigned *epsV;                 // lane l: epsV + l * plane_stride; fragment (jb32, mg = sample group) at (jb32 (M / 16) + mg) kFrag; 2^11 eps
   unsigned *WV;                   // lane l: WV + l * plane_stride; fragment (rb32, mg) at (rb32 (M / 16) + mg) kFrag
   float *winv;                    // lane l: winv + l * (M / 128) d: inverse scale of W's (row, 128-sample block): [M / 128][d]
   // dense-Gaussian target: g = -P (z - m) is a second product per lane (k_fb_prod<FB_DENSE_G>) between the draw's product and the VJP
@@ -84,7 +81,6 @@ struct FbArgs {
   double ell_const;
   RngArgs rng;                    // lane l draws estimate rng_index(rng) + l
   int n_riders;                   // k_fb_eps: grid rows in front of the lanes' that lay out tril(C)
-  int skip_v;                     // k_fb_eps: no VJP follows (values only): the draws' VJP orientation is not written
   int obj;                        // k_fb_eps: 1 = lane l draws samples [l M, (l + 1) M) of ONE estimate index (objective mode); 0 = estimate index + l
   // sharded batches: the VJP launch leaves lane l's shard-additive, UNNORMALISED partial vector at parts + l part_stride:
   //   [sum_m W_im (d) | the lower triangle of sum_m W (x) eps as its 128 x 128 tiles, tile (rb, cb <= rb) at d + (rb (rb + 1) / 2 + cb) 128^2,
@@ -210,10 +206,11 @@ __global__ __launch_bounds__(512) void k_fb_tplanes(FbArgs a) {
 }
 
 // -----------------------------------------------------------------------------------------------------------------
-// k_fb_eps: eps of L estimates as operand planes (of 2^11 eps) in both orientations.  Draws: blocks of 64 rows x 32 columns, one Philox block
+// k_fb_eps: eps of L estimates as operand planes (of 2^11 eps).  Draws: blocks of 64 rows x 32 columns, one Philox block
 // per thread (rows 4 q .. 4 q + 3 of one column: the stream and the he_part partials of the single calls' k_eps); the block's values go
-// through an LDS tile, threads 0..255 then assemble the four product fragments (column = row of the B operand, k = rows 16 ig ..),
-// threads 256..511 the four VJP fragments (row j, k = samples 16 mg ..).  blockIdx.y - n_riders = lane; the first n_riders grid rows
+// through an LDS tile, threads 0..255 then assemble the four product fragments (column = row of the B operand, k = rows 16 ig ..).
+// The kernel is bound by the generator's vector arithmetic (Philox's 32-bit multiplies + Box-Muller), not by its plane writes: halving the
+// writes (round 6) took 7 % off it.  blockIdx.y - n_riders = lane; the first n_riders grid rows
 // (a call's first draw only) lay out tril(C): one workgroup per 32-row block, the heaviest first.
 // -----------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
@@ -228,7 +225,7 @@ __global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
   const int l = (int)blockIdx.y - a.n_riders;
   const uint64_t idx = rng_index(a.rng) + (a.obj ? 0ull : (uint64_t)l);
   const int moff = a.rng.m_offset + (a.obj ? l * a.MT : 0);
-  unsigned *epsP = a.epsP + (size_t)l * a.plane_stride, *epsV = a.epsV + (size_t)l * a.plane_stride;
+  unsigned *epsP = a.epsP + (size_t)l * a.plane_stride;
   const int nrb6 = d >> 6;
   const int R64 = eb % nrb6, c32 = eb / nrb6;
   const int q = tid & 15, c = tid >> 4;
@@ -241,20 +238,14 @@ __global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
   const float he = 0.5f * (e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3]);
   const double sh = block_sum_nodrain_f32<512>(he, red);   // (its barriers also publish the tile)
   if (tid == 0) a.he_part[(size_t)l * a.he_stride + eb] = sh;
-  const int lane = tid & 63, l31 = lane & 31, h = lane >> 5, f = (tid >> 6) & 3;
+  // ONE orientation (round 6): the product's fragments (mb32 = c32, kg = 4 R64 + f): lane = column l31, slots = rows 16 f + ..; k_fb_vjp takes its B
+  // operand from these same planes and transposes it on the way out of LDS.  (Rounds 4-5 wrote a second, VJP-oriented set: 2 MB per lane.)
+  if (tid >= 256) return;
+  const int lane = tid & 63, l31 = lane & 31, h = lane >> 5, f = tid >> 6;
   float x[8];
-  unsigned *dst;
-  if (tid < 256) {   // product fragment (mb32 = c32, kg = 4 R64 + f): lane = column l31, slots = rows 16 f + ..
 #pragma unroll
-    for (int s = 0; s < 8; ++s) x[s] = E[l31 * 65 + 16 * f + 8 * (s >> 2) + 4 * h + (s & 3)];
-    dst = epsP + ((size_t)c32 * (d >> 4) + 4 * R64 + f) * kFrag;
-  } else {           // VJP fragment (jb32 = 2 R64 + f / 2, mg = 2 c32 + f % 2): lane = row l31, slots = samples 16 (f % 2) + ..
-    const int jb = f >> 1, mg = f & 1;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) x[s] = E[(16 * mg + 8 * (s >> 2) + 4 * h + (s & 3)) * 65 + 32 * jb + l31];
-    dst = epsV + ((size_t)(2 * R64 + jb) * (a.M >> 4) + 2 * c32 + mg) * kFrag;
-  }
-  if (tid < 256 || !a.skip_v) fb_store_frag(dst + 4 * lane, x);
+  for (int s = 0; s < 8; ++s) x[s] = E[l31 * 65 + 16 * f + 8 * (s >> 2) + 4 * h + (s & 3)];
+  fb_store_frag(epsP + ((size_t)c32 * (d >> 4) + 4 * R64 + f) * kFrag + 4 * lane, x);
 }
 
 // -----------------------------------------------------------------------------------------------------------------
@@ -262,8 +253,6 @@ __global__ __launch_bounds__(512) void k_fb_eps(FbArgs a) {
 // planes each) in an LDS ring.  Fragment f of a stage (2 KiB): f < 4: A fragment f; else B fragment f - 4.  Wave w issues fragments
 // WJ w .. WJ w + WJ - 1: always 2 WJ requests per wave and stage, so the vmcnt accounting is a compile-time constant.
 // -----------------------------------------------------------------------------------------------------------------
-constexpr int kRing = 4;            // LDS ring slots of the register-prefetching loops: three stages in flight behind the one being read;
-                                    // the main loops are unrolled by kRing, so every slot address is a compile-time constant
 constexpr int kImgW = 32 * 36;      // a wave-private 32 x 32 epilogue image (leading dimension 36), words
 // Wave layout of a 128 x 128 tile, WJ = 32-column blocks per wave: 8 / WJ waves = 2 (row halves of 64) x 4 / WJ (column parts of 32 WJ).
 //   WJ = 2: four waves (one per SIMD), a wave owns 64 x 64: 32 KiB of LDS reads per group and workgroup
@@ -750,10 +739,11 @@ __device__ __forceinline__ void fb_value_block(const FbArgs &a, int l, double *r
 // -----------------------------------------------------------------------------------------------------------------
 // NRV = ring slots of the plain loop, TABW = words of the scale table (M <= TABW), WPE = waves per SIMD the register budget allows:
 // (3, 256, 6) = 50 KiB of LDS and <= 80 registers: THREE workgroups per CU for n_mc <= 256; (3, 2048, 4): two per CU otherwise.
-template <int WJ, int PF, int NRV, int TABW, int WPE, bool PART = false>
-__global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbArgs a) {
+template <int WJ, int NRV, int TABW, int WPE, bool PART = false>
+__global__ __launch_bounds__(512 / WJ, WPE / WJ) void k_fb_vjp(FbArgs a) {
+  static_assert(WJ == 1, "the transposing B reads are written for the 64 x 32 wave tiles");
   constexpr int LDC = 36, NF = WJ, kPW = 2 * WJ;
-  constexpr int NR = PF ? kRing : NRV;
+  constexpr int NR = NRV;
   constexpr int kBody = (NR * kStageW > 16 * kImgW / 2) ? NR * kStageW : 16 * kImgW / 2;   // the ring, later one image per wave
   __shared__ __attribute__((aligned(16))) unsigned lds[kBody + TABW];
   // W's planes are scaled per (row, 128-sample block).  The chain accumulator stays ONE accumulator: at a block boundary its rows are
@@ -780,12 +770,32 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
   const int G = nmg;
   const int NB = M >> 7;   // 128-sample blocks
   const unsigned *sp[NF];           // the stage the next issue takes
+  // EPS ONCE (round 6): B = eps' comes from the draws' PRODUCT-orientation planes (fragment (mb32, kg): lane (sample, h) holds the eight
+  // dims 16 kg + 8 (e / 4) + 4 h + e % 4).  A B piece pair (1 KiB hi + 1 KiB lo) of a stage = the 16 samples of group mg x the 32 dims of
+  // block jb = two product fragments' sample halves: DMA lane p fetches the 16-byte chunk (kgpar, hp, s) with
+  //   p = 8 (4 (s / 8) + 2 hp + kgpar) + ((s % 8) ^ 4 hp)
+  // -- eight consecutive lanes = one 128-byte line (its two 64-byte halves swapped where hp = 1) -- and the wave's B fragment comes out of
+  // LDS through ds_read_b64_tr_b16 (lane c of a 16-lane group receives element c % 4 of the 8-byte chunks whose addresses lanes
+  // 4 j + c / 4 supply): lane (dim n = 16 (G % 2) + c, h' = G / 2) gets samples 4 h' + j (second read: + 8) = the fragment slots e = j,
+  // 4 + j.  The position map makes the 16 chunks of a 32-lane read group (kgpar, hp, s % 4) tile 256 bytes: no bank conflict.
+  unsigned btr;                     // this lane's byte offset inside a B piece for the transposing reads
+  {
+    const int G4 = lane >> 4, c16 = lane & 15;
+    const int kgpar = G4 & 1, hq = G4 >> 1, hp = c16 & 1, half = (c16 >> 1) & 1, sl = 4 * hq + (c16 >> 2);
+    btr = 16u * (unsigned)(8 * (2 * hp + kgpar) + ((sl & 7) ^ (4 * hp))) + 8u * (unsigned)half;
+  }
 #pragma unroll
   for (int f = 0; f < NF; ++f) {
     const int fs = NF * w + f, fr = fs & 3;
-    sp[f] = (fs < 4 ? a.WV + (size_t)ln * a.plane_stride + ((size_t)((row0 >> 5) + fr) * nmg) * kFrag
-                    : a.epsV + (size_t)ln * a.plane_stride + ((size_t)((col0 >> 5) + fr) * nmg) * kFrag) + 4 * lane;
+    if (fs < 4) {
+      sp[f] = a.WV + (size_t)ln * a.plane_stride + ((size_t)((row0 >> 5) + fr) * nmg) * kFrag + 4 * lane;
+    } else {
+      const int m8 = lane >> 3, s8 = m8 >> 2, hp = (m8 >> 1) & 1, kgpar = m8 & 1, sl = 8 * s8 + ((lane & 7) ^ (4 * hp));
+      sp[f] = a.epsP + (size_t)ln * a.plane_stride + ((size_t)((col0 >> 4) + 2 * fr + kgpar)) * kFrag + 4 * (sl + 32 * hp);
+    }
   }
+  int gi = 0;                       // groups requested so far (EPS ONCE: the B pointers alternate between a fragment's sample halves)
+  const int bstep_odd = (d >> 4) * kFrag - 64;   // from the second sample half of (mb32, kg) to the first of (mb32 + 1, kg), words
   // W's inverse scales: loaded IN FRONT of the prologue's DMA requests and not waited for (load_table); the divisions and the LDS writes
   // behind the requests (build_table).  (Round 6: they were loaded inside the serial loop, behind the requests: n_mc / 128 dependent round
   // trips, each behind a vmcnt(0), in front of a main loop of only n_mc / 16 groups.)
@@ -822,8 +832,26 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
       unsigned *dst = lds + slot * kStageW + (NF * w + f) * 512;
       FB_GLDS16(sp[f], dst, 0);
       FB_GLDS16(sp[f], dst, 1024);
-      sp[f] += kFrag;
+      if (NF * w + f >= 4) sp[f] += (gi & 1) ? bstep_odd : 64;
+      else sp[f] += kFrag;
     }
+    ++gi;
+  };
+  auto read_frags = [&](int slot, FbFrags<WJ> &F) {
+    const unsigned *cur = lds + slot * kStageW + 4 * lane;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) F.A[i][p] = *(const u32x4v *)(cur + ((2 * wm + i) * 2 + p) * 256);
+    // (assembly, not __builtin_amdgcn_ds_read_tr16_b64: behind the builtin the compiler waits vmcnt(0) -- for the LDS-DMA requests just issued --
+    //  in every group; the block ends with lgkmcnt(0), so the values are valid for whatever the compiler does with them)
+    const unsigned bb = (unsigned)(uintptr_t)(lds + slot * kStageW) + (8 + 2 * wn) * 1024 + btr;
+    uint2 t0, t1, t2, t3;
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\tds_read_b64_tr_b16 %2, %4 offset:1024\n\t"
+                 "ds_read_b64_tr_b16 %3, %4 offset:1536\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(bb) : "memory");
+    F.B[0][0] = u32x4v{t0.x, t0.y, t1.x, t1.y};
+    F.B[0][1] = u32x4v{t2.x, t2.y, t3.x, t3.y};
   };
   // this wave's 32 x 32 sub-tiles: (ri[i], cj[j]) = global 32-blocks; stored iff cj <= ri
   const int ri[2] = {(row0 >> 5) + 2 * wm, (row0 >> 5) + 2 * wm + 1};
@@ -880,54 +908,9 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
   };
   auto compute = [&](auto S, int g, const FbFrags<WJ> &F) {
     fb_group<WJ>(F, acc);
-    if constexpr (PF) fb_sched_interleave<WJ>();
     after_group(S, g, F);
   };
-  auto step = [&](auto S, auto VM, auto ISS, auto CMP, int g, const FbFrags<WJ> &Fc, FbFrags<WJ> &Fn) {   // (as in k_fb_prod)
-    constexpr int sl = decltype(S)::value;
-    fb_wait_vm<kPW * decltype(VM)::value>();
-    fb_barrier();
-    if constexpr (decltype(ISS)::value) issue(sl);
-    if constexpr (decltype(CMP)::value) {   // (k_fb_prod's pinned assembly group body in here: tools/experiments/r05_vjp_prefetch_asm_body.patch -- faster, not parity clean)
-      fb_read_frags<WJ>(lds, (sl + 1) % kRing, wm, wn, lane, Fn);
-      compute(S, g, Fc);
-    }
-  };
-  if constexpr (PF) {
-    static_assert(kRing == 4, "the unrolled loops below are written for four slots");
-    load_table();
-    issue(0); issue(1); issue(2); issue(3);   // (G >= 8: M >= 128)
-    fb_wait_vm<kPW * 4>();   // (the table's loads are older than the requests)
-    build_table();
-    fb_wait_vm<kPW * 3>();
-    fb_barrier();
-    FbFrags<WJ> F0, F1;
-    fb_read_frags<WJ>(lds, 0, wm, wn, lane, F0);
-    if (work) {
-      int g = 0;
-      for (; g + 4 < G; g += 4) {   // (G is a multiple of 8)
-        step(FbI0{}, FbI2{}, FbT{}, FbT{}, g, F0, F1);
-        step(FbI1{}, FbI2{}, FbT{}, FbT{}, g + 1, F1, F0);
-        step(FbI2{}, FbI2{}, FbT{}, FbT{}, g + 2, F0, F1);
-        step(FbI3{}, FbI2{}, FbT{}, FbT{}, g + 3, F1, F0);
-      }
-      step(FbI0{}, FbI2{}, FbN{}, FbT{}, g, F0, F1);
-      step(FbI1{}, FbI1{}, FbN{}, FbT{}, g + 1, F1, F0);
-      step(FbI2{}, FbI0{}, FbN{}, FbT{}, g + 2, F0, F1);
-      compute(FbI3{}, g + 3, F1);
-    } else {      // a wave above the diagonal: it only carries its share of the staging
-      int g = 0;
-      for (; g + 4 < G; g += 4) {
-        step(FbI0{}, FbI2{}, FbT{}, FbN{}, g, F0, F1);
-        step(FbI1{}, FbI2{}, FbT{}, FbN{}, g + 1, F1, F0);
-        step(FbI2{}, FbI2{}, FbT{}, FbN{}, g + 2, F0, F1);
-        step(FbI3{}, FbI2{}, FbT{}, FbN{}, g + 3, F1, F0);
-      }
-      step(FbI0{}, FbI2{}, FbN{}, FbN{}, g, F0, F1);
-      step(FbI1{}, FbI1{}, FbN{}, FbN{}, g + 1, F1, F0);
-      step(FbI2{}, FbI0{}, FbN{}, FbN{}, g + 2, F0, F1);
-    }
-  } else {
+  {
     // plain loop, NR-slot ring: wait for stage g, barrier, request stage g + NR - 1 into the slot stage g - 1 was read from, read, compute -- the
     // other workgroup of the CU runs its MFMAs under this one's waits
     FB_STAMP(a, 0);
@@ -947,7 +930,7 @@ __global__ __launch_bounds__(512 / WJ, PF ? 2 / WJ : WPE / WJ) void k_fb_vjp(FbA
       if (g + NR - 1 < G) issue(slot == 0 ? NR - 1 : slot - 1);
       if (work) {
         FbFrags<WJ> F;
-        fb_read_frags<WJ>(lds, slot, wm, wn, lane, F);
+        read_frags(slot, F);
         compute(std::integral_constant<int, -1>{}, g, F);
       }
       slot = slot == NR - 1 ? 0 : slot + 1;
@@ -1085,7 +1068,7 @@ namespace {
 constexpr int kBM = 128, kBN = 128;
 constexpr int kWJ = FB_WJ;      // 32-column blocks per wave (k_fb_prod / k_fb_vjp): 2 = four waves of 64 x 64 per tile, 1 = eight waves of 64 x 32
 constexpr int kOwnCuTilesPerCU10 = 17;   // (x 0.1) tiles per CU up to which the triangular products keep one workgroup per CU at d = 1024 (fb_launch_compute: scaled by the heaviest tile's chain)
-constexpr int kPFvjp = FB_PF_VJP;   // the product: register prefetch + one workgroup per CU (its heaviest tile must own a CU); the VJP: two plain workgroups per CU (equal tiles)
+// (the product: register prefetch + one workgroup per CU at few lanes; the VJP: plain loops, three workgroups per CU)
 
 void fb_upload(DevBuf &b, const void *src, size_t bytes) {
   if (b.bytes < bytes || !b.p) {
@@ -1232,7 +1215,6 @@ static FbArgs fb_args(mivi_ctx *c, const void *params, int M_true) {
   a.winv = (float *)t.winv.p;
   a.rinv = (float *)t.rinv.p;
   a.epsP = (unsigned *)t.epsP.p;
-  a.epsV = (unsigned *)t.epsV.p;
   a.WV = (unsigned *)t.WV.p;
   a.t_prec = (const float *)c->t_prec.p; a.dP = c->dP;
   a.PA = (unsigned *)t.PA.p;
@@ -1256,7 +1238,6 @@ void fb_launch_eps(mivi_ctx *c, const FbStep &s, bool with_cplanes, hipStream_t 
   a.L = L;
   a.rng = s.rng;
   a.obj = s.obj;
-  a.skip_v = s.values_only;
   const int gx = (d / 64) * (M / 32);
   a.n_riders = with_cplanes ? (4 * (d / 32) + gx - 1) / gx : 0;   // tril(C)'s planes: four workgroups per 32-row block, in FRONT of the lanes' draws
   hipLaunchKernelGGL(k_fb_eps, dim3(gx, L + a.n_riders), dim3(512), 0, stream, a);
@@ -1348,18 +1329,18 @@ void fb_launch_compute(mivi_ctx *c, const FbStep &s, hipStream_t stream, int whi
   }
   a.work = (const int4 *)tb.vjp.p; a.n_work = tb.n_vjp;
   if (s.values_only) {   // values only (objective mode; the each entry without gradients): the lanes' value workgroups alone, no VJP tile
-    if (which & 2) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 256, 6>), dim3(s.L), dim3(512 / kWJ), 0, stream, a);
+    if (which & 2) hipLaunchKernelGGL((k_fb_vjp<kWJ, 3, 256, 6>), dim3(s.L), dim3(512 / kWJ), 0, stream, a);
     return;
   }
   if (which & 2) {
     // measured at the north star (us per 20 / 50 / 80 lanes): ring 3 + three workgroups per CU 26.5 / 63.3 / 105-115; ring 3, two per CU 26.4 /
     // 69.8 / 109; ring 4, two per CU 36.7 / 81.5 / 126; ring 2, three per CU 26.4 / 72.6 / 113 (round 4's kernel with its second accumulator: 29 / 70 / 115)
     if (s.parts) {   // sharded batches: the lanes' partial vectors instead of gradients
-      if (a.M <= 256) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 256, 6, true>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
-      else hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 2048, 4, true>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
+      if (a.M <= 256) hipLaunchKernelGGL((k_fb_vjp<kWJ, 3, 256, 6, true>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
+      else hipLaunchKernelGGL((k_fb_vjp<kWJ, 3, 2048, 4, true>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
     }
-    else if (a.M <= 256) hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 256, 6>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
-    else hipLaunchKernelGGL((k_fb_vjp<kWJ, kPFvjp, 3, 2048, 4>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
+    else if (a.M <= 256) hipLaunchKernelGGL((k_fb_vjp<kWJ, 3, 256, 6>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
+    else hipLaunchKernelGGL((k_fb_vjp<kWJ, 3, 2048, 4>), dim3(tb.n_vjp + s.L), dim3(512 / kWJ), 0, stream, a);
 #ifdef MIVI_DEV
     dump("k_fb_vjp", tb.n_vjp);
 #endif

@@ -214,7 +214,7 @@ struct FbTab {
 struct FbTables {
   FbTab tab[4];                           // per lane count (the full step's, the last shorter step's, other batch lengths'), round robin
   int next_tab = 0;
-  DevBuf CA, epsP, epsV, WV, ell, he, ld, grads, values;   // operand planes (tril(C) once per call; eps in both orientations and W per lane)
+  DevBuf CA, epsP, WV, ell, he, ld, grads, values;   // operand planes (tril(C) once per call; eps -- ONE orientation since round 6 -- and W per lane)
   DevBuf cscale, pscale, tscale, winv, rinv;               // power-of-two scales of the planes (fr_planes.h): rows of tril(C) / P / C^-T [2][d]; W per lane [M / 128][d]; R per lane [d / 128][M]
   DevBuf PA, RP;                          // dense-Gaussian target: planes of P (once per target), R = Z - m per lane
   bool PA_valid = false;

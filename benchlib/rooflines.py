@@ -249,10 +249,10 @@ def fr_roofline(ctx, params, cost, w, reps=300, lanes=0):
                         algorithmic_flops_per_launch=lanes * kfl[dk], estimates_per_launch=lanes,
                         avg_launch_us=tb[dk], traffic=traffic_of(dk), rocprof_in_chain=rocprof_avg(sub[dk], w.get("key", "ns"), lanes),
                         other_contraction=others[0] if len(others) == 1 else others,
-                        draws=dict(kernel="k_fb_eps (Philox + Box-Muller draws of all lanes as operand planes in both orientations)", avg_launch_us=tb["eps"],
-                                   algorithmic_bytes_per_launch=lanes * 2 * PLANE_BYTES * w["d"] * w["n_mc"],
-                                   achieved_GBs=lanes * 2 * PLANE_BYTES * w["d"] * w["n_mc"] / (tb["eps"] * 1e-6) / 1e9,
-                                   note="%d bytes per element and orientation written once: bound by the memory side and the vector ALU" % PLANE_BYTES),
+                        draws=dict(kernel="k_fb_eps (Philox + Box-Muller draws of all lanes as operand planes, ONE orientation since round 6)", avg_launch_us=tb["eps"],
+                                   algorithmic_bytes_per_launch=lanes * PLANE_BYTES * w["d"] * w["n_mc"],
+                                   achieved_GBs=lanes * PLANE_BYTES * w["d"] * w["n_mc"] / (tb["eps"] * 1e-6) / 1e9,
+                                   note="%d bytes per element written once; bound by the generator's vector arithmetic (Philox's 32-bit multiplies + Box-Muller), not by the writes" % PLANE_BYTES),
                         timing="%d back-to-back launches of each kernel for %d lanes, hipEvents on the launch stream" % (max(5, reps // 10), lanes),
                         basis="achieved = bytes the launch moves (vjp: W + eps planes read, lower-triangle tiles written per scratch lane, dense d^2 for the caller's lane) / launch time; peak = HBM 8 TB/s; frac_survey_8d = SURVEY 8d's lanes x (2 d n_mc + d^2) x 4 B instead; traffic = PMC counters; frac_f32_mfma = d^2 n_mc flops x lanes / time / 157.3 TF; frac_16bit_pipe = x%d executed / 2500 TF" % nprod,
                         f32_mfma=dict(achieved_TFLOPs=aL, peak=PEAK_F32_MFMA_TF, frac=aL / PEAK_F32_MFMA_TF),
