@@ -31,6 +31,9 @@
 #include "fr_elem.h"
 #include "fr_planes.h"
 
+#ifndef FB_VK
+#define FB_VK 0   // developer: compile-time work-skipping knock-outs of k_fb_vjp (16 no DMA, 32 no MFMA, 64 no LDS fragment reads, 128 no epilogue): tools/dbg/knock_vjp.sh
+#endif
 #ifndef FB_WJ
 #define FB_WJ 1
 #endif
@@ -830,14 +833,17 @@ __global__ __launch_bounds__(512 / WJ, WPE / WJ) void k_fb_vjp(FbArgs a) {
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
       unsigned *dst = lds + slot * kStageW + (NF * w + f) * 512;
-      FB_GLDS16(sp[f], dst, 0);
-      FB_GLDS16(sp[f], dst, 1024);
+      if (!(FB_VK & 16)) {
+        FB_GLDS16(sp[f], dst, 0);
+        FB_GLDS16(sp[f], dst, 1024);
+      }
       if (NF * w + f >= 4) sp[f] += (gi & 1) ? bstep_odd : 64;
       else sp[f] += kFrag;
     }
     ++gi;
   };
   auto read_frags = [&](int slot, FbFrags<WJ> &F) {
+    if ((FB_VK & 64)) return;
     const unsigned *cur = lds + slot * kStageW + 4 * lane;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -907,7 +913,7 @@ __global__ __launch_bounds__(512 / WJ, WPE / WJ) void k_fb_vjp(FbArgs a) {
     }
   };
   auto compute = [&](auto S, int g, const FbFrags<WJ> &F) {
-    fb_group<WJ>(F, acc);
+    if (!(FB_VK & 32)) fb_group<WJ>(F, acc);
     after_group(S, g, F);
   };
   {
@@ -938,6 +944,7 @@ __global__ __launch_bounds__(512 / WJ, WPE / WJ) void k_fb_vjp(FbArgs a) {
   }
   fb_barrier();
   FB_STAMP(a, 2);
+  if ((FB_VK & 128)) return;   // (developer knock-out: no epilogue)
   float *Cs = reinterpret_cast<float *>(lds) + w * kImgW;
   const float *wfin = wf + (NB - 1) * 128 + 64 * wm;   // the closing factors of this wave's rows
   const double invM = 1.0 / (double)a.M_total;
