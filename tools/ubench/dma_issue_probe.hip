@@ -14,24 +14,24 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 template <int P, int R, int M, int KIND, int NW>
-__global__ __launch_bounds__(64 * NW) void k_probe(const unsigned *src, float *out, int G) {
+__global__ __launch_bounds__(64 * NW) void k_probe(const unsigned *src, float *out, int G, size_t wg_stride, int span) {
   __shared__ __attribute__((aligned(16))) unsigned lds[NW * 4 * 256 + 8 * 1024];   // per wave: 4 pieces of 1 KiB; + a 32 KiB read area
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   unsigned *ring = lds + w * 4 * 256;
   const unsigned *rd = lds + NW * 4 * 256 + 4 * lane;
-  const unsigned *g0 = src + (size_t)w * 4096 + 4 * lane;   // this wave's 16 KiB of the buffer
+  const unsigned *g0 = src + (size_t)blockIdx.x * wg_stride + (size_t)w * 256 + 4 * lane;   // wave w's piece of a 8 KiB row; rows 8 KiB apart (span rows, then wrap)
   f32x16 acc0, acc1;
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
   u32x4 fa = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u}, fb = fa;
   // buffer resource over the whole source buffer
   __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)src, 0, 0x7fffffff, 0x00020000);
-  const unsigned voff0 = (unsigned)((size_t)w * 4096 * 4 + 16 * lane);
+  const unsigned voff0 = (unsigned)(((size_t)blockIdx.x * wg_stride + (size_t)w * 256) * 4 + 16 * lane);
   unsigned x = 0;
   for (int g = 0; g < G; ++g) {
     if (P > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P) : "memory");
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      const int piece = (g * P + p) & 15;
+      const int piece = ((g * P + p) % span) * 8;   // (a stage = the 8 waves' pieces of P consecutive rows)
       unsigned *dst = ring + ((g * P + p) & 3) * 256;
       if (KIND == 0) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g0 + piece * 256),
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64 * NW) void k_probe(const unsigned *src, float *o
 }
 
 template <int P, int R, int M, int KIND, int NW>
-void run(const unsigned *src, float *out, const char *name) {
+void run(const unsigned *src, float *out, const char *name, size_t wg_stride = 0, int span = 16) {
   const int G = 4000, NCU = 256;
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
@@ -67,7 +67,7 @@ void run(const unsigned *src, float *out, const char *name) {
   float best = 1e9f;
   for (int t = 0; t < 5; ++t) {
     (void)hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k_probe<P, R, M, KIND, NW>), dim3(NCU), dim3(64 * NW), 0, 0, src, out, G);
+    hipLaunchKernelGGL((k_probe<P, R, M, KIND, NW>), dim3(NCU), dim3(64 * NW), 0, 0, src, out, G, wg_stride, span);
     (void)hipEventRecord(e1, 0);
     (void)hipEventSynchronize(e1);
     float ms;
@@ -82,8 +82,9 @@ void run(const unsigned *src, float *out, const char *name) {
 int main() {
   unsigned *src;
   float *out;
-  (void)hipMalloc(&src, 16 * 4096 * 4 * 4);
-  (void)hipMemset(src, 0, 16 * 4096 * 4 * 4);
+  const size_t total = (size_t)1 << 30;   // 1 GiB
+  (void)hipMalloc(&src, total);
+  (void)hipMemset(src, 0, total);
   (void)hipMalloc(&out, 4096);
   run<0, 0, 6, 0, 8>(src, out, "MFMA only");
   run<2, 0, 0, 0, 8>(src, out, "DMA only, global_load_lds");
@@ -100,5 +101,13 @@ int main() {
   run<0, 0, 6, 0, 16>(src, out, "16 waves: MFMA only");
   run<2, 8, 12, 0, 4>(src, out, "4 waves of 64 x 64: 12 MFMA + 8 reads + 2 pieces");
   run<4, 8, 12, 0, 4>(src, out, "4 waves of 64 x 64: 12 MFMA + 8 reads + 4 pieces");
+  // where the operands come from: every workgroup its own region (words): 128 KiB (L2: 32 MiB in all), 1 MiB (256 MiB in all: the memory-side cache),
+  // 4 MiB (1 GiB in all: HBM), streamed row by row (span = rows of 8 KiB before the wrap)
+  run<2, 0, 0, 0, 8>(src, out, "DMA only, own 128 KiB per workgroup", (size_t)32 * 1024, 16);
+  run<2, 6, 6, 0, 8>(src, out, "group, own 128 KiB per workgroup (L2)", (size_t)32 * 1024, 16);
+  run<2, 0, 0, 0, 8>(src, out, "DMA only, own 1 MiB per workgroup", (size_t)256 * 1024, 128);
+  run<2, 6, 6, 0, 8>(src, out, "group, own 1 MiB per workgroup (MALL)", (size_t)256 * 1024, 128);
+  run<2, 0, 0, 0, 8>(src, out, "DMA only, own 4 MiB per workgroup", (size_t)1024 * 1024, 512);
+  run<2, 6, 6, 0, 8>(src, out, "group, own 4 MiB per workgroup (HBM)", (size_t)1024 * 1024, 512);
   return 0;
 }
